@@ -1,0 +1,266 @@
+"""ctypes binding of oracle/liboracle.so (and oracle/_ref/libref.so when present).
+
+TEST INFRASTRUCTURE ONLY -- see oracle/__init__.py.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "liboracle.so")
+_REF = os.path.join(_HERE, "_ref", "libref.so")
+
+f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
+i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+
+
+class MfccCfg(C.Structure):
+    _fields_ = [("sample_rate", C.c_double), ("win_len_s", C.c_double), ("win_shift_s", C.c_double),
+                ("preemph_alpha", C.c_double), ("fft_max_input_s", C.c_double), ("apply_scale", C.c_int),
+                ("mel_filter_width", C.c_double), ("mel_spacing", C.c_double),
+                ("warp_differential_unit", C.c_int), ("n_ceps", C.c_int), ("dct_normalize", C.c_int)]
+
+    @staticmethod
+    def default(n_ceps=16, filter_width=268.258, sample_rate=16000.0, alpha=1.0):
+        return MfccCfg(sample_rate, 0.025, 0.01, alpha, 0.025, 1, filter_width, 0.0, 1, n_ceps, 0)
+
+
+class _GmmModel(C.Structure):
+    _fields_ = [("dim", C.c_int), ("n_mix", C.c_int), ("n_dens", C.c_int), ("n_mean", C.c_int), ("n_cov", C.c_int),
+                ("mix_offsets", C.c_void_p), ("dens_index", C.c_void_p), ("log_weight", C.c_void_p),
+                ("dens_mean", C.c_void_p), ("dens_cov", C.c_void_p), ("means", C.c_void_p),
+                ("variances", C.c_void_p), ("mixture_weight_scale", C.c_float), ("gaussian_scale", C.c_float)]
+
+
+class _FfnnModel(C.Structure):
+    _fields_ = [("n_layers", C.c_int), ("in_dim", C.c_void_p), ("out_dim", C.c_void_p), ("W", C.c_void_p),
+                ("bias", C.c_void_p), ("activation", C.c_void_p), ("log_prior", C.c_void_p),
+                ("prior_scale", C.c_float)]
+
+
+def build_oracle(force=False):
+    """gcc-compile oracle/liboracle.so (and _ref/libref.so when the reference tree is mounted)."""
+    if force or not os.path.exists(_LIB) or any(
+            os.path.getmtime(os.path.join(_HERE, s)) > os.path.getmtime(_LIB)
+            for s in ("orc_mfcc.c", "orc_score.c", "orc.h")):
+        subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+    if os.path.isdir("/root/reference/src") and (force or not os.path.exists(_REF)):
+        subprocess.check_call(["make", "-C", os.path.join(_HERE, "ref")], stdout=subprocess.DEVNULL)
+
+
+_lib = None
+
+
+def Oracle():
+    global _lib
+    if _lib is not None:
+        return _lib
+    build_oracle()
+    L = C.CDLL(_LIB)
+    L.orc_mfcc_create.restype = C.c_void_p
+    L.orc_mfcc_create.argtypes = [C.POINTER(MfccCfg)]
+    L.orc_mfcc_destroy.argtypes = [C.c_void_p]
+    for n in ("frame_len", "frame_shift", "fft_len", "n_bins", "n_filters", "n_ceps"):
+        f = getattr(L, "orc_mfcc_" + n)
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p]
+    L.orc_mfcc_n_frames.restype = C.c_long
+    L.orc_mfcc_n_frames.argtypes = [C.c_void_p, C.c_long]
+    for n, t in (("window", C.c_float), ("filter_start", C.c_int), ("filter_end", C.c_int),
+                 ("filter_offset", C.c_int), ("filter_weights", C.c_float), ("dct", C.c_float)):
+        f = getattr(L, "orc_mfcc_" + n)
+        f.restype = C.POINTER(t)
+        f.argtypes = [C.c_void_p]
+    L.orc_mfcc_mel_max.restype = C.c_double
+    L.orc_mfcc_mel_max.argtypes = [C.c_void_p]
+    L.orc_mfcc_run.restype = C.c_long
+    L.orc_mfcc_run.argtypes = [C.c_void_p, f32p, C.c_long, f32p]
+    L.orc_mfcc_stages.restype = C.c_int
+    L.orc_mfcc_stages.argtypes = [C.c_void_p, f32p, C.c_long, C.c_long] + [C.c_void_p] * 6
+    L.orc_preemphasis.argtypes = [f32p, C.c_long, C.c_float]
+    L.orc_fft_real.argtypes = [f32p, C.c_int]
+    L.orc_fft_complex.argtypes = [f32p, C.c_int]
+    for n in ("orc_mel", "orc_mel_derivative", "orc_mel_inverse"):
+        getattr(L, n).restype = C.c_double
+        getattr(L, n).argtypes = [C.c_double]
+    L.orc_gmm_create.restype = C.c_void_p
+    L.orc_gmm_create.argtypes = [C.POINTER(_GmmModel)]
+    L.orc_gmm_destroy.argtypes = [C.c_void_p]
+    for n in ("minus2_log_weights", "inv_sqrt_var", "log_norm"):
+        f = getattr(L, "orc_gmm_" + n)
+        f.restype = C.POINTER(C.c_float)
+        f.argtypes = [C.c_void_p]
+    L.orc_gmm_score.argtypes = [C.c_void_p, C.c_int, f32p, C.c_int, f32p, C.c_void_p]
+    L.orc_gmm_score_batch_float.restype = C.c_int
+    L.orc_gmm_score_batch_float.argtypes = [C.c_void_p, f64p, f32p, f32p, C.c_int, f32p]
+    L.orc_ffnn_score.argtypes = [C.POINTER(_FfnnModel), f32p, C.c_int, f32p, C.c_int]
+    _lib = L
+    return L
+
+
+_ref = None
+
+
+def load_ref():
+    """oracle/_ref/libref.so (reference TUs compiled unmodified) or None when not built."""
+    global _ref
+    if _ref is not None:
+        return _ref
+    if not os.path.exists(_REF):
+        if os.path.isdir("/root/reference/src"):
+            build_oracle()
+        if not os.path.exists(_REF):
+            return None
+    R = C.CDLL(_REF)
+    R.ref_fft_real.argtypes = [f32p, C.c_int]
+    R.ref_fft_complex.argtypes = [f32p, C.c_int]
+    for n in ("ref_mel", "ref_mel_derivative", "ref_mel_inverse"):
+        getattr(R, n).restype = C.c_double
+        getattr(R, n).argtypes = [C.c_double]
+    for n in ("ref_warped_bin", "ref_warped_bin_inverse", "ref_warped_bin_derivative"):
+        getattr(R, n).restype = C.c_double
+        getattr(R, n).argtypes = [C.c_double, C.c_double]
+    R.ref_gauss_log_norm_factor.restype = C.c_double
+    R.ref_gauss_log_norm_factor.argtypes = [f32p, C.c_int]
+    R.ref_inverse_square_root.restype = C.c_float
+    R.ref_inverse_square_root.argtypes = [C.c_float]
+    R.ref_window_frames.restype = C.c_long
+    R.ref_window_frames.argtypes = [f32p, C.c_long, C.c_long, C.c_uint, C.c_uint, C.c_double, C.c_long,
+                                    C.c_void_p, C.c_void_p, C.c_void_p]
+    _ref = R
+    return R
+
+
+class OracleMfcc:
+    def __init__(self, cfg=None, **kw):
+        self.L = Oracle()
+        self.cfg = cfg if cfg is not None else MfccCfg.default(**kw)
+        self.h = self.L.orc_mfcc_create(C.byref(self.cfg))
+        if not self.h:
+            raise ValueError("oracle: invalid MFCC configuration")
+        g = lambda n: getattr(self.L, "orc_mfcc_" + n)(self.h)
+        self.frame_len, self.frame_shift, self.fft_len = g("frame_len"), g("frame_shift"), g("fft_len")
+        self.n_bins, self.n_filters, self.n_ceps = g("n_bins"), g("n_filters"), g("n_ceps")
+        self.mel_max = self.L.orc_mfcc_mel_max(self.h)
+
+    def __del__(self):
+        try:
+            self.L.orc_mfcc_destroy(self.h)
+        except Exception:
+            pass
+
+    def _arr(self, name, n, dt):
+        p = getattr(self.L, "orc_mfcc_" + name)(self.h)
+        return np.ctypeslib.as_array(p, shape=(n,)).astype(dt).copy()
+
+    @property
+    def window(self):
+        return self._arr("window", self.frame_len, np.float32)
+
+    @property
+    def filters(self):
+        s = self._arr("filter_start", self.n_filters, np.int32)
+        e = self._arr("filter_end", self.n_filters, np.int32)
+        o = self._arr("filter_offset", self.n_filters + 1, np.int32)
+        w = self._arr("filter_weights", int(o[-1]), np.float32)
+        return s, e, o, w
+
+    @property
+    def dct(self):
+        return self._arr("dct", self.n_ceps * self.n_filters, np.float32).reshape(self.n_ceps, self.n_filters)
+
+    def n_frames(self, n):
+        return int(self.L.orc_mfcc_n_frames(self.h, n))
+
+    def run(self, pcm):
+        pcm = np.ascontiguousarray(pcm, dtype=np.float32)
+        T = self.n_frames(len(pcm))
+        out = np.zeros((T, self.n_ceps), dtype=np.float32)
+        if T:
+            self.L.orc_mfcc_run(self.h, pcm, len(pcm), out.reshape(-1))
+        return out
+
+    def stages(self, pcm, frame):
+        pcm = np.ascontiguousarray(pcm, dtype=np.float32)
+        o = dict(windowed=np.zeros(self.fft_len, np.float32), spectrum=np.zeros(self.fft_len + 2, np.float32),
+                 amplitude=np.zeros(self.n_bins, np.float32), mel=np.zeros(self.n_filters, np.float32),
+                 logmel=np.zeros(self.n_filters, np.float32), ceps=np.zeros(self.n_ceps, np.float32))
+        r = self.L.orc_mfcc_stages(self.h, pcm, len(pcm), frame, *[v.ctypes.data for v in o.values()])
+        if r != 0:
+            raise IndexError("frame out of range")
+        return o
+
+
+class OracleGmm:
+    """model: dict with dim, mix_offsets(u32), dens_index(u32), log_weight(f64), dens_mean, dens_cov (u32),
+    means [n_mean,dim] f32, variances [n_cov,dim] f32."""
+
+    def __init__(self, model, mixture_weight_scale=1.0, gaussian_scale=1.0):
+        self.L = Oracle()
+        self.m = {k: (np.ascontiguousarray(v) if isinstance(v, np.ndarray) else v) for k, v in model.items()}
+        m = self.m
+        self.n_mix = len(m["mix_offsets"]) - 1
+        self.dim = int(m["dim"])
+        st = _GmmModel(self.dim, self.n_mix, len(m["dens_mean"]), m["means"].shape[0], m["variances"].shape[0],
+                       m["mix_offsets"].ctypes.data, m["dens_index"].ctypes.data, m["log_weight"].ctypes.data,
+                       m["dens_mean"].ctypes.data, m["dens_cov"].ctypes.data, m["means"].ctypes.data,
+                       m["variances"].ctypes.data, mixture_weight_scale, gaussian_scale)
+        assert m["mix_offsets"].dtype == np.uint32 and m["log_weight"].dtype == np.float64
+        assert m["means"].dtype == np.float32 and m["variances"].dtype == np.float32
+        self.h = self.L.orc_gmm_create(C.byref(st))
+
+    def __del__(self):
+        try:
+            self.L.orc_gmm_destroy(self.h)
+        except Exception:
+            pass
+
+    def tables(self):
+        nk = int(self.m["mix_offsets"][-1])
+        nc = self.m["variances"].shape[0]
+        a = lambda n, k: np.ctypeslib.as_array(getattr(self.L, "orc_gmm_" + n)(self.h), shape=(k,)).copy()
+        return a("minus2_log_weights", nk), a("inv_sqrt_var", nc * self.dim).reshape(nc, self.dim), a("log_norm", nc)
+
+    def score(self, feats, mode=0, want_best=True):
+        feats = np.ascontiguousarray(feats, dtype=np.float32)
+        T = feats.shape[0]
+        sc = np.zeros((T, self.n_mix), np.float32)
+        best = np.zeros((T, self.n_mix), np.uint32) if want_best else None
+        self.L.orc_gmm_score(self.h, mode, feats.reshape(-1), T, sc.reshape(-1),
+                             best.ctypes.data if want_best else None)
+        return (sc, best) if want_best else sc
+
+    def score_batch_float(self, feats):
+        feats = np.ascontiguousarray(feats, dtype=np.float32)
+        T = feats.shape[0]
+        sc = np.zeros((T, self.n_mix), np.float32)
+        r = self.L.orc_gmm_score_batch_float(self.h, self.m["log_weight"], self.m["variances"].reshape(-1),
+                                             feats.reshape(-1), T, sc.reshape(-1))
+        if r != 0:
+            raise ValueError("batch-float scorer supports only a globally pooled covariance")
+        return sc
+
+
+def oracle_ffnn_score(Ws, biases, acts, feats, log_prior=None, prior_scale=1.0, acc64=False):
+    """Ws[l]: [out,in] f32; returns scores [T,out_last] = -(Wx+b-alpha*logprior)."""
+    L = Oracle()
+    n = len(Ws)
+    Ws = [np.ascontiguousarray(w, dtype=np.float32) for w in Ws]
+    bs = [np.ascontiguousarray(b, dtype=np.float32) for b in biases]
+    ind = np.array([w.shape[1] for w in Ws], np.int32)
+    outd = np.array([w.shape[0] for w in Ws], np.int32)
+    act = np.array(acts, np.int32)
+    Wp = (C.c_void_p * n)(*[w.ctypes.data for w in Ws])
+    Bp = (C.c_void_p * n)(*[b.ctypes.data for b in bs])
+    lp = None if log_prior is None else np.ascontiguousarray(log_prior, dtype=np.float32)
+    st = _FfnnModel(n, ind.ctypes.data, outd.ctypes.data, C.cast(Wp, C.c_void_p), C.cast(Bp, C.c_void_p),
+                    act.ctypes.data, None if lp is None else lp.ctypes.data, prior_scale)
+    feats = np.ascontiguousarray(feats, dtype=np.float32)
+    T = feats.shape[0]
+    out = np.zeros((T, int(outd[-1])), np.float32)
+    L.orc_ffnn_score(C.byref(st), feats.reshape(-1), T, out.reshape(-1), 1 if acc64 else 0)
+    return out

@@ -1,0 +1,141 @@
+/*
+ * oracle/orc.h -- CPU restatement of the RASR acoustic front-end + emission scorers.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load liboracle.so.  The product (rasr_amd/) never
+ * links, imports or calls anything in this directory.
+ *
+ * Plain C, no dependency on the reference tree.  Every function cites the reference
+ * file:line whose arithmetic it restates (paths relative to /root/reference/src).
+ * The library is compiled with -ffp-contract=off so that every f32 / f64 operation
+ * rounds exactly once, like the reference's x86-64 (SSE, no FMA) build.
+ *
+ * Pinning status (see DESIGN.md "Oracle"):
+ *   FFT core, framing/flush, mel warp/derivative/inverse, GMM logNorm / 1/sqrt(var):
+ *       pinned bit-exactly against oracle/_ref (reference sources compiled unmodified).
+ *   Hamming, filterbank geometry, DCT, GMM max score: pinned by the known answers the
+ *       reference produced in this container.
+ *   NN forward: pinned by the reference's own unit-test vectors
+ *       (Test/Nn_LinearAndActivationLayer.cc, Test/Nn_NeuralNetwork.cc).
+ *   GMM log-add (sum) scorer: parity unpinned (class is not reachable from reference
+ *       config, no reference test holds a vector for it).
+ */
+#ifndef ORC_H
+#define ORC_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------------------------------------------------------- MFCC chain */
+
+typedef struct {
+    double sample_rate;            /* Hz, e.g. 16000 */
+    double win_len_s;              /* signal-window length, mfcc.flow: 0.025 */
+    double win_shift_s;            /* signal-window shift,  mfcc.flow: 0.01  */
+    double preemph_alpha;          /* signal-preemphasis alpha, mfcc.flow: 1.00 */
+    double fft_max_input_s;        /* maximum-input-size, mfcc.flow: 0.025 */
+    int    apply_scale;            /* apply-scale (default true): multiply by 1/fs */
+    double mel_filter_width;       /* filter-width, default 268.258 */
+    double mel_spacing;            /* spacing, default 0 -> 0.5*width */
+    int    warp_differential_unit; /* default true */
+    int    n_ceps;                 /* nr-outputs of signal-cosine-transform */
+    int    dct_normalize;          /* normalize (default false) */
+} orc_mfcc_cfg;
+
+typedef struct orc_mfcc orc_mfcc;
+
+orc_mfcc* orc_mfcc_create(const orc_mfcc_cfg* cfg);
+void      orc_mfcc_destroy(orc_mfcc* h);
+
+/* geometry */
+int  orc_mfcc_frame_len(const orc_mfcc* h);   /* samples per window (400) */
+int  orc_mfcc_frame_shift(const orc_mfcc* h); /* 160 */
+int  orc_mfcc_fft_len(const orc_mfcc* h);     /* 512 */
+int  orc_mfcc_n_bins(const orc_mfcc* h);      /* 257 */
+int  orc_mfcc_n_filters(const orc_mfcc* h);   /* 20 / 40 */
+int  orc_mfcc_n_ceps(const orc_mfcc* h);
+long orc_mfcc_n_frames(const orc_mfcc* h, long n_samples);
+
+/* tables (pointers owned by h) */
+const float* orc_mfcc_window(const orc_mfcc* h);          /* [frame_len] */
+const int*   orc_mfcc_filter_start(const orc_mfcc* h);    /* [n_filters] */
+const int*   orc_mfcc_filter_end(const orc_mfcc* h);      /* [n_filters] */
+const int*   orc_mfcc_filter_offset(const orc_mfcc* h);   /* [n_filters+1] into weights */
+const float* orc_mfcc_filter_weights(const orc_mfcc* h);  /* concatenated */
+const float* orc_mfcc_dct(const orc_mfcc* h);             /* [n_ceps][n_filters] row-major */
+double       orc_mfcc_mel_max(const orc_mfcc* h);         /* warped maximum frequency */
+
+/* whole utterance: pcm f32 (s16 values, unscaled) -> ceps [n_frames x n_ceps] row-major.
+ * returns number of frames written. */
+long orc_mfcc_run(const orc_mfcc* h, const float* pcm, long n_samples, float* ceps);
+
+/* per-stage taps for one frame of an utterance (any pointer may be NULL) */
+int orc_mfcc_stages(const orc_mfcc* h, const float* pcm, long n_samples, long frame,
+                    float* windowed /*[fft_len], zero padded*/,
+                    float* spectrum /*[fft_len+2] alternating re,im, scaled*/,
+                    float* amplitude /*[n_bins]*/, float* mel /*[n_filters]*/,
+                    float* logmel /*[n_filters]*/, float* ceps /*[n_ceps]*/);
+
+/* building blocks, exposed so they can be pinned one by one */
+void   orc_preemphasis(float* x, long n, float alpha);            /* in place, segment start */
+void   orc_fft_real(float* v, int n);                             /* Math::FastFourierTransform::transformReal */
+void   orc_fft_complex(float* v, int n_floats);                   /* ::transform (forward) */
+double orc_mel(double f);                                         /* continuous-domain mel warp */
+double orc_mel_derivative(double f);
+double orc_mel_inverse(double m);
+
+/* ---------------------------------------------------------------- diag-GMM */
+
+typedef struct {
+    int dim, n_mix, n_dens, n_mean, n_cov;
+    const uint32_t* mix_offsets; /* [n_mix+1] */
+    const uint32_t* dens_index;  /* [sum K_m] density index per (mixture, k) */
+    const double*   log_weight;  /* [sum K_m] f64 log weights (Mm::Weight) */
+    const uint32_t* dens_mean;   /* [n_dens] */
+    const uint32_t* dens_cov;    /* [n_dens] */
+    const float*    means;       /* [n_mean x dim] */
+    const float*    variances;   /* [n_cov  x dim] */
+    float           mixture_weight_scale;
+    float           gaussian_scale;
+} orc_gmm_model;
+
+typedef struct orc_gmm orc_gmm;
+orc_gmm* orc_gmm_create(const orc_gmm_model* m);
+void     orc_gmm_destroy(orc_gmm* h);
+/* prepared tables, for pinning */
+const float* orc_gmm_minus2_log_weights(const orc_gmm* h); /* [sum K_m] */
+const float* orc_gmm_inv_sqrt_var(const orc_gmm* h);       /* [n_cov x dim] */
+const float* orc_gmm_log_norm(const orc_gmm* h);           /* [n_cov] */
+/* mode 0 = maximum approximation, 1 = log-add.  feats [T x dim] row-major;
+ * scores [T x n_mix]; best [T x n_mix] density-in-mixture index (nullable) */
+void orc_gmm_score(const orc_gmm* h, int mode, const float* feats, int T, float* scores, uint32_t* best);
+/* Mm::BatchFloatFeatureScorer arithmetic (pooled covariance only, n_cov == 1) */
+int orc_gmm_score_batch_float(const orc_gmm* h, const double* log_weight, const float* variances,
+                              const float* feats, int T, float* scores);
+
+/* ---------------------------------------------------------------- FFNN forward */
+
+enum { ORC_ACT_NONE = 0, ORC_ACT_RELU = 1, ORC_ACT_SIGMOID = 2, ORC_ACT_TANH = 3 };
+
+typedef struct {
+    int                 n_layers;
+    const int*          in_dim;
+    const int*          out_dim;
+    const float* const* W;    /* per layer [out x in] row-major == RASR weights_[0] [in x out] col-major */
+    const float* const* bias; /* per layer [out] */
+    const int*          activation;
+    const float*        log_prior; /* nullable [out_last] */
+    float               prior_scale;
+} orc_ffnn_model;
+
+/* feats [T x in0] row-major; scores [T x out_last] = -(W x + b - alpha*logprior).
+ * acc64 != 0 accumulates dot products in f64 (tight "truth"), else f32 k-ordered. */
+void orc_ffnn_score(const orc_ffnn_model* m, const float* feats, int T, float* scores, int acc64);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,445 @@
+/*
+ * oracle/orc_mfcc.c -- CPU restatement of the mfcc.flow chain (TEST INFRASTRUCTURE, see orc.h).
+ *
+ *   signal-preemphasis -> signal-window(hamming) -> signal-real-fast-fourier-transform
+ *   -> signal-vector-alternating-complex-f32-amplitude -> signal-filterbank(mel)
+ *   -> generic-vector-f32-log -> signal-cosine-transform
+ *   (Tools/FeatureExtraction/share/mfcc.flow:8-34)
+ *
+ * Arithmetic types follow the reference exactly: f32 sample data, f64 trigonometric
+ * recurrences and table construction, f32 tables.  Compile with -ffp-contract=off.
+ */
+#include "orc.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+struct orc_mfcc {
+    orc_mfcc_cfg cfg;
+    int          frame_len, frame_shift, fft_len, n_bins, n_filters, n_ceps;
+    float        fft_scale;    /* 1/(f32)fs */
+    float*       window;       /* [frame_len] */
+    int *        f_start, *f_end, *f_off;
+    float*       f_weights;
+    float*       dct;          /* [n_ceps][n_filters] */
+    double       mel_max;
+};
+
+/* ------------------------------------------------------------------ preemphasis
+ * Signal/Preemphasis.cc:51-77.  At segment start previous_ = x[0].  alpha == 1 uses the
+ * pure first difference; otherwise y[i] = x[i] - alpha*prev with an f32 product. */
+void orc_preemphasis(float* x, long n, float alpha) {
+    if (n <= 0)
+        return;
+    float prev = x[0];
+    if (alpha != 1.0) {
+        for (long i = 0; i < n; ++i) {
+            float cur  = x[i];
+            float prod = alpha * prev;
+            x[i]       = cur - prod;
+            prev       = cur;
+        }
+    }
+    else {
+        for (long i = n - 1; i > 0; --i)
+            x[i] = x[i] - x[i - 1];
+        x[0] = x[0] - prev;
+    }
+}
+
+/* ------------------------------------------------------------------ FFT
+ * Math/FastFourierTransform.cc:22-23 -- note DPi is a truncated 2*pi. */
+static const double ORC_PI  = 3.141592653589793238;
+static const double ORC_DPI = 6.28318530717959;
+
+/* Math/FastFourierTransform.cc:28-57: bit reversal of the n_floats/2 complex values */
+static void orc_bit_reverse(float* v, int n_floats) {
+    int half = n_floats / 2;
+    int j    = 1;
+    for (int i = 1; i < n_floats; i += 2) {
+        if (j > i) {
+            float a = v[i - 1], b = v[i];
+            v[i - 1] = v[j - 1];
+            v[i]     = v[j];
+            v[j - 1] = a;
+            v[j]     = b;
+        }
+        int m = half;
+        while (m >= 2 && j > m) {
+            j -= m;
+            m >>= 1;
+        }
+        j += m;
+    }
+}
+
+/* Math/FastFourierTransform.cc:59-93: radix-2 DIT, +i sign, f64 twiddle recurrence,
+ * twiddle*data product formed in f64 and rounded to f32, butterflies in f32. */
+void orc_fft_complex(float* v, int n_floats) {
+    orc_bit_reverse(v, n_floats);
+    for (int span = 2; span < n_floats; span <<= 1) {
+        int    stride = span << 1;
+        double theta  = ORC_DPI / span;
+        double sh     = sin(0.5 * theta);
+        double dr     = -2.0 * sh * sh;
+        double di     = sin(theta);
+        double wr = 1.0, wi = 0.0;
+        for (int m = 1; m < span; m += 2) {
+            for (int i = m; i <= n_floats; i += stride) {
+                int   j  = i + span;
+                float tr = (float)(wr * v[j - 1] - wi * v[j]);
+                float ti = (float)(wr * v[j] + wi * v[j - 1]);
+                v[j - 1] = v[i - 1] - tr;
+                v[j]     = v[i] - ti;
+                v[i - 1] += tr;
+                v[i] += ti;
+            }
+            double old = wr;
+            wr         = wr * dr - wi * di + wr;
+            wi         = wi * dr + old * di + wi;
+        }
+    }
+}
+
+/* Math/FastFourierTransform.cc:95-146 (forward branch): complex transform of the packed
+ * data followed by the even/odd split with f64 temporaries. */
+void orc_fft_real(float* v, int n) {
+    const double theta = ORC_PI / (n >> 1);
+    const float  c     = -0.5f;
+    orc_fft_complex(v, n);
+    double sh = sin(0.5 * theta);
+    double dr = -2.0 * sh * sh;
+    double di = sin(theta);
+    double wr = dr + 1;
+    double wi = di;
+    for (int i = 1; i < (n >> 2); ++i) {
+        int    a = i + i, b = a + 1, p = n - a, q = p + 1;
+        double h1r = 0.5 * (v[a] + v[p]);
+        double h1i = 0.5 * (v[b] - v[q]);
+        double h2r = -c * (v[b] + v[q]);
+        double h2i = c * (v[a] - v[p]);
+        v[a]       = (float)(h1r + wr * h2r - wi * h2i);
+        v[b]       = (float)(h1i + wr * h2i + wi * h2r);
+        v[p]       = (float)(h1r - wr * h2r + wi * h2i);
+        v[q]       = (float)(-h1i + wr * h2i + wi * h2r);
+        double old = wr;
+        wr         = wr * dr - wi * di + wr;
+        wi         = wi * dr + old * di + wi;
+    }
+    float h = v[0];
+    v[0]    = h + v[1];
+    v[1]    = h - v[1];
+}
+
+/* ------------------------------------------------------------------ mel warping
+ * Math/AcousticalAnalyticFunctions.hh:24-60 composed as in
+ * Math/AnalyticFunctionFactory.cc:338-341 (continuous domain): nest(scale(2595), melCore). */
+double orc_mel(double f) {
+    return 2595.0 * log10(1.0 + f / 700.0);
+}
+/* derive(): AnalyticNesting::derive (Math/AnalyticFunction.hh:119-122) gives
+ * (const(2595) o melCore)(f) * derivedMelCore(f) */
+double orc_mel_derivative(double f) {
+    return 2595.0 * (1.0 / log(10) / (700.0 + f));
+}
+/* invert(): nest(inverseMelCore, scale(1/2595)) (Math/AnalyticFunction.hh:123-126,
+ * Math/SimpleAnalyticFunctions.hh:107-123) */
+double orc_mel_inverse(double m) {
+    double a = 1 / 2595.0;
+    return (pow(10, a * m) - 1.0) * 700.0;
+}
+
+/* Flow attributes carry doubles as text with 6 significant digits
+ * (Flow/Attributes.hh:109-113: ostringstream << f64), and nodes read them back with atof. */
+static double orc_attr_roundtrip(double x) {
+    char buf[64];
+    snprintf(buf, sizeof buf, "%g", x);
+    return atof(buf);
+}
+
+static int orc_almost_integer(double x) { /* Signal/Filterbank.cc:691-694 */
+    return fabs(x - round(x)) < 1e-10;
+}
+
+/* Core/Utility.hh:322-327 */
+static int orc_almost_equal(double a, double b) {
+    const double eps   = 2.220446049250313e-16; /* Core::Type<f64>::epsilon = DBL_EPSILON */
+    const double delta = 2.2250738585072014e-308; /* Core::Type<f64>::delta   = DBL_MIN */
+    double       d     = fabs(a - b);
+    double       e     = (fabs(a) + fabs(b) + delta) * eps * 1.0;
+    return d < e;
+}
+
+/* ------------------------------------------------------------------ table construction */
+
+/* Signal/WindowFunction.cc:92-101 (Hamming), symmetric fill, f64 -> f32 */
+static void orc_build_hamming(float* w, int len) {
+    if (len <= 1) {
+        for (int i = 0; i < len; ++i)
+            w[i] = 0; /* init() fails in the reference; not reachable from mfcc.flow */
+        return;
+    }
+    unsigned M = (unsigned)len - 1;
+    for (unsigned n = 0; n <= M / 2; ++n) {
+        float c  = (float)(0.54 - 0.46 * cos(2.0 * M_PI * n / M));
+        w[n]     = c;
+        w[M - n] = c;
+    }
+}
+
+/* Signal/Filterbank.cc:144-244,519-567,640-672,765-819: triangular filters,
+ * stretch-to-cover boundary, mel warping of the continuous frequency axis. */
+static int orc_build_filterbank(orc_mfcc* h) {
+    const orc_mfcc_cfg* c  = &h->cfg;
+    /* FilterBankNode::configure reads sample-rate = N/fs from the attribute text */
+    double sr_attr = orc_attr_roundtrip((double)h->fft_len / c->sample_rate);
+    double d2c     = 1 / sr_attr;                    /* createScaling(1 / sampleRate_) */
+    double inv_d2c = 1 / d2c;                        /* ScalingFunction::invert */
+    int    B       = h->n_bins;
+    double fmin    = 0.0;                            /* filtering-interval-start default */
+    double fmaxw   = orc_mel(d2c * (double)(B - 1)); /* FilterBankNode::init */
+    h->mel_max     = fmaxw;
+
+    double width   = c->mel_filter_width;
+    double spacing = c->mel_spacing;
+    double ncp     = 0.5; /* SymmetricalTriangularFilterBuilder::normalizedCenterPosition */
+    if (spacing == 0)
+        spacing = ncp * width;
+    /* StretchToCover::getNumberOfFilters / init */
+    double nf = (fmaxw - fmin - width) / spacing + 1;
+    if (nf < 1)
+        nf = 1;
+    else if (orc_almost_integer(nf))
+        nf = round(nf);
+    size_t n_filters = (size_t)floor(nf);
+    double coverage  = (spacing * (double)(n_filters - 1) + width) / (fmaxw - fmin);
+    if (!(n_filters == 1 && coverage > 1 && !orc_almost_equal(coverage, 1))) {
+        width /= coverage;
+        spacing /= coverage;
+    }
+    h->n_filters = (int)n_filters;
+    h->f_start   = (int*)calloc(n_filters, sizeof(int));
+    h->f_end     = (int*)calloc(n_filters, sizeof(int));
+    h->f_off     = (int*)calloc(n_filters + 1, sizeof(int));
+    h->f_weights = (float*)calloc(n_filters * (size_t)B, sizeof(float));
+    int off      = 0;
+    for (size_t i = 0; i < n_filters; ++i) {
+        double center = fmin + spacing * (double)i + ncp * width;
+        /* setStart */
+        double lo = center - ncp * width;
+        if (!(lo > fmin))
+            lo = fmin; /* std::max(a, b) returns a unless a < b */
+        double s = inv_d2c * orc_mel_inverse(lo);
+        s        = orc_almost_integer(s) ? round(s) : ceil(s);
+        if (s < 0)
+            return -1;
+        /* setEnd */
+        double hi = center + (1.0 - ncp) * width;
+        if (fmaxw < hi)
+            hi = fmaxw;
+        double e = inv_d2c * orc_mel_inverse(hi);
+        e        = orc_almost_integer(e) ? round(e) + 1 : ceil(e);
+        size_t start = (size_t)s;
+        if (!(e > 0 && start < (size_t)e))
+            return -1;
+        size_t end = (size_t)e;
+        h->f_start[i] = (int)start;
+        h->f_end[i]   = (int)end;
+        h->f_off[i]   = off;
+        /* setWeights: f32 triangle weight times f64 derivative, rounded to f32 */
+        for (unsigned b = (unsigned)start; b < end; ++b) {
+            double fw  = orc_mel(d2c * (double)b);
+            float  tri = (float)((double)1 - fabs(fw - center) / (width / 2));
+            if (!(tri >= 0))
+                tri = 0;
+            double der = c->warp_differential_unit ? orc_mel_derivative(d2c * (double)b) : 1.0;
+            h->f_weights[off++] = (float)(tri * der);
+        }
+    }
+    h->f_off[n_filters] = off;
+    return 0;
+}
+
+/* Signal/CosineTransform.cc:62-74 (even about N - 1/2, identity warping) */
+static void orc_build_dct(orc_mfcc* h) {
+    size_t N = (size_t)h->n_filters;
+    h->dct   = (float*)calloc((size_t)h->n_ceps * N, sizeof(float));
+    for (size_t k = 0; k < (size_t)h->n_ceps; ++k)
+        for (size_t n = 0; n < N; ++n) {
+            double omega      = M_PI * (n + 0.5) / N;
+            h->dct[k * N + n] = (float)(cos(omega * k) * 1.0);
+        }
+}
+
+/* Signal/FastFourierTransform.cc:30-41 and FastFourierTransform.hh:299-308 */
+static int orc_fft_length(double max_input_s, double fs) {
+    unsigned maxlen = (unsigned)ceil(max_input_s * fs);
+    if (maxlen == 0)
+        return 0;
+    double power = log((double)maxlen) / log((double)2);
+    /* Core::isAlmostEqual(power, rint(power)) */
+    if (orc_almost_equal(power, rint(power)))
+        power = rint(power);
+    else
+        power = ceil(power);
+    return 1 << (unsigned)power;
+}
+
+orc_mfcc* orc_mfcc_create(const orc_mfcc_cfg* cfg) {
+    orc_mfcc* h = (orc_mfcc*)calloc(1, sizeof *h);
+    h->cfg      = *cfg;
+    /* Signal/Window.cc:69-80: rint of seconds * sample rate */
+    h->frame_len   = (int)(unsigned)rint(cfg->win_len_s * cfg->sample_rate);
+    h->frame_shift = (int)(unsigned)rint(cfg->win_shift_s * cfg->sample_rate);
+    h->fft_len     = orc_fft_length(cfg->fft_max_input_s, cfg->sample_rate);
+    if (h->frame_len <= 0 || h->frame_shift <= 0 || h->fft_len < h->frame_len) {
+        free(h);
+        return NULL;
+    }
+    h->n_bins    = h->fft_len / 2 + 1;
+    h->n_ceps    = cfg->n_ceps;
+    h->fft_scale = 1 / (float)cfg->sample_rate; /* Signal/FastFourierTransform.cc:66-73 */
+    h->window    = (float*)calloc((size_t)h->frame_len, sizeof(float));
+    orc_build_hamming(h->window, h->frame_len);
+    if (orc_build_filterbank(h) != 0) {
+        orc_mfcc_destroy(h);
+        return NULL;
+    }
+    orc_build_dct(h);
+    return h;
+}
+
+void orc_mfcc_destroy(orc_mfcc* h) {
+    if (!h)
+        return;
+    free(h->window);
+    free(h->f_start);
+    free(h->f_end);
+    free(h->f_off);
+    free(h->f_weights);
+    free(h->dct);
+    free(h);
+}
+
+int          orc_mfcc_frame_len(const orc_mfcc* h) { return h->frame_len; }
+int          orc_mfcc_frame_shift(const orc_mfcc* h) { return h->frame_shift; }
+int          orc_mfcc_fft_len(const orc_mfcc* h) { return h->fft_len; }
+int          orc_mfcc_n_bins(const orc_mfcc* h) { return h->n_bins; }
+int          orc_mfcc_n_filters(const orc_mfcc* h) { return h->n_filters; }
+int          orc_mfcc_n_ceps(const orc_mfcc* h) { return h->n_ceps; }
+const float* orc_mfcc_window(const orc_mfcc* h) { return h->window; }
+const int*   orc_mfcc_filter_start(const orc_mfcc* h) { return h->f_start; }
+const int*   orc_mfcc_filter_end(const orc_mfcc* h) { return h->f_end; }
+const int*   orc_mfcc_filter_offset(const orc_mfcc* h) { return h->f_off; }
+const float* orc_mfcc_filter_weights(const orc_mfcc* h) { return h->f_weights; }
+const float* orc_mfcc_dct(const orc_mfcc* h) { return h->dct; }
+double       orc_mfcc_mel_max(const orc_mfcc* h) { return h->mel_max; }
+
+/* Signal/WindowBuffer.cc:84-125 + Signal/SlidingAlgorithmNode.hh:60-79: get() emits full
+ * frames while >= 2*max(len,shift) samples are buffered; at end of segment flush() keeps
+ * emitting every `shift` samples until the remainder fits one window; the last frame is
+ * short (not re-centred).  Closed form: */
+long orc_mfcc_n_frames(const orc_mfcc* h, long n) {
+    if (n <= 0)
+        return 0;
+    long L = h->frame_len > h->frame_shift ? h->frame_len : h->frame_shift;
+    if (n <= L)
+        return 1;
+    return (n - L + h->frame_shift - 1) / h->frame_shift + 1;
+}
+
+static void orc_frame(const orc_mfcc* h, const float* pre, long n_samples, long frame,
+                      float* windowed, float* spectrum, float* amplitude, float* mel,
+                      float* logmel, float* ceps) {
+    const int N = h->fft_len;
+    float     buf[N + 2];
+    long      start = frame * (long)h->frame_shift;
+    long      avail = n_samples - start;
+    int       len   = avail < h->frame_len ? (int)avail : h->frame_len;
+    /* Window::transform -> WindowFunction::work (Signal/WindowFunction.hh:81-96) */
+    for (int i = 0; i < len; ++i)
+        buf[i] = h->window[i] * pre[start + i];
+    /* FastFourierTransform::zeroPadding */
+    for (int i = len; i < N; ++i)
+        buf[i] = 0;
+    if (windowed)
+        memcpy(windowed, buf, (size_t)N * sizeof(float));
+    orc_fft_real(buf, N);
+    /* RealFastFourierTransform::unpack (Signal/FastFourierTransform.cc:88-94) */
+    buf[N]     = buf[1];
+    buf[N + 1] = 0;
+    buf[1]     = 0;
+    /* estimateContinuous (Signal/FastFourierTransform.cc:66-73) */
+    if (h->cfg.apply_scale && h->cfg.sample_rate != 1)
+        for (int i = 0; i < N + 2; ++i)
+            buf[i] = buf[i] * h->fft_scale;
+    if (spectrum)
+        memcpy(spectrum, buf, (size_t)(N + 2) * sizeof(float));
+    /* amplitude: std::abs(std::complex<f32>) (Signal/ComplexVectorFunction.hh:30-47) */
+    float amp[h->n_bins];
+    for (int k = 0; k < h->n_bins; ++k)
+        amp[k] = hypotf(buf[2 * k], buf[2 * k + 1]);
+    if (amplitude)
+        memcpy(amplitude, amp, (size_t)h->n_bins * sizeof(float));
+    /* FilterBank::Filter::apply (Signal/Filterbank.cc:65-71): f32 accumulate, ascending bin */
+    float fb[h->n_filters];
+    for (int f = 0; f < h->n_filters; ++f) {
+        float        acc = 0;
+        const float* w   = h->f_weights + h->f_off[f];
+        for (int b = h->f_start[f]; b < h->f_end[f]; ++b) {
+            float prod = amp[b] * w[b - h->f_start[f]];
+            acc        = acc + prod;
+        }
+        fb[f] = acc;
+    }
+    if (mel)
+        memcpy(mel, fb, (size_t)h->n_filters * sizeof(float));
+    /* Flow::VectorLogFunction<f32> (Flow/SimpleFunction.hh:40-49): log10f, no floor */
+    for (int f = 0; f < h->n_filters; ++f)
+        fb[f] = log10f(fb[f]);
+    if (logmel)
+        memcpy(logmel, fb, (size_t)h->n_filters * sizeof(float));
+    /* CosineTransform::apply (Signal/CosineTransform.cc:76-83; Math/Vector.hh:95-101) */
+    if (ceps) {
+        for (int k = 0; k < h->n_ceps; ++k) {
+            float        acc = 0;
+            const float* row = h->dct + (size_t)k * h->n_filters;
+            for (int n = 0; n < h->n_filters; ++n) {
+                float prod = row[n] * fb[n];
+                acc        = acc + prod;
+            }
+            if (h->cfg.dct_normalize)
+                acc = acc / (float)h->n_filters;
+            ceps[k] = acc;
+        }
+    }
+}
+
+long orc_mfcc_run(const orc_mfcc* h, const float* pcm, long n_samples, float* ceps) {
+    long T = orc_mfcc_n_frames(h, n_samples);
+    if (T == 0)
+        return 0;
+    float* pre = (float*)malloc((size_t)n_samples * sizeof(float));
+    memcpy(pre, pcm, (size_t)n_samples * sizeof(float));
+    orc_preemphasis(pre, n_samples, (float)h->cfg.preemph_alpha);
+    for (long t = 0; t < T; ++t)
+        orc_frame(h, pre, n_samples, t, NULL, NULL, NULL, NULL, NULL, ceps + t * h->n_ceps);
+    free(pre);
+    return T;
+}
+
+int orc_mfcc_stages(const orc_mfcc* h, const float* pcm, long n_samples, long frame,
+                    float* windowed, float* spectrum, float* amplitude, float* mel,
+                    float* logmel, float* ceps) {
+    long T = orc_mfcc_n_frames(h, n_samples);
+    if (frame < 0 || frame >= T)
+        return -1;
+    float* pre = (float*)malloc((size_t)n_samples * sizeof(float));
+    memcpy(pre, pcm, (size_t)n_samples * sizeof(float));
+    orc_preemphasis(pre, n_samples, (float)h->cfg.preemph_alpha);
+    orc_frame(h, pre, n_samples, frame, windowed, spectrum, amplitude, mel, logmel, ceps);
+    free(pre);
+    return 0;
+}

@@ -1,0 +1,298 @@
+/*
+ * oracle/orc_score.c -- CPU restatement of the emission scorers (TEST INFRASTRUCTURE, see orc.h).
+ *
+ *   Mm::GaussDiagonalMaximumFeatureScorer / GaussDiagonalSumFeatureScorer
+ *       (Mm/GaussDiagonalMaximumFeatureScorer.cc:64-86,116-298)
+ *   Mm::BatchFloatFeatureScorer arithmetic (Mm/BatchFeatureScorer.cc:164-254)
+ *   Nn::BatchFeatureScorer forward (Nn/BatchFeatureScorer.cc:148-171, Nn/LinearLayer.cc:298-324,
+ *       Nn/ActivationLayer.cc:272-282, Nn/LinearAndActivationLayer.hh:137-160)
+ *
+ * Compile with -ffp-contract=off: the reference's x86-64 build has no fused multiply-add.
+ */
+#include "orc.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+struct orc_gmm {
+    int       dim, n_mix, n_dens, n_mean, n_cov;
+    uint32_t *mix_off, *dens_index, *dens_mean, *dens_cov;
+    float*    m2lw;    /* [sum K] */
+    float*    means;   /* [n_mean x dim] */
+    float*    isr;     /* [n_cov x dim] */
+    float*    lognorm; /* [n_cov] */
+};
+
+orc_gmm* orc_gmm_create(const orc_gmm_model* m) {
+    orc_gmm* h = (orc_gmm*)calloc(1, sizeof *h);
+    h->dim     = m->dim;
+    h->n_mix   = m->n_mix;
+    h->n_dens  = m->n_dens;
+    h->n_mean  = m->n_mean;
+    h->n_cov   = m->n_cov;
+    size_t nk  = m->mix_offsets[m->n_mix];
+    h->mix_off = (uint32_t*)malloc((size_t)(m->n_mix + 1) * 4);
+    memcpy(h->mix_off, m->mix_offsets, (size_t)(m->n_mix + 1) * 4);
+    h->dens_index = (uint32_t*)malloc(nk * 4);
+    memcpy(h->dens_index, m->dens_index, nk * 4);
+    h->dens_mean = (uint32_t*)malloc((size_t)m->n_dens * 4);
+    memcpy(h->dens_mean, m->dens_mean, (size_t)m->n_dens * 4);
+    h->dens_cov = (uint32_t*)malloc((size_t)m->n_dens * 4);
+    memcpy(h->dens_cov, m->dens_cov, (size_t)m->n_dens * 4);
+    h->means = (float*)malloc((size_t)m->n_mean * m->dim * 4);
+    memcpy(h->means, m->means, (size_t)m->n_mean * m->dim * 4);
+
+    /* Mm/MixtureFeatureScorerElement.cc:21-33: -2*logw in f64 -> f32, then f32 * scale */
+    h->m2lw = (float*)malloc(nk * 4);
+    for (size_t k = 0; k < nk; ++k) {
+        float v    = (float)(-2 * m->log_weight[k]);
+        h->m2lw[k] = v * m->mixture_weight_scale;
+    }
+    /* GaussDiagonalMaximumFeatureScorer ctor (:46-62): gaussianScale_ = sqrt(scale) in f32 */
+    float gs = sqrtf(m->gaussian_scale);
+    /* Mm/CovarianceFeatureScorerElement.cc:21-51, Mm/Utilities.hh:53-91 */
+    h->isr     = (float*)malloc((size_t)m->n_cov * m->dim * 4);
+    h->lognorm = (float*)malloc((size_t)m->n_cov * 4);
+    for (int c = 0; c < m->n_cov; ++c) {
+        const float* var = m->variances + (size_t)c * m->dim;
+        double       ln  = 0;
+        for (int i = 0; i < m->dim; ++i) {
+            /* (T)1 / (T)sqrt(x): sqrt resolves to the double overload, rounded back to f32 */
+            float r                        = (float)1 / (float)sqrt((double)var[i]);
+            h->isr[(size_t)c * m->dim + i] = r * gs;
+            /* logNorm: log(double) of the f32 value, f64 accumulation */
+            ln += log((double)fabsf(var[i]));
+        }
+        double g      = (double)m->dim * log((double)2 * M_PI) + ln;
+        float  f      = (float)g;
+        h->lognorm[c] = f * (gs * gs); /* logNormalizationFactor_ *= factor * factor (f32) */
+    }
+    return h;
+}
+
+void orc_gmm_destroy(orc_gmm* h) {
+    if (!h)
+        return;
+    free(h->mix_off);
+    free(h->dens_index);
+    free(h->dens_mean);
+    free(h->dens_cov);
+    free(h->m2lw);
+    free(h->means);
+    free(h->isr);
+    free(h->lognorm);
+    free(h);
+}
+
+const float* orc_gmm_minus2_log_weights(const orc_gmm* h) { return h->m2lw; }
+const float* orc_gmm_inv_sqrt_var(const orc_gmm* h) { return h->isr; }
+const float* orc_gmm_log_norm(const orc_gmm* h) { return h->lognorm; }
+
+/* GaussDiagonalMaximumFeatureScorer::distance, __SSE3__ branch (:144-180): four strided f32
+ * partial sums, hadd => (l0+l1),(l2+l3); result = 0 + ((l0+l1)+(l2+l3)); scalar tail. */
+static float orc_distance(const float* x, const float* mu, const float* isr, int dim) {
+    float l0 = 0, l1 = 0, l2 = 0, l3 = 0;
+    int   eff = dim & ~3;
+    int   i   = 0;
+    for (; i < eff; i += 4) {
+        float d0 = (mu[i] - x[i]) * isr[i];
+        float d1 = (mu[i + 1] - x[i + 1]) * isr[i + 1];
+        float d2 = (mu[i + 2] - x[i + 2]) * isr[i + 2];
+        float d3 = (mu[i + 3] - x[i + 3]) * isr[i + 3];
+        l0       = l0 + d0 * d0;
+        l1       = l1 + d1 * d1;
+        l2       = l2 + d2 * d2;
+        l3       = l3 + d3 * d3;
+    }
+    float h01    = l0 + l1;
+    float h23    = l2 + l3;
+    float result = 0;
+    result       = result + (h01 + h23);
+    for (; i < dim; ++i) {
+        float df = (mu[i] - x[i]) * isr[i];
+        result   = result + df * df;
+    }
+    return result;
+}
+
+void orc_gmm_score(const orc_gmm* h, int mode, const float* feats, int T, float* scores, uint32_t* best) {
+    int    maxk = 0;
+    for (int m = 0; m < h->n_mix; ++m) {
+        int k = (int)(h->mix_off[m + 1] - h->mix_off[m]);
+        if (k > maxk)
+            maxk = k;
+    }
+    float* sk = (float*)malloc((size_t)(maxk > 0 ? maxk : 1) * 4);
+    for (int t = 0; t < T; ++t) {
+        const float* x = feats + (size_t)t * h->dim;
+        for (int m = 0; m < h->n_mix; ++m) {
+            uint32_t k0 = h->mix_off[m], k1 = h->mix_off[m + 1];
+            if (mode == 0) {
+                /* calculateScoreAndDensity (:116-141): f64 combine, f32 running best,
+                 * strict '>' so the first minimum wins */
+                float    bestScore = FLT_MAX;
+                uint32_t bestDns   = UINT32_MAX;
+                for (uint32_t k = k0; k < k1; ++k) {
+                    uint32_t d    = h->dens_index[k];
+                    uint32_t c    = h->dens_cov[d];
+                    float    dist = orc_distance(x, h->means + (size_t)h->dens_mean[d] * h->dim,
+                                                 h->isr + (size_t)c * h->dim, h->dim);
+                    double   s    = (double)h->m2lw[k] + (double)h->lognorm[c] + (double)dist;
+                    if ((double)bestScore > s) {
+                        bestScore = (float)s;
+                        bestDns   = k - k0;
+                    }
+                }
+                scores[(size_t)t * h->n_mix + m] = (float)(0.5 * bestScore);
+                if (best)
+                    best[(size_t)t * h->n_mix + m] = bestDns;
+            }
+            else {
+                /* GaussDiagonalSumFeatureScorer (:252-298): all f32 */
+                for (uint32_t k = k0; k < k1; ++k) {
+                    uint32_t d     = h->dens_index[k];
+                    uint32_t c     = h->dens_cov[d];
+                    float    dist  = orc_distance(x, h->means + (size_t)h->dens_mean[d] * h->dim,
+                                                  h->isr + (size_t)c * h->dim, h->dim);
+                    float    score = h->m2lw[k] + h->lognorm[c] + dist;
+                    sk[k - k0]     = (float)(0.5 * score);
+                }
+                float    bestScore = FLT_MAX;
+                uint32_t bestDns   = UINT32_MAX;
+                for (uint32_t k = 0; k < k1 - k0; ++k)
+                    if (bestScore > sk[k]) {
+                        bestScore = sk[k];
+                        bestDns   = k;
+                    }
+                float sumExp = 0;
+                for (uint32_t k = 0; k < k1 - k0; ++k)
+                    sumExp += expf(bestScore - sk[k]);
+                scores[(size_t)t * h->n_mix + m] = bestScore - logf(sumExp);
+                if (best)
+                    best[(size_t)t * h->n_mix + m] = bestDns;
+            }
+        }
+    }
+    free(sk);
+}
+
+/* Mm/BatchFeatureScorer.cc:164-254 (BatchFloatFeatureScorer, "batch-diagonal-maximum-float",
+ * pooled covariance only).  init(): means and features are multiplied by 1/sigma (f32), the
+ * per-density constant is (f32)(logNorm - 2*logw) with the subtraction in f64 (no weight or
+ * gaussian scale).  fillScoreCacheTpl(): two 4-lane f32 accumulators over 8-wide blocks,
+ * lane 0 of the first one starts at the constant; a = s1+s2; result = (a3+a1)+(a2+a0);
+ * min over densities; times 0.5.  log_weight must be the model's f64 log weights. */
+int orc_gmm_score_batch_float(const orc_gmm* h, const double* log_weight, const float* variances,
+                              const float* feats, int T, float* scores) {
+    if (h->n_cov != 1)
+        return -1;
+    int    dim  = h->dim;
+    int    pdim = ((dim + 7) / 8) * 8;
+    size_t nk   = h->mix_off[h->n_mix];
+    float* isr  = (float*)calloc((size_t)pdim, 4);
+    double ln   = 0;
+    for (int i = 0; i < dim; ++i) {
+        isr[i] = (float)1 / (float)sqrt((double)variances[i]);
+        ln += log((double)fabsf(variances[i]));
+    }
+    float  lognorm = (float)((double)dim * log((double)2 * M_PI) + ln);
+    float* xs      = (float*)calloc((size_t)pdim, 4);
+    float* ms      = (float*)calloc(nk * (size_t)pdim, 4);
+    float* cst     = (float*)calloc(nk, 4);
+    for (size_t k = 0; k < nk; ++k) {
+        const float* mu = h->means + (size_t)h->dens_mean[h->dens_index[k]] * dim;
+        for (int i = 0; i < dim; ++i)
+            ms[k * pdim + i] = mu[i] * isr[i];
+        cst[k] = (float)((double)lognorm - 2 * log_weight[k]);
+    }
+    for (int t = 0; t < T; ++t) {
+        for (int i = 0; i < dim; ++i)
+            xs[i] = feats[(size_t)t * dim + i] * isr[i];
+        for (int m = 0; m < h->n_mix; ++m) {
+            float best = FLT_MAX;
+            for (uint32_t k = h->mix_off[m]; k < h->mix_off[m + 1]; ++k) {
+                const float* mu    = ms + (size_t)k * pdim;
+                float        s1[4] = {cst[k], 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+                for (int d = 0; d < pdim; d += 8)
+                    for (int j = 0; j < 4; ++j) {
+                        float x1 = mu[d + j] - xs[d + j];
+                        s1[j]    = s1[j] + x1 * x1;
+                        float x2 = mu[d + 4 + j] - xs[d + 4 + j];
+                        s2[j]    = s2[j] + x2 * x2;
+                    }
+                float a0 = s1[0] + s2[0], a1 = s1[1] + s2[1], a2 = s1[2] + s2[2], a3 = s1[3] + s2[3];
+                float r = (a3 + a1) + (a2 + a0);
+                if (r < best)
+                    best = r;
+            }
+            if (best < FLT_MAX)
+                best = (float)(best * 0.5);
+            scores[(size_t)t * h->n_mix + m] = best;
+        }
+    }
+    free(isr);
+    free(xs);
+    free(ms);
+    free(cst);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ FFNN forward */
+
+static float orc_act(float v, int act) {
+    switch (act) {
+        case ORC_ACT_RELU: return v < 0 ? 0 : v;                     /* ensureMinimalValue(0) */
+        case ORC_ACT_SIGMOID: return (float)(1.0 / (1.0 + exp(-(double)v))); /* Math/FastMatrix sigmoid */
+        case ORC_ACT_TANH: return tanhf(v);
+        default: return v;
+    }
+}
+
+void orc_ffnn_score(const orc_ffnn_model* m, const float* feats, int T, float* scores, int acc64) {
+    int maxd = m->in_dim[0];
+    for (int l = 0; l < m->n_layers; ++l)
+        if (m->out_dim[l] > maxd)
+            maxd = m->out_dim[l];
+    float* a = (float*)malloc((size_t)maxd * 4);
+    float* b = (float*)malloc((size_t)maxd * 4);
+    for (int t = 0; t < T; ++t) {
+        memcpy(a, feats + (size_t)t * m->in_dim[0], (size_t)m->in_dim[0] * 4);
+        for (int l = 0; l < m->n_layers; ++l) {
+            int          in = m->in_dim[l], out = m->out_dim[l];
+            const float* W    = m->W[l];
+            int          last = (l == m->n_layers - 1);
+            for (int o = 0; o < out; ++o) {
+                const float* w = W + (size_t)o * in;
+                float        z;
+                if (acc64) {
+                    double s = 0;
+                    for (int i = 0; i < in; ++i)
+                        s += (double)w[i] * (double)a[i];
+                    z = (float)s;
+                }
+                else {
+                    float s = 0;
+                    for (int i = 0; i < in; ++i)
+                        s = s + w[i] * a[i];
+                    z = s;
+                }
+                float bias = m->bias[l] ? m->bias[l][o] : 0.f;
+                if (last && m->log_prior && m->prior_scale != 0.f)
+                    bias = bias - m->prior_scale * m->log_prior[o]; /* removeLogPriorFromBias */
+                z = z + bias;                                        /* addToAllColumns */
+                z = orc_act(z, m->activation[l]);
+                b[o] = z;
+            }
+            float* tmp = a;
+            a          = b;
+            b          = tmp;
+        }
+        int outl = m->out_dim[m->n_layers - 1];
+        for (int o = 0; o < outl; ++o)
+            scores[(size_t)t * outl + o] = -a[o]; /* Nn/BatchFeatureScorer.cc:165 */
+    }
+    free(a);
+    free(b);
+}

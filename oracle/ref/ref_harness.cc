@@ -1,0 +1,135 @@
+// oracle/ref/ref_harness.cc -- thin C entry points onto UNMODIFIED reference translation units.
+//
+// TEST INFRASTRUCTURE.  Built only where /root/reference exists (see Makefile); the resulting
+// oracle/_ref/libref.so is used by tests/ to pin oracle/liboracle.so bit-exactly and, via
+// tests/golden/make_golden.py, to produce the committed golden vectors.
+//
+// Everything called here is reference code compiled from where it lies:
+//   Math::FastFourierTransform            src/Math/FastFourierTransform.cc
+//   Signal::WindowBuffer (put/get/flush)  src/Signal/WindowBuffer.cc (+ Flow/Core closure, see Makefile)
+//   Math::{ScalingFunction,MelWarpingCore,AnalyticNesting}  header-only, composed exactly like
+//       Math::AnalyticFunctionFactory::createMelWarpingFunction (AnalyticFunctionFactory.cc:338-341)
+//   Mm::gaussLogNormFactor, Mm::inverseSquareRoot           src/Mm/Utilities.hh:53-91
+// No reference header, library or tool is replaced by a stand-in; translation units that need
+// boost / bison / cblas (anything including Core/Configuration.hh) are simply not built.
+#include <Math/AcousticalAnalyticFunctions.hh>
+#include <Math/FastFourierTransform.hh>
+#include <Math/SimpleAnalyticFunctions.hh>
+#include <Mm/Utilities.hh>
+#include <Signal/WindowBuffer.hh>
+
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+namespace {
+Math::UnaryAnalyticFunctionRef melWarp() {
+    // continuousDomain branch of createMelWarpingFunction
+    return Math::nest(Math::UnaryAnalyticFunctionRef(new Math::ScalingFunction(2595.0)),
+                      Math::UnaryAnalyticFunctionRef(new Math::MelWarpingCore));
+}
+}  // namespace
+
+extern "C" {
+
+void ref_fft_real(float* v, int n) {
+    std::vector<float> d(v, v + n);
+    Math::FastFourierTransform fft;
+    fft.transformReal(d, false);
+    std::memcpy(v, d.data(), sizeof(float) * n);
+}
+
+void ref_fft_complex(float* v, int n_floats) {
+    std::vector<float> d(v, v + n_floats);
+    Math::FastFourierTransform fft;
+    fft.transform(d, false);
+    std::memcpy(v, d.data(), sizeof(float) * n_floats);
+}
+
+double ref_mel(double f) {
+    return melWarp()->value(f);
+}
+double ref_mel_derivative(double f) {
+    return melWarp()->derive()->value(f);
+}
+double ref_mel_inverse(double m) {
+    return melWarp()->invert()->value(m);
+}
+// nest(warp, disc-to-cont) and its inverse / derivative, as FilterBuilder::create composes them
+double ref_warped_bin(double bin, double inputSampleRate) {
+    Math::UnaryAnalyticFunctionRef d2c(new Math::ScalingFunction(1 / inputSampleRate));
+    return Math::nest(melWarp(), d2c)->value(bin);
+}
+double ref_warped_bin_inverse(double warped, double inputSampleRate) {
+    Math::UnaryAnalyticFunctionRef d2c(new Math::ScalingFunction(1 / inputSampleRate));
+    return Math::nest(melWarp(), d2c)->invert()->value(warped);
+}
+double ref_warped_bin_derivative(double bin, double inputSampleRate) {
+    Math::UnaryAnalyticFunctionRef d2c(new Math::ScalingFunction(1 / inputSampleRate));
+    return Math::nest(melWarp()->derive(), d2c)->value(bin);
+}
+
+double ref_gauss_log_norm_factor(const float* var, int n) {
+    std::vector<float> v(var, var + n);
+    return Mm::gaussLogNormFactor(v.begin(), v.end());
+}
+float ref_inverse_square_root(float x) {
+    return Mm::inverseSquareRoot<float>()(x);
+}
+
+// Drives Signal::WindowBuffer the way SlidingAlgorithmNode::work does
+// (src/Signal/SlidingAlgorithmNode.hh:60-79): get() until it fails, then put the next input
+// block; at end of stream flush() until flushed().  No window function is applied (the
+// default WindowBuffer::transform is the identity).  Returns the number of frames;
+// frame_len[i] / frame_start_time[i] describe frame i, frames (if not null) receives the
+// samples of every frame padded to `length` floats.
+long ref_window_frames(const float* pcm, long n, long block, unsigned length, unsigned shift,
+                       double sampleRate, long max_frames, int* frame_len,
+                       double* frame_start_time, float* frames) {
+    Signal::WindowBuffer wb;
+    wb.setLength(length);
+    wb.setShift(shift);
+    wb.setSampleRate(sampleRate);
+    long nf  = 0;
+    long pos = 0;
+    Flow::Vector<float> out;
+    auto emit = [&]() {
+        if (nf < max_frames) {
+            if (frame_len)
+                frame_len[nf] = (int)out.size();
+            if (frame_start_time)
+                frame_start_time[nf] = out.startTime();
+            if (frames) {
+                std::fill(frames + nf * length, frames + (nf + 1) * length, 0.0f);
+                std::copy(out.begin(), out.end(), frames + nf * length);
+            }
+        }
+        ++nf;
+    };
+    bool eos = false;
+    while (true) {
+        if (wb.get(out)) {
+            emit();
+            continue;
+        }
+        if (!eos) {
+            if (pos < n) {
+                long                cnt = std::min(block, n - pos);
+                Flow::Vector<float> in(pcm + pos, pcm + pos + cnt);
+                in.setStartTime(pos / sampleRate);
+                in.setEndTime((pos + cnt) / sampleRate);
+                wb.put(in);
+                pos += cnt;
+                continue;
+            }
+            eos = true;
+        }
+        // end of stream: flush
+        if (wb.flushed() || !wb.flush(out))
+            break;
+        emit();
+    }
+    return nf;
+}
+
+}  // extern "C"
