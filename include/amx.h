@@ -1,0 +1,216 @@
+/*
+ * amx.h -- C ABI of librasr_amd.so: MI355X (gfx950) acoustic front-end and emission scorers
+ * for RASR.  Plain C, no RASR / torch types.  This is the drop-in boundary: the RASR-side
+ * adapters subclass Flow::Node and Mm::FeatureScorer and forward to these
+ * entry points; nothing else of RASR is replaced.
+ *
+ * Reference interfaces replaced (paths relative to /root/reference/src):
+ *   amx_mfcc_*   the Flow sub-network Tools/FeatureExtraction/share/mfcc.flow:8-34, i.e. the nodes
+ *                Signal/Preemphasis.cc:108-124, Signal/SlidingAlgorithmNode.hh:60-79 (signal-window),
+ *                Signal/FastFourierTransform.hh:311-320, Signal/ComplexVectorFunction.hh:234-243,
+ *                Signal/Filterbank.cc:860-876, Flow/SimpleFunction.hh:497-507,
+ *                Signal/CosineTransform.cc:213-228 -- driven per segment by
+ *                Speech/DataExtractor.cc:101-111 (FeatureExtractor::processSegment).
+ *   amx_gmm_*    Mm::FeatureScorer::getScorer(x)->score(e) as implemented by
+ *                Mm/GaussDiagonalMaximumFeatureScorer.cc:116-141 (max) and :252-298 (log-add),
+ *                constructed by Mm/FeatureScorerFactory.hh:72-82 from a Mm::MixtureSet.
+ *   amx_ffnn_*   Nn::BatchFeatureScorer (Nn/BatchFeatureScorer.cc:45-171): forward of
+ *                Nn::NeuralNetwork<f32> (Nn/NeuralNetwork.cc:313-331) with the softmax disabled and
+ *                the scaled log-prior removed from the output bias; score = -activation.
+ *   amx_stats_*  the per-partition accumulator files + `combine-mixture-set-estimators`
+ *                (Tools/AcousticModelTrainer/AcousticModelTrainer.cc:317-325) -- here a flat device
+ *                buffer the caller all-reduces (RCCL) once per epoch.
+ *
+ * Conventions
+ *   - every function returns an amx_status (0 = ok, < 0 = error); amx_last_error() gives the
+ *     thread-local message of the last failure.  Nothing exits or throws across the boundary.
+ *   - "host" pointers are ordinary process memory (pinned recommended); "dev" pointers are HBM
+ *     addresses on the context's device (hipMalloc / torch tensor data_ptr).
+ *   - all matrices handed over the boundary are row-major [frames x dim] f32.
+ *   - scores are negative log-likelihoods (Mm::Score = f32, smaller is better).
+ *   - a context is bound to one device and one HIP stream; calls on one context must be
+ *     externally serialised (RASR's corpus loop is single threaded, Speech/Recognizer.cc:271-281).
+ */
+#ifndef RASR_AMD_AMX_H
+#define RASR_AMD_AMX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    AMX_OK              = 0,
+    AMX_ERR_INVALID     = -1, /* bad argument / configuration (reference would criticalError) */
+    AMX_ERR_UNSUPPORTED = -2, /* valid RASR configuration this build has no kernel for */
+    AMX_ERR_DEVICE      = -3, /* HIP runtime failure, no gfx950 device, out of memory */
+    AMX_ERR_STATE       = -4  /* call sequence violates the protocol (reference would require()) */
+} amx_status;
+
+typedef struct amx_ctx  amx_ctx;
+typedef struct amx_mfcc amx_mfcc;
+typedef struct amx_mfcc_plan amx_mfcc_plan;
+typedef struct amx_gmm  amx_gmm;
+typedef struct amx_ffnn amx_ffnn;
+
+/* ------------------------------------------------------------------ context */
+
+const char* amx_version(void);
+const char* amx_last_error(void);
+/* Creates a context on HIP device `device_ordinal` with its own non-blocking stream. */
+int  amx_init(int device_ordinal, amx_ctx** out);
+void amx_destroy(amx_ctx* ctx);
+/* Run all subsequent launches of this context on the caller's hipStream_t (e.g. torch's current
+ * stream); NULL restores the context's own stream. */
+int amx_set_stream(amx_ctx* ctx, void* hip_stream);
+int amx_synchronize(amx_ctx* ctx);
+/* Per-kernel timing with HIP events on the context's stream (used by bench.py for the roofline
+ * line).  enable=1 makes every launch of the named hot kernels record start/stop events. */
+int amx_profile_enable(amx_ctx* ctx, int enable);
+int amx_profile_reset(amx_ctx* ctx);
+/* kernel: "mfcc", "gmm", "gmm_dist", "gmm_combine", "ffnn_gemm" (all layers), "ffnn_gemm_max"
+ * (largest layer only).  Synchronises the stream.  avg_ms = mean launch duration. */
+int amx_profile_get(amx_ctx* ctx, const char* kernel, double* avg_ms, long* n_launches);
+
+/* ------------------------------------------------------------------ MFCC front-end */
+
+typedef struct {
+    double sample_rate;            /* Hz */
+    double win_len_s;              /* signal-window length        (mfcc.flow: 0.025) */
+    double win_shift_s;            /* signal-window shift         (mfcc.flow: 0.01)  */
+    double preemph_alpha;          /* signal-preemphasis alpha    (mfcc.flow: 1.00)  */
+    double fft_max_input_s;        /* maximum-input-size          (mfcc.flow: 0.025) */
+    int    apply_scale;            /* apply-scale, default 1: spectrum * 1/(f32)fs   */
+    double mel_filter_width;       /* filter-width, default 268.258 (mel)            */
+    double mel_spacing;            /* spacing, default 0 => 0.5 * width              */
+    int    warp_differential_unit; /* warp-differential-unit, default 1              */
+    int    n_ceps;                 /* signal-cosine-transform nr-outputs             */
+    int    dct_normalize;          /* normalize, default 0                           */
+} amx_mfcc_cfg;
+
+typedef struct {
+    int    frame_len, frame_shift, fft_len, n_bins, n_filters, n_ceps;
+    double fft_output_sample_rate; /* attribute "sample-rate" after the FFT node = N/fs */
+    double mel_max;                /* warped maximum frequency */
+} amx_mfcc_info;
+
+void amx_mfcc_default_cfg(amx_mfcc_cfg* cfg); /* the values of mfcc.flow + node defaults, 16 ceps */
+int  amx_mfcc_create(amx_ctx* ctx, const amx_mfcc_cfg* cfg, amx_mfcc** out);
+void amx_mfcc_destroy(amx_mfcc* h);
+int  amx_mfcc_describe(const amx_mfcc* h, amx_mfcc_info* info);
+/* frames produced for a segment of n_samples (framing + flush rule of Signal/WindowBuffer.cc:84-125) */
+long amx_mfcc_n_frames(const amx_mfcc* h, long n_samples);
+/* start time of frame k relative to the segment start, accumulated exactly like
+ * WindowBuffer::get (bufferStartTime_ += shift / sampleRate) */
+double amx_mfcc_frame_start_time(const amx_mfcc* h, long frame);
+/* host copies of the tables the kernel uses (any pointer may be NULL):
+ * window[frame_len], filter_start/end[n_filters], filter_offset[n_filters+1],
+ * filter_weights[filter_offset[n_filters]], dct[n_ceps*n_filters] */
+int amx_mfcc_tables(const amx_mfcc* h, float* window, int* filter_start, int* filter_end,
+                    int* filter_offset, float* filter_weights, float* dct);
+
+/* One segment, host buffers: pcm f32 (s16 sample values, unscaled, Flow/TypeConverter.hh:35-43)
+ * -> ceps [n_frames x n_ceps].  Includes H2D/D2H. */
+int amx_mfcc_run(amx_mfcc* h, const float* pcm_host, long n_samples, float* ceps_host);
+/* Batch of segments, host buffers. */
+int amx_mfcc_run_batch(amx_mfcc* h, int n_seg, const float* const* pcm_host, const long* n_samples,
+                       float* const* ceps_host);
+
+/* Device-resident batches.  A plan fixes the segmentation: segment u occupies samples
+ * [sample_offsets[u], sample_offsets[u+1]) of one concatenated PCM buffer and frames
+ * [frame_offsets[u], frame_offsets[u+1]) of one [total_frames x n_ceps] output. */
+int  amx_mfcc_plan_create(amx_mfcc* h, int n_seg, const long* sample_offsets /*[n_seg+1]*/, amx_mfcc_plan** out);
+void amx_mfcc_plan_destroy(amx_mfcc_plan* p);
+long amx_mfcc_plan_total_frames(const amx_mfcc_plan* p);
+int  amx_mfcc_plan_frame_offsets(const amx_mfcc_plan* p, long* frame_offsets /*[n_seg+1]*/);
+int  amx_mfcc_run_plan_dev(amx_mfcc* h, const amx_mfcc_plan* p, const float* pcm_dev, float* ceps_dev);
+
+/* Sliding-window concatenation of feature frames per segment (f1 "next" row:
+ * signal-vector-f32-sequence-concatenation, Signal/SlidingWindow.hh:66-76 copy margin policy):
+ * out[t] = [x[t-left] .. x[t+right]] with indices clamped to the segment.  out_dev is
+ * [total_frames x out_stride] f32 (out_stride >= (left+right+1)*dim, padding zero-filled). */
+int amx_context_window_dev(amx_ctx* ctx, const amx_mfcc_plan* p, const float* feats_dev, int dim,
+                           int left, int right, float* out_dev, int out_stride);
+
+/* ------------------------------------------------------------------ diagonal-covariance GMM */
+
+typedef struct {
+    int dim, n_mix, n_dens, n_mean, n_cov;
+    const uint32_t* mix_offsets; /* [n_mix+1]  mixture m owns entries [mix_offsets[m], mix_offsets[m+1]) */
+    const uint32_t* dens_index;  /* [mix_offsets[n_mix]]  density index (Mm::Mixture::densityIndex) */
+    const double*   log_weight;  /* [mix_offsets[n_mix]]  log weights (Mm::Weight = f64) */
+    const uint32_t* dens_mean;   /* [n_dens]  Mm::GaussDensity::meanIndex */
+    const uint32_t* dens_cov;    /* [n_dens]  Mm::GaussDensity::covarianceIndex */
+    const float*    means;       /* [n_mean x dim] */
+    const float*    variances;   /* [n_cov  x dim] diagonal variances */
+    float           mixture_weight_scale; /* mixture-weight-scale, default 1 */
+    float           gaussian_scale;       /* gaussian-scale, default 1 */
+} amx_gmm_model;
+
+enum { AMX_GMM_MAX = 0, AMX_GMM_SUM = 1 }; /* diagonal-maximum / diagonal-sum */
+
+int  amx_gmm_create(amx_ctx* ctx, const amx_gmm_model* model, amx_gmm** out); /* copies everything */
+void amx_gmm_destroy(amx_gmm* h);
+int  amx_gmm_n_mixtures(const amx_gmm* h);
+int  amx_gmm_dimension(const amx_gmm* h);
+/* host copies of the prepared scorer tables (Mm/MixtureFeatureScorerElement.cc:21-33,
+ * Mm/CovarianceFeatureScorerElement.cc:21-51); any pointer may be NULL */
+int amx_gmm_tables(const amx_gmm* h, float* minus2_log_weights, float* inv_sqrt_var, float* log_norm);
+/* scores [T x n_mix]; best_density (nullable) [T x n_mix] = index within the mixture of the
+ * minimising density (AssigningFeatureScorer::ScoreAndBestDensity). */
+int amx_gmm_score(amx_gmm* h, int mode, const float* feats_host, int T, float* scores_host, uint32_t* best_density_host);
+int amx_gmm_score_dev(amx_gmm* h, int mode, const float* feats_dev, int T, float* scores_dev, uint32_t* best_density_dev);
+
+/* ------------------------------------------------------------------ mixture-set text files (.pms) */
+
+/* Reader / writer of RASR's text mixture-set format, "#Version: 2.0" (Mm/MixtureSet.cc:141-216,
+ * Mm/Mixture.cc:80-105, Mm/MixtureSetTopology.cc:19-30, Mm/GaussDensity.cc:25-70).  Version < 2.0
+ * files carry linear weights (converted with log), covariances are stored as (variance, weight)
+ * pairs whose product is the diagonal.  The returned object owns its arrays; amx_mixture_set_view
+ * fills an amx_gmm_model with pointers into it (scales set to 1). */
+typedef struct amx_mixture_set amx_mixture_set;
+int  amx_pms_read(const char* path, amx_mixture_set** out);
+int  amx_pms_write(const amx_gmm_model* model, const char* path);
+int  amx_mixture_set_view(const amx_mixture_set* ms, amx_gmm_model* view);
+void amx_mixture_set_destroy(amx_mixture_set* ms);
+
+/* ------------------------------------------------------------------ feed-forward NN scorer */
+
+enum { AMX_ACT_NONE = 0, AMX_ACT_RELU = 1, AMX_ACT_SIGMOID = 2, AMX_ACT_TANH = 3 };
+enum { AMX_PREC_FP32 = 0, AMX_PREC_BF16 = 1 }; /* MFMA input type; accumulation is always f32 */
+
+typedef struct {
+    int                 n_layers;
+    const int*          in_dim;     /* [n_layers] */
+    const int*          out_dim;    /* [n_layers] */
+    const float* const* W;          /* [n_layers] each [out x in] row-major (== RASR weights_[0], [in x out] col-major) */
+    const float* const* bias;       /* [n_layers] each [out] */
+    const int*          activation; /* [n_layers] AMX_ACT_*; last layer must be AMX_ACT_NONE */
+    const float*        log_prior;  /* nullable [out_last]  (Nn::Prior) */
+    float               prior_scale;/* priori-scale alpha */
+    int                 precision;  /* AMX_PREC_* */
+} amx_ffnn_model;
+
+int  amx_ffnn_create(amx_ctx* ctx, const amx_ffnn_model* model, amx_ffnn** out);
+void amx_ffnn_destroy(amx_ffnn* h);
+int  amx_ffnn_input_dim(const amx_ffnn* h);
+int  amx_ffnn_output_dim(const amx_ffnn* h);
+/* feats [T x in0]; scores [T x out_last] = -(W x + b - alpha * log_prior) */
+int amx_ffnn_score(amx_ffnn* h, const float* feats_host, int T, float* scores_host);
+int amx_ffnn_score_dev(amx_ffnn* h, const float* feats_dev, int feats_stride, int T, float* scores_dev);
+
+/* ------------------------------------------------------------------ per-epoch statistics */
+
+/* For every frame t: best state = argmin_e scores[t][e] (first minimum wins);
+ * state_counts[e] += 1 (u64), *score_sum += scores[t][best] (f64).  The caller all-reduces
+ * state_counts / score_sum across ranks once per epoch. best_state_dev nullable [T]. */
+int amx_stats_accumulate_dev(amx_ctx* ctx, const float* scores_dev, int T, int n_emissions,
+                             uint32_t* best_state_dev, unsigned long long* state_counts_dev,
+                             double* score_sum_dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

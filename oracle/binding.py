@@ -262,5 +262,5 @@ def oracle_ffnn_score(Ws, biases, acts, feats, log_prior=None, prior_scale=1.0, 
     feats = np.ascontiguousarray(feats, dtype=np.float32)
     T = feats.shape[0]
     out = np.zeros((T, int(outd[-1])), np.float32)
-    L.orc_ffnn_score(C.byref(st), feats.reshape(-1), T, out.reshape(-1), 1 if acc64 else 0)
+    L.orc_ffnn_score(C.byref(st), feats.reshape(-1), T, out.reshape(-1), int(acc64))
     return out

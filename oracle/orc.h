@@ -132,7 +132,8 @@ typedef struct {
 } orc_ffnn_model;
 
 /* feats [T x in0] row-major; scores [T x out_last] = -(W x + b - alpha*logprior).
- * acc64 != 0 accumulates dot products in f64 (tight "truth"), else f32 k-ordered. */
+ * acc64: 0 = f32 multiply-then-add in ascending k, 1 = f64 accumulation (tight "truth"),
+ * 2 = f32 fmaf chain in ascending k (bit pattern of an f32 MFMA / FMA GEMM). */
 void orc_ffnn_score(const orc_ffnn_model* m, const float* feats, int T, float* scores, int acc64);
 
 #ifdef __cplusplus

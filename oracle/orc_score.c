@@ -244,7 +244,10 @@ int orc_gmm_score_batch_float(const orc_gmm* h, const double* log_weight, const 
 static float orc_act(float v, int act) {
     switch (act) {
         case ORC_ACT_RELU: return v < 0 ? 0 : v;                     /* ensureMinimalValue(0) */
-        case ORC_ACT_SIGMOID: return (float)(1.0 / (1.0 + exp(-(double)v))); /* Math/FastMatrix sigmoid */
+        case ORC_ACT_SIGMOID: { /* Math/FastMatrix.hh:802-808: scale(-1), exp() in f32, 1.0/(1.0+e) in f64 */
+            float e = expf(-v);
+            return (float)(1.0 / (1.0 + e));
+        }
         case ORC_ACT_TANH: return tanhf(v);
         default: return v;
     }
@@ -266,7 +269,13 @@ void orc_ffnn_score(const orc_ffnn_model* m, const float* feats, int T, float* s
             for (int o = 0; o < out; ++o) {
                 const float* w = W + (size_t)o * in;
                 float        z;
-                if (acc64) {
+                if (acc64 == 2) { /* k-ordered fused multiply-add chain (what an f32 MFMA computes) */
+                    float s = 0;
+                    for (int i = 0; i < in; ++i)
+                        s = fmaf(w[i], a[i], s);
+                    z = s;
+                }
+                else if (acc64) {
                     double s = 0;
                     for (int i = 0; i < in; ++i)
                         s += (double)w[i] * (double)a[i];

@@ -1,0 +1,304 @@
+"""rasr_amd -- MI355X-native acoustic front-end and emission scorers for RASR.
+
+Python here is plumbing only (ctypes onto librasr_amd.so, torch for device buffers / streams /
+torch.distributed); all arithmetic runs in the HIP kernels behind include/amx.h.  The C++
+adapters a RASR maintainer links are described in INTEGRATION.md; the classes below mirror the
+same reference interfaces for tests and benchmarks:
+
+  MfccExtractor        mfcc.flow network (Tools/FeatureExtraction/share/mfcc.flow)
+  GmmFeatureScorer     Mm::FeatureScorer over a Mm::MixtureSet (diagonal-maximum / diagonal-sum)
+  NnBatchFeatureScorer Nn::BatchFeatureScorer (nn-batch-feature-scorer)
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import (AMX_ACT_NONE, AMX_ACT_RELU, AMX_ACT_SIGMOID, AMX_ACT_TANH, AMX_GMM_MAX, AMX_GMM_SUM,  # noqa: F401
+                   AMX_PREC_BF16, AMX_PREC_FP32, AmxError, MfccCfg)
+
+__all__ = ["Context", "MfccExtractor", "GmmFeatureScorer", "NnBatchFeatureScorer", "AmxError", "read_pms", "write_pms"]
+
+
+def _ptr(a):
+    """address of a numpy array or of a (device) torch tensor"""
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data
+    return a.data_ptr()
+
+
+class Context:
+    """One per process and GPU (amx_ctx)."""
+
+    def __init__(self, device=0):
+        self.L = _lib.lib()
+        h = C.c_void_p()
+        _lib.check(self.L.amx_init(device, C.byref(h)))
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.amx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def use_torch_stream(self):
+        """Launch on torch's current HIP stream (so torch events / allocator ordering apply)."""
+        import torch
+        _lib.check(self.L.amx_set_stream(self.h, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+
+    def synchronize(self):
+        _lib.check(self.L.amx_synchronize(self.h))
+
+    def profile(self, enable=True):
+        _lib.check(self.L.amx_profile_enable(self.h, 1 if enable else 0))
+
+    def profile_reset(self):
+        _lib.check(self.L.amx_profile_reset(self.h))
+
+    def profile_get(self, kernel):
+        ms, n = C.c_double(), C.c_long()
+        _lib.check(self.L.amx_profile_get(self.h, kernel.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def context_window(self, plan, feats, dim, left, right, out, out_stride):
+        _lib.check(self.L.amx_context_window_dev(self.h, plan.h, _ptr(feats), dim, left, right, _ptr(out), out_stride))
+
+    def stats_accumulate(self, scores, T, M, best_state, counts, score_sum):
+        _lib.check(self.L.amx_stats_accumulate_dev(self.h, _ptr(scores), T, M, _ptr(best_state), _ptr(counts), _ptr(score_sum)))
+
+
+class _Plan:
+    def __init__(self, owner, sample_offsets):
+        self.owner = owner
+        self.L = owner.L
+        off = np.ascontiguousarray(sample_offsets, dtype=np.int64)
+        self.n_seg = len(off) - 1
+        h = C.c_void_p()
+        _lib.check(self.L.amx_mfcc_plan_create(owner.h, self.n_seg, off.ctypes.data, C.byref(h)))
+        self.h = h
+        self.total_frames = int(self.L.amx_mfcc_plan_total_frames(h))
+        fo = np.zeros(self.n_seg + 1, np.int64)
+        _lib.check(self.L.amx_mfcc_plan_frame_offsets(h, fo.ctypes.data))
+        self.frame_offsets = fo
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.L.amx_mfcc_plan_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+class MfccExtractor:
+    """The mfcc.flow chain.  Keyword names follow the Flow node parameters."""
+
+    def __init__(self, ctx, nr_cepstrum_coefficients=16, filter_width=268.258, sample_rate=16000.0, alpha=1.0,
+                 length=0.025, shift=0.01, maximum_input_size=0.025, apply_scale=True, spacing=0.0,
+                 warp_differential_unit=True, normalize=False):
+        self.ctx, self.L = ctx, ctx.L
+        cfg = MfccCfg(sample_rate, length, shift, alpha, maximum_input_size, int(apply_scale), filter_width, spacing,
+                      int(warp_differential_unit), nr_cepstrum_coefficients, int(normalize))
+        h = C.c_void_p()
+        _lib.check(self.L.amx_mfcc_create(ctx.h, C.byref(cfg), C.byref(h)))
+        self.h = h
+        info = _lib.MfccInfo()
+        _lib.check(self.L.amx_mfcc_describe(h, C.byref(info)))
+        self.info = info
+        self.n_ceps, self.n_filters = info.n_ceps, info.n_filters
+        self.frame_len, self.frame_shift, self.fft_len = info.frame_len, info.frame_shift, info.fft_len
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.L.amx_mfcc_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def n_frames(self, n_samples):
+        return int(self.L.amx_mfcc_n_frames(self.h, n_samples))
+
+    def frame_start_time(self, frame):
+        return float(self.L.amx_mfcc_frame_start_time(self.h, frame))
+
+    def tables(self):
+        i = self.info
+        win = np.zeros(i.frame_len, np.float32)
+        fs, fe, fo = np.zeros(i.n_filters, np.int32), np.zeros(i.n_filters, np.int32), np.zeros(i.n_filters + 1, np.int32)
+        _lib.check(self.L.amx_mfcc_tables(self.h, None, None, None, fo.ctypes.data, None, None))
+        fw = np.zeros(int(fo[-1]), np.float32)
+        dct = np.zeros((i.n_ceps, i.n_filters), np.float32)
+        _lib.check(self.L.amx_mfcc_tables(self.h, win.ctypes.data, fs.ctypes.data, fe.ctypes.data, fo.ctypes.data,
+                                          fw.ctypes.data, dct.ctypes.data))
+        return dict(window=win, filter_start=fs, filter_end=fe, filter_offset=fo, filter_weights=fw, dct=dct)
+
+    def run(self, pcm):
+        """host path: one segment of f32 samples -> [n_frames, n_ceps]"""
+        pcm = np.ascontiguousarray(pcm, dtype=np.float32)
+        out = np.zeros((self.n_frames(len(pcm)), self.n_ceps), np.float32)
+        _lib.check(self.L.amx_mfcc_run(self.h, pcm.ctypes.data, len(pcm), out.ctypes.data))
+        return out
+
+    def run_batch(self, pcms):
+        pcms = [np.ascontiguousarray(p, dtype=np.float32) for p in pcms]
+        outs = [np.zeros((self.n_frames(len(p)), self.n_ceps), np.float32) for p in pcms]
+        n = len(pcms)
+        ip = (C.c_void_p * n)(*[p.ctypes.data for p in pcms])
+        op = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+        ln = np.array([len(p) for p in pcms], np.int64)
+        _lib.check(self.L.amx_mfcc_run_batch(self.h, n, C.cast(ip, C.c_void_p), ln.ctypes.data, C.cast(op, C.c_void_p)))
+        return outs
+
+    def plan(self, sample_offsets):
+        return _Plan(self, sample_offsets)
+
+    def run_plan(self, plan, pcm_dev, ceps_dev):
+        """device path: concatenated PCM tensor -> [total_frames, n_ceps] tensor (both resident in HBM)"""
+        _lib.check(self.L.amx_mfcc_run_plan_dev(self.h, plan.h, _ptr(pcm_dev), _ptr(ceps_dev)))
+
+
+def _gmm_struct(model, mixture_weight_scale, gaussian_scale, keep):
+    m = {k: (np.ascontiguousarray(v) if isinstance(v, np.ndarray) else v) for k, v in model.items()}
+    assert m["mix_offsets"].dtype == np.uint32 and m["dens_index"].dtype == np.uint32
+    assert m["dens_mean"].dtype == np.uint32 and m["dens_cov"].dtype == np.uint32
+    assert m["log_weight"].dtype == np.float64 and m["means"].dtype == np.float32 and m["variances"].dtype == np.float32
+    keep.append(m)
+    return _lib.GmmModel(int(m["dim"]), len(m["mix_offsets"]) - 1, len(m["dens_mean"]), m["means"].shape[0],
+                         m["variances"].shape[0], m["mix_offsets"].ctypes.data, m["dens_index"].ctypes.data,
+                         m["log_weight"].ctypes.data, m["dens_mean"].ctypes.data, m["dens_cov"].ctypes.data,
+                         m["means"].ctypes.data, m["variances"].ctypes.data, mixture_weight_scale, gaussian_scale)
+
+
+class GmmFeatureScorer:
+    """Mm::FeatureScorer over a mixture set; feature_scorer_type in {"diagonal-maximum", "diagonal-sum"}.
+
+    model: dict(dim, mix_offsets u32[M+1], dens_index u32[sumK], log_weight f64[sumK], dens_mean u32[D],
+    dens_cov u32[D], means f32[n_mean,dim], variances f32[n_cov,dim]).
+    """
+
+    def __init__(self, ctx, model, feature_scorer_type="diagonal-maximum", mixture_weight_scale=1.0, gaussian_scale=1.0):
+        self.ctx, self.L = ctx, ctx.L
+        self.mode = {"diagonal-maximum": AMX_GMM_MAX, "diagonal-sum": AMX_GMM_SUM}[feature_scorer_type]
+        keep = []
+        st = _gmm_struct(model, mixture_weight_scale, gaussian_scale, keep)
+        h = C.c_void_p()
+        _lib.check(self.L.amx_gmm_create(ctx.h, C.byref(st), C.byref(h)))
+        self.h = h
+        self.n_mix, self.dim = st.n_mix, st.dim
+        self._nk, self._ncov = int(keep[0]["mix_offsets"][-1]), st.n_cov
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.L.amx_gmm_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def nMixtures(self):
+        return int(self.L.amx_gmm_n_mixtures(self.h))
+
+    def dimension(self):
+        return int(self.L.amx_gmm_dimension(self.h))
+
+    def tables(self):
+        a, b, c = np.zeros(self._nk, np.float32), np.zeros((self._ncov, self.dim), np.float32), np.zeros(self._ncov, np.float32)
+        _lib.check(self.L.amx_gmm_tables(self.h, a.ctypes.data, b.ctypes.data, c.ctypes.data))
+        return a, b, c
+
+    def score(self, feats, want_best=True):
+        """host path: feats [T, dim] -> (scores [T, M], best_density [T, M])"""
+        feats = np.ascontiguousarray(feats, dtype=np.float32)
+        T = feats.shape[0]
+        sc = np.zeros((T, self.n_mix), np.float32)
+        best = np.zeros((T, self.n_mix), np.uint32) if want_best else None
+        _lib.check(self.L.amx_gmm_score(self.h, self.mode, feats.ctypes.data, T, sc.ctypes.data, _ptr(best)))
+        return (sc, best) if want_best else sc
+
+    def score_dev(self, feats_dev, T, scores_dev, best_dev=None):
+        _lib.check(self.L.amx_gmm_score_dev(self.h, self.mode, _ptr(feats_dev), T, _ptr(scores_dev), _ptr(best_dev)))
+
+
+class NnBatchFeatureScorer:
+    """Nn::BatchFeatureScorer: Ws[l] is [out, in] (RASR weights_[0] is the same memory, [in x out] col-major)."""
+
+    def __init__(self, ctx, Ws, biases, activations, log_prior=None, priori_scale=1.0, precision="bf16"):
+        self.ctx, self.L = ctx, ctx.L
+        n = len(Ws)
+        self._Ws = [np.ascontiguousarray(w, dtype=np.float32) for w in Ws]
+        self._bs = [np.ascontiguousarray(b, dtype=np.float32) for b in biases]
+        self._ind = np.array([w.shape[1] for w in self._Ws], np.int32)
+        self._outd = np.array([w.shape[0] for w in self._Ws], np.int32)
+        self._act = np.array(activations, np.int32)
+        self._lp = None if log_prior is None else np.ascontiguousarray(log_prior, dtype=np.float32)
+        Wp = (C.c_void_p * n)(*[w.ctypes.data for w in self._Ws])
+        Bp = (C.c_void_p * n)(*[b.ctypes.data for b in self._bs])
+        st = _lib.FfnnModel(n, self._ind.ctypes.data, self._outd.ctypes.data, C.cast(Wp, C.c_void_p), C.cast(Bp, C.c_void_p),
+                            self._act.ctypes.data, _ptr(self._lp), priori_scale,
+                            {"fp32": AMX_PREC_FP32, "bf16": AMX_PREC_BF16}[precision])
+        h = C.c_void_p()
+        _lib.check(self.L.amx_ffnn_create(ctx.h, C.byref(st), C.byref(h)))
+        self.h = h
+        self.in_dim, self.out_dim = int(self._ind[0]), int(self._outd[-1])
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.L.amx_ffnn_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def nMixtures(self):
+        return int(self.L.amx_ffnn_output_dim(self.h))
+
+    def score(self, feats):
+        feats = np.ascontiguousarray(feats, dtype=np.float32)
+        T = feats.shape[0]
+        out = np.zeros((T, self.out_dim), np.float32)
+        _lib.check(self.L.amx_ffnn_score(self.h, feats.ctypes.data, T, out.ctypes.data))
+        return out
+
+    def score_dev(self, feats_dev, feats_stride, T, scores_dev):
+        _lib.check(self.L.amx_ffnn_score_dev(self.h, _ptr(feats_dev), feats_stride, T, _ptr(scores_dev)))
+
+
+def read_pms(path):
+    """text mixture set -> model dict (see GmmFeatureScorer)"""
+    L = _lib.lib()
+    h = C.c_void_p()
+    _lib.check(L.amx_pms_read(path.encode(), C.byref(h)))
+    try:
+        v = _lib.GmmModel()
+        _lib.check(L.amx_mixture_set_view(h, C.byref(v)))
+        nk_arr = np.ctypeslib.as_array(C.cast(v.mix_offsets, C.POINTER(C.c_uint32)), shape=(v.n_mix + 1,)).copy()
+        nk = int(nk_arr[-1])
+
+        def arr(p, t, shape):
+            n = int(np.prod(shape))
+            if n == 0:
+                return np.zeros(shape, np.dtype(t))
+            return np.ctypeslib.as_array(C.cast(p, C.POINTER(t)), shape=shape).copy()
+
+        return dict(dim=v.dim, mix_offsets=nk_arr, dens_index=arr(v.dens_index, C.c_uint32, (nk,)),
+                    log_weight=arr(v.log_weight, C.c_double, (nk,)), dens_mean=arr(v.dens_mean, C.c_uint32, (v.n_dens,)),
+                    dens_cov=arr(v.dens_cov, C.c_uint32, (v.n_dens,)), means=arr(v.means, C.c_float, (v.n_mean, v.dim)),
+                    variances=arr(v.variances, C.c_float, (v.n_cov, v.dim)))
+    finally:
+        L.amx_mixture_set_destroy(h)
+
+
+def write_pms(model, path):
+    keep = []
+    st = _gmm_struct(model, 1.0, 1.0, keep)
+    _lib.check(_lib.lib().amx_pms_write(C.byref(st), path.encode()))

@@ -1,0 +1,118 @@
+"""ctypes view of librasr_amd.so (include/amx.h).  No compute happens in Python.
+
+The library is built in-tree by ``__graft_entry__.build()`` (``make -C rasr_amd/csrc``).  There is
+no fallback: if the shared object is missing or no gfx950 device is visible, the calls raise.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librasr_amd.so")
+
+AMX_OK, AMX_ERR_INVALID, AMX_ERR_UNSUPPORTED, AMX_ERR_DEVICE, AMX_ERR_STATE = 0, -1, -2, -3, -4
+AMX_GMM_MAX, AMX_GMM_SUM = 0, 1
+AMX_ACT_NONE, AMX_ACT_RELU, AMX_ACT_SIGMOID, AMX_ACT_TANH = 0, 1, 2, 3
+AMX_PREC_FP32, AMX_PREC_BF16 = 0, 1
+
+
+class AmxError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__("amx status %d: %s" % (status, message))
+        self.status = status
+
+
+class MfccCfg(C.Structure):
+    _fields_ = [("sample_rate", C.c_double), ("win_len_s", C.c_double), ("win_shift_s", C.c_double),
+                ("preemph_alpha", C.c_double), ("fft_max_input_s", C.c_double), ("apply_scale", C.c_int),
+                ("mel_filter_width", C.c_double), ("mel_spacing", C.c_double),
+                ("warp_differential_unit", C.c_int), ("n_ceps", C.c_int), ("dct_normalize", C.c_int)]
+
+
+class MfccInfo(C.Structure):
+    _fields_ = [("frame_len", C.c_int), ("frame_shift", C.c_int), ("fft_len", C.c_int), ("n_bins", C.c_int),
+                ("n_filters", C.c_int), ("n_ceps", C.c_int), ("fft_output_sample_rate", C.c_double),
+                ("mel_max", C.c_double)]
+
+
+class GmmModel(C.Structure):
+    _fields_ = [("dim", C.c_int), ("n_mix", C.c_int), ("n_dens", C.c_int), ("n_mean", C.c_int), ("n_cov", C.c_int),
+                ("mix_offsets", C.c_void_p), ("dens_index", C.c_void_p), ("log_weight", C.c_void_p),
+                ("dens_mean", C.c_void_p), ("dens_cov", C.c_void_p), ("means", C.c_void_p),
+                ("variances", C.c_void_p), ("mixture_weight_scale", C.c_float), ("gaussian_scale", C.c_float)]
+
+
+class FfnnModel(C.Structure):
+    _fields_ = [("n_layers", C.c_int), ("in_dim", C.c_void_p), ("out_dim", C.c_void_p), ("W", C.c_void_p),
+                ("bias", C.c_void_p), ("activation", C.c_void_p), ("log_prior", C.c_void_p),
+                ("prior_scale", C.c_float), ("precision", C.c_int)]
+
+
+# name -> (restype, argtypes); this table is also what tests/test_abi.py checks against amx.h
+_P = C.c_void_p
+SIGNATURES = {
+    "amx_version": (C.c_char_p, []),
+    "amx_last_error": (C.c_char_p, []),
+    "amx_init": (C.c_int, [C.c_int, C.POINTER(_P)]),
+    "amx_destroy": (None, [_P]),
+    "amx_set_stream": (C.c_int, [_P, _P]),
+    "amx_synchronize": (C.c_int, [_P]),
+    "amx_profile_enable": (C.c_int, [_P, C.c_int]),
+    "amx_profile_reset": (C.c_int, [_P]),
+    "amx_profile_get": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_long)]),
+    "amx_mfcc_default_cfg": (None, [C.POINTER(MfccCfg)]),
+    "amx_mfcc_create": (C.c_int, [_P, C.POINTER(MfccCfg), C.POINTER(_P)]),
+    "amx_mfcc_destroy": (None, [_P]),
+    "amx_mfcc_describe": (C.c_int, [_P, C.POINTER(MfccInfo)]),
+    "amx_mfcc_n_frames": (C.c_long, [_P, C.c_long]),
+    "amx_mfcc_frame_start_time": (C.c_double, [_P, C.c_long]),
+    "amx_mfcc_tables": (C.c_int, [_P] * 7),
+    "amx_mfcc_run": (C.c_int, [_P, _P, C.c_long, _P]),
+    "amx_mfcc_run_batch": (C.c_int, [_P, C.c_int, _P, _P, _P]),
+    "amx_mfcc_plan_create": (C.c_int, [_P, C.c_int, _P, C.POINTER(_P)]),
+    "amx_mfcc_plan_destroy": (None, [_P]),
+    "amx_mfcc_plan_total_frames": (C.c_long, [_P]),
+    "amx_mfcc_plan_frame_offsets": (C.c_int, [_P, _P]),
+    "amx_mfcc_run_plan_dev": (C.c_int, [_P, _P, _P, _P]),
+    "amx_context_window_dev": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int]),
+    "amx_gmm_create": (C.c_int, [_P, C.POINTER(GmmModel), C.POINTER(_P)]),
+    "amx_gmm_destroy": (None, [_P]),
+    "amx_gmm_n_mixtures": (C.c_int, [_P]),
+    "amx_gmm_dimension": (C.c_int, [_P]),
+    "amx_gmm_tables": (C.c_int, [_P, _P, _P, _P]),
+    "amx_gmm_score": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, _P]),
+    "amx_gmm_score_dev": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, _P]),
+    "amx_pms_read": (C.c_int, [C.c_char_p, C.POINTER(_P)]),
+    "amx_pms_write": (C.c_int, [C.POINTER(GmmModel), C.c_char_p]),
+    "amx_mixture_set_view": (C.c_int, [_P, C.POINTER(GmmModel)]),
+    "amx_mixture_set_destroy": (None, [_P]),
+    "amx_ffnn_create": (C.c_int, [_P, C.POINTER(FfnnModel), C.POINTER(_P)]),
+    "amx_ffnn_destroy": (None, [_P]),
+    "amx_ffnn_input_dim": (C.c_int, [_P]),
+    "amx_ffnn_output_dim": (C.c_int, [_P]),
+    "amx_ffnn_score": (C.c_int, [_P, _P, C.c_int, _P]),
+    "amx_ffnn_score_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
+    "amx_stats_accumulate_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load librasr_amd.so; raises if it has not been built (there is no CPU fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("rasr_amd: %s is missing -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(hipcc, gfx950). This package has no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the ABI symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(status):
+    if status != AMX_OK:
+        raise AmxError(status, lib().amx_last_error().decode("utf-8", "replace"))

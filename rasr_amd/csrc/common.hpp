@@ -1,0 +1,85 @@
+// common.hpp -- internals shared by the librasr_amd.so translation units (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/amx.h"
+
+namespace amx {
+
+void set_error(const char* fmt, ...);
+
+#define AMX_HIP(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e__ = (expr);                                                               \
+        if (e__ != hipSuccess) {                                                               \
+            amx::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+            return AMX_ERR_DEVICE;                                                             \
+        }                                                                                      \
+    } while (0)
+
+#define AMX_REQUIRE(cond, status, ...)   \
+    do {                                 \
+        if (!(cond)) {                   \
+            amx::set_error(__VA_ARGS__); \
+            return (status);             \
+        }                                \
+    } while (0)
+
+// Per-kernel event timing (amx_profile_*): pairs of events recorded around a launch on the
+// context's current stream; resolved lazily in amx_profile_get.
+struct ProfileSlot {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    double                                          total_ms = 0;
+    long                                            n        = 0;
+};
+
+}  // namespace amx
+
+struct amx_ctx {
+    int                                      device     = 0;
+    hipStream_t                              own_stream = nullptr;
+    hipStream_t                              stream     = nullptr;
+    bool                                     profiling  = false;
+    std::map<std::string, amx::ProfileSlot>  prof;
+    int                                      n_cu = 0;
+    // scratch for amx_stats_accumulate_dev
+    void*  scratch       = nullptr;
+    size_t scratch_bytes = 0;
+
+    int ensure_scratch(size_t bytes);
+};
+
+namespace amx {
+
+// RAII-less helper: records start/stop events around a launch when profiling is on.
+struct ScopedKernelTimer {
+    amx_ctx*    ctx;
+    const char* name;
+    hipEvent_t  a = nullptr, b = nullptr;
+    ScopedKernelTimer(amx_ctx* c, const char* n)
+            : ctx(c), name(n) {
+        if (ctx->profiling) {
+            hipEventCreate(&a);
+            hipEventCreate(&b);
+            hipEventRecord(a, ctx->stream);
+        }
+    }
+    ~ScopedKernelTimer() {
+        if (a) {
+            hipEventRecord(b, ctx->stream);
+            ctx->prof[name].events.emplace_back(a, b);
+        }
+    }
+};
+
+inline int ceil_div(long a, long b) {
+    return (int)((a + b - 1) / b);
+}
+
+}  // namespace amx

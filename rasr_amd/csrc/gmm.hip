@@ -1,0 +1,651 @@
+// gmm.hip -- diagonal-covariance GMM emission scorer for gfx950 and the amx_gmm_* ABI.
+//
+// Replaces Mm::GaussDiagonalMaximumFeatureScorer / GaussDiagonalSumFeatureScorer
+// (Mm/GaussDiagonalMaximumFeatureScorer.cc:116-298) evaluated for ALL emissions of a batch of
+// frames (the reference evaluates lazily per active state; a batch scorer answers score(e)
+// from the [T x M] matrix like Nn::BatchFeatureScorer::getScore does).
+//
+// Mapping to the hardware
+//   * lane = frame.  A wavefront owns 64 consecutive frames and keeps each frame's feature
+//     vector in VGPRs (DIM registers per lane).  The model is wave-uniform: means, 1/sigma and
+//     the per-density constants stream through the SCALAR data path (s_load via the constant
+//     cache), so every VALU instruction takes one SGPR model operand and one VGPR feature
+//     operand -- no LDS, no cross-lane traffic, and the reduction over the densities of a
+//     mixture is a sequential per-lane loop exactly like the reference's.
+//   * direct kernel: workgroup = 4 frame-waves x one tile of MT mixtures (densities private to
+//     mixtures, CART-style models).
+//   * tied models (sum K_m >> #densities): stage 1 computes every density's distance once
+//     (dist[d][t], coalesced along t), stage 2 combines dist with the mixture weights.
+//
+// Exactness (max mode): the squared distance is accumulated in the reference's SSE order --
+// four strided partial sums over dim&~3, (l0+l1)+(l2+l3), scalar tail -- with separate
+// multiply and add (-ffp-contract=off); the combine (f64)m2lw + (f64)logNorm + (f64)dist is done
+// in f64 (the first f64 addition is folded on the host, it does not depend on the frame); the
+// running best is an f32 compared as f64 with strict '>', so the first minimum wins.  Scores and
+// best-density indices are therefore bit-identical to the reference's x86-64 build.
+#include "common.hpp"
+
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+
+namespace amx {
+
+struct GmmParams {
+    const float* __restrict__ feats;     // [T x dim]
+    float* __restrict__ scores;          // [T x n_mix]
+    uint32_t* __restrict__ best;         // nullable [T x n_mix]
+    const uint32_t* __restrict__ mix_off;  // [n_mix+1]
+    const uint32_t* __restrict__ k_mean;   // [nk] mean row of entry k
+    const uint32_t* __restrict__ k_cov;    // [nk] covariance row of entry k
+    const double* __restrict__ k_c64;      // [nk] (f64)m2lw + (f64)logNorm
+    const float* __restrict__ k_c32;       // [nk] m2lw + logNorm in f32 (sum mode)
+    const float* __restrict__ means;       // [n_mean x dim]
+    const float* __restrict__ isr;         // [n_cov x dim]
+    int T, dim, n_mix, mix_tile;
+};
+
+// distance in the reference's association order; mu / is are wave-uniform pointers
+template<int DIM>
+__device__ __forceinline__ float gmm_distance(const float (&x)[DIM], const float* __restrict__ mu, const float* __restrict__ is) {
+    float         l0 = 0.f, l1 = 0.f, l2 = 0.f, l3 = 0.f;
+    constexpr int EFF = DIM & ~3;
+#pragma unroll
+    for (int i = 0; i < EFF; i += 4) {
+        float d0 = (mu[i] - x[i]) * is[i];
+        float d1 = (mu[i + 1] - x[i + 1]) * is[i + 1];
+        float d2 = (mu[i + 2] - x[i + 2]) * is[i + 2];
+        float d3 = (mu[i + 3] - x[i + 3]) * is[i + 3];
+        l0       = l0 + d0 * d0;
+        l1       = l1 + d1 * d1;
+        l2       = l2 + d2 * d2;
+        l3       = l3 + d3 * d3;
+    }
+    float result = 0.f;
+    result       = result + ((l0 + l1) + (l2 + l3));
+#pragma unroll
+    for (int i = EFF; i < DIM; ++i) {
+        float df = (mu[i] - x[i]) * is[i];
+        result   = result + df * df;
+    }
+    return result;
+}
+
+// runtime-dimension variant: features live in LDS as [dim][64] (one column per lane)
+__device__ __forceinline__ float gmm_distance_rt(const float* xs, int dim, const float* __restrict__ mu, const float* __restrict__ is) {
+    float     l0 = 0.f, l1 = 0.f, l2 = 0.f, l3 = 0.f;
+    const int eff = dim & ~3;
+    for (int i = 0; i < eff; i += 4) {
+        float d0 = (mu[i] - xs[i * 64]) * is[i];
+        float d1 = (mu[i + 1] - xs[(i + 1) * 64]) * is[i + 1];
+        float d2 = (mu[i + 2] - xs[(i + 2) * 64]) * is[i + 2];
+        float d3 = (mu[i + 3] - xs[(i + 3) * 64]) * is[i + 3];
+        l0       = l0 + d0 * d0;
+        l1       = l1 + d1 * d1;
+        l2       = l2 + d2 * d2;
+        l3       = l3 + d3 * d3;
+    }
+    float result = 0.f;
+    result       = result + ((l0 + l1) + (l2 + l3));
+    for (int i = eff; i < dim; ++i) {
+        float df = (mu[i] - xs[i * 64]) * is[i];
+        result   = result + df * df;
+    }
+    return result;
+}
+
+struct MaxState {
+    float    best   = FLT_MAX;
+    double   best_d = (double)FLT_MAX;
+    uint32_t idx    = 0xffffffffu;
+    __device__ __forceinline__ void add(double c64, float, float dist, uint32_t k) {
+        double s = c64 + (double)dist;
+        if (best_d > s) {
+            best   = (float)s;
+            best_d = (double)best;
+            idx    = k;
+        }
+    }
+    __device__ __forceinline__ float result() const { return 0.5f * best; }
+};
+
+struct SumState {
+    float    best = FLT_MAX;
+    float    sum  = 0.f;
+    uint32_t idx  = 0xffffffffu;
+    __device__ __forceinline__ void add(double, float c32, float dist, uint32_t k) {
+        float score = c32 + dist;  // (m2lw + logNorm) + dist, all f32
+        float s     = 0.5f * score;
+        if (best > s) {
+            sum  = sum * expf(s - best) + 1.f;
+            best = s;
+            idx  = k;
+        }
+        else
+            sum = sum + expf(best - s);
+    }
+    __device__ __forceinline__ float result() const { return best - logf(sum); }
+};
+
+// DIM > 0: features in registers; DIM == 0: runtime dimension, features in LDS
+struct GmmDims {
+    int T, dim, n_mix, mix_tile;
+};
+
+// All model tables are separate `const __restrict__` kernel arguments so that the compiler may
+// prove them read-only and fetch them through the scalar cache (s_load) -- struct members lose
+// the qualifier and fall back to per-lane vector loads.
+template<int DIM, class State>
+__global__ __launch_bounds__(256) void gmm_direct_kernel(const float* __restrict__ g_feats, float* __restrict__ g_scores,
+                                                        uint32_t* __restrict__ g_best, const uint32_t* __restrict__ g_mix_off,
+                                                        const uint32_t* __restrict__ g_k_mean, const uint32_t* __restrict__ g_k_cov,
+                                                        const double* __restrict__ g_k_c64, const float* __restrict__ g_k_c32,
+                                                        const float* __restrict__ g_means, const float* __restrict__ g_isr,
+                                                        GmmDims dims) {
+    struct {
+        const float* __restrict__ feats; float* __restrict__ scores; uint32_t* __restrict__ best;
+        const uint32_t* __restrict__ mix_off; const uint32_t* __restrict__ k_mean; const uint32_t* __restrict__ k_cov;
+        const double* __restrict__ k_c64; const float* __restrict__ k_c32; const float* __restrict__ means;
+        const float* __restrict__ isr; int T, dim, n_mix, mix_tile;
+    } p = {g_feats, g_scores, g_best, g_mix_off, g_k_mean, g_k_cov, g_k_c64, g_k_c32, g_means, g_isr,
+           dims.T, dims.dim, dims.n_mix, dims.mix_tile};
+    extern __shared__ float xs_all[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int t    = (blockIdx.y * 4 + wave) * 64 + lane;
+    const bool live = t < p.T;
+    const int  tt   = live ? t : (p.T - 1);
+
+    float  x[DIM > 0 ? DIM : 1];
+    float* xs = nullptr;
+    if (DIM > 0) {
+#pragma unroll
+        for (int i = 0; i < DIM; ++i)
+            x[i] = p.feats[(size_t)tt * DIM + i];
+    }
+    else {
+        xs = xs_all + wave * 64 * p.dim + lane;
+        for (int i = 0; i < p.dim; ++i)
+            xs[i * 64] = p.feats[(size_t)tt * p.dim + i];
+    }
+    // wave-uniform loop bounds (blockIdx only)
+    const int m0 = blockIdx.x * p.mix_tile;
+    const int m1 = min(m0 + p.mix_tile, p.n_mix);
+    for (int m = m0; m < m1; ++m) {
+        const uint32_t k0 = p.mix_off[m], k1 = p.mix_off[m + 1];
+        State          st;
+        for (uint32_t k = k0; k < k1; ++k) {
+            const float* mu = p.means + (size_t)p.k_mean[k] * (DIM > 0 ? DIM : p.dim);
+            const float* is = p.isr + (size_t)p.k_cov[k] * (DIM > 0 ? DIM : p.dim);
+            float        dist;
+            if (DIM > 0)
+                dist = gmm_distance<(DIM > 0 ? DIM : 1)>(x, mu, is);
+            else
+                dist = gmm_distance_rt(xs, p.dim, mu, is);
+            st.add(p.k_c64[k], p.k_c32[k], dist, k - k0);
+        }
+        if (live) {
+            p.scores[(size_t)t * p.n_mix + m] = st.result();
+            if (p.best)
+                p.best[(size_t)t * p.n_mix + m] = st.idx;
+        }
+    }
+}
+
+// ---- two-stage path for tied models
+struct GmmDistParams {
+    const float* __restrict__ feats;     // [T x dim] (chunk)
+    float* __restrict__ dist;            // [n_dens x Tpad]
+    const uint32_t* __restrict__ d_mean; // [n_dens]
+    const uint32_t* __restrict__ d_cov;  // [n_dens]
+    const float* __restrict__ means;
+    const float* __restrict__ isr;
+    int T, Tpad, dim, n_dens, dens_tile;
+};
+
+struct GmmDistDims {
+    int T, Tpad, dim, n_dens, dens_tile;
+};
+
+template<int DIM>
+__global__ __launch_bounds__(256) void gmm_dist_kernel(const float* __restrict__ g_feats, float* __restrict__ g_dist,
+                                                      const uint32_t* __restrict__ g_d_mean, const uint32_t* __restrict__ g_d_cov,
+                                                      const float* __restrict__ g_means, const float* __restrict__ g_isr,
+                                                      GmmDistDims dims) {
+    struct {
+        const float* __restrict__ feats; float* __restrict__ dist; const uint32_t* __restrict__ d_mean;
+        const uint32_t* __restrict__ d_cov; const float* __restrict__ means; const float* __restrict__ isr;
+        int T, Tpad, dim, n_dens, dens_tile;
+    } p = {g_feats, g_dist, g_d_mean, g_d_cov, g_means, g_isr, dims.T, dims.Tpad, dims.dim, dims.n_dens, dims.dens_tile};
+    extern __shared__ float xs_all[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int t    = (blockIdx.y * 4 + wave) * 64 + lane;
+    const int tt   = t < p.T ? t : (p.T - 1);
+    float     x[DIM > 0 ? DIM : 1];
+    float*    xs = nullptr;
+    if (DIM > 0) {
+#pragma unroll
+        for (int i = 0; i < DIM; ++i)
+            x[i] = p.feats[(size_t)tt * DIM + i];
+    }
+    else {
+        xs = xs_all + wave * 64 * p.dim + lane;
+        for (int i = 0; i < p.dim; ++i)
+            xs[i * 64] = p.feats[(size_t)tt * p.dim + i];
+    }
+    const int d0 = blockIdx.x * p.dens_tile;
+    const int d1 = min(d0 + p.dens_tile, p.n_dens);
+    for (int d = d0; d < d1; ++d) {
+        const float* mu = p.means + (size_t)p.d_mean[d] * (DIM > 0 ? DIM : p.dim);
+        const float* is = p.isr + (size_t)p.d_cov[d] * (DIM > 0 ? DIM : p.dim);
+        float        dist;
+        if (DIM > 0)
+            dist = gmm_distance<(DIM > 0 ? DIM : 1)>(x, mu, is);
+        else
+            dist = gmm_distance_rt(xs, p.dim, mu, is);
+        if (t < p.Tpad)
+            p.dist[(size_t)d * p.Tpad + t] = dist;  // coalesced along t
+    }
+}
+
+struct GmmCombineParams {
+    const float* __restrict__ dist;        // [n_dens x Tpad]
+    float* __restrict__ scores;            // [T x n_mix]
+    uint32_t* __restrict__ best;           // nullable
+    const uint32_t* __restrict__ mix_off;
+    const uint32_t* __restrict__ k_dens;   // [nk] density of entry k
+    const double* __restrict__ k_c64;
+    const float* __restrict__ k_c32;
+    int T, Tpad, n_mix, mix_tile;
+};
+
+struct GmmCombineDims {
+    int T, Tpad, n_mix, mix_tile;
+};
+
+template<class State>
+__global__ __launch_bounds__(256) void gmm_combine_kernel(const float* __restrict__ g_dist, float* __restrict__ g_scores,
+                                                         uint32_t* __restrict__ g_best, const uint32_t* __restrict__ g_mix_off,
+                                                         const uint32_t* __restrict__ g_k_dens, const double* __restrict__ g_k_c64,
+                                                         const float* __restrict__ g_k_c32, GmmCombineDims dims) {
+    struct {
+        const float* __restrict__ dist; float* __restrict__ scores; uint32_t* __restrict__ best;
+        const uint32_t* __restrict__ mix_off; const uint32_t* __restrict__ k_dens; const double* __restrict__ k_c64;
+        const float* __restrict__ k_c32; int T, Tpad, n_mix, mix_tile;
+    } p = {g_dist, g_scores, g_best, g_mix_off, g_k_dens, g_k_c64, g_k_c32, dims.T, dims.Tpad, dims.n_mix, dims.mix_tile};
+    const int  lane = threadIdx.x & 63;
+    const int  wave = threadIdx.x >> 6;
+    const int  t    = (blockIdx.y * 4 + wave) * 64 + lane;
+    const bool live = t < p.T;
+    const int  tt   = live ? t : (p.T - 1);
+    const int  m0   = blockIdx.x * p.mix_tile;
+    const int  m1   = min(m0 + p.mix_tile, p.n_mix);
+    for (int m = m0; m < m1; ++m) {
+        const uint32_t k0 = p.mix_off[m], k1 = p.mix_off[m + 1];
+        State          st;
+        for (uint32_t k = k0; k < k1; ++k) {
+            float dist = p.dist[(size_t)p.k_dens[k] * p.Tpad + tt];
+            st.add(p.k_c64[k], p.k_c32[k], dist, k - k0);
+        }
+        if (live) {
+            p.scores[(size_t)t * p.n_mix + m] = st.result();
+            if (p.best)
+                p.best[(size_t)t * p.n_mix + m] = st.idx;
+        }
+    }
+}
+
+}  // namespace amx
+
+// ------------------------------------------------------------------------------------ ABI
+
+struct amx_gmm {
+    amx_ctx* ctx = nullptr;
+    int      dim = 0, n_mix = 0, n_dens = 0, n_mean = 0, n_cov = 0;
+    size_t   nk = 0;
+    // host copies of the prepared tables (amx_gmm_tables)
+    std::vector<float>    m2lw, isr, lognorm;
+    std::vector<uint32_t> mix_off;
+    // device
+    uint32_t *d_mix_off = nullptr, *d_k_mean = nullptr, *d_k_cov = nullptr, *d_k_dens = nullptr;
+    uint32_t *d_d_mean = nullptr, *d_d_cov = nullptr;
+    double*   d_k_c64 = nullptr;
+    float *   d_k_c32 = nullptr, *d_means = nullptr, *d_isr = nullptr;
+    bool      tied    = false;  // use the two-stage path
+    float*    d_dist  = nullptr;
+    size_t    dist_floats = 0;
+};
+
+namespace {
+
+template<class T>
+int gupload(T** dst, const T* src, size_t n) {
+    AMX_HIP(hipMalloc((void**)dst, std::max<size_t>(n, 1) * sizeof(T)));
+    if (n)
+        AMX_HIP(hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
+    return AMX_OK;
+}
+
+template<class State>
+int launch_direct(amx_gmm* h, const amx::GmmParams& p, dim3 grid) {
+    hipStream_t  st  = h->ctx->stream;
+    size_t       lds = 0;
+    amx::GmmDims dims{p.T, p.dim, p.n_mix, p.mix_tile};
+    switch (h->dim) {
+#define AMX_GMM_CASE(D)                                                                                  \
+    case D:                                                                                              \
+        hipLaunchKernelGGL((amx::gmm_direct_kernel<D, State>), grid, dim3(256), 0, st, p.feats, p.scores, p.best, \
+                               p.mix_off, p.k_mean, p.k_cov, p.k_c64, p.k_c32, p.means, p.isr, dims);       \
+            break;
+        AMX_GMM_CASE(16)
+        AMX_GMM_CASE(24)
+        AMX_GMM_CASE(32)
+        AMX_GMM_CASE(33)
+        AMX_GMM_CASE(39)
+        AMX_GMM_CASE(40)
+        AMX_GMM_CASE(45)
+        AMX_GMM_CASE(48)
+        AMX_GMM_CASE(64)
+#undef AMX_GMM_CASE
+        default:
+            lds = (size_t)4 * 64 * h->dim * sizeof(float);
+            hipLaunchKernelGGL((amx::gmm_direct_kernel<0, State>), grid, dim3(256), lds, st, p.feats, p.scores, p.best,
+                               p.mix_off, p.k_mean, p.k_cov, p.k_c64, p.k_c32, p.means, p.isr, dims);
+    }
+    AMX_HIP(hipGetLastError());
+    return AMX_OK;
+}
+
+int launch_dist(amx_gmm* h, const amx::GmmDistParams& p, dim3 grid) {
+    hipStream_t      st  = h->ctx->stream;
+    size_t           lds = 0;
+    amx::GmmDistDims dims{p.T, p.Tpad, p.dim, p.n_dens, p.dens_tile};
+    switch (h->dim) {
+#define AMX_GMM_CASE(D)                                                                      \
+    case D:                                                                                  \
+        hipLaunchKernelGGL((amx::gmm_dist_kernel<D>), grid, dim3(256), 0, st, p.feats, p.dist, p.d_mean, p.d_cov, p.means, \
+                           p.isr, dims);                                                     \
+        break;
+        AMX_GMM_CASE(16)
+        AMX_GMM_CASE(24)
+        AMX_GMM_CASE(32)
+        AMX_GMM_CASE(33)
+        AMX_GMM_CASE(39)
+        AMX_GMM_CASE(40)
+        AMX_GMM_CASE(45)
+        AMX_GMM_CASE(48)
+        AMX_GMM_CASE(64)
+#undef AMX_GMM_CASE
+        default:
+            lds = (size_t)4 * 64 * h->dim * sizeof(float);
+            hipLaunchKernelGGL((amx::gmm_dist_kernel<0>), grid, dim3(256), lds, st, p.feats, p.dist, p.d_mean, p.d_cov, p.means,
+                               p.isr, dims);
+    }
+    AMX_HIP(hipGetLastError());
+    return AMX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int amx_gmm_create(amx_ctx* ctx, const amx_gmm_model* m, amx_gmm** out) {
+    // ctx == NULL creates a host-only handle (prepared tables only; scoring returns AMX_ERR_STATE)
+    AMX_REQUIRE(m && out, AMX_ERR_INVALID, "amx_gmm_create: NULL argument");
+    *out = nullptr;
+    AMX_REQUIRE(m->dim > 0 && m->n_mix > 0 && m->n_dens > 0 && m->n_mean > 0 && m->n_cov > 0, AMX_ERR_INVALID,
+                "amx_gmm_create: empty mixture set");
+    AMX_REQUIRE(m->dim <= 1024, AMX_ERR_UNSUPPORTED, "amx_gmm_create: feature dimension %d > 1024", m->dim);
+    AMX_REQUIRE(m->mix_offsets && m->dens_index && m->log_weight && m->dens_mean && m->dens_cov && m->means && m->variances,
+                AMX_ERR_INVALID, "amx_gmm_create: NULL table");
+    const size_t nk = m->mix_offsets[m->n_mix];
+    for (int i = 0; i < m->n_mix; ++i)
+        AMX_REQUIRE(m->mix_offsets[i] <= m->mix_offsets[i + 1], AMX_ERR_INVALID, "amx_gmm_create: mix_offsets not monotone");
+    for (size_t k = 0; k < nk; ++k)
+        AMX_REQUIRE(m->dens_index[k] < (uint32_t)m->n_dens, AMX_ERR_INVALID, "amx_gmm_create: density index out of range");
+    for (int d = 0; d < m->n_dens; ++d)
+        AMX_REQUIRE(m->dens_mean[d] < (uint32_t)m->n_mean && m->dens_cov[d] < (uint32_t)m->n_cov, AMX_ERR_INVALID,
+                    "amx_gmm_create: mean/covariance index out of range");
+    // CovarianceFeatureScorerElement::checkDiagonal: require(all variances > 0)
+    for (size_t i = 0; i < (size_t)m->n_cov * m->dim; ++i)
+        AMX_REQUIRE(m->variances[i] > 0, AMX_ERR_INVALID, "amx_gmm_create: non-positive variance");
+
+    amx_gmm* h = new amx_gmm;
+    h->ctx     = ctx;
+    h->dim     = m->dim;
+    h->n_mix   = m->n_mix;
+    h->n_dens  = m->n_dens;
+    h->n_mean  = m->n_mean;
+    h->n_cov   = m->n_cov;
+    h->nk      = nk;
+    h->mix_off.assign(m->mix_offsets, m->mix_offsets + m->n_mix + 1);
+
+    // ---- model preparation (Mm/MixtureFeatureScorerElement.cc:21-33,
+    //      Mm/CovarianceFeatureScorerElement.cc:21-51, Mm/Utilities.hh:53-91)
+    h->m2lw.resize(nk);
+    for (size_t k = 0; k < nk; ++k) {
+        float minus2 = (float)(-2 * m->log_weight[k]);  // f64 product stored as Score
+        h->m2lw[k]   = minus2 * m->mixture_weight_scale;
+    }
+    const float gs = std::sqrt(m->gaussian_scale);  // gaussianScale_(std::sqrt(param)) as f32
+    h->isr.resize((size_t)m->n_cov * m->dim);
+    h->lognorm.resize(m->n_cov);
+    for (int c = 0; c < m->n_cov; ++c) {
+        const float* var  = m->variances + (size_t)c * m->dim;
+        double       lsum = 0;
+        for (int i = 0; i < m->dim; ++i) {
+            float inv                      = (float)1 / (float)std::sqrt((double)var[i]);
+            h->isr[(size_t)c * m->dim + i] = inv * gs;
+            lsum += std::log((double)std::fabs(var[i]));
+        }
+        float ln      = (float)((double)m->dim * std::log((double)2 * M_PI) + lsum);
+        h->lognorm[c] = ln * (gs * gs);
+    }
+    std::vector<uint32_t> k_mean(nk), k_cov(nk), k_dens(nk);
+    std::vector<double>   c64(nk);
+    std::vector<float>    c32(nk);
+    for (size_t k = 0; k < nk; ++k) {
+        uint32_t d = m->dens_index[k];
+        k_dens[k]  = d;
+        k_mean[k]  = m->dens_mean[d];
+        k_cov[k]   = m->dens_cov[d];
+        c64[k]     = (double)h->m2lw[k] + (double)h->lognorm[k_cov[k]];
+        c32[k]     = h->m2lw[k] + h->lognorm[k_cov[k]];
+    }
+    // tied model: each density is referenced by several mixtures -> compute distances once
+    h->tied = nk >= (size_t)4 * (size_t)m->n_dens;
+
+    int r = AMX_OK;
+    if (!ctx) {
+        *out = h;
+        return AMX_OK;
+    }
+    hipSetDevice(ctx->device);
+    if ((r = gupload(&h->d_mix_off, h->mix_off.data(), h->mix_off.size())) != AMX_OK ||
+        (r = gupload(&h->d_k_mean, k_mean.data(), nk)) != AMX_OK || (r = gupload(&h->d_k_cov, k_cov.data(), nk)) != AMX_OK ||
+        (r = gupload(&h->d_k_dens, k_dens.data(), nk)) != AMX_OK ||
+        (r = gupload(&h->d_d_mean, m->dens_mean, (size_t)m->n_dens)) != AMX_OK ||
+        (r = gupload(&h->d_d_cov, m->dens_cov, (size_t)m->n_dens)) != AMX_OK ||
+        (r = gupload(&h->d_k_c64, c64.data(), nk)) != AMX_OK || (r = gupload(&h->d_k_c32, c32.data(), nk)) != AMX_OK ||
+        (r = gupload(&h->d_means, m->means, (size_t)m->n_mean * m->dim)) != AMX_OK ||
+        (r = gupload(&h->d_isr, h->isr.data(), h->isr.size())) != AMX_OK) {
+        amx_gmm_destroy(h);
+        return r;
+    }
+    *out = h;
+    return AMX_OK;
+}
+
+void amx_gmm_destroy(amx_gmm* h) {
+    if (!h)
+        return;
+    if (!h->ctx) {
+        delete h;
+        return;
+    }
+    hipSetDevice(h->ctx->device);
+    hipFree(h->d_mix_off);
+    hipFree(h->d_k_mean);
+    hipFree(h->d_k_cov);
+    hipFree(h->d_k_dens);
+    hipFree(h->d_d_mean);
+    hipFree(h->d_d_cov);
+    hipFree(h->d_k_c64);
+    hipFree(h->d_k_c32);
+    hipFree(h->d_means);
+    hipFree(h->d_isr);
+    hipFree(h->d_dist);
+    delete h;
+}
+
+int amx_gmm_n_mixtures(const amx_gmm* h) {
+    return h ? h->n_mix : 0;
+}
+int amx_gmm_dimension(const amx_gmm* h) {
+    return h ? h->dim : 0;
+}
+
+int amx_gmm_tables(const amx_gmm* h, float* m2lw, float* isr, float* lognorm) {
+    AMX_REQUIRE(h, AMX_ERR_INVALID, "amx_gmm_tables: NULL handle");
+    if (m2lw)
+        memcpy(m2lw, h->m2lw.data(), h->m2lw.size() * 4);
+    if (isr)
+        memcpy(isr, h->isr.data(), h->isr.size() * 4);
+    if (lognorm)
+        memcpy(lognorm, h->lognorm.data(), h->lognorm.size() * 4);
+    return AMX_OK;
+}
+
+int amx_gmm_score_dev(amx_gmm* h, int mode, const float* feats_dev, int T, float* scores_dev, uint32_t* best_dev) {
+    AMX_REQUIRE(h, AMX_ERR_INVALID, "amx_gmm_score_dev: NULL handle");
+    AMX_REQUIRE(h->ctx, AMX_ERR_STATE, "amx_gmm_score_dev: host-only handle (created without a context)");
+    AMX_REQUIRE(mode == AMX_GMM_MAX || mode == AMX_GMM_SUM, AMX_ERR_INVALID, "amx_gmm_score_dev: unknown mode %d", mode);
+    AMX_REQUIRE(T >= 0, AMX_ERR_INVALID, "amx_gmm_score_dev: negative frame count");
+    if (T == 0)
+        return AMX_OK;
+    AMX_REQUIRE(feats_dev && scores_dev, AMX_ERR_INVALID, "amx_gmm_score_dev: NULL buffer");
+    AMX_HIP(hipSetDevice(h->ctx->device));
+    const int fblocks = amx::ceil_div(T, 256);
+    if (!h->tied) {
+        amx::GmmParams p;
+        p.feats   = feats_dev;
+        p.scores  = scores_dev;
+        p.best    = best_dev;
+        p.mix_off = h->d_mix_off;
+        p.k_mean  = h->d_k_mean;
+        p.k_cov   = h->d_k_cov;
+        p.k_c64   = h->d_k_c64;
+        p.k_c32   = h->d_k_c32;
+        p.means   = h->d_means;
+        p.isr     = h->d_isr;
+        p.T       = T;
+        p.dim     = h->dim;
+        p.n_mix   = h->n_mix;
+        // enough workgroups to fill 256 CUs several times over, but >= 64 B of scores per row
+        int mt = 16;
+        while (mt > 4 && (long)amx::ceil_div(h->n_mix, mt) * fblocks < 2048)
+            mt /= 2;
+        p.mix_tile = mt;
+        dim3                   grid(amx::ceil_div(h->n_mix, mt), fblocks);
+        amx::ScopedKernelTimer timer(h->ctx, "gmm");
+        return mode == AMX_GMM_MAX ? launch_direct<amx::MaxState>(h, p, grid) : launch_direct<amx::SumState>(h, p, grid);
+    }
+    // ---- tied: chunk frames so the distance scratch stays <= 256 MB
+    const int chunk_max = (int)std::max<size_t>(256, std::min<size_t>(16384, ((size_t)64 << 20) / (size_t)h->n_dens / 256 * 256));
+    for (int t0 = 0; t0 < T; t0 += chunk_max) {
+        const int Tc   = std::min(chunk_max, T - t0);
+        const int Tpad = (Tc + 63) & ~63;
+        size_t    need = (size_t)h->n_dens * Tpad;
+        if (need > h->dist_floats) {
+            hipFree(h->d_dist);
+            h->d_dist      = nullptr;
+            h->dist_floats = 0;
+            AMX_HIP(hipMalloc((void**)&h->d_dist, need * sizeof(float)));
+            h->dist_floats = need;
+        }
+        amx::GmmDistParams dp;
+        dp.feats     = feats_dev + (size_t)t0 * h->dim;
+        dp.dist      = h->d_dist;
+        dp.d_mean    = h->d_d_mean;
+        dp.d_cov     = h->d_d_cov;
+        dp.means     = h->d_means;
+        dp.isr       = h->d_isr;
+        dp.T         = Tc;
+        dp.Tpad      = Tpad;
+        dp.dim       = h->dim;
+        dp.n_dens    = h->n_dens;
+        dp.dens_tile = 16;
+        const int fb = amx::ceil_div(Tc, 256);
+        {
+            amx::ScopedKernelTimer timer(h->ctx, "gmm_dist");
+            int r = launch_dist(h, dp, dim3(amx::ceil_div(h->n_dens, dp.dens_tile), fb));
+            if (r != AMX_OK)
+                return r;
+        }
+        amx::GmmCombineParams cp;
+        cp.dist     = h->d_dist;
+        cp.scores   = scores_dev + (size_t)t0 * h->n_mix;
+        cp.best     = best_dev ? best_dev + (size_t)t0 * h->n_mix : nullptr;
+        cp.mix_off  = h->d_mix_off;
+        cp.k_dens   = h->d_k_dens;
+        cp.k_c64    = h->d_k_c64;
+        cp.k_c32    = h->d_k_c32;
+        cp.T        = Tc;
+        cp.Tpad     = Tpad;
+        cp.n_mix    = h->n_mix;
+        cp.mix_tile = 4;
+        dim3                   grid(amx::ceil_div(h->n_mix, cp.mix_tile), fb);
+        amx::ScopedKernelTimer timer(h->ctx, "gmm_combine");
+        amx::GmmCombineDims    cd{cp.T, cp.Tpad, cp.n_mix, cp.mix_tile};
+        if (mode == AMX_GMM_MAX)
+            hipLaunchKernelGGL((amx::gmm_combine_kernel<amx::MaxState>), grid, dim3(256), 0, h->ctx->stream, cp.dist, cp.scores,
+                               cp.best, cp.mix_off, cp.k_dens, cp.k_c64, cp.k_c32, cd);
+        else
+            hipLaunchKernelGGL((amx::gmm_combine_kernel<amx::SumState>), grid, dim3(256), 0, h->ctx->stream, cp.dist, cp.scores,
+                               cp.best, cp.mix_off, cp.k_dens, cp.k_c64, cp.k_c32, cd);
+        AMX_HIP(hipGetLastError());
+    }
+    return AMX_OK;
+}
+
+int amx_gmm_score(amx_gmm* h, int mode, const float* feats_host, int T, float* scores_host, uint32_t* best_host) {
+    AMX_REQUIRE(h, AMX_ERR_INVALID, "amx_gmm_score: NULL handle");
+    AMX_REQUIRE(h->ctx, AMX_ERR_STATE, "amx_gmm_score: host-only handle (created without a context)");
+    AMX_REQUIRE(T >= 0, AMX_ERR_INVALID, "amx_gmm_score: negative frame count");
+    if (T == 0)
+        return AMX_OK;
+    AMX_REQUIRE(feats_host && scores_host, AMX_ERR_INVALID, "amx_gmm_score: NULL buffer");
+    AMX_HIP(hipSetDevice(h->ctx->device));
+    float *     d_f = nullptr, *d_s = nullptr;
+    uint32_t*   d_b = nullptr;
+    hipStream_t st  = h->ctx->stream;
+    auto        done = [&](int code) {
+        hipFree(d_f);
+        hipFree(d_s);
+        hipFree(d_b);
+        return code;
+    };
+    const size_t nf = (size_t)T * h->dim, ns = (size_t)T * h->n_mix;
+    if (hipMalloc((void**)&d_f, nf * 4) != hipSuccess || hipMalloc((void**)&d_s, ns * 4) != hipSuccess ||
+        (best_host && hipMalloc((void**)&d_b, ns * 4) != hipSuccess)) {
+        amx::set_error("amx_gmm_score: out of device memory");
+        return done(AMX_ERR_DEVICE);
+    }
+    if (hipMemcpyAsync(d_f, feats_host, nf * 4, hipMemcpyHostToDevice, st) != hipSuccess) {
+        amx::set_error("amx_gmm_score: H2D copy failed");
+        return done(AMX_ERR_DEVICE);
+    }
+    int r = amx_gmm_score_dev(h, mode, d_f, T, d_s, d_b);
+    if (r != AMX_OK)
+        return done(r);
+    if (hipMemcpyAsync(scores_host, d_s, ns * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        (best_host && hipMemcpyAsync(best_host, d_b, ns * 4, hipMemcpyDeviceToHost, st) != hipSuccess) ||
+        hipStreamSynchronize(st) != hipSuccess) {
+        amx::set_error("amx_gmm_score: D2H copy / kernel execution failed: %s", hipGetErrorString(hipGetLastError()));
+        return done(AMX_ERR_DEVICE);
+    }
+    return done(AMX_OK);
+}
+
+}  // extern "C"

@@ -1,0 +1,112 @@
+"""Regenerates the golden vectors in tests/golden/.  Run in the build container only:
+
+    python tests/golden/make_golden.py
+
+* ref_*.npz / ref_*.json are OUTPUTS OF THE REFERENCE ITSELF: oracle/_ref/libref.so is built by
+  oracle/ref/Makefile from unmodified reference translation units (Math::FastFourierTransform,
+  Signal::WindowBuffer, the mel warping functors, Mm::gaussLogNormFactor / inverseSquareRoot).
+* survey_c1.json holds the known answers the reference produced in this container during the survey
+  (SURVEY.md Appendix C.1).
+* nn_kat.json is transcribed from the reference's unit tests (see its "source" field).
+* orc_*.npz are outputs of the oracle (oracle/liboracle.so) AFTER it has been pinned against all of the
+  above; they let the GPU box (which has no reference tree) detect any drift of the oracle or the kernels.
+Only inputs and expected outputs are stored -- no reference source text.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+from oracle import OracleGmm, OracleMfcc, load_ref, oracle_ffnn_score  # noqa: E402
+from tests import synth  # noqa: E402
+
+
+def main():
+    R = load_ref()
+    if R is None:
+        raise SystemExit("oracle/_ref/libref.so not available (needs /root/reference)")
+    rng = np.random.Generator(np.random.PCG64(2024))
+    # ---- reference FFT vectors
+    fft = {}
+    for n in (8, 64, 256, 512, 1024):
+        x = (rng.standard_normal(n) * 3000).astype(np.float32)
+        y = x.copy()
+        R.ref_fft_real(y, n)
+        z = x.copy()
+        R.ref_fft_complex(z, n)
+        fft["in_%d" % n], fft["real_%d" % n], fft["cplx_%d" % n] = x, y, z
+    # the survey's probe: sinf(0.1 i), i < 400, zero padded to 512
+    x = np.zeros(512, np.float32)
+    x[:400] = np.sin((np.float32(0.1) * np.arange(400, dtype=np.float32)).astype(np.float32)).astype(np.float32)
+    y = x.copy()
+    R.ref_fft_real(y, 512)
+    fft["in_sin"], fft["real_sin"] = x, y
+    np.savez_compressed(os.path.join(HERE, "ref_fft.npz"), **fft)
+    # ---- reference framing (Signal::WindowBuffer driven like SlidingAlgorithmNode)
+    framing = []
+    for length, shift, fs in ((400, 160, 16000.0), (200, 80, 8000.0), (160, 160, 16000.0), (100, 160, 16000.0)):
+        for n in (1, 2, shift - 1, shift, length - 1, length, length + 1, length + shift, length + shift + 1,
+                  2 * length, 2 * length + 1, 1000, 4096, 4097, 12345, 48077, 160000):
+            if n <= 0:
+                continue
+            pcm = np.zeros(n, np.float32)
+            fl = np.zeros(4000, np.int32)
+            st = np.zeros(4000, np.float64)
+            for block in (4096, 1000):
+                nf = R.ref_window_frames(pcm, n, block, length, shift, fs, 4000, fl.ctypes.data, st.ctypes.data, None)
+                framing.append(dict(length=length, shift=shift, fs=fs, n=n, block=block, n_frames=int(nf),
+                                    last_len=int(fl[nf - 1]), last_start=float(st[nf - 1]).hex(),
+                                    lens_ok=bool(np.all(fl[:nf - 1] == length))))
+    json.dump(framing, open(os.path.join(HERE, "ref_framing.json"), "w"), indent=0)
+    # ---- reference mel warping / GMM normalisation terms (f64 as hex strings)
+    mel = []
+    for f in [0.0, 31.25, 62.5, 440.0, 1234.5, 3999.99, 7968.75, 8000.0]:
+        mel.append(dict(f=float(f).hex(), mel=float(R.ref_mel(f)).hex(), dmel=float(R.ref_mel_derivative(f)).hex(),
+                        inv=float(R.ref_mel_inverse(R.ref_mel(f))).hex()))
+    bins = []
+    for b in [0, 1, 7, 100, 255, 256]:
+        bins.append(dict(bin=b, sr=0.032, warped=float(R.ref_warped_bin(b, 0.032)).hex(),
+                         dwarped=float(R.ref_warped_bin_derivative(b, 0.032)).hex(),
+                         back=float(R.ref_warped_bin_inverse(R.ref_warped_bin(b, 0.032), 0.032)).hex()))
+    var = rng.uniform(0.3, 3.0, 40).astype(np.float32)
+    norm = dict(var=[float(v) for v in var], log_norm=float(R.ref_gauss_log_norm_factor(var, 40)).hex(),
+                isr=[float(R.ref_inverse_square_root(float(v))) for v in var])
+    json.dump(dict(mel=mel, bins=bins, norm=norm), open(os.path.join(HERE, "ref_functions.json"), "w"), indent=0)
+    # ---- SURVEY.md C.1 known answers (reference outputs recorded by the survey)
+    c1 = dict(frames_160000=999, last_frame_len=320, w0=0.08, w1=0.08005703,
+              filters_268=dict(n=20, mel_max=2840.023047, out0=4.27929, out1=4.360105, out19=4.327153),
+              filters_138=dict(n=40, out0=1.994625, out1=2.381036, out39=2.215316),
+              fft_sin=dict(x0_re=0.00101768, x1_re=0.000768944, x1_im=-0.000380571),
+              dct_20_16_ones=dict(out0=20.0, out1=-1.78814e-07), gmm_score=5.59973)
+    json.dump(c1, open(os.path.join(HERE, "survey_c1.json"), "w"), indent=1)
+    # ---- oracle outputs on the BASELINE config-1 style inputs
+    pcm = synth.waveform(16000, seed=1)
+    gold = dict(pcm_s16=pcm.astype(np.int16))
+    for tag, kw in (("mfcc16", dict(n_ceps=16)), ("mfcc40", dict(n_ceps=40, filter_width=138.0))):
+        m = OracleMfcc(**kw)
+        gold[tag] = m.run(pcm)
+        st = m.stages(pcm, 3)
+        for k, v in st.items():
+            gold[tag + "_f3_" + k] = v
+    np.savez_compressed(os.path.join(HERE, "orc_mfcc.npz"), **gold)
+    model = synth.gmm_cart(32, 1, 8, 40, seed=2, pooled=False)
+    x = gold["mfcc40"][:24]
+    g = OracleGmm(model)
+    sc, best = g.score(x, mode=0)
+    ssum, _ = g.score(x, mode=1)
+    np.savez_compressed(os.path.join(HERE, "orc_gmm.npz"), feats=x, max_scores=sc, max_best=best, sum_scores=ssum,
+                        **{"model_" + k: np.asarray(v) for k, v in model.items()})
+    Ws, bs, acts, logp = synth.ffnn([40, 48, 48, 30], seed=7)
+    np.savez_compressed(os.path.join(HERE, "orc_ffnn.npz"), feats=x, log_prior=logp,
+                        scores64=oracle_ffnn_score(Ws, bs, acts, x, log_prior=logp, acc64=1),
+                        scores_fma=oracle_ffnn_score(Ws, bs, acts, x, log_prior=logp, acc64=2),
+                        **{"W%d" % i: w for i, w in enumerate(Ws)}, **{"b%d" % i: b for i, b in enumerate(bs)})
+    print("golden vectors written to", HERE)
+
+
+if __name__ == "__main__":
+    main()

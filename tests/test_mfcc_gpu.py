@@ -1,0 +1,138 @@
+"""GPU parity: fused MFCC kernel (through the C ABI) against the oracle restatement of mfcc.flow."""
+import numpy as np
+import pytest
+
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+
+# Tolerance: cepstra are sums of n_filters log10 energies (|c0| ~ 100, higher ones O(1)).  The device FFT
+# uses f32 fmaf butterflies with table twiddles, the reference f64-recurrence twiddles with f32 data, so
+# spectra agree to ~1e-6 relative; after log10 and the DCT that is <= 1e-4 relative plus a small absolute
+# term for coefficients that cancel to near zero.
+RTOL, ATOL = 1e-4, 2e-3
+
+
+def close(a, b):
+    return np.all(np.abs(a - b) <= RTOL * np.abs(b) + ATOL)
+
+
+def configs():
+    return [dict(n_ceps=16, filter_width=268.258), dict(n_ceps=40, filter_width=138.0)]
+
+
+@pytest.mark.parametrize("cfg", configs())
+def test_cfg1_ten_seconds(ctx, cfg):
+    import rasr_amd
+    from oracle import OracleMfcc
+    pcm = synth.waveform(160000, seed=1)
+    fe = rasr_amd.MfccExtractor(ctx, nr_cepstrum_coefficients=cfg["n_ceps"], filter_width=cfg["filter_width"])
+    got = fe.run(pcm)
+    want = OracleMfcc(**cfg).run(pcm)
+    assert got.shape == want.shape == (999, cfg["n_ceps"])
+    assert close(got, want), np.abs(got - want).max()
+    # tight check on the bulk: median relative error is at f32 round-off level
+    assert np.median(np.abs(got - want) / (np.abs(want) + 1e-3)) < 2e-6
+
+
+@pytest.mark.parametrize("n", [1, 2, 159, 160, 399, 400, 401, 560, 561, 800, 801, 1000, 4096, 5281, 48077])
+def test_ragged_lengths_and_short_last_frame(ctx, n):
+    import rasr_amd
+    from oracle import OracleMfcc
+    pcm = synth.waveform(n, seed=100 + n)
+    fe = rasr_amd.MfccExtractor(ctx, nr_cepstrum_coefficients=16)
+    got = fe.run(pcm)
+    want = OracleMfcc(n_ceps=16).run(pcm)
+    assert got.shape == want.shape
+    fin = np.isfinite(want)
+    assert np.array_equal(np.isfinite(got), fin)      # log10(0) = -inf propagates like the reference
+    assert close(got[fin], want[fin]), np.abs(got[fin] - want[fin]).max()
+
+
+def test_empty_segment(ctx):
+    import rasr_amd
+    fe = rasr_amd.MfccExtractor(ctx)
+    assert fe.run(np.zeros(0, np.float32)).shape == (0, 16)
+
+
+def test_batch_equals_single(ctx):
+    import rasr_amd
+    fe = rasr_amd.MfccExtractor(ctx, nr_cepstrum_coefficients=40, filter_width=138.0)
+    lens = [16000, 1, 401, 33333, 0, 8000]
+    pcms = [synth.waveform(n, seed=7 + i) for i, n in enumerate(lens)]
+    outs = fe.run_batch(pcms)
+    for p, o in zip(pcms, outs):
+        single = fe.run(p)
+        assert np.array_equal(single.view(np.uint32), o.view(np.uint32))
+
+
+@pytest.mark.parametrize("alpha", [0.97, 0.0])
+def test_preemphasis_alpha(ctx, alpha):
+    import rasr_amd
+    from oracle import OracleMfcc
+    pcm = synth.waveform(20000, seed=5)
+    got = rasr_amd.MfccExtractor(ctx, nr_cepstrum_coefficients=16, alpha=alpha).run(pcm)
+    want = OracleMfcc(n_ceps=16, alpha=alpha).run(pcm)
+    assert close(got, want), np.abs(got - want).max()
+
+
+@pytest.mark.parametrize("fs,width", [(8000.0, 268.258), (11025.0, 200.0), (22050.0, 268.258), (32000.0, 268.258), (44100.0, 268.258)])
+def test_other_sample_rates(ctx, fs, width):
+    """FFT lengths 256 .. 2048 (radix-4 plus the radix-2 tail stage)."""
+    import rasr_amd
+    from oracle import OracleMfcc
+    pcm = synth.waveform(int(fs * 1.3), seed=11, fs=fs)
+    got = rasr_amd.MfccExtractor(ctx, nr_cepstrum_coefficients=12, sample_rate=fs, filter_width=width).run(pcm)
+    want = OracleMfcc(n_ceps=12, sample_rate=fs, filter_width=width).run(pcm)
+    assert got.shape == want.shape
+    assert close(got, want), np.abs(got - want).max()
+
+
+def test_device_resident_plan_matches_host_path(ctx):
+    import torch
+
+    import rasr_amd
+    fe = rasr_amd.MfccExtractor(ctx, nr_cepstrum_coefficients=40, filter_width=138.0)
+    lens = synth.utterance_lengths(12, seed=3, lo_s=0.5, hi_s=2.0)
+    pcms = [synth.waveform(int(n), seed=50 + i) for i, n in enumerate(lens)]
+    off = np.concatenate([[0], np.cumsum(lens)])
+    plan = fe.plan(off)
+    pcm_dev = torch.from_numpy(np.concatenate(pcms)).cuda()
+    ceps_dev = torch.empty((plan.total_frames, 40), dtype=torch.float32, device="cuda")
+    ctx.use_torch_stream()
+    fe.run_plan(plan, pcm_dev, ceps_dev)
+    torch.cuda.synchronize()
+    got = ceps_dev.cpu().numpy()
+    outs = fe.run_batch(pcms)
+    for u in range(len(pcms)):
+        seg = got[plan.frame_offsets[u]:plan.frame_offsets[u + 1]]
+        assert np.array_equal(seg.view(np.uint32), outs[u].view(np.uint32))
+
+
+def test_full_size_properties(ctx):
+    """BASELINE config 2 scale (1000 utterances): size-independent checks -- frame counts, finiteness,
+    and equality of every 97th utterance with the oracle."""
+    import torch
+
+    import rasr_amd
+    from oracle import OracleMfcc
+    fe = rasr_amd.MfccExtractor(ctx, nr_cepstrum_coefficients=40, filter_width=138.0)
+    orc = OracleMfcc(n_ceps=40, filter_width=138.0)
+    lens = synth.utterance_lengths(1000, seed=3)
+    off = np.concatenate([[0], np.cumsum(lens)])
+    base = synth.waveform(int(lens.max()), seed=4)
+    # utterance u = base waveform rotated by u samples (cheap to build, all different)
+    pcm = np.concatenate([np.roll(base, u)[:n] for u, n in enumerate(lens)])
+    plan = fe.plan(off)
+    assert plan.total_frames == sum(orc.n_frames(int(n)) for n in lens)
+    pcm_dev = torch.from_numpy(pcm).cuda()
+    ceps_dev = torch.empty((plan.total_frames, 40), dtype=torch.float32, device="cuda")
+    ctx.use_torch_stream()
+    fe.run_plan(plan, pcm_dev, ceps_dev)
+    torch.cuda.synchronize()
+    got = ceps_dev.cpu().numpy()
+    assert np.isfinite(got).all()
+    for u in range(0, 1000, 97):
+        want = orc.run(pcm[off[u]:off[u + 1]])
+        seg = got[plan.frame_offsets[u]:plan.frame_offsets[u + 1]]
+        assert close(seg, want), (u, np.abs(seg - want).max())
