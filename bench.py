@@ -1,0 +1,424 @@
+#!/usr/bin/env python3
+"""bench.py -- frames scored per second on MI355X (metric of BASELINE.json).
+
+Default workload ("pipeline"): one step = one batch of synthetic 16 kHz utterances, resident in HBM, through the
+whole hot path: fused MFCC-40 kernel -> 11-frame context window -> FFNN emission scorer 440 -> 6 x 2048 (ReLU)
+-> 10 000 states (bf16 MFMA) -> per-frame best state + per-state counts (the epoch accumulators).  A frame counts
+as "scored" when its 10 000 emission scores exist in HBM.  Other workloads time one stage on its BASELINE config:
+  --workload mfcc      config 2  (batched MFCC-40, HBM roofline)
+  --workload gmm       config 3  (CART-style instance: 10 000 states x 16 densities, pooled covariance, batch 256)
+  --workload gmm-tied  config 3  (tied-mixture instance: 4096 shared densities, 10 000 states)
+  --workload nn        config 4  (6x2048 FFNN, batch 1024)
+
+Launch: `python bench.py` (1 GPU) or `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`.
+Utterances shard across ranks (weak scaling: every rank owns a full batch); the only collective is ONE all-reduce of
+the accumulators at the end of the timed epoch.  Rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak
+FP32_TFLOPS = 157.3        # f32 vector (= f32 MFMA) peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="pipeline", choices=["pipeline", "mfcc", "gmm", "gmm-tied", "nn"])
+    ap.add_argument("--utterances", type=int, default=64, help="utterances per step and rank (pipeline / mfcc)")
+    ap.add_argument("--utt-seconds", type=float, default=10.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    return ap.parse_args()
+
+
+def dist_setup(n_gpus):
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    return rank, world, local
+
+
+def barrier(world):
+    import torch
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def make_batch(n_utt, seconds, seed):
+    """n_utt utterances of `seconds` s: one synthetic waveform, rotated per utterance (cheap, all different)."""
+    from tests import synth
+    n = int(round(seconds * 16000))
+    base = synth.waveform(n + n_utt, seed=seed)
+    pcm = np.concatenate([base[u:u + n] for u in range(n_utt)])
+    off = np.arange(n_utt + 1, dtype=np.int64) * n
+    return pcm, off
+
+
+class Pipeline:
+    """MFCC-40 -> context 11 -> FFNN 440-6x2048-10000 -> accumulators, everything resident in HBM."""
+
+    CHUNK = 32768  # frames per scoring pass (bounds the [frames x 10000] f32 score buffer to 1.3 GB)
+
+    def __init__(self, ctx, args, rank):
+        import torch
+
+        import rasr_amd
+        from tests import synth
+        self.torch, self.ctx = torch, ctx
+        self.fe = rasr_amd.MfccExtractor(ctx, nr_cepstrum_coefficients=40, filter_width=138.0)
+        pcm, off = make_batch(args.utterances, args.utt_seconds, seed=9 + rank)
+        self.plan = self.fe.plan(off)
+        self.F = self.plan.total_frames
+        self.pcm = torch.from_numpy(pcm).cuda()
+        self.ceps = torch.empty((self.F, 40), dtype=torch.float32, device="cuda")
+        self.ctxwin = torch.empty((self.F, 440), dtype=torch.float32, device="cuda")
+        dims = [440] + [2048] * 6 + [10000]
+        Ws, bs, acts, logp = synth.ffnn(dims, seed=7)
+        self.nn = rasr_amd.NnBatchFeatureScorer(ctx, Ws, bs, acts, log_prior=logp, priori_scale=1.0, precision=args.precision)
+        self.flops_per_frame = 2.0 * sum(dims[i] * dims[i + 1] for i in range(len(dims) - 1))
+        self.M = 10000
+        self.scores = torch.empty((min(self.CHUNK, self.F), self.M), dtype=torch.float32, device="cuda")
+        self.best = torch.empty((self.F,), dtype=torch.int32, device="cuda")
+        self.counts = torch.zeros((self.M,), dtype=torch.int64, device="cuda")
+        self.score_sum = torch.zeros((1,), dtype=torch.float64, device="cuda")
+        self.units = self.F
+
+    def step(self):
+        self.fe.run_plan(self.plan, self.pcm, self.ceps)
+        self.ctx.context_window(self.plan, self.ceps, 40, 5, 5, self.ctxwin, 440)
+        for t0 in range(0, self.F, self.CHUNK):
+            T = min(self.CHUNK, self.F - t0)
+            self.nn.score_dev(self.ctxwin[t0:], 440, T, self.scores)
+            self.ctx.stats_accumulate(self.scores, T, self.M, self.best[t0:], self.counts, self.score_sum)
+
+    def epoch_reduce(self, world):
+        if world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.counts)
+            dist.all_reduce(self.score_sum)
+
+    def roofline(self):
+        # dominant kernel: the output-layer GEMM (2048 -> 10000), 48 % of the chain's flops
+        ms, n = self.ctx.profile_get("ffnn_gemm_max")
+        if n == 0:
+            return None
+        rows = []
+        for t0 in range(0, self.F, self.CHUNK):
+            rows.append(min(self.CHUNK, self.F - t0))
+        flops = 2.0 * 2048 * 10000 * (sum(rows) / len(rows))
+        peak = MFMA_BF16_TFLOPS if self.nn_precision == "bf16" else FP32_TFLOPS
+        ach = flops / (ms * 1e-3) / 1e12
+        return dict(bound="mfma", kernel="gemm_bf16_kernel<NONE,LAST> (2048->10000)" if self.nn_precision == "bf16" else "gemm_f32_kernel (2048->10000)",
+                    achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4), traffic=None,
+                    avg_launch_ms=round(ms, 4), launches=n, flops_per_launch=flops)
+
+    def stage_report(self):
+        out = {}
+        for k in ("mfcc", "context_window", "ffnn_pack", "ffnn_gemm", "ffnn_gemm_max", "stats"):
+            ms, n = self.ctx.profile_get(k)
+            if n:
+                out[k] = dict(avg_ms=round(ms, 4), launches=n)
+        ms, n = self.ctx.profile_get("mfcc")
+        if n:
+            gbs = self.F * 800.0 / (ms * 1e-3) / 1e9
+            out["mfcc"].update(algorithmic_GBps=round(gbs, 1), frac_hbm=round(gbs / HBM_PEAK_GBS, 4))
+        return out
+
+
+class MfccOnly:
+    def __init__(self, ctx, args, rank):
+        import torch
+
+        import rasr_amd
+        from tests import synth
+        self.ctx = ctx
+        self.fe = rasr_amd.MfccExtractor(ctx, nr_cepstrum_coefficients=40, filter_width=138.0)
+        lens = synth.utterance_lengths(1000, seed=3)
+        base = synth.waveform(int(lens.max()) + 1000, seed=4 + rank)
+        pcm = np.concatenate([base[u:u + int(n)] for u, n in enumerate(lens)])
+        off = np.concatenate([[0], np.cumsum(lens)])
+        self.plan = self.fe.plan(off)
+        self.F = self.plan.total_frames
+        self.pcm = torch.from_numpy(pcm).cuda()
+        self.ceps = torch.empty((self.F, 40), dtype=torch.float32, device="cuda")
+        self.units = self.F
+
+    def step(self):
+        self.fe.run_plan(self.plan, self.pcm, self.ceps)
+
+    def epoch_reduce(self, world):
+        pass
+
+    def roofline(self):
+        ms, n = self.ctx.profile_get("mfcc")
+        if n == 0:
+            return None
+        gbs = self.F * 800.0 / (ms * 1e-3) / 1e9  # 160 samples*4 B in + 40 ceps*4 B out per frame
+        return dict(bound="hbm", kernel="mfcc_kernel<256>", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=round(gbs / HBM_PEAK_GBS, 4), traffic=None, avg_launch_ms=round(ms, 4), launches=n,
+                    bytes_per_launch=self.F * 800.0)
+
+    def stage_report(self):
+        return {}
+
+
+class GmmOnly:
+    def __init__(self, ctx, args, rank, tied):
+        import torch
+
+        import rasr_amd
+        from tests import synth
+        self.ctx, self.tied = ctx, tied
+        if tied:
+            model = synth.gmm_tied(10000, 4096, 40, seed=5, pooled=True)
+        else:
+            model = synth.gmm_cart(10000, 16, 16, 40, seed=5, pooled=True)
+        self.nk = int(model["mix_offsets"][-1])
+        self.nd = len(model["dens_mean"])
+        self.sc = rasr_amd.GmmFeatureScorer(ctx, model)
+        self.T = 256
+        x = np.random.Generator(np.random.PCG64(4 + rank)).standard_normal((self.T, 40)).astype(np.float32)
+        self.x = torch.from_numpy(x).cuda()
+        self.scores = torch.empty((self.T, 10000), dtype=torch.float32, device="cuda")
+        self.best = torch.empty((self.T, 10000), dtype=torch.int32, device="cuda")
+        self.units = self.T
+
+    def step(self):
+        self.sc.score_dev(self.x, self.T, self.scores, self.best)
+
+    def epoch_reduce(self, world):
+        pass
+
+    def roofline(self):
+        # exact-order distance: sub, mul, mul, add per (frame, density, dim) = 4 f32 VALU ops; the f32 vector peak is
+        # numerically the f32 MFMA peak (157.3 TFLOP/s counts an FMA as 2), so unfused ops can reach half of it.
+        if self.tied:
+            ms, n = self.ctx.profile_get("gmm_combine")
+            ops = 2.0 * self.nk * self.T  # (f64 add, compare/select) per (frame, mixture, density)
+            name = "gmm_combine_kernel<MaxState>"
+        else:
+            ms, n = self.ctx.profile_get("gmm")
+            ops = 4.0 * self.nk * 40 * self.T
+            name = "gmm_direct_kernel<40,MaxState>"
+        if n == 0:
+            return None
+        ach = ops / (ms * 1e-3) / 1e12
+        return dict(bound="mfma", note="f32 VALU kernel priced against the f32 vector peak (= f32 MFMA peak)", kernel=name,
+                    achieved=round(ach, 3), peak=FP32_TFLOPS, unit="TFLOP/s", frac=round(ach / FP32_TFLOPS, 4), traffic=None,
+                    avg_launch_ms=round(ms, 4), launches=n, flops_per_launch=ops)
+
+    def stage_report(self):
+        out = {}
+        for k in ("gmm", "gmm_dist", "gmm_combine"):
+            ms, n = self.ctx.profile_get(k)
+            if n:
+                out[k] = dict(avg_ms=round(ms, 4), launches=n)
+        return out
+
+
+class NnOnly:
+    def __init__(self, ctx, args, rank):
+        import torch
+
+        import rasr_amd
+        from tests import synth
+        self.ctx = ctx
+        dims = [440] + [2048] * 6 + [10000]
+        Ws, bs, acts, logp = synth.ffnn(dims, seed=7)
+        self.nn = rasr_amd.NnBatchFeatureScorer(ctx, Ws, bs, acts, log_prior=logp, priori_scale=1.0, precision=args.precision)
+        self.nn_precision = args.precision
+        self.T = 1024
+        x = np.random.Generator(np.random.PCG64(6 + rank)).standard_normal((self.T, 440)).astype(np.float32)
+        self.x = torch.from_numpy(x).cuda()
+        self.scores = torch.empty((self.T, 10000), dtype=torch.float32, device="cuda")
+        self.units = self.T
+        self.flops = 2.0 * sum(dims[i] * dims[i + 1] for i in range(len(dims) - 1)) * self.T
+
+    def step(self):
+        self.nn.score_dev(self.x, 440, self.T, self.scores)
+
+    def epoch_reduce(self, world):
+        pass
+
+    def roofline(self):
+        ms, n = self.ctx.profile_get("ffnn_gemm_max")
+        if n == 0:
+            return None
+        flops = 2.0 * 2048 * 10000 * self.T
+        peak = MFMA_BF16_TFLOPS if self.nn_precision == "bf16" else FP32_TFLOPS
+        ach = flops / (ms * 1e-3) / 1e12
+        return dict(bound="mfma", kernel="output-layer GEMM 2048->10000", achieved=round(ach, 2), peak=peak, unit="TFLOP/s",
+                    frac=round(ach / peak, 4), traffic=None, avg_launch_ms=round(ms, 4), launches=n, flops_per_launch=flops)
+
+    def stage_report(self):
+        out = {}
+        for k in ("ffnn_pack", "ffnn_gemm", "ffnn_gemm_max"):
+            ms, n = self.ctx.profile_get(k)
+            if n:
+                out[k] = dict(avg_ms=round(ms, 4), launches=n)
+        return out
+
+
+# ----------------------------------------------------------------------------------------------- CPU baseline
+
+def _cpu_mfcc_worker(job):
+    from oracle import OracleMfcc
+    pcm_list = job
+    m = OracleMfcc(n_ceps=40, filter_width=138.0)
+    n = 0
+    for p in pcm_list:
+        n += m.run(p).shape[0]
+    return n
+
+
+def cpu_baseline(workload):
+    """The oracle (CPU restatement of the reference path, kind "port") timed on a bounded sample with all host cores:
+    MFCC frame-by-frame (one process per core), FFNN via numpy float32 matmul = OpenBLAS sgemm with separate bias / ReLU
+    passes like Nn::LinearLayer + ActivationLayer, GMM via the oracle's diagonal-maximum loop."""
+    import multiprocessing as mp
+
+    from tests import synth
+    cores = os.cpu_count() or 1
+    res = {}
+    if workload in ("pipeline", "mfcc"):
+        n_utt = max(cores, 8)
+        pcms = [synth.waveform(160000, seed=1000 + u) for u in range(n_utt)]
+        jobs = [pcms[i::cores] for i in range(cores) if pcms[i::cores]]
+        t0 = time.perf_counter()
+        with mp.get_context("spawn").Pool(len(jobs)) as pool:
+            frames = sum(pool.map(_cpu_mfcc_worker, jobs))
+        dt = time.perf_counter() - t0
+        res["mfcc"] = (frames, dt)
+    if workload in ("pipeline", "nn"):
+        dims = [440] + [2048] * 6 + [10000]
+        Ws, bs, acts, logp = synth.ffnn(dims, seed=7)
+        T = 2048
+        x = np.random.Generator(np.random.PCG64(6)).standard_normal((T, 440)).astype(np.float32)
+        WT = [np.ascontiguousarray(w.T) for w in Ws]
+        bl = bs[-1] - np.float32(1.0) * logp
+
+        def fwd():
+            a = x
+            for l in range(len(Ws)):
+                z = a @ WT[l]                 # sgemm
+                z += (bl if l == len(Ws) - 1 else bs[l])   # addToAllColumns
+                if l < len(Ws) - 1:
+                    np.maximum(z, 0, out=z)   # ensureMinimalValue(0)
+                a = z
+            return -a
+        fwd()
+        reps = 0
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < 8.0:
+            fwd()
+            reps += 1
+        res["nn"] = (T * reps, time.perf_counter() - t0)
+    if workload in ("gmm", "gmm-tied"):
+        from oracle import OracleGmm
+        if workload == "gmm":
+            model = synth.gmm_cart(10000, 16, 16, 40, seed=5, pooled=True)
+            T = 16
+        else:
+            model = synth.gmm_tied(10000, 4096, 40, seed=5, pooled=True)
+            T = 1
+        x = np.random.Generator(np.random.PCG64(4)).standard_normal((T, 40)).astype(np.float32)
+        g = OracleGmm(model)
+        t0 = time.perf_counter()
+        g.score(x, mode=0, want_best=False)
+        res["gmm"] = (T, time.perf_counter() - t0)
+        cores = 1
+    # frames/s of the whole CPU job = 1 / sum(stage seconds per frame)
+    spf = sum(dt / fr for fr, dt in res.values())
+    detail = ", ".join("%s %d frames in %.2fs" % (k, fr, dt) for k, (fr, dt) in res.items())
+    return dict(value=round(1.0 / spf, 2), unit="frames/s", cores=cores, kind="port",
+                sample=detail + (" (MFCC: one oracle process per core; NN: numpy/OpenBLAS sgemm, %d threads)" % cores
+                                 if workload in ("pipeline", "nn", "mfcc") else " (oracle diagonal-maximum loop, 1 thread)"))
+
+
+def main():
+    args = parse()
+    import torch
+
+    import rasr_amd
+    rank, world, local = dist_setup(args.gpus)
+    ctx = rasr_amd.Context(local)
+    stream = torch.cuda.Stream(device=local)
+    with torch.cuda.stream(stream):
+        ctx.use_torch_stream()
+        if args.workload == "pipeline":
+            job = Pipeline(ctx, args, rank)
+            job.nn_precision = args.precision
+        elif args.workload == "mfcc":
+            job = MfccOnly(ctx, args, rank)
+        elif args.workload in ("gmm", "gmm-tied"):
+            job = GmmOnly(ctx, args, rank, tied=args.workload == "gmm-tied")
+        else:
+            job = NnOnly(ctx, args, rank)
+        for _ in range(args.warmup):
+            job.step()
+        barrier(world)
+        ctx.profile(True)
+        ctx.profile_reset()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            job.step()
+        job.epoch_reduce(world)
+        barrier(world)
+        dt = time.perf_counter() - t0
+        ctx.profile(False)
+    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        import torch.distributed as dist
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    units = job.units * args.steps * world
+    if rank == 0:
+        value = units / dt
+        names = {"pipeline": "cfg5-shard: MFCC-40 -> ctx11 -> FFNN 440-6x2048-10000 (bf16 MFMA) -> best-state accumulators; "
+                             "%d utterances x %.0f s per step and rank" % (args.utterances, args.utt_seconds),
+                 "mfcc": "cfg2: batched MFCC-40 on 1000 utterances (5-15 s)",
+                 "gmm": "cfg3-cart: 10000 states x 16 densities, d=40, pooled covariance, batch 256, diagonal-maximum",
+                 "gmm-tied": "cfg3-tied: 4096 shared densities x 10000 states, d=40, batch 256, diagonal-maximum",
+                 "nn": "cfg4: FFNN 440-6x2048-10000, batch 1024"}
+        line = {"metric": "acoustic frames scored/sec (1e4-state AM)", "value": round(value, 1), "unit": "frames/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": ("bf16" if args.precision == "bf16" else "f32") if args.workload in ("pipeline", "nn") else "f32",
+                "data": "synthetic", "config": {"workload": names[args.workload], "frames_per_step_per_gpu": job.units},
+                "rtf": round(dt / (units * 0.01), 8)}
+        line["roofline"] = job.roofline()
+        line["stages"] = job.stage_report()
+        if not args.no_cpu_baseline:
+            cb = cpu_baseline(args.workload)
+            line["cpu_baseline"] = cb
+            line["speedup_vs_cpu"] = round(value / world / cb["value"], 1)
+        print(json.dumps(line))
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,187 @@
+"""CPU: the C-ABI library loads, exports every symbol include/amx.h declares, and its HOST logic (geometry,
+table construction, model preparation, .pms IO, error behaviour) agrees with the oracle.  No kernel runs here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import MfccCfg as OrcCfg, OracleGmm, OracleMfcc
+from rasr_amd import _lib
+from tests import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "amx.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(amx_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    L = _lib.lib()
+    names = header_functions()
+    assert len(names) >= 40
+    for n in names:
+        assert hasattr(L, n), "librasr_amd.so does not export %s" % n
+    assert sorted(_lib.SIGNATURES) == names, set(names) ^ set(_lib.SIGNATURES)
+
+
+def test_no_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    L = _lib.lib()
+    h = C.c_void_p()
+    assert L.amx_init(0, C.byref(h)) == _lib.AMX_ERR_DEVICE
+    assert b"no CPU fallback" in L.amx_last_error()
+    import rasr_amd
+    with pytest.raises(rasr_amd.AmxError):
+        rasr_amd.Context(0)
+
+
+def host_mfcc(**kw):
+    L = _lib.lib()
+    cfg = _lib.MfccCfg()
+    L.amx_mfcc_default_cfg(C.byref(cfg))
+    for k, v in kw.items():
+        setattr(cfg, k, v)
+    h = C.c_void_p()
+    st = L.amx_mfcc_create(None, C.byref(cfg), C.byref(h))
+    return L, h, st
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(n_ceps=40, mel_filter_width=138.0), dict(sample_rate=8000.0),
+                                dict(sample_rate=44100.0, n_ceps=13), dict(sample_rate=11025.0, mel_filter_width=150.0),
+                                dict(mel_spacing=100.0), dict(warp_differential_unit=0), dict(win_len_s=0.02, win_shift_s=0.0125)])
+def test_host_tables_bit_identical_to_oracle(kw):
+    L, h, st = host_mfcc(**kw)
+    assert st == 0, L.amx_last_error()
+    info = _lib.MfccInfo()
+    L.amx_mfcc_describe(h, C.byref(info))
+    o = OrcCfg.default()
+    for k, v in kw.items():
+        setattr(o, k, v)
+    m = OracleMfcc(o)
+    assert (info.frame_len, info.frame_shift, info.fft_len, info.n_bins, info.n_filters, info.n_ceps) == \
+           (m.frame_len, m.frame_shift, m.fft_len, m.n_bins, m.n_filters, m.n_ceps)
+    assert info.mel_max == m.mel_max
+    fo = np.zeros(info.n_filters + 1, np.int32)
+    L.amx_mfcc_tables(h, None, None, None, fo.ctypes.data, None, None)
+    win, fs, fe = np.zeros(info.frame_len, np.float32), np.zeros(info.n_filters, np.int32), np.zeros(info.n_filters, np.int32)
+    fw, dct = np.zeros(fo[-1], np.float32), np.zeros((info.n_ceps, info.n_filters), np.float32)
+    L.amx_mfcc_tables(h, win.ctypes.data, fs.ctypes.data, fe.ctypes.data, fo.ctypes.data, fw.ctypes.data, dct.ctypes.data)
+    s, e, off, w = m.filters
+    assert np.array_equal(win.view(np.uint32), m.window.view(np.uint32))
+    assert np.array_equal(fs, s) and np.array_equal(fe, e) and np.array_equal(fo, off)
+    assert np.array_equal(fw.view(np.uint32), w.view(np.uint32))
+    assert np.array_equal(dct.view(np.uint32), m.dct.view(np.uint32))
+    for n in (0, 1, 399, 400, 401, 5000, 160000, 123457):
+        assert L.amx_mfcc_n_frames(h, n) == m.n_frames(n)
+    # frame start times accumulate like WindowBuffer (bufferStartTime_ += shift/fs)
+    t = 0.0
+    for k in range(1000):
+        if k in (0, 1, 17, 998):
+            assert L.amx_mfcc_frame_start_time(h, k) == t
+        t += info.frame_shift / o.sample_rate
+    # a host-only handle cannot run
+    out = np.zeros(16, np.float32)
+    assert L.amx_mfcc_run(h, out.ctypes.data, 4, out.ctypes.data) == _lib.AMX_ERR_STATE
+    L.amx_mfcc_destroy(h)
+
+
+def test_mfcc_configuration_errors():
+    L, h, st = host_mfcc(sample_rate=0.0)
+    assert st == _lib.AMX_ERR_INVALID and b"not positive" in L.amx_last_error()
+    # window longer than the FFT: the reference node raises "Input data size ... is larger then maximal input size"
+    L, h, st = host_mfcc(win_len_s=0.05)
+    assert st == _lib.AMX_ERR_INVALID and b"larger then maximal input size" in L.amx_last_error()
+    L, h, st = host_mfcc(n_ceps=0)
+    assert st == _lib.AMX_ERR_INVALID
+
+
+def test_gmm_prepared_tables_bit_identical_to_oracle():
+    import rasr_amd
+    L = _lib.lib()
+    for pooled, mws, gsc in ((True, 1.0, 1.0), (False, 0.7, 1.3)):
+        model = synth.gmm_cart(50, 1, 8, 40, seed=2, pooled=pooled)
+        keep = []
+        st = rasr_amd._gmm_struct(model, mws, gsc, keep)
+        h = C.c_void_p()
+        assert L.amx_gmm_create(None, C.byref(st), C.byref(h)) == 0, L.amx_last_error()
+        nk, nc = int(model["mix_offsets"][-1]), model["variances"].shape[0]
+        a, b, c = np.zeros(nk, np.float32), np.zeros((nc, 40), np.float32), np.zeros(nc, np.float32)
+        L.amx_gmm_tables(h, a.ctypes.data, b.ctypes.data, c.ctypes.data)
+        oa, ob, oc = OracleGmm(model, mws, gsc).tables()
+        assert np.array_equal(a.view(np.uint32), oa.view(np.uint32))
+        assert np.array_equal(b.view(np.uint32), ob.view(np.uint32))
+        assert np.array_equal(c.view(np.uint32), oc.view(np.uint32))
+        assert L.amx_gmm_n_mixtures(h) == 50 and L.amx_gmm_dimension(h) == 40
+        x = np.zeros((1, 40), np.float32)
+        assert L.amx_gmm_score(h, 0, x.ctypes.data, 1, x.ctypes.data, None) == _lib.AMX_ERR_STATE
+        L.amx_gmm_destroy(h)
+
+
+def test_gmm_model_validation():
+    import rasr_amd
+    L = _lib.lib()
+    model = synth.gmm_cart(4, 1, 2, 8, seed=1)
+    bad = dict(model)
+    bad["dens_index"] = model["dens_index"].copy()
+    bad["dens_index"][0] = 999
+    keep = []
+    h = C.c_void_p()
+    assert L.amx_gmm_create(None, C.byref(rasr_amd._gmm_struct(bad, 1.0, 1.0, keep)), C.byref(h)) == _lib.AMX_ERR_INVALID
+    bad = dict(model)
+    bad["variances"] = -model["variances"]
+    assert L.amx_gmm_create(None, C.byref(rasr_amd._gmm_struct(bad, 1.0, 1.0, keep)), C.byref(h)) == _lib.AMX_ERR_INVALID
+    assert b"variance" in L.amx_last_error()
+
+
+def test_pms_round_trip(tmp_path):
+    import rasr_amd
+    model = synth.gmm_cart(12, 1, 5, 7, seed=3, pooled=False)
+    p = str(tmp_path / "m.pms")
+    rasr_amd.write_pms(model, p)
+    head = open(p).read().split("\n")[:3]
+    assert head[0] == "#Version: 2.0" and head[1] == "#CovarianceType: DiagonalCovariance"
+    assert head[2].split() == ["7", "12", str(len(model["dens_mean"])), str(model["means"].shape[0]), str(model["variances"].shape[0])]
+    back = rasr_amd.read_pms(p)
+    for k in ("mix_offsets", "dens_index", "dens_mean", "dens_cov", "log_weight", "means", "variances"):
+        assert np.array_equal(back[k], model[k]), k
+
+
+def test_pms_reads_reference_style_files(tmp_path):
+    """a file as Mm::MixtureSet::write emits it (6 significant digits, weight column), and a version-1 file with
+    linear mixture weights and non-unit covariance weights"""
+    import rasr_amd
+    p = str(tmp_path / "v2.pms")
+    open(p, "w").write("#Version: 2.0\n#CovarianceType: DiagonalCovariance\n2 2 3 3 1\n"
+                       "2 0 -0.693147 1 -0.693147\n1 2 0\n0 0\n1 0\n2 0\n2 0.5 -1\n2 1.5 2\n2 0 0\n 2 2 1 0.5 1\n")
+    m = rasr_amd.read_pms(p)
+    assert m["dim"] == 2 and list(m["mix_offsets"]) == [0, 2, 3] and list(m["dens_index"]) == [0, 1, 2]
+    assert np.allclose(m["log_weight"], [-0.693147, -0.693147, 0]) and np.allclose(m["variances"], [[2, 0.5]])
+    p1 = str(tmp_path / "v1.pms")
+    open(p1, "w").write("#Version: 1.0\n#CovarianceType: DiagonalCovariance\n1 1 2 2 1\n2 0 0.25 1 0.75\n0 0\n1 0\n1 0\n1 1\n 1 2 1.5\n")
+    m = rasr_amd.read_pms(p1)
+    assert np.allclose(m["log_weight"], np.log([0.25, 0.75])) and np.allclose(m["variances"], [[3.0]])
+    bad = str(tmp_path / "bad.pms")
+    open(bad, "w").write("#Version: 3.0\n#CovarianceType: DiagonalCovariance\n")
+    with pytest.raises(rasr_amd.AmxError) as e:
+        rasr_amd.read_pms(bad)
+    assert e.value.status == _lib.AMX_ERR_UNSUPPORTED
+    with pytest.raises(rasr_amd.AmxError):
+        rasr_amd.read_pms(str(tmp_path / "missing.pms"))
+
+
+def test_product_does_not_reference_the_oracle():
+    """the shipped package must never import, link or call anything under oracle/"""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "rasr_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h", ".hh")) or f == "Makefile":
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "oracle" not in text.lower() or f == "__init__.py" and "oracle" not in text, os.path.join(dirpath, f)
+    out = os.popen("ldd %s" % _lib.LIB_PATH).read()
+    assert "liboracle" not in out and "libref" not in out

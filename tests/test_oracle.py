@@ -1,0 +1,248 @@
+"""CPU: pins the oracle (oracle/liboracle.so) against (a) outputs of the reference itself -- live through
+oracle/_ref/libref.so when /root/reference is mounted, and through the committed tests/golden/ref_* vectors
+everywhere -- (b) the known answers of SURVEY.md C.1, (c) the reference's unit-test vectors."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import MfccCfg, Oracle, OracleGmm, OracleMfcc, load_ref, oracle_ffnn_score
+from tests import synth
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+HAVE_REF = os.path.isdir("/root/reference/src")
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+# ----------------------------------------------------------------------------- reference outputs (golden)
+
+def test_fft_bit_exact_against_reference_vectors():
+    L = Oracle()
+    z = np.load(os.path.join(GOLD, "ref_fft.npz"))
+    for n in (8, 64, 256, 512, 1024):
+        a = z["in_%d" % n].copy()
+        L.orc_fft_real(a, n)
+        assert np.array_equal(bits(a), bits(z["real_%d" % n]))
+        a = z["in_%d" % n].copy()
+        L.orc_fft_complex(a, n)
+        assert np.array_equal(bits(a), bits(z["cplx_%d" % n]))
+    a = z["in_sin"].copy()
+    L.orc_fft_real(a, 512)
+    assert np.array_equal(bits(a), bits(z["real_sin"]))
+
+
+def test_framing_against_reference_window_buffer():
+    L = Oracle()
+    rows = json.load(open(os.path.join(GOLD, "ref_framing.json")))
+    assert len(rows) > 100
+    for r in rows:
+        cfg = MfccCfg.default()
+        cfg.sample_rate = r["fs"]
+        cfg.win_len_s = r["length"] / r["fs"]
+        cfg.win_shift_s = r["shift"] / r["fs"]
+        cfg.fft_max_input_s = max(r["length"], 8) / r["fs"]
+        m = OracleMfcc(cfg)
+        assert (m.frame_len, m.frame_shift) == (r["length"], r["shift"])
+        T = m.n_frames(r["n"])
+        assert T == r["n_frames"], r
+        last = r["n"] - (T - 1) * r["shift"]
+        assert min(r["length"], last) == r["last_len"], r
+        assert r["lens_ok"]
+
+
+def test_mel_functions_against_reference_functors():
+    L = Oracle()
+    g = json.load(open(os.path.join(GOLD, "ref_functions.json")))
+    for r in g["mel"]:
+        f = float.fromhex(r["f"])
+        assert L.orc_mel(f) == float.fromhex(r["mel"])
+        assert L.orc_mel_derivative(f) == float.fromhex(r["dmel"])
+        assert L.orc_mel_inverse(L.orc_mel(f)) == float.fromhex(r["inv"])
+    for r in g["bins"]:   # nest(mel, scale(1/0.032)) as the filter builder composes it
+        d2c = 1 / r["sr"]
+        assert L.orc_mel(d2c * r["bin"]) == float.fromhex(r["warped"])
+        assert L.orc_mel_derivative(d2c * r["bin"]) == float.fromhex(r["dwarped"])
+        assert (1 / d2c) * L.orc_mel_inverse(L.orc_mel(d2c * r["bin"])) == float.fromhex(r["back"])
+
+
+def test_gmm_normalisation_terms_against_reference_templates():
+    g = json.load(open(os.path.join(GOLD, "ref_functions.json")))["norm"]
+    var = np.array(g["var"], np.float32)
+    model = synth.gmm_cart(2, 1, 1, 40, seed=1)
+    model["variances"] = var.reshape(1, 40).copy()
+    m2lw, isr, ln = OracleGmm(model).tables()
+    assert ln[0] == np.float32(float.fromhex(g["log_norm"]))
+    assert np.array_equal(bits(isr[0]), bits(np.array(g["isr"], np.float32)))
+
+
+@pytest.mark.skipif(not HAVE_REF, reason="reference tree not mounted (GPU box)")
+def test_live_reference_build_agrees():
+    """Same checks against the freshly built reference TUs, on fresh random inputs."""
+    L, R = Oracle(), load_ref()
+    assert R is not None
+    rng = np.random.Generator(np.random.PCG64(77))
+    for n in (16, 128, 512, 2048):
+        x = (rng.standard_normal(n) * 1e4).astype(np.float32)
+        a, b = x.copy(), x.copy()
+        L.orc_fft_real(a, n)
+        R.ref_fft_real(b, n)
+        assert np.array_equal(bits(a), bits(b))
+    m = OracleMfcc(n_ceps=16)
+    for n in rng.integers(1, 60000, 40):
+        n = int(n)
+        fl = np.zeros(1000, np.int32)
+        nf = R.ref_window_frames(np.zeros(n, np.float32), n, 4096, 400, 160, 16000.0, 1000, fl.ctypes.data, None, None)
+        assert nf == m.n_frames(n)
+        assert fl[nf - 1] == min(400, n - (nf - 1) * 160)
+    for f in rng.uniform(0, 8000, 50):
+        assert L.orc_mel(f) == R.ref_mel(f) and L.orc_mel_derivative(f) == R.ref_mel_derivative(f)
+        assert L.orc_mel_inverse(L.orc_mel(f)) == R.ref_mel_inverse(R.ref_mel(f))
+    v = rng.uniform(0.1, 5, 39).astype(np.float32)
+    model = synth.gmm_cart(1, 1, 1, 39, seed=3)
+    model["variances"] = v.reshape(1, -1).copy()
+    _, isr, ln = OracleGmm(model).tables()
+    assert ln[0] == np.float32(R.ref_gauss_log_norm_factor(v, 39))
+    assert all(isr[0][i] == np.float32(R.ref_inverse_square_root(float(v[i]))) for i in range(39))
+
+
+# ----------------------------------------------------------------------------- SURVEY.md C.1 known answers
+
+def _apply_filters(m, amp):
+    s, e, o, w = m.filters
+    out = []
+    for f in range(m.n_filters):
+        acc = np.float32(0)
+        for b in range(s[f], e[f]):
+            acc = np.float32(acc + np.float32(amp[b] * w[o[f] + b - s[f]]))
+        out.append(acc)
+    return out
+
+
+def test_survey_known_answers():
+    c1 = json.load(open(os.path.join(GOLD, "survey_c1.json")))
+    m = OracleMfcc(n_ceps=16)
+    assert m.n_frames(160000) == c1["frames_160000"]
+    assert 160000 - 998 * 160 == c1["last_frame_len"]
+    w = m.window
+    assert w[0] == np.float32(c1["w0"]) and abs(w[1] - c1["w1"]) < 5e-9
+    ones = np.ones(257, np.float32)
+    f = c1["filters_268"]
+    out = _apply_filters(m, ones)
+    assert m.n_filters == f["n"] and abs(m.mel_max - f["mel_max"]) < 1e-6
+    assert abs(out[0] - f["out0"]) < 5e-6 and abs(out[1] - f["out1"]) < 5e-6 and abs(out[19] - f["out19"]) < 5e-6
+    m40 = OracleMfcc(n_ceps=40, filter_width=138.0)
+    f = c1["filters_138"]
+    out = _apply_filters(m40, ones)
+    assert m40.n_filters == f["n"]
+    assert abs(out[0] - f["out0"]) < 5e-6 and abs(out[1] - f["out1"]) < 5e-6 and abs(out[39] - f["out39"]) < 5e-6
+    d = m.dct
+    r0 = np.float32(0)
+    r1 = np.float32(0)
+    for n in range(20):
+        r0 = np.float32(r0 + d[0, n])
+        r1 = np.float32(r1 + d[1, n])
+    assert r0 == np.float32(c1["dct_20_16_ones"]["out0"]) and abs(r1 - c1["dct_20_16_ones"]["out1"]) < 1e-12
+    model = dict(dim=4, mix_offsets=np.array([0, 2], np.uint32), dens_index=np.array([0, 1], np.uint32),
+                 log_weight=np.log(np.array([0.25, 0.75])), dens_mean=np.array([0, 1], np.uint32),
+                 dens_cov=np.array([0, 0], np.uint32), means=np.array([[0] * 4, [1] * 4], np.float32),
+                 variances=np.full((1, 4), 2, np.float32))
+    sc, best = OracleGmm(model).score(np.full((1, 4), 0.5, np.float32))
+    assert abs(sc[0, 0] - c1["gmm_score"]) < 5e-6 and best[0, 0] == 1
+    assert abs(OracleGmm(model).score_batch_float(np.full((1, 4), 0.5, np.float32))[0, 0] - c1["gmm_score"]) < 5e-6
+
+
+# ----------------------------------------------------------------------------- reference unit-test vectors
+
+def test_nn_forward_reference_unit_tests():
+    kat = json.load(open(os.path.join(GOLD, "nn_kat.json")))
+    for c in kat["cases"]:
+        Ws = [np.array(w, np.float32) for w in c["W"]]
+        bs = [np.array(b, np.float32) for b in c["bias"]]
+        x = np.array(c["input"], np.float32)
+        for acc in (0, 1, 2):
+            z = -oracle_ffnn_score(Ws, bs, c["hidden_activation"] + [0], x, acc64=acc).astype(np.float64)
+            e = np.exp(z - z.max(1, keepdims=True))
+            assert np.allclose(e / e.sum(1, keepdims=True), np.array(c["softmax"]), atol=c["tol"])
+            if "linear" in c:
+                assert np.allclose(z, np.array(c["linear"]), atol=1e-6)
+            if "sigmoid" in c:
+                assert np.allclose(1 / (1 + np.exp(-z)), np.array(c["sigmoid"]), atol=c["tol"])
+
+
+# ----------------------------------------------------------------------------- oracle self-consistency / drift
+
+def test_oracle_outputs_have_not_drifted():
+    z = np.load(os.path.join(GOLD, "orc_mfcc.npz"))
+    pcm = z["pcm_s16"].astype(np.float32)
+    assert np.array_equal(pcm, synth.waveform(16000, seed=1))
+    for tag, kw in (("mfcc16", dict(n_ceps=16)), ("mfcc40", dict(n_ceps=40, filter_width=138.0))):
+        m = OracleMfcc(**kw)
+        assert np.array_equal(bits(m.run(pcm)), bits(z[tag]))
+        st = m.stages(pcm, 3)
+        for k, v in st.items():
+            assert np.array_equal(bits(v), bits(z[tag + "_f3_" + k])), (tag, k)
+    g = np.load(os.path.join(GOLD, "orc_gmm.npz"))
+    model = {k[6:]: g[k] for k in g.files if k.startswith("model_")}
+    model["dim"] = int(model["dim"])
+    o = OracleGmm(model)
+    sc, best = o.score(g["feats"], mode=0)
+    assert np.array_equal(bits(sc), bits(g["max_scores"])) and np.array_equal(best, g["max_best"])
+    assert np.array_equal(bits(o.score(g["feats"], mode=1)[0]), bits(g["sum_scores"]))
+
+
+def test_mfcc_against_numpy_restatement():
+    """independent float64 numpy computation of the same chain (rfft based): agreement to ~1e-5 shows the oracle
+    computes MFCCs, not merely something self-consistent."""
+    pcm = synth.waveform(8000, seed=21)
+    m = OracleMfcc(n_ceps=40, filter_width=138.0)
+    got = m.run(pcm)
+    x = pcm.astype(np.float64)
+    y = np.concatenate([[0.0], x[1:] - x[:-1]])
+    s, e, o, w = m.filters
+    win = m.window.astype(np.float64)
+    dct = m.dct.astype(np.float64)
+    T = m.n_frames(len(pcm))
+    ref = np.zeros((T, 40))
+    for t in range(T):
+        fr = y[t * 160:t * 160 + 400]
+        buf = np.zeros(512)
+        buf[:len(fr)] = fr * win[:len(fr)]
+        amp = np.abs(np.fft.rfft(buf)) / 16000.0
+        mel = np.array([np.dot(amp[s[f]:e[f]], w[o[f]:o[f + 1]].astype(np.float64)) for f in range(40)])
+        ref[t] = dct @ np.log10(mel)
+    assert np.allclose(got, ref, rtol=2e-5, atol=2e-4)
+
+
+def test_gmm_max_against_numpy_restatement():
+    model = synth.gmm_cart(30, 1, 6, 24, seed=8, pooled=False)
+    x = np.random.Generator(np.random.PCG64(9)).standard_normal((20, 24)).astype(np.float32)
+    sc, best = OracleGmm(model).score(x)
+    mu, var = model["means"].astype(np.float64), model["variances"].astype(np.float64)
+    for m in range(30):
+        k0, k1 = model["mix_offsets"][m], model["mix_offsets"][m + 1]
+        d = model["dens_index"][k0:k1]
+        ll = (-2 * model["log_weight"][k0:k1])[None, :] + (24 * np.log(2 * np.pi) + np.log(var[d]).sum(1))[None, :] + \
+             (((x[:, None, :].astype(np.float64) - mu[d][None]) ** 2) / var[d][None]).sum(2)
+        assert np.allclose(sc[:, m], 0.5 * ll.min(1), rtol=1e-5)
+        assert np.array_equal(best[:, m], ll.argmin(1))
+    ssum, _ = OracleGmm(model).score(x, mode=1)
+    for m in range(30):
+        k0, k1 = model["mix_offsets"][m], model["mix_offsets"][m + 1]
+        d = model["dens_index"][k0:k1]
+        ll = 0.5 * ((-2 * model["log_weight"][k0:k1])[None, :] + (24 * np.log(2 * np.pi) + np.log(var[d]).sum(1))[None, :] +
+                    (((x[:, None, :].astype(np.float64) - mu[d][None]) ** 2) / var[d][None]).sum(2))
+        lse = -np.log(np.exp(-(ll - ll.min(1, keepdims=True))).sum(1)) + ll.min(1)
+        assert np.allclose(ssum[:, m], lse, rtol=1e-5, atol=1e-5)
+
+
+def test_batch_float_scorer_close_to_diagonal_maximum():
+    model = synth.gmm_cart(40, 1, 8, 40, seed=18, pooled=True)
+    x = np.random.Generator(np.random.PCG64(19)).standard_normal((10, 40)).astype(np.float32)
+    o = OracleGmm(model)
+    assert np.allclose(o.score_batch_float(x), o.score(x)[0], rtol=2e-6)
+    with pytest.raises(ValueError):
+        OracleGmm(synth.gmm_cart(4, 1, 2, 8, seed=1, pooled=False)).score_batch_float(np.zeros((1, 8), np.float32))

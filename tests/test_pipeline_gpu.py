@@ -1,0 +1,94 @@
+"""GPU: committed golden vectors, the context window, the epoch accumulators and the whole chain."""
+import os
+
+import numpy as np
+import pytest
+
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_golden_vectors(ctx):
+    import rasr_amd
+    z = np.load(os.path.join(GOLD, "orc_mfcc.npz"))
+    pcm = z["pcm_s16"].astype(np.float32)
+    for tag, kw in (("mfcc16", dict(nr_cepstrum_coefficients=16)), ("mfcc40", dict(nr_cepstrum_coefficients=40, filter_width=138.0))):
+        got = rasr_amd.MfccExtractor(ctx, **kw).run(pcm)
+        assert np.all(np.abs(got - z[tag]) <= 1e-4 * np.abs(z[tag]) + 2e-3)
+    g = np.load(os.path.join(GOLD, "orc_gmm.npz"))
+    model = {k[6:]: g[k] for k in g.files if k.startswith("model_")}
+    model["dim"] = int(model["dim"])
+    sc, best = rasr_amd.GmmFeatureScorer(ctx, model).score(g["feats"])
+    assert np.array_equal(sc.view(np.uint32), g["max_scores"].view(np.uint32)) and np.array_equal(best, g["max_best"])
+    ss, _ = rasr_amd.GmmFeatureScorer(ctx, model, feature_scorer_type="diagonal-sum").score(g["feats"])
+    assert np.allclose(ss, g["sum_scores"], rtol=1e-5, atol=1e-5)
+    f = np.load(os.path.join(GOLD, "orc_ffnn.npz"))
+    Ws, bs = [f["W%d" % i] for i in range(3)], [f["b%d" % i] for i in range(3)]
+    got = rasr_amd.NnBatchFeatureScorer(ctx, Ws, bs, [1, 1, 0], log_prior=f["log_prior"], precision="fp32").score(f["feats"])
+    assert np.array_equal(got.view(np.uint32), f["scores_fma"].view(np.uint32))
+    assert np.all(np.abs(got - f["scores64"]) <= 1e-4 * np.abs(f["scores64"]) + 1e-4)
+
+
+def test_context_window_copy_margin(ctx):
+    import torch
+
+    import rasr_amd
+    fe = rasr_amd.MfccExtractor(ctx, nr_cepstrum_coefficients=8)
+    lens = np.array([400, 2000, 161 * 7, 5000])          # 1, 11, 6, 30 frames
+    off = np.concatenate([[0], np.cumsum(lens)])
+    plan = fe.plan(off)
+    F = plan.total_frames
+    x = np.random.Generator(np.random.PCG64(1)).standard_normal((F, 8)).astype(np.float32)
+    xd = torch.from_numpy(x).cuda()
+    out = torch.empty((F, 72), dtype=torch.float32, device="cuda")
+    ctx.use_torch_stream()
+    ctx.context_window(plan, xd, 8, 3, 2, out, 72)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    for u in range(len(lens)):
+        s0, s1 = plan.frame_offsets[u], plan.frame_offsets[u + 1]
+        for t in range(s0, s1):
+            idx = np.clip(np.arange(t - 3, t + 3), s0, s1 - 1)
+            assert np.array_equal(got[t, :48], x[idx].reshape(-1))
+            assert np.all(got[t, 48:] == 0)
+
+
+def test_epoch_accumulators(ctx):
+    import torch
+    rng = np.random.Generator(np.random.PCG64(5))
+    T, M = 1000, 777
+    sc = rng.standard_normal((T, M)).astype(np.float32)
+    sc[10, 5] = sc[10, 700] = -50.0                     # tie: the smaller state index wins
+    sc[11] = 3.0                                        # all equal: state 0
+    d = torch.from_numpy(sc).cuda()
+    best = torch.empty(T, dtype=torch.int32, device="cuda")
+    counts = torch.zeros(M, dtype=torch.int64, device="cuda")
+    ssum = torch.zeros(1, dtype=torch.float64, device="cuda")
+    ctx.use_torch_stream()
+    ctx.stats_accumulate(d, T, M, best, counts, ssum)
+    ctx.stats_accumulate(d, T, M, best, counts, ssum)   # accumulates
+    torch.cuda.synchronize()
+    want = sc.argmin(axis=1)
+    assert np.array_equal(best.cpu().numpy(), want) and want[10] == 5 and want[11] == 0
+    assert np.array_equal(counts.cpu().numpy(), 2 * np.bincount(want, minlength=M))
+    assert abs(float(ssum[0]) - 2 * sc.min(axis=1).astype(np.float64).sum()) < 1e-6
+
+
+def test_chain_audio_to_best_state(ctx):
+    """audio -> MFCC -> GMM scores -> best state, against the oracle chain; the state decision is identical
+    wherever the oracle's top-2 margin exceeds the front-end tolerance."""
+    import rasr_amd
+    from oracle import OracleGmm, OracleMfcc
+    pcm = synth.waveform(40000, seed=77)
+    model = synth.gmm_cart(500, 1, 4, 16, seed=78, pooled=False)
+    ceps = rasr_amd.MfccExtractor(ctx, nr_cepstrum_coefficients=16).run(pcm)
+    sc, _ = rasr_amd.GmmFeatureScorer(ctx, model).score(ceps)
+    oc = OracleMfcc(n_ceps=16).run(pcm)
+    osc, _ = OracleGmm(model).score(oc)
+    part = np.partition(osc, 1, axis=1)
+    clear = (part[:, 1] - part[:, 0]) > 1e-2
+    assert clear.mean() > 0.9
+    assert np.array_equal(sc.argmin(1)[clear], osc.argmin(1)[clear])
+    assert np.allclose(sc, osc, rtol=1e-4, atol=1e-3)
