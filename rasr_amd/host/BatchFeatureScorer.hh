@@ -1,0 +1,211 @@
+// rasr_amd/host/BatchFeatureScorer.hh -- header-only C++ mirror of the reference's buffered feature-scorer
+// protocol on top of the C ABI (include/amx.h).  This is the code a RASR adapter derives from / copies
+// (INTEGRATION.md); it has no RASR dependency so it can be compiled and tested on its own.
+//
+// Mirrors, with the same names and argument meaning:
+//   Mm::FeatureScorer buffered protocol            src/Mm/FeatureScorer.hh:89-137
+//   Nn::BatchFeatureScorer ring buffer             src/Nn/BatchFeatureScorer.cc:92-171, BatchFeatureScorer.hh:156-171
+//   Mm::FeatureScorer::ContextScorer               src/Mm/FeatureScorer.hh:31-46
+// Differences: the batch is evaluated on the GPU for ALL emissions the first time any score of an
+// up-to-date buffer is requested (the reference does the same with network_.forward(buffer_)); scores are kept in
+// a host matrix [bufferSize x nEmissions] so score(e) is a plain read, thread-safe once computed.
+#ifndef RASR_AMD_HOST_BATCH_FEATURE_SCORER_HH
+#define RASR_AMD_HOST_BATCH_FEATURE_SCORER_HH
+
+#include <cstdio>
+#include <cstdlib>
+#include <limits>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/amx.h"
+
+namespace AmxHost {
+
+// The reference aborts on contract violations (Core/Assertions.hh require()).  Tests define
+// AMXHOST_REQUIRE_THROWS to observe them as exceptions instead.
+#ifdef AMXHOST_REQUIRE_THROWS
+#define amxhost_require(expr)                                                                         \
+    do {                                                                                              \
+        if (!(expr))                                                                                  \
+            throw std::logic_error(std::string("precondition ") + #expr + " violated");               \
+    } while (0)
+#else
+#define amxhost_require(expr)                                                                         \
+    do {                                                                                              \
+        if (!(expr)) {                                                                                \
+            std::fprintf(stderr, "PROGRAM DEFECTIVE: precondition %s violated (%s:%d)\n", #expr, __FILE__, __LINE__); \
+            std::abort();                                                                             \
+        }                                                                                             \
+    } while (0)
+#endif
+
+typedef float              Score;          // Mm::Score
+typedef unsigned           EmissionIndex;  // Mm::EmissionIndex
+typedef std::vector<float> FeatureVector;  // Mm::FeatureVector
+
+/** Backend: anything that scores a batch of frames for all emissions. */
+class BatchBackend {
+public:
+    virtual ~BatchBackend() {}
+    virtual unsigned nEmissions() const = 0;
+    virtual unsigned dimension() const  = 0;
+    /** feats [T x dim] row-major -> scores [T x nEmissions]; returns amx_status */
+    virtual int score(const float* feats, int T, float* scores) = 0;
+};
+
+class GmmBackend : public BatchBackend {
+    amx_gmm* h_;
+    int      mode_;
+
+public:
+    /** featureScorerType: "diagonal-maximum" (registered in Mm/Module.cc:83-105) or "diagonal-sum" */
+    GmmBackend(amx_ctx* ctx, const amx_gmm_model& model, const std::string& featureScorerType = "diagonal-maximum")
+            : h_(nullptr), mode_(featureScorerType == "diagonal-sum" ? AMX_GMM_SUM : AMX_GMM_MAX) {
+        if (amx_gmm_create(ctx, &model, &h_) != AMX_OK)
+            throw std::runtime_error(amx_last_error());
+    }
+    ~GmmBackend() { amx_gmm_destroy(h_); }
+    unsigned nEmissions() const { return (unsigned)amx_gmm_n_mixtures(h_); }
+    unsigned dimension() const { return (unsigned)amx_gmm_dimension(h_); }
+    int      score(const float* f, int T, float* s) { return amx_gmm_score(h_, mode_, f, T, s, nullptr); }
+};
+
+class FfnnBackend : public BatchBackend {
+    amx_ffnn* h_;
+
+public:
+    FfnnBackend(amx_ctx* ctx, const amx_ffnn_model& model)
+            : h_(nullptr) {
+        if (amx_ffnn_create(ctx, &model, &h_) != AMX_OK)
+            throw std::runtime_error(amx_last_error());
+    }
+    ~FfnnBackend() { amx_ffnn_destroy(h_); }
+    unsigned nEmissions() const { return (unsigned)amx_ffnn_output_dim(h_); }
+    unsigned dimension() const { return (unsigned)amx_ffnn_input_dim(h_); }
+    int      score(const float* f, int T, float* s) { return amx_ffnn_score(h_, f, T, s); }
+};
+
+class BatchFeatureScorer;
+
+/** Mm::FeatureScorer::ContextScorer: scores of ONE buffered frame. */
+class ContextScorer {
+    const BatchFeatureScorer* parent_;
+    unsigned                  position_;
+
+public:
+    ContextScorer(const BatchFeatureScorer* parent, unsigned position)
+            : parent_(parent), position_(position) {}
+    inline EmissionIndex nEmissions() const;
+    inline Score         score(EmissionIndex e) const;
+};
+typedef std::shared_ptr<const ContextScorer> Scorer;  // Core::Ref<const ContextScorer>
+
+/** The buffered scorer.  Caller protocol (Speech/Recognizer.cc:271-281,197-205):
+ *    if (isBuffered() && !bufferFilled()) addFeature(f); else feed(getScorer(f));
+ *    at segment end: while (!bufferEmpty()) feed(flush());
+ */
+class BatchFeatureScorer {
+    friend class ContextScorer;
+    std::unique_ptr<BatchBackend> backend_;
+    unsigned                      bufferSize_;
+    mutable unsigned              nBufferedFeatures_, currentFeature_;
+    mutable std::vector<bool>     scoreComputed_;
+    mutable std::vector<float>    buffer_;  // [bufferSize x dim] row-major (frame major)
+    mutable std::vector<float>    scores_;  // [bufferSize x nEmissions]
+    unsigned                      dim_, nEmissions_;
+
+    void setFeature(unsigned position, const FeatureVector& f) const {
+        amxhost_require(position < bufferSize_);
+        amxhost_require(f.size() == dim_);
+        for (unsigned i = 0; i < dim_; ++i)
+            buffer_[(size_t)position * dim_ + i] = f[i];
+    }
+
+public:
+    /** bufferSize: "buffer-size (and also batch size) for the feature scorer"; the reference default of 8
+     *  (Nn/BatchFeatureScorer.cc:21-22) is far too small for a GPU -- use 256..1024. */
+    BatchFeatureScorer(std::unique_ptr<BatchBackend> backend, unsigned bufferSize)
+            : backend_(std::move(backend)),
+              bufferSize_(bufferSize),
+              nBufferedFeatures_(0),
+              currentFeature_(0),
+              scoreComputed_(bufferSize, false),
+              dim_(backend_->dimension()),
+              nEmissions_(backend_->nEmissions()) {
+        amxhost_require(bufferSize_ >= 1);
+        buffer_.assign((size_t)bufferSize_ * dim_, 0.f);
+        scores_.assign((size_t)bufferSize_ * nEmissions_, 0.f);
+    }
+
+    EmissionIndex nMixtures() const { return nEmissions_; }
+    unsigned      dimension() const { return dim_; }
+
+    bool     isBuffered() const { return true; }
+    unsigned bufferSize() const { return bufferSize_; }
+    bool     bufferFilled() const { return nBufferedFeatures_ + 1 >= bufferSize_; }  // >= bufferSize_ - 1
+    bool     bufferEmpty() const { return nBufferedFeatures_ == 0; }
+
+    void reset() const {
+        scoreComputed_.assign(bufferSize_, false);
+        nBufferedFeatures_ = 0;
+        currentFeature_    = 0;
+    }
+
+    void addFeature(const FeatureVector& f) const {
+        amxhost_require(!bufferFilled());
+        setFeature(nBufferedFeatures_, f);
+        scoreComputed_[nBufferedFeatures_] = false;
+        nBufferedFeatures_++;
+    }
+
+    /** stores f in the slot behind the oldest frame and returns the scorer of the oldest frame */
+    Scorer getScorer(const FeatureVector& f) const {
+        amxhost_require(bufferFilled());
+        unsigned position = currentFeature_ ? (currentFeature_ - 1) % bufferSize_ : bufferSize_ - 1;
+        setFeature(position, f);
+        scoreComputed_[position] = false;
+        Scorer scorer(new ContextScorer(this, currentFeature_));
+        currentFeature_ = (currentFeature_ + 1) % bufferSize_;
+        return scorer;
+    }
+
+    Scorer flush() const {
+        amxhost_require(!bufferEmpty());
+        Scorer scorer(new ContextScorer(this, currentFeature_));
+        currentFeature_ = (currentFeature_ + 1) % bufferSize_;
+        nBufferedFeatures_--;
+        if (bufferEmpty()) {
+            currentFeature_ = 0;
+            buffer_.assign(buffer_.size(), 0.f);
+        }
+        return scorer;
+    }
+
+    Score getScore(EmissionIndex e, unsigned position) const {
+        amxhost_require(position < bufferSize_);
+        amxhost_require(e < nEmissions_);
+        if (!scoreComputed_[position]) {
+            // whole buffer in one batch, exactly like network_.forward(buffer_)
+            if (backend_->score(buffer_.data(), (int)bufferSize_, scores_.data()) != AMX_OK) {
+                // the reference would criticalError() and exit; the message is amx_last_error()
+                std::fprintf(stderr, "amx batch scoring failed: %s\n", amx_last_error());
+                std::abort();
+            }
+            scoreComputed_.assign(bufferSize_, true);
+        }
+        return scores_[(size_t)position * nEmissions_ + e];
+    }
+};
+
+inline EmissionIndex ContextScorer::nEmissions() const {
+    return parent_->nMixtures();
+}
+inline Score ContextScorer::score(EmissionIndex e) const {
+    return parent_->getScore(e, position_);
+}
+
+}  // namespace AmxHost
+#endif

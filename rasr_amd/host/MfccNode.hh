@@ -1,0 +1,123 @@
+// rasr_amd/host/MfccNode.hh -- header-only C++ mirror of the mfcc.flow sub-network as ONE node on top of the C
+// ABI.  It follows the Flow::Node life cycle (src/Flow/Node.hh:37-185): setParameter(name, value) with the
+// parameter names of the replaced nodes, configure() (reads "sample-rate", publishes the output attributes of
+// signal-cosine-transform / signal-window: sample-rate = 1, frame-shift, datatype = vector-f32), then per segment
+// putSamples()* / eos() / getFeature()* -- the pull loop of Speech::FeatureExtractor::processSegment
+// (src/Speech/DataExtractor.cc:101-111) sees one Flow::Vector<f32> per frame with the reference's timestamps.
+#ifndef RASR_AMD_HOST_MFCC_NODE_HH
+#define RASR_AMD_HOST_MFCC_NODE_HH
+
+#include <cstdlib>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/amx.h"
+
+namespace AmxHost {
+
+struct FeaturePacket {  // Flow::Vector<f32> + Flow::Timestamp
+    std::vector<float> data;
+    double             startTime, endTime;
+};
+
+class MfccNode {
+    amx_ctx*                           ctx_;
+    amx_mfcc_cfg                       cfg_;
+    amx_mfcc*                          h_;
+    amx_mfcc_info                      info_;
+    std::vector<float>                 samples_;
+    double                             segmentStart_;
+    std::vector<float>                 ceps_;
+    long                               nFrames_, next_;
+    std::map<std::string, std::string> outputAttributes_;
+
+public:
+    static std::string filterName() { return "signal-mfcc-amx"; }
+
+    explicit MfccNode(amx_ctx* ctx)
+            : ctx_(ctx), h_(nullptr), segmentStart_(0), nFrames_(0), next_(0) {
+        amx_mfcc_default_cfg(&cfg_);
+    }
+    ~MfccNode() { amx_mfcc_destroy(h_); }
+
+    /** parameter names of the replaced nodes: alpha (signal-preemphasis), shift / length (signal-window),
+     *  maximum-input-size / apply-scale (signal-real-fast-fourier-transform), filter-width / spacing /
+     *  warp-differential-unit (signal-filterbank), nr-outputs / normalize (signal-cosine-transform) */
+    bool setParameter(const std::string& name, const std::string& value) {
+        const double v = atof(value.c_str());
+        const bool   b = value == "true" || value == "yes" || value == "1";
+        if (name == "alpha") cfg_.preemph_alpha = v;
+        else if (name == "shift") cfg_.win_shift_s = v;
+        else if (name == "length") cfg_.win_len_s = v;
+        else if (name == "maximum-input-size") cfg_.fft_max_input_s = v;
+        else if (name == "apply-scale") cfg_.apply_scale = b;
+        else if (name == "filter-width") cfg_.mel_filter_width = v;
+        else if (name == "spacing") cfg_.mel_spacing = v;
+        else if (name == "warp-differential-unit") cfg_.warp_differential_unit = b;
+        else if (name == "nr-outputs") cfg_.n_ceps = atoi(value.c_str());
+        else if (name == "normalize") cfg_.dct_normalize = b;
+        else return false;
+        return true;
+    }
+
+    /** inputAttributes must carry "sample-rate" (samples.flow).  false + amx_last_error() on a bad configuration
+     *  (the reference nodes call criticalError with the same texts). */
+    bool configure(const std::map<std::string, std::string>& inputAttributes) {
+        auto it = inputAttributes.find("sample-rate");
+        cfg_.sample_rate = it == inputAttributes.end() ? 0.0 : atof(it->second.c_str());
+        amx_mfcc_destroy(h_);
+        h_ = nullptr;
+        if (amx_mfcc_create(ctx_, &cfg_, &h_) != AMX_OK)
+            return false;
+        amx_mfcc_describe(h_, &info_);
+        outputAttributes_                = inputAttributes;
+        outputAttributes_["sample-rate"] = "1";
+        outputAttributes_["datatype"]    = "vector-f32";
+        char buf[64];
+        snprintf(buf, sizeof buf, "%g", cfg_.win_shift_s);
+        outputAttributes_["frame-shift"] = buf;
+        return true;
+    }
+    const std::map<std::string, std::string>& outputAttributes() const { return outputAttributes_; }
+
+    /** one input packet of the `samples` stream; the first packet of a segment fixes its start time */
+    void putSamples(const float* x, size_t n, double startTime) {
+        if (samples_.empty() && next_ == nFrames_)
+            segmentStart_ = startTime;
+        samples_.insert(samples_.end(), x, x + n);
+    }
+
+    /** end of the segment's input: runs the fused kernel over the whole segment */
+    bool eos() {
+        if (!h_)
+            return false;
+        nFrames_ = amx_mfcc_n_frames(h_, (long)samples_.size());
+        next_    = 0;
+        ceps_.assign((size_t)nFrames_ * info_.n_ceps, 0.f);
+        int r = amx_mfcc_run(h_, samples_.data(), (long)samples_.size(), ceps_.data());
+        nSamples_ = (long)samples_.size();
+        samples_.clear();
+        return r == AMX_OK;
+    }
+
+    /** next feature packet; false = end of segment (Flow::Data::eos()) */
+    bool getFeature(FeaturePacket& out) {
+        if (next_ >= nFrames_)
+            return false;
+        out.data.assign(ceps_.begin() + next_ * info_.n_ceps, ceps_.begin() + (next_ + 1) * info_.n_ceps);
+        const long remaining = nSamples_ - next_ * info_.frame_shift;
+        const long len       = remaining < info_.frame_len ? remaining : info_.frame_len;
+        out.startTime        = segmentStart_ + amx_mfcc_frame_start_time(h_, next_);
+        out.endTime          = out.startTime + (double)len / cfg_.sample_rate;  // WindowBuffer::copy
+        ++next_;
+        return true;
+    }
+
+private:
+    long nSamples_ = 0;
+};
+
+}  // namespace AmxHost
+#endif

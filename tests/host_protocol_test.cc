@@ -1,0 +1,144 @@
+// Exercises rasr_amd/host/*.hh against librasr_amd.so on a GPU (driven by tests/test_host_gpu.py).
+// Prints one line per check; the Python side compares the scores with the oracle.
+#define AMXHOST_REQUIRE_THROWS
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <random>
+
+#include "../rasr_amd/host/BatchFeatureScorer.hh"
+#include "../rasr_amd/host/MfccNode.hh"
+
+using namespace AmxHost;
+
+static int fails = 0;
+#define CHECK(c)                                             \
+    do {                                                     \
+        if (!(c)) {                                          \
+            printf("FAIL %s:%d %s\n", __FILE__, __LINE__, #c); \
+            ++fails;                                         \
+        }                                                    \
+    } while (0)
+
+int main(int argc, char** argv) {
+    amx_ctx* ctx = nullptr;
+    if (amx_init(0, &ctx) != AMX_OK) {
+        printf("FAIL init: %s\n", amx_last_error());
+        return 2;
+    }
+    // ---- a small GMM, 3 mixtures x 2 densities, d = 4
+    const int             dim = 4, M = 3;
+    std::vector<uint32_t> off = {0, 2, 4, 6}, didx = {0, 1, 2, 3, 4, 5}, dmean = {0, 1, 2, 3, 4, 5}, dcov(6, 0);
+    std::vector<double>   lw(6, std::log(0.5));
+    std::vector<float>    means(6 * dim), var(dim, 1.5f);
+    std::mt19937          rng(5);
+    std::normal_distribution<float> nd;
+    for (auto& v : means)
+        v = nd(rng);
+    amx_gmm_model model = {dim, M, 6, 6, 1, off.data(), didx.data(), lw.data(), dmean.data(), dcov.data(), means.data(), var.data(), 1.f, 1.f};
+
+    const unsigned     B = 4;
+    BatchFeatureScorer fs(std::unique_ptr<BatchBackend>(new GmmBackend(ctx, model)), B);
+    CHECK(fs.isBuffered() && fs.bufferSize() == B && fs.bufferEmpty() && !fs.bufferFilled());
+    CHECK(fs.nMixtures() == 3 && fs.dimension() == 4);
+
+    // reference scores for T frames, computed in one plain batch call
+    const int          T = 11;
+    std::vector<float> feats(T * dim), want(T * M);
+    for (auto& v : feats)
+        v = nd(rng);
+    {
+        GmmBackend direct(ctx, model);
+        CHECK(direct.score(feats.data(), T, want.data()) == AMX_OK);
+    }
+    // the caller protocol of Speech/Recognizer.cc: every frame must come back once, in order
+    std::vector<Scorer> fed;
+    for (int t = 0; t < T; ++t) {
+        FeatureVector f(feats.begin() + t * dim, feats.begin() + (t + 1) * dim);
+        if (fs.isBuffered() && !fs.bufferFilled())
+            fs.addFeature(f);
+        else
+            fed.push_back(fs.getScorer(f));
+        // the decoder consumes the scorer right away
+        if (!fed.empty()) {
+            int k = (int)fed.size() - 1;
+            for (int e = 0; e < M; ++e)
+                CHECK(fed[k]->score(e) == want[k * M + e]);
+        }
+    }
+    while (!fs.bufferEmpty()) {
+        fed.push_back(fs.flush());
+        int k = (int)fed.size() - 1;
+        for (int e = 0; e < M; ++e)
+            CHECK(fed[k]->score(e) == want[k * M + e]);
+    }
+    CHECK((int)fed.size() == T);
+    CHECK(fed[0]->nEmissions() == 3);
+    // contract violations
+    bool threw = false;
+    try {
+        fs.flush();
+    } catch (const std::logic_error&) {
+        threw = true;
+    }
+    CHECK(threw);  // require(!bufferEmpty())
+    threw = false;
+    try {
+        fs.getScorer(FeatureVector(dim, 0.f));
+    } catch (const std::logic_error&) {
+        threw = true;
+    }
+    CHECK(threw);  // require(bufferFilled())
+    fs.reset();
+    CHECK(fs.bufferEmpty());
+    for (unsigned i = 0; i + 1 < B; ++i)
+        fs.addFeature(FeatureVector(dim, 0.f));
+    CHECK(fs.bufferFilled());
+    threw = false;
+    try {
+        fs.addFeature(FeatureVector(dim, 0.f));
+    } catch (const std::logic_error&) {
+        threw = true;
+    }
+    CHECK(threw);  // require(!bufferFilled())
+
+    // ---- MFCC node: parameters, attributes, packets, timestamps
+    MfccNode node(ctx);
+    CHECK(node.setParameter("nr-outputs", "12") && node.setParameter("filter-width", "268.258") && !node.setParameter("bogus", "1"));
+    std::map<std::string, std::string> attr;
+    attr["sample-rate"] = "16000";
+    CHECK(node.configure(attr));
+    CHECK(node.outputAttributes().at("sample-rate") == "1" && node.outputAttributes().at("frame-shift") == "0.01" &&
+          node.outputAttributes().at("datatype") == "vector-f32");
+    std::vector<float> pcm(16000);
+    for (size_t i = 0; i < pcm.size(); ++i)
+        pcm[i] = 8000.f * std::sin(0.05f * i) + 100.f * nd(rng);
+    node.putSamples(pcm.data(), 4096, 2.5);
+    node.putSamples(pcm.data() + 4096, pcm.size() - 4096, 2.5 + 4096 / 16000.0);
+    CHECK(node.eos());
+    FeaturePacket p;
+    int           n = 0;
+    double        lastEnd = 0;
+    FILE*         dump = argc > 1 ? fopen(argv[1], "wb") : nullptr;
+    while (node.getFeature(p)) {
+        CHECK(p.data.size() == 12);
+        if (n == 0)
+            CHECK(p.startTime == 2.5 && std::fabs(p.endTime - 2.525) < 1e-12);
+        if (dump)
+            fwrite(p.data.data(), 4, 12, dump);
+        lastEnd = p.endTime;
+        ++n;
+    }
+    if (dump) {
+        fwrite(pcm.data(), 4, pcm.size(), dump);
+        fclose(dump);
+    }
+    CHECK(n == 99);                                   // ceil((16000-400)/160)+1
+    CHECK(std::fabs(lastEnd - (2.5 + 1.0)) < 1e-9);   // last (short) frame ends with the audio
+    attr["sample-rate"] = "0";
+    CHECK(!node.configure(attr) && strstr(amx_last_error(), "not positive"));
+
+    amx_destroy(ctx);
+    printf(fails ? "FAILED %d\n" : "OK\n", fails);
+    return fails ? 1 : 0;
+}

@@ -1,0 +1,26 @@
+"""GPU: the C++ host-side mirror (rasr_amd/host/*.hh) of the reference's buffered FeatureScorer protocol and of the
+MFCC Flow node, compiled with g++ against librasr_amd.so, i.e. the same way a RASR adapter links it."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_host_mirror_protocol(tmp_path):
+    exe = str(tmp_path / "host_protocol_test")
+    lib = os.path.join(ROOT, "rasr_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", os.path.join(ROOT, "tests", "host_protocol_test.cc"), "-o", exe,
+                           "-L" + lib, "-lrasr_amd", "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib"])
+    dump = str(tmp_path / "ceps.bin")
+    out = subprocess.run([exe, dump], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("OK"), out.stdout + out.stderr
+    # the packets the node emitted equal the oracle chain on the same samples
+    from oracle import OracleMfcc
+    raw = np.fromfile(dump, dtype=np.float32)
+    ceps, pcm = raw[:99 * 12].reshape(99, 12), raw[99 * 12:]
+    want = OracleMfcc(n_ceps=12).run(pcm)
+    assert np.all(np.abs(ceps - want) <= 1e-4 * np.abs(want) + 2e-3)
