@@ -109,8 +109,7 @@ class Pipeline:
         self.ctx.context_window(self.plan, self.ceps, 40, 5, 5, self.ctxwin, 440)
         for t0 in range(0, self.F, self.CHUNK):
             T = min(self.CHUNK, self.F - t0)
-            self.nn.score_dev(self.ctxwin[t0:], 440, T, self.scores)
-            self.ctx.stats_accumulate(self.scores, T, self.M, self.best[t0:], self.counts, self.score_sum)
+            self.nn.score_stats_dev(self.ctxwin[t0:], 440, T, self.scores, self.best[t0:], self.counts, self.score_sum)
 
     def epoch_reduce(self, world):
         if world > 1:

@@ -200,6 +200,11 @@ int  amx_ffnn_output_dim(const amx_ffnn* h);
 /* feats [T x in0]; scores [T x out_last] = -(W x + b - alpha * log_prior) */
 int amx_ffnn_score(amx_ffnn* h, const float* feats_host, int T, float* scores_host);
 int amx_ffnn_score_dev(amx_ffnn* h, const float* feats_dev, int feats_stride, int T, float* scores_dev);
+/* Same, and additionally the per-epoch statistics of amx_stats_accumulate_dev for these frames: the arg-min over
+ * the states is taken in the output layer's epilogue, so the [T x n_states] score matrix is written once and
+ * never re-read.  best_state_dev nullable [T]. */
+int amx_ffnn_score_stats_dev(amx_ffnn* h, const float* feats_dev, int feats_stride, int T, float* scores_dev,
+                             uint32_t* best_state_dev, unsigned long long* state_counts_dev, double* score_sum_dev);
 
 /* ------------------------------------------------------------------ per-epoch statistics */
 

@@ -272,6 +272,11 @@ class NnBatchFeatureScorer:
     def score_dev(self, feats_dev, feats_stride, T, scores_dev):
         _lib.check(self.L.amx_ffnn_score_dev(self.h, _ptr(feats_dev), feats_stride, T, _ptr(scores_dev)))
 
+    def score_stats_dev(self, feats_dev, feats_stride, T, scores_dev, best_state, counts, score_sum):
+        """scores plus best state / per-state counts / sum of best scores (arg-min fused into the output layer)"""
+        _lib.check(self.L.amx_ffnn_score_stats_dev(self.h, _ptr(feats_dev), feats_stride, T, _ptr(scores_dev), _ptr(best_state),
+                                                   _ptr(counts), _ptr(score_sum)))
+
 
 def read_pms(path):
     """text mixture set -> model dict (see GmmFeatureScorer)"""

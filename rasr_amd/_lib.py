@@ -91,6 +91,7 @@ SIGNATURES = {
     "amx_ffnn_output_dim": (C.c_int, [_P]),
     "amx_ffnn_score": (C.c_int, [_P, _P, C.c_int, _P]),
     "amx_ffnn_score_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
+    "amx_ffnn_score_stats_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P, _P]),
     "amx_stats_accumulate_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P]),
 }
 

@@ -93,122 +93,208 @@ __global__ __launch_bounds__(256) void pack_input_f32(const float* __restrict__ 
 // ---------------------------------------------------------------------------------------------
 // bf16 GEMM: D[n][t] = sum_k W[n][k] X[t][k];  W [Npad x Kpad], X [Tpad x ldx] bf16.
 // hidden layers: out bf16 [Tpad x ldo] = act(D + bias);  last layer: out f32 [T x n_valid] = -(D + bias)
-constexpr int BN = 128, BT = 128, BK = 64;
-constexpr int TILE_BYTES = BN * BK * 2;  // 16 KB per operand tile
+constexpr int BK      = 64;   // k per stage: one 128-byte LDS row per matrix row
+constexpr int PAD_NT  = 256;  // N and T are padded to this (largest tile edge)
 
-// byte offset of 16-byte chunk `c` (0..7) of row `r` inside a [128][64] bf16 tile
+template<int BN_, int BT_, int WN_, int WT_, int STAGES_>
+struct GemmCfg {
+    static constexpr int BN = BN_, BT = BT_, WN = WN_, WT = WT_, STAGES = STAGES_;
+    static constexpr int NW = WN * WT, THREADS = NW * 64;
+    static constexpr int A_BYTES = BN * 128, B_BYTES = BT * 128, STAGE_BYTES = A_BYTES + B_BYTES;
+    static constexpr int LDS_BYTES = STAGES * STAGE_BYTES;
+    static constexpr int A_LOADS = BN / 8 / NW, B_LOADS = BT / 8 / NW, LOADS = A_LOADS + B_LOADS;  // glds per wave per stage
+    static constexpr int MI = BN / WN / 32, MJ = BT / WT / 32;                                      // 32x32 tiles per wave
+    static_assert(BN % (8 * NW) == 0 && BT % (8 * NW) == 0, "staging needs whole 8-row groups per wave");
+    static_assert(BN % (WN * 32) == 0 && BT % (WT * 32) == 0, "wave tile must be a multiple of 32x32");
+};
+
+// byte offset of 16-byte chunk `c` (0..7) of row `r` inside a [rows][64] bf16 tile
 __device__ __forceinline__ int swz(int r, int c) {
     return r * 128 + ((c ^ ((r >> 1) & 7)) << 4);
 }
 
-template<int ACT, bool LAST>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16_t* __restrict__ W, const bf16_t* __restrict__ X,
-                                                          const float* __restrict__ bias, void* __restrict__ out, int Kpad, int ldx,
-                                                          int ldo, int n_valid, int t_valid, int n_tiles_n) {
-    extern __shared__ __attribute__((aligned(16))) char lds[];  // [2 buffers][W tile | X tile]
+template<int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N >= 0 && N < 64, "vmcnt immediate");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template<class C, int ACT, bool LAST, int VAR>
+__global__ __launch_bounds__(C::THREADS) void gemm_bf16_kernel(const bf16_t* __restrict__ W, const bf16_t* __restrict__ X,
+                                                              const float* __restrict__ bias, void* __restrict__ out, int Kpad, int ldx,
+                                                              int ldo, int n_valid, int t_valid, int n_tiles_n, int GT, int GN, float* __restrict__ part_min,
+                                                              unsigned* __restrict__ part_idx, int part_ld) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];  // [STAGES][W tile | X tile]
     const int tid  = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wn   = wave >> 1, wt = wave & 1;
+    const int wn   = wave / C::WT, wt = wave % C::WT;
 
-    // XCD-aware tile order: consecutive workgroup ids land on different XCDs (id % 8); give each
-    // XCD a contiguous run of tiles that share the same frame block, so its L2 keeps that X panel.
+    // XCD-aware tile order.  Workgroup b runs on XCD b%8 (observed placement, speed only); the CUs of
+    // an XCD pick up their workgroups in increasing b/8.  Give every XCD a contiguous range of a virtual
+    // order v in which 32 consecutive tiles (= the 32 CUs of the XCD at one time) form a 4(t) x 8(n)
+    // super-tile: per K-step the XCD's L2 then fetches 4 X slabs + 8 W slabs for 32 tiles instead of
+    // 1 + 32, and neighbouring super-tiles keep sharing the X panel.
     const int nwg = gridDim.x;
-    int       id  = blockIdx.x;
+    int       tile_t, tile_n;
     {
-        const int q = nwg >> 3, r = nwg & 7, xcd = id & 7, k = id >> 3;
-        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+        const int b = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = b & 7, k = b >> 3;
+        const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;  // bijective for any nwg
+        const int n_tiles_t = nwg / n_tiles_n;
+        if (GT > 0 && (n_tiles_n % GN) == 0 && (n_tiles_t % GT) == 0) {
+            const int sg = v / (GT * GN), w = v % (GT * GN);
+            const int sn = n_tiles_n / GN;
+            tile_t       = (sg / sn) * GT + w / GN;
+            tile_n       = (sg % sn) * GN + w % GN;
+        }
+        else {
+            tile_t = v / n_tiles_n;
+            tile_n = v - tile_t * n_tiles_n;
+        }
     }
-    const int tile_t = id / n_tiles_n;
-    const int tile_n = id - tile_t * n_tiles_n;
-    const int n0 = tile_n * BN, t0 = tile_t * BT;
+    const int n0 = tile_n * C::BN, t0 = tile_t * C::BT;
 
-    // ---- staging: each wave moves 8 rows x 128 B per instruction; 4 instructions per operand
-    // LDS linear position of this lane's 16 B within the tile for instruction i:
-    //   pos = (i*4 + wave) * 1024 + lane*16  -> row = pos / 128, physical chunk = (pos % 128) / 16
-    // it must hold logical chunk = phys ^ ((row>>1)&7) of that row.
-    const bf16_t* gW[4];
-    const bf16_t* gX[4];
+    // ---- staging: one global_load_lds moves 8 rows x 128 B per wave.  LDS linear position of this
+    // lane's 16 B for instruction i: pos = (i*NW + wave)*1024 + lane*16 -> row = pos/128, physical
+    // chunk = (pos%128)/16; it must hold logical chunk = phys ^ ((row>>1)&7) of that row.
+    const bf16_t* gW[C::A_LOADS];
+    const bf16_t* gX[C::B_LOADS];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int pos  = (i * 4 + wave) * 1024 + lane * 16;
-        const int row  = pos >> 7;
-        const int phys = (pos & 127) >> 4;
-        const int chunk = phys ^ ((row >> 1) & 7);
-        gW[i] = W + (size_t)(n0 + row) * Kpad + chunk * 8;
-        gX[i] = X + (size_t)(t0 + row) * ldx + chunk * 8;
+    for (int i = 0; i < C::A_LOADS; ++i) {
+        const int pos = (i * C::NW + wave) * 1024 + lane * 16;
+        const int row = pos >> 7, phys = (pos & 127) >> 4;
+        gW[i]         = W + (size_t)(n0 + row) * Kpad + (phys ^ ((row >> 1) & 7)) * 8;
     }
-    auto stage = [&](int buf, int kt) {
-        char* base = lds + buf * (2 * TILE_BYTES);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < C::B_LOADS; ++i) {
+        const int pos = (i * C::NW + wave) * 1024 + lane * 16;
+        const int row = pos >> 7, phys = (pos & 127) >> 4;
+        gX[i]         = X + (size_t)(t0 + row) * ldx + (phys ^ ((row >> 1) & 7)) * 8;
+    }
+    auto stage = [&](int slot, int kt) {
+        char* base = lds + slot * C::STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < C::A_LOADS; ++i)
             __builtin_amdgcn_global_load_lds((const void*)(gW[i] + (size_t)kt * BK),
-                                             (__attribute__((address_space(3))) void*)(base + (i * 4 + wave) * 1024), 16, 0, 0);
-        }
+                                             (__attribute__((address_space(3))) void*)(base + (i * C::NW + wave) * 1024), 16, 0, 0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < C::B_LOADS; ++i)
             __builtin_amdgcn_global_load_lds((const void*)(gX[i] + (size_t)kt * BK),
-                                             (__attribute__((address_space(3))) void*)(base + TILE_BYTES + (i * 4 + wave) * 1024), 16, 0, 0);
-        }
+                                             (__attribute__((address_space(3))) void*)(base + C::A_BYTES + (i * C::NW + wave) * 1024), 16, 0, 0);
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[C::MI][C::MJ];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < C::MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < C::MJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 acc[i][j][r] = 0.f;
 
+    // ---- software pipeline, ONE barrier per K-tile:
+    //   wait(my loads of tile kt) ; barrier (=> everybody's loads of kt landed AND everybody finished
+    //   reading tile kt-1) ; issue tile kt+STAGES-1 into the slot tile kt-1 occupied ; multiply tile kt.
+    // STAGES-1 tiles stay in flight across the barrier (counted vmcnt, never a drain).
     const int KT = Kpad / BK;
-    stage(0, 0);
+#pragma unroll
+    for (int s = 0; s < C::STAGES - 1; ++s)
+        if (s < KT)
+            stage(s, s);
+    const int frow = lane & 31;
+    const int fk   = lane >> 5;  // which 8-element half of a 16-wide k slab
     for (int kt = 0; kt < KT; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < KT) {
-            stage(buf ^ 1, kt + 1);
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // tile kt landed, tile kt+1 (8 loads) in flight
-        }
+        // tiles kt .. min(kt+STAGES-2, KT-1) are outstanding; keep all but tile kt in flight
+        const int ahead = min(C::STAGES - 2, KT - 1 - kt);
+        if (C::STAGES >= 4 && ahead == 2)
+            wait_vmcnt<2 * C::LOADS>();
+        else if (C::STAGES >= 3 && ahead == 1)
+            wait_vmcnt<C::LOADS>();
         else
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
-        const char* wbase = lds + buf * (2 * TILE_BYTES);
-        const char* xbase = wbase + TILE_BYTES;
-        const int   frow  = lane & 31;
-        const int   fk    = lane >> 5;  // which 8-element half of the 16-wide k slab
+        const bool more  = kt + C::STAGES - 1 < KT;
+        const int  nslot = (kt + C::STAGES - 1) % C::STAGES;
+        if (!(VAR & 4) && more)
+            stage(nslot, kt + C::STAGES - 1);
+        const char* wbase = lds + (kt % C::STAGES) * C::STAGE_BYTES;
+        const char* xbase = wbase + C::A_BYTES;
+        if (VAR & 1) {
+            // fragments double-buffered in registers: the reads of k-slab ks+1 are in flight while ks multiplies
+            bf16x8 a[2][C::MI], b[2][C::MJ];
+            auto   load = [&](int buf, int ks) {
 #pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
-            bf16x8 a[2], b[2];
+                for (int i = 0; i < C::MI; ++i)
+                    a[buf][i] = *(const bf16x8*)(wbase + swz(wn * (C::BN / C::WN) + i * 32 + frow, ks * 2 + fk));
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int r = wn * 64 + i * 32 + frow;
-                a[i]        = *(const bf16x8*)(wbase + swz(r, ks * 2 + fk));
+                for (int j = 0; j < C::MJ; ++j)
+                    b[buf][j] = *(const bf16x8*)(xbase + swz(wt * (C::BT / C::WT) + j * 32 + frow, ks * 2 + fk));
+            };
+            load(0, 0);
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                if (ks + 1 < BK / 16)
+                    load((ks + 1) & 1, ks + 1);
+                if ((VAR & 4) && more && ks == 0)
+                    stage(nslot, kt + C::STAGES - 1);
+                if (VAR & 2)
+                    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < C::MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < C::MJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks & 1][i], b[ks & 1][j], acc[i][j], 0, 0, 0);
+                if (VAR & 2)
+                    __builtin_amdgcn_s_setprio(0);
             }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int r = wt * 64 + j * 32 + frow;
-                b[j]        = *(const bf16x8*)(xbase + swz(r, ks * 2 + fk));
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
-        // all of this wave's LDS reads have returned before it signals that buf may be restaged
+        else {
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                bf16x8 a[C::MI], b[C::MJ];
+#pragma unroll
+                for (int i = 0; i < C::MI; ++i)
+                    a[i] = *(const bf16x8*)(wbase + swz(wn * (C::BN / C::WN) + i * 32 + frow, ks * 2 + fk));
+#pragma unroll
+                for (int j = 0; j < C::MJ; ++j)
+                    b[j] = *(const bf16x8*)(xbase + swz(wt * (C::BT / C::WT) + j * 32 + frow, ks * 2 + fk));
+                if ((VAR & 4) && more && ks == 0)
+                    stage(nslot, kt + C::STAGES - 1);
+                if (VAR & 2)
+                    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < C::MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < C::MJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                if (VAR & 2)
+                    __builtin_amdgcn_s_setprio(0);
+            }
+        }
+        // this wave's LDS reads have returned before it can arrive at the next barrier
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
     }
 
     // ---- epilogue: lane holds, per 32x32 tile, col t = lane&31 and rows n = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    // Output layer: besides the scores, the tile's arg-min over its n range is produced per frame
+    // (first minimum wins) so that the best-state statistics never re-read the score matrix.
+    const bool want_best = LAST && part_min != nullptr;
+    if (want_best)
+        __syncthreads();  // every wave is done with the last stage: LDS is reused for the cross-wave arg-min
+    float*    s_min = (float*)lds;                              // [WN][BT]
+    unsigned* s_idx = (unsigned*)(lds + C::WN * C::BT * 4);     // [WN][BT]
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int j = 0; j < C::MJ; ++j) {
+        const int tl = wt * (C::BT / C::WT) + j * 32 + (lane & 31);
+        const int t  = t0 + tl;
+        float     bmin = 3.402823466e+38f;
+        unsigned  bidx = 0xffffffffu;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int t = t0 + wt * 64 + j * 32 + (lane & 31);
+        for (int i = 0; i < C::MI; ++i) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int n = n0 + wn * 64 + i * 32 + 8 * g + 4 * (lane >> 5);
+                const int n = n0 + wn * (C::BN / C::WN) + i * 32 + 8 * g + 4 * (lane >> 5);
                 float     v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
@@ -223,6 +309,16 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16_t* __restr
                                 if (n + e < n_valid)
                                     o[e] = -v[e];
                     }
+                    if (want_best) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float sc = -v[e];
+                            if (n + e < n_valid && sc < bmin) {  // ascending n within the lane
+                                bmin = sc;
+                                bidx = (unsigned)(n + e);
+                            }
+                        }
+                    }
                 }
                 else {
                     uint2 pk;
@@ -232,11 +328,86 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16_t* __restr
                 }
             }
         }
+        if (want_best) {
+            // lanes l and l+32 hold the same frame, interleaved n: smaller index wins ties
+            const float    om = __shfl_xor(bmin, 32, 64);
+            const unsigned oi = (unsigned)__shfl_xor((int)bidx, 32, 64);
+            if (om < bmin || (om == bmin && oi < bidx)) {
+                bmin = om;
+                bidx = oi;
+            }
+            if (lane < 32) {
+                s_min[wn * C::BT + tl] = bmin;
+                s_idx[wn * C::BT + tl] = bidx;
+            }
+        }
     }
+    if (want_best) {
+        __syncthreads();
+        for (int tl = tid; tl < C::BT; tl += C::THREADS) {
+            float    bmin = s_min[tl];
+            unsigned bidx = s_idx[tl];
+#pragma unroll
+            for (int w = 1; w < C::WN; ++w) {  // ascending n ranges: strict '<' keeps the first minimum
+                const float m = s_min[w * C::BT + tl];
+                if (m < bmin) {
+                    bmin = m;
+                    bidx = s_idx[w * C::BT + tl];
+                }
+            }
+            part_min[(size_t)tile_n * part_ld + t0 + tl] = bmin;
+            part_idx[(size_t)tile_n * part_ld + t0 + tl] = bidx;
+        }
+    }
+}
+
+// combines the per-tile arg-min partials: best state per frame, per-state counts, sum of best scores
+__global__ __launch_bounds__(256) void best_state_reduce_kernel(const float* __restrict__ part_min, const unsigned* __restrict__ part_idx,
+                                                               int n_tiles_n, int part_ld, int T, unsigned* __restrict__ best_state,
+                                                               unsigned long long* __restrict__ counts, double* __restrict__ score_sum) {
+    const int t   = blockIdx.x * 256 + threadIdx.x;
+    double    sum = 0.0;
+    unsigned  my  = 0xffffffffu;
+    if (t < T) {
+        float    bmin = 3.402823466e+38f;
+        unsigned bidx = 0xffffffffu;
+        for (int k = 0; k < n_tiles_n; ++k) {
+            const float m = part_min[(size_t)k * part_ld + t];
+            if (m < bmin) {
+                bmin = m;
+                bidx = part_idx[(size_t)k * part_ld + t];
+            }
+        }
+        if (best_state)
+            best_state[t] = bidx;
+        if (bidx != 0xffffffffu)
+            sum = (double)bmin;
+        my = bidx;
+    }
+    // per-state counts: lanes of a wave that chose the same state issue ONE atomic (neighbouring frames
+    // often share the best state, and a hot counter would otherwise serialise 32768 atomics per pass)
+    {
+        unsigned long long todo = __ballot(my != 0xffffffffu);
+        while (todo) {
+            const int      leader = __ffsll((long long)todo) - 1;
+            const unsigned key    = (unsigned)__shfl((int)my, leader, 64);
+            const unsigned long long same = __ballot(my == key) & todo;
+            if ((int)(threadIdx.x & 63) == leader)
+                atomicAdd(&counts[key], (unsigned long long)__popcll(same));
+            todo &= ~same;
+        }
+    }
+    // wave-level sum, one atomic per wave
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        sum += __shfl_xor(sum, off, 64);
+    if ((threadIdx.x & 63) == 0 && sum != 0.0)
+        atomicAdd(score_sum, sum);
 }
 
 // ---------------------------------------------------------------------------------------------
 // fp32 GEMM (parity mode): exact f32 MFMA, register-staged LDS tiles with padded rows.
+constexpr int BN = 128, BT = 128;  // f32 tile
 constexpr int FK  = 32;       // k per tile
 constexpr int FLD = FK + 1;   // padded row (floats) -> conflict-free column reads
 
@@ -330,6 +501,16 @@ struct amx_ffnn {
     void*  d_act[2] = {nullptr, nullptr};
     int    max_hidden_pad = 0;
     int    largest_layer  = 0;
+    int    group_t = -1, group_n = -1;  // super-tile of the XCD-aware tile order
+    // fused best-state statistics (amx_ffnn_score_stats_dev): per n-tile arg-min partials [ntn x Tpad]
+    float*    d_part_min = nullptr;
+    unsigned* d_part_idx = nullptr;
+    size_t    part_cap   = 0;
+    float*    cur_part_min = nullptr;
+    unsigned* cur_part_idx = nullptr;
+    int       cur_ntn      = 0;
+    int    gemm_var       = 0;   // schedule variant bits: 1 = register double-buffered fragments, 2 = setprio, 4 = late stage issue
+    int    gemm_cfg       = -1;  // -1 = automatic; index into the bf16 tile configurations (launch_bf16_cfg)
     size_t elt() const { return precision == AMX_PREC_BF16 ? 2 : 4; }
 };
 
@@ -356,12 +537,47 @@ int ensure_workspace(amx_ffnn* h, int Tpad) {
     return AMX_OK;
 }
 
+// tile configurations of the bf16 GEMM, selected at run time (AMX_GEMM_CFG overrides for experiments)
+using CfgA = amx::GemmCfg<128, 128, 2, 2, 2>;  //  64 KB LDS, 2 workgroups per CU
+using CfgC = amx::GemmCfg<256, 256, 2, 4, 2>;  // 128 KB LDS, 8 waves, wave tile 128x64
+// measured and dropped: 256x128x64 3-stage (753 TF), 256x256 with 64x128 wave tiles (973 TF) vs CfgC (1000 TF), CfgA (870 TF)
+
+template<class C, int ACT, bool LAST, int VAR>
+void launch_bf16v(amx_ffnn* h, int l, const void* x, int ldx, void* out, int ldo, int T, int Tpad) {
+    const int ntn = h->Npad[l] / C::BN, ntt = Tpad / C::BT;
+    auto      k   = amx::gemm_bf16_kernel<C, ACT, LAST, VAR>;
+    // 128x128 tiles (2 workgroups per CU) profit from the 2x4 super-tile order, 256x256 tiles do not
+    const int gt = h->group_t >= 0 ? h->group_t : (C::BN == 128 ? 2 : 0), gn = h->group_n >= 0 ? h->group_n : (C::BN == 128 ? 4 : 0);
+    hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    hipLaunchKernelGGL(k, dim3(ntn * ntt), dim3(C::THREADS), C::LDS_BYTES, h->ctx->stream, (const amx::bf16_t*)h->d_W[l],
+                       (const amx::bf16_t*)x, h->d_bias[l], out, h->Kpad[l], ldx, ldo, h->out[l], T, ntn, gt, gn,
+                       LAST ? h->cur_part_min : nullptr, LAST ? h->cur_part_idx : nullptr, Tpad);
+    if (LAST)
+        h->cur_ntn = ntn;
+}
+
+template<class C, int ACT, bool LAST>
+void launch_bf16(amx_ffnn* h, int l, const void* x, int ldx, void* out, int ldo, int T, int Tpad) {
+    // schedule variants 1..7 (register double-buffered fragments, s_setprio around the MFMA cluster, late
+    // stage issue) were measured within +-3 % of variant 0 on MI355X and are not instantiated
+    launch_bf16v<C, ACT, LAST, 0>(h, l, x, ldx, out, ldo, T, Tpad);
+}
+
+template<int ACT, bool LAST>
+void launch_bf16_cfg(amx_ffnn* h, int l, const void* x, int ldx, void* out, int ldo, int T, int Tpad) {
+    // default: 256x256 tiles when they still give >= 2 tiles per CU, else 128x128 (small batches)
+    int cfg = h->gemm_cfg;
+    if (cfg < 0)
+        cfg = ((long)(h->Npad[l] / 256) * (Tpad / 256) >= 2L * h->ctx->n_cu) ? 2 : 0;
+    switch (cfg) {
+        case 2: launch_bf16<CfgC, ACT, LAST>(h, l, x, ldx, out, ldo, T, Tpad); break;
+        default: launch_bf16<CfgA, ACT, LAST>(h, l, x, ldx, out, ldo, T, Tpad); break;
+    }
+}
+
 template<bool LAST>
 int launch_layer(amx_ffnn* h, int l, const void* x, int ldx, void* out, int ldo, int T, int Tpad) {
-    const int   ntn = h->Npad[l] / amx::BN, ntt = Tpad / amx::BT;
-    dim3        grid(ntn * ntt), block(256);
-    hipStream_t st = h->ctx->stream;
-    const int   nv = h->out[l];
+    hipStream_t            st = h->ctx->stream;
     amx::ScopedKernelTimer t_all(h->ctx, "ffnn_gemm");
     hipEvent_t             e0 = nullptr, e1 = nullptr;
     const bool             time_max = h->ctx->profiling && l == h->largest_layer;
@@ -370,28 +586,23 @@ int launch_layer(amx_ffnn* h, int l, const void* x, int ldx, void* out, int ldo,
         hipEventCreate(&e1);
         hipEventRecord(e0, st);
     }
+    const int act = LAST ? AMX_ACT_NONE : h->act[l];
     if (h->precision == AMX_PREC_BF16) {
-        const size_t lds = 2 * 2 * amx::TILE_BYTES;
-#define AMX_L(ACT)                                                                                                     \
-    {                                                                                                                  \
-        auto k = amx::gemm_bf16_kernel<ACT, LAST>;                                                                      \
-        hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                      \
-        hipLaunchKernelGGL(k, grid, block, lds, st, (const amx::bf16_t*)h->d_W[l], (const amx::bf16_t*)x, h->d_bias[l], \
-                           out, h->Kpad[l], ldx, ldo, nv, T, ntn);                                                      \
-    }
-        switch (LAST ? AMX_ACT_NONE : h->act[l]) {
-            case AMX_ACT_RELU: AMX_L(AMX_ACT_RELU) break;
-            case AMX_ACT_SIGMOID: AMX_L(AMX_ACT_SIGMOID) break;
-            case AMX_ACT_TANH: AMX_L(AMX_ACT_TANH) break;
-            default: AMX_L(AMX_ACT_NONE) break;
+        switch (act) {
+            case AMX_ACT_RELU: launch_bf16_cfg<AMX_ACT_RELU, LAST>(h, l, x, ldx, out, ldo, T, Tpad); break;
+            case AMX_ACT_SIGMOID: launch_bf16_cfg<AMX_ACT_SIGMOID, LAST>(h, l, x, ldx, out, ldo, T, Tpad); break;
+            case AMX_ACT_TANH: launch_bf16_cfg<AMX_ACT_TANH, LAST>(h, l, x, ldx, out, ldo, T, Tpad); break;
+            default: launch_bf16_cfg<AMX_ACT_NONE, LAST>(h, l, x, ldx, out, ldo, T, Tpad); break;
         }
-#undef AMX_L
     }
     else {
+        const int ntn = h->Npad[l] / amx::BN, ntt = Tpad / amx::BT;
+        dim3      grid(ntn * ntt), block(256);
+        const int nv = h->out[l];
 #define AMX_L(ACT)                                                                                                   \
     hipLaunchKernelGGL((amx::gemm_f32_kernel<ACT, LAST>), grid, block, 0, st, (const float*)h->d_W[l], (const float*)x, \
                        h->d_bias[l], (float*)out, h->Kpad[l], ldx, ldo, nv, T, ntn);
-        switch (LAST ? AMX_ACT_NONE : h->act[l]) {
+        switch (act) {
             case AMX_ACT_RELU: AMX_L(AMX_ACT_RELU) break;
             case AMX_ACT_SIGMOID: AMX_L(AMX_ACT_SIGMOID) break;
             case AMX_ACT_TANH: AMX_L(AMX_ACT_TANH) break;
@@ -432,6 +643,12 @@ int amx_ffnn_create(amx_ctx* ctx, const amx_ffnn_model* m, amx_ffnn** out) {
     h->ctx       = ctx;
     h->n_layers  = m->n_layers;
     h->precision = m->precision;
+    if (const char* e = getenv("AMX_GEMM_CFG"))
+        h->gemm_cfg = atoi(e);
+    if (const char* e = getenv("AMX_GEMM_VAR"))
+        h->gemm_var = atoi(e);
+    if (const char* e = getenv("AMX_GEMM_GROUP"))
+        sscanf(e, "%dx%d", &h->group_t, &h->group_n);
     hipSetDevice(ctx->device);
     const int kmult = (m->precision == AMX_PREC_BF16) ? amx::BK : amx::FK;
     long      best_flops = -1;
@@ -441,7 +658,7 @@ int amx_ffnn_create(amx_ctx* ctx, const amx_ffnn_model* m, amx_ffnn** out) {
         h->act.push_back(m->activation[l]);
         // hidden activations are stored with a row stride of Npad(l-1) >= Kpad(l)
         h->Kpad.push_back(pad_to(m->in_dim[l], kmult));
-        h->Npad.push_back(pad_to(m->out_dim[l], amx::BN));
+        h->Npad.push_back(pad_to(m->out_dim[l], amx::PAD_NT));
         if (l + 1 < m->n_layers)
             h->max_hidden_pad = std::max(h->max_hidden_pad, h->Npad[l]);
         long fl = (long)m->in_dim[l] * m->out_dim[l];
@@ -512,6 +729,8 @@ void amx_ffnn_destroy(amx_ffnn* h) {
     hipFree(h->d_in);
     hipFree(h->d_act[0]);
     hipFree(h->d_act[1]);
+    hipFree(h->d_part_min);
+    hipFree(h->d_part_idx);
     delete h;
 }
 
@@ -522,7 +741,10 @@ int amx_ffnn_output_dim(const amx_ffnn* h) {
     return h ? h->out.back() : 0;
 }
 
-int amx_ffnn_score_dev(amx_ffnn* h, const float* feats_dev, int feats_stride, int T, float* scores_dev) {
+extern "C" int amx_stats_accumulate_dev(amx_ctx*, const float*, int, int, uint32_t*, unsigned long long*, double*);
+
+static int ffnn_score_impl(amx_ffnn* h, const float* feats_dev, int feats_stride, int T, float* scores_dev, bool stats,
+                           uint32_t* best_state_dev, unsigned long long* counts_dev, double* score_sum_dev) {
     AMX_REQUIRE(h, AMX_ERR_INVALID, "amx_ffnn_score_dev: NULL handle");
     AMX_REQUIRE(T >= 0, AMX_ERR_INVALID, "amx_ffnn_score_dev: negative frame count");
     if (T == 0)
@@ -534,7 +756,7 @@ int amx_ffnn_score_dev(amx_ffnn* h, const float* feats_dev, int feats_stride, in
     const int L     = h->n_layers;
     for (int t0 = 0; t0 < T; t0 += chunk) {
         const int Tc   = std::min(chunk, T - t0);
-        const int Tpad = pad_to(Tc, amx::BT);
+        const int Tpad = pad_to(Tc, amx::PAD_NT);
         int       r    = ensure_workspace(h, Tpad);
         if (r != AMX_OK)
             return r;
@@ -552,9 +774,39 @@ int amx_ffnn_score_dev(amx_ffnn* h, const float* feats_dev, int feats_stride, in
         }
         const void* cur = h->d_in;
         int         ldx = h->Kpad[0];
+        const bool  fused = stats && h->precision == AMX_PREC_BF16;
+        h->cur_part_min = nullptr;
+        h->cur_part_idx = nullptr;
+        if (fused) {
+            const size_t need = (size_t)(h->Npad[L - 1] / 128) * Tpad;  // >= n-tiles of any configuration
+            if (need > h->part_cap) {
+                hipFree(h->d_part_min);
+                hipFree(h->d_part_idx);
+                h->d_part_min = nullptr;
+                h->d_part_idx = nullptr;
+                h->part_cap   = 0;
+                AMX_HIP(hipMalloc((void**)&h->d_part_min, need * 4));
+                AMX_HIP(hipMalloc((void**)&h->d_part_idx, need * 4));
+                h->part_cap = need;
+            }
+            h->cur_part_min = h->d_part_min;
+            h->cur_part_idx = h->d_part_idx;
+        }
         for (int l = 0; l < L; ++l) {
-            if (l == L - 1)
-                r = launch_layer<true>(h, l, cur, ldx, scores_dev + (size_t)t0 * h->out[l], h->out[l], Tc, Tpad);
+            if (l == L - 1) {
+                float* sc = scores_dev + (size_t)t0 * h->out[l];
+                r         = launch_layer<true>(h, l, cur, ldx, sc, h->out[l], Tc, Tpad);
+                if (r == AMX_OK && fused) {
+                    amx::ScopedKernelTimer timer(h->ctx, "stats");
+                    hipLaunchKernelGGL(amx::best_state_reduce_kernel, dim3((Tc + 255) / 256), dim3(256), 0, h->ctx->stream,
+                                       h->d_part_min, h->d_part_idx, h->cur_ntn, Tpad, Tc, best_state_dev ? best_state_dev + t0 : nullptr,
+                                       counts_dev, score_sum_dev);
+                    AMX_HIP(hipGetLastError());
+                }
+                else if (r == AMX_OK && stats)  // fp32 parity path: separate arg-min pass over the scores
+                    r = amx_stats_accumulate_dev(h->ctx, sc, Tc, h->out[l], best_state_dev ? best_state_dev + t0 : nullptr, counts_dev,
+                                                 score_sum_dev);
+            }
             else {
                 void* dst = h->d_act[l & 1];
                 r         = launch_layer<false>(h, l, cur, ldx, dst, h->Npad[l], Tc, Tpad);
@@ -565,7 +817,19 @@ int amx_ffnn_score_dev(amx_ffnn* h, const float* feats_dev, int feats_stride, in
                 return r;
         }
     }
+    h->cur_part_min = nullptr;
+    h->cur_part_idx = nullptr;
     return AMX_OK;
+}
+
+int amx_ffnn_score_dev(amx_ffnn* h, const float* feats_dev, int feats_stride, int T, float* scores_dev) {
+    return ffnn_score_impl(h, feats_dev, feats_stride, T, scores_dev, false, nullptr, nullptr, nullptr);
+}
+
+int amx_ffnn_score_stats_dev(amx_ffnn* h, const float* feats_dev, int feats_stride, int T, float* scores_dev, uint32_t* best_state_dev,
+                             unsigned long long* state_counts_dev, double* score_sum_dev) {
+    AMX_REQUIRE(state_counts_dev && score_sum_dev, AMX_ERR_INVALID, "amx_ffnn_score_stats_dev: NULL accumulator");
+    return ffnn_score_impl(h, feats_dev, feats_stride, T, scores_dev, true, best_state_dev, state_counts_dev, score_sum_dev);
 }
 
 int amx_ffnn_score(amx_ffnn* h, const float* feats_host, int T, float* scores_host) {

@@ -16,6 +16,8 @@ __global__ __launch_bounds__(256) void argmin_accumulate_kernel(const float* __r
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     double    local_sum = 0.0;
+    uint32_t           run_idx = 0xffffffffu;
+    unsigned long long run_len = 0;
     for (long long t = (long long)blockIdx.x * 4 + wave; t < T; t += (long long)gridDim.x * 4) {
         const float* row  = scores + (size_t)t * M;
         float        best = FLT_MAX;
@@ -41,11 +43,21 @@ __global__ __launch_bounds__(256) void argmin_accumulate_kernel(const float* __r
             if (best_state)
                 best_state[t] = idx;
             if (idx != 0xffffffffu) {
-                atomicAdd(&counts[idx], 1ull);
+                // run-length aggregation: consecutive frames of this wave that pick the same state share one atomic
+                if (idx == run_idx)
+                    ++run_len;
+                else {
+                    if (run_len)
+                        atomicAdd(&counts[run_idx], run_len);
+                    run_idx = idx;
+                    run_len = 1;
+                }
                 local_sum += (double)best;
             }
         }
     }
+    if (lane == 0 && run_len)
+        atomicAdd(&counts[run_idx], run_len);
     if (lane == 0 && local_sum != 0.0)
         atomicAdd(score_sum, local_sum);
 }

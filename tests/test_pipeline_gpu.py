@@ -92,3 +92,31 @@ def test_chain_audio_to_best_state(ctx):
     assert clear.mean() > 0.9
     assert np.array_equal(sc.argmin(1)[clear], osc.argmin(1)[clear])
     assert np.allclose(sc, osc, rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+@pytest.mark.parametrize("T", [1, 300, 1025])
+def test_fused_best_state_statistics(ctx, precision, T):
+    """arg-min fused into the output-layer epilogue == arg-min over the score matrix it wrote (first minimum wins)"""
+    import torch
+
+    import rasr_amd
+    Ws, bs, acts, logp = synth.ffnn([40, 300, 1000], seed=5)
+    Ws[-1][7] = Ws[-1][900]                 # states 7 and 900 tie on every frame
+    bs[-1][7] = bs[-1][900]
+    logp[7] = logp[900]
+    nn = rasr_amd.NnBatchFeatureScorer(ctx, Ws, bs, acts, log_prior=logp, precision=precision)
+    x = torch.from_numpy(np.random.Generator(np.random.PCG64(2)).standard_normal((T, 40)).astype(np.float32)).cuda()
+    sc = torch.empty((T, 1000), dtype=torch.float32, device="cuda")
+    best = torch.full((T,), -1, dtype=torch.int32, device="cuda")
+    counts = torch.zeros(1000, dtype=torch.int64, device="cuda")
+    ssum = torch.zeros(1, dtype=torch.float64, device="cuda")
+    ctx.use_torch_stream()
+    nn.score_stats_dev(x, 40, T, sc, best, counts, ssum)
+    torch.cuda.synchronize()
+    s = sc.cpu().numpy()
+    want = s.argmin(axis=1)
+    assert np.array_equal(best.cpu().numpy(), want)
+    assert 900 not in want
+    assert np.array_equal(counts.cpu().numpy(), np.bincount(want, minlength=1000))
+    assert abs(float(ssum[0]) - s.min(axis=1).astype(np.float64).sum()) < 1e-6 * max(1.0, abs(float(ssum[0])))
