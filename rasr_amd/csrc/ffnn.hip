@@ -540,6 +540,7 @@ int ensure_workspace(amx_ffnn* h, int Tpad) {
 // tile configurations of the bf16 GEMM, selected at run time (AMX_GEMM_CFG overrides for experiments)
 using CfgA = amx::GemmCfg<128, 128, 2, 2, 2>;  //  64 KB LDS, 2 workgroups per CU
 using CfgC = amx::GemmCfg<256, 256, 2, 4, 2>;  // 128 KB LDS, 8 waves, wave tile 128x64
+using CfgE = amx::GemmCfg<256, 256, 2, 2, 2>;  // 128 KB LDS, 4 waves (one per SIMD), wave tile 128x128
 // measured and dropped: 256x128x64 3-stage (753 TF), 256x256 with 64x128 wave tiles (973 TF) vs CfgC (1000 TF), CfgA (870 TF)
 
 template<class C, int ACT, bool LAST, int VAR>
@@ -560,7 +561,10 @@ template<class C, int ACT, bool LAST>
 void launch_bf16(amx_ffnn* h, int l, const void* x, int ldx, void* out, int ldo, int T, int Tpad) {
     // schedule variants 1..7 (register double-buffered fragments, s_setprio around the MFMA cluster, late
     // stage issue) were measured within +-3 % of variant 0 on MI355X and are not instantiated
-    launch_bf16v<C, ACT, LAST, 0>(h, l, x, ldx, out, ldo, T, Tpad);
+    if (h->gemm_var == 1)
+        launch_bf16v<C, ACT, LAST, 1>(h, l, x, ldx, out, ldo, T, Tpad);
+    else
+        launch_bf16v<C, ACT, LAST, 0>(h, l, x, ldx, out, ldo, T, Tpad);
 }
 
 template<int ACT, bool LAST>
@@ -571,6 +575,7 @@ void launch_bf16_cfg(amx_ffnn* h, int l, const void* x, int ldx, void* out, int 
         cfg = ((long)(h->Npad[l] / 256) * (Tpad / 256) >= 2L * h->ctx->n_cu) ? 2 : 0;
     switch (cfg) {
         case 2: launch_bf16<CfgC, ACT, LAST>(h, l, x, ldx, out, ldo, T, Tpad); break;
+        case 4: launch_bf16<CfgE, ACT, LAST>(h, l, x, ldx, out, ldo, T, Tpad); break;
         default: launch_bf16<CfgA, ACT, LAST>(h, l, x, ldx, out, ldo, T, Tpad); break;
     }
 }

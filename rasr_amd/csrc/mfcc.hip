@@ -53,7 +53,7 @@ struct MfccParams {
     const float2*   tw;     // [NC]  e^{+2 pi i k / NC}
     const float2*   stw;    // [NC/2+1] e^{+pi i k / NC}
     int             frame_len, frame_shift, n_filters, n_ceps, n_weights;
-    int             frames_per_tile;
+    int             frames_per_tile, n_tiles;
     float           alpha, fft_scale;
     int             apply_scale, dct_normalize;
 };
@@ -84,56 +84,84 @@ struct FftPlan {
     static constexpr int B2  = (NC / 2 + 63) / 64;  // radix-2 butterflies per lane
 };
 
+constexpr int FT = 16;  // frames per tile = M of the DCT MFMA
+// wavefronts per workgroup: 8, or 4 when the per-wave FFT buffers get large
+__host__ __device__ constexpr int mfcc_waves(int nc) { return nc >= 1024 ? 4 : 8; }
+// FFT work buffer index swizzle (a bijection inside every 16-point block): makes the stride-4 / stride-16 Stockham
+// writes of the first two radix-4 stages bank-conflict free (ds_write_b64, 16-lane groups)
+__host__ __device__ constexpr int zpad(int i) { return i ^ (5 * ((i >> 4) & 3)); }
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+// LDS carve-up shared by the kernel and the host-side size computation (all sizes in floats)
+struct MfccLds {
+    int y, amp, lm, dct, fw, fidx, fft, total;
+    int y_len, amp_ld, lm_ld, dct_ld, kpad;
+    __host__ __device__ MfccLds(int frame_len, int frame_shift, int fft_len, int n_filters, int n_ceps, int n_weights) {
+        auto r4 = [](int v) { return (v + 3) & ~3; };
+        y_len   = (FT - 1) * frame_shift + (fft_len > frame_len ? fft_len : frame_len);  // zero-pad region of the last frame included
+        amp_ld  = fft_len / 2 + 1;                                                       // 2^k + 1: odd, conflict-free across frames
+        kpad    = r4(n_filters);                                                         // K of the DCT, multiple of 4
+        lm_ld   = kpad + 1;
+        dct_ld  = (n_ceps + 15) & ~15;
+        y       = 0;
+        amp     = y + r4(y_len);
+        lm      = amp + r4(FT * amp_ld);
+        dct     = lm + r4(FT * lm_ld);
+        fw      = dct + r4(kpad * dct_ld);
+        fidx    = fw + r4(n_weights);
+        fft     = fidx + r4(3 * n_filters);
+        total   = fft + mfcc_waves(fft_len / 2) * 2 * (zpad(fft_len / 2) + 4);  // per wave: padded NC float2
+    }
+};
+
 template<int NC>
-__global__ __launch_bounds__(256) void mfcc_kernel(MfccParams p) {
+__global__ __launch_bounds__(mfcc_waves(NC) * 64, (NC >= 1024 ? 1 : 4)) void mfcc_kernel(MfccParams p) {
     using P = FftPlan<NC>;
+    constexpr int MW = mfcc_waves(NC), MT = MW * 64;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid  = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
 
-    const MfccTile tile = p.tiles[blockIdx.x];
-    const int      span = (tile.n_frames - 1) * p.frame_shift + p.frame_len;  // samples touched (clipped below)
+    const MfccLds  L(p.frame_len, p.frame_shift, 2 * NC, p.n_filters, p.n_ceps, p.n_weights);
+    float*  s_y   = smem + L.y;     // pre-emphasised samples of the tile, zero beyond the segment
+    float*  s_amp = smem + L.amp;   // [FT][amp_ld] amplitude spectra
+    float*  s_lm  = smem + L.lm;    // [FT][lm_ld]  log10 mel energies (columns >= n_filters are 0)
+    float*  s_dct = smem + L.dct;   // [kpad][dct_ld] DCT matrix, transposed and zero padded
+    float*  s_fw  = smem + L.fw;    // filter weights
+    int*    s_fs  = (int*)(smem + L.fidx);
+    int*    s_fe  = s_fs + p.n_filters;
+    int*    s_fo  = s_fe + p.n_filters;
+    float2* s_z   = (float2*)(smem + L.fft) + wave * (zpad(NC) + 4);  // this wave's FFT work buffer (index via zpad)
 
-    // ---- LDS carve-up
-    const int span_max = (p.frames_per_tile - 1) * p.frame_shift + p.frame_len + 1;
-    float*    s_pcm    = smem;                                   // [span_max] raw samples, [0] = predecessor
-    float*    s_win    = s_pcm + ((span_max + 3) & ~3);          // [frame_len]
-    float*    s_fw     = s_win + ((p.frame_len + 3) & ~3);       // [n_weights]
-    float*    s_dct    = s_fw + ((p.n_weights + 3) & ~3);        // [n_filters * n_ceps] transposed
-    int*      s_fs     = (int*)(s_dct + ((p.n_filters * p.n_ceps + 3) & ~3));
-    int*      s_fe     = s_fs + p.n_filters;
-    int*      s_fo     = s_fe + p.n_filters;
-    float*    s_wave   = (float*)(s_fo + ((p.n_filters + 3) & ~3));
-    const int wave_floats = 2 * NC + ((p.n_filters + 3) & ~3);
-    float2*   s_z      = (float2*)(s_wave + wave * wave_floats);  // [NC] complex work buffer
-    float*    s_amp    = (float*)s_z;                            // [NC+1] amplitudes (aliases s_z)
-    float*    s_lm     = s_wave + wave * wave_floats + 2 * NC;   // [n_filters] log-mel
-
-    // ---- stage the tile: PCM span (coalesced, once) and the small tables
-    {
-        const long long first = (long long)tile.frame0 * p.frame_shift;  // within segment
-        const float*    src   = p.pcm + tile.sample_base;
-        const int       avail = (int)min((long long)span, (long long)tile.n_samples - first);
-        for (int i = tid; i <= avail; i += 256) {
-            // s_pcm[i] = x[first + i - 1]; at the segment start the predecessor is x[0]
-            long long g = first + i - 1;
-            s_pcm[i]    = src[g < 0 ? 0 : g];
-        }
-        for (int i = tid; i < p.frame_len; i += 256)
-            s_win[i] = p.window[i];
-        for (int i = tid; i < p.n_weights; i += 256)
-            s_fw[i] = p.fweights[i];
-        for (int i = tid; i < p.n_filters * p.n_ceps; i += 256)
-            s_dct[i] = p.dct_t[i];
-        for (int i = tid; i < p.n_filters; i += 256) {
-            s_fs[i] = p.fstart[i];
-            s_fe[i] = p.fend[i];
-            s_fo[i] = p.foff[i];
-        }
+    // ---- tables: staged ONCE per workgroup (workgroups are persistent and loop over tiles)
+    for (int i = tid; i < p.n_weights; i += MT)
+        s_fw[i] = p.fweights[i];
+    for (int i = tid; i < p.n_filters; i += MT) {
+        s_fs[i] = p.fstart[i];
+        s_fe[i] = p.fend[i];
+        s_fo[i] = p.foff[i];
     }
+    // DCT^T [kpad][dct_ld], zero padded (p.dct_t is [n_filters][n_ceps])
+    for (int i = tid; i < L.kpad * L.dct_ld; i += MT) {
+        const int n = i / L.dct_ld, c = i - n * L.dct_ld;
+        s_dct[i]    = (n < p.n_filters && c < p.n_ceps) ? p.dct_t[n * p.n_ceps + c] : 0.f;
+    }
+    for (int i = tid; i < FT * L.lm_ld; i += MT)
+        s_lm[i] = 0.f;
 
-    // ---- per-lane twiddles, constant across frames
+    // ---- per-lane constants: window coefficients of this lane's samples and FFT twiddles
+    // complex point c = lane + 64*b + r*(NC/4) holds samples 2c, 2c+1 of the zero-padded frame
+    float wlo[P::B4][4], whi[P::B4][4];
+#pragma unroll
+    for (int b = 0; b < P::B4; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = lane + 64 * b + r * (NC / 4);
+            wlo[b][r]   = (lane + 64 * b < NC / 4 && 2 * c < p.frame_len) ? p.window[2 * c] : 0.f;
+            whi[b][r]   = (lane + 64 * b < NC / 4 && 2 * c + 1 < p.frame_len) ? p.window[2 * c + 1] : 0.f;
+        }
     float2 tw4[P::S4 > 1 ? P::S4 - 1 : 1][P::B4][3];
 #pragma unroll
     for (int s = 1; s < P::S4; ++s) {
@@ -150,46 +178,75 @@ __global__ __launch_bounds__(256) void mfcc_kernel(MfccParams p) {
     }
     float2 tw2[P::B2];
     if (P::R2) {
-        const int Ns = NC / 2;
 #pragma unroll
-        for (int b = 0; b < P::B2; ++b) {
-            const int j = lane + 64 * b;
-            tw2[b]      = p.tw[(j & (Ns - 1)) & (NC - 1)];  // k * NC/(2*Ns) = k
+        for (int b = 0; b < P::B2; ++b)
+            tw2[b] = p.tw[(lane + 64 * b) & (NC / 2 - 1)];
+    }
+    // split twiddles of the bin pairs this lane owns
+    constexpr int NPAIR = NC / 2 - 1;
+    constexpr int PB    = (NPAIR + 63) / 64 > 0 ? (NPAIR + 63) / 64 : 1;
+    float2        stw[PB];
+#pragma unroll
+    for (int b = 0; b < PB; ++b) {
+        const int i = 1 + lane + 64 * b;
+        stw[b]      = p.stw[i <= NPAIR ? i : 0];
+    }
+    const float scale   = p.fft_scale;
+    const bool  doscale = p.apply_scale != 0;
+    const float alpha   = p.alpha;
+    const bool  alpha1  = (alpha == 1.0f);
+
+  for (int tile_id = blockIdx.x; tile_id < p.n_tiles; tile_id += gridDim.x) {
+    const MfccTile tile = p.tiles[tile_id];
+    // ================= phase A: stage the tile's PCM span (read once, coalesced; pre-emphasis on the fly).
+    // Four independent loads per thread are in flight per batch so the HBM latency is paid once per batch.
+    {
+        const long long first = (long long)tile.frame0 * p.frame_shift;  // first sample of the tile in the segment
+        const float*    src   = p.pcm + tile.sample_base;
+        const long long avail = (long long)tile.n_samples - first;       // samples of the segment from `first` on
+        for (int base = 0; base < L.y_len; base += 4 * MT) {
+            float x[4], pv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = base + u * MT + tid;
+                x[u]        = (i < L.y_len && i < avail) ? src[first + i] : 0.f;
+                pv[u]       = 0.f;
+                if (lane == 0 && i < L.y_len && i < avail) {
+                    const long long g = first + i - 1;
+                    pv[u]             = src[g < 0 ? 0 : g];  // segment start: previous_ = x[0]
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = base + u * MT + tid;
+                // predecessor sample: the neighbouring lane's x, except for the first lane of each wave
+                float prev = __shfl_up(x[u], 1, 64);
+                if (lane == 0)
+                    prev = pv[u];
+                if (i < L.y_len) {
+                    float yv;
+                    if (alpha1)
+                        yv = x[u] - prev;  // Signal/Preemphasis.cc:69-75
+                    else {
+                        float prod = alpha * prev;  // :62-67
+                        yv         = x[u] - prod;
+                    }
+                    s_y[i] = (i < avail) ? yv : 0.f;
+                }
+            }
         }
     }
     __syncthreads();
 
-    const float alpha   = p.alpha;
-    const bool  alpha1  = (alpha == 1.0f);
-    const float scale   = p.fft_scale;
-    const bool  doscale = p.apply_scale != 0;
-
-    for (int f = wave; f < tile.n_frames; f += 4) {
-        const int       o     = f * p.frame_shift;  // offset of the frame in the tile span
-        const long long start = ((long long)tile.frame0 + f) * p.frame_shift;
-        const int       len   = (int)min((long long)p.frame_len, (long long)tile.n_samples - start);
-
-        // windowed, pre-emphasised sample i of this frame (0 beyond the frame)
-        auto sample = [&](int i) -> float {
-            if (i >= len)
-                return 0.f;
-            float x    = s_pcm[o + i + 1];
-            float prev = s_pcm[o + i];
-            float y;
-            if (alpha1)
-                y = x - prev;  // Signal/Preemphasis.cc:69-75
-            else {
-                float prod = alpha * prev;  // :62-67, f32 product then f32 difference
-                y          = x - prod;
-            }
-            return s_win[i] * y;  // WindowFunction::work
-        };
-
-        // ================= complex FFT of NC points, natural order in/out (Stockham)
-        wave_sync();  // previous frame's readers of s_z / s_amp / s_lm are done
-        if (P::S4 >= 1) {
-            // first radix-4 stage (Ns = 1, twiddles are 1) is fed straight from the PCM tile
-            float2 y[P::B4][4];
+    // ================= phase B: one frame per wavefront: FFT -> split -> |X| into s_amp[f][*]
+    for (int f = wave; f < FT; f += MW) {
+        if (f >= tile.n_frames)
+            break;  // wave-uniform
+        const float* yf = s_y + f * p.frame_shift;
+        wave_sync();  // the previous frame's readers of s_z are done
+        // first radix-4 stage (Ns = 1, unit twiddles) straight from the pre-emphasised tile
+        {
+            float2 y4[P::B4][4];
 #pragma unroll
             for (int b = 0; b < P::B4; ++b) {
                 const int j = lane + 64 * b;
@@ -198,16 +255,16 @@ __global__ __launch_bounds__(256) void mfcc_kernel(MfccParams p) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int c = j + r * (NC / 4);
-                        x[r]        = make_float2(sample(2 * c), sample(2 * c + 1));
+                        x[r]        = make_float2(wlo[b][r] * yf[2 * c], whi[b][r] * yf[2 * c + 1]);  // WindowFunction::work
                     }
-                    float2 a = make_float2(x[0].x + x[2].x, x[0].y + x[2].y);
-                    float2 bb = make_float2(x[0].x - x[2].x, x[0].y - x[2].y);
-                    float2 c = make_float2(x[1].x + x[3].x, x[1].y + x[3].y);
-                    float2 d = make_float2(x[1].x - x[3].x, x[1].y - x[3].y);
-                    y[b][0]  = make_float2(a.x + c.x, a.y + c.y);
-                    y[b][1]  = make_float2(bb.x - d.y, bb.y + d.x);  // (x0-x2) + i(x1-x3)
-                    y[b][2]  = make_float2(a.x - c.x, a.y - c.y);
-                    y[b][3]  = make_float2(bb.x + d.y, bb.y - d.x);  // (x0-x2) - i(x1-x3)
+                    const float2 a  = make_float2(x[0].x + x[2].x, x[0].y + x[2].y);
+                    const float2 bb = make_float2(x[0].x - x[2].x, x[0].y - x[2].y);
+                    const float2 c  = make_float2(x[1].x + x[3].x, x[1].y + x[3].y);
+                    const float2 d  = make_float2(x[1].x - x[3].x, x[1].y - x[3].y);
+                    y4[b][0]        = make_float2(a.x + c.x, a.y + c.y);
+                    y4[b][1]        = make_float2(bb.x - d.y, bb.y + d.x);  // (x0-x2) + i(x1-x3)
+                    y4[b][2]        = make_float2(a.x - c.x, a.y - c.y);
+                    y4[b][3]        = make_float2(bb.x + d.y, bb.y - d.x);  // (x0-x2) - i(x1-x3)
                 }
             }
 #pragma unroll
@@ -216,36 +273,31 @@ __global__ __launch_bounds__(256) void mfcc_kernel(MfccParams p) {
                 if (j < NC / 4) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
-                        s_z[4 * j + q] = y[b][q];
+                        s_z[zpad(4 * j + q)] = y4[b][q];
                 }
             }
-        }
-        else {
-            // NC == 2: no radix-4 stage; load the points
-            for (int j = lane; j < NC; j += 64)
-                s_z[j] = make_float2(sample(2 * j), sample(2 * j + 1));
         }
 #pragma unroll
         for (int s = 1; s < P::S4; ++s) {
             const int Ns = 1 << (2 * s);
             wave_sync();
-            float2 y[P::B4][4];
+            float2 y4[P::B4][4];
 #pragma unroll
             for (int b = 0; b < P::B4; ++b) {
                 const int j = lane + 64 * b;
                 if (j < NC / 4) {
-                    float2 x0 = s_z[j];
-                    float2 x1 = cmul(s_z[j + NC / 4], tw4[s - 1][b][0]);
-                    float2 x2 = cmul(s_z[j + 2 * (NC / 4)], tw4[s - 1][b][1]);
-                    float2 x3 = cmul(s_z[j + 3 * (NC / 4)], tw4[s - 1][b][2]);
-                    float2 a  = make_float2(x0.x + x2.x, x0.y + x2.y);
-                    float2 bb = make_float2(x0.x - x2.x, x0.y - x2.y);
-                    float2 c  = make_float2(x1.x + x3.x, x1.y + x3.y);
-                    float2 d  = make_float2(x1.x - x3.x, x1.y - x3.y);
-                    y[b][0]   = make_float2(a.x + c.x, a.y + c.y);
-                    y[b][1]   = make_float2(bb.x - d.y, bb.y + d.x);
-                    y[b][2]   = make_float2(a.x - c.x, a.y - c.y);
-                    y[b][3]   = make_float2(bb.x + d.y, bb.y - d.x);
+                    const float2 x0 = s_z[zpad(j)];
+                    const float2 x1 = cmul(s_z[zpad(j + NC / 4)], tw4[s - 1][b][0]);
+                    const float2 x2 = cmul(s_z[zpad(j + 2 * (NC / 4))], tw4[s - 1][b][1]);
+                    const float2 x3 = cmul(s_z[zpad(j + 3 * (NC / 4))], tw4[s - 1][b][2]);
+                    const float2 a  = make_float2(x0.x + x2.x, x0.y + x2.y);
+                    const float2 bb = make_float2(x0.x - x2.x, x0.y - x2.y);
+                    const float2 c  = make_float2(x1.x + x3.x, x1.y + x3.y);
+                    const float2 d  = make_float2(x1.x - x3.x, x1.y - x3.y);
+                    y4[b][0]        = make_float2(a.x + c.x, a.y + c.y);
+                    y4[b][1]        = make_float2(bb.x - d.y, bb.y + d.x);
+                    y4[b][2]        = make_float2(a.x - c.x, a.y - c.y);
+                    y4[b][3]        = make_float2(bb.x + d.y, bb.y - d.x);
                 }
             }
             wave_sync();
@@ -257,22 +309,22 @@ __global__ __launch_bounds__(256) void mfcc_kernel(MfccParams p) {
                     const int j0 = ((j - k) << 2) + k;
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
-                        s_z[j0 + q * Ns] = y[b][q];
+                        s_z[zpad(j0 + q * Ns)] = y4[b][q];
                 }
             }
         }
         if (P::R2) {
-            const int Ns = NC / 2;
+            constexpr int Ns = NC / 2;
             wave_sync();
-            float2 y[P::B2][2];
+            float2 y2[P::B2][2];
 #pragma unroll
             for (int b = 0; b < P::B2; ++b) {
                 const int j = lane + 64 * b;
                 if (j < NC / 2) {
-                    float2 x0 = s_z[j];
-                    float2 x1 = cmul(s_z[j + NC / 2], tw2[b]);
-                    y[b][0]   = make_float2(x0.x + x1.x, x0.y + x1.y);
-                    y[b][1]   = make_float2(x0.x - x1.x, x0.y - x1.y);
+                    const float2 x0 = s_z[zpad(j)];
+                    const float2 x1 = cmul(s_z[zpad(j + NC / 2)], tw2[b]);
+                    y2[b][0]        = make_float2(x0.x + x1.x, x0.y + x1.y);
+                    y2[b][1]        = make_float2(x0.x - x1.x, x0.y - x1.y);
                 }
             }
             wave_sync();
@@ -280,26 +332,22 @@ __global__ __launch_bounds__(256) void mfcc_kernel(MfccParams p) {
             for (int b = 0; b < P::B2; ++b) {
                 const int j = lane + 64 * b;
                 if (j < NC / 2) {
-                    // Ns == NC/2: j0 = j, outputs at j and j + Ns
-                    s_z[j]      = y[b][0];
-                    s_z[j + Ns] = y[b][1];
+                    s_z[zpad(j)]      = y2[b][0];
+                    s_z[zpad(j + Ns)] = y2[b][1];
                 }
             }
         }
         wave_sync();
 
-        // ================= real split (Math/FastFourierTransform.cc:113-133), 1/fs, amplitude
-        // pairs (i, NC-i), i = 1..NC/2-1; bins 0, NC/2 and NC (Nyquist) handled by lane 0
-        constexpr int NPAIR = NC / 2 - 1;
-        constexpr int PB    = (NPAIR + 63) / 64 > 0 ? (NPAIR + 63) / 64 : 1;
-        float         amp_lo[PB], amp_hi[PB];
+        // real split (Math/FastFourierTransform.cc:113-133), 1/fs, amplitude; bin pairs (i, NC-i)
+        float* amp = s_amp + f * L.amp_ld;
 #pragma unroll
         for (int b = 0; b < PB; ++b) {
             const int i = 1 + lane + 64 * b;
             if (i <= NPAIR) {
-                const float2 za  = s_z[i];
-                const float2 zb  = s_z[NC - i];
-                const float2 w   = p.stw[i];
+                const float2 za  = s_z[zpad(i)];
+                const float2 zb  = s_z[zpad(NC - i)];
+                const float2 w   = stw[b];
                 const float  h1r = 0.5f * (za.x + zb.x);
                 const float  h1i = 0.5f * (za.y - zb.y);
                 const float  h2r = 0.5f * (za.y + zb.y);
@@ -314,72 +362,73 @@ __global__ __launch_bounds__(256) void mfcc_kernel(MfccParams p) {
                     br *= scale;
                     bi *= scale;
                 }
-                amp_lo[b] = sqrtf(fmaf(ar, ar, ai * ai));
-                amp_hi[b] = sqrtf(fmaf(br, br, bi * bi));
+                amp[i]      = __builtin_amdgcn_sqrtf(fmaf(ar, ar, ai * ai));
+                amp[NC - i] = __builtin_amdgcn_sqrtf(fmaf(br, br, bi * bi));
             }
         }
-        float amp0 = 0, ampn = 0, ampm = 0;
         if (lane == 0) {
-            const float2 z0 = s_z[0];
+            const float2 z0 = s_z[zpad(0)];
             float        dc = z0.x + z0.y, ny = z0.x - z0.y;
+            float2       zm = s_z[zpad(NC / 2)];  // untouched by the reference's split loop
             if (doscale) {
                 dc *= scale;
                 ny *= scale;
+                zm.x *= scale;
+                zm.y *= scale;
             }
-            amp0 = fabsf(dc);
-            ampn = fabsf(ny);
-            if (NC >= 2) {
-                float2 zm = s_z[NC / 2];  // untouched by the reference's split loop
-                if (doscale) {
-                    zm.x *= scale;
-                    zm.y *= scale;
-                }
-                ampm = sqrtf(fmaf(zm.x, zm.x, zm.y * zm.y));
-            }
-        }
-        wave_sync();
-#pragma unroll
-        for (int b = 0; b < PB; ++b) {
-            const int i = 1 + lane + 64 * b;
-            if (i <= NPAIR) {
-                s_amp[i]      = amp_lo[b];
-                s_amp[NC - i] = amp_hi[b];
-            }
-        }
-        if (lane == 0) {
-            s_amp[0]      = amp0;
-            s_amp[NC]     = ampn;
-            s_amp[NC / 2] = ampm;
-        }
-        wave_sync();
-
-        // ================= mel filter bank (Signal/Filterbank.cc:65-71): lane = filter,
-        // f32 accumulate in ascending bin order; then log10 (Flow/SimpleFunction.hh:40-49)
-        for (int flt = lane; flt < p.n_filters; flt += 64) {
-            const int    b0  = s_fs[flt], b1 = s_fe[flt];
-            const float* w   = s_fw + s_fo[flt] - b0;
-            float        acc = 0.f;
-            for (int b = b0; b < b1; ++b) {
-                float prod = s_amp[b] * w[b];
-                acc        = acc + prod;
-            }
-            s_lm[flt] = log10f(acc);
-        }
-        wave_sync();
-
-        // ================= DCT-II (Signal/CosineTransform.cc:76-83): lane = coefficient
-        float* out = p.ceps + (tile.out_frame + f) * (long long)p.n_ceps;
-        for (int k = lane; k < p.n_ceps; k += 64) {
-            float acc = 0.f;
-            for (int n = 0; n < p.n_filters; ++n) {
-                float prod = s_dct[n * p.n_ceps + k] * s_lm[n];
-                acc        = acc + prod;
-            }
-            if (p.dct_normalize)
-                acc = acc / (float)p.n_filters;
-            out[k] = acc;
+            amp[0]      = fabsf(dc);
+            amp[NC]     = fabsf(ny);
+            amp[NC / 2] = __builtin_amdgcn_sqrtf(fmaf(zm.x, zm.x, zm.y * zm.y));
         }
     }
+    __syncthreads();
+
+    // ================= phase C: mel filter bank + log10 for the whole tile (Signal/Filterbank.cc:65-71,
+    // Flow/SimpleFunction.hh:40-49).  item = filter * FT + frame: the 64 lanes of a wave work on 4
+    // neighbouring filters (similar supports, broadcast weights) x 16 frames; f32 sum in ascending bin order.
+    for (int item = tid; item < p.n_filters * FT; item += MT) {
+        const int flt = item / FT, f = item - flt * FT;
+        const int b0 = s_fs[flt], b1 = s_fe[flt];
+        const float* w   = s_fw + s_fo[flt] - b0;
+        const float* amp = s_amp + f * L.amp_ld;
+        float        acc = 0.f;
+        for (int b = b0; b < b1; ++b) {
+            float prod = amp[b] * w[b];
+            acc        = acc + prod;
+        }
+        if (f < tile.n_frames)
+            s_lm[f * L.lm_ld + flt] = __log10f(acc);  // v_log_f32 * log10(2): ~1 ulp of log2
+    }
+    __syncthreads();
+
+    // ================= phase D: DCT-II as a [FT x kpad] x [kpad x n_ceps] product on the f32 matrix
+    // cores (Signal/CosineTransform.cc:76-83).  v_mfma_f32_16x16x4_f32 is an exact f32 fma chain in
+    // ascending n, i.e. the reference's left-to-right accumulation with fused instead of separate rounding.
+    {
+        const int n_tiles = L.dct_ld / 16;
+        const int arow = lane & 15, akq = lane >> 4;
+        for (int nt = wave; nt < n_tiles; nt += MW) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int kk = 0; kk < L.kpad / 4; ++kk) {
+                const float a = s_lm[arow * L.lm_ld + 4 * kk + akq];
+                const float b = s_dct[(4 * kk + akq) * L.dct_ld + nt * 16 + arow];
+                acc           = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+            }
+            const int cep = nt * 16 + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int f = (lane >> 4) * 4 + r;
+                if (f < tile.n_frames && cep < p.n_ceps) {
+                    float v = acc[r];
+                    if (p.dct_normalize)
+                        v = v / (float)p.n_filters;
+                    p.ceps[(tile.out_frame + f) * (long long)p.n_ceps + cep] = v;
+                }
+            }
+        }
+    }
+    __syncthreads();  // s_lm / s_amp / s_y are rewritten by the next tile
+  }
 }
 
 // out[t] = concat(x[clamp(t-left)], ..., x[clamp(t+right)]) per segment
@@ -419,7 +468,7 @@ __global__ __launch_bounds__(256) void context_window_kernel(const float* __rest
 struct amx_mfcc {
     amx_ctx*        ctx = nullptr;
     amx::MfccTables tab;
-    int             frames_per_tile = 32;
+    int             frames_per_tile = 16;
     // device copies of the tables
     float * d_window = nullptr, *d_fw = nullptr, *d_dct_t = nullptr;
     int *   d_fs = nullptr, *d_fe = nullptr, *d_fo = nullptr;
@@ -446,13 +495,9 @@ int upload(T** dst, const T* src, size_t n) {
     return AMX_OK;
 }
 
-size_t mfcc_lds_bytes(const amx::MfccTables& t, int ft) {
-    auto   r4       = [](size_t v) { return (v + 3) & ~(size_t)3; };
-    size_t span_max = (size_t)(ft - 1) * t.frame_shift + t.frame_len + 1;
-    size_t fl       = r4(span_max) + r4(t.frame_len) + r4(t.filter_weights.size()) + r4((size_t)t.n_filters * t.n_ceps);
-    fl += 2 * (size_t)t.n_filters + r4(t.n_filters);  // ints
-    fl += 4 * ((size_t)t.fft_len + r4(t.n_filters));  // per wave: 2*NC floats + log-mel
-    return fl * 4;
+size_t mfcc_lds_bytes(const amx::MfccTables& t) {
+    amx::MfccLds L(t.frame_len, t.frame_shift, t.fft_len, t.n_filters, t.n_ceps, (int)t.filter_weights.size());
+    return (size_t)L.total * 4;
 }
 
 template<int NC>
@@ -460,10 +505,13 @@ int launch_mfcc(amx_mfcc* h, const amx::MfccParams& p, int n_tiles) {
     if (n_tiles <= 0)
         return AMX_OK;
     auto kern = amx::mfcc_kernel<NC>;
-    if (h->lds_bytes > 64 * 1024)
+    if (h->lds_bytes > 48 * 1024)
         AMX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
+    // persistent workgroups: as many as are co-resident (LDS bound), each loops over tiles
+    int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / std::max<size_t>(h->lds_bytes, 1)));
+    int grid   = std::min(n_tiles, per_cu * std::max(h->ctx->n_cu, 1));
     amx::ScopedKernelTimer timer(h->ctx, "mfcc");
-    hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(256), h->lds_bytes, h->ctx->stream, p);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(amx::mfcc_waves(NC) * 64), h->lds_bytes, h->ctx->stream, p);
     AMX_HIP(hipGetLastError());
     return AMX_OK;
 }
@@ -501,8 +549,8 @@ int amx_mfcc_create(amx_ctx* ctx, const amx_mfcc_cfg* cfg, amx_mfcc** out) {
         return r;
     }
     const amx::MfccTables& t = h->tab;
-    if (t.fft_len < 8 || t.fft_len > 4096) {
-        amx::set_error("amx_mfcc_create: FFT length %d not supported by the gfx950 kernel (8..4096)", t.fft_len);
+    if (t.fft_len < 8 || t.fft_len > 2048) {
+        amx::set_error("amx_mfcc_create: FFT length %d not supported by the gfx950 kernel (8..2048)", t.fft_len);
         delete h;
         return AMX_ERR_UNSUPPORTED;
     }
@@ -511,11 +559,8 @@ int amx_mfcc_create(amx_ctx* ctx, const amx_mfcc_cfg* cfg, amx_mfcc** out) {
         return AMX_OK;
     }
     AMX_HIP(hipSetDevice(ctx->device));
-    // frames per tile: as many as keep the workgroup's LDS under ~40 KB (4 workgroups per CU)
-    h->frames_per_tile = 32;
-    while (h->frames_per_tile > 4 && mfcc_lds_bytes(t, h->frames_per_tile) > 40 * 1024)
-        h->frames_per_tile /= 2;
-    h->lds_bytes = mfcc_lds_bytes(t, h->frames_per_tile);
+    h->frames_per_tile = amx::FT;
+    h->lds_bytes       = mfcc_lds_bytes(t);
     if (h->lds_bytes > 160 * 1024) {
         amx::set_error("amx_mfcc_create: configuration needs %zu bytes of LDS per workgroup (> 160 KiB)", h->lds_bytes);
         delete h;
@@ -690,20 +735,20 @@ int amx_mfcc_run_plan_dev(amx_mfcc* h, const amx_mfcc_plan* p, const float* pcm_
     k.frames_per_tile = h->frames_per_tile;
     k.alpha           = (float)t.cfg.preemph_alpha;
     k.fft_scale       = t.fft_scale;
+    const int n_tiles_total = (int)p->tiles.size();
+    k.n_tiles               = n_tiles_total;
     k.apply_scale     = (t.cfg.apply_scale && t.cfg.sample_rate != 1) ? 1 : 0;
     k.dct_normalize   = t.cfg.dct_normalize;
-    const int n_tiles = (int)p->tiles.size();
     switch (t.fft_len / 2) {
-        case 4: return launch_mfcc<4>(h, k, n_tiles);
-        case 8: return launch_mfcc<8>(h, k, n_tiles);
-        case 16: return launch_mfcc<16>(h, k, n_tiles);
-        case 32: return launch_mfcc<32>(h, k, n_tiles);
-        case 64: return launch_mfcc<64>(h, k, n_tiles);
-        case 128: return launch_mfcc<128>(h, k, n_tiles);
-        case 256: return launch_mfcc<256>(h, k, n_tiles);
-        case 512: return launch_mfcc<512>(h, k, n_tiles);
-        case 1024: return launch_mfcc<1024>(h, k, n_tiles);
-        case 2048: return launch_mfcc<2048>(h, k, n_tiles);
+        case 4: return launch_mfcc<4>(h, k, n_tiles_total);
+        case 8: return launch_mfcc<8>(h, k, n_tiles_total);
+        case 16: return launch_mfcc<16>(h, k, n_tiles_total);
+        case 32: return launch_mfcc<32>(h, k, n_tiles_total);
+        case 64: return launch_mfcc<64>(h, k, n_tiles_total);
+        case 128: return launch_mfcc<128>(h, k, n_tiles_total);
+        case 256: return launch_mfcc<256>(h, k, n_tiles_total);
+        case 512: return launch_mfcc<512>(h, k, n_tiles_total);
+        case 1024: return launch_mfcc<1024>(h, k, n_tiles_total);
         default:
             amx::set_error("amx_mfcc_run_plan_dev: no kernel for FFT length %d", t.fft_len);
             return AMX_ERR_UNSUPPORTED;
