@@ -213,9 +213,16 @@ class GmmOnly:
         # exact-order distance: sub, mul, mul, add per (frame, density, dim) = 4 f32 VALU ops; the f32 vector peak is
         # numerically the f32 MFMA peak (157.3 TFLOP/s counts an FMA as 2), so unfused ops can reach half of it.
         if self.tied:
+            # combine stage: one f64 add + one f64 compare/select per (frame, mixture, density) -- priced against the
+            # f64 vector peak (78.6 TFLOP/s); the distances (gmm_dist) are 0.5 MFLOP/frame and negligible
             ms, n = self.ctx.profile_get("gmm_combine")
-            ops = 2.0 * self.nk * self.T  # (f64 add, compare/select) per (frame, mixture, density)
-            name = "gmm_combine_kernel<MaxState>"
+            if n == 0:
+                return None
+            ops = 2.0 * self.nk * self.T
+            ach = ops / (ms * 1e-3) / 1e12
+            return dict(bound="mfma", note="f64 VALU tropical (min,+) contraction priced against the f64 vector peak; not MFMA-able",
+                        kernel="gmm_combine_uniform_kernel<MaxState,8>", achieved=round(ach, 3), peak=78.6, unit="TFLOP/s",
+                        frac=round(ach / 78.6, 4), traffic=None, avg_launch_ms=round(ms, 4), launches=n, flops_per_launch=ops)
         else:
             ms, n = self.ctx.profile_get("gmm")
             ops = 4.0 * self.nk * 40 * self.T

@@ -106,7 +106,18 @@ struct MaxState {
             idx    = k;
         }
     }
+    // distance already widened to f64 (uniform-list path keeps no f32 copy of the running best)
+    __device__ __forceinline__ void add_d(double c64, double dist64, uint32_t k) {
+        const double s  = c64 + dist64;
+        const float  sf = (float)s;
+        const bool   c  = best_d > s;
+        best            = c ? sf : best;
+        idx             = c ? k : idx;
+        best_d          = (double)best;
+    }
+    __device__ __forceinline__ float result_d() const { return 0.5f * best; }
     __device__ __forceinline__ float result() const { return 0.5f * best; }
+    static constexpr bool kF64 = true;
 };
 
 struct SumState {
@@ -125,6 +136,9 @@ struct SumState {
             sum = sum + expf(best - s);
     }
     __device__ __forceinline__ float result() const { return best - logf(sum); }
+    __device__ __forceinline__ void  add_d(double, double, uint32_t) {}
+    __device__ __forceinline__ float result_d() const { return result(); }
+    static constexpr bool kF64 = false;
 };
 
 // DIM > 0: features in registers; DIM == 0: runtime dimension, features in LDS
@@ -208,7 +222,7 @@ struct GmmDistDims {
 };
 
 template<int DIM>
-__global__ __launch_bounds__(256) void gmm_dist_kernel(const float* __restrict__ g_feats, float* __restrict__ g_dist,
+__global__ __launch_bounds__(256) void gmm_dist_kernel(const float* __restrict__ g_feats, float* __restrict__ g_dist, double* __restrict__ g_dist64,
                                                       const uint32_t* __restrict__ g_d_mean, const uint32_t* __restrict__ g_d_cov,
                                                       const float* __restrict__ g_means, const float* __restrict__ g_isr,
                                                       GmmDistDims dims) {
@@ -244,8 +258,11 @@ __global__ __launch_bounds__(256) void gmm_dist_kernel(const float* __restrict__
             dist = gmm_distance<(DIM > 0 ? DIM : 1)>(x, mu, is);
         else
             dist = gmm_distance_rt(xs, p.dim, mu, is);
-        if (t < p.Tpad)
+        if (t < p.Tpad) {
             p.dist[(size_t)d * p.Tpad + t] = dist;  // coalesced along t
+            if (g_dist64)
+                g_dist64[(size_t)d * p.Tpad + t] = (double)dist;
+        }
     }
 }
 
@@ -259,6 +276,55 @@ struct GmmCombineParams {
     const float* __restrict__ k_c32;
     int T, Tpad, n_mix, mix_tile;
 };
+
+// ---- uniform-list tied models: every mixture weights the SAME density list (tied-mixture / semi-continuous
+// systems).  lane = mixture, FR frames per pass live in registers; the distances of the current density are
+// wave-uniform and arrive through the scalar cache, the weights are read once per pass, transposed [k][mixture]
+// (coalesced).  Scores are written coalesced along the mixture index.
+struct GmmUniformDims {
+    int T, Tpad, n_mix, mix_pad, K, t0;
+};
+
+template<class State, int FR>
+__global__ __launch_bounds__(256) void gmm_combine_uniform_kernel(const float* __restrict__ g_dist, const double* __restrict__ g_dist64,
+                                                                 float* __restrict__ g_scores, uint32_t* __restrict__ g_best,
+                                                                 const float* __restrict__ g_m2lw_t, const uint32_t* __restrict__ g_k_dens,
+                                                                 const double* __restrict__ g_ln64, const float* __restrict__ g_ln32,
+                                                                 GmmUniformDims dims) {
+    const int  m    = blockIdx.x * 256 + threadIdx.x;
+    const int  t0   = blockIdx.y * FR;  // within the chunk
+    const bool live = m < dims.n_mix;
+    const int  mm   = live ? m : dims.n_mix - 1;
+    State      st[FR];
+    for (int k = 0; k < dims.K; ++k) {
+        const float    w   = g_m2lw_t[(size_t)k * dims.mix_pad + mm];
+        const uint32_t d   = g_k_dens[k];  // wave-uniform
+        const size_t   row = (size_t)d * dims.Tpad + t0;
+        if (State::kF64) {
+            const double c64 = (double)w + g_ln64[k];
+#pragma unroll
+            for (int f = 0; f < FR; ++f)
+                st[f].add_d(c64, g_dist64[row + f], (uint32_t)k);
+        }
+        else {
+            const float c32 = w + g_ln32[k];
+#pragma unroll
+            for (int f = 0; f < FR; ++f)
+                st[f].add(0.0, c32, g_dist[row + f], (uint32_t)k);
+        }
+    }
+    if (live) {
+#pragma unroll
+        for (int f = 0; f < FR; ++f) {
+            const int t = t0 + f;
+            if (t < dims.T) {
+                g_scores[(size_t)t * dims.n_mix + m] = State::kF64 ? st[f].result_d() : st[f].result();
+                if (g_best)
+                    g_best[(size_t)t * dims.n_mix + m] = st[f].idx;
+            }
+        }
+    }
+}
 
 struct GmmCombineDims {
     int T, Tpad, n_mix, mix_tile;
@@ -313,6 +379,12 @@ struct amx_gmm {
     double*   d_k_c64 = nullptr;
     float *   d_k_c32 = nullptr, *d_means = nullptr, *d_isr = nullptr;
     bool      tied    = false;  // use the two-stage path
+    bool      uniform = false;  // tied AND every mixture lists the same densities: lane = mixture combine
+    int       K = 0, mix_pad = 0;
+    float*    d_m2lw_t = nullptr;  // [K][mix_pad]
+    double *  d_ln64 = nullptr, *d_dist64 = nullptr;
+    float*    d_ln32 = nullptr;
+    size_t    dist64_cap = 0;
     float*    d_dist  = nullptr;
     size_t    dist_floats = 0;
 };
@@ -357,14 +429,14 @@ int launch_direct(amx_gmm* h, const amx::GmmParams& p, dim3 grid) {
     return AMX_OK;
 }
 
-int launch_dist(amx_gmm* h, const amx::GmmDistParams& p, dim3 grid) {
+int launch_dist(amx_gmm* h, const amx::GmmDistParams& p, dim3 grid, double* dist64) {
     hipStream_t      st  = h->ctx->stream;
     size_t           lds = 0;
     amx::GmmDistDims dims{p.T, p.Tpad, p.dim, p.n_dens, p.dens_tile};
     switch (h->dim) {
 #define AMX_GMM_CASE(D)                                                                      \
     case D:                                                                                  \
-        hipLaunchKernelGGL((amx::gmm_dist_kernel<D>), grid, dim3(256), 0, st, p.feats, p.dist, p.d_mean, p.d_cov, p.means, \
+        hipLaunchKernelGGL((amx::gmm_dist_kernel<D>), grid, dim3(256), 0, st, p.feats, p.dist, dist64, p.d_mean, p.d_cov, p.means, \
                            p.isr, dims);                                                     \
         break;
         AMX_GMM_CASE(16)
@@ -379,7 +451,7 @@ int launch_dist(amx_gmm* h, const amx::GmmDistParams& p, dim3 grid) {
 #undef AMX_GMM_CASE
         default:
             lds = (size_t)4 * 64 * h->dim * sizeof(float);
-            hipLaunchKernelGGL((amx::gmm_dist_kernel<0>), grid, dim3(256), lds, st, p.feats, p.dist, p.d_mean, p.d_cov, p.means,
+            hipLaunchKernelGGL((amx::gmm_dist_kernel<0>), grid, dim3(256), lds, st, p.feats, p.dist, dist64, p.d_mean, p.d_cov, p.means,
                                p.isr, dims);
     }
     AMX_HIP(hipGetLastError());
@@ -455,6 +527,15 @@ int amx_gmm_create(amx_ctx* ctx, const amx_gmm_model* m, amx_gmm** out) {
     }
     // tied model: each density is referenced by several mixtures -> compute distances once
     h->tied = nk >= (size_t)4 * (size_t)m->n_dens;
+    if (h->tied) {
+        const uint32_t K = m->mix_offsets[1] - m->mix_offsets[0];
+        bool           u = K > 0 && nk == (size_t)K * (size_t)m->n_mix;
+        for (int i = 0; u && i < m->n_mix; ++i)
+            u = (m->mix_offsets[i + 1] - m->mix_offsets[i] == K) &&
+                (i == 0 || memcmp(m->dens_index + m->mix_offsets[i], m->dens_index, (size_t)K * 4) == 0);
+        h->uniform = u;
+        h->K       = (int)K;
+    }
 
     int r = AMX_OK;
     if (!ctx) {
@@ -472,6 +553,24 @@ int amx_gmm_create(amx_ctx* ctx, const amx_gmm_model* m, amx_gmm** out) {
         (r = gupload(&h->d_isr, h->isr.data(), h->isr.size())) != AMX_OK) {
         amx_gmm_destroy(h);
         return r;
+    }
+    if (h->uniform) {
+        h->mix_pad = (h->n_mix + 63) & ~63;
+        std::vector<float>  wt((size_t)h->K * h->mix_pad, 0.f);
+        std::vector<double> ln64(h->K);
+        std::vector<float>  ln32(h->K);
+        for (int i = 0; i < h->n_mix; ++i)
+            for (int k = 0; k < h->K; ++k)
+                wt[(size_t)k * h->mix_pad + i] = h->m2lw[(size_t)i * h->K + k];
+        for (int k = 0; k < h->K; ++k) {
+            ln32[k] = h->lognorm[k_cov[k]];
+            ln64[k] = (double)ln32[k];
+        }
+        if ((r = gupload(&h->d_m2lw_t, wt.data(), wt.size())) != AMX_OK || (r = gupload(&h->d_ln64, ln64.data(), ln64.size())) != AMX_OK ||
+            (r = gupload(&h->d_ln32, ln32.data(), ln32.size())) != AMX_OK) {
+            amx_gmm_destroy(h);
+            return r;
+        }
     }
     *out = h;
     return AMX_OK;
@@ -496,6 +595,10 @@ void amx_gmm_destroy(amx_gmm* h) {
     hipFree(h->d_means);
     hipFree(h->d_isr);
     hipFree(h->d_dist);
+    hipFree(h->d_dist64);
+    hipFree(h->d_m2lw_t);
+    hipFree(h->d_ln64);
+    hipFree(h->d_ln32);
     delete h;
 }
 
@@ -576,12 +679,48 @@ int amx_gmm_score_dev(amx_gmm* h, int mode, const float* feats_dev, int T, float
         dp.dim       = h->dim;
         dp.n_dens    = h->n_dens;
         dp.dens_tile = 16;
-        const int fb = amx::ceil_div(Tc, 256);
+        const int  fb      = amx::ceil_div(Tc, 256);
+        const bool use_uni = h->uniform;
+        const bool need64  = use_uni && mode == AMX_GMM_MAX;
+        if (need64 && need > h->dist64_cap) {
+            hipFree(h->d_dist64);
+            h->d_dist64   = nullptr;
+            h->dist64_cap = 0;
+            AMX_HIP(hipMalloc((void**)&h->d_dist64, need * sizeof(double)));
+            h->dist64_cap = need;
+        }
         {
             amx::ScopedKernelTimer timer(h->ctx, "gmm_dist");
-            int r = launch_dist(h, dp, dim3(amx::ceil_div(h->n_dens, dp.dens_tile), fb));
+            int r = launch_dist(h, dp, dim3(amx::ceil_div(h->n_dens, dp.dens_tile), fb), need64 ? h->d_dist64 : nullptr);
             if (r != AMX_OK)
                 return r;
+        }
+        if (use_uni) {
+            int FR = 8;
+            if (const char* e = getenv("AMX_GMM_FR"))
+                FR = atoi(e);
+            amx::GmmUniformDims    ud{Tc, Tpad, h->n_mix, h->mix_pad, h->K, 0};
+            dim3                   grid(amx::ceil_div(h->n_mix, 256), amx::ceil_div(Tc, FR));
+            float*                 sc = scores_dev + (size_t)t0 * h->n_mix;
+            uint32_t*              bd = best_dev ? best_dev + (size_t)t0 * h->n_mix : nullptr;
+            amx::ScopedKernelTimer timer(h->ctx, "gmm_combine");
+#define AMX_UNI(STATE, F)                                                                                                        \
+    hipLaunchKernelGGL((amx::gmm_combine_uniform_kernel<amx::STATE, F>), grid, dim3(256), 0, h->ctx->stream, h->d_dist, h->d_dist64, \
+                       sc, bd, h->d_m2lw_t, h->d_k_dens, h->d_ln64, h->d_ln32, ud)
+            if (mode == AMX_GMM_MAX) {
+                if (FR == 4) AMX_UNI(MaxState, 4);
+                else if (FR == 16) AMX_UNI(MaxState, 16);
+                else if (FR == 2) AMX_UNI(MaxState, 2);
+                else AMX_UNI(MaxState, 8);
+            }
+            else {
+                FR = 8;
+                grid = dim3(amx::ceil_div(h->n_mix, 256), amx::ceil_div(Tc, FR));
+                AMX_UNI(SumState, 8);
+            }
+#undef AMX_UNI
+            AMX_HIP(hipGetLastError());
+            continue;
         }
         amx::GmmCombineParams cp;
         cp.dist     = h->d_dist;
