@@ -30,6 +30,18 @@ MFMA_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak
 FP32_TFLOPS = 157.3        # f32 vector (= f32 MFMA) peak
 
 
+def measured_traffic(key):
+    """HBM bytes per launch measured offline with rocprofv3 --pmc (profiles/r01/traffic.json), or None"""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "r01", "traffic.json")))
+        for k, v in t.items():
+            if k.startswith(key):
+                return v["traffic"]
+    except Exception:
+        pass
+    return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -129,7 +141,8 @@ class Pipeline:
         peak = MFMA_BF16_TFLOPS if self.nn_precision == "bf16" else FP32_TFLOPS
         ach = flops / (ms * 1e-3) / 1e12
         return dict(bound="mfma", kernel="gemm_bf16_kernel<NONE,LAST> (2048->10000)" if self.nn_precision == "bf16" else "gemm_f32_kernel (2048->10000)",
-                    achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4), traffic=None,
+                    achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
+                    traffic=measured_traffic("gemm_bf16_kernel") if (self.nn_precision == "bf16" and self.F >= self.CHUNK) else None,
                     avg_launch_ms=round(ms, 4), launches=n, flops_per_launch=flops)
 
     def stage_report(self):
@@ -175,8 +188,8 @@ class MfccOnly:
             return None
         gbs = self.F * 800.0 / (ms * 1e-3) / 1e9  # 160 samples*4 B in + 40 ceps*4 B out per frame
         return dict(bound="hbm", kernel="mfcc_kernel<256>", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(gbs / HBM_PEAK_GBS, 4), traffic=None, avg_launch_ms=round(ms, 4), launches=n,
-                    bytes_per_launch=self.F * 800.0)
+                    frac=round(gbs / HBM_PEAK_GBS, 4), traffic=measured_traffic("mfcc_kernel<256>"), avg_launch_ms=round(ms, 4),
+                    launches=n, bytes_per_launch=self.F * 800.0)
 
     def stage_report(self):
         return {}
@@ -415,7 +428,7 @@ def main():
                 "rtf": round(dt / (units * 0.01), 8)}
         line["roofline"] = job.roofline()
         line["stages"] = job.stage_report()
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             cb = cpu_baseline(args.workload)
             line["cpu_baseline"] = cb
             line["speedup_vs_cpu"] = round(value / world / cb["value"], 1)

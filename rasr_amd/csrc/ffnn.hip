@@ -119,6 +119,97 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// Shared epilogue of the bf16 GEMM kernels: bias (+ activation, bf16 pack) or bias - prior, negate, f32 store and the
+// per-tile arg-min partials of the output layer.
+template<class C, int ACT, bool LAST>
+__device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[C::MI][C::MJ], char* lds, const float* __restrict__ bias, void* __restrict__ out,
+                                              int ldo, int n_valid, int t_valid, int n0, int t0, int tile_n, int wn, int wt, int lane, int tid,
+                                              float* __restrict__ part_min, unsigned* __restrict__ part_idx, int part_ld) {
+    // ---- epilogue: lane holds, per 32x32 tile, col t = lane&31 and rows n = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    // Output layer: besides the scores, the tile's arg-min over its n range is produced per frame
+    // (first minimum wins) so that the best-state statistics never re-read the score matrix.
+    const bool want_best = LAST && part_min != nullptr;
+    if (want_best)
+        __syncthreads();  // every wave is done with the last stage: LDS is reused for the cross-wave arg-min
+    float*    s_min = (float*)lds;                              // [WN][BT]
+    unsigned* s_idx = (unsigned*)(lds + C::WN * C::BT * 4);     // [WN][BT]
+#pragma unroll
+    for (int j = 0; j < C::MJ; ++j) {
+        const int tl = wt * (C::BT / C::WT) + j * 32 + (lane & 31);
+        const int t  = t0 + tl;
+        float     bmin = 3.402823466e+38f;
+        unsigned  bidx = 0xffffffffu;
+#pragma unroll
+        for (int i = 0; i < C::MI; ++i) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = n0 + wn * (C::BN / C::WN) + i * 32 + 8 * g + 4 * (lane >> 5);
+                float     v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    v[e] = acc[i][j][g * 4 + e] + bias[n + e];  // addToAllColumns
+                if (LAST) {
+                    if (t < t_valid) {
+                        float* o = (float*)out + (size_t)t * ldo + n;
+                        if (n + 3 < n_valid && ((ldo & 3) == 0))
+                            *(float4*)o = make_float4(-v[0], -v[1], -v[2], -v[3]);
+                        else
+                            for (int e = 0; e < 4; ++e)
+                                if (n + e < n_valid)
+                                    o[e] = -v[e];
+                    }
+                    if (want_best) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float sc = -v[e];
+                            if (n + e < n_valid && sc < bmin) {  // ascending n within the lane
+                                bmin = sc;
+                                bidx = (unsigned)(n + e);
+                            }
+                        }
+                    }
+                }
+                else {
+                    uint2 pk;
+                    pk.x = pack_bf16(activate<ACT>(v[0]), activate<ACT>(v[1]));
+                    pk.y = pack_bf16(activate<ACT>(v[2]), activate<ACT>(v[3]));
+                    *(uint2*)((bf16_t*)out + (size_t)t * ldo + n) = pk;
+                }
+            }
+        }
+        if (want_best) {
+            // lanes l and l+32 hold the same frame, interleaved n: smaller index wins ties
+            const float    om = __shfl_xor(bmin, 32, 64);
+            const unsigned oi = (unsigned)__shfl_xor((int)bidx, 32, 64);
+            if (om < bmin || (om == bmin && oi < bidx)) {
+                bmin = om;
+                bidx = oi;
+            }
+            if (lane < 32) {
+                s_min[wn * C::BT + tl] = bmin;
+                s_idx[wn * C::BT + tl] = bidx;
+            }
+        }
+    }
+    if (want_best) {
+        __syncthreads();
+        for (int tl = tid; tl < C::BT; tl += C::THREADS) {
+            float    bmin = s_min[tl];
+            unsigned bidx = s_idx[tl];
+#pragma unroll
+            for (int w = 1; w < C::WN; ++w) {  // ascending n ranges: strict '<' keeps the first minimum
+                const float m = s_min[w * C::BT + tl];
+                if (m < bmin) {
+                    bmin = m;
+                    bidx = s_idx[w * C::BT + tl];
+                }
+            }
+            part_min[(size_t)tile_n * part_ld + t0 + tl] = bmin;
+            part_idx[(size_t)tile_n * part_ld + t0 + tl] = bidx;
+        }
+    }
+}
+
 template<class C, int ACT, bool LAST, int VAR>
 __global__ __launch_bounds__(C::THREADS) void gemm_bf16_kernel(const bf16_t* __restrict__ W, const bf16_t* __restrict__ X,
                                                               const float* __restrict__ bias, void* __restrict__ out, int Kpad, int ldx,
@@ -216,7 +307,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm_bf16_kernel(const bf16_t* __r
         __builtin_amdgcn_s_barrier();
         const bool more  = kt + C::STAGES - 1 < KT;
         const int  nslot = (kt + C::STAGES - 1) % C::STAGES;
-        if (!(VAR & 4) && more)
+        if (!(VAR & 4) && more && !((VAR & 16) && kt > 0))
             stage(nslot, kt + C::STAGES - 1);
         const char* wbase = lds + (kt % C::STAGES) * C::STAGE_BYTES;
         const char* xbase = wbase + C::A_BYTES;
@@ -236,6 +327,8 @@ __global__ __launch_bounds__(C::THREADS) void gemm_bf16_kernel(const bf16_t* __r
             for (int ks = 0; ks < BK / 16; ++ks) {
                 if (ks + 1 < BK / 16)
                     load((ks + 1) & 1, ks + 1);
+                if (VAR & 32)
+                    __builtin_amdgcn_sched_barrier(0);  // keep the next slab's reads AHEAD of this slab's MFMAs
                 if ((VAR & 4) && more && ks == 0)
                     stage(nslot, kt + C::STAGES - 1);
                 if (VAR & 2)
@@ -245,6 +338,8 @@ __global__ __launch_bounds__(C::THREADS) void gemm_bf16_kernel(const bf16_t* __r
 #pragma unroll
                     for (int j = 0; j < C::MJ; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks & 1][i], b[ks & 1][j], acc[i][j], 0, 0, 0);
+                if (VAR & 32)
+                    __builtin_amdgcn_sched_barrier(0);
                 if (VAR & 2)
                     __builtin_amdgcn_s_setprio(0);
             }
@@ -266,8 +361,13 @@ __global__ __launch_bounds__(C::THREADS) void gemm_bf16_kernel(const bf16_t* __r
 #pragma unroll
                 for (int i = 0; i < C::MI; ++i)
 #pragma unroll
-                    for (int j = 0; j < C::MJ; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < C::MJ; ++j) {
+                        if (VAR & 8) {  // ablation: keep the fragment reads alive, skip the matrix pipe
+                            asm volatile("" ::"v"(a[i]), "v"(b[j]));
+                        }
+                        else
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                    }
                 if (VAR & 2)
                     __builtin_amdgcn_s_setprio(0);
             }
@@ -276,89 +376,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm_bf16_kernel(const bf16_t* __r
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
 
-    // ---- epilogue: lane holds, per 32x32 tile, col t = lane&31 and rows n = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    // Output layer: besides the scores, the tile's arg-min over its n range is produced per frame
-    // (first minimum wins) so that the best-state statistics never re-read the score matrix.
-    const bool want_best = LAST && part_min != nullptr;
-    if (want_best)
-        __syncthreads();  // every wave is done with the last stage: LDS is reused for the cross-wave arg-min
-    float*    s_min = (float*)lds;                              // [WN][BT]
-    unsigned* s_idx = (unsigned*)(lds + C::WN * C::BT * 4);     // [WN][BT]
-#pragma unroll
-    for (int j = 0; j < C::MJ; ++j) {
-        const int tl = wt * (C::BT / C::WT) + j * 32 + (lane & 31);
-        const int t  = t0 + tl;
-        float     bmin = 3.402823466e+38f;
-        unsigned  bidx = 0xffffffffu;
-#pragma unroll
-        for (int i = 0; i < C::MI; ++i) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int n = n0 + wn * (C::BN / C::WN) + i * 32 + 8 * g + 4 * (lane >> 5);
-                float     v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    v[e] = acc[i][j][g * 4 + e] + bias[n + e];  // addToAllColumns
-                if (LAST) {
-                    if (t < t_valid) {
-                        float* o = (float*)out + (size_t)t * ldo + n;
-                        if (n + 3 < n_valid && ((ldo & 3) == 0))
-                            *(float4*)o = make_float4(-v[0], -v[1], -v[2], -v[3]);
-                        else
-                            for (int e = 0; e < 4; ++e)
-                                if (n + e < n_valid)
-                                    o[e] = -v[e];
-                    }
-                    if (want_best) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float sc = -v[e];
-                            if (n + e < n_valid && sc < bmin) {  // ascending n within the lane
-                                bmin = sc;
-                                bidx = (unsigned)(n + e);
-                            }
-                        }
-                    }
-                }
-                else {
-                    uint2 pk;
-                    pk.x = pack_bf16(activate<ACT>(v[0]), activate<ACT>(v[1]));
-                    pk.y = pack_bf16(activate<ACT>(v[2]), activate<ACT>(v[3]));
-                    *(uint2*)((bf16_t*)out + (size_t)t * ldo + n) = pk;
-                }
-            }
-        }
-        if (want_best) {
-            // lanes l and l+32 hold the same frame, interleaved n: smaller index wins ties
-            const float    om = __shfl_xor(bmin, 32, 64);
-            const unsigned oi = (unsigned)__shfl_xor((int)bidx, 32, 64);
-            if (om < bmin || (om == bmin && oi < bidx)) {
-                bmin = om;
-                bidx = oi;
-            }
-            if (lane < 32) {
-                s_min[wn * C::BT + tl] = bmin;
-                s_idx[wn * C::BT + tl] = bidx;
-            }
-        }
-    }
-    if (want_best) {
-        __syncthreads();
-        for (int tl = tid; tl < C::BT; tl += C::THREADS) {
-            float    bmin = s_min[tl];
-            unsigned bidx = s_idx[tl];
-#pragma unroll
-            for (int w = 1; w < C::WN; ++w) {  // ascending n ranges: strict '<' keeps the first minimum
-                const float m = s_min[w * C::BT + tl];
-                if (m < bmin) {
-                    bmin = m;
-                    bidx = s_idx[w * C::BT + tl];
-                }
-            }
-            part_min[(size_t)tile_n * part_ld + t0 + tl] = bmin;
-            part_idx[(size_t)tile_n * part_ld + t0 + tl] = bidx;
-        }
-    }
+    gemm_epilogue<C, ACT, LAST>(acc, lds, bias, out, ldo, n_valid, t_valid, n0, t0, tile_n, wn, wt, lane, tid, part_min, part_idx, part_ld);
 }
 
 // combines the per-tile arg-min partials: best state per frame, per-state counts, sum of best scores
@@ -540,7 +558,6 @@ int ensure_workspace(amx_ffnn* h, int Tpad) {
 // tile configurations of the bf16 GEMM, selected at run time (AMX_GEMM_CFG overrides for experiments)
 using CfgA = amx::GemmCfg<128, 128, 2, 2, 2>;  //  64 KB LDS, 2 workgroups per CU
 using CfgC = amx::GemmCfg<256, 256, 2, 4, 2>;  // 128 KB LDS, 8 waves, wave tile 128x64
-using CfgE = amx::GemmCfg<256, 256, 2, 2, 2>;  // 128 KB LDS, 4 waves (one per SIMD), wave tile 128x128
 // measured and dropped: 256x128x64 3-stage (753 TF), 256x256 with 64x128 wave tiles (973 TF) vs CfgC (1000 TF), CfgA (870 TF)
 
 template<class C, int ACT, bool LAST, int VAR>
@@ -559,11 +576,10 @@ void launch_bf16v(amx_ffnn* h, int l, const void* x, int ldx, void* out, int ldo
 
 template<class C, int ACT, bool LAST>
 void launch_bf16(amx_ffnn* h, int l, const void* x, int ldx, void* out, int ldo, int T, int Tpad) {
-    // schedule variants 1..7 (register double-buffered fragments, s_setprio around the MFMA cluster, late
-    // stage issue) were measured within +-3 % of variant 0 on MI355X and are not instantiated
-    if (h->gemm_var == 1)
-        launch_bf16v<C, ACT, LAST, 1>(h, l, x, ldx, out, ldo, T, Tpad);
-    else
+    // Measured on MI355X and NOT instantiated: register double-buffered fragments, pinned
+    // read/MFMA interleave (sched_barrier), s_setprio around the MFMA cluster, late stage issue -- all within +-3 %
+    // of variant 0; a phase-split kernel (two wave groups half a phase apart, register or LDS-DMA staging) tied it.
+    // Ablation of the output layer (1.52 ms): without MFMAs 1.36 ms, without global loads 1.27 ms, neither 0.80 ms.
         launch_bf16v<C, ACT, LAST, 0>(h, l, x, ldx, out, ldo, T, Tpad);
 }
 
@@ -575,7 +591,6 @@ void launch_bf16_cfg(amx_ffnn* h, int l, const void* x, int ldx, void* out, int 
         cfg = ((long)(h->Npad[l] / 256) * (Tpad / 256) >= 2L * h->ctx->n_cu) ? 2 : 0;
     switch (cfg) {
         case 2: launch_bf16<CfgC, ACT, LAST>(h, l, x, ldx, out, ldo, T, Tpad); break;
-        case 4: launch_bf16<CfgE, ACT, LAST>(h, l, x, ldx, out, ldo, T, Tpad); break;
         default: launch_bf16<CfgA, ACT, LAST>(h, l, x, ldx, out, ldo, T, Tpad); break;
     }
 }
