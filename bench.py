@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--utt-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--gmm-type", default="diagonal-maximum", choices=["diagonal-maximum", "batch-diagonal-maximum-float"])
     return ap.parse_args()
 
 
@@ -208,7 +209,8 @@ class GmmOnly:
             model = synth.gmm_cart(10000, 16, 16, 40, seed=5, pooled=True)
         self.nk = int(model["mix_offsets"][-1])
         self.nd = len(model["dens_mean"])
-        self.sc = rasr_amd.GmmFeatureScorer(ctx, model)
+        self.gmm_type = args.gmm_type
+        self.sc = rasr_amd.GmmFeatureScorer(ctx, model, feature_scorer_type=args.gmm_type)
         self.T = 256
         x = np.random.Generator(np.random.PCG64(4 + rank)).standard_normal((self.T, 40)).astype(np.float32)
         self.x = torch.from_numpy(x).cuda()
@@ -217,7 +219,7 @@ class GmmOnly:
         self.units = self.T
 
     def step(self):
-        self.sc.score_dev(self.x, self.T, self.scores, self.best)
+        self.sc.score_dev(self.x, self.T, self.scores, None if self.gmm_type != "diagonal-maximum" else self.best)
 
     def epoch_reduce(self, world):
         pass
@@ -238,8 +240,9 @@ class GmmOnly:
                         frac=round(ach / 78.6, 4), traffic=None, avg_launch_ms=round(ms, 4), launches=n, flops_per_launch=ops)
         else:
             ms, n = self.ctx.profile_get("gmm")
-            ops = 4.0 * self.nk * 40 * self.T
-            name = "gmm_direct_kernel<40,MaxState>"
+            per_dim = 4.0 if self.gmm_type == "diagonal-maximum" else 3.0  # batch-float: pre-scaled means, sub/mul/add
+            ops = per_dim * self.nk * 40 * self.T
+            name = "gmm_direct_kernel<40,MaxState>" if self.gmm_type == "diagonal-maximum" else "gmm_batch_float_kernel<40>"
         if n == 0:
             return None
         ach = ops / (ms * 1e-3) / 1e12

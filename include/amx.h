@@ -149,7 +149,9 @@ typedef struct {
     float           gaussian_scale;       /* gaussian-scale, default 1 */
 } amx_gmm_model;
 
-enum { AMX_GMM_MAX = 0, AMX_GMM_SUM = 1 }; /* diagonal-maximum / diagonal-sum */
+/* diagonal-maximum / diagonal-sum / batch-diagonal-maximum-float (Mm/BatchFeatureScorer.cc:164-254: pooled
+ * covariance only, no best-density output, ignores the two scales like the reference class) */
+enum { AMX_GMM_MAX = 0, AMX_GMM_SUM = 1, AMX_GMM_BATCH_FLOAT = 2 };
 
 int  amx_gmm_create(amx_ctx* ctx, const amx_gmm_model* model, amx_gmm** out); /* copies everything */
 void amx_gmm_destroy(amx_gmm* h);

@@ -14,7 +14,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import (AMX_ACT_NONE, AMX_ACT_RELU, AMX_ACT_SIGMOID, AMX_ACT_TANH, AMX_GMM_MAX, AMX_GMM_SUM,  # noqa: F401
+from ._lib import (AMX_ACT_NONE, AMX_ACT_RELU, AMX_ACT_SIGMOID, AMX_ACT_TANH, AMX_GMM_BATCH_FLOAT, AMX_GMM_MAX, AMX_GMM_SUM,  # noqa: F401
                    AMX_PREC_BF16, AMX_PREC_FP32, AmxError, MfccCfg)
 
 __all__ = ["Context", "MfccExtractor", "GmmFeatureScorer", "NnBatchFeatureScorer", "AmxError", "read_pms", "write_pms"]
@@ -180,7 +180,8 @@ def _gmm_struct(model, mixture_weight_scale, gaussian_scale, keep):
 
 
 class GmmFeatureScorer:
-    """Mm::FeatureScorer over a mixture set; feature_scorer_type in {"diagonal-maximum", "diagonal-sum"}.
+    """Mm::FeatureScorer over a mixture set; feature_scorer_type in {"diagonal-maximum", "diagonal-sum",
+    "batch-diagonal-maximum-float"}.
 
     model: dict(dim, mix_offsets u32[M+1], dens_index u32[sumK], log_weight f64[sumK], dens_mean u32[D],
     dens_cov u32[D], means f32[n_mean,dim], variances f32[n_cov,dim]).
@@ -188,7 +189,8 @@ class GmmFeatureScorer:
 
     def __init__(self, ctx, model, feature_scorer_type="diagonal-maximum", mixture_weight_scale=1.0, gaussian_scale=1.0):
         self.ctx, self.L = ctx, ctx.L
-        self.mode = {"diagonal-maximum": AMX_GMM_MAX, "diagonal-sum": AMX_GMM_SUM}[feature_scorer_type]
+        self.mode = {"diagonal-maximum": AMX_GMM_MAX, "diagonal-sum": AMX_GMM_SUM,
+                     "batch-diagonal-maximum-float": AMX_GMM_BATCH_FLOAT}[feature_scorer_type]
         keep = []
         st = _gmm_struct(model, mixture_weight_scale, gaussian_scale, keep)
         h = C.c_void_p()

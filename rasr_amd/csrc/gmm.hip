@@ -206,6 +206,55 @@ __global__ __launch_bounds__(256) void gmm_direct_kernel(const float* __restrict
     }
 }
 
+// ---- Mm::BatchFloatFeatureScorer ("batch-diagonal-maximum-float", Mm/BatchFeatureScorer.cc:164-254): pooled
+// covariance only; means and features pre-multiplied by 1/sigma, per-density constant c = (f32)(logNorm - 2 logw);
+// two 4-lane f32 accumulators over 8-wide blocks, lane 0 of the first starts at c; a = s1 + s2;
+// result = (a3 + a1) + (a2 + a0); min over the densities; 0.5 * min.  3 ops per dimension instead of 4.
+template<int DIM>
+__global__ __launch_bounds__(256) void gmm_batch_float_kernel(const float* __restrict__ g_feats, float* __restrict__ g_scores,
+                                                             const uint32_t* __restrict__ g_mix_off, const uint32_t* __restrict__ g_k_mean,
+                                                             const float* __restrict__ g_k_const, const float* __restrict__ g_smeans,
+                                                             const float* __restrict__ g_isr0, GmmDims dims) {
+    const int  lane = threadIdx.x & 63;
+    const int  wave = threadIdx.x >> 6;
+    const int  t    = (blockIdx.y * 4 + wave) * 64 + lane;
+    const bool live = t < dims.T;
+    const int  tt   = live ? t : (dims.T - 1);
+    float      x[DIM];
+#pragma unroll
+    for (int i = 0; i < DIM; ++i)
+        x[i] = g_feats[(size_t)tt * DIM + i] * g_isr0[i];  // setFeature: f * variance_
+    const int m0 = blockIdx.x * dims.mix_tile;
+    const int m1 = min(m0 + dims.mix_tile, dims.n_mix);
+    for (int m = m0; m < m1; ++m) {
+        const uint32_t k0 = g_mix_off[m], k1 = g_mix_off[m + 1];
+        float          best = FLT_MAX;
+        for (uint32_t k = k0; k < k1; ++k) {
+            const float* mu    = g_smeans + (size_t)g_k_mean[k] * DIM;
+            float        s1[4] = {g_k_const[k], 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int d = 0; d < DIM; d += 8) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (d + j < DIM) {
+                        float x1 = mu[d + j] - x[d + j];
+                        s1[j]    = s1[j] + x1 * x1;
+                    }
+                    if (d + 4 + j < DIM) {
+                        float x2 = mu[d + 4 + j] - x[d + 4 + j];
+                        s2[j]    = s2[j] + x2 * x2;
+                    }
+                }
+            }
+            const float a0 = s1[0] + s2[0], a1 = s1[1] + s2[1], a2 = s1[2] + s2[2], a3 = s1[3] + s2[3];
+            const float r  = (a3 + a1) + (a2 + a0);
+            best           = r < best ? r : best;  // _mm_min_ps(score, r)
+        }
+        if (live)
+            g_scores[(size_t)t * dims.n_mix + m] = best < FLT_MAX ? 0.5f * best : best;
+    }
+}
+
 // ---- two-stage path for tied models
 struct GmmDistParams {
     const float* __restrict__ feats;     // [T x dim] (chunk)
@@ -378,6 +427,9 @@ struct amx_gmm {
     uint32_t *d_d_mean = nullptr, *d_d_cov = nullptr;
     double*   d_k_c64 = nullptr;
     float *   d_k_c32 = nullptr, *d_means = nullptr, *d_isr = nullptr;
+    // batch-float mode tables (pooled covariance only)
+    float *   d_smeans = nullptr, *d_k_const = nullptr, *d_isr0 = nullptr;
+    bool      pooled = false;
     bool      tied    = false;  // use the two-stage path
     bool      uniform = false;  // tied AND every mixture lists the same densities: lane = mixture combine
     int       K = 0, mix_pad = 0;
@@ -554,6 +606,27 @@ int amx_gmm_create(amx_ctx* ctx, const amx_gmm_model* m, amx_gmm** out) {
         amx_gmm_destroy(h);
         return r;
     }
+    h->pooled = (m->n_cov == 1);
+    if (h->pooled) {
+        // BatchFloatFeatureScorer::init: unscaled covariance element, c = logNormFactor - 2 * logWeight
+        std::vector<float> isr0(m->dim), smeans((size_t)m->n_mean * m->dim), kc(nk);
+        double             lsum = 0;
+        for (int i = 0; i < m->dim; ++i) {
+            isr0[i] = (float)1 / (float)std::sqrt((double)m->variances[i]);
+            lsum += std::log((double)std::fabs(m->variances[i]));
+        }
+        const float ln = (float)((double)m->dim * std::log((double)2 * M_PI) + lsum);
+        for (int j = 0; j < m->n_mean; ++j)
+            for (int i = 0; i < m->dim; ++i)
+                smeans[(size_t)j * m->dim + i] = m->means[(size_t)j * m->dim + i] * isr0[i];
+        for (size_t k = 0; k < nk; ++k)
+            kc[k] = (float)((double)ln - 2 * m->log_weight[k]);
+        if ((r = gupload(&h->d_isr0, isr0.data(), isr0.size())) != AMX_OK || (r = gupload(&h->d_smeans, smeans.data(), smeans.size())) != AMX_OK ||
+            (r = gupload(&h->d_k_const, kc.data(), kc.size())) != AMX_OK) {
+            amx_gmm_destroy(h);
+            return r;
+        }
+    }
     if (h->uniform) {
         h->mix_pad = (h->n_mix + 63) & ~63;
         std::vector<float>  wt((size_t)h->K * h->mix_pad, 0.f);
@@ -594,6 +667,9 @@ void amx_gmm_destroy(amx_gmm* h) {
     hipFree(h->d_k_c32);
     hipFree(h->d_means);
     hipFree(h->d_isr);
+    hipFree(h->d_smeans);
+    hipFree(h->d_k_const);
+    hipFree(h->d_isr0);
     hipFree(h->d_dist);
     hipFree(h->d_dist64);
     hipFree(h->d_m2lw_t);
@@ -623,13 +699,47 @@ int amx_gmm_tables(const amx_gmm* h, float* m2lw, float* isr, float* lognorm) {
 int amx_gmm_score_dev(amx_gmm* h, int mode, const float* feats_dev, int T, float* scores_dev, uint32_t* best_dev) {
     AMX_REQUIRE(h, AMX_ERR_INVALID, "amx_gmm_score_dev: NULL handle");
     AMX_REQUIRE(h->ctx, AMX_ERR_STATE, "amx_gmm_score_dev: host-only handle (created without a context)");
-    AMX_REQUIRE(mode == AMX_GMM_MAX || mode == AMX_GMM_SUM, AMX_ERR_INVALID, "amx_gmm_score_dev: unknown mode %d", mode);
+    AMX_REQUIRE(mode == AMX_GMM_MAX || mode == AMX_GMM_SUM || mode == AMX_GMM_BATCH_FLOAT, AMX_ERR_INVALID,
+                "amx_gmm_score_dev: unknown mode %d", mode);
     AMX_REQUIRE(T >= 0, AMX_ERR_INVALID, "amx_gmm_score_dev: negative frame count");
     if (T == 0)
         return AMX_OK;
     AMX_REQUIRE(feats_dev && scores_dev, AMX_ERR_INVALID, "amx_gmm_score_dev: NULL buffer");
     AMX_HIP(hipSetDevice(h->ctx->device));
     const int fblocks = amx::ceil_div(T, 256);
+    if (mode == AMX_GMM_BATCH_FLOAT) {
+        // Mm::BatchFloatFeatureScorer::init: criticalError("feature scorer supports only globally pooled covariance")
+        AMX_REQUIRE(h->pooled, AMX_ERR_INVALID, "amx_gmm_score_dev: feature scorer supports only globally pooled covariance");
+        AMX_REQUIRE(best_dev == nullptr, AMX_ERR_UNSUPPORTED, "amx_gmm_score_dev: batch-diagonal-maximum-float does not assign densities");
+        int mt = 16;
+        while (mt > 4 && (long)amx::ceil_div(h->n_mix, mt) * fblocks < 2048)
+            mt /= 2;
+        amx::GmmDims           dims{T, h->dim, h->n_mix, mt};
+        dim3                   grid(amx::ceil_div(h->n_mix, mt), fblocks);
+        amx::ScopedKernelTimer timer(h->ctx, "gmm");
+        switch (h->dim) {
+#define AMX_GMM_CASE(D)                                                                                                   \
+    case D:                                                                                                               \
+        hipLaunchKernelGGL((amx::gmm_batch_float_kernel<D>), grid, dim3(256), 0, h->ctx->stream, feats_dev, scores_dev,    \
+                           h->d_mix_off, h->d_k_mean, h->d_k_const, h->d_smeans, h->d_isr0, dims);                         \
+        break;
+            AMX_GMM_CASE(16)
+            AMX_GMM_CASE(24)
+            AMX_GMM_CASE(32)
+            AMX_GMM_CASE(33)
+            AMX_GMM_CASE(39)
+            AMX_GMM_CASE(40)
+            AMX_GMM_CASE(45)
+            AMX_GMM_CASE(48)
+            AMX_GMM_CASE(64)
+#undef AMX_GMM_CASE
+            default:
+                amx::set_error("amx_gmm_score_dev: batch-diagonal-maximum-float has no kernel for dimension %d", h->dim);
+                return AMX_ERR_UNSUPPORTED;
+        }
+        AMX_HIP(hipGetLastError());
+        return AMX_OK;
+    }
     if (!h->tied) {
         amx::GmmParams p;
         p.feats   = feats_dev;

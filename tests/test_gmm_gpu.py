@@ -111,3 +111,26 @@ def test_errors(ctx):
     s = rasr_amd.GmmFeatureScorer(ctx, model)
     sc, _ = s.score(np.zeros((0, 8), np.float32))
     assert sc.shape == (0, 4)
+
+
+@pytest.mark.parametrize("dim", [40, 39, 33, 16])
+def test_batch_float_scorer_exact(ctx, dim):
+    """batch-diagonal-maximum-float: bit-identical to the oracle's restatement of Mm::BatchFloatFeatureScorer
+    (8-wide blocks incl. dims that are not a multiple of 8), and within f32 round-off of diagonal-maximum"""
+    import rasr_amd
+    from oracle import OracleGmm
+    model = synth.gmm_cart(300, 1, 8, dim, seed=40 + dim, pooled=True)
+    x = feats(200, dim, 41)
+    got = rasr_amd.GmmFeatureScorer(ctx, model, feature_scorer_type="batch-diagonal-maximum-float").score(x, want_best=False)
+    o = OracleGmm(model)
+    want = o.score_batch_float(x)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), np.abs(got - want).max()
+    assert np.allclose(got, o.score(x)[0], rtol=3e-6)
+
+
+def test_batch_float_scorer_errors(ctx):
+    import rasr_amd
+    s = rasr_amd.GmmFeatureScorer(ctx, synth.gmm_cart(10, 1, 3, 40, seed=1, pooled=False), feature_scorer_type="batch-diagonal-maximum-float")
+    with pytest.raises(rasr_amd.AmxError) as e:
+        s.score(feats(4, 40, 2), want_best=False)
+    assert e.value.status == -1 and "globally pooled covariance" in str(e.value)
