@@ -208,6 +208,20 @@ int amx_ffnn_score_dev(amx_ffnn* h, const float* feats_dev, int feats_stride, in
 int amx_ffnn_score_stats_dev(amx_ffnn* h, const float* feats_dev, int feats_stride, int T, float* scores_dev,
                              uint32_t* best_state_dev, unsigned long long* state_counts_dev, double* score_sum_dev);
 
+/* ------------------------------------------------------------------ NN parameter files and the state prior */
+
+/* Binary Math::Matrix<f32> as RASR writes NN layer parameters ("bin:<base>-f32-layer-<i>.bin",
+ * Nn/NeuralNetwork.cc:542-570; layout Math/Matrix.hh:560-574 + Math/Vector.hh:286-299): u32 rows, u32 cols, u32 rows,
+ * then per row u32 cols + f32 values.  *data is malloc'ed row-major [rows x cols]; release it with amx_free. */
+int  amx_nn_matrix_read(const char* path, int* rows, int* cols, float** data);
+int  amx_nn_matrix_write(const char* path, int rows, int cols, const float* data);
+void amx_free(void* p);
+/* LinearLayer::setParameters (Nn/LinearLayer.cc:383-420): parameter matrix [out x (has_bias + in)], column 0 = bias,
+ * -> W [out x in] row-major (== weights_[0] [in x out] column-major) and bias [out] (nullable). */
+int amx_nn_layer_from_parameters(const float* params, int rows, int cols, int has_bias, float* W, float* bias);
+/* Nn::Prior<f32>::setFromMixtureSet (Nn/Prior.cc:159-188), one-to-one class mapping: log_prior [n_mix]. */
+int amx_prior_from_mixture_set(const amx_gmm_model* model, float* log_prior);
+
 /* ------------------------------------------------------------------ per-epoch statistics */
 
 /* For every frame t: best state = argmin_e scores[t][e] (first minimum wins);

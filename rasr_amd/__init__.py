@@ -17,7 +17,8 @@ from . import _lib
 from ._lib import (AMX_ACT_NONE, AMX_ACT_RELU, AMX_ACT_SIGMOID, AMX_ACT_TANH, AMX_GMM_BATCH_FLOAT, AMX_GMM_MAX, AMX_GMM_SUM,  # noqa: F401
                    AMX_PREC_BF16, AMX_PREC_FP32, AmxError, MfccCfg)
 
-__all__ = ["Context", "MfccExtractor", "GmmFeatureScorer", "NnBatchFeatureScorer", "AmxError", "read_pms", "write_pms"]
+__all__ = ["Context", "MfccExtractor", "GmmFeatureScorer", "NnBatchFeatureScorer", "AmxError", "read_pms", "write_pms",
+           "read_nn_matrix", "write_nn_matrix", "layer_from_parameters", "prior_from_mixture_set"]
 
 
 def _ptr(a):
@@ -309,3 +310,40 @@ def write_pms(model, path):
     keep = []
     st = _gmm_struct(model, 1.0, 1.0, keep)
     _lib.check(_lib.lib().amx_pms_write(C.byref(st), path.encode()))
+
+
+def read_nn_matrix(path):
+    """binary Math::Matrix<f32> (RASR NN layer parameter file) -> numpy [rows, cols]"""
+    L = _lib.lib()
+    r, c, p = C.c_int(), C.c_int(), C.c_void_p()
+    _lib.check(L.amx_nn_matrix_read(path.encode(), C.byref(r), C.byref(c), C.byref(p)))
+    try:
+        n = r.value * c.value
+        a = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(max(n, 1),))[:n].copy()
+        return a.reshape(r.value, c.value)
+    finally:
+        L.amx_free(p)
+
+
+def write_nn_matrix(path, m):
+    m = np.ascontiguousarray(m, dtype=np.float32)
+    _lib.check(_lib.lib().amx_nn_matrix_write(path.encode(), m.shape[0], m.shape[1], m.ctypes.data))
+
+
+def layer_from_parameters(params, has_bias=True):
+    """parameter matrix [out, has_bias + in] (column 0 = bias) -> (W [out, in], bias [out])"""
+    p = np.ascontiguousarray(params, dtype=np.float32)
+    out, cols = p.shape
+    W = np.zeros((out, cols - int(has_bias)), np.float32)
+    b = np.zeros(out, np.float32)
+    _lib.check(_lib.lib().amx_nn_layer_from_parameters(p.ctypes.data, out, cols, int(has_bias), W.ctypes.data, b.ctypes.data))
+    return W, b
+
+
+def prior_from_mixture_set(model):
+    """Nn::Prior::setFromMixtureSet: log prior per mixture from the mixture weights"""
+    keep = []
+    st = _gmm_struct(model, 1.0, 1.0, keep)
+    out = np.zeros(st.n_mix, np.float32)
+    _lib.check(_lib.lib().amx_prior_from_mixture_set(C.byref(st), out.ctypes.data))
+    return out

@@ -92,6 +92,11 @@ SIGNATURES = {
     "amx_ffnn_score": (C.c_int, [_P, _P, C.c_int, _P]),
     "amx_ffnn_score_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
     "amx_ffnn_score_stats_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P, _P]),
+    "amx_nn_matrix_read": (C.c_int, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(_P)]),
+    "amx_nn_matrix_write": (C.c_int, [C.c_char_p, C.c_int, C.c_int, _P]),
+    "amx_free": (None, [_P]),
+    "amx_nn_layer_from_parameters": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "amx_prior_from_mixture_set": (C.c_int, [C.POINTER(GmmModel), _P]),
     "amx_stats_accumulate_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P]),
 }
 

@@ -185,3 +185,43 @@ def test_product_does_not_reference_the_oracle():
                 assert "oracle" not in text.lower() or f == "__init__.py" and "oracle" not in text, os.path.join(dirpath, f)
     out = os.popen("ldd %s" % _lib.LIB_PATH).read()
     assert "liboracle" not in out and "libref" not in out
+
+
+def test_nn_parameter_file_round_trip_and_layout(tmp_path):
+    """the reference's own layout test (Test/Nn_LinearLayer.cc:43-63): parameter matrix [out x (1+in)], column 0 = bias"""
+    import struct
+
+    import rasr_amd
+    params = np.arange(12, dtype=np.float32).reshape(3, 4) * 0.5 - 1
+    p = str(tmp_path / "net-f32-layer-1.bin")
+    rasr_amd.write_nn_matrix("bin:" + p, params)
+    raw = open(p, "rb").read()
+    assert struct.unpack("<III", raw[:12]) == (3, 4, 3)                     # Matrix::write + vector<Vector> header
+    assert struct.unpack("<I", raw[12:16]) == (4,) and len(raw) == 12 + 3 * (4 + 16)
+    assert struct.unpack("<4f", raw[16:32]) == tuple(params[0])
+    back = rasr_amd.read_nn_matrix(p)
+    assert np.array_equal(back, params)
+    W, b = rasr_amd.layer_from_parameters(back, has_bias=True)
+    assert np.array_equal(b, params[:, 0]) and np.array_equal(W, params[:, 1:])
+    W2, b2 = rasr_amd.layer_from_parameters(back, has_bias=False)
+    assert np.array_equal(W2, params) and not b2.any()
+    open(p, "wb").write(raw[:-3])
+    with pytest.raises(rasr_amd.AmxError):
+        rasr_amd.read_nn_matrix(p)
+
+
+def test_prior_from_mixture_set():
+    import rasr_amd
+    model = synth.gmm_cart(40, 1, 6, 8, seed=4)
+    got = rasr_amd.prior_from_mixture_set(model)
+    # numpy restatement of Nn/Prior.cc:159-188 with the same f32 / f64 steps
+    pri = np.zeros(40, np.float32)
+    for m in range(40):
+        acc = np.float32(0)
+        for k in range(model["mix_offsets"][m], model["mix_offsets"][m + 1]):
+            acc = np.float32(np.float64(acc) + np.exp(model["log_weight"][k]))
+        pri[m] = acc
+    obs = np.float32(pri.astype(np.float64).sum())
+    want = np.log((pri / obs).astype(np.float32)).astype(np.float32)
+    assert np.allclose(got, want, rtol=0, atol=2e-7)
+    assert abs(np.exp(got.astype(np.float64)).sum() - 1) < 1e-5
