@@ -96,16 +96,24 @@ __global__ __launch_bounds__(256) void pack_input_f32(const float* __restrict__ 
 constexpr int BK      = 64;   // k per stage: one 128-byte LDS row per matrix row
 constexpr int PAD_NT  = 256;  // N and T are padded to this (largest tile edge)
 
-template<int BN_, int BT_, int WN_, int WT_, int STAGES_>
+template<int BN_, int BT_, int WN_, int WT_, int STAGES_, int BK_ = 64>
 struct GemmCfg {
-    static constexpr int BN = BN_, BT = BT_, WN = WN_, WT = WT_, STAGES = STAGES_;
+    static constexpr int BN = BN_, BT = BT_, WN = WN_, WT = WT_, STAGES = STAGES_, BKC = BK_;
     static constexpr int NW = WN * WT, THREADS = NW * 64;
-    static constexpr int A_BYTES = BN * 128, B_BYTES = BT * 128, STAGE_BYTES = A_BYTES + B_BYTES;
+    static constexpr int ROW_BYTES = BKC * 2;               // one LDS row per matrix row: 128 B (BK 64) or 64 B (BK 32)
+    static constexpr int ROWS_PER_LOAD = 1024 / ROW_BYTES;  // rows covered by one wave-wide 16-byte global_load_lds
+    static constexpr int CHUNKS = ROW_BYTES / 16;
+    static constexpr int A_BYTES = BN * ROW_BYTES, B_BYTES = BT * ROW_BYTES, STAGE_BYTES = A_BYTES + B_BYTES;
     static constexpr int LDS_BYTES = STAGES * STAGE_BYTES;
-    static constexpr int A_LOADS = BN / 8 / NW, B_LOADS = BT / 8 / NW, LOADS = A_LOADS + B_LOADS;  // glds per wave per stage
-    static constexpr int MI = BN / WN / 32, MJ = BT / WT / 32;                                      // 32x32 tiles per wave
-    static_assert(BN % (8 * NW) == 0 && BT % (8 * NW) == 0, "staging needs whole 8-row groups per wave");
+    static constexpr int A_LOADS = BN / ROWS_PER_LOAD / NW, B_LOADS = BT / ROWS_PER_LOAD / NW, LOADS = A_LOADS + B_LOADS;
+    static constexpr int MI = BN / WN / 32, MJ = BT / WT / 32;  // 32x32 tiles per wave
+    static_assert(BKC == 64 || BKC == 32, "BK must be 32 or 64");
+    static_assert(BN % (ROWS_PER_LOAD * NW) == 0 && BT % (ROWS_PER_LOAD * NW) == 0, "staging needs whole row groups per wave");
     static_assert(BN % (WN * 32) == 0 && BT % (WT * 32) == 0, "wave tile must be a multiple of 32x32");
+    // XOR swizzle of the 16-byte chunks of a row so that ds_read_b128 of a 32-row MFMA fragment is conflict free:
+    // 128-byte rows: chunk ^ ((row>>1)&7); 64-byte rows: chunk ^ ((row>>2)&3)
+    __host__ __device__ static constexpr int xor_term(int r) { return BKC == 64 ? ((r >> 1) & 7) : ((r >> 2) & 3); }
+    __host__ __device__ static constexpr int swz(int r, int c) { return r * ROW_BYTES + ((c ^ xor_term(r)) << 4); }
 };
 
 // byte offset of 16-byte chunk `c` (0..7) of row `r` inside a [rows][64] bf16 tile
@@ -119,45 +127,60 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// Shared epilogue of the bf16 GEMM kernels: bias (+ activation, bf16 pack) or bias - prior, negate, f32 store and the
-// per-tile arg-min partials of the output layer.
-template<class C, int ACT, bool LAST>
-__device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[C::MI][C::MJ], char* lds, const float* __restrict__ bias, void* __restrict__ out,
+// Epilogue of the bf16 GEMM kernels: bias (+ activation, bf16 pack) or bias - prior, negate, and the per-tile arg-min
+// partials of the output layer.  The MFMA accumulator layout gives a lane 4 consecutive outputs of ONE frame, i.e. a
+// wave-wide store would touch 32 different output rows with 16/32-byte pieces.  Instead every wave transposes its
+// tile through a private, padded LDS region (32 frames x 128 outputs at a time) and writes whole contiguous row
+// segments (512 B per frame for f32 scores, 256 B for bf16 activations) with 16-byte lanes.
+template<class C, bool LAST>
+struct EpiCfg {
+    static constexpr int WNR  = C::BN / C::WN;                // outputs (n) per wave
+    static constexpr int WTT  = C::BT / C::WT;                // frames (t) per wave
+    static constexpr int ELT  = LAST ? 4 : 2;                 // bytes per stored element
+    static constexpr int ROWB = WNR * ELT + 16;               // padded LDS row: conflict-free b128 writes
+    static constexpr int WAVE_BYTES = 32 * ROWB;
+    static constexpr int STAGE_BYTES = C::NW * WAVE_BYTES;
+    static constexpr int BEST_OFF = STAGE_BYTES;                                      // arg-min exchange [2][WN][BT]
+    static constexpr int BYTES    = STAGE_BYTES + (LAST ? 2 * C::WN * C::BT * 4 : 0);
+};
+
+// LDS carve-up: [max(stage buffers, epilogue scratch)] [bias of the tile: BN floats]
+template<class C, bool LAST>
+__host__ __device__ constexpr int gemm_scratch_bytes() {
+    return C::LDS_BYTES > EpiCfg<C, LAST>::BYTES ? C::LDS_BYTES : EpiCfg<C, LAST>::BYTES;
+}
+
+template<class C, int ACT, bool LAST, bool NOSTORE = false>
+__device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[C::MI][C::MJ], char* lds, const float* s_bias, void* __restrict__ out,
                                               int ldo, int n_valid, int t_valid, int n0, int t0, int tile_n, int wn, int wt, int lane, int tid,
                                               float* __restrict__ part_min, unsigned* __restrict__ part_idx, int part_ld) {
-    // ---- epilogue: lane holds, per 32x32 tile, col t = lane&31 and rows n = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    // Output layer: besides the scores, the tile's arg-min over its n range is produced per frame
-    // (first minimum wins) so that the best-state statistics never re-read the score matrix.
+    using E = EpiCfg<C, LAST>;
+    const int  wave      = tid >> 6;
     const bool want_best = LAST && part_min != nullptr;
-    if (want_best)
-        __syncthreads();  // every wave is done with the last stage: LDS is reused for the cross-wave arg-min
-    float*    s_min = (float*)lds;                              // [WN][BT]
-    unsigned* s_idx = (unsigned*)(lds + C::WN * C::BT * 4);     // [WN][BT]
+    __syncthreads();  // every wave is done with the last K-tile: the stage buffers become epilogue scratch
+    char*     w_lds = lds + wave * E::WAVE_BYTES;
+    float*    s_min = (float*)(lds + E::BEST_OFF);                    // [WN][BT]
+    unsigned* s_idx = (unsigned*)(lds + E::BEST_OFF + C::WN * C::BT * 4);
+    const int tl32 = lane & 31, hh = lane >> 5;
 #pragma unroll
     for (int j = 0; j < C::MJ; ++j) {
-        const int tl = wt * (C::BT / C::WT) + j * 32 + (lane & 31);
-        const int t  = t0 + tl;
-        float     bmin = 3.402823466e+38f;
-        unsigned  bidx = 0xffffffffu;
+        float    bmin = 3.402823466e+38f;
+        unsigned bidx = 0xffffffffu;
+        // ---- registers -> LDS [frame][output]
 #pragma unroll
         for (int i = 0; i < C::MI; ++i) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int n = n0 + wn * (C::BN / C::WN) + i * 32 + 8 * g + 4 * (lane >> 5);
+                const int nl = i * 32 + 8 * g + 4 * hh;  // output index inside the wave tile
+                const int n  = n0 + wn * E::WNR + nl;
                 float     v[4];
+                const float4 b4 = *(const float4*)(s_bias + wn * E::WNR + nl);  // bias of this tile, staged in LDS
+                const float  bv[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    v[e] = acc[i][j][g * 4 + e] + bias[n + e];  // addToAllColumns
+                    v[e] = acc[i][j][g * 4 + e] + bv[e];  // addToAllColumns
                 if (LAST) {
-                    if (t < t_valid) {
-                        float* o = (float*)out + (size_t)t * ldo + n;
-                        if (n + 3 < n_valid && ((ldo & 3) == 0))
-                            *(float4*)o = make_float4(-v[0], -v[1], -v[2], -v[3]);
-                        else
-                            for (int e = 0; e < 4; ++e)
-                                if (n + e < n_valid)
-                                    o[e] = -v[e];
-                    }
+                    *(float4*)(w_lds + tl32 * E::ROWB + nl * 4) = make_float4(-v[0], -v[1], -v[2], -v[3]);
                     if (want_best) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
@@ -173,7 +196,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[C::MI][C::MJ], char*
                     uint2 pk;
                     pk.x = pack_bf16(activate<ACT>(v[0]), activate<ACT>(v[1]));
                     pk.y = pack_bf16(activate<ACT>(v[2]), activate<ACT>(v[3]));
-                    *(uint2*)((bf16_t*)out + (size_t)t * ldo + n) = pk;
+                    *(uint2*)(w_lds + tl32 * E::ROWB + nl * 2) = pk;
                 }
             }
         }
@@ -186,10 +209,50 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[C::MI][C::MJ], char*
                 bidx = oi;
             }
             if (lane < 32) {
+                const int tl = wt * E::WTT + j * 32 + tl32;
                 s_min[wn * C::BT + tl] = bmin;
                 s_idx[wn * C::BT + tl] = bidx;
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // ---- LDS -> global: whole row segments, 16 bytes per lane
+        const int tbase = t0 + wt * E::WTT + j * 32;
+        const int nbase = n0 + wn * E::WNR;
+        if (LAST) {
+            constexpr int LPR = E::WNR / 4;   // lanes per row (float4 each)
+            constexpr int RPI = 64 / LPR;     // rows per wave-wide store
+#pragma unroll
+            for (int it = 0; it < 32 / RPI; ++it) {
+                const int    row = it * RPI + lane / LPR, c4 = lane % LPR;
+                const float4 v   = *(const float4*)(w_lds + row * E::ROWB + c4 * 16);
+                const int    t = tbase + row, n = nbase + 4 * c4;
+                if (t < t_valid && !(NOSTORE && v.x != 123.456f)) {
+                    float* o = (float*)out + (size_t)t * ldo + n;
+                    if (n + 3 < n_valid && ((ldo & 3) == 0))
+                        *(float4*)o = v;
+                    else {
+                        if (n < n_valid) o[0] = v.x;
+                        if (n + 1 < n_valid) o[1] = v.y;
+                        if (n + 2 < n_valid) o[2] = v.z;
+                        if (n + 3 < n_valid) o[3] = v.w;
+                    }
+                }
+            }
+        }
+        else {
+            constexpr int LPR = E::WNR / 8;   // lanes per row (8 bf16 each)
+            constexpr int RPI = 64 / LPR;
+#pragma unroll
+            for (int it = 0; it < 32 / RPI; ++it) {
+                const int   row = it * RPI + lane / LPR, c8 = lane % LPR;
+                const uint4 v   = *(const uint4*)(w_lds + row * E::ROWB + c8 * 16);
+                if (!(NOSTORE && v.x != 0x12345678u))
+                    *(uint4*)((bf16_t*)out + (size_t)(tbase + row) * ldo + nbase + 8 * c8) = v;  // padded buffer: no guards
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
     if (want_best) {
         __syncthreads();
@@ -213,7 +276,8 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[C::MI][C::MJ], char*
 template<class C, int ACT, bool LAST, int VAR>
 __global__ __launch_bounds__(C::THREADS) void gemm_bf16_kernel(const bf16_t* __restrict__ W, const bf16_t* __restrict__ X,
                                                               const float* __restrict__ bias, void* __restrict__ out, int Kpad, int ldx,
-                                                              int ldo, int n_valid, int t_valid, int n_tiles_n, int GT, int GN, float* __restrict__ part_min,
+                                                              int ldo, int n_valid, int t_valid, int n_tiles_n, int n_tiles_total, int GT, int GN,
+                                                              float* __restrict__ part_min,
                                                               unsigned* __restrict__ part_idx, int part_ld) {
     extern __shared__ __attribute__((aligned(16))) char lds[];  // [STAGES][W tile | X tile]
     const int tid  = threadIdx.x;
@@ -226,10 +290,13 @@ __global__ __launch_bounds__(C::THREADS) void gemm_bf16_kernel(const bf16_t* __r
     // order v in which 32 consecutive tiles (= the 32 CUs of the XCD at one time) form a 4(t) x 8(n)
     // super-tile: per K-step the XCD's L2 then fetches 4 X slabs + 8 W slabs for 32 tiles instead of
     // 1 + 32, and neighbouring super-tiles keep sharing the X panel.
-    const int nwg = gridDim.x;
+    // Persistent workgroups: the grid covers the CUs once and every workgroup walks a strided list of tiles, so
+    // the epilogue stores of one tile drain while the next tile's operands stream in (no workgroup turnaround).
+  for (int vi = blockIdx.x; vi < n_tiles_total; vi += gridDim.x) {
+    const int nwg = n_tiles_total;
     int       tile_t, tile_n;
     {
-        const int b = blockIdx.x;
+        const int b = vi;  // vi % 8 == blockIdx.x % 8 (grid is a multiple of 8): same XCD for all tiles of a workgroup
         const int q = nwg >> 3, r = nwg & 7, xcd = b & 7, k = b >> 3;
         const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;  // bijective for any nwg
         const int n_tiles_t = nwg / n_tiles_n;
@@ -254,24 +321,24 @@ __global__ __launch_bounds__(C::THREADS) void gemm_bf16_kernel(const bf16_t* __r
 #pragma unroll
     for (int i = 0; i < C::A_LOADS; ++i) {
         const int pos = (i * C::NW + wave) * 1024 + lane * 16;
-        const int row = pos >> 7, phys = (pos & 127) >> 4;
-        gW[i]         = W + (size_t)(n0 + row) * Kpad + (phys ^ ((row >> 1) & 7)) * 8;
+        const int row = pos / C::ROW_BYTES, phys = (pos % C::ROW_BYTES) >> 4;
+        gW[i]         = W + (size_t)(n0 + row) * Kpad + (phys ^ C::xor_term(row)) * 8;
     }
 #pragma unroll
     for (int i = 0; i < C::B_LOADS; ++i) {
         const int pos = (i * C::NW + wave) * 1024 + lane * 16;
-        const int row = pos >> 7, phys = (pos & 127) >> 4;
-        gX[i]         = X + (size_t)(t0 + row) * ldx + (phys ^ ((row >> 1) & 7)) * 8;
+        const int row = pos / C::ROW_BYTES, phys = (pos % C::ROW_BYTES) >> 4;
+        gX[i]         = X + (size_t)(t0 + row) * ldx + (phys ^ C::xor_term(row)) * 8;
     }
     auto stage = [&](int slot, int kt) {
         char* base = lds + slot * C::STAGE_BYTES;
 #pragma unroll
         for (int i = 0; i < C::A_LOADS; ++i)
-            __builtin_amdgcn_global_load_lds((const void*)(gW[i] + (size_t)kt * BK),
+            __builtin_amdgcn_global_load_lds((const void*)(gW[i] + (size_t)kt * C::BKC),
                                              (__attribute__((address_space(3))) void*)(base + (i * C::NW + wave) * 1024), 16, 0, 0);
 #pragma unroll
         for (int i = 0; i < C::B_LOADS; ++i)
-            __builtin_amdgcn_global_load_lds((const void*)(gX[i] + (size_t)kt * BK),
+            __builtin_amdgcn_global_load_lds((const void*)(gX[i] + (size_t)kt * C::BKC),
                                              (__attribute__((address_space(3))) void*)(base + C::A_BYTES + (i * C::NW + wave) * 1024), 16, 0, 0);
     };
 
@@ -283,12 +350,17 @@ __global__ __launch_bounds__(C::THREADS) void gemm_bf16_kernel(const bf16_t* __r
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 acc[i][j][r] = 0.f;
+    // the tile's bias vector goes to LDS now (visible after the K-loop's barriers): per-lane global bias loads in
+    // the epilogue were a chain of ~30 dependent L2 round trips per tile
+    float* s_bias = (float*)(lds + gemm_scratch_bytes<C, LAST>());
+    for (int i = tid; i < C::BN; i += C::THREADS)
+        s_bias[i] = bias[n0 + i];
 
     // ---- software pipeline, ONE barrier per K-tile:
     //   wait(my loads of tile kt) ; barrier (=> everybody's loads of kt landed AND everybody finished
     //   reading tile kt-1) ; issue tile kt+STAGES-1 into the slot tile kt-1 occupied ; multiply tile kt.
     // STAGES-1 tiles stay in flight across the barrier (counted vmcnt, never a drain).
-    const int KT = Kpad / BK;
+    const int KT = Kpad / C::BKC;
 #pragma unroll
     for (int s = 0; s < C::STAGES - 1; ++s)
         if (s < KT)
@@ -317,15 +389,15 @@ __global__ __launch_bounds__(C::THREADS) void gemm_bf16_kernel(const bf16_t* __r
             auto   load = [&](int buf, int ks) {
 #pragma unroll
                 for (int i = 0; i < C::MI; ++i)
-                    a[buf][i] = *(const bf16x8*)(wbase + swz(wn * (C::BN / C::WN) + i * 32 + frow, ks * 2 + fk));
+                    a[buf][i] = *(const bf16x8*)(wbase + C::swz(wn * (C::BN / C::WN) + i * 32 + frow, ks * 2 + fk));
 #pragma unroll
                 for (int j = 0; j < C::MJ; ++j)
-                    b[buf][j] = *(const bf16x8*)(xbase + swz(wt * (C::BT / C::WT) + j * 32 + frow, ks * 2 + fk));
+                    b[buf][j] = *(const bf16x8*)(xbase + C::swz(wt * (C::BT / C::WT) + j * 32 + frow, ks * 2 + fk));
             };
             load(0, 0);
 #pragma unroll
-            for (int ks = 0; ks < BK / 16; ++ks) {
-                if (ks + 1 < BK / 16)
+            for (int ks = 0; ks < C::BKC / 16; ++ks) {
+                if (ks + 1 < C::BKC / 16)
                     load((ks + 1) & 1, ks + 1);
                 if (VAR & 32)
                     __builtin_amdgcn_sched_barrier(0);  // keep the next slab's reads AHEAD of this slab's MFMAs
@@ -344,16 +416,19 @@ __global__ __launch_bounds__(C::THREADS) void gemm_bf16_kernel(const bf16_t* __r
                     __builtin_amdgcn_s_setprio(0);
             }
         }
+        else if (VAR & 64) {
+            // ablation: operand streaming only (no fragment reads, no MFMA)
+        }
         else {
 #pragma unroll
-            for (int ks = 0; ks < BK / 16; ++ks) {
+            for (int ks = 0; ks < C::BKC / 16; ++ks) {
                 bf16x8 a[C::MI], b[C::MJ];
 #pragma unroll
                 for (int i = 0; i < C::MI; ++i)
-                    a[i] = *(const bf16x8*)(wbase + swz(wn * (C::BN / C::WN) + i * 32 + frow, ks * 2 + fk));
+                    a[i] = *(const bf16x8*)(wbase + C::swz(wn * (C::BN / C::WN) + i * 32 + frow, ks * 2 + fk));
 #pragma unroll
                 for (int j = 0; j < C::MJ; ++j)
-                    b[j] = *(const bf16x8*)(xbase + swz(wt * (C::BT / C::WT) + j * 32 + frow, ks * 2 + fk));
+                    b[j] = *(const bf16x8*)(xbase + C::swz(wt * (C::BT / C::WT) + j * 32 + frow, ks * 2 + fk));
                 if ((VAR & 4) && more && ks == 0)
                     stage(nslot, kt + C::STAGES - 1);
                 if (VAR & 2)
@@ -376,7 +451,24 @@ __global__ __launch_bounds__(C::THREADS) void gemm_bf16_kernel(const bf16_t* __r
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
 
-    gemm_epilogue<C, ACT, LAST>(acc, lds, bias, out, ldo, n_valid, t_valid, n0, t0, tile_n, wn, wt, lane, tid, part_min, part_idx, part_ld);
+    if (VAR & 128) {  // ablation: no epilogue (a reduction over ALL accumulators keeps every MFMA alive)
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < C::MI; ++i)
+#pragma unroll
+            for (int j = 0; j < C::MJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    sum += acc[i][j][r];
+        if (sum == 123.456f)
+            ((float*)out)[tid] = sum;
+    }
+    else if (VAR & 256)
+        gemm_epilogue<C, ACT, LAST, true>(acc, lds, s_bias, out, ldo, n_valid, t_valid, n0, t0, tile_n, wn, wt, lane, tid, part_min, part_idx, part_ld);
+    else
+        gemm_epilogue<C, ACT, LAST>(acc, lds, s_bias, out, ldo, n_valid, t_valid, n0, t0, tile_n, wn, wt, lane, tid, part_min, part_idx, part_ld);
+    __syncthreads();  // LDS (stages / arg-min scratch) is reused by the next tile
+  }
 }
 
 // combines the per-tile arg-min partials: best state per frame, per-state counts, sum of best scores
@@ -527,6 +619,7 @@ struct amx_ffnn {
     float*    cur_part_min = nullptr;
     unsigned* cur_part_idx = nullptr;
     int       cur_ntn      = 0;
+    int    gemm_persistent = 1;
     int    gemm_var       = 0;   // schedule variant bits: 1 = register double-buffered fragments, 2 = setprio, 4 = late stage issue
     int    gemm_cfg       = -1;  // -1 = automatic; index into the bf16 tile configurations (launch_bf16_cfg)
     size_t elt() const { return precision == AMX_PREC_BF16 ? 2 : 4; }
@@ -558,6 +651,7 @@ int ensure_workspace(amx_ffnn* h, int Tpad) {
 // tile configurations of the bf16 GEMM, selected at run time (AMX_GEMM_CFG overrides for experiments)
 using CfgA = amx::GemmCfg<128, 128, 2, 2, 2>;  //  64 KB LDS, 2 workgroups per CU
 using CfgC = amx::GemmCfg<256, 256, 2, 4, 2>;  // 128 KB LDS, 8 waves, wave tile 128x64
+// measured and dropped: GemmCfg<256,256,2,4,4,32> (4 stages of BK=32, three K-tiles in flight): 800 TF
 // measured and dropped: 256x128x64 3-stage (753 TF), 256x256 with 64x128 wave tiles (973 TF) vs CfgC (1000 TF), CfgA (870 TF)
 
 template<class C, int ACT, bool LAST, int VAR>
@@ -566,9 +660,17 @@ void launch_bf16v(amx_ffnn* h, int l, const void* x, int ldx, void* out, int ldo
     auto      k   = amx::gemm_bf16_kernel<C, ACT, LAST, VAR>;
     // 128x128 tiles (2 workgroups per CU) profit from the 2x4 super-tile order, 256x256 tiles do not
     const int gt = h->group_t >= 0 ? h->group_t : (C::BN == 128 ? 2 : 0), gn = h->group_n >= 0 ? h->group_n : (C::BN == 128 ? 4 : 0);
-    hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-    hipLaunchKernelGGL(k, dim3(ntn * ntt), dim3(C::THREADS), C::LDS_BYTES, h->ctx->stream, (const amx::bf16_t*)h->d_W[l],
-                       (const amx::bf16_t*)x, h->d_bias[l], out, h->Kpad[l], ldx, ldo, h->out[l], T, ntn, gt, gn,
+    constexpr int lds_bytes = amx::gemm_scratch_bytes<C, LAST>() + C::BN * 4;
+    static_assert(lds_bytes <= 160 * 1024, "LDS budget");
+    hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    const int per_cu = std::max(1, (160 * 1024) / lds_bytes);
+    int       grid   = std::min(ntn * ntt, per_cu * std::max(h->ctx->n_cu, 8));
+    if (grid >= 8)
+        grid &= ~7;  // keep blockIdx % 8 == tile index % 8 for every stride step
+    if (h->gemm_persistent == 0)
+        grid = ntn * ntt;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(C::THREADS), lds_bytes, h->ctx->stream, (const amx::bf16_t*)h->d_W[l],
+                       (const amx::bf16_t*)x, h->d_bias[l], out, h->Kpad[l], ldx, ldo, h->out[l], T, ntn, ntn * ntt, gt, gn,
                        LAST ? h->cur_part_min : nullptr, LAST ? h->cur_part_idx : nullptr, Tpad);
     if (LAST)
         h->cur_ntn = ntn;
@@ -576,10 +678,11 @@ void launch_bf16v(amx_ffnn* h, int l, const void* x, int ldx, void* out, int ldo
 
 template<class C, int ACT, bool LAST>
 void launch_bf16(amx_ffnn* h, int l, const void* x, int ldx, void* out, int ldo, int T, int Tpad) {
-    // Measured on MI355X and NOT instantiated: register double-buffered fragments, pinned
-    // read/MFMA interleave (sched_barrier), s_setprio around the MFMA cluster, late stage issue -- all within +-3 %
-    // of variant 0; a phase-split kernel (two wave groups half a phase apart, register or LDS-DMA staging) tied it.
-    // Ablation of the output layer (1.52 ms): without MFMAs 1.36 ms, without global loads 1.27 ms, neither 0.80 ms.
+    // VAR bits are experiment switches; only variant 0 is instantiated in the shipped library.
+    //   1 register double-buffered fragments, 2 s_setprio around the MFMA cluster, 4 late stage issue, 32 pinned
+    //   read/MFMA interleave: all within +-3 % of variant 0.  Ablations of the output layer (1.37 ms): 8 no MFMA,
+    //   16 no global loads, 64 streaming only 1.31 ms, 128 no epilogue 0.98 ms, 256 epilogue without global stores
+    //   1.13 ms.  A phase-split kernel (two wave groups half a phase apart) and a 4-stage BK=32 pipeline tied or lost.
         launch_bf16v<C, ACT, LAST, 0>(h, l, x, ldx, out, ldo, T, Tpad);
 }
 
@@ -665,6 +768,8 @@ int amx_ffnn_create(amx_ctx* ctx, const amx_ffnn_model* m, amx_ffnn** out) {
     h->precision = m->precision;
     if (const char* e = getenv("AMX_GEMM_CFG"))
         h->gemm_cfg = atoi(e);
+    if (const char* e = getenv("AMX_GEMM_PERSISTENT"))
+        h->gemm_persistent = atoi(e);
     if (const char* e = getenv("AMX_GEMM_VAR"))
         h->gemm_var = atoi(e);
     if (const char* e = getenv("AMX_GEMM_GROUP"))
