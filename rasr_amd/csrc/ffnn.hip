@@ -651,6 +651,7 @@ int ensure_workspace(amx_ffnn* h, int Tpad) {
 // tile configurations of the bf16 GEMM, selected at run time (AMX_GEMM_CFG overrides for experiments)
 using CfgA = amx::GemmCfg<128, 128, 2, 2, 2>;  //  64 KB LDS, 2 workgroups per CU
 using CfgC = amx::GemmCfg<256, 256, 2, 4, 2>;  // 128 KB LDS, 8 waves, wave tile 128x64
+using CfgS = amx::GemmCfg<128, 64, 2, 2, 2>;   //  48 KB LDS, 3 workgroups per CU: small batches (fills the CUs)
 // measured and dropped: GemmCfg<256,256,2,4,4,32> (4 stages of BK=32, three K-tiles in flight): 800 TF
 // measured and dropped: 256x128x64 3-stage (753 TF), 256x256 with 64x128 wave tiles (973 TF) vs CfgC (1000 TF), CfgA (870 TF)
 
@@ -690,10 +691,17 @@ template<int ACT, bool LAST>
 void launch_bf16_cfg(amx_ffnn* h, int l, const void* x, int ldx, void* out, int ldo, int T, int Tpad) {
     // default: 256x256 tiles when they still give >= 2 tiles per CU, else 128x128 (small batches)
     int cfg = h->gemm_cfg;
-    if (cfg < 0)
-        cfg = ((long)(h->Npad[l] / 256) * (Tpad / 256) >= 2L * h->ctx->n_cu) ? 2 : 0;
+    if (cfg < 0) {
+        if ((long)(h->Npad[l] / 256) * (Tpad / 256) >= 2L * h->ctx->n_cu)
+            cfg = 2;
+        else if ((long)(h->Npad[l] / 128) * (Tpad / 128) >= (long)h->ctx->n_cu)
+            cfg = 0;
+        else
+            cfg = 3;
+    }
     switch (cfg) {
         case 2: launch_bf16<CfgC, ACT, LAST>(h, l, x, ldx, out, ldo, T, Tpad); break;
+        case 3: launch_bf16<CfgS, ACT, LAST>(h, l, x, ldx, out, ldo, T, Tpad); break;
         default: launch_bf16<CfgA, ACT, LAST>(h, l, x, ldx, out, ldo, T, Tpad); break;
     }
 }

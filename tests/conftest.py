@@ -10,6 +10,12 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+    # a clean checkout has no built artefacts (they are git-ignored): build them once, like __graft_entry__.build()
+    lib = os.path.join(ROOT, "rasr_amd", "librasr_amd.so")
+    orc = os.path.join(ROOT, "oracle", "liboracle.so")
+    if not (os.path.exists(lib) and os.path.exists(orc)):
+        import __graft_entry__
+        __graft_entry__.build()
 
 
 def _has_gpu():
