@@ -9,6 +9,8 @@ as "scored" when its 10 000 emission scores exist in HBM.  Other workloads time 
   --workload gmm       config 3  (CART-style instance: 10 000 states x 16 densities, pooled covariance, batch 256)
   --workload gmm-tied  config 3  (tied-mixture instance: 4096 shared densities, 10 000 states)
   --workload nn        config 4  (6x2048 FFNN, batch 1024)
+  --workload gmm-train config 5, GMM leg: MFCC -> 10 000 x 16 GMM scoring -> Viterbi statistics (f64 weights, sum x, sum x^2;
+                       a 104 MB accumulator) -> ONE all-reduce of the accumulator per epoch
 
 Launch: `python bench.py` (1 GPU) or `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`.
 Utterances shard across ranks (weak scaling: every rank owns a full batch); the only collective is ONE all-reduce of
@@ -47,7 +49,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="pipeline", choices=["pipeline", "mfcc", "gmm", "gmm-tied", "nn"])
+    ap.add_argument("--workload", default="pipeline", choices=["pipeline", "mfcc", "gmm", "gmm-tied", "nn", "gmm-train"])
     ap.add_argument("--utterances", type=int, default=64, help="utterances per step and rank (pipeline / mfcc)")
     ap.add_argument("--utt-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -156,6 +158,70 @@ class Pipeline:
         if n:
             gbs = self.F * 800.0 / (ms * 1e-3) / 1e9
             out["mfcc"].update(algorithmic_GBps=round(gbs, 1), frac_hbm=round(gbs / HBM_PEAK_GBS, 4))
+        return out
+
+
+class GmmTrain:
+    """config 5, GMM leg: audio -> MFCC-40 -> CART GMM (10 000 states x 16 densities) -> best state / density -> accumulators"""
+
+    CHUNK = 8192
+
+    def __init__(self, ctx, args, rank):
+        import torch
+
+        import rasr_amd
+        from tests import synth
+        self.ctx = ctx
+        self.fe = rasr_amd.MfccExtractor(ctx, nr_cepstrum_coefficients=40, filter_width=138.0)
+        pcm, off = make_batch(args.utterances, args.utt_seconds, seed=9 + rank)
+        self.plan = self.fe.plan(off)
+        self.F = self.plan.total_frames
+        self.pcm = torch.from_numpy(pcm).cuda()
+        self.ceps = torch.empty((self.F, 40), dtype=torch.float32, device="cuda")
+        model = synth.gmm_cart(10000, 16, 16, 40, seed=5, pooled=True)
+        self.nk = int(model["mix_offsets"][-1])
+        self.sc = rasr_amd.GmmFeatureScorer(ctx, model)
+        self.M = 10000
+        self.scores = torch.empty((self.CHUNK, self.M), dtype=torch.float32, device="cuda")
+        self.bestd = torch.empty((self.CHUNK, self.M), dtype=torch.int32, device="cuda")
+        self.state = torch.empty((self.CHUNK,), dtype=torch.int32, device="cuda")
+        self.counts = torch.zeros((self.M,), dtype=torch.int64, device="cuda")
+        self.score_sum = torch.zeros((1,), dtype=torch.float64, device="cuda")
+        self.acc = torch.zeros((self.sc.accumulator_size(),), dtype=torch.float64, device="cuda")
+        self.units = self.F
+
+    def step(self):
+        self.fe.run_plan(self.plan, self.pcm, self.ceps)
+        for t0 in range(0, self.F, self.CHUNK):
+            T = min(self.CHUNK, self.F - t0)
+            x = self.ceps[t0:]
+            self.sc.score_dev(x, T, self.scores, self.bestd)
+            self.ctx.stats_accumulate(self.scores, T, self.M, self.state, self.counts, self.score_sum)
+            self.sc.accumulate_dev(x, T, self.state, self.bestd, self.M, self.acc)
+
+    def epoch_reduce(self, world):
+        if world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.acc)          # 8*(sum K + n_mean*(1+d) + n_cov*(1+d)) bytes = 53.8 MB here
+            dist.all_reduce(self.counts)
+            dist.all_reduce(self.score_sum)
+
+    def roofline(self):
+        ms, n = self.ctx.profile_get("gmm")
+        if n == 0:
+            return None
+        ops = 4.0 * self.nk * 40 * self.CHUNK
+        ach = ops / (ms * 1e-3) / 1e12
+        return dict(bound="mfma", note="f32 VALU kernel priced against the f32 vector peak (= f32 MFMA peak)",
+                    kernel="gmm_direct_kernel<40,MaxState>", achieved=round(ach, 3), peak=FP32_TFLOPS, unit="TFLOP/s",
+                    frac=round(ach / FP32_TFLOPS, 4), traffic=None, avg_launch_ms=round(ms, 4), launches=n, flops_per_launch=ops)
+
+    def stage_report(self):
+        out = {"accumulator_bytes": int(self.acc.numel() * 8)}
+        for k in ("mfcc", "gmm", "stats", "gmm_accumulate"):
+            ms, n = self.ctx.profile_get(k)
+            if n:
+                out[k] = dict(avg_ms=round(ms, 4), launches=n)
         return out
 
 
@@ -371,9 +437,9 @@ def cpu_baseline(workload):
             reps += 1
         res["nn"] = (T * reps, time.perf_counter() - t0)
         notes.append("NN: numpy/OpenBLAS sgemm batch %d, %d BLAS threads" % (T, nthreads))
-    if workload in ("gmm", "gmm-tied"):
+    if workload in ("gmm", "gmm-tied", "gmm-train"):
         from oracle import OracleGmm
-        if workload == "gmm":
+        if workload in ("gmm", "gmm-train"):
             model = synth.gmm_cart(10000, 16, 16, 40, seed=5, pooled=True)
             T = 16
         else:
@@ -388,7 +454,7 @@ def cpu_baseline(workload):
     # frames/s of the whole CPU job = 1 / sum(stage seconds per frame)
     spf = sum(dt / fr for fr, dt in res.values())
     detail = ", ".join("%s %d frames in %.2fs" % (k, fr, dt) for k, (fr, dt) in res.items())
-    if workload in ("gmm", "gmm-tied"):
+    if workload in ("gmm", "gmm-tied", "gmm-train"):
         notes.append("oracle diagonal-maximum loop, 1 thread")
     return dict(value=round(1.0 / spf, 2), unit="frames/s", cores=cores, kind="port", sample=detail + " (" + "; ".join(notes) + ")")
 
@@ -408,6 +474,8 @@ def main():
             job.nn_precision = args.precision
         elif args.workload == "mfcc":
             job = MfccOnly(ctx, args, rank)
+        elif args.workload == "gmm-train":
+            job = GmmTrain(ctx, args, rank)
         elif args.workload in ("gmm", "gmm-tied"):
             job = GmmOnly(ctx, args, rank, tied=args.workload == "gmm-tied")
         else:
@@ -437,7 +505,9 @@ def main():
                  "mfcc": "cfg2: batched MFCC-40 on 1000 utterances (5-15 s)",
                  "gmm": "cfg3-cart: 10000 states x 16 densities, d=40, pooled covariance, batch 256, diagonal-maximum",
                  "gmm-tied": "cfg3-tied: 4096 shared densities x 10000 states, d=40, batch 256, diagonal-maximum",
-                 "nn": "cfg4: FFNN 440-6x2048-10000, batch 1024"}
+                 "nn": "cfg4: FFNN 440-6x2048-10000, batch 1024",
+                 "gmm-train": "cfg5 GMM leg: MFCC-40 -> 10000x16 GMM (diagonal-maximum) -> Viterbi accumulators (f64) ; "
+                              "%d utterances x %.0f s per step and rank" % (args.utterances, args.utt_seconds)}
         line = {"metric": "acoustic frames scored/sec (1e4-state AM)", "value": round(value, 1), "unit": "frames/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

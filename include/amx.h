@@ -165,6 +165,17 @@ int amx_gmm_tables(const amx_gmm* h, float* minus2_log_weights, float* inv_sqrt_
 int amx_gmm_score(amx_gmm* h, int mode, const float* feats_host, int T, float* scores_host, uint32_t* best_density_host);
 int amx_gmm_score_dev(amx_gmm* h, int mode, const float* feats_dev, int T, float* scores_dev, uint32_t* best_density_dev);
 
+/* Viterbi training statistics of Mm::AbstractMixtureSetEstimator::accumulate (Mm/AbstractMixtureSetEstimator.cc:117-125,
+ * Mm/GaussDensityEstimator.hh:152-208): frame t, aligned to mixture_dev[t], adds 1 to the weight of its best density
+ * (best_density_dev[t * best_density_ld + mixture] as written by amx_gmm_score_dev, or best_density_dev[t] when
+ * best_density_ld == 0), x to that density's mean accumulator and x*x to its covariance accumulator, all in f64.
+ * acc_dev is ONE flat f64 buffer -- [sum K_m weights][n_mean weights][n_mean x dim sums][n_cov weights][n_cov x dim sums],
+ * amx_gmm_accumulator_size() doubles -- so that data-parallel ranks combine their statistics with a single all-reduce
+ * (the reference combines per-partition accumulator files offline, Tools/AcousticModelTrainer/AcousticModelTrainer.cc:317-325). */
+long amx_gmm_accumulator_size(const amx_gmm* h);
+int  amx_gmm_accumulate_dev(amx_gmm* h, const float* feats_dev, int T, const uint32_t* mixture_dev,
+                            const uint32_t* best_density_dev, int best_density_ld, double* acc_dev);
+
 /* ------------------------------------------------------------------ mixture-set text files (.pms) */
 
 /* Reader / writer of RASR's text mixture-set format, "#Version: 2.0" (Mm/MixtureSet.cc:141-216,

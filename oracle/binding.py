@@ -97,6 +97,9 @@ def Oracle():
     L.orc_gmm_score.argtypes = [C.c_void_p, C.c_int, f32p, C.c_int, f32p, C.c_void_p]
     L.orc_gmm_score_batch_float.restype = C.c_int
     L.orc_gmm_score_batch_float.argtypes = [C.c_void_p, f64p, f32p, f32p, C.c_int, f32p]
+    L.orc_gmm_accumulator_size.restype = C.c_long
+    L.orc_gmm_accumulator_size.argtypes = [C.c_void_p]
+    L.orc_gmm_accumulate.argtypes = [C.c_void_p, f32p, C.c_int, u32p, u32p, f64p]
     L.orc_ffnn_score.argtypes = [C.POINTER(_FfnnModel), f32p, C.c_int, f32p, C.c_int]
     _lib = L
     return L
@@ -233,6 +236,17 @@ class OracleGmm:
         self.L.orc_gmm_score(self.h, mode, feats.reshape(-1), T, sc.reshape(-1),
                              best.ctypes.data if want_best else None)
         return (sc, best) if want_best else sc
+
+    def accumulator_size(self):
+        return int(self.L.orc_gmm_accumulator_size(self.h))
+
+    def accumulate(self, feats, mixture, density_in_mixture, acc=None):
+        feats = np.ascontiguousarray(feats, dtype=np.float32)
+        if acc is None:
+            acc = np.zeros(self.accumulator_size(), np.float64)
+        self.L.orc_gmm_accumulate(self.h, feats.reshape(-1), feats.shape[0], np.ascontiguousarray(mixture, dtype=np.uint32),
+                                  np.ascontiguousarray(density_in_mixture, dtype=np.uint32), acc)
+        return acc
 
     def score_batch_float(self, feats):
         feats = np.ascontiguousarray(feats, dtype=np.float32)

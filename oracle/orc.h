@@ -116,6 +116,11 @@ void orc_gmm_score(const orc_gmm* h, int mode, const float* feats, int T, float*
 int orc_gmm_score_batch_float(const orc_gmm* h, const double* log_weight, const float* variances,
                               const float* feats, int T, float* scores);
 
+/* Viterbi training statistics: see orc_score.c for the accumulator layout */
+long orc_gmm_accumulator_size(const orc_gmm* h);
+void orc_gmm_accumulate(const orc_gmm* h, const float* feats, int T, const uint32_t* mixture,
+                        const uint32_t* density_in_mixture, double* acc);
+
 /* ---------------------------------------------------------------- FFNN forward */
 
 enum { ORC_ACT_NONE = 0, ORC_ACT_RELU = 1, ORC_ACT_SIGMOID = 2, ORC_ACT_TANH = 3 };

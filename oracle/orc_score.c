@@ -239,6 +239,39 @@ int orc_gmm_score_batch_float(const orc_gmm* h, const double* log_weight, const 
     return 0;
 }
 
+/* ------------------------------------------------------------------ Viterbi accumulation (training statistics)
+ * Mm::AbstractMixtureSetEstimator::accumulate(mixture, x) with viterbi_ = true
+ * (Mm/AbstractMixtureSetEstimator.cc:117-125): the density with the best score of the aligned mixture gets
+ * weight += 1 (Mm::MixtureEstimator), its mean accumulator sum += x, weight += 1 (std::plus<f64>), its covariance
+ * accumulator sum += x*x, weight += 1 (plusSquare<f64>) (Mm/GaussDensityEstimator.hh:152-208, Mm/VectorAccumulator.hh:60-63).
+ * Layout of acc (f64): [nk mixture-density weights][n_mean weights][n_mean x dim sums][n_cov weights][n_cov x dim sums]. */
+long orc_gmm_accumulator_size(const orc_gmm* h) {
+    return (long)h->mix_off[h->n_mix] + (long)h->n_mean * (1 + h->dim) + (long)h->n_cov * (1 + h->dim);
+}
+
+void orc_gmm_accumulate(const orc_gmm* h, const float* feats, int T, const uint32_t* mixture, const uint32_t* density_in_mixture,
+                        double* acc) {
+    const size_t nk = h->mix_off[h->n_mix];
+    double*      mw = acc + nk;
+    double*      ms = mw + h->n_mean;
+    double*      cw = ms + (size_t)h->n_mean * h->dim;
+    double*      cs = cw + h->n_cov;
+    for (int t = 0; t < T; ++t) {
+        const uint32_t k  = h->mix_off[mixture[t]] + density_in_mixture[t];
+        const uint32_t d  = h->dens_index[k];
+        const uint32_t mi = h->dens_mean[d], ci = h->dens_cov[d];
+        const float*   x  = feats + (size_t)t * h->dim;
+        acc[k] += 1;
+        mw[mi] += 1;
+        cw[ci] += 1;
+        for (int i = 0; i < h->dim; ++i) {
+            double y = x[i];
+            ms[(size_t)mi * h->dim + i] = ms[(size_t)mi * h->dim + i] + y;
+            cs[(size_t)ci * h->dim + i] = cs[(size_t)ci * h->dim + i] + y * y;
+        }
+    }
+}
+
 /* ------------------------------------------------------------------ FFNN forward */
 
 static float orc_act(float v, int act) {

@@ -231,6 +231,14 @@ class GmmFeatureScorer:
     def score_dev(self, feats_dev, T, scores_dev, best_dev=None):
         _lib.check(self.L.amx_gmm_score_dev(self.h, self.mode, _ptr(feats_dev), T, _ptr(scores_dev), _ptr(best_dev)))
 
+    def accumulator_size(self):
+        return int(self.L.amx_gmm_accumulator_size(self.h))
+
+    def accumulate_dev(self, feats_dev, T, mixture_dev, best_density_dev, best_density_ld, acc_dev):
+        """Viterbi statistics (weights, sum x, sum x^2 in f64) into the flat accumulator acc_dev"""
+        _lib.check(self.L.amx_gmm_accumulate_dev(self.h, _ptr(feats_dev), T, _ptr(mixture_dev), _ptr(best_density_dev),
+                                                 best_density_ld, _ptr(acc_dev)))
+
 
 class NnBatchFeatureScorer:
     """Nn::BatchFeatureScorer: Ws[l] is [out, in] (RASR weights_[0] is the same memory, [in x out] col-major)."""

@@ -255,6 +255,52 @@ __global__ __launch_bounds__(256) void gmm_batch_float_kernel(const float* __res
     }
 }
 
+// ---- Viterbi training statistics (Mm/AbstractMixtureSetEstimator.cc:117-125): one wavefront per frame, lane = dim.
+// The density chosen for frame t is best_density[t][mixture[t]] (what amx_gmm_score_dev wrote).  Sums are f64 like
+// Mm::Sum; with a pooled covariance every frame hits the same row, so each wave first sums its frames in
+// registers and issues one atomic per dimension at the end.
+__global__ __launch_bounds__(256) void gmm_accumulate_kernel(const float* __restrict__ feats, const uint32_t* __restrict__ mixture,
+                                                            const uint32_t* __restrict__ best, int best_ld, int T, int dim,
+                                                            const uint32_t* __restrict__ mix_off, const uint32_t* __restrict__ k_dens,
+                                                            const uint32_t* __restrict__ d_mean, const uint32_t* __restrict__ d_cov,
+                                                            double* __restrict__ acc, long long off_mw, long long off_ms,
+                                                            long long off_cw, long long off_cs, int pooled) {
+    const int lane = threadIdx.x & 63;
+    const int wid  = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nw   = gridDim.x * 4;
+    // pooled covariance: private partial sums for up to 4 x 64 dims
+    double pc[4]  = {0, 0, 0, 0};
+    double pcw    = 0;
+    for (int t = wid; t < T; t += nw) {
+        const uint32_t m  = mixture[t];
+        const uint32_t kk = best_ld > 0 ? best[(size_t)t * best_ld + m] : best[t];
+        const uint32_t k  = mix_off[m] + kk;
+        const uint32_t d  = k_dens[k];
+        const uint32_t mi = d_mean[d], ci = d_cov[d];
+        if (lane == 0) {
+            atomicAdd(&acc[k], 1.0);
+            atomicAdd(&acc[off_mw + mi], 1.0);
+            if (!pooled)
+                atomicAdd(&acc[off_cw + ci], 1.0);
+        }
+        pcw += 1.0;
+        for (int i = lane, c = 0; i < dim; i += 64, ++c) {
+            const double y = (double)feats[(size_t)t * dim + i];
+            atomicAdd(&acc[off_ms + (long long)mi * dim + i], y);
+            if (pooled && c < 4)
+                pc[c] += y * y;
+            else
+                atomicAdd(&acc[off_cs + (long long)ci * dim + i], y * y);
+        }
+    }
+    if (pooled) {
+        for (int i = lane, c = 0; i < dim && c < 4; i += 64, ++c)
+            atomicAdd(&acc[off_cs + i], pc[c]);
+        if (lane == 0 && pcw != 0.0)
+            atomicAdd(&acc[off_cw], pcw);
+    }
+}
+
 // ---- two-stage path for tied models
 struct GmmDistParams {
     const float* __restrict__ feats;     // [T x dim] (chunk)
@@ -855,6 +901,31 @@ int amx_gmm_score_dev(amx_gmm* h, int mode, const float* feats_dev, int T, float
                                cp.best, cp.mix_off, cp.k_dens, cp.k_c64, cp.k_c32, cd);
         AMX_HIP(hipGetLastError());
     }
+    return AMX_OK;
+}
+
+long amx_gmm_accumulator_size(const amx_gmm* h) {
+    return h ? (long)h->nk + (long)h->n_mean * (1 + h->dim) + (long)h->n_cov * (1 + h->dim) : 0;
+}
+
+int amx_gmm_accumulate_dev(amx_gmm* h, const float* feats_dev, int T, const uint32_t* mixture_dev, const uint32_t* best_density_dev,
+                           int best_density_ld, double* acc_dev) {
+    AMX_REQUIRE(h, AMX_ERR_INVALID, "amx_gmm_accumulate_dev: NULL handle");
+    AMX_REQUIRE(h->ctx, AMX_ERR_STATE, "amx_gmm_accumulate_dev: host-only handle (created without a context)");
+    AMX_REQUIRE(T >= 0 && (best_density_ld == 0 || best_density_ld >= h->n_mix), AMX_ERR_INVALID, "amx_gmm_accumulate_dev: bad shape");
+    if (T == 0)
+        return AMX_OK;
+    AMX_REQUIRE(feats_dev && mixture_dev && best_density_dev && acc_dev, AMX_ERR_INVALID, "amx_gmm_accumulate_dev: NULL buffer");
+    AMX_HIP(hipSetDevice(h->ctx->device));
+    const long long off_mw = (long long)h->nk, off_ms = off_mw + h->n_mean, off_cw = off_ms + (long long)h->n_mean * h->dim,
+                    off_cs = off_cw + h->n_cov;
+    const int              pooled = (h->n_cov == 1 && h->dim <= 256) ? 1 : 0;
+    const int              blocks = (int)std::min<long>(((long)T + 3) / 4, 2048);
+    amx::ScopedKernelTimer timer(h->ctx, "gmm_accumulate");
+    hipLaunchKernelGGL(amx::gmm_accumulate_kernel, dim3(blocks), dim3(256), 0, h->ctx->stream, feats_dev, mixture_dev, best_density_dev,
+                       best_density_ld, T, h->dim, h->d_mix_off, h->d_k_dens, h->d_d_mean, h->d_d_cov, acc_dev, off_mw, off_ms, off_cw,
+                       off_cs, pooled);
+    AMX_HIP(hipGetLastError());
     return AMX_OK;
 }
 

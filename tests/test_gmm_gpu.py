@@ -134,3 +134,45 @@ def test_batch_float_scorer_errors(ctx):
     with pytest.raises(rasr_amd.AmxError) as e:
         s.score(feats(4, 40, 2), want_best=False)
     assert e.value.status == -1 and "globally pooled covariance" in str(e.value)
+
+
+@pytest.mark.parametrize("pooled", [True, False])
+def test_viterbi_accumulators(ctx, pooled):
+    """GMM training statistics: f64 sums equal the oracle's sequential accumulation up to summation order (1e-12),
+    weights exactly; accumulating twice doubles everything (buffers add, which is what the epoch all-reduce relies on)."""
+    import torch
+
+    import rasr_amd
+    from oracle import OracleGmm
+    model = synth.gmm_cart(50, 1, 6, 40, seed=60, pooled=pooled)
+    x = feats(3000, 40, 61)
+    sc = rasr_amd.GmmFeatureScorer(ctx, model)
+    o = OracleGmm(model)
+    xd = torch.from_numpy(x).cuda()
+    scores = torch.empty((3000, 50), dtype=torch.float32, device="cuda")
+    best = torch.empty((3000, 50), dtype=torch.int32, device="cuda")
+    ctx.use_torch_stream()
+    sc.score_dev(xd, 3000, scores, best)
+    mix = scores.argmin(dim=1).to(torch.int32)           # Viterbi "alignment" = best state per frame
+    acc = torch.zeros(sc.accumulator_size(), dtype=torch.float64, device="cuda")
+    sc.accumulate_dev(xd, 3000, mix, best, 50, acc)
+    torch.cuda.synchronize()
+    got = acc.cpu().numpy()
+    osc, obest = o.score(x)
+    omix = osc.argmin(axis=1).astype(np.uint32)
+    assert np.array_equal(mix.cpu().numpy().astype(np.uint32), omix)
+    want = o.accumulate(x, omix, obest[np.arange(3000), omix])
+    assert sc.accumulator_size() == o.accumulator_size() == len(want)
+    nk, nm, nc = int(model["mix_offsets"][-1]), model["means"].shape[0], model["variances"].shape[0]
+    assert np.array_equal(got[:nk], want[:nk]) and got[:nk].sum() == 3000
+    assert np.array_equal(got[nk:nk + nm], want[nk:nk + nm])
+    assert np.allclose(got, want, rtol=1e-12, atol=1e-9)
+    sc.accumulate_dev(xd, 3000, mix, best, 50, acc)
+    torch.cuda.synchronize()
+    assert np.allclose(acc.cpu().numpy(), 2 * want, rtol=1e-12, atol=1e-9)
+    # per-frame density list (best_density_ld == 0)
+    acc2 = torch.zeros_like(acc)
+    chosen = best[torch.arange(3000, device="cuda"), mix.long()].contiguous()
+    sc.accumulate_dev(xd, 3000, mix, chosen, 0, acc2)
+    torch.cuda.synchronize()
+    assert np.allclose(acc2.cpu().numpy(), want, rtol=1e-12, atol=1e-9)
