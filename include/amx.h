@@ -219,6 +219,45 @@ int amx_ffnn_score_dev(amx_ffnn* h, const float* feats_dev, int feats_stride, in
 int amx_ffnn_score_stats_dev(amx_ffnn* h, const float* feats_dev, int feats_stride, int T, float* scores_dev,
                              uint32_t* best_state_dev, unsigned long long* state_counts_dev, double* score_sum_dev);
 
+/* ------------------------------------------------------------------ feature caches */
+
+/* Core::FileArchive, the single-file "SP_ARC1" container RASR keeps feature caches, alignments and lattices in
+ * (src/Core/FileArchive.cc:27-85 format, :165-225 open, :300-458 table / scan, :504-563 write; compression
+ * src/Core/Archive.cc:52-222).  Host-side IO, no device involved.  AMX_ARCHIVE_WRITE opens read-write and creates the
+ * file if it is missing or empty; an existing entry of the same name is replaced (the reference's
+ * allow-overwrite=true).  amx_archive_close writes the file-info table (FileArchive::~FileArchive); an archive that
+ * was never closed is still readable through the recovery-tag scan.  Directory and bundle archives are not handled. */
+typedef struct amx_archive amx_archive;
+#define AMX_ARCHIVE_READ 0
+#define AMX_ARCHIVE_WRITE 1
+int amx_archive_open(const char* path, int mode, amx_archive** out);
+int amx_archive_close(amx_archive* a);
+int amx_archive_n_files(amx_archive* a);
+/* i-th live entry in archive order; *name stays valid until the archive is modified or closed. */
+int amx_archive_file_info(amx_archive* a, int i, const char** name, uint32_t* size, uint32_t* compressed);
+int amx_archive_has_file(amx_archive* a, const char* name);
+/* Archive::readFile: *data is the uncompressed content, malloc'ed (amx_free). */
+int amx_archive_read_file(amx_archive* a, const char* name, void** data, size_t* len);
+/* Archive::writeFile: compress != 0 stores the gzip member the reference assembles (Archive.cc:162-215). */
+int amx_archive_write_file(amx_archive* a, const char* name, const void* data, size_t len, int compress);
+int amx_archive_remove_file(amx_archive* a, const char* name);
+
+/* One Flow cache entry (= one segment) of vector-f32 packets, as Flow::CacheWriter / CacheReader exchange them
+ * (src/Flow/Cache.cc:47-120, src/Flow/Datatype.cc:28-52, src/Flow/Vector.hh:88-106): blocks of
+ * [string "vector-f32"][u32 n][n x (u32 dim, f32 x dim, f64 start, f64 end)].
+ * feats [n x dim] row-major, times [n x 2] (start, end) -- the layout amx_gmm_score / amx_ffnn_score take.
+ * gather: the node's `gather` parameter (a block holds gather+1 packets; 0xffffffff = one block per segment).
+ * read: *feats / *times are malloc'ed (amx_free), times nullable; entries holding another datatype or vectors of
+ * differing size return AMX_ERR_UNSUPPORTED. */
+int amx_feature_cache_write(amx_archive* a, const char* segment, int n, int dim, const float* feats, const double* times,
+                            unsigned gather, int compress);
+int amx_feature_cache_read(amx_archive* a, const char* segment, int* n, int* dim, float** feats, double** times);
+/* "<segment>.attribs": the Flow::Attributes of the cached stream as the reference's XmlWriter prints them
+ * (src/Flow/Cache.cc:78-85, src/Flow/Attributes.hh:67-70,132-138).  read returns the XML text (amx_free). */
+int amx_feature_cache_write_attributes(amx_archive* a, const char* segment, int n, const char* const* names,
+                                       const char* const* values, int compress);
+int amx_feature_cache_read_attributes(amx_archive* a, const char* segment, char** xml);
+
 /* ------------------------------------------------------------------ NN parameter files and the state prior */
 
 /* Binary Math::Matrix<f32> as RASR writes NN layer parameters ("bin:<base>-f32-layer-<i>.bin",

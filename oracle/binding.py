@@ -134,8 +134,51 @@ def load_ref():
     R.ref_window_frames.restype = C.c_long
     R.ref_window_frames.argtypes = [f32p, C.c_long, C.c_long, C.c_uint, C.c_uint, C.c_double, C.c_long,
                                     C.c_void_p, C.c_void_p, C.c_void_p]
+    R.ref_cache_block_write.restype = C.c_long
+    R.ref_cache_block_write.argtypes = [f32p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_long]
+    R.ref_cache_block_read.restype = C.c_long
+    R.ref_cache_block_read.argtypes = [C.c_char_p, C.c_long, C.c_int, C.c_void_p, C.c_void_p, C.c_long,
+                                       C.POINTER(C.c_long), C.c_char_p, C.c_int]
+    R.ref_attribs_xml.restype = C.c_long
+    R.ref_attribs_xml.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_char_p, C.c_long]
     _ref = R
     return R
+
+
+def ref_cache_block(feats, times):
+    """bytes of one Flow cache block written by the reference's Flow::Vector<f32> / Datatype code (libref)"""
+    R = load_ref()
+    x = np.ascontiguousarray(feats, np.float32)
+    t = np.ascontiguousarray(times, np.float64)
+    cap = x.size * 4 + x.shape[0] * 20 + 64
+    buf = C.create_string_buffer(cap)
+    n = R.ref_cache_block_write(x, t.ctypes.data, x.shape[0], x.shape[1], buf, cap)
+    if n < 0:
+        raise RuntimeError("ref_cache_block_write failed (%d)" % n)
+    return buf.raw[:n]
+
+
+def ref_cache_block_parse(data, dim, max_frames):
+    """parse one block with the reference reader -> (feats, times, consumed bytes, datatype name)"""
+    R = load_ref()
+    x = np.zeros((max_frames, dim), np.float32)
+    t = np.zeros((max_frames, 2), np.float64)
+    used, name = C.c_long(), C.create_string_buffer(64)
+    n = R.ref_cache_block_read(data, len(data), dim, x.ctypes.data, t.ctypes.data, max_frames, C.byref(used), name, 64)
+    if n < 0:
+        raise RuntimeError("ref_cache_block_read failed (%d)" % n)
+    return x[:n], t[:n], used.value, name.value.decode()
+
+
+def ref_attribs_xml(attrs):
+    R = load_ref()
+    names = (C.c_char_p * len(attrs))(*[k.encode() for k in attrs])
+    vals = (C.c_char_p * len(attrs))(*[str(v).encode() for v in attrs.values()])
+    buf = C.create_string_buffer(1 << 16)
+    n = R.ref_attribs_xml(names, vals, len(attrs), buf, 1 << 16)
+    if n < 0:
+        raise RuntimeError("ref_attribs_xml failed")
+    return buf.value.decode()
 
 
 class OracleMfcc:

@@ -10,6 +10,8 @@
 //   Math::{ScalingFunction,MelWarpingCore,AnalyticNesting}  header-only, composed exactly like
 //       Math::AnalyticFunctionFactory::createMelWarpingFunction (AnalyticFunctionFactory.cc:338-341)
 //   Mm::gaussLogNormFactor, Mm::inverseSquareRoot           src/Mm/Utilities.hh:53-91
+//   Flow::Vector<f32>::{read,write}, Flow::Datatype::{read,write}GatheredData, Core::Binary{In,Out}putStream,
+//       Core::XmlWriter          src/Flow/Vector.hh:88-106, src/Flow/Datatype.cc:28-52 (feature-cache payload)
 // No reference header, library or tool is replaced by a stand-in; translation units that need
 // boost / bison / cblas (anything including Core/Configuration.hh) are simply not built.
 #include <Math/AcousticalAnalyticFunctions.hh>
@@ -17,6 +19,10 @@
 #include <Math/SimpleAnalyticFunctions.hh>
 #include <Mm/Utilities.hh>
 #include <Signal/WindowBuffer.hh>
+#include <Core/BinaryStream.hh>
+#include <Core/XmlStream.hh>
+#include <Flow/Vector.hh>
+#include <sstream>
 
 #include <algorithm>
 #include <cstring>
@@ -130,6 +136,75 @@ long ref_window_frames(const float* pcm, long n, long block, unsigned length, un
         emit();
     }
     return nf;
+}
+
+// One Flow cache block as Flow::CacheWriter emits it (src/Flow/Cache.cc:88-93: datatype name, then
+// Datatype::writeGatheredData) for n vector-f32 packets of `dim` floats; times = [n][2] start/end.
+long ref_cache_block_write(const float* feats, const double* times, int n, int dim, unsigned char* out, long cap) {
+    std::vector<Flow::DataPtr<Flow::Data>> data;
+    for (int i = 0; i < n; ++i) {
+        Flow::Vector<f32>* v = new Flow::Vector<f32>(feats + (size_t)i * dim, feats + (size_t)(i + 1) * dim);
+        v->setStartTime(times[2 * i]);
+        v->setEndTime(times[2 * i + 1]);
+        data.push_back(Flow::DataPtr<Flow::Data>(v));
+    }
+    std::ostringstream       os;
+    Core::BinaryOutputStream b(os);
+    const Flow::Datatype*    dt = Flow::Vector<f32>::type();
+    b << dt->name();
+    if (!dt->writeGatheredData(b, data))
+        return -1;
+    std::string s = os.str();
+    if ((long)s.size() > cap)
+        return -(long)s.size();
+    std::memcpy(out, s.data(), s.size());
+    return (long)s.size();
+}
+
+// Parse one block back with the reference reader (src/Flow/Cache.cc:47-58 minus the registry lookup).
+// Returns n packets (all must have `dim` floats) or <0; *consumed = bytes read.
+long ref_cache_block_read(const unsigned char* in, long len, int dim, float* feats, double* times, long cap_frames,
+                          long* consumed, char* type_name, int type_cap) {
+    std::istringstream      is(std::string((const char*)in, (size_t)len));
+    Core::BinaryInputStream b(is);
+    std::string             name;
+    if (!(b >> name))
+        return -1;
+    std::snprintf(type_name, type_cap, "%s", name.c_str());
+    std::vector<Flow::DataPtr<Flow::Data>> data;
+    if (!Flow::Vector<f32>::type()->readGatheredData(b, data))
+        return -2;
+    if ((long)data.size() > cap_frames)
+        return -3;
+    for (size_t i = 0; i < data.size(); ++i) {
+        const Flow::Vector<f32>* v = static_cast<const Flow::Vector<f32>*>(data[i].get());
+        if ((int)v->size() != dim)
+            return -4;
+        std::memcpy(feats + i * dim, v->data(), sizeof(float) * dim);
+        times[2 * i]     = v->startTime();
+        times[2 * i + 1] = v->endTime();
+    }
+    *consumed = (long)is.tellg();
+    return (long)data.size();
+}
+
+// The ".attribs" side file: the statements of Flow::Attributes' XmlWriter operator (src/Flow/Attributes.hh:67-70,
+// 132-138) issued on the reference's Core::XmlWriter (Attributes.hh itself pulls in Core/Configuration.hh -> boost).
+long ref_attribs_xml(const char** names, const char** values, int n, char* out, long cap) {
+    std::ostringstream os;
+    {
+        Core::XmlWriter xw(os);
+        xw << Core::XmlOpen("flow-attributes");
+        for (int i = 0; i < n; ++i)
+            xw << Core::XmlEmpty("flow-attribute") + Core::XmlAttribute("name", std::string(names[i])) +
+                            Core::XmlAttribute("value", std::string(values[i]));
+        xw << Core::XmlClose("flow-attributes");
+    }
+    std::string s = os.str();
+    if ((long)s.size() + 1 > cap)
+        return -(long)s.size();
+    std::memcpy(out, s.c_str(), s.size() + 1);
+    return (long)s.size();
 }
 
 }  // extern "C"

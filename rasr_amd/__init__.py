@@ -8,8 +8,10 @@ same reference interfaces for tests and benchmarks:
   MfccExtractor        mfcc.flow network (Tools/FeatureExtraction/share/mfcc.flow)
   GmmFeatureScorer     Mm::FeatureScorer over a Mm::MixtureSet (diagonal-maximum / diagonal-sum)
   NnBatchFeatureScorer Nn::BatchFeatureScorer (nn-batch-feature-scorer)
+  FileArchive          Core::FileArchive + Flow cache entries (feature caches between jobs; host IO)
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -17,7 +19,7 @@ from . import _lib
 from ._lib import (AMX_ACT_NONE, AMX_ACT_RELU, AMX_ACT_SIGMOID, AMX_ACT_TANH, AMX_GMM_BATCH_FLOAT, AMX_GMM_MAX, AMX_GMM_SUM,  # noqa: F401
                    AMX_PREC_BF16, AMX_PREC_FP32, AmxError, MfccCfg)
 
-__all__ = ["Context", "MfccExtractor", "GmmFeatureScorer", "NnBatchFeatureScorer", "AmxError", "read_pms", "write_pms",
+__all__ = ["Context", "MfccExtractor", "GmmFeatureScorer", "NnBatchFeatureScorer", "FileArchive", "AmxError", "read_pms", "write_pms",
            "read_nn_matrix", "write_nn_matrix", "layer_from_parameters", "prior_from_mixture_set"]
 
 
@@ -318,6 +320,101 @@ def write_pms(model, path):
     keep = []
     st = _gmm_struct(model, 1.0, 1.0, keep)
     _lib.check(_lib.lib().amx_pms_write(C.byref(st), path.encode()))
+
+
+
+class FileArchive:
+    """Core::FileArchive ("SP_ARC1") over the C ABI: a RASR feature cache file.  ``mode`` "r" or "w" (read-write,
+    created when missing).  Mirrors the calls of Flow::Cache / Core::Archive (src/Flow/Cache.cc, src/Core/Archive.hh)."""
+
+    def __init__(self, path, mode="r"):
+        self._h = C.c_void_p()
+        m = {"r": _lib.AMX_ARCHIVE_READ, "w": _lib.AMX_ARCHIVE_WRITE}[mode]
+        _lib.check(_lib.lib().amx_archive_open(os.fsencode(path), m, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            h, self._h = self._h, C.c_void_p()
+            _lib.check(_lib.lib().amx_archive_close(h))
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def files(self):
+        """[(name, size, compressed_size)] in archive order"""
+        L, out = _lib.lib(), []
+        for i in range(L.amx_archive_n_files(self._h)):
+            name, size, comp = C.c_char_p(), C.c_uint32(), C.c_uint32()
+            _lib.check(L.amx_archive_file_info(self._h, i, C.byref(name), C.byref(size), C.byref(comp)))
+            out.append((name.value.decode(), size.value, comp.value))
+        return out
+
+    def __contains__(self, name):
+        return bool(_lib.lib().amx_archive_has_file(self._h, name.encode()))
+
+    def read_file(self, name):
+        L, p, n = _lib.lib(), C.c_void_p(), C.c_size_t()
+        _lib.check(L.amx_archive_read_file(self._h, name.encode(), C.byref(p), C.byref(n)))
+        try:
+            return C.string_at(p, n.value)
+        finally:
+            L.amx_free(p)
+
+    def write_file(self, name, data, compress=False):
+        data = bytes(data)
+        _lib.check(_lib.lib().amx_archive_write_file(self._h, name.encode(), data, len(data), int(compress)))
+
+    def remove_file(self, name):
+        _lib.check(_lib.lib().amx_archive_remove_file(self._h, name.encode()))
+
+    # ---- Flow cache entries (vector-f32 packets)
+    def write_features(self, segment, feats, times, gather=0xFFFFFFFF, compress=False, attributes=None):
+        """feats [n, dim] f32, times [n, 2] f64 (start, end); attributes: optional {name: value} -> '<segment>.attribs'"""
+        x = np.ascontiguousarray(feats, dtype=np.float32)
+        t = np.ascontiguousarray(times, dtype=np.float64)
+        if x.ndim != 2 or t.shape != (x.shape[0], 2):
+            raise ValueError("write_features: feats [n, dim] and times [n, 2] expected")
+        L = _lib.lib()
+        if attributes is not None:
+            names = (C.c_char_p * len(attributes))(*[k.encode() for k in attributes])
+            vals = (C.c_char_p * len(attributes))(*[str(v).encode() for v in attributes.values()])
+            _lib.check(L.amx_feature_cache_write_attributes(self._h, segment.encode(), len(attributes), names, vals, int(compress)))
+        _lib.check(L.amx_feature_cache_write(self._h, segment.encode(), x.shape[0], x.shape[1], x.ctypes.data, t.ctypes.data,
+                                             int(gather), int(compress)))
+
+    def read_features(self, segment):
+        """-> (feats [n, dim] f32, times [n, 2] f64)"""
+        L = _lib.lib()
+        n, d, px, pt = C.c_int(), C.c_int(), C.c_void_p(), C.c_void_p()
+        _lib.check(L.amx_feature_cache_read(self._h, segment.encode(), C.byref(n), C.byref(d), C.byref(px), C.byref(pt)))
+        try:
+            cnt = n.value * d.value
+            x = np.ctypeslib.as_array(C.cast(px, C.POINTER(C.c_float)), shape=(max(cnt, 1),))[:cnt].copy()
+            t = np.ctypeslib.as_array(C.cast(pt, C.POINTER(C.c_double)), shape=(max(2 * n.value, 1),))[:2 * n.value].copy()
+            return x.reshape(n.value, d.value), t.reshape(n.value, 2)
+        finally:
+            L.amx_free(px)
+            L.amx_free(pt)
+
+    def read_attributes(self, segment):
+        """'<segment>.attribs' -> {name: value}"""
+        import xml.etree.ElementTree as ET
+        L, p = _lib.lib(), C.c_void_p()
+        _lib.check(L.amx_feature_cache_read_attributes(self._h, segment.encode(), C.byref(p)))
+        try:
+            root = ET.fromstring(C.string_at(p).decode())
+        finally:
+            L.amx_free(p)
+        return {e.get("name"): e.get("value") for e in root.iter("flow-attribute")}
 
 
 def read_nn_matrix(path):

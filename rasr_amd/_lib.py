@@ -13,6 +13,7 @@ AMX_OK, AMX_ERR_INVALID, AMX_ERR_UNSUPPORTED, AMX_ERR_DEVICE, AMX_ERR_STATE = 0,
 AMX_GMM_MAX, AMX_GMM_SUM, AMX_GMM_BATCH_FLOAT = 0, 1, 2
 AMX_ACT_NONE, AMX_ACT_RELU, AMX_ACT_SIGMOID, AMX_ACT_TANH = 0, 1, 2, 3
 AMX_PREC_FP32, AMX_PREC_BF16 = 0, 1
+AMX_ARCHIVE_READ, AMX_ARCHIVE_WRITE = 0, 1
 
 
 class AmxError(RuntimeError):
@@ -99,6 +100,18 @@ SIGNATURES = {
     "amx_free": (None, [_P]),
     "amx_nn_layer_from_parameters": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P]),
     "amx_prior_from_mixture_set": (C.c_int, [C.POINTER(GmmModel), _P]),
+    "amx_archive_open": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(_P)]),
+    "amx_archive_close": (C.c_int, [_P]),
+    "amx_archive_n_files": (C.c_int, [_P]),
+    "amx_archive_file_info": (C.c_int, [_P, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "amx_archive_has_file": (C.c_int, [_P, C.c_char_p]),
+    "amx_archive_read_file": (C.c_int, [_P, C.c_char_p, C.POINTER(_P), C.POINTER(C.c_size_t)]),
+    "amx_archive_write_file": (C.c_int, [_P, C.c_char_p, _P, C.c_size_t, C.c_int]),
+    "amx_archive_remove_file": (C.c_int, [_P, C.c_char_p]),
+    "amx_feature_cache_write": (C.c_int, [_P, C.c_char_p, C.c_int, C.c_int, _P, _P, C.c_uint, C.c_int]),
+    "amx_feature_cache_read": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(_P), C.POINTER(_P)]),
+    "amx_feature_cache_write_attributes": (C.c_int, [_P, C.c_char_p, C.c_int, _P, _P, C.c_int]),
+    "amx_feature_cache_read_attributes": (C.c_int, [_P, C.c_char_p, C.POINTER(_P)]),
     "amx_stats_accumulate_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P]),
 }
 

@@ -120,3 +120,32 @@ def test_fused_best_state_statistics(ctx, precision, T):
     assert 900 not in want
     assert np.array_equal(counts.cpu().numpy(), np.bincount(want, minlength=1000))
     assert abs(float(ssum[0]) - s.min(axis=1).astype(np.float64).sum()) < 1e-6 * max(1.0, abs(float(ssum[0])))
+
+
+def test_feature_cache_between_front_end_and_scorer(ctx, tmp_path):
+    """feature-extraction job writes a cache, the scoring job reads it: scores are bit-identical to
+    scoring the extractor's output directly, and the cache entry is the reference's block layout."""
+    import rasr_amd
+    from oracle import cache_format as cf
+    fe = rasr_amd.MfccExtractor(ctx, nr_cepstrum_coefficients=16)
+    model = synth.gmm_cart(50, 2, 6, 16, seed=31, pooled=False)
+    gmm = rasr_amd.GmmFeatureScorer(ctx, model)
+    path = str(tmp_path / "mfcc.cache")
+    direct = {}
+    with rasr_amd.FileArchive(path, "w") as a:
+        for s, n in enumerate((16000, 4000, 23456)):
+            pcm = synth.waveform(n, seed=40 + s)
+            x = fe.run(pcm)
+            start = np.array([fe.frame_start_time(i) for i in range(len(x))])
+            end = np.minimum(start + 0.025, n / 16000.0)
+            a.write_features("corpus/rec/%d" % s, x, np.stack([start, end], 1), compress=bool(s % 2),
+                             attributes={"sample-rate": "100", "datatype": "vector-f32"})
+            direct["corpus/rec/%d" % s] = (x, gmm.score(x))
+    with rasr_amd.FileArchive(path) as a:
+        for seg, (x, (sc, best)) in direct.items():
+            rx, rt = a.read_features(seg)
+            assert rx.tobytes() == x.tobytes()
+            assert a.read_file(seg) == cf.entry_payload(x, rt)
+            assert a.read_attributes(seg)["datatype"] == "vector-f32"
+            sc2, best2 = gmm.score(rx)
+            assert np.array_equal(sc2.view(np.uint32), sc.view(np.uint32)) and np.array_equal(best2, best)
