@@ -37,6 +37,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef unsigned short                              bf16_t;
 
 typedef float  f32x2 __attribute__((ext_vector_type(2)));
+typedef float  f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 // two f32 -> packed bf16 (round to nearest even); lowers to one v_cvt_pk_bf16_f32 on gfx950
@@ -273,6 +274,12 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[C::MI][C::MJ], char*
     }
 }
 
+// experiment hooks (tools/gemm_probe.hip only; the library instantiates VAR = 0 and never touches them):
+//   VAR & 512  per-tile time stamps  g_gemm_trace[(block * 64 + step) * 4 + {start, k-loop end, epilogue end, XCC id}]
+//   VAR & 1024 the workgroups of one XCD start every tile together (bounded spin on g_gemm_sync[xcd * 64 + step])
+__device__ unsigned long long* g_gemm_trace = nullptr;
+__device__ unsigned*           g_gemm_sync  = nullptr;
+
 template<class C, int ACT, bool LAST, int VAR>
 __global__ __launch_bounds__(C::THREADS) void gemm_bf16_kernel(const bf16_t* __restrict__ W, const bf16_t* __restrict__ X,
                                                               const float* __restrict__ bias, void* __restrict__ out, int Kpad, int ldx,
@@ -300,11 +307,15 @@ __global__ __launch_bounds__(C::THREADS) void gemm_bf16_kernel(const bf16_t* __r
         const int q = nwg >> 3, r = nwg & 7, xcd = b & 7, k = b >> 3;
         const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;  // bijective for any nwg
         const int n_tiles_t = nwg / n_tiles_n;
-        if (GT > 0 && (n_tiles_n % GN) == 0 && (n_tiles_t % GT) == 0) {
-            const int sg = v / (GT * GN), w = v % (GT * GN);
-            const int sn = n_tiles_n / GN;
-            tile_t       = (sg / sn) * GT + w / GN;
-            tile_n       = (sg % sn) * GN + w % GN;
+        if (GT > 0 && GN > 0) {
+            // bands of GT frame-tiles; inside a band the tiles are walked in column blocks of GN: the 32 tiles an XCD
+            // works on at one time form (up to edge effects) a GT x GN block = GT X panels + GN W panels per K-step
+            const int band  = v / (GT * n_tiles_n), w = v - band * (GT * n_tiles_n);
+            const int bt0   = band * GT, bh = min(GT, n_tiles_t - bt0);  // last band may be shorter
+            const int blk   = w / (bh * GN), u = w - blk * (bh * GN);
+            const int bn0   = blk * GN, bw = min(GN, n_tiles_n - bn0);   // last column block may be narrower
+            tile_t          = bt0 + u / bw;
+            tile_n          = bn0 + u % bw;
         }
         else {
             tile_t = v / n_tiles_n;
@@ -312,6 +323,26 @@ __global__ __launch_bounds__(C::THREADS) void gemm_bf16_kernel(const bf16_t* __r
         }
     }
     const int n0 = tile_n * C::BN, t0 = tile_t * C::BT;
+    const int step = (vi - (int)blockIdx.x) / (int)gridDim.x;
+    if (VAR & 1024) {
+        if (tid == 0) {
+            const int xcd  = blockIdx.x & 7;
+            const int lo   = step * (int)gridDim.x, hi = min(lo + (int)gridDim.x, n_tiles_total);
+            const int want = (hi - lo + 7 - xcd) / 8;  // tiles of this step with index % 8 == xcd (lo % 8 == 0)
+            unsigned* c    = g_gemm_sync + xcd * 64 + (step & 63);
+            __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int spin = 0; spin < 20000; ++spin) {
+                if ((int)__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want)
+                    break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        __syncthreads();
+    }
+    if ((VAR & 512) && tid == 0) {
+        g_gemm_trace[((size_t)blockIdx.x * 64 + (step & 63)) * 4 + 0] = wall_clock64();
+        g_gemm_trace[((size_t)blockIdx.x * 64 + (step & 63)) * 4 + 3] = __builtin_amdgcn_s_getreg((3 << 11) | 20);  // HW_REG_XCC_ID
+    }
 
     // ---- staging: one global_load_lds moves 8 rows x 128 B per wave.  LDS linear position of this
     // lane's 16 B for instruction i: pos = (i*NW + wave)*1024 + lane*16 -> row = pos/128, physical
@@ -361,12 +392,62 @@ __global__ __launch_bounds__(C::THREADS) void gemm_bf16_kernel(const bf16_t* __r
     //   reading tile kt-1) ; issue tile kt+STAGES-1 into the slot tile kt-1 occupied ; multiply tile kt.
     // STAGES-1 tiles stay in flight across the barrier (counted vmcnt, never a drain).
     const int KT = Kpad / C::BKC;
+    const int frow = lane & 31;
+    const int fk   = lane >> 5;  // which 8-element half of a 16-wide k slab
+    if constexpr ((VAR & 2048) != 0) {
+        // Register pipeline ACROSS the barrier: the fragments of k-slab ks+1 are read while slab ks multiplies, and
+        // the barrier that publishes K-tile kt+1 sits between the reads and the MFMAs of the LAST slab of tile kt.
+        // Every wave therefore still holds 8 MFMAs (256 matrix-pipe cycles, 512 per SIMD) when it arrives at the
+        // barrier, which covers the barrier skew and the LDS latency of the next tile's first fragments.
+        static_assert(C::STAGES == 2 && C::BKC == 64, "cross-barrier pipeline is written for two 64-wide stages");
+        bf16x8 a[2][C::MI], b[2][C::MJ];
+#define AMX_FRAG_LOAD(buf, base, ks)                                                                                        \
+    {                                                                                                                       \
+        _Pragma("unroll") for (int i = 0; i < C::MI; ++i) a[buf][i] =                                                       \
+                *(const bf16x8*)((base) + C::swz(wn * (C::BN / C::WN) + i * 32 + frow, (ks) * 2 + fk));                     \
+        _Pragma("unroll") for (int j = 0; j < C::MJ; ++j) b[buf][j] =                                                       \
+                *(const bf16x8*)((base) + C::A_BYTES + C::swz(wt * (C::BT / C::WT) + j * 32 + frow, (ks) * 2 + fk));        \
+    }
+        stage(0, 0);
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (KT > 1)
+            stage(1, 1);
+        AMX_FRAG_LOAD(0, lds, 0)
+        for (int kt = 0; kt < KT; ++kt) {
+            const char* wbase = lds + (kt & 1) * C::STAGE_BYTES;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                if (ks < 3) {
+                    AMX_FRAG_LOAD((ks + 1) & 1, wbase, ks + 1)
+                }
+                else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // all my reads of tile kt have returned
+                    if (kt + 1 < KT) {
+                        wait_vmcnt<0>();  // my share of tile kt+1 landed (issued one K-tile ago)
+                        __builtin_amdgcn_s_barrier();
+                        if (kt + 2 < KT)
+                            stage(kt & 1, kt + 2);
+                        const char* nbase = lds + ((kt + 1) & 1) * C::STAGE_BYTES;
+                        AMX_FRAG_LOAD(0, nbase, 0)
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < C::MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < C::MJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks & 1][i], b[ks & 1][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#undef AMX_FRAG_LOAD
+    }
+    else {
 #pragma unroll
     for (int s = 0; s < C::STAGES - 1; ++s)
         if (s < KT)
             stage(s, s);
-    const int frow = lane & 31;
-    const int fk   = lane >> 5;  // which 8-element half of a 16-wide k slab
     for (int kt = 0; kt < KT; ++kt) {
         // tiles kt .. min(kt+STAGES-2, KT-1) are outstanding; keep all but tile kt in flight
         const int ahead = min(C::STAGES - 2, KT - 1 - kt);
@@ -450,7 +531,10 @@ __global__ __launch_bounds__(C::THREADS) void gemm_bf16_kernel(const bf16_t* __r
         // this wave's LDS reads have returned before it can arrive at the next barrier
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
+    }
 
+    if ((VAR & 512) && tid == 0)
+        g_gemm_trace[((size_t)blockIdx.x * 64 + (step & 63)) * 4 + 1] = wall_clock64();
     if (VAR & 128) {  // ablation: no epilogue (a reduction over ALL accumulators keeps every MFMA alive)
         float sum = 0.f;
 #pragma unroll
@@ -468,7 +552,319 @@ __global__ __launch_bounds__(C::THREADS) void gemm_bf16_kernel(const bf16_t* __r
     else
         gemm_epilogue<C, ACT, LAST>(acc, lds, s_bias, out, ldo, n_valid, t_valid, n0, t0, tile_n, wn, wt, lane, tid, part_min, part_idx, part_ld);
     __syncthreads();  // LDS (stages / arg-min scratch) is reused by the next tile
+    if ((VAR & 512) && tid == 0)
+        g_gemm_trace[((size_t)blockIdx.x * 64 + (step & 63)) * 4 + 2] = wall_clock64();
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// gemm_bf16_pipe_kernel: the large-batch kernel (256x256x64 tiles, 8 waves of 128x64).  Same K-loop as above, but the
+// operand stream runs ACROSS tiles and the epilogue is rebuilt around it:
+//   * in the last K-step of a tile the free stage already receives the first K-tile of the workgroup's NEXT tile (and
+//     its bias vector, by LDS-DMA), so those loads precede the epilogue's global stores in the wave's VMEM order.  The
+//     next tile's first wait is then `s_waitcnt vmcnt(#stores)`: it waits for the loads, not for the score stores
+//     (completion is reported in issue order on gfx9), which keep draining under the first K-steps.
+//   * the epilogue transposes through the OTHER stage: 8 KB per wave (32 frames x 256 B, 16-byte chunks XOR-swizzled by
+//     the row, conflict free for ds_write_b128/b64 and ds_read_b128 -- tools/lds_conflicts.py), f32 scores in four
+//     sub-passes of 32 frames x 64 states, bf16 activations in two passes of 32 frames x 128 units.  Bias values are
+//     fetched four float4 at a time, fragment reads and stores are batched, so a pass has ~6 waits instead of ~50.
+//   * interior tiles store without guards (their store count is what the counted wait relies on); edge tiles use the
+//     guarded path and fall back to a full drain.
+template<class C, bool LAST>
+struct PipeLds {
+    static constexpr int WAVE_SCRATCH = 32 * 256;
+    static constexpr int BEST_OFF     = 2 * C::STAGE_BYTES;                 // arg-min exchange [2][WN][BT]
+    static constexpr int BEST_BYTES   = LAST ? 2 * C::WN * C::BT * 4 : 0;
+    static constexpr int BIAS_OFF     = BEST_OFF + BEST_BYTES;              // [2][BN] f32, double buffered per tile
+    static constexpr int BYTES        = BIAS_OFF + 2 * C::BN * 4;
+    static constexpr int STORES       = LAST ? C::MJ * 2 * 8 : C::MJ * 8;   // global stores per wave and interior tile
+    static_assert(C::STAGES == 2 && C::BKC == 64, "two 64-wide stages");
+    static_assert(C::BN / C::WN == 128 && C::MI == 4, "wave tile is 128 outputs wide");
+    static_assert(C::NW * WAVE_SCRATCH <= C::STAGE_BYTES, "epilogue scratch must fit into one stage");
+    static_assert(C::BN * 4 == 1024, "the bias vector is one wave-wide 16-byte LDS-DMA");
+    static_assert(STORES + 2 < 64, "vmcnt immediate");
+};
+
+__device__ __forceinline__ int pipe_swz(int row, int chunk) {
+    return row * 256 + ((chunk ^ (row & 15)) << 4);
+}
+
+template<class C, int ACT, bool LAST>
+__global__ __launch_bounds__(C::THREADS) void gemm_bf16_pipe_kernel(const bf16_t* __restrict__ W, const bf16_t* __restrict__ X,
+                                                                   const float* __restrict__ bias, void* __restrict__ out, int Kpad, int ldx,
+                                                                   int ldo, int n_valid, int t_valid, int n_tiles_n, int n_tiles_total, int GT,
+                                                                   int GN, int out_aligned, float* __restrict__ part_min,
+                                                                   unsigned* __restrict__ part_idx, int part_ld) {
+    using P = PipeLds<C, LAST>;
+    extern __shared__ __attribute__((aligned(16))) char lds[];  // [stage 0 | stage 1 | arg-min exchange | bias x 2]
+    const int tid  = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn   = wave / C::WT, wt = wave % C::WT;
+    const int KT   = Kpad / C::BKC;
+    const bool want_best = LAST && part_min != nullptr;
+
+    auto coords = [&](int vi, int& tile_t, int& tile_n) {  // same XCD-aware order as gemm_bf16_kernel
+        const int nwg = n_tiles_total;
+        const int q = nwg >> 3, r = nwg & 7, xcd = vi & 7, k = vi >> 3;
+        const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+        const int n_tiles_t = nwg / n_tiles_n;
+        if (GT > 0 && GN > 0) {
+            const int band = v / (GT * n_tiles_n), w = v - band * (GT * n_tiles_n);
+            const int bt0  = band * GT, bh = min(GT, n_tiles_t - bt0);
+            const int blk  = w / (bh * GN), u = w - blk * (bh * GN);
+            const int bn0  = blk * GN, bw = min(GN, n_tiles_n - bn0);
+            tile_t         = bt0 + u / bw;
+            tile_n         = bn0 + u % bw;
+        }
+        else {
+            tile_t = v / n_tiles_n;
+            tile_n = v - tile_t * n_tiles_n;
+        }
+    };
+    // staging: instruction i of a wave covers rows (i*NW + wave)*8 .. +7 of the tile; a lane's 16 bytes sit at row
+    // lane/8, physical chunk lane%8, which must hold logical chunk phys ^ ((row>>1)&7) = phys ^ xr (independent of i)
+    const int    xr   = ((wave & 1) * 4 + (lane >> 4)) & 7;
+    const size_t offW = (size_t)(wave * 8 + (lane >> 3)) * Kpad + (((lane & 7) ^ xr) << 3);
+    const size_t offX = (size_t)(wave * 8 + (lane >> 3)) * ldx + (((lane & 7) ^ xr) << 3);
+    const size_t stepW = (size_t)C::NW * 8 * Kpad, stepX = (size_t)C::NW * 8 * ldx;
+    auto issue = [&](int slot, const bf16_t* pw, const bf16_t* px) {
+        char* base = lds + slot * C::STAGE_BYTES + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < C::A_LOADS; ++i)
+            __builtin_amdgcn_global_load_lds((const void*)(pw + i * stepW), (__attribute__((address_space(3))) void*)(base + i * C::NW * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < C::B_LOADS; ++i)
+            __builtin_amdgcn_global_load_lds((const void*)(px + i * stepX),
+                                             (__attribute__((address_space(3))) void*)(base + C::A_BYTES + i * C::NW * 1024), 16, 0, 0);
+    };
+    auto issue_bias = [&](int buf, int tile_n) {  // wave 0: BN floats = 64 lanes x 16 B
+        if (wave == 0)
+            __builtin_amdgcn_global_load_lds((const void*)(bias + tile_n * C::BN + lane * 4),
+                                             (__attribute__((address_space(3))) void*)(lds + P::BIAS_OFF + buf * C::BN * 4), 16, 0, 0);
+    };
+
+    int vi = blockIdx.x;
+    if (vi >= n_tiles_total)
+        return;
+    int tile_t, tile_n;
+    coords(vi, tile_t, tile_n);
+    const bf16_t* pw = W + (size_t)tile_n * C::BN * Kpad + offW;
+    const bf16_t* px = X + (size_t)tile_t * C::BT * ldx + offX;
+    int           bias_buf = 0;
+    issue_bias(0, tile_n);
+    issue(0, pw, px);
+    unsigned g       = 0;      // running K-tile count; K-tile g lives in stage g & 1
+    bool     counted = false;  // the loads in flight are followed by exactly P::STORES (+2) stores of this wave
+    const int frow = lane & 31, fk = lane >> 5, tl32 = lane & 31, hh = lane >> 5;
+    const bool extra = LAST && want_best && wave * 64 < C::BT;  // waves that also write the arg-min partials
+
+    for (;;) {
+        f32x16 acc[C::MI][C::MJ];
+#pragma unroll
+        for (int i = 0; i < C::MI; ++i)
+#pragma unroll
+            for (int j = 0; j < C::MJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    acc[i][j][r] = 0.f;
+        const int  n0 = tile_n * C::BN, t0 = tile_t * C::BT, cur_tile_n = tile_n;
+        const int  nvi      = vi + (int)gridDim.x;
+        const bool has_next = nvi < n_tiles_total;
+
+        for (int kt = 0; kt < KT; ++kt, ++g) {
+            if (kt == 0 && counted) {
+                if (extra)
+                    wait_vmcnt<P::STORES + 2>();
+                else
+                    wait_vmcnt<P::STORES>();
+            }
+            else
+                wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            const int nslot = (g + 1) & 1;
+            if (kt + 1 < KT) {
+                pw += C::BKC;
+                px += C::BKC;
+                issue(nslot, pw, px);
+            }
+            else if (has_next) {  // the stream continues with the next tile
+                coords(nvi, tile_t, tile_n);
+                pw = W + (size_t)tile_n * C::BN * Kpad + offW;
+                px = X + (size_t)tile_t * C::BT * ldx + offX;
+                issue(nslot, pw, px);
+                issue_bias(bias_buf ^ 1, tile_n);
+            }
+            const char* wbase = lds + (g & 1) * C::STAGE_BYTES;
+            const char* xbase = wbase + C::A_BYTES;
+#pragma unroll
+            for (int ks = 0; ks < C::BKC / 16; ++ks) {
+                bf16x8 a[C::MI], b[C::MJ];
+#pragma unroll
+                for (int i = 0; i < C::MI; ++i)
+                    a[i] = *(const bf16x8*)(wbase + C::swz(wn * (C::BN / C::WN) + i * 32 + frow, ks * 2 + fk));
+#pragma unroll
+                for (int j = 0; j < C::MJ; ++j)
+                    b[j] = *(const bf16x8*)(xbase + C::swz(wt * (C::BT / C::WT) + j * 32 + frow, ks * 2 + fk));
+#pragma unroll
+                for (int i = 0; i < C::MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < C::MJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+
+        // ------------------------------------------------------------------ epilogue of tile (t0, n0)
+        // every wave is done reading stage (g-1)&1 (its LDS reads were waited for above): that stage becomes the
+        // transposition scratch.  A raw barrier: __syncthreads() would also drain the next tile's loads.
+        __builtin_amdgcn_s_barrier();
+        char*        w_lds = lds + ((g - 1) & 1) * C::STAGE_BYTES + wave * P::WAVE_SCRATCH;
+        const float* sb    = (const float*)(lds + P::BIAS_OFF + bias_buf * C::BN * 4) + wn * 128;
+        const int    nbase = n0 + wn * 128;
+        const bool   interior = LAST ? (t0 + C::BT <= t_valid && n0 + C::BN <= n_valid && out_aligned) : true;
+        const int    prow = lane >> 4, pc = lane & 15;  // phase 2: 4 rows x 16 chunks per wave-wide access
+        if (LAST) {
+            float*    s_min = (float*)(lds + P::BEST_OFF);
+            unsigned* s_idx = (unsigned*)(lds + P::BEST_OFF + C::WN * C::BT * 4);
+            const bool edge_n = n0 + C::BN > n_valid;
+#pragma unroll
+            for (int j = 0; j < C::MJ; ++j) {
+                float    bmin = 3.402823466e+38f;
+                unsigned bidx = 0xffffffffu;
+                const int tbase = t0 + wt * (C::BT / C::WT) + j * 32;
+#pragma unroll
+                for (int ih = 0; ih < 2; ++ih) {
+                    float4 b4[2][4];
+#pragma unroll
+                    for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+                        for (int gq = 0; gq < 4; ++gq)
+                            b4[i2][gq] = *(const float4*)(sb + ih * 64 + i2 * 32 + 8 * gq + 4 * hh);
+#pragma unroll
+                    for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+                        for (int gq = 0; gq < 4; ++gq) {
+                            const f32x16& c  = acc[ih * 2 + i2][j];
+                            const float4  bv = b4[i2][gq];
+                            // score = -(activation + bias) = (-bias) - activation (exact)
+                            const float4 v = make_float4((-bv.x) - c[gq * 4 + 0], (-bv.y) - c[gq * 4 + 1], (-bv.z) - c[gq * 4 + 2],
+                                                         (-bv.w) - c[gq * 4 + 3]);
+                            *(float4*)(w_lds + pipe_swz(tl32, i2 * 8 + 2 * gq + hh)) = v;
+                            if (want_best) {
+                                const int   n     = nbase + ih * 64 + i2 * 32 + 8 * gq + 4 * hh;
+                                const float sc[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    const bool ok = edge_n ? (n + e < n_valid) : true;
+                                    if (ok && sc[e] < bmin) {  // ascending n within the lane
+                                        bmin = sc[e];
+                                        bidx = (unsigned)(n + e);
+                                    }
+                                }
+                            }
+                        }
+                    // LDS -> global: 8 accesses of 4 frames x 256 B
+                    float4 o[8];
+#pragma unroll
+                    for (int it = 0; it < 8; ++it)
+                        o[it] = *(const float4*)(w_lds + pipe_swz(it * 4 + prow, pc));
+                    const int n = nbase + ih * 64 + 4 * pc;
+                    if (interior) {
+#pragma unroll
+                        for (int it = 0; it < 8; ++it)  // written once, never re-read here: keep the operand panels in L2
+                            __builtin_nontemporal_store(f32x4{o[it].x, o[it].y, o[it].z, o[it].w},
+                                                        (f32x4*)((float*)out + (size_t)(tbase + it * 4 + prow) * ldo + n));
+                    }
+                    else {
+#pragma unroll
+                        for (int it = 0; it < 8; ++it) {
+                            const int t = tbase + it * 4 + prow;
+                            if (t < t_valid) {
+                                float* po = (float*)out + (size_t)t * ldo + n;
+                                if (n + 3 < n_valid && out_aligned)
+                                    *(float4*)po = o[it];
+                                else {
+                                    if (n < n_valid) po[0] = o[it].x;
+                                    if (n + 1 < n_valid) po[1] = o[it].y;
+                                    if (n + 2 < n_valid) po[2] = o[it].z;
+                                    if (n + 3 < n_valid) po[3] = o[it].w;
+                                }
+                            }
+                        }
+                    }
+                }
+                if (want_best) {
+                    // lanes l and l+32 hold the same frame, interleaved n: smaller index wins ties
+                    const float    om = __shfl_xor(bmin, 32, 64);
+                    const unsigned oi = (unsigned)__shfl_xor((int)bidx, 32, 64);
+                    if (om < bmin || (om == bmin && oi < bidx)) {
+                        bmin = om;
+                        bidx = oi;
+                    }
+                    if (lane < 32) {
+                        const int tl = wt * (C::BT / C::WT) + j * 32 + tl32;
+                        s_min[wn * C::BT + tl] = bmin;
+                        s_idx[wn * C::BT + tl] = bidx;
+                    }
+                }
+            }
+            if (want_best) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // s_min / s_idx written; no VMEM drain here
+                __builtin_amdgcn_s_barrier();
+                for (int tl = tid; tl < C::BT; tl += C::THREADS) {
+                    float    bmin = s_min[tl];
+                    unsigned bidx = s_idx[tl];
+#pragma unroll
+                    for (int w = 1; w < C::WN; ++w) {  // ascending n ranges: strict '<' keeps the first minimum
+                        const float m = s_min[w * C::BT + tl];
+                        if (m < bmin) {
+                            bmin = m;
+                            bidx = s_idx[w * C::BT + tl];
+                        }
+                    }
+                    part_min[(size_t)cur_tile_n * part_ld + t0 + tl] = bmin;
+                    part_idx[(size_t)cur_tile_n * part_ld + t0 + tl] = bidx;
+                }
+            }
+        }
+        else {
+#pragma unroll
+            for (int j = 0; j < C::MJ; ++j) {
+                const int tbase = t0 + wt * (C::BT / C::WT) + j * 32;
+#pragma unroll
+                for (int i = 0; i < C::MI; ++i) {
+                    float4 b4[4];
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq)
+                        b4[gq] = *(const float4*)(sb + i * 32 + 8 * gq + 4 * hh);
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        const f32x16& c = acc[i][j];
+                        uint2         pk;
+                        pk.x = pack_bf16(activate<ACT>(c[gq * 4 + 0] + b4[gq].x), activate<ACT>(c[gq * 4 + 1] + b4[gq].y));
+                        pk.y = pack_bf16(activate<ACT>(c[gq * 4 + 2] + b4[gq].z), activate<ACT>(c[gq * 4 + 3] + b4[gq].w));
+                        // the 8-byte half inside the chunk alternates with bit 3 of the row (b64 writes of rows r, r+8)
+                        *(uint2*)(w_lds + pipe_swz(tl32, i * 4 + gq) + 8 * (hh ^ ((tl32 >> 3) & 1))) = pk;
+                    }
+                }
+                uint4 o[8];
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const uint4 v = *(const uint4*)(w_lds + pipe_swz(it * 4 + prow, pc));
+                    o[it]         = ((it >> 1) & 1) ? make_uint4(v.z, v.w, v.x, v.y) : v;  // rows 8-15, 24-31: halves swapped
+                }
+#pragma unroll
+                for (int it = 0; it < 8; ++it)  // padded activation buffer: no guards
+                    *(uint4*)((bf16_t*)out + (size_t)(tbase + it * 4 + prow) * ldo + nbase + 8 * pc) = o[it];
+            }
+        }
+        counted = interior;
+        if (!has_next)
+            break;
+        vi = nvi;
+        bias_buf ^= 1;
+    }
 }
 
 // combines the per-tile arg-min partials: best state per frame, per-state counts, sum of best scores
@@ -659,8 +1055,9 @@ template<class C, int ACT, bool LAST, int VAR>
 void launch_bf16v(amx_ffnn* h, int l, const void* x, int ldx, void* out, int ldo, int T, int Tpad) {
     const int ntn = h->Npad[l] / C::BN, ntt = Tpad / C::BT;
     auto      k   = amx::gemm_bf16_kernel<C, ACT, LAST, VAR>;
-    // 128x128 tiles (2 workgroups per CU) profit from the 2x4 super-tile order, 256x256 tiles do not
-    const int gt = h->group_t >= 0 ? h->group_t : (C::BN == 128 ? 2 : 0), gn = h->group_n >= 0 ? h->group_n : (C::BN == 128 ? 4 : 0);
+    // super-tile order: the tiles one XCD holds at a time share operand panels in its L2 (tools/gemm_probe.hip: output
+    // layer 1.66 -> 1.44 ms with 8x4 blocks of 256x256 tiles; row-major order re-fetches every W panel per tile)
+    const int gt = h->group_t >= 0 ? h->group_t : (C::BN == 128 ? 2 : 8), gn = h->group_n >= 0 ? h->group_n : 4;
     constexpr int lds_bytes = amx::gemm_scratch_bytes<C, LAST>() + C::BN * 4;
     static_assert(lds_bytes <= 160 * 1024, "LDS budget");
     hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
@@ -679,12 +1076,28 @@ void launch_bf16v(amx_ffnn* h, int l, const void* x, int ldx, void* out, int ldo
 
 template<class C, int ACT, bool LAST>
 void launch_bf16(amx_ffnn* h, int l, const void* x, int ldx, void* out, int ldo, int T, int Tpad) {
-    // VAR bits are experiment switches; only variant 0 is instantiated in the shipped library.
-    //   1 register double-buffered fragments, 2 s_setprio around the MFMA cluster, 4 late stage issue, 32 pinned
-    //   read/MFMA interleave: all within +-3 % of variant 0.  Ablations of the output layer (1.37 ms): 8 no MFMA,
-    //   16 no global loads, 64 streaming only 1.31 ms, 128 no epilogue 0.98 ms, 256 epilogue without global stores
-    //   1.13 ms.  A phase-split kernel (two wave groups half a phase apart) and a 4-stage BK=32 pipeline tied or lost.
-        launch_bf16v<C, ACT, LAST, 0>(h, l, x, ldx, out, ldo, T, Tpad);
+    // VAR bits are experiment switches (tools/gemm_probe.hip); the library instantiates variant 0.
+    launch_bf16v<C, ACT, LAST, 0>(h, l, x, ldx, out, ldo, T, Tpad);
+}
+
+// large batches: the cross-tile pipelined kernel
+template<class C, int ACT, bool LAST>
+void launch_bf16_pipe(amx_ffnn* h, int l, const void* x, int ldx, void* out, int ldo, int T, int Tpad) {
+    using P       = amx::PipeLds<C, LAST>;
+    const int ntn = h->Npad[l] / C::BN, ntt = Tpad / C::BT;
+    auto      k   = amx::gemm_bf16_pipe_kernel<C, ACT, LAST>;
+    const int gt = h->group_t >= 0 ? h->group_t : 2, gn = h->group_n >= 0 ? h->group_n : 16;
+    static_assert(P::BYTES <= 160 * 1024, "LDS budget");
+    hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, P::BYTES);
+    int grid = std::min(ntn * ntt, std::max(h->ctx->n_cu, 8));
+    if (grid >= 8)
+        grid &= ~7;  // keep blockIdx % 8 == tile index % 8 for every stride step
+    const int aligned = LAST ? (((uintptr_t)out & 15) == 0 && (ldo & 3) == 0) : 1;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(C::THREADS), P::BYTES, h->ctx->stream, (const amx::bf16_t*)h->d_W[l], (const amx::bf16_t*)x,
+                       h->d_bias[l], out, h->Kpad[l], ldx, ldo, h->out[l], T, ntn, ntn * ntt, gt, gn, aligned,
+                       LAST ? h->cur_part_min : nullptr, LAST ? h->cur_part_idx : nullptr, Tpad);
+    if (LAST)
+        h->cur_ntn = ntn;
 }
 
 template<int ACT, bool LAST>
@@ -700,7 +1113,8 @@ void launch_bf16_cfg(amx_ffnn* h, int l, const void* x, int ldx, void* out, int 
             cfg = 3;
     }
     switch (cfg) {
-        case 2: launch_bf16<CfgC, ACT, LAST>(h, l, x, ldx, out, ldo, T, Tpad); break;
+        case 2: launch_bf16_pipe<CfgC, ACT, LAST>(h, l, x, ldx, out, ldo, T, Tpad); break;
+        case 4: launch_bf16<CfgC, ACT, LAST>(h, l, x, ldx, out, ldo, T, Tpad); break;  // previous large-batch kernel (A/B runs)
         case 3: launch_bf16<CfgS, ACT, LAST>(h, l, x, ldx, out, ldo, T, Tpad); break;
         default: launch_bf16<CfgA, ACT, LAST>(h, l, x, ldx, out, ldo, T, Tpad); break;
     }

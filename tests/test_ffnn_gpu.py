@@ -116,3 +116,41 @@ def test_config4_shape_bf16_properties(ctx):
     base = nn0.score(x[:64])
     # score = -(z + b - logp) = base + logp; the bias is added in f32 in the epilogue
     assert np.allclose(full[:64] - base, logp[None, :], atol=1e-3)
+
+
+@pytest.mark.parametrize("n_out", [2500, 2501])
+def test_tile_configurations_agree(ctx, monkeypatch, n_out):
+    """Every tile configuration of the bf16 GEMM (128x128, 128x64, 256x256, and the cross-tile pipelined 256x256 kernel
+    the large batches use) accumulates in the same k order, so scores, best states and accumulators are bit-identical.
+    Shape chosen so that workgroups of the persistent kernels walk several tiles, including frame- and state-edge tiles
+    (8200 = 32*256 + 8 frames; 2500 = 9*256 + 196 states; 2501 makes the score rows unaligned -> guarded stores)."""
+    import torch
+
+    import rasr_amd
+    Ws, bs, acts, logp = synth.ffnn([64, 300, n_out], seed=21)
+    x = feats(8200, 64, 22)
+    xd = torch.from_numpy(x).cuda()
+    ctx.use_torch_stream()
+    results = {}
+    for cfg in ("0", "3", "4", "2"):
+        monkeypatch.setenv("AMX_GEMM_CFG", cfg)
+        nn = rasr_amd.NnBatchFeatureScorer(ctx, Ws, bs, acts, log_prior=logp, precision="bf16")
+        sc = torch.full((8200, n_out), float("nan"), dtype=torch.float32, device="cuda")
+        best = torch.zeros(8200, dtype=torch.int32, device="cuda")
+        counts = torch.zeros(n_out, dtype=torch.int64, device="cuda")
+        ssum = torch.zeros(1, dtype=torch.float64, device="cuda")
+        for _ in range(2):  # second pass: the counted-wait path of the pipelined kernel in steady state
+            nn.score_stats_dev(xd, 64, 8200, sc, best, counts, ssum)
+        torch.cuda.synchronize()
+        results[cfg] = (sc.cpu().numpy(), best.cpu().numpy(), counts.cpu().numpy(), float(ssum.item()))
+        plain = nn.score(x[:700])
+        assert np.array_equal(plain.view(np.uint32), results[cfg][0][:700].view(np.uint32))
+    ref = results["0"]
+    assert np.isfinite(ref[0]).all()
+    assert np.array_equal(ref[1], ref[0].argmin(axis=1))
+    assert np.array_equal(ref[2], 2 * np.bincount(ref[1], minlength=n_out))
+    for cfg in ("3", "4", "2"):
+        got = results[cfg]
+        assert np.array_equal(got[0].view(np.uint32), ref[0].view(np.uint32)), cfg
+        assert np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2]), cfg
+        assert abs(got[3] - ref[3]) <= 1e-9 * abs(ref[3]), cfg

@@ -1,0 +1,8 @@
+#!/bin/bash
+# builds tools/build/gemm_probe (see tools/gemm_probe.hip)
+set -e
+cd "$(dirname "$0")/.."
+make -s -C rasr_amd/csrc
+mkdir -p tools/build
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -w -I include -I rasr_amd/csrc -save-temps=obj -c tools/gemm_probe.hip -o tools/build/gemm_probe.o
+hipcc --offload-arch=gfx950 tools/build/gemm_probe.o rasr_amd/csrc/build/api.o rasr_amd/csrc/build/stats.o -o tools/build/gemm_probe

@@ -1,0 +1,140 @@
+// tools/gemm_probe.hip -- experiment driver for the bf16 GEMM kernel (not part of the library, not a test).
+//   make -C rasr_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I include -I rasr_amd/csrc \
+//        tools/gemm_probe.hip rasr_amd/csrc/build/api.o rasr_amd/csrc/build/stats.o -o gpurun_out/gemm_probe
+// Runs the output layer of the bench network (2048 -> 10000, 32768 frames) under the schedule variants named on the
+// command line (VAR bit masks, see gemm_bf16_kernel) and prints the average launch time; `trace` adds the per-tile
+// time stamps of variant 512 (skew between the workgroups of an XCD).
+#include "../rasr_amd/csrc/ffnn.hip"
+
+#include <cstdio>
+#include <random>
+#include <string>
+
+#define CK(x)                                                                       \
+    do {                                                                            \
+        hipError_t e_ = (x);                                                        \
+        if (e_ != hipSuccess) {                                                     \
+            fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); \
+            exit(1);                                                                \
+        }                                                                           \
+    } while (0)
+
+struct Problem {
+    int             N = 10000, K = 2048, T = 32768, Npad, Tpad;
+    amx::bf16_t *   W, *X;
+    float *         bias, *out, *pmin;
+    unsigned*       pidx;
+    unsigned long long* trace;
+    unsigned*       sync;
+    int             n_cu;
+    int             gt = 0, gn = 0;
+};
+
+template<class C, int VAR>
+float run(Problem& p, int iters, bool quiet = false) {
+    auto          k   = amx::gemm_bf16_kernel<C, AMX_ACT_NONE, true, VAR>;
+    const int     ntn = p.Npad / C::BN, ntt = p.Tpad / C::BT;
+    constexpr int lds = amx::gemm_scratch_bytes<C, true>() + C::BN * 4;
+    CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    const int per_cu = std::max(1, (160 * 1024) / lds);
+    int       grid   = std::min(ntn * ntt, per_cu * p.n_cu) & ~7;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    float total = 0;
+    for (int it = -2; it < iters; ++it) {
+        CK(hipMemsetAsync(p.sync, 0, 8 * 64 * 4, 0));
+        CK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL(k, dim3(grid), dim3(C::THREADS), lds, 0, p.W, p.X, p.bias, (void*)p.out, p.K, p.K, p.N, p.N, p.T, ntn, ntn * ntt, p.gt, p.gn,
+                           p.pmin, p.pidx, p.Tpad);
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        if (it >= 0)
+            total += ms;
+    }
+    const float ms = total / iters;
+    if (!quiet) printf("var %4d  group %dx%d  tile %dx%d  grid %d  %.4f ms  %.0f TFLOP/s\n", VAR, p.gt, p.gn, C::BN, C::BT, grid, ms, 2.0 * p.N * p.K * p.T / ms * 1e-9);
+    fflush(stdout);
+    return ms;
+}
+
+int main(int argc, char** argv) {
+    Problem p;
+    p.Npad = (p.N + 255) / 256 * 256;
+    p.Tpad = p.T;
+    hipDeviceProp_t prop;
+    CK(hipGetDeviceProperties(&prop, 0));
+    p.n_cu = prop.multiProcessorCount;
+    std::vector<amx::bf16_t> w((size_t)p.Npad * p.K), x((size_t)p.Tpad * p.K);
+    std::mt19937             rng(1);
+    std::normal_distribution<float> nd(0.f, 1.f);
+    for (auto& v : w) v = amx::f2bf_host(nd(rng) * 0.02f);
+    const bool relu = getenv("PROBE_RELU") != nullptr;  // hidden activations after ReLU: half the operand is zero
+    for (auto& v : x) { float f = nd(rng); v = amx::f2bf_host(relu && f < 0.f ? 0.f : f); }
+    CK(hipMalloc((void**)&p.W, w.size() * 2));
+    CK(hipMalloc((void**)&p.X, x.size() * 2));
+    CK(hipMemcpy(p.W, w.data(), w.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(p.X, x.data(), x.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMalloc((void**)&p.bias, p.Npad * 4));
+    CK(hipMemset(p.bias, 0, p.Npad * 4));
+    CK(hipMalloc((void**)&p.out, (size_t)p.T * p.N * 4));
+    CK(hipMalloc((void**)&p.pmin, (size_t)(p.Npad / 128) * p.Tpad * 4));
+    CK(hipMalloc((void**)&p.pidx, (size_t)(p.Npad / 128) * p.Tpad * 4));
+    const size_t trace_n = (size_t)2048 * 64 * 4;
+    CK(hipMalloc((void**)&p.trace, trace_n * 8));
+    CK(hipMemset(p.trace, 0, trace_n * 8));
+    CK(hipMalloc((void**)&p.sync, 8 * 64 * 4));
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(amx::g_gemm_trace), &p.trace, sizeof(void*)));
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(amx::g_gemm_sync), &p.sync, sizeof(void*)));
+    using CfgC = amx::GemmCfg<256, 256, 2, 4, 2>;
+    const int iters = 10;
+    { Problem q = p; fprintf(stderr, "warm-up\n"); for (int w = 0; w < 30; ++w) run<CfgC, 128>(q, 10, true); }
+    for (int a = 1; a < argc; ++a) {
+        std::string s = argv[a];
+        p.gt = p.gn = 0;
+        if (s.find(':') != std::string::npos) {
+            sscanf(s.c_str() + s.find(':') + 1, "%dx%d", &p.gt, &p.gn);
+            s = s.substr(0, s.find(':'));
+        }
+        if (s == "0") run<CfgC, 0>(p, iters);
+        else if (s == "64") run<CfgC, 64 | 128>(p, iters);       // operand streaming only, no epilogue
+        else if (s == "128") run<CfgC, 128>(p, iters);           // K-loop only
+        else if (s == "256") run<CfgC, 256>(p, iters);           // epilogue without global stores
+        else if (s == "136") run<CfgC, 8 | 128>(p, iters);        // loads + fragment reads, no MFMA, no epilogue
+        else if (s == "144") run<CfgC, 16 | 128>(p, iters);       // no global loads after the first: reads + MFMA
+        else if (s == "129") run<CfgC, 1 | 128>(p, iters);
+        else if (s == "130") run<CfgC, 2 | 128>(p, iters);
+        else if (s == "2048") run<CfgC, 2048>(p, iters);
+        else if (s == "2176") run<CfgC, 2048 | 128>(p, iters);
+        else if (s == "1024") run<CfgC, 1024>(p, iters);         // XCD tile barrier
+        else if (s == "1088") run<CfgC, 1024 | 64 | 128>(p, iters);
+        else if (s == "1152") run<CfgC, 1024 | 128>(p, iters);
+        else if (s == "trace" || s == "trace1024") {
+            if (s == "trace") run<CfgC, 512>(p, 1);
+            else run<CfgC, 512 | 1024>(p, 1);
+            std::vector<unsigned long long> tr(trace_n);
+            CK(hipMemcpy(tr.data(), p.trace, trace_n * 8, hipMemcpyDeviceToHost));
+            const int grid = 256, steps = (p.Npad / 256) * (p.Tpad / 256) / grid;
+            unsigned long long t00 = ~0ull;
+            for (int b = 0; b < grid; ++b) t00 = std::min(t00, tr[(size_t)b * 256]);
+            int xcc_mismatch = 0;
+            for (int b = 0; b < grid; ++b) xcc_mismatch += ((int)tr[(size_t)b * 256 + 3] & 15) != (b & 7);
+            printf("workgroups whose XCC_ID != blockIdx %% 8: %d of %d\n", xcc_mismatch, grid);
+            printf("step: per XCD 0 start skew (us) | all: start min..max, kloop avg, epilogue avg (us)   [100 MHz clock]\n");
+            for (int st = 0; st < steps; ++st) {
+                double smin = 1e30, smax = 0, kl = 0, ep = 0, x0min = 1e30, x0max = 0;
+                for (int b = 0; b < grid; ++b) {
+                    const unsigned long long* r = &tr[((size_t)b * 64 + st) * 4];
+                    double s0 = (r[0] - t00) * 0.01, s1 = (r[1] - t00) * 0.01, s2 = (r[2] - t00) * 0.01;
+                    smin = std::min(smin, s0); smax = std::max(smax, s0);
+                    if ((b & 7) == 0) { x0min = std::min(x0min, s0); x0max = std::max(x0max, s0); }
+                    kl += s1 - s0; ep += s2 - s1;
+                }
+                printf("%2d: xcd0 skew %6.1f | start %8.1f..%8.1f  kloop %6.1f  epi %6.1f\n", st, x0max - x0min, smin, smax, kl / grid, ep / grid);
+            }
+        }
+    }
+    return 0;
+}
