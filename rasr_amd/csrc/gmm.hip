@@ -421,6 +421,188 @@ __global__ __launch_bounds__(256) void gmm_combine_uniform_kernel(const float* _
     }
 }
 
+// ---- screened maximum approximation for uniform-list tied models.
+// The reference's per-(frame, mixture) loop is `s = (m2lw + logNorm) + dist` in f64 and `if ((double)best > s) { best =
+// (float)s; idx = k; }` (Mm/GaussDiagonalMaximumFeatureScorer.cc:116-141).  Because f32 rounding is monotone, the final
+// best is f32(min_k s_k) = b, and the final index is the last k that is either the first k with f32(s_k) == b or has
+// s_k < (double)b -- both sets contain only densities whose sum rounds to b.  So running the very same sequential rule
+// over ANY subsequence that contains every k with f32(s_k) == b gives bit-identical (best, idx).
+// Pass 1 finds an f32 approximation of the minimum (1 add + 1 min per density and frame), pass 2 recomputes the f32
+// sum and applies the exact f64 rule only to densities within tau of it (1 add + 1 compare; the exact branch runs for
+// ~1 density per frame and mixture).  |s^ - s| <= 2^-24 (|a^| + |s^|) for a^ = fl32(m2lw + logNorm), s^ = fl32(a^ + dist),
+// and two sums that round to the same f32 differ by <= ulp32(b), hence tau = 2^-21 (max_k |a^| + |min s^|) covers every
+// such k with a 2x margin.  Replaces 4 f64-rate + 3 f32 operations per density by 4 f32 operations.
+typedef float gmm_f32x2 __attribute__((ext_vector_type(2)));
+
+// IEEE minNum of three without the canonicalising v_max the compiler puts in front of a loop-carried fminf
+__device__ __forceinline__ float min3_raw(float a, float b, float c) {
+    float o;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(o) : "v"(a), "v"(b), "v"(c));
+    return o;
+}
+
+// ---- register-tiled (min,+) product carrying that screen: C[t][m] = min_k (a^[k][m] + dist[k][t]), a^ tabulated
+// [K][mix_pad] next to the weights, max_k |a^| per mixture tabulated too.
+// Neither operand may come through the scalar cache (measured: a lane = frame variant with the a^ rows as SGPR operands
+// was bound by scalar-cache misses at ~0.25 TB/s chip-wide, 2.2 ms; a lane = mixture variant re-streamed the 164 MB
+// table once per 8 frames, 2.7 ms; the plain f64 kernel below 2.53 ms; this kernel 1.7 ms).  Both operands are staged in
+// LDS like GEMM operands: a workgroup owns 64 mixtures x 64 frames, a thread 4 x 4 of them, and a
+// K-chunk of 64 densities (16 KB of a^ rows + 16 KB of distance rows, coalesced 256-byte rows) is fetched into registers
+// while the previous chunk is consumed from LDS.  Per density a lane reads one float4 of each operand (16 / 4 distinct
+// addresses per wave, conflict free) for 16 sums: 8 packed adds + 8 v_min3 in pass 1; pass 2 forms min(s^ - thr) the
+// same way and enters the exact f64 rule only where it is <= 0.
+constexpr int TT_KB = 64;  // densities per chunk
+
+__global__ __launch_bounds__(256) void gmm_tied_tile_kernel(const float* __restrict__ g_dist, float* __restrict__ g_scores,
+                                                           uint32_t* __restrict__ g_best, const float* __restrict__ g_m2lw_t,
+                                                           const float* __restrict__ g_ahat_t, const float* __restrict__ g_amax,
+                                                           const uint32_t* __restrict__ g_k_dens, const double* __restrict__ g_ln64,
+                                                           GmmUniformDims dims) {
+    __shared__ __attribute__((aligned(16))) float sA[TT_KB][64];
+    __shared__ __attribute__((aligned(16))) float sD[TT_KB][64];
+    const int tid = threadIdx.x;
+    const int mi = tid & 15, ti = tid >> 4;  // thread tile: mixtures 4*mi.., frames 4*ti..
+    const int m_blk = blockIdx.x * 64, t_blk = blockIdx.y * 64;
+    const unsigned Tp = (unsigned)dims.Tpad, mp = (unsigned)dims.mix_pad;
+    const int n_chunks = (dims.K + TT_KB - 1) / TT_KB;
+    // staging: 64 rows x 256 B per operand = 1024 float4; thread -> rows r0 + 16*i (i < 4), float4 column c4
+    const int r0 = tid >> 4, c4 = (tid & 15) * 4;
+    float4    ra[4], rd[4];
+    auto fetch = [&](int chunk) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = chunk * TT_KB + r0 + 16 * i;
+            if (k < dims.K) {
+                ra[i] = *(const float4*)(g_ahat_t + (size_t)k * mp + m_blk + c4);
+                rd[i] = *(const float4*)(g_dist + g_k_dens[k] * Tp + t_blk + c4);
+            }
+            else {  // beyond the density list: sums that can never win or pass the threshold
+                ra[i] = make_float4(FLT_MAX, FLT_MAX, FLT_MAX, FLT_MAX);
+                rd[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *(float4*)&sA[r0 + 16 * i][c4] = ra[i];
+            *(float4*)&sD[r0 + 16 * i][c4] = rd[i];
+        }
+    };
+
+    // ---------------- pass 1: f32 minimum
+    float mn[4][4];  // [mixture][frame]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            mn[i][j] = FLT_MAX;
+    fetch(0);
+    for (int c = 0; c < n_chunks; ++c) {
+        __syncthreads();  // everybody is done with the previous chunk
+        stash();
+        __syncthreads();
+        if (c + 1 < n_chunks)
+            fetch(c + 1);
+        // two densities per v_min3; the fragments of the next pair are read while this pair is folded
+        float4 xa0, xa1, xd0, xd1, ya0, ya1, yd0, yd1;
+#define TT_LOAD(P, K)                                  \
+    P##a0 = *(const float4*)&sA[(K)][4 * mi];          \
+    P##a1 = *(const float4*)&sA[(K) + 1][4 * mi];      \
+    P##d0 = *(const float4*)&sD[(K)][4 * ti];          \
+    P##d1 = *(const float4*)&sD[(K) + 1][4 * ti];
+#define TT_FOLD(P)                                                                                                          \
+    {                                                                                                                       \
+        const float av0[4] = {P##a0.x, P##a0.y, P##a0.z, P##a0.w}, av1[4] = {P##a1.x, P##a1.y, P##a1.z, P##a1.w};           \
+        const float dv0[4] = {P##d0.x, P##d0.y, P##d0.z, P##d0.w}, dv1[4] = {P##d1.x, P##d1.y, P##d1.z, P##d1.w};           \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 4; j += 2) {                    \
+            const gmm_f32x2 s0 = gmm_f32x2{dv0[j], dv0[j + 1]} + gmm_f32x2{av0[i], av0[i]};                                 \
+            const gmm_f32x2 s1 = gmm_f32x2{dv1[j], dv1[j + 1]} + gmm_f32x2{av1[i], av1[i]};                                 \
+            mn[i][j]           = min3_raw(mn[i][j], s0.x, s1.x);                                                            \
+            mn[i][j + 1]       = min3_raw(mn[i][j + 1], s0.y, s1.y);                                                        \
+        }                                                                                                                   \
+    }
+        TT_LOAD(x, 0)
+#pragma unroll 2
+        for (int k = 0; k < TT_KB; k += 4) {
+            TT_LOAD(y, k + 2)
+            TT_FOLD(x)
+            if (k + 4 < TT_KB) {
+                TT_LOAD(x, k + 4)
+            }
+            TT_FOLD(y)
+        }
+#undef TT_LOAD
+#undef TT_FOLD
+    }
+    float thr[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float am = g_amax[m_blk + 4 * mi + i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            thr[i][j] = mn[i][j] + (4.76837158e-7f * (am + fabsf(mn[i][j])) + 1e-30f);  // tau = 2^-21 (...)
+    }
+
+    // ---------------- pass 2: exact rule on the densities within tau
+    MaxState st[4][4];
+    fetch(0);
+    for (int c = 0; c < n_chunks; ++c) {
+        __syncthreads();
+        stash();
+        __syncthreads();
+        if (c + 1 < n_chunks)
+            fetch(c + 1);
+#pragma unroll 4
+        for (int k = 0; k < TT_KB; ++k) {
+            const float4 a4 = *(const float4*)&sA[k][4 * mi];
+            const float4 d4 = *(const float4*)&sD[k][4 * ti];
+            const float  av[4] = {a4.x, a4.y, a4.z, a4.w}, dv[4] = {d4.x, d4.y, d4.z, d4.w};
+            float        worst = FLT_MAX;  // min over the tile of s^ - thr  (x - y <= 0 <=> x <= y exactly)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; j += 2) {
+                    const gmm_f32x2 e = (gmm_f32x2{dv[j], dv[j + 1]} + gmm_f32x2{av[i], av[i]}) - gmm_f32x2{thr[i][j], thr[i][j + 1]};
+                    worst             = min3_raw(worst, e.x, e.y);
+                }
+            if (worst <= 0.f) {
+                const int kk = c * TT_KB + k;  // < K: padded rows are FLT_MAX
+                const double ln = g_ln64[kk];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    bool hit = false;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        hit |= (dv[j] + av[i]) <= thr[i][j];
+                    if (hit) {
+                        const double c64 = (double)g_m2lw_t[(size_t)kk * mp + m_blk + 4 * mi + i] + ln;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if ((dv[j] + av[i]) <= thr[i][j])
+                                st[i][j].add(c64, 0.f, dv[j], (uint32_t)kk);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int t = t_blk + 4 * ti + j;
+        if (t >= dims.T)
+            continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m_blk + 4 * mi + i;
+            if (m < dims.n_mix) {
+                g_scores[(size_t)t * dims.n_mix + m] = st[i][j].result();
+                if (g_best)
+                    g_best[(size_t)t * dims.n_mix + m] = st[i][j].idx;
+            }
+        }
+    }
+}
+
 struct GmmCombineDims {
     int T, Tpad, n_mix, mix_tile;
 };
@@ -480,6 +662,7 @@ struct amx_gmm {
     bool      uniform = false;  // tied AND every mixture lists the same densities: lane = mixture combine
     int       K = 0, mix_pad = 0;
     float*    d_m2lw_t = nullptr;  // [K][mix_pad]
+    float *   d_ahat_t = nullptr, *d_amax = nullptr;  // screen tables: fl32(m2lw + logNorm) [K][mix_pad], max_k |.| [mix_pad]
     double *  d_ln64 = nullptr, *d_dist64 = nullptr;
     float*    d_ln32 = nullptr;
     size_t    dist64_cap = 0;
@@ -685,8 +868,17 @@ int amx_gmm_create(amx_ctx* ctx, const amx_gmm_model* m, amx_gmm** out) {
             ln32[k] = h->lognorm[k_cov[k]];
             ln64[k] = (double)ln32[k];
         }
+        // screen tables (gmm_tied_tile_kernel): an f32 image of the per-entry constant and its largest magnitude per mixture
+        std::vector<float> ahat((size_t)h->K * h->mix_pad, 0.f), amax(h->mix_pad, 0.f);
+        for (int k = 0; k < h->K; ++k)
+            for (int i = 0; i < h->n_mix; ++i) {
+                const float a                    = wt[(size_t)k * h->mix_pad + i] + ln32[k];
+                ahat[(size_t)k * h->mix_pad + i] = a;
+                amax[i]                          = std::max(amax[i], std::fabs(a));
+            }
         if ((r = gupload(&h->d_m2lw_t, wt.data(), wt.size())) != AMX_OK || (r = gupload(&h->d_ln64, ln64.data(), ln64.size())) != AMX_OK ||
-            (r = gupload(&h->d_ln32, ln32.data(), ln32.size())) != AMX_OK) {
+            (r = gupload(&h->d_ln32, ln32.data(), ln32.size())) != AMX_OK || (r = gupload(&h->d_ahat_t, ahat.data(), ahat.size())) != AMX_OK ||
+            (r = gupload(&h->d_amax, amax.data(), amax.size())) != AMX_OK) {
             amx_gmm_destroy(h);
             return r;
         }
@@ -719,6 +911,8 @@ void amx_gmm_destroy(amx_gmm* h) {
     hipFree(h->d_dist);
     hipFree(h->d_dist64);
     hipFree(h->d_m2lw_t);
+    hipFree(h->d_ahat_t);
+    hipFree(h->d_amax);
     hipFree(h->d_ln64);
     hipFree(h->d_ln32);
     delete h;
@@ -837,7 +1031,8 @@ int amx_gmm_score_dev(amx_gmm* h, int mode, const float* feats_dev, int T, float
         dp.dens_tile = 16;
         const int  fb      = amx::ceil_div(Tc, 256);
         const bool use_uni = h->uniform;
-        const bool need64  = use_uni && mode == AMX_GMM_MAX;
+        static const int screen = getenv("AMX_GMM_SCREEN") ? atoi(getenv("AMX_GMM_SCREEN")) : 1;  // 0: plain f64 kernel (A/B)
+        const bool need64  = use_uni && mode == AMX_GMM_MAX && !screen;
         if (need64 && need > h->dist64_cap) {
             hipFree(h->d_dist64);
             h->d_dist64   = nullptr;
@@ -863,7 +1058,11 @@ int amx_gmm_score_dev(amx_gmm* h, int mode, const float* feats_dev, int T, float
 #define AMX_UNI(STATE, F)                                                                                                        \
     hipLaunchKernelGGL((amx::gmm_combine_uniform_kernel<amx::STATE, F>), grid, dim3(256), 0, h->ctx->stream, h->d_dist, h->d_dist64, \
                        sc, bd, h->d_m2lw_t, h->d_k_dens, h->d_ln64, h->d_ln32, ud)
-            if (mode == AMX_GMM_MAX) {
+            if (mode == AMX_GMM_MAX && screen) {
+                hipLaunchKernelGGL(amx::gmm_tied_tile_kernel, dim3(h->mix_pad / 64, Tpad / 64), dim3(256), 0, h->ctx->stream, h->d_dist, sc, bd,
+                                   h->d_m2lw_t, h->d_ahat_t, h->d_amax, h->d_k_dens, h->d_ln64, ud);
+            }
+            else if (mode == AMX_GMM_MAX) {
                 if (FR == 4) AMX_UNI(MaxState, 4);
                 else if (FR == 16) AMX_UNI(MaxState, 16);
                 else if (FR == 2) AMX_UNI(MaxState, 2);

@@ -60,6 +60,66 @@ float run(Problem& p, int iters, bool quiet = false) {
     return ms;
 }
 
+template<class C, int DBG>
+float run_pipe(Problem& p, int iters, bool quiet = false) {
+    using P       = amx::PipeLds<C, true>;
+    auto      k   = amx::gemm_bf16_pipe_kernel<C, AMX_ACT_NONE, true, DBG>;
+    const int ntn = p.Npad / C::BN, ntt = p.Tpad / C::BT;
+    CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, P::BYTES));
+    int        grid = std::min(ntn * ntt, p.n_cu) & ~7;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    float total = 0;
+    for (int it = -2; it < iters; ++it) {
+        CK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL(k, dim3(grid), dim3(C::THREADS), P::BYTES, 0, p.W, p.X, p.bias, (void*)p.out, p.K, p.K, p.N, p.N, p.T, ntn, ntn * ntt,
+                           p.gt, p.gn, 1, p.pmin, p.pidx, p.Tpad);
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        if (it >= 0)
+            total += ms;
+    }
+    const float ms = total / iters;
+    if (!quiet) printf("pipe %3d  group %dx%d  tile %dx%d  grid %d  %.4f ms  %.0f TFLOP/s\n", DBG, p.gt, p.gn, C::BN, C::BT, grid, ms, 2.0 * p.N * p.K * p.T / ms * 1e-9);
+    fflush(stdout);
+    return ms;
+}
+
+void dump_trace(Problem& p, size_t trace_n) {
+    std::vector<unsigned long long> tr(trace_n);
+    CK(hipMemcpy(tr.data(), p.trace, trace_n * 8, hipMemcpyDeviceToHost));
+    const int grid = 256, steps = (p.Npad / 256) * (p.Tpad / 256) / grid;
+    unsigned long long t00 = ~0ull;
+    for (int b = 0; b < grid; ++b) t00 = std::min(t00, tr[(size_t)b * 256]);
+    printf("step: per XCD 0 start skew (us) | all: start min..max, kloop avg, epilogue avg (us)   [100 MHz clock]\n");
+    for (int st = 0; st < steps; ++st) {
+        double smin = 1e30, smax = 0, kl = 0, ep = 0, x0min = 1e30, x0max = 0;
+        for (int b = 0; b < grid; ++b) {
+            const unsigned long long* r = &tr[((size_t)b * 64 + st) * 4];
+            double s0 = (r[0] - t00) * 0.01, s1 = (r[1] - t00) * 0.01, s2 = (r[2] - t00) * 0.01;
+            smin = std::min(smin, s0); smax = std::max(smax, s0);
+            if ((b & 7) == 0) { x0min = std::min(x0min, s0); x0max = std::max(x0max, s0); }
+            kl += s1 - s0; ep += s2 - s1;
+        }
+        if (st == steps - 1) {
+            printf("end of last tile per XCD (us): ");
+            for (int x = 0; x < 8; ++x) {
+                double mn = 1e30, mx = 0;
+                for (int b = x; b < grid; b += 8) {
+                    double e = (tr[((size_t)b * 64 + st) * 4 + 2] - t00) * 0.01;
+                    mn = std::min(mn, e); mx = std::max(mx, e);
+                }
+                printf(" x%d %.0f..%.0f", x, mn, mx);
+            }
+            printf("\n");
+        }
+        printf("%2d: xcd0 skew %6.1f | start %8.1f..%8.1f  kloop %6.1f  epi %6.1f\n", st, x0max - x0min, smin, smax, kl / grid, ep / grid);
+    }
+}
+
 int main(int argc, char** argv) {
     Problem p;
     p.Npad = (p.N + 255) / 256 * 256;
@@ -98,7 +158,13 @@ int main(int argc, char** argv) {
             sscanf(s.c_str() + s.find(':') + 1, "%dx%d", &p.gt, &p.gn);
             s = s.substr(0, s.find(':'));
         }
-        if (s == "0") run<CfgC, 0>(p, iters);
+        if (s == "p0") run_pipe<CfgC, 0>(p, iters);
+        else if (s == "p2") run_pipe<CfgC, 2>(p, iters);
+        else if (s == "p8") run_pipe<CfgC, 8>(p, iters);
+        else if (s == "p12") run_pipe<CfgC, 12>(p, iters);
+        else if (s == "p4") run_pipe<CfgC, 4>(p, iters);
+        else if (s == "ptrace") { run_pipe<CfgC, 1>(p, 1); dump_trace(p, trace_n); }
+        else if (s == "0") run<CfgC, 0>(p, iters);
         else if (s == "64") run<CfgC, 64 | 128>(p, iters);       // operand streaming only, no epilogue
         else if (s == "128") run<CfgC, 128>(p, iters);           // K-loop only
         else if (s == "256") run<CfgC, 256>(p, iters);           // epilogue without global stores
@@ -132,7 +198,19 @@ int main(int argc, char** argv) {
                     if ((b & 7) == 0) { x0min = std::min(x0min, s0); x0max = std::max(x0max, s0); }
                     kl += s1 - s0; ep += s2 - s1;
                 }
-                printf("%2d: xcd0 skew %6.1f | start %8.1f..%8.1f  kloop %6.1f  epi %6.1f\n", st, x0max - x0min, smin, smax, kl / grid, ep / grid);
+                if (st == steps - 1) {
+            printf("end of last tile per XCD (us): ");
+            for (int x = 0; x < 8; ++x) {
+                double mn = 1e30, mx = 0;
+                for (int b = x; b < grid; b += 8) {
+                    double e = (tr[((size_t)b * 64 + st) * 4 + 2] - t00) * 0.01;
+                    mn = std::min(mn, e); mx = std::max(mx, e);
+                }
+                printf(" x%d %.0f..%.0f", x, mn, mx);
+            }
+            printf("\n");
+        }
+        printf("%2d: xcd0 skew %6.1f | start %8.1f..%8.1f  kloop %6.1f  epi %6.1f\n", st, x0max - x0min, smin, smax, kl / grid, ep / grid);
             }
         }
     }
