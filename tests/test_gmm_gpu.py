@@ -176,3 +176,48 @@ def test_viterbi_accumulators(ctx, pooled):
     sc.accumulate_dev(xd, 3000, mix, chosen, 0, acc2)
     torch.cuda.synchronize()
     assert np.allclose(acc2.cpu().numpy(), want, rtol=1e-12, atol=1e-9)
+
+
+def _tied_adversarial(seed, n_mix, n_dens, dim, dup_every, big=False):
+    """uniform-list tied model whose densities contain exact duplicates (equal f64 sums: the FIRST must win) and whose
+    weights contain neighbours one f32 ulp apart (sums that round to the same f32: the reference's index then moves to
+    the LAST density that is still smaller in f64)."""
+    model = synth.gmm_tied(n_mix, n_dens, dim, seed=seed, pooled=True, alpha=2.0)
+    rng = np.random.Generator(np.random.PCG64(seed + 1))
+    means = model["means"]
+    for d in range(dup_every, n_dens, dup_every):
+        means[d] = means[d - dup_every]                 # same distance for every frame
+    lw = model["log_weight"].reshape(n_mix, n_dens)
+    for d in range(dup_every, n_dens, dup_every):
+        which = rng.integers(0, 3, n_mix)
+        base = (-2 * lw[:, d - dup_every]).astype(np.float32)
+        nudged = np.where(which == 0, base, np.where(which == 1, np.nextafter(base, np.float32(np.inf)),
+                                                      np.nextafter(base, np.float32(-np.inf)))).astype(np.float32)
+        lw[:, d] = nudged.astype(np.float64) / -2.0      # (float)(-2 * logw) reproduces `nudged` exactly
+    if big:
+        lw += 3.0e5                                      # |constant| ~ 6e5: tau must scale with it
+    model["log_weight"] = lw.reshape(-1)
+    return model
+
+
+@pytest.mark.parametrize("n_dens,dup_every,big", [(96, 7, False), (200, 3, False), (130, 5, True)])
+def test_tied_screen_ties_and_ulp_neighbours(ctx, n_dens, dup_every, big):
+    """the f32-screened tied kernel applies the reference's sequential f64 rule to the survivors only; ties, one-ulp
+    neighbours, density counts that are not a multiple of the 64-wide chunk and huge constants must not change a bit"""
+    model = _tied_adversarial(41 + n_dens, 150, n_dens, 24, dup_every, big)
+    x = feats(100, 24, 43)
+    assert_exact(ctx, model, x)
+    import rasr_amd
+    _, best = rasr_amd.GmmFeatureScorer(ctx, model).score(x)
+    assert (best % dup_every != 0).any() and (best >= dup_every).any()  # duplicates do win sometimes
+
+
+def test_tied_screen_non_finite_and_constant_features(ctx):
+    model = synth.gmm_tied(70, 64, 16, seed=9, pooled=True)
+    x = feats(64, 16, 10)
+    x[3] = 0.0
+    x[5, 2] = np.inf          # distance +inf for every density: no density ever beats FLT_MAX
+    x[6, 0] = np.nan
+    x[7] = 1e18               # squares overflow to +inf
+    x[8] = 3e3                # large but finite distances (~1e8): tau scales with |min|
+    assert_exact(ctx, model, x)
