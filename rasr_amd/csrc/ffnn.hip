@@ -576,14 +576,12 @@ struct PipeLds {
     static constexpr int BEST_OFF     = 2 * C::STAGE_BYTES;                 // arg-min exchange [2][WN][BT]
     static constexpr int BEST_BYTES   = LAST ? 2 * C::WN * C::BT * 4 : 0;
     static constexpr int BIAS_OFF     = BEST_OFF + BEST_BYTES;              // [2][BN] f32, double buffered per tile
-    static constexpr int PF_OFF       = BIAS_OFF + 2 * C::BN * 4;           // landing pad of the L2 prefetch touches
-    static constexpr int BYTES        = PF_OFF + C::NW * 256;
+    static constexpr int BYTES        = BIAS_OFF + 2 * C::BN * 4;
     static constexpr int STORES       = LAST ? C::MJ * 2 * 8 : C::MJ * 8;   // global stores per wave and interior tile
     static_assert(C::STAGES == 2 && C::BKC == 64, "two 64-wide stages");
     static_assert(C::BN / C::WN == 128 && C::MI == 4, "wave tile is 128 outputs wide");
     static_assert(C::NW * WAVE_SCRATCH <= C::STAGE_BYTES, "epilogue scratch must fit into one stage");
     static_assert(C::BN * 4 == 1024, "the bias vector is one wave-wide 16-byte LDS-DMA");
-    static_assert(C::NW == 8 && C::BN == 256 && C::BT == 256, "prefetch roles: 4 waves x 64 rows per panel");
     static_assert(STORES + 2 < 64, "vmcnt immediate");
 };
 
@@ -591,7 +589,7 @@ __device__ __forceinline__ int pipe_swz(int row, int chunk) {
     return row * 256 + ((chunk ^ (row & 15)) << 4);
 }
 
-// DBG: tools/gemm_probe.hip only (1 time stamps, 2 no global stores, 4 no epilogue, 8 no L2 prefetch)
+// DBG: tools/gemm_probe.hip only (1 time stamps, 2 no global stores, 4 no epilogue)
 template<class C, int ACT, bool LAST, int DBG = 0>
 __global__ __launch_bounds__(C::THREADS) void gemm_bf16_pipe_kernel(const bf16_t* __restrict__ W, const bf16_t* __restrict__ X,
                                                                    const float* __restrict__ bias, void* __restrict__ out, int Kpad, int ldx,
@@ -675,12 +673,6 @@ __global__ __launch_bounds__(C::THREADS) void gemm_bf16_pipe_kernel(const bf16_t
         const int  nvi      = vi + (int)gridDim.x;
         const bool has_next = nvi < n_tiles_total;
         const int  step     = (vi - (int)blockIdx.x) / (int)gridDim.x;
-        // which panels this workgroup touches ahead: W (waves 0-3) for the first tile row of a super-tile, X (waves 4-7)
-        // for its first tile column; without super-tiles every workgroup owns its W panel and X is shared by the row
-        const bool pf_w = GT > 0 ? (tile_t % GT == 0) : true, pf_x = GN > 0 ? (tile_n % GN == 0) : (tile_n % 8 == 0);
-        const bool my_pf = !(DBG & 8) && (wave < 4 ? pf_w : pf_x);
-        const bf16_t* pf_base = wave < 4 ? W + (size_t)(tile_n * C::BN + wave * 64 + lane) * Kpad
-                                         : X + (size_t)(tile_t * C::BT + (wave - 4) * 64 + lane) * ldx;
         if ((DBG & 1) && tid == 0) {
             g_gemm_trace[((size_t)blockIdx.x * 64 + (step & 63)) * 4 + 0] = wall_clock64();
             g_gemm_trace[((size_t)blockIdx.x * 64 + (step & 63)) * 4 + 3] = __builtin_amdgcn_s_getreg((3 << 11) | 20);
@@ -693,8 +685,6 @@ __global__ __launch_bounds__(C::THREADS) void gemm_bf16_pipe_kernel(const bf16_t
                 else
                     wait_vmcnt<P::STORES>();
             }
-            else if (my_pf && kt >= 1 && kt < KT - 1)
-                wait_vmcnt<2>();  // the two prefetch touches issued behind K-tile kt's loads may stay in flight
             else
                 wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
@@ -703,15 +693,6 @@ __global__ __launch_bounds__(C::THREADS) void gemm_bf16_pipe_kernel(const bf16_t
                 pw += C::BKC;
                 px += C::BKC;
                 issue(nslot, pw, px);
-                if (my_pf && kt + 2 < KT) {
-                    // L2 prefetch of this wave's 64 panel rows of K-tile kt+2 (both 64-byte halves of the 128-byte row
-                    // piece): one dword per lane into a dummy LDS pad.  The operand loads have only one K-step (~1.7 us)
-                    // between issue and use; a first touch that misses L2 takes longer, and every workgroup sharing the
-                    // panel would wait for the same fill.  One workgroup per panel touches it a K-step earlier.
-                    const bf16_t* q = pf_base + (size_t)(kt + 2) * C::BKC;
-                    __builtin_amdgcn_global_load_lds((const void*)q, (__attribute__((address_space(3))) void*)(lds + P::PF_OFF + wave * 256), 4, 0, 0);
-                    __builtin_amdgcn_global_load_lds((const void*)(q + 32), (__attribute__((address_space(3))) void*)(lds + P::PF_OFF + wave * 256), 4, 0, 0);
-                }
             }
             else if (has_next) {  // the stream continues with the next tile
                 coords(nvi, tile_t, tile_n);
@@ -1136,7 +1117,7 @@ void launch_bf16_pipe(amx_ffnn* h, int l, const void* x, int ldx, void* out, int
     using P       = amx::PipeLds<C, LAST>;
     const int ntn = h->Npad[l] / C::BN, ntt = Tpad / C::BT;
     auto      k   = amx::gemm_bf16_pipe_kernel<C, ACT, LAST>;
-    const int gt = h->group_t >= 0 ? h->group_t : 2, gn = h->group_n >= 0 ? h->group_n : 16;
+    const int gt = h->group_t >= 0 ? h->group_t : 16, gn = h->group_n >= 0 ? h->group_n : 8;  // bench: 16x8 / 32x8 / 8x8 within noise, 2x16 and row-major 2-10 % slower
     static_assert(P::BYTES <= 160 * 1024, "LDS budget");
     hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, P::BYTES);
     int grid = std::min(ntn * ntt, std::max(h->ctx->n_cu, 8));

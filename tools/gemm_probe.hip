@@ -160,8 +160,6 @@ int main(int argc, char** argv) {
         }
         if (s == "p0") run_pipe<CfgC, 0>(p, iters);
         else if (s == "p2") run_pipe<CfgC, 2>(p, iters);
-        else if (s == "p8") run_pipe<CfgC, 8>(p, iters);
-        else if (s == "p12") run_pipe<CfgC, 12>(p, iters);
         else if (s == "p4") run_pipe<CfgC, 4>(p, iters);
         else if (s == "ptrace") { run_pipe<CfgC, 1>(p, 1); dump_trace(p, trace_n); }
         else if (s == "0") run<CfgC, 0>(p, iters);
