@@ -63,7 +63,8 @@ const char* amx_last_error(void);
 int  amx_init(int device_ordinal, amx_ctx** out);
 void amx_destroy(amx_ctx* ctx);
 /* Run all subsequent launches of this context on the caller's hipStream_t (e.g. torch's current
- * stream); NULL restores the context's own stream. */
+ * stream); NULL restores the context's own stream.  To run on the legacy default stream pass hipStreamLegacy
+ * ((hipStream_t)1): the handle 0 that frameworks report for it would read as NULL here. */
 int amx_set_stream(amx_ctx* ctx, void* hip_stream);
 int amx_synchronize(amx_ctx* ctx);
 /* Per-kernel timing with HIP events on the context's stream (used by bench.py for the roofline

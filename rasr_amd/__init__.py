@@ -56,7 +56,10 @@ class Context:
     def use_torch_stream(self):
         """Launch on torch's current HIP stream (so torch events / allocator ordering apply)."""
         import torch
-        _lib.check(self.L.amx_set_stream(self.h, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+        handle = torch.cuda.current_stream(self.device).cuda_stream
+        # torch's default stream is the legacy NULL stream (handle 0); amx_set_stream(NULL) would select the context's own
+        # non-blocking stream, which is NOT ordered against it -> name the legacy stream explicitly (hipStreamLegacy = 1)
+        _lib.check(self.L.amx_set_stream(self.h, C.c_void_p(handle if handle else 1)))
 
     def synchronize(self):
         _lib.check(self.L.amx_synchronize(self.h))

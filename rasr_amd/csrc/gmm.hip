@@ -603,6 +603,250 @@ __global__ __launch_bounds__(256) void gmm_tied_tile_kernel(const float* __restr
     }
 }
 
+// =================================================================================================================
+// MFMA-screened maximum approximation for mixtures with PRIVATE densities (CART-style models, <= 16 densities each).
+//
+// gmm_direct_kernel evaluates every density exactly: 4 unfused f32 operations per (frame, density, dimension) in the
+// reference's association order, which already runs near the unpacked VALU issue ceiling.  But only the densities whose
+// f64 sum rounds to the winning f32 value can influence (score, best density) -- see the subsequence argument in front
+// of gmm_tied_tile_kernel -- and those can be found with arithmetic that need not be exact, as long as its error is
+// bounded.  Expanding ((mu - x) r)^2 turns the distance into a dot product plus a per-density constant (the frame term is
+// common to a mixture's densities and drops out of the comparison):
+//     pooled covariance      g[t][k] = c_k + sum_i (-2 mu_ki r_i)   * (x_ti r_i)                   K = dim
+//     per-density covariance g[t][k] = c_k + sum_i (-2 mu_ki r_ki^2) * x_ti + (r_ki^2) * x_ti^2    K = 2 dim
+// with c_k = m2lw_k + logNorm_k + sum_i (mu_ki r_ki)^2.  That is a GEMM with f16 operands on the matrix cores
+// (gmm_screen_kernel, 256 density slots x 256 frames per workgroup, mixtures padded to 16 slots).  Its epilogue takes the
+// minimum over each mixture's 16 slots and emits a 16-bit candidate mask: slot j is kept unless g_j > g_min + tau, where
+//     tau = 2.2e-3 na nx + 1.3e-4 sqrt(K) (na + nx) + 1.6e-5 (|g_min| + max|c| + q)
+// bounds twice the worst difference between g and the reference's own f64 sum minus the frame term: f16 rounding of both
+// operands (2^-11 relative each, 2^-14 absolute if subnormals were flushed; Cauchy-Schwarz with na = max ||A_k||, nx =
+// ||X_t|| of the rounded operands), f32 accumulation of <= 128 exact products, rounding of c_k, the (dim + 3) ulp error of
+// the reference's f32 distance, plus one ulp of the winning f32 (q bounds the dropped frame term).  Frames whose operand
+// does not fit f16 get nx = inf and therefore all-ones masks; models whose operand does not fit are not screened at all.
+// gmm_screen_exact_kernel then runs gmm_distance and the reference's sequential f64 rule over the surviving slots only
+// (~1 of 16), in slot order: bit-identical scores and density indices at ~1/10 of the exact arithmetic.
+typedef _Float16 gmm_f16x8 __attribute__((ext_vector_type(8)));
+typedef float    gmm_f32x16 __attribute__((ext_vector_type(16)));
+
+struct GmmScreenDims {
+    int   T, Tpad, dim, Kp, Mpad16, pooled;
+    float rmax2, sqrtK;
+};
+
+// features -> f16 operand rows [Tpad x Kp] (zero padded), nx[t] = ||row|| (inf when the row does not fit f16), q[t]
+__global__ __launch_bounds__(256) void gmm_screen_pack_kernel(const float* __restrict__ g_feats, const float* __restrict__ g_isr0,
+                                                             _Float16* __restrict__ g_X, float* __restrict__ g_nx,
+                                                             float* __restrict__ g_q, GmmScreenDims d) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= d.Tpad)
+        return;
+    _Float16* row = g_X + (size_t)t * d.Kp;
+    float     n2 = 0.f, q = 0.f;
+    bool      fits = true;
+    for (int i = 0; i < d.Kp; ++i) {
+        float v = 0.f;
+        if (t < d.T) {
+            if (d.pooled) {
+                if (i < d.dim)
+                    v = g_feats[(size_t)t * d.dim + i] * g_isr0[i];
+            }
+            else if (i < d.dim)
+                v = g_feats[(size_t)t * d.dim + i];
+            else if (i < 2 * d.dim) {
+                const float x = g_feats[(size_t)t * d.dim + i - d.dim];
+                v             = x * x;
+            }
+        }
+        fits &= fabsf(v) <= 65504.f;  // false for NaN as well
+        const _Float16 hv = (_Float16)v;
+        row[i]            = hv;
+        const float r     = (float)hv;
+        n2 += r * r;
+        if (d.pooled || i < d.dim)
+            q += v * v;
+    }
+    g_nx[t] = fits ? sqrtf(n2) : __builtin_inff();
+    g_q[t]  = d.pooled ? q : q * d.rmax2;
+}
+
+// LDS: [KT][A tile 256 x 128 B | X tile 256 x 128 B] [c: 256 f32]; same row swizzle as the bf16 GEMM
+template<int KT>
+__global__ __launch_bounds__(512) void gmm_screen_kernel(const _Float16* __restrict__ g_A, const _Float16* __restrict__ g_X,
+                                                        const float* __restrict__ g_c, const float* __restrict__ g_na,
+                                                        const float* __restrict__ g_cabs, const float* __restrict__ g_nx,
+                                                        const float* __restrict__ g_q, uint16_t* __restrict__ g_masks, int n_tiles_r,
+                                                        GmmScreenDims d) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr int STAGE = 64 * 1024, A_BYTES = 32 * 1024;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave >> 2, wt = wave & 3;  // wave tile: 128 slots x 64 frames
+    const int tile_r = blockIdx.x % n_tiles_r, tile_t = blockIdx.x / n_tiles_r;
+    const int r0 = tile_r * 256, t0 = tile_t * 256;
+    const int Kp = KT * 64;
+    float*    s_c = (float*)(lds + KT * STAGE);
+    if (tid < 256)
+        s_c[tid] = g_c[r0 + tid];
+    {
+        const int xr = ((wave & 1) * 4 + (lane >> 4)) & 7;
+        const size_t off = (size_t)(wave * 8 + (lane >> 3)) * Kp + (((lane & 7) ^ xr) << 3);
+        const _Float16* pa = g_A + (size_t)r0 * Kp + off;
+        const _Float16* px = g_X + (size_t)t0 * Kp + off;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            char* base = lds + kt * STAGE + wave * 1024;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                __builtin_amdgcn_global_load_lds((const void*)(pa + (size_t)i * 64 * Kp + kt * 64),
+                                                 (__attribute__((address_space(3))) void*)(base + i * 8 * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const void*)(px + (size_t)i * 64 * Kp + kt * 64),
+                                                 (__attribute__((address_space(3))) void*)(base + A_BYTES + i * 8 * 1024), 16, 0, 0);
+            }
+        }
+    }
+    gmm_f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                acc[i][j][r] = 0.f;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int frow = lane & 31, fk = lane >> 5;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+        const char* abase = lds + kt * STAGE;
+        const char* xbase = abase + A_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            gmm_f16x8 a[4], b[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = wn * 128 + i * 32 + frow;
+                a[i]        = *(const gmm_f16x8*)(abase + r * 128 + (((ks * 2 + fk) ^ ((r >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int r = wt * 64 + j * 32 + frow;
+                b[j]        = *(const gmm_f16x8*)(xbase + r * 128 + (((ks * 2 + fk) ^ ((r >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    // ---- epilogue: lane (tl32, hh) holds, for frame tl32 of pass j, slots i*32 + 8g + 4hh + e: mixture 2i + (g >> 1) of the
+    // wave's 8, slot (g & 1) * 8 + 4hh + e within it.  The partner lane (lane ^ 32) holds the other 8 slots of each mixture.
+    const int tl32 = lane & 31, hh = lane >> 5;
+    const int mt0  = tile_r * 16 + wn * 8;  // first mixture slot group of this wave
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int   t  = t0 + wt * 64 + j * 32 + tl32;
+        const float nx = g_nx[t], q = g_q[t];
+        unsigned    packed[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            unsigned two = 0;
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp) {
+                float v[8];
+#pragma unroll
+                for (int gg = 0; gg < 2; ++gg) {
+                    const int    g  = gp * 2 + gg;
+                    const float4 c4 = *(const float4*)(s_c + wn * 128 + i * 32 + 8 * g + 4 * hh);
+                    v[gg * 4 + 0]   = acc[i][j][g * 4 + 0] + c4.x;
+                    v[gg * 4 + 1]   = acc[i][j][g * 4 + 1] + c4.y;
+                    v[gg * 4 + 2]   = acc[i][j][g * 4 + 2] + c4.z;
+                    v[gg * 4 + 3]   = acc[i][j][g * 4 + 3] + c4.w;
+                }
+                float mn = v[0];
+#pragma unroll
+                for (int e = 1; e < 8; ++e)
+                    mn = fminf(mn, v[e]);
+                mn = fminf(mn, __shfl_xor(mn, 32, 64));
+                const int   m   = mt0 + i * 2 + gp;
+                const float na  = g_na[m];
+                const float tau = 2.2e-3f * na * nx + 1.3e-4f * d.sqrtK * (na + nx) + 1.6e-5f * (fabsf(mn) + g_cabs[m] + q) + 1e-30f;
+                const float thr = mn + tau;
+                unsigned    bits = 0;
+#pragma unroll
+                for (int gg = 0; gg < 2; ++gg)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        bits |= (!(v[gg * 4 + e] > thr) ? 1u : 0u) << (gg * 8 + 4 * hh + e);  // NaN keeps the slot
+                bits |= (unsigned)__shfl_xor((int)bits, 32, 64);
+                two |= bits << (16 * gp);
+            }
+            packed[i] = two;
+        }
+        if (hh == 0)  // 8 masks x 16 bit = one 16-byte store; rows and groups are 16-byte aligned (Mpad16 % 16 == 0)
+            *(uint4*)(g_masks + (size_t)t * d.Mpad16 + mt0) = make_uint4(packed[0], packed[1], packed[2], packed[3]);
+    }
+}
+
+// exact evaluation of the surviving slots: thread = frame (features in registers), workgroup = 16 mixtures x 256 frames,
+// the 256 slot means (and 1/sigma rows when not pooled) of the tile in LDS, rows padded to DIM + 1 floats
+template<int DIM, bool POOLED>
+__global__ __launch_bounds__(256) void gmm_screen_exact_kernel(const float* __restrict__ g_feats, const uint16_t* __restrict__ g_masks,
+                                                              const uint32_t* __restrict__ g_mix_off, const uint32_t* __restrict__ g_k_mean,
+                                                              const uint32_t* __restrict__ g_k_cov, const double* __restrict__ g_k_c64,
+                                                              const float* __restrict__ g_means, const float* __restrict__ g_isr,
+                                                              float* __restrict__ g_scores, uint32_t* __restrict__ g_best, int T, int n_mix,
+                                                              int Mpad16) {
+    constexpr int LD = DIM + 1;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    float* s_mu = (float*)lds;                    // [256][LD]
+    float* s_is = s_mu + 256 * LD;                // [256][LD] (per-density covariance only)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.x * 16;
+    const int t  = blockIdx.y * 256 + tid;
+    for (int r = wave * 64; r < wave * 64 + 64; ++r) {
+        const int      m  = m0 + (r >> 4), jj = r & 15;
+        const uint32_t k0 = m < n_mix ? g_mix_off[m] : 0u, k1 = m < n_mix ? g_mix_off[m + 1] : 0u;
+        if (k0 + jj < k1 && lane < DIM) {
+            s_mu[r * LD + lane] = g_means[(size_t)g_k_mean[k0 + jj] * DIM + lane];
+            if (!POOLED)
+                s_is[r * LD + lane] = g_isr[(size_t)g_k_cov[k0 + jj] * DIM + lane];
+        }
+    }
+    float x[DIM];
+    const int tt = t < T ? t : T - 1;
+#pragma unroll
+    for (int i = 0; i < DIM; ++i)
+        x[i] = g_feats[(size_t)tt * DIM + i];
+    const uint4* mrow = (const uint4*)(g_masks + (size_t)tt * Mpad16 + m0);
+    const uint4  ma = mrow[0], mb = mrow[1];
+    const unsigned mw[8] = {ma.x, ma.y, ma.z, ma.w, mb.x, mb.y, mb.z, mb.w};
+    __syncthreads();
+#pragma unroll 1
+    for (int mi = 0; mi < 16; ++mi) {
+        const int m = m0 + mi;
+        if (m >= n_mix)
+            break;
+        const uint32_t k0 = g_mix_off[m], nk = g_mix_off[m + 1] - k0;
+        unsigned       mask = ((mi & 1) ? (mw[mi >> 1] >> 16) : mw[mi >> 1]) & 0xffffu & ((1u << nk) - 1u);
+        MaxState       st;
+        while (mask) {  // ascending slot order = the reference's density order
+            const int jj = __ffs((int)mask) - 1;
+            mask &= mask - 1;
+            const float* mu = s_mu + (mi * 16 + jj) * LD;
+            const float* is = POOLED ? g_isr : s_is + (mi * 16 + jj) * LD;
+            const float  dist = gmm_distance<DIM>(x, mu, is);
+            st.add(g_k_c64[k0 + jj], 0.f, dist, (uint32_t)jj);
+        }
+        if (t < T) {
+            g_scores[(size_t)t * n_mix + m] = st.result();
+            if (g_best)
+                g_best[(size_t)t * n_mix + m] = st.idx;
+        }
+    }
+}
+
+
 struct GmmCombineDims {
     int T, Tpad, n_mix, mix_tile;
 };
@@ -668,6 +912,17 @@ struct amx_gmm {
     size_t    dist64_cap = 0;
     float*    d_dist  = nullptr;
     size_t    dist_floats = 0;
+    // MFMA screen (private-density models, <= 16 densities per mixture; see gmm_screen_kernel)
+    bool      screen = false;
+    int       scr_Kp = 0, scr_Rpad = 0, scr_Mpad16 = 0;
+    float     scr_rmax2 = 0.f;
+    _Float16* d_scr_A = nullptr;
+    float *   d_scr_c = nullptr, *d_scr_na = nullptr, *d_scr_cabs = nullptr;
+    // per-call workspace of the screen
+    _Float16* d_scr_X = nullptr;
+    float *   d_scr_nx = nullptr, *d_scr_q = nullptr;
+    uint16_t* d_scr_masks = nullptr;
+    int       scr_cap_T = 0;
 };
 
 namespace {
@@ -677,6 +932,97 @@ int gupload(T** dst, const T* src, size_t n) {
     AMX_HIP(hipMalloc((void**)dst, std::max<size_t>(n, 1) * sizeof(T)));
     if (n)
         AMX_HIP(hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
+    return AMX_OK;
+}
+
+bool screen_dim_supported(int d) {
+    switch (d) {
+        case 16: case 24: case 32: case 33: case 39: case 40: case 45: case 48: case 64: return true;
+        default: return false;
+    }
+}
+
+// maximum approximation through the MFMA screen (see gmm_screen_kernel); frames in chunks that bound the mask workspace
+int score_screened(amx_gmm* h, const float* feats_dev, int T, float* scores_dev, uint32_t* best_dev) {
+    hipStream_t st = h->ctx->stream;
+    const int   chunk = 16384;
+    for (int t0 = 0; t0 < T; t0 += chunk) {
+        const int Tc = std::min(chunk, T - t0), Tpad = (Tc + 255) / 256 * 256;
+        if (Tpad > h->scr_cap_T) {
+            hipFree(h->d_scr_X);
+            hipFree(h->d_scr_nx);
+            hipFree(h->d_scr_q);
+            hipFree(h->d_scr_masks);
+            h->d_scr_X = nullptr;
+            h->d_scr_nx = h->d_scr_q = nullptr;
+            h->d_scr_masks = nullptr;
+            h->scr_cap_T = 0;
+            AMX_HIP(hipMalloc((void**)&h->d_scr_X, (size_t)Tpad * h->scr_Kp * sizeof(_Float16)));
+            AMX_HIP(hipMalloc((void**)&h->d_scr_nx, (size_t)Tpad * 4));
+            AMX_HIP(hipMalloc((void**)&h->d_scr_q, (size_t)Tpad * 4));
+            AMX_HIP(hipMalloc((void**)&h->d_scr_masks, (size_t)Tpad * h->scr_Mpad16 * 2));
+            h->scr_cap_T = Tpad;
+        }
+        const float*       x = feats_dev + (size_t)t0 * h->dim;
+        amx::GmmScreenDims d{Tc, Tpad, h->dim, h->scr_Kp, h->scr_Mpad16, h->pooled ? 1 : 0, h->scr_rmax2,
+                             std::sqrt((float)(h->pooled ? h->dim : 2 * h->dim))};
+        {
+            amx::ScopedKernelTimer timer(h->ctx, "gmm_screen_pack");
+            hipLaunchKernelGGL(amx::gmm_screen_pack_kernel, dim3(Tpad / 256), dim3(256), 0, st, x, h->d_isr, h->d_scr_X, h->d_scr_nx, h->d_scr_q, d);
+        }
+        {
+            amx::ScopedKernelTimer timer(h->ctx, "gmm_screen");
+            const int ntr = h->scr_Rpad / 256, ntt = Tpad / 256;
+            if (h->scr_Kp == 64) {
+                auto k = amx::gmm_screen_kernel<1>;
+                hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024 + 1024);
+                hipLaunchKernelGGL(k, dim3(ntr * ntt), dim3(512), 64 * 1024 + 1024, st, h->d_scr_A, h->d_scr_X, h->d_scr_c, h->d_scr_na,
+                                   h->d_scr_cabs, h->d_scr_nx, h->d_scr_q, h->d_scr_masks, ntr, d);
+            }
+            else {
+                auto k = amx::gmm_screen_kernel<2>;
+                hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024 + 1024);
+                hipLaunchKernelGGL(k, dim3(ntr * ntt), dim3(512), 128 * 1024 + 1024, st, h->d_scr_A, h->d_scr_X, h->d_scr_c, h->d_scr_na,
+                                   h->d_scr_cabs, h->d_scr_nx, h->d_scr_q, h->d_scr_masks, ntr, d);
+            }
+        }
+        {
+            amx::ScopedKernelTimer timer(h->ctx, "gmm");
+            dim3      grid(h->scr_Mpad16 / 16, Tpad / 256);
+            float*    sc = scores_dev + (size_t)t0 * h->n_mix;
+            uint32_t* bd = best_dev ? best_dev + (size_t)t0 * h->n_mix : nullptr;
+#define AMX_EXACT(D)                                                                                                                \
+    case D: {                                                                                                                       \
+        const size_t lds = (size_t)256 * (D + 1) * 4 * (h->pooled ? 1 : 2);                                                         \
+        if (h->pooled) {                                                                                                            \
+            auto k = amx::gmm_screen_exact_kernel<D, true>;                                                                         \
+            hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
+            hipLaunchKernelGGL(k, grid, dim3(256), lds, st, x, h->d_scr_masks, h->d_mix_off, h->d_k_mean, h->d_k_cov, h->d_k_c64,   \
+                               h->d_means, h->d_isr, sc, bd, Tc, h->n_mix, h->scr_Mpad16);                                          \
+        }                                                                                                                           \
+        else {                                                                                                                      \
+            auto k = amx::gmm_screen_exact_kernel<D, false>;                                                                        \
+            hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
+            hipLaunchKernelGGL(k, grid, dim3(256), lds, st, x, h->d_scr_masks, h->d_mix_off, h->d_k_mean, h->d_k_cov, h->d_k_c64,   \
+                               h->d_means, h->d_isr, sc, bd, Tc, h->n_mix, h->scr_Mpad16);                                          \
+        }                                                                                                                           \
+    } break;
+            switch (h->dim) {
+                AMX_EXACT(16)
+                AMX_EXACT(24)
+                AMX_EXACT(32)
+                AMX_EXACT(33)
+                AMX_EXACT(39)
+                AMX_EXACT(40)
+                AMX_EXACT(45)
+                AMX_EXACT(48)
+                AMX_EXACT(64)
+                default: break;
+            }
+#undef AMX_EXACT
+        }
+        AMX_HIP(hipGetLastError());
+    }
     return AMX_OK;
 }
 
@@ -883,6 +1229,66 @@ int amx_gmm_create(amx_ctx* ctx, const amx_gmm_model* m, amx_gmm** out) {
             return r;
         }
     }
+    // ---- MFMA screen tables (gmm_screen_kernel): private densities, <= 16 per mixture, operand fits f16
+    if (!h->tied && screen_dim_supported(m->dim) && !(getenv("AMX_GMM_SCREEN") && atoi(getenv("AMX_GMM_SCREEN")) == 0)) {
+        uint32_t kmax = 0;
+        for (int i = 0; i < m->n_mix; ++i)
+            kmax = std::max(kmax, m->mix_offsets[i + 1] - m->mix_offsets[i]);
+        const int d = m->dim, Kd = h->pooled ? d : 2 * d;
+        if (kmax >= 1 && kmax <= 16 && Kd <= 128) {
+            const int Kp = Kd <= 64 ? 64 : 128, Rpad = (m->n_mix * 16 + 255) / 256 * 256, Mp = Rpad / 16;
+            std::vector<_Float16> A((size_t)Rpad * Kp, (_Float16)0.f);
+            std::vector<float>    c((size_t)Rpad, std::numeric_limits<float>::infinity()), na(Mp, 0.f), cabs(Mp, 0.f);
+            bool                  fits = true;
+            double                rmax2 = 0;
+            for (size_t i = 0; i < h->isr.size(); ++i)
+                rmax2 = std::max(rmax2, (double)h->isr[i] * (double)h->isr[i]);
+            for (int i = 0; i < m->n_mix && fits; ++i)
+                for (uint32_t k = m->mix_offsets[i]; k < m->mix_offsets[i + 1]; ++k) {
+                    const size_t row = (size_t)i * 16 + (k - m->mix_offsets[i]);
+                    const float* mu  = m->means + (size_t)k_mean[k] * d;
+                    const float* is  = h->isr.data() + (size_t)k_cov[k] * d;
+                    double       cc = c64[k], n2 = 0;
+                    for (int x = 0; x < d; ++x) {
+                        const double mr = (double)mu[x] * (double)is[x];
+                        cc += mr * mr;
+                        double a0, a1 = 0;
+                        if (h->pooled)
+                            a0 = -2.0 * mr;
+                        else {
+                            a0 = -2.0 * mr * (double)is[x];
+                            a1 = (double)is[x] * (double)is[x];
+                        }
+                        if (!(std::fabs(a0) <= 65504.0 && a1 <= 65504.0))
+                            fits = false;
+                        const _Float16 h0 = (_Float16)(float)a0, h1 = (_Float16)(float)a1;
+                        A[row * Kp + x]   = h0;
+                        n2 += (double)(float)h0 * (double)(float)h0;
+                        if (!h->pooled) {
+                            A[row * Kp + d + x] = h1;
+                            n2 += (double)(float)h1 * (double)(float)h1;
+                        }
+                    }
+                    c[row]  = (float)cc;
+                    na[i]   = std::max(na[i], (float)(std::sqrt(n2) * 1.0000001));
+                    cabs[i] = std::max(cabs[i], std::fabs((float)cc));
+                    if (!std::isfinite(cc))
+                        fits = false;
+                }
+            if (fits) {
+                h->scr_Kp = Kp;
+                h->scr_Rpad = Rpad;
+                h->scr_Mpad16 = Mp;
+                h->scr_rmax2 = (float)(rmax2 * 1.000001);
+                if ((r = gupload(&h->d_scr_A, A.data(), A.size())) != AMX_OK || (r = gupload(&h->d_scr_c, c.data(), c.size())) != AMX_OK ||
+                    (r = gupload(&h->d_scr_na, na.data(), na.size())) != AMX_OK || (r = gupload(&h->d_scr_cabs, cabs.data(), cabs.size())) != AMX_OK) {
+                    amx_gmm_destroy(h);
+                    return r;
+                }
+                h->screen = true;
+            }
+        }
+    }
     *out = h;
     return AMX_OK;
 }
@@ -910,6 +1316,14 @@ void amx_gmm_destroy(amx_gmm* h) {
     hipFree(h->d_isr0);
     hipFree(h->d_dist);
     hipFree(h->d_dist64);
+    hipFree(h->d_scr_A);
+    hipFree(h->d_scr_c);
+    hipFree(h->d_scr_na);
+    hipFree(h->d_scr_cabs);
+    hipFree(h->d_scr_X);
+    hipFree(h->d_scr_nx);
+    hipFree(h->d_scr_q);
+    hipFree(h->d_scr_masks);
     hipFree(h->d_m2lw_t);
     hipFree(h->d_ahat_t);
     hipFree(h->d_amax);
@@ -980,6 +1394,8 @@ int amx_gmm_score_dev(amx_gmm* h, int mode, const float* feats_dev, int T, float
         AMX_HIP(hipGetLastError());
         return AMX_OK;
     }
+    if (!h->tied && h->screen && mode == AMX_GMM_MAX)
+        return score_screened(h, feats_dev, T, scores_dev, best_dev);
     if (!h->tied) {
         amx::GmmParams p;
         p.feats   = feats_dev;
