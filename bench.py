@@ -218,7 +218,7 @@ class GmmTrain:
 
     def stage_report(self):
         out = {"accumulator_bytes": int(self.acc.numel() * 8)}
-        for k in ("mfcc", "gmm", "stats", "gmm_accumulate"):
+        for k in ("mfcc", "gmm_screen_pack", "gmm_screen", "gmm", "stats", "gmm_accumulate"):
             ms, n = self.ctx.profile_get(k)
             if n:
                 out[k] = dict(avg_ms=round(ms, 4), launches=n)

@@ -71,6 +71,32 @@ __device__ __forceinline__ float gmm_distance(const float (&x)[DIM], const float
     return result;
 }
 
+// Same arithmetic, two dimensions per instruction: v_pk_add_f32 / v_pk_mul_f32 round each half exactly like the scalar
+// operations (nothing is fused), and the partial sums (l0, l1) and (l2, l3) are updated as pairs -- bit-identical to
+// gmm_distance at half the instruction count.  mu and is must be 8-byte aligned.
+typedef float gmm_pk2 __attribute__((ext_vector_type(2)));
+
+template<int DIM>
+__device__ __forceinline__ float gmm_distance_pk(const float (&x)[DIM], const float* __restrict__ mu, const float* __restrict__ is) {
+    gmm_pk2       l01 = {0.f, 0.f}, l23 = {0.f, 0.f};
+    constexpr int EFF = DIM & ~3;
+#pragma unroll
+    for (int i = 0; i < EFF; i += 4) {
+        const gmm_pk2 d01 = (*(const gmm_pk2*)(mu + i) - gmm_pk2{x[i], x[i + 1]}) * *(const gmm_pk2*)(is + i);
+        const gmm_pk2 d23 = (*(const gmm_pk2*)(mu + i + 2) - gmm_pk2{x[i + 2], x[i + 3]}) * *(const gmm_pk2*)(is + i + 2);
+        l01               = l01 + d01 * d01;
+        l23               = l23 + d23 * d23;
+    }
+    float result = 0.f;
+    result       = result + ((l01.x + l01.y) + (l23.x + l23.y));
+#pragma unroll
+    for (int i = EFF; i < DIM; ++i) {
+        float df = (mu[i] - x[i]) * is[i];
+        result   = result + df * df;
+    }
+    return result;
+}
+
 // runtime-dimension variant: features live in LDS as [dim][64] (one column per lane)
 __device__ __forceinline__ float gmm_distance_rt(const float* xs, int dim, const float* __restrict__ mu, const float* __restrict__ is) {
     float     l0 = 0.f, l1 = 0.f, l2 = 0.f, l3 = 0.f;
@@ -797,22 +823,46 @@ __global__ __launch_bounds__(256) void gmm_screen_exact_kernel(const float* __re
                                                               const float* __restrict__ g_means, const float* __restrict__ g_isr,
                                                               float* __restrict__ g_scores, uint32_t* __restrict__ g_best, int T, int n_mix,
                                                               int Mpad16) {
-    constexpr int LD = DIM + 1;
+    constexpr int LD = (DIM + 2) & ~1;  // even (8-byte aligned rows for the packed distance); 42 for DIM = 40 spreads the banks
     extern __shared__ __attribute__((aligned(16))) char lds[];
     float* s_mu = (float*)lds;                    // [256][LD]
     float* s_is = s_mu + 256 * LD;                // [256][LD] (per-density covariance only)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int FG = 4;
     const int m0 = blockIdx.x * 16;
-    const int t  = blockIdx.y * 256 + tid;
-    for (int r = wave * 64; r < wave * 64 + 64; ++r) {
-        const int      m  = m0 + (r >> 4), jj = r & 15;
+    // slot -> mean / covariance row (one slot per thread), then a cooperative copy: 256 rows x DIM floats, consecutive
+    // threads on consecutive floats of a row
+    // plus the slot constants and the mixture sizes, so that the survivor loop touches LDS only
+    double* s_c64 = (double*)(s_mu + (POOLED ? 1 : 2) * 256 * LD);  // [256]; LD is even, so this is 8-byte aligned
+    int*    s_row = (int*)(s_c64 + 256);  // [256] mean row, [256] covariance row (-1 = empty slot), [16] densities per mixture
+    float*  s_sc  = (float*)(s_row + 528);                 // [256][17] scores of the current frame group
+    unsigned char* s_bd = (unsigned char*)(s_sc + 256 * 17);  // [256][20] best slot
+    {
+        const int      m  = m0 + (tid >> 4), jj = tid & 15;
         const uint32_t k0 = m < n_mix ? g_mix_off[m] : 0u, k1 = m < n_mix ? g_mix_off[m + 1] : 0u;
-        if (k0 + jj < k1 && lane < DIM) {
-            s_mu[r * LD + lane] = g_means[(size_t)g_k_mean[k0 + jj] * DIM + lane];
+        const bool     ok = k0 + jj < k1;
+        s_row[tid]       = ok ? (int)g_k_mean[k0 + jj] : -1;
+        s_row[256 + tid] = ok ? (int)g_k_cov[k0 + jj] : -1;
+        s_c64[tid]       = ok ? g_k_c64[k0 + jj] : 0.0;
+        if (jj == 0)
+            s_row[512 + (tid >> 4)] = (int)(k1 - k0);
+    }
+    __syncthreads();
+    for (int e = tid; e < 256 * DIM; e += 256) {
+        const int r = e / DIM, i = e - r * DIM;
+        const int mr = s_row[r];
+        if (mr >= 0) {
+            s_mu[r * LD + i] = g_means[(size_t)mr * DIM + i];
             if (!POOLED)
-                s_is[r * LD + lane] = g_isr[(size_t)g_k_cov[k0 + jj] * DIM + lane];
+                s_is[r * LD + i] = g_isr[(size_t)s_row[256 + r] * DIM + i];
         }
     }
+    __syncthreads();
+    // the tile serves FG groups of 256 frames
+  for (int fg = 0; fg < FG; ++fg) {
+    const int t = (blockIdx.y * FG + fg) * 256 + tid;
+    if (t - tid >= T)
+        break;
     float x[DIM];
     const int tt = t < T ? t : T - 1;
 #pragma unroll
@@ -821,31 +871,67 @@ __global__ __launch_bounds__(256) void gmm_screen_exact_kernel(const float* __re
     const uint4* mrow = (const uint4*)(g_masks + (size_t)tt * Mpad16 + m0);
     const uint4  ma = mrow[0], mb = mrow[1];
     const unsigned mw[8] = {ma.x, ma.y, ma.z, ma.w, mb.x, mb.y, mb.z, mb.w};
-    __syncthreads();
-#pragma unroll 1
-    for (int mi = 0; mi < 16; ++mi) {
-        const int m = m0 + mi;
-        if (m >= n_mix)
-            break;
-        const uint32_t k0 = g_mix_off[m], nk = g_mix_off[m + 1] - k0;
-        unsigned       mask = ((mi & 1) ? (mw[mi >> 1] >> 16) : mw[mi >> 1]) & 0xffffu & ((1u << nk) - 1u);
-        MaxState       st;
-        while (mask) {  // ascending slot order = the reference's density order
+    // Every lane walks ITS OWN list of (mixture, slot) survivors: one distance per loop trip for every lane that still has
+    // work, instead of a trip count of max-over-lanes per mixture (16 x ~2.2 trips become ~1.1 x 16 + spread).
+    const int nm = min(16, n_mix - m0);
+    int       mi = 0;
+    unsigned  mask = 0;
+    MaxState  st;
+    bool      open = false;  // a mixture is loaded into (mask, k0, st)
+    for (;;) {
+        if (!open) {
+            if (mi >= nm)
+                break;
+            const uint32_t nk = (uint32_t)s_row[512 + mi];
+            mask              = ((mi & 1) ? (mw[mi >> 1] >> 16) : mw[mi >> 1]) & 0xffffu & ((1u << nk) - 1u);
+            st                = MaxState();
+            open              = true;
+        }
+        if (mask) {  // ascending slot order = the reference's density order
             const int jj = __ffs((int)mask) - 1;
             mask &= mask - 1;
-            const float* mu = s_mu + (mi * 16 + jj) * LD;
-            const float* is = POOLED ? g_isr : s_is + (mi * 16 + jj) * LD;
-            const float  dist = gmm_distance<DIM>(x, mu, is);
-            st.add(g_k_c64[k0 + jj], 0.f, dist, (uint32_t)jj);
+            const float* mu   = s_mu + (mi * 16 + jj) * LD;
+            const float* is   = POOLED ? g_isr : s_is + (mi * 16 + jj) * LD;
+            const float  dist = gmm_distance_pk<DIM>(x, mu, is);
+            st.add(s_c64[mi * 16 + jj], 0.f, dist, (uint32_t)jj);
         }
-        if (t < T) {
-            g_scores[(size_t)t * n_mix + m] = st.result();
-            if (g_best)
-                g_best[(size_t)t * n_mix + m] = st.idx;
+        if (!mask) {
+            s_sc[tid * 17 + mi] = st.result();
+            s_bd[tid * 20 + mi] = (unsigned char)st.idx;  // 0..15, or 0xff for "no density" (idx = 0xffffffff)
+            ++mi;
+            open = false;
         }
     }
+    // The [256 frames x 16 mixtures] result tile leaves through LDS: four adjacent lanes write the 64 contiguous bytes of one
+    // frame in ONE instruction.  (Per-lane 4-byte stores at a 40 KB stride cost more than the whole evaluation.)
+    __syncthreads();
+    const int  tb   = (blockIdx.y * FG + fg) * 256;
+    const bool wide = nm == 16 && (n_mix & 3) == 0 && ((uintptr_t)g_scores & 15) == 0 && (!g_best || ((uintptr_t)g_best & 15) == 0);
+    for (int e = tid; e < 1024; e += 256) {
+        const int fr = e >> 2, c4 = (e & 3) * 4, tg = tb + fr;
+        if (tg >= T)
+            continue;
+        const float*         ps = s_sc + fr * 17 + c4;
+        const unsigned char* pb = s_bd + fr * 20 + c4;
+        float*               gs = g_scores + (size_t)tg * n_mix + m0 + c4;
+        uint32_t*            gb = g_best ? g_best + (size_t)tg * n_mix + m0 + c4 : nullptr;
+        if (wide) {
+            *(float4*)gs = make_float4(ps[0], ps[1], ps[2], ps[3]);
+            if (gb)
+                *(uint4*)gb = make_uint4(pb[0] == 0xff ? 0xffffffffu : pb[0], pb[1] == 0xff ? 0xffffffffu : pb[1],
+                                         pb[2] == 0xff ? 0xffffffffu : pb[2], pb[3] == 0xff ? 0xffffffffu : pb[3]);
+        }
+        else {
+            for (int q = 0; q < 4 && c4 + q < nm; ++q) {
+                gs[q] = ps[q];
+                if (gb)
+                    gb[q] = pb[q] == 0xff ? 0xffffffffu : pb[q];
+            }
+        }
+    }
+    __syncthreads();
+  }
 }
-
 
 struct GmmCombineDims {
     int T, Tpad, n_mix, mix_tile;
@@ -988,12 +1074,12 @@ int score_screened(amx_gmm* h, const float* feats_dev, int T, float* scores_dev,
         }
         {
             amx::ScopedKernelTimer timer(h->ctx, "gmm");
-            dim3      grid(h->scr_Mpad16 / 16, Tpad / 256);
+            dim3      grid(h->scr_Mpad16 / 16, (Tpad / 256 + 3) / 4);  // FG = 4 frame groups per workgroup
             float*    sc = scores_dev + (size_t)t0 * h->n_mix;
             uint32_t* bd = best_dev ? best_dev + (size_t)t0 * h->n_mix : nullptr;
 #define AMX_EXACT(D)                                                                                                                \
     case D: {                                                                                                                       \
-        const size_t lds = (size_t)256 * (D + 1) * 4 * (h->pooled ? 1 : 2);                                                         \
+        const size_t lds = (size_t)256 * ((D + 2) & ~1) * 4 * (h->pooled ? 1 : 2) + 2048 + 2112 + 256 * 17 * 4 + 256 * 20; \
         if (h->pooled) {                                                                                                            \
             auto k = amx::gmm_screen_exact_kernel<D, true>;                                                                         \
             hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
