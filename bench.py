@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="pipeline", choices=["pipeline", "mfcc", "gmm", "gmm-tied", "nn", "gmm-train"])
+    ap.add_argument("--workload", default="pipeline", choices=["pipeline", "nn-pipeline", "mfcc", "gmm", "gmm-tied", "nn", "gmm-train"])
     ap.add_argument("--utterances", type=int, default=64, help="utterances per step and rank (pipeline / mfcc)")
     ap.add_argument("--utt-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -90,7 +90,7 @@ def make_batch(n_utt, seconds, seed):
     return pcm, off
 
 
-class Pipeline:
+class NnPipeline:
     """MFCC-40 -> context 11 -> FFNN 440-6x2048-10000 -> accumulators, everything resident in HBM."""
 
     CHUNK = 32768  # frames per scoring pass (bounds the [frames x 10000] f32 score buffer to 1.3 GB)
@@ -158,6 +158,106 @@ class Pipeline:
         if n:
             gbs = self.F * 800.0 / (ms * 1e-3) / 1e9
             out["mfcc"].update(algorithmic_GBps=round(gbs, 1), frac_hbm=round(gbs / HBM_PEAK_GBS, 4))
+        return out
+
+
+class Pipeline(NnPipeline):
+    """Per-GPU shard of BASELINE config 5: every frame is scored by BOTH acoustic models.
+    audio -> MFCC-40 -+-> CART GMM 10 000 states x 16 densities (diagonal-maximum) -> best state / density -> Viterbi accumulators
+                      +-> 11-frame context -> FFNN 440-6x2048-10000 (bf16 MFMA)   -> best state -> per-state counts
+    The two legs only share the MFCC output (AMX_BENCH_TWO_STREAMS=1 runs them on two HIP streams)."""
+
+    GCHUNK = 8192  # frames per GMM pass: [frames x 10000] f32 scores + u32 best densities = 655 MB
+
+    def __init__(self, ctx, args, rank):
+        super().__init__(ctx, args, rank)
+        import torch
+
+        import rasr_amd
+        from tests import synth
+        model = synth.gmm_cart(10000, 16, 16, 40, seed=5, pooled=True)
+        self.nk = int(model["mix_offsets"][-1])
+        self.gmm = rasr_amd.GmmFeatureScorer(ctx, model)
+        g = min(self.GCHUNK, self.F)
+        self.gscores = torch.empty((g, self.M), dtype=torch.float32, device="cuda")
+        self.gbestd = torch.empty((g, self.M), dtype=torch.int32, device="cuda")
+        self.gstate = torch.empty((g,), dtype=torch.int32, device="cuda")
+        self.gcounts = torch.zeros((self.M,), dtype=torch.int64, device="cuda")
+        self.gscore_sum = torch.zeros((1,), dtype=torch.float64, device="cuda")
+        self.acc = torch.zeros((self.gmm.accumulator_size(),), dtype=torch.float64, device="cuda")
+        self.main = torch.cuda.current_stream()
+        self.side = torch.cuda.Stream()
+        self.ev_feat, self.ev_side = torch.cuda.Event(), torch.cuda.Event()
+
+    def gmm_leg(self):
+        for t0 in range(0, self.F, self.GCHUNK):
+            T = min(self.GCHUNK, self.F - t0)
+            x = self.ceps[t0:]
+            self.gmm.score_dev(x, T, self.gscores, self.gbestd)
+            self.ctx.stats_accumulate(self.gscores, T, self.M, self.gstate, self.gcounts, self.gscore_sum)
+            self.gmm.accumulate_dev(x, T, self.gstate, self.gbestd, self.M, self.acc)
+
+    def nn_leg(self):
+        self.ctx.context_window(self.plan, self.ceps, 40, 5, 5, self.ctxwin, 440)
+        for t0 in range(0, self.F, self.CHUNK):
+            T = min(self.CHUNK, self.F - t0)
+            self.nn.score_stats_dev(self.ctxwin[t0:], 440, T, self.scores, self.best[t0:], self.counts, self.score_sum)
+
+    def step(self):
+        torch = self.torch
+        self.fe.run_plan(self.plan, self.pcm, self.ceps)
+        if not os.environ.get("AMX_BENCH_TWO_STREAMS"):  # both legs saturate the GPU: overlapping them gained < 2 %
+            self.gmm_leg()
+            self.nn_leg()
+            return
+        self.ev_feat.record(self.main)
+        self.side.wait_event(self.ev_feat)
+        with torch.cuda.stream(self.side):   # GMM leg on the side stream
+            self.ctx.use_torch_stream()
+            self.gmm_leg()
+            self.ev_side.record(self.side)
+        self.ctx.use_torch_stream()          # back on the main stream: NN leg
+        self.nn_leg()
+        self.main.wait_event(self.ev_side)   # the next step's MFCC overwrites ceps
+
+    def epoch_reduce(self, world):
+        if world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.acc)        # 53.8 MB of f64 GMM statistics
+            for t in (self.counts, self.score_sum, self.gcounts, self.gscore_sum):
+                dist.all_reduce(t)
+
+    def roofline(self):
+        nn = super().roofline()
+        ms_x, n_x = self.ctx.profile_get("gmm")
+        ms_s, n_s = self.ctx.profile_get("gmm_screen")
+        if n_x == 0:
+            return nn
+        # the two candidates for "dominant kernel": the GMM's exact stage (all launches) vs the output-layer GEMM
+        t_gmm = ms_x * n_x
+        t_nn = nn["avg_launch_ms"] * nn["launches"] if nn else 0.0
+        frames = min(self.GCHUNK, self.F)
+        alg = 122.0 * self.nk * frames   # SURVEY 8(d) cfg 3 secondary: D (3d + 2) flop per frame for the reference scorer
+        gm = dict(bound="mfma", kernel="gmm_screen_exact_kernel<40,pooled> (+ gmm_screen_kernel<1>)",
+                  note="f32 VALU kernel pair priced against the f32 vector peak (= f32 MFMA peak). achieved = the reference scorer's "
+                       "algorithmic flops (160 000 densities x 122 flop per frame) / (screen + exact time): the f16 MFMA screen leaves "
+                       "1.04 of 16 densities per state for the exact f32 evaluation, which executes ~%d flop per frame" % int(1.04 * 10000 * 170),
+                  achieved=round(alg / ((ms_x + ms_s) * 1e-3) / 1e12, 2), peak=FP32_TFLOPS, unit="TFLOP/s",
+                  frac=round(alg / ((ms_x + ms_s) * 1e-3) / 1e12 / FP32_TFLOPS, 4), traffic=None,
+                  avg_launch_ms=round(ms_x, 4), screen_launch_ms=round(ms_s, 4), launches=n_x, flops_per_launch=alg)
+        if t_gmm >= t_nn:
+            gm["second"] = nn
+            return gm
+        nn["second"] = gm
+        return nn
+
+    def stage_report(self):
+        out = super().stage_report()
+        out["accumulator_bytes"] = int(self.acc.numel() * 8)
+        for k in ("gmm_screen_pack", "gmm_screen", "gmm", "gmm_accumulate"):
+            ms, n = self.ctx.profile_get(k)
+            if n:
+                out[k] = dict(avg_ms=round(ms, 4), launches=n)
         return out
 
 
@@ -388,6 +488,19 @@ def _cpu_mfcc_worker(job):
     return n, time.perf_counter() - t0
 
 
+def _cpu_gmm_worker(T):
+    """runs in a spawned process: (frames, seconds) of the oracle's diagonal-maximum scorer on the config-3 CART model"""
+    from oracle import OracleGmm
+    from tests import synth
+    model = synth.gmm_cart(10000, 16, 16, 40, seed=5, pooled=True)
+    x = np.random.Generator(np.random.PCG64(4)).standard_normal((T, 40)).astype(np.float32)
+    g = OracleGmm(model)
+    g.score(x[:1], mode=0, want_best=False)  # warm
+    t0 = time.perf_counter()
+    g.score(x, mode=0, want_best=True)
+    return T, time.perf_counter() - t0
+
+
 def cpu_baseline(workload):
     """The oracle (CPU restatement of the reference path, kind "port") timed on a bounded sample with all host cores:
     MFCC frame-by-frame (one process per core, start-up excluded), FFNN via numpy float32 matmul = OpenBLAS sgemm with
@@ -398,7 +511,7 @@ def cpu_baseline(workload):
     cores = os.cpu_count() or 1
     res = {}
     notes = []
-    if workload in ("pipeline", "mfcc"):
+    if workload in ("pipeline", "nn-pipeline", "mfcc"):
         procs = min(cores, 64)
         jobs = [([1000 + i], 6) for i in range(procs)]   # 6 x 10 s of audio per process
         with mp.get_context("spawn").Pool(procs) as pool:
@@ -408,7 +521,16 @@ def cpu_baseline(workload):
         # processes run concurrently: wall time of the slowest; scale to all cores (embarrassingly parallel)
         res["mfcc"] = (frames * cores / procs, dt)
         notes.append("MFCC: %d oracle processes x 60 s audio each, %.2f s compute, scaled x%d/%d to all cores" % (procs, dt, cores, procs))
-    if workload in ("pipeline", "nn"):
+    if workload == "pipeline":
+        procs = min(cores, 64)
+        with mp.get_context("spawn").Pool(procs) as pool:
+            out = pool.map(_cpu_gmm_worker, [16] * procs)
+        frames = sum(o[0] for o in out)
+        dt = max(o[1] for o in out)
+        res["gmm"] = (frames * cores / procs, dt)
+        notes.append("GMM: %d oracle processes (diagonal-maximum loop, 10000x16 densities) x 16 frames each, %.2f s compute, scaled x%d/%d"
+                     % (procs, dt, cores, procs))
+    if workload in ("pipeline", "nn-pipeline", "nn"):
         dims = [440] + [2048] * 6 + [10000]
         Ws, bs, acts, logp = synth.ffnn(dims, seed=7)
         T = 8192
@@ -471,8 +593,8 @@ def main():
     stream = torch.cuda.Stream(device=local)
     with torch.cuda.stream(stream):
         ctx.use_torch_stream()
-        if args.workload == "pipeline":
-            job = Pipeline(ctx, args, rank)
+        if args.workload in ("pipeline", "nn-pipeline"):
+            job = (Pipeline if args.workload == "pipeline" else NnPipeline)(ctx, args, rank)
             job.nn_precision = args.precision
         elif args.workload == "mfcc":
             job = MfccOnly(ctx, args, rank)
@@ -502,8 +624,11 @@ def main():
     units = job.units * args.steps * world
     if rank == 0:
         value = units / dt
-        names = {"pipeline": "cfg5-shard: MFCC-40 -> ctx11 -> FFNN 440-6x2048-10000 (bf16 MFMA) -> best-state accumulators; "
-                             "%d utterances x %.0f s per step and rank" % (args.utterances, args.utt_seconds),
+        names = {"pipeline": "cfg5-shard: MFCC-40 -> {GMM 10000x16 diagonal-maximum -> Viterbi accumulators | ctx11 -> FFNN 440-6x2048-10000 "
+                             "(bf16 MFMA) -> best-state counts}, every frame scored by both models; %d utterances x %.0f s per step and rank"
+                             % (args.utterances, args.utt_seconds),
+                 "nn-pipeline": "cfg5-shard, NN leg only: MFCC-40 -> ctx11 -> FFNN 440-6x2048-10000 (bf16 MFMA) -> best-state counts; "
+                                "%d utterances x %.0f s per step and rank" % (args.utterances, args.utt_seconds),
                  "mfcc": "cfg2: batched MFCC-40 on 1000 utterances (5-15 s)",
                  "gmm": "cfg3-cart: 10000 states x 16 densities, d=40, pooled covariance, batch 256, diagonal-maximum",
                  "gmm-tied": "cfg3-tied: 4096 shared densities x 10000 states, d=40, batch 256, diagonal-maximum",
@@ -513,7 +638,7 @@ def main():
         line = {"metric": "acoustic frames scored/sec (1e4-state AM)", "value": round(value, 1), "unit": "frames/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                "dtype": ("bf16" if args.precision == "bf16" else "f32") if args.workload in ("pipeline", "nn") else "f32",
+                "dtype": ("bf16" if args.precision == "bf16" else "f32") if args.workload in ("pipeline", "nn-pipeline", "nn") else "f32",
                 "data": "synthetic", "config": {"workload": names[args.workload], "frames_per_step_per_gpu": job.units},
                 "rtf": round(dt / (units * 0.01), 8)}
         line["roofline"] = job.roofline()

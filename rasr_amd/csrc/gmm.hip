@@ -691,8 +691,60 @@ __global__ __launch_bounds__(256) void gmm_screen_pack_kernel(const float* __res
         if (d.pooled || i < d.dim)
             q += v * v;
     }
-    g_nx[t] = fits ? sqrtf(n2) : __builtin_inff();
-    g_q[t]  = d.pooled ? q : q * d.rmax2;
+    const int kd = d.pooled ? d.dim : 2 * d.dim;  // columns kd, kd + 1 multiply the split constant c_hi, c_lo
+    row[kd]      = (_Float16)(t < d.T ? 1.f : 0.f);
+    row[kd + 1]  = (_Float16)(t < d.T ? 1.f : 0.f);
+    g_nx[t]      = fits ? sqrtf(n2) : __builtin_inff();
+    g_q[t]       = 1.6e-5f * (d.pooled ? q : q * d.rmax2);
+}
+
+// epilogue of the screen: lane (tl32, hh) holds, for frame tl32 of pass j, slots i*32 + 8g + 4hh + e of the wave's 128: mixture
+// 2i + (g >> 1) of its 8, slot (g & 1) * 8 + 4hh + e within it.  The partner lane (lane ^ 32) holds the other 8 slots.
+// The per-density constant already sits in the accumulators (two extra K columns c_hi + c_lo against X = 1), the threshold is
+// three fused operations on per-mixture / per-frame precomputed pieces, and a survivor bit is the sign of thr - g shifted into
+// the mask by v_alignbit: ~30 VALU operations per mixture and frame pair instead of ~60 (this epilogue, not the 32 MFMAs per
+// wave, is what the kernel's time goes to).
+__device__ __forceinline__ void gmm_screen_epilogue(const gmm_f32x16 (&acc)[4][2], const float* __restrict__ g_p1,
+                                                    const float* __restrict__ g_p2, const float (&nxv)[2], const float (&qv)[2],
+                                                    uint16_t* __restrict__ g_masks, int t_first, int mt0, int lane, int Mpad16) {
+    const int tl32 = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int   t  = t_first + j * 32 + tl32;
+        const float nx = nxv[j], q = qv[j];
+        const bool  all = !(nx < __builtin_inff());  // operand row did not fit f16: keep every slot
+        unsigned    packed[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            unsigned two = 0;
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp) {
+                const gmm_f32x16& c = acc[i][j];
+                const int         o = gp * 8;
+                float mn = min3_raw(c[o], c[o + 1], c[o + 2]);
+                mn       = min3_raw(mn, c[o + 3], c[o + 4]);
+                mn       = min3_raw(mn, c[o + 5], c[o + 6]);
+                mn       = min3_raw(mn, c[o + 7], c[o + 7]);
+                mn       = min3_raw(mn, __shfl_xor(mn, 32, 64), mn);  // the partner lane's 8 slots
+                const int   m   = mt0 + i * 2 + gp;
+                // tau = 2.2e-3 na nx + 1.3e-4 sqrtK (na + nx) + 1.6e-5 (|mn| + cabs + q): p1 = 2.2e-3 na + 1.3e-4 sqrtK,
+                // p2 = 1.3e-4 sqrtK na + 1.6e-5 cabs per mixture, q pre-scaled per frame
+                const float thr = mn + fmaf(nx, g_p1[m], fmaf(fabsf(mn), 1.6e-5f, g_p2[m] + q)) + 1e-30f;
+                unsigned    bits = 0;  // bit k = "slot value k is above the threshold", filled from the top slot down
+#pragma unroll
+                for (int e = 7; e >= 0; --e)
+                    bits = __builtin_amdgcn_alignbit(bits, __float_as_uint(thr - c[o + e]), 31);  // (bits << 1) | sign(thr - g)
+                // lane's 8 slots: e < 4 -> slot 4hh + e, e >= 4 -> slot 8 + 4hh + (e - 4)
+                unsigned keep = ~bits;
+                unsigned mine = ((keep & 0xfu) << (4 * hh)) | (((keep >> 4) & 0xfu) << (8 + 4 * hh));
+                mine |= (unsigned)__shfl_xor((int)mine, 32, 64);
+                two |= (all ? 0xffffu : mine) << (16 * gp);
+            }
+            packed[i] = two;
+        }
+        if (hh == 0)  // 8 masks x 16 bit = one 16-byte store; rows and groups are 16-byte aligned (Mpad16 % 16 == 0)
+            *(uint4*)(g_masks + (size_t)t * Mpad16 + mt0) = make_uint4(packed[0], packed[1], packed[2], packed[3]);
+    }
 }
 
 // LDS: [KT][A tile 256 x 128 B | X tile 256 x 128 B] [c: 256 f32]; same row swizzle as the bf16 GEMM
@@ -710,9 +762,6 @@ __global__ __launch_bounds__(512) void gmm_screen_kernel(const _Float16* __restr
     const int tile_r = blockIdx.x % n_tiles_r, tile_t = blockIdx.x / n_tiles_r;
     const int r0 = tile_r * 256, t0 = tile_t * 256;
     const int Kp = KT * 64;
-    float*    s_c = (float*)(lds + KT * STAGE);
-    if (tid < 256)
-        s_c[tid] = g_c[r0 + tid];
     {
         const int xr = ((wave & 1) * 4 + (lane >> 4)) & 7;
         const size_t off = (size_t)(wave * 8 + (lane >> 3)) * Kp + (((lane & 7) ^ xr) << 3);
@@ -765,52 +814,78 @@ __global__ __launch_bounds__(512) void gmm_screen_kernel(const _Float16* __restr
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
     }
-    // ---- epilogue: lane (tl32, hh) holds, for frame tl32 of pass j, slots i*32 + 8g + 4hh + e: mixture 2i + (g >> 1) of the
-    // wave's 8, slot (g & 1) * 8 + 4hh + e within it.  The partner lane (lane ^ 32) holds the other 8 slots of each mixture.
-    const int tl32 = lane & 31, hh = lane >> 5;
-    const int mt0  = tile_r * 16 + wn * 8;  // first mixture slot group of this wave
+    const float nxv[2] = {g_nx[t0 + wt * 64 + (lane & 31)], g_nx[t0 + wt * 64 + 32 + (lane & 31)]};
+    const float qv[2]  = {g_q[t0 + wt * 64 + (lane & 31)], g_q[t0 + wt * 64 + 32 + (lane & 31)]};
+    gmm_screen_epilogue(acc, g_na, g_cabs, nxv, qv, g_masks, t0 + wt * 64, tile_r * 16 + wn * 8, lane, d.Mpad16);
+}
+
+// K <= 64 (pooled covariance, dim <= 64): the frame tile stays in LDS and the workgroup walks a range of slot tiles, the next
+// tile's operand (32 KB) arriving while the current one is multiplied and reduced.  [X 32 KB][A x2 32 KB][c x2 1 KB]
+__global__ __launch_bounds__(512) void gmm_screen_persist_kernel(const _Float16* __restrict__ g_A, const _Float16* __restrict__ g_X,
+                                                                const float* __restrict__ g_c, const float* __restrict__ g_na,
+                                                                const float* __restrict__ g_cabs, const float* __restrict__ g_nx,
+                                                                const float* __restrict__ g_q, uint16_t* __restrict__ g_masks, int n_tiles_r,
+                                                                int r_split, GmmScreenDims d) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr int TILE = 32 * 1024;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave >> 2, wt = wave & 3;
+    const int tile_t = blockIdx.x / r_split, part = blockIdx.x % r_split;
+    const int per = (n_tiles_r + r_split - 1) / r_split;
+    const int r_begin = part * per, r_end = min(n_tiles_r, r_begin + per);
+    if (r_begin >= r_end)
+        return;
+    const int t0 = tile_t * 256;
+    const int xr = ((wave & 1) * 4 + (lane >> 4)) & 7;
+    const size_t off = (size_t)(wave * 8 + (lane >> 3)) * 64 + (((lane & 7) ^ xr) << 3);
+    auto load_tile = [&](const _Float16* base, char* dst) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int   t  = t0 + wt * 64 + j * 32 + tl32;
-        const float nx = g_nx[t], q = g_q[t];
-        unsigned    packed[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            unsigned two = 0;
-#pragma unroll
-            for (int gp = 0; gp < 2; ++gp) {
-                float v[8];
-#pragma unroll
-                for (int gg = 0; gg < 2; ++gg) {
-                    const int    g  = gp * 2 + gg;
-                    const float4 c4 = *(const float4*)(s_c + wn * 128 + i * 32 + 8 * g + 4 * hh);
-                    v[gg * 4 + 0]   = acc[i][j][g * 4 + 0] + c4.x;
-                    v[gg * 4 + 1]   = acc[i][j][g * 4 + 1] + c4.y;
-                    v[gg * 4 + 2]   = acc[i][j][g * 4 + 2] + c4.z;
-                    v[gg * 4 + 3]   = acc[i][j][g * 4 + 3] + c4.w;
-                }
-                float mn = v[0];
-#pragma unroll
-                for (int e = 1; e < 8; ++e)
-                    mn = fminf(mn, v[e]);
-                mn = fminf(mn, __shfl_xor(mn, 32, 64));
-                const int   m   = mt0 + i * 2 + gp;
-                const float na  = g_na[m];
-                const float tau = 2.2e-3f * na * nx + 1.3e-4f * d.sqrtK * (na + nx) + 1.6e-5f * (fabsf(mn) + g_cabs[m] + q) + 1e-30f;
-                const float thr = mn + tau;
-                unsigned    bits = 0;
-#pragma unroll
-                for (int gg = 0; gg < 2; ++gg)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        bits |= (!(v[gg * 4 + e] > thr) ? 1u : 0u) << (gg * 8 + 4 * hh + e);  // NaN keeps the slot
-                bits |= (unsigned)__shfl_xor((int)bits, 32, 64);
-                two |= bits << (16 * gp);
-            }
-            packed[i] = two;
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((const void*)(base + off + (size_t)i * 64 * 64),
+                                             (__attribute__((address_space(3))) void*)(dst + wave * 1024 + i * 8 * 1024), 16, 0, 0);
+    };
+    load_tile(g_X + (size_t)t0 * 64, lds);
+    load_tile(g_A + (size_t)r_begin * 256 * 64, lds + TILE);
+    const float nxv[2] = {g_nx[t0 + wt * 64 + (lane & 31)], g_nx[t0 + wt * 64 + 32 + (lane & 31)]};
+    const float qv[2]  = {g_q[t0 + wt * 64 + (lane & 31)], g_q[t0 + wt * 64 + 32 + (lane & 31)]};
+    const int   frow = lane & 31, fk = lane >> 5;
+    for (int r = r_begin; r < r_end; ++r) {
+        const int buf = (r - r_begin) & 1;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // my share of tile r is in LDS
+        __builtin_amdgcn_s_barrier();                                // ... everybody's is, and buffer buf^1 is free again
+        if (r + 1 < r_end) {
+            load_tile(g_A + (size_t)(r + 1) * 256 * 64, lds + TILE + (buf ^ 1) * TILE);
         }
-        if (hh == 0)  // 8 masks x 16 bit = one 16-byte store; rows and groups are 16-byte aligned (Mpad16 % 16 == 0)
-            *(uint4*)(g_masks + (size_t)t * d.Mpad16 + mt0) = make_uint4(packed[0], packed[1], packed[2], packed[3]);
+        gmm_f32x16 acc[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 16; ++q)
+                    acc[i][j][q] = 0.f;
+        const char* abase = lds + TILE + buf * TILE;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            gmm_f16x8 a[4], b[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int rr = wn * 128 + i * 32 + frow;
+                a[i]         = *(const gmm_f16x8*)(abase + rr * 128 + (((ks * 2 + fk) ^ ((rr >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int rr = wt * 64 + j * 32 + frow;
+                b[j]         = *(const gmm_f16x8*)(lds + rr * 128 + (((ks * 2 + fk) ^ ((rr >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        gmm_screen_epilogue(acc, g_na, g_cabs, nxv, qv, g_masks, t0 + wt * 64, r * 16 + wn * 8, lane, d.Mpad16);
     }
 }
 
@@ -1059,7 +1134,16 @@ int score_screened(amx_gmm* h, const float* feats_dev, int T, float* scores_dev,
         {
             amx::ScopedKernelTimer timer(h->ctx, "gmm_screen");
             const int ntr = h->scr_Rpad / 256, ntt = Tpad / 256;
-            if (h->scr_Kp == 64) {
+            if (h->scr_Kp == 64 && !getenv("AMX_GMM_SCREEN_SIMPLE")) {
+                auto      k   = amx::gmm_screen_persist_kernel;
+                const int lds = 3 * 32 * 1024 + 2048;
+                hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                // one workgroup per CU, each a frame tile x a contiguous range of slot tiles
+                const int split = std::max(1, std::min(ntr, (std::max(h->ctx->n_cu, 8) + ntt - 1) / ntt));
+                hipLaunchKernelGGL(k, dim3(ntt * split), dim3(512), lds, st, h->d_scr_A, h->d_scr_X, h->d_scr_c, h->d_scr_na, h->d_scr_cabs,
+                                   h->d_scr_nx, h->d_scr_q, h->d_scr_masks, ntr, split, d);
+            }
+            else if (h->scr_Kp == 64) {
                 auto k = amx::gmm_screen_kernel<1>;
                 hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024 + 1024);
                 hipLaunchKernelGGL(k, dim3(ntr * ntt), dim3(512), 64 * 1024 + 1024, st, h->d_scr_A, h->d_scr_X, h->d_scr_c, h->d_scr_na,
@@ -1321,8 +1405,8 @@ int amx_gmm_create(amx_ctx* ctx, const amx_gmm_model* m, amx_gmm** out) {
         for (int i = 0; i < m->n_mix; ++i)
             kmax = std::max(kmax, m->mix_offsets[i + 1] - m->mix_offsets[i]);
         const int d = m->dim, Kd = h->pooled ? d : 2 * d;
-        if (kmax >= 1 && kmax <= 16 && Kd <= 128) {
-            const int Kp = Kd <= 64 ? 64 : 128, Rpad = (m->n_mix * 16 + 255) / 256 * 256, Mp = Rpad / 16;
+        if (kmax >= 1 && kmax <= 16 && Kd + 2 <= 128) {  // two more K columns carry the per-density constant as c_hi + c_lo
+            const int Kp = Kd + 2 <= 64 ? 64 : 128, Rpad = (m->n_mix * 16 + 255) / 256 * 256, Mp = Rpad / 16;
             std::vector<_Float16> A((size_t)Rpad * Kp, (_Float16)0.f);
             std::vector<float>    c((size_t)Rpad, std::numeric_limits<float>::infinity()), na(Mp, 0.f), cabs(Mp, 0.f);
             bool                  fits = true;
@@ -1358,9 +1442,21 @@ int amx_gmm_create(amx_ctx* ctx, const amx_gmm_model* m, amx_gmm** out) {
                     c[row]  = (float)cc;
                     na[i]   = std::max(na[i], (float)(std::sqrt(n2) * 1.0000001));
                     cabs[i] = std::max(cabs[i], std::fabs((float)cc));
-                    if (!std::isfinite(cc))
+                    if (!std::isfinite(cc) || std::fabs(cc) > 65000.0)
                         fits = false;
+                    const _Float16 chi = (_Float16)(float)cc;
+                    A[row * Kp + Kd]     = chi;
+                    A[row * Kp + Kd + 1] = (_Float16)(float)(cc - (double)(float)chi);
                 }
+            for (size_t row = 0; row < (size_t)Rpad; ++row)  // empty slots: +inf (never a survivor unless the frame keeps all)
+                if (!std::isfinite(c[row]))
+                    A[row * Kp + Kd] = (_Float16)std::numeric_limits<float>::infinity();
+            const float sK = std::sqrt((float)Kd);
+            for (int i = 0; i < Mp; ++i) {  // na -> p1, cabs -> p2 (see gmm_screen_epilogue)
+                const float a = na[i], cb = cabs[i];
+                na[i]   = 2.2e-3f * a + 1.3e-4f * sK;
+                cabs[i] = 1.3e-4f * sK * a + 1.6e-5f * cb;
+            }
             if (fits) {
                 h->scr_Kp = Kp;
                 h->scr_Rpad = Rpad;
