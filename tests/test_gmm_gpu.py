@@ -221,3 +221,72 @@ def test_tied_screen_non_finite_and_constant_features(ctx):
     x[7] = 1e18               # squares overflow to +inf
     x[8] = 3e3                # large but finite distances (~1e8): tau scales with |min|
     assert_exact(ctx, model, x)
+
+
+def _cart_adversarial(seed, n_mix, dim, pooled):
+    """private-density model with exact duplicate densities and one-ulp weight neighbours inside mixtures"""
+    model = synth.gmm_cart(n_mix, 1, 16, dim, seed=seed, pooled=pooled)
+    rng = np.random.Generator(np.random.PCG64(seed + 7))
+    off = model["mix_offsets"]
+    means, lw = model["means"], model["log_weight"]
+    var = model["variances"]
+    for m in range(n_mix):
+        k0, k1 = int(off[m]), int(off[m + 1])
+        if k1 - k0 < 3:
+            continue
+        a, b = k0, k1 - 1                              # first and last density of the mixture become twins
+        means[model["dens_mean"][model["dens_index"][b]]] = means[model["dens_mean"][model["dens_index"][a]]]
+        if not pooled:
+            var[model["dens_cov"][model["dens_index"][b]]] = var[model["dens_cov"][model["dens_index"][a]]]
+        base = np.float32(-2 * lw[a])
+        pick = rng.integers(0, 3)
+        nudged = base if pick == 0 else np.nextafter(base, np.float32(np.inf if pick == 1 else -np.inf))
+        lw[b] = np.float64(nudged) / -2.0
+    return model
+
+
+@pytest.mark.parametrize("dim,pooled", [(40, True), (40, False), (64, True), (33, False), (16, True)])
+def test_mfma_screen_twins_and_ulp_neighbours(ctx, dim, pooled):
+    """MFMA-screened private-density path (one and two K-tiles, persistent and plain screen kernels): twin densities with
+    equal or one-ulp-apart constants inside a mixture must resolve exactly like the reference's sequential f64 rule;
+    45 mixtures (not a multiple of 16) and 700 frames (not a multiple of 256) exercise the padding"""
+    model = _cart_adversarial(70 + dim, 45, dim, pooled)
+    x = feats(700, dim, 71)
+    assert_exact(ctx, model, x)
+    import rasr_amd
+    _, best = rasr_amd.GmmFeatureScorer(ctx, model).score(x)
+    assert (best > 0).any()
+
+
+def test_mfma_screen_operand_range(ctx):
+    """features that do not fit the f16 screen operand (|x / sigma| > 65504, inf, NaN) keep every density and are evaluated
+    exactly; large but representable features widen tau; tiny variances make the MODEL unscreenable (exact fallback)"""
+    import rasr_amd
+    model = synth.gmm_cart(30, 2, 16, 24, seed=81, pooled=True)
+    x = feats(300, 24, 82)
+    x[5] *= 300.0
+    x[6] *= 3.0e4
+    x[7] = 1.0e6
+    x[8, 3] = np.inf
+    x[9, 0] = np.nan
+    x[10] = 0.0
+    x[11] = -65000.0
+    assert_exact(ctx, model, x)
+    tiny = dict(model)
+    tiny["variances"] = (model["variances"] * 1e-12).astype(np.float32)   # 1/sigma = 1e6: the means operand overflows f16
+    assert_exact(ctx, tiny, feats(40, 24, 83))
+    big = dict(model)
+    big["means"] = (model["means"] * 1.0e4).astype(np.float32)
+    assert_exact(ctx, big, feats(40, 24, 84) * 1.0e4)
+
+
+def test_mfma_screen_many_frames_and_chunks(ctx):
+    """more than one 16384-frame chunk of the screen workspace, frame count not a multiple of anything"""
+    model = synth.gmm_cart(20, 1, 16, 40, seed=91, pooled=True)
+    x = feats(16384 + 301, 40, 92)
+    import rasr_amd
+    from oracle import OracleGmm
+    sc, best = rasr_amd.GmmFeatureScorer(ctx, model).score(x)
+    sel = np.r_[0:64, 16300:16500, len(x) - 64:len(x)]
+    osc, obest = OracleGmm(model).score(x[sel], mode=0)
+    assert np.array_equal(sc[sel].view(np.uint32), osc.view(np.uint32)) and np.array_equal(best[sel], obest)
