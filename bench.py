@@ -193,8 +193,7 @@ class Pipeline(NnPipeline):
         for t0 in range(0, self.F, self.GCHUNK):
             T = min(self.GCHUNK, self.F - t0)
             x = self.ceps[t0:]
-            self.gmm.score_dev(x, T, self.gscores, self.gbestd)
-            self.ctx.stats_accumulate(self.gscores, T, self.M, self.gstate, self.gcounts, self.gscore_sum)
+            self.gmm.score_stats_dev(x, T, self.gscores, self.gbestd, self.gstate, self.gcounts, self.gscore_sum)
             self.gmm.accumulate_dev(x, T, self.gstate, self.gbestd, self.M, self.acc)
 
     def nn_leg(self):
@@ -295,8 +294,7 @@ class GmmTrain:
         for t0 in range(0, self.F, self.CHUNK):
             T = min(self.CHUNK, self.F - t0)
             x = self.ceps[t0:]
-            self.sc.score_dev(x, T, self.scores, self.bestd)
-            self.ctx.stats_accumulate(self.scores, T, self.M, self.state, self.counts, self.score_sum)
+            self.sc.score_stats_dev(x, T, self.scores, self.bestd, self.state, self.counts, self.score_sum)
             self.sc.accumulate_dev(x, T, self.state, self.bestd, self.M, self.acc)
 
     def epoch_reduce(self, world):

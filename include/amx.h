@@ -165,6 +165,12 @@ int amx_gmm_tables(const amx_gmm* h, float* minus2_log_weights, float* inv_sqrt_
  * minimising density (AssigningFeatureScorer::ScoreAndBestDensity). */
 int amx_gmm_score(amx_gmm* h, int mode, const float* feats_host, int T, float* scores_host, uint32_t* best_density_host);
 int amx_gmm_score_dev(amx_gmm* h, int mode, const float* feats_dev, int T, float* scores_dev, uint32_t* best_density_dev);
+/* diagonal-maximum scores plus the per-epoch statistics of amx_stats_accumulate_dev for these frames (best state per
+ * frame, per-state counts, sum of best scores), the counterpart of amx_ffnn_score_stats_dev.  For screened models the
+ * arg-min over the states is taken inside the exact stage, so the [T x n_mix] score matrix is written once and not
+ * re-read.  best_density_dev and best_state_dev are nullable. */
+int amx_gmm_score_stats_dev(amx_gmm* h, const float* feats_dev, int T, float* scores_dev, uint32_t* best_density_dev,
+                            uint32_t* best_state_dev, unsigned long long* state_counts_dev, double* score_sum_dev);
 
 /* Viterbi training statistics of Mm::AbstractMixtureSetEstimator::accumulate (Mm/AbstractMixtureSetEstimator.cc:117-125,
  * Mm/GaussDensityEstimator.hh:152-208): frame t, aligned to mixture_dev[t], adds 1 to the weight of its best density

@@ -236,6 +236,11 @@ class GmmFeatureScorer:
     def score_dev(self, feats_dev, T, scores_dev, best_dev=None):
         _lib.check(self.L.amx_gmm_score_dev(self.h, self.mode, _ptr(feats_dev), T, _ptr(scores_dev), _ptr(best_dev)))
 
+    def score_stats_dev(self, feats_dev, T, scores_dev, best_density, best_state, counts, score_sum):
+        """diagonal-maximum scores plus best state / per-state counts / sum of best scores (arg-min fused where possible)"""
+        _lib.check(self.L.amx_gmm_score_stats_dev(self.h, _ptr(feats_dev), T, _ptr(scores_dev), _ptr(best_density), _ptr(best_state),
+                                                  _ptr(counts), _ptr(score_sum)))
+
     def accumulator_size(self):
         return int(self.L.amx_gmm_accumulator_size(self.h))
 

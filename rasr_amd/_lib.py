@@ -82,6 +82,7 @@ SIGNATURES = {
     "amx_gmm_tables": (C.c_int, [_P, _P, _P, _P]),
     "amx_gmm_score": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, _P]),
     "amx_gmm_score_dev": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, _P]),
+    "amx_gmm_score_stats_dev": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P, _P]),
     "amx_gmm_accumulator_size": (C.c_long, [_P]),
     "amx_gmm_accumulate_dev": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, _P]),
     "amx_pms_read": (C.c_int, [C.c_char_p, C.POINTER(_P)]),

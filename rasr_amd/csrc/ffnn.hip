@@ -898,21 +898,46 @@ __global__ __launch_bounds__(C::THREADS) void gemm_bf16_pipe_kernel(const bf16_t
     }
 }
 
-// combines the per-tile arg-min partials: best state per frame, per-state counts, sum of best scores
+// combines the per-tile arg-min partials: best state per frame, per-state counts, sum of best scores.
+// A workgroup owns 64 frames; its 4 waves take the tiles k = w, w + 4, ... (the GMM scorer has 625 of them) and meet in LDS.
+// "First minimum in ascending state order" = smallest (value, state index) pair, so the order of combination is free.
 __global__ __launch_bounds__(256) void best_state_reduce_kernel(const float* __restrict__ part_min, const unsigned* __restrict__ part_idx,
                                                                int n_tiles_n, int part_ld, int T, unsigned* __restrict__ best_state,
                                                                unsigned long long* __restrict__ counts, double* __restrict__ score_sum) {
-    const int t   = blockIdx.x * 256 + threadIdx.x;
-    double    sum = 0.0;
-    unsigned  my  = 0xffffffffu;
-    if (t < T) {
+    __shared__ float    s_min[4][64];
+    __shared__ unsigned s_idx[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t    = blockIdx.x * 64 + lane;
+    {
         float    bmin = 3.402823466e+38f;
         unsigned bidx = 0xffffffffu;
-        for (int k = 0; k < n_tiles_n; ++k) {
-            const float m = part_min[(size_t)k * part_ld + t];
-            if (m < bmin) {
+        if (t < T)
+            for (int k = wave; k < n_tiles_n; k += 4) {
+                const float    m = part_min[(size_t)k * part_ld + t];
+                const unsigned i = part_idx[(size_t)k * part_ld + t];
+                if (m < bmin || (m == bmin && i < bidx)) {
+                    bmin = m;
+                    bidx = i;
+                }
+            }
+        s_min[wave][lane] = bmin;
+        s_idx[wave][lane] = bidx;
+    }
+    __syncthreads();
+    if (wave != 0)
+        return;
+    double   sum = 0.0;
+    unsigned my  = 0xffffffffu;
+    if (t < T) {
+        float    bmin = s_min[0][lane];
+        unsigned bidx = s_idx[0][lane];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const float    m = s_min[w][lane];
+            const unsigned i = s_idx[w][lane];
+            if (m < bmin || (m == bmin && i < bidx)) {
                 bmin = m;
-                bidx = part_idx[(size_t)k * part_ld + t];
+                bidx = i;
             }
         }
         if (best_state)
@@ -929,7 +954,7 @@ __global__ __launch_bounds__(256) void best_state_reduce_kernel(const float* __r
             const int      leader = __ffsll((long long)todo) - 1;
             const unsigned key    = (unsigned)__shfl((int)my, leader, 64);
             const unsigned long long same = __ballot(my == key) & todo;
-            if ((int)(threadIdx.x & 63) == leader)
+            if (lane == leader)
                 atomicAdd(&counts[key], (unsigned long long)__popcll(same));
             todo &= ~same;
         }
@@ -938,7 +963,7 @@ __global__ __launch_bounds__(256) void best_state_reduce_kernel(const float* __r
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1)
         sum += __shfl_xor(sum, off, 64);
-    if ((threadIdx.x & 63) == 0 && sum != 0.0)
+    if (lane == 0 && sum != 0.0)
         atomicAdd(score_sum, sum);
 }
 
@@ -1321,6 +1346,15 @@ int amx_ffnn_output_dim(const amx_ffnn* h) {
 
 extern "C" int amx_stats_accumulate_dev(amx_ctx*, const float*, int, int, uint32_t*, unsigned long long*, double*);
 
+// internal (not in amx.h): combine per-tile arg-min partials [n_tiles x part_ld]; shared with the GMM scorer's fused statistics
+extern "C" int amx_internal_best_state_reduce(amx_ctx* ctx, const float* part_min, const unsigned* part_idx, int n_tiles, int part_ld, int T,
+                                              uint32_t* best_state_dev, unsigned long long* counts_dev, double* score_sum_dev) {
+    hipLaunchKernelGGL(amx::best_state_reduce_kernel, dim3((T + 63) / 64), dim3(256), 0, ctx->stream, part_min, part_idx, n_tiles, part_ld, T,
+                       best_state_dev, counts_dev, score_sum_dev);
+    AMX_HIP(hipGetLastError());
+    return AMX_OK;
+}
+
 static int ffnn_score_impl(amx_ffnn* h, const float* feats_dev, int feats_stride, int T, float* scores_dev, bool stats,
                            uint32_t* best_state_dev, unsigned long long* counts_dev, double* score_sum_dev) {
     AMX_REQUIRE(h, AMX_ERR_INVALID, "amx_ffnn_score_dev: NULL handle");
@@ -1376,7 +1410,7 @@ static int ffnn_score_impl(amx_ffnn* h, const float* feats_dev, int feats_stride
                 r         = launch_layer<true>(h, l, cur, ldx, sc, h->out[l], Tc, Tpad);
                 if (r == AMX_OK && fused) {
                     amx::ScopedKernelTimer timer(h->ctx, "stats");
-                    hipLaunchKernelGGL(amx::best_state_reduce_kernel, dim3((Tc + 255) / 256), dim3(256), 0, h->ctx->stream,
+                    hipLaunchKernelGGL(amx::best_state_reduce_kernel, dim3((Tc + 63) / 64), dim3(256), 0, h->ctx->stream,
                                        h->d_part_min, h->d_part_idx, h->cur_ntn, Tpad, Tc, best_state_dev ? best_state_dev + t0 : nullptr,
                                        counts_dev, score_sum_dev);
                     AMX_HIP(hipGetLastError());

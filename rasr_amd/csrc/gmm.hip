@@ -897,7 +897,8 @@ __global__ __launch_bounds__(256) void gmm_screen_exact_kernel(const float* __re
                                                               const uint32_t* __restrict__ g_k_cov, const double* __restrict__ g_k_c64,
                                                               const float* __restrict__ g_means, const float* __restrict__ g_isr,
                                                               float* __restrict__ g_scores, uint32_t* __restrict__ g_best, int T, int n_mix,
-                                                              int Mpad16) {
+                                                              int Mpad16, float* __restrict__ g_part_min, unsigned* __restrict__ g_part_idx,
+                                                              int part_ld) {
     constexpr int LD = (DIM + 2) & ~1;  // even (8-byte aligned rows for the packed distance); 42 for DIM = 40 spreads the banks
     extern __shared__ __attribute__((aligned(16))) char lds[];
     float* s_mu = (float*)lds;                    // [256][LD]
@@ -980,6 +981,22 @@ __global__ __launch_bounds__(256) void gmm_screen_exact_kernel(const float* __re
     // The [256 frames x 16 mixtures] result tile leaves through LDS: four adjacent lanes write the 64 contiguous bytes of one
     // frame in ONE instruction.  (Per-lane 4-byte stores at a 40 KB stride cost more than the whole evaluation.)
     __syncthreads();
+    if (g_part_min) {  // fused statistics: best state of this tile per frame (ascending state, strict '<': first minimum)
+        const int tg = (blockIdx.y * FG + fg) * 256 + tid;
+        float     bm = 3.402823466e+38f;
+        unsigned  bi = 0xffffffffu;
+        for (int q = 0; q < nm; ++q) {
+            const float v = s_sc[tid * 17 + q];
+            if (v < bm) {
+                bm = v;
+                bi = (unsigned)(m0 + q);
+            }
+        }
+        if (tg < T) {
+            g_part_min[(size_t)blockIdx.x * part_ld + tg] = bm;
+            g_part_idx[(size_t)blockIdx.x * part_ld + tg] = bi;
+        }
+    }
     const int  tb   = (blockIdx.y * FG + fg) * 256;
     const bool wide = nm == 16 && (n_mix & 3) == 0 && ((uintptr_t)g_scores & 15) == 0 && (!g_best || ((uintptr_t)g_best & 15) == 0);
     for (int e = tid; e < 1024; e += 256) {
@@ -1084,6 +1101,9 @@ struct amx_gmm {
     float *   d_scr_nx = nullptr, *d_scr_q = nullptr;
     uint16_t* d_scr_masks = nullptr;
     int       scr_cap_T = 0;
+    float*    d_scr_pmin = nullptr;  // fused statistics: per-tile arg-min partials
+    unsigned* d_scr_pidx = nullptr;
+    size_t    scr_part_cap = 0;
 };
 
 namespace {
@@ -1104,7 +1124,10 @@ bool screen_dim_supported(int d) {
 }
 
 // maximum approximation through the MFMA screen (see gmm_screen_kernel); frames in chunks that bound the mask workspace
-int score_screened(amx_gmm* h, const float* feats_dev, int T, float* scores_dev, uint32_t* best_dev) {
+extern "C" int amx_internal_best_state_reduce(amx_ctx*, const float*, const unsigned*, int, int, int, uint32_t*, unsigned long long*, double*);
+
+int score_screened(amx_gmm* h, const float* feats_dev, int T, float* scores_dev, uint32_t* best_dev, bool stats, uint32_t* best_state_dev,
+                   unsigned long long* counts_dev, double* score_sum_dev) {
     hipStream_t st = h->ctx->stream;
     const int   chunk = 16384;
     for (int t0 = 0; t0 < T; t0 += chunk) {
@@ -1114,6 +1137,8 @@ int score_screened(amx_gmm* h, const float* feats_dev, int T, float* scores_dev,
             hipFree(h->d_scr_nx);
             hipFree(h->d_scr_q);
             hipFree(h->d_scr_masks);
+    hipFree(h->d_scr_pmin);
+    hipFree(h->d_scr_pidx);
             h->d_scr_X = nullptr;
             h->d_scr_nx = h->d_scr_q = nullptr;
             h->d_scr_masks = nullptr;
@@ -1156,6 +1181,23 @@ int score_screened(amx_gmm* h, const float* feats_dev, int T, float* scores_dev,
                                    h->d_scr_cabs, h->d_scr_nx, h->d_scr_q, h->d_scr_masks, ntr, d);
             }
         }
+        float*    pmin = nullptr;
+        unsigned* pidx = nullptr;
+        if (stats) {
+            const size_t need = (size_t)(h->scr_Mpad16 / 16) * Tpad;
+            if (need > h->scr_part_cap) {
+                hipFree(h->d_scr_pmin);
+                hipFree(h->d_scr_pidx);
+                h->d_scr_pmin = nullptr;
+                h->d_scr_pidx = nullptr;
+                h->scr_part_cap = 0;
+                AMX_HIP(hipMalloc((void**)&h->d_scr_pmin, need * 4));
+                AMX_HIP(hipMalloc((void**)&h->d_scr_pidx, need * 4));
+                h->scr_part_cap = need;
+            }
+            pmin = h->d_scr_pmin;
+            pidx = h->d_scr_pidx;
+        }
         {
             amx::ScopedKernelTimer timer(h->ctx, "gmm");
             dim3      grid(h->scr_Mpad16 / 16, (Tpad / 256 + 3) / 4);  // FG = 4 frame groups per workgroup
@@ -1168,13 +1210,13 @@ int score_screened(amx_gmm* h, const float* feats_dev, int T, float* scores_dev,
             auto k = amx::gmm_screen_exact_kernel<D, true>;                                                                         \
             hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
             hipLaunchKernelGGL(k, grid, dim3(256), lds, st, x, h->d_scr_masks, h->d_mix_off, h->d_k_mean, h->d_k_cov, h->d_k_c64,   \
-                               h->d_means, h->d_isr, sc, bd, Tc, h->n_mix, h->scr_Mpad16);                                          \
+                               h->d_means, h->d_isr, sc, bd, Tc, h->n_mix, h->scr_Mpad16, pmin, pidx, Tpad);                                          \
         }                                                                                                                           \
         else {                                                                                                                      \
             auto k = amx::gmm_screen_exact_kernel<D, false>;                                                                        \
             hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
             hipLaunchKernelGGL(k, grid, dim3(256), lds, st, x, h->d_scr_masks, h->d_mix_off, h->d_k_mean, h->d_k_cov, h->d_k_c64,   \
-                               h->d_means, h->d_isr, sc, bd, Tc, h->n_mix, h->scr_Mpad16);                                          \
+                               h->d_means, h->d_isr, sc, bd, Tc, h->n_mix, h->scr_Mpad16, pmin, pidx, Tpad);                                          \
         }                                                                                                                           \
     } break;
             switch (h->dim) {
@@ -1192,6 +1234,13 @@ int score_screened(amx_gmm* h, const float* feats_dev, int T, float* scores_dev,
 #undef AMX_EXACT
         }
         AMX_HIP(hipGetLastError());
+        if (stats) {
+            amx::ScopedKernelTimer timer(h->ctx, "stats");
+            int r = amx_internal_best_state_reduce(h->ctx, pmin, pidx, h->scr_Mpad16 / 16, Tpad, Tc, best_state_dev ? best_state_dev + t0 : nullptr,
+                                                   counts_dev, score_sum_dev);
+            if (r != AMX_OK)
+                return r;
+        }
     }
     return AMX_OK;
 }
@@ -1577,7 +1626,7 @@ int amx_gmm_score_dev(amx_gmm* h, int mode, const float* feats_dev, int T, float
         return AMX_OK;
     }
     if (!h->tied && h->screen && mode == AMX_GMM_MAX)
-        return score_screened(h, feats_dev, T, scores_dev, best_dev);
+        return score_screened(h, feats_dev, T, scores_dev, best_dev, false, nullptr, nullptr, nullptr);
     if (!h->tied) {
         amx::GmmParams p;
         p.feats   = feats_dev;
@@ -1699,6 +1748,26 @@ int amx_gmm_score_dev(amx_gmm* h, int mode, const float* feats_dev, int T, float
         AMX_HIP(hipGetLastError());
     }
     return AMX_OK;
+}
+
+extern "C" int amx_stats_accumulate_dev(amx_ctx*, const float*, int, int, uint32_t*, unsigned long long*, double*);
+
+int amx_gmm_score_stats_dev(amx_gmm* h, const float* feats_dev, int T, float* scores_dev, uint32_t* best_density_dev, uint32_t* best_state_dev,
+                            unsigned long long* state_counts_dev, double* score_sum_dev) {
+    AMX_REQUIRE(h, AMX_ERR_INVALID, "amx_gmm_score_stats_dev: NULL handle");
+    AMX_REQUIRE(h->ctx, AMX_ERR_STATE, "amx_gmm_score_stats_dev: host-only handle (created without a context)");
+    AMX_REQUIRE(state_counts_dev && score_sum_dev, AMX_ERR_INVALID, "amx_gmm_score_stats_dev: NULL accumulator");
+    AMX_REQUIRE(T >= 0, AMX_ERR_INVALID, "amx_gmm_score_stats_dev: negative frame count");
+    if (T == 0)
+        return AMX_OK;
+    AMX_REQUIRE(feats_dev && scores_dev, AMX_ERR_INVALID, "amx_gmm_score_stats_dev: NULL buffer");
+    AMX_HIP(hipSetDevice(h->ctx->device));
+    if (!h->tied && h->screen)  // arg-min over the states fused into the exact stage: the score matrix is not read again
+        return score_screened(h, feats_dev, T, scores_dev, best_density_dev, true, best_state_dev, state_counts_dev, score_sum_dev);
+    int r = amx_gmm_score_dev(h, AMX_GMM_MAX, feats_dev, T, scores_dev, best_density_dev);
+    if (r != AMX_OK)
+        return r;
+    return amx_stats_accumulate_dev(h->ctx, scores_dev, T, h->n_mix, best_state_dev, state_counts_dev, score_sum_dev);
 }
 
 long amx_gmm_accumulator_size(const amx_gmm* h) {

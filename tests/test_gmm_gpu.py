@@ -290,3 +290,40 @@ def test_mfma_screen_many_frames_and_chunks(ctx):
     sel = np.r_[0:64, 16300:16500, len(x) - 64:len(x)]
     osc, obest = OracleGmm(model).score(x[sel], mode=0)
     assert np.array_equal(sc[sel].view(np.uint32), osc.view(np.uint32)) and np.array_equal(best[sel], obest)
+
+
+@pytest.mark.parametrize("kind", ["cart", "cart-wide", "tied"])
+def test_score_stats_dev(ctx, kind):
+    """amx_gmm_score_stats_dev: scores / best densities identical to amx_gmm_score_dev, best state = first arg-min over the
+    states, counts and score sum accumulate -- on the screened path (arg-min fused into the exact stage), on a model the
+    screen does not take (more than 16 densities per mixture) and on the tied path"""
+    import torch
+
+    import rasr_amd
+    if kind == "cart":
+        model = synth.gmm_cart(333, 1, 16, 40, seed=101, pooled=True)
+    elif kind == "cart-wide":
+        model = synth.gmm_cart(40, 10, 24, 40, seed=102, pooled=False)
+    else:
+        model = synth.gmm_tied(120, 64, 40, seed=103)
+    T, M = 1000, len(model["mix_offsets"]) - 1
+    x = feats(T, 40, 104)
+    sc = rasr_amd.GmmFeatureScorer(ctx, model)
+    ref_scores, ref_best = sc.score(x)
+    xd = torch.from_numpy(x).cuda()
+    scores = torch.empty((T, M), dtype=torch.float32, device="cuda")
+    bestd = torch.empty((T, M), dtype=torch.int32, device="cuda")
+    state = torch.empty((T,), dtype=torch.int32, device="cuda")
+    counts = torch.zeros((M,), dtype=torch.int64, device="cuda")
+    ssum = torch.zeros((1,), dtype=torch.float64, device="cuda")
+    ctx.use_torch_stream()
+    for _ in range(2):
+        sc.score_stats_dev(xd, T, scores, bestd, state, counts, ssum)
+    torch.cuda.synchronize()
+    assert np.array_equal(scores.cpu().numpy().view(np.uint32), ref_scores.view(np.uint32))
+    assert np.array_equal(bestd.cpu().numpy().astype(np.uint32), ref_best)
+    want_state = ref_scores.argmin(axis=1)
+    assert np.array_equal(state.cpu().numpy(), want_state)
+    assert np.array_equal(counts.cpu().numpy(), 2 * np.bincount(want_state, minlength=M))
+    want_sum = 2 * ref_scores.min(axis=1).astype(np.float64).sum()
+    assert abs(float(ssum.item()) - want_sum) <= 1e-9 * abs(want_sum)
