@@ -90,6 +90,30 @@ def make_batch(n_utt, seconds, seed):
     return pcm, off
 
 
+def gmm_cart_roofline(ctx, nk, frames):
+    """roofline entry of the MFMA-screened private-density GMM scorer (f16 screen GEMM + exact f32 evaluation of survivors)"""
+    ms_x, n_x = ctx.profile_get("gmm")
+    ms_s, n_s = ctx.profile_get("gmm_screen")
+    ms_p, n_p = ctx.profile_get("gmm_screen_pack")
+    if n_x == 0:
+        return None
+    if n_s == 0:  # screen disabled (AMX_GMM_SCREEN=0): the exact-everything kernel
+        ops = 4.0 * nk * 40 * frames
+        ach = ops / (ms_x * 1e-3) / 1e12
+        return dict(bound="mfma", note="f32 VALU kernel priced against the f32 vector peak (= f32 MFMA peak)", kernel="gmm_direct_kernel<40,MaxState>",
+                    achieved=round(ach, 3), peak=FP32_TFLOPS, unit="TFLOP/s", frac=round(ach / FP32_TFLOPS, 4), traffic=None,
+                    avg_launch_ms=round(ms_x, 4), launches=n_x, flops_per_launch=ops)
+    alg = 122.0 * nk * frames   # SURVEY 8(d) cfg 3 secondary: D (3d + 2) flop per frame for the reference scorer
+    t = (ms_x + ms_s + ms_p) * 1e-3
+    return dict(bound="mfma", kernel="gmm_screen_exact_kernel<40,pooled> (+ gmm_screen_persist_kernel, gmm_screen_pack_kernel)",
+                note="f32 VALU kernel priced against the f32 vector peak (= f32 MFMA peak). achieved = the reference scorer's algorithmic "
+                     "flops (densities x 122 flop per frame) / (pack + screen + exact time); the f16 MFMA screen leaves ~1.04 of 16 "
+                     "densities per state for the exact f32 evaluation, so the flops actually executed are ~9 % of the algorithmic count",
+                achieved=round(alg / t / 1e12, 2), peak=FP32_TFLOPS, unit="TFLOP/s", frac=round(alg / t / 1e12 / FP32_TFLOPS, 4),
+                traffic=measured_traffic("gmm_screen_exact_kernel") if frames == 8192 else None,
+                avg_launch_ms=round(ms_x, 4), screen_launch_ms=round(ms_s, 4), pack_launch_ms=round(ms_p, 4), launches=n_x, flops_per_launch=alg)
+
+
 class NnPipeline:
     """MFCC-40 -> context 11 -> FFNN 440-6x2048-10000 -> accumulators, everything resident in HBM."""
 
@@ -145,7 +169,7 @@ class NnPipeline:
         ach = flops / (ms * 1e-3) / 1e12
         return dict(bound="mfma", kernel="gemm_bf16_pipe_kernel<NONE,LAST> (2048->10000)" if self.nn_precision == "bf16" else "gemm_f32_kernel (2048->10000)",
                     achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
-                    traffic=measured_traffic("gemm_bf16_kernel") if (self.nn_precision == "bf16" and self.F >= self.CHUNK) else None,
+                    traffic=measured_traffic("gemm_bf16_pipe_kernel<GemmCfg<256,256,2,4,2>,NONE,LAST>") if (self.nn_precision == "bf16" and self.F >= self.CHUNK) else None,
                     avg_launch_ms=round(ms, 4), launches=n, flops_per_launch=flops)
 
     def stage_report(self):
@@ -228,27 +252,15 @@ class Pipeline(NnPipeline):
 
     def roofline(self):
         nn = super().roofline()
-        ms_x, n_x = self.ctx.profile_get("gmm")
-        ms_s, n_s = self.ctx.profile_get("gmm_screen")
-        if n_x == 0:
+        gm = gmm_cart_roofline(self.ctx, self.nk, min(self.GCHUNK, self.F))
+        if gm is None:
             return nn
-        # the two candidates for "dominant kernel": the GMM's exact stage (all launches) vs the output-layer GEMM
-        t_gmm = ms_x * n_x
+        # "dominant kernel" = the one with the larger total time in the step: the GMM's exact stage or the output-layer GEMM
+        t_gmm = gm["avg_launch_ms"] * gm["launches"]
         t_nn = nn["avg_launch_ms"] * nn["launches"] if nn else 0.0
-        frames = min(self.GCHUNK, self.F)
-        alg = 122.0 * self.nk * frames   # SURVEY 8(d) cfg 3 secondary: D (3d + 2) flop per frame for the reference scorer
-        gm = dict(bound="mfma", kernel="gmm_screen_exact_kernel<40,pooled> (+ gmm_screen_kernel<1>)",
-                  note="f32 VALU kernel pair priced against the f32 vector peak (= f32 MFMA peak). achieved = the reference scorer's "
-                       "algorithmic flops (160 000 densities x 122 flop per frame) / (screen + exact time): the f16 MFMA screen leaves "
-                       "1.04 of 16 densities per state for the exact f32 evaluation, which executes ~%d flop per frame" % int(1.04 * 10000 * 170),
-                  achieved=round(alg / ((ms_x + ms_s) * 1e-3) / 1e12, 2), peak=FP32_TFLOPS, unit="TFLOP/s",
-                  frac=round(alg / ((ms_x + ms_s) * 1e-3) / 1e12 / FP32_TFLOPS, 4), traffic=None,
-                  avg_launch_ms=round(ms_x, 4), screen_launch_ms=round(ms_s, 4), launches=n_x, flops_per_launch=alg)
-        if t_gmm >= t_nn:
-            gm["second"] = nn
-            return gm
-        nn["second"] = gm
-        return nn
+        first, second = (gm, nn) if t_gmm >= t_nn else (nn, gm)
+        first["second"] = second
+        return first
 
     def stage_report(self):
         out = super().stage_report()
@@ -305,14 +317,7 @@ class GmmTrain:
             dist.all_reduce(self.score_sum)
 
     def roofline(self):
-        ms, n = self.ctx.profile_get("gmm")
-        if n == 0:
-            return None
-        ops = 4.0 * self.nk * 40 * self.CHUNK
-        ach = ops / (ms * 1e-3) / 1e12
-        return dict(bound="mfma", note="f32 VALU kernel priced against the f32 vector peak (= f32 MFMA peak)",
-                    kernel="gmm_direct_kernel<40,MaxState>", achieved=round(ach, 3), peak=FP32_TFLOPS, unit="TFLOP/s",
-                    frac=round(ach / FP32_TFLOPS, 4), traffic=None, avg_launch_ms=round(ms, 4), launches=n, flops_per_launch=ops)
+        return gmm_cart_roofline(self.ctx, self.nk, min(self.CHUNK, self.F))
 
     def stage_report(self):
         out = {"accumulator_bytes": int(self.acc.numel() * 8)}
@@ -404,11 +409,12 @@ class GmmOnly:
                                            "vector peak; not MFMA-able", kernel="gmm_tied_tile_kernel", achieved=round(ach, 3),
                         peak=FP32_TFLOPS, unit="TFLOP/s", frac=round(ach / FP32_TFLOPS, 4), traffic=None, avg_launch_ms=round(ms, 4),
                         launches=n, flops_per_launch=ops)
+        elif self.gmm_type == "diagonal-maximum":
+            return gmm_cart_roofline(self.ctx, self.nk, self.T)
         else:
             ms, n = self.ctx.profile_get("gmm")
-            per_dim = 4.0 if self.gmm_type == "diagonal-maximum" else 3.0  # batch-float: pre-scaled means, sub/mul/add
-            ops = per_dim * self.nk * 40 * self.T
-            name = "gmm_direct_kernel<40,MaxState>" if self.gmm_type == "diagonal-maximum" else "gmm_batch_float_kernel<40>"
+            ops = 3.0 * self.nk * 40 * self.T   # batch-float: pre-scaled means, sub/mul/add
+            name = "gmm_batch_float_kernel<40>"
         if n == 0:
             return None
         ach = ops / (ms * 1e-3) / 1e12
@@ -418,7 +424,7 @@ class GmmOnly:
 
     def stage_report(self):
         out = {}
-        for k in ("gmm", "gmm_dist", "gmm_combine"):
+        for k in ("gmm_screen_pack", "gmm_screen", "gmm", "gmm_dist", "gmm_combine"):
             ms, n = self.ctx.profile_get(k)
             if n:
                 out[k] = dict(avg_ms=round(ms, 4), launches=n)
