@@ -97,6 +97,28 @@ __device__ __forceinline__ float gmm_distance_pk(const float (&x)[DIM], const fl
     return result;
 }
 
+// the same with the mean already in registers (software-pipelined callers)
+template<int DIM>
+__device__ __forceinline__ float gmm_distance_pk_reg(const float (&x)[DIM], const float (&mu)[DIM], const float* __restrict__ is) {
+    gmm_pk2       l01 = {0.f, 0.f}, l23 = {0.f, 0.f};
+    constexpr int EFF = DIM & ~3;
+#pragma unroll
+    for (int i = 0; i < EFF; i += 4) {
+        const gmm_pk2 d01 = (gmm_pk2{mu[i], mu[i + 1]} - gmm_pk2{x[i], x[i + 1]}) * *(const gmm_pk2*)(is + i);
+        const gmm_pk2 d23 = (gmm_pk2{mu[i + 2], mu[i + 3]} - gmm_pk2{x[i + 2], x[i + 3]}) * *(const gmm_pk2*)(is + i + 2);
+        l01               = l01 + d01 * d01;
+        l23               = l23 + d23 * d23;
+    }
+    float result = 0.f;
+    result       = result + ((l01.x + l01.y) + (l23.x + l23.y));
+#pragma unroll
+    for (int i = EFF; i < DIM; ++i) {
+        float df = (mu[i] - x[i]) * is[i];
+        result   = result + df * df;
+    }
+    return result;
+}
+
 // runtime-dimension variant: features live in LDS as [dim][64] (one column per lane)
 __device__ __forceinline__ float gmm_distance_rt(const float* xs, int dim, const float* __restrict__ mu, const float* __restrict__ is) {
     float     l0 = 0.f, l1 = 0.f, l2 = 0.f, l3 = 0.f;
@@ -948,35 +970,61 @@ __global__ __launch_bounds__(256) void gmm_screen_exact_kernel(const float* __re
     const uint4  ma = mrow[0], mb = mrow[1];
     const unsigned mw[8] = {ma.x, ma.y, ma.z, ma.w, mb.x, mb.y, mb.z, mb.w};
     // Every lane walks ITS OWN list of (mixture, slot) survivors: one distance per loop trip for every lane that still has
-    // work, instead of a trip count of max-over-lanes per mixture (16 x ~2.2 trips become ~1.1 x 16 + spread).
+    // work, instead of a trip count of max-over-lanes per mixture (16 x ~2.2 trips become ~1.1 x 16 + spread).  The walk is
+    // software-pipelined by one survivor: the mean row of the next survivor is read from LDS while the current one is evaluated.
     const int nm = min(16, n_mix - m0);
-    int       mi = 0;
-    unsigned  mask = 0;
-    MaxState  st;
-    bool      open = false;  // a mixture is loaded into (mask, k0, st)
-    for (;;) {
-        if (!open) {
-            if (mi >= nm)
-                break;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {  // mixtures without densities keep the empty result
+        s_sc[tid * 17 + q] = MaxState().result();
+        s_bd[tid * 20 + q] = 0xff;
+    }
+    int      mi = -1;
+    unsigned mask = 0;
+    auto     advance = [&]() -> int {  // slot row (mixture * 16 + slot) of the next survivor in ascending order, -1 at the end
+        while (mask == 0) {
+            if (++mi >= nm)
+                return -1;
             const uint32_t nk = (uint32_t)s_row[512 + mi];
             mask              = ((mi & 1) ? (mw[mi >> 1] >> 16) : mw[mi >> 1]) & 0xffffu & ((1u << nk) - 1u);
-            st                = MaxState();
-            open              = true;
         }
-        if (mask) {  // ascending slot order = the reference's density order
-            const int jj = __ffs((int)mask) - 1;
-            mask &= mask - 1;
-            const float* mu   = s_mu + (mi * 16 + jj) * LD;
-            const float* is   = POOLED ? g_isr : s_is + (mi * 16 + jj) * LD;
-            const float  dist = gmm_distance_pk<DIM>(x, mu, is);
-            st.add(s_c64[mi * 16 + jj], 0.f, dist, (uint32_t)jj);
+        const int jj = __ffs((int)mask) - 1;
+        mask &= mask - 1;
+        return mi * 16 + jj;
+    };
+    float mua[DIM], mub[DIM];
+    auto  fetch = [&](float (&dst)[DIM], int row) {
+        const float* src = s_mu + (row < 0 ? 0 : row) * LD;
+#pragma unroll
+        for (int i = 0; i + 1 < DIM; i += 2) {
+            const gmm_pk2 v = *(const gmm_pk2*)(src + i);
+            dst[i]          = v.x;
+            dst[i + 1]      = v.y;
         }
-        if (!mask) {
-            s_sc[tid * 17 + mi] = st.result();
-            s_bd[tid * 20 + mi] = (unsigned char)st.idx;  // 0..15, or 0xff for "no density" (idx = 0xffffffff)
-            ++mi;
-            open = false;
+        if (DIM & 1)
+            dst[DIM - 1] = src[DIM - 1];
+    };
+    MaxState st;
+    auto     eval = [&](const float (&mu)[DIM], int row, int next_row) {
+        const float* is   = POOLED ? g_isr : s_is + row * LD;
+        const float  dist = gmm_distance_pk_reg<DIM>(x, mu, is);
+        st.add(s_c64[row], 0.f, dist, (uint32_t)(row & 15));
+        if ((next_row >> 4) != (row >> 4)) {  // last survivor of this mixture (next_row = -1 gives mixture -1)
+            s_sc[tid * 17 + (row >> 4)] = st.result();
+            s_bd[tid * 20 + (row >> 4)] = (unsigned char)st.idx;  // 0..15, or 0xff for "no density" (idx = 0xffffffff)
+            st                          = MaxState();
         }
+    };
+    int ra = advance();
+    fetch(mua, ra);
+    while (ra >= 0) {
+        const int rb = advance();
+        fetch(mub, rb);
+        eval(mua, ra, rb);
+        if (rb < 0)
+            break;
+        ra = advance();
+        fetch(mua, ra);
+        eval(mub, rb, ra);
     }
     // The [256 frames x 16 mixtures] result tile leaves through LDS: four adjacent lanes write the 64 contiguous bytes of one
     // frame in ONE instruction.  (Per-lane 4-byte stores at a 40 KB stride cost more than the whole evaluation.)
