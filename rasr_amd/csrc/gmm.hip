@@ -313,37 +313,86 @@ __global__ __launch_bounds__(256) void gmm_accumulate_kernel(const float* __rest
                                                             const uint32_t* __restrict__ d_mean, const uint32_t* __restrict__ d_cov,
                                                             double* __restrict__ acc, long long off_mw, long long off_ms,
                                                             long long off_cw, long long off_cs, int pooled) {
-    const int lane = threadIdx.x & 63;
-    const int wid  = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int nw   = gridDim.x * 4;
-    // pooled covariance: private partial sums for up to 4 x 64 dims
-    double pc[4]  = {0, 0, 0, 0};
-    double pcw    = 0;
-    for (int t = wid; t < T; t += nw) {
-        const uint32_t m  = mixture[t];
-        const uint32_t kk = best_ld > 0 ? best[(size_t)t * best_ld + m] : best[t];
-        const uint32_t k  = mix_off[m] + kk;
-        const uint32_t d  = k_dens[k];
-        const uint32_t mi = d_mean[d], ci = d_cov[d];
-        if (lane == 0) {
-            atomicAdd(&acc[k], 1.0);
-            atomicAdd(&acc[off_mw + mi], 1.0);
-            if (!pooled)
-                atomicAdd(&acc[off_cw + ci], 1.0);
+    // A workgroup owns 256 consecutive frames.  Frames aligned to the same (state, density) are chained first and summed in
+    // registers, so a density that wins many frames of the block costs ONE set of atomics (aligned speech is bursty: the
+    // per-frame version spent its time on serialised f64 atomics to a handful of hot rows).
+    __shared__ uint32_t s_k[256], s_mi[256], s_ci[256];
+    __shared__ short    s_next[256];
+    __shared__ unsigned char s_lead[256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int t0 = blockIdx.x * 256;
+    {
+        const int t = t0 + tid;
+        uint32_t  k = 0xffffffffu, mi = 0, ci = 0;
+        if (t < T) {
+            const uint32_t m  = mixture[t];
+            const uint32_t kk = best_ld > 0 ? best[(size_t)t * best_ld + m] : best[t];
+            k                 = mix_off[m] + kk;
+            const uint32_t d  = k_dens[k];
+            mi                = d_mean[d];
+            ci                = d_cov[d];
         }
-        pcw += 1.0;
-        for (int i = lane, c = 0; i < dim; i += 64, ++c) {
-            const double y = (double)feats[(size_t)t * dim + i];
-            atomicAdd(&acc[off_ms + (long long)mi * dim + i], y);
-            if (pooled && c < 4)
-                pc[c] += y * y;
+        s_k[tid]  = k;
+        s_mi[tid] = mi;
+        s_ci[tid] = ci;
+    }
+    __syncthreads();
+    {
+        const uint32_t k = s_k[tid];
+        bool lead = k != 0xffffffffu;
+        for (int j = 0; j < tid && lead; ++j)
+            lead = s_k[j] != k;
+        int next = -1;
+        if (k != 0xffffffffu)
+            for (int j = tid + 1; j < 256; ++j)
+                if (s_k[j] == k) {
+                    next = j;
+                    break;
+                }
+        s_lead[tid] = lead ? 1 : 0;
+        s_next[tid] = (short)next;
+    }
+    __syncthreads();
+    double pc[4] = {0, 0, 0, 0};  // pooled covariance: private partial sums for up to 4 x 64 dims
+    double pcw   = 0;
+    for (int j = wave; j < 256; j += 4) {
+        if (!s_lead[j])
+            continue;
+        const uint32_t k = s_k[j], mi = s_mi[j], ci = s_ci[j];
+        double         sx[4] = {0, 0, 0, 0}, sxx[4] = {0, 0, 0, 0};
+        int            count = 0;
+        for (int m = j; m >= 0; m = s_next[m]) {
+            ++count;
+            for (int i = lane, c = 0; i < dim && c < 4; i += 64, ++c) {
+                const double y = (double)feats[(size_t)(t0 + m) * dim + i];
+                sx[c] += y;
+                sxx[c] += y * y;
+            }
+            for (int i = lane + 256; i < dim; i += 64) {  // dimensions beyond 256: straight atomics
+                const double y = (double)feats[(size_t)(t0 + m) * dim + i];
+                atomicAdd(&acc[off_ms + (long long)mi * dim + i], y);
+                atomicAdd(&acc[off_cs + (pooled ? 0 : (long long)ci * dim) + i], y * y);
+            }
+        }
+        if (lane == 0) {
+            atomicAdd(&acc[k], (double)count);
+            atomicAdd(&acc[off_mw + mi], (double)count);
+            if (!pooled)
+                atomicAdd(&acc[off_cw + ci], (double)count);
+        }
+        pcw += (double)count;
+        for (int i = lane, c = 0; i < dim && c < 4; i += 64, ++c) {
+            atomicAdd(&acc[off_ms + (long long)mi * dim + i], sx[c]);
+            if (pooled)
+                pc[c] += sxx[c];
             else
-                atomicAdd(&acc[off_cs + (long long)ci * dim + i], y * y);
+                atomicAdd(&acc[off_cs + (long long)ci * dim + i], sxx[c]);
         }
     }
     if (pooled) {
         for (int i = lane, c = 0; i < dim && c < 4; i += 64, ++c)
-            atomicAdd(&acc[off_cs + i], pc[c]);
+            if (pc[c] != 0.0)
+                atomicAdd(&acc[off_cs + i], pc[c]);
         if (lane == 0 && pcw != 0.0)
             atomicAdd(&acc[off_cw], pcw);
     }
@@ -1834,7 +1883,7 @@ int amx_gmm_accumulate_dev(amx_gmm* h, const float* feats_dev, int T, const uint
     const long long off_mw = (long long)h->nk, off_ms = off_mw + h->n_mean, off_cw = off_ms + (long long)h->n_mean * h->dim,
                     off_cs = off_cw + h->n_cov;
     const int              pooled = (h->n_cov == 1 && h->dim <= 256) ? 1 : 0;
-    const int              blocks = (int)std::min<long>(((long)T + 3) / 4, 2048);
+    const int              blocks = (T + 255) / 256;
     amx::ScopedKernelTimer timer(h->ctx, "gmm_accumulate");
     hipLaunchKernelGGL(amx::gmm_accumulate_kernel, dim3(blocks), dim3(256), 0, h->ctx->stream, feats_dev, mixture_dev, best_density_dev,
                        best_density_ld, T, h->dim, h->d_mix_off, h->d_k_dens, h->d_d_mean, h->d_d_cov, acc_dev, off_mw, off_ms, off_cw,
