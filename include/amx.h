@@ -135,6 +135,27 @@ int  amx_mfcc_run_plan_dev(amx_mfcc* h, const amx_mfcc_plan* p, const float* pcm
 int amx_context_window_dev(amx_ctx* ctx, const amx_mfcc_plan* p, const float* feats_dev, int dim,
                            int left, int right, float* out_dev, int out_stride);
 
+/* Feature back-end between the front-end and the scorers, on device-resident
+ * [total_frames x ld] f32 matrices segmented like the plan.  in/out may point into wider matrices (column offset by
+ * pointer arithmetic, row stride *_ld), which is how "generic-vector-f32-concat" of features and derivatives is laid out.
+ *
+ * signal-normalization (src/Signal/Normalization.cc:46-66,120-187): per segment, type mean or mean-and-variance;
+ * length = 0: whole segment (length="infinite" right="infinite"); otherwise a sliding window of `length` frames with the
+ * output point `right` frames from its newest end (0 <= right < length), statistics kept as the reference's running
+ * f64 sums (the last `right` frames of a segment leave with the statistics of the last window, as in the reference). */
+#define AMX_NORM_MEAN 0
+#define AMX_NORM_MEAN_AND_VARIANCE 1
+int amx_normalize_dev(amx_ctx* ctx, const amx_mfcc_plan* plan, const float* in_dev, int in_ld, int dim, int type,
+                      int length, int right, float* out_dev, int out_ld);
+/* signal-delay (max-size = 2*right+1, margin-policy copy, margin-condition present-not-empty; src/Signal/Delay.hh:33-47)
+ * + signal-regression order 1 or 2 (src/Signal/Regression.cc:25-68), as wired in derivationWithRegression.flow. */
+int amx_regression_dev(amx_ctx* ctx, const amx_mfcc_plan* plan, const float* in_dev, int in_ld, int dim, int order,
+                       int right, float* out_dev, int out_ld);
+/* signal-matrix-multiplication-f32 (src/Signal/MatrixMult.hh:246-255; LDA in lda.flow): out[t] = M in[t], M [rows x cols]
+ * row-major on the device (read the file with amx_nn_matrix_read: same binary Math::Matrix<f32> format). */
+int amx_matrix_multiply_dev(amx_ctx* ctx, const float* matrix_dev, int rows, int cols, const float* in_dev, int in_ld,
+                            int T, float* out_dev, int out_ld);
+
 /* ------------------------------------------------------------------ diagonal-covariance GMM */
 
 typedef struct {

@@ -145,6 +145,35 @@ def load_ref():
     return R
 
 
+def oracle_normalize(x, variance=False, length=0, right=0):
+    """orc_normalize over one segment [n, dim]"""
+    L = Oracle()
+    x = np.ascontiguousarray(x, np.float32)
+    out = np.empty_like(x)
+    L.orc_normalize.argtypes = [f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32p]
+    L.orc_normalize(x.reshape(-1), x.shape[0], x.shape[1], 1 if variance else 0, length, right, out.reshape(-1))
+    return out
+
+
+def oracle_regression(x, order=1, right=2):
+    L = Oracle()
+    x = np.ascontiguousarray(x, np.float32)
+    out = np.empty_like(x)
+    L.orc_regression.argtypes = [f32p, C.c_int, C.c_int, C.c_int, C.c_int, f32p]
+    L.orc_regression(x.reshape(-1), x.shape[0], x.shape[1], order, right, out.reshape(-1))
+    return out
+
+
+def oracle_matrix_multiply(M, x):
+    L = Oracle()
+    M = np.ascontiguousarray(M, np.float32)
+    x = np.ascontiguousarray(x, np.float32)
+    out = np.empty((x.shape[0], M.shape[0]), np.float32)
+    L.orc_matrix_multiply.argtypes = [f32p, C.c_int, C.c_int, f32p, C.c_int, f32p]
+    L.orc_matrix_multiply(M.reshape(-1), M.shape[0], M.shape[1], x.reshape(-1), x.shape[0], out.reshape(-1))
+    return out
+
+
 def ref_cache_block(feats, times):
     """bytes of one Flow cache block written by the reference's Flow::Vector<f32> / Datatype code (libref)"""
     R = load_ref()

@@ -144,4 +144,10 @@ void orc_ffnn_score(const orc_ffnn_model* m, const float* feats, int T, float* s
 #ifdef __cplusplus
 }
 #endif
+
+/* ---- feature back-end, orc_backend.c; parity unpinned (see that file) */
+void orc_normalize(const float* in, int n, int dim, int type, int length, int right, float* out);
+void orc_regression(const float* in, int n, int dim, int order, int right, float* out);
+void orc_matrix_multiply(const float* M, int rows, int cols, const float* in, int T, float* out);
+
 #endif

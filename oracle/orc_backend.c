@@ -1,0 +1,143 @@
+/* oracle/orc_backend.c -- CPU restatement of the feature back-end between the front-end and the scorers
+ * (SURVEY.md section 8 row f1).  TEST INFRASTRUCTURE (see orc.h).
+ *
+ * PARITY UNPINNED against the reference: Signal/Normalization.cc, Regression.cc and MatrixMult.hh sit on Flow::Node /
+ * Core::Configuration (boost) and cannot be compiled here, and the reference has no test vectors for them.  Each
+ * function follows the cited source lines operation by operation (types, order of the f32 / f64 operations).
+ */
+#include "orc.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* Signal::MeanNormalization / MeanAndVarianceNormalization over one segment (Signal/Normalization.cc:46-66 update,
+ * :120-137 mean, :157-187 variance; sliding window Signal/SlidingWindow.hh:401-448).
+ * length = right = 0 means "infinite" (whole segment).  For a finite window the frame added at time t evicts frame
+ * t - length; frame u leaves while frame u + right is being added, normalised with the running f64 sums at that moment
+ * (sum += added, then sum -= removed); the last `right` frames leave at flush time with the statistics of the LAST add
+ * (Normalization::update does not touch the statistics while flushing).  type 0 = mean, 1 = mean-and-variance. */
+void orc_normalize(const float* in, int n, int dim, int type, int length, int right, float* out) {
+    if (n <= 0)
+        return;
+    const int infinite = (length <= 0);
+    double*   sum   = (double*)calloc((size_t)dim, sizeof(double));
+    double*   sumsq = (double*)calloc((size_t)dim, sizeof(double));
+    float*    mean  = (float*)calloc((size_t)dim, sizeof(float));
+    float*    sd    = (float*)calloc((size_t)dim, sizeof(float));
+    double    w = 0;
+    for (int t = 0; t < n; ++t) {
+        const float* x = in + (size_t)t * dim;
+        for (int d = 0; d < dim; ++d) {
+            sum[d] = sum[d] + (double)x[d];
+            sumsq[d] += (double)x[d] * (double)x[d];
+        }
+        w += 1;
+        if (!infinite && t >= length) {
+            const float* r = in + (size_t)(t - length) * dim;
+            for (int d = 0; d < dim; ++d) {
+                sum[d] = sum[d] - (double)r[d];
+                sumsq[d] -= (double)r[d] * (double)r[d];
+            }
+            w -= 1;
+        }
+        const int emit_now = !infinite && t >= right;
+        const int last     = (t == n - 1);
+        if (emit_now || last) {
+            for (int d = 0; d < dim; ++d) {
+                mean[d] = (float)(sum[d] / w);
+                if (type == 1) {
+                    sd[d] = (float)sqrt((sumsq[d] - sum[d] * sum[d] / w) / w);
+                    if (sd[d] == 0)
+                        sd[d] = 1.0f;
+                }
+            }
+        }
+        if (emit_now) {
+            const int    u = t - right;
+            const float* s = in + (size_t)u * dim;
+            float*       o = out + (size_t)u * dim;
+            for (int d = 0; d < dim; ++d) {
+                float v = s[d] - mean[d];
+                if (type == 1)
+                    v = v / sd[d];
+                o[d] = v;
+            }
+        }
+    }
+    /* flush: frames that have not left yet, with the statistics of the last add */
+    const int first = infinite ? 0 : (n - right > 0 ? n - right : 0);
+    for (int u = first; u < n; ++u) {
+        const float* s = in + (size_t)u * dim;
+        float*       o = out + (size_t)u * dim;
+        for (int d = 0; d < dim; ++d) {
+            float v = s[d] - mean[d];
+            if (type == 1)
+                v = v / sd[d];
+            o[d] = v;
+        }
+    }
+    free(sum);
+    free(sumsq);
+    free(mean);
+    free(sd);
+}
+
+/* Signal::Regression::regressFirstOrder / regressSecondOrder (Signal/Regression.cc:25-68) over the window
+ * [t - right, t + right] of a segment, missing frames replaced by the closest one (signal-delay, margin-policy copy,
+ * margin-condition present-not-empty: Signal/Delay.hh:33-47, derivationWithRegression.flow:7-8). */
+void orc_regression(const float* in, int n, int dim, int order, int right, float* out) {
+    const int len = 2 * right + 1;
+    for (int t = 0; t < n; ++t) {
+        float* o = out + (size_t)t * dim;
+        for (int c = 0; c < dim; ++c)
+            o[c] = 0.0f;
+        if (order == 1) {
+            float tm = 0.0f;
+            for (int i = 0; i < len; ++i) {
+                int tt = t - right + i;
+                tt     = tt < 0 ? 0 : (tt >= n ? n - 1 : tt);
+                const float* f  = in + (size_t)tt * dim;
+                const float  dt = (float)((double)(float)i - (double)(float)(len - 1) / 2.0);
+                for (int c = 0; c < dim; ++c)
+                    o[c] += dt * f[c];
+                tm += dt * dt;
+            }
+            for (int c = 0; c < dim; ++c)
+                o[c] /= tm;
+        }
+        else {
+            float tm = 0.0f, ns = 0.0f;
+            for (int i = 0; i < len; ++i) {
+                const float dt = (float)((double)(float)i - (double)(float)(len - 1) / 2.0);
+                tm += dt * dt;
+                ns += dt * dt * dt * dt;
+            }
+            ns = tm * tm - (float)len * ns;
+            for (int i = 0; i < len; ++i) {
+                int tt = t - right + i;
+                tt     = tt < 0 ? 0 : (tt >= n ? n - 1 : tt);
+                const float* f  = in + (size_t)tt * dim;
+                const float  dt = (float)((double)(float)i - (double)(float)(len - 1) / 2.0);
+                for (int c = 0; c < dim; ++c) {
+                    o[c] += f[c] * tm;
+                    o[c] -= f[c] * dt * dt * (float)len;
+                }
+            }
+            for (int c = 0; c < dim; ++c)
+                o[c] = (float)((double)o[c] * (2.0 / (double)ns));
+        }
+    }
+}
+
+/* signal-matrix-multiplication-f32: y = M x with Math::Matrix::operator*(Vector) (Math/Matrix.hh:487-494) =
+ * one Math::Vector dot product per row, f32 accumulation left to right (Math/Vector.hh:95-101). */
+void orc_matrix_multiply(const float* M, int rows, int cols, const float* in, int T, float* out) {
+    for (int t = 0; t < T; ++t)
+        for (int r = 0; r < rows; ++r) {
+            float acc = 0.0f;
+            for (int k = 0; k < cols; ++k)
+                acc = acc + M[(size_t)r * cols + k] * in[(size_t)t * cols + k];
+            out[(size_t)t * rows + r] = acc;
+        }
+}

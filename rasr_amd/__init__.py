@@ -78,6 +78,20 @@ class Context:
     def context_window(self, plan, feats, dim, left, right, out, out_stride):
         _lib.check(self.L.amx_context_window_dev(self.h, plan.h, _ptr(feats), dim, left, right, _ptr(out), out_stride))
 
+    # ---- feature back-end: device matrices [total_frames x ld], segmented like the plan
+    def normalize(self, plan, feats, in_ld, dim, out, out_ld, variance=False, length=0, right=0):
+        """signal-normalization: type mean / mean-and-variance; length = 0 is the whole segment"""
+        _lib.check(self.L.amx_normalize_dev(self.h, plan.h, _ptr(feats), in_ld, dim,
+                                            _lib.AMX_NORM_MEAN_AND_VARIANCE if variance else _lib.AMX_NORM_MEAN, length, right, _ptr(out), out_ld))
+
+    def regression(self, plan, feats, in_ld, dim, out, out_ld, order=1, right=2):
+        """signal-delay (copy margin) + signal-regression of the given order over 2 * right + 1 frames"""
+        _lib.check(self.L.amx_regression_dev(self.h, plan.h, _ptr(feats), in_ld, dim, order, right, _ptr(out), out_ld))
+
+    def matrix_multiply(self, matrix, rows, cols, feats, in_ld, T, out, out_ld):
+        """signal-matrix-multiplication-f32: out[t] = M feats[t]"""
+        _lib.check(self.L.amx_matrix_multiply_dev(self.h, _ptr(matrix), rows, cols, _ptr(feats), in_ld, T, _ptr(out), out_ld))
+
     def stats_accumulate(self, scores, T, M, best_state, counts, score_sum):
         _lib.check(self.L.amx_stats_accumulate_dev(self.h, _ptr(scores), T, M, _ptr(best_state), _ptr(counts), _ptr(score_sum)))
 

@@ -14,6 +14,7 @@ AMX_GMM_MAX, AMX_GMM_SUM, AMX_GMM_BATCH_FLOAT = 0, 1, 2
 AMX_ACT_NONE, AMX_ACT_RELU, AMX_ACT_SIGMOID, AMX_ACT_TANH = 0, 1, 2, 3
 AMX_PREC_FP32, AMX_PREC_BF16 = 0, 1
 AMX_ARCHIVE_READ, AMX_ARCHIVE_WRITE = 0, 1
+AMX_NORM_MEAN, AMX_NORM_MEAN_AND_VARIANCE = 0, 1
 
 
 class AmxError(RuntimeError):
@@ -75,6 +76,9 @@ SIGNATURES = {
     "amx_mfcc_plan_frame_offsets": (C.c_int, [_P, _P]),
     "amx_mfcc_run_plan_dev": (C.c_int, [_P, _P, _P, _P]),
     "amx_context_window_dev": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int]),
+    "amx_normalize_dev": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int]),
+    "amx_regression_dev": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int]),
+    "amx_matrix_multiply_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_int, C.c_int, _P, C.c_int]),
     "amx_gmm_create": (C.c_int, [_P, C.POINTER(GmmModel), C.POINTER(_P)]),
     "amx_gmm_destroy": (None, [_P]),
     "amx_gmm_n_mixtures": (C.c_int, [_P]),

@@ -1,0 +1,201 @@
+// backend.hip -- feature back-end between the front-end and the scorers on device-resident
+// [frames x dim] matrices: segment-wise mean (/ variance) normalisation, regression derivatives, linear transform (LDA).
+// The sliding-window concatenation of the same row is context_window_kernel in mfcc.hip.
+//
+// Replaces, per Tools/FeatureExtraction/share/processing.standard_system.flow, derivationWithRegression.flow, lda.flow:
+//   signal-normalization           Signal/Normalization.cc:46-66,120-187 (+ Signal/SlidingWindow.hh:401-448)
+//   signal-delay + signal-regression   Signal/Delay.hh:33-47 (copy margin, present-not-empty), Signal/Regression.cc:25-68
+//   signal-matrix-multiplication-f32   Signal/MatrixMult.hh:246-255 -> Math/Matrix.hh:487-494, Math/Vector.hh:95-101
+// All three follow the reference's operation order (f64 running sums updated add-then-remove, f32 taps accumulated in
+// window order, f32 dot products left to right), so they are compared bit for bit with oracle/orc_backend.c.
+#include "common.hpp"
+
+#include <algorithm>
+
+// internal view of an MFCC plan's segmentation (mfcc.hip)
+extern "C" int amx_internal_plan_view(const amx_mfcc_plan* p, const long long** d_frame_off, int* n_seg, long long* total);
+
+namespace amx {
+
+// One workgroup per segment, one lane per dimension (strided), frames in order: the reference's statistics are a
+// sequential recurrence per dimension.  64 segments x 40 dimensions of work are tiny next to the scorers.
+__global__ __launch_bounds__(64) void normalize_kernel(const float* __restrict__ in, int in_ld, const long long* __restrict__ frame_off,
+                                                      int dim, int type, int length, int right, float* __restrict__ out, int out_ld) {
+    const long long s0 = frame_off[blockIdx.x], s1 = frame_off[blockIdx.x + 1];
+    const int       n  = (int)(s1 - s0);
+    if (n <= 0)
+        return;
+    const bool infinite = length <= 0;
+    for (int d = threadIdx.x; d < dim; d += 64) {
+        double sum = 0.0, sumsq = 0.0, w = 0.0;
+        float  mean = 0.f, sd = 1.f;
+        for (int t = 0; t < n; ++t) {
+            const double x = (double)in[(s0 + t) * in_ld + d];
+            sum            = sum + x;
+            sumsq += x * x;
+            w += 1.0;
+            if (!infinite && t >= length) {
+                const double r = (double)in[(s0 + t - length) * in_ld + d];
+                sum            = sum - r;
+                sumsq -= r * r;
+                w -= 1.0;
+            }
+            const bool emit_now = !infinite && t >= right;
+            if (emit_now || t == n - 1) {
+                mean = (float)(sum / w);
+                if (type == 1) {
+                    sd = (float)sqrt((sumsq - sum * sum / w) / w);
+                    if (sd == 0.f)
+                        sd = 1.f;
+                }
+            }
+            if (emit_now) {
+                float v = in[(s0 + t - right) * in_ld + d] - mean;
+                if (type == 1)
+                    v = v / sd;
+                out[(s0 + t - right) * out_ld + d] = v;
+            }
+        }
+        const int first = infinite ? 0 : max(n - right, 0);
+        for (int u = first; u < n; ++u) {  // flush: statistics of the last add
+            float v = in[(s0 + u) * in_ld + d] - mean;
+            if (type == 1)
+                v = v / sd;
+            out[(s0 + u) * out_ld + d] = v;
+        }
+    }
+}
+
+__device__ __forceinline__ int segment_of(const long long* __restrict__ frame_off, int n_seg, long long t) {
+    int lo = 0, hi = n_seg;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (frame_off[mid] <= t)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+
+// one workgroup per frame, lanes over the coefficients
+__global__ __launch_bounds__(64) void regression_kernel(const float* __restrict__ in, int in_ld, const long long* __restrict__ frame_off,
+                                                       int n_seg, int dim, int order, int right, float* __restrict__ out, int out_ld) {
+    const long long t   = blockIdx.x;
+    const int       seg = segment_of(frame_off, n_seg, t);
+    const long long s0 = frame_off[seg], s1 = frame_off[seg + 1];
+    const int       len = 2 * right + 1;
+    for (int c = threadIdx.x; c < dim; c += 64) {
+        float o = 0.f;
+        if (order == 1) {
+            float tm = 0.f;
+            for (int i = 0; i < len; ++i) {
+                long long tt = t - right + i;
+                tt           = tt < s0 ? s0 : (tt >= s1 ? s1 - 1 : tt);
+                const float dt = (float)((double)(float)i - (double)(float)(len - 1) / 2.0);
+                o              = o + dt * in[tt * in_ld + c];
+                tm             = tm + dt * dt;
+            }
+            o = o / tm;
+        }
+        else {
+            float tm = 0.f, ns = 0.f;
+            for (int i = 0; i < len; ++i) {
+                const float dt = (float)((double)(float)i - (double)(float)(len - 1) / 2.0);
+                tm             = tm + dt * dt;
+                ns             = ns + dt * dt * dt * dt;
+            }
+            ns = tm * tm - (float)len * ns;
+            for (int i = 0; i < len; ++i) {
+                long long tt = t - right + i;
+                tt           = tt < s0 ? s0 : (tt >= s1 ? s1 - 1 : tt);
+                const float f  = in[tt * in_ld + c];
+                const float dt = (float)((double)(float)i - (double)(float)(len - 1) / 2.0);
+                o              = o + f * tm;
+                o              = o - f * dt * dt * (float)len;
+            }
+            o = (float)((double)o * (2.0 / (double)ns));
+        }
+        out[t * out_ld + c] = o;
+    }
+}
+
+// y[t][r] = sum_k M[r][k] x[t][k], f32, k ascending.  lane = frame (its row streams through L1), matrix rows are
+// wave-uniform -> scalar loads.  A 45 x 440 LDA over 64 k frames is 2.5 GFLOP: not worth an MFMA path that would change the sums.
+__global__ __launch_bounds__(256) void matrix_multiply_kernel(const float* __restrict__ M, int rows, int cols, const float* __restrict__ in,
+                                                             int in_ld, int T, float* __restrict__ out, int out_ld) {
+    const int t  = blockIdx.x * 256 + threadIdx.x;
+    const int tt = t < T ? t : T - 1;
+    const float* x = in + (size_t)tt * in_ld;
+    for (int r = blockIdx.y; r < rows; r += gridDim.y) {
+        const float* m   = M + (size_t)r * cols;
+        float        acc = 0.f;
+        for (int k = 0; k < cols; ++k)
+            acc = acc + m[k] * x[k];
+        if (t < T)
+            out[(size_t)t * out_ld + r] = acc;
+    }
+}
+
+}  // namespace amx
+
+extern "C" {
+
+int amx_normalize_dev(amx_ctx* ctx, const amx_mfcc_plan* plan, const float* in_dev, int in_ld, int dim, int type, int length, int right,
+                      float* out_dev, int out_ld) {
+    AMX_REQUIRE(ctx && plan && in_dev && out_dev, AMX_ERR_INVALID, "amx_normalize_dev: NULL argument");
+    AMX_REQUIRE(dim > 0 && in_ld >= dim && out_ld >= dim, AMX_ERR_INVALID, "amx_normalize_dev: bad dimension / stride");
+    AMX_REQUIRE(type == AMX_NORM_MEAN || type == AMX_NORM_MEAN_AND_VARIANCE, AMX_ERR_INVALID, "amx_normalize_dev: unknown type %d", type);
+    // SlidingWindow::init: "return false if maxSize <= right" -> the node reports "Cannot initialize with parameters ..."
+    AMX_REQUIRE(length == 0 || (length > 0 && right >= 0 && right < length), AMX_ERR_INVALID,
+                "amx_normalize_dev: Cannot initialize with parameters length (%d), right (%d)", length, right);
+    const long long* d_off;
+    int              n_seg;
+    long long        total;
+    int              r = amx_internal_plan_view(plan, &d_off, &n_seg, &total);
+    if (r != AMX_OK || total == 0)
+        return r;
+    AMX_HIP(hipSetDevice(ctx->device));
+    amx::ScopedKernelTimer timer(ctx, "normalize");
+    hipLaunchKernelGGL(amx::normalize_kernel, dim3(n_seg), dim3(64), 0, ctx->stream, in_dev, in_ld, d_off, dim, type, length, right, out_dev, out_ld);
+    AMX_HIP(hipGetLastError());
+    return AMX_OK;
+}
+
+int amx_regression_dev(amx_ctx* ctx, const amx_mfcc_plan* plan, const float* in_dev, int in_ld, int dim, int order, int right,
+                       float* out_dev, int out_ld) {
+    AMX_REQUIRE(ctx && plan && in_dev && out_dev, AMX_ERR_INVALID, "amx_regression_dev: NULL argument");
+    AMX_REQUIRE(dim > 0 && in_ld >= dim && out_ld >= dim && right >= 1, AMX_ERR_INVALID, "amx_regression_dev: bad dimension / stride / window");
+    // RegressionNode::merge: criticalError("signal-regression only implemented for 1st and 2nd order derivatives")
+    AMX_REQUIRE(order == 1 || order == 2, AMX_ERR_UNSUPPORTED, "signal-regression only implemented for 1st and 2nd order derivatives");
+    const long long* d_off;
+    int              n_seg;
+    long long        total;
+    int              r = amx_internal_plan_view(plan, &d_off, &n_seg, &total);
+    if (r != AMX_OK || total == 0)
+        return r;
+    AMX_HIP(hipSetDevice(ctx->device));
+    amx::ScopedKernelTimer timer(ctx, "regression");
+    hipLaunchKernelGGL(amx::regression_kernel, dim3((unsigned)total), dim3(64), 0, ctx->stream, in_dev, in_ld, d_off, n_seg, dim, order, right,
+                       out_dev, out_ld);
+    AMX_HIP(hipGetLastError());
+    return AMX_OK;
+}
+
+int amx_matrix_multiply_dev(amx_ctx* ctx, const float* matrix_dev, int rows, int cols, const float* in_dev, int in_ld, int T, float* out_dev,
+                            int out_ld) {
+    AMX_REQUIRE(ctx && matrix_dev && in_dev && out_dev, AMX_ERR_INVALID, "amx_matrix_multiply_dev: NULL argument");
+    // MatrixMultiplicationNode::work: "vector/matrix dimension mismatch" when the input size differs from nColumns
+    AMX_REQUIRE(rows > 0 && cols > 0 && in_ld >= cols && out_ld >= rows && T >= 0, AMX_ERR_INVALID,
+                "amx_matrix_multiply_dev: vector/matrix dimension mismatch: vector stride %d, matrix %d columns", in_ld, cols);
+    if (T == 0)
+        return AMX_OK;
+    AMX_HIP(hipSetDevice(ctx->device));
+    amx::ScopedKernelTimer timer(ctx, "matrix_multiply");
+    hipLaunchKernelGGL(amx::matrix_multiply_kernel, dim3((T + 255) / 256, std::min(rows, 64)), dim3(256), 0, ctx->stream, matrix_dev, rows, cols,
+                       in_dev, in_ld, T, out_dev, out_ld);
+    AMX_HIP(hipGetLastError());
+    return AMX_OK;
+}
+
+}  // extern "C"

@@ -815,6 +815,15 @@ int amx_mfcc_run(amx_mfcc* h, const float* pcm_host, long n_samples, float* ceps
     return amx_mfcc_run_batch(h, 1, in, n, out);
 }
 
+// internal (not in amx.h): the segmentation of a plan for the back-end kernels in backend.hip
+int amx_internal_plan_view(const amx_mfcc_plan* p, const long long** d_frame_off, int* n_seg, long long* total) {
+    AMX_REQUIRE(p && d_frame_off && n_seg && total, AMX_ERR_INVALID, "plan view: NULL argument");
+    *d_frame_off = p->d_frame_off;
+    *n_seg       = p->n_seg;
+    *total       = p->frame_off.back();
+    return AMX_OK;
+}
+
 int amx_context_window_dev(amx_ctx* ctx, const amx_mfcc_plan* p, const float* feats_dev, int dim, int left, int right,
                            float* out_dev, int out_stride) {
     AMX_REQUIRE(ctx && p && feats_dev && out_dev, AMX_ERR_INVALID, "amx_context_window_dev: NULL argument");

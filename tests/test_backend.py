@@ -1,0 +1,160 @@
+"""Feature back-end.  CPU part: the oracle restatement (oracle/orc_backend.c, parity unpinned
+against the reference -- see that file) against independent numpy formulations of the same definitions.  GPU part: the
+HIP kernels against the oracle, bit for bit (both follow the reference's operation order)."""
+import numpy as np
+import pytest
+
+from oracle.binding import oracle_matrix_multiply, oracle_normalize, oracle_regression
+
+
+def seg(n, dim, seed):
+    r = np.random.Generator(np.random.PCG64(seed))
+    return (r.standard_normal((n, dim)) * 3 + r.standard_normal(dim) * 5).astype(np.float32)
+
+
+# ------------------------------------------------------------------ oracle vs the definitions
+@pytest.mark.parametrize("variance", [False, True])
+def test_oracle_whole_segment_normalisation(variance):
+    x = seg(500, 16, 1)
+    got = oracle_normalize(x, variance=variance)
+    mean = (x.astype(np.float64).sum(0) / len(x)).astype(np.float32)
+    want = x - mean
+    if variance:
+        s = x.astype(np.float64)
+        sd = np.sqrt(((s * s).sum(0) - s.sum(0) ** 2 / len(x)) / len(x)).astype(np.float32)
+        want = want / sd
+    assert np.allclose(got, want, rtol=1e-6, atol=1e-6)
+    assert np.allclose(got.mean(0), 0, atol=1e-4)
+    if variance:
+        assert np.allclose(got.std(0), 1, atol=1e-3)
+    const = np.full((7, 3), 2.5, np.float32)          # zero variance -> standard deviation forced to 1
+    assert np.array_equal(oracle_normalize(const, variance=True), np.zeros((7, 3), np.float32))
+
+
+def test_oracle_sliding_window_normalisation():
+    """length 21, right 10: frame u is normalised with the frames [u - 10, u + 10] that exist; the last `right` frames keep
+    the statistics of the last full step (Normalization::update does not update them while flushing)"""
+    L, R, n = 21, 10, 60
+    x = seg(n, 4, 2)
+    got = oracle_normalize(x, length=L, right=R)
+    for u in range(n):
+        hi = u + R if u + R <= n - 1 else n - 1
+        lo = max(0, hi - L + 1)
+        want = x[u] - x[lo:hi + 1].astype(np.float64).mean(0).astype(np.float32)
+        assert np.allclose(got[u], want, rtol=1e-5, atol=1e-5), u
+    short = seg(6, 4, 3)                               # fewer frames than `right`: everything leaves at flush time
+    assert np.allclose(oracle_normalize(short, length=L, right=R), short - short.mean(0), atol=1e-5)
+
+
+def test_oracle_regression_is_the_least_squares_slope():
+    n, right = 40, 2
+    x = seg(n, 5, 4)
+    d1 = oracle_regression(x, 1, right)
+    d2 = oracle_regression(x, 2, right)
+    tt = np.arange(-right, right + 1, dtype=np.float64)
+    for t in range(n):
+        idx = np.clip(np.arange(t - right, t + right + 1), 0, n - 1)     # copy margin
+        w = x[idx].astype(np.float64)
+        slope = (tt[:, None] * w).sum(0) / (tt ** 2).sum()
+        assert np.allclose(d1[t], slope, rtol=1e-5, atol=1e-5)
+        quad = np.polyfit(tt, w, 2)[0] * 2                                # second derivative of the LS parabola
+        assert np.allclose(d2[t], quad, rtol=1e-4, atol=1e-4)
+    line = (np.arange(n, dtype=np.float32)[:, None] * np.float32(0.5)) + np.float32(3)
+    assert np.allclose(oracle_regression(line, 1, 2)[2:-2], 0.5, atol=1e-6)
+    assert np.allclose(oracle_regression(line, 2, 2)[2:-2], 0.0, atol=1e-5)
+
+
+def test_oracle_matrix_multiply():
+    r = np.random.Generator(np.random.PCG64(5))
+    M = r.standard_normal((9, 33)).astype(np.float32)
+    x = r.standard_normal((20, 33)).astype(np.float32)
+    assert np.allclose(oracle_matrix_multiply(M, x), x.astype(np.float64) @ M.T.astype(np.float64), rtol=1e-5, atol=1e-5)
+
+
+# ------------------------------------------------------------------ HIP kernels vs the oracle
+def _plan(ctx, lens):
+    """an MFCC plan whose segments have exactly `lens` frames (frame i covers samples [160 i, 160 i + 400))"""
+    import rasr_amd
+    fe = rasr_amd.MfccExtractor(ctx, nr_cepstrum_coefficients=8)
+    samples = [400 + 160 * (n - 1) for n in lens]
+    off = np.concatenate([[0], np.cumsum(samples)])
+    plan = fe.plan(off)
+    assert list(np.diff(plan.frame_offsets)) == list(lens)
+    return plan
+
+
+@pytest.mark.gpu
+def test_backend_kernels_match_the_oracle(ctx):
+    import torch
+    lens = [1, 2, 5, 9, 64, 333, 7]
+    plan = _plan(ctx, lens)
+    F, dim, ld = sum(lens), 13, 20
+    x = np.zeros((F, ld), np.float32)
+    x[:, 3:3 + dim] = seg(F, dim, 11)
+    xd = torch.from_numpy(x).cuda()
+    ctx.use_torch_stream()
+    off = np.concatenate([[0], np.cumsum(lens)])
+    view = lambda a: [a[off[i]:off[i + 1], 3:3 + dim] for i in range(len(lens))]
+    for kw in (dict(), dict(variance=True), dict(length=21, right=10), dict(variance=True, length=5, right=0), dict(length=9, right=8)):
+        out = torch.full((F, 16), 7.0, dtype=torch.float32, device="cuda")
+        ctx.normalize(plan, xd[:, 3:], ld, dim, out[:, 1:], 16, **kw)
+        torch.cuda.synchronize()
+        got = out.cpu().numpy()
+        assert np.all(got[:, 0] == 7.0) and np.all(got[:, 1 + dim:] == 7.0)          # only the addressed columns are written
+        for i, s in enumerate(view(x)):
+            want = oracle_normalize(s, **kw)
+            assert np.array_equal(got[off[i]:off[i + 1], 1:1 + dim].view(np.uint32), want.view(np.uint32)), (kw, i)
+    for order in (1, 2):
+        for right in (1, 2, 4):
+            out = torch.zeros((F, dim), dtype=torch.float32, device="cuda")
+            ctx.regression(plan, xd[:, 3:], ld, dim, out, dim, order=order, right=right)
+            torch.cuda.synchronize()
+            got = out.cpu().numpy()
+            for i, s in enumerate(view(x)):
+                want = oracle_regression(s, order, right)
+                assert np.array_equal(got[off[i]:off[i + 1]].view(np.uint32), want.view(np.uint32)), (order, right, i)
+    M = np.random.Generator(np.random.PCG64(12)).standard_normal((45, dim)).astype(np.float32)
+    Md = torch.from_numpy(M).cuda()
+    out = torch.zeros((F, 48), dtype=torch.float32, device="cuda")
+    ctx.matrix_multiply(Md, 45, dim, xd[:, 3:], ld, F, out, 48)
+    torch.cuda.synchronize()
+    want = oracle_matrix_multiply(M, x[:, 3:3 + dim])
+    assert np.array_equal(out.cpu().numpy()[:, :45].view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_backend_chain_cmvn_derivatives_lda(ctx):
+    """processing.standard_system.flow in one pass: MFCC-16 -> segment CMVN -> [c, delta, deltadelta(c0)] -> 3-frame window
+    -> LDA, all device resident; the result equals the oracle's chain on every segment"""
+    import torch
+
+    import rasr_amd
+    from oracle import OracleMfcc
+    from tests import synth
+    fe = rasr_amd.MfccExtractor(ctx, nr_cepstrum_coefficients=16)
+    lens = [16000, 5000, 23000]
+    pcm = np.concatenate([synth.waveform(n, seed=30 + i) for i, n in enumerate(lens)])
+    plan = fe.plan(np.concatenate([[0], np.cumsum(lens)]))
+    F = plan.total_frames
+    ctx.use_torch_stream()
+    ceps = torch.empty((F, 16), dtype=torch.float32, device="cuda")
+    fe.run_plan(plan, torch.from_numpy(pcm).cuda(), ceps)
+    feat = torch.zeros((F, 33), dtype=torch.float32, device="cuda")       # [16 normalised | 16 delta | 1 deltadelta of c0]
+    ctx.normalize(plan, ceps, 16, 16, feat, 33)
+    ctx.regression(plan, feat, 33, 16, feat[:, 16:], 33, order=1, right=2)
+    ctx.regression(plan, feat, 33, 1, feat[:, 32:], 33, order=2, right=2)
+    win = torch.empty((F, 99), dtype=torch.float32, device="cuda")
+    ctx.context_window(plan, feat, 33, 1, 1, win, 99)
+    M = np.random.Generator(np.random.PCG64(40)).standard_normal((24, 99)).astype(np.float32)
+    out = torch.empty((F, 24), dtype=torch.float32, device="cuda")
+    ctx.matrix_multiply(torch.from_numpy(M).cuda(), 24, 99, win, 99, F, out, 24)
+    torch.cuda.synchronize()
+    got, c = out.cpu().numpy(), ceps.cpu().numpy()
+    fo = plan.frame_offsets
+    for i in range(len(lens)):
+        s = c[fo[i]:fo[i + 1]]
+        nrm = oracle_normalize(s)
+        f = np.concatenate([nrm, oracle_regression(nrm, 1, 2), oracle_regression(nrm[:, :1], 2, 2)], axis=1)
+        n = len(f)
+        w = np.concatenate([f[np.clip(np.arange(n) + k, 0, n - 1)] for k in (-1, 0, 1)], axis=1)
+        assert np.array_equal(got[fo[i]:fo[i + 1]].view(np.uint32), oracle_matrix_multiply(M, w).view(np.uint32)), i
