@@ -7,7 +7,7 @@
 //   signal-delay + signal-regression   Signal/Delay.hh:33-47 (copy margin, present-not-empty), Signal/Regression.cc:25-68
 //   signal-matrix-multiplication-f32   Signal/MatrixMult.hh:246-255 -> Math/Matrix.hh:487-494, Math/Vector.hh:95-101
 // All three follow the reference's operation order (f64 running sums updated add-then-remove, f32 taps accumulated in
-// window order, f32 dot products left to right), so they are compared bit for bit with oracle/orc_backend.c.
+// window order, f32 dot products left to right), so the tests can compare them bit for bit with a CPU restatement.
 #include "common.hpp"
 
 #include <algorithm>
