@@ -204,6 +204,13 @@ long amx_gmm_accumulator_size(const amx_gmm* h);
 int  amx_gmm_accumulate_dev(amx_gmm* h, const float* feats_dev, int T, const uint32_t* mixture_dev,
                             const uint32_t* best_density_dev, int best_density_ld, double* acc_dev);
 
+/* The same statistics as a binary "MIXSET" accumulator file, version 2 (Mm::MixtureSetEstimator::write / read,
+ * src/Mm/AbstractMixtureSetEstimator.cc:404-508, src/Mm/VectorAccumulator.hh:80-100, src/Mm/MixtureEstimator.cc:140-170):
+ * what RASR's accumulate / combine-mixture-set-estimators / estimate actions exchange.  acc_host is the flat buffer of
+ * amx_gmm_accumulator_size() doubles (host memory); read requires the file's topology to equal the model's. */
+int amx_gmm_accumulator_write(const amx_gmm* h, const double* acc_host, const char* path);
+int amx_gmm_accumulator_read(const amx_gmm* h, const char* path, double* acc_host);
+
 /* ------------------------------------------------------------------ mixture-set text files (.pms) */
 
 /* Reader / writer of RASR's text mixture-set format, "#Version: 2.0" (Mm/MixtureSet.cc:141-216,

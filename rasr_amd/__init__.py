@@ -208,13 +208,14 @@ class GmmFeatureScorer:
     """
 
     def __init__(self, ctx, model, feature_scorer_type="diagonal-maximum", mixture_weight_scale=1.0, gaussian_scale=1.0):
-        self.ctx, self.L = ctx, ctx.L
+        # ctx = None: host-only handle (prepared tables, accumulator files); scoring then fails with AMX_ERR_STATE
+        self.ctx, self.L = ctx, (ctx.L if ctx is not None else _lib.lib())
         self.mode = {"diagonal-maximum": AMX_GMM_MAX, "diagonal-sum": AMX_GMM_SUM,
                      "batch-diagonal-maximum-float": AMX_GMM_BATCH_FLOAT}[feature_scorer_type]
         keep = []
         st = _gmm_struct(model, mixture_weight_scale, gaussian_scale, keep)
         h = C.c_void_p()
-        _lib.check(self.L.amx_gmm_create(ctx.h, C.byref(st), C.byref(h)))
+        _lib.check(self.L.amx_gmm_create(ctx.h if ctx is not None else None, C.byref(st), C.byref(h)))
         self.h = h
         self.n_mix, self.dim = st.n_mix, st.dim
         self._nk, self._ncov = int(keep[0]["mix_offsets"][-1]), st.n_cov
@@ -257,6 +258,18 @@ class GmmFeatureScorer:
 
     def accumulator_size(self):
         return int(self.L.amx_gmm_accumulator_size(self.h))
+
+    def write_accumulator(self, acc, path):
+        """flat f64 accumulator (numpy, host) -> binary MIXSET estimator file (Mm::MixtureSetEstimator::write)"""
+        a = np.ascontiguousarray(acc, dtype=np.float64)
+        if a.size != self.accumulator_size():
+            raise ValueError("accumulator has %d entries, expected %d" % (a.size, self.accumulator_size()))
+        _lib.check(self.L.amx_gmm_accumulator_write(self.h, a.ctypes.data, os.fsencode(path)))
+
+    def read_accumulator(self, path):
+        a = np.zeros(self.accumulator_size(), np.float64)
+        _lib.check(self.L.amx_gmm_accumulator_read(self.h, os.fsencode(path), a.ctypes.data))
+        return a
 
     def accumulate_dev(self, feats_dev, T, mixture_dev, best_density_dev, best_density_ld, acc_dev):
         """Viterbi statistics (weights, sum x, sum x^2 in f64) into the flat accumulator acc_dev"""

@@ -89,6 +89,8 @@ SIGNATURES = {
     "amx_gmm_score_stats_dev": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P, _P]),
     "amx_gmm_accumulator_size": (C.c_long, [_P]),
     "amx_gmm_accumulate_dev": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, _P]),
+    "amx_gmm_accumulator_write": (C.c_int, [_P, _P, C.c_char_p]),
+    "amx_gmm_accumulator_read": (C.c_int, [_P, C.c_char_p, _P]),
     "amx_pms_read": (C.c_int, [C.c_char_p, C.POINTER(_P)]),
     "amx_pms_write": (C.c_int, [C.POINTER(GmmModel), C.c_char_p]),
     "amx_mixture_set_view": (C.c_int, [_P, C.POINTER(GmmModel)]),

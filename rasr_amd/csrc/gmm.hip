@@ -1168,7 +1168,7 @@ struct amx_gmm {
     size_t   nk = 0;
     // host copies of the prepared tables (amx_gmm_tables)
     std::vector<float>    m2lw, isr, lognorm;
-    std::vector<uint32_t> mix_off;
+    std::vector<uint32_t> mix_off, h_k_dens, h_d_mean, h_d_cov;  // topology (accumulator files)
     // device
     uint32_t *d_mix_off = nullptr, *d_k_mean = nullptr, *d_k_cov = nullptr, *d_k_dens = nullptr;
     uint32_t *d_d_mean = nullptr, *d_d_cov = nullptr;
@@ -1435,6 +1435,9 @@ int amx_gmm_create(amx_ctx* ctx, const amx_gmm_model* m, amx_gmm** out) {
     h->n_cov   = m->n_cov;
     h->nk      = nk;
     h->mix_off.assign(m->mix_offsets, m->mix_offsets + m->n_mix + 1);
+    h->h_k_dens.assign(m->dens_index, m->dens_index + nk);
+    h->h_d_mean.assign(m->dens_mean, m->dens_mean + m->n_dens);
+    h->h_d_cov.assign(m->dens_cov, m->dens_cov + m->n_dens);
 
     // ---- model preparation (Mm/MixtureFeatureScorerElement.cc:21-33,
     //      Mm/CovarianceFeatureScorerElement.cc:21-51, Mm/Utilities.hh:53-91)
@@ -1869,6 +1872,114 @@ int amx_gmm_score_stats_dev(amx_gmm* h, const float* feats_dev, int T, float* sc
 
 long amx_gmm_accumulator_size(const amx_gmm* h) {
     return h ? (long)h->nk + (long)h->n_mean * (1 + h->dim) + (long)h->n_cov * (1 + h->dim) : 0;
+}
+
+// ---- "MIXSET" accumulator files (Mm::MixtureSetEstimator::write / read, binary, version 2):
+//   char[8] "MIXSET\0\0" | u32 version | u32 dimension
+//   u32 nMeans       { u32 dim, f64 sum[dim], f64 weight }          Mm/VectorAccumulator.hh:80-100
+//   u32 nCovariances { u32 dim, f64 sumOfSquares[dim], f64 weight }
+//   u32 nDensities   { u32 meanIndex, u32 covarianceIndex }          Mm/GaussDensityEstimator.cc:46-62
+//   u32 nMixtures    { u32 n, { u32 densityIndex, f64 weight } x n } Mm/MixtureEstimator.cc:140-170
+// (Mm/AbstractMixtureSetEstimator.cc:404-508; little endian like every Core::BinaryStream file).  The flat accumulator keeps
+// the model's own index order, which is what the reference's index maps produce for an estimator built from that model.
+extern "C++" {
+namespace {
+struct AccLayout {
+    long long off_mw, off_ms, off_cw, off_cs;
+};
+AccLayout acc_layout(const amx_gmm* h) {
+    AccLayout l;
+    l.off_mw = (long long)h->nk;
+    l.off_ms = l.off_mw + h->n_mean;
+    l.off_cw = l.off_ms + (long long)h->n_mean * h->dim;
+    l.off_cs = l.off_cw + h->n_cov;
+    return l;
+}
+template<class T>
+bool put(FILE* f, T v) {
+    return fwrite(&v, sizeof(T), 1, f) == 1;  // little-endian host
+}
+template<class T>
+bool get(FILE* f, T* v) {
+    return fread(v, sizeof(T), 1, f) == 1;
+}
+}  // namespace
+}  // extern "C++"
+
+int amx_gmm_accumulator_write(const amx_gmm* h, const double* acc, const char* path) {
+    AMX_REQUIRE(h && acc && path, AMX_ERR_INVALID, "amx_gmm_accumulator_write: NULL argument");
+    FILE* f = fopen(path, "wb");
+    AMX_REQUIRE(f, AMX_ERR_INVALID, "amx_gmm_accumulator_write: cannot open '%s'", path);
+    const AccLayout l = acc_layout(h);
+    const char      magic[8] = {'M', 'I', 'X', 'S', 'E', 'T', 0, 0};
+    bool            ok = fwrite(magic, 1, 8, f) == 8 && put(f, (uint32_t)2) && put(f, (uint32_t)h->dim);
+    ok                 = ok && put(f, (uint32_t)h->n_mean);
+    for (int i = 0; ok && i < h->n_mean; ++i)
+        ok = put(f, (uint32_t)h->dim) && fwrite(acc + l.off_ms + (long long)i * h->dim, 8, (size_t)h->dim, f) == (size_t)h->dim &&
+             put(f, acc[l.off_mw + i]);
+    ok = ok && put(f, (uint32_t)h->n_cov);
+    for (int i = 0; ok && i < h->n_cov; ++i)
+        ok = put(f, (uint32_t)h->dim) && fwrite(acc + l.off_cs + (long long)i * h->dim, 8, (size_t)h->dim, f) == (size_t)h->dim &&
+             put(f, acc[l.off_cw + i]);
+    ok = ok && put(f, (uint32_t)h->n_dens);
+    for (int d = 0; ok && d < h->n_dens; ++d)
+        ok = put(f, h->h_d_mean[d]) && put(f, h->h_d_cov[d]);
+    ok = ok && put(f, (uint32_t)h->n_mix);
+    for (int m = 0; ok && m < h->n_mix; ++m) {
+        ok = put(f, (uint32_t)(h->mix_off[m + 1] - h->mix_off[m]));
+        for (uint32_t k = h->mix_off[m]; ok && k < h->mix_off[m + 1]; ++k)
+            ok = put(f, h->h_k_dens[k]) && put(f, acc[k]);
+    }
+    ok = (fclose(f) == 0) && ok;
+    AMX_REQUIRE(ok, AMX_ERR_INVALID, "amx_gmm_accumulator_write: write to '%s' failed", path);
+    return AMX_OK;
+}
+
+int amx_gmm_accumulator_read(const amx_gmm* h, const char* path, double* acc) {
+    AMX_REQUIRE(h && acc && path, AMX_ERR_INVALID, "amx_gmm_accumulator_read: NULL argument");
+    FILE* f = fopen(path, "rb");
+    AMX_REQUIRE(f, AMX_ERR_INVALID, "amx_gmm_accumulator_read: cannot open '%s'", path);
+    const AccLayout l = acc_layout(h);
+    char            magic[8] = {0};
+    uint32_t        version = 0, dim = 0, n = 0;
+    const char*     why = nullptr;
+    bool            ok = fread(magic, 1, 8, f) == 8 && get(f, &version) && get(f, &dim);
+    if (ok && strncmp(magic, "MIXSET", 7) != 0)
+        why = "not a MIXSET estimator file";  // the reference: 'Mixture set estimator file with magic "..." could not be read'
+    else if (ok && version == 0)
+        why = "version 0 files (integer counts) are not supported";
+    else if (ok && (int)dim != h->dim)
+        why = "dimension differs from the model";
+    auto vec = [&](double* sums, double* weight) {
+        uint32_t size = 0;
+        return get(f, &size) && (int)size == h->dim && fread(sums, 8, (size_t)h->dim, f) == (size_t)h->dim && get(f, weight);
+    };
+    ok = ok && !why && get(f, &n) && (int)n == h->n_mean;
+    for (int i = 0; ok && i < h->n_mean; ++i)
+        ok = vec(acc + l.off_ms + (long long)i * h->dim, acc + l.off_mw + i);
+    ok = ok && get(f, &n) && (int)n == h->n_cov;
+    for (int i = 0; ok && i < h->n_cov; ++i)
+        ok = vec(acc + l.off_cs + (long long)i * h->dim, acc + l.off_cw + i);
+    ok = ok && get(f, &n) && (int)n == h->n_dens;
+    for (int d = 0; ok && d < h->n_dens; ++d) {
+        uint32_t mi = 0, ci = 0;
+        ok          = get(f, &mi) && get(f, &ci) && mi == h->h_d_mean[d] && ci == h->h_d_cov[d];
+    }
+    ok = ok && get(f, &n) && (int)n == h->n_mix;
+    for (int m = 0; ok && m < h->n_mix; ++m) {
+        ok = get(f, &n) && n == h->mix_off[m + 1] - h->mix_off[m];
+        for (uint32_t k = h->mix_off[m]; ok && k < h->mix_off[m + 1]; ++k) {
+            uint32_t d = 0;
+            ok         = get(f, &d) && d == h->h_k_dens[k] && get(f, &acc[k]);
+        }
+    }
+    fclose(f);
+    if (why) {
+        amx::set_error("amx_gmm_accumulator_read: '%s': %s", path, why);
+        return AMX_ERR_INVALID;
+    }
+    AMX_REQUIRE(ok, AMX_ERR_INVALID, "amx_gmm_accumulator_read: '%s' is truncated or its topology differs from the model", path);
+    return AMX_OK;
 }
 
 int amx_gmm_accumulate_dev(amx_gmm* h, const float* feats_dev, int T, const uint32_t* mixture_dev, const uint32_t* best_density_dev,

@@ -258,3 +258,37 @@ def test_large_segment_round_trip(tmp_path):
         for k in ("big", "raw"):
             rx, rt = a.read_features(k)
             assert rx.tobytes() == x.tobytes() and rt.tobytes() == t.tobytes()
+
+
+# ---------------------------------------------------------------- mixture-set estimator ("accumulator") files
+def test_accumulator_file_round_trip_and_layout(tmp_path):
+    """amx_gmm_accumulator_write / _read (host-only handle: no GPU needed) against oracle/acc_format.py"""
+    from oracle import acc_format as af
+    from tests import synth
+    model = synth.gmm_cart(9, 1, 5, 6, seed=3, pooled=False)
+    sc = rasr_amd.GmmFeatureScorer(None, model)
+    n = sc.accumulator_size()
+    rng = np.random.default_rng(7)
+    acc = rng.standard_normal(n) * 100
+    nk = int(model["mix_offsets"][-1])
+    acc[:nk] = rng.integers(0, 50, nk)
+    p = str(tmp_path / "acc.1")
+    sc.write_accumulator(acc, p)
+    raw = open(p, "rb").read()
+    assert raw == af.write(model, acc)
+    parsed = af.read(raw)
+    assert parsed["version"] == 2 and parsed["dim"] == 6 and len(parsed["means"]) == model["means"].shape[0]
+    assert [d for d, _ in parsed["mixtures"][2]] == list(model["dens_index"][model["mix_offsets"][2]:model["mix_offsets"][3]])
+    back = sc.read_accumulator(p)
+    assert back.tobytes() == acc.tobytes()
+    # a file from another topology / a truncated file / a foreign file are refused
+    other = rasr_amd.GmmFeatureScorer(None, synth.gmm_cart(9, 1, 5, 6, seed=4, pooled=False))
+    with pytest.raises(rasr_amd.AmxError):
+        other.read_accumulator(p)
+    open(p, "wb").write(raw[:-5])
+    with pytest.raises(rasr_amd.AmxError):
+        sc.read_accumulator(p)
+    open(p, "wb").write(b"SP_ARC1\x00" + raw[8:])
+    with pytest.raises(rasr_amd.AmxError) as e:
+        sc.read_accumulator(p)
+    assert "MIXSET" in str(e.value)
