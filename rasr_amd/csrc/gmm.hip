@@ -960,6 +960,10 @@ __global__ __launch_bounds__(512) void gmm_screen_persist_kernel(const _Float16*
     }
 }
 
+__host__ __device__ constexpr int gmm_exact_ld(int dim, bool pooled) {
+    return (pooled || dim < 64) ? 4 * (((dim + 3) / 4) | 1) : ((dim + 3) & ~3);
+}
+
 // exact evaluation of the surviving slots: thread = frame (features in registers), workgroup = 16 mixtures x 256 frames,
 // the 256 slot means (and 1/sigma rows when not pooled) of the tile in LDS, rows padded to DIM + 1 floats
 template<int DIM, bool POOLED>
@@ -970,7 +974,10 @@ __global__ __launch_bounds__(256) void gmm_screen_exact_kernel(const float* __re
                                                               float* __restrict__ g_scores, uint32_t* __restrict__ g_best, int T, int n_mix,
                                                               int Mpad16, float* __restrict__ g_part_min, unsigned* __restrict__ g_part_idx,
                                                               int part_ld) {
-    constexpr int LD = (DIM + 2) & ~1;  // even (8-byte aligned rows for the packed distance); 42 for DIM = 40 spreads the banks
+    // rows are 16-byte aligned for ds_read_b128 (the survivor walk was co-limited by LDS issue with 8-byte reads) and an ODD
+    // number of 16-byte slots long, so that consecutive rows start in different slots: 44 floats for DIM = 40
+    // (per-density covariances at DIM = 64 only fit unpadded)
+    constexpr int LD = gmm_exact_ld(DIM, POOLED);
     extern __shared__ __attribute__((aligned(16))) char lds[];
     float* s_mu = (float*)lds;                    // [256][LD]
     float* s_is = s_mu + 256 * LD;                // [256][LD] (per-density covariance only)
@@ -1044,13 +1051,16 @@ __global__ __launch_bounds__(256) void gmm_screen_exact_kernel(const float* __re
     auto  fetch = [&](float (&dst)[DIM], int row) {
         const float* src = s_mu + (row < 0 ? 0 : row) * LD;
 #pragma unroll
-        for (int i = 0; i + 1 < DIM; i += 2) {
-            const gmm_pk2 v = *(const gmm_pk2*)(src + i);
-            dst[i]          = v.x;
-            dst[i + 1]      = v.y;
+        for (int i = 0; i + 3 < DIM; i += 4) {
+            const float4 v = *(const float4*)(src + i);
+            dst[i]         = v.x;
+            dst[i + 1]     = v.y;
+            dst[i + 2]     = v.z;
+            dst[i + 3]     = v.w;
         }
-        if (DIM & 1)
-            dst[DIM - 1] = src[DIM - 1];
+#pragma unroll
+        for (int i = DIM & ~3; i < DIM; ++i)
+            dst[i] = src[i];
     };
     MaxState st;
     auto     eval = [&](const float (&mu)[DIM], int row, int next_row) {
@@ -1302,7 +1312,7 @@ int score_screened(amx_gmm* h, const float* feats_dev, int T, float* scores_dev,
             uint32_t* bd = best_dev ? best_dev + (size_t)t0 * h->n_mix : nullptr;
 #define AMX_EXACT(D)                                                                                                                \
     case D: {                                                                                                                       \
-        const size_t lds = (size_t)256 * ((D + 2) & ~1) * 4 * (h->pooled ? 1 : 2) + 2048 + 2112 + 256 * 17 * 4 + 256 * 20; \
+        const size_t lds = (size_t)256 * amx::gmm_exact_ld(D, h->pooled) * 4 * (h->pooled ? 1 : 2) + 2048 + 2112 + 256 * 17 * 4 + 256 * 20; \
         if (h->pooled) {                                                                                                            \
             auto k = amx::gmm_screen_exact_kernel<D, true>;                                                                         \
             hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
