@@ -982,7 +982,7 @@ __global__ __launch_bounds__(256) void gmm_screen_exact_kernel(const float* __re
     float* s_mu = (float*)lds;                    // [256][LD]
     float* s_is = s_mu + 256 * LD;                // [256][LD] (per-density covariance only)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    constexpr int FG = 4;
+    constexpr int FG = 8;
     const int m0 = blockIdx.x * 16;
     // slot -> mean / covariance row (one slot per thread), then a cooperative copy: 256 rows x DIM floats, consecutive
     // threads on consecutive floats of a row
@@ -1307,7 +1307,7 @@ int score_screened(amx_gmm* h, const float* feats_dev, int T, float* scores_dev,
         }
         {
             amx::ScopedKernelTimer timer(h->ctx, "gmm");
-            dim3      grid(h->scr_Mpad16 / 16, (Tpad / 256 + 3) / 4);  // FG = 4 frame groups per workgroup
+            dim3      grid(h->scr_Mpad16 / 16, (Tpad / 256 + 7) / 8);  // FG = 8 frame groups per workgroup
             float*    sc = scores_dev + (size_t)t0 * h->n_mix;
             uint32_t* bd = best_dev ? best_dev + (size_t)t0 * h->n_mix : nullptr;
 #define AMX_EXACT(D)                                                                                                                \
