@@ -110,14 +110,17 @@ def gmm_cart_roofline(ctx, nk, frames):
                      "flops (densities x 122 flop per frame) / (pack + screen + exact time); the f16 MFMA screen leaves ~1.04 of 16 "
                      "densities per state for the exact f32 evaluation, so the flops actually executed are ~9 % of the algorithmic count",
                 achieved=round(alg / t / 1e12, 2), peak=FP32_TFLOPS, unit="TFLOP/s", frac=round(alg / t / 1e12 / FP32_TFLOPS, 4),
-                traffic=measured_traffic("gmm_screen_exact_kernel") if frames == 8192 else None,
-                avg_launch_ms=round(ms_x, 4), screen_launch_ms=round(ms_s, 4), pack_launch_ms=round(ms_p, 4), launches=n_x, flops_per_launch=alg)
+                traffic=measured_traffic("gmm_screen_exact_kernel<40,pooled> (10000 x 16 densities, %d frames)" % frames),
+                avg_launch_ms=round(ms_x, 4), screen_launch_ms=round(ms_s, 4), pack_launch_ms=round(ms_p, 4), launches=n_x, flops_per_launch=alg,
+                # what the exact stage really executes: ~1.04 survivors per state x (4 dim + 10) f32 operations, unfused by definition
+                executed_tflops=round(1.04 * (nk / 16.0) * 170.0 * frames / (ms_x * 1e-3) / 1e12, 2),
+                executed_frac=round(1.04 * (nk / 16.0) * 170.0 * frames / (ms_x * 1e-3) / 1e12 / FP32_TFLOPS, 4))
 
 
 class NnPipeline:
     """MFCC-40 -> context 11 -> FFNN 440-6x2048-10000 -> accumulators, everything resident in HBM."""
 
-    CHUNK = 32768  # frames per scoring pass (bounds the [frames x 10000] f32 score buffer to 1.3 GB)
+    CHUNK = int(os.environ.get("AMX_BENCH_CHUNK", "32768"))  # frames per scoring pass (bounds the [frames x 10000] f32 score buffer to 1.3 GB)
 
     def __init__(self, ctx, args, rank):
         import torch
@@ -191,7 +194,7 @@ class Pipeline(NnPipeline):
                       +-> 11-frame context -> FFNN 440-6x2048-10000 (bf16 MFMA)   -> best state -> per-state counts
     The two legs only share the MFCC output (AMX_BENCH_TWO_STREAMS=1 runs them on two HIP streams)."""
 
-    GCHUNK = 8192  # frames per GMM pass: [frames x 10000] f32 scores + u32 best densities = 655 MB
+    GCHUNK = int(os.environ.get("AMX_BENCH_GCHUNK", "65536"))  # frames per GMM pass (>= a step: one pass; scores + best densities = 5.1 GB)
 
     def __init__(self, ctx, args, rank):
         super().__init__(ctx, args, rank)
@@ -275,7 +278,7 @@ class Pipeline(NnPipeline):
 class GmmTrain:
     """config 5, GMM leg: audio -> MFCC-40 -> CART GMM (10 000 states x 16 densities) -> best state / density -> accumulators"""
 
-    CHUNK = 8192
+    CHUNK = int(os.environ.get("AMX_BENCH_GCHUNK", "65536"))
 
     def __init__(self, ctx, args, rank):
         import torch
@@ -293,9 +296,10 @@ class GmmTrain:
         self.nk = int(model["mix_offsets"][-1])
         self.sc = rasr_amd.GmmFeatureScorer(ctx, model)
         self.M = 10000
-        self.scores = torch.empty((self.CHUNK, self.M), dtype=torch.float32, device="cuda")
-        self.bestd = torch.empty((self.CHUNK, self.M), dtype=torch.int32, device="cuda")
-        self.state = torch.empty((self.CHUNK,), dtype=torch.int32, device="cuda")
+        g = min(self.CHUNK, self.F)
+        self.scores = torch.empty((g, self.M), dtype=torch.float32, device="cuda")
+        self.bestd = torch.empty((g, self.M), dtype=torch.int32, device="cuda")
+        self.state = torch.empty((g,), dtype=torch.int32, device="cuda")
         self.counts = torch.zeros((self.M,), dtype=torch.int64, device="cuda")
         self.score_sum = torch.zeros((1,), dtype=torch.float64, device="cuda")
         self.acc = torch.zeros((self.sc.accumulator_size(),), dtype=torch.float64, device="cuda")

@@ -1364,7 +1364,7 @@ static int ffnn_score_impl(amx_ffnn* h, const float* feats_dev, int feats_stride
     AMX_REQUIRE(feats_dev && scores_dev, AMX_ERR_INVALID, "amx_ffnn_score_dev: NULL buffer");
     AMX_REQUIRE(feats_stride >= h->in[0], AMX_ERR_INVALID, "amx_ffnn_score_dev: feature stride %d < input dimension %d", feats_stride, h->in[0]);
     AMX_HIP(hipSetDevice(h->ctx->device));
-    const int chunk = 32768;  // frames per pass (workspace: 2 x 32768 x max_hidden x 2 B)
+    static const int chunk = getenv("AMX_FFNN_CHUNK") ? atoi(getenv("AMX_FFNN_CHUNK")) : 32768;  // frames per pass (workspace: 2 x chunk x max_hidden x 2 B)
     const int L     = h->n_layers;
     for (int t0 = 0; t0 < T; t0 += chunk) {
         const int Tc   = std::min(chunk, T - t0);

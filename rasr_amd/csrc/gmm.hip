@@ -1236,7 +1236,7 @@ extern "C" int amx_internal_best_state_reduce(amx_ctx*, const float*, const unsi
 int score_screened(amx_gmm* h, const float* feats_dev, int T, float* scores_dev, uint32_t* best_dev, bool stats, uint32_t* best_state_dev,
                    unsigned long long* counts_dev, double* score_sum_dev) {
     hipStream_t st = h->ctx->stream;
-    const int   chunk = 16384;
+    const int   chunk = getenv("AMX_GMM_CHUNK") ? atoi(getenv("AMX_GMM_CHUNK")) : 65536;  // frames per pass: the workspace (survivor masks, 2 B per frame and mixture slot) grows to what a call needs
     for (int t0 = 0; t0 < T; t0 += chunk) {
         const int Tc = std::min(chunk, T - t0), Tpad = (Tc + 255) / 256 * 256;
         if (Tpad > h->scr_cap_T) {
