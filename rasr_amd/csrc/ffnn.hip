@@ -688,21 +688,22 @@ __global__ __launch_bounds__(C::THREADS) void gemm_bf16_pipe_kernel(const bf16_t
             else
                 wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
-            const int nslot = (g + 1) & 1;
+            const int  nslot = (g + 1) & 1;
+            const bool more  = kt + 1 < KT || has_next;
             if (kt + 1 < KT) {
                 pw += C::BKC;
                 px += C::BKC;
-                issue(nslot, pw, px);
             }
             else if (has_next) {  // the stream continues with the next tile
                 coords(nvi, tile_t, tile_n);
                 pw = W + (size_t)tile_n * C::BN * Kpad + offW;
                 px = X + (size_t)tile_t * C::BT * ldx + offX;
-                issue(nslot, pw, px);
-                issue_bias(bias_buf ^ 1, tile_n);
             }
+            if (kt + 1 >= KT && has_next)
+                issue_bias(bias_buf ^ 1, tile_n);
             const char* wbase = lds + (g & 1) * C::STAGE_BYTES;
             const char* xbase = wbase + C::A_BYTES;
+            static_assert(C::A_LOADS == C::BKC / 16 && C::B_LOADS == C::BKC / 16, "one W and one X piece per k-slab");
 #pragma unroll
             for (int ks = 0; ks < C::BKC / 16; ++ks) {
                 bf16x8 a[C::MI], b[C::MJ];
@@ -712,6 +713,13 @@ __global__ __launch_bounds__(C::THREADS) void gemm_bf16_pipe_kernel(const bf16_t
 #pragma unroll
                 for (int j = 0; j < C::MJ; ++j)
                     b[j] = *(const bf16x8*)(xbase + C::swz(wt * (C::BT / C::WT) + j * 32 + frow, ks * 2 + fk));
+                if (more) {  // the 8 LDS-DMA pieces of the next K-tile are spread over the 4 k-slabs (issued in one burst behind
+                             // the barrier they kept both waves of a SIMD off the matrix pipe at the same time: +2 %)
+                    char* base = lds + nslot * C::STAGE_BYTES + wave * 1024;
+                    __builtin_amdgcn_global_load_lds((const void*)(pw + ks * stepW), (__attribute__((address_space(3))) void*)(base + ks * C::NW * 1024), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((const void*)(px + ks * stepX),
+                                                     (__attribute__((address_space(3))) void*)(base + C::A_BYTES + ks * C::NW * 1024), 16, 0, 0);
+                }
 #pragma unroll
                 for (int i = 0; i < C::MI; ++i)
 #pragma unroll
