@@ -730,17 +730,20 @@ struct GmmScreenDims {
     float rmax2, sqrtK;
 };
 
-// features -> f16 operand rows [Tpad x Kp] (zero padded), nx[t] = ||row|| (inf when the row does not fit f16), q[t]
+// features -> f16 operand rows [Tpad x Kp] (zero padded), nx[t] = ||row|| (inf when the row does not fit f16), q[t].
+// One wavefront per frame, lane = operand column (coalesced 128-byte rows; a thread-per-frame loop took 23 us at batch 256).
 __global__ __launch_bounds__(256) void gmm_screen_pack_kernel(const float* __restrict__ g_feats, const float* __restrict__ g_isr0,
                                                              _Float16* __restrict__ g_X, float* __restrict__ g_nx,
                                                              float* __restrict__ g_q, GmmScreenDims d) {
-    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int t    = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= d.Tpad)
         return;
     _Float16* row = g_X + (size_t)t * d.Kp;
+    const int kd  = d.pooled ? d.dim : 2 * d.dim;  // columns kd, kd + 1 multiply the split constant c_hi, c_lo
     float     n2 = 0.f, q = 0.f;
     bool      fits = true;
-    for (int i = 0; i < d.Kp; ++i) {
+    for (int i = lane; i < d.Kp; i += 64) {
         float v = 0.f;
         if (t < d.T) {
             if (d.pooled) {
@@ -756,17 +759,22 @@ __global__ __launch_bounds__(256) void gmm_screen_pack_kernel(const float* __res
         }
         fits &= fabsf(v) <= 65504.f;  // false for NaN as well
         const _Float16 hv = (_Float16)v;
-        row[i]            = hv;
-        const float r     = (float)hv;
+        const float    r  = (float)hv;
         n2 += r * r;
         if (d.pooled || i < d.dim)
             q += v * v;
+        row[i] = (i == kd || i == kd + 1) ? (_Float16)(t < d.T ? 1.f : 0.f) : hv;
     }
-    const int kd = d.pooled ? d.dim : 2 * d.dim;  // columns kd, kd + 1 multiply the split constant c_hi, c_lo
-    row[kd]      = (_Float16)(t < d.T ? 1.f : 0.f);
-    row[kd + 1]  = (_Float16)(t < d.T ? 1.f : 0.f);
-    g_nx[t]      = fits ? sqrtf(n2) : __builtin_inff();
-    g_q[t]       = 1.6e-5f * (d.pooled ? q : q * d.rmax2);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        n2 += __shfl_xor(n2, off, 64);
+        q += __shfl_xor(q, off, 64);
+    }
+    const bool all_fit = __ballot(!fits) == 0ull;
+    if (lane == 0) {
+        g_nx[t] = all_fit ? sqrtf(n2) : __builtin_inff();
+        g_q[t]  = 1.6e-5f * (d.pooled ? q : q * d.rmax2);
+    }
 }
 
 // epilogue of the screen: lane (tl32, hh) holds, for frame tl32 of pass j, slots i*32 + 8g + 4hh + e of the wave's 128: mixture
@@ -973,7 +981,7 @@ __global__ __launch_bounds__(256) void gmm_screen_exact_kernel(const float* __re
                                                               const float* __restrict__ g_means, const float* __restrict__ g_isr,
                                                               float* __restrict__ g_scores, uint32_t* __restrict__ g_best, int T, int n_mix,
                                                               int Mpad16, float* __restrict__ g_part_min, unsigned* __restrict__ g_part_idx,
-                                                              int part_ld) {
+                                                              int part_ld, int FG) {
     // rows are 16-byte aligned for ds_read_b128 (the survivor walk was co-limited by LDS issue with 8-byte reads) and an ODD
     // number of 16-byte slots long, so that consecutive rows start in different slots: 44 floats for DIM = 40
     // (per-density covariances at DIM = 64 only fit unpadded)
@@ -982,7 +990,6 @@ __global__ __launch_bounds__(256) void gmm_screen_exact_kernel(const float* __re
     float* s_mu = (float*)lds;                    // [256][LD]
     float* s_is = s_mu + 256 * LD;                // [256][LD] (per-density covariance only)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    constexpr int FG = 8;
     const int m0 = blockIdx.x * 16;
     // slot -> mean / covariance row (one slot per thread), then a cooperative copy: 256 rows x DIM floats, consecutive
     // threads on consecutive floats of a row
@@ -1261,7 +1268,7 @@ int score_screened(amx_gmm* h, const float* feats_dev, int T, float* scores_dev,
                              std::sqrt((float)(h->pooled ? h->dim : 2 * h->dim))};
         {
             amx::ScopedKernelTimer timer(h->ctx, "gmm_screen_pack");
-            hipLaunchKernelGGL(amx::gmm_screen_pack_kernel, dim3(Tpad / 256), dim3(256), 0, st, x, h->d_isr, h->d_scr_X, h->d_scr_nx, h->d_scr_q, d);
+            hipLaunchKernelGGL(amx::gmm_screen_pack_kernel, dim3(Tpad / 4), dim3(256), 0, st, x, h->d_isr, h->d_scr_X, h->d_scr_nx, h->d_scr_q, d);
         }
         {
             amx::ScopedKernelTimer timer(h->ctx, "gmm_screen");
@@ -1307,7 +1314,10 @@ int score_screened(amx_gmm* h, const float* feats_dev, int T, float* scores_dev,
         }
         {
             amx::ScopedKernelTimer timer(h->ctx, "gmm");
-            dim3      grid(h->scr_Mpad16 / 16, (Tpad / 256 + 7) / 8);  // FG = 8 frame groups per workgroup
+            // FG frame groups of 256 share one slot tile in LDS; enough of them that the tile load is amortised, few enough that
+            // ~2500 workgroups remain (measured: 8 at 8192 frames, 32 at 64 k frames)
+            const int FG = std::max(1, std::min(32, (int)((long)(Tpad / 256) * (h->scr_Mpad16 / 16) / 2500)));
+            dim3      grid(h->scr_Mpad16 / 16, (Tpad / 256 + FG - 1) / FG);
             float*    sc = scores_dev + (size_t)t0 * h->n_mix;
             uint32_t* bd = best_dev ? best_dev + (size_t)t0 * h->n_mix : nullptr;
 #define AMX_EXACT(D)                                                                                                                \
@@ -1317,13 +1327,13 @@ int score_screened(amx_gmm* h, const float* feats_dev, int T, float* scores_dev,
             auto k = amx::gmm_screen_exact_kernel<D, true>;                                                                         \
             hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
             hipLaunchKernelGGL(k, grid, dim3(256), lds, st, x, h->d_scr_masks, h->d_mix_off, h->d_k_mean, h->d_k_cov, h->d_k_c64,   \
-                               h->d_means, h->d_isr, sc, bd, Tc, h->n_mix, h->scr_Mpad16, pmin, pidx, Tpad);                                          \
+                               h->d_means, h->d_isr, sc, bd, Tc, h->n_mix, h->scr_Mpad16, pmin, pidx, Tpad, FG);                                          \
         }                                                                                                                           \
         else {                                                                                                                      \
             auto k = amx::gmm_screen_exact_kernel<D, false>;                                                                        \
             hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
             hipLaunchKernelGGL(k, grid, dim3(256), lds, st, x, h->d_scr_masks, h->d_mix_off, h->d_k_mean, h->d_k_cov, h->d_k_c64,   \
-                               h->d_means, h->d_isr, sc, bd, Tc, h->n_mix, h->scr_Mpad16, pmin, pidx, Tpad);                                          \
+                               h->d_means, h->d_isr, sc, bd, Tc, h->n_mix, h->scr_Mpad16, pmin, pidx, Tpad, FG);                                          \
         }                                                                                                                           \
     } break;
             switch (h->dim) {
