@@ -1020,18 +1020,32 @@ __global__ __launch_bounds__(256) void gmm_screen_exact_kernel(const float* __re
     }
     __syncthreads();
     // the tile serves FG groups of 256 frames
+  // features and masks of the NEXT frame group are requested before this group's walk: they come from L2 / MALL (the
+  // feature rows are re-read per mixture tile) and a round trip is a fifth of a walk
+  float xn[DIM];
+  uint4 man, mbn;
+  auto  prefetch = [&](int fgn) {
+      const int tn  = (blockIdx.y * FG + fgn) * 256 + tid;
+      const int ttn = tn < T ? tn : T - 1;
+#pragma unroll
+      for (int i = 0; i < DIM; ++i)
+          xn[i] = g_feats[(size_t)ttn * DIM + i];
+      const uint4* mrow = (const uint4*)(g_masks + (size_t)ttn * Mpad16 + m0);
+      man = mrow[0];
+      mbn = mrow[1];
+  };
+  prefetch(0);
   for (int fg = 0; fg < FG; ++fg) {
     const int t = (blockIdx.y * FG + fg) * 256 + tid;
     if (t - tid >= T)
         break;
     float x[DIM];
-    const int tt = t < T ? t : T - 1;
 #pragma unroll
     for (int i = 0; i < DIM; ++i)
-        x[i] = g_feats[(size_t)tt * DIM + i];
-    const uint4* mrow = (const uint4*)(g_masks + (size_t)tt * Mpad16 + m0);
-    const uint4  ma = mrow[0], mb = mrow[1];
-    const unsigned mw[8] = {ma.x, ma.y, ma.z, ma.w, mb.x, mb.y, mb.z, mb.w};
+        x[i] = xn[i];
+    const unsigned mw[8] = {man.x, man.y, man.z, man.w, mbn.x, mbn.y, mbn.z, mbn.w};
+    if (fg + 1 < FG && (blockIdx.y * FG + fg + 1) * 256 < T)
+        prefetch(fg + 1);
     // Every lane walks ITS OWN list of (mixture, slot) survivors: one distance per loop trip for every lane that still has
     // work, instead of a trip count of max-over-lanes per mixture (16 x ~2.2 trips become ~1.1 x 16 + spread).  The walk is
     // software-pipelined by one survivor: the mean row of the next survivor is read from LDS while the current one is evaluated.
