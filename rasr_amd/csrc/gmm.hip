@@ -1106,9 +1106,11 @@ __global__ __launch_bounds__(256) void gmm_screen_exact_kernel(const float* __re
         fetch(mua, ra);
         eval(mub, rb, ra);
     }
-    // The [256 frames x 16 mixtures] result tile leaves through LDS: four adjacent lanes write the 64 contiguous bytes of one
-    // frame in ONE instruction.  (Per-lane 4-byte stores at a 40 KB stride cost more than the whole evaluation.)
-    __syncthreads();
+    // The result tile leaves through LDS: four adjacent lanes write the 64 contiguous bytes of one frame in ONE instruction.
+    // (Per-lane 4-byte stores at a 40 KB stride cost more than the whole evaluation.)  Every wave transposes and stores ITS OWN
+    // 64 frames, so the frame groups need no workgroup barrier: LDS operations of a wave execute in order.
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     if (g_part_min) {  // fused statistics: best state of this tile per frame (ascending state, strict '<': first minimum)
         const int tg = (blockIdx.y * FG + fg) * 256 + tid;
         float     bm = 3.402823466e+38f;
@@ -1127,8 +1129,11 @@ __global__ __launch_bounds__(256) void gmm_screen_exact_kernel(const float* __re
     }
     const int  tb   = (blockIdx.y * FG + fg) * 256;
     const bool wide = nm == 16 && (n_mix & 3) == 0 && ((uintptr_t)g_scores & 15) == 0 && (!g_best || ((uintptr_t)g_best & 15) == 0);
-    for (int e = tid; e < 1024; e += 256) {
-        const int fr = e >> 2, c4 = (e & 3) * 4, tg = tb + fr;
+    const int  w0   = (tid >> 6) * 64;  // first frame of this wave inside the group
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+        const int e  = q4 * 64 + (tid & 63);           // 256 (frame, 16-byte chunk) pairs per wave
+        const int fr = w0 + (e >> 2), c4 = (e & 3) * 4, tg = tb + fr;
         if (tg >= T)
             continue;
         const float*         ps = s_sc + fr * 17 + c4;
@@ -1149,7 +1154,8 @@ __global__ __launch_bounds__(256) void gmm_screen_exact_kernel(const float* __re
             }
         }
     }
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
