@@ -777,8 +777,10 @@ __global__ __launch_bounds__(256) void gmm_screen_pack_kernel(const float* __res
     }
 }
 
-// epilogue of the screen: lane (tl32, hh) holds, for frame tl32 of pass j, slots i*32 + 8g + 4hh + e of the wave's 128: mixture
-// 2i + (g >> 1) of its 8, slot (g & 1) * 8 + 4hh + e within it.  The partner lane (lane ^ 32) holds the other 8 slots.
+// epilogue of the screen: lane (tl32, hh) holds, for frame tl32 of pass j, operand rows i*32 + 8g + 4hh + e of the wave's 128:
+// mixture 2i + (g >> 1) of its 8, row (g & 1) * 8 + 4hh + e within it; the partner lane (lane ^ 32) holds the other 8 rows.  The
+// model side stores slot s of a mixture at row ((s >> 2) & 1) * 8 + (s >> 3) * 4 + (s & 3), which makes a lane's 8 values the
+// slots 8hh .. 8hh + 7 in order (the mask byte needs no bit shuffling).
 // The per-density constant already sits in the accumulators (two extra K columns c_hi + c_lo against X = 1), the threshold is
 // three fused operations on per-mixture / per-frame precomputed pieces, and a survivor bit is the sign of thr - g shifted into
 // the mask by v_alignbit: ~30 VALU operations per mixture and frame pair instead of ~60 (this epilogue, not the 32 MFMAs per
@@ -809,13 +811,15 @@ __device__ __forceinline__ void gmm_screen_epilogue(const gmm_f32x16 (&acc)[4][2
                 // tau = 2.2e-3 na nx + 1.3e-4 sqrtK (na + nx) + 1.6e-5 (|mn| + cabs + q): p1 = 2.2e-3 na + 1.3e-4 sqrtK,
                 // p2 = 1.3e-4 sqrtK na + 1.6e-5 cabs per mixture, q pre-scaled per frame
                 const float thr = mn + fmaf(nx, g_p1[m], fmaf(fabsf(mn), 1.6e-5f, g_p2[m] + q)) + 1e-30f;
-                unsigned    bits = 0;  // bit k = "slot value k is above the threshold", filled from the top slot down
+                unsigned    bits = 0;  // bit k = "value k is above the threshold", filled from the top down
 #pragma unroll
-                for (int e = 7; e >= 0; --e)
-                    bits = __builtin_amdgcn_alignbit(bits, __float_as_uint(thr - c[o + e]), 31);  // (bits << 1) | sign(thr - g)
-                // lane's 8 slots: e < 4 -> slot 4hh + e, e >= 4 -> slot 8 + 4hh + (e - 4)
-                unsigned keep = ~bits;
-                unsigned mine = ((keep & 0xfu) << (4 * hh)) | (((keep >> 4) & 0xfu) << (8 + 4 * hh));
+                for (int e = 6; e >= 0; e -= 2) {  // packed subtract, two values per instruction
+                    const gmm_pk2 dd = gmm_pk2{thr, thr} - gmm_pk2{c[o + e], c[o + e + 1]};
+                    bits             = __builtin_amdgcn_alignbit(bits, __float_as_uint(dd.y), 31);  // (bits << 1) | sign(thr - g)
+                    bits             = __builtin_amdgcn_alignbit(bits, __float_as_uint(dd.x), 31);
+                }
+                // the slot rows of a mixture are stored so that this lane's 8 values are slots 8 hh .. 8 hh + 7 in order
+                unsigned mine = (~bits & 0xffu) << (8 * hh);
                 mine |= (unsigned)__shfl_xor((int)mine, 32, 64);
                 two |= (all ? 0xffffu : mine) << (16 * gp);
             }
@@ -1604,7 +1608,8 @@ int amx_gmm_create(amx_ctx* ctx, const amx_gmm_model* m, amx_gmm** out) {
                 rmax2 = std::max(rmax2, (double)h->isr[i] * (double)h->isr[i]);
             for (int i = 0; i < m->n_mix && fits; ++i)
                 for (uint32_t k = m->mix_offsets[i]; k < m->mix_offsets[i + 1]; ++k) {
-                    const size_t row = (size_t)i * 16 + (k - m->mix_offsets[i]);
+                    const uint32_t slot = k - m->mix_offsets[i];  // row inside the mixture's 16: see gmm_screen_epilogue
+                    const size_t   row  = (size_t)i * 16 + (((slot >> 2) & 1) * 8 + (slot >> 3) * 4 + (slot & 3));
                     const float* mu  = m->means + (size_t)k_mean[k] * d;
                     const float* is  = h->isr.data() + (size_t)k_cov[k] * d;
                     double       cc = c64[k], n2 = 0;
