@@ -614,8 +614,11 @@ def main():
             job = NnOnly(ctx, args, rank)
         for _ in range(args.warmup):
             job.step()
+        # config 4 (batch 1024) replays its forward pass as a HIP graph, which the per-launch events of the library's profiler
+        # would switch off: that workload is timed without them and its kernel timings come from a separate profiled pass
+        graph_mode = args.workload == "nn" and os.environ.get("AMX_FFNN_GRAPH", "1") != "0"
         barrier(world)
-        ctx.profile(True)
+        ctx.profile(not graph_mode)
         ctx.profile_reset()
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -623,6 +626,11 @@ def main():
         job.epoch_reduce(world)
         barrier(world)
         dt = time.perf_counter() - t0
+        if graph_mode:
+            ctx.profile(True)
+            for _ in range(min(args.steps, 20)):
+                job.step()
+            torch.cuda.synchronize()
         ctx.profile(False)
     t = torch.tensor([dt], dtype=torch.float64, device="cuda")
     if world > 1:
@@ -651,6 +659,8 @@ def main():
                 "rtf": round(dt / (units * 0.01), 8)}
         line["roofline"] = job.roofline()
         line["stages"] = job.stage_report()
+        if graph_mode:
+            line["config"]["launch"] = "forward pass replayed as one HIP graph; roofline / stages timed in a separate pass with plain launches"
         if not args.no_cpu_baseline and world == 1:
             cb = cpu_baseline(args.workload)
             line["cpu_baseline"] = cb

@@ -27,6 +27,8 @@
 #include <hip/hip_bf16.h>
 
 #include <algorithm>
+#include <map>
+#include <tuple>
 #include <cmath>
 #include <cstring>
 
@@ -1079,6 +1081,18 @@ struct amx_ffnn {
     float*    cur_part_min = nullptr;
     unsigned* cur_part_idx = nullptr;
     int       cur_ntn      = 0;
+    // HIP graphs of whole forward passes, for small batches where the 8-10 launches of a pass cost as much as a third of it
+    struct GraphKey {
+        const void *feats, *scores, *best, *counts, *sum;
+        hipStream_t stream;
+        int         stride, T, stats;
+        bool operator<(const GraphKey& o) const {
+            return std::tie(feats, scores, best, counts, sum, stream, stride, T, stats) <
+                   std::tie(o.feats, o.scores, o.best, o.counts, o.sum, o.stream, o.stride, o.T, o.stats);
+        }
+    };
+    std::map<GraphKey, hipGraphExec_t> graphs;
+    int    use_graphs = 1;
     int    gemm_persistent = 1;
     int    gemm_var       = 0;   // schedule variant bits: 1 = register double-buffered fragments, 2 = setprio, 4 = late stage issue
     int    gemm_cfg       = -1;  // -1 = automatic; index into the bf16 tile configurations (launch_bf16_cfg)
@@ -1254,6 +1268,8 @@ int amx_ffnn_create(amx_ctx* ctx, const amx_ffnn_model* m, amx_ffnn** out) {
     h->precision = m->precision;
     if (const char* e = getenv("AMX_GEMM_CFG"))
         h->gemm_cfg = atoi(e);
+    if (const char* e = getenv("AMX_FFNN_GRAPH"))
+        h->use_graphs = atoi(e);
     if (const char* e = getenv("AMX_GEMM_PERSISTENT"))
         h->gemm_persistent = atoi(e);
     if (const char* e = getenv("AMX_GEMM_VAR"))
@@ -1342,6 +1358,9 @@ void amx_ffnn_destroy(amx_ffnn* h) {
     hipFree(h->d_act[1]);
     hipFree(h->d_part_min);
     hipFree(h->d_part_idx);
+    for (auto& kv : h->graphs)
+        if (kv.second)  // nullptr marks a signature seen once
+            hipGraphExecDestroy(kv.second);
     delete h;
 }
 
@@ -1363,6 +1382,9 @@ extern "C" int amx_internal_best_state_reduce(amx_ctx* ctx, const float* part_mi
     return AMX_OK;
 }
 
+static int ffnn_score_launches(amx_ffnn* h, const float* feats_dev, int feats_stride, int T, float* scores_dev, bool stats,
+                               uint32_t* best_state_dev, unsigned long long* counts_dev, double* score_sum_dev);
+
 static int ffnn_score_impl(amx_ffnn* h, const float* feats_dev, int feats_stride, int T, float* scores_dev, bool stats,
                            uint32_t* best_state_dev, unsigned long long* counts_dev, double* score_sum_dev) {
     AMX_REQUIRE(h, AMX_ERR_INVALID, "amx_ffnn_score_dev: NULL handle");
@@ -1372,6 +1394,49 @@ static int ffnn_score_impl(amx_ffnn* h, const float* feats_dev, int feats_stride
     AMX_REQUIRE(feats_dev && scores_dev, AMX_ERR_INVALID, "amx_ffnn_score_dev: NULL buffer");
     AMX_REQUIRE(feats_stride >= h->in[0], AMX_ERR_INVALID, "amx_ffnn_score_dev: feature stride %d < input dimension %d", feats_stride, h->in[0]);
     AMX_HIP(hipSetDevice(h->ctx->device));
+    // Small batches (the decoder's ring buffer: 256 ... 1024 frames, the same device buffers every time): replay the pass as a
+    // HIP graph.  Not while profiling (the per-launch events are not part of the graph).
+    const bool graphable = h->use_graphs && !h->ctx->profiling && T <= 4096 && h->precision == AMX_PREC_BF16;
+    if (!graphable)
+        return ffnn_score_launches(h, feats_dev, feats_stride, T, scores_dev, stats, best_state_dev, counts_dev, score_sum_dev);
+    const amx_ffnn::GraphKey key{feats_dev, scores_dev, best_state_dev, counts_dev, score_sum_dev, h->ctx->stream, feats_stride, T, stats ? 1 : 0};
+    auto                     it = h->graphs.find(key);
+    if (it == h->graphs.end()) {
+        // first call with this signature: run it plainly once (sizes the workspace, sets kernel attributes), capture the second time
+        static const hipGraphExec_t kSeenOnce = nullptr;
+        h->graphs[key] = kSeenOnce;
+        return ffnn_score_launches(h, feats_dev, feats_stride, T, scores_dev, stats, best_state_dev, counts_dev, score_sum_dev);
+    }
+    if (it->second == nullptr) {
+        if (h->graphs.size() > 64) {  // a caller that keeps changing buffers: stop caching
+            h->use_graphs = 0;
+            return ffnn_score_launches(h, feats_dev, feats_stride, T, scores_dev, stats, best_state_dev, counts_dev, score_sum_dev);
+        }
+        hipGraph_t g = nullptr;
+        if (hipStreamBeginCapture(h->ctx->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+            (void)hipGetLastError();
+            h->use_graphs = 0;
+            return ffnn_score_launches(h, feats_dev, feats_stride, T, scores_dev, stats, best_state_dev, counts_dev, score_sum_dev);
+        }
+        const int  r   = ffnn_score_launches(h, feats_dev, feats_stride, T, scores_dev, stats, best_state_dev, counts_dev, score_sum_dev);
+        const bool ok  = hipStreamEndCapture(h->ctx->stream, &g) == hipSuccess && r == AMX_OK && g != nullptr;
+        hipGraphExec_t ex = nullptr;
+        if (!ok || hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            if (g)
+                hipGraphDestroy(g);
+            h->use_graphs = 0;  // capture is not available on this stream: plain launches from now on
+            return ffnn_score_launches(h, feats_dev, feats_stride, T, scores_dev, stats, best_state_dev, counts_dev, score_sum_dev);
+        }
+        hipGraphDestroy(g);
+        it->second = ex;
+    }
+    AMX_HIP(hipGraphLaunch(it->second, h->ctx->stream));
+    return AMX_OK;
+}
+
+static int ffnn_score_launches(amx_ffnn* h, const float* feats_dev, int feats_stride, int T, float* scores_dev, bool stats,
+                               uint32_t* best_state_dev, unsigned long long* counts_dev, double* score_sum_dev) {
     static const int chunk = getenv("AMX_FFNN_CHUNK") ? atoi(getenv("AMX_FFNN_CHUNK")) : 32768;  // frames per pass (workspace: 2 x chunk x max_hidden x 2 B)
     const int L     = h->n_layers;
     for (int t0 = 0; t0 < T; t0 += chunk) {

@@ -154,3 +154,38 @@ def test_tile_configurations_agree(ctx, monkeypatch, n_out):
         assert np.array_equal(got[0].view(np.uint32), ref[0].view(np.uint32)), cfg
         assert np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2]), cfg
         assert abs(got[3] - ref[3]) <= 1e-9 * abs(ref[3]), cfg
+
+
+def test_small_batch_graph_replay(ctx):
+    """batches of <= 4096 frames on unchanged device buffers are replayed as a HIP graph from the third call on: the results
+    must follow the CURRENT buffer contents, and the fused statistics must keep accumulating"""
+    import torch
+
+    import rasr_amd
+    Ws, bs, acts, logp = synth.ffnn([64, 256, 256, 1000], seed=31)
+    nn = rasr_amd.NnBatchFeatureScorer(ctx, Ws, bs, acts, log_prior=logp, precision="bf16")
+    T = 300
+    xd = torch.empty((T, 64), dtype=torch.float32, device="cuda")
+    sc = torch.empty((T, 1000), dtype=torch.float32, device="cuda")
+    best = torch.empty((T,), dtype=torch.int32, device="cuda")
+    counts = torch.zeros((1000,), dtype=torch.int64, device="cuda")
+    ssum = torch.zeros((1,), dtype=torch.float64, device="cuda")
+    ctx.use_torch_stream()
+    total = np.zeros(1000, np.int64)
+    for rep in range(5):
+        x = feats(T, 64, 40 + rep)
+        xd.copy_(torch.from_numpy(x))
+        nn.score_stats_dev(xd, 64, T, sc, best, counts, ssum)
+        torch.cuda.synchronize()
+        want = nn.score(x)                                  # host path: different buffers, plain launches
+        got = sc.cpu().numpy()
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), rep
+        assert np.array_equal(best.cpu().numpy(), want.argmin(axis=1)), rep
+        total += np.bincount(want.argmin(axis=1), minlength=1000)
+        assert np.array_equal(counts.cpu().numpy(), total), rep
+    for rep in range(4):                                    # plain scoring on the same buffers: its own graph
+        x = feats(T, 64, 50 + rep)
+        xd.copy_(torch.from_numpy(x))
+        nn.score_dev(xd, 64, T, sc)
+        torch.cuda.synchronize()
+        assert np.array_equal(sc.cpu().numpy().view(np.uint32), nn.score(x).view(np.uint32)), rep
