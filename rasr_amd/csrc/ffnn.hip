@@ -1092,6 +1092,8 @@ struct amx_ffnn {
         }
     };
     std::map<GraphKey, hipGraphExec_t> graphs;
+    float *d_host_f = nullptr, *d_host_s = nullptr;  // staging buffers of the host-buffer entry point amx_ffnn_score
+    size_t host_f_cap = 0, host_s_cap = 0;
     int    use_graphs = 1;
     int    gemm_persistent = 1;
     int    gemm_var       = 0;   // schedule variant bits: 1 = register double-buffered fragments, 2 = setprio, 4 = late stage issue
@@ -1358,6 +1360,8 @@ void amx_ffnn_destroy(amx_ffnn* h) {
     hipFree(h->d_act[1]);
     hipFree(h->d_part_min);
     hipFree(h->d_part_idx);
+    hipFree(h->d_host_f);
+    hipFree(h->d_host_s);
     for (auto& kv : h->graphs)
         if (kv.second)  // nullptr marks a signature seen once
             hipGraphExecDestroy(kv.second);
@@ -1524,30 +1528,38 @@ int amx_ffnn_score(amx_ffnn* h, const float* feats_host, int T, float* scores_ho
         return AMX_OK;
     AMX_REQUIRE(feats_host && scores_host, AMX_ERR_INVALID, "amx_ffnn_score: NULL buffer");
     AMX_HIP(hipSetDevice(h->ctx->device));
-    float *      d_f = nullptr, *d_s = nullptr;
+    // staging buffers live in the handle and only grow (no hipMalloc / hipFree per call; unchanged device addresses also let
+    // ffnn_score_impl replay its HIP graph)
     hipStream_t  st = h->ctx->stream;
     const size_t nf = (size_t)T * h->in[0], ns = (size_t)T * h->out.back();
-    auto         done = [&](int code) {
-        hipFree(d_f);
-        hipFree(d_s);
-        return code;
+    auto grow = [](float** p, size_t* cap, size_t need) {
+        if (need <= *cap)
+            return true;
+        hipFree(*p);
+        *p   = nullptr;
+        *cap = 0;
+        if (hipMalloc((void**)p, need * 4) != hipSuccess)
+            return false;
+        *cap = need;
+        return true;
     };
-    if (hipMalloc((void**)&d_f, nf * 4) != hipSuccess || hipMalloc((void**)&d_s, ns * 4) != hipSuccess) {
+    if (!grow(&h->d_host_f, &h->host_f_cap, nf) || !grow(&h->d_host_s, &h->host_s_cap, ns)) {
+        (void)hipGetLastError();
         amx::set_error("amx_ffnn_score: out of device memory");
-        return done(AMX_ERR_DEVICE);
+        return AMX_ERR_DEVICE;
     }
-    if (hipMemcpyAsync(d_f, feats_host, nf * 4, hipMemcpyHostToDevice, st) != hipSuccess) {
+    if (hipMemcpyAsync(h->d_host_f, feats_host, nf * 4, hipMemcpyHostToDevice, st) != hipSuccess) {
         amx::set_error("amx_ffnn_score: H2D copy failed");
-        return done(AMX_ERR_DEVICE);
+        return AMX_ERR_DEVICE;
     }
-    int r = amx_ffnn_score_dev(h, d_f, h->in[0], T, d_s);
+    int r = amx_ffnn_score_dev(h, h->d_host_f, h->in[0], T, h->d_host_s);
     if (r != AMX_OK)
-        return done(r);
-    if (hipMemcpyAsync(scores_host, d_s, ns * 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+        return r;
+    if (hipMemcpyAsync(scores_host, h->d_host_s, ns * 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
         amx::set_error("amx_ffnn_score: D2H copy / kernel execution failed: %s", hipGetErrorString(hipGetLastError()));
-        return done(AMX_ERR_DEVICE);
+        return AMX_ERR_DEVICE;
     }
-    return done(AMX_OK);
+    return AMX_OK;
 }
 
 }  // extern "C"

@@ -1239,6 +1239,10 @@ struct amx_gmm {
     float *   d_scr_nx = nullptr, *d_scr_q = nullptr;
     uint16_t* d_scr_masks = nullptr;
     int       scr_cap_T = 0;
+    // staging buffers of the host-buffer entry point amx_gmm_score
+    float *   d_host_f = nullptr, *d_host_s = nullptr;
+    uint32_t* d_host_b = nullptr;
+    size_t    host_f_cap = 0, host_s_cap = 0, host_b_cap = 0;
     float*    d_scr_pmin = nullptr;  // fused statistics: per-tile arg-min partials
     unsigned* d_scr_pidx = nullptr;
     size_t    scr_part_cap = 0;
@@ -1275,8 +1279,6 @@ int score_screened(amx_gmm* h, const float* feats_dev, int T, float* scores_dev,
             hipFree(h->d_scr_nx);
             hipFree(h->d_scr_q);
             hipFree(h->d_scr_masks);
-    hipFree(h->d_scr_pmin);
-    hipFree(h->d_scr_pidx);
             h->d_scr_X = nullptr;
             h->d_scr_nx = h->d_scr_q = nullptr;
             h->d_scr_masks = nullptr;
@@ -1700,6 +1702,11 @@ void amx_gmm_destroy(amx_gmm* h) {
     hipFree(h->d_scr_nx);
     hipFree(h->d_scr_q);
     hipFree(h->d_scr_masks);
+    hipFree(h->d_scr_pmin);
+    hipFree(h->d_scr_pidx);
+    hipFree(h->d_host_f);
+    hipFree(h->d_host_s);
+    hipFree(h->d_host_b);
     hipFree(h->d_m2lw_t);
     hipFree(h->d_ahat_t);
     hipFree(h->d_amax);
@@ -2056,35 +2063,44 @@ int amx_gmm_score(amx_gmm* h, int mode, const float* feats_host, int T, float* s
         return AMX_OK;
     AMX_REQUIRE(feats_host && scores_host, AMX_ERR_INVALID, "amx_gmm_score: NULL buffer");
     AMX_HIP(hipSetDevice(h->ctx->device));
-    float *     d_f = nullptr, *d_s = nullptr;
-    uint32_t*   d_b = nullptr;
-    hipStream_t st  = h->ctx->stream;
-    auto        done = [&](int code) {
-        hipFree(d_f);
-        hipFree(d_s);
-        hipFree(d_b);
-        return code;
-    };
+    // staging buffers live in the handle and only grow: the decoder calls this once per ring-buffer fill, and a
+    // hipMalloc / hipFree pair per call costs more than scoring a small batch
+    hipStream_t  st = h->ctx->stream;
     const size_t nf = (size_t)T * h->dim, ns = (size_t)T * h->n_mix;
-    if (hipMalloc((void**)&d_f, nf * 4) != hipSuccess || hipMalloc((void**)&d_s, ns * 4) != hipSuccess ||
-        (best_host && hipMalloc((void**)&d_b, ns * 4) != hipSuccess)) {
+    auto grow = [](void** p, size_t* cap, size_t need) {
+        if (need <= *cap)
+            return true;
+        hipFree(*p);
+        *p   = nullptr;
+        *cap = 0;
+        if (hipMalloc(p, need) != hipSuccess)
+            return false;
+        *cap = need;
+        return true;
+    };
+    if (!grow((void**)&h->d_host_f, &h->host_f_cap, nf * 4) || !grow((void**)&h->d_host_s, &h->host_s_cap, ns * 4) ||
+        (best_host && !grow((void**)&h->d_host_b, &h->host_b_cap, ns * 4))) {
+        (void)hipGetLastError();
         amx::set_error("amx_gmm_score: out of device memory");
-        return done(AMX_ERR_DEVICE);
+        return AMX_ERR_DEVICE;
     }
+    float*    d_f = h->d_host_f;
+    float*    d_s = h->d_host_s;
+    uint32_t* d_b = best_host ? h->d_host_b : nullptr;
     if (hipMemcpyAsync(d_f, feats_host, nf * 4, hipMemcpyHostToDevice, st) != hipSuccess) {
         amx::set_error("amx_gmm_score: H2D copy failed");
-        return done(AMX_ERR_DEVICE);
+        return AMX_ERR_DEVICE;
     }
     int r = amx_gmm_score_dev(h, mode, d_f, T, d_s, d_b);
     if (r != AMX_OK)
-        return done(r);
+        return r;
     if (hipMemcpyAsync(scores_host, d_s, ns * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
         (best_host && hipMemcpyAsync(best_host, d_b, ns * 4, hipMemcpyDeviceToHost, st) != hipSuccess) ||
         hipStreamSynchronize(st) != hipSuccess) {
         amx::set_error("amx_gmm_score: D2H copy / kernel execution failed: %s", hipGetErrorString(hipGetLastError()));
-        return done(AMX_ERR_DEVICE);
+        return AMX_ERR_DEVICE;
     }
-    return done(AMX_OK);
+    return AMX_OK;
 }
 
 }  // extern "C"

@@ -327,3 +327,35 @@ def test_score_stats_dev(ctx, kind):
     assert np.array_equal(counts.cpu().numpy(), 2 * np.bincount(want_state, minlength=M))
     want_sum = 2 * ref_scores.min(axis=1).astype(np.float64).sum()
     assert abs(float(ssum.item()) - want_sum) <= 1e-9 * abs(want_sum)
+
+
+def test_workspaces_regrow_between_calls(ctx):
+    """the screen workspace, the fused-statistics partials and the host staging buffers of one handle grow with the batch:
+    alternate small and large batches through the device and the host entry points"""
+    import torch
+
+    import rasr_amd
+    model = synth.gmm_cart(100, 1, 16, 40, seed=111, pooled=True)
+    sc = rasr_amd.GmmFeatureScorer(ctx, model)
+    M = 100
+    ctx.use_torch_stream()
+    counts = torch.zeros((M,), dtype=torch.int64, device="cuda")
+    ssum = torch.zeros((1,), dtype=torch.float64, device="cuda")
+    total = np.zeros(M, np.int64)
+    for i, T in enumerate((300, 5000, 64, 9000, 300)):
+        x = feats(T, 40, 112 + i)
+        want, want_best = sc.score(x)                                    # host path (staging buffers regrow)
+        xd = torch.from_numpy(x).cuda()
+        scores = torch.empty((T, M), dtype=torch.float32, device="cuda")
+        bestd = torch.empty((T, M), dtype=torch.int32, device="cuda")
+        state = torch.empty((T,), dtype=torch.int32, device="cuda")
+        sc.score_stats_dev(xd, T, scores, bestd, state, counts, ssum)    # device path (screen workspace + partials regrow)
+        torch.cuda.synchronize()
+        assert np.array_equal(scores.cpu().numpy().view(np.uint32), want.view(np.uint32)), T
+        assert np.array_equal(bestd.cpu().numpy().astype(np.uint32), want_best), T
+        assert np.array_equal(state.cpu().numpy(), want.argmin(axis=1)), T
+        total += np.bincount(want.argmin(axis=1), minlength=M)
+        assert np.array_equal(counts.cpu().numpy(), total), T
+    from oracle import OracleGmm
+    osc, _ = OracleGmm(model).score(x[:50], mode=0)
+    assert np.array_equal(want[:50].view(np.uint32), osc.view(np.uint32))
