@@ -276,7 +276,9 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[C::MI][C::MJ], char*
     }
 }
 
-// experiment hooks (tools/gemm_probe.hip only; the library instantiates VAR = 0 and never touches them):
+// ablation / trace hooks (tools/gemm_probe.hip only; the library instantiates VAR = 0 and never touches them):
+//   VAR & 8 no MFMA, 16 no operand loads after the first K-tile, 64 operand streaming only, 128 no epilogue, 256 epilogue
+//   without global stores
 //   VAR & 512  per-tile time stamps  g_gemm_trace[(block * 64 + step) * 4 + {start, k-loop end, epilogue end, XCC id}]
 //   VAR & 1024 the workgroups of one XCD start every tile together (bounded spin on g_gemm_sync[xcd * 64 + step])
 __device__ unsigned long long* g_gemm_trace = nullptr;
@@ -396,56 +398,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm_bf16_kernel(const bf16_t* __r
     const int KT = Kpad / C::BKC;
     const int frow = lane & 31;
     const int fk   = lane >> 5;  // which 8-element half of a 16-wide k slab
-    if constexpr ((VAR & 2048) != 0) {
-        // Register pipeline ACROSS the barrier: the fragments of k-slab ks+1 are read while slab ks multiplies, and
-        // the barrier that publishes K-tile kt+1 sits between the reads and the MFMAs of the LAST slab of tile kt.
-        // Every wave therefore still holds 8 MFMAs (256 matrix-pipe cycles, 512 per SIMD) when it arrives at the
-        // barrier, which covers the barrier skew and the LDS latency of the next tile's first fragments.
-        static_assert(C::STAGES == 2 && C::BKC == 64, "cross-barrier pipeline is written for two 64-wide stages");
-        bf16x8 a[2][C::MI], b[2][C::MJ];
-#define AMX_FRAG_LOAD(buf, base, ks)                                                                                        \
-    {                                                                                                                       \
-        _Pragma("unroll") for (int i = 0; i < C::MI; ++i) a[buf][i] =                                                       \
-                *(const bf16x8*)((base) + C::swz(wn * (C::BN / C::WN) + i * 32 + frow, (ks) * 2 + fk));                     \
-        _Pragma("unroll") for (int j = 0; j < C::MJ; ++j) b[buf][j] =                                                       \
-                *(const bf16x8*)((base) + C::A_BYTES + C::swz(wt * (C::BT / C::WT) + j * 32 + frow, (ks) * 2 + fk));        \
-    }
-        stage(0, 0);
-        wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-        if (KT > 1)
-            stage(1, 1);
-        AMX_FRAG_LOAD(0, lds, 0)
-        for (int kt = 0; kt < KT; ++kt) {
-            const char* wbase = lds + (kt & 1) * C::STAGE_BYTES;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                if (ks < 3) {
-                    AMX_FRAG_LOAD((ks + 1) & 1, wbase, ks + 1)
-                }
-                else {
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // all my reads of tile kt have returned
-                    if (kt + 1 < KT) {
-                        wait_vmcnt<0>();  // my share of tile kt+1 landed (issued one K-tile ago)
-                        __builtin_amdgcn_s_barrier();
-                        if (kt + 2 < KT)
-                            stage(kt & 1, kt + 2);
-                        const char* nbase = lds + ((kt + 1) & 1) * C::STAGE_BYTES;
-                        AMX_FRAG_LOAD(0, nbase, 0)
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 0; i < C::MI; ++i)
-#pragma unroll
-                    for (int j = 0; j < C::MJ; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks & 1][i], b[ks & 1][j], acc[i][j], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-#undef AMX_FRAG_LOAD
-    }
-    else {
+    {
 #pragma unroll
     for (int s = 0; s < C::STAGES - 1; ++s)
         if (s < KT)
@@ -462,44 +415,11 @@ __global__ __launch_bounds__(C::THREADS) void gemm_bf16_kernel(const bf16_t* __r
         __builtin_amdgcn_s_barrier();
         const bool more  = kt + C::STAGES - 1 < KT;
         const int  nslot = (kt + C::STAGES - 1) % C::STAGES;
-        if (!(VAR & 4) && more && !((VAR & 16) && kt > 0))
+        if (more && !((VAR & 16) && kt > 0))  // VAR & 16: ablation, no operand loads after the first K-tile
             stage(nslot, kt + C::STAGES - 1);
         const char* wbase = lds + (kt % C::STAGES) * C::STAGE_BYTES;
         const char* xbase = wbase + C::A_BYTES;
-        if (VAR & 1) {
-            // fragments double-buffered in registers: the reads of k-slab ks+1 are in flight while ks multiplies
-            bf16x8 a[2][C::MI], b[2][C::MJ];
-            auto   load = [&](int buf, int ks) {
-#pragma unroll
-                for (int i = 0; i < C::MI; ++i)
-                    a[buf][i] = *(const bf16x8*)(wbase + C::swz(wn * (C::BN / C::WN) + i * 32 + frow, ks * 2 + fk));
-#pragma unroll
-                for (int j = 0; j < C::MJ; ++j)
-                    b[buf][j] = *(const bf16x8*)(xbase + C::swz(wt * (C::BT / C::WT) + j * 32 + frow, ks * 2 + fk));
-            };
-            load(0, 0);
-#pragma unroll
-            for (int ks = 0; ks < C::BKC / 16; ++ks) {
-                if (ks + 1 < C::BKC / 16)
-                    load((ks + 1) & 1, ks + 1);
-                if (VAR & 32)
-                    __builtin_amdgcn_sched_barrier(0);  // keep the next slab's reads AHEAD of this slab's MFMAs
-                if ((VAR & 4) && more && ks == 0)
-                    stage(nslot, kt + C::STAGES - 1);
-                if (VAR & 2)
-                    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                for (int i = 0; i < C::MI; ++i)
-#pragma unroll
-                    for (int j = 0; j < C::MJ; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks & 1][i], b[ks & 1][j], acc[i][j], 0, 0, 0);
-                if (VAR & 32)
-                    __builtin_amdgcn_sched_barrier(0);
-                if (VAR & 2)
-                    __builtin_amdgcn_s_setprio(0);
-            }
-        }
-        else if (VAR & 64) {
+        if (VAR & 64) {
             // ablation: operand streaming only (no fragment reads, no MFMA)
         }
         else {
@@ -512,10 +432,6 @@ __global__ __launch_bounds__(C::THREADS) void gemm_bf16_kernel(const bf16_t* __r
 #pragma unroll
                 for (int j = 0; j < C::MJ; ++j)
                     b[j] = *(const bf16x8*)(xbase + C::swz(wt * (C::BT / C::WT) + j * 32 + frow, ks * 2 + fk));
-                if ((VAR & 4) && more && ks == 0)
-                    stage(nslot, kt + C::STAGES - 1);
-                if (VAR & 2)
-                    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int i = 0; i < C::MI; ++i)
 #pragma unroll
@@ -526,8 +442,6 @@ __global__ __launch_bounds__(C::THREADS) void gemm_bf16_kernel(const bf16_t* __r
                         else
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
                     }
-                if (VAR & 2)
-                    __builtin_amdgcn_s_setprio(0);
             }
         }
         // this wave's LDS reads have returned before it can arrive at the next barrier
@@ -1096,7 +1010,6 @@ struct amx_ffnn {
     size_t host_f_cap = 0, host_s_cap = 0;
     int    use_graphs = 1;
     int    gemm_persistent = 1;
-    int    gemm_var       = 0;   // schedule variant bits: 1 = register double-buffered fragments, 2 = setprio, 4 = late stage issue
     int    gemm_cfg       = -1;  // -1 = automatic; index into the bf16 tile configurations (launch_bf16_cfg)
     size_t elt() const { return precision == AMX_PREC_BF16 ? 2 : 4; }
 };
@@ -1274,8 +1187,6 @@ int amx_ffnn_create(amx_ctx* ctx, const amx_ffnn_model* m, amx_ffnn** out) {
         h->use_graphs = atoi(e);
     if (const char* e = getenv("AMX_GEMM_PERSISTENT"))
         h->gemm_persistent = atoi(e);
-    if (const char* e = getenv("AMX_GEMM_VAR"))
-        h->gemm_var = atoi(e);
     if (const char* e = getenv("AMX_GEMM_GROUP"))
         sscanf(e, "%dx%d", &h->group_t, &h->group_n);
     hipSetDevice(ctx->device);

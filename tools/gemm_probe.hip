@@ -168,10 +168,6 @@ int main(int argc, char** argv) {
         else if (s == "256") run<CfgC, 256>(p, iters);           // epilogue without global stores
         else if (s == "136") run<CfgC, 8 | 128>(p, iters);        // loads + fragment reads, no MFMA, no epilogue
         else if (s == "144") run<CfgC, 16 | 128>(p, iters);       // no global loads after the first: reads + MFMA
-        else if (s == "129") run<CfgC, 1 | 128>(p, iters);
-        else if (s == "130") run<CfgC, 2 | 128>(p, iters);
-        else if (s == "2048") run<CfgC, 2048>(p, iters);
-        else if (s == "2176") run<CfgC, 2048 | 128>(p, iters);
         else if (s == "1024") run<CfgC, 1024>(p, iters);         // XCD tile barrier
         else if (s == "1088") run<CfgC, 1024 | 64 | 128>(p, iters);
         else if (s == "1152") run<CfgC, 1024 | 128>(p, iters);
