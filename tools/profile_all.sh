@@ -2,6 +2,7 @@
 # tools/profile_all.sh -- regenerates the artefacts under profiles/rNN on a GPU box:
 #   <workload>_bench.log          the bench.py JSON line (default workload: with cpu_baseline)
 #   <workload>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary of the same command
+#   ceilings.json                 measured HBM / MFMA / VALU ceilings of the box (tools/ceilings.hip)
 #   pmc/<workload>_{fetch,write}.txt   FETCH_SIZE / WRITE_SIZE per kernel, separate --pmc passes (kernel-trace only)
 # usage (through gpurun):  tools/profile_all.sh r01 ; results land in gpurun_out/<round>/ -> copy to profiles/<round>/
 round=${1:-r01}
@@ -25,6 +26,7 @@ run_pmc() {  # name, counter, suffix, bench args...
     f=$(find /tmp/pmc_${name}_$suf -name "*counter_collection.csv" | head -1)
     [ -n "$f" ] && python $root/tools/pmc_summary.py $f > $out/pmc/${name}_$suf.txt
 }
+[ -x $root/tools/build/ceilings ] && $root/tools/build/ceilings > $out/ceilings.json   # tools/build_probe.sh builds it
 run_stats pipeline --steps 8 --warmup 2
 run_stats nn-pipeline --workload nn-pipeline --steps 8 --warmup 2 --no-cpu-baseline
 run_stats mfcc --workload mfcc --steps 8 --warmup 2 --no-cpu-baseline
