@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--utt-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--estimation-mode", default="viterbi", choices=["viterbi", "baum-welch"],
+                    help="gmm-train: statistics of the best density only, or of every density by its posterior (reference: mode)")
     ap.add_argument("--gmm-type", default="diagonal-maximum", choices=["diagonal-maximum", "batch-diagonal-maximum-float"])
     return ap.parse_args()
 
@@ -304,14 +306,19 @@ class GmmTrain:
         self.score_sum = torch.zeros((1,), dtype=torch.float64, device="cuda")
         self.acc = torch.zeros((self.sc.accumulator_size(),), dtype=torch.float64, device="cuda")
         self.units = self.F
+        self.baum_welch = getattr(args, "estimation_mode", "viterbi") == "baum-welch"
 
     def step(self):
+        import rasr_amd
         self.fe.run_plan(self.plan, self.pcm, self.ceps)
         for t0 in range(0, self.F, self.CHUNK):
             T = min(self.CHUNK, self.F - t0)
             x = self.ceps[t0:]
             self.sc.score_stats_dev(x, T, self.scores, self.bestd, self.state, self.counts, self.score_sum)
-            self.sc.accumulate_dev(x, T, self.state, self.bestd, self.M, self.acc)
+            if self.baum_welch:
+                self.sc.accumulate_weighted_dev(rasr_amd.AMX_GMM_BAUM_WELCH, x, T, self.state, None, None, 0, self.acc)
+            else:
+                self.sc.accumulate_dev(x, T, self.state, self.bestd, self.M, self.acc)
 
     def epoch_reduce(self, world):
         if world > 1:
@@ -325,7 +332,7 @@ class GmmTrain:
 
     def stage_report(self):
         out = {"accumulator_bytes": int(self.acc.numel() * 8)}
-        for k in ("mfcc", "gmm_screen_pack", "gmm_screen", "gmm", "stats", "gmm_accumulate"):
+        for k in ("mfcc", "gmm_screen_pack", "gmm_screen", "gmm", "stats", "gmm_accumulate", "gmm_accumulate_weighted"):
             ms, n = self.ctx.profile_get(k)
             if n:
                 out[k] = dict(avg_ms=round(ms, 4), launches=n)

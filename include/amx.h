@@ -211,6 +211,45 @@ int  amx_gmm_accumulate_dev(amx_gmm* h, const float* feats_dev, int T, const uin
 int amx_gmm_accumulator_write(const amx_gmm* h, const double* acc_host, const char* path);
 int amx_gmm_accumulator_read(const amx_gmm* h, const char* path, double* acc_host);
 
+/* Weighted Viterbi / Baum-Welch statistics: Mm::AbstractMixtureSetEstimator::accumulate(mixture, x, weight)
+ * (Mm/AbstractMixtureSetEstimator.cc:127-147).  weight_dev: per-frame f64 weights (the alignment's posterior weight), NULL = 1.
+ *   AMX_GMM_VITERBI     the best density (best_density_dev as above) gets the whole frame weight;
+ *   AMX_GMM_BAUM_WELCH  every density k of the aligned mixture gets weight * exp(score(e) - s_k), the density posterior of
+ *                       the log-add scorer (Mm/GaussDiagonalMaximumFeatureScorer.cc:291-298), if that product exceeds
+ *                       Core::Type<f32>::epsilon; best_density_dev is not used.
+ * Sums are weight * x and (weight * x) * x in f64 (plusWeighted / plusSquareWeighted, Mm/Utilities.hh:108-153). */
+enum { AMX_GMM_VITERBI = 0, AMX_GMM_BAUM_WELCH = 1 };
+int amx_gmm_accumulate_weighted_dev(amx_gmm* h, int mode, const float* feats_dev, int T, const uint32_t* mixture_dev,
+                                    const double* weight_dev, const uint32_t* best_density_dev, int best_density_ld,
+                                    double* acc_dev);
+
+/* Re-estimation from the (all-reduced) statistics: Mm::AbstractMixtureSetEstimator::estimate
+ * (Mm/AbstractMixtureSetEstimator.cc:305-338: densities below the observation-weight limits leave their mixture except
+ * the heaviest one, Mm/MixtureEstimator.cc:64-82; remaining densities / means / covariances are renumbered in order of
+ * first appearance, :804-817; mixture weights log(w) normalised by logExpNorm, Mm/Mixture.cc:63-74; mean = sum / weight,
+ * variance = (sum x^2 - sum_j sum_j^2 / N_j) / N floored at min_variance, Mm/GaussDensityEstimator.cc:148-233), and with
+ * cfg->split the acoustic model trainer's splitting step on top of it (Mm::MixtureSetSplitter::split,
+ * Mm/MixtureSetSplitter.cc:38-123: means with enough observations become mean +- sqrt(var) * perturbation * f32 epsilon).
+ * `topology` is the model the statistics were accumulated with (its means / variances / weights are not read); acc_host the
+ * flat buffer of amx_gmm_accumulator_size() doubles.  The result is a mixture set like amx_pms_read's: view it, write it
+ * with amx_pms_write, or build the next iteration's scorer from it.  Host work, model-sized, once per epoch. */
+typedef struct {
+    double min_observation_weight;    /* minimum-observation-weight, default 5 */
+    double min_relative_weight;       /* minimum-relative-weight, default 0 */
+    double min_variance;              /* minimum-variance, default 0 (compared and stored as f32) */
+    int    normalize_mixture_weights; /* normalize-mixture-weights, default 1 */
+    int    allow_zero_weights;        /* allow-zero-weights, default 0: a mixture without observations is an error */
+    int    split;                     /* 0: estimate only; 1: estimate, then split */
+    double split_min_mean_observation_weight;       /* minimum-mean-observation-weight, default 20 */
+    double split_min_covariance_observation_weight; /* minimum-covariance-observation-weight, default f32 max (never) */
+    double split_perturbation_weight;               /* perturbation-weight, default 0.1 */
+    int    split_normalize_mixture_weights;         /* normalize-mixture-weights of the splitter, default 0 */
+} amx_gmm_estimate_cfg;
+typedef struct amx_mixture_set amx_mixture_set;
+void amx_gmm_estimate_cfg_default(amx_gmm_estimate_cfg* cfg);
+int  amx_gmm_estimate(const amx_gmm_model* topology, const double* acc_host, const amx_gmm_estimate_cfg* cfg /* NULL: defaults */,
+                      amx_mixture_set** out);
+
 /* ------------------------------------------------------------------ mixture-set text files (.pms) */
 
 /* Reader / writer of RASR's text mixture-set format, "#Version: 2.0" (Mm/MixtureSet.cc:141-216,
@@ -218,7 +257,6 @@ int amx_gmm_accumulator_read(const amx_gmm* h, const char* path, double* acc_hos
  * files carry linear weights (converted with log), covariances are stored as (variance, weight)
  * pairs whose product is the diagonal.  The returned object owns its arrays; amx_mixture_set_view
  * fills an amx_gmm_model with pointers into it (scales set to 1). */
-typedef struct amx_mixture_set amx_mixture_set;
 int  amx_pms_read(const char* path, amx_mixture_set** out);
 int  amx_pms_write(const amx_gmm_model* model, const char* path);
 int  amx_mixture_set_view(const amx_mixture_set* ms, amx_gmm_model* view);

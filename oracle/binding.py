@@ -100,6 +100,7 @@ def Oracle():
     L.orc_gmm_accumulator_size.restype = C.c_long
     L.orc_gmm_accumulator_size.argtypes = [C.c_void_p]
     L.orc_gmm_accumulate.argtypes = [C.c_void_p, f32p, C.c_int, u32p, u32p, f64p]
+    L.orc_gmm_accumulate_weighted.argtypes = [C.c_void_p, C.c_int, f32p, C.c_int, u32p, C.c_void_p, C.c_void_p, f64p]
     L.orc_ffnn_score.argtypes = [C.POINTER(_FfnnModel), f32p, C.c_int, f32p, C.c_int]
     _lib = L
     return L
@@ -210,6 +211,37 @@ def ref_attribs_xml(attrs):
     return buf.value.decode()
 
 
+def ref_accumulate_vector(sum_, v, weight, kind):
+    """reference functors on one accumulator row (libref): kind 0 plus, 1 plusWeighted, 2 plusSquare, 3 plusSquareWeighted (v f32),
+    4 plusNormalizedSquare (v f64)"""
+    R = load_ref()
+    s = np.array(sum_, dtype=np.float64)
+    v = np.ascontiguousarray(v, dtype=np.float64 if kind == 4 else np.float32)
+    R.ref_accumulate_vector.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int]
+    R.ref_accumulate_vector.restype = None
+    R.ref_accumulate_vector(s.ctypes.data, v.ctypes.data, len(s), float(weight), kind)
+    return s
+
+
+def ref_log_exp_norm(v):
+    R = load_ref()
+    v = np.ascontiguousarray(v, dtype=np.float64)
+    R.ref_log_exp_norm.argtypes = [C.c_void_p, C.c_int]
+    R.ref_log_exp_norm.restype = C.c_double
+    return R.ref_log_exp_norm(v.ctypes.data, len(v))
+
+
+def ref_normalized_minus(x, y, weight):
+    R = load_ref()
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    out = np.zeros(len(x), np.float32)
+    R.ref_normalized_minus.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p]
+    R.ref_normalized_minus.restype = None
+    R.ref_normalized_minus(x.ctypes.data, y.ctypes.data, len(x), float(weight), out.ctypes.data)
+    return out
+
+
 class OracleMfcc:
     def __init__(self, cfg=None, **kw):
         self.L = Oracle()
@@ -318,6 +350,17 @@ class OracleGmm:
             acc = np.zeros(self.accumulator_size(), np.float64)
         self.L.orc_gmm_accumulate(self.h, feats.reshape(-1), feats.shape[0], np.ascontiguousarray(mixture, dtype=np.uint32),
                                   np.ascontiguousarray(density_in_mixture, dtype=np.uint32), acc)
+        return acc
+
+    def accumulate_weighted(self, mode, feats, mixture, weight=None, density_in_mixture=None, acc=None):
+        """mode 0: weighted Viterbi (needs density_in_mixture); mode 1: Baum-Welch posteriors of the log-add scorer"""
+        feats = np.ascontiguousarray(feats, dtype=np.float32)
+        if acc is None:
+            acc = np.zeros(self.accumulator_size(), np.float64)
+        w = None if weight is None else np.ascontiguousarray(weight, dtype=np.float64)
+        b = None if density_in_mixture is None else np.ascontiguousarray(density_in_mixture, dtype=np.uint32)
+        self.L.orc_gmm_accumulate_weighted(self.h, mode, feats.reshape(-1), feats.shape[0], np.ascontiguousarray(mixture, dtype=np.uint32),
+                                           None if w is None else w.ctypes.data, None if b is None else b.ctypes.data, acc)
         return acc
 
     def score_batch_float(self, feats):

@@ -120,6 +120,9 @@ int orc_gmm_score_batch_float(const orc_gmm* h, const double* log_weight, const 
 long orc_gmm_accumulator_size(const orc_gmm* h);
 void orc_gmm_accumulate(const orc_gmm* h, const float* feats, int T, const uint32_t* mixture,
                         const uint32_t* density_in_mixture, double* acc);
+/* weighted Viterbi (mode 0) / Baum-Welch (mode 1) statistics, Mm/AbstractMixtureSetEstimator.cc:127-147; weight nullable (= 1) */
+void orc_gmm_accumulate_weighted(const orc_gmm* h, int mode, const float* feats, int T, const uint32_t* mixture,
+                                 const double* weight, const uint32_t* density_in_mixture, double* acc);
 
 /* ---------------------------------------------------------------- FFNN forward */
 

@@ -272,6 +272,81 @@ void orc_gmm_accumulate(const orc_gmm* h, const float* feats, int T, const uint3
     }
 }
 
+/* Weighted Viterbi and Baum-Welch accumulation: Mm::AbstractMixtureSetEstimator::accumulate(mixture, x, weight)
+ * (Mm/AbstractMixtureSetEstimator.cc:127-147).
+ *   mode 0 (viterbi): the best density of the aligned mixture gets the frame's weight: MixtureEstimator weights_[k] += w
+ *     (Mm/MixtureEstimator.cc:99-104), mean sum = sum + w*x (plusWeighted<f64>, Mm/Utilities.hh:108-122), covariance
+ *     sum = sum + w*x*x (plusSquareWeighted<f64>, :135-153: left to right, (w*x)*x), both weights += w
+ *     (Mm/VectorAccumulator.hh:64-67).
+ *   mode 1 (baum-welch): density posteriors of the log-add scorer, p_k = exp(score(e) - s_k) in f32
+ *     (Mm/GaussDiagonalMaximumFeatureScorer.cc:291-298 with logDenominator = score(e), Mm/AssigningFeatureScorer.hh:139-141);
+ *     final weight = w * p_k in f64; densities with final weight > Core::Type<f32>::epsilon (weightThreshold_, ctor :63)
+ *     accumulate x with that weight.
+ * weight == NULL means 1.0 for every frame. */
+void orc_gmm_accumulate_weighted(const orc_gmm* h, int mode, const float* feats, int T, const uint32_t* mixture, const double* weight,
+                                 const uint32_t* density_in_mixture, double* acc) {
+    const size_t nk = h->mix_off[h->n_mix];
+    double*      mw = acc + nk;
+    double*      ms = mw + h->n_mean;
+    double*      cw = ms + (size_t)h->n_mean * h->dim;
+    double*      cs = cw + h->n_cov;
+    int          maxk = 1;
+    for (int m = 0; m < h->n_mix; ++m)
+        if ((int)(h->mix_off[m + 1] - h->mix_off[m]) > maxk)
+            maxk = (int)(h->mix_off[m + 1] - h->mix_off[m]);
+    float* sk = (float*)malloc((size_t)maxk * 4);
+    for (int t = 0; t < T; ++t) {
+        const uint32_t m  = mixture[t];
+        const uint32_t k0 = h->mix_off[m], nd = h->mix_off[m + 1] - k0;
+        const float*   x  = feats + (size_t)t * h->dim;
+        const double   w  = weight ? weight[t] : 1.0;
+        float          logDen = 0;
+        if (mode == 1) {
+            for (uint32_t j = 0; j < nd; ++j) {
+                uint32_t d     = h->dens_index[k0 + j];
+                uint32_t c     = h->dens_cov[d];
+                float    dist  = orc_distance(x, h->means + (size_t)h->dens_mean[d] * h->dim, h->isr + (size_t)c * h->dim, h->dim);
+                float    score = h->m2lw[k0 + j] + h->lognorm[c] + dist;
+                sk[j]          = (float)(0.5 * score);
+            }
+            float bestScore = FLT_MAX;
+            for (uint32_t j = 0; j < nd; ++j)
+                if (bestScore > sk[j])
+                    bestScore = sk[j];
+            float sumExp = 0;
+            for (uint32_t j = 0; j < nd; ++j)
+                sumExp += expf(bestScore - sk[j]);
+            logDen = bestScore - logf(sumExp);
+        }
+        for (uint32_t j = 0; j < nd; ++j) {
+            double fw;
+            if (mode == 1) {
+                double p = (double)expf(logDen - sk[j]);
+                fw       = w * p;
+                if (!(fw > (double)FLT_EPSILON))
+                    continue;
+            }
+            else {
+                if (j != density_in_mixture[t])
+                    continue;
+                fw = w;
+            }
+            const uint32_t k  = k0 + j;
+            const uint32_t d  = h->dens_index[k];
+            const uint32_t mi = h->dens_mean[d], ci = h->dens_cov[d];
+            acc[k] += fw;
+            mw[mi] += fw;
+            cw[ci] += fw;
+            for (int i = 0; i < h->dim; ++i) {
+                double y = x[i];
+                ms[(size_t)mi * h->dim + i] = ms[(size_t)mi * h->dim + i] + fw * y;
+                cs[(size_t)ci * h->dim + i] = cs[(size_t)ci * h->dim + i] + fw * y * y;
+            }
+        }
+    }
+    free(sk);
+}
+
 /* ------------------------------------------------------------------ FFNN forward */
 
 static float orc_act(float v, int act) {

@@ -22,6 +22,7 @@
 #include <Core/BinaryStream.hh>
 #include <Core/XmlStream.hh>
 #include <Flow/Vector.hh>
+#include <functional>
 #include <sstream>
 
 #include <algorithm>
@@ -205,6 +206,45 @@ long ref_attribs_xml(const char** names, const char** values, int n, char* out, 
         return -(long)s.size();
     std::memcpy(out, s.c_str(), s.size() + 1);
     return (long)s.size();
+}
+
+// Training statistics and re-estimation arithmetic, as far as it lives in the header-only Mm/Utilities.hh
+// (Mm/VectorAccumulator.hh and the estimator classes pull in Core/Configuration.hh -> boost and cannot be built):
+// the element-wise update VectorAccumulator::accumulate(v, weight) issues (Mm/VectorAccumulator.hh:60-67) through the
+// reference's own unrolledTransform and functors.  kind 0: std::plus (mean, unweighted) 1: plusWeighted 2: plusSquare
+// 3: plusSquareWeighted (input f32); kind 4: plusNormalizedSquare (input f64, CovarianceEstimator::estimate's
+// WeighedMeanSquareSum, Mm/GaussDensityEstimator.cc:203-214).
+void ref_accumulate_vector(double* sum, const void* in, int n, double weight, int kind) {
+    std::vector<double> s(sum, sum + n);
+    if (kind == 4) {
+        const double* y = (const double*)in;
+        std::vector<double> v(y, y + n);
+        Mm::unrolledTransform(s.begin(), s.end(), v.begin(), s.begin(), Mm::plusNormalizedSquare<double>(weight));
+    }
+    else {
+        const float* y = (const float*)in;
+        std::vector<float> v(y, y + n);
+        if (kind == 0)
+            Mm::unrolledTransform(s.begin(), s.end(), v.begin(), s.begin(), std::plus<double>());
+        else if (kind == 1)
+            Mm::unrolledTransform(s.begin(), s.end(), v.begin(), s.begin(), Mm::plusWeighted<double>(weight));
+        else if (kind == 2)
+            Mm::unrolledTransform(s.begin(), s.end(), v.begin(), s.begin(), Mm::plusSquare<double>());
+        else
+            Mm::unrolledTransform(s.begin(), s.end(), v.begin(), s.begin(), Mm::plusSquareWeighted<double>(weight));
+    }
+    std::copy(s.begin(), s.end(), sum);
+}
+// Mixture::normalizeWeights' norm (Mm/Mixture.cc:68-74) and the covariance estimate's (x - y) / weight -> f32
+double ref_log_exp_norm(const double* v, int n) {
+    std::vector<double> w(v, v + n);
+    return Mm::logExpNorm(w.begin(), w.end());
+}
+void ref_normalized_minus(const double* x, const double* y, int n, double weight, float* out) {
+    std::vector<double> a(x, x + n), b(y, y + n);
+    std::vector<float>  r(n);
+    std::transform(a.begin(), a.end(), b.begin(), r.begin(), Mm::normalizedMinus<double>(weight));
+    std::copy(r.begin(), r.end(), out);
 }
 
 }  // extern "C"

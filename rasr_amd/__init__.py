@@ -16,11 +16,12 @@ import os
 import numpy as np
 
 from . import _lib
-from ._lib import (AMX_ACT_NONE, AMX_ACT_RELU, AMX_ACT_SIGMOID, AMX_ACT_TANH, AMX_GMM_BATCH_FLOAT, AMX_GMM_MAX, AMX_GMM_SUM,  # noqa: F401
+from ._lib import (AMX_ACT_NONE, AMX_ACT_RELU, AMX_ACT_SIGMOID, AMX_ACT_TANH, AMX_GMM_BATCH_FLOAT, AMX_GMM_BAUM_WELCH, AMX_GMM_MAX, AMX_GMM_SUM, AMX_GMM_VITERBI,  # noqa: F401
                    AMX_PREC_BF16, AMX_PREC_FP32, AmxError, MfccCfg)
 
 __all__ = ["Context", "MfccExtractor", "GmmFeatureScorer", "NnBatchFeatureScorer", "FileArchive", "AmxError", "read_pms", "write_pms",
-           "read_nn_matrix", "write_nn_matrix", "layer_from_parameters", "prior_from_mixture_set"]
+           "read_nn_matrix", "write_nn_matrix", "layer_from_parameters", "prior_from_mixture_set", "gmm_estimate",
+           "AMX_GMM_VITERBI", "AMX_GMM_BAUM_WELCH"]
 
 
 def _ptr(a):
@@ -277,6 +278,12 @@ class GmmFeatureScorer:
                                                  best_density_ld, _ptr(acc_dev)))
 
 
+    def accumulate_weighted_dev(self, mode, feats_dev, T, mixture_dev, weight_dev, best_density_dev, best_density_ld, acc_dev):
+        """weighted Viterbi (mode AMX_GMM_VITERBI) or Baum-Welch (AMX_GMM_BAUM_WELCH) statistics; weight_dev f64 per frame or None"""
+        _lib.check(self.L.amx_gmm_accumulate_weighted_dev(self.h, mode, _ptr(feats_dev), T, _ptr(mixture_dev), _ptr(weight_dev),
+                                                          _ptr(best_density_dev), best_density_ld, _ptr(acc_dev)))
+
+
 class NnBatchFeatureScorer:
     """Nn::BatchFeatureScorer: Ws[l] is [out, in] (RASR weights_[0] is the same memory, [in x out] col-major)."""
 
@@ -326,11 +333,8 @@ class NnBatchFeatureScorer:
                                                    _ptr(counts), _ptr(score_sum)))
 
 
-def read_pms(path):
-    """text mixture set -> model dict (see GmmFeatureScorer)"""
+def _mixture_set_to_dict(h):
     L = _lib.lib()
-    h = C.c_void_p()
-    _lib.check(L.amx_pms_read(path.encode(), C.byref(h)))
     try:
         v = _lib.GmmModel()
         _lib.check(L.amx_mixture_set_view(h, C.byref(v)))
@@ -349,6 +353,36 @@ def read_pms(path):
                     variances=arr(v.variances, C.c_float, (v.n_cov, v.dim)))
     finally:
         L.amx_mixture_set_destroy(h)
+
+
+def read_pms(path):
+    """text mixture set -> model dict (see GmmFeatureScorer)"""
+    h = C.c_void_p()
+    _lib.check(_lib.lib().amx_pms_read(path.encode(), C.byref(h)))
+    return _mixture_set_to_dict(h)
+
+
+def gmm_estimate(model, acc, **cfg):
+    """Re-estimation (and, with split=True, splitting) from the flat f64 statistics: Mm::AbstractMixtureSetEstimator::estimate /
+    Mm::MixtureSetSplitter::split.  `model` is the model dict the statistics were accumulated with; keyword arguments are the
+    fields of amx_gmm_estimate_cfg.  Returns the new model dict."""
+    L = _lib.lib()
+    c = _lib.GmmEstimateCfg()
+    L.amx_gmm_estimate_cfg_default(C.byref(c))
+    for k, v in cfg.items():
+        if not hasattr(c, k):
+            raise TypeError("unknown estimate option %r" % k)
+        setattr(c, k, v)
+    keep = []
+    st = _gmm_struct(model, 1.0, 1.0, keep)
+    a = np.ascontiguousarray(acc, dtype=np.float64)
+    nk = int(np.asarray(model["mix_offsets"])[-1])
+    need = nk + st.n_mean * (1 + st.dim) + st.n_cov * (1 + st.dim)
+    if a.size != need:
+        raise ValueError("accumulator has %d entries, expected %d" % (a.size, need))
+    h = C.c_void_p()
+    _lib.check(L.amx_gmm_estimate(C.byref(st), a.ctypes.data, C.byref(c), C.byref(h)))
+    return _mixture_set_to_dict(h)
 
 
 def write_pms(model, path):

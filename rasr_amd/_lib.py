@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(_HERE, "librasr_amd.so")
 
 AMX_OK, AMX_ERR_INVALID, AMX_ERR_UNSUPPORTED, AMX_ERR_DEVICE, AMX_ERR_STATE = 0, -1, -2, -3, -4
 AMX_GMM_MAX, AMX_GMM_SUM, AMX_GMM_BATCH_FLOAT = 0, 1, 2
+AMX_GMM_VITERBI, AMX_GMM_BAUM_WELCH = 0, 1
 AMX_ACT_NONE, AMX_ACT_RELU, AMX_ACT_SIGMOID, AMX_ACT_TANH = 0, 1, 2, 3
 AMX_PREC_FP32, AMX_PREC_BF16 = 0, 1
 AMX_ARCHIVE_READ, AMX_ARCHIVE_WRITE = 0, 1
@@ -41,6 +42,13 @@ class GmmModel(C.Structure):
                 ("mix_offsets", C.c_void_p), ("dens_index", C.c_void_p), ("log_weight", C.c_void_p),
                 ("dens_mean", C.c_void_p), ("dens_cov", C.c_void_p), ("means", C.c_void_p),
                 ("variances", C.c_void_p), ("mixture_weight_scale", C.c_float), ("gaussian_scale", C.c_float)]
+
+
+class GmmEstimateCfg(C.Structure):
+    _fields_ = [("min_observation_weight", C.c_double), ("min_relative_weight", C.c_double), ("min_variance", C.c_double),
+                ("normalize_mixture_weights", C.c_int), ("allow_zero_weights", C.c_int), ("split", C.c_int),
+                ("split_min_mean_observation_weight", C.c_double), ("split_min_covariance_observation_weight", C.c_double),
+                ("split_perturbation_weight", C.c_double), ("split_normalize_mixture_weights", C.c_int)]
 
 
 class FfnnModel(C.Structure):
@@ -89,6 +97,9 @@ SIGNATURES = {
     "amx_gmm_score_stats_dev": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P, _P]),
     "amx_gmm_accumulator_size": (C.c_long, [_P]),
     "amx_gmm_accumulate_dev": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, _P]),
+    "amx_gmm_accumulate_weighted_dev": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, _P, _P, C.c_int, _P]),
+    "amx_gmm_estimate_cfg_default": (None, [C.POINTER(GmmEstimateCfg)]),
+    "amx_gmm_estimate": (C.c_int, [C.POINTER(GmmModel), _P, C.POINTER(GmmEstimateCfg), C.POINTER(_P)]),
     "amx_gmm_accumulator_write": (C.c_int, [_P, _P, C.c_char_p]),
     "amx_gmm_accumulator_read": (C.c_int, [_P, C.c_char_p, _P]),
     "amx_pms_read": (C.c_int, [C.c_char_p, C.POINTER(_P)]),

@@ -398,6 +398,114 @@ __global__ __launch_bounds__(256) void gmm_accumulate_kernel(const float* __rest
     }
 }
 
+// ---- weighted Viterbi / Baum-Welch statistics (Mm/AbstractMixtureSetEstimator.cc:127-147): one wavefront per frame.
+// Baum-Welch: lane = density computes s_k = 0.5 * ((m2lw + logNorm) + distance) in f32 with the reference's distance order
+// (GaussDiagonalSumFeatureScorer::calculateScoresAndNumberOfDensities, Mm/GaussDiagonalMaximumFeatureScorer.cc:239-262), the
+// wave takes the minimum, sums exp(best - s_k) in density order like calculateScoreAndDensity (:264-289), and every density
+// whose weight * exp(score - s_k) exceeds f32 epsilon adds weight * x and (weight * x) * x to its rows (lane = dimension).
+// Pooled covariance: all frames hit one row, so a wave keeps that row's sums in registers over its frames.
+constexpr int kBwMaxDens   = 4096;  // densities per mixture the LDS score buffer holds (4 waves x 16 KB)
+constexpr int kBwFramesPerWave = 16;
+
+__global__ __launch_bounds__(256) void gmm_accumulate_weighted_kernel(
+        int mode, const float* __restrict__ feats, const uint32_t* __restrict__ mixture, const double* __restrict__ weight,
+        const uint32_t* __restrict__ best, int best_ld, int T, int dim, const uint32_t* __restrict__ mix_off,
+        const uint32_t* __restrict__ k_dens, const uint32_t* __restrict__ d_mean, const uint32_t* __restrict__ d_cov,
+        const float* __restrict__ k_c32, const float* __restrict__ means, const float* __restrict__ isr, double* __restrict__ acc,
+        long long off_mw, long long off_ms, long long off_cw, long long off_cs, int pooled) {
+    __shared__ float s_p[4][kBwMaxDens];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float*    sp   = s_p[wave];
+    double    pc[4] = {0, 0, 0, 0};
+    double    pcw   = 0;
+    const int t_begin = (blockIdx.x * 4 + wave) * kBwFramesPerWave;
+    for (int t = t_begin; t < min(t_begin + kBwFramesPerWave, T); ++t) {
+        const uint32_t m  = mixture[t];
+        const uint32_t k0 = mix_off[m], nd = mix_off[m + 1] - k0;
+        const float*   x  = feats + (size_t)t * dim;
+        const double   w  = weight ? weight[t] : 1.0;
+        uint32_t       j_lo = 0, j_hi = nd;
+        if (mode == 1) {
+            float lmin = FLT_MAX;
+            for (uint32_t j = lane; j < nd; j += 64) {
+                const uint32_t d  = k_dens[k0 + j];
+                const float*   mu = means + (size_t)d_mean[d] * dim;
+                const float*   is = isr + (size_t)d_cov[d] * dim;
+                float          l0 = 0.f, l1 = 0.f, l2 = 0.f, l3 = 0.f;
+                const int      eff = dim & ~3;
+                for (int i = 0; i < eff; i += 4) {
+                    const float d0 = (mu[i] - x[i]) * is[i], d1 = (mu[i + 1] - x[i + 1]) * is[i + 1];
+                    const float d2 = (mu[i + 2] - x[i + 2]) * is[i + 2], d3 = (mu[i + 3] - x[i + 3]) * is[i + 3];
+                    l0 = l0 + d0 * d0;
+                    l1 = l1 + d1 * d1;
+                    l2 = l2 + d2 * d2;
+                    l3 = l3 + d3 * d3;
+                }
+                float dist = 0.f;
+                dist       = dist + ((l0 + l1) + (l2 + l3));
+                for (int i = eff; i < dim; ++i) {
+                    const float df = (mu[i] - x[i]) * is[i];
+                    dist           = dist + df * df;
+                }
+                const float sk = 0.5f * (k_c32[k0 + j] + dist);
+                sp[j]          = sk;
+                lmin           = fminf(lmin, sk);
+            }
+            for (int o = 32; o > 0; o >>= 1)
+                lmin = fminf(lmin, __shfl_xor(lmin, o));
+            __builtin_amdgcn_wave_barrier();  // LDS traffic of one wave is ordered; this only pins the compiler's schedule
+            float sum_exp = 0.f;
+            for (uint32_t j = 0; j < nd; ++j)  // density order, like the reference's loop (all lanes compute the same sum)
+                sum_exp += expf(lmin - sp[j]);
+            const float log_den = lmin - logf(sum_exp);
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t j = lane; j < nd; j += 64)
+                sp[j] = expf(log_den - sp[j]);  // the posterior; each lane rewrites only its own entries
+        }
+        else {
+            const uint32_t kk = best_ld > 0 ? best[(size_t)t * best_ld + m] : best[t];
+            j_lo              = kk;
+            j_hi              = kk + 1;
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t j = j_lo; j < j_hi; ++j) {
+            double fw = w;
+            if (mode == 1) {
+                fw = w * (double)sp[j];
+                if (!(fw > (double)FLT_EPSILON))
+                    continue;
+            }
+            const uint32_t k  = k0 + j;
+            const uint32_t d  = k_dens[k];
+            const uint32_t mi = d_mean[d], ci = d_cov[d];
+            if (lane == 0) {
+                atomicAdd(&acc[k], fw);
+                atomicAdd(&acc[off_mw + mi], fw);
+                if (!pooled)
+                    atomicAdd(&acc[off_cw + ci], fw);
+            }
+            pcw += fw;
+            for (int i = lane, c = 0; i < dim; i += 64, ++c) {
+                const double y  = (double)x[i];
+                const double wy = fw * y;
+                atomicAdd(&acc[off_ms + (long long)mi * dim + i], wy);
+                if (pooled && c < 4)
+                    pc[c] += wy * y;
+                else
+                    atomicAdd(&acc[off_cs + (long long)ci * dim + i], wy * y);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (pooled) {
+        for (int i = lane, c = 0; i < dim && c < 4; i += 64, ++c)
+            if (pc[c] != 0.0)
+                atomicAdd(&acc[off_cs + i], pc[c]);
+        if (lane == 0 && pcw != 0.0)
+            atomicAdd(&acc[off_cw], pcw);
+    }
+}
+
 // ---- two-stage path for tied models
 struct GmmDistParams {
     const float* __restrict__ feats;     // [T x dim] (chunk)
@@ -2051,6 +2159,38 @@ int amx_gmm_accumulate_dev(amx_gmm* h, const float* feats_dev, int T, const uint
     hipLaunchKernelGGL(amx::gmm_accumulate_kernel, dim3(blocks), dim3(256), 0, h->ctx->stream, feats_dev, mixture_dev, best_density_dev,
                        best_density_ld, T, h->dim, h->d_mix_off, h->d_k_dens, h->d_d_mean, h->d_d_cov, acc_dev, off_mw, off_ms, off_cw,
                        off_cs, pooled);
+    AMX_HIP(hipGetLastError());
+    return AMX_OK;
+}
+
+int amx_gmm_accumulate_weighted_dev(amx_gmm* h, int mode, const float* feats_dev, int T, const uint32_t* mixture_dev,
+                                    const double* weight_dev, const uint32_t* best_density_dev, int best_density_ld, double* acc_dev) {
+    AMX_REQUIRE(h, AMX_ERR_INVALID, "amx_gmm_accumulate_weighted_dev: NULL handle");
+    AMX_REQUIRE(h->ctx, AMX_ERR_STATE, "amx_gmm_accumulate_weighted_dev: host-only handle (created without a context)");
+    AMX_REQUIRE(mode == AMX_GMM_VITERBI || mode == AMX_GMM_BAUM_WELCH, AMX_ERR_INVALID, "amx_gmm_accumulate_weighted_dev: unknown mode %d", mode);
+    AMX_REQUIRE(T >= 0 && (best_density_ld == 0 || best_density_ld >= h->n_mix), AMX_ERR_INVALID, "amx_gmm_accumulate_weighted_dev: bad shape");
+    if (T == 0)
+        return AMX_OK;
+    AMX_REQUIRE(feats_dev && mixture_dev && acc_dev && (mode == AMX_GMM_BAUM_WELCH || best_density_dev), AMX_ERR_INVALID,
+                "amx_gmm_accumulate_weighted_dev: NULL buffer");
+    if (mode == AMX_GMM_BAUM_WELCH) {
+        uint32_t kmax = 0;
+        for (int m = 0; m < h->n_mix; ++m)
+            kmax = std::max(kmax, h->mix_off[m + 1] - h->mix_off[m]);
+        AMX_REQUIRE(kmax <= (uint32_t)amx::kBwMaxDens, AMX_ERR_UNSUPPORTED,
+                    "amx_gmm_accumulate_weighted_dev: Baum-Welch statistics support up to %d densities per mixture (model has %u)",
+                    amx::kBwMaxDens, kmax);
+    }
+    AMX_HIP(hipSetDevice(h->ctx->device));
+    const long long off_mw = (long long)h->nk, off_ms = off_mw + h->n_mean, off_cw = off_ms + (long long)h->n_mean * h->dim,
+                    off_cs = off_cw + h->n_cov;
+    const int              pooled = (h->n_cov == 1) ? 1 : 0;
+    const int              per_block = 4 * amx::kBwFramesPerWave;
+    const int              blocks = (T + per_block - 1) / per_block;
+    amx::ScopedKernelTimer timer(h->ctx, "gmm_accumulate_weighted");
+    hipLaunchKernelGGL(amx::gmm_accumulate_weighted_kernel, dim3(blocks), dim3(256), 0, h->ctx->stream, mode, feats_dev, mixture_dev,
+                       weight_dev, best_density_dev, best_density_ld, T, h->dim, h->d_mix_off, h->d_k_dens, h->d_d_mean, h->d_d_cov,
+                       h->d_k_c32, h->d_means, h->d_isr, acc_dev, off_mw, off_ms, off_cw, off_cs, pooled);
     AMX_HIP(hipGetLastError());
     return AMX_OK;
 }

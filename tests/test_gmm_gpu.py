@@ -359,3 +359,104 @@ def test_workspaces_regrow_between_calls(ctx):
     from oracle import OracleGmm
     osc, _ = OracleGmm(model).score(x[:50], mode=0)
     assert np.array_equal(want[:50].view(np.uint32), osc.view(np.uint32))
+
+
+def _alignment(T, n_mix, seed):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    runs = rng.integers(0, n_mix, T // 7 + 1)
+    return np.repeat(runs, 7)[:T].astype(np.uint32)       # bursty, like an aligned utterance
+
+
+@pytest.mark.parametrize("pooled", [True, False])
+def test_weighted_viterbi_accumulators(ctx, pooled):
+    """accumulate(mixture, x, weight) with viterbi_: the best density takes the frame weight; f64 sums of w*x and (w*x)*x equal the
+    oracle's sequential accumulation up to summation order (1e-12); NULL weights reproduce the unweighted statistics."""
+    import torch
+
+    import rasr_amd
+    from oracle import OracleGmm
+    model = synth.gmm_cart(40, 1, 6, 40, seed=70, pooled=pooled)
+    T = 2500
+    x = feats(T, 40, 71)
+    w = np.random.Generator(np.random.PCG64(72)).uniform(0.0, 2.0, T)
+    w[::17] = 0.0
+    sc, o = rasr_amd.GmmFeatureScorer(ctx, model), OracleGmm(model)
+    mix = _alignment(T, 40, 73)
+    osc, obest = o.score(x)
+    chosen = obest[np.arange(T), mix].astype(np.uint32)
+    ctx.use_torch_stream()
+    xd, md, cd, wd = (torch.from_numpy(a).cuda() for a in (x, mix.astype(np.int32), chosen.astype(np.int32), w))
+    acc = torch.zeros(sc.accumulator_size(), dtype=torch.float64, device="cuda")
+    sc.accumulate_weighted_dev(rasr_amd.AMX_GMM_VITERBI, xd, T, md, wd, cd, 0, acc)
+    torch.cuda.synchronize()
+    want = o.accumulate_weighted(0, x, mix, w, chosen)
+    assert np.allclose(acc.cpu().numpy(), want, rtol=1e-12, atol=1e-9)
+    acc.zero_()
+    sc.accumulate_weighted_dev(rasr_amd.AMX_GMM_VITERBI, xd, T, md, None, cd, 0, acc)
+    torch.cuda.synchronize()
+    assert np.allclose(acc.cpu().numpy(), o.accumulate(x, mix, chosen), rtol=1e-12, atol=1e-9)
+    with pytest.raises(rasr_amd.AmxError):
+        sc.accumulate_weighted_dev(7, xd, T, md, None, cd, 0, acc)
+
+
+@pytest.mark.parametrize("kind", ["cart-pooled", "cart-private", "tied", "odd-dim"])
+def test_baum_welch_accumulators(ctx, kind):
+    """Baum-Welch statistics: density posteriors exp(score(e) - s_k) of the log-add scorer times the frame weight, kept above f32
+    epsilon.  The device's expf / logf differ from glibc's by ulps, so posteriors agree to ~1e-6 relative; a density whose weight
+    sits at the 1.2e-7 threshold may be kept on one side only (absolute term)."""
+    import torch
+
+    import rasr_amd
+    from oracle import OracleGmm
+    model = {"cart-pooled": lambda: synth.gmm_cart(30, 1, 9, 40, seed=80, pooled=True),
+             "cart-private": lambda: synth.gmm_cart(30, 2, 7, 24, seed=81, pooled=False),
+             "tied": lambda: synth.gmm_tied(20, 150, 16, seed=82, pooled=True, alpha=1.0),
+             "odd-dim": lambda: synth.gmm_cart(12, 3, 5, 7, seed=83, pooled=False)}[kind]()
+    dim, n_mix, T = int(model["dim"]), len(model["mix_offsets"]) - 1, 1500
+    x = (feats(T, dim, 84) * 0.6).astype(np.float32)
+    w = np.random.Generator(np.random.PCG64(85)).uniform(0.2, 1.0, T)
+    mix = _alignment(T, n_mix, 86)
+    sc, o = rasr_amd.GmmFeatureScorer(ctx, model), OracleGmm(model)
+    ctx.use_torch_stream()
+    xd, md, wd = (torch.from_numpy(a).cuda() for a in (x, mix.astype(np.int32), w))
+    acc = torch.zeros(sc.accumulator_size(), dtype=torch.float64, device="cuda")
+    sc.accumulate_weighted_dev(rasr_amd.AMX_GMM_BAUM_WELCH, xd, T, md, wd, None, 0, acc)
+    torch.cuda.synchronize()
+    got = acc.cpu().numpy()
+    want = o.accumulate_weighted(1, x, mix, w)
+    nk = int(model["mix_offsets"][-1])
+    assert abs(got[:nk].sum() - w.sum()) < 1e-3 * w.sum()            # posteriors of a frame sum to ~1 (minus the dropped tail)
+    scale = np.abs(want).max()
+    assert np.allclose(got, want, rtol=2e-5, atol=2e-6 * max(scale, 1.0)), np.abs(got - want).max()
+    # more than one density per frame really takes part
+    assert (want[:nk] > 0).sum() > n_mix
+
+
+def test_baum_welch_em_does_not_decrease_likelihood(ctx):
+    """size-independent property of the whole training loop on the device path: log-add scores -> Baum-Welch statistics ->
+    amx_gmm_estimate -> new scorer; the total negative log-likelihood of the aligned frames must not increase (EM)."""
+    import torch
+
+    import rasr_amd
+    rng = np.random.Generator(np.random.PCG64(90))
+    n_mix, K, dim, T = 6, 4, 12, 6000
+    true_mu = rng.standard_normal((n_mix, K, dim)) * 2.5
+    mix = _alignment(T, n_mix, 91)
+    comp = rng.integers(0, K, T)
+    x = (true_mu[mix, comp] + rng.standard_normal((T, dim)) * rng.uniform(0.5, 1.5, dim)).astype(np.float32)
+    model = synth.gmm_cart(n_mix, K, K, dim, seed=92, pooled=False)
+    ctx.use_torch_stream()
+    xd, md = torch.from_numpy(x).cuda(), torch.from_numpy(mix.astype(np.int32)).cuda()
+    nll = []
+    for it in range(4):
+        sc = rasr_amd.GmmFeatureScorer(ctx, model, feature_scorer_type="diagonal-sum")
+        scores = torch.empty((T, n_mix), dtype=torch.float32, device="cuda")
+        sc.score_dev(xd, T, scores, None)
+        nll.append(float(scores[torch.arange(T, device="cuda"), md.long()].double().sum()))
+        acc = torch.zeros(sc.accumulator_size(), dtype=torch.float64, device="cuda")
+        sc.accumulate_weighted_dev(rasr_amd.AMX_GMM_BAUM_WELCH, xd, T, md, None, None, 0, acc)
+        torch.cuda.synchronize()
+        model = rasr_amd.gmm_estimate(model, acc.cpu().numpy(), min_observation_weight=0.0)
+        assert len(model["mix_offsets"]) == n_mix + 1
+    assert all(b <= a + 1e-3 * abs(a) for a, b in zip(nll, nll[1:])), nll
+    assert nll[-1] < nll[0] - 0.05 * abs(nll[0]), nll
