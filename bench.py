@@ -56,7 +56,8 @@ def parse():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--estimation-mode", default="viterbi", choices=["viterbi", "baum-welch"],
                     help="gmm-train: statistics of the best density only, or of every density by its posterior (reference: mode)")
-    ap.add_argument("--gmm-type", default="diagonal-maximum", choices=["diagonal-maximum", "batch-diagonal-maximum-float"])
+    ap.add_argument("--gmm-type", default="diagonal-maximum", choices=["diagonal-maximum", "batch-diagonal-maximum-float", "SIMD-diagonal-maximum"])
+    ap.add_argument("--gmm-frames", type=int, default=256, help="gmm / gmm-tied: frames per step (config 3: 256)")
     return ap.parse_args()
 
 
@@ -391,7 +392,7 @@ class GmmOnly:
         self.nd = len(model["dens_mean"])
         self.gmm_type = args.gmm_type
         self.sc = rasr_amd.GmmFeatureScorer(ctx, model, feature_scorer_type=args.gmm_type)
-        self.T = 256
+        self.T = int(getattr(args, "gmm_frames", 256))
         x = np.random.Generator(np.random.PCG64(4 + rank)).standard_normal((self.T, 40)).astype(np.float32)
         self.x = torch.from_numpy(x).cuda()
         self.scores = torch.empty((self.T, 10000), dtype=torch.float32, device="cuda")
@@ -399,7 +400,7 @@ class GmmOnly:
         self.units = self.T
 
     def step(self):
-        self.sc.score_dev(self.x, self.T, self.scores, None if self.gmm_type != "diagonal-maximum" else self.best)
+        self.sc.score_dev(self.x, self.T, self.scores, None if self.gmm_type == "batch-diagonal-maximum-float" else self.best)
 
     def epoch_reduce(self, world):
         pass
@@ -422,6 +423,18 @@ class GmmOnly:
                         launches=n, flops_per_launch=ops)
         elif self.gmm_type == "diagonal-maximum":
             return gmm_cart_roofline(self.ctx, self.nk, self.T)
+        elif self.gmm_type == "SIMD-diagonal-maximum":
+            # u8 means and features, integer distance: the products run on the i8 matrix pipes (2 x 160 000 x 64 ops per frame fit
+            # 2.5 POP/s many times over), so the bound is the 8 bytes of (score, best density) per frame and mixture that leave
+            ms, n = self.ctx.profile_get("gmm_simd")
+            qs, _ = self.ctx.profile_get("gmm_simd_quantize")
+            if n == 0:
+                return None
+            by = float(self.T) * (10000 * 8 + 40 * 4)
+            ach = by / ((ms + qs) * 1e-3) / 1e9
+            return dict(bound="hbm", kernel="simd_mfma_kernel (+ simd_quantize_kernel)", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=round(ach / HBM_PEAK_GBS, 4), traffic=None, avg_launch_ms=round(ms + qs, 4), launches=n, bytes_per_launch=by,
+                        note="algorithmic bytes = scores + best densities out (8 B per frame and mixture) + features in")
         else:
             ms, n = self.ctx.profile_get("gmm")
             ops = 3.0 * self.nk * 40 * self.T   # batch-float: pre-scaled means, sub/mul/add
@@ -435,7 +448,7 @@ class GmmOnly:
 
     def stage_report(self):
         out = {}
-        for k in ("gmm_screen_pack", "gmm_screen", "gmm", "gmm_dist", "gmm_combine"):
+        for k in ("gmm_screen_pack", "gmm_screen", "gmm", "gmm_dist", "gmm_combine", "gmm_simd_quantize", "gmm_simd", "gmm_simd_dist"):
             ms, n = self.ctx.profile_get(k)
             if n:
                 out[k] = dict(avg_ms=round(ms, 4), launches=n)

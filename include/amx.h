@@ -172,8 +172,11 @@ typedef struct {
 } amx_gmm_model;
 
 /* diagonal-maximum / diagonal-sum / batch-diagonal-maximum-float (Mm/BatchFeatureScorer.cc:164-254: pooled
- * covariance only, no best-density output, ignores the two scales like the reference class) */
-enum { AMX_GMM_MAX = 0, AMX_GMM_SUM = 1, AMX_GMM_BATCH_FLOAT = 2 };
+ * covariance only, no best-density output, ignores the two scales like the reference class) /
+ * SIMD-diagonal-maximum (Mm::SimdGaussDiagonalMaximumFeatureScorer, Mm/SimdFeatureScorer.cc:68-176 with
+ * Mm/IntelOptimization.cc:37-66: means and features times scaling / sigma quantised to u8, integer distance and constant,
+ * first minimum, score = 0.5 * min / scaling^2; assigns densities; ignores the two scales like the reference class) */
+enum { AMX_GMM_MAX = 0, AMX_GMM_SUM = 1, AMX_GMM_BATCH_FLOAT = 2, AMX_GMM_SIMD = 3 };
 
 int  amx_gmm_create(amx_ctx* ctx, const amx_gmm_model* model, amx_gmm** out); /* copies everything */
 void amx_gmm_destroy(amx_gmm* h);
@@ -182,6 +185,9 @@ int  amx_gmm_dimension(const amx_gmm* h);
 /* host copies of the prepared scorer tables (Mm/MixtureFeatureScorerElement.cc:21-33,
  * Mm/CovarianceFeatureScorerElement.cc:21-51); any pointer may be NULL */
 int amx_gmm_tables(const amx_gmm* h, float* minus2_log_weights, float* inv_sqrt_var, float* log_norm);
+/* quantisation scaling factor of the SIMD-diagonal-maximum scorer (SimdGaussDiagonalMaximumFeatureScorer::getScaling,
+ * logged as "Scaling factor"); 0 for a host-only handle */
+float amx_gmm_simd_scaling(const amx_gmm* h);
 /* scores [T x n_mix]; best_density (nullable) [T x n_mix] = index within the mixture of the
  * minimising density (AssigningFeatureScorer::ScoreAndBestDensity). */
 int amx_gmm_score(amx_gmm* h, int mode, const float* feats_host, int T, float* scores_host, uint32_t* best_density_host);

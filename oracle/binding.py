@@ -97,6 +97,10 @@ def Oracle():
     L.orc_gmm_score.argtypes = [C.c_void_p, C.c_int, f32p, C.c_int, f32p, C.c_void_p]
     L.orc_gmm_score_batch_float.restype = C.c_int
     L.orc_gmm_score_batch_float.argtypes = [C.c_void_p, f64p, f32p, f32p, C.c_int, f32p]
+    L.orc_gmm_score_simd.restype = C.c_int
+    L.orc_gmm_score_simd.argtypes = [C.c_void_p, f64p, f32p, f32p, C.c_int, f32p, C.c_void_p, C.c_void_p]
+    L.orc_quantize.restype = C.c_uint
+    L.orc_quantize.argtypes = [C.c_float]
     L.orc_gmm_accumulator_size.restype = C.c_long
     L.orc_gmm_accumulator_size.argtypes = [C.c_void_p]
     L.orc_gmm_accumulate.argtypes = [C.c_void_p, f32p, C.c_int, u32p, u32p, f64p]
@@ -372,6 +376,33 @@ class OracleGmm:
         if r != 0:
             raise ValueError("batch-float scorer supports only a globally pooled covariance")
         return sc
+
+
+def _simd(self, feats):
+    """SIMD-diagonal-maximum: (scores, best density, scaling)"""
+    feats = np.ascontiguousarray(feats, dtype=np.float32)
+    T = feats.shape[0]
+    sc = np.zeros((T, self.n_mix), np.float32)
+    best = np.zeros((T, self.n_mix), np.uint32)
+    scaling = C.c_float()
+    self.L.orc_gmm_score_simd(self.h, self.m["log_weight"], self.m["variances"].reshape(-1), feats.reshape(-1), T, sc.reshape(-1),
+                              best.ctypes.data, C.addressof(scaling))
+    return sc, best, scaling.value
+
+
+OracleGmm.score_simd = _simd
+
+
+def oracle_quantize(v):
+    return int(Oracle().orc_quantize(float(np.float32(v))))
+
+
+def ref_quantize(v):
+    """the reference's quantize<f32, u8> functor (Mm/Utilities.hh:190-202) through libref"""
+    R = load_ref()
+    R.ref_quantize_u8.restype = C.c_uint
+    R.ref_quantize_u8.argtypes = [C.c_float]
+    return int(R.ref_quantize_u8(float(np.float32(v))))
 
 
 def oracle_ffnn_score(Ws, biases, acts, feats, log_prior=None, prior_scale=1.0, acc64=False):

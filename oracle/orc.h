@@ -116,6 +116,12 @@ void orc_gmm_score(const orc_gmm* h, int mode, const float* feats, int T, float*
 int orc_gmm_score_batch_float(const orc_gmm* h, const double* log_weight, const float* variances,
                               const float* feats, int T, float* scores);
 
+/* Mm::SimdGaussDiagonalMaximumFeatureScorer ("SIMD-diagonal-maximum"): u8-quantised means and features, integer distance;
+ * scaling_out (nullable) receives the quantisation scaling factor */
+int      orc_gmm_score_simd(const orc_gmm* h, const double* log_weight, const float* variances, const float* feats, int T,
+                            float* scores, uint32_t* best, float* scaling_out);
+unsigned orc_quantize(float v);
+
 /* Viterbi training statistics: see orc_score.c for the accumulator layout */
 long orc_gmm_accumulator_size(const orc_gmm* h);
 void orc_gmm_accumulate(const orc_gmm* h, const float* feats, int T, const uint32_t* mixture,

@@ -239,6 +239,114 @@ int orc_gmm_score_batch_float(const orc_gmm* h, const double* log_weight, const 
     return 0;
 }
 
+/* Mm::SimdGaussDiagonalMaximumFeatureScorer ("SIMD-diagonal-maximum", Mm/SimdFeatureScorer.cc:68-176) with
+ * Mm::FeatureScorerIntelOptimization (Mm/IntelOptimization.cc:37-66) and quantize<f32,u8> (Mm/Utilities.hh:190-202):
+ *   init (:68-82)        scaling = quantizationScalingFactor(min, max of mean * 1/sigma over all densities) (:112-137):
+ *                        (f32)255 / (1.25 * 2*max(|min|,|max|)); scalingSquared = scaling^2 (f32); every covariance element
+ *                        is scaled: 1/sigma *= scaling, logNorm *= scaling*scaling (Mm/CovarianceFeatureScorerElement.cc:46-52)
+ *   per density (:84-109) constantWeight = (s32)((f32)((f64)(scalingSquared * -2) * logWeight) + logNorm);
+ *                        preparedMean[i] = quantize(mean[i] * scaled 1/sigma[i]) = clip((int)round(v) + 128, 0, 255), zero padded
+ *   per frame (:22-35)   one quantised feature vector per covariance: quantize(x[i] * scaled 1/sigma_c[i])
+ *   score (:139-176)     min over the mixture's densities of constantWeight + sum (mean - feature)^2 in int, strict '<' (first
+ *                        minimum); the SSE2 routine (Mm/SSE2CodeGenerator.cc: psubusb both ways, punpck, pmaddwd, paddd) is the
+ *                        exact integer sum; score = (f32)(0.5 * min / scalingSquared) in f64; neither scale parameter is used.
+ * (int)round(v) outside the int range is undefined in C; like the reference's x86-64 build this code relies on cvttsd2si
+ * returning INT_MIN. */
+static uint8_t orc_quantize_u8(float v) {
+    int q = (int)round(v) + 128;
+    if (q < 0)
+        q = 0;
+    if (q > 255)
+        q = 255;
+    return (uint8_t)q;
+}
+
+int orc_gmm_score_simd(const orc_gmm* h, const double* log_weight, const float* variances, const float* feats, int T, float* scores,
+                       uint32_t* best, float* scaling_out) {
+    const int dim = h->dim;
+    size_t    nk  = h->mix_off[h->n_mix];
+    float*    isr = (float*)malloc((size_t)h->n_cov * dim * 4);
+    float*    lognorm = (float*)malloc((size_t)h->n_cov * 4);
+    for (int c = 0; c < h->n_cov; ++c) {
+        double ln = 0;
+        for (int i = 0; i < dim; ++i) {
+            float v                 = variances[(size_t)c * dim + i];
+            isr[(size_t)c * dim + i] = (float)1 / (float)sqrt((double)v);
+            ln += log((double)fabsf(v));
+        }
+        lognorm[c] = (float)((double)dim * log((double)2 * M_PI) + ln);
+    }
+    float minMean = FLT_MAX, maxMean = -FLT_MAX;
+    for (int d = 0; d < h->n_dens; ++d) {
+        const float* mu = h->means + (size_t)h->dens_mean[d] * dim;
+        const float* is = isr + (size_t)h->dens_cov[d] * dim;
+        for (int i = 0; i < dim; ++i) {
+            float dm = mu[i] * is[i];
+            minMean  = dm < minMean ? dm : minMean;
+            maxMean  = maxMean < dm ? dm : maxMean;
+        }
+    }
+    float amin = fabsf(minMean), amax = fabsf(maxMean);
+    float intervalSize = 2 * (amin < amax ? amax : amin);
+    float scaling      = (float)((float)255 / (1.25 * intervalSize));
+    float scaling2     = scaling * scaling;
+    if (scaling_out)
+        *scaling_out = scaling;
+    for (int c = 0; c < h->n_cov; ++c) {
+        for (int i = 0; i < dim; ++i)
+            isr[(size_t)c * dim + i] = isr[(size_t)c * dim + i] * scaling;
+        lognorm[c] = lognorm[c] * (scaling * scaling);
+    }
+    uint8_t* qmean = (uint8_t*)malloc((size_t)h->n_dens * dim);
+    for (int d = 0; d < h->n_dens; ++d)
+        for (int i = 0; i < dim; ++i)
+            qmean[(size_t)d * dim + i] = orc_quantize_u8(h->means[(size_t)h->dens_mean[d] * dim + i] * isr[(size_t)h->dens_cov[d] * dim + i]);
+    int32_t* cst = (int32_t*)malloc((nk ? nk : 1) * 4);
+    for (size_t k = 0; k < nk; ++k) {
+        double scaledM2lw = (double)(scaling2 * -2) * log_weight[k];
+        float  asScore    = (float)scaledM2lw;
+        cst[k]            = (int32_t)(asScore + lognorm[h->dens_cov[h->dens_index[k]]]);
+    }
+    uint8_t* qx = (uint8_t*)malloc((size_t)h->n_cov * dim);
+    for (int t = 0; t < T; ++t) {
+        const float* x = feats + (size_t)t * dim;
+        for (int c = 0; c < h->n_cov; ++c)
+            for (int i = 0; i < dim; ++i)
+                qx[(size_t)c * dim + i] = orc_quantize_u8(x[i] * isr[(size_t)c * dim + i]);
+        for (int m = 0; m < h->n_mix; ++m) {
+            int      minScore = INT32_MAX;
+            uint32_t bestDns  = UINT32_MAX;
+            for (uint32_t k = h->mix_off[m]; k < h->mix_off[m + 1]; ++k) {
+                uint32_t       d  = h->dens_index[k];
+                const uint8_t* a  = qmean + (size_t)d * dim;
+                const uint8_t* b  = qx + (size_t)h->dens_cov[d] * dim;
+                int            ds = 0;
+                for (int i = 0; i < dim; ++i) {
+                    int df = (int)a[i] - (int)b[i];
+                    ds += df * df;
+                }
+                int score = cst[k] + ds;
+                if (score < minScore) {
+                    minScore = score;
+                    bestDns  = k - h->mix_off[m];
+                }
+            }
+            scores[(size_t)t * h->n_mix + m] = (float)(0.5 * minScore / scaling2);
+            if (best)
+                best[(size_t)t * h->n_mix + m] = bestDns;
+        }
+    }
+    free(isr);
+    free(lognorm);
+    free(qmean);
+    free(cst);
+    free(qx);
+    return 0;
+}
+
+/* the quantiser alone, for pinning against the reference's functor */
+unsigned orc_quantize(float v) { return orc_quantize_u8(v); }
+
 /* ------------------------------------------------------------------ Viterbi accumulation (training statistics)
  * Mm::AbstractMixtureSetEstimator::accumulate(mixture, x) with viterbi_ = true
  * (Mm/AbstractMixtureSetEstimator.cc:117-125): the density with the best score of the aligned mixture gets

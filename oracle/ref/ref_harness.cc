@@ -247,4 +247,9 @@ void ref_normalized_minus(const double* x, const double* y, int n, double weight
     std::copy(r.begin(), r.end(), out);
 }
 
+// quantize<f32, u8> of the SIMD-diagonal-maximum scorer (Mm/Utilities.hh:190-202)
+unsigned ref_quantize_u8(float v) {
+    return Mm::quantize<float, unsigned char>()(v);
+}
+
 }  // extern "C"

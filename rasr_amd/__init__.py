@@ -202,7 +202,7 @@ def _gmm_struct(model, mixture_weight_scale, gaussian_scale, keep):
 
 class GmmFeatureScorer:
     """Mm::FeatureScorer over a mixture set; feature_scorer_type in {"diagonal-maximum", "diagonal-sum",
-    "batch-diagonal-maximum-float"}.
+    "batch-diagonal-maximum-float", "SIMD-diagonal-maximum"}.
 
     model: dict(dim, mix_offsets u32[M+1], dens_index u32[sumK], log_weight f64[sumK], dens_mean u32[D],
     dens_cov u32[D], means f32[n_mean,dim], variances f32[n_cov,dim]).
@@ -212,7 +212,7 @@ class GmmFeatureScorer:
         # ctx = None: host-only handle (prepared tables, accumulator files); scoring then fails with AMX_ERR_STATE
         self.ctx, self.L = ctx, (ctx.L if ctx is not None else _lib.lib())
         self.mode = {"diagonal-maximum": AMX_GMM_MAX, "diagonal-sum": AMX_GMM_SUM,
-                     "batch-diagonal-maximum-float": AMX_GMM_BATCH_FLOAT}[feature_scorer_type]
+                     "batch-diagonal-maximum-float": AMX_GMM_BATCH_FLOAT, "SIMD-diagonal-maximum": _lib.AMX_GMM_SIMD}[feature_scorer_type]
         keep = []
         st = _gmm_struct(model, mixture_weight_scale, gaussian_scale, keep)
         h = C.c_void_p()
@@ -256,6 +256,10 @@ class GmmFeatureScorer:
         """diagonal-maximum scores plus best state / per-state counts / sum of best scores (arg-min fused where possible)"""
         _lib.check(self.L.amx_gmm_score_stats_dev(self.h, _ptr(feats_dev), T, _ptr(scores_dev), _ptr(best_density), _ptr(best_state),
                                                   _ptr(counts), _ptr(score_sum)))
+
+    def simd_scaling(self):
+        """quantisation scaling factor of the SIMD-diagonal-maximum scorer"""
+        return float(self.L.amx_gmm_simd_scaling(self.h))
 
     def accumulator_size(self):
         return int(self.L.amx_gmm_accumulator_size(self.h))

@@ -1351,6 +1351,7 @@ struct amx_gmm {
     float *   d_host_f = nullptr, *d_host_s = nullptr;
     uint32_t* d_host_b = nullptr;
     size_t    host_f_cap = 0, host_s_cap = 0, host_b_cap = 0;
+    void*     simd = nullptr;        // SIMD-diagonal-maximum tables and workspaces (gmm_simd.hip)
     float*    d_scr_pmin = nullptr;  // fused statistics: per-tile arg-min partials
     unsigned* d_scr_pidx = nullptr;
     size_t    scr_part_cap = 0;
@@ -1372,6 +1373,11 @@ bool screen_dim_supported(int d) {
         default: return false;
     }
 }
+
+extern "C" int   amx_internal_gmm_simd_create(const amx_gmm_model* m, void** out, float* scaling_out);
+extern "C" void  amx_internal_gmm_simd_destroy(void* p);
+extern "C" float amx_internal_gmm_simd_scaling(const void* p);
+extern "C" int   amx_internal_gmm_simd_score(void* p, amx_ctx* ctx, const float* feats_dev, int T, float* scores_dev, uint32_t* best_dev);
 
 // maximum approximation through the MFMA screen (see gmm_screen_kernel); frames in chunks that bound the mask workspace
 extern "C" int amx_internal_best_state_reduce(amx_ctx*, const float*, const unsigned*, int, int, int, uint32_t*, unsigned long long*, double*);
@@ -1775,6 +1781,11 @@ int amx_gmm_create(amx_ctx* ctx, const amx_gmm_model* m, amx_gmm** out) {
             }
         }
     }
+    // ---- SIMD-diagonal-maximum tables (quantised means, integer constants; gmm_simd.hip)
+    if ((r = amx_internal_gmm_simd_create(m, &h->simd, nullptr)) != AMX_OK) {
+        amx_gmm_destroy(h);
+        return r;
+    }
     *out = h;
     return AMX_OK;
 }
@@ -1787,6 +1798,7 @@ void amx_gmm_destroy(amx_gmm* h) {
         return;
     }
     hipSetDevice(h->ctx->device);
+    amx_internal_gmm_simd_destroy(h->simd);
     hipFree(h->d_mix_off);
     hipFree(h->d_k_mean);
     hipFree(h->d_k_cov);
@@ -1844,7 +1856,7 @@ int amx_gmm_tables(const amx_gmm* h, float* m2lw, float* isr, float* lognorm) {
 int amx_gmm_score_dev(amx_gmm* h, int mode, const float* feats_dev, int T, float* scores_dev, uint32_t* best_dev) {
     AMX_REQUIRE(h, AMX_ERR_INVALID, "amx_gmm_score_dev: NULL handle");
     AMX_REQUIRE(h->ctx, AMX_ERR_STATE, "amx_gmm_score_dev: host-only handle (created without a context)");
-    AMX_REQUIRE(mode == AMX_GMM_MAX || mode == AMX_GMM_SUM || mode == AMX_GMM_BATCH_FLOAT, AMX_ERR_INVALID,
+    AMX_REQUIRE(mode == AMX_GMM_MAX || mode == AMX_GMM_SUM || mode == AMX_GMM_BATCH_FLOAT || mode == AMX_GMM_SIMD, AMX_ERR_INVALID,
                 "amx_gmm_score_dev: unknown mode %d", mode);
     AMX_REQUIRE(T >= 0, AMX_ERR_INVALID, "amx_gmm_score_dev: negative frame count");
     if (T == 0)
@@ -1852,6 +1864,8 @@ int amx_gmm_score_dev(amx_gmm* h, int mode, const float* feats_dev, int T, float
     AMX_REQUIRE(feats_dev && scores_dev, AMX_ERR_INVALID, "amx_gmm_score_dev: NULL buffer");
     AMX_HIP(hipSetDevice(h->ctx->device));
     const int fblocks = amx::ceil_div(T, 256);
+    if (mode == AMX_GMM_SIMD)
+        return amx_internal_gmm_simd_score(h->simd, h->ctx, feats_dev, T, scores_dev, best_dev);
     if (mode == AMX_GMM_BATCH_FLOAT) {
         // Mm::BatchFloatFeatureScorer::init: criticalError("feature scorer supports only globally pooled covariance")
         AMX_REQUIRE(h->pooled, AMX_ERR_INVALID, "amx_gmm_score_dev: feature scorer supports only globally pooled covariance");
@@ -2028,6 +2042,10 @@ int amx_gmm_score_stats_dev(amx_gmm* h, const float* feats_dev, int T, float* sc
     if (r != AMX_OK)
         return r;
     return amx_stats_accumulate_dev(h->ctx, scores_dev, T, h->n_mix, best_state_dev, state_counts_dev, score_sum_dev);
+}
+
+float amx_gmm_simd_scaling(const amx_gmm* h) {
+    return h ? amx_internal_gmm_simd_scaling(h->simd) : 0.f;
 }
 
 long amx_gmm_accumulator_size(const amx_gmm* h) {

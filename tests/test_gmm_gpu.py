@@ -460,3 +460,102 @@ def test_baum_welch_em_does_not_decrease_likelihood(ctx):
         assert len(model["mix_offsets"]) == n_mix + 1
     assert all(b <= a + 1e-3 * abs(a) for a, b in zip(nll, nll[1:])), nll
     assert nll[-1] < nll[0] - 0.05 * abs(nll[0]), nll
+
+
+def assert_simd_exact(ctx, model, x, expect_scaling=True):
+    import rasr_amd
+    from oracle import OracleGmm
+    sc = rasr_amd.GmmFeatureScorer(ctx, model, feature_scorer_type="SIMD-diagonal-maximum")
+    got, best = sc.score(x)
+    want, obest, scaling = OracleGmm(model).score_simd(x)
+    if expect_scaling:
+        assert np.float32(sc.simd_scaling()) == np.float32(scaling)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), np.abs(got - want).max()
+    assert np.array_equal(best, obest)
+    return got
+
+
+@pytest.mark.parametrize("n_mix,dim,T", [(256, 40, 300), (37, 40, 65), (50, 16, 256), (16, 64, 1), (130, 39, 700), (10, 33, 513)])
+def test_simd_scorer_pooled_mfma_exact(ctx, n_mix, dim, T):
+    """SIMD-diagonal-maximum on the i8 MFMA path (pooled covariance, <= 16 densities per mixture): integer scores and the first
+    minimum are exact, so scores and best densities equal the oracle bit for bit; mixture counts that are not multiples of 16 / 4
+    and frame counts that are not multiples of 256 exercise the guarded stores."""
+    model = synth.gmm_cart(n_mix, 1, 16, dim, seed=100 + n_mix, pooled=True)
+    got = assert_simd_exact(ctx, model, feats(T, dim, 101))
+    # the quantised scorer approximates the float one: same best density for most frames, scores within the quantisation error
+    import rasr_amd
+    ref, _ = rasr_amd.GmmFeatureScorer(ctx, model).score(feats(T, dim, 101))
+    assert np.median(np.abs(got - ref)) < 1.0
+
+
+@pytest.mark.parametrize("kind", ["private-cov", "tied", "long-mixtures", "dim-80"])
+def test_simd_scorer_general_path_exact(ctx, kind):
+    """per-density covariances (one quantised feature vector per covariance), tied mixtures, > 16 densities per mixture and
+    dim > 64 take the two-stage integer path"""
+    model = {"private-cov": lambda: synth.gmm_cart(40, 1, 6, 24, seed=110, pooled=False),
+             "tied": lambda: synth.gmm_tied(60, 96, 40, seed=111, pooled=True, alpha=1.0),
+             "long-mixtures": lambda: synth.gmm_cart(12, 17, 40, 40, seed=112, pooled=True),
+             "dim-80": lambda: synth.gmm_cart(20, 1, 8, 80, seed=113, pooled=True)}[kind]()
+    assert_simd_exact(ctx, model, feats(333, int(model["dim"]), 114))
+
+
+def test_simd_scorer_paths_agree_and_edge_values(ctx, monkeypatch):
+    """the MFMA path and the general path give identical results; features far outside the quantiser's range, infinities and NaN
+    follow the reference's x86 behaviour ((int)round(v) -> INT_MIN, +128 wraps, clipped to 0 / 255); an empty mixture keeps the
+    initial INT_MAX score and no density; ties between densities go to the first one"""
+    import rasr_amd
+    model = synth.gmm_cart(45, 1, 16, 40, seed=120, pooled=True)
+    off = model["mix_offsets"]
+    model["means"][off[3] + 1] = model["means"][off[3]]           # twin densities with equal weights: first wins
+    model["log_weight"][off[3] + 1] = model["log_weight"][off[3]]
+    x = feats(200, 40, 121)
+    x[5, 3] = 1e10
+    x[6, 7] = -1e10
+    x[7, 0] = np.inf
+    x[8, 1] = -np.inf
+    x[9, 2] = np.nan
+    x[10] = 3e9
+    x[11] *= 50
+    a = assert_simd_exact(ctx, model, x)
+    monkeypatch.setenv("AMX_GMM_SIMD_MFMA", "0")
+    b = assert_simd_exact(ctx, model, x)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    monkeypatch.delenv("AMX_GMM_SIMD_MFMA")
+    # an empty mixture in the middle of the set
+    ks = np.diff(off).astype(np.int64)
+    ks2 = np.insert(ks, 7, 0)
+    model2 = dict(model)
+    model2["mix_offsets"] = np.concatenate([[0], np.cumsum(ks2)]).astype(np.uint32)
+    got = assert_simd_exact(ctx, model2, x[:70])
+    sc = rasr_amd.GmmFeatureScorer(ctx, model2, feature_scorer_type="SIMD-diagonal-maximum")
+    _, best = sc.score(x[:70])
+    assert np.all(best[:, 7] == 0xffffffff) and np.all(got[:, 7] > 1e5)
+
+
+def test_simd_scorer_large_constants_fall_back(ctx):
+    """weights so small that constant << 4 would not fit the packed key: the model must still score exactly (general path)"""
+    model = synth.gmm_cart(20, 2, 8, 40, seed=130, pooled=True)
+    model["log_weight"] = model["log_weight"] - 4.0e5
+    assert_simd_exact(ctx, model, feats(100, 40, 131))
+
+
+def test_simd_scorer_device_entry_and_chunks(ctx):
+    """device-resident call over more frames than one internal pass handles at the full BASELINE width is covered by the bench;
+    here: results of score_dev equal the host-buffer call, with and without best-density output"""
+    import torch
+
+    import rasr_amd
+    model = synth.gmm_cart(100, 16, 16, 40, seed=140, pooled=True)
+    sc = rasr_amd.GmmFeatureScorer(ctx, model, feature_scorer_type="SIMD-diagonal-maximum")
+    x = feats(1000, 40, 141)
+    want, wbest = sc.score(x)
+    ctx.use_torch_stream()
+    xd = torch.from_numpy(x).cuda()
+    s1 = torch.empty((1000, 100), dtype=torch.float32, device="cuda")
+    b1 = torch.empty((1000, 100), dtype=torch.int32, device="cuda")
+    sc.score_dev(xd, 1000, s1, b1)
+    s2 = torch.empty_like(s1)
+    sc.score_dev(xd, 1000, s2, None)
+    torch.cuda.synchronize()
+    assert np.array_equal(s1.cpu().numpy(), want) and np.array_equal(s2.cpu().numpy(), want)
+    assert np.array_equal(b1.cpu().numpy().astype(np.uint32), wbest)

@@ -246,3 +246,18 @@ def test_batch_float_scorer_close_to_diagonal_maximum():
     assert np.allclose(o.score_batch_float(x), o.score(x)[0], rtol=2e-6)
     with pytest.raises(ValueError):
         OracleGmm(synth.gmm_cart(4, 1, 2, 8, seed=1, pooled=False)).score_batch_float(np.zeros((1, 8), np.float32))
+
+
+def test_quantizer_matches_reference_functor():
+    """quantize<f32, u8> of the SIMD-diagonal-maximum scorer: oracle == the reference's functor (libref, when built) on the rounding
+    boundaries, the clipping limits and the out-of-range inputs whose conversion is undefined in C (x86: INT_MIN)."""
+    from oracle.binding import load_ref, oracle_quantize, ref_quantize
+    vals = [0.0, 0.4, 0.5, -0.5, 1.5, -1.5, 2.5, 126.49, 126.5, 127.4, 127.5, 200.0, -127.5, -128.4, -128.5, -129.0, 1e10, -1e10,
+            float("inf"), float("-inf"), float("nan"), 3e9, -3e9, 2147483520.0, -2147483648.0]
+    known = {0.0: 128, 0.5: 129, -0.5: 127, 1.5: 130, 2.5: 131, 126.5: 255, 127.5: 255, -128.5: 0, 1e10: 0, -1e10: 0}
+    for v in vals:
+        q = oracle_quantize(v)
+        if v in known:
+            assert q == known[v], (v, q)
+        if load_ref() is not None:
+            assert q == ref_quantize(v), (v, q, ref_quantize(v))
