@@ -1080,6 +1080,132 @@ __global__ __launch_bounds__(512) void gmm_screen_persist_kernel(const _Float16*
     }
 }
 
+// The same screen with a wave per 32 frames x all 256 slots of a tile and ONE 32-slot block (two mixtures) in flight at a time:
+// four MFMAs, then that block's reduction, so the matrix pipe works on block i + 1 while the vector pipe reduces block i, with
+// 16 accumulator registers live instead of 128 -- two workgroups fit a CU (the frame tile's fragments move to registers and
+// its LDS region becomes the second slot-tile buffer: 64 KB).  The slot table of this kernel (d_scr_A2) stores slot s of
+// mixture 2b + h of a tile in row b*32 + (s>>2)*8 + h*4 + (s&3): in the 32x32 accumulator layout lane half h then holds all
+// 16 slots of mixture 2b + h for its frame, in slot order -- the minimum and the mask need no cross-lane traffic, and one
+// exchange with the partner lane per tile assembles a frame's 16 masks (32 bytes, 16 per lane).
+__global__ __launch_bounds__(512, 2) void gmm_screen_rows_kernel(const _Float16* __restrict__ g_A, const _Float16* __restrict__ g_X,
+                                                                const float* __restrict__ g_p1, const float* __restrict__ g_p2,
+                                                                const float* __restrict__ g_nx, const float* __restrict__ g_q,
+                                                                uint16_t* __restrict__ g_masks, int n_tiles_r, int r_split, int Mpad16) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr int TILE = 32 * 1024;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile_t = blockIdx.x / r_split, part = blockIdx.x % r_split;
+    const int per = (n_tiles_r + r_split - 1) / r_split;
+    const int r_begin = part * per, r_end = min(n_tiles_r, r_begin + per);
+    if (r_begin >= r_end)
+        return;
+    const int t0 = tile_t * 256;
+    const int xr = ((wave & 1) * 4 + (lane >> 4)) & 7;
+    const size_t off = (size_t)(wave * 8 + (lane >> 3)) * 64 + (((lane & 7) ^ xr) << 3);
+    auto load_tile = [&](const _Float16* base, char* dst) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((const void*)(base + off + (size_t)i * 64 * 64),
+                                             (__attribute__((address_space(3))) void*)(dst + wave * 1024 + i * 8 * 1024), 16, 0, 0);
+    };
+    load_tile(g_X + (size_t)t0 * 64, lds + TILE);
+    load_tile(g_A + (size_t)r_begin * 256 * 64, lds);
+    const int   frow = lane & 31, fk = lane >> 5;
+    const int   t    = t0 + wave * 32 + frow;
+    const float nx = g_nx[t], q = g_q[t];
+    const bool  all = !(nx < __builtin_inff());  // operand row did not fit f16: keep every slot
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    gmm_f16x8 bx[4];
+    {
+        const int rr = wave * 32 + frow;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            bx[ks] = *(const gmm_f16x8*)(lds + TILE + rr * 128 + (((ks * 2 + fk) ^ ((rr >> 1) & 7)) << 4));
+    }
+    float p1n[8], p2n[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        p1n[i] = g_p1[r_begin * 16 + i * 2 + fk];
+        p2n[i] = g_p2[r_begin * 16 + i * 2 + fk];
+    }
+    for (int r = r_begin; r < r_end; ++r) {
+        const int buf = (r - r_begin) & 1;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // my share of tile r is in LDS (and my frame fragments are read)
+        __builtin_amdgcn_s_barrier();                                // ... everybody's, and the other buffer is free
+        if (r + 1 < r_end)
+            load_tile(g_A + (size_t)(r + 1) * 256 * 64, lds + (buf ^ 1) * TILE);
+        float p1v[8], p2v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            p1v[i] = p1n[i];
+            p2v[i] = p2n[i];
+        }
+        if (r + 1 < r_end) {  // the next tile's per-mixture threshold terms: a round trip to L2 that must not sit in front of
+                              // the first block's reduction
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                p1n[i] = g_p1[(r + 1) * 16 + i * 2 + fk];
+                p2n[i] = g_p2[(r + 1) * 16 + i * 2 + fk];
+            }
+        }
+        const char* abase = lds + buf * TILE;
+        unsigned    P[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int  rr = i * 32 + frow;
+            gmm_f32x16 c;
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                c[e] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const gmm_f16x8 a = *(const gmm_f16x8*)(abase + rr * 128 + (((ks * 2 + fk) ^ ((rr >> 1) & 7)) << 4));
+                c                 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bx[ks], c, 0, 0, 0);
+            }
+            float mn = min3_raw(c[0], c[1], c[2]);
+            mn       = min3_raw(mn, c[3], c[4]);
+            mn       = min3_raw(mn, c[5], c[6]);
+            mn       = min3_raw(mn, c[7], c[8]);
+            mn       = min3_raw(mn, c[9], c[10]);
+            mn       = min3_raw(mn, c[11], c[12]);
+            mn       = min3_raw(mn, c[13], c[14]);
+            mn       = min3_raw(mn, c[15], c[15]);
+            // tau as in gmm_screen_epilogue: p1 = 2.2e-3 na + 1.3e-4 sqrtK, p2 = 1.3e-4 sqrtK na + 1.6e-5 cabs, q per frame
+            const float thr = mn + fmaf(nx, p1v[i], fmaf(fabsf(mn), 1.6e-5f, p2v[i] + q)) + 1e-30f;
+            unsigned    bits = 0;  // bit k = "slot k is above the threshold", filled from the top down
+#pragma unroll
+            for (int e = 14; e >= 0; e -= 2) {
+                const gmm_pk2 dd = gmm_pk2{thr, thr} - gmm_pk2{c[e], c[e + 1]};
+                bits             = __builtin_amdgcn_alignbit(bits, __float_as_uint(dd.y), 31);  // (bits << 1) | sign(thr - g)
+                bits             = __builtin_amdgcn_alignbit(bits, __float_as_uint(dd.x), 31);
+            }
+            const unsigned m16 = all ? 0xffffu : (~bits & 0xffffu);
+            P[i >> 1] |= m16 << (16 * (i & 1));
+        }
+        // a frame's 16 masks: this lane holds mixtures i*2 + fk, the partner lane the others; lane half 0 writes masks 0..7,
+        // half 1 masks 8..15, so each needs two of the partner's packed pairs
+        const unsigned qa = (unsigned)__shfl_xor((int)(fk ? P[0] : P[2]), 32, 64);
+        const unsigned qb = (unsigned)__shfl_xor((int)(fk ? P[1] : P[3]), 32, 64);
+        const unsigned pa = fk ? P[2] : P[0], pb = fk ? P[3] : P[1];
+        uint4          w;
+        if (fk == 0) {  // mine are the even mixtures (low halves)
+            w.x = (pa & 0xffffu) | (qa << 16);
+            w.y = (pa >> 16) | (qa & 0xffff0000u);
+            w.z = (pb & 0xffffu) | (qb << 16);
+            w.w = (pb >> 16) | (qb & 0xffff0000u);
+        }
+        else {
+            w.x = (qa & 0xffffu) | (pa << 16);
+            w.y = (qa >> 16) | (pa & 0xffff0000u);
+            w.z = (qb & 0xffffu) | (pb << 16);
+            w.w = (qb >> 16) | (pb & 0xffff0000u);
+        }
+        *(uint4*)(g_masks + (size_t)t * Mpad16 + r * 16 + fk * 8) = w;
+    }
+}
+
 __host__ __device__ constexpr int gmm_exact_ld(int dim, bool pooled) {
     return (pooled || dim < 64) ? 4 * (((dim + 3) / 4) | 1) : ((dim + 3) & ~3);
 }
@@ -1341,6 +1467,7 @@ struct amx_gmm {
     int       scr_Kp = 0, scr_Rpad = 0, scr_Mpad16 = 0;
     float     scr_rmax2 = 0.f;
     _Float16* d_scr_A = nullptr;
+    _Float16* d_scr_A2 = nullptr;  // K = 64 only: the slot rows in gmm_screen_rows_kernel's order
     float *   d_scr_c = nullptr, *d_scr_na = nullptr, *d_scr_cabs = nullptr;
     // per-call workspace of the screen
     _Float16* d_scr_X = nullptr;
@@ -1413,7 +1540,17 @@ int score_screened(amx_gmm* h, const float* feats_dev, int T, float* scores_dev,
         {
             amx::ScopedKernelTimer timer(h->ctx, "gmm_screen");
             const int ntr = h->scr_Rpad / 256, ntt = Tpad / 256;
-            if (h->scr_Kp == 64 && !getenv("AMX_GMM_SCREEN_SIMPLE")) {
+            const char* variant = getenv("AMX_GMM_SCREEN_KERNEL");  // rows (default) | persist | simple
+            if (h->scr_Kp == 64 && (!variant || !strcmp(variant, "rows"))) {
+                auto      k   = amx::gmm_screen_rows_kernel;
+                const int lds = 2 * 32 * 1024;
+                hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                // two workgroups per CU, each a frame tile x a contiguous range of slot tiles
+                const int split = std::max(1, std::min(ntr, (2 * std::max(h->ctx->n_cu, 8) + ntt - 1) / ntt));
+                hipLaunchKernelGGL(k, dim3(ntt * split), dim3(512), lds, st, h->d_scr_A2, h->d_scr_X, h->d_scr_na, h->d_scr_cabs, h->d_scr_nx,
+                                   h->d_scr_q, h->d_scr_masks, ntr, split, h->scr_Mpad16);
+            }
+            else if (h->scr_Kp == 64 && strcmp(variant, "simple")) {
                 auto      k   = amx::gmm_screen_persist_kernel;
                 const int lds = 3 * 32 * 1024 + 2048;
                 hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -1717,6 +1854,7 @@ int amx_gmm_create(amx_ctx* ctx, const amx_gmm_model* m, amx_gmm** out) {
         if (kmax >= 1 && kmax <= 16 && Kd + 2 <= 128) {  // two more K columns carry the per-density constant as c_hi + c_lo
             const int Kp = Kd + 2 <= 64 ? 64 : 128, Rpad = (m->n_mix * 16 + 255) / 256 * 256, Mp = Rpad / 16;
             std::vector<_Float16> A((size_t)Rpad * Kp, (_Float16)0.f);
+            std::vector<size_t>   row2(Kp == 64 ? (size_t)Rpad : 0);  // row of the old order -> row of gmm_screen_rows_kernel's order
             std::vector<float>    c((size_t)Rpad, std::numeric_limits<float>::infinity()), na(Mp, 0.f), cabs(Mp, 0.f);
             bool                  fits = true;
             double                rmax2 = 0;
@@ -1726,6 +1864,8 @@ int amx_gmm_create(amx_ctx* ctx, const amx_gmm_model* m, amx_gmm** out) {
                 for (uint32_t k = m->mix_offsets[i]; k < m->mix_offsets[i + 1]; ++k) {
                     const uint32_t slot = k - m->mix_offsets[i];  // row inside the mixture's 16: see gmm_screen_epilogue
                     const size_t   row  = (size_t)i * 16 + (((slot >> 2) & 1) * 8 + (slot >> 3) * 4 + (slot & 3));
+                    if (Kp == 64)
+                        row2[row] = (size_t)(i >> 4) * 256 + (size_t)((i & 15) >> 1) * 32 + (slot >> 2) * 8 + (i & 1) * 4 + (slot & 3) + 1;
                     const float* mu  = m->means + (size_t)k_mean[k] * d;
                     const float* is  = h->isr.data() + (size_t)k_cov[k] * d;
                     double       cc = c64[k], n2 = 0;
@@ -1772,6 +1912,18 @@ int amx_gmm_create(amx_ctx* ctx, const amx_gmm_model* m, amx_gmm** out) {
                 h->scr_Rpad = Rpad;
                 h->scr_Mpad16 = Mp;
                 h->scr_rmax2 = (float)(rmax2 * 1.000001);
+                if (Kp == 64) {  // the same rows in the second kernel's order; rows that hold no density keep the +inf constant
+                    std::vector<_Float16> A2((size_t)Rpad * Kp, (_Float16)0.f);
+                    for (size_t row = 0; row < (size_t)Rpad; ++row)
+                        A2[row * Kp + Kd] = (_Float16)std::numeric_limits<float>::infinity();
+                    for (size_t row = 0; row < (size_t)Rpad; ++row)
+                        if (row2[row])
+                            memcpy(&A2[(row2[row] - 1) * Kp], &A[row * Kp], (size_t)Kp * sizeof(_Float16));
+                    if ((r = gupload(&h->d_scr_A2, A2.data(), A2.size())) != AMX_OK) {
+                        amx_gmm_destroy(h);
+                        return r;
+                    }
+                }
                 if ((r = gupload(&h->d_scr_A, A.data(), A.size())) != AMX_OK || (r = gupload(&h->d_scr_c, c.data(), c.size())) != AMX_OK ||
                     (r = gupload(&h->d_scr_na, na.data(), na.size())) != AMX_OK || (r = gupload(&h->d_scr_cabs, cabs.data(), cabs.size())) != AMX_OK) {
                     amx_gmm_destroy(h);
@@ -1815,6 +1967,7 @@ void amx_gmm_destroy(amx_gmm* h) {
     hipFree(h->d_dist);
     hipFree(h->d_dist64);
     hipFree(h->d_scr_A);
+    hipFree(h->d_scr_A2);
     hipFree(h->d_scr_c);
     hipFree(h->d_scr_na);
     hipFree(h->d_scr_cabs);
