@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--utt-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--front-end", default="mfcc", choices=["mfcc", "mfplp"],
+                    help="mfcc workload: mfcc.flow (40 cepstra) or mfplp.flow (20 autocorrelation / 16 cepstrum coefficients)")
     ap.add_argument("--estimation-mode", default="viterbi", choices=["viterbi", "baum-welch"],
                     help="gmm-train: statistics of the best density only, or of every density by its posterior (reference: mode)")
     ap.add_argument("--gmm-type", default="diagonal-maximum", choices=["diagonal-maximum", "batch-diagonal-maximum-float", "SIMD-diagonal-maximum"])
@@ -347,7 +349,13 @@ class MfccOnly:
         import rasr_amd
         from tests import synth
         self.ctx = ctx
-        self.fe = rasr_amd.MfccExtractor(ctx, nr_cepstrum_coefficients=40, filter_width=138.0)
+        self.plp = getattr(args, "front_end", "mfcc") == "mfplp"
+        self.nout = 16 if self.plp else 40
+        if self.plp:
+            self.fe = rasr_amd.MfccExtractor(ctx, nr_cepstrum_coefficients=16, front_end="mfplp", nr_autocorrelation_coefficients=20,
+                                             normalize=True)
+        else:
+            self.fe = rasr_amd.MfccExtractor(ctx, nr_cepstrum_coefficients=40, filter_width=138.0)
         lens = synth.utterance_lengths(1000, seed=3)
         base = synth.waveform(int(lens.max()) + 1000, seed=4 + rank)
         pcm = np.concatenate([base[u:u + int(n)] for u, n in enumerate(lens)])
@@ -355,7 +363,7 @@ class MfccOnly:
         self.plan = self.fe.plan(off)
         self.F = self.plan.total_frames
         self.pcm = torch.from_numpy(pcm).cuda()
-        self.ceps = torch.empty((self.F, 40), dtype=torch.float32, device="cuda")
+        self.ceps = torch.empty((self.F, self.nout), dtype=torch.float32, device="cuda")
         self.units = self.F
 
     def step(self):
@@ -368,13 +376,21 @@ class MfccOnly:
         ms, n = self.ctx.profile_get("mfcc")
         if n == 0:
             return None
-        gbs = self.F * 800.0 / (ms * 1e-3) / 1e9  # 160 samples*4 B in + 40 ceps*4 B out per frame
-        return dict(bound="hbm", kernel="mfcc_kernel<256>", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(gbs / HBM_PEAK_GBS, 4), traffic=measured_traffic("mfcc_kernel<256>"), avg_launch_ms=round(ms, 4),
-                    launches=n, bytes_per_launch=self.F * 800.0)
+        lp, _ = self.ctx.profile_get("lpc_cepstrum")
+        per_frame = 640.0 + 4.0 * self.nout   # 160 samples*4 B in + cepstra*4 B out per frame (800 B for MFCC-40)
+        gbs = self.F * per_frame / ((ms + lp) * 1e-3) / 1e9
+        return dict(bound="hbm", kernel="mfcc_kernel<256>" + (" + lpc_cepstrum_kernel" if self.plp else ""), achieved=round(gbs, 1),
+                    peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4),
+                    traffic=None if self.plp else measured_traffic("mfcc_kernel<256>"), avg_launch_ms=round(ms + lp, 4),
+                    launches=n, bytes_per_launch=self.F * per_frame)
 
     def stage_report(self):
-        return {}
+        out = {}
+        for k in ("mfcc", "lpc_cepstrum"):
+            ms, n = self.ctx.profile_get(k)
+            if n:
+                out[k] = dict(avg_ms=round(ms, 4), launches=n)
+        return out
 
 
 class GmmOnly:

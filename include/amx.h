@@ -89,15 +89,27 @@ typedef struct {
     int    warp_differential_unit; /* warp-differential-unit, default 1              */
     int    n_ceps;                 /* signal-cosine-transform nr-outputs             */
     int    dct_normalize;          /* normalize, default 0                           */
+    /* front_end AMX_FRONT_END_MFPLP = mfplp.flow (Tools/FeatureExtraction/share/mfplp.flow:9-47): amplitude ->
+     * generic-vector-f32-power 2 -> mel filter bank -> generic-vector-f32-power plp_power -> signal-cosine-transform
+     * (input-type N-plus-one, nr-outputs n_autocorrelation, normalize) -> signal-autocorrelation-to-autoregression
+     * (Math/LevinsonLse.cc:35-70) -> signal-autoregression-to-cepstrum (Signal/AutoregressionToCepstrum.cc:21-35,
+     * nr-outputs n_ceps).  A frame whose Levinson recursion meets a zero prediction error (digital silence) is an error in
+     * the reference ("Failed to calculate the autoregression coefficients."); it comes out as NaNs here. */
+    int    front_end;              /* AMX_FRONT_END_MFCC (0, default) or AMX_FRONT_END_MFPLP                     */
+    int    n_autocorrelation;      /* nr-autocorrelation-coefficients = LPC order + 1 (MF-PLP only)                */
+    double plp_power;              /* intensity-loudness-law value, default 0.33 (MF-PLP only)                     */
 } amx_mfcc_cfg;
+enum { AMX_FRONT_END_MFCC = 0, AMX_FRONT_END_MFPLP = 1 };
 
 typedef struct {
     int    frame_len, frame_shift, fft_len, n_bins, n_filters, n_ceps;
     double fft_output_sample_rate; /* attribute "sample-rate" after the FFT node = N/fs */
     double mel_max;                /* warped maximum frequency */
+    int    n_transform;            /* rows of the cosine-transform table: n_ceps (MFCC) or n_autocorrelation (MF-PLP) */
 } amx_mfcc_info;
 
 void amx_mfcc_default_cfg(amx_mfcc_cfg* cfg); /* the values of mfcc.flow + node defaults, 16 ceps */
+void amx_mfplp_default_cfg(amx_mfcc_cfg* cfg); /* the values of mfplp.flow, 13 autocorrelation / 13 cepstrum coefficients */
 int  amx_mfcc_create(amx_ctx* ctx, const amx_mfcc_cfg* cfg, amx_mfcc** out);
 void amx_mfcc_destroy(amx_mfcc* h);
 int  amx_mfcc_describe(const amx_mfcc* h, amx_mfcc_info* info);

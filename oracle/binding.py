@@ -22,11 +22,17 @@ class MfccCfg(C.Structure):
     _fields_ = [("sample_rate", C.c_double), ("win_len_s", C.c_double), ("win_shift_s", C.c_double),
                 ("preemph_alpha", C.c_double), ("fft_max_input_s", C.c_double), ("apply_scale", C.c_int),
                 ("mel_filter_width", C.c_double), ("mel_spacing", C.c_double),
-                ("warp_differential_unit", C.c_int), ("n_ceps", C.c_int), ("dct_normalize", C.c_int)]
+                ("warp_differential_unit", C.c_int), ("n_ceps", C.c_int), ("dct_normalize", C.c_int),
+                ("front_end", C.c_int), ("n_autocorrelation", C.c_int), ("plp_power", C.c_double)]
 
     @staticmethod
     def default(n_ceps=16, filter_width=268.258, sample_rate=16000.0, alpha=1.0):
-        return MfccCfg(sample_rate, 0.025, 0.01, alpha, 0.025, 1, filter_width, 0.0, 1, n_ceps, 0)
+        return MfccCfg(sample_rate, 0.025, 0.01, alpha, 0.025, 1, filter_width, 0.0, 1, n_ceps, 0, 0, 0, 0.33)
+
+    @staticmethod
+    def mfplp(n_ceps=13, n_autocorrelation=13, filter_width=268.258, sample_rate=16000.0, alpha=1.0):
+        """mfplp.flow: nr-cepstrum-coefficients, nr-autocorrelation-coefficients (LPC order + 1)"""
+        return MfccCfg(sample_rate, 0.025, 0.01, alpha, 0.025, 1, filter_width, 0.0, 1, n_ceps, 1, 1, n_autocorrelation, 0.33)
 
 
 class _GmmModel(C.Structure):
@@ -282,7 +288,8 @@ class OracleMfcc:
 
     @property
     def dct(self):
-        return self._arr("dct", self.n_ceps * self.n_filters, np.float32).reshape(self.n_ceps, self.n_filters)
+        rows = self.cfg.n_autocorrelation if self.cfg.front_end == 1 else self.n_ceps
+        return self._arr("dct", rows * self.n_filters, np.float32).reshape(rows, self.n_filters)
 
     def n_frames(self, n):
         return int(self.L.orc_mfcc_n_frames(self.h, n))
@@ -391,6 +398,36 @@ def _simd(self, feats):
 
 
 OracleGmm.score_simd = _simd
+
+
+def _levinson(fn, R):
+    R = np.ascontiguousarray(R, dtype=np.float32)
+    gain = C.c_float()
+    a = np.zeros(max(len(R) - 1, 1), np.float32)
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    ok = fn(R.ctypes.data, len(R), C.addressof(gain), a.ctypes.data)
+    return (np.float32(gain.value), a[:len(R) - 1]) if ok else None
+
+
+def oracle_levinson(R):
+    """(gain, a) or None: Math::LevinsonLeastSquares restated in oracle/orc_mfcc.c"""
+    return _levinson(Oracle().orc_levinson, R)
+
+
+def ref_levinson(R):
+    """the reference's own Math/LevinsonLse.cc (libref)"""
+    return _levinson(load_ref().ref_levinson, R)
+
+
+def oracle_ar_to_cepstrum(gain, a, nc):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    c = np.zeros(nc, np.float32)
+    L = Oracle()
+    L.orc_ar_to_cepstrum.restype = None
+    L.orc_ar_to_cepstrum.argtypes = [C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    L.orc_ar_to_cepstrum(float(gain), a.ctypes.data, len(a), c.ctypes.data, nc)
+    return c
 
 
 def oracle_quantize(v):

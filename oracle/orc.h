@@ -43,6 +43,11 @@ typedef struct {
     int    warp_differential_unit; /* default true */
     int    n_ceps;                 /* nr-outputs of signal-cosine-transform */
     int    dct_normalize;          /* normalize (default false) */
+    /* front_end 1 = mfplp.flow (Tools/FeatureExtraction/share/mfplp.flow): power spectrum -> mel filter bank -> ^plp_power ->
+     * cosine transform (N-plus-one input, nr-outputs n_autocorrelation, normalize) -> Levinson -> LPC cepstrum (n_ceps) */
+    int    front_end;              /* 0 = mfcc.flow, 1 = mfplp.flow */
+    int    n_autocorrelation;      /* nr-autocorrelation-coefficients (LPC order + 1) */
+    double plp_power;              /* intensity-loudness-law value, mfplp.flow: 0.33 */
 } orc_mfcc_cfg;
 
 typedef struct orc_mfcc orc_mfcc;
@@ -80,6 +85,11 @@ int orc_mfcc_stages(const orc_mfcc* h, const float* pcm, long n_samples, long fr
                     float* logmel /*[n_filters]*/, float* ceps /*[n_ceps]*/);
 
 /* building blocks, exposed so they can be pinned one by one */
+/* Math::LevinsonLeastSquares::work + gain() + a() (Math/LevinsonLse.cc:35-70, LevinsonLse.hh:49-66): R [n] autocorrelation,
+ * a [n-1]; returns 0 when the recursion meets a zero prediction error (the reference reports an error for the frame) */
+int    orc_levinson(const float* R, int n, float* gain, float* a);
+/* Signal::autoregressionToCepstrum (Signal/AutoregressionToCepstrum.cc:21-35): c [nc], 2 <= nc <= na + 1 */
+void   orc_ar_to_cepstrum(float gain, const float* a, int na, float* c, int nc);
 void   orc_preemphasis(float* x, long n, float alpha);            /* in place, segment start */
 void   orc_fft_real(float* v, int n);                             /* Math::FastFourierTransform::transformReal */
 void   orc_fft_complex(float* v, int n_floats);                   /* ::transform (forward) */

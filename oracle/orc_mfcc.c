@@ -6,6 +6,11 @@
  *   -> generic-vector-f32-log -> signal-cosine-transform
  *   (Tools/FeatureExtraction/share/mfcc.flow:8-34)
  *
+ * and, with cfg.front_end = 1, of mfplp.flow (same share directory, lines 9-47):
+ *   ... amplitude -> generic-vector-f32-power(2) -> signal-filterbank(mel) -> generic-vector-f32-power(0.33)
+ *   -> signal-cosine-transform(N-plus-one, normalize) -> signal-autocorrelation-to-autoregression
+ *   -> signal-autoregression-to-cepstrum
+ *
  * Arithmetic types follow the reference exactly: f32 sample data, f64 trigonometric
  * recurrences and table construction, f32 tables.  Compile with -ffp-contract=off.
  */
@@ -23,7 +28,7 @@ struct orc_mfcc {
     float*       window;       /* [frame_len] */
     int *        f_start, *f_end, *f_off;
     float*       f_weights;
-    float*       dct;          /* [n_ceps][n_filters] */
+    float*       dct;          /* [n_ceps][n_filters]; MF-PLP: [n_autocorrelation][n_filters], N-plus-one input type */
     double       mel_max;
 };
 
@@ -273,6 +278,75 @@ static void orc_build_dct(orc_mfcc* h) {
         }
 }
 
+/* Signal/CosineTransform.cc:46-60 (N-plus-one input data, identity warping): the inverse DFT of an even spectrum sampled at
+ * N + 1 points, which turns the compressed mel spectrum into autocorrelation coefficients */
+static void orc_build_cosine_nplus1(orc_mfcc* h) {
+    size_t cols = (size_t)h->n_filters, N = cols - 1, rows = (size_t)h->cfg.n_autocorrelation;
+    h->dct      = (float*)calloc(rows * cols, sizeof(float));
+    for (size_t k = 0; k < rows; ++k) {
+        h->dct[k * cols + 0] = (float)0.5;
+        h->dct[k * cols + N] = (float)(0.5 * pow(-1, (double)k));
+        for (size_t n = 1; n < N; ++n) {
+            double omega         = M_PI * n / N;
+            h->dct[k * cols + n] = (float)(cos(omega * k) * 1.0);
+        }
+    }
+}
+
+/* Math::LevinsonLeastSquares (Math/LevinsonLse.cc:35-70): f64 recursion on f32 autocorrelation values; note the f32
+ * division in the first reflection coefficient (-R[1] / R[0] is evaluated before it is widened) */
+static int orc_almost_zero(double e) { /* Core::isAlmostEqual(e, 0.0), Core/Utility.hh:322-327 */
+    double d = fabs(e);
+    double t = (fabs(e) + 0.0 + 2.2250738585072014e-308) * 2.2204460492503131e-16 * 1.0;
+    return d < t;
+}
+
+int orc_levinson(const float* R, int n, float* gain, float* a) {
+    int N = n - 1;
+    if (N < 1)
+        return 0;
+    double E[N + 1], k[N + 1], al[N + 1][N + 1];
+    memset(al, 0, sizeof al);
+    E[0] = R[0];
+    if (orc_almost_zero(E[0]))
+        return 0;
+    al[1][1] = k[1] = -R[1] / R[0];
+    E[1]            = R[0] + R[1] * k[1];
+    for (int i = 2; i <= N; ++i) {
+        k[i] = R[i];
+        for (int j = 1; j <= i - 1; ++j)
+            k[i] += al[j][i - 1] * R[i - j];
+        if (orc_almost_zero(E[i - 1]))
+            return 0;
+        k[i]     = -k[i] / E[i - 1];
+        al[i][i] = k[i];
+        for (int j = 1; j <= i - 1; ++j)
+            al[j][i] = al[j][i - 1] + k[i] * al[i - j][i - 1];
+        E[i] = (1.0 - k[i] * k[i]) * E[i - 1];
+    }
+    *gain = (float)sqrt(E[N]);           /* gain(): sqrt(predictionError()), stored in AutoregressiveCoefficients::gain_ (f32) */
+    for (int j = 1; j <= N; ++j)
+        a[j - 1] = (float)al[j][N];
+    return 1;
+}
+
+/* Signal/AutoregressionToCepstrum.cc:21-35.  log(gain) resolves to the double overload in that translation unit (only <cmath>
+ * is in its include closure), integer factors are converted to f32, products run left to right in f32. */
+void orc_ar_to_cepstrum(float gain, const float* a, int na, float* c, int nc) {
+    (void)na;
+    c[0] = (float)(2 * log((double)gain));
+    c[1] = -a[0];
+    for (int n = 2; n < nc; ++n) {
+        c[n] = (float)n * a[n - 1];
+        for (int k = 1; k < n; ++k) {
+            float t = (float)(n - k) * c[n - k];
+            t       = t * a[k - 1];
+            c[n]    = c[n] + t;
+        }
+        c[n] = c[n] / (-(float)n);
+    }
+}
+
 /* Signal/FastFourierTransform.cc:30-41 and FastFourierTransform.hh:299-308 */
 static int orc_fft_length(double max_input_s, double fs) {
     unsigned maxlen = (unsigned)ceil(max_input_s * fs);
@@ -307,7 +381,17 @@ orc_mfcc* orc_mfcc_create(const orc_mfcc_cfg* cfg) {
         orc_mfcc_destroy(h);
         return NULL;
     }
-    orc_build_dct(h);
+    if (cfg->front_end == 1) {
+        /* CosineTransformNode: nr-outputs <= input size; AutoregressionToCepstrumNode::init: 2 <= nr-outputs <= order + 1 */
+        if (cfg->n_autocorrelation < 2 || cfg->n_autocorrelation > h->n_filters || cfg->n_ceps < 2 ||
+            cfg->n_ceps > cfg->n_autocorrelation) {
+            orc_mfcc_destroy(h);
+            return NULL;
+        }
+        orc_build_cosine_nplus1(h);
+    }
+    else
+        orc_build_dct(h);
     return h;
 }
 
@@ -383,6 +467,10 @@ static void orc_frame(const orc_mfcc* h, const float* pre, long n_samples, long 
         amp[k] = hypotf(buf[2 * k], buf[2 * k + 1]);
     if (amplitude)
         memcpy(amplitude, amp, (size_t)h->n_bins * sizeof(float));
+    /* mfplp.flow: generic-vector-f32-power value 2 (Flow/SimpleFunction.hh:143-153: powf) */
+    if (h->cfg.front_end == 1)
+        for (int k = 0; k < h->n_bins; ++k)
+            amp[k] = powf(amp[k], 2.0f);
     /* FilterBank::Filter::apply (Signal/Filterbank.cc:65-71): f32 accumulate, ascending bin */
     float fb[h->n_filters];
     for (int f = 0; f < h->n_filters; ++f) {
@@ -396,6 +484,36 @@ static void orc_frame(const orc_mfcc* h, const float* pre, long n_samples, long 
     }
     if (mel)
         memcpy(mel, fb, (size_t)h->n_filters * sizeof(float));
+    if (h->cfg.front_end == 1) {
+        /* intensity-loudness-law, autocorrelation (CosineTransform::apply: f32 rows left to right, divided by N_ = inputs - 1),
+         * autoregression, cepstrum; a frame whose recursion fails is reported as an error by the reference: NaN here */
+        const float pw = (float)h->cfg.plp_power;
+        for (int f = 0; f < h->n_filters; ++f)
+            fb[f] = powf(fb[f], pw);
+        if (logmel)
+            memcpy(logmel, fb, (size_t)h->n_filters * sizeof(float));
+        if (ceps) {
+            const int nac = h->cfg.n_autocorrelation;
+            float     R[nac], a[nac], gain = 0;
+            for (int k = 0; k < nac; ++k) {
+                float        acc = 0;
+                const float* row = h->dct + (size_t)k * h->n_filters;
+                for (int n = 0; n < h->n_filters; ++n) {
+                    float prod = row[n] * fb[n];
+                    acc        = acc + prod;
+                }
+                if (h->cfg.dct_normalize)
+                    acc = acc / (float)(h->n_filters - 1);
+                R[k] = acc;
+            }
+            if (orc_levinson(R, nac, &gain, a))
+                orc_ar_to_cepstrum(gain, a, nac - 1, ceps, h->n_ceps);
+            else
+                for (int k = 0; k < h->n_ceps; ++k)
+                    ceps[k] = NAN;
+        }
+        return;
+    }
     /* Flow::VectorLogFunction<f32> (Flow/SimpleFunction.hh:40-49): log10f, no floor */
     for (int f = 0; f < h->n_filters; ++f)
         fb[f] = log10f(fb[f]);

@@ -16,6 +16,7 @@
 // boost / bison / cblas (anything including Core/Configuration.hh) are simply not built.
 #include <Math/AcousticalAnalyticFunctions.hh>
 #include <Math/FastFourierTransform.hh>
+#include <Math/LevinsonLse.hh>
 #include <Math/SimpleAnalyticFunctions.hh>
 #include <Mm/Utilities.hh>
 #include <Signal/WindowBuffer.hh>
@@ -250,6 +251,19 @@ void ref_normalized_minus(const double* x, const double* y, int n, double weight
 // quantize<f32, u8> of the SIMD-diagonal-maximum scorer (Mm/Utilities.hh:190-202)
 unsigned ref_quantize_u8(float v) {
     return Mm::quantize<float, unsigned char>()(v);
+}
+
+// Math::LevinsonLeastSquares (Math/LevinsonLse.cc, compiled unmodified) driven like AutocorrelationToAutoregressionNode::work
+// (Signal/ArEstimator.cc:91-101): gain and a1..aN as the f32 values AutoregressiveCoefficients stores.  Returns 0 when work() fails.
+int ref_levinson(const float* R, int n, float* gain, float* a) {
+    Math::LevinsonLeastSquares lse;
+    std::vector<float>         r(R, R + n), av;
+    if (!lse.work(r))
+        return 0;
+    *gain = (float)lse.gain();
+    lse.a(av);
+    std::copy(av.begin(), av.end(), a);
+    return 1;
 }
 
 }  // extern "C"

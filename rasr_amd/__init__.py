@@ -125,10 +125,13 @@ class MfccExtractor:
 
     def __init__(self, ctx, nr_cepstrum_coefficients=16, filter_width=268.258, sample_rate=16000.0, alpha=1.0,
                  length=0.025, shift=0.01, maximum_input_size=0.025, apply_scale=True, spacing=0.0,
-                 warp_differential_unit=True, normalize=False):
+                 warp_differential_unit=True, normalize=False, front_end="mfcc", nr_autocorrelation_coefficients=0,
+                 intensity_loudness_power=0.33):
+        """front_end "mfcc" (mfcc.flow) or "mfplp" (mfplp.flow: pass normalize=True and nr_autocorrelation_coefficients)"""
         self.ctx, self.L = ctx, ctx.L
         cfg = MfccCfg(sample_rate, length, shift, alpha, maximum_input_size, int(apply_scale), filter_width, spacing,
-                      int(warp_differential_unit), nr_cepstrum_coefficients, int(normalize))
+                      int(warp_differential_unit), nr_cepstrum_coefficients, int(normalize),
+                      {"mfcc": 0, "mfplp": 1}[front_end], int(nr_autocorrelation_coefficients), float(intensity_loudness_power))
         h = C.c_void_p()
         _lib.check(self.L.amx_mfcc_create(ctx.h, C.byref(cfg), C.byref(h)))
         self.h = h
@@ -158,7 +161,7 @@ class MfccExtractor:
         fs, fe, fo = np.zeros(i.n_filters, np.int32), np.zeros(i.n_filters, np.int32), np.zeros(i.n_filters + 1, np.int32)
         _lib.check(self.L.amx_mfcc_tables(self.h, None, None, None, fo.ctypes.data, None, None))
         fw = np.zeros(int(fo[-1]), np.float32)
-        dct = np.zeros((i.n_ceps, i.n_filters), np.float32)
+        dct = np.zeros((i.n_transform, i.n_filters), np.float32)
         _lib.check(self.L.amx_mfcc_tables(self.h, win.ctypes.data, fs.ctypes.data, fe.ctypes.data, fo.ctypes.data,
                                           fw.ctypes.data, dct.ctypes.data))
         return dict(window=win, filter_start=fs, filter_end=fe, filter_offset=fo, filter_weights=fw, dct=dct)

@@ -56,6 +56,8 @@ struct MfccParams {
     int             frames_per_tile, n_tiles;
     float           alpha, fft_scale;
     int             apply_scale, dct_normalize;
+    int             front_end;   // 1: power spectrum into the filter bank, ^plp_power instead of log10 (mfplp.flow)
+    float           norm_div, plp_power;
 };
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 w) {
@@ -392,12 +394,23 @@ __global__ __launch_bounds__(mfcc_waves(NC) * 64, (NC >= 1024 ? 1 : 4)) void mfc
         const float* w   = s_fw + s_fo[flt] - b0;
         const float* amp = s_amp + f * L.amp_ld;
         float        acc = 0.f;
-        for (int b = b0; b < b1; ++b) {
-            float prod = amp[b] * w[b];
-            acc        = acc + prod;
+        if (p.front_end) {  // mfplp.flow: generic-vector-f32-power 2 in front of the filter bank (powf(x, 2) = x * x rounded once)
+            for (int b = b0; b < b1; ++b) {
+                const float a    = amp[b];
+                const float pw   = a * a;
+                const float prod = pw * w[b];
+                acc              = acc + prod;
+            }
+        }
+        else {
+            for (int b = b0; b < b1; ++b) {
+                float prod = amp[b] * w[b];
+                acc        = acc + prod;
+            }
         }
         if (f < tile.n_frames)
-            s_lm[f * L.lm_ld + flt] = __log10f(acc);  // v_log_f32 * log10(2): ~1 ulp of log2
+            s_lm[f * L.lm_ld + flt] = p.front_end ? __powf(acc, p.plp_power)  // intensity-loudness law
+                                                  : __log10f(acc);           // v_log_f32 * log10(2): ~1 ulp of log2
     }
     __syncthreads();
 
@@ -421,7 +434,7 @@ __global__ __launch_bounds__(mfcc_waves(NC) * 64, (NC >= 1024 ? 1 : 4)) void mfc
                 if (f < tile.n_frames && cep < p.n_ceps) {
                     float v = acc[r];
                     if (p.dct_normalize)
-                        v = v / (float)p.n_filters;
+                        v = v / p.norm_div;
                     p.ceps[(tile.out_frame + f) * (long long)p.n_ceps + cep] = v;
                 }
             }
@@ -474,6 +487,8 @@ struct amx_mfcc {
     int *   d_fs = nullptr, *d_fe = nullptr, *d_fo = nullptr;
     float2 *d_tw = nullptr, *d_stw = nullptr;
     size_t  lds_bytes = 0;
+    float*  d_ac   = nullptr;  // MF-PLP: autocorrelation coefficients of the current call [frames x n_transform]
+    size_t  ac_cap = 0;
 };
 
 struct amx_mfcc_plan {
@@ -496,8 +511,85 @@ int upload(T** dst, const T* src, size_t n) {
 }
 
 size_t mfcc_lds_bytes(const amx::MfccTables& t) {
-    amx::MfccLds L(t.frame_len, t.frame_shift, t.fft_len, t.n_filters, t.n_ceps, (int)t.filter_weights.size());
+    amx::MfccLds L(t.frame_len, t.frame_shift, t.fft_len, t.n_filters, t.n_transform, (int)t.filter_weights.size());
     return (size_t)L.total * 4;
+}
+
+// MF-PLP tail, one lane per frame: autocorrelation -> Levinson recursion in f64 (Math/LevinsonLse.cc:35-70; the first
+// reflection coefficient is an f32 division like the reference's expression) -> gain, a1..aN as f32 -> LPC cepstrum
+// (Signal/AutoregressionToCepstrum.cc:21-35: 2 log(gain) in f64, the recursion in f32 left to right).  The per-lane arrays
+// live in LDS as [index][lane] (every lane touches the same index at the same time: conflict free); a failed recursion
+// (zero prediction error) writes NaNs.
+constexpr int kMaxAc = 64;
+__host__ __device__ constexpr size_t lpc_lds_bytes(int n_ac) {
+    return (size_t)64 * n_ac * (8 + 8 + 4 + 4 + 4);
+}
+__global__ __launch_bounds__(64) void lpc_cepstrum_kernel(const float* __restrict__ ac, int n_ac, float* __restrict__ out, int n_out,
+                                                         long long n_frames) {
+    extern __shared__ __attribute__((aligned(16))) char lpc_lds[];
+    const int lane  = threadIdx.x;
+    double*   prev  = (double*)lpc_lds + lane;            // [n_ac][64]
+    double*   cur   = prev + (size_t)64 * n_ac;
+    float*    R     = (float*)(cur - lane + (size_t)64 * n_ac) + lane;
+    float*    a     = R + (size_t)64 * n_ac;
+    float*    c     = a + (size_t)64 * n_ac;
+    const long long t  = (long long)blockIdx.x * 64 + lane;
+    const long long tt = t < n_frames ? t : n_frames - 1;
+    for (int i = 0; i < n_ac; ++i)
+        R[i * 64] = ac[tt * n_ac + i];
+    const int N = n_ac - 1;
+    auto almost_zero = [](double e) {  // Core::isAlmostEqual(e, 0.0)
+        return fabs(e) < (fabs(e) + 0.0 + 2.2250738585072014e-308) * 2.2204460492503131e-16 * 1.0;
+    };
+    bool   ok = true;
+    double E  = (double)R[0];
+    if (almost_zero(E))
+        ok = false;
+    if (ok) {
+        const double k1 = (double)(-R[64] / R[0]);
+        prev[64]        = k1;
+        E               = (double)R[0] + (double)R[64] * k1;
+    }
+    for (int i = 2; i <= N; ++i) {  // the trip count is uniform; lanes whose recursion failed idle through it
+        double k = (double)R[i * 64];
+        for (int j = 1; j <= i - 1; ++j)
+            k += prev[j * 64] * (double)R[(i - j) * 64];
+        if (ok && almost_zero(E))
+            ok = false;
+        if (ok) {
+            k           = -k / E;
+            cur[i * 64] = k;
+            for (int j = 1; j <= i - 1; ++j)
+                cur[j * 64] = prev[j * 64] + k * prev[(i - j) * 64];
+            E = (1.0 - k * k) * E;
+            for (int j = 1; j <= i; ++j)
+                prev[j * 64] = cur[j * 64];
+        }
+    }
+    if (t >= n_frames)
+        return;
+    float* o = out + t * n_out;
+    if (!ok) {
+        for (int n = 0; n < n_out; ++n)
+            o[n] = __builtin_nanf("");
+        return;
+    }
+    const float gain = (float)sqrt(E);
+    for (int j = 1; j <= N; ++j)
+        a[(j - 1) * 64] = (float)prev[j * 64];
+    c[0]  = (float)(2 * log((double)gain));
+    c[64] = -a[0];
+    for (int n = 2; n < n_out; ++n) {
+        float v = (float)n * a[(n - 1) * 64];
+        for (int k = 1; k < n; ++k) {
+            float tt2 = (float)(n - k) * c[(n - k) * 64];
+            tt2       = tt2 * a[(k - 1) * 64];
+            v         = v + tt2;
+        }
+        c[n * 64] = v / (-(float)n);
+    }
+    for (int n = 0; n < n_out; ++n)
+        o[n] = c[n * 64];
 }
 
 template<int NC>
@@ -534,6 +626,19 @@ void amx_mfcc_default_cfg(amx_mfcc_cfg* c) {
     c->warp_differential_unit = 1;
     c->n_ceps                 = 16;
     c->dct_normalize          = 0;
+    c->front_end              = AMX_FRONT_END_MFCC;
+    c->n_autocorrelation      = 0;
+    c->plp_power              = 0.33;
+}
+
+void amx_mfplp_default_cfg(amx_mfcc_cfg* c) {
+    if (!c)
+        return;
+    amx_mfcc_default_cfg(c);  // mfplp.flow: same window, FFT and mel filter bank (filter-width 268.258)
+    c->front_end         = AMX_FRONT_END_MFPLP;
+    c->dct_normalize     = 1;   // normalize="true"
+    c->n_autocorrelation = 13;  // LPC order 12
+    c->n_ceps            = 13;
 }
 
 int amx_mfcc_create(amx_ctx* ctx, const amx_mfcc_cfg* cfg, amx_mfcc** out) {
@@ -566,10 +671,10 @@ int amx_mfcc_create(amx_ctx* ctx, const amx_mfcc_cfg* cfg, amx_mfcc** out) {
         delete h;
         return AMX_ERR_UNSUPPORTED;
     }
-    std::vector<float> dct_t((size_t)t.n_filters * t.n_ceps);
-    for (int k = 0; k < t.n_ceps; ++k)
+    std::vector<float> dct_t((size_t)t.n_filters * t.n_transform);
+    for (int k = 0; k < t.n_transform; ++k)
         for (int n = 0; n < t.n_filters; ++n)
-            dct_t[(size_t)n * t.n_ceps + k] = t.dct[(size_t)k * t.n_filters + n];
+            dct_t[(size_t)n * t.n_transform + k] = t.dct[(size_t)k * t.n_filters + n];
     if ((r = upload(&h->d_window, t.window.data(), t.window.size())) != AMX_OK ||
         (r = upload(&h->d_fw, t.filter_weights.data(), t.filter_weights.size())) != AMX_OK ||
         (r = upload(&h->d_dct_t, dct_t.data(), dct_t.size())) != AMX_OK ||
@@ -601,6 +706,7 @@ void amx_mfcc_destroy(amx_mfcc* h) {
     hipFree(h->d_fo);
     hipFree(h->d_tw);
     hipFree(h->d_stw);
+    hipFree(h->d_ac);
     delete h;
 }
 
@@ -614,6 +720,7 @@ int amx_mfcc_describe(const amx_mfcc* h, amx_mfcc_info* info) {
     info->n_ceps                 = h->tab.n_ceps;
     info->fft_output_sample_rate = h->tab.fft_output_sample_rate;
     info->mel_max                = h->tab.mel_max;
+    info->n_transform            = h->tab.n_transform;
     return AMX_OK;
 }
 
@@ -730,8 +837,23 @@ int amx_mfcc_run_plan_dev(amx_mfcc* h, const amx_mfcc_plan* p, const float* pcm_
     k.frame_len       = t.frame_len;
     k.frame_shift     = t.frame_shift;
     k.n_filters       = t.n_filters;
-    k.n_ceps          = t.n_ceps;
+    k.n_ceps          = t.n_transform;
     k.n_weights       = (int)t.filter_weights.size();
+    k.front_end       = t.cfg.front_end == AMX_FRONT_END_MFPLP ? 1 : 0;
+    k.norm_div        = t.norm_div;
+    k.plp_power       = (float)t.cfg.plp_power;
+    const long long total_frames = p->frame_off.back();
+    if (k.front_end) {  // the fused kernel stops at the autocorrelation coefficients; lpc_cepstrum_kernel finishes the chain
+        const size_t need = (size_t)total_frames * t.n_transform;
+        if (need > h->ac_cap) {
+            hipFree(h->d_ac);
+            h->d_ac   = nullptr;
+            h->ac_cap = 0;
+            AMX_HIP(hipMalloc((void**)&h->d_ac, std::max<size_t>(need, 1) * 4));
+            h->ac_cap = need;
+        }
+        k.ceps = h->d_ac;
+    }
     k.frames_per_tile = h->frames_per_tile;
     k.alpha           = (float)t.cfg.preemph_alpha;
     k.fft_scale       = t.fft_scale;
@@ -739,20 +861,30 @@ int amx_mfcc_run_plan_dev(amx_mfcc* h, const amx_mfcc_plan* p, const float* pcm_
     k.n_tiles               = n_tiles_total;
     k.apply_scale     = (t.cfg.apply_scale && t.cfg.sample_rate != 1) ? 1 : 0;
     k.dct_normalize   = t.cfg.dct_normalize;
+    int r;
     switch (t.fft_len / 2) {
-        case 4: return launch_mfcc<4>(h, k, n_tiles_total);
-        case 8: return launch_mfcc<8>(h, k, n_tiles_total);
-        case 16: return launch_mfcc<16>(h, k, n_tiles_total);
-        case 32: return launch_mfcc<32>(h, k, n_tiles_total);
-        case 64: return launch_mfcc<64>(h, k, n_tiles_total);
-        case 128: return launch_mfcc<128>(h, k, n_tiles_total);
-        case 256: return launch_mfcc<256>(h, k, n_tiles_total);
-        case 512: return launch_mfcc<512>(h, k, n_tiles_total);
-        case 1024: return launch_mfcc<1024>(h, k, n_tiles_total);
+        case 4: r = launch_mfcc<4>(h, k, n_tiles_total); break;
+        case 8: r = launch_mfcc<8>(h, k, n_tiles_total); break;
+        case 16: r = launch_mfcc<16>(h, k, n_tiles_total); break;
+        case 32: r = launch_mfcc<32>(h, k, n_tiles_total); break;
+        case 64: r = launch_mfcc<64>(h, k, n_tiles_total); break;
+        case 128: r = launch_mfcc<128>(h, k, n_tiles_total); break;
+        case 256: r = launch_mfcc<256>(h, k, n_tiles_total); break;
+        case 512: r = launch_mfcc<512>(h, k, n_tiles_total); break;
+        case 1024: r = launch_mfcc<1024>(h, k, n_tiles_total); break;
         default:
             amx::set_error("amx_mfcc_run_plan_dev: no kernel for FFT length %d", t.fft_len);
             return AMX_ERR_UNSUPPORTED;
     }
+    if (r != AMX_OK || !k.front_end || total_frames == 0)
+        return r;
+    amx::ScopedKernelTimer timer(h->ctx, "lpc_cepstrum");
+    const size_t lpc_lds = lpc_lds_bytes(t.n_transform);
+    hipFuncSetAttribute((const void*)lpc_cepstrum_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lpc_lds);
+    hipLaunchKernelGGL(lpc_cepstrum_kernel, dim3((unsigned)((total_frames + 63) / 64)), dim3(64), lpc_lds, h->ctx->stream, h->d_ac,
+                       t.n_transform, ceps_dev, t.n_ceps, total_frames);
+    AMX_HIP(hipGetLastError());
+    return AMX_OK;
 }
 
 int amx_mfcc_run_batch(amx_mfcc* h, int n_seg, const float* const* pcm_host, const long* n_samples, float* const* ceps_host) {

@@ -150,9 +150,34 @@ int MfccTables::build(const amx_mfcc_cfg& c) {
         filter_offset[nf] = (int)filter_weights.size();
     }
 
-    // ---- DCT-II, even about N-1/2, identity warping
-    {
+    if (c.front_end == AMX_FRONT_END_MFPLP) {
+        // ---- cosine transform for N-plus-one input data (Signal/CosineTransform.cc:46-60), identity warping: the inverse DFT of
+        // an even spectrum sampled at N + 1 points -> autocorrelation coefficients
+        // CosineTransformNode: nr-outputs <= inputs; AutoregressionToCepstrumNode::init: "Incorrect output size"
+        AMX_REQUIRE(c.n_autocorrelation >= 2 && c.n_autocorrelation <= n_filters, AMX_ERR_INVALID,
+                    "mfplp: nr-autocorrelation-coefficients (%d) must be in 2..%d (filter bank outputs)", c.n_autocorrelation, n_filters);
+        AMX_REQUIRE(c.n_ceps >= 2 && c.n_ceps <= c.n_autocorrelation, AMX_ERR_INVALID,
+                    "mfplp: Incorrect output size (%d). 2 < nr-outputs <= %d.", c.n_ceps, c.n_autocorrelation);
+        AMX_REQUIRE(c.n_autocorrelation <= 64, AMX_ERR_UNSUPPORTED, "mfplp: LPC order %d > 63", c.n_autocorrelation - 1);
+        n_transform    = c.n_autocorrelation;
+        const size_t C = (size_t)n_filters, N = C - 1;
+        norm_div       = (float)N;
+        dct.assign((size_t)n_transform * C, 0.f);
+        for (size_t k = 0; k < (size_t)n_transform; ++k) {
+            dct[k * C + 0] = (float)0.5;
+            dct[k * C + N] = (float)(0.5 * std::pow(-1, (double)k));
+            for (size_t n = 1; n < N; ++n) {
+                double omega   = M_PI * n / N;
+                dct[k * C + n] = (float)(std::cos(omega * k) * 1.0);
+            }
+        }
+    }
+    else {
+        AMX_REQUIRE(c.front_end == AMX_FRONT_END_MFCC, AMX_ERR_INVALID, "mfcc: unknown front end %d", c.front_end);
+        // ---- DCT-II, even about N-1/2, identity warping
         const size_t N = (size_t)n_filters;
+        n_transform    = n_ceps;
+        norm_div       = (float)N;
         dct.assign((size_t)n_ceps * N, 0.f);
         for (size_t k = 0; k < (size_t)n_ceps; ++k)
             for (size_t n = 0; n < N; ++n) {

@@ -14,7 +14,9 @@ struct MfccTables {
     int          fft_len     = 0;  // next power of two          Signal/FastFourierTransform.cc:30-41
     int          n_bins      = 0;  // fft_len/2 + 1
     int          n_filters   = 0;
-    int          n_ceps      = 0;
+    int          n_ceps      = 0;  // output dimension
+    int          n_transform = 0;  // rows of the cosine-transform table: n_ceps, or nr-autocorrelation-coefficients (MF-PLP)
+    float        norm_div    = 1;  // CosineTransform::apply divides by N_ when normalize is set: inputs (MFCC) or inputs - 1 (N-plus-one)
     float        fft_scale   = 1;  // 1/(f32)fs                  Signal/FastFourierTransform.cc:66-73
     double       fft_output_sample_rate = 0;
     double       mel_max     = 0;
@@ -24,7 +26,7 @@ struct MfccTables {
     std::vector<int>   filter_end;     // [n_filters]
     std::vector<int>   filter_offset;  // [n_filters+1]
     std::vector<float> filter_weights; // concatenated
-    std::vector<float> dct;            // [n_ceps][n_filters]
+    std::vector<float> dct;            // [n_transform][n_filters]
     std::vector<float> twiddle;        // [fft_len/2][2] cos,sin of +2*pi*k/(fft_len/2)  (complex FFT)
     std::vector<float> split_twiddle;  // [fft_len/4][2] cos,sin of +pi*k/(fft_len/2)    (real split)
 

@@ -55,7 +55,9 @@ def host_mfcc(**kw):
 
 @pytest.mark.parametrize("kw", [dict(), dict(n_ceps=40, mel_filter_width=138.0), dict(sample_rate=8000.0),
                                 dict(sample_rate=44100.0, n_ceps=13), dict(sample_rate=11025.0, mel_filter_width=150.0),
-                                dict(mel_spacing=100.0), dict(warp_differential_unit=0), dict(win_len_s=0.02, win_shift_s=0.0125)])
+                                dict(mel_spacing=100.0), dict(warp_differential_unit=0), dict(win_len_s=0.02, win_shift_s=0.0125),
+                                dict(front_end=1, n_autocorrelation=13, n_ceps=13, dct_normalize=1),
+                                dict(front_end=1, n_autocorrelation=12, n_ceps=9, dct_normalize=1, sample_rate=8000.0)])
 def test_host_tables_bit_identical_to_oracle(kw):
     L, h, st = host_mfcc(**kw)
     assert st == 0, L.amx_last_error()
@@ -71,7 +73,8 @@ def test_host_tables_bit_identical_to_oracle(kw):
     fo = np.zeros(info.n_filters + 1, np.int32)
     L.amx_mfcc_tables(h, None, None, None, fo.ctypes.data, None, None)
     win, fs, fe = np.zeros(info.frame_len, np.float32), np.zeros(info.n_filters, np.int32), np.zeros(info.n_filters, np.int32)
-    fw, dct = np.zeros(fo[-1], np.float32), np.zeros((info.n_ceps, info.n_filters), np.float32)
+    assert info.n_transform == (kw["n_autocorrelation"] if kw.get("front_end") else info.n_ceps)
+    fw, dct = np.zeros(fo[-1], np.float32), np.zeros((info.n_transform, info.n_filters), np.float32)
     L.amx_mfcc_tables(h, win.ctypes.data, fs.ctypes.data, fe.ctypes.data, fo.ctypes.data, fw.ctypes.data, dct.ctypes.data)
     s, e, off, w = m.filters
     assert np.array_equal(win.view(np.uint32), m.window.view(np.uint32))
@@ -99,6 +102,13 @@ def test_mfcc_configuration_errors():
     L, h, st = host_mfcc(win_len_s=0.05)
     assert st == _lib.AMX_ERR_INVALID and b"larger then maximal input size" in L.amx_last_error()
     L, h, st = host_mfcc(n_ceps=0)
+    assert st == _lib.AMX_ERR_INVALID
+    # MF-PLP: the cosine transform cannot produce more outputs than the filter bank has, the cepstrum at most order + 1
+    L, h, st = host_mfcc(front_end=1, n_autocorrelation=20, n_ceps=9, sample_rate=8000.0)
+    assert st == _lib.AMX_ERR_INVALID and b"nr-autocorrelation-coefficients" in L.amx_last_error()
+    L, h, st = host_mfcc(front_end=1, n_autocorrelation=10, n_ceps=11)
+    assert st == _lib.AMX_ERR_INVALID and b"Incorrect output size" in L.amx_last_error()
+    L, h, st = host_mfcc(front_end=7)
     assert st == _lib.AMX_ERR_INVALID
 
 

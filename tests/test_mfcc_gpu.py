@@ -136,3 +136,55 @@ def test_full_size_properties(ctx):
         want = orc.run(pcm[off[u]:off[u + 1]])
         seg = got[plan.frame_offsets[u]:plan.frame_offsets[u + 1]]
         assert close(seg, want), (u, np.abs(seg - want).max())
+
+
+# MF-PLP (mfplp.flow): the chain adds powf(., 0.33), an autocorrelation transform, the Levinson recursion (f64) and the LPC cepstrum
+# recursion (f32) behind the filter bank.  The device's v_exp/v_log based __powf differs from glibc's powf by a few ulp and the
+# recursions amplify that by the conditioning of the autocorrelation matrix (order 12-19: ~1e2), hence the wider band.
+PLP_RTOL, PLP_ATOL = 2e-3, 2e-3
+
+
+@pytest.mark.parametrize("nc,nac", [(13, 13), (9, 20), (2, 2)])
+def test_mfplp_ten_seconds(ctx, nc, nac):
+    import rasr_amd
+    from oracle import OracleMfcc
+    from oracle.binding import MfccCfg
+    pcm = synth.waveform(160000, seed=3)
+    fe = rasr_amd.MfccExtractor(ctx, nr_cepstrum_coefficients=nc, front_end="mfplp", nr_autocorrelation_coefficients=nac, normalize=True)
+    got = fe.run(pcm)
+    want = OracleMfcc(MfccCfg.mfplp(n_ceps=nc, n_autocorrelation=nac)).run(pcm)
+    assert got.shape == want.shape == (999, nc) and np.all(np.isfinite(got))
+    assert np.all(np.abs(got - want) <= PLP_RTOL * np.abs(want) + PLP_ATOL), np.abs(got - want).max()
+    assert np.median(np.abs(got - want) / (np.abs(want) + 1e-2)) < 2e-5
+
+
+def test_mfplp_ragged_batch_silence_and_device_plan(ctx):
+    """segments of different lengths in one batch equal the single calls; digital silence makes the Levinson recursion fail:
+    NaN frames exactly where the oracle has them (the reference reports an error for such frames); the device-resident plan
+    entry point writes the same features"""
+    import torch
+
+    import rasr_amd
+    from oracle import OracleMfcc
+    from oracle.binding import MfccCfg
+    fe = rasr_amd.MfccExtractor(ctx, nr_cepstrum_coefficients=12, front_end="mfplp", nr_autocorrelation_coefficients=16, normalize=True)
+    o = OracleMfcc(MfccCfg.mfplp(n_ceps=12, n_autocorrelation=16))
+    segs = [synth.waveform(n, seed=200 + n) for n in (401, 5281, 160, 48077)]
+    segs.append(np.concatenate([synth.waveform(2000, seed=7), np.zeros(3000, np.float32), synth.waveform(1500, seed=8)]))
+    outs = fe.run_batch(segs)
+    for x, got in zip(segs, outs):
+        want = o.run(x)
+        assert got.shape == want.shape
+        nan = np.isnan(want)
+        assert np.array_equal(np.isnan(got), nan)
+        assert np.all(np.abs(got[~nan] - want[~nan]) <= PLP_RTOL * np.abs(want[~nan]) + PLP_ATOL)
+        assert np.array_equal(fe.run(x), got, equal_nan=True)
+    assert np.isnan(outs[-1]).any() and not np.isnan(outs[0]).any()
+    ctx.use_torch_stream()
+    off = np.concatenate([[0], np.cumsum([len(x) for x in segs])])
+    plan = fe.plan(off)
+    pcm = torch.from_numpy(np.concatenate(segs)).cuda()
+    ceps = torch.empty((plan.total_frames, 12), dtype=torch.float32, device="cuda")
+    fe.run_plan(plan, pcm, ceps)
+    torch.cuda.synchronize()
+    assert np.array_equal(ceps.cpu().numpy(), np.concatenate(outs), equal_nan=True)

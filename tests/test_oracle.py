@@ -261,3 +261,68 @@ def test_quantizer_matches_reference_functor():
             assert q == known[v], (v, q)
         if load_ref() is not None:
             assert q == ref_quantize(v), (v, q, ref_quantize(v))
+
+
+def test_levinson_matches_reference_golden_and_live():
+    """Math::LevinsonLeastSquares: the oracle's restatement against outputs of the reference's own translation unit (golden vectors
+    from libref.so, and libref.so itself when present), bit for bit, including the recursions that fail."""
+    import json
+    import os
+    from oracle.binding import load_ref, oracle_levinson, ref_levinson
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ref_levinson.json")))
+    failures = 0
+    for c in g["cases"]:
+        R = np.frombuffer(bytes.fromhex(c["R"]), "<f4")
+        out = oracle_levinson(R)
+        assert (out is not None) == c["ok"]
+        if out is None:
+            failures += 1
+            continue
+        assert np.float32(out[0]).tobytes().hex() == c["gain"] and out[1].astype("<f4").tobytes().hex() == c["a"]
+    assert failures >= 1
+    if load_ref() is not None:
+        rng = np.random.Generator(np.random.PCG64(2))
+        for _ in range(200):
+            n = int(rng.integers(2, 30))
+            x = rng.standard_normal(300)
+            R = np.array([np.dot(x[:300 - k], x[k:]) for k in range(n)], np.float32)
+            a, b = oracle_levinson(R), ref_levinson(R)
+            assert a[0].tobytes() == b[0].tobytes() and a[1].tobytes() == b[1].tobytes()
+
+
+def test_lpc_cepstrum_recursion_against_independent_definition():
+    """Signal::autoregressionToCepstrum (parity unpinned: its translation unit needs Flow): the recursion must give the cepstrum of
+    the all-pole model gain / A(z), i.e. the inverse DFT of log |H|^2 / 2 ... checked here through the power series of
+    log(1 / A(z)) computed independently with numpy polynomial arithmetic in f64."""
+    from oracle.binding import oracle_ar_to_cepstrum
+    rng = np.random.Generator(np.random.PCG64(4))
+    for _ in range(20):
+        order = int(rng.integers(1, 16))
+        # a stable A(z) = prod (1 - r_i z^-1): coefficients a_1..a_N of 1 + a_1 z^-1 + ...
+        roots = rng.uniform(-0.8, 0.8, order)
+        A = np.poly(roots)                                # [1, a1, ..., aN]
+        a = A[1:].astype(np.float32)
+        gain = np.float32(rng.uniform(0.1, 5))
+        nc = order + 1
+        c = oracle_ar_to_cepstrum(gain, a, nc)
+        # log(1/A(z)) = sum_n (sum_i r_i^n / n) z^-n ; the reference's convention for c[0] is 2 log(gain)
+        want = [2 * np.log(float(gain))] + [float(np.sum(roots ** n) / n) for n in range(1, nc)]
+        assert np.allclose(c, want, rtol=2e-4, atol=2e-5), (c, want)
+
+
+def test_mfplp_oracle_chain_properties():
+    """MF-PLP restatement end to end on a synthetic signal: finite output of the configured size, c0 = 2 log(gain) moves by
+    2 * 0.33 * 2 * log(s) when the signal is scaled by s (power spectrum ^ 0.33 -> autocorrelation scale s^0.66 -> gain^2),
+    higher cepstra are scale invariant; digital silence makes the recursion fail (NaN, where the reference reports an error)."""
+    from oracle import OracleMfcc
+    from oracle.binding import MfccCfg
+    from tests import synth
+    pcm = synth.waveform(16000, seed=9)
+    m = OracleMfcc(MfccCfg.mfplp(n_ceps=13, n_autocorrelation=15))
+    a = m.run(pcm)
+    b = m.run(pcm * np.float32(4.0))
+    assert a.shape == (99, 13) and np.all(np.isfinite(a))
+    assert np.allclose(b[:, 0] - a[:, 0], 2 * 0.33 * np.log(4.0), atol=2e-3)
+    assert np.allclose(b[:, 1:], a[:, 1:], atol=5e-4)
+    z = m.run(np.zeros(1600, np.float32))
+    assert np.all(np.isnan(z))

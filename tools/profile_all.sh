@@ -30,6 +30,7 @@ run_pmc() {  # name, counter, suffix, bench args...
 run_stats pipeline --steps 8 --warmup 2
 run_stats nn-pipeline --workload nn-pipeline --steps 8 --warmup 2 --no-cpu-baseline
 run_stats mfcc --workload mfcc --steps 8 --warmup 2 --no-cpu-baseline
+run_stats mfplp --workload mfcc --front-end mfplp --steps 8 --warmup 2 --no-cpu-baseline
 run_stats gmm --workload gmm --steps 50 --warmup 5 --no-cpu-baseline
 run_stats gmm-simd --workload gmm --gmm-type SIMD-diagonal-maximum --gmm-frames 65536 --steps 20 --warmup 3 --no-cpu-baseline
 run_stats gmm-tied --workload gmm-tied --steps 20 --warmup 3 --no-cpu-baseline
