@@ -1206,6 +1206,12 @@ __global__ __launch_bounds__(512, 2) void gmm_screen_rows_kernel(const _Float16*
     }
 }
 
+// survivor rows per lane and pass of the exact stage: 28 bytes = 7 dwords, so consecutive lanes start in different banks;
+// per-density covariances at DIM >= 64 leave room for one dword only (more passes for the rare frames that need them)
+__host__ __device__ constexpr int gmm_list_cap(int dim, bool pooled) {
+    return (pooled || dim < 64) ? 28 : 4;
+}
+
 __host__ __device__ constexpr int gmm_exact_ld(int dim, bool pooled) {
     return (pooled || dim < 64) ? 4 * (((dim + 3) / 4) | 1) : ((dim + 3) & ~3);
 }
@@ -1224,6 +1230,7 @@ __global__ __launch_bounds__(256) void gmm_screen_exact_kernel(const float* __re
     // number of 16-byte slots long, so that consecutive rows start in different slots: 44 floats for DIM = 40
     // (per-density covariances at DIM = 64 only fit unpadded)
     constexpr int LD = gmm_exact_ld(DIM, POOLED);
+    constexpr int kListCap = gmm_list_cap(DIM, POOLED);
     extern __shared__ __attribute__((aligned(16))) char lds[];
     float* s_mu = (float*)lds;                    // [256][LD]
     float* s_is = s_mu + 256 * LD;                // [256][LD] (per-density covariance only)
@@ -1236,6 +1243,7 @@ __global__ __launch_bounds__(256) void gmm_screen_exact_kernel(const float* __re
     int*    s_row = (int*)(s_c64 + 256);  // [256] mean row, [256] covariance row (-1 = empty slot), [16] densities per mixture
     float*  s_sc  = (float*)(s_row + 528);                 // [256][17] scores of the current frame group
     unsigned char* s_bd = (unsigned char*)(s_sc + 256 * 17);  // [256][20] best slot
+    unsigned char* s_list = s_bd + 256 * 20;                   // [256][kListCap] survivor rows of the current pass
     {
         const int      m  = m0 + (tid >> 4), jj = tid & 15;
         const uint32_t k0 = m < n_mix ? g_mix_off[m] : 0u, k1 = m < n_mix ? g_mix_off[m + 1] : 0u;
@@ -1257,6 +1265,12 @@ __global__ __launch_bounds__(256) void gmm_screen_exact_kernel(const float* __re
         }
     }
     __syncthreads();
+    unsigned vm[8];  // validity of the 16 x 16 slots, in the layout of the mask words (mixture 2w low half, 2w + 1 high half)
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+        const unsigned lo = (1u << (unsigned)s_row[512 + 2 * w]) - 1u, hi = (1u << (unsigned)s_row[512 + 2 * w + 1]) - 1u;
+        vm[w]             = (lo & 0xffffu) | (hi << 16);
+    }
     // the tile serves FG groups of 256 frames
   // features and masks of the NEXT frame group are requested before this group's walk: they come from L2 / MALL (the
   // feature rows are re-read per mixture tile) and a round trip is a fifth of a walk
@@ -1285,29 +1299,21 @@ __global__ __launch_bounds__(256) void gmm_screen_exact_kernel(const float* __re
     if (fg + 1 < FG && (blockIdx.y * FG + fg + 1) * 256 < T)
         prefetch(fg + 1);
     // Every lane walks ITS OWN list of (mixture, slot) survivors: one distance per loop trip for every lane that still has
-    // work, instead of a trip count of max-over-lanes per mixture (16 x ~2.2 trips become ~1.1 x 16 + spread).  The walk is
-    // software-pipelined by one survivor: the mean row of the next survivor is read from LDS while the current one is evaluated.
+    // work, instead of a trip count of max-over-lanes per mixture (16 x ~2.2 trips become ~1.1 x 16 + spread).
+    // The list is made first: the set bits of the eight mask words (static register indices, empty slots masked off with
+    // the tile's validity words) become byte-sized row numbers w*32 + bit = mixture*16 + slot in LDS, kListCap per pass.
+    // The walk then has no mask arithmetic and no data-dependent inner loops: four row numbers per 32-bit LDS read, the
+    // mean row of the next survivor fetched while the current one is evaluated.  Frames whose operand did not fit f16 keep
+    // all slots (up to 256 survivors) and simply take several passes.
     const int nm = min(16, n_mix - m0);
 #pragma unroll
     for (int q = 0; q < 16; ++q) {  // mixtures without densities keep the empty result
         s_sc[tid * 17 + q] = MaxState().result();
         s_bd[tid * 20 + q] = 0xff;
     }
-    int      mi = -1;
-    unsigned mask = 0;
-    auto     advance = [&]() -> int {  // slot row (mixture * 16 + slot) of the next survivor in ascending order, -1 at the end
-        while (mask == 0) {
-            if (++mi >= nm)
-                return -1;
-            const uint32_t nk = (uint32_t)s_row[512 + mi];
-            mask              = ((mi & 1) ? (mw[mi >> 1] >> 16) : mw[mi >> 1]) & 0xffffu & ((1u << nk) - 1u);
-        }
-        const int jj = __ffs((int)mask) - 1;
-        mask &= mask - 1;
-        return mi * 16 + jj;
-    };
-    float mua[DIM], mub[DIM];
-    auto  fetch = [&](float (&dst)[DIM], int row) {
+    unsigned char* my_list = s_list + tid * kListCap;
+    float          mua[DIM], mub[DIM];
+    auto           fetch = [&](float (&dst)[DIM], int row) {
         const float* src = s_mu + (row < 0 ? 0 : row) * LD;
 #pragma unroll
         for (int i = 0; i + 3 < DIM; i += 4) {
@@ -1332,17 +1338,52 @@ __global__ __launch_bounds__(256) void gmm_screen_exact_kernel(const float* __re
             st                          = MaxState();
         }
     };
-    int ra = advance();
-    fetch(mua, ra);
-    while (ra >= 0) {
-        const int rb = advance();
-        fetch(mub, rb);
-        eval(mua, ra, rb);
-        if (rb < 0)
+    for (int base = 0;; base += kListCap) {
+        int idx = 0, peek = -1;  // survivors seen so far; the first row behind this pass (decides the last flush of the pass)
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+            unsigned bits = mw[w] & vm[w];
+            while (bits) {
+                const int bpos = __ffs((int)bits) - 1;
+                bits &= bits - 1;
+                const int rel = idx - base;
+                if (rel >= 0 && rel < kListCap)
+                    my_list[rel] = (unsigned char)(w * 32 + bpos);
+                else if (rel == kListCap)
+                    peek = w * 32 + bpos;
+                ++idx;
+            }
+        }
+        const int n_here = min(max(idx - base, 0), kListCap);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        unsigned q4 = *(const unsigned*)my_list;
+        fetch(mua, n_here > 0 ? (int)(q4 & 0xffu) : -1);
+        for (int kb = 0; kb < n_here; kb += 4) {
+            const unsigned qn = *(const unsigned*)(my_list + ((kb + 4 < kListCap) ? kb + 4 : 0));  // the next four row numbers
+            const int      r0 = (int)(q4 & 0xffu), r1 = (int)((q4 >> 8) & 0xffu), r2 = (int)((q4 >> 16) & 0xffu), r3 = (int)(q4 >> 24);
+            const int      rn = (int)(qn & 0xffu);
+            const bool     v1 = kb + 1 < n_here, v2 = kb + 2 < n_here, v3 = kb + 3 < n_here, v4 = kb + 4 < n_here;
+            fetch(mub, v1 ? r1 : -1);
+            eval(mua, r0, v1 ? r1 : peek);
+            if (v1) {
+                fetch(mua, v2 ? r2 : -1);
+                eval(mub, r1, v2 ? r2 : peek);
+            }
+            if (v2) {
+                fetch(mub, v3 ? r3 : -1);
+                eval(mua, r2, v3 ? r3 : peek);
+            }
+            if (v3) {
+                fetch(mua, v4 ? rn : -1);
+                eval(mub, r3, v4 ? rn : peek);
+            }
+            q4 = qn;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (!__any(idx > base + kListCap))  // wave-uniform: another pass only for the frames that keep every slot
             break;
-        ra = advance();
-        fetch(mua, ra);
-        eval(mub, rb, ra);
     }
     // The result tile leaves through LDS: four adjacent lanes write the 64 contiguous bytes of one frame in ONE instruction.
     // (Per-lane 4-byte stores at a 40 KB stride cost more than the whole evaluation.)  Every wave transposes and stores ITS OWN
@@ -1599,7 +1640,7 @@ int score_screened(amx_gmm* h, const float* feats_dev, int T, float* scores_dev,
             uint32_t* bd = best_dev ? best_dev + (size_t)t0 * h->n_mix : nullptr;
 #define AMX_EXACT(D)                                                                                                                \
     case D: {                                                                                                                       \
-        const size_t lds = (size_t)256 * amx::gmm_exact_ld(D, h->pooled) * 4 * (h->pooled ? 1 : 2) + 2048 + 2112 + 256 * 17 * 4 + 256 * 20; \
+        const size_t lds = (size_t)256 * amx::gmm_exact_ld(D, h->pooled) * 4 * (h->pooled ? 1 : 2) + 2048 + 2112 + 256 * 17 * 4 + 256 * 20 + 256 * amx::gmm_list_cap(D, h->pooled); \
         if (h->pooled) {                                                                                                            \
             auto k = amx::gmm_screen_exact_kernel<D, true>;                                                                         \
             hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
