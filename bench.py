@@ -110,7 +110,7 @@ def gmm_cart_roofline(ctx, nk, frames):
                     avg_launch_ms=round(ms_x, 4), launches=n_x, flops_per_launch=ops)
     alg = 122.0 * nk * frames   # SURVEY 8(d) cfg 3 secondary: D (3d + 2) flop per frame for the reference scorer
     t = (ms_x + ms_s + ms_p) * 1e-3
-    return dict(bound="mfma", kernel="gmm_screen_exact_kernel<40,pooled> (+ gmm_screen_persist_kernel, gmm_screen_pack_kernel)",
+    return dict(bound="mfma", kernel="gmm_screen_exact_kernel<40,pooled> (+ gmm_screen_rows_kernel, gmm_screen_pack_kernel)",
                 note="f32 VALU kernel priced against the f32 vector peak (= f32 MFMA peak). achieved = the reference scorer's algorithmic "
                      "flops (densities x 122 flop per frame) / (pack + screen + exact time); the f16 MFMA screen leaves ~1.04 of 16 "
                      "densities per state for the exact f32 evaluation, so the flops actually executed are ~9 % of the algorithmic count",
