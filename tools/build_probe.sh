@@ -8,3 +8,4 @@ hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -w -I include -I ra
 hipcc --offload-arch=gfx950 tools/build/gemm_probe.o rasr_amd/csrc/build/api.o rasr_amd/csrc/build/stats.o -o tools/build/gemm_probe
 # tools/build/ceilings: measured HBM / MFMA / VALU ceilings of the box (tools/ceilings.hip)
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -w tools/ceilings.hip -o tools/build/ceilings
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -w tools/write_probe.hip -o tools/build/write_probe

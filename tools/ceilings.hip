@@ -38,6 +38,36 @@ __global__ __launch_bounds__(256) void triad(f32x4* __restrict__ a, const f32x4*
         __builtin_nontemporal_store(x[u] + s * y[u], a + base + u * 256);
 }
 
+__global__ __launch_bounds__(256) void fill4(f32x4* __restrict__ a, float v) {
+    const size_t base = (size_t)blockIdx.x * 1024 + threadIdx.x;
+    const f32x4  x    = {v, v, v, v};
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        a[base + u * 256] = x;
+}
+
+__global__ __launch_bounds__(256) void read4(const f32x4* __restrict__ b, float* __restrict__ sink) {
+    const size_t base = (size_t)blockIdx.x * 1024 + threadIdx.x;
+    f32x4        acc  = {0, 0, 0, 0};
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        acc += __builtin_nontemporal_load(b + base + u * 256);
+    if (acc.x + acc.y + acc.z + acc.w == 123.456f)
+        sink[threadIdx.x] = acc.x;
+}
+
+// 64-byte pieces at a 40 KB row stride, the store pattern of a [frames x 10000] f32 score matrix written 16 mixtures at a time
+__global__ __launch_bounds__(256) void fill_pieces(f32x4* __restrict__ a, float v, int n_rows, int row_f4, int pieces_per_row) {
+    const int    tid = threadIdx.x;
+    const f32x4  x   = {v, v, v, v};
+    const int    piece = blockIdx.x % pieces_per_row, rb = blockIdx.x / pieces_per_row;  // 256 rows per block
+    for (int it = 0; it < 4; ++it) {
+        const int e = it * 256 + tid, row = rb * 256 + (e >> 2), c = e & 3;
+        if (row < n_rows)
+            a[(size_t)row * row_f4 + piece * 4 + c] = x;
+    }
+}
+
 __global__ __launch_bounds__(256) void copy4(f32x4* __restrict__ a, const f32x4* __restrict__ b) {
     const size_t base = (size_t)blockIdx.x * 1024 + threadIdx.x;
     f32x4        x[4];
@@ -124,7 +154,7 @@ int main() {
     CK(hipMalloc((void**)&c, bytes));
     CK(hipMemset(b, 0, bytes));
     CK(hipMemset(c, 0, bytes));
-    double copy = 0, tri = 0, cpk = 0;
+    double copy = 0, tri = 0, cpk = 0, wr = 0, rd = 0, wp = 0;
     for (int rep = 0; rep < 4; ++rep) {
         CK(hipEventRecord(e0, 0));
         CK(hipMemcpyAsync(a, b, bytes, hipMemcpyDeviceToDevice, 0));
@@ -144,6 +174,27 @@ int main() {
         CK(hipEventSynchronize(e1));
         if (rep)
             cpk = std::max(cpk, 2.0 * bytes / (time_ms(e0, e1) * 1e-3) / 1e9);
+        CK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL(fill4, dim3(bytes / 16 / 1024), dim3(256), 0, 0, a, 1.5f);
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        if (rep)
+            wr = std::max(wr, 1.0 * bytes / (time_ms(e0, e1) * 1e-3) / 1e9);
+        CK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL(read4, dim3(bytes / 16 / 1024), dim3(256), 0, 0, b, (float*)c);
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        if (rep)
+            rd = std::max(rd, 1.0 * bytes / (time_ms(e0, e1) * 1e-3) / 1e9);
+        {
+            const int n_rows = 51200, row_f4 = 2500, ppr = 625;  // 51200 x 10000 floats = 2.05 GB
+            CK(hipEventRecord(e0, 0));
+            hipLaunchKernelGGL(fill_pieces, dim3(ppr * (n_rows / 256)), dim3(256), 0, 0, a, 2.5f, n_rows, row_f4, ppr);
+            CK(hipEventRecord(e1, 0));
+            CK(hipEventSynchronize(e1));
+            if (rep)
+                wp = std::max(wp, (double)n_rows * row_f4 * 16 / (time_ms(e0, e1) * 1e-3) / 1e9);
+        }
     }
     unsigned* seed;
     float*    sink;
@@ -187,11 +238,11 @@ int main() {
                 fma[pk] = std::max(fma[pk], fl / (time_ms(e0, e1) * 1e-3) / 1e12);
         }
     printf("{\"device\": \"%s\", \"compute_units\": %d, \"clock_mhz\": %d, \"memory_clock_mhz\": %d, \"hbm_bytes\": %zu,\n"
-           " \"hbm_memcpy_GBps\": %.0f, \"hbm_copy_kernel_GBps\": %.0f, \"hbm_triad_GBps\": %.0f, \"datasheet_hbm_GBps\": 8000,\n"
+           " \"hbm_memcpy_GBps\": %.0f, \"hbm_copy_kernel_GBps\": %.0f, \"hbm_triad_GBps\": %.0f, \"hbm_write_only_GBps\": %.0f, \"hbm_read_only_GBps\": %.0f, \"hbm_write_64B_pieces_GBps\": %.0f, \"datasheet_hbm_GBps\": 8000,\n"
            " \"mfma_bf16_zero_TFLOPs\": %.0f, \"mfma_bf16_random_TFLOPs\": %.0f, \"mfma_f16_zero_TFLOPs\": %.0f, \"mfma_f16_random_TFLOPs\": %.0f, "
            "\"datasheet_bf16_dense_TFLOPs\": 2500,\n"
            " \"fma_f32_TFLOPs\": %.1f, \"pk_fma_f32_TFLOPs\": %.1f, \"datasheet_f32_vector_TFLOPs\": 157.3}\n",
-           p.name, p.multiProcessorCount, p.clockRate / 1000, p.memoryClockRate / 1000, (size_t)p.totalGlobalMem, copy, cpk, tri, mf[0][0], mf[0][1],
+           p.name, p.multiProcessorCount, p.clockRate / 1000, p.memoryClockRate / 1000, (size_t)p.totalGlobalMem, copy, cpk, tri, wr, rd, wp, mf[0][0], mf[0][1],
            mf[1][0], mf[1][1], fma[0], fma[1]);
     return 0;
 }
