@@ -187,8 +187,11 @@ typedef struct {
  * covariance only, no best-density output, ignores the two scales like the reference class) /
  * SIMD-diagonal-maximum (Mm::SimdGaussDiagonalMaximumFeatureScorer, Mm/SimdFeatureScorer.cc:68-176 with
  * Mm/IntelOptimization.cc:37-66: means and features times scaling / sigma quantised to u8, integer distance and constant,
- * first minimum, score = 0.5 * min / scaling^2; assigns densities; ignores the two scales like the reference class) */
-enum { AMX_GMM_MAX = 0, AMX_GMM_SUM = 1, AMX_GMM_BATCH_FLOAT = 2, AMX_GMM_SIMD = 3 };
+ * first minimum, score = 0.5 * min / scaling^2; assigns densities; ignores the two scales like the reference class) /
+ * batch-diagonal-maximum-int and -fast (Mm::BatchIntFeatureScorer / BatchUnrolledIntFeatureScorer, Mm/BatchFeatureScorer.cc:375-504:
+ * the same u8 quantisation and integer distance, pooled covariance only, constant (s32)(logNorm scale^2 - 2 scale^2 logWeight) formed
+ * in f64, score = (f32)min / (2 scale^2) in f32, no best-density output) */
+enum { AMX_GMM_MAX = 0, AMX_GMM_SUM = 1, AMX_GMM_BATCH_FLOAT = 2, AMX_GMM_SIMD = 3, AMX_GMM_BATCH_INT = 4 };
 
 int  amx_gmm_create(amx_ctx* ctx, const amx_gmm_model* model, amx_gmm** out); /* copies everything */
 void amx_gmm_destroy(amx_gmm* h);

@@ -400,6 +400,21 @@ def _simd(self, feats):
 OracleGmm.score_simd = _simd
 
 
+def _batch_int(self, feats):
+    """batch-diagonal-maximum-int / -fast scores"""
+    feats = np.ascontiguousarray(feats, dtype=np.float32)
+    T = feats.shape[0]
+    sc = np.zeros((T, self.n_mix), np.float32)
+    self.L.orc_gmm_score_batch_int.restype = C.c_int
+    self.L.orc_gmm_score_batch_int.argtypes = [C.c_void_p, f64p, f32p, f32p, C.c_int, f32p]
+    if self.L.orc_gmm_score_batch_int(self.h, self.m["log_weight"], self.m["variances"].reshape(-1), feats.reshape(-1), T, sc.reshape(-1)) != 0:
+        raise ValueError("batch-int scorer supports only a globally pooled covariance")
+    return sc
+
+
+OracleGmm.score_batch_int = _batch_int
+
+
 def _levinson(fn, R):
     R = np.ascontiguousarray(R, dtype=np.float32)
     gain = C.c_float()

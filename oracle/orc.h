@@ -131,6 +131,9 @@ int orc_gmm_score_batch_float(const orc_gmm* h, const double* log_weight, const 
 int      orc_gmm_score_simd(const orc_gmm* h, const double* log_weight, const float* variances, const float* feats, int T,
                             float* scores, uint32_t* best, float* scaling_out);
 unsigned orc_quantize(float v);
+/* Mm::BatchIntFeatureScorer ("batch-diagonal-maximum-int" / "-fast"): pooled covariance only (-1 otherwise) */
+int      orc_gmm_score_batch_int(const orc_gmm* h, const double* log_weight, const float* variances, const float* feats, int T,
+                                 float* scores);
 
 /* Viterbi training statistics: see orc_score.c for the accumulator layout */
 long orc_gmm_accumulator_size(const orc_gmm* h);

@@ -261,8 +261,14 @@ static uint8_t orc_quantize_u8(float v) {
     return (uint8_t)q;
 }
 
-int orc_gmm_score_simd(const orc_gmm* h, const double* log_weight, const float* variances, const float* feats, int T, float* scores,
-                       uint32_t* best, float* scaling_out) {
+/* variant 1: Mm::BatchIntFeatureScorer ("batch-diagonal-maximum-int", Mm/BatchFeatureScorer.cc:338-504; "-fast" is the same
+ * arithmetic unrolled): pooled covariance only; quantizationScale (:352-373) is getScaling's formula on the unscaled 1/sigma;
+ * scale_ = (f32)(2.0 * scale^2) (:389); constants (s32)(logNorm * scale^2 - scale_ * logWeight) with the subtraction in f64 (:407);
+ * the SSE2 distance (:427-447) is the exact integer sum; score = (f32)min / scale_ in f32 (:500); no density assignment. */
+static int orc_gmm_score_quantized(const orc_gmm* h, int variant, const double* log_weight, const float* variances, const float* feats,
+                                   int T, float* scores, uint32_t* best, float* scaling_out) {
+    if (variant == 1 && h->n_cov != 1)
+        return -1;
     const int dim = h->dim;
     size_t    nk  = h->mix_off[h->n_mix];
     float*    isr = (float*)malloc((size_t)h->n_cov * dim * 4);
@@ -307,6 +313,10 @@ int orc_gmm_score_simd(const orc_gmm* h, const double* log_weight, const float* 
         float  asScore    = (float)scaledM2lw;
         cst[k]            = (int32_t)(asScore + lognorm[h->dens_cov[h->dens_index[k]]]);
     }
+    const float int_scale = (float)(2.0 * scaling2);
+    if (variant == 1)
+        for (size_t k = 0; k < nk; ++k)
+            cst[k] = (int32_t)((double)lognorm[0] - (double)int_scale * log_weight[k]);
     uint8_t* qx = (uint8_t*)malloc((size_t)h->n_cov * dim);
     for (int t = 0; t < T; ++t) {
         const float* x = feats + (size_t)t * dim;
@@ -331,7 +341,7 @@ int orc_gmm_score_simd(const orc_gmm* h, const double* log_weight, const float* 
                     bestDns  = k - h->mix_off[m];
                 }
             }
-            scores[(size_t)t * h->n_mix + m] = (float)(0.5 * minScore / scaling2);
+            scores[(size_t)t * h->n_mix + m] = variant == 1 ? (float)minScore / int_scale : (float)(0.5 * minScore / scaling2);
             if (best)
                 best[(size_t)t * h->n_mix + m] = bestDns;
         }
@@ -342,6 +352,16 @@ int orc_gmm_score_simd(const orc_gmm* h, const double* log_weight, const float* 
     free(cst);
     free(qx);
     return 0;
+}
+
+int orc_gmm_score_simd(const orc_gmm* h, const double* log_weight, const float* variances, const float* feats, int T, float* scores,
+                       uint32_t* best, float* scaling_out) {
+    return orc_gmm_score_quantized(h, 0, log_weight, variances, feats, T, scores, best, scaling_out);
+}
+
+int orc_gmm_score_batch_int(const orc_gmm* h, const double* log_weight, const float* variances, const float* feats, int T,
+                            float* scores) {
+    return orc_gmm_score_quantized(h, 1, log_weight, variances, feats, T, scores, NULL, NULL);
 }
 
 /* the quantiser alone, for pinning against the reference's functor */

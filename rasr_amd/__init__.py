@@ -215,7 +215,8 @@ class GmmFeatureScorer:
         # ctx = None: host-only handle (prepared tables, accumulator files); scoring then fails with AMX_ERR_STATE
         self.ctx, self.L = ctx, (ctx.L if ctx is not None else _lib.lib())
         self.mode = {"diagonal-maximum": AMX_GMM_MAX, "diagonal-sum": AMX_GMM_SUM,
-                     "batch-diagonal-maximum-float": AMX_GMM_BATCH_FLOAT, "SIMD-diagonal-maximum": _lib.AMX_GMM_SIMD}[feature_scorer_type]
+                     "batch-diagonal-maximum-float": AMX_GMM_BATCH_FLOAT, "SIMD-diagonal-maximum": _lib.AMX_GMM_SIMD, "batch-diagonal-maximum-int": _lib.AMX_GMM_BATCH_INT,
+                     "batch-diagonal-maximum-fast": _lib.AMX_GMM_BATCH_INT}[feature_scorer_type]
         keep = []
         st = _gmm_struct(model, mixture_weight_scale, gaussian_scale, keep)
         h = C.c_void_p()

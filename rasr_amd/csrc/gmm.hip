@@ -1545,7 +1545,7 @@ bool screen_dim_supported(int d) {
 extern "C" int   amx_internal_gmm_simd_create(const amx_gmm_model* m, void** out, float* scaling_out);
 extern "C" void  amx_internal_gmm_simd_destroy(void* p);
 extern "C" float amx_internal_gmm_simd_scaling(const void* p);
-extern "C" int   amx_internal_gmm_simd_score(void* p, amx_ctx* ctx, const float* feats_dev, int T, float* scores_dev, uint32_t* best_dev);
+extern "C" int   amx_internal_gmm_simd_score(void* p, amx_ctx* ctx, int variant, const float* feats_dev, int T, float* scores_dev, uint32_t* best_dev);
 
 // maximum approximation through the MFMA screen (see gmm_screen_kernel); frames in chunks that bound the mask workspace
 extern "C" int amx_internal_best_state_reduce(amx_ctx*, const float*, const unsigned*, int, int, int, uint32_t*, unsigned long long*, double*);
@@ -2050,7 +2050,8 @@ int amx_gmm_tables(const amx_gmm* h, float* m2lw, float* isr, float* lognorm) {
 int amx_gmm_score_dev(amx_gmm* h, int mode, const float* feats_dev, int T, float* scores_dev, uint32_t* best_dev) {
     AMX_REQUIRE(h, AMX_ERR_INVALID, "amx_gmm_score_dev: NULL handle");
     AMX_REQUIRE(h->ctx, AMX_ERR_STATE, "amx_gmm_score_dev: host-only handle (created without a context)");
-    AMX_REQUIRE(mode == AMX_GMM_MAX || mode == AMX_GMM_SUM || mode == AMX_GMM_BATCH_FLOAT || mode == AMX_GMM_SIMD, AMX_ERR_INVALID,
+    AMX_REQUIRE(mode == AMX_GMM_MAX || mode == AMX_GMM_SUM || mode == AMX_GMM_BATCH_FLOAT || mode == AMX_GMM_SIMD || mode == AMX_GMM_BATCH_INT,
+                AMX_ERR_INVALID,
                 "amx_gmm_score_dev: unknown mode %d", mode);
     AMX_REQUIRE(T >= 0, AMX_ERR_INVALID, "amx_gmm_score_dev: negative frame count");
     if (T == 0)
@@ -2059,7 +2060,11 @@ int amx_gmm_score_dev(amx_gmm* h, int mode, const float* feats_dev, int T, float
     AMX_HIP(hipSetDevice(h->ctx->device));
     const int fblocks = amx::ceil_div(T, 256);
     if (mode == AMX_GMM_SIMD)
-        return amx_internal_gmm_simd_score(h->simd, h->ctx, feats_dev, T, scores_dev, best_dev);
+        return amx_internal_gmm_simd_score(h->simd, h->ctx, 0, feats_dev, T, scores_dev, best_dev);
+    if (mode == AMX_GMM_BATCH_INT) {
+        AMX_REQUIRE(best_dev == nullptr, AMX_ERR_UNSUPPORTED, "amx_gmm_score_dev: batch-diagonal-maximum-int does not assign densities");
+        return amx_internal_gmm_simd_score(h->simd, h->ctx, 1, feats_dev, T, scores_dev, nullptr);
+    }
     if (mode == AMX_GMM_BATCH_FLOAT) {
         // Mm::BatchFloatFeatureScorer::init: criticalError("feature scorer supports only globally pooled covariance")
         AMX_REQUIRE(h->pooled, AMX_ERR_INVALID, "amx_gmm_score_dev: feature scorer supports only globally pooled covariance");

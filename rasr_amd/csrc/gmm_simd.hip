@@ -48,8 +48,11 @@ __device__ __forceinline__ int simd_quantize(float v) {
 // the IEEE division; the device's own v_div sequence is four times as long.
 struct SimdScale {
     double b, y;
+    float  int_scale;  // > 0: Mm::BatchIntFeatureScorer's conversion, (f32)min / scale_ in f32 (Mm/BatchFeatureScorer.cc:500)
 };
 __device__ __forceinline__ float simd_score(int min_score, SimdScale sc) {
+    if (sc.int_scale > 0.f)
+        return (float)min_score / sc.int_scale;
     const double a = (double)min_score;
     const double q = a * sc.y;
     const double r = fma(-q, sc.b, a);
@@ -271,14 +274,16 @@ struct GmmSimd {
     float    scaling = 0.f, scaling2 = 0.f;
     float*   d_isr = nullptr;             // [n_cov x dim], scaled
     unsigned char* d_qmean = nullptr;     // [n_dens x dim]
-    int*     d_cst = nullptr;             // [nk]
+    int*     d_cst[2] = {nullptr, nullptr};  // [nk] per-density constants: SIMD-diagonal-maximum, batch-diagonal-maximum-int
     uint32_t *d_mix_off = nullptr, *d_k_dens = nullptr, *d_d_cov = nullptr;
     int*     d_dist = nullptr;
     size_t   dist_cap = 0;
-    bool     mfma = false;
     int      n_tiles_r = 0;
     int8_t*  d_A = nullptr;
-    int*     d_key = nullptr;
+    int*     d_key[2] = {nullptr, nullptr};
+    bool     has_int = false;  // batch-int tables exist (pooled covariance)
+    bool     mfma_v[2] = {false, false};
+    float    int_scale = 0.f;
     int8_t*  d_X = nullptr;
     int*     d_nx = nullptr;
     int      cap_T = 0;
@@ -309,13 +314,15 @@ void amx_internal_gmm_simd_destroy(void* p) {
         return;
     hipFree(s->d_isr);
     hipFree(s->d_qmean);
-    hipFree(s->d_cst);
+    hipFree(s->d_cst[0]);
+    hipFree(s->d_cst[1]);
     hipFree(s->d_mix_off);
     hipFree(s->d_k_dens);
     hipFree(s->d_d_cov);
     hipFree(s->d_dist);
     hipFree(s->d_A);
-    hipFree(s->d_key);
+    hipFree(s->d_key[0]);
+    hipFree(s->d_key[1]);
     hipFree(s->d_X);
     hipFree(s->d_nx);
     delete s;
@@ -368,6 +375,17 @@ int amx_internal_gmm_simd_create(const amx_gmm_model* m, void** out, float* scal
         const float  asScore = (float)scaled;
         cst[k]               = (int)(asScore + lognorm[m->dens_cov[m->dens_index[k]]]);
     }
+    // Mm::BatchIntFeatureScorer::init (Mm/BatchFeatureScorer.cc:375-417), pooled covariance only: the same quantised means
+    // (quantizationScale is getScaling's formula), scale_ = (f32)(2.0 * scale^2), constant = (s32)(logNorm * scale^2 - scale_ * logWeight)
+    // with the subtraction in f64
+    std::vector<int> cst_int;
+    const float      int_scale = (float)(2.0 * scaling2);
+    if (m->n_cov == 1) {
+        cst_int.resize(nk);
+        const float log_norm_factor = lognorm[0];  // already logNormalizationFactor() * scaleSquared
+        for (size_t k = 0; k < nk; ++k)
+            cst_int[k] = (int)((double)log_norm_factor - (double)int_scale * m->log_weight[k]);
+    }
     GmmSimd* s  = new GmmSimd;
     s->dim      = dim;
     s->n_mix    = m->n_mix;
@@ -376,9 +394,12 @@ int amx_internal_gmm_simd_create(const amx_gmm_model* m, void** out, float* scal
     s->nk       = nk;
     s->scaling  = scaling;
     s->scaling2 = scaling2;
+    s->has_int  = m->n_cov == 1;
+    s->int_scale = int_scale;
     int r;
     if ((r = upload(&s->d_isr, isr.data(), isr.size())) != AMX_OK || (r = upload(&s->d_qmean, qmean.data(), qmean.size())) != AMX_OK ||
-        (r = upload(&s->d_cst, cst.data(), cst.size())) != AMX_OK ||
+        (r = upload(&s->d_cst[0], cst.data(), cst.size())) != AMX_OK ||
+        (s->has_int && (r = upload(&s->d_cst[1], cst_int.data(), cst_int.size())) != AMX_OK) ||
         (r = upload(&s->d_mix_off, m->mix_offsets, (size_t)m->n_mix + 1)) != AMX_OK ||
         (r = upload(&s->d_k_dens, m->dens_index, nk)) != AMX_OK || (r = upload(&s->d_d_cov, m->dens_cov, (size_t)m->n_dens)) != AMX_OK) {
         amx_internal_gmm_simd_destroy(s);
@@ -392,32 +413,38 @@ int amx_internal_gmm_simd_create(const amx_gmm_model* m, void** out, float* scal
     if (want && m->n_cov == 1 && dim <= 64 && kmax <= 16) {
         const int           n_tiles = (m->n_mix + 15) / 16;
         std::vector<int8_t> A((size_t)n_tiles * 256 * 64, 0);
-        std::vector<int>    key((size_t)n_tiles * 256, INT_MIN);  // negated keys; INT_MIN marks an empty slot
-        bool                fits = true;
-        for (int i = 0; i < m->n_mix && fits; ++i)
-            for (uint32_t k = m->mix_offsets[i]; k < m->mix_offsets[i + 1]; ++k) {
-                const uint32_t slot = k - m->mix_offsets[i];
-                const int      tile = i >> 4, ml = i & 15;
-                const size_t   row  = (size_t)tile * 256 + (ml >> 1) * 32 + (slot >> 2) * 8 + (ml & 1) * 4 + (slot & 3);
-                const unsigned char* q = qmean.data() + (size_t)m->dens_index[k] * dim;
-                long long      na = 0;
-                for (int x = 0; x < dim; ++x) {
-                    const int a     = (int)q[x] - 128;
-                    A[row * 64 + x] = (int8_t)a;
-                    na += a * a;
+        for (int v = 0; v < 2; ++v) {
+            if (v == 1 && !s->has_int)
+                break;
+            const std::vector<int>& cv = v ? cst_int : cst;
+            std::vector<int>        key((size_t)n_tiles * 256, INT_MIN);  // negated keys; INT_MIN marks an empty slot
+            bool                    fits = true;
+            for (int i = 0; i < m->n_mix && fits; ++i)
+                for (uint32_t k = m->mix_offsets[i]; k < m->mix_offsets[i + 1]; ++k) {
+                    const uint32_t slot = k - m->mix_offsets[i];
+                    const int      tile = i >> 4, ml = i & 15;
+                    const size_t   row  = (size_t)tile * 256 + (ml >> 1) * 32 + (slot >> 2) * 8 + (ml & 1) * 4 + (slot & 3);
+                    const unsigned char* q = qmean.data() + (size_t)m->dens_index[k] * dim;
+                    long long      na = 0;
+                    for (int x = 0; x < dim; ++x) {
+                        const int a     = (int)q[x] - 128;
+                        A[row * 64 + x] = (int8_t)a;
+                        na += a * a;
+                    }
+                    const long long base = (long long)cv[k] + na;
+                    if (base >= (1ll << 27) - (1ll << 22) || base <= -(1ll << 27) + (1ll << 22))
+                        fits = false;  // key - 32 a'.b' must stay inside 32 bits with room for the slot number
+                    key[(size_t)tile * 256 + ml * 16 + slot] = -(int)(base * 16 + slot);
                 }
-                const long long base = (long long)cst[k] + na;
-                if (base >= (1ll << 27) - (1ll << 22) || base <= -(1ll << 27) + (1ll << 22))
-                    fits = false;  // key - 32 a'.b' must stay inside 32 bits with room for the slot number
-                key[(size_t)tile * 256 + ml * 16 + slot] = -(int)(base * 16 + slot);
+            if (fits) {
+                if ((!s->d_A && (r = upload(&s->d_A, A.data(), A.size())) != AMX_OK) ||
+                    (r = upload(&s->d_key[v], key.data(), key.size())) != AMX_OK) {
+                    amx_internal_gmm_simd_destroy(s);
+                    return r;
+                }
+                s->mfma_v[v] = true;
+                s->n_tiles_r = n_tiles;
             }
-        if (fits) {
-            if ((r = upload(&s->d_A, A.data(), A.size())) != AMX_OK || (r = upload(&s->d_key, key.data(), key.size())) != AMX_OK) {
-                amx_internal_gmm_simd_destroy(s);
-                return r;
-            }
-            s->mfma      = true;
-            s->n_tiles_r = n_tiles;
         }
     }
     *out = s;
@@ -428,14 +455,19 @@ float amx_internal_gmm_simd_scaling(const void* p) {
     return p ? ((const amx::GmmSimd*)p)->scaling : 0.f;
 }
 
-int amx_internal_gmm_simd_score(void* p, amx_ctx* ctx, const float* feats_dev, int T, float* scores_dev, uint32_t* best_dev) {
+int amx_internal_gmm_simd_score(void* p, amx_ctx* ctx, int variant, const float* feats_dev, int T, float* scores_dev, uint32_t* best_dev) {
     using namespace amx;
     GmmSimd*    s  = (GmmSimd*)p;
     hipStream_t st = ctx->stream;
     SimdScale   scale;
     scale.b = 2.0 * (double)s->scaling2;
     scale.y = 1.0 / scale.b;
-    if (s->mfma) {
+    scale.int_scale = variant ? s->int_scale : 0.f;
+    if (variant && !s->has_int) {  // BatchIntFeatureScorer::init: criticalError
+        amx::set_error("amx_gmm_score_dev: feature scorer supports only globally pooled variance");
+        return AMX_ERR_INVALID;
+    }
+    if (s->mfma_v[variant]) {
         const int chunk = 65536;
         for (int t0 = 0; t0 < T; t0 += chunk) {
             const int Tc = std::min(chunk, T - t0), Tpad = (Tc + 255) / 256 * 256;
@@ -464,7 +496,7 @@ int amx_internal_gmm_simd_score(void* p, amx_ctx* ctx, const float* feats_dev, i
                 attr = true;
             }
             ScopedKernelTimer timer(ctx, "gmm_simd");
-            hipLaunchKernelGGL(simd_mfma_kernel, dim3(tiles_t * r_split), dim3(512), kSimdLds, st, s->d_A, s->d_X, s->d_key, s->d_nx,
+            hipLaunchKernelGGL(simd_mfma_kernel, dim3(tiles_t * r_split), dim3(512), kSimdLds, st, s->d_A, s->d_X, s->d_key[variant], s->d_nx,
                                scores_dev + (size_t)t0 * s->n_mix, best_dev ? best_dev + (size_t)t0 * s->n_mix : nullptr, Tc, s->n_mix,
                                s->n_tiles_r, r_split, scale);
         }
@@ -497,7 +529,7 @@ int amx_internal_gmm_simd_score(void* p, amx_ctx* ctx, const float* feats_dev, i
         while (mt > 1 && (long)((s->n_mix + mt - 1) / mt) * fblocks < 1024)
             mt /= 2;
         ScopedKernelTimer timer(ctx, "gmm_simd");
-        hipLaunchKernelGGL(simd_combine_kernel, dim3((s->n_mix + mt - 1) / mt, fblocks), dim3(256), 0, st, s->d_dist, s->d_cst, s->d_mix_off,
+        hipLaunchKernelGGL(simd_combine_kernel, dim3((s->n_mix + mt - 1) / mt, fblocks), dim3(256), 0, st, s->d_dist, s->d_cst[variant], s->d_mix_off,
                            s->d_k_dens, scores_dev + (size_t)t0 * s->n_mix, best_dev ? best_dev + (size_t)t0 * s->n_mix : nullptr, Tc, chunk,
                            s->n_mix, mt, scale);
     }

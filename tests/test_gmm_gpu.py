@@ -559,3 +559,30 @@ def test_simd_scorer_device_entry_and_chunks(ctx):
     torch.cuda.synchronize()
     assert np.array_equal(s1.cpu().numpy(), want) and np.array_equal(s2.cpu().numpy(), want)
     assert np.array_equal(b1.cpu().numpy().astype(np.uint32), wbest)
+
+
+@pytest.mark.parametrize("kind", ["cart", "long-mixtures", "tied"])
+def test_batch_int_scorer_exact(ctx, kind, monkeypatch):
+    """batch-diagonal-maximum-int / -fast: the SIMD scorer's quantisation with its own constants ((s32) of an f64 difference) and an
+    f32 division at the end; bit-exact on the i8 MFMA path and on the general path; pooled covariance only; no density output"""
+    import rasr_amd
+    from oracle import OracleGmm
+    model = {"cart": lambda: synth.gmm_cart(70, 1, 16, 40, seed=150, pooled=True),
+             "long-mixtures": lambda: synth.gmm_cart(9, 20, 33, 24, seed=151, pooled=True),
+             "tied": lambda: synth.gmm_tied(40, 64, 16, seed=152, pooled=True, alpha=1.0)}[kind]()
+    x = feats(300, int(model["dim"]), 153)
+    x[3] *= 40
+    want = OracleGmm(model).score_batch_int(x)
+    for name in ("batch-diagonal-maximum-int", "batch-diagonal-maximum-fast"):
+        got = rasr_amd.GmmFeatureScorer(ctx, model, feature_scorer_type=name).score(x, want_best=False)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), np.abs(got - want).max()
+    monkeypatch.setenv("AMX_GMM_SIMD_MFMA", "0")
+    got = rasr_amd.GmmFeatureScorer(ctx, model, feature_scorer_type="batch-diagonal-maximum-int").score(x, want_best=False)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    monkeypatch.delenv("AMX_GMM_SIMD_MFMA")
+    sc = rasr_amd.GmmFeatureScorer(ctx, model, feature_scorer_type="batch-diagonal-maximum-int")
+    with pytest.raises(rasr_amd.AmxError, match="does not assign densities"):
+        sc.score(x)
+    private = synth.gmm_cart(10, 1, 4, 16, seed=154, pooled=False)
+    with pytest.raises(rasr_amd.AmxError, match="globally pooled"):
+        rasr_amd.GmmFeatureScorer(ctx, private, feature_scorer_type="batch-diagonal-maximum-int").score(feats(4, 16, 1), want_best=False)
