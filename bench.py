@@ -69,7 +69,7 @@ def dist_setup(n_gpus):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
-    if world > 1:
+    if world > 1 or os.environ.get("AMX_BENCH_FORCE_DIST"):  # the env switch runs the RCCL path with a single rank (1-GPU boxes)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
@@ -77,9 +77,14 @@ def dist_setup(n_gpus):
     return rank, world, local
 
 
+def _dist_on():
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized()
+
+
 def barrier(world):
     import torch
-    if world > 1:
+    if _dist_on():
         import torch.distributed as dist
         dist.barrier()
     torch.cuda.synchronize()
@@ -159,7 +164,7 @@ class NnPipeline:
             self.nn.score_stats_dev(self.ctxwin[t0:], 440, T, self.scores, self.best[t0:], self.counts, self.score_sum)
 
     def epoch_reduce(self, world):
-        if world > 1:
+        if _dist_on():
             import torch.distributed as dist
             dist.all_reduce(self.counts)
             dist.all_reduce(self.score_sum)
@@ -252,7 +257,7 @@ class Pipeline(NnPipeline):
         self.main.wait_event(self.ev_side)   # the next step's MFCC overwrites ceps
 
     def epoch_reduce(self, world):
-        if world > 1:
+        if _dist_on():
             import torch.distributed as dist
             dist.all_reduce(self.acc)        # 53.8 MB of f64 GMM statistics
             for t in (self.counts, self.score_sum, self.gcounts, self.gscore_sum):
@@ -324,7 +329,7 @@ class GmmTrain:
                 self.sc.accumulate_dev(x, T, self.state, self.bestd, self.M, self.acc)
 
     def epoch_reduce(self, world):
-        if world > 1:
+        if _dist_on():
             import torch.distributed as dist
             dist.all_reduce(self.acc)          # 8*(sum K + n_mean*(1+d) + n_cov*(1+d)) bytes = 53.8 MB here
             dist.all_reduce(self.counts)
@@ -669,7 +674,7 @@ def main():
             torch.cuda.synchronize()
         ctx.profile(False)
     t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    if world > 1:
+    if _dist_on():
         import torch.distributed as dist
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
@@ -702,7 +707,7 @@ def main():
             line["cpu_baseline"] = cb
             line["speedup_vs_cpu"] = round(value / world / cb["value"], 1)
         print(json.dumps(line))
-    if world > 1:
+    if _dist_on():
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
