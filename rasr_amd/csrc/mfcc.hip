@@ -87,8 +87,9 @@ struct FftPlan {
 };
 
 constexpr int FT = 16;  // frames per tile = M of the DCT MFMA
-// wavefronts per workgroup: 8, or 4 when the per-wave FFT buffers get large
-__host__ __device__ constexpr int mfcc_waves(int nc) { return nc >= 1024 ? 4 : 8; }
+// wavefronts per workgroup: 4 (four frames of a tile each).  With 8 the per-wave FFT buffers push the workgroup to 57 KB of LDS and two
+// workgroups per CU; 4 give 49 KB and three, whose barrier-separated phases overlap better (A/B on one box: 1.10 -> 1.05 ms)
+__host__ __device__ constexpr int mfcc_waves(int nc) { return nc >= 1024 ? 4 : 4; }
 // FFT work buffer index swizzle (a bijection inside every 16-point block): makes the stride-4 / stride-16 Stockham
 // writes of the first two radix-4 stages bank-conflict free (ds_write_b64, 16-lane groups)
 __host__ __device__ constexpr int zpad(int i) { return i ^ (5 * ((i >> 4) & 3)); }
