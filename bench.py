@@ -655,9 +655,11 @@ def main():
             job = NnOnly(ctx, args, rank)
         for _ in range(args.warmup):
             job.step()
-        # config 4 (batch 1024) replays its forward pass as a HIP graph, which the per-launch events of the library's profiler
+        # config 4 (batch 1024) and the config-3 CART scorer (batch 256) replay their pass as a HIP graph, which the per-launch events of the library's profiler
         # would switch off: that workload is timed without them and its kernel timings come from a separate profiled pass
-        graph_mode = args.workload == "nn" and os.environ.get("AMX_FFNN_GRAPH", "1") != "0"
+        graph_mode = (args.workload == "nn" and os.environ.get("AMX_FFNN_GRAPH", "1") != "0") or \
+                     (args.workload == "gmm" and args.gmm_type == "diagonal-maximum" and args.gmm_frames <= 4096
+                      and os.environ.get("AMX_GMM_GRAPH", "1") != "0")
         barrier(world)
         ctx.profile(not graph_mode)
         ctx.profile_reset()

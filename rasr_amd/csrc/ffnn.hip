@@ -1023,6 +1023,11 @@ int pad_to(int v, int m) {
 int ensure_workspace(amx_ffnn* h, int Tpad) {
     if (Tpad <= h->cap_T)
         return AMX_OK;
+    // captured passes hold the old workspace addresses: drop them before the buffers move
+    for (auto& kv : h->graphs)
+        if (kv.second)
+            hipGraphExecDestroy(kv.second);
+    h->graphs.clear();
     hipFree(h->d_in);
     hipFree(h->d_act[0]);
     hipFree(h->d_act[1]);
@@ -1380,6 +1385,10 @@ static int ffnn_score_launches(amx_ffnn* h, const float* feats_dev, int feats_st
         if (fused) {
             const size_t need = (size_t)(h->Npad[L - 1] / 128) * Tpad;  // >= n-tiles of any configuration
             if (need > h->part_cap) {
+                for (auto& kv : h->graphs)  // captured passes hold the old addresses
+                    if (kv.second)
+                        hipGraphExecDestroy(kv.second);
+                h->graphs.clear();
                 hipFree(h->d_part_min);
                 hipFree(h->d_part_idx);
                 h->d_part_min = nullptr;

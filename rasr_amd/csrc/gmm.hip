@@ -1520,6 +1520,17 @@ struct amx_gmm {
     uint32_t* d_host_b = nullptr;
     size_t    host_f_cap = 0, host_s_cap = 0, host_b_cap = 0;
     void*     simd = nullptr;        // SIMD-diagonal-maximum tables and workspaces (gmm_simd.hip)
+    // small-batch passes of the screened scorer on unchanged device buffers (the decoder's ring buffer), replayed as HIP graphs
+    struct GraphKey {
+        const void *feats, *scores, *best;
+        hipStream_t stream;
+        int         T;
+        bool operator<(const GraphKey& o) const {
+            return std::tie(feats, scores, best, stream, T) < std::tie(o.feats, o.scores, o.best, o.stream, o.T);
+        }
+    };
+    std::map<GraphKey, hipGraphExec_t> graphs;
+    int                                use_graphs = 1;
     float*    d_scr_pmin = nullptr;  // fused statistics: per-tile arg-min partials
     unsigned* d_scr_pidx = nullptr;
     size_t    scr_part_cap = 0;
@@ -1557,6 +1568,10 @@ int score_screened(amx_gmm* h, const float* feats_dev, int T, float* scores_dev,
     for (int t0 = 0; t0 < T; t0 += chunk) {
         const int Tc = std::min(chunk, T - t0), Tpad = (Tc + 255) / 256 * 256;
         if (Tpad > h->scr_cap_T) {
+            for (auto& kv : h->graphs)  // captured passes hold the old workspace addresses: drop them before the buffers move
+                if (kv.second)
+                    hipGraphExecDestroy(kv.second);
+            h->graphs.clear();
             hipFree(h->d_scr_X);
             hipFree(h->d_scr_nx);
             hipFree(h->d_scr_q);
@@ -1979,6 +1994,8 @@ int amx_gmm_create(amx_ctx* ctx, const amx_gmm_model* m, amx_gmm** out) {
         amx_gmm_destroy(h);
         return r;
     }
+    if (const char* e = getenv("AMX_GMM_GRAPH"))
+        h->use_graphs = atoi(e);
     *out = h;
     return AMX_OK;
 }
@@ -1991,6 +2008,9 @@ void amx_gmm_destroy(amx_gmm* h) {
         return;
     }
     hipSetDevice(h->ctx->device);
+    for (auto& kv : h->graphs)
+        if (kv.second)
+            hipGraphExecDestroy(kv.second);
     amx_internal_gmm_simd_destroy(h->simd);
     hipFree(h->d_mix_off);
     hipFree(h->d_k_mean);
@@ -2098,8 +2118,40 @@ int amx_gmm_score_dev(amx_gmm* h, int mode, const float* feats_dev, int T, float
         AMX_HIP(hipGetLastError());
         return AMX_OK;
     }
-    if (!h->tied && h->screen && mode == AMX_GMM_MAX)
-        return score_screened(h, feats_dev, T, scores_dev, best_dev, false, nullptr, nullptr, nullptr);
+    if (!h->tied && h->screen && mode == AMX_GMM_MAX) {
+        // three launches and their gaps are a fifth of a 256-frame pass: replay them as a graph (not while profiling: the
+        // per-launch events are not part of the graph).  First call plain (sizes the workspaces), second call captures.
+        if (!(h->use_graphs && !h->ctx->profiling && T <= 4096))
+            return score_screened(h, feats_dev, T, scores_dev, best_dev, false, nullptr, nullptr, nullptr);
+        const amx_gmm::GraphKey key{feats_dev, scores_dev, best_dev, h->ctx->stream, T};
+        auto                    it = h->graphs.find(key);
+        if (it == h->graphs.end()) {
+            h->graphs[key] = nullptr;
+            return score_screened(h, feats_dev, T, scores_dev, best_dev, false, nullptr, nullptr, nullptr);
+        }
+        if (it->second == nullptr) {
+            hipGraph_t g = nullptr;
+            if (h->graphs.size() > 64 || hipStreamBeginCapture(h->ctx->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+                (void)hipGetLastError();
+                h->use_graphs = 0;  // a caller that keeps changing buffers, or a stream that cannot capture
+                return score_screened(h, feats_dev, T, scores_dev, best_dev, false, nullptr, nullptr, nullptr);
+            }
+            const int      r  = score_screened(h, feats_dev, T, scores_dev, best_dev, false, nullptr, nullptr, nullptr);
+            const bool     ok = hipStreamEndCapture(h->ctx->stream, &g) == hipSuccess && r == AMX_OK && g != nullptr;
+            hipGraphExec_t ex = nullptr;
+            if (!ok || hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) != hipSuccess) {
+                (void)hipGetLastError();
+                if (g)
+                    hipGraphDestroy(g);
+                h->use_graphs = 0;
+                return score_screened(h, feats_dev, T, scores_dev, best_dev, false, nullptr, nullptr, nullptr);
+            }
+            hipGraphDestroy(g);
+            it->second = ex;
+        }
+        AMX_HIP(hipGraphLaunch(it->second, h->ctx->stream));
+        return AMX_OK;
+    }
     if (!h->tied) {
         amx::GmmParams p;
         p.feats   = feats_dev;

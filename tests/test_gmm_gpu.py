@@ -586,3 +586,33 @@ def test_batch_int_scorer_exact(ctx, kind, monkeypatch):
     private = synth.gmm_cart(10, 1, 4, 16, seed=154, pooled=False)
     with pytest.raises(rasr_amd.AmxError, match="globally pooled"):
         rasr_amd.GmmFeatureScorer(ctx, private, feature_scorer_type="batch-diagonal-maximum-int").score(feats(4, 16, 1), want_best=False)
+
+
+def test_small_batch_graph_replay_and_workspace_growth(ctx):
+    """passes of <= 4096 frames on unchanged device buffers are replayed as HIP graphs from the third call on: results stay
+    bit-identical when the buffer CONTENTS change, and a larger pass in between (which moves the workspaces the captured
+    graphs point to) must not leave stale graphs behind"""
+    import torch
+
+    import rasr_amd
+    from oracle import OracleGmm
+    model = synth.gmm_cart(64, 1, 16, 40, seed=160, pooled=True)
+    sc, o = rasr_amd.GmmFeatureScorer(ctx, model), OracleGmm(model)
+    ctx.use_torch_stream()
+    xd = torch.empty((256, 40), dtype=torch.float32, device="cuda")
+    scores = torch.empty((256, 64), dtype=torch.float32, device="cuda")
+    best = torch.empty((256, 64), dtype=torch.int32, device="cuda")
+    big = torch.from_numpy(feats(6000, 40, 161)).cuda()
+    big_s = torch.empty((6000, 64), dtype=torch.float32, device="cuda")
+    for it in range(7):
+        x = feats(256, 40, 170 + it)
+        xd.copy_(torch.from_numpy(x))
+        sc.score_dev(xd, 256, scores, best)
+        torch.cuda.synchronize()
+        want, wbest = o.score(x)
+        assert np.array_equal(scores.cpu().numpy().view(np.uint32), want.view(np.uint32)), it
+        assert np.array_equal(best.cpu().numpy().astype(np.uint32), wbest)
+        if it == 3:                       # after the graph exists: a pass that regrows the workspaces
+            sc.score_dev(big, 6000, big_s, None)
+            torch.cuda.synchronize()
+            assert np.array_equal(big_s.cpu().numpy().view(np.uint32), o.score(big.cpu().numpy())[0].view(np.uint32))
