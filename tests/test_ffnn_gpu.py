@@ -189,3 +189,38 @@ def test_small_batch_graph_replay(ctx):
         nn.score_dev(xd, 64, T, sc)
         torch.cuda.synchronize()
         assert np.array_equal(sc.cpu().numpy().view(np.uint32), nn.score(x).view(np.uint32)), rep
+
+
+def test_full_size_shard_properties(ctx):
+    """BASELINE config 5 shard scale (440 -> 6 x 2048 -> 10 000 in bf16, 40 000 frames: more than one internal pass of 32 768):
+    rows are independent -- scoring the frames in another order permutes the scores bit for bit, and the fused arg-min
+    statistics equal a recount from the score matrix; a small slice scored on its own equals the rows of the big pass."""
+    import torch
+
+    import rasr_amd
+    Ws, bs, acts, logp = synth.ffnn([440] + [2048] * 6 + [10000], seed=7)
+    nn = rasr_amd.NnBatchFeatureScorer(ctx, Ws, bs, acts, log_prior=logp, priori_scale=1.0, precision="bf16")
+    T = 40000
+    x = np.random.Generator(np.random.PCG64(300)).standard_normal((T, 440)).astype(np.float32)
+    ctx.use_torch_stream()
+    xd = torch.from_numpy(x).cuda()
+    s = torch.empty((T, 10000), dtype=torch.float32, device="cuda")
+    best = torch.empty((T,), dtype=torch.int32, device="cuda")
+    counts = torch.zeros((10000,), dtype=torch.int64, device="cuda")
+    ssum = torch.zeros((1,), dtype=torch.float64, device="cuda")
+    nn.score_stats_dev(xd, 440, T, s, best, counts, ssum)
+    torch.cuda.synchronize()
+    perm = torch.randperm(T, device="cuda", generator=torch.Generator(device="cuda").manual_seed(2))
+    s2 = torch.empty_like(s)
+    nn.score_dev(xd[perm].contiguous(), 440, T, s2)
+    torch.cuda.synchronize()
+    assert torch.equal(s2.view(torch.int32), s[perm].view(torch.int32))
+    am = s.argmin(dim=1)
+    assert torch.equal(best.long(), am)
+    assert torch.equal(counts, torch.bincount(am, minlength=10000))
+    ref_sum = float(s.gather(1, am[:, None]).double().sum())
+    assert abs(float(ssum[0]) - ref_sum) <= 1e-9 * abs(ref_sum)
+    s3 = torch.empty((1024, 10000), dtype=torch.float32, device="cuda")
+    nn.score_dev(xd[32000:33024].contiguous(), 440, 1024, s3)     # small-batch tile configuration, straddling the pass boundary
+    torch.cuda.synchronize()
+    assert torch.equal(s3.view(torch.int32), s[32000:33024].view(torch.int32))

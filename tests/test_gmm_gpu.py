@@ -616,3 +616,51 @@ def test_small_batch_graph_replay_and_workspace_growth(ctx):
             sc.score_dev(big, 6000, big_s, None)
             torch.cuda.synchronize()
             assert np.array_equal(big_s.cpu().numpy().view(np.uint32), o.score(big.cpu().numpy())[0].view(np.uint32))
+
+
+def test_full_size_shard_properties(ctx, monkeypatch):
+    """BASELINE config 5 shard scale (10 000 states x 16 densities, 70 000 frames: more than one internal pass of 65 536):
+    size-independent properties instead of a full oracle run --
+      * the MFMA-screened scorer and the evaluate-everything kernel (AMX_GMM_SCREEN=0), two different algorithms, agree bit for bit
+        on every score and every best-density index;
+      * rows are independent: scoring the frames in another order permutes the results;
+      * a sample of frames on both sides of the pass boundary equals the oracle;
+      * the SIMD-diagonal-maximum scorer's i8 MFMA path and its general integer path agree bit for bit."""
+    import torch
+
+    import rasr_amd
+    from oracle import OracleGmm
+    model = synth.gmm_cart(10000, 16, 16, 40, seed=5, pooled=True)
+    T = 70000
+    x = feats(T, 40, 200)
+    ctx.use_torch_stream()
+    xd = torch.from_numpy(x).cuda()
+
+    def run(kind="diagonal-maximum", frames=xd, want_best=True):
+        sc = rasr_amd.GmmFeatureScorer(ctx, model, feature_scorer_type=kind)
+        s = torch.empty((frames.shape[0], 10000), dtype=torch.float32, device="cuda")
+        b = torch.empty((frames.shape[0], 10000), dtype=torch.int32, device="cuda") if want_best else None
+        sc.score_dev(frames, frames.shape[0], s, b)
+        torch.cuda.synchronize()
+        return s, b
+
+    s_scr, b_scr = run()
+    monkeypatch.setenv("AMX_GMM_SCREEN", "0")
+    s_dir, b_dir = run()
+    monkeypatch.delenv("AMX_GMM_SCREEN")
+    assert torch.equal(s_scr.view(torch.int32), s_dir.view(torch.int32)) and torch.equal(b_scr, b_dir)
+    del s_dir, b_dir
+    perm = torch.randperm(T, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+    s_p, b_p = run(frames=xd[perm].contiguous())
+    assert torch.equal(s_p.view(torch.int32), s_scr[perm].view(torch.int32)) and torch.equal(b_p, b_scr[perm])
+    del s_p, b_p
+    sample = np.array([0, 1, 255, 256, 65535, 65536, 65537, T - 1])
+    osc, obest = OracleGmm(model).score(x[sample])
+    assert np.array_equal(s_scr[sample].cpu().numpy().view(np.uint32), osc.view(np.uint32))
+    assert np.array_equal(b_scr[sample].cpu().numpy().astype(np.uint32), obest)
+    del s_scr, b_scr
+    s_m, b_m = run("SIMD-diagonal-maximum")
+    monkeypatch.setenv("AMX_GMM_SIMD_MFMA", "0")
+    s_g, b_g = run("SIMD-diagonal-maximum", frames=xd[:8192])
+    monkeypatch.delenv("AMX_GMM_SIMD_MFMA")
+    assert torch.equal(s_m[:8192].view(torch.int32), s_g.view(torch.int32)) and torch.equal(b_m[:8192], b_g)
