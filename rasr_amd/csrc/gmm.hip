@@ -2203,7 +2203,7 @@ int amx_gmm_score_dev(amx_gmm* h, int mode, const float* feats_dev, int T, float
         dp.dens_tile = 16;
         const int  fb      = amx::ceil_div(Tc, 256);
         const bool use_uni = h->uniform;
-        static const int screen = getenv("AMX_GMM_SCREEN") ? atoi(getenv("AMX_GMM_SCREEN")) : 1;  // 0: plain f64 kernel (A/B)
+        const int screen = getenv("AMX_GMM_SCREEN") ? atoi(getenv("AMX_GMM_SCREEN")) : 1;  // 0: plain f64 kernel (A/B runs, tests)
         const bool need64  = use_uni && mode == AMX_GMM_MAX && !screen;
         if (need64 && need > h->dist64_cap) {
             hipFree(h->d_dist64);

@@ -664,3 +664,26 @@ def test_full_size_shard_properties(ctx, monkeypatch):
     s_g, b_g = run("SIMD-diagonal-maximum", frames=xd[:8192])
     monkeypatch.delenv("AMX_GMM_SIMD_MFMA")
     assert torch.equal(s_m[:8192].view(torch.int32), s_g.view(torch.int32)) and torch.equal(b_m[:8192], b_g)
+
+
+def test_full_size_tied_properties(ctx, monkeypatch):
+    """BASELINE config 2 at full size (4096 shared densities, 10 000 tied states, batch 256): the f32-screened (min,+) tile kernel
+    and the plain f64 kernel (AMX_GMM_SCREEN=0) agree bit for bit on all 2.56 M scores and density indices; two frames equal
+    the oracle; frame permutations permute the results."""
+    import torch
+
+    import rasr_amd
+    from oracle import OracleGmm
+    model = synth.gmm_tied(10000, 4096, 40, seed=5, pooled=True)
+    x = feats(256, 40, 210)
+    sc = rasr_amd.GmmFeatureScorer(ctx, model)
+    a, ab = sc.score(x)
+    monkeypatch.setenv("AMX_GMM_SCREEN", "0")
+    b, bb = sc.score(x)
+    monkeypatch.delenv("AMX_GMM_SCREEN")
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and np.array_equal(ab, bb)
+    perm = np.random.Generator(np.random.PCG64(3)).permutation(256)
+    c, cb = sc.score(x[perm])
+    assert np.array_equal(c.view(np.uint32), a[perm].view(np.uint32)) and np.array_equal(cb, ab[perm])
+    osc, obest = OracleGmm(model).score(x[[0, 255]])
+    assert np.array_equal(a[[0, 255]].view(np.uint32), osc.view(np.uint32)) and np.array_equal(ab[[0, 255]], obest)
