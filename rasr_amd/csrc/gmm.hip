@@ -1234,7 +1234,7 @@ __global__ __launch_bounds__(256) void gmm_screen_exact_kernel(const float* __re
     extern __shared__ __attribute__((aligned(16))) char lds[];
     float* s_mu = (float*)lds;                    // [256][LD]
     float* s_is = s_mu + 256 * LD;                // [256][LD] (per-density covariance only)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x;
     const int m0 = blockIdx.x * 16;
     // slot -> mean / covariance row (one slot per thread), then a cooperative copy: 256 rows x DIM floats, consecutive
     // threads on consecutive floats of a row

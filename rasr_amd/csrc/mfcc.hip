@@ -521,7 +521,6 @@ size_t mfcc_lds_bytes(const amx::MfccTables& t) {
 // (Signal/AutoregressionToCepstrum.cc:21-35: 2 log(gain) in f64, the recursion in f32 left to right).  The per-lane arrays
 // live in LDS as [index][lane] (every lane touches the same index at the same time: conflict free); a failed recursion
 // (zero prediction error) writes NaNs.
-constexpr int kMaxAc = 64;
 __host__ __device__ constexpr size_t lpc_lds_bytes(int n_ac) {
     return (size_t)64 * n_ac * (8 + 8 + 4 + 4 + 4);
 }
