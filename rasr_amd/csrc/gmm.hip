@@ -645,6 +645,14 @@ __device__ __forceinline__ float min3_raw(float a, float b, float c) {
     asm("v_min3_f32 %0, %1, %2, %3" : "=v"(o) : "v"(a), "v"(b), "v"(c));
     return o;
 }
+// The compiler's hazard recognizer does not look into inline assembly: a min3_raw scheduled right behind the MFMA that produces
+// its operands reads the accumulator before the last K step has landed.  The FIRST reduction step of every accumulator vector
+// therefore goes through the compiler (it inserts the wait states), and the asm steps depend on its result.  (Unnoticed as long
+// as the last 16 K columns of the screen operand were zero; dim 48 pooled / dim 24 with per-density covariances put the constant
+// columns there and lost every survivor -- found by tools/fuzz_gmm.py.)
+__device__ __forceinline__ float min3_first(float a, float b, float c) {
+    return __builtin_fminf(__builtin_fminf(a, b), c);
+}
 
 // ---- register-tiled (min,+) product carrying that screen: C[t][m] = min_k (a^[k][m] + dist[k][t]), a^ tabulated
 // [K][mix_pad] next to the weights, max_k |a^| per mixture tabulated too.
@@ -910,7 +918,7 @@ __device__ __forceinline__ void gmm_screen_epilogue(const gmm_f32x16 (&acc)[4][2
             for (int gp = 0; gp < 2; ++gp) {
                 const gmm_f32x16& c = acc[i][j];
                 const int         o = gp * 8;
-                float mn = min3_raw(c[o], c[o + 1], c[o + 2]);
+                float mn = min3_first(c[o], c[o + 1], c[o + 2]);
                 mn       = min3_raw(mn, c[o + 3], c[o + 4]);
                 mn       = min3_raw(mn, c[o + 5], c[o + 6]);
                 mn       = min3_raw(mn, c[o + 7], c[o + 7]);
@@ -1164,7 +1172,7 @@ __global__ __launch_bounds__(512, 2) void gmm_screen_rows_kernel(const _Float16*
                 const gmm_f16x8 a = *(const gmm_f16x8*)(abase + rr * 128 + (((ks * 2 + fk) ^ ((rr >> 1) & 7)) << 4));
                 c                 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bx[ks], c, 0, 0, 0);
             }
-            float mn = min3_raw(c[0], c[1], c[2]);
+            float mn = min3_first(c[0], c[1], c[2]);
             mn       = min3_raw(mn, c[3], c[4]);
             mn       = min3_raw(mn, c[5], c[6]);
             mn       = min3_raw(mn, c[7], c[8]);
@@ -1628,6 +1636,8 @@ int score_screened(amx_gmm* h, const float* feats_dev, int T, float* scores_dev,
                                    h->d_scr_cabs, h->d_scr_nx, h->d_scr_q, h->d_scr_masks, ntr, d);
             }
         }
+        if (getenv("AMX_GMM_SCREEN_ALL"))  // debugging aid: every slot survives (the exact stage then evaluates all densities)
+            hipMemsetAsync(h->d_scr_masks, 0xff, (size_t)Tpad * h->scr_Mpad16 * 2, st);
         float*    pmin = nullptr;
         unsigned* pidx = nullptr;
         if (stats) {

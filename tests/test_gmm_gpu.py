@@ -687,3 +687,15 @@ def test_full_size_tied_properties(ctx, monkeypatch):
     assert np.array_equal(c.view(np.uint32), a[perm].view(np.uint32)) and np.array_equal(cb, ab[perm])
     osc, obest = OracleGmm(model).score(x[[0, 255]])
     assert np.array_equal(a[[0, 255]].view(np.uint32), osc.view(np.uint32)) and np.array_equal(ab[[0, 255]], obest)
+
+
+@pytest.mark.parametrize("variant", ["rows", "persist", "simple"])
+@pytest.mark.parametrize("dim,pooled", [(16, True), (16, False), (24, True), (24, False), (32, True), (32, False), (33, True), (39, True),
+                                        (40, True), (40, False), (45, True), (48, True), (48, False), (64, True), (64, False)])
+def test_every_screened_dimension_and_operand_width(ctx, monkeypatch, dim, pooled, variant):
+    """every dimension the MFMA screen is instantiated for, with pooled and per-density covariances: the screen operand is dim or
+    2 dim columns wide plus two constant columns.  dim 48 pooled / dim 24 per-density are the cases whose constants land in the LAST
+    16 K columns -- the MFMA step whose result an inline-asm v_min3 once read too early (found by tools/fuzz_gmm.py)."""
+    monkeypatch.setenv("AMX_GMM_SCREEN_KERNEL", variant)
+    model = synth.gmm_cart(70, 1, 16, dim, seed=300 + dim, pooled=pooled)
+    assert_exact(ctx, model, feats(300, dim, 301))

@@ -1,0 +1,51 @@
+"""tools/fuzz_gmm.py [n_cases] [seed] -- random diagonal-GMM models / feature batches through every maximum-approximation path of the
+library against the oracle, bit for bit: private and pooled covariances, 1..16 and longer mixtures, tied lists, supported and
+unsupported dimensions, features with outliers that overflow the f16 screen operand (all-slot frames), duplicated densities.
+Not part of the test suite (minutes of oracle time); run on a GPU box after touching gmm.hip / gmm_simd.hip."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import rasr_amd  # noqa: E402
+from oracle import OracleGmm  # noqa: E402
+from tests import synth  # noqa: E402
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+rng = np.random.Generator(np.random.PCG64(int(sys.argv[2]) if len(sys.argv) > 2 else 1))
+ctx = rasr_amd.Context(0)
+bad = 0
+for case in range(n_cases):
+    dim = int(rng.choice([16, 24, 32, 33, 39, 40, 45, 48, 64, 7, 50]))
+    pooled = bool(rng.integers(0, 2))
+    kind = rng.choice(["cart", "cart", "cart", "long", "tied"])
+    seed = int(rng.integers(1, 1 << 30))
+    if kind == "cart":
+        model = synth.gmm_cart(int(rng.integers(1, 300)), 1, int(rng.integers(1, 17)), dim, seed=seed, pooled=pooled)
+    elif kind == "long":
+        model = synth.gmm_cart(int(rng.integers(1, 40)), 17, 60, dim, seed=seed, pooled=pooled)
+    else:
+        nd = int(rng.integers(8, 200))
+        model = synth.gmm_tied(int(rng.integers(4, 120)), nd, dim, seed=seed, pooled=pooled, alpha=float(rng.choice([0.1, 1.0])),
+                               k_per_mix=None if rng.integers(0, 2) else int(rng.integers(4, nd + 1)))
+    if rng.integers(0, 3) == 0 and model["means"].shape[0] > 2:       # duplicated densities
+        model["means"][1] = model["means"][0]
+    T = int(rng.choice([1, 3, 63, 64, 65, 255, 256, 257, 700]))
+    x = rng.standard_normal((T, dim)).astype(np.float32) * np.float32(rng.choice([0.3, 1.0, 3.0]))
+    if rng.integers(0, 3) == 0:
+        x[rng.integers(0, T)] *= np.float32(1e4)                      # does not fit the f16 operand: frame keeps all slots
+    if rng.integers(0, 6) == 0:
+        x[rng.integers(0, T), rng.integers(0, dim)] = np.float32(rng.choice([np.inf, -np.inf, np.nan, 1e30]))
+    o = OracleGmm(model)
+    want, wbest = o.score(x)
+    got, best = rasr_amd.GmmFeatureScorer(ctx, model).score(x)
+    ok = np.array_equal(got.view(np.uint32), want.view(np.uint32)) and np.array_equal(best, wbest)
+    sw, sb, _ = o.score_simd(x)
+    sg, sgb = rasr_amd.GmmFeatureScorer(ctx, model, feature_scorer_type="SIMD-diagonal-maximum").score(x)
+    ok_simd = np.array_equal(sg.view(np.uint32), sw.view(np.uint32)) and np.array_equal(sgb, sb)
+    if not (ok and ok_simd):
+        bad += 1
+        print("MISMATCH case %d: kind=%s dim=%d pooled=%s seed=%d T=%d max=%s simd=%s" % (case, kind, dim, pooled, seed, T, ok, ok_simd))
+print("%d cases, %d mismatches" % (n_cases, bad))
+sys.exit(1 if bad else 0)
