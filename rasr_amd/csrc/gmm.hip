@@ -779,8 +779,10 @@ __global__ __launch_bounds__(256) void gmm_tied_tile_kernel(const float* __restr
                     const gmm_f32x2 e = (gmm_f32x2{dv[j], dv[j + 1]} + gmm_f32x2{av[i], av[i]}) - gmm_f32x2{thr[i][j], thr[i][j + 1]};
                     worst             = min3_raw(worst, e.x, e.y);
                 }
-            if (worst <= 0.f) {
-                const int kk = c * TT_KB + k;  // < K: padded rows are FLT_MAX
+            const int kk = c * TT_KB + k;
+            // kk < K: the padding rows (a^ = FLT_MAX) can only "pass" when a frame's sums are all inf / NaN (a non-finite feature);
+            // the reference then keeps its initial (FLT_MAX, no density), and so must this
+            if (worst <= 0.f && kk < dims.K) {
                 const double ln = g_ln64[kk];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {

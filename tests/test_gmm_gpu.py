@@ -699,3 +699,18 @@ def test_every_screened_dimension_and_operand_width(ctx, monkeypatch, dim, poole
     monkeypatch.setenv("AMX_GMM_SCREEN_KERNEL", variant)
     model = synth.gmm_cart(70, 1, 16, dim, seed=300 + dim, pooled=pooled)
     assert_exact(ctx, model, feats(300, dim, 301))
+
+
+@pytest.mark.parametrize("pooled", [True, False])
+def test_tied_non_finite_frames_keep_the_initial_result(ctx, pooled):
+    """a frame with an inf / NaN / 1e30 feature has no finite density score: the reference keeps (FLT_MAX / 2, no density).  On the
+    uniform tied path the chunk padding rows (density count not a multiple of 64) must not be taken for candidates then
+    (found by tools/fuzz_gmm.py)."""
+    model = synth.gmm_tied(30, 150, 32, seed=320, pooled=pooled, alpha=1.0)
+    x = feats(70, 32, 321)
+    x[5, 3] = np.inf
+    x[6, 0] = np.nan
+    x[7, 9] = 1e30
+    x[8, 1] = -np.inf
+    x[9] *= np.float32(1e4)
+    assert_exact(ctx, model, x)
