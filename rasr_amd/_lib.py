@@ -146,6 +146,13 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("rasr_amd: %s is missing -- run `python -c 'import __graft_entry__ as g; g.build()'` "
                                "(hipcc, gfx950). This package has no CPU fallback." % LIB_PATH)
+        # When torch is installed its bundled HIP runtime must be the one the process loads first: a process that loads
+        # /opt/rocm's libamdhip64 (through this library) and torch's copy afterwards ends up with two runtimes, and torch's
+        # then reports "No HIP GPUs are available".  Tests and bench use torch for device buffers, so import it up front.
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError if the ABI symbol is missing
