@@ -1,0 +1,53 @@
+"""tools/fuzz_ffnn.py [n_cases] [seed] -- random network shapes and batch sizes through the bf16 GEMM kernels: every tile configuration
+(AMX_GEMM_CFG 0 / 2 / 3 / 4 and the automatic choice) must give bit-identical scores and arg-min statistics, and the bf16 result must
+stay within bf16 rounding of the fp32 MFMA path (itself checked against the oracle elsewhere)."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import rasr_amd  # noqa: E402
+from tests import synth  # noqa: E402
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+rng = np.random.Generator(np.random.PCG64(int(sys.argv[2]) if len(sys.argv) > 2 else 1))
+ctx = rasr_amd.Context(0)
+ctx.use_torch_stream()
+bad = 0
+for case in range(n_cases):
+    dims = [int(rng.integers(1, 600))] + [int(rng.choice([64, 100, 257, 512, 1000, 2048])) for _ in range(int(rng.integers(0, 3)))] + \
+           [int(rng.choice([1, 37, 128, 1000, 4501, 10000]))]
+    T = int(rng.choice([1, 100, 256, 1024, 3000, 9000, 20000]))
+    Ws, bs, acts, logp = synth.ffnn(dims, seed=int(rng.integers(1, 1000)), act=int(rng.choice([1, 2, 3])))
+    x = torch.from_numpy(rng.standard_normal((T, dims[0])).astype(np.float32)).cuda()
+    outs = {}
+    for cfg in ("auto", "0", "2", "3", "4", "fp32"):
+        os.environ.pop("AMX_GEMM_CFG", None)
+        if cfg not in ("auto", "fp32"):
+            os.environ["AMX_GEMM_CFG"] = cfg
+        nn = rasr_amd.NnBatchFeatureScorer(ctx, Ws, bs, acts, log_prior=logp, priori_scale=1.0, precision="fp32" if cfg == "fp32" else "bf16")
+        s = torch.empty((T, dims[-1]), dtype=torch.float32, device="cuda")
+        best = torch.empty((T,), dtype=torch.int32, device="cuda")
+        counts = torch.zeros((dims[-1],), dtype=torch.int64, device="cuda")
+        ssum = torch.zeros((1,), dtype=torch.float64, device="cuda")
+        nn.score_stats_dev(x, dims[0], T, s, best, counts, ssum)
+        torch.cuda.synchronize()
+        outs[cfg] = (s, best, counts)
+        if cfg != "fp32" and not torch.equal(best.long(), s.argmin(dim=1)):
+            bad += 1
+            print("MISMATCH fused arg-min", cfg, dims, T)
+    ref = outs["auto"]
+    for cfg in ("0", "2", "3", "4"):
+        if not (torch.equal(outs[cfg][0].view(torch.int32), ref[0].view(torch.int32)) and torch.equal(outs[cfg][1], ref[1]) and torch.equal(outs[cfg][2], ref[2])):
+            bad += 1
+            print("MISMATCH config", cfg, "vs auto", dims, T, float((outs[cfg][0] - ref[0]).abs().max()))
+    f32 = outs["fp32"][0]
+    scale = float(f32.abs().max()) + 1.0
+    err = float((ref[0] - f32).abs().max())
+    if not err <= 3e-2 * scale:
+        bad += 1
+        print("MISMATCH bf16 vs fp32", dims, T, err, scale)
+print("%d cases, %d mismatches" % (n_cases, bad))
+sys.exit(1 if bad else 0)
