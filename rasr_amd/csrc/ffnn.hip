@@ -1055,7 +1055,8 @@ void launch_bf16v(amx_ffnn* h, int l, const void* x, int ldx, void* out, int ldo
     auto      k   = amx::gemm_bf16_kernel<C, ACT, LAST, VAR>;
     // super-tile order: the tiles one XCD holds at a time share operand panels in its L2 (tools/gemm_probe.hip: output
     // layer 1.66 -> 1.44 ms with 8x4 blocks of 256x256 tiles; row-major order re-fetches every W panel per tile)
-    const int gt = h->group_t >= 0 ? h->group_t : (C::BN == 128 ? 2 : 8), gn = h->group_n >= 0 ? h->group_n : 4;
+    // small-batch configurations (BN = 128): all frame tiles of two weight panels per XCD, so a panel is read once (batch 1024: 8x2 0.188 ms, 2x4 0.202)
+    const int gt = h->group_t >= 0 ? h->group_t : 8, gn = h->group_n >= 0 ? h->group_n : (C::BN == 128 ? 2 : 4);
     constexpr int lds_bytes = amx::gemm_scratch_bytes<C, LAST>() + C::BN * 4;
     static_assert(lds_bytes <= 160 * 1024, "LDS budget");
     hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
