@@ -23,7 +23,7 @@ for case in range(n_cases):
     Ws, bs, acts, logp = synth.ffnn(dims, seed=int(rng.integers(1, 1000)), act=int(rng.choice([1, 2, 3])))
     x = torch.from_numpy(rng.standard_normal((T, dims[0])).astype(np.float32)).cuda()
     outs = {}
-    for cfg in ("auto", "0", "2", "3", "4", "fp32"):
+    for cfg in ("auto", "0", "2", "3", "4", "6", "fp32"):
         os.environ.pop("AMX_GEMM_CFG", None)
         if cfg not in ("auto", "fp32"):
             os.environ["AMX_GEMM_CFG"] = cfg
@@ -39,7 +39,7 @@ for case in range(n_cases):
             bad += 1
             print("MISMATCH fused arg-min", cfg, dims, T)
     ref = outs["auto"]
-    for cfg in ("0", "2", "3", "4"):
+    for cfg in ("0", "2", "3", "4", "6"):
         if not (torch.equal(outs[cfg][0].view(torch.int32), ref[0].view(torch.int32)) and torch.equal(outs[cfg][1], ref[1]) and torch.equal(outs[cfg][2], ref[2])):
             bad += 1
             print("MISMATCH config", cfg, "vs auto", dims, T, float((outs[cfg][0] - ref[0]).abs().max()))
