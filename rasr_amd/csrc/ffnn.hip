@@ -406,7 +406,12 @@ __global__ __launch_bounds__(C::THREADS) void gemm_bf16_kernel(const bf16_t* __r
     for (int kt = 0; kt < KT; ++kt) {
         // tiles kt .. min(kt+STAGES-2, KT-1) are outstanding; keep all but tile kt in flight
         const int ahead = min(C::STAGES - 2, KT - 1 - kt);
-        if (C::STAGES >= 4 && ahead == 2)
+        static_assert(C::STAGES <= 6 && 4 * C::LOADS < 64, "vmcnt immediate");
+        if (C::STAGES >= 6 && ahead == 4)
+            wait_vmcnt<4 * C::LOADS>();
+        else if (C::STAGES >= 5 && ahead == 3)
+            wait_vmcnt<3 * C::LOADS>();
+        else if (C::STAGES >= 4 && ahead == 2)
             wait_vmcnt<2 * C::LOADS>();
         else if (C::STAGES >= 3 && ahead == 1)
             wait_vmcnt<C::LOADS>();

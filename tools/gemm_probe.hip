@@ -122,6 +122,9 @@ void dump_trace(Problem& p, size_t trace_n) {
 
 int main(int argc, char** argv) {
     Problem p;
+    if (getenv("PROBE_N")) p.N = atoi(getenv("PROBE_N"));  // small problems: PROBE_N=2048 PROBE_T=1024 ... s0 s128 s136 s144 s192 t0 t128
+    if (getenv("PROBE_T")) p.T = atoi(getenv("PROBE_T"));
+    if (getenv("PROBE_K")) p.K = atoi(getenv("PROBE_K"));
     p.Npad = (p.N + 255) / 256 * 256;
     p.Tpad = p.T;
     hipDeviceProp_t prop;
@@ -158,7 +161,28 @@ int main(int argc, char** argv) {
             sscanf(s.c_str() + s.find(':') + 1, "%dx%d", &p.gt, &p.gn);
             s = s.substr(0, s.find(':'));
         }
-        if (s == "p0") run_pipe<CfgC, 0>(p, iters);
+        using CfgS = amx::GemmCfg<128, 64, 2, 2, 2>;
+        using CfgS3 = amx::GemmCfg<128, 64, 2, 2, 3>;
+        using CfgS4 = amx::GemmCfg<128, 64, 2, 2, 4>;
+        using CfgS5 = amx::GemmCfg<128, 64, 2, 2, 5>;
+        using CfgS6 = amx::GemmCfg<128, 64, 2, 2, 6>;
+        if (s == "u0") run<CfgS4, 0>(p, iters);
+        else if (s == "u192") run<CfgS4, 64 | 128>(p, iters);
+        else if (s == "v0") run<CfgS5, 0>(p, iters);
+        else if (s == "v192") run<CfgS5, 64 | 128>(p, iters);
+        else if (s == "w0") run<CfgS6, 0>(p, iters);
+        else if (s == "w192") run<CfgS6, 64 | 128>(p, iters);
+        else if (s == "w128") run<CfgS6, 128>(p, iters);
+        else if (s == "s0") run<CfgS, 0>(p, iters);
+        else if (s == "s128") run<CfgS, 128>(p, iters);
+        else if (s == "s136") run<CfgS, 8 | 128>(p, iters);
+        else if (s == "s144") run<CfgS, 16 | 128>(p, iters);
+        else if (s == "s192") run<CfgS, 64 | 128>(p, iters);
+        else if (s == "s152") run<CfgS, 8 | 16 | 128>(p, iters);
+        else if (s == "t0") run<CfgS3, 0>(p, iters);
+        else if (s == "t128") run<CfgS3, 128>(p, iters);
+        else if (s == "t192") run<CfgS3, 64 | 128>(p, iters);
+        else if (s == "p0") run_pipe<CfgC, 0>(p, iters);
         else if (s == "p2") run_pipe<CfgC, 2>(p, iters);
         else if (s == "p4") run_pipe<CfgC, 4>(p, iters);
         else if (s == "ptrace") { run_pipe<CfgC, 1>(p, 1); dump_trace(p, trace_n); }
