@@ -31,6 +31,17 @@ for case in range(n_cases):
                                k_per_mix=None if rng.integers(0, 2) else int(rng.integers(4, nd + 1)))
     if rng.integers(0, 3) == 0 and model["means"].shape[0] > 2:       # duplicated densities
         model["means"][1] = model["means"][0]
+    twist = int(rng.integers(0, 8))
+    if twist == 0:      # zero-weight densities: the text reader stores Core::Type<f64>::min for them
+        lw = model["log_weight"].copy()
+        lw[rng.random(len(lw)) < 0.2] = -1.7976931348623157e+308
+        model["log_weight"] = lw
+    elif twist == 1:    # variances over eight orders of magnitude
+        model["variances"] = (model["variances"] * np.float32(10.0) ** rng.integers(-4, 5, model["variances"].shape)).astype(np.float32)
+    elif twist == 2:    # means far from the features
+        model["means"] = (model["means"] * np.float32(100.0)).astype(np.float32)
+    elif twist == 3:    # nearly equal weights and means: many near ties
+        model["means"] = (model["means"][:1] + np.float32(1e-3) * model["means"]).astype(np.float32)
     T = int(rng.choice([1, 3, 63, 64, 65, 255, 256, 257, 700]))
     x = rng.standard_normal((T, dim)).astype(np.float32) * np.float32(rng.choice([0.3, 1.0, 3.0]))
     if rng.integers(0, 3) == 0:
