@@ -62,6 +62,17 @@ for case in range(n_cases):
         tol = dict(rtol=1e-12, atol=1e-9) if mode == 0 else dict(rtol=5e-5, atol=5e-6 * max(1.0, float(np.abs(want).max())))
         if not np.allclose(g, want, **tol):
             fail("accumulate mode %d" % mode, dim=dim, pooled=pooled, T=T, seed=seed, err=float(np.abs(g - want).max()))
+    # unweighted Viterbi kernel (frames of one density chained per block), both ways of passing the chosen densities
+    run = np.repeat(rng.integers(0, nm, T // 5 + 1), 5)[:T].astype(np.uint32)     # bursty alignment
+    chosen2 = obest[np.arange(T), run].astype(np.uint32)
+    want = o.accumulate(x, run, chosen2)
+    bd = torch.from_numpy(obest.astype(np.int32)).cuda()
+    for ld, arg in ((nm, bd), (0, torch.from_numpy(chosen2.astype(np.int32)).cuda())):
+        acc = torch.zeros(sc.accumulator_size(), dtype=torch.float64, device="cuda")
+        sc.accumulate_dev(xd, T, torch.from_numpy(run.astype(np.int32)).cuda(), arg, ld, acc)
+        torch.cuda.synchronize()
+        if not np.allclose(acc.cpu().numpy(), want, rtol=1e-12, atol=1e-9):
+            fail("accumulate (unweighted, ld=%d)" % ld, dim=dim, pooled=pooled, T=T, seed=seed)
     # ---- front-ends
     fs = float(rng.choice([8000.0, 11025.0, 16000.0, 22050.0]))
     n = int(rng.choice([1, 159, 400, 401, 1999, 16000, 48001]))
