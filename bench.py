@@ -100,31 +100,53 @@ def make_batch(n_utt, seconds, seed):
     return pcm, off
 
 
-def gmm_cart_roofline(ctx, nk, frames):
-    """roofline entry of the MFMA-screened private-density GMM scorer (f16 screen GEMM + exact f32 evaluation of survivors)"""
+def gmm_cart_roofline(ctx, sc, nk, n_mix, dim, frames):
+    """roofline entry of the screened private-density GMM scorer.
+
+    Fused path (gmm_fused_kernel): `achieved` is the f32 arithmetic the kernel really issues for the reference's distance --
+    (densities evaluated exactly, from a device counter) x 4 dim operations (sub, mul, mul, add: unfused by definition of the
+    reference's SSE build) -- over the kernel's HIP-event time, priced against the f32 vector peak; `frac` is therefore a
+    utilisation <= 1.  The reference scorer's algorithmic flops (every density) over the same time are reported
+    separately as `algorithmic_speedup_vs_dense` (how much faster than a dense f32 evaluation at peak), and the HBM side as
+    `hbm_algorithmic_GBps` (scores + best densities out, features + model records in)."""
     ms_x, n_x = ctx.profile_get("gmm")
     ms_s, n_s = ctx.profile_get("gmm_screen")
     ms_p, n_p = ctx.profile_get("gmm_screen_pack")
     if n_x == 0:
         return None
+    surv, pairs = sc.screen_counts(False)
+    alg = (3.0 * dim + 2.0) * nk * frames   # SURVEY 8(d) cfg 3 secondary: D (3d + 2) flop per frame for the reference scorer
+    if pairs:  # fused kernel: one launch does screen + exact evaluation
+        t = ms_x * 1e-3
+        per_launch = surv / float(n_x)
+        ex = per_launch * 4.0 * dim
+        by = frames * (n_mix * 8.0 + dim * 4.0) + (n_mix + 15) // 16 * 78848.0
+        scr = 2.0 * 64 * ((n_mix + 15) // 16 * 256) * frames
+        return dict(bound="mfma", kernel="gmm_fused_kernel<%d> (f16 MFMA screen + exact f32/f64 evaluation of the survivors)" % dim,
+                    note="VALU-bound kernel priced against the f32 vector peak (= f32 MFMA peak, 157.3 TFLOP/s; unfused mul/add can "
+                         "reach half of it). achieved = densities evaluated exactly (device counter) x 4 dim f32 operations / kernel time",
+                    achieved=round(ex / t / 1e12, 2), peak=FP32_TFLOPS, unit="TFLOP/s", frac=round(ex / t / 1e12 / FP32_TFLOPS, 4),
+                    traffic=measured_traffic("gmm_fused_kernel<%d> (%d mixtures, %d frames)" % (dim, n_mix, frames)),
+                    avg_launch_ms=round(ms_x, 4), pack_launch_ms=round(ms_p, 4), launches=n_x, flops_per_launch=ex,
+                    survivors_per_mixture=round(surv / float(pairs), 4),
+                    screen_mfma_tflops=round(scr / t / 1e12, 1), screen_mfma_frac=round(scr / t / 1e12 / MFMA_BF16_TFLOPS, 4),
+                    hbm_algorithmic_GBps=round(by / t / 1e9, 1), hbm_frac=round(by / t / 1e9 / HBM_PEAK_GBS, 4),
+                    algorithmic_speedup_vs_dense=round(alg / (t + ms_p * 1e-3) / 1e12 / FP32_TFLOPS, 3))
     if n_s == 0:  # screen disabled (AMX_GMM_SCREEN=0): the exact-everything kernel
-        ops = 4.0 * nk * 40 * frames
+        ops = 4.0 * nk * dim * frames
         ach = ops / (ms_x * 1e-3) / 1e12
-        return dict(bound="mfma", note="f32 VALU kernel priced against the f32 vector peak (= f32 MFMA peak)", kernel="gmm_direct_kernel<40,MaxState>",
+        return dict(bound="mfma", note="f32 VALU kernel priced against the f32 vector peak (= f32 MFMA peak)", kernel="gmm_direct_kernel<%d,MaxState>" % dim,
                     achieved=round(ach, 3), peak=FP32_TFLOPS, unit="TFLOP/s", frac=round(ach / FP32_TFLOPS, 4), traffic=None,
                     avg_launch_ms=round(ms_x, 4), launches=n_x, flops_per_launch=ops)
-    alg = 122.0 * nk * frames   # SURVEY 8(d) cfg 3 secondary: D (3d + 2) flop per frame for the reference scorer
-    t = (ms_x + ms_s + ms_p) * 1e-3
-    return dict(bound="mfma", kernel="gmm_screen_exact_kernel<40,pooled> (+ gmm_screen_rows_kernel, gmm_screen_pack_kernel)",
-                note="f32 VALU kernel priced against the f32 vector peak (= f32 MFMA peak). achieved = the reference scorer's algorithmic "
-                     "flops (densities x 122 flop per frame) / (pack + screen + exact time); the f16 MFMA screen leaves ~1.04 of 16 "
-                     "densities per state for the exact f32 evaluation, so the flops actually executed are ~9 % of the algorithmic count",
-                achieved=round(alg / t / 1e12, 2), peak=FP32_TFLOPS, unit="TFLOP/s", frac=round(alg / t / 1e12 / FP32_TFLOPS, 4),
+    # two-kernel path (AMX_GMM_FUSED=0, per-density covariances, dim > 40): HBM-side figure of the exact stage (scores, best
+    # densities, survivor masks) -- no survivor counter there
+    t = ms_x * 1e-3
+    by = frames * (n_mix * 8.0 + ((n_mix + 15) // 16 * 16) * 2.0 + dim * 4.0)
+    return dict(bound="hbm", kernel="gmm_screen_exact_kernel<%d> (+ gmm_screen_rows_kernel, gmm_screen_pack_kernel)" % dim,
+                achieved=round(by / t / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(by / t / 1e9 / HBM_PEAK_GBS, 4),
                 traffic=measured_traffic("gmm_screen_exact_kernel<40,pooled> (10000 x 16 densities, %d frames)" % frames),
-                avg_launch_ms=round(ms_x, 4), screen_launch_ms=round(ms_s, 4), pack_launch_ms=round(ms_p, 4), launches=n_x, flops_per_launch=alg,
-                # what the exact stage really executes: ~1.04 survivors per state x (4 dim + 10) f32 operations, unfused by definition
-                executed_tflops=round(1.04 * (nk / 16.0) * 170.0 * frames / (ms_x * 1e-3) / 1e12, 2),
-                executed_frac=round(1.04 * (nk / 16.0) * 170.0 * frames / (ms_x * 1e-3) / 1e12 / FP32_TFLOPS, 4))
+                avg_launch_ms=round(ms_x, 4), screen_launch_ms=round(ms_s, 4), pack_launch_ms=round(ms_p, 4), launches=n_x,
+                bytes_per_launch=by, algorithmic_speedup_vs_dense=round(alg / ((ms_x + ms_s + ms_p) * 1e-3) / 1e12 / FP32_TFLOPS, 3))
 
 
 class NnPipeline:
@@ -265,7 +287,7 @@ class Pipeline(NnPipeline):
 
     def roofline(self):
         nn = super().roofline()
-        gm = gmm_cart_roofline(self.ctx, self.nk, min(self.GCHUNK, self.F))
+        gm = gmm_cart_roofline(self.ctx, self.gmm, self.nk, self.M, 40, min(self.GCHUNK, self.F))
         if gm is None:
             return nn
         # "dominant kernel" = the one with the larger total time in the step: the GMM's exact stage or the output-layer GEMM
@@ -336,7 +358,7 @@ class GmmTrain:
             dist.all_reduce(self.score_sum)
 
     def roofline(self):
-        return gmm_cart_roofline(self.ctx, self.nk, min(self.CHUNK, self.F))
+        return gmm_cart_roofline(self.ctx, self.sc, self.nk, self.M, 40, min(self.CHUNK, self.F))
 
     def stage_report(self):
         out = {"accumulator_bytes": int(self.acc.numel() * 8)}
@@ -443,7 +465,7 @@ class GmmOnly:
                         peak=FP32_TFLOPS, unit="TFLOP/s", frac=round(ach / FP32_TFLOPS, 4), traffic=None, avg_launch_ms=round(ms, 4),
                         launches=n, flops_per_launch=ops)
         elif self.gmm_type == "diagonal-maximum":
-            return gmm_cart_roofline(self.ctx, self.nk, self.T)
+            return gmm_cart_roofline(self.ctx, self.sc, self.nk, 10000, 40, self.T)
         elif self.gmm_type == "SIMD-diagonal-maximum":
             # u8 means and features, integer distance: the products run on the i8 matrix pipes (2 x 160 000 x 64 ops per frame fit
             # 2.5 POP/s many times over), so the bound is the 8 bytes of (score, best density) per frame and mixture that leave
@@ -662,6 +684,10 @@ def main():
         barrier(world)
         ctx.profile(not graph_mode)
         ctx.profile_reset()
+        for name in ("gmm", "sc"):  # survivor counter of the fused GMM scorer (one atomic per wavefront and launch)
+            g = getattr(job, name, None)
+            if g is not None and hasattr(g, "screen_counts"):
+                g.screen_counts(True)
         t0 = time.perf_counter()
         for _ in range(args.steps):
             job.step()

@@ -203,6 +203,11 @@ int amx_gmm_tables(const amx_gmm* h, float* minus2_log_weights, float* inv_sqrt_
 /* quantisation scaling factor of the SIMD-diagonal-maximum scorer (SimdGaussDiagonalMaximumFeatureScorer::getScaling,
  * logged as "Scaling factor"); 0 for a host-only handle */
 float amx_gmm_simd_scaling(const amx_gmm* h);
+/* Diagnostics of the screened diagonal-maximum scorer (no reference counterpart; bench.py prints survivors per mixture):
+ * returns and clears the number of densities evaluated exactly and the number of (frame, mixture) pairs scored since the
+ * last call, and switches the counting on (enable != 0) or off for the following calls.  Synchronises the stream.  Zero for
+ * models that do not take the fused screened path. */
+int amx_gmm_screen_counts(amx_gmm* h, int enable, unsigned long long* survivors, unsigned long long* pairs);
 /* scores [T x n_mix]; best_density (nullable) [T x n_mix] = index within the mixture of the
  * minimising density (AssigningFeatureScorer::ScoreAndBestDensity). */
 int amx_gmm_score(amx_gmm* h, int mode, const float* feats_host, int T, float* scores_host, uint32_t* best_density_host);

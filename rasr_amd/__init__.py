@@ -265,6 +265,12 @@ class GmmFeatureScorer:
         """quantisation scaling factor of the SIMD-diagonal-maximum scorer"""
         return float(self.L.amx_gmm_simd_scaling(self.h))
 
+    def screen_counts(self, enable=True):
+        """(densities evaluated exactly, (frame, mixture) pairs) of the fused screened scorer since the last call; sets counting on / off"""
+        a, b = C.c_ulonglong(0), C.c_ulonglong(0)
+        _lib.check(self.L.amx_gmm_screen_counts(self.h, 1 if enable else 0, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
     def accumulator_size(self):
         return int(self.L.amx_gmm_accumulator_size(self.h))
 

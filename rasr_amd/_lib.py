@@ -95,6 +95,7 @@ SIGNATURES = {
     "amx_gmm_dimension": (C.c_int, [_P]),
     "amx_gmm_tables": (C.c_int, [_P, _P, _P, _P]),
     "amx_gmm_simd_scaling": (C.c_float, [_P]),
+    "amx_gmm_screen_counts": (C.c_int, [_P, C.c_int, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
     "amx_gmm_score": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, _P]),
     "amx_gmm_score_dev": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, _P]),
     "amx_gmm_score_stats_dev": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P, _P]),

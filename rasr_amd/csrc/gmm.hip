@@ -24,6 +24,7 @@
 // running best is an f32 compared as f64 with strict '>', so the first minimum wins.  Scores and
 // best-density indices are therefore bit-identical to the reference's x86-64 build.
 #include "common.hpp"
+#include "gmm_device.hpp"
 
 #include <cfloat>
 #include <cmath>
@@ -63,54 +64,6 @@ __device__ __forceinline__ float gmm_distance(const float (&x)[DIM], const float
     }
     float result = 0.f;
     result       = result + ((l0 + l1) + (l2 + l3));
-#pragma unroll
-    for (int i = EFF; i < DIM; ++i) {
-        float df = (mu[i] - x[i]) * is[i];
-        result   = result + df * df;
-    }
-    return result;
-}
-
-// Same arithmetic, two dimensions per instruction: v_pk_add_f32 / v_pk_mul_f32 round each half exactly like the scalar
-// operations (nothing is fused), and the partial sums (l0, l1) and (l2, l3) are updated as pairs -- bit-identical to
-// gmm_distance at half the instruction count.  mu and is must be 8-byte aligned.
-typedef float gmm_pk2 __attribute__((ext_vector_type(2)));
-
-template<int DIM>
-__device__ __forceinline__ float gmm_distance_pk(const float (&x)[DIM], const float* __restrict__ mu, const float* __restrict__ is) {
-    gmm_pk2       l01 = {0.f, 0.f}, l23 = {0.f, 0.f};
-    constexpr int EFF = DIM & ~3;
-#pragma unroll
-    for (int i = 0; i < EFF; i += 4) {
-        const gmm_pk2 d01 = (*(const gmm_pk2*)(mu + i) - gmm_pk2{x[i], x[i + 1]}) * *(const gmm_pk2*)(is + i);
-        const gmm_pk2 d23 = (*(const gmm_pk2*)(mu + i + 2) - gmm_pk2{x[i + 2], x[i + 3]}) * *(const gmm_pk2*)(is + i + 2);
-        l01               = l01 + d01 * d01;
-        l23               = l23 + d23 * d23;
-    }
-    float result = 0.f;
-    result       = result + ((l01.x + l01.y) + (l23.x + l23.y));
-#pragma unroll
-    for (int i = EFF; i < DIM; ++i) {
-        float df = (mu[i] - x[i]) * is[i];
-        result   = result + df * df;
-    }
-    return result;
-}
-
-// the same with the mean already in registers (software-pipelined callers)
-template<int DIM>
-__device__ __forceinline__ float gmm_distance_pk_reg(const float (&x)[DIM], const float (&mu)[DIM], const float* __restrict__ is) {
-    gmm_pk2       l01 = {0.f, 0.f}, l23 = {0.f, 0.f};
-    constexpr int EFF = DIM & ~3;
-#pragma unroll
-    for (int i = 0; i < EFF; i += 4) {
-        const gmm_pk2 d01 = (gmm_pk2{mu[i], mu[i + 1]} - gmm_pk2{x[i], x[i + 1]}) * *(const gmm_pk2*)(is + i);
-        const gmm_pk2 d23 = (gmm_pk2{mu[i + 2], mu[i + 3]} - gmm_pk2{x[i + 2], x[i + 3]}) * *(const gmm_pk2*)(is + i + 2);
-        l01               = l01 + d01 * d01;
-        l23               = l23 + d23 * d23;
-    }
-    float result = 0.f;
-    result       = result + ((l01.x + l01.y) + (l23.x + l23.y));
 #pragma unroll
     for (int i = EFF; i < DIM; ++i) {
         float df = (mu[i] - x[i]) * is[i];
@@ -638,21 +591,6 @@ __global__ __launch_bounds__(256) void gmm_combine_uniform_kernel(const float* _
 // and two sums that round to the same f32 differ by <= ulp32(b), hence tau = 2^-21 (max_k |a^| + |min s^|) covers every
 // such k with a 2x margin.  Replaces 4 f64-rate + 3 f32 operations per density by 4 f32 operations.
 typedef float gmm_f32x2 __attribute__((ext_vector_type(2)));
-
-// IEEE minNum of three without the canonicalising v_max the compiler puts in front of a loop-carried fminf
-__device__ __forceinline__ float min3_raw(float a, float b, float c) {
-    float o;
-    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(o) : "v"(a), "v"(b), "v"(c));
-    return o;
-}
-// The compiler's hazard recognizer does not look into inline assembly: a min3_raw scheduled right behind the MFMA that produces
-// its operands reads the accumulator before the last K step has landed.  The FIRST reduction step of every accumulator vector
-// therefore goes through the compiler (it inserts the wait states), and the asm steps depend on its result.  (Unnoticed as long
-// as the last 16 K columns of the screen operand were zero; dim 48 pooled / dim 24 with per-density covariances put the constant
-// columns there and lost every survivor -- found by tools/fuzz_gmm.py.)
-__device__ __forceinline__ float min3_first(float a, float b, float c) {
-    return __builtin_fminf(__builtin_fminf(a, b), c);
-}
 
 // ---- register-tiled (min,+) product carrying that screen: C[t][m] = min_k (a^[k][m] + dist[k][t]), a^ tabulated
 // [K][mix_pad] next to the weights, max_k |a^| per mixture tabulated too.
@@ -1541,6 +1479,11 @@ struct amx_gmm {
     };
     std::map<GraphKey, hipGraphExec_t> graphs;
     int                                use_graphs = 1;
+    void*     d_fus_rec = nullptr;   // tile records of gmm_fused_kernel (pooled covariance, dim <= 40)
+    unsigned long long* d_fus_surv = nullptr;  // [2]: densities evaluated exactly, (frame, mixture) pairs scored (amx_gmm_screen_counts)
+    size_t    fus_rec_bytes = 0;
+    bool      count_survivors = false;
+    unsigned long long fus_pairs = 0;
     float*    d_scr_pmin = nullptr;  // fused statistics: per-tile arg-min partials
     unsigned* d_scr_pidx = nullptr;
     size_t    scr_part_cap = 0;
@@ -1568,6 +1511,15 @@ extern "C" void  amx_internal_gmm_simd_destroy(void* p);
 extern "C" float amx_internal_gmm_simd_scaling(const void* p);
 extern "C" int   amx_internal_gmm_simd_score(void* p, amx_ctx* ctx, int variant, const float* feats_dev, int T, float* scores_dev, uint32_t* best_dev);
 
+extern "C" int amx_internal_gmm_fused_supported(int dim, int pooled, int Kp);
+extern "C" int amx_internal_gmm_fused_create(int dim, int n_mix, int n_tiles, const void* A2_host, const uint32_t* mix_off, const uint32_t* k_mean,
+                                             const double* c64, const float* means, const float* p1, const float* p2, void** rec_dev,
+                                             size_t* rec_bytes);
+extern "C" int amx_internal_gmm_fused_split(int n_cu, int Tpad, int n_tiles);
+extern "C" int amx_internal_gmm_fused_score(amx_ctx* ctx, int dim, const void* rec_dev, const float* isr_dev, const float* feats, const void* X,
+                                            const float* nx, const float* q, int T, int Tpad, int n_mix, int n_tiles, int split, float* scores,
+                                            uint32_t* best, float* pmin, unsigned* pidx, int part_ld, unsigned long long* survivors);
+
 // maximum approximation through the MFMA screen (see gmm_screen_kernel); frames in chunks that bound the mask workspace
 extern "C" int amx_internal_best_state_reduce(amx_ctx*, const float*, const unsigned*, int, int, int, uint32_t*, unsigned long long*, double*);
 
@@ -1575,9 +1527,11 @@ int score_screened(amx_gmm* h, const float* feats_dev, int T, float* scores_dev,
                    unsigned long long* counts_dev, double* score_sum_dev) {
     hipStream_t st = h->ctx->stream;
     const int   chunk = getenv("AMX_GMM_CHUNK") ? atoi(getenv("AMX_GMM_CHUNK")) : 65536;  // frames per pass: the workspace (survivor masks, 2 B per frame and mixture slot) grows to what a call needs
+    // one fused kernel (gmm_fused.hip) where its tile records exist; AMX_GMM_FUSED=0 keeps the two-kernel path (A/B runs, tests)
+    const bool fused = h->d_fus_rec && !(getenv("AMX_GMM_FUSED") && atoi(getenv("AMX_GMM_FUSED")) == 0) && !getenv("AMX_GMM_SCREEN_ALL");
     for (int t0 = 0; t0 < T; t0 += chunk) {
         const int Tc = std::min(chunk, T - t0), Tpad = (Tc + 255) / 256 * 256;
-        if (Tpad > h->scr_cap_T) {
+        if (Tpad > h->scr_cap_T || (!fused && !h->d_scr_masks)) {
             for (auto& kv : h->graphs)  // captured passes hold the old workspace addresses: drop them before the buffers move
                 if (kv.second)
                     hipGraphExecDestroy(kv.second);
@@ -1593,7 +1547,8 @@ int score_screened(amx_gmm* h, const float* feats_dev, int T, float* scores_dev,
             AMX_HIP(hipMalloc((void**)&h->d_scr_X, (size_t)Tpad * h->scr_Kp * sizeof(_Float16)));
             AMX_HIP(hipMalloc((void**)&h->d_scr_nx, (size_t)Tpad * 4));
             AMX_HIP(hipMalloc((void**)&h->d_scr_q, (size_t)Tpad * 4));
-            AMX_HIP(hipMalloc((void**)&h->d_scr_masks, (size_t)Tpad * h->scr_Mpad16 * 2));
+            if (!fused)
+                AMX_HIP(hipMalloc((void**)&h->d_scr_masks, (size_t)Tpad * h->scr_Mpad16 * 2));
             h->scr_cap_T = Tpad;
         }
         const float*       x = feats_dev + (size_t)t0 * h->dim;
@@ -1602,6 +1557,45 @@ int score_screened(amx_gmm* h, const float* feats_dev, int T, float* scores_dev,
         {
             amx::ScopedKernelTimer timer(h->ctx, "gmm_screen_pack");
             hipLaunchKernelGGL(amx::gmm_screen_pack_kernel, dim3(Tpad / 4), dim3(256), 0, st, x, h->d_isr, h->d_scr_X, h->d_scr_nx, h->d_scr_q, d);
+        }
+        if (fused) {
+            const int n_tiles = h->scr_Rpad / 256;
+            const int split   = amx_internal_gmm_fused_split(h->ctx->n_cu, Tpad, n_tiles);
+            float*    pmin    = nullptr;
+            unsigned* pidx    = nullptr;
+            if (stats) {
+                const size_t need = (size_t)split * Tpad;
+                if (need > h->scr_part_cap) {
+                    hipFree(h->d_scr_pmin);
+                    hipFree(h->d_scr_pidx);
+                    h->d_scr_pmin   = nullptr;
+                    h->d_scr_pidx   = nullptr;
+                    h->scr_part_cap = 0;
+                    AMX_HIP(hipMalloc((void**)&h->d_scr_pmin, need * 4));
+                    AMX_HIP(hipMalloc((void**)&h->d_scr_pidx, need * 4));
+                    h->scr_part_cap = need;
+                }
+                pmin = h->d_scr_pmin;
+                pidx = h->d_scr_pidx;
+            }
+            {
+                amx::ScopedKernelTimer timer(h->ctx, "gmm");
+                int r = amx_internal_gmm_fused_score(h->ctx, h->dim, h->d_fus_rec, h->d_isr, x, h->d_scr_X, h->d_scr_nx, h->d_scr_q, Tc, Tpad,
+                                                     h->n_mix, n_tiles, split, scores_dev + (size_t)t0 * h->n_mix,
+                                                     best_dev ? best_dev + (size_t)t0 * h->n_mix : nullptr, pmin, pidx, Tpad,
+                                                     h->count_survivors ? h->d_fus_surv : nullptr);
+                if (r != AMX_OK)
+                    return r;
+                h->fus_pairs += (unsigned long long)Tc * (unsigned long long)h->n_mix;
+            }
+            if (stats) {
+                amx::ScopedKernelTimer timer(h->ctx, "stats");
+                int r = amx_internal_best_state_reduce(h->ctx, pmin, pidx, split, Tpad, Tc, best_state_dev ? best_state_dev + t0 : nullptr,
+                                                       counts_dev, score_sum_dev);
+                if (r != AMX_OK)
+                    return r;
+            }
+            continue;
         }
         {
             amx::ScopedKernelTimer timer(h->ctx, "gmm_screen");
@@ -1991,6 +1985,19 @@ int amx_gmm_create(amx_ctx* ctx, const amx_gmm_model* m, amx_gmm** out) {
                         amx_gmm_destroy(h);
                         return r;
                     }
+                    if (amx_internal_gmm_fused_supported(d, h->pooled ? 1 : 0, Kp) &&
+                        (r = amx_internal_gmm_fused_create(d, m->n_mix, Rpad / 256, A2.data(), m->mix_offsets, k_mean.data(), c64.data(), m->means,
+                                                           na.data(), cabs.data(), &h->d_fus_rec, &h->fus_rec_bytes)) != AMX_OK) {
+                        amx_gmm_destroy(h);
+                        return r;
+                    }
+                    if (h->d_fus_rec) {
+                        const unsigned long long zero[2] = {0, 0};
+                        if ((r = gupload(&h->d_fus_surv, zero, 2)) != AMX_OK) {
+                            amx_gmm_destroy(h);
+                            return r;
+                        }
+                    }
                 }
                 if ((r = gupload(&h->d_scr_A, A.data(), A.size())) != AMX_OK || (r = gupload(&h->d_scr_c, c.data(), c.size())) != AMX_OK ||
                     (r = gupload(&h->d_scr_na, na.data(), na.size())) != AMX_OK || (r = gupload(&h->d_scr_cabs, cabs.data(), cabs.size())) != AMX_OK) {
@@ -2041,6 +2048,8 @@ void amx_gmm_destroy(amx_gmm* h) {
     hipFree(h->d_dist64);
     hipFree(h->d_scr_A);
     hipFree(h->d_scr_A2);
+    hipFree(h->d_fus_rec);
+    hipFree(h->d_fus_surv);
     hipFree(h->d_scr_c);
     hipFree(h->d_scr_na);
     hipFree(h->d_scr_cabs);
@@ -2305,6 +2314,28 @@ int amx_gmm_score_stats_dev(amx_gmm* h, const float* feats_dev, int T, float* sc
     if (r != AMX_OK)
         return r;
     return amx_stats_accumulate_dev(h->ctx, scores_dev, T, h->n_mix, best_state_dev, state_counts_dev, score_sum_dev);
+}
+
+int amx_gmm_screen_counts(amx_gmm* h, int enable, unsigned long long* survivors, unsigned long long* pairs) {
+    AMX_REQUIRE(h, AMX_ERR_INVALID, "amx_gmm_screen_counts: NULL handle");
+    if (survivors)
+        *survivors = 0;
+    if (pairs)
+        *pairs = 0;
+    if (!h->d_fus_surv)  // not the fused screened path: nothing is counted
+        return AMX_OK;
+    AMX_HIP(hipSetDevice(h->ctx->device));
+    AMX_HIP(hipStreamSynchronize(h->ctx->stream));
+    unsigned long long v = 0;
+    AMX_HIP(hipMemcpy(&v, h->d_fus_surv, 8, hipMemcpyDeviceToHost));
+    if (survivors)
+        *survivors = v;
+    if (pairs)
+        *pairs = h->fus_pairs;
+    AMX_HIP(hipMemset(h->d_fus_surv, 0, 16));
+    h->fus_pairs       = 0;
+    h->count_survivors = enable != 0;
+    return AMX_OK;
 }
 
 float amx_gmm_simd_scaling(const amx_gmm* h) {

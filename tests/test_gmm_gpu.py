@@ -689,14 +689,19 @@ def test_full_size_tied_properties(ctx, monkeypatch):
     assert np.array_equal(a[[0, 255]].view(np.uint32), osc.view(np.uint32)) and np.array_equal(ab[[0, 255]], obest)
 
 
-@pytest.mark.parametrize("variant", ["rows", "persist", "simple"])
+@pytest.mark.parametrize("variant", ["fused", "rows", "persist", "simple"])
 @pytest.mark.parametrize("dim,pooled", [(16, True), (16, False), (24, True), (24, False), (32, True), (32, False), (33, True), (39, True),
                                         (40, True), (40, False), (45, True), (48, True), (48, False), (64, True), (64, False)])
 def test_every_screened_dimension_and_operand_width(ctx, monkeypatch, dim, pooled, variant):
     """every dimension the MFMA screen is instantiated for, with pooled and per-density covariances: the screen operand is dim or
     2 dim columns wide plus two constant columns.  dim 48 pooled / dim 24 per-density are the cases whose constants land in the LAST
     16 K columns -- the MFMA step whose result an inline-asm v_min3 once read too early (found by tools/fuzz_gmm.py)."""
-    monkeypatch.setenv("AMX_GMM_SCREEN_KERNEL", variant)
+    if variant == "fused":
+        if not (pooled and dim <= 40):
+            pytest.skip("the fused kernel serves pooled covariances up to dim 40; other shapes take the two-kernel path")
+    else:
+        monkeypatch.setenv("AMX_GMM_FUSED", "0")
+        monkeypatch.setenv("AMX_GMM_SCREEN_KERNEL", variant)
     model = synth.gmm_cart(70, 1, 16, dim, seed=300 + dim, pooled=pooled)
     assert_exact(ctx, model, feats(300, dim, 301))
 
@@ -714,3 +719,89 @@ def test_tied_non_finite_frames_keep_the_initial_result(ctx, pooled):
     x[8, 1] = -np.inf
     x[9] *= np.float32(1e4)
     assert_exact(ctx, model, x)
+
+
+# ---- gmm_fused_kernel (gmm_fused.hip): screen + exact evaluation in one kernel, pooled covariance, dim <= 40
+
+@pytest.mark.parametrize("n_mix,T", [(1, 1), (7, 31), (16, 33), (17, 256), (45, 257), (48, 1000), (333, 700), (1000, 64)])
+def test_fused_shapes_exact(ctx, n_mix, T):
+    """mixture counts around the 16-mixture tile (partial last tile, n_mix % 4 != 0 -> scalar store path) and frame counts around
+    the 32-frame wave / 256-frame workgroup, mixtures of 1..16 densities; scores and best densities bit-exact vs the oracle"""
+    model = synth.gmm_cart(n_mix, 1, 16, 40, seed=400 + n_mix, pooled=True)
+    assert_exact(ctx, model, feats(T, 40, 401 + T))
+
+
+@pytest.mark.parametrize("dim", [16, 24, 32, 33, 39, 40])
+def test_fused_adversarial_twins(ctx, dim):
+    """twin densities / one-ulp weight neighbours: the further survivors of a mixture go through the divergent loop in slot order"""
+    model = _cart_adversarial(410 + dim, 83, dim, True)
+    x = feats(515, dim, 411)
+    assert_exact(ctx, model, x)
+
+
+def test_fused_equals_two_kernel_path_with_stats(ctx, monkeypatch):
+    """the fused kernel and round 1's two kernels (AMX_GMM_FUSED=0) agree bit for bit on scores, best densities, best states,
+    counts and the score sum; frames that do not fit the f16 operand keep every slot in both; without a best-density buffer too"""
+    import torch
+
+    import rasr_amd
+    model = synth.gmm_cart(1203, 1, 16, 40, seed=420, pooled=True)
+    T, M = 5000, 1203
+    x = feats(T, 40, 421)
+    x[17] *= 3.0e4
+    x[18, 5] = np.nan
+    x[4000] = 1.0e6
+    xd = torch.from_numpy(x).cuda()
+    ctx.use_torch_stream()
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("AMX_GMM_FUSED", mode)
+        sc = rasr_amd.GmmFeatureScorer(ctx, model)
+        scores = torch.empty((T, M), dtype=torch.float32, device="cuda")
+        bestd = torch.empty((T, M), dtype=torch.int32, device="cuda")
+        state = torch.empty((T,), dtype=torch.int32, device="cuda")
+        counts = torch.zeros((M,), dtype=torch.int64, device="cuda")
+        ssum = torch.zeros((1,), dtype=torch.float64, device="cuda")
+        sc.score_stats_dev(xd, T, scores, bestd, state, counts, ssum)
+        only = torch.empty((T, M), dtype=torch.float32, device="cuda")
+        sc.score_dev(xd, T, only, None)
+        torch.cuda.synchronize()
+        res[mode] = [a.cpu().numpy() for a in (scores, bestd, state, counts, only)] + [float(ssum.item())]
+        del sc
+    for a, b in zip(res["1"][:5], res["0"][:5]):
+        assert np.array_equal(a.view(np.uint32) if a.dtype == np.float32 else a, b.view(np.uint32) if b.dtype == np.float32 else b)
+    assert np.array_equal(res["1"][0].view(np.uint32), res["1"][4].view(np.uint32))
+    assert abs(res["1"][5] - res["0"][5]) <= 1e-9 * abs(res["0"][5])
+    from oracle import OracleGmm
+    sel = np.r_[0:40, 3990:4010]
+    osc, obest = OracleGmm(model).score(x[sel], mode=0)
+    assert np.array_equal(res["1"][0][sel].view(np.uint32), osc.view(np.uint32)) and np.array_equal(res["1"][1][sel].astype(np.uint32), obest)
+
+
+def test_fused_small_batch_splits_the_model(ctx):
+    """config 3 shape: 256 frames x 10 000 mixtures -- one frame tile, the model's 625 tiles split over the CUs; best states from
+    the per-split partials"""
+    import torch
+
+    import rasr_amd
+    from oracle import OracleGmm
+    model = synth.gmm_cart(10000, 16, 16, 40, seed=5, pooled=True)
+    T, M = 256, 10000
+    x = feats(T, 40, 431)
+    sc = rasr_amd.GmmFeatureScorer(ctx, model)
+    xd = torch.from_numpy(x).cuda()
+    scores = torch.empty((T, M), dtype=torch.float32, device="cuda")
+    bestd = torch.empty((T, M), dtype=torch.int32, device="cuda")
+    state = torch.empty((T,), dtype=torch.int32, device="cuda")
+    counts = torch.zeros((M,), dtype=torch.int64, device="cuda")
+    ssum = torch.zeros((1,), dtype=torch.float64, device="cuda")
+    ctx.use_torch_stream()
+    sc.score_stats_dev(xd, T, scores, bestd, state, counts, ssum)
+    torch.cuda.synchronize()
+    got = scores.cpu().numpy()
+    sel = np.r_[0:3, 31:34, 253:256]
+    osc, obest = OracleGmm(model).score(x[sel], mode=0)
+    assert np.array_equal(got[sel].view(np.uint32), osc.view(np.uint32))
+    assert np.array_equal(bestd.cpu().numpy()[sel].astype(np.uint32), obest)
+    assert np.array_equal(state.cpu().numpy(), got.argmin(axis=1))
+    assert int(counts.sum().item()) == T
