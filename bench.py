@@ -53,7 +53,9 @@ def parse():
     ap.add_argument("--utterances", type=int, default=64, help="utterances per step and rank (pipeline / mfcc)")
     ap.add_argument("--utt-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x3", "fp32"],
+                    help="NN GEMM inputs: bf16 (BASELINE config 4), bf16x3 = split bf16, three MFMA products per f32 product (meets the "
+                         "1e-4 bar of the f32 reference), fp32 = f32 MFMA")
     ap.add_argument("--front-end", default="mfcc", choices=["mfcc", "mfplp"],
                     help="mfcc workload: mfcc.flow (40 cepstra) or mfplp.flow (20 autocorrelation / 16 cepstrum coefficients)")
     ap.add_argument("--estimation-mode", default="viterbi", choices=["viterbi", "baum-welch"],
@@ -149,6 +151,23 @@ def gmm_cart_roofline(ctx, sc, nk, n_mix, dim, frames):
                 bytes_per_launch=by, algorithmic_speedup_vs_dense=round(alg / ((ms_x + ms_s + ms_p) * 1e-3) / 1e12 / FP32_TFLOPS, 3))
 
 
+def nn_gemm_roofline(precision, ms, n, frames, full_chunk):
+    """output-layer GEMM 2048 -> 10000: `achieved` = MFMA flops the kernel executes / HIP-event time.  bf16x3 executes three bf16
+    products per algorithmic product (K is three times as long), so its algorithmic rate is a third of `achieved`."""
+    alg = 2.0 * 2048 * 10000 * frames
+    mult = 3.0 if precision == "bf16x3" else 1.0
+    peak = FP32_TFLOPS if precision == "fp32" else MFMA_BF16_TFLOPS
+    ach = mult * alg / (ms * 1e-3) / 1e12
+    name = {"bf16": "gemm_bf16_pipe_kernel<NONE,LAST> (2048->10000)", "bf16x3": "gemm_bf16_pipe_kernel<NONE,LAST> (2048->10000, split bf16: K = 3 x 2048)",
+            "fp32": "gemm_f32_kernel (2048->10000)"}[precision]
+    out = dict(bound="mfma", kernel=name, achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
+               traffic=measured_traffic("gemm_bf16_pipe_kernel<GemmCfg<256,256,2,4,2>,NONE,LAST>") if (precision == "bf16" and full_chunk) else None,
+               avg_launch_ms=round(ms, 4), launches=n, flops_per_launch=mult * alg)
+    if mult != 1.0:
+        out["algorithmic_tflops"] = round(alg / (ms * 1e-3) / 1e12, 2)
+    return out
+
+
 class NnPipeline:
     """MFCC-40 -> context 11 -> FFNN 440-6x2048-10000 -> accumulators, everything resident in HBM."""
 
@@ -199,17 +218,11 @@ class NnPipeline:
         rows = []
         for t0 in range(0, self.F, self.CHUNK):
             rows.append(min(self.CHUNK, self.F - t0))
-        flops = 2.0 * 2048 * 10000 * (sum(rows) / len(rows))
-        peak = MFMA_BF16_TFLOPS if self.nn_precision == "bf16" else FP32_TFLOPS
-        ach = flops / (ms * 1e-3) / 1e12
-        return dict(bound="mfma", kernel="gemm_bf16_pipe_kernel<NONE,LAST> (2048->10000)" if self.nn_precision == "bf16" else "gemm_f32_kernel (2048->10000)",
-                    achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
-                    traffic=measured_traffic("gemm_bf16_pipe_kernel<GemmCfg<256,256,2,4,2>,NONE,LAST>") if (self.nn_precision == "bf16" and self.F >= self.CHUNK) else None,
-                    avg_launch_ms=round(ms, 4), launches=n, flops_per_launch=flops)
+        return nn_gemm_roofline(self.nn_precision, ms, n, sum(rows) / len(rows), self.F >= self.CHUNK)
 
     def stage_report(self):
         out = {}
-        for k in ("mfcc", "context_window", "ffnn_pack", "ffnn_gemm", "ffnn_gemm_max", "stats"):
+        for k in ("mfcc", "context_window", "ffnn_pack", "ffnn_gemm", "ffnn_gemm_max", "ffnn_split", "stats"):
             ms, n = self.ctx.profile_get(k)
             if n:
                 out[k] = dict(avg_ms=round(ms, 4), launches=n)
@@ -526,15 +539,11 @@ class NnOnly:
         ms, n = self.ctx.profile_get("ffnn_gemm_max")
         if n == 0:
             return None
-        flops = 2.0 * 2048 * 10000 * self.T
-        peak = MFMA_BF16_TFLOPS if self.nn_precision == "bf16" else FP32_TFLOPS
-        ach = flops / (ms * 1e-3) / 1e12
-        return dict(bound="mfma", kernel="output-layer GEMM 2048->10000", achieved=round(ach, 2), peak=peak, unit="TFLOP/s",
-                    frac=round(ach / peak, 4), traffic=None, avg_launch_ms=round(ms, 4), launches=n, flops_per_launch=flops)
+        return nn_gemm_roofline(self.nn_precision, ms, n, self.T, False)
 
     def stage_report(self):
         out = {}
-        for k in ("ffnn_pack", "ffnn_gemm", "ffnn_gemm_max"):
+        for k in ("ffnn_pack", "ffnn_gemm", "ffnn_gemm_max", "ffnn_split"):
             ms, n = self.ctx.profile_get(k)
             if n:
                 out[k] = dict(avg_ms=round(ms, 4), launches=n)
@@ -709,20 +718,21 @@ def main():
     if rank == 0:
         value = units / dt
         names = {"pipeline": "cfg5-shard: MFCC-40 -> {GMM 10000x16 diagonal-maximum -> Viterbi accumulators | ctx11 -> FFNN 440-6x2048-10000 "
-                             "(bf16 MFMA) -> best-state counts}, every frame scored by both models; %d utterances x %.0f s per step and rank"
-                             % (args.utterances, args.utt_seconds),
-                 "nn-pipeline": "cfg5-shard, NN leg only: MFCC-40 -> ctx11 -> FFNN 440-6x2048-10000 (bf16 MFMA) -> best-state counts; "
-                                "%d utterances x %.0f s per step and rank" % (args.utterances, args.utt_seconds),
+                             "(%s MFMA) -> best-state counts}, every frame scored by both models; %d utterances x %.0f s per step and rank"
+                             % (args.precision, args.utterances, args.utt_seconds),
+                 "nn-pipeline": "cfg5-shard, NN leg only: MFCC-40 -> ctx11 -> FFNN 440-6x2048-10000 (%s MFMA) -> best-state counts; "
+                                "%d utterances x %.0f s per step and rank" % (args.precision, args.utterances, args.utt_seconds),
                  "mfcc": "cfg2: batched MFCC-40 on 1000 utterances (5-15 s)",
                  "gmm": "cfg3-cart: 10000 states x 16 densities, d=40, pooled covariance, batch 256, diagonal-maximum",
                  "gmm-tied": "cfg3-tied: 4096 shared densities x 10000 states, d=40, batch 256, diagonal-maximum",
-                 "nn": "cfg4: FFNN 440-6x2048-10000, batch 1024",
+                 "nn": "cfg4: FFNN 440-6x2048-10000 (%s MFMA), batch 1024" % args.precision,
                  "gmm-train": "cfg5 GMM leg: MFCC-40 -> 10000x16 GMM (diagonal-maximum) -> Viterbi accumulators (f64) ; "
                               "%d utterances x %.0f s per step and rank" % (args.utterances, args.utt_seconds)}
         line = {"metric": "acoustic frames scored/sec (1e4-state AM)", "value": round(value, 1), "unit": "frames/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                "dtype": ("bf16" if args.precision == "bf16" else "f32") if args.workload in ("pipeline", "nn-pipeline", "nn") else "f32",
+                "dtype": {"bf16": "bf16", "bf16x3": "bf16x3 (split bf16, three MFMA products per f32 product, f32 accumulate)", "fp32": "f32"}[args.precision]
+                         if args.workload in ("pipeline", "nn-pipeline", "nn") else "f32",
                 "data": "synthetic", "config": {"workload": names[args.workload], "frames_per_step_per_gpu": job.units},
                 "rtf": round(dt / (units * 0.01), 8)}
         line["roofline"] = job.roofline()

@@ -291,7 +291,10 @@ void amx_mixture_set_destroy(amx_mixture_set* ms);
 /* ------------------------------------------------------------------ feed-forward NN scorer */
 
 enum { AMX_ACT_NONE = 0, AMX_ACT_RELU = 1, AMX_ACT_SIGMOID = 2, AMX_ACT_TANH = 3 };
-enum { AMX_PREC_FP32 = 0, AMX_PREC_BF16 = 1 }; /* MFMA input type; accumulation is always f32 */
+/* MFMA input type; accumulation is always f32.  AMX_PREC_BF16X3 = split bf16: every operand is hi + lo (two bf16 values) and a
+ * product is taken as hi hi + lo hi + hi lo -- three bf16 MFMA products, ~2^-16 relative error per product: the mode that meets
+ * the 1e-4 bar of the f32 reference (Math::gemm<f32>, Math/Blas.hh:402-420) at a third of the bf16 rate */
+enum { AMX_PREC_FP32 = 0, AMX_PREC_BF16 = 1, AMX_PREC_BF16X3 = 2 };
 
 typedef struct {
     int                 n_layers;

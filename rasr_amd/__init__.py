@@ -314,7 +314,7 @@ class NnBatchFeatureScorer:
         Bp = (C.c_void_p * n)(*[b.ctypes.data for b in self._bs])
         st = _lib.FfnnModel(n, self._ind.ctypes.data, self._outd.ctypes.data, C.cast(Wp, C.c_void_p), C.cast(Bp, C.c_void_p),
                             self._act.ctypes.data, _ptr(self._lp), priori_scale,
-                            {"fp32": AMX_PREC_FP32, "bf16": AMX_PREC_BF16}[precision])
+                            {"fp32": AMX_PREC_FP32, "bf16": AMX_PREC_BF16, "bf16x3": _lib.AMX_PREC_BF16X3}[precision])
         h = C.c_void_p()
         _lib.check(self.L.amx_ffnn_create(ctx.h, C.byref(st), C.byref(h)))
         self.h = h

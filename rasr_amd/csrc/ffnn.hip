@@ -84,6 +84,53 @@ __global__ __launch_bounds__(256) void pack_input_bf16(const float* __restrict__
     }
 }
 
+// ---- split-bf16 ("bf16x3") mode: v = hi + lo with hi = bf16(v), lo = bf16(v - hi); a product a b is taken as
+// a_hi b_hi + a_lo b_hi + a_hi b_lo (the a_lo b_lo term is below 2^-17 |a b|), f32 accumulation -- three bf16 MFMA products
+// instead of one, relative error of a product ~2^-16 instead of 2^-8.  The three products are ONE GEMM over a three times
+// longer K: weight rows [W_hi | W_lo | W_hi], frame rows [X_hi | X_hi | X_lo], every segment `seg` columns wide.
+// features -> [Tpad x 3 seg] bf16
+__global__ __launch_bounds__(256) void pack_input_bf16x3(const float* __restrict__ x, int ldx, int T, int K, bf16_t* __restrict__ out,
+                                                        int seg, int Tpad) {
+    const long long n = (long long)Tpad * seg;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int    t = (int)(i / seg), k = (int)(i - (long long)t * seg);
+        const float  v = (t < T && k < K) ? x[(size_t)t * ldx + k] : 0.f;
+        const bf16_t hi = f2bf(v);
+        const bf16_t lo = f2bf(v - __uint_as_float((unsigned)hi << 16));
+        bf16_t*      o = out + (size_t)t * 3 * seg + k;
+        o[0]           = hi;
+        o[seg]         = hi;
+        o[2 * seg]     = lo;
+    }
+}
+
+// pre-activations z [Tpad x ldz] f32 (columns < N valid) -> activation, split, [Tpad x 3 seg] bf16 (zero beyond N)
+template<int ACT>
+__global__ __launch_bounds__(256) void split_act_bf16x3(const float* __restrict__ z, int ldz, int T, int N, bf16_t* __restrict__ out,
+                                                       int seg, int Tpad) {
+    const long long n4 = (long long)Tpad * (seg / 4);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const int t = (int)(i / (seg / 4)), k = (int)(i - (long long)t * (seg / 4)) * 4;
+        float4    v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t < T && k < N)
+            v = *(const float4*)(z + (size_t)t * ldz + k);  // ldz and k are multiples of 4, rows 16-byte aligned
+        float    a[4] = {v.x, v.y, v.z, v.w};
+        unsigned h2[2], l2[2];
+#pragma unroll
+        for (int e = 0; e < 4; e += 2) {
+            const float a0 = (t < T && k + e < N) ? activate<ACT>(a[e]) : 0.f;
+            const float a1 = (t < T && k + e + 1 < N) ? activate<ACT>(a[e + 1]) : 0.f;
+            const unsigned hp = pack_bf16(a0, a1);
+            h2[e >> 1]        = hp;
+            l2[e >> 1]        = pack_bf16(a0 - __uint_as_float(hp << 16), a1 - __uint_as_float(hp & 0xffff0000u));
+        }
+        bf16_t* o = out + (size_t)t * 3 * seg + k;
+        *(uint2*)o             = make_uint2(h2[0], h2[1]);
+        *(uint2*)(o + seg)     = make_uint2(h2[0], h2[1]);
+        *(uint2*)(o + 2 * seg) = make_uint2(l2[0], l2[1]);
+    }
+}
+
 __global__ __launch_bounds__(256) void pack_input_f32(const float* __restrict__ x, int ldx, int T, int K, float* __restrict__ out,
                                                      int Kpad, int Tpad) {
     const long long n = (long long)Tpad * Kpad;
@@ -990,6 +1037,8 @@ struct amx_ffnn {
     int    cap_T = 0;
     void*  d_in  = nullptr;      // packed input [cap_T x Kpad0]
     void*  d_act[2] = {nullptr, nullptr};
+    float* d_z      = nullptr;   // bf16x3 mode: f32 pre-activations of the current hidden layer [cap_T x max_hidden_pad]
+    std::vector<int> seg;        // bf16x3 mode: segment width of layer l's operands (Kpad of layer 0, Npad of the layer below otherwise)
     int    max_hidden_pad = 0;
     int    largest_layer  = 0;
     int    group_t = -1, group_n = -1;  // super-tile of the XCD-aware tile order
@@ -1016,7 +1065,8 @@ struct amx_ffnn {
     int    use_graphs = 1;
     int    gemm_persistent = 1;
     int    gemm_cfg       = -1;  // -1 = automatic; index into the bf16 tile configurations (launch_bf16_cfg)
-    size_t elt() const { return precision == AMX_PREC_BF16 ? 2 : 4; }
+    size_t elt() const { return precision == AMX_PREC_FP32 ? 4 : 2; }
+    bool   mfma_bf16() const { return precision != AMX_PREC_FP32; }  // bf16 and bf16x3 both run the bf16 GEMM kernels
 };
 
 namespace {
@@ -1036,8 +1086,19 @@ int ensure_workspace(amx_ffnn* h, int Tpad) {
     hipFree(h->d_in);
     hipFree(h->d_act[0]);
     hipFree(h->d_act[1]);
+    hipFree(h->d_z);
     h->d_in = h->d_act[0] = h->d_act[1] = nullptr;
+    h->d_z                              = nullptr;
     h->cap_T                            = 0;
+    if (h->precision == AMX_PREC_BF16X3) {  // one [hi | hi | lo] activation buffer (a layer's output replaces its input) + f32 pre-activations
+        AMX_HIP(hipMalloc(&h->d_in, (size_t)Tpad * 3 * h->seg[0] * 2));
+        if (h->max_hidden_pad > 0) {
+            AMX_HIP(hipMalloc(&h->d_act[0], (size_t)Tpad * 3 * h->max_hidden_pad * 2));
+            AMX_HIP(hipMalloc((void**)&h->d_z, (size_t)Tpad * h->max_hidden_pad * 4));
+        }
+        h->cap_T = Tpad;
+        return AMX_OK;
+    }
     AMX_HIP(hipMalloc(&h->d_in, (size_t)Tpad * h->Kpad[0] * h->elt()));
     if (h->max_hidden_pad > 0) {
         AMX_HIP(hipMalloc(&h->d_act[0], (size_t)Tpad * h->max_hidden_pad * h->elt()));
@@ -1140,7 +1201,7 @@ int launch_layer(amx_ffnn* h, int l, const void* x, int ldx, void* out, int ldo,
         hipEventRecord(e0, st);
     }
     const int act = LAST ? AMX_ACT_NONE : h->act[l];
-    if (h->precision == AMX_PREC_BF16) {
+    if (h->mfma_bf16()) {
         switch (act) {
             case AMX_ACT_RELU: launch_bf16_cfg<AMX_ACT_RELU, LAST>(h, l, x, ldx, out, ldo, T, Tpad); break;
             case AMX_ACT_SIGMOID: launch_bf16_cfg<AMX_ACT_SIGMOID, LAST>(h, l, x, ldx, out, ldo, T, Tpad); break;
@@ -1180,7 +1241,8 @@ int amx_ffnn_create(amx_ctx* ctx, const amx_ffnn_model* m, amx_ffnn** out) {
     *out = nullptr;
     AMX_REQUIRE(m->n_layers >= 1 && m->in_dim && m->out_dim && m->W && m->bias && m->activation, AMX_ERR_INVALID,
                 "amx_ffnn_create: empty network");
-    AMX_REQUIRE(m->precision == AMX_PREC_FP32 || m->precision == AMX_PREC_BF16, AMX_ERR_INVALID, "amx_ffnn_create: unknown precision");
+    AMX_REQUIRE(m->precision == AMX_PREC_FP32 || m->precision == AMX_PREC_BF16 || m->precision == AMX_PREC_BF16X3, AMX_ERR_INVALID,
+                "amx_ffnn_create: unknown precision");
     for (int l = 0; l < m->n_layers; ++l) {
         AMX_REQUIRE(m->in_dim[l] > 0 && m->out_dim[l] > 0 && m->W[l], AMX_ERR_INVALID, "amx_ffnn_create: layer %d is empty", l);
         if (l > 0)
@@ -1205,7 +1267,7 @@ int amx_ffnn_create(amx_ctx* ctx, const amx_ffnn_model* m, amx_ffnn** out) {
     if (const char* e = getenv("AMX_GEMM_GROUP"))
         sscanf(e, "%dx%d", &h->group_t, &h->group_n);
     hipSetDevice(ctx->device);
-    const int kmult = (m->precision == AMX_PREC_BF16) ? amx::BK : amx::FK;
+    const int kmult = (m->precision != AMX_PREC_FP32) ? amx::BK : amx::FK;
     long      best_flops = -1;
     for (int l = 0; l < m->n_layers; ++l) {
         h->in.push_back(m->in_dim[l]);
@@ -1226,7 +1288,35 @@ int amx_ffnn_create(amx_ctx* ctx, const amx_ffnn_model* m, amx_ffnn** out) {
         const int    K = h->in[l], N = h->out[l], Kp = h->Kpad[l], Np = h->Npad[l];
         const float* W = m->W[l];
         void*        d = nullptr;
-        if (m->precision == AMX_PREC_BF16) {
+        if (m->precision == AMX_PREC_BF16X3) {
+            // rows [W_hi | W_lo | W_hi], segments as wide as the rows of the activation buffer that feeds the layer.  Hidden layers
+            // go through the output-layer epilogue (f32 rows, value = -(D + bias)), so their weights and biases are stored negated
+            // and the activation is applied by split_act_bf16x3.
+            const int   sg  = l == 0 ? Kp : h->Npad[l - 1];
+            const float sgn = (l + 1 < m->n_layers) ? -1.f : 1.f;
+            h->seg.push_back(sg);
+            std::vector<amx::bf16_t> pk((size_t)Np * 3 * sg, 0);
+            for (int n = 0; n < N; ++n)
+                for (int k = 0; k < K; ++k) {
+                    const float       w  = sgn * W[(size_t)n * K + k];
+                    const amx::bf16_t hi = amx::f2bf_host(w);
+                    unsigned          hu = (unsigned)hi << 16;
+                    float             hf;
+                    memcpy(&hf, &hu, 4);
+                    const amx::bf16_t lo = amx::f2bf_host(w - hf);
+                    pk[(size_t)n * 3 * sg + k]          = hi;
+                    pk[(size_t)n * 3 * sg + sg + k]     = lo;
+                    pk[(size_t)n * 3 * sg + 2 * sg + k] = hi;
+                }
+            if (hipMalloc(&d, pk.size() * 2) != hipSuccess || hipMemcpy(d, pk.data(), pk.size() * 2, hipMemcpyHostToDevice) != hipSuccess) {
+                amx::set_error("amx_ffnn_create: device allocation of layer %d failed", l);
+                h->d_W.push_back(d);
+                amx_ffnn_destroy(h);
+                return AMX_ERR_DEVICE;
+            }
+            h->Kpad[l] = 3 * sg;  // the GEMM's K extent
+        }
+        else if (m->precision == AMX_PREC_BF16) {
             std::vector<amx::bf16_t> pk((size_t)Np * Kp, 0);
             for (int n = 0; n < N; ++n)
                 for (int k = 0; k < K; ++k)
@@ -1258,7 +1348,7 @@ int amx_ffnn_create(amx_ctx* ctx, const amx_ffnn_model* m, amx_ffnn** out) {
                 float prod = m->prior_scale * m->log_prior[n];
                 v          = v - prod;
             }
-            b[n] = v;
+            b[n] = (m->precision == AMX_PREC_BF16X3 && l + 1 < m->n_layers) ? -v : v;
         }
         float* db = nullptr;
         if (hipMalloc((void**)&db, b.size() * 4) != hipSuccess || hipMemcpy(db, b.data(), b.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
@@ -1284,6 +1374,7 @@ void amx_ffnn_destroy(amx_ffnn* h) {
     hipFree(h->d_in);
     hipFree(h->d_act[0]);
     hipFree(h->d_act[1]);
+    hipFree(h->d_z);
     hipFree(h->d_part_min);
     hipFree(h->d_part_idx);
     hipFree(h->d_host_f);
@@ -1326,7 +1417,7 @@ static int ffnn_score_impl(amx_ffnn* h, const float* feats_dev, int feats_stride
     AMX_HIP(hipSetDevice(h->ctx->device));
     // Small batches (the decoder's ring buffer: 256 ... 1024 frames, the same device buffers every time): replay the pass as a
     // HIP graph.  Not while profiling (the per-launch events are not part of the graph).
-    const bool graphable = h->use_graphs && !h->ctx->profiling && T <= 4096 && h->precision == AMX_PREC_BF16;
+    const bool graphable = h->use_graphs && !h->ctx->profiling && T <= 4096 && h->mfma_bf16();
     if (!graphable)
         return ffnn_score_launches(h, feats_dev, feats_stride, T, scores_dev, stats, best_state_dev, counts_dev, score_sum_dev);
     const amx_ffnn::GraphKey key{feats_dev, scores_dev, best_state_dev, counts_dev, score_sum_dev, h->ctx->stream, feats_stride, T, stats ? 1 : 0};
@@ -1379,7 +1470,10 @@ static int ffnn_score_launches(amx_ffnn* h, const float* feats_dev, int feats_st
         {
             amx::ScopedKernelTimer timer(h->ctx, "ffnn_pack");
             const int blocks = (int)std::min<long long>(4096, ((long long)Tpad * h->Kpad[0] + 255) / 256);
-            if (h->precision == AMX_PREC_BF16)
+            if (h->precision == AMX_PREC_BF16X3)
+                hipLaunchKernelGGL(amx::pack_input_bf16x3, dim3(blocks), dim3(256), 0, h->ctx->stream, x, feats_stride, Tc, h->in[0],
+                                   (amx::bf16_t*)h->d_in, h->seg[0], Tpad);
+            else if (h->precision == AMX_PREC_BF16)
                 hipLaunchKernelGGL(amx::pack_input_bf16, dim3(blocks), dim3(256), 0, h->ctx->stream, x, feats_stride, Tc, h->in[0],
                                    (amx::bf16_t*)h->d_in, h->Kpad[0], Tpad);
             else
@@ -1388,8 +1482,9 @@ static int ffnn_score_launches(amx_ffnn* h, const float* feats_dev, int feats_st
             AMX_HIP(hipGetLastError());
         }
         const void* cur = h->d_in;
-        int         ldx = h->Kpad[0];
-        const bool  fused = stats && h->precision == AMX_PREC_BF16;
+        const bool  x3  = h->precision == AMX_PREC_BF16X3;
+        int         ldx = x3 ? 3 * h->seg[0] : h->Kpad[0];
+        const bool  fused = stats && h->mfma_bf16();
         h->cur_part_min = nullptr;
         h->cur_part_idx = nullptr;
         if (fused) {
@@ -1425,6 +1520,34 @@ static int ffnn_score_launches(amx_ffnn* h, const float* feats_dev, int feats_st
                 else if (r == AMX_OK && stats)  // fp32 parity path: separate arg-min pass over the scores
                     r = amx_stats_accumulate_dev(h->ctx, sc, Tc, h->out[l], best_state_dev ? best_state_dev + t0 : nullptr, counts_dev,
                                                  score_sum_dev);
+            }
+            else if (x3) {
+                // hidden layer through the output-layer epilogue (negated weights: z = W x + b in f32), then activation + split
+                float*    part_min = h->cur_part_min;
+                unsigned* part_idx = h->cur_part_idx;
+                h->cur_part_min    = nullptr;  // no arg-min partials for hidden layers
+                h->cur_part_idx    = nullptr;
+                r                  = launch_layer<true>(h, l, cur, ldx, h->d_z, h->Npad[l], Tc, Tpad);
+                h->cur_part_min    = part_min;
+                h->cur_part_idx    = part_idx;
+                if (r == AMX_OK) {
+                    amx::ScopedKernelTimer timer(h->ctx, "ffnn_split");
+                    const int sg     = h->Npad[l];
+                    const int blocks = (int)std::min<long long>(8192, ((long long)Tpad * (sg / 4) + 255) / 256);
+                    amx::bf16_t* dst = (amx::bf16_t*)h->d_act[0];
+#define AMX_SPLIT(ACT) \
+    hipLaunchKernelGGL(amx::split_act_bf16x3<ACT>, dim3(blocks), dim3(256), 0, h->ctx->stream, h->d_z, h->Npad[l], Tc, h->out[l], dst, sg, Tpad)
+                    switch (h->act[l]) {
+                        case AMX_ACT_RELU: AMX_SPLIT(AMX_ACT_RELU); break;
+                        case AMX_ACT_SIGMOID: AMX_SPLIT(AMX_ACT_SIGMOID); break;
+                        case AMX_ACT_TANH: AMX_SPLIT(AMX_ACT_TANH); break;
+                        default: AMX_SPLIT(AMX_ACT_NONE); break;
+                    }
+#undef AMX_SPLIT
+                    AMX_HIP(hipGetLastError());
+                    cur = dst;
+                    ldx = 3 * sg;
+                }
             }
             else {
                 void* dst = h->d_act[l & 1];

@@ -61,26 +61,23 @@ __device__ __forceinline__ void fused_dma16(const void* gsrc, unsigned lds_byte_
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_byte_addr) : "memory");
 }
 
-// Per wavefront and tile the kernel interleaves two things (software pipeline across tiles):
-//   S(k+1)  the screen of the NEXT tile: per block 4 MFMAs + minimum / threshold / 16-bit survivor mask   (matrix pipe + VALU)
-//   E(k)    the exact evaluation of THIS tile's first survivors, one per mixture, in lockstep              (VALU only)
-// block by block, so that the MFMAs (and their dependent-issue latency) run underneath the distance arithmetic instead of in a
-// phase of their own -- with the per-tile barrier all eight waves of a workgroup would otherwise be in the MFMA phase together
-// and in the VALU phase together (measured: screen phase alone 1.8 of 5.8 ms, matrix pipe 35 % busy, VALU idle most of it).
-// LDS: screen ring 2 x 33 KB + mean ring 2 x 44 KB; at the top of iteration k (one s_barrier) the DMA of mean part k+1 and
-// screen part k+2 is issued into the two slots that iteration k-1 has just finished with.
-template<int DIM, bool BEST>
-__global__ __launch_bounds__(512, 2) void gmm_fused_kernel(const float* __restrict__ g_feats, const _Float16* __restrict__ g_X,
-                                                          const float* __restrict__ g_nx, const float* __restrict__ g_q,
-                                                          const char* __restrict__ g_rec, const float* __restrict__ g_isr,
-                                                          float* __restrict__ g_scores, uint32_t* __restrict__ g_best, int T, int n_mix,
-                                                          int n_tiles, int r_split, float* __restrict__ g_part_min,
-                                                          unsigned* __restrict__ g_part_idx, int part_ld,
-                                                          unsigned long long* __restrict__ g_survivors, int abl) {
+// Instruction costs on MI355X (tools/valu_rates.hip, wall clock, all SIMDs busy): a SIMD saturates with TWO resident waves at
+// ~1.2 ns per plain VOP2 f32 operation (sub / mul / add with VGPR operands), ~1.75 ns for VOP3 forms and for an SGPR operand,
+// ~1.95 ns for f64 add / compare, and ~3.6 ns for v_pk_mul / v_pk_add / v_pk_fma_f32 -- a packed operation costs THREE plain ones,
+// not two (a 1024-thread, 128-VGPR variant with four waves per SIMD was no faster: the VALU is the bound, not the occupancy).
+// The reference's distance is therefore written with plain operations and this file is compiled with -fno-slp-vectorize (the
+// SLP vectoriser would re-pack them).  Workgroup = 8 waves x 32 frames, two waves per SIMD, <= 256 VGPRs; per tile a wave runs the
+// screen of its 32 frames, then the exact evaluation (the MFMA latencies of one wave hide behind the VALU work of the other).
+template<int DIM, bool BEST, int NW>
+__global__ __launch_bounds__(NW * 64) void gmm_fused_kernel(const float* __restrict__ g_feats, const _Float16* __restrict__ g_X,
+                                                        const float* __restrict__ g_nx, const float* __restrict__ g_q,
+                                                        const char* __restrict__ g_rec, const float* __restrict__ g_isr,
+                                                        float* __restrict__ g_scores, uint32_t* __restrict__ g_best, int T, int Tpad,
+                                                        int n_mix, int n_tiles, int r_split, float* __restrict__ g_part_min,
+                                                        unsigned* __restrict__ g_part_idx, int part_ld,
+                                                        unsigned long long* __restrict__ g_survivors, int abl) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    constexpr int LD = fused_ld(DIM), REC = fused_rec_bytes(DIM), MU_STAGE = fused_mu_stage(DIM);
-    constexpr int NPA = kFusedAStage / 1024, NPM = MU_STAGE / 1024;
-    constexpr int MU_RING = 2 * kFusedAStage;
+    constexpr int LD = fused_ld(DIM), REC = fused_rec_bytes(DIM), NP = REC / 1024;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tile_t = blockIdx.x / r_split, part = blockIdx.x % r_split;
@@ -88,29 +85,20 @@ __global__ __launch_bounds__(512, 2) void gmm_fused_kernel(const float* __restri
     const int r_begin = part * per, r_end = min(n_tiles, r_begin + per);
     if (r_begin >= r_end)
         return;
-    const int      n_it = r_end - r_begin;
     const unsigned lds_base = (unsigned)(uintptr_t)lds;
-    auto load_A = [&](int r, int slot) {
+    auto load_tile = [&](int r, int buf) {
         const char*    src = g_rec + (size_t)r * REC + lane * 16;
-        const unsigned dst = lds_base + slot * kFusedAStage;
-        for (int p = wave; p < NPA; p += 8)
+        const unsigned dst = lds_base + buf * REC;
+        for (int p = wave; p < NP; p += NW)
             fused_dma16(src + p * 1024, (unsigned)__builtin_amdgcn_readfirstlane((int)(dst + p * 1024)));
     };
-    auto load_mu = [&](int r, int slot) {
-        const char*    src = g_rec + (size_t)r * REC + kFusedAStage + lane * 16;
-        const unsigned dst = lds_base + MU_RING + slot * MU_STAGE;
-        for (int p = wave; p < NPM; p += 8)
-            fused_dma16(src + p * 1024, (unsigned)__builtin_amdgcn_readfirstlane((int)(dst + p * 1024)));
-    };
-    load_A(r_begin, 0);
-    load_mu(r_begin, 0);
-    if (n_it > 1)
-        load_A(r_begin + 1, 1);
+    load_tile(r_begin, 0);
     const int  frow = lane & 31, fk = lane >> 5;
-    const int  t    = tile_t * 256 + wave * 32 + frow;  // < Tpad: the packed operand rows exist
+    const int  t    = tile_t * (NW * 32) + wave * 32 + frow;
     const bool live = t < T;
     const int  tt   = live ? t : T - 1;
-    const bool wave_live = tile_t * 256 + wave * 32 < T;  // wave-uniform
+    const int  tx   = min(t, Tpad - 1);  // packed operand rows exist up to Tpad
+    const bool wave_live = tile_t * (NW * 32) + wave * 32 < T;  // wave-uniform
     float      x[DIM];
 #pragma unroll
     for (int i = 0; i < DIM; ++i)
@@ -118,145 +106,124 @@ __global__ __launch_bounds__(512, 2) void gmm_fused_kernel(const float* __restri
     fus_f16x8 bx[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
-        bx[ks] = *(const fus_f16x8*)(g_X + (size_t)t * 64 + (ks * 2 + fk) * 8);
-    const float nx = g_nx[t], q = g_q[t];
+        bx[ks] = *(const fus_f16x8*)(g_X + (size_t)tx * 64 + (ks * 2 + fk) * 8);
+    const float nx = g_nx[tx], q = g_q[tx];
     const bool  all = !(nx < __builtin_inff());  // operand row did not fit f16: keep every slot
-    // output side: lane L stores 16 bytes = mixtures 4 (L & 3) .. + 3 of frame 16 s + (L >> 2) of the wave (s = 0, 1), so that four
-    // adjacent lanes cover the 64 contiguous bytes of one frame (one 64-byte request instead of four 16-byte ones)
-    const int  oj = lane & 3;
-    const int  ot0 = tile_t * 256 + wave * 32 + (lane >> 2), ot1 = ot0 + 16;
-    const int  src0 = 4 * ((lane >> 2) + 32 * (oj >> 1)), src1 = src0 + 64;  // ds_bpermute byte addresses of the source lanes
-    const bool ohi = (oj & 1) != 0;
     // stores of 16 bytes need aligned rows; otherwise (and on the model's last, partial tile) scalar guarded stores
     const bool wide_ok = (n_mix & 3) == 0 && ((uintptr_t)g_scores & 15) == 0 && (!BEST || ((uintptr_t)g_best & 15) == 0);
-    const bool counted = wide_ok && wave_live;  // this wave issues exactly (BEST ? 4 : 2) stores per full tile
+    const bool counted = wide_ok && wave_live && NW < 16;  // (the 16-wave instantiation spills: scratch traffic breaks the count)  // this wave issues exactly (BEST ? 4 : 2) stores per full tile
     // The compiler's wait-count pass does not see the inline-asm waits of the loop: without a wait it can see, it would put its own
     // vmcnt(0) in front of the first use of x[] inside the loop -- and there that waits for the next tile's DMA and the stores.
     __builtin_amdgcn_s_waitcnt(0);
-    __builtin_amdgcn_s_barrier();
     float    run_min = 3.402823466e+38f;  // best state of this lane's mixtures so far (ascending state, strict '<')
     unsigned run_idx = 0xffffffffu;
     unsigned n_surv  = 0;  // densities this lane evaluated exactly (bench: survivors per mixture)
 
-    // ---- screen of one block (two mixtures: 2 i + fk for lane half fk): 4 MFMAs, then minimum / threshold / survivor mask
-    auto screen_mfma = [&](const char* stageA, int i) {
-        const int  rr = i * 32 + frow;
-        fus_f32x16 c;
-#pragma unroll
-        for (int e = 0; e < 16; ++e)
-            c[e] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const fus_f16x8 a = *(const fus_f16x8*)(stageA + rr * 128 + (((ks * 2 + fk) ^ ((rr >> 1) & 7)) << 4));
-            c                 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bx[ks], c, 0, 0, 0);
-        }
-        return c;
-    };
-    auto screen_mask = [&](const char* stageA, int i, const fus_f32x16& c) -> unsigned {
-        const float* s_p = (const float*)(stageA + kFusedABytes);  // p1[16], p2[16], (int) densities per mixture [16]
-        float        mn = min3_first(c[0], c[1], c[2]);
-        mn              = min3_raw(mn, c[3], c[4]);
-        mn              = min3_raw(mn, c[5], c[6]);
-        mn              = min3_raw(mn, c[7], c[8]);
-        mn              = min3_raw(mn, c[9], c[10]);
-        mn              = min3_raw(mn, c[11], c[12]);
-        mn              = min3_raw(mn, c[13], c[14]);
-        mn              = min3_raw(mn, c[15], c[15]);
-        // tau as in gmm_screen_epilogue (gmm.hip): p1 = 2.2e-3 na + 1.3e-4 sqrtK, p2 = 1.3e-4 sqrtK na + 1.6e-5 cabs, q per frame
-        const float p1 = s_p[i * 2 + fk], p2 = s_p[16 + i * 2 + fk];
-        const int   nd = ((const int*)s_p)[32 + i * 2 + fk];
-        const float thr = mn + fmaf(nx, p1, fmaf(fabsf(mn), 1.6e-5f, p2 + q)) + 1e-30f;
-        unsigned    bits = 0;  // bit k = "slot k is above the threshold", filled from the top down
-#pragma unroll
-        for (int e = 14; e >= 0; e -= 2) {
-            const gmm_pk2 dd = gmm_pk2{thr, thr} - gmm_pk2{c[e], c[e + 1]};
-            bits             = __builtin_amdgcn_alignbit(bits, __float_as_uint(dd.y), 31);  // (bits << 1) | sign(thr - g)
-            bits             = __builtin_amdgcn_alignbit(bits, __float_as_uint(dd.x), 31);
-        }
-        const unsigned valid = (1u << nd) - 1u;  // nd <= 16
-        // frames behind the last one have an all-zero operand row (every slot ties): no survivors for them
-        return live ? ((all ? 0xffffu : (~bits & 0xffffu)) & valid) : 0u;
-    };
+    for (int r = r_begin; r < r_end; ++r) {
+        const int buf = (r - r_begin) & 1;
+        // my DMA pieces of tile r are older than the stores of tile r - 1: waiting until only those stores are outstanding
+        // means the pieces have landed (gfx9 retires vector memory operations in issue order)
+        if (r == r_begin || !counted)
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else if (BEST)
+            asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // everybody's pieces are there, and nobody reads the other stage any more
+        if (r + 1 < r_end)
+            load_tile(r + 1, buf ^ 1);
+        if (!wave_live)  // a wave behind the last frame only takes part in the DMA and the barriers
+            continue;
+        const char*  stage = lds + buf * REC;
+        const float* s_p   = (const float*)(stage + kFusedABytes);  // p1[16], p2[16], (int) densities per mixture [16]
 
-    unsigned M[4] = {0, 0, 0, 0};  // survivor masks of this lane's 8 mixtures (2 i + fk) of the current tile, 16 bit each
-    if (wave_live) {
+        // ---- screen: survivor masks of this lane's 8 mixtures (2 i + fk), 16 bit each
+        unsigned M[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const fus_f32x16 c = screen_mfma(lds, i);
-            M[i >> 1] |= screen_mask(lds, i, c) << (16 * (i & 1));
-        }
-    }
-
-    // ---- one iteration: exact evaluation of tile r (masks M, mean slot k & 1), interleaved with the screen of tile r + 1
-    auto tile_body = [&](auto next_tag, int k) {
-        constexpr bool NEXT = decltype(next_tag)::value;
-        const int      r = r_begin + k;
-        const char*    stageA = lds + ((k + 1) & 1) * kFusedAStage;  // screen part of tile r + 1
-        const float*   s_mu = (const float*)(lds + MU_RING + (k & 1) * MU_STAGE);
-        auto           fetch = [&](float (&dst)[DIM], double& cc, int row) {
-            const float* src = s_mu + row * LD;
+            const int  rr = i * 32 + frow;
+            fus_f32x16 c;
 #pragma unroll
-            for (int i = 0; i + 3 < DIM; i += 4) {
-                const float4 v = *(const float4*)(src + i);
-                dst[i]         = v.x;
-                dst[i + 1]     = v.y;
-                dst[i + 2]     = v.z;
-                dst[i + 3]     = v.w;
+            for (int e = 0; e < 16; ++e)
+                c[e] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const fus_f16x8 a = *(const fus_f16x8*)(stage + rr * 128 + (((ks * 2 + fk) ^ ((rr >> 1) & 7)) << 4));
+                c                 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bx[ks], c, 0, 0, 0);
             }
+            float mn = min3_first(c[0], c[1], c[2]);
+            mn       = min3_raw(mn, c[3], c[4]);
+            mn       = min3_raw(mn, c[5], c[6]);
+            mn       = min3_raw(mn, c[7], c[8]);
+            mn       = min3_raw(mn, c[9], c[10]);
+            mn       = min3_raw(mn, c[11], c[12]);
+            mn       = min3_raw(mn, c[13], c[14]);
+            mn       = min3_raw(mn, c[15], c[15]);
+            // tau as in gmm_screen_epilogue (gmm.hip): p1 = 2.2e-3 na + 1.3e-4 sqrtK, p2 = 1.3e-4 sqrtK na + 1.6e-5 cabs, q per frame
+            const float p1 = s_p[i * 2 + fk], p2 = s_p[16 + i * 2 + fk];
+            const int   nd = ((const int*)s_p)[32 + i * 2 + fk];
+            const float thr = mn + fmaf(nx, p1, fmaf(fabsf(mn), 1.6e-5f, p2 + q)) + 1e-30f;
+            unsigned    bits = 0;  // bit k = "slot k is above the threshold", filled from the top down
 #pragma unroll
-            for (int i = DIM & ~3; i < DIM; ++i)
-                dst[i] = src[i];
-            cc = *(const double*)(src + LD - 2);
-        };
+            for (int e = 15; e >= 0; --e)
+                bits = __builtin_amdgcn_alignbit(bits, __float_as_uint(thr - c[e]), 31);  // (bits << 1) | sign(thr - g)
+            const unsigned valid = (1u << nd) - 1u;  // nd <= 16
+            // frames behind the last one have an all-zero operand row (every slot ties): no survivors for them
+            const unsigned m16 = live ? ((all ? 0xffffu : (~bits & 0xffffu)) & valid) : 0u;
+            M[i >> 1] |= m16 << (16 * (i & 1));
+        }
         n_surv += __popc(M[0]) + __popc(M[1]) + __popc(M[2]) + __popc(M[3]);
+
+        // ---- exact evaluation.  First survivor of every mixture in lockstep (static register indices), the ~4 % further
+        // survivors in a divergent loop behind it, in slot order.  The mean row comes in 8-float pieces (2 x ds_read_b128).
+        const float* s_mu = (const float*)(stage + kFusedAStage);
+        // the reference's distance (Mm/GaussDiagonalMaximumFeatureScorer.cc:143-180, SSE3 build): four strided partial sums of
+        // unfused ((mu - x) / sigma)^2, (l0 + l1) + (l2 + l3), scalar tail -- plain f32 operations (see the cost table above)
+        auto         distance = [&](int row, double& cc) -> float {
+            const float*  src = s_mu + row * LD;
+            float         l0 = 0.f, l1 = 0.f, l2 = 0.f, l3 = 0.f;
+            constexpr int EFF = DIM & ~3;
+#pragma unroll
+            for (int i = 0; i < EFF; i += 4) {
+                const float4 m  = *(const float4*)(src + i);
+                const float  d0 = (m.x - x[i]) * g_isr[i], d1 = (m.y - x[i + 1]) * g_isr[i + 1];
+                const float  d2 = (m.z - x[i + 2]) * g_isr[i + 2], d3 = (m.w - x[i + 3]) * g_isr[i + 3];
+                l0              = l0 + d0 * d0;
+                l1              = l1 + d1 * d1;
+                l2              = l2 + d2 * d2;
+                l3              = l3 + d3 * d3;
+            }
+            float result = 0.f;
+            result       = result + ((l0 + l1) + (l2 + l3));
+#pragma unroll
+            for (int i = EFF; i < DIM; ++i) {
+                const float df = (src[i] - x[i]) * g_isr[i];
+                result         = result + df * df;
+            }
+            cc = *(const double*)(src + LD - 2);
+            return result;
+        };
         float    best[8];
-        unsigned bidx[8];
-        int      slot[8];
-        unsigned R[4] = {0, 0, 0, 0};  // further survivors (first one removed)
+        unsigned bpack = 0, bvalid = 0;  // best density of mixture i in nibble i / bit i set once a density was taken
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const unsigned m16 = (M[i >> 1] >> (16 * (i & 1))) & 0xffffu;
-            slot[i]            = m16 ? __ffs((int)m16) - 1 : -1;
-            R[i >> 1] |= (m16 & (m16 - 1u)) << (16 * (i & 1));
-            best[i] = FLT_MAX;
-            bidx[i] = 0xffffffffu;
+            const int      sl  = m16 ? __ffs((int)m16) - 1 : 0;
+            double         cc;
+            const float    dist = distance((i * 2 + fk) * 16 + sl, cc);
+            const double   s    = cc + (double)dist;
+            const bool     take = m16 != 0u && (double)FLT_MAX > s;  // reference: if (bestScore > score); bestScore is FLT_MAX so far
+            best[i]             = take ? (float)s : FLT_MAX;
+            bpack |= take ? ((unsigned)sl << (4 * i)) : 0u;
+            bvalid |= take ? (1u << i) : 0u;
         }
-        auto eval = [&](const float (&mu)[DIM], double cc, int sl, float& b, unsigned& bi) {
-            const float  dist = gmm_distance_pk_reg<DIM>(x, mu, g_isr);
-            const double s    = cc + (double)dist;
-            const bool   take = sl >= 0 && (double)b > s;  // reference: if (bestScore > score) with an f32 bestScore
-            b                 = take ? (float)s : b;
-            bi                = take ? (unsigned)sl : bi;
-        };
-        unsigned Mn[4] = {0, 0, 0, 0};
-        {
-            // first survivor of every mixture in lockstep (static register indices; the next mean row is fetched during the
-            // current distance), block i of the next tile's screen around it: MFMAs in front, mask arithmetic behind
-            float  mua[DIM], mub[DIM];
-            double ca, cb;
-            fetch(mua, ca, fk * 16 + max(slot[0], 0));
+        unsigned R[4];
 #pragma unroll
-            for (int i = 0; i < 8; i += 2) {
-                fus_f32x16 c0, c1;
-                if (NEXT)
-                    c0 = screen_mfma(stageA, i);
-                fetch(mub, cb, ((i + 1) * 2 + fk) * 16 + max(slot[i + 1], 0));
-                if (!(abl & 8))
-                    eval(mua, ca, slot[i], best[i], bidx[i]);
-                if (NEXT) {
-                    Mn[i >> 1] |= screen_mask(stageA, i, c0);
-                    c1 = screen_mfma(stageA, i + 1);
-                }
-                if (i + 2 < 8)
-                    fetch(mua, ca, ((i + 2) * 2 + fk) * 16 + max(slot[i + 2], 0));
-                if (!(abl & 8))
-                    eval(mub, cb, slot[i + 1], best[i + 1], bidx[i + 1]);
-                if (NEXT)
-                    Mn[i >> 1] |= screen_mask(stageA, i + 1, c1) << 16;
-            }
+        for (int w = 0; w < 4; ++w) {  // remove the first survivor of both halves
+            const unsigned lo = M[w] & 0xffffu, hi = M[w] >> 16;
+            R[w]              = (lo & (lo - 1u)) | ((hi & (hi - 1u)) << 16);
         }
-        // the ~4 % further survivors, in slot order, through select chains on the 8 running (best, index) pairs
-        while (!(abl & 4) && __any((R[0] | R[1] | R[2] | R[3]) != 0u)) {
+        while (__any((R[0] | R[1] | R[2] | R[3]) != 0u)) {
             const unsigned w01 = R[0] ? R[0] : R[1], w23 = R[2] ? R[2] : R[3];
             const bool     lo  = (R[0] | R[1]) != 0u;
             const unsigned rw  = lo ? w01 : w23;
@@ -268,23 +235,21 @@ __global__ __launch_bounds__(512, 2) void gmm_fused_kernel(const float* __restri
                 for (int j = 0; j < 4; ++j)
                     R[j] = (w == j) ? cleared : R[j];
                 const int i = 2 * w + (pos >> 4), sl = pos & 15;
-                float     mu[DIM];
                 double    cc;
-                fetch(mu, cc, (i * 2 + fk) * 16 + sl);
-                float b = best[0];
+                const float dist = distance((i * 2 + fk) * 16 + sl, cc);
+                float       b    = best[0];
 #pragma unroll
                 for (int j = 1; j < 8; ++j)
                     b = (i == j) ? best[j] : b;
-                const float  dist = gmm_distance_pk_reg<DIM>(x, mu, g_isr);
                 const double s    = cc + (double)dist;
                 const bool   take = (double)b > s;
                 const float  nb   = (float)s;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const bool hit = take && i == j;
-                    best[j]        = hit ? nb : best[j];
-                    bidx[j]        = hit ? (unsigned)sl : bidx[j];
-                }
+                for (int j = 0; j < 8; ++j)
+                    best[j] = (take && i == j) ? nb : best[j];
+                const unsigned sh = 4u * (unsigned)i;
+                bpack             = take ? ((bpack & ~(15u << sh)) | ((unsigned)sl << sh)) : bpack;
+                bvalid |= take ? (1u << i) : 0u;
             }
         }
 
@@ -300,86 +265,44 @@ __global__ __launch_bounds__(512, 2) void gmm_fused_kernel(const float* __restri
                 run_idx = (unsigned)m;
             }
         }
-        // lane halves exchange four values each (v_permlane32_swap): half 0 then holds mixtures 0..7 of the tile, half 1 mixtures
-        // 8..15, in order; a ds_bpermute pass turns that into 16 contiguous bytes per lane, four adjacent lanes per frame
-        unsigned so[8], bo[8];
+        // lane halves exchange four values each: half 0 ends up with mixtures 0..7 of the tile, half 1 with 8..15, in order
+        float    so[8];
+        unsigned bo[8];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const fus_u32x2 rs = __builtin_amdgcn_permlane32_swap(__float_as_uint(sc[j]), __float_as_uint(sc[4 + j]), false, false);
-            so[2 * j]          = rs.x;
-            so[2 * j + 1]      = rs.y;
+            so[2 * j]          = __uint_as_float(rs.x);
+            so[2 * j + 1]      = __uint_as_float(rs.y);
             if (BEST) {
-                const fus_u32x2 rb = __builtin_amdgcn_permlane32_swap(bidx[j], bidx[4 + j], false, false);
+                const unsigned  bj = (bvalid >> j) & 1u ? (bpack >> (4 * j)) & 15u : 0xffffffffu;
+                const unsigned  bk = (bvalid >> (4 + j)) & 1u ? (bpack >> (4 * (4 + j))) & 15u : 0xffffffffu;
+                const fus_u32x2 rb = __builtin_amdgcn_permlane32_swap(bj, bk, false, false);
                 bo[2 * j]          = rb.x;
                 bo[2 * j + 1]      = rb.y;
             }
         }
-        if (!(abl & 1)) {
-            const bool full = wide_ok && m0 + 16 <= n_mix;
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                const int  st  = s2 ? ot1 : ot0;
-                const int  src = s2 ? src1 : src0;
-                const bool ok  = st < T;
-                unsigned   v[4], vb[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const unsigned a0 = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)so[e]);
-                    const unsigned a1 = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)so[4 + e]);
-                    v[e]              = ohi ? a1 : a0;
-                    if (BEST) {
-                        const unsigned b0 = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)bo[e]);
-                        const unsigned b1 = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)bo[4 + e]);
-                        vb[e]             = ohi ? b1 : b0;
-                    }
-                }
-                float*    gs = g_scores + (size_t)st * n_mix + m0 + oj * 4;
-                uint32_t* gb = BEST ? g_best + (size_t)st * n_mix + m0 + oj * 4 : nullptr;
-                if (full) {
-                    if (ok) {
-                        *(uint4*)gs = make_uint4(v[0], v[1], v[2], v[3]);
-                        if (BEST)
-                            *(uint4*)gb = make_uint4(vb[0], vb[1], vb[2], vb[3]);
-                    }
-                }
-                else if (ok) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (m0 + oj * 4 + e < n_mix) {
-                            gs[e] = __uint_as_float(v[e]);
-                            if (BEST)
-                                gb[e] = vb[e];
-                        }
+        const int mb = m0 + fk * 8;
+        if (live) {
+            float*    gs = g_scores + (size_t)t * n_mix + mb;
+            uint32_t* gb = BEST ? g_best + (size_t)t * n_mix + mb : nullptr;
+            if (wide_ok && m0 + 16 <= n_mix) {
+                *(float4*)gs       = make_float4(so[0], so[1], so[2], so[3]);
+                *(float4*)(gs + 4) = make_float4(so[4], so[5], so[6], so[7]);
+                if (BEST) {
+                    *(uint4*)gb       = make_uint4(bo[0], bo[1], bo[2], bo[3]);
+                    *(uint4*)(gb + 4) = make_uint4(bo[4], bo[5], bo[6], bo[7]);
                 }
             }
-        }
+            else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            M[j] = Mn[j];
-    };
-
-    for (int k = 0; k < n_it; ++k) {
-        // my DMA pieces for this iteration are older than the stores of the previous one: waiting until only those stores are
-        // outstanding means the pieces have landed (gfx9 retires vector memory operations in issue order)
-        if (k == 0 || !counted)
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        else if (BEST)
-            asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-        else
-            asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();  // everybody's pieces are there, and nobody reads the slots refilled below any more
-        if (!(abl & 2)) {
-            if (k + 1 < n_it)
-                load_mu(r_begin + k + 1, (k + 1) & 1);
-            if (k + 2 < n_it)
-                load_A(r_begin + k + 2, k & 1);
+                for (int e = 0; e < 8; ++e)
+                    if (mb + e < n_mix) {
+                        gs[e] = so[e];
+                        if (BEST)
+                            gb[e] = bo[e];
+                    }
+            }
         }
-        if (!wave_live)  // a wave behind the last frame only takes part in the DMA and the barriers
-            continue;
-        if (k + 1 < n_it)
-            tile_body(std::true_type{}, k);
-        else
-            tile_body(std::false_type{}, k);
     }
     if (g_survivors) {
         unsigned long long n = live ? n_surv : 0u;
@@ -464,39 +387,74 @@ extern "C" int amx_internal_gmm_fused_create(int dim, int n_mix, int n_tiles, co
     return AMX_OK;
 }
 
-// how many mixture ranges a pass of Tpad frames is split into (one workgroup per CU and range); the partial arg-min arrays
-// hold that many rows
-extern "C" int amx_internal_gmm_fused_split(int n_cu, int Tpad, int n_tiles) {
-    const int ntt = Tpad / 256;
-    int       split = (std::max(n_cu, 8) + ntt - 1) / ntt;
-    if (ntt * 4 >= 3 * std::max(n_cu, 8))
-        split = 1;  // >= 3/4 of the CUs busy with whole-model workgroups: splitting would only add tile traffic
+// how many mixture ranges a pass of Tpad frames is split into (workgroup = 256 frames x one range; one workgroup per CU): the
+// smallest split that gives every CU a workgroup, unless the frame tiles alone already fill 3/4 of them.  The partial arg-min
+// arrays hold that many rows.
+// waves per workgroup: 12 (three per SIMD, 384 frames; the kernel uses 158 VGPRs) for long passes -- measured 5.1 ms against 5.9 ms
+// with 8 waves and 5.0 ms with 16 (which spills 9 registers) per 63 936 frames -- and 8 (256 frames) for the decoder's small batches,
+// where a 384-frame workgroup would idle a third of its waves.  AMX_FUSED_WAVES = 8 | 12 | 16 overrides (A/B runs).
+static int fused_waves(int Tpad) {
+    static const int forced = getenv("AMX_FUSED_WAVES") ? atoi(getenv("AMX_FUSED_WAVES")) : 0;
+    if (forced == 8 || forced == 12 || forced == 16)
+        return forced;
+    return Tpad >= 4096 ? 12 : 8;
+}
+
+static int fused_split_raw(int n_cu, int Tpad, int n_tiles) {
+    const int fpw = fused_waves(Tpad) * 32;
+    const int ntt = (Tpad + fpw - 1) / fpw, cus = std::max(n_cu, 8);
+    if (fused_waves(Tpad) != 8) {  // frame tiles of 384: pick the split whose workgroup count is closest below a whole number of rounds
+        int best = 1;
+        double best_eff = 0;
+        for (int sp = 1; sp <= std::min(n_tiles, 8); ++sp) {
+            const int    wgs = ntt * sp;
+            const double eff = (double)wgs / (double)(((wgs + cus - 1) / cus) * cus);
+            if (eff > best_eff + 0.02) {
+                best_eff = eff;
+                best     = sp;
+            }
+        }
+        return best;
+    }
+    int split = (cus + ntt - 1) / ntt;
+    if (ntt * 4 >= 3 * cus)
+        split = 1;
+    else if (ntt * split > cus && split > 1 && ntt * (split - 1) * 8 >= cus * 7)
+        --split;  // one workgroup per CU and a few idle CUs beat a second, nearly empty round
     return std::max(1, std::min(split, n_tiles));
+}
+
+extern "C" int amx_internal_gmm_fused_split(int n_cu, int Tpad, int n_tiles) {
+    // every range holds ceil(n_tiles / split) tiles: report the number of NON-EMPTY ranges, the partial arg-min arrays have
+    // exactly that many rows (an empty range would leave its row unwritten)
+    const int split = fused_split_raw(n_cu, Tpad, n_tiles);
+    const int per   = (n_tiles + split - 1) / split;
+    return (n_tiles + per - 1) / per;
 }
 
 extern "C" int amx_internal_gmm_fused_score(amx_ctx* ctx, int dim, const void* rec_dev, const float* isr_dev, const float* feats,
                                             const void* X, const float* nx, const float* q, int T, int Tpad, int n_mix, int n_tiles,
                                             int split, float* scores, uint32_t* best, float* pmin, unsigned* pidx, int part_ld,
                                             unsigned long long* survivors) {
-    const int   ntt = Tpad / 256;
+    const int   nw = fused_waves(Tpad), ntt = (Tpad + nw * 32 - 1) / (nw * 32);
     const int   lds = 2 * amx::fused_rec_bytes(dim);
     const char* rec = (const char*)rec_dev;
     hipStream_t st  = ctx->stream;
     const int   abl = getenv("AMX_FUSED_ABL") ? atoi(getenv("AMX_FUSED_ABL")) : 0;  // ablation switches (profiling only; results are wrong)
+#define AMX_FUSED_LAUNCH(D, B, W)                                                                                               \
+    {                                                                                                                           \
+        auto k = amx::gmm_fused_kernel<D, B, W>;                                                                                \
+        hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);                                   \
+        hipLaunchKernelGGL(k, dim3(ntt * split), dim3(W * 64), lds, st, feats, (const _Float16*)X, nx, q, rec, isr_dev, scores,  \
+                           best, T, Tpad, n_mix, n_tiles, split, pmin, pidx, part_ld, survivors, abl);                          \
+    }
 #define AMX_FUSED(D)                                                                                                            \
     case D: {                                                                                                                   \
-        if (best) {                                                                                                             \
-            auto k = amx::gmm_fused_kernel<D, true>;                                                                            \
-            hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);                               \
-            hipLaunchKernelGGL(k, dim3(ntt * split), dim3(512), lds, st, feats, (const _Float16*)X, nx, q, rec, isr_dev, scores, \
-                               best, T, n_mix, n_tiles, split, pmin, pidx, part_ld, survivors, abl);                            \
-        }                                                                                                                       \
-        else {                                                                                                                  \
-            auto k = amx::gmm_fused_kernel<D, false>;                                                                           \
-            hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);                               \
-            hipLaunchKernelGGL(k, dim3(ntt * split), dim3(512), lds, st, feats, (const _Float16*)X, nx, q, rec, isr_dev, scores, \
-                               best, T, n_mix, n_tiles, split, pmin, pidx, part_ld, survivors, abl);                            \
-        }                                                                                                                       \
+        if (best && nw == 16) AMX_FUSED_LAUNCH(D, true, 16)                                                                     \
+        else if (best && nw == 12) AMX_FUSED_LAUNCH(D, true, 12)                                                                \
+        else if (best) AMX_FUSED_LAUNCH(D, true, 8)                                                                             \
+        else if (nw == 12) AMX_FUSED_LAUNCH(D, false, 12)                                                                       \
+        else AMX_FUSED_LAUNCH(D, false, 8)                                                                                      \
     } break;
     switch (dim) {
         AMX_FUSED(16)
@@ -510,6 +468,7 @@ extern "C" int amx_internal_gmm_fused_score(amx_ctx* ctx, int dim, const void* r
             return AMX_ERR_UNSUPPORTED;
     }
 #undef AMX_FUSED
+#undef AMX_FUSED_LAUNCH
     AMX_HIP(hipGetLastError());
     return AMX_OK;
 }

@@ -224,3 +224,63 @@ def test_full_size_shard_properties(ctx):
     nn.score_dev(xd[32000:33024].contiguous(), 440, 1024, s3)     # small-batch tile configuration, straddling the pass boundary
     torch.cuda.synchronize()
     assert torch.equal(s3.view(torch.int32), s[32000:33024].view(torch.int32))
+
+
+# ---- split-bf16 ("bf16x3") precision: three bf16 MFMA products per f32 product, f32 accumulation
+
+@pytest.mark.parametrize("T", [1, 100, 129, 1024])
+def test_bf16x3_path_meets_the_fp32_bar(ctx, T):
+    """the same <= 1e-4 relative (+1e-4 absolute) bar as the fp32 path, arg-min state identical, ragged shapes"""
+    import rasr_amd
+    from oracle import oracle_ffnn_score
+    Ws, bs, acts, logp = synth.ffnn([440, 256, 300, 1000], seed=7)
+    x = feats(T, 440, 6)
+    got = rasr_amd.NnBatchFeatureScorer(ctx, Ws, bs, acts, log_prior=logp, priori_scale=1.0, precision="bf16x3").score(x)
+    want = oracle_ffnn_score(Ws, bs, acts, x, log_prior=logp, prior_scale=1.0, acc64=True)
+    assert np.all(np.abs(got - want) <= 1e-4 * np.abs(want) + 1e-4), np.abs(got - want).max()
+    assert np.array_equal(got.argmin(axis=1), want.argmin(axis=1))
+
+
+@pytest.mark.parametrize("act", [1, 2, 3])
+def test_bf16x3_activations(ctx, act):
+    import rasr_amd
+    from oracle import oracle_ffnn_score
+    Ws, bs, acts, logp = synth.ffnn([64, 130, 77], seed=17, act=act)
+    x = feats(50, 64, 18)
+    got = rasr_amd.NnBatchFeatureScorer(ctx, Ws, bs, acts, log_prior=logp, priori_scale=0.6, precision="bf16x3").score(x)
+    want = oracle_ffnn_score(Ws, bs, acts, x, log_prior=logp, prior_scale=0.6, acc64=True)
+    assert np.all(np.abs(got - want) <= 1e-4 * np.abs(want) + 1e-4), np.abs(got - want).max()
+
+
+def test_bf16x3_config4_full_size_against_the_oracle(ctx):
+    """BASELINE config 4 at full size -- 440-6x2048-10000, batch 1024 -- against the f64-accumulating oracle on EVERY score (not a
+    property test): |delta| <= 1e-4 |ref| + 1e-4, arg-min states identical wherever the two best scores of the reference are
+    further apart than the bar; the fused statistics agree with a recount of the scores"""
+    import torch
+
+    import rasr_amd
+    from oracle import oracle_ffnn_score
+    dims = [440] + [2048] * 6 + [10000]
+    Ws, bs, acts, logp = synth.ffnn(dims, seed=7)
+    T = 1024
+    x = feats(T, 440, 6)
+    nn = rasr_amd.NnBatchFeatureScorer(ctx, Ws, bs, acts, log_prior=logp, priori_scale=1.0, precision="bf16x3")
+    got = nn.score(x)
+    want = oracle_ffnn_score(Ws, bs, acts, x, log_prior=logp, prior_scale=1.0, acc64=True)
+    err = np.abs(got - want)
+    assert np.all(err <= 1e-4 * np.abs(want) + 1e-4), (err.max(), (err / (np.abs(want) + 1)).max())
+    srt = np.sort(want, axis=1)
+    clear = (srt[:, 1] - srt[:, 0]) > 4e-4 * (1 + np.abs(srt[:, 0]))
+    assert np.array_equal(got.argmin(axis=1)[clear], want.argmin(axis=1)[clear]) and clear.mean() > 0.9
+    xd = torch.from_numpy(x).cuda()
+    scores = torch.empty((T, 10000), dtype=torch.float32, device="cuda")
+    state = torch.empty((T,), dtype=torch.int32, device="cuda")
+    counts = torch.zeros((10000,), dtype=torch.int64, device="cuda")
+    ssum = torch.zeros((1,), dtype=torch.float64, device="cuda")
+    ctx.use_torch_stream()
+    nn.score_stats_dev(xd, 440, T, scores, state, counts, ssum)
+    torch.cuda.synchronize()
+    sc = scores.cpu().numpy()
+    assert np.array_equal(sc.view(np.uint32), got.view(np.uint32))
+    assert np.array_equal(state.cpu().numpy(), sc.argmin(axis=1))
+    assert np.array_equal(counts.cpu().numpy(), np.bincount(sc.argmin(axis=1), minlength=10000))

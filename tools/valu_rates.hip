@@ -10,14 +10,14 @@
 #define REP64(x) REP8(REP8(x))
 
 template<int OP>
-__global__ __launch_bounds__(512) void k(unsigned long long* out, float seed) {
+__global__ __launch_bounds__(1024) void k(unsigned long long* out, float seed) {
     float a0 = seed + threadIdx.x, a1 = a0 * 1.5f, a2 = a0 + 2.f, a3 = a0 - 3.f, a4 = a1 + 1.f, a5 = a2 * 0.5f, a6 = a3 + 7.f, a7 = a4 - 9.f;
     float b0 = 1.0001f, b1 = 0.9999f;
     double d0 = a0, d1 = a1;
     unsigned u0 = threadIdx.x * 2654435761u, u1 = u0 ^ 0x5bd1e995u;
     __builtin_amdgcn_s_barrier();
     unsigned long long t0 = __builtin_readcyclecounter();
-    for (int it = 0; it < 16; ++it) {
+    for (int it = 0; it < 256; ++it) {
         if (OP == 0) { REP64(asm volatile("v_mul_f32 %0, %0, %4\n v_mul_f32 %1, %1, %4\n v_mul_f32 %2, %2, %4\n v_mul_f32 %3, %3, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0));) }
         if (OP == 1) { REP64(asm volatile("v_pk_mul_f32 %0, %0, %2\n v_pk_mul_f32 %1, %1, %2" : "+v"(*(double*)&a0), "+v"(*(double*)&a2) : "v"(*(double*)&b0)); asm volatile("v_pk_mul_f32 %0, %0, %2\n v_pk_mul_f32 %1, %1, %2" : "+v"(*(double*)&a4), "+v"(*(double*)&a6) : "v"(*(double*)&b0));) }
         if (OP == 2) { REP64(asm volatile("v_fma_f32 %0, %0, %4, %0\n v_fma_f32 %1, %1, %4, %1\n v_fma_f32 %2, %2, %4, %2\n v_fma_f32 %3, %3, %4, %3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0));) }
@@ -52,14 +52,30 @@ __global__ __launch_bounds__(512) void k(unsigned long long* out, float seed) {
 
 template<int OP>
 void run(const char* name, int per_rep, unsigned long long* d) {
-    for (int threads : {256, 512, 1024}) {
-        hipLaunchKernelGGL(k<OP>, dim3(256), dim3(threads), 0, 0, d, 1.0f);
+    // wall-clock view: total wave-instructions / (kernel time x 1024 SIMDs); grid sized for 1, 2, 4 and 8 waves per SIMD
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    const int cfg[4][2] = {{256, 256}, {256, 512}, {256, 1024}, {512, 1024}};
+    printf("%-30s", name);
+    for (int c = 0; c < 4; ++c) {
+        const int blocks = cfg[c][0], threads = cfg[c][1];
+        hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(threads), 0, 0, d, 1.0f);
         hipDeviceSynchronize();
+        hipEventRecord(e0, 0);
+        hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(threads), 0, 0, d, 1.0f);
+        hipEventRecord(e1, 0);
+        hipEventSynchronize(e1);
+        float ms = 0;
+        hipEventElapsedTime(&ms, e0, e1);
         unsigned long long h = 0;
         hipMemcpy(&h, d, 8, hipMemcpyDeviceToHost);
-        double n = 16.0 * 64 * per_rep;
-        printf("%-28s %d waves/SIMD: %.2f clk per instruction (one wave's view), %.2f clk per SIMD-instruction\n", name, threads / 256, h / n, h / n / (threads / 256));
+        const double n = 256.0 * 64 * per_rep;                    // instructions per wave
+        const double waves_per_simd = (double)blocks * (threads / 64) / 1024.0;
+        const double ns_per_simd_instr = ms * 1e6 / (n * waves_per_simd);
+        printf(" | %g w/SIMD: %.2f ns/SIMD-instr, %.2f ticks/wave-instr", waves_per_simd, ns_per_simd_instr, h / n);
     }
+    printf("\n");
 }
 
 int main() {
