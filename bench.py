@@ -193,9 +193,18 @@ class NnPipeline:
         self.M = 10000
         self.scores = torch.empty((min(self.CHUNK, self.F), self.M), dtype=torch.float32, device="cuda")
         self.best = torch.empty((self.F,), dtype=torch.int32, device="cuda")
-        self.counts = torch.zeros((self.M,), dtype=torch.int64, device="cuda")
-        self.score_sum = torch.zeros((1,), dtype=torch.float64, device="cuda")
+        self.make_reduce_buffer()
         self.units = self.F
+
+    def reduce_fields(self):
+        return [("score_sum", 1, "f64"), ("counts", self.M, "count")]
+
+    def make_reduce_buffer(self):
+        """all cross-rank state of the job in ONE flat buffer: epoch_reduce is one all-reduce"""
+        from rasr_amd.partition import EpochReduceBuffer
+        self.red = EpochReduceBuffer(self.reduce_fields(), device="cuda")
+        self.counts = self.red.view("counts")
+        self.score_sum = self.red.view("score_sum")
 
     def step(self):
         self.fe.run_plan(self.plan, self.pcm, self.ceps)
@@ -205,10 +214,7 @@ class NnPipeline:
             self.nn.score_stats_dev(self.ctxwin[t0:], 440, T, self.scores, self.best[t0:], self.counts, self.score_sum)
 
     def epoch_reduce(self, world):
-        if _dist_on():
-            import torch.distributed as dist
-            dist.all_reduce(self.counts)
-            dist.all_reduce(self.score_sum)
+        self.red.all_reduce()   # ONE collective (no-op without a process group)
 
     def roofline(self):
         # dominant kernel: the output-layer GEMM (2048 -> 10000), 48 % of the chain's flops
@@ -241,8 +247,11 @@ class Pipeline(NnPipeline):
 
     GCHUNK = int(os.environ.get("AMX_BENCH_GCHUNK", "65536"))  # frames per GMM pass (>= a step: one pass; scores + best densities = 5.1 GB)
 
+    def reduce_fields(self):
+        return [("acc", self.gmm.accumulator_size(), "f64"), ("score_sum", 1, "f64"), ("gscore_sum", 1, "f64"),
+                ("counts", self.M, "count"), ("gcounts", self.M, "count")]
+
     def __init__(self, ctx, args, rank):
-        super().__init__(ctx, args, rank)
         import torch
 
         import rasr_amd
@@ -250,13 +259,14 @@ class Pipeline(NnPipeline):
         model = synth.gmm_cart(10000, 16, 16, 40, seed=5, pooled=True)
         self.nk = int(model["mix_offsets"][-1])
         self.gmm = rasr_amd.GmmFeatureScorer(ctx, model)
+        super().__init__(ctx, args, rank)
         g = min(self.GCHUNK, self.F)
         self.gscores = torch.empty((g, self.M), dtype=torch.float32, device="cuda")
         self.gbestd = torch.empty((g, self.M), dtype=torch.int32, device="cuda")
         self.gstate = torch.empty((g,), dtype=torch.int32, device="cuda")
-        self.gcounts = torch.zeros((self.M,), dtype=torch.int64, device="cuda")
-        self.gscore_sum = torch.zeros((1,), dtype=torch.float64, device="cuda")
-        self.acc = torch.zeros((self.gmm.accumulator_size(),), dtype=torch.float64, device="cuda")
+        self.gcounts = self.red.view("gcounts")
+        self.gscore_sum = self.red.view("gscore_sum")
+        self.acc = self.red.view("acc")   # the 53.8 MB of f64 GMM statistics accumulate in place in the reduce buffer
         self.main = torch.cuda.current_stream()
         self.side = torch.cuda.Stream()
         self.ev_feat, self.ev_side = torch.cuda.Event(), torch.cuda.Event()
@@ -290,13 +300,6 @@ class Pipeline(NnPipeline):
         self.ctx.use_torch_stream()          # back on the main stream: NN leg
         self.nn_leg()
         self.main.wait_event(self.ev_side)   # the next step's MFCC overwrites ceps
-
-    def epoch_reduce(self, world):
-        if _dist_on():
-            import torch.distributed as dist
-            dist.all_reduce(self.acc)        # 53.8 MB of f64 GMM statistics
-            for t in (self.counts, self.score_sum, self.gcounts, self.gscore_sum):
-                dist.all_reduce(t)
 
     def roofline(self):
         nn = super().roofline()
@@ -345,9 +348,9 @@ class GmmTrain:
         self.scores = torch.empty((g, self.M), dtype=torch.float32, device="cuda")
         self.bestd = torch.empty((g, self.M), dtype=torch.int32, device="cuda")
         self.state = torch.empty((g,), dtype=torch.int32, device="cuda")
-        self.counts = torch.zeros((self.M,), dtype=torch.int64, device="cuda")
-        self.score_sum = torch.zeros((1,), dtype=torch.float64, device="cuda")
-        self.acc = torch.zeros((self.sc.accumulator_size(),), dtype=torch.float64, device="cuda")
+        from rasr_amd.partition import EpochReduceBuffer
+        self.red = EpochReduceBuffer([("acc", self.sc.accumulator_size(), "f64"), ("score_sum", 1, "f64"), ("counts", self.M, "count")], device="cuda")
+        self.counts, self.score_sum, self.acc = self.red.view("counts"), self.red.view("score_sum"), self.red.view("acc")
         self.units = self.F
         self.baum_welch = getattr(args, "estimation_mode", "viterbi") == "baum-welch"
 
@@ -364,11 +367,7 @@ class GmmTrain:
                 self.sc.accumulate_dev(x, T, self.state, self.bestd, self.M, self.acc)
 
     def epoch_reduce(self, world):
-        if _dist_on():
-            import torch.distributed as dist
-            dist.all_reduce(self.acc)          # 8*(sum K + n_mean*(1+d) + n_cov*(1+d)) bytes = 53.8 MB here
-            dist.all_reduce(self.counts)
-            dist.all_reduce(self.score_sum)
+        self.red.all_reduce()   # ONE collective: 8 * (sum K + n_mean * (1 + d) + n_cov * (1 + d)) bytes = 53.8 MB here (+ counts, score sum)
 
     def roofline(self):
         return gmm_cart_roofline(self.ctx, self.sc, self.nk, self.M, 40, min(self.CHUNK, self.F))

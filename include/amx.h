@@ -306,6 +306,12 @@ typedef struct {
     const float*        log_prior;  /* nullable [out_last]  (Nn::Prior) */
     float               prior_scale;/* priori-scale alpha */
     int                 precision;  /* AMX_PREC_* */
+    /* Nn::ClassLabelWrapper (Nn/ClassLabelWrapper.cc:21-70, used by Nn/BatchFeatureScorer.cc:148-171 and Nn/FeatureScorer.cc):
+     * emission (class) e reads network output class_to_output[e]; -1 = disregarded class (`disregard-classes`), which scores
+     * Core::Type<f32>::max.  NULL = identity (n_classes is then ignored).  The mapping must be one-to-one and cover every
+     * output ("no one-to-one correspondence between network outputs and classes!"); scores are [T x n_classes]. */
+    int                 n_classes;
+    const int*          class_to_output;
 } amx_ffnn_model;
 
 int  amx_ffnn_create(amx_ctx* ctx, const amx_ffnn_model* model, amx_ffnn** out);
@@ -320,6 +326,32 @@ int amx_ffnn_score_dev(amx_ffnn* h, const float* feats_dev, int feats_stride, in
  * never re-read.  best_state_dev nullable [T]. */
 int amx_ffnn_score_stats_dev(amx_ffnn* h, const float* feats_dev, int feats_stride, int T, float* scores_dev,
                              uint32_t* best_state_dev, unsigned long long* state_counts_dev, double* score_sum_dev);
+
+/* Nn::OnDemandFeatureScorer (Nn/FeatureScorer.cc:37-135): the hidden layers run once per frame
+ * (forwardHiddenLayers), the output layer is evaluated only for the emissions the decoder asks for
+ * (LinearAndSoftmaxLayer::getScore, Nn/LinearAndActivationLayer.cc:154-160: -bias[e] - W[e] . activation).
+ * act_dev [T x amx_ffnn_hidden_dim] f32; pairs (frame_dev[p], emission_dev[p]) -> scores_dev[p]. */
+int amx_ffnn_hidden_dim(const amx_ffnn* h);
+int amx_ffnn_forward_hidden_dev(amx_ffnn* h, const float* feats_dev, int feats_stride, int T, float* act_dev);
+int amx_ffnn_score_on_demand_dev(amx_ffnn* h, const float* act_dev, int n_pairs, const uint32_t* frame_dev, const uint32_t* emission_dev,
+                                 float* scores_dev);
+/* Nn::PrecomputedFeatureScorer (Nn/FeatureScorer.cc:291-310): the features are network outputs computed elsewhere;
+ * score(e) = -x[out(e)] + alpha * logPrior[out(e)], Core::Type<f32>::max for a disregarded class.
+ * class_to_output_dev nullable (identity); log_prior_dev indexed by network output. */
+int amx_precomputed_score_dev(amx_ctx* ctx, const float* feats_dev, int feats_stride, int T, int n_classes, const int* class_to_output_dev,
+                              const float* log_prior_dev, float prior_scale, float* scores_dev);
+
+/* Nn::ClassLabelWrapper::initMapping (Nn/ClassLabelWrapper.cc:56-70): classes listed in `disregard` map to -1, the others to
+ * consecutive network outputs.  mapping [n_classes]; *n_targets = classes to accumulate. */
+int amx_class_labels_init(int n_classes, const int* disregard, int n_disregard, int* mapping, int* n_targets);
+/* Math::Vector<T> files as Math::Module's format set reads and writes them (Math/Module.cc:25-41, Core/VectorParser.hh,
+ * Math/Vector.hh:286-290,357-367): XML `<vector-f32 size="n"> v ... </vector-f32>` by default, `bin:<path>` = u32 n + raw
+ * elements (f32 only; the reference registers no binary format for s32).  Nn::Prior::read / write (Nn/Prior.cc:211-245) use the
+ * f32 form, ClassLabelWrapper::load / save (Nn/ClassLabelWrapper.cc:72-96) the s32 form.  *data is malloc'ed (amx_free). */
+int amx_nn_vector_read_f32(const char* path, int* n, float** data);
+int amx_nn_vector_write_f32(const char* path, int n, const float* data);
+int amx_nn_vector_read_s32(const char* path, int* n, int** data);
+int amx_nn_vector_write_s32(const char* path, int n, const int* data);
 
 /* ------------------------------------------------------------------ feature caches */
 

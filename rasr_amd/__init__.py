@@ -301,7 +301,8 @@ class GmmFeatureScorer:
 class NnBatchFeatureScorer:
     """Nn::BatchFeatureScorer: Ws[l] is [out, in] (RASR weights_[0] is the same memory, [in x out] col-major)."""
 
-    def __init__(self, ctx, Ws, biases, activations, log_prior=None, priori_scale=1.0, precision="bf16"):
+    def __init__(self, ctx, Ws, biases, activations, log_prior=None, priori_scale=1.0, precision="bf16", class_to_output=None):
+        """class_to_output: Nn::ClassLabelWrapper mapping [n_classes] (emission -> network output, -1 = disregarded class)"""
         self.ctx, self.L = ctx, ctx.L
         n = len(Ws)
         self._Ws = [np.ascontiguousarray(w, dtype=np.float32) for w in Ws]
@@ -310,15 +311,18 @@ class NnBatchFeatureScorer:
         self._outd = np.array([w.shape[0] for w in self._Ws], np.int32)
         self._act = np.array(activations, np.int32)
         self._lp = None if log_prior is None else np.ascontiguousarray(log_prior, dtype=np.float32)
+        self._map = None if class_to_output is None else np.ascontiguousarray(class_to_output, dtype=np.int32)
         Wp = (C.c_void_p * n)(*[w.ctypes.data for w in self._Ws])
         Bp = (C.c_void_p * n)(*[b.ctypes.data for b in self._bs])
         st = _lib.FfnnModel(n, self._ind.ctypes.data, self._outd.ctypes.data, C.cast(Wp, C.c_void_p), C.cast(Bp, C.c_void_p),
                             self._act.ctypes.data, _ptr(self._lp), priori_scale,
-                            {"fp32": AMX_PREC_FP32, "bf16": AMX_PREC_BF16, "bf16x3": _lib.AMX_PREC_BF16X3}[precision])
+                            {"fp32": AMX_PREC_FP32, "bf16": AMX_PREC_BF16, "bf16x3": _lib.AMX_PREC_BF16X3}[precision],
+                            0 if self._map is None else len(self._map), _ptr(self._map))
         h = C.c_void_p()
         _lib.check(self.L.amx_ffnn_create(ctx.h, C.byref(st), C.byref(h)))
         self.h = h
-        self.in_dim, self.out_dim = int(self._ind[0]), int(self._outd[-1])
+        self.in_dim, self.out_dim = int(self._ind[0]), int(self.L.amx_ffnn_output_dim(h))
+        self.hidden_dim = int(self.L.amx_ffnn_hidden_dim(h))
 
     def __del__(self):
         try:
@@ -338,6 +342,14 @@ class NnBatchFeatureScorer:
         _lib.check(self.L.amx_ffnn_score(self.h, feats.ctypes.data, T, out.ctypes.data))
         return out
 
+    def forward_hidden_dev(self, feats_dev, feats_stride, T, act_dev):
+        """Nn::OnDemandFeatureScorer::forwardHiddenLayers for T frames: act_dev [T, hidden_dim] f32"""
+        _lib.check(self.L.amx_ffnn_forward_hidden_dev(self.h, _ptr(feats_dev), feats_stride, T, _ptr(act_dev)))
+
+    def score_on_demand_dev(self, act_dev, n_pairs, frame_dev, emission_dev, scores_dev):
+        """output layer for (frame, emission) pairs only: scores_dev [n_pairs]"""
+        _lib.check(self.L.amx_ffnn_score_on_demand_dev(self.h, _ptr(act_dev), n_pairs, _ptr(frame_dev), _ptr(emission_dev), _ptr(scores_dev)))
+
     def score_dev(self, feats_dev, feats_stride, T, scores_dev):
         _lib.check(self.L.amx_ffnn_score_dev(self.h, _ptr(feats_dev), feats_stride, T, _ptr(scores_dev)))
 
@@ -345,6 +357,51 @@ class NnBatchFeatureScorer:
         """scores plus best state / per-state counts / sum of best scores (arg-min fused into the output layer)"""
         _lib.check(self.L.amx_ffnn_score_stats_dev(self.h, _ptr(feats_dev), feats_stride, T, _ptr(scores_dev), _ptr(best_state),
                                                    _ptr(counts), _ptr(score_sum)))
+
+
+def class_labels_init(n_classes, disregard=()):
+    """Nn::ClassLabelWrapper::initMapping: (mapping int32[n_classes], number of classes to accumulate)"""
+    dis = np.ascontiguousarray(list(disregard), dtype=np.int32)
+    mapping = np.zeros(n_classes, np.int32)
+    nt = C.c_int(0)
+    _lib.check(_lib.lib().amx_class_labels_init(n_classes, _ptr(dis) if len(dis) else None, len(dis), mapping.ctypes.data, C.byref(nt)))
+    return mapping, int(nt.value)
+
+
+def _read_vector(fn, path, ctype, dtype):
+    n, p = C.c_int(0), C.c_void_p()
+    L = _lib.lib()
+    _lib.check(getattr(L, fn)(os.fsencode(path), C.byref(n), C.byref(p)))
+    try:
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(ctype)), shape=(max(n.value, 1),))[:n.value].astype(dtype).copy()
+    finally:
+        L.amx_free(p)
+
+
+def read_prior(path):
+    """Nn::Prior::read: Math::Vector<f32> file (xml, or bin:<path>) -> log-prior float32[n]"""
+    return _read_vector("amx_nn_vector_read_f32", path, C.c_float, np.float32)
+
+
+def write_prior(path, log_prior):
+    v = np.ascontiguousarray(log_prior, dtype=np.float32)
+    _lib.check(_lib.lib().amx_nn_vector_write_f32(os.fsencode(path), len(v), v.ctypes.data))
+
+
+def read_class_labels(path):
+    """Nn::ClassLabelWrapper::load: Math::Vector<s32> xml file -> mapping int32[n_classes]"""
+    return _read_vector("amx_nn_vector_read_s32", path, C.c_int, np.int32)
+
+
+def write_class_labels(path, mapping):
+    v = np.ascontiguousarray(mapping, dtype=np.int32)
+    _lib.check(_lib.lib().amx_nn_vector_write_s32(os.fsencode(path), len(v), v.ctypes.data))
+
+
+def precomputed_score_dev(ctx, feats_dev, feats_stride, T, n_classes, class_to_output_dev, log_prior_dev, prior_scale, scores_dev):
+    """Nn::PrecomputedFeatureScorer: -x[out(e)] + alpha * logPrior[out(e)]"""
+    _lib.check(ctx.L.amx_precomputed_score_dev(ctx.h, _ptr(feats_dev), feats_stride, T, n_classes, _ptr(class_to_output_dev),
+                                               _ptr(log_prior_dev), prior_scale, _ptr(scores_dev)))
 
 
 def _mixture_set_to_dict(h):

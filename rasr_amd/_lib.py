@@ -55,7 +55,7 @@ class GmmEstimateCfg(C.Structure):
 class FfnnModel(C.Structure):
     _fields_ = [("n_layers", C.c_int), ("in_dim", C.c_void_p), ("out_dim", C.c_void_p), ("W", C.c_void_p),
                 ("bias", C.c_void_p), ("activation", C.c_void_p), ("log_prior", C.c_void_p),
-                ("prior_scale", C.c_float), ("precision", C.c_int)]
+                ("prior_scale", C.c_float), ("precision", C.c_int), ("n_classes", C.c_int), ("class_to_output", C.c_void_p)]
 
 
 # name -> (restype, argtypes); this table is also what tests/test_abi.py checks against amx.h
@@ -117,6 +117,15 @@ SIGNATURES = {
     "amx_ffnn_score": (C.c_int, [_P, _P, C.c_int, _P]),
     "amx_ffnn_score_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
     "amx_ffnn_score_stats_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P, _P]),
+    "amx_ffnn_hidden_dim": (C.c_int, [_P]),
+    "amx_ffnn_forward_hidden_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
+    "amx_ffnn_score_on_demand_dev": (C.c_int, [_P, _P, C.c_int, _P, _P, _P]),
+    "amx_precomputed_score_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_float, _P]),
+    "amx_class_labels_init": (C.c_int, [C.c_int, _P, C.c_int, _P, C.POINTER(C.c_int)]),
+    "amx_nn_vector_read_f32": (C.c_int, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(_P)]),
+    "amx_nn_vector_write_f32": (C.c_int, [C.c_char_p, C.c_int, _P]),
+    "amx_nn_vector_read_s32": (C.c_int, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(_P)]),
+    "amx_nn_vector_write_s32": (C.c_int, [C.c_char_p, C.c_int, _P]),
     "amx_nn_matrix_read": (C.c_int, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(_P)]),
     "amx_nn_matrix_write": (C.c_int, [C.c_char_p, C.c_int, C.c_int, _P]),
     "amx_free": (None, [_P]),

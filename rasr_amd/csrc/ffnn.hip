@@ -131,6 +131,80 @@ __global__ __launch_bounds__(256) void split_act_bf16x3(const float* __restrict_
     }
 }
 
+// last hidden activation -> f32 [T x H] (Nn::OnDemandFeatureScorer::forwardHiddenLayers keeps it per frame).
+// MODE 0: f32 rows, 1: bf16 rows, 2: split bf16 rows [hi | hi | lo] (value = hi + lo)
+template<int MODE>
+__global__ __launch_bounds__(256) void export_hidden_kernel(const void* __restrict__ src, int ld, int seg, int T, int H, float* __restrict__ out) {
+    const long long n = (long long)T * H;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int t = (int)(i / H), k = (int)(i - (long long)t * H);
+        float     v;
+        if (MODE == 0)
+            v = ((const float*)src)[(size_t)t * ld + k];
+        else if (MODE == 1)
+            v = __uint_as_float((unsigned)((const bf16_t*)src)[(size_t)t * ld + k] << 16);
+        else {
+            const bf16_t* r = (const bf16_t*)src + (size_t)t * ld;
+            v               = __uint_as_float((unsigned)r[k] << 16) + __uint_as_float((unsigned)r[2 * seg + k] << 16);
+        }
+        out[i] = v;
+    }
+}
+
+// Nn::LinearAndSoftmaxLayer::getScore (Nn/LinearAndActivationLayer.cc:154-160) for a list of (frame, emission) pairs:
+// score = -bias[e] - W[e] . act[frame]  (bias has -alpha * log prior folded in; a disregarded class has a zero row and bias
+// -FLT_MAX).  One wavefront per pair, lane-strided f32 partial sums + butterfly (the reference's sdot order is unspecified).
+__global__ __launch_bounds__(256) void on_demand_kernel(const float* __restrict__ act, int H, const float* __restrict__ W, const float* __restrict__ bias,
+                                                       const uint32_t* __restrict__ frame, const uint32_t* __restrict__ emission, int n_pairs,
+                                                       float* __restrict__ scores) {
+    const int lane = threadIdx.x & 63;
+    const int p    = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= n_pairs)
+        return;
+    const float* a = act + (size_t)frame[p] * H;
+    const float* w = W + (size_t)emission[p] * H;
+    float        s = 0.f;
+    if ((H & 3) == 0) {
+        for (int k = lane * 4; k < H; k += 256) {
+            const float4 x = *(const float4*)(a + k), y = *(const float4*)(w + k);
+            s              = fmaf(x.x, y.x, s);
+            s              = fmaf(x.y, y.y, s);
+            s              = fmaf(x.z, y.z, s);
+            s              = fmaf(x.w, y.w, s);
+        }
+    }
+    else
+        for (int k = lane; k < H; k += 64)
+            s = fmaf(a[k], w[k], s);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        s += __shfl_xor(s, off, 64);
+    if (lane == 0) {
+        float r = -bias[emission[p]];
+        r       = r - s;
+        scores[p] = r;
+    }
+}
+
+// Nn::PrecomputedFeatureScorer::calculateScore (Nn/FeatureScorer.cc:291-310): the features ARE the network outputs:
+// score(e) = -x[out(e)] + alpha * logPrior[out(e)], Core::Type<f32>::max for a disregarded class.  HBM bound: one read, one write.
+__global__ __launch_bounds__(256) void precomputed_score_kernel(const float* __restrict__ x, int ldx, int T, int n_classes,
+                                                               const int* __restrict__ class_to_output, const float* __restrict__ log_prior,
+                                                               float prior_scale, float* __restrict__ scores) {
+    const long long n = (long long)T * n_classes;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int t = (int)(i / n_classes), e = (int)(i - (long long)t * n_classes);
+        const int o = class_to_output ? class_to_output[e] : e;
+        float     sc = 3.402823466e+38f;
+        if (o >= 0) {
+            sc           = -x[(size_t)t * ldx + o];
+            const float pr = prior_scale * log_prior[o];
+            sc           = sc + pr;
+        }
+        scores[i] = sc;
+    }
+}
+
 __global__ __launch_bounds__(256) void pack_input_f32(const float* __restrict__ x, int ldx, int T, int K, float* __restrict__ out,
                                                      int Kpad, int Tpad) {
     const long long n = (long long)Tpad * Kpad;
@@ -1037,6 +1111,8 @@ struct amx_ffnn {
     int    cap_T = 0;
     void*  d_in  = nullptr;      // packed input [cap_T x Kpad0]
     void*  d_act[2] = {nullptr, nullptr};
+    std::vector<float> h_Wout, h_bout;  // output layer [n_emissions x K] f32 and its folded bias (on-demand scorer; uploaded on first use)
+    float *d_Wout = nullptr, *d_bout = nullptr;
     float* d_z      = nullptr;   // bf16x3 mode: f32 pre-activations of the current hidden layer [cap_T x max_hidden_pad]
     std::vector<int> seg;        // bf16x3 mode: segment width of layer l's operands (Kpad of layer 0, Npad of the layer below otherwise)
     int    max_hidden_pad = 0;
@@ -1254,6 +1330,51 @@ int amx_ffnn_create(amx_ctx* ctx, const amx_ffnn_model* m, amx_ffnn** out) {
     // Nn::BatchFeatureScorer: "output layer must be of type 'linear+softmax'" with the softmax switched off
     AMX_REQUIRE(m->activation[m->n_layers - 1] == AMX_ACT_NONE, AMX_ERR_INVALID, "amx_ffnn_create: output layer must be linear (softmax is not evaluated)");
 
+    // ---- Nn::ClassLabelWrapper (Nn/ClassLabelWrapper.cc:56-75, Nn/BatchFeatureScorer.cc:148-171): emission e reads network output
+    // class_to_output[e]; a disregarded class (-1) scores Core::Type<f32>::max.  The mapping is one-to-one (the reference refuses
+    // anything else), so it is applied ONCE, to the output layer: row e of the emission-ordered layer is row class_to_output[e]
+    // of the network's (with its bias and prior), a disregarded class gets a zero row and bias -FLT_MAX -- score = -(0 + bias) =
+    // FLT_MAX exactly, in every precision mode.  Scores, arg-min statistics and the on-demand scorer then index emissions.
+    const int          L0 = m->n_layers - 1;
+    std::vector<int>   out_dim(m->out_dim, m->out_dim + m->n_layers);
+    std::vector<const float*> Wl(m->W, m->W + m->n_layers), bl(m->bias, m->bias + m->n_layers);
+    const float*       prior = m->log_prior;
+    std::vector<float> Wmap, bmap, pmap;
+    if (m->class_to_output) {
+        AMX_REQUIRE(m->n_classes > 0, AMX_ERR_INVALID, "amx_ffnn_create: class_to_output without n_classes");
+        const int N = m->out_dim[L0], K = m->in_dim[L0];
+        std::vector<char> used((size_t)N, 0);
+        int               n_targets = 0;
+        for (int e = 0; e < m->n_classes; ++e) {
+            const int o = m->class_to_output[e];
+            AMX_REQUIRE(o >= -1 && o < N, AMX_ERR_INVALID, "amx_ffnn_create: class %d maps to output %d (network has %d outputs)", e, o, N);
+            if (o >= 0) {
+                // ClassLabelWrapper::isOneToOneMapping: "no one-to-one correspondence between network outputs and classes!"
+                AMX_REQUIRE(!used[o], AMX_ERR_INVALID, "amx_ffnn_create: no one-to-one correspondence between network outputs and classes (output %d)", o);
+                used[o] = 1;
+                ++n_targets;
+            }
+        }
+        // require_eq(network_.getTopLayer().getOutputDimension(), labelWrapper_->nClassesToAccumulate())
+        AMX_REQUIRE(n_targets == N, AMX_ERR_INVALID, "amx_ffnn_create: %d classes to accumulate, but the output layer has %d units", n_targets, N);
+        Wmap.assign((size_t)m->n_classes * K, 0.f);
+        bmap.assign((size_t)m->n_classes, -3.402823466e+38f);
+        pmap.assign((size_t)m->n_classes, 0.f);
+        for (int e = 0; e < m->n_classes; ++e) {
+            const int o = m->class_to_output[e];
+            if (o < 0)
+                continue;
+            memcpy(&Wmap[(size_t)e * K], m->W[L0] + (size_t)o * K, (size_t)K * 4);
+            bmap[e] = m->bias[L0] ? m->bias[L0][o] : 0.f;
+            pmap[e] = m->log_prior ? m->log_prior[o] : 0.f;
+        }
+        out_dim[L0] = m->n_classes;
+        Wl[L0]      = Wmap.data();
+        bl[L0]      = bmap.data();
+        if (m->log_prior)
+            prior = pmap.data();
+    }
+
     amx_ffnn* h  = new amx_ffnn;
     h->ctx       = ctx;
     h->n_layers  = m->n_layers;
@@ -1271,14 +1392,14 @@ int amx_ffnn_create(amx_ctx* ctx, const amx_ffnn_model* m, amx_ffnn** out) {
     long      best_flops = -1;
     for (int l = 0; l < m->n_layers; ++l) {
         h->in.push_back(m->in_dim[l]);
-        h->out.push_back(m->out_dim[l]);
+        h->out.push_back(out_dim[l]);
         h->act.push_back(m->activation[l]);
         // hidden activations are stored with a row stride of Npad(l-1) >= Kpad(l)
         h->Kpad.push_back(pad_to(m->in_dim[l], kmult));
-        h->Npad.push_back(pad_to(m->out_dim[l], amx::PAD_NT));
+        h->Npad.push_back(pad_to(out_dim[l], amx::PAD_NT));
         if (l + 1 < m->n_layers)
             h->max_hidden_pad = std::max(h->max_hidden_pad, h->Npad[l]);
-        long fl = (long)m->in_dim[l] * m->out_dim[l];
+        long fl = (long)m->in_dim[l] * out_dim[l];
         if (fl > best_flops) {
             best_flops       = fl;
             h->largest_layer = l;
@@ -1286,7 +1407,7 @@ int amx_ffnn_create(amx_ctx* ctx, const amx_ffnn_model* m, amx_ffnn** out) {
     }
     for (int l = 0; l < m->n_layers; ++l) {
         const int    K = h->in[l], N = h->out[l], Kp = h->Kpad[l], Np = h->Npad[l];
-        const float* W = m->W[l];
+        const float* W = Wl[l];
         void*        d = nullptr;
         if (m->precision == AMX_PREC_BF16X3) {
             // rows [W_hi | W_lo | W_hi], segments as wide as the rows of the activation buffer that feeds the layer.  Hidden layers
@@ -1342,13 +1463,17 @@ int amx_ffnn_create(amx_ctx* ctx, const amx_ffnn_model* m, amx_ffnn** out) {
         h->d_W.push_back(d);
         std::vector<float> b((size_t)Np, 0.f);
         for (int n = 0; n < N; ++n) {
-            float v = m->bias[l] ? m->bias[l][n] : 0.f;
+            float v = bl[l] ? bl[l][n] : 0.f;
             // removeLogPriorFromBias (Nn/LinearAndActivationLayer.hh:137-160): bias -= scale * prior
-            if (l == m->n_layers - 1 && m->log_prior && m->prior_scale != 0.f) {
-                float prod = m->prior_scale * m->log_prior[n];
+            if (l == m->n_layers - 1 && prior && m->prior_scale != 0.f) {
+                float prod = m->prior_scale * prior[n];
                 v          = v - prod;
             }
             b[n] = (m->precision == AMX_PREC_BF16X3 && l + 1 < m->n_layers) ? -v : v;
+        }
+        if (l == m->n_layers - 1) {
+            h->h_Wout.assign(W, W + (size_t)N * K);
+            h->h_bout.assign(b.begin(), b.begin() + N);
         }
         float* db = nullptr;
         if (hipMalloc((void**)&db, b.size() * 4) != hipSuccess || hipMemcpy(db, b.data(), b.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
@@ -1375,6 +1500,8 @@ void amx_ffnn_destroy(amx_ffnn* h) {
     hipFree(h->d_act[0]);
     hipFree(h->d_act[1]);
     hipFree(h->d_z);
+    hipFree(h->d_Wout);
+    hipFree(h->d_bout);
     hipFree(h->d_part_min);
     hipFree(h->d_part_idx);
     hipFree(h->d_host_f);
@@ -1456,8 +1583,17 @@ static int ffnn_score_impl(amx_ffnn* h, const float* feats_dev, int feats_stride
     return AMX_OK;
 }
 
+// hidden_out != nullptr: run the hidden layers only and export the last hidden activation as f32 [T x hidden_dim]
+static int ffnn_launches(amx_ffnn* h, const float* feats_dev, int feats_stride, int T, float* scores_dev, bool stats,
+                         uint32_t* best_state_dev, unsigned long long* counts_dev, double* score_sum_dev, float* hidden_out);
+
 static int ffnn_score_launches(amx_ffnn* h, const float* feats_dev, int feats_stride, int T, float* scores_dev, bool stats,
                                uint32_t* best_state_dev, unsigned long long* counts_dev, double* score_sum_dev) {
+    return ffnn_launches(h, feats_dev, feats_stride, T, scores_dev, stats, best_state_dev, counts_dev, score_sum_dev, nullptr);
+}
+
+static int ffnn_launches(amx_ffnn* h, const float* feats_dev, int feats_stride, int T, float* scores_dev, bool stats,
+                         uint32_t* best_state_dev, unsigned long long* counts_dev, double* score_sum_dev, float* hidden_out) {
     static const int chunk = getenv("AMX_FFNN_CHUNK") ? atoi(getenv("AMX_FFNN_CHUNK")) : 32768;  // frames per pass (workspace: 2 x chunk x max_hidden x 2 B)
     const int L     = h->n_layers;
     for (int t0 = 0; t0 < T; t0 += chunk) {
@@ -1507,7 +1643,19 @@ static int ffnn_score_launches(amx_ffnn* h, const float* feats_dev, int feats_st
             h->cur_part_idx = h->d_part_idx;
         }
         for (int l = 0; l < L; ++l) {
-            if (l == L - 1) {
+            if (l == L - 1 && hidden_out) {
+                const int H = h->in[l];  // = out[l - 1], or the input dimension of a network without hidden layers
+                float*    dst = hidden_out + (size_t)t0 * H;
+                const int blocks = (int)std::min<long long>(8192, ((long long)Tc * H + 255) / 256);
+                if (x3)
+                    hipLaunchKernelGGL(amx::export_hidden_kernel<2>, dim3(blocks), dim3(256), 0, h->ctx->stream, cur, ldx, ldx / 3, Tc, H, dst);
+                else if (h->precision == AMX_PREC_BF16)
+                    hipLaunchKernelGGL(amx::export_hidden_kernel<1>, dim3(blocks), dim3(256), 0, h->ctx->stream, cur, ldx, 0, Tc, H, dst);
+                else
+                    hipLaunchKernelGGL(amx::export_hidden_kernel<0>, dim3(blocks), dim3(256), 0, h->ctx->stream, cur, ldx, 0, Tc, H, dst);
+                AMX_HIP(hipGetLastError());
+            }
+            else if (l == L - 1) {
                 float* sc = scores_dev + (size_t)t0 * h->out[l];
                 r         = launch_layer<true>(h, l, cur, ldx, sc, h->out[l], Tc, Tpad);
                 if (r == AMX_OK && fused) {
@@ -1561,6 +1709,59 @@ static int ffnn_score_launches(amx_ffnn* h, const float* feats_dev, int feats_st
     }
     h->cur_part_min = nullptr;
     h->cur_part_idx = nullptr;
+    return AMX_OK;
+}
+
+int amx_ffnn_hidden_dim(const amx_ffnn* h) {
+    return h ? h->in.back() : 0;
+}
+
+int amx_ffnn_forward_hidden_dev(amx_ffnn* h, const float* feats_dev, int feats_stride, int T, float* act_dev) {
+    AMX_REQUIRE(h, AMX_ERR_INVALID, "amx_ffnn_forward_hidden_dev: NULL handle");
+    AMX_REQUIRE(T >= 0, AMX_ERR_INVALID, "amx_ffnn_forward_hidden_dev: negative frame count");
+    if (T == 0)
+        return AMX_OK;
+    AMX_REQUIRE(feats_dev && act_dev, AMX_ERR_INVALID, "amx_ffnn_forward_hidden_dev: NULL buffer");
+    AMX_REQUIRE(feats_stride >= h->in[0], AMX_ERR_INVALID, "amx_ffnn_forward_hidden_dev: feature stride %d < input dimension %d", feats_stride,
+                h->in[0]);
+    AMX_HIP(hipSetDevice(h->ctx->device));
+    return ffnn_launches(h, feats_dev, feats_stride, T, nullptr, false, nullptr, nullptr, nullptr, act_dev);
+}
+
+int amx_ffnn_score_on_demand_dev(amx_ffnn* h, const float* act_dev, int n_pairs, const uint32_t* frame_dev, const uint32_t* emission_dev,
+                                 float* scores_dev) {
+    AMX_REQUIRE(h, AMX_ERR_INVALID, "amx_ffnn_score_on_demand_dev: NULL handle");
+    AMX_REQUIRE(n_pairs >= 0, AMX_ERR_INVALID, "amx_ffnn_score_on_demand_dev: negative pair count");
+    if (n_pairs == 0)
+        return AMX_OK;
+    AMX_REQUIRE(act_dev && frame_dev && emission_dev && scores_dev, AMX_ERR_INVALID, "amx_ffnn_score_on_demand_dev: NULL buffer");
+    AMX_HIP(hipSetDevice(h->ctx->device));
+    if (!h->d_Wout) {  // OnDemandFeatureScorer::init pops the output layer and keeps its parameters apart: upload them on first use
+        AMX_HIP(hipMalloc((void**)&h->d_Wout, h->h_Wout.size() * 4));
+        AMX_HIP(hipMalloc((void**)&h->d_bout, h->h_bout.size() * 4));
+        AMX_HIP(hipMemcpy(h->d_Wout, h->h_Wout.data(), h->h_Wout.size() * 4, hipMemcpyHostToDevice));
+        AMX_HIP(hipMemcpy(h->d_bout, h->h_bout.data(), h->h_bout.size() * 4, hipMemcpyHostToDevice));
+    }
+    amx::ScopedKernelTimer timer(h->ctx, "ffnn_on_demand");
+    hipLaunchKernelGGL(amx::on_demand_kernel, dim3((n_pairs + 3) / 4), dim3(256), 0, h->ctx->stream, act_dev, h->in.back(), h->d_Wout, h->d_bout,
+                       frame_dev, emission_dev, n_pairs, scores_dev);
+    AMX_HIP(hipGetLastError());
+    return AMX_OK;
+}
+
+int amx_precomputed_score_dev(amx_ctx* ctx, const float* feats_dev, int feats_stride, int T, int n_classes, const int* class_to_output_dev,
+                              const float* log_prior_dev, float prior_scale, float* scores_dev) {
+    AMX_REQUIRE(ctx, AMX_ERR_INVALID, "amx_precomputed_score_dev: NULL context");
+    AMX_REQUIRE(T >= 0 && n_classes > 0, AMX_ERR_INVALID, "amx_precomputed_score_dev: bad shape");
+    if (T == 0)
+        return AMX_OK;
+    AMX_REQUIRE(feats_dev && log_prior_dev && scores_dev, AMX_ERR_INVALID, "amx_precomputed_score_dev: NULL buffer");
+    AMX_HIP(hipSetDevice(ctx->device));
+    amx::ScopedKernelTimer timer(ctx, "precomputed_score");
+    const int              blocks = (int)std::min<long long>(16384, ((long long)T * n_classes + 255) / 256);
+    hipLaunchKernelGGL(amx::precomputed_score_kernel, dim3(blocks), dim3(256), 0, ctx->stream, feats_dev, feats_stride, T, n_classes,
+                       class_to_output_dev, log_prior_dev, prior_scale, scores_dev);
+    AMX_HIP(hipGetLastError());
     return AMX_OK;
 }
 

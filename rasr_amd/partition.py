@@ -21,20 +21,58 @@ def select_partition(n_segments, partition, select):
     return np.arange(select, n_segments, partition)
 
 
-class EpochAccumulators:
+class EpochReduceBuffer:
+    """Everything a rank contributes to the per-epoch sum, in ONE flat f64 buffer, so that the exchange is literally one
+    all-reduce (one RCCL ring over xGMI per epoch; replaces `combine-mixture-set-estimators`,
+    Tools/AcousticModelTrainer/AcousticModelTrainer.cc:317-325).
+
+    fields: list of (name, n, kind); kind "f64" = a statistics block the kernels accumulate into IN PLACE (view(name) is a
+    slice of the flat buffer: the 53.8 MB of GMM statistics are never copied), kind "count" = an int64 / u64 counter tensor
+    the kernels update with integer atomics; counters travel as f64 in the tail of the buffer (exact below 2^53 -- a 100 h
+    corpus has 3.6e7 frames) and are written back as integers after the reduce.
+    """
+
+    def __init__(self, fields, device="cpu"):
+        import torch
+        self.fields = list(fields)
+        self.offsets, off = {}, 0
+        for name, n, kind in self.fields:
+            if kind not in ("f64", "count"):
+                raise ValueError("unknown field kind %r" % kind)
+            self.offsets[name] = (off, n, kind)
+            off += n
+        self.flat = torch.zeros(off, dtype=torch.float64, device=device)
+        self.counters = {name: torch.zeros(n, dtype=torch.int64, device=device) for name, n, kind in self.fields if kind == "count"}
+
+    def view(self, name):
+        """the tensor the kernels write: a slice of the flat buffer (f64 fields) or the integer counter tensor"""
+        off, n, kind = self.offsets[name]
+        return self.flat[off:off + n] if kind == "f64" else self.counters[name]
+
+    def nbytes(self):
+        return int(self.flat.numel() * 8)
+
+    def all_reduce(self, group=None):
+        """sum over all ranks with ONE collective; no-op without an initialised process group"""
+        import torch
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            return self
+        for name, c in self.counters.items():
+            off, n, _ = self.offsets[name]
+            self.flat[off:off + n] = c.to(torch.float64)
+        dist.all_reduce(self.flat, group=group)
+        for name, c in self.counters.items():
+            off, n, _ = self.offsets[name]
+            c.copy_(self.flat[off:off + n].round().to(torch.int64))
+        return self
+
+
+class EpochAccumulators(EpochReduceBuffer):
     """state_counts u64[M] (kept as int64 tensors), score_sum f64[1], n_frames i64[1] on `device`."""
 
     def __init__(self, n_states, device="cpu"):
-        import torch
-        self.counts = torch.zeros(n_states, dtype=torch.int64, device=device)
-        self.score_sum = torch.zeros(1, dtype=torch.float64, device=device)
-        self.n_frames = torch.zeros(1, dtype=torch.int64, device=device)
-
-    def all_reduce(self, group=None):
-        """sum over all ranks; no-op without an initialised process group"""
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-            dist.all_reduce(self.counts, group=group)
-            dist.all_reduce(self.score_sum, group=group)
-            dist.all_reduce(self.n_frames, group=group)
-        return self
+        super().__init__([("score_sum", 1, "f64"), ("counts", n_states, "count"), ("n_frames", 1, "count")], device)
+        self.counts = self.view("counts")
+        self.score_sum = self.view("score_sum")
+        self.n_frames = self.view("n_frames")

@@ -137,3 +137,87 @@ def test_two_rank_training_epoch_equals_single_process():
         assert np.array_equal(a[k], b[k])
     assert np.allclose(a["means"], b["means"], rtol=1e-6, atol=1e-7) and np.allclose(a["variances"], b["variances"], rtol=1e-5)
     assert np.allclose(a["log_weight"], b["log_weight"], rtol=1e-10, atol=1e-12)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def test_epoch_reduce_is_one_collective(monkeypatch):
+    """EpochReduceBuffer: statistics blocks are views of the flat buffer (no copy), counters travel in its tail, and the
+    exchange is exactly ONE all_reduce call (single-rank gloo group; the call count is what DESIGN.md section 8 promises)"""
+    import torch
+    import torch.distributed as dist
+
+    from rasr_amd.partition import EpochReduceBuffer
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        red = EpochReduceBuffer([("acc", 1000, "f64"), ("score_sum", 1, "f64"), ("counts", 50, "count"), ("gcounts", 50, "count")])
+        acc = red.view("acc")
+        assert acc.data_ptr() == red.flat.data_ptr() and red.nbytes() == 8 * (1000 + 1 + 50 + 50)
+        acc += torch.arange(1000, dtype=torch.float64)
+        red.view("score_sum").fill_(-3.5)
+        red.view("counts")[7] = 2 ** 40 + 3
+        red.view("gcounts")[49] = 11
+        calls = []
+        real = dist.all_reduce
+        monkeypatch.setattr(dist, "all_reduce", lambda t, *a, **k: (calls.append(t.numel()), real(t, *a, **k))[1])
+        red.all_reduce()
+        assert calls == [1101]
+        assert int(red.view("counts")[7]) == 2 ** 40 + 3 and int(red.view("gcounts")[49]) == 11 and int(red.view("counts").sum()) == 2 ** 40 + 3
+        assert float(red.view("score_sum")[0]) == -3.5 and float(acc[999]) == 999.0
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_rccl_all_reduce_of_device_accumulators(ctx):
+    """the RCCL path itself (backend "nccl", world size 1 on the one-GPU box): real device accumulators -- GMM Viterbi
+    statistics, per-state counts and score sums produced by the HIP kernels -- go through ONE all-reduce and come back unchanged"""
+    import torch
+    import torch.distributed as dist
+
+    import rasr_amd
+    from rasr_amd.partition import EpochReduceBuffer
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        model = synth.gmm_cart(200, 1, 16, 40, seed=61, pooled=True)
+        sc = rasr_amd.GmmFeatureScorer(ctx, model)
+        T, M = 3000, 200
+        x = np.random.Generator(np.random.PCG64(62)).standard_normal((T, 40)).astype(np.float32)
+        red = EpochReduceBuffer([("acc", sc.accumulator_size(), "f64"), ("score_sum", 1, "f64"), ("counts", M, "count")], device="cuda")
+        xd = torch.from_numpy(x).cuda()
+        scores = torch.empty((T, M), dtype=torch.float32, device="cuda")
+        bestd = torch.empty((T, M), dtype=torch.int32, device="cuda")
+        state = torch.empty((T,), dtype=torch.int32, device="cuda")
+        ctx.use_torch_stream()
+        sc.score_stats_dev(xd, T, scores, bestd, state, red.view("counts"), red.view("score_sum"))
+        sc.accumulate_dev(xd, T, state, bestd, M, red.view("acc"))
+        torch.cuda.synchronize()
+        before = (red.view("acc").cpu().numpy().copy(), red.view("counts").cpu().numpy().copy(), float(red.view("score_sum").item()))
+        assert before[1].sum() == T and before[0][:sc.accumulator_size()].sum() != 0
+        calls = []
+        real = dist.all_reduce
+
+        def counted(t, *a, **k):
+            calls.append((t.numel(), t.is_cuda))
+            return real(t, *a, **k)
+        dist.all_reduce = counted
+        try:
+            red.all_reduce()
+        finally:
+            dist.all_reduce = real
+        torch.cuda.synchronize()
+        assert calls == [(sc.accumulator_size() + 1 + M, True)]
+        assert np.array_equal(red.view("acc").cpu().numpy(), before[0]) and np.array_equal(red.view("counts").cpu().numpy(), before[1])
+        assert float(red.view("score_sum").item()) == before[2]
+    finally:
+        dist.destroy_process_group()
