@@ -353,6 +353,19 @@ int amx_nn_vector_write_f32(const char* path, int n, const float* data);
 int amx_nn_vector_read_s32(const char* path, int* n, int** data);
 int amx_nn_vector_write_s32(const char* path, int n, const int* data);
 
+/* ------------------------------------------------------------------ device buffers for resident score blocks
+ * A decoder asks for ONE score at a time (Mm::FeatureScorer::ContextScorer::score, Mm/FeatureScorer.hh:31-46) and usually for a few
+ * hundred of the 10^4 emissions of a frame; copying every [bufferSize x nEmissions] block to the host (40 kB per frame) would bound
+ * the scorer at the PCIe rate.  These calls let a C / C++ adapter keep the block in HBM (*_score_dev) and move only what is asked
+ * for: whole rows (amx_copy_to_host of one row) or (row, emission) pairs (amx_gather_scores: device gather + one small copy).
+ * amx_copy_to_device returns when the source buffer may be reused; amx_copy_to_host / amx_gather_scores synchronise the stream. */
+int  amx_device_malloc(amx_ctx* ctx, size_t bytes, void** dev);
+void amx_device_free(amx_ctx* ctx, void* dev);
+int  amx_copy_to_device(amx_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int  amx_copy_to_host(amx_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+int  amx_gather_scores(amx_ctx* ctx, const float* scores_dev, int ld, int n, const uint32_t* rows_host, const uint32_t* cols_host,
+                       float* dst_host);
+
 /* ------------------------------------------------------------------ feature caches */
 
 /* Core::FileArchive, the single-file "SP_ARC1" container RASR keeps feature caches, alignments and lattices in

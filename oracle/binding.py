@@ -152,6 +152,10 @@ def load_ref():
                                        C.POINTER(C.c_long), C.c_char_p, C.c_int]
     R.ref_attribs_xml.restype = C.c_long
     R.ref_attribs_xml.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_char_p, C.c_long]
+    if hasattr(R, "ref_matrix_vector"):
+        R.ref_matrix_vector.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        R.ref_complex_amplitude.restype = C.c_int
+        R.ref_complex_amplitude.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     _ref = R
     return R
 

@@ -10,6 +10,11 @@
 //   Math::{ScalingFunction,MelWarpingCore,AnalyticNesting}  header-only, composed exactly like
 //       Math::AnalyticFunctionFactory::createMelWarpingFunction (AnalyticFunctionFactory.cc:338-341)
 //   Mm::gaussLogNormFactor, Mm::inverseSquareRoot           src/Mm/Utilities.hh:53-91
+//   Math::Matrix<f32> * Math::Vector<f32>   src/Math/Matrix.hh:485-494, src/Math/Vector.hh:94-101 -- what
+//       Signal::CosineTransform::apply runs (f32 products accumulated left to right)
+//   Math::transformAlternatingComplex with Math::pointerAbs<f32>   src/Math/Complex.hh:39-46,104-113 (+ Core::abs,
+//       Core/Utility.hh:126-129) -- the whole body of Signal::alternatingComplexVectorAmplitude<f32>::operator()
+//       (Signal/ComplexVectorFunction.hh:30-47; that header itself pulls in Signal/Node.hh -> Core/Configuration.hh -> boost)
 //   Flow::Vector<f32>::{read,write}, Flow::Datatype::{read,write}GatheredData, Core::Binary{In,Out}putStream,
 //       Core::XmlWriter          src/Flow/Vector.hh:88-106, src/Flow/Datatype.cc:28-52 (feature-cache payload)
 // No reference header, library or tool is replaced by a stand-in; translation units that need
@@ -19,6 +24,9 @@
 #include <Math/LevinsonLse.hh>
 #include <Math/SimpleAnalyticFunctions.hh>
 #include <Mm/Utilities.hh>
+#include <Math/Matrix.hh>
+#include <Math/Vector.hh>
+#include <Math/Complex.hh>
 #include <Signal/WindowBuffer.hh>
 #include <Core/BinaryStream.hh>
 #include <Core/XmlStream.hh>
@@ -75,6 +83,29 @@ double ref_warped_bin_inverse(double warped, double inputSampleRate) {
 double ref_warped_bin_derivative(double bin, double inputSampleRate) {
     Math::UnaryAnalyticFunctionRef d2c(new Math::ScalingFunction(1 / inputSampleRate));
     return Math::nest(melWarp()->derive(), d2c)->value(bin);
+}
+
+// out = M v with the reference's own matrix and vector classes (row-major M [rows x cols])
+void ref_matrix_vector(const float* M, int rows, int cols, const float* v, float* out) {
+    Math::Matrix<f32> m(rows, cols);
+    for (int r = 0; r < rows; ++r)
+        for (int c = 0; c < cols; ++c)
+            m[r][c] = M[(size_t)r * cols + c];
+    Math::Vector<f32> x(cols);
+    for (int c = 0; c < cols; ++c)
+        x[c] = v[c];
+    const Math::Vector<f32> y = m * x;
+    for (int r = 0; r < rows; ++r)
+        out[r] = y[r];
+}
+
+// |re + i im| of an alternating complex vector (the signal-vector-alternating-complex-f32-amplitude node's functor)
+int ref_complex_amplitude(const float* x, int n_floats, float* out) {
+    std::vector<f32> in(x, x + n_floats), res(n_floats / 2);
+    Math::transformAlternatingComplex(in.begin(), in.end(), res.begin(), Math::pointerAbs<f32>());
+    for (size_t i = 0; i < res.size(); ++i)
+        out[i] = res[i];
+    return (int)res.size();
 }
 
 double ref_gauss_log_norm_factor(const float* var, int n) {

@@ -143,6 +143,11 @@ SIGNATURES = {
     "amx_feature_cache_read": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(_P), C.POINTER(_P)]),
     "amx_feature_cache_write_attributes": (C.c_int, [_P, C.c_char_p, C.c_int, _P, _P, C.c_int]),
     "amx_feature_cache_read_attributes": (C.c_int, [_P, C.c_char_p, C.POINTER(_P)]),
+    "amx_device_malloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
+    "amx_device_free": (None, [_P, _P]),
+    "amx_copy_to_device": (C.c_int, [_P, _P, _P, C.c_size_t]),
+    "amx_copy_to_host": (C.c_int, [_P, _P, _P, C.c_size_t]),
+    "amx_gather_scores": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P]),
     "amx_stats_accumulate_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P]),
 }
 

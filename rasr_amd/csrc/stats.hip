@@ -64,6 +64,74 @@ __global__ __launch_bounds__(256) void argmin_accumulate_kernel(const float* __r
 
 }  // namespace amx
 
+namespace amx {
+// scores[rows[i]][cols[i]] -> out[i]: the decoder's active (frame, emission) pairs of a device-resident score block
+__global__ __launch_bounds__(256) void gather_scores_kernel(const float* __restrict__ scores, int ld, int n, const uint32_t* __restrict__ rows,
+                                                           const uint32_t* __restrict__ cols, float* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n)
+        out[i] = scores[(size_t)rows[i] * ld + cols[i]];
+}
+}  // namespace amx
+
+// ---- device-buffer plumbing for C / C++ clients that keep score blocks resident (rasr_amd/host/BatchFeatureScorer.hh): the
+// reference's scorers hand the decoder ONE score at a time (Mm::FeatureScorer::ContextScorer::score, Mm/FeatureScorer.hh:31-46), so
+// the [bufferSize x nEmissions] block stays in HBM and only the rows / pairs the decoder asks for cross PCIe.
+extern "C" int amx_device_malloc(amx_ctx* ctx, size_t bytes, void** dev) {
+    AMX_REQUIRE(ctx && dev, AMX_ERR_INVALID, "amx_device_malloc: NULL argument");
+    *dev = nullptr;
+    AMX_HIP(hipSetDevice(ctx->device));
+    AMX_HIP(hipMalloc(dev, bytes ? bytes : 1));
+    return AMX_OK;
+}
+
+extern "C" void amx_device_free(amx_ctx* ctx, void* dev) {
+    if (!ctx || !dev)
+        return;
+    hipSetDevice(ctx->device);
+    hipFree(dev);
+}
+
+extern "C" int amx_copy_to_device(amx_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes) {
+    AMX_REQUIRE(ctx && (bytes == 0 || (dst_dev && src_host)), AMX_ERR_INVALID, "amx_copy_to_device: NULL argument");
+    AMX_HIP(hipSetDevice(ctx->device));
+    if (bytes)
+        AMX_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));  // pageable source: returns once staged
+    return AMX_OK;
+}
+
+extern "C" int amx_copy_to_host(amx_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes) {
+    AMX_REQUIRE(ctx && (bytes == 0 || (dst_host && src_dev)), AMX_ERR_INVALID, "amx_copy_to_host: NULL argument");
+    AMX_HIP(hipSetDevice(ctx->device));
+    if (bytes)
+        AMX_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    AMX_HIP(hipStreamSynchronize(ctx->stream));
+    return AMX_OK;
+}
+
+extern "C" int amx_gather_scores(amx_ctx* ctx, const float* scores_dev, int ld, int n, const uint32_t* rows_host, const uint32_t* cols_host,
+                                 float* dst_host) {
+    AMX_REQUIRE(ctx, AMX_ERR_INVALID, "amx_gather_scores: NULL context");
+    AMX_REQUIRE(n >= 0 && ld > 0, AMX_ERR_INVALID, "amx_gather_scores: bad shape");
+    if (n == 0)
+        return AMX_OK;
+    AMX_REQUIRE(scores_dev && rows_host && cols_host && dst_host, AMX_ERR_INVALID, "amx_gather_scores: NULL buffer");
+    AMX_HIP(hipSetDevice(ctx->device));
+    int r = ctx->ensure_scratch((size_t)n * 12);
+    if (r != AMX_OK)
+        return r;
+    uint32_t* d_rows = (uint32_t*)ctx->scratch;
+    uint32_t* d_cols = d_rows + n;
+    float*    d_out  = (float*)(d_cols + n);
+    AMX_HIP(hipMemcpyAsync(d_rows, rows_host, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    AMX_HIP(hipMemcpyAsync(d_cols, cols_host, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(amx::gather_scores_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, scores_dev, ld, n, d_rows, d_cols, d_out);
+    AMX_HIP(hipGetLastError());
+    AMX_HIP(hipMemcpyAsync(dst_host, d_out, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    AMX_HIP(hipStreamSynchronize(ctx->stream));
+    return AMX_OK;
+}
+
 extern "C" int amx_stats_accumulate_dev(amx_ctx* ctx, const float* scores_dev, int T, int n_emissions, uint32_t* best_state_dev,
                                         unsigned long long* state_counts_dev, double* score_sum_dev) {
     AMX_REQUIRE(ctx, AMX_ERR_INVALID, "amx_stats_accumulate_dev: NULL context");

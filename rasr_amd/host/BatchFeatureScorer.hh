@@ -7,8 +7,11 @@
 //   Nn::BatchFeatureScorer ring buffer             src/Nn/BatchFeatureScorer.cc:92-171, BatchFeatureScorer.hh:156-171
 //   Mm::FeatureScorer::ContextScorer               src/Mm/FeatureScorer.hh:31-46
 // Differences: the batch is evaluated on the GPU for ALL emissions the first time any score of an
-// up-to-date buffer is requested (the reference does the same with network_.forward(buffer_)); scores are kept in
-// a host matrix [bufferSize x nEmissions] so score(e) is a plain read, thread-safe once computed.
+// up-to-date buffer is requested (the reference does the same with network_.forward(buffer_)), and the
+// [bufferSize x nEmissions] score block STAYS IN HBM: a frame's row (40 kB at 10^4 emissions) crosses PCIe only when the
+// decoder first asks for one of its scores, after which score(e) is a plain read of the host row cache (thread-safe once
+// fetched).  ContextScorer::scores(list) is an extension for decoders that know their active set: one device gather
+// and one small copy for the listed emissions only.  bytesToHost() counts what actually crossed.
 #ifndef RASR_AMD_HOST_BATCH_FEATURE_SCORER_HH
 #define RASR_AMD_HOST_BATCH_FEATURE_SCORER_HH
 
@@ -54,16 +57,60 @@ public:
     virtual unsigned dimension() const  = 0;
     /** feats [T x dim] row-major -> scores [T x nEmissions]; returns amx_status */
     virtual int score(const float* feats, int T, float* scores) = 0;
+    /** the same into a device-resident block owned by the backend (nothing comes back to the host) */
+    virtual int scoreResident(const float* feats, int T) = 0;
+    /** one row of the resident block -> host [nEmissions] */
+    virtual int fetchRow(int row, float* dst) = 0;
+    /** scores of (row, emission) pairs of the resident block -> host [n] */
+    virtual int fetchPairs(int n, const unsigned* rows, const unsigned* emissions, float* dst) = 0;
+};
+
+/** device buffers of a backend's resident block: features in, scores out, grown on demand */
+class ResidentBlock {
+    amx_ctx* ctx_;
+    float *  d_feats_, *d_scores_;
+    size_t   capFeats_, capScores_;
+
+public:
+    explicit ResidentBlock(amx_ctx* ctx)
+            : ctx_(ctx), d_feats_(nullptr), d_scores_(nullptr), capFeats_(0), capScores_(0) {}
+    ~ResidentBlock() {
+        amx_device_free(ctx_, d_feats_);
+        amx_device_free(ctx_, d_scores_);
+    }
+    amx_ctx* ctx() const { return ctx_; }
+    float*   feats() const { return d_feats_; }
+    float*   scores() const { return d_scores_; }
+    int      reserve(size_t nFeats, size_t nScores) {
+        if (nFeats > capFeats_) {
+            amx_device_free(ctx_, d_feats_);
+            d_feats_  = nullptr;
+            capFeats_ = 0;
+            if (amx_device_malloc(ctx_, nFeats * sizeof(float), (void**)&d_feats_) != AMX_OK)
+                return AMX_ERR_DEVICE;
+            capFeats_ = nFeats;
+        }
+        if (nScores > capScores_) {
+            amx_device_free(ctx_, d_scores_);
+            d_scores_  = nullptr;
+            capScores_ = 0;
+            if (amx_device_malloc(ctx_, nScores * sizeof(float), (void**)&d_scores_) != AMX_OK)
+                return AMX_ERR_DEVICE;
+            capScores_ = nScores;
+        }
+        return AMX_OK;
+    }
 };
 
 class GmmBackend : public BatchBackend {
-    amx_gmm* h_;
-    int      mode_;
+    amx_gmm*      h_;
+    int           mode_;
+    ResidentBlock block_;
 
 public:
     /** featureScorerType: "diagonal-maximum" (registered in Mm/Module.cc:83-105) or "diagonal-sum" */
     GmmBackend(amx_ctx* ctx, const amx_gmm_model& model, const std::string& featureScorerType = "diagonal-maximum")
-            : h_(nullptr), mode_(featureScorerType == "diagonal-sum" ? AMX_GMM_SUM : AMX_GMM_MAX) {
+            : h_(nullptr), mode_(featureScorerType == "diagonal-sum" ? AMX_GMM_SUM : AMX_GMM_MAX), block_(ctx) {
         if (amx_gmm_create(ctx, &model, &h_) != AMX_OK)
             throw std::runtime_error(amx_last_error());
     }
@@ -71,14 +118,27 @@ public:
     unsigned nEmissions() const { return (unsigned)amx_gmm_n_mixtures(h_); }
     unsigned dimension() const { return (unsigned)amx_gmm_dimension(h_); }
     int      score(const float* f, int T, float* s) { return amx_gmm_score(h_, mode_, f, T, s, nullptr); }
+    int      scoreResident(const float* f, int T) {
+        int r = block_.reserve((size_t)T * dimension(), (size_t)T * nEmissions());
+        if (r == AMX_OK)
+            r = amx_copy_to_device(block_.ctx(), block_.feats(), f, (size_t)T * dimension() * sizeof(float));
+        return r == AMX_OK ? amx_gmm_score_dev(h_, mode_, block_.feats(), T, block_.scores(), nullptr) : r;
+    }
+    int fetchRow(int row, float* dst) {
+        return amx_copy_to_host(block_.ctx(), dst, block_.scores() + (size_t)row * nEmissions(), (size_t)nEmissions() * sizeof(float));
+    }
+    int fetchPairs(int n, const unsigned* rows, const unsigned* emissions, float* dst) {
+        return amx_gather_scores(block_.ctx(), block_.scores(), (int)nEmissions(), n, rows, emissions, dst);
+    }
 };
 
 class FfnnBackend : public BatchBackend {
-    amx_ffnn* h_;
+    amx_ffnn*     h_;
+    ResidentBlock block_;
 
 public:
     FfnnBackend(amx_ctx* ctx, const amx_ffnn_model& model)
-            : h_(nullptr) {
+            : h_(nullptr), block_(ctx) {
         if (amx_ffnn_create(ctx, &model, &h_) != AMX_OK)
             throw std::runtime_error(amx_last_error());
     }
@@ -86,6 +146,18 @@ public:
     unsigned nEmissions() const { return (unsigned)amx_ffnn_output_dim(h_); }
     unsigned dimension() const { return (unsigned)amx_ffnn_input_dim(h_); }
     int      score(const float* f, int T, float* s) { return amx_ffnn_score(h_, f, T, s); }
+    int      scoreResident(const float* f, int T) {
+        int r = block_.reserve((size_t)T * dimension(), (size_t)T * nEmissions());
+        if (r == AMX_OK)
+            r = amx_copy_to_device(block_.ctx(), block_.feats(), f, (size_t)T * dimension() * sizeof(float));
+        return r == AMX_OK ? amx_ffnn_score_dev(h_, block_.feats(), (int)dimension(), T, block_.scores()) : r;
+    }
+    int fetchRow(int row, float* dst) {
+        return amx_copy_to_host(block_.ctx(), dst, block_.scores() + (size_t)row * nEmissions(), (size_t)nEmissions() * sizeof(float));
+    }
+    int fetchPairs(int n, const unsigned* rows, const unsigned* emissions, float* dst) {
+        return amx_gather_scores(block_.ctx(), block_.scores(), (int)nEmissions(), n, rows, emissions, dst);
+    }
 };
 
 class BatchFeatureScorer;
@@ -100,6 +172,8 @@ public:
             : parent_(parent), position_(position) {}
     inline EmissionIndex nEmissions() const;
     inline Score         score(EmissionIndex e) const;
+    /** extension: the scores of a list of emissions of this frame in one device gather (no row copy) */
+    inline void scores(const EmissionIndex* emissions, unsigned n, Score* out) const;
 };
 typedef std::shared_ptr<const ContextScorer> Scorer;  // Core::Ref<const ContextScorer>
 
@@ -113,9 +187,25 @@ class BatchFeatureScorer {
     unsigned                      bufferSize_;
     mutable unsigned              nBufferedFeatures_, currentFeature_;
     mutable std::vector<bool>     scoreComputed_;
+    mutable std::vector<bool>     rowFetched_;  // row of the resident block copied into the host row cache
     mutable std::vector<float>    buffer_;  // [bufferSize x dim] row-major (frame major)
-    mutable std::vector<float>    scores_;  // [bufferSize x nEmissions]
+    mutable std::vector<float>    scores_;  // host row cache [bufferSize x nEmissions]
+    mutable size_t                bytesToHost_;
     unsigned                      dim_, nEmissions_;
+
+    [[noreturn]] static void fail(const char* what) {
+        // the reference would criticalError() and exit; the message is amx_last_error()
+        std::fprintf(stderr, "amx %s failed: %s\n", what, amx_last_error());
+        std::abort();
+    }
+
+    /** whole buffer in one batch, exactly like network_.forward(buffer_); the block stays on the device */
+    void computeScores() const {
+        if (backend_->scoreResident(buffer_.data(), (int)bufferSize_) != AMX_OK)
+            fail("batch scoring");
+        scoreComputed_.assign(bufferSize_, true);
+        rowFetched_.assign(bufferSize_, false);
+    }
 
     void setFeature(unsigned position, const FeatureVector& f) const {
         amxhost_require(position < bufferSize_);
@@ -133,6 +223,8 @@ public:
               nBufferedFeatures_(0),
               currentFeature_(0),
               scoreComputed_(bufferSize, false),
+              rowFetched_(bufferSize, false),
+              bytesToHost_(0),
               dim_(backend_->dimension()),
               nEmissions_(backend_->nEmissions()) {
         amxhost_require(bufferSize_ >= 1);
@@ -147,9 +239,12 @@ public:
     unsigned bufferSize() const { return bufferSize_; }
     bool     bufferFilled() const { return nBufferedFeatures_ + 1 >= bufferSize_; }  // >= bufferSize_ - 1
     bool     bufferEmpty() const { return nBufferedFeatures_ == 0; }
+    /** bytes of scores copied device -> host so far (diagnostics) */
+    size_t   bytesToHost() const { return bytesToHost_; }
 
     void reset() const {
         scoreComputed_.assign(bufferSize_, false);
+        rowFetched_.assign(bufferSize_, false);
         nBufferedFeatures_ = 0;
         currentFeature_    = 0;
     }
@@ -158,6 +253,7 @@ public:
         amxhost_require(!bufferFilled());
         setFeature(nBufferedFeatures_, f);
         scoreComputed_[nBufferedFeatures_] = false;
+        rowFetched_[nBufferedFeatures_]    = false;
         nBufferedFeatures_++;
     }
 
@@ -167,6 +263,7 @@ public:
         unsigned position = currentFeature_ ? (currentFeature_ - 1) % bufferSize_ : bufferSize_ - 1;
         setFeature(position, f);
         scoreComputed_[position] = false;
+        rowFetched_[position]    = false;
         Scorer scorer(new ContextScorer(this, currentFeature_));
         currentFeature_ = (currentFeature_ + 1) % bufferSize_;
         return scorer;
@@ -187,16 +284,34 @@ public:
     Score getScore(EmissionIndex e, unsigned position) const {
         amxhost_require(position < bufferSize_);
         amxhost_require(e < nEmissions_);
-        if (!scoreComputed_[position]) {
-            // whole buffer in one batch, exactly like network_.forward(buffer_)
-            if (backend_->score(buffer_.data(), (int)bufferSize_, scores_.data()) != AMX_OK) {
-                // the reference would criticalError() and exit; the message is amx_last_error()
-                std::fprintf(stderr, "amx batch scoring failed: %s\n", amx_last_error());
-                std::abort();
-            }
-            scoreComputed_.assign(bufferSize_, true);
+        if (!scoreComputed_[position])
+            computeScores();
+        if (!rowFetched_[position]) {  // first score of this frame: its row (and only its row) crosses PCIe
+            if (backend_->fetchRow((int)position, &scores_[(size_t)position * nEmissions_]) != AMX_OK)
+                fail("score row copy");
+            rowFetched_[position] = true;
+            bytesToHost_ += (size_t)nEmissions_ * sizeof(float);
         }
         return scores_[(size_t)position * nEmissions_ + e];
+    }
+
+    void getScores(const EmissionIndex* emissions, unsigned n, unsigned position, Score* out) const {
+        amxhost_require(position < bufferSize_);
+        if (!scoreComputed_[position])
+            computeScores();
+        if (rowFetched_[position]) {
+            for (unsigned i = 0; i < n; ++i) {
+                amxhost_require(emissions[i] < nEmissions_);
+                out[i] = scores_[(size_t)position * nEmissions_ + emissions[i]];
+            }
+            return;
+        }
+        std::vector<unsigned> rows(n, position);
+        for (unsigned i = 0; i < n; ++i)
+            amxhost_require(emissions[i] < nEmissions_);
+        if (backend_->fetchPairs((int)n, rows.data(), emissions, out) != AMX_OK)
+            fail("score gather");
+        bytesToHost_ += (size_t)n * sizeof(float);
     }
 };
 
@@ -205,6 +320,9 @@ inline EmissionIndex ContextScorer::nEmissions() const {
 }
 inline Score ContextScorer::score(EmissionIndex e) const {
     return parent_->getScore(e, position_);
+}
+inline void ContextScorer::scores(const EmissionIndex* emissions, unsigned n, Score* out) const {
+    parent_->getScores(emissions, n, position_, out);
 }
 
 }  // namespace AmxHost

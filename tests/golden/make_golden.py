@@ -4,7 +4,8 @@
 
 * ref_*.npz / ref_*.json are OUTPUTS OF THE REFERENCE ITSELF: oracle/_ref/libref.so is built by
   oracle/ref/Makefile from unmodified reference translation units (Math::FastFourierTransform,
-  Signal::WindowBuffer, the mel warping functors, Mm::gaussLogNormFactor / inverseSquareRoot).
+  Signal::WindowBuffer, the mel warping functors, Mm::gaussLogNormFactor / inverseSquareRoot,
+  Math::Matrix<f32> * Math::Vector<f32>, Math::transformAlternatingComplex / pointerAbs).
 * survey_c1.json holds the known answers the reference produced in this container during the survey
   (SURVEY.md Appendix C.1).
 * nn_kat.json is transcribed from the reference's unit tests (see its "source" field).
@@ -76,6 +77,26 @@ def main():
     norm = dict(var=[float(v) for v in var], log_norm=float(R.ref_gauss_log_norm_factor(var, 40)).hex(),
                 isr=[float(R.ref_inverse_square_root(float(v))) for v in var])
     json.dump(dict(mel=mel, bins=bins, norm=norm), open(os.path.join(HERE, "ref_functions.json"), "w"), indent=0)
+    # ---- reference Math::Matrix<f32> * Math::Vector<f32> on the oracle's DCT tables (what Signal::CosineTransform::apply runs)
+    #      and |re + i im| of alternating complex vectors through Math::transformAlternatingComplex / pointerAbs
+    lin = {}
+    for tag, kw in (("16x20", dict(n_ceps=16)), ("40x40", dict(n_ceps=40, filter_width=138.0))):
+        m = OracleMfcc(**kw)
+        table = np.ascontiguousarray(m.dct, dtype=np.float32)
+        x = (rng.standard_normal((6, table.shape[1])) * 2 - 1).astype(np.float32)
+        x[5] = 1.0
+        y = np.zeros((6, table.shape[0]), np.float32)
+        for i in range(6):
+            R.ref_matrix_vector(table.ctypes.data, table.shape[0], table.shape[1], x[i].ctypes.data, y[i].ctypes.data)
+        lin["dct_table_" + tag], lin["dct_in_" + tag], lin["dct_out_" + tag] = table, x, y
+    spec = (rng.standard_normal(514) * np.exp(rng.uniform(-12, 3, 514))).astype(np.float32)
+    spec[10:14] = [0.0, 0.0, 3.0, -4.0]
+    spec[20:22] = [1e-30, 1e-30]          # squares underflow in f32: hypot does not
+    spec[22:24] = [3e20, 4e20]            # squares overflow in f32: hypot does not
+    amp = np.zeros(257, np.float32)
+    R.ref_complex_amplitude(spec.ctypes.data, 514, amp.ctypes.data)
+    lin["spectrum"], lin["amplitude"] = spec, amp
+    np.savez_compressed(os.path.join(HERE, "ref_linear.npz"), **lin)
     # ---- SURVEY.md C.1 known answers (reference outputs recorded by the survey)
     c1 = dict(frames_160000=999, last_frame_len=320, w0=0.08, w1=0.08005703,
               filters_268=dict(n=20, mel_max=2840.023047, out0=4.27929, out1=4.360105, out19=4.327153),

@@ -74,6 +74,30 @@ int main(int argc, char** argv) {
     }
     CHECK((int)fed.size() == T);
     CHECK(fed[0]->nEmissions() == 3);
+    // resident score block: every frame's row crossed PCIe exactly once (T rows of M scores), nothing else
+    CHECK(fs.bytesToHost() == (size_t)T * M * sizeof(float));
+    {
+        // lazy rows and the gather extension: after a refill only the rows / pairs that are asked for come back
+        BatchFeatureScorer lazy(std::unique_ptr<BatchBackend>(new GmmBackend(ctx, model)), B);
+        std::vector<Scorer> sc;
+        for (int t = 0; t < (int)B + 1; ++t) {
+            FeatureVector f(feats.begin() + t * dim, feats.begin() + (t + 1) * dim);
+            if (!lazy.bufferFilled())
+                lazy.addFeature(f);
+            else
+                sc.push_back(lazy.getScorer(f));
+        }
+        CHECK(sc.size() == 2 && lazy.bytesToHost() == 0);          // nothing scored, nothing copied yet
+        const EmissionIndex want_e[2] = {2, 0};
+        Score               got[2];
+        sc[1]->scores(want_e, 2, got);                             // frame 1: two scores through the device gather
+        CHECK(got[0] == want[1 * M + 2] && got[1] == want[1 * M + 0]);
+        CHECK(lazy.bytesToHost() == 2 * sizeof(float));
+        CHECK(sc[0]->score(1) == want[0 * M + 1]);                  // frame 0: first score() fetches its row
+        CHECK(lazy.bytesToHost() == 2 * sizeof(float) + M * sizeof(float));
+        CHECK(sc[0]->score(2) == want[0 * M + 2]);                  // ... and the next one is a host read
+        CHECK(lazy.bytesToHost() == 2 * sizeof(float) + M * sizeof(float));
+    }
     // contract violations
     bool threw = false;
     try {

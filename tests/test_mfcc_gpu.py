@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 # uses f32 fmaf butterflies with table twiddles, the reference f64-recurrence twiddles with f32 data, so
 # spectra agree to ~1e-6 relative; after log10 and the DCT that is <= 1e-4 relative plus a small absolute
 # term for coefficients that cancel to near zero.
-RTOL, ATOL = 1e-4, 2e-3
+RTOL, ATOL = 1e-4, 1e-4
 
 
 def close(a, b):

@@ -109,6 +109,54 @@ def test_live_reference_build_agrees():
     assert all(isr[0][i] == np.float32(R.ref_inverse_square_root(float(v[i]))) for i in range(39))
 
 
+def _oracle_dct_apply(table, x):
+    """the oracle's DCT stage restated: out[k] = sum_n T[k][n] x[n], f32 products accumulated left to right from 0
+    (oracle/orc_mfcc.c: orc_mfcc_frame, following Math/Vector.hh:94-101 as used by Signal/CosineTransform.cc:123-158)"""
+    out = np.zeros(table.shape[0], np.float32)
+    for k in range(table.shape[0]):
+        acc = np.float32(0)
+        for n in range(table.shape[1]):
+            acc = np.float32(acc + np.float32(table[k, n] * x[n]))
+        out[k] = acc
+    return out
+
+
+def test_dct_apply_and_amplitude_against_reference_classes():
+    """Math::Matrix<f32> * Math::Vector<f32> (the reference's own classes, compiled unmodified) on the oracle's cosine tables, and
+    Math::transformAlternatingComplex + pointerAbs on spectra with entries whose squares under- / overflow in f32:
+    golden outputs of the reference (tests/golden/ref_linear.npz) -- the oracle's DCT stage and amplitude stage are bit-identical,
+    through the oracle's own frame pipeline as well (the cepstra of a frame = reference product of its log filter-bank row)"""
+    L = Oracle()
+    g = np.load(os.path.join(GOLD, "ref_linear.npz"))
+    for tag, kw in (("16x20", dict(n_ceps=16)), ("40x40", dict(n_ceps=40, filter_width=138.0))):
+        m = OracleMfcc(**kw)
+        table = np.ascontiguousarray(m.dct, dtype=np.float32)
+        assert np.array_equal(bits(table), bits(g["dct_table_" + tag]))
+        for x, y in zip(g["dct_in_" + tag], g["dct_out_" + tag]):
+            assert np.array_equal(bits(_oracle_dct_apply(table, x)), bits(y))
+        pcm = synth.waveform(4000, seed=11)
+        st = m.stages(pcm, 5)
+        assert np.array_equal(bits(_oracle_dct_apply(table, st["logmel"])), bits(st["ceps"]))
+        assert np.array_equal(bits(np.hypot(st["spectrum"][0::2], st["spectrum"][1::2]).astype(np.float32)), bits(st["amplitude"]))
+    spec, amp = g["spectrum"], g["amplitude"]
+    got = np.array([np.float32(np.hypot(np.float32(spec[2 * k]), np.float32(spec[2 * k + 1]))) for k in range(257)], np.float32)
+    assert np.array_equal(bits(got), bits(amp))        # hypotf == std::abs(std::complex<float>) incl. the under- / overflow cases
+    R = load_ref()
+    if R is not None and hasattr(R, "ref_matrix_vector"):   # live, fresh inputs
+        rng = np.random.Generator(np.random.PCG64(123))
+        m = OracleMfcc(n_ceps=40, filter_width=138.0)
+        table = np.ascontiguousarray(m.dct, dtype=np.float32)
+        for _ in range(20):
+            x = (rng.standard_normal(table.shape[1]) * 5).astype(np.float32)
+            y = np.zeros(table.shape[0], np.float32)
+            R.ref_matrix_vector(table.ctypes.data, table.shape[0], table.shape[1], x.ctypes.data, y.ctypes.data)
+            assert np.array_equal(bits(_oracle_dct_apply(table, x)), bits(y))
+        s2 = (rng.standard_normal(514) * np.exp(rng.uniform(-20, 20, 514))).astype(np.float32)
+        a2 = np.zeros(257, np.float32)
+        R.ref_complex_amplitude(s2.ctypes.data, 514, a2.ctypes.data)
+        assert np.array_equal(bits(np.hypot(s2[0::2], s2[1::2]).astype(np.float32)), bits(a2))
+
+
 # ----------------------------------------------------------------------------- SURVEY.md C.1 known answers
 
 def _apply_filters(m, amp):

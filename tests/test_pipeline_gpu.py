@@ -16,7 +16,7 @@ def test_golden_vectors(ctx):
     pcm = z["pcm_s16"].astype(np.float32)
     for tag, kw in (("mfcc16", dict(nr_cepstrum_coefficients=16)), ("mfcc40", dict(nr_cepstrum_coefficients=40, filter_width=138.0))):
         got = rasr_amd.MfccExtractor(ctx, **kw).run(pcm)
-        assert np.all(np.abs(got - z[tag]) <= 1e-4 * np.abs(z[tag]) + 2e-3)
+        assert np.all(np.abs(got - z[tag]) <= 1e-4 * np.abs(z[tag]) + 1e-4)
     g = np.load(os.path.join(GOLD, "orc_gmm.npz"))
     model = {k[6:]: g[k] for k in g.files if k.startswith("model_")}
     model["dim"] = int(model["dim"])
