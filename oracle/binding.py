@@ -59,13 +59,43 @@ def build_oracle(force=False):
 
 
 _lib = None
+_NATIVE = None   # path of the -march=native build (bench.py's cpu_baseline only), see build_native_oracle
+
+
+def build_native_oracle():
+    """The same sources with the reference's "standard" optimisation flags for THIS host (-O3 -march=native; -ffp-contract=off
+    keeps one rounding per operation, i.e. the results of the -O2 checker library), into a temporary directory: the file is
+    host-specific and must not travel.  Used by bench.py's cpu_baseline, never by the tests."""
+    global _NATIVE
+    if _NATIVE and os.path.exists(_NATIVE):
+        return _NATIVE
+    import tempfile
+    out = os.path.join(tempfile.gettempdir(), "liboracle_native_%d.so" % os.getuid())
+    srcs = [os.path.join(_HERE, f) for f in ("orc_mfcc.c", "orc_score.c", "orc_backend.c")]
+    if not os.path.exists(out) or any(os.path.getmtime(f) > os.path.getmtime(out) for f in srcs):
+        tmp = out + ".%d.tmp" % os.getpid()
+        subprocess.check_call(["gcc", "-O3", "-march=native", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-std=gnu11", "-w",
+                               "-shared", "-o", tmp] + srcs + ["-lm"])
+        os.replace(tmp, out)
+    _NATIVE = out
+    return out
+
+
+def use_native_oracle():
+    """make Oracle() of this process load the -march=native build (call before the first Oracle())"""
+    global _lib, _LIB
+    _LIB = build_native_oracle()
+    _lib = None
 
 
 def Oracle():
     global _lib
     if _lib is not None:
         return _lib
-    build_oracle()
+    if _LIB == _NATIVE and _NATIVE is not None:
+        pass  # already built by build_native_oracle
+    else:
+        build_oracle()
     L = C.CDLL(_LIB)
     L.orc_mfcc_create.restype = C.c_void_p
     L.orc_mfcc_create.argtypes = [C.POINTER(MfccCfg)]
