@@ -150,6 +150,9 @@ int amx_context_window_dev(amx_ctx* ctx, const amx_mfcc_plan* p, const float* fe
 /* Feature back-end between the front-end and the scorers, on device-resident
  * [total_frames x ld] f32 matrices segmented like the plan.  in/out may point into wider matrices (column offset by
  * pointer arithmetic, row stride *_ld), which is how "generic-vector-f32-concat" of features and derivatives is laid out.
+ * Aliasing: the input and output views must not share memory -- disjoint column ranges of one wide matrix are fine, anything
+ * else is rejected with AMX_ERR_INVALID; the one exception is whole-segment normalisation (length = 0) in place on the
+ * identical view.
  *
  * signal-normalization (src/Signal/Normalization.cc:46-66,120-187): per segment, type mean or mean-and-variance;
  * length = 0: whole segment (length="infinite" right="infinite"); otherwise a sliding window of `length` frames with the

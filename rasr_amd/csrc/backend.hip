@@ -139,6 +139,26 @@ __global__ __launch_bounds__(256) void matrix_multiply_kernel(const float* __res
 
 }  // namespace amx
 
+namespace {
+// Do the strided views in [T x in_w] (row stride in_ld) and out [T x out_w] (row stride out_ld) share memory?  Views into one wide
+// matrix (same stride) are disjoint when their column ranges are; anything else that overlaps in address range counts as aliasing.
+bool views_alias(const float* in, int in_ld, int in_w, const float* out, int out_ld, int out_w, long long T) {
+    if (T <= 0)
+        return false;
+    const float* in_end  = in + (T - 1) * (long long)in_ld + in_w;
+    const float* out_end = out + (T - 1) * (long long)out_ld + out_w;
+    if (in_end <= out || out_end <= in)
+        return false;
+    if (in_ld == out_ld) {
+        const long long ld = in_ld, delta = out - in;
+        const long long c  = ((delta % ld) + ld) % ld;  // column offset of `out` relative to `in`
+        if (c >= in_w && c + out_w <= ld)
+            return false;  // disjoint column ranges of the same matrix (also with a row shift)
+    }
+    return true;
+}
+}  // namespace
+
 extern "C" {
 
 int amx_normalize_dev(amx_ctx* ctx, const amx_mfcc_plan* plan, const float* in_dev, int in_ld, int dim, int type, int length, int right,
@@ -155,6 +175,11 @@ int amx_normalize_dev(amx_ctx* ctx, const amx_mfcc_plan* plan, const float* in_d
     int              r = amx_internal_plan_view(plan, &d_off, &n_seg, &total);
     if (r != AMX_OK || total == 0)
         return r;
+    // the sliding window re-reads in[t - length] after out[t - right] has been written: in place is only defined for whole
+    // segments with identical views (every frame is read before the first one is written back)
+    const bool same_view = in_dev == out_dev && in_ld == out_ld;
+    AMX_REQUIRE(!views_alias(in_dev, in_ld, dim, out_dev, out_ld, dim, total) || (same_view && length == 0), AMX_ERR_INVALID,
+                "amx_normalize_dev: input and output views overlap (in place is only supported for whole-segment normalisation)");
     AMX_HIP(hipSetDevice(ctx->device));
     amx::ScopedKernelTimer timer(ctx, "normalize");
     hipLaunchKernelGGL(amx::normalize_kernel, dim3(n_seg), dim3(64), 0, ctx->stream, in_dev, in_ld, d_off, dim, type, length, right, out_dev, out_ld);
@@ -174,6 +199,9 @@ int amx_regression_dev(amx_ctx* ctx, const amx_mfcc_plan* plan, const float* in_
     int              r = amx_internal_plan_view(plan, &d_off, &n_seg, &total);
     if (r != AMX_OK || total == 0)
         return r;
+    // one workgroup per frame reads its neighbours' rows while they write theirs
+    AMX_REQUIRE(!views_alias(in_dev, in_ld, dim, out_dev, out_ld, dim, total), AMX_ERR_INVALID,
+                "amx_regression_dev: input and output views overlap");
     AMX_HIP(hipSetDevice(ctx->device));
     amx::ScopedKernelTimer timer(ctx, "regression");
     hipLaunchKernelGGL(amx::regression_kernel, dim3((unsigned)total), dim3(64), 0, ctx->stream, in_dev, in_ld, d_off, n_seg, dim, order, right,
@@ -190,6 +218,8 @@ int amx_matrix_multiply_dev(amx_ctx* ctx, const float* matrix_dev, int rows, int
                 "amx_matrix_multiply_dev: vector/matrix dimension mismatch: vector stride %d, matrix %d columns", in_ld, cols);
     if (T == 0)
         return AMX_OK;
+    AMX_REQUIRE(!views_alias(in_dev, in_ld, cols, out_dev, out_ld, rows, T), AMX_ERR_INVALID,
+                "amx_matrix_multiply_dev: input and output views overlap");
     AMX_HIP(hipSetDevice(ctx->device));
     amx::ScopedKernelTimer timer(ctx, "matrix_multiply");
     hipLaunchKernelGGL(amx::matrix_multiply_kernel, dim3((T + 255) / 256, std::min(rows, 64)), dim3(256), 0, ctx->stream, matrix_dev, rows, cols,

@@ -27,6 +27,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <map>
 #include <string>
 #include <vector>
@@ -185,13 +186,19 @@ struct amx_archive {
             FileInfo fi;
             if (!rd_str(f, &fi.name, file_size) || !rd(f, &fi.pos) || !rd(f, &fi.size) || !rd(f, &fi.compressed))
                 return false;
+            // an entry is [u32 size][u32 compressed][u32 checksum][stored bytes][u32 tag] at pos: it must lie inside the file
+            const uint64_t stored = fi.compressed ? fi.compressed : fi.size;
+            if (fi.pos > file_size || stored > file_size || fi.pos + 12 + stored + 4 > file_size)
+                return false;
             add(fi);
         }
         if (!rd(f, &count))
             return false;
+        if ((uint64_t)count * 12 > file_size)
+            return false;
         for (uint32_t i = 0; i < count; ++i) {
             EmptyInfo e;
-            if (!rd(f, &e.pos) || !rd(f, &e.size))
+            if (!rd(f, &e.pos) || !rd(f, &e.size) || e.pos > file_size)
                 return false;
             empties.push_back(e);
         }
@@ -391,6 +398,11 @@ int read_file(amx_archive* a, const char* name, std::string* out) {
         return AMX_ERR_INVALID;
     }
     const size_t stored = fi->compressed ? fi->compressed : fi->size;
+    if (fi->pos + 12 + stored + 4 > a->end_of_archive ||
+        (fi->compressed && (uint64_t)fi->size > 1032ull * stored + 65536)) {  // entries end before the table; deflate expands at most ~1032 : 1
+        amx::set_error("archive '%s': file '%s' is truncated or corrupt", a->path.c_str(), name);
+        return AMX_ERR_INVALID;
+    }
     std::string  raw(stored, '\0');
     bool         ok = fseeko(a->f, (off_t)(fi->pos + 12), SEEK_SET) == 0 && (stored == 0 || fread(&raw[0], 1, stored, a->f) == stored);
     if (ok && fi->compressed) {
@@ -443,55 +455,67 @@ void xml_escape(std::string* o, const char* s) {
 extern "C" {
 
 int amx_archive_open(const char* path, int mode, amx_archive** out) {
-    AMX_REQUIRE(path && out && (mode == AMX_ARCHIVE_READ || mode == AMX_ARCHIVE_WRITE), AMX_ERR_INVALID, "amx_archive_open: bad argument");
-    *out = nullptr;
-    struct stat st;
-    const bool  exists = stat(path, &st) == 0 && st.st_size > 0;
-    AMX_REQUIRE(exists || mode == AMX_ARCHIVE_WRITE, AMX_ERR_INVALID, "archive file '%s' does not exist", path);
-    AMX_REQUIRE(!exists || S_ISREG(st.st_mode), AMX_ERR_UNSUPPORTED, "'%s' is not a file archive (directory and bundle archives are not supported)", path);
-    FILE* f = fopen(path, exists ? (mode == AMX_ARCHIVE_WRITE ? "r+b" : "rb") : "w+b");
-    AMX_REQUIRE(f, AMX_ERR_INVALID, "cannot open archive '%s'", path);
-    amx_archive* a = new amx_archive;
-    a->path        = path;
-    a->f           = f;
-    a->writable    = mode == AMX_ARCHIVE_WRITE;
-    if (!exists) {
-        bool ok           = fwrite(kHeader, 1, 8, f) == 8 && wr(f, (uint8_t)0);
-        a->changed        = true;
-        a->end_of_archive = 9;
-        if (!ok) {
-            fclose(f);
-            delete a;
-            amx::set_error("failed to create archive file '%s'", path);
-            return AMX_ERR_INVALID;
+    try {
+        AMX_REQUIRE(path && out && (mode == AMX_ARCHIVE_READ || mode == AMX_ARCHIVE_WRITE), AMX_ERR_INVALID, "amx_archive_open: bad argument");
+        *out = nullptr;
+        struct stat st;
+        const bool  exists = stat(path, &st) == 0 && st.st_size > 0;
+        AMX_REQUIRE(exists || mode == AMX_ARCHIVE_WRITE, AMX_ERR_INVALID, "archive file '%s' does not exist", path);
+        AMX_REQUIRE(!exists || S_ISREG(st.st_mode), AMX_ERR_UNSUPPORTED, "'%s' is not a file archive (directory and bundle archives are not supported)", path);
+        FILE* f = fopen(path, exists ? (mode == AMX_ARCHIVE_WRITE ? "r+b" : "rb") : "w+b");
+        AMX_REQUIRE(f, AMX_ERR_INVALID, "cannot open archive '%s'", path);
+        amx_archive* a = new amx_archive;
+        a->path        = path;
+        a->f           = f;
+        a->writable    = mode == AMX_ARCHIVE_WRITE;
+        if (!exists) {
+            bool ok           = fwrite(kHeader, 1, 8, f) == 8 && wr(f, (uint8_t)0);
+            a->changed        = true;
+            a->end_of_archive = 9;
+            if (!ok) {
+                fclose(f);
+                delete a;
+                amx::set_error("failed to create archive file '%s'", path);
+                return AMX_ERR_INVALID;
+            }
         }
-    }
-    else {
-        char    head[8];
-        uint8_t has_table = 0;
-        bool    ok        = fread(head, 1, 8, f) == 8 && memcmp(head, kHeader, 8) == 0 && rd(f, &has_table);
-        if (ok)
-            ok = has_table ? a->read_table((uint64_t)st.st_size) : a->scan((uint64_t)st.st_size);
-        if (!ok) {
-            fclose(f);
-            delete a;
-            amx::set_error("'%s' is not a readable SP_ARC1 file archive", path);
-            return AMX_ERR_INVALID;
+        else {
+            char    head[8];
+            uint8_t has_table = 0;
+            bool    ok        = fread(head, 1, 8, f) == 8 && memcmp(head, kHeader, 8) == 0 && rd(f, &has_table);
+            if (ok)
+                ok = has_table ? a->read_table((uint64_t)st.st_size) : a->scan((uint64_t)st.st_size);
+            if (!ok) {
+                fclose(f);
+                delete a;
+                amx::set_error("'%s' is not a readable SP_ARC1 file archive", path);
+                return AMX_ERR_INVALID;
+            }
         }
+        *out = a;
+        return AMX_OK;
     }
-    *out = a;
-    return AMX_OK;
+    catch (const std::exception& e) {  // std::bad_alloc / length_error on a corrupt size field must not cross the C boundary
+        amx::set_error("%s: %s", "amx_archive_open", e.what());
+        return AMX_ERR_INVALID;
+    }
 }
 
 int amx_archive_close(amx_archive* a) {
-    if (!a)
+    try {
+        if (!a)
+            return AMX_OK;
+        bool ok = a->write_table();
+        ok      = (fclose(a->f) == 0) && ok;
+        std::string path = a->path;
+        delete a;
+        AMX_REQUIRE(ok, AMX_ERR_INVALID, "failed to finish archive '%s'", path.c_str());
         return AMX_OK;
-    bool ok = a->write_table();
-    ok      = (fclose(a->f) == 0) && ok;
-    std::string path = a->path;
-    delete a;
-    AMX_REQUIRE(ok, AMX_ERR_INVALID, "failed to finish archive '%s'", path.c_str());
-    return AMX_OK;
+    }
+    catch (const std::exception& e) {  // std::bad_alloc / length_error on a corrupt size field must not cross the C boundary
+        amx::set_error("%s: %s", "amx_archive_close", e.what());
+        return AMX_ERR_INVALID;
+    }
 }
 
 int amx_archive_n_files(amx_archive* a) {
@@ -525,126 +549,168 @@ int amx_archive_has_file(amx_archive* a, const char* name) {
 }
 
 int amx_archive_read_file(amx_archive* a, const char* name, void** data, size_t* len) {
-    AMX_REQUIRE(a && name && data && len, AMX_ERR_INVALID, "amx_archive_read_file: NULL argument");
-    *data = nullptr;
-    *len  = 0;
-    std::string b;
-    int         rc = read_file(a, name, &b);
-    if (rc != AMX_OK)
-        return rc;
-    *data = dup_bytes(b.data(), b.size());
-    *len  = b.size();
-    return AMX_OK;
+    try {
+        AMX_REQUIRE(a && name && data && len, AMX_ERR_INVALID, "amx_archive_read_file: NULL argument");
+        *data = nullptr;
+        *len  = 0;
+        std::string b;
+        int         rc = read_file(a, name, &b);
+        if (rc != AMX_OK)
+            return rc;
+        *data = dup_bytes(b.data(), b.size());
+        *len  = b.size();
+        return AMX_OK;
+    }
+    catch (const std::exception& e) {  // std::bad_alloc / length_error on a corrupt size field must not cross the C boundary
+        amx::set_error("%s: %s", "amx_archive_read_file", e.what());
+        return AMX_ERR_INVALID;
+    }
 }
 
 int amx_archive_write_file(amx_archive* a, const char* name, const void* data, size_t len, int compress) {
-    AMX_REQUIRE(a && (data || len == 0), AMX_ERR_INVALID, "amx_archive_write_file: NULL argument");
-    return write_file(a, name, data, len, compress);
+    try {
+        AMX_REQUIRE(a && (data || len == 0), AMX_ERR_INVALID, "amx_archive_write_file: NULL argument");
+        return write_file(a, name, data, len, compress);
+    }
+    catch (const std::exception& e) {  // std::bad_alloc / length_error on a corrupt size field must not cross the C boundary
+        amx::set_error("%s: %s", "amx_archive_write_file", e.what());
+        return AMX_ERR_INVALID;
+    }
 }
 
 int amx_archive_remove_file(amx_archive* a, const char* name) {
-    AMX_REQUIRE(a && name, AMX_ERR_INVALID, "amx_archive_remove_file: NULL argument");
-    AMX_REQUIRE(a->writable, AMX_ERR_STATE, "archive '%s' is open read-only", a->path.c_str());
-    AMX_REQUIRE(a->remove(name), AMX_ERR_INVALID, "archive '%s' has no file '%s'", a->path.c_str(), name);
-    return AMX_OK;
+    try {
+        AMX_REQUIRE(a && name, AMX_ERR_INVALID, "amx_archive_remove_file: NULL argument");
+        AMX_REQUIRE(a->writable, AMX_ERR_STATE, "archive '%s' is open read-only", a->path.c_str());
+        AMX_REQUIRE(a->remove(name), AMX_ERR_INVALID, "archive '%s' has no file '%s'", a->path.c_str(), name);
+        return AMX_OK;
+    }
+    catch (const std::exception& e) {  // std::bad_alloc / length_error on a corrupt size field must not cross the C boundary
+        amx::set_error("%s: %s", "amx_archive_remove_file", e.what());
+        return AMX_ERR_INVALID;
+    }
 }
 
 int amx_feature_cache_write(amx_archive* a, const char* segment, int n, int dim, const float* feats, const double* times,
                             unsigned gather, int compress) {
-    AMX_REQUIRE(a && segment && n >= 0 && dim >= 0 && (feats || (size_t)n * dim == 0) && (times || n == 0), AMX_ERR_INVALID,
-                "amx_feature_cache_write: bad argument");
-    Out o;
-    o.b.reserve((size_t)n * (dim * 4 + 20) + 64);
-    // CacheWriter::putData flushes a block when it holds MORE than `gather` packets (Flow/Cache.cc:114-119)
-    const uint64_t per_block = (uint64_t)gather + 1;
-    for (int at = 0; at < n;) {
-        const int cnt = (int)std::min<uint64_t>(per_block, (uint64_t)(n - at));
-        o.put_str(kVectorF32);
-        o.put((uint32_t)cnt);
-        for (int i = at; i < at + cnt; ++i) {
-            o.put((uint32_t)dim);
-            o.put_raw(feats + (size_t)i * dim, (size_t)dim * 4);
-            o.put_f64(times[2 * i]);
-            o.put_f64(times[2 * i + 1]);
+    try {
+        AMX_REQUIRE(a && segment && n >= 0 && dim >= 0 && (feats || (size_t)n * dim == 0) && (times || n == 0), AMX_ERR_INVALID,
+                    "amx_feature_cache_write: bad argument");
+        Out o;
+        o.b.reserve((size_t)n * (dim * 4 + 20) + 64);
+        // CacheWriter::putData flushes a block when it holds MORE than `gather` packets (Flow/Cache.cc:114-119)
+        const uint64_t per_block = (uint64_t)gather + 1;
+        for (int at = 0; at < n;) {
+            const int cnt = (int)std::min<uint64_t>(per_block, (uint64_t)(n - at));
+            o.put_str(kVectorF32);
+            o.put((uint32_t)cnt);
+            for (int i = at; i < at + cnt; ++i) {
+                o.put((uint32_t)dim);
+                o.put_raw(feats + (size_t)i * dim, (size_t)dim * 4);
+                o.put_f64(times[2 * i]);
+                o.put_f64(times[2 * i + 1]);
+            }
+            at += cnt;
         }
-        at += cnt;
+        return write_file(a, segment, o.b.data(), o.b.size(), compress);
     }
-    return write_file(a, segment, o.b.data(), o.b.size(), compress);
+    catch (const std::exception& e) {  // std::bad_alloc / length_error on a corrupt size field must not cross the C boundary
+        amx::set_error("%s: %s", "amx_feature_cache_write", e.what());
+        return AMX_ERR_INVALID;
+    }
 }
 
 int amx_feature_cache_read(amx_archive* a, const char* segment, int* n_out, int* dim_out, float** feats, double** times) {
-    AMX_REQUIRE(a && segment && n_out && dim_out && feats, AMX_ERR_INVALID, "amx_feature_cache_read: NULL argument");
-    *feats = nullptr;
-    if (times)
-        *times = nullptr;
-    *n_out = *dim_out = 0;
-    std::string b;
-    int         rc = read_file(a, segment, &b);
-    if (rc != AMX_OK)
-        return rc;
-    In                  in{(const unsigned char*)b.data(), b.size()};
-    std::vector<float>  x;
-    std::vector<double> t;
-    long                n = 0;
-    int                 dim = -1;
-    while (in.at < in.n) {  // CacheReader::getData keeps calling readData until the entry is exhausted
-        std::string type = in.get_str();
-        AMX_REQUIRE(in.ok, AMX_ERR_INVALID, "feature cache entry '%s' is truncated", segment);
-        AMX_REQUIRE(type == kVectorF32, AMX_ERR_UNSUPPORTED, "feature cache entry '%s' holds '%s' packets; only vector-f32 is supported",
-                    segment, type.c_str());
-        uint32_t cnt = in.get<uint32_t>();
-        for (uint32_t i = 0; in.ok && i < cnt; ++i) {
-            uint32_t d = in.get<uint32_t>();
-            if (dim < 0)
-                dim = (int)d;
-            AMX_REQUIRE((int)d == dim, AMX_ERR_UNSUPPORTED, "feature cache entry '%s' mixes vector sizes %d and %u", segment, dim, d);
-            if (!in.ok || in.at + (size_t)d * 4 + 16 > in.n) {
-                in.ok = false;
-                break;
+    try {
+        AMX_REQUIRE(a && segment && n_out && dim_out && feats, AMX_ERR_INVALID, "amx_feature_cache_read: NULL argument");
+        *feats = nullptr;
+        if (times)
+            *times = nullptr;
+        *n_out = *dim_out = 0;
+        std::string b;
+        int         rc = read_file(a, segment, &b);
+        if (rc != AMX_OK)
+            return rc;
+        In                  in{(const unsigned char*)b.data(), b.size()};
+        std::vector<float>  x;
+        std::vector<double> t;
+        long                n = 0;
+        int                 dim = -1;
+        while (in.at < in.n) {  // CacheReader::getData keeps calling readData until the entry is exhausted
+            std::string type = in.get_str();
+            AMX_REQUIRE(in.ok, AMX_ERR_INVALID, "feature cache entry '%s' is truncated", segment);
+            AMX_REQUIRE(type == kVectorF32, AMX_ERR_UNSUPPORTED, "feature cache entry '%s' holds '%s' packets; only vector-f32 is supported",
+                        segment, type.c_str());
+            uint32_t cnt = in.get<uint32_t>();
+            for (uint32_t i = 0; in.ok && i < cnt; ++i) {
+                uint32_t d = in.get<uint32_t>();
+                if (dim < 0)
+                    dim = (int)d;
+                AMX_REQUIRE((int)d == dim, AMX_ERR_UNSUPPORTED, "feature cache entry '%s' mixes vector sizes %d and %u", segment, dim, d);
+                if (!in.ok || in.at + (size_t)d * 4 + 16 > in.n) {
+                    in.ok = false;
+                    break;
+                }
+                x.insert(x.end(), (const float*)(in.p + in.at), (const float*)(in.p + in.at) + d);  // LE host
+                in.at += (size_t)d * 4;
+                t.push_back(in.get_f64());
+                t.push_back(in.get_f64());
+                ++n;
             }
-            x.insert(x.end(), (const float*)(in.p + in.at), (const float*)(in.p + in.at) + d);  // LE host
-            in.at += (size_t)d * 4;
-            t.push_back(in.get_f64());
-            t.push_back(in.get_f64());
-            ++n;
+            AMX_REQUIRE(in.ok, AMX_ERR_INVALID, "feature cache entry '%s' is truncated", segment);
         }
-        AMX_REQUIRE(in.ok, AMX_ERR_INVALID, "feature cache entry '%s' is truncated", segment);
+        *n_out   = (int)n;
+        *dim_out = dim < 0 ? 0 : dim;
+        *feats   = (float*)dup_bytes(x.data(), x.size() * sizeof(float));
+        if (times)
+            *times = (double*)dup_bytes(t.data(), t.size() * sizeof(double));
+        return AMX_OK;
     }
-    *n_out   = (int)n;
-    *dim_out = dim < 0 ? 0 : dim;
-    *feats   = (float*)dup_bytes(x.data(), x.size() * sizeof(float));
-    if (times)
-        *times = (double*)dup_bytes(t.data(), t.size() * sizeof(double));
-    return AMX_OK;
+    catch (const std::exception& e) {  // std::bad_alloc / length_error on a corrupt size field must not cross the C boundary
+        amx::set_error("%s: %s", "amx_feature_cache_read", e.what());
+        return AMX_ERR_INVALID;
+    }
 }
 
 int amx_feature_cache_write_attributes(amx_archive* a, const char* segment, int n, const char* const* names,
                                        const char* const* values, int compress) {
-    AMX_REQUIRE(a && segment && n >= 0 && (n == 0 || (names && values)), AMX_ERR_INVALID, "amx_feature_cache_write_attributes: bad argument");
-    // Core::XmlWriter output of Flow::Attributes (Flow/Attributes.hh:67-70,132-138) on an unformatted stream
-    // (CacheWriter::~CacheWriter, Flow/Cache.cc:78-85): no declaration, no line breaks, the five XML escapes
-    std::string x = "<flow-attributes>";
-    for (int i = 0; i < n; ++i) {
-        x += "<flow-attribute name=\"";
-        xml_escape(&x, names[i]);
-        x += "\" value=\"";
-        xml_escape(&x, values[i]);
-        x += "\"/>";
+    try {
+        AMX_REQUIRE(a && segment && n >= 0 && (n == 0 || (names && values)), AMX_ERR_INVALID, "amx_feature_cache_write_attributes: bad argument");
+        // Core::XmlWriter output of Flow::Attributes (Flow/Attributes.hh:67-70,132-138) on an unformatted stream
+        // (CacheWriter::~CacheWriter, Flow/Cache.cc:78-85): no declaration, no line breaks, the five XML escapes
+        std::string x = "<flow-attributes>";
+        for (int i = 0; i < n; ++i) {
+            x += "<flow-attribute name=\"";
+            xml_escape(&x, names[i]);
+            x += "\" value=\"";
+            xml_escape(&x, values[i]);
+            x += "\"/>";
+        }
+        x += "</flow-attributes>";
+        std::string name = std::string(segment) + ".attribs";
+        return write_file(a, name.c_str(), x.data(), x.size(), compress);
     }
-    x += "</flow-attributes>";
-    std::string name = std::string(segment) + ".attribs";
-    return write_file(a, name.c_str(), x.data(), x.size(), compress);
+    catch (const std::exception& e) {  // std::bad_alloc / length_error on a corrupt size field must not cross the C boundary
+        amx::set_error("%s: %s", "amx_feature_cache_write_attributes", e.what());
+        return AMX_ERR_INVALID;
+    }
 }
 
 int amx_feature_cache_read_attributes(amx_archive* a, const char* segment, char** xml) {
-    AMX_REQUIRE(a && segment && xml, AMX_ERR_INVALID, "amx_feature_cache_read_attributes: NULL argument");
-    *xml             = nullptr;
-    std::string name = std::string(segment) + ".attribs", b;
-    int         rc   = read_file(a, name.c_str(), &b);
-    if (rc != AMX_OK)
-        return rc;
-    *xml = (char*)dup_bytes(b.c_str(), b.size() + 1);
-    return AMX_OK;
+    try {
+        AMX_REQUIRE(a && segment && xml, AMX_ERR_INVALID, "amx_feature_cache_read_attributes: NULL argument");
+        *xml             = nullptr;
+        std::string name = std::string(segment) + ".attribs", b;
+        int         rc   = read_file(a, name.c_str(), &b);
+        if (rc != AMX_OK)
+            return rc;
+        *xml = (char*)dup_bytes(b.c_str(), b.size() + 1);
+        return AMX_OK;
+    }
+    catch (const std::exception& e) {  // std::bad_alloc / length_error on a corrupt size field must not cross the C boundary
+        amx::set_error("%s: %s", "amx_feature_cache_read_attributes", e.what());
+        return AMX_ERR_INVALID;
+    }
 }
 
 }  // extern "C"

@@ -1550,7 +1550,17 @@ static int ffnn_score_impl(amx_ffnn* h, const float* feats_dev, int feats_stride
     const amx_ffnn::GraphKey key{feats_dev, scores_dev, best_state_dev, counts_dev, score_sum_dev, h->ctx->stream, feats_stride, T, stats ? 1 : 0};
     auto                     it = h->graphs.find(key);
     if (it == h->graphs.end()) {
-        // first call with this signature: run it plainly once (sizes the workspace, sets kernel attributes), capture the second time
+        // first call with this signature: run it plainly once (sizes the workspace, sets kernel attributes), capture the second time.
+        // The cap is checked HERE: a caller that slides its pointers through a large buffer never repeats a signature, and its
+        // "seen once" entries would otherwise grow the map for the life of the handle.
+        if (h->graphs.size() >= 64) {
+            for (auto& kv : h->graphs)
+                if (kv.second)
+                    hipGraphExecDestroy(kv.second);
+            h->graphs.clear();
+            h->use_graphs = 0;
+            return ffnn_score_launches(h, feats_dev, feats_stride, T, scores_dev, stats, best_state_dev, counts_dev, score_sum_dev);
+        }
         static const hipGraphExec_t kSeenOnce = nullptr;
         h->graphs[key] = kSeenOnce;
         return ffnn_score_launches(h, feats_dev, feats_stride, T, scores_dev, stats, best_state_dev, counts_dev, score_sum_dev);
@@ -1786,9 +1796,13 @@ int amx_ffnn_score(amx_ffnn* h, const float* feats_host, int T, float* scores_ho
     // ffnn_score_impl replay its HIP graph)
     hipStream_t  st = h->ctx->stream;
     const size_t nf = (size_t)T * h->in[0], ns = (size_t)T * h->out.back();
-    auto grow = [](float** p, size_t* cap, size_t need) {
+    auto grow = [h](float** p, size_t* cap, size_t need) {
         if (need <= *cap)
             return true;
+        for (auto& kv : h->graphs)  // captured passes may hold the old staging addresses: their keys would never be hit again
+            if (kv.second)
+                hipGraphExecDestroy(kv.second);
+        h->graphs.clear();
         hipFree(*p);
         *p   = nullptr;
         *cap = 0;

@@ -1467,7 +1467,11 @@ struct amx_gmm {
     float *   d_host_f = nullptr, *d_host_s = nullptr;
     uint32_t* d_host_b = nullptr;
     size_t    host_f_cap = 0, host_s_cap = 0, host_b_cap = 0;
-    void*     simd = nullptr;        // SIMD-diagonal-maximum tables and workspaces (gmm_simd.hip)
+    void*     simd = nullptr;        // SIMD-diagonal-maximum tables and workspaces (gmm_simd.hip), built on first use
+    std::vector<float>  h_means, h_vars;   // host copies of the model for that lazy build
+    std::vector<double> h_logw;
+    float     mws = 1.f, gsc = 1.f;
+    int       simd_status = 0;       // 0 = not built yet, 1 = built, < 0 = amx_status of the failed build
     // small-batch passes of the screened scorer on unchanged device buffers (the decoder's ring buffer), replayed as HIP graphs
     struct GraphKey {
         const void *feats, *scores, *best;
@@ -2008,11 +2012,14 @@ int amx_gmm_create(amx_ctx* ctx, const amx_gmm_model* m, amx_gmm** out) {
             }
         }
     }
-    // ---- SIMD-diagonal-maximum tables (quantised means, integer constants; gmm_simd.hip)
-    if ((r = amx_internal_gmm_simd_create(m, &h->simd, nullptr)) != AMX_OK) {
-        amx_gmm_destroy(h);
-        return r;
-    }
+    // ---- SIMD-diagonal-maximum / batch-int tables (quantised means, integer constants; gmm_simd.hip) are built on the first
+    // call of those scorers (ensure_simd): most handles never use them, and a model they cannot represent must not keep the
+    // float scorers from being created.  Host copies of the model for that build:
+    h->h_means.assign(m->means, m->means + (size_t)m->n_mean * m->dim);
+    h->h_vars.assign(m->variances, m->variances + (size_t)m->n_cov * m->dim);
+    h->h_logw.assign(m->log_weight, m->log_weight + nk);
+    h->mws = m->mixture_weight_scale;
+    h->gsc = m->gaussian_scale;
     if (const char* e = getenv("AMX_GMM_GRAPH"))
         h->use_graphs = atoi(e);
     *out = h;
@@ -2088,6 +2095,36 @@ int amx_gmm_tables(const amx_gmm* h, float* m2lw, float* isr, float* lognorm) {
     return AMX_OK;
 }
 
+extern "C++" {
+static int ensure_simd(amx_gmm* h) {
+    if (h->simd_status == 1)
+        return AMX_OK;
+    if (h->simd_status < 0) {
+        amx::set_error("SIMD-diagonal-maximum tables of this model could not be built");
+        return h->simd_status;
+    }
+    amx_gmm_model v;
+    memset(&v, 0, sizeof v);
+    v.dim = h->dim;
+    v.n_mix = h->n_mix;
+    v.n_dens = h->n_dens;
+    v.n_mean = h->n_mean;
+    v.n_cov = h->n_cov;
+    v.mix_offsets = h->mix_off.data();
+    v.dens_index = h->h_k_dens.data();
+    v.log_weight = h->h_logw.data();
+    v.dens_mean = h->h_d_mean.data();
+    v.dens_cov = h->h_d_cov.data();
+    v.means = h->h_means.data();
+    v.variances = h->h_vars.data();
+    v.mixture_weight_scale = h->mws;
+    v.gaussian_scale = h->gsc;
+    const int r = amx_internal_gmm_simd_create(&v, &h->simd, nullptr);
+    h->simd_status = r == AMX_OK ? 1 : r;
+    return r;
+}
+}  // extern "C++"
+
 int amx_gmm_score_dev(amx_gmm* h, int mode, const float* feats_dev, int T, float* scores_dev, uint32_t* best_dev) {
     AMX_REQUIRE(h, AMX_ERR_INVALID, "amx_gmm_score_dev: NULL handle");
     AMX_REQUIRE(h->ctx, AMX_ERR_STATE, "amx_gmm_score_dev: host-only handle (created without a context)");
@@ -2100,6 +2137,11 @@ int amx_gmm_score_dev(amx_gmm* h, int mode, const float* feats_dev, int T, float
     AMX_REQUIRE(feats_dev && scores_dev, AMX_ERR_INVALID, "amx_gmm_score_dev: NULL buffer");
     AMX_HIP(hipSetDevice(h->ctx->device));
     const int fblocks = amx::ceil_div(T, 256);
+    if (mode == AMX_GMM_SIMD || mode == AMX_GMM_BATCH_INT) {
+        const int r = ensure_simd(h);
+        if (r != AMX_OK)
+            return r;
+    }
     if (mode == AMX_GMM_SIMD)
         return amx_internal_gmm_simd_score(h->simd, h->ctx, 0, feats_dev, T, scores_dev, best_dev);
     if (mode == AMX_GMM_BATCH_INT) {
@@ -2147,7 +2189,15 @@ int amx_gmm_score_dev(amx_gmm* h, int mode, const float* feats_dev, int T, float
         const amx_gmm::GraphKey key{feats_dev, scores_dev, best_dev, h->ctx->stream, T};
         auto                    it = h->graphs.find(key);
         if (it == h->graphs.end()) {
-            h->graphs[key] = nullptr;
+            if (h->graphs.size() >= 64) {  // a caller that never repeats a signature: stop caching instead of growing the map
+                for (auto& kv : h->graphs)
+                    if (kv.second)
+                        hipGraphExecDestroy(kv.second);
+                h->graphs.clear();
+                h->use_graphs = 0;
+            }
+            else
+                h->graphs[key] = nullptr;
             return score_screened(h, feats_dev, T, scores_dev, best_dev, false, nullptr, nullptr, nullptr);
         }
         if (it->second == nullptr) {
@@ -2339,7 +2389,9 @@ int amx_gmm_screen_counts(amx_gmm* h, int enable, unsigned long long* survivors,
 }
 
 float amx_gmm_simd_scaling(const amx_gmm* h) {
-    return h ? amx_internal_gmm_simd_scaling(h->simd) : 0.f;
+    if (!h || !h->ctx || ensure_simd(const_cast<amx_gmm*>(h)) != AMX_OK)
+        return 0.f;
+    return amx_internal_gmm_simd_scaling(h->simd);
 }
 
 long amx_gmm_accumulator_size(const amx_gmm* h) {
@@ -2519,9 +2571,13 @@ int amx_gmm_score(amx_gmm* h, int mode, const float* feats_host, int T, float* s
     // hipMalloc / hipFree pair per call costs more than scoring a small batch
     hipStream_t  st = h->ctx->stream;
     const size_t nf = (size_t)T * h->dim, ns = (size_t)T * h->n_mix;
-    auto grow = [](void** p, size_t* cap, size_t need) {
+    auto grow = [h](void** p, size_t* cap, size_t need) {
         if (need <= *cap)
             return true;
+        for (auto& kv : h->graphs)  // captured passes may hold the old staging addresses
+            if (kv.second)
+                hipGraphExecDestroy(kv.second);
+        h->graphs.clear();
         hipFree(*p);
         *p   = nullptr;
         *cap = 0;

@@ -328,6 +328,13 @@ void amx_internal_gmm_simd_destroy(void* p) {
     delete s;
 }
 
+// float / double -> s32 as the reference's x86-64 build converts (cvttss2si / cvttsd2si): truncation, and the "integer indefinite"
+// value INT_MIN for NaN and anything out of range -- a zero-weight density (log weight -DBL_MAX, e.g. from a version < 2.0 .pms
+// file) makes the constant +inf.  A plain C++ cast is undefined behaviour there.
+static inline int cvt_s32_x86(double v) {
+    return (v > -2147483649.0 && v < 2147483648.0) ? (int)v : (-2147483647 - 1);
+}
+
 // SimdGaussDiagonalMaximumFeatureScorer::init + buildMixtureTable (Mm/SimdFeatureScorer.cc:68-137)
 int amx_internal_gmm_simd_create(const amx_gmm_model* m, void** out, float* scaling_out) {
     using namespace amx;
@@ -373,7 +380,7 @@ int amx_internal_gmm_simd_create(const amx_gmm_model* m, void** out, float* scal
     for (size_t k = 0; k < nk; ++k) {  // buildMixtureTable (:92-100) + createDensityElement (Mm/IntelOptimization.cc:37-46)
         const double scaled  = (double)(scaling2 * -2) * m->log_weight[k];
         const float  asScore = (float)scaled;
-        cst[k]               = (int)(asScore + lognorm[m->dens_cov[m->dens_index[k]]]);
+        cst[k]               = cvt_s32_x86((double)(asScore + lognorm[m->dens_cov[m->dens_index[k]]]));
     }
     // Mm::BatchIntFeatureScorer::init (Mm/BatchFeatureScorer.cc:375-417), pooled covariance only: the same quantised means
     // (quantizationScale is getScaling's formula), scale_ = (f32)(2.0 * scale^2), constant = (s32)(logNorm * scale^2 - scale_ * logWeight)
@@ -384,7 +391,7 @@ int amx_internal_gmm_simd_create(const amx_gmm_model* m, void** out, float* scal
         cst_int.resize(nk);
         const float log_norm_factor = lognorm[0];  // already logNormalizationFactor() * scaleSquared
         for (size_t k = 0; k < nk; ++k)
-            cst_int[k] = (int)((double)log_norm_factor - (double)int_scale * m->log_weight[k]);
+            cst_int[k] = cvt_s32_x86((double)log_norm_factor - (double)int_scale * m->log_weight[k]);
     }
     GmmSimd* s  = new GmmSimd;
     s->dim      = dim;

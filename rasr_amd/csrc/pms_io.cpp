@@ -56,10 +56,11 @@ int amx_pms_read(const char* path, amx_mixture_set** out) {
     amx_mixture_set* ms = new amx_mixture_set;
     ms->dim             = (int)dim;
     ms->mix_off.push_back(0);
-    for (unsigned m = 0; m < nMix; ++m) {
+    // every loop stops at the first failed extraction: a corrupt count in the header must not turn into 2^32 push_backs
+    for (unsigned m = 0; m < nMix && in.good(); ++m) {
         unsigned k = 0;
         in >> k;
-        for (unsigned j = 0; j < k; ++j) {
+        for (unsigned j = 0; j < k && in.good(); ++j) {
             unsigned d = 0;
             double   w = 0;
             in >> d >> w;
@@ -70,42 +71,47 @@ int amx_pms_read(const char* path, amx_mixture_set** out) {
         }
         ms->mix_off.push_back((uint32_t)ms->dens_index.size());
     }
-    for (unsigned d = 0; d < nDns; ++d) {
+    for (unsigned d = 0; d < nDns && in.good(); ++d) {
         unsigned mi = 0, ci = 0;
         in >> mi >> ci;
         ms->dens_mean.push_back(mi);
         ms->dens_cov.push_back(ci);
     }
-    for (unsigned i = 0; i < nMean; ++i) {
+    for (unsigned i = 0; i < nMean && in.good(); ++i) {
         unsigned n = 0;
         in >> n;
+        if (in.fail())
+            break;
         if (n != dim) {
             amx::set_error("amx_pms_read: mean %u has dimension %u, expected %u", i, n, dim);
             delete ms;
             return AMX_ERR_INVALID;
         }
-        for (unsigned j = 0; j < n; ++j) {
+        for (unsigned j = 0; j < n && !in.fail(); ++j) {
             float v = 0;
             in >> v;
             ms->means.push_back(v);
         }
     }
-    for (unsigned i = 0; i < nCov; ++i) {
+    for (unsigned i = 0; i < nCov && !in.fail(); ++i) {
         unsigned n = 0;
         in >> n;
+        if (in.fail())
+            break;
         if (n != dim) {
             amx::set_error("amx_pms_read: covariance %u has dimension %u, expected %u", i, n, dim);
             delete ms;
             return AMX_ERR_INVALID;
         }
-        for (unsigned j = 0; j < n; ++j) {
+        for (unsigned j = 0; j < n && !in.fail(); ++j) {
             float  v = 0;
             double w = 0;
             in >> v >> w;
             ms->variances.push_back((float)(v * w));
         }
     }
-    if (in.fail()) {
+    if (in.fail() || ms->mix_off.size() != (size_t)nMix + 1 || ms->dens_mean.size() != nDns || ms->means.size() != (size_t)nMean * dim ||
+        ms->variances.size() != (size_t)nCov * dim) {
         amx::set_error("amx_pms_read: '%s' is truncated or malformed", path);
         delete ms;
         return AMX_ERR_INVALID;

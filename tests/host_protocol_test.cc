@@ -79,24 +79,27 @@ int main(int argc, char** argv) {
     {
         // lazy rows and the gather extension: after a refill only the rows / pairs that are asked for come back
         BatchFeatureScorer lazy(std::unique_ptr<BatchBackend>(new GmmBackend(ctx, model)), B);
-        std::vector<Scorer> sc;
-        for (int t = 0; t < (int)B + 1; ++t) {
+        Scorer first;
+        for (int t = 0; t < (int)B; ++t) {
             FeatureVector f(feats.begin() + t * dim, feats.begin() + (t + 1) * dim);
             if (!lazy.bufferFilled())
                 lazy.addFeature(f);
             else
-                sc.push_back(lazy.getScorer(f));
+                first = lazy.getScorer(f);
         }
-        CHECK(sc.size() == 2 && lazy.bytesToHost() == 0);          // nothing scored, nothing copied yet
+        CHECK(first && lazy.bytesToHost() == 0);                   // nothing scored, nothing copied yet
         const EmissionIndex want_e[2] = {2, 0};
         Score               got[2];
-        sc[1]->scores(want_e, 2, got);                             // frame 1: two scores through the device gather
-        CHECK(got[0] == want[1 * M + 2] && got[1] == want[1 * M + 0]);
+        first->scores(want_e, 2, got);                             // frame 0: two scores through the device gather
+        CHECK(got[0] == want[0 * M + 2] && got[1] == want[0 * M + 0]);
         CHECK(lazy.bytesToHost() == 2 * sizeof(float));
-        CHECK(sc[0]->score(1) == want[0 * M + 1]);                  // frame 0: first score() fetches its row
+        Scorer second = lazy.flush();                              // frame 1
+        CHECK(second->score(1) == want[1 * M + 1]);                 // first score() of a frame fetches its row
         CHECK(lazy.bytesToHost() == 2 * sizeof(float) + M * sizeof(float));
-        CHECK(sc[0]->score(2) == want[0 * M + 2]);                  // ... and the next one is a host read
+        CHECK(second->score(2) == want[1 * M + 2]);                 // ... and the next one is a host read
         CHECK(lazy.bytesToHost() == 2 * sizeof(float) + M * sizeof(float));
+        second->scores(want_e, 2, got);                            // a fetched row also serves the list call
+        CHECK(got[0] == want[1 * M + 2] && lazy.bytesToHost() == 2 * sizeof(float) + M * sizeof(float));
     }
     // contract violations
     bool threw = false;

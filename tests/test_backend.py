@@ -158,3 +158,35 @@ def test_backend_chain_cmvn_derivatives_lda(ctx):
         n = len(f)
         w = np.concatenate([f[np.clip(np.arange(n) + k, 0, n - 1)] for k in (-1, 0, 1)], axis=1)
         assert np.array_equal(got[fo[i]:fo[i + 1]].view(np.uint32), oracle_matrix_multiply(M, w).view(np.uint32)), i
+
+
+@pytest.mark.gpu
+def test_overlapping_views_are_rejected(ctx):
+    """sliding-window normalisation, regression and the matrix product read neighbouring rows while others are written: views
+    that share memory are refused (disjoint column ranges of one wide matrix are not); whole-segment normalisation in place on
+    the identical view stays allowed and equals the out-of-place result"""
+    import torch
+
+    import rasr_amd
+    fe = rasr_amd.MfccExtractor(ctx, nr_cepstrum_coefficients=12)
+    plan = fe.plan(np.array([0, 16000, 40000], np.int64))
+    T = plan.total_frames
+    wide = torch.randn((T, 40), dtype=torch.float32, device="cuda")
+    ctx.use_torch_stream()
+    a, b = wide[:, 0:12], wide[:, 12:24]
+    ctx.normalize(plan, a, 40, 12, b, 40, variance=False, length=20, right=5)      # disjoint columns of one matrix: fine
+    ctx.regression(plan, a, 40, 12, b, 40, order=1, right=2)
+    shifted = wide[:, 6:18]
+    for call in (lambda: ctx.normalize(plan, a, 40, 12, shifted, 40, length=20, right=5),
+                 lambda: ctx.normalize(plan, a, 40, 12, a, 40, length=20, right=5),
+                 lambda: ctx.regression(plan, a, 40, 12, a, 40, order=1, right=2),
+                 lambda: ctx.regression(plan, a, 40, 12, shifted, 40, order=2, right=2),
+                 lambda: ctx.matrix_multiply(wide[:12, :12].contiguous(), 12, 12, a, 40, T, shifted, 40)):
+        with pytest.raises(rasr_amd.AmxError, match="overlap"):
+            call()
+    ref = torch.empty((T, 12), dtype=torch.float32, device="cuda")
+    src = a.contiguous()
+    ctx.normalize(plan, src, 12, 12, ref, 12, variance=True)
+    ctx.normalize(plan, src, 12, 12, src, 12, variance=True)                        # whole segment, in place
+    torch.cuda.synchronize()
+    assert torch.equal(src, ref)
