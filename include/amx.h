@@ -162,6 +162,15 @@ int amx_context_window_dev(amx_ctx* ctx, const amx_mfcc_plan* p, const float* fe
 #define AMX_NORM_MEAN_AND_VARIANCE 1
 int amx_normalize_dev(amx_ctx* ctx, const amx_mfcc_plan* plan, const float* in_dev, int in_ld, int dim, int type,
                       int length, int right, float* out_dev, int out_ld);
+/* the node's other types on the same window skeleton (src/Signal/Normalization.cc:100-110,196-262; NormalizationNode `type` /
+ * `level`): divide-by-mean (x / mean; the reference stops with "One of the mean components is zero." where this yields inf or
+ * NaN), level (out[level] = x[level] - max over the window, other components unchanged) and mean-and-variance-1D (one mean and
+ * standard deviation over all components of the window).  type mean / mean-and-variance are forwarded to amx_normalize_dev. */
+#define AMX_NORM_DIVIDE_BY_MEAN 2
+#define AMX_NORM_LEVEL 3
+#define AMX_NORM_MEAN_AND_VARIANCE_1D 4
+int amx_normalize_ex_dev(amx_ctx* ctx, const amx_mfcc_plan* plan, const float* in_dev, int in_ld, int dim, int type, int level,
+                         int length, int right, float* out_dev, int out_ld);
 /* signal-delay (max-size = 2*right+1, margin-policy copy, margin-condition present-not-empty; src/Signal/Delay.hh:33-47)
  * + signal-regression order 1 or 2 (src/Signal/Regression.cc:25-68), as wired in derivationWithRegression.flow. */
 int amx_regression_dev(amx_ctx* ctx, const amx_mfcc_plan* plan, const float* in_dev, int in_ld, int dim, int order,

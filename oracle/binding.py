@@ -200,6 +200,16 @@ def oracle_normalize(x, variance=False, length=0, right=0):
     return out
 
 
+def oracle_normalize_ex(x, type, level=0, length=0, right=0):
+    """orc_normalize_ex over one segment [n, dim]: type 2 divide-by-mean, 3 level, 4 mean-and-variance-1D (0 / 1 as oracle_normalize)"""
+    L = Oracle()
+    x = np.ascontiguousarray(x, np.float32)
+    out = np.empty_like(x)
+    L.orc_normalize_ex.argtypes = [f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32p]
+    L.orc_normalize_ex(x.reshape(-1), x.shape[0], x.shape[1], type, level, length, right, out.reshape(-1))
+    return out
+
+
 def oracle_regression(x, order=1, right=2):
     L = Oracle()
     x = np.ascontiguousarray(x, np.float32)
@@ -417,6 +427,29 @@ class OracleGmm:
         if r != 0:
             raise ValueError("batch-float scorer supports only a globally pooled covariance")
         return sc
+
+
+def _preselection(self, feats, n_clusters=256, n_select=32, iterations=5, backoff=40000.0):
+    """preselection-batch-float: (scores, cluster index per mixture entry, cluster means [n_clusters, padded dim])"""
+    feats = np.ascontiguousarray(feats, dtype=np.float32)
+    T = feats.shape[0]
+    nk = int(self.m["mix_offsets"][-1])
+    pdim = (self.dim + 7) // 8 * 8
+    sc = np.zeros((T, self.n_mix), np.float32)
+    cof = np.zeros(nk, np.uint32)
+    cm = np.zeros((min(n_clusters, nk), pdim), np.float32)
+    nc = C.c_int(0)
+    self.L.orc_gmm_score_preselection_float.restype = C.c_int
+    self.L.orc_gmm_score_preselection_float.argtypes = [C.c_void_p, f64p, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, f32p,
+                                                        u32p, f32p, C.POINTER(C.c_int)]
+    r = self.L.orc_gmm_score_preselection_float(self.h, self.m["log_weight"], self.m["variances"].reshape(-1), feats.reshape(-1), T,
+                                                n_clusters, n_select, iterations, backoff, sc.reshape(-1), cof, cm.reshape(-1), C.byref(nc))
+    if r != 0:
+        raise ValueError("preselection scorer: pooled covariance only, 1 <= select-clusters <= clusters (status %d)" % r)
+    return sc, cof, cm
+
+
+OracleGmm.score_preselection_float = _preselection
 
 
 def _simd(self, feats):

@@ -123,6 +123,9 @@ const float* orc_gmm_log_norm(const orc_gmm* h);           /* [n_cov] */
  * scores [T x n_mix]; best [T x n_mix] density-in-mixture index (nullable) */
 void orc_gmm_score(const orc_gmm* h, int mode, const float* feats, int T, float* scores, uint32_t* best);
 /* Mm::BatchFloatFeatureScorer arithmetic (pooled covariance only, n_cov == 1) */
+int orc_gmm_score_preselection_float(const orc_gmm* h, const double* log_weight, const float* variances, const float* feats, int T,
+                                     int n_clusters, int n_select, int iterations, float backoff, float* scores,
+                                     uint32_t* cluster_of_out, float* cluster_means_out, int* n_clusters_out);
 int orc_gmm_score_batch_float(const orc_gmm* h, const double* log_weight, const float* variances,
                               const float* feats, int T, float* scores);
 
@@ -169,6 +172,7 @@ void orc_ffnn_score(const orc_ffnn_model* m, const float* feats, int T, float* s
 
 /* ---- feature back-end, orc_backend.c; parity unpinned (see that file) */
 void orc_normalize(const float* in, int n, int dim, int type, int length, int right, float* out);
+void orc_normalize_ex(const float* in, int n, int dim, int type, int level, int length, int right, float* out);
 void orc_regression(const float* in, int n, int dim, int order, int right, float* out);
 void orc_matrix_multiply(const float* M, int rows, int cols, const float* in, int T, float* out);
 

@@ -83,6 +83,84 @@ void orc_normalize(const float* in, int n, int dim, int type, int length, int ri
     free(sd);
 }
 
+/* The other algorithms of signal-normalization (Signal/Normalization.cc:100-110 LevelNormalization, :196-254
+ * MeanAndVarianceNormalization1D, :256-262 DivideByMean) on the same sliding-window skeleton (Normalization::update, :47-70):
+ *   type 2  divide-by-mean          out = x / mean   (mean as in type 0; the reference stops with "One of the mean components is
+ *                                   zero." where this yields inf / NaN)
+ *   type 3  level (index `level`)   out[level] = x[level] - max over the window of x[level], the other components pass through
+ *   type 4  mean-and-variance-1D    one mean / standard deviation over ALL components of the window's frames:
+ *                                   sums run component by component, frame by frame, in f64; sumWeight counts components;
+ *                                   mean = (f32)sum / sumWeight (the cast binds to sum first), sd = (f32)sqrt(...), 0 -> 1
+ * Statistics follow the window exactly like orc_normalize: added frame first, then the frame that leaves the window. */
+void orc_normalize_ex(const float* in, int n, int dim, int type, int level, int length, int right, float* out) {
+    if (n <= 0)
+        return;
+    if (type == 0 || type == 1) {
+        orc_normalize(in, n, dim, type, length, right, out);
+        return;
+    }
+    const int infinite = (length <= 0);
+    double*   sum  = (double*)calloc((size_t)dim, sizeof(double));
+    float*    mean = (float*)calloc((size_t)dim, sizeof(float));
+    double    w = 0, sum1 = 0, sumsq1 = 0, w1 = 0;
+    float     mean1 = 0, sd1 = 0, mx = 0;
+    for (int t = 0; t <= n - 1 + 0; ++t) {
+        const float* x = in + (size_t)t * dim;
+        for (int d = 0; d < dim; ++d) {
+            sum[d] = sum[d] + (double)x[d];
+            sumsq1 += (double)x[d] * (double)x[d];
+            sum1 += (double)x[d];
+        }
+        w += 1;
+        w1 += dim;
+        int lo = 0;  /* oldest frame in the window after this add */
+        if (!infinite && t >= length) {
+            const float* r = in + (size_t)(t - length) * dim;
+            for (int d = 0; d < dim; ++d) {
+                sum[d] = sum[d] - (double)r[d];
+                sumsq1 -= (double)r[d] * (double)r[d];
+                sum1 -= (double)r[d];
+            }
+            w -= 1;
+            w1 -= dim;
+        }
+        if (!infinite)
+            lo = t - length + 1 > 0 ? t - length + 1 : 0;
+        const int emit_now = !infinite && t >= right;
+        const int last     = (t == n - 1);
+        if (emit_now || last) {
+            if (type == 2)
+                for (int d = 0; d < dim; ++d)
+                    mean[d] = (float)(sum[d] / w);
+            else if (type == 3) {
+                mx = -3.402823466e+38f;  /* Core::Type<f32>::min */
+                for (int u = lo; u <= t; ++u)
+                    mx = in[(size_t)u * dim + level] > mx ? in[(size_t)u * dim + level] : mx;
+            }
+            else {
+                sd1   = (float)sqrt((sumsq1 - sum1 * sum1 / w1) / w1);
+                mean1 = (float)((double)(float)sum1 / w1);
+                if (sd1 == 0)
+                    sd1 = 1.0f;
+            }
+        }
+        const int u0 = emit_now ? t - right : 0, u1 = emit_now ? t - right + 1 : 0;
+        for (int u = u0; u < u1; ++u)
+            for (int d = 0; d < dim; ++d) {
+                const float v = in[(size_t)u * dim + d];
+                out[(size_t)u * dim + d] = type == 2 ? v / mean[d] : type == 3 ? (d == level ? v - mx : v) : (v - mean1) / sd1;
+            }
+    }
+    const int first = infinite ? 0 : (n - right > 0 ? n - right : 0);
+    for (int u = first; u < n; ++u)
+        for (int d = 0; d < dim; ++d) {
+            const float v = in[(size_t)u * dim + d];
+            out[(size_t)u * dim + d] = type == 2 ? v / mean[d] : type == 3 ? (d == level ? v - mx : v) : (v - mean1) / sd1;
+        }
+    free(sum);
+    free(mean);
+}
+
 /* Signal::Regression::regressFirstOrder / regressSecondOrder (Signal/Regression.cc:25-68) over the window
  * [t - right, t + right] of a segment, missing frames replaced by the closest one (signal-delay, margin-policy copy,
  * margin-condition present-not-empty: Signal/Delay.hh:33-47, derivationWithRegression.flow:7-8). */

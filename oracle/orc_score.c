@@ -239,6 +239,162 @@ int orc_gmm_score_batch_float(const orc_gmm* h, const double* log_weight, const 
     return 0;
 }
 
+/* Mm::BatchPreselectionFloatFeatureScorer ("preselection-batch-float", Mm/BatchFeatureScorer.cc:256-318) =
+ * BatchFloatFeatureScorer + Mm::FloatDensityClustering (Mm/DensityClustering.hh/.tcc):
+ *   build (tcc:130-163)       k-means over the PRE-SCALED, zero-padded density means (dimension = padded dimension):
+ *     initializeClusters      srand(1); cluster c starts at density rand() % nDensities (redrawn while already used)
+ *     assignDensities         first cluster with the smallest unrolledVectorDistance (f32, sequential sum of squares, strict '<')
+ *     updateClusterMeans      f64 component sums in density order / count -> f32; a cluster without densities keeps its mean
+ *     `iterations` times (parameter default 5); nClusters is reduced to nDensities when there are fewer densities
+ *   selectClusters (tcc:165-186) per frame: distance of the scaled feature to every cluster mean, ascending std::sort on the
+ *     distance, the first nSelected clusters are active
+ *   fillScoreCache (cc:305-318) batch-float minimum over the densities whose cluster is active; a mixture without an active
+ *     density scores backoffScore (default 40000) -- the 0.5 factor is applied to real minima only.
+ * cluster_of [nk] and cluster_means [n_clusters x pdim] (both nullable) return the clustering.  Equal distances in the sort are
+ * broken by cluster index here (std::sort leaves their order unspecified). */
+typedef struct {
+    float    d;
+    uint32_t c;
+} orc_cl_item;
+
+static int orc_cl_cmp(const void* a, const void* b) {
+    const orc_cl_item *x = (const orc_cl_item*)a, *y = (const orc_cl_item*)b;
+    if (x->d < y->d)
+        return -1;
+    if (x->d > y->d)
+        return 1;
+    return x->c < y->c ? -1 : (x->c > y->c ? 1 : 0);
+}
+
+static float orc_seq_distance(const float* a, const float* b, int dim) { /* unrolledVectorDistance<f32, f32>, dim % 8 == 0 */
+    float score = 0;
+    for (int i = 0; i < dim; ++i) {
+        float df = a[i] - b[i];
+        score += df * df;
+    }
+    return score;
+}
+
+int orc_gmm_score_preselection_float(const orc_gmm* h, const double* log_weight, const float* variances, const float* feats, int T,
+                                     int n_clusters, int n_select, int iterations, float backoff, float* scores,
+                                     uint32_t* cluster_of_out, float* cluster_means_out, int* n_clusters_out) {
+    if (h->n_cov != 1)
+        return -1;
+    int    dim  = h->dim;
+    int    pdim = ((dim + 7) / 8) * 8;
+    size_t nk   = h->mix_off[h->n_mix];
+    if ((size_t)n_clusters > nk)
+        n_clusters = (int)nk;
+    if (n_select > n_clusters || n_select < 1)
+        return -2;
+    float* isr = (float*)calloc((size_t)pdim, 4);
+    double ln  = 0;
+    for (int i = 0; i < dim; ++i) {
+        isr[i] = (float)1 / (float)sqrt((double)variances[i]);
+        ln += log((double)fabsf(variances[i]));
+    }
+    float  lognorm = (float)((double)dim * log((double)2 * M_PI) + ln);
+    float* xs      = (float*)calloc((size_t)pdim, 4);
+    float* ms      = (float*)calloc(nk * (size_t)pdim, 4);
+    float* cst     = (float*)calloc(nk, 4);
+    for (size_t k = 0; k < nk; ++k) {
+        const float* mu = h->means + (size_t)h->dens_mean[h->dens_index[k]] * dim;
+        for (int i = 0; i < dim; ++i)
+            ms[k * pdim + i] = mu[i] * isr[i];
+        cst[k] = (float)((double)lognorm - 2 * log_weight[k]);
+    }
+    /* ---- clustering */
+    float*    cm   = (float*)calloc((size_t)n_clusters * pdim, 4);
+    uint32_t* cof  = (uint32_t*)calloc(nk, 4);
+    char*     used = (char*)calloc(nk, 1);
+    srand(1);
+    for (int c = 0; c < n_clusters; ++c) {
+        uint32_t pick;
+        do {
+            pick = (uint32_t)rand() % (uint32_t)nk;
+        } while (used[pick]);
+        used[pick] = 1;
+        memcpy(cm + (size_t)c * pdim, ms + (size_t)pick * pdim, (size_t)pdim * 4);
+    }
+    double*   sums = (double*)calloc((size_t)pdim, 8);
+    for (int it = 0; it < iterations; ++it) {
+        for (size_t k = 0; k < nk; ++k) {
+            float    bd = FLT_MAX;
+            uint32_t bc = 0;
+            for (int c = 0; c < n_clusters; ++c) {
+                float d = orc_seq_distance(cm + (size_t)c * pdim, ms + k * pdim, pdim);
+                if (d < bd) {
+                    bd = d;
+                    bc = (uint32_t)c;
+                }
+            }
+            cof[k] = bc;
+        }
+        for (int c = 0; c < n_clusters; ++c) {
+            size_t cnt = 0;
+            for (int i = 0; i < pdim; ++i)
+                sums[i] = 0;
+            for (size_t k = 0; k < nk; ++k)
+                if (cof[k] == (uint32_t)c) {
+                    for (int i = 0; i < pdim; ++i)
+                        sums[i] = sums[i] + (double)ms[k * pdim + i];
+                    ++cnt;
+                }
+            if (cnt)
+                for (int i = 0; i < pdim; ++i)
+                    cm[(size_t)c * pdim + i] = (float)(sums[i] / (double)cnt);
+        }
+    }
+    /* ---- scoring */
+    orc_cl_item* items  = (orc_cl_item*)calloc((size_t)n_clusters, sizeof(orc_cl_item));
+    char*        active = (char*)calloc((size_t)n_clusters, 1);
+    for (int t = 0; t < T; ++t) {
+        for (int i = 0; i < dim; ++i)
+            xs[i] = feats[(size_t)t * dim + i] * isr[i];
+        for (int c = 0; c < n_clusters; ++c) {
+            items[c].d = orc_seq_distance(xs, cm + (size_t)c * pdim, pdim);
+            items[c].c = (uint32_t)c;
+        }
+        qsort(items, (size_t)n_clusters, sizeof(orc_cl_item), orc_cl_cmp);
+        memset(active, 0, (size_t)n_clusters);
+        for (int i = 0; i < n_select; ++i)
+            active[items[i].c] = 1;
+        for (int m = 0; m < h->n_mix; ++m) {
+            float best = FLT_MAX;
+            for (uint32_t k = h->mix_off[m]; k < h->mix_off[m + 1]; ++k) {
+                if (!active[cof[k]])
+                    continue;
+                const float* mu    = ms + (size_t)k * pdim;
+                float        s1[4] = {cst[k], 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+                for (int d = 0; d < pdim; d += 8)
+                    for (int j = 0; j < 4; ++j) {
+                        float x1 = mu[d + j] - xs[d + j];
+                        s1[j]    = s1[j] + x1 * x1;
+                        float x2 = mu[d + 4 + j] - xs[d + 4 + j];
+                        s2[j]    = s2[j] + x2 * x2;
+                    }
+                float a0 = s1[0] + s2[0], a1 = s1[1] + s2[1], a2 = s1[2] + s2[2], a3 = s1[3] + s2[3];
+                float r = (a3 + a1) + (a2 + a0);
+                if (r < best)
+                    best = r;
+            }
+            if (best < FLT_MAX)
+                best = (float)(best * 0.5);
+            else
+                best = backoff;
+            scores[(size_t)t * h->n_mix + m] = best;
+        }
+    }
+    if (cluster_of_out)
+        memcpy(cluster_of_out, cof, nk * 4);
+    if (cluster_means_out)
+        memcpy(cluster_means_out, cm, (size_t)n_clusters * pdim * 4);
+    if (n_clusters_out)
+        *n_clusters_out = n_clusters;
+    free(isr); free(xs); free(ms); free(cst); free(cm); free(cof); free(used); free(sums); free(items); free(active);
+    return 0;
+}
+
 /* Mm::SimdGaussDiagonalMaximumFeatureScorer ("SIMD-diagonal-maximum", Mm/SimdFeatureScorer.cc:68-176) with
  * Mm::FeatureScorerIntelOptimization (Mm/IntelOptimization.cc:37-66) and quantize<f32,u8> (Mm/Utilities.hh:190-202):
  *   init (:68-82)        scaling = quantizationScalingFactor(min, max of mean * 1/sigma over all densities) (:112-137):

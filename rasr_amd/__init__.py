@@ -85,6 +85,10 @@ class Context:
         _lib.check(self.L.amx_normalize_dev(self.h, plan.h, _ptr(feats), in_ld, dim,
                                             _lib.AMX_NORM_MEAN_AND_VARIANCE if variance else _lib.AMX_NORM_MEAN, length, right, _ptr(out), out_ld))
 
+    def normalize_ex(self, plan, feats, in_ld, dim, out, out_ld, type, level=0, length=0, right=0):
+        """signal-normalization types 2 divide-by-mean, 3 level (component `level`), 4 mean-and-variance-1D"""
+        _lib.check(self.L.amx_normalize_ex_dev(self.h, plan.h, _ptr(feats), in_ld, dim, type, level, length, right, _ptr(out), out_ld))
+
     def regression(self, plan, feats, in_ld, dim, out, out_ld, order=1, right=2):
         """signal-delay (copy margin) + signal-regression of the given order over 2 * right + 1 frames"""
         _lib.check(self.L.amx_regression_dev(self.h, plan.h, _ptr(feats), in_ld, dim, order, right, _ptr(out), out_ld))

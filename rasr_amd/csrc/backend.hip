@@ -66,6 +66,93 @@ __global__ __launch_bounds__(64) void normalize_kernel(const float* __restrict__
     }
 }
 
+// divide-by-mean (type 2), level (3) and mean-and-variance-1D (4): Signal/Normalization.cc:100-110,196-262.  One workgroup per
+// segment.  The 1D variant's statistics are ONE f64 recurrence over all components of all frames in the reference's order
+// (component by component, frame by frame), so lane 0 carries them; the window maximum of the level variant is rescanned per
+// emitted frame like LevelNormalization::finalize does; the per-frame results go through LDS to the lanes that apply them.
+__global__ __launch_bounds__(64) void normalize_misc_kernel(const float* __restrict__ in, int in_ld, const long long* __restrict__ frame_off,
+                                                           int dim, int type, int level, int length, int right, float* __restrict__ out,
+                                                           int out_ld) {
+    const long long s0 = frame_off[blockIdx.x], s1 = frame_off[blockIdx.x + 1];
+    const int       n  = (int)(s1 - s0);
+    if (n <= 0)
+        return;
+    const bool infinite = length <= 0;
+    const int  lane = threadIdx.x;
+    if (type == 2) {  // per dimension, like normalize_kernel
+        for (int d = lane; d < dim; d += 64) {
+            double sum = 0.0, w = 0.0;
+            float  mean = 0.f;
+            for (int t = 0; t < n; ++t) {
+                sum = sum + (double)in[(s0 + t) * in_ld + d];
+                w += 1.0;
+                if (!infinite && t >= length) {
+                    sum = sum - (double)in[(s0 + t - length) * in_ld + d];
+                    w -= 1.0;
+                }
+                const bool emit_now = !infinite && t >= right;
+                if (emit_now || t == n - 1)
+                    mean = (float)(sum / w);
+                if (emit_now)
+                    out[(s0 + t - right) * out_ld + d] = in[(s0 + t - right) * in_ld + d] / mean;
+            }
+            for (int u = infinite ? 0 : max(n - right, 0); u < n; ++u)
+                out[(s0 + u) * out_ld + d] = in[(s0 + u) * in_ld + d] / mean;
+        }
+        return;
+    }
+    __shared__ float s_a, s_b;  // type 3: window maximum;  type 4: mean, standard deviation
+    double sum1 = 0.0, sumsq1 = 0.0, w1 = 0.0;
+    auto   apply = [&](int u) {
+        const float a = s_a, b = s_b;
+        for (int d = lane; d < dim; d += 64) {
+            const float v = in[(s0 + u) * in_ld + d];
+            out[(s0 + u) * out_ld + d] = type == 3 ? (d == level ? v - a : v) : (v - a) / b;
+        }
+    };
+    for (int t = 0; t < n; ++t) {
+        const bool emit_now = !infinite && t >= right;
+        const bool refresh  = emit_now || t == n - 1;
+        if (lane == 0) {
+            if (type == 4) {
+                for (int d = 0; d < dim; ++d) {
+                    const double x = (double)in[(s0 + t) * in_ld + d];
+                    sumsq1 += x * x;
+                    sum1 += x;
+                }
+                w1 += dim;
+                if (!infinite && t >= length) {
+                    for (int d = 0; d < dim; ++d) {
+                        const double r = (double)in[(s0 + t - length) * in_ld + d];
+                        sumsq1 -= r * r;
+                        sum1 -= r;
+                    }
+                    w1 -= dim;
+                }
+                if (refresh) {
+                    float sd = (float)sqrt((sumsq1 - sum1 * sum1 / w1) / w1);
+                    s_a      = (float)((double)(float)sum1 / w1);
+                    s_b      = sd == 0.f ? 1.f : sd;
+                }
+            }
+            else if (refresh) {
+                const int lo = infinite ? 0 : max(t - length + 1, 0);
+                float     mx = -3.402823466e+38f;
+                for (int u = lo; u <= t; ++u)
+                    mx = fmaxf(in[(s0 + u) * in_ld + level], mx);
+                s_a = mx;
+                s_b = 1.f;
+            }
+        }
+        __syncthreads();
+        if (emit_now)
+            apply(t - right);
+        __syncthreads();
+    }
+    for (int u = infinite ? 0 : max(n - right, 0); u < n; ++u)
+        apply(u);
+}
+
 __device__ __forceinline__ int segment_of(const long long* __restrict__ frame_off, int n_seg, long long t) {
     int lo = 0, hi = n_seg;
     while (hi - lo > 1) {
@@ -183,6 +270,34 @@ int amx_normalize_dev(amx_ctx* ctx, const amx_mfcc_plan* plan, const float* in_d
     AMX_HIP(hipSetDevice(ctx->device));
     amx::ScopedKernelTimer timer(ctx, "normalize");
     hipLaunchKernelGGL(amx::normalize_kernel, dim3(n_seg), dim3(64), 0, ctx->stream, in_dev, in_ld, d_off, dim, type, length, right, out_dev, out_ld);
+    AMX_HIP(hipGetLastError());
+    return AMX_OK;
+}
+
+int amx_normalize_ex_dev(amx_ctx* ctx, const amx_mfcc_plan* plan, const float* in_dev, int in_ld, int dim, int type, int level, int length,
+                         int right, float* out_dev, int out_ld) {
+    if (type == AMX_NORM_MEAN || type == AMX_NORM_MEAN_AND_VARIANCE)
+        return amx_normalize_dev(ctx, plan, in_dev, in_ld, dim, type, length, right, out_dev, out_ld);
+    AMX_REQUIRE(ctx && plan && in_dev && out_dev, AMX_ERR_INVALID, "amx_normalize_ex_dev: NULL argument");
+    AMX_REQUIRE(dim > 0 && in_ld >= dim && out_ld >= dim, AMX_ERR_INVALID, "amx_normalize_ex_dev: bad dimension / stride");
+    AMX_REQUIRE(type == AMX_NORM_DIVIDE_BY_MEAN || type == AMX_NORM_LEVEL || type == AMX_NORM_MEAN_AND_VARIANCE_1D, AMX_ERR_INVALID,
+                "amx_normalize_ex_dev: unknown type %d", type);
+    AMX_REQUIRE(type != AMX_NORM_LEVEL || (level >= 0 && level < dim), AMX_ERR_INVALID, "amx_normalize_ex_dev: level index %d outside the vector", level);
+    AMX_REQUIRE(length == 0 || (length > 0 && right >= 0 && right < length), AMX_ERR_INVALID,
+                "amx_normalize_ex_dev: Cannot initialize with parameters length (%d), right (%d)", length, right);
+    const long long* d_off;
+    int              n_seg;
+    long long        total;
+    int              r = amx_internal_plan_view(plan, &d_off, &n_seg, &total);
+    if (r != AMX_OK || total == 0)
+        return r;
+    const bool same_view = in_dev == out_dev && in_ld == out_ld;
+    AMX_REQUIRE(!views_alias(in_dev, in_ld, dim, out_dev, out_ld, dim, total) || (same_view && length == 0), AMX_ERR_INVALID,
+                "amx_normalize_ex_dev: input and output views overlap (in place is only supported for whole-segment normalisation)");
+    AMX_HIP(hipSetDevice(ctx->device));
+    amx::ScopedKernelTimer timer(ctx, "normalize");
+    hipLaunchKernelGGL(amx::normalize_misc_kernel, dim3(n_seg), dim3(64), 0, ctx->stream, in_dev, in_ld, d_off, dim, type, level, length, right,
+                       out_dev, out_ld);
     AMX_HIP(hipGetLastError());
     return AMX_OK;
 }

@@ -190,3 +190,58 @@ def test_overlapping_views_are_rejected(ctx):
     ctx.normalize(plan, src, 12, 12, src, 12, variance=True)                        # whole segment, in place
     torch.cuda.synchronize()
     assert torch.equal(src, ref)
+
+
+# ------------------------------------------------------------------ the node's other types: divide-by-mean, level, mean-and-variance-1D
+def test_oracle_other_normalisation_types_against_definitions():
+    from oracle.binding import oracle_normalize_ex
+    x = np.abs(seg(300, 6, 21)) + 1
+    got = oracle_normalize_ex(x, 2)                                     # divide-by-mean, whole segment
+    assert np.allclose(got, x / (x.astype(np.float64).sum(0) / len(x)).astype(np.float32), rtol=1e-6)
+    got = oracle_normalize_ex(x, 3, level=2)                            # level: component 2 minus its maximum, rest untouched
+    want = x.copy()
+    want[:, 2] -= x[:, 2].max()
+    assert np.array_equal(got, want) and got[:, 2].max() == 0
+    got = oracle_normalize_ex(x, 4)                                     # one mean / deviation over everything
+    flat = x.astype(np.float64)
+    assert np.allclose(got, (x - np.float32(flat.mean())) / np.float32(flat.std()), rtol=1e-5, atol=1e-6)
+    L, R, n = 11, 4, 40                                                 # sliding level: max over the frames [u + R - L + 1, u + R]
+    got = oracle_normalize_ex(x[:n], 3, level=0, length=L, right=R)
+    for u in range(n):
+        hi = min(u + R, n - 1)
+        lo = max(0, hi - L + 1)
+        assert got[u, 0] == np.float32(x[u, 0] - x[lo:hi + 1, 0].max()), u
+    const = np.full((5, 3), 2.0, np.float32)
+    assert np.array_equal(oracle_normalize_ex(const, 4), np.zeros((5, 3), np.float32))      # zero deviation -> 1
+
+
+@pytest.mark.gpu
+def test_other_normalisation_types_match_the_oracle(ctx):
+    import torch
+
+    from oracle.binding import oracle_normalize_ex
+    lens = [1, 2, 5, 9, 64, 333, 7]
+    plan = _plan(ctx, lens)
+    F, dim, ld = sum(lens), 13, 20
+    x = np.zeros((F, ld), np.float32)
+    x[:, 3:3 + dim] = np.abs(seg(F, dim, 31)) + 0.5
+    xd = torch.from_numpy(x).cuda()
+    ctx.use_torch_stream()
+    off = np.concatenate([[0], np.cumsum(lens)])
+    for type_, level in ((2, 0), (3, 0), (3, 12), (4, 0)):
+        for length, right in ((0, 0), (21, 10), (5, 0), (9, 8)):
+            out = torch.full((F, 16), 7.0, dtype=torch.float32, device="cuda")
+            ctx.normalize_ex(plan, xd[:, 3:], ld, dim, out[:, 1:], 16, type_, level=level, length=length, right=right)
+            torch.cuda.synchronize()
+            got = out.cpu().numpy()
+            assert np.all(got[:, 0] == 7.0) and np.all(got[:, 1 + dim:] == 7.0)
+            for i in range(len(lens)):
+                s = x[off[i]:off[i + 1], 3:3 + dim]
+                want = oracle_normalize_ex(s, type_, level=level, length=length, right=right)
+                assert np.array_equal(got[off[i]:off[i + 1], 1:1 + dim].view(np.uint32), want.view(np.uint32)), (type_, level, length, right, i)
+    import rasr_amd
+    out = torch.zeros((F, dim), dtype=torch.float32, device="cuda")
+    with pytest.raises(rasr_amd.AmxError, match="level index"):
+        ctx.normalize_ex(plan, xd[:, 3:], ld, dim, out, dim, 3, level=dim)
+    with pytest.raises(rasr_amd.AmxError, match="unknown type"):
+        ctx.normalize_ex(plan, xd[:, 3:], ld, dim, out, dim, 9)

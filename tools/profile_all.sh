@@ -1,43 +1,57 @@
 #!/bin/bash
-# tools/profile_all.sh -- regenerates the artefacts under profiles/rNN on a GPU box:
-#   <workload>_bench.log          the bench.py JSON line (default workload: with cpu_baseline)
+# tools/profile_all.sh <round> -- regenerates the artefacts under profiles/<round> on a GPU box:
+#   <workload>_bench.log          the bench.py JSON line (pipeline = the default run, with cpu_baseline and the secondary configs)
 #   <workload>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary of the same command
-#   ceilings.json                 measured HBM / MFMA / VALU ceilings of the box (tools/ceilings.hip)
-#   pmc/<workload>_{fetch,write}.txt   FETCH_SIZE / WRITE_SIZE per kernel, separate --pmc passes (kernel-trace only)
-# usage (through gpurun):  tools/profile_all.sh r01 ; results land in gpurun_out/<round>/ -> copy to profiles/<round>/
-round=${1:-r01}
+#   pmc/*.txt                     separate --pmc passes (kernel-trace only): FETCH_SIZE / WRITE_SIZE, SQ counters, MFMA counters
+#   force_dist_bench.log          the default workload with the RCCL path forced on (world size 1)
+#   gemm_comparator.json          torch (hipBLASLt / rocBLAS) bf16 GEMM of the output-layer shape on the same box: measurement only
+# usage (through gpurun):  tools/profile_all.sh r02 ; results land in gpurun_out/<round>/ -> copy to profiles/<round>/
+round=${1:-r02}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/$round
 mkdir -p $out/pmc
 cd /tmp && export TMPDIR=/tmp
 run_stats() {  # name, bench args...
     name=$1; shift
-    python $root/bench.py "$@" --no-cpu-baseline > /dev/null 2>&1   # warm the box / caches
     python $root/bench.py "$@" 2>/dev/null | tail -1 > $out/${name}_bench.log
     rm -rf /tmp/prof_$name
-    rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$name -- python $root/bench.py "$@" --no-cpu-baseline > /tmp/prof_$name.log 2>&1
+    rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$name -- python $root/bench.py "$@" --no-cpu-baseline --no-configs > /tmp/prof_$name.log 2>&1
     f=$(find /tmp/prof_$name -name "*kernel_stats.csv" | head -1)
     [ -n "$f" ] && cp $f $out/${name}_kernel_stats.csv
 }
-run_pmc() {  # name, counter, suffix, bench args...
-    name=$1; ctr=$2; suf=$3; shift 3
+run_pmc() {  # name, suffix, counters..., -- bench args...
+    name=$1; suf=$2; shift 2
+    ctrs=()
+    while [ "$1" != "--" ]; do ctrs+=("$1"); shift; done
+    shift
     rm -rf /tmp/pmc_${name}_$suf
-    rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d /tmp/pmc_${name}_$suf -- python $root/bench.py "$@" --no-cpu-baseline > /tmp/pmc_${name}_$suf.log 2>&1
+    rocprofv3 --kernel-trace --pmc "${ctrs[@]}" --output-format csv -d /tmp/pmc_${name}_$suf -- python $root/bench.py "$@" --no-cpu-baseline --no-configs > /tmp/pmc_${name}_$suf.log 2>&1
     f=$(find /tmp/pmc_${name}_$suf -name "*counter_collection.csv" | head -1)
     [ -n "$f" ] && python $root/tools/pmc_summary.py $f > $out/pmc/${name}_$suf.txt
 }
-[ -x $root/tools/build/ceilings ] && $root/tools/build/ceilings > $out/ceilings.json   # tools/build_probe.sh builds it
+python $root/bench.py --no-cpu-baseline --no-configs > /dev/null 2>&1   # warm the box / caches
 run_stats pipeline --steps 8 --warmup 2
+run_stats pipeline-bf16x3 --precision bf16x3 --steps 4 --warmup 1 --no-cpu-baseline --no-configs
 run_stats nn-pipeline --workload nn-pipeline --steps 8 --warmup 2 --no-cpu-baseline
-run_stats mfcc --workload mfcc --steps 8 --warmup 2 --no-cpu-baseline
-run_stats mfplp --workload mfcc --front-end mfplp --steps 8 --warmup 2 --no-cpu-baseline
-run_stats gmm --workload gmm --steps 50 --warmup 5 --no-cpu-baseline
-run_stats gmm-simd --workload gmm --gmm-type SIMD-diagonal-maximum --gmm-frames 65536 --steps 20 --warmup 3 --no-cpu-baseline
-run_stats gmm-tied --workload gmm-tied --steps 20 --warmup 3 --no-cpu-baseline
+run_stats nn-pipeline-bf16x3 --workload nn-pipeline --precision bf16x3 --steps 4 --warmup 1 --no-cpu-baseline
+run_stats nn-pipeline-fp32 --workload nn-pipeline --precision fp32 --steps 3 --warmup 1 --no-cpu-baseline
 run_stats gmm-train --workload gmm-train --steps 5 --warmup 2 --no-cpu-baseline
+run_stats mfcc --workload mfcc --steps 8 --warmup 2 --no-cpu-baseline
+run_stats gmm --workload gmm --steps 50 --warmup 5 --no-cpu-baseline
+run_stats gmm-tied --workload gmm-tied --steps 20 --warmup 3
 run_stats nn --workload nn --steps 50 --warmup 5 --no-cpu-baseline
-run_pmc pipeline FETCH_SIZE fetch --steps 3 --warmup 1
-run_pmc pipeline WRITE_SIZE write --steps 3 --warmup 1
-run_pmc mfcc FETCH_SIZE fetch --workload mfcc --steps 3 --warmup 1
-run_pmc mfcc WRITE_SIZE write --workload mfcc --steps 3 --warmup 1
+run_stats nn-bf16x3 --workload nn --precision bf16x3 --steps 30 --warmup 5 --no-cpu-baseline
+run_pmc pipeline fetch FETCH_SIZE -- --steps 3 --warmup 1
+run_pmc pipeline write WRITE_SIZE -- --steps 3 --warmup 1
+run_pmc mfcc fetch FETCH_SIZE -- --workload mfcc --steps 3 --warmup 1
+run_pmc mfcc write WRITE_SIZE -- --workload mfcc --steps 3 --warmup 1
+run_pmc nn-pipeline mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_MFMA -- --workload nn-pipeline --steps 3 --warmup 1
+run_pmc gmm-train sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES -- --workload gmm-train --steps 3 --warmup 1
+run_pmc gmm-train sq2 SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD -- --workload gmm-train --steps 3 --warmup 1
+run_pmc gmm-tied sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_LDS -- --workload gmm-tied --steps 5 --warmup 2
+AMX_BENCH_FORCE_DIST=1 python $root/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-configs 2>/dev/null | grep "^{\"metric\"" | tail -1 > $out/force_dist_bench.log
+python $root/tools/gemm_comparator.py > $out/gemm_comparator.json 2>/dev/null
+[ -x $root/tools/build/valu_rates ] && $root/tools/build/valu_rates > $out/valu_rates.log 2>&1
+[ -x $root/tools/build/ceilings ] && $root/tools/build/ceilings > $out/ceilings.json 2>/dev/null
+python $root/tools/traffic_json.py $out > $out/traffic.json 2>/dev/null
 ls -la $out $out/pmc

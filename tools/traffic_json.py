@@ -1,0 +1,28 @@
+"""profiles/<round>/traffic.json from the FETCH_SIZE / WRITE_SIZE passes: HBM-side bytes per launch and kernel.
+FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950 (128-byte requests tallied at 64 bytes); both counters are in KiB."""
+import json
+import os
+import re
+import sys
+
+out = sys.argv[1]
+res = {}
+for wl in ("pipeline", "mfcc"):
+    vals = {}
+    for suf, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+        p = os.path.join(out, "pmc", "%s_%s.txt" % (wl, suf))
+        if not os.path.exists(p):
+            continue
+        kernel = None
+        for line in open(p):
+            m = re.match(r"(\S.*) dispatches (\d+)", line)
+            if m:
+                kernel = m.group(1)
+                continue
+            m = re.match(r"\s+%s\s+\S+\s+\(per dispatch ([0-9.e+]+)\)" % ctr, line)
+            if m and kernel:
+                vals.setdefault(kernel, {})[suf] = float(m.group(1)) * 1024.0
+    for k, v in vals.items():
+        f, w = v.get("fetch", 0.0) * 2.0, v.get("write", 0.0)
+        res["%s | %s" % (wl, k)] = dict(fetch_bytes=f, write_bytes=w, traffic=f + w)
+print(json.dumps(res, indent=1))
