@@ -202,8 +202,9 @@ typedef struct {
  * first minimum, score = 0.5 * min / scaling^2; assigns densities; ignores the two scales like the reference class) /
  * batch-diagonal-maximum-int and -fast (Mm::BatchIntFeatureScorer / BatchUnrolledIntFeatureScorer, Mm/BatchFeatureScorer.cc:375-504:
  * the same u8 quantisation and integer distance, pooled covariance only, constant (s32)(logNorm scale^2 - 2 scale^2 logWeight) formed
- * in f64, score = (f32)min / (2 scale^2) in f32, no best-density output) */
-enum { AMX_GMM_MAX = 0, AMX_GMM_SUM = 1, AMX_GMM_BATCH_FLOAT = 2, AMX_GMM_SIMD = 3, AMX_GMM_BATCH_INT = 4 };
+ * in f64, score = (f32)min / (2 scale^2) in f32, no best-density output) /
+ * preselection-batch-float (see amx_gmm_set_preselection below; pooled covariance only, no best-density output) */
+enum { AMX_GMM_MAX = 0, AMX_GMM_SUM = 1, AMX_GMM_BATCH_FLOAT = 2, AMX_GMM_SIMD = 3, AMX_GMM_BATCH_INT = 4, AMX_GMM_PRESELECTION_FLOAT = 5 };
 
 int  amx_gmm_create(amx_ctx* ctx, const amx_gmm_model* model, amx_gmm** out); /* copies everything */
 void amx_gmm_destroy(amx_gmm* h);
@@ -215,6 +216,15 @@ int amx_gmm_tables(const amx_gmm* h, float* minus2_log_weights, float* inv_sqrt_
 /* quantisation scaling factor of the SIMD-diagonal-maximum scorer (SimdGaussDiagonalMaximumFeatureScorer::getScaling,
  * logged as "Scaling factor"); 0 for a host-only handle */
 float amx_gmm_simd_scaling(const amx_gmm* h);
+/* preselection-batch-float (Mm::BatchPreselectionFloatFeatureScorer, Mm/BatchFeatureScorer.cc:256-318 with
+ * Mm::FloatDensityClustering, Mm/DensityClustering.cc / .tcc): batch-diagonal-maximum-float restricted, per frame, to the densities
+ * of the `select_clusters` clusters closest to the scaled feature; k-means over the pre-scaled density means (`clusters`
+ * clusters, initial clusters drawn with srand(1) / rand(), `iterations` rounds); a mixture without an active density scores
+ * `backoff_score`.  Defaults (the reference's): 256 / 32 / 5 / 40000.  The clustering is built on the first preselection call
+ * (or amx_gmm_preselection_clustering) and rebuilt after amx_gmm_set_preselection.  amx_gmm_preselection_clustering returns
+ * it: cluster_of [sum K_m] (cluster of every mixture entry), cluster_means [n_clusters x dim]; any pointer may be NULL. */
+int amx_gmm_set_preselection(amx_gmm* h, int clusters, int select_clusters, int iterations, float backoff_score);
+int amx_gmm_preselection_clustering(amx_gmm* h, int* n_clusters, uint32_t* cluster_of, float* cluster_means);
 /* Diagnostics of the screened diagonal-maximum scorer (no reference counterpart; bench.py prints survivors per mixture):
  * returns and clears the number of densities evaluated exactly and the number of (frame, mixture) pairs scored since the
  * last call, and switches the counting on (enable != 0) or off for the following calls.  Synchronises the stream.  Zero for

@@ -1472,6 +1472,12 @@ struct amx_gmm {
     std::vector<double> h_logw;
     float     mws = 1.f, gsc = 1.f;
     int       simd_status = 0;       // 0 = not built yet, 1 = built, < 0 = amx_status of the failed build
+    // preselection-batch-float (gmm_presel.hip): density clustering, built on first use / when its parameters change
+    void*     presel = nullptr;
+    int       presel_clusters = 256, presel_select = 32, presel_iterations = 5;  // Mm/DensityClustering.cc:21-35 defaults
+    float     presel_backoff = 40000.f;
+    std::vector<uint32_t> h_k_mean;
+    std::vector<float>    h_smeans;
     // small-batch passes of the screened scorer on unchanged device buffers (the decoder's ring buffer), replayed as HIP graphs
     struct GraphKey {
         const void *feats, *scores, *best;
@@ -1510,6 +1516,14 @@ bool screen_dim_supported(int d) {
     }
 }
 
+extern "C" int   amx_internal_gmm_presel_create(amx_ctx* ctx, int dim, size_t nk, const uint32_t* k_mean_host, const float* smeans_host,
+                                                const float* d_smeans, const uint32_t* d_k_mean, int n_clusters, int n_select, int iterations,
+                                                float backoff, void** out);
+extern "C" void  amx_internal_gmm_presel_destroy(void* p);
+extern "C" int   amx_internal_gmm_presel_info(const void* p, int* n_clusters, uint32_t* cluster_of, float* cluster_means);
+extern "C" int   amx_internal_gmm_presel_score(void* p, amx_ctx* ctx, const float* feats_dev, int T, float* scores_dev, const uint32_t* d_mix_off,
+                                               const uint32_t* d_k_mean, const float* d_k_const, const float* d_smeans, const float* d_isr0,
+                                               int n_mix);
 extern "C" int   amx_internal_gmm_simd_create(const amx_gmm_model* m, void** out, float* scaling_out);
 extern "C" void  amx_internal_gmm_simd_destroy(void* p);
 extern "C" float amx_internal_gmm_simd_scaling(const void* p);
@@ -1878,6 +1892,8 @@ int amx_gmm_create(amx_ctx* ctx, const amx_gmm_model* m, amx_gmm** out) {
                 smeans[(size_t)j * m->dim + i] = m->means[(size_t)j * m->dim + i] * isr0[i];
         for (size_t k = 0; k < nk; ++k)
             kc[k] = (float)((double)ln - 2 * m->log_weight[k]);
+        h->h_smeans = smeans;  // host copies for the density clustering of preselection-batch-float
+        h->h_k_mean = k_mean;
         if ((r = gupload(&h->d_isr0, isr0.data(), isr0.size())) != AMX_OK || (r = gupload(&h->d_smeans, smeans.data(), smeans.size())) != AMX_OK ||
             (r = gupload(&h->d_k_const, kc.data(), kc.size())) != AMX_OK) {
             amx_gmm_destroy(h);
@@ -2038,6 +2054,7 @@ void amx_gmm_destroy(amx_gmm* h) {
         if (kv.second)
             hipGraphExecDestroy(kv.second);
     amx_internal_gmm_simd_destroy(h->simd);
+    amx_internal_gmm_presel_destroy(h->presel);
     hipFree(h->d_mix_off);
     hipFree(h->d_k_mean);
     hipFree(h->d_k_cov);
@@ -2128,7 +2145,8 @@ static int ensure_simd(amx_gmm* h) {
 int amx_gmm_score_dev(amx_gmm* h, int mode, const float* feats_dev, int T, float* scores_dev, uint32_t* best_dev) {
     AMX_REQUIRE(h, AMX_ERR_INVALID, "amx_gmm_score_dev: NULL handle");
     AMX_REQUIRE(h->ctx, AMX_ERR_STATE, "amx_gmm_score_dev: host-only handle (created without a context)");
-    AMX_REQUIRE(mode == AMX_GMM_MAX || mode == AMX_GMM_SUM || mode == AMX_GMM_BATCH_FLOAT || mode == AMX_GMM_SIMD || mode == AMX_GMM_BATCH_INT,
+    AMX_REQUIRE(mode == AMX_GMM_MAX || mode == AMX_GMM_SUM || mode == AMX_GMM_BATCH_FLOAT || mode == AMX_GMM_SIMD || mode == AMX_GMM_BATCH_INT ||
+                        mode == AMX_GMM_PRESELECTION_FLOAT,
                 AMX_ERR_INVALID,
                 "amx_gmm_score_dev: unknown mode %d", mode);
     AMX_REQUIRE(T >= 0, AMX_ERR_INVALID, "amx_gmm_score_dev: negative frame count");
@@ -2147,6 +2165,18 @@ int amx_gmm_score_dev(amx_gmm* h, int mode, const float* feats_dev, int T, float
     if (mode == AMX_GMM_BATCH_INT) {
         AMX_REQUIRE(best_dev == nullptr, AMX_ERR_UNSUPPORTED, "amx_gmm_score_dev: batch-diagonal-maximum-int does not assign densities");
         return amx_internal_gmm_simd_score(h->simd, h->ctx, 1, feats_dev, T, scores_dev, nullptr);
+    }
+    if (mode == AMX_GMM_PRESELECTION_FLOAT) {
+        AMX_REQUIRE(h->pooled, AMX_ERR_INVALID, "amx_gmm_score_dev: feature scorer supports only globally pooled covariance");
+        AMX_REQUIRE(best_dev == nullptr, AMX_ERR_UNSUPPORTED, "amx_gmm_score_dev: preselection-batch-float does not assign densities");
+        if (!h->presel) {
+            const int r = amx_internal_gmm_presel_create(h->ctx, h->dim, h->nk, h->h_k_mean.data(), h->h_smeans.data(), h->d_smeans, h->d_k_mean,
+                                                         h->presel_clusters, h->presel_select, h->presel_iterations, h->presel_backoff, &h->presel);
+            if (r != AMX_OK)
+                return r;
+        }
+        return amx_internal_gmm_presel_score(h->presel, h->ctx, feats_dev, T, scores_dev, h->d_mix_off, h->d_k_mean, h->d_k_const, h->d_smeans,
+                                             h->d_isr0, h->n_mix);
     }
     if (mode == AMX_GMM_BATCH_FLOAT) {
         // Mm::BatchFloatFeatureScorer::init: criticalError("feature scorer supports only globally pooled covariance")
@@ -2386,6 +2416,32 @@ int amx_gmm_screen_counts(amx_gmm* h, int enable, unsigned long long* survivors,
     h->fus_pairs       = 0;
     h->count_survivors = enable != 0;
     return AMX_OK;
+}
+
+int amx_gmm_set_preselection(amx_gmm* h, int clusters, int select_clusters, int iterations, float backoff_score) {
+    AMX_REQUIRE(h, AMX_ERR_INVALID, "amx_gmm_set_preselection: NULL handle");
+    AMX_REQUIRE(clusters >= 1 && clusters <= 256 && select_clusters >= 1 && select_clusters <= 256 && iterations >= 0, AMX_ERR_INVALID,
+                "amx_gmm_set_preselection: clusters and select-clusters must be in 1..256");
+    amx_internal_gmm_presel_destroy(h->presel);  // rebuilt with the new parameters on the next preselection call
+    h->presel            = nullptr;
+    h->presel_clusters   = clusters;
+    h->presel_select     = select_clusters;
+    h->presel_iterations = iterations;
+    h->presel_backoff    = backoff_score;
+    return AMX_OK;
+}
+
+int amx_gmm_preselection_clustering(amx_gmm* h, int* n_clusters, uint32_t* cluster_of, float* cluster_means) {
+    AMX_REQUIRE(h && h->ctx, AMX_ERR_INVALID, "amx_gmm_preselection_clustering: NULL / host-only handle");
+    AMX_REQUIRE(h->pooled, AMX_ERR_INVALID, "amx_gmm_preselection_clustering: feature scorer supports only globally pooled covariance");
+    if (!h->presel) {
+        AMX_HIP(hipSetDevice(h->ctx->device));
+        const int r = amx_internal_gmm_presel_create(h->ctx, h->dim, h->nk, h->h_k_mean.data(), h->h_smeans.data(), h->d_smeans, h->d_k_mean,
+                                                     h->presel_clusters, h->presel_select, h->presel_iterations, h->presel_backoff, &h->presel);
+        if (r != AMX_OK)
+            return r;
+    }
+    return amx_internal_gmm_presel_info(h->presel, n_clusters, cluster_of, cluster_means);
 }
 
 float amx_gmm_simd_scaling(const amx_gmm* h) {

@@ -805,3 +805,44 @@ def test_fused_small_batch_splits_the_model(ctx):
     assert np.array_equal(bestd.cpu().numpy()[sel].astype(np.uint32), obest)
     assert np.array_equal(state.cpu().numpy(), got.argmin(axis=1))
     assert int(counts.sum().item()) == T
+
+
+# ---- preselection-batch-float (Mm::BatchPreselectionFloatFeatureScorer + Mm::FloatDensityClustering)
+
+@pytest.mark.parametrize("n_mix,kmax,dim,clusters,select", [(50, 8, 24, 16, 4), (300, 16, 40, 256, 32), (20, 3, 40, 256, 32), (64, 4, 33, 8, 8)])
+def test_preselection_batch_float_exact(ctx, n_mix, kmax, dim, clusters, select):
+    """clustering (glibc rand() initialisation restated in the product vs libc's in the oracle, k-means assignment on the GPU vs
+    the oracle's loops) and the preselected scores bit-exact against the oracle; mixtures without an active density score the
+    back-off score; selecting every cluster reproduces batch-diagonal-maximum-float; fewer densities than clusters reduces the
+    cluster count like the reference"""
+    import rasr_amd
+    from oracle import OracleGmm
+    model = synth.gmm_cart(n_mix, 1, kmax, dim, seed=500 + n_mix, pooled=True)
+    x = feats(333, dim, 501)
+    sc = rasr_amd.GmmFeatureScorer(ctx, model, feature_scorer_type="preselection-batch-float")
+    sc.set_preselection(clusters, select, 5, 40000.0)
+    got = sc.score(x, want_best=False)
+    want, wcof, wcm = OracleGmm(model).score_preselection_float(x, clusters, select, 5, 40000.0)
+    cof, cm = sc.preselection_clustering()
+    assert cm.shape[0] == wcm.shape[0] == min(clusters, len(wcof))
+    assert np.array_equal(cof, wcof)
+    assert np.array_equal(cm.view(np.uint32), wcm[:, :dim].view(np.uint32))
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), np.abs(got - want).max()
+    if select < cm.shape[0]:
+        assert (got == 40000.0).any()
+    sc.set_preselection(clusters, min(clusters, len(wcof)), 5, 123.0)          # all clusters active: plain batch-float scores
+    full = rasr_amd.GmmFeatureScorer(ctx, model, feature_scorer_type="batch-diagonal-maximum-float").score(x, want_best=False)
+    assert np.array_equal(sc.score(x, want_best=False).view(np.uint32), full.view(np.uint32))
+
+
+def test_preselection_errors(ctx):
+    import rasr_amd
+    sc = rasr_amd.GmmFeatureScorer(ctx, synth.gmm_cart(10, 2, 4, 40, seed=9, pooled=False), feature_scorer_type="preselection-batch-float")
+    with pytest.raises(rasr_amd.AmxError, match="pooled covariance"):
+        sc.score(feats(3, 40, 1), want_best=False)
+    sc = rasr_amd.GmmFeatureScorer(ctx, synth.gmm_cart(10, 2, 4, 40, seed=9, pooled=True), feature_scorer_type="preselection-batch-float")
+    sc.set_preselection(8, 16)
+    with pytest.raises(rasr_amd.AmxError, match="select-clusters"):
+        sc.score(feats(3, 40, 1), want_best=False)
+    with pytest.raises(rasr_amd.AmxError):
+        sc.set_preselection(300, 16)
