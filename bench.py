@@ -32,12 +32,15 @@ MFMA_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak
 FP32_TFLOPS = 157.3        # f32 vector (= f32 MFMA) peak
 
 
-def measured_traffic(key):
-    """HBM bytes per launch measured offline with rocprofv3 --pmc (profiles/r01/traffic.json), or None"""
+def measured_traffic(workload, *needles):
+    """HBM bytes per launch measured offline in separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the `workload` bench
+    (profiles/r02/traffic.json, keys "workload | kernel name"; FETCH doubled for gfx950 by tools/traffic_json.py), or None when no
+    entry of that workload names every needle (a different launch shape than the profiled one gets None, not a stale figure)"""
     try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "r01", "traffic.json")))
+        t = json.load(open(os.path.join(ROOT, "profiles", "r02", "traffic.json")))
         for k, v in t.items():
-            if k.startswith(key):
+            w, _, name = k.partition(" | ")
+            if w == workload and all(n in name for n in needles):
                 return v["traffic"]
     except Exception:
         pass
@@ -129,7 +132,7 @@ def gmm_cart_roofline(ctx, sc, nk, n_mix, dim, frames):
                     note="VALU-bound kernel priced against the f32 vector peak (= f32 MFMA peak, 157.3 TFLOP/s; unfused mul/add can "
                          "reach half of it). achieved = densities evaluated exactly (device counter) x 4 dim f32 operations / kernel time",
                     achieved=round(ex / t / 1e12, 2), peak=FP32_TFLOPS, unit="TFLOP/s", frac=round(ex / t / 1e12 / FP32_TFLOPS, 4),
-                    traffic=measured_traffic("gmm_fused_kernel<%d> (%d mixtures, %d frames)" % (dim, n_mix, frames)),
+                    traffic=measured_traffic("pipeline", "gmm_fused_kernel", "Li%dE" % dim) if (n_mix == 10000 and frames == 63936) else None,
                     avg_launch_ms=round(ms_x, 4), pack_launch_ms=round(ms_p, 4), launches=n_x, flops_per_launch=ex,
                     survivors_per_mixture=round(surv / float(pairs), 4),
                     screen_mfma_tflops=round(scr / t / 1e12, 1), screen_mfma_frac=round(scr / t / 1e12 / MFMA_BF16_TFLOPS, 4),
@@ -147,7 +150,7 @@ def gmm_cart_roofline(ctx, sc, nk, n_mix, dim, frames):
     by = frames * (n_mix * 8.0 + ((n_mix + 15) // 16 * 16) * 2.0 + dim * 4.0)
     return dict(bound="hbm", kernel="gmm_screen_exact_kernel<%d> (+ gmm_screen_rows_kernel, gmm_screen_pack_kernel)" % dim,
                 achieved=round(by / t / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(by / t / 1e9 / HBM_PEAK_GBS, 4),
-                traffic=measured_traffic("gmm_screen_exact_kernel<40,pooled> (10000 x 16 densities, %d frames)" % frames),
+                traffic=None,
                 avg_launch_ms=round(ms_x, 4), screen_launch_ms=round(ms_s, 4), pack_launch_ms=round(ms_p, 4), launches=n_x,
                 bytes_per_launch=by, algorithmic_speedup_vs_dense=round(alg / ((ms_x + ms_s + ms_p) * 1e-3) / 1e12 / FP32_TFLOPS, 3))
 
@@ -162,7 +165,7 @@ def nn_gemm_roofline(precision, ms, n, frames, full_chunk):
     name = {"bf16": "gemm_bf16_pipe_kernel<NONE,LAST> (2048->10000)", "bf16x3": "gemm_bf16_pipe_kernel<NONE,LAST> (2048->10000, split bf16: K = 3 x 2048)",
             "fp32": "gemm_f32_kernel (2048->10000)"}[precision]
     out = dict(bound="mfma", kernel=name, achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
-               traffic=measured_traffic("gemm_bf16_pipe_kernel<GemmCfg<256,256,2,4,2>,NONE,LAST>") if (precision == "bf16" and full_chunk) else None,
+               traffic=measured_traffic("pipeline", "gemm_bf16_pipe_kernel", "GemmCfg<256, 256, 2, 4, 2, 64>, 0") if (precision == "bf16" and full_chunk) else None,
                avg_launch_ms=round(ms, 4), launches=n, flops_per_launch=mult * alg)
     if mult != 1.0:
         out["algorithmic_tflops"] = round(alg / (ms * 1e-3) / 1e12, 2)
@@ -421,7 +424,7 @@ class MfccOnly:
         gbs = self.F * per_frame / ((ms + lp) * 1e-3) / 1e9
         return dict(bound="hbm", kernel="mfcc_kernel<256>" + (" + lpc_cepstrum_kernel" if self.plp else ""), achieved=round(gbs, 1),
                     peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4),
-                    traffic=None if self.plp else measured_traffic("mfcc_kernel<256>"), avg_launch_ms=round(ms + lp, 4),
+                    traffic=None if self.plp else measured_traffic("mfcc", "mfcc_kernel<256>"), avg_launch_ms=round(ms + lp, 4),
                     launches=n, bytes_per_launch=self.F * per_frame)
 
     def stage_report(self):

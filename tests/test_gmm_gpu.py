@@ -723,6 +723,75 @@ def test_tied_non_finite_frames_keep_the_initial_result(ctx, pooled):
 
 # ---- gmm_fused_kernel (gmm_fused.hip): screen + exact evaluation in one kernel, pooled covariance, dim <= 40
 
+def _screen_worst_case(dim, n_mix, seed):
+    """Model and frames that drive the f16 screen's error towards its analytic bound.
+
+    Variance 1, so the screen operand of a density is a = -2 mu and the frame operand is x itself.  Frame m and mixture m belong
+    together: every |x_i| and every |a_i| sits 0.49 ulp(f16) off an f16 grid point just above 1.0 (the largest RELATIVE rounding
+    error f16 has), all with the same magnitude (Cauchy-Schwarz, which the bound uses, is then tight).  Density A = slot sa has
+    a_i = +(1 + (k_i + 0.49 t_i) 2^-10), density B = slot sb is its mirror image -A, t_i = sign(x_i), so that
+      * A's operand rounds so that its estimate falls by sum 0.49 * 2^-10 |x_i|, B's so that it rises by as much,
+      * the frame operand's own rounding error (-0.49 * 2^-10 per component) is multiplied by a_B - a_A ~ -2: it raises B's
+        estimate relative to A's once more, by twice that amount,
+    i.e. all four error terms of the difference point the same way: B looks 40 * 1.96 * 2^-10 ~ 0.077 worse than A to the screen
+    (the bound tau ~ 2.2e-3 * |a| * |x| ~ 0.088 has to cover exactly this), while the mixture weights are set so that B's TRUE score
+    is the smaller one by 1e-3.  A screen that drops B returns the wrong score and the wrong density."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    model = synth.gmm_cart(n_mix, 16, 16, dim, seed=seed, pooled=True)
+    model["variances"][:] = 1.0
+    model["means"] += 12.0                      # every other slot: far away
+    u = 2.0 ** -10
+    T = n_mix
+    t = rng.choice(np.array([-1.0, 1.0]), (T, dim))
+    j = rng.integers(1, 24, (T, dim))
+    x = (t * (1.0 + (j + 0.49 * t) * u)).astype(np.float32)          # x_hat - x = -0.49 u for either sign of x
+    lw = model["log_weight"]
+    slots = []
+    for m in range(n_mix):
+        k = rng.integers(1, 24, dim)
+        a_A = 1.0 + (k + 0.49 * t[m]) * u                            # a_hat_A - a_A = -0.49 u t
+        mu_A = (-0.5 * a_A).astype(np.float32)
+        mu_B = -mu_A                                                  # a_B = -a_A: a_hat_B - a_B = +0.49 u t
+        sa, sb = (0, 15) if rng.integers(0, 2) else (15, 0)
+        base = 16 * m
+        model["means"][base + sa] = mu_A
+        model["means"][base + sb] = mu_B
+        xd = x[m].astype(np.float64)
+        d_A = ((mu_A.astype(np.float64) - xd) ** 2).sum()
+        d_B = ((mu_B.astype(np.float64) - xd) ** 2).sum()
+        lw[base + sa] = -3.0
+        lw[base + sb] = -3.0 + 0.5 * (d_B - d_A + 2.0e-3)            # -2 lw_B + d_B = -2 lw_A + d_A - 2e-3 (scores are halved)
+        slots.append((sa, sb))
+    return model, x, slots
+
+
+@pytest.mark.parametrize("fused", ["1", "0"])
+@pytest.mark.parametrize("dim", [40, 24])
+def test_screen_threshold_worst_case_model(ctx, monkeypatch, dim, fused):
+    """the constructed worst case for the f16 screen (all rounding errors aligned against the true winner) is scored bit-exactly
+    by the fused kernel and by the two-kernel path, and the construction really has the disadvantaged density win"""
+    import rasr_amd
+    from oracle import OracleGmm
+    monkeypatch.setenv("AMX_GMM_FUSED", fused)
+    n_mix = 96
+    model, x, slots = _screen_worst_case(dim, n_mix, 900 + dim)
+    # what the screen sees: f16-rounded operands, difference of the two dot products against the true difference
+    a16 = (-2.0 * model["means"]).astype(np.float16).astype(np.float64)
+    x16 = x.astype(np.float16).astype(np.float64)
+    worst = np.inf
+    for m, (sa, sb) in enumerate(slots):
+        est = (a16[16 * m + sb] - a16[16 * m + sa]) @ x16[m]
+        true = (-2.0 * (model["means"][16 * m + sb].astype(np.float64) - model["means"][16 * m + sa].astype(np.float64))) @ x[m].astype(np.float64)
+        worst = min(worst, est - true)
+    assert worst > 1.9 * 2.0 ** -10 * dim                            # every pair: all four error terms aligned, ~1.96 * 2^-10 per dimension (86 % of tau)
+    osc, obest = OracleGmm(model).score(x, mode=0)
+    won = sum(int(obest[m, m]) == sb for m, (sa, sb) in enumerate(slots))
+    assert won == n_mix, won                                          # B is the reference's winner on its frame
+    sc, best = rasr_amd.GmmFeatureScorer(ctx, model).score(x)
+    assert np.array_equal(sc.view(np.uint32), osc.view(np.uint32)), np.abs(sc - osc).max()
+    assert np.array_equal(best, obest)
+
+
 @pytest.mark.parametrize("n_mix,T", [(1, 1), (7, 31), (16, 33), (17, 256), (45, 257), (48, 1000), (333, 700), (1000, 64)])
 def test_fused_shapes_exact(ctx, n_mix, T):
     """mixture counts around the 16-mixture tile (partial last tile, n_mix % 4 != 0 -> scalar store path) and frame counts around
