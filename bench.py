@@ -60,8 +60,9 @@ def parse():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x3", "fp32"],
                     help="NN GEMM inputs: bf16 (BASELINE config 4), bf16x3 = split bf16, three MFMA products per f32 product (meets the "
                          "1e-4 bar of the f32 reference), fp32 = f32 MFMA")
-    ap.add_argument("--front-end", default="mfcc", choices=["mfcc", "mfplp"],
-                    help="mfcc workload: mfcc.flow (40 cepstra) or mfplp.flow (20 autocorrelation / 16 cepstrum coefficients)")
+    ap.add_argument("--front-end", default="mfcc", choices=["mfcc", "mfplp", "plp"],
+                    help="mfcc workload: mfcc.flow (40 cepstra), mfplp.flow (20 autocorrelation / 16 cepstrum coefficients) or plp.flow "
+                         "(bark / trapeze filter bank + equal loudness, 13 / 13)")
     ap.add_argument("--estimation-mode", default="viterbi", choices=["viterbi", "baum-welch"],
                     help="gmm-train: statistics of the best density only, or of every density by its posterior (reference: mode)")
     ap.add_argument("--gmm-type", default="diagonal-maximum", choices=["diagonal-maximum", "batch-diagonal-maximum-float", "SIMD-diagonal-maximum"])
@@ -392,9 +393,12 @@ class MfccOnly:
         import rasr_amd
         from tests import synth
         self.ctx = ctx
-        self.plp = getattr(args, "front_end", "mfcc") == "mfplp"
-        self.nout = 16 if self.plp else 40
-        if self.plp:
+        fe = getattr(args, "front_end", "mfcc")
+        self.plp = fe != "mfcc"
+        self.nout = {"mfcc": 40, "mfplp": 16, "plp": 13}[fe]
+        if fe == "plp":
+            self.fe = rasr_amd.MfccExtractor.plp(ctx)
+        elif self.plp:
             self.fe = rasr_amd.MfccExtractor(ctx, nr_cepstrum_coefficients=16, front_end="mfplp", nr_autocorrelation_coefficients=20,
                                              normalize=True)
         else:
@@ -754,7 +758,8 @@ WORKLOAD_NAMES = {
                           % (a.precision, a.utterances, a.utt_seconds),
     "nn-pipeline": lambda a: "cfg5-shard, NN leg only: MFCC-40 -> ctx11 -> FFNN 440-6x2048-10000 (%s MFMA) -> best-state counts; "
                              "%d utterances x %.0f s per step and rank" % (a.precision, a.utterances, a.utt_seconds),
-    "mfcc": lambda a: "cfg2: batched MFCC-40 on 1000 utterances (5-15 s)",
+    "mfcc": lambda a: "cfg2: batched MFCC-40 on 1000 utterances (5-15 s)" if getattr(a, "front_end", "mfcc") == "mfcc"
+                      else "cfg2 audio through %s.flow: 1000 utterances (5-15 s)" % a.front_end,
     "gmm": lambda a: "cfg3-cart: 10000 states x 16 densities, d=40, pooled covariance, batch %d, %s" % (a.gmm_frames, a.gmm_type),
     "gmm-tied": lambda a: "cfg3-tied: 4096 shared densities x 10000 states, d=40, batch %d, diagonal-maximum" % a.gmm_frames,
     "nn": lambda a: "cfg4: FFNN 440-6x2048-10000 (%s MFMA), batch 1024" % a.precision,

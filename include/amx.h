@@ -95,21 +95,37 @@ typedef struct {
      * (Math/LevinsonLse.cc:35-70) -> signal-autoregression-to-cepstrum (Signal/AutoregressionToCepstrum.cc:21-35,
      * nr-outputs n_ceps).  A frame whose Levinson recursion meets a zero prediction error (digital silence) is an error in
      * the reference ("Failed to calculate the autoregression coefficients."); it comes out as NaNs here. */
-    int    front_end;              /* AMX_FRONT_END_MFCC (0, default) or AMX_FRONT_END_MFPLP                     */
-    int    n_autocorrelation;      /* nr-autocorrelation-coefficients = LPC order + 1 (MF-PLP only)                */
-    double plp_power;              /* intensity-loudness-law value, default 0.33 (MF-PLP only)                     */
+    int    front_end;              /* AMX_FRONT_END_MFCC (0, default), AMX_FRONT_END_MFPLP or AMX_FRONT_END_PLP  */
+    int    n_autocorrelation;      /* nr-autocorrelation-coefficients = LPC order + 1 (MF-PLP, PLP)                */
+    double plp_power;              /* intensity-loudness-law value, default 0.33 (MF-PLP, PLP)                     */
+    /* The other parameters of signal-filterbank (Signal/Filterbank.cc:700-745), usable with every front end; the defaults (0) are
+     * mfcc.flow's.  warp-center-positions stays true (the reference's default; stretch-to-cover accepts nothing else).
+     * front_end AMX_FRONT_END_PLP = plp.flow (Tools/FeatureExtraction/share/plp.flow): Hamming 20 ms, no preemphasis node
+     * (preemph_alpha 0), power spectrum -> trapeze / include-boundary / bark filter bank (filter-width 3.8, spacing 0.93853 = 20
+     * filters at 16 kHz; 0.973442 = 15 filters at 8 kHz) -> the vector extended by copies of its first and last element
+     * (generic-vector-f32-split / -concat) -> equal-loudness preemphasis (signal-vector-f32-continuous-transform,
+     * Signal/VectorTransform.cc:36-83, f = equal-loudness(bark^-1(index / sample-rate)), operation multiplies) -> ^plp_power ->
+     * the MF-PLP tail (cosine transform N-plus-one, Levinson, LPC cepstrum). */
+    int    filter_type;            /* type: AMX_FILTER_TRIANGULAR (0) or AMX_FILTER_TRAPEZE                        */
+    int    boundary;               /* boundary: AMX_BOUNDARY_STRETCH_TO_COVER (0), _INCLUDE, _EMPHASIZE            */
+    int    warping;                /* warping-function: AMX_WARP_MEL (0) or AMX_WARP_BARK                          */
 } amx_mfcc_cfg;
-enum { AMX_FRONT_END_MFCC = 0, AMX_FRONT_END_MFPLP = 1 };
+enum { AMX_FRONT_END_MFCC = 0, AMX_FRONT_END_MFPLP = 1, AMX_FRONT_END_PLP = 2 };
+enum { AMX_FILTER_TRIANGULAR = 0, AMX_FILTER_TRAPEZE = 1 };
+enum { AMX_BOUNDARY_STRETCH_TO_COVER = 0, AMX_BOUNDARY_INCLUDE = 1, AMX_BOUNDARY_EMPHASIZE = 2 };
+enum { AMX_WARP_MEL = 0, AMX_WARP_BARK = 1 };
 
 typedef struct {
     int    frame_len, frame_shift, fft_len, n_bins, n_filters, n_ceps;
     double fft_output_sample_rate; /* attribute "sample-rate" after the FFT node = N/fs */
     double mel_max;                /* warped maximum frequency */
-    int    n_transform;            /* rows of the cosine-transform table: n_ceps (MFCC) or n_autocorrelation (MF-PLP) */
+    int    n_transform;            /* rows of the cosine-transform table: n_ceps (MFCC) or n_autocorrelation (MF-PLP, PLP) */
+    int    n_transform_inputs;     /* its columns: n_filters, or n_filters + 2 (PLP: first and last filter output duplicated) */
 } amx_mfcc_info;
 
 void amx_mfcc_default_cfg(amx_mfcc_cfg* cfg); /* the values of mfcc.flow + node defaults, 16 ceps */
 void amx_mfplp_default_cfg(amx_mfcc_cfg* cfg); /* the values of mfplp.flow, 13 autocorrelation / 13 cepstrum coefficients */
+void amx_plp_default_cfg(amx_mfcc_cfg* cfg);   /* the values of plp.flow at 16 kHz, 13 autocorrelation / 13 cepstrum coefficients */
 int  amx_mfcc_create(amx_ctx* ctx, const amx_mfcc_cfg* cfg, amx_mfcc** out);
 void amx_mfcc_destroy(amx_mfcc* h);
 int  amx_mfcc_describe(const amx_mfcc* h, amx_mfcc_info* info);
@@ -120,9 +136,11 @@ long amx_mfcc_n_frames(const amx_mfcc* h, long n_samples);
 double amx_mfcc_frame_start_time(const amx_mfcc* h, long frame);
 /* host copies of the tables the kernel uses (any pointer may be NULL):
  * window[frame_len], filter_start/end[n_filters], filter_offset[n_filters+1],
- * filter_weights[filter_offset[n_filters]], dct[n_ceps*n_filters] */
+ * filter_weights[filter_offset[n_filters]], dct[n_transform*n_transform_inputs] */
 int amx_mfcc_tables(const amx_mfcc* h, float* window, int* filter_start, int* filter_end,
                     int* filter_offset, float* filter_weights, float* dct);
+/* PLP: the equal-loudness factors [n_transform_inputs] (f64, as the reference's f(i)); AMX_ERR_STATE for the other front ends */
+int amx_mfcc_equal_loudness(const amx_mfcc* h, double* factors);
 
 /* One segment, host buffers: pcm f32 (s16 sample values, unscaled, Flow/TypeConverter.hh:35-43)
  * -> ceps [n_frames x n_ceps].  Includes H2D/D2H. */

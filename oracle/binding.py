@@ -23,7 +23,8 @@ class MfccCfg(C.Structure):
                 ("preemph_alpha", C.c_double), ("fft_max_input_s", C.c_double), ("apply_scale", C.c_int),
                 ("mel_filter_width", C.c_double), ("mel_spacing", C.c_double),
                 ("warp_differential_unit", C.c_int), ("n_ceps", C.c_int), ("dct_normalize", C.c_int),
-                ("front_end", C.c_int), ("n_autocorrelation", C.c_int), ("plp_power", C.c_double)]
+                ("front_end", C.c_int), ("n_autocorrelation", C.c_int), ("plp_power", C.c_double),
+                ("filter_type", C.c_int), ("boundary", C.c_int), ("warping", C.c_int)]
 
     @staticmethod
     def default(n_ceps=16, filter_width=268.258, sample_rate=16000.0, alpha=1.0):
@@ -33,6 +34,12 @@ class MfccCfg(C.Structure):
     def mfplp(n_ceps=13, n_autocorrelation=13, filter_width=268.258, sample_rate=16000.0, alpha=1.0):
         """mfplp.flow: nr-cepstrum-coefficients, nr-autocorrelation-coefficients (LPC order + 1)"""
         return MfccCfg(sample_rate, 0.025, 0.01, alpha, 0.025, 1, filter_width, 0.0, 1, n_ceps, 1, 1, n_autocorrelation, 0.33)
+
+    @staticmethod
+    def plp(n_ceps=13, n_autocorrelation=13, filter_width=3.8, spacing=0.93853, sample_rate=16000.0):
+        """plp.flow: 20 ms Hamming window, no preemphasis, trapeze / include-boundary / bark filter bank, equal loudness"""
+        return MfccCfg(sample_rate, 0.02, 0.01, 0.0, 0.02, 1, filter_width, spacing, 1, n_ceps, 1, 2, n_autocorrelation, 0.33,
+                       1, 1, 1)
 
 
 class _GmmModel(C.Structure):
@@ -107,7 +114,7 @@ def Oracle():
     L.orc_mfcc_n_frames.restype = C.c_long
     L.orc_mfcc_n_frames.argtypes = [C.c_void_p, C.c_long]
     for n, t in (("window", C.c_float), ("filter_start", C.c_int), ("filter_end", C.c_int),
-                 ("filter_offset", C.c_int), ("filter_weights", C.c_float), ("dct", C.c_float)):
+                 ("filter_offset", C.c_int), ("filter_weights", C.c_float), ("dct", C.c_float), ("equal_loudness", C.c_double)):
         f = getattr(L, "orc_mfcc_" + n)
         f.restype = C.POINTER(t)
         f.argtypes = [C.c_void_p]
@@ -120,7 +127,8 @@ def Oracle():
     L.orc_preemphasis.argtypes = [f32p, C.c_long, C.c_float]
     L.orc_fft_real.argtypes = [f32p, C.c_int]
     L.orc_fft_complex.argtypes = [f32p, C.c_int]
-    for n in ("orc_mel", "orc_mel_derivative", "orc_mel_inverse"):
+    for n in ("orc_mel", "orc_mel_derivative", "orc_mel_inverse", "orc_bark", "orc_bark_derivative", "orc_bark_inverse",
+              "orc_equal_loudness", "orc_equal_loudness_4khz"):
         getattr(L, n).restype = C.c_double
         getattr(L, n).argtypes = [C.c_double]
     L.orc_gmm_create.restype = C.c_void_p
@@ -162,10 +170,15 @@ def load_ref():
     R = C.CDLL(_REF)
     R.ref_fft_real.argtypes = [f32p, C.c_int]
     R.ref_fft_complex.argtypes = [f32p, C.c_int]
-    for n in ("ref_mel", "ref_mel_derivative", "ref_mel_inverse"):
+    for n in ("ref_mel", "ref_mel_derivative", "ref_mel_inverse", "ref_bark", "ref_bark_derivative", "ref_bark_inverse"):
         getattr(R, n).restype = C.c_double
         getattr(R, n).argtypes = [C.c_double]
-    for n in ("ref_warped_bin", "ref_warped_bin_inverse", "ref_warped_bin_derivative"):
+    R.ref_equal_loudness.restype = C.c_double
+    R.ref_equal_loudness.argtypes = [C.c_double, C.c_int]
+    R.ref_plp_equal_loudness.restype = C.c_double
+    R.ref_plp_equal_loudness.argtypes = [C.c_double, C.c_double, C.c_int]
+    for n in ("ref_warped_bin", "ref_warped_bin_inverse", "ref_warped_bin_derivative", "ref_bark_bin", "ref_bark_bin_inverse",
+              "ref_bark_bin_derivative"):
         getattr(R, n).restype = C.c_double
         getattr(R, n).argtypes = [C.c_double, C.c_double]
     R.ref_gauss_log_norm_factor.restype = C.c_double
@@ -332,8 +345,18 @@ class OracleMfcc:
 
     @property
     def dct(self):
-        rows = self.cfg.n_autocorrelation if self.cfg.front_end == 1 else self.n_ceps
-        return self._arr("dct", rows * self.n_filters, np.float32).reshape(rows, self.n_filters)
+        rows = self.cfg.n_autocorrelation if self.cfg.front_end != 0 else self.n_ceps
+        cols = self.n_transform_inputs
+        return self._arr("dct", rows * cols, np.float32).reshape(rows, cols)
+
+    @property
+    def n_transform_inputs(self):
+        """size of the vector the cosine transform sees: the filter-bank outputs, plus the duplicated first / last one (plp.flow)"""
+        return self.n_filters + (2 if self.cfg.front_end == 2 else 0)
+
+    @property
+    def equal_loudness(self):
+        return self._arr("equal_loudness", self.n_transform_inputs, np.float64) if self.cfg.front_end == 2 else None
 
     def n_frames(self, n):
         return int(self.L.orc_mfcc_n_frames(self.h, n))
@@ -350,7 +373,7 @@ class OracleMfcc:
         pcm = np.ascontiguousarray(pcm, dtype=np.float32)
         o = dict(windowed=np.zeros(self.fft_len, np.float32), spectrum=np.zeros(self.fft_len + 2, np.float32),
                  amplitude=np.zeros(self.n_bins, np.float32), mel=np.zeros(self.n_filters, np.float32),
-                 logmel=np.zeros(self.n_filters, np.float32), ceps=np.zeros(self.n_ceps, np.float32))
+                 logmel=np.zeros(self.n_transform_inputs, np.float32), ceps=np.zeros(self.n_ceps, np.float32))
         r = self.L.orc_mfcc_stages(self.h, pcm, len(pcm), frame, *[v.ctypes.data for v in o.values()])
         if r != 0:
             raise IndexError("frame out of range")

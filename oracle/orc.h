@@ -48,6 +48,13 @@ typedef struct {
     int    front_end;              /* 0 = mfcc.flow, 1 = mfplp.flow */
     int    n_autocorrelation;      /* nr-autocorrelation-coefficients (LPC order + 1) */
     double plp_power;              /* intensity-loudness-law value, mfplp.flow: 0.33 */
+    /* signal-filterbank parameters beyond mfcc.flow's (Signal/Filterbank.cc:700-745) and plp.flow
+     * (Tools/FeatureExtraction/share/plp.flow): front_end 2 = Hamming 20 ms, no preemphasis node (alpha 0), power spectrum ->
+     * trapeze / include-boundary / bark filter bank (width 3.8, spacing 0.93853) -> first and last output duplicated ->
+     * equal-loudness preemphasis (multiplies) -> ^plp_power -> cosine transform (N-plus-one) -> Levinson -> LPC cepstrum */
+    int    filter_type;            /* type: 0 triangular, 1 trapeze */
+    int    boundary;               /* boundary: 0 stretch-to-cover, 1 include-boundary, 2 emphasize-boundary */
+    int    warping;                /* warping-function: 0 mel, 1 bark */
 } orc_mfcc_cfg;
 
 typedef struct orc_mfcc orc_mfcc;
@@ -70,7 +77,13 @@ const int*   orc_mfcc_filter_start(const orc_mfcc* h);    /* [n_filters] */
 const int*   orc_mfcc_filter_end(const orc_mfcc* h);      /* [n_filters] */
 const int*   orc_mfcc_filter_offset(const orc_mfcc* h);   /* [n_filters+1] into weights */
 const float* orc_mfcc_filter_weights(const orc_mfcc* h);  /* concatenated */
-const float* orc_mfcc_dct(const orc_mfcc* h);             /* [n_ceps][n_filters] row-major */
+const float* orc_mfcc_dct(const orc_mfcc* h);             /* [n_ceps][n_filters] row-major; plp.flow: [n_autocorrelation][n_filters + 2] */
+const double* orc_mfcc_equal_loudness(const orc_mfcc* h); /* plp.flow: [n_filters + 2], else NULL */
+double orc_bark(double f);
+double orc_bark_derivative(double f);
+double orc_bark_inverse(double b);
+double orc_equal_loudness(double f);
+double orc_equal_loudness_4khz(double f);
 double       orc_mfcc_mel_max(const orc_mfcc* h);         /* warped maximum frequency */
 
 /* whole utterance: pcm f32 (s16 values, unscaled) -> ceps [n_frames x n_ceps] row-major.

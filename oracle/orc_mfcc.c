@@ -28,8 +28,10 @@ struct orc_mfcc {
     float*       window;       /* [frame_len] */
     int *        f_start, *f_end, *f_off;
     float*       f_weights;
-    float*       dct;          /* [n_ceps][n_filters]; MF-PLP: [n_autocorrelation][n_filters], N-plus-one input type */
+    float*       dct;          /* [n_ceps][n_filters]; MF-PLP: [n_autocorrelation][n_filters], N-plus-one input type;
+                                * PLP: [n_autocorrelation][n_filters + 2] */
     double       mel_max;
+    double*      eql;          /* PLP: equal-loudness factor per element of the first/last-extended filter-bank vector [n_filters + 2] */
 };
 
 /* ------------------------------------------------------------------ preemphasis
@@ -156,6 +158,39 @@ double orc_mel_inverse(double m) {
     return (pow(10, a * m) - 1.0) * 700.0;
 }
 
+/* ------------------------------------------------------------------ bark warping
+ * Math/AnalyticFunctionFactory.cc:369-373 (continuous domain): nest(scaling(6), nest(asinh, scaling(1 / 600)))
+ * with Math/SimpleAnalyticFunctions.hh:107-123 (ScalingFunction), :158-176,214-222 (ArcSinh, DerivedArcSinh, Sinh). */
+double orc_bark(double f) {
+    return 6.0 * asinh((1.0 / 600.0) * f);
+}
+/* AnalyticNesting::derive twice: (const(6) o g)(f) * g'(f), g' = (DerivedArcSinh o scaling)(f) * const(1 / 600) */
+double orc_bark_derivative(double f) {
+    double u = (1.0 / 600.0) * f;
+    return 6.0 * (((double)1 / sqrt(u * u + (double)1)) * (1.0 / 600.0));
+}
+/* AnalyticNesting::invert twice: scaling(1 / (1 / 600)) o sinh o scaling(1 / 6) */
+double orc_bark_inverse(double b) {
+    double s6 = 1 / 6.0, s600 = 1 / (1.0 / 600.0);
+    return s600 * sinh(s6 * b);
+}
+
+/* Math/AcousticalAnalyticFunctions.cc:21-37 */
+double orc_equal_loudness(double f) {
+    double omega       = 2 * M_PI * f;
+    double omegaSquare = omega * omega;
+    double omegaFourth = omegaSquare * omegaSquare;
+    double omegaSixth  = omegaFourth * omegaSquare;
+    return (omegaFourth * (omegaSquare + 56.8e6)) /
+           ((omegaSquare + 6.3e6) * (omegaSquare + 6.3e6) * (omegaSquare + 0.38e9) * (omegaSixth / 9.58e26 + 1));
+}
+double orc_equal_loudness_4khz(double f) {
+    double omega       = 2 * M_PI * f;
+    double omegaSquare = omega * omega;
+    double termFourth  = omegaSquare / (omegaSquare + (double)6.3e6);
+    return termFourth * termFourth * (omegaSquare + (double)56.8e6) / (omegaSquare + (double)0.38e9);
+}
+
 /* Flow attributes carry doubles as text with 6 significant digits
  * (Flow/Attributes.hh:109-113: ostringstream << f64), and nodes read them back with atof. */
 static double orc_attr_roundtrip(double x) {
@@ -169,12 +204,15 @@ static int orc_almost_integer(double x) { /* Signal/Filterbank.cc:691-694 */
 }
 
 /* Core/Utility.hh:322-327 */
-static int orc_almost_equal(double a, double b) {
+static int orc_almost_equal_tol(double a, double b, double tolerance) {
     const double eps   = 2.220446049250313e-16; /* Core::Type<f64>::epsilon = DBL_EPSILON */
     const double delta = 2.2250738585072014e-308; /* Core::Type<f64>::delta   = DBL_MIN */
     double       d     = fabs(a - b);
-    double       e     = (fabs(a) + fabs(b) + delta) * eps * 1.0;
+    double       e     = (fabs(a) + fabs(b) + delta) * eps * tolerance;
     return d < e;
+}
+static int orc_almost_equal(double a, double b) {
+    return orc_almost_equal_tol(a, b, 1.0);
 }
 
 /* ------------------------------------------------------------------ table construction */
@@ -194,36 +232,72 @@ static void orc_build_hamming(float* w, int len) {
     }
 }
 
-/* Signal/Filterbank.cc:144-244,519-567,640-672,765-819: triangular filters,
- * stretch-to-cover boundary, mel warping of the continuous frequency axis. */
+/* Signal/Filterbank.cc:144-244 (filter builder, triangle), :246-275 (trapeze), :330-470 (boundaries: include-boundary),
+ * :519-567 (stretch-to-cover), :575-595 (emphasize-boundary), :640-672 (FilterBank::init: with warp-center-positions = true, the
+ * default, the boundary works on the warped axis with an identity warping), :765-819 (node init); warping of the continuous
+ * frequency axis by mel or bark. */
+typedef struct {
+    double (*value)(double);
+    double (*derivative)(double);
+    double (*inverse)(double);
+} orc_warp;
+
+/* TrapezeFilterBuilder (Signal/Filterbank.cc:246-275) */
+static float orc_trapeze_weight(double frequency, double center, double width) {
+    const double nmb               = 0.5 / (1.3 - (-2.5)); /* normalizedMiddleBorder */
+    double       relativeFrequency = frequency - center;
+    double       middleLeftBorder  = -nmb * width;
+    if (relativeFrequency < middleLeftBorder)
+        return (float)pow(10, relativeFrequency - middleLeftBorder);
+    double middleRightBorder = nmb * width;
+    if (relativeFrequency <= middleRightBorder)
+        return 1;
+    return (float)pow(10, -2.5 * (relativeFrequency - middleRightBorder));
+}
+
+static double orc_postprocess_nfilters(double nf) { /* Boundary::postprocessNumberOfFilters */
+    if (nf < 1)
+        return 1;
+    if (orc_almost_integer(nf))
+        return round(nf);
+    return nf;
+}
+
 static int orc_build_filterbank(orc_mfcc* h) {
     const orc_mfcc_cfg* c  = &h->cfg;
+    const orc_warp mel = {orc_mel, orc_mel_derivative, orc_mel_inverse}, bark = {orc_bark, orc_bark_derivative, orc_bark_inverse};
+    if (c->warping < 0 || c->warping > 1 || c->filter_type < 0 || c->filter_type > 1 || c->boundary < 0 || c->boundary > 2)
+        return -1;
+    const orc_warp* W = c->warping == 1 ? &bark : &mel;
     /* FilterBankNode::configure reads sample-rate = N/fs from the attribute text */
     double sr_attr = orc_attr_roundtrip((double)h->fft_len / c->sample_rate);
     double d2c     = 1 / sr_attr;                    /* createScaling(1 / sampleRate_) */
     double inv_d2c = 1 / d2c;                        /* ScalingFunction::invert */
     int    B       = h->n_bins;
     double fmin    = 0.0;                            /* filtering-interval-start default */
-    double fmaxw   = orc_mel(d2c * (double)(B - 1)); /* FilterBankNode::init */
+    double fmaxw   = W->value(d2c * (double)(B - 1)); /* FilterBankNode::init */
     h->mel_max     = fmaxw;
 
     double width   = c->mel_filter_width;
     double spacing = c->mel_spacing;
-    double ncp     = 0.5; /* SymmetricalTriangularFilterBuilder::normalizedCenterPosition */
+    /* normalizedCenterPosition: symmetrical triangle 0.5, trapeze 2.5 / 3.8 */
+    double ncp     = c->filter_type == 1 ? 2.5 / (1.3 - (-2.5)) : 0.5;
     if (spacing == 0)
-        spacing = ncp * width;
-    /* StretchToCover::getNumberOfFilters / init */
-    double nf = (fmaxw - fmin - width) / spacing + 1;
-    if (nf < 1)
-        nf = 1;
-    else if (orc_almost_integer(nf))
-        nf = round(nf);
-    size_t n_filters = (size_t)floor(nf);
-    double coverage  = (spacing * (double)(n_filters - 1) + width) / (fmaxw - fmin);
-    if (!(n_filters == 1 && coverage > 1 && !orc_almost_equal(coverage, 1))) {
-        width /= coverage;
-        spacing /= coverage;
+        spacing = ncp * width; /* Boundary::setSpacing */
+    size_t n_filters;
+    if (c->boundary == 0) {
+        /* StretchToCover::getNumberOfFilters / init */
+        n_filters       = (size_t)floor(orc_postprocess_nfilters((fmaxw - fmin - width) / spacing + 1));
+        double coverage = (spacing * (double)(n_filters - 1) + width) / (fmaxw - fmin);
+        if (!(n_filters == 1 && coverage > 1 && !orc_almost_equal(coverage, 1))) {
+            width /= coverage;
+            spacing /= coverage;
+        }
     }
+    else if (c->boundary == 1) /* IncludeBoundary::getNumberOfFilters; inverseWarpingFunction_ is the identity */
+        n_filters = (size_t)ceil(orc_postprocess_nfilters((fmaxw - (1 - ncp) * width) / spacing));
+    else /* EmphasizeBoundary::getNumberOfFilters */
+        n_filters = (size_t)floor(orc_postprocess_nfilters(fmaxw / spacing + 1));
     h->n_filters = (int)n_filters;
     h->f_start   = (int*)calloc(n_filters, sizeof(int));
     h->f_end     = (int*)calloc(n_filters, sizeof(int));
@@ -231,12 +305,18 @@ static int orc_build_filterbank(orc_mfcc* h) {
     h->f_weights = (float*)calloc(n_filters * (size_t)B, sizeof(float));
     int off      = 0;
     for (size_t i = 0; i < n_filters; ++i) {
-        double center = fmin + spacing * (double)i + ncp * width;
+        double center;
+        if (c->boundary == 0)
+            center = fmin + spacing * (double)i + ncp * width;
+        else if (c->boundary == 1)
+            center = spacing * (double)(i + 1);
+        else
+            center = spacing * (double)i;
         /* setStart */
         double lo = center - ncp * width;
         if (!(lo > fmin))
             lo = fmin; /* std::max(a, b) returns a unless a < b */
-        double s = inv_d2c * orc_mel_inverse(lo);
+        double s = inv_d2c * W->inverse(lo);
         s        = orc_almost_integer(s) ? round(s) : ceil(s);
         if (s < 0)
             return -1;
@@ -244,26 +324,53 @@ static int orc_build_filterbank(orc_mfcc* h) {
         double hi = center + (1.0 - ncp) * width;
         if (fmaxw < hi)
             hi = fmaxw;
-        double e = inv_d2c * orc_mel_inverse(hi);
+        double e = inv_d2c * W->inverse(hi);
         e        = orc_almost_integer(e) ? round(e) + 1 : ceil(e);
         size_t start = (size_t)s;
         if (!(e > 0 && start < (size_t)e))
             return -1;
         size_t end = (size_t)e;
+        if (end > (size_t)B)
+            return -1; /* Filter::apply would read beyond the spectrum */
         h->f_start[i] = (int)start;
         h->f_end[i]   = (int)end;
         h->f_off[i]   = off;
-        /* setWeights: f32 triangle weight times f64 derivative, rounded to f32 */
+        /* setWeights: f32 shape weight times f64 derivative, rounded to f32 */
         for (unsigned b = (unsigned)start; b < end; ++b) {
-            double fw  = orc_mel(d2c * (double)b);
-            float  tri = (float)((double)1 - fabs(fw - center) / (width / 2));
-            if (!(tri >= 0))
-                tri = 0;
-            double der = c->warp_differential_unit ? orc_mel_derivative(d2c * (double)b) : 1.0;
-            h->f_weights[off++] = (float)(tri * der);
+            double fw = W->value(d2c * (double)b);
+            float  sh;
+            if (c->filter_type == 1)
+                sh = orc_trapeze_weight(fw, center, width);
+            else {
+                sh = (float)((double)1 - fabs(fw - center) / (width / 2));
+                if (!(sh >= 0))
+                    sh = 0;
+            }
+            double der = c->warp_differential_unit ? W->derivative(d2c * (double)b) : 1.0;
+            h->f_weights[off++] = (float)(sh * der);
         }
     }
     h->f_off[n_filters] = off;
+
+    if (c->front_end == 2) {
+        /* plp.flow: signal-vector-f32-continuous-transform f = nest(nest(disc-to-cont, invert(bark)), equal-loudness-preemphasis)
+         * on the vector [first, filters..., last] (Signal/VectorTransform.cc:36-83; Math/AnalyticFunctionFactory.cc:161-180:
+         * "nest(g, f)" is f o g and f is created with maximal argument g(max); :322-327 disc-to-cont = scaling(1 / sample-rate),
+         * sample-rate = the filter bank's output attribute 1 / spacing (Boundary::outputSampleRate) as text; :543-556 the 4 kHz
+         * variant unless the largest frequency is significantly greater than 4000) */
+        if (c->boundary == 0)
+            return -1; /* stretch-to-cover reports sample rate 1: not the bark axis */
+        size_t n_in = n_filters + 2;
+        double sr   = orc_attr_roundtrip((double)1 / spacing);
+        double g    = 1 / sr;
+        double top  = orc_bark_inverse(g * (double)(n_in - 1));
+        int    full = top > 4000.0 && !orc_almost_equal_tol(top, 4000.0, 1e12);
+        h->eql      = (double*)calloc(n_in, sizeof(double));
+        for (size_t i = 0; i < n_in; ++i) {
+            double f  = orc_bark_inverse(g * (double)i);
+            h->eql[i] = full ? orc_equal_loudness(f) : orc_equal_loudness_4khz(f);
+        }
+    }
     return 0;
 }
 
@@ -281,7 +388,7 @@ static void orc_build_dct(orc_mfcc* h) {
 /* Signal/CosineTransform.cc:46-60 (N-plus-one input data, identity warping): the inverse DFT of an even spectrum sampled at
  * N + 1 points, which turns the compressed mel spectrum into autocorrelation coefficients */
 static void orc_build_cosine_nplus1(orc_mfcc* h) {
-    size_t cols = (size_t)h->n_filters, N = cols - 1, rows = (size_t)h->cfg.n_autocorrelation;
+    size_t cols = (size_t)h->n_filters + (h->cfg.front_end == 2 ? 2 : 0), N = cols - 1, rows = (size_t)h->cfg.n_autocorrelation;
     h->dct      = (float*)calloc(rows * cols, sizeof(float));
     for (size_t k = 0; k < rows; ++k) {
         h->dct[k * cols + 0] = (float)0.5;
@@ -381,9 +488,9 @@ orc_mfcc* orc_mfcc_create(const orc_mfcc_cfg* cfg) {
         orc_mfcc_destroy(h);
         return NULL;
     }
-    if (cfg->front_end == 1) {
+    if (cfg->front_end == 1 || cfg->front_end == 2) {
         /* CosineTransformNode: nr-outputs <= input size; AutoregressionToCepstrumNode::init: 2 <= nr-outputs <= order + 1 */
-        if (cfg->n_autocorrelation < 2 || cfg->n_autocorrelation > h->n_filters || cfg->n_ceps < 2 ||
+        if (cfg->n_autocorrelation < 2 || cfg->n_autocorrelation > h->n_filters + (cfg->front_end == 2 ? 2 : 0) || cfg->n_ceps < 2 ||
             cfg->n_ceps > cfg->n_autocorrelation) {
             orc_mfcc_destroy(h);
             return NULL;
@@ -404,6 +511,7 @@ void orc_mfcc_destroy(orc_mfcc* h) {
     free(h->f_off);
     free(h->f_weights);
     free(h->dct);
+    free(h->eql);
     free(h);
 }
 
@@ -420,6 +528,7 @@ const int*   orc_mfcc_filter_offset(const orc_mfcc* h) { return h->f_off; }
 const float* orc_mfcc_filter_weights(const orc_mfcc* h) { return h->f_weights; }
 const float* orc_mfcc_dct(const orc_mfcc* h) { return h->dct; }
 double       orc_mfcc_mel_max(const orc_mfcc* h) { return h->mel_max; }
+const double* orc_mfcc_equal_loudness(const orc_mfcc* h) { return h->eql; }
 
 /* Signal/WindowBuffer.cc:84-125 + Signal/SlidingAlgorithmNode.hh:60-79: get() emits full
  * frames while >= 2*max(len,shift) samples are buffered; at end of segment flush() keeps
@@ -468,7 +577,7 @@ static void orc_frame(const orc_mfcc* h, const float* pre, long n_samples, long 
     if (amplitude)
         memcpy(amplitude, amp, (size_t)h->n_bins * sizeof(float));
     /* mfplp.flow: generic-vector-f32-power value 2 (Flow/SimpleFunction.hh:143-153: powf) */
-    if (h->cfg.front_end == 1)
+    if (h->cfg.front_end != 0)
         for (int k = 0; k < h->n_bins; ++k)
             amp[k] = powf(amp[k], 2.0f);
     /* FilterBank::Filter::apply (Signal/Filterbank.cc:65-71): f32 accumulate, ascending bin */
@@ -484,26 +593,41 @@ static void orc_frame(const orc_mfcc* h, const float* pre, long n_samples, long 
     }
     if (mel)
         memcpy(mel, fb, (size_t)h->n_filters * sizeof(float));
-    if (h->cfg.front_end == 1) {
+    if (h->cfg.front_end != 0) {
+        int   n_in = h->n_filters;
+        float ext[h->n_filters + 2];
+        if (h->cfg.front_end == 2) {
+            /* plp.flow: generic-vector-f32-split port 0 / reversed port 0 + generic-vector-f32-concat (Flow/VectorSplit.hh:104-135):
+             * [fb[0], fb[0..n-1], fb[n-1]]; then in[i] = (f32)((f64)in[i] * f(i)) (Signal/VectorTransform.cc:78-83,
+             * Math/SimpleAnalyticFunctions.hh MultiplicationFunction) */
+            n_in   = h->n_filters + 2;
+            ext[0] = fb[0];
+            memcpy(ext + 1, fb, (size_t)h->n_filters * sizeof(float));
+            ext[n_in - 1] = fb[h->n_filters - 1];
+            for (int i = 0; i < n_in; ++i)
+                ext[i] = (float)((double)ext[i] * h->eql[i]);
+        }
+        else
+            memcpy(ext, fb, (size_t)n_in * sizeof(float));
         /* intensity-loudness-law, autocorrelation (CosineTransform::apply: f32 rows left to right, divided by N_ = inputs - 1),
          * autoregression, cepstrum; a frame whose recursion fails is reported as an error by the reference: NaN here */
         const float pw = (float)h->cfg.plp_power;
-        for (int f = 0; f < h->n_filters; ++f)
-            fb[f] = powf(fb[f], pw);
+        for (int f = 0; f < n_in; ++f)
+            ext[f] = powf(ext[f], pw);
         if (logmel)
-            memcpy(logmel, fb, (size_t)h->n_filters * sizeof(float));
+            memcpy(logmel, ext, (size_t)n_in * sizeof(float));
         if (ceps) {
             const int nac = h->cfg.n_autocorrelation;
             float     R[nac], a[nac], gain = 0;
             for (int k = 0; k < nac; ++k) {
                 float        acc = 0;
-                const float* row = h->dct + (size_t)k * h->n_filters;
-                for (int n = 0; n < h->n_filters; ++n) {
-                    float prod = row[n] * fb[n];
+                const float* row = h->dct + (size_t)k * n_in;
+                for (int n = 0; n < n_in; ++n) {
+                    float prod = row[n] * ext[n];
                     acc        = acc + prod;
                 }
                 if (h->cfg.dct_normalize)
-                    acc = acc / (float)(h->n_filters - 1);
+                    acc = acc / (float)(n_in - 1);
                 R[k] = acc;
             }
             if (orc_levinson(R, nac, &gain, a))

@@ -9,6 +9,8 @@
 //   Signal::WindowBuffer (put/get/flush)  src/Signal/WindowBuffer.cc (+ Flow/Core closure, see Makefile)
 //   Math::{ScalingFunction,MelWarpingCore,AnalyticNesting}  header-only, composed exactly like
 //       Math::AnalyticFunctionFactory::createMelWarpingFunction (AnalyticFunctionFactory.cc:338-341)
+//   Math::{Sinh,ArcSinh,DerivedArcSinh} (SimpleAnalyticFunctions.hh:152-222) composed like createBarkWarpingFunction
+//       (AnalyticFunctionFactory.cc:369-373); Math::EqualLoudnessPreemphasis[4Khz]  src/Math/AcousticalAnalyticFunctions.cc
 //   Mm::gaussLogNormFactor, Mm::inverseSquareRoot           src/Mm/Utilities.hh:53-91
 //   Math::Matrix<f32> * Math::Vector<f32>   src/Math/Matrix.hh:485-494, src/Math/Vector.hh:94-101 -- what
 //       Signal::CosineTransform::apply runs (f32 products accumulated left to right)
@@ -44,9 +46,50 @@ Math::UnaryAnalyticFunctionRef melWarp() {
     return Math::nest(Math::UnaryAnalyticFunctionRef(new Math::ScalingFunction(2595.0)),
                       Math::UnaryAnalyticFunctionRef(new Math::MelWarpingCore));
 }
+Math::UnaryAnalyticFunctionRef scaling(double a) {
+    return Math::UnaryAnalyticFunctionRef(new Math::ScalingFunction(a));
+}
+Math::UnaryAnalyticFunctionRef barkWarp() {
+    // continuousDomain branch of createBarkWarpingFunction (AnalyticFunctionFactory.cc:369-373); createSinh() = new Sinh
+    return Math::nest(scaling(6.0), Math::nest(Math::UnaryAnalyticFunctionRef(new Math::Sinh)->invert(), scaling(1.0 / 600.0)));
+}
 }  // namespace
 
 extern "C" {
+
+// bark warping, its derivative and inverse, alone and nested with disc-to-cont as FilterBuilder::create composes them
+double ref_bark(double f) {
+    return barkWarp()->value(f);
+}
+double ref_bark_derivative(double f) {
+    return barkWarp()->derive()->value(f);
+}
+double ref_bark_inverse(double b) {
+    return barkWarp()->invert()->value(b);
+}
+double ref_bark_bin(double bin, double inputSampleRate) {
+    return Math::nest(barkWarp(), scaling(1 / inputSampleRate))->value(bin);
+}
+double ref_bark_bin_inverse(double warped, double inputSampleRate) {
+    return Math::nest(barkWarp(), scaling(1 / inputSampleRate))->invert()->value(warped);
+}
+double ref_bark_bin_derivative(double bin, double inputSampleRate) {
+    return Math::nest(barkWarp()->derive(), scaling(1 / inputSampleRate))->value(bin);
+}
+// Math::EqualLoudnessPreemphasis / EqualLoudnessPreemphasis4Khz (Math/AcousticalAnalyticFunctions.cc:21-37, compiled unmodified)
+double ref_equal_loudness(double f, int fourKhz) {
+    Math::UnaryAnalyticFunctionRef e = fourKhz ? Math::UnaryAnalyticFunctionRef(new Math::EqualLoudnessPreemphasis4Khz)
+                                               : Math::UnaryAnalyticFunctionRef(new Math::EqualLoudnessPreemphasis);
+    return e->value(f);
+}
+// plp.flow's f = "nest(nest(disc-to-cont, invert(bark)), equal-loudness-preemphasis)": the factory's "nest(g, f)" builds
+// Math::nest(f, g) (AnalyticFunctionFactory.cc:161-180), disc-to-cont = scaling(1 / sampleRate) (:322-327)
+double ref_plp_equal_loudness(double index, double sampleRate, int fourKhz) {
+    Math::UnaryAnalyticFunctionRef g = Math::nest(barkWarp()->invert(), scaling(1 / sampleRate));
+    Math::UnaryAnalyticFunctionRef e = fourKhz ? Math::UnaryAnalyticFunctionRef(new Math::EqualLoudnessPreemphasis4Khz)
+                                               : Math::UnaryAnalyticFunctionRef(new Math::EqualLoudnessPreemphasis);
+    return Math::nest(e, g)->value(index);
+}
 
 void ref_fft_real(float* v, int n) {
     std::vector<float> d(v, v + n);

@@ -130,12 +130,15 @@ class MfccExtractor:
     def __init__(self, ctx, nr_cepstrum_coefficients=16, filter_width=268.258, sample_rate=16000.0, alpha=1.0,
                  length=0.025, shift=0.01, maximum_input_size=0.025, apply_scale=True, spacing=0.0,
                  warp_differential_unit=True, normalize=False, front_end="mfcc", nr_autocorrelation_coefficients=0,
-                 intensity_loudness_power=0.33):
-        """front_end "mfcc" (mfcc.flow) or "mfplp" (mfplp.flow: pass normalize=True and nr_autocorrelation_coefficients)"""
+                 intensity_loudness_power=0.33, type="triangular", boundary="stretch-to-cover", warping_function="mel"):
+        """front_end "mfcc" (mfcc.flow), "mfplp" (mfplp.flow: pass normalize=True and nr_autocorrelation_coefficients) or "plp"
+        (plp.flow: MfccExtractor.plp() fills in that file's values); type / boundary / warping_function are signal-filterbank's"""
         self.ctx, self.L = ctx, ctx.L
         cfg = MfccCfg(sample_rate, length, shift, alpha, maximum_input_size, int(apply_scale), filter_width, spacing,
                       int(warp_differential_unit), nr_cepstrum_coefficients, int(normalize),
-                      {"mfcc": 0, "mfplp": 1}[front_end], int(nr_autocorrelation_coefficients), float(intensity_loudness_power))
+                      {"mfcc": 0, "mfplp": 1, "plp": 2}[front_end], int(nr_autocorrelation_coefficients), float(intensity_loudness_power),
+                      {"triangular": 0, "trapeze": 1}[type], {"stretch-to-cover": 0, "include-boundary": 1, "emphasize-boundary": 2}[boundary],
+                      {"mel": 0, "bark": 1}[warping_function])
         h = C.c_void_p()
         _lib.check(self.L.amx_mfcc_create(ctx.h, C.byref(cfg), C.byref(h)))
         self.h = h
@@ -153,6 +156,19 @@ class MfccExtractor:
         except Exception:
             pass
 
+    @classmethod
+    def plp(cls, ctx, nr_cepstrum_coefficients=13, nr_autocorrelation_coefficients=13, sample_rate=16000.0, spacing=0.93853,
+            filter_width=3.8, **kw):
+        """plp.flow: 20 ms Hamming window, no preemphasis, trapeze / include-boundary / bark filter bank, equal loudness"""
+        return cls(ctx, nr_cepstrum_coefficients=nr_cepstrum_coefficients, nr_autocorrelation_coefficients=nr_autocorrelation_coefficients,
+                   sample_rate=sample_rate, spacing=spacing, filter_width=filter_width, alpha=0.0, length=0.02, maximum_input_size=0.02,
+                   normalize=True, front_end="plp", type="trapeze", boundary="include-boundary", warping_function="bark", **kw)
+
+    def equal_loudness(self):
+        out = np.zeros(self.info.n_transform_inputs, np.float64)
+        _lib.check(self.L.amx_mfcc_equal_loudness(self.h, out.ctypes.data))
+        return out
+
     def n_frames(self, n_samples):
         return int(self.L.amx_mfcc_n_frames(self.h, n_samples))
 
@@ -165,7 +181,7 @@ class MfccExtractor:
         fs, fe, fo = np.zeros(i.n_filters, np.int32), np.zeros(i.n_filters, np.int32), np.zeros(i.n_filters + 1, np.int32)
         _lib.check(self.L.amx_mfcc_tables(self.h, None, None, None, fo.ctypes.data, None, None))
         fw = np.zeros(int(fo[-1]), np.float32)
-        dct = np.zeros((i.n_transform, i.n_filters), np.float32)
+        dct = np.zeros((i.n_transform, i.n_transform_inputs), np.float32)
         _lib.check(self.L.amx_mfcc_tables(self.h, win.ctypes.data, fs.ctypes.data, fe.ctypes.data, fo.ctypes.data,
                                           fw.ctypes.data, dct.ctypes.data))
         return dict(window=win, filter_start=fs, filter_end=fe, filter_offset=fo, filter_weights=fw, dct=dct)

@@ -29,13 +29,14 @@ class MfccCfg(C.Structure):
                 ("preemph_alpha", C.c_double), ("fft_max_input_s", C.c_double), ("apply_scale", C.c_int),
                 ("mel_filter_width", C.c_double), ("mel_spacing", C.c_double),
                 ("warp_differential_unit", C.c_int), ("n_ceps", C.c_int), ("dct_normalize", C.c_int),
-                ("front_end", C.c_int), ("n_autocorrelation", C.c_int), ("plp_power", C.c_double)]
+                ("front_end", C.c_int), ("n_autocorrelation", C.c_int), ("plp_power", C.c_double),
+                ("filter_type", C.c_int), ("boundary", C.c_int), ("warping", C.c_int)]
 
 
 class MfccInfo(C.Structure):
     _fields_ = [("frame_len", C.c_int), ("frame_shift", C.c_int), ("fft_len", C.c_int), ("n_bins", C.c_int),
                 ("n_filters", C.c_int), ("n_ceps", C.c_int), ("fft_output_sample_rate", C.c_double),
-                ("mel_max", C.c_double), ("n_transform", C.c_int)]
+                ("mel_max", C.c_double), ("n_transform", C.c_int), ("n_transform_inputs", C.c_int)]
 
 
 class GmmModel(C.Structure):
@@ -72,6 +73,8 @@ SIGNATURES = {
     "amx_profile_get": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_long)]),
     "amx_mfcc_default_cfg": (None, [C.POINTER(MfccCfg)]),
     "amx_mfplp_default_cfg": (None, [C.POINTER(MfccCfg)]),
+    "amx_plp_default_cfg": (None, [C.POINTER(MfccCfg)]),
+    "amx_mfcc_equal_loudness": (C.c_int, [_P, _P]),
     "amx_mfcc_create": (C.c_int, [_P, C.POINTER(MfccCfg), C.POINTER(_P)]),
     "amx_mfcc_destroy": (None, [_P]),
     "amx_mfcc_describe": (C.c_int, [_P, C.POINTER(MfccInfo)]),

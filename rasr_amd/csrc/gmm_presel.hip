@@ -166,8 +166,8 @@ __global__ __launch_bounds__(256) void presel_score_kernel(const float* __restri
 }
 
 // glibc's srand(seed) / rand() (TYPE_3 additive feedback generator, r[i] = r[i-3] + r[i-31]): what the reference's
-// initializeClusters draws from.  Restated so that the library leaves the process-wide generator alone; tests compare the
-// clustering with the oracle, which calls libc's srand / rand.
+// initializeClusters draws from.  Restated so that the library leaves the process-wide generator alone; the tests compare the
+// clustering with a checker that calls libc's srand / rand.
 struct GlibcRand {
     std::vector<int32_t> state;  // r[0 .. i-1]; output k is r[k + 344] >> 1
     explicit GlibcRand(unsigned seed) {

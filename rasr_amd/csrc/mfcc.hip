@@ -50,9 +50,10 @@ struct MfccParams {
     const int*      foff;
     const float*    fweights;
     const float*    dct_t;  // transposed [n_filters][n_ceps]
+    const double*   eql;    // plp.flow: equal-loudness factor per cosine-transform input, else null
     const float2*   tw;     // [NC]  e^{+2 pi i k / NC}
     const float2*   stw;    // [NC/2+1] e^{+pi i k / NC}
-    int             frame_len, frame_shift, n_filters, n_ceps, n_weights;
+    int             frame_len, frame_shift, n_filters, n_ceps, n_weights;  // n_filters = cosine-transform inputs (plp.flow: first / last filter twice)
     int             frames_per_tile, n_tiles;
     float           alpha, fft_scale;
     int             apply_scale, dct_normalize;
@@ -409,6 +410,8 @@ __global__ __launch_bounds__(mfcc_waves(NC) * 64, (NC >= 1024 ? 1 : 4)) void mfc
                 acc        = acc + prod;
             }
         }
+        if (p.eql)  // plp.flow: in[i] = (f32)((f64)in[i] * f(i)) (Signal/VectorTransform.cc:78-83)
+            acc = (float)((double)acc * p.eql[flt]);
         if (f < tile.n_frames)
             s_lm[f * L.lm_ld + flt] = p.front_end ? __powf(acc, p.plp_power)  // intensity-loudness law
                                                   : __log10f(acc);           // v_log_f32 * log10(2): ~1 ulp of log2
@@ -487,6 +490,7 @@ struct amx_mfcc {
     float * d_window = nullptr, *d_fw = nullptr, *d_dct_t = nullptr;
     int *   d_fs = nullptr, *d_fe = nullptr, *d_fo = nullptr;
     float2 *d_tw = nullptr, *d_stw = nullptr;
+    double* d_eql = nullptr;
     size_t  lds_bytes = 0;
     float*  d_ac   = nullptr;  // MF-PLP: autocorrelation coefficients of the current call [frames x n_transform]
     size_t  ac_cap = 0;
@@ -512,7 +516,7 @@ int upload(T** dst, const T* src, size_t n) {
 }
 
 size_t mfcc_lds_bytes(const amx::MfccTables& t) {
-    amx::MfccLds L(t.frame_len, t.frame_shift, t.fft_len, t.n_filters, t.n_transform, (int)t.filter_weights.size());
+    amx::MfccLds L(t.frame_len, t.frame_shift, t.fft_len, t.n_inputs, t.n_transform, (int)t.filter_weights.size());
     return (size_t)L.total * 4;
 }
 
@@ -629,6 +633,27 @@ void amx_mfcc_default_cfg(amx_mfcc_cfg* c) {
     c->front_end              = AMX_FRONT_END_MFCC;
     c->n_autocorrelation      = 0;
     c->plp_power              = 0.33;
+    c->filter_type            = AMX_FILTER_TRIANGULAR;
+    c->boundary               = AMX_BOUNDARY_STRETCH_TO_COVER;
+    c->warping                = AMX_WARP_MEL;
+}
+
+void amx_plp_default_cfg(amx_mfcc_cfg* c) {
+    if (!c)
+        return;
+    amx_mfcc_default_cfg(c);
+    c->win_len_s         = 0.02;  // plp.flow: window length 0.02, maximum-input-size 0.02, no signal-preemphasis node
+    c->fft_max_input_s   = 0.02;
+    c->preemph_alpha     = 0.0;
+    c->mel_filter_width  = 3.8;
+    c->mel_spacing       = 0.93853;
+    c->filter_type       = AMX_FILTER_TRAPEZE;
+    c->boundary          = AMX_BOUNDARY_INCLUDE;
+    c->warping           = AMX_WARP_BARK;
+    c->front_end         = AMX_FRONT_END_PLP;
+    c->dct_normalize     = 1;
+    c->n_autocorrelation = 13;
+    c->n_ceps            = 13;
 }
 
 void amx_mfplp_default_cfg(amx_mfcc_cfg* c) {
@@ -671,16 +696,26 @@ int amx_mfcc_create(amx_ctx* ctx, const amx_mfcc_cfg* cfg, amx_mfcc** out) {
         delete h;
         return AMX_ERR_UNSUPPORTED;
     }
-    std::vector<float> dct_t((size_t)t.n_filters * t.n_transform);
+    std::vector<float> dct_t((size_t)t.n_inputs * t.n_transform);
     for (int k = 0; k < t.n_transform; ++k)
-        for (int n = 0; n < t.n_filters; ++n)
-            dct_t[(size_t)n * t.n_transform + k] = t.dct[(size_t)k * t.n_filters + n];
+        for (int n = 0; n < t.n_inputs; ++n)
+            dct_t[(size_t)n * t.n_transform + k] = t.dct[(size_t)k * t.n_inputs + n];
+    // the kernel walks the cosine-transform inputs: plp.flow's copies of the first and last filter output are two more entries
+    // that point at the same weights (generic-vector-f32-split port 0 / reversed port 0 + generic-vector-f32-concat)
+    std::vector<int> in_start((size_t)t.n_inputs), in_end((size_t)t.n_inputs), in_off((size_t)t.n_inputs);
+    for (int i = 0; i < t.n_inputs; ++i) {
+        const int src = t.n_inputs == t.n_filters ? i : std::min(std::max(i - 1, 0), t.n_filters - 1);
+        in_start[(size_t)i] = t.filter_start[(size_t)src];
+        in_end[(size_t)i]   = t.filter_end[(size_t)src];
+        in_off[(size_t)i]   = t.filter_offset[(size_t)src];
+    }
     if ((r = upload(&h->d_window, t.window.data(), t.window.size())) != AMX_OK ||
         (r = upload(&h->d_fw, t.filter_weights.data(), t.filter_weights.size())) != AMX_OK ||
         (r = upload(&h->d_dct_t, dct_t.data(), dct_t.size())) != AMX_OK ||
-        (r = upload(&h->d_fs, t.filter_start.data(), t.filter_start.size())) != AMX_OK ||
-        (r = upload(&h->d_fe, t.filter_end.data(), t.filter_end.size())) != AMX_OK ||
-        (r = upload(&h->d_fo, t.filter_offset.data(), t.filter_offset.size())) != AMX_OK ||
+        (r = upload(&h->d_fs, in_start.data(), in_start.size())) != AMX_OK ||
+        (r = upload(&h->d_fe, in_end.data(), in_end.size())) != AMX_OK ||
+        (r = upload(&h->d_fo, in_off.data(), in_off.size())) != AMX_OK ||
+        (!t.eql.empty() && (r = upload(&h->d_eql, t.eql.data(), t.eql.size())) != AMX_OK) ||
         (r = upload(&h->d_tw, (const float2*)t.twiddle.data(), t.twiddle.size() / 2)) != AMX_OK ||
         (r = upload(&h->d_stw, (const float2*)t.split_twiddle.data(), t.split_twiddle.size() / 2)) != AMX_OK) {
         amx_mfcc_destroy(h);
@@ -706,6 +741,7 @@ void amx_mfcc_destroy(amx_mfcc* h) {
     hipFree(h->d_fo);
     hipFree(h->d_tw);
     hipFree(h->d_stw);
+    hipFree(h->d_eql);
     hipFree(h->d_ac);
     delete h;
 }
@@ -721,6 +757,7 @@ int amx_mfcc_describe(const amx_mfcc* h, amx_mfcc_info* info) {
     info->fft_output_sample_rate = h->tab.fft_output_sample_rate;
     info->mel_max                = h->tab.mel_max;
     info->n_transform            = h->tab.n_transform;
+    info->n_transform_inputs     = h->tab.n_inputs;
     return AMX_OK;
 }
 
@@ -747,6 +784,13 @@ int amx_mfcc_tables(const amx_mfcc* h, float* window, int* fs, int* fe, int* fo,
         memcpy(fw, t.filter_weights.data(), t.filter_weights.size() * 4);
     if (dct)
         memcpy(dct, t.dct.data(), t.dct.size() * 4);
+    return AMX_OK;
+}
+
+int amx_mfcc_equal_loudness(const amx_mfcc* h, double* factors) {
+    AMX_REQUIRE(h && factors, AMX_ERR_INVALID, "amx_mfcc_equal_loudness: NULL argument");
+    AMX_REQUIRE(!h->tab.eql.empty(), AMX_ERR_STATE, "amx_mfcc_equal_loudness: not a plp.flow front end");
+    memcpy(factors, h->tab.eql.data(), h->tab.eql.size() * sizeof(double));
     return AMX_OK;
 }
 
@@ -836,10 +880,11 @@ int amx_mfcc_run_plan_dev(amx_mfcc* h, const amx_mfcc_plan* p, const float* pcm_
     k.stw             = h->d_stw;
     k.frame_len       = t.frame_len;
     k.frame_shift     = t.frame_shift;
-    k.n_filters       = t.n_filters;
+    k.n_filters       = t.n_inputs;
+    k.eql             = h->d_eql;
     k.n_ceps          = t.n_transform;
     k.n_weights       = (int)t.filter_weights.size();
-    k.front_end       = t.cfg.front_end == AMX_FRONT_END_MFPLP ? 1 : 0;
+    k.front_end       = t.cfg.front_end != AMX_FRONT_END_MFCC ? 1 : 0;
     k.norm_div        = t.norm_div;
     k.plp_power       = (float)t.cfg.plp_power;
     const long long total_frames = p->frame_off.back();

@@ -4,9 +4,11 @@
 // configure()/init() time, so that the device kernel consumes bit-identical tables:
 //   Hamming window        Signal/WindowFunction.cc:92-101
 //   FFT length            Signal/FastFourierTransform.cc:30-41, FastFourierTransform.hh:299-308
-//   mel filter bank       Signal/Filterbank.cc:144-244 (filter builder), :519-567 (stretch-to-cover),
-//                         :765-819 (node init), Math/AcousticalAnalyticFunctions.hh:24-60,
-//                         Math/AnalyticFunctionFactory.cc:338-341
+//   filter bank           Signal/Filterbank.cc:144-244 (filter builder, triangle), :246-275 (trapeze), :432-470
+//                         (include-boundary), :519-567 (stretch-to-cover), :575-595 (emphasize-boundary), :765-819 (node init);
+//                         mel: Math/AcousticalAnalyticFunctions.hh:24-60, Math/AnalyticFunctionFactory.cc:338-341;
+//                         bark: Math/AnalyticFunctionFactory.cc:369-373, Math/SimpleAnalyticFunctions.hh:152-222
+//   equal loudness        Signal/VectorTransform.cc:36-83, Math/AcousticalAnalyticFunctions.cc:21-37 (plp.flow)
 //   cosine transform      Signal/CosineTransform.cc:62-74
 #include "mfcc_tables.hpp"
 
@@ -35,13 +37,63 @@ struct MelWarp {  // nest(Scaling(2595), MelWarpingCore) in the continuous domai
     double inverse(double m) const { return (std::pow(10, outer.inverse()(m)) - 1.0) * 700.0; }
 };
 
+struct BarkWarp {  // nest(Scaling(6), nest(ArcSinh, Scaling(1/600))) in the continuous domain
+    Scaling outer{6.0}, inner{1.0 / 600.0};
+    double  operator()(double f) const { return outer(std::asinh(inner(f))); }
+    // derive(): (const(6) o g)(f) * g'(f) with g' = (DerivedArcSinh o inner)(f) * const(1/600)
+    double derivative(double f) const {
+        const double u = inner(f);
+        return outer.a * ((1.0 / std::sqrt(u * u + 1.0)) * inner.a);
+    }
+    // invert(): inner^-1 o sinh o outer^-1
+    double inverse(double b) const { return inner.inverse()(std::sinh(outer.inverse()(b))); }
+};
+
+// the warping-function parameter: one of the two, behind one interface
+struct Warp {
+    int      kind;  // AMX_WARP_MEL / AMX_WARP_BARK
+    MelWarp  mel;
+    BarkWarp bark;
+    double   operator()(double f) const { return kind == AMX_WARP_BARK ? bark(f) : mel(f); }
+    double   derivative(double f) const { return kind == AMX_WARP_BARK ? bark.derivative(f) : mel.derivative(f); }
+    double   inverse(double w) const { return kind == AMX_WARP_BARK ? bark.inverse(w) : mel.inverse(w); }
+};
+
+// Math::EqualLoudnessPreemphasis / EqualLoudnessPreemphasis4Khz
+double equal_loudness(double f) {
+    const double omega = 2 * M_PI * f, o2 = omega * omega, o4 = o2 * o2, o6 = o4 * o2;
+    return (o4 * (o2 + 56.8e6)) / ((o2 + 6.3e6) * (o2 + 6.3e6) * (o2 + 0.38e9) * (o6 / 9.58e26 + 1));
+}
+double equal_loudness_4khz(double f) {
+    const double omega = 2 * M_PI * f, o2 = omega * omega, t4 = o2 / (o2 + 6.3e6);
+    return t4 * t4 * (o2 + 56.8e6) / (o2 + 0.38e9);
+}
+
 bool almost_integer(double x) {  // FilterBank::isAlmostInteger, tolerance 1e-10
     return std::fabs(x - std::round(x)) < 1e-10;
 }
 
-bool almost_equal(double a, double b) {  // Core::isAlmostEqual(f64, f64, 1)
+bool almost_equal(double a, double b, double tolerance = 1.0) {  // Core::isAlmostEqual(f64, f64, tolerance)
     const double eps = 2.2204460492503131e-16, delta = 2.2250738585072014e-308;
-    return std::fabs(a - b) < (std::fabs(a) + std::fabs(b) + delta) * eps;
+    return std::fabs(a - b) < (std::fabs(a) + std::fabs(b) + delta) * eps * tolerance;
+}
+
+double postprocess_filter_count(double n) {  // Boundary::postprocessNumberOfFilters
+    if (n < 1)
+        return 1;
+    return almost_integer(n) ? std::round(n) : n;
+}
+
+float trapeze_weight(double frequency, double centre, double width) {  // TrapezeFilterBuilder::weight
+    const double middle = 0.5 / (1.3 - (-2.5));
+    const double rel    = frequency - centre;
+    const double left   = -middle * width;
+    if (rel < left)
+        return (float)std::pow(10, rel - left);
+    const double right = middle * width;
+    if (rel <= right)
+        return 1;
+    return (float)std::pow(10, -2.5 * (rel - right));
 }
 
 // Flow attributes are strings: "sample-rate" is written with operator<<(f64) (6 significant
@@ -87,48 +139,57 @@ int MfccTables::build(const amx_mfcc_cfg& c) {
             window[n] = window[M - n] = (float)(0.54 - 0.46 * std::cos(2.0 * M_PI * n / M));
     }
 
-    // ---- mel filter bank (triangular, stretch-to-cover, warp-center-positions = true)
+    // ---- filter bank (warp-center-positions = true: the boundary places the centres on the warped axis)
+    AMX_REQUIRE(c.filter_type == AMX_FILTER_TRIANGULAR || c.filter_type == AMX_FILTER_TRAPEZE, AMX_ERR_INVALID, "mfcc: unknown filter type %d", c.filter_type);
+    AMX_REQUIRE(c.boundary >= AMX_BOUNDARY_STRETCH_TO_COVER && c.boundary <= AMX_BOUNDARY_EMPHASIZE, AMX_ERR_INVALID, "mfcc: unknown boundary type %d", c.boundary);
+    AMX_REQUIRE(c.warping == AMX_WARP_MEL || c.warping == AMX_WARP_BARK, AMX_ERR_INVALID, "mfcc: unknown warping function %d", c.warping);
+    AMX_REQUIRE(c.front_end >= AMX_FRONT_END_MFCC && c.front_end <= AMX_FRONT_END_PLP, AMX_ERR_INVALID, "mfcc: unknown front end %d", c.front_end);
+    eql.clear();
     {
         const double  bin_rate = through_attribute(fft_output_sample_rate);
         const Scaling disc2cont{1 / bin_rate};
         const Scaling cont2disc = disc2cont.inverse();
-        const MelWarp mel;
-        const double  f_min = 0.0;
-        const double  f_max = mel(disc2cont((double)(n_bins - 1)));
+        Warp          warp;
+        warp.kind           = c.warping;
+        const double f_min  = 0.0;
+        const double f_max  = warp(disc2cont((double)(n_bins - 1)));
         mel_max             = f_max;
 
-        const double centre_pos = 0.5;  // symmetrical triangle
+        const double centre_pos = c.filter_type == AMX_FILTER_TRAPEZE ? 2.5 / (1.3 - (-2.5)) : 0.5;  // normalizedCenterPosition
         double       width      = c.mel_filter_width;
         double       spacing    = c.mel_spacing == 0 ? centre_pos * width : c.mel_spacing;
-        // StretchToCover::getNumberOfFilters + postprocessNumberOfFilters
-        double count = (f_max - f_min - width) / spacing + 1;
-        if (count < 1)
-            count = 1;
-        else if (almost_integer(count))
-            count = std::round(count);
-        const size_t nf = (size_t)std::floor(count);
-        // StretchToCover::init: stretch width and spacing so the last filter ends on f_max
-        const double coverage = (spacing * (double)(nf - 1) + width) / (f_max - f_min);
-        const bool   single_covers = nf == 1 && coverage > 1 && !almost_equal(coverage, 1);
-        if (!single_covers) {
-            AMX_REQUIRE(almost_equal(coverage, 1) || coverage < 1, AMX_ERR_INVALID, "mfcc: filter bank coverage %f > 1", coverage);
-            width /= coverage;
-            spacing /= coverage;
+        size_t       nf;
+        if (c.boundary == AMX_BOUNDARY_STRETCH_TO_COVER) {
+            // StretchToCover::getNumberOfFilters, then init: stretch width and spacing so the last filter ends on f_max
+            nf                     = (size_t)std::floor(postprocess_filter_count((f_max - f_min - width) / spacing + 1));
+            const double coverage  = (spacing * (double)(nf - 1) + width) / (f_max - f_min);
+            const bool   single_covers = nf == 1 && coverage > 1 && !almost_equal(coverage, 1);
+            if (!single_covers) {
+                AMX_REQUIRE(almost_equal(coverage, 1) || coverage < 1, AMX_ERR_INVALID, "mfcc: filter bank coverage %f > 1", coverage);
+                width /= coverage;
+                spacing /= coverage;
+            }
         }
+        else if (c.boundary == AMX_BOUNDARY_INCLUDE)  // first centre at `spacing`, last filter reaches beyond f_max
+            nf = (size_t)std::ceil(postprocess_filter_count((f_max - (1 - centre_pos) * width) / spacing));
+        else  // emphasize-boundary: first centre at 0
+            nf = (size_t)std::floor(postprocess_filter_count(f_max / spacing + 1));
         n_filters = (int)nf;
         filter_start.assign(nf, 0);
         filter_end.assign(nf, 0);
         filter_offset.assign(nf + 1, 0);
         filter_weights.clear();
         for (size_t i = 0; i < nf; ++i) {
-            const double centre = f_min + spacing * (double)i + centre_pos * width;
+            const double centre = c.boundary == AMX_BOUNDARY_STRETCH_TO_COVER ? f_min + spacing * (double)i + centre_pos * width
+                                  : c.boundary == AMX_BOUNDARY_INCLUDE        ? spacing * (double)(i + 1)
+                                                                              : spacing * (double)i;
             // FilterBuilder::setStart / setEnd
             double left  = std::max(centre - centre_pos * width, f_min);
-            double first = cont2disc(mel.inverse(left));
+            double first = cont2disc(warp.inverse(left));
             first        = almost_integer(first) ? std::round(first) : std::ceil(first);
             AMX_REQUIRE(first >= 0, AMX_ERR_INVALID, "mfcc: Start point of the filter at center %f became negative (%d).", centre, (int)first);
             double right = std::min(centre + (1.0 - centre_pos) * width, f_max);
-            double last  = cont2disc(mel.inverse(right));
+            double last  = cont2disc(warp.inverse(right));
             last         = almost_integer(last) ? std::round(last) + 1 : std::ceil(last);
             const size_t b0 = (size_t)first;
             AMX_REQUIRE(last > 0 && b0 < (size_t)last, AMX_ERR_INVALID,
@@ -138,29 +199,54 @@ int MfccTables::build(const amx_mfcc_cfg& c) {
             filter_start[i]  = (int)b0;
             filter_end[i]    = (int)b1;
             filter_offset[i] = (int)filter_weights.size();
-            // FilterBuilder::setWeights: triangle (rounded to f32) * d mel / d f (f64) -> f32
+            // FilterBuilder::setWeights: shape (rounded to f32) * d warp / d f (f64) -> f32
             for (unsigned b = (unsigned)b0; b < b1; ++b) {
-                const double warped = mel(disc2cont((double)b));
-                float        tri    = (float)((double)1 - std::fabs(warped - centre) / (width / 2));
-                tri                 = tri >= 0 ? tri : 0;
-                const double slope  = c.warp_differential_unit ? mel.derivative(disc2cont((double)b)) : 1.0;
-                filter_weights.push_back((float)(tri * slope));
+                const double warped = warp(disc2cont((double)b));
+                float        shape;
+                if (c.filter_type == AMX_FILTER_TRAPEZE)
+                    shape = trapeze_weight(warped, centre, width);
+                else {
+                    shape = (float)((double)1 - std::fabs(warped - centre) / (width / 2));
+                    shape = shape >= 0 ? shape : 0;
+                }
+                const double slope = c.warp_differential_unit ? warp.derivative(disc2cont((double)b)) : 1.0;
+                filter_weights.push_back((float)(shape * slope));
             }
         }
         filter_offset[nf] = (int)filter_weights.size();
+        n_inputs          = n_filters;
+
+        if (c.front_end == AMX_FRONT_END_PLP) {
+            // plp.flow: the filter-bank vector is extended by copies of its first and last element and multiplied by
+            // f(i) = equal-loudness(bark^-1(i / sample-rate)), sample-rate = the filter bank's output attribute 1 / spacing as text
+            // ("nest(nest(disc-to-cont, invert(bark)), equal-loudness-preemphasis)", Math/AnalyticFunctionFactory.cc:161-180,322-327);
+            // the 4 kHz curve unless the top of the axis is significantly greater than 4000 Hz (:543-556)
+            AMX_REQUIRE(c.boundary != AMX_BOUNDARY_STRETCH_TO_COVER, AMX_ERR_INVALID,
+                        "plp: stretch-to-cover reports an output sample rate of 1, the equal-loudness transform needs the bark axis");
+            n_inputs = n_filters + 2;
+            const BarkWarp bark;
+            const Scaling  index_to_bark{1 / through_attribute((double)1 / spacing)};
+            const double   top  = bark.inverse(index_to_bark((double)(n_inputs - 1)));
+            const bool     full = top > 4000.0 && !almost_equal(top, 4000.0, 1e12);
+            eql.resize((size_t)n_inputs);
+            for (int i = 0; i < n_inputs; ++i) {
+                const double f = bark.inverse(index_to_bark((double)i));
+                eql[(size_t)i] = full ? equal_loudness(f) : equal_loudness_4khz(f);
+            }
+        }
     }
 
-    if (c.front_end == AMX_FRONT_END_MFPLP) {
+    if (c.front_end == AMX_FRONT_END_MFPLP || c.front_end == AMX_FRONT_END_PLP) {
         // ---- cosine transform for N-plus-one input data (Signal/CosineTransform.cc:46-60), identity warping: the inverse DFT of
         // an even spectrum sampled at N + 1 points -> autocorrelation coefficients
         // CosineTransformNode: nr-outputs <= inputs; AutoregressionToCepstrumNode::init: "Incorrect output size"
-        AMX_REQUIRE(c.n_autocorrelation >= 2 && c.n_autocorrelation <= n_filters, AMX_ERR_INVALID,
-                    "mfplp: nr-autocorrelation-coefficients (%d) must be in 2..%d (filter bank outputs)", c.n_autocorrelation, n_filters);
+        AMX_REQUIRE(c.n_autocorrelation >= 2 && c.n_autocorrelation <= n_inputs, AMX_ERR_INVALID,
+                    "mfplp: nr-autocorrelation-coefficients (%d) must be in 2..%d (cosine transform inputs)", c.n_autocorrelation, n_inputs);
         AMX_REQUIRE(c.n_ceps >= 2 && c.n_ceps <= c.n_autocorrelation, AMX_ERR_INVALID,
                     "mfplp: Incorrect output size (%d). 2 < nr-outputs <= %d.", c.n_ceps, c.n_autocorrelation);
         AMX_REQUIRE(c.n_autocorrelation <= 64, AMX_ERR_UNSUPPORTED, "mfplp: LPC order %d > 63", c.n_autocorrelation - 1);
         n_transform    = c.n_autocorrelation;
-        const size_t C = (size_t)n_filters, N = C - 1;
+        const size_t C = (size_t)n_inputs, N = C - 1;
         norm_div       = (float)N;
         dct.assign((size_t)n_transform * C, 0.f);
         for (size_t k = 0; k < (size_t)n_transform; ++k) {
@@ -173,7 +259,6 @@ int MfccTables::build(const amx_mfcc_cfg& c) {
         }
     }
     else {
-        AMX_REQUIRE(c.front_end == AMX_FRONT_END_MFCC, AMX_ERR_INVALID, "mfcc: unknown front end %d", c.front_end);
         // ---- DCT-II, even about N-1/2, identity warping
         const size_t N = (size_t)n_filters;
         n_transform    = n_ceps;

@@ -13,7 +13,8 @@ struct MfccTables {
     int          frame_shift = 0;  // rint(shift * fs)
     int          fft_len     = 0;  // next power of two          Signal/FastFourierTransform.cc:30-41
     int          n_bins      = 0;  // fft_len/2 + 1
-    int          n_filters   = 0;
+    int          n_filters   = 0;  // filters of the bank
+    int          n_inputs    = 0;  // size of the vector the cosine transform sees: n_filters, or n_filters + 2 (plp.flow copies the first and last output)
     int          n_ceps      = 0;  // output dimension
     int          n_transform = 0;  // rows of the cosine-transform table: n_ceps, or nr-autocorrelation-coefficients (MF-PLP)
     float        norm_div    = 1;  // CosineTransform::apply divides by N_ when normalize is set: inputs (MFCC) or inputs - 1 (N-plus-one)
@@ -26,7 +27,8 @@ struct MfccTables {
     std::vector<int>   filter_end;     // [n_filters]
     std::vector<int>   filter_offset;  // [n_filters+1]
     std::vector<float> filter_weights; // concatenated
-    std::vector<float> dct;            // [n_transform][n_filters]
+    std::vector<float> dct;            // [n_transform][n_inputs]
+    std::vector<double> eql;           // [n_inputs] equal-loudness factors (plp.flow), else empty
     std::vector<float> twiddle;        // [fft_len/2][2] cos,sin of +2*pi*k/(fft_len/2)  (complex FFT)
     std::vector<float> split_twiddle;  // [fft_len/4][2] cos,sin of +pi*k/(fft_len/2)    (real split)
 

@@ -5,7 +5,8 @@
 * ref_*.npz / ref_*.json are OUTPUTS OF THE REFERENCE ITSELF: oracle/_ref/libref.so is built by
   oracle/ref/Makefile from unmodified reference translation units (Math::FastFourierTransform,
   Signal::WindowBuffer, the mel warping functors, Mm::gaussLogNormFactor / inverseSquareRoot,
-  Math::Matrix<f32> * Math::Vector<f32>, Math::transformAlternatingComplex / pointerAbs).
+  Math::Matrix<f32> * Math::Vector<f32>, Math::transformAlternatingComplex / pointerAbs, the bark warping functors and
+  Math::EqualLoudnessPreemphasis[4Khz]).
 * survey_c1.json holds the known answers the reference produced in this container during the survey
   (SURVEY.md Appendix C.1).
 * nn_kat.json is transcribed from the reference's unit tests (see its "source" field).
@@ -26,8 +27,48 @@ from oracle import OracleGmm, OracleMfcc, load_ref, oracle_ffnn_score  # noqa: E
 from tests import synth  # noqa: E402
 
 
+def bark_golden(R):
+    """ref_bark.json: bark warping (value / derivative / inverse, alone and nested with disc-to-cont), both equal-loudness curves and
+    plp.flow's composed f(index), evaluated by the reference's own analytic-function classes (f64 as hex strings); plus
+    orc_plp.npz, outputs of the oracle's plp.flow chain after it has been pinned on those"""
+    rows = []
+    for f in [0.0, 31.25, 62.5, 440.0, 1234.5, 3999.99, 4000.0, 7968.75, 8000.0]:
+        b = R.ref_bark(f)
+        rows.append(dict(f=float(f).hex(), bark=float(b).hex(), dbark=float(R.ref_bark_derivative(f)).hex(),
+                         inv=float(R.ref_bark_inverse(b)).hex(), eql=float(R.ref_equal_loudness(f, 0)).hex(),
+                         eql4k=float(R.ref_equal_loudness(f, 1)).hex()))
+    bins = []
+    for sr in (0.032, 0.064):
+        for b in [0, 1, 7, 100, 255, 256]:
+            w = R.ref_bark_bin(b, sr)
+            bins.append(dict(bin=b, sr=sr, warped=float(w).hex(), dwarped=float(R.ref_bark_bin_derivative(b, sr)).hex(),
+                             back=float(R.ref_bark_bin_inverse(w, sr)).hex()))
+    idx = []
+    for sr_text, n, four in (("1.0655", 22, 0), ("1.02728", 17, 1)):   # "%g" of 1 / 0.93853 and of 1 / 0.973442 (plp.flow's two spacings)
+        sr = float(sr_text)
+        idx.append(dict(sr=sr, four_khz=four, values=[float(R.ref_plp_equal_loudness(float(i), sr, four)).hex() for i in range(n)]))
+    json.dump(dict(bark=rows, bins=bins, plp_f=idx), open(os.path.join(HERE, "ref_bark.json"), "w"), indent=0)
+    from oracle.binding import MfccCfg
+    pcm = synth.waveform(16000, seed=1)
+    gold = {}
+    for tag, cfg in (("plp16k", MfccCfg.plp(n_ceps=13, n_autocorrelation=13)),
+                     ("plp8k", MfccCfg.plp(n_ceps=11, n_autocorrelation=11, spacing=0.973442, sample_rate=8000.0))):
+        m = OracleMfcc(cfg)
+        gold[tag] = m.run(pcm)
+        for k, v in m.stages(pcm, 3).items():
+            if k in ("mel", "logmel", "ceps"):
+                gold[tag + "_f3_" + k] = v
+        gold[tag + "_eql"] = m.equal_loudness
+        s, e, o, w = m.filters
+        gold[tag + "_fstart"], gold[tag + "_fend"], gold[tag + "_fweights"] = s, e, w
+    np.savez_compressed(os.path.join(HERE, "orc_plp.npz"), **gold)
+
+
 def main():
     R = load_ref()
+    if sys.argv[1:] == ["bark"]:
+        bark_golden(R)
+        return
     if R is None:
         raise SystemExit("oracle/_ref/libref.so not available (needs /root/reference)")
     rng = np.random.Generator(np.random.PCG64(2024))
@@ -126,6 +167,7 @@ def main():
                         scores64=oracle_ffnn_score(Ws, bs, acts, x, log_prior=logp, acc64=1),
                         scores_fma=oracle_ffnn_score(Ws, bs, acts, x, log_prior=logp, acc64=2),
                         **{"W%d" % i: w for i, w in enumerate(Ws)}, **{"b%d" % i: b for i, b in enumerate(bs)})
+    bark_golden(R)
     print("golden vectors written to", HERE)
 
 

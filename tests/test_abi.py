@@ -42,6 +42,11 @@ def test_no_gpu_fails_loudly():
         rasr_amd.Context(0)
 
 
+# plp.flow's parameter values (amx_plp_default_cfg)
+PLP = dict(front_end=2, win_len_s=0.02, fft_max_input_s=0.02, preemph_alpha=0.0, mel_filter_width=3.8, mel_spacing=0.93853,
+           filter_type=1, boundary=1, warping=1, dct_normalize=1, n_autocorrelation=13, n_ceps=13)
+
+
 def host_mfcc(**kw):
     L = _lib.lib()
     cfg = _lib.MfccCfg()
@@ -57,7 +62,12 @@ def host_mfcc(**kw):
                                 dict(sample_rate=44100.0, n_ceps=13), dict(sample_rate=11025.0, mel_filter_width=150.0),
                                 dict(mel_spacing=100.0), dict(warp_differential_unit=0), dict(win_len_s=0.02, win_shift_s=0.0125),
                                 dict(front_end=1, n_autocorrelation=13, n_ceps=13, dct_normalize=1),
-                                dict(front_end=1, n_autocorrelation=12, n_ceps=9, dct_normalize=1, sample_rate=8000.0)])
+                                dict(front_end=1, n_autocorrelation=12, n_ceps=9, dct_normalize=1, sample_rate=8000.0),
+                                PLP, dict(PLP, sample_rate=8000.0, mel_spacing=0.973442, n_autocorrelation=11, n_ceps=11),
+                                dict(PLP, mel_spacing=0.0, n_autocorrelation=9, n_ceps=8), dict(PLP, boundary=2, sample_rate=11025.0),
+                                dict(filter_type=1, warping=1, boundary=1, mel_filter_width=3.8, mel_spacing=0.9),
+                                dict(warping=1, mel_filter_width=2.0), dict(boundary=2, mel_filter_width=300.0),
+                                dict(filter_type=1, mel_filter_width=500.0)])
 def test_host_tables_bit_identical_to_oracle(kw):
     L, h, st = host_mfcc(**kw)
     assert st == 0, L.amx_last_error()
@@ -74,13 +84,19 @@ def test_host_tables_bit_identical_to_oracle(kw):
     L.amx_mfcc_tables(h, None, None, None, fo.ctypes.data, None, None)
     win, fs, fe = np.zeros(info.frame_len, np.float32), np.zeros(info.n_filters, np.int32), np.zeros(info.n_filters, np.int32)
     assert info.n_transform == (kw["n_autocorrelation"] if kw.get("front_end") else info.n_ceps)
-    fw, dct = np.zeros(fo[-1], np.float32), np.zeros((info.n_transform, info.n_filters), np.float32)
+    assert info.n_transform_inputs == m.n_transform_inputs
+    fw, dct = np.zeros(fo[-1], np.float32), np.zeros((info.n_transform, info.n_transform_inputs), np.float32)
     L.amx_mfcc_tables(h, win.ctypes.data, fs.ctypes.data, fe.ctypes.data, fo.ctypes.data, fw.ctypes.data, dct.ctypes.data)
     s, e, off, w = m.filters
     assert np.array_equal(win.view(np.uint32), m.window.view(np.uint32))
     assert np.array_equal(fs, s) and np.array_equal(fe, e) and np.array_equal(fo, off)
     assert np.array_equal(fw.view(np.uint32), w.view(np.uint32))
     assert np.array_equal(dct.view(np.uint32), m.dct.view(np.uint32))
+    eql = np.zeros(info.n_transform_inputs, np.float64)
+    if kw.get("front_end") == 2:
+        assert L.amx_mfcc_equal_loudness(h, eql.ctypes.data) == 0 and np.array_equal(eql, m.equal_loudness)
+    else:
+        assert L.amx_mfcc_equal_loudness(h, eql.ctypes.data) == _lib.AMX_ERR_STATE
     for n in (0, 1, 399, 400, 401, 5000, 160000, 123457):
         assert L.amx_mfcc_n_frames(h, n) == m.n_frames(n)
     # frame start times accumulate like WindowBuffer (bufferStartTime_ += shift/fs)

@@ -1,4 +1,6 @@
 """GPU parity: fused MFCC kernel (through the C ABI) against the oracle restatement of mfcc.flow."""
+import os
+
 import numpy as np
 import pytest
 
@@ -188,3 +190,64 @@ def test_mfplp_ragged_batch_silence_and_device_plan(ctx):
     fe.run_plan(plan, pcm, ceps)
     torch.cuda.synchronize()
     assert np.array_equal(ceps.cpu().numpy(), np.concatenate(outs), equal_nan=True)
+
+
+# PLP (plp.flow): bark / trapeze / include-boundary filter bank, duplicated first / last output, equal-loudness weighting, then the
+# MF-PLP tail; same tolerance band as MF-PLP for the same reason (device __powf, conditioning of the recursions)
+@pytest.mark.parametrize("fs,spacing,nc,nac", [(16000.0, 0.93853, 13, 13), (16000.0, 0.93853, 9, 20), (8000.0, 0.973442, 11, 11)])
+def test_plp_ten_seconds(ctx, fs, spacing, nc, nac):
+    import rasr_amd
+    from oracle import OracleMfcc
+    from oracle.binding import MfccCfg
+    n = int(10 * fs)
+    pcm = synth.waveform(n, seed=5)
+    fe = rasr_amd.MfccExtractor.plp(ctx, nr_cepstrum_coefficients=nc, nr_autocorrelation_coefficients=nac, sample_rate=fs, spacing=spacing)
+    o = OracleMfcc(MfccCfg.plp(n_ceps=nc, n_autocorrelation=nac, spacing=spacing, sample_rate=fs))
+    assert (fe.n_filters, fe.info.n_transform_inputs) == (o.n_filters, o.n_filters + 2)
+    assert np.array_equal(fe.equal_loudness(), o.equal_loudness)
+    got, want = fe.run(pcm), o.run(pcm)
+    assert got.shape == want.shape == (999, nc) and np.all(np.isfinite(got))    # 20 ms window: (n - 320) / 160 + 1 frames at 16 kHz
+    assert np.all(np.abs(got - want) <= PLP_RTOL * np.abs(want) + PLP_ATOL), np.abs(got - want).max()
+    assert np.median(np.abs(got - want) / (np.abs(want) + 1e-2)) < 2e-5
+
+
+def test_plp_golden_and_ragged_batch(ctx):
+    """the committed oracle outputs (tests/golden/orc_plp.npz) and a ragged batch incl. a one-sample and a silent segment"""
+    import rasr_amd
+    from oracle import OracleMfcc
+    from oracle.binding import MfccCfg
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "orc_plp.npz"))
+    pcm = synth.waveform(16000, seed=1)
+    fe = rasr_amd.MfccExtractor.plp(ctx)
+    got = fe.run(pcm)
+    assert np.all(np.abs(got - g["plp16k"]) <= PLP_RTOL * np.abs(g["plp16k"]) + PLP_ATOL)
+    o = OracleMfcc(MfccCfg.plp())
+    segs = [synth.waveform(n, seed=300 + n) for n in (1, 319, 320, 321, 5281, 48077)]
+    segs.append(np.concatenate([synth.waveform(2000, seed=7), np.zeros(3000, np.float32), synth.waveform(1500, seed=8)]))
+    outs = fe.run_batch(segs)
+    for x, y in zip(segs, outs):
+        want = o.run(x)
+        assert y.shape == want.shape
+        nan = np.isnan(want)
+        assert np.array_equal(np.isnan(y), nan)
+        assert np.all(np.abs(y[~nan] - want[~nan]) <= PLP_RTOL * np.abs(want[~nan]) + PLP_ATOL)
+    assert np.isnan(outs[-1]).any()
+
+
+@pytest.mark.parametrize("kw,okw", [
+    (dict(type="trapeze", boundary="include-boundary", warping_function="bark", filter_width=3.8, spacing=0.9),
+     dict(filter_type=1, boundary=1, warping=1, mel_filter_width=3.8, mel_spacing=0.9)),
+    (dict(boundary="emphasize-boundary", filter_width=300.0), dict(boundary=2, mel_filter_width=300.0)),
+    (dict(warping_function="bark", filter_width=2.0), dict(warping=1, mel_filter_width=2.0))])
+def test_mfcc_with_other_filter_banks(ctx, kw, okw):
+    """signal-filterbank's other types / boundaries / warping functions in front of the MFCC tail (log10 + DCT)"""
+    import rasr_amd
+    from oracle import OracleMfcc
+    from oracle.binding import MfccCfg
+    cfg = MfccCfg.default(n_ceps=12)
+    for k, v in okw.items():
+        setattr(cfg, k, v)
+    pcm = synth.waveform(48000, seed=11)
+    got = rasr_amd.MfccExtractor(ctx, nr_cepstrum_coefficients=12, **kw).run(pcm)
+    want = OracleMfcc(cfg).run(pcm)
+    assert got.shape == want.shape and close(got, want), np.abs(got - want).max()

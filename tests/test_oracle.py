@@ -69,6 +69,72 @@ def test_mel_functions_against_reference_functors():
         assert (1 / d2c) * L.orc_mel_inverse(L.orc_mel(d2c * r["bin"])) == float.fromhex(r["back"])
 
 
+def test_bark_and_equal_loudness_against_reference_functors():
+    """bark warping (value, derivative, inverse; alone and nested with disc-to-cont like FilterBuilder::create) and both
+    equal-loudness curves against the reference's analytic-function classes compiled unmodified (ref_bark.json, f64 bit-exact);
+    plp.flow's composed f(index) equals the oracle's equal-loudness table for both documented spacings"""
+    from oracle.binding import MfccCfg
+    L = Oracle()
+    g = json.load(open(os.path.join(GOLD, "ref_bark.json")))
+    for r in g["bark"]:
+        f = float.fromhex(r["f"])
+        assert L.orc_bark(f) == float.fromhex(r["bark"])
+        assert L.orc_bark_derivative(f) == float.fromhex(r["dbark"])
+        assert L.orc_bark_inverse(L.orc_bark(f)) == float.fromhex(r["inv"])
+        assert L.orc_equal_loudness(f) == float.fromhex(r["eql"])
+        assert L.orc_equal_loudness_4khz(f) == float.fromhex(r["eql4k"])
+    for r in g["bins"]:
+        d2c = 1 / r["sr"]
+        assert L.orc_bark(d2c * r["bin"]) == float.fromhex(r["warped"])
+        assert L.orc_bark_derivative(d2c * r["bin"]) == float.fromhex(r["dwarped"])
+        assert (1 / d2c) * L.orc_bark_inverse(L.orc_bark(d2c * r["bin"])) == float.fromhex(r["back"])
+    for r, cfg in zip(g["plp_f"], (MfccCfg.plp(), MfccCfg.plp(n_ceps=11, n_autocorrelation=11, spacing=0.973442, sample_rate=8000.0))):
+        m = OracleMfcc(cfg)
+        want = np.array([float.fromhex(v) for v in r["values"]])
+        assert m.n_transform_inputs == len(want)
+        assert np.array_equal(m.equal_loudness, want)        # also pins the choice of the 4 kHz curve for the 8 kHz front-end
+
+
+def test_plp_filter_bank_known_answers():
+    """the reference's own plp.flow documents its filter bank (Tools/FeatureExtraction/share/plp.flow:24-25):
+    '8000 Hz -> 19.708905 Bark; #filters 20 -> spacing = 0.93853; 4000 Hz -> 15.575071 Bark; #filters 15 -> spacing = 0.973442'"""
+    from oracle.binding import MfccCfg
+    m = OracleMfcc(MfccCfg.plp())
+    assert m.n_filters == 20 and abs(m.mel_max - 19.708905) < 1e-6 and (m.frame_len, m.fft_len) == (320, 512)
+    m = OracleMfcc(MfccCfg.plp(n_ceps=11, n_autocorrelation=11, spacing=0.973442, sample_rate=8000.0))
+    assert m.n_filters == 15 and abs(m.mel_max - 15.575071) < 1e-6 and (m.frame_len, m.fft_len) == (160, 256)
+    # trapeze geometry: a filter's weights are the f32 shape value times the f64 bark derivative; inside the flat top the shape
+    # is exactly 1, so the weight is the derivative itself
+    L = Oracle()
+    m = OracleMfcc(MfccCfg.plp())
+    s, e, o, w = m.filters
+    d2c = 1 / 0.032
+    for i in (3, 10, 19):
+        centre = 0.93853 * (i + 1)
+        flat = [b for b in range(s[i], e[i]) if abs(L.orc_bark(d2c * b) - centre) <= 0.5 - 1e-9]
+        assert flat, i
+        for b in flat:
+            assert w[o[i] + b - s[i]] == np.float32(L.orc_bark_derivative(d2c * b))
+        # left flank rises by a factor 10 per bark, right flank falls by 10^2.5 per bark
+        b = s[i] + 1
+        if L.orc_bark(d2c * b) - centre < -0.5:
+            rel = L.orc_bark(d2c * b) - centre
+            left = -(0.5 / (1.3 - (-2.5))) * 3.8
+            assert w[o[i] + 1] == np.float32(float(np.float32(10.0 ** (rel - left))) * L.orc_bark_derivative(d2c * b))
+
+
+def test_plp_oracle_outputs_unchanged():
+    """orc_plp.npz: the oracle's plp.flow outputs recorded after pinning -- drift detector for the GPU box"""
+    from oracle.binding import MfccCfg
+    g = np.load(os.path.join(GOLD, "orc_plp.npz"))
+    pcm = synth.waveform(16000, seed=1)
+    for tag, cfg in (("plp16k", MfccCfg.plp(n_ceps=13, n_autocorrelation=13)),
+                     ("plp8k", MfccCfg.plp(n_ceps=11, n_autocorrelation=11, spacing=0.973442, sample_rate=8000.0))):
+        m = OracleMfcc(cfg)
+        assert np.array_equal(bits(m.run(pcm)), bits(g[tag]))
+        assert np.array_equal(m.filters[3].view(np.uint32), g[tag + "_fweights"].view(np.uint32))
+
+
 def test_gmm_normalisation_terms_against_reference_templates():
     g = json.load(open(os.path.join(GOLD, "ref_functions.json")))["norm"]
     var = np.array(g["var"], np.float32)
@@ -101,6 +167,10 @@ def test_live_reference_build_agrees():
     for f in rng.uniform(0, 8000, 50):
         assert L.orc_mel(f) == R.ref_mel(f) and L.orc_mel_derivative(f) == R.ref_mel_derivative(f)
         assert L.orc_mel_inverse(L.orc_mel(f)) == R.ref_mel_inverse(R.ref_mel(f))
+    for f in rng.uniform(0, 8000, 50):
+        assert L.orc_bark(f) == R.ref_bark(f) and L.orc_bark_derivative(f) == R.ref_bark_derivative(f)
+        assert L.orc_bark_inverse(L.orc_bark(f)) == R.ref_bark_inverse(R.ref_bark(f))
+        assert L.orc_equal_loudness(f) == R.ref_equal_loudness(f, 0) and L.orc_equal_loudness_4khz(f) == R.ref_equal_loudness(f, 1)
     v = rng.uniform(0.1, 5, 39).astype(np.float32)
     model = synth.gmm_cart(1, 1, 1, 39, seed=3)
     model["variances"] = v.reshape(1, -1).copy()
