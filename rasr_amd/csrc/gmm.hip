@@ -1446,6 +1446,15 @@ struct amx_gmm {
     int       K = 0, mix_pad = 0;
     float*    d_m2lw_t = nullptr;  // [K][mix_pad]
     float *   d_ahat_t = nullptr, *d_amax = nullptr;  // screen tables: fl32(m2lw + logNorm) [K][mix_pad], max_k |.| [mix_pad]
+    // pruned path (gmm_tied.hip): per-tile minima of a^, per-call workspace, survivor statistics of earlier calls
+    float*              d_amin       = nullptr;  // [mix_pad / 64][Kpad]
+    void*               d_tied_ws    = nullptr;
+    size_t              tied_ws_cap  = 0;
+    unsigned long long* d_tied_surv  = nullptr;  // [256] survivors (density, frame, tile) of the calls so far, spread over 256 counters
+    unsigned long long* h_tied_surv  = nullptr;  // pinned host copy, refreshed asynchronously after every pruned call
+    unsigned long long  tied_seen    = 0;        // value of *h_tied_surv at the previous decision
+    unsigned long long  tied_triples = 0;        // (density, frame, tile) triples submitted since then
+    int                 tied_dense_calls = 0;    // > 0: stay on gmm_tied_tile_kernel for that many calls, then probe again
     double *  d_ln64 = nullptr, *d_dist64 = nullptr;
     float*    d_ln32 = nullptr;
     size_t    dist64_cap = 0;
@@ -1529,6 +1538,12 @@ extern "C" void  amx_internal_gmm_simd_destroy(void* p);
 extern "C" float amx_internal_gmm_simd_scaling(const void* p);
 extern "C" int   amx_internal_gmm_simd_score(void* p, amx_ctx* ctx, int variant, const float* feats_dev, int T, float* scores_dev, uint32_t* best_dev);
 
+extern "C" int    amx_internal_gmm_tied_create(int K, int n_mix, int mix_pad, const float* ahat_t_host, float** d_amin);
+extern "C" size_t amx_internal_gmm_tied_workspace(int K, int T, int mix_pad);
+extern "C" int    amx_internal_gmm_tied_score(amx_ctx* ctx, const float* dist_dev, const uint32_t* k_dens_dev, int K, int T, int Tpad, int n_mix,
+                                              int mix_pad, const float* ln32, const float* amax, const float* m2lw_t, const double* ln64,
+                                              const float* amin, void* workspace, float* scores, uint32_t* best,
+                                              unsigned long long* survivors_dev);
 extern "C" int amx_internal_gmm_fused_supported(int dim, int pooled, int Kp);
 extern "C" int amx_internal_gmm_fused_create(int dim, int n_mix, int n_tiles, const void* A2_host, const uint32_t* mix_off, const uint32_t* k_mean,
                                              const double* c64, const float* means, const float* p1, const float* p2, void** rec_dev,
@@ -1922,10 +1937,18 @@ int amx_gmm_create(amx_ctx* ctx, const amx_gmm_model* m, amx_gmm** out) {
             }
         if ((r = gupload(&h->d_m2lw_t, wt.data(), wt.size())) != AMX_OK || (r = gupload(&h->d_ln64, ln64.data(), ln64.size())) != AMX_OK ||
             (r = gupload(&h->d_ln32, ln32.data(), ln32.size())) != AMX_OK || (r = gupload(&h->d_ahat_t, ahat.data(), ahat.size())) != AMX_OK ||
-            (r = gupload(&h->d_amax, amax.data(), amax.size())) != AMX_OK) {
+            (r = gupload(&h->d_amax, amax.data(), amax.size())) != AMX_OK ||
+            (r = amx_internal_gmm_tied_create(h->K, h->n_mix, h->mix_pad, ahat.data(), &h->d_amin)) != AMX_OK) {
             amx_gmm_destroy(h);
             return r;
         }
+        if (hipMalloc((void**)&h->d_tied_surv, 256 * 8) != hipSuccess || hipMemset(h->d_tied_surv, 0, 256 * 8) != hipSuccess ||
+            hipHostMalloc((void**)&h->h_tied_surv, 256 * 8) != hipSuccess) {
+            amx::set_error("amx_gmm_create: out of memory (tied-model statistics)");
+            amx_gmm_destroy(h);
+            return AMX_ERR_DEVICE;
+        }
+        memset(h->h_tied_surv, 0, 256 * 8);
     }
     // ---- MFMA screen tables (gmm_screen_kernel): private densities, <= 16 per mixture, operand fits f16
     if (!h->tied && screen_dim_supported(m->dim) && !(getenv("AMX_GMM_SCREEN") && atoi(getenv("AMX_GMM_SCREEN")) == 0)) {
@@ -2089,6 +2112,11 @@ void amx_gmm_destroy(amx_gmm* h) {
     hipFree(h->d_m2lw_t);
     hipFree(h->d_ahat_t);
     hipFree(h->d_amax);
+    hipFree(h->d_amin);
+    hipFree(h->d_tied_ws);
+    hipFree(h->d_tied_surv);
+    if (h->h_tied_surv)
+        hipHostFree(h->h_tied_surv);
     hipFree(h->d_ln64);
     hipFree(h->d_ln32);
     delete h;
@@ -2332,8 +2360,50 @@ int amx_gmm_score_dev(amx_gmm* h, int mode, const float* feats_dev, int T, float
     hipLaunchKernelGGL((amx::gmm_combine_uniform_kernel<amx::STATE, F>), grid, dim3(256), 0, h->ctx->stream, h->d_dist, h->d_dist64, \
                        sc, bd, h->d_m2lw_t, h->d_k_dens, h->d_ln64, h->d_ln32, ud)
             if (mode == AMX_GMM_MAX && screen) {
-                hipLaunchKernelGGL(amx::gmm_tied_tile_kernel, dim3(h->mix_pad / 64, Tpad / 64), dim3(256), 0, h->ctx->stream, h->d_dist, sc, bd,
-                                   h->d_m2lw_t, h->d_ahat_t, h->d_amax, h->d_k_dens, h->d_ln64, ud);
+                // pruned exact path (gmm_tied.hip) unless the survivor statistics of earlier calls say that this model / these
+                // features leave too much standing (every table element would then be used once instead of 16 times from
+                // registers): AMX_GMM_TIED_PRUNE=0 forces the dense kernel, =1 the pruned one, default adaptive
+                const char* pe     = getenv("AMX_GMM_TIED_PRUNE");
+                const int   forced = pe ? atoi(pe) : -1;
+                bool        prune  = forced != 0;
+                if (forced < 0) {
+                    unsigned long long seen = 0;
+                    for (int i = 0; i < 256; ++i)
+                        seen += ((volatile unsigned long long*)h->h_tied_surv)[i];
+                    if (h->tied_dense_calls > 0) {
+                        --h->tied_dense_calls;
+                        prune = false;
+                    }
+                    else if (h->tied_triples >= (1ull << 20) && seen > h->tied_seen) {
+                        // fraction of the triples submitted up to the copy that stood (the copy may lag by a call: conservative enough)
+                        const double frac = (double)(seen - h->tied_seen) / (double)h->tied_triples;
+                        if (frac > 0.10) {
+                            h->tied_dense_calls = 64;
+                            prune               = false;
+                        }
+                        h->tied_seen    = seen;
+                        h->tied_triples = 0;
+                    }
+                }
+                if (prune) {
+                    const size_t need_ws = amx_internal_gmm_tied_workspace(h->K, Tc, h->mix_pad);
+                    if (need_ws > h->tied_ws_cap) {
+                        hipFree(h->d_tied_ws);
+                        h->d_tied_ws   = nullptr;
+                        h->tied_ws_cap = 0;
+                        AMX_HIP(hipMalloc(&h->d_tied_ws, need_ws));
+                        h->tied_ws_cap = need_ws;
+                    }
+                    int r = amx_internal_gmm_tied_score(h->ctx, h->d_dist, h->d_k_dens, h->K, Tc, Tpad, h->n_mix, h->mix_pad, h->d_ln32,
+                                                        h->d_amax, h->d_m2lw_t, h->d_ln64, h->d_amin, h->d_tied_ws, sc, bd, h->d_tied_surv);
+                    if (r != AMX_OK)
+                        return r;
+                    AMX_HIP(hipMemcpyAsync(h->h_tied_surv, h->d_tied_surv, 256 * 8, hipMemcpyDeviceToHost, h->ctx->stream));
+                    h->tied_triples += (unsigned long long)h->K * (unsigned long long)Tc * (unsigned long long)(h->mix_pad / 64);
+                }
+                else
+                    hipLaunchKernelGGL(amx::gmm_tied_tile_kernel, dim3(h->mix_pad / 64, Tpad / 64), dim3(256), 0, h->ctx->stream, h->d_dist, sc,
+                                       bd, h->d_m2lw_t, h->d_ahat_t, h->d_amax, h->d_k_dens, h->d_ln64, ud);
             }
             else if (mode == AMX_GMM_MAX) {
                 if (FR == 4) AMX_UNI(MaxState, 4);

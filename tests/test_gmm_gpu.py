@@ -706,6 +706,45 @@ def test_every_screened_dimension_and_operand_width(ctx, monkeypatch, dim, poole
     assert_exact(ctx, model, feats(300, dim, 301))
 
 
+@pytest.mark.parametrize("prune", ["1", "0"])
+@pytest.mark.parametrize("n_mix,n_dens,T,alpha", [(150, 96, 100, 2.0), (70, 64, 64, 0.1), (333, 1000, 37, 0.1), (65, 9000, 9, 0.3),
+                                                  (1000, 300, 513, 5.0)])
+def test_tied_pruned_and_dense_paths_exact(ctx, monkeypatch, prune, n_mix, n_dens, T, alpha):
+    """the pruned path (gmm_tied.hip: nearest-density bounds -> per-tile thresholds -> exact rule over the survivors) and the dense
+    (min,+) tile kernel, each forced, against the oracle: mixture counts that leave a partial last tile, density counts below /
+    above the near-list size, above the LDS staging of the selection kernel (9000) and not multiples of 64; flat weights
+    (alpha 5: little to prune) and peaked ones"""
+    monkeypatch.setenv("AMX_GMM_TIED_PRUNE", prune)
+    model = synth.gmm_tied(n_mix, n_dens, 24, seed=500 + n_dens, pooled=True, alpha=alpha)
+    x = feats(T, 24, 501 + T)
+    x[T // 2] *= 30.0
+    assert_exact(ctx, model, x)
+
+
+def test_tied_pruned_adversarial_and_statistics(ctx, monkeypatch):
+    """ties / one-ulp neighbours / huge constants through the pruned path; duplicated densities survive together (equal distances,
+    so equal bounds) and the FIRST wins.  The adaptive switch: a model where nothing can be pruned (all weights equal, all
+    distances equal) sends later calls to the dense kernel; results stay exact either way"""
+    import rasr_amd
+    monkeypatch.setenv("AMX_GMM_TIED_PRUNE", "1")
+    for n_dens, dup_every, big in ((96, 7, False), (200, 3, False), (130, 5, True)):
+        model = _tied_adversarial(41 + n_dens, 150, n_dens, 24, dup_every, big)
+        assert_exact(ctx, model, feats(100, 24, 43))
+    monkeypatch.delenv("AMX_GMM_TIED_PRUNE")
+    model = synth.gmm_tied(640, 512, 16, seed=77, pooled=True)
+    model["means"][:] = model["means"][0]                      # every density at the same place: equal distances
+    model["log_weight"][:] = np.log(1.0 / 512)                 # and equal weights: everything is a candidate
+    sc = rasr_amd.GmmFeatureScorer(ctx, model)
+    from oracle import OracleGmm
+    x = feats(256, 16, 78)
+    osc, ob = OracleGmm(model).score(x, mode=0)
+    for _ in range(6):                                         # the statistics of the first calls arrive, later calls go dense
+        a, b = sc.score(x)
+        assert np.array_equal(a.view(np.uint32), osc.view(np.uint32)) and np.array_equal(b, ob)
+    # equal f64 sums: the first density wins where (float)s rounded down, the LAST where it rounded up ((double)best > s again)
+    assert set(np.unique(ob)) <= {0, 511}
+
+
 @pytest.mark.parametrize("pooled", [True, False])
 def test_tied_non_finite_frames_keep_the_initial_result(ctx, pooled):
     """a frame with an inf / NaN / 1e30 feature has no finite density score: the reference keeps (FLT_MAX / 2, no density).  On the
