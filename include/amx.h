@@ -246,7 +246,9 @@ int amx_gmm_preselection_clustering(amx_gmm* h, int* n_clusters, uint32_t* clust
 /* Diagnostics of the screened diagonal-maximum scorer (no reference counterpart; bench.py prints survivors per mixture):
  * returns and clears the number of densities evaluated exactly and the number of (frame, mixture) pairs scored since the
  * last call, and switches the counting on (enable != 0) or off for the following calls.  Synchronises the stream.  Zero for
- * models that do not take the fused screened path. */
+ * models that do not take the fused screened path.  Tied models whose mixtures share one density list (pruned path,
+ * gmm_tied.hip): survivors = (density, frame, 64-mixture tile) triples whose weight rows were read, pairs = triples submitted
+ * (densities x frames x tiles); always counted. */
 int amx_gmm_screen_counts(amx_gmm* h, int enable, unsigned long long* survivors, unsigned long long* pairs);
 /* scores [T x n_mix]; best_density (nullable) [T x n_mix] = index within the mixture of the
  * minimising density (AssigningFeatureScorer::ScoreAndBestDensity). */

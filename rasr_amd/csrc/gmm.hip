@@ -1455,6 +1455,7 @@ struct amx_gmm {
     unsigned long long  tied_seen    = 0;        // value of *h_tied_surv at the previous decision
     unsigned long long  tied_triples = 0;        // (density, frame, tile) triples submitted since then
     int                 tied_dense_calls = 0;    // > 0: stay on gmm_tied_tile_kernel for that many calls, then probe again
+    unsigned long long  tied_rep_seen = 0, tied_rep_triples = 0;  // amx_gmm_screen_counts: counter value / triples at the last report
     double *  d_ln64 = nullptr, *d_dist64 = nullptr;
     float*    d_ln32 = nullptr;
     size_t    dist64_cap = 0;
@@ -2400,6 +2401,7 @@ int amx_gmm_score_dev(amx_gmm* h, int mode, const float* feats_dev, int T, float
                         return r;
                     AMX_HIP(hipMemcpyAsync(h->h_tied_surv, h->d_tied_surv, 256 * 8, hipMemcpyDeviceToHost, h->ctx->stream));
                     h->tied_triples += (unsigned long long)h->K * (unsigned long long)Tc * (unsigned long long)(h->mix_pad / 64);
+                    h->tied_rep_triples += (unsigned long long)h->K * (unsigned long long)Tc * (unsigned long long)(h->mix_pad / 64);
                 }
                 else
                     hipLaunchKernelGGL(amx::gmm_tied_tile_kernel, dim3(h->mix_pad / 64, Tpad / 64), dim3(256), 0, h->ctx->stream, h->d_dist, sc,
@@ -2472,6 +2474,21 @@ int amx_gmm_screen_counts(amx_gmm* h, int enable, unsigned long long* survivors,
         *survivors = 0;
     if (pairs)
         *pairs = 0;
+    if (h->d_tied_surv) {  // tied model on the pruned path: (density, frame, 64-mixture tile) triples that survived / were submitted
+        AMX_HIP(hipSetDevice(h->ctx->device));
+        AMX_HIP(hipStreamSynchronize(h->ctx->stream));
+        unsigned long long c[256], v = 0;
+        AMX_HIP(hipMemcpy(c, h->d_tied_surv, sizeof c, hipMemcpyDeviceToHost));
+        for (int i = 0; i < 256; ++i)
+            v += c[i];
+        if (survivors)
+            *survivors = v - h->tied_rep_seen;
+        if (pairs)
+            *pairs = h->tied_rep_triples;
+        h->tied_rep_seen    = v;
+        h->tied_rep_triples = 0;
+        return AMX_OK;
+    }
     if (!h->d_fus_surv)  // not the fused screened path: nothing is counted
         return AMX_OK;
     AMX_HIP(hipSetDevice(h->ctx->device));
