@@ -222,7 +222,8 @@ typedef struct {
  * the same u8 quantisation and integer distance, pooled covariance only, constant (s32)(logNorm scale^2 - 2 scale^2 logWeight) formed
  * in f64, score = (f32)min / (2 scale^2) in f32, no best-density output) /
  * preselection-batch-float (see amx_gmm_set_preselection below; pooled covariance only, no best-density output) */
-enum { AMX_GMM_MAX = 0, AMX_GMM_SUM = 1, AMX_GMM_BATCH_FLOAT = 2, AMX_GMM_SIMD = 3, AMX_GMM_BATCH_INT = 4, AMX_GMM_PRESELECTION_FLOAT = 5 };
+enum { AMX_GMM_MAX = 0, AMX_GMM_SUM = 1, AMX_GMM_BATCH_FLOAT = 2, AMX_GMM_SIMD = 3, AMX_GMM_BATCH_INT = 4, AMX_GMM_PRESELECTION_FLOAT = 5,
+       AMX_GMM_PRESELECTION_INT = 6 };
 
 int  amx_gmm_create(amx_ctx* ctx, const amx_gmm_model* model, amx_gmm** out); /* copies everything */
 void amx_gmm_destroy(amx_gmm* h);
@@ -243,6 +244,12 @@ float amx_gmm_simd_scaling(const amx_gmm* h);
  * it: cluster_of [sum K_m] (cluster of every mixture entry), cluster_means [n_clusters x dim]; any pointer may be NULL. */
 int amx_gmm_set_preselection(amx_gmm* h, int clusters, int select_clusters, int iterations, float backoff_score);
 int amx_gmm_preselection_clustering(amx_gmm* h, int* n_clusters, uint32_t* cluster_of, float* cluster_means);
+/* AMX_GMM_PRESELECTION_INT = Mm::BatchPreselectionIntFeatureScorer ("preselection-batch-int", Mm/BatchFeatureScorer.cc:514-578):
+ * the batch-int scorer over the densities of the select-clusters clusters closest to the QUANTISED feature, with
+ * Mm::DensityClustering<u8, s32> over the quantised means (integer distances, cluster means truncated to u8); a mixture without an
+ * active density scores (f32)INT_MAX / scale_ -- the int class has no back-off score.  Same parameters
+ * (amx_gmm_set_preselection; backoff_score unused).  cluster_means [n_clusters x dim]: the u8 values as floats. */
+int amx_gmm_preselection_int_clustering(amx_gmm* h, int* n_clusters, uint32_t* cluster_of, float* cluster_means);
 /* Diagnostics of the screened diagonal-maximum scorer (no reference counterpart; bench.py prints survivors per mixture):
  * returns and clears the number of densities evaluated exactly and the number of (frame, mixture) pairs scored since the
  * last call, and switches the counting on (enable != 0) or off for the following calls.  Synchronises the stream.  Zero for

@@ -475,6 +475,28 @@ def _preselection(self, feats, n_clusters=256, n_select=32, iterations=5, backof
 OracleGmm.score_preselection_float = _preselection
 
 
+def _preselection_int(self, feats, n_clusters=256, n_select=32, iterations=5):
+    """preselection-batch-int: (scores, cluster index per mixture entry, cluster means [n_clusters, dim] u8)"""
+    feats = np.ascontiguousarray(feats, dtype=np.float32)
+    T = feats.shape[0]
+    nk = int(self.m["mix_offsets"][-1])
+    sc = np.zeros((T, self.n_mix), np.float32)
+    cof = np.zeros(nk, np.uint32)
+    cm = np.zeros((min(n_clusters, nk), self.dim), np.uint8)
+    nc = C.c_int(0)
+    self.L.orc_gmm_score_preselection_int.restype = C.c_int
+    self.L.orc_gmm_score_preselection_int.argtypes = [C.c_void_p, f64p, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, f32p, u32p,
+                                                      C.c_void_p, C.POINTER(C.c_int)]
+    r = self.L.orc_gmm_score_preselection_int(self.h, self.m["log_weight"], self.m["variances"].reshape(-1), feats.reshape(-1), T,
+                                              n_clusters, n_select, iterations, sc.reshape(-1), cof, cm.ctypes.data, C.byref(nc))
+    if r != 0:
+        raise ValueError("preselection-int scorer: pooled covariance only, 1 <= select-clusters <= clusters (status %d)" % r)
+    return sc, cof, cm
+
+
+OracleGmm.score_preselection_int = _preselection_int
+
+
 def _simd(self, feats):
     """SIMD-diagonal-maximum: (scores, best density, scaling)"""
     feats = np.ascontiguousarray(feats, dtype=np.float32)

@@ -139,6 +139,10 @@ void orc_gmm_score(const orc_gmm* h, int mode, const float* feats, int T, float*
 int orc_gmm_score_preselection_float(const orc_gmm* h, const double* log_weight, const float* variances, const float* feats, int T,
                                      int n_clusters, int n_select, int iterations, float backoff, float* scores,
                                      uint32_t* cluster_of_out, float* cluster_means_out, int* n_clusters_out);
+/* Mm::BatchPreselectionIntFeatureScorer ("preselection-batch-int"): cluster_means [n_clusters x dim] u8; parity unpinned */
+int orc_gmm_score_preselection_int(const orc_gmm* h, const double* log_weight, const float* variances, const float* feats, int T,
+                                   int n_clusters, int n_select, int iterations, float* scores, uint32_t* cluster_of_out,
+                                   uint8_t* cluster_means_out, int* n_clusters_out);
 int orc_gmm_score_batch_float(const orc_gmm* h, const double* log_weight, const float* variances,
                               const float* feats, int T, float* scores);
 

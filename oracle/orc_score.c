@@ -421,8 +421,42 @@ static uint8_t orc_quantize_u8(float v) {
  * arithmetic unrolled): pooled covariance only; quantizationScale (:352-373) is getScaling's formula on the unscaled 1/sigma;
  * scale_ = (f32)(2.0 * scale^2) (:389); constants (s32)(logNorm * scale^2 - scale_ * logWeight) with the subtraction in f64 (:407);
  * the SSE2 distance (:427-447) is the exact integer sum; score = (f32)min / scale_ in f32 (:500); no density assignment. */
+/* variant 1 with `ps`: Mm::BatchPreselectionIntFeatureScorer ("preselection-batch-int", Mm/BatchFeatureScorer.cc:514-578) =
+ * the batch-int scorer restricted to the densities of the nSelected clusters closest to the quantised feature, with
+ * Mm::DensityClustering<u8, s32> (Mm/DensityClustering.tcc, see the float variant above) over the quantised per-entry means:
+ * s32 sums of squared differences (Mm/Utilities.hh unrolledVectorDistance<u8, s32>), strict '<', f64 component sums / count
+ * converted to u8 (truncation); a mixture without an active density keeps best = INT_MAX and scores (f32)INT_MAX / scale_
+ * (fillScoreCacheTpl, :458-499: no back-off score in the int class). */
+typedef struct {
+    int       n_clusters, n_select, iterations;
+    uint32_t* cluster_of_out;     /* [nk], nullable */
+    uint8_t*  cluster_means_out;  /* [n_clusters x dim], nullable */
+    int*      n_clusters_out;
+} orc_presel_int;
+
+typedef struct {
+    int      d;
+    uint32_t c;
+} orc_cli_item;
+
+static int orc_cli_cmp(const void* a, const void* b) {
+    const orc_cli_item *x = (const orc_cli_item*)a, *y = (const orc_cli_item*)b;
+    if (x->d != y->d)
+        return x->d < y->d ? -1 : 1;
+    return x->c < y->c ? -1 : (x->c > y->c ? 1 : 0);
+}
+
+static int orc_int_distance(const uint8_t* a, const uint8_t* b, int dim) {
+    int s = 0;
+    for (int i = 0; i < dim; ++i) {
+        int df = (int)a[i] - (int)b[i];
+        s += df * df;
+    }
+    return s;
+}
+
 static int orc_gmm_score_quantized(const orc_gmm* h, int variant, const double* log_weight, const float* variances, const float* feats,
-                                   int T, float* scores, uint32_t* best, float* scaling_out) {
+                                   int T, float* scores, uint32_t* best, float* scaling_out, orc_presel_int* ps) {
     if (variant == 1 && h->n_cov != 1)
         return -1;
     const int dim = h->dim;
@@ -473,16 +507,94 @@ static int orc_gmm_score_quantized(const orc_gmm* h, int variant, const double* 
     if (variant == 1)
         for (size_t k = 0; k < nk; ++k)
             cst[k] = (int32_t)((double)lognorm[0] - (double)int_scale * log_weight[k]);
+    /* ---- density clustering over the per-entry quantised means (preselection only) */
+    uint8_t*      cm     = NULL;
+    uint32_t*     cof    = NULL;
+    char*         active = NULL;
+    orc_cli_item* items  = NULL;
+    int           n_clusters = 0;
+    if (ps) {
+        n_clusters = ps->n_clusters;
+        if ((size_t)n_clusters > nk)
+            n_clusters = (int)nk;
+        if (variant != 1 || ps->n_select > n_clusters || ps->n_select < 1 || n_clusters < 1) {
+            free(isr); free(lognorm); free(qmean); free(cst);
+            return -2;
+        }
+        cm         = (uint8_t*)calloc((size_t)n_clusters * dim, 1);
+        cof        = (uint32_t*)calloc(nk, 4);
+        active     = (char*)calloc((size_t)n_clusters, 1);
+        items      = (orc_cli_item*)calloc((size_t)n_clusters, sizeof(orc_cli_item));
+        char* used = (char*)calloc(nk, 1);
+        srand(1);
+        for (int c = 0; c < n_clusters; ++c) {
+            uint32_t pick;
+            do {
+                pick = (uint32_t)rand() % (uint32_t)nk;
+            } while (used[pick]);
+            used[pick] = 1;
+            memcpy(cm + (size_t)c * dim, qmean + (size_t)h->dens_index[pick] * dim, (size_t)dim);
+        }
+        free(used);
+        double* sums = (double*)calloc((size_t)dim, 8);
+        for (int it = 0; it < ps->iterations; ++it) {
+            for (size_t k = 0; k < nk; ++k) {
+                int      bd = INT32_MAX;
+                uint32_t bc = 0;
+                for (int c = 0; c < n_clusters; ++c) {
+                    int d = orc_int_distance(cm + (size_t)c * dim, qmean + (size_t)h->dens_index[k] * dim, dim);
+                    if (d < bd) {
+                        bd = d;
+                        bc = (uint32_t)c;
+                    }
+                }
+                cof[k] = bc;
+            }
+            for (int c = 0; c < n_clusters; ++c) {
+                size_t cnt = 0;
+                for (int i = 0; i < dim; ++i)
+                    sums[i] = 0;
+                for (size_t k = 0; k < nk; ++k)
+                    if (cof[k] == (uint32_t)c) {
+                        for (int i = 0; i < dim; ++i)
+                            sums[i] = sums[i] + (double)qmean[(size_t)h->dens_index[k] * dim + i];
+                        ++cnt;
+                    }
+                if (cnt)
+                    for (int i = 0; i < dim; ++i)
+                        cm[(size_t)c * dim + i] = (uint8_t)(sums[i] / (double)cnt);
+            }
+        }
+        free(sums);
+        if (ps->cluster_of_out)
+            memcpy(ps->cluster_of_out, cof, nk * 4);
+        if (ps->cluster_means_out)
+            memcpy(ps->cluster_means_out, cm, (size_t)n_clusters * dim);
+        if (ps->n_clusters_out)
+            *ps->n_clusters_out = n_clusters;
+    }
     uint8_t* qx = (uint8_t*)malloc((size_t)h->n_cov * dim);
     for (int t = 0; t < T; ++t) {
         const float* x = feats + (size_t)t * dim;
         for (int c = 0; c < h->n_cov; ++c)
             for (int i = 0; i < dim; ++i)
                 qx[(size_t)c * dim + i] = orc_quantize_u8(x[i] * isr[(size_t)c * dim + i]);
+        if (ps) { /* selectClusters: ascending sort on the distance, the first nSelected are active (ties: by cluster index) */
+            for (int c = 0; c < n_clusters; ++c) {
+                items[c].d = orc_int_distance(qx, cm + (size_t)c * dim, dim);
+                items[c].c = (uint32_t)c;
+            }
+            qsort(items, (size_t)n_clusters, sizeof(orc_cli_item), orc_cli_cmp);
+            memset(active, 0, (size_t)n_clusters);
+            for (int i = 0; i < ps->n_select; ++i)
+                active[items[i].c] = 1;
+        }
         for (int m = 0; m < h->n_mix; ++m) {
             int      minScore = INT32_MAX;
             uint32_t bestDns  = UINT32_MAX;
             for (uint32_t k = h->mix_off[m]; k < h->mix_off[m + 1]; ++k) {
+                if (ps && !active[cof[k]])
+                    continue;
                 uint32_t       d  = h->dens_index[k];
                 const uint8_t* a  = qmean + (size_t)d * dim;
                 const uint8_t* b  = qx + (size_t)h->dens_cov[d] * dim;
@@ -507,17 +619,28 @@ static int orc_gmm_score_quantized(const orc_gmm* h, int variant, const double* 
     free(qmean);
     free(cst);
     free(qx);
+    free(cm);
+    free(cof);
+    free(active);
+    free(items);
     return 0;
 }
 
 int orc_gmm_score_simd(const orc_gmm* h, const double* log_weight, const float* variances, const float* feats, int T, float* scores,
                        uint32_t* best, float* scaling_out) {
-    return orc_gmm_score_quantized(h, 0, log_weight, variances, feats, T, scores, best, scaling_out);
+    return orc_gmm_score_quantized(h, 0, log_weight, variances, feats, T, scores, best, scaling_out, NULL);
 }
 
 int orc_gmm_score_batch_int(const orc_gmm* h, const double* log_weight, const float* variances, const float* feats, int T,
                             float* scores) {
-    return orc_gmm_score_quantized(h, 1, log_weight, variances, feats, T, scores, NULL, NULL);
+    return orc_gmm_score_quantized(h, 1, log_weight, variances, feats, T, scores, NULL, NULL, NULL);
+}
+
+int orc_gmm_score_preselection_int(const orc_gmm* h, const double* log_weight, const float* variances, const float* feats, int T,
+                                   int n_clusters, int n_select, int iterations, float* scores, uint32_t* cluster_of_out,
+                                   uint8_t* cluster_means_out, int* n_clusters_out) {
+    orc_presel_int ps = {n_clusters, n_select, iterations, cluster_of_out, cluster_means_out, n_clusters_out};
+    return orc_gmm_score_quantized(h, 1, log_weight, variances, feats, T, scores, NULL, NULL, &ps);
 }
 
 /* the quantiser alone, for pinning against the reference's functor */

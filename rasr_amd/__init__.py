@@ -236,7 +236,8 @@ class GmmFeatureScorer:
         self.ctx, self.L = ctx, (ctx.L if ctx is not None else _lib.lib())
         self.mode = {"diagonal-maximum": AMX_GMM_MAX, "diagonal-sum": AMX_GMM_SUM,
                      "batch-diagonal-maximum-float": AMX_GMM_BATCH_FLOAT, "SIMD-diagonal-maximum": _lib.AMX_GMM_SIMD, "batch-diagonal-maximum-int": _lib.AMX_GMM_BATCH_INT,
-                     "batch-diagonal-maximum-fast": _lib.AMX_GMM_BATCH_INT, "preselection-batch-float": _lib.AMX_GMM_PRESELECTION_FLOAT}[feature_scorer_type]
+                     "batch-diagonal-maximum-fast": _lib.AMX_GMM_BATCH_INT, "preselection-batch-float": _lib.AMX_GMM_PRESELECTION_FLOAT,
+                     "preselection-batch-int": _lib.AMX_GMM_PRESELECTION_INT}[feature_scorer_type]
         keep = []
         st = _gmm_struct(model, mixture_weight_scale, gaussian_scale, keep)
         h = C.c_void_p()
@@ -291,11 +292,12 @@ class GmmFeatureScorer:
 
     def preselection_clustering(self):
         """(cluster index of every mixture entry uint32[sum K], cluster means float32[n_clusters, dim])"""
+        fn = self.L.amx_gmm_preselection_int_clustering if self.mode == _lib.AMX_GMM_PRESELECTION_INT else self.L.amx_gmm_preselection_clustering
         n = C.c_int(0)
-        _lib.check(self.L.amx_gmm_preselection_clustering(self.h, C.byref(n), None, None))
+        _lib.check(fn(self.h, C.byref(n), None, None))
         cof = np.zeros(self._nk, np.uint32)
         cm = np.zeros((n.value, self.dim), np.float32)
-        _lib.check(self.L.amx_gmm_preselection_clustering(self.h, C.byref(n), cof.ctypes.data, cm.ctypes.data))
+        _lib.check(fn(self.h, C.byref(n), cof.ctypes.data, cm.ctypes.data))
         return cof, cm
 
     def screen_counts(self, enable=True):

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AMX_LIBRARY", os.path.join(_HERE, "librasr_amd.so"))  # AMX_LIBRARY: A/B runs of two builds (tools/)
 
 AMX_OK, AMX_ERR_INVALID, AMX_ERR_UNSUPPORTED, AMX_ERR_DEVICE, AMX_ERR_STATE = 0, -1, -2, -3, -4
-AMX_GMM_MAX, AMX_GMM_SUM, AMX_GMM_BATCH_FLOAT, AMX_GMM_SIMD, AMX_GMM_BATCH_INT, AMX_GMM_PRESELECTION_FLOAT = 0, 1, 2, 3, 4, 5
+AMX_GMM_MAX, AMX_GMM_SUM, AMX_GMM_BATCH_FLOAT, AMX_GMM_SIMD, AMX_GMM_BATCH_INT, AMX_GMM_PRESELECTION_FLOAT, AMX_GMM_PRESELECTION_INT = 0, 1, 2, 3, 4, 5, 6
 AMX_GMM_VITERBI, AMX_GMM_BAUM_WELCH = 0, 1
 AMX_ACT_NONE, AMX_ACT_RELU, AMX_ACT_SIGMOID, AMX_ACT_TANH = 0, 1, 2, 3
 AMX_PREC_FP32, AMX_PREC_BF16, AMX_PREC_BF16X3 = 0, 1, 2
@@ -101,6 +101,7 @@ SIGNATURES = {
     "amx_gmm_simd_scaling": (C.c_float, [_P]),
     "amx_gmm_set_preselection": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_float]),
     "amx_gmm_preselection_clustering": (C.c_int, [_P, C.POINTER(C.c_int), _P, _P]),
+    "amx_gmm_preselection_int_clustering": (C.c_int, [_P, C.POINTER(C.c_int), _P, _P]),
     "amx_gmm_screen_counts": (C.c_int, [_P, C.c_int, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
     "amx_gmm_score": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, _P]),
     "amx_gmm_score_dev": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, _P]),

@@ -1538,6 +1538,9 @@ extern "C" int   amx_internal_gmm_simd_create(const amx_gmm_model* m, void** out
 extern "C" void  amx_internal_gmm_simd_destroy(void* p);
 extern "C" float amx_internal_gmm_simd_scaling(const void* p);
 extern "C" int   amx_internal_gmm_simd_score(void* p, amx_ctx* ctx, int variant, const float* feats_dev, int T, float* scores_dev, uint32_t* best_dev);
+extern "C" int   amx_internal_gmm_simd_presel_build(void* p, amx_ctx* ctx, int n_clusters, int n_select, int iterations);
+extern "C" int   amx_internal_gmm_simd_presel_info(const void* p, int* n_clusters, uint32_t* cluster_of, float* cluster_means);
+extern "C" int   amx_internal_gmm_simd_presel_score(void* p, amx_ctx* ctx, const float* feats_dev, int T, float* scores_dev);
 
 extern "C" int    amx_internal_gmm_tied_create(int K, int n_mix, int mix_pad, const float* ahat_t_host, float** d_amin);
 extern "C" size_t amx_internal_gmm_tied_workspace(int K, int T, int mix_pad);
@@ -2175,7 +2178,7 @@ int amx_gmm_score_dev(amx_gmm* h, int mode, const float* feats_dev, int T, float
     AMX_REQUIRE(h, AMX_ERR_INVALID, "amx_gmm_score_dev: NULL handle");
     AMX_REQUIRE(h->ctx, AMX_ERR_STATE, "amx_gmm_score_dev: host-only handle (created without a context)");
     AMX_REQUIRE(mode == AMX_GMM_MAX || mode == AMX_GMM_SUM || mode == AMX_GMM_BATCH_FLOAT || mode == AMX_GMM_SIMD || mode == AMX_GMM_BATCH_INT ||
-                        mode == AMX_GMM_PRESELECTION_FLOAT,
+                        mode == AMX_GMM_PRESELECTION_FLOAT || mode == AMX_GMM_PRESELECTION_INT,
                 AMX_ERR_INVALID,
                 "amx_gmm_score_dev: unknown mode %d", mode);
     AMX_REQUIRE(T >= 0, AMX_ERR_INVALID, "amx_gmm_score_dev: negative frame count");
@@ -2184,10 +2187,17 @@ int amx_gmm_score_dev(amx_gmm* h, int mode, const float* feats_dev, int T, float
     AMX_REQUIRE(feats_dev && scores_dev, AMX_ERR_INVALID, "amx_gmm_score_dev: NULL buffer");
     AMX_HIP(hipSetDevice(h->ctx->device));
     const int fblocks = amx::ceil_div(T, 256);
-    if (mode == AMX_GMM_SIMD || mode == AMX_GMM_BATCH_INT) {
+    if (mode == AMX_GMM_SIMD || mode == AMX_GMM_BATCH_INT || mode == AMX_GMM_PRESELECTION_INT) {
         const int r = ensure_simd(h);
         if (r != AMX_OK)
             return r;
+    }
+    if (mode == AMX_GMM_PRESELECTION_INT) {
+        AMX_REQUIRE(best_dev == nullptr, AMX_ERR_UNSUPPORTED, "amx_gmm_score_dev: preselection-batch-int does not assign densities");
+        const int r = amx_internal_gmm_simd_presel_build(h->simd, h->ctx, h->presel_clusters, h->presel_select, h->presel_iterations);
+        if (r != AMX_OK)
+            return r;
+        return amx_internal_gmm_simd_presel_score(h->simd, h->ctx, feats_dev, T, scores_dev);
     }
     if (mode == AMX_GMM_SIMD)
         return amx_internal_gmm_simd_score(h->simd, h->ctx, 0, feats_dev, T, scores_dev, best_dev);
@@ -2529,6 +2539,16 @@ int amx_gmm_preselection_clustering(amx_gmm* h, int* n_clusters, uint32_t* clust
             return r;
     }
     return amx_internal_gmm_presel_info(h->presel, n_clusters, cluster_of, cluster_means);
+}
+
+int amx_gmm_preselection_int_clustering(amx_gmm* h, int* n_clusters, uint32_t* cluster_of, float* cluster_means) {
+    AMX_REQUIRE(h && h->ctx, AMX_ERR_INVALID, "amx_gmm_preselection_int_clustering: NULL / host-only handle");
+    int r = ensure_simd(h);
+    if (r != AMX_OK)
+        return r;
+    if ((r = amx_internal_gmm_simd_presel_build(h->simd, h->ctx, h->presel_clusters, h->presel_select, h->presel_iterations)) != AMX_OK)
+        return r;
+    return amx_internal_gmm_simd_presel_info(h->simd, n_clusters, cluster_of, cluster_means);
 }
 
 float amx_gmm_simd_scaling(const amx_gmm* h) {

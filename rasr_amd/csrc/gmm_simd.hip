@@ -23,6 +23,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "common.hpp"
@@ -268,6 +269,114 @@ __global__ __launch_bounds__(256) void simd_combine_kernel(const int* __restrict
     }
 }
 
+// ---- Mm::BatchPreselectionIntFeatureScorer ("preselection-batch-int", Mm/BatchFeatureScorer.cc:514-578) with
+// Mm::DensityClustering<u8, s32> (Mm/DensityClustering.tcc) over the quantised means of the mixture entries.
+// lane = mixture entry: first closest cluster (s32 sum of squared differences, strict '<')
+__global__ __launch_bounds__(256) void simd_presel_assign_kernel(const unsigned char* __restrict__ qmean, const uint32_t* __restrict__ k_dens,
+                                                                int nk, int dim, const unsigned char* __restrict__ cm, int n_clusters,
+                                                                uint32_t* __restrict__ cluster_of) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= nk)
+        return;
+    const unsigned char* q  = qmean + (size_t)k_dens[k] * dim;
+    int                  bd = INT_MAX;
+    uint32_t             bc = 0;
+    for (int c = 0; c < n_clusters; ++c) {
+        const unsigned char* m = cm + (size_t)c * dim;  // wave-uniform
+        int                  s = 0;
+        for (int i = 0; i < dim; ++i) {
+            const int df = (int)m[i] - (int)q[i];
+            s += df * df;
+        }
+        if (s < bd) {
+            bd = s;
+            bc = (uint32_t)c;
+        }
+    }
+    cluster_of[k] = bc;
+}
+
+// lane = frame: quantised feature (LDS, [dim][64] bytes), s32 distance to every cluster mean -> scratch [n_clusters x Tpad], the
+// n_select smallest (distance, cluster) pairs are active (selectClusters sorts by distance only and leaves ties unspecified; here
+// the cluster index breaks them), one 64-bit lane mask per (wave of 64 frames, cluster)
+__global__ __launch_bounds__(64) void simd_presel_select_kernel(const float* __restrict__ feats, const float* __restrict__ isr, int T, int Tpad,
+                                                               int dim, const unsigned char* __restrict__ cm, int n_clusters, int n_select,
+                                                               int* __restrict__ g_dist, unsigned long long* __restrict__ g_masks) {
+    extern __shared__ unsigned char s_q[];  // [dim][64]
+    const int  lane = threadIdx.x, t = blockIdx.x * 64 + lane;
+    const bool live = t < T;
+    const float* x  = feats + (size_t)(live ? t : T - 1) * dim;
+    for (int i = 0; i < dim; ++i)
+        s_q[i * 64 + lane] = (unsigned char)simd_quantize(x[i] * isr[i]);
+    for (int c = 0; c < n_clusters; ++c) {
+        const unsigned char* m = cm + (size_t)c * dim;
+        int                  s = 0;
+        for (int i = 0; i < dim; ++i) {
+            const int df = (int)s_q[i * 64 + lane] - (int)m[i];
+            s += df * df;
+        }
+        g_dist[(size_t)c * Tpad + t] = s;
+    }
+    int pd = -1, pc = -1;  // distances are >= 0
+    for (int sel = 0; sel < n_select; ++sel) {
+        int  bd = INT_MAX, bc = n_clusters;
+        bool any = false;
+        for (int c = 0; c < n_clusters; ++c) {
+            const int  d     = g_dist[(size_t)c * Tpad + t];
+            const bool above = d > pd || (d == pd && c > pc);
+            const bool lower = d < bd || (d == bd && c < bc);
+            if (above && lower) {
+                bd  = d;
+                bc  = c;
+                any = true;
+            }
+        }
+        if (!any)
+            break;
+        pd = bd;
+        pc = bc;
+    }
+    for (int c = 0; c < n_clusters; ++c) {
+        const int                d      = g_dist[(size_t)c * Tpad + t];
+        const bool               active = live && (d < pd || (d == pd && c <= pc));
+        const unsigned long long m      = __ballot(active);
+        if (lane == 0)
+            g_masks[(size_t)blockIdx.x * n_clusters + c] = m;
+    }
+}
+
+// simd_combine_kernel restricted to the densities of active clusters; a mixture without one keeps INT_MAX (the int class has
+// no back-off score: (f32)INT_MAX / scale_)
+__global__ __launch_bounds__(256) void simd_presel_combine_kernel(const int* __restrict__ dist, const int* __restrict__ cst,
+                                                                 const uint32_t* __restrict__ mix_off, const uint32_t* __restrict__ k_dens,
+                                                                 const uint32_t* __restrict__ cluster_of,
+                                                                 const unsigned long long* __restrict__ g_masks, int n_clusters,
+                                                                 float* __restrict__ scores, int T, int ld, int n_mix, int mix_tile,
+                                                                 SimdScale scale) {
+    const int  t    = blockIdx.y * 256 + threadIdx.x;
+    const int  lane = threadIdx.x & 63;
+    const bool live = t < T;
+    const int  tt   = live ? t : T - 1;
+    if ((t & ~63) >= T)
+        return;
+    const unsigned long long* masks = g_masks + (size_t)(t >> 6) * n_clusters;
+    const int m0 = blockIdx.x * mix_tile, m1 = min(m0 + mix_tile, n_mix);
+    for (int m = m0; m < m1; ++m) {
+        const uint32_t k0 = mix_off[m], k1 = mix_off[m + 1];
+        int            mn = INT_MAX;
+        for (uint32_t k = k0; k < k1; ++k) {
+            const unsigned long long am = masks[cluster_of[k]];  // wave-uniform
+            if (am == 0ull)
+                continue;
+            const int s = cst[k] + dist[(size_t)k_dens[k] * ld + tt];
+            if (((am >> lane) & 1ull) && s < mn)
+                mn = s;
+        }
+        if (live)
+            scores[(size_t)t * n_mix + m] = simd_score(mn, scale);
+    }
+}
+
 struct GmmSimd {
     int      dim = 0, n_mix = 0, n_dens = 0, n_cov = 0;
     size_t   nk = 0;
@@ -287,6 +396,17 @@ struct GmmSimd {
     int8_t*  d_X = nullptr;
     int*     d_nx = nullptr;
     int      cap_T = 0;
+    // preselection-batch-int
+    std::vector<unsigned char> h_qmean;
+    std::vector<uint32_t>      h_k_dens;
+    int                        ps_clusters = 0, ps_select = 0, ps_iterations = -1;  // parameters of the clustering below
+    std::vector<unsigned char> h_cm;
+    std::vector<uint32_t>      h_cluster_of;
+    unsigned char*             d_cm = nullptr;
+    uint32_t*                  d_cluster_of = nullptr;
+    int*                       d_cdist = nullptr;
+    unsigned long long*        d_masks = nullptr;
+    int                        ps_cap_T = 0;
 };
 
 template<class T>
@@ -325,6 +445,10 @@ void amx_internal_gmm_simd_destroy(void* p) {
     hipFree(s->d_key[1]);
     hipFree(s->d_X);
     hipFree(s->d_nx);
+    hipFree(s->d_cm);
+    hipFree(s->d_cluster_of);
+    hipFree(s->d_cdist);
+    hipFree(s->d_masks);
     delete s;
 }
 
@@ -403,6 +527,10 @@ int amx_internal_gmm_simd_create(const amx_gmm_model* m, void** out, float* scal
     s->scaling2 = scaling2;
     s->has_int  = m->n_cov == 1;
     s->int_scale = int_scale;
+    if (s->has_int) {
+        s->h_qmean = qmean;
+        s->h_k_dens.assign(m->dens_index, m->dens_index + nk);
+    }
     int r;
     if ((r = upload(&s->d_isr, isr.data(), isr.size())) != AMX_OK || (r = upload(&s->d_qmean, qmean.data(), qmean.size())) != AMX_OK ||
         (r = upload(&s->d_cst[0], cst.data(), cst.size())) != AMX_OK ||
@@ -538,6 +666,169 @@ int amx_internal_gmm_simd_score(void* p, amx_ctx* ctx, int variant, const float*
         ScopedKernelTimer timer(ctx, "gmm_simd");
         hipLaunchKernelGGL(simd_combine_kernel, dim3((s->n_mix + mt - 1) / mt, fblocks), dim3(256), 0, st, s->d_dist, s->d_cst[variant], s->d_mix_off,
                            s->d_k_dens, scores_dev + (size_t)t0 * s->n_mix, best_dev ? best_dev + (size_t)t0 * s->n_mix : nullptr, Tc, chunk,
+                           s->n_mix, mt, scale);
+    }
+    AMX_HIP(hipGetLastError());
+    return AMX_OK;
+}
+
+// glibc's srand(1) / rand() stream (TYPE_3 additive feedback generator), as in gmm_presel.hip: initializeClusters draws from it
+static void simd_glibc_rand_init(std::vector<int32_t>& st) {
+    int32_t r[34];
+    r[0] = 1;
+    for (int i = 1; i < 31; ++i) {
+        const int64_t hi = r[i - 1] / 127773, lo = r[i - 1] % 127773;
+        int64_t       w  = 16807 * lo - 2836 * hi;
+        if (w < 0)
+            w += 2147483647;
+        r[i] = (int32_t)w;
+    }
+    st.assign(r, r + 31);
+    for (int i = 31; i < 34; ++i)
+        st.push_back(st[i - 31]);
+    for (int i = 34; i < 344; ++i)
+        st.push_back((int32_t)((uint32_t)st[i - 31] + (uint32_t)st[i - 3]));
+}
+static int simd_glibc_rand_next(std::vector<int32_t>& st) {
+    const size_t   i = st.size();
+    const uint32_t v = (uint32_t)st[i - 31] + (uint32_t)st[i - 3];
+    st.push_back((int32_t)v);
+    if (st.size() > 4096)
+        st.erase(st.begin(), st.end() - 64);
+    return (int)(v >> 1);
+}
+
+// DensityClustering<u8, s32>::build over the quantised means of the mixture entries (rebuilt when the parameters change)
+int amx_internal_gmm_simd_presel_build(void* p, amx_ctx* ctx, int n_clusters, int n_select, int iterations) {
+    using namespace amx;
+    GmmSimd* s = (GmmSimd*)p;
+    if (!s->has_int) {
+        amx::set_error("amx_gmm_score_dev: feature scorer supports only globally pooled variance");
+        return AMX_ERR_INVALID;
+    }
+    const size_t nk = s->nk;
+    if ((size_t)n_clusters > nk)
+        n_clusters = (int)nk;  // "reducing number of clusters ... because there are too few densities"
+    AMX_REQUIRE(n_clusters >= 1 && n_clusters <= 256, AMX_ERR_INVALID, "preselection: clusters must be in 1..256 (got %d)", n_clusters);
+    AMX_REQUIRE(n_select >= 1 && n_select <= n_clusters, AMX_ERR_INVALID, "preselection: select-clusters (%d) must be in 1..clusters (%d)", n_select,
+                n_clusters);
+    if (s->d_cm && s->ps_clusters == n_clusters && s->ps_iterations == iterations) {
+        s->ps_select = n_select;
+        return AMX_OK;
+    }
+    const int dim = s->dim;
+    s->h_cm.assign((size_t)n_clusters * dim, 0);
+    s->h_cluster_of.assign(nk, 0u);
+    {
+        std::vector<int32_t> st;
+        simd_glibc_rand_init(st);
+        std::vector<char> used(nk, 0);
+        for (int c = 0; c < n_clusters; ++c) {
+            uint32_t pick;
+            do {
+                pick = (uint32_t)simd_glibc_rand_next(st) % (uint32_t)nk;
+            } while (used[pick]);
+            used[pick] = 1;
+            memcpy(&s->h_cm[(size_t)c * dim], &s->h_qmean[(size_t)s->h_k_dens[pick] * dim], (size_t)dim);
+        }
+    }
+    AMX_HIP(hipSetDevice(ctx->device));
+    hipFree(s->d_cm);
+    hipFree(s->d_cluster_of);
+    s->d_cm         = nullptr;
+    s->d_cluster_of = nullptr;
+    AMX_HIP(hipMalloc((void**)&s->d_cm, s->h_cm.size()));
+    AMX_HIP(hipMalloc((void**)&s->d_cluster_of, std::max<size_t>(nk, 1) * 4));
+    std::vector<double> sums((size_t)n_clusters * dim);
+    std::vector<size_t> cnt(n_clusters);
+    for (int it = 0; it < iterations; ++it) {
+        AMX_HIP(hipMemcpyAsync(s->d_cm, s->h_cm.data(), s->h_cm.size(), hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(simd_presel_assign_kernel, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, ctx->stream, s->d_qmean, s->d_k_dens,
+                           (int)nk, dim, s->d_cm, n_clusters, s->d_cluster_of);
+        AMX_HIP(hipMemcpyAsync(s->h_cluster_of.data(), s->d_cluster_of, nk * 4, hipMemcpyDeviceToHost, ctx->stream));
+        AMX_HIP(hipStreamSynchronize(ctx->stream));
+        std::fill(sums.begin(), sums.end(), 0.0);  // updateClusterMeans: f64 sums in density order / count -> u8 (truncation)
+        std::fill(cnt.begin(), cnt.end(), (size_t)0);
+        for (size_t k = 0; k < nk; ++k) {
+            const uint32_t       c = s->h_cluster_of[k];
+            const unsigned char* q = &s->h_qmean[(size_t)s->h_k_dens[k] * dim];
+            double*              sm = &sums[(size_t)c * dim];
+            for (int i = 0; i < dim; ++i)
+                sm[i] = sm[i] + (double)q[i];
+            ++cnt[c];
+        }
+        for (int c = 0; c < n_clusters; ++c)
+            if (cnt[c])
+                for (int i = 0; i < dim; ++i)
+                    s->h_cm[(size_t)c * dim + i] = (unsigned char)(sums[(size_t)c * dim + i] / (double)cnt[c]);
+    }
+    AMX_HIP(hipMemcpy(s->d_cm, s->h_cm.data(), s->h_cm.size(), hipMemcpyHostToDevice));
+    AMX_HIP(hipMemcpy(s->d_cluster_of, s->h_cluster_of.data(), nk * 4, hipMemcpyHostToDevice));
+    s->ps_clusters   = n_clusters;
+    s->ps_select     = n_select;
+    s->ps_iterations = iterations;
+    return AMX_OK;
+}
+
+int amx_internal_gmm_simd_presel_info(const void* p, int* n_clusters, uint32_t* cluster_of, float* cluster_means) {
+    const amx::GmmSimd* s = (const amx::GmmSimd*)p;
+    if (n_clusters)
+        *n_clusters = s->ps_clusters;
+    if (cluster_of)
+        memcpy(cluster_of, s->h_cluster_of.data(), s->nk * 4);
+    if (cluster_means)
+        for (size_t i = 0; i < s->h_cm.size(); ++i)
+            cluster_means[i] = (float)s->h_cm[i];
+    return AMX_OK;
+}
+
+int amx_internal_gmm_simd_presel_score(void* p, amx_ctx* ctx, const float* feats_dev, int T, float* scores_dev) {
+    using namespace amx;
+    GmmSimd*    s  = (GmmSimd*)p;
+    hipStream_t st = ctx->stream;
+    SimdScale   scale;
+    scale.b         = 2.0 * (double)s->scaling2;
+    scale.y         = 1.0 / scale.b;
+    scale.int_scale = s->int_scale;
+    int chunk = (int)std::min<size_t>((size_t)T, std::max<size_t>(256, ((size_t)64 << 20) / (size_t)s->n_dens / 256 * 256));
+    chunk     = (chunk + 255) / 256 * 256;
+    const size_t need = (size_t)s->n_dens * chunk;
+    if (need > s->dist_cap) {
+        hipFree(s->d_dist);
+        s->d_dist   = nullptr;
+        s->dist_cap = 0;
+        AMX_HIP(hipMalloc((void**)&s->d_dist, need * 4));
+        s->dist_cap = need;
+    }
+    if (chunk > s->ps_cap_T) {
+        hipFree(s->d_cdist);
+        hipFree(s->d_masks);
+        s->d_cdist  = nullptr;
+        s->d_masks  = nullptr;
+        s->ps_cap_T = 0;
+        AMX_HIP(hipMalloc((void**)&s->d_cdist, (size_t)256 * chunk * 4));
+        AMX_HIP(hipMalloc((void**)&s->d_masks, (size_t)(chunk / 64) * 256 * 8));
+        s->ps_cap_T = chunk;
+    }
+    for (int t0 = 0; t0 < T; t0 += chunk) {
+        const int    Tc = std::min(chunk, T - t0), fblocks = (Tc + 255) / 256;
+        const float* x  = feats_dev + (size_t)t0 * s->dim;
+        int          dt = 64;
+        while (dt > 4 && (long)((s->n_dens + dt - 1) / dt) * fblocks < 1024)
+            dt /= 2;
+        {
+            ScopedKernelTimer timer(ctx, "gmm_simd_dist");
+            hipLaunchKernelGGL(simd_dist_kernel, dim3((s->n_dens + dt - 1) / dt, fblocks), dim3(256), 0, st, x, s->d_isr, s->d_qmean, s->d_d_cov,
+                               s->d_dist, Tc, chunk, s->dim, s->n_dens, dt);
+        }
+        ScopedKernelTimer timer(ctx, "gmm_simd");
+        hipLaunchKernelGGL(simd_presel_select_kernel, dim3((Tc + 63) / 64), dim3(64), (size_t)s->dim * 64, st, x, s->d_isr, Tc, chunk, s->dim,
+                           s->d_cm, s->ps_clusters, s->ps_select, s->d_cdist, s->d_masks);
+        int mt = 16;
+        while (mt > 1 && (long)((s->n_mix + mt - 1) / mt) * fblocks < 1024)
+            mt /= 2;
+        hipLaunchKernelGGL(simd_presel_combine_kernel, dim3((s->n_mix + mt - 1) / mt, fblocks), dim3(256), 0, st, s->d_dist, s->d_cst[1],
+                           s->d_mix_off, s->d_k_dens, s->d_cluster_of, s->d_masks, s->ps_clusters, scores_dev + (size_t)t0 * s->n_mix, Tc, chunk,
                            s->n_mix, mt, scale);
     }
     AMX_HIP(hipGetLastError());

@@ -954,3 +954,40 @@ def test_preselection_errors(ctx):
         sc.score(feats(3, 40, 1), want_best=False)
     with pytest.raises(rasr_amd.AmxError):
         sc.set_preselection(300, 16)
+
+
+@pytest.mark.parametrize("n_mix,kmax,dim,clusters,select", [(200, 16, 40, 64, 8), (50, 8, 24, 16, 4), (300, 12, 33, 256, 32), (3, 3, 16, 256, 2),
+                                                            (120, 16, 39, 32, 32)])
+def test_preselection_batch_int_exact(ctx, n_mix, kmax, dim, clusters, select):
+    """preselection-batch-int: integer k-means over the quantised means (same glibc rand() seeds, s32 distances, cluster means
+    truncated to u8) and the preselected integer scores bit-exact against the oracle; a mixture without an active density scores
+    (f32)INT_MAX / scale; selecting every cluster reproduces batch-diagonal-maximum-int; any dimension (runtime loop)"""
+    import rasr_amd
+    from oracle import OracleGmm
+    model = synth.gmm_cart(n_mix, 1, kmax, dim, seed=600 + n_mix, pooled=True)
+    x = feats(333, dim, 601)
+    x[7] *= 40.0                                   # saturates the quantiser
+    sc = rasr_amd.GmmFeatureScorer(ctx, model, feature_scorer_type="preselection-batch-int")
+    sc.set_preselection(clusters, select, 5, 0.0)
+    got = sc.score(x, want_best=False)
+    want, wcof, wcm = OracleGmm(model).score_preselection_int(x, clusters, select, 5)
+    cof, cm = sc.preselection_clustering()
+    assert cm.shape[0] == wcm.shape[0] == min(clusters, len(wcof))
+    assert np.array_equal(cof, wcof) and np.array_equal(cm, wcm.astype(np.float32))
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), np.abs(got - want).max()
+    if select < cm.shape[0] and n_mix > 10:
+        assert (got > 1e5).any()                   # INT_MAX / scale: some mixture had no active density
+    sc.set_preselection(clusters, min(clusters, len(wcof)), 5, 0.0)
+    full = rasr_amd.GmmFeatureScorer(ctx, model, feature_scorer_type="batch-diagonal-maximum-int").score(x, want_best=False)
+    assert np.array_equal(sc.score(x, want_best=False).view(np.uint32), full.view(np.uint32))
+
+
+def test_preselection_batch_int_errors(ctx):
+    import rasr_amd
+    sc = rasr_amd.GmmFeatureScorer(ctx, synth.gmm_cart(10, 2, 4, 40, seed=9, pooled=False), feature_scorer_type="preselection-batch-int")
+    with pytest.raises(rasr_amd.AmxError, match="pooled"):
+        sc.score(feats(3, 40, 1), want_best=False)
+    sc = rasr_amd.GmmFeatureScorer(ctx, synth.gmm_cart(10, 2, 4, 40, seed=9, pooled=True), feature_scorer_type="preselection-batch-int")
+    sc.set_preselection(8, 16)
+    with pytest.raises(rasr_amd.AmxError, match="select-clusters"):
+        sc.score(feats(3, 40, 1), want_best=False)
