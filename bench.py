@@ -60,9 +60,10 @@ def parse():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x3", "fp32"],
                     help="NN GEMM inputs: bf16 (BASELINE config 4), bf16x3 = split bf16, three MFMA products per f32 product (meets the "
                          "1e-4 bar of the f32 reference), fp32 = f32 MFMA")
-    ap.add_argument("--front-end", default="mfcc", choices=["mfcc", "mfplp", "plp"],
+    ap.add_argument("--front-end", default="mfcc", choices=["mfcc", "mfplp", "plp", "gammatone"],
                     help="mfcc workload: mfcc.flow (40 cepstra), mfplp.flow (20 autocorrelation / 16 cepstrum coefficients) or plp.flow "
-                         "(bark / trapeze filter bank + equal loudness, 13 / 13)")
+                         "(bark / trapeze filter bank + equal loudness, 13 / 13) or the gammatone nodes (68 channels, cascade 4, 25 / 10 ms "
+                         "Hanning temporal integration, spectral integration 9 / 4, 10th root, 12 cepstra)")
     ap.add_argument("--estimation-mode", default="viterbi", choices=["viterbi", "baum-welch"],
                     help="gmm-train: statistics of the best density only, or of every density by its posterior (reference: mode)")
     ap.add_argument("--gmm-type", default="diagonal-maximum", choices=["diagonal-maximum", "batch-diagonal-maximum-float", "SIMD-diagonal-maximum"])
@@ -395,8 +396,11 @@ class MfccOnly:
         self.ctx = ctx
         fe = getattr(args, "front_end", "mfcc")
         self.plp = fe != "mfcc"
-        self.nout = {"mfcc": 40, "mfplp": 16, "plp": 13}[fe]
-        if fe == "plp":
+        self.nout = {"mfcc": 40, "mfplp": 16, "plp": 13, "gammatone": 12}[fe]
+        self.gt = fe == "gammatone"
+        if self.gt:
+            self.fe = rasr_amd.GammatoneExtractor(ctx, channels=68, max_freq=7500.0, si_length=9, si_shift=4, power=0.1, n_ceps=12)
+        elif fe == "plp":
             self.fe = rasr_amd.MfccExtractor.plp(ctx)
         elif self.plp:
             self.fe = rasr_amd.MfccExtractor(ctx, nr_cepstrum_coefficients=16, front_end="mfplp", nr_autocorrelation_coefficients=20,
@@ -407,19 +411,37 @@ class MfccOnly:
         base = synth.waveform(int(lens.max()) + 1000, seed=4 + rank)
         pcm = np.concatenate([base[u:u + int(n)] for u, n in enumerate(lens)])
         off = np.concatenate([[0], np.cumsum(lens)])
-        self.plan = self.fe.plan(off)
-        self.F = self.plan.total_frames
+        if self.gt:
+            self.off = off.astype(np.int64)
+            self.F = int(sum(self.fe.n_frames(int(n)) for n in lens))
+        else:
+            self.plan = self.fe.plan(off)
+            self.F = self.plan.total_frames
         self.pcm = torch.from_numpy(pcm).cuda()
         self.ceps = torch.empty((self.F, self.nout), dtype=torch.float32, device="cuda")
         self.units = self.F
 
     def step(self):
-        self.fe.run_plan(self.plan, self.pcm, self.ceps)
+        if self.gt:
+            self.fe.run_batch_dev(self.off, self.pcm, self.ceps)
+        else:
+            self.fe.run_plan(self.plan, self.pcm, self.ceps)
 
     def epoch_reduce(self, world):
         pass
 
     def roofline(self):
+        if self.gt:
+            # sequential recursions (4 second-order sections per channel and sample, f32 in the reference's order): the parallel axes are
+            # channels x segments only, so the kernel is bound by the latency of one dependent f32 chain per lane, not by bytes or flops
+            ms, n = self.ctx.profile_get("gammatone")
+            if n == 0:
+                return None
+            flops = self.F * 160.0 * 68 * (4 * 6 + 9)   # per sample and channel: 4 sections x 6 operations + temporal integration
+            t = flops / (ms * 1e-3) / 1e12
+            return dict(bound="mfma", kernel="gammatone_filter_kernel (+ gammatone_post_kernel)", note="f32 vector operations against the f32 "
+                        "vector peak; time-sequential IIR cascade, lane = (segment, channel)", achieved=round(t, 3), peak=FP32_TFLOPS,
+                        unit="TFLOP/s", frac=round(t / FP32_TFLOPS, 5), traffic=None, avg_launch_ms=round(ms, 4), launches=n, flops_per_launch=flops)
         ms, n = self.ctx.profile_get("mfcc")
         if n == 0:
             return None
@@ -433,7 +455,7 @@ class MfccOnly:
 
     def stage_report(self):
         out = {}
-        for k in ("mfcc", "lpc_cepstrum"):
+        for k in ("mfcc", "lpc_cepstrum", "gammatone"):
             ms, n = self.ctx.profile_get(k)
             if n:
                 out[k] = dict(avg_ms=round(ms, 4), launches=n)

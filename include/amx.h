@@ -158,6 +158,56 @@ long amx_mfcc_plan_total_frames(const amx_mfcc_plan* p);
 int  amx_mfcc_plan_frame_offsets(const amx_mfcc_plan* p, long* frame_offsets /*[n_seg+1]*/);
 int  amx_mfcc_run_plan_dev(amx_mfcc* h, const amx_mfcc_plan* p, const float* pcm_dev, float* ceps_dev);
 
+/* ------------------------------------------------------------------ gammatone front-end
+ * The three nodes of Signal/Module.cc:169-173 -- signal-gammatone (Signal/GammaTone.cc:20-231), signal-temporalintegration
+ * (Signal/TemporalIntegration.cc:60-84 over Signal/TimeWindowBuffer.cc:52-125) and signal-spectralintegration
+ * (Signal/SpectralIntegration.cc:55-74) -- as one front end, PCM in, one vector per 10 ms frame out, with the usual tail
+ * (generic-vector-f32-power, signal-cosine-transform) optional.  Field names are the nodes' parameter names; the defaults are the
+ * nodes' own.  Temporal integration frames follow the window node's rule (short last frames, amx_gammatone_n_frames); the state
+ * of the filter cascade starts at zero with every segment (the node resets at end of segment). */
+typedef struct {
+    double sample_rate;      /* Hz */
+    int    cascade;          /* signal-gammatone cascade, default 4 (0..8)                                   */
+    double min_freq;         /* minfreq, default 100                                                         */
+    double max_freq;         /* maxfreq, default 6000                                                        */
+    double q;                /* q, default 9.264491981582191 (the 0 Hz bandwidth l = 24.7 is not a parameter) */
+    int    channels;         /* channels, default 50                                                         */
+    int    cf_mode;          /* cfmode: AMX_GAMMATONE_HUMAN (0, default) or AMX_GAMMATONE_ERB                */
+    double warp_freq_break;  /* warp-freqbreak, default 6600                                                 */
+    double warping_factor;   /* warping-factor, default 1 (the upper end of the warping is sample_rate / 2)  */
+    int    ti_window;        /* signal-temporalintegration type: AMX_WINDOW_HANNING (0) or AMX_WINDOW_RECTANGULAR */
+    double ti_length_s;      /* length (seconds)                                                             */
+    double ti_shift_s;       /* shift (seconds)                                                              */
+    int    si_window;        /* signal-spectralintegration type                                              */
+    int    si_length;        /* length in channels; 0 = node absent                                          */
+    int    si_shift;         /* shift in channels                                                            */
+    double power;            /* generic-vector-f32-power value (e.g. 0.1 for the 10th root); 0 = node absent */
+    int    n_ceps;           /* signal-cosine-transform nr-outputs; 0 = node absent                          */
+    int    dct_normalize;    /* normalize                                                                    */
+} amx_gammatone_cfg;
+enum { AMX_GAMMATONE_HUMAN = 0, AMX_GAMMATONE_ERB = 1 };
+enum { AMX_WINDOW_HANNING = 0, AMX_WINDOW_RECTANGULAR = 1 };
+typedef struct {
+    int channels, cascade, frame_len, frame_shift;
+    int si_channels; /* channels after spectral integration */
+    int n_out;       /* output dimension */
+} amx_gammatone_info;
+typedef struct amx_gammatone amx_gammatone;
+void amx_gammatone_default_cfg(amx_gammatone_cfg* cfg);
+int  amx_gammatone_create(amx_ctx* ctx, const amx_gammatone_cfg* cfg, amx_gammatone** out); /* ctx NULL: host-only (tables, geometry) */
+void amx_gammatone_destroy(amx_gammatone* h);
+int  amx_gammatone_describe(const amx_gammatone* h, amx_gammatone_info* info);
+long amx_gammatone_n_frames(const amx_gammatone* h, long n_samples);
+/* centre frequencies [channels] and filter coefficients [channels][4] = a0, a1, b1, b2 (GammaTone::Coefficient); nullable */
+int amx_gammatone_tables(const amx_gammatone* h, float* center_freq, float* coefficients);
+/* one segment, host buffers: pcm f32 -> out [n_frames x n_out] */
+int amx_gammatone_run(amx_gammatone* h, const float* pcm_host, long n_samples, float* out_host);
+/* a batch of segments resident in HBM: segment u = samples [sample_offsets[u], sample_offsets[u+1]) of pcm_dev (offsets on the
+ * host), its frames follow those of segment u - 1 in out_dev [total frames x n_out].  filtered_dev (nullable, [total samples x
+ * channels]) receives the signal-gammatone node's own output. */
+int amx_gammatone_run_batch_dev(amx_gammatone* h, int n_seg, const long* sample_offsets, const float* pcm_dev, float* out_dev,
+                                float* filtered_dev);
+
 /* Sliding-window concatenation of feature frames per segment (f1 "next" row:
  * signal-vector-f32-sequence-concatenation, Signal/SlidingWindow.hh:66-76 copy margin policy):
  * out[t] = [x[t-left] .. x[t+right]] with indices clamped to the segment.  out_dev is

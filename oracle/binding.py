@@ -59,7 +59,7 @@ def build_oracle(force=False):
     """gcc-compile oracle/liboracle.so (and _ref/libref.so when the reference tree is mounted)."""
     if force or not os.path.exists(_LIB) or any(
             os.path.getmtime(os.path.join(_HERE, s)) > os.path.getmtime(_LIB)
-            for s in ("orc_mfcc.c", "orc_score.c", "orc.h")):
+            for s in ("orc_mfcc.c", "orc_score.c", "orc_backend.c", "orc_gammatone.c", "orc.h")):
         subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
     if os.path.isdir("/root/reference/src") and (force or not os.path.exists(_REF)):
         subprocess.check_call(["make", "-C", os.path.join(_HERE, "ref")], stdout=subprocess.DEVNULL)
@@ -78,7 +78,7 @@ def build_native_oracle():
         return _NATIVE
     import tempfile
     out = os.path.join(tempfile.gettempdir(), "liboracle_native_%d.so" % os.getuid())
-    srcs = [os.path.join(_HERE, f) for f in ("orc_mfcc.c", "orc_score.c", "orc_backend.c")]
+    srcs = [os.path.join(_HERE, f) for f in ("orc_mfcc.c", "orc_score.c", "orc_backend.c", "orc_gammatone.c")]
     if not os.path.exists(out) or any(os.path.getmtime(f) > os.path.getmtime(out) for f in srcs):
         tmp = out + ".%d.tmp" % os.getpid()
         subprocess.check_call(["gcc", "-O3", "-march=native", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-std=gnu11", "-w",
@@ -588,3 +588,64 @@ def oracle_ffnn_score(Ws, biases, acts, feats, log_prior=None, prior_scale=1.0, 
     out = np.zeros((T, int(outd[-1])), np.float32)
     L.orc_ffnn_score(C.byref(st), feats.reshape(-1), T, out.reshape(-1), int(acc64))
     return out
+
+
+class GammatoneCfg(C.Structure):
+    _fields_ = [("sample_rate", C.c_double), ("cascade", C.c_int), ("min_freq", C.c_double), ("max_freq", C.c_double), ("q", C.c_double),
+                ("channels", C.c_int), ("cf_mode", C.c_int), ("warp_freq_break", C.c_double), ("warping_factor", C.c_double),
+                ("ti_window", C.c_int), ("ti_length_s", C.c_double), ("ti_shift_s", C.c_double), ("si_window", C.c_int),
+                ("si_length", C.c_int), ("si_shift", C.c_int), ("power", C.c_double), ("n_ceps", C.c_int), ("dct_normalize", C.c_int)]
+
+    @staticmethod
+    def default(**kw):
+        """the nodes' own defaults (signal-gammatone: cascade 4, 100..6000 Hz, 50 channels, human centre frequencies) with a 25 ms /
+        10 ms Hanning temporal integration; spectral integration, root compression and cosine transform absent"""
+        c = GammatoneCfg(16000.0, 4, 100.0, 6000.0, 9.264491981582191, 50, 0, 6600.0, 1.0, 0, 0.025, 0.01, 0, 0, 1, 0.0, 0, 0)
+        for k, v in kw.items():
+            setattr(c, k, v)
+        return c
+
+
+class OracleGammatone:
+    def __init__(self, cfg=None, **kw):
+        self.L = Oracle()
+        L = self.L
+        L.orc_gammatone_create.restype = C.c_void_p
+        L.orc_gammatone_create.argtypes = [C.POINTER(GammatoneCfg)]
+        L.orc_gammatone_destroy.argtypes = [C.c_void_p]
+        for n in ("n_out", "frame_len", "frame_shift", "si_channels"):
+            f = getattr(L, "orc_gammatone_" + n)
+            f.restype, f.argtypes = C.c_int, [C.c_void_p]
+        for n in ("center_frequencies", "coefficients"):
+            f = getattr(L, "orc_gammatone_" + n)
+            f.restype, f.argtypes = C.POINTER(C.c_float), [C.c_void_p]
+        L.orc_gammatone_n_frames.restype, L.orc_gammatone_n_frames.argtypes = C.c_long, [C.c_void_p, C.c_long]
+        L.orc_gammatone_run.restype = C.c_long
+        L.orc_gammatone_run.argtypes = [C.c_void_p, f32p, C.c_long, C.c_void_p, f32p]
+        self.cfg = cfg if cfg is not None else GammatoneCfg.default(**kw)
+        self.h = L.orc_gammatone_create(C.byref(self.cfg))
+        if not self.h:
+            raise ValueError("oracle: invalid gammatone configuration")
+        self.n_out, self.frame_len = L.orc_gammatone_n_out(self.h), L.orc_gammatone_frame_len(self.h)
+        self.frame_shift, self.si_channels = L.orc_gammatone_frame_shift(self.h), L.orc_gammatone_si_channels(self.h)
+        ch = self.cfg.channels
+        self.center_frequencies = np.ctypeslib.as_array(L.orc_gammatone_center_frequencies(self.h), shape=(ch,)).copy()
+        self.coefficients = np.ctypeslib.as_array(L.orc_gammatone_coefficients(self.h), shape=(ch, 4)).copy()
+
+    def __del__(self):
+        try:
+            self.L.orc_gammatone_destroy(self.h)
+        except Exception:
+            pass
+
+    def n_frames(self, n):
+        return int(self.L.orc_gammatone_n_frames(self.h, n))
+
+    def run(self, pcm, want_filtered=False):
+        pcm = np.ascontiguousarray(pcm, dtype=np.float32)
+        T = self.n_frames(len(pcm))
+        out = np.zeros((T, self.n_out), np.float32)
+        filt = np.zeros((len(pcm), self.cfg.channels), np.float32) if want_filtered else None
+        if T:
+            self.L.orc_gammatone_run(self.h, pcm, len(pcm), filt.ctypes.data if want_filtered else None, out.reshape(-1))
+        return (out, filt) if want_filtered else out

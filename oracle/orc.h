@@ -86,6 +86,40 @@ double orc_equal_loudness(double f);
 double orc_equal_loudness_4khz(double f);
 double       orc_mfcc_mel_max(const orc_mfcc* h);         /* warped maximum frequency */
 
+/* ---------------------------------------------------------------- gammatone front-end (orc_gammatone.c; parity unpinned) */
+typedef struct {
+    double sample_rate;
+    int    cascade;          /* signal-gammatone cascade (node default 4) */
+    double min_freq;         /* minfreq (100) */
+    double max_freq;         /* maxfreq (6000) */
+    double q;                /* q (9.264491981582191) */
+    int    channels;         /* channels (50) */
+    int    cf_mode;          /* cfmode: 0 human, 1 erb */
+    double warp_freq_break;  /* warp-freqbreak (6600) */
+    double warping_factor;   /* warping-factor (1) */
+    int    ti_window;        /* signal-temporalintegration type: 0 hanning, 1 rectangular */
+    double ti_length_s;      /* length */
+    double ti_shift_s;       /* shift */
+    int    si_window;        /* signal-spectralintegration type: 0 hanning, 1 rectangular */
+    int    si_length;        /* length in channels; 0 = node absent */
+    int    si_shift;         /* shift in channels */
+    double power;            /* generic-vector-f32-power value; 0 = node absent */
+    int    n_ceps;           /* signal-cosine-transform nr-outputs; 0 = node absent */
+    int    dct_normalize;
+} orc_gammatone_cfg;
+typedef struct orc_gammatone orc_gammatone;
+orc_gammatone* orc_gammatone_create(const orc_gammatone_cfg* cfg);
+void           orc_gammatone_destroy(orc_gammatone* h);
+int            orc_gammatone_n_out(const orc_gammatone* h);
+int            orc_gammatone_frame_len(const orc_gammatone* h);
+int            orc_gammatone_frame_shift(const orc_gammatone* h);
+int            orc_gammatone_si_channels(const orc_gammatone* h);
+const float*   orc_gammatone_center_frequencies(const orc_gammatone* h);
+const float*   orc_gammatone_coefficients(const orc_gammatone* h); /* [channels][4] a0 a1 b1 b2 */
+long           orc_gammatone_n_frames(const orc_gammatone* h, long n_samples);
+/* filtered [n_samples x channels] (nullable): the signal-gammatone output; out [n_frames x n_out] */
+long           orc_gammatone_run(const orc_gammatone* h, const float* pcm, long n_samples, float* filtered, float* out);
+
 /* whole utterance: pcm f32 (s16 values, unscaled) -> ceps [n_frames x n_ceps] row-major.
  * returns number of frames written. */
 long orc_mfcc_run(const orc_mfcc* h, const float* pcm, long n_samples, float* ceps);

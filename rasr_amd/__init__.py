@@ -124,6 +124,55 @@ class _Plan:
             pass
 
 
+class GammatoneExtractor:
+    """signal-gammatone -> signal-temporalintegration [-> signal-spectralintegration -> generic-vector-f32-power ->
+    signal-cosine-transform].  Keyword names are the fields of amx_gammatone_cfg (= the nodes' parameters)."""
+
+    def __init__(self, ctx, **kw):
+        self.ctx, self.L = ctx, (ctx.L if ctx is not None else _lib.lib())
+        cfg = _lib.GammatoneCfg()
+        self.L.amx_gammatone_default_cfg(C.byref(cfg))
+        for k, v in kw.items():
+            if not hasattr(cfg, k):
+                raise TypeError("unknown gammatone parameter %r" % k)
+            setattr(cfg, k, v)
+        self.cfg = cfg
+        h = C.c_void_p()
+        _lib.check(self.L.amx_gammatone_create(ctx.h if ctx is not None else None, C.byref(cfg), C.byref(h)))
+        self.h = h
+        info = _lib.GammatoneInfo()
+        _lib.check(self.L.amx_gammatone_describe(h, C.byref(info)))
+        self.info, self.n_out, self.channels = info, info.n_out, info.channels
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.L.amx_gammatone_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def n_frames(self, n_samples):
+        return int(self.L.amx_gammatone_n_frames(self.h, n_samples))
+
+    def tables(self):
+        cf, co = np.zeros(self.channels, np.float32), np.zeros((self.channels, 4), np.float32)
+        _lib.check(self.L.amx_gammatone_tables(self.h, cf.ctypes.data, co.ctypes.data))
+        return cf, co
+
+    def run(self, pcm):
+        pcm = np.ascontiguousarray(pcm, dtype=np.float32)
+        out = np.zeros((self.n_frames(len(pcm)), self.n_out), np.float32)
+        _lib.check(self.L.amx_gammatone_run(self.h, pcm.ctypes.data, len(pcm), out.ctypes.data))
+        return out
+
+    def run_batch_dev(self, sample_offsets, pcm_dev, out_dev, filtered_dev=None):
+        """torch tensors on the device; sample_offsets: host int64 [n_seg + 1]"""
+        off = np.ascontiguousarray(sample_offsets, dtype=np.int64)
+        _lib.check(self.L.amx_gammatone_run_batch_dev(self.h, len(off) - 1, off.ctypes.data, pcm_dev.data_ptr(), out_dev.data_ptr(),
+                                                      filtered_dev.data_ptr() if filtered_dev is not None else None))
+
+
 class MfccExtractor:
     """The mfcc.flow chain.  Keyword names follow the Flow node parameters."""
 

@@ -33,6 +33,18 @@ class MfccCfg(C.Structure):
                 ("filter_type", C.c_int), ("boundary", C.c_int), ("warping", C.c_int)]
 
 
+class GammatoneCfg(C.Structure):
+    _fields_ = [("sample_rate", C.c_double), ("cascade", C.c_int), ("min_freq", C.c_double), ("max_freq", C.c_double), ("q", C.c_double),
+                ("channels", C.c_int), ("cf_mode", C.c_int), ("warp_freq_break", C.c_double), ("warping_factor", C.c_double),
+                ("ti_window", C.c_int), ("ti_length_s", C.c_double), ("ti_shift_s", C.c_double), ("si_window", C.c_int),
+                ("si_length", C.c_int), ("si_shift", C.c_int), ("power", C.c_double), ("n_ceps", C.c_int), ("dct_normalize", C.c_int)]
+
+
+class GammatoneInfo(C.Structure):
+    _fields_ = [("channels", C.c_int), ("cascade", C.c_int), ("frame_len", C.c_int), ("frame_shift", C.c_int), ("si_channels", C.c_int),
+                ("n_out", C.c_int)]
+
+
 class MfccInfo(C.Structure):
     _fields_ = [("frame_len", C.c_int), ("frame_shift", C.c_int), ("fft_len", C.c_int), ("n_bins", C.c_int),
                 ("n_filters", C.c_int), ("n_ceps", C.c_int), ("fft_output_sample_rate", C.c_double),
@@ -74,6 +86,14 @@ SIGNATURES = {
     "amx_mfcc_default_cfg": (None, [C.POINTER(MfccCfg)]),
     "amx_mfplp_default_cfg": (None, [C.POINTER(MfccCfg)]),
     "amx_plp_default_cfg": (None, [C.POINTER(MfccCfg)]),
+    "amx_gammatone_default_cfg": (None, [C.POINTER(GammatoneCfg)]),
+    "amx_gammatone_create": (C.c_int, [_P, C.POINTER(GammatoneCfg), C.POINTER(C.c_void_p)]),
+    "amx_gammatone_destroy": (None, [_P]),
+    "amx_gammatone_describe": (C.c_int, [_P, C.POINTER(GammatoneInfo)]),
+    "amx_gammatone_n_frames": (C.c_long, [_P, C.c_long]),
+    "amx_gammatone_tables": (C.c_int, [_P, _P, _P]),
+    "amx_gammatone_run": (C.c_int, [_P, _P, C.c_long, _P]),
+    "amx_gammatone_run_batch_dev": (C.c_int, [_P, C.c_int, _P, _P, _P, _P]),
     "amx_mfcc_equal_loudness": (C.c_int, [_P, _P]),
     "amx_mfcc_create": (C.c_int, [_P, C.POINTER(MfccCfg), C.POINTER(_P)]),
     "amx_mfcc_destroy": (None, [_P]),

@@ -1,0 +1,123 @@
+"""Gammatone front-end (signal-gammatone, -temporalintegration, -spectralintegration): host tables on the CPU, kernels on the GPU."""
+import numpy as np
+import pytest
+
+from tests import synth
+
+CASES = [dict(), dict(channels=68, max_freq=7500.0), dict(cf_mode=1, channels=40), dict(sample_rate=8000.0, max_freq=3800.0, warp_freq_break=3300.0),
+         dict(warping_factor=0.9), dict(warping_factor=1.1, channels=30), dict(cascade=1), dict(ti_length_s=0.02, ti_shift_s=0.005)]
+
+
+def _cfgs(kw):
+    from oracle.binding import GammatoneCfg
+    return GammatoneCfg.default(**kw)
+
+
+@pytest.mark.parametrize("kw", CASES)
+def test_host_tables_bit_identical_to_oracle(kw):
+    """centre frequencies, filter coefficients and frame geometry of a host-only handle against the oracle's restatement of
+    GammaTone::init (f32 members, double libm calls, complex<f32> division)"""
+    import rasr_amd
+    from oracle.binding import OracleGammatone
+    fe = rasr_amd.GammatoneExtractor(None, **kw)
+    o = OracleGammatone(_cfgs(kw))
+    cf, co = fe.tables()
+    assert np.array_equal(cf.view(np.uint32), o.center_frequencies.view(np.uint32))
+    assert np.array_equal(co.view(np.uint32), o.coefficients.view(np.uint32))
+    assert (fe.info.frame_len, fe.info.frame_shift, fe.n_out) == (o.frame_len, o.frame_shift, o.n_out)
+    for n in (0, 1, 159, 160, 399, 400, 401, 5000, 160000):
+        assert fe.n_frames(n) == o.n_frames(n)
+    with pytest.raises(rasr_amd.AmxError):
+        fe.run(np.zeros(10, np.float32))                 # host-only handle
+
+
+def test_filter_design_properties():
+    """independent checks of the restated design: centre frequencies run from minfreq to maxfreq, every channel's impulse response
+    peaks at its centre frequency with unit gain (a0 normalises the cascade stage at the centre frequency), bandwidths grow with
+    frequency like the ERB scale"""
+    from oracle.binding import OracleGammatone
+    o = OracleGammatone()
+    cf = o.center_frequencies
+    assert abs(cf[0] - 100) < 1e-3 and abs(cf[-1] - 6000) < 1e-2 and np.all(np.diff(cf) > 0)
+    imp = np.zeros(8192, np.float32)
+    imp[0] = 1
+    _, resp = o.run(imp, want_filtered=True)
+    spec = np.abs(np.fft.rfft(resp.astype(np.float64), axis=0))
+    for ch in (0, 10, 25, 40, 49):
+        peak = np.argmax(spec[:, ch]) * 16000.0 / 8192
+        assert abs(peak - cf[ch]) < max(8.0, 0.01 * cf[ch]), (ch, peak, cf[ch])   # real-valued filter: the mirror pole pulls low channels up a little
+        assert abs(spec[:, ch].max() - 1.0) < 0.06            # four stages, each normalised to gain 1 at the centre frequency
+    half = [(spec[:, ch] > spec[:, ch].max() / np.sqrt(2)).sum() for ch in (5, 25, 45)]
+    assert half[0] < half[1] < half[2]
+
+
+def test_configuration_errors():
+    import rasr_amd
+    with pytest.raises(rasr_amd.AmxError, match="warping function"):
+        rasr_amd.GammatoneExtractor(None, warping_factor=1.5)          # warpingFactor * freqBreak >= maxFreq
+    with pytest.raises(rasr_amd.AmxError):
+        rasr_amd.GammatoneExtractor(None, channels=1)
+    with pytest.raises(rasr_amd.AmxError):
+        rasr_amd.GammatoneExtractor(None, si_length=60)
+    with pytest.raises(rasr_amd.AmxError):
+        rasr_amd.GammatoneExtractor(None, ti_window=5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [dict(), dict(channels=68, max_freq=7500.0), dict(cf_mode=1, channels=70, cascade=2), dict(ti_window=1),
+                                dict(sample_rate=8000.0, max_freq=3800.0, warp_freq_break=3300.0, ti_length_s=0.032, ti_shift_s=0.004)])
+def test_filter_and_temporal_integration_bit_exact(ctx, kw):
+    """the node's own output (every sample of every channel) and the temporal integration are pure IEEE f32 / f64 arithmetic in a fixed
+    order: bit-identical to the oracle, incl. the short last frames whose window is made for their own length"""
+    import torch
+
+    import rasr_amd
+    from oracle.binding import OracleGammatone
+    fe = rasr_amd.GammatoneExtractor(ctx, **kw)
+    o = OracleGammatone(_cfgs(kw))
+    ctx.use_torch_stream()
+    for n in (1, 2, 159, 401, 5281, 16000):
+        pcm = synth.waveform(n, seed=40 + n)
+        want, wfilt = o.run(pcm, want_filtered=True)
+        got = fe.run(pcm)
+        assert got.shape == want.shape
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (n, np.abs(got - want).max())
+        pd = torch.from_numpy(pcm).cuda()
+        out = torch.empty(want.shape, dtype=torch.float32, device="cuda")
+        filt = torch.empty(wfilt.shape, dtype=torch.float32, device="cuda")
+        fe.run_batch_dev([0, n], pd, out, filt)
+        torch.cuda.synchronize()
+        assert np.array_equal(filt.cpu().numpy().view(np.uint32), wfilt.view(np.uint32))
+        assert np.array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_full_chain_and_ragged_batch(ctx):
+    """68 channels -> spectral integration 9 / 4 -> 10th root -> cosine transform: device pow differs from glibc's powf by a few ulp,
+    hence a tolerance on the cepstra; a ragged batch (incl. an empty segment) equals the single calls; spectral integration and root
+    compression alone are checked too"""
+    import torch
+
+    import rasr_amd
+    from oracle.binding import OracleGammatone
+    kw = dict(channels=68, max_freq=7500.0, si_length=9, si_shift=4, power=0.1, n_ceps=12)
+    fe = rasr_amd.GammatoneExtractor(ctx, **kw)
+    o = OracleGammatone(_cfgs(kw))
+    assert fe.n_out == 12 and fe.info.si_channels == 15
+    segs = [synth.waveform(n, seed=60 + n) for n in (48000, 401, 0, 7777)]
+    outs = [fe.run(x) for x in segs]
+    for x, y in zip(segs, outs):
+        want = o.run(x)
+        assert y.shape == want.shape
+        assert np.all(np.abs(y - want) <= 1e-4 * np.abs(want) + 1e-4), np.abs(y - want).max()
+    ctx.use_torch_stream()
+    off = np.concatenate([[0], np.cumsum([len(x) for x in segs])])
+    pcm = torch.from_numpy(np.concatenate(segs)).cuda()
+    out = torch.empty((sum(len(y) for y in outs), 12), dtype=torch.float32, device="cuda")
+    fe.run_batch_dev(off, pcm, out)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), np.concatenate(outs))
+    kw = dict(channels=68, max_freq=7500.0, si_length=9, si_shift=4)
+    x = segs[0]
+    got, want = rasr_amd.GammatoneExtractor(ctx, **kw).run(x), OracleGammatone(_cfgs(kw)).run(x)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))          # spectral integration: f32 products summed in order
