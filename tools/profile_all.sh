@@ -40,6 +40,8 @@ run_stats mfcc --workload mfcc --steps 8 --warmup 2 --no-cpu-baseline
 run_stats gmm --workload gmm --steps 50 --warmup 5 --no-cpu-baseline
 run_stats gmm-tied --workload gmm-tied --steps 20 --warmup 3
 run_stats nn --workload nn --steps 50 --warmup 5 --no-cpu-baseline
+run_stats mfcc-plp --workload mfcc --front-end plp --steps 8 --warmup 2 --no-cpu-baseline
+run_stats mfcc-gammatone --workload mfcc --front-end gammatone --steps 3 --warmup 1 --no-cpu-baseline
 run_stats nn-bf16x3 --workload nn --precision bf16x3 --steps 30 --warmup 5 --no-cpu-baseline
 run_pmc pipeline fetch FETCH_SIZE -- --steps 3 --warmup 1
 run_pmc pipeline write WRITE_SIZE -- --steps 3 --warmup 1
@@ -49,6 +51,9 @@ run_pmc nn-pipeline mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_M
 run_pmc gmm-train sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES -- --workload gmm-train --steps 3 --warmup 1
 run_pmc gmm-train sq2 SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD -- --workload gmm-train --steps 3 --warmup 1
 run_pmc gmm-tied sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_LDS -- --workload gmm-tied --steps 5 --warmup 2
+run_pmc gmm-tied fetch FETCH_SIZE -- --workload gmm-tied --steps 5 --warmup 2
+run_pmc gmm-tied write WRITE_SIZE -- --workload gmm-tied --steps 5 --warmup 2
+(cd $root && timeout 1500 python -m pytest tests -m gpu -q > $out/gpu_tests.log 2>&1)
 AMX_BENCH_FORCE_DIST=1 python $root/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-configs 2>/dev/null | grep "^{\"metric\"" | tail -1 > $out/force_dist_bench.log
 python $root/tools/gemm_comparator.py > $out/gemm_comparator.json 2>/dev/null
 [ -x $root/tools/build/valu_rates ] && $root/tools/build/valu_rates > $out/valu_rates.log 2>&1
