@@ -503,11 +503,11 @@ class GmmOnly:
             ops = 2.0 * self.nk * self.T
             surv, triples = self.sc.screen_counts(True)
             if triples:
-                # pruned path (gmm_tied.hip): the time goes into reading 256-byte rows of the 164 MB weight table at random -- 32 near
-                # rows per frame for the bounds (whole rows: every mixture) and one row per surviving (density, frame, tile) triple --
+                # pruned path (gmm_tied.hip): the time goes into reading rows of the 164 MB weight table at random -- 32 near rows per
+                # frame for the bounds (whole rows of its bf16 image: every mixture) and one 256-byte row per surviving (density, frame, tile) triple --
                 # plus the scores and density indices that leave.  `achieved` = those bytes / time of the four kernels.
                 launches = triples / float(4096 * self.T * 157) if self.T else 1.0
-                by = (self.T * 32.0 * 10048 * 4 + (surv / max(launches, 1.0)) * 256.0 + self.T * 10000 * 8.0 + self.T * 4096 * 12.0)
+                by = (self.T * 32.0 * 10048 * 2 + (surv / max(launches, 1.0)) * 256.0 + self.T * 10000 * 8.0 + self.T * 4096 * 12.0)
                 gbs = by / (ms * 1e-3) / 1e9
                 return dict(bound="hbm", kernel="tied_pruned_kernel + tied_bound_kernel + tied_list_kernel + tied_transpose_kernel",
                             note="exact pruning: bounds from 32 near densities per frame, then the reference's f64 rule over the surviving "

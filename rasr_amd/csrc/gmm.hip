@@ -1447,7 +1447,8 @@ struct amx_gmm {
     float*    d_m2lw_t = nullptr;  // [K][mix_pad]
     float *   d_ahat_t = nullptr, *d_amax = nullptr;  // screen tables: fl32(m2lw + logNorm) [K][mix_pad], max_k |.| [mix_pad]
     // pruned path (gmm_tied.hip): per-tile minima of a^, per-call workspace, survivor statistics of earlier calls
-    float*              d_amin       = nullptr;  // [mix_pad / 64][Kpad]
+    float*              d_amin       = nullptr;  // [mix_pad / 64 + 1][Kpad]
+    unsigned short*     d_aup        = nullptr;  // [K][mix_pad] bf16 image of a^, rounded up (bounds only)
     void*               d_tied_ws    = nullptr;
     size_t              tied_ws_cap  = 0;
     unsigned long long* d_tied_surv  = nullptr;  // [256] survivors (density, frame, tile) of the calls so far, spread over 256 counters
@@ -1542,10 +1543,10 @@ extern "C" int   amx_internal_gmm_simd_presel_build(void* p, amx_ctx* ctx, int n
 extern "C" int   amx_internal_gmm_simd_presel_info(const void* p, int* n_clusters, uint32_t* cluster_of, float* cluster_means);
 extern "C" int   amx_internal_gmm_simd_presel_score(void* p, amx_ctx* ctx, const float* feats_dev, int T, float* scores_dev);
 
-extern "C" int    amx_internal_gmm_tied_create(int K, int n_mix, int mix_pad, const float* ahat_t_host, float** d_amin);
+extern "C" int    amx_internal_gmm_tied_create(int K, int n_mix, int mix_pad, const float* ahat_t_host, float** d_amin, unsigned short** d_aup);
 extern "C" size_t amx_internal_gmm_tied_workspace(int K, int T, int mix_pad);
 extern "C" int    amx_internal_gmm_tied_score(amx_ctx* ctx, const float* dist_dev, const uint32_t* k_dens_dev, int K, int T, int Tpad, int n_mix,
-                                              int mix_pad, const float* ln32, const float* amax, const float* m2lw_t, const double* ln64,
+                                              int mix_pad, const unsigned short* aup, const float* amax, const float* m2lw_t, const double* ln64,
                                               const float* amin, void* workspace, float* scores, uint32_t* best,
                                               unsigned long long* survivors_dev);
 extern "C" int amx_internal_gmm_fused_supported(int dim, int pooled, int Kp);
@@ -1942,7 +1943,7 @@ int amx_gmm_create(amx_ctx* ctx, const amx_gmm_model* m, amx_gmm** out) {
         if ((r = gupload(&h->d_m2lw_t, wt.data(), wt.size())) != AMX_OK || (r = gupload(&h->d_ln64, ln64.data(), ln64.size())) != AMX_OK ||
             (r = gupload(&h->d_ln32, ln32.data(), ln32.size())) != AMX_OK || (r = gupload(&h->d_ahat_t, ahat.data(), ahat.size())) != AMX_OK ||
             (r = gupload(&h->d_amax, amax.data(), amax.size())) != AMX_OK ||
-            (r = amx_internal_gmm_tied_create(h->K, h->n_mix, h->mix_pad, ahat.data(), &h->d_amin)) != AMX_OK) {
+            (r = amx_internal_gmm_tied_create(h->K, h->n_mix, h->mix_pad, ahat.data(), &h->d_amin, &h->d_aup)) != AMX_OK) {
             amx_gmm_destroy(h);
             return r;
         }
@@ -2117,6 +2118,7 @@ void amx_gmm_destroy(amx_gmm* h) {
     hipFree(h->d_ahat_t);
     hipFree(h->d_amax);
     hipFree(h->d_amin);
+    hipFree(h->d_aup);
     hipFree(h->d_tied_ws);
     hipFree(h->d_tied_surv);
     if (h->h_tied_surv)
@@ -2405,7 +2407,7 @@ int amx_gmm_score_dev(amx_gmm* h, int mode, const float* feats_dev, int T, float
                         AMX_HIP(hipMalloc(&h->d_tied_ws, need_ws));
                         h->tied_ws_cap = need_ws;
                     }
-                    int r = amx_internal_gmm_tied_score(h->ctx, h->d_dist, h->d_k_dens, h->K, Tc, Tpad, h->n_mix, h->mix_pad, h->d_ln32,
+                    int r = amx_internal_gmm_tied_score(h->ctx, h->d_dist, h->d_k_dens, h->K, Tc, Tpad, h->n_mix, h->mix_pad, h->d_aup,
                                                         h->d_amax, h->d_m2lw_t, h->d_ln64, h->d_amin, h->d_tied_ws, sc, bd, h->d_tied_surv);
                     if (r != AMX_OK)
                         return r;

@@ -6,7 +6,7 @@
 // densely: K x n_mix x T sums, twice.  But a density far from the frame cannot win in ANY mixture, and that can be proven
 // per (density, frame, 64-mixture tile) from small tables:
 //
-//   a^[k][m]     = fl32(m2lw[k][m] + logNorm[k])             (formed on the fly from the weight table [K][mix_pad])
+//   a^[k][m]     = fl32(m2lw[k][m] + logNorm[k])             (model; the bound kernel reads a bf16 image rounded up, [K][mix_pad])
 //   amin[j][k]   = min over the mixtures of tile j of a^[k][m] (model, [n_tiles][Kpad]);  aminG[k] = min over all tiles
 //   U[t][m]      = min over 32 densities NEAR frame t (the closest density of each residue class k mod 32) of
 //                  s^_k = fl32(a^[k][m] + dist[k][t])         -- an upper bound of min_k s^_k, because it is a minimum over a subset
@@ -30,6 +30,7 @@
 #include "common.hpp"
 
 #include <cfloat>
+#include <cstring>
 #include <vector>
 
 namespace amx {
@@ -60,19 +61,25 @@ __global__ __launch_bounds__(256) void tied_transpose_kernel(const float* __rest
 // Thr[t][tile]: thread = mixture, 256 mixtures = 4 tiles per workgroup.  Prologue: the frame's closest density of every residue
 // class k mod 32 (any subset gives a valid bound; this one needs no selection).  U = min over them of fl32(a^ + dist); the tile's
 // threshold is the maximum of U + tau' over its real mixtures.
-__global__ __launch_bounds__(256) void tied_bound_kernel(const float* __restrict__ g_m2lw_t, const float* __restrict__ g_ln32,
-                                                        const float* __restrict__ g_amax, const float* __restrict__ g_dt, int K, int Kpad,
-                                                        int n_mix, int mix_pad, int n_tiles, float* __restrict__ g_thr) {
-    __shared__ float    s_v[256];
-    __shared__ uint32_t s_i[256];
-    __shared__ float    s_nd[kTiedNear], s_nl[kTiedNear];
+// The sums only have to bound the minimum from ABOVE, so the 32 table rows per frame are read from a bf16 image of a^ that was
+// rounded UP (a^_up >= a^, hence fl32(a^_up + dist) >= fl32(a^ + dist)): half the bytes of the kernel's only real traffic, for a
+// bound that is at most 2^-8 |a^| looser.
+constexpr int kTiedBoundThreads = 1024;  // mixtures per workgroup of tied_bound_kernel (the prologue is paid once per workgroup)
+
+__global__ __launch_bounds__(kTiedBoundThreads) void tied_bound_kernel(const unsigned short* __restrict__ g_aup, const float* __restrict__ g_amax,
+                                                                      const float* __restrict__ g_dt, int K, int Kpad, int n_mix, int mix_pad,
+                                                                      int n_tiles, float* __restrict__ g_thr) {
+    constexpr int       NT = kTiedBoundThreads;
+    __shared__ float    s_v[NT];
+    __shared__ uint32_t s_i[NT];
+    __shared__ float    s_nd[kTiedNear];
     __shared__ uint32_t s_nk[kTiedNear];
-    const int           t = blockIdx.y, tid = threadIdx.x, m = blockIdx.x * 256 + tid;
+    const int           t = blockIdx.y, tid = threadIdx.x, m = blockIdx.x * NT + tid;
     const float*        row = g_dt + (size_t)t * Kpad;
     {
         float    bv = __builtin_inff();
         uint32_t bi = 0;
-        for (int k = tid; k < K; k += 256) {  // 256 = 8 x 32: a thread stays inside one residue class
+        for (int k = tid; k < K; k += NT) {  // NT is a multiple of 32: a thread stays inside one residue class
             const float v = row[k];
             if (v < bv) {
                 bv = v;
@@ -86,27 +93,24 @@ __global__ __launch_bounds__(256) void tied_bound_kernel(const float* __restrict
     if (tid < kTiedNear) {
         float    bv = s_v[tid];
         uint32_t bi = s_i[tid];
-#pragma unroll
-        for (int j = 1; j < 256 / kTiedNear; ++j)
+        for (int j = 1; j < NT / kTiedNear; ++j)
             if (s_v[tid + kTiedNear * j] < bv) {
                 bv = s_v[tid + kTiedNear * j];
                 bi = s_i[tid + kTiedNear * j];
             }
-        s_nd[tid] = bv;  // +inf: empty class, or no finite distance (NaN / inf frame)
+        s_nd[tid] = bv;  // +inf: empty class, or no finite distance (NaN / inf frame); row 0 stands in, its sum is +inf
         s_nk[tid] = bi;
-        s_nl[tid] = g_ln32[bi];
     }
     __syncthreads();
     float u = FLT_MAX;
     if (m < mix_pad) {
-#pragma unroll 8
-        for (int i = 0; i < kTiedNear; ++i) {
-            const float d = s_nd[i];
-            if (d < __builtin_inff()) {  // wave-uniform
-                const float a = g_m2lw_t[(size_t)s_nk[i] * mix_pad + m] + s_nl[i];
-                u             = fminf(u, a + d);
-            }
-        }
+        float a[kTiedNear];
+#pragma unroll
+        for (int i = 0; i < kTiedNear; ++i)  // all rows in flight before the first use
+            a[i] = __uint_as_float((uint32_t)g_aup[(size_t)s_nk[i] * mix_pad + m] << 16);
+#pragma unroll
+        for (int i = 0; i < kTiedNear; ++i)
+            u = fminf(u, a[i] + s_nd[i]);
     }
     float thr = -__builtin_inff();
     if (m < n_mix) {
@@ -138,18 +142,26 @@ __global__ __launch_bounds__(64) void tied_list_kernel(const float* __restrict__
     uint32_t*    lk  = g_lk + (size_t)t * Kpad;
     float*       ld  = g_ld + (size_t)t * Kpad;
     int          n   = 0;
-#pragma unroll 4
-    for (int kb = 0; kb < K; kb += 64) {
-        const int                k    = kb + lane;
-        const float              dv   = row[k];
-        const bool               rel  = k < K && (g_amin_all[k] + dv) <= thr;  // k < K: +inf <= thr when the threshold is +inf itself
-        const unsigned long long mask = __ballot(rel);
-        if (rel) {
-            const int pos = n + __popcll(mask & ((1ull << lane) - 1ull));
-            lk[pos]       = (uint32_t)k;
-            ld[pos]       = dv;
+    for (int kb = 0; kb < Kpad; kb += 256) {  // four 64-density steps per trip, their eight loads in flight together
+        float dv[4], am[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = kb + 64 * u + lane;
+            dv[u]       = k < Kpad ? row[k] : __builtin_inff();
+            am[u]       = k < Kpad ? g_amin_all[k] : __builtin_inff();
         }
-        n += __popcll(mask);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int                k    = kb + 64 * u + lane;
+            const bool               rel  = k < K && (am[u] + dv[u]) <= thr;  // k < K: +inf <= thr when the threshold is +inf itself
+            const unsigned long long mask = __ballot(rel);
+            if (rel) {
+                const int pos = n + __popcll(mask & ((1ull << lane) - 1ull));
+                lk[pos]       = (uint32_t)k;
+                ld[pos]       = dv[u];
+            }
+            n += __popcll(mask);
+        }
     }
     if (lane == 0)
         g_ln[t] = n;
@@ -172,7 +184,7 @@ struct TiedMax {  // MaxState of gmm.hip (the reference's rule), restated here t
 // One wave per (64-mixture tile, frame).  Phase 1 (lane = list entry) applies the tile's test to the frame's list and compacts
 // the survivors -- position, distance, log-normalisation term -- into LDS; phase 2 (lane = mixture) runs the f64 rule over them
 // in ascending order with PF rows of the weight table in flight.
-constexpr int kTiedSeg = 128;  // survivors buffered per wave; a fuller list is worked off and the scan resumes
+constexpr int kTiedSeg = 256;  // survivors buffered per wave; a fuller list is worked off and the scan resumes
 
 __global__ __launch_bounds__(256) void tied_pruned_kernel(const uint32_t* __restrict__ g_lk, const float* __restrict__ g_ld,
                                                          const int* __restrict__ g_ln, const float* __restrict__ g_amin,
@@ -184,8 +196,12 @@ __global__ __launch_bounds__(256) void tied_pruned_kernel(const uint32_t* __rest
     __shared__ float    s_d[4][kTiedSeg];
     __shared__ double   s_l[4][kTiedSeg];
     const int           lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int           tile = blockIdx.x, t = blockIdx.y * 4 + wave;
-    if (t >= T)
+    // Workgroup b runs on XCD b % 8 (each XCD has its own L2).  A row of the weight table is wanted by ~3 of a 256-frame batch's
+    // frames, so all frame groups of one tile go to ONE XCD, back to back: tile = 8 * (slot / n_fg) + xcd, frame group = slot % n_fg.
+    // The tile's 1 MB slice of the table then comes from HBM once instead of once per frame that wants it.
+    const int n_fg = (T + 3) / 4, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int tile = (slot / n_fg) * 8 + xcd, t = (slot % n_fg) * 4 + wave;
+    if (tile >= n_tiles || t >= T)
         return;
     const int       m    = tile * 64 + lane;
     const float     Thr  = g_thr[(size_t)t * n_tiles + tile];
@@ -199,20 +215,35 @@ __global__ __launch_bounds__(256) void tied_pruned_kernel(const uint32_t* __rest
     while (ib < nl) {
         // ---- phase 1
         int n = 0;
-        for (; ib < nl && n + 64 <= kTiedSeg; ib += 64) {
-            const int      i  = ib + lane;
-            const bool     in = i < nl;
-            const uint32_t k  = in ? lk[i] : 0u;
-            const float    dv = in ? ld[i] : 0.f;
-            const bool     rel = in && (arow[k] + dv) <= Thr;
-            const unsigned long long mask = __ballot(rel);
-            if (rel) {
-                const int pos   = n + __popcll(mask & ((1ull << lane) - 1ull));
-                s_k[wave][pos] = k;
-                s_d[wave][pos] = dv;
-                s_l[wave][pos] = g_ln64[k];
+        for (; ib < nl && n + 128 <= kTiedSeg; ib += 128) {  // two 64-entry steps per trip: list loads, then gathers, then the tests
+            uint32_t k[2];
+            float    dv[2], am[2];
+            double   ln[2];
+            bool     in[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int i = ib + 64 * u + lane;
+                in[u]       = i < nl;
+                k[u]        = in[u] ? lk[i] : 0u;
+                dv[u]       = in[u] ? ld[i] : 0.f;
             }
-            n += __popcll(mask);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                am[u] = arow[k[u]];
+                ln[u] = g_ln64[k[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const bool               rel  = in[u] && (am[u] + dv[u]) <= Thr;
+                const unsigned long long mask = __ballot(rel);
+                if (rel) {
+                    const int pos  = n + __popcll(mask & ((1ull << lane) - 1ull));
+                    s_k[wave][pos] = k[u];
+                    s_d[wave][pos] = dv[u];
+                    s_l[wave][pos] = ln[u];
+                }
+                n += __popcll(mask);
+            }
         }
         total += n;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -248,8 +279,26 @@ __global__ __launch_bounds__(256) void tied_pruned_kernel(const uint32_t* __rest
 
 // amin[tile][k] = min over the real mixtures of the tile of a^[k][m]; aminG[k] = min over the tiles.  Returns one device table
 // [(n_tiles + 1)][Kpad] (+inf padded), row n_tiles = aminG.
-extern "C" int amx_internal_gmm_tied_create(int K, int n_mix, int mix_pad, const float* ahat_t_host, float** d_amin) {
+// bf16 that is >= the f32 value (NaN / inf pass through; +0 for the padding columns)
+static unsigned short tied_bf16_up(float v) {
+    uint32_t u;
+    memcpy(&u, &v, 4);
+    if ((u & 0x7f800000u) == 0x7f800000u || (u & 0xffffu) == 0)
+        return (unsigned short)(u >> 16);
+    // positive: truncation rounds down -> next bf16 up; negative: truncation (towards zero) already rounds up
+    return (unsigned short)((u >> 16) + ((u >> 31) ? 0u : 1u));
+}
+
+extern "C" int amx_internal_gmm_tied_create(int K, int n_mix, int mix_pad, const float* ahat_t_host, float** d_amin, unsigned short** d_aup) {
     const int          n_tiles = mix_pad / 64, Kpad = (K + 63) & ~63;
+    {
+        std::vector<unsigned short> up((size_t)K * mix_pad);
+        for (size_t i = 0; i < up.size(); ++i)
+            up[i] = tied_bf16_up(ahat_t_host[i]);
+        *d_aup = nullptr;
+        AMX_HIP(hipMalloc((void**)d_aup, up.size() * 2));
+        AMX_HIP(hipMemcpy(*d_aup, up.data(), up.size() * 2, hipMemcpyHostToDevice));
+    }
     std::vector<float> amin((size_t)(n_tiles + 1) * Kpad, __builtin_inff());
     for (int k = 0; k < K; ++k)
         for (int i = 0; i < n_mix; ++i) {
@@ -297,7 +346,7 @@ extern "C" size_t amx_internal_gmm_tied_workspace(int K, int T, int mix_pad) {
 }
 
 extern "C" int amx_internal_gmm_tied_score(amx_ctx* ctx, const float* dist_dev, const uint32_t* k_dens_dev, int K, int T, int Tpad, int n_mix,
-                                           int mix_pad, const float* ln32, const float* amax, const float* m2lw_t, const double* ln64,
+                                           int mix_pad, const unsigned short* aup, const float* amax, const float* m2lw_t, const double* ln64,
                                            const float* amin, void* workspace, float* scores, uint32_t* best,
                                            unsigned long long* survivors_dev) {
     if (T <= 0)
@@ -306,11 +355,11 @@ extern "C" int amx_internal_gmm_tied_score(amx_ctx* ctx, const float* dist_dev, 
     const TiedWs w    = tied_ws(workspace, K, T, mix_pad);
     hipLaunchKernelGGL(amx::tied_transpose_kernel, dim3(Kpad / 64, (T + 63) / 64), dim3(256), 0, ctx->stream, dist_dev, k_dens_dev, K, Kpad, T,
                        Tpad, w.dt);
-    hipLaunchKernelGGL(amx::tied_bound_kernel, dim3((mix_pad + 255) / 256, T), dim3(256), 0, ctx->stream, m2lw_t, ln32, amax, w.dt, K, Kpad,
-                       n_mix, mix_pad, n_tiles, w.thr);
+    hipLaunchKernelGGL(amx::tied_bound_kernel, dim3((mix_pad + amx::kTiedBoundThreads - 1) / amx::kTiedBoundThreads, T), dim3(amx::kTiedBoundThreads), 0, ctx->stream, aup, amax, w.dt, K, Kpad, n_mix,
+                       mix_pad, n_tiles, w.thr);
     hipLaunchKernelGGL(amx::tied_list_kernel, dim3(T), dim3(64), 0, ctx->stream, w.dt, amin + (size_t)n_tiles * Kpad, w.thr, K, Kpad, n_tiles,
                        w.lk, w.ld, w.ln);
-    hipLaunchKernelGGL(amx::tied_pruned_kernel, dim3(n_tiles, (T + 3) / 4), dim3(256), 0, ctx->stream, w.lk, w.ld, w.ln, amin, w.thr, m2lw_t,
+    hipLaunchKernelGGL(amx::tied_pruned_kernel, dim3(8 * ((n_tiles + 7) / 8) * ((T + 3) / 4)), dim3(256), 0, ctx->stream, w.lk, w.ld, w.ln, amin, w.thr, m2lw_t,
                        ln64, Kpad, T, n_mix, mix_pad, n_tiles, scores, best, survivors_dev);
     AMX_HIP(hipGetLastError());
     return AMX_OK;
