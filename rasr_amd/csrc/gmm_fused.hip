@@ -75,7 +75,7 @@ __global__ __launch_bounds__(NW * 64) void gmm_fused_kernel(const float* __restr
                                                         float* __restrict__ g_scores, uint32_t* __restrict__ g_best, int T, int Tpad,
                                                         int n_mix, int n_tiles, int r_split, float* __restrict__ g_part_min,
                                                         unsigned* __restrict__ g_part_idx, int part_ld,
-                                                        unsigned long long* __restrict__ g_survivors, int abl) {
+                                                        unsigned long long* __restrict__ g_survivors) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int LD = fused_ld(DIM), REC = fused_rec_bytes(DIM), NP = REC / 1024;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -387,9 +387,6 @@ extern "C" int amx_internal_gmm_fused_create(int dim, int n_mix, int n_tiles, co
     return AMX_OK;
 }
 
-// how many mixture ranges a pass of Tpad frames is split into (workgroup = 256 frames x one range; one workgroup per CU): the
-// smallest split that gives every CU a workgroup, unless the frame tiles alone already fill 3/4 of them.  The partial arg-min
-// arrays hold that many rows.
 // waves per workgroup: 12 (three per SIMD, 384 frames; the kernel uses 158 VGPRs) for long passes -- measured 5.1 ms against 5.9 ms
 // with 8 waves and 5.0 ms with 16 (which spills 9 registers) per 63 936 frames -- and 8 (256 frames) for the decoder's small batches,
 // where a 384-frame workgroup would idle a third of its waves.  AMX_FUSED_WAVES = 8 | 12 | 16 overrides (A/B runs).
@@ -400,6 +397,9 @@ static int fused_waves(int Tpad) {
     return Tpad >= 4096 ? 12 : 8;
 }
 
+// how many mixture ranges a pass of Tpad frames is split into (workgroup = its frames x one range; one workgroup per CU): the
+// smallest split that gives every CU a workgroup, unless the frame tiles alone already fill 3/4 of them.  The partial arg-min
+// arrays hold that many rows.
 static int fused_split_raw(int n_cu, int Tpad, int n_tiles) {
     const int fpw = fused_waves(Tpad) * 32;
     const int ntt = (Tpad + fpw - 1) / fpw, cus = std::max(n_cu, 8);
@@ -440,13 +440,12 @@ extern "C" int amx_internal_gmm_fused_score(amx_ctx* ctx, int dim, const void* r
     const int   lds = 2 * amx::fused_rec_bytes(dim);
     const char* rec = (const char*)rec_dev;
     hipStream_t st  = ctx->stream;
-    const int   abl = getenv("AMX_FUSED_ABL") ? atoi(getenv("AMX_FUSED_ABL")) : 0;  // ablation switches (profiling only; results are wrong)
 #define AMX_FUSED_LAUNCH(D, B, W)                                                                                               \
     {                                                                                                                           \
         auto k = amx::gmm_fused_kernel<D, B, W>;                                                                                \
         hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);                                   \
         hipLaunchKernelGGL(k, dim3(ntt * split), dim3(W * 64), lds, st, feats, (const _Float16*)X, nx, q, rec, isr_dev, scores,  \
-                           best, T, Tpad, n_mix, n_tiles, split, pmin, pidx, part_ld, survivors, abl);                          \
+                           best, T, Tpad, n_mix, n_tiles, split, pmin, pidx, part_ld, survivors);                          \
     }
 #define AMX_FUSED(D)                                                                                                            \
     case D: {                                                                                                                   \
