@@ -27,6 +27,7 @@
 #include "mfcc_tables.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 namespace amx {
@@ -108,8 +109,8 @@ struct MfccLds {
         kpad    = r4(n_filters);                                                         // K of the DCT, multiple of 4
         lm_ld   = kpad + 1;
         dct_ld  = (n_ceps + 15) & ~15;
-        y       = 0;
-        amp     = y + r4(y_len);
+        y       = 0;  // (no staged PCM span any more, see the kernel)
+        amp     = 0;
         lm      = amp + r4(FT * amp_ld);
         dct     = lm + r4(FT * lm_ld);
         fw      = dct + r4(kpad * dct_ld);
@@ -129,7 +130,6 @@ __global__ __launch_bounds__(mfcc_waves(NC) * 64, (NC >= 1024 ? 1 : 4)) void mfc
     const int wave = tid >> 6;
 
     const MfccLds  L(p.frame_len, p.frame_shift, 2 * NC, p.n_filters, p.n_ceps, p.n_weights);
-    float*  s_y   = smem + L.y;     // pre-emphasised samples of the tile, zero beyond the segment
     float*  s_amp = smem + L.amp;   // [FT][amp_ld] amplitude spectra
     float*  s_lm  = smem + L.lm;    // [FT][lm_ld]  log10 mel energies (columns >= n_filters are 0)
     float*  s_dct = smem + L.dct;   // [kpad][dct_ld] DCT matrix, transposed and zero padded
@@ -202,51 +202,18 @@ __global__ __launch_bounds__(mfcc_waves(NC) * 64, (NC >= 1024 ? 1 : 4)) void mfc
 
   for (int tile_id = blockIdx.x; tile_id < p.n_tiles; tile_id += gridDim.x) {
     const MfccTile tile = p.tiles[tile_id];
-    // ================= phase A: stage the tile's PCM span (read once, coalesced; pre-emphasis on the fly).
-    // Four independent loads per thread are in flight per batch so the HBM latency is paid once per batch.
-    {
-        const long long first = (long long)tile.frame0 * p.frame_shift;  // first sample of the tile in the segment
-        const float*    src   = p.pcm + tile.sample_base;
-        const long long avail = (long long)tile.n_samples - first;       // samples of the segment from `first` on
-        for (int base = 0; base < L.y_len; base += 4 * MT) {
-            float x[4], pv[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = base + u * MT + tid;
-                x[u]        = (i < L.y_len && i < avail) ? src[first + i] : 0.f;
-                pv[u]       = 0.f;
-                if (lane == 0 && i < L.y_len && i < avail) {
-                    const long long g = first + i - 1;
-                    pv[u]             = src[g < 0 ? 0 : g];  // segment start: previous_ = x[0]
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = base + u * MT + tid;
-                // predecessor sample: the neighbouring lane's x, except for the first lane of each wave
-                float prev = __shfl_up(x[u], 1, 64);
-                if (lane == 0)
-                    prev = pv[u];
-                if (i < L.y_len) {
-                    float yv;
-                    if (alpha1)
-                        yv = x[u] - prev;  // Signal/Preemphasis.cc:69-75
-                    else {
-                        float prod = alpha * prev;  // :62-67
-                        yv         = x[u] - prod;
-                    }
-                    s_y[i] = (i < avail) ? yv : 0.f;
-                }
-            }
-        }
-    }
-    __syncthreads();
-
+    // ================= (round 1's phase A -- staging the tile's PCM span in LDS behind a workgroup barrier -- is gone.)  A frame's
+    // samples are read where they are used: neighbouring frames overlap, so the re-reads come from L2; 11.6 KB of LDS and one
+    // barrier per tile less, four workgroups per CU for MFCC-40 instead of three.  A/B on one box (tools/ab_mfcc.sh, ms per
+    // 993 k frames, staged -> direct at four workgroups per CU): mfcc.flow 1.02 -> 0.95, mfplp.flow 1.09 -> 0.97, plp.flow 1.32 ->
+    // 1.17; five workgroups per CU (the PLP variants' smaller LDS would allow them) are 30 % SLOWER, hence the cap in launch_mfcc.
+    const float*    seg   = p.pcm + tile.sample_base;
+    const long long nseg  = tile.n_samples;
     // ================= phase B: one frame per wavefront: FFT -> split -> |X| into s_amp[f][*]
     for (int f = wave; f < FT; f += MW) {
         if (f >= tile.n_frames)
             break;  // wave-uniform
-        const float* yf = s_y + f * p.frame_shift;
+        const long long fbase = (long long)(tile.frame0 + f) * p.frame_shift;  // the frame's first sample within the segment
         wave_sync();  // the previous frame's readers of s_z are done
         // first radix-4 stage (Ns = 1, unit twiddles) straight from the pre-emphasised tile
         {
@@ -256,10 +223,33 @@ __global__ __launch_bounds__(mfcc_waves(NC) * 64, (NC >= 1024 ? 1 : 4)) void mfc
                 const int j = lane + 64 * b;
                 if (j < NC / 4) {
                     float2 x[4];
+                    float  xm[4], x0[4], x1[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {  // samples 2c - 1, 2c, 2c + 1 of the frame (zero beyond the segment and the window)
+                        const int       c = j + r * (NC / 4);
+                        const long long n = fbase + 2 * c;
+                        const bool      w = 2 * c < p.frame_len;
+                        x0[r]             = (w && n < nseg) ? seg[n] : 0.f;
+                        x1[r]             = (w && n + 1 < nseg) ? seg[n + 1] : 0.f;
+                        xm[r]             = (w && n < nseg) ? seg[n > 0 ? n - 1 : 0] : 0.f;  // segment start: previous_ = x[0]
+                    }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int c = j + r * (NC / 4);
-                        x[r]        = make_float2(wlo[b][r] * yf[2 * c], whi[b][r] * yf[2 * c + 1]);  // WindowFunction::work
+                        const int       c = j + r * (NC / 4);
+                        const long long n = fbase + 2 * c;
+                        float           y0, y1;
+                        if (alpha1) {  // Signal/Preemphasis.cc:69-75
+                            y0 = x0[r] - xm[r];
+                            y1 = x1[r] - x0[r];
+                        }
+                        else {  // :62-67
+                            const float p0 = alpha * xm[r], p1 = alpha * x0[r];
+                            y0             = x0[r] - p0;
+                            y1             = x1[r] - p1;
+                        }
+                        y0   = n < nseg ? y0 : 0.f;  // zero padding behind the segment (short last frames)
+                        y1   = n + 1 < nseg ? y1 : 0.f;
+                        x[r] = make_float2(wlo[b][r] * y0, whi[b][r] * y1);  // WindowFunction::work
                     }
                     const float2 a  = make_float2(x[0].x + x[2].x, x[0].y + x[2].y);
                     const float2 bb = make_float2(x[0].x - x[2].x, x[0].y - x[2].y);
@@ -444,7 +434,7 @@ __global__ __launch_bounds__(mfcc_waves(NC) * 64, (NC >= 1024 ? 1 : 4)) void mfc
             }
         }
     }
-    __syncthreads();  // s_lm / s_amp / s_y are rewritten by the next tile
+    __syncthreads();  // s_lm / s_amp are rewritten by the next tile
   }
 }
 
@@ -604,7 +594,10 @@ int launch_mfcc(amx_mfcc* h, const amx::MfccParams& p, int n_tiles) {
     if (h->lds_bytes > 48 * 1024)
         AMX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
     // persistent workgroups: as many as are co-resident (LDS bound), each loops over tiles
-    int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / std::max<size_t>(h->lds_bytes, 1)));
+    // (at most four per CU: five were 30 % slower on the PLP front ends, whose LDS footprint would allow them)
+    int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / std::max<size_t>(h->lds_bytes, 1)));
+    if (const char* e = getenv("AMX_MFCC_WGS"))  // A/B runs: cap the workgroups per CU
+        per_cu = std::max(1, std::min(per_cu, atoi(e)));
     int grid   = std::min(n_tiles, per_cu * std::max(h->ctx->n_cu, 1));
     amx::ScopedKernelTimer timer(h->ctx, "mfcc");
     hipLaunchKernelGGL(kern, dim3(grid), dim3(amx::mfcc_waves(NC) * 64), h->lds_bytes, h->ctx->stream, p);
