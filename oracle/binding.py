@@ -127,6 +127,9 @@ def Oracle():
     L.orc_preemphasis.argtypes = [f32p, C.c_long, C.c_float]
     L.orc_fft_real.argtypes = [f32p, C.c_int]
     L.orc_fft_complex.argtypes = [f32p, C.c_int]
+    for n in ("orc_core_is_almost_equal", "orc_core_is_significantly_greater"):
+        getattr(L, n).restype = C.c_int
+        getattr(L, n).argtypes = [C.c_double, C.c_double, C.c_double]
     for n in ("orc_mel", "orc_mel_derivative", "orc_mel_inverse", "orc_bark", "orc_bark_derivative", "orc_bark_inverse",
               "orc_equal_loudness", "orc_equal_loudness_4khz"):
         getattr(L, n).restype = C.c_double
@@ -173,6 +176,9 @@ def load_ref():
     for n in ("ref_mel", "ref_mel_derivative", "ref_mel_inverse", "ref_bark", "ref_bark_derivative", "ref_bark_inverse"):
         getattr(R, n).restype = C.c_double
         getattr(R, n).argtypes = [C.c_double]
+    for n in ("ref_is_almost_equal", "ref_is_significantly_greater"):
+        getattr(R, n).restype = C.c_int
+        getattr(R, n).argtypes = [C.c_double, C.c_double, C.c_double]
     R.ref_equal_loudness.restype = C.c_double
     R.ref_equal_loudness.argtypes = [C.c_double, C.c_int]
     R.ref_plp_equal_loudness.restype = C.c_double

@@ -79,6 +79,8 @@ const int*   orc_mfcc_filter_offset(const orc_mfcc* h);   /* [n_filters+1] into 
 const float* orc_mfcc_filter_weights(const orc_mfcc* h);  /* concatenated */
 const float* orc_mfcc_dct(const orc_mfcc* h);             /* [n_ceps][n_filters] row-major; plp.flow: [n_autocorrelation][n_filters + 2] */
 const double* orc_mfcc_equal_loudness(const orc_mfcc* h); /* plp.flow: [n_filters + 2], else NULL */
+int    orc_core_is_almost_equal(double a, double b, double tolerance);          /* Core/Utility.hh:322-327 */
+int    orc_core_is_significantly_greater(double a, double b, double tolerance); /* Core/Utility.hh:343-345 */
 double orc_bark(double f);
 double orc_bark_derivative(double f);
 double orc_bark_inverse(double b);

@@ -214,6 +214,9 @@ static int orc_almost_equal_tol(double a, double b, double tolerance) {
 static int orc_almost_equal(double a, double b) {
     return orc_almost_equal_tol(a, b, 1.0);
 }
+/* for pinning against Core::isAlmostEqual / Core::isSignificantlyGreater (tests only) */
+int orc_core_is_almost_equal(double a, double b, double tolerance) { return orc_almost_equal_tol(a, b, tolerance); }
+int orc_core_is_significantly_greater(double a, double b, double tolerance) { return a > b && !orc_almost_equal_tol(a, b, tolerance); }
 
 /* ------------------------------------------------------------------ table construction */
 

@@ -31,6 +31,7 @@
 #include <Math/Complex.hh>
 #include <Signal/WindowBuffer.hh>
 #include <Core/BinaryStream.hh>
+#include <Core/Utility.hh>
 #include <Core/XmlStream.hh>
 #include <Flow/Vector.hh>
 #include <functional>
@@ -56,6 +57,15 @@ Math::UnaryAnalyticFunctionRef barkWarp() {
 }  // namespace
 
 extern "C" {
+
+// Core::isAlmostEqual / isSignificantlyGreater (Core/Utility.hh:322-345): they decide the FFT length, the filter-bank edge rounding
+// and which equal-loudness curve plp.flow gets
+int ref_is_almost_equal(double a, double b, double tolerance) {
+    return Core::isAlmostEqual(a, b, tolerance) ? 1 : 0;
+}
+int ref_is_significantly_greater(double a, double b, double tolerance) {
+    return Core::isSignificantlyGreater(a, b, tolerance) ? 1 : 0;
+}
 
 // bark warping, its derivative and inverse, alone and nested with disc-to-cont as FilterBuilder::create composes them
 double ref_bark(double f) {

@@ -167,6 +167,12 @@ def test_live_reference_build_agrees():
     for f in rng.uniform(0, 8000, 50):
         assert L.orc_mel(f) == R.ref_mel(f) and L.orc_mel_derivative(f) == R.ref_mel_derivative(f)
         assert L.orc_mel_inverse(L.orc_mel(f)) == R.ref_mel_inverse(R.ref_mel(f))
+    for _ in range(2000):   # Core::isAlmostEqual / isSignificantlyGreater incl. one-ulp neighbours, zero, the tolerance plp.flow uses
+        a = float(rng.choice([0.0, 1.0, 9.0, 4000.0, rng.uniform(-10, 10), rng.uniform(0, 1e6)]))
+        b = float(rng.choice([a, np.nextafter(a, np.inf), np.nextafter(a, -np.inf), a * (1 + 3e-16), a + rng.uniform(-1e-3, 1e-3), a + 2.0]))
+        tol = float(rng.choice([1.0, 2.0, 1e12]))
+        assert L.orc_core_is_almost_equal(a, b, tol) == R.ref_is_almost_equal(a, b, tol), (a, b, tol)
+        assert L.orc_core_is_significantly_greater(a, b, tol) == R.ref_is_significantly_greater(a, b, tol), (a, b, tol)
     for f in rng.uniform(0, 8000, 50):
         assert L.orc_bark(f) == R.ref_bark(f) and L.orc_bark_derivative(f) == R.ref_bark_derivative(f)
         assert L.orc_bark_inverse(L.orc_bark(f)) == R.ref_bark_inverse(R.ref_bark(f))
