@@ -73,15 +73,19 @@ struct GtParams {
 // and leaves its outputs in LDS, then every temporal-integration slot -- frame f lives in slot f % overlap, at most one frame per
 // slot at a time -- consumes the part of the chunk that belongs to its frame in a branch-free inner loop.  Frame openings and
 // completions are wave-uniform events handled between those loops.
+// The two halves of a chunk's work have nothing in common but the chunk itself, so they run as a producer / consumer pair of waves
+// (on different SIMDs of the CU): wave 0 filters chunk k into one of two LDS buffers while wave 1 integrates chunk k - 1 from the
+// other; one workgroup barrier per chunk.  The critical path per sample is the longer of the two instead of their sum.
 template<int CASCADE>
-__global__ __launch_bounds__(64) void gammatone_filter_kernel(GtParams p) {
+__global__ __launch_bounds__(128) void gammatone_filter_kernel(GtParams p) {
     extern __shared__ float s_mem[];
     float*                  s_win = s_mem;                                 // [ti_len]
-    float*                  s_o   = s_mem + ((p.ti_len + 63) & ~63);       // [64 samples][64 lanes]
-    const int               lane = threadIdx.x;
+    float*                  s_ob  = s_mem + ((p.ti_len + 63) & ~63);       // [2][64 samples][64 lanes]
+    const int               lane = threadIdx.x & 63;
+    const int               role = threadIdx.x >> 6;                       // 0: filter cascade, 1: temporal integration
     const int               ch   = blockIdx.y * 64 + lane;
     const bool              live = ch < p.channels;
-    for (int i = lane; i < p.ti_len; i += 64)
+    for (int i = threadIdx.x; i < p.ti_len; i += 128)
         s_win[i] = p.ti_win[i];
     __syncthreads();
     const long long s0 = p.sample_off[blockIdx.x], f0 = p.frame_off[blockIdx.x];
@@ -106,7 +110,11 @@ __global__ __launch_bounds__(64) void gammatone_filter_kernel(GtParams p) {
         nstart[r] = r * p.ti_shift;
     }
     const bool hann = p.ti_window != AMX_WINDOW_RECTANGULAR;
-    for (int nb = 0; nb < Ni; nb += 64) {
+    const int n_chunks = (Ni + 63) / 64;
+    for (int kc = 0; kc <= n_chunks; ++kc) {
+      if (role == 0 && kc < n_chunks) {
+        const int   nb    = kc * 64;
+        float*      s_o   = s_ob + (kc & 1) * 4096;
         const float chunk = nb + lane < Ni ? p.pcm[s0 + nb + lane] : 0.f;
         const int   cnt   = Ni - nb < 64 ? Ni - nb : 64;
         // ---- the cascade over the chunk
@@ -130,7 +138,12 @@ __global__ __launch_bounds__(64) void gammatone_filter_kernel(GtParams p) {
             if (p.filtered && live)
                 p.filtered[(s0 + nb + j) * p.channels + ch] = o;
         }
-        // ---- temporal integration of the chunk, slot by slot (a lane reads back only what it wrote: no barrier)
+      }
+      else if (role == 1 && kc > 0) {
+        const int    nb  = (kc - 1) * 64;
+        const float* s_o = s_ob + ((kc - 1) & 1) * 4096;
+        const int    cnt = Ni - nb < 64 ? Ni - nb : 64;
+        // ---- temporal integration of the previous chunk, slot by slot
 #pragma unroll
         for (int r = 0; r < kGtMaxOverlap; ++r) {
             if (r >= p.overlap)
@@ -189,6 +202,8 @@ __global__ __launch_bounds__(64) void gammatone_filter_kernel(GtParams p) {
                     break;
             }
         }
+      }
+      __syncthreads();  // chunk kc is complete in its buffer; the other buffer is free again
     }
 }
 
@@ -532,11 +547,11 @@ int amx_gammatone_run_batch_dev(amx_gammatone* h, int n_seg, const long* sample_
     {
         ScopedKernelTimer timer(h->ctx, "gammatone");
         const dim3   grid(n_seg, (h->channels + 63) / 64);
-        const size_t lds = (size_t)(((h->ti_len + 63) & ~63) + 64 * 64) * 4;
+        const size_t lds = (size_t)(((h->ti_len + 63) & ~63) + 2 * 64 * 64) * 4;
         if (p.cascade == 4)  // the node's default
-            hipLaunchKernelGGL((gammatone_filter_kernel<4>), grid, dim3(64), lds, h->ctx->stream, p);
+            hipLaunchKernelGGL((gammatone_filter_kernel<4>), grid, dim3(128), lds, h->ctx->stream, p);
         else
-            hipLaunchKernelGGL((gammatone_filter_kernel<0>), grid, dim3(64), lds, h->ctx->stream, p);
+            hipLaunchKernelGGL((gammatone_filter_kernel<0>), grid, dim3(128), lds, h->ctx->stream, p);
     }
     if (tail) {
         GtPostParams q;
