@@ -43,6 +43,8 @@ namespace amx {
 
 constexpr int kGtMaxCascade = 8;
 constexpr int kGtMaxOverlap = 8;     // frames that can contain one sample: ceil(length / shift)
+constexpr int kGtChunk      = 32;    // samples per producer / consumer hand-over (LDS: 2 x kGtChunk x 256 B per workgroup, which
+                                     // decides how many (segment, 64 channels) workgroups a CU holds: 9 at 32, 4 at 64)
 constexpr int kGtMaxWindow  = 4096;  // temporal-integration window kept in LDS (with the 16 KB chunk buffer: <= 32 KB per wave)
 
 // not inlined: only the short frames at the end of a segment come here, and the f64 cosine would bloat the sample loop 16 times over
@@ -69,7 +71,7 @@ struct GtParams {
 };
 
 // CASCADE: compile-time cascade depth (0 = run-time value, bounded by kGtMaxCascade).
-// A wave works through its segment in chunks of 64 samples: the filter cascade runs over the chunk (one dependent f32 chain per lane)
+// A wave works through its segment in chunks of kGtChunk samples: the filter cascade runs over the chunk (one dependent f32 chain per lane)
 // and leaves its outputs in LDS, then every temporal-integration slot -- frame f lives in slot f % overlap, at most one frame per
 // slot at a time -- consumes the part of the chunk that belongs to its frame in a branch-free inner loop.  Frame openings and
 // completions are wave-uniform events handled between those loops.
@@ -80,7 +82,7 @@ template<int CASCADE>
 __global__ __launch_bounds__(128) void gammatone_filter_kernel(GtParams p) {
     extern __shared__ float s_mem[];
     float*                  s_win = s_mem;                                 // [ti_len]
-    float*                  s_ob  = s_mem + ((p.ti_len + 63) & ~63);       // [2][64 samples][64 lanes]
+    float*                  s_ob  = s_mem + ((p.ti_len + 63) & ~63);       // [2][kGtChunk samples][64 lanes]
     const int               lane = threadIdx.x & 63;
     const int               role = threadIdx.x >> 6;                       // 0: filter cascade, 1: temporal integration
     const int               ch   = blockIdx.y * 64 + lane;
@@ -110,13 +112,14 @@ __global__ __launch_bounds__(128) void gammatone_filter_kernel(GtParams p) {
         nstart[r] = r * p.ti_shift;
     }
     const bool hann = p.ti_window != AMX_WINDOW_RECTANGULAR;
-    const int n_chunks = (Ni + 63) / 64;
+    constexpr int CH = kGtChunk;
+    const int n_chunks = (Ni + CH - 1) / CH;
     for (int kc = 0; kc <= n_chunks; ++kc) {
       if (role == 0 && kc < n_chunks) {
-        const int   nb    = kc * 64;
-        float*      s_o   = s_ob + (kc & 1) * 4096;
-        const float chunk = nb + lane < Ni ? p.pcm[s0 + nb + lane] : 0.f;
-        const int   cnt   = Ni - nb < 64 ? Ni - nb : 64;
+        const int   nb    = kc * CH;
+        float*      s_o   = s_ob + (kc & 1) * (CH * 64);
+        const float chunk = (lane < CH && nb + lane < Ni) ? p.pcm[s0 + nb + lane] : 0.f;
+        const int   cnt   = Ni - nb < CH ? Ni - nb : CH;
         // ---- the cascade over the chunk
         for (int j = 0; j < cnt; ++j) {
             float o = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(chunk), j));
@@ -140,9 +143,9 @@ __global__ __launch_bounds__(128) void gammatone_filter_kernel(GtParams p) {
         }
       }
       else if (role == 1 && kc > 0) {
-        const int    nb  = (kc - 1) * 64;
-        const float* s_o = s_ob + ((kc - 1) & 1) * 4096;
-        const int    cnt = Ni - nb < 64 ? Ni - nb : 64;
+        const int    nb  = (kc - 1) * CH;
+        const float* s_o = s_ob + ((kc - 1) & 1) * (CH * 64);
+        const int    cnt = Ni - nb < CH ? Ni - nb : CH;
         // ---- temporal integration of the previous chunk, slot by slot
 #pragma unroll
         for (int r = 0; r < kGtMaxOverlap; ++r) {
@@ -547,7 +550,7 @@ int amx_gammatone_run_batch_dev(amx_gammatone* h, int n_seg, const long* sample_
     {
         ScopedKernelTimer timer(h->ctx, "gammatone");
         const dim3   grid(n_seg, (h->channels + 63) / 64);
-        const size_t lds = (size_t)(((h->ti_len + 63) & ~63) + 2 * 64 * 64) * 4;
+        const size_t lds = (size_t)(((h->ti_len + 63) & ~63) + 2 * kGtChunk * 64) * 4;
         if (p.cascade == 4)  // the node's default
             hipLaunchKernelGGL((gammatone_filter_kernel<4>), grid, dim3(128), lds, h->ctx->stream, p);
         else
