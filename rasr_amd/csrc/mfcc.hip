@@ -586,6 +586,94 @@ __global__ __launch_bounds__(64) void lpc_cepstrum_kernel(const float* __restric
         o[n] = c[n * 64];
 }
 
+// The same recursions with every array in registers (loops unrolled to MAXA coefficients, steps beyond n_ac skipped by uniform
+// branches): the LDS version above holds one wave per SIMD -- 36 KB of LDS per wave at 20 coefficients -- and pays an LDS round trip
+// per array access; this one runs the O(n_ac^2) f64 work from VGPRs (mfplp.flow: 0.47 -> see DESIGN 4.1).  Identical operations in
+// identical order.
+template<int MAXA>
+__global__ __launch_bounds__(64) void lpc_cepstrum_reg_kernel(const float* __restrict__ ac, int n_ac, float* __restrict__ out, int n_out,
+                                                             long long n_frames) {
+    const long long t  = (long long)blockIdx.x * 64 + threadIdx.x;
+    const long long tt = t < n_frames ? t : n_frames - 1;
+    float           R[MAXA];
+    double          prev[MAXA], cur[MAXA];
+#pragma unroll
+    for (int i = 0; i < MAXA; ++i) {
+        R[i]    = i < n_ac ? ac[tt * n_ac + i] : 0.f;
+        prev[i] = 0.0;
+        cur[i]  = 0.0;
+    }
+    const int N = n_ac - 1;
+    auto almost_zero = [](double e) {  // Core::isAlmostEqual(e, 0.0)
+        return fabs(e) < (fabs(e) + 0.0 + 2.2250738585072014e-308) * 2.2204460492503131e-16 * 1.0;
+    };
+    bool   ok = true;
+    double E  = (double)R[0];
+    if (almost_zero(E))
+        ok = false;
+    if (ok) {
+        const double k1 = (double)(-R[1] / R[0]);
+        prev[1]         = k1;
+        E               = (double)R[0] + (double)R[1] * k1;
+    }
+#pragma unroll
+    for (int i = 2; i < MAXA; ++i) {
+        if (i <= N) {  // uniform
+            double k = (double)R[i];
+#pragma unroll
+            for (int j = 1; j <= i - 1; ++j)
+                k += prev[j] * (double)R[i - j];
+            if (ok && almost_zero(E))
+                ok = false;
+            if (ok) {
+                k      = -k / E;
+                cur[i] = k;
+#pragma unroll
+                for (int j = 1; j <= i - 1; ++j)
+                    cur[j] = prev[j] + k * prev[i - j];
+                E = (1.0 - k * k) * E;
+#pragma unroll
+                for (int j = 1; j <= i; ++j)
+                    prev[j] = cur[j];
+            }
+        }
+    }
+    if (t >= n_frames)
+        return;
+    float* o = out + t * n_out;
+    if (!ok) {
+        for (int n = 0; n < n_out; ++n)
+            o[n] = __builtin_nanf("");
+        return;
+    }
+    const float gain = (float)sqrt(E);
+    float       a[MAXA], c[MAXA];
+#pragma unroll
+    for (int j = 1; j < MAXA; ++j)
+        a[j - 1] = (float)prev[j];
+    a[MAXA - 1] = 0.f;
+    c[0] = (float)(2 * log((double)gain));
+    c[1] = -a[0];
+#pragma unroll
+    for (int n = 2; n < MAXA; ++n) {
+        c[n] = 0.f;
+        if (n < n_out) {
+            float v = (float)n * a[n - 1];
+#pragma unroll
+            for (int k = 1; k < n; ++k) {
+                float tt2 = (float)(n - k) * c[n - k];
+                tt2       = tt2 * a[k - 1];
+                v         = v + tt2;
+            }
+            c[n] = v / (-(float)n);
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < MAXA; ++n)
+        if (n < n_out)
+            o[n] = c[n];
+}
+
 template<int NC>
 int launch_mfcc(amx_mfcc* h, const amx::MfccParams& p, int n_tiles) {
     if (n_tiles <= 0)
@@ -917,10 +1005,18 @@ int amx_mfcc_run_plan_dev(amx_mfcc* h, const amx_mfcc_plan* p, const float* pcm_
     if (r != AMX_OK || !k.front_end || total_frames == 0)
         return r;
     amx::ScopedKernelTimer timer(h->ctx, "lpc_cepstrum");
-    const size_t lpc_lds = lpc_lds_bytes(t.n_transform);
-    hipFuncSetAttribute((const void*)lpc_cepstrum_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lpc_lds);
-    hipLaunchKernelGGL(lpc_cepstrum_kernel, dim3((unsigned)((total_frames + 63) / 64)), dim3(64), lpc_lds, h->ctx->stream, h->d_ac,
-                       t.n_transform, ceps_dev, t.n_ceps, total_frames);
+    const dim3 lgrid((unsigned)((total_frames + 63) / 64));
+    const bool in_regs = !(getenv("AMX_LPC_REGS") && atoi(getenv("AMX_LPC_REGS")) == 0);  // 0: the LDS kernel (A/B runs, tests)
+    if (in_regs && t.n_transform <= 16)
+        hipLaunchKernelGGL(lpc_cepstrum_reg_kernel<16>, lgrid, dim3(64), 0, h->ctx->stream, h->d_ac, t.n_transform, ceps_dev, t.n_ceps, total_frames);
+    else if (in_regs && t.n_transform <= 24)
+        hipLaunchKernelGGL(lpc_cepstrum_reg_kernel<24>, lgrid, dim3(64), 0, h->ctx->stream, h->d_ac, t.n_transform, ceps_dev, t.n_ceps, total_frames);
+    else {
+        const size_t lpc_lds = lpc_lds_bytes(t.n_transform);
+        hipFuncSetAttribute((const void*)lpc_cepstrum_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lpc_lds);
+        hipLaunchKernelGGL(lpc_cepstrum_kernel, lgrid, dim3(64), lpc_lds, h->ctx->stream, h->d_ac, t.n_transform, ceps_dev, t.n_ceps,
+                           total_frames);
+    }
     AMX_HIP(hipGetLastError());
     return AMX_OK;
 }

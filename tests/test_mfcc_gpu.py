@@ -251,3 +251,28 @@ def test_mfcc_with_other_filter_banks(ctx, kw, okw):
     got = rasr_amd.MfccExtractor(ctx, nr_cepstrum_coefficients=12, **kw).run(pcm)
     want = OracleMfcc(cfg).run(pcm)
     assert got.shape == want.shape and close(got, want), np.abs(got - want).max()
+
+
+def test_lpc_cepstrum_register_and_lds_kernels_agree(ctx, monkeypatch):
+    """the register-resident LPC / cepstrum kernel (<= 24 autocorrelation coefficients) and the LDS kernel run the same operations in
+    the same order: identical bits, NaN frames included; more than 24 coefficients take the LDS kernel and match the oracle"""
+    import rasr_amd
+    from oracle import OracleMfcc
+    from oracle.binding import MfccCfg
+    pcm = np.concatenate([synth.waveform(30000, seed=21), np.zeros(2000, np.float32), synth.waveform(9000, seed=22)])
+    for nac, nc in ((13, 13), (16, 12), (17, 17), (24, 20)):
+        monkeypatch.setenv("AMX_LPC_REGS", "1")
+        a = rasr_amd.MfccExtractor(ctx, nr_cepstrum_coefficients=nc, front_end="mfplp", nr_autocorrelation_coefficients=nac, normalize=True,
+                                   filter_width=138.0).run(pcm)
+        monkeypatch.setenv("AMX_LPC_REGS", "0")
+        b = rasr_amd.MfccExtractor(ctx, nr_cepstrum_coefficients=nc, front_end="mfplp", nr_autocorrelation_coefficients=nac, normalize=True,
+                                   filter_width=138.0).run(pcm)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and np.isnan(a).any()
+    monkeypatch.delenv("AMX_LPC_REGS")
+    got = rasr_amd.MfccExtractor(ctx, nr_cepstrum_coefficients=25, front_end="mfplp", nr_autocorrelation_coefficients=30, normalize=True,
+                                 filter_width=138.0).run(pcm)
+    cfg = MfccCfg.mfplp(n_ceps=25, n_autocorrelation=30, filter_width=138.0)
+    want = OracleMfcc(cfg).run(pcm)
+    nan = np.isnan(want)
+    assert np.array_equal(np.isnan(got), nan)
+    assert np.median(np.abs(got[~nan] - want[~nan]) / (np.abs(want[~nan]) + 1e-2)) < 1e-4      # order-29 recursions: ill-conditioned tail
