@@ -758,7 +758,7 @@ def is_graph_mode(args):
     # config 4 (batch 1024) and the config-3 CART scorer (batch 256) replay their pass as a HIP graph, which the per-launch events of the
     # library's profiler would switch off: that workload is timed without them and its kernel timings come from a separate profiled pass
     return (args.workload == "nn" and os.environ.get("AMX_FFNN_GRAPH", "1") != "0") or \
-           (args.workload == "gmm" and args.gmm_type == "diagonal-maximum" and args.gmm_frames <= 4096
+           (args.workload in ("gmm", "gmm-tied") and args.gmm_type == "diagonal-maximum" and args.gmm_frames <= 4096
             and os.environ.get("AMX_GMM_GRAPH", "1") != "0")
 
 

@@ -1457,6 +1457,7 @@ struct amx_gmm {
     unsigned long long  tied_triples = 0;        // (density, frame, tile) triples submitted since then
     int                 tied_dense_calls = 0;    // > 0: stay on gmm_tied_tile_kernel for that many calls, then probe again
     unsigned long long  tied_rep_seen = 0, tied_rep_triples = 0;  // amx_gmm_screen_counts: counter value / triples at the last report
+    int                 tied_forced = -1;        // set around a nested call: 1 = pruned path, 0 = dense kernel, -1 = decide
     double *  d_ln64 = nullptr, *d_dist64 = nullptr;
     float*    d_ln32 = nullptr;
     size_t    dist64_cap = 0;
@@ -2176,6 +2177,34 @@ static int ensure_simd(amx_gmm* h) {
 }
 }  // extern "C++"
 
+// dense or pruned for this call of a shared-list tied model: AMX_GMM_TIED_PRUNE=0 forces the dense kernel, =1 the pruned path,
+// default adaptive -- the pruned kernel counts the (density, frame, tile) triples it had to evaluate, the host reads the count of
+// EARLIER calls from pinned memory (no synchronisation) and stays on the dense kernel for 64 calls while more than 10 % stood
+static bool tied_decide_prune(amx_gmm* h) {
+    const char* pe     = getenv("AMX_GMM_TIED_PRUNE");
+    const int   forced = pe ? atoi(pe) : -1;
+    if (forced >= 0)
+        return forced != 0;
+    unsigned long long seen = 0;
+    for (int i = 0; i < 256; ++i)
+        seen += ((volatile unsigned long long*)h->h_tied_surv)[i];
+    if (h->tied_dense_calls > 0) {
+        --h->tied_dense_calls;
+        return false;
+    }
+    if (h->tied_triples >= (1ull << 20) && seen > h->tied_seen) {
+        // fraction of the triples submitted up to the copy that stood (the copy may lag by a call: conservative enough)
+        const double frac = (double)(seen - h->tied_seen) / (double)h->tied_triples;
+        h->tied_seen      = seen;
+        h->tied_triples   = 0;
+        if (frac > 0.10) {
+            h->tied_dense_calls = 64;
+            return false;
+        }
+    }
+    return true;
+}
+
 int amx_gmm_score_dev(amx_gmm* h, int mode, const float* feats_dev, int T, float* scores_dev, uint32_t* best_dev) {
     AMX_REQUIRE(h, AMX_ERR_INVALID, "amx_gmm_score_dev: NULL handle");
     AMX_REQUIRE(h->ctx, AMX_ERR_STATE, "amx_gmm_score_dev: host-only handle (created without a context)");
@@ -2320,11 +2349,72 @@ int amx_gmm_score_dev(amx_gmm* h, int mode, const float* feats_dev, int T, float
     }
     // ---- tied: chunk frames so the distance scratch stays <= 256 MB
     const int chunk_max = (int)std::max<size_t>(256, std::min<size_t>(16384, ((size_t)64 << 20) / (size_t)h->n_dens / 256 * 256));
+    // The pruned path of a shared-list model is five launches and a 2 KB copy: at the decoder's batch sizes their gaps are a seventh
+    // of the pass, so repeated passes on unchanged buffers are replayed as one HIP graph like the screened CART path above (the
+    // dense / pruned decision stays outside: a graph is only recorded and replayed for the pruned path).
+    if (h->uniform && mode == AMX_GMM_MAX && h->tied_forced < 0 && T <= chunk_max && T <= 4096 &&
+        !(getenv("AMX_GMM_SCREEN") && atoi(getenv("AMX_GMM_SCREEN")) == 0)) {
+        const bool prune = tied_decide_prune(h);
+        auto       nested = [&](int forced) {
+            h->tied_forced = forced;
+            const int r    = amx_gmm_score_dev(h, mode, feats_dev, T, scores_dev, best_dev);
+            h->tied_forced = -1;
+            return r;
+        };
+        if (!prune || !h->use_graphs || h->ctx->profiling)
+            return nested(prune ? 1 : 0);
+        const amx_gmm::GraphKey key{feats_dev, scores_dev, best_dev, h->ctx->stream, T};
+        auto                    it = h->graphs.find(key);
+        if (it == h->graphs.end()) {  // first pass with this signature: plain launches (they size the workspaces)
+            if (h->graphs.size() >= 64) {
+                for (auto& kv : h->graphs)
+                    if (kv.second)
+                        hipGraphExecDestroy(kv.second);
+                h->graphs.clear();
+                h->use_graphs = 0;
+            }
+            else
+                h->graphs[key] = nullptr;
+            return nested(1);
+        }
+        if (it->second == nullptr) {
+            hipGraph_t gr = nullptr;
+            if (hipStreamBeginCapture(h->ctx->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+                (void)hipGetLastError();
+                h->use_graphs = 0;
+                return nested(1);
+            }
+            const int      r  = nested(1);
+            const bool     ok = hipStreamEndCapture(h->ctx->stream, &gr) == hipSuccess && r == AMX_OK && gr != nullptr;
+            hipGraphExec_t ex = nullptr;
+            if (!ok || hipGraphInstantiate(&ex, gr, nullptr, nullptr, 0) != hipSuccess) {
+                (void)hipGetLastError();
+                if (gr)
+                    hipGraphDestroy(gr);
+                h->use_graphs = 0;
+                return nested(1);
+            }
+            hipGraphDestroy(gr);
+            h->graphs[key] = ex;  // (by key: a nested call that had to grow a scratch buffer empties the map)
+            it             = h->graphs.find(key);
+        }
+        else {  // replay: the statistics the nested call would have kept
+            const unsigned long long tr = (unsigned long long)h->K * (unsigned long long)T * (unsigned long long)(h->mix_pad / 64);
+            h->tied_triples += tr;
+            h->tied_rep_triples += tr;
+        }
+        AMX_HIP(hipGraphLaunch(it->second, h->ctx->stream));
+        return AMX_OK;
+    }
     for (int t0 = 0; t0 < T; t0 += chunk_max) {
         const int Tc   = std::min(chunk_max, T - t0);
         const int Tpad = (Tc + 63) & ~63;
         size_t    need = (size_t)h->n_dens * Tpad;
         if (need > h->dist_floats) {
+            for (auto& kv : h->graphs)  // recorded passes hold the old scratch addresses
+                if (kv.second)
+                    hipGraphExecDestroy(kv.second);
+            h->graphs.clear();
             hipFree(h->d_dist);
             h->d_dist      = nullptr;
             h->dist_floats = 0;
@@ -2374,33 +2464,15 @@ int amx_gmm_score_dev(amx_gmm* h, int mode, const float* feats_dev, int T, float
                        sc, bd, h->d_m2lw_t, h->d_k_dens, h->d_ln64, h->d_ln32, ud)
             if (mode == AMX_GMM_MAX && screen) {
                 // pruned exact path (gmm_tied.hip) unless the survivor statistics of earlier calls say that this model / these
-                // features leave too much standing (every table element would then be used once instead of 16 times from
-                // registers): AMX_GMM_TIED_PRUNE=0 forces the dense kernel, =1 the pruned one, default adaptive
-                const char* pe     = getenv("AMX_GMM_TIED_PRUNE");
-                const int   forced = pe ? atoi(pe) : -1;
-                bool        prune  = forced != 0;
-                if (forced < 0) {
-                    unsigned long long seen = 0;
-                    for (int i = 0; i < 256; ++i)
-                        seen += ((volatile unsigned long long*)h->h_tied_surv)[i];
-                    if (h->tied_dense_calls > 0) {
-                        --h->tied_dense_calls;
-                        prune = false;
-                    }
-                    else if (h->tied_triples >= (1ull << 20) && seen > h->tied_seen) {
-                        // fraction of the triples submitted up to the copy that stood (the copy may lag by a call: conservative enough)
-                        const double frac = (double)(seen - h->tied_seen) / (double)h->tied_triples;
-                        if (frac > 0.10) {
-                            h->tied_dense_calls = 64;
-                            prune               = false;
-                        }
-                        h->tied_seen    = seen;
-                        h->tied_triples = 0;
-                    }
-                }
+                // features leave too much standing (tied_decide_prune)
+                const bool prune = h->tied_forced >= 0 ? h->tied_forced == 1 : tied_decide_prune(h);
                 if (prune) {
                     const size_t need_ws = amx_internal_gmm_tied_workspace(h->K, Tc, h->mix_pad);
                     if (need_ws > h->tied_ws_cap) {
+                        for (auto& kv : h->graphs)
+                            if (kv.second)
+                                hipGraphExecDestroy(kv.second);
+                        h->graphs.clear();
                         hipFree(h->d_tied_ws);
                         h->d_tied_ws   = nullptr;
                         h->tied_ws_cap = 0;
