@@ -1451,10 +1451,10 @@ struct amx_gmm {
     unsigned short*     d_aup        = nullptr;  // [K][mix_pad] bf16 image of a^, rounded up (bounds only)
     void*               d_tied_ws    = nullptr;
     size_t              tied_ws_cap  = 0;
-    unsigned long long* d_tied_surv  = nullptr;  // [256] survivors (density, frame, tile) of the calls so far, spread over 256 counters
+    unsigned long long* d_tied_surv  = nullptr;  // [256] survivors (density, frame, tile) of the calls so far, spread over 256 counters; [256] = triples examined
     unsigned long long* h_tied_surv  = nullptr;  // pinned host copy, refreshed asynchronously after every pruned call
-    unsigned long long  tied_seen    = 0;        // value of *h_tied_surv at the previous decision
-    unsigned long long  tied_triples = 0;        // (density, frame, tile) triples submitted since then
+    unsigned long long  tied_seen    = 0;        // survivors / examined triples in the host copy at the previous decision
+    unsigned long long  tied_triples = 0;
     int                 tied_dense_calls = 0;    // > 0: stay on gmm_tied_tile_kernel for that many calls, then probe again
     unsigned long long  tied_rep_seen = 0, tied_rep_triples = 0;  // amx_gmm_screen_counts: counter value / triples at the last report
     int                 tied_forced = -1;        // set around a nested call: 1 = pruned path, 0 = dense kernel, -1 = decide
@@ -1948,13 +1948,13 @@ int amx_gmm_create(amx_ctx* ctx, const amx_gmm_model* m, amx_gmm** out) {
             amx_gmm_destroy(h);
             return r;
         }
-        if (hipMalloc((void**)&h->d_tied_surv, 256 * 8) != hipSuccess || hipMemset(h->d_tied_surv, 0, 256 * 8) != hipSuccess ||
-            hipHostMalloc((void**)&h->h_tied_surv, 256 * 8) != hipSuccess) {
+        if (hipMalloc((void**)&h->d_tied_surv, 257 * 8) != hipSuccess || hipMemset(h->d_tied_surv, 0, 257 * 8) != hipSuccess ||
+            hipHostMalloc((void**)&h->h_tied_surv, 257 * 8) != hipSuccess) {
             amx::set_error("amx_gmm_create: out of memory (tied-model statistics)");
             amx_gmm_destroy(h);
             return AMX_ERR_DEVICE;
         }
-        memset(h->h_tied_surv, 0, 256 * 8);
+        memset(h->h_tied_surv, 0, 257 * 8);
     }
     // ---- MFMA screen tables (gmm_screen_kernel): private densities, <= 16 per mixture, operand fits f16
     if (!h->tied && screen_dim_supported(m->dim) && !(getenv("AMX_GMM_SCREEN") && atoi(getenv("AMX_GMM_SCREEN")) == 0)) {
@@ -2185,18 +2185,20 @@ static bool tied_decide_prune(amx_gmm* h) {
     const int   forced = pe ? atoi(pe) : -1;
     if (forced >= 0)
         return forced != 0;
+    // one asynchronous copy delivers survivors and examined triples of the calls that have COMPLETED: a consistent pair, however far
+    // the host runs ahead
     unsigned long long seen = 0;
     for (int i = 0; i < 256; ++i)
         seen += ((volatile unsigned long long*)h->h_tied_surv)[i];
+    const unsigned long long examined = ((volatile unsigned long long*)h->h_tied_surv)[256];
     if (h->tied_dense_calls > 0) {
         --h->tied_dense_calls;
         return false;
     }
-    if (h->tied_triples >= (1ull << 20) && seen > h->tied_seen) {
-        // fraction of the triples submitted up to the copy that stood (the copy may lag by a call: conservative enough)
-        const double frac = (double)(seen - h->tied_seen) / (double)h->tied_triples;
+    if (examined - h->tied_triples >= (1ull << 20) && seen >= h->tied_seen) {
+        const double frac = (double)(seen - h->tied_seen) / (double)(examined - h->tied_triples);
         h->tied_seen      = seen;
-        h->tied_triples   = 0;
+        h->tied_triples   = examined;
         if (frac > 0.10) {
             h->tied_dense_calls = 64;
             return false;
@@ -2399,9 +2401,7 @@ int amx_gmm_score_dev(amx_gmm* h, int mode, const float* feats_dev, int T, float
             it             = h->graphs.find(key);
         }
         else {  // replay: the statistics the nested call would have kept
-            const unsigned long long tr = (unsigned long long)h->K * (unsigned long long)T * (unsigned long long)(h->mix_pad / 64);
-            h->tied_triples += tr;
-            h->tied_rep_triples += tr;
+            h->tied_rep_triples += (unsigned long long)h->K * (unsigned long long)T * (unsigned long long)(h->mix_pad / 64);
         }
         AMX_HIP(hipGraphLaunch(it->second, h->ctx->stream));
         return AMX_OK;
@@ -2483,8 +2483,7 @@ int amx_gmm_score_dev(amx_gmm* h, int mode, const float* feats_dev, int T, float
                                                         h->d_amax, h->d_m2lw_t, h->d_ln64, h->d_amin, h->d_tied_ws, sc, bd, h->d_tied_surv);
                     if (r != AMX_OK)
                         return r;
-                    AMX_HIP(hipMemcpyAsync(h->h_tied_surv, h->d_tied_surv, 256 * 8, hipMemcpyDeviceToHost, h->ctx->stream));
-                    h->tied_triples += (unsigned long long)h->K * (unsigned long long)Tc * (unsigned long long)(h->mix_pad / 64);
+                    AMX_HIP(hipMemcpyAsync(h->h_tied_surv, h->d_tied_surv, 257 * 8, hipMemcpyDeviceToHost, h->ctx->stream));
                     h->tied_rep_triples += (unsigned long long)h->K * (unsigned long long)Tc * (unsigned long long)(h->mix_pad / 64);
                 }
                 else

@@ -130,8 +130,13 @@ __global__ __launch_bounds__(kTiedBoundThreads) void tied_bound_kernel(const uns
 // distances.  lk / ld [T][Kpad], ln [T].
 __global__ __launch_bounds__(64) void tied_list_kernel(const float* __restrict__ g_dt, const float* __restrict__ g_amin_all,
                                                       const float* __restrict__ g_thr, int K, int Kpad, int n_tiles, uint32_t* __restrict__ g_lk,
-                                                      float* __restrict__ g_ld, int* __restrict__ g_ln) {
+                                                      float* __restrict__ g_ld, int* __restrict__ g_ln,
+                                                      unsigned long long* __restrict__ g_examined, unsigned long long examined) {
     const int t = blockIdx.x, lane = threadIdx.x;
+    // the denominator of the survivor statistic travels with the numerator (the host reads both from ONE asynchronous copy: counting
+    // the submitted triples on the host instead made the ratio wrong whenever the host ran ahead of the device)
+    if (g_examined && t == 0 && lane == 0)
+        atomicAdd(g_examined, examined);
     float     thr = -__builtin_inff();
     for (int j = lane; j < n_tiles; j += 64)
         thr = fmaxf(thr, g_thr[(size_t)t * n_tiles + j]);
@@ -358,7 +363,8 @@ extern "C" int amx_internal_gmm_tied_score(amx_ctx* ctx, const float* dist_dev, 
     hipLaunchKernelGGL(amx::tied_bound_kernel, dim3((mix_pad + amx::kTiedBoundThreads - 1) / amx::kTiedBoundThreads, T), dim3(amx::kTiedBoundThreads), 0, ctx->stream, aup, amax, w.dt, K, Kpad, n_mix,
                        mix_pad, n_tiles, w.thr);
     hipLaunchKernelGGL(amx::tied_list_kernel, dim3(T), dim3(64), 0, ctx->stream, w.dt, amin + (size_t)n_tiles * Kpad, w.thr, K, Kpad, n_tiles,
-                       w.lk, w.ld, w.ln);
+                       w.lk, w.ld, w.ln, survivors_dev ? survivors_dev + amx::kTiedCounters : nullptr,
+                       (unsigned long long)K * (unsigned long long)T * (unsigned long long)n_tiles);
     hipLaunchKernelGGL(amx::tied_pruned_kernel, dim3(8 * ((n_tiles + 7) / 8) * ((T + 3) / 4)), dim3(256), 0, ctx->stream, w.lk, w.ld, w.ln, amin, w.thr, m2lw_t,
                        ln64, Kpad, T, n_mix, mix_pad, n_tiles, scores, best, survivors_dev);
     AMX_HIP(hipGetLastError());

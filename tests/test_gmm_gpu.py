@@ -991,3 +991,30 @@ def test_preselection_batch_int_errors(ctx):
     sc.set_preselection(8, 16)
     with pytest.raises(rasr_amd.AmxError, match="select-clusters"):
         sc.score(feats(3, 40, 1), want_best=False)
+
+
+def test_tied_statistics_stay_consistent_when_the_host_runs_ahead(ctx):
+    """200 passes enqueued back to back without a synchronisation (graph replays from the third on): the survivor statistic the host reads
+    asynchronously must not mistake the device's lag for a high surviving fraction -- every pass takes the pruned path (regression: the
+    denominator used to be counted on the host at submission time, the numerator arrived late, and the ratio of a later window came out
+    20 times too high, which sent a perfectly prunable model to the dense kernel)"""
+    import torch
+
+    import rasr_amd
+    model = synth.gmm_tied(1000, 4096, 40, seed=88, pooled=True)      # prunable: ~2 % of the (density, frame, tile) triples survive
+    sc = rasr_amd.GmmFeatureScorer(ctx, model)
+    T, M = 256, 1000
+    x = torch.from_numpy(feats(T, 40, 89)).cuda()
+    scores = torch.empty((T, M), dtype=torch.float32, device="cuda")
+    best = torch.empty((T, M), dtype=torch.int32, device="cuda")
+    ctx.use_torch_stream()
+    sc.screen_counts(True)
+    for _ in range(200):
+        sc.score_dev(x, T, scores, best)
+    torch.cuda.synchronize()
+    surv, triples = sc.screen_counts(True)
+    assert triples == 200 * 4096 * T * 16, triples           # every pass was a pruned one
+    assert 0 < surv < 0.05 * triples, surv / triples
+    from oracle import OracleGmm
+    osc, ob = OracleGmm(model).score(x.cpu().numpy())
+    assert np.array_equal(scores.cpu().numpy().view(np.uint32), osc.view(np.uint32)) and np.array_equal(best.cpu().numpy().astype(np.uint32), ob)
