@@ -838,6 +838,46 @@ def secondary_configs(ctx, args, rank):
     return out
 
 
+def decoder_facing(ctx, args, rank):
+    """PCIe-inclusive rates of the NN scorer as a decoder sees them (never `value`): one buffer fill of 256 frames scored into a resident
+    [256 x 10000] block (AmxHost::BatchFeatureScorer::scoreResident), then (a) nothing fetched, (b) every frame's full 40 kB row copied
+    to the host (ContextScorer::score(e) on every frame), (c) 500 emissions per frame gathered (ContextScorer::scores(list))."""
+    import torch
+
+    import rasr_amd
+    from tests import synth
+    dims = [440] + [2048] * 6 + [10000]
+    Ws, bs, acts, logp = synth.ffnn(dims, seed=7)
+    nn = rasr_amd.NnBatchFeatureScorer(ctx, Ws, bs, acts, log_prior=logp, priori_scale=1.0, precision=args.precision)
+    T = 256
+    x = torch.from_numpy(np.random.Generator(np.random.PCG64(60 + rank)).standard_normal((T, 440)).astype(np.float32)).cuda()
+    scores = torch.empty((T, 10000), dtype=torch.float32, device="cuda")
+    host = torch.empty((T, 10000), dtype=torch.float32).pin_memory()
+    rng = np.random.Generator(np.random.PCG64(61))
+    rows = np.repeat(np.arange(T, dtype=np.uint32), 500)
+    cols = rng.integers(0, 10000, T * 500).astype(np.uint32)
+    out = {}
+    for name in ("resident", "full_rows", "active_set_500"):
+        def one():
+            nn.score_dev(x, 440, T, scores)
+            if name == "full_rows":
+                host.copy_(scores, non_blocking=True)
+            elif name == "active_set_500":
+                ctx.gather_scores(scores, 10000, rows, cols)
+        for _ in range(3):
+            one()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 20
+        for _ in range(n):
+            one()
+        torch.cuda.synchronize()
+        out[name + "_frames_per_s"] = round(T * n / (time.perf_counter() - t0), 1)
+    out["batch"] = T
+    out["note"] = "cfg-4 network, one 256-frame buffer fill per pass; full rows = 40 kB per frame over the host link"
+    return out
+
+
 def main():
     args = parse()
     import torch
@@ -881,6 +921,10 @@ def main():
             with torch.cuda.stream(stream):
                 ctx.use_torch_stream()
                 line["configs"] = secondary_configs(ctx, args, rank)
+                try:
+                    line["decoder_facing"] = decoder_facing(ctx, args, rank)
+                except Exception as e:  # never take the headline down
+                    line["decoder_facing"] = dict(error=str(e)[:200])
         print(json.dumps(line))
     if _dist_on():
         import torch.distributed as dist

@@ -65,6 +65,16 @@ class Context:
     def synchronize(self):
         _lib.check(self.L.amx_synchronize(self.h))
 
+    def gather_scores(self, scores_dev, ld, rows, cols):
+        """scores_dev[rows[i] * ld + cols[i]] for host index arrays -> host float32 array (device gather + one small copy: what a
+        decoder's ContextScorer::scores(list) costs against a resident score block)"""
+        rows = np.ascontiguousarray(rows, dtype=np.uint32)
+        cols = np.ascontiguousarray(cols, dtype=np.uint32)
+        out = np.empty(len(rows), np.float32)
+        _lib.check(self.L.amx_gather_scores(self.h, scores_dev.data_ptr(), int(ld), len(rows), rows.ctypes.data, cols.ctypes.data,
+                                            out.ctypes.data))
+        return out
+
     def profile(self, enable=True):
         _lib.check(self.L.amx_profile_enable(self.h, 1 if enable else 0))
 
