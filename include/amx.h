@@ -239,6 +239,14 @@ int amx_normalize_dev(amx_ctx* ctx, const amx_mfcc_plan* plan, const float* in_d
 #define AMX_NORM_MEAN_AND_VARIANCE_1D 4
 int amx_normalize_ex_dev(amx_ctx* ctx, const amx_mfcc_plan* plan, const float* in_dev, int in_ld, int dim, int type, int level,
                          int length, int right, float* out_dev, int out_ld);
+/* signal-vector-f32-{amplitude-spectrum-energy,energy,maximum,mean-energy,mean,variance}-normalization
+ * (src/Signal/VectorNormalization.hh:31-163, registered in src/Signal/Module.cc:108-113): every vector on its own -- divided by
+ * sqrt of its (Parseval / plain / mean) energy or by its maximum, or shifted to zero mean (and scaled to unit deviation).  A zero
+ * statistic gives inf / NaN like the reference's unguarded division.  [n_vectors x dim] views with row strides; in place is
+ * allowed on the identical view. */
+enum { AMX_VNORM_AMPLITUDE_SPECTRUM_ENERGY = 0, AMX_VNORM_ENERGY = 1, AMX_VNORM_MAXIMUM = 2, AMX_VNORM_MEAN_ENERGY = 3, AMX_VNORM_MEAN = 4,
+       AMX_VNORM_VARIANCE = 5 };
+int amx_vector_normalize_dev(amx_ctx* ctx, int type, const float* in_dev, int in_ld, long n_vectors, int dim, float* out_dev, int out_ld);
 /* signal-delay (max-size = 2*right+1, margin-policy copy, margin-condition present-not-empty; src/Signal/Delay.hh:33-47)
  * + signal-regression order 1 or 2 (src/Signal/Regression.cc:25-68), as wired in derivationWithRegression.flow. */
 int amx_regression_dev(amx_ctx* ctx, const amx_mfcc_plan* plan, const float* in_dev, int in_ld, int dim, int order,

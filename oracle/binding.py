@@ -229,6 +229,17 @@ def oracle_normalize_ex(x, type, level=0, length=0, right=0):
     return out
 
 
+def oracle_vector_normalize(x, kind):
+    """signal-vector-f32-<kind>-normalization of every row of x"""
+    L = Oracle()
+    x = np.ascontiguousarray(x, np.float32)
+    out = np.empty_like(x)
+    types = {"amplitude-spectrum-energy": 0, "energy": 1, "maximum": 2, "mean-energy": 3, "mean": 4, "variance": 5}
+    L.orc_vector_normalize.argtypes = [C.c_int, f32p, C.c_int, C.c_int, f32p]
+    L.orc_vector_normalize(types[kind], x.reshape(-1), x.shape[0], x.shape[1], out.reshape(-1))
+    return out
+
+
 def oracle_regression(x, order=1, right=2):
     L = Oracle()
     x = np.ascontiguousarray(x, np.float32)

@@ -219,3 +219,65 @@ void orc_matrix_multiply(const float* M, int rows, int cols, const float* in, in
             out[(size_t)t * rows + r] = acc;
         }
 }
+
+/* ------------------------------------------------------------------ signal-vector-f32-*-normalization
+ * Signal/VectorNormalization.hh:31-163, one vector at a time: std::inner_product / std::accumulate with a 0.0 (double) seed add
+ * the f32-rounded products / the f32 elements to a double in index order; the statistics are then narrowed to f32 (`Value`), and
+ * the elements are scaled with f32 operations.  Unqualified sqrt resolves to the double overload (see orc_gammatone.c); narrowing
+ * its result to f32 equals sqrtf.  types: 0 amplitude-spectrum-energy, 1 energy, 2 maximum, 3 mean-energy, 4 mean, 5 variance.
+ * Parity unpinned (the header includes Flow/Node.hh -> boost). */
+void orc_vector_normalize(int type, const float* in, int n, int dim, float* out) {
+    for (int t = 0; t < n; ++t) {
+        const float* v = in + (size_t)t * dim;
+        float*       o = out + (size_t)t * dim;
+        double       inner = 0.0, acc = 0.0;
+        for (int i = 0; i < dim; ++i) {
+            float p = v[i] * v[i];
+            inner   = inner + p;
+            acc     = acc + v[i];
+        }
+        if (type == 0) { /* amplitude spectrum: first and last bin once, the others twice (Parseval for a real signal) */
+            double mid = 0.0;
+            for (int i = 1; i < dim - 1; ++i) {
+                float p = v[i] * v[i];
+                mid     = mid + p;
+            }
+            float ff = v[0] * v[0], bb = v[dim - 1] * v[dim - 1];
+            float ends = ff + bb;
+            float sq = (float)sqrt((ends + 2 * mid) / (float)((size_t)(dim - 1) * 2));
+            float r  = (float)1 / sq;
+            for (int i = 0; i < dim; ++i)
+                o[i] = v[i] * r;
+        }
+        else if (type == 1 || type == 3) {
+            float sq = type == 1 ? (float)sqrt(inner) : (float)sqrt(inner / (double)(size_t)dim);
+            float r  = (float)1 / sq;
+            for (int i = 0; i < dim; ++i)
+                o[i] = v[i] * r;
+        }
+        else if (type == 2) {
+            float mx = v[0];
+            for (int i = 1; i < dim; ++i)
+                if (mx < v[i])
+                    mx = v[i]; /* std::max_element: first of the largest */
+            float r = (float)1 / mx;
+            for (int i = 0; i < dim; ++i)
+                o[i] = v[i] * r;
+        }
+        else if (type == 4) {
+            float mean = (float)(acc / (double)(size_t)dim);
+            for (int i = 0; i < dim; ++i)
+                o[i] = v[i] + -mean;
+        }
+        else {
+            float sum = (float)acc, sumSquare = (float)inner;
+            float mean = sum / (float)(size_t)dim;
+            float dev  = (float)sqrt((double)((sumSquare - sum * sum / (float)(size_t)dim) / (float)(size_t)dim));
+            float r    = (float)1 / dev;
+            for (int i = 0; i < dim; ++i) {
+                float c = v[i] + -mean;
+                o[i]    = c * r;
+            }
+        }
+    }
+}

@@ -99,6 +99,12 @@ class Context:
         """signal-normalization types 2 divide-by-mean, 3 level (component `level`), 4 mean-and-variance-1D"""
         _lib.check(self.L.amx_normalize_ex_dev(self.h, plan.h, _ptr(feats), in_ld, dim, type, level, length, right, _ptr(out), out_ld))
 
+    VECTOR_NORMALIZATIONS = {"amplitude-spectrum-energy": 0, "energy": 1, "maximum": 2, "mean-energy": 3, "mean": 4, "variance": 5}
+
+    def vector_normalize(self, kind, feats, in_ld, n, dim, out, out_ld):
+        """signal-vector-f32-<kind>-normalization on [n x dim] device views (in place on the identical view is allowed)"""
+        _lib.check(self.L.amx_vector_normalize_dev(self.h, self.VECTOR_NORMALIZATIONS[kind], _ptr(feats), in_ld, n, dim, _ptr(out), out_ld))
+
     def regression(self, plan, feats, in_ld, dim, out, out_ld, order=1, right=2):
         """signal-delay (copy margin) + signal-regression of the given order over 2 * right + 1 frames"""
         _lib.check(self.L.amx_regression_dev(self.h, plan.h, _ptr(feats), in_ld, dim, order, right, _ptr(out), out_ld))

@@ -229,6 +229,63 @@ __global__ __launch_bounds__(256) void matrix_multiply_kernel(const float* __res
 namespace {
 // Do the strided views in [T x in_w] (row stride in_ld) and out [T x out_w] (row stride out_ld) share memory?  Views into one wide
 // matrix (same stride) are disjoint when their column ranges are; anything else that overlaps in address range counts as aliasing.
+// signal-vector-f32-*-normalization (Signal/VectorNormalization.hh:31-163): one vector at a time, thread = vector.  The statistics
+// are std::inner_product / std::accumulate with a double seed -- f32-rounded products (or the elements) added to a double in
+// index order --, narrowed to f32; the elements are scaled with f32 operations.  A thread reads its whole row before it writes
+// the first element, so the identical view may be normalised in place.
+__global__ __launch_bounds__(256) void vector_normalize_kernel(const float* __restrict__ in, int in_ld, long long n, int dim, int type,
+                                                              float* __restrict__ out, int out_ld) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n)
+        return;
+    const float* v = in + t * in_ld;
+    float*       o = out + t * out_ld;
+    double       inner = 0.0, acc = 0.0, mid = 0.0;
+    float        mx = v[0];
+    for (int i = 0; i < dim; ++i) {
+        const float x = v[i], p = x * x;
+        inner         = inner + (double)p;
+        acc           = acc + (double)x;
+        if (i > 0 && i < dim - 1)
+            mid = mid + (double)p;
+        mx = (i > 0 && mx < x) ? x : mx;
+    }
+    float sub = 0.f, r = 1.f;
+    if (type == AMX_VNORM_AMPLITUDE_SPECTRUM_ENERGY) {
+        const float ff = v[0] * v[0], bb = v[dim - 1] * v[dim - 1];
+        const float ends = ff + bb;
+        r = (float)1 / (float)sqrt(((double)ends + 2 * mid) / (double)(float)((size_t)(dim - 1) * 2));
+    }
+    else if (type == AMX_VNORM_ENERGY)
+        r = (float)1 / (float)sqrt(inner);
+    else if (type == AMX_VNORM_MEAN_ENERGY)
+        r = (float)1 / (float)sqrt(inner / (double)(size_t)dim);
+    else if (type == AMX_VNORM_MAXIMUM)
+        r = (float)1 / mx;
+    else if (type == AMX_VNORM_MEAN)
+        sub = (float)(acc / (double)(size_t)dim);
+    else {  // variance
+        const float sum = (float)acc, sumSquare = (float)inner, fn = (float)(size_t)dim;
+        sub             = sum / fn;
+        const float q   = sum * sum;
+        const float e   = (sumSquare - q / fn) / fn;
+        r               = (float)1 / (float)sqrt((double)e);
+    }
+    if (type == AMX_VNORM_MEAN) {
+        for (int i = 0; i < dim; ++i)
+            o[i] = v[i] + -sub;
+    }
+    else if (type == AMX_VNORM_VARIANCE) {
+        for (int i = 0; i < dim; ++i) {
+            const float c = v[i] + -sub;
+            o[i]          = c * r;
+        }
+    }
+    else
+        for (int i = 0; i < dim; ++i)
+            o[i] = v[i] * r;
+}
+
 bool views_alias(const float* in, int in_ld, int in_w, const float* out, int out_ld, int out_w, long long T) {
     if (T <= 0)
         return false;
@@ -298,6 +355,26 @@ int amx_normalize_ex_dev(amx_ctx* ctx, const amx_mfcc_plan* plan, const float* i
     amx::ScopedKernelTimer timer(ctx, "normalize");
     hipLaunchKernelGGL(amx::normalize_misc_kernel, dim3(n_seg), dim3(64), 0, ctx->stream, in_dev, in_ld, d_off, dim, type, level, length, right,
                        out_dev, out_ld);
+    AMX_HIP(hipGetLastError());
+    return AMX_OK;
+}
+
+int amx_vector_normalize_dev(amx_ctx* ctx, int type, const float* in_dev, int in_ld, long n_vectors, int dim, float* out_dev, int out_ld) {
+    AMX_REQUIRE(ctx && (n_vectors == 0 || (in_dev && out_dev)), AMX_ERR_INVALID, "amx_vector_normalize_dev: NULL argument");
+    AMX_REQUIRE(type >= AMX_VNORM_AMPLITUDE_SPECTRUM_ENERGY && type <= AMX_VNORM_VARIANCE, AMX_ERR_INVALID,
+                "amx_vector_normalize_dev: unknown type %d", type);
+    AMX_REQUIRE(n_vectors >= 0 && dim > 0 && in_ld >= dim && out_ld >= dim, AMX_ERR_INVALID, "amx_vector_normalize_dev: bad shape / stride");
+    AMX_REQUIRE(type != AMX_VNORM_AMPLITUDE_SPECTRUM_ENERGY || dim >= 2, AMX_ERR_INVALID,
+                "amx_vector_normalize_dev: an amplitude spectrum has at least two bins");
+    if (n_vectors == 0)
+        return AMX_OK;
+    const bool same_view = in_dev == out_dev && in_ld == out_ld;
+    AMX_REQUIRE(same_view || !views_alias(in_dev, in_ld, dim, out_dev, out_ld, dim, n_vectors), AMX_ERR_INVALID,
+                "amx_vector_normalize_dev: input and output views overlap (in place is supported on the identical view only)");
+    AMX_HIP(hipSetDevice(ctx->device));
+    amx::ScopedKernelTimer timer(ctx, "normalize");
+    hipLaunchKernelGGL(vector_normalize_kernel, dim3((unsigned)((n_vectors + 255) / 256)), dim3(256), 0, ctx->stream, in_dev, in_ld,
+                       (long long)n_vectors, dim, type, out_dev, out_ld);
     AMX_HIP(hipGetLastError());
     return AMX_OK;
 }

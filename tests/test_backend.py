@@ -245,3 +245,56 @@ def test_other_normalisation_types_match_the_oracle(ctx):
         ctx.normalize_ex(plan, xd[:, 3:], ld, dim, out, dim, 3, level=dim)
     with pytest.raises(rasr_amd.AmxError, match="unknown type"):
         ctx.normalize_ex(plan, xd[:, 3:], ld, dim, out, dim, 9)
+
+
+# ------------------------------------------------------------------ signal-vector-f32-*-normalization (per-vector)
+VNORM = ["amplitude-spectrum-energy", "energy", "maximum", "mean-energy", "mean", "variance"]
+
+
+def test_oracle_vector_normalisations_against_definitions():
+    """oracle/orc_backend.c: orc_vector_normalize against the node names' definitions: unit (Parseval / plain / mean) energy, unit
+    maximum, zero mean, zero mean and unit deviation"""
+    from oracle.binding import oracle_vector_normalize
+    x = np.abs(seg(40, 257, 31)) + 0.1
+    x64 = x.astype(np.float64)
+    y = oracle_vector_normalize(x, "energy").astype(np.float64)
+    assert np.allclose((y * y).sum(1), 1, atol=1e-5)
+    y = oracle_vector_normalize(x, "mean-energy").astype(np.float64)
+    assert np.allclose((y * y).mean(1), 1, atol=1e-5)
+    y = oracle_vector_normalize(x, "amplitude-spectrum-energy").astype(np.float64)
+    e = (y[:, 0] ** 2 + y[:, -1] ** 2 + 2 * (y[:, 1:-1] ** 2).sum(1)) / (2 * 256)
+    assert np.allclose(e, 1, atol=1e-5)
+    assert np.allclose(oracle_vector_normalize(x, "maximum").max(1), 1, atol=1e-6)
+    assert np.allclose(oracle_vector_normalize(x, "mean"), x64 - x64.mean(1, keepdims=True), atol=1e-5)
+    y = oracle_vector_normalize(x, "variance").astype(np.float64)
+    assert np.allclose(y.mean(1), 0, atol=1e-5) and np.allclose(y.std(1), 1, atol=1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", VNORM)
+def test_vector_normalisations_match_the_oracle(ctx, kind):
+    """the kernel follows the same operation order (f32 products added to a double in index order, f32 scaling): bit-identical, with
+    row strides, in place on the identical view, a zero vector (division by zero like the reference: inf / NaN) and dim 2"""
+    import torch
+
+    import rasr_amd
+    from oracle.binding import oracle_vector_normalize
+    ctx.use_torch_stream()
+    for n, dim in ((1, 2), (300, 40), (77, 257), (1000, 13)):
+        x = seg(n, dim, 40 + dim)
+        if n > 5:
+            x[3] = 0.0
+        want = oracle_vector_normalize(x, kind)
+        wide = torch.zeros((n, dim + 5), dtype=torch.float32, device="cuda")
+        wide[:, 2:2 + dim] = torch.from_numpy(x).cuda()
+        out = torch.full((n, dim + 3), 9.0, dtype=torch.float32, device="cuda")
+        ctx.vector_normalize(kind, wide[:, 2:], dim + 5, n, dim, out[:, 1:], dim + 3)
+        torch.cuda.synchronize()
+        got = out[:, 1:1 + dim].cpu().numpy()
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (kind, n, dim)
+        assert (out[:, 0] == 9.0).all() and (out[:, dim + 1:] == 9.0).all()
+        ctx.vector_normalize(kind, wide[:, 2:], dim + 5, n, dim, wide[:, 2:], dim + 5)        # in place
+        torch.cuda.synchronize()
+        assert np.array_equal(wide[:, 2:2 + dim].cpu().numpy().view(np.uint32), want.view(np.uint32))
+    with pytest.raises(rasr_amd.AmxError, match="overlap"):
+        ctx.vector_normalize(kind, wide[:, 2:], dim + 5, n, dim, wide[:, 3:], dim + 5)
