@@ -191,6 +191,9 @@ def load_ref():
     R.ref_gauss_log_norm_factor.argtypes = [f32p, C.c_int]
     R.ref_inverse_square_root.restype = C.c_float
     R.ref_inverse_square_root.argtypes = [C.c_float]
+    R.ref_time_window_frames.restype = C.c_long
+    R.ref_time_window_frames.argtypes = [C.c_long, C.c_long, C.c_int, C.c_uint, C.c_uint, C.c_int, C.c_double, C.c_long,
+                                         C.c_void_p, C.c_void_p, C.c_void_p]
     R.ref_window_frames.restype = C.c_long
     R.ref_window_frames.argtypes = [f32p, C.c_long, C.c_long, C.c_uint, C.c_uint, C.c_double, C.c_long,
                                     C.c_void_p, C.c_void_p, C.c_void_p]
@@ -621,6 +624,17 @@ class GammatoneCfg(C.Structure):
         for k, v in kw.items():
             setattr(c, k, v)
         return c
+
+
+def oracle_time_window_frames(n, length, shift):
+    """(starts, lens) of the frames signal-temporalintegration cuts out of n samples (orc_time_window_frames)"""
+    L = Oracle()
+    L.orc_time_window_frames.restype = C.c_long
+    L.orc_time_window_frames.argtypes = [C.c_long, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_long]
+    T = L.orc_time_window_frames(n, length, shift, None, None, 0)
+    starts, lens = np.zeros(T, np.int64), np.zeros(T, np.int32)
+    L.orc_time_window_frames(n, length, shift, starts.ctypes.data, lens.ctypes.data, T)
+    return starts, lens
 
 
 class OracleGammatone:

@@ -202,14 +202,31 @@ int          orc_gammatone_si_channels(const orc_gammatone* h) { return h->si_ch
 const float* orc_gammatone_center_frequencies(const orc_gammatone* h) { return h->cf; }
 const float* orc_gammatone_coefficients(const orc_gammatone* h) { return h->coef; }
 
-/* TimeWindowBuffer::get / flush (Signal/TimeWindowBuffer.cc:83-125), flush-all = false: the rule of WindowBuffer */
-long orc_gammatone_n_frames(const orc_gammatone* h, long n) {
-    if (n <= 0)
+/* TimeWindowBuffer::get / flush (Signal/TimeWindowBuffer.cc:83-125) driven by SlidingAlgorithmNode::work, flush-all = false:
+ * get() delivers `length` samples and drops `shift` while the buffer holds >= 2 max(length, shift); at end of stream flush()
+ * delivers min(length, rest) and stops once rest <= max(length, shift).  Frame f starts at f * shift.
+ * PINNED on the reference class compiled unmodified (oracle/ref: ref_time_window_frames; tests/golden/ref_time_framing.json). */
+long orc_time_window_frames(long n, int length, int shift, long* starts, int* lens, long cap) {
+    if (n <= 0 || length <= 0 || shift <= 0)
         return 0;
-    long L = h->ti_len > h->ti_shift ? h->ti_len : h->ti_shift;
-    if (n <= L)
-        return 1;
-    return (n - L + h->ti_shift - 1) / h->ti_shift + 1;
+    long L = length > shift ? length : shift, T = 0;
+    for (long start = 0;; start += shift) {
+        long rest = n - start;
+        if (T < cap) {
+            if (starts)
+                starts[T] = start;
+            if (lens)
+                lens[T] = rest < length ? (int)rest : length;
+        }
+        ++T;
+        if (rest <= L)
+            break;
+    }
+    return T;
+}
+
+long orc_gammatone_n_frames(const orc_gammatone* h, long n) {
+    return orc_time_window_frames(n, h->ti_len, h->ti_shift, 0, 0, 0);
 }
 
 /* filtered [n_samples x channels] (nullable), out [n_frames x n_out]; returns the number of frames */

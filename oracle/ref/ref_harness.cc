@@ -7,6 +7,8 @@
 // Everything called here is reference code compiled from where it lies:
 //   Math::FastFourierTransform            src/Math/FastFourierTransform.cc
 //   Signal::WindowBuffer (put/get/flush)  src/Signal/WindowBuffer.cc (+ Flow/Core closure, see Makefile)
+//   Signal::TimeWindowBuffer<Flow::Vector<f32>> (put/get/flush)  src/Signal/TimeWindowBuffer.cc -- the framing under
+//       signal-temporalintegration (Signal/TemporalIntegration.hh:33)
 //   Math::{ScalingFunction,MelWarpingCore,AnalyticNesting}  header-only, composed exactly like
 //       Math::AnalyticFunctionFactory::createMelWarpingFunction (AnalyticFunctionFactory.cc:338-341)
 //   Math::{Sinh,ArcSinh,DerivedArcSinh} (SimpleAnalyticFunctions.hh:152-222) composed like createBarkWarpingFunction
@@ -29,6 +31,7 @@
 #include <Math/Matrix.hh>
 #include <Math/Vector.hh>
 #include <Math/Complex.hh>
+#include <Signal/TimeWindowBuffer.hh>
 #include <Signal/WindowBuffer.hh>
 #include <Core/BinaryStream.hh>
 #include <Core/Utility.hh>
@@ -217,6 +220,57 @@ long ref_window_frames(const float* pcm, long n, long block, unsigned length, un
             eos = true;
         }
         // end of stream: flush
+        if (wb.flushed() || !wb.flush(out))
+            break;
+        emit();
+    }
+    return nf;
+}
+
+// The same driver loop over Signal::TimeWindowBuffer<Flow::Vector<f32>> -- the base class of Signal::TemporalIntegration
+// (Signal/TemporalIntegration.hh:33; its init() sets length = rint(length-in-s * rate), shift likewise) -- with the identity
+// transform.  Sample i of the input carries the value i in every channel, so first_sample[f] is the start index of frame f.
+long ref_time_window_frames(long n, long block, int channels, unsigned length, unsigned shift, int flush_all, double sampleRate,
+                            long max_frames, int* frame_len, double* frame_start_time, long* first_sample) {
+    typedef Flow::Vector<f32> Sample;
+    Signal::TimeWindowBuffer<Sample> wb;
+    wb.setLength(length);
+    wb.setShift(shift);
+    wb.setSampleRate(sampleRate);
+    wb.setFlushAll(flush_all != 0);
+    long                 nf = 0, pos = 0;
+    Flow::Vector<Sample> out;
+    auto                 emit = [&]() {
+        if (nf < max_frames) {
+            if (frame_len)
+                frame_len[nf] = (int)out.size();
+            if (frame_start_time)
+                frame_start_time[nf] = out.startTime();
+            if (first_sample)
+                first_sample[nf] = out.empty() ? -1 : (long)out[0][0];
+        }
+        ++nf;
+    };
+    bool eos = false;
+    while (true) {
+        if (wb.get(out)) {
+            emit();
+            continue;
+        }
+        if (!eos) {
+            if (pos < n) {
+                long                 cnt = std::min(block, n - pos);
+                Flow::Vector<Sample> in;
+                for (long i = 0; i < cnt; ++i)
+                    in.push_back(Sample(channels, (f32)(pos + i)));
+                in.setStartTime(pos / sampleRate);
+                in.setEndTime((pos + cnt) / sampleRate);
+                wb.put(in);
+                pos += cnt;
+                continue;
+            }
+            eos = true;
+        }
         if (wb.flushed() || !wb.flush(out))
             break;
         emit();

@@ -64,10 +64,38 @@ def bark_golden(R):
     np.savez_compressed(os.path.join(HERE, "orc_plp.npz"), **gold)
 
 
+def time_framing_golden(R):
+    """ref_time_framing.json: frames of Signal::TimeWindowBuffer<Flow::Vector<f32>> (the base of signal-temporalintegration) driven
+    like SlidingAlgorithmNode::work: every frame's first sample index and length (full lists as run-length-free arrays for small n,
+    the count and the last three frames for long inputs)"""
+    rows = []
+    for length, shift, fs in ((400, 160, 16000.0), (200, 80, 8000.0), (160, 160, 16000.0), (100, 160, 16000.0), (7, 3, 100.0)):
+        for n in (1, 2, shift - 1, shift, shift + 1, length - 1, length, length + 1, length + shift, length + shift + 1,
+                  2 * length - 1, 2 * length, 2 * length + 1, 2 * length + shift, 1000, 4096, 4097, 12345, 48077, 160000):
+            if n <= 0:
+                continue
+            for block in (4096, 1000, 1):
+                if block == 1 and n > 5000:
+                    continue
+                cap = n // shift + 8
+                fl, st, first = np.zeros(cap, np.int32), np.zeros(cap, np.float64), np.zeros(cap, np.int64)
+                nf = R.ref_time_window_frames(n, block, 3, length, shift, 0, fs, cap, fl.ctypes.data, st.ctypes.data, first.ctypes.data)
+                keep = slice(0, nf) if nf <= 12 else slice(nf - 3, nf)
+                rows.append(dict(length=length, shift=shift, fs=fs, n=n, block=block, n_frames=int(nf),
+                                 first=[int(v) for v in first[keep]], lens=[int(v) for v in fl[keep]],
+                                 starts_are_multiples_of_shift=bool(np.all(first[:nf] == np.arange(nf) * shift)),
+                                 inner_lens_full=bool(np.all(fl[:max(nf - 3, 0)] == length)),
+                                 last_start_time=float(st[nf - 1]).hex()))
+    json.dump(rows, open(os.path.join(HERE, "ref_time_framing.json"), "w"), indent=0)
+
+
 def main():
     R = load_ref()
     if sys.argv[1:] == ["bark"]:
         bark_golden(R)
+        return
+    if sys.argv[1:] == ["time-framing"]:
+        time_framing_golden(R)
         return
     if R is None:
         raise SystemExit("oracle/_ref/libref.so not available (needs /root/reference)")

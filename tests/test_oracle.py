@@ -54,6 +54,22 @@ def test_framing_against_reference_window_buffer():
         assert r["lens_ok"]
 
 
+def test_temporal_integration_framing_against_reference_time_window_buffer():
+    """oracle/orc_gammatone.c: orc_time_window_frames against Signal::TimeWindowBuffer<Flow::Vector<f32>> compiled unmodified
+    (tests/golden/ref_time_framing.json, made by make_golden.py time-framing): frame count, every start, every length"""
+    from oracle.binding import oracle_time_window_frames
+    rows = json.load(open(os.path.join(GOLD, "ref_time_framing.json")))
+    assert len(rows) > 200
+    for r in rows:
+        starts, lens = oracle_time_window_frames(r["n"], r["length"], r["shift"])
+        assert len(starts) == r["n_frames"], r
+        assert r["starts_are_multiples_of_shift"] and np.array_equal(starts, np.arange(len(starts)) * r["shift"])
+        k = len(r["first"])
+        assert list(starts[-k:]) == r["first"] and list(lens[-k:]) == r["lens"], r
+        assert r["inner_lens_full"] and np.all(lens[:max(len(lens) - 3, 0)] == r["length"])
+        assert float.fromhex(r["last_start_time"]) == pytest.approx(starts[-1] / r["fs"], rel=1e-9, abs=1e-9)   # the class accumulates shift / rate
+
+
 def test_mel_functions_against_reference_functors():
     L = Oracle()
     g = json.load(open(os.path.join(GOLD, "ref_functions.json")))
@@ -164,6 +180,15 @@ def test_live_reference_build_agrees():
         nf = R.ref_window_frames(np.zeros(n, np.float32), n, 4096, 400, 160, 16000.0, 1000, fl.ctypes.data, None, None)
         assert nf == m.n_frames(n)
         assert fl[nf - 1] == min(400, n - (nf - 1) * 160)
+    from oracle.binding import oracle_time_window_frames
+    for _ in range(60):   # Signal::TimeWindowBuffer (temporal integration) on fresh lengths / shifts / block sizes
+        length, shift = int(rng.integers(1, 500)), int(rng.integers(1, 300))
+        n, block = int(rng.integers(1, 20000)), int(rng.integers(1, 5000))
+        cap = n // shift + 8
+        fl, first = np.zeros(cap, np.int32), np.zeros(cap, np.int64)
+        nf = R.ref_time_window_frames(n, block, 2, length, shift, 0, 16000.0, cap, fl.ctypes.data, None, first.ctypes.data)
+        starts, lens = oracle_time_window_frames(n, length, shift)
+        assert nf == len(starts) and np.array_equal(first[:nf], starts) and np.array_equal(fl[:nf], lens), (n, length, shift, block)
     for f in rng.uniform(0, 8000, 50):
         assert L.orc_mel(f) == R.ref_mel(f) and L.orc_mel_derivative(f) == R.ref_mel_derivative(f)
         assert L.orc_mel_inverse(L.orc_mel(f)) == R.ref_mel_inverse(R.ref_mel(f))
