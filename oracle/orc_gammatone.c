@@ -5,7 +5,8 @@
  *   signal-temporalintegration  Signal/TemporalIntegration.cc:60-84 on Signal/TimeWindowBuffer.cc:52-125 (the framing / flush rule
  *                                                            of WindowBuffer: short last frames, the window is re-made for them)
  *   signal-spectralintegration  Signal/SpectralIntegration.cc:55-74
- *   generic-vector-f32-power    Flow/SimpleFunction.hh:143-153 (powf), signal-cosine-transform Signal/CosineTransform.cc:62-83
+ *   generic-vector-f32-power    Flow/SimpleFunction.hh:143-153 (unqualified pow on floats = ::pow(double, double), narrowed),
+ *   signal-cosine-transform     Signal/CosineTransform.cc:62-83
  *   Hanning / rectangular       Signal/WindowFunction.cc:66-72,103-120
  *
  * PARITY UNPINNED: GammaTone.cc, TemporalIntegration.cc and SpectralIntegration.cc all include Flow node headers
@@ -287,7 +288,7 @@ long orc_gammatone_run(const orc_gammatone* h, const float* pcm, long n_samples,
             memcpy(si, ti, (size_t)C * 4);
         if (h->cfg.power != 0)
             for (int ch = 0; ch < h->si_channels; ++ch)
-                si[ch] = powf(si[ch], (float)h->cfg.power);
+                si[ch] = (float)pow((double)si[ch], (double)(float)h->cfg.power);   /* ::pow(double, double), see the header */
         float* o = out + t * h->n_out;
         if (h->cfg.n_ceps > 0) {
             for (int k = 0; k < h->cfg.n_ceps; ++k) {

@@ -579,10 +579,12 @@ static void orc_frame(const orc_mfcc* h, const float* pre, long n_samples, long 
         amp[k] = hypotf(buf[2 * k], buf[2 * k + 1]);
     if (amplitude)
         memcpy(amplitude, amp, (size_t)h->n_bins * sizeof(float));
-    /* mfplp.flow: generic-vector-f32-power value 2 (Flow/SimpleFunction.hh:143-153: powf) */
+    /* mfplp.flow: generic-vector-f32-power value 2.  Flow::VectorPowerFunction<f32> (Flow/SimpleFunction.hh:143-153) calls the
+     * UNQUALIFIED pow(v[i], parameter) on two floats; with the headers that file sees (<cmath>, no using-directive) that is ::pow(double,
+     * double), narrowed to f32 on assignment -- checked with g++ against the reference's own headers (sizeof(pow(1.0f, 2.0f)) == 8) */
     if (h->cfg.front_end != 0)
         for (int k = 0; k < h->n_bins; ++k)
-            amp[k] = powf(amp[k], 2.0f);
+            amp[k] = (float)pow((double)amp[k], (double)2.0f);
     /* FilterBank::Filter::apply (Signal/Filterbank.cc:65-71): f32 accumulate, ascending bin */
     float fb[h->n_filters];
     for (int f = 0; f < h->n_filters; ++f) {
@@ -616,7 +618,7 @@ static void orc_frame(const orc_mfcc* h, const float* pre, long n_samples, long 
          * autoregression, cepstrum; a frame whose recursion fails is reported as an error by the reference: NaN here */
         const float pw = (float)h->cfg.plp_power;
         for (int f = 0; f < n_in; ++f)
-            ext[f] = powf(ext[f], pw);
+            ext[f] = (float)pow((double)ext[f], (double)pw);   /* the same node: double pow of the f32 parameter, narrowed */
         if (logmel)
             memcpy(logmel, ext, (size_t)n_in * sizeof(float));
         if (ceps) {

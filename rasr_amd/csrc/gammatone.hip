@@ -238,7 +238,7 @@ __global__ __launch_bounds__(128) void gammatone_post_kernel(GtPostParams p) {
         else
             v = in[ch];
         if (p.power != 0.f)
-            v = __powf(v, p.power);
+            v = (float)pow((double)v, (double)p.power);  // generic-vector-f32-power: unqualified pow on floats = ::pow(double, double), narrowed
         s_si[ch] = v;
         if (p.n_ceps == 0)
             p.out[t * p.n_out + ch] = v;

@@ -120,6 +120,13 @@ struct MfccLds {
     }
 };
 
+// generic-vector-f32-power (Flow/SimpleFunction.hh:143-153): the node calls the unqualified pow on two floats, which is
+// ::pow(double, double) with the headers that file sees, and narrows the result.  Out of line: inlined, the f64 routine's
+// registers spill the MFCC path of the same kernel.
+__device__ __noinline__ float power_node(float v, float power) {
+    return (float)pow((double)v, (double)power);
+}
+
 template<int NC>
 __global__ __launch_bounds__(mfcc_waves(NC) * 64, (NC >= 1024 ? 1 : 4)) void mfcc_kernel(MfccParams p) {
     using P = FftPlan<NC>;
@@ -386,7 +393,7 @@ __global__ __launch_bounds__(mfcc_waves(NC) * 64, (NC >= 1024 ? 1 : 4)) void mfc
         const float* w   = s_fw + s_fo[flt] - b0;
         const float* amp = s_amp + f * L.amp_ld;
         float        acc = 0.f;
-        if (p.front_end) {  // mfplp.flow: generic-vector-f32-power 2 in front of the filter bank (powf(x, 2) = x * x rounded once)
+        if (p.front_end) {  // mfplp.flow: generic-vector-f32-power 2 in front of the filter bank ((f32)pow((f64)x, 2.0) = x * x rounded once)
             for (int b = b0; b < b1; ++b) {
                 const float a    = amp[b];
                 const float pw   = a * a;
@@ -403,7 +410,7 @@ __global__ __launch_bounds__(mfcc_waves(NC) * 64, (NC >= 1024 ? 1 : 4)) void mfc
         if (p.eql)  // plp.flow: in[i] = (f32)((f64)in[i] * f(i)) (Signal/VectorTransform.cc:78-83)
             acc = (float)((double)acc * p.eql[flt]);
         if (f < tile.n_frames)
-            s_lm[f * L.lm_ld + flt] = p.front_end ? __powf(acc, p.plp_power)  // intensity-loudness law
+            s_lm[f * L.lm_ld + flt] = p.front_end ? power_node(acc, p.plp_power)  // intensity-loudness law
                                                   : __log10f(acc);           // v_log_f32 * log10(2): ~1 ulp of log2
     }
     __syncthreads();

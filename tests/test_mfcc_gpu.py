@@ -140,10 +140,11 @@ def test_full_size_properties(ctx):
         assert close(seg, want), (u, np.abs(seg - want).max())
 
 
-# MF-PLP (mfplp.flow): the chain adds powf(., 0.33), an autocorrelation transform, the Levinson recursion (f64) and the LPC cepstrum
-# recursion (f32) behind the filter bank.  The device's v_exp/v_log based __powf differs from glibc's powf by a few ulp and the
-# recursions amplify that by the conditioning of the autocorrelation matrix (order 12-19: ~1e2), hence the wider band.
-PLP_RTOL, PLP_ATOL = 2e-3, 2e-3
+# MF-PLP (mfplp.flow): the chain adds the power node (^0.33), an autocorrelation transform, the Levinson recursion (f64) and the LPC
+# cepstrum recursion (f32) behind the filter bank.  The power node is the reference's ::pow(double, double) narrowed to f32 on both sides
+# (round 2; the earlier v_exp / v_log based __powf was ~10 ulp off and the recursions amplified that to 2e-3), so what is left is the
+# FFT's rounding carried through the recursions: the MFCC band holds (fuzz campaign: worst 1.1e-5 relative).
+PLP_RTOL, PLP_ATOL = 1e-4, 1e-4
 
 
 @pytest.mark.parametrize("nc,nac", [(13, 13), (9, 20), (2, 2)])
@@ -193,7 +194,7 @@ def test_mfplp_ragged_batch_silence_and_device_plan(ctx):
 
 
 # PLP (plp.flow): bark / trapeze / include-boundary filter bank, duplicated first / last output, equal-loudness weighting, then the
-# MF-PLP tail; same tolerance band as MF-PLP for the same reason (device __powf, conditioning of the recursions)
+# MF-PLP tail; same tolerance band as MF-PLP
 @pytest.mark.parametrize("fs,spacing,nc,nac", [(16000.0, 0.93853, 13, 13), (16000.0, 0.93853, 9, 20), (8000.0, 0.973442, 11, 11)])
 def test_plp_ten_seconds(ctx, fs, spacing, nc, nac):
     import rasr_amd
