@@ -267,8 +267,9 @@ typedef struct {
     const uint32_t* dens_cov;    /* [n_dens]  Mm::GaussDensity::covarianceIndex */
     const float*    means;       /* [n_mean x dim] */
     const float*    variances;   /* [n_cov  x dim] diagonal variances */
-    float           mixture_weight_scale; /* mixture-weight-scale, default 1 */
-    float           gaussian_scale;       /* gaussian-scale, default 1 */
+    double          mixture_weight_scale; /* mixture-weight-scale (Core::ParameterFloat = f64; the scorer keeps it as f32), default 1 */
+    double          gaussian_scale;       /* gaussian-scale (f64; the scorer keeps (f32)sqrt of the f64 value,
+                                           * Mm/GaussDiagonalMaximumFeatureScorer.cc:52), default 1 */
 } amx_gmm_model;
 
 /* diagonal-maximum / diagonal-sum / batch-diagonal-maximum-float (Mm/BatchFeatureScorer.cc:164-254: pooled

@@ -46,7 +46,7 @@ class _GmmModel(C.Structure):
     _fields_ = [("dim", C.c_int), ("n_mix", C.c_int), ("n_dens", C.c_int), ("n_mean", C.c_int), ("n_cov", C.c_int),
                 ("mix_offsets", C.c_void_p), ("dens_index", C.c_void_p), ("log_weight", C.c_void_p),
                 ("dens_mean", C.c_void_p), ("dens_cov", C.c_void_p), ("means", C.c_void_p),
-                ("variances", C.c_void_p), ("mixture_weight_scale", C.c_float), ("gaussian_scale", C.c_float)]
+                ("variances", C.c_void_p), ("mixture_weight_scale", C.c_double), ("gaussian_scale", C.c_double)]
 
 
 class _FfnnModel(C.Structure):
@@ -194,6 +194,8 @@ def load_ref():
     R.ref_time_window_frames.restype = C.c_long
     R.ref_time_window_frames.argtypes = [C.c_long, C.c_long, C.c_int, C.c_uint, C.c_uint, C.c_int, C.c_double, C.c_long,
                                          C.c_void_p, C.c_void_p, C.c_void_p]
+    R.ref_mt_vr_exp.restype = None
+    R.ref_mt_vr_exp.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
     R.ref_window_frames.restype = C.c_long
     R.ref_window_frames.argtypes = [f32p, C.c_long, C.c_long, C.c_uint, C.c_uint, C.c_double, C.c_long,
                                     C.c_void_p, C.c_void_p, C.c_void_p]
@@ -624,6 +626,13 @@ class GammatoneCfg(C.Structure):
         for k, v in kw.items():
             setattr(c, k, v)
         return c
+
+
+def oracle_activation(x, act):
+    """orc_activation elementwise; act: 1 ReLU, 2 sigmoid, 3 tanh (the layers' own functions)"""
+    L = Oracle()
+    L.orc_activation.restype, L.orc_activation.argtypes = C.c_float, [C.c_float, C.c_int]
+    return np.array([L.orc_activation(float(v), act) for v in np.asarray(x, np.float32).ravel()], np.float32)
 
 
 def oracle_time_window_frames(n, length, shift):

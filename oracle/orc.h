@@ -158,8 +158,8 @@ typedef struct {
     const uint32_t* dens_cov;    /* [n_dens] */
     const float*    means;       /* [n_mean x dim] */
     const float*    variances;   /* [n_cov  x dim] */
-    float           mixture_weight_scale;
-    float           gaussian_scale;
+    double          mixture_weight_scale;
+    double          gaussian_scale;
 } orc_gmm_model;
 
 typedef struct orc_gmm orc_gmm;
@@ -218,6 +218,7 @@ typedef struct {
 /* feats [T x in0] row-major; scores [T x out_last] = -(W x + b - alpha*logprior).
  * acc64: 0 = f32 multiply-then-add in ascending k, 1 = f64 accumulation (tight "truth"),
  * 2 = f32 fmaf chain in ascending k (bit pattern of an f32 MFMA / FMA GEMM). */
+float orc_activation(float v, int act); /* one activation value (ORC_ACT_*), as the layers apply it */
 void orc_ffnn_score(const orc_ffnn_model* m, const float* feats, int T, float* scores, int acc64);
 
 #ifdef __cplusplus

@@ -48,10 +48,11 @@ orc_gmm* orc_gmm_create(const orc_gmm_model* m) {
     h->m2lw = (float*)malloc(nk * 4);
     for (size_t k = 0; k < nk; ++k) {
         float v    = (float)(-2 * m->log_weight[k]);
-        h->m2lw[k] = v * m->mixture_weight_scale;
+        h->m2lw[k] = v * (float)m->mixture_weight_scale; /* mixtureWeightScale_ is a Score (f32) */
     }
-    /* GaussDiagonalMaximumFeatureScorer ctor (:46-62): gaussianScale_ = sqrt(scale) in f32 */
-    float gs = sqrtf(m->gaussian_scale);
+    /* GaussDiagonalMaximumFeatureScorer ctor (:46-62): gaussianScale_(std::sqrt(paramGaussianScale(c))): the parameter is f64,
+     * std::sqrt(double), narrowed to the f32 member */
+    float gs = (float)sqrt(m->gaussian_scale);
     /* Mm/CovarianceFeatureScorerElement.cc:21-51, Mm/Utilities.hh:53-91 */
     h->isr     = (float*)malloc((size_t)m->n_cov * m->dim * 4);
     h->lognorm = (float*)malloc((size_t)m->n_cov * 4);
@@ -759,14 +760,18 @@ void orc_gmm_accumulate_weighted(const orc_gmm* h, int mode, const float* feats,
 static float orc_act(float v, int act) {
     switch (act) {
         case ORC_ACT_RELU: return v < 0 ? 0 : v;                     /* ensureMinimalValue(0) */
-        case ORC_ACT_SIGMOID: { /* Math/FastMatrix.hh:802-808: scale(-1), exp() in f32, 1.0/(1.0+e) in f64 */
-            float e = expf(-v);
+        case ORC_ACT_SIGMOID: { /* Math/FastMatrix.hh:802-808: scale(-1), exp(), 1.0 / (1.0 + e) in f64.  exp() is mt_vr_exp
+                                 * (Math/FastVectorOperations.hh:57-63): the unqualified exp(x[i]) on a float resolves to ::exp(double)
+                                 * there, narrowed on assignment -- PINNED on that template compiled unmodified (ref_mt_vr_exp) */
+            float e = (float)exp((double)-v);
             return (float)(1.0 / (1.0 + e));
         }
         case ORC_ACT_TANH: return tanhf(v);
         default: return v;
     }
 }
+
+float orc_activation(float v, int act) { return orc_act(v, act); }
 
 void orc_ffnn_score(const orc_ffnn_model* m, const float* feats, int T, float* scores, int acc64) {
     int maxd = m->in_dim[0];

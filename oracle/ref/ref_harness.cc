@@ -13,6 +13,8 @@
 //       Math::AnalyticFunctionFactory::createMelWarpingFunction (AnalyticFunctionFactory.cc:338-341)
 //   Math::{Sinh,ArcSinh,DerivedArcSinh} (SimpleAnalyticFunctions.hh:152-222) composed like createBarkWarpingFunction
 //       (AnalyticFunctionFactory.cc:369-373); Math::EqualLoudnessPreemphasis[4Khz]  src/Math/AcousticalAnalyticFunctions.cc
+//   Math::mt_vr_exp<f32> (src/Math/FastVectorOperations.hh:57-63) -- what Math::FastMatrix<f32>::exp() runs inside sigmoid()
+//       (Math/FastMatrix.hh:785-787,802-808): the unqualified exp() on a float there is ::exp(double), narrowed
 //   Mm::gaussLogNormFactor, Mm::inverseSquareRoot           src/Mm/Utilities.hh:53-91
 //   Math::Matrix<f32> * Math::Vector<f32>   src/Math/Matrix.hh:485-494, src/Math/Vector.hh:94-101 -- what
 //       Signal::CosineTransform::apply runs (f32 products accumulated left to right)
@@ -25,6 +27,7 @@
 // boost / bison / cblas (anything including Core/Configuration.hh) are simply not built.
 #include <Math/AcousticalAnalyticFunctions.hh>
 #include <Math/FastFourierTransform.hh>
+#include <Math/FastVectorOperations.hh>
 #include <Math/LevinsonLse.hh>
 #include <Math/SimpleAnalyticFunctions.hh>
 #include <Mm/Utilities.hh>
@@ -276,6 +279,12 @@ long ref_time_window_frames(long n, long block, int channels, unsigned length, u
         emit();
     }
     return nf;
+}
+
+// y = exp(x) elementwise exactly as Math::FastMatrix<f32>::exp() computes it (mt_vr_exp, one thread)
+void ref_mt_vr_exp(int n, const float* x, float* y) {
+    std::vector<float> in(x, x + n);
+    Math::mt_vr_exp(n, in.data(), y, 1);
 }
 
 // One Flow cache block as Flow::CacheWriter emits it (src/Flow/Cache.cc:88-93: datatype name, then

@@ -55,7 +55,7 @@ class GmmModel(C.Structure):
     _fields_ = [("dim", C.c_int), ("n_mix", C.c_int), ("n_dens", C.c_int), ("n_mean", C.c_int), ("n_cov", C.c_int),
                 ("mix_offsets", C.c_void_p), ("dens_index", C.c_void_p), ("log_weight", C.c_void_p),
                 ("dens_mean", C.c_void_p), ("dens_cov", C.c_void_p), ("means", C.c_void_p),
-                ("variances", C.c_void_p), ("mixture_weight_scale", C.c_float), ("gaussian_scale", C.c_float)]
+                ("variances", C.c_void_p), ("mixture_weight_scale", C.c_double), ("gaussian_scale", C.c_double)]
 
 
 class GmmEstimateCfg(C.Structure):

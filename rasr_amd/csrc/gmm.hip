@@ -1482,7 +1482,7 @@ struct amx_gmm {
     void*     simd = nullptr;        // SIMD-diagonal-maximum tables and workspaces (gmm_simd.hip), built on first use
     std::vector<float>  h_means, h_vars;   // host copies of the model for that lazy build
     std::vector<double> h_logw;
-    float     mws = 1.f, gsc = 1.f;
+    double    mws = 1.0, gsc = 1.0;
     int       simd_status = 0;       // 0 = not built yet, 1 = built, < 0 = amx_status of the failed build
     // preselection-batch-float (gmm_presel.hip): density clustering, built on first use / when its parameters change
     void*     presel = nullptr;
@@ -1842,9 +1842,9 @@ int amx_gmm_create(amx_ctx* ctx, const amx_gmm_model* m, amx_gmm** out) {
     h->m2lw.resize(nk);
     for (size_t k = 0; k < nk; ++k) {
         float minus2 = (float)(-2 * m->log_weight[k]);  // f64 product stored as Score
-        h->m2lw[k]   = minus2 * m->mixture_weight_scale;
+        h->m2lw[k]   = minus2 * (float)m->mixture_weight_scale;  // mixtureWeightScale_ is a Score
     }
-    const float gs = std::sqrt(m->gaussian_scale);  // gaussianScale_(std::sqrt(param)) as f32
+    const float gs = (float)std::sqrt(m->gaussian_scale);  // gaussianScale_(std::sqrt(param)): f64 parameter, f64 root, f32 member
     h->isr.resize((size_t)m->n_cov * m->dim);
     h->lognorm.resize(m->n_cov);
     for (int c = 0; c < m->n_cov; ++c) {

@@ -169,8 +169,8 @@ int amx_mixture_set_view(const amx_mixture_set* ms, amx_gmm_model* v) {
     v->dens_cov             = ms->dens_cov.data();
     v->means                = ms->means.data();
     v->variances            = ms->variances.data();
-    v->mixture_weight_scale = 1.f;
-    v->gaussian_scale       = 1.f;
+    v->mixture_weight_scale = 1.0;
+    v->gaussian_scale       = 1.0;
     return AMX_OK;
 }
 

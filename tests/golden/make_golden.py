@@ -89,8 +89,20 @@ def time_framing_golden(R):
     json.dump(rows, open(os.path.join(HERE, "ref_time_framing.json"), "w"), indent=0)
 
 
+def activation_golden(R):
+    """ref_activation.json: Math::mt_vr_exp<f32> (what FastMatrix<f32>::exp() runs inside sigmoid()) on the negated inputs"""
+    rng = np.random.Generator(np.random.PCG64(99))
+    x = np.concatenate([(rng.standard_normal(4000) * 5).astype(np.float32), np.float32([0, -0.0, 1, -1, 20, -20, 88, -88, 89, -104, 1e-8])])
+    nx, y = (-x).astype(np.float32), np.zeros(len(x), np.float32)
+    R.ref_mt_vr_exp(len(x), nx.ctypes.data, y.ctypes.data)
+    json.dump(dict(x=[float(v).hex() for v in x], exp_neg_x=[float(v).hex() for v in y]), open(os.path.join(HERE, "ref_activation.json"), "w"))
+
+
 def main():
     R = load_ref()
+    if sys.argv[1:] == ["activation"]:
+        activation_golden(R)
+        return
     if sys.argv[1:] == ["bark"]:
         bark_golden(R)
         return

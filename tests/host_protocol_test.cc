@@ -35,7 +35,7 @@ int main(int argc, char** argv) {
     std::normal_distribution<float> nd;
     for (auto& v : means)
         v = nd(rng);
-    amx_gmm_model model = {dim, M, 6, 6, 1, off.data(), didx.data(), lw.data(), dmean.data(), dcov.data(), means.data(), var.data(), 1.f, 1.f};
+    amx_gmm_model model = {dim, M, 6, 6, 1, off.data(), didx.data(), lw.data(), dmean.data(), dcov.data(), means.data(), var.data(), 1.0, 1.0};
 
     const unsigned     B = 4;
     BatchFeatureScorer fs(std::unique_ptr<BatchBackend>(new GmmBackend(ctx, model)), B);

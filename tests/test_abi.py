@@ -131,7 +131,8 @@ def test_mfcc_configuration_errors():
 def test_gmm_prepared_tables_bit_identical_to_oracle():
     import rasr_amd
     L = _lib.lib()
-    for pooled, mws, gsc in ((True, 1.0, 1.0), (False, 0.7, 1.3)):
+    # gaussian-scale 0.9: the f64 root narrowed to f32 (what the reference's constructor does) differs from a root taken in f32
+    for pooled, mws, gsc in ((True, 1.0, 1.0), (False, 0.7, 1.3), (False, 0.3, 0.9)):
         model = synth.gmm_cart(50, 1, 8, 40, seed=2, pooled=pooled)
         keep = []
         st = rasr_amd._gmm_struct(model, mws, gsc, keep)
@@ -144,6 +145,10 @@ def test_gmm_prepared_tables_bit_identical_to_oracle():
         assert np.array_equal(a.view(np.uint32), oa.view(np.uint32))
         assert np.array_equal(b.view(np.uint32), ob.view(np.uint32))
         assert np.array_equal(c.view(np.uint32), oc.view(np.uint32))
+        if gsc == 0.9:   # inverse root of the first variance times (f32)sqrt((f64)0.9), from the definition (CovarianceFeatureScorerElement::scale)
+            gs = np.float32(np.sqrt(np.float64(0.9)))
+            assert gs != np.sqrt(np.float32(0.9))
+            assert ob[0, 0] == np.float32(np.float32(1.0) / np.float32(np.sqrt(np.float64(model["variances"][0, 0])))) * gs
         assert L.amx_gmm_n_mixtures(h) == 50 and L.amx_gmm_dimension(h) == 40
         x = np.zeros((1, 40), np.float32)
         assert L.amx_gmm_score(h, 0, x.ctypes.data, 1, x.ctypes.data, None) == _lib.AMX_ERR_STATE

@@ -70,6 +70,19 @@ def test_temporal_integration_framing_against_reference_time_window_buffer():
         assert float.fromhex(r["last_start_time"]) == pytest.approx(starts[-1] / r["fs"], rel=1e-9, abs=1e-9)   # the class accumulates shift / rate
 
 
+def test_sigmoid_against_reference_exp_template():
+    """orc_activation (sigmoid) = (f32)(1.0 / (1.0 + e)), e = Math::mt_vr_exp<f32>(-x) compiled unmodified (ref_activation.json): the
+    unqualified exp on a float inside that template is ::exp(double) narrowed, not expf"""
+    from oracle.binding import oracle_activation
+    g = json.load(open(os.path.join(GOLD, "ref_activation.json")))
+    x = np.array([float.fromhex(v) for v in g["x"]], np.float32)
+    e = np.array([float.fromhex(v) for v in g["exp_neg_x"]], np.float32)
+    with np.errstate(over="ignore"):
+        want = (1.0 / (1.0 + e.astype(np.float64))).astype(np.float32)
+    assert np.array_equal(bits(oracle_activation(x, 2)), bits(want))
+    assert np.array_equal(oracle_activation(x, 1), np.maximum(x, 0))
+
+
 def test_mel_functions_against_reference_functors():
     L = Oracle()
     g = json.load(open(os.path.join(GOLD, "ref_functions.json")))
@@ -180,6 +193,11 @@ def test_live_reference_build_agrees():
         nf = R.ref_window_frames(np.zeros(n, np.float32), n, 4096, 400, 160, 16000.0, 1000, fl.ctypes.data, None, None)
         assert nf == m.n_frames(n)
         assert fl[nf - 1] == min(400, n - (nf - 1) * 160)
+    from oracle.binding import oracle_activation
+    xs = (rng.standard_normal(3000) * 6).astype(np.float32)
+    nx, e = (-xs).astype(np.float32), np.zeros(3000, np.float32)
+    R.ref_mt_vr_exp(3000, nx.ctypes.data, e.ctypes.data)
+    assert np.array_equal(bits(oracle_activation(xs, 2)), bits((1.0 / (1.0 + e.astype(np.float64))).astype(np.float32)))
     from oracle.binding import oracle_time_window_frames
     for _ in range(60):   # Signal::TimeWindowBuffer (temporal integration) on fresh lengths / shifts / block sizes
         length, shift = int(rng.integers(1, 500)), int(rng.integers(1, 300))
