@@ -221,34 +221,17 @@ __global__ __launch_bounds__(256) void gmm_batch_float_kernel(const float* __res
     const int  t    = (blockIdx.y * 4 + wave) * 64 + lane;
     const bool live = t < dims.T;
     const int  tt   = live ? t : (dims.T - 1);
-    float      x[DIM];
-#pragma unroll
-    for (int i = 0; i < DIM; ++i)
-        x[i] = g_feats[(size_t)tt * DIM + i] * g_isr0[i];  // setFeature: f * variance_
+    const int  dim = DIM > 0 ? DIM : dims.dim;
+    ScaledRow<DIM> x;
+    x.load(g_feats + (size_t)tt * dim, g_isr0, dim);  // setFeature: f * variance_
     const int m0 = blockIdx.x * dims.mix_tile;
     const int m1 = min(m0 + dims.mix_tile, dims.n_mix);
     for (int m = m0; m < m1; ++m) {
         const uint32_t k0 = g_mix_off[m], k1 = g_mix_off[m + 1];
         float          best = FLT_MAX;
         for (uint32_t k = k0; k < k1; ++k) {
-            const float* mu    = g_smeans + (size_t)g_k_mean[k] * DIM;
-            float        s1[4] = {g_k_const[k], 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int d = 0; d < DIM; d += 8) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (d + j < DIM) {
-                        float x1 = mu[d + j] - x[d + j];
-                        s1[j]    = s1[j] + x1 * x1;
-                    }
-                    if (d + 4 + j < DIM) {
-                        float x2 = mu[d + 4 + j] - x[d + 4 + j];
-                        s2[j]    = s2[j] + x2 * x2;
-                    }
-                }
-            }
-            const float a0 = s1[0] + s2[0], a1 = s1[1] + s2[1], a2 = s1[2] + s2[2], a3 = s1[3] + s2[3];
-            const float r  = (a3 + a1) + (a2 + a0);
+            const float* mu = g_smeans + (size_t)g_k_mean[k] * dim;
+            const float  r  = batch_float_distance<DIM>(mu, x, g_k_const[k], dim);
             best           = r < best ? r : best;  // _mm_min_ps(score, r)
         }
         if (live)
@@ -2276,9 +2259,10 @@ int amx_gmm_score_dev(amx_gmm* h, int mode, const float* feats_dev, int T, float
             AMX_GMM_CASE(48)
             AMX_GMM_CASE(64)
 #undef AMX_GMM_CASE
-            default:
-                amx::set_error("amx_gmm_score_dev: batch-diagonal-maximum-float has no kernel for dimension %d", h->dim);
-                return AMX_ERR_UNSUPPORTED;
+            default:  // any other dimension: the same arithmetic with the feature row re-read from memory
+                hipLaunchKernelGGL((amx::gmm_batch_float_kernel<0>), grid, dim3(256), 0, h->ctx->stream, feats_dev, scores_dev, h->d_mix_off,
+                                   h->d_k_mean, h->d_k_const, h->d_smeans, h->d_isr0, dims);
+                break;
         }
         AMX_HIP(hipGetLastError());
         return AMX_OK;

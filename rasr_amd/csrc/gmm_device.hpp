@@ -67,4 +67,58 @@ __device__ __forceinline__ float min3_first(float a, float b, float c) {
     return __builtin_fminf(__builtin_fminf(a, b), c);
 }
 
+// A feature row pre-multiplied by 1 / sigma (Mm::BatchFloatFeatureScorer::setFeature: f * variance_), for the kernels of the
+// batch-float family.  DIM > 0: the row lives in registers; DIM == 0 (any other dimension): every element is re-read from global
+// memory (L1 / L2 hits) and scaled again -- the same f32 product, so both forms give identical bits.
+template<int DIM>
+struct ScaledRow {
+    float x[DIM > 0 ? DIM : 1];
+    __device__ __forceinline__ void load(const float* row, const float* scale, int) {
+#pragma unroll
+        for (int i = 0; i < DIM; ++i)
+            x[i] = row[i] * scale[i];
+    }
+    __device__ __forceinline__ float operator()(int i) const { return x[i]; }
+};
+template<>
+struct ScaledRow<0> {
+    const float* row;
+    const float* scale;
+    __device__ __forceinline__ void load(const float* r, const float* s, int) {
+        row   = r;
+        scale = s;
+    }
+    __device__ __forceinline__ float operator()(int i) const { return row[i] * scale[i]; }
+};
+
+// Mm::BatchFloatFeatureScorer's distance (Mm/BatchFeatureScorer.cc:164-254): two 4-lane f32 accumulators over 8-wide blocks, lane 0
+// of the first starts at the density's constant; a = s1 + s2; (a3 + a1) + (a2 + a0)
+template<int DIM, class Row>
+__device__ __forceinline__ float batch_float_distance(const float* __restrict__ mu, const Row& x, float c0, int dim_rt) {
+    float s1[4] = {c0, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    auto  block = [&](int d, int n) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (d + j < n) {
+                float x1 = mu[d + j] - x(d + j);
+                s1[j]    = s1[j] + x1 * x1;
+            }
+            if (d + 4 + j < n) {
+                float x2 = mu[d + 4 + j] - x(d + 4 + j);
+                s2[j]    = s2[j] + x2 * x2;
+            }
+        }
+    };
+    if (DIM > 0) {
+#pragma unroll
+        for (int d = 0; d < DIM; d += 8)
+            block(d, DIM);
+    }
+    else
+        for (int d = 0; d < dim_rt; d += 8)
+            block(d, dim_rt);
+    const float a0 = s1[0] + s2[0], a1 = s1[1] + s2[1], a2 = s1[2] + s2[2], a3 = s1[3] + s2[3];
+    return (a3 + a1) + (a2 + a0);
+}
+
 }  // namespace amx

@@ -16,6 +16,7 @@
 //              presel_score_kernel: gmm_batch_float_kernel's arithmetic with the wave's lane mask of the density's cluster read
 //              through the scalar cache -- a density whose cluster no frame of the wave selected is skipped altogether.
 #include "common.hpp"
+#include "gmm_device.hpp"
 
 #include <cfloat>
 #include <cmath>
@@ -29,24 +30,34 @@ constexpr int kPreselMaxClusters = 256;  // Mm/DensityClustering.cc:21-22: param
 // lane = density (mixture entry): first closest cluster
 template<int DIM>
 __global__ __launch_bounds__(256) void presel_assign_kernel(const float* __restrict__ g_smeans, const uint32_t* __restrict__ g_k_mean, int nk,
-                                                           const float* __restrict__ g_cm, int n_clusters, uint32_t* __restrict__ g_cluster_of) {
+                                                           const float* __restrict__ g_cm, int n_clusters, uint32_t* __restrict__ g_cluster_of,
+                                                           int dim_rt) {
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= nk)
         return;
-    float mu[DIM];
+    const int    dim = DIM > 0 ? DIM : dim_rt;
+    const float* row = g_smeans + (size_t)g_k_mean[k] * dim;
+    float        mu[DIM > 0 ? DIM : 1];  // DIM == 0 (a dimension without a specialised kernel): the row is re-read from memory
 #pragma unroll
     for (int i = 0; i < DIM; ++i)
-        mu[i] = g_smeans[(size_t)g_k_mean[k] * DIM + i];
+        mu[i] = row[i];
     float    bd = FLT_MAX;
     uint32_t bc = 0;
     for (int c = 0; c < n_clusters; ++c) {
-        const float* cm = g_cm + (size_t)c * DIM;  // wave-uniform: scalar loads
+        const float* cm = g_cm + (size_t)c * dim;  // wave-uniform: scalar loads
         float        score = 0.f;
+        if (DIM > 0) {
 #pragma unroll
-        for (int i = 0; i < DIM; ++i) {  // unrolledVectorDistance(meanForCluster, meanForDensity): sequential, a = cluster mean
-            const float df = cm[i] - mu[i];
-            score          = score + df * df;
+            for (int i = 0; i < DIM; ++i) {  // unrolledVectorDistance(meanForCluster, meanForDensity): sequential, a = cluster mean
+                const float df = cm[i] - mu[i];
+                score          = score + df * df;
+            }
         }
+        else
+            for (int i = 0; i < dim; ++i) {
+                const float df = cm[i] - row[i];
+                score          = score + df * df;
+            }
         if (score < bd) {
             bd = score;
             bc = (uint32_t)c;
@@ -60,23 +71,29 @@ __global__ __launch_bounds__(256) void presel_assign_kernel(const float* __restr
 template<int DIM>
 __global__ __launch_bounds__(64) void cluster_select_kernel(const float* __restrict__ g_feats, const float* __restrict__ g_isr0, int T, int Tpad,
                                                            const float* __restrict__ g_cm, int n_clusters, int n_select,
-                                                           float* __restrict__ g_dist, unsigned long long* __restrict__ g_masks) {
+                                                           float* __restrict__ g_dist, unsigned long long* __restrict__ g_masks, int dim_rt) {
     const int  lane = threadIdx.x;
     const int  t    = blockIdx.x * 64 + lane;
     const bool live = t < T;
     const int  tt   = live ? t : T - 1;
-    float      x[DIM];
-#pragma unroll
-    for (int i = 0; i < DIM; ++i)
-        x[i] = g_feats[(size_t)tt * DIM + i] * g_isr0[i];  // setFeature: f * variance_ (1 / sigma)
+    const int  dim  = DIM > 0 ? DIM : dim_rt;
+    ScaledRow<DIM> x;
+    x.load(g_feats + (size_t)tt * dim, g_isr0, dim);  // setFeature: f * variance_ (1 / sigma)
     for (int c = 0; c < n_clusters; ++c) {
-        const float* cm = g_cm + (size_t)c * DIM;
+        const float* cm = g_cm + (size_t)c * dim;
         float        score = 0.f;
+        if (DIM > 0) {
 #pragma unroll
-        for (int i = 0; i < DIM; ++i) {  // unrolledVectorDistance(feature, meanForCluster)
-            const float df = x[i] - cm[i];
-            score          = score + df * df;
+            for (int i = 0; i < DIM; ++i) {  // unrolledVectorDistance(feature, meanForCluster)
+                const float df = x(i) - cm[i];
+                score          = score + df * df;
+            }
         }
+        else
+            for (int i = 0; i < dim; ++i) {
+                const float df = x(i) - cm[i];
+                score          = score + df * df;
+            }
         g_dist[(size_t)c * Tpad + t] = score;
     }
     // the n_select-th smallest (distance, cluster) pair of this frame
@@ -116,7 +133,7 @@ __global__ __launch_bounds__(256) void presel_score_kernel(const float* __restri
                                                           const float* __restrict__ g_k_const, const float* __restrict__ g_smeans,
                                                           const float* __restrict__ g_isr0, const uint32_t* __restrict__ g_cluster_of,
                                                           const unsigned long long* __restrict__ g_masks, int n_clusters, float backoff, int T,
-                                                          int n_mix, int mix_tile) {
+                                                          int n_mix, int mix_tile, int dim_rt) {
     const int  lane = threadIdx.x & 63;
     const int  wave = threadIdx.x >> 6;
     const int  wg   = blockIdx.y * 4 + wave;  // 64-frame group = row of the mask table
@@ -125,10 +142,9 @@ __global__ __launch_bounds__(256) void presel_score_kernel(const float* __restri
         return;
     const bool live = t < T;
     const int  tt   = live ? t : (T - 1);
-    float      x[DIM];
-#pragma unroll
-    for (int i = 0; i < DIM; ++i)
-        x[i] = g_feats[(size_t)tt * DIM + i] * g_isr0[i];
+    const int  dim  = DIM > 0 ? DIM : dim_rt;
+    ScaledRow<DIM> x;
+    x.load(g_feats + (size_t)tt * dim, g_isr0, dim);
     const unsigned long long* masks = g_masks + (size_t)wg * n_clusters;
     const int m0 = blockIdx.x * mix_tile;
     const int m1 = min(m0 + mix_tile, n_mix);
@@ -139,24 +155,8 @@ __global__ __launch_bounds__(256) void presel_score_kernel(const float* __restri
             const unsigned long long am = masks[g_cluster_of[k]];  // wave-uniform
             if (am == 0ull)
                 continue;  // no frame of this wave selected the density's cluster
-            const float* mu    = g_smeans + (size_t)g_k_mean[k] * DIM;
-            float        s1[4] = {g_k_const[k], 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int d = 0; d < DIM; d += 8) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (d + j < DIM) {
-                        float x1 = mu[d + j] - x[d + j];
-                        s1[j]    = s1[j] + x1 * x1;
-                    }
-                    if (d + 4 + j < DIM) {
-                        float x2 = mu[d + 4 + j] - x[d + 4 + j];
-                        s2[j]    = s2[j] + x2 * x2;
-                    }
-                }
-            }
-            const float a0 = s1[0] + s2[0], a1 = s1[1] + s2[1], a2 = s1[2] + s2[2], a3 = s1[3] + s2[3];
-            const float r  = (a3 + a1) + (a2 + a0);
+            const float* mu = g_smeans + (size_t)g_k_mean[k] * dim;
+            const float  r  = batch_float_distance<DIM>(mu, x, g_k_const[k], dim);
             const bool  act = (am >> lane) & 1ull;
             best            = (act && r < best) ? r : best;
         }
@@ -237,11 +237,6 @@ extern "C" int amx_internal_gmm_presel_create(amx_ctx* ctx, int dim, size_t nk, 
     AMX_REQUIRE(n_select >= 1 && n_select <= n_clusters, AMX_ERR_INVALID, "preselection: select-clusters (%d) must be in 1..clusters (%d)", n_select,
                 n_clusters);
     AMX_REQUIRE(iterations >= 0, AMX_ERR_INVALID, "preselection: negative iteration count");
-    bool dim_ok = false;
-#define X(D) dim_ok |= dim == D;
-    AMX_PRESEL_DIMS(X)
-#undef X
-    AMX_REQUIRE(dim_ok, AMX_ERR_UNSUPPORTED, "preselection-batch-float has no kernel for dimension %d", dim);
     GmmPresel* s = new GmmPresel;
     s->dim = dim;
     s->nk = nk;
@@ -280,10 +275,14 @@ extern "C" int amx_internal_gmm_presel_create(amx_ctx* ctx, int dim, size_t nk, 
 #define X(D)                                                                                                                        \
     case D:                                                                                                                         \
         hipLaunchKernelGGL(presel_assign_kernel<D>, grid, dim3(256), 0, ctx->stream, d_smeans, d_k_mean, (int)nk, s->d_cm, n_clusters, \
-                           s->d_cluster_of);                                                                                        \
+                           s->d_cluster_of, dim);                                                                                   \
         break;
             AMX_PRESEL_DIMS(X)
 #undef X
+            default:  // any other dimension: rows re-read from memory, the same sums
+                hipLaunchKernelGGL(presel_assign_kernel<0>, grid, dim3(256), 0, ctx->stream, d_smeans, d_k_mean, (int)nk, s->d_cm, n_clusters,
+                                   s->d_cluster_of, dim);
+                break;
         }
         if (hipMemcpyAsync(s->h_cluster_of.data(), s->d_cluster_of, nk * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
             hipStreamSynchronize(ctx->stream) != hipSuccess)
@@ -345,10 +344,14 @@ extern "C" int amx_internal_gmm_presel_score(void* p, amx_ctx* ctx, const float*
 #define X(D)                                                                                                                             \
     case D:                                                                                                                              \
         hipLaunchKernelGGL(cluster_select_kernel<D>, dim3(n_groups), dim3(64), 0, ctx->stream, feats_dev, d_isr0, T, Tpad, s->d_cm,     \
-                           s->n_clusters, s->n_select, s->d_dist, s->d_masks);                                                           \
+                           s->n_clusters, s->n_select, s->d_dist, s->d_masks, s->dim);                                                   \
         break;
             AMX_PRESEL_DIMS(X)
 #undef X
+            default:
+                hipLaunchKernelGGL(cluster_select_kernel<0>, dim3(n_groups), dim3(64), 0, ctx->stream, feats_dev, d_isr0, T, Tpad, s->d_cm,
+                                   s->n_clusters, s->n_select, s->d_dist, s->d_masks, s->dim);
+                break;
         }
         AMX_HIP(hipGetLastError());
     }
@@ -361,10 +364,14 @@ extern "C" int amx_internal_gmm_presel_score(void* p, amx_ctx* ctx, const float*
 #define X(D)                                                                                                                             \
     case D:                                                                                                                              \
         hipLaunchKernelGGL(presel_score_kernel<D>, grid, dim3(256), 0, ctx->stream, feats_dev, scores_dev, d_mix_off, d_k_mean, d_k_const, \
-                           d_smeans, d_isr0, s->d_cluster_of, s->d_masks, s->n_clusters, s->backoff, T, n_mix, mt);                      \
+                           d_smeans, d_isr0, s->d_cluster_of, s->d_masks, s->n_clusters, s->backoff, T, n_mix, mt, s->dim);              \
         break;
         AMX_PRESEL_DIMS(X)
 #undef X
+        default:
+            hipLaunchKernelGGL(presel_score_kernel<0>, grid, dim3(256), 0, ctx->stream, feats_dev, scores_dev, d_mix_off, d_k_mean, d_k_const,
+                               d_smeans, d_isr0, s->d_cluster_of, s->d_masks, s->n_clusters, s->backoff, T, n_mix, mt, s->dim);
+            break;
     }
     AMX_HIP(hipGetLastError());
     return AMX_OK;

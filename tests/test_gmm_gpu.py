@@ -917,7 +917,8 @@ def test_fused_small_batch_splits_the_model(ctx):
 
 # ---- preselection-batch-float (Mm::BatchPreselectionFloatFeatureScorer + Mm::FloatDensityClustering)
 
-@pytest.mark.parametrize("n_mix,kmax,dim,clusters,select", [(50, 8, 24, 16, 4), (300, 16, 40, 256, 32), (20, 3, 40, 256, 32), (64, 4, 33, 8, 8)])
+@pytest.mark.parametrize("n_mix,kmax,dim,clusters,select", [(50, 8, 24, 16, 4), (300, 16, 40, 256, 32), (20, 3, 40, 256, 32), (64, 4, 33, 8, 8),
+                                                            (70, 6, 8, 16, 5), (40, 5, 50, 8, 3)])   # dims 8 / 50: the runtime-dimension kernels
 def test_preselection_batch_float_exact(ctx, n_mix, kmax, dim, clusters, select):
     """clustering (glibc rand() initialisation restated in the product vs libc's in the oracle, k-means assignment on the GPU vs
     the oracle's loops) and the preselected scores bit-exact against the oracle; mixtures without an active density score the

@@ -28,7 +28,7 @@ def fail(what, **kw):
 for case in range(n_cases):
     seed = int(rng.integers(1, 1 << 30))
     # ---- pooled GMM variants
-    dim = int(rng.choice([16, 24, 32, 33, 39, 40, 45, 48, 64]))
+    dim = int(rng.choice([5, 8, 16, 24, 32, 33, 39, 40, 45, 48, 50, 64, 72]))
     n_mix, kmax = int(rng.integers(1, 200)), int(rng.integers(1, 30))
     model = synth.gmm_cart(n_mix, 1, kmax, dim, seed=seed, pooled=True)
     T = int(rng.choice([1, 5, 64, 129, 256, 600]))
