@@ -753,10 +753,13 @@ __global__ __launch_bounds__(256) void gmm_tied_tile_kernel(const float* __restr
 // with c_k = m2lw_k + logNorm_k + sum_i (mu_ki r_ki)^2.  That is a GEMM with f16 operands on the matrix cores
 // (gmm_screen_kernel, 256 density slots x 256 frames per workgroup, mixtures padded to 16 slots).  Its epilogue takes the
 // minimum over each mixture's 16 slots and emits a 16-bit candidate mask: slot j is kept unless g_j > g_min + tau, where
-//     tau = 2.2e-3 na nx + 1.3e-4 sqrt(K) (na + nx) + 1.6e-5 (|g_min| + max|c| + q)
-// bounds twice the worst difference between g and the reference's own f64 sum minus the frame term: f16 rounding of both
-// operands (2^-11 relative each, 2^-14 absolute if subnormals were flushed; Cauchy-Schwarz with na = max ||A_k||, nx =
-// ||X_t|| of the rounded operands), f32 accumulation of <= 128 exact products, rounding of c_k, the (dim + 3) ulp error of
+//     tau = 2.05 (ra nx + NA rx) + 1.3e-4 sqrt(K) (na + nx) + 1.6e-5 (|g_min| + max|c| + q)
+// bounds twice the worst difference between g and the reference's own f64 sum minus the frame term.  f16 rounding of the operands:
+// with A = A^ + dA, X = X^ + dX (the rounded rows and their residuals) the dot product is off by exactly dA.X^ + A.dX, at most
+// ||dA|| ||X^|| + ||A|| ||dX|| (Cauchy-Schwarz) -- ra = the largest residual norm among the mixture's rows (host, f64), nx = ||X^||,
+// rx = ||dX|| (pack kernel: v - (f32)(f16)v is exact), NA = the largest row norm of the model; round 1 used the worst case
+// 2^-11 ||A|| for both residuals, which is 2.4 times the typical one and kept 2.3 times as many further survivors.  2^-14 absolute
+// per element if subnormals were flushed, f32 accumulation of <= 128 exact products, rounding of c_k, the (dim + 3) ulp error of
 // the reference's f32 distance, plus one ulp of the winning f32 (q bounds the dropped frame term).  Frames whose operand
 // does not fit f16 get nx = inf and therefore all-ones masks; models whose operand does not fit are not screened at all.
 // gmm_screen_exact_kernel then runs gmm_distance and the reference's sequential f64 rule over the surviving slots only
@@ -767,6 +770,7 @@ typedef float    gmm_f32x16 __attribute__((ext_vector_type(16)));
 struct GmmScreenDims {
     int   T, Tpad, dim, Kp, Mpad16, pooled;
     float rmax2, sqrtK;
+    float na_all;  // 2.05 x the largest operand-row norm of the model: weighs the frame operand's f16 residual (see the threshold)
 };
 
 // features -> f16 operand rows [Tpad x Kp] (zero padded), nx[t] = ||row|| (inf when the row does not fit f16), q[t].
@@ -780,7 +784,7 @@ __global__ __launch_bounds__(256) void gmm_screen_pack_kernel(const float* __res
         return;
     _Float16* row = g_X + (size_t)t * d.Kp;
     const int kd  = d.pooled ? d.dim : 2 * d.dim;  // columns kd, kd + 1 multiply the split constant c_hi, c_lo
-    float     n2 = 0.f, q = 0.f;
+    float     n2 = 0.f, q = 0.f, r2 = 0.f;  // r2: squared norm of the f16 rounding residual of the row (v - r is exact in f32)
     bool      fits = true;
     for (int i = lane; i < d.Kp; i += 64) {
         float v = 0.f;
@@ -800,6 +804,7 @@ __global__ __launch_bounds__(256) void gmm_screen_pack_kernel(const float* __res
         const _Float16 hv = (_Float16)v;
         const float    r  = (float)hv;
         n2 += r * r;
+        r2 += (v - r) * (v - r);
         if (d.pooled || i < d.dim)
             q += v * v;
         row[i] = (i == kd || i == kd + 1) ? (_Float16)(t < d.T ? 1.f : 0.f) : hv;
@@ -808,11 +813,12 @@ __global__ __launch_bounds__(256) void gmm_screen_pack_kernel(const float* __res
     for (int off = 32; off > 0; off >>= 1) {
         n2 += __shfl_xor(n2, off, 64);
         q += __shfl_xor(q, off, 64);
+        r2 += __shfl_xor(r2, off, 64);
     }
     const bool all_fit = __ballot(!fits) == 0ull;
     if (lane == 0) {
         g_nx[t] = all_fit ? sqrtf(n2) : __builtin_inff();
-        g_q[t]  = 1.6e-5f * (d.pooled ? q : q * d.rmax2);
+        g_q[t]  = 1.6e-5f * (d.pooled ? q : q * d.rmax2) + d.na_all * (sqrtf(r2) * 1.00001f);
     }
 }
 
@@ -847,8 +853,8 @@ __device__ __forceinline__ void gmm_screen_epilogue(const gmm_f32x16 (&acc)[4][2
                 mn       = min3_raw(mn, c[o + 7], c[o + 7]);
                 mn       = min3_raw(mn, __shfl_xor(mn, 32, 64), mn);  // the partner lane's 8 slots
                 const int   m   = mt0 + i * 2 + gp;
-                // tau = 2.2e-3 na nx + 1.3e-4 sqrtK (na + nx) + 1.6e-5 (|mn| + cabs + q): p1 = 2.2e-3 na + 1.3e-4 sqrtK,
-                // p2 = 1.3e-4 sqrtK na + 1.6e-5 cabs per mixture, q pre-scaled per frame
+                // tau = 2.05 (ra nx + NA rx) + 1.3e-4 sqrtK (na + nx) + 1.6e-5 (|mn| + cabs + q): p1 = 2.05 ra + 1.3e-4 sqrtK,
+                // p2 = 1.3e-4 sqrtK na + 1.6e-5 cabs per mixture, q (incl. 2.05 NA rx) per frame
                 const float thr = mn + fmaf(nx, g_p1[m], fmaf(fabsf(mn), 1.6e-5f, g_p2[m] + q)) + 1e-30f;
                 unsigned    bits = 0;  // bit k = "value k is above the threshold", filled from the top down
 #pragma unroll
@@ -1103,7 +1109,7 @@ __global__ __launch_bounds__(512, 2) void gmm_screen_rows_kernel(const _Float16*
             mn       = min3_raw(mn, c[11], c[12]);
             mn       = min3_raw(mn, c[13], c[14]);
             mn       = min3_raw(mn, c[15], c[15]);
-            // tau as in gmm_screen_epilogue: p1 = 2.2e-3 na + 1.3e-4 sqrtK, p2 = 1.3e-4 sqrtK na + 1.6e-5 cabs, q per frame
+            // tau as in gmm_screen_epilogue: p1 = 2.05 ra + 1.3e-4 sqrtK, p2 = 1.3e-4 sqrtK na + 1.6e-5 cabs, q per frame
             const float thr = mn + fmaf(nx, p1v[i], fmaf(fabsf(mn), 1.6e-5f, p2v[i] + q)) + 1e-30f;
             unsigned    bits = 0;  // bit k = "slot k is above the threshold", filled from the top down
 #pragma unroll
@@ -1449,7 +1455,7 @@ struct amx_gmm {
     // MFMA screen (private-density models, <= 16 densities per mixture; see gmm_screen_kernel)
     bool      screen = false;
     int       scr_Kp = 0, scr_Rpad = 0, scr_Mpad16 = 0;
-    float     scr_rmax2 = 0.f;
+    float     scr_rmax2 = 0.f, scr_na_all = 0.f;
     _Float16* d_scr_A = nullptr;
     _Float16* d_scr_A2 = nullptr;  // K = 64 only: the slot rows in gmm_screen_rows_kernel's order
     float *   d_scr_c = nullptr, *d_scr_na = nullptr, *d_scr_cabs = nullptr;
@@ -1575,7 +1581,7 @@ int score_screened(amx_gmm* h, const float* feats_dev, int T, float* scores_dev,
         }
         const float*       x = feats_dev + (size_t)t0 * h->dim;
         amx::GmmScreenDims d{Tc, Tpad, h->dim, h->scr_Kp, h->scr_Mpad16, h->pooled ? 1 : 0, h->scr_rmax2,
-                             std::sqrt((float)(h->pooled ? h->dim : 2 * h->dim))};
+                             std::sqrt((float)(h->pooled ? h->dim : 2 * h->dim)), h->scr_na_all};
         {
             amx::ScopedKernelTimer timer(h->ctx, "gmm_screen_pack");
             hipLaunchKernelGGL(amx::gmm_screen_pack_kernel, dim3(Tpad / 4), dim3(256), 0, st, x, h->d_isr, h->d_scr_X, h->d_scr_nx, h->d_scr_q, d);
@@ -1949,7 +1955,8 @@ int amx_gmm_create(amx_ctx* ctx, const amx_gmm_model* m, amx_gmm** out) {
             const int Kp = Kd + 2 <= 64 ? 64 : 128, Rpad = (m->n_mix * 16 + 255) / 256 * 256, Mp = Rpad / 16;
             std::vector<_Float16> A((size_t)Rpad * Kp, (_Float16)0.f);
             std::vector<size_t>   row2(Kp == 64 ? (size_t)Rpad : 0);  // row of the old order -> row of gmm_screen_rows_kernel's order
-            std::vector<float>    c((size_t)Rpad, std::numeric_limits<float>::infinity()), na(Mp, 0.f), cabs(Mp, 0.f);
+            std::vector<float>    c((size_t)Rpad, std::numeric_limits<float>::infinity()), na(Mp, 0.f), cabs(Mp, 0.f), ra(Mp, 0.f);
+            double                na_all = 0;
             bool                  fits = true;
             double                rmax2 = 0;
             for (size_t i = 0; i < h->isr.size(); ++i)
@@ -1962,7 +1969,7 @@ int amx_gmm_create(amx_ctx* ctx, const amx_gmm_model* m, amx_gmm** out) {
                         row2[row] = (size_t)(i >> 4) * 256 + (size_t)((i & 15) >> 1) * 32 + (slot >> 2) * 8 + (i & 1) * 4 + (slot & 3) + 1;
                     const float* mu  = m->means + (size_t)k_mean[k] * d;
                     const float* is  = h->isr.data() + (size_t)k_cov[k] * d;
-                    double       cc = c64[k], n2 = 0;
+                    double       cc = c64[k], n2 = 0, res2 = 0, true2 = 0;  // squared norms: rounded row, its f16 residual, the exact row
                     for (int x = 0; x < d; ++x) {
                         const double mr = (double)mu[x] * (double)is[x];
                         cc += mr * mr;
@@ -1978,13 +1985,19 @@ int amx_gmm_create(amx_ctx* ctx, const amx_gmm_model* m, amx_gmm** out) {
                         const _Float16 h0 = (_Float16)(float)a0, h1 = (_Float16)(float)a1;
                         A[row * Kp + x]   = h0;
                         n2 += (double)(float)h0 * (double)(float)h0;
+                        res2 += (a0 - (double)(float)h0) * (a0 - (double)(float)h0);
+                        true2 += a0 * a0;
                         if (!h->pooled) {
                             A[row * Kp + d + x] = h1;
                             n2 += (double)(float)h1 * (double)(float)h1;
+                            res2 += (a1 - (double)(float)h1) * (a1 - (double)(float)h1);
+                            true2 += a1 * a1;
                         }
                     }
                     c[row]  = (float)cc;
                     na[i]   = std::max(na[i], (float)(std::sqrt(n2) * 1.0000001));
+                    ra[i]   = std::max(ra[i], (float)(std::sqrt(res2) * 1.000001));
+                    na_all  = std::max(na_all, std::sqrt(true2) * 1.000001);
                     cabs[i] = std::max(cabs[i], std::fabs((float)cc));
                     if (!std::isfinite(cc) || std::fabs(cc) > 65000.0)
                         fits = false;
@@ -1998,7 +2011,7 @@ int amx_gmm_create(amx_ctx* ctx, const amx_gmm_model* m, amx_gmm** out) {
             const float sK = std::sqrt((float)Kd);
             for (int i = 0; i < Mp; ++i) {  // na -> p1, cabs -> p2 (see gmm_screen_epilogue)
                 const float a = na[i], cb = cabs[i];
-                na[i]   = 2.2e-3f * a + 1.3e-4f * sK;
+                na[i]   = 2.05f * ra[i] + 1.3e-4f * sK;
                 cabs[i] = 1.3e-4f * sK * a + 1.6e-5f * cb;
             }
             if (fits) {
@@ -2006,6 +2019,7 @@ int amx_gmm_create(amx_ctx* ctx, const amx_gmm_model* m, amx_gmm** out) {
                 h->scr_Rpad = Rpad;
                 h->scr_Mpad16 = Mp;
                 h->scr_rmax2 = (float)(rmax2 * 1.000001);
+                h->scr_na_all = (float)(2.05 * na_all * 1.000001);
                 if (Kp == 64) {  // the same rows in the second kernel's order; rows that hold no density keep the +inf constant
                     std::vector<_Float16> A2((size_t)Rpad * Kp, (_Float16)0.f);
                     for (size_t row = 0; row < (size_t)Rpad; ++row)

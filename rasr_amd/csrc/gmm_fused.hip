@@ -159,7 +159,7 @@ __global__ __launch_bounds__(NW * 64) void gmm_fused_kernel(const float* __restr
             mn       = min3_raw(mn, c[11], c[12]);
             mn       = min3_raw(mn, c[13], c[14]);
             mn       = min3_raw(mn, c[15], c[15]);
-            // tau as in gmm_screen_epilogue (gmm.hip): p1 = 2.2e-3 na + 1.3e-4 sqrtK, p2 = 1.3e-4 sqrtK na + 1.6e-5 cabs, q per frame
+            // tau as in gmm_screen_epilogue (gmm.hip): p1 = 2.05 ra + 1.3e-4 sqrtK, p2 = 1.3e-4 sqrtK na + 1.6e-5 cabs, q per frame
             const float p1 = s_p[i * 2 + fk], p2 = s_p[16 + i * 2 + fk];
             const int   nd = ((const int*)s_p)[32 + i * 2 + fk];
             const float thr = mn + fmaf(nx, p1, fmaf(fabsf(mn), 1.6e-5f, p2 + q)) + 1e-30f;
