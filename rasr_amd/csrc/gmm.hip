@@ -1614,7 +1614,8 @@ int score_screened(amx_gmm* h, const float* feats_dev, int T, float* scores_dev,
                                                      h->count_survivors ? h->d_fus_surv : nullptr);
                 if (r != AMX_OK)
                     return r;
-                h->fus_pairs += (unsigned long long)Tc * (unsigned long long)h->n_mix;
+                if (h->count_survivors)
+                    h->fus_pairs += (unsigned long long)Tc * (unsigned long long)h->n_mix;
             }
             if (stats) {
                 amx::ScopedKernelTimer timer(h->ctx, "stats");
@@ -2320,6 +2321,8 @@ int amx_gmm_score_dev(amx_gmm* h, int mode, const float* feats_dev, int T, float
             hipGraphDestroy(g);
             it->second = ex;
         }
+        else if (h->count_survivors && h->d_fus_rec)  // a replay runs the counting kernel without passing score_screened's bookkeeping
+            h->fus_pairs += (unsigned long long)T * (unsigned long long)h->n_mix;
         AMX_HIP(hipGraphLaunch(it->second, h->ctx->stream));
         return AMX_OK;
     }
@@ -2581,7 +2584,13 @@ int amx_gmm_screen_counts(amx_gmm* h, int enable, unsigned long long* survivors,
     if (pairs)
         *pairs = h->fus_pairs;
     AMX_HIP(hipMemset(h->d_fus_surv, 0, 16));
-    h->fus_pairs       = 0;
+    h->fus_pairs = 0;
+    if (h->count_survivors != (enable != 0)) {  // captured passes carry the counter argument they were recorded with
+        for (auto& kv : h->graphs)
+            if (kv.second)
+                hipGraphExecDestroy(kv.second);
+        h->graphs.clear();
+    }
     h->count_survivors = enable != 0;
     return AMX_OK;
 }

@@ -1019,3 +1019,35 @@ def test_tied_statistics_stay_consistent_when_the_host_runs_ahead(ctx):
     from oracle import OracleGmm
     osc, ob = OracleGmm(model).score(x.cpu().numpy())
     assert np.array_equal(scores.cpu().numpy().view(np.uint32), osc.view(np.uint32)) and np.array_equal(best.cpu().numpy().astype(np.uint32), ob)
+
+
+def test_fused_survivor_statistics_under_graph_replay(ctx):
+    """decoder-sized passes on unchanged buffers are replayed as a HIP graph from the third call on: the (frame, mixture) pairs the
+    statistic is normalised by must count the replays too (regression: only the captured call was counted, 1.02 survivors per mixture
+    were reported as 1.8), and switching the counter off and on drops the graphs recorded with the other setting"""
+    import torch
+
+    import rasr_amd
+    model = synth.gmm_cart(300, 16, 16, 40, seed=71, pooled=True)
+    sc = rasr_amd.GmmFeatureScorer(ctx, model)
+    T, M = 256, 300
+    x = torch.from_numpy(feats(T, 40, 72)).cuda()
+    scores = torch.empty((T, M), dtype=torch.float32, device="cuda")
+    best = torch.empty((T, M), dtype=torch.int32, device="cuda")
+    ctx.use_torch_stream()
+    for _ in range(4):                       # graphs recorded without the counter
+        sc.score_dev(x, T, scores, best)
+    sc.screen_counts(True)
+    for _ in range(9):
+        sc.score_dev(x, T, scores, best)
+    torch.cuda.synchronize()
+    surv, pairs = sc.screen_counts(True)
+    assert pairs == 9 * T * M, pairs
+    assert pairs <= surv < 1.3 * pairs, surv / pairs
+    one = surv // 9
+    assert surv == 9 * one                   # every pass evaluates the same densities
+    sc.screen_counts(False)
+    for _ in range(4):
+        sc.score_dev(x, T, scores, best)
+    torch.cuda.synchronize()
+    assert sc.screen_counts(False) == (0, 0)
