@@ -1491,7 +1491,8 @@ struct amx_gmm {
     std::map<GraphKey, hipGraphExec_t> graphs;
     int                                use_graphs = 1;
     void*     d_fus_rec = nullptr;   // tile records of gmm_fused_kernel (pooled covariance, dim <= 40)
-    unsigned long long* d_fus_surv = nullptr;  // [2]: densities evaluated exactly, (frame, mixture) pairs scored (amx_gmm_screen_counts)
+    unsigned long long* d_fus_surv = nullptr;  // [256] partial counts of the densities evaluated exactly (amx_gmm_screen_counts): one
+                                               // address for every wave's atomicAdd cost a quarter of a 256-frame pass
     size_t    fus_rec_bytes = 0;
     bool      count_survivors = false;
     unsigned long long fus_pairs = 0;
@@ -2039,8 +2040,8 @@ int amx_gmm_create(amx_ctx* ctx, const amx_gmm_model* m, amx_gmm** out) {
                         return r;
                     }
                     if (h->d_fus_rec) {
-                        const unsigned long long zero[2] = {0, 0};
-                        if ((r = gupload(&h->d_fus_surv, zero, 2)) != AMX_OK) {
+                        const std::vector<unsigned long long> zero(256, 0ull);
+                        if ((r = gupload(&h->d_fus_surv, zero.data(), zero.size())) != AMX_OK) {
                             amx_gmm_destroy(h);
                             return r;
                         }
@@ -2577,13 +2578,15 @@ int amx_gmm_screen_counts(amx_gmm* h, int enable, unsigned long long* survivors,
         return AMX_OK;
     AMX_HIP(hipSetDevice(h->ctx->device));
     AMX_HIP(hipStreamSynchronize(h->ctx->stream));
-    unsigned long long v = 0;
-    AMX_HIP(hipMemcpy(&v, h->d_fus_surv, 8, hipMemcpyDeviceToHost));
+    unsigned long long v = 0, part[256];
+    AMX_HIP(hipMemcpy(part, h->d_fus_surv, sizeof part, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 256; ++i)
+        v += part[i];
     if (survivors)
         *survivors = v;
     if (pairs)
         *pairs = h->fus_pairs;
-    AMX_HIP(hipMemset(h->d_fus_surv, 0, 16));
+    AMX_HIP(hipMemset(h->d_fus_surv, 0, 256 * 8));
     h->fus_pairs = 0;
     if (h->count_survivors != (enable != 0)) {  // captured passes carry the counter argument they were recorded with
         for (auto& kv : h->graphs)

@@ -15,7 +15,7 @@
 //     no cross-lane traffic (identical arithmetic to gmm_screen_rows_kernel: same masks);
 //   * exact stage in the SAME lane layout: a lane owns 8 (frame, mixture) pairs per tile.  Every pair has a first survivor
 //     (the screen keeps the minimum), so the 8 first survivors are evaluated in lockstep -- static register indices, the next
-//     mean row (ds_read_b128, rows 16 B-slot staggered) fetched during the current distance -- and the ~4 % further survivors
+//     mean row (ds_read_b128, rows 16 B-slot staggered) fetched during the current distance -- and the ~2 % further survivors
 //     follow in a short divergent loop, in slot order, through select chains on the 8 running (best, index) pairs;
 //   * a frame's 16 scores / 16 best densities leave as 2 x 32 B per lane after ONE v_permlane32_swap per pair of values
 //     (no LDS transposition), and the best state of a frame is carried across tiles in registers: the per-tile arg-min
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(NW * 64) void gmm_fused_kernel(const float* __restr
         for (int off = 32; off > 0; off >>= 1)
             n += __shfl_xor(n, off, 64);
         if (lane == 0 && n)
-            atomicAdd(g_survivors, n);
+            atomicAdd(g_survivors + ((blockIdx.x * NW + wave) & 255), n);  // 256 partial counters (summed by the host)
     }
     if (g_part_min) {  // this workgroup's (min, state) of every frame: the partner lane holds the other half of the states
         const float    om = __shfl_xor(run_min, 32, 64);

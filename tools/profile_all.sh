@@ -3,6 +3,7 @@
 #   <workload>_bench.log          the bench.py JSON line (pipeline = the default run, with cpu_baseline and the secondary configs)
 #   <workload>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary of the same command
 #   pmc/*.txt                     separate --pmc passes (kernel-trace only): FETCH_SIZE / WRITE_SIZE, SQ counters, MFMA counters
+#   gpu_tests.log / gpu_fuzz.log  the -m gpu suite and one campaign of every GPU fuzzer (tools/fuzz_*.py)
 #   force_dist_bench.log          the default workload with the RCCL path forced on (world size 1)
 #   gemm_comparator.json          torch (hipBLASLt / rocBLAS) bf16 GEMM of the output-layer shape on the same box: measurement only
 # usage (through gpurun):  tools/profile_all.sh r02 ; results land in gpurun_out/<round>/ -> copy to profiles/<round>/
@@ -41,6 +42,7 @@ run_stats gmm --workload gmm --steps 50 --warmup 5 --no-cpu-baseline
 run_stats gmm-tied --workload gmm-tied --steps 20 --warmup 3
 run_stats nn --workload nn --steps 50 --warmup 5 --no-cpu-baseline
 run_stats mfcc-plp --workload mfcc --front-end plp --steps 8 --warmup 2 --no-cpu-baseline
+run_stats mfcc-mfplp --workload mfcc --front-end mfplp --steps 8 --warmup 2 --no-cpu-baseline
 run_stats mfcc-gammatone --workload mfcc --front-end gammatone --steps 3 --warmup 1 --no-cpu-baseline
 run_stats nn-bf16x3 --workload nn --precision bf16x3 --steps 30 --warmup 5 --no-cpu-baseline
 run_pmc pipeline fetch FETCH_SIZE -- --steps 3 --warmup 1
@@ -54,6 +56,7 @@ run_pmc gmm-tied sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE
 run_pmc gmm-tied fetch FETCH_SIZE -- --workload gmm-tied --steps 5 --warmup 2
 run_pmc gmm-tied write WRITE_SIZE -- --workload gmm-tied --steps 5 --warmup 2
 (cd $root && timeout 1500 python -m pytest tests -m gpu -q > $out/gpu_tests.log 2>&1)
+(cd $root && for f in "fuzz_frontends.py 300 31" "fuzz_scorers.py 300 32" "fuzz_gmm.py 200 33" "fuzz_tied.py 300 34" "fuzz_more.py 100 35" "fuzz_ffnn.py 60 36" "fuzz_backend.py 100 37"; do echo "== tools/$f"; timeout 900 python tools/$f 2>&1 | grep -v amdgpu.ids | tail -2; done > $out/gpu_fuzz.log 2>&1)
 AMX_BENCH_FORCE_DIST=1 python $root/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-configs 2>/dev/null | grep "^{\"metric\"" | tail -1 > $out/force_dist_bench.log
 python $root/tools/gemm_comparator.py > $out/gemm_comparator.json 2>/dev/null
 [ -x $root/tools/build/valu_rates ] && $root/tools/build/valu_rates > $out/valu_rates.log 2>&1
