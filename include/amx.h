@@ -429,6 +429,13 @@ int  amx_ffnn_output_dim(const amx_ffnn* h);
 /* feats [T x in0]; scores [T x out_last] = -(W x + b - alpha * log_prior) */
 int amx_ffnn_score(amx_ffnn* h, const float* feats_host, int T, float* scores_host);
 int amx_ffnn_score_dev(amx_ffnn* h, const float* feats_dev, int feats_stride, int T, float* scores_dev);
+/* Nn::NeuralNetworkForwardNode ("neural-network-forward", Nn/Module.cc:107, Nn/NeuralNetworkForwardNode.cc:140-180): the network's
+ * top-layer output per frame instead of a score.  AMX_NN_TOP_LINEAR: W x + b - alpha * log_prior (what a linear+softmax layer
+ * yields with evaluate-softmax = false; exactly -score).  AMX_NN_TOP_SOFTMAX: the layer's default -- Math::FastMatrix<f32>::softmax
+ * per frame (maximum, exp of the difference as ::exp(double) narrowed, sequential f32 sum, times (f32)1 / sum).  out [T x out_last]
+ * in the network's own output order: a handle created with class_to_output is refused. */
+enum { AMX_NN_TOP_LINEAR = 0, AMX_NN_TOP_SOFTMAX = 1 };
+int amx_ffnn_forward_dev(amx_ffnn* h, const float* feats_dev, int feats_stride, int T, float* out_dev, int top);
 /* Same, and additionally the per-epoch statistics of amx_stats_accumulate_dev for these frames: the arg-min over
  * the states is taken in the output layer's epilogue, so the [T x n_states] score matrix is written once and
  * never re-read.  best_state_dev nullable [T]. */

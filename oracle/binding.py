@@ -591,7 +591,7 @@ def ref_quantize(v):
     return int(R.ref_quantize_u8(float(np.float32(v))))
 
 
-def oracle_ffnn_score(Ws, biases, acts, feats, log_prior=None, prior_scale=1.0, acc64=False):
+def oracle_ffnn_score(Ws, biases, acts, feats, log_prior=None, prior_scale=1.0, acc64=False, top=None):
     """Ws[l]: [out,in] f32; returns scores [T,out_last] = -(Wx+b-alpha*logprior)."""
     L = Oracle()
     n = len(Ws)
@@ -608,8 +608,26 @@ def oracle_ffnn_score(Ws, biases, acts, feats, log_prior=None, prior_scale=1.0, 
     feats = np.ascontiguousarray(feats, dtype=np.float32)
     T = feats.shape[0]
     out = np.zeros((T, int(outd[-1])), np.float32)
-    L.orc_ffnn_score(C.byref(st), feats.reshape(-1), T, out.reshape(-1), int(acc64))
+    if top is None:
+        L.orc_ffnn_score(C.byref(st), feats.reshape(-1), T, out.reshape(-1), int(acc64))
+    else:
+        L.orc_ffnn_forward.argtypes = [C.c_void_p, f32p, C.c_int, f32p, C.c_int, C.c_int]
+        L.orc_ffnn_forward(C.byref(st), feats.reshape(-1), T, out.reshape(-1), int(top), int(acc64))
     return out
+
+
+def oracle_ffnn_forward(Ws, biases, acts, feats, top, log_prior=None, prior_scale=1.0, acc64=False):
+    """the forward node's output [T, out_last]: top 0 = W x + b - alpha log prior, 1 = its softmax (orc_ffnn_forward)"""
+    return oracle_ffnn_score(Ws, biases, acts, feats, log_prior, prior_scale, acc64, top=top)
+
+
+def oracle_softmax_rows(x):
+    """Math::FastMatrix<f32>::softmax per row (orc_softmax_rows)"""
+    L = Oracle()
+    y = np.ascontiguousarray(x, dtype=np.float32).copy()
+    L.orc_softmax_rows.argtypes = [f32p, C.c_int, C.c_int]
+    L.orc_softmax_rows(y.reshape(-1), y.shape[0], y.shape[1])
+    return y
 
 
 class GammatoneCfg(C.Structure):

@@ -220,6 +220,8 @@ typedef struct {
  * 2 = f32 fmaf chain in ascending k (bit pattern of an f32 MFMA / FMA GEMM). */
 float orc_activation(float v, int act); /* one activation value (ORC_ACT_*), as the layers apply it */
 void orc_ffnn_score(const orc_ffnn_model* m, const float* feats, int T, float* scores, int acc64);
+void orc_softmax_rows(float* x, int T, int n);
+void orc_ffnn_forward(const orc_ffnn_model* m, const float* feats, int T, float* out, int top, int acc64);
 
 #ifdef __cplusplus
 }

@@ -825,3 +825,40 @@ void orc_ffnn_score(const orc_ffnn_model* m, const float* feats, int T, float* s
     free(a);
     free(b);
 }
+
+/* Math::FastMatrix<f32>::softmax (Math/FastMatrix.hh:818-834) on every row of x [T x n] (a row = one frame = a column of the reference's
+ * activation matrix): maximum (FastVector::getMaxOfColumns: std::max_element), x + (-1 * max) (addToAllRows), exp() = mt_vr_exp
+ * (Math/FastVectorOperations.hh:57-63: ::exp(double) narrowed; pinned by ref_mt_vr_exp), the sequential f32 sum of
+ * FastVector::addSummedRows (Math/FastVector.hh:481-489), scal by (f32)1.0 / sum (divideColumnsByScalars).  PARITY UNPINNED as a
+ * whole (FastMatrix.hh needs the BLAS headers); the exponential is pinned. */
+void orc_softmax_rows(float* x, int T, int n) {
+    for (int t = 0; t < T; ++t) {
+        float* r  = x + (size_t)t * n;
+        float  mx = r[0];
+        for (int i = 1; i < n; ++i)
+            if (mx < r[i])
+                mx = r[i];
+        const float value = -1.f * mx;
+        for (int i = 0; i < n; ++i) {
+            float d = r[i] + value;
+            r[i]    = (float)exp((double)d);
+        }
+        float sum = 0.f;
+        for (int i = 0; i < n; ++i)
+            sum += 1.f * r[i];
+        const float inv = (float)1.0 / sum;
+        for (int i = 0; i < n; ++i)
+            r[i] = r[i] * inv;
+    }
+}
+
+/* Nn::NeuralNetworkForwardNode (Nn/NeuralNetworkForwardNode.cc:140-180): the top layer's output per frame -- the activation
+ * W x + b - alpha logPrior (top = 0; a linear+softmax layer with evaluate-softmax = false) or its softmax (top = 1, the default) */
+void orc_ffnn_forward(const orc_ffnn_model* m, const float* feats, int T, float* out, int top, int acc64) {
+    orc_ffnn_score(m, feats, T, out, acc64);
+    const int n = m->out_dim[m->n_layers - 1];
+    for (size_t i = 0; i < (size_t)T * n; ++i)
+        out[i] = -out[i];
+    if (top == 1)
+        orc_softmax_rows(out, T, n);
+}

@@ -446,6 +446,10 @@ class NnBatchFeatureScorer:
         """Nn::OnDemandFeatureScorer::forwardHiddenLayers for T frames: act_dev [T, hidden_dim] f32"""
         _lib.check(self.L.amx_ffnn_forward_hidden_dev(self.h, _ptr(feats_dev), feats_stride, T, _ptr(act_dev)))
 
+    def forward_dev(self, feats_dev, feats_stride, T, out_dev, top="softmax"):
+        """Nn::NeuralNetworkForwardNode: the top layer's output [T, out_last]; top "linear" (W x + b - alpha log prior) or "softmax"""
+        _lib.check(self.L.amx_ffnn_forward_dev(self.h, _ptr(feats_dev), feats_stride, T, _ptr(out_dev), {"linear": 0, "softmax": 1}[top]))
+
     def score_on_demand_dev(self, act_dev, n_pairs, frame_dev, emission_dev, scores_dev):
         """output layer for (frame, emission) pairs only: scores_dev [n_pairs]"""
         _lib.check(self.L.amx_ffnn_score_on_demand_dev(self.h, _ptr(act_dev), n_pairs, _ptr(frame_dev), _ptr(emission_dev), _ptr(scores_dev)))

@@ -14,6 +14,7 @@ AMX_GMM_MAX, AMX_GMM_SUM, AMX_GMM_BATCH_FLOAT, AMX_GMM_SIMD, AMX_GMM_BATCH_INT, 
 AMX_GMM_VITERBI, AMX_GMM_BAUM_WELCH = 0, 1
 AMX_ACT_NONE, AMX_ACT_RELU, AMX_ACT_SIGMOID, AMX_ACT_TANH = 0, 1, 2, 3
 AMX_PREC_FP32, AMX_PREC_BF16, AMX_PREC_BF16X3 = 0, 1, 2
+AMX_NN_TOP_LINEAR, AMX_NN_TOP_SOFTMAX = 0, 1
 AMX_ARCHIVE_READ, AMX_ARCHIVE_WRITE = 0, 1
 AMX_NORM_MEAN, AMX_NORM_MEAN_AND_VARIANCE = 0, 1
 
@@ -147,6 +148,7 @@ SIGNATURES = {
     "amx_ffnn_score_stats_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P, _P]),
     "amx_ffnn_hidden_dim": (C.c_int, [_P]),
     "amx_ffnn_forward_hidden_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
+    "amx_ffnn_forward_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_int]),
     "amx_ffnn_score_on_demand_dev": (C.c_int, [_P, _P, C.c_int, _P, _P, _P]),
     "amx_precomputed_score_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_float, _P]),
     "amx_class_labels_init": (C.c_int, [C.c_int, _P, C.c_int, _P, C.POINTER(C.c_int)]),

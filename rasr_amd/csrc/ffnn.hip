@@ -186,6 +186,65 @@ __global__ __launch_bounds__(256) void on_demand_kernel(const float* __restrict_
     }
 }
 
+// ---- Nn::NeuralNetworkForwardNode's top layer (Nn/NeuralNetworkForwardNode.cc:140-160: the node emits network_.getTopLayerOutput()).
+// The scorers keep LinearAndSoftmaxLayer's softmax switched off and negate; the node keeps it on (evaluate-softmax, default true,
+// Nn/LinearAndActivationLayer.cc:85-106).  Math::FastMatrix<f32>::softmax per frame (Math/FastMatrix.hh:818-834): maximum of the
+// column, x + (-1 * max), exp() = mt_vr_exp (::exp(double) narrowed, Math/FastVectorOperations.hh:57-63), the SEQUENTIAL f32 sum of
+// FastVector::addSummedRows (Math/FastVector.hh:481-489), scal by (f32)1.0 / sum.
+// top_negmax_kernel: one workgroup per frame; a = -score (the activation, exact), row maximum, e = exp(a - max) written in place.
+__global__ __launch_bounds__(256) void top_negexp_kernel(float* __restrict__ x, int n, float* __restrict__ g_max) {
+    __shared__ float s_red[4];
+    float*           row = x + (size_t)blockIdx.x * n;
+    float            mx  = -__builtin_inff();
+    for (int i = threadIdx.x; i < n; i += 256)
+        mx = fmaxf(mx, -row[i]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    if ((threadIdx.x & 63) == 0)
+        s_red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+    const float value = -1.f * mx;  // addToAllRows(tmp, -1): alpha * max, then elem + value
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float a = -row[i];
+        row[i]        = (float)exp((double)(a + value));
+    }
+    if (threadIdx.x == 0)
+        g_max[blockIdx.x] = mx;
+}
+
+// lane = frame: the reference's sequential f32 sum over the outputs, in output order; 64 x 64 tiles go through LDS so that the global
+// reads stay coalesced
+__global__ __launch_bounds__(64) void top_rowsum_kernel(const float* __restrict__ x, int T, int n, float* __restrict__ g_sum) {
+    __shared__ float s_tile[64][65];
+    const int        lane = threadIdx.x, t0 = blockIdx.x * 64;
+    float            acc = 0.f;
+    for (int c0 = 0; c0 < n; c0 += 64) {
+        const int w = min(64, n - c0);
+        for (int r = 0; r < 64; ++r)
+            s_tile[r][lane] = (t0 + r < T && lane < w) ? x[(size_t)(t0 + r) * n + c0 + lane] : 0.f;
+        __syncthreads();
+        for (int c = 0; c < w; ++c)
+            acc = acc + s_tile[lane][c];
+        __syncthreads();
+    }
+    if (t0 + lane < T)
+        g_sum[t0 + lane] = acc;
+}
+
+// elementwise tail: LINEAR negates the scores (activation = -score, exact), SOFTMAX multiplies by (f32)1.0 / sum (Math::scal)
+__global__ __launch_bounds__(256) void top_finish_kernel(float* __restrict__ x, long long total, int n, const float* __restrict__ g_sum) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        if (g_sum) {
+            const float r = 1.f / g_sum[i / n];
+            x[i]          = x[i] * r;
+        }
+        else
+            x[i] = -x[i];
+    }
+}
+
 // Nn::PrecomputedFeatureScorer::calculateScore (Nn/FeatureScorer.cc:291-310): the features ARE the network outputs:
 // score(e) = -x[out(e)] + alpha * logPrior[out(e)], Core::Type<f32>::max for a disregarded class.  HBM bound: one read, one write.
 __global__ __launch_bounds__(256) void precomputed_score_kernel(const float* __restrict__ x, int ldx, int T, int n_classes,
@@ -1112,6 +1171,9 @@ struct amx_ffnn {
     void*  d_in  = nullptr;      // packed input [cap_T x Kpad0]
     void*  d_act[2] = {nullptr, nullptr};
     std::vector<float> h_Wout, h_bout;  // output layer [n_emissions x K] f32 and its folded bias (on-demand scorer; uploaded on first use)
+    bool   class_mapped = false; // a class-label wrapper reordered the output layer (amx_ffnn_forward_dev wants the network's own order)
+    float* d_rowstat = nullptr;  // softmax top layer: per-frame maximum / sum [2][cap]
+    int    rowstat_cap = 0;
     float *d_Wout = nullptr, *d_bout = nullptr;
     float* d_z      = nullptr;   // bf16x3 mode: f32 pre-activations of the current hidden layer [cap_T x max_hidden_pad]
     std::vector<int> seg;        // bf16x3 mode: segment width of layer l's operands (Kpad of layer 0, Npad of the layer below otherwise)
@@ -1340,6 +1402,7 @@ int amx_ffnn_create(amx_ctx* ctx, const amx_ffnn_model* m, amx_ffnn** out) {
     std::vector<const float*> Wl(m->W, m->W + m->n_layers), bl(m->bias, m->bias + m->n_layers);
     const float*       prior = m->log_prior;
     std::vector<float> Wmap, bmap, pmap;
+    const bool class_mapped = m->class_to_output != nullptr;
     if (m->class_to_output) {
         AMX_REQUIRE(m->n_classes > 0, AMX_ERR_INVALID, "amx_ffnn_create: class_to_output without n_classes");
         const int N = m->out_dim[L0], K = m->in_dim[L0];
@@ -1379,6 +1442,7 @@ int amx_ffnn_create(amx_ctx* ctx, const amx_ffnn_model* m, amx_ffnn** out) {
     h->ctx       = ctx;
     h->n_layers  = m->n_layers;
     h->precision = m->precision;
+    h->class_mapped = class_mapped;
     if (const char* e = getenv("AMX_GEMM_CFG"))
         h->gemm_cfg = atoi(e);
     if (const char* e = getenv("AMX_FFNN_GRAPH"))
@@ -1502,6 +1566,7 @@ void amx_ffnn_destroy(amx_ffnn* h) {
     hipFree(h->d_z);
     hipFree(h->d_Wout);
     hipFree(h->d_bout);
+    hipFree(h->d_rowstat);
     hipFree(h->d_part_min);
     hipFree(h->d_part_idx);
     hipFree(h->d_host_f);
@@ -1777,6 +1842,38 @@ int amx_precomputed_score_dev(amx_ctx* ctx, const float* feats_dev, int feats_st
 
 int amx_ffnn_score_dev(amx_ffnn* h, const float* feats_dev, int feats_stride, int T, float* scores_dev) {
     return ffnn_score_impl(h, feats_dev, feats_stride, T, scores_dev, false, nullptr, nullptr, nullptr);
+}
+
+int amx_ffnn_forward_dev(amx_ffnn* h, const float* feats_dev, int feats_stride, int T, float* out_dev, int top) {
+    AMX_REQUIRE(h, AMX_ERR_INVALID, "amx_ffnn_forward_dev: NULL handle");
+    AMX_REQUIRE(top == AMX_NN_TOP_LINEAR || top == AMX_NN_TOP_SOFTMAX, AMX_ERR_INVALID, "amx_ffnn_forward_dev: unknown top layer mode %d", top);
+    AMX_REQUIRE(!h->class_mapped, AMX_ERR_INVALID,
+                "amx_ffnn_forward_dev: the handle carries a class-label mapping; the forward node emits the network's own outputs");
+    const int r = ffnn_score_impl(h, feats_dev, feats_stride, T, out_dev, false, nullptr, nullptr, nullptr);
+    if (r != AMX_OK || T == 0)
+        return r;
+    const int       n = h->out.back();
+    const long long total = (long long)T * n;
+    hipStream_t     st = h->ctx->stream;
+    amx::ScopedKernelTimer timer(h->ctx, "ffnn_top");
+    const int blocks = (int)std::min<long long>(16384, (total + 255) / 256);
+    if (top == AMX_NN_TOP_LINEAR) {
+        hipLaunchKernelGGL(amx::top_finish_kernel, dim3(blocks), dim3(256), 0, st, out_dev, total, n, (const float*)nullptr);
+        AMX_HIP(hipGetLastError());
+        return AMX_OK;
+    }
+    if (T > h->rowstat_cap) {
+        hipFree(h->d_rowstat);
+        h->d_rowstat   = nullptr;
+        h->rowstat_cap = 0;
+        AMX_HIP(hipMalloc((void**)&h->d_rowstat, (size_t)2 * T * 4));
+        h->rowstat_cap = T;
+    }
+    hipLaunchKernelGGL(amx::top_negexp_kernel, dim3(T), dim3(256), 0, st, out_dev, n, h->d_rowstat);
+    hipLaunchKernelGGL(amx::top_rowsum_kernel, dim3((T + 63) / 64), dim3(64), 0, st, out_dev, T, n, h->d_rowstat + h->rowstat_cap);
+    hipLaunchKernelGGL(amx::top_finish_kernel, dim3(blocks), dim3(256), 0, st, out_dev, total, n, (const float*)(h->d_rowstat + h->rowstat_cap));
+    AMX_HIP(hipGetLastError());
+    return AMX_OK;
 }
 
 int amx_ffnn_score_stats_dev(amx_ffnn* h, const float* feats_dev, int feats_stride, int T, float* scores_dev, uint32_t* best_state_dev,

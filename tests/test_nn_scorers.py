@@ -171,3 +171,56 @@ def test_precomputed_scorer_bit_exact(ctx):
         torch.cuda.synchronize()
         want = nn_scorers.precomputed_scores(x[:, :n_out], logp, 0.6, mp)
         assert np.array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32))
+
+
+# ---------------------------------------------------------------- neural-network-forward (the Flow node in front of the precomputed scorer)
+
+def test_oracle_softmax_rows_against_the_definition():
+    from oracle.binding import oracle_ffnn_forward, oracle_softmax_rows
+    rng = np.random.Generator(np.random.PCG64(61))
+    x = (rng.standard_normal((37, 301)) * 5).astype(np.float32)
+    y = oracle_softmax_rows(x)
+    e = np.exp(x.astype(np.float64) - x.max(1, keepdims=True))
+    assert np.allclose(y, e / e.sum(1, keepdims=True), rtol=2e-6, atol=1e-12)
+    assert np.allclose(y.sum(1), 1, atol=1e-5) and np.array_equal(y.argmax(1), x.argmax(1))
+    Ws, bs, acts, logp = synth.ffnn([12, 20, 9], seed=62)
+    f = feats(5, 12, 63)
+    from oracle import oracle_ffnn_score
+    lin = oracle_ffnn_forward(Ws, bs, acts, f, 0, log_prior=logp, prior_scale=0.7)
+    assert np.array_equal(lin, -oracle_ffnn_score(Ws, bs, acts, f, log_prior=logp, prior_scale=0.7))
+    assert np.array_equal(oracle_ffnn_forward(Ws, bs, acts, f, 1, log_prior=logp, prior_scale=0.7).view(np.uint32), oracle_softmax_rows(lin).view(np.uint32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-5), ("bf16x3", 1e-4), ("bf16", 5e-2)])
+def test_forward_node_outputs(ctx, precision, tol):
+    """amx_ffnn_forward_dev: the linear top layer is exactly the negated score; the softmax of THOSE activations is bit-identical to the
+    oracle's restatement of FastMatrix::softmax (maximum, f64 exponential narrowed, sequential f32 sum, reciprocal multiply); against the
+    oracle's own forward pass the outputs agree to the precision of the GEMM path; a handle with a class mapping is refused"""
+    import torch
+
+    import rasr_amd
+    from oracle.binding import oracle_ffnn_forward, oracle_softmax_rows
+    dims = [40, 96, 64, 257]
+    Ws, bs, acts, logp = synth.ffnn(dims, seed=71)
+    nn = rasr_amd.NnBatchFeatureScorer(ctx, Ws, bs, acts, log_prior=logp, priori_scale=0.8, precision=precision)
+    ctx.use_torch_stream()
+    for T in (1, 77, 300):
+        x = feats(T, 40, 72 + T)
+        xd = torch.from_numpy(x).cuda()
+        sc = torch.empty((T, 257), dtype=torch.float32, device="cuda")
+        lin = torch.empty((T, 257), dtype=torch.float32, device="cuda")
+        sm = torch.empty((T, 257), dtype=torch.float32, device="cuda")
+        nn.score_dev(xd, 40, T, sc)
+        nn.forward_dev(xd, 40, T, lin, top="linear")
+        nn.forward_dev(xd, 40, T, sm, top="softmax")
+        torch.cuda.synchronize()
+        a = lin.cpu().numpy()
+        assert np.array_equal(a.view(np.uint32), (-sc.cpu().numpy()).view(np.uint32))
+        assert np.array_equal(sm.cpu().numpy().view(np.uint32), oracle_softmax_rows(a).view(np.uint32))
+        want = oracle_ffnn_forward(Ws, bs, acts, x, 1, log_prior=logp, prior_scale=0.8, acc64=True)
+        assert np.all(np.abs(sm.cpu().numpy() - want) <= tol * np.abs(want) + tol * 1e-2)
+    mapping, _ = rasr_amd.class_labels_init(258, (3,))
+    mapped = rasr_amd.NnBatchFeatureScorer(ctx, Ws, bs, acts, log_prior=logp, precision=precision, class_to_output=mapping)
+    with pytest.raises(rasr_amd.AmxError, match="class-label mapping"):
+        mapped.forward_dev(xd, 40, T, torch.empty((T, 258), dtype=torch.float32, device="cuda"))
