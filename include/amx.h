@@ -158,6 +158,18 @@ long amx_mfcc_plan_total_frames(const amx_mfcc_plan* p);
 int  amx_mfcc_plan_frame_offsets(const amx_mfcc_plan* p, long* frame_offsets /*[n_seg+1]*/);
 int  amx_mfcc_run_plan_dev(amx_mfcc* h, const amx_mfcc_plan* p, const float* pcm_dev, float* ceps_dev);
 
+/* ------------------------------------------------------------------ sample stream in front of the feature chains (samples.flow)
+ * signal-dc-detection (Signal::DcDetection, src/Signal/DcDetection.cc:90-235): a host-side scan over one segment's samples that tells
+ * the caller which sample ranges reach the feature chain.  Runs of at least min-dc-length seconds whose samples stay within
+ * max-dc-increment of the last accepted sample are dropped, and so are non-DC stretches shorter than min-non-dc-segment-length (node
+ * defaults .0125 / 0.9 / .02, maximal-output-size 4096; samples.flow uses .0125 / 0.9 / .026).  max_dc_increment = 0 disables the
+ * detection (every sample is accepted).  Output: the node's blocks as (first sample, length) in stream order -- merge = 0: exactly
+ * the vectors the node emits; merge = 1: neighbouring blocks without a time gap joined, i.e. the ranges the window buffer behind it
+ * frames without an intermediate flush (one entry of an amx_mfcc_plan's sample_offsets each).  starts / lengths may be NULL to count. */
+int amx_dc_detection(const float* pcm, long long n_samples, double sample_rate, double min_dc_length_s, float max_dc_increment,
+                     double min_non_dc_segment_length_s, int maximal_output_size, int merge, long long* starts, long long* lengths,
+                     long long capacity, long long* n_blocks);
+
 /* ------------------------------------------------------------------ gammatone front-end
  * The three nodes of Signal/Module.cc:169-173 -- signal-gammatone (Signal/GammaTone.cc:20-231), signal-temporalintegration
  * (Signal/TemporalIntegration.cc:60-84 over Signal/TimeWindowBuffer.cc:52-125) and signal-spectralintegration

@@ -653,6 +653,22 @@ def oracle_activation(x, act):
     return np.array([L.orc_activation(float(v), act) for v in np.asarray(x, np.float32).ravel()], np.float32)
 
 
+def oracle_dc_detection(pcm, block=4096, sample_rate=16000.0, min_dc_length=0.0125, max_dc_increment=0.9, min_non_dc_segment_length=0.02,
+                        maximal_output_size=4096):
+    """signal-dc-detection: [(first sample, length)] of the vectors the node emits for one segment fed in vectors of `block` samples"""
+    L = Oracle()
+    x = np.ascontiguousarray(pcm, dtype=np.float32)
+    L.orc_dc_detection.restype = C.c_longlong
+    L.orc_dc_detection.argtypes = [C.c_void_p, C.c_longlong, C.c_longlong, C.c_double, C.c_double, C.c_float, C.c_double, C.c_int, C.c_void_p,
+                                   C.c_void_p, C.c_longlong]
+    args = (x.ctypes.data if len(x) else None, len(x), block, sample_rate, min_dc_length, max_dc_increment, min_non_dc_segment_length,
+            maximal_output_size)
+    n = L.orc_dc_detection(*args, None, None, 0)
+    st, ln = np.zeros(n, np.int64), np.zeros(n, np.int64)
+    L.orc_dc_detection(*args, st.ctypes.data, ln.ctypes.data, n)
+    return list(zip(st.tolist(), ln.tolist()))
+
+
 def oracle_time_window_frames(n, length, shift):
     """(starts, lens) of the frames signal-temporalintegration cuts out of n samples (orc_time_window_frames)"""
     L = Oracle()

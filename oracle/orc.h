@@ -120,6 +120,8 @@ const float*   orc_gammatone_center_frequencies(const orc_gammatone* h);
 const float*   orc_gammatone_coefficients(const orc_gammatone* h); /* [channels][4] a0 a1 b1 b2 */
 long           orc_gammatone_n_frames(const orc_gammatone* h, long n_samples);
 long           orc_time_window_frames(long n, int length, int shift, long* starts, int* lens, long cap);
+long long      orc_dc_detection(const float* pcm, long long n, long long block, double sample_rate, double min_dc_length_s, float max_dc_increment,
+                                double min_non_dc_segment_length_s, int maximal_output_size, long long* starts, long long* lens, long long cap);
 /* filtered [n_samples x channels] (nullable): the signal-gammatone output; out [n_frames x n_out] */
 long           orc_gammatone_run(const orc_gammatone* h, const float* pcm, long n_samples, float* filtered, float* out);
 

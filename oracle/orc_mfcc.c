@@ -690,3 +690,95 @@ int orc_mfcc_stages(const orc_mfcc* h, const float* pcm, long n_samples, long fr
     free(pre);
     return 0;
 }
+
+/* ------------------------------------------------------------------ signal-dc-detection (samples.flow)
+ * Signal::DcDetection (Signal/DcDetection.cc:90-235, DcDetection.hh:75-84) kept literal: a sample buffer with the three counters,
+ * put / get / flush driven like SlidingAlgorithmNode::work (get until it fails, then the next input block, flush at end of
+ * stream).  `block` = size of the input vectors (the result must not depend on it).  Blocks are reported as (first sample, length).
+ * PARITY UNPINNED: DcDetection.cc includes the Flow node headers (boost); nothing in the reference's tests exercises it. */
+typedef struct {
+    const float* x;     /* the whole segment; buffer_ = x[base .. have) */
+    long long    base, have;
+    unsigned     minDc, minSeg, maxOut;
+    float        maxInc;
+    unsigned long long nonDc, dc, segLen;
+} orc_dcd;
+
+static int orc_dcd_next_block(orc_dcd* s) {
+    while ((long long)(s->nonDc + s->dc) < s->have - s->base) {
+        float v = s->x[s->base + s->nonDc + s->dc], ref = s->x[s->base + s->nonDc - 1];
+        if (fabs(v - ref) >= s->maxInc) { /* isNonDC */
+            if (s->dc >= s->minDc)
+                return 1;
+            s->nonDc += s->dc;
+            s->dc = 0;
+            unsigned lim = s->minSeg > s->maxOut ? s->minSeg : s->maxOut;
+            if (s->nonDc >= lim)
+                return 1;
+            s->nonDc++;
+        }
+        else
+            s->dc++;
+    }
+    return 0;
+}
+
+static int orc_dcd_flush_block(orc_dcd* s, long long* starts, long long* lens, long long cap, long long* count) {
+    int result = 0;
+    if ((s->segLen += s->nonDc) >= s->minSeg) { /* copyBlock */
+        if (*count < cap && starts) {
+            starts[*count] = s->base;
+            lens[*count]   = (long long)s->nonDc;
+        }
+        ++*count;
+        result = 1;
+    }
+    if (s->dc > 0)
+        s->segLen = 0;
+    s->base += (long long)(s->nonDc + s->dc); /* eraseBlock */
+    s->nonDc = 1;
+    s->dc    = 0;
+    return result;
+}
+
+long long orc_dc_detection(const float* pcm, long long n, long long block, double sample_rate, double min_dc_length_s, float max_dc_increment,
+                           double min_non_dc_segment_length_s, int maximal_output_size, long long* starts, long long* lens, long long cap) {
+    orc_dcd s = {pcm, 0, 0, (unsigned)rint(min_dc_length_s * sample_rate), (unsigned)rint(min_non_dc_segment_length_s * sample_rate),
+                 (unsigned)maximal_output_size, max_dc_increment, 1, 0, 0};
+    long long count = 0;
+    int       eos = 0;
+    if (block < 1)
+        block = 1;
+    for (;;) {
+        /* get(): do { if (!nextBlock()) return false; } while (!flushBlock(out)); */
+        int got = 0;
+        for (;;) {
+            if (!orc_dcd_next_block(&s))
+                break;
+            if (orc_dcd_flush_block(&s, starts, lens, cap, &count)) {
+                got = 1;
+                break;
+            }
+        }
+        if (got)
+            continue;
+        if (s.have < n) { /* put the next input vector */
+            s.have = s.have + block < n ? s.have + block : n;
+            continue;
+        }
+        if (eos)
+            break;
+        /* flush(): lastBlock + flushBlock, once per stream */
+        if (s.have - s.base > 0) {
+            if (s.dc < s.minDc) {
+                s.nonDc += s.dc;
+                s.dc = 0;
+            }
+            orc_dcd_flush_block(&s, starts, lens, cap, &count);
+        }
+        eos = 1;
+        if (s.have - s.base <= 0)
+            break;
+    }
+    return count;
+}

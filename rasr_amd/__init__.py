@@ -463,6 +463,21 @@ class NnBatchFeatureScorer:
                                                    _ptr(counts), _ptr(score_sum)))
 
 
+def dc_detection(pcm, sample_rate=16000.0, min_dc_length=0.0125, max_dc_increment=0.9, min_non_dc_segment_length=0.02, maximal_output_size=4096,
+                 merge=False):
+    """signal-dc-detection over one segment (host): [(first sample, length)] of the blocks the node lets through; merge=True joins blocks
+    without a gap (the ranges to frame separately)"""
+    x = np.ascontiguousarray(pcm, dtype=np.float32)
+    L = _lib.lib()
+    n = C.c_longlong(0)
+    args = (x.ctypes.data if len(x) else None, len(x), float(sample_rate), float(min_dc_length), float(max_dc_increment),
+            float(min_non_dc_segment_length), int(maximal_output_size), int(merge))
+    _lib.check(L.amx_dc_detection(*args, None, None, 0, C.byref(n)))
+    st, ln = np.zeros(n.value, np.int64), np.zeros(n.value, np.int64)
+    _lib.check(L.amx_dc_detection(*args, st.ctypes.data, ln.ctypes.data, n.value, C.byref(n)))
+    return list(zip(st.tolist(), ln.tolist()))
+
+
 def class_labels_init(n_classes, disregard=()):
     """Nn::ClassLabelWrapper::initMapping: (mapping int32[n_classes], number of classes to accumulate)"""
     dis = np.ascontiguousarray(list(disregard), dtype=np.int32)

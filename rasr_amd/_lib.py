@@ -147,6 +147,7 @@ SIGNATURES = {
     "amx_ffnn_score_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
     "amx_ffnn_score_stats_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P, _P]),
     "amx_ffnn_hidden_dim": (C.c_int, [_P]),
+    "amx_dc_detection": (C.c_int, [_P, C.c_longlong, C.c_double, C.c_double, C.c_float, C.c_double, C.c_int, C.c_int, _P, _P, C.c_longlong, _P]),
     "amx_ffnn_forward_hidden_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
     "amx_ffnn_forward_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_int]),
     "amx_ffnn_score_on_demand_dev": (C.c_int, [_P, _P, C.c_int, _P, _P, _P]),

@@ -256,3 +256,61 @@ def test_prior_from_mixture_set():
     want = np.log((pri / obs).astype(np.float32)).astype(np.float32)
     assert np.allclose(got, want, rtol=0, atol=2e-7)
     assert abs(np.exp(got.astype(np.float64)).sum() - 1) < 1e-5
+
+
+# ------------------------------------------------------------------ signal-dc-detection (host code, no GPU)
+
+def _dc_signal(rng, n):
+    """noise with planted constant runs (some longer, some shorter than min-dc-length), near-constant stretches inside the increment,
+    and short bursts between two DC runs"""
+    x = (rng.standard_normal(n) * rng.choice([30.0, 3000.0])).astype(np.float32)
+    for _ in range(int(rng.integers(0, 8))):
+        a = int(rng.integers(0, max(1, n - 1)))
+        ln = int(rng.choice([5, 150, 199, 200, 201, 400, 3000, 9000]))
+        kind = int(rng.integers(0, 3))
+        seg = slice(a, min(n, a + ln))
+        if kind == 0:
+            x[seg] = np.float32(rng.choice([0.0, -32768.0, 32767.0, 12.5]))
+        elif kind == 1:
+            x[seg] = np.float32(100.0) + (rng.uniform(-0.4, 0.4, seg.stop - seg.start)).astype(np.float32)     # within the increment
+        else:
+            x[seg] = 0.0
+            b = min(n, a + ln // 2)
+            e = min(n, b + int(rng.integers(1, 300)))
+            if b < e:
+                x[b:e] = (rng.standard_normal(e - b) * 500).astype(np.float32)
+    return x
+
+
+def test_dc_detection_matches_the_restatement_and_its_definition():
+    """amx_dc_detection against the oracle's literal transcription of Signal::DcDetection (any input vector size gives the same blocks),
+    and against what the node documents: accepted blocks are disjoint and ordered, never longer than max(min segment, maximal output
+    size) + a DC hypothesis shorter than min-dc-length, dropped stretches are DC runs or short segments, noise passes untouched"""
+    import rasr_amd
+    from oracle.binding import oracle_dc_detection
+    rng = np.random.Generator(np.random.PCG64(81))
+    for case in range(120):
+        n = int(rng.choice([0, 1, 2, 199, 200, 201, 321, 5000, 40000]))
+        fs = float(rng.choice([8000.0, 16000.0]))
+        x = _dc_signal(rng, n) if n else np.zeros(0, np.float32)
+        kw = dict(sample_rate=fs, min_dc_length=float(rng.choice([0.0125, 0.005, 0.0])), max_dc_increment=float(rng.choice([0.9, 0.0, 5.0])),
+                  min_non_dc_segment_length=float(rng.choice([0.02, 0.026, 0.0])), maximal_output_size=int(rng.choice([4096, 256, 1])))
+        got = rasr_amd.dc_detection(x, **kw)
+        for block in (4096, 1000, 1, int(rng.integers(1, 5000))):
+            assert got == oracle_dc_detection(x, block=block, **kw), (case, n, kw, block)
+        pos = 0
+        for s, l in got:
+            assert s >= pos and l >= 1 and s + l <= n
+            pos = s + l
+        merged = rasr_amd.dc_detection(x, merge=True, **kw)
+        assert sum(l for _, l in merged) == sum(l for _, l in got)
+        assert all(a[0] + a[1] < b[0] for a, b in zip(merged, merged[1:]))            # a real gap between two merged ranges
+    x = (rng.standard_normal(50000) * 3000).astype(np.float32)
+    assert rasr_amd.dc_detection(x, merge=True) == [(0, 50000)]                      # nothing to drop
+    x[10000:10400] = 7.0
+    assert rasr_amd.dc_detection(x, merge=True) == [(0, 10001), (10400, 39600)]      # the first constant sample still differs from its predecessor
+    x[10400:10500] = (rng.standard_normal(100) * 3000).astype(np.float32)
+    x[10500:11000] = -3.0                                                            # 100 samples between two DC runs: shorter than 20 ms
+    assert rasr_amd.dc_detection(x, merge=True) == [(0, 10001), (11000, 39000)]
+    assert rasr_amd.dc_detection(np.zeros(5000, np.float32)) == []                   # digital silence: one sample + a DC run, too short to keep
+    assert rasr_amd.dc_detection(np.zeros(5000, np.float32), max_dc_increment=0.0, merge=True) == [(0, 5000)]    # detection disabled
