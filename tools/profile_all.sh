@@ -49,6 +49,8 @@ run_pmc pipeline fetch FETCH_SIZE -- --steps 3 --warmup 1
 run_pmc pipeline write WRITE_SIZE -- --steps 3 --warmup 1
 run_pmc mfcc fetch FETCH_SIZE -- --workload mfcc --steps 3 --warmup 1
 run_pmc mfcc write WRITE_SIZE -- --workload mfcc --steps 3 --warmup 1
+run_pmc mfcc sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_LDS -- --workload mfcc --steps 3 --warmup 1
+run_pmc mfcc sq2 SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_MFMA SQ_ACTIVE_INST_ANY -- --workload mfcc --steps 3 --warmup 1
 run_pmc nn-pipeline mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_MFMA -- --workload nn-pipeline --steps 3 --warmup 1
 run_pmc gmm-train sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES -- --workload gmm-train --steps 3 --warmup 1
 run_pmc gmm-train sq2 SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD -- --workload gmm-train --steps 3 --warmup 1
