@@ -231,20 +231,10 @@ __global__ __launch_bounds__(mfcc_waves(NC) * 64, (NC >= 1024 ? 1 : 4)) void mfc
                 if (j < NC / 4) {
                     float2 x[4];
                     float  xm[4], x0[4], x1[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {  // samples 2c - 1, 2c, 2c + 1 of the frame (zero beyond the segment and the window)
-                        const int       c = j + r * (NC / 4);
-                        const long long n = fbase + 2 * c;
-                        const bool      w = 2 * c < p.frame_len;
-                        x0[r]             = (w && n < nseg) ? seg[n] : 0.f;
-                        x1[r]             = (w && n + 1 < nseg) ? seg[n + 1] : 0.f;
-                        xm[r]             = (w && n < nseg) ? seg[n > 0 ? n - 1 : 0] : 0.f;  // segment start: previous_ = x[0]
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int       c = j + r * (NC / 4);
-                        const long long n = fbase + 2 * c;
-                        float           y0, y1;
+                    // a frame that lies inside its segment with a predecessor sample (all but the first and the last few of a segment:
+                    // wave-uniform) needs none of the per-sample segment guards -- 64-bit compares and selects on twelve loads
+                    const bool inner = fbase >= 1 && fbase + p.frame_len < nseg;
+                    auto       emphasise = [&](int r, float& y0, float& y1) {
                         if (alpha1) {  // Signal/Preemphasis.cc:69-75
                             y0 = x0[r] - xm[r];
                             y1 = x1[r] - x0[r];
@@ -254,9 +244,44 @@ __global__ __launch_bounds__(mfcc_waves(NC) * 64, (NC >= 1024 ? 1 : 4)) void mfc
                             y0             = x0[r] - p0;
                             y1             = x1[r] - p1;
                         }
-                        y0   = n < nseg ? y0 : 0.f;  // zero padding behind the segment (short last frames)
-                        y1   = n + 1 < nseg ? y1 : 0.f;
-                        x[r] = make_float2(wlo[b][r] * y0, whi[b][r] * y1);  // WindowFunction::work
+                    };
+                    if (inner) {
+                        const float* fr = seg + fbase;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int  c = j + r * (NC / 4);
+                            const bool w = 2 * c < p.frame_len;
+                            x0[r]        = w ? fr[2 * c] : 0.f;
+                            x1[r]        = w ? fr[2 * c + 1] : 0.f;   // 2c + 1 <= frame_len: still inside the segment
+                            xm[r]        = w ? fr[2 * c - 1] : 0.f;
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float y0, y1;
+                            emphasise(r, y0, y1);
+                            x[r] = make_float2(wlo[b][r] * y0, whi[b][r] * y1);  // WindowFunction::work
+                        }
+                    }
+                    else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {  // samples 2c - 1, 2c, 2c + 1 of the frame (zero beyond the segment and the window)
+                            const int       c = j + r * (NC / 4);
+                            const long long n = fbase + 2 * c;
+                            const bool      w = 2 * c < p.frame_len;
+                            x0[r]             = (w && n < nseg) ? seg[n] : 0.f;
+                            x1[r]             = (w && n + 1 < nseg) ? seg[n + 1] : 0.f;
+                            xm[r]             = (w && n < nseg) ? seg[n > 0 ? n - 1 : 0] : 0.f;  // segment start: previous_ = x[0]
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int       c = j + r * (NC / 4);
+                            const long long n = fbase + 2 * c;
+                            float           y0, y1;
+                            emphasise(r, y0, y1);
+                            y0   = n < nseg ? y0 : 0.f;  // zero padding behind the segment (short last frames)
+                            y1   = n + 1 < nseg ? y1 : 0.f;
+                            x[r] = make_float2(wlo[b][r] * y0, whi[b][r] * y1);
+                        }
                     }
                     const float2 a  = make_float2(x[0].x + x[2].x, x[0].y + x[2].y);
                     const float2 bb = make_float2(x[0].x - x[2].x, x[0].y - x[2].y);
