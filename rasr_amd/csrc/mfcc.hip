@@ -418,8 +418,20 @@ __global__ __launch_bounds__(mfcc_waves(NC) * 64, (NC >= 1024 ? 1 : 4)) void mfc
         const float* w   = s_fw + s_fo[flt] - b0;
         const float* amp = s_amp + f * L.amp_ld;
         float        acc = 0.f;
+        // four bins per trip (the same ascending-bin f32 sum): the one-bin loop spent eight of its ten instructions on LDS addressing,
+        // the wait and the loop itself
+        int b = b0;
         if (p.front_end) {  // mfplp.flow: generic-vector-f32-power 2 in front of the filter bank ((f32)pow((f64)x, 2.0) = x * x rounded once)
-            for (int b = b0; b < b1; ++b) {
+            for (; b + 4 <= b1; b += 4) {
+                const float a0 = amp[b], a1 = amp[b + 1], a2 = amp[b + 2], a3 = amp[b + 3];
+                const float w0 = w[b], w1 = w[b + 1], w2 = w[b + 2], w3 = w[b + 3];
+                const float q0 = (a0 * a0) * w0, q1 = (a1 * a1) * w1, q2 = (a2 * a2) * w2, q3 = (a3 * a3) * w3;
+                acc            = acc + q0;
+                acc            = acc + q1;
+                acc            = acc + q2;
+                acc            = acc + q3;
+            }
+            for (; b < b1; ++b) {
                 const float a    = amp[b];
                 const float pw   = a * a;
                 const float prod = pw * w[b];
@@ -427,7 +439,14 @@ __global__ __launch_bounds__(mfcc_waves(NC) * 64, (NC >= 1024 ? 1 : 4)) void mfc
             }
         }
         else {
-            for (int b = b0; b < b1; ++b) {
+            for (; b + 4 <= b1; b += 4) {
+                const float q0 = amp[b] * w[b], q1 = amp[b + 1] * w[b + 1], q2 = amp[b + 2] * w[b + 2], q3 = amp[b + 3] * w[b + 3];
+                acc            = acc + q0;
+                acc            = acc + q1;
+                acc            = acc + q2;
+                acc            = acc + q3;
+            }
+            for (; b < b1; ++b) {
                 float prod = amp[b] * w[b];
                 acc        = acc + prod;
             }
