@@ -259,6 +259,16 @@ int amx_normalize_ex_dev(amx_ctx* ctx, const amx_mfcc_plan* plan, const float* i
 enum { AMX_VNORM_AMPLITUDE_SPECTRUM_ENERGY = 0, AMX_VNORM_ENERGY = 1, AMX_VNORM_MAXIMUM = 2, AMX_VNORM_MEAN_ENERGY = 3, AMX_VNORM_MEAN = 4,
        AMX_VNORM_VARIANCE = 5 };
 int amx_vector_normalize_dev(amx_ctx* ctx, int type, const float* in_dev, int in_ld, long n_vectors, int dim, float* out_dev, int out_ld);
+/* generic-vector-f32-<function> (Flow::SimpleFunctionNode over src/Flow/SimpleFunction.hh:40-345; e.g. the x 500 scaling and the
+ * quantisation of mfcc.standard_system.flow, the power nodes of mfplp.flow): one parameter, every element on its own.  Addition,
+ * multiplication, quantize (rint(v / p) * p; rint(v) for p = 1 or 0), abs, minimum, maximum, sqrt and power (the node's unqualified
+ * pow on floats = ::pow(double, double) narrowed) follow the reference's arithmetic exactly; log (log10), log-plus (log10(v + p)), ln,
+ * exp and cos are the device's f32 functions, a few ulp from glibc's.  Views and in-place rule as for amx_vector_normalize_dev. */
+enum { AMX_VFUNC_LOG = 0, AMX_VFUNC_LOG_PLUS = 1, AMX_VFUNC_LN = 2, AMX_VFUNC_EXP = 3, AMX_VFUNC_POWER = 4, AMX_VFUNC_SQRT = 5, AMX_VFUNC_COS = 6,
+       AMX_VFUNC_ADDITION = 7, AMX_VFUNC_MULTIPLICATION = 8, AMX_VFUNC_QUANTIZE = 9, AMX_VFUNC_ABS = 10, AMX_VFUNC_MINIMUM = 11,
+       AMX_VFUNC_MAXIMUM = 12 };
+int amx_vector_function_dev(amx_ctx* ctx, int kind, float parameter, const float* in_dev, int in_ld, long n_vectors, int dim, float* out_dev,
+                            int out_ld);
 /* signal-delay (max-size = 2*right+1, margin-policy copy, margin-condition present-not-empty; src/Signal/Delay.hh:33-47)
  * + signal-regression order 1 or 2 (src/Signal/Regression.cc:25-68), as wired in derivationWithRegression.flow. */
 int amx_regression_dev(amx_ctx* ctx, const amx_mfcc_plan* plan, const float* in_dev, int in_ld, int dim, int order,

@@ -653,6 +653,16 @@ def oracle_activation(x, act):
     return np.array([L.orc_activation(float(v), act) for v in np.asarray(x, np.float32).ravel()], np.float32)
 
 
+def oracle_vector_function(x, kind, parameter=0.0):
+    """generic-vector-f32-<function> elementwise (orc_vector_function); kind: index of AMX_VFUNC_*"""
+    L = Oracle()
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    y = np.zeros_like(x)
+    L.orc_vector_function.argtypes = [C.c_int, C.c_float, f32p, C.c_long, C.c_int, f32p]
+    L.orc_vector_function(int(kind), float(parameter), x.reshape(-1), x.shape[0], x.shape[1], y.reshape(-1))
+    return y
+
+
 def oracle_dc_detection(pcm, block=4096, sample_rate=16000.0, min_dc_length=0.0125, max_dc_increment=0.9, min_non_dc_segment_length=0.02,
                         maximal_output_size=4096):
     """signal-dc-detection: [(first sample, length)] of the vectors the node emits for one segment fed in vectors of `block` samples"""

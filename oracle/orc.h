@@ -235,5 +235,6 @@ void orc_normalize_ex(const float* in, int n, int dim, int type, int level, int 
 void orc_regression(const float* in, int n, int dim, int order, int right, float* out);
 void orc_matrix_multiply(const float* M, int rows, int cols, const float* in, int T, float* out);
 void orc_vector_normalize(int type, const float* in, int n, int dim, float* out);
+void orc_vector_function(int kind, float prm, const float* in, long n, int dim, float* out);
 
 #endif

@@ -281,3 +281,29 @@ void orc_vector_normalize(int type, const float* in, int n, int dim, float* out)
         }
     }
 }
+
+/* generic-vector-f32-<function> (Flow/SimpleFunction.hh:40-345), kinds as AMX_VFUNC_*.  Overloads as the header resolves them: the
+ * vector forms of log / ln / exp / sqrt / cos cast std::log10 etc. to T (*)(T) -> the float functions; log-plus, power and quantize
+ * call the unqualified log10 / pow / rint on floats -> the double functions, narrowed on assignment (checked for pow with g++ on
+ * the reference's headers, see orc_mfcc.c).  PARITY UNPINNED (SimpleFunction.hh includes Flow/Node.hh). */
+void orc_vector_function(int kind, float prm, const float* in, long n, int dim, float* out) {
+    for (long i = 0; i < n * dim; ++i) {
+        float v = in[i], y;
+        switch (kind) {
+            case 0: y = log10f(v); break;
+            case 1: y = (float)log10((double)(v + prm)); break;
+            case 2: y = logf(v); break;
+            case 3: y = expf(v); break;
+            case 4: y = (float)pow((double)v, (double)prm); break;
+            case 5: y = sqrtf(v); break;
+            case 6: y = cosf(v); break;
+            case 7: y = v + prm; break;
+            case 8: y = v * prm; break;
+            case 9: y = (prm == 1.0f || prm == 0.0f) ? (float)rint((double)v) : (float)(rint((double)(v / prm)) * (double)prm); break;
+            case 10: y = fabsf(v); break;
+            case 11: y = prm < v ? prm : v; break;
+            default: y = v < prm ? prm : v; break;
+        }
+        out[i] = y;
+    }
+}

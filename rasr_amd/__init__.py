@@ -105,6 +105,13 @@ class Context:
         """signal-vector-f32-<kind>-normalization on [n x dim] device views (in place on the identical view is allowed)"""
         _lib.check(self.L.amx_vector_normalize_dev(self.h, self.VECTOR_NORMALIZATIONS[kind], _ptr(feats), in_ld, n, dim, _ptr(out), out_ld))
 
+    VECTOR_FUNCTIONS = {"log": 0, "log-plus": 1, "ln": 2, "exp": 3, "power": 4, "sqrt": 5, "cos": 6, "addition": 7, "multiplication": 8,
+                        "quantize": 9, "abs": 10, "minimum": 11, "maximum": 12}
+
+    def vector_function(self, kind, parameter, feats, in_ld, n, dim, out, out_ld):
+        """generic-vector-f32-<kind> on [n, dim] device views (row strides in_ld / out_ld)"""
+        _lib.check(self.L.amx_vector_function_dev(self.h, self.VECTOR_FUNCTIONS[kind], float(parameter), _ptr(feats), in_ld, n, dim, _ptr(out), out_ld))
+
     def regression(self, plan, feats, in_ld, dim, out, out_ld, order=1, right=2):
         """signal-delay (copy margin) + signal-regression of the given order over 2 * right + 1 frames"""
         _lib.check(self.L.amx_regression_dev(self.h, plan.h, _ptr(feats), in_ld, dim, order, right, _ptr(out), out_ld))

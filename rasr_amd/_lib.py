@@ -113,6 +113,7 @@ SIGNATURES = {
     "amx_normalize_dev": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int]),
     "amx_normalize_ex_dev": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int]),
     "amx_vector_normalize_dev": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_long, C.c_int, _P, C.c_int]),
+    "amx_vector_function_dev": (C.c_int, [_P, C.c_int, C.c_float, _P, C.c_int, C.c_long, C.c_int, _P, C.c_int]),
     "amx_regression_dev": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int]),
     "amx_matrix_multiply_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_int, C.c_int, _P, C.c_int]),
     "amx_gmm_create": (C.c_int, [_P, C.POINTER(GmmModel), C.POINTER(_P)]),

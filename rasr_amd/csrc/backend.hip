@@ -226,6 +226,40 @@ __global__ __launch_bounds__(256) void matrix_multiply_kernel(const float* __res
 
 }  // namespace amx
 
+// generic-vector-f32-{log, log-plus, ln, exp, power, sqrt, cos, addition, multiplication, quantize, abs, minimum, maximum}
+// (Flow/SimpleFunction.hh:40-345): one element per thread.  The arithmetic ones are exact; log / ln / exp / cos are the device's f32
+// functions (the reference calls std::log10 / std::log / std::exp / std::cos on floats: glibc's, a few ulp apart); power is the
+// unqualified pow on floats = ::pow(double, double) narrowed (see power_node in mfcc.hip), quantize is rint(v / p) * p with the
+// unqualified rint on a float = ::rint(double).
+__global__ __launch_bounds__(256) void vector_function_kernel(const float* __restrict__ in, int in_ld, long long n, int dim, int kind, float prm,
+                                                             float* __restrict__ out, int out_ld) {
+    const long long total = n * dim;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long r = i / dim;
+        const int       c = (int)(i - r * dim);
+        const float     v = in[r * in_ld + c];
+        float           y;
+        switch (kind) {
+            case AMX_VFUNC_LOG: y = log10f(v); break;
+            case AMX_VFUNC_LOG_PLUS: y = log10f(v + prm); break;
+            case AMX_VFUNC_LN: y = logf(v); break;
+            case AMX_VFUNC_EXP: y = expf(v); break;
+            case AMX_VFUNC_POWER: y = (float)pow((double)v, (double)prm); break;
+            case AMX_VFUNC_SQRT: y = sqrtf(v); break;
+            case AMX_VFUNC_COS: y = cosf(v); break;
+            case AMX_VFUNC_ADDITION: y = v + prm; break;
+            case AMX_VFUNC_MULTIPLICATION: y = v * prm; break;
+            case AMX_VFUNC_QUANTIZE:
+                y = (prm == 1.0f || prm == 0.0f) ? (float)rint((double)v) : (float)(rint((double)(v / prm)) * (double)prm);
+                break;
+            case AMX_VFUNC_ABS: y = fabsf(v); break;
+            case AMX_VFUNC_MINIMUM: y = prm < v ? prm : v; break;   // std::min(a, value): value only if value < a
+            default: y = v < prm ? prm : v; break;                  // std::max(a, value): value only if a < value
+        }
+        out[r * out_ld + c] = y;
+    }
+}
+
 namespace {
 // Do the strided views in [T x in_w] (row stride in_ld) and out [T x out_w] (row stride out_ld) share memory?  Views into one wide
 // matrix (same stride) are disjoint when their column ranges are; anything else that overlaps in address range counts as aliasing.
@@ -375,6 +409,25 @@ int amx_vector_normalize_dev(amx_ctx* ctx, int type, const float* in_dev, int in
     amx::ScopedKernelTimer timer(ctx, "normalize");
     hipLaunchKernelGGL(vector_normalize_kernel, dim3((unsigned)((n_vectors + 255) / 256)), dim3(256), 0, ctx->stream, in_dev, in_ld,
                        (long long)n_vectors, dim, type, out_dev, out_ld);
+    AMX_HIP(hipGetLastError());
+    return AMX_OK;
+}
+
+int amx_vector_function_dev(amx_ctx* ctx, int kind, float parameter, const float* in_dev, int in_ld, long n_vectors, int dim, float* out_dev,
+                            int out_ld) {
+    AMX_REQUIRE(ctx && in_dev && out_dev, AMX_ERR_INVALID, "amx_vector_function_dev: NULL argument");
+    AMX_REQUIRE(kind >= AMX_VFUNC_LOG && kind <= AMX_VFUNC_MAXIMUM, AMX_ERR_INVALID, "amx_vector_function_dev: unknown function %d", kind);
+    AMX_REQUIRE(n_vectors >= 0 && dim > 0 && in_ld >= dim && out_ld >= dim, AMX_ERR_INVALID, "amx_vector_function_dev: bad shape / stride");
+    if (n_vectors == 0)
+        return AMX_OK;
+    const bool same_view = in_dev == out_dev && in_ld == out_ld;
+    AMX_REQUIRE(same_view || !views_alias(in_dev, in_ld, dim, out_dev, out_ld, dim, n_vectors), AMX_ERR_INVALID,
+                "amx_vector_function_dev: input and output views overlap (in place is supported on the identical view only)");
+    AMX_HIP(hipSetDevice(ctx->device));
+    amx::ScopedKernelTimer timer(ctx, "normalize");
+    const long long total = (long long)n_vectors * dim;
+    hipLaunchKernelGGL(vector_function_kernel, dim3((unsigned)std::min<long long>(16384, (total + 255) / 256)), dim3(256), 0, ctx->stream, in_dev,
+                       in_ld, (long long)n_vectors, dim, kind, parameter, out_dev, out_ld);
     AMX_HIP(hipGetLastError());
     return AMX_OK;
 }

@@ -298,3 +298,59 @@ def test_vector_normalisations_match_the_oracle(ctx, kind):
         assert np.array_equal(wide[:, 2:2 + dim].cpu().numpy().view(np.uint32), want.view(np.uint32))
     with pytest.raises(rasr_amd.AmxError, match="overlap"):
         ctx.vector_normalize(kind, wide[:, 2:], dim + 5, n, dim, wide[:, 3:], dim + 5)
+
+
+# ------------------------------------------------------------------ generic-vector-f32-<function> (Flow/SimpleFunction.hh)
+VFUNC_EXACT = {"power": 0.33, "sqrt": 0.0, "addition": -3.25, "multiplication": 500.0, "quantize": 1.0, "abs": 0.0, "minimum": 0.5, "maximum": 0.5}
+VFUNC_ULPS = {"log": 0.0, "log-plus": 1.5, "ln": 0.0, "exp": 0.0, "cos": 0.0}
+
+
+def test_oracle_vector_functions_against_definitions():
+    from oracle.binding import oracle_vector_function
+    import rasr_amd
+    K = rasr_amd.Context.VECTOR_FUNCTIONS
+    x = np.abs(seg(20, 33, 5)) * 3 + 0.01
+    x64 = x.astype(np.float64)
+    assert np.array_equal(oracle_vector_function(x, K["multiplication"], 500.0), x * np.float32(500))
+    assert np.array_equal(oracle_vector_function(x * 500, K["quantize"], 1.0), np.rint(x * 500))
+    assert np.array_equal(oracle_vector_function(x, K["quantize"], 0.25), (np.rint((x / np.float32(0.25)).astype(np.float64)) * 0.25).astype(np.float32))
+    assert np.allclose(oracle_vector_function(x, K["log"]), np.log10(x64), rtol=1e-6, atol=1e-7)
+    assert np.allclose(oracle_vector_function(x, K["power"], 0.33), x64 ** np.float64(np.float32(0.33)), rtol=1e-7)
+    assert np.array_equal(oracle_vector_function(x - 1, K["maximum"], 0.5), np.maximum(x - 1, np.float32(0.5)))
+    assert np.array_equal(oracle_vector_function(x - 1, K["abs"]), np.abs(x - 1))
+
+
+@pytest.mark.gpu
+def test_vector_functions_match_the_oracle(ctx):
+    """arithmetic kinds bit-identical (incl. the f64 power and the f64 rint of quantize), the transcendental ones within a few ulp of
+    glibc; strided views, in place on the identical view, overlap rejected"""
+    import torch
+
+    import rasr_amd
+    from oracle.binding import oracle_vector_function
+    ctx.use_torch_stream()
+    K = rasr_amd.Context.VECTOR_FUNCTIONS
+    n, dim = 517, 40
+    x = np.abs(seg(n, dim, 91)) * 4 + 0.02
+    x[5, 3] = 0.0
+    wide = torch.zeros((n, dim + 3), dtype=torch.float32, device="cuda")
+    wide[:, 1:1 + dim] = torch.from_numpy(x).cuda()
+    for kind, prm in list(VFUNC_EXACT.items()) + list(VFUNC_ULPS.items()):
+        xin = x - 1.0 if kind in ("abs", "minimum", "maximum", "addition", "quantize", "cos", "exp") else x
+        wide[:, 1:1 + dim] = torch.from_numpy(xin.astype(np.float32)).cuda()
+        out = torch.full((n, dim + 2), 9.0, dtype=torch.float32, device="cuda")
+        ctx.vector_function(kind, prm, wide[:, 1:], dim + 3, n, dim, out[:, 1:], dim + 2)
+        torch.cuda.synchronize()
+        got, want = out[:, 1:1 + dim].cpu().numpy(), oracle_vector_function(xin.astype(np.float32), K[kind], prm)
+        assert bool((out[:, 0] == 9.0).all()) and bool((out[:, dim + 1] == 9.0).all())
+        if kind in VFUNC_EXACT:
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), kind
+        else:
+            fin = np.isfinite(want)
+            assert np.array_equal(np.isfinite(got), fin) and np.array_equal(got[~fin], want[~fin]), kind
+            assert np.all(np.abs(got[fin] - want[fin]) <= 4e-7 * np.abs(want[fin]) + 1e-7), (kind, np.abs(got - want)[fin].max())
+    ctx.vector_function("multiplication", 2.0, wide[:, 1:], dim + 3, n, dim, wide[:, 1:], dim + 3)   # in place
+    with pytest.raises(rasr_amd.AmxError, match="overlap"):
+        ctx.vector_function("abs", 0.0, wide[:, 1:], dim + 3, n, dim, wide[:, 2:], dim + 3)
+    with pytest.raises(rasr_amd.AmxError):
+        ctx.vector_function("abs", 0.0, wide, dim + 3, n, dim + 4, out, dim + 2)
