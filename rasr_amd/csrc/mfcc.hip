@@ -134,7 +134,7 @@ __global__ __launch_bounds__(mfcc_waves(NC) * 64, (NC >= 1024 ? 1 : 4)) void mfc
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid  = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform for the compiler: frame base, segment tests and LDS rows become scalar work
 
     const MfccLds  L(p.frame_len, p.frame_shift, 2 * NC, p.n_filters, p.n_ceps, p.n_weights);
     float*  s_amp = smem + L.amp;   // [FT][amp_ld] amplitude spectra
