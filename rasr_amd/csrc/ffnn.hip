@@ -86,9 +86,9 @@ __global__ __launch_bounds__(256) void pack_input_bf16(const float* __restrict__
 
 // ---- split-bf16 ("bf16x3") mode: v = hi + lo with hi = bf16(v), lo = bf16(v - hi); a product a b is taken as
 // a_hi b_hi + a_lo b_hi + a_hi b_lo (the a_lo b_lo term is below 2^-17 |a b|), f32 accumulation -- three bf16 MFMA products
-// instead of one, relative error of a product ~2^-16 instead of 2^-8.  The three products are ONE GEMM over a three times
-// longer K: weight rows [W_hi | W_lo | W_hi], frame rows [X_hi | X_hi | X_lo], every segment `seg` columns wide.
-// features -> [Tpad x 3 seg] bf16
+// instead of one, relative error of a product ~2^-16 instead of 2^-8.  Operand rows are [hi plane | lo plane]; the GEMM kernels
+// stage both planes of a K-tile and issue the three products from one set of fragment reads (GemmCfg::X3).
+// features -> [Tpad x 2 seg] bf16
 __global__ __launch_bounds__(256) void pack_input_bf16x3(const float* __restrict__ x, int ldx, int T, int K, bf16_t* __restrict__ out,
                                                         int seg, int Tpad) {
     const long long n = (long long)Tpad * seg;
@@ -96,43 +96,14 @@ __global__ __launch_bounds__(256) void pack_input_bf16x3(const float* __restrict
         const int    t = (int)(i / seg), k = (int)(i - (long long)t * seg);
         const float  v = (t < T && k < K) ? x[(size_t)t * ldx + k] : 0.f;
         const bf16_t hi = f2bf(v);
-        const bf16_t lo = f2bf(v - __uint_as_float((unsigned)hi << 16));
-        bf16_t*      o = out + (size_t)t * 3 * seg + k;
+        bf16_t*      o = out + (size_t)t * 2 * seg + k;
         o[0]           = hi;
-        o[seg]         = hi;
-        o[2 * seg]     = lo;
-    }
-}
-
-// pre-activations z [Tpad x ldz] f32 (columns < N valid) -> activation, split, [Tpad x 3 seg] bf16 (zero beyond N)
-template<int ACT>
-__global__ __launch_bounds__(256) void split_act_bf16x3(const float* __restrict__ z, int ldz, int T, int N, bf16_t* __restrict__ out,
-                                                       int seg, int Tpad) {
-    const long long n4 = (long long)Tpad * (seg / 4);
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
-        const int t = (int)(i / (seg / 4)), k = (int)(i - (long long)t * (seg / 4)) * 4;
-        float4    v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (t < T && k < N)
-            v = *(const float4*)(z + (size_t)t * ldz + k);  // ldz and k are multiples of 4, rows 16-byte aligned
-        float    a[4] = {v.x, v.y, v.z, v.w};
-        unsigned h2[2], l2[2];
-#pragma unroll
-        for (int e = 0; e < 4; e += 2) {
-            const float a0 = (t < T && k + e < N) ? activate<ACT>(a[e]) : 0.f;
-            const float a1 = (t < T && k + e + 1 < N) ? activate<ACT>(a[e + 1]) : 0.f;
-            const unsigned hp = pack_bf16(a0, a1);
-            h2[e >> 1]        = hp;
-            l2[e >> 1]        = pack_bf16(a0 - __uint_as_float(hp << 16), a1 - __uint_as_float(hp & 0xffff0000u));
-        }
-        bf16_t* o = out + (size_t)t * 3 * seg + k;
-        *(uint2*)o             = make_uint2(h2[0], h2[1]);
-        *(uint2*)(o + seg)     = make_uint2(h2[0], h2[1]);
-        *(uint2*)(o + 2 * seg) = make_uint2(l2[0], l2[1]);
+        o[seg]         = f2bf(v - __uint_as_float((unsigned)hi << 16));
     }
 }
 
 // last hidden activation -> f32 [T x H] (Nn::OnDemandFeatureScorer::forwardHiddenLayers keeps it per frame).
-// MODE 0: f32 rows, 1: bf16 rows, 2: split bf16 rows [hi | hi | lo] (value = hi + lo)
+// MODE 0: f32 rows, 1: bf16 rows, 2: split bf16 rows [hi | lo], lo plane at column seg (value = hi + lo)
 template<int MODE>
 __global__ __launch_bounds__(256) void export_hidden_kernel(const void* __restrict__ src, int ld, int seg, int T, int H, float* __restrict__ out) {
     const long long n = (long long)T * H;
@@ -145,7 +116,7 @@ __global__ __launch_bounds__(256) void export_hidden_kernel(const void* __restri
             v = __uint_as_float((unsigned)((const bf16_t*)src)[(size_t)t * ld + k] << 16);
         else {
             const bf16_t* r = (const bf16_t*)src + (size_t)t * ld;
-            v               = __uint_as_float((unsigned)r[k] << 16) + __uint_as_float((unsigned)r[2 * seg + k] << 16);
+            v               = __uint_as_float((unsigned)r[k] << 16) + __uint_as_float((unsigned)r[seg + k] << 16);
         }
         out[i] = v;
     }
@@ -276,21 +247,33 @@ __global__ __launch_bounds__(256) void pack_input_f32(const float* __restrict__ 
 // ---------------------------------------------------------------------------------------------
 // bf16 GEMM: D[n][t] = sum_k W[n][k] X[t][k];  W [Npad x Kpad], X [Tpad x ldx] bf16.
 // hidden layers: out bf16 [Tpad x ldo] = act(D + bias);  last layer: out f32 [T x n_valid] = -(D + bias)
+// Row strides and plane offsets (bf16 elements) of a GEMM launch.  Plain bf16: ldw = Kpad, every *lo = 0.  Split bf16: rows are
+// [hi plane | lo plane]; wlo / xlo / olo are the columns where the lo planes of W, X and the hidden-layer output start.
+struct GemmLd {
+    int ldw, wlo, ldx, xlo, ldo, olo;
+};
+
 constexpr int BK      = 64;   // k per stage: one 128-byte LDS row per matrix row
 constexpr int PAD_NT  = 256;  // N and T are padded to this (largest tile edge)
 
-template<int BN_, int BT_, int WN_, int WT_, int STAGES_, int BK_ = 64>
+template<int BN_, int BT_, int WN_, int WT_, int STAGES_, int BK_ = 64, bool X3_ = false>
 struct GemmCfg {
     static constexpr int BN = BN_, BT = BT_, WN = WN_, WT = WT_, STAGES = STAGES_, BKC = BK_;
+    // X3: split-bf16 tiles.  Every operand tile is staged as TWO planes (hi = bf16(v), lo = bf16(v - hi)), the hi plane first,
+    // and a k-slab issues the three products hi.hi, lo.hi, hi.lo from ONE set of fragment reads (4 planes per 3 products).
+    static constexpr bool X3     = X3_;
+    static constexpr int  PLANES = X3 ? 2 : 1;
     static constexpr int NW = WN * WT, THREADS = NW * 64;
     static constexpr int ROW_BYTES = BKC * 2;               // one LDS row per matrix row: 128 B (BK 64) or 64 B (BK 32)
     static constexpr int ROWS_PER_LOAD = 1024 / ROW_BYTES;  // rows covered by one wave-wide 16-byte global_load_lds
     static constexpr int CHUNKS = ROW_BYTES / 16;
-    static constexpr int A_BYTES = BN * ROW_BYTES, B_BYTES = BT * ROW_BYTES, STAGE_BYTES = A_BYTES + B_BYTES;
+    static constexpr int A_PLANE = BN * ROW_BYTES, B_PLANE = BT * ROW_BYTES;
+    static constexpr int A_BYTES = PLANES * A_PLANE, B_BYTES = PLANES * B_PLANE, STAGE_BYTES = A_BYTES + B_BYTES;
     static constexpr int LDS_BYTES = STAGES * STAGE_BYTES;
-    static constexpr int A_LOADS = BN / ROWS_PER_LOAD / NW, B_LOADS = BT / ROWS_PER_LOAD / NW, LOADS = A_LOADS + B_LOADS;
+    static constexpr int A_LOADS = A_BYTES / 1024 / NW, B_LOADS = B_BYTES / 1024 / NW, LOADS = A_LOADS + B_LOADS;
     static constexpr int MI = BN / WN / 32, MJ = BT / WT / 32;  // 32x32 tiles per wave
     static_assert(BKC == 64 || BKC == 32, "BK must be 32 or 64");
+    static_assert(!X3 || BKC == 32, "split-bf16 tiles are 32 k wide (four planes per stage)");
     static_assert(BN % (ROWS_PER_LOAD * NW) == 0 && BT % (ROWS_PER_LOAD * NW) == 0, "staging needs whole row groups per wave");
     static_assert(BN % (WN * 32) == 0 && BT % (WT * 32) == 0, "wave tile must be a multiple of 32x32");
     // XOR swizzle of the 16-byte chunks of a row so that ds_read_b128 of a 32-row MFMA fragment is conflict free:
@@ -335,7 +318,7 @@ __host__ __device__ constexpr int gemm_scratch_bytes() {
 
 template<class C, int ACT, bool LAST, bool NOSTORE = false>
 __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[C::MI][C::MJ], char* lds, const float* s_bias, void* __restrict__ out,
-                                              int ldo, int n_valid, int t_valid, int n0, int t0, int tile_n, int wn, int wt, int lane, int tid,
+                                              int ldo, int olo, int n_valid, int t_valid, int n0, int t0, int tile_n, int wn, int wt, int lane, int tid,
                                               float* __restrict__ part_min, unsigned* __restrict__ part_idx, int part_ld) {
     using E = EpiCfg<C, LAST>;
     const int  wave      = tid >> 6;
@@ -347,6 +330,9 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[C::MI][C::MJ], char*
     const int tl32 = lane & 31, hh = lane >> 5;
 #pragma unroll
     for (int j = 0; j < C::MJ; ++j) {
+      // split-bf16 hidden layers leave as two planes per row, [hi | lo] (lo at column olo): one pass per plane
+#pragma unroll
+      for (int pl = 0; pl < (LAST ? 1 : C::PLANES); ++pl) {
         float    bmin = 3.402823466e+38f;
         unsigned bidx = 0xffffffffu;
         // ---- registers -> LDS [frame][output]
@@ -376,9 +362,15 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[C::MI][C::MJ], char*
                     }
                 }
                 else {
-                    uint2 pk;
-                    pk.x = pack_bf16(activate<ACT>(v[0]), activate<ACT>(v[1]));
-                    pk.y = pack_bf16(activate<ACT>(v[2]), activate<ACT>(v[3]));
+                    const float a0 = activate<ACT>(v[0]), a1 = activate<ACT>(v[1]), a2 = activate<ACT>(v[2]), a3 = activate<ACT>(v[3]);
+                    uint2       pk;
+                    pk.x = pack_bf16(a0, a1);
+                    pk.y = pack_bf16(a2, a3);
+                    if (pl == 1) {  // lo = bf16(v - hi)
+                        const unsigned h0 = pk.x, h1 = pk.y;
+                        pk.x = pack_bf16(a0 - __uint_as_float(h0 << 16), a1 - __uint_as_float(h0 & 0xffff0000u));
+                        pk.y = pack_bf16(a2 - __uint_as_float(h1 << 16), a3 - __uint_as_float(h1 & 0xffff0000u));
+                    }
                     *(uint2*)(w_lds + tl32 * E::ROWB + nl * 2) = pk;
                 }
             }
@@ -431,11 +423,12 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[C::MI][C::MJ], char*
                 const int   row = it * RPI + lane / LPR, c8 = lane % LPR;
                 const uint4 v   = *(const uint4*)(w_lds + row * E::ROWB + c8 * 16);
                 if (!(NOSTORE && v.x != 0x12345678u))
-                    *(uint4*)((bf16_t*)out + (size_t)(tbase + row) * ldo + nbase + 8 * c8) = v;  // padded buffer: no guards
+                    *(uint4*)((bf16_t*)out + (size_t)(tbase + row) * ldo + pl * olo + nbase + 8 * c8) = v;  // padded buffer: no guards
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
+      }
     }
     if (want_best) {
         __syncthreads();
@@ -466,10 +459,11 @@ __device__ unsigned*           g_gemm_sync  = nullptr;
 
 template<class C, int ACT, bool LAST, int VAR>
 __global__ __launch_bounds__(C::THREADS) void gemm_bf16_kernel(const bf16_t* __restrict__ W, const bf16_t* __restrict__ X,
-                                                              const float* __restrict__ bias, void* __restrict__ out, int Kpad, int ldx,
-                                                              int ldo, int n_valid, int t_valid, int n_tiles_n, int n_tiles_total, int GT, int GN,
+                                                              const float* __restrict__ bias, void* __restrict__ out, int Kpad, GemmLd ld,
+                                                              int n_valid, int t_valid, int n_tiles_n, int n_tiles_total, int GT, int GN,
                                                               float* __restrict__ part_min,
                                                               unsigned* __restrict__ part_idx, int part_ld) {
+    const int ldx = ld.ldx, ldo = ld.ldo;
     extern __shared__ __attribute__((aligned(16))) char lds[];  // [STAGES][W tile | X tile]
     const int tid  = threadIdx.x;
     const int lane = tid & 63;
@@ -536,14 +530,16 @@ __global__ __launch_bounds__(C::THREADS) void gemm_bf16_kernel(const bf16_t* __r
 #pragma unroll
     for (int i = 0; i < C::A_LOADS; ++i) {
         const int pos = (i * C::NW + wave) * 1024 + lane * 16;
-        const int row = pos / C::ROW_BYTES, phys = (pos % C::ROW_BYTES) >> 4;
-        gW[i]         = W + (size_t)(n0 + row) * Kpad + (phys ^ C::xor_term(row)) * 8;
+        const int plane = pos / C::A_PLANE, rpos = pos % C::A_PLANE;  // split bf16: hi plane, then lo plane
+        const int row = rpos / C::ROW_BYTES, phys = (rpos % C::ROW_BYTES) >> 4;
+        gW[i]         = W + (size_t)(n0 + row) * ld.ldw + plane * ld.wlo + (phys ^ C::xor_term(row)) * 8;
     }
 #pragma unroll
     for (int i = 0; i < C::B_LOADS; ++i) {
         const int pos = (i * C::NW + wave) * 1024 + lane * 16;
-        const int row = pos / C::ROW_BYTES, phys = (pos % C::ROW_BYTES) >> 4;
-        gX[i]         = X + (size_t)(t0 + row) * ldx + (phys ^ C::xor_term(row)) * 8;
+        const int plane = pos / C::B_PLANE, rpos = pos % C::B_PLANE;
+        const int row = rpos / C::ROW_BYTES, phys = (rpos % C::ROW_BYTES) >> 4;
+        gX[i]         = X + (size_t)(t0 + row) * ldx + plane * ld.xlo + (phys ^ C::xor_term(row)) * 8;
     }
     auto stage = [&](int slot, int kt) {
         char* base = lds + slot * C::STAGE_BYTES;
@@ -617,6 +613,33 @@ __global__ __launch_bounds__(C::THREADS) void gemm_bf16_kernel(const bf16_t* __r
 #pragma unroll
                 for (int j = 0; j < C::MJ; ++j)
                     b[j] = *(const bf16x8*)(xbase + C::swz(wt * (C::BT / C::WT) + j * 32 + frow, ks * 2 + fk));
+                if (C::X3) {
+                    // one set of fragment reads, three products: hi.hi, lo.hi, hi.lo -- in this order in EVERY split-bf16 kernel, so
+                    // that all tile configurations accumulate identically
+                    bf16x8 al[C::MI], bl[C::MJ];
+#pragma unroll
+                    for (int i = 0; i < C::MI; ++i)
+                        al[i] = *(const bf16x8*)(wbase + C::A_PLANE + C::swz(wn * (C::BN / C::WN) + i * 32 + frow, ks * 2 + fk));
+#pragma unroll
+                    for (int j = 0; j < C::MJ; ++j)
+                        bl[j] = *(const bf16x8*)(xbase + C::B_PLANE + C::swz(wt * (C::BT / C::WT) + j * 32 + frow, ks * 2 + fk));
+#pragma unroll
+                    for (int i = 0; i < C::MI; ++i)
+#pragma unroll
+                        for (int j = 0; j < C::MJ; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < C::MI; ++i)
+#pragma unroll
+                        for (int j = 0; j < C::MJ; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], b[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < C::MI; ++i)
+#pragma unroll
+                        for (int j = 0; j < C::MJ; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bl[j], acc[i][j], 0, 0, 0);
+                    continue;
+                }
 #pragma unroll
                 for (int i = 0; i < C::MI; ++i)
 #pragma unroll
@@ -649,9 +672,9 @@ __global__ __launch_bounds__(C::THREADS) void gemm_bf16_kernel(const bf16_t* __r
             ((float*)out)[tid] = sum;
     }
     else if (VAR & 256)
-        gemm_epilogue<C, ACT, LAST, true>(acc, lds, s_bias, out, ldo, n_valid, t_valid, n0, t0, tile_n, wn, wt, lane, tid, part_min, part_idx, part_ld);
+        gemm_epilogue<C, ACT, LAST, true>(acc, lds, s_bias, out, ldo, ld.olo, n_valid, t_valid, n0, t0, tile_n, wn, wt, lane, tid, part_min, part_idx, part_ld);
     else
-        gemm_epilogue<C, ACT, LAST>(acc, lds, s_bias, out, ldo, n_valid, t_valid, n0, t0, tile_n, wn, wt, lane, tid, part_min, part_idx, part_ld);
+        gemm_epilogue<C, ACT, LAST>(acc, lds, s_bias, out, ldo, ld.olo, n_valid, t_valid, n0, t0, tile_n, wn, wt, lane, tid, part_min, part_idx, part_ld);
     __syncthreads();  // LDS (stages / arg-min scratch) is reused by the next tile
     if ((VAR & 512) && tid == 0)
         g_gemm_trace[((size_t)blockIdx.x * 64 + (step & 63)) * 4 + 2] = wall_clock64();
@@ -678,8 +701,8 @@ struct PipeLds {
     static constexpr int BEST_BYTES   = LAST ? 2 * C::WN * C::BT * 4 : 0;
     static constexpr int BIAS_OFF     = BEST_OFF + BEST_BYTES;              // [2][BN] f32, double buffered per tile
     static constexpr int BYTES        = BIAS_OFF + 2 * C::BN * 4;
-    static constexpr int STORES       = LAST ? C::MJ * 2 * 8 : C::MJ * 8;   // global stores per wave and interior tile
-    static_assert(C::STAGES == 2 && C::BKC == 64, "two 64-wide stages");
+    static constexpr int STORES       = LAST ? C::MJ * 2 * 8 : C::MJ * 8 * C::PLANES;   // global stores per wave and interior tile
+    static_assert(C::STAGES == 2 && (C::X3 ? C::BKC == 32 : C::BKC == 64), "two stages of 64 KB: 2 x 256 rows x 64 k, or 4 planes x 256 rows x 32 k");
     static_assert(C::BN / C::WN == 128 && C::MI == 4, "wave tile is 128 outputs wide");
     static_assert(C::NW * WAVE_SCRATCH <= C::STAGE_BYTES, "epilogue scratch must fit into one stage");
     static_assert(C::BN * 4 == 1024, "the bias vector is one wave-wide 16-byte LDS-DMA");
@@ -690,14 +713,65 @@ __device__ __forceinline__ int pipe_swz(int row, int chunk) {
     return row * 256 + ((chunk ^ (row & 15)) << 4);
 }
 
-// DBG: tools/gemm_probe.hip only (1 time stamps, 2 no global stores, 4 no epilogue)
+// fragment registers of half a K-tile of the pipelined kernel.  Plain bf16: two k-slabs of (W, X) fragments, 2 MI MJ MFMAs.  Split
+// bf16: one k-slab of (W_hi, W_lo, X_hi, X_lo) fragments, 3 MI MJ MFMAs.  12 fragments = 48 registers either way.
+template<class C>
+struct PipeFrag {
+    static constexpr int NS = C::X3 ? 1 : 2;
+    bf16x8 a[NS][C::MI], b[NS][C::MJ], al[C::X3 ? C::MI : 1], bl[C::X3 ? C::MJ : 1];
+};
+
+template<class C, int H>
+__device__ __forceinline__ void pipe_read_half(PipeFrag<C>& f, const char* stage, int a_row, int b_row, int fk) {
+    const char* wbase = stage;
+    const char* xbase = stage + C::A_BYTES;
+#pragma unroll
+    for (int s = 0; s < PipeFrag<C>::NS; ++s) {
+        const int ks = H * PipeFrag<C>::NS + s;  // k-slab of the K-tile
+#pragma unroll
+        for (int i = 0; i < C::MI; ++i)
+            f.a[s][i] = *(const bf16x8*)(wbase + C::swz(a_row + i * 32, ks * 2 + fk));
+#pragma unroll
+        for (int j = 0; j < C::MJ; ++j)
+            f.b[s][j] = *(const bf16x8*)(xbase + C::swz(b_row + j * 32, ks * 2 + fk));
+        if (C::X3) {
+#pragma unroll
+            for (int i = 0; i < C::MI; ++i)
+                f.al[i] = *(const bf16x8*)(wbase + C::A_PLANE + C::swz(a_row + i * 32, ks * 2 + fk));
+#pragma unroll
+            for (int j = 0; j < C::MJ; ++j)
+                f.bl[j] = *(const bf16x8*)(xbase + C::B_PLANE + C::swz(b_row + j * 32, ks * 2 + fk));
+        }
+    }
+}
+
+// MFMAs of one half in the order every bf16 GEMM kernel of this file uses (slab by slab; split bf16: hi.hi, lo.hi, hi.lo of the slab),
+// PART 0 = the first half of that sequence, PART 1 = the rest
+template<class C, int PART, int DBG>
+__device__ __forceinline__ void pipe_mfma_part(f32x16 (&acc)[C::MI][C::MJ], const PipeFrag<C>& f) {
+    constexpr int T = C::MI * C::MJ, MPH = (C::X3 ? 3 : 2) * T, HALF = MPH / 2;
+#pragma unroll
+    for (int m = PART * HALF; m < (PART + 1) * HALF; ++m) {
+        const int grp = m / T, i = (m % T) / C::MJ, j = m % C::MJ;
+        const bf16x8 av = C::X3 ? (grp == 1 ? f.al[i] : f.a[0][i]) : f.a[grp][i];
+        const bf16x8 bv = C::X3 ? (grp == 2 ? f.bl[j] : f.b[0][j]) : f.b[grp][j];
+        if (DBG & 8)  // ablation: fragment reads stay alive, the matrix pipe is idle
+            asm volatile("" ::"v"(av), "v"(bv));
+        else
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[i][j], 0, 0, 0);
+    }
+}
+
+// DBG: tools/gemm_probe.hip only (1 time stamps, 2 no global stores, 4 no epilogue, 8 no MFMA, 16 no operand DMA after the prologue,
+// 64 L2-resident operands)
 template<class C, int ACT, bool LAST, int DBG = 0>
 __global__ __launch_bounds__(C::THREADS) void gemm_bf16_pipe_kernel(const bf16_t* __restrict__ W, const bf16_t* __restrict__ X,
-                                                                   const float* __restrict__ bias, void* __restrict__ out, int Kpad, int ldx,
-                                                                   int ldo, int n_valid, int t_valid, int n_tiles_n, int n_tiles_total, int GT,
+                                                                   const float* __restrict__ bias, void* __restrict__ out, int Kpad, GemmLd ld,
+                                                                   int n_valid, int t_valid, int n_tiles_n, int n_tiles_total, int GT,
                                                                    int GN, int out_aligned, float* __restrict__ part_min,
                                                                    unsigned* __restrict__ part_idx, int part_ld) {
     using P = PipeLds<C, LAST>;
+    const int ldx = ld.ldx, ldo = ld.ldo;
     extern __shared__ __attribute__((aligned(16))) char lds[];  // [stage 0 | stage 1 | arg-min exchange | bias x 2]
     const int tid  = threadIdx.x;
     const int lane = tid & 63;
@@ -707,6 +781,11 @@ __global__ __launch_bounds__(C::THREADS) void gemm_bf16_pipe_kernel(const bf16_t
     const bool want_best = LAST && part_min != nullptr;
 
     auto coords = [&](int vi, int& tile_t, int& tile_n) {  // same XCD-aware order as gemm_bf16_kernel
+        if (DBG & 64) {  // ablation: every workgroup streams the operands of ONE of 8 tiles (everything an L2 hit)
+            tile_t = blockIdx.x & 7;
+            tile_n = 0;
+            return;
+        }
         const int nwg = n_tiles_total;
         const int q = nwg >> 3, r = nwg & 7, xcd = vi & 7, k = vi >> 3;
         const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
@@ -724,43 +803,103 @@ __global__ __launch_bounds__(C::THREADS) void gemm_bf16_pipe_kernel(const bf16_t
             tile_n = v - tile_t * n_tiles_n;
         }
     };
-    // staging: instruction i of a wave covers rows (i*NW + wave)*8 .. +7 of the tile; a lane's 16 bytes sit at row
-    // lane/8, physical chunk lane%8, which must hold logical chunk phys ^ ((row>>1)&7) = phys ^ xr (independent of i)
-    const int    xr   = ((wave & 1) * 4 + (lane >> 4)) & 7;
-    const size_t offW = (size_t)(wave * 8 + (lane >> 3)) * Kpad + (((lane & 7) ^ xr) << 3);
-    const size_t offX = (size_t)(wave * 8 + (lane >> 3)) * ldx + (((lane & 7) ^ xr) << 3);
-    const size_t stepW = (size_t)C::NW * 8 * Kpad, stepX = (size_t)C::NW * 8 * ldx;
-    auto issue = [&](int slot, const bf16_t* pw, const bf16_t* px) {
+    // staging: piece i of a wave (one wave-wide 16-byte LDS-DMA = 1 KB) lands at LDS offset (i*NW + wave) KB of the operand's region.
+    // 128-byte rows (bf16): a piece is 8 rows, a lane's 16 bytes sit at row lane/8, physical chunk lane%8, which must hold logical
+    // chunk phys ^ ((row>>1)&7) = phys ^ xr (independent of i).  64-byte rows (split bf16): 16 rows per piece, row lane/4, physical
+    // chunk lane%4 ^ ((row>>2)&3) = lane%4 ^ (lane>>4); the region is the hi plane followed by the lo plane, i.e. the wave's pieces
+    // 0 .. A_LOADS/2-1 read the hi columns and the rest the same rows of the lo columns (wlo / xlo further right).
+    // Addresses are a wave-uniform 64-bit base (SGPR pair: tile, K-tile, plane, piece and the wave's rows) plus ONE 32-bit lane offset per
+    // operand (row lane/4 or lane/8 of the piece, swizzled chunk): the global_load_lds saddr form, two address VGPRs for the whole kernel.
+    constexpr int  RPL  = C::ROWS_PER_LOAD;
+    const int      lrow = C::X3 ? (lane >> 2) : (lane >> 3);
+    const int      lchk = C::X3 ? ((lane & 3) ^ ((lane >> 4) & 3)) : ((lane & 7) ^ (((wave & 1) * 4 + (lane >> 4)) & 7));
+    const unsigned voffW = (unsigned)(lrow * ld.ldw + (lchk << 3)) * 2u, voffX = (unsigned)(lrow * ldx + (lchk << 3)) * 2u;  // bytes
+    const size_t   waveW = (size_t)wave * RPL * ld.ldw, waveX = (size_t)wave * RPL * ldx;
+    const size_t   stepW = (size_t)C::NW * RPL * ld.ldw, stepX = (size_t)C::NW * RPL * ldx;
+    constexpr int  PPA = C::A_LOADS / C::PLANES, PPB = C::B_LOADS / C::PLANES;  // pieces per plane and wave
+    auto issue = [&](int slot, const bf16_t* pw, const bf16_t* px) {  // pw / px: wave-uniform, first row of the tile, first k of the K-tile
         char* base = lds + slot * C::STAGE_BYTES + wave * 1024;
 #pragma unroll
-        for (int i = 0; i < C::A_LOADS; ++i)
-            __builtin_amdgcn_global_load_lds((const void*)(pw + i * stepW), (__attribute__((address_space(3))) void*)(base + i * C::NW * 1024), 16, 0, 0);
+        for (int i = 0; i < C::A_LOADS; ++i) {
+            const bf16_t* u = pw + waveW + (size_t)(i / PPA) * ld.wlo + (size_t)(i % PPA) * stepW;
+            __builtin_amdgcn_global_load_lds((const void*)((const char*)u + voffW), (__attribute__((address_space(3))) void*)(base + i * C::NW * 1024), 16, 0, 0);
+        }
 #pragma unroll
-        for (int i = 0; i < C::B_LOADS; ++i)
-            __builtin_amdgcn_global_load_lds((const void*)(px + i * stepX),
+        for (int i = 0; i < C::B_LOADS; ++i) {
+            const bf16_t* u = px + waveX + (size_t)(i / PPB) * ld.xlo + (size_t)(i % PPB) * stepX;
+            __builtin_amdgcn_global_load_lds((const void*)((const char*)u + voffX),
                                              (__attribute__((address_space(3))) void*)(base + C::A_BYTES + i * C::NW * 1024), 16, 0, 0);
+        }
     };
     auto issue_bias = [&](int buf, int tile_n) {  // wave 0: BN floats = 64 lanes x 16 B
-        if (wave == 0)
-            __builtin_amdgcn_global_load_lds((const void*)(bias + tile_n * C::BN + lane * 4),
+        if (wave == 0) {  // scalar base + 32-bit lane offset (saddr form: no 64-bit lane pointer kept alive across the K-loop)
+            const unsigned long long ub = (unsigned long long)(bias + tile_n * C::BN);
+            const char* sbase = (const char*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ub >> 32)) << 32) |
+                                              (unsigned)__builtin_amdgcn_readfirstlane((int)ub));
+            __builtin_amdgcn_global_load_lds((const void*)(sbase + (unsigned)(lane * 16)),
                                              (__attribute__((address_space(3))) void*)(lds + P::BIAS_OFF + buf * C::BN * 4), 16, 0, 0);
+        }
     };
 
     int vi = blockIdx.x;
     if (vi >= n_tiles_total)
         return;
-    int tile_t, tile_n;
-    coords(vi, tile_t, tile_n);
-    const bf16_t* pw = W + (size_t)tile_n * C::BN * Kpad + offW;
-    const bf16_t* px = X + (size_t)tile_t * C::BT * ldx + offX;
-    int           bias_buf = 0;
-    issue_bias(0, tile_n);
-    issue(0, pw, px);
-    unsigned g       = 0;      // running K-tile count; K-tile g lives in stage g & 1
-    bool     counted = false;  // the loads in flight are followed by exactly P::STORES (+2) stores of this wave
-    const int frow = lane & 31, fk = lane >> 5, tl32 = lane & 31, hh = lane >> 5;
+    // ---- fetch cursor: the operand stream is ONE sequence of K-tiles across the workgroup's tiles; K-tile number c of the stream goes
+    // to stage c & 1.  The cursor runs up to two K-tiles ahead of the arithmetic.
+    int           c_vi = vi, c_kt = 0, c_buf = 0, c_tn = 0;
+    unsigned      c       = 0;     // K-tiles issued so far
+    bool          c_valid = true;  // the cursor points at an existing K-tile
+    const bf16_t *c_pw, *c_px;
+    {
+        int tt;
+        coords(c_vi, tt, c_tn);
+        c_pw = W + (size_t)c_tn * C::BN * ld.ldw;
+        c_px = X + (size_t)tt * C::BT * ldx;
+    }
+    auto issue_next = [&]() {
+        if (!((DBG & 16) && c >= 2)) {  // DBG 16: ablation, no operand traffic after the prologue
+            if (c_kt == 0)
+                issue_bias(c_buf, c_tn);  // the tile's bias vector travels in front of its first K-tile
+            issue(c & 1, c_pw, c_px);
+        }
+        ++c;
+        if (++c_kt < KT) {
+            c_pw += C::BKC;
+            c_px += C::BKC;
+        }
+        else {  // the stream continues with the workgroup's next tile
+            c_kt = 0;
+            c_buf ^= 1;
+            c_vi += (int)gridDim.x;
+            c_valid = c_vi < n_tiles_total;
+            if (c_valid) {
+                int tt;
+                coords(c_vi, tt, c_tn);
+                c_pw = W + (size_t)c_tn * C::BN * ld.ldw;
+                c_px = X + (size_t)tt * C::BT * ldx;
+            }
+        }
+    };
+    issue_next();
+    if (c_valid)
+        issue_next();
+    int      bias_buf = 0;
+    unsigned g        = 0;      // running K-tile count of the arithmetic; K-tile g lives in stage g & 1
+    bool     counted  = false;  // the loads in flight are followed by exactly P::STORES (+2) stores of this wave
+    const int frow = lane & 31, fk = lane >> 5;
     const bool extra = LAST && want_best && wave * 64 < C::BT;  // waves that also write the arg-min partials
+    const int  a_row = wn * (C::BN / C::WN) + frow, b_row = wt * (C::BT / C::WT) + frow;
+    PipeFrag<C> S0, S1;  // fragment registers of the two halves of a K-tile
 
+    // K-loop schedule (one K-tile = two halves of MPH MFMAs each; S0 / S1 hold the halves' fragments):
+    //     read S1 <- stage(g) | MFMA S0 (first part) | lgkmcnt(0), barrier R(g): everybody has stage(g) in registers | DMA(g+2) -> stage(g)
+    //     | MFMA S0 (rest), MFMA S1 (first part) | vmcnt(younger loads), barrier X(g+1): K-tile g+1 has landed | read S0 <- stage(g+1)
+    //     | MFMA S1 (rest)
+    // i.e. a stage is occupied only from its landing to the moment its two halves sit in registers, the LDS-DMA of K-tile g+2 has one and
+    // a half K-tiles of MFMA time to land (the two-stage loop with one barrier per K-tile gave it at most one; it measured 1.9 us per
+    // 64 KB K-tile against 1.7 us of MFMA work), and every fragment read is issued half a K-tile before its first use.
+    // At the last K-tile of a tile nothing is issued at R(g): the freed stage is the epilogue's transposition scratch; that K-tile of the
+    // stream is issued behind the next tile's first barrier instead.
     for (;;) {
         f32x16 acc[C::MI][C::MJ];
 #pragma unroll
@@ -770,6 +909,8 @@ __global__ __launch_bounds__(C::THREADS) void gemm_bf16_pipe_kernel(const bf16_t
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     acc[i][j][r] = 0.f;
+        int tile_t, tile_n;
+        coords(vi, tile_t, tile_n);
         const int  n0 = tile_n * C::BN, t0 = tile_t * C::BT, cur_tile_n = tile_n;
         const int  nvi      = vi + (int)gridDim.x;
         const bool has_next = nvi < n_tiles_total;
@@ -778,56 +919,52 @@ __global__ __launch_bounds__(C::THREADS) void gemm_bf16_pipe_kernel(const bf16_t
             g_gemm_trace[((size_t)blockIdx.x * 64 + (step & 63)) * 4 + 0] = wall_clock64();
             g_gemm_trace[((size_t)blockIdx.x * 64 + (step & 63)) * 4 + 3] = __builtin_amdgcn_s_getreg((3 << 11) | 20);
         }
-
-        for (int kt = 0; kt < KT; ++kt, ++g) {
-            if (kt == 0 && counted) {
-                if (extra)
-                    wait_vmcnt<P::STORES + 2>();
-                else
-                    wait_vmcnt<P::STORES>();
-            }
+        // ---- X(g) of the tile's first K-tile: its loads are followed by the previous tile's stores (counted) or, in the very first
+        // tile, by the second K-tile of the stream
+        if (g == 0) {
+            if (c >= 2)
+                wait_vmcnt<C::LOADS>();
             else
                 wait_vmcnt<0>();
-            __builtin_amdgcn_s_barrier();
-            const int  nslot = (g + 1) & 1;
-            const bool more  = kt + 1 < KT || has_next;
-            if (kt + 1 < KT) {
-                pw += C::BKC;
-                px += C::BKC;
-            }
-            else if (has_next) {  // the stream continues with the next tile
-                coords(nvi, tile_t, tile_n);
-                pw = W + (size_t)tile_n * C::BN * Kpad + offW;
-                px = X + (size_t)tile_t * C::BT * ldx + offX;
-            }
-            if (kt + 1 >= KT && has_next)
-                issue_bias(bias_buf ^ 1, tile_n);
-            const char* wbase = lds + (g & 1) * C::STAGE_BYTES;
-            const char* xbase = wbase + C::A_BYTES;
-            static_assert(C::A_LOADS == C::BKC / 16 && C::B_LOADS == C::BKC / 16, "one W and one X piece per k-slab");
-#pragma unroll
-            for (int ks = 0; ks < C::BKC / 16; ++ks) {
-                bf16x8 a[C::MI], b[C::MJ];
-#pragma unroll
-                for (int i = 0; i < C::MI; ++i)
-                    a[i] = *(const bf16x8*)(wbase + C::swz(wn * (C::BN / C::WN) + i * 32 + frow, ks * 2 + fk));
-#pragma unroll
-                for (int j = 0; j < C::MJ; ++j)
-                    b[j] = *(const bf16x8*)(xbase + C::swz(wt * (C::BT / C::WT) + j * 32 + frow, ks * 2 + fk));
-                if (more) {  // the 8 LDS-DMA pieces of the next K-tile are spread over the 4 k-slabs (issued in one burst behind
-                             // the barrier they kept both waves of a SIMD off the matrix pipe at the same time: +2 %)
-                    char* base = lds + nslot * C::STAGE_BYTES + wave * 1024;
-                    __builtin_amdgcn_global_load_lds((const void*)(pw + ks * stepW), (__attribute__((address_space(3))) void*)(base + ks * C::NW * 1024), 16, 0, 0);
-                    __builtin_amdgcn_global_load_lds((const void*)(px + ks * stepX),
-                                                     (__attribute__((address_space(3))) void*)(base + C::A_BYTES + ks * C::NW * 1024), 16, 0, 0);
-                }
-#pragma unroll
-                for (int i = 0; i < C::MI; ++i)
-#pragma unroll
-                    for (int j = 0; j < C::MJ; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-            }
+        }
+        else if (counted) {
+            if (extra)
+                wait_vmcnt<P::STORES + 2>();
+            else
+                wait_vmcnt<P::STORES>();
+        }
+        else
+            wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();  // also: every wave is through with the previous tile's epilogue scratch
+        if (c == g + 1 && c_valid)
+            issue_next();  // the K-tile that was held back at the previous tile's last R
+        pipe_read_half<C, 0>(S0, lds + (g & 1) * C::STAGE_BYTES, a_row, b_row, fk);
+
+        for (int kt = 0; kt < KT; ++kt, ++g) {
+            const bool  last = kt + 1 == KT;
+            const char* cur  = lds + (g & 1) * C::STAGE_BYTES;
+            const char* nxt  = lds + ((g + 1) & 1) * C::STAGE_BYTES;
+            pipe_read_half<C, 1>(S1, cur, a_row, b_row, fk);
+            pipe_mfma_part<C, 0, DBG>(acc, S0);
+            __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();  // R(g)
+            if (!last && c_valid)
+                issue_next();
+            __builtin_amdgcn_sched_barrier(0);
+            pipe_mfma_part<C, 1, DBG>(acc, S0);
+            pipe_mfma_part<C, 0, DBG>(acc, S1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!last) {
+                if (c >= g + 3)
+                    wait_vmcnt<C::LOADS>();
+                else
+                    wait_vmcnt<0>();
+                __builtin_amdgcn_s_barrier();  // X(g+1)
+                pipe_read_half<C, 0>(S0, nxt, a_row, b_row, fk);
+            }
+            pipe_mfma_part<C, 1, DBG>(acc, S1);
+            __builtin_amdgcn_sched_barrier(0);
         }
 
         if ((DBG & 1) && tid == 0)
@@ -848,18 +985,22 @@ __global__ __launch_bounds__(C::THREADS) void gemm_bf16_pipe_kernel(const bf16_t
                 break;
             vi = nvi;
             bias_buf ^= 1;
-            __builtin_amdgcn_s_barrier();
             continue;
         }
         // ------------------------------------------------------------------ epilogue of tile (t0, n0)
-        // every wave is done reading stage (g-1)&1 (its LDS reads were waited for above): that stage becomes the
-        // transposition scratch.  A raw barrier: __syncthreads() would also drain the next tile's loads.
-        __builtin_amdgcn_s_barrier();
+        // every wave is through R of the last K-tile, i.e. done reading stage (g-1)&1, and nothing has been issued into it: that
+        // stage is the transposition scratch
+        // the epilogue's lane-dependent addresses are derived from an opaque copy of the lane id: computed from `lane` they are
+        // loop invariants of the tile loop, get hoisted in front of the K-loop, spilled there (the K-loop owns the register file) and
+        // reloaded between the stores behind s_waitcnt vmcnt(0)
+        int elane = lane;
+        asm volatile("" : "+v"(elane));
+        const int    tl32 = elane & 31, hh = elane >> 5;
         char*        w_lds = lds + ((g - 1) & 1) * C::STAGE_BYTES + wave * P::WAVE_SCRATCH;
         const float* sb    = (const float*)(lds + P::BIAS_OFF + bias_buf * C::BN * 4) + wn * 128;
         const int    nbase = n0 + wn * 128;
         const bool   interior = LAST ? (t0 + C::BT <= t_valid && n0 + C::BN <= n_valid && out_aligned) : true;
-        const int    prow = lane >> 4, pc = lane & 15;  // phase 2: 4 rows x 16 chunks per wave-wide access
+        const int    prow = elane >> 4, pc = elane & 15;  // phase 2: 4 rows x 16 chunks per wave-wide access
         if (LAST) {
             float*    s_min = (float*)(lds + P::BEST_OFF);
             unsigned* s_idx = (unsigned*)(lds + P::BEST_OFF + C::WN * C::BT * 4);
@@ -909,10 +1050,13 @@ __global__ __launch_bounds__(C::THREADS) void gemm_bf16_pipe_kernel(const bf16_t
                     if ((DBG & 2) && o[0].x != 123.456f) {
                     }
                     else if (interior) {
+                        // wave-uniform row base + one 32-bit lane offset (4 frames x 256 B per access)
+                        const unsigned voff = (unsigned)(prow * ldo + 4 * pc) * 4u;
 #pragma unroll
-                        for (int it = 0; it < 8; ++it)  // written once, never re-read here: keep the operand panels in L2
-                            __builtin_nontemporal_store(f32x4{o[it].x, o[it].y, o[it].z, o[it].w},
-                                                        (f32x4*)((float*)out + (size_t)(tbase + it * 4 + prow) * ldo + n));
+                        for (int it = 0; it < 8; ++it) {  // written once, never re-read here: keep the operand panels in L2
+                            char* ub = (char*)((float*)out + (size_t)(tbase + it * 4) * ldo + nbase + ih * 64);
+                            __builtin_nontemporal_store(f32x4{o[it].x, o[it].y, o[it].z, o[it].w}, (f32x4*)(ub + voff));
+                        }
                     }
                     else {
 #pragma unroll
@@ -940,7 +1084,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm_bf16_pipe_kernel(const bf16_t
                         bmin = om;
                         bidx = oi;
                     }
-                    if (lane < 32) {
+                    if (elane < 32) {
                         const int tl = wt * (C::BT / C::WT) + j * 32 + tl32;
                         s_min[wn * C::BT + tl] = bmin;
                         s_idx[wn * C::BT + tl] = bidx;
@@ -950,7 +1094,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm_bf16_pipe_kernel(const bf16_t
             if (want_best) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // s_min / s_idx written; no VMEM drain here
                 __builtin_amdgcn_s_barrier();
-                for (int tl = tid; tl < C::BT; tl += C::THREADS) {
+                for (int tl = wave * 64 + elane; tl < C::BT; tl += C::THREADS) {
                     float    bmin = s_min[tl];
                     unsigned bidx = s_idx[tl];
 #pragma unroll
@@ -970,6 +1114,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm_bf16_pipe_kernel(const bf16_t
 #pragma unroll
             for (int j = 0; j < C::MJ; ++j) {
                 const int tbase = t0 + wt * (C::BT / C::WT) + j * 32;
+                uint2     lo[C::X3 ? C::MI : 1][4];  // split bf16: the lo plane of the 32 frames x 128 units, stored in a second pass
 #pragma unroll
                 for (int i = 0; i < C::MI; ++i) {
                     float4 b4[4];
@@ -978,23 +1123,40 @@ __global__ __launch_bounds__(C::THREADS) void gemm_bf16_pipe_kernel(const bf16_t
                         b4[gq] = *(const float4*)(sb + i * 32 + 8 * gq + 4 * hh);
 #pragma unroll
                     for (int gq = 0; gq < 4; ++gq) {
-                        const f32x16& c = acc[i][j];
+                        const f32x16& c  = acc[i][j];
+                        const float   a0 = activate<ACT>(c[gq * 4 + 0] + b4[gq].x), a1 = activate<ACT>(c[gq * 4 + 1] + b4[gq].y);
+                        const float   a2 = activate<ACT>(c[gq * 4 + 2] + b4[gq].z), a3 = activate<ACT>(c[gq * 4 + 3] + b4[gq].w);
                         uint2         pk;
-                        pk.x = pack_bf16(activate<ACT>(c[gq * 4 + 0] + b4[gq].x), activate<ACT>(c[gq * 4 + 1] + b4[gq].y));
-                        pk.y = pack_bf16(activate<ACT>(c[gq * 4 + 2] + b4[gq].z), activate<ACT>(c[gq * 4 + 3] + b4[gq].w));
+                        pk.x = pack_bf16(a0, a1);
+                        pk.y = pack_bf16(a2, a3);
+                        if (C::X3) {  // lo = bf16(v - hi)
+                            lo[i][gq].x = pack_bf16(a0 - __uint_as_float(pk.x << 16), a1 - __uint_as_float(pk.x & 0xffff0000u));
+                            lo[i][gq].y = pack_bf16(a2 - __uint_as_float(pk.y << 16), a3 - __uint_as_float(pk.y & 0xffff0000u));
+                        }
                         // the 8-byte half inside the chunk alternates with bit 3 of the row (b64 writes of rows r, r+8)
                         *(uint2*)(w_lds + pipe_swz(tl32, i * 4 + gq) + 8 * (hh ^ ((tl32 >> 3) & 1))) = pk;
                     }
                 }
-                uint4 o[8];
 #pragma unroll
-                for (int it = 0; it < 8; ++it) {
-                    const uint4 v = *(const uint4*)(w_lds + pipe_swz(it * 4 + prow, pc));
-                    o[it]         = ((it >> 1) & 1) ? make_uint4(v.z, v.w, v.x, v.y) : v;  // rows 8-15, 24-31: halves swapped
+                for (int pl = 0; pl < C::PLANES; ++pl) {
+                    if (pl == 1) {
+#pragma unroll
+                        for (int i = 0; i < C::MI; ++i)
+#pragma unroll
+                            for (int gq = 0; gq < 4; ++gq)
+                                *(uint2*)(w_lds + pipe_swz(tl32, i * 4 + gq) + 8 * (hh ^ ((tl32 >> 3) & 1))) = lo[C::X3 ? i : 0][gq];
+                    }
+                    uint4 o[8];
+#pragma unroll
+                    for (int it = 0; it < 8; ++it) {
+                        const uint4 v = *(const uint4*)(w_lds + pipe_swz(it * 4 + prow, pc));
+                        o[it]         = ((it >> 1) & 1) ? make_uint4(v.z, v.w, v.x, v.y) : v;  // rows 8-15, 24-31: halves swapped
+                    }
+                    const unsigned voff = (unsigned)(prow * ldo + 8 * pc) * 2u;  // wave-uniform row base + one 32-bit lane offset
+#pragma unroll
+                    for (int it = 0; it < 8; ++it)  // padded activation buffer: no guards
+                        *(uint4*)((char*)((bf16_t*)out + (size_t)(tbase + it * 4) * ldo + pl * ld.olo + nbase) + voff) = o[it];
                 }
-#pragma unroll
-                for (int it = 0; it < 8; ++it)  // padded activation buffer: no guards
-                    *(uint4*)((bf16_t*)out + (size_t)(tbase + it * 4 + prow) * ldo + nbase + 8 * pc) = o[it];
             }
         }
         counted = interior && !(DBG & 2);
@@ -1175,8 +1337,6 @@ struct amx_ffnn {
     float* d_rowstat = nullptr;  // softmax top layer: per-frame maximum / sum [2][cap]
     int    rowstat_cap = 0;
     float *d_Wout = nullptr, *d_bout = nullptr;
-    float* d_z      = nullptr;   // bf16x3 mode: f32 pre-activations of the current hidden layer [cap_T x max_hidden_pad]
-    std::vector<int> seg;        // bf16x3 mode: segment width of layer l's operands (Kpad of layer 0, Npad of the layer below otherwise)
     int    max_hidden_pad = 0;
     int    largest_layer  = 0;
     int    group_t = -1, group_n = -1;  // super-tile of the XCD-aware tile order
@@ -1224,23 +1384,13 @@ int ensure_workspace(amx_ffnn* h, int Tpad) {
     hipFree(h->d_in);
     hipFree(h->d_act[0]);
     hipFree(h->d_act[1]);
-    hipFree(h->d_z);
     h->d_in = h->d_act[0] = h->d_act[1] = nullptr;
-    h->d_z                              = nullptr;
     h->cap_T                            = 0;
-    if (h->precision == AMX_PREC_BF16X3) {  // one [hi | hi | lo] activation buffer (a layer's output replaces its input) + f32 pre-activations
-        AMX_HIP(hipMalloc(&h->d_in, (size_t)Tpad * 3 * h->seg[0] * 2));
-        if (h->max_hidden_pad > 0) {
-            AMX_HIP(hipMalloc(&h->d_act[0], (size_t)Tpad * 3 * h->max_hidden_pad * 2));
-            AMX_HIP(hipMalloc((void**)&h->d_z, (size_t)Tpad * h->max_hidden_pad * 4));
-        }
-        h->cap_T = Tpad;
-        return AMX_OK;
-    }
-    AMX_HIP(hipMalloc(&h->d_in, (size_t)Tpad * h->Kpad[0] * h->elt()));
+    const size_t planes = h->precision == AMX_PREC_BF16X3 ? 2 : 1;  // split bf16: rows are [hi plane | lo plane]
+    AMX_HIP(hipMalloc(&h->d_in, (size_t)Tpad * planes * h->Kpad[0] * h->elt()));
     if (h->max_hidden_pad > 0) {
-        AMX_HIP(hipMalloc(&h->d_act[0], (size_t)Tpad * h->max_hidden_pad * h->elt()));
-        AMX_HIP(hipMalloc(&h->d_act[1], (size_t)Tpad * h->max_hidden_pad * h->elt()));
+        AMX_HIP(hipMalloc(&h->d_act[0], (size_t)Tpad * planes * h->max_hidden_pad * h->elt()));
+        AMX_HIP(hipMalloc(&h->d_act[1], (size_t)Tpad * planes * h->max_hidden_pad * h->elt()));
     }
     h->cap_T = Tpad;
     return AMX_OK;
@@ -1253,6 +1403,25 @@ using CfgS = amx::GemmCfg<128, 64, 2, 2, 2>;   //  48 KB LDS, 3 workgroups per C
 using CfgS3 = amx::GemmCfg<128, 64, 2, 2, 3>;  //  72 KB LDS, two K-tiles in flight: layers with about one tile per CU (batch 1024 hidden layers: 19 -> 15.5 us)
 // measured and dropped: GemmCfg<256,256,2,4,4,32> (4 stages of BK=32, three K-tiles in flight): 800 TF
 // measured and dropped: 256x128x64 3-stage (753 TF), 256x256 with 64x128 wave tiles (973 TF) vs CfgC (1000 TF), CfgA (870 TF)
+// split bf16: the same tile shapes with four planes (W_hi, W_lo, X_hi, X_lo) of 32 k per stage -- the same LDS bytes per stage as
+// the 64-k bf16 tiles, 1.5 times the MFMA work per staged byte
+using XfgA  = amx::GemmCfg<128, 128, 2, 2, 2, 32, true>;
+using XfgC  = amx::GemmCfg<256, 256, 2, 4, 2, 32, true>;
+using XfgS  = amx::GemmCfg<128, 64, 2, 2, 2, 32, true>;
+using XfgS3 = amx::GemmCfg<128, 64, 2, 2, 3, 32, true>;
+
+// strides and plane offsets of layer l's launch (x: ldx elements per row, lo plane at xlo; out: ldo, olo)
+amx::GemmLd gemm_ld(const amx_ffnn* h, int l, int ldx, int ldo) {
+    amx::GemmLd ld;
+    const bool  x3 = h->precision == AMX_PREC_BF16X3;
+    ld.ldw = x3 ? 2 * h->Kpad[l] : h->Kpad[l];
+    ld.wlo = x3 ? h->Kpad[l] : 0;
+    ld.ldx = ldx;
+    ld.xlo = x3 ? ldx / 2 : 0;
+    ld.ldo = ldo;
+    ld.olo = x3 ? ldo / 2 : 0;  // hidden layers only; the output layer writes f32 scores
+    return ld;
+}
 
 template<class C, int ACT, bool LAST, int VAR>
 void launch_bf16v(amx_ffnn* h, int l, const void* x, int ldx, void* out, int ldo, int T, int Tpad) {
@@ -1272,7 +1441,7 @@ void launch_bf16v(amx_ffnn* h, int l, const void* x, int ldx, void* out, int ldo
     if (h->gemm_persistent == 0)
         grid = ntn * ntt;
     hipLaunchKernelGGL(k, dim3(grid), dim3(C::THREADS), lds_bytes, h->ctx->stream, (const amx::bf16_t*)h->d_W[l],
-                       (const amx::bf16_t*)x, h->d_bias[l], out, h->Kpad[l], ldx, ldo, h->out[l], T, ntn, ntn * ntt, gt, gn,
+                       (const amx::bf16_t*)x, h->d_bias[l], out, h->Kpad[l], gemm_ld(h, l, ldx, ldo), h->out[l], T, ntn, ntn * ntt, gt, gn,
                        LAST ? h->cur_part_min : nullptr, LAST ? h->cur_part_idx : nullptr, Tpad);
     if (LAST)
         h->cur_ntn = ntn;
@@ -1298,7 +1467,7 @@ void launch_bf16_pipe(amx_ffnn* h, int l, const void* x, int ldx, void* out, int
         grid &= ~7;  // keep blockIdx % 8 == tile index % 8 for every stride step
     const int aligned = LAST ? (((uintptr_t)out & 15) == 0 && (ldo & 3) == 0) : 1;
     hipLaunchKernelGGL(k, dim3(grid), dim3(C::THREADS), P::BYTES, h->ctx->stream, (const amx::bf16_t*)h->d_W[l], (const amx::bf16_t*)x,
-                       h->d_bias[l], out, h->Kpad[l], ldx, ldo, h->out[l], T, ntn, ntn * ntt, gt, gn, aligned,
+                       h->d_bias[l], out, h->Kpad[l], gemm_ld(h, l, ldx, ldo), h->out[l], T, ntn, ntn * ntt, gt, gn, aligned,
                        LAST ? h->cur_part_min : nullptr, LAST ? h->cur_part_idx : nullptr, Tpad);
     if (LAST)
         h->cur_ntn = ntn;
@@ -1317,6 +1486,16 @@ void launch_bf16_cfg(amx_ffnn* h, int l, const void* x, int ldx, void* out, int 
             cfg = 6;  // about one tile per CU: nothing else hides the operand latency, keep two K-tiles in flight
         else
             cfg = 3;
+    }
+    if (h->precision == AMX_PREC_BF16X3) {
+        switch (cfg) {
+            case 2: launch_bf16_pipe<XfgC, ACT, LAST>(h, l, x, ldx, out, ldo, T, Tpad); break;
+            case 4: launch_bf16<XfgC, ACT, LAST>(h, l, x, ldx, out, ldo, T, Tpad); break;
+            case 3: launch_bf16<XfgS, ACT, LAST>(h, l, x, ldx, out, ldo, T, Tpad); break;
+            case 6: launch_bf16<XfgS3, ACT, LAST>(h, l, x, ldx, out, ldo, T, Tpad); break;
+            default: launch_bf16<XfgA, ACT, LAST>(h, l, x, ldx, out, ldo, T, Tpad); break;
+        }
+        return;
     }
     switch (cfg) {
         case 2: launch_bf16_pipe<CfgC, ACT, LAST>(h, l, x, ldx, out, ldo, T, Tpad); break;
@@ -1474,24 +1653,18 @@ int amx_ffnn_create(amx_ctx* ctx, const amx_ffnn_model* m, amx_ffnn** out) {
         const float* W = Wl[l];
         void*        d = nullptr;
         if (m->precision == AMX_PREC_BF16X3) {
-            // rows [W_hi | W_lo | W_hi], segments as wide as the rows of the activation buffer that feeds the layer.  Hidden layers
-            // go through the output-layer epilogue (f32 rows, value = -(D + bias)), so their weights and biases are stored negated
-            // and the activation is applied by split_act_bf16x3.
-            const int   sg  = l == 0 ? Kp : h->Npad[l - 1];
-            const float sgn = (l + 1 < m->n_layers) ? -1.f : 1.f;
-            h->seg.push_back(sg);
-            std::vector<amx::bf16_t> pk((size_t)Np * 3 * sg, 0);
+            // rows [W_hi | W_lo], each plane Kp columns wide (zero padded); the rows that feed the layer are [X_hi | X_lo] with the
+            // lo plane at column xlo = Kpad (layer 0) or Npad of the layer below
+            std::vector<amx::bf16_t> pk((size_t)Np * 2 * Kp, 0);
             for (int n = 0; n < N; ++n)
                 for (int k = 0; k < K; ++k) {
-                    const float       w  = sgn * W[(size_t)n * K + k];
+                    const float       w  = W[(size_t)n * K + k];
                     const amx::bf16_t hi = amx::f2bf_host(w);
                     unsigned          hu = (unsigned)hi << 16;
                     float             hf;
                     memcpy(&hf, &hu, 4);
-                    const amx::bf16_t lo = amx::f2bf_host(w - hf);
-                    pk[(size_t)n * 3 * sg + k]          = hi;
-                    pk[(size_t)n * 3 * sg + sg + k]     = lo;
-                    pk[(size_t)n * 3 * sg + 2 * sg + k] = hi;
+                    pk[(size_t)n * 2 * Kp + k]      = hi;
+                    pk[(size_t)n * 2 * Kp + Kp + k] = amx::f2bf_host(w - hf);
                 }
             if (hipMalloc(&d, pk.size() * 2) != hipSuccess || hipMemcpy(d, pk.data(), pk.size() * 2, hipMemcpyHostToDevice) != hipSuccess) {
                 amx::set_error("amx_ffnn_create: device allocation of layer %d failed", l);
@@ -1499,7 +1672,6 @@ int amx_ffnn_create(amx_ctx* ctx, const amx_ffnn_model* m, amx_ffnn** out) {
                 amx_ffnn_destroy(h);
                 return AMX_ERR_DEVICE;
             }
-            h->Kpad[l] = 3 * sg;  // the GEMM's K extent
         }
         else if (m->precision == AMX_PREC_BF16) {
             std::vector<amx::bf16_t> pk((size_t)Np * Kp, 0);
@@ -1533,7 +1705,7 @@ int amx_ffnn_create(amx_ctx* ctx, const amx_ffnn_model* m, amx_ffnn** out) {
                 float prod = m->prior_scale * prior[n];
                 v          = v - prod;
             }
-            b[n] = (m->precision == AMX_PREC_BF16X3 && l + 1 < m->n_layers) ? -v : v;
+            b[n] = v;
         }
         if (l == m->n_layers - 1) {
             h->h_Wout.assign(W, W + (size_t)N * K);
@@ -1563,7 +1735,6 @@ void amx_ffnn_destroy(amx_ffnn* h) {
     hipFree(h->d_in);
     hipFree(h->d_act[0]);
     hipFree(h->d_act[1]);
-    hipFree(h->d_z);
     hipFree(h->d_Wout);
     hipFree(h->d_bout);
     hipFree(h->d_rowstat);
@@ -1683,7 +1854,7 @@ static int ffnn_launches(amx_ffnn* h, const float* feats_dev, int feats_stride, 
             const int blocks = (int)std::min<long long>(4096, ((long long)Tpad * h->Kpad[0] + 255) / 256);
             if (h->precision == AMX_PREC_BF16X3)
                 hipLaunchKernelGGL(amx::pack_input_bf16x3, dim3(blocks), dim3(256), 0, h->ctx->stream, x, feats_stride, Tc, h->in[0],
-                                   (amx::bf16_t*)h->d_in, h->seg[0], Tpad);
+                                   (amx::bf16_t*)h->d_in, h->Kpad[0], Tpad);
             else if (h->precision == AMX_PREC_BF16)
                 hipLaunchKernelGGL(amx::pack_input_bf16, dim3(blocks), dim3(256), 0, h->ctx->stream, x, feats_stride, Tc, h->in[0],
                                    (amx::bf16_t*)h->d_in, h->Kpad[0], Tpad);
@@ -1694,7 +1865,8 @@ static int ffnn_launches(amx_ffnn* h, const float* feats_dev, int feats_stride, 
         }
         const void* cur = h->d_in;
         const bool  x3  = h->precision == AMX_PREC_BF16X3;
-        int         ldx = x3 ? 3 * h->seg[0] : h->Kpad[0];
+        const int   planes = x3 ? 2 : 1;  // split bf16: rows are [hi plane | lo plane]
+        int         ldx    = planes * h->Kpad[0];
         const bool  fused = stats && h->mfma_bf16();
         h->cur_part_min = nullptr;
         h->cur_part_idx = nullptr;
@@ -1723,7 +1895,7 @@ static int ffnn_launches(amx_ffnn* h, const float* feats_dev, int feats_stride, 
                 float*    dst = hidden_out + (size_t)t0 * H;
                 const int blocks = (int)std::min<long long>(8192, ((long long)Tc * H + 255) / 256);
                 if (x3)
-                    hipLaunchKernelGGL(amx::export_hidden_kernel<2>, dim3(blocks), dim3(256), 0, h->ctx->stream, cur, ldx, ldx / 3, Tc, H, dst);
+                    hipLaunchKernelGGL(amx::export_hidden_kernel<2>, dim3(blocks), dim3(256), 0, h->ctx->stream, cur, ldx, ldx / 2, Tc, H, dst);
                 else if (h->precision == AMX_PREC_BF16)
                     hipLaunchKernelGGL(amx::export_hidden_kernel<1>, dim3(blocks), dim3(256), 0, h->ctx->stream, cur, ldx, 0, Tc, H, dst);
                 else
@@ -1744,39 +1916,11 @@ static int ffnn_launches(amx_ffnn* h, const float* feats_dev, int feats_stride, 
                     r = amx_stats_accumulate_dev(h->ctx, sc, Tc, h->out[l], best_state_dev ? best_state_dev + t0 : nullptr, counts_dev,
                                                  score_sum_dev);
             }
-            else if (x3) {
-                // hidden layer through the output-layer epilogue (negated weights: z = W x + b in f32), then activation + split
-                float*    part_min = h->cur_part_min;
-                unsigned* part_idx = h->cur_part_idx;
-                h->cur_part_min    = nullptr;  // no arg-min partials for hidden layers
-                h->cur_part_idx    = nullptr;
-                r                  = launch_layer<true>(h, l, cur, ldx, h->d_z, h->Npad[l], Tc, Tpad);
-                h->cur_part_min    = part_min;
-                h->cur_part_idx    = part_idx;
-                if (r == AMX_OK) {
-                    amx::ScopedKernelTimer timer(h->ctx, "ffnn_split");
-                    const int sg     = h->Npad[l];
-                    const int blocks = (int)std::min<long long>(8192, ((long long)Tpad * (sg / 4) + 255) / 256);
-                    amx::bf16_t* dst = (amx::bf16_t*)h->d_act[0];
-#define AMX_SPLIT(ACT) \
-    hipLaunchKernelGGL(amx::split_act_bf16x3<ACT>, dim3(blocks), dim3(256), 0, h->ctx->stream, h->d_z, h->Npad[l], Tc, h->out[l], dst, sg, Tpad)
-                    switch (h->act[l]) {
-                        case AMX_ACT_RELU: AMX_SPLIT(AMX_ACT_RELU); break;
-                        case AMX_ACT_SIGMOID: AMX_SPLIT(AMX_ACT_SIGMOID); break;
-                        case AMX_ACT_TANH: AMX_SPLIT(AMX_ACT_TANH); break;
-                        default: AMX_SPLIT(AMX_ACT_NONE); break;
-                    }
-#undef AMX_SPLIT
-                    AMX_HIP(hipGetLastError());
-                    cur = dst;
-                    ldx = 3 * sg;
-                }
-            }
             else {
-                void* dst = h->d_act[l & 1];
-                r         = launch_layer<false>(h, l, cur, ldx, dst, h->Npad[l], Tc, Tpad);
+                void* dst = h->d_act[l & 1];  // split bf16: the epilogue applies the activation and writes both planes
+                r         = launch_layer<false>(h, l, cur, ldx, dst, planes * h->Npad[l], Tc, Tpad);
                 cur       = dst;
-                ldx       = h->Npad[l];
+                ldx       = planes * h->Npad[l];
             }
             if (r != AMX_OK)
                 return r;

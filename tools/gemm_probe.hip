@@ -21,13 +21,15 @@
 
 struct Problem {
     int             N = 10000, K = 2048, T = 32768, Npad, Tpad;
-    amx::bf16_t *   W, *X;
+    amx::bf16_t *   W, *X;      // rows [hi plane | lo plane], 2 K columns (plain bf16 launches use the hi plane only)
     float *         bias, *out, *pmin;
     unsigned*       pidx;
     unsigned long long* trace;
     unsigned*       sync;
     int             n_cu;
     int             gt = 0, gn = 0;
+    int             pad = 0;    // PROBE_PAD: extra elements per operand row (row stride 2 K + pad)
+    amx::GemmLd ld(bool x3) const { return amx::GemmLd{2 * K + pad, x3 ? K : 0, 2 * K + pad, x3 ? K : 0, N, 0}; }
 };
 
 template<class C, int VAR>
@@ -45,7 +47,7 @@ float run(Problem& p, int iters, bool quiet = false) {
     for (int it = -2; it < iters; ++it) {
         CK(hipMemsetAsync(p.sync, 0, 8 * 64 * 4, 0));
         CK(hipEventRecord(e0, 0));
-        hipLaunchKernelGGL(k, dim3(grid), dim3(C::THREADS), lds, 0, p.W, p.X, p.bias, (void*)p.out, p.K, p.K, p.N, p.N, p.T, ntn, ntn * ntt, p.gt, p.gn,
+        hipLaunchKernelGGL(k, dim3(grid), dim3(C::THREADS), lds, 0, p.W, p.X, p.bias, (void*)p.out, p.K, p.ld(C::X3), p.N, p.T, ntn, ntn * ntt, p.gt, p.gn,
                            p.pmin, p.pidx, p.Tpad);
         CK(hipEventRecord(e1, 0));
         CK(hipEventSynchronize(e1));
@@ -55,7 +57,8 @@ float run(Problem& p, int iters, bool quiet = false) {
             total += ms;
     }
     const float ms = total / iters;
-    if (!quiet) printf("var %4d  group %dx%d  tile %dx%d  grid %d  %.4f ms  %.0f TFLOP/s\n", VAR, p.gt, p.gn, C::BN, C::BT, grid, ms, 2.0 * p.N * p.K * p.T / ms * 1e-9);
+    if (!quiet) printf("%s var %4d  group %dx%d  tile %dx%dx%d  grid %d  %.4f ms  %.0f TFLOP/s executed\n", C::X3 ? "x3  " : "bf16", VAR, p.gt, p.gn, C::BN, C::BT, C::BKC, grid, ms,
+                       (C::X3 ? 3.0 : 1.0) * 2.0 * p.N * p.K * p.T / ms * 1e-9);
     fflush(stdout);
     return ms;
 }
@@ -73,7 +76,7 @@ float run_pipe(Problem& p, int iters, bool quiet = false) {
     float total = 0;
     for (int it = -2; it < iters; ++it) {
         CK(hipEventRecord(e0, 0));
-        hipLaunchKernelGGL(k, dim3(grid), dim3(C::THREADS), P::BYTES, 0, p.W, p.X, p.bias, (void*)p.out, p.K, p.K, p.N, p.N, p.T, ntn, ntn * ntt,
+        hipLaunchKernelGGL(k, dim3(grid), dim3(C::THREADS), P::BYTES, 0, p.W, p.X, p.bias, (void*)p.out, p.K, p.ld(C::X3), p.N, p.T, ntn, ntn * ntt,
                            p.gt, p.gn, 1, p.pmin, p.pidx, p.Tpad);
         CK(hipEventRecord(e1, 0));
         CK(hipEventSynchronize(e1));
@@ -83,7 +86,8 @@ float run_pipe(Problem& p, int iters, bool quiet = false) {
             total += ms;
     }
     const float ms = total / iters;
-    if (!quiet) printf("pipe %3d  group %dx%d  tile %dx%d  grid %d  %.4f ms  %.0f TFLOP/s\n", DBG, p.gt, p.gn, C::BN, C::BT, grid, ms, 2.0 * p.N * p.K * p.T / ms * 1e-9);
+    if (!quiet) printf("%s pipe %3d  group %dx%d  tile %dx%dx%d  grid %d  %.4f ms  %.0f TFLOP/s executed\n", C::X3 ? "x3  " : "bf16", DBG, p.gt, p.gn, C::BN, C::BT, C::BKC, grid, ms,
+                       (C::X3 ? 3.0 : 1.0) * 2.0 * p.N * p.K * p.T / ms * 1e-9);
     fflush(stdout);
     return ms;
 }
@@ -94,6 +98,9 @@ void dump_trace(Problem& p, size_t trace_n) {
     const int grid = 256, steps = (p.Npad / 256) * (p.Tpad / 256) / grid;
     unsigned long long t00 = ~0ull;
     for (int b = 0; b < grid; ++b) t00 = std::min(t00, tr[(size_t)b * 256]);
+    int xcc_mismatch = 0;
+    for (int b = 0; b < grid; ++b) xcc_mismatch += ((int)tr[(size_t)b * 256 + 3] & 15) != (b & 7);
+    printf("workgroups whose XCC_ID != blockIdx %% 8: %d of %d\n", xcc_mismatch, grid);
     printf("step: per XCD 0 start skew (us) | all: start min..max, kloop avg, epilogue avg (us)   [100 MHz clock]\n");
     for (int st = 0; st < steps; ++st) {
         double smin = 1e30, smax = 0, kl = 0, ep = 0, x0min = 1e30, x0max = 0;
@@ -120,6 +127,7 @@ void dump_trace(Problem& p, size_t trace_n) {
     }
 }
 
+// arguments: <variant>[:<GT>x<GN>] ...   variants: see the table in main(); a leading 'x' selects the split-bf16 kernels
 int main(int argc, char** argv) {
     Problem p;
     if (getenv("PROBE_N")) p.N = atoi(getenv("PROBE_N"));  // small problems: PROBE_N=2048 PROBE_T=1024 ... s0 s128 s136 s144 s192 t0 t128
@@ -130,12 +138,27 @@ int main(int argc, char** argv) {
     hipDeviceProp_t prop;
     CK(hipGetDeviceProperties(&prop, 0));
     p.n_cu = prop.multiProcessorCount;
-    std::vector<amx::bf16_t> w((size_t)p.Npad * p.K), x((size_t)p.Tpad * p.K);
+    if (getenv("PROBE_PAD")) p.pad = atoi(getenv("PROBE_PAD"));
+    const size_t rs = (size_t)2 * p.K + p.pad;
+    std::vector<amx::bf16_t> w((size_t)p.Npad * rs), x((size_t)p.Tpad * rs);
     std::mt19937             rng(1);
     std::normal_distribution<float> nd(0.f, 1.f);
-    for (auto& v : w) v = amx::f2bf_host(nd(rng) * 0.02f);
     const bool relu = getenv("PROBE_RELU") != nullptr;  // hidden activations after ReLU: half the operand is zero
-    for (auto& v : x) { float f = nd(rng); v = amx::f2bf_host(relu && f < 0.f ? 0.f : f); }
+    auto fill = [&](std::vector<amx::bf16_t>& v, size_t rows, float scale, bool rl) {
+        for (size_t r = 0; r < rows; ++r)
+            for (int k = 0; k < p.K; ++k) {
+                float f = nd(rng) * scale;
+                if (rl && f < 0.f) f = 0.f;
+                const amx::bf16_t hi = amx::f2bf_host(f);
+                unsigned hu = (unsigned)hi << 16;
+                float    hf;
+                memcpy(&hf, &hu, 4);
+                v[r * rs + k]       = hi;
+                v[r * rs + p.K + k] = amx::f2bf_host(f - hf);
+            }
+    };
+    fill(w, p.Npad, 0.02f, false);
+    fill(x, p.Tpad, 1.f, relu);
     CK(hipMalloc((void**)&p.W, w.size() * 2));
     CK(hipMalloc((void**)&p.X, x.size() * 2));
     CK(hipMemcpy(p.W, w.data(), w.size() * 2, hipMemcpyHostToDevice));
@@ -151,8 +174,14 @@ int main(int argc, char** argv) {
     CK(hipMalloc((void**)&p.sync, 8 * 64 * 4));
     CK(hipMemcpyToSymbol(HIP_SYMBOL(amx::g_gemm_trace), &p.trace, sizeof(void*)));
     CK(hipMemcpyToSymbol(HIP_SYMBOL(amx::g_gemm_sync), &p.sync, sizeof(void*)));
-    using CfgC = amx::GemmCfg<256, 256, 2, 4, 2>;
-    const int iters = 10;
+    using CfgC  = amx::GemmCfg<256, 256, 2, 4, 2>;
+    using XfgC  = amx::GemmCfg<256, 256, 2, 4, 2, 32, true>;
+    using XfgA  = amx::GemmCfg<128, 128, 2, 2, 2, 32, true>;
+    using CfgS  = amx::GemmCfg<128, 64, 2, 2, 2>;
+    using CfgS3 = amx::GemmCfg<128, 64, 2, 2, 3>;
+    using XfgS  = amx::GemmCfg<128, 64, 2, 2, 2, 32, true>;
+    using XfgS3 = amx::GemmCfg<128, 64, 2, 2, 3, 32, true>;
+    const int iters = getenv("PROBE_ITERS") ? atoi(getenv("PROBE_ITERS")) : 10;
     { Problem q = p; fprintf(stderr, "warm-up\n"); for (int w = 0; w < 30; ++w) run<CfgC, 128>(q, 10, true); }
     for (int a = 1; a < argc; ++a) {
         std::string s = argv[a];
@@ -161,76 +190,46 @@ int main(int argc, char** argv) {
             sscanf(s.c_str() + s.find(':') + 1, "%dx%d", &p.gt, &p.gn);
             s = s.substr(0, s.find(':'));
         }
-        using CfgS = amx::GemmCfg<128, 64, 2, 2, 2>;
-        using CfgS3 = amx::GemmCfg<128, 64, 2, 2, 3>;
-        using CfgS4 = amx::GemmCfg<128, 64, 2, 2, 4>;
-        using CfgS5 = amx::GemmCfg<128, 64, 2, 2, 5>;
-        using CfgS6 = amx::GemmCfg<128, 64, 2, 2, 6>;
-        if (s == "u0") run<CfgS4, 0>(p, iters);
-        else if (s == "u192") run<CfgS4, 64 | 128>(p, iters);
-        else if (s == "v0") run<CfgS5, 0>(p, iters);
-        else if (s == "v192") run<CfgS5, 64 | 128>(p, iters);
-        else if (s == "w0") run<CfgS6, 0>(p, iters);
-        else if (s == "w192") run<CfgS6, 64 | 128>(p, iters);
-        else if (s == "w128") run<CfgS6, 128>(p, iters);
-        else if (s == "s0") run<CfgS, 0>(p, iters);
-        else if (s == "s128") run<CfgS, 128>(p, iters);
-        else if (s == "s136") run<CfgS, 8 | 128>(p, iters);
-        else if (s == "s144") run<CfgS, 16 | 128>(p, iters);
-        else if (s == "s192") run<CfgS, 64 | 128>(p, iters);
-        else if (s == "s152") run<CfgS, 8 | 16 | 128>(p, iters);
-        else if (s == "t0") run<CfgS3, 0>(p, iters);
-        else if (s == "t128") run<CfgS3, 128>(p, iters);
-        else if (s == "t192") run<CfgS3, 64 | 128>(p, iters);
-        else if (s == "p0") run_pipe<CfgC, 0>(p, iters);
+        // pipelined 256x256 kernel: p<DBG> (bf16), xp<DBG> (split bf16)
+        if (s == "p0") run_pipe<CfgC, 0>(p, iters);
         else if (s == "p2") run_pipe<CfgC, 2>(p, iters);
         else if (s == "p4") run_pipe<CfgC, 4>(p, iters);
+        else if (s == "p8") run_pipe<CfgC, 8>(p, iters);          // no MFMA
+        else if (s == "p16") run_pipe<CfgC, 16>(p, iters);        // no operand DMA after the first K-tile
+        else if (s == "p32") run_pipe<CfgC, 32>(p, iters);        // DMA burst behind the barrier
         else if (s == "ptrace") { run_pipe<CfgC, 1>(p, 1); dump_trace(p, trace_n); }
+        else if (s == "xp0") run_pipe<XfgC, 0>(p, iters);
+        else if (s == "xp4") run_pipe<XfgC, 4>(p, iters);
+        else if (s == "xp8") run_pipe<XfgC, 8>(p, iters);
+        else if (s == "xp16") run_pipe<XfgC, 16>(p, iters);
+        else if (s == "xp24") run_pipe<XfgC, 24>(p, iters);       // fragment reads + barriers only
+        else if (s == "xp32") run_pipe<XfgC, 32>(p, iters);
+        else if (s == "xp40") run_pipe<XfgC, 40>(p, iters);       // DMA burst, no MFMA
+        else if (s == "xp72") run_pipe<XfgC, 72>(p, iters);       // no MFMA, L2-resident operands
+        else if (s == "xp64") run_pipe<XfgC, 64>(p, iters);       // L2-resident operands
+        else if (s == "p72") run_pipe<CfgC, 72>(p, iters);
+        else if (s == "p64") run_pipe<CfgC, 64>(p, iters);
+        else if (s == "xptrace") { run_pipe<XfgC, 1>(p, 1); dump_trace(p, trace_n); }
+        else if (s == "xptrace32") { run_pipe<XfgC, 33>(p, 1); dump_trace(p, trace_n); }
+        // generic kernel, 256x256 tiles
         else if (s == "0") run<CfgC, 0>(p, iters);
+        else if (s == "x0") run<XfgC, 0>(p, iters);
+        else if (s == "xa0") run<XfgA, 0>(p, iters);
         else if (s == "64") run<CfgC, 64 | 128>(p, iters);       // operand streaming only, no epilogue
         else if (s == "128") run<CfgC, 128>(p, iters);           // K-loop only
         else if (s == "256") run<CfgC, 256>(p, iters);           // epilogue without global stores
         else if (s == "136") run<CfgC, 8 | 128>(p, iters);        // loads + fragment reads, no MFMA, no epilogue
         else if (s == "144") run<CfgC, 16 | 128>(p, iters);       // no global loads after the first: reads + MFMA
-        else if (s == "1024") run<CfgC, 1024>(p, iters);         // XCD tile barrier
-        else if (s == "1088") run<CfgC, 1024 | 64 | 128>(p, iters);
-        else if (s == "1152") run<CfgC, 1024 | 128>(p, iters);
-        else if (s == "trace" || s == "trace1024") {
-            if (s == "trace") run<CfgC, 512>(p, 1);
-            else run<CfgC, 512 | 1024>(p, 1);
-            std::vector<unsigned long long> tr(trace_n);
-            CK(hipMemcpy(tr.data(), p.trace, trace_n * 8, hipMemcpyDeviceToHost));
-            const int grid = 256, steps = (p.Npad / 256) * (p.Tpad / 256) / grid;
-            unsigned long long t00 = ~0ull;
-            for (int b = 0; b < grid; ++b) t00 = std::min(t00, tr[(size_t)b * 256]);
-            int xcc_mismatch = 0;
-            for (int b = 0; b < grid; ++b) xcc_mismatch += ((int)tr[(size_t)b * 256 + 3] & 15) != (b & 7);
-            printf("workgroups whose XCC_ID != blockIdx %% 8: %d of %d\n", xcc_mismatch, grid);
-            printf("step: per XCD 0 start skew (us) | all: start min..max, kloop avg, epilogue avg (us)   [100 MHz clock]\n");
-            for (int st = 0; st < steps; ++st) {
-                double smin = 1e30, smax = 0, kl = 0, ep = 0, x0min = 1e30, x0max = 0;
-                for (int b = 0; b < grid; ++b) {
-                    const unsigned long long* r = &tr[((size_t)b * 64 + st) * 4];
-                    double s0 = (r[0] - t00) * 0.01, s1 = (r[1] - t00) * 0.01, s2 = (r[2] - t00) * 0.01;
-                    smin = std::min(smin, s0); smax = std::max(smax, s0);
-                    if ((b & 7) == 0) { x0min = std::min(x0min, s0); x0max = std::max(x0max, s0); }
-                    kl += s1 - s0; ep += s2 - s1;
-                }
-                if (st == steps - 1) {
-            printf("end of last tile per XCD (us): ");
-            for (int x = 0; x < 8; ++x) {
-                double mn = 1e30, mx = 0;
-                for (int b = x; b < grid; b += 8) {
-                    double e = (tr[((size_t)b * 64 + st) * 4 + 2] - t00) * 0.01;
-                    mn = std::min(mn, e); mx = std::max(mx, e);
-                }
-                printf(" x%d %.0f..%.0f", x, mn, mx);
-            }
-            printf("\n");
-        }
-        printf("%2d: xcd0 skew %6.1f | start %8.1f..%8.1f  kloop %6.1f  epi %6.1f\n", st, x0max - x0min, smin, smax, kl / grid, ep / grid);
-            }
-        }
+        // small tiles (PROBE_N=2048 PROBE_T=1024: a hidden layer of config 4)
+        else if (s == "s0") run<CfgS, 0>(p, iters);
+        else if (s == "s128") run<CfgS, 128>(p, iters);
+        else if (s == "s192") run<CfgS, 64 | 128>(p, iters);
+        else if (s == "t0") run<CfgS3, 0>(p, iters);
+        else if (s == "t128") run<CfgS3, 128>(p, iters);
+        else if (s == "xs0") run<XfgS, 0>(p, iters);
+        else if (s == "xt0") run<XfgS3, 0>(p, iters);
+        else if (s == "trace") { run<CfgC, 512>(p, 1); dump_trace(p, trace_n); }
+        else fprintf(stderr, "unknown variant %s\n", s.c_str());
     }
     return 0;
 }
