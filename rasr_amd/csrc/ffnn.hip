@@ -29,6 +29,7 @@
 #include <algorithm>
 #include <map>
 #include <tuple>
+#include <type_traits>
 #include <cmath>
 #include <cstring>
 
@@ -745,13 +746,13 @@ __device__ __forceinline__ void pipe_read_half(PipeFrag<C>& f, const char* stage
     }
 }
 
-// MFMAs of one half in the order every bf16 GEMM kernel of this file uses (slab by slab; split bf16: hi.hi, lo.hi, hi.lo of the slab),
-// PART 0 = the first half of that sequence, PART 1 = the rest
-template<class C, int PART, int DBG>
-__device__ __forceinline__ void pipe_mfma_part(f32x16 (&acc)[C::MI][C::MJ], const PipeFrag<C>& f) {
-    constexpr int T = C::MI * C::MJ, MPH = (C::X3 ? 3 : 2) * T, HALF = MPH / 2;
+// MFMAs M0 .. M1-1 of one half, in the order every bf16 GEMM kernel of this file uses (slab by slab; split bf16: hi.hi, lo.hi, hi.lo
+// of the slab)
+template<class C, int M0, int M1, int DBG>
+__device__ __forceinline__ void pipe_mfma_range(f32x16 (&acc)[C::MI][C::MJ], const PipeFrag<C>& f) {
+    constexpr int T = C::MI * C::MJ;
 #pragma unroll
-    for (int m = PART * HALF; m < (PART + 1) * HALF; ++m) {
+    for (int m = M0; m < M1; ++m) {
         const int grp = m / T, i = (m % T) / C::MJ, j = m % C::MJ;
         const bf16x8 av = C::X3 ? (grp == 1 ? f.al[i] : f.a[0][i]) : f.a[grp][i];
         const bf16x8 bv = C::X3 ? (grp == 2 ? f.bl[j] : f.b[0][j]) : f.b[grp][j];
@@ -831,6 +832,19 @@ __global__ __launch_bounds__(C::THREADS) void gemm_bf16_pipe_kernel(const bf16_t
                                              (__attribute__((address_space(3))) void*)(base + C::A_BYTES + i * C::NW * 1024), 16, 0, 0);
         }
     };
+    auto issue_piece = [&](int i, int slot, const bf16_t* pw, const bf16_t* px) {  // piece i of the K-tile: 0 .. A_LOADS-1 W, then X
+        char* base = lds + slot * C::STAGE_BYTES + wave * 1024;
+        if (i < C::A_LOADS) {
+            const bf16_t* u = pw + waveW + (size_t)(i / PPA) * ld.wlo + (size_t)(i % PPA) * stepW;
+            __builtin_amdgcn_global_load_lds((const void*)((const char*)u + voffW), (__attribute__((address_space(3))) void*)(base + i * C::NW * 1024), 16, 0, 0);
+        }
+        else {
+            const int q = i - C::A_LOADS;
+            const bf16_t* u = px + waveX + (size_t)(q / PPB) * ld.xlo + (size_t)(q % PPB) * stepX;
+            __builtin_amdgcn_global_load_lds((const void*)((const char*)u + voffX),
+                                             (__attribute__((address_space(3))) void*)(base + C::A_BYTES + q * C::NW * 1024), 16, 0, 0);
+        }
+    };
     auto issue_bias = [&](int buf, int tile_n) {  // wave 0: BN floats = 64 lanes x 16 B
         if (wave == 0) {  // scalar base + 32-bit lane offset (saddr form: no 64-bit lane pointer kept alive across the K-loop)
             const unsigned long long ub = (unsigned long long)(bias + tile_n * C::BN);
@@ -856,12 +870,18 @@ __global__ __launch_bounds__(C::THREADS) void gemm_bf16_pipe_kernel(const bf16_t
         c_pw = W + (size_t)c_tn * C::BN * ld.ldw;
         c_px = X + (size_t)tt * C::BT * ldx;
     }
-    auto issue_next = [&]() {
-        if (!((DBG & 16) && c >= 2)) {  // DBG 16: ablation, no operand traffic after the prologue
-            if (c_kt == 0)
-                issue_bias(c_buf, c_tn);  // the tile's bias vector travels in front of its first K-tile
-            issue(c & 1, c_pw, c_px);
-        }
+    // cursor_take: the K-tile at the cursor becomes (q_slot, q_pw, q_px), whose pieces are issued by issue_piece / issue_rest; the
+    // cursor moves on
+    const bf16_t *q_pw = nullptr, *q_px = nullptr;
+    int           q_slot = 0;
+    bool          q_on   = false;
+    auto cursor_take = [&]() {
+        q_on   = !((DBG & 16) && c >= 2);  // DBG 16: ablation, no operand traffic after the prologue
+        q_slot = c & 1;
+        q_pw   = c_pw;
+        q_px   = c_px;
+        if (q_on && c_kt == 0)
+            issue_bias(c_buf, c_tn);  // the tile's bias vector travels in front of its first K-tile
         ++c;
         if (++c_kt < KT) {
             c_pw += C::BKC;
@@ -879,6 +899,11 @@ __global__ __launch_bounds__(C::THREADS) void gemm_bf16_pipe_kernel(const bf16_t
                 c_px = X + (size_t)tt * C::BT * ldx;
             }
         }
+    };
+    auto issue_next = [&]() {  // a whole K-tile in one burst (prologue, first K-tile of a tile)
+        cursor_take();
+        if (q_on)
+            issue(q_slot, q_pw, q_px);
     };
     issue_next();
     if (c_valid)
@@ -941,30 +966,54 @@ __global__ __launch_bounds__(C::THREADS) void gemm_bf16_pipe_kernel(const bf16_t
         pipe_read_half<C, 0>(S0, lds + (g & 1) * C::STAGE_BYTES, a_row, b_row, fk);
 
         for (int kt = 0; kt < KT; ++kt, ++g) {
+            constexpr int MPH = (C::X3 ? 3 : 2) * C::MI * C::MJ, QN = MPH / 4;
+            static_assert(MPH % 4 == 0 && C::LOADS == 8, "eight pieces per wave and K-tile, between quarters of a half");
             const bool  last = kt + 1 == KT;
             const char* cur  = lds + (g & 1) * C::STAGE_BYTES;
             const char* nxt  = lds + ((g + 1) & 1) * C::STAGE_BYTES;
+            // The 8 LDS-DMA pieces of K-tile g+2 go out one at a time between groups of MFMAs: a burst of 64 pieces per workgroup behind
+            // the barrier parks every wave in front of the address unit, and a wave issues in order -- no MFMA leaves while its load
+            // waits (burst -> spread: output layer 3.53 -> 3.19 ms in split bf16, 1.37 -> 1.27 ms in bf16).  Measured and dropped: the
+            // two waves of a SIMD handing their pieces over half an interval apart (3.25 ms).
+#define AMX_PIECE(I)                                       \
+    do {                                                   \
+        __builtin_amdgcn_sched_barrier(0);                 \
+        if (on)                                            \
+            issue_piece(I, q_slot, q_pw, q_px);            \
+        __builtin_amdgcn_sched_barrier(0);                 \
+    } while (0)
             pipe_read_half<C, 1>(S1, cur, a_row, b_row, fk);
-            pipe_mfma_part<C, 0, DBG>(acc, S0);
+            pipe_mfma_range<C, 0, 2 * QN, DBG>(acc, S0);
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();  // R(g)
-            if (!last && c_valid)
-                issue_next();
-            __builtin_amdgcn_sched_barrier(0);
-            pipe_mfma_part<C, 1, DBG>(acc, S0);
-            pipe_mfma_part<C, 0, DBG>(acc, S1);
-            __builtin_amdgcn_sched_barrier(0);
+            const bool iss = !last && c_valid;
+            if (iss)
+                cursor_take();
+            const bool on = iss && q_on;
+            AMX_PIECE(0);
+            pipe_mfma_range<C, 2 * QN, 3 * QN, DBG>(acc, S0);
+            AMX_PIECE(1);
+            pipe_mfma_range<C, 3 * QN, 4 * QN, DBG>(acc, S0);
+            AMX_PIECE(2);
+            pipe_mfma_range<C, 0, QN, DBG>(acc, S1);
+            AMX_PIECE(3);
+            pipe_mfma_range<C, QN, 2 * QN, DBG>(acc, S1);
+            AMX_PIECE(4);
             if (!last) {
-                if (c >= g + 3)
-                    wait_vmcnt<C::LOADS>();
+                if (on)
+                    wait_vmcnt<5>();  // K-tile g+1 has landed; the five pieces of K-tile g+2 stay in flight
                 else
                     wait_vmcnt<0>();
                 __builtin_amdgcn_s_barrier();  // X(g+1)
                 pipe_read_half<C, 0>(S0, nxt, a_row, b_row, fk);
             }
-            pipe_mfma_part<C, 1, DBG>(acc, S1);
-            __builtin_amdgcn_sched_barrier(0);
+            AMX_PIECE(5);
+            pipe_mfma_range<C, 2 * QN, 3 * QN, DBG>(acc, S1);
+            AMX_PIECE(6);
+            pipe_mfma_range<C, 3 * QN, 4 * QN, DBG>(acc, S1);
+            AMX_PIECE(7);
+#undef AMX_PIECE
         }
 
         if ((DBG & 1) && tid == 0)
