@@ -57,6 +57,8 @@ typedef struct amx_ffnn amx_ffnn;
 
 /* ------------------------------------------------------------------ context */
 
+/* "rasr_amd <version> (gfx950; <compiler>; <flags>; src=<12 hex digits>)": the source hash is the SHA-1 of rasr_amd/csrc/* and
+ * include/amx.h the library was built from (rasr_amd/csrc/Makefile), so that a measurement can be tied to a build. */
 const char* amx_version(void);
 const char* amx_last_error(void);
 /* Creates a context on HIP device `device_ordinal` with its own non-blocking stream. */
@@ -564,6 +566,36 @@ int amx_prior_from_mixture_set(const amx_gmm_model* model, float* log_prior);
 int amx_stats_accumulate_dev(amx_ctx* ctx, const float* scores_dev, int T, int n_emissions,
                              uint32_t* best_state_dev, unsigned long long* state_counts_dev,
                              double* score_sum_dev);
+
+/* ------------------------------------------------------------------ the per-epoch exchange between data-parallel ranks
+ * The reference has no communication layer: `acoustic-model-trainer` processes take `partition = N`, `select-partition = k`
+ * (segment i belongs to process i % N, src/Bliss/CorpusDescription.cc:174-190), write one accumulator file each, and
+ * `combine-mixture-set-estimators` adds the files up offline (src/Tools/AcousticModelTrainer/AcousticModelTrainer.cc:317-325 ->
+ * src/Mm/AbstractMixtureSetEstimator.cc:173-250).  Here the ranks of one node (one process and one amx_ctx per GPU) keep their
+ * accumulators resident in HBM -- ONE flat f64 buffer per rank: amx_gmm_accumulator_size() doubles of statistics, score sums, and
+ * the u64 counters converted with amx_counts_to_f64_dev -- and add them with ONE RCCL all-reduce over xGMI per epoch.
+ *
+ *   rank 0:  amx_comm_unique_id(id);  hand the 128 bytes to the other ranks (file, environment, MPI, socket: the caller's business)
+ *   all:     amx_comm_init(ctx, rank, world, id, &comm);          collective: returns when all `world` ranks have called it
+ *            ... one epoch of amx_*_score_stats_dev / amx_gmm_accumulate_dev into the flat buffer ...
+ *            amx_comm_all_reduce_f64_dev(comm, flat_dev, n);      in place, on the context's stream, sum over ranks
+ *
+ * RCCL is bound at run time (dlopen of librccl.so; AMX_RCCL_LIB names another file): the library loads and every other entry
+ * point works without it, amx_comm_available() tells.  The result equals the single-process accumulators up to the f64 summation
+ * order of the ring.  A communicator belongs to its context (same device, same stream) and must be destroyed before it. */
+typedef struct amx_comm amx_comm;
+#define AMX_COMM_ID_BYTES 128
+int  amx_comm_available(void);
+int  amx_comm_unique_id(unsigned char id[AMX_COMM_ID_BYTES]);
+int  amx_comm_init(amx_ctx* ctx, int rank, int world, const unsigned char id[AMX_COMM_ID_BYTES], amx_comm** out);
+int  amx_comm_rank(const amx_comm* c);
+int  amx_comm_world(const amx_comm* c);
+int  amx_comm_all_reduce_f64_dev(amx_comm* c, double* buf_dev, size_t n);
+void amx_comm_destroy(amx_comm* c);
+/* Integer counters (state counts: u64, Mm/AbstractMixtureSetEstimator.cc keeps them as Weight = f64 anyway) ride in the same f64
+ * buffer: exact below 2^53.  counts -> doubles before the all-reduce, doubles -> counts (rounded to nearest) after it. */
+int amx_counts_to_f64_dev(amx_ctx* ctx, const unsigned long long* counts_dev, double* out_dev, size_t n);
+int amx_f64_to_counts_dev(amx_ctx* ctx, const double* in_dev, unsigned long long* counts_dev, size_t n);
 
 #ifdef __cplusplus
 }

@@ -33,6 +33,63 @@ def _ptr(a):
     return a.data_ptr()
 
 
+def version():
+    """amx_version(): library version, compiler, flags and the hash of the sources it was built from"""
+    return _lib.lib().amx_version().decode()
+
+
+class Comm:
+    """The per-epoch exchange between data-parallel ranks (amx_comm_*): RCCL all-reduce of ONE flat f64 device buffer.
+
+    rank 0 creates the 128-byte id (Comm.unique_id()) and hands it to the others -- bench.py broadcasts it through the
+    torch.distributed group that also carries its barrier; a RASR trainer would use a file or its own launcher."""
+
+    @staticmethod
+    def available():
+        return bool(_lib.lib().amx_comm_available())
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_ubyte * _lib.AMX_COMM_ID_BYTES)()
+        _lib.check(_lib.lib().amx_comm_unique_id(buf))
+        return bytes(buf)
+
+    def __init__(self, ctx, rank, world, unique_id):
+        if len(unique_id) != _lib.AMX_COMM_ID_BYTES:
+            raise ValueError("unique id must be %d bytes" % _lib.AMX_COMM_ID_BYTES)
+        self.L, self.ctx = _lib.lib(), ctx
+        buf = (C.c_ubyte * _lib.AMX_COMM_ID_BYTES).from_buffer_copy(unique_id)
+        h = C.c_void_p()
+        _lib.check(self.L.amx_comm_init(ctx.h, int(rank), int(world), buf, C.byref(h)))
+        self.h = h
+        self.rank, self.world = int(rank), int(world)
+
+    def all_reduce_f64(self, flat):
+        """in-place sum over the ranks of a contiguous float64 device tensor, on the context's stream"""
+        import torch
+        if flat.dtype != torch.float64 or not flat.is_contiguous() or not flat.is_cuda:
+            raise ValueError("all_reduce_f64 wants a contiguous float64 device tensor")
+        _lib.check(self.L.amx_comm_all_reduce_f64_dev(self.h, flat.data_ptr(), flat.numel()))
+        return flat
+
+    def counts_to_f64(self, counts, out):
+        _lib.check(self.L.amx_counts_to_f64_dev(self.ctx.h, counts.data_ptr(), out.data_ptr(), counts.numel()))
+
+    def f64_to_counts(self, src, counts):
+        _lib.check(self.L.amx_f64_to_counts_dev(self.ctx.h, src.data_ptr(), counts.data_ptr(), counts.numel()))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.amx_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Context:
     """One per process and GPU (amx_ctx)."""
 

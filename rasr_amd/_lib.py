@@ -181,7 +181,17 @@ SIGNATURES = {
     "amx_copy_to_host": (C.c_int, [_P, _P, _P, C.c_size_t]),
     "amx_gather_scores": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P]),
     "amx_stats_accumulate_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P]),
+    "amx_comm_available": (C.c_int, []),
+    "amx_comm_unique_id": (C.c_int, [_P]),
+    "amx_comm_init": (C.c_int, [_P, C.c_int, C.c_int, _P, C.POINTER(_P)]),
+    "amx_comm_rank": (C.c_int, [_P]),
+    "amx_comm_world": (C.c_int, [_P]),
+    "amx_comm_all_reduce_f64_dev": (C.c_int, [_P, _P, C.c_size_t]),
+    "amx_comm_destroy": (None, [_P]),
+    "amx_counts_to_f64_dev": (C.c_int, [_P, _P, _P, C.c_size_t]),
+    "amx_f64_to_counts_dev": (C.c_int, [_P, _P, _P, C.c_size_t]),
 }
+AMX_COMM_ID_BYTES = 128
 
 _lib = None
 

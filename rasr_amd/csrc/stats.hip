@@ -5,6 +5,7 @@
 // (Tools/AcousticModelTrainer/AcousticModelTrainer.cc:317-325).
 #include "common.hpp"
 
+#include <algorithm>
 #include <cfloat>
 
 namespace amx {
@@ -144,6 +145,42 @@ extern "C" int amx_stats_accumulate_dev(amx_ctx* ctx, const float* scores_dev, i
     amx::ScopedKernelTimer timer(ctx, "stats");
     hipLaunchKernelGGL(amx::argmin_accumulate_kernel, dim3(blocks), dim3(256), 0, ctx->stream, scores_dev, T, n_emissions,
                        best_state_dev, state_counts_dev, score_sum_dev);
+    AMX_HIP(hipGetLastError());
+    return AMX_OK;
+}
+
+// ---- u64 counters <-> f64 slots of the flat per-epoch reduce buffer (amx_comm_all_reduce_f64_dev sums doubles)
+namespace amx {
+__global__ __launch_bounds__(256) void counts_to_f64_kernel(const unsigned long long* __restrict__ c, double* __restrict__ out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        out[i] = (double)c[i];
+}
+__global__ __launch_bounds__(256) void f64_to_counts_kernel(const double* __restrict__ in, unsigned long long* __restrict__ c, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        c[i] = (unsigned long long)llrint(in[i]);
+}
+}  // namespace amx
+
+extern "C" int amx_counts_to_f64_dev(amx_ctx* ctx, const unsigned long long* counts_dev, double* out_dev, size_t n) {
+    AMX_REQUIRE(ctx, AMX_ERR_INVALID, "amx_counts_to_f64_dev: NULL context");
+    if (n == 0)
+        return AMX_OK;
+    AMX_REQUIRE(counts_dev && out_dev, AMX_ERR_INVALID, "amx_counts_to_f64_dev: NULL buffer");
+    AMX_HIP(hipSetDevice(ctx->device));
+    const int blocks = (int)std::min<size_t>(4096, (n + 255) / 256);
+    hipLaunchKernelGGL(amx::counts_to_f64_kernel, dim3(blocks), dim3(256), 0, ctx->stream, counts_dev, out_dev, n);
+    AMX_HIP(hipGetLastError());
+    return AMX_OK;
+}
+
+extern "C" int amx_f64_to_counts_dev(amx_ctx* ctx, const double* in_dev, unsigned long long* counts_dev, size_t n) {
+    AMX_REQUIRE(ctx, AMX_ERR_INVALID, "amx_f64_to_counts_dev: NULL context");
+    if (n == 0)
+        return AMX_OK;
+    AMX_REQUIRE(counts_dev && in_dev, AMX_ERR_INVALID, "amx_f64_to_counts_dev: NULL buffer");
+    AMX_HIP(hipSetDevice(ctx->device));
+    const int blocks = (int)std::min<size_t>(4096, (n + 255) / 256);
+    hipLaunchKernelGGL(amx::f64_to_counts_kernel, dim3(blocks), dim3(256), 0, ctx->stream, in_dev, counts_dev, n);
     AMX_HIP(hipGetLastError());
     return AMX_OK;
 }

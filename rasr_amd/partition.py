@@ -5,7 +5,8 @@ RASR has no communication backend: data-parallel jobs are independent processes 
 Bliss/CorpusDescription.cc:242-248,488-498; select-partition == N is accepted as 0) and write their own
 accumulator files, which `combine-mixture-set-estimators` sums offline
 (Tools/AcousticModelTrainer/AcousticModelTrainer.cc:317-325).  Here the ranks of one torch.distributed job
-take the same partitions and the sum is ONE all-reduce (RCCL over xGMI on GPUs, gloo in CPU tests).
+take the same partitions and the sum is ONE all-reduce: amx_comm_all_reduce_f64_dev (RCCL over xGMI, include/amx.h) on GPUs,
+torch.distributed's gloo backend in the CPU tests.
 """
 import numpy as np
 
@@ -52,9 +53,22 @@ class EpochReduceBuffer:
     def nbytes(self):
         return int(self.flat.numel() * 8)
 
-    def all_reduce(self, group=None):
-        """sum over all ranks with ONE collective; no-op without an initialised process group"""
+    def all_reduce(self, group=None, comm=None):
+        """sum over all ranks with ONE collective.
+
+        comm (rasr_amd.Comm): the product path -- amx_comm_all_reduce_f64_dev on the flat device buffer (RCCL over xGMI), counters
+        converted on the device by amx_counts_to_f64_dev / amx_f64_to_counts_dev.  Without one: torch.distributed (the gloo tests
+        on CPU), or a no-op when no process group is initialised."""
         import torch
+        if comm is not None:
+            for name, c in self.counters.items():
+                off, n, _ = self.offsets[name]
+                comm.counts_to_f64(c, self.flat[off:off + n])
+            comm.all_reduce_f64(self.flat)
+            for name, c in self.counters.items():
+                off, n, _ = self.offsets[name]
+                comm.f64_to_counts(self.flat[off:off + n], c)
+            return self
         import torch.distributed as dist
         if not (dist.is_available() and dist.is_initialized()):
             return self

@@ -10,12 +10,16 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
-    # a clean checkout has no built artefacts (they are git-ignored): build them once, like __graft_entry__.build()
+    # A clean checkout has no built artefacts (they are git-ignored): build them once, like __graft_entry__.build().  A library that
+    # travelled with the checkout is rebuilt when it was made from other sources than the tree's (content hash recorded in
+    # amx_version(), see __graft_entry__.is_stale) or when AMX_FORCE_BUILD=1 asks for a from-scratch build.
+    import __graft_entry__
     lib = os.path.join(ROOT, "rasr_amd", "librasr_amd.so")
     orc = os.path.join(ROOT, "oracle", "liboracle.so")
-    if not (os.path.exists(lib) and os.path.exists(orc)):
-        import __graft_entry__
+    forced = os.environ.get("AMX_FORCE_BUILD", "0") not in ("", "0")
+    if forced or not (os.path.exists(lib) and os.path.exists(orc)) or __graft_entry__.is_stale():
         __graft_entry__.build()
+        os.environ["AMX_FORCE_BUILD"] = "0"   # once per session (pytest-xdist workers inherit the environment)
 
 
 def _has_gpu():

@@ -221,3 +221,149 @@ def test_rccl_all_reduce_of_device_accumulators(ctx):
         assert float(red.view("score_sum").item()) == before[2]
     finally:
         dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------------------------- N ranks, started by bench.py itself
+
+def _run_bench(argv, env_extra=None, timeout=240):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + argv, capture_output=True, text=True, timeout=timeout, env=env, cwd=root)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    return p.returncode, (json.loads(lines[-1]) if lines else None), p.stderr
+
+
+def test_bench_gpus_2_starts_two_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher and no WORLD_SIZE in the environment (the shape of the driver's 1-GPU command with N
+    changed): bench.py starts the ranks, they meet on 127.0.0.1, take the reference's partitions, reduce once, and rank 0 reports
+    n_gpus = 2.  Host-only stand-in for the rank's work (gloo): no GPU here."""
+    rc, line, err = _run_bench(["--gpus", "2", "--backend", "gloo", "--workload", "null", "--steps", "3", "--warmup", "1", "--utterances", "9"])
+    assert rc == 0, err[-2000:]
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "weak"
+    assert line["stages"]["reduce_ok"] and line["stages"]["reduced_frames"] == line["stages"]["expected_frames"] > 0
+    assert line["epoch_reduce"]["collectives"] == 1
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    """ranks started by someone else with another world size than --gpus: fail loudly instead of printing a wrong n_gpus"""
+    rc, line, err = _run_bench(["--gpus", "2", "--backend", "gloo", "--workload", "null"], env_extra={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert rc != 0 and line is None and "WORLD_SIZE=1 but --gpus 2" in err
+
+
+def test_bench_product_workloads_refuse_the_cpu_backend():
+    rc, line, err = _run_bench(["--backend", "gloo", "--workload", "nn"])
+    assert rc != 0 and line is None and "no CPU path" in err
+
+
+# ---------------------------------------------------------------------------------------------- the product's host path on two ranks
+
+def _cache_worker(rank, world, port, path, names, q):
+    """one rank of a feature-cache pass: its partition of the segments, read through the product's archive reader (amx_feature_cache_read,
+    host code of librasr_amd.so), per-dimension sums and frame counts into the flat reduce buffer, ONE all-reduce"""
+    import torch
+    import torch.distributed as dist
+
+    import rasr_amd
+    from rasr_amd.partition import EpochReduceBuffer, select_partition
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    red = EpochReduceBuffer([("sum_x", 12, "f64"), ("sum_xx", 12, "f64"), ("frames", 1, "count"), ("segments", 1, "count")])
+    ar = rasr_amd.FileArchive(path, "r")
+    for i in select_partition(len(names), world, rank):
+        x, _ = ar.read_features(names[i])
+        x = x.astype(np.float64)
+        red.view("sum_x").add_(torch.from_numpy(x.sum(axis=0)))
+        red.view("sum_xx").add_(torch.from_numpy((x * x).sum(axis=0)))
+        red.view("frames").add_(x.shape[0])
+        red.view("segments").add_(1)
+    ar.close()
+    red.all_reduce()
+    if rank == 0:
+        q.put((red.view("sum_x").numpy().copy(), red.view("sum_xx").numpy().copy(), int(red.view("frames")[0]), int(red.view("segments")[0])))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_read_their_partitions_of_a_feature_cache(tmp_path):
+    """world size 2 over gloo with the PRODUCT's host code on both ranks: a SP_ARC1 feature cache written by amx_feature_cache_write,
+    every rank reads the segments of its partition (i % 2) through amx_feature_cache_read and the reduced statistics equal the
+    single-process pass over all segments"""
+    import torch.multiprocessing as mp
+
+    import rasr_amd
+    rng = np.random.Generator(np.random.PCG64(77))
+    path = str(tmp_path / "features.cache")
+    names, feats = [], []
+    ar = rasr_amd.FileArchive(path, "w")
+    for u in range(7):
+        n = 20 + 13 * u
+        x = rng.standard_normal((n, 12)).astype(np.float32)
+        t = np.stack([np.arange(n) * 0.01, np.arange(n) * 0.01 + 0.025], axis=1)
+        name = "corpus/rec%d/seg%d" % (u // 3, u)
+        ar.write_features(name, x, t, compress=bool(u & 1))
+        names.append(name)
+        feats.append(x)
+    ar.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_cache_worker, args=(r, 2, port, path, names, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    sx, sxx, nfr, nseg = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    allx = np.concatenate(feats).astype(np.float64)
+    assert nseg == 7 and nfr == allx.shape[0]
+    assert np.allclose(sx, allx.sum(axis=0), rtol=1e-12, atol=1e-9) and np.allclose(sxx, (allx * allx).sum(axis=0), rtol=1e-12)
+
+
+@pytest.mark.gpu
+def test_amx_comm_all_reduce_through_the_c_abi(ctx):
+    """amx_comm_* (RCCL bound by the library itself, no torch.distributed anywhere): communicator of one rank on the one-GPU box,
+    real device accumulators of the HIP kernels through EpochReduceBuffer.all_reduce(comm=...) -- ONE amx_comm_all_reduce_f64_dev --
+    and back unchanged, counters exact through their f64 slots"""
+    import torch
+
+    import rasr_amd
+    from rasr_amd.partition import EpochReduceBuffer
+    assert rasr_amd.Comm.available()
+    uid = rasr_amd.Comm.unique_id()
+    assert len(uid) == 128 and uid != bytes(128)
+    comm = rasr_amd.Comm(ctx, 0, 1, uid)
+    try:
+        assert comm.rank == 0 and comm.world == 1
+        model = synth.gmm_cart(200, 1, 16, 40, seed=61, pooled=True)
+        sc = rasr_amd.GmmFeatureScorer(ctx, model)
+        T, M = 3000, 200
+        x = np.random.Generator(np.random.PCG64(62)).standard_normal((T, 40)).astype(np.float32)
+        red = EpochReduceBuffer([("acc", sc.accumulator_size(), "f64"), ("score_sum", 1, "f64"), ("counts", M, "count")], device="cuda")
+        xd = torch.from_numpy(x).cuda()
+        scores = torch.empty((T, M), dtype=torch.float32, device="cuda")
+        bestd = torch.empty((T, M), dtype=torch.int32, device="cuda")
+        state = torch.empty((T,), dtype=torch.int32, device="cuda")
+        ctx.use_torch_stream()
+        sc.score_stats_dev(xd, T, scores, bestd, state, red.view("counts"), red.view("score_sum"))
+        sc.accumulate_dev(xd, T, state, bestd, M, red.view("acc"))
+        red.view("counts")[3] += 2 ** 40   # beyond f32, within the exact range of an f64 slot
+        torch.cuda.synchronize()
+        before = (red.view("acc").cpu().numpy().copy(), red.view("counts").cpu().numpy().copy(), float(red.view("score_sum").item()))
+        assert before[1].sum() == T + 2 ** 40 and before[0].sum() != 0
+        calls = []
+        real = comm.all_reduce_f64
+        comm.all_reduce_f64 = lambda t: (calls.append(t.numel()), real(t))[1]
+        red.all_reduce(comm=comm)
+        torch.cuda.synchronize()
+        assert calls == [sc.accumulator_size() + 1 + M]
+        assert np.array_equal(red.view("acc").cpu().numpy(), before[0]) and np.array_equal(red.view("counts").cpu().numpy(), before[1])
+        assert float(red.view("score_sum").item()) == before[2]
+    finally:
+        comm.close()
+    with pytest.raises(rasr_amd.AmxError):
+        rasr_amd.Comm(ctx, 2, 2, uid)   # rank out of range

@@ -24,3 +24,22 @@ def test_host_mirror_protocol(tmp_path):
     ceps, pcm = raw[:99 * 12].reshape(99, 12), raw[99 * 12:]
     want = OracleMfcc(n_ceps=12).run(pcm)
     assert np.all(np.abs(ceps - want) <= 1e-4 * np.abs(want) + 2e-3)
+
+
+def test_host_epoch_reduce_client(tmp_path):
+    """rasr_amd/host/EpochReduce.hh compiled with g++ against librasr_amd.so only (no torch, no Python in the process): communicator id
+    through a file, ONE amx_comm_all_reduce_f64_dev over statistics + counters, results checked inside the C++ program.  One rank per
+    GPU: as many ranks as the box has GPUs (1 on the test box)."""
+    import torch
+    exe = str(tmp_path / "host_epoch_reduce_test")
+    lib = os.path.join(ROOT, "rasr_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", os.path.join(ROOT, "tests", "host_epoch_reduce_test.cc"), "-o", exe,
+                           "-L" + lib, "-lrasr_amd", "-lpthread", "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib"])
+    world = min(torch.cuda.device_count(), 8)
+    idf = str(tmp_path / "comm.id")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([exe, str(r), str(world), idf], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env)
+             for r in range(world)]
+    for r, p in enumerate(procs):
+        out, _ = p.communicate(timeout=300)
+        assert p.returncode == 0 and out.strip().endswith("OK"), "rank %d: %s" % (r, out)
