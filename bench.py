@@ -525,6 +525,41 @@ class MfccOnly:
             ms, n = self.ctx.profile_get(k)
             if n:
                 out[k] = dict(avg_ms=round(ms, 4), launches=n)
+        if not self.gt:
+            try:
+                out["end_to_end"] = self.end_to_end()
+            except Exception as e:  # never take the line down
+                out["end_to_end"] = dict(error=str(e)[:200])
+        return out
+
+    def end_to_end(self):
+        """SURVEY 8(d) cfg 2 asks for the device-resident AND the host-link-inclusive rate (never `value`): the same batch with the
+        samples (a) resident as s16 -- what the audio file holds, widened in the kernel like Flow/TypeConverter.hh:35-43 --, (b) copied
+        from pinned host memory as f32 (640 B per frame over the link) and (c) as s16 (320 B per frame), copy and kernel on one stream"""
+        import torch
+        torch.cuda.synchronize()
+        pcm16 = self.pcm.to(torch.int16)
+        host32 = self.pcm.cpu().pin_memory()
+        host16 = pcm16.cpu().pin_memory()
+        dev32 = torch.empty_like(self.pcm)
+        dev16 = torch.empty_like(pcm16)
+        ref = torch.empty_like(self.ceps)
+        self.fe.run_plan(self.plan, self.pcm, ref)
+
+        def rate(fn, n=10):
+            for _ in range(2):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            return round(self.F * n / (time.perf_counter() - t0), 1)
+        out = {"resident_s16_frames_per_s": rate(lambda: self.fe.run_plan(self.plan, pcm16, self.ceps))}
+        out["s16_equals_f32_bitwise"] = bool(torch.equal(ref.view(torch.int32), self.ceps.view(torch.int32)))
+        out["h2d_f32_frames_per_s"] = rate(lambda: (dev32.copy_(host32, non_blocking=True), self.fe.run_plan(self.plan, dev32, self.ceps)))
+        out["h2d_s16_frames_per_s"] = rate(lambda: (dev16.copy_(host16, non_blocking=True), self.fe.run_plan(self.plan, dev16, self.ceps)))
+        out["note"] = "pinned host PCM -> HBM -> cepstra in HBM; bytes over the link per frame: 640 (f32) / 320 (s16)"
         return out
 
 

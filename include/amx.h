@@ -150,6 +150,12 @@ int amx_mfcc_run(amx_mfcc* h, const float* pcm_host, long n_samples, float* ceps
 /* Batch of segments, host buffers. */
 int amx_mfcc_run_batch(amx_mfcc* h, int n_seg, const float* const* pcm_host, const long* n_samples,
                        float* const* ceps_host);
+/* The same with the samples as the audio file holds them: s16, widened to f32 without scaling inside the kernel exactly like the
+ * converter node in front of the chain (Flow/TypeConverter.hh:35-43) -- 320 instead of 640 bytes per frame over the host link and
+ * out of HBM; results are bit-identical to the f32 entry points on the same sample values. */
+int amx_mfcc_run_s16(amx_mfcc* h, const int16_t* pcm_host, long n_samples, float* ceps_host);
+int amx_mfcc_run_batch_s16(amx_mfcc* h, int n_seg, const int16_t* const* pcm_host, const long* n_samples,
+                           float* const* ceps_host);
 
 /* Device-resident batches.  A plan fixes the segmentation: segment u occupies samples
  * [sample_offsets[u], sample_offsets[u+1]) of one concatenated PCM buffer and frames
@@ -159,6 +165,7 @@ void amx_mfcc_plan_destroy(amx_mfcc_plan* p);
 long amx_mfcc_plan_total_frames(const amx_mfcc_plan* p);
 int  amx_mfcc_plan_frame_offsets(const amx_mfcc_plan* p, long* frame_offsets /*[n_seg+1]*/);
 int  amx_mfcc_run_plan_dev(amx_mfcc* h, const amx_mfcc_plan* p, const float* pcm_dev, float* ceps_dev);
+int  amx_mfcc_run_plan_dev_s16(amx_mfcc* h, const amx_mfcc_plan* p, const int16_t* pcm_dev, float* ceps_dev);
 
 /* ------------------------------------------------------------------ sample stream in front of the feature chains (samples.flow)
  * signal-dc-detection (Signal::DcDetection, src/Signal/DcDetection.cc:90-235): a host-side scan over one segment's samples that tells

@@ -316,28 +316,37 @@ class MfccExtractor:
         return dict(window=win, filter_start=fs, filter_end=fe, filter_offset=fo, filter_weights=fw, dct=dct)
 
     def run(self, pcm):
-        """host path: one segment of f32 samples -> [n_frames, n_ceps]"""
-        pcm = np.ascontiguousarray(pcm, dtype=np.float32)
+        """host path: one segment of samples -> [n_frames, n_ceps].  An int16 array goes through the s16 entry point (the samples as
+        the audio file holds them, widened inside the kernel); anything else is taken as f32 sample values"""
+        s16 = isinstance(pcm, np.ndarray) and pcm.dtype == np.int16
+        pcm = np.ascontiguousarray(pcm, dtype=np.int16 if s16 else np.float32)
         out = np.zeros((self.n_frames(len(pcm)), self.n_ceps), np.float32)
-        _lib.check(self.L.amx_mfcc_run(self.h, pcm.ctypes.data, len(pcm), out.ctypes.data))
+        fn = self.L.amx_mfcc_run_s16 if s16 else self.L.amx_mfcc_run
+        _lib.check(fn(self.h, pcm.ctypes.data, len(pcm), out.ctypes.data))
         return out
 
     def run_batch(self, pcms):
-        pcms = [np.ascontiguousarray(p, dtype=np.float32) for p in pcms]
+        s16 = all(isinstance(p, np.ndarray) and p.dtype == np.int16 for p in pcms) and len(pcms) > 0
+        pcms = [np.ascontiguousarray(p, dtype=np.int16 if s16 else np.float32) for p in pcms]
         outs = [np.zeros((self.n_frames(len(p)), self.n_ceps), np.float32) for p in pcms]
         n = len(pcms)
         ip = (C.c_void_p * n)(*[p.ctypes.data for p in pcms])
         op = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
         ln = np.array([len(p) for p in pcms], np.int64)
-        _lib.check(self.L.amx_mfcc_run_batch(self.h, n, C.cast(ip, C.c_void_p), ln.ctypes.data, C.cast(op, C.c_void_p)))
+        fn = self.L.amx_mfcc_run_batch_s16 if s16 else self.L.amx_mfcc_run_batch
+        _lib.check(fn(self.h, n, C.cast(ip, C.c_void_p), ln.ctypes.data, C.cast(op, C.c_void_p)))
         return outs
 
     def plan(self, sample_offsets):
         return _Plan(self, sample_offsets)
 
     def run_plan(self, plan, pcm_dev, ceps_dev):
-        """device path: concatenated PCM tensor -> [total_frames, n_ceps] tensor (both resident in HBM)"""
-        _lib.check(self.L.amx_mfcc_run_plan_dev(self.h, plan.h, _ptr(pcm_dev), _ptr(ceps_dev)))
+        """device path: concatenated PCM tensor (float32 or int16) -> [total_frames, n_ceps] tensor (both resident in HBM)"""
+        import torch
+        if pcm_dev.dtype == torch.int16:
+            _lib.check(self.L.amx_mfcc_run_plan_dev_s16(self.h, plan.h, _ptr(pcm_dev), _ptr(ceps_dev)))
+        else:
+            _lib.check(self.L.amx_mfcc_run_plan_dev(self.h, plan.h, _ptr(pcm_dev), _ptr(ceps_dev)))
 
 
 def _gmm_struct(model, mixture_weight_scale, gaussian_scale, keep):

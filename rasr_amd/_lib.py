@@ -104,11 +104,14 @@ SIGNATURES = {
     "amx_mfcc_tables": (C.c_int, [_P] * 7),
     "amx_mfcc_run": (C.c_int, [_P, _P, C.c_long, _P]),
     "amx_mfcc_run_batch": (C.c_int, [_P, C.c_int, _P, _P, _P]),
+    "amx_mfcc_run_s16": (C.c_int, [_P, _P, C.c_long, _P]),
+    "amx_mfcc_run_batch_s16": (C.c_int, [_P, C.c_int, _P, _P, _P]),
     "amx_mfcc_plan_create": (C.c_int, [_P, C.c_int, _P, C.POINTER(_P)]),
     "amx_mfcc_plan_destroy": (None, [_P]),
     "amx_mfcc_plan_total_frames": (C.c_long, [_P]),
     "amx_mfcc_plan_frame_offsets": (C.c_int, [_P, _P]),
     "amx_mfcc_run_plan_dev": (C.c_int, [_P, _P, _P, _P]),
+    "amx_mfcc_run_plan_dev_s16": (C.c_int, [_P, _P, _P, _P]),
     "amx_context_window_dev": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int]),
     "amx_normalize_dev": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int]),
     "amx_normalize_ex_dev": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int]),

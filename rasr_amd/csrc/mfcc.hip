@@ -29,6 +29,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 namespace amx {
 
@@ -42,7 +43,7 @@ struct MfccTile {
 };
 
 struct MfccParams {
-    const float*    pcm;
+    const void*     pcm;    // f32 samples, or s16 (kernel variant bit 2): s16 widened without scaling like Flow/TypeConverter.hh:35-43
     float*          ceps;
     const MfccTile* tiles;
     const float*    window;
@@ -127,9 +128,24 @@ __device__ __noinline__ float power_node(float v, float power) {
     return (float)pow((double)v, (double)power);
 }
 
-template<int NC>
+// VAR bit 1: the 256-point complex FFT (fft length 512) on the f32 matrix cores instead of four Stockham radix-4 stages through LDS;
+// bit 2: s16 samples.
+//
+// FFT on MFMA (NC = 256 = 16 x 16, n = 16 n1 + n2, k = k1 + 16 k2, W_N = e^{+2 pi i / N} -- the reference's sign):
+//     Z[k1 + 16 k2] = sum_n2 ( (sum_n1 z[16 n1 + n2] W16^(n1 k1)) W256^(n2 k1) ) W16^(n2 k2)
+// i.e. two 16x16x16 complex matrix products with a twiddle in between, all in registers: a lane already holds the complex points
+// lane + 64 r (r = 0..3), which IS the A operand of v_mfma_f32_16x16x4_f32 for D^T[n2][k1] = sum_n1 Z^T[n2][n1] F[n1][k1] (K-step r
+// covers n1 = 4 r + lane / 16); the result's layout (lane: n2 = 4 (lane / 16) + reg, k1 = lane % 16) is the B operand of the second
+// product X^T[k2][k1] = sum_n2 F[k2][n2] B[n2][k1] when the constant A operand is taken in the order n2 = 4 (lane / 16) + K-step.
+// A complex product costs three real ones (P1 = Zr Fr, P2 = Zi Fi, P3 = (Zr + Zi)(Fr + Fi); re = P1 - P2, im = P3 - P1 - P2):
+// 24 MFMAs per frame on the otherwise idle matrix pipe replace ~160 of the frame's ~310 vector instructions and three of its four LDS
+// round trips; the f32 MFMA is an exact fma chain, the error class is that of the f32 butterflies.
+template<int NC, int VAR>
 __global__ __launch_bounds__(mfcc_waves(NC) * 64, (NC >= 1024 ? 1 : 4)) void mfcc_kernel(MfccParams p) {
     using P = FftPlan<NC>;
+    constexpr bool MF  = (VAR & 1) != 0 && NC == 256;
+    constexpr bool S16 = (VAR & 2) != 0;
+    using Sample       = typename std::conditional<S16, short, float>::type;
     constexpr int MW = mfcc_waves(NC), MT = MW * 64;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid  = threadIdx.x;
@@ -202,6 +218,20 @@ __global__ __launch_bounds__(mfcc_waves(NC) * 64, (NC >= 1024 ? 1 : 4)) void mfc
         const int i = 1 + lane + 64 * b;
         stw[b]      = p.stw[i <= NPAIR ? i : 0];
     }
+    // MFMA FFT: this lane's constants (m = lane % 16, q = lane / 16; W = e^{+2 pi i / 256} from the host table)
+    float f1r[4], f1i[4], f1s[4], wr[4], wi[4], gr[4], gi[4], gs[4];
+    if (MF) {
+        const int m = lane & 15, q = lane >> 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float2 f = p.tw[(16 * ((4 * r + q) * m)) & (NC - 1)];  // F[n1 = 4 r + q][k1 = m]
+            f1r[r] = f.x, f1i[r] = f.y, f1s[r] = f.x + f.y;
+            const float2 w = p.tw[(m * (4 * q + r)) & (NC - 1)];         // W256^(k1 n2), n2 = 4 q + r
+            wr[r] = w.x, wi[r] = w.y;
+            const float2 g = p.tw[(16 * (m * (4 * q + r))) & (NC - 1)];  // F[k2 = m][n2 = 4 q + r]
+            gr[r] = g.x, gi[r] = g.y, gs[r] = g.x + g.y;
+        }
+    }
     const float scale   = p.fft_scale;
     const bool  doscale = p.apply_scale != 0;
     const float alpha   = p.alpha;
@@ -214,7 +244,7 @@ __global__ __launch_bounds__(mfcc_waves(NC) * 64, (NC >= 1024 ? 1 : 4)) void mfc
     // barrier per tile less, four workgroups per CU for MFCC-40 instead of three.  A/B on one box (tools/ab_mfcc.sh, ms per
     // 993 k frames, staged -> direct at four workgroups per CU): mfcc.flow 1.02 -> 0.95, mfplp.flow 1.09 -> 0.97, plp.flow 1.32 ->
     // 1.17; five workgroups per CU (the PLP variants' smaller LDS would allow them) are 30 % SLOWER, hence the cap in launch_mfcc.
-    const float*    seg   = p.pcm + tile.sample_base;
+    const Sample*   seg   = (const Sample*)p.pcm + tile.sample_base;
     const long long nseg  = tile.n_samples;
     // ================= phase B: one frame per wavefront: FFT -> split -> |X| into s_amp[f][*]
     for (int f = wave; f < FT; f += MW) {
@@ -246,14 +276,14 @@ __global__ __launch_bounds__(mfcc_waves(NC) * 64, (NC >= 1024 ? 1 : 4)) void mfc
                         }
                     };
                     if (inner) {
-                        const float* fr = seg + fbase;
+                        const Sample* fr = seg + fbase;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int  c = j + r * (NC / 4);
                             const bool w = 2 * c < p.frame_len;
-                            x0[r]        = w ? fr[2 * c] : 0.f;
-                            x1[r]        = w ? fr[2 * c + 1] : 0.f;   // 2c + 1 <= frame_len: still inside the segment
-                            xm[r]        = w ? fr[2 * c - 1] : 0.f;
+                            x0[r]        = w ? (float)fr[2 * c] : 0.f;
+                            x1[r]        = w ? (float)fr[2 * c + 1] : 0.f;   // 2c + 1 <= frame_len: still inside the segment
+                            xm[r]        = w ? (float)fr[2 * c - 1] : 0.f;
                         }
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
@@ -268,9 +298,9 @@ __global__ __launch_bounds__(mfcc_waves(NC) * 64, (NC >= 1024 ? 1 : 4)) void mfc
                             const int       c = j + r * (NC / 4);
                             const long long n = fbase + 2 * c;
                             const bool      w = 2 * c < p.frame_len;
-                            x0[r]             = (w && n < nseg) ? seg[n] : 0.f;
-                            x1[r]             = (w && n + 1 < nseg) ? seg[n + 1] : 0.f;
-                            xm[r]             = (w && n < nseg) ? seg[n > 0 ? n - 1 : 0] : 0.f;  // segment start: previous_ = x[0]
+                            x0[r]             = (w && n < nseg) ? (float)seg[n] : 0.f;
+                            x1[r]             = (w && n + 1 < nseg) ? (float)seg[n + 1] : 0.f;
+                            xm[r]             = (w && n < nseg) ? (float)seg[n > 0 ? n - 1 : 0] : 0.f;  // segment start: previous_ = x[0]
                         }
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
@@ -282,6 +312,37 @@ __global__ __launch_bounds__(mfcc_waves(NC) * 64, (NC >= 1024 ? 1 : 4)) void mfc
                             y1   = n + 1 < nseg ? y1 : 0.f;
                             x[r] = make_float2(wlo[b][r] * y0, whi[b][r] * y1);
                         }
+                    }
+                    if (MF) {
+                        // ---- first product: D^T[n2][k1], three real products (A = this lane's points, B = F constants)
+                        f32x4 p1 = {0.f, 0.f, 0.f, 0.f}, p2 = p1, p3 = p1;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            p1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[r].x, f1r[r], p1, 0, 0, 0);
+                            p2 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[r].y, f1i[r], p2, 0, 0, 0);
+                            p3 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[r].x + x[r].y, f1s[r], p3, 0, 0, 0);
+                        }
+                        // ---- twiddle W256^(k1 n2) on this lane's four values (n2 = 4 q + r, k1 = m)
+                        float br[4], bi[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float dr = p1[r] - p2[r], di = (p3[r] - p1[r]) - p2[r];
+                            br[r]          = fmaf(dr, wr[r], -(di * wi[r]));
+                            bi[r]          = fmaf(dr, wi[r], di * wr[r]);
+                        }
+                        // ---- second product: X^T[k2][k1] (A = F constants in the order n2 = 4 q + K-step, B = the twiddled values)
+                        f32x4 q1 = {0.f, 0.f, 0.f, 0.f}, q2 = q1, q3 = q1;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            q1 = __builtin_amdgcn_mfma_f32_16x16x4f32(gr[r], br[r], q1, 0, 0, 0);
+                            q2 = __builtin_amdgcn_mfma_f32_16x16x4f32(gi[r], bi[r], q2, 0, 0, 0);
+                            q3 = __builtin_amdgcn_mfma_f32_16x16x4f32(gs[r], br[r] + bi[r], q3, 0, 0, 0);
+                        }
+                        // lane (q, m), register r: bin k = k1 + 16 k2 = m + 16 (4 q + r)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            s_z[zpad((lane & 15) + 64 * (lane >> 4) + 16 * r)] = make_float2(q1[r] - q2[r], (q3[r] - q1[r]) - q2[r]);
+                        continue;
                     }
                     const float2 a  = make_float2(x[0].x + x[2].x, x[0].y + x[2].y);
                     const float2 bb = make_float2(x[0].x - x[2].x, x[0].y - x[2].y);
@@ -296,7 +357,7 @@ __global__ __launch_bounds__(mfcc_waves(NC) * 64, (NC >= 1024 ? 1 : 4)) void mfc
 #pragma unroll
             for (int b = 0; b < P::B4; ++b) {
                 const int j = lane + 64 * b;
-                if (j < NC / 4) {
+                if (!MF && j < NC / 4) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
                         s_z[zpad(4 * j + q)] = y4[b][q];
@@ -304,7 +365,7 @@ __global__ __launch_bounds__(mfcc_waves(NC) * 64, (NC >= 1024 ? 1 : 4)) void mfc
             }
         }
 #pragma unroll
-        for (int s = 1; s < P::S4; ++s) {
+        for (int s = 1; s < (MF ? 0 : P::S4); ++s) {
             const int Ns = 1 << (2 * s);
             wave_sync();
             float2 y4[P::B4][4];
@@ -339,7 +400,7 @@ __global__ __launch_bounds__(mfcc_waves(NC) * 64, (NC >= 1024 ? 1 : 4)) void mfc
                 }
             }
         }
-        if (P::R2) {
+        if (P::R2 && !MF) {
             constexpr int Ns = NC / 2;
             wave_sync();
             float2 y2[P::B2][2];
@@ -725,11 +786,9 @@ __global__ __launch_bounds__(64) void lpc_cepstrum_reg_kernel(const float* __res
             o[n] = c[n];
 }
 
-template<int NC>
-int launch_mfcc(amx_mfcc* h, const amx::MfccParams& p, int n_tiles) {
-    if (n_tiles <= 0)
-        return AMX_OK;
-    auto kern = amx::mfcc_kernel<NC>;
+template<int NC, int VAR>
+int launch_mfcc_var(amx_mfcc* h, const amx::MfccParams& p, int n_tiles) {
+    auto kern = amx::mfcc_kernel<NC, VAR>;
     if (h->lds_bytes > 48 * 1024)
         AMX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
     // persistent workgroups: as many as are co-resident (LDS bound), each loops over tiles
@@ -742,6 +801,22 @@ int launch_mfcc(amx_mfcc* h, const amx::MfccParams& p, int n_tiles) {
     hipLaunchKernelGGL(kern, dim3(grid), dim3(amx::mfcc_waves(NC) * 64), h->lds_bytes, h->ctx->stream, p);
     AMX_HIP(hipGetLastError());
     return AMX_OK;
+}
+
+template<int NC>
+int launch_mfcc(amx_mfcc* h, const amx::MfccParams& p, int n_tiles, bool s16) {
+    if (n_tiles <= 0)
+        return AMX_OK;
+    // AMX_MFCC_FFT=mfma: the 512-point transform as two 16x16x16 complex products on the f32 matrix cores (see mfcc_kernel).  Measured
+    // on config 2 (993 k frames, same box): 0.958 ms against 0.748 ms for the radix-4 LDS stages -- the 24 v_mfma_f32_16x16x4_f32 per
+    // frame (768 matrix-pipe cycles per SIMD) do not hide behind the other waves' vector work, the frame costs what the removed ~110
+    // vector instructions cost plus ~1250 cycles -- so the butterflies stay the default and the product form is kept for A/B runs.
+    static const bool mfma = getenv("AMX_MFCC_FFT") && !strcmp(getenv("AMX_MFCC_FFT"), "mfma");
+    if constexpr (NC == 256) {
+        if (mfma)
+            return s16 ? launch_mfcc_var<NC, 3>(h, p, n_tiles) : launch_mfcc_var<NC, 1>(h, p, n_tiles);
+    }
+    return s16 ? launch_mfcc_var<NC, 2>(h, p, n_tiles) : launch_mfcc_var<NC, 0>(h, p, n_tiles);
 }
 
 }  // namespace
@@ -990,7 +1065,17 @@ int amx_mfcc_plan_frame_offsets(const amx_mfcc_plan* p, long* frame_offsets) {
     return AMX_OK;
 }
 
+static int mfcc_run_plan(amx_mfcc* h, const amx_mfcc_plan* p, const void* pcm_dev, bool s16, float* ceps_dev);
+
 int amx_mfcc_run_plan_dev(amx_mfcc* h, const amx_mfcc_plan* p, const float* pcm_dev, float* ceps_dev) {
+    return mfcc_run_plan(h, p, pcm_dev, false, ceps_dev);
+}
+
+int amx_mfcc_run_plan_dev_s16(amx_mfcc* h, const amx_mfcc_plan* p, const int16_t* pcm_dev, float* ceps_dev) {
+    return mfcc_run_plan(h, p, pcm_dev, true, ceps_dev);
+}
+
+static int mfcc_run_plan(amx_mfcc* h, const amx_mfcc_plan* p, const void* pcm_dev, bool s16, float* ceps_dev) {
     AMX_REQUIRE(h && p, AMX_ERR_INVALID, "amx_mfcc_run_plan_dev: NULL handle");
     AMX_REQUIRE(p->owner == h, AMX_ERR_STATE, "amx_mfcc_run_plan_dev: plan belongs to another front-end handle");
     if (p->tiles.empty())
@@ -1040,15 +1125,15 @@ int amx_mfcc_run_plan_dev(amx_mfcc* h, const amx_mfcc_plan* p, const float* pcm_
     k.dct_normalize   = t.cfg.dct_normalize;
     int r;
     switch (t.fft_len / 2) {
-        case 4: r = launch_mfcc<4>(h, k, n_tiles_total); break;
-        case 8: r = launch_mfcc<8>(h, k, n_tiles_total); break;
-        case 16: r = launch_mfcc<16>(h, k, n_tiles_total); break;
-        case 32: r = launch_mfcc<32>(h, k, n_tiles_total); break;
-        case 64: r = launch_mfcc<64>(h, k, n_tiles_total); break;
-        case 128: r = launch_mfcc<128>(h, k, n_tiles_total); break;
-        case 256: r = launch_mfcc<256>(h, k, n_tiles_total); break;
-        case 512: r = launch_mfcc<512>(h, k, n_tiles_total); break;
-        case 1024: r = launch_mfcc<1024>(h, k, n_tiles_total); break;
+        case 4: r = launch_mfcc<4>(h, k, n_tiles_total, s16); break;
+        case 8: r = launch_mfcc<8>(h, k, n_tiles_total, s16); break;
+        case 16: r = launch_mfcc<16>(h, k, n_tiles_total, s16); break;
+        case 32: r = launch_mfcc<32>(h, k, n_tiles_total, s16); break;
+        case 64: r = launch_mfcc<64>(h, k, n_tiles_total, s16); break;
+        case 128: r = launch_mfcc<128>(h, k, n_tiles_total, s16); break;
+        case 256: r = launch_mfcc<256>(h, k, n_tiles_total, s16); break;
+        case 512: r = launch_mfcc<512>(h, k, n_tiles_total, s16); break;
+        case 1024: r = launch_mfcc<1024>(h, k, n_tiles_total, s16); break;
         default:
             amx::set_error("amx_mfcc_run_plan_dev: no kernel for FFT length %d", t.fft_len);
             return AMX_ERR_UNSUPPORTED;
@@ -1072,12 +1157,13 @@ int amx_mfcc_run_plan_dev(amx_mfcc* h, const amx_mfcc_plan* p, const float* pcm_
     return AMX_OK;
 }
 
-int amx_mfcc_run_batch(amx_mfcc* h, int n_seg, const float* const* pcm_host, const long* n_samples, float* const* ceps_host) {
+static int mfcc_run_batch(amx_mfcc* h, int n_seg, const void* const* pcm_host, bool s16, const long* n_samples, float* const* ceps_host) {
     AMX_REQUIRE(h && n_seg >= 0, AMX_ERR_INVALID, "amx_mfcc_run_batch: bad argument");
     AMX_REQUIRE(h->ctx, AMX_ERR_STATE, "amx_mfcc_run_batch: host-only handle (created without a context)");
     if (n_seg == 0)
         return AMX_OK;
     AMX_REQUIRE(pcm_host && n_samples && ceps_host, AMX_ERR_INVALID, "amx_mfcc_run_batch: NULL argument");
+    const size_t ss = s16 ? 2 : 4;  // bytes per sample on the host link and in HBM
     std::vector<long> off((size_t)n_seg + 1, 0);
     for (int u = 0; u < n_seg; ++u) {
         AMX_REQUIRE(n_samples[u] >= 0, AMX_ERR_INVALID, "amx_mfcc_run_batch: negative segment length");
@@ -1088,7 +1174,8 @@ int amx_mfcc_run_batch(amx_mfcc* h, int n_seg, const float* const* pcm_host, con
     if (r != AMX_OK)
         return r;
     const long total_frames = amx_mfcc_plan_total_frames(plan);
-    float *    d_pcm = nullptr, *d_ceps = nullptr;
+    char*      d_pcm  = nullptr;
+    float*     d_ceps = nullptr;
     hipStream_t st = h->ctx->stream;
     auto fail = [&](int code) {
         hipFree(d_pcm);
@@ -1096,18 +1183,18 @@ int amx_mfcc_run_batch(amx_mfcc* h, int n_seg, const float* const* pcm_host, con
         amx_mfcc_plan_destroy(plan);
         return code;
     };
-    if (hipMalloc((void**)&d_pcm, std::max<long>(off[n_seg], 1) * 4) != hipSuccess ||
+    if (hipMalloc((void**)&d_pcm, std::max<long>(off[n_seg], 1) * ss) != hipSuccess ||
         hipMalloc((void**)&d_ceps, std::max<long>(total_frames * h->tab.n_ceps, 1) * 4) != hipSuccess) {
         amx::set_error("amx_mfcc_run_batch: out of device memory");
         return fail(AMX_ERR_DEVICE);
     }
     for (int u = 0; u < n_seg; ++u)
         if (n_samples[u] > 0 &&
-            hipMemcpyAsync(d_pcm + off[u], pcm_host[u], (size_t)n_samples[u] * 4, hipMemcpyHostToDevice, st) != hipSuccess) {
+            hipMemcpyAsync(d_pcm + off[u] * ss, pcm_host[u], (size_t)n_samples[u] * ss, hipMemcpyHostToDevice, st) != hipSuccess) {
             amx::set_error("amx_mfcc_run_batch: H2D copy failed");
             return fail(AMX_ERR_DEVICE);
         }
-    r = amx_mfcc_run_plan_dev(h, plan, d_pcm, d_ceps);
+    r = mfcc_run_plan(h, plan, d_pcm, s16, d_ceps);
     if (r != AMX_OK)
         return fail(r);
     for (int u = 0; u < n_seg; ++u) {
@@ -1125,11 +1212,26 @@ int amx_mfcc_run_batch(amx_mfcc* h, int n_seg, const float* const* pcm_host, con
     return fail(AMX_OK);
 }
 
+int amx_mfcc_run_batch(amx_mfcc* h, int n_seg, const float* const* pcm_host, const long* n_samples, float* const* ceps_host) {
+    return mfcc_run_batch(h, n_seg, (const void* const*)pcm_host, false, n_samples, ceps_host);
+}
+
+int amx_mfcc_run_batch_s16(amx_mfcc* h, int n_seg, const int16_t* const* pcm_host, const long* n_samples, float* const* ceps_host) {
+    return mfcc_run_batch(h, n_seg, (const void* const*)pcm_host, true, n_samples, ceps_host);
+}
+
 int amx_mfcc_run(amx_mfcc* h, const float* pcm_host, long n_samples, float* ceps_host) {
     const float* in[1]  = {pcm_host};
     float*       out[1] = {ceps_host};
     long         n[1]   = {n_samples};
     return amx_mfcc_run_batch(h, 1, in, n, out);
+}
+
+int amx_mfcc_run_s16(amx_mfcc* h, const int16_t* pcm_host, long n_samples, float* ceps_host) {
+    const int16_t* in[1]  = {pcm_host};
+    float*         out[1] = {ceps_host};
+    long           n[1]   = {n_samples};
+    return amx_mfcc_run_batch_s16(h, 1, in, n, out);
 }
 
 // internal (not in amx.h): the segmentation of a plan for the back-end kernels in backend.hip

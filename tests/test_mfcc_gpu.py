@@ -277,3 +277,69 @@ def test_lpc_cepstrum_register_and_lds_kernels_agree(ctx, monkeypatch):
     nan = np.isnan(want)
     assert np.array_equal(np.isnan(got), nan)
     assert np.median(np.abs(got[~nan] - want[~nan]) / (np.abs(want[~nan]) + 1e-2)) < 1e-4      # order-29 recursions: ill-conditioned tail
+
+
+def test_s16_samples_give_the_same_bits_as_f32(ctx):
+    """amx_mfcc_run_s16 / _run_batch_s16 / _run_plan_dev_s16: the samples as the audio file holds them (Flow/TypeConverter.hh:35-43 widens
+    s16 to f32 without scaling in front of the chain; here inside the kernel) -- bit-identical cepstra, ragged batch, every front end"""
+    import torch
+
+    import rasr_amd
+    for kw in (dict(nr_cepstrum_coefficients=40, filter_width=138.0), dict(nr_cepstrum_coefficients=16),
+               dict(nr_cepstrum_coefficients=16, front_end="mfplp", nr_autocorrelation_coefficients=20, normalize=True)):
+        fe = rasr_amd.MfccExtractor(ctx, **kw)
+        lens = [16000, 401, 399, 7, 0, 52345]
+        pcm = [synth.waveform(n, seed=70 + i) for i, n in enumerate(lens)]
+        assert all(np.array_equal(p, np.rint(p)) and np.abs(p).max(initial=0) <= 32767 for p in pcm)
+        want = fe.run_batch(pcm)
+        got = fe.run_batch([p.astype(np.int16) for p in pcm])
+        for w, g in zip(want, got):
+            assert w.shape == g.shape and np.array_equal(w.view(np.uint32), g.view(np.uint32))
+        one = fe.run(pcm[0].astype(np.int16))
+        assert np.array_equal(one.view(np.uint32), want[0].view(np.uint32))
+        off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        plan = fe.plan(off)
+        cat = np.concatenate(pcm)
+        ctx.use_torch_stream()
+        out32 = torch.empty((plan.total_frames, fe.n_ceps), dtype=torch.float32, device="cuda")
+        out16 = torch.empty_like(out32)
+        fe.run_plan(plan, torch.from_numpy(cat).cuda(), out32)
+        fe.run_plan(plan, torch.from_numpy(cat.astype(np.int16)).cuda(), out16)
+        torch.cuda.synchronize()
+        assert torch.equal(out32.view(torch.int32), out16.view(torch.int32))
+        assert np.array_equal(out32.cpu().numpy().view(np.uint32), np.concatenate(want).view(np.uint32))
+
+
+def test_matrix_core_fft_against_the_butterfly_fft_and_the_oracle(ctx, tmp_path):
+    """AMX_MFCC_FFT=mfma runs the 512-point transform as two 16x16x16 complex products on v_mfma_f32_16x16x4_f32 (slower than the
+    radix-4 LDS stages, kept for A/B runs): within the MFCC bar of the oracle and within f32 round-off of the default kernel --
+    incl. the transform's corner cases: a unit impulse at every position class, a constant, a tone on a bin, silence"""
+    import subprocess
+    import sys
+    import rasr_amd
+    from oracle import OracleMfcc
+    fe = rasr_amd.MfccExtractor(ctx, nr_cepstrum_coefficients=40, filter_width=138.0)
+    orc = OracleMfcc(n_ceps=40, filter_width=138.0)
+    n = 4000
+    t = np.arange(n)
+    sigs = [synth.waveform(n, seed=91), np.full(n, 1000.0, np.float32), (8000 * np.sin(2 * np.pi * t * 1000 / 16000)).astype(np.float32),
+            np.zeros(n, np.float32)]
+    for pos in (0, 1, 63, 64, 199, 200, 399, 400, 1234):
+        imp = np.zeros(n, np.float32)
+        imp[pos] = 20000.0
+        sigs.append(imp)
+    np.save(str(tmp_path / "sigs.npy"), np.stack(sigs))
+    # the matrix-core kernel in a fresh process (the choice is read once per process)
+    code = ("import numpy as np, rasr_amd, sys; ctx = rasr_amd.Context(0); "
+            "fe = rasr_amd.MfccExtractor(ctx, nr_cepstrum_coefficients=40, filter_width=138.0); "
+            "np.save(sys.argv[2], np.stack(fe.run_batch(list(np.load(sys.argv[1])))))")
+    env = dict(os.environ, AMX_MFCC_FFT="mfma", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    subprocess.check_call([sys.executable, "-c", code, str(tmp_path / "sigs.npy"), str(tmp_path / "mfma.npy")], env=env)
+    got = np.load(str(tmp_path / "mfma.npy"))
+    ref = np.stack(fe.run_batch(sigs))
+    for g, r, x in zip(got, ref, sigs):
+        want = orc.run(x)
+        ok = np.isfinite(want)
+        assert np.array_equal(np.isfinite(g), ok)
+        assert np.all(np.abs(g[ok] - want[ok]) <= 1e-4 * np.abs(want[ok]) + 1e-4), np.abs(g[ok] - want[ok]).max()
+        assert np.all(np.abs(g[ok] - r[ok]) <= 1e-4 * np.abs(r[ok]) + 1e-4)
