@@ -331,7 +331,12 @@ float amx_gmm_simd_scaling(const amx_gmm* h);
  * clusters, initial clusters drawn with srand(1) / rand(), `iterations` rounds); a mixture without an active density scores
  * `backoff_score`.  Defaults (the reference's): 256 / 32 / 5 / 40000.  The clustering is built on the first preselection call
  * (or amx_gmm_preselection_clustering) and rebuilt after amx_gmm_set_preselection.  amx_gmm_preselection_clustering returns
- * it: cluster_of [sum K_m] (cluster of every mixture entry), cluster_means [n_clusters x dim]; any pointer may be NULL. */
+ * it: cluster_of [sum K_m] (cluster of every mixture entry), cluster_means [n_clusters x dim]; any pointer may be NULL.
+ * Parity with the reference binary holds up to DISTANCE TIES between clusters: the reference ranks them with std::sort on the
+ * distance alone (selectClusters), whose order among equal distances is implementation-defined; here (and in the oracle) the
+ * lower cluster index wins.  Exact ties are rare in f32 and common in the u8 / s32 variant below -- there the selected cluster set,
+ * and with it a score or a back-off value, can differ from a given reference build at a tie.  A frame whose distances are all NaN
+ * selects the first `select_clusters` clusters (what an index-ordered sort of incomparable keys leaves in front). */
 int amx_gmm_set_preselection(amx_gmm* h, int clusters, int select_clusters, int iterations, float backoff_score);
 int amx_gmm_preselection_clustering(amx_gmm* h, int* n_clusters, uint32_t* cluster_of, float* cluster_means);
 /* AMX_GMM_PRESELECTION_INT = Mm::BatchPreselectionIntFeatureScorer ("preselection-batch-int", Mm/BatchFeatureScorer.cc:514-578):
@@ -504,13 +509,15 @@ int amx_nn_vector_write_s32(const char* path, int n, const int* data);
  * hundred of the 10^4 emissions of a frame; copying every [bufferSize x nEmissions] block to the host (40 kB per frame) would bound
  * the scorer at the PCIe rate.  These calls let a C / C++ adapter keep the block in HBM (*_score_dev) and move only what is asked
  * for: whole rows (amx_copy_to_host of one row) or (row, emission) pairs (amx_gather_scores: device gather + one small copy).
- * amx_copy_to_device returns when the source buffer may be reused; amx_copy_to_host / amx_gather_scores synchronise the stream. */
+ * amx_copy_to_device returns when the source buffer may be reused (a pageable source is staged by the runtime; for a pinned source the
+ * copy is waited for); amx_copy_to_host / amx_gather_scores synchronise the stream.  amx_gather_scores checks every (row, column)
+ * pair against the block's shape [n_rows x ld] and refuses the call (AMX_ERR_INVALID) if one lies outside. */
 int  amx_device_malloc(amx_ctx* ctx, size_t bytes, void** dev);
 void amx_device_free(amx_ctx* ctx, void* dev);
 int  amx_copy_to_device(amx_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
 int  amx_copy_to_host(amx_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
-int  amx_gather_scores(amx_ctx* ctx, const float* scores_dev, int ld, int n, const uint32_t* rows_host, const uint32_t* cols_host,
-                       float* dst_host);
+int  amx_gather_scores(amx_ctx* ctx, const float* scores_dev, int n_rows, int ld, int n, const uint32_t* rows_host,
+                       const uint32_t* cols_host, float* dst_host);
 
 /* ------------------------------------------------------------------ feature caches */
 

@@ -122,14 +122,17 @@ class Context:
     def synchronize(self):
         _lib.check(self.L.amx_synchronize(self.h))
 
-    def gather_scores(self, scores_dev, ld, rows, cols):
+    def gather_scores(self, scores_dev, ld, rows, cols, n_rows=None):
         """scores_dev[rows[i] * ld + cols[i]] for host index arrays -> host float32 array (device gather + one small copy: what a
-        decoder's ContextScorer::scores(list) costs against a resident score block)"""
+        decoder's ContextScorer::scores(list) costs against a resident score block); n_rows: rows of the block (default: the
+        tensor's first dimension) -- pairs outside [n_rows x ld] are refused"""
         rows = np.ascontiguousarray(rows, dtype=np.uint32)
         cols = np.ascontiguousarray(cols, dtype=np.uint32)
         out = np.empty(len(rows), np.float32)
-        _lib.check(self.L.amx_gather_scores(self.h, scores_dev.data_ptr(), int(ld), len(rows), rows.ctypes.data, cols.ctypes.data,
-                                            out.ctypes.data))
+        if n_rows is None:
+            n_rows = int(scores_dev.shape[0]) if scores_dev.dim() > 1 else int(scores_dev.numel() // int(ld))
+        _lib.check(self.L.amx_gather_scores(self.h, scores_dev.data_ptr(), int(n_rows), int(ld), len(rows), rows.ctypes.data,
+                                            cols.ctypes.data, out.ctypes.data))
         return out
 
     def profile(self, enable=True):

@@ -182,7 +182,7 @@ SIGNATURES = {
     "amx_device_free": (None, [_P, _P]),
     "amx_copy_to_device": (C.c_int, [_P, _P, _P, C.c_size_t]),
     "amx_copy_to_host": (C.c_int, [_P, _P, _P, C.c_size_t]),
-    "amx_gather_scores": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P]),
+    "amx_gather_scores": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "amx_stats_accumulate_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P]),
     "amx_comm_available": (C.c_int, []),
     "amx_comm_unique_id": (C.c_int, [_P]),

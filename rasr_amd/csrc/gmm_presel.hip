@@ -16,6 +16,8 @@
 //              presel_score_kernel: gmm_batch_float_kernel's arithmetic with the wave's lane mask of the density's cluster read
 //              through the scalar cache -- a density whose cluster no frame of the wave selected is skipped altogether.
 #include "common.hpp"
+
+#include <algorithm>
 #include "gmm_device.hpp"
 
 #include <cfloat>
@@ -118,9 +120,12 @@ __global__ __launch_bounds__(64) void cluster_select_kernel(const float* __restr
         pd = bd;
         pc = bc;
     }
+    // A frame whose distances are all NaN (a NaN feature) ranks no cluster above another: the reference's std::sort leaves such a
+    // list in index order and still marks the first n_select clusters (Mm/BatchFeatureScorer.cc selectClusters); so does this.
+    const bool none = pc < 0;
     for (int c = 0; c < n_clusters; ++c) {
         const float d      = g_dist[(size_t)c * Tpad + t];
-        const bool  active = live && (d < pd || (d == pd && c <= pc));
+        const bool  active = live && (none ? c < n_select : (d < pd || (d == pd && c <= pc)));
         const unsigned long long m = __ballot(active);
         if (lane == 0)
             g_masks[(size_t)blockIdx.x * n_clusters + c] = m;
@@ -321,11 +326,28 @@ extern "C" int amx_internal_gmm_presel_info(const void* p, int* n_clusters, uint
     return AMX_OK;
 }
 
+static int presel_score_chunk(amx::GmmPresel* s, amx_ctx* ctx, const float* feats_dev, int T, float* scores_dev, const uint32_t* d_mix_off,
+                              const uint32_t* d_k_mean, const float* d_k_const, const float* d_smeans, const float* d_isr0, int n_mix);
+
+// frames in chunks of 16 384 like every other scorer: the distance / mask scratch stays bounded (16 MB for 256 clusters) and is
+// allocated once instead of following the largest batch ever seen with a synchronising hipFree / hipMalloc
 extern "C" int amx_internal_gmm_presel_score(void* p, amx_ctx* ctx, const float* feats_dev, int T, float* scores_dev, const uint32_t* d_mix_off,
                                              const uint32_t* d_k_mean, const float* d_k_const, const float* d_smeans, const float* d_isr0,
                                              int n_mix) {
+    amx::GmmPresel* s = (amx::GmmPresel*)p;
+    constexpr int   kChunk = 16384;
+    for (int t0 = 0; t0 < T; t0 += kChunk) {
+        const int r = presel_score_chunk(s, ctx, feats_dev + (size_t)t0 * s->dim, std::min(kChunk, T - t0), scores_dev + (size_t)t0 * n_mix,
+                                         d_mix_off, d_k_mean, d_k_const, d_smeans, d_isr0, n_mix);
+        if (r != AMX_OK)
+            return r;
+    }
+    return AMX_OK;
+}
+
+static int presel_score_chunk(amx::GmmPresel* s, amx_ctx* ctx, const float* feats_dev, int T, float* scores_dev, const uint32_t* d_mix_off,
+                              const uint32_t* d_k_mean, const float* d_k_const, const float* d_smeans, const float* d_isr0, int n_mix) {
     using namespace amx;
-    GmmPresel* s = (GmmPresel*)p;
     AMX_HIP(hipSetDevice(ctx->device));
     const int Tpad = (T + 63) / 64 * 64, n_groups = Tpad / 64;
     if (Tpad > s->cap_T) {

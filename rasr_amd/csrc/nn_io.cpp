@@ -46,6 +46,7 @@ int amx_nn_matrix_read(const char* path, int* rows, int* cols, float** data) {
     uint32_t nr = 0, nc = 0, n2 = 0;
     bool     ok = read_u32(f, &nr) && read_u32(f, &nc) && read_u32(f, &n2) && n2 == nr && (uint64_t)nr * nc < (1ull << 31);
     float*   d  = ok ? (float*)malloc(std::max<size_t>((size_t)nr * nc, 1) * sizeof(float)) : nullptr;
+    ok          = ok && d != nullptr;
     for (uint32_t r = 0; ok && r < nr; ++r) {
         uint32_t len = 0;
         ok           = read_u32(f, &len) && len == nc && fread(d + (size_t)r * nc, 4, nc, f) == nc;
@@ -110,6 +111,13 @@ static int vector_read_xml(const char* path, const char* type, int* n, T** data,
         amx::set_error("%s: cannot open '%s'", who, path);
         return AMX_ERR_INVALID;
     }
+    // XML comments may quote the element: blank them out before looking for it (Core/VectorParser.hh sits behind a real XML parser)
+    for (size_t c0 = doc.find("<!--"); c0 != std::string::npos; c0 = doc.find("<!--", c0)) {
+        const size_t c1 = doc.find("-->", c0 + 4);
+        const size_t ce = c1 == std::string::npos ? doc.size() : c1 + 3;
+        for (size_t i = c0; i < ce; ++i)
+            doc[i] = ' ';
+    }
     const std::string open_tag = std::string("<vector-") + type;
     size_t            p0 = doc.find(open_tag);
     size_t            p1 = p0 == std::string::npos ? p0 : doc.find('>', p0);
@@ -120,9 +128,24 @@ static int vector_read_xml(const char* path, const char* type, int* n, T** data,
     }
     long              want = -1;
     const std::string head = doc.substr(p0, p1 - p0);
-    const size_t      ps = head.find("size=");
-    if (ps != std::string::npos && ps + 6 < head.size())
-        want = atol(head.c_str() + ps + 6);
+    // size = "3", size='3', size="3": white space around '=' and either quote character, as any XML parser accepts them
+    for (size_t ps = head.find("size"); ps != std::string::npos; ps = head.find("size", ps + 4)) {
+        if (ps > 0 && !isspace((unsigned char)head[ps - 1]))
+            continue;  // part of another attribute name
+        size_t q = ps + 4;
+        while (q < head.size() && isspace((unsigned char)head[q]))
+            ++q;
+        if (q >= head.size() || head[q] != '=')
+            continue;
+        ++q;
+        while (q < head.size() && isspace((unsigned char)head[q]))
+            ++q;
+        if (q < head.size() && (head[q] == '"' || head[q] == '\''))
+            ++q;
+        if (q < head.size() && isdigit((unsigned char)head[q]))
+            want = atol(head.c_str() + q);
+        break;
+    }
     std::vector<T> v;
     const char*    c = doc.c_str() + p1 + 1;
     const char*    e = doc.c_str() + p2;
@@ -146,6 +169,10 @@ static int vector_read_xml(const char* path, const char* type, int* n, T** data,
         return AMX_ERR_INVALID;
     }
     T* d = (T*)malloc(std::max<size_t>(v.size(), 1) * sizeof(T));
+    if (!d) {
+        amx::set_error("%s: out of memory", who);
+        return AMX_ERR_INVALID;
+    }
     memcpy(d, v.data(), v.size() * sizeof(T));
     *n    = (int)v.size();
     *data = d;

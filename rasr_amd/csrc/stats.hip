@@ -96,8 +96,18 @@ extern "C" void amx_device_free(amx_ctx* ctx, void* dev) {
 extern "C" int amx_copy_to_device(amx_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes) {
     AMX_REQUIRE(ctx && (bytes == 0 || (dst_dev && src_host)), AMX_ERR_INVALID, "amx_copy_to_device: NULL argument");
     AMX_HIP(hipSetDevice(ctx->device));
-    if (bytes)
-        AMX_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));  // pageable source: returns once staged
+    if (!bytes)
+        return AMX_OK;
+    // The contract is "the source may be reused on return".  A pageable source is staged by the runtime before hipMemcpyAsync
+    // returns; a pinned one (hipHostMalloc / hipHostRegister, e.g. a torch pinned tensor) is read by the DMA engine later, so the
+    // copy is waited for.
+    hipPointerAttribute_t attr;
+    const bool pinned = hipPointerGetAttributes(&attr, src_host) == hipSuccess && attr.type == hipMemoryTypeHost;
+    if (!pinned)
+        (void)hipGetLastError();  // "not a registered pointer" is the expected answer for pageable memory
+    AMX_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (pinned)
+        AMX_HIP(hipStreamSynchronize(ctx->stream));
     return AMX_OK;
 }
 
@@ -110,13 +120,16 @@ extern "C" int amx_copy_to_host(amx_ctx* ctx, void* dst_host, const void* src_de
     return AMX_OK;
 }
 
-extern "C" int amx_gather_scores(amx_ctx* ctx, const float* scores_dev, int ld, int n, const uint32_t* rows_host, const uint32_t* cols_host,
-                                 float* dst_host) {
+extern "C" int amx_gather_scores(amx_ctx* ctx, const float* scores_dev, int n_rows, int ld, int n, const uint32_t* rows_host,
+                                 const uint32_t* cols_host, float* dst_host) {
     AMX_REQUIRE(ctx, AMX_ERR_INVALID, "amx_gather_scores: NULL context");
-    AMX_REQUIRE(n >= 0 && ld > 0, AMX_ERR_INVALID, "amx_gather_scores: bad shape");
+    AMX_REQUIRE(n >= 0 && ld > 0 && n_rows >= 0, AMX_ERR_INVALID, "amx_gather_scores: bad shape");
     if (n == 0)
         return AMX_OK;
     AMX_REQUIRE(scores_dev && rows_host && cols_host && dst_host, AMX_ERR_INVALID, "amx_gather_scores: NULL buffer");
+    for (int i = 0; i < n; ++i)  // the decoder's indices are caller data: an index outside the resident block must not become a wild device read
+        AMX_REQUIRE(rows_host[i] < (uint32_t)n_rows && cols_host[i] < (uint32_t)ld, AMX_ERR_INVALID,
+                    "amx_gather_scores: pair %d = (row %u, column %u) outside the %d x %d block", i, rows_host[i], cols_host[i], n_rows, ld);
     AMX_HIP(hipSetDevice(ctx->device));
     int r = ctx->ensure_scratch((size_t)n * 12);
     if (r != AMX_OK)

@@ -106,6 +106,7 @@ class GmmBackend : public BatchBackend {
     amx_gmm*      h_;
     int           mode_;
     ResidentBlock block_;
+    int           rows_ = 0;  // frames of the resident score block (bounds of fetchPairs)
 
 public:
     /** featureScorerType: "diagonal-maximum" (registered in Mm/Module.cc:83-105) or "diagonal-sum" */
@@ -122,19 +123,21 @@ public:
         int r = block_.reserve((size_t)T * dimension(), (size_t)T * nEmissions());
         if (r == AMX_OK)
             r = amx_copy_to_device(block_.ctx(), block_.feats(), f, (size_t)T * dimension() * sizeof(float));
+        rows_ = r == AMX_OK ? T : 0;
         return r == AMX_OK ? amx_gmm_score_dev(h_, mode_, block_.feats(), T, block_.scores(), nullptr) : r;
     }
     int fetchRow(int row, float* dst) {
         return amx_copy_to_host(block_.ctx(), dst, block_.scores() + (size_t)row * nEmissions(), (size_t)nEmissions() * sizeof(float));
     }
     int fetchPairs(int n, const unsigned* rows, const unsigned* emissions, float* dst) {
-        return amx_gather_scores(block_.ctx(), block_.scores(), (int)nEmissions(), n, rows, emissions, dst);
+        return amx_gather_scores(block_.ctx(), block_.scores(), rows_, (int)nEmissions(), n, rows, emissions, dst);
     }
 };
 
 class FfnnBackend : public BatchBackend {
     amx_ffnn*     h_;
     ResidentBlock block_;
+    int           rows_ = 0;  // frames of the resident score block (bounds of fetchPairs)
 
 public:
     FfnnBackend(amx_ctx* ctx, const amx_ffnn_model& model)
@@ -150,13 +153,14 @@ public:
         int r = block_.reserve((size_t)T * dimension(), (size_t)T * nEmissions());
         if (r == AMX_OK)
             r = amx_copy_to_device(block_.ctx(), block_.feats(), f, (size_t)T * dimension() * sizeof(float));
+        rows_ = r == AMX_OK ? T : 0;
         return r == AMX_OK ? amx_ffnn_score_dev(h_, block_.feats(), (int)dimension(), T, block_.scores()) : r;
     }
     int fetchRow(int row, float* dst) {
         return amx_copy_to_host(block_.ctx(), dst, block_.scores() + (size_t)row * nEmissions(), (size_t)nEmissions() * sizeof(float));
     }
     int fetchPairs(int n, const unsigned* rows, const unsigned* emissions, float* dst) {
-        return amx_gather_scores(block_.ctx(), block_.scores(), (int)nEmissions(), n, rows, emissions, dst);
+        return amx_gather_scores(block_.ctx(), block_.scores(), rows_, (int)nEmissions(), n, rows, emissions, dst);
     }
 };
 

@@ -314,3 +314,27 @@ def test_dc_detection_matches_the_restatement_and_its_definition():
     assert rasr_amd.dc_detection(x, merge=True) == [(0, 10001), (11000, 39000)]
     assert rasr_amd.dc_detection(np.zeros(5000, np.float32)) == []                   # digital silence: one sample + a DC run, too short to keep
     assert rasr_amd.dc_detection(np.zeros(5000, np.float32), max_dc_increment=0.0, merge=True) == [(0, 5000)]    # detection disabled
+
+
+def test_vector_files_accept_the_attribute_forms_an_xml_parser_accepts(tmp_path):
+    """amx_nn_vector_read_*: the reference reads Math::Vector files through a real XML parser (Core/VectorParser.hh), so
+    `size = "3"`, single quotes, line breaks inside the tag and a commented-out copy of the element in front of it are all the
+    same document; a wrong size is still the reference's "Vector dimension mismatch" error"""
+    L = _lib.lib()
+    heads = ['<vector-f32 size="3">', '<vector-f32 size = "3">', "<vector-f32 size='3'>", '<vector-f32  size =\n "3" >',
+             '<!-- <vector-f32 size="9"> 1 </vector-f32> -->\n<vector-f32 size="3">', '<vector-f32>']
+    for i, head in enumerate(heads):
+        p = str(tmp_path / ("v%d.xml" % i))
+        with open(p, "w") as f:
+            f.write('<?xml version="1.0" encoding="ISO-8859-1"?>\n' + head + " 1.5 -2 3e1 </vector-f32>\n")
+        n, ptr = C.c_int(), C.c_void_p()
+        assert L.amx_nn_vector_read_f32(p.encode(), C.byref(n), C.byref(ptr)) == 0, (head, L.amx_last_error())
+        v = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_float)), shape=(n.value,)).copy()
+        L.amx_free(ptr)
+        assert v.tolist() == [1.5, -2.0, 30.0], head
+    p = str(tmp_path / "bad.xml")
+    with open(p, "w") as f:
+        f.write('<vector-f32 size = "4"> 1 2 3 </vector-f32>\n')
+    n, ptr = C.c_int(), C.c_void_p()
+    assert L.amx_nn_vector_read_f32(p.encode(), C.byref(n), C.byref(ptr)) == _lib.AMX_ERR_INVALID
+    assert b"Vector dimension mismatch: 4 given and 3 read" in L.amx_last_error()

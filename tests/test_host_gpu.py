@@ -43,3 +43,39 @@ def test_host_epoch_reduce_client(tmp_path):
     for r, p in enumerate(procs):
         out, _ = p.communicate(timeout=300)
         assert p.returncode == 0 and out.strip().endswith("OK"), "rank %d: %s" % (r, out)
+
+
+def test_gather_refuses_pairs_outside_the_resident_block(ctx):
+    """amx_gather_scores validates the decoder's (row, emission) pairs against the block's shape instead of reading wherever they point"""
+    import torch
+
+    import rasr_amd
+    ctx.use_torch_stream()
+    block = torch.arange(6 * 50, dtype=torch.float32, device="cuda").reshape(6, 50)
+    got = ctx.gather_scores(block, 50, [0, 5, 3], [0, 49, 7])
+    assert got.tolist() == [0.0, 5 * 50 + 49.0, 3 * 50 + 7.0]
+    for rows, cols in (([6], [0]), ([0], [50]), ([0, 2 ** 31], [1, 1])):
+        with pytest.raises(rasr_amd.AmxError) as e:
+            ctx.gather_scores(block, 50, rows, cols)
+        assert "outside the 6 x 50 block" in str(e.value)
+
+
+def test_copy_to_device_from_pinned_memory_may_reuse_the_source_on_return(ctx):
+    """amx_copy_to_device's contract ("the source may be reused on return") also for a pinned source, where hipMemcpyAsync alone
+    would return before the DMA engine has read it"""
+    import ctypes as C
+
+    import torch
+
+    from rasr_amd import _lib
+    L = _lib.lib()
+    n = 8 << 20
+    src = torch.ones(n, dtype=torch.float32).pin_memory()
+    dst = torch.zeros(n, dtype=torch.float32, device="cuda")
+    ctx.use_torch_stream()
+    for rep in range(3):
+        src.fill_(float(rep + 1))
+        _lib.check(L.amx_copy_to_device(ctx.h, C.c_void_p(dst.data_ptr()), C.c_void_p(src.data_ptr()), n * 4))
+        src.fill_(-1.0)   # overwrite immediately: must not reach the device copy
+        torch.cuda.synchronize()
+        assert float(dst.min()) == float(dst.max()) == float(rep + 1)
