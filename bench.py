@@ -233,7 +233,9 @@ def nn_gemm_roofline(precision, ms, n, frames, full_chunk):
     name = {"bf16": "gemm_bf16_pipe_kernel<NONE,LAST> (2048->10000)", "bf16x3": "gemm_bf16_pipe_kernel<X3,NONE,LAST> (2048->10000, split bf16: W_hi/W_lo/X_hi/X_lo staged once, 3 MFMA products per fragment set)",
             "fp32": "gemm_f32_kernel (2048->10000)"}[precision]
     out = dict(bound="mfma", kernel=name, achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
-               traffic=measured_traffic("pipeline", "gemm_bf16_pipe_kernel", "GemmCfg<256, 256, 2, 4, 2, 64>, 0") if (precision == "bf16" and full_chunk) else None,
+               traffic=(measured_traffic("pipeline" if precision == "bf16x3" else "pipeline-bf16", "gemm_bf16_pipe_kernel",
+                                         {"bf16x3": "32, true>, 0, true", "bf16": "64, false>, 0, true"}[precision])
+                        if (precision in ("bf16", "bf16x3") and full_chunk) else None),
                avg_launch_ms=round(ms, 4), launches=n, flops_per_launch=mult * alg)
     if mult != 1.0:
         out["algorithmic_tflops"] = round(alg / (ms * 1e-3) / 1e12, 2)

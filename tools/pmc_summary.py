@@ -3,7 +3,7 @@ rows=list(csv.DictReader(open(sys.argv[1])))
 pat=sys.argv[2] if len(sys.argv)>2 else ''
 agg=collections.defaultdict(lambda: collections.defaultdict(float)); disp=collections.defaultdict(set)
 for r in rows:
-    k=r['Kernel_Name'][:70]
+    k=r['Kernel_Name'].split('(')[0][:120]  # template arguments included, parameter list dropped
     if pat and pat not in k: continue
     agg[k][r['Counter_Name']]+=float(r['Counter_Value']); disp[k].add(r['Dispatch_Id'])
 for k,v in agg.items():
