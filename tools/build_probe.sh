@@ -4,8 +4,10 @@ set -e
 cd "$(dirname "$0")/.."
 make -s -C rasr_amd/csrc
 mkdir -p tools/build
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -w -I include -I rasr_amd/csrc -save-temps=obj -c tools/gemm_probe.hip -o tools/build/gemm_probe.o
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -w -I include -I rasr_amd/csrc -c tools/gemm_probe.hip -o tools/build/gemm_probe.o
 hipcc --offload-arch=gfx950 tools/build/gemm_probe.o rasr_amd/csrc/build/api.o rasr_amd/csrc/build/stats.o -o tools/build/gemm_probe
 # tools/build/ceilings: measured HBM / MFMA / VALU ceilings of the box (tools/ceilings.hip)
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -w tools/ceilings.hip -o tools/build/ceilings
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -w tools/write_probe.hip -o tools/build/write_probe
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -w tools/valu_rates.hip -o tools/build/valu_rates
+rm -f tools/build/*.bc tools/build/*.hipi tools/build/*.out tools/build/*.s tools/build/*.resolution.txt tools/build/*gfx950.o tools/build/*x86_64*
