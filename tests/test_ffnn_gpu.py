@@ -284,3 +284,87 @@ def test_bf16x3_config4_full_size_against_the_oracle(ctx):
     assert np.array_equal(sc.view(np.uint32), got.view(np.uint32))
     assert np.array_equal(state.cpu().numpy(), sc.argmin(axis=1))
     assert np.array_equal(counts.cpu().numpy(), np.bincount(sc.argmin(axis=1), minlength=10000))
+
+
+@pytest.mark.parametrize("n_out", [2500, 2501])
+def test_bf16x3_tile_configurations_agree(ctx, monkeypatch, n_out):
+    """split bf16: every tile configuration -- 128x128, 128x64 (two and three stages), 256x256 and the cross-tile pipelined 256x256
+    kernel with its two-barrier K-loop -- stages the same four planes and issues hi.hi, lo.hi, hi.lo in the same order, so scores,
+    best states and accumulators are bit-identical; and they meet the 1e-4 bar of the oracle.  Shape as in the bf16 test: persistent
+    workgroups walk several tiles incl. frame- and state-edge tiles, 2501 makes the score rows unaligned (guarded stores); the
+    hidden layer (64 -> 300 -> n_out) goes through the fused activation + split epilogue of every configuration."""
+    import torch
+
+    import rasr_amd
+    from oracle import oracle_ffnn_score
+    Ws, bs, acts, logp = synth.ffnn([64, 300, n_out], seed=21)
+    x = feats(8200, 64, 22)
+    xd = torch.from_numpy(x).cuda()
+    ctx.use_torch_stream()
+    results = {}
+    for cfg in ("0", "3", "6", "4", "2"):
+        monkeypatch.setenv("AMX_GEMM_CFG", cfg)
+        nn = rasr_amd.NnBatchFeatureScorer(ctx, Ws, bs, acts, log_prior=logp, precision="bf16x3")
+        sc = torch.full((8200, n_out), float("nan"), dtype=torch.float32, device="cuda")
+        best = torch.zeros(8200, dtype=torch.int32, device="cuda")
+        counts = torch.zeros(n_out, dtype=torch.int64, device="cuda")
+        ssum = torch.zeros(1, dtype=torch.float64, device="cuda")
+        for _ in range(2):  # second pass: the counted-wait path of the pipelined kernel in steady state
+            nn.score_stats_dev(xd, 64, 8200, sc, best, counts, ssum)
+        torch.cuda.synchronize()
+        results[cfg] = (sc.cpu().numpy(), best.cpu().numpy(), counts.cpu().numpy(), float(ssum.item()))
+        plain = nn.score(x[:700])
+        assert np.array_equal(plain.view(np.uint32), results[cfg][0][:700].view(np.uint32))
+    ref = results["0"]
+    assert np.isfinite(ref[0]).all()
+    assert np.array_equal(ref[1], ref[0].argmin(axis=1))
+    assert np.array_equal(ref[2], 2 * np.bincount(ref[1], minlength=n_out))
+    for cfg in ("3", "6", "4", "2"):
+        got = results[cfg]
+        assert np.array_equal(got[0].view(np.uint32), ref[0].view(np.uint32)), cfg
+        assert np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2]), cfg
+        assert abs(got[3] - ref[3]) <= 1e-9 * abs(ref[3]), cfg
+    want = oracle_ffnn_score(Ws, bs, acts, x[:1500], log_prior=logp, prior_scale=1.0, acc64=True)
+    assert np.all(np.abs(ref[0][:1500] - want) <= 1e-4 * np.abs(want) + 1e-4), np.abs(ref[0][:1500] - want).max()
+
+
+def test_bf16x3_full_size_shard_properties(ctx):
+    """BASELINE config 5 shard scale in split bf16 (440 -> 6 x 2048 -> 10 000, 40 000 frames: more than one internal pass of 32 768,
+    every layer on the pipelined kernel): rows are independent -- scoring the frames in another order permutes the scores bit for
+    bit --, the fused arg-min statistics equal a recount, a slice scored with the small-batch tiles equals the rows of the big pass,
+    and a sample of rows meets the 1e-4 bar of the f64-accumulating oracle."""
+    import torch
+
+    import rasr_amd
+    from oracle import oracle_ffnn_score
+    Ws, bs, acts, logp = synth.ffnn([440] + [2048] * 6 + [10000], seed=7)
+    nn = rasr_amd.NnBatchFeatureScorer(ctx, Ws, bs, acts, log_prior=logp, priori_scale=1.0, precision="bf16x3")
+    T = 40000
+    x = np.random.Generator(np.random.PCG64(300)).standard_normal((T, 440)).astype(np.float32)
+    ctx.use_torch_stream()
+    xd = torch.from_numpy(x).cuda()
+    s = torch.empty((T, 10000), dtype=torch.float32, device="cuda")
+    best = torch.empty((T,), dtype=torch.int32, device="cuda")
+    counts = torch.zeros((10000,), dtype=torch.int64, device="cuda")
+    ssum = torch.zeros((1,), dtype=torch.float64, device="cuda")
+    nn.score_stats_dev(xd, 440, T, s, best, counts, ssum)
+    torch.cuda.synchronize()
+    perm = torch.randperm(T, device="cuda", generator=torch.Generator(device="cuda").manual_seed(2))
+    s2 = torch.empty_like(s)
+    nn.score_dev(xd[perm].contiguous(), 440, T, s2)
+    torch.cuda.synchronize()
+    assert torch.equal(s2.view(torch.int32), s[perm].view(torch.int32))
+    del s2
+    am = s.argmin(dim=1)
+    assert torch.equal(best.long(), am)
+    assert torch.equal(counts, torch.bincount(am, minlength=10000))
+    ref_sum = float(s.gather(1, am[:, None]).double().sum())
+    assert abs(float(ssum[0]) - ref_sum) <= 1e-9 * abs(ref_sum)
+    s3 = torch.empty((1024, 10000), dtype=torch.float32, device="cuda")
+    nn.score_dev(xd[32000:33024].contiguous(), 440, 1024, s3)     # small-batch tile configuration, straddling the pass boundary
+    torch.cuda.synchronize()
+    assert torch.equal(s3.view(torch.int32), s[32000:33024].view(torch.int32))
+    rows = np.r_[0:24, 32760:32776, 39990:40000]                  # first tile, the pass boundary, the ragged last tile
+    want = oracle_ffnn_score(Ws, bs, acts, x[rows], log_prior=logp, prior_scale=1.0, acc64=True)
+    got = s[torch.from_numpy(rows).cuda()].cpu().numpy()
+    assert np.all(np.abs(got - want) <= 1e-4 * np.abs(want) + 1e-4), np.abs(got - want).max()
