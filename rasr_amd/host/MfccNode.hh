@@ -8,6 +8,7 @@
 #define RASR_AMD_HOST_MFCC_NODE_HH
 
 #include <cstdlib>
+#include <cstdint>
 #include <map>
 #include <stdexcept>
 #include <string>
@@ -28,6 +29,7 @@ class MfccNode {
     amx_mfcc*                          h_;
     amx_mfcc_info                      info_;
     std::vector<float>                 samples_;
+    std::vector<int16_t>               samples16_;
     double                             segmentStart_;
     std::vector<float>                 ceps_;
     long                               nFrames_, next_;
@@ -89,16 +91,27 @@ public:
         samples_.insert(samples_.end(), x, x + n);
     }
 
+    /** the same for a `vector-s16` stream, i.e. with the node linked straight behind the audio reader instead of behind
+     *  generic-convert-vector-s16-to-vector-f32 (Flow/TypeConverter.hh:35-43 widens without scaling; the kernel does the same):
+     *  half the bytes to the device.  A segment is all-s16 or all-f32. */
+    void putSamples(const int16_t* x, size_t n, double startTime) {
+        if (samples16_.empty() && next_ == nFrames_)
+            segmentStart_ = startTime;
+        samples16_.insert(samples16_.end(), x, x + n);
+    }
+
     /** end of the segment's input: runs the fused kernel over the whole segment */
     bool eos() {
-        if (!h_)
+        if (!h_ || (!samples_.empty() && !samples16_.empty()))
             return false;
-        nFrames_ = amx_mfcc_n_frames(h_, (long)samples_.size());
-        next_    = 0;
+        const bool s16 = !samples16_.empty();
+        nSamples_      = (long)(s16 ? samples16_.size() : samples_.size());
+        nFrames_       = amx_mfcc_n_frames(h_, nSamples_);
+        next_          = 0;
         ceps_.assign((size_t)nFrames_ * info_.n_ceps, 0.f);
-        int r = amx_mfcc_run(h_, samples_.data(), (long)samples_.size(), ceps_.data());
-        nSamples_ = (long)samples_.size();
+        const int r = s16 ? amx_mfcc_run_s16(h_, samples16_.data(), nSamples_, ceps_.data()) : amx_mfcc_run(h_, samples_.data(), nSamples_, ceps_.data());
         samples_.clear();
+        samples16_.clear();
         return r == AMX_OK;
     }
 

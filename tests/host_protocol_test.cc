@@ -162,6 +162,31 @@ int main(int argc, char** argv) {
     }
     CHECK(n == 99);                                   // ceil((16000-400)/160)+1
     CHECK(std::fabs(lastEnd - (2.5 + 1.0)) < 1e-9);   // last (short) frame ends with the audio
+    // the same segment as a vector-s16 stream (node behind the audio reader, no converter node): integer-valued samples give
+    // the same bits on both paths
+    {
+        std::vector<int16_t> pcm16(16000);
+        std::vector<float>   pcmf(16000);
+        for (size_t i = 0; i < pcm16.size(); ++i) {
+            pcm16[i] = (int16_t)std::lrint(pcm[i]);
+            pcmf[i]  = (float)pcm16[i];
+        }
+        std::vector<std::vector<float>> a, b;
+        node.putSamples(pcmf.data(), pcmf.size(), 0.0);
+        CHECK(node.eos());
+        while (node.getFeature(p))
+            a.push_back(p.data);
+        node.putSamples(pcm16.data(), 1000, 0.0);
+        node.putSamples(pcm16.data() + 1000, pcm16.size() - 1000, 1000 / 16000.0);
+        CHECK(node.eos());
+        while (node.getFeature(p))
+            b.push_back(p.data);
+        CHECK(a.size() == 99 && b.size() == 99);
+        bool same = a.size() == b.size();
+        for (size_t i = 0; same && i < a.size(); ++i)
+            same = memcmp(a[i].data(), b[i].data(), 12 * sizeof(float)) == 0;
+        CHECK(same);
+    }
     attr["sample-rate"] = "0";
     CHECK(!node.configure(attr) && strstr(amx_last_error(), "not positive"));
 
