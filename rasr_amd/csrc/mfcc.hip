@@ -808,9 +808,10 @@ int launch_mfcc(amx_mfcc* h, const amx::MfccParams& p, int n_tiles, bool s16) {
     if (n_tiles <= 0)
         return AMX_OK;
     // AMX_MFCC_FFT=mfma: the 512-point transform as two 16x16x16 complex products on the f32 matrix cores (see mfcc_kernel).  Measured
-    // on config 2 (993 k frames, same box): 0.958 ms against 0.748 ms for the radix-4 LDS stages -- the 24 v_mfma_f32_16x16x4_f32 per
-    // frame (768 matrix-pipe cycles per SIMD) do not hide behind the other waves' vector work, the frame costs what the removed ~110
-    // vector instructions cost plus ~1250 cycles -- so the butterflies stay the default and the product form is kept for A/B runs.
+    // on config 2 (993 k frames, same box): 0.958 ms against 0.748 ms for the radix-4 LDS stages.  SQ counters (profiles/r03/pmc/
+    // mfcc_fft_*): matrix pipe busy 36 % + vector ALUs busy 51 % = 87 % of the dispatch -- v_mfma_f32_16x16x4_f32 runs at the f32
+    // vector rate and does not overlap with vector instructions on a SIMD, so 24 of them cost like 192 vector instructions, more
+    // than the ~125 they replace.  The butterflies stay the default; the product form is kept for A/B runs.
     static const bool mfma = getenv("AMX_MFCC_FFT") && !strcmp(getenv("AMX_MFCC_FFT"), "mfma");
     if constexpr (NC == 256) {
         if (mfma)
