@@ -1527,7 +1527,13 @@ void launch_bf16_cfg(amx_ffnn* h, int l, const void* x, int ldx, void* out, int 
     // default: 256x256 tiles when they still give >= 2 tiles per CU, else 128x128 (small batches)
     int cfg = h->gemm_cfg;
     if (cfg < 0) {
-        if ((long)(h->Npad[l] / 256) * (Tpad / 256) >= 2L * h->ctx->n_cu)
+        const long ncu = std::max(h->ctx->n_cu, 1), t256 = (long)(h->Npad[l] / 256) * (Tpad / 256), t128 = (long)(h->Npad[l] / 128) * (Tpad / 128);
+        if (t256 >= 2L * ncu)
+            cfg = 2;
+        // between one half and two tiles of 256 x 256 per CU (the output layer at batch 1024: 160 tiles): the pipelined kernel in ONE
+        // round against the 128 x 128 tiles in ceil(tiles / 2 per CU) rounds -- a 256 x 256 tile takes 1.8 rounds of the small ones
+        // (57 vs 32 us at K = 2048); output layer at batch 1024: 64 -> 57 us bf16, 147 -> 135 us split bf16
+        else if (2 * t256 >= ncu && ((t256 + ncu - 1) / ncu) * 9 < ((t128 + 2 * ncu - 1) / (2 * ncu)) * 5)
             cfg = 2;
         else if ((long)(h->Npad[l] / 128) * (Tpad / 128) >= (long)h->ctx->n_cu)
             cfg = 0;
