@@ -1537,9 +1537,9 @@ extern "C" int   amx_internal_gmm_simd_presel_score(void* p, amx_ctx* ctx, const
 extern "C" int    amx_internal_gmm_tied_create(int K, int n_mix, int mix_pad, const float* ahat_t_host, float** d_amin, unsigned short** d_aup);
 extern "C" size_t amx_internal_gmm_tied_workspace(int K, int T, int mix_pad);
 extern "C" int    amx_internal_gmm_tied_score(amx_ctx* ctx, const float* dist_dev, const uint32_t* k_dens_dev, int K, int T, int Tpad, int n_mix,
-                                              int mix_pad, const unsigned short* aup, const float* amax, const float* m2lw_t, const double* ln64,
-                                              const float* amin, void* workspace, float* scores, uint32_t* best,
-                                              unsigned long long* survivors_dev);
+                                              int mix_pad, const unsigned short* aup, const float* amax, const float* m2lw_t, const float* ahat_t,
+                                              const double* ln64, const float* ln32, const float* amin, void* workspace, float* scores,
+                                              uint32_t* best, unsigned long long* survivors_dev);
 extern "C" int amx_internal_gmm_fused_supported(int dim, int pooled, int Kp);
 extern "C" int amx_internal_gmm_fused_create(int dim, int n_mix, int n_tiles, const void* A2_host, const uint32_t* mix_off, const uint32_t* k_mean,
                                              const double* c64, const float* means, const float* p1, const float* p2, void** rec_dev,
@@ -2482,7 +2482,8 @@ int amx_gmm_score_dev(amx_gmm* h, int mode, const float* feats_dev, int T, float
                         h->tied_ws_cap = need_ws;
                     }
                     int r = amx_internal_gmm_tied_score(h->ctx, h->d_dist, h->d_k_dens, h->K, Tc, Tpad, h->n_mix, h->mix_pad, h->d_aup,
-                                                        h->d_amax, h->d_m2lw_t, h->d_ln64, h->d_amin, h->d_tied_ws, sc, bd, h->d_tied_surv);
+                                                        h->d_amax, h->d_m2lw_t, h->d_ahat_t, h->d_ln64, h->d_ln32, h->d_amin, h->d_tied_ws, sc, bd,
+                                                        h->d_tied_surv);
                     if (r != AMX_OK)
                         return r;
                     AMX_HIP(hipMemcpyAsync(h->h_tied_surv, h->d_tied_surv, 257 * 8, hipMemcpyDeviceToHost, h->ctx->stream));

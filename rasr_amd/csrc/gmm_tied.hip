@@ -33,21 +33,29 @@
 #include <cstring>
 #include <vector>
 
+#ifndef AMX_TIED_EXP
+#define AMX_TIED_EXP 0  // experiments (tools/): 1 = never take the unscreened loop (timing only, wrong on ties), 2 = no screening
+#endif
+
 namespace amx {
+#if AMX_TIED_EXP & 4
+__device__ unsigned long long g_tied_hist[64];  // [0..31] candidates per (lane, wave); [32..63] survivors / 8 per wave
+#endif
 
 constexpr int kTiedNear     = 32;   // near densities per frame = residue classes of the density index
 constexpr int kTiedCounters = 256;  // survivor counters (summed by the host)
 
 // dist [n_dens][Tpad] (coalesced along frames) -> dt [T][Kpad] (coalesced along the density list); 64 x 64 tiles through LDS
+// (g_dist points at the first column of the pass: cols = the padded columns from there on, Tpad = the row stride)
 __global__ __launch_bounds__(256) void tied_transpose_kernel(const float* __restrict__ g_dist, const uint32_t* __restrict__ g_k_dens, int K,
-                                                           int Kpad, int T, int Tpad, float* __restrict__ g_dt) {
+                                                           int Kpad, int T, int cols, int Tpad, float* __restrict__ g_dt) {
     __shared__ float s[64][65];
     const int        k0 = blockIdx.x * 64, t0 = blockIdx.y * 64;
     const int        c = threadIdx.x & 63, r0 = threadIdx.x >> 6;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int k = k0 + r0 + 4 * i;
-        s[r0 + 4 * i][c] = (k < K && t0 + c < Tpad) ? g_dist[(size_t)g_k_dens[k] * Tpad + t0 + c] : __builtin_inff();
+        s[r0 + 4 * i][c] = (k < K && t0 + c < cols) ? g_dist[(size_t)g_k_dens[k] * Tpad + t0 + c] : __builtin_inff();
     }
     __syncthreads();
 #pragma unroll
@@ -68,7 +76,7 @@ constexpr int kTiedBoundThreads = 1024;  // mixtures per workgroup of tied_bound
 
 __global__ __launch_bounds__(kTiedBoundThreads) void tied_bound_kernel(const unsigned short* __restrict__ g_aup, const float* __restrict__ g_amax,
                                                                       const float* __restrict__ g_dt, int K, int Kpad, int n_mix, int mix_pad,
-                                                                      int n_tiles, float* __restrict__ g_thr) {
+                                                                      int n_tiles, float* __restrict__ g_thr, float* __restrict__ g_thr_m) {
     constexpr int       NT = kTiedBoundThreads;
     __shared__ float    s_v[NT];
     __shared__ uint32_t s_i[NT];
@@ -118,6 +126,8 @@ __global__ __launch_bounds__(kTiedBoundThreads) void tied_bound_kernel(const uns
         if (!(thr == thr))
             thr = __builtin_inff();
     }
+    if (m < mix_pad)
+        g_thr_m[(size_t)t * mix_pad + m] = thr;  // the mixture's own threshold: tied_pruned_kernel screens with it (-inf: padding)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1)
         thr = fmaxf(thr, __shfl_xor(thr, o));
@@ -127,10 +137,11 @@ __global__ __launch_bounds__(kTiedBoundThreads) void tied_bound_kernel(const uns
 }
 
 // One wave per frame: ThrG = max over the tiles, then the densities with fl32(aminG[k] + dist) <= ThrG, ascending, with their
-// distances.  lk / ld [T][Kpad], ln [T].
+// distances and log-normalisation terms.  lk / ld / ll [T][Kpad], ln [T].
 __global__ __launch_bounds__(64) void tied_list_kernel(const float* __restrict__ g_dt, const float* __restrict__ g_amin_all,
-                                                      const float* __restrict__ g_thr, int K, int Kpad, int n_tiles, uint32_t* __restrict__ g_lk,
-                                                      float* __restrict__ g_ld, int* __restrict__ g_ln,
+                                                      const float* __restrict__ g_thr, const float* __restrict__ g_ln32, int K, int Kpad,
+                                                      int n_tiles, uint32_t* __restrict__ g_lk, float* __restrict__ g_ld,
+                                                      float* __restrict__ g_ll, int* __restrict__ g_ln,
                                                       unsigned long long* __restrict__ g_examined, unsigned long long examined) {
     const int t = blockIdx.x, lane = threadIdx.x;
     // the denominator of the survivor statistic travels with the numerator (the host reads both from ONE asynchronous copy: counting
@@ -146,14 +157,16 @@ __global__ __launch_bounds__(64) void tied_list_kernel(const float* __restrict__
     const float* row = g_dt + (size_t)t * Kpad;
     uint32_t*    lk  = g_lk + (size_t)t * Kpad;
     float*       ld  = g_ld + (size_t)t * Kpad;
+    float*       ll  = g_ll + (size_t)t * Kpad;
     int          n   = 0;
-    for (int kb = 0; kb < Kpad; kb += 256) {  // four 64-density steps per trip, their eight loads in flight together
-        float dv[4], am[4];
+    for (int kb = 0; kb < Kpad; kb += 256) {  // four 64-density steps per trip, their twelve loads in flight together
+        float dv[4], am[4], lv[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int k = kb + 64 * u + lane;
             dv[u]       = k < Kpad ? row[k] : __builtin_inff();
             am[u]       = k < Kpad ? g_amin_all[k] : __builtin_inff();
+            lv[u]       = k < K ? g_ln32[k] : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -164,12 +177,24 @@ __global__ __launch_bounds__(64) void tied_list_kernel(const float* __restrict__
                 const int pos = n + __popcll(mask & ((1ull << lane) - 1ull));
                 lk[pos]       = (uint32_t)k;
                 ld[pos]       = dv[u];
+                ll[pos]       = lv[u];  // logNorm (an f32 value) travels with the entry
             }
             n += __popcll(mask);
         }
     }
     if (lane == 0)
         g_ln[t] = n;
+}
+
+// tab[(row_off + lane_off) bytes] as the (scalar base, 32-bit lane offset) form of global_load: row_off is wave-uniform, so the row
+// address is scalar arithmetic and no 64-bit address per lane exists.  The two empty asm statements keep the compiler from
+// re-associating the sum into (tab + lane_off) + row_off, which it otherwise hoists and pays for with a 64-bit vector add per load.
+__device__ __forceinline__ float tied_load(const float* tab, uint32_t row_off, uint32_t lane_off) {
+    typedef const __attribute__((address_space(1))) char* gptr;
+    gptr row = (gptr)tab + row_off;
+    asm("" : "+s"(row));
+    asm("" : "+v"(lane_off));
+    return *(const __attribute__((address_space(1))) float*)(row + lane_off);
 }
 
 struct TiedMax {  // MaxState of gmm.hip (the reference's rule), restated here to keep this file self-contained
@@ -186,37 +211,66 @@ struct TiedMax {  // MaxState of gmm.hip (the reference's rule), restated here t
     }
 };
 
-// One wave per (64-mixture tile, frame).  Phase 1 (lane = list entry) applies the tile's test to the frame's list and compacts
-// the survivors -- position, distance, log-normalisation term -- into LDS; phase 2 (lane = mixture) runs the f64 rule over them
-// in ascending order with PF rows of the weight table in flight.
-constexpr int kTiedSeg = 256;  // survivors buffered per wave; a fuller list is worked off and the scan resumes
+constexpr int kTiedCand = 8;    // candidates a lane keeps from the screening pass; more: the wave takes the unscreened path
+constexpr int kTiedSeg  = 256;  // survivors the unscreened path buffers per wave; a fuller list is worked off and the scan resumes
+constexpr int kTiedCap  = 256;  // entries of a (frame, tile) survivor list in LDS; a longer one takes the unscreened path
 
-__global__ __launch_bounds__(256) void tied_pruned_kernel(const uint32_t* __restrict__ g_lk, const float* __restrict__ g_ld,
-                                                         const int* __restrict__ g_ln, const float* __restrict__ g_amin,
-                                                         const float* __restrict__ g_thr, const float* __restrict__ g_m2lw_t,
-                                                         const double* __restrict__ g_ln64, int Kpad, int T, int n_mix, int mix_pad,
-                                                         int n_tiles, float* __restrict__ g_scores, uint32_t* __restrict__ g_best,
-                                                         unsigned long long* __restrict__ g_survivors) {
-    __shared__ uint32_t s_k[4][kTiedSeg];
-    __shared__ float    s_d[4][kTiedSeg];
-    __shared__ double   s_l[4][kTiedSeg];
-    const int           lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // Workgroup b runs on XCD b % 8 (each XCD has its own L2).  A row of the weight table is wanted by ~3 of a 256-frame batch's
-    // frames, so all frame groups of one tile go to ONE XCD, back to back: tile = 8 * (slot / n_fg) + xcd, frame group = slot % n_fg.
-    // The tile's 1 MB slice of the table then comes from HBM once instead of once per frame that wants it.
-    const int n_fg = (T + 3) / 4, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int tile = (slot / n_fg) * 8 + xcd, t = (slot % n_fg) * 4 + wave;
-    if (tile >= n_tiles || t >= T)
-        return;
-    const int       m    = tile * 64 + lane;
-    const float     Thr  = g_thr[(size_t)t * n_tiles + tile];
-    const float*    arow = g_amin + (size_t)tile * Kpad;
+// Per (frame, 64 list entries, tile): the 64-bit mask of the entries that pass the TILE's test.  lane = tile, so the test reads the
+// transposed table amin_t[k][tile] -- one coalesced row per list entry for 64 tiles -- where a wave of tied_pruned_kernel would gather
+// 4 bytes per entry for ONE tile (a scattered 64-lane gather costs the CU 150 cycles, tools/gather_probe.hip).  Wave w of a
+// workgroup takes the chunks c = w, w + 4, ...; the list entry sits in lane registers, the entry under test is a v_readlane scalar.
+// masks [T][Kpad / 64][tiles_pad].
+__global__ __launch_bounds__(256) void tied_mask_kernel(const uint32_t* __restrict__ g_lk, const float* __restrict__ g_ld,
+                                                       const int* __restrict__ g_ln, const float* __restrict__ g_amin_t,
+                                                       const float* __restrict__ g_thr, int Kpad, int n_tiles, int tiles_pad,
+                                                       unsigned long long* __restrict__ g_mask) {
+    const int       lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int       t = blockIdx.y, tile = blockIdx.x * 64 + lane;
+    const bool      live = tile < n_tiles;
+    const float     Thr  = live ? g_thr[(size_t)t * n_tiles + tile] : -__builtin_inff();
+    const int       nl   = g_ln[t];
     const uint32_t* lk   = g_lk + (size_t)t * Kpad;
     const float*    ld   = g_ld + (size_t)t * Kpad;
-    const int       nl   = g_ln[t];
-    TiedMax         st;
-    int             total = 0;
-    int             ib    = 0;
+    const uint32_t  row_bytes = (uint32_t)tiles_pad * 4u, lane_off = (uint32_t)tile * 4u;
+    constexpr int   PS = 16;
+    for (int c = wave; 64 * c < nl; c += 4) {
+        const int          e  = 64 * c + lane;
+        const uint32_t     rk = e < nl ? lk[e] : 0u;
+        const float        rd = e < nl ? ld[e] : __builtin_nanf("");  // NaN: never passes
+        const int          ne = min(64, nl - 64 * c);
+        unsigned long long mask = 0;
+        for (int jb = 0; jb < ne; jb += PS) {
+            float a[PS];
+#pragma unroll
+            for (int u = 0; u < PS; ++u)
+                a[u] = tied_load(g_amin_t, (uint32_t)__builtin_amdgcn_readlane((int)rk, jb + u) * row_bytes, lane_off);
+#pragma unroll
+            for (int u = 0; u < PS; ++u) {
+                const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rd), jb + u));
+                if (live && (a[u] + d) <= Thr)
+                    mask |= 1ull << (jb + u);
+            }
+        }
+        g_mask[((size_t)t * (Kpad / 64) + c) * tiles_pad + tile] = mask;
+    }
+}
+
+// The unscreened path of tied_pruned_kernel: the tile's test over the frame's list and the reference's f64 rule over EVERY survivor
+// for all 64 mixtures.  Phase 1 (lane = list entry) compacts the survivors -- position, distance, log-normalisation term -- into
+// LDS; phase 2 (lane = mixture) runs the rule over them in ascending order with PF rows of the weight table in flight.
+struct TiedLds {
+    uint32_t k[1][kTiedSeg];
+    float    d[1][kTiedSeg];
+    double   l[1][kTiedSeg];
+};
+struct TiedList {  // the (frame, tile) survivor list of tied_pruned_kernel: row offset in the weight table, distance, logNorm, density
+    uint32_t rk[kTiedCap], d[kTiedCap], l[kTiedCap], k[kTiedCap];
+};
+
+__device__ __forceinline__ void tied_unscreened(TiedLds& lds, int wave, int lane, const uint32_t* __restrict__ lk, const float* __restrict__ ld,
+                                                int nl, const float* __restrict__ arow, float Thr, const float* __restrict__ g_m2lw_t,
+                                                const double* __restrict__ g_ln64, int mix_pad, int m, TiedMax& st) {
+    int ib = 0;
     while (ib < nl) {
         // ---- phase 1
         int n = 0;
@@ -242,32 +296,188 @@ __global__ __launch_bounds__(256) void tied_pruned_kernel(const uint32_t* __rest
                 const bool               rel  = in[u] && (am[u] + dv[u]) <= Thr;
                 const unsigned long long mask = __ballot(rel);
                 if (rel) {
-                    const int pos  = n + __popcll(mask & ((1ull << lane) - 1ull));
-                    s_k[wave][pos] = k[u];
-                    s_d[wave][pos] = dv[u];
-                    s_l[wave][pos] = ln[u];
+                    const int pos    = n + __popcll(mask & ((1ull << lane) - 1ull));
+                    lds.k[wave][pos] = k[u];
+                    lds.d[wave][pos] = dv[u];
+                    lds.l[wave][pos] = ln[u];
                 }
                 n += __popcll(mask);
             }
         }
-        total += n;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         // ---- phase 2
-        constexpr int PF = 16;
+        constexpr int PF = 8;
         for (int i = 0; i < n; i += PF) {
             float w[PF];
 #pragma unroll
             for (int j = 0; j < PF; ++j) {
                 const int ii = i + j < n ? i + j : n - 1;
-                w[j]         = g_m2lw_t[(size_t)s_k[wave][ii] * mix_pad + m];
+                w[j]         = g_m2lw_t[(size_t)lds.k[wave][ii] * mix_pad + m];
             }
 #pragma unroll
             for (int j = 0; j < PF; ++j)
                 if (i + j < n)
-                    st.add((double)w[j] + s_l[wave][i + j], s_d[wave][i + j], s_k[wave][i + j]);
+                    st.add((double)w[j] + lds.l[wave][i + j], lds.d[wave][i + j], lds.k[wave][i + j]);
         }
         __builtin_amdgcn_wave_barrier();  // the lists are rewritten by the next segment
+    }
+}
+
+// tab[byte_off] with a scalar table address and a 32-bit byte offset per lane
+__device__ __forceinline__ float tied_load_v(const float* tab, uint32_t byte_off) {
+    typedef const __attribute__((address_space(1))) char* gptr;
+    gptr base = (gptr)tab;
+    asm("" : "+s"(base));
+    asm("" : "+v"(byte_off));
+    return *(const __attribute__((address_space(1))) float*)(base + byte_off);
+}
+
+// One wave (= one workgroup: no wave waits for its neighbours' lists) per (64-mixture tile, frame).
+// Phase 1 (lane = list entry): the tile's masks (tied_mask_kernel) compact the frame's list into LDS -- weight-table row offset,
+// distance, logNorm, density -- in list order.
+// Phase 2 (lane = mixture): a survivor of the TILE's test is a candidate for one or two of the tile's 64 mixtures, so the lane first
+// screens its OWN mixture in f32 with the threshold the bound kernel derived for it: s^ = fl32(a^[k][m] + dist) <= U[t][m] + tau'
+// holds for every candidate of mixture m (file header).  The list positions that pass -- one bit per position and lane -- are again
+// a subsequence with every candidate in it, and only those go through the reference's f64 rule, in list order (phase 3).
+//
+// The kernel is bound by the NUMBER of instructions a wave issues (a wave issues one per 4 cycles whatever the unit; with 40 waves
+// per SIMD the row gather itself is a quarter of the time), so the loop is built to need few:
+//   * 32 consecutive entries of a list field sit in one register (lane l and lane l + 32: entry l); the entry under test reaches all
+//     lanes by ds_swizzle BROADCAST -- an LDS-crossbar instruction, no scalar round trip (v_readlane + s_add + s_addc per row) --
+//     and the hit is shifted into the mask by ONE v_addc (mask + mask + carry): 8 instructions per survivor, where position lists
+//     and scalar row addresses took 18.
+//   * a^ = fl32(weight + logNorm) is what the a^ table holds, bit for bit; the loop reads the WEIGHT table and adds, so the kernel
+//     stays on one 164 MB table and the candidates' weights (fetched again in phase 3, one 64-byte sector per lane and candidate)
+//     are L2 hits.
+// A list longer than kTiedCap or a table beyond 32-bit offsets takes tied_unscreened.
+__global__ __launch_bounds__(64) void tied_pruned_kernel(const unsigned long long* __restrict__ g_mask, const uint32_t* __restrict__ g_lk,
+                                                        const float* __restrict__ g_ld, const float* __restrict__ g_ll,
+                                                        const int* __restrict__ g_ln, const float* __restrict__ g_amin,
+                                                        const float* __restrict__ g_thr, const float* __restrict__ g_m2lw_t,
+                                                        const float* __restrict__ g_thr_m, const double* __restrict__ g_ln64, int Kpad, int T,
+                                                        int n_mix, int mix_pad, int n_tiles, int tiles_pad, float* __restrict__ g_scores,
+                                                        uint32_t* __restrict__ g_best, unsigned long long* __restrict__ g_survivors) {
+    __shared__ union {
+        TiedLds  u;
+        TiedList s;
+    } lds;
+    const int lane = threadIdx.x, h = lane & 31;
+    // Workgroup b runs on XCD b % 8 (each XCD has its own L2).  A row of the weight table is wanted by ~3 of a 256-frame batch's
+    // frames, so all frames of one tile go to ONE XCD, back to back: tile = 8 * (slot / T) + xcd, frame = slot % T.  The tile's
+    // 1 MB slice of the table then comes from HBM once instead of once per frame that wants it.
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int tile = (slot / T) * 8 + xcd, t = slot % T;
+    if (tile >= n_tiles)
+        return;
+    const int       m      = tile * 64 + lane;
+    const int       nl     = g_ln[t];
+    const float     thr_m  = g_thr_m[(size_t)t * mix_pad + m];
+    const bool      narrow = (unsigned long long)Kpad * mix_pad * 4ull < (1ull << 32);  // table offsets fit 32 bits
+    const uint32_t  m_off  = (uint32_t)m * 4u, row_bytes = (uint32_t)mix_pad * 4u;
+    const uint32_t* lk     = g_lk + (size_t)t * Kpad;
+    const float*    ld     = g_ld + (size_t)t * Kpad;
+    const float*    ll     = g_ll + (size_t)t * Kpad;
+    constexpr int   NW     = kTiedCap / 32;  // 32-entry words of a list
+    // ---- phase 1
+    int n = 0;
+    for (int c = 0; 64 * c < nl; ++c) {
+        const unsigned long long mask = g_mask[((size_t)t * (Kpad / 64) + c) * tiles_pad + tile];  // wave-uniform
+        const int                e    = 64 * c + lane;  // < Kpad; the mask is clear past the list's end
+        const uint32_t           k    = lk[e];
+        const float              d    = ld[e], l = ll[e];
+        const int                pos  = n + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+        if (((mask >> lane) & 1ull) && pos < kTiedCap) {
+            lds.s.rk[pos] = k * row_bytes;
+            lds.s.d[pos]  = __float_as_uint(d);
+            lds.s.l[pos]  = __float_as_uint(l);
+            lds.s.k[pos]  = k;
+        }
+        n += __popcll(mask);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    TiedMax st;
+    if (narrow && n <= kTiedCap) {
+        // ---- phase 2
+        uint32_t hit[NW];  // bit 31 - j of hit[w]: list position 32 w + j
+#pragma unroll
+        for (int w = 0; w < NW; ++w)
+            hit[w] = 0u;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            if (32 * w >= n)
+                break;
+            const int  e    = 32 * w + h;
+            const bool in   = e < n;
+            const int  e_rk = in ? (int)lds.s.rk[e] : 0;          // row 0 stands in past the end ...
+            const int  e_d  = in ? (int)lds.s.d[e] : 0x7fc00000;  // ... with a NaN distance: never a candidate
+            const int  e_l  = in ? (int)lds.s.l[e] : 0;
+            const bool two  = 32 * w + 16 < n;  // the second 16 entries of the word exist
+            float      a[32];
+            uint32_t   hm = 0u;
+#define AMX_TIED_ROW(J) a[J] = tied_load_v(g_m2lw_t, (uint32_t)__builtin_amdgcn_ds_swizzle(e_rk, (J) << 5) + m_off);
+#define AMX_TIED_TEST(J)                                                                                                      \
+    {                                                                                                                         \
+        const float l_ = __int_as_float(__builtin_amdgcn_ds_swizzle(e_l, (J) << 5));                                          \
+        const float d_ = __int_as_float(__builtin_amdgcn_ds_swizzle(e_d, (J) << 5));                                          \
+        const float s_ = (a[J] + l_) + d_;                                                                                    \
+        asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(hm) : "v"(s_), "v"(thr_m) : "vcc");      \
+    }
+#define AMX_TIED_16(F, B) F(B + 0) F(B + 1) F(B + 2) F(B + 3) F(B + 4) F(B + 5) F(B + 6) F(B + 7) F(B + 8) F(B + 9) F(B + 10) F(B + 11) F(B + 12) F(B + 13) F(B + 14) F(B + 15)
+            AMX_TIED_16(AMX_TIED_ROW, 0)
+            if (two) {
+                AMX_TIED_16(AMX_TIED_ROW, 16)
+            }
+            AMX_TIED_16(AMX_TIED_TEST, 0)
+            if (two) {
+                AMX_TIED_16(AMX_TIED_TEST, 16)
+            }
+            else
+                hm <<= 16;
+#undef AMX_TIED_16
+#undef AMX_TIED_ROW
+#undef AMX_TIED_TEST
+            hit[w] = hm;
+        }
+#if AMX_TIED_EXP & 4
+        {
+            int cnt = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w)
+                cnt += __popc(hit[w]);
+            if (m < n_mix)
+                atomicAdd(&g_tied_hist[min(cnt, 31)], 1ull);
+            if (lane == 0)
+                atomicAdd(&g_tied_hist[32 + min(n / 8, 31)], 1ull);
+        }
+#endif
+        // ---- phase 3: every pass takes each lane's first remaining position (entry from LDS, the lane's own weight from the table)
+        // through the reference's rule.  One or two passes for most waves; a lane whose threshold is infinite walks its whole list.
+        for (;;) {
+            int ii = -1;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                if (32 * w >= n)
+                    break;
+                if (ii < 0 && hit[w] != 0u) {
+                    const int b = __builtin_clz(hit[w]);
+                    ii          = 32 * w + b;
+                    hit[w] &= ~(0x80000000u >> b);
+                }
+            }
+            if (!__any(ii >= 0))
+                break;
+            if (ii >= 0) {
+                const float w = tied_load_v(g_m2lw_t, lds.s.rk[ii] + m_off);
+                st.add((double)w + (double)__uint_as_float(lds.s.l[ii]), __uint_as_float(lds.s.d[ii]), lds.s.k[ii]);
+            }
+        }
+    }
+    else {
+        __builtin_amdgcn_wave_barrier();
+        tied_unscreened(lds.u, 0, lane, lk, ld, nl, g_amin + (size_t)tile * Kpad, g_thr[(size_t)t * n_tiles + tile], g_m2lw_t, g_ln64, mix_pad,
+                        m, st);
     }
     if (m < n_mix) {
         g_scores[(size_t)t * n_mix + m] = 0.5f * st.best;
@@ -277,13 +487,13 @@ __global__ __launch_bounds__(256) void tied_pruned_kernel(const uint32_t* __rest
     // statistics for the host's dense / pruned decision: spread over kTiedCounters addresses (40 000 atomics on ONE address cost
     // 0.37 ms, more than the rest of this kernel)
     if (lane == 0 && g_survivors)
-        atomicAdd(g_survivors + ((tile * 7 + t) & (kTiedCounters - 1)), (unsigned long long)total);
+        atomicAdd(g_survivors + ((tile * 7 + t) & (kTiedCounters - 1)), (unsigned long long)n);
 }
 
 }  // namespace amx
 
 // amin[tile][k] = min over the real mixtures of the tile of a^[k][m]; aminG[k] = min over the tiles.  Returns one device table
-// [(n_tiles + 1)][Kpad] (+inf padded), row n_tiles = aminG.
+// [(n_tiles + 1)][Kpad] (+inf padded), row n_tiles = aminG, followed by amin transposed, [Kpad][tiles_pad].
 // bf16 that is >= the f32 value (NaN / inf pass through; +0 for the padding columns)
 static unsigned short tied_bf16_up(float v) {
     uint32_t u;
@@ -313,6 +523,13 @@ extern "C" int amx_internal_gmm_tied_create(int K, int n_mix, int mix_pad, const
             float& g      = amin[(size_t)n_tiles * Kpad + k];
             g             = a < g ? a : g;
         }
+    // the same numbers transposed, [Kpad][tiles_pad] (+inf padded), behind them: tied_tile_list_kernel tests 64 tiles per load
+    const int    tiles_pad = (n_tiles + 63) & ~63;
+    const size_t t0        = amin.size();
+    amin.resize(t0 + (size_t)Kpad * tiles_pad, __builtin_inff());
+    for (int j = 0; j < n_tiles; ++j)
+        for (int k = 0; k < K; ++k)
+            amin[t0 + (size_t)k * tiles_pad + j] = amin[(size_t)j * Kpad + k];
     *d_amin = nullptr;
     AMX_HIP(hipMalloc((void**)d_amin, amin.size() * sizeof(float)));
     AMX_HIP(hipMemcpy(*d_amin, amin.data(), amin.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -320,27 +537,36 @@ extern "C" int amx_internal_gmm_tied_create(int K, int n_mix, int mix_pad, const
 }
 
 namespace {
+constexpr int kTiedFrames = 4096;  // frames per pass of amx_internal_gmm_tied_score: bounds the workspace
 struct TiedWs {
-    float *   dt, *ld, *thr;
-    uint32_t* lk;
-    int*      ln;
-    size_t    bytes;
+    float *             dt, *ld, *ll, *thr, *thr_m;
+    uint32_t*           lk;
+    int*                ln;
+    unsigned long long* mask;
+    size_t              bytes;
 };
 TiedWs tied_ws(void* base, int K, int T, int mix_pad) {
-    const size_t Kpad = (size_t)((K + 63) & ~63), n_tiles = (size_t)mix_pad / 64;
+    const size_t Kpad = (size_t)((K + 63) & ~63), n_tiles = (size_t)mix_pad / 64, tiles_pad = (n_tiles + 63) & ~(size_t)63;
     auto         al = [](size_t b) { return (b + 255) & ~(size_t)255; };
     char*        p  = (char*)base;
     TiedWs       w;
+    T    = std::min(T, kTiedFrames);
     w.dt = (float*)p;
     p += al((size_t)T * Kpad * 4);
     w.lk = (uint32_t*)p;
     p += al((size_t)T * Kpad * 4);
     w.ld = (float*)p;
     p += al((size_t)T * Kpad * 4);
+    w.ll = (float*)p;
+    p += al((size_t)T * Kpad * 4);
     w.ln = (int*)p;
     p += al((size_t)T * 4);
     w.thr = (float*)p;
     p += al((size_t)T * n_tiles * 4);
+    w.thr_m = (float*)p;
+    p += al((size_t)T * mix_pad * 4);
+    w.mask = (unsigned long long*)p;
+    p += al((size_t)T * (Kpad / 64) * tiles_pad * 8);
     w.bytes = (size_t)(p - (char*)base);
     return w;
 }
@@ -351,22 +577,45 @@ extern "C" size_t amx_internal_gmm_tied_workspace(int K, int T, int mix_pad) {
 }
 
 extern "C" int amx_internal_gmm_tied_score(amx_ctx* ctx, const float* dist_dev, const uint32_t* k_dens_dev, int K, int T, int Tpad, int n_mix,
-                                           int mix_pad, const unsigned short* aup, const float* amax, const float* m2lw_t, const double* ln64,
-                                           const float* amin, void* workspace, float* scores, uint32_t* best,
-                                           unsigned long long* survivors_dev) {
+                                           int mix_pad, const unsigned short* aup, const float* amax, const float* m2lw_t, const float* ahat_t,
+                                           const double* ln64, const float* ln32, const float* amin, void* workspace, float* scores,
+                                           uint32_t* best, unsigned long long* survivors_dev) {
     if (T <= 0)
         return AMX_OK;
-    const int    Kpad = (K + 63) & ~63, n_tiles = mix_pad / 64;
+    const int    Kpad = (K + 63) & ~63, n_tiles = mix_pad / 64, tiles_pad = (n_tiles + 63) & ~63;
     const TiedWs w    = tied_ws(workspace, K, T, mix_pad);
-    hipLaunchKernelGGL(amx::tied_transpose_kernel, dim3(Kpad / 64, (T + 63) / 64), dim3(256), 0, ctx->stream, dist_dev, k_dens_dev, K, Kpad, T,
-                       Tpad, w.dt);
-    hipLaunchKernelGGL(amx::tied_bound_kernel, dim3((mix_pad + amx::kTiedBoundThreads - 1) / amx::kTiedBoundThreads, T), dim3(amx::kTiedBoundThreads), 0, ctx->stream, aup, amax, w.dt, K, Kpad, n_mix,
-                       mix_pad, n_tiles, w.thr);
-    hipLaunchKernelGGL(amx::tied_list_kernel, dim3(T), dim3(64), 0, ctx->stream, w.dt, amin + (size_t)n_tiles * Kpad, w.thr, K, Kpad, n_tiles,
-                       w.lk, w.ld, w.ln, survivors_dev ? survivors_dev + amx::kTiedCounters : nullptr,
-                       (unsigned long long)K * (unsigned long long)T * (unsigned long long)n_tiles);
-    hipLaunchKernelGGL(amx::tied_pruned_kernel, dim3(8 * ((n_tiles + 7) / 8) * ((T + 3) / 4)), dim3(256), 0, ctx->stream, w.lk, w.ld, w.ln, amin, w.thr, m2lw_t,
-                       ln64, Kpad, T, n_mix, mix_pad, n_tiles, scores, best, survivors_dev);
+    const float* amin_t = amin + (size_t)(n_tiles + 1) * Kpad;
+    for (int t0 = 0; t0 < T; t0 += kTiedFrames) {  // dist is [n_dens][Tpad]: a pass is a column range
+        const int Tc = std::min(kTiedFrames, T - t0);
+        float*    sc = scores + (size_t)t0 * n_mix;
+        uint32_t* bd = best ? best + (size_t)t0 * n_mix : nullptr;
+        hipLaunchKernelGGL(amx::tied_transpose_kernel, dim3(Kpad / 64, (Tc + 63) / 64), dim3(256), 0, ctx->stream, dist_dev + t0, k_dens_dev, K,
+                           Kpad, Tc, Tpad - t0, Tpad, w.dt);
+        hipLaunchKernelGGL(amx::tied_bound_kernel, dim3((mix_pad + amx::kTiedBoundThreads - 1) / amx::kTiedBoundThreads, Tc),
+                           dim3(amx::kTiedBoundThreads), 0, ctx->stream, aup, amax, w.dt, K, Kpad, n_mix, mix_pad, n_tiles, w.thr, w.thr_m);
+        hipLaunchKernelGGL(amx::tied_list_kernel, dim3(Tc), dim3(64), 0, ctx->stream, w.dt, amin + (size_t)n_tiles * Kpad, w.thr, ln32, K, Kpad,
+                           n_tiles, w.lk, w.ld, w.ll, w.ln, survivors_dev ? survivors_dev + amx::kTiedCounters : nullptr,
+                           (unsigned long long)K * (unsigned long long)Tc * (unsigned long long)n_tiles);
+        hipLaunchKernelGGL(amx::tied_mask_kernel, dim3(tiles_pad / 64, Tc), dim3(256), 0, ctx->stream, w.lk, w.ld, w.ln, amin_t, w.thr, Kpad,
+                           n_tiles, tiles_pad, w.mask);
+        hipLaunchKernelGGL(amx::tied_pruned_kernel, dim3(8 * ((n_tiles + 7) / 8) * Tc), dim3(64), 0, ctx->stream, w.mask, w.lk, w.ld, w.ll, w.ln,
+                           amin, w.thr, m2lw_t, w.thr_m, ln64, Kpad, Tc, n_mix, mix_pad, n_tiles, tiles_pad, sc, bd, survivors_dev);
+    }
     AMX_HIP(hipGetLastError());
+#if AMX_TIED_EXP & 4
+    static int calls = 0;
+    if (++calls == 20) {
+        unsigned long long h[64];
+        hipStreamSynchronize(ctx->stream);
+        hipMemcpyFromSymbol(h, HIP_SYMBOL(amx::g_tied_hist), sizeof h);
+        fprintf(stderr, "tied candidates per lane:");
+        for (int i = 0; i < 32; ++i)
+            fprintf(stderr, " %llu", h[i]);
+        fprintf(stderr, "\ntied survivors/8 per wave:");
+        for (int i = 32; i < 64; ++i)
+            fprintf(stderr, " %llu", h[i]);
+        fprintf(stderr, "\n");
+    }
+#endif
     return AMX_OK;
 }

@@ -8,7 +8,7 @@ shift
 cd /tmp && export TMPDIR=/tmp
 out=/tmp/pmc_$tag
 rm -rf $out
-rocprofv3 --kernel-trace --pmc "${ctrs[@]}" --output-format csv -d $out -- "$@" > /tmp/pmc_$tag.log 2>&1
+timeout ${PMC_TIMEOUT:-180} rocprofv3 --kernel-trace --pmc "${ctrs[@]}" --output-format csv -d $out -- "$@" > /tmp/pmc_$tag.log 2>&1
 tail -5 /tmp/pmc_$tag.log > $GRAFT_REPO_ROOT/gpurun_out/pmc_$tag.log
 f=$(find $out -name "*counter_collection.csv" | head -1)
 python $GRAFT_REPO_ROOT/tools/pmc_summary.py "$f" "${PMC_FILTER:-}" > $GRAFT_REPO_ROOT/gpurun_out/pmc_$tag.txt 2>&1
