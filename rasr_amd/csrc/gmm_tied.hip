@@ -136,31 +136,46 @@ __global__ __launch_bounds__(kTiedBoundThreads) void tied_bound_kernel(const uns
         g_thr[(size_t)t * n_tiles + tile] = thr;
 }
 
-// One wave per frame: ThrG = max over the tiles, then the densities with fl32(aminG[k] + dist) <= ThrG, ascending, with their
-// distances and log-normalisation terms.  lk / ld / ll [T][Kpad], ln [T].
-__global__ __launch_bounds__(64) void tied_list_kernel(const float* __restrict__ g_dt, const float* __restrict__ g_amin_all,
-                                                      const float* __restrict__ g_thr, const float* __restrict__ g_ln32, int K, int Kpad,
-                                                      int n_tiles, uint32_t* __restrict__ g_lk, float* __restrict__ g_ld,
-                                                      float* __restrict__ g_ll, int* __restrict__ g_ln,
-                                                      unsigned long long* __restrict__ g_examined, unsigned long long examined) {
-    const int t = blockIdx.x, lane = threadIdx.x;
+// One workgroup of 16 waves per frame: ThrG = max over the tiles, then the densities with fl32(aminG[k] + dist) <= ThrG, ascending,
+// with their distances and log-normalisation terms.  Wave w tests densities [256 w, 256 w + 256) of every 4096 (one trip to memory:
+// the frame's whole list is a handful of trips deep, not K / 256), the waves' counts meet in LDS, and each wave appends behind the
+// waves before it.  lk / ld / ll [T][Kpad], ln [T].
+constexpr int kTiedListWaves = 16;
+
+__global__ __launch_bounds__(64 * kTiedListWaves) void tied_list_kernel(const float* __restrict__ g_dt, const float* __restrict__ g_amin_all,
+                                                                       const float* __restrict__ g_thr, const float* __restrict__ g_ln32, int K,
+                                                                       int Kpad, int n_tiles, uint32_t* __restrict__ g_lk,
+                                                                       float* __restrict__ g_ld, float* __restrict__ g_ll, int* __restrict__ g_ln,
+                                                                       unsigned long long* __restrict__ g_examined, unsigned long long examined) {
+    constexpr int    NWV = kTiedListWaves;
+    __shared__ float s_thr[NWV];
+    __shared__ int   s_cnt[NWV];
+    const int        t = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // the denominator of the survivor statistic travels with the numerator (the host reads both from ONE asynchronous copy: counting
     // the submitted triples on the host instead made the ratio wrong whenever the host ran ahead of the device)
-    if (g_examined && t == 0 && lane == 0)
+    if (g_examined && t == 0 && threadIdx.x == 0)
         atomicAdd(g_examined, examined);
-    float     thr = -__builtin_inff();
-    for (int j = lane; j < n_tiles; j += 64)
+    float thr = -__builtin_inff();
+    for (int j = threadIdx.x; j < n_tiles; j += 64 * NWV)
         thr = fmaxf(thr, g_thr[(size_t)t * n_tiles + j]);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1)
         thr = fmaxf(thr, __shfl_xor(thr, o));
-    const float* row = g_dt + (size_t)t * Kpad;
-    uint32_t*    lk  = g_lk + (size_t)t * Kpad;
-    float*       ld  = g_ld + (size_t)t * Kpad;
-    float*       ll  = g_ll + (size_t)t * Kpad;
-    int          n   = 0;
-    for (int kb = 0; kb < Kpad; kb += 256) {  // four 64-density steps per trip, their twelve loads in flight together
-        float dv[4], am[4], lv[4];
+    if (lane == 0)
+        s_thr[wave] = thr;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < NWV; ++w)
+        thr = fmaxf(thr, s_thr[w]);
+    const float* row  = g_dt + (size_t)t * Kpad;
+    uint32_t*    lk   = g_lk + (size_t)t * Kpad;
+    float*       ld   = g_ld + (size_t)t * Kpad;
+    float*       ll   = g_ll + (size_t)t * Kpad;
+    int          base = 0;
+    for (int r0 = 0; r0 < Kpad; r0 += 256 * NWV) {
+        const int          kb = r0 + 256 * wave;
+        float              dv[4], am[4], lv[4];
+        unsigned long long mask[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int k = kb + 64 * u + lane;
@@ -168,22 +183,37 @@ __global__ __launch_bounds__(64) void tied_list_kernel(const float* __restrict__
             am[u]       = k < Kpad ? g_amin_all[k] : __builtin_inff();
             lv[u]       = k < K ? g_ln32[k] : 0.f;
         }
+        int cnt = 0;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int                k    = kb + 64 * u + lane;
-            const bool               rel  = k < K && (am[u] + dv[u]) <= thr;  // k < K: +inf <= thr when the threshold is +inf itself
-            const unsigned long long mask = __ballot(rel);
-            if (rel) {
-                const int pos = n + __popcll(mask & ((1ull << lane) - 1ull));
-                lk[pos]       = (uint32_t)k;
-                ld[pos]       = dv[u];
-                ll[pos]       = lv[u];  // logNorm (an f32 value) travels with the entry
+            const int k = kb + 64 * u + lane;
+            mask[u]     = __ballot(k < K && (am[u] + dv[u]) <= thr);  // k < K: +inf <= thr when the threshold is +inf itself
+            cnt += __popcll(mask[u]);
+        }
+        if (lane == 0)
+            s_cnt[wave] = cnt;
+        __syncthreads();
+        int pos = base;
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) {
+            const int c = s_cnt[w];
+            pos += w < wave ? c : 0;
+            base += c;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if ((mask[u] >> lane) & 1ull) {
+                const int p = pos + __popcll(mask[u] & ((1ull << lane) - 1ull));
+                lk[p]       = (uint32_t)(kb + 64 * u + lane);
+                ld[p]       = dv[u];
+                ll[p]       = lv[u];  // logNorm (an f32 value) travels with the entry
             }
-            n += __popcll(mask);
+            pos += __popcll(mask[u]);
         }
     }
-    if (lane == 0)
-        g_ln[t] = n;
+    if (threadIdx.x == 0)
+        g_ln[t] = base;
 }
 
 // tab[(row_off + lane_off) bytes] as the (scalar base, 32-bit lane offset) form of global_load: row_off is wave-uniform, so the row
@@ -217,13 +247,16 @@ constexpr int kTiedCap  = 256;  // entries of a (frame, tile) survivor list in L
 
 // Per (frame, 64 list entries, tile): the 64-bit mask of the entries that pass the TILE's test.  lane = tile, so the test reads the
 // transposed table amin_t[k][tile] -- one coalesced row per list entry for 64 tiles -- where a wave of tied_pruned_kernel would gather
-// 4 bytes per entry for ONE tile (a scattered 64-lane gather costs the CU 150 cycles, tools/gather_probe.hip).  Wave w of a
-// workgroup takes the chunks c = w, w + 4, ...; the list entry sits in lane registers, the entry under test is a v_readlane scalar.
-// masks [T][Kpad / 64][tiles_pad].
-__global__ __launch_bounds__(256) void tied_mask_kernel(const uint32_t* __restrict__ g_lk, const float* __restrict__ g_ld,
-                                                       const int* __restrict__ g_ln, const float* __restrict__ g_amin_t,
-                                                       const float* __restrict__ g_thr, int Kpad, int n_tiles, int tiles_pad,
-                                                       unsigned long long* __restrict__ g_mask) {
+// 4 bytes per entry for ONE tile (a scattered 64-lane gather costs the CU 150 cycles, tools/gather_probe.hip).  A wave tests 16
+// entries (one trip to memory: the kernel has 3 x T workgroups, its time is the depth of a wave's chain of loads) and stores its 16
+// bits of the mask; the entries sit in lane registers, the entry under test is a v_readlane scalar.
+// masks [T][Kpad / 64][tiles_pad] of 64 bits = 4 x 16.
+constexpr int kTiedMaskWaves = 16;
+
+__global__ __launch_bounds__(64 * kTiedMaskWaves) void tied_mask_kernel(const uint32_t* __restrict__ g_lk, const float* __restrict__ g_ld,
+                                                                       const int* __restrict__ g_ln, const float* __restrict__ g_amin_t,
+                                                                       const float* __restrict__ g_thr, int Kpad, int n_tiles, int tiles_pad,
+                                                                       unsigned short* __restrict__ g_mask) {
     const int       lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int       t = blockIdx.y, tile = blockIdx.x * 64 + lane;
     const bool      live = tile < n_tiles;
@@ -232,26 +265,22 @@ __global__ __launch_bounds__(256) void tied_mask_kernel(const uint32_t* __restri
     const uint32_t* lk   = g_lk + (size_t)t * Kpad;
     const float*    ld   = g_ld + (size_t)t * Kpad;
     const uint32_t  row_bytes = (uint32_t)tiles_pad * 4u, lane_off = (uint32_t)tile * 4u;
-    constexpr int   PS = 16;
-    for (int c = wave; 64 * c < nl; c += 4) {
-        const int          e  = 64 * c + lane;
-        const uint32_t     rk = e < nl ? lk[e] : 0u;
-        const float        rd = e < nl ? ld[e] : __builtin_nanf("");  // NaN: never passes
-        const int          ne = min(64, nl - 64 * c);
-        unsigned long long mask = 0;
-        for (int jb = 0; jb < ne; jb += PS) {
-            float a[PS];
+    const int       n_groups = 4 * ((nl + 63) / 64);  // whole 64-entry chunks: tied_pruned_kernel reads the masks chunk by chunk
+    for (int g = wave; g < n_groups; g += kTiedMaskWaves) {
+        const int      e  = 16 * g + (lane & 15);
+        const uint32_t rk = e < nl ? lk[e] : 0u;
+        const float    rd = e < nl ? ld[e] : __builtin_nanf("");  // NaN: never passes
+        float          a[16];
+        uint32_t       mask = 0;
 #pragma unroll
-            for (int u = 0; u < PS; ++u)
-                a[u] = tied_load(g_amin_t, (uint32_t)__builtin_amdgcn_readlane((int)rk, jb + u) * row_bytes, lane_off);
+        for (int u = 0; u < 16; ++u)
+            a[u] = tied_load(g_amin_t, (uint32_t)__builtin_amdgcn_readlane((int)rk, u) * row_bytes, lane_off);
 #pragma unroll
-            for (int u = 0; u < PS; ++u) {
-                const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rd), jb + u));
-                if (live && (a[u] + d) <= Thr)
-                    mask |= 1ull << (jb + u);
-            }
+        for (int u = 0; u < 16; ++u) {
+            const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rd), u));
+            mask |= live && (a[u] + d) <= Thr ? 1u << u : 0u;
         }
-        g_mask[((size_t)t * (Kpad / 64) + c) * tiles_pad + tile] = mask;
+        g_mask[(((size_t)t * (Kpad / 64) + (g >> 2)) * tiles_pad + tile) * 4 + (g & 3)] = (unsigned short)mask;
     }
 }
 
@@ -593,11 +622,11 @@ extern "C" int amx_internal_gmm_tied_score(amx_ctx* ctx, const float* dist_dev, 
                            Kpad, Tc, Tpad - t0, Tpad, w.dt);
         hipLaunchKernelGGL(amx::tied_bound_kernel, dim3((mix_pad + amx::kTiedBoundThreads - 1) / amx::kTiedBoundThreads, Tc),
                            dim3(amx::kTiedBoundThreads), 0, ctx->stream, aup, amax, w.dt, K, Kpad, n_mix, mix_pad, n_tiles, w.thr, w.thr_m);
-        hipLaunchKernelGGL(amx::tied_list_kernel, dim3(Tc), dim3(64), 0, ctx->stream, w.dt, amin + (size_t)n_tiles * Kpad, w.thr, ln32, K, Kpad,
+        hipLaunchKernelGGL(amx::tied_list_kernel, dim3(Tc), dim3(64 * amx::kTiedListWaves), 0, ctx->stream, w.dt, amin + (size_t)n_tiles * Kpad, w.thr, ln32, K, Kpad,
                            n_tiles, w.lk, w.ld, w.ll, w.ln, survivors_dev ? survivors_dev + amx::kTiedCounters : nullptr,
                            (unsigned long long)K * (unsigned long long)Tc * (unsigned long long)n_tiles);
-        hipLaunchKernelGGL(amx::tied_mask_kernel, dim3(tiles_pad / 64, Tc), dim3(256), 0, ctx->stream, w.lk, w.ld, w.ln, amin_t, w.thr, Kpad,
-                           n_tiles, tiles_pad, w.mask);
+        hipLaunchKernelGGL(amx::tied_mask_kernel, dim3(tiles_pad / 64, Tc), dim3(64 * amx::kTiedMaskWaves), 0, ctx->stream, w.lk, w.ld, w.ln,
+                           amin_t, w.thr, Kpad, n_tiles, tiles_pad, (unsigned short*)w.mask);
         hipLaunchKernelGGL(amx::tied_pruned_kernel, dim3(8 * ((n_tiles + 7) / 8) * Tc), dim3(64), 0, ctx->stream, w.mask, w.lk, w.ld, w.ll, w.ln,
                            amin, w.thr, m2lw_t, w.thr_m, ln64, Kpad, Tc, n_mix, mix_pad, n_tiles, tiles_pad, sc, bd, survivors_dev);
     }
