@@ -372,10 +372,11 @@ __device__ __forceinline__ float tied_load_v(const float* tab, uint32_t byte_off
 //
 // The kernel is bound by the NUMBER of instructions a wave issues (a wave issues one per 4 cycles whatever the unit; with 40 waves
 // per SIMD the row gather itself is a quarter of the time), so the loop is built to need few:
-//   * 32 consecutive entries of a list field sit in one register (lane l and lane l + 32: entry l); the entry under test reaches all
-//     lanes by ds_swizzle BROADCAST -- an LDS-crossbar instruction, no scalar round trip (v_readlane + s_add + s_addc per row) --
-//     and the hit is shifted into the mask by ONE v_addc (mask + mask + carry): 8 instructions per survivor, where position lists
-//     and scalar row addresses took 18.
+//   * 16 consecutive entries of a list field sit in one register (entry j in lane j of every row of 16 lanes); the entry under test
+//     reaches all lanes as the DPP operand row_newbcast:j of the add that consumes it -- no instruction of its own, where a scalar
+//     round trip costs v_readlane + s_add + s_addc per row -- and the hit is shifted into the mask by ONE v_addc (mask + mask +
+//     carry): 6 instructions per survivor (offset, load, two sums, compare, shift-in), where position lists and scalar row
+//     addresses took 18.
 //   * a^ = fl32(weight + logNorm) is what the a^ table holds, bit for bit; the loop reads the WEIGHT table and adds, so the kernel
 //     stays on one 164 MB table and the candidates' weights (fetched again in phase 3, one 64-byte sector per lane and candidate)
 //     are L2 hits.
@@ -391,7 +392,7 @@ __global__ __launch_bounds__(64) void tied_pruned_kernel(const unsigned long lon
         TiedLds  u;
         TiedList s;
     } lds;
-    const int lane = threadIdx.x, h = lane & 31;
+    const int lane = threadIdx.x;
     // Workgroup b runs on XCD b % 8 (each XCD has its own L2).  A row of the weight table is wanted by ~3 of a 256-frame batch's
     // frames, so all frames of one tile go to ONE XCD, back to back: tile = 8 * (slot / T) + xcd, frame = slot % T.  The tile's
     // 1 MB slice of the table then comes from HBM once instead of once per frame that wants it.
@@ -437,36 +438,46 @@ __global__ __launch_bounds__(64) void tied_pruned_kernel(const unsigned long lon
         for (int w = 0; w < NW; ++w) {
             if (32 * w >= n)
                 break;
-            const int  e    = 32 * w + h;
-            const bool in   = e < n;
-            const int  e_rk = in ? (int)lds.s.rk[e] : 0;          // row 0 stands in past the end ...
-            const int  e_d  = in ? (int)lds.s.d[e] : 0x7fc00000;  // ... with a NaN distance: never a candidate
-            const int  e_l  = in ? (int)lds.s.l[e] : 0;
-            const bool two  = 32 * w + 16 < n;  // the second 16 entries of the word exist
+            // two blocks of 16 entries; entry j of a block sits in lane j of EVERY row of 16 lanes, so that the DPP operand
+            // row_newbcast:j hands it to all lanes inside the add that consumes it
+            const int  e0   = 32 * w + (lane & 15), e1 = e0 + 16;
+            const bool two  = e1 - (lane & 15) < n;  // the second block exists
+            const int  rk0  = e0 < n ? (int)lds.s.rk[e0] : 0;          // row 0 stands in past the end ...
+            const int  d0   = e0 < n ? (int)lds.s.d[e0] : 0x7fc00000;  // ... with a NaN distance: never a candidate
+            const int  l0   = e0 < n ? (int)lds.s.l[e0] : 0;
+            const int  rk1  = e1 < n ? (int)lds.s.rk[e1] : 0;
+            const int  d1   = e1 < n ? (int)lds.s.d[e1] : 0x7fc00000;
+            const int  l1   = e1 < n ? (int)lds.s.l[e1] : 0;
             float      a[32];
             uint32_t   hm = 0u;
-#define AMX_TIED_ROW(J) a[J] = tied_load_v(g_m2lw_t, (uint32_t)__builtin_amdgcn_ds_swizzle(e_rk, (J) << 5) + m_off);
-#define AMX_TIED_TEST(J)                                                                                                      \
+#define AMX_TIED_BC(V, J) __builtin_amdgcn_update_dpp(0, V, 0x150 + (J), 0xf, 0xf, false) /* row_newbcast:J */
+#define AMX_TIED_ROW0(J) a[J] = tied_load_v(g_m2lw_t, (uint32_t)AMX_TIED_BC(rk0, J) + m_off);
+#define AMX_TIED_ROW1(J) a[16 + J] = tied_load_v(g_m2lw_t, (uint32_t)AMX_TIED_BC(rk1, J) + m_off);
+#define AMX_TIED_TEST(A, L, D, J)                                                                                             \
     {                                                                                                                         \
-        const float l_ = __int_as_float(__builtin_amdgcn_ds_swizzle(e_l, (J) << 5));                                          \
-        const float d_ = __int_as_float(__builtin_amdgcn_ds_swizzle(e_d, (J) << 5));                                          \
-        const float s_ = (a[J] + l_) + d_;                                                                                    \
+        const float s_ = (A + __int_as_float(AMX_TIED_BC(L, J))) + __int_as_float(AMX_TIED_BC(D, J));                         \
         asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(hm) : "v"(s_), "v"(thr_m) : "vcc");      \
     }
-#define AMX_TIED_16(F, B) F(B + 0) F(B + 1) F(B + 2) F(B + 3) F(B + 4) F(B + 5) F(B + 6) F(B + 7) F(B + 8) F(B + 9) F(B + 10) F(B + 11) F(B + 12) F(B + 13) F(B + 14) F(B + 15)
-            AMX_TIED_16(AMX_TIED_ROW, 0)
+#define AMX_TIED_TEST0(J) AMX_TIED_TEST(a[J], l0, d0, J)
+#define AMX_TIED_TEST1(J) AMX_TIED_TEST(a[16 + J], l1, d1, J)
+#define AMX_TIED_16(F) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(8) F(9) F(10) F(11) F(12) F(13) F(14) F(15)
+            AMX_TIED_16(AMX_TIED_ROW0)
             if (two) {
-                AMX_TIED_16(AMX_TIED_ROW, 16)
+                AMX_TIED_16(AMX_TIED_ROW1)
             }
-            AMX_TIED_16(AMX_TIED_TEST, 0)
+            AMX_TIED_16(AMX_TIED_TEST0)
             if (two) {
-                AMX_TIED_16(AMX_TIED_TEST, 16)
+                AMX_TIED_16(AMX_TIED_TEST1)
             }
             else
                 hm <<= 16;
 #undef AMX_TIED_16
-#undef AMX_TIED_ROW
+#undef AMX_TIED_TEST1
+#undef AMX_TIED_TEST0
 #undef AMX_TIED_TEST
+#undef AMX_TIED_ROW1
+#undef AMX_TIED_ROW0
+#undef AMX_TIED_BC
             hit[w] = hm;
         }
 #if AMX_TIED_EXP & 4
