@@ -457,7 +457,10 @@ struct GmmDistDims {
     int T, Tpad, dim, n_dens, dens_tile;
 };
 
-template<int DIM>
+// STAGE: the workgroup's 256 frames come in as ONE coalesced run through LDS.  Lane = frame reads feats[t][i] with a stride of dim
+// floats -- 64 separate 64-byte sectors per load instruction, ~150 cycles of the CU's address unit each (tools/gather_probe.hip) --
+// which is noise behind a long density loop but most of the kernel when a small batch is cut into many short workgroups.
+template<int DIM, bool STAGE = false>
 __global__ __launch_bounds__(256) void gmm_dist_kernel(const float* __restrict__ g_feats, float* __restrict__ g_dist, double* __restrict__ g_dist64,
                                                       const uint32_t* __restrict__ g_d_mean, const uint32_t* __restrict__ g_d_cov,
                                                       const float* __restrict__ g_means, const float* __restrict__ g_isr,
@@ -474,7 +477,19 @@ __global__ __launch_bounds__(256) void gmm_dist_kernel(const float* __restrict__
     const int tt   = t < p.T ? t : (p.T - 1);
     float     x[DIM > 0 ? DIM : 1];
     float*    xs = nullptr;
-    if (DIM > 0) {
+    if (DIM > 0 && STAGE) {
+        constexpr int LD   = (DIM > 0 ? DIM : 1) + 1;  // odd row stride: the lanes' reads spread over the banks
+        const int     base = blockIdx.y * 256;
+        for (int e = threadIdx.x; e < 256 * DIM; e += 256) {
+            const int r = e / DIM, i = e - r * DIM;
+            xs_all[r * LD + i] = p.feats[(size_t)min(base + r, p.T - 1) * DIM + i];  // past the end: the last frame, as below
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < DIM; ++i)
+            x[i] = xs_all[(wave * 64 + lane) * LD + i];
+    }
+    else if (DIM > 0) {
 #pragma unroll
         for (int i = 0; i < DIM; ++i)
             x[i] = p.feats[(size_t)tt * DIM + i];
@@ -1761,15 +1776,19 @@ int launch_direct(amx_gmm* h, const amx::GmmParams& p, dim3 grid) {
     return AMX_OK;
 }
 
-int launch_dist(amx_gmm* h, const amx::GmmDistParams& p, dim3 grid, double* dist64) {
+int launch_dist(amx_gmm* h, const amx::GmmDistParams& p, dim3 grid, double* dist64, bool stage) {
     hipStream_t      st  = h->ctx->stream;
     size_t           lds = 0;
     amx::GmmDistDims dims{p.T, p.Tpad, p.dim, p.n_dens, p.dens_tile};
     switch (h->dim) {
-#define AMX_GMM_CASE(D)                                                                      \
-    case D:                                                                                  \
-        hipLaunchKernelGGL((amx::gmm_dist_kernel<D>), grid, dim3(256), 0, st, p.feats, p.dist, dist64, p.d_mean, p.d_cov, p.means, \
-                           p.isr, dims);                                                     \
+#define AMX_GMM_CASE(D)                                                                                                                   \
+    case D:                                                                                                                               \
+        if (stage)                                                                                                                        \
+            hipLaunchKernelGGL((amx::gmm_dist_kernel<D, true>), grid, dim3(256), (size_t)256 * (D + 1) * sizeof(float), st, p.feats, p.dist, \
+                               dist64, p.d_mean, p.d_cov, p.means, p.isr, dims);                                                          \
+        else                                                                                                                              \
+            hipLaunchKernelGGL((amx::gmm_dist_kernel<D>), grid, dim3(256), 0, st, p.feats, p.dist, dist64, p.d_mean, p.d_cov, p.means,     \
+                               p.isr, dims);                                                                                              \
         break;
         AMX_GMM_CASE(16)
         AMX_GMM_CASE(24)
@@ -2434,8 +2453,11 @@ int amx_gmm_score_dev(amx_gmm* h, int mode, const float* feats_dev, int T, float
         dp.Tpad      = Tpad;
         dp.dim       = h->dim;
         dp.n_dens    = h->n_dens;
-        dp.dens_tile = 16;
         const int  fb      = amx::ceil_div(Tc, 256);
+        // densities per workgroup: 16, fewer while that leaves the chip short of workgroups (a 256-frame batch of config 3 is ONE
+        // frame block: 256 workgroups of 16 densities each wait for 16 scalar fetches in a row; 1024 of 4 do not)
+        const bool stage   = (long)amx::ceil_div(h->n_dens, 16) * fb < 4L * std::max(h->ctx->n_cu, 1);
+        dp.dens_tile       = stage ? (int)std::min<long>(16, std::max<long>(2, (long)h->n_dens * fb / (4L * std::max(h->ctx->n_cu, 1)))) : 16;
         const bool use_uni = h->uniform;
         const int screen = getenv("AMX_GMM_SCREEN") ? atoi(getenv("AMX_GMM_SCREEN")) : 1;  // 0: plain f64 kernel (A/B runs, tests)
         const bool need64  = use_uni && mode == AMX_GMM_MAX && !screen;
@@ -2448,7 +2470,7 @@ int amx_gmm_score_dev(amx_gmm* h, int mode, const float* feats_dev, int T, float
         }
         {
             amx::ScopedKernelTimer timer(h->ctx, "gmm_dist");
-            int r = launch_dist(h, dp, dim3(amx::ceil_div(h->n_dens, dp.dens_tile), fb), need64 ? h->d_dist64 : nullptr);
+            int r = launch_dist(h, dp, dim3(amx::ceil_div(h->n_dens, dp.dens_tile), fb), need64 ? h->d_dist64 : nullptr, stage);
             if (r != AMX_OK)
                 return r;
         }
