@@ -66,73 +66,86 @@ __global__ __launch_bounds__(256) void tied_transpose_kernel(const float* __rest
     }
 }
 
-// Thr[t][tile]: thread = mixture, 256 mixtures = 4 tiles per workgroup.  Prologue: the frame's closest density of every residue
-// class k mod 32 (any subset gives a valid bound; this one needs no selection).  U = min over them of fl32(a^ + dist); the tile's
-// threshold is the maximum of U + tau' over its real mixtures.
-// The sums only have to bound the minimum from ABOVE, so the 32 table rows per frame are read from a bf16 image of a^ that was
-// rounded UP (a^_up >= a^, hence fl32(a^_up + dist) >= fl32(a^ + dist)): half the bytes of the kernel's only real traffic, for a
-// bound that is at most 2^-8 |a^| looser.
-constexpr int kTiedBoundThreads = 1024;  // mixtures per workgroup of tied_bound_kernel (the prologue is paid once per workgroup)
+// The frame's closest density of every residue class k mod 32, for tied_bound_kernel (any subset gives a valid bound; this one needs
+// no selection).  One workgroup per frame; nd / nk [T][32].
+constexpr int kTiedNearThreads = 1024;
 
-__global__ __launch_bounds__(kTiedBoundThreads) void tied_bound_kernel(const unsigned short* __restrict__ g_aup, const float* __restrict__ g_amax,
-                                                                      const float* __restrict__ g_dt, int K, int Kpad, int n_mix, int mix_pad,
-                                                                      int n_tiles, float* __restrict__ g_thr, float* __restrict__ g_thr_m) {
-    constexpr int       NT = kTiedBoundThreads;
+__global__ __launch_bounds__(kTiedNearThreads) void tied_near_kernel(const float* __restrict__ g_dt, int K, int Kpad, float* __restrict__ g_nd,
+                                                                    uint32_t* __restrict__ g_nk) {
+    constexpr int       NT = kTiedNearThreads;
     __shared__ float    s_v[NT];
     __shared__ uint32_t s_i[NT];
-    __shared__ float    s_nd[kTiedNear];
-    __shared__ uint32_t s_nk[kTiedNear];
-    const int           t = blockIdx.y, tid = threadIdx.x, m = blockIdx.x * NT + tid;
+    const int           t = blockIdx.x, tid = threadIdx.x;
     const float*        row = g_dt + (size_t)t * Kpad;
-    {
-        float    bv = __builtin_inff();
-        uint32_t bi = 0;
-        for (int k = tid; k < K; k += NT) {  // NT is a multiple of 32: a thread stays inside one residue class
-            const float v = row[k];
-            if (v < bv) {
-                bv = v;
-                bi = (uint32_t)k;
-            }
+    float               bv = __builtin_inff();
+    uint32_t            bi = 0;
+    for (int k = tid; k < K; k += NT) {  // NT is a multiple of 32: a thread stays inside one residue class
+        const float v = row[k];
+        if (v < bv) {
+            bv = v;
+            bi = (uint32_t)k;
         }
-        s_v[tid] = bv;
-        s_i[tid] = bi;
     }
+    s_v[tid] = bv;
+    s_i[tid] = bi;
     __syncthreads();
     if (tid < kTiedNear) {
-        float    bv = s_v[tid];
-        uint32_t bi = s_i[tid];
         for (int j = 1; j < NT / kTiedNear; ++j)
             if (s_v[tid + kTiedNear * j] < bv) {
                 bv = s_v[tid + kTiedNear * j];
                 bi = s_i[tid + kTiedNear * j];
             }
-        s_nd[tid] = bv;  // +inf: empty class, or no finite distance (NaN / inf frame); row 0 stands in, its sum is +inf
-        s_nk[tid] = bi;
+        g_nd[(size_t)t * kTiedNear + tid] = bv;  // +inf: empty class, or no finite distance (NaN / inf frame); row 0 stands in, its sum is +inf
+        g_nk[(size_t)t * kTiedNear + tid] = bi;
     }
-    __syncthreads();
-    float u = FLT_MAX;
-    if (m < mix_pad) {
-        float a[kTiedNear];
+}
+
+// Thr[t][tile] and the mixtures' own thresholds: U = min over the frame's near densities of fl32(a^ + dist); the tile's threshold is
+// the maximum of U + tau' over its real mixtures.
+// The sums only have to bound the minimum from ABOVE, so the 32 table rows per frame are read from a bf16 image of a^ that was
+// rounded UP (a^_up >= a^, hence fl32(a^_up + dist) >= fl32(a^ + dist)): half the bytes of the kernel's only real traffic, for a
+// bound that is at most 2^-8 |a^| looser.
+// A lane takes TWO mixtures (one dword = two bf16 per row): the near densities and their distances are wave-uniform scalars, so a row
+// costs the wave one load, two unpacks, two sums and two minima for 128 mixtures.  64 mixtures = one tile = 32 lanes.
+__global__ __launch_bounds__(256) void tied_bound_kernel(const unsigned short* __restrict__ g_aup, const float* __restrict__ g_amax,
+                                                        const float* __restrict__ g_nd, const uint32_t* __restrict__ g_nk, int n_mix,
+                                                        int mix_pad, int n_tiles, float* __restrict__ g_thr, float* __restrict__ g_thr_m) {
+    const int t = blockIdx.y, lane = threadIdx.x & 63;
+    const int m = 2 * (blockIdx.x * 256 + threadIdx.x);  // mix_pad is a multiple of 64: m + 1 < mix_pad with m
+    if (m >= mix_pad)
+        return;  // whole 32-lane halves leave together (a half = one tile)
+    const float*    nd = g_nd + (size_t)t * kTiedNear;
+    const uint32_t* nk = g_nk + (size_t)t * kTiedNear;
+    uint32_t        v[kTiedNear];
 #pragma unroll
-        for (int i = 0; i < kTiedNear; ++i)  // all rows in flight before the first use
-            a[i] = __uint_as_float((uint32_t)g_aup[(size_t)s_nk[i] * mix_pad + m] << 16);
+    for (int i = 0; i < kTiedNear; ++i)  // all rows in flight before the first use
+        v[i] = *(const uint32_t*)(g_aup + (size_t)nk[i] * mix_pad + m);
+    float u0 = FLT_MAX, u1 = FLT_MAX;
 #pragma unroll
-        for (int i = 0; i < kTiedNear; ++i)
-            u = fminf(u, a[i] + s_nd[i]);
+    for (int i = 0; i < kTiedNear; ++i) {
+        const float d = nd[i];
+        u0            = fminf(u0, __uint_as_float(v[i] << 16) + d);
+        u1            = fminf(u1, __uint_as_float(v[i] & 0xffff0000u) + d);
     }
-    float thr = -__builtin_inff();
+    // tau' = 2^-21 (2 max|a^| + |U|)
+    float thr0 = -__builtin_inff(), thr1 = -__builtin_inff();
     if (m < n_mix) {
-        thr = u + (4.76837158e-7f * (2.f * g_amax[m] + fabsf(u)) + 1e-30f);  // tau' = 2^-21 (2 max|a^| + |U|)
-        if (!(thr == thr))
-            thr = __builtin_inff();
+        thr0 = u0 + (4.76837158e-7f * (2.f * g_amax[m] + fabsf(u0)) + 1e-30f);
+        if (!(thr0 == thr0))
+            thr0 = __builtin_inff();
     }
-    if (m < mix_pad)
-        g_thr_m[(size_t)t * mix_pad + m] = thr;  // the mixture's own threshold: tied_pruned_kernel screens with it (-inf: padding)
+    if (m + 1 < n_mix) {
+        thr1 = u1 + (4.76837158e-7f * (2.f * g_amax[m + 1] + fabsf(u1)) + 1e-30f);
+        if (!(thr1 == thr1))
+            thr1 = __builtin_inff();
+    }
+    *(float2*)(g_thr_m + (size_t)t * mix_pad + m) = make_float2(thr0, thr1);  // the mixtures' own thresholds: tied_pruned_kernel screens with them (-inf: padding)
+    float thr = fmaxf(thr0, thr1);
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
+    for (int o = 16; o > 0; o >>= 1)
         thr = fmaxf(thr, __shfl_xor(thr, o));
     const int tile = m >> 6;
-    if ((tid & 63) == 0 && tile < n_tiles)
+    if ((lane & 31) == 0 && tile < n_tiles)
         g_thr[(size_t)t * n_tiles + tile] = thr;
 }
 
@@ -579,8 +592,8 @@ extern "C" int amx_internal_gmm_tied_create(int K, int n_mix, int mix_pad, const
 namespace {
 constexpr int kTiedFrames = 4096;  // frames per pass of amx_internal_gmm_tied_score: bounds the workspace
 struct TiedWs {
-    float *             dt, *ld, *ll, *thr, *thr_m;
-    uint32_t*           lk;
+    float *             dt, *ld, *ll, *thr, *thr_m, *nd;
+    uint32_t *          lk, *nk;
     int*                ln;
     unsigned long long* mask;
     size_t              bytes;
@@ -605,6 +618,10 @@ TiedWs tied_ws(void* base, int K, int T, int mix_pad) {
     p += al((size_t)T * n_tiles * 4);
     w.thr_m = (float*)p;
     p += al((size_t)T * mix_pad * 4);
+    w.nd = (float*)p;
+    p += al((size_t)T * amx::kTiedNear * 4);
+    w.nk = (uint32_t*)p;
+    p += al((size_t)T * amx::kTiedNear * 4);
     w.mask = (unsigned long long*)p;
     p += al((size_t)T * (Kpad / 64) * tiles_pad * 8);
     w.bytes = (size_t)(p - (char*)base);
@@ -631,8 +648,9 @@ extern "C" int amx_internal_gmm_tied_score(amx_ctx* ctx, const float* dist_dev, 
         uint32_t* bd = best ? best + (size_t)t0 * n_mix : nullptr;
         hipLaunchKernelGGL(amx::tied_transpose_kernel, dim3(Kpad / 64, (Tc + 63) / 64), dim3(256), 0, ctx->stream, dist_dev + t0, k_dens_dev, K,
                            Kpad, Tc, Tpad - t0, Tpad, w.dt);
-        hipLaunchKernelGGL(amx::tied_bound_kernel, dim3((mix_pad + amx::kTiedBoundThreads - 1) / amx::kTiedBoundThreads, Tc),
-                           dim3(amx::kTiedBoundThreads), 0, ctx->stream, aup, amax, w.dt, K, Kpad, n_mix, mix_pad, n_tiles, w.thr, w.thr_m);
+        hipLaunchKernelGGL(amx::tied_near_kernel, dim3(Tc), dim3(amx::kTiedNearThreads), 0, ctx->stream, w.dt, K, Kpad, w.nd, w.nk);
+        hipLaunchKernelGGL(amx::tied_bound_kernel, dim3((mix_pad / 2 + 255) / 256, Tc), dim3(256), 0, ctx->stream, aup, amax, w.nd, w.nk, n_mix,
+                           mix_pad, n_tiles, w.thr, w.thr_m);
         hipLaunchKernelGGL(amx::tied_list_kernel, dim3(Tc), dim3(64 * amx::kTiedListWaves), 0, ctx->stream, w.dt, amin + (size_t)n_tiles * Kpad, w.thr, ln32, K, Kpad,
                            n_tiles, w.lk, w.ld, w.ll, w.ln, survivors_dev ? survivors_dev + amx::kTiedCounters : nullptr,
                            (unsigned long long)K * (unsigned long long)Tc * (unsigned long long)n_tiles);
