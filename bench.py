@@ -617,7 +617,7 @@ class GmmOnly:
                 rows = (self.T * 32.0 * 10048 * 2 + (surv / max(launches, 1.0)) * 256.0 + self.T * 10000 * 8.0 + self.T * 4096 * 12.0)
                 by = self.nk * 4.0 + self.T * 10000 * 8.0 + self.T * 40 * 4.0
                 gbs = by / (ms * 1e-3) / 1e9
-                return dict(bound="hbm", kernel="tied_pruned_kernel + tied_bound_kernel + gmm_dist_kernel (+ tied_list / tied_transpose)",
+                return dict(bound="hbm", kernel="tied_pruned_kernel + tied_bound_kernel + gmm_dist_kernel (+ tied_mask / tied_transpose / tied_list / tied_near)",
                             note="exact pruning: bounds from 32 near densities per frame, then the reference's f64 rule over the surviving "
                                  "(density, frame, 64-mixture tile) triples only; algorithmic bytes = weight table once per batch + results",
                             achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4), traffic=None,

@@ -16,13 +16,22 @@
 // tau' = 2^-21 (2 max_k|a^[.][m]| + |U|) (the bound of that comment, written for an upper bound of the minimum: |min s^| <=
 // max(|U|, max|a^|) since dist >= 0).  With Thr[t][j] = max over the tile's mixtures of U + tau', and fl32 monotone,
 //   fl32(amin[j][k] + dist[k][t]) > Thr[t][j]   ==>   no mixture of tile j has density k as a candidate for frame t
-// and the same with aminG and ThrG[t] = max_j Thr[t][j] for the whole model.  Four small kernels:
+// and the same with aminG and ThrG[t] = max_j Thr[t][j] for the whole model.  The kernels:
 //   tied_transpose_kernel   dist[k][t] -> dt[t][k] (list order), so that a frame's distances are one contiguous row
-//   tied_bound_kernel       near densities of the frame, U, Thr[t][j]
-//   tied_list_kernel        per frame: the densities that pass the model-wide test (4 % on the config-3 instance), ascending
-//   tied_pruned_kernel      per (tile, frame): the tile test over that list (1.2 % of all densities pass), then the
-//                           reference's own f64 rule over the survivors in ascending k for the tile's 64 mixtures (lane = mixture).
+//   tied_near_kernel        the frame's near densities
+//   tied_bound_kernel       U and the mixtures' thresholds U + tau', Thr[t][j]
+//   tied_list_kernel        per frame: the densities that pass the model-wide test (4 % on the config-3 instance), ascending, with
+//                           their distances and log-normalisation terms
+//   tied_mask_kernel        per (frame, tile): which list entries pass the TILE's test (1.2 % of all densities), as bit masks
+//   tied_pruned_kernel      per (tile, frame): the survivors compacted into LDS, each lane's own f32 screen over them (1.3 of ~65
+//                           pass per mixture), and the reference's f64 rule over what is left, in ascending k.
 // Running the rule over a subsequence that contains every candidate, in the original order, is bit-identical.
+//
+// What bounds these kernels is not arithmetic and not bytes: the pruned kernel is a few hundred instructions per wave that each wait
+// on the one before (list -> row addresses -> rows -> candidates -> weights), so its time is (instructions a wave issues) x (waves
+// per SIMD) x 4 cycles at about one instruction per issue slot, and the small kernels are as long as their chain of memory round
+// trips.  Hence one trip per wave in the list / mask kernels, and the 6-instruction survivor test in tied_pruned_kernel
+// (profiles/r03/NOTES_tied.md has the measurements that led here).
 //
 // A model / feature distribution without that structure (everything survives) would make this slower than the dense
 // kernel -- each table element is then used once instead of 16 times from registers.  The kernel counts the survivors; the host
@@ -34,7 +43,7 @@
 #include <vector>
 
 #ifndef AMX_TIED_EXP
-#define AMX_TIED_EXP 0  // experiments (tools/): 1 = never take the unscreened loop (timing only, wrong on ties), 2 = no screening
+#define AMX_TIED_EXP 0  // 4: histograms of candidates per mixture and survivors per (frame, tile) on stderr after 20 calls
 #endif
 
 namespace amx {
@@ -254,7 +263,6 @@ struct TiedMax {  // MaxState of gmm.hip (the reference's rule), restated here t
     }
 };
 
-constexpr int kTiedCand = 8;    // candidates a lane keeps from the screening pass; more: the wave takes the unscreened path
 constexpr int kTiedSeg  = 256;  // survivors the unscreened path buffers per wave; a fuller list is worked off and the scan resumes
 constexpr int kTiedCap  = 256;  // entries of a (frame, tile) survivor list in LDS; a longer one takes the unscreened path
 
@@ -406,11 +414,11 @@ __global__ __launch_bounds__(64) void tied_pruned_kernel(const unsigned long lon
         TiedList s;
     } lds;
     const int lane = threadIdx.x;
-    // Workgroup b runs on XCD b % 8 (each XCD has its own L2).  A row of the weight table is wanted by ~3 of a 256-frame batch's
-    // frames, so all frames of one tile go to ONE XCD, back to back: tile = 8 * (slot / T) + xcd, frame = slot % T.  The tile's
-    // 1 MB slice of the table then comes from HBM once instead of once per frame that wants it.
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int tile = (slot / T) * 8 + xcd, t = slot % T;
+    // Workgroup b (in launch order: x fastest) runs on XCD b % 8, and each XCD has its own L2.  A row of the weight table is wanted
+    // by ~3 of a 256-frame batch's frames, so all frames of one tile go to ONE XCD, back to back: the grid is (8 T, tiles / 8),
+    // xcd = x % 8, frame = x / 8, tile = 8 y + xcd.  The tile's 1 MB slice of the table then comes from HBM once instead of once per
+    // frame that wants it.
+    const int tile = blockIdx.y * 8 + (blockIdx.x & 7), t = blockIdx.x >> 3;
     if (tile >= n_tiles)
         return;
     const int       m      = tile * 64 + lane;
@@ -454,7 +462,7 @@ __global__ __launch_bounds__(64) void tied_pruned_kernel(const unsigned long lon
             // two blocks of 16 entries; entry j of a block sits in lane j of EVERY row of 16 lanes, so that the DPP operand
             // row_newbcast:j hands it to all lanes inside the add that consumes it
             const int  e0   = 32 * w + (lane & 15), e1 = e0 + 16;
-            const bool two  = e1 - (lane & 15) < n;  // the second block exists
+            const bool two  = 32 * w + 16 < n;  // the second block exists
             const int  rk0  = e0 < n ? (int)lds.s.rk[e0] : 0;          // row 0 stands in past the end ...
             const int  d0   = e0 < n ? (int)lds.s.d[e0] : 0x7fc00000;  // ... with a NaN distance: never a candidate
             const int  l0   = e0 < n ? (int)lds.s.l[e0] : 0;
@@ -656,7 +664,7 @@ extern "C" int amx_internal_gmm_tied_score(amx_ctx* ctx, const float* dist_dev, 
                            (unsigned long long)K * (unsigned long long)Tc * (unsigned long long)n_tiles);
         hipLaunchKernelGGL(amx::tied_mask_kernel, dim3(tiles_pad / 64, Tc), dim3(64 * amx::kTiedMaskWaves), 0, ctx->stream, w.lk, w.ld, w.ln,
                            amin_t, w.thr, Kpad, n_tiles, tiles_pad, (unsigned short*)w.mask);
-        hipLaunchKernelGGL(amx::tied_pruned_kernel, dim3(8 * ((n_tiles + 7) / 8) * Tc), dim3(64), 0, ctx->stream, w.mask, w.lk, w.ld, w.ll, w.ln,
+        hipLaunchKernelGGL(amx::tied_pruned_kernel, dim3(8 * Tc, (n_tiles + 7) / 8), dim3(64), 0, ctx->stream, w.mask, w.lk, w.ld, w.ll, w.ln,
                            amin, w.thr, m2lw_t, w.thr_m, ln64, Kpad, Tc, n_mix, mix_pad, n_tiles, tiles_pad, sc, bd, survivors_dev);
     }
     AMX_HIP(hipGetLastError());

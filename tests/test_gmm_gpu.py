@@ -745,6 +745,26 @@ def test_tied_pruned_adversarial_and_statistics(ctx, monkeypatch):
     assert set(np.unique(ob)) <= {0, 511}
 
 
+def test_tied_pruned_list_lengths_and_frame_passes(ctx, monkeypatch):
+    """the pruned path's branches by survivor-list length and call size: (a) densities almost on top of each other -- every density
+    survives every tile's test: lists of 16 .. 1000 entries, i.e. a partial 16-entry block, whole 32-entry words, exactly the 256
+    the wave keeps in LDS, and the longer ones that go through the unscreened loop; (b) equal weights and equal distances: every
+    list position is a candidate of every mixture (the rule walks whole lists, the first / last density wins); (c) more frames than
+    one pass of the tied kernels takes (4096), with the frame count not a multiple of anything"""
+    monkeypatch.setenv("AMX_GMM_TIED_PRUNE", "1")
+    for n_dens in (16, 33, 64, 255, 256, 257, 1000):
+        model = synth.gmm_tied(130, n_dens, 16, seed=900 + n_dens, pooled=True)
+        model["means"] = (model["means"][:1] + np.float32(1e-4) * model["means"]).astype(np.float32)
+        assert_exact(ctx, model, feats(70, 16, 901))
+    for n_dens in (40, 256, 300):
+        model = synth.gmm_tied(70, n_dens, 16, seed=910 + n_dens, pooled=True)
+        model["means"][:] = model["means"][0]
+        model["log_weight"][:] = np.log(1.0 / n_dens)
+        assert_exact(ctx, model, feats(33, 16, 911))
+    model = synth.gmm_tied(100, 64, 16, seed=920, pooled=True)
+    assert_exact(ctx, model, feats(4096 + 777, 16, 921))
+
+
 @pytest.mark.parametrize("pooled", [True, False])
 def test_tied_non_finite_frames_keep_the_initial_result(ctx, pooled):
     """a frame with an inf / NaN / 1e30 feature has no finite density score: the reference keeps (FLT_MAX / 2, no density).  On the

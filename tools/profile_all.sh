@@ -6,6 +6,7 @@
 #   gpu_tests.log / gpu_fuzz.log  the -m gpu suite and one campaign of every GPU fuzzer (tools/fuzz_*.py)
 #   force_dist_bench.log          the default workload with the RCCL path forced on (world size 1)
 #   gemm_comparator.json          torch (hipBLASLt / rocBLAS) bf16 GEMM of the output-layer shape on the same box: measurement only
+#   gather_probe.log              scattered 256-byte rows out of L2 by request shape; cost of a scattered 64-lane gather (tools/gather_probe.hip)
 #   gemm_probe.log                ablation table of the pipelined GEMM (tools/gemm_probe.hip: full / no MFMA / no DMA / L2-resident operands)
 # usage (through gpurun):  tools/profile_all.sh r03 ; results land in gpurun_out/<round>/ -> copy to profiles/<round>/
 round=${1:-r03}
@@ -13,7 +14,9 @@ root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/$round
 mkdir -p $out/pmc
 cd /tmp && export TMPDIR=/tmp
+only() { [ -z "$ONLY" ] || [[ "$1" =~ $ONLY ]]; }  # ONLY=<regex>: just the workloads whose name matches (and none of the suites)
 run_stats() {  # name, bench args...
+    only $1 || return 0
     name=$1; shift
     python $root/bench.py "$@" 2>/dev/null | tail -1 > $out/${name}_bench.log
     rm -rf /tmp/prof_$name
@@ -22,12 +25,13 @@ run_stats() {  # name, bench args...
     [ -n "$f" ] && cp $f $out/${name}_kernel_stats.csv
 }
 run_pmc() {  # name, suffix, counters..., -- bench args...
+    only $1 || return 0
     name=$1; suf=$2; shift 2
     ctrs=()
     while [ "$1" != "--" ]; do ctrs+=("$1"); shift; done
     shift
     rm -rf /tmp/pmc_${name}_$suf
-    rocprofv3 --kernel-trace --pmc "${ctrs[@]}" --output-format csv -d /tmp/pmc_${name}_$suf -- python $root/bench.py "$@" --no-cpu-baseline --no-configs > /tmp/pmc_${name}_$suf.log 2>&1
+    timeout 300 rocprofv3 --kernel-trace --pmc "${ctrs[@]}" --output-format csv -d /tmp/pmc_${name}_$suf -- python $root/bench.py "$@" --no-cpu-baseline --no-configs > /tmp/pmc_${name}_$suf.log 2>&1
     f=$(find /tmp/pmc_${name}_$suf -name "*counter_collection.csv" | head -1)
     [ -n "$f" ] && python $root/tools/pmc_summary.py $f > $out/pmc/${name}_$suf.txt
 }
@@ -60,8 +64,11 @@ run_pmc nn-pipeline-bf16 mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_V
 run_pmc gmm-train sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES -- --workload gmm-train --steps 3 --warmup 1
 run_pmc gmm-train sq2 SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD -- --workload gmm-train --steps 3 --warmup 1
 run_pmc gmm-tied sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_LDS -- --workload gmm-tied --steps 5 --warmup 2
+run_pmc gmm-tied sq2 SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_WAVES GRBM_GUI_ACTIVE SQ_ACTIVE_INST_ANY -- --workload gmm-tied --steps 5 --warmup 2
 run_pmc gmm-tied fetch FETCH_SIZE -- --workload gmm-tied --steps 5 --warmup 2
 run_pmc gmm-tied write WRITE_SIZE -- --workload gmm-tied --steps 5 --warmup 2
+[ -x $root/tools/build/gather_probe ] && $root/tools/build/gather_probe > $out/gather_probe.log 2>&1
+if [ -n "$ONLY" ]; then ls -la $out $out/pmc; exit 0; fi
 (cd $root && timeout 1500 python -m pytest tests -m gpu -q > $out/gpu_tests.log 2>&1)
 (cd $root && for f in "fuzz_frontends.py 300 31" "fuzz_scorers.py 300 32" "fuzz_gmm.py 200 33" "fuzz_tied.py 300 34" "fuzz_more.py 100 35" "fuzz_ffnn.py 60 36" "fuzz_backend.py 100 37"; do echo "== tools/$f"; timeout 900 python tools/$f 2>&1 | grep -v amdgpu.ids | tail -2; done > $out/gpu_fuzz.log 2>&1)
 AMX_BENCH_FORCE_DIST=1 python $root/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-configs 2>/dev/null | grep "^{\"metric\"" | tail -1 > $out/force_dist_bench.log
