@@ -42,6 +42,11 @@ __global__ __launch_bounds__(1024) void k(unsigned long long* out, float seed) {
         if (OP == 22) { REP64(asm volatile("v_mul_f32 %0, %0, %4\n v_mul_f32 %1, %1, %4\n v_mul_f32 %2, %2, %4\n v_mul_f32 %3, %3, %4\n v_mul_f32 %5, %5, %4\n v_mul_f32 %6, %6, %4\n v_mul_f32 %7, %7, %4\n v_mul_f32 %8, %8, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0), "v"(a4), "v"(a5), "v"(a6), "v"(a7));) }
         if (OP == 23) { REP64(asm volatile("v_mov_b32 %0, %1\n v_mov_b32 %1, %2\n v_mov_b32 %2, %3\n v_mov_b32 %3, %0" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));) }
         if (OP == 24) { REP64(asm volatile("v_cndmask_b32 %0, %1, %2, vcc\n v_cndmask_b32 %3, %1, %2, vcc\n v_cndmask_b32 %0, %2, %1, vcc\n v_cndmask_b32 %3, %2, %1, vcc" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) :: "vcc");) }
+        if (OP == 25) { REP64(asm volatile("v_mul_f32_dpp %0, %4, %0 row_newbcast:3 row_mask:0xf bank_mask:0xf\n v_mul_f32_dpp %1, %4, %1 row_newbcast:7 row_mask:0xf bank_mask:0xf\n v_mul_f32_dpp %2, %4, %2 row_newbcast:11 row_mask:0xf bank_mask:0xf\n v_mul_f32_dpp %3, %4, %3 row_newbcast:15 row_mask:0xf bank_mask:0xf" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0));) }
+        if (OP == 26) { REP64(asm volatile("v_sub_f32 %0, %0, %4\n v_mul_f32_dpp %0, %4, %0 row_newbcast:3 row_mask:0xf bank_mask:0xf\n v_mul_f32 %1, %0, %0\n v_add_f32 %2, %2, %1" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0));) }
+        if (OP == 27) { REP64(asm volatile("v_sub_f32 %0, %0, %4\n v_mul_f32 %0, s0, %0\n v_mul_f32 %1, %0, %0\n v_add_f32 %2, %2, %1" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0));) }
+        if (OP == 28) { REP64(asm volatile("v_cmp_lt_f32 vcc, %2, %3\n v_addc_co_u32 %0, vcc, %0, %0, vcc\n v_cmp_lt_f32 vcc, %3, %2\n v_addc_co_u32 %1, vcc, %1, %1, vcc" : "+v"(u0), "+v"(u1) : "v"(a2), "v"(a3) : "vcc");) }
+        if (OP == 29) { REP64(asm volatile("v_sub_f32 %4, %2, %3\n v_alignbit_b32 %0, %0, %4, 31\n v_sub_f32 %4, %3, %2\n v_alignbit_b32 %1, %1, %4, 31" : "+v"(u0), "+v"(u1) : "v"(a2), "v"(a3), "v"(a4));) }
         if (OP == 15) { REP64(asm volatile("v_permlane32_swap_b32 %0, %1\n v_permlane32_swap_b32 %2, %3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));) }
     }
     unsigned long long t1 = __builtin_readcyclecounter();
@@ -85,6 +90,11 @@ int main() {
     run<8>("v_add_f32", 4, d);
     run<2>("v_fma_f32", 4, d);
     run<13>("v_mul_f32 (sgpr operand)", 4, d);
+    run<25>("v_mul_f32_dpp row_newbcast", 4, d);
+    run<26>("distance step, isr by DPP", 4, d);
+    run<27>("distance step, isr in SGPR", 4, d);
+    run<28>("v_cmp + v_addc (mask shift-in)", 4, d);
+    run<29>("v_sub + v_alignbit (mask)", 4, d);
     run<1>("v_pk_mul_f32", 4, d);
     run<14>("v_pk_mul_f32 (sgpr pair)", 4, d);
     run<7>("v_pk_add_f32", 4, d);
