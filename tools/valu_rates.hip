@@ -15,6 +15,12 @@ __global__ __launch_bounds__(1024) void k(unsigned long long* out, float seed) {
     float b0 = 1.0001f, b1 = 0.9999f;
     double d0 = a0, d1 = a1;
     unsigned u0 = threadIdx.x * 2654435761u, u1 = u0 ^ 0x5bd1e995u;
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+    f32x16 acc0, acc1;
+    f16x8  fa, fb;
+    for (int i = 0; i < 16; ++i) { acc0[i] = a0 + i; acc1[i] = a1 - i; }
+    for (int i = 0; i < 8; ++i) { fa[i] = (_Float16)(0.001f * (threadIdx.x & 7) + i); fb[i] = (_Float16)(0.5f - 0.01f * i); }
     __builtin_amdgcn_s_barrier();
     unsigned long long t0 = __builtin_readcyclecounter();
     for (int it = 0; it < 256; ++it) {
@@ -47,10 +53,13 @@ __global__ __launch_bounds__(1024) void k(unsigned long long* out, float seed) {
         if (OP == 27) { REP64(asm volatile("v_sub_f32 %0, %0, %4\n v_mul_f32 %0, s0, %0\n v_mul_f32 %1, %0, %0\n v_add_f32 %2, %2, %1" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0));) }
         if (OP == 28) { REP64(asm volatile("v_cmp_lt_f32 vcc, %2, %3\n v_addc_co_u32 %0, vcc, %0, %0, vcc\n v_cmp_lt_f32 vcc, %3, %2\n v_addc_co_u32 %1, vcc, %1, %1, vcc" : "+v"(u0), "+v"(u1) : "v"(a2), "v"(a3) : "vcc");) }
         if (OP == 29) { REP64(asm volatile("v_sub_f32 %4, %2, %3\n v_alignbit_b32 %0, %0, %4, 31\n v_sub_f32 %4, %3, %2\n v_alignbit_b32 %1, %1, %4, 31" : "+v"(u0), "+v"(u1) : "v"(a2), "v"(a3), "v"(a4));) }
+        if (OP == 30) { REP64(asm volatile("v_mfma_f32_32x32x16_f16 %0, %2, %3, %0\n v_mfma_f32_32x32x16_f16 %1, %2, %3, %1" : "+v"(acc0), "+v"(acc1) : "v"(fa), "v"(fb));) }
+        if (OP == 31) { REP64(asm volatile("v_mfma_f32_32x32x16_f16 %0, %2, %3, %0\n v_mul_f32 %4, %4, %8\n v_add_f32 %5, %5, %8\n v_mul_f32 %6, %6, %8\n v_add_f32 %7, %7, %8\n v_mul_f32 %4, %4, %8\n v_add_f32 %5, %5, %8\n v_mul_f32 %6, %6, %8\n v_add_f32 %7, %7, %8\n v_mfma_f32_32x32x16_f16 %1, %2, %3, %1\n v_mul_f32 %4, %4, %8\n v_add_f32 %5, %5, %8\n v_mul_f32 %6, %6, %8\n v_add_f32 %7, %7, %8\n v_mul_f32 %4, %4, %8\n v_add_f32 %5, %5, %8\n v_mul_f32 %6, %6, %8\n v_add_f32 %7, %7, %8" : "+v"(acc0), "+v"(acc1) : "v"(fa), "v"(fb), "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(b0));) }
+        if (OP == 32) { REP64(asm volatile("v_mul_f32 %0, %0, %4\n v_add_f32 %1, %1, %4\n v_mul_f32 %2, %2, %4\n v_add_f32 %3, %3, %4\n v_mul_f32 %0, %0, %4\n v_add_f32 %1, %1, %4\n v_mul_f32 %2, %2, %4\n v_add_f32 %3, %3, %4\n v_mul_f32 %0, %0, %4\n v_add_f32 %1, %1, %4\n v_mul_f32 %2, %2, %4\n v_add_f32 %3, %3, %4\n v_mul_f32 %0, %0, %4\n v_add_f32 %1, %1, %4\n v_mul_f32 %2, %2, %4\n v_add_f32 %3, %3, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0));) }
         if (OP == 15) { REP64(asm volatile("v_permlane32_swap_b32 %0, %1\n v_permlane32_swap_b32 %2, %3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));) }
     }
     unsigned long long t1 = __builtin_readcyclecounter();
-    float r = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + (float)d0 + (float)d1 + (float)(u0 + u1);
+    float r = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + (float)d0 + (float)d1 + (float)(u0 + u1) + acc0[3] + acc1[5];
     if (r == 123.456f) out[1] = 1;
     if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = t1 - t0;
 }
@@ -94,6 +103,9 @@ int main() {
     run<26>("distance step, isr by DPP", 4, d);
     run<27>("distance step, isr in SGPR", 4, d);
     run<28>("v_cmp + v_addc (mask shift-in)", 4, d);
+    run<30>("v_mfma_f32_32x32x16_f16 alone (2 chains)", 2, d);
+    run<32>("16 plain VALU alone", 16, d);
+    run<31>("2 MFMA + 16 plain VALU interleaved", 18, d);
     run<29>("v_sub + v_alignbit (mask)", 4, d);
     run<1>("v_pk_mul_f32", 4, d);
     run<14>("v_pk_mul_f32 (sgpr pair)", 4, d);
