@@ -464,7 +464,8 @@ template<int DIM, bool STAGE = false>
 __global__ __launch_bounds__(256) void gmm_dist_kernel(const float* __restrict__ g_feats, float* __restrict__ g_dist, double* __restrict__ g_dist64,
                                                       const uint32_t* __restrict__ g_d_mean, const uint32_t* __restrict__ g_d_cov,
                                                       const float* __restrict__ g_means, const float* __restrict__ g_isr,
-                                                      GmmDistDims dims) {
+                                                      GmmDistDims dims, float* __restrict__ g_dt = nullptr,
+                                                      const uint32_t* __restrict__ g_pos = nullptr, int dt_ld = 0) {
     struct {
         const float* __restrict__ feats; float* __restrict__ dist; const uint32_t* __restrict__ d_mean;
         const uint32_t* __restrict__ d_cov; const float* __restrict__ means; const float* __restrict__ isr;
@@ -501,18 +502,45 @@ __global__ __launch_bounds__(256) void gmm_dist_kernel(const float* __restrict__
     }
     const int d0 = blockIdx.x * p.dens_tile;
     const int d1 = min(d0 + p.dens_tile, p.n_dens);
-    for (int d = d0; d < d1; ++d) {
-        const float* mu = p.means + (size_t)p.d_mean[d] * (DIM > 0 ? DIM : p.dim);
-        const float* is = p.isr + (size_t)p.d_cov[d] * (DIM > 0 ? DIM : p.dim);
-        float        dist;
-        if (DIM > 0)
-            dist = gmm_distance<(DIM > 0 ? DIM : 1)>(x, mu, is);
-        else
-            dist = gmm_distance_rt(xs, p.dim, mu, is);
-        if (t < p.Tpad) {
-            p.dist[(size_t)d * p.Tpad + t] = dist;  // coalesced along t
-            if (g_dist64)
-                g_dist64[(size_t)d * p.Tpad + t] = (double)dist;
+    for (int db = d0; db < d1; db += 4) {  // four densities per trip: their frame-major pieces leave as one 16-byte store
+        float q[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int d = db + j;
+            if (d >= d1)
+                break;
+            const float* mu = p.means + (size_t)p.d_mean[d] * (DIM > 0 ? DIM : p.dim);
+            const float* is = p.isr + (size_t)p.d_cov[d] * (DIM > 0 ? DIM : p.dim);
+            float        dist;
+            if (DIM > 0)
+                dist = gmm_distance<(DIM > 0 ? DIM : 1)>(x, mu, is);
+            else
+                dist = gmm_distance_rt(xs, p.dim, mu, is);
+            q[j] = dist;
+            if (t < p.Tpad) {
+                p.dist[(size_t)d * p.Tpad + t] = dist;  // coalesced along t
+                if (g_dist64)
+                    g_dist64[(size_t)d * p.Tpad + t] = (double)dist;
+            }
+        }
+        // shared-list models, pruned scorer (gmm_tied.hip): the frame-major image dt[t][list position] it works on, written here
+        // instead of by a transposing kernel (10 us, all of it the latency of two dependent trips).  A lane's piece is a sector of its
+        // own (64 sectors per store instruction, ~150 cycles of the CU's address unit), hence four list-adjacent densities at once.
+        if (g_dt && t < p.T) {
+            const uint32_t p0 = g_pos[db];  // wave-uniform
+            const bool     quad = db + 3 < d1 && p0 != 0xffffffffu && (p0 & 3u) == 0u && g_pos[db + 1] == p0 + 1u && g_pos[db + 2] == p0 + 2u &&
+                              g_pos[db + 3] == p0 + 3u;
+            if (quad)
+                *(float4*)(g_dt + (size_t)t * dt_ld + p0) = make_float4(q[0], q[1], q[2], q[3]);
+            else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (db + j < d1) {
+                        const uint32_t pos = g_pos[db + j];
+                        if (pos != 0xffffffffu)
+                            g_dt[(size_t)t * dt_ld + pos] = q[j];
+                    }
+            }
         }
     }
 }
@@ -1439,6 +1467,7 @@ struct amx_gmm {
     std::vector<uint32_t> mix_off, h_k_dens, h_d_mean, h_d_cov;  // topology (accumulator files)
     // device
     uint32_t *d_mix_off = nullptr, *d_k_mean = nullptr, *d_k_cov = nullptr, *d_k_dens = nullptr;
+    uint32_t* d_dens_pos = nullptr;  // shared-list models whose list names every density at most once: density -> list position (~0: not listed)
     uint32_t *d_d_mean = nullptr, *d_d_cov = nullptr;
     double*   d_k_c64 = nullptr;
     float *   d_k_c32 = nullptr, *d_means = nullptr, *d_isr = nullptr;
@@ -1554,7 +1583,8 @@ extern "C" size_t amx_internal_gmm_tied_workspace(int K, int T, int mix_pad);
 extern "C" int    amx_internal_gmm_tied_score(amx_ctx* ctx, const float* dist_dev, const uint32_t* k_dens_dev, int K, int T, int Tpad, int n_mix,
                                               int mix_pad, const unsigned short* aup, const float* amax, const float* m2lw_t, const float* ahat_t,
                                               const double* ln64, const float* ln32, const float* amin, void* workspace, float* scores,
-                                              uint32_t* best, unsigned long long* survivors_dev);
+                                              uint32_t* best, unsigned long long* survivors_dev, int dt_written);
+extern "C" float* amx_internal_gmm_tied_dt(void* workspace, int K, int T, int have_positions);
 extern "C" int amx_internal_gmm_fused_supported(int dim, int pooled, int Kp);
 extern "C" int amx_internal_gmm_fused_create(int dim, int n_mix, int n_tiles, const void* A2_host, const uint32_t* mix_off, const uint32_t* k_mean,
                                              const double* c64, const float* means, const float* p1, const float* p2, void** rec_dev,
@@ -1776,7 +1806,7 @@ int launch_direct(amx_gmm* h, const amx::GmmParams& p, dim3 grid) {
     return AMX_OK;
 }
 
-int launch_dist(amx_gmm* h, const amx::GmmDistParams& p, dim3 grid, double* dist64, bool stage) {
+int launch_dist(amx_gmm* h, const amx::GmmDistParams& p, dim3 grid, double* dist64, bool stage, float* dt = nullptr, int dt_ld = 0) {
     hipStream_t      st  = h->ctx->stream;
     size_t           lds = 0;
     amx::GmmDistDims dims{p.T, p.Tpad, p.dim, p.n_dens, p.dens_tile};
@@ -1785,10 +1815,10 @@ int launch_dist(amx_gmm* h, const amx::GmmDistParams& p, dim3 grid, double* dist
     case D:                                                                                                                               \
         if (stage)                                                                                                                        \
             hipLaunchKernelGGL((amx::gmm_dist_kernel<D, true>), grid, dim3(256), (size_t)256 * (D + 1) * sizeof(float), st, p.feats, p.dist, \
-                               dist64, p.d_mean, p.d_cov, p.means, p.isr, dims);                                                          \
+                               dist64, p.d_mean, p.d_cov, p.means, p.isr, dims, dt, (const uint32_t*)h->d_dens_pos, dt_ld);               \
         else                                                                                                                              \
             hipLaunchKernelGGL((amx::gmm_dist_kernel<D>), grid, dim3(256), 0, st, p.feats, p.dist, dist64, p.d_mean, p.d_cov, p.means,     \
-                               p.isr, dims);                                                                                              \
+                               p.isr, dims, dt, (const uint32_t*)h->d_dens_pos, dt_ld);                                                   \
         break;
         AMX_GMM_CASE(16)
         AMX_GMM_CASE(24)
@@ -1803,7 +1833,7 @@ int launch_dist(amx_gmm* h, const amx::GmmDistParams& p, dim3 grid, double* dist
         default:
             lds = (size_t)4 * 64 * h->dim * sizeof(float);
             hipLaunchKernelGGL((amx::gmm_dist_kernel<0>), grid, dim3(256), lds, st, p.feats, p.dist, dist64, p.d_mean, p.d_cov, p.means,
-                               p.isr, dims);
+                               p.isr, dims, dt, (const uint32_t*)h->d_dens_pos, dt_ld);
     }
     AMX_HIP(hipGetLastError());
     return AMX_OK;
@@ -1942,6 +1972,19 @@ int amx_gmm_create(amx_ctx* ctx, const amx_gmm_model* m, amx_gmm** out) {
         for (int k = 0; k < h->K; ++k) {
             ln32[k] = h->lognorm[k_cov[k]];
             ln64[k] = (double)ln32[k];
+        }
+        {  // density -> list position, when that is a function (gmm_dist_kernel then writes the pruned scorer's frame-major image itself)
+            std::vector<uint32_t> pos((size_t)h->n_dens, 0xffffffffu);
+            bool                  once = true;
+            for (int k = 0; k < h->K && once; ++k) {
+                once = k_dens[k] < (uint32_t)h->n_dens && pos[k_dens[k]] == 0xffffffffu;
+                if (once)
+                    pos[k_dens[k]] = (uint32_t)k;
+            }
+            if (once && (r = gupload(&h->d_dens_pos, pos.data(), pos.size())) != AMX_OK) {
+                amx_gmm_destroy(h);
+                return r;
+            }
         }
         // screen tables (gmm_tied_tile_kernel): an f32 image of the per-entry constant and its largest magnitude per mixture
         std::vector<float> ahat((size_t)h->K * h->mix_pad, 0.f), amax(h->mix_pad, 0.f);
@@ -2106,6 +2149,7 @@ void amx_gmm_destroy(amx_gmm* h) {
     hipFree(h->d_k_mean);
     hipFree(h->d_k_cov);
     hipFree(h->d_k_dens);
+    hipFree(h->d_dens_pos);
     hipFree(h->d_d_mean);
     hipFree(h->d_d_cov);
     hipFree(h->d_k_c64);
@@ -2468,9 +2512,30 @@ int amx_gmm_score_dev(amx_gmm* h, int mode, const float* feats_dev, int T, float
             AMX_HIP(hipMalloc((void**)&h->d_dist64, need * sizeof(double)));
             h->dist64_cap = need;
         }
+        // pruned exact path of a shared-list model (gmm_tied.hip) unless the survivor statistics of earlier calls say that this model /
+        // these features leave too much standing (tied_decide_prune); decided here because the distance kernel then also writes the
+        // frame-major image that path works on
+        const bool prune = use_uni && mode == AMX_GMM_MAX && screen && (h->tied_forced >= 0 ? h->tied_forced == 1 : tied_decide_prune(h));
+        float*     dt    = nullptr;
+        if (prune) {
+            const size_t need_ws = amx_internal_gmm_tied_workspace(h->K, Tc, h->mix_pad);
+            if (need_ws > h->tied_ws_cap) {
+                for (auto& kv : h->graphs)
+                    if (kv.second)
+                        hipGraphExecDestroy(kv.second);
+                h->graphs.clear();
+                hipFree(h->d_tied_ws);
+                h->d_tied_ws   = nullptr;
+                h->tied_ws_cap = 0;
+                AMX_HIP(hipMalloc(&h->d_tied_ws, need_ws));
+                h->tied_ws_cap = need_ws;
+            }
+            dt = amx_internal_gmm_tied_dt(h->d_tied_ws, h->K, Tc, h->d_dens_pos != nullptr);
+        }
         {
             amx::ScopedKernelTimer timer(h->ctx, "gmm_dist");
-            int r = launch_dist(h, dp, dim3(amx::ceil_div(h->n_dens, dp.dens_tile), fb), need64 ? h->d_dist64 : nullptr, stage);
+            int r = launch_dist(h, dp, dim3(amx::ceil_div(h->n_dens, dp.dens_tile), fb), need64 ? h->d_dist64 : nullptr, stage, dt,
+                                (h->K + 63) & ~63);
             if (r != AMX_OK)
                 return r;
         }
@@ -2487,25 +2552,10 @@ int amx_gmm_score_dev(amx_gmm* h, int mode, const float* feats_dev, int T, float
     hipLaunchKernelGGL((amx::gmm_combine_uniform_kernel<amx::STATE, F>), grid, dim3(256), 0, h->ctx->stream, h->d_dist, h->d_dist64, \
                        sc, bd, h->d_m2lw_t, h->d_k_dens, h->d_ln64, h->d_ln32, ud)
             if (mode == AMX_GMM_MAX && screen) {
-                // pruned exact path (gmm_tied.hip) unless the survivor statistics of earlier calls say that this model / these
-                // features leave too much standing (tied_decide_prune)
-                const bool prune = h->tied_forced >= 0 ? h->tied_forced == 1 : tied_decide_prune(h);
                 if (prune) {
-                    const size_t need_ws = amx_internal_gmm_tied_workspace(h->K, Tc, h->mix_pad);
-                    if (need_ws > h->tied_ws_cap) {
-                        for (auto& kv : h->graphs)
-                            if (kv.second)
-                                hipGraphExecDestroy(kv.second);
-                        h->graphs.clear();
-                        hipFree(h->d_tied_ws);
-                        h->d_tied_ws   = nullptr;
-                        h->tied_ws_cap = 0;
-                        AMX_HIP(hipMalloc(&h->d_tied_ws, need_ws));
-                        h->tied_ws_cap = need_ws;
-                    }
                     int r = amx_internal_gmm_tied_score(h->ctx, h->d_dist, h->d_k_dens, h->K, Tc, Tpad, h->n_mix, h->mix_pad, h->d_aup,
                                                         h->d_amax, h->d_m2lw_t, h->d_ahat_t, h->d_ln64, h->d_ln32, h->d_amin, h->d_tied_ws, sc, bd,
-                                                        h->d_tied_surv);
+                                                        h->d_tied_surv, dt != nullptr);
                     if (r != AMX_OK)
                         return r;
                     AMX_HIP(hipMemcpyAsync(h->h_tied_surv, h->d_tied_surv, 257 * 8, hipMemcpyDeviceToHost, h->ctx->stream));

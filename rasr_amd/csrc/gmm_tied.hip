@@ -641,10 +641,16 @@ extern "C" size_t amx_internal_gmm_tied_workspace(int K, int T, int mix_pad) {
     return tied_ws(nullptr, K, T, mix_pad).bytes;
 }
 
+// where gmm_dist_kernel may write the frame-major distances itself (then amx_internal_gmm_tied_score skips its transposing kernel):
+// the call must be ONE pass, and the model's list must name every density at most once
+extern "C" float* amx_internal_gmm_tied_dt(void* workspace, int K, int T, int have_positions) {
+    return have_positions && T <= kTiedFrames ? tied_ws(workspace, K, T, 64).dt : nullptr;
+}
+
 extern "C" int amx_internal_gmm_tied_score(amx_ctx* ctx, const float* dist_dev, const uint32_t* k_dens_dev, int K, int T, int Tpad, int n_mix,
                                            int mix_pad, const unsigned short* aup, const float* amax, const float* m2lw_t, const float* ahat_t,
                                            const double* ln64, const float* ln32, const float* amin, void* workspace, float* scores,
-                                           uint32_t* best, unsigned long long* survivors_dev) {
+                                           uint32_t* best, unsigned long long* survivors_dev, int dt_written) {
     if (T <= 0)
         return AMX_OK;
     const int    Kpad = (K + 63) & ~63, n_tiles = mix_pad / 64, tiles_pad = (n_tiles + 63) & ~63;
@@ -654,8 +660,9 @@ extern "C" int amx_internal_gmm_tied_score(amx_ctx* ctx, const float* dist_dev, 
         const int Tc = std::min(kTiedFrames, T - t0);
         float*    sc = scores + (size_t)t0 * n_mix;
         uint32_t* bd = best ? best + (size_t)t0 * n_mix : nullptr;
-        hipLaunchKernelGGL(amx::tied_transpose_kernel, dim3(Kpad / 64, (Tc + 63) / 64), dim3(256), 0, ctx->stream, dist_dev + t0, k_dens_dev, K,
-                           Kpad, Tc, Tpad - t0, Tpad, w.dt);
+        if (!dt_written)  // (gmm_dist_kernel wrote w.dt: amx_internal_gmm_tied_dt)
+            hipLaunchKernelGGL(amx::tied_transpose_kernel, dim3(Kpad / 64, (Tc + 63) / 64), dim3(256), 0, ctx->stream, dist_dev + t0, k_dens_dev,
+                               K, Kpad, Tc, Tpad - t0, Tpad, w.dt);
         hipLaunchKernelGGL(amx::tied_near_kernel, dim3(Tc), dim3(amx::kTiedNearThreads), 0, ctx->stream, w.dt, K, Kpad, w.nd, w.nk);
         hipLaunchKernelGGL(amx::tied_bound_kernel, dim3((mix_pad / 2 + 255) / 256, Tc), dim3(256), 0, ctx->stream, aup, amax, w.nd, w.nk, n_mix,
                            mix_pad, n_tiles, w.thr, w.thr_m);
