@@ -765,6 +765,31 @@ def test_tied_pruned_list_lengths_and_frame_passes(ctx, monkeypatch):
     assert_exact(ctx, model, feats(4096 + 777, 16, 921))
 
 
+def test_tied_pruned_lists_that_are_not_the_identity(ctx, monkeypatch):
+    """the pruned path's frame-major distance image: written by the distance kernel when the shared list names every density once
+    (here: a permutation, list position != density id, and a list that skips densities), by the transposing kernel when a density
+    is listed twice (the duplicate has the same distance; the first position wins ties)"""
+    monkeypatch.setenv("AMX_GMM_TIED_PRUNE", "1")
+    rng = np.random.Generator(np.random.PCG64(930))
+    for variant in ("permutation", "subset", "duplicate"):
+        n_dens, n_mix = 200, 130
+        model = synth.gmm_tied(n_mix, n_dens, 16, seed=931, pooled=True)
+        if variant == "permutation":
+            lst = rng.permutation(n_dens).astype(np.uint32)
+        elif variant == "subset":
+            lst = np.sort(rng.choice(n_dens, 150, replace=False)).astype(np.uint32)
+        else:
+            lst = np.arange(n_dens, dtype=np.uint32)
+            lst[37] = 5
+            lst[150] = 5
+        k = len(lst)
+        model["dens_index"] = np.tile(lst, n_mix)
+        model["mix_offsets"] = (np.arange(n_mix + 1, dtype=np.uint64) * k).astype(np.uint32)
+        g = rng.gamma(0.1, 1.0, (n_mix, k)) + 1e-30
+        model["log_weight"] = np.log(g / g.sum(axis=1, keepdims=True)).reshape(-1).astype(np.float64)
+        assert_exact(ctx, model, feats(70, 16, 932))
+
+
 @pytest.mark.parametrize("pooled", [True, False])
 def test_tied_non_finite_frames_keep_the_initial_result(ctx, pooled):
     """a frame with an inf / NaN / 1e30 feature has no finite density score: the reference keeps (FLT_MAX / 2, no density).  On the
