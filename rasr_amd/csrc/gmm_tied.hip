@@ -513,25 +513,22 @@ __global__ __launch_bounds__(64) void tied_pruned_kernel(const unsigned long lon
                 atomicAdd(&g_tied_hist[32 + min(n / 8, 31)], 1ull);
         }
 #endif
-        // ---- phase 3: every pass takes each lane's first remaining position (entry from LDS, the lane's own weight from the table)
-        // through the reference's rule.  One or two passes for most waves; a lane whose threshold is infinite walks its whole list.
-        for (;;) {
-            int ii = -1;
+        // ---- phase 3: 64 list positions at a time, every pass takes each lane's first remaining one (entry from LDS, the lane's own
+        // weight from the table) through the reference's rule -- list order within a lane is all the rule needs.  One or two passes
+        // per 64 positions for most waves; a lane whose threshold is infinite walks its whole list.
 #pragma unroll
-            for (int w = 0; w < NW; ++w) {
-                if (32 * w >= n)
-                    break;
-                if (ii < 0 && hit[w] != 0u) {
-                    const int b = __builtin_clz(hit[w]);
-                    ii          = 32 * w + b;
-                    hit[w] &= ~(0x80000000u >> b);
-                }
-            }
-            if (!__any(ii >= 0))
+        for (int w = 0; w < NW; w += 2) {
+            if (32 * w >= n)
                 break;
-            if (ii >= 0) {
-                const float w = tied_load_v(g_m2lw_t, lds.s.rk[ii] + m_off);
-                st.add((double)w + (double)__uint_as_float(lds.s.l[ii]), __uint_as_float(lds.s.d[ii]), lds.s.k[ii]);
+            unsigned long long h64 = ((unsigned long long)hit[w] << 32) | hit[w + 1];
+            while (__any(h64 != 0ull)) {
+                if (h64 != 0ull) {
+                    const int b = __builtin_clzll(h64);
+                    h64 &= ~(0x8000000000000000ull >> b);
+                    const int   ii = 32 * w + b;
+                    const float wt = tied_load_v(g_m2lw_t, lds.s.rk[ii] + m_off);
+                    st.add((double)wt + (double)__uint_as_float(lds.s.l[ii]), __uint_as_float(lds.s.d[ii]), lds.s.k[ii]);
+                }
             }
         }
     }
