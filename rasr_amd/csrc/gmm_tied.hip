@@ -422,7 +422,6 @@ __global__ __launch_bounds__(64) void tied_pruned_kernel(const unsigned long lon
     if (tile >= n_tiles)
         return;
     const int       m      = tile * 64 + lane;
-    const int       nl     = g_ln[t];
     const float     thr_m  = g_thr_m[(size_t)t * mix_pad + m];
     const bool      narrow = (unsigned long long)Kpad * mix_pad * 4ull < (1ull << 32);  // table offsets fit 32 bits
     const uint32_t  m_off  = (uint32_t)m * 4u, row_bytes = (uint32_t)mix_pad * 4u;
@@ -430,14 +429,11 @@ __global__ __launch_bounds__(64) void tied_pruned_kernel(const unsigned long lon
     const float*    ld     = g_ld + (size_t)t * Kpad;
     const float*    ll     = g_ll + (size_t)t * Kpad;
     constexpr int   NW     = kTiedCap / 32;  // 32-entry words of a list
-    // ---- phase 1
-    int n = 0;
-    for (int c = 0; 64 * c < nl; ++c) {
-        const unsigned long long mask = g_mask[((size_t)t * (Kpad / 64) + c) * tiles_pad + tile];  // wave-uniform
-        const int                e    = 64 * c + lane;  // < Kpad; the mask is clear past the list's end
-        const uint32_t           k    = lk[e];
-        const float              d    = ld[e], l = ll[e];
-        const int                pos  = n + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+    // ---- phase 1.  The first 256 list entries and their masks are fetched before the list's length is known (the rows are Kpad
+    // long; what lies past the end is masked out below): one trip to memory for the usual list, not one per 64 entries.
+    int  n       = 0;
+    auto compact = [&](unsigned long long mask, uint32_t k, float d, float l) {
+        const int pos = n + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
         if (((mask >> lane) & 1ull) && pos < kTiedCap) {
             lds.s.rk[pos] = k * row_bytes;
             lds.s.d[pos]  = __float_as_uint(d);
@@ -445,6 +441,27 @@ __global__ __launch_bounds__(64) void tied_pruned_kernel(const unsigned long lon
             lds.s.k[pos]  = k;
         }
         n += __popcll(mask);
+    };
+    constexpr int      NC = 4;
+    unsigned long long mk[NC];
+    uint32_t           kk[NC];
+    float              dd[NC], l4[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const bool ok = 64 * c < Kpad;
+        const int  e  = ok ? 64 * c + lane : 0;
+        mk[c]         = ok ? g_mask[((size_t)t * (Kpad / 64) + c) * tiles_pad + tile] : 0ull;  // wave-uniform
+        kk[c]         = lk[e];
+        dd[c]         = ld[e];
+        l4[c]         = ll[e];
+    }
+    const int nl = g_ln[t];
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+        compact(64 * c < nl ? mk[c] : 0ull, kk[c], dd[c], l4[c]);  // (the mask kernel writes the chunks that hold list entries only)
+    for (int c = NC; 64 * c < nl; ++c) {
+        const int e = 64 * c + lane;  // < Kpad; the mask is clear past the list's end
+        compact(g_mask[((size_t)t * (Kpad / 64) + c) * tiles_pad + tile], lk[e], ld[e], ll[e]);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -522,13 +539,23 @@ __global__ __launch_bounds__(64) void tied_pruned_kernel(const unsigned long lon
                 break;
             unsigned long long h64 = ((unsigned long long)hit[w] << 32) | hit[w + 1];
             while (__any(h64 != 0ull)) {
-                if (h64 != 0ull) {
-                    const int b = __builtin_clzll(h64);
-                    h64 &= ~(0x8000000000000000ull >> b);
-                    const int   ii = 32 * w + b;
-                    const float wt = tied_load_v(g_m2lw_t, lds.s.rk[ii] + m_off);
-                    st.add((double)wt + (double)__uint_as_float(lds.s.l[ii]), __uint_as_float(lds.s.d[ii]), lds.s.k[ii]);
+                int   pos[4];
+                float wt[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {  // up to four candidates' weights in flight: one trip, not four
+                    pos[j] = -1;
+                    wt[j]  = 0.f;
+                    if (h64 != 0ull) {
+                        const int b = __builtin_clzll(h64);
+                        h64 &= ~(0x8000000000000000ull >> b);
+                        pos[j] = 32 * w + b;
+                        wt[j]  = tied_load_v(g_m2lw_t, lds.s.rk[pos[j]] + m_off);
+                    }
                 }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (pos[j] >= 0)
+                        st.add((double)wt[j] + (double)__uint_as_float(lds.s.l[pos[j]]), __uint_as_float(lds.s.d[pos[j]]), lds.s.k[pos[j]]);
             }
         }
     }
