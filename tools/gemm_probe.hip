@@ -211,6 +211,7 @@ int main(int argc, char** argv) {
         else if (s == "p64") run_pipe<CfgC, 64>(p, iters);
         else if (s == "xptrace") { run_pipe<XfgC, 1>(p, 1); dump_trace(p, trace_n); }
         else if (s == "xptrace32") { run_pipe<XfgC, 33>(p, 1); dump_trace(p, trace_n); }
+        else if (s == "xptrace64") { run_pipe<XfgC, 65>(p, 1); dump_trace(p, trace_n); }
         // generic kernel, 256x256 tiles
         else if (s == "0") run<CfgC, 0>(p, iters);
         else if (s == "x0") run<XfgC, 0>(p, iters);
