@@ -2416,7 +2416,7 @@ int amx_gmm_score_dev(amx_gmm* h, int mode, const float* feats_dev, int T, float
     }
     // ---- tied: chunk frames so the distance scratch stays <= 256 MB
     const int chunk_max = (int)std::max<size_t>(256, std::min<size_t>(16384, ((size_t)64 << 20) / (size_t)h->n_dens / 256 * 256));
-    // The pruned path of a shared-list model is five launches and a 2 KB copy: at the decoder's batch sizes their gaps are a seventh
+    // The pruned path of a shared-list model is six launches and a 2 KB copy: at the decoder's batch sizes their gaps are a seventh
     // of the pass, so repeated passes on unchanged buffers are replayed as one HIP graph like the screened CART path above (the
     // dense / pruned decision stays outside: a graph is only recorded and replayed for the pruned path).
     if (h->uniform && mode == AMX_GMM_MAX && h->tied_forced < 0 && T <= chunk_max && T <= 4096 &&

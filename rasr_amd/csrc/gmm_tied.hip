@@ -17,7 +17,9 @@
 // max(|U|, max|a^|) since dist >= 0).  With Thr[t][j] = max over the tile's mixtures of U + tau', and fl32 monotone,
 //   fl32(amin[j][k] + dist[k][t]) > Thr[t][j]   ==>   no mixture of tile j has density k as a candidate for frame t
 // and the same with aminG and ThrG[t] = max_j Thr[t][j] for the whole model.  The kernels:
-//   tied_transpose_kernel   dist[k][t] -> dt[t][k] (list order), so that a frame's distances are one contiguous row
+//   tied_transpose_kernel   dist[k][t] -> dt[t][k] (list order), so that a frame's distances are one contiguous row; only when the
+//                           shared list repeats a density or a call is cut into passes -- otherwise gmm_dist_kernel (gmm.hip)
+//                           writes dt itself
 //   tied_near_kernel        the frame's near densities
 //   tied_bound_kernel       U and the mixtures' thresholds U + tau', Thr[t][j]
 //   tied_list_kernel        per frame: the densities that pass the model-wide test (4 % on the config-3 instance), ascending, with
