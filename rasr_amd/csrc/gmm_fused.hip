@@ -286,11 +286,13 @@ __global__ __launch_bounds__(NW * 64) void gmm_fused_kernel(const float* __restr
             float*    gs = g_scores + (size_t)t * n_mix + mb;
             uint32_t* gb = BEST ? g_best + (size_t)t * n_mix + mb : nullptr;
             if (wide_ok && m0 + 16 <= n_mix) {
-                *(float4*)gs       = make_float4(so[0], so[1], so[2], so[3]);
-                *(float4*)(gs + 4) = make_float4(so[4], so[5], so[6], so[7]);
+                typedef float    nt_f4 __attribute__((ext_vector_type(4)));
+                typedef unsigned nt_u4 __attribute__((ext_vector_type(4)));
+                __builtin_nontemporal_store(nt_f4{so[0], so[1], so[2], so[3]}, (nt_f4*)gs);
+                __builtin_nontemporal_store(nt_f4{so[4], so[5], so[6], so[7]}, (nt_f4*)(gs + 4));
                 if (BEST) {
-                    *(uint4*)gb       = make_uint4(bo[0], bo[1], bo[2], bo[3]);
-                    *(uint4*)(gb + 4) = make_uint4(bo[4], bo[5], bo[6], bo[7]);
+                    __builtin_nontemporal_store(nt_u4{bo[0], bo[1], bo[2], bo[3]}, (nt_u4*)gb);
+                    __builtin_nontemporal_store(nt_u4{bo[4], bo[5], bo[6], bo[7]}, (nt_u4*)(gb + 4));
                 }
             }
             else {
