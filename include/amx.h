@@ -438,7 +438,14 @@ enum { AMX_ACT_NONE = 0, AMX_ACT_RELU = 1, AMX_ACT_SIGMOID = 2, AMX_ACT_TANH = 3
 /* MFMA input type; accumulation is always f32.  AMX_PREC_BF16X3 = split bf16: every operand is hi + lo (two bf16 values) and a
  * product is taken as hi hi + lo hi + hi lo -- three bf16 MFMA products, ~2^-16 relative error per product: the mode that meets
  * the 1e-4 bar of the f32 reference (Math::gemm<f32>, Math/Blas.hh:402-420) at a third of the bf16 rate */
-enum { AMX_PREC_FP32 = 0, AMX_PREC_BF16 = 1, AMX_PREC_BF16X3 = 2 };
+enum { AMX_PREC_FP32 = 0, AMX_PREC_BF16 = 1, AMX_PREC_BF16X3 = 2, AMX_PREC_F16MX = 3 };
+/* AMX_PREC_F16MX (round 4): every operand is f16(v) plus MX-fp4 images of v and of v - f16(v) (OCP e2m1, one e8m0 scale per 32 k);
+ * a product is f16 f16 + fp4(v) fp4(w - f16 w) + fp4(v - f16 v) fp4(w) -- one f16 MFMA product and ONE block-scaled fp4 MFMA
+ * product for both cross terms: 1.5 units of matrix time per product instead of split bf16's 3, relative error ~2^-13 per
+ * product (random sign), inside the 1e-4 bar with a factor of nine on BASELINE config 4 (profiles/r04/emulation_f16_f8.json).
+ * Limits: weights and activations must stay inside the f16 range (|v| < 65520): amx_ffnn_create refuses such weights, a pass
+ * that meets such a feature or hidden activation sets a sticky flag and every later call on the handle returns AMX_ERR_STATE
+ * (amx_ffnn_score, which waits for its results, returns it at once).  AMX_PREC_BF16X3 has no such limit. */
 
 typedef struct {
     int                 n_layers;

@@ -492,7 +492,7 @@ class NnBatchFeatureScorer:
         Bp = (C.c_void_p * n)(*[b.ctypes.data for b in self._bs])
         st = _lib.FfnnModel(n, self._ind.ctypes.data, self._outd.ctypes.data, C.cast(Wp, C.c_void_p), C.cast(Bp, C.c_void_p),
                             self._act.ctypes.data, _ptr(self._lp), priori_scale,
-                            {"fp32": AMX_PREC_FP32, "bf16": AMX_PREC_BF16, "bf16x3": _lib.AMX_PREC_BF16X3}[precision],
+                            {"fp32": AMX_PREC_FP32, "bf16": AMX_PREC_BF16, "bf16x3": _lib.AMX_PREC_BF16X3, "f16mx": _lib.AMX_PREC_F16MX}[precision],
                             0 if self._map is None else len(self._map), _ptr(self._map))
         h = C.c_void_p()
         _lib.check(self.L.amx_ffnn_create(ctx.h, C.byref(st), C.byref(h)))

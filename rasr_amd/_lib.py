@@ -13,7 +13,7 @@ AMX_OK, AMX_ERR_INVALID, AMX_ERR_UNSUPPORTED, AMX_ERR_DEVICE, AMX_ERR_STATE = 0,
 AMX_GMM_MAX, AMX_GMM_SUM, AMX_GMM_BATCH_FLOAT, AMX_GMM_SIMD, AMX_GMM_BATCH_INT, AMX_GMM_PRESELECTION_FLOAT, AMX_GMM_PRESELECTION_INT = 0, 1, 2, 3, 4, 5, 6
 AMX_GMM_VITERBI, AMX_GMM_BAUM_WELCH = 0, 1
 AMX_ACT_NONE, AMX_ACT_RELU, AMX_ACT_SIGMOID, AMX_ACT_TANH = 0, 1, 2, 3
-AMX_PREC_FP32, AMX_PREC_BF16, AMX_PREC_BF16X3 = 0, 1, 2
+AMX_PREC_FP32, AMX_PREC_BF16, AMX_PREC_BF16X3, AMX_PREC_F16MX = 0, 1, 2, 3
 AMX_NN_TOP_LINEAR, AMX_NN_TOP_SOFTMAX = 0, 1
 AMX_ARCHIVE_READ, AMX_ARCHIVE_WRITE = 0, 1
 AMX_NORM_MEAN, AMX_NORM_MEAN_AND_VARIANCE = 0, 1

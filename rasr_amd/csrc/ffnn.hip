@@ -450,6 +450,10 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[C::MI][C::MJ], char*
     }
 }
 
+}  // namespace amx
+#include "ffnn_mx.hpp"
+namespace amx {
+
 // ablation / trace hooks (tools/gemm_probe.hip only; the library instantiates VAR = 0 and never touches them):
 //   VAR & 8 no MFMA, 16 no operand loads after the first K-tile, 64 operand streaming only, 128 no epilogue, 256 epilogue
 //   without global stores
@@ -1412,8 +1416,13 @@ struct amx_ffnn {
     int    use_graphs = 1;
     int    gemm_persistent = 1;
     int    gemm_cfg       = -1;  // -1 = automatic; index into the bf16 tile configurations (launch_bf16_cfg)
+    // AMX_PREC_F16MX: host-mapped word the kernels set when a value leaves the f16 range (sticky: every later call fails)
+    unsigned* h_overflow = nullptr;
+    unsigned* d_overflow = nullptr;
     size_t elt() const { return precision == AMX_PREC_FP32 ? 4 : 2; }
-    bool   mfma_bf16() const { return precision != AMX_PREC_FP32; }  // bf16 and bf16x3 both run the bf16 GEMM kernels
+    bool   mfma_bf16() const { return precision != AMX_PREC_FP32; }  // everything but the exact-f32 kernels (fused statistics, HIP graphs)
+    bool   is_mx() const { return precision == AMX_PREC_F16MX; }
+    int    overflowed() const { return h_overflow && *(volatile unsigned*)h_overflow; }
 };
 
 namespace {
@@ -1436,6 +1445,15 @@ int ensure_workspace(amx_ffnn* h, int Tpad) {
     h->d_in = h->d_act[0] = h->d_act[1] = nullptr;
     h->cap_T                            = 0;
     const size_t planes = h->precision == AMX_PREC_BF16X3 ? 2 : 1;  // split bf16: rows are [hi plane | lo plane]
+    if (h->is_mx()) {  // 25 KB blocks per (256 rows, 32 k)
+        AMX_HIP(hipMalloc(&h->d_in, (size_t)(Tpad / 256) * (h->Kpad[0] / 32) * amx::mx::BLK));
+        if (h->max_hidden_pad > 0) {
+            AMX_HIP(hipMalloc(&h->d_act[0], (size_t)(Tpad / 256) * (h->max_hidden_pad / 32) * amx::mx::BLK));
+            AMX_HIP(hipMalloc(&h->d_act[1], (size_t)(Tpad / 256) * (h->max_hidden_pad / 32) * amx::mx::BLK));
+        }
+        h->cap_T = Tpad;
+        return AMX_OK;
+    }
     AMX_HIP(hipMalloc(&h->d_in, (size_t)Tpad * planes * h->Kpad[0] * h->elt()));
     if (h->max_hidden_pad > 0) {
         AMX_HIP(hipMalloc(&h->d_act[0], (size_t)Tpad * planes * h->max_hidden_pad * h->elt()));
@@ -1561,6 +1579,51 @@ void launch_bf16_cfg(amx_ffnn* h, int l, const void* x, int ldx, void* out, int 
     }
 }
 
+// AMX_PREC_F16MX tile configurations (ffnn_mx.hpp): the same shapes and the same selection rule as the bf16 kernels
+using MfgL = amx::mx::MxCfg<256, 256, 2, 4, 3>;  // 147 KB LDS, 8 waves of 128 x 64, two K-tiles in flight
+using MfgA = amx::mx::MxCfg<128, 128, 2, 2, 3>;  //  74 KB: 2 workgroups per CU
+using MfgS = amx::mx::MxCfg<128, 64, 2, 2, 4>;   //  74 KB: small batches, three K-tiles in flight
+
+template<class C, int ACT, bool LAST>
+void launch_mx(amx_ffnn* h, int l, const void* x, int xkts, void* out, int ldo, int T, int Tpad, int n_valid) {
+    const int ntn = h->Npad[l] / C::BN, ntt = Tpad / C::BT;
+    auto      k   = amx::mx::gemm_mx_kernel<C, ACT, LAST>;
+    const int gt = h->group_t >= 0 ? h->group_t : (C::BN == 256 ? 16 : 8), gn = h->group_n >= 0 ? h->group_n : (C::BN == 256 ? 8 : 2);
+    constexpr int lds_bytes = amx::gemm_scratch_bytes<C, LAST>() + C::BN * 4;
+    static_assert(lds_bytes <= 160 * 1024, "LDS budget");
+    hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    const int per_cu = std::max(1, (160 * 1024) / lds_bytes);
+    int       grid   = std::min(ntn * ntt, per_cu * std::max(h->ctx->n_cu, 8));
+    if (grid >= 8)
+        grid &= ~7;  // keep blockIdx % 8 == tile index % 8 for every stride step
+    hipLaunchKernelGGL(k, dim3(grid), dim3(C::THREADS), lds_bytes, h->ctx->stream, (const char*)h->d_W[l], (const char*)x, h->d_bias[l], out,
+                       h->Kpad[l] / 32, xkts, h->Npad[l] / 32, ldo, n_valid, T, ntn, ntn * ntt, gt, gn, LAST ? h->cur_part_min : nullptr,
+                       LAST ? h->cur_part_idx : nullptr, Tpad, h->d_overflow);
+    if (LAST)
+        h->cur_ntn = ntn;
+}
+
+template<int ACT, bool LAST>
+void launch_mx_cfg(amx_ffnn* h, int l, const void* x, int xkts, void* out, int ldo, int T, int Tpad, int n_valid) {
+    int cfg = h->gemm_cfg;
+    if (cfg < 0) {
+        const long ncu = std::max(h->ctx->n_cu, 1), t256 = (long)(h->Npad[l] / 256) * (Tpad / 256), t128 = (long)(h->Npad[l] / 128) * (Tpad / 128);
+        if (t256 >= 2L * ncu)
+            cfg = 2;
+        else if (t128 >= ncu)
+            cfg = 0;
+        else
+            cfg = 3;
+    }
+    switch (cfg) {
+        case 2:
+        case 4: launch_mx<MfgL, ACT, LAST>(h, l, x, xkts, out, ldo, T, Tpad, n_valid); break;
+        case 3:
+        case 6: launch_mx<MfgS, ACT, LAST>(h, l, x, xkts, out, ldo, T, Tpad, n_valid); break;
+        default: launch_mx<MfgA, ACT, LAST>(h, l, x, xkts, out, ldo, T, Tpad, n_valid); break;
+    }
+}
+
 template<bool LAST>
 int launch_layer(amx_ffnn* h, int l, const void* x, int ldx, void* out, int ldo, int T, int Tpad) {
     hipStream_t            st = h->ctx->stream;
@@ -1573,7 +1636,15 @@ int launch_layer(amx_ffnn* h, int l, const void* x, int ldx, void* out, int ldo,
         hipEventRecord(e0, st);
     }
     const int act = LAST ? AMX_ACT_NONE : h->act[l];
-    if (h->mfma_bf16()) {
+    if (h->is_mx()) {  // LAST with l < n_layers - 1: the last hidden layer as f32 rows (amx_ffnn_forward_hidden_dev)
+        switch (act) {
+            case AMX_ACT_RELU: launch_mx_cfg<AMX_ACT_RELU, LAST>(h, l, x, ldx, out, ldo, T, Tpad, h->out[l]); break;
+            case AMX_ACT_SIGMOID: launch_mx_cfg<AMX_ACT_SIGMOID, LAST>(h, l, x, ldx, out, ldo, T, Tpad, h->out[l]); break;
+            case AMX_ACT_TANH: launch_mx_cfg<AMX_ACT_TANH, LAST>(h, l, x, ldx, out, ldo, T, Tpad, h->out[l]); break;
+            default: launch_mx_cfg<AMX_ACT_NONE, LAST>(h, l, x, ldx, out, ldo, T, Tpad, h->out[l]); break;
+        }
+    }
+    else if (h->mfma_bf16()) {
         switch (act) {
             case AMX_ACT_RELU: launch_bf16_cfg<AMX_ACT_RELU, LAST>(h, l, x, ldx, out, ldo, T, Tpad); break;
             case AMX_ACT_SIGMOID: launch_bf16_cfg<AMX_ACT_SIGMOID, LAST>(h, l, x, ldx, out, ldo, T, Tpad); break;
@@ -1613,8 +1684,9 @@ int amx_ffnn_create(amx_ctx* ctx, const amx_ffnn_model* m, amx_ffnn** out) {
     *out = nullptr;
     AMX_REQUIRE(m->n_layers >= 1 && m->in_dim && m->out_dim && m->W && m->bias && m->activation, AMX_ERR_INVALID,
                 "amx_ffnn_create: empty network");
-    AMX_REQUIRE(m->precision == AMX_PREC_FP32 || m->precision == AMX_PREC_BF16 || m->precision == AMX_PREC_BF16X3, AMX_ERR_INVALID,
-                "amx_ffnn_create: unknown precision");
+    AMX_REQUIRE(m->precision == AMX_PREC_FP32 || m->precision == AMX_PREC_BF16 || m->precision == AMX_PREC_BF16X3 ||
+                        m->precision == AMX_PREC_F16MX,
+                AMX_ERR_INVALID, "amx_ffnn_create: unknown precision");
     for (int l = 0; l < m->n_layers; ++l) {
         AMX_REQUIRE(m->in_dim[l] > 0 && m->out_dim[l] > 0 && m->W[l], AMX_ERR_INVALID, "amx_ffnn_create: layer %d is empty", l);
         if (l > 0)
@@ -1686,7 +1758,17 @@ int amx_ffnn_create(amx_ctx* ctx, const amx_ffnn_model* m, amx_ffnn** out) {
     if (const char* e = getenv("AMX_GEMM_GROUP"))
         sscanf(e, "%dx%d", &h->group_t, &h->group_n);
     hipSetDevice(ctx->device);
-    const int kmult = (m->precision != AMX_PREC_FP32) ? amx::BK : amx::FK;
+    const int kmult = m->precision == AMX_PREC_F16MX ? amx::mx::TK : (m->precision != AMX_PREC_FP32) ? amx::BK : amx::FK;
+    if (m->precision == AMX_PREC_F16MX) {
+        if (hipHostMalloc((void**)&h->h_overflow, 4, hipHostMallocMapped) != hipSuccess ||
+            hipHostGetDevicePointer((void**)&h->d_overflow, h->h_overflow, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            amx::set_error("amx_ffnn_create: cannot allocate the overflow flag");
+            amx_ffnn_destroy(h);
+            return AMX_ERR_DEVICE;
+        }
+        *h->h_overflow = 0;
+    }
     long      best_flops = -1;
     for (int l = 0; l < m->n_layers; ++l) {
         h->in.push_back(m->in_dim[l]);
@@ -1707,7 +1789,24 @@ int amx_ffnn_create(amx_ctx* ctx, const amx_ffnn_model* m, amx_ffnn** out) {
         const int    K = h->in[l], N = h->out[l], Kp = h->Kpad[l], Np = h->Npad[l];
         const float* W = Wl[l];
         void*        d = nullptr;
-        if (m->precision == AMX_PREC_BF16X3) {
+        if (m->precision == AMX_PREC_F16MX) {
+            for (size_t i = 0; i < (size_t)N * K; ++i)
+                if (std::fabs(W[i]) >= 65520.f) {  // not a number a trained layer holds; f16 cannot
+                    amx::set_error("amx_ffnn_create: layer %d holds a weight outside the f16 range (%g): use AMX_PREC_BF16X3", l, (double)W[i]);
+                    h->d_W.push_back(nullptr);
+                    amx_ffnn_destroy(h);
+                    return AMX_ERR_INVALID;
+                }
+            std::vector<unsigned char> pk;
+            amx::mx::pack_weights_host(W, N, K, K, Np, Kp / 32, pk);
+            if (hipMalloc(&d, pk.size()) != hipSuccess || hipMemcpy(d, pk.data(), pk.size(), hipMemcpyHostToDevice) != hipSuccess) {
+                amx::set_error("amx_ffnn_create: device allocation of layer %d failed", l);
+                h->d_W.push_back(d);
+                amx_ffnn_destroy(h);
+                return AMX_ERR_DEVICE;
+            }
+        }
+        else if (m->precision == AMX_PREC_BF16X3) {
             // rows [W_hi | W_lo], each plane Kp columns wide (zero padded); the rows that feed the layer are [X_hi | X_lo] with the
             // lo plane at column xlo = Kpad (layer 0) or Npad of the layer below
             std::vector<amx::bf16_t> pk((size_t)Np * 2 * Kp, 0);
@@ -1797,6 +1896,8 @@ void amx_ffnn_destroy(amx_ffnn* h) {
     hipFree(h->d_part_idx);
     hipFree(h->d_host_f);
     hipFree(h->d_host_s);
+    if (h->h_overflow)
+        hipHostFree(h->h_overflow);
     for (auto& kv : h->graphs)
         if (kv.second)  // nullptr marks a signature seen once
             hipGraphExecDestroy(kv.second);
@@ -1832,6 +1933,9 @@ static int ffnn_score_impl(amx_ffnn* h, const float* feats_dev, int feats_stride
         return AMX_OK;
     AMX_REQUIRE(feats_dev && scores_dev, AMX_ERR_INVALID, "amx_ffnn_score_dev: NULL buffer");
     AMX_REQUIRE(feats_stride >= h->in[0], AMX_ERR_INVALID, "amx_ffnn_score_dev: feature stride %d < input dimension %d", feats_stride, h->in[0]);
+    AMX_REQUIRE(!h->overflowed(), AMX_ERR_STATE,
+                "amx_ffnn_score_dev: a feature or hidden activation left the f16 range (|v| >= 65520) in an earlier pass of this AMX_PREC_F16MX "
+                "handle; its scores were not valid -- create the scorer with AMX_PREC_BF16X3");
     AMX_HIP(hipSetDevice(h->ctx->device));
     // Small batches (the decoder's ring buffer: 256 ... 1024 frames, the same device buffers every time): replay the pass as a
     // HIP graph.  Not while profiling (the per-launch events are not part of the graph).
@@ -1907,7 +2011,12 @@ static int ffnn_launches(amx_ffnn* h, const float* feats_dev, int feats_stride, 
         {
             amx::ScopedKernelTimer timer(h->ctx, "ffnn_pack");
             const int blocks = (int)std::min<long long>(4096, ((long long)Tpad * h->Kpad[0] + 255) / 256);
-            if (h->precision == AMX_PREC_BF16X3)
+            if (h->is_mx()) {
+                const int b2 = (int)std::min<long long>(8192, ((long long)Tpad * (h->Kpad[0] / 32) * 2 + 255) / 256);
+                hipLaunchKernelGGL(amx::mx::pack_input_mx, dim3(b2), dim3(256), 0, h->ctx->stream, x, feats_stride, Tc, h->in[0], (char*)h->d_in,
+                                   h->Kpad[0] / 32, Tpad, h->d_overflow);
+            }
+            else if (h->precision == AMX_PREC_BF16X3)
                 hipLaunchKernelGGL(amx::pack_input_bf16x3, dim3(blocks), dim3(256), 0, h->ctx->stream, x, feats_stride, Tc, h->in[0],
                                    (amx::bf16_t*)h->d_in, h->Kpad[0], Tpad);
             else if (h->precision == AMX_PREC_BF16)
@@ -1921,7 +2030,7 @@ static int ffnn_launches(amx_ffnn* h, const float* feats_dev, int feats_stride, 
         const void* cur = h->d_in;
         const bool  x3  = h->precision == AMX_PREC_BF16X3;
         const int   planes = x3 ? 2 : 1;  // split bf16: rows are [hi plane | lo plane]
-        int         ldx    = planes * h->Kpad[0];
+        int         ldx    = h->is_mx() ? h->Kpad[0] / 32 : planes * h->Kpad[0];  // f16mx: K-tiles per 256-row block of the operand
         const bool  fused = stats && h->mfma_bf16();
         h->cur_part_min = nullptr;
         h->cur_part_idx = nullptr;
@@ -1945,6 +2054,33 @@ static int ffnn_launches(amx_ffnn* h, const float* feats_dev, int feats_stride, 
             h->cur_part_idx = h->d_part_idx;
         }
         for (int l = 0; l < L; ++l) {
+            if (h->is_mx() && hidden_out && l >= L - 2) {
+                // the on-demand scorer's f32 hidden activation: the last hidden layer leaves through the score epilogue as
+                // -(W x + b) in f32 (exact), act(-v) restores the activation; a network without hidden layers exports its input
+                const int H = h->in[L - 1];
+                float*    dst = hidden_out + (size_t)t0 * H;
+                if (L == 1) {
+                    const int blocks = (int)std::min<long long>(8192, ((long long)Tc * H + 255) / 256);
+                    hipLaunchKernelGGL(amx::export_hidden_kernel<0>, dim3(blocks), dim3(256), 0, h->ctx->stream, (const void*)x, feats_stride, 0, Tc, H, dst);
+                }
+                else if (l == L - 2) {
+                    r = launch_layer<true>(h, l, cur, ldx, dst, H, Tc, Tpad);
+                    if (r != AMX_OK)
+                        return r;
+                    const long long n = (long long)Tc * H;
+                    const int blocks = (int)std::min<long long>(8192, (n + 255) / 256);
+                    switch (h->act[l]) {
+                        case AMX_ACT_RELU: hipLaunchKernelGGL(amx::mx::neg_act_kernel<AMX_ACT_RELU>, dim3(blocks), dim3(256), 0, h->ctx->stream, dst, n); break;
+                        case AMX_ACT_SIGMOID: hipLaunchKernelGGL(amx::mx::neg_act_kernel<AMX_ACT_SIGMOID>, dim3(blocks), dim3(256), 0, h->ctx->stream, dst, n); break;
+                        case AMX_ACT_TANH: hipLaunchKernelGGL(amx::mx::neg_act_kernel<AMX_ACT_TANH>, dim3(blocks), dim3(256), 0, h->ctx->stream, dst, n); break;
+                        default: hipLaunchKernelGGL(amx::mx::neg_act_kernel<AMX_ACT_NONE>, dim3(blocks), dim3(256), 0, h->ctx->stream, dst, n); break;
+                    }
+                }
+                AMX_HIP(hipGetLastError());
+                if (L == 1 || l == L - 2)
+                    break;
+                continue;
+            }
             if (l == L - 1 && hidden_out) {
                 const int H = h->in[l];  // = out[l - 1], or the input dimension of a network without hidden layers
                 float*    dst = hidden_out + (size_t)t0 * H;
@@ -1975,7 +2111,7 @@ static int ffnn_launches(amx_ffnn* h, const float* feats_dev, int feats_stride, 
                 void* dst = h->d_act[l & 1];  // split bf16: the epilogue applies the activation and writes both planes
                 r         = launch_layer<false>(h, l, cur, ldx, dst, planes * h->Npad[l], Tc, Tpad);
                 cur       = dst;
-                ldx       = planes * h->Npad[l];
+                ldx       = h->is_mx() ? h->Npad[l] / 32 : planes * h->Npad[l];
             }
             if (r != AMX_OK)
                 return r;
@@ -2123,6 +2259,9 @@ int amx_ffnn_score(amx_ffnn* h, const float* feats_host, int T, float* scores_ho
         amx::set_error("amx_ffnn_score: D2H copy / kernel execution failed: %s", hipGetErrorString(hipGetLastError()));
         return AMX_ERR_DEVICE;
     }
+    AMX_REQUIRE(!h->overflowed(), AMX_ERR_STATE,
+                "amx_ffnn_score: a feature or hidden activation left the f16 range (|v| >= 65520); the scores are not valid -- create the "
+                "scorer with AMX_PREC_BF16X3");
     return AMX_OK;
 }
 

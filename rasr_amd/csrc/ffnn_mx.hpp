@@ -1,0 +1,470 @@
+// ffnn_mx.hpp -- AMX_PREC_F16MX: the round-4 arithmetic of the NN leg (included by ffnn.hip, after gemm_epilogue).
+//
+// An f32 product x w of the reference's sgemm (Nn/LinearLayer.cc:298-324 -> Math/Blas.hh:402-420) is taken as
+//     h(x) h(w)                        h = f16(v), round to nearest              v_mfma_f32_32x32x16_f16        (1 unit of matrix time)
+//   + q(x) r(w) + r(x) q(w)            q = fp6(h(v)), r = fp6(v - h(v))          v_mfma_scale_f32_32x32x64_f8f6f4, e2m3 x e2m3
+// with OCP-MX block scales (one e8m0 exponent per 32 k and row: 2^(E-2) for q, E the exponent of the block maximum, and 2^-11 of
+// that for r -- |v - f16(v)| <= 2^-11 2^E, so r never saturates and needs no maximum of its own).  Because both cross terms carry
+// the same total scale 2^(Ew-2) 2^(Ex-13), ONE 64-deep scaled product does both for 16 k:
+//     A = [ q(w) (16 k) | r(w) (the same 16 k) ]   scale 2^(Ew-2)
+//     B = [ r(x)        | q(x)                 ]   scale 2^(Ex-13)
+// and the 16 k of a lane are the 16 k its two f16 fragments of the K-tile hold anyway (lanes 0-31: chunks 0 and 2 of a row's 32 k,
+// lanes 32-63: chunks 1 and 3), so q is NOT stored: it is converted from the fragment registers (v_cvt_scalef32_pk32_fp6_f16, one
+// instruction per fragment pair).  Memory holds, per value, 2 bytes of f16 and 6 bits of r (+ one scale byte per 16 values):
+// 3 B, against 4 B for split bf16 -- and 1.5 units of matrix time per product instead of 3 (fp6 x fp6 runs at four times the f16
+// rate: 32 cycles per 32x32x64).  The dropped r r term is <= 2^-22 |x w|; the cross terms carry a relative error of ~2^-4 on a
+// 2^-11 term.  tools/emulate_split_f16_f8.py evaluates the scheme on all 10.24 M scores of BASELINE config 4
+// (profiles/r04/emulation_f16_f8.json): worst |d| = 0.024 of the 1e-4 |ref| + 1e-4 bar, no arg-min change; the fp4 form (0.11 of
+// the bar, built first) failed the bar on a one-output network whose scores are not carried by a prior (tests/test_ffnn_f16mx_gpu.py).
+// f16 range: an activation or feature beyond +-65504 raises the handle's overflow flag and every later call fails (use bf16x3).
+//
+// Memory layout (weights and activations alike; rows = output units or frames, padded to 256; K padded to 32):
+//   one 24 KB block per (256 rows, K-tile of 32 k), blocks ordered [row block][K-tile]; a block is the LDS image of the tile:
+//     H  @0      [256 rows][64 B]        f16, the row's four 16-byte chunks XOR-swizzled by (row >> 2) & 3 (conflict-free ds_read_b128)
+//     R  @16384  [2 halves][256 rows][16 B]   per (row, half): 16 e2m3 fields (12 B) = r of the half's 16 k in fragment order, then
+//                                        one dword whose low byte is the scale the row brings to the scaled product
+//                                        (weights: E - 2, activations: E - 13)
+//   so every LDS-DMA piece (one wave-wide 16-byte global_load_lds = 1 KB) reads 1 KB of CONTIGUOUS memory -- eight whole cache
+//   lines -- instead of 16 row pieces of 64 B at an 8 KB stride, and a line is used up by one K-tile.
+//   Order of the 32 k inside a tile (free, as long as both operands agree): natural index u = 8 g + 4 hh + e is what an MFMA
+//   accumulator lane (hh = lane >> 5) holds in registers (g, e) of a 32 x 32 result block; the f16 plane keeps it at position
+//   pos16(u): lane (frame, hh) of the hidden-layer epilogue owns f16 chunks hh and 2 + hh and the whole R record of half hh, and
+//   writes them straight from its registers (no exchange, no LDS round trip).
+#pragma once
+
+namespace amx {
+namespace mx {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x32 __attribute__((ext_vector_type(32)));
+typedef float    f32v16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x6 __attribute__((ext_vector_type(6)));
+typedef int      v8i __attribute__((ext_vector_type(8)));
+
+constexpr int TK    = 32;     // k per K-tile
+constexpr int R_OFF = 16384;  // residual records
+constexpr int BLK   = 24576;  // bytes per (256 rows, K-tile)
+
+__host__ __device__ constexpr int pos16(int u) {  // position of natural index u in the f16 plane (8 per 16-byte chunk)
+    return 8 * (2 * (u >> 4) + ((u >> 2) & 1)) + 4 * ((u >> 3) & 1) + (u & 3);
+}
+__host__ __device__ inline int h_off(int r, int c) {  // 16-byte chunk c of row r (0..255) of a block's f16 plane
+    return r * 64 + ((c ^ ((r >> 2) & 3)) << 4);
+}
+__host__ __device__ inline int r_off(int r, int half) {  // residual record of (row, half)
+    return R_OFF + half * 4096 + r * 16;
+}
+
+// biased exponent E of the block maximum, at least 14 (E - 13 stays the exponent field of a normal float)
+__host__ __device__ inline int block_exponent(float max_abs) {
+    unsigned u;
+#if defined(__HIP_DEVICE_COMPILE__)
+    u = __float_as_uint(max_abs);
+#else
+    memcpy(&u, &max_abs, 4);
+#endif
+    const int e = (int)((u >> 23) & 0xffu);
+    return e < 14 ? 14 : e;
+}
+
+// ---- host side (weights, once): e2m3 code of v / 2^(sbyte - 127), round to nearest even, saturating -- what the device
+// conversions do (tools/build/fp6_probe, cvt_probe)
+static inline unsigned fp6_code_host(float v, int sbyte) {
+    const double a = std::fabs((double)v) * std::ldexp(1.0, 127 - sbyte);
+    unsigned     code;
+    if (a >= 7.5)
+        code = 31;
+    else {
+        const double step = a >= 4.0 ? 0.5 : a >= 2.0 ? 0.25 : 0.125;  // subnormals and the binade [1, 2) share the step 1/8
+        const double qv   = std::nearbyint(a / step) * step;            // default rounding mode: to nearest even
+        if (qv >= 4.0)  // the rounded value may have crossed into the next binade
+            code = 24 + (unsigned)((qv - 4.0) / 0.5);
+        else if (qv >= 2.0)
+            code = 16 + (unsigned)((qv - 2.0) / 0.25);
+        else
+            code = (unsigned)(qv / 0.125);
+    }
+    return code | (std::signbit(v) ? 32u : 0u);
+}
+
+// packs rows [n_rows x K] (f32, row stride ld) into blocks [Rpad / 256][KT]; rows / columns beyond the matrix are zero
+static inline void pack_weights_host(const float* W, int n_rows, int K, int ld, int Rpad, int KT, std::vector<unsigned char>& out) {
+    out.assign((size_t)(Rpad / 256) * KT * BLK, 0);
+    for (int n = 0; n < n_rows; ++n) {
+        const int rb = n >> 8, r = n & 255;
+        for (int kt = 0; kt < KT; ++kt) {
+            unsigned char* blk = out.data() + ((size_t)rb * KT + kt) * BLK;
+            float          v[32], lo[32];
+            _Float16       hi[32];
+            float          m = 0.f;
+            for (int u = 0; u < 32; ++u) {
+                const int k = kt * 32 + u;
+                v[u]        = k < K ? W[(size_t)n * ld + k] : 0.f;
+                hi[u]       = (_Float16)v[u];
+                lo[u]       = v[u] - (float)hi[u];
+                m           = std::fmax(m, std::fabs(v[u]));
+            }
+            const int ec = block_exponent(m);
+            unsigned  rec[2][4] = {{0, 0, 0, (unsigned)(ec - 2)}, {0, 0, 0, (unsigned)(ec - 2)}};
+            for (int u = 0; u < 32; ++u) {
+                const int p = pos16(u), chunk = p >> 3, half = chunk & 1, f = 8 * (chunk >> 1) + (p & 7);  // field f of the half's record
+                memcpy(blk + h_off(r, chunk) + (p & 7) * 2, &hi[u], 2);
+                const unsigned code = fp6_code_host(lo[u], ec - 13);
+                const int      bit = 6 * f, d = bit >> 5, sh = bit & 31;
+                rec[half][d] |= code << sh;
+                if (sh > 26)
+                    rec[half][d + 1] |= code >> (32 - sh);
+            }
+            memcpy(blk + r_off(r, 0), rec[0], 16);
+            memcpy(blk + r_off(r, 1), rec[1], 16);
+        }
+    }
+}
+
+// 16 values of one accumulator lane (natural indices u = 8 g + 4 hh + e at a[4 g + e]: the half's fragment order) -> its two f16
+// chunks and its residual record (scale byte: sbyte)
+struct LanePack {
+    uint4 h0, h1, rec;
+};
+
+__device__ __forceinline__ unsigned pk_f16(float a, float b) {
+    f16x2 v = {(_Float16)a, (_Float16)b};
+    return __builtin_bit_cast(unsigned, v);
+}
+
+__device__ __forceinline__ LanePack lane_pack(const float (&a)[16], int ec, int sbyte) {
+    LanePack o;
+    unsigned h[8];
+    f32v16   le, lod;  // residuals of the even / odd fields (the conversion interleaves its two inputs)
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        h[p]           = pk_f16(a[2 * p], a[2 * p + 1]);
+        const f16x2 hv = __builtin_bit_cast(f16x2, h[p]);
+        le[p]          = a[2 * p] - (float)hv[0];
+        lod[p]         = a[2 * p + 1] - (float)hv[1];
+        le[8 + p]      = 0.f;
+        lod[8 + p]     = 0.f;
+    }
+    o.h0 = make_uint4(h[0], h[1], h[2], h[3]);
+    o.h1 = make_uint4(h[4], h[5], h[6], h[7]);
+    // The conversion WRITES ITS FIRST RESULT DWORD BEFORE IT HAS READ ALL 32 INPUTS, and this compiler does not know: through the
+    // builtin it gave the result the registers of input elements 4-9 (v[6:11] out of v[2:17]) and field 8 came out as garbage
+    // (first seen in the tanh instantiation only, where the allocator happened to overlap them).  Inline assembly with an
+    // early-clobber result forbids the overlap; the trailing s_nop covers the wait states the compiler's hazard recogniser would
+    // put between a vector write and a matrix-instruction read of the result (it does not look into an asm statement).
+    u32x6       r;
+    const float scale = __uint_as_float((unsigned)(ec - 13) << 23);
+    asm("v_cvt_scalef32_2xpk16_fp6_f32 %0, %1, %2, %3\n\ts_nop 2" : "=&v"(r) : "v"(le), "v"(lod), "v"(scale));
+    o.rec = make_uint4(r[0], r[1], r[2], (unsigned)sbyte);
+    return o;
+}
+
+// one lane's share of row r of block `blk` (hh = which half of the 32 k it holds)
+__device__ __forceinline__ void lane_store(char* blk, int r, int hh, const LanePack& p) {
+    *(uint4*)(blk + h_off(r, hh))     = p.h0;
+    *(uint4*)(blk + h_off(r, 2 + hh)) = p.h1;
+    *(uint4*)(blk + r_off(r, hh))     = p.rec;
+}
+
+// f32 frames [T x K] (row stride ldx) -> blocks [Tpad / 256][KT].  Two lanes per (frame, K-tile): lane half hh holds the natural
+// indices 8 g + 4 hh + e, exactly like an accumulator lane of the GEMM epilogue, so both go through lane_pack / lane_store.
+__global__ __launch_bounds__(256) void pack_input_mx(const float* __restrict__ x, int ldx, int T, int K, char* __restrict__ out, int KT, int Tpad,
+                                                    unsigned* __restrict__ overflow) {
+    const long long n = (long long)Tpad * KT * 2;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int       hh = (int)(i & 1);
+        const long long j  = i >> 1;
+        const int       kt = (int)(j % KT), t = (int)(j / KT);
+        float           a[16], m = 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int   k = kt * 32 + 8 * g + 4 * hh + e;
+                const float v = (t < T && k < K) ? x[(size_t)t * ldx + k] : 0.f;
+                a[4 * g + e]  = v;
+                m             = fmaxf(m, fabsf(v));
+            }
+        m = fmaxf(m, __shfl_xor(m, 1, 64));
+        if (m >= 65520.f && m < __builtin_inff())
+            *overflow = 1u;
+        const int ec = block_exponent(m);
+        lane_store(out + ((size_t)(t >> 8) * KT + kt) * BLK, t & 255, hh, lane_pack(a, ec, ec - 13));
+    }
+}
+
+// in place: v -> act(-v) (the last hidden layer run through the score epilogue, -(W x + b): exact)
+template<int ACT>
+__global__ __launch_bounds__(256) void neg_act_kernel(float* __restrict__ x, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        x[i] = activate<ACT>(-x[i]);
+}
+
+// ---------------------------------------------------------------------------------------------- tile configurations
+template<int BN_, int BT_, int WN_, int WT_, int STAGES_>
+struct MxCfg {
+    static constexpr int BN = BN_, BT = BT_, WN = WN_, WT = WT_, STAGES = STAGES_;
+    static constexpr int NW = WN * WT, THREADS = NW * 64, PLANES = 1;
+    static constexpr int MI = BN / WN / 32, MJ = BT / WT / 32;
+    static constexpr int A_R = BN * 64, A_BYTES = BN * 96;  // [H: 64 B/row][R: 2 halves x 16 B/row]
+    static constexpr int B_R = BT * 64, B_BYTES = BT * 96;
+    static constexpr int STAGE_BYTES = A_BYTES + B_BYTES, LDS_BYTES = STAGES * STAGE_BYTES;
+    static constexpr int A_PIECES = BN / 16 + BN / 32, B_PIECES = BT / 16 + BT / 32;  // 1 KB pieces of H and R
+    static constexpr int TOTAL = A_PIECES + B_PIECES;
+    static constexpr int PPW = (TOTAL + NW - 1) / NW;  // pieces per wave, at most
+    static constexpr int NHI = TOTAL % NW;             // waves 0 .. NHI-1 issue PPW pieces, the rest PPW - 1 (NHI == 0: all PPW)
+    static_assert(BN % 64 == 0 && BT % 64 == 0 && 256 % BN == 0 && 256 % BT == 0, "tiles are whole record pieces of a 256-row block");
+    static_assert(STAGES >= 2 && STAGES <= 4 && 3 * PPW < 64, "vmcnt immediate");
+};
+
+// LDS-DMA piece p of a K-tile: source offset inside the operand's block (ha / hb: which part of the 256 rows the tile covers),
+// destination offset inside the stage, operand
+template<class C>
+__device__ __forceinline__ void piece_offsets(int p, int ha, int hb, int& src, int& dst, bool& is_b) {
+    is_b = p >= C::A_PIECES;
+    if (!is_b) {
+        if (p < C::BN / 16) {
+            src = (ha * (C::BN / 16) + p) * 1024;
+            dst = p * 1024;
+        }
+        else {
+            const int j = p - C::BN / 16, half = j / (C::BN / 64), gq = j % (C::BN / 64);
+            src = R_OFF + half * 4096 + (ha * (C::BN / 64) + gq) * 1024;
+            dst = C::A_R + half * (C::BN * 16) + gq * 1024;
+        }
+    }
+    else {
+        const int q = p - C::A_PIECES;
+        if (q < C::BT / 16) {
+            src = (hb * (C::BT / 16) + q) * 1024;
+            dst = C::A_BYTES + q * 1024;
+        }
+        else {
+            const int j = q - C::BT / 16, half = j / (C::BT / 64), gq = j % (C::BT / 64);
+            src = R_OFF + half * 4096 + (hb * (C::BT / 64) + gq) * 1024;
+            dst = C::A_BYTES + C::B_R + half * (C::BT * 16) + gq * 1024;
+        }
+    }
+}
+
+template<int N>
+__device__ __forceinline__ void mx_wait() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// q of a lane's 16 k from its two f16 fragments.  FIRST: the fields go to dwords 0-2 of the operand (the A side), else to dwords
+// 3-5 (the B side); the other half of the conversion's input is left undefined, its output is not used.
+template<bool FIRST>
+__device__ __forceinline__ u32x6 q_fields(f16x8 c0, f16x8 c1, unsigned scale_byte) {
+    const f16x16 v = __builtin_shufflevector(c0, c1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+    f16x32       w;
+    if (FIRST)
+        w = __builtin_shufflevector(v, v, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1);
+    else
+        w = __builtin_shufflevector(v, v, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+    u32x6       q;  // early-clobber result: see lane_pack
+    const float scale = __uint_as_float(scale_byte << 23);
+    asm("v_cvt_scalef32_pk32_fp6_f16 %0, %1, %2\n\ts_nop 2" : "=&v"(q) : "v"(w), "v"(scale));
+    return q;
+}
+
+// D[n][t] = sum_k W[n][k] X[t][k] in the arithmetic above.  W, X: blocks (see the head of the file; xkts = K-tiles per row block
+// of X); hidden layers write the next layer's blocks (ktn K-tiles per row block), the output layer f32 scores [T x n_valid] =
+// -(D + bias) with the arg-min partials of the fused statistics.  Persistent workgroups, XCD-aware tile order, STAGES-deep LDS
+// ring with ONE barrier per K-tile and counted vmcnt (never a drain inside the loop).
+template<class C, int ACT, bool LAST>
+__global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const char* __restrict__ W, const char* __restrict__ X, const float* __restrict__ bias,
+                                                            void* __restrict__ out, int KT, int xkts, int ktn, int ldo, int n_valid, int t_valid,
+                                                            int n_tiles_n, int n_tiles_total, int GT, int GN, float* __restrict__ part_min,
+                                                            unsigned* __restrict__ part_idx, int part_ld, unsigned* __restrict__ overflow) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];  // [STAGES][A: H | R][B: H | R] ... [bias]
+    const int tid  = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn   = wave / C::WT, wt = wave % C::WT;
+    constexpr int WNR = C::BN / C::WN, WTT = C::BT / C::WT;
+    const bool    hi_wave = C::NHI == 0 || wave < C::NHI;  // issues PPW pieces per K-tile
+
+    for (int vi = blockIdx.x; vi < n_tiles_total; vi += gridDim.x) {
+        int tile_t, tile_n;
+        {  // the XCD-aware order of gemm_bf16_kernel
+            const int nwg = n_tiles_total;
+            const int q = nwg >> 3, r = nwg & 7, xcd = vi & 7, k = vi >> 3;
+            const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+            const int n_tiles_t = nwg / n_tiles_n;
+            if (GT > 0 && GN > 0) {
+                const int band = v / (GT * n_tiles_n), w = v - band * (GT * n_tiles_n);
+                const int bt0  = band * GT, bh = min(GT, n_tiles_t - bt0);
+                const int blk  = w / (bh * GN), u = w - blk * (bh * GN);
+                const int bn0  = blk * GN, bw = min(GN, n_tiles_n - bn0);
+                tile_t         = bt0 + u / bw;
+                tile_n         = bn0 + u % bw;
+            }
+            else {
+                tile_t = v / n_tiles_n;
+                tile_n = v - tile_t * n_tiles_n;
+            }
+        }
+        const int   n0 = tile_n * C::BN, t0 = tile_t * C::BT;
+        const char* wblk = W + (size_t)(n0 >> 8) * KT * BLK;
+        const char* xblk = X + (size_t)(t0 >> 8) * xkts * BLK;  // xkts >= KT: the producer padded its outputs to 256
+        const int   ha = (n0 & 255) / C::BN, hb = (t0 & 255) / C::BT;
+
+        // ---- this wave's pieces of a K-tile (wave-uniform: scalar registers)
+        int  p_src[C::PPW], p_dst[C::PPW];
+        bool p_b[C::PPW];
+#pragma unroll
+        for (int q = 0; q < C::PPW; ++q) {
+            const int p = q * C::NW + wave;
+            if (p < C::TOTAL)
+                piece_offsets<C>(p, ha, hb, p_src[q], p_dst[q], p_b[q]);
+            else {
+                p_src[q] = p_dst[q] = 0;
+                p_b[q]              = false;
+            }
+        }
+        const unsigned voff = (unsigned)lane * 16u;
+        auto stage = [&](int slot, int kt) {
+            char* base = lds + slot * C::STAGE_BYTES;
+#pragma unroll
+            for (int q = 0; q < C::PPW; ++q) {
+                if (q == C::PPW - 1 && !hi_wave)
+                    break;
+                const char* src = (p_b[q] ? xblk : wblk) + (size_t)kt * BLK + p_src[q];
+                __builtin_amdgcn_global_load_lds((const void*)(src + voff), (__attribute__((address_space(3))) void*)(base + p_dst[q]), 16, 0, 0);
+            }
+        };
+
+        f32x16 acc[C::MI][C::MJ];
+#pragma unroll
+        for (int i = 0; i < C::MI; ++i)
+#pragma unroll
+            for (int j = 0; j < C::MJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    acc[i][j][r] = 0.f;
+        float* s_bias = (float*)(lds + gemm_scratch_bytes<C, LAST>());
+        for (int i = tid; i < C::BN; i += C::THREADS)
+            s_bias[i] = bias[n0 + i];
+
+#pragma unroll
+        for (int s = 0; s < C::STAGES - 1; ++s)
+            if (s < KT)
+                stage(s, s);
+        const int frow = lane & 31, fk = lane >> 5;
+        const int a_row = wn * WNR + frow, b_row = wt * WTT + frow;
+        for (int kt = 0; kt < KT; ++kt) {
+            const int ahead = min(C::STAGES - 2, KT - 1 - kt);  // K-tiles that stay in flight
+            if (hi_wave) {
+                if (C::STAGES >= 4 && ahead == 2)
+                    mx_wait<2 * C::PPW>();
+                else if (C::STAGES >= 3 && ahead == 1)
+                    mx_wait<C::PPW>();
+                else
+                    mx_wait<0>();
+            }
+            else {
+                if (C::STAGES >= 4 && ahead == 2)
+                    mx_wait<2 * (C::PPW - 1)>();
+                else if (C::STAGES >= 3 && ahead == 1)
+                    mx_wait<C::PPW - 1>();
+                else
+                    mx_wait<0>();
+            }
+            __builtin_amdgcn_s_barrier();
+            if (kt + C::STAGES - 1 < KT)
+                stage((kt + C::STAGES - 1) % C::STAGES, kt + C::STAGES - 1);
+            const char* ab = lds + (kt % C::STAGES) * C::STAGE_BYTES;
+            const char* bb = ab + C::A_BYTES;
+            f16x8 a[2][C::MI], b[2][C::MJ];
+            uint4 ra[C::MI], rb[C::MJ];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int i = 0; i < C::MI; ++i)
+                    a[ks][i] = *(const f16x8*)(ab + h_off(a_row + 32 * i, 2 * ks + fk));
+#pragma unroll
+                for (int j = 0; j < C::MJ; ++j)
+                    b[ks][j] = *(const f16x8*)(bb + h_off(b_row + 32 * j, 2 * ks + fk));
+            }
+#pragma unroll
+            for (int i = 0; i < C::MI; ++i)
+                ra[i] = *(const uint4*)(ab + C::A_R + fk * (C::BN * 16) + (a_row + 32 * i) * 16);
+#pragma unroll
+            for (int j = 0; j < C::MJ; ++j)
+                rb[j] = *(const uint4*)(bb + C::B_R + fk * (C::BT * 16) + (b_row + 32 * j) * 16);
+            // the same order in every configuration: h.h of k-slab 0, of k-slab 1, then the scaled cross product
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < C::MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < C::MJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks][i], b[ks][j], acc[i][j], 0, 0, 0);
+            v8i av[C::MI], bv[C::MJ];
+#pragma unroll
+            for (int i = 0; i < C::MI; ++i) {
+                const u32x6 q = q_fields<true>(a[0][i], a[1][i], ra[i].w);  // q(w) = fp6(h(w) / 2^(Ew - 2))
+                av[i]         = v8i{(int)q[0], (int)q[1], (int)q[2], (int)ra[i].x, (int)ra[i].y, (int)ra[i].z, 0, 0};
+            }
+#pragma unroll
+            for (int j = 0; j < C::MJ; ++j) {
+                const u32x6 q = q_fields<false>(b[0][j], b[1][j], rb[j].w + 11u);  // q(x) = fp6(h(x) / 2^(Ex - 2)); the record holds Ex - 13
+                bv[j]         = v8i{(int)rb[j].x, (int)rb[j].y, (int)rb[j].z, (int)q[3], (int)q[4], (int)q[5], 0, 0};
+            }
+#pragma unroll
+            for (int i = 0; i < C::MI; ++i)
+#pragma unroll
+                for (int j = 0; j < C::MJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av[i], bv[j], acc[i][j], 2, 2, 0, (int)ra[i].w, 0, (int)rb[j].w);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+
+        // the epilogue's lane-dependent addresses are derived from opaque copies of the lane / thread id: computed from `lane` they are
+        // invariants of the tile loop, get hoisted in front of the K-loop and spilled there (the K-loop owns the register file) -- and a
+        // scratch access inside the loop would join the queue the counted vmcnt waits count
+        int elane = lane, etid = tid;
+        asm volatile("" : "+v"(elane), "+v"(etid));
+        if (LAST)
+            gemm_epilogue<C, ACT, true>(acc, lds, s_bias, out, ldo, 0, n_valid, t_valid, n0, t0, tile_n, wn, wt, elane, etid, part_min, part_idx, part_ld);
+        else {
+            // next layer's blocks, straight from the accumulators: lane (frame, hh) of result block (i, j) owns natural indices
+            // 8 g + 4 hh + e of K-tile (n0 + wn WNR + 32 i) / 32, i.e. half hh of that row
+            __syncthreads();  // bias visible
+            const int tl32 = elane & 31, hh = elane >> 5;
+            bool      over = false;
+#pragma unroll
+            for (int j = 0; j < C::MJ; ++j) {
+                const int t = t0 + wt * WTT + 32 * j + tl32;
+#pragma unroll
+                for (int i = 0; i < C::MI; ++i) {
+                    float v[16], m = 0.f;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float4 b4 = *(const float4*)(s_bias + wn * WNR + 32 * i + 8 * g + 4 * hh);
+                        v[4 * g + 0]    = activate<ACT>(acc[i][j][4 * g + 0] + b4.x);
+                        v[4 * g + 1]    = activate<ACT>(acc[i][j][4 * g + 1] + b4.y);
+                        v[4 * g + 2]    = activate<ACT>(acc[i][j][4 * g + 2] + b4.z);
+                        v[4 * g + 3]    = activate<ACT>(acc[i][j][4 * g + 3] + b4.w);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 16; ++u)
+                        m = fmaxf(m, fabsf(v[u]));
+                    m    = fmaxf(m, __shfl_xor(m, 32, 64));
+                    over = over || (m >= 65520.f && m < __builtin_inff());
+                    const int ec = block_exponent(m);
+                    char*     blk = (char*)out + ((size_t)(t >> 8) * ktn + ((n0 + wn * WNR + 32 * i) >> 5)) * BLK;
+                    lane_store(blk, t & 255, hh, lane_pack(v, ec, ec - 13));
+                }
+            }
+            if (over)
+                *overflow = 1u;
+        }
+        __syncthreads();  // LDS (stages / epilogue scratch / bias) is reused by the next tile
+    }
+}
+
+}  // namespace mx
+}  // namespace amx
