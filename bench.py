@@ -68,9 +68,11 @@ def parse():
     ap.add_argument("--utt-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the secondary BASELINE configs of the default run")
-    ap.add_argument("--precision", default="bf16x3", choices=["bf16", "bf16x3", "fp32"],
-                    help="NN GEMM inputs: bf16x3 = split bf16, three MFMA products per f32 product (default: meets north_star's 1e-4 bar "
-                         "against the f32 reference), bf16 (BASELINE config 4's literal dtype; 2e-3-grade scores), fp32 = f32 MFMA")
+    ap.add_argument("--precision", default="f16mx", choices=["bf16", "bf16x3", "f16mx", "fp32"],
+                    help="NN GEMM inputs: f16mx = f16 product + one MX-fp6 scaled product for both cross terms (default since round 4: meets "
+                         "north_star's 1e-4 bar against the f32 reference at 1.5 units of matrix time per product), bf16x3 = split bf16, "
+                         "three MFMA products per f32 product (the round-3 default, same bar), bf16 (BASELINE config 4's literal dtype; "
+                         "2e-3-grade scores), fp32 = f32 MFMA")
     ap.add_argument("--front-end", default="mfcc", choices=["mfcc", "mfplp", "plp", "gammatone"],
                     help="mfcc workload: mfcc.flow (40 cepstra), mfplp.flow (20 autocorrelation / 16 cepstrum coefficients) or plp.flow "
                          "(bark / trapeze filter bank + equal loudness, 13 / 13) or the gammatone nodes (68 channels, cascade 4, 25 / 10 ms "
@@ -227,15 +229,20 @@ def nn_gemm_roofline(precision, ms, n, frames, full_chunk):
     """output-layer GEMM 2048 -> 10000: `achieved` = MFMA flops the kernel executes / HIP-event time.  bf16x3 executes three bf16
     products per algorithmic product, so its algorithmic rate is a third of `achieved`."""
     alg = 2.0 * 2048 * 10000 * frames
-    mult = 3.0 if precision == "bf16x3" else 1.0
+    # f16mx: the f16 product (1 x alg flops at the 2.5 PF rate) + the fp6 x fp6 scaled product (2 x alg flops at the 10 PF rate) keep
+    # the matrix pipe busy like 1.5 x alg flops at the 2.5 PF rate: `achieved` is that bf16-equivalent figure, so `frac` is pipe time
+    mult = {"bf16x3": 3.0, "f16mx": 1.5}.get(precision, 1.0)
     peak = FP32_TFLOPS if precision == "fp32" else MFMA_BF16_TFLOPS
     ach = mult * alg / (ms * 1e-3) / 1e12
     name = {"bf16": "gemm_bf16_pipe_kernel<NONE,LAST> (2048->10000)", "bf16x3": "gemm_bf16_pipe_kernel<X3,NONE,LAST> (2048->10000, split bf16: W_hi/W_lo/X_hi/X_lo staged once, 3 MFMA products per fragment set)",
+            "f16mx": "gemm_mx_kernel<256x256,NONE,LAST> (2048->10000; per 32 k: 2 x v_mfma_f32_32x32x16_f16 + 1 x v_mfma_scale_f32_32x32x64_f8f6f4 "
+                     "fp6 x fp6 = 1.5 f16-equivalent units per product)",
             "fp32": "gemm_f32_kernel (2048->10000)"}[precision]
     out = dict(bound="mfma", kernel=name, achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
-               traffic=(measured_traffic("pipeline" if precision == "bf16x3" else "pipeline-bf16", "gemm_bf16_pipe_kernel",
-                                         {"bf16x3": "32, true>, 0, true", "bf16": "64, false>, 0, true"}[precision])
-                        if (precision in ("bf16", "bf16x3") and full_chunk) else None),
+               traffic=(measured_traffic({"bf16x3": "pipeline-bf16x3", "bf16": "pipeline-bf16", "f16mx": "pipeline"}[precision],
+                                         "gemm_mx_kernel" if precision == "f16mx" else "gemm_bf16_pipe_kernel",
+                                         {"bf16x3": "32, true>, 0, true", "bf16": "64, false>, 0, true", "f16mx": "256, 256"}[precision])
+                        if (precision in ("bf16", "bf16x3", "f16mx") and full_chunk) else None),
                avg_launch_ms=round(ms, 4), launches=n, flops_per_launch=mult * alg)
     if mult != 1.0:
         out["algorithmic_tflops"] = round(alg / (ms * 1e-3) / 1e12, 2)
@@ -978,6 +985,9 @@ def secondary_configs(ctx, args, rank):
             ("cfg2 mfcc", dict(workload="mfcc", steps=20, warmup=2)),
             ("cfg3 gmm-tied (4096 shared densities x 10000 states, batch 256)", dict(workload="gmm-tied", steps=20, warmup=3)),
             ("cfg3 gmm-cart (10000 x 16 densities, batch 256)", dict(workload="gmm", steps=50, warmup=5)),
+            ("cfg5-shard with the NN in split bf16 (round 3's default, the same 1e-4 bar at 3 MFMA products per product)",
+             dict(workload="pipeline", precision="bf16x3", steps=20, warmup=2)),
+            ("cfg4 nn f16mx (batch 1024)", dict(workload="nn", precision="f16mx", steps=50, warmup=5)),
             ("cfg4 nn bf16x3 (batch 1024)", dict(workload="nn", precision="bf16x3", steps=50, warmup=5)),
             ("cfg4 nn bf16 (batch 1024)", dict(workload="nn", precision="bf16", steps=50, warmup=5))]
     for name, over in plan:
@@ -1091,7 +1101,9 @@ def main():
         line = {"metric": "acoustic frames scored/sec (1e4-state AM)", "value": round(value, 1), "unit": "frames/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                "dtype": {"bf16": "bf16", "bf16x3": "bf16x3 (split bf16, three MFMA products per f32 product, f32 accumulate)", "fp32": "f32"}[args.precision]
+                "dtype": {"bf16": "bf16", "bf16x3": "bf16x3 (split bf16, three MFMA products per f32 product, f32 accumulate)", "fp32": "f32",
+                          "f16mx": "f16+mxfp6 (per f32 product: one f16 MFMA product + one block-scaled fp6 x fp6 MFMA product for both cross "
+                                   "terms, f32 accumulate)"}[args.precision]
                          if args.workload in ("pipeline", "nn-pipeline", "nn") else "f32",
                 "data": "synthetic", "config": {"workload": WORKLOAD_NAMES[args.workload](args), "frames_per_step_per_gpu": job.units},
                 "rtf": round(dt / (units * 0.01), 8), "build": rasr_amd.version()}

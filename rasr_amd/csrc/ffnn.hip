@@ -1587,18 +1587,42 @@ using MfgS = amx::mx::MxCfg<128, 64, 2, 2, 4>;   //  74 KB: small batches, three
 template<class C, int ACT, bool LAST>
 void launch_mx(amx_ffnn* h, int l, const void* x, int xkts, void* out, int ldo, int T, int Tpad, int n_valid) {
     const int ntn = h->Npad[l] / C::BN, ntt = Tpad / C::BT;
-    auto      k   = amx::mx::gemm_mx_kernel<C, ACT, LAST>;
     const int gt = h->group_t >= 0 ? h->group_t : (C::BN == 256 ? 16 : 8), gn = h->group_n >= 0 ? h->group_n : (C::BN == 256 ? 8 : 2);
     constexpr int lds_bytes = amx::gemm_scratch_bytes<C, LAST>() + C::BN * 4;
     static_assert(lds_bytes <= 160 * 1024, "LDS budget");
-    hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     const int per_cu = std::max(1, (160 * 1024) / lds_bytes);
     int       grid   = std::min(ntn * ntt, per_cu * std::max(h->ctx->n_cu, 8));
     if (grid >= 8)
         grid &= ~7;  // keep blockIdx % 8 == tile index % 8 for every stride step
-    hipLaunchKernelGGL(k, dim3(grid), dim3(C::THREADS), lds_bytes, h->ctx->stream, (const char*)h->d_W[l], (const char*)x, h->d_bias[l], out,
-                       h->Kpad[l] / 32, xkts, h->Npad[l] / 32, ldo, n_valid, T, ntn, ntn * ntt, gt, gn, LAST ? h->cur_part_min : nullptr,
-                       LAST ? h->cur_part_idx : nullptr, Tpad, h->d_overflow);
+#define AMX_MX_LAUNCH(DBG)                                                                                                                  \
+    do {                                                                                                                                    \
+        auto k = amx::mx::gemm_mx_kernel<C, ACT, LAST, DBG>;                                                                                \
+        hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);                                         \
+        hipLaunchKernelGGL(k, dim3(grid), dim3(C::THREADS), lds_bytes, h->ctx->stream, (const char*)h->d_W[l], (const char*)x, h->d_bias[l], \
+                           out, h->Kpad[l] / 32, xkts, h->Npad[l] / 32, ldo, n_valid, T, ntn, ntn * ntt, gt, gn,                            \
+                           LAST ? h->cur_part_min : nullptr, LAST ? h->cur_part_idx : nullptr, Tpad, h->d_overflow);                        \
+    } while (0)
+    int dbg = 0;
+#ifdef AMX_LAB  // ablations of the large-batch kernel (tools/ab_mx.sh, profiles/r04/gemm_mx_ablation.log)
+    if (const char* e = getenv("AMX_MX_DBG"))
+        dbg = atoi(e);
+    if constexpr (C::BN == 256 && ACT == AMX_ACT_RELU * (LAST ? 0 : 1)) {
+        switch (dbg) {
+            case 8: AMX_MX_LAUNCH(8); break;
+            case 16: AMX_MX_LAUNCH(16); break;
+            case 24: AMX_MX_LAUNCH(24); break;
+            case 32: AMX_MX_LAUNCH(32); break;
+            case 64: AMX_MX_LAUNCH(64); break;
+            case 72: AMX_MX_LAUNCH(72); break;
+            default: dbg = 0; break;
+        }
+    }
+    else
+        dbg = 0;
+#endif
+    if (dbg == 0)
+        AMX_MX_LAUNCH(0);
+#undef AMX_MX_LAUNCH
     if (LAST)
         h->cur_ntn = ntn;
 }

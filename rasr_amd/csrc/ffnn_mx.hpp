@@ -249,6 +249,12 @@ __device__ __forceinline__ void piece_offsets(int p, int ha, int hb, int& src, i
     }
 }
 
+// ablation builds: keep a register value alive without using it (plain __device__ functions: the host pass does not look at their asm;
+// as a template the substitution failed on the host -- silently, and the kernel's host stub was never emitted)
+__device__ __forceinline__ void keep_alive(const v8i& v) { asm volatile("" ::"v"(v)); }
+__device__ __forceinline__ void keep_alive(const f16x8& v) { asm volatile("" ::"v"(v)); }
+__device__ __forceinline__ void keep_alive(unsigned v) { asm volatile("" ::"v"(v)); }
+
 template<int N>
 __device__ __forceinline__ void mx_wait() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -274,7 +280,9 @@ __device__ __forceinline__ u32x6 q_fields(f16x8 c0, f16x8 c1, unsigned scale_byt
 // of X); hidden layers write the next layer's blocks (ktn K-tiles per row block), the output layer f32 scores [T x n_valid] =
 // -(D + bias) with the arg-min partials of the fused statistics.  Persistent workgroups, XCD-aware tile order, STAGES-deep LDS
 // ring with ONE barrier per K-tile and counted vmcnt (never a drain inside the loop).
-template<class C, int ACT, bool LAST>
+// DBG (lab builds only, -DAMX_LAB + AMX_MX_DBG): 8 no matrix instructions, 16 no operand DMA after the prologue, 32 no scaled product
+// (conversions and MX MFMAs skipped), 64 every workgroup streams one of 8 tiles (all operands L2 hits)
+template<class C, int ACT, bool LAST, int DBG = 0>
 __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const char* __restrict__ W, const char* __restrict__ X, const float* __restrict__ bias,
                                                             void* __restrict__ out, int KT, int xkts, int ktn, int ldo, int n_valid, int t_valid,
                                                             int n_tiles_n, int n_tiles_total, int GT, int GN, float* __restrict__ part_min,
@@ -307,6 +315,10 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const char* __restr
                 tile_n = v - tile_t * n_tiles_n;
             }
         }
+        if constexpr ((DBG & 64) != 0) {
+            tile_t = blockIdx.x & 7;
+            tile_n = 0;
+        }
         const int   n0 = tile_n * C::BN, t0 = tile_t * C::BT;
         const char* wblk = W + (size_t)(n0 >> 8) * KT * BLK;
         const char* xblk = X + (size_t)(t0 >> 8) * xkts * BLK;  // xkts >= KT: the producer padded its outputs to 256
@@ -325,15 +337,22 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const char* __restr
                 p_b[q]              = false;
             }
         }
+        // 1 KB per wave-instruction straight into LDS (LDS address = M0 + lane * 16; global address = scalar base + lane * 16).  Inline
+        // assembly on purpose: for an LDS-DMA it knows about, the compiler's wait-count pass puts s_waitcnt vmcnt(0) in front of the
+        // first LDS read it cannot prove disjoint -- here a record read of the CURRENT stage, i.e. every K-tile drained the two K-tiles
+        // in flight (found in the ISA; the ablation table of profiles/r04/gemm_mx_ablation.log was taken with that drain in place).
+        // The ordering is explicit: counted vmcnt + s_barrier at the top of a K-tile.  Nothing else in the kernel uses M0.
         const unsigned voff = (unsigned)lane * 16u;
+        const unsigned lds_base = (unsigned)(uintptr_t)lds;
         auto stage = [&](int slot, int kt) {
-            char* base = lds + slot * C::STAGE_BYTES;
+            const unsigned base = lds_base + slot * C::STAGE_BYTES;
 #pragma unroll
             for (int q = 0; q < C::PPW; ++q) {
                 if (q == C::PPW - 1 && !hi_wave)
                     break;
-                const char* src = (p_b[q] ? xblk : wblk) + (size_t)kt * BLK + p_src[q];
-                __builtin_amdgcn_global_load_lds((const void*)(src + voff), (__attribute__((address_space(3))) void*)(base + p_dst[q]), 16, 0, 0);
+                const char*    src = (p_b[q] ? xblk : wblk) + (size_t)kt * BLK + p_src[q];
+                const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(base + p_dst[q]));
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(src), "s"(dst) : "memory");
             }
         };
 
@@ -374,7 +393,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const char* __restr
                     mx_wait<0>();
             }
             __builtin_amdgcn_s_barrier();
-            if (kt + C::STAGES - 1 < KT)
+            if (kt + C::STAGES - 1 < KT && !(DBG & 16))
                 stage((kt + C::STAGES - 1) % C::STAGES, kt + C::STAGES - 1);
             const char* ab = lds + (kt % C::STAGES) * C::STAGE_BYTES;
             const char* bb = ab + C::A_BYTES;
@@ -391,18 +410,35 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const char* __restr
             }
 #pragma unroll
             for (int i = 0; i < C::MI; ++i)
-                ra[i] = *(const uint4*)(ab + C::A_R + fk * (C::BN * 16) + (a_row + 32 * i) * 16);
+                ra[i] = __builtin_bit_cast(uint4, *(const f16x8*)(ab + C::A_R + fk * (C::BN * 16) + (a_row + 32 * i) * 16));  // typed like the fragment reads: a uint4 read made the compiler drain vmcnt in front of it
 #pragma unroll
             for (int j = 0; j < C::MJ; ++j)
-                rb[j] = *(const uint4*)(bb + C::B_R + fk * (C::BT * 16) + (b_row + 32 * j) * 16);
+                rb[j] = __builtin_bit_cast(uint4, *(const f16x8*)(bb + C::B_R + fk * (C::BT * 16) + (b_row + 32 * j) * 16));
             // the same order in every configuration: h.h of k-slab 0, of k-slab 1, then the scaled cross product
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
                 for (int i = 0; i < C::MI; ++i)
 #pragma unroll
-                    for (int j = 0; j < C::MJ; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks][i], b[ks][j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < C::MJ; ++j) {
+                        if constexpr ((DBG & 8) != 0)
+                        {
+                            keep_alive(a[ks][i]);
+                            keep_alive(b[ks][j]);
+                        }
+                        else
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks][i], b[ks][j], acc[i][j], 0, 0, 0);
+                    }
+            if constexpr ((DBG & 32) != 0) {
+#pragma unroll
+                for (int i = 0; i < C::MI; ++i)
+                    keep_alive(ra[i].x), keep_alive(ra[i].y), keep_alive(ra[i].z), keep_alive(ra[i].w);
+#pragma unroll
+                for (int j = 0; j < C::MJ; ++j)
+                    keep_alive(rb[j].x), keep_alive(rb[j].y), keep_alive(rb[j].z), keep_alive(rb[j].w);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                continue;
+            }
             v8i av[C::MI], bv[C::MJ];
 #pragma unroll
             for (int i = 0; i < C::MI; ++i) {
@@ -417,8 +453,15 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const char* __restr
 #pragma unroll
             for (int i = 0; i < C::MI; ++i)
 #pragma unroll
-                for (int j = 0; j < C::MJ; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av[i], bv[j], acc[i][j], 2, 2, 0, (int)ra[i].w, 0, (int)rb[j].w);
+                for (int j = 0; j < C::MJ; ++j) {
+                    if constexpr ((DBG & 8) != 0)
+                    {
+                        keep_alive(av[i]);
+                        keep_alive(bv[j]);
+                    }
+                    else
+                        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av[i], bv[j], acc[i][j], 2, 2, 0, (int)ra[i].w, 0, (int)rb[j].w);
+                }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
 
