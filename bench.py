@@ -66,6 +66,13 @@ def parse():
                     help="torch.distributed backend of the control plane: nccl (= RCCL; GPU runs) or gloo (the CPU launcher test)")
     ap.add_argument("--utterances", type=int, default=64, help="utterances per step and rank (pipeline / mfcc)")
     ap.add_argument("--utt-seconds", type=float, default=10.0)
+    ap.add_argument("--ingest", default="auto", choices=["auto", "resident", "streamed"],
+                    help="pipeline / nn-pipeline / gmm-train: where a step's audio comes from.  resident: the same 64 utterances, f32, already in "
+                         "HBM (the single-GPU `value`: inputs resident when the timed region starts).  streamed: every step takes the NEXT "
+                         "utterances of the rank's corpus partition as s16 from pinned host memory over the host link into a "
+                         "double-buffered HBM slot (copy stream, events), so the timed region carries the ingest.  auto = resident on "
+                         "one GPU (the line then also reports the streamed rate next to it), streamed for --gpus N > 1")
+    ap.add_argument("--corpus-hours", type=float, default=100.0, help="size of the synthetic corpus all ranks share (config 5: 100 h)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the secondary BASELINE configs of the default run")
     ap.add_argument("--precision", default="f16mx", choices=["bf16", "bf16x3", "f16mx", "fp32"],
@@ -176,6 +183,91 @@ def make_batch(n_utt, seconds, seed):
     return pcm, off
 
 
+def ingest_mode(args, world):
+    m = getattr(args, "ingest", "auto")
+    return m if m != "auto" else ("streamed" if world > 1 else "resident")
+
+
+class StreamedIngest:
+    """The audio of BASELINE config 5 as a rank of the job sees it: a corpus of `--corpus-hours` of utterances, of which this
+    rank owns the partition `i % world == rank` (rasr_amd.partition.CorpusWalker = the reference's partition rule,
+    Bliss/CorpusDescription.cc:174-190).  The samples wait in pinned host memory as s16 -- what the audio files hold; the kernel
+    widens them like Flow/TypeConverter.hh:35-43 -- and every step's batch crosses the host link inside the timed region:
+    one hipMemcpyAsync per batch on a copy stream into one of two HBM slots; the MFCC kernel of step k waits for slot k % 2's
+    event, the copy of batch k + 2 waits for the event recorded behind that kernel.
+
+    Host memory holds the rank's first `resident_batches` batches (a window of the partition: generating 12.5 h of synthetic
+    audio per rank would only lengthen start-up); the walker keeps handing out the partition's real indices and the window
+    wraps.  All utterances have `seconds` s, so one MFCC plan serves every batch."""
+
+    def __init__(self, args, rank, world, n_steps):
+        import torch
+
+        from rasr_amd.partition import CorpusWalker
+        from tests import synth
+        self.torch = torch
+        n = int(round(args.utt_seconds * 16000))
+        self.n, self.B = n, args.utterances
+        n_global = max(int(args.corpus_hours * 3600.0 / args.utt_seconds), self.B * world)
+        self.walker = CorpusWalker(n_global, world, rank, self.B)
+        self.n_global, self.n_local = n_global, len(self.walker.segments)
+        nb = max(2, min(self.walker.batches_per_epoch(), n_steps + 2))
+        base = synth.waveform(n + 8192, seed=9).astype(np.int16)       # utterance g = the base waveform rotated by g (all different)
+        host = torch.empty((nb * self.B, n), dtype=torch.int16).pin_memory()
+        hv = host.numpy()
+        w = CorpusWalker(n_global, world, rank, self.B)
+        self.window = []
+        for b in range(nb):
+            ids = w.next_batch()
+            self.window.append(ids)
+            for j, g in enumerate(ids):
+                r = int(g) % 8192
+                hv[b * self.B + j] = base[r:r + n]
+            for j in range(len(ids), self.B):                          # short last batch of the partition: padded with silence
+                hv[b * self.B + j] = 0
+        self.host, self.nb = host, nb
+        self.slots = [torch.empty((self.B * n,), dtype=torch.int16, device="cuda") for _ in range(2)]
+        self.ready = [torch.cuda.Event(), torch.cuda.Event()]
+        self.free = [torch.cuda.Event(), torch.cuda.Event()]
+        self.copy_stream = torch.cuda.Stream()
+        self.issued = 0          # batches handed to the copy stream
+        self.taken = 0           # batches handed to the compute stream
+        self.visited = []        # corpus indices, in the order this rank scored them
+        self.bytes_per_batch = self.B * n * 2
+        self._issue(first=True)
+        self._issue(first=True)
+
+    def _issue(self, first=False):
+        torch = self.torch
+        slot = self.issued % 2
+        b = self.issued % self.nb
+        with torch.cuda.stream(self.copy_stream):
+            if not first:
+                self.copy_stream.wait_event(self.free[slot])           # the kernel that read this slot has finished
+            self.slots[slot].view(self.B, self.n).copy_(self.host[b * self.B:(b + 1) * self.B], non_blocking=True)
+            self.ready[slot].record(self.copy_stream)
+        self.issued += 1
+
+    def take(self):
+        """the next batch, as an s16 tensor in HBM; the caller's stream waits for its copy"""
+        slot = self.taken % 2
+        self.torch.cuda.current_stream().wait_event(self.ready[slot])
+        self.visited.append(self.walker.next_batch())
+        return self.slots[slot]
+
+    def release(self):
+        """behind the kernel that read the batch: the slot may be overwritten, the next copy starts"""
+        slot = self.taken % 2
+        self.free[slot].record(self.torch.cuda.current_stream())
+        self.taken += 1
+        self._issue()
+
+    def report(self):
+        return dict(mode="streamed", sample_format="s16", bytes_over_link_per_step=self.bytes_per_batch, corpus_utterances=self.n_global,
+                    rank_partition_utterances=self.n_local, host_window_batches=self.nb,
+                    path="pinned host s16 -> hipMemcpyAsync (copy stream) -> 2 HBM slots -> amx_mfcc_run_plan_dev_s16 behind an event")
+
+
 def gmm_cart_roofline(ctx, sc, nk, n_mix, dim, frames):
     """roofline entry of the screened private-density GMM scorer.
 
@@ -265,6 +357,7 @@ class NnPipeline:
         self.plan = self.fe.plan(off)
         self.F = self.plan.total_frames
         self.pcm = torch.from_numpy(pcm).cuda()
+        self.setup_ingest(args, rank)
         self.ceps = torch.empty((self.F, 40), dtype=torch.float32, device="cuda")
         self.ctxwin = torch.empty((self.F, 440), dtype=torch.float32, device="cuda")
         dims = [440] + [2048] * 6 + [10000]
@@ -277,6 +370,23 @@ class NnPipeline:
         self.make_reduce_buffer()
         self.units = self.F
 
+    def setup_ingest(self, args, rank):
+        self.args, self.rank, self.world = args, rank, getattr(args, "_world", 1)
+        self.ingest = StreamedIngest(args, rank, self.world, args.steps + args.warmup) if ingest_mode(args, self.world) == "streamed" else None
+
+    def torch_mod(self):
+        import torch
+        return torch
+
+    def front_end(self):
+        """audio -> cepstra: from the resident batch, or from the next batch of the rank's corpus partition (StreamedIngest)"""
+        if self.ingest is None:
+            self.fe.run_plan(self.plan, self.pcm, self.ceps)
+            return
+        pcm = self.ingest.take()
+        self.fe.run_plan(self.plan, pcm, self.ceps)
+        self.ingest.release()
+
     def reduce_fields(self):
         return [("score_sum", 1, "f64"), ("counts", self.M, "count")]
 
@@ -288,7 +398,7 @@ class NnPipeline:
         self.score_sum = self.red.view("score_sum")
 
     def step(self):
-        self.fe.run_plan(self.plan, self.pcm, self.ceps)
+        self.front_end()
         self.ctx.context_window(self.plan, self.ceps, 40, 5, 5, self.ctxwin, 440)
         for t0 in range(0, self.F, self.CHUNK):
             T = min(self.CHUNK, self.F - t0)
@@ -367,7 +477,7 @@ class Pipeline(NnPipeline):
 
     def step(self):
         torch = self.torch
-        self.fe.run_plan(self.plan, self.pcm, self.ceps)
+        self.front_end()
         if not os.environ.get("AMX_BENCH_TWO_STREAMS"):  # both legs saturate the GPU: overlapping them gained < 2 %
             self.gmm_leg()
             self.nn_leg()
@@ -420,6 +530,7 @@ class GmmTrain:
         self.plan = self.fe.plan(off)
         self.F = self.plan.total_frames
         self.pcm = torch.from_numpy(pcm).cuda()
+        self.setup_ingest(args, rank)
         self.ceps = torch.empty((self.F, 40), dtype=torch.float32, device="cuda")
         model = synth.gmm_cart(10000, 16, 16, 40, seed=5, pooled=True)
         self.nk = int(model["mix_offsets"][-1])
@@ -435,9 +546,13 @@ class GmmTrain:
         self.units = self.F
         self.baum_welch = getattr(args, "estimation_mode", "viterbi") == "baum-welch"
 
+    setup_ingest = NnPipeline.setup_ingest
+    front_end = NnPipeline.front_end
+    torch_mod = NnPipeline.torch_mod
+
     def step(self):
         import rasr_amd
-        self.fe.run_plan(self.plan, self.pcm, self.ceps)
+        self.front_end()
         for t0 in range(0, self.F, self.CHUNK):
             T = min(self.CHUNK, self.F - t0)
             x = self.ceps[t0:]
@@ -623,12 +738,15 @@ class GmmOnly:
                 launches = triples / float(4096 * self.T * 157) if self.T else 1.0
                 rows = (self.T * 32.0 * 10048 * 2 + (surv / max(launches, 1.0)) * 256.0 + self.T * 10000 * 8.0 + self.T * 4096 * 12.0)
                 by = self.nk * 4.0 + self.T * 10000 * 8.0 + self.T * 40 * 4.0
+                ms_d, n_d = self.ctx.profile_get("gmm_dist")     # the distance kernel the `kernel` string names belongs to the time
+                ms_combine, ms = ms, ms + (ms_d if n_d else 0.0)
                 gbs = by / (ms * 1e-3) / 1e9
                 return dict(bound="hbm", kernel="tied_pruned_kernel + tied_bound_kernel + gmm_dist_kernel (+ tied_mask / tied_transpose / tied_list / tied_near)",
                             note="exact pruning: bounds from 32 near densities per frame, then the reference's f64 rule over the surviving "
                                  "(density, frame, 64-mixture tile) triples only; algorithmic bytes = weight table once per batch + results",
                             achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4), traffic=None,
                             avg_launch_ms=round(ms, 4), launches=n, bytes_per_launch=by,
+                            time_is="gmm_dist (%.4f ms) + gmm_combine (%.4f ms: near / bound / list / mask / pruned kernels)" % (ms - ms_combine, ms_combine),
                             l2_rows_GBps=round(rows / (ms * 1e-3) / 1e9, 1),
                             surviving_fraction=round(surv / float(triples), 5),
                             dense_equivalent_tops=round(ops / (ms * 1e-3) / 1e12, 2),
@@ -700,7 +818,21 @@ class NnOnly:
         ms, n = self.ctx.profile_get("ffnn_gemm_max")
         if n == 0:
             return None
-        return nn_gemm_roofline(self.nn_precision, ms, n, self.T, False)
+        out = nn_gemm_roofline(self.nn_precision, ms, n, self.T, False)
+        # the whole network (7 GEMMs + packing), not only its largest layer: matrix-pipe time of all layers / time of the pass
+        ms_all, n_all = self.ctx.profile_get("ffnn_gemm")
+        ms_pk, n_pk = self.ctx.profile_get("ffnn_pack")
+        if n_all:
+            per_pass = ms_all * n_all / n + (ms_pk * n_pk / n if n_pk else 0.0)
+            out["whole_network"] = self.whole_network(per_pass, "sum of the pass's kernels, plain launches (HIP events)")
+        return out
+
+    def whole_network(self, ms_per_pass, what):
+        mult = {"bf16x3": 3.0, "f16mx": 1.5}.get(self.nn_precision, 1.0)
+        peak = FP32_TFLOPS if self.nn_precision == "fp32" else MFMA_BF16_TFLOPS
+        ach = mult * self.flops / (ms_per_pass * 1e-3) / 1e12
+        return dict(achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4), ms_per_pass=round(ms_per_pass, 4), time_is=what,
+                    algorithmic_tflops=round(self.flops / (ms_per_pass * 1e-3) / 1e12, 2))
 
     def stage_report(self):
         out = {}
@@ -727,9 +859,17 @@ class NullJob:
         self.units = int(self.frames.sum())
         self.red = EpochReduceBuffer([("score_sum", 1, "f64"), ("counts", self.N_STATES, "count"), ("frames", 1, "count")], device="cpu")
         self.steps_done = 0
+        # --ingest streamed: the corpus walk of StreamedIngest without the copies -- which utterances this rank would stream
+        self.walker, self.visited, self.world, self.rank = None, [], world, rank
+        if ingest_mode(args, world) == "streamed":
+            from rasr_amd.partition import CorpusWalker
+            self.n_corpus = max(int(args.corpus_hours * 3600.0 / args.utt_seconds), args.utterances * world)
+            self.walker = CorpusWalker(self.n_corpus, world, rank, args.utterances)
 
     def step(self):
         import torch
+        if self.walker is not None:
+            self.visited.append(self.walker.next_batch())
         self.red.view("counts").add_(torch.from_numpy(np.bincount(np.asarray(self.mine) % self.N_STATES, weights=self.frames,
                                                                   minlength=self.N_STATES).astype(np.int64)))
         self.red.view("frames").add_(int(self.units))
@@ -747,7 +887,26 @@ class NullJob:
         all_frames = 100 + 7 * (np.arange(self.n_total) % 5)
         want = int(all_frames.sum()) * self.steps_done
         got = int(self.red.view("frames")[0])
-        return {"reduced_frames": got, "expected_frames": want, "reduce_ok": bool(got == want and int(self.red.view("counts").sum()) == want)}
+        out = {"reduced_frames": got, "expected_frames": want, "reduce_ok": bool(got == want and int(self.red.view("counts").sum()) == want)}
+        if self.walker is not None:
+            out["corpus_walk"] = self.walk_report()
+        return out
+
+    def gather_walks(self):
+        """every rank's visited list on every rank (control plane, gloo); called by all ranks"""
+        import torch.distributed as dist
+        mine = np.concatenate(self.visited).tolist() if self.visited else []
+        self.walks = [mine]
+        if dist.is_available() and dist.is_initialized():
+            self.walks = [None] * self.world
+            dist.all_gather_object(self.walks, mine)
+
+    def walk_report(self):
+        allv = np.concatenate([np.asarray(w, dtype=np.int64) for w in self.walks]) if self.walks else np.zeros(0, np.int64)
+        per_rank_ok = all(all(int(g) % self.world == r for g in w) for r, w in enumerate(self.walks))
+        return {"corpus_utterances": self.n_corpus, "visited": int(len(allv)), "distinct": int(len(np.unique(allv))),
+                "ranks_disjoint": bool(len(np.unique(allv)) == len(allv) or self.walker.epoch > 0),
+                "every_rank_in_its_partition": bool(per_rank_ok), "first_of_each_rank": [w[:3] for w in self.walks]}
 
 
 # ----------------------------------------------------------------------------------------------- CPU baseline
@@ -894,7 +1053,57 @@ def cpu_baseline(workload):
                 sample=detail + " (" + "; ".join(notes + [vtxt]) + "; oracle built %s)" % ("-O3 -march=native -ffp-contract=off" if native else "-O2"))
 
 
+def parity_check(ctx, job, args, n_nn=256, n_gmm=24):
+    """Part of the cpu_baseline leg: the oracle as the CHECKER of this run's scorers on a sample of the frames the timed steps
+    scored (the first frames of the last batch: real cepstra / context windows of the job, not a separate input).
+      nn:  every score of n_nn frames against the f64-accumulating oracle (Nn/LinearLayer.cc:298-324 arithmetic with exact sums) --
+           worst error over the 1e-4 |ref| + 1e-4 bar, worst PURE relative error over |ref| > 1e-2, arg-min mismatches over all
+           sampled frames against the oracle and against the library's exact-f32 MFMA path, frames a 1e-5 gap rule would exclude
+           (tests/parity.py; the contract is what a decoder reads, Nn/BatchFeatureScorer.cc:92-171)
+      gmm: scores and best-density indices of n_gmm frames x 10 000 mixtures, bit for bit (Mm/GaussDiagonalMaximumFeatureScorer.cc:116-180)"""
+    import torch
+
+    import rasr_amd
+    from oracle import OracleGmm, oracle_ffnn_score
+    from tests import synth
+    from tests.parity import nn_parity_report
+    out = {}
+    torch.cuda.synchronize()
+    if hasattr(job, "nn"):
+        dims = [440] + [2048] * 6 + [10000]
+        Ws, bs, acts, logp = synth.ffnn(dims, seed=7)
+        x = job.ctxwin[:n_nn].contiguous()
+        got = torch.empty((n_nn, 10000), dtype=torch.float32, device="cuda")
+        job.nn.score_dev(x, 440, n_nn, got)
+        f32 = torch.empty_like(got)
+        rasr_amd.NnBatchFeatureScorer(ctx, Ws, bs, acts, log_prior=logp, priori_scale=1.0, precision="fp32").score_dev(x, 440, n_nn, f32)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        want = oracle_ffnn_score(Ws, bs, acts, x.cpu().numpy(), log_prior=logp, prior_scale=1.0, acc64=True)
+        rep = nn_parity_report(got.cpu().numpy(), want, other=f32.cpu().numpy(), gap=1e-5)
+        rep.update(precision=args.precision, reference="oracle_ffnn_score(acc64=True) on the job's own context windows",
+                   oracle_seconds=round(time.perf_counter() - t0, 2))
+        out["nn"] = rep
+    g = getattr(job, "gmm", None) or getattr(job, "sc", None)
+    if g is not None:
+        model = synth.gmm_cart(10000, 16, 16, 40, seed=5, pooled=True)
+        x = job.ceps[:n_gmm].contiguous()
+        sc = torch.empty((n_gmm, 10000), dtype=torch.float32, device="cuda")
+        bd = torch.empty((n_gmm, 10000), dtype=torch.int32, device="cuda")
+        g.score_dev(x, n_gmm, sc, bd)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ws, wb = OracleGmm(model).score(x.cpu().numpy(), mode=0, want_best=True)
+        gs, gb = sc.cpu().numpy(), bd.cpu().numpy()
+        out["gmm"] = dict(frames=n_gmm, scores=int(gs.size), score_bit_mismatches=int((gs.view(np.uint32) != ws.view(np.uint32)).sum()),
+                          best_density_mismatches=int((gb.astype(np.int64) != wb.astype(np.int64)).sum()),
+                          reference="OracleGmm.score (orc_score.c, diagonal-maximum) on the job's own cepstra",
+                          oracle_seconds=round(time.perf_counter() - t0, 2))
+    return out
+
+
 def make_job(ctx, args, rank, world=1):
+    args._world = world
     if args.workload == "null":
         return NullJob(args, rank, world)
     if args.workload in ("pipeline", "nn-pipeline"):
@@ -972,6 +1181,39 @@ WORKLOAD_NAMES = {
                            "%d utterances x %.0f s per step and rank" % (a.utterances, a.utt_seconds)}
 
 
+def streamed_comparison(ctx, job, args, resident_value):
+    """Single-GPU line: the same job once more with its audio streamed (StreamedIngest) and once with the batch resident as s16 --
+    the streamed run's kernel -- so that the cost of the ingest is on record next to the resident `value`.  Called after the
+    roofline / stage numbers of the headline have been read (the profiler is reset here)."""
+    a = copy_args(args, ingest="streamed")
+    ing = StreamedIngest(a, job.rank, 1, a.steps + a.warmup)
+    job.ingest = ing
+    dt = measure(ctx, job, a, 1)
+    streamed = job.units * a.steps / dt
+    visited = np.concatenate(ing.visited)
+    job.ingest = None
+    pcm32 = job.pcm
+    job.pcm = pcm32.to(job.torch_mod().int16) if hasattr(job, "torch_mod") else pcm32
+    dt16 = measure(ctx, job, a, 1)
+    job.pcm = pcm32
+    res16 = job.units * a.steps / dt16
+    out = ing.report()
+    del out["mode"]
+    out.update(frames_per_s=round(streamed, 1), ms_per_step=round(1e3 * dt / a.steps, 4), resident_s16_frames_per_s=round(res16, 1),
+               streamed_over_resident=round(streamed / resident_value, 4), streamed_over_resident_s16=round(streamed / res16, 4),
+               link_GBps=round(ing.bytes_per_batch * a.steps / dt / 1e9, 3),
+               utterances_visited=int(len(visited)), distinct_utterances_visited=int(len(np.unique(visited))))
+    return out
+
+
+def copy_args(args, **over):
+    import copy
+    a = copy.copy(args)
+    for k, v in over.items():
+        setattr(a, k, v)
+    return a
+
+
 def secondary_configs(ctx, args, rank):
     """The other BASELINE configs and the plain-bf16 variant of the headline, measured in the same process (rank 0, one GPU):
     short runs of the single-stage workloads so that the driver's record carries them next to the headline."""
@@ -1001,6 +1243,14 @@ def secondary_configs(ctx, args, rank):
             out[name] = dict(value=round(job.units * a.steps / dt, 1), unit="frames/s", ms_per_step=round(1e3 * dt / a.steps, 4),
                              kernel=r.get("kernel"), roofline_frac=r.get("frac"), roofline_bound=r.get("bound"),
                              workload=WORKLOAD_NAMES[a.workload](a))
+            if a.workload == "nn":
+                # config 4: `roofline_frac` is the WHOLE network against the wall time of a pass (HIP-graph replay); the largest
+                # layer's own figure stays next to it
+                wn = job.whole_network(1e3 * dt / a.steps, "wall time of one pass (HIP-graph replay)")
+                out[name].update(roofline_frac=wn["frac"], output_layer_frac=r.get("frac"), whole_network=wn,
+                                 kernel="all 7 GEMMs of the pass; largest: " + str(r.get("kernel")))
+            if r.get("time_is"):
+                out[name]["time_is"] = r["time_is"]
         except Exception as e:  # a secondary line must never take the headline down
             out[name] = dict(error=str(e)[:200])
         job = None
@@ -1060,6 +1310,8 @@ def main():
         job = make_job(None, args, rank, world)
         dt = measure(None, job, args, world)
         import torch
+        if job.walker is not None:
+            job.gather_walks()
         t = torch.tensor([dt], dtype=torch.float64)
         if _dist_on():
             import torch.distributed as dist
@@ -1071,7 +1323,7 @@ def main():
                               "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                               "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
                               "vs_baseline": None, "dtype": "none", "data": "synthetic",
-                              "config": {"workload": "null (no GPU work)", "backend": "gloo"},
+                              "config": {"workload": "null (no GPU work)", "backend": "gloo", "ingest": ingest_mode(args, world)},
                               "epoch_reduce": dict(collectives=1, bytes=job.red.nbytes(), backend="gloo (CPU stand-in)"),
                               "stages": job.stage_report()}))
         if _dist_on():
@@ -1111,6 +1363,16 @@ def main():
         if line["roofline"] and line["roofline"].get("traffic") is not None:
             line["roofline"]["traffic_source"] = TRAFFIC_SOURCE + " (offline rocprofv3 --pmc passes on the profiling box, not this run)"
         line["stages"] = job.stage_report()
+        if getattr(job, "ingest", None) is not None:
+            line["ingest"] = job.ingest.report()
+        elif hasattr(job, "setup_ingest") and world == 1:
+            line["ingest"] = dict(mode="resident", sample_format="f32", bytes_over_link_per_step=0,
+                                  note="the same %d utterances every step, in HBM before the timed region" % args.utterances)
+            try:
+                with torch.cuda.stream(stream):
+                    line["ingest"]["streamed"] = streamed_comparison(ctx, job, args, value)
+            except Exception as e:  # never take the headline down
+                line["ingest"]["streamed"] = dict(error=str(e)[:200])
         if hasattr(job, "red"):
             ms_ar, n_ar = ctx.profile_get("all_reduce")
             line["epoch_reduce"] = dict(collectives=1, bytes=job.red.nbytes(),
@@ -1121,6 +1383,13 @@ def main():
             cb = cpu_baseline(args.workload)
             line["cpu_baseline"] = cb
             line["speedup_vs_cpu"] = round(value / world / cb["value"], 1)
+            if args.workload in ("pipeline", "nn-pipeline", "gmm-train"):
+                try:
+                    with torch.cuda.stream(stream):
+                        ctx.use_torch_stream()
+                        line["parity_check"] = parity_check(ctx, job, args)
+                except Exception as e:  # never take the headline down
+                    line["parity_check"] = dict(error=str(e)[:300])
         if args.workload == "pipeline" and world == 1 and not args.no_configs:
             job = None
             torch.cuda.empty_cache()

@@ -1609,11 +1609,21 @@ void launch_mx(amx_ffnn* h, int l, const void* x, int xkts, void* out, int ldo, 
     if constexpr (C::BN == 256 && ACT == AMX_ACT_RELU * (LAST ? 0 : 1)) {
         switch (dbg) {
             case 8: AMX_MX_LAUNCH(8); break;
-            case 16: AMX_MX_LAUNCH(16); break;
             case 24: AMX_MX_LAUNCH(24); break;
             case 32: AMX_MX_LAUNCH(32); break;
             case 64: AMX_MX_LAUNCH(64); break;
             case 72: AMX_MX_LAUNCH(72); break;
+            case 128: AMX_MX_LAUNCH(128); break;
+            case 136: AMX_MX_LAUNCH(136); break;
+            case 152: AMX_MX_LAUNCH(152); break;
+            case 256: AMX_MX_LAUNCH(256); break;
+            case 280: AMX_MX_LAUNCH(280); break;
+            case 512: AMX_MX_LAUNCH(512); break;
+            case 768: AMX_MX_LAUNCH(768); break;
+            case 1024: AMX_MX_LAUNCH(1024); break;
+            case 1032: AMX_MX_LAUNCH(1032); break;
+            case 1160: AMX_MX_LAUNCH(1160); break;
+            case 16: AMX_MX_LAUNCH(16); break;
             default: dbg = 0; break;
         }
     }

@@ -207,6 +207,10 @@ template<int BN_, int BT_, int WN_, int WT_, int STAGES_>
 struct MxCfg {
     static constexpr int BN = BN_, BT = BT_, WN = WN_, WT = WT_, STAGES = STAGES_;
     static constexpr int NW = WN * WT, THREADS = NW * 64, PLANES = 1;
+    // K-loop variants of gemm_mx_kernel, both measured on the output layer (profiles/r04/gemm_mx_ablation3.log: 2.17-2.31 ms in
+    // all four combinations, i.e. no gain) and left off: SKEW = the two waves of a SIMD half a K-tile apart, SPREAD = the LDS-DMA
+    // pieces issued between the matrix instructions instead of as a burst behind the barrier.  Lab builds flip them (DBG 256 / 512).
+    static constexpr bool SKEW = false, SPREAD = false;
     static constexpr int MI = BN / WN / 32, MJ = BT / WT / 32;
     static constexpr int A_R = BN * 64, A_BYTES = BN * 96;  // [H: 64 B/row][R: 2 halves x 16 B/row]
     static constexpr int B_R = BT * 64, B_BYTES = BT * 96;
@@ -281,7 +285,7 @@ __device__ __forceinline__ u32x6 q_fields(f16x8 c0, f16x8 c1, unsigned scale_byt
 // -(D + bias) with the arg-min partials of the fused statistics.  Persistent workgroups, XCD-aware tile order, STAGES-deep LDS
 // ring with ONE barrier per K-tile and counted vmcnt (never a drain inside the loop).
 // DBG (lab builds only, -DAMX_LAB + AMX_MX_DBG): 8 no matrix instructions, 16 no operand DMA after the prologue, 32 no scaled product
-// (conversions and MX MFMAs skipped), 64 every workgroup streams one of 8 tiles (all operands L2 hits)
+// (conversions and MX MFMAs skipped), 64 every workgroup streams one of 8 tiles (all operands L2 hits), 128 no fp6 conversions, 256 wave skew, 512 LDS-DMA pieces spread between the products, 1024 rotated K walk per tile
 template<class C, int ACT, bool LAST, int DBG = 0>
 __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const char* __restrict__ W, const char* __restrict__ X, const float* __restrict__ bias,
                                                             void* __restrict__ out, int KT, int xkts, int ktn, int ldo, int n_valid, int t_valid,
@@ -344,16 +348,22 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const char* __restr
         // The ordering is explicit: counted vmcnt + s_barrier at the top of a K-tile.  Nothing else in the kernel uses M0.
         const unsigned voff = (unsigned)lane * 16u;
         const unsigned lds_base = (unsigned)(uintptr_t)lds;
-        auto stage = [&](int slot, int kt) {
-            const unsigned base = lds_base + slot * C::STAGE_BYTES;
-#pragma unroll
-            for (int q = 0; q < C::PPW; ++q) {
-                if (q == C::PPW - 1 && !hi_wave)
-                    break;
-                const char*    src = (p_b[q] ? xblk : wblk) + (size_t)kt * BLK + p_src[q];
-                const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(base + p_dst[q]));
-                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(src), "s"(dst) : "memory");
+        auto piece = [&](int q, int slot, int kt) {  // q: compile-time constant after unrolling
+            if (q == C::PPW - 1 && !hi_wave)
+                return;
+            int ktm = kt;
+            if constexpr ((DBG & 1024) != 0) {  // ablation: every tile starts its walk over K somewhere else (other L2 channels)
+                ktm = kt + (tile_n * 5 + tile_t * 3) % KT;
+                ktm = ktm >= KT ? ktm - KT : ktm;
             }
+            const char*    src = (p_b[q] ? xblk : wblk) + (size_t)ktm * BLK + p_src[q];
+            const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_base + slot * C::STAGE_BYTES + p_dst[q]));
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(src), "s"(dst) : "memory");
+        };
+        auto stage = [&](int slot, int kt) {
+#pragma unroll
+            for (int q = 0; q < C::PPW; ++q)
+                piece(q, slot, kt);
         };
 
         f32x16 acc[C::MI][C::MJ];
@@ -374,7 +384,119 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const char* __restr
                 stage(s, s);
         const int frow = lane & 31, fk = lane >> 5;
         const int a_row = wn * WNR + frow, b_row = wt * WTT + frow;
-        for (int kt = 0; kt < KT; ++kt) {
+        // Register image of one K-tile: the f16 fragments of both k-slabs and the residual records.
+        f16x8 a[2][C::MI], b[2][C::MJ];
+        uint4 ra[C::MI], rb[C::MJ];
+        auto  reads = [&](int kt) {
+            const char* ab = lds + (kt % C::STAGES) * C::STAGE_BYTES;
+            const char* bb = ab + C::A_BYTES;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int i = 0; i < C::MI; ++i)
+                    a[ks][i] = *(const f16x8*)(ab + h_off(a_row + 32 * i, 2 * ks + fk));
+#pragma unroll
+                for (int j = 0; j < C::MJ; ++j)
+                    b[ks][j] = *(const f16x8*)(bb + h_off(b_row + 32 * j, 2 * ks + fk));
+            }
+#pragma unroll
+            for (int i = 0; i < C::MI; ++i)
+                ra[i] = __builtin_bit_cast(uint4, *(const f16x8*)(ab + C::A_R + fk * (C::BN * 16) + (a_row + 32 * i) * 16));  // typed like the fragment reads: a uint4 read made the compiler drain vmcnt in front of it
+#pragma unroll
+            for (int j = 0; j < C::MJ; ++j)
+                rb[j] = __builtin_bit_cast(uint4, *(const f16x8*)(bb + C::B_R + fk * (C::BT * 16) + (b_row + 32 * j) * 16));
+        };
+        // SPREAD variant: the LDS-DMA pieces of the K-tile that refills the freed stage are issued BETWEEN the matrix instructions,
+        // GAP apart (a piece holds the issuing wave for 100-200 cycles while the address unit takes its 1 KB, and a wave issues in
+        // order).  Measured: no gain over the burst behind the barrier (MxCfg).
+        constexpr int N_MFMA = 3 * C::MI * C::MJ, GAP = N_MFMA / C::PPW > 0 ? N_MFMA / C::PPW : 1;  // matrix instructions per piece
+        int           dma_kt = -1;  // K-tile whose pieces the next products() issues (-1: none)
+        auto products = [&]() {
+            int n_issued = 0;  // compile-time after unrolling
+            auto after_mfma = [&]() {
+                if constexpr (C::SPREAD != ((DBG & 512) != 0)) {
+                    if (n_issued % GAP == GAP / 2 && n_issued / GAP < C::PPW) {
+                        if (dma_kt >= 0)
+                            piece(n_issued / GAP, dma_kt % C::STAGES, dma_kt);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                ++n_issued;
+            };
+            // the same order in every configuration: h.h of k-slab 0, of k-slab 1, then the scaled cross product
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < C::MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < C::MJ; ++j) {
+                        if constexpr ((DBG & 8) != 0)
+                        {
+                            keep_alive(a[ks][i]);
+                            keep_alive(b[ks][j]);
+                        }
+                        else
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks][i], b[ks][j], acc[i][j], 0, 0, 0);
+                        after_mfma();
+                    }
+            if constexpr ((DBG & 32) != 0) {
+#pragma unroll
+                for (int i = 0; i < C::MI; ++i)
+                    keep_alive(ra[i].x), keep_alive(ra[i].y), keep_alive(ra[i].z), keep_alive(ra[i].w);
+#pragma unroll
+                for (int j = 0; j < C::MJ; ++j)
+                    keep_alive(rb[j].x), keep_alive(rb[j].y), keep_alive(rb[j].z), keep_alive(rb[j].w);
+                for (int m = 0; m < C::MI * C::MJ; ++m)
+                    after_mfma();
+                dma_kt = -1;
+                return;
+            }
+            v8i av[C::MI], bv[C::MJ];
+#pragma unroll
+            for (int i = 0; i < C::MI; ++i) {
+                u32x6 q;
+                if constexpr ((DBG & 128) != 0)
+                    q = u32x6{ra[i].y, ra[i].z, ra[i].x, 0, 0, 0};  // ablation: no conversion
+                else
+                    q = q_fields<true>(a[0][i], a[1][i], ra[i].w);  // q(w) = fp6(h(w) / 2^(Ew - 2))
+                av[i] = v8i{(int)q[0], (int)q[1], (int)q[2], (int)ra[i].x, (int)ra[i].y, (int)ra[i].z, 0, 0};
+            }
+#pragma unroll
+            for (int j = 0; j < C::MJ; ++j) {
+                u32x6 q;
+                if constexpr ((DBG & 128) != 0)
+                    q = u32x6{0, 0, 0, rb[j].y, rb[j].z, rb[j].x};
+                else
+                    q = q_fields<false>(b[0][j], b[1][j], rb[j].w + 11u);  // q(x) = fp6(h(x) / 2^(Ex - 2)); the record holds Ex - 13
+                bv[j] = v8i{(int)rb[j].x, (int)rb[j].y, (int)rb[j].z, (int)q[3], (int)q[4], (int)q[5], 0, 0};
+            }
+#pragma unroll
+            for (int i = 0; i < C::MI; ++i)
+#pragma unroll
+                for (int j = 0; j < C::MJ; ++j) {
+                    if constexpr ((DBG & 8) != 0)
+                    {
+                        keep_alive(av[i]);
+                        keep_alive(bv[j]);
+                    }
+                    else
+                        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av[i], bv[j], acc[i][j], 2, 2, 0, (int)ra[i].w, 0, (int)rb[j].w);
+                    after_mfma();
+                }
+            dma_kt = -1;
+        };
+        // Skewed wave groups (8-wave tiles; waves w and w + 4 share a SIMD): between two barriers the EARLY wave of a SIMD reads
+        // K-tile kt into registers and then issues its products, the LATE wave first issues the products of K-tile kt - 1 -- read in
+        // the previous period -- and reads K-tile kt afterwards.  One wave of every SIMD feeds the matrix pipe while the other one
+        // waits for LDS; with all eight waves in phase (reads, then products, every period) the LDS round trips and the matrix work
+        // added up (ablations of profiles/r04/gemm_mx_ablation.log: 2.20 ms full, 1.20 ms reads + conversions alone, 1.19 ms of
+        // matrix work).  Both groups touch stage kt only in period kt, so the ring and its one barrier per K-tile stay as they were;
+        // every accumulator still sums its K-tiles in ascending order (bit-identical results).
+        const bool late = (C::SKEW != ((DBG & 256) != 0)) && C::NW == 8 && wave >= C::NW / 2;
+        // sync(kt): K-tile kt has landed in its stage for every wave; the stage of K-tile kt - 1 is free (every wave finished its reads
+        // before it arrived here) and receives K-tile kt + STAGES - 1
+        auto sync = [&](int kt) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             const int ahead = min(C::STAGES - 2, KT - 1 - kt);  // K-tiles that stay in flight
             if (hi_wave) {
                 if (C::STAGES >= 4 && ahead == 2)
@@ -393,77 +515,30 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const char* __restr
                     mx_wait<0>();
             }
             __builtin_amdgcn_s_barrier();
-            if (kt + C::STAGES - 1 < KT && !(DBG & 16))
-                stage((kt + C::STAGES - 1) % C::STAGES, kt + C::STAGES - 1);
-            const char* ab = lds + (kt % C::STAGES) * C::STAGE_BYTES;
-            const char* bb = ab + C::A_BYTES;
-            f16x8 a[2][C::MI], b[2][C::MJ];
-            uint4 ra[C::MI], rb[C::MJ];
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-                for (int i = 0; i < C::MI; ++i)
-                    a[ks][i] = *(const f16x8*)(ab + h_off(a_row + 32 * i, 2 * ks + fk));
-#pragma unroll
-                for (int j = 0; j < C::MJ; ++j)
-                    b[ks][j] = *(const f16x8*)(bb + h_off(b_row + 32 * j, 2 * ks + fk));
+            if (kt + C::STAGES - 1 < KT && !(DBG & 16)) {
+                if constexpr (C::SPREAD != ((DBG & 512) != 0))
+                    dma_kt = kt + C::STAGES - 1;  // issued by the next products()
+                else
+                    stage((kt + C::STAGES - 1) % C::STAGES, kt + C::STAGES - 1);  // as a burst behind the barrier
             }
-#pragma unroll
-            for (int i = 0; i < C::MI; ++i)
-                ra[i] = __builtin_bit_cast(uint4, *(const f16x8*)(ab + C::A_R + fk * (C::BN * 16) + (a_row + 32 * i) * 16));  // typed like the fragment reads: a uint4 read made the compiler drain vmcnt in front of it
-#pragma unroll
-            for (int j = 0; j < C::MJ; ++j)
-                rb[j] = __builtin_bit_cast(uint4, *(const f16x8*)(bb + C::B_R + fk * (C::BT * 16) + (b_row + 32 * j) * 16));
-            // the same order in every configuration: h.h of k-slab 0, of k-slab 1, then the scaled cross product
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int i = 0; i < C::MI; ++i)
-#pragma unroll
-                    for (int j = 0; j < C::MJ; ++j) {
-                        if constexpr ((DBG & 8) != 0)
-                        {
-                            keep_alive(a[ks][i]);
-                            keep_alive(b[ks][j]);
-                        }
-                        else
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks][i], b[ks][j], acc[i][j], 0, 0, 0);
-                    }
-            if constexpr ((DBG & 32) != 0) {
-#pragma unroll
-                for (int i = 0; i < C::MI; ++i)
-                    keep_alive(ra[i].x), keep_alive(ra[i].y), keep_alive(ra[i].z), keep_alive(ra[i].w);
-#pragma unroll
-                for (int j = 0; j < C::MJ; ++j)
-                    keep_alive(rb[j].x), keep_alive(rb[j].y), keep_alive(rb[j].z), keep_alive(rb[j].w);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                continue;
-            }
-            v8i av[C::MI], bv[C::MJ];
-#pragma unroll
-            for (int i = 0; i < C::MI; ++i) {
-                const u32x6 q = q_fields<true>(a[0][i], a[1][i], ra[i].w);  // q(w) = fp6(h(w) / 2^(Ew - 2))
-                av[i]         = v8i{(int)q[0], (int)q[1], (int)q[2], (int)ra[i].x, (int)ra[i].y, (int)ra[i].z, 0, 0};
-            }
-#pragma unroll
-            for (int j = 0; j < C::MJ; ++j) {
-                const u32x6 q = q_fields<false>(b[0][j], b[1][j], rb[j].w + 11u);  // q(x) = fp6(h(x) / 2^(Ex - 2)); the record holds Ex - 13
-                bv[j]         = v8i{(int)rb[j].x, (int)rb[j].y, (int)rb[j].z, (int)q[3], (int)q[4], (int)q[5], 0, 0};
-            }
-#pragma unroll
-            for (int i = 0; i < C::MI; ++i)
-#pragma unroll
-                for (int j = 0; j < C::MJ; ++j) {
-                    if constexpr ((DBG & 8) != 0)
-                    {
-                        keep_alive(av[i]);
-                        keep_alive(bv[j]);
-                    }
-                    else
-                        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av[i], bv[j], acc[i][j], 2, 2, 0, (int)ra[i].w, 0, (int)rb[j].w);
-                }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        };
+        // one code path for both groups -- early: sync(kt) reads(kt) products(kt); late: reads(kt) sync(kt + 1) products(kt), i.e. the
+        // late wave's products of K-tile kt run in period kt + 1, in front of its reads of K-tile kt + 1.  Both execute KT barriers.
+        if (late) {
+            sync(0);
+            if (dma_kt >= 0)  // the refill that belongs to barrier 0: the late wave has no products to spread it over yet
+                stage(dma_kt % C::STAGES, dma_kt);
+            dma_kt = -1;
         }
+        for (int kt = 0; kt < KT; ++kt) {
+            if (!late)
+                sync(kt);
+            reads(kt);
+            if (late && kt + 1 < KT)
+                sync(kt + 1);
+            products();
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
         // the epilogue's lane-dependent addresses are derived from opaque copies of the lane / thread id: computed from `lane` they are
         // invariants of the tile loop, get hoisted in front of the K-loop and spilled there (the K-loop owns the register file) -- and a

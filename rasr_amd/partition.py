@@ -22,6 +22,38 @@ def select_partition(n_segments, partition, select):
     return np.arange(select, n_segments, partition)
 
 
+class CorpusWalker:
+    """The order in which one rank of a data-parallel job visits a corpus: the segments of its partition (`select_partition`,
+    i.e. the reference's `partition` / `select-partition` rule, Bliss/CorpusDescription.cc:174-190), `batch` at a time, in corpus
+    order (the reference's CorpusVisitor walks recordings / segments in document order, Speech/CorpusProcessor.cc:49-58).
+    A partition that is not a multiple of `batch` ends with a short batch; `next_batch` starts the next epoch after it.
+
+    Host logic only: the streamed ingest of bench.py asks it which utterances to copy next, and the gloo test checks that two
+    ranks walk disjoint lists that cover the corpus."""
+
+    def __init__(self, n_segments, partition, select, batch):
+        if batch <= 0:
+            raise ValueError("batch must be positive")
+        self.segments = select_partition(n_segments, partition, select)
+        if len(self.segments) == 0:
+            raise ValueError("partition %d of %d holds no segment of a %d-segment corpus" % (select, partition, n_segments))
+        self.batch = int(batch)
+        self.pos = 0
+        self.epoch = 0
+
+    def batches_per_epoch(self):
+        return (len(self.segments) + self.batch - 1) // self.batch
+
+    def next_batch(self):
+        """corpus indices of the next `batch` segments of this rank (fewer at the end of its partition)"""
+        if self.pos >= len(self.segments):
+            self.pos = 0
+            self.epoch += 1
+        out = self.segments[self.pos:self.pos + self.batch]
+        self.pos += len(out)
+        return out
+
+
 class EpochReduceBuffer:
     """Everything a rank contributes to the per-epoch sum, in ONE flat f64 buffer, so that the exchange is literally one
     all-reduce (one RCCL ring over xGMI per epoch; replaces `combine-mixture-set-estimators`,

@@ -248,6 +248,40 @@ def test_bench_gpus_2_starts_two_ranks_itself():
     assert line["epoch_reduce"]["collectives"] == 1
 
 
+def test_corpus_walker_batches_follow_the_partition_rule():
+    """the streamed ingest's walk: batches of the rank's partition in corpus order, a short batch at its end, then the next epoch"""
+    from rasr_amd.partition import CorpusWalker, select_partition
+    w = CorpusWalker(23, 3, 1, 4)
+    assert w.batches_per_epoch() == 2
+    seen = [w.next_batch().tolist() for _ in range(3)]
+    assert seen[0] == [1, 4, 7, 10] and seen[1] == [13, 16, 19, 22] and seen[2] == seen[0] and w.epoch == 1
+    w = CorpusWalker(10, 4, 3, 2)
+    assert [w.next_batch().tolist() for _ in range(3)] == [[3, 7], [3, 7], [3, 7]]
+    w = CorpusWalker(10, 4, 1, 2)
+    assert [w.next_batch().tolist() for _ in range(3)] == [[1, 5], [9], [1, 5]]
+    parts = [CorpusWalker(1000, 8, k, 64) for k in range(8)]
+    got = np.concatenate([np.concatenate([p.next_batch() for _ in range(p.batches_per_epoch())]) for p in parts])
+    assert sorted(got.tolist()) == list(range(1000))
+    assert all(np.array_equal(p.segments, select_partition(1000, 8, k)) for k, p in enumerate(parts))
+    with pytest.raises(ValueError):
+        CorpusWalker(3, 8, 5, 2)   # this partition holds no segment
+
+
+def test_two_ranks_stream_disjoint_utterance_lists():
+    """`bench.py --gpus 2` defaults to --ingest streamed: every step takes the NEXT utterances of the rank's partition of the 100 h
+    corpus.  The host-only stand-in runs the same walk (CorpusWalker) on two gloo ranks; the lists are gathered over the control
+    plane: disjoint, every index in its rank's partition, steps x batch x ranks utterances in total."""
+    rc, line, err = _run_bench(["--gpus", "2", "--backend", "gloo", "--workload", "null", "--steps", "4", "--warmup", "1", "--utterances", "16"])
+    assert rc == 0, err[-2000:]
+    assert line["config"]["ingest"] == "streamed"
+    walk = line["stages"]["corpus_walk"]
+    assert walk["corpus_utterances"] == 36000 and walk["visited"] == walk["distinct"] == (4 + 1) * 16 * 2
+    assert walk["ranks_disjoint"] and walk["every_rank_in_its_partition"]
+    assert walk["first_of_each_rank"] == [[0, 2, 4], [1, 3, 5]]
+    rc, line, err = _run_bench(["--backend", "gloo", "--workload", "null", "--steps", "2", "--warmup", "0"])
+    assert rc == 0 and line["config"]["ingest"] == "resident" and "corpus_walk" not in line["stages"]
+
+
 def test_bench_refuses_a_world_size_that_contradicts_gpus():
     """ranks started by someone else with another world size than --gpus: fail loudly instead of printing a wrong n_gpus"""
     rc, line, err = _run_bench(["--gpus", "2", "--backend", "gloo", "--workload", "null"], env_extra={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
