@@ -60,7 +60,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="pipeline", choices=["pipeline", "nn-pipeline", "mfcc", "gmm", "gmm-tied", "nn", "gmm-train", "null"],
+    ap.add_argument("--workload", default="pipeline", choices=["pipeline", "nn-pipeline", "mfcc", "gmm", "gmm-tied", "nn", "gmm-train", "gmm-trained", "null"],
                     help="null: host-only stand-in (no GPU, --backend gloo): launcher, rendezvous, partitioning, epoch reduce and the JSON line")
     ap.add_argument("--backend", default=os.environ.get("AMX_BENCH_BACKEND", "nccl"), choices=["nccl", "gloo"],
                     help="torch.distributed backend of the control plane: nccl (= RCCL; GPU runs) or gloo (the CPU launcher test)")
@@ -73,6 +73,10 @@ def parse():
                          "double-buffered HBM slot (copy stream, events), so the timed region carries the ingest.  auto = resident on "
                          "one GPU (the line then also reports the streamed rate next to it), streamed for --gpus N > 1")
     ap.add_argument("--corpus-hours", type=float, default=100.0, help="size of the synthetic corpus all ranks share (config 5: 100 h)")
+    ap.add_argument("--trained-frames-per-state", type=int, default=600, help="gmm-trained: training frames per state of the split-trained model")
+    ap.add_argument("--gmm-tuning", default=None, help='amx_gmm_model.tuning of every GMM scorer the workload builds, e.g. "screen=0" (A/B runs)')
+    ap.add_argument("--nn-tuning", default=None, help='amx_ffnn_model.tuning, e.g. "tile=4" or "graph=0"')
+    ap.add_argument("--mfcc-tuning", default=None, help='amx_mfcc_cfg.tuning, e.g. "fft=mfma" or "wgs=3"')
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the secondary BASELINE configs of the default run")
     ap.add_argument("--precision", default="f16mx", choices=["bf16", "bf16x3", "f16mx", "fp32"],
@@ -300,13 +304,13 @@ def gmm_cart_roofline(ctx, sc, nk, n_mix, dim, frames):
                     screen_mfma_tflops=round(scr / t / 1e12, 1), screen_mfma_frac=round(scr / t / 1e12 / MFMA_BF16_TFLOPS, 4),
                     hbm_algorithmic_GBps=round(by / t / 1e9, 1), hbm_frac=round(by / t / 1e9 / HBM_PEAK_GBS, 4),
                     algorithmic_speedup_vs_dense=round(alg / (t + ms_p * 1e-3) / 1e12 / FP32_TFLOPS, 3))
-    if n_s == 0:  # screen disabled (AMX_GMM_SCREEN=0): the exact-everything kernel
+    if n_s == 0:  # screen disabled (--gmm-tuning screen=0): the exact-everything kernel
         ops = 4.0 * nk * dim * frames
         ach = ops / (ms_x * 1e-3) / 1e12
         return dict(bound="valu", note="f32 VALU kernel priced against the f32 vector peak", kernel="gmm_direct_kernel<%d,MaxState>" % dim,
                     achieved=round(ach, 3), peak=FP32_TFLOPS, unit="TFLOP/s", frac=round(ach / FP32_TFLOPS, 4), traffic=None,
                     avg_launch_ms=round(ms_x, 4), launches=n_x, flops_per_launch=ops)
-    # two-kernel path (AMX_GMM_FUSED=0, per-density covariances, dim > 40): HBM-side figure of the exact stage (scores, best
+    # two-kernel path (--gmm-tuning fused=0, per-density covariances, dim > 40): HBM-side figure of the exact stage (scores, best
     # densities, survivor masks) -- no survivor counter there
     t = ms_x * 1e-3
     by = frames * (n_mix * 8.0 + ((n_mix + 15) // 16 * 16) * 2.0 + dim * 4.0)
@@ -352,7 +356,7 @@ class NnPipeline:
         import rasr_amd
         from tests import synth
         self.torch, self.ctx = torch, ctx
-        self.fe = rasr_amd.MfccExtractor(ctx, nr_cepstrum_coefficients=40, filter_width=138.0)
+        self.fe = rasr_amd.MfccExtractor(ctx, nr_cepstrum_coefficients=40, filter_width=138.0, tuning=args.mfcc_tuning)
         pcm, off = make_batch(args.utterances, args.utt_seconds, seed=9 + rank)
         self.plan = self.fe.plan(off)
         self.F = self.plan.total_frames
@@ -362,7 +366,7 @@ class NnPipeline:
         self.ctxwin = torch.empty((self.F, 440), dtype=torch.float32, device="cuda")
         dims = [440] + [2048] * 6 + [10000]
         Ws, bs, acts, logp = synth.ffnn(dims, seed=7)
-        self.nn = rasr_amd.NnBatchFeatureScorer(ctx, Ws, bs, acts, log_prior=logp, priori_scale=1.0, precision=args.precision)
+        self.nn = rasr_amd.NnBatchFeatureScorer(ctx, Ws, bs, acts, log_prior=logp, priori_scale=1.0, precision=args.precision, tuning=args.nn_tuning)
         self.flops_per_frame = 2.0 * sum(dims[i] * dims[i + 1] for i in range(len(dims) - 1))
         self.M = 10000
         self.scores = torch.empty((min(self.CHUNK, self.F), self.M), dtype=torch.float32, device="cuda")
@@ -449,7 +453,7 @@ class Pipeline(NnPipeline):
         from tests import synth
         model = synth.gmm_cart(10000, 16, 16, 40, seed=5, pooled=True)
         self.nk = int(model["mix_offsets"][-1])
-        self.gmm = rasr_amd.GmmFeatureScorer(ctx, model)
+        self.gmm = rasr_amd.GmmFeatureScorer(ctx, model, tuning=args.gmm_tuning)
         super().__init__(ctx, args, rank)
         g = min(self.GCHUNK, self.F)
         self.gscores = torch.empty((g, self.M), dtype=torch.float32, device="cuda")
@@ -525,7 +529,7 @@ class GmmTrain:
         import rasr_amd
         from tests import synth
         self.ctx = ctx
-        self.fe = rasr_amd.MfccExtractor(ctx, nr_cepstrum_coefficients=40, filter_width=138.0)
+        self.fe = rasr_amd.MfccExtractor(ctx, nr_cepstrum_coefficients=40, filter_width=138.0, tuning=args.mfcc_tuning)
         pcm, off = make_batch(args.utterances, args.utt_seconds, seed=9 + rank)
         self.plan = self.fe.plan(off)
         self.F = self.plan.total_frames
@@ -534,7 +538,7 @@ class GmmTrain:
         self.ceps = torch.empty((self.F, 40), dtype=torch.float32, device="cuda")
         model = synth.gmm_cart(10000, 16, 16, 40, seed=5, pooled=True)
         self.nk = int(model["mix_offsets"][-1])
-        self.sc = rasr_amd.GmmFeatureScorer(ctx, model)
+        self.sc = rasr_amd.GmmFeatureScorer(ctx, model, tuning=args.gmm_tuning)
         self.M = 10000
         g = min(self.CHUNK, self.F)
         self.scores = torch.empty((g, self.M), dtype=torch.float32, device="cuda")
@@ -577,6 +581,88 @@ class GmmTrain:
         return out
 
 
+class GmmTrained(GmmTrain):
+    """The GMM leg of config 5 on a trained-SHAPED model instead of the random-init one: 10 000 states grown from one density to (up
+    to) 16 by the repository's own loop -- accumulate, amx_gmm_estimate + split, Viterbi re-estimation (tests/trained_gmm.py;
+    Mm/MixtureSetSplitter.cc:38-123, Mm/AbstractMixtureSetEstimator.cc:117-150,305-338) -- on synthetic clustered features, scored on
+    63 936 frames of those features.  The densities of a mixture are close relatives here, so more of them survive the f16 screen of
+    gmm_fused_kernel than of the random-init model's (survivors_per_mixture); the line reports that, the time per pass and the
+    evaluate-everything kernel (tuning screen=0) on the same model and frames."""
+
+    def __init__(self, ctx, args, rank):
+        import torch
+
+        import rasr_amd
+        from rasr_amd.partition import EpochReduceBuffer
+        from tests.trained_gmm import split_trained_gmm
+        self.ctx = ctx
+        t0 = time.perf_counter()
+        model, x, align, self.history = split_trained_gmm(ctx, n_mix=10000, dim=40, frames_per_state=args.trained_frames_per_state,
+                                                           rounds=4, iters=2, seed=11 + rank)
+        self.train_seconds = time.perf_counter() - t0
+        self.F = 63936
+        self.x = x[:self.F].clone()
+        self.align = align[:self.F].clone()
+        del x, align
+        torch.cuda.empty_cache()
+        self.model = model
+        self.nk = int(model["mix_offsets"][-1])
+        self.kmax = int(np.diff(model["mix_offsets"]).max())
+        self.sc = rasr_amd.GmmFeatureScorer(ctx, model, tuning=args.gmm_tuning)
+        self.args_gmm_tuning = args.gmm_tuning
+        self.M = 10000
+        self.scores = torch.empty((self.F, self.M), dtype=torch.float32, device="cuda")
+        self.bestd = torch.empty((self.F, self.M), dtype=torch.int32, device="cuda")
+        self.state = torch.empty((self.F,), dtype=torch.int32, device="cuda")
+        self.red = EpochReduceBuffer([("acc", self.sc.accumulator_size(), "f64"), ("score_sum", 1, "f64"), ("counts", self.M, "count")], device="cuda")
+        self.counts, self.score_sum, self.acc = self.red.view("counts"), self.red.view("score_sum"), self.red.view("acc")
+        self.units = self.F
+        self.ingest = None
+
+    def step(self):
+        self.sc.score_stats_dev(self.x, self.F, self.scores, self.bestd, self.state, self.counts, self.score_sum)
+        self.sc.accumulate_dev(self.x, self.F, self.state, self.bestd, self.M, self.acc)
+
+    def stage_report(self):
+        import torch
+
+        import rasr_amd
+        out = super().stage_report()
+        out["model"] = dict(densities=self.nk, max_densities_per_mixture=self.kmax, training=self.history, training_seconds=round(self.train_seconds, 1),
+                            best_state_is_aligned_state=round(float((self.state == self.align).float().mean()), 4))
+        # the evaluate-everything kernel on the same model and frames (what a scorer without the screen costs)
+        dense = rasr_amd.GmmFeatureScorer(self.ctx, self.model, tuning="screen=0")
+        s2, b2 = torch.empty_like(self.scores), torch.empty_like(self.bestd)
+        dense.score_dev(self.x, self.F, s2, b2)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        dense.score_dev(self.x, self.F, s2, b2)
+        torch.cuda.synchronize()
+        out["dense_kernel_ms"] = round(1e3 * (time.perf_counter() - t0), 3)
+        self.sc.score_dev(self.x, self.F, self.scores, self.bestd)
+        torch.cuda.synchronize()
+        out["screened_equals_dense_bitwise"] = bool(torch.equal(s2.view(torch.int32), self.scores.view(torch.int32)) and torch.equal(b2, self.bestd))
+        # the worst case for the screen: the model as the trainer writes it right after its last split (every mean with >= 20
+        # observations replaced by the twins mean +- eps sqrt(var), Mm/MixtureSetSplitter.cc:59-75), before any re-estimation
+        from tests.trained_gmm import split_trained_gmm
+        twins = getattr(split_trained_gmm, "fresh_split", None)
+        if twins is not None:
+            tw = rasr_amd.GmmFeatureScorer(self.ctx, twins, tuning=self.args_gmm_tuning)
+            tw.score_dev(self.x, self.F, s2, b2)
+            tw.screen_counts(True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                tw.score_dev(self.x, self.F, s2, b2)
+            torch.cuda.synchronize()
+            ms = 1e3 * (time.perf_counter() - t0) / 3
+            surv, pairs = tw.screen_counts(False)
+            out["just_split_twins"] = dict(densities=int(twins["mix_offsets"][-1]), ms_per_pass=round(ms, 3),
+                                           survivors_per_mixture=round(surv / float(max(pairs, 1)), 4),
+                                           note="exact twins survive the f16 screen together; the next re-estimation separates them")
+        return out
+
+
 class MfccOnly:
     def __init__(self, ctx, args, rank):
         import torch
@@ -591,12 +677,12 @@ class MfccOnly:
         if self.gt:
             self.fe = rasr_amd.GammatoneExtractor(ctx, channels=68, max_freq=7500.0, si_length=9, si_shift=4, power=0.1, n_ceps=12)
         elif fe == "plp":
-            self.fe = rasr_amd.MfccExtractor.plp(ctx)
+            self.fe = rasr_amd.MfccExtractor.plp(ctx, tuning=args.mfcc_tuning)
         elif self.plp:
             self.fe = rasr_amd.MfccExtractor(ctx, nr_cepstrum_coefficients=16, front_end="mfplp", nr_autocorrelation_coefficients=20,
-                                             normalize=True)
+                                             normalize=True, tuning=args.mfcc_tuning)
         else:
-            self.fe = rasr_amd.MfccExtractor(ctx, nr_cepstrum_coefficients=40, filter_width=138.0)
+            self.fe = rasr_amd.MfccExtractor(ctx, nr_cepstrum_coefficients=40, filter_width=138.0, tuning=args.mfcc_tuning)
         lens = synth.utterance_lengths(1000, seed=3)
         base = synth.waveform(int(lens.max()) + 1000, seed=4 + rank)
         pcm = np.concatenate([base[u:u + int(n)] for u, n in enumerate(lens)])
@@ -701,7 +787,7 @@ class GmmOnly:
         self.nk = int(model["mix_offsets"][-1])
         self.nd = len(model["dens_mean"])
         self.gmm_type = args.gmm_type
-        self.sc = rasr_amd.GmmFeatureScorer(ctx, model, feature_scorer_type=args.gmm_type)
+        self.sc = rasr_amd.GmmFeatureScorer(ctx, model, feature_scorer_type=args.gmm_type, tuning=args.gmm_tuning)
         self.T = int(getattr(args, "gmm_frames", 256))
         x = np.random.Generator(np.random.PCG64(4 + rank)).standard_normal((self.T, 40)).astype(np.float32)
         self.x = torch.from_numpy(x).cuda()
@@ -799,7 +885,7 @@ class NnOnly:
         self.ctx = ctx
         dims = [440] + [2048] * 6 + [10000]
         Ws, bs, acts, logp = synth.ffnn(dims, seed=7)
-        self.nn = rasr_amd.NnBatchFeatureScorer(ctx, Ws, bs, acts, log_prior=logp, priori_scale=1.0, precision=args.precision)
+        self.nn = rasr_amd.NnBatchFeatureScorer(ctx, Ws, bs, acts, log_prior=logp, priori_scale=1.0, precision=args.precision, tuning=args.nn_tuning)
         self.nn_precision = args.precision
         self.T = 1024
         x = np.random.Generator(np.random.PCG64(6 + rank)).standard_normal((self.T, 440)).astype(np.float32)
@@ -1113,6 +1199,8 @@ def make_job(ctx, args, rank, world=1):
         job = MfccOnly(ctx, args, rank)
     elif args.workload == "gmm-train":
         job = GmmTrain(ctx, args, rank)
+    elif args.workload == "gmm-trained":
+        job = GmmTrained(ctx, args, rank)
     elif args.workload in ("gmm", "gmm-tied"):
         job = GmmOnly(ctx, args, rank, tied=args.workload == "gmm-tied")
     else:
@@ -1123,9 +1211,9 @@ def make_job(ctx, args, rank, world=1):
 def is_graph_mode(args):
     # config 4 (batch 1024) and the config-3 CART scorer (batch 256) replay their pass as a HIP graph, which the per-launch events of the
     # library's profiler would switch off: that workload is timed without them and its kernel timings come from a separate profiled pass
-    return (args.workload == "nn" and os.environ.get("AMX_FFNN_GRAPH", "1") != "0") or \
+    return (args.workload == "nn" and "graph=0" not in (args.nn_tuning or "")) or \
            (args.workload in ("gmm", "gmm-tied") and args.gmm_type == "diagonal-maximum" and args.gmm_frames <= 4096
-            and os.environ.get("AMX_GMM_GRAPH", "1") != "0")
+            and "graph=0" not in (args.gmm_tuning or ""))
 
 
 def reset_survivor_counters(job):
@@ -1177,6 +1265,8 @@ WORKLOAD_NAMES = {
     "gmm": lambda a: "cfg3-cart: 10000 states x 16 densities, d=40, pooled covariance, batch %d, %s" % (a.gmm_frames, a.gmm_type),
     "gmm-tied": lambda a: "cfg3-tied: 4096 shared densities x 10000 states, d=40, batch %d, diagonal-maximum" % a.gmm_frames,
     "nn": lambda a: "cfg4: FFNN 440-6x2048-10000 (%s MFMA), batch 1024" % a.precision,
+    "gmm-trained": lambda a: "cfg5 GMM leg on a split-trained model: 10000 states grown 1 -> 16 densities by estimate + split + Viterbi "
+                             "re-estimation on clustered synthetic features (pooled covariance), 63936 frames of those features per step",
     "gmm-train": lambda a: "cfg5 GMM leg: MFCC-40 -> 10000x16 GMM (diagonal-maximum) -> Viterbi accumulators (f64) ; "
                            "%d utterances x %.0f s per step and rank" % (a.utterances, a.utt_seconds)}
 
@@ -1227,6 +1317,9 @@ def secondary_configs(ctx, args, rank):
             ("cfg2 mfcc", dict(workload="mfcc", steps=20, warmup=2)),
             ("cfg3 gmm-tied (4096 shared densities x 10000 states, batch 256)", dict(workload="gmm-tied", steps=20, warmup=3)),
             ("cfg3 gmm-cart (10000 x 16 densities, batch 256)", dict(workload="gmm", steps=50, warmup=5)),
+            ("cfg5-shard GMM leg, split-trained model (10000 states grown 1 -> 16 densities by the repository's training loop)",
+             dict(workload="gmm-trained", steps=8, warmup=2)),
+            ("cfg5-shard GMM leg, random-init model (the headline's GMM leg alone)", dict(workload="gmm-train", steps=8, warmup=2)),
             ("cfg5-shard with the NN in split bf16 (round 3's default, the same 1e-4 bar at 3 MFMA products per product)",
              dict(workload="pipeline", precision="bf16x3", steps=20, warmup=2)),
             ("cfg4 nn f16mx (batch 1024)", dict(workload="nn", precision="f16mx", steps=50, warmup=5)),
@@ -1251,6 +1344,13 @@ def secondary_configs(ctx, args, rank):
                                  kernel="all 7 GEMMs of the pass; largest: " + str(r.get("kernel")))
             if r.get("time_is"):
                 out[name]["time_is"] = r["time_is"]
+            if a.workload in ("gmm-trained", "gmm-train"):
+                out[name]["survivors_per_mixture"] = r.get("survivors_per_mixture")
+                out[name]["gmm_kernel_ms"] = r.get("avg_launch_ms")
+                if a.workload == "gmm-trained":
+                    st = job.stage_report()
+                    out[name].update(model=st.get("model"), dense_kernel_ms=st.get("dense_kernel_ms"),
+                                     screened_equals_dense_bitwise=st.get("screened_equals_dense_bitwise"), just_split_twins=st.get("just_split_twins"))
         except Exception as e:  # a secondary line must never take the headline down
             out[name] = dict(error=str(e)[:200])
         job = None
@@ -1269,7 +1369,7 @@ def decoder_facing(ctx, args, rank):
     from tests import synth
     dims = [440] + [2048] * 6 + [10000]
     Ws, bs, acts, logp = synth.ffnn(dims, seed=7)
-    nn = rasr_amd.NnBatchFeatureScorer(ctx, Ws, bs, acts, log_prior=logp, priori_scale=1.0, precision=args.precision)
+    nn = rasr_amd.NnBatchFeatureScorer(ctx, Ws, bs, acts, log_prior=logp, priori_scale=1.0, precision=args.precision, tuning=args.nn_tuning)
     T = 256
     x = torch.from_numpy(np.random.Generator(np.random.PCG64(60 + rank)).standard_normal((T, 440)).astype(np.float32)).cuda()
     scores = torch.empty((T, 10000), dtype=torch.float32, device="cuda")
@@ -1365,7 +1465,7 @@ def main():
         line["stages"] = job.stage_report()
         if getattr(job, "ingest", None) is not None:
             line["ingest"] = job.ingest.report()
-        elif hasattr(job, "setup_ingest") and world == 1:
+        elif hasattr(job, "setup_ingest") and getattr(job, "pcm", None) is not None and world == 1:
             line["ingest"] = dict(mode="resident", sample_format="f32", bytes_over_link_per_step=0,
                                   note="the same %d utterances every step, in HBM before the timed region" % args.utterances)
             try:

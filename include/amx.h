@@ -111,6 +111,10 @@ typedef struct {
     int    filter_type;            /* type: AMX_FILTER_TRIANGULAR (0) or AMX_FILTER_TRAPEZE                        */
     int    boundary;               /* boundary: AMX_BOUNDARY_STRETCH_TO_COVER (0), _INCLUDE, _EMPHASIZE            */
     int    warping;                /* warping-function: AMX_WARP_MEL (0) or AMX_WARP_BARK                          */
+    /* Kernel selection for A/B runs and tests, "key=value,key=value" (NULL: defaults; an unknown key fails amx_mfcc_create).  None
+     * of them changes a result beyond the parity bars.  fft=stockham|mfma (LDS radix-4 butterflies | the 256-point transform as
+     * two matrix products), wgs=N (workgroups per CU), lpc=regs|lds (LPC-cepstrum recursion in registers | the LDS kernel). */
+    const char* tuning;
 } amx_mfcc_cfg;
 enum { AMX_FRONT_END_MFCC = 0, AMX_FRONT_END_MFPLP = 1, AMX_FRONT_END_PLP = 2 };
 enum { AMX_FILTER_TRIANGULAR = 0, AMX_FILTER_TRAPEZE = 1 };
@@ -301,6 +305,14 @@ typedef struct {
     double          mixture_weight_scale; /* mixture-weight-scale (Core::ParameterFloat = f64; the scorer keeps it as f32), default 1 */
     double          gaussian_scale;       /* gaussian-scale (f64; the scorer keeps (f32)sqrt of the f64 value,
                                            * Mm/GaussDiagonalMaximumFeatureScorer.cc:52), default 1 */
+    /* Kernel selection for A/B runs and tests, "key=value,key=value" (NULL: defaults; an unknown key fails amx_gmm_create; read by
+     * amx_gmm_create only -- amx_pms_write, amx_gmm_estimate, amx_prior_from_mixture_set ignore it).  Every path gives the same
+     * scores and density indices bit for bit.  screen=0 (no MFMA / f32 screen: every density evaluated), fused=0 (two-kernel
+     * screen path instead of gmm_fused_kernel), screen_kernel=rows|persist|simple, graph=0 (no HIP-graph replay of small batches),
+     * tied_prune=0|1 (tied models: dense tile kernel | pruned scorer, default adaptive), chunk=N (frames per internal pass),
+     * fused_waves=8|12|16, fr=N (frames per workgroup of the uniform tied kernel), simd_mfma=0 (SIMD / batch-int scorers without
+     * the i8 matrix kernel). */
+    const char*     tuning;
 } amx_gmm_model;
 
 /* diagonal-maximum / diagonal-sum / batch-diagonal-maximum-float (Mm/BatchFeatureScorer.cc:164-254: pooled
@@ -439,10 +451,11 @@ enum { AMX_ACT_NONE = 0, AMX_ACT_RELU = 1, AMX_ACT_SIGMOID = 2, AMX_ACT_TANH = 3
  * product is taken as hi hi + lo hi + hi lo -- three bf16 MFMA products, ~2^-16 relative error per product: the mode that meets
  * the 1e-4 bar of the f32 reference (Math::gemm<f32>, Math/Blas.hh:402-420) at a third of the bf16 rate */
 enum { AMX_PREC_FP32 = 0, AMX_PREC_BF16 = 1, AMX_PREC_BF16X3 = 2, AMX_PREC_F16MX = 3 };
-/* AMX_PREC_F16MX (round 4): every operand is f16(v) plus MX-fp4 images of v and of v - f16(v) (OCP e2m1, one e8m0 scale per 32 k);
- * a product is f16 f16 + fp4(v) fp4(w - f16 w) + fp4(v - f16 v) fp4(w) -- one f16 MFMA product and ONE block-scaled fp4 MFMA
- * product for both cross terms: 1.5 units of matrix time per product instead of split bf16's 3, relative error ~2^-13 per
- * product (random sign), inside the 1e-4 bar with a factor of nine on BASELINE config 4 (profiles/r04/emulation_f16_f8.json).
+/* AMX_PREC_F16MX (round 4): every operand v is h = f16(v) plus an MX-fp6 image of the residual v - h (OCP e2m3, one e8m0 scale per
+ * 32 k); a product is h h + fp6(h) fp6(w - h_w) + fp6(v - h_v) fp6(h_w) -- one f16 MFMA product and ONE block-scaled fp6 x fp6 MFMA
+ * product for both cross terms (the fp6 image of h is converted from the f16 fragments in registers): 1.5 units of matrix time
+ * per product instead of split bf16's 3, worst error 0.03 of the 1e-4 bar on BASELINE config 4 (profiles/r04/emulation_f16_f8.json,
+ * tests/test_ffnn_f16mx_gpu.py).
  * Limits: weights and activations must stay inside the f16 range (|v| < 65520): amx_ffnn_create refuses such weights, a pass
  * that meets such a feature or hidden activation sets a sticky flag and every later call on the handle returns AMX_ERR_STATE
  * (amx_ffnn_score, which waits for its results, returns it at once).  AMX_PREC_BF16X3 has no such limit. */
@@ -463,6 +476,11 @@ typedef struct {
      * output ("no one-to-one correspondence between network outputs and classes!"); scores are [T x n_classes]. */
     int                 n_classes;
     const int*          class_to_output;
+    /* Kernel selection for A/B runs and tests, "key=value,key=value" (NULL: defaults; an unknown key fails amx_ffnn_create).  Every
+     * tile configuration of a precision gives bit-identical scores.  tile=N (GEMM tile configuration: 0 128x128, 2 256x256
+     * pipelined, 3 128x64, 4 256x256 single-tile, 6 128x64 three stages; default by layer shape), graph=0 (no HIP-graph replay of
+     * small batches), persistent=0, group=TxN (tiles per XCD-aware super-tile), chunk=N (frames per internal pass). */
+    const char*         tuning;
 } amx_ffnn_model;
 
 int  amx_ffnn_create(amx_ctx* ctx, const amx_ffnn_model* model, amx_ffnn** out);

@@ -63,24 +63,33 @@ class Comm:
         _lib.check(self.L.amx_comm_init(ctx.h, int(rank), int(world), buf, C.byref(h)))
         self.h = h
         self.rank, self.world = int(rank), int(world)
+        ctx._comms.append(self)   # a communicator belongs to its context: Context.close() closes it first (amx_comm_destroy reads the context)
+
+    def _on_torch_stream(self):
+        # the tensors handed in were produced on torch's current stream: launch there (the context's own stream is not ordered against it)
+        self.ctx.use_torch_stream()
 
     def all_reduce_f64(self, flat):
-        """in-place sum over the ranks of a contiguous float64 device tensor, on the context's stream"""
+        """in-place sum over the ranks of a contiguous float64 device tensor, on torch's current stream"""
         import torch
         if flat.dtype != torch.float64 or not flat.is_contiguous() or not flat.is_cuda:
             raise ValueError("all_reduce_f64 wants a contiguous float64 device tensor")
+        self._on_torch_stream()
         _lib.check(self.L.amx_comm_all_reduce_f64_dev(self.h, flat.data_ptr(), flat.numel()))
         return flat
 
     def counts_to_f64(self, counts, out):
+        self._on_torch_stream()
         _lib.check(self.L.amx_counts_to_f64_dev(self.ctx.h, counts.data_ptr(), out.data_ptr(), counts.numel()))
 
     def f64_to_counts(self, src, counts):
+        self._on_torch_stream()
         _lib.check(self.L.amx_f64_to_counts_dev(self.ctx.h, src.data_ptr(), counts.data_ptr(), counts.numel()))
 
     def close(self):
         if getattr(self, "h", None):
-            self.L.amx_comm_destroy(self.h)
+            if getattr(self.ctx, "h", None):   # the context is gone (finalisers run in any order at shutdown): nothing left to destroy safely
+                self.L.amx_comm_destroy(self.h)
             self.h = None
 
     def __del__(self):
@@ -99,9 +108,13 @@ class Context:
         _lib.check(self.L.amx_init(device, C.byref(h)))
         self.h = h
         self.device = device
+        self._comms = []
 
     def close(self):
         if getattr(self, "h", None):
+            for c in list(getattr(self, "_comms", [])):
+                c.close()
+            self._comms = []
             self.L.amx_destroy(self.h)
             self.h = None
 
@@ -262,7 +275,7 @@ class MfccExtractor:
     def __init__(self, ctx, nr_cepstrum_coefficients=16, filter_width=268.258, sample_rate=16000.0, alpha=1.0,
                  length=0.025, shift=0.01, maximum_input_size=0.025, apply_scale=True, spacing=0.0,
                  warp_differential_unit=True, normalize=False, front_end="mfcc", nr_autocorrelation_coefficients=0,
-                 intensity_loudness_power=0.33, type="triangular", boundary="stretch-to-cover", warping_function="mel"):
+                 intensity_loudness_power=0.33, type="triangular", boundary="stretch-to-cover", warping_function="mel", tuning=None):
         """front_end "mfcc" (mfcc.flow), "mfplp" (mfplp.flow: pass normalize=True and nr_autocorrelation_coefficients) or "plp"
         (plp.flow: MfccExtractor.plp() fills in that file's values); type / boundary / warping_function are signal-filterbank's"""
         self.ctx, self.L = ctx, ctx.L
@@ -270,7 +283,7 @@ class MfccExtractor:
                       int(warp_differential_unit), nr_cepstrum_coefficients, int(normalize),
                       {"mfcc": 0, "mfplp": 1, "plp": 2}[front_end], int(nr_autocorrelation_coefficients), float(intensity_loudness_power),
                       {"triangular": 0, "trapeze": 1}[type], {"stretch-to-cover": 0, "include-boundary": 1, "emphasize-boundary": 2}[boundary],
-                      {"mel": 0, "bark": 1}[warping_function])
+                      {"mel": 0, "bark": 1}[warping_function], _tuning(tuning))
         h = C.c_void_p()
         _lib.check(self.L.amx_mfcc_create(ctx.h, C.byref(cfg), C.byref(h)))
         self.h = h
@@ -352,7 +365,16 @@ class MfccExtractor:
             _lib.check(self.L.amx_mfcc_run_plan_dev(self.h, plan.h, _ptr(pcm_dev), _ptr(ceps_dev)))
 
 
-def _gmm_struct(model, mixture_weight_scale, gaussian_scale, keep):
+def _tuning(t):
+    """tuning=None | "key=value,..." | dict -> bytes for the `tuning` field of the ABI structs (A/B runs and tests)"""
+    if not t:
+        return None
+    if isinstance(t, dict):
+        t = ",".join("%s=%s" % (k, v) for k, v in t.items())
+    return t.encode()
+
+
+def _gmm_struct(model, mixture_weight_scale, gaussian_scale, keep, tuning=None):
     m = {k: (np.ascontiguousarray(v) if isinstance(v, np.ndarray) else v) for k, v in model.items()}
     assert m["mix_offsets"].dtype == np.uint32 and m["dens_index"].dtype == np.uint32
     assert m["dens_mean"].dtype == np.uint32 and m["dens_cov"].dtype == np.uint32
@@ -361,7 +383,7 @@ def _gmm_struct(model, mixture_weight_scale, gaussian_scale, keep):
     return _lib.GmmModel(int(m["dim"]), len(m["mix_offsets"]) - 1, len(m["dens_mean"]), m["means"].shape[0],
                          m["variances"].shape[0], m["mix_offsets"].ctypes.data, m["dens_index"].ctypes.data,
                          m["log_weight"].ctypes.data, m["dens_mean"].ctypes.data, m["dens_cov"].ctypes.data,
-                         m["means"].ctypes.data, m["variances"].ctypes.data, mixture_weight_scale, gaussian_scale)
+                         m["means"].ctypes.data, m["variances"].ctypes.data, mixture_weight_scale, gaussian_scale, _tuning(tuning))
 
 
 class GmmFeatureScorer:
@@ -372,7 +394,7 @@ class GmmFeatureScorer:
     dens_cov u32[D], means f32[n_mean,dim], variances f32[n_cov,dim]).
     """
 
-    def __init__(self, ctx, model, feature_scorer_type="diagonal-maximum", mixture_weight_scale=1.0, gaussian_scale=1.0):
+    def __init__(self, ctx, model, feature_scorer_type="diagonal-maximum", mixture_weight_scale=1.0, gaussian_scale=1.0, tuning=None):
         # ctx = None: host-only handle (prepared tables, accumulator files); scoring then fails with AMX_ERR_STATE
         self.ctx, self.L = ctx, (ctx.L if ctx is not None else _lib.lib())
         self.mode = {"diagonal-maximum": AMX_GMM_MAX, "diagonal-sum": AMX_GMM_SUM,
@@ -380,7 +402,7 @@ class GmmFeatureScorer:
                      "batch-diagonal-maximum-fast": _lib.AMX_GMM_BATCH_INT, "preselection-batch-float": _lib.AMX_GMM_PRESELECTION_FLOAT,
                      "preselection-batch-int": _lib.AMX_GMM_PRESELECTION_INT}[feature_scorer_type]
         keep = []
-        st = _gmm_struct(model, mixture_weight_scale, gaussian_scale, keep)
+        st = _gmm_struct(model, mixture_weight_scale, gaussian_scale, keep, tuning)   # tuning: amx_gmm_model.tuning, e.g. "screen=0"
         h = C.c_void_p()
         _lib.check(self.L.amx_gmm_create(ctx.h if ctx is not None else None, C.byref(st), C.byref(h)))
         self.h = h
@@ -477,7 +499,7 @@ class GmmFeatureScorer:
 class NnBatchFeatureScorer:
     """Nn::BatchFeatureScorer: Ws[l] is [out, in] (RASR weights_[0] is the same memory, [in x out] col-major)."""
 
-    def __init__(self, ctx, Ws, biases, activations, log_prior=None, priori_scale=1.0, precision="bf16", class_to_output=None):
+    def __init__(self, ctx, Ws, biases, activations, log_prior=None, priori_scale=1.0, precision="bf16", class_to_output=None, tuning=None):
         """class_to_output: Nn::ClassLabelWrapper mapping [n_classes] (emission -> network output, -1 = disregarded class)"""
         self.ctx, self.L = ctx, ctx.L
         n = len(Ws)
@@ -493,7 +515,7 @@ class NnBatchFeatureScorer:
         st = _lib.FfnnModel(n, self._ind.ctypes.data, self._outd.ctypes.data, C.cast(Wp, C.c_void_p), C.cast(Bp, C.c_void_p),
                             self._act.ctypes.data, _ptr(self._lp), priori_scale,
                             {"fp32": AMX_PREC_FP32, "bf16": AMX_PREC_BF16, "bf16x3": _lib.AMX_PREC_BF16X3, "f16mx": _lib.AMX_PREC_F16MX}[precision],
-                            0 if self._map is None else len(self._map), _ptr(self._map))
+                            0 if self._map is None else len(self._map), _ptr(self._map), _tuning(tuning))   # e.g. tuning="tile=3"
         h = C.c_void_p()
         _lib.check(self.L.amx_ffnn_create(ctx.h, C.byref(st), C.byref(h)))
         self.h = h

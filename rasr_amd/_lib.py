@@ -31,7 +31,7 @@ class MfccCfg(C.Structure):
                 ("mel_filter_width", C.c_double), ("mel_spacing", C.c_double),
                 ("warp_differential_unit", C.c_int), ("n_ceps", C.c_int), ("dct_normalize", C.c_int),
                 ("front_end", C.c_int), ("n_autocorrelation", C.c_int), ("plp_power", C.c_double),
-                ("filter_type", C.c_int), ("boundary", C.c_int), ("warping", C.c_int)]
+                ("filter_type", C.c_int), ("boundary", C.c_int), ("warping", C.c_int), ("tuning", C.c_char_p)]
 
 
 class GammatoneCfg(C.Structure):
@@ -56,7 +56,7 @@ class GmmModel(C.Structure):
     _fields_ = [("dim", C.c_int), ("n_mix", C.c_int), ("n_dens", C.c_int), ("n_mean", C.c_int), ("n_cov", C.c_int),
                 ("mix_offsets", C.c_void_p), ("dens_index", C.c_void_p), ("log_weight", C.c_void_p),
                 ("dens_mean", C.c_void_p), ("dens_cov", C.c_void_p), ("means", C.c_void_p),
-                ("variances", C.c_void_p), ("mixture_weight_scale", C.c_double), ("gaussian_scale", C.c_double)]
+                ("variances", C.c_void_p), ("mixture_weight_scale", C.c_double), ("gaussian_scale", C.c_double), ("tuning", C.c_char_p)]
 
 
 class GmmEstimateCfg(C.Structure):
@@ -69,7 +69,8 @@ class GmmEstimateCfg(C.Structure):
 class FfnnModel(C.Structure):
     _fields_ = [("n_layers", C.c_int), ("in_dim", C.c_void_p), ("out_dim", C.c_void_p), ("W", C.c_void_p),
                 ("bias", C.c_void_p), ("activation", C.c_void_p), ("log_prior", C.c_void_p),
-                ("prior_scale", C.c_float), ("precision", C.c_int), ("n_classes", C.c_int), ("class_to_output", C.c_void_p)]
+                ("prior_scale", C.c_float), ("precision", C.c_int), ("n_classes", C.c_int), ("class_to_output", C.c_void_p),
+                ("tuning", C.c_char_p)]
 
 
 # name -> (restype, argtypes); this table is also what tests/test_abi.py checks against amx.h

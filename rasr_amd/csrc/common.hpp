@@ -78,6 +78,23 @@ struct ScopedKernelTimer {
     }
 };
 
+// The `tuning` string of amx_mfcc_cfg / amx_gmm_model / amx_ffnn_model: "key=value,key=value".  A handle parses it once at
+// creation against the list of keys it knows (an unknown key fails the creation: a typo must not silently select the default
+// kernel) and keeps the values; nothing in the library reads kernel-selecting switches from the environment.  Lab builds
+// (-DAMX_LAB, tools/ab_*.sh) append the AMX_TUNING environment variable to every handle's string, unknown keys ignored there.
+struct Tuning {
+    std::map<std::string, std::string> kv;
+    // returns false (error text set) on a malformed string or a key that is not in `allowed` (NULL-terminated list)
+    bool parse(const char* s, const char* const* allowed, const char* who);
+    int  get(const char* key, int dflt) const;
+    bool has(const char* key) const { return kv.count(key) != 0; }
+    std::string str(const char* key, const char* dflt) const;
+};
+
+// keys of amx_gmm_model.tuning (gmm.hip and gmm_simd.hip parse the same string)
+static const char* const gmm_tuning_keys[] = {"screen", "fused", "screen_all", "screen_kernel", "graph", "tied_prune", "chunk", "fused_waves", "fr",
+                                              "simd_mfma", nullptr};
+
 inline int ceil_div(long a, long b) {
     return (int)((a + b - 1) / b);
 }

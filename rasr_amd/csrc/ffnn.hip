@@ -1415,7 +1415,9 @@ struct amx_ffnn {
     size_t host_f_cap = 0, host_s_cap = 0;
     int    use_graphs = 1;
     int    gemm_persistent = 1;
-    int    gemm_cfg       = -1;  // -1 = automatic; index into the bf16 tile configurations (launch_bf16_cfg)
+    int    gemm_cfg       = -1;  // -1 = automatic; index into the bf16 tile configurations (launch_bf16_cfg); tuning "tile"
+    int    chunk          = 32768;  // frames per internal pass (tuning "chunk")
+    int    mx_dbg         = 0;   // lab builds: ablation variant of gemm_mx_kernel (tuning "mx_dbg")
     // AMX_PREC_F16MX: host-mapped word the kernels set when a value leaves the f16 range (sticky: every later call fails)
     unsigned* h_overflow = nullptr;
     unsigned* d_overflow = nullptr;
@@ -1540,6 +1542,14 @@ void launch_bf16_pipe(amx_ffnn* h, int l, const void* x, int ldx, void* out, int
         h->cur_ntn = ntn;
 }
 
+// workgroups of the pipelined kernel for `tiles` 256 x 256 tiles (launch_bf16_pipe: one per CU, a multiple of 8 from 8 on)
+static inline long pipe_grid(long tiles, long ncu) {
+    long g = std::min(tiles, std::max(ncu, 8L));
+    if (g >= 8)
+        g &= ~7L;
+    return std::max(g, 1L);
+}
+
 template<int ACT, bool LAST>
 void launch_bf16_cfg(amx_ffnn* h, int l, const void* x, int ldx, void* out, int ldo, int T, int Tpad) {
     // default: 256x256 tiles when they still give >= 2 tiles per CU, else 128x128 (small batches)
@@ -1551,7 +1561,9 @@ void launch_bf16_cfg(amx_ffnn* h, int l, const void* x, int ldx, void* out, int 
         // between one half and two tiles of 256 x 256 per CU (the output layer at batch 1024: 160 tiles): the pipelined kernel in ONE
         // round against the 128 x 128 tiles in ceil(tiles / 2 per CU) rounds -- a 256 x 256 tile takes 1.8 rounds of the small ones
         // (57 vs 32 us at K = 2048); output layer at batch 1024: 64 -> 57 us bf16, 147 -> 135 us split bf16
-        else if (2 * t256 >= ncu && ((t256 + ncu - 1) / ncu) * 9 < ((t128 + 2 * ncu - 1) / (2 * ncu)) * 5)
+        // (rounds with the grid the launch really uses: launch_bf16_pipe rounds the workgroup count down to a multiple of 8, so
+        // e.g. 129 tiles on 256 CUs run as 128 workgroups and one of them takes a second tile)
+        else if (2 * t256 >= ncu && ((t256 + pipe_grid(t256, ncu) - 1) / pipe_grid(t256, ncu)) * 9 < ((t128 + 2 * ncu - 1) / (2 * ncu)) * 5)
             cfg = 2;
         else if ((long)(h->Npad[l] / 128) * (Tpad / 128) >= (long)h->ctx->n_cu)
             cfg = 0;
@@ -1604,8 +1616,7 @@ void launch_mx(amx_ffnn* h, int l, const void* x, int xkts, void* out, int ldo, 
     } while (0)
     int dbg = 0;
 #ifdef AMX_LAB  // ablations of the large-batch kernel (tools/ab_mx.sh, profiles/r04/gemm_mx_ablation.log)
-    if (const char* e = getenv("AMX_MX_DBG"))
-        dbg = atoi(e);
+    dbg = h->mx_dbg;
     if constexpr (C::BN == 256 && ACT == AMX_ACT_RELU * (LAST ? 0 : 1)) {
         switch (dbg) {
             case 8: AMX_MX_LAUNCH(8); break;
@@ -1621,6 +1632,10 @@ void launch_mx(amx_ffnn* h, int l, const void* x, int xkts, void* out, int ldo, 
             case 512: AMX_MX_LAUNCH(512); break;
             case 768: AMX_MX_LAUNCH(768); break;
             case 1024: AMX_MX_LAUNCH(1024); break;
+            case 2048: AMX_MX_LAUNCH(2048); break;
+            case 2304: AMX_MX_LAUNCH(2304); break;
+            case 2560: AMX_MX_LAUNCH(2560); break;
+            case 2816: AMX_MX_LAUNCH(2816); break;
             case 1032: AMX_MX_LAUNCH(1032); break;
             case 1160: AMX_MX_LAUNCH(1160); break;
             case 16: AMX_MX_LAUNCH(16); break;
@@ -1778,19 +1793,24 @@ int amx_ffnn_create(amx_ctx* ctx, const amx_ffnn_model* m, amx_ffnn** out) {
             prior = pmap.data();
     }
 
+    amx::Tuning tune;
+    {
+        static const char* const keys[] = {"tile", "graph", "persistent", "group", "chunk", "mx_dbg", nullptr};
+        if (!tune.parse(m->tuning, keys, "amx_ffnn_create"))
+            return AMX_ERR_INVALID;
+    }
     amx_ffnn* h  = new amx_ffnn;
     h->ctx       = ctx;
     h->n_layers  = m->n_layers;
     h->precision = m->precision;
     h->class_mapped = class_mapped;
-    if (const char* e = getenv("AMX_GEMM_CFG"))
-        h->gemm_cfg = atoi(e);
-    if (const char* e = getenv("AMX_FFNN_GRAPH"))
-        h->use_graphs = atoi(e);
-    if (const char* e = getenv("AMX_GEMM_PERSISTENT"))
-        h->gemm_persistent = atoi(e);
-    if (const char* e = getenv("AMX_GEMM_GROUP"))
-        sscanf(e, "%dx%d", &h->group_t, &h->group_n);
+    h->gemm_cfg        = tune.get("tile", -1);
+    h->use_graphs      = tune.get("graph", 1);
+    h->gemm_persistent = tune.get("persistent", 1);
+    h->chunk           = std::max(256, tune.get("chunk", 32768));
+    h->mx_dbg          = tune.get("mx_dbg", 0);
+    if (tune.has("group"))
+        sscanf(tune.str("group", "").c_str(), "%dx%d", &h->group_t, &h->group_n);
     hipSetDevice(ctx->device);
     const int kmult = m->precision == AMX_PREC_F16MX ? amx::mx::TK : (m->precision != AMX_PREC_FP32) ? amx::BK : amx::FK;
     if (m->precision == AMX_PREC_F16MX) {
@@ -2033,7 +2053,7 @@ static int ffnn_score_launches(amx_ffnn* h, const float* feats_dev, int feats_st
 
 static int ffnn_launches(amx_ffnn* h, const float* feats_dev, int feats_stride, int T, float* scores_dev, bool stats,
                          uint32_t* best_state_dev, unsigned long long* counts_dev, double* score_sum_dev, float* hidden_out) {
-    static const int chunk = getenv("AMX_FFNN_CHUNK") ? atoi(getenv("AMX_FFNN_CHUNK")) : 32768;  // frames per pass (workspace: 2 x chunk x max_hidden x 2 B)
+    const int chunk = h->chunk;  // frames per pass (workspace: 2 x chunk x max_hidden x 2 B)
     const int L     = h->n_layers;
     for (int t0 = 0; t0 < T; t0 += chunk) {
         const int Tc   = std::min(chunk, T - t0);
@@ -2300,3 +2320,9 @@ int amx_ffnn_score(amx_ffnn* h, const float* feats_host, int T, float* scores_ho
 }
 
 }  // extern "C"
+
+#ifdef AMX_LAB
+extern "C" int amx_lab_mx_stamps(unsigned long long* out /* [8 * 48 * 4] */) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(amx::mx::mx_stamps), sizeof(amx::mx::mx_stamps)) == hipSuccess ? AMX_OK : AMX_ERR_DEVICE;
+}
+#endif

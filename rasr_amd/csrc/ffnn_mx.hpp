@@ -253,6 +253,12 @@ __device__ __forceinline__ void piece_offsets(int p, int ha, int hb, int& src, i
     }
 }
 
+#ifdef AMX_LAB
+// lab builds (DBG 2048): s_memtime stamps of workgroup 0's first tile, [wave][K-tile < 48][phase]: 0 barrier passed, 1 refill issued,
+// 2 fragments in registers, 3 products issued; read back with amx_lab_mx_stamps (tools/mx_timeline.py)
+__device__ unsigned long long mx_stamps[8 * 48 * 4];
+#endif
+
 // ablation builds: keep a register value alive without using it (plain __device__ functions: the host pass does not look at their asm;
 // as a template the substitution failed on the host -- silently, and the kernel's host stub was never emitted)
 __device__ __forceinline__ void keep_alive(const v8i& v) { asm volatile("" ::"v"(v)); }
@@ -285,7 +291,7 @@ __device__ __forceinline__ u32x6 q_fields(f16x8 c0, f16x8 c1, unsigned scale_byt
 // -(D + bias) with the arg-min partials of the fused statistics.  Persistent workgroups, XCD-aware tile order, STAGES-deep LDS
 // ring with ONE barrier per K-tile and counted vmcnt (never a drain inside the loop).
 // DBG (lab builds only, -DAMX_LAB + AMX_MX_DBG): 8 no matrix instructions, 16 no operand DMA after the prologue, 32 no scaled product
-// (conversions and MX MFMAs skipped), 64 every workgroup streams one of 8 tiles (all operands L2 hits), 128 no fp6 conversions, 256 wave skew, 512 LDS-DMA pieces spread between the products, 1024 rotated K walk per tile
+// (conversions and MX MFMAs skipped), 64 every workgroup streams one of 8 tiles (all operands L2 hits), 128 no fp6 conversions, 256 wave skew, 512 LDS-DMA pieces spread between the products, 1024 rotated K walk per tile, 2048 s_memtime stamps of workgroup 0 (mx_stamps)
 template<class C, int ACT, bool LAST, int DBG = 0>
 __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const char* __restrict__ W, const char* __restrict__ X, const float* __restrict__ bias,
                                                             void* __restrict__ out, int KT, int xkts, int ktn, int ldo, int n_valid, int t_valid,
@@ -495,6 +501,14 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const char* __restr
         const bool late = (C::SKEW != ((DBG & 256) != 0)) && C::NW == 8 && wave >= C::NW / 2;
         // sync(kt): K-tile kt has landed in its stage for every wave; the stage of K-tile kt - 1 is free (every wave finished its reads
         // before it arrived here) and receives K-tile kt + STAGES - 1
+        auto stamp = [&](int kt, int phase) {
+#ifdef AMX_LAB
+            if constexpr ((DBG & 2048) != 0) {
+                if (blockIdx.x == 0 && vi == (int)blockIdx.x && kt < 48 && lane == 0)
+                    mx_stamps[(wave * 48 + kt) * 4 + phase] = __builtin_amdgcn_s_memtime();
+            }
+#endif
+        };
         auto sync = [&](int kt) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             const int ahead = min(C::STAGES - 2, KT - 1 - kt);  // K-tiles that stay in flight
@@ -515,12 +529,14 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const char* __restr
                     mx_wait<0>();
             }
             __builtin_amdgcn_s_barrier();
+            stamp(kt, 0);
             if (kt + C::STAGES - 1 < KT && !(DBG & 16)) {
                 if constexpr (C::SPREAD != ((DBG & 512) != 0))
                     dma_kt = kt + C::STAGES - 1;  // issued by the next products()
                 else
                     stage((kt + C::STAGES - 1) % C::STAGES, kt + C::STAGES - 1);  // as a burst behind the barrier
             }
+            stamp(kt, 1);
         };
         // one code path for both groups -- early: sync(kt) reads(kt) products(kt); late: reads(kt) sync(kt + 1) products(kt), i.e. the
         // late wave's products of K-tile kt run in period kt + 1, in front of its reads of K-tile kt + 1.  Both execute KT barriers.
@@ -534,9 +550,14 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const char* __restr
             if (!late)
                 sync(kt);
             reads(kt);
+            if constexpr ((DBG & 2048) != 0) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                stamp(kt, 2);
+            }
             if (late && kt + 1 < KT)
                 sync(kt + 1);
             products();
+            stamp(kt, 3);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 

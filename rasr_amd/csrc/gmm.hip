@@ -1534,6 +1534,10 @@ struct amx_gmm {
     };
     std::map<GraphKey, hipGraphExec_t> graphs;
     int                                use_graphs = 1;
+    // amx_gmm_model.tuning (A/B runs, tests)
+    int         tune_screen = 1, tune_fused = 1, tune_screen_all = 0, tune_tied_prune = -1, tune_chunk = 65536, tune_fused_waves = 0, tune_fr = 8,
+                tune_simd_mfma = 1;
+    std::string tune_screen_kernel = "rows";
     void*     d_fus_rec = nullptr;   // tile records of gmm_fused_kernel (pooled covariance, dim <= 40)
     unsigned long long* d_fus_surv = nullptr;  // [256] partial counts of the densities evaluated exactly (amx_gmm_screen_counts): one
                                                // address for every wave's atomicAdd cost a quarter of a 256-frame pass
@@ -1589,10 +1593,10 @@ extern "C" int amx_internal_gmm_fused_supported(int dim, int pooled, int Kp);
 extern "C" int amx_internal_gmm_fused_create(int dim, int n_mix, int n_tiles, const void* A2_host, const uint32_t* mix_off, const uint32_t* k_mean,
                                              const double* c64, const float* means, const float* p1, const float* p2, void** rec_dev,
                                              size_t* rec_bytes);
-extern "C" int amx_internal_gmm_fused_split(int n_cu, int Tpad, int n_tiles);
+extern "C" int amx_internal_gmm_fused_split(int n_cu, int Tpad, int n_tiles, int forced_waves);
 extern "C" int amx_internal_gmm_fused_score(amx_ctx* ctx, int dim, const void* rec_dev, const float* isr_dev, const float* feats, const void* X,
                                             const float* nx, const float* q, int T, int Tpad, int n_mix, int n_tiles, int split, float* scores,
-                                            uint32_t* best, float* pmin, unsigned* pidx, int part_ld, unsigned long long* survivors);
+                                            uint32_t* best, float* pmin, unsigned* pidx, int part_ld, unsigned long long* survivors, int forced_waves);
 
 // maximum approximation through the MFMA screen (see gmm_screen_kernel); frames in chunks that bound the mask workspace
 extern "C" int amx_internal_best_state_reduce(amx_ctx*, const float*, const unsigned*, int, int, int, uint32_t*, unsigned long long*, double*);
@@ -1600,9 +1604,9 @@ extern "C" int amx_internal_best_state_reduce(amx_ctx*, const float*, const unsi
 int score_screened(amx_gmm* h, const float* feats_dev, int T, float* scores_dev, uint32_t* best_dev, bool stats, uint32_t* best_state_dev,
                    unsigned long long* counts_dev, double* score_sum_dev) {
     hipStream_t st = h->ctx->stream;
-    const int   chunk = getenv("AMX_GMM_CHUNK") ? atoi(getenv("AMX_GMM_CHUNK")) : 65536;  // frames per pass: the workspace (survivor masks, 2 B per frame and mixture slot) grows to what a call needs
-    // one fused kernel (gmm_fused.hip) where its tile records exist; AMX_GMM_FUSED=0 keeps the two-kernel path (A/B runs, tests)
-    const bool fused = h->d_fus_rec && !(getenv("AMX_GMM_FUSED") && atoi(getenv("AMX_GMM_FUSED")) == 0) && !getenv("AMX_GMM_SCREEN_ALL");
+    const int   chunk = h->tune_chunk;  // frames per pass: the workspace (survivor masks, 2 B per frame and mixture slot) grows to what a call needs
+    // one fused kernel (gmm_fused.hip) where its tile records exist; tuning fused=0 keeps the two-kernel path (A/B runs, tests)
+    const bool fused = h->d_fus_rec && h->tune_fused && !h->tune_screen_all;
     for (int t0 = 0; t0 < T; t0 += chunk) {
         const int Tc = std::min(chunk, T - t0), Tpad = (Tc + 255) / 256 * 256;
         if (Tpad > h->scr_cap_T || (!fused && !h->d_scr_masks)) {
@@ -1634,7 +1638,7 @@ int score_screened(amx_gmm* h, const float* feats_dev, int T, float* scores_dev,
         }
         if (fused) {
             const int n_tiles = h->scr_Rpad / 256;
-            const int split   = amx_internal_gmm_fused_split(h->ctx->n_cu, Tpad, n_tiles);
+            const int split   = amx_internal_gmm_fused_split(h->ctx->n_cu, Tpad, n_tiles, h->tune_fused_waves);
             float*    pmin    = nullptr;
             unsigned* pidx    = nullptr;
             if (stats) {
@@ -1657,7 +1661,7 @@ int score_screened(amx_gmm* h, const float* feats_dev, int T, float* scores_dev,
                 int r = amx_internal_gmm_fused_score(h->ctx, h->dim, h->d_fus_rec, h->d_isr, x, h->d_scr_X, h->d_scr_nx, h->d_scr_q, Tc, Tpad,
                                                      h->n_mix, n_tiles, split, scores_dev + (size_t)t0 * h->n_mix,
                                                      best_dev ? best_dev + (size_t)t0 * h->n_mix : nullptr, pmin, pidx, Tpad,
-                                                     h->count_survivors ? h->d_fus_surv : nullptr);
+                                                     h->count_survivors ? h->d_fus_surv : nullptr, h->tune_fused_waves);
                 if (r != AMX_OK)
                     return r;
                 if (h->count_survivors)
@@ -1675,8 +1679,8 @@ int score_screened(amx_gmm* h, const float* feats_dev, int T, float* scores_dev,
         {
             amx::ScopedKernelTimer timer(h->ctx, "gmm_screen");
             const int ntr = h->scr_Rpad / 256, ntt = Tpad / 256;
-            const char* variant = getenv("AMX_GMM_SCREEN_KERNEL");  // rows (default) | persist | simple
-            if (h->scr_Kp == 64 && (!variant || !strcmp(variant, "rows"))) {
+            const char* variant = h->tune_screen_kernel.c_str();  // rows (default) | persist | simple
+            if (h->scr_Kp == 64 && !strcmp(variant, "rows")) {
                 auto      k   = amx::gmm_screen_rows_kernel;
                 const int lds = 2 * 32 * 1024;
                 hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -1707,7 +1711,7 @@ int score_screened(amx_gmm* h, const float* feats_dev, int T, float* scores_dev,
                                    h->d_scr_cabs, h->d_scr_nx, h->d_scr_q, h->d_scr_masks, ntr, d);
             }
         }
-        if (getenv("AMX_GMM_SCREEN_ALL"))  // debugging aid: every slot survives (the exact stage then evaluates all densities)
+        if (h->tune_screen_all)  // debugging aid: every slot survives (the exact stage then evaluates all densities)
             hipMemsetAsync(h->d_scr_masks, 0xff, (size_t)Tpad * h->scr_Mpad16 * 2, st);
         float*    pmin = nullptr;
         unsigned* pidx = nullptr;
@@ -1864,7 +1868,20 @@ int amx_gmm_create(amx_ctx* ctx, const amx_gmm_model* m, amx_gmm** out) {
     for (size_t i = 0; i < (size_t)m->n_cov * m->dim; ++i)
         AMX_REQUIRE(m->variances[i] > 0, AMX_ERR_INVALID, "amx_gmm_create: non-positive variance");
 
+    amx::Tuning tune;
+    if (!tune.parse(m->tuning, amx::gmm_tuning_keys, "amx_gmm_create"))
+        return AMX_ERR_INVALID;
     amx_gmm* h = new amx_gmm;
+    h->tune_screen        = tune.get("screen", 1);
+    h->tune_fused         = tune.get("fused", 1);
+    h->tune_screen_all    = tune.get("screen_all", 0);
+    h->tune_tied_prune    = tune.get("tied_prune", -1);
+    h->tune_chunk         = std::max(256, tune.get("chunk", 65536));
+    h->tune_fused_waves   = tune.get("fused_waves", 0);
+    h->tune_fr            = std::max(1, tune.get("fr", 8));
+    h->tune_simd_mfma     = tune.get("simd_mfma", 1);
+    h->tune_screen_kernel = tune.str("screen_kernel", "rows");
+    h->use_graphs         = tune.get("graph", 1);
     h->ctx     = ctx;
     h->dim     = m->dim;
     h->n_mix   = m->n_mix;
@@ -2010,7 +2027,7 @@ int amx_gmm_create(amx_ctx* ctx, const amx_gmm_model* m, amx_gmm** out) {
         memset(h->h_tied_surv, 0, 257 * 8);
     }
     // ---- MFMA screen tables (gmm_screen_kernel): private densities, <= 16 per mixture, operand fits f16
-    if (!h->tied && screen_dim_supported(m->dim) && !(getenv("AMX_GMM_SCREEN") && atoi(getenv("AMX_GMM_SCREEN")) == 0)) {
+    if (!h->tied && screen_dim_supported(m->dim) && h->tune_screen) {
         uint32_t kmax = 0;
         for (int i = 0; i < m->n_mix; ++i)
             kmax = std::max(kmax, m->mix_offsets[i + 1] - m->mix_offsets[i]);
@@ -2126,8 +2143,6 @@ int amx_gmm_create(amx_ctx* ctx, const amx_gmm_model* m, amx_gmm** out) {
     h->h_logw.assign(m->log_weight, m->log_weight + nk);
     h->mws = m->mixture_weight_scale;
     h->gsc = m->gaussian_scale;
-    if (const char* e = getenv("AMX_GMM_GRAPH"))
-        h->use_graphs = atoi(e);
     *out = h;
     return AMX_OK;
 }
@@ -2233,6 +2248,7 @@ static int ensure_simd(amx_gmm* h) {
     v.variances = h->h_vars.data();
     v.mixture_weight_scale = h->mws;
     v.gaussian_scale = h->gsc;
+    v.tuning = h->tune_simd_mfma ? nullptr : "simd_mfma=0";
     const int r = amx_internal_gmm_simd_create(&v, &h->simd, nullptr);
     h->simd_status = r == AMX_OK ? 1 : r;
     return r;
@@ -2243,8 +2259,7 @@ static int ensure_simd(amx_gmm* h) {
 // default adaptive -- the pruned kernel counts the (density, frame, tile) triples it had to evaluate, the host reads the count of
 // EARLIER calls from pinned memory (no synchronisation) and stays on the dense kernel for 64 calls while more than 10 % stood
 static bool tied_decide_prune(amx_gmm* h) {
-    const char* pe     = getenv("AMX_GMM_TIED_PRUNE");
-    const int   forced = pe ? atoi(pe) : -1;
+    const int forced = h->tune_tied_prune;
     if (forced >= 0)
         return forced != 0;
     // one asynchronous copy delivers survivors and examined triples of the calls that have COMPLETED: a consistent pair, however far
@@ -2419,8 +2434,7 @@ int amx_gmm_score_dev(amx_gmm* h, int mode, const float* feats_dev, int T, float
     // The pruned path of a shared-list model is six launches and a 2 KB copy: at the decoder's batch sizes their gaps are a seventh
     // of the pass, so repeated passes on unchanged buffers are replayed as one HIP graph like the screened CART path above (the
     // dense / pruned decision stays outside: a graph is only recorded and replayed for the pruned path).
-    if (h->uniform && mode == AMX_GMM_MAX && h->tied_forced < 0 && T <= chunk_max && T <= 4096 &&
-        !(getenv("AMX_GMM_SCREEN") && atoi(getenv("AMX_GMM_SCREEN")) == 0)) {
+    if (h->uniform && mode == AMX_GMM_MAX && h->tied_forced < 0 && T <= chunk_max && T <= 4096 && h->tune_screen) {
         const bool prune = tied_decide_prune(h);
         auto       nested = [&](int forced) {
             h->tied_forced = forced;
@@ -2503,7 +2517,7 @@ int amx_gmm_score_dev(amx_gmm* h, int mode, const float* feats_dev, int T, float
         const bool stage   = (long)amx::ceil_div(h->n_dens, 16) * fb < 4L * std::max(h->ctx->n_cu, 1);
         dp.dens_tile       = stage ? (int)std::min<long>(16, std::max<long>(2, (long)h->n_dens * fb / (4L * std::max(h->ctx->n_cu, 1)))) : 16;
         const bool use_uni = h->uniform;
-        const int screen = getenv("AMX_GMM_SCREEN") ? atoi(getenv("AMX_GMM_SCREEN")) : 1;  // 0: plain f64 kernel (A/B runs, tests)
+        const int screen = h->tune_screen;  // 0: plain f64 kernel (A/B runs, tests)
         const bool need64  = use_uni && mode == AMX_GMM_MAX && !screen;
         if (need64 && need > h->dist64_cap) {
             hipFree(h->d_dist64);
@@ -2540,9 +2554,7 @@ int amx_gmm_score_dev(amx_gmm* h, int mode, const float* feats_dev, int T, float
                 return r;
         }
         if (use_uni) {
-            int FR = 8;
-            if (const char* e = getenv("AMX_GMM_FR"))
-                FR = atoi(e);
+            int FR = h->tune_fr;
             amx::GmmUniformDims    ud{Tc, Tpad, h->n_mix, h->mix_pad, h->K, 0};
             dim3                   grid(amx::ceil_div(h->n_mix, 256), amx::ceil_div(Tc, FR));
             float*                 sc = scores_dev + (size_t)t0 * h->n_mix;

@@ -391,9 +391,8 @@ extern "C" int amx_internal_gmm_fused_create(int dim, int n_mix, int n_tiles, co
 
 // waves per workgroup: 12 (three per SIMD, 384 frames; the kernel uses 158 VGPRs) for long passes -- measured 5.1 ms against 5.9 ms
 // with 8 waves and 5.0 ms with 16 (which spills 9 registers) per 63 936 frames -- and 8 (256 frames) for the decoder's small batches,
-// where a 384-frame workgroup would idle a third of its waves.  AMX_FUSED_WAVES = 8 | 12 | 16 overrides (A/B runs).
-static int fused_waves(int Tpad) {
-    static const int forced = getenv("AMX_FUSED_WAVES") ? atoi(getenv("AMX_FUSED_WAVES")) : 0;
+// where a 384-frame workgroup would idle a third of its waves.  amx_gmm_model.tuning fused_waves = 8 | 12 | 16 overrides (A/B runs).
+static int fused_waves(int Tpad, int forced) {
     if (forced == 8 || forced == 12 || forced == 16)
         return forced;
     return Tpad >= 4096 ? 12 : 8;
@@ -402,10 +401,10 @@ static int fused_waves(int Tpad) {
 // how many mixture ranges a pass of Tpad frames is split into (workgroup = its frames x one range; one workgroup per CU): the
 // smallest split that gives every CU a workgroup, unless the frame tiles alone already fill 3/4 of them.  The partial arg-min
 // arrays hold that many rows.
-static int fused_split_raw(int n_cu, int Tpad, int n_tiles) {
-    const int fpw = fused_waves(Tpad) * 32;
+static int fused_split_raw(int n_cu, int Tpad, int n_tiles, int forced) {
+    const int fpw = fused_waves(Tpad, forced) * 32;
     const int ntt = (Tpad + fpw - 1) / fpw, cus = std::max(n_cu, 8);
-    if (fused_waves(Tpad) != 8) {  // frame tiles of 384: pick the split whose workgroup count is closest below a whole number of rounds
+    if (fused_waves(Tpad, forced) != 8) {  // frame tiles of 384: pick the split whose workgroup count is closest below a whole number of rounds
         int best = 1;
         double best_eff = 0;
         for (int sp = 1; sp <= std::min(n_tiles, 8); ++sp) {
@@ -426,10 +425,10 @@ static int fused_split_raw(int n_cu, int Tpad, int n_tiles) {
     return std::max(1, std::min(split, n_tiles));
 }
 
-extern "C" int amx_internal_gmm_fused_split(int n_cu, int Tpad, int n_tiles) {
+extern "C" int amx_internal_gmm_fused_split(int n_cu, int Tpad, int n_tiles, int forced_waves) {
     // every range holds ceil(n_tiles / split) tiles: report the number of NON-EMPTY ranges, the partial arg-min arrays have
     // exactly that many rows (an empty range would leave its row unwritten)
-    const int split = fused_split_raw(n_cu, Tpad, n_tiles);
+    const int split = fused_split_raw(n_cu, Tpad, n_tiles, forced_waves);
     const int per   = (n_tiles + split - 1) / split;
     return (n_tiles + per - 1) / per;
 }
@@ -437,8 +436,8 @@ extern "C" int amx_internal_gmm_fused_split(int n_cu, int Tpad, int n_tiles) {
 extern "C" int amx_internal_gmm_fused_score(amx_ctx* ctx, int dim, const void* rec_dev, const float* isr_dev, const float* feats,
                                             const void* X, const float* nx, const float* q, int T, int Tpad, int n_mix, int n_tiles,
                                             int split, float* scores, uint32_t* best, float* pmin, unsigned* pidx, int part_ld,
-                                            unsigned long long* survivors) {
-    const int   nw = fused_waves(Tpad), ntt = (Tpad + nw * 32 - 1) / (nw * 32);
+                                            unsigned long long* survivors, int forced_waves) {
+    const int   nw = fused_waves(Tpad, forced_waves), ntt = (Tpad + nw * 32 - 1) / (nw * 32);
     const int   lds = 2 * amx::fused_rec_bytes(dim);
     const char* rec = (const char*)rec_dev;
     hipStream_t st  = ctx->stream;

@@ -544,7 +544,12 @@ int amx_internal_gmm_simd_create(const amx_gmm_model* m, void** out, float* scal
     uint32_t kmax = 0;
     for (int i = 0; i < m->n_mix; ++i)
         kmax = std::max(kmax, m->mix_offsets[i + 1] - m->mix_offsets[i]);
-    const bool want = !(getenv("AMX_GMM_SIMD_MFMA") && atoi(getenv("AMX_GMM_SIMD_MFMA")) == 0);
+    amx::Tuning tune;
+    if (!tune.parse(m->tuning, amx::gmm_tuning_keys, "amx_gmm_create")) {
+        amx_internal_gmm_simd_destroy(s);
+        return AMX_ERR_INVALID;
+    }
+    const bool want = tune.get("simd_mfma", 1) != 0;
     if (want && m->n_cov == 1 && dim <= 64 && kmax <= 16) {
         const int           n_tiles = (m->n_mix + 15) / 16;
         std::vector<int8_t> A((size_t)n_tiles * 256 * 64, 0);

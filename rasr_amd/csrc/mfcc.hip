@@ -586,6 +586,8 @@ __global__ __launch_bounds__(256) void context_window_kernel(const float* __rest
 
 struct amx_mfcc {
     amx_ctx*        ctx = nullptr;
+    bool            tune_fft_mfma = false, tune_lpc_lds = false;  // amx_mfcc_cfg.tuning
+    int             tune_wgs = 0;
     amx::MfccTables tab;
     int             frames_per_tile = 16;
     // device copies of the tables
@@ -794,8 +796,8 @@ int launch_mfcc_var(amx_mfcc* h, const amx::MfccParams& p, int n_tiles) {
     // persistent workgroups: as many as are co-resident (LDS bound), each loops over tiles
     // (at most four per CU: five were 30 % slower on the PLP front ends, whose LDS footprint would allow them)
     int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / std::max<size_t>(h->lds_bytes, 1)));
-    if (const char* e = getenv("AMX_MFCC_WGS"))  // A/B runs: cap the workgroups per CU
-        per_cu = std::max(1, std::min(per_cu, atoi(e)));
+    if (h->tune_wgs > 0)  // A/B runs (tuning wgs=N): cap the workgroups per CU
+        per_cu = std::max(1, std::min(per_cu, h->tune_wgs));
     int grid   = std::min(n_tiles, per_cu * std::max(h->ctx->n_cu, 1));
     amx::ScopedKernelTimer timer(h->ctx, "mfcc");
     hipLaunchKernelGGL(kern, dim3(grid), dim3(amx::mfcc_waves(NC) * 64), h->lds_bytes, h->ctx->stream, p);
@@ -807,12 +809,12 @@ template<int NC>
 int launch_mfcc(amx_mfcc* h, const amx::MfccParams& p, int n_tiles, bool s16) {
     if (n_tiles <= 0)
         return AMX_OK;
-    // AMX_MFCC_FFT=mfma: the 512-point transform as two 16x16x16 complex products on the f32 matrix cores (see mfcc_kernel).  Measured
+    // amx_mfcc_cfg.tuning fft=mfma: the 512-point transform as two 16x16x16 complex products on the f32 matrix cores (see mfcc_kernel).  Measured
     // on config 2 (993 k frames, same box): 0.958 ms against 0.748 ms for the radix-4 LDS stages.  SQ counters (profiles/r03/pmc/
     // mfcc_fft_*): matrix pipe busy 36 % + vector ALUs busy 51 % = 87 % of the dispatch -- v_mfma_f32_16x16x4_f32 runs at the f32
     // vector rate and does not overlap with vector instructions on a SIMD, so 24 of them cost like 192 vector instructions, more
     // than the ~125 they replace.  The butterflies stay the default; the product form is kept for A/B runs.
-    static const bool mfma = getenv("AMX_MFCC_FFT") && !strcmp(getenv("AMX_MFCC_FFT"), "mfma");
+    const bool mfma = h->tune_fft_mfma;
     if constexpr (NC == 256) {
         if (mfma)
             return s16 ? launch_mfcc_var<NC, 3>(h, p, n_tiles) : launch_mfcc_var<NC, 1>(h, p, n_tiles);
@@ -844,6 +846,7 @@ void amx_mfcc_default_cfg(amx_mfcc_cfg* c) {
     c->filter_type            = AMX_FILTER_TRIANGULAR;
     c->boundary               = AMX_BOUNDARY_STRETCH_TO_COVER;
     c->warping                = AMX_WARP_MEL;
+    c->tuning                 = nullptr;
 }
 
 void amx_plp_default_cfg(amx_mfcc_cfg* c) {
@@ -879,8 +882,20 @@ int amx_mfcc_create(amx_ctx* ctx, const amx_mfcc_cfg* cfg, amx_mfcc** out) {
     // (amx_mfcc_describe / _n_frames / _tables), running it returns AMX_ERR_STATE.
     AMX_REQUIRE(cfg && out, AMX_ERR_INVALID, "amx_mfcc_create: NULL argument");
     *out        = nullptr;
+    amx::Tuning tune;
+    {
+        static const char* const keys[] = {"fft", "wgs", "lpc", nullptr};
+        if (!tune.parse(cfg->tuning, keys, "amx_mfcc_create"))
+            return AMX_ERR_INVALID;
+        const std::string fft = tune.str("fft", "stockham"), lpc = tune.str("lpc", "regs");
+        AMX_REQUIRE(fft == "stockham" || fft == "mfma", AMX_ERR_INVALID, "amx_mfcc_create: tuning fft=%s (stockham | mfma)", fft.c_str());
+        AMX_REQUIRE(lpc == "regs" || lpc == "lds", AMX_ERR_INVALID, "amx_mfcc_create: tuning lpc=%s (regs | lds)", lpc.c_str());
+    }
     amx_mfcc* h = new amx_mfcc;
     h->ctx      = ctx;
+    h->tune_fft_mfma = tune.str("fft", "stockham") == "mfma";
+    h->tune_lpc_lds  = tune.str("lpc", "regs") == "lds";
+    h->tune_wgs      = tune.get("wgs", 0);
     int r       = h->tab.build(*cfg);
     if (r != AMX_OK) {
         delete h;
@@ -1143,7 +1158,7 @@ static int mfcc_run_plan(amx_mfcc* h, const amx_mfcc_plan* p, const void* pcm_de
         return r;
     amx::ScopedKernelTimer timer(h->ctx, "lpc_cepstrum");
     const dim3 lgrid((unsigned)((total_frames + 63) / 64));
-    const bool in_regs = !(getenv("AMX_LPC_REGS") && atoi(getenv("AMX_LPC_REGS")) == 0);  // 0: the LDS kernel (A/B runs, tests)
+    const bool in_regs = !h->tune_lpc_lds;  // tuning lpc=lds: the LDS kernel (A/B runs, tests)
     if (in_regs && t.n_transform <= 16)
         hipLaunchKernelGGL(lpc_cepstrum_reg_kernel<16>, lgrid, dim3(64), 0, h->ctx->stream, h->d_ac, t.n_transform, ceps_dev, t.n_ceps, total_frames);
     else if (in_regs && t.n_transform <= 24)

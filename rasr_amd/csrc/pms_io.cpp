@@ -171,6 +171,7 @@ int amx_mixture_set_view(const amx_mixture_set* ms, amx_gmm_model* v) {
     v->variances            = ms->variances.data();
     v->mixture_weight_scale = 1.0;
     v->gaussian_scale       = 1.0;
+    v->tuning               = nullptr;
     return AMX_OK;
 }
 

@@ -7,11 +7,14 @@
 // With one process per GPU of a node, the sum is ONE RCCL all-reduce over xGMI of ONE flat f64 device buffer:
 //
 //     AmxHost::EpochReduce red(ctx);                                    // after amx_init
-//     double*   acc    = red.addStatistics("acc", amx_gmm_accumulator_size(gmm));   // kernels accumulate in place
-//     uint64_t* counts = red.addCounters("counts", nStates);            // integer atomics of amx_*_score_stats_dev
-//     double*   sum    = red.addStatistics("score-sum", 1);
-//     red.allocate();
-//     amx_comm* comm = AmxHost::connect(ctx, rank, world, "/shared/job-1234.amx-id");   // id file written by rank 0
+//     red.addStatistics("acc", amx_gmm_accumulator_size(gmm));          // declare the fields ...
+//     red.addCounters("counts", nStates);
+//     red.addStatistics("score-sum", 1);
+//     red.allocate();                                                   // ... then allocate; the pointers are valid from here on
+//     double*             acc    = red.statistics("acc");               // kernels accumulate in place
+//     unsigned long long* counts = red.counters("counts");              // integer atomics of amx_*_score_stats_dev
+//     double*             sum    = red.statistics("score-sum");
+//     amx_comm* comm = AmxHost::connect(ctx, rank, world, "/shared/job-1234.amx-id", 600, jobTag);   // id file written by rank 0
 //     ... one epoch: amx_gmm_score_stats_dev(..., counts, sum); amx_gmm_accumulate_dev(..., acc); ...
 //     red.allReduce(comm);                                              // ONE amx_comm_all_reduce_f64_dev
 //     if (rank == 0) { red.download("acc", host); amx_gmm_accumulator_write(gmm, host, "combined.acc"); }
@@ -35,15 +38,22 @@ inline void epochCheck(int status, const char* what) {
 
 // Rank 0 creates the communicator id and publishes it as a file (written under a temporary name, then renamed); the other ranks
 // wait for the file.  Any other transport of the 128 bytes does as well -- the library only needs every rank to pass the same id.
-inline amx_comm* connect(amx_ctx* ctx, int rank, int world, const std::string& idFile, int timeoutSeconds = 600) {
+// A file left behind by an EARLIER job must not be taken for this job's (RCCL has no timeout: ranks holding different ids wait
+// for ever): the file carries `jobTag` in front of the id and a rank only accepts a file with its own tag -- pass something unique to
+// the run and equal on all ranks (scheduler job id, start time of the launcher).  Rank 0 removes an existing file before it
+// publishes and removes its own after amx_comm_init has returned, i.e. after every rank has joined with the id it read.
+inline amx_comm* connect(amx_ctx* ctx, int rank, int world, const std::string& idFile, int timeoutSeconds = 600, uint64_t jobTag = 0) {
     unsigned char id[AMX_COMM_ID_BYTES];
     if (rank == 0) {
+        remove(idFile.c_str());
         epochCheck(amx_comm_unique_id(id), "amx_comm_unique_id");
         const std::string tmp = idFile + ".tmp";
         FILE*             f   = fopen(tmp.c_str(), "wb");
-        if (!f || fwrite(id, 1, sizeof id, f) != sizeof id)
+        const bool        ok  = f && fwrite(&jobTag, 1, sizeof jobTag, f) == sizeof jobTag && fwrite(id, 1, sizeof id, f) == sizeof id;
+        if (f)
+            fclose(f);
+        if (!ok)
             throw std::runtime_error("cannot write " + tmp);
-        fclose(f);
         if (rename(tmp.c_str(), idFile.c_str()) != 0)
             throw std::runtime_error("cannot publish " + idFile);
     }
@@ -52,18 +62,21 @@ inline amx_comm* connect(amx_ctx* ctx, int rank, int world, const std::string& i
         for (;;) {
             FILE* f = fopen(idFile.c_str(), "rb");
             if (f) {
-                const size_t n = fread(id, 1, sizeof id, f);
+                uint64_t     tag = 0;
+                const size_t nt = fread(&tag, 1, sizeof tag, f), n = fread(id, 1, sizeof id, f);
                 fclose(f);
-                if (n == sizeof id)
+                if (nt == sizeof tag && n == sizeof id && tag == jobTag)
                     break;
             }
             if (std::chrono::steady_clock::now() > deadline)
-                throw std::runtime_error("no communicator id in " + idFile);
+                throw std::runtime_error("no communicator id of this job in " + idFile);
             std::this_thread::sleep_for(std::chrono::milliseconds(50));
         }
     }
     amx_comm* comm = nullptr;
     epochCheck(amx_comm_init(ctx, rank, world, id, &comm), "amx_comm_init");
+    if (rank == 0)
+        remove(idFile.c_str());
     return comm;
 }
 

@@ -102,8 +102,15 @@ public:
 
     /** end of the segment's input: runs the fused kernel over the whole segment */
     bool eos() {
-        if (!h_ || (!samples_.empty() && !samples16_.empty()))
+        if (!h_)
             return false;
+        if (!samples_.empty() && !samples16_.empty()) {  // a segment is all-s16 or all-f32: drop it, the node stays usable for the next one
+            samples_.clear();
+            samples16_.clear();
+            nFrames_ = next_ = 0;
+            nSamples_ = 0;
+            return false;
+        }
         const bool s16 = !samples16_.empty();
         nSamples_      = (long)(s16 ? samples16_.size() : samples_.size());
         nFrames_       = amx_mfcc_n_frames(h_, nSamples_);

@@ -207,6 +207,30 @@ def test_pms_reads_reference_style_files(tmp_path):
         rasr_amd.read_pms(str(tmp_path / "missing.pms"))
 
 
+def test_tuning_strings_are_parsed_strictly_and_nothing_reads_kernel_switches_from_the_environment():
+    """amx_*_model.tuning: "key=value,..." chooses kernels for A/B runs and tests; a key the handle does not know or an item that is
+    not key=value fails the creation (a typo must not silently give the default kernel).  The shipped library reads no AMX_*
+    switch from the environment except AMX_RCCL_LIB (the file name of the RCCL library, include/amx.h)."""
+    import subprocess
+
+    import rasr_amd
+    model = synth.gmm_cart(4, 1, 2, 8, seed=1)
+    rasr_amd.GmmFeatureScorer(None, model, tuning="screen=0, fused=0,tied_prune=1")      # host-only handle: parsed, unused
+    rasr_amd.GmmFeatureScorer(None, model, tuning={"chunk": 4096, "screen_kernel": "persist"})
+    for bad in ("scren=0", "screen", "screen=0,=1", "tile=3"):
+        with pytest.raises(rasr_amd.AmxError, match="tuning"):
+            rasr_amd.GmmFeatureScorer(None, model, tuning=bad)
+    out = subprocess.run(["strings", _lib.LIB_PATH], capture_output=True, text=True).stdout.split()
+    env_names = sorted({w for w in out if w.startswith("AMX_") and w.isupper() and not w.startswith("AMX_PREC_")})   # enum names in error texts
+    assert env_names == ["AMX_RCCL_LIB"], env_names
+    srcs = os.path.join(ROOT, "rasr_amd", "csrc")
+    for f in os.listdir(srcs):
+        if f.endswith((".hip", ".cpp", ".hpp")):
+            for n, line in enumerate(open(os.path.join(srcs, f), errors="replace"), 1):
+                if "getenv" in line:
+                    assert "AMX_RCCL_LIB" in line or "AMX_TUNING" in line, "%s:%d reads the environment: %s" % (f, n, line.strip())
+
+
 def test_product_does_not_reference_the_oracle():
     """the shipped package must never import, link or call anything under oracle/"""
     for dirpath, _, files in os.walk(os.path.join(ROOT, "rasr_amd")):

@@ -15,7 +15,7 @@ def assert_exact(ctx, model, x, **kw):
     import rasr_amd
     from oracle import OracleGmm
     sc, best = rasr_amd.GmmFeatureScorer(ctx, model, **kw).score(x)
-    osc, obest = OracleGmm(model, **{k: v for k, v in kw.items() if k != "feature_scorer_type"}).score(x, mode=0)
+    osc, obest = OracleGmm(model, **{k: v for k, v in kw.items() if k not in ("feature_scorer_type", "tuning")}).score(x, mode=0)
     assert np.array_equal(sc.view(np.uint32), osc.view(np.uint32)), np.abs(sc - osc).max()
     assert np.array_equal(best, obest)
 
@@ -462,10 +462,54 @@ def test_baum_welch_em_does_not_decrease_likelihood(ctx):
     assert nll[-1] < nll[0] - 0.05 * abs(nll[0]), nll
 
 
-def assert_simd_exact(ctx, model, x, expect_scaling=True):
+def test_split_trained_model_scores_bit_exact(ctx):
+    """a trained-SHAPED model -- grown 1 -> 16 densities per state by the repository's own loop (accumulate, amx_gmm_estimate + split,
+    Viterbi re-estimation: tests/trained_gmm.py) on clustered features, so the densities of a mixture are close relatives and far
+    more of them pass the f16 screen than of a random-init model's -- is scored bit for bit like the oracle, scores and best
+    densities, by the fused kernel, the two-kernel screen path and the evaluate-everything kernel; the loop itself behaves like
+    training (every round doubles the densities, the mean score of the aligned state falls)"""
+    import torch
+
     import rasr_amd
     from oracle import OracleGmm
-    sc = rasr_amd.GmmFeatureScorer(ctx, model, feature_scorer_type="SIMD-diagonal-maximum")
+    from tests.trained_gmm import split_trained_gmm
+    n_mix = 160
+    model, x, align, hist = split_trained_gmm(ctx, n_mix=n_mix, dim=40, frames_per_state=500, rounds=4, iters=2, seed=5)
+    ks = np.diff(model["mix_offsets"])
+    assert ks.max() == 16 and ks.min() >= 4 and model["variances"].shape[0] == 1, (ks.min(), ks.max())
+    dens = [h["densities"] for h in hist]        # a mean splits once it has seen 20 frames: nearly a doubling per round
+    assert dens[0] == 2 * n_mix and all(1.5 * a < b <= 2 * a for a, b in zip(dens, dens[1:])), dens
+    assert all(b["mean_score"] < a["mean_score"] for a, b in zip(hist, hist[1:])), hist
+    T = 700
+    xs = x[:T].contiguous()
+    xh = xs.cpu().numpy()
+    want, wbest = OracleGmm(model).score(xh, mode=0)
+    fused = rasr_amd.GmmFeatureScorer(ctx, model)
+    fused.screen_counts(True)
+    for tuning in (None, "fused=0", "screen=0"):
+        sc = fused if tuning is None else rasr_amd.GmmFeatureScorer(ctx, model, tuning=tuning)
+        got, best = sc.score(xh)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (tuning, np.abs(got - want).max())
+        assert np.array_equal(best, wbest), tuning
+    surv, pairs = fused.screen_counts(False)
+    assert pairs > 0 and surv / pairs >= 1.0, (surv, pairs)
+    # the frames of a state are scored best by that state most of the time: the model has learnt the clusters
+    assert (got.argmin(axis=1) == align[:T].cpu().numpy()).mean() > 0.8
+    # the model right after the last split -- exact twins mean +- eps sqrt(var), the screen cannot separate them -- is exact as well
+    twins = split_trained_gmm.fresh_split
+    want, wbest = OracleGmm(twins).score(xh[:200], mode=0)
+    sc = rasr_amd.GmmFeatureScorer(ctx, twins)
+    sc.screen_counts(True)
+    got, best = sc.score(xh[:200])
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)) and np.array_equal(best, wbest)
+    surv2, pairs2 = sc.screen_counts(False)
+    assert surv2 / pairs2 > 1.8, (surv2, pairs2)                       # both twins of the winner survive
+
+
+def assert_simd_exact(ctx, model, x, expect_scaling=True, tuning=None):
+    import rasr_amd
+    from oracle import OracleGmm
+    sc = rasr_amd.GmmFeatureScorer(ctx, model, feature_scorer_type="SIMD-diagonal-maximum", tuning=tuning)
     got, best = sc.score(x)
     want, obest, scaling = OracleGmm(model).score_simd(x)
     if expect_scaling:
@@ -517,10 +561,8 @@ def test_simd_scorer_paths_agree_and_edge_values(ctx, monkeypatch):
     x[10] = 3e9
     x[11] *= 50
     a = assert_simd_exact(ctx, model, x)
-    monkeypatch.setenv("AMX_GMM_SIMD_MFMA", "0")
-    b = assert_simd_exact(ctx, model, x)
+    b = assert_simd_exact(ctx, model, x, tuning="simd_mfma=0")
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
-    monkeypatch.delenv("AMX_GMM_SIMD_MFMA")
     # an empty mixture in the middle of the set
     ks = np.diff(off).astype(np.int64)
     ks2 = np.insert(ks, 7, 0)
@@ -576,10 +618,8 @@ def test_batch_int_scorer_exact(ctx, kind, monkeypatch):
     for name in ("batch-diagonal-maximum-int", "batch-diagonal-maximum-fast"):
         got = rasr_amd.GmmFeatureScorer(ctx, model, feature_scorer_type=name).score(x, want_best=False)
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), np.abs(got - want).max()
-    monkeypatch.setenv("AMX_GMM_SIMD_MFMA", "0")
-    got = rasr_amd.GmmFeatureScorer(ctx, model, feature_scorer_type="batch-diagonal-maximum-int").score(x, want_best=False)
+    got = rasr_amd.GmmFeatureScorer(ctx, model, feature_scorer_type="batch-diagonal-maximum-int", tuning="simd_mfma=0").score(x, want_best=False)
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
-    monkeypatch.delenv("AMX_GMM_SIMD_MFMA")
     sc = rasr_amd.GmmFeatureScorer(ctx, model, feature_scorer_type="batch-diagonal-maximum-int")
     with pytest.raises(rasr_amd.AmxError, match="does not assign densities"):
         sc.score(x)
@@ -621,7 +661,7 @@ def test_small_batch_graph_replay_and_workspace_growth(ctx):
 def test_full_size_shard_properties(ctx, monkeypatch):
     """BASELINE config 5 shard scale (10 000 states x 16 densities, 70 000 frames: more than one internal pass of 65 536):
     size-independent properties instead of a full oracle run --
-      * the MFMA-screened scorer and the evaluate-everything kernel (AMX_GMM_SCREEN=0), two different algorithms, agree bit for bit
+      * the MFMA-screened scorer and the evaluate-everything kernel (tuning screen=0), two different algorithms, agree bit for bit
         on every score and every best-density index;
       * rows are independent: scoring the frames in another order permutes the results;
       * a sample of frames on both sides of the pass boundary equals the oracle;
@@ -636,8 +676,8 @@ def test_full_size_shard_properties(ctx, monkeypatch):
     ctx.use_torch_stream()
     xd = torch.from_numpy(x).cuda()
 
-    def run(kind="diagonal-maximum", frames=xd, want_best=True):
-        sc = rasr_amd.GmmFeatureScorer(ctx, model, feature_scorer_type=kind)
+    def run(kind="diagonal-maximum", frames=xd, want_best=True, tuning=None):
+        sc = rasr_amd.GmmFeatureScorer(ctx, model, feature_scorer_type=kind, tuning=tuning)
         s = torch.empty((frames.shape[0], 10000), dtype=torch.float32, device="cuda")
         b = torch.empty((frames.shape[0], 10000), dtype=torch.int32, device="cuda") if want_best else None
         sc.score_dev(frames, frames.shape[0], s, b)
@@ -645,9 +685,7 @@ def test_full_size_shard_properties(ctx, monkeypatch):
         return s, b
 
     s_scr, b_scr = run()
-    monkeypatch.setenv("AMX_GMM_SCREEN", "0")
-    s_dir, b_dir = run()
-    monkeypatch.delenv("AMX_GMM_SCREEN")
+    s_dir, b_dir = run(tuning="screen=0")
     assert torch.equal(s_scr.view(torch.int32), s_dir.view(torch.int32)) and torch.equal(b_scr, b_dir)
     del s_dir, b_dir
     perm = torch.randperm(T, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
@@ -660,15 +698,13 @@ def test_full_size_shard_properties(ctx, monkeypatch):
     assert np.array_equal(b_scr[sample].cpu().numpy().astype(np.uint32), obest)
     del s_scr, b_scr
     s_m, b_m = run("SIMD-diagonal-maximum")
-    monkeypatch.setenv("AMX_GMM_SIMD_MFMA", "0")
-    s_g, b_g = run("SIMD-diagonal-maximum", frames=xd[:8192])
-    monkeypatch.delenv("AMX_GMM_SIMD_MFMA")
+    s_g, b_g = run("SIMD-diagonal-maximum", frames=xd[:8192], tuning="simd_mfma=0")
     assert torch.equal(s_m[:8192].view(torch.int32), s_g.view(torch.int32)) and torch.equal(b_m[:8192], b_g)
 
 
 def test_full_size_tied_properties(ctx, monkeypatch):
     """BASELINE config 2 at full size (4096 shared densities, 10 000 tied states, batch 256): the f32-screened (min,+) tile kernel
-    and the plain f64 kernel (AMX_GMM_SCREEN=0) agree bit for bit on all 2.56 M scores and density indices; two frames equal
+    and the plain f64 kernel (tuning screen=0) agree bit for bit on all 2.56 M scores and density indices; two frames equal
     the oracle; frame permutations permute the results."""
     import torch
 
@@ -678,9 +714,7 @@ def test_full_size_tied_properties(ctx, monkeypatch):
     x = feats(256, 40, 210)
     sc = rasr_amd.GmmFeatureScorer(ctx, model)
     a, ab = sc.score(x)
-    monkeypatch.setenv("AMX_GMM_SCREEN", "0")
-    b, bb = sc.score(x)
-    monkeypatch.delenv("AMX_GMM_SCREEN")
+    b, bb = rasr_amd.GmmFeatureScorer(ctx, model, tuning="screen=0").score(x)
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and np.array_equal(ab, bb)
     perm = np.random.Generator(np.random.PCG64(3)).permutation(256)
     c, cb = sc.score(x[perm])
@@ -699,11 +733,8 @@ def test_every_screened_dimension_and_operand_width(ctx, monkeypatch, dim, poole
     if variant == "fused":
         if not (pooled and dim <= 40):
             pytest.skip("the fused kernel serves pooled covariances up to dim 40; other shapes take the two-kernel path")
-    else:
-        monkeypatch.setenv("AMX_GMM_FUSED", "0")
-        monkeypatch.setenv("AMX_GMM_SCREEN_KERNEL", variant)
     model = synth.gmm_cart(70, 1, 16, dim, seed=300 + dim, pooled=pooled)
-    assert_exact(ctx, model, feats(300, dim, 301))
+    assert_exact(ctx, model, feats(300, dim, 301), tuning=None if variant == "fused" else "fused=0,screen_kernel=" + variant)
 
 
 @pytest.mark.parametrize("prune", ["1", "0"])
@@ -714,11 +745,10 @@ def test_tied_pruned_and_dense_paths_exact(ctx, monkeypatch, prune, n_mix, n_den
     (min,+) tile kernel, each forced, against the oracle: mixture counts that leave a partial last tile, density counts below /
     above the near-list size, above the LDS staging of the selection kernel (9000) and not multiples of 64; flat weights
     (alpha 5: little to prune) and peaked ones"""
-    monkeypatch.setenv("AMX_GMM_TIED_PRUNE", prune)
     model = synth.gmm_tied(n_mix, n_dens, 24, seed=500 + n_dens, pooled=True, alpha=alpha)
     x = feats(T, 24, 501 + T)
     x[T // 2] *= 30.0
-    assert_exact(ctx, model, x)
+    assert_exact(ctx, model, x, tuning="tied_prune=" + prune)
 
 
 def test_tied_pruned_adversarial_and_statistics(ctx, monkeypatch):
@@ -726,11 +756,9 @@ def test_tied_pruned_adversarial_and_statistics(ctx, monkeypatch):
     so equal bounds) and the FIRST wins.  The adaptive switch: a model where nothing can be pruned (all weights equal, all
     distances equal) sends later calls to the dense kernel; results stay exact either way"""
     import rasr_amd
-    monkeypatch.setenv("AMX_GMM_TIED_PRUNE", "1")
     for n_dens, dup_every, big in ((96, 7, False), (200, 3, False), (130, 5, True)):
         model = _tied_adversarial(41 + n_dens, 150, n_dens, 24, dup_every, big)
-        assert_exact(ctx, model, feats(100, 24, 43))
-    monkeypatch.delenv("AMX_GMM_TIED_PRUNE")
+        assert_exact(ctx, model, feats(100, 24, 43), tuning="tied_prune=1")
     model = synth.gmm_tied(640, 512, 16, seed=77, pooled=True)
     model["means"][:] = model["means"][0]                      # every density at the same place: equal distances
     model["log_weight"][:] = np.log(1.0 / 512)                 # and equal weights: everything is a candidate
@@ -751,25 +779,23 @@ def test_tied_pruned_list_lengths_and_frame_passes(ctx, monkeypatch):
     the wave keeps in LDS, and the longer ones that go through the unscreened loop; (b) equal weights and equal distances: every
     list position is a candidate of every mixture (the rule walks whole lists, the first / last density wins); (c) more frames than
     one pass of the tied kernels takes (4096), with the frame count not a multiple of anything"""
-    monkeypatch.setenv("AMX_GMM_TIED_PRUNE", "1")
     for n_dens in (16, 33, 64, 255, 256, 257, 1000):
         model = synth.gmm_tied(130, n_dens, 16, seed=900 + n_dens, pooled=True)
         model["means"] = (model["means"][:1] + np.float32(1e-4) * model["means"]).astype(np.float32)
-        assert_exact(ctx, model, feats(70, 16, 901))
+        assert_exact(ctx, model, feats(70, 16, 901), tuning="tied_prune=1")
     for n_dens in (40, 256, 300):
         model = synth.gmm_tied(70, n_dens, 16, seed=910 + n_dens, pooled=True)
         model["means"][:] = model["means"][0]
         model["log_weight"][:] = np.log(1.0 / n_dens)
-        assert_exact(ctx, model, feats(33, 16, 911))
+        assert_exact(ctx, model, feats(33, 16, 911), tuning="tied_prune=1")
     model = synth.gmm_tied(100, 64, 16, seed=920, pooled=True)
-    assert_exact(ctx, model, feats(4096 + 777, 16, 921))
+    assert_exact(ctx, model, feats(4096 + 777, 16, 921), tuning="tied_prune=1")
 
 
 def test_tied_pruned_lists_that_are_not_the_identity(ctx, monkeypatch):
     """the pruned path's frame-major distance image: written by the distance kernel when the shared list names every density once
     (here: a permutation, list position != density id, and a list that skips densities), by the transposing kernel when a density
     is listed twice (the duplicate has the same distance; the first position wins ties)"""
-    monkeypatch.setenv("AMX_GMM_TIED_PRUNE", "1")
     rng = np.random.Generator(np.random.PCG64(930))
     for variant in ("permutation", "subset", "duplicate"):
         n_dens, n_mix = 200, 130
@@ -787,7 +813,7 @@ def test_tied_pruned_lists_that_are_not_the_identity(ctx, monkeypatch):
         model["mix_offsets"] = (np.arange(n_mix + 1, dtype=np.uint64) * k).astype(np.uint32)
         g = rng.gamma(0.1, 1.0, (n_mix, k)) + 1e-30
         model["log_weight"] = np.log(g / g.sum(axis=1, keepdims=True)).reshape(-1).astype(np.float64)
-        assert_exact(ctx, model, feats(70, 16, 932))
+        assert_exact(ctx, model, feats(70, 16, 932), tuning="tied_prune=1")
 
 
 @pytest.mark.parametrize("pooled", [True, False])
@@ -856,7 +882,6 @@ def test_screen_threshold_worst_case_model(ctx, monkeypatch, dim, fused):
     by the fused kernel and by the two-kernel path, and the construction really has the disadvantaged density win"""
     import rasr_amd
     from oracle import OracleGmm
-    monkeypatch.setenv("AMX_GMM_FUSED", fused)
     n_mix = 96
     model, x, slots = _screen_worst_case(dim, n_mix, 900 + dim)
     # what the screen sees: f16-rounded operands, difference of the two dot products against the true difference
@@ -871,7 +896,7 @@ def test_screen_threshold_worst_case_model(ctx, monkeypatch, dim, fused):
     osc, obest = OracleGmm(model).score(x, mode=0)
     won = sum(int(obest[m, m]) == sb for m, (sa, sb) in enumerate(slots))
     assert won == n_mix, won                                          # B is the reference's winner on its frame
-    sc, best = rasr_amd.GmmFeatureScorer(ctx, model).score(x)
+    sc, best = rasr_amd.GmmFeatureScorer(ctx, model, tuning="fused=" + fused).score(x)
     assert np.array_equal(sc.view(np.uint32), osc.view(np.uint32)), np.abs(sc - osc).max()
     assert np.array_equal(best, obest)
 
@@ -893,7 +918,7 @@ def test_fused_adversarial_twins(ctx, dim):
 
 
 def test_fused_equals_two_kernel_path_with_stats(ctx, monkeypatch):
-    """the fused kernel and round 1's two kernels (AMX_GMM_FUSED=0) agree bit for bit on scores, best densities, best states,
+    """the fused kernel and round 1's two kernels (tuning fused=0) agree bit for bit on scores, best densities, best states,
     counts and the score sum; frames that do not fit the f16 operand keep every slot in both; without a best-density buffer too"""
     import torch
 
@@ -908,8 +933,7 @@ def test_fused_equals_two_kernel_path_with_stats(ctx, monkeypatch):
     ctx.use_torch_stream()
     res = {}
     for mode in ("1", "0"):
-        monkeypatch.setenv("AMX_GMM_FUSED", mode)
-        sc = rasr_amd.GmmFeatureScorer(ctx, model)
+        sc = rasr_amd.GmmFeatureScorer(ctx, model, tuning="fused=" + mode)
         scores = torch.empty((T, M), dtype=torch.float32, device="cuda")
         bestd = torch.empty((T, M), dtype=torch.int32, device="cuda")
         state = torch.empty((T,), dtype=torch.int32, device="cuda")

@@ -262,14 +262,11 @@ def test_lpc_cepstrum_register_and_lds_kernels_agree(ctx, monkeypatch):
     from oracle.binding import MfccCfg
     pcm = np.concatenate([synth.waveform(30000, seed=21), np.zeros(2000, np.float32), synth.waveform(9000, seed=22)])
     for nac, nc in ((13, 13), (16, 12), (17, 17), (24, 20)):
-        monkeypatch.setenv("AMX_LPC_REGS", "1")
         a = rasr_amd.MfccExtractor(ctx, nr_cepstrum_coefficients=nc, front_end="mfplp", nr_autocorrelation_coefficients=nac, normalize=True,
-                                   filter_width=138.0).run(pcm)
-        monkeypatch.setenv("AMX_LPC_REGS", "0")
+                                   filter_width=138.0, tuning="lpc=regs").run(pcm)
         b = rasr_amd.MfccExtractor(ctx, nr_cepstrum_coefficients=nc, front_end="mfplp", nr_autocorrelation_coefficients=nac, normalize=True,
-                                   filter_width=138.0).run(pcm)
+                                   filter_width=138.0, tuning="lpc=lds").run(pcm)
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and np.isnan(a).any()
-    monkeypatch.delenv("AMX_LPC_REGS")
     got = rasr_amd.MfccExtractor(ctx, nr_cepstrum_coefficients=25, front_end="mfplp", nr_autocorrelation_coefficients=30, normalize=True,
                                  filter_width=138.0).run(pcm)
     cfg = MfccCfg.mfplp(n_ceps=25, n_autocorrelation=30, filter_width=138.0)
@@ -311,11 +308,9 @@ def test_s16_samples_give_the_same_bits_as_f32(ctx):
 
 
 def test_matrix_core_fft_against_the_butterfly_fft_and_the_oracle(ctx, tmp_path):
-    """AMX_MFCC_FFT=mfma runs the 512-point transform as two 16x16x16 complex products on v_mfma_f32_16x16x4_f32 (slower than the
+    """amx_mfcc_cfg.tuning "fft=mfma" runs the 512-point transform as two 16x16x16 complex products on v_mfma_f32_16x16x4_f32 (slower than the
     radix-4 LDS stages, kept for A/B runs): within the MFCC bar of the oracle and within f32 round-off of the default kernel --
     incl. the transform's corner cases: a unit impulse at every position class, a constant, a tone on a bin, silence"""
-    import subprocess
-    import sys
     import rasr_amd
     from oracle import OracleMfcc
     fe = rasr_amd.MfccExtractor(ctx, nr_cepstrum_coefficients=40, filter_width=138.0)
@@ -328,14 +323,7 @@ def test_matrix_core_fft_against_the_butterfly_fft_and_the_oracle(ctx, tmp_path)
         imp = np.zeros(n, np.float32)
         imp[pos] = 20000.0
         sigs.append(imp)
-    np.save(str(tmp_path / "sigs.npy"), np.stack(sigs))
-    # the matrix-core kernel in a fresh process (the choice is read once per process)
-    code = ("import numpy as np, rasr_amd, sys; ctx = rasr_amd.Context(0); "
-            "fe = rasr_amd.MfccExtractor(ctx, nr_cepstrum_coefficients=40, filter_width=138.0); "
-            "np.save(sys.argv[2], np.stack(fe.run_batch(list(np.load(sys.argv[1])))))")
-    env = dict(os.environ, AMX_MFCC_FFT="mfma", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    subprocess.check_call([sys.executable, "-c", code, str(tmp_path / "sigs.npy"), str(tmp_path / "mfma.npy")], env=env)
-    got = np.load(str(tmp_path / "mfma.npy"))
+    got = np.stack(rasr_amd.MfccExtractor(ctx, nr_cepstrum_coefficients=40, filter_width=138.0, tuning="fft=mfma").run_batch(sigs))
     ref = np.stack(fe.run_batch(sigs))
     for g, r, x in zip(got, ref, sigs):
         want = orc.run(x)

@@ -61,15 +61,19 @@ def viterbi_pass(ctx, model, x, align, chunk=32768):
 
 
 def split_trained_gmm(ctx, n_mix=10000, dim=40, frames_per_state=600, rounds=4, iters=2, seed=11, log=None):
-    """-> (model dict with up to 2^rounds densities per mixture and a pooled covariance, x, align, history)"""
+    """-> (model dict with up to 2^rounds densities per mixture and a pooled covariance, x, align, history); the model right after
+    the last split (exact twins, before any re-estimation) is left in split_trained_gmm.fresh_split"""
     import rasr_amd
     ctx.use_torch_stream()
     x, align = clustered_features(n_mix, dim, frames_per_state, seed)
     model = initial_model(n_mix, dim)
     hist = []
+    split_trained_gmm.fresh_split = None
     acc, s = viterbi_pass(ctx, model, x, align)
     for r in range(rounds):
         model = rasr_amd.gmm_estimate(model, acc, split=1)
+        if r == rounds - 1:   # the model as the trainer writes it right after its last split: twins mean +- eps, not yet re-estimated
+            split_trained_gmm.fresh_split = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in model.items()}
         for it in range(iters):
             acc, s = viterbi_pass(ctx, model, x, align)
             if it < iters - 1:   # the last pass's statistics go into the next round's estimate + split (or the final estimate)

@@ -5,7 +5,7 @@ cd "$(dirname "$0")/.."
 export AMX_LIBRARY=$PWD/rasr_amd/librasr_amd_lab.so
 for d in "${@:-0 8 16 24 32 64 72}"; do
   for dd in $d; do
-    AMX_MX_DBG=$dd python bench.py --workload nn-pipeline --precision f16mx --steps 6 --warmup 2 --no-cpu-baseline --no-configs 2>&1 | grep "^{" | tail -1 | \
+    AMX_TUNING=mx_dbg=$dd python bench.py --workload nn-pipeline --precision f16mx --steps 6 --warmup 2 --no-cpu-baseline --no-configs 2>&1 | grep "^{" | tail -1 | \
       python -c "import sys,json; d=json.loads(sys.stdin.readline()); s=d['stages']; print('dbg %3s  step %.3f ms  output layer %.3f ms  mean gemm %.3f ms' % ('$dd', d['ms_per_step'], s['ffnn_gemm_max']['avg_ms'], s['ffnn_gemm']['avg_ms']))"
   done
 done

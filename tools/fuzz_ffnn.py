@@ -1,7 +1,7 @@
 """tools/fuzz_ffnn.py [n_cases] [seed] -- random network shapes and batch sizes through the bf16 GEMM kernels: every tile configuration
-(AMX_GEMM_CFG 0 / 2 / 3 / 4 / 6 and the automatic choice) must give bit-identical scores and arg-min statistics, in plain bf16 AND in
-split bf16 (bf16x3); the bf16 result must stay within bf16 rounding of the fp32 MFMA path (itself checked against the oracle elsewhere),
-the split-bf16 result within 2e-4 relative of it (both are f32-accumulated; the bar against f64 accumulation is in the test suite)."""
+(amx_ffnn_model.tuning tile = 0 / 2 / 3 / 4 / 6 and the automatic choice) must give bit-identical scores and arg-min statistics, in plain bf16 AND in
+split bf16 (bf16x3) AND in f16 + MX-fp6 (f16mx); the bf16 result must stay within bf16 rounding of the fp32 MFMA path (itself checked against the oracle elsewhere),
+the split-bf16 and f16mx results within 2e-4 relative of it (both are f32-accumulated; the bar against f64 accumulation is in the test suite)."""
 import os
 import sys
 
@@ -25,10 +25,8 @@ for case in range(n_cases):
     x = torch.from_numpy(rng.standard_normal((T, dims[0])).astype(np.float32)).cuda()
     outs = {}
     for cfg in ("auto", "0", "2", "3", "4", "6", "fp32"):
-        os.environ.pop("AMX_GEMM_CFG", None)
-        if cfg not in ("auto", "fp32"):
-            os.environ["AMX_GEMM_CFG"] = cfg
-        nn = rasr_amd.NnBatchFeatureScorer(ctx, Ws, bs, acts, log_prior=logp, priori_scale=1.0, precision="fp32" if cfg == "fp32" else "bf16")
+        nn = rasr_amd.NnBatchFeatureScorer(ctx, Ws, bs, acts, log_prior=logp, priori_scale=1.0, precision="fp32" if cfg == "fp32" else "bf16",
+                                           tuning=None if cfg in ("auto", "fp32") else "tile=" + cfg)
         s = torch.empty((T, dims[-1]), dtype=torch.float32, device="cuda")
         best = torch.empty((T,), dtype=torch.int32, device="cuda")
         counts = torch.zeros((dims[-1],), dtype=torch.int64, device="cuda")
@@ -53,10 +51,8 @@ for case in range(n_cases):
     # ---- split bf16: the same configurations, bit-identical among themselves, close to the fp32 MFMA path
     x3 = {}
     for cfg in ("auto", "0", "2", "3", "4", "6"):
-        os.environ.pop("AMX_GEMM_CFG", None)
-        if cfg != "auto":
-            os.environ["AMX_GEMM_CFG"] = cfg
-        nn = rasr_amd.NnBatchFeatureScorer(ctx, Ws, bs, acts, log_prior=logp, priori_scale=1.0, precision="bf16x3")
+        nn = rasr_amd.NnBatchFeatureScorer(ctx, Ws, bs, acts, log_prior=logp, priori_scale=1.0, precision="bf16x3",
+                                           tuning=None if cfg == "auto" else "tile=" + cfg)
         s = torch.empty((T, dims[-1]), dtype=torch.float32, device="cuda")
         best = torch.empty((T,), dtype=torch.int32, device="cuda")
         counts = torch.zeros((dims[-1],), dtype=torch.int64, device="cuda")
@@ -67,7 +63,6 @@ for case in range(n_cases):
         if not torch.equal(best.long(), s.argmin(dim=1)):
             bad += 1
             print("MISMATCH fused arg-min (bf16x3)", cfg, dims, T)
-    os.environ.pop("AMX_GEMM_CFG", None)
     for cfg in ("0", "2", "3", "4", "6"):
         if not (torch.equal(x3[cfg][0].view(torch.int32), x3["auto"][0].view(torch.int32)) and torch.equal(x3[cfg][1], x3["auto"][1]) and
                 torch.equal(x3[cfg][2], x3["auto"][2])):
@@ -77,5 +72,29 @@ for case in range(n_cases):
     if not err3 <= 2e-4:
         bad += 1
         print("MISMATCH bf16x3 vs fp32", dims, T, err3)
+    # ---- f16 + MX-fp6 (AMX_PREC_F16MX): its three tile configurations bit-identical among themselves, the split-bf16 bar against fp32
+    mx = {}
+    for cfg in ("auto", "0", "2", "3"):
+        nn = rasr_amd.NnBatchFeatureScorer(ctx, Ws, bs, acts, log_prior=logp, priori_scale=1.0, precision="f16mx",
+                                           tuning=None if cfg == "auto" else "tile=" + cfg)
+        s = torch.empty((T, dims[-1]), dtype=torch.float32, device="cuda")
+        best = torch.empty((T,), dtype=torch.int32, device="cuda")
+        counts = torch.zeros((dims[-1],), dtype=torch.int64, device="cuda")
+        ssum = torch.zeros((1,), dtype=torch.float64, device="cuda")
+        nn.score_stats_dev(x, dims[0], T, s, best, counts, ssum)
+        torch.cuda.synchronize()
+        mx[cfg] = (s, best, counts)
+        if not torch.equal(best.long(), s.argmin(dim=1)):
+            bad += 1
+            print("MISMATCH fused arg-min (f16mx)", cfg, dims, T)
+    for cfg in ("0", "2", "3"):
+        if not (torch.equal(mx[cfg][0].view(torch.int32), mx["auto"][0].view(torch.int32)) and torch.equal(mx[cfg][1], mx["auto"][1]) and
+                torch.equal(mx[cfg][2], mx["auto"][2])):
+            bad += 1
+            print("MISMATCH f16mx config", cfg, "vs auto", dims, T, float((mx[cfg][0] - mx["auto"][0]).abs().max()))
+    errm = float(((mx["auto"][0] - f32).abs() - 2e-4 * f32.abs()).max())
+    if not errm <= 2e-4:
+        bad += 1
+        print("MISMATCH f16mx vs fp32", dims, T, errm)
 print("%d cases, %d mismatches" % (n_cases, bad))
 sys.exit(1 if bad else 0)

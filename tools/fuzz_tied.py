@@ -1,5 +1,5 @@
 """tools/fuzz_tied.py [n_cases] [seed] -- random tied models whose mixtures share one density list through the pruned exact scorer
-(gmm_tied.hip, forced with AMX_GMM_TIED_PRUNE=1), the dense tile kernel (=0) and the adaptive default, against the oracle bit for
+(gmm_tied.hip, forced with amx_gmm_model.tuning tied_prune=1), the dense tile kernel (=0) and the adaptive default, against the oracle bit for
 bit: density counts 1..9000, mixture counts that leave partial tiles, flat and peaked weights, zero-weight densities (a^ = +inf),
 tiny variances (negative constants), huge constants, near ties and duplicates, frames with outliers / inf / NaN.
 Not part of the test suite; run on a GPU box after touching gmm_tied.hip or the tied part of gmm.hip."""
@@ -52,11 +52,7 @@ for case in range(n_cases):
     want, wbest = OracleGmm(model).score(x)
     status = []
     for mode in ("1", "0", None):
-        if mode is None:
-            os.environ.pop("AMX_GMM_TIED_PRUNE", None)
-        else:
-            os.environ["AMX_GMM_TIED_PRUNE"] = mode
-        sc = rasr_amd.GmmFeatureScorer(ctx, model)
+        sc = rasr_amd.GmmFeatureScorer(ctx, model, tuning=None if mode is None else "tied_prune=" + mode)
         ok = True
         for _ in range(3 if mode is None else 1):        # the adaptive default: later calls see the statistics of earlier ones
             got, best = sc.score(x)

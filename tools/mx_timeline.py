@@ -1,0 +1,50 @@
+"""tools/mx_timeline.py [variant bits] -- where the time of a K-tile goes in gemm_mx_kernel (lab build of the library:
+make -C rasr_amd/csrc OBJDIR=build_lab OUT=../librasr_amd_lab.so EXTRA=-DAMX_LAB).
+
+Runs the config-5 output layer (2048 -> 10000, 32768 frames, f16mx) with DBG 2048 | variant bits: workgroup 0 stamps s_memtime in
+every wave for its first 48 K-tiles -- 0 barrier passed, 1 refill issued, 2 fragments in registers (an extra lgkmcnt(0): the
+instrumented kernel serialises reads and products of a wave), 3 products issued -- and prints per wave the mean cycles of the phases
+and of the whole period (steady state: K-tiles 8..47).  a tick of s_memtime is one shader cycle (guide, constants table)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ.setdefault("AMX_LIBRARY", os.path.join(ROOT, "rasr_amd", "librasr_amd_lab.so"))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+import rasr_amd  # noqa: E402
+from rasr_amd import _lib  # noqa: E402
+from tests import synth  # noqa: E402
+
+bits = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+ctx = rasr_amd.Context(0)
+ctx.use_torch_stream()
+Ws, bs, acts, logp = synth.ffnn([2048, 10000], seed=7)
+T = 32768
+x = torch.from_numpy(np.random.Generator(np.random.PCG64(1)).standard_normal((T, 2048)).astype(np.float32)).cuda()
+nn = rasr_amd.NnBatchFeatureScorer(ctx, Ws, bs, acts, log_prior=logp, precision="f16mx", tuning="mx_dbg=%d" % (2048 | bits))
+s = torch.empty((T, 10000), dtype=torch.float32, device="cuda")
+for _ in range(3):
+    nn.score_dev(x, 2048, T, s)
+torch.cuda.synchronize()
+L = _lib.lib()
+buf = (C.c_ulonglong * (8 * 48 * 4))()
+L.amx_lab_mx_stamps.restype = C.c_int
+assert L.amx_lab_mx_stamps(buf) == 0
+st = np.frombuffer(buf, dtype=np.uint64).reshape(8, 48, 4).astype(np.int64)
+t0 = st[:, 8, 0].min()
+print("variant bits %d; shader cycles (s_memtime); K-tiles 8..47 of workgroup 0" % bits)
+print("wave  period   barrier->refill  refill->frags  frags->products  products->next barrier   first barrier (rel)")
+for w in range(8):
+    a = st[w, 8:47]
+    nxt = st[w, 9:48, 0]
+    per = np.diff(st[w, 8:48, 0]).mean()
+    print("%4d  %6.1f   %15.1f  %13.1f  %15.1f  %22.1f   %d" % (w, per, (a[:, 1] - a[:, 0]).mean(), (a[:, 2] - a[:, 1]).mean(),
+                                                               (a[:, 3] - a[:, 2]).mean(), (nxt - a[:, 3]).mean(), st[w, 8, 0] - t0))
+print("raw, wave 0 and wave 4, K-tiles 8..11 (relative ticks):")
+for w in (0, 4):
+    print(w, (st[w, 8:12] - t0).tolist())
