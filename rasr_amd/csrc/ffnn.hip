@@ -406,7 +406,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[C::MI][C::MJ], char*
                 if (t < t_valid && !(NOSTORE && v.x != 123.456f)) {
                     float* o = (float*)out + (size_t)t * ldo + n;
                     if (n + 3 < n_valid && ((ldo & 3) == 0))
-                        *(float4*)o = v;
+                        __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, (f32x4*)o);  // 1.3 GB of scores per pass must not push the operand panels out of L2
                     else {
                         if (n < n_valid) o[0] = v.x;
                         if (n + 1 < n_valid) o[1] = v.y;
@@ -1592,7 +1592,10 @@ void launch_bf16_cfg(amx_ffnn* h, int l, const void* x, int ldx, void* out, int 
 }
 
 // AMX_PREC_F16MX tile configurations (ffnn_mx.hpp): the same shapes and the same selection rule as the bf16 kernels
-using MfgL = amx::mx::MxCfg<256, 256, 2, 4, 3>;  // 147 KB LDS, 8 waves of 128 x 64, two K-tiles in flight
+using MfgL = amx::mx::MxCfg<256, 256, 2, 4, 3>;      // 147 KB LDS, 8 waves of 128 x 64, two K-tiles in flight
+using MfgLP = amx::mx::MxCfg<256, 256, 2, 4, 3, 4>;  // the same with the software L2 prefetch 4 K-tiles ahead (tuning tile=4: A/B runs; measured 6 % SLOWER: the
+                                                     // prefetch loads sit in the in-order vmcnt queue in front of the next K-tile's pieces)
+using MfgLH = amx::mx::MxCfg<256, 256, 2, 4, 3, 0, 4>;  // the first wave of every SIMD issues all LDS-DMA pieces (tuning tile=5: A/B runs)
 using MfgA = amx::mx::MxCfg<128, 128, 2, 2, 3>;  //  74 KB: 2 workgroups per CU
 using MfgS = amx::mx::MxCfg<128, 64, 2, 2, 4>;   //  74 KB: small batches, three K-tiles in flight
 
@@ -1636,6 +1639,8 @@ void launch_mx(amx_ffnn* h, int l, const void* x, int xkts, void* out, int ldo, 
             case 2304: AMX_MX_LAUNCH(2304); break;
             case 2560: AMX_MX_LAUNCH(2560); break;
             case 2816: AMX_MX_LAUNCH(2816); break;
+            case 4096: AMX_MX_LAUNCH(4096); break;
+            case 6144: AMX_MX_LAUNCH(6144); break;
             case 1032: AMX_MX_LAUNCH(1032); break;
             case 1160: AMX_MX_LAUNCH(1160); break;
             case 16: AMX_MX_LAUNCH(16); break;
@@ -1665,8 +1670,9 @@ void launch_mx_cfg(amx_ffnn* h, int l, const void* x, int xkts, void* out, int l
             cfg = 3;
     }
     switch (cfg) {
-        case 2:
-        case 4: launch_mx<MfgL, ACT, LAST>(h, l, x, xkts, out, ldo, T, Tpad, n_valid); break;
+        case 2: launch_mx<MfgL, ACT, LAST>(h, l, x, xkts, out, ldo, T, Tpad, n_valid); break;
+        case 4: launch_mx<MfgLP, ACT, LAST>(h, l, x, xkts, out, ldo, T, Tpad, n_valid); break;
+        case 5: launch_mx<MfgLH, ACT, LAST>(h, l, x, xkts, out, ldo, T, Tpad, n_valid); break;
         case 3:
         case 6: launch_mx<MfgS, ACT, LAST>(h, l, x, xkts, out, ldo, T, Tpad, n_valid); break;
         default: launch_mx<MfgA, ACT, LAST>(h, l, x, xkts, out, ldo, T, Tpad, n_valid); break;

@@ -203,9 +203,16 @@ __global__ __launch_bounds__(256) void neg_act_kernel(float* __restrict__ x, lon
 }
 
 // ---------------------------------------------------------------------------------------------- tile configurations
-template<int BN_, int BT_, int WN_, int WT_, int STAGES_>
+template<int BN_, int BT_, int WN_, int WT_, int STAGES_, int PF_ = 0, int IW_ = 0>
 struct MxCfg {
     static constexpr int BN = BN_, BT = BT_, WN = WN_, WT = WT_, STAGES = STAGES_;
+    // PF > 0 (256 x 256 tiles only): waves 0-5 touch the 384 cache lines of the K-tile PF steps ahead of the one whose LDS-DMA they
+    // have just issued (one dword per 128-byte line, 64 lines per wave-instruction) -- a software prefetch from the Infinity Cache /
+    // HBM into L2.  The LDS ring holds two K-tiles in flight (~2 periods of 1.7 us); a K-tile whose lines miss L2 (23 % of the
+    // requests, pmc/pmc_l2a.txt) arrives later than that and every wave ends its period waiting (tools/mx_timeline.py: 500-1600 of
+    // 3500 cycles per K-tile in s_waitcnt vmcnt).
+    static constexpr int PF = PF_;
+    static_assert(PF_ == 0 || (BN_ == 256 && BT_ == 256 && WN_ * WT_ == 8), "the prefetch walks whole 256-row blocks with six waves");
     static constexpr int NW = WN * WT, THREADS = NW * 64, PLANES = 1;
     // K-loop variants of gemm_mx_kernel, both measured on the output layer (profiles/r04/gemm_mx_ablation3.log: 2.17-2.31 ms in
     // all four combinations, i.e. no gain) and left off: SKEW = the two waves of a SIMD half a K-tile apart, SPREAD = the LDS-DMA
@@ -217,10 +224,14 @@ struct MxCfg {
     static constexpr int STAGE_BYTES = A_BYTES + B_BYTES, LDS_BYTES = STAGES * STAGE_BYTES;
     static constexpr int A_PIECES = BN / 16 + BN / 32, B_PIECES = BT / 16 + BT / 32;  // 1 KB pieces of H and R
     static constexpr int TOTAL = A_PIECES + B_PIECES;
-    static constexpr int PPW = (TOTAL + NW - 1) / NW;  // pieces per wave, at most
-    static constexpr int NHI = TOTAL % NW;             // waves 0 .. NHI-1 issue PPW pieces, the rest PPW - 1 (NHI == 0: all PPW)
+    // IW: waves that issue the LDS-DMA (default all).  IW = NW / 2: the first wave of every SIMD issues all pieces, its partner none
+    // -- the partner goes from its fragment reads straight to its products while the issuing wave sits in the address unit's queue
+    static constexpr int IW  = IW_ > 0 ? IW_ : NW;
+    static constexpr int PPW = (TOTAL + IW - 1) / IW;  // pieces per issuing wave, at most
+    static constexpr int NHI = TOTAL % IW;             // waves 0 .. NHI-1 issue PPW pieces, the other issuing waves PPW - 1 (NHI == 0: all PPW)
+    static_assert(PF_ == 0 || IW_ == 0, "the prefetch accounting assumes every wave issues PPW pieces");
     static_assert(BN % 64 == 0 && BT % 64 == 0 && 256 % BN == 0 && 256 % BT == 0, "tiles are whole record pieces of a 256-row block");
-    static_assert(STAGES >= 2 && STAGES <= 4 && 3 * PPW < 64, "vmcnt immediate");
+    static_assert(STAGES >= 2 && STAGES <= 4 && 3 * PPW + 3 < 64, "vmcnt immediate");
 };
 
 // LDS-DMA piece p of a K-tile: source offset inside the operand's block (ha / hb: which part of the 256 rows the tile covers),
@@ -291,7 +302,7 @@ __device__ __forceinline__ u32x6 q_fields(f16x8 c0, f16x8 c1, unsigned scale_byt
 // -(D + bias) with the arg-min partials of the fused statistics.  Persistent workgroups, XCD-aware tile order, STAGES-deep LDS
 // ring with ONE barrier per K-tile and counted vmcnt (never a drain inside the loop).
 // DBG (lab builds only, -DAMX_LAB + AMX_MX_DBG): 8 no matrix instructions, 16 no operand DMA after the prologue, 32 no scaled product
-// (conversions and MX MFMAs skipped), 64 every workgroup streams one of 8 tiles (all operands L2 hits), 128 no fp6 conversions, 256 wave skew, 512 LDS-DMA pieces spread between the products, 1024 rotated K walk per tile, 2048 s_memtime stamps of workgroup 0 (mx_stamps)
+// (conversions and MX MFMAs skipped), 64 every workgroup streams one of 8 tiles (all operands L2 hits), 128 no fp6 conversions, 256 wave skew, 512 LDS-DMA pieces spread between the products, 1024 rotated K walk per tile, 2048 s_memtime stamps of workgroup 0 (mx_stamps), 4096 fragment reads awaited in front of the refill burst
 template<class C, int ACT, bool LAST, int DBG = 0>
 __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const char* __restrict__ W, const char* __restrict__ X, const float* __restrict__ bias,
                                                             void* __restrict__ out, int KT, int xkts, int ktn, int ldo, int n_valid, int t_valid,
@@ -339,8 +350,8 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const char* __restr
         bool p_b[C::PPW];
 #pragma unroll
         for (int q = 0; q < C::PPW; ++q) {
-            const int p = q * C::NW + wave;
-            if (p < C::TOTAL)
+            const int p = q * C::IW + wave;
+            if (p < C::TOTAL && wave < C::IW)
                 piece_offsets<C>(p, ha, hb, p_src[q], p_dst[q], p_b[q]);
             else {
                 p_src[q] = p_dst[q] = 0;
@@ -355,7 +366,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const char* __restr
         const unsigned voff = (unsigned)lane * 16u;
         const unsigned lds_base = (unsigned)(uintptr_t)lds;
         auto piece = [&](int q, int slot, int kt) {  // q: compile-time constant after unrolling
-            if (q == C::PPW - 1 && !hi_wave)
+            if ((q == C::PPW - 1 && !hi_wave) || (C::IW < C::NW && wave >= C::IW))
                 return;
             int ktm = kt;
             if constexpr ((DBG & 1024) != 0) {  // ablation: every tile starts its walk over K somewhere else (other L2 channels)
@@ -366,10 +377,22 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const char* __restr
             const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_base + slot * C::STAGE_BYTES + p_dst[q]));
             asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(src), "s"(dst) : "memory");
         };
+        float    pf_reg  = 0.f;  // destination of the prefetch loads: stays allocated for the whole K-loop (a load may land any time)
+        const bool pf_wave = C::PF > 0 && wave < 6;
+        auto prefetch = [&](int kt) {  // K-tile kt of the operand stream: lines [64 w, 64 w + 64) of W's block (waves 0-2) or X's (3-5)
+            if constexpr (C::PF > 0) {
+                if (pf_wave) {
+                    const int   ktc = min(kt, KT - 1);
+                    const char* p   = (wave < 3 ? wblk : xblk) + (size_t)ktc * BLK + (wave % 3) * 8192;
+                    asm volatile("global_load_dword %0, %1, %2" : "+v"(pf_reg) : "v"((unsigned)lane * 128u), "s"(p) : "memory");
+                }
+            }
+        };
         auto stage = [&](int slot, int kt) {
 #pragma unroll
             for (int q = 0; q < C::PPW; ++q)
                 piece(q, slot, kt);
+            prefetch(kt + C::PF);
         };
 
         f32x16 acc[C::MI][C::MJ];
@@ -454,6 +477,8 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const char* __restr
                     keep_alive(rb[j].x), keep_alive(rb[j].y), keep_alive(rb[j].z), keep_alive(rb[j].w);
                 for (int m = 0; m < C::MI * C::MJ; ++m)
                     after_mfma();
+                if (dma_kt >= 0)
+                    prefetch(dma_kt + C::PF);
                 dma_kt = -1;
                 return;
             }
@@ -489,6 +514,8 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const char* __restr
                         acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av[i], bv[j], acc[i][j], 2, 2, 0, (int)ra[i].w, 0, (int)rb[j].w);
                     after_mfma();
                 }
+            if (dma_kt >= 0)
+                prefetch(dma_kt + C::PF);  // SPREAD variant: the refill's prefetch follows its last piece, as in stage()
             dma_kt = -1;
         };
         // Skewed wave groups (8-wave tiles; waves w and w + 4 share a SIMD): between two barriers the EARLY wave of a SIMD reads
@@ -512,7 +539,17 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const char* __restr
         auto sync = [&](int kt) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             const int ahead = min(C::STAGES - 2, KT - 1 - kt);  // K-tiles that stay in flight
-            if (hi_wave) {
+            if (C::PF > 0 && pf_wave) {  // every refill of this wave is PPW pieces + one prefetch load (C::PF > 0: all waves issue PPW pieces)
+                if (C::STAGES >= 4 && ahead == 2)
+                    mx_wait<2 * (C::PPW + 1) + 1>();
+                else if (C::STAGES >= 3 && ahead == 1)
+                    mx_wait<C::PPW + 2>();
+                else
+                    mx_wait<0>();
+            }
+            else if (C::IW < C::NW && wave >= C::IW)
+                mx_wait<0>();  // nothing of its own in flight: the issuing waves' waits + the barrier cover the K-tile
+            else if (hi_wave) {
                 if (C::STAGES >= 4 && ahead == 2)
                     mx_wait<2 * C::PPW>();
                 else if (C::STAGES >= 3 && ahead == 1)
@@ -531,10 +568,17 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const char* __restr
             __builtin_amdgcn_s_barrier();
             stamp(kt, 0);
             if (kt + C::STAGES - 1 < KT && !(DBG & 16)) {
-                if constexpr (C::SPREAD != ((DBG & 512) != 0))
-                    dma_kt = kt + C::STAGES - 1;  // issued by the next products()
-                else
-                    stage((kt + C::STAGES - 1) % C::STAGES, kt + C::STAGES - 1);  // as a burst behind the barrier
+                dma_kt = kt + C::STAGES - 1;  // issued by refill() or, piece by piece, by the next products() (SPREAD)
+            }
+        };
+        // The refill burst goes BEHIND the fragment reads of the K-tile: a piece holds the issuing wave until the address unit has
+        // taken its 1 KB (eight waves share the unit: 360-800 cycles for a wave's six pieces, tools/mx_timeline.py), and the LDS
+        // reads issued in front of it complete meanwhile -- issued behind it they added their ~500 cycles of latency to every period.
+        auto refill = [&](int kt) {
+            if constexpr (C::SPREAD == ((DBG & 512) != 0)) {
+                if (dma_kt >= 0)
+                    stage(dma_kt % C::STAGES, dma_kt);
+                dma_kt = -1;
             }
             stamp(kt, 1);
         };
@@ -550,16 +594,21 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const char* __restr
             if (!late)
                 sync(kt);
             reads(kt);
+            if (late && kt + 1 < KT)
+                sync(kt + 1);
+            if constexpr ((DBG & 4096) != 0)  // ablation: the burst in front of the reads' completion, as before
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            refill(kt);
             if constexpr ((DBG & 2048) != 0) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 stamp(kt, 2);
             }
-            if (late && kt + 1 < KT)
-                sync(kt + 1);
             products();
             stamp(kt, 3);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (C::PF > 0)
+            asm volatile("" ::"v"(pf_reg));
 
         // the epilogue's lane-dependent addresses are derived from opaque copies of the lane / thread id: computed from `lane` they are
         // invariants of the tile loop, get hoisted in front of the K-loop and spilled there (the K-loop owns the register file) -- and a
