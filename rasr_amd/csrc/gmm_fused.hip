@@ -68,6 +68,21 @@ __device__ __forceinline__ void fused_dma16(const void* gsrc, unsigned lds_byte_
 // The reference's distance is therefore written with plain operations and this file is compiled with -fno-slp-vectorize (the
 // SLP vectoriser would re-pack them).  Workgroup = 8 waves x 32 frames, two waves per SIMD, <= 256 VGPRs; per tile a wave runs the
 // screen of its 32 frames, then the exact evaluation (the MFMA latencies of one wave hide behind the VALU work of the other).
+#ifdef AMX_LAB
+// lab builds: s_memtime stamps of workgroup 0, [wave < 16][tile < 64][phase]: 0 barrier passed (+ next tile's DMA issued), 1 screen
+// done, 2 first survivors done, 3 further survivors done, 4 results issued; amx_lab_fused_stamps (tools/fused_timeline.py)
+__device__ unsigned long long fused_stamps[16 * 64 * 6];
+#define FUSED_STAMP(phase)                                                                                             \
+    do {                                                                                                               \
+        if (blockIdx.x == 0 && lane == 0 && (r - r_begin) < 64)                                                        \
+            fused_stamps[(wave * 64 + (r - r_begin)) * 6 + (phase)] = __builtin_amdgcn_s_memtime();                    \
+    } while (0)
+#else
+#define FUSED_STAMP(phase) \
+    do {                   \
+    } while (0)
+#endif
+
 template<int DIM, bool BEST, int NW>
 __global__ __launch_bounds__(NW * 64) void gmm_fused_kernel(const float* __restrict__ g_feats, const _Float16* __restrict__ g_X,
                                                         const float* __restrict__ g_nx, const float* __restrict__ g_q,
@@ -78,6 +93,11 @@ __global__ __launch_bounds__(NW * 64) void gmm_fused_kernel(const float* __restr
                                                         unsigned long long* __restrict__ g_survivors) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int LD = fused_ld(DIM), REC = fused_rec_bytes(DIM), NP = REC / 1024;
+#ifdef FUSED_ISSUE_ALL
+    constexpr bool ISSUE4 = false;
+#else
+    constexpr bool ISSUE4 = true;
+#endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tile_t = blockIdx.x / r_split, part = blockIdx.x % r_split;
@@ -86,13 +106,28 @@ __global__ __launch_bounds__(NW * 64) void gmm_fused_kernel(const float* __restr
     if (r_begin >= r_end)
         return;
     const unsigned lds_base = (unsigned)(uintptr_t)lds;
+    // Which waves issue the record's LDS-DMA: with three waves per SIMD only the first of each SIMD (waves 0-3).  A piece holds its
+    // wave until the address unit has taken it; the first wave of a SIMD wins the vector-issue arbitration, finishes every tile
+    // first and waits a third of the period at the barrier (tools/fused_timeline.py) -- the issue time comes out of that slack
+    // instead of out of every wave's start of the tile.
+    constexpr int IW = (NW == 12 && ISSUE4) ? 4 : NW;
     auto load_tile = [&](int r, int buf) {
+        if (wave >= IW)
+            return;
         const char*    src = g_rec + (size_t)r * REC + lane * 16;
         const unsigned dst = lds_base + buf * REC;
-        for (int p = wave; p < NP; p += NW)
+        for (int p = wave; p < NP; p += IW)
             fused_dma16(src + p * 1024, (unsigned)__builtin_amdgcn_readfirstlane((int)(dst + p * 1024)));
     };
     load_tile(r_begin, 0);
+#ifdef FUSED_PRIO  // lab: static priorities so that the three waves of a SIMD finish a tile together (the arbitration prefers the oldest)
+    if (NW == 12) {
+        if ((wave >> 2) == 2)
+            __builtin_amdgcn_s_setprio(2);
+        else if ((wave >> 2) == 1)
+            __builtin_amdgcn_s_setprio(1);
+    }
+#endif
     const int  frow = lane & 31, fk = lane >> 5;
     const int  t    = tile_t * (NW * 32) + wave * 32 + frow;
     const bool live = t < T;
@@ -123,7 +158,9 @@ __global__ __launch_bounds__(NW * 64) void gmm_fused_kernel(const float* __restr
         const int buf = (r - r_begin) & 1;
         // my DMA pieces of tile r are older than the stores of tile r - 1: waiting until only those stores are outstanding
         // means the pieces have landed (gfx9 retires vector memory operations in issue order)
-        if (r == r_begin || !counted)
+        if (wave >= IW)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // no DMA of its own in flight; its stores need no wait
+        else if (r == r_begin || !counted)
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         else if (BEST)
             asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
@@ -132,6 +169,15 @@ __global__ __launch_bounds__(NW * 64) void gmm_fused_kernel(const float* __restr
         __builtin_amdgcn_s_barrier();  // everybody's pieces are there, and nobody reads the other stage any more
         if (r + 1 < r_end)
             load_tile(r + 1, buf ^ 1);
+        FUSED_STAMP(0);
+#ifdef FUSED_SLEEP  // lab: the three waves of a SIMD enter the screen one after the other instead of sharing the matrix pipe
+        if (NW == 12) {
+            if ((wave >> 2) == 1)
+                __builtin_amdgcn_s_sleep(FUSED_SLEEP);
+            else if ((wave >> 2) == 2)
+                __builtin_amdgcn_s_sleep(2 * FUSED_SLEEP);
+        }
+#endif
         if (!wave_live)  // a wave behind the last frame only takes part in the DMA and the barriers
             continue;
         const char*  stage = lds + buf * REC;
@@ -173,6 +219,7 @@ __global__ __launch_bounds__(NW * 64) void gmm_fused_kernel(const float* __restr
             M[i >> 1] |= m16 << (16 * (i & 1));
         }
         n_surv += __popc(M[0]) + __popc(M[1]) + __popc(M[2]) + __popc(M[3]);
+        FUSED_STAMP(1);
 
         // ---- exact evaluation.  First survivor of every mixture in lockstep (static register indices), the ~4 % further
         // survivors in a divergent loop behind it, in slot order.  The mean row comes in 8-float pieces (2 x ds_read_b128).
@@ -217,6 +264,7 @@ __global__ __launch_bounds__(NW * 64) void gmm_fused_kernel(const float* __restr
             bpack |= take ? ((unsigned)sl << (4 * i)) : 0u;
             bvalid |= take ? (1u << i) : 0u;
         }
+        FUSED_STAMP(2);
         unsigned R[4];
 #pragma unroll
         for (int w = 0; w < 4; ++w) {  // remove the first survivor of both halves
@@ -253,6 +301,7 @@ __global__ __launch_bounds__(NW * 64) void gmm_fused_kernel(const float* __restr
             }
         }
 
+        FUSED_STAMP(3);
         // ---- results: score = 0.5 * best (f32 * double -> f32 in the reference: the same value), best density, best state so far
         const int m0 = r * 16;
         float     sc[8];
@@ -305,6 +354,7 @@ __global__ __launch_bounds__(NW * 64) void gmm_fused_kernel(const float* __restr
                     }
             }
         }
+        FUSED_STAMP(4);
     }
     if (g_survivors) {
         unsigned long long n = live ? n_surv : 0u;
@@ -472,3 +522,9 @@ extern "C" int amx_internal_gmm_fused_score(amx_ctx* ctx, int dim, const void* r
     AMX_HIP(hipGetLastError());
     return AMX_OK;
 }
+
+#ifdef AMX_LAB
+extern "C" int amx_lab_fused_stamps(unsigned long long* out /* [16 * 64 * 6] */) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(amx::fused_stamps), sizeof(amx::fused_stamps)) == hipSuccess ? AMX_OK : AMX_ERR_DEVICE;
+}
+#endif
