@@ -140,11 +140,16 @@ __device__ __noinline__ float power_node(float v, float power) {
 // A complex product costs three real ones (P1 = Zr Fr, P2 = Zi Fi, P3 = (Zr + Zi)(Fr + Fi); re = P1 - P2, im = P3 - P1 - P2):
 // 24 MFMAs per frame on the otherwise idle matrix pipe replace ~160 of the frame's ~310 vector instructions and three of its four LDS
 // round trips; the f32 MFMA is an exact fma chain, the error class is that of the f32 butterflies.
+// bit 4 (NC = 256; amx_mfcc_cfg.tuning prefetch=1): a wave fetches the samples of its NEXT frame while it transforms the current one
+// (12 more registers: 127 instead of 109, still four workgroups per CU).  Measured on config 2, one box, twice: 0.795 ms against
+// 0.743 ms -- SLOWER: the samples of a wave's next frame are the neighbours' current ones (60 % overlap, L1 / L2 hits), their
+// latency is not what a frame waits for.  Kept as an A/B variant (round-3 review item 7).
 template<int NC, int VAR>
-__global__ __launch_bounds__(mfcc_waves(NC) * 64, (NC >= 1024 ? 1 : 4)) void mfcc_kernel(MfccParams p) {
+__global__ __launch_bounds__(mfcc_waves(NC) * 64, (NC >= 1024 ? 1 : ((VAR & 8) != 0 ? 3 : 4))) void mfcc_kernel(MfccParams p) {
     using P = FftPlan<NC>;
     constexpr bool MF  = (VAR & 1) != 0 && NC == 256;
     constexpr bool S16 = (VAR & 2) != 0;
+    constexpr bool PF  = (VAR & 4) != 0 && NC == 256;
     using Sample       = typename std::conditional<S16, short, float>::type;
     constexpr int MW = mfcc_waves(NC), MT = MW * 64;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -247,6 +252,8 @@ __global__ __launch_bounds__(mfcc_waves(NC) * 64, (NC >= 1024 ? 1 : 4)) void mfc
     const Sample*   seg   = (const Sample*)p.pcm + tile.sample_base;
     const long long nseg  = tile.n_samples;
     // ================= phase B: one frame per wavefront: FFT -> split -> |X| into s_amp[f][*]
+    float pn0[4], pn1[4], pnm[4];  // PF: samples 2c, 2c + 1, 2c - 1 of this wave's next frame (window mask applied)
+    bool  have = false;            // wave-uniform: pn* hold the frame about to be transformed
     for (int f = wave; f < FT; f += MW) {
         if (f >= tile.n_frames)
             break;  // wave-uniform
@@ -277,6 +284,15 @@ __global__ __launch_bounds__(mfcc_waves(NC) * 64, (NC >= 1024 ? 1 : 4)) void mfc
                     };
                     if (inner) {
                         const Sample* fr = seg + fbase;
+                        if (PF && have) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                x0[r] = pn0[r];
+                                x1[r] = pn1[r];
+                                xm[r] = pnm[r];
+                            }
+                        }
+                        else {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int  c = j + r * (NC / 4);
@@ -284,6 +300,23 @@ __global__ __launch_bounds__(mfcc_waves(NC) * 64, (NC >= 1024 ? 1 : 4)) void mfc
                             x0[r]        = w ? (float)fr[2 * c] : 0.f;
                             x1[r]        = w ? (float)fr[2 * c + 1] : 0.f;   // 2c + 1 <= frame_len: still inside the segment
                             xm[r]        = w ? (float)fr[2 * c - 1] : 0.f;
+                        }
+                        }
+                        if constexpr (PF) {  // this wave's next frame of the tile, if it is an inner frame too
+                            const int       fn     = f + MW;
+                            const long long fbn    = fbase + (long long)MW * p.frame_shift;
+                            have                   = fn < FT && fn < tile.n_frames && fbn + p.frame_len < nseg;
+                            if (have) {
+                                const Sample* fq = seg + fbn;
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    const int  c = j + r * (NC / 4);
+                                    const bool w = 2 * c < p.frame_len;
+                                    pn0[r]       = w ? (float)fq[2 * c] : 0.f;
+                                    pn1[r]       = w ? (float)fq[2 * c + 1] : 0.f;
+                                    pnm[r]       = w ? (float)fq[2 * c - 1] : 0.f;
+                                }
+                            }
                         }
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
@@ -293,6 +326,7 @@ __global__ __launch_bounds__(mfcc_waves(NC) * 64, (NC >= 1024 ? 1 : 4)) void mfc
                         }
                     }
                     else {
+                        have = false;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {  // samples 2c - 1, 2c, 2c + 1 of the frame (zero beyond the segment and the window)
                             const int       c = j + r * (NC / 4);
@@ -586,7 +620,7 @@ __global__ __launch_bounds__(256) void context_window_kernel(const float* __rest
 
 struct amx_mfcc {
     amx_ctx*        ctx = nullptr;
-    bool            tune_fft_mfma = false, tune_lpc_lds = false;  // amx_mfcc_cfg.tuning
+    bool            tune_fft_mfma = false, tune_lpc_lds = false, tune_prefetch = false;  // amx_mfcc_cfg.tuning
     int             tune_wgs = 0;
     amx::MfccTables tab;
     int             frames_per_tile = 16;
@@ -795,7 +829,7 @@ int launch_mfcc_var(amx_mfcc* h, const amx::MfccParams& p, int n_tiles) {
         AMX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
     // persistent workgroups: as many as are co-resident (LDS bound), each loops over tiles
     // (at most four per CU: five were 30 % slower on the PLP front ends, whose LDS footprint would allow them)
-    int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / std::max<size_t>(h->lds_bytes, 1)));
+    int per_cu = (int)std::max<size_t>(1, std::min<size_t>((VAR & 8) ? 3 : 4, (160 * 1024) / std::max<size_t>(h->lds_bytes, 1)));
     if (h->tune_wgs > 0)  // A/B runs (tuning wgs=N): cap the workgroups per CU
         per_cu = std::max(1, std::min(per_cu, h->tune_wgs));
     int grid   = std::min(n_tiles, per_cu * std::max(h->ctx->n_cu, 1));
@@ -818,6 +852,10 @@ int launch_mfcc(amx_mfcc* h, const amx::MfccParams& p, int n_tiles, bool s16) {
     if constexpr (NC == 256) {
         if (mfma)
             return s16 ? launch_mfcc_var<NC, 3>(h, p, n_tiles) : launch_mfcc_var<NC, 1>(h, p, n_tiles);
+    }
+    if constexpr (NC == 256) {
+        if (h->tune_prefetch)
+            return s16 ? launch_mfcc_var<NC, 6>(h, p, n_tiles) : launch_mfcc_var<NC, 4>(h, p, n_tiles);
     }
     return s16 ? launch_mfcc_var<NC, 2>(h, p, n_tiles) : launch_mfcc_var<NC, 0>(h, p, n_tiles);
 }
@@ -884,7 +922,7 @@ int amx_mfcc_create(amx_ctx* ctx, const amx_mfcc_cfg* cfg, amx_mfcc** out) {
     *out        = nullptr;
     amx::Tuning tune;
     {
-        static const char* const keys[] = {"fft", "wgs", "lpc", nullptr};
+        static const char* const keys[] = {"fft", "wgs", "lpc", "prefetch", nullptr};
         if (!tune.parse(cfg->tuning, keys, "amx_mfcc_create"))
             return AMX_ERR_INVALID;
         const std::string fft = tune.str("fft", "stockham"), lpc = tune.str("lpc", "regs");
@@ -896,6 +934,7 @@ int amx_mfcc_create(amx_ctx* ctx, const amx_mfcc_cfg* cfg, amx_mfcc** out) {
     h->tune_fft_mfma = tune.str("fft", "stockham") == "mfma";
     h->tune_lpc_lds  = tune.str("lpc", "regs") == "lds";
     h->tune_wgs      = tune.get("wgs", 0);
+    h->tune_prefetch = tune.get("prefetch", 0) != 0;
     int r       = h->tab.build(*cfg);
     if (r != AMX_OK) {
         delete h;
