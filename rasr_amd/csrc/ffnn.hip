@@ -1597,7 +1597,10 @@ using MfgLP = amx::mx::MxCfg<256, 256, 2, 4, 3, 4>;  // the same with the softwa
                                                      // prefetch loads sit in the in-order vmcnt queue in front of the next K-tile's pieces)
 using MfgLH = amx::mx::MxCfg<256, 256, 2, 4, 3, 0, 4>;  // the first wave of every SIMD issues all LDS-DMA pieces (tuning tile=5: A/B runs)
 using MfgA = amx::mx::MxCfg<128, 128, 2, 2, 3>;  //  74 KB: 2 workgroups per CU
-using MfgS = amx::mx::MxCfg<128, 64, 2, 2, 4>;   //  74 KB: small batches, three K-tiles in flight
+using MfgS = amx::mx::MxCfg<128, 64, 2, 2, 8, 0, 0, 2>;  // 147 KB: small batches, ONE tile per CU, two K-tiles per barrier, four more in flight (a
+                                                         // 2048 x 2048 layer at batch 1024 is 64 K-tiles of 9 matrix instructions per wave: barrier and LDS round trip per K-tile were its time)
+using MfgS4 = amx::mx::MxCfg<128, 64, 2, 2, 4>;          //  74 KB, one K-tile per barrier, three in flight (tuning tile=6: A/B runs)
+using MfgSL = amx::mx::MxCfg<128, 64, 2, 2, 8, 0, 0, 2, 4>;  // hidden layers: MfgS + four loader waves (512 threads: a computing and a loading wave per SIMD)
 
 template<class C, int ACT, bool LAST>
 void launch_mx(amx_ffnn* h, int l, const void* x, int xkts, void* out, int ldo, int T, int Tpad, int n_valid) {
@@ -1647,6 +1650,9 @@ void launch_mx(amx_ffnn* h, int l, const void* x, int xkts, void* out, int ldo, 
             default: dbg = 0; break;
         }
     }
+    else if (dbg == 2048 && ACT == AMX_ACT_RELU * (LAST ? 0 : 1)) {
+        AMX_MX_LAUNCH(2048);  // time stamps of any tile configuration (tools/mx_timeline.py small)
+    }
     else
         dbg = 0;
 #endif
@@ -1674,7 +1680,12 @@ void launch_mx_cfg(amx_ffnn* h, int l, const void* x, int xkts, void* out, int l
         case 4: launch_mx<MfgLP, ACT, LAST>(h, l, x, xkts, out, ldo, T, Tpad, n_valid); break;
         case 5: launch_mx<MfgLH, ACT, LAST>(h, l, x, xkts, out, ldo, T, Tpad, n_valid); break;
         case 3:
-        case 6: launch_mx<MfgS, ACT, LAST>(h, l, x, xkts, out, ldo, T, Tpad, n_valid); break;
+            if constexpr (LAST)
+                launch_mx<MfgS, ACT, LAST>(h, l, x, xkts, out, ldo, T, Tpad, n_valid);
+            else
+                launch_mx<MfgSL, ACT, LAST>(h, l, x, xkts, out, ldo, T, Tpad, n_valid);
+            break;
+        case 6: launch_mx<MfgS4, ACT, LAST>(h, l, x, xkts, out, ldo, T, Tpad, n_valid); break;
         default: launch_mx<MfgA, ACT, LAST>(h, l, x, xkts, out, ldo, T, Tpad, n_valid); break;
     }
 }

@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void neg_act_kernel(float* __restrict__ x, lon
 }
 
 // ---------------------------------------------------------------------------------------------- tile configurations
-template<int BN_, int BT_, int WN_, int WT_, int STAGES_, int PF_ = 0, int IW_ = 0>
+template<int BN_, int BT_, int WN_, int WT_, int STAGES_, int PF_ = 0, int IW_ = 0, int U_ = 1, int LW_ = 0>
 struct MxCfg {
     static constexpr int BN = BN_, BT = BT_, WN = WN_, WT = WT_, STAGES = STAGES_;
     // PF > 0 (256 x 256 tiles only): waves 0-5 touch the 384 cache lines of the K-tile PF steps ahead of the one whose LDS-DMA they
@@ -212,8 +212,17 @@ struct MxCfg {
     // requests, pmc/pmc_l2a.txt) arrives later than that and every wave ends its period waiting (tools/mx_timeline.py: 500-1600 of
     // 3500 cycles per K-tile in s_waitcnt vmcnt).
     static constexpr int PF = PF_;
+    // U: K-tiles per barrier.  Small-batch tiles (one 128 x 64 tile per CU, 6 + 3 matrix instructions per wave and K-tile) spend a
+    // K-tile's period on the barrier and the LDS round trip, not on arithmetic: with U = 2 a wave reads two K-tiles into two
+    // register images behind ONE barrier and issues both sets of products (still in ascending K: bit-identical results).
+    static constexpr int U = U_;
+    static_assert(U_ >= 1 && U_ <= 2 && STAGES_ >= 2 * U_, "ring: U K-tiles being read + at least U in flight");
     static_assert(PF_ == 0 || (BN_ == 256 && BT_ == 256 && WN_ * WT_ == 8), "the prefetch walks whole 256-row blocks with six waves");
-    static constexpr int NW = WN * WT, THREADS = NW * 64, PLANES = 1;
+    // LW > 0 (hidden layers only): LW extra LOADER waves that issue every LDS-DMA piece and nothing else; the NW compute waves never
+    // touch the address unit.  A piece holds its issuing wave ~85 cycles (tools/mx_timeline.py small: 850 of the 2450 cycles of a
+    // two-K-tile period of a 128 x 64 tile went into a compute wave's ten pieces, one wave per SIMD and nothing to overlap with).
+    static constexpr int NW = WN * WT, LW = LW_, THREADS = (NW + LW_) * 64, PLANES = 1;
+    static_assert(LW_ == 0 || (IW_ == 0 && PF_ == 0), "loader waves replace the issuing-wave variants");
     // K-loop variants of gemm_mx_kernel, both measured on the output layer (profiles/r04/gemm_mx_ablation3.log: 2.17-2.31 ms in
     // all four combinations, i.e. no gain) and left off: SKEW = the two waves of a SIMD half a K-tile apart, SPREAD = the LDS-DMA
     // pieces issued between the matrix instructions instead of as a burst behind the barrier.  Lab builds flip them (DBG 256 / 512).
@@ -226,12 +235,12 @@ struct MxCfg {
     static constexpr int TOTAL = A_PIECES + B_PIECES;
     // IW: waves that issue the LDS-DMA (default all).  IW = NW / 2: the first wave of every SIMD issues all pieces, its partner none
     // -- the partner goes from its fragment reads straight to its products while the issuing wave sits in the address unit's queue
-    static constexpr int IW  = IW_ > 0 ? IW_ : NW;
+    static constexpr int IW  = LW_ > 0 ? LW_ : IW_ > 0 ? IW_ : NW;
     static constexpr int PPW = (TOTAL + IW - 1) / IW;  // pieces per issuing wave, at most
     static constexpr int NHI = TOTAL % IW;             // waves 0 .. NHI-1 issue PPW pieces, the other issuing waves PPW - 1 (NHI == 0: all PPW)
     static_assert(PF_ == 0 || IW_ == 0, "the prefetch accounting assumes every wave issues PPW pieces");
     static_assert(BN % 64 == 0 && BT % 64 == 0 && 256 % BN == 0 && 256 % BT == 0, "tiles are whole record pieces of a 256-row block");
-    static_assert(STAGES >= 2 && STAGES <= 4 && 3 * PPW + 3 < 64, "vmcnt immediate");
+    static_assert(STAGES >= 2 && STAGES <= 8 && (STAGES - 2) * (PPW + (PF_ > 0 ? 1 : 0)) + 1 < 64, "vmcnt immediate");
 };
 
 // LDS-DMA piece p of a K-tile: source offset inside the operand's block (ha / hb: which part of the 256 rows the tile covers),
@@ -281,6 +290,19 @@ __device__ __forceinline__ void mx_wait() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// s_waitcnt vmcnt(ahead * PER + EXTRA) for ahead = 0 .. MAXA (0: everything; the immediate must be a constant: one branch per value)
+template<int PER, int EXTRA, int MAXA>
+__device__ __forceinline__ void mx_wait_ahead(int ahead) {
+    if constexpr (MAXA <= 0)
+        mx_wait<0>();
+    else {
+        if (ahead >= MAXA)
+            mx_wait<MAXA * PER + EXTRA>();
+        else
+            mx_wait_ahead<PER, EXTRA, MAXA - 1>(ahead);
+    }
+}
+
 // q of a lane's 16 k from its two f16 fragments.  FIRST: the fields go to dwords 0-2 of the operand (the A side), else to dwords
 // 3-5 (the B side); the other half of the conversion's input is left undefined, its output is not used.
 template<bool FIRST>
@@ -312,9 +334,12 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const char* __restr
     const int tid  = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn   = wave / C::WT, wt = wave % C::WT;
+    const int wn   = (wave % C::NW) / C::WT, wt = wave % C::WT;  // (a loader wave's tile coordinates are never used)
     constexpr int WNR = C::BN / C::WN, WTT = C::BT / C::WT;
-    const bool    hi_wave = C::NHI == 0 || wave < C::NHI;  // issues PPW pieces per K-tile
+    const bool    loader  = C::LW > 0 && wave >= C::NW;             // issues the LDS-DMA, takes part in the barriers, computes nothing
+    const int     iwave   = C::LW > 0 ? wave - C::NW : wave;        // index among the issuing waves (negative: not one of them)
+    const bool    issuer  = iwave >= 0 && iwave < C::IW;
+    const bool    hi_wave = C::NHI == 0 || iwave < C::NHI;          // issues PPW pieces per K-tile
 
     for (int vi = blockIdx.x; vi < n_tiles_total; vi += gridDim.x) {
         int tile_t, tile_n;
@@ -350,8 +375,8 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const char* __restr
         bool p_b[C::PPW];
 #pragma unroll
         for (int q = 0; q < C::PPW; ++q) {
-            const int p = q * C::IW + wave;
-            if (p < C::TOTAL && wave < C::IW)
+            const int p = q * C::IW + iwave;
+            if (p < C::TOTAL && issuer)
                 piece_offsets<C>(p, ha, hb, p_src[q], p_dst[q], p_b[q]);
             else {
                 p_src[q] = p_dst[q] = 0;
@@ -366,7 +391,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const char* __restr
         const unsigned voff = (unsigned)lane * 16u;
         const unsigned lds_base = (unsigned)(uintptr_t)lds;
         auto piece = [&](int q, int slot, int kt) {  // q: compile-time constant after unrolling
-            if ((q == C::PPW - 1 && !hi_wave) || (C::IW < C::NW && wave >= C::IW))
+            if ((q == C::PPW - 1 && !hi_wave) || !issuer)
                 return;
             int ktm = kt;
             if constexpr ((DBG & 1024) != 0) {  // ablation: every tile starts its walk over K somewhere else (other L2 channels)
@@ -408,15 +433,22 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const char* __restr
             s_bias[i] = bias[n0 + i];
 
 #pragma unroll
-        for (int s = 0; s < C::STAGES - 1; ++s)
+        for (int s = 0; s < C::STAGES - C::U; ++s)
             if (s < KT)
                 stage(s, s);
         const int frow = lane & 31, fk = lane >> 5;
         const int a_row = wn * WNR + frow, b_row = wt * WTT + frow;
         // Register image of one K-tile: the f16 fragments of both k-slabs and the residual records.
-        f16x8 a[2][C::MI], b[2][C::MJ];
-        uint4 ra[C::MI], rb[C::MJ];
-        auto  reads = [&](int kt) {
+        struct Frag {
+            f16x8 a[2][C::MI], b[2][C::MJ];
+            uint4 ra[C::MI], rb[C::MJ];
+        };
+        Frag fr[C::U];
+        auto reads = [&](int kt, Frag& F) {
+            auto& a  = F.a;
+            auto& b  = F.b;
+            auto& ra = F.ra;
+            auto& rb = F.rb;
             const char* ab = lds + (kt % C::STAGES) * C::STAGE_BYTES;
             const char* bb = ab + C::A_BYTES;
 #pragma unroll
@@ -440,7 +472,11 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const char* __restr
         // order).  Measured: no gain over the burst behind the barrier (MxCfg).
         constexpr int N_MFMA = 3 * C::MI * C::MJ, GAP = N_MFMA / C::PPW > 0 ? N_MFMA / C::PPW : 1;  // matrix instructions per piece
         int           dma_kt = -1;  // K-tile whose pieces the next products() issues (-1: none)
-        auto products = [&]() {
+        auto products = [&](Frag& F) {
+            auto& a  = F.a;
+            auto& b  = F.b;
+            auto& ra = F.ra;
+            auto& rb = F.rb;
             int n_issued = 0;  // compile-time after unrolling
             auto after_mfma = [&]() {
                 if constexpr (C::SPREAD != ((DBG & 512) != 0)) {
@@ -531,7 +567,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const char* __restr
         auto stamp = [&](int kt, int phase) {
 #ifdef AMX_LAB
             if constexpr ((DBG & 2048) != 0) {
-                if (blockIdx.x == 0 && vi == (int)blockIdx.x && kt < 48 && lane == 0)
+                if (blockIdx.x == 0 && vi == (int)blockIdx.x && kt < 48 && lane == 0 && (!LAST || n_tiles_total > 1000))
                     mx_stamps[(wave * 48 + kt) * 4 + phase] = __builtin_amdgcn_s_memtime();
             }
 #endif
@@ -539,32 +575,16 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const char* __restr
         auto sync = [&](int kt) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             const int ahead = min(C::STAGES - 2, KT - 1 - kt);  // K-tiles that stay in flight
-            if (C::PF > 0 && pf_wave) {  // every refill of this wave is PPW pieces + one prefetch load (C::PF > 0: all waves issue PPW pieces)
-                if (C::STAGES >= 4 && ahead == 2)
-                    mx_wait<2 * (C::PPW + 1) + 1>();
-                else if (C::STAGES >= 3 && ahead == 1)
-                    mx_wait<C::PPW + 2>();
-                else
-                    mx_wait<0>();
-            }
-            else if (C::IW < C::NW && wave >= C::IW)
+            // `ahead` K-tiles stay in flight behind the awaited one: the wave's own operations per refill x ahead (+ for a prefetching
+            // wave the prefetch load issued behind the awaited K-tile's pieces)
+            if (C::PF > 0 && pf_wave)
+                mx_wait_ahead<C::PPW + 1, 1, C::STAGES - 2>(ahead);
+            else if (!issuer)
                 mx_wait<0>();  // nothing of its own in flight: the issuing waves' waits + the barrier cover the K-tile
-            else if (hi_wave) {
-                if (C::STAGES >= 4 && ahead == 2)
-                    mx_wait<2 * C::PPW>();
-                else if (C::STAGES >= 3 && ahead == 1)
-                    mx_wait<C::PPW>();
-                else
-                    mx_wait<0>();
-            }
-            else {
-                if (C::STAGES >= 4 && ahead == 2)
-                    mx_wait<2 * (C::PPW - 1)>();
-                else if (C::STAGES >= 3 && ahead == 1)
-                    mx_wait<C::PPW - 1>();
-                else
-                    mx_wait<0>();
-            }
+            else if (hi_wave)
+                mx_wait_ahead<C::PPW, 0, C::STAGES - 2>(ahead);
+            else
+                mx_wait_ahead<C::PPW - 1, 0, C::STAGES - 2>(ahead);
             __builtin_amdgcn_s_barrier();
             stamp(kt, 0);
             if (kt + C::STAGES - 1 < KT && !(DBG & 16)) {
@@ -584,6 +604,50 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const char* __restr
         };
         // one code path for both groups -- early: sync(kt) reads(kt) products(kt); late: reads(kt) sync(kt + 1) products(kt), i.e. the
         // late wave's products of K-tile kt run in period kt + 1, in front of its reads of K-tile kt + 1.  Both execute KT barriers.
+        if constexpr (C::U > 1 || C::LW > 0) {
+            static_assert(!C::SKEW && !C::SPREAD && C::PF == 0 && (C::IW == C::NW || C::LW > 0), "plain burst refill only");
+            for (int kt = 0; kt < KT; kt += C::U) {
+                const int nk = min(C::U, KT - kt);
+                // K-tiles kt .. kt + nk - 1 have landed; issued so far: up to kt + STAGES - U - 1
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const int ahead = max(0, min(kt + C::STAGES - C::U - 1, KT - 1) - (kt + nk - 1));
+                if (!issuer)
+                    mx_wait<0>();
+                else if (hi_wave)
+                    mx_wait_ahead<C::PPW, 0, C::STAGES - C::U - 1>(ahead);
+                else
+                    mx_wait_ahead<C::PPW - 1, 0, C::STAGES - C::U - 1>(ahead);
+                __builtin_amdgcn_s_barrier();  // ... for every wave, and the stages read in the previous iteration are free
+                stamp(kt / C::U, 0);
+                if (!loader) {
+#pragma unroll
+                    for (int u = 0; u < C::U; ++u)
+                        if (u < nk)
+                            reads(kt + u, fr[u]);
+                }
+                if (issuer) {
+#pragma unroll
+                    for (int u = 0; u < C::U; ++u) {
+                        const int n = kt + u + C::STAGES - C::U;
+                        if (n < KT)
+                            stage(n % C::STAGES, n);
+                    }
+                }
+                stamp(kt / C::U, 1);
+                if constexpr ((DBG & 2048) != 0) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    stamp(kt / C::U, 2);
+                }
+                if (!loader) {
+#pragma unroll
+                    for (int u = 0; u < C::U; ++u)
+                        if (u < nk)
+                            products(fr[u]);
+                }
+                stamp(kt / C::U, 3);
+            }
+        }
+        else {
         if (late) {
             sync(0);
             if (dma_kt >= 0)  // the refill that belongs to barrier 0: the late wave has no products to spread it over yet
@@ -593,7 +657,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const char* __restr
         for (int kt = 0; kt < KT; ++kt) {
             if (!late)
                 sync(kt);
-            reads(kt);
+            reads(kt, fr[0]);
             if (late && kt + 1 < KT)
                 sync(kt + 1);
             if constexpr ((DBG & 4096) != 0)  // ablation: the burst in front of the reads' completion, as before
@@ -603,8 +667,9 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const char* __restr
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 stamp(kt, 2);
             }
-            products();
+            products(fr[0]);
             stamp(kt, 3);
+        }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if constexpr (C::PF > 0)
@@ -615,6 +680,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const char* __restr
         // scratch access inside the loop would join the queue the counted vmcnt waits count
         int elane = lane, etid = tid;
         asm volatile("" : "+v"(elane), "+v"(etid));
+        static_assert(!(LAST && C::LW > 0), "loader waves: hidden layers only (gemm_epilogue's barriers expect NW computing waves)");
         if (LAST)
             gemm_epilogue<C, ACT, true>(acc, lds, s_bias, out, ldo, 0, n_valid, t_valid, n0, t0, tile_n, wn, wt, elane, etid, part_min, part_idx, part_ld);
         else {
@@ -623,6 +689,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const char* __restr
             __syncthreads();  // bias visible
             const int tl32 = elane & 31, hh = elane >> 5;
             bool      over = false;
+            if (!loader) {
 #pragma unroll
             for (int j = 0; j < C::MJ; ++j) {
                 const int t = t0 + wt * WTT + 32 * j + tl32;
@@ -646,6 +713,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const char* __restr
                     char*     blk = (char*)out + ((size_t)(t >> 8) * ktn + ((n0 + wn * WNR + 32 * i) >> 5)) * BLK;
                     lane_store(blk, t & 255, hh, lane_pack(v, ec, ec - 13));
                 }
+            }
             }
             if (over)
                 *overflow = 1u;

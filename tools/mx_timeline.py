@@ -20,14 +20,15 @@ import rasr_amd  # noqa: E402
 from rasr_amd import _lib  # noqa: E402
 from tests import synth  # noqa: E402
 
-bits = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+bits = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1] != "small" else 0
+small = len(sys.argv) > 1 and sys.argv[1] == "small"   # a 2048 x 2048 hidden layer at batch 1024: the 128 x 64 tiles, one per CU
 ctx = rasr_amd.Context(0)
 ctx.use_torch_stream()
-Ws, bs, acts, logp = synth.ffnn([2048, 10000], seed=7)
-T = 32768
+Ws, bs, acts, logp = synth.ffnn([2048, 2048, 64] if small else [2048, 10000], seed=7)
+T = 1024 if small else 32768
 x = torch.from_numpy(np.random.Generator(np.random.PCG64(1)).standard_normal((T, 2048)).astype(np.float32)).cuda()
-nn = rasr_amd.NnBatchFeatureScorer(ctx, Ws, bs, acts, log_prior=logp, precision="f16mx", tuning="mx_dbg=%d" % (2048 | bits))
-s = torch.empty((T, 10000), dtype=torch.float32, device="cuda")
+nn = rasr_amd.NnBatchFeatureScorer(ctx, Ws, bs, acts, log_prior=logp, precision="f16mx", tuning="graph=0,mx_dbg=%d" % (2048 | bits))
+s = torch.empty((T, 64 if small else 10000), dtype=torch.float32, device="cuda")
 for _ in range(3):
     nn.score_dev(x, 2048, T, s)
 torch.cuda.synchronize()
@@ -36,15 +37,15 @@ buf = (C.c_ulonglong * (8 * 48 * 4))()
 L.amx_lab_mx_stamps.restype = C.c_int
 assert L.amx_lab_mx_stamps(buf) == 0
 st = np.frombuffer(buf, dtype=np.uint64).reshape(8, 48, 4).astype(np.int64)
-t0 = st[:, 8, 0].min()
-print("variant bits %d; shader cycles (s_memtime); K-tiles 8..47 of workgroup 0" % bits)
+lo, hi = (4, 30) if small else (8, 47)
+t0 = st[:, lo, 0][st[:, lo, 0] > 0].min()
+print("variant bits %d%s; shader cycles (s_memtime); iterations %d..%d of workgroup 0" % (bits, " (small: 128 x 64 tiles, U K-tiles per iteration)" if small else "", lo, hi))
 print("wave  period   barrier->refill  refill->frags  frags->products  products->next barrier   first barrier (rel)")
 for w in range(8):
-    a = st[w, 8:47]
-    nxt = st[w, 9:48, 0]
-    per = np.diff(st[w, 8:48, 0]).mean()
+    if st[w, lo, 0] == 0:
+        continue
+    a = st[w, lo:hi]
+    nxt = st[w, lo + 1:hi + 1, 0]
+    per = np.diff(st[w, lo:hi + 1, 0]).mean()
     print("%4d  %6.1f   %15.1f  %13.1f  %15.1f  %22.1f   %d" % (w, per, (a[:, 1] - a[:, 0]).mean(), (a[:, 2] - a[:, 1]).mean(),
-                                                               (a[:, 3] - a[:, 2]).mean(), (nxt - a[:, 3]).mean(), st[w, 8, 0] - t0))
-print("raw, wave 0 and wave 4, K-tiles 8..11 (relative ticks):")
-for w in (0, 4):
-    print(w, (st[w, 8:12] - t0).tolist())
+                                                               (a[:, 3] - a[:, 2]).mean(), (nxt - a[:, 3]).mean(), st[w, lo, 0] - t0))
