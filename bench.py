@@ -36,7 +36,7 @@ MFMA_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak
 FP32_TFLOPS = 157.3        # f32 vector (= f32 MFMA) peak
 
 
-TRAFFIC_SOURCE = os.path.join("profiles", "r03", "traffic.json")
+TRAFFIC_SOURCE = os.path.join("profiles", "r04", "traffic.json")
 
 
 def measured_traffic(workload, *needles):
@@ -337,7 +337,7 @@ def nn_gemm_roofline(precision, ms, n, frames, full_chunk):
     out = dict(bound="mfma", kernel=name, achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
                traffic=(measured_traffic({"bf16x3": "pipeline-bf16x3", "bf16": "pipeline-bf16", "f16mx": "pipeline"}[precision],
                                          "gemm_mx_kernel" if precision == "f16mx" else "gemm_bf16_pipe_kernel",
-                                         {"bf16x3": "32, true>, 0, true", "bf16": "64, false>, 0, true", "f16mx": "256, 256"}[precision])
+                                         {"bf16x3": "32, true>, 0, true", "bf16": "64, false>, 0, true", "f16mx": ">, 0, true, 0>"}[precision])
                         if (precision in ("bf16", "bf16x3", "f16mx") and full_chunk) else None),
                avg_launch_ms=round(ms, 4), launches=n, flops_per_launch=mult * alg)
     if mult != 1.0:

@@ -11,4 +11,5 @@ hipcc --offload-arch=gfx950 -O3 -std=c++17 -w tools/ceilings.hip -o tools/build/
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -w tools/write_probe.hip -o tools/build/write_probe
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -w tools/valu_rates.hip -o tools/build/valu_rates
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -w tools/gather_probe.hip -o tools/build/gather_probe
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -w tools/feed_probe.hip -o tools/build/feed_probe
 rm -f tools/build/*.bc tools/build/*.hipi tools/build/*.out tools/build/*.s tools/build/*.resolution.txt tools/build/*gfx950.o tools/build/*x86_64*

@@ -8,8 +8,8 @@
 #   gemm_comparator.json          torch (hipBLASLt / rocBLAS) bf16 GEMM of the output-layer shape on the same box: measurement only
 #   gather_probe.log              scattered 256-byte rows out of L2 by request shape; cost of a scattered 64-lane gather (tools/gather_probe.hip)
 #   gemm_probe.log                ablation table of the pipelined GEMM (tools/gemm_probe.hip: full / no MFMA / no DMA / L2-resident operands)
-# usage (through gpurun):  tools/profile_all.sh r03 ; results land in gpurun_out/<round>/ -> copy to profiles/<round>/
-round=${1:-r03}
+# usage (through gpurun):  tools/profile_all.sh r04 ; results land in gpurun_out/<round>/ -> copy to profiles/<round>/
+round=${1:-r04}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/$round
 mkdir -p $out/pmc
@@ -37,15 +37,20 @@ run_pmc() {  # name, suffix, counters..., -- bench args...
 }
 python $root/bench.py --no-cpu-baseline --no-configs > /dev/null 2>&1   # warm the box / caches
 run_stats pipeline --steps 10 --warmup 2
+run_stats pipeline-streamed --ingest streamed --steps 20 --warmup 2 --no-cpu-baseline --no-configs
 run_stats pipeline-bf16 --precision bf16 --steps 10 --warmup 2 --no-cpu-baseline --no-configs
+run_stats pipeline-bf16x3 --precision bf16x3 --steps 10 --warmup 2 --no-cpu-baseline --no-configs
 run_stats nn-pipeline --workload nn-pipeline --steps 10 --warmup 2 --no-cpu-baseline
+run_stats nn-pipeline-bf16x3 --workload nn-pipeline --precision bf16x3 --steps 10 --warmup 2 --no-cpu-baseline
 run_stats nn-pipeline-bf16 --workload nn-pipeline --precision bf16 --steps 10 --warmup 2 --no-cpu-baseline
 run_stats nn-pipeline-fp32 --workload nn-pipeline --precision fp32 --steps 3 --warmup 1 --no-cpu-baseline
 run_stats gmm-train --workload gmm-train --steps 5 --warmup 2 --no-cpu-baseline
+run_stats gmm-trained --workload gmm-trained --steps 5 --warmup 2 --no-cpu-baseline
 run_stats mfcc --workload mfcc --steps 20 --warmup 2 --no-cpu-baseline
 run_stats gmm --workload gmm --steps 50 --warmup 5 --no-cpu-baseline
 run_stats gmm-tied --workload gmm-tied --steps 20 --warmup 3
 run_stats nn --workload nn --steps 50 --warmup 5 --no-cpu-baseline
+run_stats nn-bf16x3 --workload nn --precision bf16x3 --steps 50 --warmup 5 --no-cpu-baseline
 run_stats nn-bf16 --workload nn --precision bf16 --steps 50 --warmup 5 --no-cpu-baseline
 run_stats mfcc-plp --workload mfcc --front-end plp --steps 8 --warmup 2 --no-cpu-baseline
 run_stats mfcc-mfplp --workload mfcc --front-end mfplp --steps 8 --warmup 2 --no-cpu-baseline
@@ -58,6 +63,9 @@ run_pmc mfcc fetch FETCH_SIZE -- --workload mfcc --steps 3 --warmup 1
 run_pmc mfcc write WRITE_SIZE -- --workload mfcc --steps 3 --warmup 1
 run_pmc mfcc sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_LDS -- --workload mfcc --steps 3 --warmup 1
 run_pmc mfcc sq2 SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_MFMA SQ_ACTIVE_INST_ANY -- --workload mfcc --steps 3 --warmup 1
+run_pmc nn-pipeline l2 TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum TCC_EA0_RDREQ_sum -- --workload nn-pipeline --steps 3 --warmup 1
+run_pmc nn-pipeline fetch FETCH_SIZE -- --workload nn-pipeline --steps 3 --warmup 1
+run_pmc nn-pipeline write WRITE_SIZE -- --workload nn-pipeline --steps 3 --warmup 1
 run_pmc nn-pipeline mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_MFMA -- --workload nn-pipeline --steps 3 --warmup 1
 run_pmc nn-pipeline sq2 SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_ANY -- --workload nn-pipeline --steps 3 --warmup 1
 run_pmc nn-pipeline-bf16 mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_MFMA -- --workload nn-pipeline --precision bf16 --steps 3 --warmup 1
@@ -70,9 +78,13 @@ run_pmc gmm-tied write WRITE_SIZE -- --workload gmm-tied --steps 5 --warmup 2
 [ -x $root/tools/build/gather_probe ] && $root/tools/build/gather_probe > $out/gather_probe.log 2>&1
 if [ -n "$ONLY" ]; then ls -la $out $out/pmc; exit 0; fi
 (cd $root && timeout 1500 python -m pytest tests -m gpu -q > $out/gpu_tests.log 2>&1)
-(cd $root && for f in "fuzz_frontends.py 300 31" "fuzz_scorers.py 300 32" "fuzz_gmm.py 200 33" "fuzz_tied.py 300 34" "fuzz_more.py 100 35" "fuzz_ffnn.py 60 36" "fuzz_backend.py 100 37"; do echo "== tools/$f"; timeout 900 python tools/$f 2>&1 | grep -v amdgpu.ids | tail -2; done > $out/gpu_fuzz.log 2>&1)
+(cd $root && for f in "fuzz_frontends.py 300 31" "fuzz_scorers.py 300 32" "fuzz_gmm.py 200 33" "fuzz_tied.py 300 34" "fuzz_more.py 100 35" "fuzz_ffnn.py 40 36" "fuzz_backend.py 100 37"; do echo "== tools/$f"; timeout 900 python tools/$f 2>&1 | grep -v amdgpu.ids | tail -2; done > $out/gpu_fuzz.log 2>&1)
 AMX_BENCH_FORCE_DIST=1 python $root/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-configs 2>/dev/null | grep "^{\"metric\"" | tail -1 > $out/force_dist_bench.log
 python $root/tools/gemm_comparator.py > $out/gemm_comparator.json 2>/dev/null
+[ -x $root/tools/build/feed_probe ] && $root/tools/build/feed_probe > $out/feed_probe.log 2>&1
+if [ -f $root/rasr_amd/librasr_amd_lab.so ]; then
+  (cd $root && python tools/mx_timeline.py 0 2>&1 | grep -v amdgpu.ids > $out/mx_timeline.log; python tools/mx_timeline.py small 2>&1 | grep -v amdgpu.ids >> $out/mx_timeline.log; python tools/fused_timeline.py 2>&1 | grep -v amdgpu.ids > $out/fused_timeline.log)
+fi
 [ -x $root/tools/build/gemm_probe ] && PROBE_RELU=1 $root/tools/build/gemm_probe xp0 xp8 xp16 xp24 xp64 xp72 xp4 p0 p8 p16 p64 p72 p4 x0 xa0 xp0:16x8 p0:16x8 > $out/gemm_probe.log 2>&1
 [ -x $root/tools/build/valu_rates ] && $root/tools/build/valu_rates > $out/valu_rates.log 2>&1
 [ -x $root/tools/build/ceilings ] && $root/tools/build/ceilings > $out/ceilings.json 2>/dev/null

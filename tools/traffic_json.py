@@ -7,7 +7,7 @@ import sys
 
 out = sys.argv[1]
 res = {}
-for wl in ("pipeline", "pipeline-bf16", "mfcc", "gmm-tied"):
+for wl in ("pipeline", "pipeline-bf16", "nn-pipeline", "mfcc", "gmm-tied"):
     vals = {}
     for suf, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
         p = os.path.join(out, "pmc", "%s_%s.txt" % (wl, suf))
