@@ -144,6 +144,21 @@ __device__ __noinline__ float power_node(float v, float power) {
 // (12 more registers: 127 instead of 109, still four workgroups per CU).  Measured on config 2, one box, twice: 0.795 ms against
 // 0.743 ms -- SLOWER: the samples of a wave's next frame are the neighbours' current ones (60 % overlap, L1 / L2 hits), their
 // latency is not what a frame waits for.  Kept as an A/B variant (round-3 review item 7).
+#ifdef AMX_LAB
+// lab builds: s_memtime stamps of workgroup 0, [wave < 4][tile < 32][7]: tile start, phase B done, barrier passed, phase C done,
+// barrier passed, phase D done, last barrier passed; amx_lab_mfcc_stamps (tools/mfcc_timeline.py)
+__device__ unsigned long long mfcc_stamps[4 * 32 * 8];
+#define MFCC_STAMP(k)                                                                                          \
+    do {                                                                                                       \
+        if (blockIdx.x == 0 && lane == 0 && wave < 4 && lab_tile < 32)                                         \
+            mfcc_stamps[(wave * 32 + lab_tile) * 8 + (k)] = __builtin_amdgcn_s_memtime();                      \
+    } while (0)
+#else
+#define MFCC_STAMP(k) \
+    do {              \
+    } while (0)
+#endif
+
 template<int NC, int VAR>
 __global__ __launch_bounds__(mfcc_waves(NC) * 64, (NC >= 1024 ? 1 : ((VAR & 8) != 0 ? 3 : 4))) void mfcc_kernel(MfccParams p) {
     using P = FftPlan<NC>;
@@ -242,8 +257,11 @@ __global__ __launch_bounds__(mfcc_waves(NC) * 64, (NC >= 1024 ? 1 : ((VAR & 8) !
     const float alpha   = p.alpha;
     const bool  alpha1  = (alpha == 1.0f);
 
+  [[maybe_unused]] int lab_tile = -1;
   for (int tile_id = blockIdx.x; tile_id < p.n_tiles; tile_id += gridDim.x) {
     const MfccTile tile = p.tiles[tile_id];
+    ++lab_tile;
+    MFCC_STAMP(0);
     // ================= (round 1's phase A -- staging the tile's PCM span in LDS behind a workgroup barrier -- is gone.)  A frame's
     // samples are read where they are used: neighbouring frames overlap, so the re-reads come from L2; 11.6 KB of LDS and one
     // barrier per tile less, four workgroups per CU for MFCC-40 instead of three.  A/B on one box (tools/ab_mfcc.sh, ms per
@@ -502,7 +520,9 @@ __global__ __launch_bounds__(mfcc_waves(NC) * 64, (NC >= 1024 ? 1 : ((VAR & 8) !
             amp[NC / 2] = __builtin_amdgcn_sqrtf(fmaf(zm.x, zm.x, zm.y * zm.y));
         }
     }
+    MFCC_STAMP(1);
     __syncthreads();
+    MFCC_STAMP(2);
 
     // ================= phase C: mel filter bank + log10 for the whole tile (Signal/Filterbank.cc:65-71,
     // Flow/SimpleFunction.hh:40-49).  item = filter * FT + frame: the 64 lanes of a wave work on 4
@@ -552,7 +572,9 @@ __global__ __launch_bounds__(mfcc_waves(NC) * 64, (NC >= 1024 ? 1 : ((VAR & 8) !
             s_lm[f * L.lm_ld + flt] = p.front_end ? power_node(acc, p.plp_power)  // intensity-loudness law
                                                   : __log10f(acc);           // v_log_f32 * log10(2): ~1 ulp of log2
     }
+    MFCC_STAMP(3);
     __syncthreads();
+    MFCC_STAMP(4);
 
     // ================= phase D: DCT-II as a [FT x kpad] x [kpad x n_ceps] product on the f32 matrix
     // cores (Signal/CosineTransform.cc:76-83).  v_mfma_f32_16x16x4_f32 is an exact f32 fma chain in
@@ -580,7 +602,9 @@ __global__ __launch_bounds__(mfcc_waves(NC) * 64, (NC >= 1024 ? 1 : ((VAR & 8) !
             }
         }
     }
+    MFCC_STAMP(5);
     __syncthreads();  // s_lm / s_amp are rewritten by the next tile
+    MFCC_STAMP(6);
   }
 }
 
@@ -1315,3 +1339,9 @@ int amx_context_window_dev(amx_ctx* ctx, const amx_mfcc_plan* p, const float* fe
 }
 
 }  // extern "C"
+
+#ifdef AMX_LAB
+extern "C" int amx_lab_mfcc_stamps(unsigned long long* out /* [4 * 32 * 8] */) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(amx::mfcc_stamps), sizeof(amx::mfcc_stamps)) == hipSuccess ? AMX_OK : AMX_ERR_DEVICE;
+}
+#endif
