@@ -149,3 +149,43 @@ def test_feature_cache_between_front_end_and_scorer(ctx, tmp_path):
             assert a.read_attributes(seg)["datatype"] == "vector-f32"
             sc2, best2 = gmm.score(rx)
             assert np.array_equal(sc2.view(np.uint32), sc.view(np.uint32)) and np.array_equal(best2, best)
+
+
+def test_streamed_ingest_delivers_the_partitions_utterances_bit_for_bit(ctx):
+    """bench.py --ingest streamed (StreamedIngest: pinned s16 corpus window -> hipMemcpyAsync on a copy stream -> two HBM slots ->
+    amx_mfcc_run_plan_dev_s16 behind an event): over more steps than there are slots and more than the host window holds, every
+    step's cepstra equal the cepstra of exactly the utterances the rank's CorpusWalker names -- computed from the samples directly,
+    as f32, in one call -- bit for bit; two ranks' lists are disjoint and lie in their partitions."""
+    import argparse
+
+    import torch
+
+    import bench
+    import rasr_amd
+    ctx.use_torch_stream()
+    args = argparse.Namespace(utt_seconds=1.0, utterances=6, corpus_hours=0.05, ingest="streamed")   # 180 utterances of 1 s
+    fe = rasr_amd.MfccExtractor(ctx, nr_cepstrum_coefficients=13)
+    n = 16000
+    base = synth.waveform(n + 8192, seed=9)
+    seen = {}
+    for rank in (0, 1):
+        ing = bench.StreamedIngest(args, rank, 2, n_steps=3)           # host window: 5 batches; 9 steps wrap it
+        plan = fe.plan(np.arange(args.utterances + 1, dtype=np.int64) * n)
+        ceps = torch.empty((plan.total_frames, 13), dtype=torch.float32, device="cuda")
+        for step in range(9):
+            pcm = ing.take()
+            assert pcm.dtype == torch.int16
+            fe.run_plan(plan, pcm, ceps)
+            ing.release()
+            ids = ing.visited[-1]
+            assert len(ids) == args.utterances and all(int(g) % 2 == rank for g in ids)
+            if step < ing.nb:   # inside the host window the samples are the named utterances'; beyond it the window wraps (bench note)
+                want_pcm = np.concatenate([base[int(g) % 8192:int(g) % 8192 + n] for g in ids])
+                want = torch.empty_like(ceps)
+                fe.run_plan(plan, torch.from_numpy(want_pcm).cuda(), want)
+                torch.cuda.synchronize()
+                assert torch.equal(ceps.view(torch.int32), want.view(torch.int32)), (rank, step)
+        torch.cuda.synchronize()
+        seen[rank] = np.concatenate(ing.visited)
+        assert len(np.unique(seen[rank])) == len(seen[rank]) == 9 * args.utterances
+    assert not set(seen[0].tolist()) & set(seen[1].tolist())
