@@ -238,7 +238,11 @@ struct MxCfg {
     static constexpr int IW  = LW_ > 0 ? LW_ : IW_ > 0 ? IW_ : NW;
     static constexpr int PPW = (TOTAL + IW - 1) / IW;  // pieces per issuing wave, at most
     static constexpr int NHI = TOTAL % IW;             // waves 0 .. NHI-1 issue PPW pieces, the other issuing waves PPW - 1 (NHI == 0: all PPW)
-    static_assert(PF_ == 0 || IW_ == 0, "the prefetch accounting assumes every wave issues PPW pieces");
+    // PF with IW = NW / 2 (the FREE form): the waves that issue no LDS-DMA issue the prefetch loads and never wait on vmcnt inside the
+    // K-loop -- the loads float freely, nothing queues behind them.  PF with IW = NW: waves 0-5 carry one load per refill in their
+    // counted queue (measured 6 % slower: a load that misses L2 holds back the count of the next K-tile's pieces).
+    static constexpr bool PF_FREE = PF_ > 0 && IW_ > 0;
+    static_assert(PF_ == 0 || IW_ == 0 || IW_ * 2 == WN_ * WT_, "free prefetch: half of the waves issue the DMA");
     static_assert(BN % 64 == 0 && BT % 64 == 0 && 256 % BN == 0 && 256 % BT == 0, "tiles are whole record pieces of a 256-row block");
     static_assert(STAGES >= 2 && STAGES <= 8 && (STAGES - 2) * (PPW + (PF_ > 0 ? 1 : 0)) + 1 < 64, "vmcnt immediate");
 };
@@ -403,13 +407,25 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const char* __restr
             asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(src), "s"(dst) : "memory");
         };
         float    pf_reg  = 0.f;  // destination of the prefetch loads: stays allocated for the whole K-loop (a load may land any time)
-        const bool pf_wave = C::PF > 0 && wave < 6;
-        auto prefetch = [&](int kt) {  // K-tile kt of the operand stream: lines [64 w, 64 w + 64) of W's block (waves 0-2) or X's (3-5)
+        const bool pf_wave = C::PF > 0 && (C::PF_FREE ? wave >= C::IW : wave < 6);
+        auto prefetch = [&](int kt) {  // K-tile kt of the operand stream: 8 KB chunks (64 lines) 0-2 of W's block, 3-5 of X's
             if constexpr (C::PF > 0) {
                 if (pf_wave) {
-                    const int   ktc = min(kt, KT - 1);
-                    const char* p   = (wave < 3 ? wblk : xblk) + (size_t)ktc * BLK + (wave % 3) * 8192;
-                    asm volatile("global_load_dword %0, %1, %2" : "+v"(pf_reg) : "v"((unsigned)lane * 128u), "s"(p) : "memory");
+                    const int ktc = min(kt, KT - 1);
+                    if constexpr (C::PF_FREE) {  // four waves share the six chunks: waves IW, IW + 1 take two
+#pragma unroll
+                        for (int c = 0; c < 2; ++c) {
+                            const int ch = (wave - C::IW) + 4 * c;
+                            if (ch < 6) {
+                                const char* p = (ch < 3 ? wblk : xblk) + (size_t)ktc * BLK + (ch % 3) * 8192;
+                                asm volatile("global_load_dword %0, %1, %2" : "+v"(pf_reg) : "v"((unsigned)lane * 128u), "s"(p) : "memory");
+                            }
+                        }
+                    }
+                    else {
+                        const char* p = (wave < 3 ? wblk : xblk) + (size_t)ktc * BLK + (wave % 3) * 8192;
+                        asm volatile("global_load_dword %0, %1, %2" : "+v"(pf_reg) : "v"((unsigned)lane * 128u), "s"(p) : "memory");
+                    }
                 }
             }
         };
@@ -417,7 +433,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const char* __restr
 #pragma unroll
             for (int q = 0; q < C::PPW; ++q)
                 piece(q, slot, kt);
-            prefetch(kt + C::PF);
+            prefetch(kt + C::PF);   // (piece() returns at once for a wave that issues no DMA: the free form's prefetching waves land here too)
         };
 
         f32x16 acc[C::MI][C::MJ];
@@ -577,7 +593,10 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const char* __restr
             const int ahead = min(C::STAGES - 2, KT - 1 - kt);  // K-tiles that stay in flight
             // `ahead` K-tiles stay in flight behind the awaited one: the wave's own operations per refill x ahead (+ for a prefetching
             // wave the prefetch load issued behind the awaited K-tile's pieces)
-            if (C::PF > 0 && pf_wave)
+            if (C::PF_FREE && !issuer) {
+                // no DMA of its own, and its prefetch loads are never waited for inside the loop
+            }
+            else if (C::PF > 0 && pf_wave)
                 mx_wait_ahead<C::PPW + 1, 1, C::STAGES - 2>(ahead);
             else if (!issuer)
                 mx_wait<0>();  // nothing of its own in flight: the issuing waves' waits + the barrier cover the K-tile
