@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void neg_act_kernel(float* __restrict__ x, lon
 }
 
 // ---------------------------------------------------------------------------------------------- tile configurations
-template<int BN_, int BT_, int WN_, int WT_, int STAGES_, int PF_ = 0, int IW_ = 0, int U_ = 1, int LW_ = 0>
+template<int BN_, int BT_, int WN_, int WT_, int STAGES_, int PF_ = 0, int IW_ = 0, int U_ = 1, int LW_ = 0, int RP_ = 0>
 struct MxCfg {
     static constexpr int BN = BN_, BT = BT_, WN = WN_, WT = WT_, STAGES = STAGES_;
     // PF > 0 (256 x 256 tiles only): waves 0-5 touch the 384 cache lines of the K-tile PF steps ahead of the one whose LDS-DMA they
@@ -211,6 +211,12 @@ struct MxCfg {
     // HBM into L2.  The LDS ring holds two K-tiles in flight (~2 periods of 1.7 us); a K-tile whose lines miss L2 (23 % of the
     // requests, pmc/pmc_l2a.txt) arrives later than that and every wave ends its period waiting (tools/mx_timeline.py: 500-1600 of
     // 3500 cycles per K-tile in s_waitcnt vmcnt).
+    // RP: register pipelining.  The products of K-tile kt - 1 run in period kt, from the registers read in period kt - 1, and every
+    // fragment register is re-read from K-tile kt's stage right behind its last use: the matrix pipe starts at the barrier instead
+    // of behind an LDS round trip, with no register more than the plain order needs (tools/feed_probe.hip: 953 -> 851 ns per K-tile
+    // against 817 ns matrix-bound).  The ring and the order of the sums are unchanged.
+    static constexpr bool RP = RP_ != 0;
+    static_assert(RP_ == 0 || (U_ == 1 && LW_ == 0), "register pipelining: the one-K-tile-per-barrier loop");
     static constexpr int PF = PF_;
     // U: K-tiles per barrier.  Small-batch tiles (one 128 x 64 tile per CU, 6 + 3 matrix instructions per wave and K-tile) spend a
     // K-tile's period on the barrier and the LDS round trip, not on arithmetic: with U = 2 a wave reads two K-tiles into two
@@ -570,6 +576,54 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const char* __restr
                 prefetch(dma_kt + C::PF);  // SPREAD variant: the refill's prefetch follows its last piece, as in stage()
             dma_kt = -1;
         };
+        // RP: consume the register image F (K-tile ktn - 1) and refill it from K-tile ktn's stage, register by register
+        auto products_rp = [&](Frag& F, int ktn) {
+            auto& a  = F.a;
+            auto& b  = F.b;
+            auto& ra = F.ra;
+            auto& rb = F.rb;
+            const char* ab = lds + (ktn % C::STAGES) * C::STAGE_BYTES;
+            const char* bb = ab + C::A_BYTES;
+            // q fields first: they need both k-slabs of a fragment row, which are overwritten below
+            u32x6 qa[C::MI], qb[C::MJ];
+#pragma unroll
+            for (int i = 0; i < C::MI; ++i)
+                qa[i] = q_fields<true>(a[0][i], a[1][i], ra[i].w);
+#pragma unroll
+            for (int j = 0; j < C::MJ; ++j)
+                qb[j] = q_fields<false>(b[0][j], b[1][j], rb[j].w + 11u);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < C::MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < C::MJ; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks][i], b[ks][j], acc[i][j], 0, 0, 0);
+                        if (j == C::MJ - 1)
+                            a[ks][i] = *(const f16x8*)(ab + h_off(a_row + 32 * i, 2 * ks + fk));
+                        if (i == C::MI - 1)
+                            b[ks][j] = *(const f16x8*)(bb + h_off(b_row + 32 * j, 2 * ks + fk));
+                    }
+            v8i av[C::MI], bv[C::MJ];
+            int sa[C::MI], sb[C::MJ];
+#pragma unroll
+            for (int i = 0; i < C::MI; ++i) {
+                av[i] = v8i{(int)qa[i][0], (int)qa[i][1], (int)qa[i][2], (int)ra[i].x, (int)ra[i].y, (int)ra[i].z, 0, 0};
+                sa[i] = (int)ra[i].w;
+                ra[i] = __builtin_bit_cast(uint4, *(const f16x8*)(ab + C::A_R + fk * (C::BN * 16) + (a_row + 32 * i) * 16));
+            }
+#pragma unroll
+            for (int j = 0; j < C::MJ; ++j) {
+                bv[j] = v8i{(int)rb[j].x, (int)rb[j].y, (int)rb[j].z, (int)qb[j][3], (int)qb[j][4], (int)qb[j][5], 0, 0};
+                sb[j] = (int)rb[j].w;
+                rb[j] = __builtin_bit_cast(uint4, *(const f16x8*)(bb + C::B_R + fk * (C::BT * 16) + (b_row + 32 * j) * 16));
+            }
+#pragma unroll
+            for (int i = 0; i < C::MI; ++i)
+#pragma unroll
+                for (int j = 0; j < C::MJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av[i], bv[j], acc[i][j], 2, 2, 0, sa[i], 0, sb[j]);
+        };
         // Skewed wave groups (8-wave tiles; waves w and w + 4 share a SIMD): between two barriers the EARLY wave of a SIMD reads
         // K-tile kt into registers and then issues its products, the LATE wave first issues the products of K-tile kt - 1 -- read in
         // the previous period -- and reads K-tile kt afterwards.  One wave of every SIMD feeds the matrix pipe while the other one
@@ -623,7 +677,20 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const char* __restr
         };
         // one code path for both groups -- early: sync(kt) reads(kt) products(kt); late: reads(kt) sync(kt + 1) products(kt), i.e. the
         // late wave's products of K-tile kt run in period kt + 1, in front of its reads of K-tile kt + 1.  Both execute KT barriers.
-        if constexpr (C::U > 1 || C::LW > 0) {
+        if constexpr (C::RP && (DBG == 0 || DBG == 2048)) {
+            sync(0);
+            reads(0, fr[0]);
+            refill(0);
+            for (int kt = 1; kt < KT; ++kt) {
+                sync(kt);      // stamp 0: barrier passed
+                refill(kt);    // stamp 1: refill issued
+                stamp(kt, 2);
+                products_rp(fr[0], kt);
+                stamp(kt, 3);  // products and re-reads issued
+            }
+            products(fr[0]);
+        }
+        else if constexpr (C::U > 1 || C::LW > 0) {
             static_assert(!C::SKEW && !C::SPREAD && C::PF == 0 && (C::IW == C::NW || C::LW > 0), "plain burst refill only");
             for (int kt = 0; kt < KT; kt += C::U) {
                 const int nk = min(C::U, KT - kt);

@@ -20,7 +20,7 @@ typedef float    v4f __attribute__((ext_vector_type(4)));  // a register tuple t
 
 constexpr int PPW = 6, KT_BYTES = 8 * PPW * 1024, STAGES = 3;
 
-template<int MODE, bool MFMA, int MISS = 0, int PF = 0>
+template<int MODE, bool MFMA, int MISS = 0, int PF = 0, int PIPE = 0, int PSPAN = 8>
 __global__ __launch_bounds__(512) void feed(const char* __restrict__ src, int n_kt, int span, int shared, float* __restrict__ sink) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int      lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -32,15 +32,18 @@ __global__ __launch_bounds__(512) void feed(const char* __restrict__ src, int n_
         for (int r = 0; r < 16; ++r)
             acc[i][r] = 0.f;
     v4f r0[PPW], r1[PPW];
+    f16x8 fr0[18], fr1[18];
+    for (int r = 0; r < 18; ++r)
+        fr0[r] = fr1[r] = fa;
     float  s = 0.f;
     // MISS > 0 (with shared = 1): the last MISS of a wave's 6 pieces come from a region of its own (384 KB per workgroup: L2 misses
     // served by the Infinity Cache) -- the real kernel's mix is 77 % L2 hits; PF > 0: those lines are touched PF K-tiles ahead with
     // one dword per 128-byte line (a software prefetch into L2; wave 0 only, one load per 8 KB)
-    const char* priv = src + (size_t)(32 + blockIdx.x * 8) * KT_BYTES;
+    const char* priv = src + (size_t)(32 + blockIdx.x * PSPAN) * KT_BYTES;  // PSPAN 8: 384 KB per workgroup (Infinity Cache); 60: 2.9 MB (HBM)
     auto        dma  = [&](int kt, int q) {
         const char* p = base + (size_t)((kt + (shared ? blockIdx.x : 0)) % span) * KT_BYTES + (q * 8 + wave) * 1024;
         if (MISS > 0 && q >= PPW - MISS)
-            p = priv + (size_t)(kt % 8) * KT_BYTES + (q * 8 + wave) * 1024;
+            p = priv + (size_t)(kt % PSPAN) * KT_BYTES + (q * 8 + wave) * 1024;
         const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_base + (kt % STAGES) * KT_BYTES + (q * 8 + wave) * 1024));
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(p), "s"(dst) : "memory");
     };
@@ -49,7 +52,7 @@ __global__ __launch_bounds__(512) void feed(const char* __restrict__ src, int n_
         if (PF > 0 && MISS > 0 && wave == 0) {
 #pragma unroll
             for (int j = 0; j < MISS; ++j) {
-                const char* p = priv + (size_t)(kt % 8) * KT_BYTES + ((PPW - MISS + j) * 8) * 1024;
+                const char* p = priv + (size_t)(kt % PSPAN) * KT_BYTES + ((PPW - MISS + j) * 8) * 1024;
                 float       v;
                 asm volatile("global_load_dword %0, %1, %2" : "=&v"(v) : "v"(lane * 128u), "s"(p) : "memory");
                 pf_sink += v;   // never waited for explicitly: it is older than the pieces the counted wait covers
@@ -110,18 +113,36 @@ __global__ __launch_bounds__(512) void feed(const char* __restrict__ src, int n_
 #pragma unroll
         for (int q = 0; q < NREG; ++q)
             regs[q] = ld(kt + 2, NDMA + q);
-        if (MODE != 2) {  // consume: 18 fragment-sized reads per wave like the kernel
-            const char* st = lds + (kt % STAGES) * KT_BYTES;
+        if (PIPE == 0) {
+            if (MODE != 2) {  // consume: 18 fragment-sized reads per wave like the kernel
+                const char* st = lds + (kt % STAGES) * KT_BYTES;
 #pragma unroll
-            for (int r = 0; r < 18; ++r) {
-                const f16x8 v = *(const f16x8*)(st + ((r * 8 + wave) % 48) * 1024 + voff);
-                fa[r & 7] += v[0];
+                for (int r = 0; r < 18; ++r) {
+                    const f16x8 v = *(const f16x8*)(st + ((r * 8 + wave) % 48) * 1024 + voff);
+                    fa[r & 7] += v[0];
+                }
+            }
+            if (MFMA) {
+#pragma unroll
+                for (int m = 0; m < 24; ++m)
+                    acc[m & 7] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb, acc[m & 7], 0, 0, 0);
             }
         }
-        if (MFMA) {
+        else {
+            // PIPE 1: 18 fragment registers, 24 matrix instructions on them right behind the reads (the kernel's order)
+            // PIPE 2: the reads of this period fill the OTHER register set; the matrix instructions run on the set read one period
+            //         earlier -- they can start at the barrier, the LDS round trip hides behind them (needs 72 more registers)
+            const char* st = lds + (kt % STAGES) * KT_BYTES;
+            f16x8 (&dst)[18] = (PIPE == 2 && (kt & 1)) ? fr1 : fr0;
+            f16x8 (&src)[18] = (PIPE == 2) ? ((kt & 1) ? fr0 : fr1) : fr0;
 #pragma unroll
-            for (int m = 0; m < 24; ++m)
-                acc[m & 7] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb, acc[m & 7], 0, 0, 0);
+            for (int r = 0; r < 18; ++r)
+                dst[r] = *(const f16x8*)(st + ((r * 8 + wave) % 48) * 1024 + voff);
+            if (MFMA) {
+#pragma unroll
+                for (int m = 0; m < 24; ++m)
+                    acc[m & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(src[m % 12], src[12 + m % 6], acc[m & 3], 0, 0, 0);
+            }
         }
     };
     for (int kt = 0; kt < n_kt; kt += 2) {
@@ -131,15 +152,15 @@ __global__ __launch_bounds__(512) void feed(const char* __restrict__ src, int n_
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     for (int i = 0; i < 8; ++i)
         s += acc[i][0] + acc[i][7];
-    s += (float)fa[0] + pf_sink;
+    s += (float)fa[0] + pf_sink + (float)fr0[3][1] + (float)fr1[5][2];
     if (s == 123.456f)
         sink[threadIdx.x] = s;
 }
 
-template<int MODE, bool MFMA, int MISS = 0, int PF = 0>
+template<int MODE, bool MFMA, int MISS = 0, int PF = 0, int PIPE = 0, int PSPAN = 8>
 static void run(const char* name, const char* src, int span, int shared, float* sink, int n_cu) {
     const int n_kt = 4096, lds_bytes = STAGES * KT_BYTES;
-    auto      k    = feed<MODE, MFMA, MISS, PF>;
+    auto      k    = feed<MODE, MFMA, MISS, PF, PIPE, PSPAN>;
     hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     hipEvent_t a, b;
     hipEventCreate(&a);
@@ -160,7 +181,7 @@ int main() {
     hipDeviceProp_t prop;
     hipGetDeviceProperties(&prop, 0);
     const int    n_cu = prop.multiProcessorCount;
-    const size_t cap  = (size_t)n_cu * 64 * KT_BYTES + 4 * KT_BYTES;
+    const size_t cap  = (size_t)n_cu * 64 * KT_BYTES + 40 * KT_BYTES;
     char*        src  = nullptr;
     float*       sink = nullptr;
     hipMalloc(&src, cap);
@@ -183,6 +204,12 @@ int main() {
             run<3, true>("3 half / half + 24 MFMA", src, sp, shared, sink, n_cu);
             run<2, true>("2 registers only + 24 MFMA", src, sp, shared, sink, n_cu);
             if (shared) {
+                run<0, true, 0, 0, 1>("0 LDS-DMA + MFMA on 18 fragment registers, reads then products", src, sp, shared, sink, n_cu);
+                run<0, true, 0, 0, 2>("0 LDS-DMA + MFMA, products on the set read one period earlier", src, sp, shared, sink, n_cu);
+                run<0, true, 1, 0, 1, 60>("0 LDS-DMA + MFMA (fragment form), 1 of 6 pieces from HBM", src, sp, shared, sink, n_cu);
+                run<0, true, 2, 0, 1, 60>("0 LDS-DMA + MFMA (fragment form), 2 of 6 pieces from HBM", src, sp, shared, sink, n_cu);
+                run<0, true, 2, 0, 2, 60>("0 LDS-DMA + MFMA (pipelined form), 2 of 6 pieces from HBM", src, sp, shared, sink, n_cu);
+                run<0, true, 2, 0, 1, 8>("0 LDS-DMA + MFMA (fragment form), 2 of 6 from the Infinity Cache", src, sp, shared, sink, n_cu);
                 run<0, true, 1>("0 LDS-DMA + MFMA, 1 of 6 pieces misses L2", src, sp, shared, sink, n_cu);
                 run<0, true, 2>("0 LDS-DMA + MFMA, 2 of 6 pieces miss L2", src, sp, shared, sink, n_cu);
                 run<0, true, 2, 3>("0 LDS-DMA + MFMA, 2 of 6 miss, prefetched 3 K-tiles ahead", src, sp, shared, sink, n_cu);

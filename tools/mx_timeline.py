@@ -27,7 +27,7 @@ ctx.use_torch_stream()
 Ws, bs, acts, logp = synth.ffnn([2048, 2048, 64] if small else [2048, 10000], seed=7)
 T = 1024 if small else 32768
 x = torch.from_numpy(np.random.Generator(np.random.PCG64(1)).standard_normal((T, 2048)).astype(np.float32)).cuda()
-nn = rasr_amd.NnBatchFeatureScorer(ctx, Ws, bs, acts, log_prior=logp, precision="f16mx", tuning="graph=0,mx_dbg=%d" % (2048 | bits))
+nn = rasr_amd.NnBatchFeatureScorer(ctx, Ws, bs, acts, log_prior=logp, precision="f16mx", tuning="graph=0,mx_dbg=%d" % (2048 | bits) + ("," + sys.argv[2] if len(sys.argv) > 2 else ""))
 s = torch.empty((T, 64 if small else 10000), dtype=torch.float32, device="cuda")
 for _ in range(3):
     nn.score_dev(x, 2048, T, s)
