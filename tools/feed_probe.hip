@@ -16,11 +16,13 @@
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float    f32x16 __attribute__((ext_vector_type(16)));
-typedef float    v4f __attribute__((ext_vector_type(4)));  // a register tuple the asm constraints accept (HIP's float4 is a struct)
+typedef float    v4f __attribute__((ext_vector_type(4)));
+typedef int      v4i __attribute__((ext_vector_type(4)));
+typedef int      v8i __attribute__((ext_vector_type(8)));  // a register tuple the asm constraints accept (HIP's float4 is a struct)
 
 constexpr int PPW = 6, KT_BYTES = 8 * PPW * 1024, STAGES = 3;
 
-template<int MODE, bool MFMA, int MISS = 0, int PF = 0, int PIPE = 0, int PSPAN = 8>
+template<int MODE, bool MFMA, int MISS = 0, int PF = 0, int PIPE = 0, int PSPAN = 8, bool MXMIX = false>
 __global__ __launch_bounds__(512) void feed(const char* __restrict__ src, int n_kt, int span, int shared, float* __restrict__ sink) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int      lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -139,9 +141,22 @@ __global__ __launch_bounds__(512) void feed(const char* __restrict__ src, int n_
             for (int r = 0; r < 18; ++r)
                 dst[r] = *(const f16x8*)(st + ((r * 8 + wave) % 48) * 1024 + voff);
             if (MFMA) {
+                if (MXMIX) {  // the kernel's mix: 16 f16 products (32 cycles each) + 8 block-scaled fp6 x fp6 products (64 cycles), operands built from the fragments
 #pragma unroll
-                for (int m = 0; m < 24; ++m)
-                    acc[m & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(src[m % 12], src[12 + m % 6], acc[m & 3], 0, 0, 0);
+                    for (int m = 0; m < 16; ++m)
+                        acc[m & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(src[m % 12], src[12 + m % 6], acc[m & 3], 0, 0, 0);
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) {
+                        const v8i av = __builtin_shufflevector(__builtin_bit_cast(v4i, src[m % 12]), __builtin_bit_cast(v4i, src[(m + 1) % 12]), 0, 1, 2, 3, 4, 5, 6, 7);
+                        const v8i bv = __builtin_shufflevector(__builtin_bit_cast(v4i, src[12 + m % 6]), __builtin_bit_cast(v4i, src[12 + (m + 1) % 6]), 0, 1, 2, 3, 4, 5, 6, 7);
+                        acc[m & 3] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, acc[m & 3], 2, 2, 0, 127, 0, 127);
+                    }
+                }
+                else {
+#pragma unroll
+                    for (int m = 0; m < 24; ++m)
+                        acc[m & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(src[m % 12], src[12 + m % 6], acc[m & 3], 0, 0, 0);
+                }
             }
         }
     };
@@ -157,10 +172,10 @@ __global__ __launch_bounds__(512) void feed(const char* __restrict__ src, int n_
         sink[threadIdx.x] = s;
 }
 
-template<int MODE, bool MFMA, int MISS = 0, int PF = 0, int PIPE = 0, int PSPAN = 8>
+template<int MODE, bool MFMA, int MISS = 0, int PF = 0, int PIPE = 0, int PSPAN = 8, bool MXMIX = false>
 static void run(const char* name, const char* src, int span, int shared, float* sink, int n_cu) {
     const int n_kt = 4096, lds_bytes = STAGES * KT_BYTES;
-    auto      k    = feed<MODE, MFMA, MISS, PF, PIPE, PSPAN>;
+    auto      k    = feed<MODE, MFMA, MISS, PF, PIPE, PSPAN, MXMIX>;
     hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     hipEvent_t a, b;
     hipEventCreate(&a);
@@ -210,6 +225,10 @@ int main() {
                 run<0, true, 2, 0, 1, 60>("0 LDS-DMA + MFMA (fragment form), 2 of 6 pieces from HBM", src, sp, shared, sink, n_cu);
                 run<0, true, 2, 0, 2, 60>("0 LDS-DMA + MFMA (pipelined form), 2 of 6 pieces from HBM", src, sp, shared, sink, n_cu);
                 run<0, true, 2, 0, 1, 8>("0 LDS-DMA + MFMA (fragment form), 2 of 6 from the Infinity Cache", src, sp, shared, sink, n_cu);
+                run<0, true, 0, 0, 1, 8, true>("0 LDS-DMA + 16 f16 + 8 scaled fp6 products (fragment form), L2 hits", src, sp, shared, sink, n_cu);
+                run<0, true, 2, 0, 1, 60, true>("0 LDS-DMA + 16 f16 + 8 scaled fp6 products, 2 of 6 pieces from HBM", src, sp, shared, sink, n_cu);
+                run<0, true, 2, 0, 2, 60, true>("0 ... the same, pipelined form", src, sp, shared, sink, n_cu);
+                run<2, true, 0, 0, 1, 8, true>("2 registers only + 16 f16 + 8 scaled fp6 products (matrix-bound)", src, sp, shared, sink, n_cu);
                 run<0, true, 1>("0 LDS-DMA + MFMA, 1 of 6 pieces misses L2", src, sp, shared, sink, n_cu);
                 run<0, true, 2>("0 LDS-DMA + MFMA, 2 of 6 pieces miss L2", src, sp, shared, sink, n_cu);
                 run<0, true, 2, 3>("0 LDS-DMA + MFMA, 2 of 6 miss, prefetched 3 K-tiles ahead", src, sp, shared, sink, n_cu);
