@@ -378,6 +378,322 @@ __global__ __launch_bounds__(NW * 64) void gmm_fused_kernel(const float* __restr
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// gmm_fused_spec_kernel: the same scorer with SPECIALISED waves (round-3 review item 4; amx_gmm_model.tuning fused_waves=13).
+// tools/mx_probe.hip `coresident`: a wave that only issues matrix instructions and a wave that only runs the distance step overlap
+// by 0.83 on one SIMD, while gmm_fused_kernel's waves all sit in the screen's MFMAs together and then all in the exact stage.  Here a
+// workgroup is 4 SCREEN waves (one per SIMD) + NE = 8 or 12 EXACT waves (two or three per SIMD) over NE x 32 frames:
+//   screen wave s   owns the frames of exact waves G s .. G s + G - 1 (G = 2 or 3 groups of 32 frames): their 32 MFMAs per tile and the mask
+//                   epilogue -- exactly gmm_fused_kernel's screen, same masks -- and issues ALL of the workgroup's LDS-DMA;
+//   exact wave e    owns 32 frames: reads its 4 mask words, then gmm_fused_kernel's exact stage, results and stores, unchanged.
+// The screen runs ONE TILE AHEAD of the exact stage: in period r the screen waves work on tile r + 1 (its f16 rows arrived a period
+// earlier) while the exact waves evaluate tile r from the masks of the period before.  LDS = gmm_fused_kernel's two records, now two
+// rings of different phase: A ring [2][33 KB] (f16 rows + thresholds; A(q) in slot q & 1) and mean ring [2][mu stage]; the masks of
+// tile r travel through the first 8 KB of A's slot r & 1 -- dead once every screen wave has finished tile r -- which takes three
+// barriers per tile: A (screen of r + ... done, exact of r - 1 done) | screen waves write masks(r) | B | exact waves fetch them |
+// C (slot free) | screen waves refill the slot by DMA and screen tile r + 1, exact waves evaluate tile r.
+// MEASURED (tools/spec_test.py, 63 936 frames x 10 000 x 16): bit-identical to gmm_fused_kernel and SLOWER, 6.0 ms against 4.75 ms.
+// The vector work per frame is the same in both kernels (75 against 73 instructions per frame and SIMD); two exact waves per SIMD do
+// not keep the vector pipe as busy as three mixed waves do (their chains of dependent f32 / f64 operations and mean-row reads want a
+// third wave to hide behind), and what the screen waves take off them was never on the critical path.  With twelve exact waves
+// (NE = 12, sixteen waves of 128 registers) the kernel spills 448 bytes per lane: 11.7 ms.  Kept as an A/B variant (fused_waves=13)
+// with its own parity test; gmm_fused_kernel stays the default.
+template<int DIM, bool BEST, int NE>
+__global__ __launch_bounds__((4 + NE) * 64) void gmm_fused_spec_kernel(const float* __restrict__ g_feats, const _Float16* __restrict__ g_X,
+                                                             const float* __restrict__ g_nx, const float* __restrict__ g_q,
+                                                             const char* __restrict__ g_rec, const float* __restrict__ g_isr,
+                                                             float* __restrict__ g_scores, uint32_t* __restrict__ g_best, int T, int Tpad,
+                                                             int n_mix, int n_tiles, int r_split, float* __restrict__ g_part_min,
+                                                             unsigned* __restrict__ g_part_idx, int part_ld,
+                                                             unsigned long long* __restrict__ g_survivors) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr int LD = fused_ld(DIM), REC = fused_rec_bytes(DIM), A_ST = kFusedAStage, MU_ST = fused_mu_stage(DIM);
+    constexpr int NS = 4, G = NE / NS, FPW = NE * 32;  // screen waves, frame groups per screen wave, frames per workgroup
+    static_assert(NE % NS == 0, "every screen wave serves the same number of exact waves");
+    static_assert(2 * REC == 2 * A_ST + 2 * MU_ST && A_ST % 1024 == 0 && MU_ST % 1024 == 0, "two rings out of two records");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile_t = blockIdx.x / r_split, part = blockIdx.x % r_split;
+    const int per = (n_tiles + r_split - 1) / r_split;
+    const int r_begin = part * per, r_end = min(n_tiles, r_begin + per);
+    if (r_begin >= r_end)
+        return;
+    const unsigned lds_base = (unsigned)(uintptr_t)lds;
+    auto a_slot  = [&](int q) { return lds + (q & 1) * A_ST; };
+    auto mu_slot = [&](int q) { return lds + 2 * A_ST + (q & 1) * MU_ST; };
+    const int frow = lane & 31, fk = lane >> 5;
+    const int t_wg = tile_t * FPW;
+
+    if (wave < NS) {
+        // ============================================================ screen wave
+        auto dma = [&](const char* src, unsigned dst, int n_pieces) {  // this wave's share of n_pieces KB
+            for (int p = wave; p < n_pieces; p += NS)
+                fused_dma16(src + p * 1024 + lane * 16, (unsigned)__builtin_amdgcn_readfirstlane((int)(dst + p * 1024)));
+        };
+        auto load_a = [&](int r) {
+            if (r < r_end)
+                dma(g_rec + (size_t)r * REC, lds_base + (r & 1) * A_ST, A_ST / 1024);
+        };
+        auto load_mu = [&](int r) {
+            if (r < r_end)
+                dma(g_rec + (size_t)r * REC + A_ST, lds_base + 2 * A_ST + (r & 1) * MU_ST, MU_ST / 1024);
+        };
+        load_a(r_begin);
+        load_mu(r_begin);
+        load_a(r_begin + 1);
+        // the two frame groups of this wave
+        fus_f16x8 bx[G][4];
+        float     nx[G], qq[G];
+        bool      live[G], all[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int t  = t_wg + (G * wave + g) * 32 + frow;
+            const int tx = min(t, Tpad - 1);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                bx[g][ks] = *(const fus_f16x8*)(g_X + (size_t)tx * 64 + (ks * 2 + fk) * 8);
+            nx[g]   = g_nx[tx];
+            qq[g]   = g_q[tx];
+            live[g] = t < T;
+            all[g]  = !(nx[g] < __builtin_inff());
+        }
+        unsigned M[G][4];
+        auto     screen = [&](int r) {  // masks of tile r from A's slot r & 1: gmm_fused_kernel's screen, twice
+            const char*  stage = a_slot(r);
+            const float* s_p   = (const float*)(stage + kFusedABytes);
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+#pragma unroll
+                for (int w = 0; w < 4; ++w)
+                    M[g][w] = 0;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int  rr = i * 32 + frow;
+                    fus_f32x16 c;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        c[e] = 0.f;
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        const fus_f16x8 a = *(const fus_f16x8*)(stage + rr * 128 + (((ks * 2 + fk) ^ ((rr >> 1) & 7)) << 4));
+                        c                 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bx[g][ks], c, 0, 0, 0);
+                    }
+                    float mn = min3_first(c[0], c[1], c[2]);
+                    mn       = min3_raw(mn, c[3], c[4]);
+                    mn       = min3_raw(mn, c[5], c[6]);
+                    mn       = min3_raw(mn, c[7], c[8]);
+                    mn       = min3_raw(mn, c[9], c[10]);
+                    mn       = min3_raw(mn, c[11], c[12]);
+                    mn       = min3_raw(mn, c[13], c[14]);
+                    mn       = min3_raw(mn, c[15], c[15]);
+                    const float p1 = s_p[i * 2 + fk], p2 = s_p[16 + i * 2 + fk];
+                    const int   nd = ((const int*)s_p)[32 + i * 2 + fk];
+                    const float thr = mn + fmaf(nx[g], p1, fmaf(fabsf(mn), 1.6e-5f, p2 + qq[g])) + 1e-30f;
+                    unsigned    bits = 0;
+#pragma unroll
+                    for (int e = 15; e >= 0; --e)
+                        bits = __builtin_amdgcn_alignbit(bits, __float_as_uint(thr - c[e]), 31);
+                    const unsigned valid = (1u << nd) - 1u;
+                    const unsigned m16   = live[g] ? ((all[g] ? 0xffffu : (~bits & 0xffffu)) & valid) : 0u;
+                    M[g][i >> 1] |= m16 << (16 * (i & 1));
+                }
+            }
+        };
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // P: A(r_begin), mean rows of r_begin, A(r_begin + 1) are there
+        screen(r_begin);
+        for (int r = r_begin; r < r_end; ++r) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();  // A: every screen wave is done with A(r); this period's DMA has landed; exact(r - 1) is done
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+                *(uint4*)(a_slot(r) + (((G * wave + g) * 32 + frow) * 2 + fk) * 16) = make_uint4(M[g][0], M[g][1], M[g][2], M[g][3]);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();  // B: masks(r) visible
+            __builtin_amdgcn_s_barrier();  // C: the exact waves hold them: A's slot r & 1 is free
+            load_a(r + 2);
+            load_mu(r + 1);
+            if (r + 1 < r_end)
+                screen(r + 1);
+        }
+        return;
+    }
+
+    // ================================================================ exact wave
+    const int  ew   = wave - NS;
+    const int  t    = t_wg + ew * 32 + frow;
+    const bool live = t < T;
+    const int  tt   = live ? t : T - 1;
+    const bool wave_live = t_wg + ew * 32 < T;
+    float      x[DIM];
+#pragma unroll
+    for (int i = 0; i < DIM; ++i)
+        x[i] = g_feats[(size_t)tt * DIM + i];
+    const bool wide_ok = (n_mix & 3) == 0 && ((uintptr_t)g_scores & 15) == 0 && (!BEST || ((uintptr_t)g_best & 15) == 0);
+    __builtin_amdgcn_s_waitcnt(0);
+    float    run_min = 3.402823466e+38f;
+    unsigned run_idx = 0xffffffffu;
+    unsigned n_surv  = 0;
+    __builtin_amdgcn_s_barrier();  // P
+    for (int r = r_begin; r < r_end; ++r) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // A
+        __builtin_amdgcn_s_barrier();  // B: masks(r) are in A's slot r & 1
+        const uint4 mw = *(const uint4*)(a_slot(r) + ((ew * 32 + frow) * 2 + fk) * 16);
+        unsigned    M[4] = {mw.x, mw.y, mw.z, mw.w};
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // C
+        if (!wave_live)
+            continue;
+        n_surv += __popc(M[0]) + __popc(M[1]) + __popc(M[2]) + __popc(M[3]);
+        const float* s_mu = (const float*)mu_slot(r);
+        auto         distance = [&](int row, double& cc) -> float {
+            const float*  src = s_mu + row * LD;
+            float         l0 = 0.f, l1 = 0.f, l2 = 0.f, l3 = 0.f;
+            constexpr int EFF = DIM & ~3;
+#pragma unroll
+            for (int i = 0; i < EFF; i += 4) {
+                const float4 m  = *(const float4*)(src + i);
+                const float  d0 = (m.x - x[i]) * g_isr[i], d1 = (m.y - x[i + 1]) * g_isr[i + 1];
+                const float  d2 = (m.z - x[i + 2]) * g_isr[i + 2], d3 = (m.w - x[i + 3]) * g_isr[i + 3];
+                l0              = l0 + d0 * d0;
+                l1              = l1 + d1 * d1;
+                l2              = l2 + d2 * d2;
+                l3              = l3 + d3 * d3;
+            }
+            float result = 0.f;
+            result       = result + ((l0 + l1) + (l2 + l3));
+#pragma unroll
+            for (int i = EFF; i < DIM; ++i) {
+                const float df = (src[i] - x[i]) * g_isr[i];
+                result         = result + df * df;
+            }
+            cc = *(const double*)(src + LD - 2);
+            return result;
+        };
+        float    best[8];
+        unsigned bpack = 0, bvalid = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const unsigned m16 = (M[i >> 1] >> (16 * (i & 1))) & 0xffffu;
+            const int      sl  = m16 ? __ffs((int)m16) - 1 : 0;
+            double         cc;
+            const float    dist = distance((i * 2 + fk) * 16 + sl, cc);
+            const double   s    = cc + (double)dist;
+            const bool     take = m16 != 0u && (double)FLT_MAX > s;
+            best[i]             = take ? (float)s : FLT_MAX;
+            bpack |= take ? ((unsigned)sl << (4 * i)) : 0u;
+            bvalid |= take ? (1u << i) : 0u;
+        }
+        unsigned R[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const unsigned lo = M[w] & 0xffffu, hi = M[w] >> 16;
+            R[w]              = (lo & (lo - 1u)) | ((hi & (hi - 1u)) << 16);
+        }
+        while (__any((R[0] | R[1] | R[2] | R[3]) != 0u)) {
+            const unsigned w01 = R[0] ? R[0] : R[1], w23 = R[2] ? R[2] : R[3];
+            const bool     lo  = (R[0] | R[1]) != 0u;
+            const unsigned rw  = lo ? w01 : w23;
+            if (rw) {
+                const int      w   = lo ? (R[0] ? 0 : 1) : (R[2] ? 2 : 3);
+                const int      pos = __ffs((int)rw) - 1;
+                const unsigned cleared = rw & (rw - 1u);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    R[j] = (w == j) ? cleared : R[j];
+                const int i = 2 * w + (pos >> 4), sl = pos & 15;
+                double    cc;
+                const float dist = distance((i * 2 + fk) * 16 + sl, cc);
+                float       b    = best[0];
+#pragma unroll
+                for (int j = 1; j < 8; ++j)
+                    b = (i == j) ? best[j] : b;
+                const double s    = cc + (double)dist;
+                const bool   take = (double)b > s;
+                const float  nb   = (float)s;
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    best[j] = (take && i == j) ? nb : best[j];
+                const unsigned sh = 4u * (unsigned)i;
+                bpack             = take ? ((bpack & ~(15u << sh)) | ((unsigned)sl << sh)) : bpack;
+                bvalid |= take ? (1u << i) : 0u;
+            }
+        }
+        const int m0 = r * 16;
+        float     sc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            sc[i]       = 0.5f * best[i];
+            const int m = m0 + i * 2 + fk;
+            if (g_part_min && m < n_mix && sc[i] < run_min) {
+                run_min = sc[i];
+                run_idx = (unsigned)m;
+            }
+        }
+        float    so[8];
+        unsigned bo[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const fus_u32x2 rs = __builtin_amdgcn_permlane32_swap(__float_as_uint(sc[j]), __float_as_uint(sc[4 + j]), false, false);
+            so[2 * j]          = __uint_as_float(rs.x);
+            so[2 * j + 1]      = __uint_as_float(rs.y);
+            if (BEST) {
+                const unsigned  bj = (bvalid >> j) & 1u ? (bpack >> (4 * j)) & 15u : 0xffffffffu;
+                const unsigned  bk = (bvalid >> (4 + j)) & 1u ? (bpack >> (4 * (4 + j))) & 15u : 0xffffffffu;
+                const fus_u32x2 rb = __builtin_amdgcn_permlane32_swap(bj, bk, false, false);
+                bo[2 * j]          = rb.x;
+                bo[2 * j + 1]      = rb.y;
+            }
+        }
+        const int mb = m0 + fk * 8;
+        if (live) {
+            float*    gs = g_scores + (size_t)t * n_mix + mb;
+            uint32_t* gb = BEST ? g_best + (size_t)t * n_mix + mb : nullptr;
+            if (wide_ok && m0 + 16 <= n_mix) {
+                typedef float    nt_f4 __attribute__((ext_vector_type(4)));
+                typedef unsigned nt_u4 __attribute__((ext_vector_type(4)));
+                __builtin_nontemporal_store(nt_f4{so[0], so[1], so[2], so[3]}, (nt_f4*)gs);
+                __builtin_nontemporal_store(nt_f4{so[4], so[5], so[6], so[7]}, (nt_f4*)(gs + 4));
+                if (BEST) {
+                    __builtin_nontemporal_store(nt_u4{bo[0], bo[1], bo[2], bo[3]}, (nt_u4*)gb);
+                    __builtin_nontemporal_store(nt_u4{bo[4], bo[5], bo[6], bo[7]}, (nt_u4*)(gb + 4));
+                }
+            }
+            else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (mb + e < n_mix) {
+                        gs[e] = so[e];
+                        if (BEST)
+                            gb[e] = bo[e];
+                    }
+            }
+        }
+    }
+    if (g_survivors) {
+        unsigned long long n = live ? n_surv : 0u;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+            n += __shfl_xor(n, off, 64);
+        if (lane == 0 && n)
+            atomicAdd(g_survivors + ((blockIdx.x * NE + ew) & 255), n);
+    }
+    if (g_part_min) {
+        const float    om = __shfl_xor(run_min, 32, 64);
+        const unsigned oi = (unsigned)__shfl_xor((int)run_idx, 32, 64);
+        if (om < run_min || (om == run_min && oi < run_idx)) {
+            run_min = om;
+            run_idx = oi;
+        }
+        if (fk == 0 && live) {
+            g_part_min[(size_t)part * part_ld + t] = run_min;
+            g_part_idx[(size_t)part * part_ld + t] = run_idx;
+        }
+    }
+}
+
 }  // namespace amx
 
 // ---- host side (internal to librasr_amd.so; called from gmm.hip)
@@ -443,16 +759,20 @@ extern "C" int amx_internal_gmm_fused_create(int dim, int n_mix, int n_tiles, co
 // with 8 waves and 5.0 ms with 16 (which spills 9 registers) per 63 936 frames -- and 8 (256 frames) for the decoder's small batches,
 // where a 384-frame workgroup would idle a third of its waves.  amx_gmm_model.tuning fused_waves = 8 | 12 | 16 overrides (A/B runs).
 static int fused_waves(int Tpad, int forced) {
-    if (forced == 8 || forced == 12 || forced == 16)
+    if (forced == 8 || forced == 12 || forced == 16 || forced == 13)  // 13: the specialised kernel (4 screen + 8 exact waves)
         return forced;
     return Tpad >= 4096 ? 12 : 8;
+}
+static int fused_frames(int Tpad, int forced) {  // frames per workgroup
+    const int w = fused_waves(Tpad, forced);
+    return w == 13 ? 256 : w * 32;
 }
 
 // how many mixture ranges a pass of Tpad frames is split into (workgroup = its frames x one range; one workgroup per CU): the
 // smallest split that gives every CU a workgroup, unless the frame tiles alone already fill 3/4 of them.  The partial arg-min
 // arrays hold that many rows.
 static int fused_split_raw(int n_cu, int Tpad, int n_tiles, int forced) {
-    const int fpw = fused_waves(Tpad, forced) * 32;
+    const int fpw = fused_frames(Tpad, forced);
     const int ntt = (Tpad + fpw - 1) / fpw, cus = std::max(n_cu, 8);
     if (fused_waves(Tpad, forced) != 8) {  // frame tiles of 384: pick the split whose workgroup count is closest below a whole number of rounds
         int best = 1;
@@ -487,7 +807,7 @@ extern "C" int amx_internal_gmm_fused_score(amx_ctx* ctx, int dim, const void* r
                                             const void* X, const float* nx, const float* q, int T, int Tpad, int n_mix, int n_tiles,
                                             int split, float* scores, uint32_t* best, float* pmin, unsigned* pidx, int part_ld,
                                             unsigned long long* survivors, int forced_waves) {
-    const int   nw = fused_waves(Tpad, forced_waves), ntt = (Tpad + nw * 32 - 1) / (nw * 32);
+    const int   nw = fused_waves(Tpad, forced_waves), fpw = fused_frames(Tpad, forced_waves), ntt = (Tpad + fpw - 1) / fpw;
     const int   lds = 2 * amx::fused_rec_bytes(dim);
     const char* rec = (const char*)rec_dev;
     hipStream_t st  = ctx->stream;
@@ -498,9 +818,18 @@ extern "C" int amx_internal_gmm_fused_score(amx_ctx* ctx, int dim, const void* r
         hipLaunchKernelGGL(k, dim3(ntt * split), dim3(W * 64), lds, st, feats, (const _Float16*)X, nx, q, rec, isr_dev, scores,  \
                            best, T, Tpad, n_mix, n_tiles, split, pmin, pidx, part_ld, survivors);                          \
     }
+#define AMX_FUSED_SPEC(D, B, E)                                                                                                 \
+    {                                                                                                                           \
+        auto k = amx::gmm_fused_spec_kernel<D, B, E>;                                                                           \
+        hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);                                   \
+        hipLaunchKernelGGL(k, dim3(ntt * split), dim3((4 + E) * 64), lds, st, feats, (const _Float16*)X, nx, q, rec, isr_dev, scores,    \
+                           best, T, Tpad, n_mix, n_tiles, split, pmin, pidx, part_ld, survivors);                          \
+    }
 #define AMX_FUSED(D)                                                                                                            \
     case D: {                                                                                                                   \
-        if (best && nw == 16) AMX_FUSED_LAUNCH(D, true, 16)                                                                     \
+        if (nw == 13 && best) AMX_FUSED_SPEC(D, true, 8)                                                                        \
+        else if (nw == 13) AMX_FUSED_SPEC(D, false, 8)                                                                          \
+        else if (best && nw == 16) AMX_FUSED_LAUNCH(D, true, 16)                                                                     \
         else if (best && nw == 12) AMX_FUSED_LAUNCH(D, true, 12)                                                                \
         else if (best) AMX_FUSED_LAUNCH(D, true, 8)                                                                             \
         else if (nw == 12) AMX_FUSED_LAUNCH(D, false, 12)                                                                       \
@@ -518,6 +847,7 @@ extern "C" int amx_internal_gmm_fused_score(amx_ctx* ctx, int dim, const void* r
             return AMX_ERR_UNSUPPORTED;
     }
 #undef AMX_FUSED
+#undef AMX_FUSED_SPEC
 #undef AMX_FUSED_LAUNCH
     AMX_HIP(hipGetLastError());
     return AMX_OK;

@@ -917,6 +917,37 @@ def test_fused_adversarial_twins(ctx, dim):
     assert_exact(ctx, model, x)
 
 
+@pytest.mark.parametrize("n_mix,dim,T", [(70, 40, 300), (333, 40, 700), (48, 24, 1000), (17, 16, 257), (45, 33, 513), (1000, 40, 3000)])
+def test_fused_specialised_waves_variant_exact(ctx, n_mix, dim, T):
+    """gmm_fused_spec_kernel (tuning fused_waves=13: four screen waves that run the MFMA screen one tile ahead and issue the DMA,
+    eight exact waves that evaluate the survivors; masks handed over through LDS behind three barriers per tile) -- the form the
+    round-3 review asked for; slower than gmm_fused_kernel (6.0 vs 4.75 ms), kept for A/B runs: scores, best densities and the fused
+    best-state statistics bit-exact against the oracle, partial last tiles and frame counts off the 256-frame workgroup included"""
+    import torch
+
+    import rasr_amd
+    from oracle import OracleGmm
+    model = synth.gmm_cart(n_mix, 1, 16, dim, seed=400 + n_mix, pooled=True)
+    x = feats(T, dim, 401 + T)
+    x[T // 3] *= 40.0
+    want, wbest = OracleGmm(model).score(x, mode=0)
+    sc = rasr_amd.GmmFeatureScorer(ctx, model, tuning="fused_waves=13")
+    ctx.use_torch_stream()
+    xd = torch.from_numpy(x).cuda()
+    s = torch.empty((T, n_mix), dtype=torch.float32, device="cuda")
+    b = torch.empty((T, n_mix), dtype=torch.int32, device="cuda")
+    st = torch.empty((T,), dtype=torch.int32, device="cuda")
+    cnt = torch.zeros((n_mix,), dtype=torch.int64, device="cuda")
+    ss = torch.zeros((1,), dtype=torch.float64, device="cuda")
+    sc.score_stats_dev(xd, T, s, b, st, cnt, ss)
+    torch.cuda.synchronize()
+    g = s.cpu().numpy()
+    assert np.array_equal(g.view(np.uint32), want.view(np.uint32)), np.abs(g - want).max()
+    assert np.array_equal(b.cpu().numpy().astype(np.uint32), wbest)
+    assert np.array_equal(st.cpu().numpy(), g.argmin(axis=1))
+    assert np.array_equal(cnt.cpu().numpy(), np.bincount(g.argmin(axis=1), minlength=n_mix))
+
+
 def test_fused_equals_two_kernel_path_with_stats(ctx, monkeypatch):
     """the fused kernel and round 1's two kernels (tuning fused=0) agree bit for bit on scores, best densities, best states,
     counts and the score sum; frames that do not fit the f16 operand keep every slot in both; without a best-density buffer too"""

@@ -1,0 +1,36 @@
+import sys, numpy as np, torch, time
+sys.path.insert(0, "/root/repo")
+import rasr_amd
+from tests import synth
+from oracle import OracleGmm
+ctx = rasr_amd.Context(0); ctx.use_torch_stream()
+ok = True
+for (n_mix, dim, T, seed) in [(70, 40, 300, 1), (333, 40, 700, 2), (48, 24, 1000, 3), (1000, 40, 5000, 4), (17, 16, 257, 5), (45, 33, 513, 6)]:
+    model = synth.gmm_cart(n_mix, 1, 16, dim, seed=400 + seed, pooled=True)
+    x = np.random.Generator(np.random.PCG64(seed)).standard_normal((T, dim)).astype(np.float32)
+    want, wbest = OracleGmm(model).score(x, mode=0)
+    sc = rasr_amd.GmmFeatureScorer(ctx, model, tuning="fused_waves=17")
+    xd = torch.from_numpy(x).cuda()
+    s = torch.empty((T, n_mix), dtype=torch.float32, device="cuda"); b = torch.empty((T, n_mix), dtype=torch.int32, device="cuda")
+    st = torch.empty((T,), dtype=torch.int32, device="cuda"); cnt = torch.zeros((n_mix,), dtype=torch.int64, device="cuda"); ss = torch.zeros((1,), dtype=torch.float64, device="cuda")
+    sc.score_stats_dev(xd, T, s, b, st, cnt, ss)
+    torch.cuda.synchronize()
+    g, gb = s.cpu().numpy(), b.cpu().numpy().astype(np.uint32)
+    e1 = np.array_equal(g.view(np.uint32), want.view(np.uint32)); e2 = np.array_equal(gb, wbest); e3 = np.array_equal(st.cpu().numpy(), g.argmin(axis=1))
+    print(n_mix, dim, T, "scores", e1, "best", e2, "state", e3)
+    ok = ok and e1 and e2 and e3
+print("ALL OK" if ok else "FAILED")
+# speed on the config-5 shape
+model = synth.gmm_cart(10000, 16, 16, 40, seed=5, pooled=True)
+T = 63936
+x = torch.from_numpy(np.random.Generator(np.random.PCG64(4)).standard_normal((T, 40)).astype(np.float32)).cuda()
+s = torch.empty((T, 10000), dtype=torch.float32, device="cuda"); b = torch.empty((T, 10000), dtype=torch.int32, device="cuda")
+res = {}
+for tun in (None, "fused_waves=13", "fused_waves=17", None, "fused_waves=17"):
+    sc = rasr_amd.GmmFeatureScorer(ctx, model, tuning=tun)
+    for _ in range(2): sc.score_dev(x, T, s, b)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(5): sc.score_dev(x, T, s, b)
+    torch.cuda.synchronize(); print(tun, "%.3f ms per pass (kernel + pack)" % ((time.perf_counter() - t0) / 5 * 1e3))
+    res[tun] = (s.clone(), b.clone()) if tun not in res else res[tun]
+print("spec == default bitwise:", torch.equal(res[None][0].view(torch.int32), res["fused_waves=13"][0].view(torch.int32)) and torch.equal(res[None][1], res["fused_waves=13"][1]))
