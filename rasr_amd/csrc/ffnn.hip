@@ -1465,7 +1465,7 @@ int ensure_workspace(amx_ffnn* h, int Tpad) {
     return AMX_OK;
 }
 
-// tile configurations of the bf16 GEMM, selected at run time (AMX_GEMM_CFG overrides for experiments)
+// tile configurations of the bf16 GEMM, selected at run time (amx_ffnn_model.tuning tile=N overrides for experiments)
 using CfgA = amx::GemmCfg<128, 128, 2, 2, 2>;  //  64 KB LDS, 2 workgroups per CU
 using CfgC = amx::GemmCfg<256, 256, 2, 4, 2>;  // 128 KB LDS, 8 waves, wave tile 128x64
 using CfgS = amx::GemmCfg<128, 64, 2, 2, 2>;   //  48 KB LDS, 3 workgroups per CU: small batches (fills the CUs)

@@ -2255,7 +2255,7 @@ static int ensure_simd(amx_gmm* h) {
 }
 }  // extern "C++"
 
-// dense or pruned for this call of a shared-list tied model: AMX_GMM_TIED_PRUNE=0 forces the dense kernel, =1 the pruned path,
+// dense or pruned for this call of a shared-list tied model: amx_gmm_model.tuning tied_prune=0 forces the dense kernel, =1 the pruned path,
 // default adaptive -- the pruned kernel counts the (density, frame, tile) triples it had to evaluate, the host reads the count of
 // EARLIER calls from pinned memory (no synchronisation) and stays on the dense kernel for 64 calls while more than 10 % stood
 static bool tied_decide_prune(amx_gmm* h) {
