@@ -1596,8 +1596,6 @@ using MfgL = amx::mx::MxCfg<256, 256, 2, 4, 3>;      // 147 KB LDS, 8 waves of 1
 using MfgLP = amx::mx::MxCfg<256, 256, 2, 4, 3, 4>;  // the same with the software L2 prefetch 4 K-tiles ahead (tuning tile=4: A/B runs; measured 6 % SLOWER: the
                                                      // prefetch loads sit in the in-order vmcnt queue in front of the next K-tile's pieces)
 using MfgLH = amx::mx::MxCfg<256, 256, 2, 4, 3, 0, 4>;  // the first wave of every SIMD issues all LDS-DMA pieces (tuning tile=5: A/B runs)
-using MfgLR = amx::mx::MxCfg<256, 256, 2, 4, 3, 0, 0, 1, 0, 1>;  // register pipelining, all waves issue DMA (tile=8)
-using MfgLRH = amx::mx::MxCfg<256, 256, 2, 4, 3, 0, 4, 1, 0, 1>; // register pipelining, the first wave of every SIMD issues the DMA (tile=9)
 using MfgLF = amx::mx::MxCfg<256, 256, 2, 4, 3, 4, 4>;  // ... and its partner prefetches four K-tiles ahead into L2, outside every counted queue (tile=7)
 using MfgA = amx::mx::MxCfg<128, 128, 2, 2, 3>;  //  74 KB: 2 workgroups per CU
 using MfgS = amx::mx::MxCfg<128, 64, 2, 2, 8, 0, 0, 2>;  // 147 KB: small batches, ONE tile per CU, two K-tiles per barrier, four more in flight (a
@@ -1640,6 +1638,7 @@ void launch_mx(amx_ffnn* h, int l, const void* x, int xkts, void* out, int ldo, 
             case 280: AMX_MX_LAUNCH(280); break;
             case 512: AMX_MX_LAUNCH(512); break;
             case 768: AMX_MX_LAUNCH(768); break;
+            case 192: AMX_MX_LAUNCH(192); break;
             case 1024: AMX_MX_LAUNCH(1024); break;
             case 2048: AMX_MX_LAUNCH(2048); break;
             case 2304: AMX_MX_LAUNCH(2304); break;
@@ -1683,8 +1682,6 @@ void launch_mx_cfg(amx_ffnn* h, int l, const void* x, int xkts, void* out, int l
         case 4: launch_mx<MfgLP, ACT, LAST>(h, l, x, xkts, out, ldo, T, Tpad, n_valid); break;
         case 5: launch_mx<MfgLH, ACT, LAST>(h, l, x, xkts, out, ldo, T, Tpad, n_valid); break;
         case 7: launch_mx<MfgLF, ACT, LAST>(h, l, x, xkts, out, ldo, T, Tpad, n_valid); break;
-        case 8: launch_mx<MfgLR, ACT, LAST>(h, l, x, xkts, out, ldo, T, Tpad, n_valid); break;
-        case 9: launch_mx<MfgLRH, ACT, LAST>(h, l, x, xkts, out, ldo, T, Tpad, n_valid); break;
         case 3:
             if constexpr (LAST)
                 launch_mx<MfgS, ACT, LAST>(h, l, x, xkts, out, ldo, T, Tpad, n_valid);

@@ -4,7 +4,13 @@
 //     h(x) h(w)                        h = f16(v), round to nearest              v_mfma_f32_32x32x16_f16        (1 unit of matrix time)
 //   + q(x) r(w) + r(x) q(w)            q = fp6(h(v)), r = fp6(v - h(v))          v_mfma_scale_f32_32x32x64_f8f6f4, e2m3 x e2m3
 // with OCP-MX block scales (one e8m0 exponent per 32 k and row: 2^(E-2) for q, E the exponent of the block maximum, and 2^-11 of
-// that for r -- |v - f16(v)| <= 2^-11 2^E, so r never saturates and needs no maximum of its own).  Because both cross terms carry
+// that for r -- |v - f16(v)| <= 2^-11 2^E, so r never saturates and needs no maximum of its own).  WEIGHT rows n and n ^ 32 share
+// their exponent (the maximum of the two blocks): a lane of the GEMM serves both (two 32-row blocks of its wave tile), the conversion
+// instruction converts 32 values under ONE scale, so one instruction yields q for both rows -- four conversions per K-tile and wave
+// (two for the weights, two for the frames) instead of six.  They cost: tools/cvt_rate.hip measures 28 ns per conversion and SIMD and
+// NO overlap with the matrix instructions (16 + 8 of them: 675 ns; with six conversions: 966 ns).  Frames keep an exponent of their
+// own: paired like the rows (measured: another 2 % of the layer) a frame's scores would depend on which frame shares its batch, and
+// scoring a segment in pieces would no longer give the bits of scoring it whole.  Because both cross terms carry
 // the same total scale 2^(Ew-2) 2^(Ex-13), ONE 64-deep scaled product does both for 16 k:
 //     A = [ q(w) (16 k) | r(w) (the same 16 k) ]   scale 2^(Ew-2)
 //     B = [ r(x)        | q(x)                 ]   scale 2^(Ex-13)
@@ -14,7 +20,7 @@
 // 3 B, against 4 B for split bf16 -- and 1.5 units of matrix time per product instead of 3 (fp6 x fp6 runs at four times the f16
 // rate: 32 cycles per 32x32x64).  The dropped r r term is <= 2^-22 |x w|; the cross terms carry a relative error of ~2^-4 on a
 // 2^-11 term.  tools/emulate_split_f16_f8.py evaluates the scheme on all 10.24 M scores of BASELINE config 4
-// (profiles/r04/emulation_f16_f8.json): worst |d| = 0.024 of the 1e-4 |ref| + 1e-4 bar, no arg-min change; the fp4 form (0.11 of
+// (profiles/r04/emulation_f16_f8.json): worst |d| = 0.029 of the 1e-4 |ref| + 1e-4 bar, no arg-min change; the fp4 form (0.11 of
 // the bar, built first) failed the bar on a one-output network whose scores are not carried by a prior (tests/test_ffnn_f16mx_gpu.py).
 // f16 range: an activation or feature beyond +-65504 raises the handle's overflow flag and every later call fails (use bf16x3).
 //
@@ -92,21 +98,29 @@ static inline unsigned fp6_code_host(float v, int sbyte) {
 // packs rows [n_rows x K] (f32, row stride ld) into blocks [Rpad / 256][KT]; rows / columns beyond the matrix are zero
 static inline void pack_weights_host(const float* W, int n_rows, int K, int ld, int Rpad, int KT, std::vector<unsigned char>& out) {
     out.assign((size_t)(Rpad / 256) * KT * BLK, 0);
+    auto block_max = [&](int n, int kt) {
+        float m = 0.f;
+        if (n < n_rows)
+            for (int u = 0; u < 32; ++u) {
+                const int k = kt * 32 + u;
+                if (k < K)
+                    m = std::fmax(m, std::fabs(W[(size_t)n * ld + k]));
+            }
+        return m;
+    };
     for (int n = 0; n < n_rows; ++n) {
         const int rb = n >> 8, r = n & 255;
         for (int kt = 0; kt < KT; ++kt) {
             unsigned char* blk = out.data() + ((size_t)rb * KT + kt) * BLK;
             float          v[32], lo[32];
             _Float16       hi[32];
-            float          m = 0.f;
             for (int u = 0; u < 32; ++u) {
                 const int k = kt * 32 + u;
                 v[u]        = k < K ? W[(size_t)n * ld + k] : 0.f;
                 hi[u]       = (_Float16)v[u];
                 lo[u]       = v[u] - (float)hi[u];
-                m           = std::fmax(m, std::fabs(v[u]));
             }
-            const int ec = block_exponent(m);
+            const int ec = block_exponent(std::fmax(block_max(n, kt), block_max(n ^ 32, kt)));  // one exponent for rows n and n ^ 32
             unsigned  rec[2][4] = {{0, 0, 0, (unsigned)(ec - 2)}, {0, 0, 0, (unsigned)(ec - 2)}};
             for (int u = 0; u < 32; ++u) {
                 const int p = pos16(u), chunk = p >> 3, half = chunk & 1, f = 8 * (chunk >> 1) + (p & 7);  // field f of the half's record
@@ -203,7 +217,7 @@ __global__ __launch_bounds__(256) void neg_act_kernel(float* __restrict__ x, lon
 }
 
 // ---------------------------------------------------------------------------------------------- tile configurations
-template<int BN_, int BT_, int WN_, int WT_, int STAGES_, int PF_ = 0, int IW_ = 0, int U_ = 1, int LW_ = 0, int RP_ = 0>
+template<int BN_, int BT_, int WN_, int WT_, int STAGES_, int PF_ = 0, int IW_ = 0, int U_ = 1, int LW_ = 0>
 struct MxCfg {
     static constexpr int BN = BN_, BT = BT_, WN = WN_, WT = WT_, STAGES = STAGES_;
     // PF > 0 (256 x 256 tiles only): waves 0-5 touch the 384 cache lines of the K-tile PF steps ahead of the one whose LDS-DMA they
@@ -211,12 +225,6 @@ struct MxCfg {
     // HBM into L2.  The LDS ring holds two K-tiles in flight (~2 periods of 1.7 us); a K-tile whose lines miss L2 (23 % of the
     // requests, pmc/pmc_l2a.txt) arrives later than that and every wave ends its period waiting (tools/mx_timeline.py: 500-1600 of
     // 3500 cycles per K-tile in s_waitcnt vmcnt).
-    // RP: register pipelining.  The products of K-tile kt - 1 run in period kt, from the registers read in period kt - 1, and every
-    // fragment register is re-read from K-tile kt's stage right behind its last use: the matrix pipe starts at the barrier instead
-    // of behind an LDS round trip, with no register more than the plain order needs (tools/feed_probe.hip: 953 -> 851 ns per K-tile
-    // against 817 ns matrix-bound).  The ring and the order of the sums are unchanged.
-    static constexpr bool RP = RP_ != 0;
-    static_assert(RP_ == 0 || (U_ == 1 && LW_ == 0), "register pipelining: the one-K-tile-per-barrier loop");
     static constexpr int PF = PF_;
     // U: K-tiles per barrier.  Small-batch tiles (one 128 x 64 tile per CU, 6 + 3 matrix instructions per wave and K-tile) spend a
     // K-tile's period on the barrier and the LDS round trip, not on arithmetic: with U = 2 a wave reads two K-tiles into two
@@ -313,8 +321,20 @@ __device__ __forceinline__ void mx_wait_ahead(int ahead) {
     }
 }
 
-// q of a lane's 16 k from its two f16 fragments.  FIRST: the fields go to dwords 0-2 of the operand (the A side), else to dwords
-// 3-5 (the B side); the other half of the conversion's input is left undefined, its output is not used.
+// q of a lane's 16 k of TWO rows (n, n ^ 32: they share the block exponent) from their four f16 fragments in ONE conversion:
+// dwords 0-2 = the first row's fields, 3-5 = the second row's
+__device__ __forceinline__ u32x6 q_fields_pair(f16x8 c0, f16x8 c1, f16x8 d0, f16x8 d1, unsigned scale_byte) {
+    const f16x16 v = __builtin_shufflevector(c0, c1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+    const f16x16 u = __builtin_shufflevector(d0, d1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+    const f16x32 w = __builtin_shufflevector(v, u, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31);
+    u32x6        q;  // early-clobber result: see lane_pack
+    const float  scale = __uint_as_float(scale_byte << 23);
+    asm("v_cvt_scalef32_pk32_fp6_f16 %0, %1, %2\n\ts_nop 2" : "=&v"(q) : "v"(w), "v"(scale));
+    return q;
+}
+
+// q of a lane's 16 k from its two f16 fragments (a wave tile with ONE 32-row block on that side).  FIRST: the fields go to dwords 0-2
+// of the operand (the A side), else to dwords 3-5 (the B side); the other half of the conversion's input is left undefined.
 template<bool FIRST>
 __device__ __forceinline__ u32x6 q_fields(f16x8 c0, f16x8 c1, unsigned scale_byte) {
     const f16x16 v = __builtin_shufflevector(c0, c1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
@@ -543,15 +563,31 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const char* __restr
                 dma_kt = -1;
                 return;
             }
+            // q(w) = fp6(h(w) / 2^(Ew - 2)), q(x) = fp6(h(x) / 2^(Ex - 2)) (the x record holds Ex - 13).  Rows 32 i and 32 (i + 1) of
+            // the wave tile (i even) are a pair n, n ^ 32 with one exponent: one conversion for both
             v8i av[C::MI], bv[C::MJ];
+            if constexpr (C::MI % 2 == 0) {
 #pragma unroll
-            for (int i = 0; i < C::MI; ++i) {
-                u32x6 q;
-                if constexpr ((DBG & 128) != 0)
-                    q = u32x6{ra[i].y, ra[i].z, ra[i].x, 0, 0, 0};  // ablation: no conversion
-                else
-                    q = q_fields<true>(a[0][i], a[1][i], ra[i].w);  // q(w) = fp6(h(w) / 2^(Ew - 2))
-                av[i] = v8i{(int)q[0], (int)q[1], (int)q[2], (int)ra[i].x, (int)ra[i].y, (int)ra[i].z, 0, 0};
+                for (int i = 0; i < C::MI; i += 2) {
+                    u32x6 q;
+                    if constexpr ((DBG & 128) != 0)
+                        q = u32x6{ra[i].y, ra[i].z, ra[i].x, ra[i + 1].y, ra[i + 1].z, ra[i + 1].x};  // ablation: no conversion
+                    else
+                        q = q_fields_pair(a[0][i], a[1][i], a[0][i + 1], a[1][i + 1], ra[i].w);
+                    av[i]     = v8i{(int)q[0], (int)q[1], (int)q[2], (int)ra[i].x, (int)ra[i].y, (int)ra[i].z, 0, 0};
+                    av[i + 1] = v8i{(int)q[3], (int)q[4], (int)q[5], (int)ra[i + 1].x, (int)ra[i + 1].y, (int)ra[i + 1].z, 0, 0};
+                }
+            }
+            else {
+#pragma unroll
+                for (int i = 0; i < C::MI; ++i) {
+                    u32x6 q;
+                    if constexpr ((DBG & 128) != 0)
+                        q = u32x6{ra[i].y, ra[i].z, ra[i].x, 0, 0, 0};
+                    else
+                        q = q_fields<true>(a[0][i], a[1][i], ra[i].w);
+                    av[i] = v8i{(int)q[0], (int)q[1], (int)q[2], (int)ra[i].x, (int)ra[i].y, (int)ra[i].z, 0, 0};
+                }
             }
 #pragma unroll
             for (int j = 0; j < C::MJ; ++j) {
@@ -559,7 +595,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const char* __restr
                 if constexpr ((DBG & 128) != 0)
                     q = u32x6{0, 0, 0, rb[j].y, rb[j].z, rb[j].x};
                 else
-                    q = q_fields<false>(b[0][j], b[1][j], rb[j].w + 11u);  // q(x) = fp6(h(x) / 2^(Ex - 2)); the record holds Ex - 13
+                    q = q_fields<false>(b[0][j], b[1][j], rb[j].w + 11u);
                 bv[j] = v8i{(int)rb[j].x, (int)rb[j].y, (int)rb[j].z, (int)q[3], (int)q[4], (int)q[5], 0, 0};
             }
 #pragma unroll
@@ -578,54 +614,6 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const char* __restr
             if (dma_kt >= 0)
                 prefetch(dma_kt + C::PF);  // SPREAD variant: the refill's prefetch follows its last piece, as in stage()
             dma_kt = -1;
-        };
-        // RP: consume the register image F (K-tile ktn - 1) and refill it from K-tile ktn's stage, register by register
-        auto products_rp = [&](Frag& F, int ktn) {
-            auto& a  = F.a;
-            auto& b  = F.b;
-            auto& ra = F.ra;
-            auto& rb = F.rb;
-            const char* ab = lds + (ktn % C::STAGES) * C::STAGE_BYTES;
-            const char* bb = ab + C::A_BYTES;
-            // q fields first: they need both k-slabs of a fragment row, which are overwritten below
-            u32x6 qa[C::MI], qb[C::MJ];
-#pragma unroll
-            for (int i = 0; i < C::MI; ++i)
-                qa[i] = q_fields<true>(a[0][i], a[1][i], ra[i].w);
-#pragma unroll
-            for (int j = 0; j < C::MJ; ++j)
-                qb[j] = q_fields<false>(b[0][j], b[1][j], rb[j].w + 11u);
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int i = 0; i < C::MI; ++i)
-#pragma unroll
-                    for (int j = 0; j < C::MJ; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks][i], b[ks][j], acc[i][j], 0, 0, 0);
-                        if (j == C::MJ - 1)
-                            a[ks][i] = *(const f16x8*)(ab + h_off(a_row + 32 * i, 2 * ks + fk));
-                        if (i == C::MI - 1)
-                            b[ks][j] = *(const f16x8*)(bb + h_off(b_row + 32 * j, 2 * ks + fk));
-                    }
-            v8i av[C::MI], bv[C::MJ];
-            int sa[C::MI], sb[C::MJ];
-#pragma unroll
-            for (int i = 0; i < C::MI; ++i) {
-                av[i] = v8i{(int)qa[i][0], (int)qa[i][1], (int)qa[i][2], (int)ra[i].x, (int)ra[i].y, (int)ra[i].z, 0, 0};
-                sa[i] = (int)ra[i].w;
-                ra[i] = __builtin_bit_cast(uint4, *(const f16x8*)(ab + C::A_R + fk * (C::BN * 16) + (a_row + 32 * i) * 16));
-            }
-#pragma unroll
-            for (int j = 0; j < C::MJ; ++j) {
-                bv[j] = v8i{(int)rb[j].x, (int)rb[j].y, (int)rb[j].z, (int)qb[j][3], (int)qb[j][4], (int)qb[j][5], 0, 0};
-                sb[j] = (int)rb[j].w;
-                rb[j] = __builtin_bit_cast(uint4, *(const f16x8*)(bb + C::B_R + fk * (C::BT * 16) + (b_row + 32 * j) * 16));
-            }
-#pragma unroll
-            for (int i = 0; i < C::MI; ++i)
-#pragma unroll
-                for (int j = 0; j < C::MJ; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av[i], bv[j], acc[i][j], 2, 2, 0, sa[i], 0, sb[j]);
         };
         // Skewed wave groups (8-wave tiles; waves w and w + 4 share a SIMD): between two barriers the EARLY wave of a SIMD reads
         // K-tile kt into registers and then issues its products, the LATE wave first issues the products of K-tile kt - 1 -- read in
@@ -680,20 +668,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const char* __restr
         };
         // one code path for both groups -- early: sync(kt) reads(kt) products(kt); late: reads(kt) sync(kt + 1) products(kt), i.e. the
         // late wave's products of K-tile kt run in period kt + 1, in front of its reads of K-tile kt + 1.  Both execute KT barriers.
-        if constexpr (C::RP && (DBG == 0 || DBG == 2048)) {
-            sync(0);
-            reads(0, fr[0]);
-            refill(0);
-            for (int kt = 1; kt < KT; ++kt) {
-                sync(kt);      // stamp 0: barrier passed
-                refill(kt);    // stamp 1: refill issued
-                stamp(kt, 2);
-                products_rp(fr[0], kt);
-                stamp(kt, 3);  // products and re-reads issued
-            }
-            products(fr[0]);
-        }
-        else if constexpr (C::U > 1 || C::LW > 0) {
+        if constexpr (C::U > 1 || C::LW > 0) {
             static_assert(!C::SKEW && !C::SPREAD && C::PF == 0 && (C::IW == C::NW || C::LW > 0), "plain burst refill only");
             for (int kt = 0; kt < KT; kt += C::U) {
                 const int nk = min(C::U, KT - kt);

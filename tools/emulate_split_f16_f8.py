@@ -45,7 +45,18 @@ def minifloat(v, fmt, trunc=False):
     return np.sign(v) * np.minimum(q, vmax)
 
 
-def quant(v, fmt, scaling, trunc=False, tied_to=None, tie_offset=0):
+def pair_max(m):
+    """block maxima [rows, blocks, 1] -> the larger of rows r and r ^ 32 (the two 32-row blocks one lane of the GEMM serves): ONE
+    conversion instruction converts both rows' 16 values and takes one scale"""
+    r = m.shape[0]
+    pad = (-r) % 64
+    mp = np.pad(m, ((0, pad), (0, 0), (0, 0))) if pad else m
+    g = mp.reshape(-1, 2, 32, m.shape[1], 1)
+    g = np.maximum(g[:, 0], g[:, 1])
+    return np.repeat(g[:, None], 2, axis=1).reshape(mp.shape)[:r]
+
+
+def quant(v, fmt, scaling, trunc=False, tied_to=None, tie_offset=0, pair=False):
     """quantise v [rows, K] (f32) to fmt; scaling: 'tensor' = one power of two for the whole array (max -> top binade),
     'block' = OCP MX: per row and 32-element K block the shared exponent floor(log2 max) - emax(fmt).  Returns the dequantised
     values (f32: exactly what the scaled MFMA multiplies)."""
@@ -67,6 +78,8 @@ def quant(v, fmt, scaling, trunc=False, tied_to=None, tie_offset=0):
         m = np.abs(t64.reshape(r, -1, 32)).max(axis=2, keepdims=True) * np.exp2(tie_offset)
     else:
         m = np.abs(b).max(axis=2, keepdims=True)
+    if pair:
+        m = pair_max(m)
     s = np.exp2(np.floor(np.log2(np.where(m > 0, m, 1.0))) - emax)
     q = (minifloat(b / s, fmt, trunc) * s).reshape(r, -1)[:, :k]
     return q.astype(np.float32)
@@ -78,7 +91,7 @@ def e5m2_of_f16_top_byte(h16):
     return bits.view(np.float16).astype(np.float32)
 
 
-def split(v, hi_fmt, lo_fmt, scaling, tie_lo=False):
+def split(v, hi_fmt, lo_fmt, scaling, tie_lo=False, pair=False):
     """-> hi16 (f32 values), q_hi, q_lo"""
     h16 = v.astype(np.float16)
     hi = h16.astype(np.float32)
@@ -88,11 +101,11 @@ def split(v, hi_fmt, lo_fmt, scaling, tie_lo=False):
     elif hi_fmt is None:
         qh = None
     else:
-        qh = quant(hi, hi_fmt, scaling)
+        qh = quant(hi, hi_fmt, scaling, tied_to=v if pair else None, pair=pair)
     if lo_fmt is None:
         ql = None
     elif tie_lo:  # lo's block scale = hi's block scale 2^-11 (|lo| <= 2^-11 2^E: never saturates), no second maximum
-        ql = quant(lo, lo_fmt, "block", tied_to=v, tie_offset=-11)
+        ql = quant(lo, lo_fmt, "block", tied_to=v, tie_offset=-11, pair=pair)
     else:
         ql = quant(lo, lo_fmt, scaling)
     return hi, qh, ql
@@ -115,8 +128,8 @@ def forward(Ws, bs, acts, logp, x, scheme):
             xh = bf16_round(y); xl = bf16_round(y - xh)
             z = xh @ wh.T + (xh @ wl.T + xl @ wh.T)
         else:
-            wh, wqh, wql = split(W, scheme.get("hi"), scheme.get("lo"), scheme.get("w_scaling", "tensor"))
-            xh, xqh, xql = split(y, scheme.get("hi"), scheme.get("lo"), scheme.get("x_scaling", "block"), scheme.get("tie_lo", False))
+            wh, wqh, wql = split(W, scheme.get("hi"), scheme.get("lo"), scheme.get("w_scaling", "tensor"), scheme.get("tie_w", False), scheme.get("pair", False) or scheme.get("pair_w", False))
+            xh, xqh, xql = split(y, scheme.get("hi"), scheme.get("lo"), scheme.get("x_scaling", "block"), scheme.get("tie_lo", False), scheme.get("pair", False))
             z = xh @ wh.T
             if scheme["kind"] == "f16x":
                 z = z + (xqh @ wql.T + xql @ wqh.T)
@@ -177,6 +190,12 @@ def main():
         ("f16 + fp4 e2m1 x e2m1 cross terms, MX blocks both", dict(kind="f16x", hi="e2m1", lo="e2m1", w_scaling="block")),
         ("f16 + fp4 e2m1 x e2m1, MX blocks both, activation lo scale tied to the hi scale (2^-11): the scheme built as AMX_PREC_F16MX4",
          dict(kind="f16x", hi="e2m1", lo="e2m1", w_scaling="block", tie_lo=True)),
+        ("f16 + fp6 e2m3 x e2m3, block scales, residual scale tied to the block scale (2^-11) on both operands, an exponent per row and block",
+         dict(kind="f16x", hi="e2m3", lo="e2m3", w_scaling="block", tie_lo=True, tie_w=True)),
+        ("the same with ONE block exponent per pair of WEIGHT rows n, n ^ 32 (one conversion instruction serves both: 4 instead of 6 per K-tile): AMX_PREC_F16MX as built",
+         dict(kind="f16x", hi="e2m3", lo="e2m3", w_scaling="block", tie_lo=True, tie_w=True, pair_w=True)),
+        ("the same with frames t, t ^ 32 paired as well (3 conversions; not built: a frame's scores would depend on its batch)",
+         dict(kind="f16x", hi="e2m3", lo="e2m3", w_scaling="block", tie_lo=True, tie_w=True, pair=True)),
     ]
     out = []
     for name, sch in schemes:
