@@ -6,11 +6,12 @@
 // with OCP-MX block scales (one e8m0 exponent per 32 k and row: 2^(E-2) for q, E the exponent of the block maximum, and 2^-11 of
 // that for r -- |v - f16(v)| <= 2^-11 2^E, so r never saturates and needs no maximum of its own).  WEIGHT rows n and n ^ 32 share
 // their exponent (the maximum of the two blocks): a lane of the GEMM serves both (two 32-row blocks of its wave tile), the conversion
-// instruction converts 32 values under ONE scale, so one instruction yields q for both rows -- four conversions per K-tile and wave
-// (two for the weights, two for the frames) instead of six.  They cost: tools/cvt_rate.hip measures 28 ns per conversion and SIMD and
-// NO overlap with the matrix instructions (16 + 8 of them: 675 ns; with six conversions: 966 ns).  Frames keep an exponent of their
-// own: paired like the rows (measured: another 2 % of the layer) a frame's scores would depend on which frame shares its batch, and
-// scoring a segment in pieces would no longer give the bits of scoring it whole.  Because both cross terms carry
+// instruction converts 32 values under ONE scale, so one instruction yields q for both rows.  Frames keep an exponent of their own
+// (paired like the rows a frame's scores would depend on which frame shares its batch, and scoring a segment in pieces would no
+// longer give the bits of scoring it whole); there the lane's two frames trade k-halves with the partner lane instead
+// (v_permlane32_swap: a lane then holds all 32 k of ONE frame, see products()).  Three conversions per K-tile and wave of 128 x 64
+// instead of six; they cost: tools/cvt_rate.hip measures 28 ns per conversion and SIMD and NO overlap with the matrix instructions
+// (16 + 8 of them: 675 ns; with six conversions: 966 ns).  Because both cross terms carry
 // the same total scale 2^(Ew-2) 2^(Ex-13), ONE 64-deep scaled product does both for 16 k:
 //     A = [ q(w) (16 k) | r(w) (the same 16 k) ]   scale 2^(Ew-2)
 //     B = [ r(x)        | q(x)                 ]   scale 2^(Ex-13)
@@ -42,6 +43,8 @@ namespace amx {
 namespace mx {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x32 __attribute__((ext_vector_type(32)));
@@ -589,14 +592,49 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const char* __restr
                     av[i] = v8i{(int)q[0], (int)q[1], (int)q[2], (int)ra[i].x, (int)ra[i].y, (int)ra[i].z, 0, 0};
                 }
             }
+            // Frames keep an exponent each, and a lane holds HALF of a frame's 32 k (chunks fk and 2 + fk) for its two frames t and
+            // t + 32.  v_permlane32_swap trades the upper lanes' first frame for the lower lanes' second one: the lower lane then holds
+            // all four chunks of frame t, the upper lane those of frame t + 32 -- 32 values under one exponent, ONE conversion for the
+            // pair of blocks -- and three more swaps hand the fields of the other half back.  Same inputs, same scales, same fields as
+            // the two half-filled conversions: bit-identical.
+            if constexpr (C::MJ % 2 == 0 && (DBG & 128) == 0) {
 #pragma unroll
-            for (int j = 0; j < C::MJ; ++j) {
-                u32x6 q;
-                if constexpr ((DBG & 128) != 0)
-                    q = u32x6{0, 0, 0, rb[j].y, rb[j].z, rb[j].x};
-                else
-                    q = q_fields<false>(b[0][j], b[1][j], rb[j].w + 11u);
-                bv[j] = v8i{(int)rb[j].x, (int)rb[j].y, (int)rb[j].z, (int)q[3], (int)q[4], (int)q[5], 0, 0};
+                for (int j = 0; j < C::MJ; j += 2) {
+                    u32x4 x0[2], x1[2];
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        x0[ks] = __builtin_bit_cast(u32x4, b[ks][j]);
+                        x1[ks] = __builtin_bit_cast(u32x4, b[ks][j + 1]);
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) {
+                            const u32x2 sw = __builtin_amdgcn_permlane32_swap(x0[ks][d], x1[ks][d], false, false);
+                            x0[ks][d]      = sw[0];  // lanes 0-31: frame t chunk 2 ks;     lanes 32-63: frame t + 32 chunk 2 ks
+                            x1[ks][d]      = sw[1];  // lanes 0-31: frame t chunk 2 ks + 1; lanes 32-63: frame t + 32 chunk 2 ks + 1
+                        }
+                    }
+                    const unsigned sc = (fk ? rb[j + 1].w : rb[j].w) + 11u;
+                    u32x6          q  = q_fields_pair(__builtin_bit_cast(f16x8, x0[0]), __builtin_bit_cast(f16x8, x0[1]), __builtin_bit_cast(f16x8, x1[0]),
+                                                      __builtin_bit_cast(f16x8, x1[1]), sc);  // dwords 0-2: chunks 0, 2; 3-5: chunks 1, 3 of the lane's frame
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) {
+                        const u32x2 sw = __builtin_amdgcn_permlane32_swap(q[d], q[3 + d], false, false);
+                        q[d]           = sw[0];  // the lane's own half (chunks fk, 2 + fk) of frame t
+                        q[3 + d]       = sw[1];  // ... of frame t + 32
+                    }
+                    bv[j]     = v8i{(int)rb[j].x, (int)rb[j].y, (int)rb[j].z, (int)q[0], (int)q[1], (int)q[2], 0, 0};
+                    bv[j + 1] = v8i{(int)rb[j + 1].x, (int)rb[j + 1].y, (int)rb[j + 1].z, (int)q[3], (int)q[4], (int)q[5], 0, 0};
+                }
+            }
+            else {
+#pragma unroll
+                for (int j = 0; j < C::MJ; ++j) {
+                    u32x6 q;
+                    if constexpr ((DBG & 128) != 0)
+                        q = u32x6{0, 0, 0, rb[j].y, rb[j].z, rb[j].x};
+                    else
+                        q = q_fields<false>(b[0][j], b[1][j], rb[j].w + 11u);
+                    bv[j] = v8i{(int)rb[j].x, (int)rb[j].y, (int)rb[j].z, (int)q[3], (int)q[4], (int)q[5], 0, 0};
+                }
             }
 #pragma unroll
             for (int i = 0; i < C::MI; ++i)
