@@ -1417,6 +1417,7 @@ struct amx_ffnn {
     int    gemm_persistent = 1;
     int    gemm_cfg       = -1;  // -1 = automatic; index into the bf16 tile configurations (launch_bf16_cfg); tuning "tile"
     int    chunk          = 32768;  // frames per internal pass (tuning "chunk")
+    int    mx_stagger     = 0;   // 10 ns ticks per XCD of gemm_mx_kernel's staggered start (0 = off, the default; tuning "stagger")
     int    mx_dbg         = 0;   // lab builds: ablation variant of gemm_mx_kernel (tuning "mx_dbg")
     // AMX_PREC_F16MX: host-mapped word the kernels set when a value leaves the f16 range (sticky: every later call fails)
     unsigned* h_overflow = nullptr;
@@ -1613,13 +1614,16 @@ void launch_mx(amx_ffnn* h, int l, const void* x, int xkts, void* out, int ldo, 
     int       grid   = std::min(ntn * ntt, per_cu * std::max(h->ctx->n_cu, 8));
     if (grid >= 8)
         grid &= ~7;  // keep blockIdx % 8 == tile index % 8 for every stride step
+    // staggered XCDs (see the kernel): off by default -- 0 / 1 / 3 / 6 us per XCD measured within noise of one another
+    // (profiles/r04/stagger.log: output layer 2.085-2.111 ms in every setting)
+    const int stagger = (LAST && C::BN == 256 && ntn * ntt >= 8 * grid && h->mx_stagger > 0) ? h->mx_stagger : 0;
 #define AMX_MX_LAUNCH(DBG)                                                                                                                  \
     do {                                                                                                                                    \
         auto k = amx::mx::gemm_mx_kernel<C, ACT, LAST, DBG>;                                                                                \
         hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);                                         \
         hipLaunchKernelGGL(k, dim3(grid), dim3(C::THREADS), lds_bytes, h->ctx->stream, (const char*)h->d_W[l], (const char*)x, h->d_bias[l], \
                            out, h->Kpad[l] / 32, xkts, h->Npad[l] / 32, ldo, n_valid, T, ntn, ntn * ntt, gt, gn,                            \
-                           LAST ? h->cur_part_min : nullptr, LAST ? h->cur_part_idx : nullptr, Tpad, h->d_overflow);                        \
+                           LAST ? h->cur_part_min : nullptr, LAST ? h->cur_part_idx : nullptr, Tpad, h->d_overflow, stagger);               \
     } while (0)
     int dbg = 0;
 #ifdef AMX_LAB  // ablations of the large-batch kernel (tools/ab_mx.sh, profiles/r04/gemm_mx_ablation.log)
@@ -1815,7 +1819,7 @@ int amx_ffnn_create(amx_ctx* ctx, const amx_ffnn_model* m, amx_ffnn** out) {
 
     amx::Tuning tune;
     {
-        static const char* const keys[] = {"tile", "graph", "persistent", "group", "chunk", "mx_dbg", nullptr};
+        static const char* const keys[] = {"tile", "graph", "persistent", "group", "chunk", "stagger", "mx_dbg", nullptr};
         if (!tune.parse(m->tuning, keys, "amx_ffnn_create"))
             return AMX_ERR_INVALID;
     }
@@ -1829,6 +1833,7 @@ int amx_ffnn_create(amx_ctx* ctx, const amx_ffnn_model* m, amx_ffnn** out) {
     h->gemm_persistent = tune.get("persistent", 1);
     h->chunk           = std::max(256, tune.get("chunk", 32768));
     h->mx_dbg          = tune.get("mx_dbg", 0);
+    h->mx_stagger      = tune.get("stagger", 0);
     if (tune.has("group"))
         sscanf(tune.str("group", "").c_str(), "%dx%d", &h->group_t, &h->group_n);
     hipSetDevice(ctx->device);
@@ -2342,6 +2347,9 @@ int amx_ffnn_score(amx_ffnn* h, const float* feats_host, int T, float* scores_ho
 }  // extern "C"
 
 #ifdef AMX_LAB
+extern "C" int amx_lab_mx_tile_stamps(unsigned long long* out /* [4 tiles][3 phases][memtime, memrealtime] */) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(amx::mx::mx_tile_stamps), sizeof(amx::mx::mx_tile_stamps)) == hipSuccess ? AMX_OK : AMX_ERR_DEVICE;
+}
 extern "C" int amx_lab_mx_stamps(unsigned long long* out /* [8 * 48 * 4] */) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(amx::mx::mx_stamps), sizeof(amx::mx::mx_stamps)) == hipSuccess ? AMX_OK : AMX_ERR_DEVICE;
 }

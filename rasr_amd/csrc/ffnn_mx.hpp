@@ -298,6 +298,8 @@ __device__ __forceinline__ void piece_offsets(int p, int ha, int hb, int& src, i
 // lab builds (DBG 2048): s_memtime stamps of workgroup 0's first tile, [wave][K-tile < 48][phase]: 0 barrier passed, 1 refill issued,
 // 2 fragments in registers, 3 products issued; read back with amx_lab_mx_stamps (tools/mx_timeline.py)
 __device__ unsigned long long mx_stamps[8 * 48 * 4];
+// tile-level stamps of workgroup 0, wave 0: for its first four tiles {s_memtime, s_memrealtime} at tile start, K-loop end, tile end
+__device__ unsigned long long mx_tile_stamps[4 * 3 * 2];
 #endif
 
 // ablation builds: keep a register value alive without using it (plain __device__ functions: the host pass does not look at their asm;
@@ -362,7 +364,7 @@ template<class C, int ACT, bool LAST, int DBG = 0>
 __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const char* __restrict__ W, const char* __restrict__ X, const float* __restrict__ bias,
                                                             void* __restrict__ out, int KT, int xkts, int ktn, int ldo, int n_valid, int t_valid,
                                                             int n_tiles_n, int n_tiles_total, int GT, int GN, float* __restrict__ part_min,
-                                                            unsigned* __restrict__ part_idx, int part_ld, unsigned* __restrict__ overflow) {
+                                                            unsigned* __restrict__ part_idx, int part_ld, unsigned* __restrict__ overflow, int stagger) {
     extern __shared__ __attribute__((aligned(16))) char lds[];  // [STAGES][A: H | R][B: H | R] ... [bias]
     const int tid  = threadIdx.x;
     const int lane = tid & 63;
@@ -374,6 +376,16 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const char* __restr
     const bool    issuer  = iwave >= 0 && iwave < C::IW;
     const bool    hi_wave = C::NHI == 0 || iwave < C::NHI;          // issues PPW pieces per K-tile
 
+    // Staggered start (tuning "stagger" > 0, in 10 ns ticks per XCD; off by default).  All workgroups run tiles of the same length, so
+    // they reach their epilogues together: 64 MB of scores per round of tiles leave in one burst (tools/mx_timeline.py: 9-10 us of
+    // a 125 us tile).  XCD x starts x * stagger late, so the bursts of the eight XCDs would follow one another -- measured: no
+    // change at 1 / 3 / 6 us per XCD (profiles/r04/stagger.log); the non-temporal stores already drain behind the next tile's K loop.
+    if (stagger > 0) {
+        const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+        const unsigned long long ticks   = (unsigned long long)(blockIdx.x & 7) * (unsigned)stagger;
+        while (__builtin_amdgcn_s_memrealtime() - t_start < ticks)
+            __builtin_amdgcn_s_sleep(8);
+    }
     for (int vi = blockIdx.x; vi < n_tiles_total; vi += gridDim.x) {
         int tile_t, tile_n;
         {  // the XCD-aware order of gemm_bf16_kernel
@@ -398,6 +410,18 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const char* __restr
             tile_t = blockIdx.x & 7;
             tile_n = 0;
         }
+        auto tile_stamp = [&](int phase) {
+#ifdef AMX_LAB
+            if constexpr ((DBG & 2048) != 0) {
+                const int nth = (vi - (int)blockIdx.x) / (int)gridDim.x;
+                if (blockIdx.x == 0 && nth < 4 && tid == 0 && (!LAST || n_tiles_total > 1000)) {
+                    mx_tile_stamps[(nth * 3 + phase) * 2]     = __builtin_amdgcn_s_memtime();
+                    mx_tile_stamps[(nth * 3 + phase) * 2 + 1] = __builtin_amdgcn_s_memrealtime();
+                }
+            }
+#endif
+        };
+        tile_stamp(0);
         const int   n0 = tile_n * C::BN, t0 = tile_t * C::BT;
         const char* wblk = W + (size_t)(n0 >> 8) * KT * BLK;
         const char* xblk = X + (size_t)(t0 >> 8) * xkts * BLK;  // xkts >= KT: the producer padded its outputs to 256
@@ -776,6 +800,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const char* __restr
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if constexpr (C::PF > 0)
             asm volatile("" ::"v"(pf_reg));
+        tile_stamp(1);
 
         // the epilogue's lane-dependent addresses are derived from opaque copies of the lane / thread id: computed from `lane` they are
         // invariants of the tile loop, get hoisted in front of the K-loop and spilled there (the K-loop owns the register file) -- and a
@@ -821,6 +846,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const char* __restr
                 *overflow = 1u;
         }
         __syncthreads();  // LDS (stages / epilogue scratch / bias) is reused by the next tile
+        tile_stamp(2);
     }
 }
 

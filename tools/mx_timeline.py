@@ -49,3 +49,18 @@ for w in range(8):
     per = np.diff(st[w, lo:hi + 1, 0]).mean()
     print("%4d  %6.1f   %15.1f  %13.1f  %15.1f  %22.1f   %d" % (w, per, (a[:, 1] - a[:, 0]).mean(), (a[:, 2] - a[:, 1]).mean(),
                                                                (a[:, 3] - a[:, 2]).mean(), (nxt - a[:, 3]).mean(), st[w, lo, 0] - t0))
+
+# tile level (workgroup 0, thread 0): tile start -> K-loop end -> tile end, for the workgroup's first four tiles; s_memrealtime
+# (100 MHz) beside s_memtime gives the shader clock under this load
+tb = (C.c_ulonglong * 24)()
+L.amx_lab_mx_tile_stamps.restype = C.c_int
+if L.amx_lab_mx_tile_stamps(tb) == 0:
+    ts = np.frombuffer(tb, dtype=np.uint64).reshape(4, 3, 2).astype(np.int64)
+    if ts[0, 0, 0] > 0:
+        dc, dr = ts[-1, 2, 0] - ts[0, 0, 0], ts[-1, 2, 1] - ts[0, 0, 1]
+        ghz = dc / (dr * 10.0) if dr > 0 else float("nan")
+        print("tiles of workgroup 0: %d s_memtime ticks in %d s_memrealtime ticks of 10 ns -> %.3f ticks per ns" % (dc, dr, ghz))
+        print("tile   K-loop (prologue + %d K-tiles)   epilogue (+ the closing barrier)   gap to the next tile start      [us]" % (2048 // 32))
+        for i in range(4):
+            gap = (ts[i + 1, 0, 0] - ts[i, 2, 0]) / ghz / 1e3 if i < 3 else float("nan")
+            print("%4d   %10.2f %30.2f %34.2f" % (i, (ts[i, 1, 0] - ts[i, 0, 0]) / ghz / 1e3, (ts[i, 2, 0] - ts[i, 1, 0]) / ghz / 1e3, gap))
