@@ -74,6 +74,9 @@ def parse():
                          "one GPU (the line then also reports the streamed rate next to it), streamed for --gpus N > 1")
     ap.add_argument("--corpus-hours", type=float, default=100.0, help="size of the synthetic corpus all ranks share (config 5: 100 h)")
     ap.add_argument("--trained-frames-per-state", type=int, default=600, help="gmm-trained: training frames per state of the split-trained model")
+    ap.add_argument("--best-density", choices=["u8", "u32"], default="u32",
+                    help="element type of the GMM leg's best-density matrix [frames x 10000]: u32 (Mm::DensityInMixture as RASR declares it) or u8 "
+                         "(amx_gmm_score_stats_u8_dev: a quarter of the matrix's memory, the same time -- profiles/r04/gmm_store_ab.log)")
     ap.add_argument("--gmm-tuning", default=None, help='amx_gmm_model.tuning of every GMM scorer the workload builds, e.g. "screen=0" (A/B runs)')
     ap.add_argument("--nn-tuning", default=None, help='amx_ffnn_model.tuning, e.g. "tile=4" or "graph=0"')
     ap.add_argument("--mfcc-tuning", default=None, help='amx_mfcc_cfg.tuning, e.g. "fft=mfma" or "wgs=3"')
@@ -272,7 +275,7 @@ class StreamedIngest:
                     path="pinned host s16 -> hipMemcpyAsync (copy stream) -> 2 HBM slots -> amx_mfcc_run_plan_dev_s16 behind an event")
 
 
-def gmm_cart_roofline(ctx, sc, nk, n_mix, dim, frames):
+def gmm_cart_roofline(ctx, sc, nk, n_mix, dim, frames, best_bytes=4):
     """roofline entry of the screened private-density GMM scorer.
 
     Fused path (gmm_fused_kernel): `achieved` is the f32 arithmetic the kernel really issues for the reference's distance --
@@ -292,13 +295,15 @@ def gmm_cart_roofline(ctx, sc, nk, n_mix, dim, frames):
         t = ms_x * 1e-3
         per_launch = surv / float(n_x)
         ex = per_launch * 4.0 * dim
-        by = frames * (n_mix * 8.0 + dim * 4.0) + (n_mix + 15) // 16 * 78848.0
+        by = frames * (n_mix * (4.0 + best_bytes) + dim * 4.0) + (n_mix + 15) // 16 * 78848.0
         scr = 2.0 * 64 * ((n_mix + 15) // 16 * 256) * frames
         return dict(bound="valu", kernel="gmm_fused_kernel<%d> (f16 MFMA screen + exact f32/f64 evaluation of the survivors)" % dim,
                     note="VALU-issue-bound kernel priced against the f32 vector peak (157.3 TFLOP/s; unfused mul/add can "
                          "reach half of it). achieved = densities evaluated exactly (device counter) x 4 dim f32 operations / kernel time",
                     achieved=round(ex / t / 1e12, 2), peak=FP32_TFLOPS, unit="TFLOP/s", frac=round(ex / t / 1e12 / FP32_TFLOPS, 4),
-                    traffic=measured_traffic("pipeline", "gmm_fused_kernel", "Li%dE" % dim) if (n_mix == 10000 and frames == 63936) else None,
+                    traffic=measured_traffic("pipeline", "gmm_fused_kernel", "Li%dELi%d" % (dim, 2 if best_bytes == 1 else 1))
+                    if (n_mix == 10000 and frames == 63936) else None,
+                    best_density_bytes=best_bytes,
                     avg_launch_ms=round(ms_x, 4), pack_launch_ms=round(ms_p, 4), launches=n_x, flops_per_launch=ex,
                     survivors_per_mixture=round(surv / float(pairs), 4),
                     screen_mfma_tflops=round(scr / t / 1e12, 1), screen_mfma_frac=round(scr / t / 1e12 / MFMA_BF16_TFLOPS, 4),
@@ -457,7 +462,7 @@ class Pipeline(NnPipeline):
         super().__init__(ctx, args, rank)
         g = min(self.GCHUNK, self.F)
         self.gscores = torch.empty((g, self.M), dtype=torch.float32, device="cuda")
-        self.gbestd = torch.empty((g, self.M), dtype=torch.int32, device="cuda")
+        self.gbestd = torch.empty((g, self.M), dtype=torch.uint8 if args.best_density == "u8" else torch.int32, device="cuda")
         self.gstate = torch.empty((g,), dtype=torch.int32, device="cuda")
         self.gcounts = self.red.view("gcounts")
         self.gscore_sum = self.red.view("gscore_sum")
@@ -498,7 +503,7 @@ class Pipeline(NnPipeline):
 
     def roofline(self):
         nn = super().roofline()
-        gm = gmm_cart_roofline(self.ctx, self.gmm, self.nk, self.M, 40, min(self.GCHUNK, self.F))
+        gm = gmm_cart_roofline(self.ctx, self.gmm, self.nk, self.M, 40, min(self.GCHUNK, self.F), self.gbestd.element_size())
         if gm is None:
             return nn
         # "dominant kernel" = the one with the larger total time in the step: the GMM's exact stage or the output-layer GEMM
@@ -542,7 +547,7 @@ class GmmTrain:
         self.M = 10000
         g = min(self.CHUNK, self.F)
         self.scores = torch.empty((g, self.M), dtype=torch.float32, device="cuda")
-        self.bestd = torch.empty((g, self.M), dtype=torch.int32, device="cuda")
+        self.bestd = torch.empty((g, self.M), dtype=torch.uint8 if args.best_density == "u8" else torch.int32, device="cuda")
         self.state = torch.empty((g,), dtype=torch.int32, device="cuda")
         from rasr_amd.partition import EpochReduceBuffer
         self.red = EpochReduceBuffer([("acc", self.sc.accumulator_size(), "f64"), ("score_sum", 1, "f64"), ("counts", self.M, "count")], device="cuda")
@@ -570,7 +575,7 @@ class GmmTrain:
         self.red.all_reduce(comm=getattr(self, "comm", None))   # ONE collective: 8 * (sum K + n_mean * (1 + d) + n_cov * (1 + d)) bytes = 53.8 MB here (+ counts, score sum)
 
     def roofline(self):
-        return gmm_cart_roofline(self.ctx, self.sc, self.nk, self.M, 40, min(self.CHUNK, self.F))
+        return gmm_cart_roofline(self.ctx, self.sc, self.nk, self.M, 40, min(self.CHUNK, self.F), self.bestd.element_size())
 
     def stage_report(self):
         out = {"accumulator_bytes": int(self.acc.numel() * 8)}
@@ -1255,7 +1260,7 @@ def measure(ctx, job, args, world):
 
 
 WORKLOAD_NAMES = {
-    "pipeline": lambda a: "cfg5-shard: MFCC-40 -> {GMM 10000x16 diagonal-maximum -> Viterbi accumulators | ctx11 -> FFNN 440-6x2048-10000 "
+    "pipeline": lambda a: "cfg5-shard: MFCC-40 -> {GMM 10000x16 diagonal-maximum (scores f32 + best densities " + a.best_density + ", all states) -> Viterbi accumulators | ctx11 -> FFNN 440-6x2048-10000 "
                           "(%s MFMA) -> best-state counts}, every frame scored by both models; %d utterances x %.0f s per step and rank"
                           % (a.precision, a.utterances, a.utt_seconds),
     "nn-pipeline": lambda a: "cfg5-shard, NN leg only: MFCC-40 -> ctx11 -> FFNN 440-6x2048-10000 (%s MFMA) -> best-state counts; "

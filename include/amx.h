@@ -374,6 +374,16 @@ int amx_gmm_score_dev(amx_gmm* h, int mode, const float* feats_dev, int T, float
  * re-read.  best_density_dev and best_state_dev are nullable. */
 int amx_gmm_score_stats_dev(amx_gmm* h, const float* feats_dev, int T, float* scores_dev, uint32_t* best_density_dev,
                             uint32_t* best_state_dev, unsigned long long* state_counts_dev, double* score_sum_dev);
+/* The same pass with the best densities as ONE BYTE per (frame, mixture): best_density_dev [T x n_mix] bytes, required, the same
+ * index within the mixture (Mm::DensityInMixture, Mm/Types.hh:36, is u32 in RASR; no mixture of a real model comes near 255
+ * densities), 0xff where the u32 form writes 0xffffffff.  A quarter of the u32 matrix's MEMORY -- for a 10 000-state model 10 kB
+ * instead of 40 kB per frame, next to 40 kB of scores: 0.64 GB instead of 2.56 GB per 63 936-frame pass -- and no gain in TIME:
+ * the fused screened kernel writes it directly, but what the best densities cost that kernel (0.3 ms of 4.7) is the vector work of
+ * tracking them, not their bytes (tools/gmm_store_ab.py, profiles/r04/gmm_store_ab.log: 4.58-4.62 ms against 4.50-4.76 for u32,
+ * 4.22-4.30 without).  Every other path scores into a u32 workspace and narrows it.
+ * AMX_ERR_UNSUPPORTED for a model with a mixture of more than 255 densities. */
+int amx_gmm_score_stats_u8_dev(amx_gmm* h, const float* feats_dev, int T, float* scores_dev, uint8_t* best_density_dev,
+                               uint32_t* best_state_dev, unsigned long long* state_counts_dev, double* score_sum_dev);
 
 /* Viterbi training statistics of Mm::AbstractMixtureSetEstimator::accumulate (Mm/AbstractMixtureSetEstimator.cc:117-125,
  * Mm/GaussDensityEstimator.hh:152-208): frame t, aligned to mixture_dev[t], adds 1 to the weight of its best density
@@ -385,6 +395,9 @@ int amx_gmm_score_stats_dev(amx_gmm* h, const float* feats_dev, int T, float* sc
 long amx_gmm_accumulator_size(const amx_gmm* h);
 int  amx_gmm_accumulate_dev(amx_gmm* h, const float* feats_dev, int T, const uint32_t* mixture_dev,
                             const uint32_t* best_density_dev, int best_density_ld, double* acc_dev);
+/* the same statistics from the byte form of the best-density matrix (amx_gmm_score_stats_u8_dev) */
+int  amx_gmm_accumulate_u8_dev(amx_gmm* h, const float* feats_dev, int T, const uint32_t* mixture_dev,
+                               const uint8_t* best_density_dev, int best_density_ld, double* acc_dev);
 
 /* The same statistics as a binary "MIXSET" accumulator file, version 2 (Mm::MixtureSetEstimator::write / read,
  * src/Mm/AbstractMixtureSetEstimator.cc:404-508, src/Mm/VectorAccumulator.hh:80-100, src/Mm/MixtureEstimator.cc:140-170):

@@ -33,6 +33,11 @@ def _ptr(a):
     return a.data_ptr()
 
 
+def _is_bytes(a):
+    """a best-density matrix in its byte form (torch.uint8 tensor)"""
+    return a is not None and not isinstance(a, np.ndarray) and a.element_size() == 1
+
+
 def version():
     """amx_version(): library version, compiler, flags and the hash of the sources it was built from"""
     return _lib.lib().amx_version().decode()
@@ -441,9 +446,10 @@ class GmmFeatureScorer:
         _lib.check(self.L.amx_gmm_score_dev(self.h, self.mode, _ptr(feats_dev), T, _ptr(scores_dev), _ptr(best_dev)))
 
     def score_stats_dev(self, feats_dev, T, scores_dev, best_density, best_state, counts, score_sum):
-        """diagonal-maximum scores plus best state / per-state counts / sum of best scores (arg-min fused where possible)"""
-        _lib.check(self.L.amx_gmm_score_stats_dev(self.h, _ptr(feats_dev), T, _ptr(scores_dev), _ptr(best_density), _ptr(best_state),
-                                                  _ptr(counts), _ptr(score_sum)))
+        """diagonal-maximum scores plus best state / per-state counts / sum of best scores (arg-min fused where possible); a
+        one-byte best_density tensor (torch.uint8) selects the byte form of the matrix (amx_gmm_score_stats_u8_dev)"""
+        fn = self.L.amx_gmm_score_stats_u8_dev if _is_bytes(best_density) else self.L.amx_gmm_score_stats_dev
+        _lib.check(fn(self.h, _ptr(feats_dev), T, _ptr(scores_dev), _ptr(best_density), _ptr(best_state), _ptr(counts), _ptr(score_sum)))
 
     def simd_scaling(self):
         """quantisation scaling factor of the SIMD-diagonal-maximum scorer"""
@@ -485,9 +491,9 @@ class GmmFeatureScorer:
         return a
 
     def accumulate_dev(self, feats_dev, T, mixture_dev, best_density_dev, best_density_ld, acc_dev):
-        """Viterbi statistics (weights, sum x, sum x^2 in f64) into the flat accumulator acc_dev"""
-        _lib.check(self.L.amx_gmm_accumulate_dev(self.h, _ptr(feats_dev), T, _ptr(mixture_dev), _ptr(best_density_dev),
-                                                 best_density_ld, _ptr(acc_dev)))
+        """Viterbi statistics (weights, sum x, sum x^2 in f64) into the flat accumulator acc_dev; best_density_dev u32 or bytes"""
+        fn = self.L.amx_gmm_accumulate_u8_dev if _is_bytes(best_density_dev) else self.L.amx_gmm_accumulate_dev
+        _lib.check(fn(self.h, _ptr(feats_dev), T, _ptr(mixture_dev), _ptr(best_density_dev), best_density_ld, _ptr(acc_dev)))
 
 
     def accumulate_weighted_dev(self, mode, feats_dev, T, mixture_dev, weight_dev, best_density_dev, best_density_ld, acc_dev):

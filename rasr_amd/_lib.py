@@ -133,7 +133,9 @@ SIGNATURES = {
     "amx_gmm_score": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, _P]),
     "amx_gmm_score_dev": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, _P]),
     "amx_gmm_score_stats_dev": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P, _P]),
+    "amx_gmm_score_stats_u8_dev": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P, _P]),
     "amx_gmm_accumulator_size": (C.c_long, [_P]),
+    "amx_gmm_accumulate_u8_dev": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, _P]),
     "amx_gmm_accumulate_dev": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, _P]),
     "amx_gmm_accumulate_weighted_dev": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, _P, _P, C.c_int, _P]),
     "amx_gmm_estimate_cfg_default": (None, [C.POINTER(GmmEstimateCfg)]),

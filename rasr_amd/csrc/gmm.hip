@@ -239,12 +239,20 @@ __global__ __launch_bounds__(256) void gmm_batch_float_kernel(const float* __res
     }
 }
 
+// u32 best densities -> bytes (paths without a byte-writing kernel; 0xffffffff -> 0xff)
+__global__ __launch_bounds__(256) void best_narrow_kernel(const uint32_t* __restrict__ in, unsigned char* __restrict__ out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        out[i] = (unsigned char)min(in[i], 255u);
+}
+
 // ---- Viterbi training statistics (Mm/AbstractMixtureSetEstimator.cc:117-125): one wavefront per frame, lane = dim.
 // The density chosen for frame t is best_density[t][mixture[t]] (what amx_gmm_score_dev wrote).  Sums are f64 like
 // Mm::Sum; with a pooled covariance every frame hits the same row, so each wave first sums its frames in
 // registers and issues one atomic per dimension at the end.
+// best8 (nullable): the byte form of the best-density matrix (amx_gmm_score_stats_u8_dev; 0xff widens to the u32 form's 0xffffffff)
 __global__ __launch_bounds__(256) void gmm_accumulate_kernel(const float* __restrict__ feats, const uint32_t* __restrict__ mixture,
-                                                            const uint32_t* __restrict__ best, int best_ld, int T, int dim,
+                                                            const uint32_t* __restrict__ best, const unsigned char* __restrict__ best8,
+                                                            int best_ld, int T, int dim,
                                                             const uint32_t* __restrict__ mix_off, const uint32_t* __restrict__ k_dens,
                                                             const uint32_t* __restrict__ d_mean, const uint32_t* __restrict__ d_cov,
                                                             double* __restrict__ acc, long long off_mw, long long off_ms,
@@ -262,8 +270,14 @@ __global__ __launch_bounds__(256) void gmm_accumulate_kernel(const float* __rest
         uint32_t  k = 0xffffffffu, mi = 0, ci = 0;
         if (t < T) {
             const uint32_t m  = mixture[t];
-            const uint32_t kk = best_ld > 0 ? best[(size_t)t * best_ld + m] : best[t];
-            k                 = mix_off[m] + kk;
+            uint32_t       kk;
+            if (best8) {
+                const unsigned char b = best_ld > 0 ? best8[(size_t)t * best_ld + m] : best8[t];
+                kk                    = b == 0xffu ? 0xffffffffu : (uint32_t)b;
+            }
+            else
+                kk = best_ld > 0 ? best[(size_t)t * best_ld + m] : best[t];
+            k = mix_off[m] + kk;
             const uint32_t d  = k_dens[k];
             mi                = d_mean[d];
             ci                = d_cov[d];
@@ -1539,6 +1553,8 @@ struct amx_gmm {
                 tune_simd_mfma = 1;
     std::string tune_screen_kernel = "rows";
     void*     d_fus_rec = nullptr;   // tile records of gmm_fused_kernel (pooled covariance, dim <= 40)
+    uint32_t* d_best32   = nullptr;  // u32 workspace of amx_gmm_score_stats_u8_dev on paths without a byte-writing kernel
+    size_t    best32_cap = 0;
     unsigned long long* d_fus_surv = nullptr;  // [256] partial counts of the densities evaluated exactly (amx_gmm_screen_counts): one
                                                // address for every wave's atomicAdd cost a quarter of a 256-frame pass
     size_t    fus_rec_bytes = 0;
@@ -1596,13 +1612,16 @@ extern "C" int amx_internal_gmm_fused_create(int dim, int n_mix, int n_tiles, co
 extern "C" int amx_internal_gmm_fused_split(int n_cu, int Tpad, int n_tiles, int forced_waves);
 extern "C" int amx_internal_gmm_fused_score(amx_ctx* ctx, int dim, const void* rec_dev, const float* isr_dev, const float* feats, const void* X,
                                             const float* nx, const float* q, int T, int Tpad, int n_mix, int n_tiles, int split, float* scores,
-                                            uint32_t* best, float* pmin, unsigned* pidx, int part_ld, unsigned long long* survivors, int forced_waves);
+                                            uint32_t* best, float* pmin, unsigned* pidx, int part_ld, unsigned long long* survivors, int forced_waves,
+                                            int best_bytes);
+extern "C" int amx_internal_gmm_fused_waves(int Tpad, int forced_waves);
 
 // maximum approximation through the MFMA screen (see gmm_screen_kernel); frames in chunks that bound the mask workspace
 extern "C" int amx_internal_best_state_reduce(amx_ctx*, const float*, const unsigned*, int, int, int, uint32_t*, unsigned long long*, double*);
 
+// best_bytes = 1 (fused path only, see fused_bytes_ok): best_dev is a byte matrix [T x n_mix] (amx_gmm_score_stats_u8_dev)
 int score_screened(amx_gmm* h, const float* feats_dev, int T, float* scores_dev, uint32_t* best_dev, bool stats, uint32_t* best_state_dev,
-                   unsigned long long* counts_dev, double* score_sum_dev) {
+                   unsigned long long* counts_dev, double* score_sum_dev, int best_bytes = 4) {
     hipStream_t st = h->ctx->stream;
     const int   chunk = h->tune_chunk;  // frames per pass: the workspace (survivor masks, 2 B per frame and mixture slot) grows to what a call needs
     // one fused kernel (gmm_fused.hip) where its tile records exist; tuning fused=0 keeps the two-kernel path (A/B runs, tests)
@@ -1660,8 +1679,8 @@ int score_screened(amx_gmm* h, const float* feats_dev, int T, float* scores_dev,
                 amx::ScopedKernelTimer timer(h->ctx, "gmm");
                 int r = amx_internal_gmm_fused_score(h->ctx, h->dim, h->d_fus_rec, h->d_isr, x, h->d_scr_X, h->d_scr_nx, h->d_scr_q, Tc, Tpad,
                                                      h->n_mix, n_tiles, split, scores_dev + (size_t)t0 * h->n_mix,
-                                                     best_dev ? best_dev + (size_t)t0 * h->n_mix : nullptr, pmin, pidx, Tpad,
-                                                     h->count_survivors ? h->d_fus_surv : nullptr, h->tune_fused_waves);
+                                                     best_dev ? (uint32_t*)((char*)best_dev + (size_t)t0 * h->n_mix * best_bytes) : nullptr, pmin,
+                                                     pidx, Tpad, h->count_survivors ? h->d_fus_surv : nullptr, h->tune_fused_waves, best_bytes);
                 if (r != AMX_OK)
                     return r;
                 if (h->count_survivors)
@@ -2180,6 +2199,7 @@ void amx_gmm_destroy(amx_gmm* h) {
     hipFree(h->d_scr_A2);
     hipFree(h->d_fus_rec);
     hipFree(h->d_fus_surv);
+    hipFree(h->d_best32);
     hipFree(h->d_scr_c);
     hipFree(h->d_scr_na);
     hipFree(h->d_scr_cabs);
@@ -2638,6 +2658,47 @@ int amx_gmm_score_stats_dev(amx_gmm* h, const float* feats_dev, int T, float* sc
     return amx_stats_accumulate_dev(h->ctx, scores_dev, T, h->n_mix, best_state_dev, state_counts_dev, score_sum_dev);
 }
 
+// byte form of the best-density matrix: a quarter of the u32 form's memory, the same time (tools/gmm_store_ab.py: the kernel pays
+// for tracking the best density, not for its bytes).  The fused kernel writes it directly; every other path scores into a u32
+// workspace and narrows it.
+int amx_gmm_score_stats_u8_dev(amx_gmm* h, const float* feats_dev, int T, float* scores_dev, uint8_t* best_density_dev, uint32_t* best_state_dev,
+                               unsigned long long* state_counts_dev, double* score_sum_dev) {
+    AMX_REQUIRE(h, AMX_ERR_INVALID, "amx_gmm_score_stats_u8_dev: NULL handle");
+    AMX_REQUIRE(h->ctx, AMX_ERR_STATE, "amx_gmm_score_stats_u8_dev: host-only handle (created without a context)");
+    AMX_REQUIRE(state_counts_dev && score_sum_dev, AMX_ERR_INVALID, "amx_gmm_score_stats_u8_dev: NULL accumulator");
+    AMX_REQUIRE(T >= 0, AMX_ERR_INVALID, "amx_gmm_score_stats_u8_dev: negative frame count");
+    for (size_t m = 0; m + 1 < h->mix_off.size(); ++m)
+        AMX_REQUIRE(h->mix_off[m + 1] - h->mix_off[m] <= 255u, AMX_ERR_UNSUPPORTED,
+                    "amx_gmm_score_stats_u8_dev: mixture %zu has %u densities (a byte holds an index below 255)", m, h->mix_off[m + 1] - h->mix_off[m]);
+    if (T == 0)
+        return AMX_OK;
+    AMX_REQUIRE(feats_dev && scores_dev && best_density_dev, AMX_ERR_INVALID, "amx_gmm_score_stats_u8_dev: NULL buffer");
+    AMX_HIP(hipSetDevice(h->ctx->device));
+    const bool fused = !h->tied && h->screen && h->d_fus_rec && h->tune_fused && !h->tune_screen_all;
+    bool       direct = fused;
+    for (int t0 = 0; t0 < T && direct; t0 += h->tune_chunk) {  // every chunk of the pass on an 8- or 12-wave kernel
+        const int nw = amx_internal_gmm_fused_waves((std::min(h->tune_chunk, T - t0) + 255) / 256 * 256, h->tune_fused_waves);
+        direct       = nw == 8 || nw == 12;
+    }
+    if (direct)
+        return score_screened(h, feats_dev, T, scores_dev, (uint32_t*)best_density_dev, true, best_state_dev, state_counts_dev, score_sum_dev, 1);
+    const size_t need = (size_t)T * h->n_mix;
+    if (need > h->best32_cap) {
+        hipFree(h->d_best32);
+        h->d_best32   = nullptr;
+        h->best32_cap = 0;
+        AMX_HIP(hipMalloc((void**)&h->d_best32, need * 4));
+        h->best32_cap = need;
+    }
+    int r = amx_gmm_score_stats_dev(h, feats_dev, T, scores_dev, h->d_best32, best_state_dev, state_counts_dev, score_sum_dev);
+    if (r != AMX_OK)
+        return r;
+    hipLaunchKernelGGL(amx::best_narrow_kernel, dim3((unsigned)std::min<size_t>((need + 1023) / 1024, 65536)), dim3(256), 0, h->ctx->stream,
+                       h->d_best32, best_density_dev, need);
+    AMX_HIP(hipGetLastError());
+    return AMX_OK;
+}
+
 int amx_gmm_screen_counts(amx_gmm* h, int enable, unsigned long long* survivors, unsigned long long* pairs) {
     AMX_REQUIRE(h, AMX_ERR_INVALID, "amx_gmm_screen_counts: NULL handle");
     if (survivors)
@@ -2852,8 +2913,29 @@ int amx_gmm_accumulate_dev(amx_gmm* h, const float* feats_dev, int T, const uint
     const int              blocks = (T + 255) / 256;
     amx::ScopedKernelTimer timer(h->ctx, "gmm_accumulate");
     hipLaunchKernelGGL(amx::gmm_accumulate_kernel, dim3(blocks), dim3(256), 0, h->ctx->stream, feats_dev, mixture_dev, best_density_dev,
-                       best_density_ld, T, h->dim, h->d_mix_off, h->d_k_dens, h->d_d_mean, h->d_d_cov, acc_dev, off_mw, off_ms, off_cw,
-                       off_cs, pooled);
+                       (const unsigned char*)nullptr, best_density_ld, T, h->dim, h->d_mix_off, h->d_k_dens, h->d_d_mean, h->d_d_cov, acc_dev,
+                       off_mw, off_ms, off_cw, off_cs, pooled);
+    AMX_HIP(hipGetLastError());
+    return AMX_OK;
+}
+
+int amx_gmm_accumulate_u8_dev(amx_gmm* h, const float* feats_dev, int T, const uint32_t* mixture_dev, const uint8_t* best_density_dev,
+                              int best_density_ld, double* acc_dev) {
+    AMX_REQUIRE(h, AMX_ERR_INVALID, "amx_gmm_accumulate_u8_dev: NULL handle");
+    AMX_REQUIRE(h->ctx, AMX_ERR_STATE, "amx_gmm_accumulate_u8_dev: host-only handle (created without a context)");
+    AMX_REQUIRE(T >= 0 && (best_density_ld == 0 || best_density_ld >= h->n_mix), AMX_ERR_INVALID, "amx_gmm_accumulate_u8_dev: bad shape");
+    if (T == 0)
+        return AMX_OK;
+    AMX_REQUIRE(feats_dev && mixture_dev && best_density_dev && acc_dev, AMX_ERR_INVALID, "amx_gmm_accumulate_u8_dev: NULL buffer");
+    AMX_HIP(hipSetDevice(h->ctx->device));
+    const long long off_mw = (long long)h->nk, off_ms = off_mw + h->n_mean, off_cw = off_ms + (long long)h->n_mean * h->dim,
+                    off_cs = off_cw + h->n_cov;
+    const int              pooled = (h->n_cov == 1 && h->dim <= 256) ? 1 : 0;
+    const int              blocks = (T + 255) / 256;
+    amx::ScopedKernelTimer timer(h->ctx, "gmm_accumulate");
+    hipLaunchKernelGGL(amx::gmm_accumulate_kernel, dim3(blocks), dim3(256), 0, h->ctx->stream, feats_dev, mixture_dev, (const uint32_t*)nullptr,
+                       (const unsigned char*)best_density_dev, best_density_ld, T, h->dim, h->d_mix_off, h->d_k_dens, h->d_d_mean, h->d_d_cov,
+                       acc_dev, off_mw, off_ms, off_cw, off_cs, pooled);
     AMX_HIP(hipGetLastError());
     return AMX_OK;
 }

@@ -83,7 +83,10 @@ __device__ unsigned long long fused_stamps[16 * 64 * 6];
     } while (0)
 #endif
 
-template<int DIM, bool BEST, int NW>
+// BEST: 0 scores only | 1 best density as u32 [T x n_mix] | 2 as ONE BYTE per (frame, mixture) (g_best is then a byte matrix with
+// rows of n_mix bytes; 0xff where the u32 form writes 0xffffffff): a quarter of the index MEMORY, 10 MB instead of 40 per 1000 frames --
+// the same time (what BEST costs this kernel is the vector work of tracking the index, 0.3 ms of 4.7, not the bytes)
+template<int DIM, int BEST, int NW>
 __global__ __launch_bounds__(NW * 64) void gmm_fused_kernel(const float* __restrict__ g_feats, const _Float16* __restrict__ g_X,
                                                         const float* __restrict__ g_nx, const float* __restrict__ g_q,
                                                         const char* __restrict__ g_rec, const float* __restrict__ g_isr,
@@ -145,8 +148,9 @@ __global__ __launch_bounds__(NW * 64) void gmm_fused_kernel(const float* __restr
     const float nx = g_nx[tx], q = g_q[tx];
     const bool  all = !(nx < __builtin_inff());  // operand row did not fit f16: keep every slot
     // stores of 16 bytes need aligned rows; otherwise (and on the model's last, partial tile) scalar guarded stores
-    const bool wide_ok = (n_mix & 3) == 0 && ((uintptr_t)g_scores & 15) == 0 && (!BEST || ((uintptr_t)g_best & 15) == 0);
-    const bool counted = wide_ok && wave_live && NW < 16;  // (the 16-wave instantiation spills: scratch traffic breaks the count)  // this wave issues exactly (BEST ? 4 : 2) stores per full tile
+    const bool wide_ok = (n_mix & (BEST == 2 ? 7 : 3)) == 0 && ((uintptr_t)g_scores & 15) == 0 &&
+                         (!BEST || ((uintptr_t)g_best & (BEST == 2 ? 7 : 15)) == 0);
+    const bool counted = wide_ok && wave_live && NW < 16;  // (the 16-wave instantiation spills: scratch traffic breaks the count)  // this wave issues exactly (4 | 3 | 2 for BEST = 1 | 2 | 0) stores per full tile
     // The compiler's wait-count pass does not see the inline-asm waits of the loop: without a wait it can see, it would put its own
     // vmcnt(0) in front of the first use of x[] inside the loop -- and there that waits for the next tile's DMA and the stores.
     __builtin_amdgcn_s_waitcnt(0);
@@ -162,8 +166,10 @@ __global__ __launch_bounds__(NW * 64) void gmm_fused_kernel(const float* __restr
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // no DMA of its own in flight; its stores need no wait
         else if (r == r_begin || !counted)
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        else if (BEST)
+        else if (BEST == 1)
             asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        else if (BEST == 2)
+            asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
         else
             asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // everybody's pieces are there, and nobody reads the other stage any more
@@ -322,7 +328,7 @@ __global__ __launch_bounds__(NW * 64) void gmm_fused_kernel(const float* __restr
             const fus_u32x2 rs = __builtin_amdgcn_permlane32_swap(__float_as_uint(sc[j]), __float_as_uint(sc[4 + j]), false, false);
             so[2 * j]          = __uint_as_float(rs.x);
             so[2 * j + 1]      = __uint_as_float(rs.y);
-            if (BEST) {
+            if (BEST == 1) {
                 const unsigned  bj = (bvalid >> j) & 1u ? (bpack >> (4 * j)) & 15u : 0xffffffffu;
                 const unsigned  bk = (bvalid >> (4 + j)) & 1u ? (bpack >> (4 * (4 + j))) & 15u : 0xffffffffu;
                 const fus_u32x2 rb = __builtin_amdgcn_permlane32_swap(bj, bk, false, false);
@@ -330,18 +336,38 @@ __global__ __launch_bounds__(NW * 64) void gmm_fused_kernel(const float* __restr
                 bo[2 * j + 1]      = rb.y;
             }
         }
+        unsigned b8[2] = {0, 0};  // BEST == 2: the same eight indices as bytes, mixtures in order
+        if (BEST == 2) {
+            // 4-bit slots -> bytes (pairs 0..3 | 4..7), 0xff where no density was taken; ONE swap moves both words' halves
+            auto nib2byte = [](unsigned n) {
+                const unsigned x = (n | (n << 8)) & 0x00ff00ffu;
+                return (x | (x << 4)) & 0x0f0f0f0fu;
+            };
+            auto bit2byte = [](unsigned v) { return ((v | (v << 7) | (v << 14) | (v << 21)) & 0x01010101u) * 0xffu; };
+            const unsigned  wa = nib2byte(bpack & 0xffffu) | ~bit2byte(bvalid & 15u);
+            const unsigned  wb = nib2byte(bpack >> 16) | ~bit2byte((bvalid >> 4) & 15u);
+            const fus_u32x2 rb = __builtin_amdgcn_permlane32_swap(wa, wb, false, false);
+            b8[0]              = __builtin_amdgcn_perm(rb.y, rb.x, 0x05010400u);  // x0 y0 x1 y1
+            b8[1]              = __builtin_amdgcn_perm(rb.y, rb.x, 0x07030602u);  // x2 y2 x3 y3
+        }
         const int mb = m0 + fk * 8;
         if (live) {
             float*    gs = g_scores + (size_t)t * n_mix + mb;
-            uint32_t* gb = BEST ? g_best + (size_t)t * n_mix + mb : nullptr;
+            uint32_t* gb = BEST == 1 ? g_best + (size_t)t * n_mix + mb : nullptr;
+            unsigned char* gb8 = BEST == 2 ? (unsigned char*)g_best + (size_t)t * n_mix + mb : nullptr;
             if (wide_ok && m0 + 16 <= n_mix) {
                 typedef float    nt_f4 __attribute__((ext_vector_type(4)));
                 typedef unsigned nt_u4 __attribute__((ext_vector_type(4)));
                 __builtin_nontemporal_store(nt_f4{so[0], so[1], so[2], so[3]}, (nt_f4*)gs);
                 __builtin_nontemporal_store(nt_f4{so[4], so[5], so[6], so[7]}, (nt_f4*)(gs + 4));
-                if (BEST) {
+                if (BEST == 1) {
                     __builtin_nontemporal_store(nt_u4{bo[0], bo[1], bo[2], bo[3]}, (nt_u4*)gb);
                     __builtin_nontemporal_store(nt_u4{bo[4], bo[5], bo[6], bo[7]}, (nt_u4*)(gb + 4));
+                }
+                if (BEST == 2) {
+                    typedef unsigned nt_u2 __attribute__((ext_vector_type(2)));
+                    // (plain stores, left to the L2 to merge into lines, measured the same: 4.59-4.63 against 4.58-4.62 ms)
+                    __builtin_nontemporal_store(nt_u2{b8[0], b8[1]}, (nt_u2*)gb8);
                 }
             }
             else {
@@ -349,8 +375,10 @@ __global__ __launch_bounds__(NW * 64) void gmm_fused_kernel(const float* __restr
                 for (int e = 0; e < 8; ++e)
                     if (mb + e < n_mix) {
                         gs[e] = so[e];
-                        if (BEST)
+                        if (BEST == 1)
                             gb[e] = bo[e];
+                        if (BEST == 2)
+                            gb8[e] = (unsigned char)(b8[e >> 2] >> (8 * (e & 3)));
                     }
             }
         }
@@ -795,6 +823,11 @@ static int fused_split_raw(int n_cu, int Tpad, int n_tiles, int forced) {
     return std::max(1, std::min(split, n_tiles));
 }
 
+// waves per workgroup the pass will run with (the byte-sized best-density output exists for 8 and 12)
+extern "C" int amx_internal_gmm_fused_waves(int Tpad, int forced_waves) {
+    return fused_waves(Tpad, forced_waves);
+}
+
 extern "C" int amx_internal_gmm_fused_split(int n_cu, int Tpad, int n_tiles, int forced_waves) {
     // every range holds ceil(n_tiles / split) tiles: report the number of NON-EMPTY ranges, the partial arg-min arrays have
     // exactly that many rows (an empty range would leave its row unwritten)
@@ -806,7 +839,7 @@ extern "C" int amx_internal_gmm_fused_split(int n_cu, int Tpad, int n_tiles, int
 extern "C" int amx_internal_gmm_fused_score(amx_ctx* ctx, int dim, const void* rec_dev, const float* isr_dev, const float* feats,
                                             const void* X, const float* nx, const float* q, int T, int Tpad, int n_mix, int n_tiles,
                                             int split, float* scores, uint32_t* best, float* pmin, unsigned* pidx, int part_ld,
-                                            unsigned long long* survivors, int forced_waves) {
+                                            unsigned long long* survivors, int forced_waves, int best_bytes) {
     const int   nw = fused_waves(Tpad, forced_waves), fpw = fused_frames(Tpad, forced_waves), ntt = (Tpad + fpw - 1) / fpw;
     const int   lds = 2 * amx::fused_rec_bytes(dim);
     const char* rec = (const char*)rec_dev;
@@ -829,12 +862,18 @@ extern "C" int amx_internal_gmm_fused_score(amx_ctx* ctx, int dim, const void* r
     case D: {                                                                                                                   \
         if (nw == 13 && best) AMX_FUSED_SPEC(D, true, 8)                                                                        \
         else if (nw == 13) AMX_FUSED_SPEC(D, false, 8)                                                                          \
-        else if (best && nw == 16) AMX_FUSED_LAUNCH(D, true, 16)                                                                     \
-        else if (best && nw == 12) AMX_FUSED_LAUNCH(D, true, 12)                                                                \
-        else if (best) AMX_FUSED_LAUNCH(D, true, 8)                                                                             \
-        else if (nw == 12) AMX_FUSED_LAUNCH(D, false, 12)                                                                       \
-        else AMX_FUSED_LAUNCH(D, false, 8)                                                                                      \
+        else if (best && nw == 16) AMX_FUSED_LAUNCH(D, 1, 16)                                                                   \
+        else if (best && nw == 12 && best_bytes == 1) AMX_FUSED_LAUNCH(D, 2, 12)                                                \
+        else if (best && best_bytes == 1) AMX_FUSED_LAUNCH(D, 2, 8)                                                             \
+        else if (best && nw == 12) AMX_FUSED_LAUNCH(D, 1, 12)                                                                   \
+        else if (best) AMX_FUSED_LAUNCH(D, 1, 8)                                                                                \
+        else if (nw == 12) AMX_FUSED_LAUNCH(D, 0, 12)                                                                           \
+        else AMX_FUSED_LAUNCH(D, 0, 8)                                                                                          \
     } break;
+    if (best && best_bytes == 1 && nw != 8 && nw != 12) {
+        amx::set_error("gmm fused scorer: byte-sized best densities exist for the 8- and 12-wave kernels only (fused_waves=%d)", nw);
+        return AMX_ERR_UNSUPPORTED;
+    }
     switch (dim) {
         AMX_FUSED(16)
         AMX_FUSED(24)

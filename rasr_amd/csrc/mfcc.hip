@@ -99,11 +99,64 @@ __host__ __device__ constexpr int zpad(int i) { return i ^ (5 * ((i >> 4) & 3));
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
+// ---- radix-16 form of the 256-point complex transform (VAR & 16; amx_mfcc_cfg.tuning fft=r16).  A wave works on FOUR frames at once:
+// lane = 16 q + m holds 16 complex points of frame q in registers, so a 16-point DFT is register arithmetic (two levels of radix-4
+// butterflies, constants W16^j) and the whole transform is  DFT-16 over n1 | twiddle W256^(n2 k1) | ONE transposition through LDS |
+// DFT-16 over n2  (n = 16 n1 + n2, k = k1 + 16 k2) -- two LDS round trips per frame (transposition, natural order for the real
+// split) instead of the Stockham form's five, and a tile's chain of dependent LDS round trips is walked once per wave, not once per
+// frame.  Work buffer of a frame: 16 rows of 18 complex (row stride 144 B: sixteen lanes' ds_read_b128 of 16 different rows touch
+// 16 different bank groups) + 16 complex of skew between frames (neighbouring frames' rows start 32 banks apart).
+// MEASURED (config 2, 993 k frames, profiles/r04/mfcc_r16_ab.log, mfcc_r16_timeline.log): parity-green (tests/test_mfcc_gpu.py) and
+// SLOWER, 1.04 ms against 0.76 ms for the Stockham stages.  One 2.4 KB work buffer per frame in flight puts a workgroup at 72 KB of
+// LDS: two workgroups per CU, two waves per SIMD -- and a lone wave issues one vector instruction per four cycles, so ~1000 vector
+// instructions of a batch are >= 2 us whatever their dependences (batch 5.7 us: samples 1.5, two DFT-16 0.9, transposition 0.75,
+// split + next fetch 2.6), while the mel filter bank and the DCT behind the workgroup barriers (7000-8000 ticks of a 17 800-tick
+// tile) find one other workgroup to overlap with instead of three.  History of the batch: 1.22 ms (sample loads inside uniform
+// branches: sixteen serial memory round trips) -> 1.10 (branch-free loads) -> 1.01 (split operands read before the amplitude
+// stores) -> 1.04-1.05 with the next tile's samples fetched ahead (no gain: the wait was not the memory's).  mfcc.flow only.  Kept
+// as tuning fft=r16 (round-3 review item 7, second form).
+constexpr int kR16Row = 18, kR16Frame = 16 * kR16Row + 16;
+
+__device__ __forceinline__ void r16_dft4(float2& x0, float2& x1, float2& x2, float2& x3) {  // y_d = sum_b x_b (+i)^(b d), in place
+    const float2 a = make_float2(x0.x + x2.x, x0.y + x2.y), b = make_float2(x0.x - x2.x, x0.y - x2.y);
+    const float2 c = make_float2(x1.x + x3.x, x1.y + x3.y), d = make_float2(x1.x - x3.x, x1.y - x3.y);
+    x0 = make_float2(a.x + c.x, a.y + c.y);
+    x1 = make_float2(b.x - d.y, b.y + d.x);
+    x2 = make_float2(a.x - c.x, a.y - c.y);
+    x3 = make_float2(b.x + d.y, b.y - d.x);
+}
+// position of output index k = c + 4 d of r16_dft16 in its register array
+__host__ __device__ constexpr int r16_reg(int k) { return 4 * (k & 3) + (k >> 2); }
+// 16-point DFT with W16 = e^{+2 pi i / 16}, in place: input z[n], n = 4 a + b; output index k = c + 4 d at z[r16_reg(k)] = z[4 c + d]
+__device__ __forceinline__ void r16_dft16(float2 (&z)[16]) {
+    constexpr float C1 = 0.92387953251128673848f, S1 = 0.38268343236508978178f, R = 0.70710678118654752440f;
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+        r16_dft4(z[b], z[4 + b], z[8 + b], z[12 + b]);  // z[4 c + b] = T[b][c] = sum_a z[4 a + b] W4^(a c)
+    // T[b][c] *= W16^(b c)
+    auto mul = [](float2& v, float wr, float wi) { v = make_float2(fmaf(v.x, wr, -(v.y * wi)), fmaf(v.x, wi, v.y * wr)); };
+    auto mulr = [&](float2& v) { v = make_float2(R * (v.x - v.y), R * (v.x + v.y)); };    // W16^2 = (R, R)
+    auto muli = [](float2& v) { v = make_float2(-v.y, v.x); };                            // W16^4 = i
+    auto mulm = [&](float2& v) { v = make_float2(-R * (v.x + v.y), R * (v.x - v.y)); };   // W16^6 = (-R, R)
+    mul(z[4 * 1 + 1], C1, S1);    // b = 1, c = 1: W^1
+    mulr(z[4 * 2 + 1]);           // b = 1, c = 2: W^2
+    mul(z[4 * 3 + 1], S1, C1);    // b = 1, c = 3: W^3
+    mulr(z[4 * 1 + 2]);           // b = 2, c = 1: W^2
+    muli(z[4 * 2 + 2]);           // b = 2, c = 2: W^4
+    mulm(z[4 * 3 + 2]);           // b = 2, c = 3: W^6
+    mul(z[4 * 1 + 3], S1, C1);    // b = 3, c = 1: W^3
+    mulm(z[4 * 2 + 3]);           // b = 3, c = 2: W^6
+    mul(z[4 * 3 + 3], -C1, -S1);  // b = 3, c = 3: W^9
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        r16_dft4(z[4 * c], z[4 * c + 1], z[4 * c + 2], z[4 * c + 3]);  // z[4 c + d] = sum_b T[b][c] W4^(b d) = D[c + 4 d]
+}
+
 // LDS carve-up shared by the kernel and the host-side size computation (all sizes in floats)
 struct MfccLds {
     int y, amp, lm, dct, fw, fidx, fft, total;
     int y_len, amp_ld, lm_ld, dct_ld, kpad;
-    __host__ __device__ MfccLds(int frame_len, int frame_shift, int fft_len, int n_filters, int n_ceps, int n_weights) {
+    __host__ __device__ MfccLds(int frame_len, int frame_shift, int fft_len, int n_filters, int n_ceps, int n_weights, bool r16 = false) {
         auto r4 = [](int v) { return (v + 3) & ~3; };
         y_len   = (FT - 1) * frame_shift + (fft_len > frame_len ? fft_len : frame_len);  // zero-pad region of the last frame included
         amp_ld  = fft_len / 2 + 1;                                                       // 2^k + 1: odd, conflict-free across frames
@@ -117,7 +170,8 @@ struct MfccLds {
         fw      = dct + r4(kpad * dct_ld);
         fidx    = fw + r4(n_weights);
         fft     = fidx + r4(3 * n_filters);
-        total   = fft + mfcc_waves(fft_len / 2) * 2 * (zpad(fft_len / 2) + 4);  // per wave: padded NC float2
+        total   = fft + (r16 ? FT * 2 * kR16Frame + 256 + 512                         // radix-16 form: one work buffer per FRAME of the tile + 128 split twiddles + 256 window pairs
+                             : mfcc_waves(fft_len / 2) * 2 * (zpad(fft_len / 2) + 4));  // per wave: padded NC float2
     }
 };
 
@@ -148,6 +202,13 @@ __device__ __noinline__ float power_node(float v, float power) {
 // lab builds: s_memtime stamps of workgroup 0, [wave < 4][tile < 32][7]: tile start, phase B done, barrier passed, phase C done,
 // barrier passed, phase D done, last barrier passed; amx_lab_mfcc_stamps (tools/mfcc_timeline.py)
 __device__ unsigned long long mfcc_stamps[4 * 32 * 8];
+// radix-16 phase B of the same workgroup: samples in registers, first DFT + twiddle, transposed row read, second DFT, split done
+__device__ unsigned long long mfcc_r16_stamps[4 * 32 * 8];
+#define MFCC_R16_STAMP(k)                                                                                      \
+    do {                                                                                                       \
+        if (blockIdx.x == 0 && lane == 0 && wave < 4 && lab_tile < 32)                                         \
+            mfcc_r16_stamps[(wave * 32 + lab_tile) * 8 + (k)] = __builtin_amdgcn_s_memtime();                  \
+    } while (0)
 #define MFCC_STAMP(k)                                                                                          \
     do {                                                                                                       \
         if (blockIdx.x == 0 && lane == 0 && wave < 4 && lab_tile < 32)                                         \
@@ -157,12 +218,16 @@ __device__ unsigned long long mfcc_stamps[4 * 32 * 8];
 #define MFCC_STAMP(k) \
     do {              \
     } while (0)
+#define MFCC_R16_STAMP(k) \
+    do {                  \
+    } while (0)
 #endif
 
 template<int NC, int VAR>
-__global__ __launch_bounds__(mfcc_waves(NC) * 64, (NC >= 1024 ? 1 : ((VAR & 8) != 0 ? 3 : 4))) void mfcc_kernel(MfccParams p) {
+__global__ __launch_bounds__(mfcc_waves(NC) * 64, (NC >= 1024 ? 1 : ((VAR & 16) != 0 ? 2 : (VAR & 8) != 0 ? 3 : 4))) void mfcc_kernel(MfccParams p) {
     using P = FftPlan<NC>;
-    constexpr bool MF  = (VAR & 1) != 0 && NC == 256;
+    constexpr bool R16 = (VAR & 16) != 0 && NC == 256;  // radix-16 register butterflies, four frames per wave (see r16_dft16)
+    constexpr bool MF  = (VAR & 1) != 0 && NC == 256 && !R16;
     constexpr bool S16 = (VAR & 2) != 0;
     constexpr bool PF  = (VAR & 4) != 0 && NC == 256;
     using Sample       = typename std::conditional<S16, short, float>::type;
@@ -172,7 +237,7 @@ __global__ __launch_bounds__(mfcc_waves(NC) * 64, (NC >= 1024 ? 1 : ((VAR & 8) !
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform for the compiler: frame base, segment tests and LDS rows become scalar work
 
-    const MfccLds  L(p.frame_len, p.frame_shift, 2 * NC, p.n_filters, p.n_ceps, p.n_weights);
+    const MfccLds  L(p.frame_len, p.frame_shift, 2 * NC, p.n_filters, p.n_ceps, p.n_weights, R16);
     float*  s_amp = smem + L.amp;   // [FT][amp_ld] amplitude spectra
     float*  s_lm  = smem + L.lm;    // [FT][lm_ld]  log10 mel energies (columns >= n_filters are 0)
     float*  s_dct = smem + L.dct;   // [kpad][dct_ld] DCT matrix, transposed and zero padded
@@ -197,6 +262,8 @@ __global__ __launch_bounds__(mfcc_waves(NC) * 64, (NC >= 1024 ? 1 : ((VAR & 8) !
     }
     for (int i = tid; i < FT * L.lm_ld; i += MT)
         s_lm[i] = 0.f;
+    if constexpr (R16)
+        __syncthreads();  // phase B of the first tile reads the window and split-twiddle tables
 
     // ---- per-lane constants: window coefficients of this lane's samples and FFT twiddles
     // complex point c = lane + 64*b + r*(NC/4) holds samples 2c, 2c+1 of the zero-padded frame
@@ -252,11 +319,73 @@ __global__ __launch_bounds__(mfcc_waves(NC) * 64, (NC >= 1024 ? 1 : ((VAR & 8) !
             gr[r] = g.x, gi[r] = g.y, gs[r] = g.x + g.y;
         }
     }
+    // radix-16 form: lane = 16 q + m; window pairs of its points c = 16 n1 + m, W256^(m k1) in r16_dft16's output order, split
+    // twiddles of its bin pairs i = m + 16 j
+    [[maybe_unused]] float2 r_tw[16];
+    [[maybe_unused]] float2* s_stw  = (float2*)(smem + L.fft + FT * 2 * kR16Frame);  // split twiddles of bins 0..127 (radix-16 form; registers are short there)
+    [[maybe_unused]] float2* s_win2 = s_stw + 128;                                   // window values of the samples (2c, 2c + 1) of point c, zero behind the window
+    if constexpr (R16) {
+        const int m = lane & 15;
+        for (int i = tid; i < 128; i += MT)
+            s_stw[i] = p.stw[i];
+        for (int c = tid; c < 256; c += MT)
+            s_win2[c] = make_float2(2 * c < p.frame_len ? p.window[2 * c] : 0.f, 2 * c + 1 < p.frame_len ? p.window[2 * c + 1] : 0.f);
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            r_tw[r] = p.tw[(m * ((r >> 2) + 4 * (r & 3))) & 255];
+    }
     const float scale   = p.fft_scale;
     const bool  doscale = p.apply_scale != 0;
     const float alpha   = p.alpha;
     const bool  alpha1  = (alpha == 1.0f);
 
+  // radix-16 form: the samples of this wave's four frames of the workgroup's NEXT tile, fetched at the end of phase B so that their
+  // memory round trip (1.9 us with two waves per SIMD and nothing else to issue, tools/mfcc_timeline.py) runs under phases C and D
+  // Two registers per point: sample 2c - 1 is the neighbour lane's 2c + 1 (lane m - 1 of the same n1, or lane 15 of n1 - 1), taken by
+  // two DPP moves when the batch is transformed; pfp = the sample in front of the frame (lane m = 0 of n1 = 0).
+  [[maybe_unused]] float pf0[16], pf1[16], pfp = 0.f;
+  [[maybe_unused]] bool  pf_have = false;  // wave-uniform
+  // all 32 + 1 loads of a batch without a branch between them (a load inside a conditional block is waited for at the block's end:
+  // sixteen serial memory round trips, 3.4 us of a batch's 6, tools/mfcc_timeline.py); a point behind the window reads sample 1.
+  // Batches whose frames all lie inside their segment with a predecessor sample (wave-uniform test) load without guards; the
+  // others clamp every index into the segment and zero what lies behind it (pf_guard: the transform masks those points).
+  [[maybe_unused]] int  pf_nvalid = 0;      // samples of the segment from this lane's frame start on (clamped to 2^30)
+  [[maybe_unused]] bool pf_guard  = false;  // wave-uniform
+  [[maybe_unused]] auto fetch_batch = [&](const MfccTile& nt) -> bool {
+      if (wave * 4 >= nt.n_frames)
+          return false;
+      const int       m  = lane & 15, fq = wave * 4 + (lane >> 4);
+      const int       fl = fq < nt.n_frames ? fq : nt.n_frames - 1;
+      const long long fb = (long long)(nt.frame0 + fl) * p.frame_shift;
+      const long long nv = (long long)nt.n_samples - fb;
+      pf_nvalid          = (int)(nv < (1ll << 30) ? nv : (1ll << 30));
+      pf_guard           = !__all(fb >= 1 && fb + p.frame_len < (long long)nt.n_samples);
+      const Sample* fr   = (const Sample*)p.pcm + nt.sample_base + fb;
+      if (!pf_guard) {
+#pragma unroll
+          for (int n1 = 0; n1 < 16; ++n1) {
+              const int   c  = 16 * n1 + m;
+              const bool  w  = 2 * c < p.frame_len;
+              const int   o  = w ? 2 * c : 1;
+              pf0[n1]        = (float)fr[o];  // RAW values: a select here would wait for the load (the window mask is applied by the consumer)
+              pf1[n1]        = (float)fr[o + 1];
+          }
+          pfp = (float)fr[-1];
+      }
+      else {
+          const int last = pf_nvalid - 1;  // >= 0: a frame starts inside its segment
+#pragma unroll
+          for (int n1 = 0; n1 < 16; ++n1) {
+              const int   c  = 16 * n1 + m;
+              const bool  w  = 2 * c < p.frame_len;
+              const int   o  = w ? 2 * c : 1;
+              pf0[n1]        = (float)fr[o < last ? o : last];  // behind the segment: some sample of it, masked out by the consumer
+              pf1[n1]        = (float)fr[o + 1 < last ? o + 1 : last];
+          }
+          pfp = fb >= 1 ? (float)fr[-1] : (float)fr[0];  // segment start: previous_ = x[0] (Signal/Preemphasis.cc)
+      }
+      return true;
+  };
   [[maybe_unused]] int lab_tile = -1;
   for (int tile_id = blockIdx.x; tile_id < p.n_tiles; tile_id += gridDim.x) {
     const MfccTile tile = p.tiles[tile_id];
@@ -270,6 +399,142 @@ __global__ __launch_bounds__(mfcc_waves(NC) * 64, (NC >= 1024 ? 1 : ((VAR & 8) !
     const Sample*   seg   = (const Sample*)p.pcm + tile.sample_base;
     const long long nseg  = tile.n_samples;
     // ================= phase B: one frame per wavefront: FFT -> split -> |X| into s_amp[f][*]
+    if constexpr (R16) {
+      // ================= phase B, radix-16 form: wave w transforms frames 4 w .. 4 w + 3 of the tile together
+      if (wave * 4 < tile.n_frames) {  // wave-uniform
+        const int  q = lane >> 4, m = lane & 15;
+        const int  f = wave * 4 + q;
+        const bool live = f < tile.n_frames;
+        const int  fl = live ? f : tile.n_frames - 1;  // a lane group behind the tile's last frame repeats it (nothing written)
+        const long long fbase = (long long)(tile.frame0 + fl) * p.frame_shift;
+        float2 z[16];
+        if (!pf_have)  // first tile of the workgroup
+            fetch_batch(tile);
+        const bool guard  = pf_guard;
+        const int  nvalid = pf_nvalid;
+#pragma unroll
+        for (int n1 = 0; n1 < 16; ++n1) {
+            // predecessor sample: lane 0 of a row takes lane 15 of the previous point's odd sample (row_ror:1), the other lanes
+            // their left neighbour's odd sample of this point (row_shr:1 keeps `old` in lane 0)
+            const bool  w    = 2 * (16 * n1 + m) < p.frame_len;
+            const int   wrap = n1 > 0 ? __builtin_amdgcn_update_dpp(0, __float_as_int(pf1[n1 > 0 ? n1 - 1 : 0]), 0x121, 0xf, 0xf, false)
+                                      : __float_as_int(pfp);
+            const float xm   = w ? __int_as_float(__builtin_amdgcn_update_dpp(wrap, __float_as_int(pf1[n1]), 0x111, 0xf, 0xf, false)) : 0.f;
+            const float x0v  = w ? pf0[n1] : 0.f;
+            const float x1v  = w ? pf1[n1] : 0.f;
+            float       y0, y1;
+            if (alpha1) {  // Signal/Preemphasis.cc:69-75
+                y0 = x0v - xm;
+                y1 = x1v - x0v;
+            }
+            else {  // :62-67
+                const float p0 = alpha * xm, p1 = alpha * x0v;
+                y0             = x0v - p0;
+                y1             = x1v - p1;
+            }
+            z[n1] = make_float2(s_win2[16 * n1 + m].x * y0, s_win2[16 * n1 + m].y * y1);  // WindowFunction::work
+        }
+        if (guard) {  // zero padding behind the segment (short last frames): the pre-emphasised sample itself is zero there (whatever the clamped loads read)
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1) {
+                const int n = 2 * (16 * n1 + m);
+                z[n1].x     = n < nvalid ? z[n1].x : 0.f;
+                z[n1].y     = n + 1 < nvalid ? z[n1].y : 0.f;
+            }
+        }
+        // D[n2 = m][k1] = sum_n1 z[16 n1 + m] W16^(n1 k1), then the twiddle W256^(m k1)
+        asm volatile("" ::"v"(z[0].x), "v"(z[15].y));
+        MFCC_R16_STAMP(0);
+        r16_dft16(z);
+#pragma unroll
+        for (int r = 1; r < 16; ++r)  // (register 0 holds k1 = 0: unit twiddle)
+            z[r] = cmul(z[r], r_tw[r]);
+        // transposition: row k1, column n2 = m
+        asm volatile("" ::"v"(z[0].x), "v"(z[15].y));
+        MFCC_R16_STAMP(1);
+        float2* zb = (float2*)(smem + L.fft) + f * kR16Frame;
+        wave_sync();  // the previous tile's split readers of this buffer are done (a wave's LDS operations stay in order)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            zb[((r >> 2) + 4 * (r & 3)) * kR16Row + m] = z[r];
+        wave_sync();
+        // lane (q, k1 = m) reads row k1: E[n2][k1], n2 = 0..15
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const f32x4 v = *(const f32x4*)(zb + m * kR16Row + 2 * t);
+            z[2 * t]      = make_float2(v[0], v[1]);
+            z[2 * t + 1]  = make_float2(v[2], v[3]);
+        }
+        // Z[k1 + 16 k2] = sum_n2 E[n2][k1] W16^(n2 k2)
+        asm volatile("" ::"v"(z[0].x), "v"(z[15].y));
+        MFCC_R16_STAMP(2);
+        r16_dft16(z);
+        wave_sync();  // every lane has its row before the buffer takes the natural order
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            zb[m + 16 * ((r >> 2) + 4 * (r & 3))] = z[r];
+        wave_sync();
+        // real split (Math/FastFourierTransform.cc:113-133), 1/fs, amplitude; this lane's bin pairs (i, 256 - i), i = m + 16 j
+        MFCC_R16_STAMP(3);
+        float* amp = s_amp + f * L.amp_ld;
+        float2 sza[8], szb[8];  // all sixteen reads first: the amplitude stores of one pair would hold back the reads of the next
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int i = m + 16 * j;
+            sza[j]      = zb[i];
+            szb[j]      = zb[(NC - i) & (NC - 1)];
+        }
+        const float2 zmid = zb[NC / 2];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int    i   = m + 16 * j;
+            const float2 za = sza[j], zbb = szb[j];
+            const float2 w   = s_stw[i];
+            const float  h1r = 0.5f * (za.x + zbb.x);
+            const float  h1i = 0.5f * (za.y - zbb.y);
+            const float  h2r = 0.5f * (za.y + zbb.y);
+            const float  h2i = -0.5f * (za.x - zbb.x);
+            float        ar  = fmaf(-w.y, h2i, fmaf(w.x, h2r, h1r));
+            float        ai  = fmaf(w.y, h2r, fmaf(w.x, h2i, h1i));
+            float        br  = fmaf(w.y, h2i, fmaf(-w.x, h2r, h1r));
+            float        bi  = fmaf(w.y, h2r, fmaf(w.x, h2i, -h1i));
+            if (j == 0 && m == 0) {  // i = 0: DC and Nyquist bins of the real transform
+                ar = za.x + za.y;
+                ai = 0.f;
+                br = za.x - za.y;
+                bi = 0.f;
+            }
+            if (doscale) {
+                ar *= scale;
+                ai *= scale;
+                br *= scale;
+                bi *= scale;
+            }
+            if (live) {
+                if (j == 0 && m == 0) {
+                    amp[0]  = fabsf(ar);
+                    amp[NC] = fabsf(br);
+                }
+                else {
+                    amp[i]      = __builtin_amdgcn_sqrtf(fmaf(ar, ar, ai * ai));
+                    amp[NC - i] = __builtin_amdgcn_sqrtf(fmaf(br, br, bi * bi));
+                }
+            }
+        }
+        if (m == 0 && live) {  // bin 128: untouched by the reference's split loop
+            float2 zm = zmid;
+            if (doscale) {
+                zm.x *= scale;
+                zm.y *= scale;
+            }
+            amp[NC / 2] = __builtin_amdgcn_sqrtf(fmaf(zm.x, zm.x, zm.y * zm.y));
+        }
+      }
+      pf_have = false;
+      if (tile_id + (int)gridDim.x < p.n_tiles)
+          pf_have = fetch_batch(p.tiles[tile_id + gridDim.x]);
+    }
+    else {
     float pn0[4], pn1[4], pnm[4];  // PF: samples 2c, 2c + 1, 2c - 1 of this wave's next frame (window mask applied)
     bool  have = false;            // wave-uniform: pn* hold the frame about to be transformed
     for (int f = wave; f < FT; f += MW) {
@@ -520,6 +785,7 @@ __global__ __launch_bounds__(mfcc_waves(NC) * 64, (NC >= 1024 ? 1 : ((VAR & 8) !
             amp[NC / 2] = __builtin_amdgcn_sqrtf(fmaf(zm.x, zm.x, zm.y * zm.y));
         }
     }
+    }  // !R16
     MFCC_STAMP(1);
     __syncthreads();
     MFCC_STAMP(2);
@@ -533,44 +799,69 @@ __global__ __launch_bounds__(mfcc_waves(NC) * 64, (NC >= 1024 ? 1 : ((VAR & 8) !
         const float* w   = s_fw + s_fo[flt] - b0;
         const float* amp = s_amp + f * L.amp_ld;
         float        acc = 0.f;
-        // four bins per trip (the same ascending-bin f32 sum): the one-bin loop spent eight of its ten instructions on LDS addressing,
-        // the wait and the loop itself
-        int b = b0;
-        if (p.front_end) {  // mfplp.flow: generic-vector-f32-power 2 in front of the filter bank ((f32)pow((f64)x, 2.0) = x * x rounded once)
-            for (; b + 4 <= b1; b += 4) {
-                const float a0 = amp[b], a1 = amp[b + 1], a2 = amp[b + 2], a3 = amp[b + 3];
-                const float w0 = w[b], w1 = w[b + 1], w2 = w[b + 2], w3 = w[b + 3];
-                const float q0 = (a0 * a0) * w0, q1 = (a1 * a1) * w1, q2 = (a2 * a2) * w2, q3 = (a3 * a3) * w3;
+        // The sum is the reference's: f32, ascending bins, one rounding per product and per addition -- a dependent chain.  The PRODUCTS do
+        // not depend on it: a trip of four bins fetches the next trip's eight LDS operands before it multiplies and adds the four it fetched a trip earlier, so
+        // the LDS latency of a trip hides behind the previous trip's additions (it used to be paid once per four bins, serially: the
+        // filter bank was 13-24 % of a tile's time, tools/mfcc_timeline.py).
+        // mfplp.flow: generic-vector-f32-power 2 in front of the filter bank ((f32)pow((f64)x, 2.0) = x * x rounded once) -- decided ONCE per
+        // item (wave-uniform), not per product: as a run-time select it cost a multiply and a v_cndmask on every bin
+        auto bank = [&](auto sq_tag) {
+        constexpr bool sq = decltype(sq_tag)::value;
+        int            b  = b0;
+        auto prod = [&](int i) {
+            const float a = amp[i];
+            return (sq ? a * a : a) * w[i];
+        };
+        auto mulw = [&](float a, float wt) { return (sq ? a * a : a) * wt; };
+        {
+            // two operand sets in turn (trips of four bins): set B is fetched before set A is multiplied and added, and A's next
+            // fetch goes out before B is consumed -- written out as a ping-pong, because the compiler renames a rotating single set
+            // into "fetch, wait, consume".  A fetch behind the lane's last trip reads LDS it does not use.
+            const int n4 = (b1 - b0) >> 2;
+            float     A[8], B[8];
+            auto fetch = [&](float (&o)[8], int i) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o[e]     = amp[i + e];
+                    o[4 + e] = w[i + e];
+                }
+            };
+            auto consume = [&](const float (&o)[8]) {
+                const float q0 = mulw(o[0], o[4]), q1 = mulw(o[1], o[5]), q2 = mulw(o[2], o[6]), q3 = mulw(o[3], o[7]);
                 acc            = acc + q0;
                 acc            = acc + q1;
                 acc            = acc + q2;
                 acc            = acc + q3;
+            };
+            int t = 0;
+            if (n4 > 0)
+                fetch(A, b0);
+            for (; t + 2 <= n4; t += 2) {
+                fetch(B, b0 + 4 * (t + 1));
+                consume(A);
+                fetch(A, b0 + 4 * (t + 2));
+                consume(B);
             }
-            for (; b < b1; ++b) {
-                const float a    = amp[b];
-                const float pw   = a * a;
-                const float prod = pw * w[b];
-                acc              = acc + prod;
+            if (t < n4) {
+                consume(A);
+                ++t;
             }
+            b = b0 + 4 * t;
         }
-        else {
-            for (; b + 4 <= b1; b += 4) {
-                const float q0 = amp[b] * w[b], q1 = amp[b + 1] * w[b + 1], q2 = amp[b + 2] * w[b + 2], q3 = amp[b + 3] * w[b + 3];
-                acc            = acc + q0;
-                acc            = acc + q1;
-                acc            = acc + q2;
-                acc            = acc + q3;
-            }
-            for (; b < b1; ++b) {
-                float prod = amp[b] * w[b];
-                acc        = acc + prod;
-            }
+        for (; b < b1; ++b) {
+            const float q0 = prod(b);
+            acc            = acc + q0;
         }
+        };
+        if (!R16 && p.front_end)
+            bank(std::true_type{});
+        else
+            bank(std::false_type{});
         if (p.eql)  // plp.flow: in[i] = (f32)((f64)in[i] * f(i)) (Signal/VectorTransform.cc:78-83)
             acc = (float)((double)acc * p.eql[flt]);
         if (f < tile.n_frames)
-            s_lm[f * L.lm_ld + flt] = p.front_end ? power_node(acc, p.plp_power)  // intensity-loudness law
-                                                  : __log10f(acc);           // v_log_f32 * log10(2): ~1 ulp of log2
+            s_lm[f * L.lm_ld + flt] = (!R16 && p.front_end) ? power_node(acc, p.plp_power)  // intensity-loudness law (the radix-16 form is built
+                                                            : __log10f(acc);  // for mfcc.flow only: the call's registers do not fit beside its batch) // v_log_f32 * log10(2): ~1 ulp of log2
     }
     MFCC_STAMP(3);
     __syncthreads();
@@ -645,6 +936,7 @@ __global__ __launch_bounds__(256) void context_window_kernel(const float* __rest
 struct amx_mfcc {
     amx_ctx*        ctx = nullptr;
     bool            tune_fft_mfma = false, tune_lpc_lds = false, tune_prefetch = false;  // amx_mfcc_cfg.tuning
+    bool            fft_r16 = false;  // the radix-16 form of the 512-point transform (tuning fft=r16; LDS sized for it)
     int             tune_wgs = 0;
     amx::MfccTables tab;
     int             frames_per_tile = 16;
@@ -677,8 +969,8 @@ int upload(T** dst, const T* src, size_t n) {
     return AMX_OK;
 }
 
-size_t mfcc_lds_bytes(const amx::MfccTables& t) {
-    amx::MfccLds L(t.frame_len, t.frame_shift, t.fft_len, t.n_inputs, t.n_transform, (int)t.filter_weights.size());
+size_t mfcc_lds_bytes(const amx::MfccTables& t, bool r16) {
+    amx::MfccLds L(t.frame_len, t.frame_shift, t.fft_len, t.n_inputs, t.n_transform, (int)t.filter_weights.size(), r16);
     return (size_t)L.total * 4;
 }
 
@@ -853,7 +1145,7 @@ int launch_mfcc_var(amx_mfcc* h, const amx::MfccParams& p, int n_tiles) {
         AMX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
     // persistent workgroups: as many as are co-resident (LDS bound), each loops over tiles
     // (at most four per CU: five were 30 % slower on the PLP front ends, whose LDS footprint would allow them)
-    int per_cu = (int)std::max<size_t>(1, std::min<size_t>((VAR & 8) ? 3 : 4, (160 * 1024) / std::max<size_t>(h->lds_bytes, 1)));
+    int per_cu = (int)std::max<size_t>(1, std::min<size_t>((VAR & 16) ? 2 : (VAR & 8) ? 3 : 4, (160 * 1024) / std::max<size_t>(h->lds_bytes, 1)));
     if (h->tune_wgs > 0)  // A/B runs (tuning wgs=N): cap the workgroups per CU
         per_cu = std::max(1, std::min(per_cu, h->tune_wgs));
     int grid   = std::min(n_tiles, per_cu * std::max(h->ctx->n_cu, 1));
@@ -873,6 +1165,10 @@ int launch_mfcc(amx_mfcc* h, const amx::MfccParams& p, int n_tiles, bool s16) {
     // vector rate and does not overlap with vector instructions on a SIMD, so 24 of them cost like 192 vector instructions, more
     // than the ~125 they replace.  The butterflies stay the default; the product form is kept for A/B runs.
     const bool mfma = h->tune_fft_mfma;
+    if constexpr (NC == 256) {
+        if (h->fft_r16)
+            return s16 ? launch_mfcc_var<NC, 18>(h, p, n_tiles) : launch_mfcc_var<NC, 16>(h, p, n_tiles);
+    }
     if constexpr (NC == 256) {
         if (mfma)
             return s16 ? launch_mfcc_var<NC, 3>(h, p, n_tiles) : launch_mfcc_var<NC, 1>(h, p, n_tiles);
@@ -950,7 +1246,8 @@ int amx_mfcc_create(amx_ctx* ctx, const amx_mfcc_cfg* cfg, amx_mfcc** out) {
         if (!tune.parse(cfg->tuning, keys, "amx_mfcc_create"))
             return AMX_ERR_INVALID;
         const std::string fft = tune.str("fft", "stockham"), lpc = tune.str("lpc", "regs");
-        AMX_REQUIRE(fft == "stockham" || fft == "mfma", AMX_ERR_INVALID, "amx_mfcc_create: tuning fft=%s (stockham | mfma)", fft.c_str());
+        AMX_REQUIRE(fft == "stockham" || fft == "mfma" || fft == "r16", AMX_ERR_INVALID, "amx_mfcc_create: tuning fft=%s (stockham | mfma | r16)",
+                    fft.c_str());
         AMX_REQUIRE(lpc == "regs" || lpc == "lds", AMX_ERR_INVALID, "amx_mfcc_create: tuning lpc=%s (regs | lds)", lpc.c_str());
     }
     amx_mfcc* h = new amx_mfcc;
@@ -976,7 +1273,8 @@ int amx_mfcc_create(amx_ctx* ctx, const amx_mfcc_cfg* cfg, amx_mfcc** out) {
     }
     AMX_HIP(hipSetDevice(ctx->device));
     h->frames_per_tile = amx::FT;
-    h->lds_bytes       = mfcc_lds_bytes(t);
+    h->fft_r16         = tune.str("fft", "stockham") == "r16" && t.fft_len == 512 && cfg->front_end == AMX_FRONT_END_MFCC;  // (other lengths and front ends: the Stockham stages)
+    h->lds_bytes       = mfcc_lds_bytes(t, h->fft_r16);
     if (h->lds_bytes > 160 * 1024) {
         amx::set_error("amx_mfcc_create: configuration needs %zu bytes of LDS per workgroup (> 160 KiB)", h->lds_bytes);
         delete h;
@@ -1341,6 +1639,9 @@ int amx_context_window_dev(amx_ctx* ctx, const amx_mfcc_plan* p, const float* fe
 }  // extern "C"
 
 #ifdef AMX_LAB
+extern "C" int amx_lab_mfcc_r16_stamps(unsigned long long* out /* [4 * 32 * 8] */) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(amx::mfcc_r16_stamps), sizeof(amx::mfcc_r16_stamps)) == hipSuccess ? AMX_OK : AMX_ERR_DEVICE;
+}
 extern "C" int amx_lab_mfcc_stamps(unsigned long long* out /* [4 * 32 * 8] */) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(amx::mfcc_stamps), sizeof(amx::mfcc_stamps)) == hipSuccess ? AMX_OK : AMX_ERR_DEVICE;
 }

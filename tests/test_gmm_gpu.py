@@ -329,6 +329,86 @@ def test_score_stats_dev(ctx, kind):
     assert abs(float(ssum.item()) - want_sum) <= 1e-9 * abs(want_sum)
 
 
+@pytest.mark.parametrize("kind,n_mix,T,tuning", [("cart", 333, 1000, ""), ("cart", 10000, 4200, ""), ("cart", 45, 257, ""), ("cart", 17, 31, ""),
+                                                 ("cart", 1001, 700, ""), ("cart", 70, 300, "fused_waves=13"), ("cart", 70, 5000, "fused_waves=16"),
+                                                 ("cart", 70, 300, "fused=0"), ("cart-wide", 40, 1000, ""), ("tied", 120, 1000, ""),
+                                                 ("adversarial", 83, 515, ""), ("nan", 64, 200, "")])
+def test_score_stats_u8_dev(ctx, kind, n_mix, T, tuning):
+    """amx_gmm_score_stats_u8_dev: the best-density matrix as one byte per (frame, mixture).  gmm_fused_kernel<., 2, 8 | 12> writes
+    it directly (8-byte pieces, n_mix % 8 != 0 -> scalar path; both wave counts); every other path (specialised / 16-wave kernels,
+    two-kernel screen, per-density covariances, tied models) narrows a u32 workspace.  Scores, statistics and indices equal the u32
+    form's -- which the other tests pin against the oracle -- with 0xff where it writes 0xffffffff; and Viterbi statistics
+    accumulated from the byte matrix equal those from the u32 matrix bit for bit"""
+    import torch
+
+    import rasr_amd
+    dim = 40
+    if kind == "cart":
+        model = synth.gmm_cart(n_mix, 1, 16, dim, seed=700 + n_mix, pooled=True)
+    elif kind == "cart-wide":
+        model = synth.gmm_cart(n_mix, 10, 24, dim, seed=702, pooled=False)
+    elif kind == "tied":
+        model = synth.gmm_tied(n_mix, 64, dim, seed=703)
+    elif kind == "adversarial":
+        model = _cart_adversarial(704, n_mix, dim, True)
+    else:
+        model = synth.gmm_cart(n_mix, 16, 16, dim, seed=705, pooled=True)
+    x = feats(T, dim, 706 + T)
+    if kind == "nan":
+        x[3, 5] = np.nan
+        x[150] = np.nan
+    M = len(model["mix_offsets"]) - 1
+    sc = rasr_amd.GmmFeatureScorer(ctx, model, tuning=tuning)
+    xd = torch.from_numpy(x).cuda()
+    ctx.use_torch_stream()
+
+    def run(dtype):
+        scores = torch.empty((T, M), dtype=torch.float32, device="cuda")
+        bestd = torch.full((T, M), 7, dtype=dtype, device="cuda")
+        state = torch.empty((T,), dtype=torch.int32, device="cuda")
+        counts = torch.zeros((M,), dtype=torch.int64, device="cuda")
+        ssum = torch.zeros((1,), dtype=torch.float64, device="cuda")
+        sc.score_stats_dev(xd, T, scores, bestd, state, counts, ssum)
+        torch.cuda.synchronize()
+        return scores, bestd, state, counts, ssum
+
+    s32, b32, st32, c32, sum32 = run(torch.int32)
+    s8, b8, st8, c8, sum8 = run(torch.uint8)
+    assert np.array_equal(s8.cpu().numpy().view(np.uint32), s32.cpu().numpy().view(np.uint32))
+    want = b32.cpu().numpy().astype(np.uint32)
+    assert want.max() == 0xffffffff or want.max() < 255
+    assert np.array_equal(b8.cpu().numpy(), np.where(want == 0xffffffff, 255, want).astype(np.uint8))
+    assert np.array_equal(st8.cpu().numpy(), st32.cpu().numpy()) and np.array_equal(c8.cpu().numpy(), c32.cpu().numpy())
+    assert sum8.cpu().numpy().tobytes() == sum32.cpu().numpy().tobytes()
+    if kind != "nan":  # (the u32 form indexes with 0xffffffff there too: statistics of a NaN frame are the caller's to avoid)
+        acc32 = torch.zeros((sc.accumulator_size(),), dtype=torch.float64, device="cuda")
+        acc8 = torch.zeros_like(acc32)
+        sc.accumulate_dev(xd, T, st32, b32, M, acc32)
+        sc.accumulate_dev(xd, T, st8, b8, M, acc8)
+        torch.cuda.synchronize()
+        a32, a8 = acc32.cpu().numpy(), acc8.cpu().numpy()
+        nk = int(model["mix_offsets"][-1])
+        assert a32[:nk].sum() == T and np.array_equal(a32[:nk], a8[:nk])      # density weights: whole numbers, exact
+        assert np.allclose(a32, a8, rtol=1e-12, atol=0)                       # f64 sums through atomics: order of addition varies
+
+
+def test_score_stats_u8_rejects_wide_mixtures(ctx):
+    """a mixture of more than 255 densities cannot be indexed by a byte: AMX_ERR_UNSUPPORTED, nothing written"""
+    import torch
+
+    import rasr_amd
+    model = synth.gmm_cart(3, 300, 300, 16, seed=710, pooled=True)
+    sc = rasr_amd.GmmFeatureScorer(ctx, model)
+    T, M = 8, 3
+    xd = torch.from_numpy(feats(T, 16, 711)).cuda()
+    ctx.use_torch_stream()
+    with pytest.raises(rasr_amd.AmxError) as e:
+        sc.score_stats_dev(xd, T, torch.empty((T, M), dtype=torch.float32, device="cuda"), torch.empty((T, M), dtype=torch.uint8, device="cuda"),
+                           torch.empty((T,), dtype=torch.int32, device="cuda"), torch.zeros((M,), dtype=torch.int64, device="cuda"),
+                           torch.zeros((1,), dtype=torch.float64, device="cuda"))
+    assert "255" in str(e.value)
+
+
 def test_workspaces_regrow_between_calls(ctx):
     """the screen workspace, the fused-statistics partials and the host staging buffers of one handle grow with the batch:
     alternate small and large batches through the device and the host entry points"""

@@ -307,8 +307,10 @@ def test_s16_samples_give_the_same_bits_as_f32(ctx):
         assert np.array_equal(out32.cpu().numpy().view(np.uint32), np.concatenate(want).view(np.uint32))
 
 
-def test_matrix_core_fft_against_the_butterfly_fft_and_the_oracle(ctx, tmp_path):
-    """amx_mfcc_cfg.tuning "fft=mfma" runs the 512-point transform as two 16x16x16 complex products on v_mfma_f32_16x16x4_f32 (slower than the
+@pytest.mark.parametrize("fft", ["mfma", "r16"])
+def test_matrix_core_fft_against_the_butterfly_fft_and_the_oracle(ctx, tmp_path, fft):
+    """amx_mfcc_cfg.tuning "fft=r16": radix-16 register butterflies, four frames per wave, two LDS round trips per transform.
+    amx_mfcc_cfg.tuning "fft=mfma" runs the 512-point transform as two 16x16x16 complex products on v_mfma_f32_16x16x4_f32 (slower than the
     radix-4 LDS stages, kept for A/B runs): within the MFCC bar of the oracle and within f32 round-off of the default kernel --
     incl. the transform's corner cases: a unit impulse at every position class, a constant, a tone on a bin, silence"""
     import rasr_amd
@@ -323,7 +325,7 @@ def test_matrix_core_fft_against_the_butterfly_fft_and_the_oracle(ctx, tmp_path)
         imp = np.zeros(n, np.float32)
         imp[pos] = 20000.0
         sigs.append(imp)
-    got = np.stack(rasr_amd.MfccExtractor(ctx, nr_cepstrum_coefficients=40, filter_width=138.0, tuning="fft=mfma").run_batch(sigs))
+    got = np.stack(rasr_amd.MfccExtractor(ctx, nr_cepstrum_coefficients=40, filter_width=138.0, tuning="fft=" + fft).run_batch(sigs))
     ref = np.stack(fe.run_batch(sigs))
     for g, r, x in zip(got, ref, sigs):
         want = orc.run(x)
@@ -331,3 +333,27 @@ def test_matrix_core_fft_against_the_butterfly_fft_and_the_oracle(ctx, tmp_path)
         assert np.array_equal(np.isfinite(g), ok)
         assert np.all(np.abs(g[ok] - want[ok]) <= 1e-4 * np.abs(want[ok]) + 1e-4), np.abs(g[ok] - want[ok]).max()
         assert np.all(np.abs(g[ok] - r[ok]) <= 1e-4 * np.abs(r[ok]) + 1e-4)
+
+
+@pytest.mark.parametrize("alpha", [1.0, 0.97, 0.0])
+def test_radix16_fft_ragged_batch_s16_and_preemphasis(ctx, alpha):
+    """fft=r16 on a ragged batch (segments shorter than a frame, frame counts off the 4-frame wave group and the 16-frame tile, first
+    and last frames of a segment through the guarded loads), every pre-emphasis form, f32 and s16 samples: within the MFCC bar of
+    the oracle; s16 and f32 samples of whole-numbered audio give the same bits"""
+    import rasr_amd
+    from oracle import OracleMfcc
+    lens = [100, 399, 400, 401, 560, 561, 720, 1040, 1360, 2960, 3000, 16000, 16001, 33333]
+    sigs = [np.round(synth.waveform(n, seed=300 + i)).astype(np.float32) for i, n in enumerate(lens)]
+    kw = dict(nr_cepstrum_coefficients=40, filter_width=138.0, alpha=alpha)
+    fe = rasr_amd.MfccExtractor(ctx, tuning="fft=r16", **kw)
+    orc = OracleMfcc(n_ceps=40, filter_width=138.0, alpha=alpha)
+    got = fe.run_batch(sigs)
+    for g, x in zip(got, sigs):
+        want = orc.run(x)
+        assert g.shape == want.shape, (g.shape, want.shape, len(x))
+        ok = np.isfinite(want)
+        assert np.array_equal(np.isfinite(g), ok)
+        assert np.all(np.abs(g[ok] - want[ok]) <= 1e-4 * np.abs(want[ok]) + 1e-4), (len(x), np.abs(g[ok] - want[ok]).max())
+    got16 = fe.run_batch([x.astype(np.int16) for x in sigs])
+    for g, g16 in zip(got, got16):
+        assert g.shape == g16.shape and np.array_equal(g.view(np.uint32), g16.view(np.uint32))

@@ -1,5 +1,5 @@
 """A/B: how much of gmm_fused_kernel's time are its stores?  The same 63 936 x 10 000 x 16 pass with the best-density matrix (u32, 2.56 GB)
-and without it (scores only).  python tools/gmm_store_ab.py"""
+as bytes (amx_gmm_score_stats_u8_dev, 0.64 GB) and without it (scores only).  python tools/gmm_store_ab.py"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -18,7 +18,8 @@ bestd = torch.empty((T, M), dtype=torch.int32, device="cuda")
 state = torch.empty((T,), dtype=torch.int32, device="cuda")
 counts = torch.zeros((M,), dtype=torch.int64, device="cuda")
 ssum = torch.zeros((1,), dtype=torch.float64, device="cuda")
-for name, bd in (("scores + best density", bestd), ("scores only", None), ("scores + best density", bestd), ("scores only", None)):
+bestd8 = torch.empty((T, M), dtype=torch.uint8, device="cuda")
+for name, bd in (("scores + best density u32", bestd), ("scores + best density u8", bestd8), ("scores only", None)) * 2:
     for _ in range(2):
         gmm.score_stats_dev(x, T, scores, bd, state, counts, ssum)
     torch.cuda.synchronize()
@@ -28,4 +29,4 @@ for name, bd in (("scores + best density", bestd), ("scores only", None), ("scor
         gmm.score_stats_dev(x, T, scores, bd, state, counts, ssum)
     e1.record()
     torch.cuda.synchronize()
-    print("%-24s %.3f ms per pass" % (name, e0.elapsed_time(e1) / 6))
+    print("%-28s %.3f ms per pass" % (name, e0.elapsed_time(e1) / 6))

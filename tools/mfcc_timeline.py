@@ -43,3 +43,16 @@ for w in range(4):
     per = np.diff(st[w, 4:31, 0]).mean()
     ph = [(a[:, k + 1] - a[:, k]).mean() for k in range(6)]
     print("%4d  %11.0f  " % (w, per) + "  ".join("%8.0f (%4.1f %%)       " % (v, 100 * v / per) for v in ph))
+
+if len(sys.argv) > 1 and "r16" in sys.argv[1]:  # inside the radix-16 phase B (one batch of four frames per wave)
+    b2 = (C.c_ulonglong * (4 * 32 * 8))()
+    L.amx_lab_mfcc_r16_stamps.restype = C.c_int
+    assert L.amx_lab_mfcc_r16_stamps(b2) == 0
+    r = np.frombuffer(b2, dtype=np.uint64).reshape(4, 32, 8).astype(np.int64)
+    print("radix-16 phase B: tile start -> samples, pre-emphasis, window | DFT-16 + twiddle | transposition | DFT-16 + natural-order write | split, amplitudes")
+    for w in range(4):
+        a, t0, t1 = r[w, 4:30], st[w, 4:30, 0], st[w, 4:30, 1]
+        ok = (a[:, :4] > 0).all(axis=1) & (a[:, 0] >= t0) & (t1 >= a[:, 3])  # tiles in which this wave had a batch
+        a, t0, t1 = a[ok], t0[ok], t1[ok]
+        ph = [(a[:, 0] - t0).mean(), (a[:, 1] - a[:, 0]).mean(), (a[:, 2] - a[:, 1]).mean(), (a[:, 3] - a[:, 2]).mean(), (t1 - a[:, 3]).mean()]
+        print("%4d  " % w + "  ".join("%8.0f" % v for v in ph))
