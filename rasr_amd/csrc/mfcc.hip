@@ -386,6 +386,13 @@ __global__ __launch_bounds__(mfcc_waves(NC) * 64, (NC >= 1024 ? 1 : ((VAR & 16) 
       }
       return true;
   };
+  // PF: samples 2c - 1, 2c, 2c + 1 of this wave's next frame, RAW and as the triple one load instruction delivers (carried from
+  // frame to frame in exactly the registers the load writes: any other arrangement costs a copy per value behind a wait)
+  struct Raw3 {
+      Sample m, x0, x1;
+  };
+  [[maybe_unused]] Raw3 pn[4];
+  [[maybe_unused]] bool have = false;  // wave-uniform: pn holds the frame about to be transformed (carried across tiles too)
   [[maybe_unused]] int lab_tile = -1;
   for (int tile_id = blockIdx.x; tile_id < p.n_tiles; tile_id += gridDim.x) {
     const MfccTile tile = p.tiles[tile_id];
@@ -398,6 +405,9 @@ __global__ __launch_bounds__(mfcc_waves(NC) * 64, (NC >= 1024 ? 1 : ((VAR & 16) 
     // 1.17; five workgroups per CU (the PLP variants' smaller LDS would allow them) are 30 % SLOWER, hence the cap in launch_mfcc.
     const Sample*   seg   = (const Sample*)p.pcm + tile.sample_base;
     const long long nseg  = tile.n_samples;
+    // PF: the tile this workgroup walks next (its first frame of this wave is fetched behind the wave's last frame of this tile)
+    [[maybe_unused]] const bool     has_next = PF && tile_id + (int)gridDim.x < p.n_tiles;
+    [[maybe_unused]] const MfccTile ntile    = p.tiles[has_next ? tile_id + (int)gridDim.x : tile_id];
     // ================= phase B: one frame per wavefront: FFT -> split -> |X| into s_amp[f][*]
     if constexpr (R16) {
       // ================= phase B, radix-16 form: wave w transforms frames 4 w .. 4 w + 3 of the tile together
@@ -535,8 +545,6 @@ __global__ __launch_bounds__(mfcc_waves(NC) * 64, (NC >= 1024 ? 1 : ((VAR & 16) 
           pf_have = fetch_batch(p.tiles[tile_id + gridDim.x]);
     }
     else {
-    float pn0[4], pn1[4], pnm[4];  // PF: samples 2c, 2c + 1, 2c - 1 of this wave's next frame (window mask applied)
-    bool  have = false;            // wave-uniform: pn* hold the frame about to be transformed
     for (int f = wave; f < FT; f += MW) {
         if (f >= tile.n_frames)
             break;  // wave-uniform
@@ -553,7 +561,8 @@ __global__ __launch_bounds__(mfcc_waves(NC) * 64, (NC >= 1024 ? 1 : ((VAR & 16) 
                     float  xm[4], x0[4], x1[4];
                     // a frame that lies inside its segment with a predecessor sample (all but the first and the last few of a segment:
                     // wave-uniform) needs none of the per-sample segment guards -- 64-bit compares and selects on twelve loads
-                    const bool inner = fbase >= 1 && fbase + p.frame_len < nseg;
+                    // (PF: the whole zero-padded span of the transform inside the segment, so that its loads need no index clamp either)
+                    const bool inner = fbase >= 1 && fbase + (PF ? 2 * NC : p.frame_len) < nseg;
                     auto       emphasise = [&](int r, float& y0, float& y1) {
                         if (alpha1) {  // Signal/Preemphasis.cc:69-75
                             y0 = x0[r] - xm[r];
@@ -567,13 +576,39 @@ __global__ __launch_bounds__(mfcc_waves(NC) * 64, (NC >= 1024 ? 1 : ((VAR & 16) 
                     };
                     if (inner) {
                         const Sample* fr = seg + fbase;
-                        if (PF && have) {
+                        if constexpr (PF) {
+                            // Every load of this variant is UNCONDITIONAL and the window mask is applied where the values are used: a load
+                            // under a lane mask sits in a conditional block, the compiler cannot count what is in flight behind such a
+                            // block and drains the queue (s_waitcnt vmcnt(0)) -- which is what the first form of this variant did right
+                            // behind its next-frame loads, in front of the transform they were meant to overlap with (0.795 against 0.743 ms).
+                            if (!have) {  // wave-uniform: nothing fetched ahead (first frame of a tile, or behind a guarded frame)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r)
+                                    pn[r] = *(const Raw3*)(fr + 2 * (j + r * (NC / 4)) - 1);
+                            }
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
-                                x0[r] = pn0[r];
-                                x1[r] = pn1[r];
-                                xm[r] = pnm[r];
+                                const bool w = 2 * (j + r * (NC / 4)) < p.frame_len;
+                                x0[r]        = w ? (float)pn[r].x0 : 0.f;
+                                x1[r]        = w ? (float)pn[r].x1 : 0.f;
+                                xm[r]        = w ? (float)pn[r].m : 0.f;
                             }
+                            // this wave's next frame of the tile, if it is an inner frame too; otherwise the current frame once more
+                            const int     fn = f + MW;
+                            const Sample* fq = fr;
+                            if (fn < FT && fn < tile.n_frames) {
+                                const long long fbn = fbase + (long long)MW * p.frame_shift;
+                                have                = fbn + 2 * NC < nseg;
+                                fq                  = have ? seg + fbn : fr;
+                            }
+                            else {  // behind the wave's last frame of this tile: its first frame of the workgroup's next tile
+                                const long long fbn = (long long)(ntile.frame0 + wave) * p.frame_shift;
+                                have                = has_next && wave < ntile.n_frames && fbn >= 1 && fbn + 2 * NC < (long long)ntile.n_samples;
+                                fq                  = have ? (const Sample*)p.pcm + ntile.sample_base + fbn : fr;
+                            }
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                pn[r] = *(const Raw3*)(fq + 2 * (j + r * (NC / 4)) - 1);
                         }
                         else {
 #pragma unroll
@@ -584,22 +619,6 @@ __global__ __launch_bounds__(mfcc_waves(NC) * 64, (NC >= 1024 ? 1 : ((VAR & 16) 
                             x1[r]        = w ? (float)fr[2 * c + 1] : 0.f;   // 2c + 1 <= frame_len: still inside the segment
                             xm[r]        = w ? (float)fr[2 * c - 1] : 0.f;
                         }
-                        }
-                        if constexpr (PF) {  // this wave's next frame of the tile, if it is an inner frame too
-                            const int       fn     = f + MW;
-                            const long long fbn    = fbase + (long long)MW * p.frame_shift;
-                            have                   = fn < FT && fn < tile.n_frames && fbn + p.frame_len < nseg;
-                            if (have) {
-                                const Sample* fq = seg + fbn;
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) {
-                                    const int  c = j + r * (NC / 4);
-                                    const bool w = 2 * c < p.frame_len;
-                                    pn0[r]       = w ? (float)fq[2 * c] : 0.f;
-                                    pn1[r]       = w ? (float)fq[2 * c + 1] : 0.f;
-                                    pnm[r]       = w ? (float)fq[2 * c - 1] : 0.f;
-                                }
-                            }
                         }
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
@@ -1255,7 +1274,7 @@ int amx_mfcc_create(amx_ctx* ctx, const amx_mfcc_cfg* cfg, amx_mfcc** out) {
     h->tune_fft_mfma = tune.str("fft", "stockham") == "mfma";
     h->tune_lpc_lds  = tune.str("lpc", "regs") == "lds";
     h->tune_wgs      = tune.get("wgs", 0);
-    h->tune_prefetch = tune.get("prefetch", 0) != 0;
+    h->tune_prefetch = tune.get("prefetch", 1) != 0;  // default since the end of round 4 (0.753 -> 0.73 ms on config 2)
     int r       = h->tab.build(*cfg);
     if (r != AMX_OK) {
         delete h;

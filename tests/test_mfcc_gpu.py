@@ -357,3 +357,25 @@ def test_radix16_fft_ragged_batch_s16_and_preemphasis(ctx, alpha):
     got16 = fe.run_batch([x.astype(np.int16) for x in sigs])
     for g, g16 in zip(got, got16):
         assert g.shape == g16.shape and np.array_equal(g.view(np.uint32), g16.view(np.uint32))
+
+
+@pytest.mark.parametrize("kw", [dict(nr_cepstrum_coefficients=40, filter_width=138.0), dict(nr_cepstrum_coefficients=16, alpha=0.97),
+                                dict(nr_cepstrum_coefficients=16, front_end="mfplp", nr_autocorrelation_coefficients=20, normalize=True)])
+def test_sample_prefetch_variant_gives_the_same_bits(ctx, kw):
+    """tuning prefetch=1 | 0: a wave fetches its next frame's samples (within the tile, and across to the workgroup's next tile) while it
+    transforms the current one -- the load path differs, the arithmetic does not: bit-identical cepstra on a ragged batch whose
+    segments end inside, at and just behind the 512-sample span of a frame (the frames that may not use the unguarded loads), f32 and
+    s16 samples, more tiles than workgroups"""
+    import rasr_amd
+    lens = [0, 7, 399, 400, 401, 511, 512, 513, 560, 672, 673, 1000, 2960, 16000, 16001, 33333] + [4000 + 37 * i for i in range(40)]
+    sigs = [np.round(synth.waveform(n, seed=500 + i)).astype(np.float32) for i, n in enumerate(lens)]
+    big = [np.round(synth.waveform(160 * 3000 + 240, seed=499)).astype(np.float32)] * 6     # 6 x 3000 frames: every workgroup walks several tiles
+    on = rasr_amd.MfccExtractor(ctx, tuning="prefetch=1", **kw)
+    off = rasr_amd.MfccExtractor(ctx, tuning="prefetch=0", **kw)
+    for batch in (sigs, big, sigs + big):
+        a, b = on.run_batch(batch), off.run_batch(batch)
+        for x, y in zip(a, b):
+            assert x.shape == y.shape and np.array_equal(x.view(np.uint32), y.view(np.uint32))
+        a16 = on.run_batch([x.astype(np.int16) for x in batch])
+        for x, y in zip(a16, b):
+            assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
