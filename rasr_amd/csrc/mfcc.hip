@@ -894,6 +894,7 @@ __global__ __launch_bounds__(mfcc_waves(NC) * 64, (NC >= 1024 ? 1 : ((VAR & 16) 
         const int arow = lane & 15, akq = lane >> 4;
         for (int nt = wave; nt < n_tiles; nt += MW) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            // (four K-steps per trip with their eight LDS operands fetched together: measured slower, 0.749 against 0.732 ms on config 2)
             for (int kk = 0; kk < L.kpad / 4; ++kk) {
                 const float a = s_lm[arow * L.lm_ld + 4 * kk + akq];
                 const float b = s_dct[(4 * kk + akq) * L.dct_ld + nt * 16 + arow];
