@@ -74,9 +74,11 @@ def parse():
                          "one GPU (the line then also reports the streamed rate next to it), streamed for --gpus N > 1")
     ap.add_argument("--corpus-hours", type=float, default=100.0, help="size of the synthetic corpus all ranks share (config 5: 100 h)")
     ap.add_argument("--trained-frames-per-state", type=int, default=600, help="gmm-trained: training frames per state of the split-trained model")
-    ap.add_argument("--best-density", choices=["u8", "u32"], default="u32",
-                    help="element type of the GMM leg's best-density matrix [frames x 10000]: u32 (Mm::DensityInMixture as RASR declares it) or u8 "
-                         "(amx_gmm_score_stats_u8_dev: a quarter of the matrix's memory, the same time -- profiles/r04/gmm_store_ab.log)")
+    ap.add_argument("--best-density", choices=["u8", "u32", "aligned"], default="u32",
+                    help="best densities of the GMM leg: u32 = the matrix [frames x 10000] (Mm::DensityInMixture as RASR declares it); u8 = the "
+                         "same matrix in bytes (amx_gmm_score_stats_u8_dev: a quarter of the memory, the same time, profiles/r04/gmm_store_ab.log); "
+                         "aligned = no matrix: every state scored without index bookkeeping, then amx_gmm_best_density_dev for the aligned "
+                         "(here: best) state of each frame -- what AssigningContextScorer::bestDensity(e) is asked for in Viterbi accumulation")
     ap.add_argument("--gmm-tuning", default=None, help='amx_gmm_model.tuning of every GMM scorer the workload builds, e.g. "screen=0" (A/B runs)')
     ap.add_argument("--nn-tuning", default=None, help='amx_ffnn_model.tuning, e.g. "tile=4" or "graph=0"')
     ap.add_argument("--mfcc-tuning", default=None, help='amx_mfcc_cfg.tuning, e.g. "fft=mfma" or "wgs=3"')
@@ -301,7 +303,7 @@ def gmm_cart_roofline(ctx, sc, nk, n_mix, dim, frames, best_bytes=4):
                     note="VALU-issue-bound kernel priced against the f32 vector peak (157.3 TFLOP/s; unfused mul/add can "
                          "reach half of it). achieved = densities evaluated exactly (device counter) x 4 dim f32 operations / kernel time",
                     achieved=round(ex / t / 1e12, 2), peak=FP32_TFLOPS, unit="TFLOP/s", frac=round(ex / t / 1e12 / FP32_TFLOPS, 4),
-                    traffic=measured_traffic("pipeline", "gmm_fused_kernel", "Li%dELi%d" % (dim, 2 if best_bytes == 1 else 1))
+                    traffic=measured_traffic("pipeline", "gmm_fused_kernel", "Li%dELi%d" % (dim, {0: 0, 1: 2}.get(best_bytes, 1)))
                     if (n_mix == 10000 and frames == 63936) else None,
                     best_density_bytes=best_bytes,
                     avg_launch_ms=round(ms_x, 4), pack_launch_ms=round(ms_p, 4), launches=n_x, flops_per_launch=ex,
@@ -462,7 +464,9 @@ class Pipeline(NnPipeline):
         super().__init__(ctx, args, rank)
         g = min(self.GCHUNK, self.F)
         self.gscores = torch.empty((g, self.M), dtype=torch.float32, device="cuda")
-        self.gbestd = torch.empty((g, self.M), dtype=torch.uint8 if args.best_density == "u8" else torch.int32, device="cuda")
+        self.aligned = args.best_density == "aligned"
+        self.gbestd = (torch.empty((g,), dtype=torch.int32, device="cuda") if self.aligned else
+                       torch.empty((g, self.M), dtype=torch.uint8 if args.best_density == "u8" else torch.int32, device="cuda"))
         self.gstate = torch.empty((g,), dtype=torch.int32, device="cuda")
         self.gcounts = self.red.view("gcounts")
         self.gscore_sum = self.red.view("gscore_sum")
@@ -475,8 +479,13 @@ class Pipeline(NnPipeline):
         for t0 in range(0, self.F, self.GCHUNK):
             T = min(self.GCHUNK, self.F - t0)
             x = self.ceps[t0:]
-            self.gmm.score_stats_dev(x, T, self.gscores, self.gbestd, self.gstate, self.gcounts, self.gscore_sum)
-            self.gmm.accumulate_dev(x, T, self.gstate, self.gbestd, self.M, self.acc)
+            if self.aligned:
+                self.gmm.score_stats_dev(x, T, self.gscores, None, self.gstate, self.gcounts, self.gscore_sum)
+                self.gmm.best_density_dev(x, T, self.gstate, self.gbestd)
+                self.gmm.accumulate_dev(x, T, self.gstate, self.gbestd, 0, self.acc)
+            else:
+                self.gmm.score_stats_dev(x, T, self.gscores, self.gbestd, self.gstate, self.gcounts, self.gscore_sum)
+                self.gmm.accumulate_dev(x, T, self.gstate, self.gbestd, self.M, self.acc)
 
     def nn_leg(self):
         self.ctx.context_window(self.plan, self.ceps, 40, 5, 5, self.ctxwin, 440)
@@ -503,7 +512,7 @@ class Pipeline(NnPipeline):
 
     def roofline(self):
         nn = super().roofline()
-        gm = gmm_cart_roofline(self.ctx, self.gmm, self.nk, self.M, 40, min(self.GCHUNK, self.F), self.gbestd.element_size())
+        gm = gmm_cart_roofline(self.ctx, self.gmm, self.nk, self.M, 40, min(self.GCHUNK, self.F), 0 if self.aligned else self.gbestd.element_size())
         if gm is None:
             return nn
         # "dominant kernel" = the one with the larger total time in the step: the GMM's exact stage or the output-layer GEMM
@@ -516,7 +525,7 @@ class Pipeline(NnPipeline):
     def stage_report(self):
         out = super().stage_report()
         out["accumulator_bytes"] = int(self.acc.numel() * 8)
-        for k in ("gmm_screen_pack", "gmm_screen", "gmm", "gmm_accumulate"):
+        for k in ("gmm_screen_pack", "gmm_screen", "gmm", "gmm_best_density", "gmm_accumulate"):
             ms, n = self.ctx.profile_get(k)
             if n:
                 out[k] = dict(avg_ms=round(ms, 4), launches=n)
@@ -1260,7 +1269,7 @@ def measure(ctx, job, args, world):
 
 
 WORKLOAD_NAMES = {
-    "pipeline": lambda a: "cfg5-shard: MFCC-40 -> {GMM 10000x16 diagonal-maximum (scores f32 + best densities " + a.best_density + ", all states) -> Viterbi accumulators | ctx11 -> FFNN 440-6x2048-10000 "
+    "pipeline": lambda a: "cfg5-shard: MFCC-40 -> {GMM 10000x16 diagonal-maximum (scores f32 of all states; best densities: " + {"u32": "u32 matrix, all states", "u8": "byte matrix, all states", "aligned": "of each frame's aligned (= best) state, amx_gmm_best_density_dev"}[a.best_density] + ") -> Viterbi accumulators | ctx11 -> FFNN 440-6x2048-10000 "
                           "(%s MFMA) -> best-state counts}, every frame scored by both models; %d utterances x %.0f s per step and rank"
                           % (a.precision, a.utterances, a.utt_seconds),
     "nn-pipeline": lambda a: "cfg5-shard, NN leg only: MFCC-40 -> ctx11 -> FFNN 440-6x2048-10000 (%s MFMA) -> best-state counts; "

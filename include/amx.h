@@ -392,6 +392,15 @@ int amx_gmm_score_stats_u8_dev(amx_gmm* h, const float* feats_dev, int T, float*
  * acc_dev is ONE flat f64 buffer -- [sum K_m weights][n_mean weights][n_mean x dim sums][n_cov weights][n_cov x dim sums],
  * amx_gmm_accumulator_size() doubles -- so that data-parallel ranks combine their statistics with a single all-reduce
  * (the reference combines per-partition accumulator files offline, Tools/AcousticModelTrainer/AcousticModelTrainer.cc:317-325). */
+/* AssigningContextScorer::bestDensity(e) for ONE mixture per frame (Mm/AssigningFeatureScorer.hh:127-131 ->
+ * GaussDiagonalMaximumFeatureScorer::calculateScoreAndDensity, Mm/GaussDiagonalMaximumFeatureScorer.cc:116-142): best_density_dev[t] =
+ * index within mixture_dev[t] of the density that minimises frame t's score, scores_dev[t] (nullable) that score -- the same bits as
+ * entry (t, mixture_dev[t]) of amx_gmm_score_dev's matrices (0xffffffff / Type<f32>::max for a mixture index >= n_mix).  It is what the
+ * Viterbi accumulation asks of an assigning scorer: a trainer that scores every state (amx_gmm_score_stats_dev with
+ * best_density_dev = NULL: the screened kernel is 0.3 ms of 4.7 faster without the index bookkeeping) needs the density of the
+ * ALIGNED state only, and gets it here for amx_gmm_accumulate_dev(..., best_density_ld = 0). */
+int amx_gmm_best_density_dev(amx_gmm* h, const float* feats_dev, int T, const uint32_t* mixture_dev, uint32_t* best_density_dev,
+                             float* scores_dev);
 long amx_gmm_accumulator_size(const amx_gmm* h);
 int  amx_gmm_accumulate_dev(amx_gmm* h, const float* feats_dev, int T, const uint32_t* mixture_dev,
                             const uint32_t* best_density_dev, int best_density_ld, double* acc_dev);

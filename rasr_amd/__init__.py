@@ -490,6 +490,10 @@ class GmmFeatureScorer:
         _lib.check(self.L.amx_gmm_accumulator_read(self.h, os.fsencode(path), a.ctypes.data))
         return a
 
+    def best_density_dev(self, feats_dev, T, mixture_dev, best_density_dev, scores_dev=None):
+        """AssigningContextScorer::bestDensity(e) for one mixture per frame: best_density_dev[t] (u32) and, optionally, scores_dev[t]"""
+        _lib.check(self.L.amx_gmm_best_density_dev(self.h, _ptr(feats_dev), T, _ptr(mixture_dev), _ptr(best_density_dev), _ptr(scores_dev)))
+
     def accumulate_dev(self, feats_dev, T, mixture_dev, best_density_dev, best_density_ld, acc_dev):
         """Viterbi statistics (weights, sum x, sum x^2 in f64) into the flat accumulator acc_dev; best_density_dev u32 or bytes"""
         fn = self.L.amx_gmm_accumulate_u8_dev if _is_bytes(best_density_dev) else self.L.amx_gmm_accumulate_dev

@@ -134,6 +134,7 @@ SIGNATURES = {
     "amx_gmm_score_dev": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, _P]),
     "amx_gmm_score_stats_dev": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P, _P]),
     "amx_gmm_score_stats_u8_dev": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P, _P]),
+    "amx_gmm_best_density_dev": (C.c_int, [_P, _P, C.c_int, _P, _P, _P]),
     "amx_gmm_accumulator_size": (C.c_long, [_P]),
     "amx_gmm_accumulate_u8_dev": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, _P]),
     "amx_gmm_accumulate_dev": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, _P]),

@@ -239,6 +239,52 @@ __global__ __launch_bounds__(256) void gmm_batch_float_kernel(const float* __res
     }
 }
 
+// ---- AssigningContextScorer::bestDensity(e) for ONE mixture per frame (Mm/AssigningFeatureScorer.hh:127-131 ->
+// GaussDiagonalMaximumFeatureScorer::calculateScoreAndDensity, Mm/GaussDiagonalMaximumFeatureScorer.cc:116-142): what the Viterbi
+// accumulation asks of the scorer -- the best density of the ALIGNED mixture, not of all of them.  Thread = frame; the reference's
+// arithmetic and rule (gmm_distance's operation order, MaxState), so index and score equal the full pass's entry (t, mixture[t]).
+__global__ __launch_bounds__(256) void gmm_best_density_kernel(const float* __restrict__ feats, const uint32_t* __restrict__ mixture,
+                                                              uint32_t* __restrict__ best, float* __restrict__ score, const uint32_t* __restrict__ mix_off,
+                                                              const uint32_t* __restrict__ k_mean, const uint32_t* __restrict__ k_cov,
+                                                              const double* __restrict__ k_c64, const float* __restrict__ means,
+                                                              const float* __restrict__ isr, int T, int dim, int n_mix) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= T)
+        return;
+    const uint32_t m = mixture[t];
+    MaxState       st;
+    if (m < (uint32_t)n_mix) {
+        const float*   x  = feats + (size_t)t * dim;
+        const uint32_t k0 = mix_off[m], k1 = mix_off[m + 1];
+        const int      eff = dim & ~3;
+        for (uint32_t k = k0; k < k1; ++k) {
+            const float* mu = means + (size_t)k_mean[k] * dim;
+            const float* is = isr + (size_t)k_cov[k] * dim;
+            float        l0 = 0.f, l1 = 0.f, l2 = 0.f, l3 = 0.f;
+            for (int i = 0; i < eff; i += 4) {
+                const float d0 = (mu[i] - x[i]) * is[i];
+                const float d1 = (mu[i + 1] - x[i + 1]) * is[i + 1];
+                const float d2 = (mu[i + 2] - x[i + 2]) * is[i + 2];
+                const float d3 = (mu[i + 3] - x[i + 3]) * is[i + 3];
+                l0             = l0 + d0 * d0;
+                l1             = l1 + d1 * d1;
+                l2             = l2 + d2 * d2;
+                l3             = l3 + d3 * d3;
+            }
+            float dist = 0.f;
+            dist       = dist + ((l0 + l1) + (l2 + l3));
+            for (int i = eff; i < dim; ++i) {
+                const float df = (mu[i] - x[i]) * is[i];
+                dist           = dist + df * df;
+            }
+            st.add(k_c64[k], 0.f, dist, k - k0);
+        }
+    }
+    best[t] = st.idx;
+    if (score)
+        score[t] = st.result();
+}
+
 // u32 best densities -> bytes (paths without a byte-writing kernel; 0xffffffff -> 0xff)
 __global__ __launch_bounds__(256) void best_narrow_kernel(const uint32_t* __restrict__ in, unsigned char* __restrict__ out, size_t n) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
@@ -2895,6 +2941,24 @@ int amx_gmm_accumulator_read(const amx_gmm* h, const char* path, double* acc) {
         return AMX_ERR_INVALID;
     }
     AMX_REQUIRE(ok, AMX_ERR_INVALID, "amx_gmm_accumulator_read: '%s' is truncated or its topology differs from the model", path);
+    return AMX_OK;
+}
+
+int amx_gmm_best_density_dev(amx_gmm* h, const float* feats_dev, int T, const uint32_t* mixture_dev, uint32_t* best_density_dev,
+                             float* scores_dev) {
+    AMX_REQUIRE(h, AMX_ERR_INVALID, "amx_gmm_best_density_dev: NULL handle");
+    AMX_REQUIRE(h->ctx, AMX_ERR_STATE, "amx_gmm_best_density_dev: host-only handle (created without a context)");
+    AMX_REQUIRE(T >= 0, AMX_ERR_INVALID, "amx_gmm_best_density_dev: negative frame count");
+    AMX_REQUIRE(h->d_k_mean && h->d_k_cov && h->d_k_c64 && h->d_means && h->d_isr, AMX_ERR_UNSUPPORTED,
+                "amx_gmm_best_density_dev: the model's scorer keeps no diagonal-maximum tables on the device");
+    if (T == 0)
+        return AMX_OK;
+    AMX_REQUIRE(feats_dev && mixture_dev && best_density_dev, AMX_ERR_INVALID, "amx_gmm_best_density_dev: NULL buffer");
+    AMX_HIP(hipSetDevice(h->ctx->device));
+    amx::ScopedKernelTimer timer(h->ctx, "gmm_best_density");
+    hipLaunchKernelGGL(amx::gmm_best_density_kernel, dim3((T + 255) / 256), dim3(256), 0, h->ctx->stream, feats_dev, mixture_dev, best_density_dev,
+                       scores_dev, h->d_mix_off, h->d_k_mean, h->d_k_cov, h->d_k_c64, h->d_means, h->d_isr, T, h->dim, h->n_mix);
+    AMX_HIP(hipGetLastError());
     return AMX_OK;
 }
 

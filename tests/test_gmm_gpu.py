@@ -409,6 +409,63 @@ def test_score_stats_u8_rejects_wide_mixtures(ctx):
     assert "255" in str(e.value)
 
 
+@pytest.mark.parametrize("kind", ["cart", "cart-wide", "cart-dim33", "tied", "adversarial"])
+def test_best_density_of_the_aligned_mixture(ctx, kind):
+    """amx_gmm_best_density_dev = AssigningContextScorer::bestDensity(e) for one mixture per frame: index and score equal entry
+    (t, mixture[t]) of the full pass (which the other tests pin against the oracle) bit for bit -- also for out-of-range mixture
+    indices (0xffffffff / f32 max) -- and the Viterbi statistics accumulated from it (best_density_ld = 0) equal those taken from
+    the full best-density matrix"""
+    import torch
+
+    import rasr_amd
+    from oracle import OracleGmm
+    dim = 33 if kind == "cart-dim33" else 40
+    if kind in ("cart", "cart-dim33"):
+        model = synth.gmm_cart(333, 1, 16, dim, seed=720, pooled=True)
+    elif kind == "cart-wide":
+        model = synth.gmm_cart(40, 10, 24, dim, seed=721, pooled=False)
+    elif kind == "tied":
+        model = synth.gmm_tied(120, 64, dim, seed=722)
+    else:
+        model = _cart_adversarial(723, 83, dim, True)
+    M = len(model["mix_offsets"]) - 1
+    T = 1500
+    x = feats(T, dim, 724)
+    sc = rasr_amd.GmmFeatureScorer(ctx, model)
+    ref_scores, ref_best = sc.score(x)
+    rng = np.random.Generator(np.random.PCG64(725))
+    mix = rng.integers(0, M, T).astype(np.int32)
+    mix[:50] = ref_scores[:50].argmin(axis=1)
+    xd, md = torch.from_numpy(x).cuda(), torch.from_numpy(mix).cuda()
+    bd = torch.full((T,), 7, dtype=torch.int32, device="cuda")
+    sd = torch.zeros((T,), dtype=torch.float32, device="cuda")
+    ctx.use_torch_stream()
+    sc.best_density_dev(xd, T, md, bd, sd)
+    torch.cuda.synchronize()
+    assert np.array_equal(bd.cpu().numpy().astype(np.uint32), ref_best[np.arange(T), mix])
+    assert np.array_equal(sd.cpu().numpy().view(np.uint32), ref_scores[np.arange(T), mix].view(np.uint32))
+    osc, obest = OracleGmm(model).score(x[:64], mode=0)
+    assert np.array_equal(bd.cpu().numpy()[:64].astype(np.uint32), obest[np.arange(64), mix[:64]])
+    # statistics: per-frame indices (ld = 0) against the full matrix (ld = M)
+    full = torch.from_numpy(ref_best.astype(np.int32)).cuda()
+    acc_a = torch.zeros((sc.accumulator_size(),), dtype=torch.float64, device="cuda")
+    acc_b = torch.zeros_like(acc_a)
+    sc.accumulate_dev(xd, T, md, bd, 0, acc_a)
+    sc.accumulate_dev(xd, T, md, full, M, acc_b)
+    torch.cuda.synchronize()
+    a, b = acc_a.cpu().numpy(), acc_b.cpu().numpy()
+    nk = int(model["mix_offsets"][-1])
+    assert a[:nk].sum() == T and np.array_equal(a[:nk], b[:nk]) and np.allclose(a, b, rtol=1e-12, atol=0)
+    # a mixture index outside the model
+    md2 = md.clone()
+    md2[3] = M
+    sc.best_density_dev(xd, T, md2, bd, sd)
+    torch.cuda.synchronize()
+    assert int(bd[3].item()) == -1 and float(sd[3].item()) == np.float32(0.5) * np.finfo(np.float32).max
+    sc.best_density_dev(xd, T, md2, bd)   # scores are optional
+    torch.cuda.synchronize()
+
+
 def test_workspaces_regrow_between_calls(ctx):
     """the screen workspace, the fused-statistics partials and the host staging buffers of one handle grow with the batch:
     alternate small and large batches through the device and the host entry points"""
