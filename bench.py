@@ -740,7 +740,7 @@ class MfccOnly:
         gbs = self.F * per_frame / ((ms + lp) * 1e-3) / 1e9
         return dict(bound="hbm", kernel="mfcc_kernel<256>" + (" + lpc_cepstrum_kernel" if self.plp else ""), achieved=round(gbs, 1),
                     peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4),
-                    traffic=None if self.plp else measured_traffic("mfcc", "mfcc_kernel<256, 0>"), avg_launch_ms=round(ms + lp, 4),
+                    traffic=None if self.plp else measured_traffic("mfcc", "mfcc_kernel<256, 4>"), avg_launch_ms=round(ms + lp, 4),
                     launches=n, bytes_per_launch=self.F * per_frame)
 
     def stage_report(self):
