@@ -812,6 +812,9 @@ __global__ __launch_bounds__(mfcc_waves(NC) * 64, (NC >= 1024 ? 1 : ((VAR & 16) 
     // ================= phase C: mel filter bank + log10 for the whole tile (Signal/Filterbank.cc:65-71,
     // Flow/SimpleFunction.hh:40-49).  item = filter * FT + frame: the 64 lanes of a wave work on 4
     // neighbouring filters (similar supports, broadcast weights) x 16 frames; f32 sum in ascending bin order.
+    // (Dealing the groups of four filters to the waves by load -- widest first to the least loaded wave, so that no wave carries
+    // 4 + 12 + 40 trips while another carries 5 + 16 -- was measured too: 0.736-0.750 against 0.730-0.739 ms on one box, not kept; the
+    // waves' idle slots at the barrier belong to the CU's other three workgroups already.)
     for (int item = tid; item < p.n_filters * FT; item += MT) {
         const int flt = item / FT, f = item - flt * FT;
         const int b0 = s_fs[flt], b1 = s_fe[flt];
