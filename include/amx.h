@@ -112,8 +112,10 @@ typedef struct {
     int    boundary;               /* boundary: AMX_BOUNDARY_STRETCH_TO_COVER (0), _INCLUDE, _EMPHASIZE            */
     int    warping;                /* warping-function: AMX_WARP_MEL (0) or AMX_WARP_BARK                          */
     /* Kernel selection for A/B runs and tests, "key=value,key=value" (NULL: defaults; an unknown key fails amx_mfcc_create).  None
-     * of them changes a result beyond the parity bars.  fft=stockham|mfma (LDS radix-4 butterflies | the 256-point transform as
-     * two matrix products), wgs=N (workgroups per CU), lpc=regs|lds (LPC-cepstrum recursion in registers | the LDS kernel). */
+     * of them changes a result beyond the parity bars.  fft=stockham|mfma|r16 (LDS radix-4 butterflies | the 256-point transform as
+     * two matrix products | radix-16 register butterflies, four frames per wave: mfcc.flow with a 512-point transform only),
+     * prefetch=1|0 (a wave fetches its next frame's samples while it transforms the current one; default 1), wgs=N (workgroups
+     * per CU), lpc=regs|lds (LPC-cepstrum recursion in registers | the LDS kernel). */
     const char* tuning;
 } amx_mfcc_cfg;
 enum { AMX_FRONT_END_MFCC = 0, AMX_FRONT_END_MFPLP = 1, AMX_FRONT_END_PLP = 2 };
@@ -310,7 +312,7 @@ typedef struct {
      * scores and density indices bit for bit.  screen=0 (no MFMA / f32 screen: every density evaluated), fused=0 (two-kernel
      * screen path instead of gmm_fused_kernel), screen_kernel=rows|persist|simple, graph=0 (no HIP-graph replay of small batches),
      * tied_prune=0|1 (tied models: dense tile kernel | pruned scorer, default adaptive), chunk=N (frames per internal pass),
-     * fused_waves=8|12|16, fr=N (frames per workgroup of the uniform tied kernel), simd_mfma=0 (SIMD / batch-int scorers without
+     * fused_waves=8|12|16|13 (13: the wave-specialised kernel), fr=N (frames per workgroup of the uniform tied kernel), simd_mfma=0 (SIMD / batch-int scorers without
      * the i8 matrix kernel). */
     const char*     tuning;
 } amx_gmm_model;
@@ -501,7 +503,8 @@ typedef struct {
     /* Kernel selection for A/B runs and tests, "key=value,key=value" (NULL: defaults; an unknown key fails amx_ffnn_create).  Every
      * tile configuration of a precision gives bit-identical scores.  tile=N (GEMM tile configuration: 0 128x128, 2 256x256
      * pipelined, 3 128x64, 4 256x256 single-tile, 6 128x64 three stages; default by layer shape), graph=0 (no HIP-graph replay of
-     * small batches), persistent=0, group=TxN (tiles per XCD-aware super-tile), chunk=N (frames per internal pass). */
+     * small batches), persistent=0, group=TxN (tiles per XCD-aware super-tile), chunk=N (frames per internal pass),
+     * stagger=N (f16mx output layer of a large batch: XCD x starts x * N * 10 ns late; default 0). */
     const char*         tuning;
 } amx_ffnn_model;
 
