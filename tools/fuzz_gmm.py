@@ -52,6 +52,32 @@ for case in range(n_cases):
     want, wbest = o.score(x)
     got, best = rasr_amd.GmmFeatureScorer(ctx, model).score(x)
     ok = np.array_equal(got.view(np.uint32), want.view(np.uint32)) and np.array_equal(best, wbest)
+    # the byte form of the best-density matrix (amx_gmm_score_stats_u8_dev) and the best density / score of ONE mixture per frame
+    # (amx_gmm_best_density_dev), both against the oracle
+    import torch
+    sc_u8 = rasr_amd.GmmFeatureScorer(ctx, model)
+    M = want.shape[1]
+    ctx.use_torch_stream()
+    xd = torch.from_numpy(x).cuda()
+    s8 = torch.empty((T, M), dtype=torch.float32, device="cuda")
+    b8 = torch.empty((T, M), dtype=torch.uint8, device="cuda")
+    st = torch.empty((T,), dtype=torch.int32, device="cuda")
+    cn = torch.zeros((M,), dtype=torch.int64, device="cuda")
+    ss = torch.zeros((1,), dtype=torch.float64, device="cuda")
+    ok_u8 = True
+    if int(np.diff(model["mix_offsets"]).max()) <= 255:
+        sc_u8.score_stats_dev(xd, T, s8, b8, st, cn, ss)
+        torch.cuda.synchronize()
+        ok_u8 = (np.array_equal(s8.cpu().numpy().view(np.uint32), want.view(np.uint32)) and
+                 np.array_equal(b8.cpu().numpy(), np.where(wbest == 0xffffffff, 255, wbest).astype(np.uint8)))
+    mix = rng.integers(0, M, T).astype(np.int32)
+    bd = torch.empty((T,), dtype=torch.int32, device="cuda")
+    sd = torch.empty((T,), dtype=torch.float32, device="cuda")
+    sc_u8.best_density_dev(xd, T, torch.from_numpy(mix).cuda(), bd, sd)
+    torch.cuda.synchronize()
+    ok_bd = (np.array_equal(bd.cpu().numpy().astype(np.uint32), wbest[np.arange(T), mix]) and
+             np.array_equal(sd.cpu().numpy().view(np.uint32), want[np.arange(T), mix].view(np.uint32)))
+    ok = ok and ok_u8 and ok_bd
     sw, sb, _ = o.score_simd(x)
     sg, sgb = rasr_amd.GmmFeatureScorer(ctx, model, feature_scorer_type="SIMD-diagonal-maximum").score(x)
     ok_simd = np.array_equal(sg.view(np.uint32), sw.view(np.uint32)) and np.array_equal(sgb, sb)
