@@ -1672,6 +1672,7 @@ int score_screened(amx_gmm* h, const float* feats_dev, int T, float* scores_dev,
     const int   chunk = h->tune_chunk;  // frames per pass: the workspace (survivor masks, 2 B per frame and mixture slot) grows to what a call needs
     // one fused kernel (gmm_fused.hip) where its tile records exist; tuning fused=0 keeps the two-kernel path (A/B runs, tests)
     const bool fused = h->d_fus_rec && h->tune_fused && !h->tune_screen_all;
+    AMX_REQUIRE(best_bytes == 4 || (best_bytes == 1 && fused), AMX_ERR_STATE, "score_screened: byte-sized best densities exist on the fused path only");
     for (int t0 = 0; t0 < T; t0 += chunk) {
         const int Tc = std::min(chunk, T - t0), Tpad = (Tc + 255) / 256 * 256;
         if (Tpad > h->scr_cap_T || (!fused && !h->d_scr_masks)) {
