@@ -298,7 +298,7 @@ def gmm_cart_roofline(ctx, sc, nk, n_mix, dim, frames, best_bytes=4):
         per_launch = surv / float(n_x)
         ex = per_launch * 4.0 * dim
         by = frames * (n_mix * (4.0 + best_bytes) + dim * 4.0) + (n_mix + 15) // 16 * 78848.0
-        scr = 2.0 * 64 * ((n_mix + 15) // 16 * 256) * frames
+        scr = 2.0 * (16 * ((dim + 2 + 15) // 16)) * ((n_mix + 15) // 16 * 256) * frames   # K-steps that hold non-zero columns (dim + 2)
         return dict(bound="valu", kernel="gmm_fused_kernel<%d> (f16 MFMA screen + exact f32/f64 evaluation of the survivors)" % dim,
                     note="VALU-issue-bound kernel priced against the f32 vector peak (157.3 TFLOP/s; unfused mul/add can "
                          "reach half of it). achieved = densities evaluated exactly (device counter) x 4 dim f32 operations / kernel time",

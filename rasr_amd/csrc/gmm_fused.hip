@@ -141,9 +141,14 @@ __global__ __launch_bounds__(NW * 64) void gmm_fused_kernel(const float* __restr
 #pragma unroll
     for (int i = 0; i < DIM; ++i)
         x[i] = g_feats[(size_t)tt * DIM + i];
-    fus_f16x8 bx[4];
+    // K-steps of the screen: the operand rows are 64 f16 wide, but only DIM + 2 columns are used (a = -2 mu / sigma^2 and the constant as
+    // c_hi + c_lo; pooled covariance) -- the columns behind them are zero in both operands, so their products are skipped: 3 matrix
+    // instructions per block instead of 4 for dim 32-40, 2 for dim 16-24 (the masks, built from sums that only lose zero terms, stay the same)
+    constexpr int KS = (DIM + 2 + 15) / 16;
+    static_assert(KS >= 1 && KS <= 4, "screen operand rows hold 64 columns");
+    fus_f16x8 bx[KS];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
+    for (int ks = 0; ks < KS; ++ks)
         bx[ks] = *(const fus_f16x8*)(g_X + (size_t)tx * 64 + (ks * 2 + fk) * 8);
     const float nx = g_nx[tx], q = g_q[tx];
     const bool  all = !(nx < __builtin_inff());  // operand row did not fit f16: keep every slot
@@ -199,7 +204,7 @@ __global__ __launch_bounds__(NW * 64) void gmm_fused_kernel(const float* __restr
             for (int e = 0; e < 16; ++e)
                 c[e] = 0.f;
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
+            for (int ks = 0; ks < KS; ++ks) {
                 const fus_f16x8 a = *(const fus_f16x8*)(stage + rr * 128 + (((ks * 2 + fk) ^ ((rr >> 1) & 7)) << 4));
                 c                 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bx[ks], c, 0, 0, 0);
             }
