@@ -9,8 +9,12 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, "liboracle.so")
-_REF = os.path.join(_HERE, "_ref", "libref.so")
+# The reference has two arithmetics (orc.h): contract "off" = built for plain x86-64 (-msse3), "fma" = its default -march=native build
+# on an FMA host.  One oracle library and one flavour of the compiled reference per mode.
+CONTRACTS = ("off", "fma")
+_LIBS = {"off": os.path.join(_HERE, "liboracle.so"), "fma": os.path.join(_HERE, "liboracle_fma.so")}
+_REFS = {"off": os.path.join(_HERE, "_ref", "libref.so"), "fma": os.path.join(_HERE, "_ref", "libref_native.so")}
+_SRCS = ("orc_mfcc.c", "orc_score.c", "orc_backend.c", "orc_gammatone.c")
 
 f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
 f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
@@ -57,53 +61,71 @@ class _FfnnModel(C.Structure):
 
 def build_oracle(force=False):
     """gcc-compile oracle/liboracle.so (and _ref/libref.so when the reference tree is mounted)."""
-    if force or not os.path.exists(_LIB) or any(
-            os.path.getmtime(os.path.join(_HERE, s)) > os.path.getmtime(_LIB)
-            for s in ("orc_mfcc.c", "orc_score.c", "orc_backend.c", "orc_gammatone.c", "orc.h")):
-        subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
-    if os.path.isdir("/root/reference/src") and (force or not os.path.exists(_REF)):
+    if force or any(not os.path.exists(lib) or any(os.path.getmtime(os.path.join(_HERE, s)) > os.path.getmtime(lib) for s in _SRCS + ("orc.h",))
+                    for lib in _LIBS.values()):
+        subprocess.check_call(["make", "-C", _HERE, "all"], stdout=subprocess.DEVNULL)
+    if os.path.isdir("/root/reference/src") and (force or not all(os.path.exists(r) for r in _REFS.values())):
         subprocess.check_call(["make", "-C", os.path.join(_HERE, "ref")], stdout=subprocess.DEVNULL)
 
 
-_lib = None
-_NATIVE = None   # path of the -march=native build (bench.py's cpu_baseline only), see build_native_oracle
+_libs = {}
+_NATIVE = {}     # contract -> path of the -march=native build (bench.py's cpu_baseline only), see build_native_oracle
+_use_native = False
+DEFAULT_CONTRACT = "off"
 
 
-def build_native_oracle():
-    """The same sources with the reference's "standard" optimisation flags for THIS host (-O3 -march=native; -ffp-contract=off
-    keeps one rounding per operation, i.e. the results of the -O2 checker library), into a temporary directory: the file is
-    host-specific and must not travel.  Used by bench.py's cpu_baseline, never by the tests."""
-    global _NATIVE
-    if _NATIVE and os.path.exists(_NATIVE):
-        return _NATIVE
+def build_native_oracle(contract="off"):
+    """The same sources tuned for THIS host (-O3 -march=native), into a temporary directory: the file is host-specific and must not
+    travel.  -ffp-contract=off in both modes -- the compiler fuses nothing on its own, so the results are those of the -O2 checker
+    library of the same mode; contract "fma" adds -DORC_CONTRACT_FMA, and with -march=native its fmaf() sites become vfmadd
+    instructions, i.e. the instruction mix of the reference's DEFAULT build (-march=native, GCC's -ffp-contract=fast).  Used by
+    bench.py's cpu_baseline, never by the tests."""
+    if _NATIVE.get(contract) and os.path.exists(_NATIVE[contract]):
+        return _NATIVE[contract]
     import tempfile
-    out = os.path.join(tempfile.gettempdir(), "liboracle_native_%d.so" % os.getuid())
-    srcs = [os.path.join(_HERE, f) for f in ("orc_mfcc.c", "orc_score.c", "orc_backend.c", "orc_gammatone.c")]
-    if not os.path.exists(out) or any(os.path.getmtime(f) > os.path.getmtime(out) for f in srcs):
+    out = os.path.join(tempfile.gettempdir(), "liboracle_native_%s_%d.so" % (contract, os.getuid()))
+    srcs = [os.path.join(_HERE, f) for f in _SRCS]
+    if not os.path.exists(out) or any(os.path.getmtime(f) > os.path.getmtime(out) for f in srcs + [os.path.join(_HERE, "orc.h")]):
         tmp = out + ".%d.tmp" % os.getpid()
-        subprocess.check_call(["gcc", "-O3", "-march=native", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-std=gnu11", "-w",
-                               "-shared", "-o", tmp] + srcs + ["-lm"])
+        subprocess.check_call(["gcc", "-O3", "-march=native", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-std=gnu11", "-w"] +
+                              (["-DORC_CONTRACT_FMA"] if contract == "fma" else []) + ["-shared", "-o", tmp] + srcs + ["-lm"])
         os.replace(tmp, out)
-    _NATIVE = out
+    _NATIVE[contract] = out
     return out
 
 
 def use_native_oracle():
-    """make Oracle() of this process load the -march=native build (call before the first Oracle())"""
-    global _lib, _LIB
-    _LIB = build_native_oracle()
-    _lib = None
+    """make Oracle() of this process load the -march=native builds (call before the first Oracle())"""
+    global _use_native
+    _use_native = True
+    _libs.clear()
 
 
-def Oracle():
-    global _lib
-    if _lib is not None:
-        return _lib
-    if _LIB == _NATIVE and _NATIVE is not None:
-        pass  # already built by build_native_oracle
+def set_default_contract(contract):
+    """the mode Oracle() and the Oracle* classes use when none is named (bench.py's cpu_baseline worker processes)"""
+    global DEFAULT_CONTRACT
+    assert contract in CONTRACTS, contract
+    DEFAULT_CONTRACT = contract
+
+
+def Oracle(contract=None):
+    """the oracle library that restates the reference's `contract` build ("off" | "fma"; None = DEFAULT_CONTRACT)"""
+    contract = DEFAULT_CONTRACT if contract is None else contract
+    assert contract in CONTRACTS, contract
+    if contract in _libs:
+        return _libs[contract]
+    if _use_native:
+        path = build_native_oracle(contract)
     else:
         build_oracle()
-    L = C.CDLL(_LIB)
+        path = _LIBS[contract]
+    L = C.CDLL(path)
+    L.orc_contract.restype = C.c_int
+    assert L.orc_contract() == (1 if contract == "fma" else 0), "%s restates the other build" % path
+    L.orc_gmm_distance.restype = C.c_float
+    L.orc_gmm_distance.argtypes = [f32p, f32p, f32p, C.c_int]
+    L.orc_filter_apply.restype = C.c_float
+    L.orc_filter_apply.argtypes = [f32p, C.c_int, C.c_int, f32p]
     L.orc_mfcc_create.restype = C.c_void_p
     L.orc_mfcc_create.argtypes = [C.POINTER(MfccCfg)]
     L.orc_mfcc_destroy.argtypes = [C.c_void_p]
@@ -153,24 +175,25 @@ def Oracle():
     L.orc_gmm_accumulate.argtypes = [C.c_void_p, f32p, C.c_int, u32p, u32p, f64p]
     L.orc_gmm_accumulate_weighted.argtypes = [C.c_void_p, C.c_int, f32p, C.c_int, u32p, C.c_void_p, C.c_void_p, f64p]
     L.orc_ffnn_score.argtypes = [C.POINTER(_FfnnModel), f32p, C.c_int, f32p, C.c_int]
-    _lib = L
+    _libs[contract] = L
     return L
 
 
-_ref = None
+_refs = {}
 
 
-def load_ref():
-    """oracle/_ref/libref.so (reference TUs compiled unmodified) or None when not built."""
-    global _ref
-    if _ref is not None:
-        return _ref
-    if not os.path.exists(_REF):
+def load_ref(contract="off"):
+    """oracle/_ref/libref.so (contract "off": reference TUs compiled unmodified with -msse3) or libref_native.so (contract "fma":
+    the same with the reference's default -march=native, host-specific, build container only); None when not built."""
+    if contract in _refs:
+        return _refs[contract]
+    path = _REFS[contract]
+    if not os.path.exists(path):
         if os.path.isdir("/root/reference/src"):
             build_oracle()
-        if not os.path.exists(_REF):
+        if not os.path.exists(path):
             return None
-    R = C.CDLL(_REF)
+    R = C.CDLL(path)
     R.ref_fft_real.argtypes = [f32p, C.c_int]
     R.ref_fft_complex.argtypes = [f32p, C.c_int]
     for n in ("ref_mel", "ref_mel_derivative", "ref_mel_inverse", "ref_bark", "ref_bark_derivative", "ref_bark_inverse"):
@@ -210,7 +233,13 @@ def load_ref():
         R.ref_matrix_vector.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         R.ref_complex_amplitude.restype = C.c_int
         R.ref_complex_amplitude.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
-    _ref = R
+    if hasattr(R, "ref_gdm_distance"):   # function-text pins (oracle/ref/extract_fn.py)
+        R.ref_gdm_distance.restype = C.c_float
+        R.ref_gdm_distance.argtypes = [f32p, f32p, f32p, C.c_int]
+        R.ref_regression.argtypes = [C.c_int, f32p, C.c_int, C.c_int, f32p]
+        R.ref_filter_apply.restype = C.c_float
+        R.ref_filter_apply.argtypes = [f32p, C.c_int, C.c_int, C.c_int, f32p]
+    _refs[contract] = R
     return R
 
 
@@ -245,8 +274,8 @@ def oracle_vector_normalize(x, kind):
     return out
 
 
-def oracle_regression(x, order=1, right=2):
-    L = Oracle()
+def oracle_regression(x, order=1, right=2, contract=None):
+    L = Oracle(contract)
     x = np.ascontiguousarray(x, np.float32)
     out = np.empty_like(x)
     L.orc_regression.argtypes = [f32p, C.c_int, C.c_int, C.c_int, C.c_int, f32p]
@@ -254,8 +283,8 @@ def oracle_regression(x, order=1, right=2):
     return out
 
 
-def oracle_matrix_multiply(M, x):
-    L = Oracle()
+def oracle_matrix_multiply(M, x, contract=None):
+    L = Oracle(contract)
     M = np.ascontiguousarray(M, np.float32)
     x = np.ascontiguousarray(x, np.float32)
     out = np.empty((x.shape[0], M.shape[0]), np.float32)
@@ -332,8 +361,8 @@ def ref_normalized_minus(x, y, weight):
 
 
 class OracleMfcc:
-    def __init__(self, cfg=None, **kw):
-        self.L = Oracle()
+    def __init__(self, cfg=None, contract=None, **kw):
+        self.L = Oracle(contract)
         self.cfg = cfg if cfg is not None else MfccCfg.default(**kw)
         self.h = self.L.orc_mfcc_create(C.byref(self.cfg))
         if not self.h:
@@ -406,8 +435,10 @@ class OracleGmm:
     """model: dict with dim, mix_offsets(u32), dens_index(u32), log_weight(f64), dens_mean, dens_cov (u32),
     means [n_mean,dim] f32, variances [n_cov,dim] f32."""
 
-    def __init__(self, model, mixture_weight_scale=1.0, gaussian_scale=1.0):
-        self.L = Oracle()
+    def __init__(self, model, mixture_weight_scale=1.0, gaussian_scale=1.0, contract=None):
+        """contract: which build of the reference to restate -- "off" (-DMARCH=x86-64: no fused multiply-add) or "fma" (its default
+        -march=native build on an FMA host: `sum += df * df` of the distance is one fused operation); None = the module default"""
+        self.L = Oracle(contract)
         self.m = {k: (np.ascontiguousarray(v) if isinstance(v, np.ndarray) else v) for k, v in model.items()}
         m = self.m
         self.n_mix = len(m["mix_offsets"]) - 1

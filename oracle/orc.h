@@ -7,8 +7,21 @@
  *
  * Plain C, no dependency on the reference tree.  Every function cites the reference
  * file:line whose arithmetic it restates (paths relative to /root/reference/src).
- * The library is compiled with -ffp-contract=off so that every f32 / f64 operation
- * rounds exactly once, like the reference's x86-64 (SSE, no FMA) build.
+ *
+ * THE REFERENCE HAS TWO ARITHMETICS, and so has this library (cmake_resources/CompileOptions.cmake:21-48):
+ *   contract=off  liboracle.so      the reference configured with -DMARCH=x86-64 (or built on a host without FMA units): -msse3 only,
+ *                                   every f32 / f64 operation rounds once.
+ *   contract=fma  liboracle_fma.so  the reference's DEFAULT configuration (MARCH defaults to "native") on any FMA host: GCC's default
+ *                                   -ffp-contract=fast (the build uses gnu++20) fuses a product whose only use is an addition or
+ *                                   subtraction into one fused multiply-add.  The same sources with -DORC_CONTRACT_FMA: the sites
+ *                                   where GCC contracts are written ORC_FMAF / ORC_FMA (everything else is compiled with
+ *                                   -ffp-contract=off in BOTH flavours, so the flavours differ at exactly those sites).
+ * Which sites: read off the reference built both ways (oracle/ref/Makefile: libref.so / libref_native.so, objdump of the native
+ * objects) -- the GMM distance's `sum += df * df` (vfmadd231ps / vfmadd231ss, function-text pin gdm_distance), the f32 dot product
+ * of Math::Vector (cosine transform), gaussLogNormFactor's N * log(2 pi) + sum (f64).  Sites in translation units that cannot be
+ * compiled here follow GCC's rule by reading (filter bank apply, batch-float accumulate, preemphasis, back-end sums) and say so.
+ * NOT restated in fma form: the FFT's f64 twiddle recurrences (14 fused operations in the native object; the f32 results were
+ * bit-identical to the plain build on every frame tried, tests/test_contract.py) and the f4 front ends / quantised scorers.
  *
  * Pinning status (see DESIGN.md "Oracle"):
  *   FFT core, framing/flush, mel warp/derivative/inverse, GMM logNorm / 1/sqrt(var):
@@ -28,6 +41,17 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+
+/* a * b + c as the reference's build evaluates it at a site GCC contracts (see the header comment) */
+#ifdef ORC_CONTRACT_FMA
+#define ORC_FMAF(a, b, c) __builtin_fmaf((a), (b), (c))
+#define ORC_FMA(a, b, c) __builtin_fma((a), (b), (c))
+#else
+#define ORC_FMAF(a, b, c) ((a) * (b) + (c))
+#define ORC_FMA(a, b, c) ((a) * (b) + (c))
+#endif
+/* 0 = this library restates the contract=off build, 1 = contract=fma */
+int orc_contract(void);
 
 /* ---------------------------------------------------------------- MFCC chain */
 
@@ -143,6 +167,7 @@ int    orc_levinson(const float* R, int n, float* gain, float* a);
 /* Signal::autoregressionToCepstrum (Signal/AutoregressionToCepstrum.cc:21-35): c [nc], 2 <= nc <= na + 1 */
 void   orc_ar_to_cepstrum(float gain, const float* a, int na, float* c, int nc);
 void   orc_preemphasis(float* x, long n, float alpha);            /* in place, segment start */
+float  orc_filter_apply(const float* in, int start, int end, const float* weights); /* one filter of the bank: sum over bins [start, end) */
 void   orc_fft_real(float* v, int n);                             /* Math::FastFourierTransform::transformReal */
 void   orc_fft_complex(float* v, int n_floats);                   /* ::transform (forward) */
 double orc_mel(double f);                                         /* continuous-domain mel warp */
@@ -174,6 +199,8 @@ const float* orc_gmm_log_norm(const orc_gmm* h);           /* [n_cov] */
 /* mode 0 = maximum approximation, 1 = log-add.  feats [T x dim] row-major;
  * scores [T x n_mix]; best [T x n_mix] density-in-mixture index (nullable) */
 void orc_gmm_score(const orc_gmm* h, int mode, const float* feats, int T, float* scores, uint32_t* best);
+/* GaussDiagonalMaximumFeatureScorer::distance alone (pinned by tests/test_contract.py on the reference's own function text) */
+float orc_gmm_distance(const float* x, const float* mu, const float* inv_sqrt_var, int dim);
 /* Mm::BatchFloatFeatureScorer arithmetic (pooled covariance only, n_cov == 1) */
 int orc_gmm_score_preselection_float(const orc_gmm* h, const double* log_weight, const float* variances, const float* feats, int T,
                                      int n_clusters, int n_select, int iterations, float backoff, float* scores,

@@ -1,9 +1,13 @@
 /* oracle/orc_backend.c -- CPU restatement of the feature back-end between the front-end and the scorers
  * (SURVEY.md section 8 row f1).  TEST INFRASTRUCTURE (see orc.h).
  *
- * PARITY UNPINNED against the reference: Signal/Normalization.cc, Regression.cc and MatrixMult.hh sit on Flow::Node /
- * Core::Configuration (boost) and cannot be compiled here, and the reference has no test vectors for them.  Each
- * function follows the cited source lines operation by operation (types, order of the f32 / f64 operations).
+ * Signal/Normalization.cc, Regression.cc and MatrixMult.hh sit on Flow::Node / Core::Configuration (boost) and cannot be compiled
+ * here as translation units, and the reference has no test vectors for them.  Each function follows the cited source lines
+ * operation by operation (types, order of the f32 / f64 operations).  Pinned since round 5: orc_regression on the text of
+ * Signal::Regression::regressFirstOrder / regressSecondOrder compiled stand-alone in both flag sets (function-text pin
+ * `regression`, oracle/ref/extract_fn.py; tests/test_contract.py), orc_matrix_multiply's row product on Math::Matrix x Vector in
+ * both flavours of libref.  Normalisation: PARITY UNPINNED (its sums are contraction-insensitive: the f64 product of two widened f32
+ * values is exact, so `sumSquare += (Sum)x * (Sum)x` gives the same bits fused or not).
  */
 #include "orc.h"
 
@@ -178,8 +182,8 @@ void orc_regression(const float* in, int n, int dim, int order, int right, float
                 const float* f  = in + (size_t)tt * dim;
                 const float  dt = (float)((double)(float)i - (double)(float)(len - 1) / 2.0);
                 for (int c = 0; c < dim; ++c)
-                    o[c] += dt * f[c];
-                tm += dt * dt;
+                    o[c] = ORC_FMAF(dt, f[c], o[c]); /* native build: vfmadd213ss */
+                tm = ORC_FMAF(dt, dt, tm);           /* vfmadd231ss */
             }
             for (int c = 0; c < dim; ++c)
                 o[c] /= tm;
@@ -188,18 +192,20 @@ void orc_regression(const float* in, int n, int dim, int order, int right, float
             float tm = 0.0f, ns = 0.0f;
             for (int i = 0; i < len; ++i) {
                 const float dt = (float)((double)(float)i - (double)(float)(len - 1) / 2.0);
+                /* dt * dt feeds both sums: a product with a second use that is not an addition stays a product (vmulss, vaddss),
+                 * the last product of the fourth power is fused (vfmadd231ss) */
                 tm += dt * dt;
-                ns += dt * dt * dt * dt;
+                ns = ORC_FMAF(dt * dt * dt, dt, ns);
             }
-            ns = tm * tm - (float)len * ns;
+            ns = ORC_FMAF(tm, tm, -((float)len * ns)); /* vmulss, vfmsub231ss */
             for (int i = 0; i < len; ++i) {
                 int tt = t - right + i;
                 tt     = tt < 0 ? 0 : (tt >= n ? n - 1 : tt);
                 const float* f  = in + (size_t)tt * dim;
                 const float  dt = (float)((double)(float)i - (double)(float)(len - 1) / 2.0);
                 for (int c = 0; c < dim; ++c) {
-                    o[c] += f[c] * tm;
-                    o[c] -= f[c] * dt * dt * (float)len;
+                    o[c] = ORC_FMAF(f[c], tm, o[c]);                      /* vfmadd213ss */
+                    o[c] = ORC_FMAF(-(f[c] * dt * dt), (float)len, o[c]); /* vmulss, vmulss, vfnmadd213ss */
                 }
             }
             for (int c = 0; c < dim; ++c)
@@ -215,7 +221,7 @@ void orc_matrix_multiply(const float* M, int rows, int cols, const float* in, in
         for (int r = 0; r < rows; ++r) {
             float acc = 0.0f;
             for (int k = 0; k < cols; ++k)
-                acc = acc + M[(size_t)r * cols + k] * in[(size_t)t * cols + k];
+                acc = ORC_FMAF(M[(size_t)r * cols + k], in[(size_t)t * cols + k], acc); /* Math::Vector::operator*, vfmadd231ss */
             out[(size_t)t * rows + r] = acc;
         }
 }

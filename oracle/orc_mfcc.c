@@ -44,8 +44,7 @@ void orc_preemphasis(float* x, long n, float alpha) {
     if (alpha != 1.0) {
         for (long i = 0; i < n; ++i) {
             float cur  = x[i];
-            float prod = alpha * prev;
-            x[i]       = cur - prod;
+            x[i]       = ORC_FMAF(-alpha, prev, cur); /* v[i] -= alpha_ * previous_: vfnmadd under contraction (by rule; TU needs boost) */
             prev       = cur;
         }
     }
@@ -546,6 +545,15 @@ long orc_mfcc_n_frames(const orc_mfcc* h, long n) {
     return (n - L + h->frame_shift - 1) / h->frame_shift + 1;
 }
 
+/* FilterBank::Filter::apply (Signal/Filterbank.cc:65-71): `result += in[f] * weights_[f - start_]`, f32, ascending bin -- one
+ * vfmadd231ss in the native build; pinned in both flavours by the function-text pin ref_filter_apply (oracle/ref/extract_fn.py) */
+float orc_filter_apply(const float* in, int start, int end, const float* weights) {
+    float acc = 0;
+    for (int b = start; b < end; ++b)
+        acc = ORC_FMAF(in[b], weights[b - start], acc);
+    return acc;
+}
+
 static void orc_frame(const orc_mfcc* h, const float* pre, long n_samples, long frame,
                       float* windowed, float* spectrum, float* amplitude, float* mel,
                       float* logmel, float* ceps) {
@@ -585,17 +593,9 @@ static void orc_frame(const orc_mfcc* h, const float* pre, long n_samples, long 
     if (h->cfg.front_end != 0)
         for (int k = 0; k < h->n_bins; ++k)
             amp[k] = (float)pow((double)amp[k], (double)2.0f);
-    /* FilterBank::Filter::apply (Signal/Filterbank.cc:65-71): f32 accumulate, ascending bin */
     float fb[h->n_filters];
-    for (int f = 0; f < h->n_filters; ++f) {
-        float        acc = 0;
-        const float* w   = h->f_weights + h->f_off[f];
-        for (int b = h->f_start[f]; b < h->f_end[f]; ++b) {
-            float prod = amp[b] * w[b - h->f_start[f]];
-            acc        = acc + prod;
-        }
-        fb[f] = acc;
-    }
+    for (int f = 0; f < h->n_filters; ++f)
+        fb[f] = orc_filter_apply(amp, h->f_start[f], h->f_end[f], h->f_weights + h->f_off[f]);
     if (mel)
         memcpy(mel, fb, (size_t)h->n_filters * sizeof(float));
     if (h->cfg.front_end != 0) {
@@ -627,10 +627,8 @@ static void orc_frame(const orc_mfcc* h, const float* pre, long n_samples, long 
             for (int k = 0; k < nac; ++k) {
                 float        acc = 0;
                 const float* row = h->dct + (size_t)k * n_in;
-                for (int n = 0; n < n_in; ++n) {
-                    float prod = row[n] * ext[n];
-                    acc        = acc + prod;
-                }
+                for (int n = 0; n < n_in; ++n)
+                    acc = ORC_FMAF(row[n], ext[n], acc);
                 if (h->cfg.dct_normalize)
                     acc = acc / (float)(n_in - 1);
                 R[k] = acc;
@@ -653,10 +651,8 @@ static void orc_frame(const orc_mfcc* h, const float* pre, long n_samples, long 
         for (int k = 0; k < h->n_ceps; ++k) {
             float        acc = 0;
             const float* row = h->dct + (size_t)k * h->n_filters;
-            for (int n = 0; n < h->n_filters; ++n) {
-                float prod = row[n] * fb[n];
-                acc        = acc + prod;
-            }
+            for (int n = 0; n < h->n_filters; ++n)
+                acc = ORC_FMAF(row[n], fb[n], acc); /* Math::Vector::operator*: result += a[i] * b[i] -- one vfmadd231ss in the native build of ref_matrix_vector */
             if (h->cfg.dct_normalize)
                 acc = acc / (float)h->n_filters;
             ceps[k] = acc;

@@ -7,7 +7,8 @@
  *   Nn::BatchFeatureScorer forward (Nn/BatchFeatureScorer.cc:148-171, Nn/LinearLayer.cc:298-324,
  *       Nn/ActivationLayer.cc:272-282, Nn/LinearAndActivationLayer.hh:137-160)
  *
- * Compile with -ffp-contract=off: the reference's x86-64 build has no fused multiply-add.
+ * Compile with -ffp-contract=off in both flavours (orc.h): the reference built for plain x86-64 (-msse3) has no fused
+ * multiply-add; its default build (-march=native on an FMA host) fuses exactly the sites written ORC_FMAF / ORC_FMA here.
  */
 #include "orc.h"
 
@@ -66,7 +67,7 @@ orc_gmm* orc_gmm_create(const orc_gmm_model* m) {
             /* logNorm: log(double) of the f32 value, f64 accumulation */
             ln += log((double)fabsf(var[i]));
         }
-        double g      = (double)m->dim * log((double)2 * M_PI) + ln;
+        double g      = ORC_FMA((double)m->dim, log((double)2 * M_PI), ln); /* gaussLogNormFactor: N * log(2 pi) + logNorm, one vfmadd in the native build */
         float  f      = (float)g;
         h->lognorm[c] = f * (gs * gs); /* logNormalizationFactor_ *= factor * factor (f32) */
     }
@@ -87,12 +88,22 @@ void orc_gmm_destroy(orc_gmm* h) {
     free(h);
 }
 
+int orc_contract(void) {
+#ifdef ORC_CONTRACT_FMA
+    return 1;
+#else
+    return 0;
+#endif
+}
+
 const float* orc_gmm_minus2_log_weights(const orc_gmm* h) { return h->m2lw; }
 const float* orc_gmm_inv_sqrt_var(const orc_gmm* h) { return h->isr; }
 const float* orc_gmm_log_norm(const orc_gmm* h) { return h->lognorm; }
 
 /* GaussDiagonalMaximumFeatureScorer::distance, __SSE3__ branch (:144-180): four strided f32
- * partial sums, hadd => (l0+l1),(l2+l3); result = 0 + ((l0+l1)+(l2+l3)); scalar tail. */
+ * partial sums, hadd => (l0+l1),(l2+l3); result = 0 + ((l0+l1)+(l2+l3)); scalar tail.
+ * `sum += df * df` and the tail's `result += df * df` are the contracted sites (native build: vfmadd231ps, vfmadd231ss);
+ * pinned in both flavours by the function-text pin ref_gdm_distance (oracle/ref/extract_fn.py, tests/test_contract.py). */
 static float orc_distance(const float* x, const float* mu, const float* isr, int dim) {
     float l0 = 0, l1 = 0, l2 = 0, l3 = 0;
     int   eff = dim & ~3;
@@ -102,10 +113,10 @@ static float orc_distance(const float* x, const float* mu, const float* isr, int
         float d1 = (mu[i + 1] - x[i + 1]) * isr[i + 1];
         float d2 = (mu[i + 2] - x[i + 2]) * isr[i + 2];
         float d3 = (mu[i + 3] - x[i + 3]) * isr[i + 3];
-        l0       = l0 + d0 * d0;
-        l1       = l1 + d1 * d1;
-        l2       = l2 + d2 * d2;
-        l3       = l3 + d3 * d3;
+        l0       = ORC_FMAF(d0, d0, l0);
+        l1       = ORC_FMAF(d1, d1, l1);
+        l2       = ORC_FMAF(d2, d2, l2);
+        l3       = ORC_FMAF(d3, d3, l3);
     }
     float h01    = l0 + l1;
     float h23    = l2 + l3;
@@ -113,10 +124,12 @@ static float orc_distance(const float* x, const float* mu, const float* isr, int
     result       = result + (h01 + h23);
     for (; i < dim; ++i) {
         float df = (mu[i] - x[i]) * isr[i];
-        result   = result + df * df;
+        result   = ORC_FMAF(df, df, result);
     }
     return result;
 }
+
+float orc_gmm_distance(const float* x, const float* mu, const float* isr, int dim) { return orc_distance(x, mu, isr, dim); }
 
 void orc_gmm_score(const orc_gmm* h, int mode, const float* feats, int T, float* scores, uint32_t* best) {
     int    maxk = 0;
@@ -198,7 +211,7 @@ int orc_gmm_score_batch_float(const orc_gmm* h, const double* log_weight, const 
         isr[i] = (float)1 / (float)sqrt((double)variances[i]);
         ln += log((double)fabsf(variances[i]));
     }
-    float  lognorm = (float)((double)dim * log((double)2 * M_PI) + ln);
+    float  lognorm = (float)ORC_FMA((double)dim, log((double)2 * M_PI), ln);
     float* xs      = (float*)calloc((size_t)pdim, 4);
     float* ms      = (float*)calloc(nk * (size_t)pdim, 4);
     float* cst     = (float*)calloc(nk, 4);
@@ -219,9 +232,9 @@ int orc_gmm_score_batch_float(const orc_gmm* h, const double* log_weight, const 
                 for (int d = 0; d < pdim; d += 8)
                     for (int j = 0; j < 4; ++j) {
                         float x1 = mu[d + j] - xs[d + j];
-                        s1[j]    = s1[j] + x1 * x1;
+                        s1[j]    = ORC_FMAF(x1, x1, s1[j]); /* _mm_add_ps(s1, _mm_mul_ps(x1, x1)): contracted by rule (TU needs boost) */
                         float x2 = mu[d + 4 + j] - xs[d + 4 + j];
-                        s2[j]    = s2[j] + x2 * x2;
+                        s2[j]    = ORC_FMAF(x2, x2, s2[j]);
                     }
                 float a0 = s1[0] + s2[0], a1 = s1[1] + s2[1], a2 = s1[2] + s2[2], a3 = s1[3] + s2[3];
                 float r = (a3 + a1) + (a2 + a0);
@@ -294,7 +307,7 @@ int orc_gmm_score_preselection_float(const orc_gmm* h, const double* log_weight,
         isr[i] = (float)1 / (float)sqrt((double)variances[i]);
         ln += log((double)fabsf(variances[i]));
     }
-    float  lognorm = (float)((double)dim * log((double)2 * M_PI) + ln);
+    float  lognorm = (float)ORC_FMA((double)dim, log((double)2 * M_PI), ln);
     float* xs      = (float*)calloc((size_t)pdim, 4);
     float* ms      = (float*)calloc(nk * (size_t)pdim, 4);
     float* cst     = (float*)calloc(nk, 4);
@@ -370,9 +383,9 @@ int orc_gmm_score_preselection_float(const orc_gmm* h, const double* log_weight,
                 for (int d = 0; d < pdim; d += 8)
                     for (int j = 0; j < 4; ++j) {
                         float x1 = mu[d + j] - xs[d + j];
-                        s1[j]    = s1[j] + x1 * x1;
+                        s1[j]    = ORC_FMAF(x1, x1, s1[j]); /* _mm_add_ps(s1, _mm_mul_ps(x1, x1)): contracted by rule (TU needs boost) */
                         float x2 = mu[d + 4 + j] - xs[d + 4 + j];
-                        s2[j]    = s2[j] + x2 * x2;
+                        s2[j]    = ORC_FMAF(x2, x2, s2[j]);
                     }
                 float a0 = s1[0] + s2[0], a1 = s1[1] + s2[1], a2 = s1[2] + s2[2], a3 = s1[3] + s2[3];
                 float r = (a3 + a1) + (a2 + a0);

@@ -1,0 +1,158 @@
+#!/usr/bin/env python3
+"""oracle/ref/extract_fn.py -- FUNCTION-TEXT pins: reference member functions compiled stand-alone.  TEST INFRASTRUCTURE.
+
+Some arithmetic of the hot path lives in translation units that cannot be built here as a whole (anything that reaches
+Core/Configuration.hh needs boost, which the image lacks).  For a function whose BODY touches nothing but its arguments, the
+text of the definition is taken from where it lies under /root/reference at build time -- by line range, checked against a
+SHA-256 so that a moved or edited function fails the build instead of silently pinning something else -- and written into
+oracle/_ref/gen/ between a class shell that only declares the member (the real class declaration pulls in the configuration
+headers) and a C entry point.  Nothing of the reference's text is stored in this repository: the generated file exists only under
+oracle/_ref/ (git-ignored) and only where the reference tree is mounted.
+
+What such a pin proves, and what it does not: the function's own operations, in the reference's own words, compiled with the
+flag sets of oracle/ref/Makefile (so the compiler's contraction decisions are the real ones); NOT the class around it.
+
+    python3 extract_fn.py <name> <out.cc>
+"""
+import hashlib
+import sys
+
+REF = "/root/reference/src"
+
+# name -> (file, [(first line, last line (inclusive)), ...], sha256 of those lines concatenated, text in front, text behind)
+SPECS = {
+    # Mm::GaussDiagonalMaximumFeatureScorer::distance (both the __SSE3__ branch and the plain one; the flag sets of the Makefile
+    # define __SSE3__, so the first is what gets compiled -- as in the reference's own build, CompileOptions.cmake:21-26)
+    "gdm_distance": (
+        "Mm/GaussDiagonalMaximumFeatureScorer.cc", [(144, 218)],
+        "4f9abec35b194e3f16a49f7082b381b0c7897149f65eb7e40afae00f9dfbccbb",
+        """#include <Mm/Types.hh>
+#include <vector>
+#ifdef __SSE3__
+#include <pmmintrin.h>
+#include <xmmintrin.h>
+#endif
+namespace Mm {
+// shell: declares the one member whose definition follows (the reference's class declaration,
+// Mm/GaussDiagonalMaximumFeatureScorer.hh:28-62, needs Core/Configuration.hh)
+class GaussDiagonalMaximumFeatureScorer {
+public:
+    Score distance(const std::vector<FeatureType>& feature, const std::vector<MeanType>& mean,
+                   const std::vector<VarianceType>& inverseSquareRootVar) const;
+};
+}  // namespace Mm
+using namespace Mm;
+// ---- reference text, %(file)s:%(ranges)s ----
+""",
+        """
+// ---- end of reference text ----
+extern "C" float ref_gdm_distance(const float* x, const float* mu, const float* isr, int dim) {
+    // the reference's containers: std::vector<f32> (glibc's allocator returns 16-byte aligned blocks, which _mm_load_ps needs)
+    std::vector<Mm::FeatureType>  f(x, x + dim);
+    std::vector<Mm::MeanType>     m(mu, mu + dim);
+    std::vector<Mm::VarianceType> v(isr, isr + dim);
+    return Mm::GaussDiagonalMaximumFeatureScorer().distance(f, m, v);
+}
+"""),
+    # Signal::Regression::regressFirstOrder / regressSecondOrder (signal-regression): the class declaration
+    # (Signal/Regression.hh:75-85) sits behind Flow/Merger.hh -> Flow/Node.hh -> Core/Configuration.hh (boost); its two members work on
+    # std::vector<f32> only
+    "regression": (
+        "Signal/Regression.cc", [(24, 65)],
+        "a190f93de931f220e600ac3bedca896a6db5066f6e4c33e9d2266469636a0c7d",
+        """#include <Core/Types.hh>
+#include <Core/Assertions.hh>
+#include <vector>
+namespace Signal {
+// shell: the two members and the Frame type of Signal/Regression.hh:75-85
+class Regression {
+protected:
+    typedef std::vector<f32> Frame;
+public:
+    void regressFirstOrder(const std::vector<const Frame*>& in, Frame& out);
+    void regressSecondOrder(const std::vector<const Frame*>& in, Frame& out);
+};
+}  // namespace Signal
+using namespace Signal;
+// ---- reference text, %(file)s:%(ranges)s ----
+""",
+        """
+// ---- end of reference text ----
+// in: n_in frames of dim floats (row-major), out: dim floats
+extern "C" void ref_regression(int order, const float* in, int n_in, int dim, float* out) {
+    std::vector<std::vector<f32>>        frames(n_in);
+    std::vector<const std::vector<f32>*> ptr(n_in);
+    for (int i = 0; i < n_in; ++i) {
+        frames[i].assign(in + (size_t)i * dim, in + (size_t)(i + 1) * dim);
+        ptr[i] = &frames[i];
+    }
+    std::vector<f32> o(dim);
+    Signal::Regression r;
+    if (order == 1)
+        r.regressFirstOrder(ptr, o);
+    else
+        r.regressSecondOrder(ptr, o);
+    for (int c = 0; c < dim; ++c)
+        out[c] = o[c];
+}
+"""),
+    # Signal::FilterBank::Filter -- declared and defined inside Filterbank.cc: the class declaration, its constructor and apply() are
+    # reference text; the shell supplies the three typedefs and the enum of the enclosing class (Signal/Filterbank.hh:50-71, a
+    # Core::Component, i.e. Core/Configuration.hh -> boost)
+    "filter_apply": (
+        "Signal/Filterbank.cc", [(27, 50), (65, 71)],
+        "d658510f8fe34343289991527c1f11276dc3166e536ebd2117ca989e5cbeb614",
+        """#include <Core/Types.hh>
+#include <Core/Assertions.hh>
+#include <Core/ReferenceCounting.hh>
+#include <Core/XmlStream.hh>
+#include <vector>
+namespace Signal {
+// shell: the member types Signal::FilterBank::Filter uses (Signal/Filterbank.hh:52-54,65-68,71)
+class FilterBank {
+public:
+    typedef f64  Frequency;
+    typedef f32  Data;
+    typedef Data FilterWeight;
+    enum NormalizationType { normalizeNone, normalizeSurface };
+    class Filter;
+};
+}  // namespace Signal
+using namespace Signal;
+// ---- reference text, %(file)s:%(ranges)s ----
+""",
+        """
+// ---- end of reference text ----
+extern "C" float ref_filter_apply(const float* in, int n_in, int start, int end, const float* weights) {
+    std::vector<Signal::FilterBank::FilterWeight> w(weights, weights + (end - start));
+    std::vector<Signal::FilterBank::Data>         v(in, in + n_in);
+    Signal::FilterBank::Filter* f = new Signal::FilterBank::Filter((size_t)start, (size_t)end, w);
+    const float r = f->apply(v);
+    delete f;
+    return r;
+}
+"""),
+}
+
+
+def main():
+    name, out = sys.argv[1], sys.argv[2]
+    file, ranges, sha, head, tail = SPECS[name]
+    with open("%s/%s" % (REF, file), "r", encoding="utf-8", errors="replace") as f:
+        lines = f.readlines()
+    text = "".join("".join(lines[first - 1:last]) for first, last in ranges)
+    got = hashlib.sha256(text.encode()).hexdigest()
+    if len(sys.argv) > 3 and sys.argv[3] == "--print-sha":
+        print(got)
+        return
+    if got != sha:
+        sys.exit("extract_fn: %s:%s hashes to %s, expected %s -- the reference moved; re-check the line ranges" % (file, ranges, got, sha))
+    with open(out, "w") as f:
+        f.write("// GENERATED by oracle/ref/extract_fn.py -- do not commit (oracle/_ref/ is git-ignored)\n")
+        f.write(head % {"file": file, "ranges": ",".join("%d-%d" % r for r in ranges)})
+        f.write(text)
+        f.write(tail)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,176 @@
+"""Regenerates tests/golden/ref_contract.npz and profiles/r05/contract_pins.json.  Run in the build container only:
+
+    python tests/golden/make_contract_golden.py
+
+The reference has two arithmetics (cmake_resources/CompileOptions.cmake:21-48): built with -DMARCH=x86-64 it rounds every operation
+once; its DEFAULT configuration (-march=native, GCC's -ffp-contract=fast) on an FMA host fuses a product whose only use is an
+addition into one fused multiply-add.  oracle/ref/Makefile compiles the reference both ways (libref.so: -msse3; libref_native.so:
+-msse3 -march=native) -- whole translation units where they build, and FUNCTION-TEXT pins (oracle/ref/extract_fn.py) for
+Mm::GaussDiagonalMaximumFeatureScorer::distance, Signal::Regression and Signal::FilterBank::Filter::apply.
+
+ref_contract.npz: seeded INPUTS and the OUTPUTS OF THE REFERENCE in both flavours ("<pin>_off", "<pin>_fma") for the
+contraction-sensitive pins; tests/test_contract.py holds both oracle libraries to them bit for bit, everywhere (no reference tree
+needed).  contract_pins.json: for EVERY pin of libref, how many of the tried inputs give different bits in the two flavours.
+Only data is stored -- no reference source text.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle.binding import load_ref  # noqa: E402
+
+import ctypes as C  # noqa: E402
+
+
+def bits(a):
+    a = np.ascontiguousarray(a)
+    return a.view(np.uint32 if a.dtype == np.float32 else np.uint64)
+
+
+def ndiff(a, b):
+    return int(np.count_nonzero(bits(a) != bits(b)))
+
+
+def main():
+    R = {c: load_ref(c) for c in ("off", "fma")}
+    assert all(R.values()), "both flavours of oracle/_ref are needed (make -C oracle/ref)"
+    rng = np.random.default_rng(20260930)
+    gold, report = {}, {}
+
+    # ---- a13 / a14: the distance (function-text pin)
+    dims = [40, 39, 33, 32, 24, 16, 7, 3, 45]
+    n = 250
+    for dim in dims:
+        x = rng.standard_normal((n, dim)).astype(np.float32)
+        mu = rng.standard_normal((n, dim)).astype(np.float32)
+        isr = rng.uniform(0.5, 2.0, (n, dim)).astype(np.float32)
+        # a few large-magnitude rows: products far from 1
+        x[:20] *= 100.0
+        mu[20:40] *= 1e-3
+        gold["dist_x_%d" % dim], gold["dist_mu_%d" % dim], gold["dist_isr_%d" % dim] = x, mu, isr
+        for c in R:
+            gold["dist_%d_%s" % (dim, c)] = np.array([R[c].ref_gdm_distance(x[i], mu[i], isr[i], dim) for i in range(n)], np.float32)
+    tot = sum(ndiff(gold["dist_%d_off" % d], gold["dist_%d_fma" % d]) for d in dims)
+    report["Mm::GaussDiagonalMaximumFeatureScorer::distance (function text, GaussDiagonalMaximumFeatureScorer.cc:144-218)"] = dict(
+        tried=n * len(dims), differ=tot, fma_sites="vfmadd231ps (sum += df * df), vfmadd231ss (tail)")
+
+    # ---- f1: regression (function text)
+    for order in (1, 2):
+        for right in (1, 2, 3):
+            nin, dim = 2 * right + 1, 45
+            w = (rng.standard_normal((60, nin, dim)) * 10).astype(np.float32)
+            gold["reg_in_%d_%d" % (order, right)] = w
+            for c in R:
+                out = np.zeros((60, dim), np.float32)
+                for i in range(60):
+                    R[c].ref_regression(order, w[i].reshape(-1), nin, dim, out[i])
+                gold["reg_%d_%d_%s" % (order, right, c)] = out
+    report["Signal::Regression::regressFirstOrder / regressSecondOrder (function text, Regression.cc:24-65)"] = dict(
+        tried=6 * 60 * 45, differ=sum(ndiff(gold["reg_%d_%d_off" % (o, r)], gold["reg_%d_%d_fma" % (o, r)]) for o in (1, 2) for r in (1, 2, 3)),
+        fma_sites="first order: out += dt * f, tm += dt * dt; second order: ns += (dt^3) * dt, ns = tm * tm - n * ns (vfmsub), out += f * tm, "
+                  "out -= (f dt dt) * n (vfnmadd); NOT tm += dt * dt there (the product has a second use)")
+
+    # ---- a7: one filter of the bank (function text)
+    nb = 257
+    amp = np.abs(rng.standard_normal((200, nb)) * 50).astype(np.float32)
+    start = rng.integers(0, 200, 200).astype(np.int32)
+    end = (start + rng.integers(1, 57, 200)).astype(np.int32)
+    wts = rng.uniform(0, 1, (200, 56)).astype(np.float32)
+    gold["fb_amp"], gold["fb_start"], gold["fb_end"], gold["fb_w"] = amp, start, end, wts
+    for c in R:
+        gold["fb_%s" % c] = np.array([R[c].ref_filter_apply(amp[i], nb, int(start[i]), int(end[i]), wts[i]) for i in range(200)], np.float32)
+    report["Signal::FilterBank::Filter::apply (function text, Filterbank.cc:27-50,65-71)"] = dict(
+        tried=200, differ=ndiff(gold["fb_off"], gold["fb_fma"]), fma_sites="vfmadd231ss (result += in[f] * weights_[f - start_])")
+
+    # ---- a10 / f1: Math::Matrix x Math::Vector (whole TU headers)
+    M = rng.standard_normal((40, 40)).astype(np.float32)
+    v = (rng.standard_normal((100, 40)) * 3).astype(np.float32)
+    gold["mv_M"], gold["mv_v"] = M, v
+    for c in R:
+        out = np.zeros((100, 40), np.float32)
+        for i in range(100):
+            R[c].ref_matrix_vector(M.ctypes.data, 40, 40, v[i].ctypes.data, out[i].ctypes.data)
+        gold["mv_%s" % c] = out
+    report["Math::Matrix<f32> * Math::Vector<f32> (Matrix.hh:485-494, Vector.hh:94-101): cosine transform, signal-matrix-multiplication"] = dict(
+        tried=4000, differ=ndiff(gold["mv_off"], gold["mv_fma"]), fma_sites="vfmadd231ss (result += a[i] * b[i])")
+
+    # ---- a15: gaussLogNormFactor (f64), as the scorer uses it: narrowed to f32
+    tot = tot32 = 0
+    for dim in (40, 39, 33, 24, 13):
+        var = rng.uniform(0.05, 20.0, (120, dim)).astype(np.float32)
+        gold["ln_var_%d" % dim] = var
+        for c in R:
+            gold["ln_%d_%s" % (dim, c)] = np.array([R[c].ref_gauss_log_norm_factor(var[i], dim) for i in range(120)], np.float64)
+        tot += ndiff(gold["ln_%d_off" % dim], gold["ln_%d_fma" % dim])
+        tot32 += ndiff(gold["ln_%d_off" % dim].astype(np.float32), gold["ln_%d_fma" % dim].astype(np.float32))
+    report["Mm::gaussLogNormFactor (Utilities.hh:70-75), f64, dims 40 39 33 24 13"] = dict(
+        tried=600, differ=tot, differ_after_f32=tot32, fma_sites="vfmadd (N * log(2 pi) + logNorm); 40 * log(2 pi) happens to be exact in f64")
+
+    # ---- pins that turn out flag-INSENSITIVE on everything tried: recorded, no fixture needed
+    def fft_pair(nfl, real):
+        d = 0
+        for _ in range(300):
+            a = (rng.standard_normal(nfl) * 3000).astype(np.float32)
+            o = []
+            for c in R:
+                b = a.copy()
+                (R[c].ref_fft_real if real else R[c].ref_fft_complex)(b, nfl)
+                o.append(b)
+            d += ndiff(o[0], o[1])
+        return d
+    report["Math::FastFourierTransform::transformReal (FastFourierTransform.cc), 512 points, 300 frames"] = dict(
+        tried=300 * 512, differ=fft_pair(512, True), fma_sites="14 f64 fused operations (twiddle recurrence, butterflies' f64 products, real split); "
+                                                               "the f32 results hide them")
+    report["Math::FastFourierTransform::transform, 1024 floats, 300 frames"] = dict(tried=300 * 1024, differ=fft_pair(1024, False))
+
+    from oracle.binding import ref_levinson
+    import oracle.binding as B
+    d = tried = 0
+    for _ in range(300):
+        nac = 13
+        x = rng.standard_normal(400)
+        Rv = np.array([np.dot(x[:400 - k], x[k:]) for k in range(nac)], np.float32)
+        outs = []
+        for c in R:
+            gain = C.c_float(0)
+            a = np.zeros(nac, np.float32)
+            R[c].ref_levinson.restype = C.c_int
+            R[c].ref_levinson.argtypes = [B.f32p, C.c_int, C.POINTER(C.c_float), B.f32p]
+            ok = R[c].ref_levinson(Rv, nac, C.byref(gain), a)
+            outs.append(np.concatenate([[np.float32(gain.value)], a]).astype(np.float32))
+        d += ndiff(outs[0], outs[1])
+        tried += nac + 1
+    report["Math::LevinsonLeastSquares (LevinsonLse.cc), order 12, 300 autocorrelations (MF-PLP / PLP, compared at 1e-4)"] = dict(
+        tried=tried, differ=d, fma_sites="4 f64 fused operations")
+
+    fns = [("ref_mel", 1), ("ref_mel_derivative", 1), ("ref_mel_inverse", 1), ("ref_bark", 1), ("ref_bark_derivative", 1), ("ref_bark_inverse", 1)]
+    for name, _ in fns:
+        xs = rng.uniform(0, 8000, 2000) if "inverse" not in name else rng.uniform(0, 20, 2000)
+        a = np.array([getattr(R["off"], name)(float(t)) for t in xs])
+        b = np.array([getattr(R["fma"], name)(float(t)) for t in xs])
+        report["%s (f64, filter-bank construction)" % name] = dict(tried=2000, differ=ndiff(a, b))
+    a = np.array([R["off"].ref_inverse_square_root(float(t)) for t in gold["ln_var_40"][:50].reshape(-1)], np.float32)
+    b = np.array([R["fma"].ref_inverse_square_root(float(t)) for t in gold["ln_var_40"][:50].reshape(-1)], np.float32)
+    report["Mm::inverseSquareRoot<f32> (Utilities.hh:86-91)"] = dict(tried=2000, differ=ndiff(a, b))
+
+    np.savez_compressed(os.path.join(HERE, "ref_contract.npz"), **gold)
+    out = os.path.join(ROOT, "profiles", "r05")
+    os.makedirs(out, exist_ok=True)
+    import subprocess
+    meta = dict(host_march=subprocess.run("gcc -march=native -Q --help=target | grep -m1 march=", shell=True, capture_output=True, text=True).stdout.split()[-1],
+                gcc=subprocess.run(["gcc", "--version"], capture_output=True, text=True).stdout.splitlines()[0],
+                flavours=dict(off="-std=c++20 -O2 -msse3 (the reference with -DMARCH=x86-64)", fma="-std=c++20 -O2 -msse3 -march=native (the reference's default)"),
+                note="differ = outputs whose bits differ between the two flavours of the compiled reference on the same inputs")
+    json.dump(dict(meta=meta, pins=report), open(os.path.join(out, "contract_pins.json"), "w"), indent=1)
+    for k, v in report.items():
+        print("%6d / %-7d %s" % (v["differ"], v["tried"], k))
+
+
+if __name__ == "__main__":
+    main()
