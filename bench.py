@@ -79,6 +79,11 @@ def parse():
                          "same matrix in bytes (amx_gmm_score_stats_u8_dev: a quarter of the memory, the same time, profiles/r04/gmm_store_ab.log); "
                          "aligned = no matrix: every state scored without index bookkeeping, then amx_gmm_best_density_dev for the aligned "
                          "(here: best) state of each frame -- what AssigningContextScorer::bestDensity(e) is asked for in Viterbi accumulation")
+    ap.add_argument("--contract", default="fma", choices=["fma", "off"],
+                    help="which build of the reference the GMM scorers are bit-identical to (amx_gmm_model.tuning contract=...): fma = its DEFAULT "
+                         "configuration, -march=native with GCC's -ffp-contract=fast on an FMA host (the distance accumulates with fused "
+                         "multiply-adds); off = configured with -DMARCH=x86-64.  The oracle that checks the run and the CPU baseline are built "
+                         "the same way")
     ap.add_argument("--gmm-tuning", default=None, help='amx_gmm_model.tuning of every GMM scorer the workload builds, e.g. "screen=0" (A/B runs)')
     ap.add_argument("--nn-tuning", default=None, help='amx_ffnn_model.tuning, e.g. "tile=4" or "graph=0"')
     ap.add_argument("--mfcc-tuning", default=None, help='amx_mfcc_cfg.tuning, e.g. "fft=mfma" or "wgs=3"')
@@ -281,8 +286,9 @@ def gmm_cart_roofline(ctx, sc, nk, n_mix, dim, frames, best_bytes=4):
     """roofline entry of the screened private-density GMM scorer.
 
     Fused path (gmm_fused_kernel): `achieved` is the f32 arithmetic the kernel really issues for the reference's distance --
-    (densities evaluated exactly, from a device counter) x 4 dim operations (sub, mul, mul, add: unfused by definition of the
-    reference's SSE build) -- over the kernel's HIP-event time, priced against the f32 vector peak; `frac` is therefore a
+    (densities evaluated exactly, from a device counter) x 4 dim flops (contract=off: sub, mul, mul, add -- unfused by definition of
+    the reference's -DMARCH=x86-64 build; contract=fma: sub, mul, fma -- the same four flops in three instructions, the reference's
+    default build) -- over the kernel's HIP-event time, priced against the f32 vector peak; `frac` is therefore a
     utilisation <= 1.  The reference scorer's algorithmic flops (every density) over the same time are reported
     separately as `algorithmic_speedup_vs_dense` (how much faster than a dense f32 evaluation at peak), and the HBM side as
     `hbm_algorithmic_GBps` (scores + best densities out, features + model records in)."""
@@ -301,7 +307,8 @@ def gmm_cart_roofline(ctx, sc, nk, n_mix, dim, frames, best_bytes=4):
         scr = 2.0 * (16 * ((dim + 2 + 15) // 16)) * ((n_mix + 15) // 16 * 256) * frames   # K-steps that hold non-zero columns (dim + 2)
         return dict(bound="valu", kernel="gmm_fused_kernel<%d> (f16 MFMA screen + exact f32/f64 evaluation of the survivors)" % dim,
                     note="VALU-issue-bound kernel priced against the f32 vector peak (157.3 TFLOP/s; unfused mul/add can "
-                         "reach half of it). achieved = densities evaluated exactly (device counter) x 4 dim f32 operations / kernel time",
+                         "reach half of it). achieved = densities evaluated exactly (device counter) x 4 dim f32 flops (sub, mul, mul, add; "
+                         "contract=fma: sub, mul, fma) / kernel time",
                     achieved=round(ex / t / 1e12, 2), peak=FP32_TFLOPS, unit="TFLOP/s", frac=round(ex / t / 1e12 / FP32_TFLOPS, 4),
                     traffic=measured_traffic("pipeline", "gmm_fused_kernel", "Li%dELi%d" % (dim, {0: 0, 1: 2}.get(best_bytes, 1)))
                     if (n_mix == 10000 and frames == 63936) else None,
@@ -1014,8 +1021,12 @@ class NullJob:
 def _cpu_mfcc_worker(job):
     """runs in a spawned process: returns (frames, seconds of compute) for its utterances, excluding start-up"""
     from oracle import OracleMfcc
-    seeds, reps = job
+    from oracle.binding import set_default_contract, use_native_oracle
+    seeds, reps, native, contract = job
     from tests import synth
+    set_default_contract(contract)
+    if native:
+        use_native_oracle()
     pcms = [synth.waveform(160000, seed=s) for s in seeds]
     m = OracleMfcc(n_ceps=40, filter_width=138.0)
     m.run(pcms[0][:16000])  # warm
@@ -1032,9 +1043,11 @@ def _cpu_gmm_worker(job):
     kind "frame": Mm::GaussDiagonalMaximumFeatureScorer loop (one frame at a time, a13); "batch": Mm::BatchFloatFeatureScorer
     (a18, pooled covariance, pre-scaled means -- the reference's fastest CPU scorer), model preparation excluded by differencing
     a T-frame and a 1-frame call; "tied": the per-frame loop on the tied 4096 x 10000 model."""
-    kind, T, native = job
+    kind, T, native, contract = job
     from oracle import OracleGmm
+    from oracle.binding import set_default_contract
     from tests import synth
+    set_default_contract(contract)
     if native:
         from oracle.binding import use_native_oracle
         use_native_oracle()
@@ -1097,10 +1110,12 @@ def _cpu_nn(threads, seconds):
     return T * reps, dt
 
 
-def cpu_baseline(workload):
+def cpu_baseline(workload, contract="fma"):
     """The oracle (CPU restatement of the reference path, kind "port") timed on a bounded sample of the same workload on the
-    host's cores.  The oracle is rebuilt for this with the reference's "standard" flags (-O3 -march=native, -ffp-contract=off so
-    that the results stay the reference's) into a temporary directory.  Every variant SURVEY 8(d) lists is timed and named in
+    host's cores.  The oracle is rebuilt for this host (-O3 -march=native) into a temporary directory, in the run's contract mode: with
+    contract=fma its accumulates are vfmadd instructions -- the instruction mix of the reference's DEFAULT build (-march=native, GCC's
+    -ffp-contract=fast) -- with contract=off they are separate products and sums like a -DMARCH=x86-64 build; nothing else is
+    contracted in either (the results are those of the checker library of the same mode).  Every variant SURVEY 8(d) lists is timed and named in
     `sample`; `value` combines the FASTEST variant of each stage (the honest comparison):
       MFCC   frame by frame, one process per hardware thread
       GMM    (i) Mm::GaussDiagonalMaximumFeatureScorer per frame, all threads; (ii) Mm::BatchFloatFeatureScorer (a18), all threads
@@ -1112,21 +1127,21 @@ def cpu_baseline(workload):
     native = True
     try:
         from oracle.binding import build_native_oracle
-        build_native_oracle()
+        build_native_oracle(contract)
     except Exception as e:  # no compiler on the box: the -O2 library that travelled with the repository
         native = False
         notes.append("native oracle build failed (%s): -O2 build used" % str(e)[:60])
     pool = lambda: mp.get_context("spawn").Pool(cores)
     if workload in ("pipeline", "nn-pipeline", "mfcc"):
         with pool() as p:
-            out = p.map(_cpu_mfcc_worker, [([1000 + i], 4) for i in range(cores)])   # 4 x 10 s of audio per process
+            out = p.map(_cpu_mfcc_worker, [([1000 + i], 4, native, contract) for i in range(cores)])   # 4 x 10 s of audio per process
         res["mfcc"] = (sum(o[0] for o in out), max(o[1] for o in out))
         notes.append("MFCC: %d oracle processes x 40 s audio, %.2f s" % (cores, res["mfcc"][1]))
     if workload in ("pipeline", "gmm", "gmm-train"):
         with pool() as p:
-            a = p.map(_cpu_gmm_worker, [("frame", 8, native)] * cores)
+            a = p.map(_cpu_gmm_worker, [("frame", 8, native, contract)] * cores)
         with pool() as p:
-            b = p.map(_cpu_gmm_worker, [("batch", 129, native)] * cores)
+            b = p.map(_cpu_gmm_worker, [("batch", 129, native, contract)] * cores)
         va = (sum(o[0] for o in a), max(o[1] for o in a))
         vb = (sum(o[0] for o in b), max(o[1] for o in b))
         variants["gmm diagonal-maximum per frame, %d threads" % cores] = va[0] / va[1]
@@ -1135,7 +1150,7 @@ def cpu_baseline(workload):
     if workload == "gmm-tied":
         n = min(cores, 32)   # 164 MB of weights per process
         with mp.get_context("spawn").Pool(n) as p:
-            a = p.map(_cpu_gmm_worker, [("tied", 1, native)] * n)
+            a = p.map(_cpu_gmm_worker, [("tied", 1, native, contract)] * n)
         res["gmm"] = (sum(o[0] for o in a), max(o[1] for o in a))
         variants["gmm tied 4096 x 10000 diagonal-maximum per frame, %d threads" % n] = res["gmm"][0] / res["gmm"][1]
         cores = n
@@ -1150,7 +1165,7 @@ def cpu_baseline(workload):
     detail = ", ".join("%s %d frames in %.2fs" % (k, fr, dt) for k, (fr, dt) in res.items())
     vtxt = "; ".join("%s: %.1f frames/s" % (k, v) for k, v in variants.items())
     return dict(value=round(1.0 / spf, 2), unit="frames/s", cores=cores, kind="port",
-                sample=detail + " (" + "; ".join(notes + [vtxt]) + "; oracle built %s)" % ("-O3 -march=native -ffp-contract=off" if native else "-O2"))
+                sample=detail + " (" + "; ".join(notes + [vtxt]) + "; oracle built %s, contract=%s)" % ("-O3 -march=native" if native else "-O2", contract))
 
 
 def parity_check(ctx, job, args, n_nn=256, n_gmm=24):
@@ -1193,11 +1208,11 @@ def parity_check(ctx, job, args, n_nn=256, n_gmm=24):
         g.score_dev(x, n_gmm, sc, bd)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        ws, wb = OracleGmm(model).score(x.cpu().numpy(), mode=0, want_best=True)
+        ws, wb = OracleGmm(model, contract=args.contract).score(x.cpu().numpy(), mode=0, want_best=True)
         gs, gb = sc.cpu().numpy(), bd.cpu().numpy()
         out["gmm"] = dict(frames=n_gmm, scores=int(gs.size), score_bit_mismatches=int((gs.view(np.uint32) != ws.view(np.uint32)).sum()),
                           best_density_mismatches=int((gb.astype(np.int64) != wb.astype(np.int64)).sum()),
-                          reference="OracleGmm.score (orc_score.c, diagonal-maximum) on the job's own cepstra",
+                          reference="OracleGmm.score (orc_score.c, diagonal-maximum, contract=%s) on the job's own cepstra" % args.contract,
                           oracle_seconds=round(time.perf_counter() - t0, 2))
     return out
 
@@ -1413,8 +1428,26 @@ def decoder_facing(ctx, args, rank):
     return out
 
 
+def apply_contract(args):
+    """--contract -> the GMM scorers' tuning string (the quantised scorer is integer arithmetic: it takes no contract) and the oracle's mode"""
+    from_tuning = [i.split("=", 1)[1] for i in (args.gmm_tuning or "").split(",") if i.strip().startswith("contract=")]
+    if from_tuning:
+        args.contract = from_tuning[-1]
+    elif args.gmm_type == "SIMD-diagonal-maximum":
+        args.contract = "off"
+    elif args.contract == "fma":
+        args.gmm_tuning = ",".join(i for i in (args.gmm_tuning, "contract=fma") if i)
+
+
+CONTRACT_TEXT = {"fma": "fma: bit-identical to the reference's default build (-march=native, GCC -ffp-contract=fast: the GMM distance accumulates "
+                        "with fused multiply-adds), checked against oracle/liboracle_fma.so",
+                 "off": "off: bit-identical to the reference configured with -DMARCH=x86-64 (every f32 operation rounds once), checked against "
+                        "oracle/liboracle.so"}
+
+
 def main():
     args = parse()
+    apply_contract(args)
     launch_ranks(args)   # --gpus N without a launcher: this process becomes the launcher and exits with the ranks' status
     gpu = args.backend == "nccl"
     if not gpu and args.workload != "null":
@@ -1471,7 +1504,8 @@ def main():
                           "f16mx": "f16+mxfp6 (per f32 product: one f16 MFMA product + one block-scaled fp6 x fp6 MFMA product for both cross "
                                    "terms, f32 accumulate)"}[args.precision]
                          if args.workload in ("pipeline", "nn-pipeline", "nn") else "f32",
-                "data": "synthetic", "config": {"workload": WORKLOAD_NAMES[args.workload](args), "frames_per_step_per_gpu": job.units},
+                "data": "synthetic", "config": {"workload": WORKLOAD_NAMES[args.workload](args), "frames_per_step_per_gpu": job.units,
+                                                "contract": CONTRACT_TEXT[args.contract]},
                 "rtf": round(dt / (units * 0.01), 8), "build": rasr_amd.version()}
         line["roofline"] = job.roofline()
         if line["roofline"] and line["roofline"].get("traffic") is not None:
@@ -1494,7 +1528,7 @@ def main():
         if is_graph_mode(args):
             line["config"]["launch"] = "forward pass replayed as one HIP graph; roofline / stages timed in a separate pass with plain launches"
         if not args.no_cpu_baseline and world == 1:
-            cb = cpu_baseline(args.workload)
+            cb = cpu_baseline(args.workload, args.contract)
             line["cpu_baseline"] = cb
             line["speedup_vs_cpu"] = round(value / world / cb["value"], 1)
             if args.workload in ("pipeline", "nn-pipeline", "gmm-train"):

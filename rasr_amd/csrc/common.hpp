@@ -86,14 +86,16 @@ struct Tuning {
     std::map<std::string, std::string> kv;
     // returns false (error text set) on a malformed string or a key that is not in `allowed` (NULL-terminated list)
     bool parse(const char* s, const char* const* allowed, const char* who);
-    int  get(const char* key, int dflt) const;
     bool has(const char* key) const { return kv.count(key) != 0; }
-    std::string str(const char* key, const char* dflt) const;
+    // Typed reads, checked at creation: false (error text set) unless the value is a whole decimal number within [lo, hi] /
+    // one of `words` (NULL-terminated).  A value the key does not take fails the creation like an unknown key does.
+    bool get_int(const char* key, int dflt, long lo, long hi, int* out, const char* who) const;
+    bool get_word(const char* key, const char* dflt, const char* const* words, std::string* out, const char* who) const;
 };
 
 // keys of amx_gmm_model.tuning (gmm.hip and gmm_simd.hip parse the same string)
 static const char* const gmm_tuning_keys[] = {"screen", "fused", "screen_all", "screen_kernel", "graph", "tied_prune", "chunk", "fused_waves", "fr",
-                                              "simd_mfma", nullptr};
+                                              "simd_mfma", "contract", nullptr};
 
 inline int ceil_div(long a, long b) {
     return (int)((a + b - 1) / b);

@@ -1823,19 +1823,35 @@ int amx_ffnn_create(amx_ctx* ctx, const amx_ffnn_model* m, amx_ffnn** out) {
         if (!tune.parse(m->tuning, keys, "amx_ffnn_create"))
             return AMX_ERR_INVALID;
     }
+    // values are checked like keys (a typo must not silently select the default kernel)
+    int t_tile, t_graph, t_persistent, t_chunk, t_mx_dbg, t_stagger, t_group_t = -1, t_group_n = -1;
+    {
+        const char* who = "amx_ffnn_create";
+        if (!tune.get_int("tile", -1, -1, 9, &t_tile, who) || !tune.get_int("graph", 1, 0, 1, &t_graph, who) ||
+            !tune.get_int("persistent", 1, 0, 1, &t_persistent, who) || !tune.get_int("chunk", 32768, 256, 1 << 24, &t_chunk, who) ||
+            !tune.get_int("mx_dbg", 0, 0, 1 << 16, &t_mx_dbg, who) || !tune.get_int("stagger", 0, 0, 100000, &t_stagger, who))
+            return AMX_ERR_INVALID;
+        if (tune.has("group")) {
+            const std::string g = tune.kv["group"];
+            char              tail = 0;
+            AMX_REQUIRE(sscanf(g.c_str(), "%dx%d%c", &t_group_t, &t_group_n, &tail) == 2 && t_group_t >= 1 && t_group_n >= 1 && t_group_t <= 4096 &&
+                                t_group_n <= 4096,
+                        AMX_ERR_INVALID, "amx_ffnn_create: tuning group=%s: expected <frame tiles>x<output tiles>, e.g. 16x8", g.c_str());
+        }
+    }
     amx_ffnn* h  = new amx_ffnn;
     h->ctx       = ctx;
     h->n_layers  = m->n_layers;
     h->precision = m->precision;
     h->class_mapped = class_mapped;
-    h->gemm_cfg        = tune.get("tile", -1);
-    h->use_graphs      = tune.get("graph", 1);
-    h->gemm_persistent = tune.get("persistent", 1);
-    h->chunk           = std::max(256, tune.get("chunk", 32768));
-    h->mx_dbg          = tune.get("mx_dbg", 0);
-    h->mx_stagger      = tune.get("stagger", 0);
-    if (tune.has("group"))
-        sscanf(tune.str("group", "").c_str(), "%dx%d", &h->group_t, &h->group_n);
+    h->gemm_cfg        = t_tile;
+    h->use_graphs      = t_graph;
+    h->gemm_persistent = t_persistent;
+    h->chunk           = t_chunk;
+    h->mx_dbg          = t_mx_dbg;
+    h->mx_stagger      = t_stagger;
+    h->group_t         = t_group_t;
+    h->group_n         = t_group_n;
     hipSetDevice(ctx->device);
     const int kmult = m->precision == AMX_PREC_F16MX ? amx::mx::TK : (m->precision != AMX_PREC_FP32) ? amx::BK : amx::FK;
     if (m->precision == AMX_PREC_F16MX) {

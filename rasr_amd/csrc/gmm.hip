@@ -19,10 +19,13 @@
 //
 // Exactness (max mode): the squared distance is accumulated in the reference's SSE order --
 // four strided partial sums over dim&~3, (l0+l1)+(l2+l3), scalar tail -- with separate
-// multiply and add (-ffp-contract=off); the combine (f64)m2lw + (f64)logNorm + (f64)dist is done
-// in f64 (the first f64 addition is folded on the host, it does not depend on the frame); the
-// running best is an f32 compared as f64 with strict '>', so the first minimum wins.  Scores and
-// best-density indices are therefore bit-identical to the reference's x86-64 build.
+// multiply and add (-ffp-contract=off) -- or, with amx_gmm_model.tuning contract=fma, with the accumulate `sum += df * df` as ONE
+// fused multiply-add, which is what the reference's DEFAULT build (-march=native, GCC's -ffp-contract=fast) executes on an FMA host
+// (template parameter FMA of every kernel that evaluates the distance; sq_acc in gmm_device.hpp); the combine
+// (f64)m2lw + (f64)logNorm + (f64)dist is done in f64 (the first f64 addition is folded on the host, it does not depend on the
+// frame); the running best is an f32 compared as f64 with strict '>', so the first minimum wins.  Scores and best-density indices
+// are therefore bit-identical to the reference built with -DMARCH=x86-64 (contract=off, the default) or to its default build
+// (contract=fma) -- INTEGRATION.md has the table.
 #include "common.hpp"
 #include "gmm_device.hpp"
 
@@ -47,7 +50,7 @@ struct GmmParams {
 };
 
 // distance in the reference's association order; mu / is are wave-uniform pointers
-template<int DIM>
+template<int DIM, bool FMA = false>
 __device__ __forceinline__ float gmm_distance(const float (&x)[DIM], const float* __restrict__ mu, const float* __restrict__ is) {
     float         l0 = 0.f, l1 = 0.f, l2 = 0.f, l3 = 0.f;
     constexpr int EFF = DIM & ~3;
@@ -57,22 +60,23 @@ __device__ __forceinline__ float gmm_distance(const float (&x)[DIM], const float
         float d1 = (mu[i + 1] - x[i + 1]) * is[i + 1];
         float d2 = (mu[i + 2] - x[i + 2]) * is[i + 2];
         float d3 = (mu[i + 3] - x[i + 3]) * is[i + 3];
-        l0       = l0 + d0 * d0;
-        l1       = l1 + d1 * d1;
-        l2       = l2 + d2 * d2;
-        l3       = l3 + d3 * d3;
+        l0       = sq_acc<FMA>(d0, l0);
+        l1       = sq_acc<FMA>(d1, l1);
+        l2       = sq_acc<FMA>(d2, l2);
+        l3       = sq_acc<FMA>(d3, l3);
     }
     float result = 0.f;
     result       = result + ((l0 + l1) + (l2 + l3));
 #pragma unroll
     for (int i = EFF; i < DIM; ++i) {
         float df = (mu[i] - x[i]) * is[i];
-        result   = result + df * df;
+        result   = sq_acc<FMA>(df, result);
     }
     return result;
 }
 
 // runtime-dimension variant: features live in LDS as [dim][64] (one column per lane)
+template<bool FMA = false>
 __device__ __forceinline__ float gmm_distance_rt(const float* xs, int dim, const float* __restrict__ mu, const float* __restrict__ is) {
     float     l0 = 0.f, l1 = 0.f, l2 = 0.f, l3 = 0.f;
     const int eff = dim & ~3;
@@ -81,16 +85,16 @@ __device__ __forceinline__ float gmm_distance_rt(const float* xs, int dim, const
         float d1 = (mu[i + 1] - xs[(i + 1) * 64]) * is[i + 1];
         float d2 = (mu[i + 2] - xs[(i + 2) * 64]) * is[i + 2];
         float d3 = (mu[i + 3] - xs[(i + 3) * 64]) * is[i + 3];
-        l0       = l0 + d0 * d0;
-        l1       = l1 + d1 * d1;
-        l2       = l2 + d2 * d2;
-        l3       = l3 + d3 * d3;
+        l0       = sq_acc<FMA>(d0, l0);
+        l1       = sq_acc<FMA>(d1, l1);
+        l2       = sq_acc<FMA>(d2, l2);
+        l3       = sq_acc<FMA>(d3, l3);
     }
     float result = 0.f;
     result       = result + ((l0 + l1) + (l2 + l3));
     for (int i = eff; i < dim; ++i) {
         float df = (mu[i] - xs[i * 64]) * is[i];
-        result   = result + df * df;
+        result   = sq_acc<FMA>(df, result);
     }
     return result;
 }
@@ -150,7 +154,7 @@ struct GmmDims {
 // All model tables are separate `const __restrict__` kernel arguments so that the compiler may
 // prove them read-only and fetch them through the scalar cache (s_load) -- struct members lose
 // the qualifier and fall back to per-lane vector loads.
-template<int DIM, class State>
+template<int DIM, class State, bool FMA = false>
 __global__ __launch_bounds__(256) void gmm_direct_kernel(const float* __restrict__ g_feats, float* __restrict__ g_scores,
                                                         uint32_t* __restrict__ g_best, const uint32_t* __restrict__ g_mix_off,
                                                         const uint32_t* __restrict__ g_k_mean, const uint32_t* __restrict__ g_k_cov,
@@ -194,9 +198,9 @@ __global__ __launch_bounds__(256) void gmm_direct_kernel(const float* __restrict
             const float* is = p.isr + (size_t)p.k_cov[k] * (DIM > 0 ? DIM : p.dim);
             float        dist;
             if (DIM > 0)
-                dist = gmm_distance<(DIM > 0 ? DIM : 1)>(x, mu, is);
+                dist = gmm_distance<(DIM > 0 ? DIM : 1), FMA>(x, mu, is);
             else
-                dist = gmm_distance_rt(xs, p.dim, mu, is);
+                dist = gmm_distance_rt<FMA>(xs, p.dim, mu, is);
             st.add(p.k_c64[k], p.k_c32[k], dist, k - k0);
         }
         if (live) {
@@ -211,7 +215,7 @@ __global__ __launch_bounds__(256) void gmm_direct_kernel(const float* __restrict
 // covariance only; means and features pre-multiplied by 1/sigma, per-density constant c = (f32)(logNorm - 2 logw);
 // two 4-lane f32 accumulators over 8-wide blocks, lane 0 of the first starts at c; a = s1 + s2;
 // result = (a3 + a1) + (a2 + a0); min over the densities; 0.5 * min.  3 ops per dimension instead of 4.
-template<int DIM>
+template<int DIM, bool FMA = false>
 __global__ __launch_bounds__(256) void gmm_batch_float_kernel(const float* __restrict__ g_feats, float* __restrict__ g_scores,
                                                              const uint32_t* __restrict__ g_mix_off, const uint32_t* __restrict__ g_k_mean,
                                                              const float* __restrict__ g_k_const, const float* __restrict__ g_smeans,
@@ -231,7 +235,7 @@ __global__ __launch_bounds__(256) void gmm_batch_float_kernel(const float* __res
         float          best = FLT_MAX;
         for (uint32_t k = k0; k < k1; ++k) {
             const float* mu = g_smeans + (size_t)g_k_mean[k] * dim;
-            const float  r  = batch_float_distance<DIM>(mu, x, g_k_const[k], dim);
+            const float  r  = batch_float_distance<DIM, FMA>(mu, x, g_k_const[k], dim);
             best           = r < best ? r : best;  // _mm_min_ps(score, r)
         }
         if (live)
@@ -243,6 +247,7 @@ __global__ __launch_bounds__(256) void gmm_batch_float_kernel(const float* __res
 // GaussDiagonalMaximumFeatureScorer::calculateScoreAndDensity, Mm/GaussDiagonalMaximumFeatureScorer.cc:116-142): what the Viterbi
 // accumulation asks of the scorer -- the best density of the ALIGNED mixture, not of all of them.  Thread = frame; the reference's
 // arithmetic and rule (gmm_distance's operation order, MaxState), so index and score equal the full pass's entry (t, mixture[t]).
+template<bool FMA>
 __global__ __launch_bounds__(256) void gmm_best_density_kernel(const float* __restrict__ feats, const uint32_t* __restrict__ mixture,
                                                               uint32_t* __restrict__ best, float* __restrict__ score, const uint32_t* __restrict__ mix_off,
                                                               const uint32_t* __restrict__ k_mean, const uint32_t* __restrict__ k_cov,
@@ -266,16 +271,16 @@ __global__ __launch_bounds__(256) void gmm_best_density_kernel(const float* __re
                 const float d1 = (mu[i + 1] - x[i + 1]) * is[i + 1];
                 const float d2 = (mu[i + 2] - x[i + 2]) * is[i + 2];
                 const float d3 = (mu[i + 3] - x[i + 3]) * is[i + 3];
-                l0             = l0 + d0 * d0;
-                l1             = l1 + d1 * d1;
-                l2             = l2 + d2 * d2;
-                l3             = l3 + d3 * d3;
+                l0             = sq_acc<FMA>(d0, l0);
+                l1             = sq_acc<FMA>(d1, l1);
+                l2             = sq_acc<FMA>(d2, l2);
+                l3             = sq_acc<FMA>(d3, l3);
             }
             float dist = 0.f;
             dist       = dist + ((l0 + l1) + (l2 + l3));
             for (int i = eff; i < dim; ++i) {
                 const float df = (mu[i] - x[i]) * is[i];
-                dist           = dist + df * df;
+                dist           = sq_acc<FMA>(df, dist);
             }
             st.add(k_c64[k], 0.f, dist, k - k0);
         }
@@ -298,7 +303,7 @@ __global__ __launch_bounds__(256) void best_narrow_kernel(const uint32_t* __rest
 // best8 (nullable): the byte form of the best-density matrix (amx_gmm_score_stats_u8_dev; 0xff widens to the u32 form's 0xffffffff)
 __global__ __launch_bounds__(256) void gmm_accumulate_kernel(const float* __restrict__ feats, const uint32_t* __restrict__ mixture,
                                                             const uint32_t* __restrict__ best, const unsigned char* __restrict__ best8,
-                                                            int best_ld, int T, int dim,
+                                                            int best_ld, int T, int dim, int n_mix,
                                                             const uint32_t* __restrict__ mix_off, const uint32_t* __restrict__ k_dens,
                                                             const uint32_t* __restrict__ d_mean, const uint32_t* __restrict__ d_cov,
                                                             double* __restrict__ acc, long long off_mw, long long off_ms,
@@ -314,7 +319,10 @@ __global__ __launch_bounds__(256) void gmm_accumulate_kernel(const float* __rest
     {
         const int t = t0 + tid;
         uint32_t  k = 0xffffffffu, mi = 0, ci = 0;
-        if (t < T) {
+        // A frame without a density is skipped (k stays 0xffffffff: neither a lead nor chained): a mixture index outside the model,
+        // or "no density" -- 0xffffffff / 0xff is what amx_gmm_score_dev and amx_gmm_best_density_dev write for a frame no density
+        // ever beat FLT_MAX on (NaN / over-range features) -- or any index behind the mixture's last density
+        if (t < T && mixture[t] < (uint32_t)n_mix) {
             const uint32_t m  = mixture[t];
             uint32_t       kk;
             if (best8) {
@@ -323,10 +331,12 @@ __global__ __launch_bounds__(256) void gmm_accumulate_kernel(const float* __rest
             }
             else
                 kk = best_ld > 0 ? best[(size_t)t * best_ld + m] : best[t];
-            k = mix_off[m] + kk;
-            const uint32_t d  = k_dens[k];
-            mi                = d_mean[d];
-            ci                = d_cov[d];
+            if (kk < mix_off[m + 1] - mix_off[m]) {
+                k                = mix_off[m] + kk;
+                const uint32_t d = k_dens[k];
+                mi               = d_mean[d];
+                ci               = d_cov[d];
+            }
         }
         s_k[tid]  = k;
         s_mi[tid] = mi;
@@ -403,9 +413,10 @@ __global__ __launch_bounds__(256) void gmm_accumulate_kernel(const float* __rest
 constexpr int kBwMaxDens   = 4096;  // densities per mixture the LDS score buffer holds (4 waves x 16 KB)
 constexpr int kBwFramesPerWave = 16;
 
+template<bool FMA>
 __global__ __launch_bounds__(256) void gmm_accumulate_weighted_kernel(
         int mode, const float* __restrict__ feats, const uint32_t* __restrict__ mixture, const double* __restrict__ weight,
-        const uint32_t* __restrict__ best, int best_ld, int T, int dim, const uint32_t* __restrict__ mix_off,
+        const uint32_t* __restrict__ best, int best_ld, int T, int dim, int n_mix, const uint32_t* __restrict__ mix_off,
         const uint32_t* __restrict__ k_dens, const uint32_t* __restrict__ d_mean, const uint32_t* __restrict__ d_cov,
         const float* __restrict__ k_c32, const float* __restrict__ means, const float* __restrict__ isr, double* __restrict__ acc,
         long long off_mw, long long off_ms, long long off_cw, long long off_cs, int pooled) {
@@ -417,6 +428,8 @@ __global__ __launch_bounds__(256) void gmm_accumulate_weighted_kernel(
     const int t_begin = (blockIdx.x * 4 + wave) * kBwFramesPerWave;
     for (int t = t_begin; t < min(t_begin + kBwFramesPerWave, T); ++t) {
         const uint32_t m  = mixture[t];
+        if (m >= (uint32_t)n_mix)  // wave-uniform: a frame aligned to no mixture of this model contributes nothing
+            continue;
         const uint32_t k0 = mix_off[m], nd = mix_off[m + 1] - k0;
         const float*   x  = feats + (size_t)t * dim;
         const double   w  = weight ? weight[t] : 1.0;
@@ -432,16 +445,16 @@ __global__ __launch_bounds__(256) void gmm_accumulate_weighted_kernel(
                 for (int i = 0; i < eff; i += 4) {
                     const float d0 = (mu[i] - x[i]) * is[i], d1 = (mu[i + 1] - x[i + 1]) * is[i + 1];
                     const float d2 = (mu[i + 2] - x[i + 2]) * is[i + 2], d3 = (mu[i + 3] - x[i + 3]) * is[i + 3];
-                    l0 = l0 + d0 * d0;
-                    l1 = l1 + d1 * d1;
-                    l2 = l2 + d2 * d2;
-                    l3 = l3 + d3 * d3;
+                    l0 = sq_acc<FMA>(d0, l0);
+                    l1 = sq_acc<FMA>(d1, l1);
+                    l2 = sq_acc<FMA>(d2, l2);
+                    l3 = sq_acc<FMA>(d3, l3);
                 }
                 float dist = 0.f;
                 dist       = dist + ((l0 + l1) + (l2 + l3));
                 for (int i = eff; i < dim; ++i) {
                     const float df = (mu[i] - x[i]) * is[i];
-                    dist           = dist + df * df;
+                    dist           = sq_acc<FMA>(df, dist);
                 }
                 const float sk = 0.5f * (k_c32[k0 + j] + dist);
                 sp[j]          = sk;
@@ -460,6 +473,8 @@ __global__ __launch_bounds__(256) void gmm_accumulate_weighted_kernel(
         }
         else {
             const uint32_t kk = best_ld > 0 ? best[(size_t)t * best_ld + m] : best[t];
+            if (kk >= nd)  // "no density" (0xffffffff: a NaN / over-range frame) or an index behind the mixture's last density
+                continue;
             j_lo              = kk;
             j_hi              = kk + 1;
         }
@@ -520,7 +535,7 @@ struct GmmDistDims {
 // STAGE: the workgroup's 256 frames come in as ONE coalesced run through LDS.  Lane = frame reads feats[t][i] with a stride of dim
 // floats -- 64 separate 64-byte sectors per load instruction, ~150 cycles of the CU's address unit each (tools/gather_probe.hip) --
 // which is noise behind a long density loop but most of the kernel when a small batch is cut into many short workgroups.
-template<int DIM, bool STAGE = false>
+template<int DIM, bool STAGE = false, bool FMA = false>
 __global__ __launch_bounds__(256) void gmm_dist_kernel(const float* __restrict__ g_feats, float* __restrict__ g_dist, double* __restrict__ g_dist64,
                                                       const uint32_t* __restrict__ g_d_mean, const uint32_t* __restrict__ g_d_cov,
                                                       const float* __restrict__ g_means, const float* __restrict__ g_isr,
@@ -573,9 +588,9 @@ __global__ __launch_bounds__(256) void gmm_dist_kernel(const float* __restrict__
             const float* is = p.isr + (size_t)p.d_cov[d] * (DIM > 0 ? DIM : p.dim);
             float        dist;
             if (DIM > 0)
-                dist = gmm_distance<(DIM > 0 ? DIM : 1)>(x, mu, is);
+                dist = gmm_distance<(DIM > 0 ? DIM : 1), FMA>(x, mu, is);
             else
-                dist = gmm_distance_rt(xs, p.dim, mu, is);
+                dist = gmm_distance_rt<FMA>(xs, p.dim, mu, is);
             q[j] = dist;
             if (t < p.Tpad) {
                 p.dist[(size_t)d * p.Tpad + t] = dist;  // coalesced along t
@@ -1258,7 +1273,7 @@ __host__ __device__ constexpr int gmm_exact_ld(int dim, bool pooled) {
 
 // exact evaluation of the surviving slots: thread = frame (features in registers), workgroup = 16 mixtures x 256 frames,
 // the 256 slot means (and 1/sigma rows when not pooled) of the tile in LDS, rows padded to DIM + 1 floats
-template<int DIM, bool POOLED>
+template<int DIM, bool POOLED, bool FMA = false>
 __global__ __launch_bounds__(256) void gmm_screen_exact_kernel(const float* __restrict__ g_feats, const uint16_t* __restrict__ g_masks,
                                                               const uint32_t* __restrict__ g_mix_off, const uint32_t* __restrict__ g_k_mean,
                                                               const uint32_t* __restrict__ g_k_cov, const double* __restrict__ g_k_c64,
@@ -1370,7 +1385,7 @@ __global__ __launch_bounds__(256) void gmm_screen_exact_kernel(const float* __re
     MaxState st;
     auto     eval = [&](const float (&mu)[DIM], int row, int next_row) {
         const float* is   = POOLED ? g_isr : s_is + row * LD;
-        const float  dist = gmm_distance_pk_reg<DIM>(x, mu, is);
+        const float  dist = gmm_distance_pk_reg<DIM, FMA>(x, mu, is);
         st.add(s_c64[row], 0.f, dist, (uint32_t)(row & 15));
         if ((next_row >> 4) != (row >> 4)) {  // last survivor of this mixture (next_row = -1 gives mixture -1)
             s_sc[tid * 17 + (row >> 4)] = st.result();
@@ -1598,6 +1613,10 @@ struct amx_gmm {
     int         tune_screen = 1, tune_fused = 1, tune_screen_all = 0, tune_tied_prune = -1, tune_chunk = 65536, tune_fused_waves = 0, tune_fr = 8,
                 tune_simd_mfma = 1;
     std::string tune_screen_kernel = "rows";
+    // amx_gmm_model.tuning contract=fma: the distance's `sum += df * df` as one fused multiply-add = the reference's default build
+    // (-march=native on an FMA host); off (default) = the reference built with -DMARCH=x86-64.  Not a speed switch: it selects WHICH
+    // build of RASR the scores are bit-identical to.
+    bool        contract_fma = false;
     void*     d_fus_rec = nullptr;   // tile records of gmm_fused_kernel (pooled covariance, dim <= 40)
     uint32_t* d_best32   = nullptr;  // u32 workspace of amx_gmm_score_stats_u8_dev on paths without a byte-writing kernel
     size_t    best32_cap = 0;
@@ -1659,7 +1678,7 @@ extern "C" int amx_internal_gmm_fused_split(int n_cu, int Tpad, int n_tiles, int
 extern "C" int amx_internal_gmm_fused_score(amx_ctx* ctx, int dim, const void* rec_dev, const float* isr_dev, const float* feats, const void* X,
                                             const float* nx, const float* q, int T, int Tpad, int n_mix, int n_tiles, int split, float* scores,
                                             uint32_t* best, float* pmin, unsigned* pidx, int part_ld, unsigned long long* survivors, int forced_waves,
-                                            int best_bytes);
+                                            int best_bytes, int contract_fma);
 extern "C" int amx_internal_gmm_fused_waves(int Tpad, int forced_waves);
 
 // maximum approximation through the MFMA screen (see gmm_screen_kernel); frames in chunks that bound the mask workspace
@@ -1727,7 +1746,8 @@ int score_screened(amx_gmm* h, const float* feats_dev, int T, float* scores_dev,
                 int r = amx_internal_gmm_fused_score(h->ctx, h->dim, h->d_fus_rec, h->d_isr, x, h->d_scr_X, h->d_scr_nx, h->d_scr_q, Tc, Tpad,
                                                      h->n_mix, n_tiles, split, scores_dev + (size_t)t0 * h->n_mix,
                                                      best_dev ? (uint32_t*)((char*)best_dev + (size_t)t0 * h->n_mix * best_bytes) : nullptr, pmin,
-                                                     pidx, Tpad, h->count_survivors ? h->d_fus_surv : nullptr, h->tune_fused_waves, best_bytes);
+                                                     pidx, Tpad, h->count_survivors ? h->d_fus_surv : nullptr, h->tune_fused_waves, best_bytes,
+                                                     h->contract_fma ? 1 : 0);
                 if (r != AMX_OK)
                     return r;
                 if (h->count_survivors)
@@ -1808,13 +1828,13 @@ int score_screened(amx_gmm* h, const float* feats_dev, int T, float* scores_dev,
     case D: {                                                                                                                       \
         const size_t lds = (size_t)256 * amx::gmm_exact_ld(D, h->pooled) * 4 * (h->pooled ? 1 : 2) + 2048 + 2112 + 256 * 17 * 4 + 256 * 20 + 256 * amx::gmm_list_cap(D, h->pooled); \
         if (h->pooled) {                                                                                                            \
-            auto k = amx::gmm_screen_exact_kernel<D, true>;                                                                         \
+            auto k = h->contract_fma ? amx::gmm_screen_exact_kernel<D, true, true> : amx::gmm_screen_exact_kernel<D, true, false>;  \
             hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
             hipLaunchKernelGGL(k, grid, dim3(256), lds, st, x, h->d_scr_masks, h->d_mix_off, h->d_k_mean, h->d_k_cov, h->d_k_c64,   \
                                h->d_means, h->d_isr, sc, bd, Tc, h->n_mix, h->scr_Mpad16, pmin, pidx, Tpad, FG);                                          \
         }                                                                                                                           \
         else {                                                                                                                      \
-            auto k = amx::gmm_screen_exact_kernel<D, false>;                                                                        \
+            auto k = h->contract_fma ? amx::gmm_screen_exact_kernel<D, false, true> : amx::gmm_screen_exact_kernel<D, false, false>; \
             hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
             hipLaunchKernelGGL(k, grid, dim3(256), lds, st, x, h->d_scr_masks, h->d_mix_off, h->d_k_mean, h->d_k_cov, h->d_k_c64,   \
                                h->d_means, h->d_isr, sc, bd, Tc, h->n_mix, h->scr_Mpad16, pmin, pidx, Tpad, FG);                                          \
@@ -1853,10 +1873,11 @@ int launch_direct(amx_gmm* h, const amx::GmmParams& p, dim3 grid) {
     amx::GmmDims dims{p.T, p.dim, p.n_mix, p.mix_tile};
     switch (h->dim) {
 #define AMX_GMM_CASE(D)                                                                                  \
-    case D:                                                                                              \
-        hipLaunchKernelGGL((amx::gmm_direct_kernel<D, State>), grid, dim3(256), 0, st, p.feats, p.scores, p.best, \
+    case D: {                                                                                            \
+        auto k = h->contract_fma ? amx::gmm_direct_kernel<D, State, true> : amx::gmm_direct_kernel<D, State, false>; \
+        hipLaunchKernelGGL(k, grid, dim3(256), 0, st, p.feats, p.scores, p.best,                          \
                                p.mix_off, p.k_mean, p.k_cov, p.k_c64, p.k_c32, p.means, p.isr, dims);       \
-            break;
+    } break;
         AMX_GMM_CASE(16)
         AMX_GMM_CASE(24)
         AMX_GMM_CASE(32)
@@ -1869,8 +1890,8 @@ int launch_direct(amx_gmm* h, const amx::GmmParams& p, dim3 grid) {
 #undef AMX_GMM_CASE
         default:
             lds = (size_t)4 * 64 * h->dim * sizeof(float);
-            hipLaunchKernelGGL((amx::gmm_direct_kernel<0, State>), grid, dim3(256), lds, st, p.feats, p.scores, p.best,
-                               p.mix_off, p.k_mean, p.k_cov, p.k_c64, p.k_c32, p.means, p.isr, dims);
+            hipLaunchKernelGGL((h->contract_fma ? amx::gmm_direct_kernel<0, State, true> : amx::gmm_direct_kernel<0, State, false>), grid, dim3(256),
+                               lds, st, p.feats, p.scores, p.best, p.mix_off, p.k_mean, p.k_cov, p.k_c64, p.k_c32, p.means, p.isr, dims);
     }
     AMX_HIP(hipGetLastError());
     return AMX_OK;
@@ -1884,10 +1905,12 @@ int launch_dist(amx_gmm* h, const amx::GmmDistParams& p, dim3 grid, double* dist
 #define AMX_GMM_CASE(D)                                                                                                                   \
     case D:                                                                                                                               \
         if (stage)                                                                                                                        \
-            hipLaunchKernelGGL((amx::gmm_dist_kernel<D, true>), grid, dim3(256), (size_t)256 * (D + 1) * sizeof(float), st, p.feats, p.dist, \
+            hipLaunchKernelGGL((h->contract_fma ? amx::gmm_dist_kernel<D, true, true> : amx::gmm_dist_kernel<D, true, false>), grid, dim3(256), \
+                               (size_t)256 * (D + 1) * sizeof(float), st, p.feats, p.dist,                                               \
                                dist64, p.d_mean, p.d_cov, p.means, p.isr, dims, dt, (const uint32_t*)h->d_dens_pos, dt_ld);               \
         else                                                                                                                              \
-            hipLaunchKernelGGL((amx::gmm_dist_kernel<D>), grid, dim3(256), 0, st, p.feats, p.dist, dist64, p.d_mean, p.d_cov, p.means,     \
+            hipLaunchKernelGGL((h->contract_fma ? amx::gmm_dist_kernel<D, false, true> : amx::gmm_dist_kernel<D, false, false>), grid,    \
+                               dim3(256), 0, st, p.feats, p.dist, dist64, p.d_mean, p.d_cov, p.means,                                    \
                                p.isr, dims, dt, (const uint32_t*)h->d_dens_pos, dt_ld);                                                   \
         break;
         AMX_GMM_CASE(16)
@@ -1902,7 +1925,7 @@ int launch_dist(amx_gmm* h, const amx::GmmDistParams& p, dim3 grid, double* dist
 #undef AMX_GMM_CASE
         default:
             lds = (size_t)4 * 64 * h->dim * sizeof(float);
-            hipLaunchKernelGGL((amx::gmm_dist_kernel<0>), grid, dim3(256), lds, st, p.feats, p.dist, dist64, p.d_mean, p.d_cov, p.means,
+            hipLaunchKernelGGL((h->contract_fma ? amx::gmm_dist_kernel<0, false, true> : amx::gmm_dist_kernel<0, false, false>), grid, dim3(256), lds, st, p.feats, p.dist, dist64, p.d_mean, p.d_cov, p.means,
                                p.isr, dims, dt, (const uint32_t*)h->d_dens_pos, dt_ld);
     }
     AMX_HIP(hipGetLastError());
@@ -1937,17 +1960,37 @@ int amx_gmm_create(amx_ctx* ctx, const amx_gmm_model* m, amx_gmm** out) {
     amx::Tuning tune;
     if (!tune.parse(m->tuning, amx::gmm_tuning_keys, "amx_gmm_create"))
         return AMX_ERR_INVALID;
+    // values are checked like keys: a typo must not silently select the default kernel (or the other arithmetic)
+    int         t_screen, t_fused, t_screen_all, t_tied_prune, t_chunk, t_fused_waves, t_fr, t_simd_mfma, t_graph;
+    std::string t_screen_kernel, t_contract;
+    static const char* const screen_kernels[] = {"rows", "persist", "simple", nullptr};
+    static const char* const contracts[]      = {"off", "fma", nullptr};
+    const char*              who              = "amx_gmm_create";
+    if (!tune.get_int("screen", 1, 0, 1, &t_screen, who) || !tune.get_int("fused", 1, 0, 1, &t_fused, who) ||
+        !tune.get_int("screen_all", 0, 0, 1, &t_screen_all, who) || !tune.get_int("tied_prune", -1, -1, 1, &t_tied_prune, who) ||
+        !tune.get_int("chunk", 65536, 256, 1 << 24, &t_chunk, who) || !tune.get_int("fused_waves", 0, 0, 16, &t_fused_waves, who) ||
+        !tune.get_int("fr", 8, 2, 16, &t_fr, who) || !tune.get_int("simd_mfma", 1, 0, 1, &t_simd_mfma, who) ||
+        !tune.get_int("graph", 1, 0, 1, &t_graph, who) || !tune.get_word("screen_kernel", "rows", screen_kernels, &t_screen_kernel, who) ||
+        !tune.get_word("contract", "off", contracts, &t_contract, who))
+        return AMX_ERR_INVALID;
+    AMX_REQUIRE(t_fused_waves == 0 || t_fused_waves == 8 || t_fused_waves == 12 || t_fused_waves == 13 || t_fused_waves == 16, AMX_ERR_INVALID,
+                "amx_gmm_create: tuning fused_waves=%d: expected 8 | 12 | 13 | 16", t_fused_waves);
+    AMX_REQUIRE(t_fr == 2 || t_fr == 4 || t_fr == 8 || t_fr == 16, AMX_ERR_INVALID, "amx_gmm_create: tuning fr=%d: expected 2 | 4 | 8 | 16", t_fr);
+    // contract=fma exists for the specialised-wave experiment's kernel neither (fused_waves=13): a measured-slower lab form
+    AMX_REQUIRE(!(t_contract == "fma" && t_fused_waves == 13), AMX_ERR_UNSUPPORTED,
+                "amx_gmm_create: tuning contract=fma has no fused_waves=13 kernel (the specialised-wave form exists for contract=off only)");
     amx_gmm* h = new amx_gmm;
-    h->tune_screen        = tune.get("screen", 1);
-    h->tune_fused         = tune.get("fused", 1);
-    h->tune_screen_all    = tune.get("screen_all", 0);
-    h->tune_tied_prune    = tune.get("tied_prune", -1);
-    h->tune_chunk         = std::max(256, tune.get("chunk", 65536));
-    h->tune_fused_waves   = tune.get("fused_waves", 0);
-    h->tune_fr            = std::max(1, tune.get("fr", 8));
-    h->tune_simd_mfma     = tune.get("simd_mfma", 1);
-    h->tune_screen_kernel = tune.str("screen_kernel", "rows");
-    h->use_graphs         = tune.get("graph", 1);
+    h->tune_screen        = t_screen;
+    h->tune_fused         = t_fused;
+    h->tune_screen_all    = t_screen_all;
+    h->tune_tied_prune    = t_tied_prune;
+    h->tune_chunk         = t_chunk;
+    h->tune_fused_waves   = t_fused_waves;
+    h->tune_fr            = t_fr;
+    h->tune_simd_mfma     = t_simd_mfma;
+    h->tune_screen_kernel = t_screen_kernel;
+    h->use_graphs         = t_graph;
+    h->contract_fma       = t_contract == "fma";
     h->ctx     = ctx;
     h->dim     = m->dim;
     h->n_mix   = m->n_mix;
@@ -1978,7 +2021,8 @@ int amx_gmm_create(amx_ctx* ctx, const amx_gmm_model* m, amx_gmm** out) {
             h->isr[(size_t)c * m->dim + i] = inv * gs;
             lsum += std::log((double)std::fabs(var[i]));
         }
-        float ln      = (float)((double)m->dim * std::log((double)2 * M_PI) + lsum);
+        // gaussLogNormFactor (Mm/Utilities.hh:70-75): N * log(2 pi) + logNorm; one vfmadd in the reference's default build
+        float ln      = (float)(h->contract_fma ? std::fma((double)m->dim, std::log((double)2 * M_PI), lsum) : (double)m->dim * std::log((double)2 * M_PI) + lsum);
         h->lognorm[c] = ln * (gs * gs);
     }
     std::vector<uint32_t> k_mean(nk), k_cov(nk), k_dens(nk);
@@ -2030,7 +2074,7 @@ int amx_gmm_create(amx_ctx* ctx, const amx_gmm_model* m, amx_gmm** out) {
             isr0[i] = (float)1 / (float)std::sqrt((double)m->variances[i]);
             lsum += std::log((double)std::fabs(m->variances[i]));
         }
-        const float ln = (float)((double)m->dim * std::log((double)2 * M_PI) + lsum);
+        const float ln = (float)(h->contract_fma ? std::fma((double)m->dim, std::log((double)2 * M_PI), lsum) : (double)m->dim * std::log((double)2 * M_PI) + lsum);
         for (int j = 0; j < m->n_mean; ++j)
             for (int i = 0; i < m->dim; ++i)
                 smeans[(size_t)j * m->dim + i] = m->means[(size_t)j * m->dim + i] * isr0[i];
@@ -2364,6 +2408,11 @@ int amx_gmm_score_dev(amx_gmm* h, int mode, const float* feats_dev, int T, float
     AMX_REQUIRE(feats_dev && scores_dev, AMX_ERR_INVALID, "amx_gmm_score_dev: NULL buffer");
     AMX_HIP(hipSetDevice(h->ctx->device));
     const int fblocks = amx::ceil_div(T, 256);
+    // contract=fma covers the scorers whose contraction sites were read off the reference built both ways (maximum, log-add,
+    // batch-float); the quantised and preselection scorers (clustering distances, quantiser, int conversions)
+    // have not been examined under the reference's default flags and refuse rather than claim a build they were not checked against
+    AMX_REQUIRE(!h->contract_fma || mode == AMX_GMM_MAX || mode == AMX_GMM_SUM || mode == AMX_GMM_BATCH_FLOAT, AMX_ERR_UNSUPPORTED,
+                "amx_gmm_score_dev: tuning contract=fma covers modes maximum / sum / batch-float only (mode %d)", mode);
     if (mode == AMX_GMM_SIMD || mode == AMX_GMM_BATCH_INT || mode == AMX_GMM_PRESELECTION_INT) {
         const int r = ensure_simd(h);
         if (r != AMX_OK)
@@ -2407,7 +2456,7 @@ int amx_gmm_score_dev(amx_gmm* h, int mode, const float* feats_dev, int T, float
         switch (h->dim) {
 #define AMX_GMM_CASE(D)                                                                                                   \
     case D:                                                                                                               \
-        hipLaunchKernelGGL((amx::gmm_batch_float_kernel<D>), grid, dim3(256), 0, h->ctx->stream, feats_dev, scores_dev,    \
+        hipLaunchKernelGGL((h->contract_fma ? amx::gmm_batch_float_kernel<D, true> : amx::gmm_batch_float_kernel<D, false>), grid, dim3(256), 0, h->ctx->stream, feats_dev, scores_dev,    \
                            h->d_mix_off, h->d_k_mean, h->d_k_const, h->d_smeans, h->d_isr0, dims);                         \
         break;
             AMX_GMM_CASE(16)
@@ -2421,7 +2470,7 @@ int amx_gmm_score_dev(amx_gmm* h, int mode, const float* feats_dev, int T, float
             AMX_GMM_CASE(64)
 #undef AMX_GMM_CASE
             default:  // any other dimension: the same arithmetic with the feature row re-read from memory
-                hipLaunchKernelGGL((amx::gmm_batch_float_kernel<0>), grid, dim3(256), 0, h->ctx->stream, feats_dev, scores_dev, h->d_mix_off,
+                hipLaunchKernelGGL((h->contract_fma ? amx::gmm_batch_float_kernel<0, true> : amx::gmm_batch_float_kernel<0, false>), grid, dim3(256), 0, h->ctx->stream, feats_dev, scores_dev, h->d_mix_off,
                                    h->d_k_mean, h->d_k_const, h->d_smeans, h->d_isr0, dims);
                 break;
         }
@@ -2957,7 +3006,7 @@ int amx_gmm_best_density_dev(amx_gmm* h, const float* feats_dev, int T, const ui
     AMX_REQUIRE(feats_dev && mixture_dev && best_density_dev, AMX_ERR_INVALID, "amx_gmm_best_density_dev: NULL buffer");
     AMX_HIP(hipSetDevice(h->ctx->device));
     amx::ScopedKernelTimer timer(h->ctx, "gmm_best_density");
-    hipLaunchKernelGGL(amx::gmm_best_density_kernel, dim3((T + 255) / 256), dim3(256), 0, h->ctx->stream, feats_dev, mixture_dev, best_density_dev,
+    hipLaunchKernelGGL((h->contract_fma ? amx::gmm_best_density_kernel<true> : amx::gmm_best_density_kernel<false>), dim3((T + 255) / 256), dim3(256), 0, h->ctx->stream, feats_dev, mixture_dev, best_density_dev,
                        scores_dev, h->d_mix_off, h->d_k_mean, h->d_k_cov, h->d_k_c64, h->d_means, h->d_isr, T, h->dim, h->n_mix);
     AMX_HIP(hipGetLastError());
     return AMX_OK;
@@ -2978,7 +3027,7 @@ int amx_gmm_accumulate_dev(amx_gmm* h, const float* feats_dev, int T, const uint
     const int              blocks = (T + 255) / 256;
     amx::ScopedKernelTimer timer(h->ctx, "gmm_accumulate");
     hipLaunchKernelGGL(amx::gmm_accumulate_kernel, dim3(blocks), dim3(256), 0, h->ctx->stream, feats_dev, mixture_dev, best_density_dev,
-                       (const unsigned char*)nullptr, best_density_ld, T, h->dim, h->d_mix_off, h->d_k_dens, h->d_d_mean, h->d_d_cov, acc_dev,
+                       (const unsigned char*)nullptr, best_density_ld, T, h->dim, h->n_mix, h->d_mix_off, h->d_k_dens, h->d_d_mean, h->d_d_cov, acc_dev,
                        off_mw, off_ms, off_cw, off_cs, pooled);
     AMX_HIP(hipGetLastError());
     return AMX_OK;
@@ -2999,7 +3048,7 @@ int amx_gmm_accumulate_u8_dev(amx_gmm* h, const float* feats_dev, int T, const u
     const int              blocks = (T + 255) / 256;
     amx::ScopedKernelTimer timer(h->ctx, "gmm_accumulate");
     hipLaunchKernelGGL(amx::gmm_accumulate_kernel, dim3(blocks), dim3(256), 0, h->ctx->stream, feats_dev, mixture_dev, (const uint32_t*)nullptr,
-                       (const unsigned char*)best_density_dev, best_density_ld, T, h->dim, h->d_mix_off, h->d_k_dens, h->d_d_mean, h->d_d_cov,
+                       (const unsigned char*)best_density_dev, best_density_ld, T, h->dim, h->n_mix, h->d_mix_off, h->d_k_dens, h->d_d_mean, h->d_d_cov,
                        acc_dev, off_mw, off_ms, off_cw, off_cs, pooled);
     AMX_HIP(hipGetLastError());
     return AMX_OK;
@@ -3030,8 +3079,8 @@ int amx_gmm_accumulate_weighted_dev(amx_gmm* h, int mode, const float* feats_dev
     const int              per_block = 4 * amx::kBwFramesPerWave;
     const int              blocks = (T + per_block - 1) / per_block;
     amx::ScopedKernelTimer timer(h->ctx, "gmm_accumulate_weighted");
-    hipLaunchKernelGGL(amx::gmm_accumulate_weighted_kernel, dim3(blocks), dim3(256), 0, h->ctx->stream, mode, feats_dev, mixture_dev,
-                       weight_dev, best_density_dev, best_density_ld, T, h->dim, h->d_mix_off, h->d_k_dens, h->d_d_mean, h->d_d_cov,
+    hipLaunchKernelGGL((h->contract_fma ? amx::gmm_accumulate_weighted_kernel<true> : amx::gmm_accumulate_weighted_kernel<false>), dim3(blocks), dim3(256), 0, h->ctx->stream, mode, feats_dev, mixture_dev,
+                       weight_dev, best_density_dev, best_density_ld, T, h->dim, h->n_mix, h->d_mix_off, h->d_k_dens, h->d_d_mean, h->d_d_cov,
                        h->d_k_c32, h->d_means, h->d_isr, acc_dev, off_mw, off_ms, off_cw, off_cs, pooled);
     AMX_HIP(hipGetLastError());
     return AMX_OK;

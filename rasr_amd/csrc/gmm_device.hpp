@@ -4,12 +4,21 @@
 
 namespace amx {
 
+// The reference's `sum += df * df` in its two builds (amx_gmm_model.tuning contract=off | fma, include/amx.h): built for plain x86-64
+// the product and the sum round separately; its default -march=native build on an FMA host contracts them to one vfmadd231ps
+// (cmake_resources/CompileOptions.cmake:21-48; tests/test_contract.py: the function text compiled both ways).  This file is compiled with
+// -ffp-contract=off, so the fused form only ever comes from here.
+template<bool FMA>
+__device__ __forceinline__ float sq_acc(float d, float acc) {
+    return FMA ? __builtin_fmaf(d, d, acc) : acc + d * d;
+}
+
 // Same arithmetic, two dimensions per instruction: v_pk_add_f32 / v_pk_mul_f32 round each half exactly like the scalar
 // operations (nothing is fused), and the partial sums (l0, l1) and (l2, l3) are updated as pairs -- bit-identical to
 // gmm_distance at half the instruction count.  mu and is must be 8-byte aligned.
 typedef float gmm_pk2 __attribute__((ext_vector_type(2)));
 
-template<int DIM>
+template<int DIM, bool FMA = false>
 __device__ __forceinline__ float gmm_distance_pk(const float (&x)[DIM], const float* __restrict__ mu, const float* __restrict__ is) {
     gmm_pk2       l01 = {0.f, 0.f}, l23 = {0.f, 0.f};
     constexpr int EFF = DIM & ~3;
@@ -17,21 +26,27 @@ __device__ __forceinline__ float gmm_distance_pk(const float (&x)[DIM], const fl
     for (int i = 0; i < EFF; i += 4) {
         const gmm_pk2 d01 = (*(const gmm_pk2*)(mu + i) - gmm_pk2{x[i], x[i + 1]}) * *(const gmm_pk2*)(is + i);
         const gmm_pk2 d23 = (*(const gmm_pk2*)(mu + i + 2) - gmm_pk2{x[i + 2], x[i + 3]}) * *(const gmm_pk2*)(is + i + 2);
-        l01               = l01 + d01 * d01;
-        l23               = l23 + d23 * d23;
+        if (FMA) {
+            l01 = gmm_pk2{__builtin_fmaf(d01.x, d01.x, l01.x), __builtin_fmaf(d01.y, d01.y, l01.y)};
+            l23 = gmm_pk2{__builtin_fmaf(d23.x, d23.x, l23.x), __builtin_fmaf(d23.y, d23.y, l23.y)};
+        }
+        else {
+            l01 = l01 + d01 * d01;
+            l23 = l23 + d23 * d23;
+        }
     }
     float result = 0.f;
     result       = result + ((l01.x + l01.y) + (l23.x + l23.y));
 #pragma unroll
     for (int i = EFF; i < DIM; ++i) {
         float df = (mu[i] - x[i]) * is[i];
-        result   = result + df * df;
+        result   = sq_acc<FMA>(df, result);
     }
     return result;
 }
 
 // the same with the mean already in registers (software-pipelined callers)
-template<int DIM>
+template<int DIM, bool FMA = false>
 __device__ __forceinline__ float gmm_distance_pk_reg(const float (&x)[DIM], const float (&mu)[DIM], const float* __restrict__ is) {
     gmm_pk2       l01 = {0.f, 0.f}, l23 = {0.f, 0.f};
     constexpr int EFF = DIM & ~3;
@@ -39,15 +54,21 @@ __device__ __forceinline__ float gmm_distance_pk_reg(const float (&x)[DIM], cons
     for (int i = 0; i < EFF; i += 4) {
         const gmm_pk2 d01 = (gmm_pk2{mu[i], mu[i + 1]} - gmm_pk2{x[i], x[i + 1]}) * *(const gmm_pk2*)(is + i);
         const gmm_pk2 d23 = (gmm_pk2{mu[i + 2], mu[i + 3]} - gmm_pk2{x[i + 2], x[i + 3]}) * *(const gmm_pk2*)(is + i + 2);
-        l01               = l01 + d01 * d01;
-        l23               = l23 + d23 * d23;
+        if (FMA) {
+            l01 = gmm_pk2{__builtin_fmaf(d01.x, d01.x, l01.x), __builtin_fmaf(d01.y, d01.y, l01.y)};
+            l23 = gmm_pk2{__builtin_fmaf(d23.x, d23.x, l23.x), __builtin_fmaf(d23.y, d23.y, l23.y)};
+        }
+        else {
+            l01 = l01 + d01 * d01;
+            l23 = l23 + d23 * d23;
+        }
     }
     float result = 0.f;
     result       = result + ((l01.x + l01.y) + (l23.x + l23.y));
 #pragma unroll
     for (int i = EFF; i < DIM; ++i) {
         float df = (mu[i] - x[i]) * is[i];
-        result   = result + df * df;
+        result   = sq_acc<FMA>(df, result);
     }
     return result;
 }
@@ -93,7 +114,7 @@ struct ScaledRow<0> {
 
 // Mm::BatchFloatFeatureScorer's distance (Mm/BatchFeatureScorer.cc:164-254): two 4-lane f32 accumulators over 8-wide blocks, lane 0
 // of the first starts at the density's constant; a = s1 + s2; (a3 + a1) + (a2 + a0)
-template<int DIM, class Row>
+template<int DIM, bool FMA, class Row>
 __device__ __forceinline__ float batch_float_distance(const float* __restrict__ mu, const Row& x, float c0, int dim_rt) {
     float s1[4] = {c0, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
     auto  block = [&](int d, int n) {
@@ -101,11 +122,11 @@ __device__ __forceinline__ float batch_float_distance(const float* __restrict__ 
         for (int j = 0; j < 4; ++j) {
             if (d + j < n) {
                 float x1 = mu[d + j] - x(d + j);
-                s1[j]    = s1[j] + x1 * x1;
+                s1[j]    = sq_acc<FMA>(x1, s1[j]);  // _mm_add_ps(s1, _mm_mul_ps(x1, x1)): fused in the reference's default build
             }
             if (d + 4 + j < n) {
                 float x2 = mu[d + 4 + j] - x(d + 4 + j);
-                s2[j]    = s2[j] + x2 * x2;
+                s2[j]    = sq_acc<FMA>(x2, s2[j]);
             }
         }
     };

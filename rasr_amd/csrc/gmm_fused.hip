@@ -86,7 +86,12 @@ __device__ unsigned long long fused_stamps[16 * 64 * 6];
 // BEST: 0 scores only | 1 best density as u32 [T x n_mix] | 2 as ONE BYTE per (frame, mixture) (g_best is then a byte matrix with
 // rows of n_mix bytes; 0xff where the u32 form writes 0xffffffff): a quarter of the index MEMORY, 10 MB instead of 40 per 1000 frames --
 // the same time (what BEST costs this kernel is the vector work of tracking the index, 0.3 ms of 4.7, not the bytes)
-template<int DIM, int BEST, int NW>
+// FMA: the reference's two builds (amx_gmm_model.tuning contract=off | fma, gmm_device.hpp sq_acc): false = `sum += df * df` as a
+// product and a sum (-DMARCH=x86-64), true = as ONE v_fmac_f32, what the reference's default -march=native build executes on an FMA
+// host -- three vector operations per dimension and survivor instead of four.  The screen does not change: its threshold bounds the
+// distance of the f16 operands to the EXACT sum plus the (dim + 3) ulp of the unfused f32 evaluation, and the fused evaluation
+// rounds half as often.
+template<int DIM, int BEST, int NW, bool FMA = false>
 __global__ __launch_bounds__(NW * 64) void gmm_fused_kernel(const float* __restrict__ g_feats, const _Float16* __restrict__ g_X,
                                                         const float* __restrict__ g_nx, const float* __restrict__ g_q,
                                                         const char* __restrict__ g_rec, const float* __restrict__ g_isr,
@@ -246,17 +251,17 @@ __global__ __launch_bounds__(NW * 64) void gmm_fused_kernel(const float* __restr
                 const float4 m  = *(const float4*)(src + i);
                 const float  d0 = (m.x - x[i]) * g_isr[i], d1 = (m.y - x[i + 1]) * g_isr[i + 1];
                 const float  d2 = (m.z - x[i + 2]) * g_isr[i + 2], d3 = (m.w - x[i + 3]) * g_isr[i + 3];
-                l0              = l0 + d0 * d0;
-                l1              = l1 + d1 * d1;
-                l2              = l2 + d2 * d2;
-                l3              = l3 + d3 * d3;
+                l0              = sq_acc<FMA>(d0, l0);
+                l1              = sq_acc<FMA>(d1, l1);
+                l2              = sq_acc<FMA>(d2, l2);
+                l3              = sq_acc<FMA>(d3, l3);
             }
             float result = 0.f;
             result       = result + ((l0 + l1) + (l2 + l3));
 #pragma unroll
             for (int i = EFF; i < DIM; ++i) {
                 const float df = (src[i] - x[i]) * g_isr[i];
-                result         = result + df * df;
+                result         = sq_acc<FMA>(df, result);
             }
             cc = *(const double*)(src + LD - 2);
             return result;
@@ -844,14 +849,14 @@ extern "C" int amx_internal_gmm_fused_split(int n_cu, int Tpad, int n_tiles, int
 extern "C" int amx_internal_gmm_fused_score(amx_ctx* ctx, int dim, const void* rec_dev, const float* isr_dev, const float* feats,
                                             const void* X, const float* nx, const float* q, int T, int Tpad, int n_mix, int n_tiles,
                                             int split, float* scores, uint32_t* best, float* pmin, unsigned* pidx, int part_ld,
-                                            unsigned long long* survivors, int forced_waves, int best_bytes) {
+                                            unsigned long long* survivors, int forced_waves, int best_bytes, int contract_fma) {
     const int   nw = fused_waves(Tpad, forced_waves), fpw = fused_frames(Tpad, forced_waves), ntt = (Tpad + fpw - 1) / fpw;
     const int   lds = 2 * amx::fused_rec_bytes(dim);
     const char* rec = (const char*)rec_dev;
     hipStream_t st  = ctx->stream;
 #define AMX_FUSED_LAUNCH(D, B, W)                                                                                               \
     {                                                                                                                           \
-        auto k = amx::gmm_fused_kernel<D, B, W>;                                                                                \
+        auto k = contract_fma ? amx::gmm_fused_kernel<D, B, W, true> : amx::gmm_fused_kernel<D, B, W, false>;                   \
         hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);                                   \
         hipLaunchKernelGGL(k, dim3(ntt * split), dim3(W * 64), lds, st, feats, (const _Float16*)X, nx, q, rec, isr_dev, scores,  \
                            best, T, Tpad, n_mix, n_tiles, split, pmin, pidx, part_ld, survivors);                          \
@@ -872,9 +877,14 @@ extern "C" int amx_internal_gmm_fused_score(amx_ctx* ctx, int dim, const void* r
         else if (best && best_bytes == 1) AMX_FUSED_LAUNCH(D, 2, 8)                                                             \
         else if (best && nw == 12) AMX_FUSED_LAUNCH(D, 1, 12)                                                                   \
         else if (best) AMX_FUSED_LAUNCH(D, 1, 8)                                                                                \
+        else if (nw == 16) AMX_FUSED_LAUNCH(D, 0, 16)                                                                           \
         else if (nw == 12) AMX_FUSED_LAUNCH(D, 0, 12)                                                                           \
         else AMX_FUSED_LAUNCH(D, 0, 8)                                                                                          \
     } break;
+    if (nw == 13 && contract_fma) {
+        amx::set_error("gmm fused scorer: the specialised-wave kernel (fused_waves=13) exists for contract=off only");
+        return AMX_ERR_UNSUPPORTED;
+    }
     if (best && best_bytes == 1 && nw != 8 && nw != 12) {
         amx::set_error("gmm fused scorer: byte-sized best densities exist for the 8- and 12-wave kernels only (fused_waves=%d)", nw);
         return AMX_ERR_UNSUPPORTED;

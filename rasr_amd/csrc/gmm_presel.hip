@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void presel_score_kernel(const float* __restri
             if (am == 0ull)
                 continue;  // no frame of this wave selected the density's cluster
             const float* mu = g_smeans + (size_t)g_k_mean[k] * dim;
-            const float  r  = batch_float_distance<DIM>(mu, x, g_k_const[k], dim);
+            const float  r  = batch_float_distance<DIM, false>(mu, x, g_k_const[k], dim);
             const bool  act = (am >> lane) & 1ull;
             best            = (act && r < best) ? r : best;
         }

@@ -549,7 +549,12 @@ int amx_internal_gmm_simd_create(const amx_gmm_model* m, void** out, float* scal
         amx_internal_gmm_simd_destroy(s);
         return AMX_ERR_INVALID;
     }
-    const bool want = tune.get("simd_mfma", 1) != 0;
+    int want_i = 1;
+    if (!tune.get_int("simd_mfma", 1, 0, 1, &want_i, "amx_gmm_create")) {
+        amx_internal_gmm_simd_destroy(s);
+        return AMX_ERR_INVALID;
+    }
+    const bool want = want_i != 0;
     if (want && m->n_cov == 1 && dim <= 64 && kmax <= 16) {
         const int           n_tiles = (m->n_mix + 15) / 16;
         std::vector<int8_t> A((size_t)n_tiles * 256 * 64, 0);

@@ -1268,17 +1268,23 @@ int amx_mfcc_create(amx_ctx* ctx, const amx_mfcc_cfg* cfg, amx_mfcc** out) {
         static const char* const keys[] = {"fft", "wgs", "lpc", "prefetch", nullptr};
         if (!tune.parse(cfg->tuning, keys, "amx_mfcc_create"))
             return AMX_ERR_INVALID;
-        const std::string fft = tune.str("fft", "stockham"), lpc = tune.str("lpc", "regs");
-        AMX_REQUIRE(fft == "stockham" || fft == "mfma" || fft == "r16", AMX_ERR_INVALID, "amx_mfcc_create: tuning fft=%s (stockham | mfma | r16)",
-                    fft.c_str());
-        AMX_REQUIRE(lpc == "regs" || lpc == "lds", AMX_ERR_INVALID, "amx_mfcc_create: tuning lpc=%s (regs | lds)", lpc.c_str());
+    }
+    std::string t_fft, t_lpc;
+    int         t_wgs, t_prefetch;
+    {
+        static const char* const ffts[] = {"stockham", "mfma", "r16", nullptr};
+        static const char* const lpcs[] = {"regs", "lds", nullptr};
+        const char*              who    = "amx_mfcc_create";
+        if (!tune.get_word("fft", "stockham", ffts, &t_fft, who) || !tune.get_word("lpc", "regs", lpcs, &t_lpc, who) ||
+            !tune.get_int("wgs", 0, 0, 64, &t_wgs, who) || !tune.get_int("prefetch", 1, 0, 1, &t_prefetch, who))
+            return AMX_ERR_INVALID;
     }
     amx_mfcc* h = new amx_mfcc;
     h->ctx      = ctx;
-    h->tune_fft_mfma = tune.str("fft", "stockham") == "mfma";
-    h->tune_lpc_lds  = tune.str("lpc", "regs") == "lds";
-    h->tune_wgs      = tune.get("wgs", 0);
-    h->tune_prefetch = tune.get("prefetch", 1) != 0;  // default since the end of round 4 (0.753 -> 0.73 ms on config 2)
+    h->tune_fft_mfma = t_fft == "mfma";
+    h->tune_lpc_lds  = t_lpc == "lds";
+    h->tune_wgs      = t_wgs;
+    h->tune_prefetch = t_prefetch != 0;  // default since the end of round 4 (0.753 -> 0.73 ms on config 2)
     int r       = h->tab.build(*cfg);
     if (r != AMX_OK) {
         delete h;
@@ -1296,7 +1302,7 @@ int amx_mfcc_create(amx_ctx* ctx, const amx_mfcc_cfg* cfg, amx_mfcc** out) {
     }
     AMX_HIP(hipSetDevice(ctx->device));
     h->frames_per_tile = amx::FT;
-    h->fft_r16         = tune.str("fft", "stockham") == "r16" && t.fft_len == 512 && cfg->front_end == AMX_FRONT_END_MFCC;  // (other lengths and front ends: the Stockham stages)
+    h->fft_r16         = t_fft == "r16" && t.fft_len == 512 && cfg->front_end == AMX_FRONT_END_MFCC;  // (other lengths and front ends: the Stockham stages)
     h->lds_bytes       = mfcc_lds_bytes(t, h->fft_r16);
     if (h->lds_bytes > 160 * 1024) {
         amx::set_error("amx_mfcc_create: configuration needs %zu bytes of LDS per workgroup (> 160 KiB)", h->lds_bytes);

@@ -11,11 +11,17 @@ def feats(T, dim, seed):
     return np.random.Generator(np.random.PCG64(seed)).standard_normal((T, dim)).astype(np.float32)
 
 
+def contract_of(tuning):
+    """which build of the reference a tuning string asks for: "contract=fma" -> "fma", else "off" (the oracle library to compare with)"""
+    return "fma" if "contract=fma" in (tuning or "") else "off"
+
+
 def assert_exact(ctx, model, x, **kw):
     import rasr_amd
     from oracle import OracleGmm
     sc, best = rasr_amd.GmmFeatureScorer(ctx, model, **kw).score(x)
-    osc, obest = OracleGmm(model, **{k: v for k, v in kw.items() if k not in ("feature_scorer_type", "tuning")}).score(x, mode=0)
+    osc, obest = OracleGmm(model, contract=contract_of(kw.get("tuning")),
+                           **{k: v for k, v in kw.items() if k not in ("feature_scorer_type", "tuning")}).score(x, mode=0)
     assert np.array_equal(sc.view(np.uint32), osc.view(np.uint32)), np.abs(sc - osc).max()
     assert np.array_equal(best, obest)
 
@@ -176,6 +182,70 @@ def test_viterbi_accumulators(ctx, pooled):
     sc.accumulate_dev(xd, 3000, mix, chosen, 0, acc2)
     torch.cuda.synchronize()
     assert np.allclose(acc2.cpu().numpy(), want, rtol=1e-12, atol=1e-9)
+
+
+@pytest.mark.parametrize("pooled", [True, False])
+def test_accumulators_skip_frames_without_a_density(ctx, pooled):
+    """a NaN frame has no best density (0xffffffff / 0xff: what the scorers and amx_gmm_best_density_dev write), a mixture index may lie
+    outside the model, an index may point behind its mixture's last density: such frames contribute NOTHING to the statistics -- in the
+    u32 matrix form, the byte matrix form, the per-frame list (best_density_ld = 0) and the weighted kernel.  (The sentinel used to be
+    added to mix_off[m]: the frame went to the previous mixture's last density, or 4 G entries out of bounds for mixture 0.)"""
+    import torch
+
+    import rasr_amd
+    model = synth.gmm_cart(40, 2, 6, 24, seed=160, pooled=pooled)
+    T, M = 700, 40
+    x = feats(T, 24, 161)
+    x[5, 3] = np.nan          # frame 5: no density beats FLT_MAX
+    x[300] = np.inf
+    sc = rasr_amd.GmmFeatureScorer(ctx, model)
+    xd = torch.from_numpy(x).cuda()
+    scores = torch.empty((T, M), dtype=torch.float32, device="cuda")
+    best = torch.empty((T, M), dtype=torch.int32, device="cuda")
+    ctx.use_torch_stream()
+    sc.score_dev(xd, T, scores, best)
+    mix = np.random.Generator(np.random.PCG64(162)).integers(0, M, T).astype(np.int32)
+    mix[0] = 0                # mixture 0 with the sentinel: the old code read k_dens[0xffffffff]
+    mix[17] = M               # outside the model
+    mix[18] = -1
+    md = torch.from_numpy(mix).cuda()
+    bh = best.cpu().numpy().astype(np.uint32)
+    assert (bh[5] == 0xffffffff).all() and (bh[300] == 0xffffffff).all()
+    bh[0, 0] = 0xffffffff
+    bh[40, mix[40]] = 6       # behind the last density of a mixture with fewer than seven
+    n_of = np.diff(model["mix_offsets"])
+    if n_of[mix[40]] > 6:
+        bh[40, mix[40]] = 0xfffffffe
+    skip = np.zeros(T, bool)
+    skip[[0, 5, 17, 18, 40, 300]] = True
+    # what the statistics must be: the oracle over the frames that do have a density
+    from oracle import OracleGmm
+    keep = np.nonzero(~skip)[0]
+    want = OracleGmm(model).accumulate(x[keep], mix[keep].astype(np.uint32), bh[keep, mix[keep]])
+    nk = int(model["mix_offsets"][-1])
+    full = torch.from_numpy(bh.astype(np.int32)).cuda()
+    acc = torch.zeros(sc.accumulator_size(), dtype=torch.float64, device="cuda")
+    sc.accumulate_dev(xd, T, md, full, M, acc)                                             # u32 matrix
+    torch.cuda.synchronize()
+    got = acc.cpu().numpy()
+    assert np.isfinite(got).all() and got[:nk].sum() == len(keep) and np.array_equal(got[:nk], want[:nk])
+    assert np.allclose(got, want, rtol=1e-12, atol=1e-9)
+    b8 = torch.from_numpy(np.minimum(bh, 255).astype(np.uint8)).cuda()                    # byte matrix (0xff = no density)
+    acc.zero_()
+    sc.accumulate_dev(xd, T, md, b8, M, acc)
+    torch.cuda.synchronize()
+    assert np.allclose(acc.cpu().numpy(), want, rtol=1e-12, atol=1e-9) and acc.cpu().numpy()[:nk].sum() == len(keep)
+    safe = np.clip(mix, 0, M - 1)
+    per = torch.from_numpy(np.where((mix >= 0) & (mix < M), bh[np.arange(T), safe], 0).astype(np.int32)).cuda()   # per-frame list
+    acc.zero_()
+    sc.accumulate_dev(xd, T, md, per, 0, acc)
+    torch.cuda.synchronize()
+    assert np.allclose(acc.cpu().numpy(), want, rtol=1e-12, atol=1e-9)
+    w = torch.ones(T, dtype=torch.float64, device="cuda")                                  # weighted Viterbi, unit weights
+    acc.zero_()
+    sc.accumulate_weighted_dev(rasr_amd.AMX_GMM_VITERBI, xd, T, md, w, full, M, acc)
+    torch.cuda.synchronize()
+    assert np.allclose(acc.cpu().numpy(), want, rtol=1e-12, atol=1e-9)
 
 
 def _tied_adversarial(seed, n_mix, n_dens, dim, dup_every, big=False):
