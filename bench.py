@@ -426,14 +426,36 @@ class NnPipeline:
         self.red.all_reduce(comm=getattr(self, "comm", None))   # ONE collective (amx_comm_all_reduce_f64_dev; no-op in a single process)
 
     def roofline(self):
-        # dominant kernel: the output-layer GEMM (2048 -> 10000), 48 % of the chain's flops
-        ms, n = self.ctx.profile_get("ffnn_gemm_max")
-        if n == 0:
+        """The GEMM TEMPLATE of the NN leg (the kernel with the largest summed time of the step): algorithmic flops of all seven layers
+        (84.7 MFLOP per frame) over the summed HIP-event time of their launches, against the dense bf16 / f16 matrix peak.
+        `frac` is ALGORITHMIC (one f32 product of the reference = one unit); what the matrix pipes execute for it is next to it:
+        f16mx = one f16 product + half an fp6 x fp6 32x32x64 product per 16 k, nominally 1.5 units -- measured, the fp6 product costs
+        1.6 f16 products on this chip (tools/feed_probe.hip), i.e. 1.8 units; bf16x3 = 3 units.  The output layer alone: `largest_launch`."""
+        ms_o, n_o = self.ctx.profile_get("ffnn_gemm_max")
+        ms_h, n_h = self.ctx.profile_get("ffnn_gemm")
+        if n_o == 0:
             return None
         rows = []
         for t0 in range(0, self.F, self.CHUNK):
             rows.append(min(self.CHUNK, self.F - t0))
-        return nn_gemm_roofline(self.nn_precision, ms, n, sum(rows) / len(rows), self.F >= self.CHUNK)
+        frames = sum(rows) / len(rows)
+        largest = nn_gemm_roofline(self.nn_precision, ms_o, n_o, frames, self.F >= self.CHUNK)
+        t_ms = ms_o * n_o + ms_h * n_h                       # every GEMM launch of the profiled steps
+        alg = self.flops_per_frame * frames * n_o             # one output-layer launch per scoring pass
+        peak = FP32_TFLOPS if self.nn_precision == "fp32" else MFMA_BF16_TFLOPS
+        ach = alg / (t_ms * 1e-3) / 1e12
+        units = {"bf16x3": (3.0, 3.0), "f16mx": (1.5, 1.8)}.get(self.nn_precision, (1.0, 1.0))
+        return dict(bound="mfma", kernel={"f16mx": "gemm_mx_kernel", "fp32": "gemm_f32_kernel"}.get(self.nn_precision, "gemm_bf16_pipe_kernel") +
+                    " (all 7 GEMMs of the forward pass: 440-6x2048-10000; the template with the largest summed time of the step)",
+                    achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
+                    note="ALGORITHMIC: 2 x 42.35 M products per frame (SURVEY 8(d)) over the summed time of the %d GEMM launches" % (n_o + n_h),
+                    executed_units_per_product=dict(nominal=units[0], measured_on_this_chip=units[1],
+                                                    frac_of_peak_in_executed_units=round(units[1] * ach / peak, 4),
+                                                    what="f16mx: 1 f16 MFMA product + 0.5 fp6 x fp6 scaled product per 16 k; the scaled product "
+                                                         "costs 1.6 f16 products here (feed probe), nominally 1" if self.nn_precision == "f16mx" else
+                                                         "matrix products executed per f32 product of the reference"),
+                    traffic=None, avg_launch_ms=round(t_ms / (n_o + n_h), 4), launches=n_o + n_h, flops_per_launch=alg / (n_o + n_h),
+                    summed_ms_per_step=round(t_ms / max(1, n_o // len(rows)), 4), largest_launch=largest)
 
     def stage_report(self):
         out = {}
@@ -522,7 +544,7 @@ class Pipeline(NnPipeline):
         gm = gmm_cart_roofline(self.ctx, self.gmm, self.nk, self.M, 40, min(self.GCHUNK, self.F), 0 if self.aligned else self.gbestd.element_size())
         if gm is None:
             return nn
-        # "dominant kernel" = the one with the larger total time in the step: the GMM's exact stage or the output-layer GEMM
+        # "dominant kernel" = the kernel TEMPLATE with the larger summed time in the step: gmm_fused_kernel or the GEMM (all its launches)
         t_gmm = gm["avg_launch_ms"] * gm["launches"]
         t_nn = nn["avg_launch_ms"] * nn["launches"] if nn else 0.0
         first, second = (gm, nn) if t_gmm >= t_nn else (nn, gm)
@@ -1257,24 +1279,24 @@ def measure(ctx, job, args, world):
     gpu = ctx is not None
     for _ in range(args.warmup):
         job.step()
-    graph_mode = gpu and is_graph_mode(args)
     barrier(world, gpu)
     if gpu:
-        ctx.profile(not graph_mode)
+        ctx.profile(False)   # the timed region runs WITHOUT the per-launch events (two hipEventRecord per launch); see below
         ctx.profile_reset()
-        reset_survivor_counters(job)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         job.step()
     job.epoch_reduce(world)
     barrier(world, gpu)
     dt = time.perf_counter() - t0
-    if graph_mode:
-        # the kernel timings of a graph-replayed workload come from a separate pass with plain launches; the survivor counter is
-        # reset WITH the profiler, so that it covers exactly the launches the events cover
+    if gpu:
+        # kernel timings (roofline, stages) come from a SECOND pass over the same steps with the per-launch HIP events on (for a
+        # graph-replayed workload: with plain launches).  The survivor counter is reset WITH the profiler, so that it covers exactly
+        # the launches the events cover.
         import torch
         reset_survivor_counters(job)
         ctx.profile(True)
+        ctx.profile_reset()
         for _ in range(min(args.steps, 20)):
             job.step()
         torch.cuda.synchronize()
@@ -1525,8 +1547,10 @@ def main():
             ms_ar, n_ar = ctx.profile_get("all_reduce")
             line["epoch_reduce"] = dict(collectives=1, bytes=job.red.nbytes(),
                                         backend="rccl via amx_comm_all_reduce_f64_dev (%d ranks)" % comm.world if comm else "none (single process)")
+        line["config"]["timing"] = ("value / ms_per_step: K steps with the library's per-launch events OFF; roofline / stages: a second pass over "
+                                    "min(K, 20) steps with a HIP-event pair around every launch on the stream the kernels run on")
         if is_graph_mode(args):
-            line["config"]["launch"] = "forward pass replayed as one HIP graph; roofline / stages timed in a separate pass with plain launches"
+            line["config"]["launch"] = "forward pass replayed as one HIP graph; roofline / stages timed in the second pass with plain launches"
         if not args.no_cpu_baseline and world == 1:
             cb = cpu_baseline(args.workload, args.contract)
             line["cpu_baseline"] = cb

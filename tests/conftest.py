@@ -15,9 +15,9 @@ def pytest_configure(config):
     # amx_version(), see __graft_entry__.is_stale) or when AMX_FORCE_BUILD=1 asks for a from-scratch build.
     import __graft_entry__
     lib = os.path.join(ROOT, "rasr_amd", "librasr_amd.so")
-    orc = os.path.join(ROOT, "oracle", "liboracle.so")
+    orcs = [os.path.join(ROOT, "oracle", n) for n in ("liboracle.so", "liboracle_fma.so")]
     forced = os.environ.get("AMX_FORCE_BUILD", "0") not in ("", "0")
-    if forced or not (os.path.exists(lib) and os.path.exists(orc)) or __graft_entry__.is_stale():
+    if forced or not (os.path.exists(lib) and all(os.path.exists(o) for o in orcs)) or __graft_entry__.is_stale():
         __graft_entry__.build()
         os.environ["AMX_FORCE_BUILD"] = "0"   # once per session (pytest-xdist workers inherit the environment)
 

@@ -1,8 +1,8 @@
 #!/bin/bash
-# ablations of gemm_mx_kernel (lab build of the library: make -C rasr_amd/csrc OBJDIR=build_lab OUT=../librasr_amd_lab.so EXTRA=-DAMX_LAB)
+# ablations of gemm_mx_kernel (lab build of the library: make -C rasr_amd/csrc OBJDIR=build_lab OUT=../../tools/build/librasr_amd_lab.so EXTRA=-DAMX_LAB)
 # usage: tools/ab_mx.sh [dbg values...]   prints the output-layer time (ffnn_gemm_max) and the mean GEMM time of the NN leg
 cd "$(dirname "$0")/.."
-export AMX_LIBRARY=$PWD/rasr_amd/librasr_amd_lab.so
+export AMX_LIBRARY=$PWD/tools/build/librasr_amd_lab.so
 for d in "${@:-0 8 16 24 32 64 72}"; do
   for dd in $d; do
     AMX_TUNING=mx_dbg=$dd python bench.py --workload nn-pipeline --precision f16mx --steps 6 --warmup 2 --no-cpu-baseline --no-configs 2>&1 | grep "^{" | tail -1 | \

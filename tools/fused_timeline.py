@@ -1,5 +1,5 @@
 """tools/fused_timeline.py -- where a tile's time goes in gmm_fused_kernel (lab build: make -C rasr_amd/csrc OBJDIR=build_lab
-OUT=../librasr_amd_lab.so EXTRA=-DAMX_LAB).  Workgroup 0 of a 63 936-frame pass over the 10 000 x 16 model stamps s_memtime per wave
+OUT=../../tools/build/librasr_amd_lab.so EXTRA=-DAMX_LAB).  Workgroup 0 of a 63 936-frame pass over the 10 000 x 16 model stamps s_memtime per wave
 and tile: barrier passed, screen done, first survivors done, further survivors done, results issued.  Prints per wave the mean
 cycles of the phases over tiles 8..55 and the wait at the next barrier (= period - busy)."""
 import ctypes as C
@@ -9,7 +9,7 @@ import sys
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ.setdefault("AMX_LIBRARY", os.path.join(ROOT, "rasr_amd", "librasr_amd_lab.so"))
+os.environ.setdefault("AMX_LIBRARY", os.path.join(ROOT, "tools", "build", "librasr_amd_lab.so"))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 

@@ -1,5 +1,5 @@
 """tools/mfcc_timeline.py -- where a tile's time goes in mfcc_kernel (lab build: make -C rasr_amd/csrc OBJDIR=build_lab
-OUT=../librasr_amd_lab.so EXTRA=-DAMX_LAB CHECK=-).  Workgroup 0 of the config-2 run (1000 utterances, MFCC-40) stamps s_memtime per
+OUT=../../tools/build/librasr_amd_lab.so EXTRA=-DAMX_LAB CHECK=-).  Workgroup 0 of the config-2 run (1000 utterances, MFCC-40) stamps s_memtime per
 wave and tile: tile start, phase B (4 frames per wave: samples -> FFT -> amplitudes) done, barrier, phase C (mel filter bank + log) done,
 barrier, phase D (DCT on the matrix cores + stores) done, barrier.  Prints per wave the mean share of each interval over tiles 4..30."""
 import ctypes as C
@@ -9,7 +9,7 @@ import sys
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ.setdefault("AMX_LIBRARY", os.path.join(ROOT, "rasr_amd", "librasr_amd_lab.so"))
+os.environ.setdefault("AMX_LIBRARY", os.path.join(ROOT, "tools", "build", "librasr_amd_lab.so"))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 

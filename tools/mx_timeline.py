@@ -1,5 +1,5 @@
 """tools/mx_timeline.py [variant bits] -- where the time of a K-tile goes in gemm_mx_kernel (lab build of the library:
-make -C rasr_amd/csrc OBJDIR=build_lab OUT=../librasr_amd_lab.so EXTRA=-DAMX_LAB).
+make -C rasr_amd/csrc OBJDIR=build_lab OUT=../../tools/build/librasr_amd_lab.so EXTRA=-DAMX_LAB).
 
 Runs the config-5 output layer (2048 -> 10000, 32768 frames, f16mx) with DBG 2048 | variant bits: workgroup 0 stamps s_memtime in
 every wave for its first 48 K-tiles -- 0 barrier passed, 1 refill issued, 2 fragments in registers (an extra lgkmcnt(0): the
@@ -12,7 +12,7 @@ import sys
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ.setdefault("AMX_LIBRARY", os.path.join(ROOT, "rasr_amd", "librasr_amd_lab.so"))
+os.environ.setdefault("AMX_LIBRARY", os.path.join(ROOT, "tools", "build", "librasr_amd_lab.so"))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 

@@ -82,7 +82,7 @@ if [ -n "$ONLY" ]; then ls -la $out $out/pmc; exit 0; fi
 AMX_BENCH_FORCE_DIST=1 python $root/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-configs 2>/dev/null | grep "^{\"metric\"" | tail -1 > $out/force_dist_bench.log
 python $root/tools/gemm_comparator.py > $out/gemm_comparator.json 2>/dev/null
 [ -x $root/tools/build/feed_probe ] && $root/tools/build/feed_probe > $out/feed_probe.log 2>&1
-if [ -f $root/rasr_amd/librasr_amd_lab.so ]; then
+if [ -f $root/tools/build/librasr_amd_lab.so ]; then
   (cd $root && python tools/mx_timeline.py 0 2>&1 | grep -v amdgpu.ids > $out/mx_timeline.log; python tools/mx_timeline.py small 2>&1 | grep -v amdgpu.ids >> $out/mx_timeline.log; python tools/fused_timeline.py 2>&1 | grep -v amdgpu.ids > $out/fused_timeline.log)
 fi
 [ -x $root/tools/build/gemm_probe ] && PROBE_RELU=1 $root/tools/build/gemm_probe xp0 xp8 xp16 xp24 xp64 xp72 xp4 p0 p8 p16 p64 p72 p4 x0 xa0 xp0:16x8 p0:16x8 > $out/gemm_probe.log 2>&1

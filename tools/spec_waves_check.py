@@ -1,8 +1,8 @@
-"""tools/spec_test.py -- gmm_fused_spec_kernel (tuning fused_waves=13: screen waves + exact waves) against the oracle on six shapes, and
+"""tools/spec_waves_check.py (a script, not a pytest module: run it on the GPU box with `python tools/spec_waves_check.py`) -- gmm_fused_spec_kernel (tuning fused_waves=13: screen waves + exact waves) against the oracle on six shapes, and
 its time per pass next to gmm_fused_kernel with 12 (default), 16 and 8 waves on the config-5 GMM (63 936 frames x 10 000 x 16).
 Round 4, one box: default 4.75-4.82 ms, 16 waves 4.86, 8 waves 5.24, specialised 6.0; all bit-identical."""
-import sys, numpy as np, torch, time
-sys.path.insert(0, "/root/repo")
+import os, sys, numpy as np, torch, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import rasr_amd
 from tests import synth
 from oracle import OracleGmm
