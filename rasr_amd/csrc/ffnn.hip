@@ -1598,6 +1598,7 @@ using MfgLP = amx::mx::MxCfg<256, 256, 2, 4, 3, 4>;  // the same with the softwa
                                                      // prefetch loads sit in the in-order vmcnt queue in front of the next K-tile's pieces)
 using MfgLH = amx::mx::MxCfg<256, 256, 2, 4, 3, 0, 4>;  // the first wave of every SIMD issues all LDS-DMA pieces (tuning tile=5: A/B runs)
 using MfgLF = amx::mx::MxCfg<256, 256, 2, 4, 3, 4, 4>;  // ... and its partner prefetches four K-tiles ahead into L2, outside every counted queue (tile=7)
+using MfgLQ = amx::mx::MxCfg<256, 256, 2, 4, 3, 0, 0, 1, 0, 1>;  // round 5: ping-pong halves -- one wave of a SIMD issues its products while its partner reads / refills (tile=8)
 using MfgA = amx::mx::MxCfg<128, 128, 2, 2, 3>;  //  74 KB: 2 workgroups per CU
 using MfgS = amx::mx::MxCfg<128, 64, 2, 2, 8, 0, 0, 2>;  // 147 KB: small batches, ONE tile per CU, two K-tiles per barrier, four more in flight (a
                                                          // 2048 x 2048 layer at batch 1024 is 64 K-tiles of 9 matrix instructions per wave: barrier and LDS round trip per K-tile were its time)
@@ -1675,7 +1676,7 @@ void launch_mx_cfg(amx_ffnn* h, int l, const void* x, int xkts, void* out, int l
     if (cfg < 0) {
         const long ncu = std::max(h->ctx->n_cu, 1), t256 = (long)(h->Npad[l] / 256) * (Tpad / 256), t128 = (long)(h->Npad[l] / 128) * (Tpad / 128);
         if (t256 >= 2L * ncu)
-            cfg = 2;
+            cfg = 8;  // round 5: the 256 x 256 tile with the ping-pong K loop (tile=2: all eight waves in phase, round 4's default)
         else if (t128 >= ncu)
             cfg = 0;
         else
@@ -1686,6 +1687,7 @@ void launch_mx_cfg(amx_ffnn* h, int l, const void* x, int xkts, void* out, int l
         case 4: launch_mx<MfgLP, ACT, LAST>(h, l, x, xkts, out, ldo, T, Tpad, n_valid); break;
         case 5: launch_mx<MfgLH, ACT, LAST>(h, l, x, xkts, out, ldo, T, Tpad, n_valid); break;
         case 7: launch_mx<MfgLF, ACT, LAST>(h, l, x, xkts, out, ldo, T, Tpad, n_valid); break;
+        case 8: launch_mx<MfgLQ, ACT, LAST>(h, l, x, xkts, out, ldo, T, Tpad, n_valid); break;
         case 3:
             if constexpr (LAST)
                 launch_mx<MfgS, ACT, LAST>(h, l, x, xkts, out, ldo, T, Tpad, n_valid);
@@ -1827,7 +1829,7 @@ int amx_ffnn_create(amx_ctx* ctx, const amx_ffnn_model* m, amx_ffnn** out) {
     int t_tile, t_graph, t_persistent, t_chunk, t_mx_dbg, t_stagger, t_group_t = -1, t_group_n = -1;
     {
         const char* who = "amx_ffnn_create";
-        if (!tune.get_int("tile", -1, -1, 9, &t_tile, who) || !tune.get_int("graph", 1, 0, 1, &t_graph, who) ||
+        if (!tune.get_int("tile", -1, -1, 8, &t_tile, who) || !tune.get_int("graph", 1, 0, 1, &t_graph, who) ||
             !tune.get_int("persistent", 1, 0, 1, &t_persistent, who) || !tune.get_int("chunk", 32768, 256, 1 << 24, &t_chunk, who) ||
             !tune.get_int("mx_dbg", 0, 0, 1 << 16, &t_mx_dbg, who) || !tune.get_int("stagger", 0, 0, 100000, &t_stagger, who))
             return AMX_ERR_INVALID;

@@ -220,9 +220,24 @@ __global__ __launch_bounds__(256) void neg_act_kernel(float* __restrict__ x, lon
 }
 
 // ---------------------------------------------------------------------------------------------- tile configurations
-template<int BN_, int BT_, int WN_, int WT_, int STAGES_, int PF_ = 0, int IW_ = 0, int U_ = 1, int LW_ = 0>
+template<int BN_, int BT_, int WN_, int WT_, int STAGES_, int PF_ = 0, int IW_ = 0, int U_ = 1, int LW_ = 0, int PIPE_ = 0>
 struct MxCfg {
     static constexpr int BN = BN_, BT = BT_, WN = WN_, WT = WT_, STAGES = STAGES_;
+    // PIPE = 1 (round 5): PING-PONG halves.  Waves w and w + 4 share a SIMD; a K-tile's period is cut into two halves by a SECOND
+    // barrier, and in each half one wave of every SIMD issues its products while its partner does everything that is not matrix work
+    // -- the fragment reads of its next K-tile, its share of the refill's LDS-DMA pieces -- then the roles swap:
+    //     half 1 of K-tile kt    waves 0-3: products(kt)                      waves 4-7: refill share, reads(kt)
+    //     half 2                 waves 0-3: refill share, reads(kt + 1)       waves 4-7: products(kt)
+    // Round 4's ablations of this kernel added up exactly (fragment reads + barriers 0.76 ms, conversions 0.44, DMA issue 0.25, matrix
+    // work 0.8 of the output layer's 2.2 ms): with all eight waves in phase nothing overlapped, and without the second barrier (the
+    // SKEW variant below) the two groups drift until both sit in the same kind of segment again.  Here a SIMD's matrix pipe is handed
+    // from one wave to the other at every barrier.  No second register image (a wave reads its next K-tile into the registers whose
+    // products were issued a half period earlier), the same three-stage ring with the same two K-tiles in flight (a stage is read by
+    // the first group in half 2 of period kt - 1 and by the second in half 1 of period kt, and is refilled behind that), the same
+    // matrix instructions in the same order per accumulator: bit-identical scores.
+    static constexpr int PIPE = PIPE_;
+    static_assert(PIPE_ == 0 || (PIPE_ == 1 && U_ == 1 && LW_ == 0 && PF_ == 0 && IW_ == 0 && STAGES_ == 3 && WN_ * WT_ == 8),
+                  "ping-pong K loop: eight waves, every one of them issuing, plain three-stage ring");
     // PF > 0 (256 x 256 tiles only): waves 0-5 touch the 384 cache lines of the K-tile PF steps ahead of the one whose LDS-DMA they
     // have just issued (one dword per 128-byte line, 64 lines per wave-instruction) -- a software prefetch from the Infinity Cache /
     // HBM into L2.  The LDS ring holds two K-tiles in flight (~2 periods of 1.7 us); a K-tile whose lines miss L2 (23 % of the
@@ -502,7 +517,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const char* __restr
             s_bias[i] = bias[n0 + i];
 
 #pragma unroll
-        for (int s = 0; s < C::STAGES - C::U; ++s)
+        for (int s = 0; s < (C::PIPE > 0 ? C::STAGES : C::STAGES - C::U); ++s)
             if (s < KT)
                 stage(s, s);
         const int frow = lane & 31, fk = lane >> 5;
@@ -730,7 +745,59 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const char* __restr
         };
         // one code path for both groups -- early: sync(kt) reads(kt) products(kt); late: reads(kt) sync(kt + 1) products(kt), i.e. the
         // late wave's products of K-tile kt run in period kt + 1, in front of its reads of K-tile kt + 1.  Both execute KT barriers.
-        if constexpr (C::U > 1 || C::LW > 0) {
+        if constexpr (C::PIPE > 0) {
+            static_assert(DBG == 0 || DBG == 2048, "the ping-pong K loop has no ablation variants");
+            const bool second = wave >= C::NW / 2;  // the group that runs half a period behind (waves 4-7: the partners of waves 0-3)
+            auto await_tile = [&](int ahead_tiles, int max_ahead) {  // own pieces of a K-tile have landed; `ahead_tiles` younger K-tiles may stay in flight
+                if (!issuer)
+                    mx_wait<0>();
+                else if (max_ahead >= 2) {
+                    if (hi_wave)
+                        mx_wait_ahead<C::PPW, 0, 2>(ahead_tiles);
+                    else
+                        mx_wait_ahead<C::PPW - 1, 0, 2>(ahead_tiles);
+                }
+                else {
+                    if (hi_wave)
+                        mx_wait_ahead<C::PPW, 0, 1>(ahead_tiles);
+                    else
+                        mx_wait_ahead<C::PPW - 1, 0, 1>(ahead_tiles);
+                }
+            };
+            // prologue: K-tiles 0 .. 2 are on their way (all three stages); K-tile 0 has landed -> the first group's image
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            await_tile(min(2, KT - 1), 2);
+            __builtin_amdgcn_s_barrier();
+            // ONE loop body for both groups -- barrier, load K-tile kt (refill share + fragment reads), barrier, products of K-tile kt --
+            // and the first group runs it one barrier AHEAD of the second: it skips the first barrier of the loop (and executes one
+            // more behind it), so its load segments coincide with its partners' compute segments and the other way round.  (Branching
+            // the roles inside the loop, or one loop per group, made the register allocator keep copies of the accumulators: 170-700
+            // bytes of scratch per lane.)  With b0, b1, ... the barriers behind the prologue's, the first group loads K-tile kt in
+            // [b(2 kt - 1), b(2 kt)] and the second in [b(2 kt), b(2 kt + 1)]:
+            //   * the refill issued in load(kt) is K-tile kt + 2 -> the stage of K-tile kt - 1, which
+            //     the first group read in [b(2 kt - 3), b(2 kt - 2)] and the second in [b(2 kt - 2), b(2 kt - 1)]: free for both;
+            //   * every wave has awaited its pieces of K-tile kt in front of b(2 kt - 1) at the latest (the await of load(kt - 1)).
+            for (int kt = 0; kt < KT; ++kt) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (second || kt > 0)
+                    __builtin_amdgcn_s_barrier();
+                stamp(kt, 0);
+                if (kt >= 1 && kt + 2 < KT)
+                    stage((kt + 2) % C::STAGES, kt + 2);
+                reads(kt, fr[0]);
+                stamp(kt, 1);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (kt + 1 < KT)
+                    await_tile(kt + 2 < KT ? 1 : 0, 1);  // own pieces of K-tile kt + 1 have landed; kt + 2 may stay in flight
+                __builtin_amdgcn_s_barrier();
+                stamp(kt, 2);
+                products(fr[0]);
+                stamp(kt, 3);
+            }
+            if (!second)
+                __builtin_amdgcn_s_barrier();
+        }
+        else if constexpr (C::U > 1 || C::LW > 0) {
             static_assert(!C::SKEW && !C::SPREAD && C::PF == 0 && (C::IW == C::NW || C::LW > 0), "plain burst refill only");
             for (int kt = 0; kt < KT; kt += C::U) {
                 const int nk = min(C::U, KT - kt);
