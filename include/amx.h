@@ -480,9 +480,15 @@ enum { AMX_PREC_FP32 = 0, AMX_PREC_BF16 = 1, AMX_PREC_BF16X3 = 2, AMX_PREC_F16MX
  * product for both cross terms (the fp6 image of h is converted from the f16 fragments in registers): 1.5 units of matrix time
  * per product instead of split bf16's 3, worst error 0.03 of the 1e-4 bar on BASELINE config 4 (profiles/r04/emulation_f16_f8.json,
  * tests/test_ffnn_f16mx_gpu.py).
- * Limits: weights and activations must stay inside the f16 range (|v| < 65520): amx_ffnn_create refuses such weights, a pass
- * that meets such a feature or hidden activation sets a sticky flag and every later call on the handle returns AMX_ERR_STATE
- * (amx_ffnn_score, which waits for its results, returns it at once).  AMX_PREC_BF16X3 has no such limit. */
+ * Limits: weights and activations must stay inside the f16 range (|v| < 65520, and finite): amx_ffnn_create refuses such weights; a
+ * pass that meets such a feature or hidden activation (inf and NaN included) FAILS, its scores are not valid:
+ *   amx_ffnn_score (host buffers; it waits for its results) returns AMX_ERR_STATE for that very pass;
+ *   the *_dev entry points only enqueue work: call amx_ffnn_wait_dev(h) behind a pass and before its scores are used -- it waits for
+ *     the handle's stream and returns AMX_ERR_STATE if the pass (or an earlier one) left the range.  rasr_amd/host/
+ *     BatchFeatureScorer.hh does so before a row of the block reaches the decoder (Nn/BatchFeatureScorer.cc:148-171 hands out scores
+ *     of a batch it has computed synchronously);
+ *   the flag is sticky: every later call on the handle returns AMX_ERR_STATE too (create the scorer with AMX_PREC_BF16X3, which
+ *     has no such limit). */
 
 typedef struct {
     int                 n_layers;
@@ -515,6 +521,17 @@ int  amx_ffnn_output_dim(const amx_ffnn* h);
 /* feats [T x in0]; scores [T x out_last] = -(W x + b - alpha * log_prior) */
 int amx_ffnn_score(amx_ffnn* h, const float* feats_host, int T, float* scores_host);
 int amx_ffnn_score_dev(amx_ffnn* h, const float* feats_dev, int feats_stride, int T, float* scores_dev);
+/* Waits for everything enqueued on the handle's stream and reports the state of the passes so far: AMX_OK, or AMX_ERR_STATE if a pass
+ * of an AMX_PREC_F16MX handle met a value outside the f16 range (the scores of that pass are not valid).  The other precisions have
+ * no failing pass: for them this is amx_synchronize. */
+int amx_ffnn_wait_dev(amx_ffnn* h);
+/* The AMX_PREC_* the handle computes in, and (nullable) the statistic that decided it.  A scorer requested as AMX_PREC_F16MX whose
+ * weights are heavy-tailed computes in AMX_PREC_BF16X3 instead: with one exponent per 32 k a block whose maximum dwarfs the rest loses
+ * the fp6 image of the small values (error 54-115 x that of f32 accumulation instead of 27 x; profiles/r05/f16mx_families.log).
+ * *mx_block_ratio = rms of the block maxima / rms of the elements, the largest over the layers: 2.4 for Gaussian weights, 3.0 Laplace,
+ * 3.3 Student-t(4), 5.0 log-normal(1.5), 5.66 at most; the switch happens above 4.0 (amx_ffnn_model.tuning mx_fallback=off keeps
+ * f16mx, =auto is the default). */
+int amx_ffnn_precision(const amx_ffnn* h, double* mx_block_ratio);
 /* Nn::NeuralNetworkForwardNode ("neural-network-forward", Nn/Module.cc:107, Nn/NeuralNetworkForwardNode.cc:140-180): the network's
  * top-layer output per frame instead of a score.  AMX_NN_TOP_LINEAR: W x + b - alpha * log_prior (what a linear+softmax layer
  * yields with evaluate-softmax = false; exactly -score).  AMX_NN_TOP_SOFTMAX: the layer's default -- Math::FastMatrix<f32>::softmax

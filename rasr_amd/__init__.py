@@ -562,6 +562,16 @@ class NnBatchFeatureScorer:
         """output layer for (frame, emission) pairs only: scores_dev [n_pairs]"""
         _lib.check(self.L.amx_ffnn_score_on_demand_dev(self.h, _ptr(act_dev), n_pairs, _ptr(frame_dev), _ptr(emission_dev), _ptr(scores_dev)))
 
+    def effective_precision(self):
+        """(precision the handle computes in, block-maximum statistic of its weights): "f16mx" requested on heavy-tailed weights runs "bf16x3"""
+        r = C.c_double(0.0)
+        p = self.L.amx_ffnn_precision(self.h, C.byref(r))
+        return {0: "fp32", 1: "bf16", 2: "bf16x3", 3: "f16mx"}[p], float(r.value)
+
+    def wait_dev(self):
+        """amx_ffnn_wait_dev: waits for the handle's stream; raises if a pass of an f16mx scorer left the f16 range"""
+        _lib.check(self.L.amx_ffnn_wait_dev(self.h))
+
     def score_dev(self, feats_dev, feats_stride, T, scores_dev):
         _lib.check(self.L.amx_ffnn_score_dev(self.h, _ptr(feats_dev), feats_stride, T, _ptr(scores_dev)))
 

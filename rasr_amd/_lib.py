@@ -153,6 +153,8 @@ SIGNATURES = {
     "amx_ffnn_output_dim": (C.c_int, [_P]),
     "amx_ffnn_score": (C.c_int, [_P, _P, C.c_int, _P]),
     "amx_ffnn_score_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
+    "amx_ffnn_wait_dev": (C.c_int, [_P]),
+    "amx_ffnn_precision": (C.c_int, [_P, C.POINTER(C.c_double)]),
     "amx_ffnn_score_stats_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P, _P]),
     "amx_ffnn_hidden_dim": (C.c_int, [_P]),
     "amx_dc_detection": (C.c_int, [_P, C.c_longlong, C.c_double, C.c_double, C.c_float, C.c_double, C.c_int, C.c_int, _P, _P, C.c_longlong, _P]),

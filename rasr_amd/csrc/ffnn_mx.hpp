@@ -202,10 +202,10 @@ __global__ __launch_bounds__(256) void pack_input_mx(const float* __restrict__ x
                 const int   k = kt * 32 + 8 * g + 4 * hh + e;
                 const float v = (t < T && k < K) ? x[(size_t)t * ldx + k] : 0.f;
                 a[4 * g + e]  = v;
-                m             = fmaxf(m, fabsf(v));
+                m             = (v != v) ? __builtin_inff() : fmaxf(m, fabsf(v));  // a NaN counts as out of range (fmaxf would drop it)
             }
         m = fmaxf(m, __shfl_xor(m, 1, 64));
-        if (m >= 65520.f && m < __builtin_inff())
+        if (!(m < 65520.f))  // beyond the f16 range, or not finite (fmaxf drops a NaN: see nan below)
             *overflow = 1u;
         const int ec = block_exponent(m);
         lane_store(out + ((size_t)(t >> 8) * KT + kt) * BLK, t & 255, hh, lane_pack(a, ec, ec - 13));
@@ -782,6 +782,10 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const char* __restr
                 if (second || kt > 0)
                     __builtin_amdgcn_s_barrier();
                 stamp(kt, 0);
+                // (measured on one box, profiles/r05/pingpong_ab.log: the fragment reads in front of the refill's pieces +0.7 %; a static
+                // s_setprio 1 for the second group: no change; the conversions moved to the end of the load segment, so that the compute
+                // segment is matrix instructions only: output layer 1.86 -> 3.0 ms -- a conversion does not run beside the partner's
+                // matrix instructions (tools/cvt_rate.hip), it takes their pipe)
                 if (kt >= 1 && kt + 2 < KT)
                     stage((kt + 2) % C::STAGES, kt + 2);
                 reads(kt, fr[0]);
@@ -900,9 +904,9 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const char* __restr
                     }
 #pragma unroll
                     for (int u = 0; u < 16; ++u)
-                        m = fmaxf(m, fabsf(v[u]));
+                        m = (v[u] != v[u]) ? __builtin_inff() : fmaxf(m, fabsf(v[u]));  // NaN: out of range
                     m    = fmaxf(m, __shfl_xor(m, 32, 64));
-                    over = over || (m >= 65520.f && m < __builtin_inff());
+                    over = over || !(m < 65520.f);
                     const int ec = block_exponent(m);
                     char*     blk = (char*)out + ((size_t)(t >> 8) * ktn + ((n0 + wn * WNR + 32 * i) >> 5)) * BLK;
                     lane_store(blk, t & 255, hh, lane_pack(v, ec, ec - 13));

@@ -154,7 +154,15 @@ public:
         if (r == AMX_OK)
             r = amx_copy_to_device(block_.ctx(), block_.feats(), f, (size_t)T * dimension() * sizeof(float));
         rows_ = r == AMX_OK ? T : 0;
-        return r == AMX_OK ? amx_ffnn_score_dev(h_, block_.feats(), (int)dimension(), T, block_.scores()) : r;
+        if (r == AMX_OK)
+            r = amx_ffnn_score_dev(h_, block_.feats(), (int)dimension(), T, block_.scores());
+        // the pass itself must fail if it cannot be trusted (AMX_PREC_F16MX: a value outside the f16 range), not the next one: the
+        // reference's scorer hands out scores of a batch it has computed synchronously (Nn/BatchFeatureScorer.cc:148-171)
+        if (r == AMX_OK)
+            r = amx_ffnn_wait_dev(h_);
+        if (r != AMX_OK)
+            rows_ = 0;
+        return r;
     }
     int fetchRow(int row, float* dst) {
         return amx_copy_to_host(block_.ctx(), dst, block_.scores() + (size_t)row * nEmissions(), (size_t)nEmissions() * sizeof(float));

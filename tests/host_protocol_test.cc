@@ -129,6 +129,30 @@ int main(int argc, char** argv) {
     }
     CHECK(threw);  // require(!bufferFilled())
 
+    // ---- NN backend in the bench's default arithmetic (AMX_PREC_F16MX): a buffer fill whose features leave the f16 range must FAIL
+    // ITSELF (scoreResident waits for the pass, amx_ffnn_wait_dev) -- the decoder never sees a row of it -- not the fill after it
+    {
+        const int    nin = 8, nout = 5, Tn = 6;
+        std::vector<float> W((size_t)nout * nin), bias(nout, 0.1f);
+        for (size_t i = 0; i < W.size(); ++i)
+            W[i] = 0.01f * (float)((int)(i % 7) - 3);
+        const float* Wp[1]   = {W.data()};
+        const float* bp[1]   = {bias.data()};
+        const int    ind[1]  = {nin}, outd[1] = {nout}, act[1] = {AMX_ACT_NONE};
+        amx_ffnn_model nm;
+        memset(&nm, 0, sizeof nm);
+        nm.n_layers = 1; nm.in_dim = ind; nm.out_dim = outd; nm.W = Wp; nm.bias = bp; nm.activation = act; nm.precision = AMX_PREC_F16MX;
+        FfnnBackend nb(ctx, nm);
+        std::vector<float> x((size_t)Tn * nin, 0.5f), row(nout);
+        CHECK(nb.scoreResident(x.data(), Tn) == AMX_OK);
+        CHECK(nb.fetchRow(2, row.data()) == AMX_OK && std::isfinite(row[0]));
+        x[3 * nin + 1] = 1.0e6f;
+        CHECK(nb.scoreResident(x.data(), Tn) == AMX_ERR_STATE && strstr(amx_last_error(), "f16 range"));   // THIS fill fails
+        unsigned r0 = 0, e0 = 0;
+        float    one = 0.f;
+        CHECK(nb.fetchPairs(1, &r0, &e0, &one) != AMX_OK);                                                  // ... and exposes no row
+    }
+
     // ---- MFCC node: parameters, attributes, packets, timestamps
     MfccNode node(ctx);
     CHECK(node.setParameter("nr-outputs", "12") && node.setParameter("filter-width", "268.258") && !node.setParameter("bogus", "1"));

@@ -74,7 +74,7 @@ for case in range(n_cases):
         print("MISMATCH bf16x3 vs fp32", dims, T, err3)
     # ---- f16 + MX-fp6 (AMX_PREC_F16MX): its three tile configurations bit-identical among themselves, the split-bf16 bar against fp32
     mx = {}
-    for cfg in ("auto", "0", "2", "3"):
+    for cfg in ("auto", "0", "2", "3", "8"):   # 8: the 256 x 256 tile's ping-pong K loop (round 5; "auto" picks it for large batches)
         nn = rasr_amd.NnBatchFeatureScorer(ctx, Ws, bs, acts, log_prior=logp, priori_scale=1.0, precision="f16mx",
                                            tuning=None if cfg == "auto" else "tile=" + cfg)
         s = torch.empty((T, dims[-1]), dtype=torch.float32, device="cuda")
@@ -87,7 +87,7 @@ for case in range(n_cases):
         if not torch.equal(best.long(), s.argmin(dim=1)):
             bad += 1
             print("MISMATCH fused arg-min (f16mx)", cfg, dims, T)
-    for cfg in ("0", "2", "3"):
+    for cfg in ("0", "2", "3", "8"):
         if not (torch.equal(mx[cfg][0].view(torch.int32), mx["auto"][0].view(torch.int32)) and torch.equal(mx[cfg][1], mx["auto"][1]) and
                 torch.equal(mx[cfg][2], mx["auto"][2])):
             bad += 1
@@ -96,5 +96,24 @@ for case in range(n_cases):
     if not errm <= 2e-4:
         bad += 1
         print("MISMATCH f16mx vs fp32", dims, T, errm)
+    # ---- f16mx on operands that are not Gaussian (tests/ffnn_families.py): against the exact-f32 MFMA path of the same network, errors
+    # relative to the frame's score scale (1e-4 of the largest |score| of the frame); heavy-tailed weights must switch to split bf16
+    from tests.ffnn_families import FAMILIES, make
+    fam = FAMILIES[int(rng.integers(0, len(FAMILIES)))]
+    fd = [440, int(rng.choice([256, 512, 1024])), int(rng.choice([300, 1000]))]
+    fW, fb, fa, fl, fx = make(fam, fd, int(rng.choice([64, 300])), int(rng.integers(1, 10000)))
+    ref32 = rasr_amd.NnBatchFeatureScorer(ctx, fW, fb, fa, log_prior=fl, precision="fp32").score(fx)
+    raw = rasr_amd.NnBatchFeatureScorer(ctx, fW, fb, fa, log_prior=fl, precision="f16mx", tuning="mx_fallback=off").score(fx)
+    dfl = rasr_amd.NnBatchFeatureScorer(ctx, fW, fb, fa, log_prior=fl, precision="f16mx")
+    eff, ratio = dfl.effective_precision()
+    scale = np.maximum(np.abs(ref32), np.abs(ref32).max(axis=1, keepdims=True))
+    for name, got, lim in (("raw f16mx", raw, 2.0), ("default (%s)" % eff, dfl.score(fx), 2.0 if eff == "f16mx" else 1.0)):
+        w = float((np.abs(got - ref32) / (1e-4 * scale + 1e-4)).max())
+        if not w <= lim:
+            bad += 1
+            print("MISMATCH family", fam, name, fd, "worst over the frame-scale bar", w)
+    if (ratio > 4.0) != (eff == "bf16x3"):
+        bad += 1
+        print("MISMATCH family", fam, "block ratio", ratio, "but the handle runs", eff)
 print("%d cases, %d mismatches" % (n_cases, bad))
 sys.exit(1 if bad else 0)
