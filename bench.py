@@ -440,7 +440,8 @@ class NnPipeline:
             rows.append(min(self.CHUNK, self.F - t0))
         frames = sum(rows) / len(rows)
         largest = nn_gemm_roofline(self.nn_precision, ms_o, n_o, frames, self.F >= self.CHUNK)
-        t_ms = ms_o * n_o + ms_h * n_h                       # every GEMM launch of the profiled steps
+        t_ms = ms_h * n_h                                     # every GEMM launch of the profiled steps ("ffnn_gemm" times all seven layers of a
+                                                              # pass, "ffnn_gemm_max" the output layer once more on its own)
         alg = self.flops_per_frame * frames * n_o             # one output-layer launch per scoring pass
         peak = FP32_TFLOPS if self.nn_precision == "fp32" else MFMA_BF16_TFLOPS
         ach = alg / (t_ms * 1e-3) / 1e12
@@ -448,13 +449,13 @@ class NnPipeline:
         return dict(bound="mfma", kernel={"f16mx": "gemm_mx_kernel", "fp32": "gemm_f32_kernel"}.get(self.nn_precision, "gemm_bf16_pipe_kernel") +
                     " (all 7 GEMMs of the forward pass: 440-6x2048-10000; the template with the largest summed time of the step)",
                     achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
-                    note="ALGORITHMIC: 2 x 42.35 M products per frame (SURVEY 8(d)) over the summed time of the %d GEMM launches" % (n_o + n_h),
+                    note="ALGORITHMIC: 2 x 42.35 M products per frame (SURVEY 8(d)) over the summed time of the %d GEMM launches" % n_h,
                     executed_units_per_product=dict(nominal=units[0], measured_on_this_chip=units[1],
                                                     frac_of_peak_in_executed_units=round(units[1] * ach / peak, 4),
                                                     what="f16mx: 1 f16 MFMA product + 0.5 fp6 x fp6 scaled product per 16 k; the scaled product "
                                                          "costs 1.6 f16 products here (feed probe), nominally 1" if self.nn_precision == "f16mx" else
                                                          "matrix products executed per f32 product of the reference"),
-                    traffic=None, avg_launch_ms=round(t_ms / (n_o + n_h), 4), launches=n_o + n_h, flops_per_launch=alg / (n_o + n_h),
+                    traffic=None, avg_launch_ms=round(t_ms / n_h, 4), launches=n_h, flops_per_launch=alg / n_h,
                     summed_ms_per_step=round(t_ms / max(1, n_o // len(rows)), 4), largest_launch=largest)
 
     def stage_report(self):
@@ -1376,6 +1377,12 @@ def secondary_configs(ctx, args, rank):
             ("cfg4 nn f16mx (batch 1024)", dict(workload="nn", precision="f16mx", steps=50, warmup=5)),
             ("cfg4 nn bf16x3 (batch 1024)", dict(workload="nn", precision="bf16x3", steps=50, warmup=5)),
             ("cfg4 nn bf16 (batch 1024)", dict(workload="nn", precision="bf16", steps=50, warmup=5))]
+    try:   # config 5 at N = 1 as one epoch (7-8 s): first, while the chip is cool -- its last second is the sustained figure
+        out["cfg5 full epoch on one GPU (100 h = 36 000 utterances streamed, every frame through both models, ONE reduce at the end)"] = full_epoch(ctx, args, rank)
+    except Exception as e:
+        out["cfg5 full epoch on one GPU"] = dict(error=str(e)[:300])
+    gc.collect()
+    torch.cuda.empty_cache()
     for name, over in plan:
         a = copy.copy(args)
         for k, v in over.items():
@@ -1408,6 +1415,61 @@ def secondary_configs(ctx, args, rank):
         gc.collect()
         torch.cuda.empty_cache()
     return out
+
+
+def full_epoch(ctx, args, rank):
+    """BASELINE config 5 run as what it says, on ONE GPU: a whole epoch over the 100 h corpus (36 000 utterances of 10 s: 563 batches of
+    64), every batch streamed from pinned host memory, every frame scored by both models, the accumulators reduced ONCE at the end.  This
+    is the job a rank of an 8-GPU run executes on its partition.  Reports what a 20-step figure cannot: frames/s over the first and over
+    the last second of the epoch, the shader clock the chip sustains at both ends (s_memtime ticks per s_memrealtime tick, sampled in
+    stream order), and the real-time factor as the reference defines it (Speech/CorpusProcessor.cc:49-58: wall time / audio time)."""
+    import copy
+
+    import torch
+    a = copy.copy(args)
+    a.workload, a.ingest, a.steps, a.warmup = "pipeline", "streamed", 22, 0   # host window: 24 batches of the partition (it wraps)
+    job = make_job(ctx, a, rank, 1)
+    ing = job.ingest
+    for _ in range(3):   # untimed: workspaces, graphs, the first copies
+        job.step()
+    torch.cuda.synchronize()
+    ing.walker.pos, ing.walker.epoch, ing.visited = 0, 0, []
+    job.red.zero()
+    n_steps = ing.walker.batches_per_epoch()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(n_steps + 1)]
+    clk = torch.zeros((4, 2), dtype=torch.int64, device="cuda")
+    marks = {8: 0, min(n_steps - 1, 70): 1, max(9, n_steps - 70): 2, n_steps - 1: 3}   # ~1 s apart at ~14 ms per step
+    ctx.profile(False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev[0].record()
+    for s_ in range(n_steps):
+        job.step()
+        ev[s_ + 1].record()
+        if s_ in marks:
+            ctx.device_clocks(clk[marks[s_]])
+    job.epoch_reduce(1)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    t_ms = np.array([ev[0].elapsed_time(e) for e in ev[1:]])          # completion time of every step on the device
+    real = [len(v) for v in ing.visited[:n_steps]]                    # utterances of the corpus in each batch (the last one is short)
+    frames = np.array([u * (job.F // a.utterances) for u in real], np.float64)
+    total_frames, audio_s = float(frames.sum()), float(sum(real)) * a.utt_seconds
+    first = t_ms <= 1000.0
+    last = t_ms > t_ms[-1] - 1000.0
+    ck = clk.cpu().numpy().astype(np.float64)
+    ghz = lambda i, j: round(float((ck[j, 0] - ck[i, 0]) / max(ck[j, 1] - ck[i, 1], 1.0) * 0.1), 3)   # ticks per 10 ns -> GHz
+    return dict(value=round(total_frames / wall, 1), unit="frames/s", wall_s=round(wall, 3), steps=n_steps, utterances=int(sum(real)),
+                frames=int(total_frames), audio_hours=round(audio_s / 3600.0, 2), rtf=round(wall / audio_s, 8),
+                rtf_definition="wall time / audio time (Speech/CorpusProcessor.cc:49-58); 1 / rtf = %.0f x real time" % (audio_s / wall),
+                device_time_s=round(float(t_ms[-1]) * 1e-3, 3),
+                frames_per_s_first_second=round(float(frames[first].sum()) / (float(t_ms[first][-1]) * 1e-3), 1) if first.any() else None,
+                frames_per_s_last_second=round(float(frames[last].sum()) / ((float(t_ms[-1]) - float(t_ms[~last][-1] if (~last).any() else 0.0)) * 1e-3), 1),
+                ms_per_step_first_20=round(float(t_ms[19] / 20.0), 4), ms_per_step_last_20=round(float((t_ms[-2] - t_ms[-22]) / 20.0), 4),
+                shader_clock_GHz=dict(first_second=ghz(0, 1), last_second=ghz(2, 3), whole_epoch=ghz(0, 3),
+                                      how="s_memtime ticks / s_memrealtime ticks (100 MHz) between two one-wave kernels in stream order"),
+                ingest=ing.report(), epoch_reduce=dict(collectives=1, bytes=job.red.nbytes()),
+                workload=WORKLOAD_NAMES["pipeline"](a), contract=args.contract, precision=args.precision)
 
 
 def decoder_facing(ctx, args, rank):

@@ -585,6 +585,10 @@ int  amx_copy_to_device(amx_ctx* ctx, void* dst_dev, const void* src_host, size_
 int  amx_copy_to_host(amx_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
 int  amx_gather_scores(amx_ctx* ctx, const float* scores_dev, int n_rows, int ld, int n, const uint32_t* rows_host,
                        const uint32_t* cols_host, float* dst_host);
+/* Measurement: out_dev[0] = s_memtime (shader clock ticks), out_dev[1] = s_memrealtime (100 MHz), sampled by a one-wave kernel in stream
+ * order.  Two samples around a stretch of work give the shader clock the chip sustained over it (delta ticks / delta 10 ns units); the
+ * epoch run of bench.py prints it next to the real-time factor (Speech/CorpusProcessor.cc:49-58: wall time / audio time). */
+int  amx_device_clocks_dev(amx_ctx* ctx, unsigned long long* out_dev);
 
 /* ------------------------------------------------------------------ feature caches */
 

@@ -159,6 +159,10 @@ class Context:
     def profile_reset(self):
         _lib.check(self.L.amx_profile_reset(self.h))
 
+    def device_clocks(self, out_dev):
+        """enqueue a sample of (s_memtime, s_memrealtime) into out_dev (2 x int64 / uint64 on the device)"""
+        _lib.check(self.L.amx_device_clocks_dev(self.h, _ptr(out_dev)))
+
     def profile_get(self, kernel):
         ms, n = C.c_double(), C.c_long()
         _lib.check(self.L.amx_profile_get(self.h, kernel.encode(), C.byref(ms), C.byref(n)))

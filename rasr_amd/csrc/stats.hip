@@ -197,3 +197,23 @@ extern "C" int amx_f64_to_counts_dev(amx_ctx* ctx, const double* in_dev, unsigne
     AMX_HIP(hipGetLastError());
     return AMX_OK;
 }
+
+// ---- the two device clocks, sampled in stream order (measurement: bench.py's epoch run reports the shader clock the chip sustains
+// under the job's load -- real-time factor as Speech/CorpusProcessor.cc:49-58 defines it needs wall time only, but a throughput
+// figure from 20 steps says nothing about the clock a 100 h epoch ends at)
+namespace amx {
+__global__ void device_clocks_kernel(unsigned long long* __restrict__ out) {
+    if (threadIdx.x == 0) {
+        out[0] = __builtin_amdgcn_s_memtime();      // shader clock ticks
+        out[1] = __builtin_amdgcn_s_memrealtime();  // constant 100 MHz counter
+    }
+}
+}  // namespace amx
+
+extern "C" int amx_device_clocks_dev(amx_ctx* ctx, unsigned long long* out_dev) {
+    AMX_REQUIRE(ctx && out_dev, AMX_ERR_INVALID, "amx_device_clocks_dev: NULL argument");
+    AMX_HIP(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(amx::device_clocks_kernel, dim3(1), dim3(64), 0, ctx->stream, out_dev);
+    AMX_HIP(hipGetLastError());
+    return AMX_OK;
+}

@@ -85,6 +85,13 @@ class EpochReduceBuffer:
     def nbytes(self):
         return int(self.flat.numel() * 8)
 
+    def zero(self):
+        """start of an epoch: statistics and counters back to zero (in place: the kernels keep their views)"""
+        self.flat.zero_()
+        for c in self.counters.values():
+            c.zero_()
+        return self
+
     def all_reduce(self, group=None, comm=None):
         """sum over all ranks with ONE collective.
 
