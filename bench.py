@@ -1502,11 +1502,24 @@ def decoder_facing(ctx, args, rank):
             one()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        n = 20
+        n = 100 if name == "resident" else 20
         for _ in range(n):
             one()
         torch.cuda.synchronize()
         out[name + "_frames_per_s"] = round(T * n / (time.perf_counter() - t0), 1)
+    if args.precision == "f16mx" and "ksplit" not in (args.nn_tuning or ""):
+        # the opt-in mode for a decoder's fixed buffer size: split-K across workgroups for passes of at most 256 frames (another order of
+        # summation than the default's: scores differ by f32 rounding, tests/test_ffnn_f16mx_gpu.py)
+        nk = rasr_amd.NnBatchFeatureScorer(ctx, Ws, bs, acts, log_prior=logp, priori_scale=1.0, precision=args.precision,
+                                           tuning=",".join(i for i in (args.nn_tuning, "ksplit=4") if i))
+        for _ in range(3):
+            nk.score_dev(x, 440, T, scores)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(100):
+            nk.score_dev(x, 440, T, scores)
+        torch.cuda.synchronize()
+        out["resident_frames_per_s_tuning_ksplit4"] = round(T * 100 / (time.perf_counter() - t0), 1)
     out["batch"] = T
     out["note"] = "cfg-4 network, one 256-frame buffer fill per pass; full rows = 40 kB per frame over the host link"
     return out

@@ -1419,6 +1419,10 @@ struct amx_ffnn {
     int    chunk          = 32768;  // frames per internal pass (tuning "chunk")
     int    mx_stagger     = 0;   // 10 ns ticks per XCD of gemm_mx_kernel's staggered start (0 = off, the default; tuning "stagger")
     int    mx_dbg         = 0;   // lab builds: ablation variant of gemm_mx_kernel (tuning "mx_dbg")
+    int    mx_ksplit      = 1;   // tuning "ksplit": 4 = small batches (the one-tile-per-CU configuration with fewer tiles than a quarter of the
+                                 // CUs) split K over four workgroups per tile (gemm_mx_kernel's comment)
+    float*    d_ks_ws  = nullptr;   // split-K workspace: partial sums [tile][group][wave][register][lane]
+    size_t    ks_ws_cap = 0;
     // AMX_PREC_F16MX: host-mapped word the kernels set when a value leaves the f16 range (sticky: every later call fails)
     unsigned* h_overflow = nullptr;
     unsigned* d_overflow = nullptr;
@@ -1611,10 +1615,34 @@ template<class C, int ACT, bool LAST>
 void launch_mx(amx_ffnn* h, int l, const void* x, int xkts, void* out, int ldo, int T, int Tpad, int n_valid) {
     const int ntn = h->Npad[l] / C::BN, ntt = Tpad / C::BT;
     const int gt = h->group_t >= 0 ? h->group_t : (C::BN == 256 ? 16 : 8), gn = h->group_n >= 0 ? h->group_n : (C::BN == 256 ? 8 : 2);
-    constexpr int lds_bytes = amx::gemm_scratch_bytes<C, LAST>() + C::BN * 4;
+    constexpr int lds_bytes = amx::gemm_scratch_bytes<C, LAST>() + C::BN * 4 + 16;   // + the split-K arrival flag
     static_assert(lds_bytes <= 160 * 1024, "LDS budget");
     const int per_cu = std::max(1, (160 * 1024) / lds_bytes);
-    int       grid   = std::min(ntn * ntt, per_cu * std::max(h->ctx->n_cu, 8));
+    // split-K across workgroups (tuning ksplit=4): only where it multiplies the CUs that pull operands -- the one-tile-per-CU
+    // configuration with at most a quarter of the CUs busy and enough K-tiles per group to fill the ring
+    int ksplit = 1;
+    if (h->mx_ksplit > 1 && C::BN == 128 && C::BT == 64 && C::U == 2 && (long)ntn * ntt * h->mx_ksplit <= (long)std::max(h->ctx->n_cu, 8) &&
+        h->Kpad[l] / 32 >= 8 * h->mx_ksplit)
+        ksplit = h->mx_ksplit;
+    if (ksplit > 1) {
+        const size_t need_ws = (size_t)ntn * ntt * ksplit * C::NW * C::MI * C::MJ * 16 * 64;
+        if (need_ws > h->ks_ws_cap) {
+            for (auto& kv : h->graphs)  // captured passes hold the old workspace address
+                if (kv.second)
+                    hipGraphExecDestroy(kv.second);
+            h->graphs.clear();
+            hipFree(h->d_ks_ws);
+            h->d_ks_ws   = nullptr;
+            h->ks_ws_cap = 0;
+            if (hipMalloc((void**)&h->d_ks_ws, need_ws * 4) != hipSuccess) {
+                (void)hipGetLastError();
+                ksplit = 1;  // no workspace: the default order
+            }
+            else
+                h->ks_ws_cap = need_ws;
+        }
+    }
+    int       grid   = std::min(ntn * ntt * ksplit, per_cu * std::max(h->ctx->n_cu, 8));
     if (grid >= 8)
         grid &= ~7;  // keep blockIdx % 8 == tile index % 8 for every stride step
     // staggered XCDs (see the kernel): off by default -- 0 / 1 / 3 / 6 us per XCD measured within noise of one another
@@ -1626,7 +1654,13 @@ void launch_mx(amx_ffnn* h, int l, const void* x, int xkts, void* out, int ldo, 
         hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);                                         \
         hipLaunchKernelGGL(k, dim3(grid), dim3(C::THREADS), lds_bytes, h->ctx->stream, (const char*)h->d_W[l], (const char*)x, h->d_bias[l], \
                            out, h->Kpad[l] / 32, xkts, h->Npad[l] / 32, ldo, n_valid, T, ntn, ntn * ntt, gt, gn,                            \
-                           LAST ? h->cur_part_min : nullptr, LAST ? h->cur_part_idx : nullptr, Tpad, h->d_overflow, stagger);               \
+                           LAST ? h->cur_part_min : nullptr, LAST ? h->cur_part_idx : nullptr, Tpad, h->d_overflow, stagger, ksplit,       \
+                           h->d_ks_ws);                                                                                                     \
+        if (ksplit > 1) /* launch 2: the partial sums of every tile, in group order, then the epilogue */                                  \
+            hipLaunchKernelGGL(k, dim3(std::min(ntn * ntt, grid)), dim3(C::THREADS), lds_bytes, h->ctx->stream, (const char*)h->d_W[l],     \
+                               (const char*)x, h->d_bias[l], out, h->Kpad[l] / 32, xkts, h->Npad[l] / 32, ldo, n_valid, T, ntn, ntn * ntt,  \
+                               gt, gn, LAST ? h->cur_part_min : nullptr, LAST ? h->cur_part_idx : nullptr, Tpad, h->d_overflow, 0, -ksplit, \
+                               h->d_ks_ws);                                                                                                 \
     } while (0)
     int dbg = 0;
 #ifdef AMX_LAB  // ablations of the large-batch kernel (tools/ab_mx.sh, profiles/r04/gemm_mx_ablation.log)
@@ -1677,10 +1711,17 @@ void launch_mx_cfg(amx_ffnn* h, int l, const void* x, int xkts, void* out, int l
     int cfg = h->gemm_cfg;
     if (cfg < 0) {
         const long ncu = std::max(h->ctx->n_cu, 1), t256 = (long)(h->Npad[l] / 256) * (Tpad / 256), t128 = (long)(h->Npad[l] / 128) * (Tpad / 128);
+        const long t64 = (long)(h->Npad[l] / 128) * (Tpad / 64);  // tiles of 128 x 64
         if (t256 >= 2L * ncu)
             cfg = 8;  // round 5: the 256 x 256 tile with the ping-pong K loop (tile=2: all eight waves in phase, round 4's default)
         else if (t128 >= ncu)
             cfg = 0;
+        else if (t64 > ncu && t64 <= 2 * ncu)
+            // between one and two tiles of 128 x 64 per CU (the output layer of a 256-frame fill: 316 tiles): the one-tile-per-CU
+            // configuration would run a full round and a quarter-full second one; with the 74 KB ring two workgroups share a CU and
+            // everything is resident at once -- output layer at 256 frames 87 -> 42 us (profiles/r05/fill_breakdown.log); the same
+            // K order, the same matrix instructions: bit-identical
+            cfg = 6;
         else
             cfg = 3;
     }
@@ -1823,18 +1864,20 @@ int amx_ffnn_create(amx_ctx* ctx, const amx_ffnn_model* m, amx_ffnn** out) {
 
     amx::Tuning tune;
     {
-        static const char* const keys[] = {"tile", "graph", "persistent", "group", "chunk", "stagger", "mx_dbg", "mx_fallback", nullptr};
+        static const char* const keys[] = {"tile", "graph", "persistent", "group", "chunk", "stagger", "mx_dbg", "mx_fallback", "ksplit", nullptr};
         if (!tune.parse(m->tuning, keys, "amx_ffnn_create"))
             return AMX_ERR_INVALID;
     }
     // values are checked like keys (a typo must not silently select the default kernel)
-    int t_tile, t_graph, t_persistent, t_chunk, t_mx_dbg, t_stagger, t_group_t = -1, t_group_n = -1;
+    int t_tile, t_graph, t_persistent, t_chunk, t_mx_dbg, t_stagger, t_group_t = -1, t_group_n = -1, t_ksplit = 1;
     std::string t_mx_fallback;
     {
         const char* who = "amx_ffnn_create";
         static const char* const fallbacks[] = {"auto", "off", nullptr};
-        if (!tune.get_word("mx_fallback", "auto", fallbacks, &t_mx_fallback, who))
+        if (!tune.get_word("mx_fallback", "auto", fallbacks, &t_mx_fallback, who) || !tune.get_int("ksplit", 1, 1, 4, &t_ksplit, who))
             return AMX_ERR_INVALID;
+        AMX_REQUIRE(t_ksplit == 1 || t_ksplit == 4, AMX_ERR_INVALID, "amx_ffnn_create: tuning ksplit=%d: expected 1 | 4", t_ksplit);
+        AMX_REQUIRE(t_ksplit == 1 || m->precision == AMX_PREC_F16MX, AMX_ERR_UNSUPPORTED, "amx_ffnn_create: tuning ksplit exists for AMX_PREC_F16MX only");
         if (!tune.get_int("tile", -1, -1, 8, &t_tile, who) || !tune.get_int("graph", 1, 0, 1, &t_graph, who) ||
             !tune.get_int("persistent", 1, 0, 1, &t_persistent, who) || !tune.get_int("chunk", 32768, 256, 1 << 24, &t_chunk, who) ||
             !tune.get_int("mx_dbg", 0, 0, 1 << 16, &t_mx_dbg, who) || !tune.get_int("stagger", 0, 0, 100000, &t_stagger, who))
@@ -1893,6 +1936,7 @@ int amx_ffnn_create(amx_ctx* ctx, const amx_ffnn_model* m, amx_ffnn** out) {
     h->chunk           = t_chunk;
     h->mx_dbg          = t_mx_dbg;
     h->mx_stagger      = t_stagger;
+    h->mx_ksplit       = t_ksplit;
     h->group_t         = t_group_t;
     h->group_n         = t_group_n;
     hipSetDevice(ctx->device);
@@ -2036,6 +2080,7 @@ void amx_ffnn_destroy(amx_ffnn* h) {
     hipFree(h->d_host_s);
     if (h->h_overflow)
         hipHostFree(h->h_overflow);
+    hipFree(h->d_ks_ws);
     for (auto& kv : h->graphs)
         if (kv.second)  // nullptr marks a signature seen once
             hipGraphExecDestroy(kv.second);

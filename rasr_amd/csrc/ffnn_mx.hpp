@@ -375,11 +375,24 @@ __device__ __forceinline__ u32x6 q_fields(f16x8 c0, f16x8 c1, unsigned scale_byt
 // ring with ONE barrier per K-tile and counted vmcnt (never a drain inside the loop).
 // DBG (lab builds only, -DAMX_LAB + AMX_MX_DBG): 8 no matrix instructions, 16 no operand DMA after the prologue, 32 no scaled product
 // (conversions and MX MFMAs skipped), 64 every workgroup streams one of 8 tiles (all operands L2 hits), 128 no fp6 conversions, 256 wave skew, 512 LDS-DMA pieces spread between the products, 1024 rotated K walk per tile, 2048 s_memtime stamps of workgroup 0 (mx_stamps), 4096 fragment reads awaited in front of the refill burst
+// ksplit (round 5, opt-in: amx_ffnn_model.tuning ksplit=4; small batches only): SPLIT-K ACROSS WORKGROUPS, in two launches.  A decoder's
+// buffer fill (256 frames) gives a 2048 x 2048 layer 64 tiles of 128 x 64 -- 64 of the 256 CUs stream 1.2 MB of operands each, at the
+// ~47 GB/s ONE CU's LDS ring pulls from the Infinity Cache (ring bytes in flight / memory latency: Little's law -- not arithmetic, and not
+// the barrier chain: splitting K among the waves of one workgroup was built first and was slower, it pulls the same bytes through the
+// same ring).  ksplit > 1: launch 1, `ksplit` workgroups per tile, each walks its share of K and parks its accumulators in a workspace
+// (no epilogue); ksplit < -1: launch 2, one workgroup per tile adds the |ksplit| partial sums in group order, ((P0 + P1) + P2) + P3, and
+// runs the epilogue.  (One launch with an arrival counter and the last workgroup reducing was built too: bit-identical, and 3 x slower
+// than not splitting -- the eight L2s are not coherent with one another, so the device-scope fences around the counter write back and
+// invalidate a whole L2 per workgroup.  A kernel boundary does that once.)  The sum over k is associated differently from the default
+// (one accumulator, ascending k): scores differ from the default's by f32 rounding -- both meet the 1e-4 bar against the
+// f64-accumulating oracle -- and are bit-identical among all passes that run split (every pass of at most 256 frames of a handle
+// created with ksplit=4): a decoder runs one buffer size for life.
 template<class C, int ACT, bool LAST, int DBG = 0>
 __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const char* __restrict__ W, const char* __restrict__ X, const float* __restrict__ bias,
                                                             void* __restrict__ out, int KT, int xkts, int ktn, int ldo, int n_valid, int t_valid,
                                                             int n_tiles_n, int n_tiles_total, int GT, int GN, float* __restrict__ part_min,
-                                                            unsigned* __restrict__ part_idx, int part_ld, unsigned* __restrict__ overflow, int stagger) {
+                                                            unsigned* __restrict__ part_idx, int part_ld, unsigned* __restrict__ overflow, int stagger,
+                                                            int ksplit, float* __restrict__ ks_ws) {
     extern __shared__ __attribute__((aligned(16))) char lds[];  // [STAGES][A: H | R][B: H | R] ... [bias]
     const int tid  = threadIdx.x;
     const int lane = tid & 63;
@@ -401,7 +414,14 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const char* __restr
         while (__builtin_amdgcn_s_memrealtime() - t_start < ticks)
             __builtin_amdgcn_s_sleep(8);
     }
-    for (int vi = blockIdx.x; vi < n_tiles_total; vi += gridDim.x) {
+    // split-K exists for the one-tile-per-CU configurations only (the host passes ksplit = 1 to every other one): compiled out elsewhere,
+    // where the reduction's code cost the 256 x 256 tiles registers they do not have
+    constexpr bool KSPLIT = C::BN == 128 && C::BT == 64 && C::U == 2;
+    const int  ks     = KSPLIT ? (ksplit > 1 ? ksplit : 1) : 1;   // launch 1: K groups per tile
+    const bool reduce = KSPLIT && ksplit < -1;                    // launch 2: partial sums -> epilogue
+    const int n_units = n_tiles_total * ks;  // ks > 1: unit = (tile, K group), the K groups of a tile on neighbouring workgroups
+    for (int ui = blockIdx.x; ui < n_units; ui += gridDim.x) {
+        const int vi = KSPLIT ? ui / ks : ui, kgroup = KSPLIT ? ui - vi * ks : 0;
         int tile_t, tile_n;
         {  // the XCD-aware order of gemm_bf16_kernel
             const int nwg = n_tiles_total;
@@ -441,6 +461,17 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const char* __restr
         const char* wblk = W + (size_t)(n0 >> 8) * KT * BLK;
         const char* xblk = X + (size_t)(t0 >> 8) * xkts * BLK;  // xkts >= KT: the producer padded its outputs to 256
         const int   ha = (n0 & 255) / C::BN, hb = (t0 & 255) / C::BT;
+        // split-K: this workgroup walks K-tiles [kt_lo, kt_lo + KT) of the KT_all (whole multiples of U per group); the K loop below
+        // is the usual one on shifted operand pointers
+        const int KT_all = KT;
+        if (reduce)
+            KT = 0;   // no K loop: the accumulators come from the workspace
+        if (KSPLIT && ks > 1) {
+            const int per = ((KT_all + ks - 1) / ks + C::U - 1) / C::U * C::U, kt_lo = min(kgroup * per, KT_all);
+            KT   = min(per, KT_all - kt_lo);
+            wblk += (size_t)kt_lo * BLK;
+            xblk += (size_t)kt_lo * BLK;
+        }
 
         // ---- this wave's pieces of a K-tile (wave-uniform: scalar registers)
         int  p_src[C::PPW], p_dst[C::PPW];
@@ -872,7 +903,40 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const char* __restr
         if constexpr (C::PF > 0)
             asm volatile("" ::"v"(pf_reg));
         tile_stamp(1);
-
+        if constexpr (KSPLIT) {
+            constexpr int PER_WAVE = C::MI * C::MJ * 16 * 64;  // [tile][group][wave][register][lane]: 256 contiguous bytes per wave-instruction
+            if (ks > 1) {  // launch 1: park the partial sums, no epilogue
+                float* mine = ks_ws + ((size_t)(vi * ks + kgroup) * C::NW + (wave % C::NW)) * PER_WAVE + lane;
+                if (!loader) {
+#pragma unroll
+                    for (int i = 0; i < C::MI; ++i)
+#pragma unroll
+                        for (int j = 0; j < C::MJ; ++j)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r)
+                                mine[((i * C::MJ + j) * 16 + r) * 64] = acc[i][j][r];
+                }
+                __syncthreads();
+                KT = KT_all;
+                continue;
+            }
+            if (reduce && !loader) {  // launch 2: ((P0 + P1) + P2) + P3
+                const int ng = -ksplit;
+#pragma unroll 1
+                for (int g = 0; g < ng; ++g) {
+                    const float* theirs = ks_ws + ((size_t)(vi * ng + g) * C::NW + (wave % C::NW)) * PER_WAVE + lane;
+#pragma unroll
+                    for (int i = 0; i < C::MI; ++i)
+#pragma unroll
+                        for (int j = 0; j < C::MJ; ++j)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const float p = theirs[((i * C::MJ + j) * 16 + r) * 64];
+                                acc[i][j][r]  = g == 0 ? p : acc[i][j][r] + p;
+                            }
+                }
+            }
+        }
         // the epilogue's lane-dependent addresses are derived from opaque copies of the lane / thread id: computed from `lane` they are
         // invariants of the tile loop, get hoisted in front of the K-loop and spilled there (the K-loop owns the register file) -- and a
         // scratch access inside the loop would join the queue the counted vmcnt waits count
@@ -918,6 +982,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const char* __restr
         }
         __syncthreads();  // LDS (stages / epilogue scratch / bias) is reused by the next tile
         tile_stamp(2);
+        KT = KT_all;
     }
 }
 

@@ -91,6 +91,53 @@ def test_f16mx_config4_full_size_against_the_oracle(ctx, capsys):
     assert np.array_equal(counts.cpu().numpy(), np.bincount(sc.argmin(axis=1), minlength=10000))
 
 
+def test_f16mx_split_k_mode_config4_against_the_oracle_and_across_buffer_sizes(ctx, capsys):
+    """amx_ffnn_model.tuning ksplit=4 (opt-in, round 5): in a pass of at most 256 frames every 2048 x 2048 layer runs FOUR workgroups per
+    tile, each over a quarter of K; the last one to arrive adds the four partial sums in group order -- a different association of the
+    sum over k than the default's.  So
+      (a) BASELINE config 4's network on 1024 frames, scored as the decoder would (fills of 256), against the f64-accumulating oracle on
+          EVERY score -- the same assertions as the default mode;
+      (b) within the mode a frame's scores do not depend on the fill it is scored in, as long as the fill is split at all: 256 frames at
+          once = fills of 1, 100, 255 frames, bit for bit, run after run (the arrival order of the workgroups must not matter);
+      (c) against the default order the scores differ by f32 rounding only, and a pass too large to be split (1024 frames) IS the default;
+      (d) networks whose layers are too short to split and every activation still work"""
+    import rasr_amd
+    from oracle import oracle_ffnn_score
+    dims = [440] + [2048] * 6 + [10000]
+    Ws, bs, acts, logp = synth.ffnn(dims, seed=7)
+    T = 1024
+    x = feats(T, 440, 6)
+    nn = rasr_amd.NnBatchFeatureScorer(ctx, Ws, bs, acts, log_prior=logp, priori_scale=1.0, precision="f16mx", tuning="ksplit=4")
+    got = np.concatenate([nn.score(x[t0:t0 + 256]) for t0 in range(0, T, 256)])
+    want = oracle_ffnn_score(Ws, bs, acts, x, log_prior=logp, prior_scale=1.0, acc64=True)
+    dflt = rasr_amd.NnBatchFeatureScorer(ctx, Ws, bs, acts, log_prior=logp, priori_scale=1.0, precision="f16mx").score(x)
+    rep = nn_parity_report(got, want, other=dflt, gap=1e-5)
+    with capsys.disabled():
+        print("\nf16mx ksplit=4 config 4 parity (fills of 256):", json.dumps(rep))
+    assert rep["bar_violations"] == 0 and rep["worst_over_bar"] <= 0.5, rep
+    assert rep["worst_pure_relative"] <= 1e-4, rep
+    assert rep["argmin_mismatches_outside_gap_rule"] == 0, rep
+    assert np.count_nonzero(got.view(np.uint32) != dflt.view(np.uint32)) > 0                 # another order of summation ...
+    assert np.max(np.abs(got - dflt) / (np.abs(dflt) + 1.0)) < 2e-5                         # ... by rounding only
+    assert np.array_equal(nn.score(x).view(np.uint32), dflt.view(np.uint32))                # 1024 frames at once: not split = the default
+    for rep_ in range(3):
+        for n, t0 in ((256, 0), (1, 5), (100, 37), (255, 1), (256, 768)):
+            part = nn.score(x[t0:t0 + n])
+            assert np.array_equal(part.view(np.uint32), got[t0:t0 + n].view(np.uint32)), (n, t0, rep_)
+    # a fill that straddles two of the reference fills is still the same frames through the same split kernels
+    assert np.array_equal(nn.score(x[100:300]).view(np.uint32), got[100:300].view(np.uint32))
+    for d, act in (([440, 300, 33, 64, 50], 1), ([64, 96, 96, 10], 2), ([200, 2048, 2048, 40], 3)):
+        W2, b2, a2, l2 = synth.ffnn(d, seed=11 + act, act=act)
+        x2 = feats(200, d[0], 12)
+        g2 = rasr_amd.NnBatchFeatureScorer(ctx, W2, b2, a2, log_prior=l2, precision="f16mx", tuning="ksplit=4").score(x2)
+        w2 = oracle_ffnn_score(W2, b2, a2, x2, log_prior=l2, prior_scale=1.0, acc64=True)
+        assert np.all(np.abs(g2 - w2) <= 1e-4 * np.abs(w2) + 1e-4), (d, np.abs(g2 - w2).max())
+    with pytest.raises(rasr_amd.AmxError):
+        rasr_amd.NnBatchFeatureScorer(ctx, Ws[:1], bs[:1], [0], precision="bf16", tuning="ksplit=4")
+    with pytest.raises(rasr_amd.AmxError):
+        rasr_amd.NnBatchFeatureScorer(ctx, Ws[:1], bs[:1], [0], precision="f16mx", tuning="ksplit=3")
+
+
 @pytest.mark.parametrize("n_out", [2500, 2501])
 def test_f16mx_tile_configurations_agree(ctx, monkeypatch, n_out):
     """every tile configuration (128x128, 128x64, 256x256) walks the K-tiles in the same order and issues f16 slab 0, f16 slab 1,
