@@ -385,7 +385,7 @@ __device__ __forceinline__ u32x6 q_fields(f16x8 c0, f16x8 c1, unsigned scale_byt
 // than not splitting -- the eight L2s are not coherent with one another, so the device-scope fences around the counter write back and
 // invalidate a whole L2 per workgroup.  A kernel boundary does that once.)  The sum over k is associated differently from the default
 // (one accumulator, ascending k): scores differ from the default's by f32 rounding -- both meet the 1e-4 bar against the
-// f64-accumulating oracle -- and are bit-identical among all passes that run split (every pass of at most 256 frames of a handle
+// f64-accumulating reference sum -- and are bit-identical among all passes that run split (every pass of at most 256 frames of a handle
 // created with ksplit=4): a decoder runs one buffer size for life.
 template<class C, int ACT, bool LAST, int DBG = 0>
 __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const char* __restrict__ W, const char* __restrict__ X, const float* __restrict__ bias,
