@@ -42,7 +42,11 @@ inline void epochCheck(int status, const char* what) {
 // for ever): the file carries `jobTag` in front of the id and a rank only accepts a file with its own tag -- pass something unique to
 // the run and equal on all ranks (scheduler job id, start time of the launcher).  Rank 0 removes an existing file before it
 // publishes and removes its own after amx_comm_init has returned, i.e. after every rank has joined with the id it read.
-inline amx_comm* connect(amx_ctx* ctx, int rank, int world, const std::string& idFile, int timeoutSeconds = 600, uint64_t jobTag = 0) {
+// The tag is REQUIRED and must not be 0: with a default tag every job carries the same one, and a rank that starts before rank 0 has
+// removed last job's file would accept the old id -- the very hang the tag is there to prevent.
+inline amx_comm* connect(amx_ctx* ctx, int rank, int world, const std::string& idFile, int timeoutSeconds, uint64_t jobTag) {
+    if (jobTag == 0)
+        throw std::invalid_argument("AmxHost::connect: jobTag must be a non-zero value unique to this run and equal on all ranks");
     unsigned char id[AMX_COMM_ID_BYTES];
     if (rank == 0) {
         remove(idFile.c_str());

@@ -37,7 +37,15 @@ int main(int argc, char** argv) {
             AmxHost::epochCheck(amx_copy_to_device(ctx, red.statistics("acc"), acc.data(), acc.size() * 8), "upload");
             AmxHost::epochCheck(amx_copy_to_device(ctx, red.counters("counts"), counts.data(), counts.size() * 8), "upload");
             AmxHost::epochCheck(amx_copy_to_device(ctx, red.statistics("score-sum"), &sum, 8), "upload");
-            amx_comm* comm = AmxHost::connect(ctx, rank, world, argv[3], 120);
+            bool refused = false;   // a zero tag is refused (every job would carry the same one)
+            try {
+                AmxHost::connect(ctx, rank, world, argv[3], 1, 0);
+            } catch (const std::invalid_argument&) {
+                refused = true;
+            }
+            if (!refused)
+                throw std::runtime_error("connect accepted jobTag 0");
+            amx_comm* comm = AmxHost::connect(ctx, rank, world, argv[3], 120, /*jobTag*/ 0x5eed0001ull);
             if (amx_comm_rank(comm) != rank || amx_comm_world(comm) != world)
                 throw std::runtime_error("communicator reports another rank / world size");
             red.allReduce(comm);

@@ -1,7 +1,8 @@
-"""tools/fuzz_gmm.py [n_cases] [seed] -- random diagonal-GMM models / feature batches through every maximum-approximation path of the
+"""tools/fuzz_gmm.py [n_cases] [seed] [contract: off | fma | both (default)] -- random diagonal-GMM models / feature batches through every maximum-approximation path of the
 library against the oracle, bit for bit: private and pooled covariances, 1..16 and longer mixtures, tied lists, supported and
 unsupported dimensions, features with outliers that overflow the f16 screen operand (all-slot frames), duplicated densities.
-Not part of the test suite (minutes of oracle time); run on a GPU box after touching gmm.hip / gmm_simd.hip."""
+Every case draws one of the reference's two arithmetics (amx_gmm_model.tuning contract=off | fma) and is held to the oracle library of that
+build.  Not part of the test suite (minutes of oracle time); run on a GPU box after touching gmm.hip / gmm_simd.hip."""
 import os
 import sys
 
@@ -14,6 +15,7 @@ from tests import synth  # noqa: E402
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.Generator(np.random.PCG64(int(sys.argv[2]) if len(sys.argv) > 2 else 1))
+contracts = {"off": ["off"], "fma": ["fma"]}.get(sys.argv[3] if len(sys.argv) > 3 else "both", ["off", "fma"])
 ctx = rasr_amd.Context(0)
 bad = 0
 for case in range(n_cases):
@@ -48,14 +50,16 @@ for case in range(n_cases):
         x[rng.integers(0, T)] *= np.float32(1e4)                      # does not fit the f16 operand: frame keeps all slots
     if rng.integers(0, 6) == 0:
         x[rng.integers(0, T), rng.integers(0, dim)] = np.float32(rng.choice([np.inf, -np.inf, np.nan, 1e30]))
-    o = OracleGmm(model)
+    contract = contracts[int(rng.integers(0, len(contracts)))]
+    tun = "contract=fma" if contract == "fma" else None
+    o = OracleGmm(model, contract=contract)
     want, wbest = o.score(x)
-    got, best = rasr_amd.GmmFeatureScorer(ctx, model).score(x)
+    got, best = rasr_amd.GmmFeatureScorer(ctx, model, tuning=tun).score(x)
     ok = np.array_equal(got.view(np.uint32), want.view(np.uint32)) and np.array_equal(best, wbest)
     # the byte form of the best-density matrix (amx_gmm_score_stats_u8_dev) and the best density / score of ONE mixture per frame
     # (amx_gmm_best_density_dev), both against the oracle
     import torch
-    sc_u8 = rasr_amd.GmmFeatureScorer(ctx, model)
+    sc_u8 = rasr_amd.GmmFeatureScorer(ctx, model, tuning=tun)
     M = want.shape[1]
     ctx.use_torch_stream()
     xd = torch.from_numpy(x).cuda()
@@ -83,6 +87,6 @@ for case in range(n_cases):
     ok_simd = np.array_equal(sg.view(np.uint32), sw.view(np.uint32)) and np.array_equal(sgb, sb)
     if not (ok and ok_simd):
         bad += 1
-        print("MISMATCH case %d: kind=%s dim=%d pooled=%s seed=%d T=%d max=%s simd=%s" % (case, kind, dim, pooled, seed, T, ok, ok_simd))
+        print("MISMATCH case %d: contract=%s kind=%s dim=%d pooled=%s seed=%d T=%d max=%s simd=%s" % (case, contract, kind, dim, pooled, seed, T, ok, ok_simd))
 print("%d cases, %d mismatches" % (n_cases, bad))
 sys.exit(1 if bad else 0)

@@ -49,10 +49,12 @@ for case in range(n_cases):
         x[rng.integers(0, T)] *= np.float32(rng.choice([30.0, 1e4]))
     if rng.integers(0, 5) == 0:
         x[rng.integers(0, T), rng.integers(0, dim)] = np.float32(rng.choice([np.inf, -np.inf, np.nan, 1e30]))
-    want, wbest = OracleGmm(model).score(x)
+    contract = ("off", "fma")[int(rng.integers(0, 2))]   # the reference's two arithmetics (amx_gmm_model.tuning contract=...)
+    want, wbest = OracleGmm(model, contract=contract).score(x)
     status = []
     for mode in ("1", "0", None):
-        sc = rasr_amd.GmmFeatureScorer(ctx, model, tuning=None if mode is None else "tied_prune=" + mode)
+        sc = rasr_amd.GmmFeatureScorer(ctx, model, tuning=",".join(i for i in (None if mode is None else "tied_prune=" + mode,
+                                                                                   "contract=fma" if contract == "fma" else None) if i) or None)
         ok = True
         for _ in range(3 if mode is None else 1):        # the adaptive default: later calls see the statistics of earlier ones
             got, best = sc.score(x)
@@ -60,7 +62,7 @@ for case in range(n_cases):
         status.append(ok)
     if not all(status):
         bad += 1
-        print("MISMATCH case %d: dim=%d nd=%d n_mix=%d seed=%d alpha=%g twist=%d T=%d pruned/dense/adaptive=%s" %
-              (case, dim, nd, n_mix, seed, alpha, twist, T, status))
+        print("MISMATCH case %d: contract=%s dim=%d nd=%d n_mix=%d seed=%d alpha=%g twist=%d T=%d pruned/dense/adaptive=%s" %
+              (case, contract, dim, nd, n_mix, seed, alpha, twist, T, status))
 print("%d cases, %d mismatches" % (n_cases, bad))
 sys.exit(1 if bad else 0)
