@@ -307,13 +307,27 @@ typedef struct {
     double          mixture_weight_scale; /* mixture-weight-scale (Core::ParameterFloat = f64; the scorer keeps it as f32), default 1 */
     double          gaussian_scale;       /* gaussian-scale (f64; the scorer keeps (f32)sqrt of the f64 value,
                                            * Mm/GaussDiagonalMaximumFeatureScorer.cc:52), default 1 */
-    /* Kernel selection for A/B runs and tests, "key=value,key=value" (NULL: defaults; an unknown key fails amx_gmm_create; read by
-     * amx_gmm_create only -- amx_pms_write, amx_gmm_estimate, amx_prior_from_mixture_set ignore it).  Every path gives the same
-     * scores and density indices bit for bit.  screen=0 (no MFMA / f32 screen: every density evaluated), fused=0 (two-kernel
-     * screen path instead of gmm_fused_kernel), screen_kernel=rows|persist|simple, graph=0 (no HIP-graph replay of small batches),
-     * tied_prune=0|1 (tied models: dense tile kernel | pruned scorer, default adaptive), chunk=N (frames per internal pass),
-     * fused_waves=8|12|16|13 (13: the wave-specialised kernel), fr=N (frames per workgroup of the uniform tied kernel), simd_mfma=0 (SIMD / batch-int scorers without
-     * the i8 matrix kernel). */
+    /* "key=value,key=value" (NULL: defaults).  Keys AND values are checked by amx_gmm_create -- an unknown key, a number that is not one,
+     * a value the key does not take fail the creation (AMX_ERR_INVALID): a typo must not silently select another kernel or arithmetic.
+     * Read by amx_gmm_create only (amx_pms_write, amx_gmm_estimate, amx_prior_from_mixture_set ignore it).
+     *
+     * contract=off|fma -- WHICH BUILD OF THE REFERENCE the scores are bit-identical to (not a speed switch; default off):
+     *   off  RASR configured with -DMARCH=x86-64, or built on a host without FMA units: every f32 operation of the distance
+     *        (Mm/GaussDiagonalMaximumFeatureScorer.cc:144-218) rounds once;
+     *   fma  RASR's DEFAULT configuration (cmake_resources/CompileOptions.cmake:39-48: -march=native) built with GCC on an FMA host:
+     *        its default -ffp-contract=fast turns `sum += df * df` into one fused multiply-add (vfmadd231ps / vfmadd231ss); about a
+     *        fifth of the d = 40 distances differ in the last bit from the other build.
+     *   Covers the modes AMX_GMM_MAX, AMX_GMM_SUM, AMX_GMM_BATCH_FLOAT, amx_gmm_best_density_dev and the Baum-Welch statistics; the
+     *   quantised and preselection scorers were not examined under the reference's default flags and return AMX_ERR_UNSUPPORTED with
+     *   contract=fma, as does fused_waves=13.  Both arithmetics are pinned on the reference's own function text compiled both ways
+     *   (tests/test_contract.py) and bit-exact on every kernel path (tests/test_gmm_gpu.py, tests/test_gmm_contract_gpu.py).
+     *
+     * Kernel selection for A/B runs and tests -- every path gives the same scores and density indices bit for bit (within a contract):
+     * screen=0 (no MFMA / f32 screen: every density evaluated), fused=0 (two-kernel screen path instead of gmm_fused_kernel),
+     * screen_kernel=rows|persist|simple, graph=0 (no HIP-graph replay of small batches), tied_prune=0|1 (tied models: dense tile
+     * kernel | pruned scorer, default -1 adaptive), chunk=N (frames per internal pass, >= 256), fused_waves=8|12|16|13 (13: the
+     * wave-specialised kernel), fr=2|4|8|16 (frames per workgroup of the uniform tied kernel), simd_mfma=0 (SIMD / batch-int scorers
+     * without the i8 matrix kernel). */
     const char*     tuning;
 } amx_gmm_model;
 
@@ -506,11 +520,20 @@ typedef struct {
      * output ("no one-to-one correspondence between network outputs and classes!"); scores are [T x n_classes]. */
     int                 n_classes;
     const int*          class_to_output;
-    /* Kernel selection for A/B runs and tests, "key=value,key=value" (NULL: defaults; an unknown key fails amx_ffnn_create).  Every
-     * tile configuration of a precision gives bit-identical scores.  tile=N (GEMM tile configuration: 0 128x128, 2 256x256
-     * pipelined, 3 128x64, 4 256x256 single-tile, 6 128x64 three stages; default by layer shape), graph=0 (no HIP-graph replay of
-     * small batches), persistent=0, group=TxN (tiles per XCD-aware super-tile), chunk=N (frames per internal pass),
-     * stagger=N (f16mx output layer of a large batch: XCD x starts x * N * 10 ns late; default 0). */
+    /* "key=value,key=value" (NULL: defaults); keys and values are checked by amx_ffnn_create like amx_gmm_model.tuning's.
+     * Two keys change RESULTS (within the 1e-4 bar of the f32 reference either way):
+     *   ksplit=4 (AMX_PREC_F16MX; default 1)  passes of at most 256 frames -- a decoder's ring-buffer fill -- split the K of every
+     *        2048-wide layer over four workgroups per tile (two launches: partial sums, then ((P0 + P1) + P2) + P3 and the epilogue):
+     *        four times as many CUs pull operands, a 256-frame fill of BASELINE config 4's network takes 0.146 instead of 0.170 ms.
+     *        Another association of the sum over k than the default (one accumulator, ascending k): scores differ from the default's
+     *        by f32 rounding and are bit-identical among all passes that are split; larger passes of the same handle run the default
+     *        order.  Without it, scoring a segment in pieces gives the bits of scoring it whole.
+     *   mx_fallback=auto|off (AMX_PREC_F16MX; default auto)  auto: heavy-tailed weights compute in split bf16 (amx_ffnn_precision).
+     * Kernel selection for A/B runs and tests -- every tile configuration of a precision gives bit-identical scores: tile=N (GEMM tile
+     * configuration: 0 128x128, 2 256x256 with all waves in phase, 8 256x256 with the ping-pong K loop (f16mx; the default for large
+     * batches since round 5), 3 128x64 one tile per CU, 6 128x64 two per CU, 4 / 5 / 7 K-loop variants of 2; default by layer shape),
+     * graph=0 (no HIP-graph replay of small batches), persistent=0, group=TxN (tiles per XCD-aware super-tile), chunk=N (frames per
+     * internal pass, >= 256), stagger=N (f16mx output layer of a large batch: XCD x starts x * N * 10 ns late; default 0). */
     const char*         tuning;
 } amx_ffnn_model;
 
