@@ -36,7 +36,7 @@ MFMA_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak
 FP32_TFLOPS = 157.3        # f32 vector (= f32 MFMA) peak
 
 
-TRAFFIC_SOURCE = os.path.join("profiles", "r04", "traffic.json")
+TRAFFIC_SOURCE = os.path.join("profiles", "r05", "traffic.json")
 
 
 def measured_traffic(workload, *needles):
@@ -455,8 +455,16 @@ class NnPipeline:
                                                     what="f16mx: 1 f16 MFMA product + 0.5 fp6 x fp6 scaled product per 16 k; the scaled product "
                                                          "costs 1.6 f16 products here (feed probe), nominally 1" if self.nn_precision == "f16mx" else
                                                          "matrix products executed per f32 product of the reference"),
-                    traffic=None, avg_launch_ms=round(t_ms / n_h, 4), launches=n_h, flops_per_launch=alg / n_h,
+                    traffic=self.template_traffic(largest), avg_launch_ms=round(t_ms / n_h, 4), launches=n_h, flops_per_launch=alg / n_h,
                     summed_ms_per_step=round(t_ms / max(1, n_o // len(rows)), 4), largest_launch=largest)
+
+    def template_traffic(self, largest):
+        """HBM-side bytes per launch of the GEMM template, averaged over the seven launches of a pass like `achieved`: six hidden-layer
+        launches (one PMC entry: same instantiation) and the output layer's, from the offline FETCH_SIZE / WRITE_SIZE passes"""
+        if self.nn_precision != "f16mx" or self.F < self.CHUNK or largest.get("traffic") is None:
+            return None
+        hid = measured_traffic("pipeline", "gemm_mx_kernel", ">, 1, false, 0>")
+        return None if hid is None else round((6.0 * hid + largest["traffic"]) / 7.0, 1)
 
     def stage_report(self):
         out = {}
