@@ -1283,6 +1283,9 @@ def reset_survivor_counters(job):
             g.screen_counts(True)
 
 
+SHADER_CLOCK_GHZ = None   # set by measure(): mean shader clock over the second (per-launch timed) pass
+
+
 def measure(ctx, job, args, world):
     """W untimed steps, then exactly K steps + the epoch reduce between barrier + synchronize; returns seconds"""
     gpu = ctx is not None
@@ -1306,9 +1309,18 @@ def measure(ctx, job, args, world):
         reset_survivor_counters(job)
         ctx.profile(True)
         ctx.profile_reset()
+        # shader clock of the same pass: (s_memtime, s_memrealtime) sampled by a one-wave kernel in front of and behind it, in stream
+        # order.  The NN workloads sit at the package's 1400 W power cap and the firmware lowers sclk until they fit
+        # (profiles/r05/power_probe.log): `peak` in the roofline object is priced at the 2.4 GHz ceiling, this says what the run got.
+        clk = torch.zeros((2, 2), dtype=torch.int64, device="cuda")
+        ctx.device_clocks(clk[0])
         for _ in range(min(args.steps, 20)):
             job.step()
+        ctx.device_clocks(clk[1])
         torch.cuda.synchronize()
+        ck = clk.cpu().numpy().astype(np.float64)
+        global SHADER_CLOCK_GHZ
+        SHADER_CLOCK_GHZ = round(float((ck[1, 0] - ck[0, 0]) / max(ck[1, 1] - ck[0, 1], 1.0) * 0.1), 3)
     if gpu:
         ctx.profile(False)
     return dt
@@ -1615,6 +1627,15 @@ def main():
         line["roofline"] = job.roofline()
         if line["roofline"] and line["roofline"].get("traffic") is not None:
             line["roofline"]["traffic_source"] = TRAFFIC_SOURCE + " (offline rocprofv3 --pmc passes on the profiling box, not this run)"
+        if line["roofline"] and SHADER_CLOCK_GHZ:
+            r = line["roofline"]
+            r["shader_clock_GHz"] = SHADER_CLOCK_GHZ
+            if r.get("bound") == "mfma":
+                r["peak_at_shader_clock"] = round(r["peak"] * SHADER_CLOCK_GHZ / 2.4, 1)
+                r["frac_at_shader_clock"] = round(r["achieved"] / (r["peak"] * SHADER_CLOCK_GHZ / 2.4), 4)
+            r["clock_note"] = ("mean sclk of the per-launch timed pass (s_memtime / s_memrealtime).  `peak` is priced at the 2.4 GHz ceiling; the NN "
+                               "GEMMs run at the package's 1400 W power cap, where the firmware holds sclk at 1.85-2.1 GHz whatever the kernel "
+                               "does per cycle (profiles/r05/power_probe.log: rocm-smi power and sclk sampled during each workload)")
         line["stages"] = job.stage_report()
         if getattr(job, "ingest", None) is not None:
             line["ingest"] = job.ingest.report()

@@ -317,6 +317,19 @@ __host__ __device__ constexpr int gemm_scratch_bytes() {
     return C::LDS_BYTES > EpiCfg<C, LAST>::BYTES ? C::LDS_BYTES : EpiCfg<C, LAST>::BYTES;
 }
 
+// Tile configurations whose accumulators live in the AGPR half of the register file (one wave per SIMD, 256 accumulator registers:
+// MxCfg::PIPE == 2).  Left alone, the allocator copies all 256 of them into VGPRs behind the K loop -- and spills whatever else is alive.
+// The epilogues pin one 32 x 32 block at a time ("a" constraint) right in front of its use: sixteen registers cross over at a time.
+template<class C, class = void>
+struct AccInAgprs : std::false_type {};
+template<class C>
+struct AccInAgprs<C, std::void_t<decltype(C::PIPE)>> : std::integral_constant<bool, C::PIPE == 2> {};
+template<class C>
+__device__ __forceinline__ void pin_block(f32x16& a) {
+    if constexpr (AccInAgprs<C>::value)
+        asm volatile("" : "+a"(a));
+}
+
 template<class C, int ACT, bool LAST, bool NOSTORE = false>
 __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[C::MI][C::MJ], char* lds, const float* s_bias, void* __restrict__ out,
                                               int ldo, int olo, int n_valid, int t_valid, int n0, int t0, int tile_n, int wn, int wt, int lane, int tid,
@@ -339,6 +352,8 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[C::MI][C::MJ], char*
         // ---- registers -> LDS [frame][output]
 #pragma unroll
         for (int i = 0; i < C::MI; ++i) {
+            if (pl == 0)
+                pin_block<C>(acc[i][j]);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int nl = i * 32 + 8 * g + 4 * hh;  // output index inside the wave tile
@@ -1605,6 +1620,7 @@ using MfgLP = amx::mx::MxCfg<256, 256, 2, 4, 3, 4>;  // the same with the softwa
 using MfgLH = amx::mx::MxCfg<256, 256, 2, 4, 3, 0, 4>;  // the first wave of every SIMD issues all LDS-DMA pieces (tuning tile=5: A/B runs)
 using MfgLF = amx::mx::MxCfg<256, 256, 2, 4, 3, 4, 4>;  // ... and its partner prefetches four K-tiles ahead into L2, outside every counted queue (tile=7)
 using MfgLQ = amx::mx::MxCfg<256, 256, 2, 4, 3, 0, 0, 1, 0, 1>;  // round 5: ping-pong halves -- one wave of a SIMD issues its products while its partner reads / refills (tile=8)
+using MfgLW = amx::mx::MxCfg<256, 256, 2, 2, 3, 0, 0, 1, 0, 2>;  // round 5: ONE wave per SIMD, four waves of 128 x 128 that pipeline themselves (tile=9)
 using MfgA = amx::mx::MxCfg<128, 128, 2, 2, 3>;  //  74 KB: 2 workgroups per CU
 using MfgS = amx::mx::MxCfg<128, 64, 2, 2, 8, 0, 0, 2>;  // 147 KB: small batches, ONE tile per CU, two K-tiles per barrier, four more in flight (a
                                                          // 2048 x 2048 layer at batch 1024 is 64 K-tiles of 9 matrix instructions per wave: barrier and LDS round trip per K-tile were its time)
@@ -1665,7 +1681,7 @@ void launch_mx(amx_ffnn* h, int l, const void* x, int xkts, void* out, int ldo, 
     int dbg = 0;
 #ifdef AMX_LAB  // ablations of the large-batch kernel (tools/ab_mx.sh, profiles/r04/gemm_mx_ablation.log)
     dbg = h->mx_dbg;
-    if constexpr (C::BN == 256 && ACT == AMX_ACT_RELU * (LAST ? 0 : 1)) {
+    if constexpr (C::BN == 256 && C::PIPE == 0 && ACT == AMX_ACT_RELU * (LAST ? 0 : 1)) {
         switch (dbg) {
             case 8: AMX_MX_LAUNCH(8); break;
             case 24: AMX_MX_LAUNCH(24); break;
@@ -1731,6 +1747,7 @@ void launch_mx_cfg(amx_ffnn* h, int l, const void* x, int xkts, void* out, int l
         case 5: launch_mx<MfgLH, ACT, LAST>(h, l, x, xkts, out, ldo, T, Tpad, n_valid); break;
         case 7: launch_mx<MfgLF, ACT, LAST>(h, l, x, xkts, out, ldo, T, Tpad, n_valid); break;
         case 8: launch_mx<MfgLQ, ACT, LAST>(h, l, x, xkts, out, ldo, T, Tpad, n_valid); break;
+        case 9: launch_mx<MfgLW, ACT, LAST>(h, l, x, xkts, out, ldo, T, Tpad, n_valid); break;
         case 3:
             if constexpr (LAST)
                 launch_mx<MfgS, ACT, LAST>(h, l, x, xkts, out, ldo, T, Tpad, n_valid);
@@ -1878,7 +1895,7 @@ int amx_ffnn_create(amx_ctx* ctx, const amx_ffnn_model* m, amx_ffnn** out) {
             return AMX_ERR_INVALID;
         AMX_REQUIRE(t_ksplit == 1 || t_ksplit == 4, AMX_ERR_INVALID, "amx_ffnn_create: tuning ksplit=%d: expected 1 | 4", t_ksplit);
         AMX_REQUIRE(t_ksplit == 1 || m->precision == AMX_PREC_F16MX, AMX_ERR_UNSUPPORTED, "amx_ffnn_create: tuning ksplit exists for AMX_PREC_F16MX only");
-        if (!tune.get_int("tile", -1, -1, 8, &t_tile, who) || !tune.get_int("graph", 1, 0, 1, &t_graph, who) ||
+        if (!tune.get_int("tile", -1, -1, 9, &t_tile, who) || !tune.get_int("graph", 1, 0, 1, &t_graph, who) ||
             !tune.get_int("persistent", 1, 0, 1, &t_persistent, who) || !tune.get_int("chunk", 32768, 256, 1 << 24, &t_chunk, who) ||
             !tune.get_int("mx_dbg", 0, 0, 1 << 16, &t_mx_dbg, who) || !tune.get_int("stagger", 0, 0, 100000, &t_stagger, who))
             return AMX_ERR_INVALID;

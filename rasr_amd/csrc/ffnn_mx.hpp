@@ -236,8 +236,13 @@ struct MxCfg {
     // the first group in half 2 of period kt - 1 and by the second in half 1 of period kt, and is refilled behind that), the same
     // matrix instructions in the same order per accumulator: bit-identical scores.
     static constexpr int PIPE = PIPE_;
-    static_assert(PIPE_ == 0 || (PIPE_ == 1 && U_ == 1 && LW_ == 0 && PF_ == 0 && IW_ == 0 && STAGES_ == 3 && WN_ * WT_ == 8),
-                  "ping-pong K loop: eight waves, every one of them issuing, plain three-stage ring");
+    // PIPE = 2: ONE WAVE PER SIMD (four waves, each a 128 x 128 wave tile: 256 accumulator registers in the AGPR half of a 512-register
+    // file) that pipelines itself -- see the K loop.  Against the eight-wave tile: a third fewer fragment bytes out of LDS per K-tile
+    // (4 x (128 + 128) rows instead of 8 x (64 + 128)), four conversions per SIMD and K-tile instead of six (a conversion takes the
+    // matrix pipe), one barrier per K-tile among four waves instead of two among eight.
+    static_assert(PIPE_ == 0 || (PIPE_ == 1 && U_ == 1 && LW_ == 0 && PF_ == 0 && IW_ == 0 && STAGES_ == 3 && WN_ * WT_ == 8) ||
+                      (PIPE_ == 2 && U_ == 1 && LW_ == 0 && PF_ == 0 && IW_ == 0 && STAGES_ == 3 && WN_ * WT_ == 4 && BN_ / WN_ == 128 && BT_ / WT_ == 128),
+                  "ping-pong K loop: eight waves, every one of them issuing, plain three-stage ring; self-pipelined: four waves of 128 x 128");
     // PF > 0 (256 x 256 tiles only): waves 0-5 touch the 384 cache lines of the K-tile PF steps ahead of the one whose LDS-DMA they
     // have just issued (one dword per 128-byte line, 64 lines per wave-instruction) -- a software prefetch from the Infinity Cache /
     // HBM into L2.  The LDS ring holds two K-tiles in flight (~2 periods of 1.7 us); a K-tile whose lines miss L2 (23 % of the
@@ -776,7 +781,172 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const char* __restr
         };
         // one code path for both groups -- early: sync(kt) reads(kt) products(kt); late: reads(kt) sync(kt + 1) products(kt), i.e. the
         // late wave's products of K-tile kt run in period kt + 1, in front of its reads of K-tile kt + 1.  Both execute KT barriers.
-        if constexpr (C::PIPE > 0) {
+        if constexpr (C::PIPE == 2) {
+            static_assert(DBG == 0 || DBG == 2048, "the self-pipelined K loop has no ablation variants");
+            static_assert(C::NHI == 0 && C::IW == C::NW && C::MI == 4 && C::MJ == 4, "every wave issues PPW pieces");
+            // ONE WAVE PER SIMD, pipelining itself (tuning tile=9; opt-in -- see the measurement below).  A K-tile's 48 matrix instructions
+            // go out in three phases of 16 -- f16 products of k-slab 0 (A), of k-slab 1 (B), the scaled cross products (C) -- and everything
+            // else rides between them, in their shadow:
+            //   A  the four conversions of THIS K-tile (fragments and records are in registers from the previous iteration), their lane
+            //      swaps and the assembly of the scaled operands;
+            //   B  the fragment reads of k-slab 0 of the NEXT K-tile, into the registers phase A has just finished with, and eight of
+            //      this wave's twelve LDS-DMA pieces of K-tile kt + 3 (into the stage of K-tile kt, which every wave has finished reading:
+            //      the barrier at the top);
+            //   C  the reads of k-slab 1 and of the records of the next K-tile, the other four pieces.
+            // One barrier per K-tile, at the top: this wave's reads of K-tile kt are complete (lgkmcnt), its pieces of K-tile kt + 1
+            // have landed (counted vmcnt, K-tile kt + 2 stays in flight).  Per accumulator the same three instructions in the same
+            // order as in every other configuration: bit-identical.  sched_barrier(0) pins the interleave (left to itself the
+            // scheduler gathers the reads at the head of the block and the matrix instructions behind them).  180-186 VGPRs + 256 AGPRs,
+            // no scratch (the epilogues pin the accumulator blocks in AGPRs until their use: pin_block).
+            // MEASURED (one box, output layer 2048 -> 10000): 1.99 ms against the ping-pong tile's 1.87 ms.  With neither reads nor pieces
+            // the loop runs 1.41 ms; the twelve pieces cost 0.35 ms, the 24 reads 0.21 ms (additive; all operands L2 hits: -0.1 ms) --
+            // a wave issues in order, and what is not a matrix instruction takes issue time from the one wave a SIMD has, where the
+            // ping-pong tile gives it to the partner wave.  And the comparison is not run at one clock: BOTH kernels sit at the
+            // package's 1400 W power cap (profiles/r05/power_probe.log) -- the ping-pong tile at 1.88 GHz, this one at 2.03-2.1 GHz,
+            // round 4's in-phase tile at 2.08 GHz: the firmware trades clock for every gain in instructions per cycle.
+            auto await_tile = [&](int ahead_tiles) { mx_wait_ahead<C::PPW, 0, 2>(ahead_tiles); };
+            const unsigned vdma = (unsigned)lane * 16u;
+            auto dma = [&](int q, int slot, int kt) {  // piece q of this wave, unconditionally
+                const char*    src = (p_b[q] ? xblk : wblk) + (size_t)kt * BLK + p_src[q];
+                const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_base + slot * C::STAGE_BYTES + p_dst[q]));
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(vdma), "s"(src), "s"(dst) : "memory");
+            };
+            Frag& F = fr[0];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            await_tile(min(2, KT - 1));
+            __builtin_amdgcn_s_barrier();
+            reads(0, F);
+            auto f16_products = [&](int ks, int i) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.a[ks][i], F.b[ks][j], acc[i][j], 0, 0, 0);
+            };
+            auto frame_swaps = [&](int j, u32x4 (&x0)[2], u32x4 (&x1)[2]) {  // see products(): frame-major copies of the pair's fragments
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    x0[ks] = __builtin_bit_cast(u32x4, F.b[ks][j]);
+                    x1[ks] = __builtin_bit_cast(u32x4, F.b[ks][j + 1]);
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        const u32x2 sw = __builtin_amdgcn_permlane32_swap(x0[ks][d], x1[ks][d], false, false);
+                        x0[ks][d]      = sw[0];
+                        x1[ks][d]      = sw[1];
+                    }
+                }
+            };
+            auto frame_convert = [&](int j, u32x4 (&x0)[2], u32x4 (&x1)[2]) {
+                const unsigned sc = (fk ? F.rb[j + 1].w : F.rb[j].w) + 11u;
+                return q_fields_pair(__builtin_bit_cast(f16x8, x0[0]), __builtin_bit_cast(f16x8, x0[1]), __builtin_bit_cast(f16x8, x1[0]),
+                                     __builtin_bit_cast(f16x8, x1[1]), sc);
+            };
+            v8i      av[4], bv[4];
+            unsigned sa[4], sb[4];
+            auto frame_operands = [&](int j, u32x6 q) {
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    const u32x2 sw = __builtin_amdgcn_permlane32_swap(q[d], q[3 + d], false, false);
+                    q[d]           = sw[0];
+                    q[3 + d]       = sw[1];
+                }
+                bv[j]     = v8i{(int)F.rb[j].x, (int)F.rb[j].y, (int)F.rb[j].z, (int)q[0], (int)q[1], (int)q[2], 0, 0};
+                bv[j + 1] = v8i{(int)F.rb[j + 1].x, (int)F.rb[j + 1].y, (int)F.rb[j + 1].z, (int)q[3], (int)q[4], (int)q[5], 0, 0};
+                sb[j]     = F.rb[j].w;
+                sb[j + 1] = F.rb[j + 1].w;
+            };
+            auto row_operands = [&](int i, const u32x6& q) {
+                av[i]     = v8i{(int)q[0], (int)q[1], (int)q[2], (int)F.ra[i].x, (int)F.ra[i].y, (int)F.ra[i].z, 0, 0};
+                av[i + 1] = v8i{(int)q[3], (int)q[4], (int)q[5], (int)F.ra[i + 1].x, (int)F.ra[i + 1].y, (int)F.ra[i + 1].z, 0, 0};
+                sa[i]     = F.ra[i].w;
+                sa[i + 1] = F.ra[i + 1].w;
+            };
+            auto iteration = [&](int kt, auto with_dma) {
+                constexpr bool DMA = decltype(with_dma)::value;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (kt + 1 < KT)
+                    await_tile(kt + 2 < KT ? 1 : 0);
+                __builtin_amdgcn_s_barrier();
+                stamp(kt, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                const char* ab   = lds + ((kt + 1) % C::STAGES) * C::STAGE_BYTES;  // the next K-tile's stage (the last iteration reads a stale one)
+                const char* bb   = ab + C::A_BYTES;
+                const int   slot = kt % C::STAGES;                                  // free: refilled with K-tile kt + 3
+                // side operation n of the K-tile: 0-23 the fragment / record reads of the NEXT K-tile (k-slab 0 first: its registers are
+                // free since phase A), 24-35 this wave's LDS-DMA pieces.  ONE of them behind a matrix instruction (a wave issues in order:
+                // two pieces in a row hold it ~70 cycles -- the first form of this loop, 2.07 ms -- one mostly fits into the time the matrix
+                // pipe is busy with the instruction in front of it: 1.99 ms); a piece behind every fourth instruction of all three phases
+                // and a per-wave skew of 16 cycles were measured too, both slower (profiles/r05/one_wave_per_simd.log)
+                auto side = [&](int n) {
+                    if (n < 4)
+                        F.a[0][n] = *(const f16x8*)(ab + h_off(a_row + 32 * n, fk));
+                    else if (n < 8)
+                        F.b[0][n - 4] = *(const f16x8*)(bb + h_off(b_row + 32 * (n - 4), fk));
+                    else if (n < 12)
+                        F.a[1][n - 8] = *(const f16x8*)(ab + h_off(a_row + 32 * (n - 8), 2 + fk));
+                    else if (n < 16)
+                        F.b[1][n - 12] = *(const f16x8*)(bb + h_off(b_row + 32 * (n - 12), 2 + fk));
+                    else if (n < 20)
+                        F.ra[n - 16] = __builtin_bit_cast(uint4, *(const f16x8*)(ab + C::A_R + fk * (C::BN * 16) + (a_row + 32 * (n - 16)) * 16));
+                    else if (n < 24)
+                        F.rb[n - 20] = __builtin_bit_cast(uint4, *(const f16x8*)(bb + C::B_R + fk * (C::BT * 16) + (b_row + 32 * (n - 20)) * 16));
+                    else if (n < 24 + C::PPW) {
+                        if constexpr (DMA)
+                            dma(n - 24, slot, kt + 3);
+                    }
+                };
+                // ---- A
+                u32x4 x0[2], x1[2];
+                frame_swaps(0, x0, x1);
+                f16_products(0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                u32x6 qb = frame_convert(0, x0, x1);
+                f16_products(0, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                frame_operands(0, qb);
+                frame_swaps(2, x0, x1);
+                f16_products(0, 2);
+                __builtin_amdgcn_sched_barrier(0);
+                qb       = frame_convert(2, x0, x1);
+                u32x6 qa = q_fields_pair(F.a[0][0], F.a[1][0], F.a[0][1], F.a[1][1], F.ra[0].w);
+                f16_products(0, 3);
+                __builtin_amdgcn_sched_barrier(0);
+                frame_operands(2, qb);
+                row_operands(0, qa);
+                qa = q_fields_pair(F.a[0][2], F.a[1][2], F.a[0][3], F.a[1][3], F.ra[2].w);
+                // ---- B
+                stamp(kt, 1);
+#pragma unroll
+                for (int m = 0; m < 16; ++m) {  // reads 0-7 behind the first eight, pieces 0-7 behind the rest
+                    acc[m / 4][m % 4] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.a[1][m / 4], F.b[1][m % 4], acc[m / 4][m % 4], 0, 0, 0);
+                    if (m == 0)
+                        row_operands(2, qa);
+                    side(m < 8 ? m : 24 + (m - 8));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // ---- C
+                stamp(kt, 2);
+#pragma unroll
+                for (int m = 0; m < 16; ++m) {  // reads 8-23 behind the first twelve (two behind each of the first four), pieces 8-11 behind the rest
+                    acc[m / 4][m % 4] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av[m / 4], bv[m % 4], acc[m / 4][m % 4], 2, 2, 0, (int)sa[m / 4], 0, (int)sb[m % 4]);
+                    if (m < 4) {
+                        side(8 + 2 * m);
+                        side(9 + 2 * m);
+                    }
+                    else if (m < 12)
+                        side(12 + m);
+                    else
+                        side(24 + 8 + (m - 12));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                stamp(kt, 3);
+            };
+            int kt = 0;
+            for (; kt + 3 < KT; ++kt)
+                iteration(kt, std::true_type{});
+#pragma unroll 1
+            for (; kt < KT; ++kt)
+                iteration(kt, std::false_type{});
+        }
+        else if constexpr (C::PIPE > 0) {
             static_assert(DBG == 0 || DBG == 2048, "the ping-pong K loop has no ablation variants");
             const bool second = wave >= C::NW / 2;  // the group that runs half a period behind (waves 4-7: the partners of waves 0-3)
             auto await_tile = [&](int ahead_tiles, int max_ahead) {  // own pieces of a K-tile have landed; `ahead_tiles` younger K-tiles may stay in flight
@@ -957,6 +1127,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const char* __restr
                 const int t = t0 + wt * WTT + 32 * j + tl32;
 #pragma unroll
                 for (int i = 0; i < C::MI; ++i) {
+                    pin_block<C>(acc[i][j]);
                     float v[16], m = 0.f;
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
