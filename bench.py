@@ -1283,7 +1283,8 @@ def reset_survivor_counters(job):
             g.screen_counts(True)
 
 
-SHADER_CLOCK_GHZ = None   # set by measure(): mean shader clock over the second (per-launch timed) pass
+SHADER_CLOCK_GHZ = None   # set by measure(): median shader clock of the eight XCDs over the second (per-launch timed) pass
+SHADER_CLOCK_XCD = None
 
 
 def measure(ctx, job, args, world):
@@ -1312,15 +1313,19 @@ def measure(ctx, job, args, world):
         # shader clock of the same pass: (s_memtime, s_memrealtime) sampled by a one-wave kernel in front of and behind it, in stream
         # order.  The NN workloads sit at the package's 1400 W power cap and the firmware lowers sclk until they fit
         # (profiles/r05/power_probe.log): `peak` in the roofline object is priced at the 2.4 GHz ceiling, this says what the run got.
-        clk = torch.zeros((2, 2), dtype=torch.int64, device="cuda")
-        ctx.device_clocks(clk[0])
+        clk = torch.zeros((2, 8, 2), dtype=torch.int64, device="cuda")
+        ctx.device_clocks_xcd(clk[0])
         for _ in range(min(args.steps, 20)):
             job.step()
-        ctx.device_clocks(clk[1])
+        ctx.device_clocks_xcd(clk[1])
         torch.cuda.synchronize()
         ck = clk.cpu().numpy().astype(np.float64)
-        global SHADER_CLOCK_GHZ
-        SHADER_CLOCK_GHZ = round(float((ck[1, 0] - ck[0, 0]) / max(ck[1, 1] - ck[0, 1], 1.0) * 0.1), 3)
+        global SHADER_CLOCK_GHZ, SHADER_CLOCK_XCD
+        ok = (ck[0, :, 1] > 0) & (ck[1, :, 1] > ck[0, :, 1])   # XCDs both samples reached
+        per = (ck[1, :, 0] - ck[0, :, 0]) / np.maximum(ck[1, :, 1] - ck[0, :, 1], 1.0) * 0.1
+        if ok.any():
+            SHADER_CLOCK_GHZ = round(float(np.median(per[ok])), 3)   # the median: single XCDs read 1.5 or 2.9 GHz over 160 ms (their counters stop and catch up)
+            SHADER_CLOCK_XCD = [round(float(v), 3) if o else None for v, o in zip(per, ok)]
     if gpu:
         ctx.profile(False)
     return dt
@@ -1457,7 +1462,7 @@ def full_epoch(ctx, args, rank):
     job.red.zero()
     n_steps = ing.walker.batches_per_epoch()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(n_steps + 1)]
-    clk = torch.zeros((4, 2), dtype=torch.int64, device="cuda")
+    clk = torch.zeros((4, 8, 2), dtype=torch.int64, device="cuda")
     marks = {8: 0, min(n_steps - 1, 70): 1, max(9, n_steps - 70): 2, n_steps - 1: 3}   # ~1 s apart at ~14 ms per step
     ctx.profile(False)
     torch.cuda.synchronize()
@@ -1467,7 +1472,7 @@ def full_epoch(ctx, args, rank):
         job.step()
         ev[s_ + 1].record()
         if s_ in marks:
-            ctx.device_clocks(clk[marks[s_]])
+            ctx.device_clocks_xcd(clk[marks[s_]])
     job.epoch_reduce(1)
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
@@ -1478,7 +1483,10 @@ def full_epoch(ctx, args, rank):
     first = t_ms <= 1000.0
     last = t_ms > t_ms[-1] - 1000.0
     ck = clk.cpu().numpy().astype(np.float64)
-    ghz = lambda i, j: round(float((ck[j, 0] - ck[i, 0]) / max(ck[j, 1] - ck[i, 1], 1.0) * 0.1), 3)   # ticks per 10 ns -> GHz
+    def ghz(i, j):   # ticks per 10 ns -> GHz, median over the XCDs both samples reached
+        ok = (ck[i, :, 1] > 0) & (ck[j, :, 1] > ck[i, :, 1])
+        per = (ck[j, :, 0] - ck[i, :, 0]) / np.maximum(ck[j, :, 1] - ck[i, :, 1], 1.0) * 0.1
+        return round(float(np.median(per[ok])), 3) if ok.any() else None
     return dict(value=round(total_frames / wall, 1), unit="frames/s", wall_s=round(wall, 3), steps=n_steps, utterances=int(sum(real)),
                 frames=int(total_frames), audio_hours=round(audio_s / 3600.0, 2), rtf=round(wall / audio_s, 8),
                 rtf_definition="wall time / audio time (Speech/CorpusProcessor.cc:49-58); 1 / rtf = %.0f x real time" % (audio_s / wall),
@@ -1487,7 +1495,7 @@ def full_epoch(ctx, args, rank):
                 frames_per_s_last_second=round(float(frames[last].sum()) / ((float(t_ms[-1]) - float(t_ms[~last][-1] if (~last).any() else 0.0)) * 1e-3), 1),
                 ms_per_step_first_20=round(float(t_ms[19] / 20.0), 4), ms_per_step_last_20=round(float((t_ms[-2] - t_ms[-22]) / 20.0), 4),
                 shader_clock_GHz=dict(first_second=ghz(0, 1), last_second=ghz(2, 3), whole_epoch=ghz(0, 3),
-                                      how="s_memtime ticks / s_memrealtime ticks (100 MHz) between two one-wave kernels in stream order"),
+                                      how="s_memtime ticks / s_memrealtime ticks (100 MHz) between two samples in stream order, median over the eight XCDs"),
                 ingest=ing.report(), epoch_reduce=dict(collectives=1, bytes=job.red.nbytes()),
                 workload=WORKLOAD_NAMES["pipeline"](a), contract=args.contract, precision=args.precision)
 
@@ -1630,10 +1638,11 @@ def main():
         if line["roofline"] and SHADER_CLOCK_GHZ:
             r = line["roofline"]
             r["shader_clock_GHz"] = SHADER_CLOCK_GHZ
+            r["shader_clock_GHz_per_xcd"] = SHADER_CLOCK_XCD
             if r.get("bound") == "mfma":
                 r["peak_at_shader_clock"] = round(r["peak"] * SHADER_CLOCK_GHZ / 2.4, 1)
                 r["frac_at_shader_clock"] = round(r["achieved"] / (r["peak"] * SHADER_CLOCK_GHZ / 2.4), 4)
-            r["clock_note"] = ("mean sclk of the per-launch timed pass (s_memtime / s_memrealtime).  `peak` is priced at the 2.4 GHz ceiling; the NN "
+            r["clock_note"] = ("median over the eight XCDs of the per-launch timed pass (s_memtime / s_memrealtime sampled on every XCD in front of and behind it).  `peak` is priced at the 2.4 GHz ceiling; the NN "
                                "GEMMs run at the package's 1400 W power cap, where the firmware holds sclk at 1.85-2.1 GHz whatever the kernel "
                                "does per cycle (profiles/r05/power_probe.log: rocm-smi power and sclk sampled during each workload)")
         line["stages"] = job.stage_report()

@@ -613,6 +613,10 @@ int  amx_gather_scores(amx_ctx* ctx, const float* scores_dev, int n_rows, int ld
  * order.  Two samples around a stretch of work give the shader clock the chip sustained over it (delta ticks / delta 10 ns units); the
  * epoch run of bench.py prints it next to the real-time factor (Speech/CorpusProcessor.cc:49-58: wall time / audio time). */
 int  amx_device_clocks_dev(amx_ctx* ctx, unsigned long long* out_dev);
+/* The same per XCD: out_dev[2 x] / [2 x + 1] = (s_memtime, s_memrealtime) sampled on XCD x (eight one-wave workgroups, each filed under the
+ * XCC id it reads; out_dev holds 16 values, zeroed by the caller -- an XCD no workgroup reached keeps its zeros).  The eight XCDs are
+ * clocked separately: under the NN GEMMs, at the package's power cap, they differ by a few per cent (bench.py: roofline.shader_clock_GHz). */
+int  amx_device_clocks_xcd_dev(amx_ctx* ctx, unsigned long long* out_dev);
 
 /* ------------------------------------------------------------------ feature caches */
 

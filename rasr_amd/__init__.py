@@ -163,6 +163,10 @@ class Context:
         """enqueue a sample of (s_memtime, s_memrealtime) into out_dev (2 x int64 / uint64 on the device)"""
         _lib.check(self.L.amx_device_clocks_dev(self.h, _ptr(out_dev)))
 
+    def device_clocks_xcd(self, out_dev):
+        """the same per XCD: out_dev [8 x 2] int64 / uint64 on the device, zeroed by the caller"""
+        _lib.check(self.L.amx_device_clocks_xcd_dev(self.h, _ptr(out_dev)))
+
     def profile_get(self, kernel):
         ms, n = C.c_double(), C.c_long()
         _lib.check(self.L.amx_profile_get(self.h, kernel.encode(), C.byref(ms), C.byref(n)))

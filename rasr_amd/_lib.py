@@ -154,6 +154,7 @@ SIGNATURES = {
     "amx_ffnn_score": (C.c_int, [_P, _P, C.c_int, _P]),
     "amx_ffnn_score_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
     "amx_device_clocks_dev": (C.c_int, [_P, _P]),
+    "amx_device_clocks_xcd_dev": (C.c_int, [_P, _P]),
     "amx_ffnn_wait_dev": (C.c_int, [_P]),
     "amx_ffnn_precision": (C.c_int, [_P, C.POINTER(C.c_double)]),
     "amx_ffnn_score_stats_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P, _P]),

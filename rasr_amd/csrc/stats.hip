@@ -208,7 +208,24 @@ __global__ void device_clocks_kernel(unsigned long long* __restrict__ out) {
         out[1] = __builtin_amdgcn_s_memrealtime();  // constant 100 MHz counter
     }
 }
+// one workgroup per XCD (block b of a grid runs on XCD b % 8 -- observed, and not relied on: every block files its sample under the
+// XCC id it reads from the hardware register; an XCD no block reached keeps its zeros).  The eight XCDs have a clock each.
+__global__ void device_clocks_xcd_kernel(unsigned long long* __restrict__ out) {
+    if (threadIdx.x == 0) {
+        const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;  // HW_REG_XCC_ID
+        out[2 * xcc]     = __builtin_amdgcn_s_memtime();
+        out[2 * xcc + 1] = __builtin_amdgcn_s_memrealtime();
+    }
+}
 }  // namespace amx
+
+extern "C" int amx_device_clocks_xcd_dev(amx_ctx* ctx, unsigned long long* out_dev) {
+    AMX_REQUIRE(ctx && out_dev, AMX_ERR_INVALID, "amx_device_clocks_xcd_dev: NULL argument");
+    AMX_HIP(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(amx::device_clocks_xcd_kernel, dim3(8), dim3(64), 0, ctx->stream, out_dev);
+    AMX_HIP(hipGetLastError());
+    return AMX_OK;
+}
 
 extern "C" int amx_device_clocks_dev(amx_ctx* ctx, unsigned long long* out_dev) {
     AMX_REQUIRE(ctx && out_dev, AMX_ERR_INVALID, "amx_device_clocks_dev: NULL argument");
