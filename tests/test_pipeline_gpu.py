@@ -189,3 +189,27 @@ def test_streamed_ingest_delivers_the_partitions_utterances_bit_for_bit(ctx):
         seen[rank] = np.concatenate(ing.visited)
         assert len(np.unique(seen[rank])) == len(seen[rank]) == 9 * args.utterances
     assert not set(seen[0].tolist()) & set(seen[1].tolist())
+
+
+def test_device_clock_samples(ctx):
+    """measurement entry points (bench.py's shader clock): two samples in stream order are ordered in both counters; the per-XCD form
+    reaches the eight XCDs and files every sample under the XCC id it read (amx_device_clocks_dev / amx_device_clocks_xcd_dev)"""
+    import torch
+    ctx.use_torch_stream()
+    one = torch.zeros((2, 2), dtype=torch.int64, device="cuda")
+    xcd = torch.zeros((2, 8, 2), dtype=torch.int64, device="cuda")
+    ctx.device_clocks(one[0])
+    ctx.device_clocks_xcd(xcd[0])
+    a = torch.randn((2048, 2048), device="cuda")
+    for _ in range(20):
+        a = (a @ a).clamp_(-1, 1)   # a few milliseconds of work between the samples
+    ctx.device_clocks(one[1])
+    ctx.device_clocks_xcd(xcd[1])
+    torch.cuda.synchronize()
+    o, x = one.cpu().numpy(), xcd.cpu().numpy()
+    assert (o[1] > o[0]).all()
+    reached = (x[0, :, 1] > 0) & (x[1, :, 1] > 0)
+    assert reached.sum() >= 4, x          # placement is not promised; eight of eight observed
+    assert (x[1][reached] > x[0][reached]).all()
+    ghz = (x[1, :, 0] - x[0, :, 0])[reached] / (x[1, :, 1] - x[0, :, 1])[reached] * 0.1
+    assert ((ghz > 0.05) & (ghz < 4.0)).all(), ghz

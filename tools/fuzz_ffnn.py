@@ -74,7 +74,7 @@ for case in range(n_cases):
         print("MISMATCH bf16x3 vs fp32", dims, T, err3)
     # ---- f16 + MX-fp6 (AMX_PREC_F16MX): its three tile configurations bit-identical among themselves, the split-bf16 bar against fp32
     mx = {}
-    for cfg in ("auto", "0", "2", "3", "8"):   # 8: the 256 x 256 tile's ping-pong K loop (round 5; "auto" picks it for large batches)
+    for cfg in ("auto", "0", "2", "3", "8", "9"):   # 8: the 256 x 256 tile's ping-pong K loop (round 5; "auto" picks it for large batches); 9: one self-pipelined wave per SIMD
         nn = rasr_amd.NnBatchFeatureScorer(ctx, Ws, bs, acts, log_prior=logp, priori_scale=1.0, precision="f16mx",
                                            tuning=None if cfg == "auto" else "tile=" + cfg)
         s = torch.empty((T, dims[-1]), dtype=torch.float32, device="cuda")
