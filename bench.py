@@ -1285,6 +1285,61 @@ def reset_survivor_counters(job):
 
 SHADER_CLOCK_GHZ = None   # set by measure(): median shader clock of the eight XCDs over the second (per-launch timed) pass
 SHADER_CLOCK_XCD = None
+HWMON = None              # set by measure(): the driver's own sclk / socket power (rocm-smi) over a stretch of the same steps
+
+
+class SmiSampler:
+    """sclk and socket power as `rocm-smi --showpower --showclocks` reports them (the driver's gpu_metrics table), polled from a thread
+    while a stretch of work runs -- one call takes a few hundred milliseconds, so the stretch has to last seconds.  (The hwmon files
+    freq1_input / power1_input of this driver lag by seconds: 0.11 GHz / 241 W in the middle of a pass that rocm-smi puts at 1.95 GHz /
+    1350 W.)  Host-side only: nothing is enqueued on the device.  Best effort -- no rocm-smi, no entry in the line."""
+
+    def __init__(self, local_rank=0):
+        import shutil
+        self.exe = shutil.which("rocm-smi") or ("/opt/rocm/bin/rocm-smi" if os.path.exists("/opt/rocm/bin/rocm-smi") else None)
+        self.gpu, self.f, self.p, self.stop, self.th = "GPU[%d]" % local_rank, [], [], False, None
+
+    def _run(self):
+        import re
+        import subprocess
+        while not self.stop:
+            try:
+                out = subprocess.run([self.exe, "--showpower", "--showclocks"], capture_output=True, text=True, timeout=10).stdout
+                f = p = None
+                for ln in out.splitlines():
+                    if not ln.startswith(self.gpu):
+                        continue
+                    m = re.search(r"sclk clock level:.*\((\d+)Mhz\)", ln)
+                    if m:
+                        f = int(m.group(1))
+                    m = re.search(r"Power \(W\):\s*([\d.]+)", ln)
+                    if m:
+                        p = float(m.group(1))
+                if f is not None and p is not None:
+                    self.f.append(f)
+                    self.p.append(p)
+            except Exception:
+                time.sleep(0.2)
+
+    def __enter__(self):
+        if self.exe:
+            import threading
+            self.th = threading.Thread(target=self._run, daemon=True)
+            self.th.start()
+        return self
+
+    def __exit__(self, *a):
+        self.stop = True
+        if self.th:
+            self.th.join()
+
+    def report(self, what):
+        f, p = self.f[1:], self.p[1:]   # the first sample may predate the load
+        if not f:
+            return None
+        return dict(sclk_GHz=round(float(np.mean(f)) / 1e3, 3), sclk_GHz_min_max=[round(min(f) / 1e3, 3), round(max(f) / 1e3, 3)],
+                    socket_power_W=round(float(np.mean(p)), 1), power_cap_W=1400.0, samples=len(f),
+                    source="rocm-smi --showpower --showclocks, back to back during " + what)
 
 
 def measure(ctx, job, args, world):
@@ -1328,6 +1383,22 @@ def measure(ctx, job, args, world):
             SHADER_CLOCK_XCD = [round(float(v), 3) if o else None for v, o in zip(per, ok)]
     if gpu:
         ctx.profile(False)
+        if world == 1 and os.environ.get("AMX_BENCH_NO_SMI", "0") in ("", "0"):
+            # a third stretch of the same steps, ~2.5 s, with rocm-smi polled beside it: the clock and the socket power the workload
+            # settles at (the timed region and the per-launch pass are too short for a tool that takes 0.3 s per reading)
+            import torch
+            global HWMON
+            n = 0
+            t1 = time.perf_counter()
+            with SmiSampler(int(os.environ.get("LOCAL_RANK", "0"))) as smi:
+                if smi.exe:
+                    while time.perf_counter() - t1 < 2.5:
+                        job.step()
+                        n += 1
+                        if n % 8 == 0:
+                            torch.cuda.synchronize()   # keep the host at most a few steps ahead: the stretch ends when the clock says so
+                    torch.cuda.synchronize()
+            HWMON = smi.report("%d more steps of the same workload (%.1f s) behind the timed region" % (n, time.perf_counter() - t1))
     return dt
 
 
@@ -1468,14 +1539,15 @@ def full_epoch(ctx, args, rank):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     ev[0].record()
-    for s_ in range(n_steps):
-        job.step()
-        ev[s_ + 1].record()
-        if s_ in marks:
-            ctx.device_clocks_xcd(clk[marks[s_]])
-    job.epoch_reduce(1)
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
+    with SmiSampler(int(os.environ.get("LOCAL_RANK", "0"))) as hw:
+        for s_ in range(n_steps):
+            job.step()
+            ev[s_ + 1].record()
+            if s_ in marks:
+                ctx.device_clocks_xcd(clk[marks[s_]])
+        job.epoch_reduce(1)
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
     t_ms = np.array([ev[0].elapsed_time(e) for e in ev[1:]])          # completion time of every step on the device
     real = [len(v) for v in ing.visited[:n_steps]]                    # utterances of the corpus in each batch (the last one is short)
     frames = np.array([u * (job.F // a.utterances) for u in real], np.float64)
@@ -1496,7 +1568,7 @@ def full_epoch(ctx, args, rank):
                 ms_per_step_first_20=round(float(t_ms[19] / 20.0), 4), ms_per_step_last_20=round(float((t_ms[-2] - t_ms[-22]) / 20.0), 4),
                 shader_clock_GHz=dict(first_second=ghz(0, 1), last_second=ghz(2, 3), whole_epoch=ghz(0, 3),
                                       how="s_memtime ticks / s_memrealtime ticks (100 MHz) between two samples in stream order, median over the eight XCDs"),
-                ingest=ing.report(), epoch_reduce=dict(collectives=1, bytes=job.red.nbytes()),
+                hwmon=hw.report("the epoch"), ingest=ing.report(), epoch_reduce=dict(collectives=1, bytes=job.red.nbytes()),
                 workload=WORKLOAD_NAMES["pipeline"](a), contract=args.contract, precision=args.precision)
 
 
@@ -1635,14 +1707,21 @@ def main():
         line["roofline"] = job.roofline()
         if line["roofline"] and line["roofline"].get("traffic") is not None:
             line["roofline"]["traffic_source"] = TRAFFIC_SOURCE + " (offline rocprofv3 --pmc passes on the profiling box, not this run)"
-        if line["roofline"] and SHADER_CLOCK_GHZ:
+        if line["roofline"] and (SHADER_CLOCK_GHZ or HWMON):
             r = line["roofline"]
-            r["shader_clock_GHz"] = SHADER_CLOCK_GHZ
-            r["shader_clock_GHz_per_xcd"] = SHADER_CLOCK_XCD
+            # the driver's figure where it exists; the counters' otherwise (s_memtime is a counter per CU, the CUs' counters are not
+            # aligned: between two short samples on different CUs of an XCD the difference is off by their offset -- single XCDs read 1.5
+            # or 2.9 GHz over 160 ms, one even ran backwards; over the seconds of the full-epoch run the offset is 0.1 %)
+            sclk = HWMON["sclk_GHz"] if HWMON else SHADER_CLOCK_GHZ
+            r["shader_clock_GHz"] = sclk
+            if HWMON:
+                r["hwmon"] = HWMON
+            r["shader_clock_GHz_s_memtime"] = dict(median_of_xcds=SHADER_CLOCK_GHZ, per_xcd=SHADER_CLOCK_XCD)
+            SHADER = sclk
             if r.get("bound") == "mfma":
-                r["peak_at_shader_clock"] = round(r["peak"] * SHADER_CLOCK_GHZ / 2.4, 1)
-                r["frac_at_shader_clock"] = round(r["achieved"] / (r["peak"] * SHADER_CLOCK_GHZ / 2.4), 4)
-            r["clock_note"] = ("median over the eight XCDs of the per-launch timed pass (s_memtime / s_memrealtime sampled on every XCD in front of and behind it).  `peak` is priced at the 2.4 GHz ceiling; the NN "
+                r["peak_at_shader_clock"] = round(r["peak"] * SHADER / 2.4, 1)
+                r["frac_at_shader_clock"] = round(r["achieved"] / (r["peak"] * SHADER / 2.4), 4)
+            r["clock_note"] = ("mean sclk as the driver reports it (rocm-smi, over seconds of the same steps; the s_memtime / s_memrealtime deltas of the per-launch pass beside it).  `peak` is priced at the 2.4 GHz ceiling; the NN "
                                "GEMMs run at the package's 1400 W power cap, where the firmware holds sclk at 1.85-2.1 GHz whatever the kernel "
                                "does per cycle (profiles/r05/power_probe.log: rocm-smi power and sclk sampled during each workload)")
         line["stages"] = job.stage_report()

@@ -615,7 +615,9 @@ int  amx_gather_scores(amx_ctx* ctx, const float* scores_dev, int n_rows, int ld
 int  amx_device_clocks_dev(amx_ctx* ctx, unsigned long long* out_dev);
 /* The same per XCD: out_dev[2 x] / [2 x + 1] = (s_memtime, s_memrealtime) sampled on XCD x (eight one-wave workgroups, each filed under the
  * XCC id it reads; out_dev holds 16 values, zeroed by the caller -- an XCD no workgroup reached keeps its zeros).  The eight XCDs are
- * clocked separately: under the NN GEMMs, at the package's power cap, they differ by a few per cent (bench.py: roofline.shader_clock_GHz). */
+ * clocked separately.  s_memtime counts per CU and the CUs' counters are not aligned with one another: a difference of two samples is off by
+ * the offset of the two CUs that took them (milliseconds' worth of ticks) -- meaningful over seconds (bench.py's full-epoch line), not over
+ * one pass; s_memrealtime is one counter for the chip. */
 int  amx_device_clocks_xcd_dev(amx_ctx* ctx, unsigned long long* out_dev);
 
 /* ------------------------------------------------------------------ feature caches */

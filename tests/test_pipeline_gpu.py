@@ -210,6 +210,8 @@ def test_device_clock_samples(ctx):
     assert (o[1] > o[0]).all()
     reached = (x[0, :, 1] > 0) & (x[1, :, 1] > 0)
     assert reached.sum() >= 4, x          # placement is not promised; eight of eight observed
-    assert (x[1][reached] > x[0][reached]).all()
-    ghz = (x[1, :, 0] - x[0, :, 0])[reached] / (x[1, :, 1] - x[0, :, 1])[reached] * 0.1
-    assert ((ghz > 0.05) & (ghz < 4.0)).all(), ghz
+    assert (x[1, :, 1][reached] > x[0, :, 1][reached]).all()   # the 100 MHz counter is one clock for the chip: ordered
+    # s_memtime is a counter per CU and the CUs' counters are not aligned: two samples on different CUs of an XCD differ by their
+    # offset as well (seen: a "negative" interval over a few milliseconds).  Only the single-workgroup form, which lands on the same CU
+    # of an idle chip, is held to an order here; bench.py uses the deltas over seconds and the driver's hwmon figure for short passes.
+    assert (x[:, :, 0][:, reached] > 0).all()
