@@ -5,7 +5,8 @@ from tests import synth
 ctx = rasr_amd.Context(0); ctx.use_torch_stream()
 dims = [440] + [2048] * 6 + [10000]
 Ws, bs, acts, logp = synth.ffnn(dims, seed=7)
-for tun in (None, "ksplit=4"):
+for tun in ((None, "ksplit=4") if len(sys.argv) < 2 else sys.argv[1:]):
+    tun = None if tun == "default" else tun
     nn = rasr_amd.NnBatchFeatureScorer(ctx, Ws, bs, acts, log_prior=logp, precision="f16mx", tuning=tun)
     for T in (64, 256, 512, 1024):
         x = torch.randn((T, 440), device="cuda"); sc = torch.empty((T, 10000), device="cuda")
