@@ -14,13 +14,14 @@ root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/$round
 mkdir -p $out/pmc
 cd /tmp && export TMPDIR=/tmp
+# (AMX_BENCH_NO_SMI=1 under the profiler: bench.py's 2.5 s rocm-smi stretch behind the timed region would only add launches to the traces)
 only() { [ -z "$ONLY" ] || [[ "$1" =~ $ONLY ]]; }  # ONLY=<regex>: just the workloads whose name matches (and none of the suites)
 run_stats() {  # name, bench args...
     only $1 || return 0
     name=$1; shift
     python $root/bench.py "$@" 2>/dev/null | tail -1 > $out/${name}_bench.log
     rm -rf /tmp/prof_$name
-    rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$name -- python $root/bench.py "$@" --no-cpu-baseline --no-configs > /tmp/prof_$name.log 2>&1
+    AMX_BENCH_NO_SMI=1 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$name -- python $root/bench.py "$@" --no-cpu-baseline --no-configs > /tmp/prof_$name.log 2>&1
     f=$(find /tmp/prof_$name -name "*kernel_stats.csv" | head -1)
     [ -n "$f" ] && cp $f $out/${name}_kernel_stats.csv
 }
@@ -31,7 +32,7 @@ run_pmc() {  # name, suffix, counters..., -- bench args...
     while [ "$1" != "--" ]; do ctrs+=("$1"); shift; done
     shift
     rm -rf /tmp/pmc_${name}_$suf
-    timeout 300 rocprofv3 --kernel-trace --pmc "${ctrs[@]}" --output-format csv -d /tmp/pmc_${name}_$suf -- python $root/bench.py "$@" --no-cpu-baseline --no-configs > /tmp/pmc_${name}_$suf.log 2>&1
+    AMX_BENCH_NO_SMI=1 timeout 300 rocprofv3 --kernel-trace --pmc "${ctrs[@]}" --output-format csv -d /tmp/pmc_${name}_$suf -- python $root/bench.py "$@" --no-cpu-baseline --no-configs > /tmp/pmc_${name}_$suf.log 2>&1
     f=$(find /tmp/pmc_${name}_$suf -name "*counter_collection.csv" | head -1)
     [ -n "$f" ] && python $root/tools/pmc_summary.py $f > $out/pmc/${name}_$suf.txt
 }
