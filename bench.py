@@ -1559,6 +1559,11 @@ def full_epoch(ctx, args, rank):
         ok = (ck[i, :, 1] > 0) & (ck[j, :, 1] > ck[i, :, 1])
         per = (ck[j, :, 0] - ck[i, :, 0]) / np.maximum(ck[j, :, 1] - ck[i, :, 1], 1.0) * 0.1
         return round(float(np.median(per[ok])), 3) if ok.any() else None
+
+    def ghz_xcd(i, j):   # the same per XCD (over seconds the offset between the CUs that took the samples is below 0.1 %)
+        ok = (ck[i, :, 1] > 0) & (ck[j, :, 1] > ck[i, :, 1])
+        per = (ck[j, :, 0] - ck[i, :, 0]) / np.maximum(ck[j, :, 1] - ck[i, :, 1], 1.0) * 0.1
+        return [round(float(v), 3) if o else None for v, o in zip(per, ok)]
     return dict(value=round(total_frames / wall, 1), unit="frames/s", wall_s=round(wall, 3), steps=n_steps, utterances=int(sum(real)),
                 frames=int(total_frames), audio_hours=round(audio_s / 3600.0, 2), rtf=round(wall / audio_s, 8),
                 rtf_definition="wall time / audio time (Speech/CorpusProcessor.cc:49-58); 1 / rtf = %.0f x real time" % (audio_s / wall),
@@ -1566,7 +1571,7 @@ def full_epoch(ctx, args, rank):
                 frames_per_s_first_second=round(float(frames[first].sum()) / (float(t_ms[first][-1]) * 1e-3), 1) if first.any() else None,
                 frames_per_s_last_second=round(float(frames[last].sum()) / ((float(t_ms[-1]) - float(t_ms[~last][-1] if (~last).any() else 0.0)) * 1e-3), 1),
                 ms_per_step_first_20=round(float(t_ms[19] / 20.0), 4), ms_per_step_last_20=round(float((t_ms[-2] - t_ms[-22]) / 20.0), 4),
-                shader_clock_GHz=dict(first_second=ghz(0, 1), last_second=ghz(2, 3), whole_epoch=ghz(0, 3),
+                shader_clock_GHz=dict(first_second=ghz(0, 1), last_second=ghz(2, 3), whole_epoch=ghz(0, 3), whole_epoch_per_xcd=ghz_xcd(0, 3),
                                       how="s_memtime ticks / s_memrealtime ticks (100 MHz) between two samples in stream order, median over the eight XCDs"),
                 hwmon=hw.report("the epoch"), ingest=ing.report(), epoch_reduce=dict(collectives=1, bytes=job.red.nbytes()),
                 workload=WORKLOAD_NAMES["pipeline"](a), contract=args.contract, precision=args.precision)
