@@ -1342,6 +1342,27 @@ class SmiSampler:
                     source="rocm-smi --showpower --showclocks, back to back during " + what)
 
 
+def smi_stretch(job):
+    """~2.5 s more of the same steps with rocm-smi polled beside them: the clock and the socket power the workload settles at (the
+    timed region and the per-launch pass are too short for a tool that takes 0.1-0.3 s per reading).  Called AFTER the roofline and the
+    stage report have been read: the device-side survivor counters keep counting here."""
+    import torch
+    global HWMON
+    if os.environ.get("AMX_BENCH_NO_SMI", "0") not in ("", "0"):
+        return
+    n = 0
+    t1 = time.perf_counter()
+    with SmiSampler(int(os.environ.get("LOCAL_RANK", "0"))) as smi:
+        if smi.exe:
+            while time.perf_counter() - t1 < 2.5:
+                job.step()
+                n += 1
+                if n % 8 == 0:
+                    torch.cuda.synchronize()   # keep the host at most a few steps ahead: the stretch ends when the clock says so
+            torch.cuda.synchronize()
+    HWMON = smi.report("%d more steps of the same workload (%.1f s) behind the timed region" % (n, time.perf_counter() - t1))
+
+
 def measure(ctx, job, args, world):
     """W untimed steps, then exactly K steps + the epoch reduce between barrier + synchronize; returns seconds"""
     gpu = ctx is not None
@@ -1379,26 +1400,10 @@ def measure(ctx, job, args, world):
         ok = (ck[0, :, 1] > 0) & (ck[1, :, 1] > ck[0, :, 1])   # XCDs both samples reached
         per = (ck[1, :, 0] - ck[0, :, 0]) / np.maximum(ck[1, :, 1] - ck[0, :, 1], 1.0) * 0.1
         if ok.any():
-            SHADER_CLOCK_GHZ = round(float(np.median(per[ok])), 3)   # the median: single XCDs read 1.5 or 2.9 GHz over 160 ms (their counters stop and catch up)
+            SHADER_CLOCK_GHZ = round(float(np.median(per[ok])), 3)   # the median: single XCDs read 1.5 or 2.9 GHz over 160 ms (s_memtime counts per CU, unaligned)
             SHADER_CLOCK_XCD = [round(float(v), 3) if o else None for v, o in zip(per, ok)]
     if gpu:
         ctx.profile(False)
-        if world == 1 and os.environ.get("AMX_BENCH_NO_SMI", "0") in ("", "0"):
-            # a third stretch of the same steps, ~2.5 s, with rocm-smi polled beside it: the clock and the socket power the workload
-            # settles at (the timed region and the per-launch pass are too short for a tool that takes 0.3 s per reading)
-            import torch
-            global HWMON
-            n = 0
-            t1 = time.perf_counter()
-            with SmiSampler(int(os.environ.get("LOCAL_RANK", "0"))) as smi:
-                if smi.exe:
-                    while time.perf_counter() - t1 < 2.5:
-                        job.step()
-                        n += 1
-                        if n % 8 == 0:
-                            torch.cuda.synchronize()   # keep the host at most a few steps ahead: the stretch ends when the clock says so
-                    torch.cuda.synchronize()
-            HWMON = smi.report("%d more steps of the same workload (%.1f s) behind the timed region" % (n, time.perf_counter() - t1))
     return dt
 
 
@@ -1712,6 +1717,13 @@ def main():
         line["roofline"] = job.roofline()
         if line["roofline"] and line["roofline"].get("traffic") is not None:
             line["roofline"]["traffic_source"] = TRAFFIC_SOURCE + " (offline rocprofv3 --pmc passes on the profiling box, not this run)"
+        line["stages"] = job.stage_report()
+        if world == 1:
+            try:
+                with torch.cuda.stream(stream):
+                    smi_stretch(job)
+            except Exception:  # never take the headline down
+                pass
         if line["roofline"] and (SHADER_CLOCK_GHZ or HWMON):
             r = line["roofline"]
             # the driver's figure where it exists; the counters' otherwise (s_memtime is a counter per CU, the CUs' counters are not
@@ -1729,7 +1741,6 @@ def main():
             r["clock_note"] = ("mean sclk as the driver reports it (rocm-smi, over seconds of the same steps; the s_memtime / s_memrealtime deltas of the per-launch pass beside it).  `peak` is priced at the 2.4 GHz ceiling; the NN "
                                "GEMMs run at the package's 1400 W power cap, where the firmware holds sclk at 1.85-2.1 GHz whatever the kernel "
                                "does per cycle (profiles/r05/power_probe.log: rocm-smi power and sclk sampled during each workload)")
-        line["stages"] = job.stage_report()
         if getattr(job, "ingest", None) is not None:
             line["ingest"] = job.ingest.report()
         elif hasattr(job, "setup_ingest") and getattr(job, "pcm", None) is not None and world == 1:
