@@ -1712,6 +1712,10 @@ void launch_mx(amx_ffnn* h, int l, const void* x, int xkts, void* out, int ldo, 
     else if (dbg == 2048 && ACT == AMX_ACT_RELU * (LAST ? 0 : 1)) {
         AMX_MX_LAUNCH(2048);  // time stamps of any tile configuration (tools/mx_timeline.py small)
     }
+    else if (dbg == 128 && C::PIPE == 1 && ACT == AMX_ACT_RELU * (LAST ? 0 : 1)) {
+        if constexpr (C::PIPE == 1)
+            AMX_MX_LAUNCH(128);  // the ping-pong tile without conversions and lane swaps (timing only: what a q that travels with the operands would save)
+    }
     else
         dbg = 0;
 #endif

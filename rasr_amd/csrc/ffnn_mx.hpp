@@ -947,7 +947,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const char* __restr
                 iteration(kt, std::false_type{});
         }
         else if constexpr (C::PIPE > 0) {
-            static_assert(DBG == 0 || DBG == 2048, "the ping-pong K loop has no ablation variants");
+            static_assert(DBG == 0 || DBG == 2048 || DBG == 128, "the ping-pong K loop: time stamps, and the no-conversion ablation (lab builds)");
             const bool second = wave >= C::NW / 2;  // the group that runs half a period behind (waves 4-7: the partners of waves 0-3)
             auto await_tile = [&](int ahead_tiles, int max_ahead) {  // own pieces of a K-tile have landed; `ahead_tiles` younger K-tiles may stay in flight
                 if (!issuer)
