@@ -126,6 +126,9 @@ def Oracle(contract=None):
     L.orc_gmm_distance.argtypes = [f32p, f32p, f32p, C.c_int]
     L.orc_filter_apply.restype = C.c_float
     L.orc_filter_apply.argtypes = [f32p, C.c_int, C.c_int, f32p]
+    L.orc_hamming_window.argtypes = [f32p, C.c_int]
+    L.orc_batch_float_fill.restype = C.c_float
+    L.orc_batch_float_fill.argtypes = [f32p, f32p, C.c_int, f32p, C.c_int]
     L.orc_mfcc_create.restype = C.c_void_p
     L.orc_mfcc_create.argtypes = [C.POINTER(MfccCfg)]
     L.orc_mfcc_destroy.argtypes = [C.c_void_p]
@@ -239,6 +242,10 @@ def load_ref(contract="off"):
         R.ref_regression.argtypes = [C.c_int, f32p, C.c_int, C.c_int, f32p]
         R.ref_filter_apply.restype = C.c_float
         R.ref_filter_apply.argtypes = [f32p, C.c_int, C.c_int, C.c_int, f32p]
+    if hasattr(R, "ref_hamming_window"):
+        R.ref_hamming_window.restype = C.c_int
+        R.ref_hamming_window.argtypes = [C.c_int, f32p]
+        R.ref_batch_float_fill.argtypes = [f32p, f32p, C.c_int, f32p, C.c_int, C.c_int, f32p]
     _refs[contract] = R
     return R
 

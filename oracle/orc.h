@@ -18,15 +18,18 @@
  *                                   -ffp-contract=off in BOTH flavours, so the flavours differ at exactly those sites).
  * Which sites: read off the reference built both ways (oracle/ref/Makefile: libref.so / libref_native.so, objdump of the native
  * objects) -- the GMM distance's `sum += df * df` (vfmadd231ps / vfmadd231ss, function-text pin gdm_distance), the f32 dot product
- * of Math::Vector (cosine transform), gaussLogNormFactor's N * log(2 pi) + sum (f64).  Sites in translation units that cannot be
- * compiled here follow GCC's rule by reading (filter bank apply, batch-float accumulate, preemphasis, back-end sums) and say so.
+ * of Math::Vector (cosine transform), gaussLogNormFactor's N * log(2 pi) + sum (f64), the filter bank's apply, the regression
+ * sums and the batch-float scorer's SSE accumulate (function-text pins filter_apply, regression, batch_float_fill).  Sites in
+ * translation units that cannot be compiled here follow GCC's rule by reading (preemphasis, the other back-end sums) and say so.
  * NOT restated in fma form: the FFT's f64 twiddle recurrences (14 fused operations in the native object; the f32 results were
  * bit-identical to the plain build on every frame tried, tests/test_contract.py) and the f4 front ends / quantised scorers.
  *
  * Pinning status (see DESIGN.md "Oracle"):
  *   FFT core, framing/flush, mel warp/derivative/inverse, GMM logNorm / 1/sqrt(var):
  *       pinned bit-exactly against oracle/_ref (reference sources compiled unmodified).
- *   Hamming, filterbank geometry, DCT, GMM max score: pinned by the known answers the
+ *   Hamming table, GMM distance, filter apply, regression, batch-float sum / minimum: pinned bit-exactly on the reference's
+ *       own function text compiled with both flag sets (oracle/ref/extract_fn.py, tests/test_contract.py).
+ *   filterbank geometry, DCT, GMM max score (combine / tie rule): pinned by the known answers the
  *       reference produced in this container.
  *   NN forward: pinned by the reference's own unit-test vectors
  *       (Test/Nn_LinearAndActivationLayer.cc, Test/Nn_NeuralNetwork.cc).
@@ -167,6 +170,7 @@ int    orc_levinson(const float* R, int n, float* gain, float* a);
 /* Signal::autoregressionToCepstrum (Signal/AutoregressionToCepstrum.cc:21-35): c [nc], 2 <= nc <= na + 1 */
 void   orc_ar_to_cepstrum(float gain, const float* a, int na, float* c, int nc);
 void   orc_preemphasis(float* x, long n, float alpha);            /* in place, segment start */
+void   orc_hamming_window(float* w, int len); /* Signal/WindowFunction.cc:92-101: the table (len <= 1: zeros, the reference's init() fails) */
 float  orc_filter_apply(const float* in, int start, int end, const float* weights); /* one filter of the bank: sum over bins [start, end) */
 void   orc_fft_real(float* v, int n);                             /* Math::FastFourierTransform::transformReal */
 void   orc_fft_complex(float* v, int n_floats);                   /* ::transform (forward) */
@@ -209,6 +213,7 @@ int orc_gmm_score_preselection_float(const orc_gmm* h, const double* log_weight,
 int orc_gmm_score_preselection_int(const orc_gmm* h, const double* log_weight, const float* variances, const float* feats, int T,
                                    int n_clusters, int n_select, int iterations, float* scores, uint32_t* cluster_of_out,
                                    uint8_t* cluster_means_out, int* n_clusters_out);
+float orc_batch_float_fill(const float* ms, const float* cst, int nk, const float* xs, int pdim); /* fillScoreCacheTpl, one feature x one mixture */
 int orc_gmm_score_batch_float(const orc_gmm* h, const double* log_weight, const float* variances,
                               const float* feats, int T, float* scores);
 

@@ -219,7 +219,9 @@ int orc_core_is_significantly_greater(double a, double b, double tolerance) { re
 
 /* ------------------------------------------------------------------ table construction */
 
-/* Signal/WindowFunction.cc:92-101 (Hamming), symmetric fill, f64 -> f32 */
+/* Signal/WindowFunction.cc:92-101 (Hamming), symmetric fill, f64 -> f32.  PINNED on the reference's function text in both builds
+ * (oracle/ref/extract_fn.py hamming_window): the default build fuses 0.54 - 0.46 * cos() into one vfnmadd132sd, and the f32 table has
+ * the same bits for every length 2 .. 4096 -- no contract form needed here (tests/test_contract.py). */
 static void orc_build_hamming(float* w, int len) {
     if (len <= 1) {
         for (int i = 0; i < len; ++i)
@@ -233,6 +235,8 @@ static void orc_build_hamming(float* w, int len) {
         w[M - n] = c;
     }
 }
+
+void orc_hamming_window(float* w, int len) { orc_build_hamming(w, len); }
 
 /* Signal/Filterbank.cc:144-244 (filter builder, triangle), :246-275 (trapeze), :330-470 (boundaries: include-boundary),
  * :519-567 (stretch-to-cover), :575-595 (emphasize-boundary), :640-672 (FilterBank::init: with warp-center-positions = true, the

@@ -192,6 +192,34 @@ void orc_gmm_score(const orc_gmm* h, int mode, const float* feats, int T, float*
     free(sk);
 }
 
+/* Mm/BatchFeatureScorer.cc:207-253 (BatchFloatFeatureScorer::fillScoreCacheTpl) for ONE feature vector and one mixture: means ms
+ * [nk x pdim] and the feature xs [pdim] already multiplied by 1 / sigma, pdim a multiple of 8, constants cst [nk].  Two 4-lane
+ * accumulators over 8-wide blocks, lane 0 of the first starts at the constant; s1 + s2, then lanes (3 + 1) + (2 + 0); the score
+ * starts at FLT_MAX and takes _mm_min_ps(score, s) = (score < s ? score : s) per density -- a NaN sum REPLACES the score, a later finite
+ * one replaces the NaN --; 0.5 x where the result is below FLT_MAX.  The accumulate is `_mm_add_ps(s, _mm_mul_ps(x, x))`: vector
+ * arithmetic to GCC, fused in the reference's default build (two vfmadd in the loop).  PINNED on the reference's function text in both
+ * builds (oracle/ref/extract_fn.py batch_float_fill, tests/test_contract.py). */
+float orc_batch_float_fill(const float* ms, const float* cst, int nk, const float* xs, int pdim) {
+    float score = FLT_MAX;
+    for (int k = 0; k < nk; ++k) {
+        const float* mu    = ms + (size_t)k * pdim;
+        float        s1[4] = {cst[k], 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+        for (int d = 0; d < pdim; d += 8)
+            for (int j = 0; j < 4; ++j) {
+                float x1 = mu[d + j] - xs[d + j];
+                s1[j]    = ORC_FMAF(x1, x1, s1[j]);
+                float x2 = mu[d + 4 + j] - xs[d + 4 + j];
+                s2[j]    = ORC_FMAF(x2, x2, s2[j]);
+            }
+        float a0 = s1[0] + s2[0], a1 = s1[1] + s2[1], a2 = s1[2] + s2[2], a3 = s1[3] + s2[3];
+        float r = (a3 + a1) + (a2 + a0);
+        score   = score < r ? score : r; /* _mm_min_ps(score, r) */
+    }
+    if (score < FLT_MAX)
+        score = (float)(score * 0.5);
+    return score;
+}
+
 /* Mm/BatchFeatureScorer.cc:164-254 (BatchFloatFeatureScorer, "batch-diagonal-maximum-float",
  * pooled covariance only).  init(): means and features are multiplied by 1/sigma (f32), the
  * per-density constant is (f32)(logNorm - 2*logw) with the subtraction in f64 (no weight or
@@ -224,27 +252,9 @@ int orc_gmm_score_batch_float(const orc_gmm* h, const double* log_weight, const 
     for (int t = 0; t < T; ++t) {
         for (int i = 0; i < dim; ++i)
             xs[i] = feats[(size_t)t * dim + i] * isr[i];
-        for (int m = 0; m < h->n_mix; ++m) {
-            float best = FLT_MAX;
-            for (uint32_t k = h->mix_off[m]; k < h->mix_off[m + 1]; ++k) {
-                const float* mu    = ms + (size_t)k * pdim;
-                float        s1[4] = {cst[k], 0, 0, 0}, s2[4] = {0, 0, 0, 0};
-                for (int d = 0; d < pdim; d += 8)
-                    for (int j = 0; j < 4; ++j) {
-                        float x1 = mu[d + j] - xs[d + j];
-                        s1[j]    = ORC_FMAF(x1, x1, s1[j]); /* _mm_add_ps(s1, _mm_mul_ps(x1, x1)): contracted by rule (TU needs boost) */
-                        float x2 = mu[d + 4 + j] - xs[d + 4 + j];
-                        s2[j]    = ORC_FMAF(x2, x2, s2[j]);
-                    }
-                float a0 = s1[0] + s2[0], a1 = s1[1] + s2[1], a2 = s1[2] + s2[2], a3 = s1[3] + s2[3];
-                float r = (a3 + a1) + (a2 + a0);
-                if (r < best)
-                    best = r;
-            }
-            if (best < FLT_MAX)
-                best = (float)(best * 0.5);
-            scores[(size_t)t * h->n_mix + m] = best;
-        }
+        for (int m = 0; m < h->n_mix; ++m)
+            scores[(size_t)t * h->n_mix + m] = orc_batch_float_fill(ms + (size_t)h->mix_off[m] * pdim, cst + h->mix_off[m],
+                                                                    (int)(h->mix_off[m + 1] - h->mix_off[m]), xs, pdim);
     }
     free(isr);
     free(xs);
@@ -389,12 +399,11 @@ int orc_gmm_score_preselection_float(const orc_gmm* h, const double* log_weight,
                     }
                 float a0 = s1[0] + s2[0], a1 = s1[1] + s2[1], a2 = s1[2] + s2[2], a3 = s1[3] + s2[3];
                 float r = (a3 + a1) + (a2 + a0);
-                if (r < best)
-                    best = r;
+                best    = best < r ? best : r; /* _mm_min_ps(score, r): a NaN sum replaces the score (orc_batch_float_fill) */
             }
             if (best < FLT_MAX)
                 best = (float)(best * 0.5);
-            else
+            else if (best == FLT_MAX) /* Mm/BatchFeatureScorer.cc:310-314: `if (s == max) s = backoff` -- a NaN score stays NaN */
                 best = backoff;
             scores[(size_t)t * h->n_mix + m] = best;
         }

@@ -132,6 +132,112 @@ extern "C" float ref_filter_apply(const float* in, int n_in, int start, int end,
     return r;
 }
 """),
+    # Signal::HammingWindowFunction::init (SURVEY section 8 row a3): the window table, f64 arithmetic stored as f32.  The class
+    # declarations (Signal/WindowFunction.hh:30-110) need Core/Choice.hh / Core/Parameter.hh -> Core/Configuration.hh (boost); the shell
+    # declares the one data member and the base init() the text calls
+    "hamming_window": (
+        "Signal/WindowFunction.cc", [(92, 101)],
+        "38cb2b0dc246e453e25b34b27d9398b751d87b771d1a9ace61694dc9391033d8",
+        """#include <Core/Types.hh>
+#include <cmath>
+#include <vector>
+namespace Signal {
+// shell: Signal/WindowFunction.hh:30-56 (Float, window_, needInit_, init()) and the derived class's one member
+class WindowFunction {
+public:
+    typedef f32 Float;
+protected:
+    std::vector<Float> window_;
+    bool               needInit_;
+    virtual bool init() { return !(needInit_ = false); }
+public:
+    WindowFunction() : needInit_(true) {}
+    virtual ~WindowFunction() {}
+};
+class HammingWindowFunction : public WindowFunction {
+protected:
+    virtual bool init();
+public:
+    bool table(unsigned length, float* out) {
+        window_.assign(length, 0.f);
+        const bool ok = init();
+        for (unsigned i = 0; i < length; ++i)
+            out[i] = window_[i];
+        return ok;
+    }
+};
+}  // namespace Signal
+using namespace Signal;
+// ---- reference text, %(file)s:%(ranges)s ----
+""",
+        """
+// ---- end of reference text ----
+extern "C" int ref_hamming_window(int length, float* out) {
+    Signal::HammingWindowFunction w;
+    return w.table((unsigned)length, out) ? 0 : -1;
+}
+"""),
+    # Mm::BatchFloatFeatureScorer::fillScoreCacheTpl (SURVEY section 8 row a18, "batch-diagonal-maximum-float"): the SSE loop over the
+    # pre-scaled means and features, the horizontal sum, the minimum over the densities and the final 0.5.  The class declaration
+    # (Mm/BatchFeatureScorer.hh:105-260) is a FeatureScorer (Core/Component -> Core/Configuration.hh -> boost); the shell declares the
+    # members the text reads, with the reference's types (bufferSize_ is an s32 there)
+    "batch_float_fill": (
+        "Mm/BatchFeatureScorer.cc", [(207, 253)],
+        "94a3cac962622929f0eba5d4c32d819df2a4240fd652ebc3f7ca4c61cf63b34e",
+        """#include <Core/Types.hh>
+#include <Mm/Types.hh>
+#include <vector>
+#include <xmmintrin.h>
+namespace Mm {
+// shell: Mm/BatchFeatureScorer.hh:162-199,234-255
+class BatchFloatFeatureScorer {
+public:
+    struct AllDensitySelector {
+        bool operator()(size_t, size_t) const { return true; }
+    };
+    static const size_t         BlockSize;
+    std::vector<size_t>         offsets_;
+    mutable std::vector<bool>   cached_;
+    mutable f32*                scores_;
+    u32                         paddedDimension_, dimension_;
+    s32                         bufferSize_;
+    mutable f32*                features_;
+    f32*                        means_;
+    f32*                        constants_;
+    template<class DensitySelector>
+    void fillScoreCacheTpl(EmissionIndex e, u32 featureIndex, u32 length, const DensitySelector& selector) const;
+};
+const size_t BatchFloatFeatureScorer::BlockSize = 8;   // Mm/BatchFeatureScorer.cc:129
+}  // namespace Mm
+using namespace Mm;
+// ---- reference text, %(file)s:%(ranges)s ----
+""",
+        """
+// ---- end of reference text ----
+// ONE mixture of n_dens densities: means [n_dens x pdim] and features [T x pdim] already multiplied by 1 / sigma, pdim a multiple of 8
+// (init() / setFeature of the reference, restated by the caller), constants [n_dens]; scores [T]
+extern "C" void ref_batch_float_fill(const float* means, const float* constants, int n_dens, const float* features, int T, int pdim, float* scores) {
+    Mm::BatchFloatFeatureScorer s;
+    s.offsets_         = {0, (size_t)n_dens};
+    s.bufferSize_      = T;
+    s.paddedDimension_ = (u32)pdim;
+    s.dimension_       = (u32)pdim;
+    s.cached_.assign((size_t)T, false);
+    // 16-byte aligned copies (_mm_load_ps)
+    float *m = nullptr, *f = nullptr, *c = nullptr, *o = nullptr;
+    posix_memalign((void**)&m, 16, sizeof(float) * (size_t)n_dens * pdim);
+    posix_memalign((void**)&f, 16, sizeof(float) * (size_t)T * pdim);
+    posix_memalign((void**)&c, 16, sizeof(float) * (size_t)(n_dens + 4));
+    posix_memalign((void**)&o, 16, sizeof(float) * (size_t)(T + 4));
+    for (size_t i = 0; i < (size_t)n_dens * pdim; ++i) m[i] = means[i];
+    for (size_t i = 0; i < (size_t)T * pdim; ++i) f[i] = features[i];
+    for (int i = 0; i < n_dens; ++i) c[i] = constants[i];
+    s.means_ = m; s.features_ = f; s.constants_ = c; s.scores_ = o;
+    s.fillScoreCacheTpl<Mm::BatchFloatFeatureScorer::AllDensitySelector>(0, 0, (u32)T, Mm::BatchFloatFeatureScorer::AllDensitySelector());
+    for (int t = 0; t < T; ++t) scores[t] = o[t];
+    free(m); free(f); free(c); free(o);
+}
+"""),
 }
 
 

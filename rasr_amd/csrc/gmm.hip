@@ -236,7 +236,8 @@ __global__ __launch_bounds__(256) void gmm_batch_float_kernel(const float* __res
         for (uint32_t k = k0; k < k1; ++k) {
             const float* mu = g_smeans + (size_t)g_k_mean[k] * dim;
             const float  r  = batch_float_distance<DIM, FMA>(mu, x, g_k_const[k], dim);
-            best           = r < best ? r : best;  // _mm_min_ps(score, r)
+            best           = best < r ? best : r;  // _mm_min_ps(score, r) = score < r ? score : r: a NaN sum REPLACES the score, a later finite one the NaN
+                                                     // (Mm/BatchFeatureScorer.cc:245; tests/test_contract.py holds the reference's own function text to it)
         }
         if (live)
             g_scores[(size_t)t * dims.n_mix + m] = best < FLT_MAX ? 0.5f * best : best;

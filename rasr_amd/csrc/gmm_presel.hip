@@ -163,10 +163,10 @@ __global__ __launch_bounds__(256) void presel_score_kernel(const float* __restri
             const float* mu = g_smeans + (size_t)g_k_mean[k] * dim;
             const float  r  = batch_float_distance<DIM, false>(mu, x, g_k_const[k], dim);
             const bool  act = (am >> lane) & 1ull;
-            best            = (act && r < best) ? r : best;
+            best            = act ? (best < r ? best : r) : best;  // _mm_min_ps(score, r), the reference's operand order: a NaN sum replaces the score
         }
         if (live)
-            g_scores[(size_t)t * n_mix + m] = best < FLT_MAX ? 0.5f * best : backoff;
+            g_scores[(size_t)t * n_mix + m] = best < FLT_MAX ? 0.5f * best : (best == FLT_MAX ? backoff : best);  // (a NaN score is neither: it stays)
     }
 }
 

@@ -6,7 +6,8 @@ The reference has two arithmetics (cmake_resources/CompileOptions.cmake:21-48): 
 once; its DEFAULT configuration (-march=native, GCC's -ffp-contract=fast) on an FMA host fuses a product whose only use is an
 addition into one fused multiply-add.  oracle/ref/Makefile compiles the reference both ways (libref.so: -msse3; libref_native.so:
 -msse3 -march=native) -- whole translation units where they build, and FUNCTION-TEXT pins (oracle/ref/extract_fn.py) for
-Mm::GaussDiagonalMaximumFeatureScorer::distance, Signal::Regression and Signal::FilterBank::Filter::apply.
+Mm::GaussDiagonalMaximumFeatureScorer::distance, Signal::Regression, Signal::FilterBank::Filter::apply,
+Signal::HammingWindowFunction::init and Mm::BatchFloatFeatureScorer::fillScoreCacheTpl.
 
 ref_contract.npz: seeded INPUTS and the OUTPUTS OF THE REFERENCE in both flavours ("<pin>_off", "<pin>_fma") for the
 contraction-sensitive pins; tests/test_contract.py holds both oracle libraries to them bit for bit, everywhere (no reference tree
@@ -158,6 +159,53 @@ def main():
     a = np.array([R["off"].ref_inverse_square_root(float(t)) for t in gold["ln_var_40"][:50].reshape(-1)], np.float32)
     b = np.array([R["fma"].ref_inverse_square_root(float(t)) for t in gold["ln_var_40"][:50].reshape(-1)], np.float32)
     report["Mm::inverseSquareRoot<f32> (Utilities.hh:86-91)"] = dict(tried=2000, differ=ndiff(a, b))
+
+    # ---- a3: the Hamming table (function text) -- flag-insensitive for every length tried; the fixture keeps the lengths the flow
+    # files use (25 ms / 20 ms at 16 kHz and 8 kHz) and a few odd ones
+    rng2 = np.random.default_rng(20260931)   # (a second generator: the draws above keep their values)
+    lens = [2, 3, 160, 200, 320, 400, 401, 512, 1001]
+    d = 0
+    for n in range(2, 4097):
+        a, b = np.zeros(n, np.float32), np.zeros(n, np.float32)
+        R["off"].ref_hamming_window(n, a)
+        R["fma"].ref_hamming_window(n, b)
+        d += ndiff(a, b)
+        if n in lens:
+            gold["hamming_%d" % n] = a
+    report["Signal::HammingWindowFunction::init (function text, WindowFunction.cc:92-101), every length 2 .. 4096"] = dict(
+        tried=sum(range(2, 4097)), differ=d, fma_sites="vfnmadd132sd (0.54 - 0.46 * cos()), f64; the f32 table hides it")
+
+    # ---- a18: BatchFloatFeatureScorer::fillScoreCacheTpl (function text): pre-scaled means / features of one mixture, with the
+    # non-finite cases that separate _mm_min_ps(score, s) from min(s, score)
+    cases = []
+    for dim in (40, 39, 33, 16, 8, 45, 3):
+        pdim = (dim + 7) // 8 * 8
+        for trial in range(12):
+            nk, T = int(rng2.integers(1, 20)), int(rng2.integers(1, 10))
+            ms = np.zeros((nk, pdim), np.float32)
+            ms[:, :dim] = rng2.standard_normal((nk, dim)) * rng2.uniform(0.1, 30)
+            xs = np.zeros((T, pdim), np.float32)
+            xs[:, :dim] = rng2.standard_normal((T, dim)) * rng2.uniform(0.1, 30)
+            cst = (rng2.standard_normal(nk) * 20 + 60).astype(np.float32)
+            if trial % 6 == 3:
+                xs[0, 0] = np.nan                      # every density's sum is NaN: the score is NaN
+            if trial % 6 == 4 and nk > 1:
+                ms[0, 1], xs[T - 1, 1] = np.inf, np.inf  # first density NaN (inf - inf), the others +inf: NaN, then replaced by +inf
+            if trial % 6 == 5:
+                ms[nk - 1, 2], xs[0, 2] = np.inf, np.inf  # the LAST density NaN: the score ends as NaN
+            cases.append((ms, cst, xs))
+    gold["bf_n"] = np.array([len(cases)])
+    tot = dif = 0
+    for i, (ms, cst, xs) in enumerate(cases):
+        gold["bf_ms_%d" % i], gold["bf_cst_%d" % i], gold["bf_xs_%d" % i] = ms, cst, xs
+        for c in R:
+            out = np.zeros(len(xs), np.float32)
+            R[c].ref_batch_float_fill(ms.reshape(-1), cst, len(ms), xs.reshape(-1), len(xs), ms.shape[1], out)
+            gold["bf_%d_%s" % (i, c)] = out
+        tot += len(xs)
+        dif += ndiff(gold["bf_%d_off" % i], gold["bf_%d_fma" % i])
+    report["Mm::BatchFloatFeatureScorer::fillScoreCacheTpl (function text, BatchFeatureScorer.cc:207-253)"] = dict(
+        tried=tot, differ=dif, fma_sites="2 x vfmadd231ps (s = _mm_add_ps(s, _mm_mul_ps(x, x)): intrinsics are vector arithmetic to GCC)")
 
     np.savez_compressed(os.path.join(HERE, "ref_contract.npz"), **gold)
     out = os.path.join(ROOT, "profiles", "r05")

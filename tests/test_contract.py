@@ -5,6 +5,7 @@ other f32 sums into fused multiply-adds; configured with -DMARCH=x86-64 it does 
 oracle/liboracle_fma.so the first (orc.h).  Both are held, bit for bit, to
   * tests/golden/ref_contract.npz -- outputs of the reference compiled both ways (tests/golden/make_contract_golden.py), everywhere;
   * oracle/_ref/libref.so / libref_native.so live on fresh inputs, where the reference tree is mounted (build container).
+Function-text pins (oracle/ref/extract_fn.py): a13 distance, f1 regression, a7 filter apply, a3 Hamming table, a18 batch-float sum.
 """
 import os
 
@@ -67,6 +68,42 @@ def test_filter_bank_apply_against_the_reference_function_text(contract):
     L = Oracle(contract)
     got = np.array([L.orc_filter_apply(Z["fb_amp"][i], int(Z["fb_start"][i]), int(Z["fb_end"][i]), Z["fb_w"][i]) for i in range(200)], np.float32)
     assert np.array_equal(bits(got), bits(Z["fb_%s" % contract]))
+
+
+@pytest.mark.parametrize("contract", CONTRACTS)
+def test_hamming_table_against_the_reference_function_text(contract):
+    """a3: Signal::HammingWindowFunction::init.  The default build fuses 0.54 - 0.46 * cos() in f64; the f32 table has the same bits in
+    both builds for every length 2 .. 4096 (contract_pins.json), so one restatement serves both"""
+    L = Oracle(contract)
+    for n in (2, 3, 160, 200, 320, 400, 401, 512, 1001):
+        w = np.zeros(n, np.float32)
+        L.orc_hamming_window(w, n)
+        assert np.array_equal(bits(w), bits(Z["hamming_%d" % n])), (contract, n)
+
+
+def _same_bits_or_both_nan(a, b):
+    return bool(np.all((bits(a) == bits(b)) | (np.isnan(a) & np.isnan(b))))
+
+
+@pytest.mark.parametrize("contract", CONTRACTS)
+def test_batch_float_fill_against_the_reference_function_text(contract):
+    """a18: Mm::BatchFloatFeatureScorer::fillScoreCacheTpl -- the SSE accumulate (two vfmadd in the default build), the horizontal sum, the
+    minimum as `_mm_min_ps(score, s)` (a NaN sum REPLACES the score, a later finite or infinite one replaces the NaN) and the final 0.5"""
+    L = Oracle(contract)
+    n_nonfinite = 0
+    for i in range(int(Z["bf_n"][0])):
+        ms, cst, xs = Z["bf_ms_%d" % i], Z["bf_cst_%d" % i], Z["bf_xs_%d" % i]
+        got = np.array([L.orc_batch_float_fill(ms.reshape(-1), cst, len(ms), np.ascontiguousarray(xs[t]), ms.shape[1]) for t in range(len(xs))],
+                       np.float32)
+        want = Z["bf_%d_%s" % (i, contract)]
+        assert _same_bits_or_both_nan(got, want), (contract, i, got, want)
+        n_nonfinite += int(np.count_nonzero(~np.isfinite(want)))
+    assert n_nonfinite >= 10   # the cases that tell min_ps(score, s) from min(s, score) are in the fixture
+
+
+def test_the_two_builds_of_the_batch_float_sum_really_differ():
+    d = sum(int(np.count_nonzero(bits(Z["bf_%d_off" % i]) != bits(Z["bf_%d_fma" % i]))) for i in range(int(Z["bf_n"][0])))
+    assert d > 20, d
 
 
 @pytest.mark.parametrize("contract", CONTRACTS)
@@ -140,3 +177,19 @@ def test_live_against_the_compiled_reference(contract):
         assert np.array_equal(bits(oracle_regression(w, order=order, right=2, contract=contract)[2]), bits(out))
     amp, w = np.abs(rng.standard_normal(257)).astype(np.float32), rng.uniform(0, 1, 40).astype(np.float32)
     assert bits(np.float32(L.orc_filter_apply(amp, 31, 71, w))) == bits(np.float32(R.ref_filter_apply(amp, 257, 31, 71, w)))
+    for n in (2, 7, 255, 400, 777):
+        a, b = np.zeros(n, np.float32), np.zeros(n, np.float32)
+        assert R.ref_hamming_window(n, a) == 0
+        L.orc_hamming_window(b, n)
+        assert np.array_equal(bits(a), bits(b)), n
+    for dim in (40, 33, 5):
+        pdim = (dim + 7) // 8 * 8
+        for _ in range(30):
+            nk, T = int(rng.integers(1, 12)), int(rng.integers(1, 6))
+            ms, xs = np.zeros((nk, pdim), np.float32), np.zeros((T, pdim), np.float32)
+            ms[:, :dim], xs[:, :dim] = rng.standard_normal((nk, dim)) * 5, rng.standard_normal((T, dim)) * 5
+            cst = (rng.standard_normal(nk) * 10 + 50).astype(np.float32)
+            out = np.zeros(T, np.float32)
+            R.ref_batch_float_fill(ms.reshape(-1), cst, nk, xs.reshape(-1), T, pdim, out)
+            got = np.array([L.orc_batch_float_fill(ms.reshape(-1), cst, nk, np.ascontiguousarray(xs[t]), pdim) for t in range(T)], np.float32)
+            assert np.array_equal(bits(got), bits(out))

@@ -134,6 +134,46 @@ def test_batch_float_scorer_exact(ctx, dim):
     assert np.allclose(got, o.score(x)[0], rtol=3e-6)
 
 
+@pytest.mark.parametrize("contract", ["off", "fma"])
+def test_batch_float_scorer_minimum_is_the_references_min_ps(ctx, contract):
+    """Mm::BatchFloatFeatureScorer takes the minimum as _mm_min_ps(score, s) = (score < s ? score : s): a NaN sum REPLACES the score and a
+    later sum replaces the NaN (Mm/BatchFeatureScorer.cc:245, pinned on the reference's function text in tests/test_contract.py).
+    Frames with NaN -> NaN scores; a mixture whose FIRST density has an infinite mean, on a frame that is infinite there (inf - inf): NaN,
+    then +inf from the other densities -> +inf (min(s, score) would have kept FLT_MAX); the LAST density infinite: NaN"""
+    import rasr_amd
+    from oracle import OracleGmm
+    dim = 40
+    model = synth.gmm_cart(60, 1, 6, dim, seed=77, pooled=True)
+    off, idx = model["mix_offsets"], model["dens_index"]
+    means = model["means"].copy()
+    first = int(model["dens_mean"][idx[off[5]]])          # first density of mixture 5
+    last = int(model["dens_mean"][idx[off[9 + 1] - 1]])   # last density of mixture 9
+    means[first, 3] = np.inf
+    means[last, 7] = np.inf
+    model["means"] = means
+    x = feats(64, dim, 78)
+    x[10, 0] = np.nan
+    x[20, 3] = np.inf
+    x[30, 7] = np.inf
+    tun = "contract=" + contract
+    got = rasr_amd.GmmFeatureScorer(ctx, model, feature_scorer_type="batch-diagonal-maximum-float", tuning=tun).score(x, want_best=False)
+    want = OracleGmm(model, contract=contract).score_batch_float(x)
+    same = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
+    assert same.all(), np.argwhere(~same)[:5]
+    assert np.isnan(got[10]).all() and np.isposinf(got[20, 5]) and np.isnan(got[30, 9])
+    # the preselection scorer runs the same loop (Mm/BatchFeatureScorer.cc:306-315): with every cluster selected and a finite model, a NaN
+    # frame scores NaN -- `if (s == max) s = backoff` does not catch it -- and a frame that is infinite in one component scores the back-off
+    if contract == "off":
+        clean = synth.gmm_cart(60, 1, 6, dim, seed=77, pooled=True)
+        sc = rasr_amd.GmmFeatureScorer(ctx, clean, feature_scorer_type="preselection-batch-float")
+        sc.set_preselection(16, 16, 3, 777.0)
+        g2 = sc.score(x, want_best=False)
+        w2, _, _ = OracleGmm(clean).score_preselection_float(x, 16, 16, 3, 777.0)
+        same = (g2.view(np.uint32) == w2.view(np.uint32)) | (np.isnan(g2) & np.isnan(w2))
+        assert same.all(), np.argwhere(~same)[:5]
+        assert np.isnan(g2[10]).all() and (g2[20] == 777.0).all()
+
+
 def test_batch_float_scorer_errors(ctx):
     import rasr_amd
     s = rasr_amd.GmmFeatureScorer(ctx, synth.gmm_cart(10, 1, 3, 40, seed=1, pooled=False), feature_scorer_type="batch-diagonal-maximum-float")
