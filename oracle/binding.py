@@ -246,6 +246,8 @@ def load_ref(contract="off"):
         R.ref_hamming_window.restype = C.c_int
         R.ref_hamming_window.argtypes = [C.c_int, f32p]
         R.ref_batch_float_fill.argtypes = [f32p, f32p, C.c_int, f32p, C.c_int, C.c_int, f32p]
+    if hasattr(R, "ref_preemphasis"):
+        R.ref_preemphasis.argtypes = [C.c_float, C.c_double, f32p, C.c_long, C.c_int, C.c_int, f32p]
     _refs[contract] = R
     return R
 

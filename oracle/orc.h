@@ -20,14 +20,15 @@
  * objects) -- the GMM distance's `sum += df * df` (vfmadd231ps / vfmadd231ss, function-text pin gdm_distance), the f32 dot product
  * of Math::Vector (cosine transform), gaussLogNormFactor's N * log(2 pi) + sum (f64), the filter bank's apply, the regression
  * sums and the batch-float scorer's SSE accumulate (function-text pins filter_apply, regression, batch_float_fill).  Sites in
- * translation units that cannot be compiled here follow GCC's rule by reading (preemphasis, the other back-end sums) and say so.
+ * translation units that cannot be compiled here follow GCC's rule by reading (the other back-end sums) and say so; preemphasis'
+ * `v[i] -= alpha * previous` is pinned too (function-text pin preemphasis).
  * NOT restated in fma form: the FFT's f64 twiddle recurrences (14 fused operations in the native object; the f32 results were
  * bit-identical to the plain build on every frame tried, tests/test_contract.py) and the f4 front ends / quantised scorers.
  *
  * Pinning status (see DESIGN.md "Oracle"):
  *   FFT core, framing/flush, mel warp/derivative/inverse, GMM logNorm / 1/sqrt(var):
  *       pinned bit-exactly against oracle/_ref (reference sources compiled unmodified).
- *   Hamming table, GMM distance, filter apply, regression, batch-float sum / minimum: pinned bit-exactly on the reference's
+ *   preemphasis, Hamming table, GMM distance, filter apply, regression, batch-float sum / minimum: pinned bit-exactly on the reference's
  *       own function text compiled with both flag sets (oracle/ref/extract_fn.py, tests/test_contract.py).
  *   filterbank geometry, DCT, GMM max score (combine / tie rule): pinned by the known answers the
  *       reference produced in this container.

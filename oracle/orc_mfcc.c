@@ -44,7 +44,7 @@ void orc_preemphasis(float* x, long n, float alpha) {
     if (alpha != 1.0) {
         for (long i = 0; i < n; ++i) {
             float cur  = x[i];
-            x[i]       = ORC_FMAF(-alpha, prev, cur); /* v[i] -= alpha_ * previous_: vfnmadd under contraction (by rule; TU needs boost) */
+            x[i]       = ORC_FMAF(-alpha, prev, cur); /* v[i] -= alpha_ * previous_: vfnmadd132ss in the default build (function-text pin preemphasis) */
             prev       = cur;
         }
     }

@@ -238,6 +238,59 @@ extern "C" void ref_batch_float_fill(const float* means, const float* constants,
     free(m); free(f); free(c); free(o);
 }
 """),
+    # Signal::Preemphasis (SURVEY section 8 row a1): constructor, init, setAlpha, setSampleRate and apply -- the whole class except its
+    # declaration, which sits in Signal/Preemphasis.hh behind SleeveNode -> Flow/Node.hh -> Core/Configuration.hh (boost).  The shell
+    # re-declares the class member for member (Signal/Preemphasis.hh:29-53); Flow::Vector / Flow::Timestamp are the reference's own
+    # (Flow/Vector.hh, Flow/Timestamp.cc is one of the translation units of libref)
+    "preemphasis": (
+        "Signal/Preemphasis.cc", [(23, 74)],
+        "050ca20394e672246a92a01979b299682fd1c70b58cfab6baeb945220264e729",
+        """#include <Core/Types.hh>
+#include <Core/Assertions.hh>
+#include <Flow/Vector.hh>
+namespace Signal {
+class Preemphasis {
+private:
+    f32        alpha_;
+    f32        previous_;
+    Flow::Time previousEndTime_;
+    f64        sampleRate_;
+    bool       needInit_;
+    void       init(f32 initialValue);
+public:
+    Preemphasis();
+    void setAlpha(f32 alpha);
+    void setSampleRate(f64 sampleRate);
+    void reset(void) { needInit_ = true; }
+    void apply(Flow::Vector<f32>& v);
+};
+}  // namespace Signal
+using namespace Signal;
+// ---- reference text, %(file)s:%(ranges)s ----
+""",
+        """
+// ---- end of reference text ----
+// x [n] in blocks of `block` samples with contiguous time stamps, except that block number `gap_at` (if >= 0) starts one second late
+// (the node then restarts: previous_ = its first sample); out [n]
+extern "C" void ref_preemphasis(float alpha, double sample_rate, const float* x, long n, int block, int gap_at, float* out) {
+    Signal::Preemphasis p;
+    p.setAlpha(alpha);
+    p.setSampleRate(sample_rate);
+    double shift = 0;
+    int    k     = 0;
+    for (long i0 = 0; i0 < n; i0 += block, ++k) {
+        const long len = (n - i0 < block) ? n - i0 : block;
+        Flow::Vector<f32> v(x + i0, x + i0 + len);
+        if (k == gap_at)
+            shift = 1.0;
+        v.setStartTime((double)i0 / sample_rate + shift);
+        v.setEndTime((double)(i0 + len) / sample_rate + shift);
+        p.apply(v);
+        for (long i = 0; i < len; ++i)
+            out[i0 + i] = v[i];
+    }
+}
+"""),
 }
 
 

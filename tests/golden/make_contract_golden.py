@@ -7,7 +7,7 @@ once; its DEFAULT configuration (-march=native, GCC's -ffp-contract=fast) on an 
 addition into one fused multiply-add.  oracle/ref/Makefile compiles the reference both ways (libref.so: -msse3; libref_native.so:
 -msse3 -march=native) -- whole translation units where they build, and FUNCTION-TEXT pins (oracle/ref/extract_fn.py) for
 Mm::GaussDiagonalMaximumFeatureScorer::distance, Signal::Regression, Signal::FilterBank::Filter::apply,
-Signal::HammingWindowFunction::init and Mm::BatchFloatFeatureScorer::fillScoreCacheTpl.
+Signal::HammingWindowFunction::init, Mm::BatchFloatFeatureScorer::fillScoreCacheTpl and Signal::Preemphasis.
 
 ref_contract.npz: seeded INPUTS and the OUTPUTS OF THE REFERENCE in both flavours ("<pin>_off", "<pin>_fma") for the
 contraction-sensitive pins; tests/test_contract.py holds both oracle libraries to them bit for bit, everywhere (no reference tree
@@ -206,6 +206,24 @@ def main():
         dif += ndiff(gold["bf_%d_off" % i], gold["bf_%d_fma" % i])
     report["Mm::BatchFloatFeatureScorer::fillScoreCacheTpl (function text, BatchFeatureScorer.cc:207-253)"] = dict(
         tried=tot, differ=dif, fma_sites="2 x vfmadd231ps (s = _mm_add_ps(s, _mm_mul_ps(x, x)): intrinsics are vector arithmetic to GCC)")
+
+    # ---- a1: Signal::Preemphasis (function text; the whole class): 4096-sample blocks with contiguous time stamps, alpha = 1 (mfcc.flow:
+    # no product) and alpha != 1 (v[i] -= alpha * previous: vfnmadd132ss in the default build), and a restart behind a gap
+    f32p = np.ctypeslib.ndpointer(np.float32, flags="C")
+    for c in R:
+        R[c].ref_preemphasis.argtypes = [C.c_float, C.c_double, f32p, C.c_long, C.c_int, C.c_int, f32p]
+    x = (rng2.standard_normal(9000) * 3000).astype(np.float32)
+    gold["pre_x"] = x
+    tot = dif = 0
+    for name, alpha, gap in (("1", 1.0, -1), ("097", 0.97, -1), ("05", 0.5, -1), ("097_gap", 0.97, 1)):
+        for c in R:
+            out = np.zeros_like(x)
+            R[c].ref_preemphasis(alpha, 16000.0, x, len(x), 4096, gap, out)
+            gold["pre_%s_%s" % (name, c)] = out
+        tot += len(x)
+        dif += ndiff(gold["pre_%s_off" % name], gold["pre_%s_fma" % name])
+    report["Signal::Preemphasis (function text, Preemphasis.cc:23-74), alpha 1 / 0.97 / 0.5, blocks of 4096, one restart"] = dict(
+        tried=tot, differ=dif, fma_sites="vfnmadd132ss (v[i] -= alpha * previous); none for alpha = 1, the flow files' value")
 
     np.savez_compressed(os.path.join(HERE, "ref_contract.npz"), **gold)
     out = os.path.join(ROOT, "profiles", "r05")

@@ -5,7 +5,7 @@ other f32 sums into fused multiply-adds; configured with -DMARCH=x86-64 it does 
 oracle/liboracle_fma.so the first (orc.h).  Both are held, bit for bit, to
   * tests/golden/ref_contract.npz -- outputs of the reference compiled both ways (tests/golden/make_contract_golden.py), everywhere;
   * oracle/_ref/libref.so / libref_native.so live on fresh inputs, where the reference tree is mounted (build container).
-Function-text pins (oracle/ref/extract_fn.py): a13 distance, f1 regression, a7 filter apply, a3 Hamming table, a18 batch-float sum.
+Function-text pins (oracle/ref/extract_fn.py): a13 distance, f1 regression, a7 filter apply, a3 Hamming table, a18 batch-float sum, a1 preemphasis.
 """
 import os
 
@@ -79,6 +79,24 @@ def test_hamming_table_against_the_reference_function_text(contract):
         w = np.zeros(n, np.float32)
         L.orc_hamming_window(w, n)
         assert np.array_equal(bits(w), bits(Z["hamming_%d" % n])), (contract, n)
+
+
+@pytest.mark.parametrize("contract", CONTRACTS)
+def test_preemphasis_against_the_reference_function_text(contract):
+    """a1: Signal::Preemphasis, the whole class, fed 4096-sample blocks with contiguous time stamps (the state carries over) and one
+    restart behind a gap (previous = the block's first sample); alpha = 1 is a plain difference, alpha != 1 has the one product that the
+    default build fuses"""
+    L = Oracle(contract)
+    x = Z["pre_x"]
+    for name, alpha in (("1", 1.0), ("097", 0.97), ("05", 0.5)):
+        y = x.copy()
+        L.orc_preemphasis(y, len(y), alpha)
+        assert np.array_equal(bits(y), bits(Z["pre_%s_%s" % (name, contract)])), (contract, name)
+    a, b = x[:4096].copy(), x[4096:].copy()
+    L.orc_preemphasis(a, len(a), 0.97)
+    L.orc_preemphasis(b, len(b), 0.97)
+    assert np.array_equal(bits(np.concatenate([a, b])), bits(Z["pre_097_gap_%s" % contract]))
+    assert np.array_equal(bits(Z["pre_1_off"]), bits(Z["pre_1_fma"])) and not np.array_equal(bits(Z["pre_097_off"]), bits(Z["pre_097_fma"]))
 
 
 def _same_bits_or_both_nan(a, b):
@@ -177,6 +195,12 @@ def test_live_against_the_compiled_reference(contract):
         assert np.array_equal(bits(oracle_regression(w, order=order, right=2, contract=contract)[2]), bits(out))
     amp, w = np.abs(rng.standard_normal(257)).astype(np.float32), rng.uniform(0, 1, 40).astype(np.float32)
     assert bits(np.float32(L.orc_filter_apply(amp, 31, 71, w))) == bits(np.float32(R.ref_filter_apply(amp, 257, 31, 71, w)))
+    for alpha, n in ((1.0, 9001), (0.97, 9001), (0.9, 3)):
+        x = (rng.standard_normal(n) * 1000).astype(np.float32)
+        out, y = np.zeros_like(x), x.copy()
+        R.ref_preemphasis(alpha, 16000.0, x, n, 4096, -1, out)
+        L.orc_preemphasis(y, n, alpha)
+        assert np.array_equal(bits(out), bits(y)), (alpha, n)
     for n in (2, 7, 255, 400, 777):
         a, b = np.zeros(n, np.float32), np.zeros(n, np.float32)
         assert R.ref_hamming_window(n, a) == 0
