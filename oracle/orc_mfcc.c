@@ -269,6 +269,56 @@ static double orc_postprocess_nfilters(double nf) { /* Boundary::postprocessNumb
     return nf;
 }
 
+/* ONE filter (Signal/Filterbank.cc:144-217 FilterBuilder::create / setStart / setEnd / setWeights, :236-244 and :268-281 the
+ * triangular and the trapeze weight()): type 0 triangular / 1 trapeze, warping 0 mel / 1 bark, d2c = scaling of the discrete axis.
+ * Returns the number of weights (end - start), -1 where the reference's builder fails, -2 if `cap` is too small.  PINNED on the
+ * reference's function text in both builds (oracle/ref/extract_fn.py filter_build, tests/test_contract.py). */
+int orc_filter_build(int type, int warping, double center, double width, double fmin, double fmaxw, double d2c, int diff, int* start_out,
+                     int* end_out, float* weights, int cap) {
+    const orc_warp mel = {orc_mel, orc_mel_derivative, orc_mel_inverse}, bark = {orc_bark, orc_bark_derivative, orc_bark_inverse};
+    const orc_warp* W       = warping == 1 ? &bark : &mel;
+    double          inv_d2c = 1 / d2c; /* ScalingFunction::invert */
+    double          ncp     = type == 1 ? 2.5 / (1.3 - (-2.5)) : 0.5;
+    /* setStart */
+    double lo = center - ncp * width;
+    if (!(lo > fmin))
+        lo = fmin; /* std::max(a, b) returns a unless a < b */
+    double s = inv_d2c * W->inverse(lo);
+    s        = orc_almost_integer(s) ? round(s) : ceil(s);
+    if (!(s >= 0))
+        return -1;
+    /* setEnd */
+    double hi = center + (1.0 - ncp) * width;
+    if (fmaxw < hi)
+        hi = fmaxw;
+    double e = inv_d2c * W->inverse(hi);
+    e        = orc_almost_integer(e) ? round(e) + 1 : ceil(e);
+    size_t start = (size_t)s;
+    if (!(e > 0 && start < (size_t)e))
+        return -1;
+    size_t end = (size_t)e;
+    if (end - start > (size_t)cap)
+        return -2;
+    *start_out = (int)start;
+    *end_out   = (int)end;
+    /* setWeights: f32 shape weight times f64 derivative, rounded to f32 */
+    int n = 0;
+    for (unsigned b = (unsigned)start; b < end; ++b) {
+        double fw = W->value(d2c * (double)b);
+        float  sh;
+        if (type == 1)
+            sh = orc_trapeze_weight(fw, center, width);
+        else {
+            sh = (float)((double)1 - fabs(fw - center) / (width / 2));
+            if (!(sh >= 0))
+                sh = 0;
+        }
+        double der   = diff ? W->derivative(d2c * (double)b) : 1.0;
+        weights[n++] = (float)(sh * der);
+    }
+    return n;
+}
+
 static int orc_build_filterbank(orc_mfcc* h) {
     const orc_mfcc_cfg* c  = &h->cfg;
     const orc_warp mel = {orc_mel, orc_mel_derivative, orc_mel_inverse}, bark = {orc_bark, orc_bark_derivative, orc_bark_inverse};
@@ -278,7 +328,6 @@ static int orc_build_filterbank(orc_mfcc* h) {
     /* FilterBankNode::configure reads sample-rate = N/fs from the attribute text */
     double sr_attr = orc_attr_roundtrip((double)h->fft_len / c->sample_rate);
     double d2c     = 1 / sr_attr;                    /* createScaling(1 / sampleRate_) */
-    double inv_d2c = 1 / d2c;                        /* ScalingFunction::invert */
     int    B       = h->n_bins;
     double fmin    = 0.0;                            /* filtering-interval-start default */
     double fmaxw   = W->value(d2c * (double)(B - 1)); /* FilterBankNode::init */
@@ -318,43 +367,15 @@ static int orc_build_filterbank(orc_mfcc* h) {
             center = spacing * (double)(i + 1);
         else
             center = spacing * (double)i;
-        /* setStart */
-        double lo = center - ncp * width;
-        if (!(lo > fmin))
-            lo = fmin; /* std::max(a, b) returns a unless a < b */
-        double s = inv_d2c * W->inverse(lo);
-        s        = orc_almost_integer(s) ? round(s) : ceil(s);
-        if (s < 0)
-            return -1;
-        /* setEnd */
-        double hi = center + (1.0 - ncp) * width;
-        if (fmaxw < hi)
-            hi = fmaxw;
-        double e = inv_d2c * W->inverse(hi);
-        e        = orc_almost_integer(e) ? round(e) + 1 : ceil(e);
-        size_t start = (size_t)s;
-        if (!(e > 0 && start < (size_t)e))
-            return -1;
-        size_t end = (size_t)e;
-        if (end > (size_t)B)
-            return -1; /* Filter::apply would read beyond the spectrum */
-        h->f_start[i] = (int)start;
-        h->f_end[i]   = (int)end;
+        int start, end;
+        int n = orc_filter_build(c->filter_type, c->warping, center, width, fmin, fmaxw, d2c, c->warp_differential_unit, &start, &end,
+                                 h->f_weights + off, B);
+        if (n < 0 || end > B)
+            return -1; /* (end > B: Filter::apply would read beyond the spectrum) */
+        h->f_start[i] = start;
+        h->f_end[i]   = end;
         h->f_off[i]   = off;
-        /* setWeights: f32 shape weight times f64 derivative, rounded to f32 */
-        for (unsigned b = (unsigned)start; b < end; ++b) {
-            double fw = W->value(d2c * (double)b);
-            float  sh;
-            if (c->filter_type == 1)
-                sh = orc_trapeze_weight(fw, center, width);
-            else {
-                sh = (float)((double)1 - fabs(fw - center) / (width / 2));
-                if (!(sh >= 0))
-                    sh = 0;
-            }
-            double der = c->warp_differential_unit ? W->derivative(d2c * (double)b) : 1.0;
-            h->f_weights[off++] = (float)(sh * der);
-        }
+        off += n;
     }
     h->f_off[n_filters] = off;
 

@@ -96,42 +96,6 @@ extern "C" void ref_regression(int order, const float* in, int n_in, int dim, fl
         out[c] = o[c];
 }
 """),
-    # Signal::FilterBank::Filter -- declared and defined inside Filterbank.cc: the class declaration, its constructor and apply() are
-    # reference text; the shell supplies the three typedefs and the enum of the enclosing class (Signal/Filterbank.hh:50-71, a
-    # Core::Component, i.e. Core/Configuration.hh -> boost)
-    "filter_apply": (
-        "Signal/Filterbank.cc", [(27, 50), (65, 71)],
-        "d658510f8fe34343289991527c1f11276dc3166e536ebd2117ca989e5cbeb614",
-        """#include <Core/Types.hh>
-#include <Core/Assertions.hh>
-#include <Core/ReferenceCounting.hh>
-#include <Core/XmlStream.hh>
-#include <vector>
-namespace Signal {
-// shell: the member types Signal::FilterBank::Filter uses (Signal/Filterbank.hh:52-54,65-68,71)
-class FilterBank {
-public:
-    typedef f64  Frequency;
-    typedef f32  Data;
-    typedef Data FilterWeight;
-    enum NormalizationType { normalizeNone, normalizeSurface };
-    class Filter;
-};
-}  // namespace Signal
-using namespace Signal;
-// ---- reference text, %(file)s:%(ranges)s ----
-""",
-        """
-// ---- end of reference text ----
-extern "C" float ref_filter_apply(const float* in, int n_in, int start, int end, const float* weights) {
-    std::vector<Signal::FilterBank::FilterWeight> w(weights, weights + (end - start));
-    std::vector<Signal::FilterBank::Data>         v(in, in + n_in);
-    Signal::FilterBank::Filter* f = new Signal::FilterBank::Filter((size_t)start, (size_t)end, w);
-    const float r = f->apply(v);
-    delete f;
-    return r;
-}
-"""),
     # Signal::HammingWindowFunction::init (SURVEY section 8 row a3): the window table, f64 arithmetic stored as f32.  The class
     # declarations (Signal/WindowFunction.hh:30-110) need Core/Choice.hh / Core/Parameter.hh -> Core/Configuration.hh (boost); the shell
     # declares the one data member and the base init() the text calls
@@ -289,6 +253,132 @@ extern "C" void ref_preemphasis(float alpha, double sample_rate, const float* x,
         for (long i = 0; i < len; ++i)
             out[i0 + i] = v[i];
     }
+}
+"""),
+    # Signal::FilterBank::FilterBuilder::{create, setStart, setEnd, setWeights}, the triangular and the trapeze weight() and
+    # FilterBank::isAlmostInteger (SURVEY section 8 row a7: where a filter starts, where it ends and what its weights are), together with
+    # Signal::FilterBank::Filter -- class declaration, constructor and apply() (declared and defined inside Filterbank.cc).  The builder classes are declared inside Filterbank.cc as Core::Components with configuration
+    # constructors (boost): the shell re-declares them without that base -- same members, same virtuals, error() a no-op, the two
+    # one-line constants normalizedCenterPosition() / normalizedMiddleBorder() retyped from :231-233, :251-253, :263-265 -- and gives
+    # Math::AnalyticFunctionFactory::createConstant its one line (Math/AnalyticFunctionFactory.hh:231-233 forwards to
+    # Math::createConstant; that header includes Core/Component.hh).  The analytic functions are the reference's own classes.
+    "filter_build": (
+        "Signal/Filterbank.cc", [(27, 50), (65, 71), (144, 217), (236, 244), (268, 281), (691, 694)],
+        "2e63de787bbf33e254cc4405da6e200a05d066ca0817b44bc3368b129a83ae4d",
+        """#include <Core/Types.hh>
+#include <Core/Assertions.hh>
+#include <Core/ReferenceCounting.hh>
+#include <Core/Utility.hh>
+#include <Core/XmlStream.hh>
+#include <Math/AnalyticFunction.hh>
+#include <Math/SimpleAnalyticFunctions.hh>
+#include <Math/AcousticalAnalyticFunctions.hh>
+#include <algorithm>
+#include <cmath>
+#include <vector>
+namespace Math {
+struct AnalyticFunctionFactory {  // Math/AnalyticFunctionFactory.hh:231-233
+    static UnaryAnalyticFunctionRef createConstant(UnaryAnalyticFunction::Argument c) { return Math::createConstant(c); }
+};
+}  // namespace Math
+namespace Signal {
+class FilterBank {
+public:
+    typedef f64  Frequency;
+    typedef f32  Data;
+    typedef Data FilterWeight;
+    enum NormalizationType { normalizeNone, normalizeSurface };
+    class Filter;
+    class FilterBuilder;
+    static bool isAlmostInteger(Frequency x);
+};
+// Signal/Filterbank.cc:89-133 without the Core::Component base
+class FilterBank::FilterBuilder {
+protected:
+    size_t                         start_;
+    size_t                         end_;
+    std::vector<FilterWeight>      weights_;
+    Frequency                      center_;
+    Frequency                      width_;
+    Frequency                      maximumFrequency_;
+    Frequency                      minimumFrequency_;
+    Math::UnaryAnalyticFunctionRef discreteToContinuousFunction_;
+    Math::UnaryAnalyticFunctionRef continuousToDiscreteFunction_;
+    Math::UnaryAnalyticFunctionRef derivedWarpingFunction_;
+    void error(const char*, ...) const {}
+private:
+    virtual bool setStart();
+    virtual bool setEnd();
+    bool         setWeights();
+protected:
+    virtual FilterWeight weight(Frequency) const = 0;
+public:
+    FilterBuilder() : start_(0), end_(0), center_(0), width_(0) {}
+    virtual ~FilterBuilder() {}
+    Core::Ref<FilterBank::Filter> create(Frequency center, Frequency width, Frequency minimumFrequency, Frequency maximumFrequency,
+                                         Math::UnaryAnalyticFunctionRef discreteToContinuousFunction,
+                                         Math::UnaryAnalyticFunctionRef warpingFunction, bool warpDifferentialUnit);
+    virtual Frequency normalizedCenterPosition() const = 0;
+};
+class SymmetricalTriangularFilterBuilder : public FilterBank::FilterBuilder {
+protected:
+    virtual FilterBank::FilterWeight weight(FilterBank::Frequency) const;
+public:
+    virtual FilterBank::Frequency normalizedCenterPosition() const { return 0.5; }
+};
+class TrapezeFilterBuilder : public FilterBank::FilterBuilder {
+private:
+    FilterBank::Frequency normalizedMiddleBorder() const { return 0.5 / (1.3 - (-2.5)); }
+protected:
+    virtual FilterBank::FilterWeight weight(FilterBank::Frequency) const;
+public:
+    virtual FilterBank::Frequency normalizedCenterPosition() const { return 2.5 / (1.3 - (-2.5)); }
+};
+}  // namespace Signal
+using namespace Signal;
+// ---- reference text, %(file)s:%(ranges)s ----
+""",
+        """
+// ---- end of reference text ----
+namespace {
+template<class B>
+struct Probe : B {
+    int run(double center, double width, double fmin, double fmax, Math::UnaryAnalyticFunctionRef d2c, Math::UnaryAnalyticFunctionRef warp,
+            bool diff, int* start, int* end, float* weights, int cap) {
+        Core::Ref<Signal::FilterBank::Filter> f = this->create(center, width, fmin, fmax, d2c, warp, diff);
+        if (!f)
+            return -1;
+        *start = (int)this->start_;
+        *end   = (int)this->end_;
+        if ((int)this->weights_.size() > cap)
+            return -2;
+        for (size_t i = 0; i < this->weights_.size(); ++i)
+            weights[i] = this->weights_[i];
+        return (int)this->weights_.size();
+    }
+};
+Math::UnaryAnalyticFunctionRef fb_scaling(double a) { return Math::UnaryAnalyticFunctionRef(new Math::ScalingFunction(a)); }
+}  // namespace
+// Filter::apply on a filter given by its interval and weights (the pin "filter_apply" of earlier in the round: the Filter class, its
+// constructor and apply() are the first two ranges of this file)
+extern "C" float ref_filter_apply(const float* in, int n_in, int start, int end, const float* weights) {
+    std::vector<Signal::FilterBank::FilterWeight> w(weights, weights + (end - start));
+    std::vector<Signal::FilterBank::Data>         v(in, in + n_in);
+    Signal::FilterBank::Filter* f = new Signal::FilterBank::Filter((size_t)start, (size_t)end, w);
+    const float r = f->apply(v);
+    delete f;
+    return r;
+}
+// ONE filter: type 0 triangular / 1 trapeze, warping 0 mel / 1 bark (the continuous-domain functions of
+// Math/AnalyticFunctionFactory.cc:338-341,369-373), d2c = the scaling of the discrete axis (1 / sample rate of the spectrum)
+extern "C" int ref_filter_build(int type, int warping, double center, double width, double fmin, double fmax, double d2c, int diff,
+                                int* start, int* end, float* weights, int cap) {
+    Math::UnaryAnalyticFunctionRef warp =
+            warping == 0 ? Math::nest(fb_scaling(2595.0), Math::UnaryAnalyticFunctionRef(new Math::MelWarpingCore))
+                         : Math::nest(fb_scaling(6.0), Math::nest(Math::UnaryAnalyticFunctionRef(new Math::Sinh)->invert(), fb_scaling(1.0 / 600.0)));
+    if (type == 0)
+        return Probe<Signal::SymmetricalTriangularFilterBuilder>().run(center, width, fmin, fmax, fb_scaling(d2c), warp, diff != 0, start, end, weights, cap);
+    return Probe<Signal::TrapezeFilterBuilder>().run(center, width, fmin, fmax, fb_scaling(d2c), warp, diff != 0, start, end, weights, cap);
 }
 """),
 }

@@ -7,7 +7,8 @@ once; its DEFAULT configuration (-march=native, GCC's -ffp-contract=fast) on an 
 addition into one fused multiply-add.  oracle/ref/Makefile compiles the reference both ways (libref.so: -msse3; libref_native.so:
 -msse3 -march=native) -- whole translation units where they build, and FUNCTION-TEXT pins (oracle/ref/extract_fn.py) for
 Mm::GaussDiagonalMaximumFeatureScorer::distance, Signal::Regression, Signal::FilterBank::Filter::apply,
-Signal::HammingWindowFunction::init, Mm::BatchFloatFeatureScorer::fillScoreCacheTpl and Signal::Preemphasis.
+Signal::HammingWindowFunction::init, Mm::BatchFloatFeatureScorer::fillScoreCacheTpl, Signal::Preemphasis and
+Signal::FilterBank::FilterBuilder (one filter: interval and weights).
 
 ref_contract.npz: seeded INPUTS and the OUTPUTS OF THE REFERENCE in both flavours ("<pin>_off", "<pin>_fma") for the
 contraction-sensitive pins; tests/test_contract.py holds both oracle libraries to them bit for bit, everywhere (no reference tree
@@ -224,6 +225,41 @@ def main():
         dif += ndiff(gold["pre_%s_off" % name], gold["pre_%s_fma" % name])
     report["Signal::Preemphasis (function text, Preemphasis.cc:23-74), alpha 1 / 0.97 / 0.5, blocks of 4096, one restart"] = dict(
         tried=tot, differ=dif, fma_sites="vfnmadd132ss (v[i] -= alpha * previous); none for alpha = 1, the flow files' value")
+
+    # ---- a7: FilterBuilder::create for one filter (function text): interval and weights, triangular / trapeze x mel / bark x
+    # differential unit, centres on and off the grid of the discrete axis, filters that stick out at either end and ones the builder refuses
+    import math
+    ip = C.POINTER(C.c_int)
+    for c in R:
+        R[c].ref_filter_build.restype = C.c_int
+        R[c].ref_filter_build.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, ip, ip, f32p, C.c_int]
+    params, outs = [], {c: [] for c in R}
+    for trial in range(400):
+        typ, warp, diff = int(rng2.integers(0, 2)), int(rng2.integers(0, 2)), int(rng2.integers(0, 2))
+        fs, N = float(rng2.choice([8000., 16000., 11025.])), int(rng2.choice([256, 512, 1024]))
+        B, d2c = N // 2 + 1, 1.0 / (N / fs)
+        wv = (lambda f: 2595.0 * math.log10(1 + f / 700.0)) if warp == 0 else (lambda f: 6.0 * math.asinh(f / 600.0))
+        fmaxw = wv(d2c * (B - 1))
+        width = float(rng2.uniform(0.5, 400.0)) if warp == 0 else float(rng2.uniform(0.5, 6.0))
+        center = float(rng2.uniform(-0.2 * fmaxw, 1.2 * fmaxw)) if trial % 5 else wv(d2c * int(rng2.integers(0, B)))
+        params.append([typ, warp, center, width, 0.0, fmaxw, d2c, diff])
+        for c in R:
+            st, en, w = C.c_int(0), C.c_int(0), np.zeros(600, np.float32)
+            n = R[c].ref_filter_build(typ, warp, center, width, 0.0, fmaxw, d2c, diff, C.byref(st), C.byref(en), w, 600)
+            outs[c].append((n, st.value if n >= 0 else -1, en.value if n >= 0 else -1, w[:max(n, 0)].copy()))
+    gold["fbb_params"] = np.array(params, np.float64)
+    dif = 0
+    for c in R:
+        gold["fbb_n_%s" % c] = np.array([o[0] for o in outs[c]], np.int32)
+        gold["fbb_start_%s" % c] = np.array([o[1] for o in outs[c]], np.int32)
+        gold["fbb_end_%s" % c] = np.array([o[2] for o in outs[c]], np.int32)
+        gold["fbb_w_%s" % c] = np.concatenate([o[3] for o in outs[c]]).astype(np.float32)
+    same_shape = all(np.array_equal(gold["fbb_%s_off" % k], gold["fbb_%s_fma" % k]) for k in ("n", "start", "end"))
+    dif = ndiff(gold["fbb_w_off"], gold["fbb_w_fma"]) if same_shape else -1
+    report["Signal::FilterBank::FilterBuilder::create / setStart / setEnd / setWeights + triangular / trapeze weight (function text, "
+           "Filterbank.cc:144-217,236-244,268-281,691-694), 400 filters"] = dict(
+        tried=int(len(gold["fbb_w_off"])), differ=dif, refused_by_the_builder=int(np.count_nonzero(gold["fbb_n_off"] < 0)),
+        fma_sites="none that reaches a result (the weight is one f32 x f64 product, the triangle a division)")
 
     np.savez_compressed(os.path.join(HERE, "ref_contract.npz"), **gold)
     out = os.path.join(ROOT, "profiles", "r05")

@@ -5,8 +5,9 @@ other f32 sums into fused multiply-adds; configured with -DMARCH=x86-64 it does 
 oracle/liboracle_fma.so the first (orc.h).  Both are held, bit for bit, to
   * tests/golden/ref_contract.npz -- outputs of the reference compiled both ways (tests/golden/make_contract_golden.py), everywhere;
   * oracle/_ref/libref.so / libref_native.so live on fresh inputs, where the reference tree is mounted (build container).
-Function-text pins (oracle/ref/extract_fn.py): a13 distance, f1 regression, a7 filter apply, a3 Hamming table, a18 batch-float sum, a1 preemphasis.
+Function-text pins (oracle/ref/extract_fn.py): a13 distance, f1 regression, a7 filter apply, a3 Hamming table, a18 batch-float sum, a1 preemphasis, a7 filter builder.
 """
+import ctypes as C
 import os
 
 import numpy as np
@@ -97,6 +98,32 @@ def test_preemphasis_against_the_reference_function_text(contract):
     L.orc_preemphasis(b, len(b), 0.97)
     assert np.array_equal(bits(np.concatenate([a, b])), bits(Z["pre_097_gap_%s" % contract]))
     assert np.array_equal(bits(Z["pre_1_off"]), bits(Z["pre_1_fma"])) and not np.array_equal(bits(Z["pre_097_off"]), bits(Z["pre_097_fma"]))
+
+
+def _filter_build(fn, p):
+    st, en, w = C.c_int(0), C.c_int(0), np.zeros(600, np.float32)
+    n = fn(int(p[0]), int(p[1]), float(p[2]), float(p[3]), float(p[4]), float(p[5]), float(p[6]), int(p[7]), C.byref(st), C.byref(en), w, 600)
+    return n, (st.value if n >= 0 else -1), (en.value if n >= 0 else -1), w[:max(n, 0)].copy()
+
+
+@pytest.mark.parametrize("contract", CONTRACTS)
+def test_filter_builder_against_the_reference_function_text(contract):
+    """a7: FilterBank::FilterBuilder::create for ONE filter -- where it starts (ceil, or round on an almost-integer bin), where it ends,
+    its weights (f32 shape x f64 derivative of the warping), and when the builder refuses -- triangular / trapeze, mel / bark, with and
+    without the differential unit; the analytic functions are the reference's own classes"""
+    L = Oracle(contract)
+    P = Z["fbb_params"]
+    n_w, off, refused = Z["fbb_n_%s" % contract], 0, 0
+    for i in range(len(P)):
+        n, st, en, w = _filter_build(L.orc_filter_build, P[i])
+        assert (n < 0) == (n_w[i] < 0), (contract, i)
+        if n < 0:
+            refused += 1
+            continue
+        assert n == n_w[i] and st == Z["fbb_start_%s" % contract][i] and en == Z["fbb_end_%s" % contract][i], (contract, i, P[i])
+        assert np.array_equal(bits(w), bits(Z["fbb_w_%s" % contract][off:off + n])), (contract, i, P[i])
+        off += n
+    assert refused > 10 and off == len(Z["fbb_w_%s" % contract])
 
 
 def _same_bits_or_both_nan(a, b):
@@ -195,6 +222,14 @@ def test_live_against_the_compiled_reference(contract):
         assert np.array_equal(bits(oracle_regression(w, order=order, right=2, contract=contract)[2]), bits(out))
     amp, w = np.abs(rng.standard_normal(257)).astype(np.float32), rng.uniform(0, 1, 40).astype(np.float32)
     assert bits(np.float32(L.orc_filter_apply(amp, 31, 71, w))) == bits(np.float32(R.ref_filter_apply(amp, 257, 31, 71, w)))
+    import math
+    for _ in range(300):
+        typ, warp, diff = int(rng.integers(0, 2)), int(rng.integers(0, 2)), int(rng.integers(0, 2))
+        d2c = 1.0 / (512 / 16000.0)
+        fmaxw = 2595.0 * math.log10(1 + d2c * 256 / 700.0) if warp == 0 else 6.0 * math.asinh(d2c * 256 / 600.0)
+        p = [typ, warp, float(rng.uniform(-0.1, 1.1)) * fmaxw, float(rng.uniform(0.01, 0.2)) * fmaxw, 0.0, fmaxw, d2c, diff]
+        a, b = _filter_build(R.ref_filter_build, p), _filter_build(L.orc_filter_build, p)
+        assert a[:3] == b[:3] and np.array_equal(bits(a[3]), bits(b[3])), p
     for alpha, n in ((1.0, 9001), (0.97, 9001), (0.9, 3)):
         x = (rng.standard_normal(n) * 1000).astype(np.float32)
         out, y = np.zeros_like(x), x.copy()
