@@ -28,10 +28,11 @@
  * Pinning status (see DESIGN.md "Oracle"):
  *   FFT core, framing/flush, mel warp/derivative/inverse, GMM logNorm / 1/sqrt(var):
  *       pinned bit-exactly against oracle/_ref (reference sources compiled unmodified).
- *   preemphasis, Hamming table, one filter of the bank (interval, weights, apply), GMM distance, regression, batch-float sum / minimum:
+ *   preemphasis, Hamming table, the bank's boundary (filter count, width, spacing, centres) and one filter (interval, weights, apply),
+ *   GMM distance, regression, batch-float sum / minimum:
  *       pinned bit-exactly on the reference's
  *       own function text compiled with both flag sets (oracle/ref/extract_fn.py, tests/test_contract.py).
- *   filterbank boundary (number of filters, centres), DCT, GMM max score (combine / tie rule): pinned by the known answers the
+ *   the filter bank as a whole, DCT, GMM max score (combine / tie rule): pinned by the known answers the
  *       reference produced in this container.
  *   NN forward: pinned by the reference's own unit-test vectors
  *       (Test/Nn_LinearAndActivationLayer.cc, Test/Nn_NeuralNetwork.cc).
@@ -173,6 +174,9 @@ int    orc_levinson(const float* R, int n, float* gain, float* a);
 void   orc_ar_to_cepstrum(float gain, const float* a, int na, float* c, int nc);
 void   orc_preemphasis(float* x, long n, float alpha);            /* in place, segment start */
 void   orc_hamming_window(float* w, int len); /* Signal/WindowFunction.cc:92-101: the table (len <= 1: zeros, the reference's init() fails) */
+int    orc_filter_boundary(int type, double width, double spacing, double ncp, double fmin, double fmaxw, double* width_out,
+                           double* spacing_out, double* centers, int cap); /* number of filters, final width / spacing, centres */
+double orc_filter_center(int type, size_t i, double width, double spacing, double ncp, double fmin);
 int    orc_filter_build(int type, int warping, double center, double width, double fmin, double fmaxw, double d2c, int diff, int* start,
                         int* end, float* weights, int cap); /* FilterBuilder::create for one filter: its interval and weights */
 float  orc_filter_apply(const float* in, int start, int end, const float* weights); /* one filter of the bank: sum over bins [start, end) */

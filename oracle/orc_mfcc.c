@@ -166,7 +166,7 @@ double orc_bark(double f) {
 /* AnalyticNesting::derive twice: (const(6) o g)(f) * g'(f), g' = (DerivedArcSinh o scaling)(f) * const(1 / 600) */
 double orc_bark_derivative(double f) {
     double u = (1.0 / 600.0) * f;
-    return 6.0 * (((double)1 / sqrt(u * u + (double)1)) * (1.0 / 600.0));
+    return 6.0 * (((double)1 / sqrt(ORC_FMA(u, u, (double)1))) * (1.0 / 600.0)); /* DerivedArcSinh::value: vfmadd132sd in the default build */
 }
 /* AnalyticNesting::invert twice: scaling(1 / (1 / 600)) o sinh o scaling(1 / 6) */
 double orc_bark_inverse(double b) {
@@ -280,7 +280,7 @@ int orc_filter_build(int type, int warping, double center, double width, double 
     double          inv_d2c = 1 / d2c; /* ScalingFunction::invert */
     double          ncp     = type == 1 ? 2.5 / (1.3 - (-2.5)) : 0.5;
     /* setStart */
-    double lo = center - ncp * width;
+    double lo = ORC_FMA(-ncp, width, center); /* center_ - normalizedCenterPosition() * width_: vfnmadd231sd in the default build */
     if (!(lo > fmin))
         lo = fmin; /* std::max(a, b) returns a unless a < b */
     double s = inv_d2c * W->inverse(lo);
@@ -288,7 +288,7 @@ int orc_filter_build(int type, int warping, double center, double width, double 
     if (!(s >= 0))
         return -1;
     /* setEnd */
-    double hi = center + (1.0 - ncp) * width;
+    double hi = ORC_FMA(1.0 - ncp, width, center); /* vfmadd132sd */
     if (fmaxw < hi)
         hi = fmaxw;
     double e = inv_d2c * W->inverse(hi);
@@ -319,6 +319,44 @@ int orc_filter_build(int type, int warping, double center, double width, double 
     return n;
 }
 
+/* The boundary of a bank (Signal/Filterbank.cc:428-470 Boundary::init / setSpacing / postprocessNumberOfFilters, :495-501
+ * IncludeBoundary::getNumberOfFilters, :534-540 and :546-567 StretchToCover, :584-589 EmphasizeBoundary; FilterBank::init :640-650 with
+ * warp-center-positions = true: the boundary works on the warped axis with an identity warping): type 0 stretch-to-cover / 1
+ * include-boundary / 2 emphasize-boundary.  Returns the number of filters, the width and spacing the boundary ends up with and up to
+ * `cap` centres.  PINNED on the reference's function text (oracle/ref/extract_fn.py filter_build: ref_filter_boundary). */
+double orc_filter_center(int type, size_t i, double width, double spacing, double ncp, double fmin) {
+    if (type == 0)
+        return ORC_FMA(ncp, width, ORC_FMA(spacing, (double)i, fmin)); /* StretchToCover::center: two vfmadd in the default build */
+    if (type == 1)
+        return spacing * (double)(i + 1);
+    return spacing * (double)i;
+}
+
+int orc_filter_boundary(int type, double width, double spacing, double ncp, double fmin, double fmaxw, double* width_out, double* spacing_out,
+                        double* centers, int cap) {
+    if (spacing == 0)
+        spacing = ncp * width; /* Boundary::setSpacing */
+    size_t n_filters;
+    if (type == 0) {
+        /* StretchToCover::getNumberOfFilters / init */
+        n_filters       = (size_t)floor(orc_postprocess_nfilters((fmaxw - fmin - width) / spacing + 1));
+        double coverage = ORC_FMA(spacing, (double)(n_filters - 1), width) / (fmaxw - fmin); /* vfmadd132sd */
+        if (!(n_filters == 1 && coverage > 1 && !orc_almost_equal(coverage, 1))) {
+            width /= coverage;
+            spacing /= coverage;
+        }
+    }
+    else if (type == 1) /* IncludeBoundary::getNumberOfFilters; inverseWarpingFunction_ is the identity */
+        n_filters = (size_t)ceil(orc_postprocess_nfilters(ORC_FMA(-(1 - ncp), width, fmaxw) / spacing)); /* vfnmadd132sd */
+    else /* EmphasizeBoundary::getNumberOfFilters */
+        n_filters = (size_t)floor(orc_postprocess_nfilters(fmaxw / spacing + 1));
+    *width_out   = width;
+    *spacing_out = spacing;
+    for (size_t i = 0; i < n_filters && (int)i < cap; ++i)
+        centers[i] = orc_filter_center(type, i, width, spacing, ncp, fmin);
+    return (int)n_filters;
+}
+
 static int orc_build_filterbank(orc_mfcc* h) {
     const orc_mfcc_cfg* c  = &h->cfg;
     const orc_warp mel = {orc_mel, orc_mel_derivative, orc_mel_inverse}, bark = {orc_bark, orc_bark_derivative, orc_bark_inverse};
@@ -337,22 +375,10 @@ static int orc_build_filterbank(orc_mfcc* h) {
     double spacing = c->mel_spacing;
     /* normalizedCenterPosition: symmetrical triangle 0.5, trapeze 2.5 / 3.8 */
     double ncp     = c->filter_type == 1 ? 2.5 / (1.3 - (-2.5)) : 0.5;
-    if (spacing == 0)
-        spacing = ncp * width; /* Boundary::setSpacing */
-    size_t n_filters;
-    if (c->boundary == 0) {
-        /* StretchToCover::getNumberOfFilters / init */
-        n_filters       = (size_t)floor(orc_postprocess_nfilters((fmaxw - fmin - width) / spacing + 1));
-        double coverage = (spacing * (double)(n_filters - 1) + width) / (fmaxw - fmin);
-        if (!(n_filters == 1 && coverage > 1 && !orc_almost_equal(coverage, 1))) {
-            width /= coverage;
-            spacing /= coverage;
-        }
-    }
-    else if (c->boundary == 1) /* IncludeBoundary::getNumberOfFilters; inverseWarpingFunction_ is the identity */
-        n_filters = (size_t)ceil(orc_postprocess_nfilters((fmaxw - (1 - ncp) * width) / spacing));
-    else /* EmphasizeBoundary::getNumberOfFilters */
-        n_filters = (size_t)floor(orc_postprocess_nfilters(fmaxw / spacing + 1));
+    int nf = orc_filter_boundary(c->boundary, width, spacing, ncp, fmin, fmaxw, &width, &spacing, NULL, 0);
+    if (nf < 0)
+        return -1;
+    size_t n_filters = (size_t)nf;
     h->n_filters = (int)n_filters;
     h->f_start   = (int*)calloc(n_filters, sizeof(int));
     h->f_end     = (int*)calloc(n_filters, sizeof(int));
@@ -360,13 +386,7 @@ static int orc_build_filterbank(orc_mfcc* h) {
     h->f_weights = (float*)calloc(n_filters * (size_t)B, sizeof(float));
     int off      = 0;
     for (size_t i = 0; i < n_filters; ++i) {
-        double center;
-        if (c->boundary == 0)
-            center = fmin + spacing * (double)i + ncp * width;
-        else if (c->boundary == 1)
-            center = spacing * (double)(i + 1);
-        else
-            center = spacing * (double)i;
+        double center = orc_filter_center(c->boundary, i, width, spacing, ncp, fmin);
         int start, end;
         int n = orc_filter_build(c->filter_type, c->warping, center, width, fmin, fmaxw, d2c, c->warp_differential_unit, &start, &end,
                                  h->f_weights + off, B);

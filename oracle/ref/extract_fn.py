@@ -263,8 +263,8 @@ extern "C" void ref_preemphasis(float alpha, double sample_rate, const float* x,
     # Math::AnalyticFunctionFactory::createConstant its one line (Math/AnalyticFunctionFactory.hh:231-233 forwards to
     # Math::createConstant; that header includes Core/Component.hh).  The analytic functions are the reference's own classes.
     "filter_build": (
-        "Signal/Filterbank.cc", [(27, 50), (65, 71), (144, 217), (236, 244), (268, 281), (691, 694)],
-        "2e63de787bbf33e254cc4405da6e200a05d066ca0817b44bc3368b129a83ae4d",
+        "Signal/Filterbank.cc", [(27, 50), (65, 71), (144, 217), (236, 244), (268, 281), (428, 470), (495, 501), (546, 567), (691, 694)],
+        "58ba479fc06126d6362de702f6fe1723977e20fa28fa9ac78093253cdaf64ea3",
         """#include <Core/Types.hh>
 #include <Core/Assertions.hh>
 #include <Core/ReferenceCounting.hh>
@@ -277,8 +277,9 @@ extern "C" void ref_preemphasis(float alpha, double sample_rate, const float* x,
 #include <cmath>
 #include <vector>
 namespace Math {
-struct AnalyticFunctionFactory {  // Math/AnalyticFunctionFactory.hh:231-233
+struct AnalyticFunctionFactory {  // Math/AnalyticFunctionFactory.hh:230-237
     static UnaryAnalyticFunctionRef createConstant(UnaryAnalyticFunction::Argument c) { return Math::createConstant(c); }
+    static UnaryAnalyticFunctionRef createIdentity() { return UnaryAnalyticFunctionRef(new IdentityFunction); }
 };
 }  // namespace Math
 namespace Signal {
@@ -290,7 +291,61 @@ public:
     enum NormalizationType { normalizeNone, normalizeSurface };
     class Filter;
     class FilterBuilder;
+    class Boundary;
     static bool isAlmostInteger(Frequency x);
+};
+// Signal/Filterbank.cc:366-426 without the Core::Component base
+class FilterBank::Boundary {
+protected:
+    typedef FilterBank::Frequency Frequency;
+    Frequency                      filterWidth_;
+    Frequency                      spacing_;
+    Frequency                      normalizedCenterPosition_;
+    Frequency                      minimumFrequency_;
+    Frequency                      maximumFrequency_;
+    Math::UnaryAnalyticFunctionRef warpingFunction_;
+    Math::UnaryAnalyticFunctionRef inverseWarpingFunction_;
+    void      setSpacing(Frequency Spacing);
+    bool      setWarpingFunction(Math::UnaryAnalyticFunctionRef warpingFunction);
+    Frequency postprocessNumberOfFilters(Frequency nFilters) const;
+    void      error(const char*, ...) const {}
+    Boundary() : filterWidth_(0), spacing_(0), normalizedCenterPosition_(0), minimumFrequency_(0), maximumFrequency_(0) {}
+public:
+    virtual ~Boundary() {}
+    virtual void init(Frequency filterWidth, Frequency spacing, Frequency normalizedCenterPosition);
+    virtual bool init(Frequency filterWidth, Frequency spacing, Frequency normalizedCenterPosition, Frequency minimumFrequency,
+                      Frequency maximumFrequency, Math::UnaryAnalyticFunctionRef warpingFunction);
+    Frequency         filterWidth() const { return filterWidth_; }
+    Frequency         spacing() const { return spacing_; }   // (probe only)
+    virtual Frequency center(size_t filterIndex) const = 0;
+    virtual size_t    getNumberOfFilters() const       = 0;
+};
+// the three boundary types: class bodies retyped from Signal/Filterbank.cc:482-493, 519-544, 576-590 (their one-line center() /
+// getNumberOfFilters() are INSIDE the class bodies, next to configuration constructors); IncludeBoundary::getNumberOfFilters and
+// StretchToCover::init are reference text below
+class IncludeBoundary : public FilterBank::Boundary {
+    typedef FilterBank::Boundary Precursor;
+public:
+    virtual Frequency center(size_t filterIndex) const { return warpingFunction_->value(spacing_ * (filterIndex + 1)); }
+    virtual size_t    getNumberOfFilters() const;
+};
+class StretchToCover : public FilterBank::Boundary {
+    typedef FilterBank::Boundary Precursor;
+public:
+    virtual bool init(Frequency filterWidth, Frequency spacing, Frequency normalizedCenterPosition, Frequency minimumFrequency,
+                      Frequency maximumFrequency, Math::UnaryAnalyticFunctionRef warpingFunction);
+    virtual Frequency center(size_t filterIndex) const { return minimumFrequency_ + spacing_ * filterIndex + normalizedCenterPosition_ * filterWidth_; }
+    virtual size_t    getNumberOfFilters() const {
+        return (size_t)Core::floor(postprocessNumberOfFilters((maximumFrequency_ - minimumFrequency_ - filterWidth_) / spacing_ + 1));
+    }
+};
+class EmphasizeBoundary : public FilterBank::Boundary {
+    typedef FilterBank::Boundary Precursor;
+public:
+    virtual Frequency center(size_t filterIndex) const { return warpingFunction_->value(spacing_ * filterIndex); }
+    virtual size_t    getNumberOfFilters() const {
+        return (size_t)Core::floor(postprocessNumberOfFilters(inverseWarpingFunction_->value(maximumFrequency_) / spacing_ + 1));
+    }
 };
 // Signal/Filterbank.cc:89-133 without the Core::Component base
 class FilterBank::FilterBuilder {
@@ -368,6 +423,25 @@ extern "C" float ref_filter_apply(const float* in, int n_in, int start, int end,
     const float r = f->apply(v);
     delete f;
     return r;
+}
+// The boundary of a bank (FilterBank::init, Signal/Filterbank.cc:640-650, with warp-center-positions = true, the default: the boundary
+// gets no warping function): type 0 stretch-to-cover / 1 include-boundary / 2 emphasize-boundary.  Returns the number of filters
+// (-1: init refused), the width and spacing the boundary ends up with, and up to `cap` centres.
+extern "C" int ref_filter_boundary(int type, double width, double spacing, double ncp, double fmin, double fmax, double* width_out,
+                                   double* spacing_out, double* centers, int cap) {
+    Signal::FilterBank::Boundary* b = type == 0 ? (Signal::FilterBank::Boundary*)new Signal::StretchToCover
+                                    : type == 1 ? (Signal::FilterBank::Boundary*)new Signal::IncludeBoundary
+                                                : (Signal::FilterBank::Boundary*)new Signal::EmphasizeBoundary;
+    int n = -1;
+    if (b->init(width, spacing, ncp, fmin, fmax, Math::UnaryAnalyticFunctionRef())) {
+        n            = (int)b->getNumberOfFilters();
+        *width_out   = b->filterWidth();
+        *spacing_out = b->spacing();
+        for (int i = 0; i < n && i < cap; ++i)
+            centers[i] = b->center((size_t)i);
+    }
+    delete b;
+    return n;
 }
 // ONE filter: type 0 triangular / 1 trapeze, warping 0 mel / 1 bark (the continuous-domain functions of
 // Math/AnalyticFunctionFactory.cc:338-341,369-373), d2c = the scaling of the discrete axis (1 / sample rate of the spectrum)

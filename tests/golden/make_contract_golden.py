@@ -261,6 +261,39 @@ def main():
         tried=int(len(gold["fbb_w_off"])), differ=dif, refused_by_the_builder=int(np.count_nonzero(gold["fbb_n_off"] < 0)),
         fma_sites="none that reaches a result (the weight is one f32 x f64 product, the triangle a division)")
 
+    # ---- a7: the boundary of a bank (function text for Boundary::init / setSpacing / postprocessNumberOfFilters,
+    # IncludeBoundary::getNumberOfFilters, StretchToCover::init; the one-line centre formulas are retyped class bodies): number of filters,
+    # final width and spacing, centres.  The default build fuses spacing * (n - 1) + width, the two products of the stretch-to-cover
+    # centre and max - (1 - ncp) * width
+    dp = C.POINTER(C.c_double)
+    f64p = np.ctypeslib.ndpointer(np.float64, flags="C")
+    for c in R:
+        R[c].ref_filter_boundary.restype = C.c_int
+        R[c].ref_filter_boundary.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, dp, dp, f64p, C.c_int]
+    bpar, bout = [], {c: [] for c in R}
+    for trial in range(300):
+        typ, ncp = int(rng2.integers(0, 3)), float(rng2.choice([0.5, 2.5 / 3.8]))
+        fmax = float(rng2.uniform(5, 3000))
+        width = float(rng2.uniform(0.01, 1.2)) * fmax if trial % 3 else fmax / float(rng2.integers(1, 60))
+        spacing = 0.0 if trial % 2 else float(rng2.uniform(0.005, 0.6)) * fmax
+        if trial == 0:
+            typ, ncp, fmax, width, spacing = 0, 0.5, 2595.0 * math.log10(1 + 8000.0 / 700.0), 268.258, 0.0   # mfcc.flow's bank at 16 kHz
+        bpar.append([typ, width, spacing, ncp, 0.0, fmax])
+        for c in R:
+            w, sp, cen = C.c_double(0), C.c_double(0), np.zeros(256)
+            n = R[c].ref_filter_boundary(typ, width, spacing, ncp, 0.0, fmax, C.byref(w), C.byref(sp), cen, 256)
+            bout[c].append((n, w.value, sp.value, cen[:max(0, min(n, 256))].copy()))
+    gold["fbd_params"] = np.array(bpar, np.float64)
+    for c in R:
+        gold["fbd_n_%s" % c] = np.array([o[0] for o in bout[c]], np.int32)
+        gold["fbd_ws_%s" % c] = np.array([[o[1], o[2]] for o in bout[c]], np.float64)
+        gold["fbd_centers_%s" % c] = np.concatenate([o[3] for o in bout[c]])
+    report["Signal::FilterBank::Boundary (function text, Filterbank.cc:428-470,495-501,546-567; centre formulas retyped), 300 banks"] = dict(
+        tried=int(len(gold["fbd_centers_off"]) + 2 * 300), differ=ndiff(gold["fbd_centers_off"], gold["fbd_centers_fma"]) + ndiff(gold["fbd_ws_off"], gold["fbd_ws_fma"]),
+        filter_counts_differ=int(np.count_nonzero(gold["fbd_n_off"] != gold["fbd_n_fma"])),
+        fma_sites="vfmadd132sd (coverage: spacing * (n - 1) + width), 2 x vfmadd (stretch-to-cover centre), vfnmadd132sd (include-boundary: "
+                  "max - (1 - ncp) * width); in FilterBuilder: vfnmadd231sd (setStart), vfmadd132sd (setEnd); DerivedArcSinh (bark derivative): vfmadd132sd")
+
     np.savez_compressed(os.path.join(HERE, "ref_contract.npz"), **gold)
     out = os.path.join(ROOT, "profiles", "r05")
     os.makedirs(out, exist_ok=True)

@@ -126,6 +126,30 @@ def test_filter_builder_against_the_reference_function_text(contract):
     assert refused > 10 and off == len(Z["fbb_w_%s" % contract])
 
 
+def _boundary(fn, p):
+    w, sp, cen = C.c_double(0), C.c_double(0), np.zeros(256)
+    n = fn(int(p[0]), float(p[1]), float(p[2]), float(p[3]), float(p[4]), float(p[5]), C.byref(w), C.byref(sp), cen, 256)
+    return n, w.value, sp.value, cen[:max(0, min(n, 256))].copy()
+
+
+@pytest.mark.parametrize("contract", CONTRACTS)
+def test_filter_bank_boundary_against_the_reference_function_text(contract):
+    """a7: how many filters a bank has, the width and spacing the boundary ends up with (stretch-to-cover divides both by the coverage) and
+    the centres, for the three boundary types; f64, and NOT the same in the two builds: the default build fuses spacing * (n - 1) + width
+    and the products of the stretch-to-cover centre"""
+    L = Oracle(contract)
+    P, off = Z["fbd_params"], 0
+    for i in range(len(P)):
+        n, w, sp, cen = _boundary(L.orc_filter_boundary, P[i])
+        assert n == Z["fbd_n_%s" % contract][i], (contract, i, P[i])
+        assert np.array_equal(bits(np.array([w, sp])), bits(Z["fbd_ws_%s" % contract][i])), (contract, i, P[i])
+        k = min(n, 256)
+        assert np.array_equal(bits(cen), bits(Z["fbd_centers_%s" % contract][off:off + k])), (contract, i, P[i])
+        off += k
+    assert off == len(Z["fbd_centers_%s" % contract])
+    assert not np.array_equal(bits(Z["fbd_centers_off"]), bits(Z["fbd_centers_fma"])) and np.array_equal(Z["fbd_n_off"], Z["fbd_n_fma"])
+
+
 def _same_bits_or_both_nan(a, b):
     return bool(np.all((bits(a) == bits(b)) | (np.isnan(a) & np.isnan(b))))
 
@@ -230,6 +254,13 @@ def test_live_against_the_compiled_reference(contract):
         p = [typ, warp, float(rng.uniform(-0.1, 1.1)) * fmaxw, float(rng.uniform(0.01, 0.2)) * fmaxw, 0.0, fmaxw, d2c, diff]
         a, b = _filter_build(R.ref_filter_build, p), _filter_build(L.orc_filter_build, p)
         assert a[:3] == b[:3] and np.array_equal(bits(a[3]), bits(b[3])), p
+    for _ in range(300):
+        fmax = float(rng.uniform(5, 3000))
+        p = [int(rng.integers(0, 3)), float(rng.uniform(0.01, 1.2)) * fmax, float(rng.choice([0.0, 0.05 * fmax])), float(rng.choice([0.5, 2.5 / 3.8])), 0.0, fmax]
+        a, b = _boundary(R.ref_filter_boundary, p), _boundary(L.orc_filter_boundary, p)
+        assert a[:3] == b[:3] and np.array_equal(bits(a[3]), bits(b[3])), p
+    for f in rng.uniform(0, 8000, 500):
+        assert L.orc_bark_derivative(float(f)) == R.ref_bark_derivative(float(f))
     for alpha, n in ((1.0, 9001), (0.97, 9001), (0.9, 3)):
         x = (rng.standard_normal(n) * 1000).astype(np.float32)
         out, y = np.zeros_like(x), x.copy()
