@@ -127,6 +127,8 @@ def Oracle(contract=None):
     L.orc_filter_apply.restype = C.c_float
     L.orc_filter_apply.argtypes = [f32p, C.c_int, C.c_int, f32p]
     L.orc_hamming_window.argtypes = [f32p, C.c_int]
+    L.orc_cosine_transform.restype = None
+    L.orc_cosine_transform.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, f32p, f32p, f32p]
     L.orc_filter_boundary.restype = C.c_int
     L.orc_filter_boundary.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.POINTER(C.c_double),
                                       C.POINTER(C.c_double), np.ctypeslib.ndpointer(np.float64, flags="C"), C.c_int]
@@ -260,6 +262,9 @@ def load_ref(contract="off"):
         R.ref_filter_boundary.restype = C.c_int
         R.ref_filter_boundary.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.POINTER(C.c_double),
                                           C.POINTER(C.c_double), np.ctypeslib.ndpointer(np.float64, flags="C"), C.c_int]
+    if hasattr(R, "ref_cosine_transform"):
+        R.ref_cosine_transform.restype = None
+        R.ref_cosine_transform.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, f32p, f32p, f32p]
     if hasattr(R, "ref_preemphasis"):
         R.ref_preemphasis.argtypes = [C.c_float, C.c_double, f32p, C.c_long, C.c_int, C.c_int, f32p]
     _refs[contract] = R

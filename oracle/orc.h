@@ -174,6 +174,8 @@ int    orc_levinson(const float* R, int n, float* gain, float* a);
 void   orc_ar_to_cepstrum(float gain, const float* a, int na, float* c, int nc);
 void   orc_preemphasis(float* x, long n, float alpha);            /* in place, segment start */
 void   orc_hamming_window(float* w, int len); /* Signal/WindowFunction.cc:92-101: the table (len <= 1: zeros, the reference's init() fails) */
+void   orc_cosine_table(int n_plus_one, int rows, int cols, float* table);  /* CosineTransform::initEvenAboutNminusHalf / initNplusOneData */
+void   orc_cosine_transform(int n_plus_one, int n_in, int n_out, int normalize, const float* in, float* out, float* table_out);
 int    orc_filter_boundary(int type, double width, double spacing, double ncp, double fmin, double fmaxw, double* width_out,
                            double* spacing_out, double* centers, int cap); /* number of filters, final width / spacing, centres */
 double orc_filter_center(int type, size_t i, double width, double spacing, double ncp, double fmin);

@@ -421,30 +421,59 @@ static int orc_build_filterbank(orc_mfcc* h) {
     return 0;
 }
 
-/* Signal/CosineTransform.cc:62-74 (even about N - 1/2, identity warping) */
-static void orc_build_dct(orc_mfcc* h) {
-    size_t N = (size_t)h->n_filters;
-    h->dct   = (float*)calloc((size_t)h->n_ceps * N, sizeof(float));
-    for (size_t k = 0; k < (size_t)h->n_ceps; ++k)
-        for (size_t n = 0; n < N; ++n) {
-            double omega      = M_PI * (n + 0.5) / N;
-            h->dct[k * N + n] = (float)(cos(omega * k) * 1.0);
-        }
-}
-
-/* Signal/CosineTransform.cc:46-60 (N-plus-one input data, identity warping): the inverse DFT of an even spectrum sampled at
- * N + 1 points, which turns the compressed mel spectrum into autocorrelation coefficients */
-static void orc_build_cosine_nplus1(orc_mfcc* h) {
-    size_t cols = (size_t)h->n_filters + (h->cfg.front_end == 2 ? 2 : 0), N = cols - 1, rows = (size_t)h->cfg.n_autocorrelation;
-    h->dct      = (float*)calloc(rows * cols, sizeof(float));
-    for (size_t k = 0; k < rows; ++k) {
-        h->dct[k * cols + 0] = (float)0.5;
-        h->dct[k * cols + N] = (float)(0.5 * pow(-1, (double)k));
-        for (size_t n = 1; n < N; ++n) {
-            double omega         = M_PI * n / N;
-            h->dct[k * cols + n] = (float)(cos(omega * k) * 1.0);
+/* Signal/CosineTransform.cc:62-74 (even about N - 1/2) and :46-60 (N-plus-one input data: the inverse DFT of an even spectrum sampled
+ * at N + 1 points, which turns the compressed mel spectrum into autocorrelation coefficients), identity warping (the derivative is the
+ * constant 1: `* 1.0`).  table [rows x cols] f32.  PINNED on the reference's function text (oracle/ref/extract_fn.py cosine_transform). */
+void orc_cosine_table(int n_plus_one, int rows, int cols, float* table) {
+    if (n_plus_one) {
+        size_t N = (size_t)cols - 1;
+        for (size_t k = 0; k < (size_t)rows; ++k) {
+            table[k * cols + 0] = (float)0.5;
+            table[k * cols + N] = (float)(0.5 * pow(-1, (double)k));
+            for (size_t n = 1; n < N; ++n) {
+                double omega        = M_PI * n / N;
+                table[k * cols + n] = (float)(cos(omega * k) * 1.0);
+            }
         }
     }
+    else {
+        size_t N = (size_t)cols;
+        for (size_t k = 0; k < (size_t)rows; ++k)
+            for (size_t n = 0; n < N; ++n) {
+                double omega     = M_PI * (n + 0.5) / N;
+                table[k * N + n] = (float)(cos(omega * k) * 1.0);
+            }
+    }
+}
+
+/* CosineTransform::init + apply (Signal/CosineTransform.cc:24-44,76-83): out = T * in with Math::Vector's left-to-right f32 dot product
+ * (one fused multiply-add per term in the default build), divided by N_ (f32) when `normalize` -- N_ = cols for even-about-N-minus-half,
+ * cols - 1 for N-plus-one */
+void orc_cosine_transform(int n_plus_one, int n_in, int n_out, int normalize, const float* in, float* out, float* table_out) {
+    float* T = (float*)calloc((size_t)n_out * n_in, sizeof(float));
+    orc_cosine_table(n_plus_one, n_out, n_in, T);
+    for (int k = 0; k < n_out; ++k) {
+        float acc = 0;
+        for (int n = 0; n < n_in; ++n)
+            acc = ORC_FMAF(T[(size_t)k * n_in + n], in[n], acc);
+        if (normalize)
+            acc = acc / (float)(n_plus_one ? n_in - 1 : n_in);
+        out[k] = acc;
+    }
+    if (table_out)
+        memcpy(table_out, T, (size_t)n_out * n_in * sizeof(float));
+    free(T);
+}
+
+static void orc_build_dct(orc_mfcc* h) {
+    h->dct = (float*)calloc((size_t)h->n_ceps * (size_t)h->n_filters, sizeof(float));
+    orc_cosine_table(0, h->n_ceps, h->n_filters, h->dct);
+}
+
+static void orc_build_cosine_nplus1(orc_mfcc* h) {
+    size_t cols = (size_t)h->n_filters + (h->cfg.front_end == 2 ? 2 : 0), rows = (size_t)h->cfg.n_autocorrelation;
+    h->dct      = (float*)calloc(rows * cols, sizeof(float));
+    orc_cosine_table(1, (int)rows, (int)cols, h->dct);
 }
 
 /* Math::LevinsonLeastSquares (Math/LevinsonLse.cc:35-70): f64 recursion on f32 autocorrelation values; note the f32

@@ -455,6 +455,73 @@ extern "C" int ref_filter_build(int type, int warping, double center, double wid
     return Probe<Signal::TrapezeFilterBuilder>().run(center, width, fmin, fmax, fb_scaling(d2c), warp, diff != 0, start, end, weights, cap);
 }
 """),
+    # Signal::CosineTransform (SURVEY section 8 row a10): constructor, init, initNplusOneData, initEvenAboutNminusHalf and apply -- the
+    # class the node wraps.  Its declaration (Signal/CosineTransform.hh:26-78) sits in a header that includes Flow/StringExpressionNode.hh
+    # (-> Core/Configuration.hh, boost): re-declared member for member, plus one accessor for the table.  Math::Matrix / Math::Vector and
+    # the analytic functions are the reference's own headers.
+    "cosine_transform": (
+        "Signal/CosineTransform.cc", [(20, 83)],
+        "9e0dcc07fa42fe003f2fe42cc32da4109d1f528165a84bfa9908b1a70be8f685",
+        """#include <Core/Types.hh>
+#include <Core/Assertions.hh>
+#include <Math/AnalyticFunction.hh>
+#include <Math/SimpleAnalyticFunctions.hh>
+#include <Math/Matrix.hh>
+#include <algorithm>
+#include <cmath>
+#include <functional>
+#include <vector>
+namespace Math {
+struct AnalyticFunctionFactory {  // Math/AnalyticFunctionFactory.hh:230-237
+    static UnaryAnalyticFunctionRef createConstant(UnaryAnalyticFunction::Argument c) { return Math::createConstant(c); }
+    static UnaryAnalyticFunctionRef createIdentity() { return UnaryAnalyticFunctionRef(new IdentityFunction); }
+};
+}  // namespace Math
+namespace Signal {
+class CosineTransform {
+public:
+    typedef f32 Value;
+    enum InputType { NplusOneData, evenAboutNminusHalf };
+private:
+    Math::Matrix<Value> transformation_;
+    size_t              N_;
+    bool                normalize_;
+    void initNplusOneData(size_t inputSize, size_t outputSize, Math::UnaryAnalyticFunctionRef warpingFunction,
+                          Math::UnaryAnalyticFunctionRef derivedWarpingFunction);
+    void initEvenAboutNminusHalf(size_t inputSize, size_t outputSize, Math::UnaryAnalyticFunctionRef warpingFunction,
+                                 Math::UnaryAnalyticFunctionRef derivedWarpingFunction);
+public:
+    CosineTransform();
+    void init(InputType inputType, size_t inputSize, size_t outputSize, bool normalize = false) {
+        init(inputType, inputSize, outputSize, normalize, Math::AnalyticFunctionFactory::createIdentity(), true);
+    }
+    void init(InputType inputType, size_t inputSize, size_t outputSize, bool normalize, Math::UnaryAnalyticFunctionRef,
+              bool shouldWarpDifferentialUnit);
+    void   apply(const std::vector<Value>& in, std::vector<Value>& out) const;
+    size_t inputSize() const { return transformation_.nColumns(); }
+    const Math::Matrix<Value>& table() const { return transformation_; }  // (probe only)
+};
+}  // namespace Signal
+using namespace Signal;
+// ---- reference text, %(file)s:%(ranges)s ----
+""",
+        """
+// ---- end of reference text ----
+// n_plus_one: input type N-plus-one (else even-about-N-minus-half); identity warping with the differential unit, as the node's default
+extern "C" void ref_cosine_transform(int n_plus_one, int n_in, int n_out, int normalize, const float* in, float* out, float* table_out) {
+    Signal::CosineTransform t;
+    t.init(n_plus_one ? Signal::CosineTransform::NplusOneData : Signal::CosineTransform::evenAboutNminusHalf, (size_t)n_in, (size_t)n_out,
+           normalize != 0);
+    std::vector<f32> v(in, in + n_in), o;
+    t.apply(v, o);
+    for (int k = 0; k < n_out; ++k)
+        out[k] = o[k];
+    if (table_out)
+        for (int k = 0; k < n_out; ++k)
+            for (int n = 0; n < n_in; ++n)
+                table_out[(size_t)k * n_in + n] = t.table()[k][n];
+}
+"""),
 }
 
 

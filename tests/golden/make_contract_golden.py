@@ -294,6 +294,28 @@ def main():
         fma_sites="vfmadd132sd (coverage: spacing * (n - 1) + width), 2 x vfmadd (stretch-to-cover centre), vfnmadd132sd (include-boundary: "
                   "max - (1 - ncp) * width); in FilterBuilder: vfnmadd231sd (setStart), vfmadd132sd (setEnd); DerivedArcSinh (bark derivative): vfmadd132sd")
 
+    # ---- a10: Signal::CosineTransform (function text, the whole class): the two tables and apply with and without the division by N
+    for c in R:
+        R[c].ref_cosine_transform.restype = None
+        R[c].ref_cosine_transform.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, f32p, f32p, f32p]
+    ct_cases = [(0, 40, 40, 0), (0, 20, 16, 0), (1, 22, 20, 1), (1, 17, 13, 1), (0, 33, 12, 1), (1, 2, 2, 0), (0, 7, 7, 0)]
+    gold["ct_cases"] = np.array(ct_cases, np.int32)
+    dt = do = nt = no = 0
+    for i, (np1, n_in, n_out, norm) in enumerate(ct_cases):
+        x = (rng2.standard_normal((8, n_in)) * 5).astype(np.float32)
+        gold["ct_in_%d" % i] = x
+        for c in R:
+            out, tab = np.zeros((8, n_out), np.float32), np.zeros(n_out * n_in, np.float32)
+            for r in range(8):
+                R[c].ref_cosine_transform(np1, n_in, n_out, norm, x[r], out[r], tab)
+            gold["ct_out_%d_%s" % (i, c)], gold["ct_tab_%d_%s" % (i, c)] = out, tab
+        dt += ndiff(gold["ct_tab_%d_off" % i], gold["ct_tab_%d_fma" % i])
+        do += ndiff(gold["ct_out_%d_off" % i], gold["ct_out_%d_fma" % i])
+        nt += n_out * n_in
+        no += 8 * n_out
+    report["Signal::CosineTransform tables (function text, CosineTransform.cc:20-83)"] = dict(tried=nt, differ=dt)
+    report["Signal::CosineTransform::apply (the same pin)"] = dict(tried=no, differ=do, fma_sites="vfmadd231ss (Math::Vector's dot product)")
+
     np.savez_compressed(os.path.join(HERE, "ref_contract.npz"), **gold)
     out = os.path.join(ROOT, "profiles", "r05")
     os.makedirs(out, exist_ok=True)

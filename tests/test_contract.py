@@ -5,7 +5,7 @@ other f32 sums into fused multiply-adds; configured with -DMARCH=x86-64 it does 
 oracle/liboracle_fma.so the first (orc.h).  Both are held, bit for bit, to
   * tests/golden/ref_contract.npz -- outputs of the reference compiled both ways (tests/golden/make_contract_golden.py), everywhere;
   * oracle/_ref/libref.so / libref_native.so live on fresh inputs, where the reference tree is mounted (build container).
-Function-text pins (oracle/ref/extract_fn.py): a13 distance, f1 regression, a7 filter apply, a3 Hamming table, a18 batch-float sum, a1 preemphasis, a7 filter builder.
+Function-text pins (oracle/ref/extract_fn.py): a13 distance, f1 regression, a7 filter apply, a3 Hamming table, a18 batch-float sum, a1 preemphasis, a7 filter builder and boundary, a10 cosine transform.
 """
 import ctypes as C
 import os
@@ -150,6 +150,22 @@ def test_filter_bank_boundary_against_the_reference_function_text(contract):
     assert not np.array_equal(bits(Z["fbd_centers_off"]), bits(Z["fbd_centers_fma"])) and np.array_equal(Z["fbd_n_off"], Z["fbd_n_fma"])
 
 
+@pytest.mark.parametrize("contract", CONTRACTS)
+def test_cosine_transform_against_the_reference_function_text(contract):
+    """a10: Signal::CosineTransform, the whole class -- both tables (even about N - 1/2: the MFCC's DCT; N plus one: the autocorrelation of
+    MF-PLP / PLP) and apply, with and without the division by N"""
+    L = Oracle(contract)
+    for i, (np1, n_in, n_out, norm) in enumerate(Z["ct_cases"]):
+        x = Z["ct_in_%d" % i]
+        tab = np.zeros(int(n_out) * int(n_in), np.float32)
+        for r in range(len(x)):
+            out = np.zeros(int(n_out), np.float32)
+            L.orc_cosine_transform(int(np1), int(n_in), int(n_out), int(norm), np.ascontiguousarray(x[r]), out, tab)
+            assert np.array_equal(bits(out), bits(Z["ct_out_%d_%s" % (i, contract)][r])), (contract, i, r)
+        assert np.array_equal(bits(tab), bits(Z["ct_tab_%d_%s" % (i, contract)])), (contract, i)
+        assert np.array_equal(bits(Z["ct_tab_%d_off" % i]), bits(Z["ct_tab_%d_fma" % i]))   # the tables do not depend on the build
+
+
 def _same_bits_or_both_nan(a, b):
     return bool(np.all((bits(a) == bits(b)) | (np.isnan(a) & np.isnan(b))))
 
@@ -259,6 +275,12 @@ def test_live_against_the_compiled_reference(contract):
         p = [int(rng.integers(0, 3)), float(rng.uniform(0.01, 1.2)) * fmax, float(rng.choice([0.0, 0.05 * fmax])), float(rng.choice([0.5, 2.5 / 3.8])), 0.0, fmax]
         a, b = _boundary(R.ref_filter_boundary, p), _boundary(L.orc_filter_boundary, p)
         assert a[:3] == b[:3] and np.array_equal(bits(a[3]), bits(b[3])), p
+    for np1, n_in, n_out, norm in ((0, 40, 40, 0), (1, 22, 20, 1), (0, 9, 3, 1)):
+        x = (rng.standard_normal(n_in) * 4).astype(np.float32)
+        oa, ob, ta, tb = np.zeros(n_out, np.float32), np.zeros(n_out, np.float32), np.zeros(n_out * n_in, np.float32), np.zeros(n_out * n_in, np.float32)
+        R.ref_cosine_transform(np1, n_in, n_out, norm, x, oa, ta)
+        L.orc_cosine_transform(np1, n_in, n_out, norm, x, ob, tb)
+        assert np.array_equal(bits(oa), bits(ob)) and np.array_equal(bits(ta), bits(tb))
     for f in rng.uniform(0, 8000, 500):
         assert L.orc_bark_derivative(float(f)) == R.ref_bark_derivative(float(f))
     for alpha, n in ((1.0, 9001), (0.97, 9001), (0.9, 3)):
