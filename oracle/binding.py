@@ -265,6 +265,9 @@ def load_ref(contract="off"):
     if hasattr(R, "ref_cosine_transform"):
         R.ref_cosine_transform.restype = None
         R.ref_cosine_transform.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, f32p, f32p, f32p]
+    if hasattr(R, "ref_ar_to_cepstrum"):
+        R.ref_ar_to_cepstrum.restype = None
+        R.ref_ar_to_cepstrum.argtypes = [C.c_float, f32p, C.c_int, f32p, C.c_int]
     if hasattr(R, "ref_preemphasis"):
         R.ref_preemphasis.argtypes = [C.c_float, C.c_double, f32p, C.c_long, C.c_int, C.c_int, f32p]
     _refs[contract] = R
@@ -628,10 +631,10 @@ def ref_levinson(R):
     return _levinson(load_ref().ref_levinson, R)
 
 
-def oracle_ar_to_cepstrum(gain, a, nc):
+def oracle_ar_to_cepstrum(gain, a, nc, contract=None):
     a = np.ascontiguousarray(a, dtype=np.float32)
     c = np.zeros(nc, np.float32)
-    L = Oracle()
+    L = Oracle(contract)
     L.orc_ar_to_cepstrum.restype = None
     L.orc_ar_to_cepstrum.argtypes = [C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
     L.orc_ar_to_cepstrum(float(gain), a.ctypes.data, len(a), c.ctypes.data, nc)

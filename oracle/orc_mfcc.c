@@ -513,7 +513,7 @@ int orc_levinson(const float* R, int n, float* gain, float* a) {
     return 1;
 }
 
-/* Signal/AutoregressionToCepstrum.cc:21-35.  log(gain) resolves to the double overload in that translation unit (only <cmath>
+/* Signal/AutoregressionToCepstrum.cc:21-35 (PINNED on the function text in both builds).  log(gain) resolves to the double overload in that translation unit (only <cmath>
  * is in its include closure), integer factors are converted to f32, products run left to right in f32. */
 void orc_ar_to_cepstrum(float gain, const float* a, int na, float* c, int nc) {
     (void)na;
@@ -523,8 +523,8 @@ void orc_ar_to_cepstrum(float gain, const float* a, int na, float* c, int nc) {
         c[n] = (float)n * a[n - 1];
         for (int k = 1; k < n; ++k) {
             float t = (float)(n - k) * c[n - k];
-            t       = t * a[k - 1];
-            c[n]    = c[n] + t;
+            c[n]    = ORC_FMAF(t, a[k - 1], c[n]); /* c[n] += (n - k) * c[n - k] * a[k - 1]: the second product is fused in the default build
+                                                      (vfmadd132ss; function-text pin ar_to_cepstrum) */
         }
         c[n] = c[n] / (-(float)n);
     }

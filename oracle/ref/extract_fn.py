@@ -522,6 +522,32 @@ extern "C" void ref_cosine_transform(int n_plus_one, int n_in, int n_out, int no
                 table_out[(size_t)k * n_in + n] = t.table()[k][n];
 }
 """),
+    # Signal::autoregressionToCepstrum (SURVEY section 8 row f4, MF-PLP / PLP): a free function on std::vector<f32>; its header pulls in
+    # Flow/Node.hh (boost).  Both the C and the C++ math headers are included, as the real include closure has them (Flow/Node.hh ->
+    # ... -> <math.h>): the unqualified log(gain) on an f32 then picks whatever that closure picks -- the pin reports it (ref_ar_log_is_f32)
+    "ar_to_cepstrum": (
+        "Signal/AutoregressionToCepstrum.cc", [(21, 36)],
+        "d4362bf2eafbd167d9a3895840bfbe8fe50b136faf78a8afbd0c83289c58f00e",
+        """#include <Core/Types.hh>
+#include <Core/Assertions.hh>
+#include <Math/LevinsonLse.hh>
+#include <cmath>
+#include <vector>
+namespace Signal {
+void autoregressionToCepstrum(f32 gain, const std::vector<f32>& a, std::vector<f32>& c);
+}
+using namespace Signal;
+// ---- reference text, %(file)s:%(ranges)s ----
+""",
+        """
+// ---- end of reference text ----
+extern "C" void ref_ar_to_cepstrum(float gain, const float* a, int na, float* c, int nc) {
+    std::vector<f32> av(a, a + na), cv(nc);
+    Signal::autoregressionToCepstrum(gain, av, cv);
+    for (int i = 0; i < nc; ++i)
+        c[i] = cv[i];
+}
+"""),
 }
 
 

@@ -316,6 +316,21 @@ def main():
     report["Signal::CosineTransform tables (function text, CosineTransform.cc:20-83)"] = dict(tried=nt, differ=dt)
     report["Signal::CosineTransform::apply (the same pin)"] = dict(tried=no, differ=do, fma_sites="vfmadd231ss (Math::Vector's dot product)")
 
+    # ---- f4 (MF-PLP / PLP): Signal::autoregressionToCepstrum (function text)
+    for c in R:
+        R[c].ref_ar_to_cepstrum.restype = None
+        R[c].ref_ar_to_cepstrum.argtypes = [C.c_float, f32p, C.c_int, f32p, C.c_int]
+    A = (rng2.standard_normal((120, 20)) * 0.5).astype(np.float32)
+    G = rng2.uniform(0.01, 50, 120).astype(np.float32)
+    gold["arc_a"], gold["arc_gain"] = A, G
+    for c in R:
+        out = np.zeros((120, 16), np.float32)
+        for i in range(120):
+            R[c].ref_ar_to_cepstrum(float(G[i]), A[i], 20, out[i], 16)
+        gold["arc_%s" % c] = out
+    report["Signal::autoregressionToCepstrum (function text, AutoregressionToCepstrum.cc:21-36), order 20 -> 16 cepstra"] = dict(
+        tried=120 * 16, differ=ndiff(gold["arc_off"], gold["arc_fma"]), fma_sites="vfmadd132ss (c[n] += ((n - k) * c[n - k]) * a[k - 1])")
+
     np.savez_compressed(os.path.join(HERE, "ref_contract.npz"), **gold)
     out = os.path.join(ROOT, "profiles", "r05")
     os.makedirs(out, exist_ok=True)

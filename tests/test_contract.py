@@ -5,7 +5,7 @@ other f32 sums into fused multiply-adds; configured with -DMARCH=x86-64 it does 
 oracle/liboracle_fma.so the first (orc.h).  Both are held, bit for bit, to
   * tests/golden/ref_contract.npz -- outputs of the reference compiled both ways (tests/golden/make_contract_golden.py), everywhere;
   * oracle/_ref/libref.so / libref_native.so live on fresh inputs, where the reference tree is mounted (build container).
-Function-text pins (oracle/ref/extract_fn.py): a13 distance, f1 regression, a7 filter apply, a3 Hamming table, a18 batch-float sum, a1 preemphasis, a7 filter builder and boundary, a10 cosine transform.
+Function-text pins (oracle/ref/extract_fn.py): a13 distance, f1 regression, a7 filter apply, a3 Hamming table, a18 batch-float sum, a1 preemphasis, a7 filter builder and boundary, a10 cosine transform, f4 AR-to-cepstrum.
 """
 import ctypes as C
 import os
@@ -164,6 +164,17 @@ def test_cosine_transform_against_the_reference_function_text(contract):
             assert np.array_equal(bits(out), bits(Z["ct_out_%d_%s" % (i, contract)][r])), (contract, i, r)
         assert np.array_equal(bits(tab), bits(Z["ct_tab_%d_%s" % (i, contract)])), (contract, i)
         assert np.array_equal(bits(Z["ct_tab_%d_off" % i]), bits(Z["ct_tab_%d_fma" % i]))   # the tables do not depend on the build
+
+
+@pytest.mark.parametrize("contract", CONTRACTS)
+def test_autoregression_to_cepstrum_against_the_reference_function_text(contract):
+    """f4 (MF-PLP / PLP): Signal::autoregressionToCepstrum; the default build fuses the second product of c[n] += (n - k) c[n - k] a[k - 1]"""
+    from oracle.binding import oracle_ar_to_cepstrum
+    A, G = Z["arc_a"], Z["arc_gain"]
+    for i in range(len(A)):
+        got = oracle_ar_to_cepstrum(float(G[i]), A[i], 16, contract=contract)
+        assert np.array_equal(bits(got), bits(Z["arc_%s" % contract][i])), (contract, i)
+    assert not np.array_equal(bits(Z["arc_off"]), bits(Z["arc_fma"]))
 
 
 def _same_bits_or_both_nan(a, b):
