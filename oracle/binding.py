@@ -268,6 +268,10 @@ def load_ref(contract="off"):
     if hasattr(R, "ref_ar_to_cepstrum"):
         R.ref_ar_to_cepstrum.restype = None
         R.ref_ar_to_cepstrum.argtypes = [C.c_float, f32p, C.c_int, f32p, C.c_int]
+    if hasattr(R, "ref_gammatone"):
+        R.ref_gammatone.restype = C.c_int
+        R.ref_gammatone.argtypes = [C.c_double, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_double, C.c_char_p, f32p,
+                                    C.c_long, C.c_int, f32p, f32p, f32p]
     if hasattr(R, "ref_preemphasis"):
         R.ref_preemphasis.argtypes = [C.c_float, C.c_double, f32p, C.c_long, C.c_int, C.c_int, f32p]
     _refs[contract] = R
@@ -753,8 +757,8 @@ def oracle_time_window_frames(n, length, shift):
 
 
 class OracleGammatone:
-    def __init__(self, cfg=None, **kw):
-        self.L = Oracle()
+    def __init__(self, cfg=None, contract=None, **kw):
+        self.L = Oracle(contract)
         L = self.L
         L.orc_gammatone_create.restype = C.c_void_p
         L.orc_gammatone_create.argtypes = [C.POINTER(GammatoneCfg)]

@@ -118,7 +118,8 @@ double orc_equal_loudness(double f);
 double orc_equal_loudness_4khz(double f);
 double       orc_mfcc_mel_max(const orc_mfcc* h);         /* warped maximum frequency */
 
-/* ---------------------------------------------------------------- gammatone front-end (orc_gammatone.c; parity unpinned) */
+/* ---------------------------------------------------------------- gammatone front-end (orc_gammatone.c; signal-gammatone itself pinned on the
+ * reference's function text in both builds, the integration nodes' arithmetic unpinned) */
 typedef struct {
     double sample_rate;
     int    cascade;          /* signal-gammatone cascade (node default 4) */

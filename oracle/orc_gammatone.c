@@ -9,8 +9,10 @@
  *   signal-cosine-transform     Signal/CosineTransform.cc:62-83
  *   Hanning / rectangular       Signal/WindowFunction.cc:66-72,103-120
  *
- * PARITY UNPINNED: GammaTone.cc, TemporalIntegration.cc and SpectralIntegration.cc all include Flow node headers
- * (Core/Configuration.hh -> boost) and cannot be compiled here; no .flow file or test vector for them ships with the reference.
+ * signal-gammatone (WarpingFunction + GammaTone: filter design and cascade) is PINNED on the reference's function text in both builds
+ * (oracle/ref/extract_fn.py gammatone, tests/test_contract.py).  TemporalIntegration.cc and SpectralIntegration.cc remain PARITY
+ * UNPINNED beyond their framing: they include Flow node headers (Core/Configuration.hh -> boost), and no .flow file or test vector for
+ * them ships with the reference.
  * Arithmetic types follow the source literally: the class members are f32, the unqualified exp / cos / sin / log10 / pow / log /
  * fabs calls resolve to the double overloads with the headers this translation unit sees (checked with g++ on the reference's
  * Flow/Vector.hh + Math/Complex.hh + Core/Utility.hh: sizeof(exp(1.0f)) == 8), std::complex<f32> division / abs are libgcc's
@@ -54,9 +56,9 @@ static void orc_gt_warp_init(orc_gt_warp* w) {
         w->brk    = 6600.0f;
         w->maxf   = 8000.0f;
     }
-    w->beta = (w->factor * w->brk - w->maxf) / (w->brk - w->maxf);
+    w->beta = ORC_FMAF(w->factor, w->brk, -w->maxf) / (w->brk - w->maxf); /* vfmsub132ss in the default build */
     w->b    = w->maxf * (1 - w->beta);
-    w->wbrk = w->beta * w->brk + w->b; /* warping(freqBreak_): `f < freqBreak_` is false, so the upper branch */
+    w->wbrk = ORC_FMAF(w->beta, w->brk, w->b); /* warping(freqBreak_): `f < freqBreak_` is false, so the upper branch; vfmadd */
 }
 
 static float orc_gt_inverse_warping(const orc_gt_warp* w, float f) {
@@ -115,7 +117,7 @@ orc_gammatone* orc_gammatone_create(const orc_gammatone_cfg* c) {
     float xMax  = log10(maxFreq / g[0] + g[1]) / g[2];
     float scale = (xMax - xMin) / (float)(unsigned)(h->channels - 1);
     for (unsigned i = 0; i < (unsigned)h->channels; i++) {
-        float exponent = g[2] * (xMin + i * scale);
+        float exponent = g[2] * ORC_FMAF((float)(unsigned)i, scale, xMin); /* xMin + i * scale: vfmadd132ss in the default build */
         h->cf[i]       = orc_gt_inverse_warping(&w, g[0] * (pow(10.0, exponent) - g[1]));
     }
     /* initBandWidths (:166-175) */
@@ -245,14 +247,12 @@ long orc_gammatone_run(const orc_gammatone* h, const float* pcm, long n_samples,
             const float* co = h->coef + ch * 4;
             float        o  = pcm[i];
             for (int c = 0; c < K; ++c) {
-                float p1 = co[2] * b0[ch * K + c];
-                o        = o - p1;
-                float p2 = co[3] * b1[ch * K + c];
-                o        = o - p2;
+                /* the default build: two vfnmadd132ss, one vmulss, one vfmadd132ss (the SECOND product of out * a0 + a1 * buffer) */
+                o        = ORC_FMAF(-co[2], b0[ch * K + c], o);
+                o        = ORC_FMAF(-co[3], b1[ch * K + c], o);
                 float wn = o;
                 o        = o * co[0];
-                float p3 = co[1] * b0[ch * K + c];
-                o        = o + p3;
+                o        = ORC_FMAF(co[1], b0[ch * K + c], o);
                 b1[ch * K + c] = b0[ch * K + c];
                 b0[ch * K + c] = wn;
             }

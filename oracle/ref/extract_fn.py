@@ -548,6 +548,135 @@ extern "C" void ref_ar_to_cepstrum(float gain, const float* a, int na, float* c,
         c[i] = cv[i];
 }
 """),
+    # Signal::WarpingFunction and Signal::GammaTone (SURVEY section 8 row f4, the gammatone front end): everything of both classes that is
+    # defined in GammaTone.cc -- the design of the filter bank (centre frequencies on the Greenwood / ERB scale through the two-piece
+    # warping, bandwidths, the four coefficients of a channel: f32 / f64 mixed arithmetic on unqualified libm calls) and the cascade
+    # apply() with its state.  The class declarations (Signal/GammaTone.hh:20-53,79-212, re-declared member for member with two probe
+    # accessors) sit behind Flow/StringExpressionNode.hh (boost).  Driven as GammaToneNode drives it (GammaTone.cc:244-252,283-284).
+    "gammatone": (
+        "Signal/GammaTone.cc", [(20, 223)],
+        "c1894cc0529aa5c2246e2dbf276c1a45e6b8cb0c6e24eae1ceafd4a4b2673daf",
+        """#include <Core/Types.hh>
+#include <Flow/Data.hh>
+#include <Flow/Vector.hh>
+#include <Math/Complex.hh>
+#include <cmath>
+#include <complex>
+#include <iostream>
+#include <sstream>
+#include <vector>
+namespace Signal {
+class WarpingFunction {
+private:
+    f32  warpingFactor_;
+    f32  freqBreak_, maxFreq_;
+    f32  beta_, b_;
+    f32  warpedFreqBreak_;
+    bool needInit_;
+    void init();
+public:
+    WarpingFunction(f32 warpingFactor, f32 freqBreak, f32 maxFreq);
+    void setWarpingFactor(f32 warpingFactor) { warpingFactor_ = warpingFactor; reset(); }
+    void setFreqBreak(f32 freqBreak) { freqBreak_ = freqBreak; reset(); }
+    void setMaxFreq(f32 maxFreq) { maxFreq_ = maxFreq; reset(); }
+    bool checkParam();
+    void reset() { needInit_ = true; }
+    f32  warping(f32 f);
+    f32  inverseWarping(f32 f);
+};
+class GammaTone {
+public:
+    struct Coefficient { f32 a0, a1, b1, b2; };
+    enum CenterFrequencyModeType { Human, Erb };
+private:
+    WarpingFunction         warp_;
+    f32                     minFreq_;
+    f32                     maxFreq_;
+    f32                     l_, q_;
+    CenterFrequencyModeType centerFrequencyMode_;
+    u32                     channels_;
+    Flow::Time              sampleRate_;
+    u32                     cascade_;
+    bool                    needInit_;
+    std::vector<std::vector<std::vector<f32>>> buffer_;
+    std::vector<f32>                           centerFrequencyList_;
+    std::vector<Coefficient>                   coefficients_;
+    std::vector<f32>                           bandWidthList_;
+    void initializeCenterFrequencyList();
+    void initBandWidths();
+    void initCoefficients();
+    f32  invGreenWoodFunction(f32 cf, const std::vector<f32>& parameters);
+public:
+    void setCascade(const u32& cascade) { if (cascade_ != cascade) { cascade_ = cascade; reset(); } }
+    void setCenterFrequencyMode(CenterFrequencyModeType m) { if (centerFrequencyMode_ != m) { centerFrequencyMode_ = m; reset(); } }
+    void setMinFreq(const f32& minFreq) { if (minFreq_ != minFreq) { minFreq_ = minFreq; reset(); } }
+    void setMaxFreq(const f32& maxFreq) { if (maxFreq_ != maxFreq) { maxFreq_ = maxFreq; reset(); } }
+    void setChannels(const u32& channels) { if (channels_ != channels) { channels_ = channels; reset(); } }
+    void setSampleRate(const Flow::Time& sampleRate) { if (sampleRate_ != sampleRate) { sampleRate_ = sampleRate; reset(); } }
+    void setL(const f32& l) { if (l_ != l) { l_ = l; reset(); } }
+    void setQ(const f32& q) { if (q_ != q) { q_ = q; reset(); } }
+    void setWarpWarpingFactor(const f32& warpingFactor) { warp_.setWarpingFactor(warpingFactor); reset(); }
+    void setWarpFreqBreak(const f32& freqBreak) { warp_.setFreqBreak(freqBreak); reset(); }
+    void setWarpMaxFreq(const f32& maxFreq) { warp_.setMaxFreq(maxFreq); reset(); }
+    GammaTone();
+    virtual ~GammaTone() {}
+    virtual void init();
+    void reset() { needInit_ = true; }
+    bool checkParam() { return warp_.checkParam(); }
+    void apply(const Flow::Vector<f32>& in, Flow::Vector<Flow::Vector<f32>>& out);
+    const std::vector<f32>&         centerFrequencies() const { return centerFrequencyList_; }  // (probe only)
+    const std::vector<Coefficient>& coefficients() const { return coefficients_; }               // (probe only)
+};
+}  // namespace Signal
+using namespace Signal;
+// ---- reference text, %(file)s:%(ranges)s ----
+""",
+        """
+// ---- end of reference text ----
+// pcm [n] in blocks of `block` samples; cf [channels], coef [channels x 4] (a0 a1 b1 b2), filtered [n x channels].  Returns -1 where
+// GammaToneNode::init would report an error (checkParam).
+extern "C" int ref_gammatone(double sample_rate, int cascade, double minfreq, double maxfreq, double q, int channels, int cfmode,
+                             double warp_freqbreak, const char* warping_factor, const float* pcm, long n, int block, float* cf, float* coef,
+                             float* filtered) {
+    Signal::GammaTone g;
+    g.setCenterFrequencyMode(Signal::GammaTone::CenterFrequencyModeType(cfmode));
+    g.setMinFreq(minfreq);
+    g.setMaxFreq(maxfreq);
+    g.setQ(q);
+    g.setChannels(channels);
+    g.setCascade(cascade);
+    g.setWarpFreqBreak(warp_freqbreak);
+    g.setSampleRate(sample_rate);
+    g.setWarpMaxFreq(sample_rate / 2);
+    {
+        f32                warpingValue;
+        std::istringstream iss(warping_factor);
+        iss >> warpingValue;
+        g.setWarpWarpingFactor(warpingValue);
+    }
+    if (!g.checkParam())
+        return -1;
+    for (long i0 = 0; i0 < n || i0 == 0; i0 += block) {
+        const long len = n - i0 < block ? n - i0 : block;
+        Flow::Vector<f32>               in(pcm + i0, pcm + i0 + (len > 0 ? len : 0));
+        Flow::Vector<Flow::Vector<f32>> out;
+        g.apply(in, out);
+        for (long i = 0; i < len; ++i)
+            for (int ch = 0; ch < channels; ++ch)
+                filtered[(size_t)(i0 + i) * channels + ch] = out[i][ch];
+        if (n == 0)
+            break;
+    }
+    for (int ch = 0; ch < channels; ++ch) {
+        cf[ch]           = g.centerFrequencies()[ch];
+        coef[4 * ch]     = g.coefficients()[ch].a0;
+        coef[4 * ch + 1] = g.coefficients()[ch].a1;
+        coef[4 * ch + 2] = g.coefficients()[ch].b1;
+        coef[4 * ch + 3] = g.coefficients()[ch].b2;
+    }
+    return 0;
+}
+"""),
 }
 
 

@@ -331,6 +331,34 @@ def main():
     report["Signal::autoregressionToCepstrum (function text, AutoregressionToCepstrum.cc:21-36), order 20 -> 16 cepstra"] = dict(
         tried=120 * 16, differ=ndiff(gold["arc_off"], gold["arc_fma"]), fma_sites="vfmadd132ss (c[n] += ((n - k) * c[n - k]) * a[k - 1])")
 
+    # ---- f4: signal-gammatone (function text: WarpingFunction + GammaTone, design and cascade), blocks of 256 samples
+    for c in R:
+        R[c].ref_gammatone.restype = C.c_int
+        R[c].ref_gammatone.argtypes = [C.c_double, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_double, C.c_char_p, f32p,
+                                       C.c_long, C.c_int, f32p, f32p, f32p]
+    # (sample rate, cascade, minfreq, maxfreq, q, channels, cfmode, warp-freqbreak, warping-factor)
+    gt_cases = [(16000.0, 4, 100.0, 6000.0, 9.264491981582191, 12, 0, 6600.0, "1"), (8000.0, 3, 80.0, 3800.0, 9.264491981582191, 10, 1, 3300.0, "1"),
+                (16000.0, 4, 100.0, 7500.0, 7.5, 16, 0, 6600.0, "0.9"), (16000.0, 1, 50.0, 6000.0, 9.264491981582191, 5, 1, 6600.0, "1.1")]
+    gold["gt_cases"] = np.array([[v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], float(v[8])] for v in gt_cases], np.float64)
+    x = (rng2.standard_normal(700) * 2000).astype(np.float32)
+    gold["gt_x"] = x
+    dcf = dco = dfl = nfl = 0
+    for i, v in enumerate(gt_cases):
+        ch = v[5]
+        for c in R:
+            cf, coef, fl = np.zeros(ch, np.float32), np.zeros(4 * ch, np.float32), np.zeros(len(x) * ch, np.float32)
+            assert R[c].ref_gammatone(v[0], v[1], v[2], v[3], v[4], ch, v[6], v[7], v[8].encode(), x, len(x), 256, cf, coef, fl) == 0
+            gold["gt_cf_%d_%s" % (i, c)], gold["gt_coef_%d_%s" % (i, c)], gold["gt_out_%d_%s" % (i, c)] = cf, coef, fl
+        dcf += ndiff(gold["gt_cf_%d_off" % i], gold["gt_cf_%d_fma" % i])
+        dco += ndiff(gold["gt_coef_%d_off" % i], gold["gt_coef_%d_fma" % i])
+        dfl += ndiff(gold["gt_out_%d_off" % i], gold["gt_out_%d_fma" % i])
+        nfl += len(x) * ch
+    report["Signal::GammaTone design: centre frequencies + coefficients (function text, GammaTone.cc:20-223)"] = dict(
+        tried=5 * sum(v[5] for v in gt_cases), differ=dcf + dco,
+        fma_sites="vfmsub132ss (WarpingFunction::init: factor * break - max), vfmadd (warping: beta * f + b), vfmadd132ss (xMin + i * scale)")
+    report["Signal::GammaTone::apply, the cascade (the same pin)"] = dict(
+        tried=nfl, differ=dfl, fma_sites="2 x vfnmadd132ss (out -= b1 * buffer0, out -= b2 * buffer1), vfmadd132ss (the second product of out * a0 + a1 * buffer0)")
+
     np.savez_compressed(os.path.join(HERE, "ref_contract.npz"), **gold)
     out = os.path.join(ROOT, "profiles", "r05")
     os.makedirs(out, exist_ok=True)

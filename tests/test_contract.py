@@ -5,7 +5,7 @@ other f32 sums into fused multiply-adds; configured with -DMARCH=x86-64 it does 
 oracle/liboracle_fma.so the first (orc.h).  Both are held, bit for bit, to
   * tests/golden/ref_contract.npz -- outputs of the reference compiled both ways (tests/golden/make_contract_golden.py), everywhere;
   * oracle/_ref/libref.so / libref_native.so live on fresh inputs, where the reference tree is mounted (build container).
-Function-text pins (oracle/ref/extract_fn.py): a13 distance, f1 regression, a7 filter apply, a3 Hamming table, a18 batch-float sum, a1 preemphasis, a7 filter builder and boundary, a10 cosine transform, f4 AR-to-cepstrum.
+Function-text pins (oracle/ref/extract_fn.py): a13 distance, f1 regression, a7 filter apply, a3 Hamming table, a18 batch-float sum, a1 preemphasis, a7 filter builder and boundary, a10 cosine transform, f4 AR-to-cepstrum and the gammatone filter bank.
 """
 import ctypes as C
 import os
@@ -175,6 +175,24 @@ def test_autoregression_to_cepstrum_against_the_reference_function_text(contract
         got = oracle_ar_to_cepstrum(float(G[i]), A[i], 16, contract=contract)
         assert np.array_equal(bits(got), bits(Z["arc_%s" % contract][i])), (contract, i)
     assert not np.array_equal(bits(Z["arc_off"]), bits(Z["arc_fma"]))
+
+
+@pytest.mark.parametrize("contract", CONTRACTS)
+def test_gammatone_filter_bank_against_the_reference_function_text(contract):
+    """f4: signal-gammatone -- Signal::WarpingFunction and Signal::GammaTone, design (centre frequencies on the Greenwood / ERB scale
+    through the two-piece warping, bandwidths, coefficients) and the cascade with its state over blocks; the default build fuses three
+    operations of the design and three of the four products of a cascade stage"""
+    from oracle.binding import GammatoneCfg, OracleGammatone
+    x = Z["gt_x"]
+    for i, v in enumerate(Z["gt_cases"]):
+        cfg = GammatoneCfg.default(sample_rate=float(v[0]), cascade=int(v[1]), min_freq=float(v[2]), max_freq=float(v[3]), q=float(v[4]),
+                                   channels=int(v[5]), cf_mode=int(v[6]), warp_freq_break=float(v[7]), warping_factor=float(v[8]))
+        o = OracleGammatone(cfg, contract=contract)
+        _, filt = o.run(x, want_filtered=True)
+        assert np.array_equal(bits(o.center_frequencies), bits(Z["gt_cf_%d_%s" % (i, contract)])), (contract, i)
+        assert np.array_equal(bits(o.coefficients.reshape(-1)), bits(Z["gt_coef_%d_%s" % (i, contract)])), (contract, i)
+        assert np.array_equal(bits(filt.reshape(-1)), bits(Z["gt_out_%d_%s" % (i, contract)])), (contract, i)
+    assert not np.array_equal(bits(Z["gt_out_0_off"]), bits(Z["gt_out_0_fma"]))
 
 
 def _same_bits_or_both_nan(a, b):
