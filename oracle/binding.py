@@ -127,6 +127,12 @@ def Oracle(contract=None):
     L.orc_filter_apply.restype = C.c_float
     L.orc_filter_apply.argtypes = [f32p, C.c_int, C.c_int, f32p]
     L.orc_hamming_window.argtypes = [f32p, C.c_int]
+    L.orc_window_value.restype = C.c_float
+    L.orc_window_value.argtypes = [C.c_int, C.c_int, C.c_int]
+    L.orc_temporal_integrate.restype = None
+    L.orc_temporal_integrate.argtypes = [C.c_int, f32p, C.c_int, C.c_int, f32p]
+    L.orc_spectral_integrate.restype = C.c_int
+    L.orc_spectral_integrate.argtypes = [f32p, C.c_int, C.c_int, f32p, C.c_int, f32p]
     L.orc_cosine_transform.restype = None
     L.orc_cosine_transform.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, f32p, f32p, f32p]
     L.orc_filter_boundary.restype = C.c_int
@@ -253,6 +259,13 @@ def load_ref(contract="off"):
     if hasattr(R, "ref_hamming_window"):
         R.ref_hamming_window.restype = C.c_int
         R.ref_hamming_window.argtypes = [C.c_int, f32p]
+    if hasattr(R, "ref_window_table"):
+        R.ref_window_table.restype = C.c_int
+        R.ref_window_table.argtypes = [C.c_int, C.c_int, f32p]
+        R.ref_temporal_integration.restype = None
+        R.ref_temporal_integration.argtypes = [C.c_int, f32p, C.c_int, C.c_int, f32p]
+        R.ref_spectral_integration.restype = C.c_int
+        R.ref_spectral_integration.argtypes = [C.c_int, C.c_int, C.c_int, f32p, C.c_int, C.c_int, f32p]
         R.ref_batch_float_fill.argtypes = [f32p, f32p, C.c_int, f32p, C.c_int, C.c_int, f32p]
     if hasattr(R, "ref_filter_build"):
         R.ref_filter_build.restype = C.c_int

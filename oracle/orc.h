@@ -118,8 +118,8 @@ double orc_equal_loudness(double f);
 double orc_equal_loudness_4khz(double f);
 double       orc_mfcc_mel_max(const orc_mfcc* h);         /* warped maximum frequency */
 
-/* ---------------------------------------------------------------- gammatone front-end (orc_gammatone.c; signal-gammatone itself pinned on the
- * reference's function text in both builds, the integration nodes' arithmetic unpinned) */
+/* ---------------------------------------------------------------- gammatone front-end (orc_gammatone.c; filter bank, windows, temporal and
+ * spectral integration pinned on the reference's function text in both builds) */
 typedef struct {
     double sample_rate;
     int    cascade;          /* signal-gammatone cascade (node default 4) */
@@ -140,6 +140,9 @@ typedef struct {
     int    n_ceps;           /* signal-cosine-transform nr-outputs; 0 = node absent */
     int    dct_normalize;
 } orc_gammatone_cfg;
+float orc_window_value(int type, int len, int i); /* value i of the integration nodes' window: type 0 Hanning, 1 rectangular */
+void  orc_temporal_integrate(int window, const float* frame, int rows, int channels, float* out); /* TemporalIntegration::transform, one frame */
+int   orc_spectral_integrate(const float* win, int length, int shift, const float* in, int channels, float* out); /* SpectralIntegration::apply, one row */
 typedef struct orc_gammatone orc_gammatone;
 orc_gammatone* orc_gammatone_create(const orc_gammatone_cfg* cfg);
 void           orc_gammatone_destroy(orc_gammatone* h);

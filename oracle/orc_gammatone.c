@@ -10,9 +10,9 @@
  *   Hanning / rectangular       Signal/WindowFunction.cc:66-72,103-120
  *
  * signal-gammatone (WarpingFunction + GammaTone: filter design and cascade) is PINNED on the reference's function text in both builds
- * (oracle/ref/extract_fn.py gammatone, tests/test_contract.py).  TemporalIntegration.cc and SpectralIntegration.cc remain PARITY
- * UNPINNED beyond their framing: they include Flow node headers (Core/Configuration.hh -> boost), and no .flow file or test vector for
- * them ships with the reference.
+ * (oracle/ref/extract_fn.py gammatone, tests/test_contract.py), and so are the windows, TemporalIntegration (init, transform) and
+ * SpectralIntegration::apply (extract_fn.py windows); the framing is pinned on Signal/TimeWindowBuffer.cc compiled unmodified, the
+ * cosine transform on its own pin.  What remains read-only is the nodes' parameter handling.
  * Arithmetic types follow the source literally: the class members are f32, the unqualified exp / cos / sin / log10 / pow / log /
  * fabs calls resolve to the double overloads with the headers this translation unit sees (checked with g++ on the reference's
  * Flow/Vector.hh + Math/Complex.hh + Core/Utility.hh: sizeof(exp(1.0f)) == 8), std::complex<f32> division / abs are libgcc's
@@ -69,7 +69,7 @@ static float orc_gt_inverse_warping(const orc_gt_warp* w, float f) {
 
 /* window functions of Signal/WindowFunction.cc, symmetric fill, f64 -> f32; value i of a window of `len` points.
  * A window of one point is never initialised by the reference (init() fails): Hanning's first point is 0 in every history. */
-static float orc_window_value(int type, int len, int i) {
+float orc_window_value(int type, int len, int i) { /* type 0 Hanning, 1 rectangular; PINNED on the function text (tests/test_contract.py) */
     if (type == 1) /* rectangular */
         return 1.0f;
     if (len <= 1)
@@ -78,6 +78,33 @@ static float orc_window_value(int type, int len, int i) {
     if (n > M / 2)
         n = M - n;
     return (float)(0.5 - 0.5 * cos(2.0 * M_PI * n / M));
+}
+
+/* Signal::TemporalIntegration::transform (Signal/TemporalIntegration.cc:70-81) on ONE frame [rows x channels]: the first row times
+ * w[0] in f32, then `out += fabs(x) * w[i]` -- fabs is the double overload there, so the product and the sum run in f64 and the result
+ * is narrowed at every step (one vfmadd132sd in the default build).  window: 0 Hanning, 1 rectangular, of `rows` points.
+ * PINNED on the reference's function text in both builds (oracle/ref/extract_fn.py windows). */
+void orc_temporal_integrate(int window, const float* frame, int rows, int channels, float* out) {
+    for (int ch = 0; ch < channels; ++ch) {
+        float acc = frame[ch];
+        acc       = acc * orc_window_value(window, rows, 0);
+        for (int i = 1; i < rows; ++i)
+            acc = (float)ORC_FMA(fabs((double)frame[(size_t)i * channels + ch]), (double)orc_window_value(window, rows, i), (double)acc);
+        out[ch] = acc;
+    }
+}
+
+/* Signal::SpectralIntegration::apply (Signal/SpectralIntegration.cc:58-75) on one row of `channels` values: `out += w[k] * in[ch * shift +
+ * k]` in f32 (vfmadd132ss in the default build); win = the window table of `length` points.  Returns the number of outputs. */
+int orc_spectral_integrate(const float* win, int length, int shift, const float* in, int channels, float* out) {
+    int oc = (channels - length) / shift + 1;
+    for (int ch = 0; ch < oc; ++ch) {
+        float acc = 0;
+        for (int w = 0; w < length; ++w)
+            acc = ORC_FMAF(win[w], in[ch * shift + w], acc);
+        out[ch] = acc;
+    }
+    return oc;
 }
 
 orc_gammatone* orc_gammatone_create(const orc_gammatone_cfg* c) {
@@ -267,23 +294,9 @@ long orc_gammatone_run(const orc_gammatone* h, const float* pcm, long n_samples,
         long start = t * (long)h->ti_shift;
         long avail = n_samples - start;
         int  len   = avail < h->ti_len ? (int)avail : h->ti_len;
-        for (int ch = 0; ch < C; ++ch) {
-            float acc = y[start * C + ch];
-            acc       = acc * orc_window_value(h->cfg.ti_window, len, 0);
-            for (int i = 1; i < len; ++i)
-                acc = (float)((double)acc + fabs((double)y[(start + i) * C + ch]) * (double)orc_window_value(h->cfg.ti_window, len, i));
-            ti[ch] = acc;
-        }
-        if (h->cfg.si_length > 0) {
-            for (int ch = 0; ch < h->si_channels; ++ch) {
-                float acc = 0;
-                for (int w = 0; w < h->cfg.si_length; ++w) {
-                    float p = h->si_win[w] * ti[ch * h->cfg.si_shift + w];
-                    acc     = acc + p;
-                }
-                si[ch] = acc;
-            }
-        }
+        orc_temporal_integrate(h->cfg.ti_window, y + start * C, len, C, ti);
+        if (h->cfg.si_length > 0)
+            orc_spectral_integrate(h->si_win, h->cfg.si_length, h->cfg.si_shift, ti, C, si);
         else
             memcpy(si, ti, (size_t)C * 4);
         if (h->cfg.power != 0)
@@ -294,10 +307,8 @@ long orc_gammatone_run(const orc_gammatone* h, const float* pcm, long n_samples,
             for (int k = 0; k < h->cfg.n_ceps; ++k) {
                 float        acc = 0;
                 const float* row = h->dct + (size_t)k * h->si_channels;
-                for (int n = 0; n < h->si_channels; ++n) {
-                    float p = row[n] * si[n];
-                    acc     = acc + p;
-                }
+                for (int n = 0; n < h->si_channels; ++n)
+                    acc = ORC_FMAF(row[n], si[n], acc); /* CosineTransform::apply: Math::Vector's dot product (pinned, orc_cosine_transform) */
                 if (h->cfg.dct_normalize)
                     acc = acc / (float)h->si_channels;
                 o[k] = acc;

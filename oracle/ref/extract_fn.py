@@ -19,7 +19,8 @@ import sys
 
 REF = "/root/reference/src"
 
-# name -> (file, [(first line, last line (inclusive)), ...], sha256 of those lines concatenated, text in front, text behind)
+# name -> (file, [(first line, last line (inclusive)) or (another file, first, last), ...], sha256 of those lines concatenated,
+#          text in front, text behind)
 SPECS = {
     # Mm::GaussDiagonalMaximumFeatureScorer::distance (both the __SSE3__ branch and the plain one; the flag sets of the Makefile
     # define __SSE3__, so the first is what gets compiled -- as in the reference's own build, CompileOptions.cmake:21-26)
@@ -96,17 +97,26 @@ extern "C" void ref_regression(int order, const float* in, int n_in, int dim, fl
         out[c] = o[c];
 }
 """),
-    # Signal::HammingWindowFunction::init (SURVEY section 8 row a3): the window table, f64 arithmetic stored as f32.  The class
-    # declarations (Signal/WindowFunction.hh:30-110) need Core/Choice.hh / Core/Parameter.hh -> Core/Configuration.hh (boost); the shell
-    # declares the one data member and the base init() the text calls
-    "hamming_window": (
-        "Signal/WindowFunction.cc", [(92, 101)],
-        "38cb2b0dc246e453e25b34b27d9398b751d87b771d1a9ace61694dc9391033d8",
+    # Window functions and the two integration classes of the gammatone front end, in ONE generated file (they share the window classes):
+    #  * Signal::WindowFunction::setLength, the rectangular, Hamming (SURVEY section 8 row a3) and Hanning init() of Signal/WindowFunction.cc:
+    #    the window tables, f64 arithmetic stored as f32;
+    #  * Signal::TemporalIntegration (f4; whole class as defined in TemporalIntegration.cc: init() = rint of seconds x rate, transform() =
+    #    the window-weighted sum of |x| over the frame) on the reference's own Signal::TimeWindowBuffer;
+    #  * Signal::SpectralIntegration (f4; whole class as defined in SpectralIntegration.cc: apply()).
+    # The class declarations (Signal/WindowFunction.hh:30-135 needs Core/Choice.hh / Core/Parameter.hh, the integration headers need
+    # SlidingAlgorithmNode.hh / Flow/Node.hh -> Core/Configuration.hh, boost) are re-declared member for member.
+    "windows": (
+        "Signal/WindowFunction.cc", [(58, 63), (68, 73), (92, 101), (106, 120), ("Signal/TemporalIntegration.cc", 22, 81),
+                                     ("Signal/SpectralIntegration.cc", 25, 75)],
+        "c0c6c0d89cc60574d15f9c903529538d405a830985f8f0d5fe805dff2f157bb4",
         """#include <Core/Types.hh>
+#include <Core/Assertions.hh>
+#include <Flow/Vector.hh>
+#include <Signal/TimeWindowBuffer.hh>
 #include <cmath>
 #include <vector>
 namespace Signal {
-// shell: Signal/WindowFunction.hh:30-56 (Float, window_, needInit_, init()) and the derived class's one member
+// Signal/WindowFunction.hh:30-78 without the Core::Choice statics and the factory
 class WindowFunction {
 public:
     typedef f32 Float;
@@ -117,28 +127,145 @@ protected:
 public:
     WindowFunction() : needInit_(true) {}
     virtual ~WindowFunction() {}
+    void setLength(u32 l);
+    u32  length() { return window_.size(); }
+    const std::vector<Float>& getWindow() {
+        if (needInit_)
+            init();
+        return window_;
+    }
+};
+class RectangularWindowFunction : public WindowFunction {
+protected:
+    virtual bool init();
 };
 class HammingWindowFunction : public WindowFunction {
 protected:
     virtual bool init();
+};
+class HanningWindowFunction : public WindowFunction {
 public:
-    bool table(unsigned length, float* out) {
-        window_.assign(length, 0.f);
-        const bool ok = init();
-        for (unsigned i = 0; i < length; ++i)
-            out[i] = window_[i];
-        return ok;
-    }
+    HanningWindowFunction(bool periodic) : periodic_(periodic) {}
+protected:
+    virtual bool init();
+private:
+    bool periodic_;
+};
+// Signal/TemporalIntegration.hh:33-65
+class TemporalIntegration : public TimeWindowBuffer<Flow::Vector<f32>> {
+public:
+    typedef TimeWindowBuffer<Flow::Vector<f32>>       Precursor;
+    typedef TimeWindowBuffer<Flow::Vector<f32>>::Time Time;
+    typedef Flow::Vector<f32>                         Sample;
+private:
+    Time            lengthInS_;
+    Time            shiftInS_;
+    WindowFunction* windowFunction_;
+protected:
+    virtual void init();
+    virtual void transform(Flow::Vector<Sample>& out);
+public:
+    TemporalIntegration();
+    virtual ~TemporalIntegration();
+    void setWindowFunction(WindowFunction* windowFunction);
+    void setSampleRate(f64 sampleRate);
+    void setLengthInS(Time length);
+    Time lengthInS() const { return lengthInS_; }
+    void setShiftInS(Time shift);
+    Time shiftInS() const { return shiftInS_; }
+};
+// Signal/SpectralIntegration.hh:34-66
+class SpectralIntegration {
+public:
+    typedef Flow::Time        Time;
+    typedef Flow::Vector<f32> Sample;
+private:
+    u32             length_;
+    u32             shift_;
+    WindowFunction* windowFunction_;
+protected:
+    virtual void init();
+    void         apply(const Flow::Vector<Sample>& in, Flow::Vector<Sample>& out);
+public:
+    SpectralIntegration();
+    virtual ~SpectralIntegration();
+    void setWindowFunction(WindowFunction* windowFunction);
+    void setLength(u32 length);
+    u32  length() const { return length_; }
+    void setShift(u32 shift);
+    u32  shift() const { return shift_; }
 };
 }  // namespace Signal
 using namespace Signal;
+using Flow::Vector;
 // ---- reference text, %(file)s:%(ranges)s ----
 """,
         """
 // ---- end of reference text ----
-extern "C" int ref_hamming_window(int length, float* out) {
-    Signal::HammingWindowFunction w;
-    return w.table((unsigned)length, out) ? 0 : -1;
+namespace {
+Signal::WindowFunction* make_window(int type) {  // 0 Hanning, 1 periodic Hanning, 2 rectangular, 3 Hamming
+    if (type == 2)
+        return new Signal::RectangularWindowFunction;
+    if (type == 3)
+        return new Signal::HammingWindowFunction;
+    return new Signal::HanningWindowFunction(type == 1);
+}
+struct TiProbe : Signal::TemporalIntegration {
+    void run(Flow::Vector<Sample>& v) { transform(v); }
+    void initialise() { init(); }
+};
+struct SiProbe : Signal::SpectralIntegration {
+    void run(const Flow::Vector<Sample>& in, Flow::Vector<Sample>& out) { apply(in, out); }
+};
+}  // namespace
+extern "C" int ref_window_table(int type, int length, float* out) {
+    Signal::WindowFunction* w = make_window(type);
+    w->setLength((u32)length);
+    const std::vector<f32>& t = w->getWindow();
+    int rc = (int)t.size() == length ? 0 : -1;
+    for (int i = 0; i < length && i < (int)t.size(); ++i)
+        out[i] = t[i];
+    delete w;
+    return rc;
+}
+extern "C" int ref_hamming_window(int length, float* out) { return ref_window_table(3, length, out); }
+// TemporalIntegration::init: the frame length and shift in samples for a length / shift in seconds
+extern "C" void ref_temporal_integration_lengths(double length_s, double shift_s, double sample_rate, unsigned* length, unsigned* shift) {
+    TiProbe t;
+    t.setWindowFunction(make_window(0));
+    t.setSampleRate(sample_rate);
+    t.setLengthInS(length_s);
+    t.setShiftInS(shift_s);
+    t.initialise();
+    *length = t.length();
+    *shift  = t.shift();
+}
+// TemporalIntegration::transform on ONE frame [rows x channels] -> out [channels]
+extern "C" void ref_temporal_integration(int window, const float* frame, int rows, int channels, float* out) {
+    TiProbe t;
+    t.setWindowFunction(make_window(window));
+    Flow::Vector<Flow::Vector<f32>> v;
+    for (int i = 0; i < rows; ++i)
+        v.push_back(Flow::Vector<f32>(frame + (size_t)i * channels, frame + (size_t)(i + 1) * channels));
+    t.run(v);
+    for (int ch = 0; ch < channels; ++ch)
+        out[ch] = v[0][ch];
+}
+// SpectralIntegration::apply on n_frames rows of `channels` values -> out [n_frames x ((channels - length) / shift + 1)]
+extern "C" int ref_spectral_integration(int window, int length, int shift, const float* in, int n_frames, int channels, float* out) {
+    SiProbe s;
+    s.setWindowFunction(make_window(window));
+    s.setLength((u32)length);
+    s.setShift((u32)shift);
+    Flow::Vector<Flow::Vector<f32>> v, o;
+    for (int i = 0; i < n_frames; ++i)
+        v.push_back(Flow::Vector<f32>(in + (size_t)i * channels, in + (size_t)(i + 1) * channels));
+    s.run(v, o);
+    const int oc = o.empty() ? 0 : (int)o[0].size();
+    for (int i = 0; i < n_frames; ++i)
+        for (int c = 0; c < oc; ++c)
+            out[(size_t)i * oc + c] = o[i][c];
+    return oc;
 }
 """),
     # Mm::BatchFloatFeatureScorer::fillScoreCacheTpl (SURVEY section 8 row a18, "batch-diagonal-maximum-float"): the SSE loop over the
@@ -683,18 +810,25 @@ extern "C" int ref_gammatone(double sample_rate, int cascade, double minfreq, do
 def main():
     name, out = sys.argv[1], sys.argv[2]
     file, ranges, sha, head, tail = SPECS[name]
-    with open("%s/%s" % (REF, file), "r", encoding="utf-8", errors="replace") as f:
-        lines = f.readlines()
-    text = "".join("".join(lines[first - 1:last]) for first, last in ranges)
+    cache = {}
+
+    def src(name):
+        if name not in cache:
+            with open("%s/%s" % (REF, name), "r", encoding="utf-8", errors="replace") as f:
+                cache[name] = f.readlines()
+        return cache[name]
+    # a range is (first, last) in `file`, or (other file, first, last)
+    ranges = [(file,) + tuple(r) if len(r) == 2 else tuple(r) for r in ranges]
+    text = "".join("".join(src(fn)[first - 1:last]) for fn, first, last in ranges)
     got = hashlib.sha256(text.encode()).hexdigest()
     if len(sys.argv) > 3 and sys.argv[3] == "--print-sha":
         print(got)
         return
     if got != sha:
-        sys.exit("extract_fn: %s:%s hashes to %s, expected %s -- the reference moved; re-check the line ranges" % (file, ranges, got, sha))
+        sys.exit("extract_fn: %s %s hashes to %s, expected %s -- the reference moved; re-check the line ranges" % (name, ranges, got, sha))
     with open(out, "w") as f:
         f.write("// GENERATED by oracle/ref/extract_fn.py -- do not commit (oracle/_ref/ is git-ignored)\n")
-        f.write(head % {"file": file, "ranges": ",".join("%d-%d" % r for r in ranges)})
+        f.write(head % {"file": file, "ranges": ", ".join("%s:%d-%d" % r if r[0] != file else "%d-%d" % r[1:] for r in ranges)})
         f.write(text)
         f.write(tail)
 

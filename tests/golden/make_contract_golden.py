@@ -359,6 +359,54 @@ def main():
     report["Signal::GammaTone::apply, the cascade (the same pin)"] = dict(
         tried=nfl, differ=dfl, fma_sites="2 x vfnmadd132ss (out -= b1 * buffer0, out -= b2 * buffer1), vfmadd132ss (the second product of out * a0 + a1 * buffer0)")
 
+    # ---- f4: the integration nodes' windows and arithmetic (function text: WindowFunction.cc + TemporalIntegration.cc + SpectralIntegration.cc)
+    for c in R:
+        R[c].ref_window_table.restype = C.c_int
+        R[c].ref_window_table.argtypes = [C.c_int, C.c_int, f32p]
+        R[c].ref_temporal_integration.restype = None
+        R[c].ref_temporal_integration.argtypes = [C.c_int, f32p, C.c_int, C.c_int, f32p]
+        R[c].ref_spectral_integration.restype = C.c_int
+        R[c].ref_spectral_integration.argtypes = [C.c_int, C.c_int, C.c_int, f32p, C.c_int, C.c_int, f32p]
+    d = 0
+    for n in range(2, 2049):
+        a, b = np.zeros(n, np.float32), np.zeros(n, np.float32)
+        R["off"].ref_window_table(0, n, a)
+        R["fma"].ref_window_table(0, n, b)
+        d += ndiff(a, b)
+        if n in (2, 3, 9, 160, 400):
+            gold["hanning_%d" % n] = a
+    report["Signal::HanningWindowFunction::init (function text, WindowFunction.cc:106-120), every length 2 .. 2048"] = dict(
+        tried=sum(range(2, 2049)), differ=d, fma_sites="vfnmadd132sd (0.5 - 0.5 * cos()), f64; the f32 table hides it")
+    ti_cases = [(0, 400, 12), (2, 37, 5), (0, 2, 3), (0, 161, 68)]   # (window: 0 Hanning / 2 rectangular, rows, channels)
+    gold["ti_cases"] = np.array(ti_cases, np.int32)
+    dt = nt = 0
+    for i, (win, rows, ch) in enumerate(ti_cases):
+        fr = (rng2.standard_normal((rows, ch)) * 500).astype(np.float32)
+        gold["ti_in_%d" % i] = fr
+        for c in R:
+            out = np.zeros(ch, np.float32)
+            R[c].ref_temporal_integration(win, fr.reshape(-1), rows, ch, out)
+            gold["ti_out_%d_%s" % (i, c)] = out
+        dt += ndiff(gold["ti_out_%d_off" % i], gold["ti_out_%d_fma" % i])
+        nt += ch
+    report["Signal::TemporalIntegration::transform (function text, TemporalIntegration.cc:22-81)"] = dict(
+        tried=nt, differ=dt, fma_sites="vfmadd132sd (out += fabs(x) * w[i]: fabs is the double overload, product and sum in f64)")
+    si_cases = [(0, 9, 4, 68), (2, 3, 1, 12), (0, 5, 5, 50)]   # (window, length, shift, channels)
+    gold["si_cases"] = np.array(si_cases, np.int32)
+    dsp = nsp = 0
+    for i, (win, length, shift, ch) in enumerate(si_cases):
+        x = (rng2.standard_normal((6, ch)) * 100).astype(np.float32)
+        gold["si_in_%d" % i] = x
+        oc = (ch - length) // shift + 1
+        for c in R:
+            out = np.zeros((6, oc), np.float32)
+            assert R[c].ref_spectral_integration(win, length, shift, x.reshape(-1), 6, ch, out.reshape(-1)) == oc
+            gold["si_out_%d_%s" % (i, c)] = out
+        dsp += ndiff(gold["si_out_%d_off" % i], gold["si_out_%d_fma" % i])
+        nsp += 6 * oc
+    report["Signal::SpectralIntegration::apply (function text, SpectralIntegration.cc:25-75)"] = dict(
+        tried=nsp, differ=dsp, fma_sites="vfmadd132ss (out += w[k] * in[ch * shift + k])")
+
     np.savez_compressed(os.path.join(HERE, "ref_contract.npz"), **gold)
     out = os.path.join(ROOT, "profiles", "r05")
     os.makedirs(out, exist_ok=True)

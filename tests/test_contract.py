@@ -5,7 +5,7 @@ other f32 sums into fused multiply-adds; configured with -DMARCH=x86-64 it does 
 oracle/liboracle_fma.so the first (orc.h).  Both are held, bit for bit, to
   * tests/golden/ref_contract.npz -- outputs of the reference compiled both ways (tests/golden/make_contract_golden.py), everywhere;
   * oracle/_ref/libref.so / libref_native.so live on fresh inputs, where the reference tree is mounted (build container).
-Function-text pins (oracle/ref/extract_fn.py): a13 distance, f1 regression, a7 filter apply, a3 Hamming table, a18 batch-float sum, a1 preemphasis, a7 filter builder and boundary, a10 cosine transform, f4 AR-to-cepstrum and the gammatone filter bank.
+Function-text pins (oracle/ref/extract_fn.py): a13 distance, f1 regression, a7 filter apply, a3 Hamming table, a18 batch-float sum, a1 preemphasis, a7 filter builder and boundary, a10 cosine transform, f4 AR-to-cepstrum, the gammatone filter bank and the integration nodes.
 """
 import ctypes as C
 import os
@@ -193,6 +193,30 @@ def test_gammatone_filter_bank_against_the_reference_function_text(contract):
         assert np.array_equal(bits(o.coefficients.reshape(-1)), bits(Z["gt_coef_%d_%s" % (i, contract)])), (contract, i)
         assert np.array_equal(bits(filt.reshape(-1)), bits(Z["gt_out_%d_%s" % (i, contract)])), (contract, i)
     assert not np.array_equal(bits(Z["gt_out_0_off"]), bits(Z["gt_out_0_fma"]))
+
+
+@pytest.mark.parametrize("contract", CONTRACTS)
+def test_integration_nodes_against_the_reference_function_text(contract):
+    """f4: the Hanning / rectangular tables of Signal/WindowFunction.cc, Signal::TemporalIntegration::transform (|x| weighted by the window,
+    summed in f64 because fabs is the double overload there) and Signal::SpectralIntegration::apply (f32)"""
+    L = Oracle(contract)
+    for n in (2, 3, 9, 160, 400):
+        w = np.array([L.orc_window_value(0, n, i) for i in range(n)], np.float32)
+        assert np.array_equal(bits(w), bits(Z["hanning_%d" % n])), n
+    for i, (win, rows, ch) in enumerate(Z["ti_cases"]):
+        out = np.zeros(int(ch), np.float32)
+        L.orc_temporal_integrate(0 if win == 0 else 1, np.ascontiguousarray(Z["ti_in_%d" % i]).reshape(-1), int(rows), int(ch), out)
+        assert np.array_equal(bits(out), bits(Z["ti_out_%d_%s" % (i, contract)])), (contract, i)
+    for i, (win, length, shift, ch) in enumerate(Z["si_cases"]):
+        wt = np.array([L.orc_window_value(0 if win == 0 else 1, int(length), k) for k in range(int(length))], np.float32)
+        x, want = Z["si_in_%d" % i], Z["si_out_%d_%s" % (i, contract)]
+        for r in range(len(x)):
+            out = np.zeros(want.shape[1], np.float32)
+            assert L.orc_spectral_integrate(wt, int(length), int(shift), np.ascontiguousarray(x[r]), int(ch), out) == want.shape[1]
+            assert np.array_equal(bits(out), bits(want[r])), (contract, i, r)
+    # (the temporal sum's fused f64 operation hides behind the narrowing to f32 at every step: the builds agree on the fixture's 88 values;
+    # the spectral sum is f32 and differs)
+    assert not np.array_equal(bits(Z["si_out_0_off"]), bits(Z["si_out_0_fma"]))
 
 
 def _same_bits_or_both_nan(a, b):
