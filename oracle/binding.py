@@ -285,6 +285,9 @@ def load_ref(contract="off"):
         R.ref_gammatone.restype = C.c_int
         R.ref_gammatone.argtypes = [C.c_double, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_double, C.c_char_p, f32p,
                                     C.c_long, C.c_int, f32p, f32p, f32p]
+    if hasattr(R, "ref_normalization"):
+        R.ref_normalization.restype = C.c_long
+        R.ref_normalization.argtypes = [C.c_int, C.c_int, C.c_ulong, C.c_ulong, f32p, C.c_long, C.c_int, f32p]
     if hasattr(R, "ref_preemphasis"):
         R.ref_preemphasis.argtypes = [C.c_float, C.c_double, f32p, C.c_long, C.c_int, C.c_int, f32p]
     _refs[contract] = R
@@ -301,9 +304,9 @@ def oracle_normalize(x, variance=False, length=0, right=0):
     return out
 
 
-def oracle_normalize_ex(x, type, level=0, length=0, right=0):
+def oracle_normalize_ex(x, type, level=0, length=0, right=0, contract=None):
     """orc_normalize_ex over one segment [n, dim]: type 2 divide-by-mean, 3 level, 4 mean-and-variance-1D (0 / 1 as oracle_normalize)"""
-    L = Oracle()
+    L = Oracle(contract)
     x = np.ascontiguousarray(x, np.float32)
     out = np.empty_like(x)
     L.orc_normalize_ex.argtypes = [f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32p]

@@ -275,7 +275,8 @@ void orc_ffnn_forward(const orc_ffnn_model* m, const float* feats, int T, float*
 }
 #endif
 
-/* ---- feature back-end, orc_backend.c; parity unpinned (see that file) */
+/* ---- feature back-end, orc_backend.c; normalisation (five types), regression and matrix multiplication pinned on
+ * the reference's text / headers in both builds (see that file) */
 void orc_normalize(const float* in, int n, int dim, int type, int length, int right, float* out);
 void orc_normalize_ex(const float* in, int n, int dim, int type, int level, int length, int right, float* out);
 void orc_regression(const float* in, int n, int dim, int order, int right, float* out);

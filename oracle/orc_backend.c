@@ -6,8 +6,9 @@
  * operation by operation (types, order of the f32 / f64 operations).  Pinned since round 5: orc_regression on the text of
  * Signal::Regression::regressFirstOrder / regressSecondOrder compiled stand-alone in both flag sets (function-text pin
  * `regression`, oracle/ref/extract_fn.py; tests/test_contract.py), orc_matrix_multiply's row product on Math::Matrix x Vector in
- * both flavours of libref.  Normalisation: PARITY UNPINNED (its sums are contraction-insensitive: the f64 product of two widened f32
- * values is exact, so `sumSquare += (Sum)x * (Sum)x` gives the same bits fused or not).
+ * both flavours of libref, orc_normalize / orc_normalize_ex (level, mean, mean-and-variance, -1D, divide-by-mean) on the text of
+ * Signal::Normalization + Signal::SlidingWindow driven as the node drives them (function-text pin `normalization`: arithmetic and emission
+ * order; its sums are contraction-insensitive -- the f64 product of two widened f32 values is exact).  mean-norm: PARITY UNPINNED.
  */
 #include "orc.h"
 

@@ -19,6 +19,98 @@ import sys
 
 REF = "/root/reference/src"
 
+DECLS_NORMALIZATION = '''
+// ---- shell: the class declarations of Signal/Normalization.hh:35-179 (they need the template above).  The three classes that are
+// Core::Components there (for warning() / criticalError() and a configuration constructor) get a base with those two as no-ops.
+namespace Signal {
+struct ComponentShell {
+    void warning(const char*, ...) const {}
+    void criticalError(const char*, ...) const {}
+};
+class Normalization {
+public:
+    typedef f32                                Value;
+    typedef f64                                Sum;
+    typedef Flow::DataPtr<Flow::Vector<Value>> Frame;
+protected:
+    SlidingWindow<Frame> slidingWindow_;
+    u32                  length_;
+    u32                  right_;
+    Sum                  sumWeight_;
+    bool                 changed_;
+private:
+    void normalize(Frame& out);
+protected:
+    virtual bool init(size_t dimension) { return true; }
+    virtual void updateStatistics(const Frame& add, const Frame& remove);
+    virtual void finalize();
+    virtual void apply(Frame& out) = 0;
+public:
+    Normalization();
+    virtual ~Normalization() {}
+    bool         init(size_t length, size_t right, size_t dimension);
+    bool         update(const Frame& in, Frame& out);
+    bool         flush(Frame& out);
+    virtual void reset();
+};
+class LevelNormalization : public Normalization {
+    typedef Normalization Precursor;
+protected:
+    size_t index_;
+    Value  max_;
+    virtual void finalize();
+    virtual void apply(Frame& out);
+public:
+    LevelNormalization(size_t index) : index_(index), max_(0) {}
+};
+class MeanNormalization : public Normalization {
+    typedef Normalization Precursor;
+protected:
+    std::vector<Sum>   sum_;
+    std::vector<Value> mean_;
+    virtual bool init(size_t dimension);
+    virtual void reset();
+    virtual void updateStatistics(const Frame& add, const Frame& remove);
+    virtual void finalize();
+    virtual void apply(Frame& out);
+};
+class MeanAndVarianceNormalization : public ComponentShell, public MeanNormalization {
+    typedef MeanNormalization Precursor;
+protected:
+    std::vector<Sum>   sumSquare_;
+    std::vector<Value> standardDeviation_;
+    virtual bool init(size_t dimension);
+    virtual void reset();
+    virtual void updateStatistics(const Frame& add, const Frame& remove);
+    virtual void finalize();
+    virtual void apply(Frame& out);
+};
+class MeanAndVarianceNormalization1D : public ComponentShell, public Normalization {
+    typedef Normalization Precursor;
+protected:
+    Sum   sum_;
+    Sum   sumSquare_;
+    Value mean_;
+    Value standardDeviation_;
+    virtual bool init(size_t dimension);
+    virtual void reset();
+    virtual void updateStatistics(const Frame& add, const Frame& remove);
+    virtual void finalize();
+    virtual void apply(Frame& out);
+};
+class DivideByMean : public ComponentShell, public MeanNormalization {
+    typedef MeanNormalization Precursor;
+protected:
+    virtual void finalize();
+    virtual void apply(Frame& out);
+};
+}  // namespace Signal
+using namespace Signal;
+using namespace Core;
+using namespace Flow;
+// ---- reference text (Signal/Normalization.cc) ----
+'''
+
 # name -> (file, [(first line, last line (inclusive)) or (another file, first, last), ...], sha256 of those lines concatenated,
 #          text in front, text behind)
 SPECS = {
@@ -804,6 +896,61 @@ extern "C" int ref_gammatone(double sample_rate, int cascade, double minfreq, do
     return 0;
 }
 """),
+    # Signal::Normalization and five of its six algorithms (SURVEY section 8 row f1: level, mean, mean-and-variance, mean-and-variance-1D,
+    # divide-by-mean; mean-norm needs Flow::NormFunction built from a configuration) on the reference's own sliding window: the template
+    # Signal::SlidingWindow is taken whole from its header (which includes Flow/Node.hh, boost, for nothing the template uses), then the
+    # class declarations stand between it and the definitions of Normalization.cc.  Pins the arithmetic AND the window's timing: which
+    # frame leaves when, with which statistics, and what flush() hands out.
+    "normalization": (
+        "Signal/Normalization.cc", [("Signal/SlidingWindow.hh", 22, 471), DECLS_NORMALIZATION, (24, 97), (100, 109), (112, 141), (148, 191),
+                                    (198, 247), (254, 262)],
+        "151c8493588221bf3337b086dea1505de340286f8f1acd204d6d92acfa0c6be8",
+        """#include <Core/Types.hh>
+#include <Core/Assertions.hh>
+#include <Core/Utility.hh>
+#include <Flow/Data.hh>
+#include <Flow/DataAdaptor.hh>
+#include <Flow/Vector.hh>
+#include <algorithm>
+#include <cmath>
+#include <deque>
+#include <functional>
+#include <vector>
+// ---- reference text, %(file)s:%(ranges)s (the first piece: Signal/SlidingWindow.hh) ----
+""",
+        """
+// ---- end of reference text ----
+// type 0 level (index `level`), 1 mean, 2 mean-and-variance, 3 mean-and-variance-1D, 4 divide-by-mean; length / right as the node passes
+// them (both >= 2^31 - 1: the whole segment).  Frames are fed as NormalizationNode::work feeds them: update() per frame, flush() until it
+// fails.  out [n x dim] in emission order; returns the number of frames emitted (-1: init refused).
+extern "C" long ref_normalization(int type, int level, unsigned long length, unsigned long right, const float* in, long n, int dim, float* out) {
+    Signal::Normalization* a = type == 0 ? (Signal::Normalization*)new Signal::LevelNormalization((size_t)level)
+                             : type == 1 ? (Signal::Normalization*)new Signal::MeanNormalization
+                             : type == 2 ? (Signal::Normalization*)new Signal::MeanAndVarianceNormalization
+                             : type == 3 ? (Signal::Normalization*)new Signal::MeanAndVarianceNormalization1D
+                                         : (Signal::Normalization*)new Signal::DivideByMean;
+    if (!a->init((size_t)length, (size_t)right, (size_t)dim)) {
+        delete a;
+        return -1;
+    }
+    long emitted = 0;
+    auto emit = [&](Signal::Normalization::Frame& f) {
+        for (int d = 0; d < dim; ++d)
+            out[(size_t)emitted * dim + d] = (*f)[d];
+        ++emitted;
+    };
+    Signal::Normalization::Frame o;
+    for (long t = 0; t < n; ++t) {
+        Signal::Normalization::Frame f(new Flow::Vector<f32>(in + (size_t)t * dim, in + (size_t)(t + 1) * dim));
+        if (a->update(f, o))
+            emit(o);
+    }
+    while (emitted < n && a->flush(o))
+        emit(o);
+    delete a;
+    return emitted;
+}
+"""),
 }
 
 
@@ -817,9 +964,12 @@ def main():
             with open("%s/%s" % (REF, name), "r", encoding="utf-8", errors="replace") as f:
                 cache[name] = f.readlines()
         return cache[name]
-    # a range is (first, last) in `file`, or (other file, first, last)
-    ranges = [(file,) + tuple(r) if len(r) == 2 else tuple(r) for r in ranges]
+    # a range is (first, last) in `file`, or (other file, first, last); a string is shell text that has to stand BETWEEN two pieces of
+    # reference text (declarations that need the text in front of them); it is written out in place and is not part of the hash
+    items  = [r if isinstance(r, str) else ((file,) + tuple(r) if len(r) == 2 else tuple(r)) for r in ranges]
+    ranges = [r for r in items if not isinstance(r, str)]
     text = "".join("".join(src(fn)[first - 1:last]) for fn, first, last in ranges)
+    body = "".join(r if isinstance(r, str) else "".join(src(r[0])[r[1] - 1:r[2]]) for r in items)
     got = hashlib.sha256(text.encode()).hexdigest()
     if len(sys.argv) > 3 and sys.argv[3] == "--print-sha":
         print(got)
@@ -829,7 +979,7 @@ def main():
     with open(out, "w") as f:
         f.write("// GENERATED by oracle/ref/extract_fn.py -- do not commit (oracle/_ref/ is git-ignored)\n")
         f.write(head % {"file": file, "ranges": ", ".join("%s:%d-%d" % r if r[0] != file else "%d-%d" % r[1:] for r in ranges)})
-        f.write(text)
+        f.write(body)
         f.write(tail)
 
 

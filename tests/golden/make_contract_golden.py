@@ -407,6 +407,34 @@ def main():
     report["Signal::SpectralIntegration::apply (function text, SpectralIntegration.cc:25-75)"] = dict(
         tried=nsp, differ=dsp, fma_sites="vfmadd132ss (out += w[k] * in[ch * shift + k])")
 
+    # ---- f1: Signal::Normalization + five algorithms on the reference's own sliding window (function text)
+    for c in R:
+        R[c].ref_normalization.restype = C.c_long
+        R[c].ref_normalization.argtypes = [C.c_int, C.c_int, C.c_ulong, C.c_ulong, f32p, C.c_long, C.c_int, f32p]
+    BIG = 2 ** 31 - 1
+    ncases, dn, nn_ = [], 0, 0
+    for trial in range(40):
+        typ, n, dim = trial % 5, int(rng2.integers(1, 50)), int(rng2.integers(1, 14))
+        level = int(rng2.integers(0, dim))
+        if trial % 3 == 0:
+            length, right = BIG, BIG
+        else:
+            length = int(rng2.integers(1, 20))
+            right = int(rng2.integers(0, length))
+        x = (rng2.standard_normal((n, dim)) * 10 + (5 if typ == 4 else 0)).astype(np.float32)
+        ncases.append([typ, level, length, right, n, dim])
+        gold["norm_in_%d" % trial] = x
+        for c in R:
+            out = np.zeros((n, dim), np.float32)
+            assert R[c].ref_normalization(typ, level, length, right, x.reshape(-1), n, dim, out.reshape(-1)) == n
+            gold["norm_out_%d_%s" % (trial, c)] = out
+        dn += ndiff(gold["norm_out_%d_off" % trial], gold["norm_out_%d_fma" % trial])
+        nn_ += n * dim
+    gold["norm_cases"] = np.array(ncases, np.int64)
+    report["Signal::Normalization: level / mean / mean-and-variance / -1D / divide-by-mean on Signal::SlidingWindow (function text, "
+           "Normalization.cc:24-262 + SlidingWindow.hh:22-471), 40 segments"] = dict(
+        tried=nn_, differ=dn, fma_sites="f64 products of widened f32 values are exact: fused or not, the same bits")
+
     np.savez_compressed(os.path.join(HERE, "ref_contract.npz"), **gold)
     out = os.path.join(ROOT, "profiles", "r05")
     os.makedirs(out, exist_ok=True)

@@ -5,7 +5,7 @@ other f32 sums into fused multiply-adds; configured with -DMARCH=x86-64 it does 
 oracle/liboracle_fma.so the first (orc.h).  Both are held, bit for bit, to
   * tests/golden/ref_contract.npz -- outputs of the reference compiled both ways (tests/golden/make_contract_golden.py), everywhere;
   * oracle/_ref/libref.so / libref_native.so live on fresh inputs, where the reference tree is mounted (build container).
-Function-text pins (oracle/ref/extract_fn.py): a13 distance, f1 regression, a7 filter apply, a3 Hamming table, a18 batch-float sum, a1 preemphasis, a7 filter builder and boundary, a10 cosine transform, f4 AR-to-cepstrum, the gammatone filter bank and the integration nodes.
+Function-text pins (oracle/ref/extract_fn.py): a13 distance, f1 regression, a7 filter apply, a3 Hamming table, a18 batch-float sum, a1 preemphasis, a7 filter builder and boundary, a10 cosine transform, f4 AR-to-cepstrum, the gammatone filter bank and the integration nodes, f1 normalisation.
 """
 import ctypes as C
 import os
@@ -217,6 +217,21 @@ def test_integration_nodes_against_the_reference_function_text(contract):
     # (the temporal sum's fused f64 operation hides behind the narrowing to f32 at every step: the builds agree on the fixture's 88 values;
     # the spectral sum is f32 and differs)
     assert not np.array_equal(bits(Z["si_out_0_off"]), bits(Z["si_out_0_fma"]))
+
+
+@pytest.mark.parametrize("contract", CONTRACTS)
+def test_normalization_against_the_reference_function_text(contract):
+    """f1: Signal::Normalization with level / mean / mean-and-variance / mean-and-variance-1D / divide-by-mean on the reference's own
+    Signal::SlidingWindow, fed and flushed as NormalizationNode::work does: the arithmetic AND which frame leaves when, with which
+    statistics (finite windows with a look-ahead, and the whole segment)"""
+    from oracle.binding import oracle_normalize_ex
+    omap = {0: 3, 1: 0, 2: 1, 3: 4, 4: 2}   # the reference's type order -> orc_normalize_ex's
+    for i, (typ, level, length, right, n, dim) in enumerate(Z["norm_cases"]):
+        whole = length >= 2 ** 31 - 1
+        got = oracle_normalize_ex(Z["norm_in_%d" % i], omap[int(typ)], level=int(level), length=0 if whole else int(length),
+                                  right=0 if whole else int(right), contract=contract)
+        want = Z["norm_out_%d_%s" % (i, contract)]
+        assert _same_bits_or_both_nan(got, want), (contract, i, typ, length, right)
 
 
 def _same_bits_or_both_nan(a, b):
