@@ -127,6 +127,8 @@ def Oracle(contract=None):
     L.orc_filter_apply.restype = C.c_float
     L.orc_filter_apply.argtypes = [f32p, C.c_int, C.c_int, f32p]
     L.orc_hamming_window.argtypes = [f32p, C.c_int]
+    L.orc_cluster_select.restype = None
+    L.orc_cluster_select.argtypes = [f32p, C.c_int, C.c_int, C.c_int, f32p, np.ctypeslib.ndpointer(np.uint8, flags="C")]
     L.orc_window_value.restype = C.c_float
     L.orc_window_value.argtypes = [C.c_int, C.c_int, C.c_int]
     L.orc_temporal_integrate.restype = None
@@ -288,6 +290,10 @@ def load_ref(contract="off"):
     if hasattr(R, "ref_normalization"):
         R.ref_normalization.restype = C.c_long
         R.ref_normalization.argtypes = [C.c_int, C.c_int, C.c_ulong, C.c_ulong, f32p, C.c_long, C.c_int, f32p]
+    if hasattr(R, "ref_density_clustering"):
+        u8p = np.ctypeslib.ndpointer(np.uint8, flags="C")
+        R.ref_density_clustering.restype = C.c_int
+        R.ref_density_clustering.argtypes = [f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, u8p, f32p, f32p, C.c_int, u8p]
     if hasattr(R, "ref_preemphasis"):
         R.ref_preemphasis.argtypes = [C.c_float, C.c_double, f32p, C.c_long, C.c_int, C.c_int, f32p]
     _refs[contract] = R

@@ -227,6 +227,7 @@ int orc_gmm_score_preselection_float(const orc_gmm* h, const double* log_weight,
 int orc_gmm_score_preselection_int(const orc_gmm* h, const double* log_weight, const float* variances, const float* feats, int T,
                                    int n_clusters, int n_select, int iterations, float* scores, uint32_t* cluster_of_out,
                                    uint8_t* cluster_means_out, int* n_clusters_out);
+void  orc_cluster_select(const float* cm, int n_clusters, int pdim, int n_select, const float* xs, unsigned char* sel); /* DensityClustering::selectClusters */
 float orc_batch_float_fill(const float* ms, const float* cst, int nk, const float* xs, int pdim); /* fillScoreCacheTpl, one feature x one mixture */
 int orc_gmm_score_batch_float(const orc_gmm* h, const double* log_weight, const float* variances,
                               const float* feats, int T, float* scores);

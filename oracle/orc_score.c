@@ -299,6 +299,24 @@ static float orc_seq_distance(const float* a, const float* b, int dim) { /* unro
     return score;
 }
 
+/* Mm::DensityClustering::selectClusters (Mm/DensityClustering.tcc:157-180): the n_select clusters closest to the (scaled, padded) feature.
+ * The reference sorts (distance, cluster) pairs by distance with std::sort; clusters at exactly equal distances are taken here in index
+ * order (the order std::sort leaves them in is the library's; equal f32 distances to two different cluster means do not occur on
+ * continuous data).  sel [n_clusters]: 1 = selected.  PINNED on the reference's function text (oracle/ref/extract_fn.py
+ * density_clustering), x86-64 build. */
+void orc_cluster_select(const float* cm, int n_clusters, int pdim, int n_select, const float* xs, unsigned char* sel) {
+    orc_cl_item* items = (orc_cl_item*)calloc((size_t)n_clusters, sizeof(orc_cl_item));
+    for (int c = 0; c < n_clusters; ++c) {
+        items[c].d = orc_seq_distance(xs, cm + (size_t)c * pdim, pdim);
+        items[c].c = (uint32_t)c;
+    }
+    qsort(items, (size_t)n_clusters, sizeof(orc_cl_item), orc_cl_cmp);
+    memset(sel, 0, (size_t)n_clusters);
+    for (int i = 0; i < n_select; ++i)
+        sel[items[i].c] = 1;
+    free(items);
+}
+
 int orc_gmm_score_preselection_float(const orc_gmm* h, const double* log_weight, const float* variances, const float* feats, int T,
                                      int n_clusters, int n_select, int iterations, float backoff, float* scores,
                                      uint32_t* cluster_of_out, float* cluster_means_out, int* n_clusters_out) {
@@ -370,19 +388,11 @@ int orc_gmm_score_preselection_float(const orc_gmm* h, const double* log_weight,
         }
     }
     /* ---- scoring */
-    orc_cl_item* items  = (orc_cl_item*)calloc((size_t)n_clusters, sizeof(orc_cl_item));
-    char*        active = (char*)calloc((size_t)n_clusters, 1);
+    char* active = (char*)calloc((size_t)n_clusters, 1);
     for (int t = 0; t < T; ++t) {
         for (int i = 0; i < dim; ++i)
             xs[i] = feats[(size_t)t * dim + i] * isr[i];
-        for (int c = 0; c < n_clusters; ++c) {
-            items[c].d = orc_seq_distance(xs, cm + (size_t)c * pdim, pdim);
-            items[c].c = (uint32_t)c;
-        }
-        qsort(items, (size_t)n_clusters, sizeof(orc_cl_item), orc_cl_cmp);
-        memset(active, 0, (size_t)n_clusters);
-        for (int i = 0; i < n_select; ++i)
-            active[items[i].c] = 1;
+        orc_cluster_select(cm, n_clusters, pdim, n_select, xs, (unsigned char*)active);
         for (int m = 0; m < h->n_mix; ++m) {
             float best = FLT_MAX;
             for (uint32_t k = h->mix_off[m]; k < h->mix_off[m + 1]; ++k) {
@@ -414,7 +424,7 @@ int orc_gmm_score_preselection_float(const orc_gmm* h, const double* log_weight,
         memcpy(cluster_means_out, cm, (size_t)n_clusters * pdim * 4);
     if (n_clusters_out)
         *n_clusters_out = n_clusters;
-    free(isr); free(xs); free(ms); free(cst); free(cm); free(cof); free(used); free(sums); free(items); free(active);
+    free(isr); free(xs); free(ms); free(cst); free(cm); free(cof); free(used); free(sums); free(active);
     return 0;
 }
 

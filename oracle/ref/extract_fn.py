@@ -951,6 +951,102 @@ extern "C" long ref_normalization(int type, int level, unsigned long length, uns
     return emitted;
 }
 """),
+    # Mm::DensityClustering<f32, f32> (SURVEY section 8 row f4, "preselection-batch-float"): initializeClusters (srand(1) / rand()),
+    # assignDensities, updateClusterMeans, selectClusters (std::sort on the distances) and DensityClusteringBase::init (the cluster count is
+    # reduced to the number of densities).  build() itself reads its iteration count from the configuration and talks to a cache archive:
+    # its loop -- initialise, then `iterations` x (assign, update) -- is the three lines of the entry point below.  The class declarations
+    # (Mm/DensityClustering.hh:29-150, a Core::Component with archive IO) are re-declared without that base and without the IO members.
+    "density_clustering": (
+        "Mm/DensityClustering.tcc", [(61, 119), (157, 180), ("Mm/DensityClustering.cc", 45, 57)],
+        "8101564b64b4c8cebea849e2236ce68b5d81361b82a07e7ca3ea52bc50e7b63d",
+        """#include <Core/Types.hh>
+#include <Core/Assertions.hh>
+#include <Core/Extensions.hh>
+#include <Core/Utility.hh>
+#include <Mm/Utilities.hh>
+#include <algorithm>
+#include <functional>
+#include <iostream>
+#include <set>
+#include <vector>
+namespace Mm {
+class DensityClusteringBase {
+public:
+    typedef u8                                        ClusterIndex;
+    typedef std::vector<ClusterIndex>::const_iterator ClusterIndexIterator;
+    DensityClusteringBase(u32 nClusters, u32 nSelected) : nClusters_(nClusters), nSelected_(nSelected), dimension_(0), nDensities_(0), backoffScore_(0) {}
+    virtual ~DensityClusteringBase() {}
+    void         init(u32 dimension, u32 nDensities);
+    ClusterIndex clusterIndexForDensity(size_t density) const { return clusterIndexForDensity_[density]; }
+    u32          nClusters() const { return nClusters_; }
+protected:
+    std::ostream&             log() const { static std::ostream null(nullptr); return null; }
+    std::vector<ClusterIndex> clusterIndexForDensity_;
+    u32                       nClusters_, nSelected_;
+    u32                       dimension_, nDensities_;
+    const float               backoffScore_;
+};
+template<class F, class D>
+class DensityClustering : public DensityClusteringBase {
+public:
+    typedef F FeatureType;
+    typedef D DistanceType;
+    DensityClustering(u32 nClusters, u32 nSelected) : DensityClusteringBase(nClusters, nSelected), clusterMeans_(0) {}
+    ~DensityClustering() { delete[] clusterMeans_; }
+    void selectClusters(bool* selection, FeatureType* feature) const;
+    // (probe: build() without the configuration and the cache archive)
+    void buildLoop(const FeatureType* densities, u32 iterations) {
+        clusterMeans_ = new FeatureType[nClusters_ * dimension_];
+        initializeClusters(densities);
+        for (u32 i = 0; i < iterations; ++i) {
+            DensityAssignment densitiesAssignedToClusters(nClusters_);
+            assignDensities(densities, densitiesAssignedToClusters);
+            updateClusterMeans(densities, densitiesAssignedToClusters);
+        }
+    }
+    const FeatureType* means() const { return clusterMeans_; }
+private:
+    FeatureType*       meanForCluster(ClusterIndex cluster) { return clusterMeans_ + cluster * dimension_; }
+    const FeatureType* meanForCluster(ClusterIndex cluster) const { return clusterMeans_ + cluster * dimension_; }
+    const FeatureType* meanForDensity(const FeatureType* means, u32 density) const { return means + density * dimension_; }
+    typedef std::vector<std::vector<u32>> DensityAssignment;
+    void initializeClusters(const FeatureType* densities);
+    void assignDensities(const FeatureType* densities, DensityAssignment& densityAssignment);
+    f64  updateClusterMeans(const FeatureType* densities, DensityAssignment& densityAssignment);
+    FeatureType* clusterMeans_;
+};
+}  // namespace Mm
+using namespace Mm;
+namespace Mm {
+// ---- reference text, %(file)s:%(ranges)s ----
+""",
+        """
+}  // namespace Mm
+// ---- end of reference text ----
+// means [n_dens x dim] (already multiplied by 1 / sigma and padded, as BatchFloatFeatureScorer::init leaves them), features [T x dim] likewise.
+// cluster_of [n_dens], cluster_means [n_clusters_out x dim], selection [T x n_clusters_out] (1 = selected)
+extern "C" int ref_density_clustering(const float* means, int n_dens, int dim, int n_clusters, int n_select, int iterations,
+                                      unsigned char* cluster_of, float* cluster_means, const float* feats, int T, unsigned char* selection) {
+    Mm::DensityClustering<f32, f32> c((u32)n_clusters, (u32)n_select);
+    c.init((u32)dim, (u32)n_dens);
+    c.buildLoop(means, (u32)iterations);
+    const int nc = (int)c.nClusters();
+    for (int k = 0; k < n_dens; ++k)
+        cluster_of[k] = c.clusterIndexForDensity((size_t)k);
+    for (int i = 0; i < nc * dim; ++i)
+        cluster_means[i] = c.means()[i];
+    std::vector<char> sel((size_t)nc);
+    std::vector<f32>  f((size_t)dim);
+    for (int t = 0; t < T; ++t) {
+        for (int i = 0; i < dim; ++i)
+            f[i] = feats[(size_t)t * dim + i];
+        c.selectClusters((bool*)sel.data(), f.data());
+        for (int k = 0; k < nc; ++k)
+            selection[(size_t)t * nc + k] = sel[k] ? 1 : 0;
+    }
+    return nc;
+}
+"""),
 }
 
 

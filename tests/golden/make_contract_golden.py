@@ -435,6 +435,28 @@ def main():
            "Normalization.cc:24-262 + SlidingWindow.hh:22-471), 40 segments"] = dict(
         tried=nn_, differ=dn, fma_sites="f64 products of widened f32 values are exact: fused or not, the same bits")
 
+    # ---- f4: Mm::DensityClustering<f32, f32> (function text): rand()-initialised k-means over the scaled means, cluster selection
+    u8p = np.ctypeslib.ndpointer(np.uint8, flags="C")
+    for c in R:
+        R[c].ref_density_clustering.restype = C.c_int
+        R[c].ref_density_clustering.argtypes = [f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, u8p, f32p, f32p, C.c_int, u8p]
+    dc_cases = [(90, 24, 16, 4), (300, 40, 64, 10), (20, 40, 256, 32), (64, 8, 8, 8)]   # (densities, padded dim, clusters, select)
+    gold["dc_cases"] = np.array(dc_cases, np.int32)
+    dd = nd = 0
+    for i, (nk, pdim, ncl, nsel) in enumerate(dc_cases):
+        ms = (rng2.standard_normal((nk, pdim)) * 3).astype(np.float32)
+        xs = (rng2.standard_normal((12, pdim)) * 3).astype(np.float32)
+        gold["dc_ms_%d" % i], gold["dc_xs_%d" % i] = ms, xs
+        nce = min(ncl, nk)
+        for c in R:
+            cof, cm, sel = np.zeros(nk, np.uint8), np.zeros(nce * pdim, np.float32), np.zeros(12 * nce, np.uint8)
+            assert R[c].ref_density_clustering(ms.reshape(-1), nk, pdim, ncl, min(nsel, nce), 5, cof, cm, xs.reshape(-1), 12, sel) == nce
+            gold["dc_cof_%d_%s" % (i, c)], gold["dc_cm_%d_%s" % (i, c)], gold["dc_sel_%d_%s" % (i, c)] = cof, cm, sel
+        dd += ndiff(gold["dc_cm_%d_off" % i], gold["dc_cm_%d_fma" % i]) + int(np.count_nonzero(gold["dc_cof_%d_off" % i] != gold["dc_cof_%d_fma" % i]))
+        nd += nce * pdim + nk
+    report["Mm::DensityClustering<f32, f32> (function text, DensityClustering.tcc:61-119,157-180 + DensityClustering.cc:45-57): assignment + means"] = dict(
+        tried=nd, differ=dd, fma_sites="unrolledVectorDistance's score += df * df (the product has no contract=fma mode for the preselection scorers)")
+
     np.savez_compressed(os.path.join(HERE, "ref_contract.npz"), **gold)
     out = os.path.join(ROOT, "profiles", "r05")
     os.makedirs(out, exist_ok=True)

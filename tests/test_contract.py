@@ -5,7 +5,7 @@ other f32 sums into fused multiply-adds; configured with -DMARCH=x86-64 it does 
 oracle/liboracle_fma.so the first (orc.h).  Both are held, bit for bit, to
   * tests/golden/ref_contract.npz -- outputs of the reference compiled both ways (tests/golden/make_contract_golden.py), everywhere;
   * oracle/_ref/libref.so / libref_native.so live on fresh inputs, where the reference tree is mounted (build container).
-Function-text pins (oracle/ref/extract_fn.py): a13 distance, f1 regression, a7 filter apply, a3 Hamming table, a18 batch-float sum, a1 preemphasis, a7 filter builder and boundary, a10 cosine transform, f4 AR-to-cepstrum, the gammatone filter bank and the integration nodes, f1 normalisation.
+Function-text pins (oracle/ref/extract_fn.py): a13 distance, f1 regression, a7 filter apply, a3 Hamming table, a18 batch-float sum, a1 preemphasis, a7 filter builder and boundary, a10 cosine transform, f4 AR-to-cepstrum, the gammatone filter bank and the integration nodes, f1 normalisation, f4 density clustering.
 """
 import ctypes as C
 import os
@@ -232,6 +232,29 @@ def test_normalization_against_the_reference_function_text(contract):
                                   right=0 if whole else int(right), contract=contract)
         want = Z["norm_out_%d_%s" % (i, contract)]
         assert _same_bits_or_both_nan(got, want), (contract, i, typ, length, right)
+
+
+def test_density_clustering_against_the_reference_function_text():
+    """f4 (preselection-batch-float): Mm::DensityClustering<f32, f32> -- srand(1) / rand() initialisation, five k-means iterations
+    (assignment by unrolledVectorDistance, means through f64 sums), the cluster count reduced to the number of densities, and
+    selectClusters.  x86-64 build only: the preselection scorers have no contract=fma mode (the default build fuses the distance's sum)"""
+    L = Oracle("off")
+    for i, (nk, pdim, ncl, nsel) in enumerate(Z["dc_cases"]):
+        ms, xs = Z["dc_ms_%d" % i], Z["dc_xs_%d" % i]
+        nk, pdim = int(nk), int(pdim)
+        # a model whose scaled, padded means ARE ms: unit pooled variance (1 / sqrt(1) = 1 exactly), one density per mixture
+        model = dict(dim=pdim, mix_offsets=np.arange(nk + 1, dtype=np.uint32), dens_index=np.arange(nk, dtype=np.uint32),
+                     log_weight=np.zeros(nk), dens_mean=np.arange(nk, dtype=np.uint32), dens_cov=np.zeros(nk, np.uint32),
+                     means=np.ascontiguousarray(ms), variances=np.ones((1, pdim), np.float32))
+        nce = min(int(ncl), nk)
+        _, cof, cm = OracleGmm(model, contract="off").score_preselection_float(xs, int(ncl), min(int(nsel), nce), 5, 40000.0)
+        assert np.array_equal(np.asarray(cof).astype(np.uint8), Z["dc_cof_%d_off" % i]), i
+        assert np.array_equal(bits(np.ascontiguousarray(cm, np.float32).reshape(-1)), bits(Z["dc_cm_%d_off" % i])), i
+        want = Z["dc_sel_%d_off" % i].reshape(len(xs), nce)
+        for t in range(len(xs)):
+            sel = np.zeros(nce, np.uint8)
+            L.orc_cluster_select(np.ascontiguousarray(Z["dc_cm_%d_off" % i]), nce, pdim, min(int(nsel), nce), np.ascontiguousarray(xs[t]), sel)
+            assert np.array_equal(sel, want[t]), (i, t)
 
 
 def _same_bits_or_both_nan(a, b):
