@@ -252,6 +252,9 @@ def load_ref(contract="off"):
         R.ref_matrix_vector.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         R.ref_complex_amplitude.restype = C.c_int
         R.ref_complex_amplitude.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    if hasattr(R, "ref_gdm_score"):
+        R.ref_gdm_score.restype = None
+        R.ref_gdm_score.argtypes = [C.c_int, f32p, C.c_int, C.c_int, f32p, f32p, f32p, f32p, C.POINTER(C.c_float), C.POINTER(C.c_uint), C.c_void_p]
     if hasattr(R, "ref_gdm_distance"):   # function-text pins (oracle/ref/extract_fn.py)
         R.ref_gdm_distance.restype = C.c_float
         R.ref_gdm_distance.argtypes = [f32p, f32p, f32p, C.c_int]

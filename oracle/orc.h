@@ -32,12 +32,11 @@
  *   GMM distance, regression, batch-float sum / minimum:
  *       pinned bit-exactly on the reference's
  *       own function text compiled with both flag sets (oracle/ref/extract_fn.py, tests/test_contract.py).
- *   the filter bank as a whole, DCT, GMM max score (combine / tie rule): pinned by the known answers the
+ *   GMM max score (combine / tie rule) and the log-add scorer: the reference's calculateScoreAndDensity text, both builds (extract_fn.py
+ *       gdm_distance).  The filter bank as a whole: pinned by the known answers the
  *       reference produced in this container.
  *   NN forward: pinned by the reference's own unit-test vectors
  *       (Test/Nn_LinearAndActivationLayer.cc, Test/Nn_NeuralNetwork.cc).
- *   GMM log-add (sum) scorer: parity unpinned (class is not reachable from reference
- *       config, no reference test holds a vector for it).
  */
 #ifndef ORC_H
 #define ORC_H

@@ -117,21 +117,87 @@ SPECS = {
     # Mm::GaussDiagonalMaximumFeatureScorer::distance (both the __SSE3__ branch and the plain one; the flag sets of the Makefile
     # define __SSE3__, so the first is what gets compiled -- as in the reference's own build, CompileOptions.cmake:21-26)
     "gdm_distance": (
-        "Mm/GaussDiagonalMaximumFeatureScorer.cc", [(144, 218)],
-        "4f9abec35b194e3f16a49f7082b381b0c7897149f65eb7e40afae00f9dfbccbb",
-        """#include <Mm/Types.hh>
+        "Mm/GaussDiagonalMaximumFeatureScorer.cc", [(116, 142), (144, 218), (230, 298)],
+        "5c7a6289ede81c709f94063ae8f368a1dc61fe592551827da305b7b239578bf1",
+        """#include <Core/Types.hh>
+#include <Core/Assertions.hh>
+#include <Mm/Types.hh>
+#include <algorithm>
+#include <cmath>
 #include <vector>
 #ifdef __SSE3__
 #include <pmmintrin.h>
 #include <xmmintrin.h>
 #endif
 namespace Mm {
-// shell: declares the one member whose definition follows (the reference's class declaration,
-// Mm/GaussDiagonalMaximumFeatureScorer.hh:28-62, needs Core/Configuration.hh)
-class GaussDiagonalMaximumFeatureScorer {
+// shell.  The members whose definitions follow -- calculateScoreAndDensity (the f64 combine, the strict comparison, the 0.5), distance,
+// and the log-add scorer's three members -- read four tables through the accessors of the element classes
+// (Mm/MixtureFeatureScorerElement.hh:24-38, Mm/GaussDensity.hh, Mm/CovarianceFeatureScorerElement.hh:21-50: all of them sit behind
+// Core/Configuration.hh).  Re-declared here with the same accessor names, result types and storage types; nothing of their logic
+// (operator=, scale) is involved.
+class MixtureFeatureScorerElement {
 public:
+    std::vector<DensityIndex> densityIndices_;
+    std::vector<Score>        minus2LogWeights_;
+    size_t                    nDensities() const { return densityIndices_.size(); }
+    DensityIndex              densityIndex(size_t dns) const { return densityIndices_[dns]; }
+    const std::vector<Score>& minus2LogWeights() const { return minus2LogWeights_; }
+};
+class GaussDensity {
+public:
+    MeanIndex       meanIndex_;
+    CovarianceIndex covarianceIndex_;
+    MeanIndex       meanIndex() const { return meanIndex_; }
+    CovarianceIndex covarianceIndex() const { return covarianceIndex_; }
+};
+class CovarianceFeatureScorerElement {
+public:
+    std::vector<VarianceType> inverseSquareRootDiagonal_;
+    Score                     logNormalizationFactor_;
+    const std::vector<VarianceType>& inverseSquareRootDiagonal() const { return inverseSquareRootDiagonal_; }
+    Score                            logNormalizationFactor() const { return logNormalizationFactor_; }
+};
+typedef std::vector<MeanType> Mean;
+class AssigningFeatureScorer {
+public:
+    struct ScoreAndBestDensity {   // Mm/AssigningFeatureScorer.hh:29-32
+        Score            score;
+        DensityInMixture bestDensity;
+    };
+    class CachedAssigningContextScorer {
+    public:
+        virtual ~CachedAssigningContextScorer() {}
+    };
+};
+// Mm/GaussDiagonalMaximumFeatureScorer.hh:28-62
+class GaussDiagonalMaximumFeatureScorer : public AssigningFeatureScorer {
+public:
+    class Context : public CachedAssigningContextScorer {
+    public:
+        std::vector<FeatureType> featureVector_;
+    };
+    std::vector<MixtureFeatureScorerElement>    mixtureTable_;
+    std::vector<GaussDensity>                   densityTable_;
+    std::vector<Mean>                           meanTable_;
+    std::vector<CovarianceFeatureScorerElement> covarianceTable_;
+    virtual ~GaussDiagonalMaximumFeatureScorer() {}
+    virtual ScoreAndBestDensity calculateScoreAndDensity(const CachedAssigningContextScorer* cs, MixtureIndex mixtureIndex) const;
     Score distance(const std::vector<FeatureType>& feature, const std::vector<MeanType>& mean,
                    const std::vector<VarianceType>& inverseSquareRootVar) const;
+};
+// Mm/GaussDiagonalMaximumFeatureScorer.hh:96-115
+class GaussDiagonalSumFeatureScorer : public GaussDiagonalMaximumFeatureScorer {
+public:
+    typedef GaussDiagonalMaximumFeatureScorer Precursor;
+    mutable const CachedAssigningContextScorer* lastContext_      = nullptr;
+    mutable MixtureIndex                        lastMixtureIndex_ = 0;
+    mutable Score*                              scores_           = nullptr;
+    mutable size_t                              nDensities_       = 0;
+    void   calculateScoresAndNumberOfDensities(const CachedAssigningContextScorer* cs, MixtureIndex mixtureIndex) const;
+    size_t maximumNumberOfDensities() const;
+    virtual ScoreAndBestDensity calculateScoreAndDensity(const CachedAssigningContextScorer* cs, MixtureIndex mixtureIndex) const;
+    virtual void calculateDensityPosteriorProbabilities(const CachedAssigningContextScorer*, Score denominator, EmissionIndex e,
+                                                        std::vector<Mm::Weight>& result) const;
 };
 }  // namespace Mm
 using namespace Mm;
@@ -145,6 +211,41 @@ extern "C" float ref_gdm_distance(const float* x, const float* mu, const float* 
     std::vector<Mm::MeanType>     m(mu, mu + dim);
     std::vector<Mm::VarianceType> v(isr, isr + dim);
     return Mm::GaussDiagonalMaximumFeatureScorer().distance(f, m, v);
+}
+// ONE mixture of nd densities, every density with its own mean and covariance entry: m2lw [nd] (f32, as MixtureFeatureScorerElement keeps
+// them), lognorm [nd] (f32), means / isr [nd x dim].  mode 0: GaussDiagonalMaximumFeatureScorer::calculateScoreAndDensity, mode 1: the
+// log-add scorer's; posteriors (nullable, [nd], f64): calculateDensityPosteriorProbabilities with the score as denominator.
+extern "C" void ref_gdm_score(int mode, const float* x, int dim, int nd, const float* m2lw, const float* lognorm, const float* means,
+                              const float* isr, float* score, unsigned* best, double* posteriors) {
+    Mm::GaussDiagonalSumFeatureScorer s;   // (its base part serves mode 0)
+    s.mixtureTable_.resize(1);
+    for (int k = 0; k < nd; ++k) {
+        s.mixtureTable_[0].densityIndices_.push_back((Mm::DensityIndex)k);
+        s.mixtureTable_[0].minus2LogWeights_.push_back(m2lw[k]);
+        Mm::GaussDensity d;
+        d.meanIndex_ = (Mm::MeanIndex)k;
+        d.covarianceIndex_ = (Mm::CovarianceIndex)k;
+        s.densityTable_.push_back(d);
+        s.meanTable_.push_back(Mm::Mean(means + (size_t)k * dim, means + (size_t)(k + 1) * dim));
+        Mm::CovarianceFeatureScorerElement c;
+        c.inverseSquareRootDiagonal_.assign(isr + (size_t)k * dim, isr + (size_t)(k + 1) * dim);
+        c.logNormalizationFactor_ = lognorm[k];
+        s.covarianceTable_.push_back(c);
+    }
+    std::vector<Mm::Score> cache((size_t)(nd > 0 ? nd : 1));
+    s.scores_ = cache.data();
+    Mm::GaussDiagonalMaximumFeatureScorer::Context ctx;
+    ctx.featureVector_.assign(x, x + dim);
+    Mm::AssigningFeatureScorer::ScoreAndBestDensity r =
+            mode == 0 ? s.Mm::GaussDiagonalMaximumFeatureScorer::calculateScoreAndDensity(&ctx, 0) : s.calculateScoreAndDensity(&ctx, 0);
+    *score = r.score;
+    *best  = r.bestDensity;
+    if (posteriors && mode == 1) {
+        std::vector<Mm::Weight> p;
+        s.calculateDensityPosteriorProbabilities(&ctx, r.score, 0, p);
+        for (int k = 0; k < nd; ++k)
+            posteriors[k] = p[k];
+    }
 }
 """),
     # Signal::Regression::regressFirstOrder / regressSecondOrder (signal-regression, SURVEY section 8 row f1): the class declaration

@@ -457,6 +457,54 @@ def main():
     report["Mm::DensityClustering<f32, f32> (function text, DensityClustering.tcc:61-119,157-180 + DensityClustering.cc:45-57): assignment + means"] = dict(
         tried=nd, differ=dd, fma_sites="unrolledVectorDistance's score += df * df (the product has no contract=fma mode for the preselection scorers)")
 
+    # ---- a13 / a14: calculateScoreAndDensity of the maximum and of the log-add scorer (function text), per (frame, mixture), fed with
+    # the f32 tables the oracle builds from the model (those tables have their own pins: gaussLogNormFactor, inverseSquareRoot)
+    from oracle import OracleGmm
+    sys.path.insert(0, ROOT)
+    from tests import synth
+    for c in R:
+        R[c].ref_gdm_score.restype = None
+        R[c].ref_gdm_score.argtypes = [C.c_int, f32p, C.c_int, C.c_int, f32p, f32p, f32p, f32p, C.POINTER(C.c_float), C.POINTER(C.c_uint), C.c_void_p]
+    sc_cases = [(40, 16, True, 905), (39, 7, False, 906), (16, 3, True, 907), (45, 12, False, 908)]   # (dim, max densities, pooled, seed)
+    gold["sc_cases"] = np.array([[a, b, int(p_), sd] for a, b, p_, sd in sc_cases], np.int32)
+    dsc = nsc = 0
+    for i, (dim, kmax, pooled, seed) in enumerate(sc_cases):
+        model = synth.gmm_cart(6, 1, kmax, dim, seed=seed, pooled=pooled)
+        off = model["mix_offsets"]
+        if off[1] - off[0] >= 2:   # a tie inside mixture 0: the same density listed twice with the same weight
+            model["dens_index"][off[0] + 1] = model["dens_index"][off[0]]
+            model["log_weight"][off[0] + 1] = model["log_weight"][off[0]]
+        x = rng2.standard_normal((8, dim)).astype(np.float32)
+        x[6, 0] = np.nan
+        x[7] *= 1e19
+        for k, v in model.items():
+            if isinstance(v, np.ndarray):
+                gold["sc_model_%d_%s" % (i, k)] = v
+        gold["sc_x_%d" % i] = x
+        for c in R:
+            g = OracleGmm(model, contract=c)
+            m2lw, isr, ln = g.tables()
+            for mode in (0, 1):
+                sc, best = np.zeros((8, 6), np.float32), np.zeros((8, 6), np.uint32)
+                for t in range(8):
+                    for m in range(6):
+                        k0, k1 = int(off[m]), int(off[m + 1])
+                        d = model["dens_index"][k0:k1]
+                        means = np.ascontiguousarray(model["means"][model["dens_mean"][d]], np.float32)
+                        isrs = np.ascontiguousarray(isr[model["dens_cov"][d]], np.float32)
+                        lns = np.ascontiguousarray(ln[model["dens_cov"][d]], np.float32)
+                        s_, b_ = C.c_float(0), C.c_uint(0)
+                        R[c].ref_gdm_score(mode, np.ascontiguousarray(x[t]), dim, k1 - k0, np.ascontiguousarray(m2lw[k0:k1]), lns,
+                                           means.reshape(-1), isrs.reshape(-1), C.byref(s_), C.byref(b_), None)
+                        sc[t, m], best[t, m] = s_.value, b_.value
+                gold["sc_score_%d_%d_%s" % (i, mode, c)], gold["sc_best_%d_%d_%s" % (i, mode, c)] = sc, best
+        for mode in (0, 1):
+            dsc += ndiff(gold["sc_score_%d_%d_off" % (i, mode)], gold["sc_score_%d_%d_fma" % (i, mode)])
+            nsc += 48
+    report["Mm::GaussDiagonalMaximumFeatureScorer::calculateScoreAndDensity + GaussDiagonalSumFeatureScorer (function text, "
+           "GaussDiagonalMaximumFeatureScorer.cc:116-142,230-298) on the distance of the same pin"] = dict(
+        tried=nsc, differ=dsc, fma_sites="none of their own (f64 sums, one product by 0.5); the distance's")
+
     np.savez_compressed(os.path.join(HERE, "ref_contract.npz"), **gold)
     out = os.path.join(ROOT, "profiles", "r05")
     os.makedirs(out, exist_ok=True)

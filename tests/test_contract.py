@@ -5,7 +5,7 @@ other f32 sums into fused multiply-adds; configured with -DMARCH=x86-64 it does 
 oracle/liboracle_fma.so the first (orc.h).  Both are held, bit for bit, to
   * tests/golden/ref_contract.npz -- outputs of the reference compiled both ways (tests/golden/make_contract_golden.py), everywhere;
   * oracle/_ref/libref.so / libref_native.so live on fresh inputs, where the reference tree is mounted (build container).
-Function-text pins (oracle/ref/extract_fn.py): a13 distance, f1 regression, a7 filter apply, a3 Hamming table, a18 batch-float sum, a1 preemphasis, a7 filter builder and boundary, a10 cosine transform, f4 AR-to-cepstrum, the gammatone filter bank and the integration nodes, f1 normalisation, f4 density clustering.
+Function-text pins (oracle/ref/extract_fn.py): a13 / a14 distance, combine rule and log-add scorer, f1 regression, a7 filter apply, a3 Hamming table, a18 batch-float sum, a1 preemphasis, a7 filter builder and boundary, a10 cosine transform, f4 AR-to-cepstrum, the gammatone filter bank and the integration nodes, f1 normalisation, f4 density clustering.
 """
 import ctypes as C
 import os
@@ -232,6 +232,26 @@ def test_normalization_against_the_reference_function_text(contract):
                                   right=0 if whole else int(right), contract=contract)
         want = Z["norm_out_%d_%s" % (i, contract)]
         assert _same_bits_or_both_nan(got, want), (contract, i, typ, length, right)
+
+
+@pytest.mark.parametrize("contract", CONTRACTS)
+def test_score_and_best_density_against_the_reference_function_text(contract):
+    """a13 / a14: calculateScoreAndDensity of Mm::GaussDiagonalMaximumFeatureScorer (f64 sum of the three terms, `bestScore > score`
+    against the narrowed best, 0.5 x, first density on ties, 0.5 x FLT_MAX and "no density" on NaN or overflowing frames) and of the log-add scorer (f32 sum, expf / logf):
+    the reference's own function text, fed per (frame, mixture) with the oracle's f32 tables"""
+    for i, (dim, kmax, pooled, seed) in enumerate(Z["sc_cases"]):
+        model = {k[len("sc_model_%d_" % i):]: Z[k] for k in Z.files if k.startswith("sc_model_%d_" % i)}
+        model["dim"] = int(dim)
+        g = OracleGmm(model, contract=contract)
+        for mode in (0, 1):
+            sc, best = g.score(Z["sc_x_%d" % i], mode=mode)
+            want, wbest = Z["sc_score_%d_%d_%s" % (i, mode, contract)], Z["sc_best_%d_%d_%s" % (i, mode, contract)]
+            assert _same_bits_or_both_nan(sc, want), (contract, i, mode)
+            assert np.array_equal(best.astype(np.uint32), wbest), (contract, i, mode)
+        # a NaN frame (row 6) and one whose distances overflow (row 7): `bestScore > score` is never true -- 0.5 x FLT_MAX and no density
+        for row in (6, 7):
+            assert (Z["sc_score_%d_0_%s" % (i, contract)][row] == np.float32(0.5 * float(np.finfo(np.float32).max))).all()
+            assert (Z["sc_best_%d_0_%s" % (i, contract)][row] == 0xffffffff).all()
 
 
 def test_density_clustering_against_the_reference_function_text():
