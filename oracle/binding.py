@@ -127,6 +127,9 @@ def Oracle(contract=None):
     L.orc_filter_apply.restype = C.c_float
     L.orc_filter_apply.argtypes = [f32p, C.c_int, C.c_int, f32p]
     L.orc_hamming_window.argtypes = [f32p, C.c_int]
+    L.orc_cluster_u8.restype = None
+    L.orc_cluster_u8.argtypes = [np.ctypeslib.ndpointer(np.uint8, flags="C"), C.c_int, C.c_int, C.c_int, C.c_int,
+                                 np.ctypeslib.ndpointer(np.uint32, flags="C"), np.ctypeslib.ndpointer(np.uint8, flags="C")]
     L.orc_cluster_select.restype = None
     L.orc_cluster_select.argtypes = [f32p, C.c_int, C.c_int, C.c_int, f32p, np.ctypeslib.ndpointer(np.uint8, flags="C")]
     L.orc_window_value.restype = C.c_float
@@ -297,6 +300,8 @@ def load_ref(contract="off"):
         u8p = np.ctypeslib.ndpointer(np.uint8, flags="C")
         R.ref_density_clustering.restype = C.c_int
         R.ref_density_clustering.argtypes = [f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, u8p, f32p, f32p, C.c_int, u8p]
+        R.ref_density_clustering_u8.restype = C.c_int
+        R.ref_density_clustering_u8.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, u8p, u8p]
     if hasattr(R, "ref_preemphasis"):
         R.ref_preemphasis.argtypes = [C.c_float, C.c_double, f32p, C.c_long, C.c_int, C.c_int, f32p]
     _refs[contract] = R

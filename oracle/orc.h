@@ -222,10 +222,12 @@ float orc_gmm_distance(const float* x, const float* mu, const float* inv_sqrt_va
 int orc_gmm_score_preselection_float(const orc_gmm* h, const double* log_weight, const float* variances, const float* feats, int T,
                                      int n_clusters, int n_select, int iterations, float backoff, float* scores,
                                      uint32_t* cluster_of_out, float* cluster_means_out, int* n_clusters_out);
-/* Mm::BatchPreselectionIntFeatureScorer ("preselection-batch-int"): cluster_means [n_clusters x dim] u8; parity unpinned */
+/* Mm::BatchPreselectionIntFeatureScorer ("preselection-batch-int"): cluster_means [n_clusters x dim] u8; its clustering is pinned on the
+ * reference's template text (orc_cluster_u8), the integer scoring loop is read */
 int orc_gmm_score_preselection_int(const orc_gmm* h, const double* log_weight, const float* variances, const float* feats, int T,
                                    int n_clusters, int n_select, int iterations, float* scores, uint32_t* cluster_of_out,
                                    uint8_t* cluster_means_out, int* n_clusters_out);
+void  orc_cluster_u8(const uint8_t* means, int nk, int dim, int n_clusters, int iterations, uint32_t* cof, uint8_t* cm); /* DensityClustering<u8, s32> */
 void  orc_cluster_select(const float* cm, int n_clusters, int pdim, int n_select, const float* xs, unsigned char* sel); /* DensityClustering::selectClusters */
 float orc_batch_float_fill(const float* ms, const float* cst, int nk, const float* xs, int pdim); /* fillScoreCacheTpl, one feature x one mixture */
 int orc_gmm_score_batch_float(const orc_gmm* h, const double* log_weight, const float* variances,

@@ -454,6 +454,55 @@ static uint8_t orc_quantize_u8(float v) {
  * arithmetic unrolled): pooled covariance only; quantizationScale (:352-373) is getScaling's formula on the unscaled 1/sigma;
  * scale_ = (f32)(2.0 * scale^2) (:389); constants (s32)(logNorm * scale^2 - scale_ * logWeight) with the subtraction in f64 (:407);
  * the SSE2 distance (:427-447) is the exact integer sum; score = (f32)min / scale_ in f32 (:500); no density assignment. */
+/* Mm::DensityClustering<u8, s32> (Mm/DensityClustering.tcc:61-119; PINNED on the function text, oracle/ref/extract_fn.py
+ * density_clustering): srand(1) / rand() initialisation with distinct entries, `iterations` x (assign every entry to the cluster at the
+ * smallest integer distance, first on ties; cluster mean = f64 sum of its entries / count, converted to u8).  means [nk x dim] per mixture
+ * entry; cof [nk], cm [n_clusters x dim]. */
+static int orc_int_distance(const uint8_t* a, const uint8_t* b, int dim);
+void orc_cluster_u8(const uint8_t* means, int nk, int dim, int n_clusters, int iterations, uint32_t* cof, uint8_t* cm) {
+    char* used = (char*)calloc((size_t)nk, 1);
+    srand(1);
+    for (int c = 0; c < n_clusters; ++c) {
+        uint32_t pick;
+        do {
+            pick = (uint32_t)rand() % (uint32_t)nk;
+        } while (used[pick]);
+        used[pick] = 1;
+        memcpy(cm + (size_t)c * dim, means + (size_t)pick * dim, (size_t)dim);
+    }
+    free(used);
+    double* sums = (double*)calloc((size_t)dim, 8);
+    for (int it = 0; it < iterations; ++it) {
+        for (int k = 0; k < nk; ++k) {
+            int      bd = INT32_MAX;
+            uint32_t bc = 0;
+            for (int c = 0; c < n_clusters; ++c) {
+                int d = orc_int_distance(cm + (size_t)c * dim, means + (size_t)k * dim, dim);
+                if (d < bd) {
+                    bd = d;
+                    bc = (uint32_t)c;
+                }
+            }
+            cof[k] = bc;
+        }
+        for (int c = 0; c < n_clusters; ++c) {
+            size_t cnt = 0;
+            for (int i = 0; i < dim; ++i)
+                sums[i] = 0;
+            for (int k = 0; k < nk; ++k)
+                if (cof[k] == (uint32_t)c) {
+                    for (int i = 0; i < dim; ++i)
+                        sums[i] = sums[i] + (double)means[(size_t)k * dim + i];
+                    ++cnt;
+                }
+            if (cnt)
+                for (int i = 0; i < dim; ++i)
+                    cm[(size_t)c * dim + i] = (uint8_t)(sums[i] / (double)cnt);
+        }
+    }
+    free(sums);
+}
+
 /* variant 1 with `ps`: Mm::BatchPreselectionIntFeatureScorer ("preselection-batch-int", Mm/BatchFeatureScorer.cc:514-578) =
  * the batch-int scorer restricted to the densities of the nSelected clusters closest to the quantised feature, with
  * Mm::DensityClustering<u8, s32> (Mm/DensityClustering.tcc, see the float variant above) over the quantised per-entry means:
@@ -558,47 +607,12 @@ static int orc_gmm_score_quantized(const orc_gmm* h, int variant, const double* 
         cof        = (uint32_t*)calloc(nk, 4);
         active     = (char*)calloc((size_t)n_clusters, 1);
         items      = (orc_cli_item*)calloc((size_t)n_clusters, sizeof(orc_cli_item));
-        char* used = (char*)calloc(nk, 1);
-        srand(1);
-        for (int c = 0; c < n_clusters; ++c) {
-            uint32_t pick;
-            do {
-                pick = (uint32_t)rand() % (uint32_t)nk;
-            } while (used[pick]);
-            used[pick] = 1;
-            memcpy(cm + (size_t)c * dim, qmean + (size_t)h->dens_index[pick] * dim, (size_t)dim);
-        }
-        free(used);
-        double* sums = (double*)calloc((size_t)dim, 8);
-        for (int it = 0; it < ps->iterations; ++it) {
-            for (size_t k = 0; k < nk; ++k) {
-                int      bd = INT32_MAX;
-                uint32_t bc = 0;
-                for (int c = 0; c < n_clusters; ++c) {
-                    int d = orc_int_distance(cm + (size_t)c * dim, qmean + (size_t)h->dens_index[k] * dim, dim);
-                    if (d < bd) {
-                        bd = d;
-                        bc = (uint32_t)c;
-                    }
-                }
-                cof[k] = bc;
-            }
-            for (int c = 0; c < n_clusters; ++c) {
-                size_t cnt = 0;
-                for (int i = 0; i < dim; ++i)
-                    sums[i] = 0;
-                for (size_t k = 0; k < nk; ++k)
-                    if (cof[k] == (uint32_t)c) {
-                        for (int i = 0; i < dim; ++i)
-                            sums[i] = sums[i] + (double)qmean[(size_t)h->dens_index[k] * dim + i];
-                        ++cnt;
-                    }
-                if (cnt)
-                    for (int i = 0; i < dim; ++i)
-                        cm[(size_t)c * dim + i] = (uint8_t)(sums[i] / (double)cnt);
-            }
-        }
-        free(sums);
+        /* the clustering sees the means per mixture ENTRY, as BatchIntFeatureScorer::init lays them out */
+        uint8_t* em = (uint8_t*)malloc(nk * (size_t)dim);
+        for (size_t k = 0; k < nk; ++k)
+            memcpy(em + k * dim, qmean + (size_t)h->dens_index[k] * dim, (size_t)dim);
+        orc_cluster_u8(em, (int)nk, dim, n_clusters, ps->iterations, cof, cm);
+        free(em);
         if (ps->cluster_of_out)
             memcpy(ps->cluster_of_out, cof, nk * 4);
         if (ps->cluster_means_out)

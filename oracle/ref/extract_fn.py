@@ -1147,6 +1147,19 @@ extern "C" int ref_density_clustering(const float* means, int n_dens, int dim, i
     }
     return nc;
 }
+// the same for Mm::DensityClustering<u8, s32> (preselection-batch-int): means [n_dens x dim] u8 per mixture entry
+extern "C" int ref_density_clustering_u8(const unsigned char* means, int n_dens, int dim, int n_clusters, int iterations,
+                                         unsigned char* cluster_of, unsigned char* cluster_means) {
+    Mm::DensityClustering<u8, s32> c((u32)n_clusters, 1);
+    c.init((u32)dim, (u32)n_dens);
+    c.buildLoop(means, (u32)iterations);
+    const int nc = (int)c.nClusters();
+    for (int k = 0; k < n_dens; ++k)
+        cluster_of[k] = c.clusterIndexForDensity((size_t)k);
+    for (int i = 0; i < nc * dim; ++i)
+        cluster_means[i] = c.means()[i];
+    return nc;
+}
 """),
 }
 

@@ -454,6 +454,16 @@ def main():
             gold["dc_cof_%d_%s" % (i, c)], gold["dc_cm_%d_%s" % (i, c)], gold["dc_sel_%d_%s" % (i, c)] = cof, cm, sel
         dd += ndiff(gold["dc_cm_%d_off" % i], gold["dc_cm_%d_fma" % i]) + int(np.count_nonzero(gold["dc_cof_%d_off" % i] != gold["dc_cof_%d_fma" % i]))
         nd += nce * pdim + nk
+    R["off"].ref_density_clustering_u8.restype = C.c_int
+    R["off"].ref_density_clustering_u8.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, u8p, u8p]
+    for i, (nk, dim, ncl) in enumerate([(150, 48, 32), (40, 16, 256), (300, 64, 100)]):
+        q = rng2.integers(0, 256, (nk, dim)).astype(np.uint8)
+        if i == 0:
+            q[nk // 2:] = q[:nk - nk // 2]   # duplicates: ties
+        nce = min(ncl, nk)
+        cof, cm = np.zeros(nk, np.uint8), np.zeros(nce * dim, np.uint8)
+        assert R["off"].ref_density_clustering_u8(q.reshape(-1), nk, dim, ncl, 5, cof, cm) == nce
+        gold["dcu_ms_%d" % i], gold["dcu_cof_%d" % i], gold["dcu_cm_%d" % i], gold["dcu_ncl_%d" % i] = q, cof, cm, np.array([ncl])
     report["Mm::DensityClustering<f32, f32> (function text, DensityClustering.tcc:61-119,157-180 + DensityClustering.cc:45-57): assignment + means"] = dict(
         tried=nd, differ=dd, fma_sites="unrolledVectorDistance's score += df * df (the product has no contract=fma mode for the preselection scorers)")
 

@@ -277,6 +277,19 @@ def test_density_clustering_against_the_reference_function_text():
             assert np.array_equal(sel, want[t]), (i, t)
 
 
+def test_integer_density_clustering_against_the_reference_function_text():
+    """f4 (preselection-batch-int): the same template as Mm::DensityClustering<u8, s32> -- integer distances, first cluster on ties (the
+    first case repeats half of its entries), means through f64 sums converted to u8"""
+    L = Oracle("off")
+    for i in range(3):
+        q, ncl = Z["dcu_ms_%d" % i], int(Z["dcu_ncl_%d" % i][0])
+        nk, dim = q.shape
+        nce = min(ncl, nk)
+        cof, cm = np.zeros(nk, np.uint32), np.zeros(nce * dim, np.uint8)
+        L.orc_cluster_u8(np.ascontiguousarray(q).reshape(-1), nk, dim, nce, 5, cof, cm)
+        assert np.array_equal(cof.astype(np.uint8), Z["dcu_cof_%d" % i]) and np.array_equal(cm, Z["dcu_cm_%d" % i]), i
+
+
 def _same_bits_or_both_nan(a, b):
     return bool(np.all((bits(a) == bits(b)) | (np.isnan(a) & np.isnan(b))))
 
