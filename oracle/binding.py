@@ -302,6 +302,9 @@ def load_ref(contract="off"):
         R.ref_density_clustering.argtypes = [f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, u8p, f32p, f32p, C.c_int, u8p]
         R.ref_density_clustering_u8.restype = C.c_int
         R.ref_density_clustering_u8.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, u8p, u8p]
+    if hasattr(R, "ref_vector_function"):
+        R.ref_vector_function.restype = None
+        R.ref_vector_function.argtypes = [C.c_int, C.c_float, f32p, C.c_long, f32p]
     if hasattr(R, "ref_preemphasis"):
         R.ref_preemphasis.argtypes = [C.c_float, C.c_double, f32p, C.c_long, C.c_int, C.c_int, f32p]
     _refs[contract] = R

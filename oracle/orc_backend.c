@@ -292,7 +292,8 @@ void orc_vector_normalize(int type, const float* in, int n, int dim, float* out)
 /* generic-vector-f32-<function> (Flow/SimpleFunction.hh:40-345), kinds as AMX_VFUNC_*.  Overloads as the header resolves them: the
  * vector forms of log / ln / exp / sqrt / cos cast std::log10 etc. to T (*)(T) -> the float functions; log-plus, power and quantize
  * call the unqualified log10 / pow / rint on floats -> the double functions, narrowed on assignment (checked for pow with g++ on
- * the reference's headers, see orc_mfcc.c).  PARITY UNPINNED (SimpleFunction.hh includes Flow/Node.hh). */
+ * the reference's headers, see orc_mfcc.c).  PINNED on the header's templates taken whole (oracle/ref/extract_fn.py vector_functions;
+ * SimpleFunction.hh itself includes Flow/Node.hh for the node template behind them). */
 void orc_vector_function(int kind, float prm, const float* in, long n, int dim, float* out) {
     for (long i = 0; i < n * dim; ++i) {
         float v = in[i], y;

@@ -1161,6 +1161,51 @@ extern "C" int ref_density_clustering_u8(const unsigned char* means, int n_dens,
     return nc;
 }
 """),
+    # The generic-vector-f32-<function> functors of Flow/SimpleFunction.hh (SURVEY section 8 row a9: the MFCC's log10; the PLP chain's
+    # power; and the rest of the family: log-plus, ln, exp, sqrt, cos, add, multiply, quantize, abs, minimum, maximum): header-only
+    # templates, but the header includes Flow/Node.hh (boost) for the node template behind them.  The templates are taken whole
+    # (:32-358); which libm overload an unqualified log10 / pow / rint on an f32 picks depends on the math headers in scope -- <cmath>
+    # (the header's own include) here, as there.
+    "vector_functions": (
+        "Flow/SimpleFunction.hh", [(32, 358)],
+        "668385596c1ca9dc1f1fa38e9de7d55ae685431d8adf8244db629a2fe1475ccb",
+        """#include <Core/Types.hh>
+#include <Core/Utility.hh>
+#include <Flow/DataAdaptor.hh>
+#include <Flow/Vector.hh>
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+#include <string>
+namespace Flow {
+// ---- reference text, %(file)s:%(ranges)s ----
+""",
+        """
+}  // namespace Flow
+// ---- end of reference text ----
+// kind: 0 log (log10), 1 log-plus, 2 ln, 3 exp, 4 power, 5 sqrt, 6 cos, 7 addition, 8 multiplication, 9 quantize, 10 abs, 11 minimum,
+// 12 maximum; in / out [n]
+extern "C" void ref_vector_function(int kind, float prm, const float* in, long n, float* out) {
+    Flow::Vector<f32> v(in, in + n);
+    switch (kind) {
+        case 0: Flow::VectorLogFunction<f32>().apply(v, prm); break;
+        case 1: Flow::VectorLogPlusFunction<f32>().apply(v, prm); break;
+        case 2: Flow::VectorLnFunction<f32>().apply(v, prm); break;
+        case 3: Flow::VectorExpFunction<f32>().apply(v, prm); break;
+        case 4: Flow::VectorPowerFunction<f32>().apply(v, prm); break;
+        case 5: Flow::VectorSqrtFunction<f32>().apply(v, prm); break;
+        case 6: Flow::VectorCosFunction<f32>().apply(v, prm); break;
+        case 7: Flow::VectorScalarAdditionFunction<f32>().apply(v, prm); break;
+        case 8: Flow::VectorScalarMultiplicationFunction<f32>().apply(v, prm); break;
+        case 9: Flow::VectorQuantizationFunction<f32>().apply(v, prm); break;
+        case 10: Flow::VectorAbsoluteValueFunction<f32>().apply(v, prm); break;
+        case 11: Flow::VectorMinimumFunction<f32>().apply(v, prm); break;
+        default: Flow::VectorMaximumFunction<f32>().apply(v, prm); break;
+    }
+    for (long i = 0; i < n; ++i)
+        out[i] = v[i];
+}
+"""),
 }
 
 

@@ -515,6 +515,27 @@ def main():
            "GaussDiagonalMaximumFeatureScorer.cc:116-142,230-298) on the distance of the same pin"] = dict(
         tried=nsc, differ=dsc, fma_sites="none of their own (f64 sums, one product by 0.5); the distance's")
 
+    # ---- a9 and the rest of generic-vector-f32-<function> (templates of Flow/SimpleFunction.hh taken whole): 13 kinds incl. NaN / inf / +-0
+    rng3 = np.random.default_rng(20261001)
+    for c in R:
+        R[c].ref_vector_function.restype = None
+        R[c].ref_vector_function.argtypes = [C.c_int, C.c_float, f32p, C.c_long, f32p]
+    dv = 0
+    for kind in range(13):
+        x = (rng3.standard_normal(96) * rng3.choice([0.01, 1, 100, 1e6], 96)).astype(np.float32)
+        if kind in (0, 1, 2, 4, 5):
+            x = np.abs(x) + np.float32(1e-3)
+        x[:5] = [0.0, -0.0, np.inf, -np.inf, np.nan]
+        prm = np.float32([0.0, 0.33, 0.0, 0.0, 0.33, 0.0, 0.0, 2.5, 0.1, 0.25, 0.0, 1.5, -1.5][kind])
+        gold["vf_in_%d" % kind], gold["vf_prm_%d" % kind] = x, np.array([prm], np.float32)
+        for c in R:
+            out = np.zeros_like(x)
+            R[c].ref_vector_function(kind, prm, x, len(x), out)
+            gold["vf_out_%d_%s" % (kind, c)] = out
+        a, b = gold["vf_out_%d_off" % kind], gold["vf_out_%d_fma" % kind]
+        dv += int(np.count_nonzero((bits(a) != bits(b)) & ~(np.isnan(a) & np.isnan(b))))
+    report["generic-vector-f32-<function>: 13 functors of Flow/SimpleFunction.hh (templates taken whole, :32-358)"] = dict(tried=13 * 96, differ=dv)
+
     np.savez_compressed(os.path.join(HERE, "ref_contract.npz"), **gold)
     out = os.path.join(ROOT, "profiles", "r05")
     os.makedirs(out, exist_ok=True)

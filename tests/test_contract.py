@@ -277,6 +277,21 @@ def test_density_clustering_against_the_reference_function_text():
             assert np.array_equal(sel, want[t]), (i, t)
 
 
+@pytest.mark.parametrize("contract", CONTRACTS)
+def test_vector_functions_against_the_reference_templates(contract):
+    """a9 (the MFCC's log10) and the other generic-vector-f32-<function> functors: Flow/SimpleFunction.hh's templates taken whole; which
+    libm overload the unqualified log10 / pow / rint pick on an f32, min / max with NaN, +-0 and infinities"""
+    L = Oracle(contract)
+    L.orc_vector_function.restype = None
+    L.orc_vector_function.argtypes = [C.c_int, C.c_float, np.ctypeslib.ndpointer(np.float32, flags="C"), C.c_long, C.c_int,
+                                      np.ctypeslib.ndpointer(np.float32, flags="C")]
+    for kind in range(13):
+        x, prm = Z["vf_in_%d" % kind], float(Z["vf_prm_%d" % kind][0])
+        out = np.zeros_like(x)
+        L.orc_vector_function(kind, prm, np.ascontiguousarray(x), len(x), 1, out)
+        assert _same_bits_or_both_nan(out, Z["vf_out_%d_%s" % (kind, contract)]), (contract, kind)
+
+
 def test_integer_density_clustering_against_the_reference_function_text():
     """f4 (preselection-batch-int): the same template as Mm::DensityClustering<u8, s32> -- integer distances, first cluster on ties (the
     first case repeats half of its entries), means through f64 sums converted to u8"""
