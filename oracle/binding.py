@@ -305,6 +305,9 @@ def load_ref(contract="off"):
     if hasattr(R, "ref_vector_function"):
         R.ref_vector_function.restype = None
         R.ref_vector_function.argtypes = [C.c_int, C.c_float, f32p, C.c_long, f32p]
+    if hasattr(R, "ref_vector_normalize"):
+        R.ref_vector_normalize.restype = None
+        R.ref_vector_normalize.argtypes = [C.c_int, f32p, C.c_int, f32p]
     if hasattr(R, "ref_preemphasis"):
         R.ref_preemphasis.argtypes = [C.c_float, C.c_double, f32p, C.c_long, C.c_int, C.c_int, f32p]
     _refs[contract] = R

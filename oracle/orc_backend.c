@@ -232,7 +232,7 @@ void orc_matrix_multiply(const float* M, int rows, int cols, const float* in, in
  * the f32-rounded products / the f32 elements to a double in index order; the statistics are then narrowed to f32 (`Value`), and
  * the elements are scaled with f32 operations.  Unqualified sqrt resolves to the double overload (see orc_gammatone.c); narrowing
  * its result to f32 equals sqrtf.  types: 0 amplitude-spectrum-energy, 1 energy, 2 maximum, 3 mean-energy, 4 mean, 5 variance.
- * Parity unpinned (the header includes Flow/Node.hh -> boost). */
+ * PINNED on the header's templates taken whole, both builds (oracle/ref/extract_fn.py vector_normalization). */
 void orc_vector_normalize(int type, const float* in, int n, int dim, float* out) {
     for (int t = 0; t < n; ++t) {
         const float* v = in + (size_t)t * dim;
@@ -249,8 +249,8 @@ void orc_vector_normalize(int type, const float* in, int n, int dim, float* out)
                 float p = v[i] * v[i];
                 mid     = mid + p;
             }
-            float ff = v[0] * v[0], bb = v[dim - 1] * v[dim - 1];
-            float ends = ff + bb;
+            float bb   = v[dim - 1] * v[dim - 1];
+            float ends = ORC_FMAF(v[0], v[0], bb); /* v.front() * v.front() + v.back() * v.back(): the FIRST product is fused in the default build */
             float sq = (float)sqrt((ends + 2 * mid) / (float)((size_t)(dim - 1) * 2));
             float r  = (float)1 / sq;
             for (int i = 0; i < dim; ++i)

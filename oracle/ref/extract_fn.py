@@ -1206,6 +1206,44 @@ extern "C" void ref_vector_function(int kind, float prm, const float* in, long n
         out[i] = v[i];
 }
 """),
+    # signal-vector-f32-<kind>-normalization (SURVEY section 8 row f1): the six functors of Signal/VectorNormalization.hh, header-only
+    # templates taken whole (:35-171 without line 98, `hope(!v.empty())`: the assertion's handler lives in Core/Assertions.cc, which needs
+    # boost, and no stand-in is written for it); the header includes Flow/Node.hh (boost) for the node template behind them.
+    "vector_normalization": (
+        "Signal/VectorNormalization.hh", [(35, 97), (99, 171)],
+        "14551f62fd97ac7f705f759b503a4246e4d81c152c2b07bacebaeb138f4be731",
+        """#include <Core/Types.hh>
+#include <Core/Assertions.hh>
+#include <Core/Utility.hh>
+#include <Flow/Data.hh>
+#include <Flow/Vector.hh>
+#include <algorithm>
+#include <cmath>
+#include <functional>
+#include <numeric>
+#include <string>
+#include <vector>
+namespace Signal {
+// ---- reference text, %(file)s:%(ranges)s ----
+""",
+        """
+}  // namespace Signal
+// ---- end of reference text ----
+// type 0 amplitude-spectrum-energy, 1 energy, 2 maximum, 3 mean-energy, 4 mean, 5 variance; one vector of dim values
+extern "C" void ref_vector_normalize(int type, const float* in, int dim, float* out) {
+    std::vector<f32> v(in, in + dim);
+    switch (type) {
+        case 0: Signal::AmplitudeSpectrumEnergyVectorNormalization<f32>()(v); break;
+        case 1: Signal::EnergyVectorNormalization<f32>()(v); break;
+        case 2: Signal::MaximumVectorNormalization<f32>()(v); break;
+        case 3: Signal::MeanEnergyVectorNormalization<f32>()(v); break;
+        case 4: Signal::MeanVectorNormalization<f32>()(v); break;
+        default: Signal::VarianceVectorNormalization<f32>()(v); break;
+    }
+    for (int i = 0; i < dim; ++i)
+        out[i] = v[i];
+}
+"""),
 }
 
 

@@ -536,6 +536,23 @@ def main():
         dv += int(np.count_nonzero((bits(a) != bits(b)) & ~(np.isnan(a) & np.isnan(b))))
     report["generic-vector-f32-<function>: 13 functors of Flow/SimpleFunction.hh (templates taken whole, :32-358)"] = dict(tried=13 * 96, differ=dv)
 
+    # ---- f1: signal-vector-f32-<kind>-normalization (templates of Signal/VectorNormalization.hh taken whole)
+    for c in R:
+        R[c].ref_vector_normalize.restype = None
+        R[c].ref_vector_normalize.argtypes = [C.c_int, f32p, C.c_int, f32p]
+    xv = (rng3.standard_normal((40, 33)) * rng3.choice([0.01, 1, 1000], (40, 1))).astype(np.float32)
+    gold["vn_in"] = xv
+    dvn = 0
+    for typ in range(6):
+        for c in R:
+            out = np.zeros_like(xv)
+            for r in range(len(xv)):
+                R[c].ref_vector_normalize(typ, xv[r], xv.shape[1], out[r])
+            gold["vn_out_%d_%s" % (typ, c)] = out
+        dvn += ndiff(gold["vn_out_%d_off" % typ], gold["vn_out_%d_fma" % typ])
+    report["signal-vector-f32-<kind>-normalization: 6 functors of Signal/VectorNormalization.hh (templates taken whole, :35-171)"] = dict(
+        tried=6 * xv.size, differ=dvn, fma_sites="vfmadd (amplitude-spectrum-energy: front * front + back * back)")
+
     np.savez_compressed(os.path.join(HERE, "ref_contract.npz"), **gold)
     out = os.path.join(ROOT, "profiles", "r05")
     os.makedirs(out, exist_ok=True)

@@ -292,6 +292,22 @@ def test_vector_functions_against_the_reference_templates(contract):
         assert _same_bits_or_both_nan(out, Z["vf_out_%d_%s" % (kind, contract)]), (contract, kind)
 
 
+@pytest.mark.parametrize("contract", CONTRACTS)
+def test_vector_normalization_against_the_reference_templates(contract):
+    """f1: signal-vector-f32-<kind>-normalization -- the six functors of Signal/VectorNormalization.hh taken whole (sums with a double seed
+    over f32-rounded products, statistics narrowed to f32, f32 scaling); the default build fuses one product of the amplitude-spectrum
+    energy's end terms"""
+    L = Oracle(contract)
+    L.orc_vector_normalize.restype = None
+    L.orc_vector_normalize.argtypes = [C.c_int, np.ctypeslib.ndpointer(np.float32, flags="C"), C.c_int, C.c_int,
+                                       np.ctypeslib.ndpointer(np.float32, flags="C")]
+    x = Z["vn_in"]
+    for typ in range(6):
+        out = np.zeros_like(x)
+        L.orc_vector_normalize(typ, np.ascontiguousarray(x).reshape(-1), x.shape[0], x.shape[1], out.reshape(-1))
+        assert np.array_equal(bits(out), bits(Z["vn_out_%d_%s" % (typ, contract)])), (contract, typ)
+
+
 def test_integer_density_clustering_against_the_reference_function_text():
     """f4 (preselection-batch-int): the same template as Mm::DensityClustering<u8, s32> -- integer distances, first cluster on ties (the
     first case repeats half of its entries), means through f64 sums converted to u8"""
