@@ -7,7 +7,8 @@ text of the definition is taken from where it lies under /root/reference at buil
 SHA-256 so that a moved or edited function fails the build instead of silently pinning something else -- and written into
 oracle/_ref/gen/ between a class shell that only declares the member (the real class declaration pulls in the configuration
 headers) and a C entry point.  Nothing of the reference's text is stored in this repository: the generated file exists only under
-oracle/_ref/ (git-ignored) and only where the reference tree is mounted.
+oracle/_ref/ (git-ignored), only where the reference tree is mounted, and only while it is being compiled (the Makefile removes it
+once the objects are built: what stays is objects and the two libraries).
 
 What such a pin proves, and what it does not: the function's own operations, in the reference's own words, compiled with the
 flag sets of oracle/ref/Makefile (so the compiler's contraction decisions are the real ones); NOT the class around it.
