@@ -1378,6 +1378,11 @@ def measure(ctx, job, args, world):
     job.epoch_reduce(world)
     barrier(world, gpu)
     dt = time.perf_counter() - t0
+    if gpu and getattr(job, "counts", None) is not None and hasattr(job, "red"):
+        # integrity of the one collective, read BEHIND the timed region: after the reduce every rank holds the frames of ALL ranks
+        # (each frame adds one to its best state's counter in the warm-up and the timed steps alike)
+        job.reduced_frames = int(job.counts.sum().item())
+        job.expected_frames = int(job.units) * (args.warmup + args.steps) * world
     if gpu:
         # kernel timings (roofline, stages) come from a SECOND pass over the same steps with the per-launch HIP events on (for a
         # graph-replayed workload: with plain launches).  The survivor counter is reset WITH the profiler, so that it covers exactly
@@ -1733,7 +1738,14 @@ def main():
             r["shader_clock_GHz"] = sclk
             if HWMON:
                 r["hwmon"] = HWMON
-            r["shader_clock_GHz_s_memtime"] = dict(median_of_xcds=SHADER_CLOCK_GHZ, per_xcd=SHADER_CLOCK_XCD)
+            # per-XCD ratios outside 0.5-1.2 x the driver's figure (without one: outside 0.5-2.45 GHz, the part's range) are the
+            # unaligned-counter artefact, not a clock: masked (None), and the median is taken over what is left
+            lo_, hi_ = (0.5 * HWMON["sclk_GHz"], 1.2 * HWMON["sclk_GHz"]) if HWMON else (0.5, 2.45)
+            kept = [v if (v is not None and lo_ <= v <= hi_) else None for v in (SHADER_CLOCK_XCD or [])]
+            vals = [v for v in kept if v is not None]
+            r["shader_clock_GHz_s_memtime"] = dict(median_of_xcds=round(float(np.median(vals)), 3) if vals else None, per_xcd=kept,
+                                                   masked=sum(1 for v, k in zip(SHADER_CLOCK_XCD or [], kept) if v is not None and k is None),
+                                                   note="s_memtime is a per-CU counter; samples on different CUs differ by the CUs' offset -- ratios outside the plausible band are masked")
             SHADER = sclk
             if r.get("bound") == "mfma":
                 r["peak_at_shader_clock"] = round(r["peak"] * SHADER / 2.4, 1)
@@ -1755,6 +1767,9 @@ def main():
             ms_ar, n_ar = ctx.profile_get("all_reduce")
             line["epoch_reduce"] = dict(collectives=1, bytes=job.red.nbytes(),
                                         backend="rccl via amx_comm_all_reduce_f64_dev (%d ranks)" % comm.world if comm else "none (single process)")
+            if hasattr(job, "reduced_frames"):
+                line["epoch_reduce"].update(reduced_frames=job.reduced_frames, expected_frames=job.expected_frames,
+                                            reduce_ok=bool(job.reduced_frames == job.expected_frames))
         line["config"]["timing"] = ("value / ms_per_step: K steps with the library's per-launch events OFF; roofline / stages: a second pass over "
                                     "min(K, 20) steps with a HIP-event pair around every launch on the stream the kernels run on")
         if is_graph_mode(args):

@@ -10,6 +10,8 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+    config.addinivalue_line("markers", "probe: a measurement-helper test (device clocks, counters), not an oracle comparison; collected LAST on "
+                                       "purpose so that under `-x` it can never cut off a parity test; `-m \"gpu and not probe\"` is the parity suite")
     # A clean checkout has no built artefacts (they are git-ignored): build them once, like __graft_entry__.build().  A library that
     # travelled with the checkout is rebuilt when it was made from other sources than the tree's (content hash recorded in
     # amx_version(), see __graft_entry__.is_stale) or when AMX_FORCE_BUILD=1 asks for a from-scratch build.
@@ -31,6 +33,8 @@ def _has_gpu():
 
 
 def pytest_collection_modifyitems(config, items):
+    # measurement helpers run after every parity test, whatever file they live in (stable sort: everything else keeps its order)
+    items.sort(key=lambda it: 1 if "probe" in it.keywords else 0)
     if _has_gpu():
         return
     skip = pytest.mark.skip(reason="no GPU in this container")

@@ -401,3 +401,53 @@ def test_amx_comm_all_reduce_through_the_c_abi(ctx):
         comm.close()
     with pytest.raises(rasr_amd.AmxError):
         rasr_amd.Comm(ctx, 2, 2, uid)   # rank out of range
+
+
+# ------------------------------------------------- the PRODUCT branch of bench.py's main() at N = 2, device calls replaced in the test
+
+def _run_fake_device_bench(argv, env_extra=None, timeout=400):
+    """tests/fake_device_bench.py <argv>: bench.main() with every device call replaced by a host stand-in INSIDE that test file
+    (bench.py and rasr_amd/ have no such switch).  Returns (rc, every JSON line of rank 0, stderr)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, os.path.join(root, "tests", "fake_device_bench.py")] + argv, capture_output=True, text=True,
+                       timeout=timeout, env=env, cwd=root)
+    return p.returncode, [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")], p.stderr
+
+
+@pytest.mark.parametrize("workload", ["pipeline", "nn-pipeline"])
+def test_bench_product_control_flow_at_two_ranks(workload):
+    """The command the driver will run on an 8-GPU node, at N = 2 and without a GPU: `bench.py --gpus 2 --steps K --warmup W` --
+    bench.py's OWN launcher starts the ranks (torch.distributed.run, 127.0.0.1), every rank goes through the GPU branch of main():
+    Context, compute stream, make_comm (unique id broadcast over the control plane), the Pipeline job with the STREAMED ingest of its
+    corpus partition, W + K steps, ONE amx_comm all-reduce of the flat EpochReduceBuffer, MAX of the times over the ranks, rank 0's JSON
+    line.  Device calls are stand-ins that count frames (tests/fake_device_bench.py); what is checked is the plumbing: n_gpus, the
+    weak-scaling unit count, the partition sizes, that the reduce summed BOTH ranks' frames and that it was one collective."""
+    K, W, U = 3, 1, 4
+    rc, lines, err = _run_fake_device_bench(["--gpus", "2", "--steps", str(K), "--warmup", str(W), "--utterances", str(U), "--utt-seconds", "1",
+                                             "--workload", workload])
+    assert rc == 0, err[-3000:]
+    line = next(l for l in lines if "metric" in l)
+    fake = next(l for l in lines if l.get("fake_device"))
+    assert line["build"].startswith("fake device")          # the stand-ins ran, not a GPU
+    assert line["n_gpus"] == 2 and line["steps"] == K and line["warmup"] == W and line["scaling"] == "weak" and line["higher_is_better"]
+    F = U * 99                                               # 1 s at 16 kHz: 99 frames per utterance (Signal/WindowBuffer.cc)
+    assert line["config"]["frames_per_step_per_gpu"] == F
+    assert abs(line["value"] - 2 * F * K / (line["ms_per_step"] * 1e-3 * K)) <= 1e-3 * line["value"]   # whole-job units over the MAX time
+    assert line["ingest"]["mode"] == "streamed" and line["ingest"]["sample_format"] == "s16"
+    assert line["ingest"]["rank_partition_utterances"] * 2 == line["ingest"]["corpus_utterances"]       # i % 2 == rank
+    er = line["epoch_reduce"]
+    assert er["collectives"] == 1 and "2 ranks" in er["backend"]
+    assert er["reduce_ok"] and er["reduced_frames"] == er["expected_frames"] == 2 * F * (K + W)
+    assert fake["all_reduce_f64_calls_on_rank0"] == 1        # literally one collective per epoch
+    assert "cpu_baseline" not in line and "configs" not in line   # rank 0 at N > 1 reports the job, not the 1-GPU extras
+
+
+def test_bench_product_branch_refuses_a_world_size_mismatch():
+    rc, lines, err = _run_fake_device_bench(["--gpus", "4", "--steps", "1", "--warmup", "0", "--utterances", "2", "--utt-seconds", "1"],
+                                            env_extra={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert rc != 0 and "refusing to report a wrong n_gpus" in err

@@ -191,9 +191,14 @@ def test_streamed_ingest_delivers_the_partitions_utterances_bit_for_bit(ctx):
     assert not set(seen[0].tolist()) & set(seen[1].tolist())
 
 
+@pytest.mark.probe
 def test_device_clock_samples(ctx):
-    """measurement entry points (bench.py's shader clock): two samples in stream order are ordered in both counters; the per-XCD form
-    reaches the eight XCDs and files every sample under the XCC id it read (amx_device_clocks_dev / amx_device_clocks_xcd_dev)"""
+    """measurement entry points (bench.py's shader clock; a PROBE, not a parity test: marked `probe`, collected last by
+    tests/conftest.py, and it asserts only what the hardware promises).  s_memrealtime is ONE 100 MHz counter for the chip: two samples
+    in stream order, milliseconds apart, are ordered.  s_memtime is a counter PER CU and the CUs' counters are not aligned: two samples
+    may land on different CUs (also of one XCD, also for the single-workgroup form -- round 5's driver box returned a "negative"
+    interval of 3.9e7 ticks), so it is held to `> 0` and nothing else.  The per-XCD form files every sample under the XCC id it read
+    (amx_device_clocks_dev / amx_device_clocks_xcd_dev)."""
     import torch
     ctx.use_torch_stream()
     one = torch.zeros((2, 2), dtype=torch.int64, device="cuda")
@@ -207,11 +212,9 @@ def test_device_clock_samples(ctx):
     ctx.device_clocks_xcd(xcd[1])
     torch.cuda.synchronize()
     o, x = one.cpu().numpy(), xcd.cpu().numpy()
-    assert (o[1] > o[0]).all()
+    assert o[1, 1] > o[0, 1] > 0          # s_memrealtime: ordered
+    assert (o[:, 0] > 0).all()            # s_memtime: sampled, no order promised
     reached = (x[0, :, 1] > 0) & (x[1, :, 1] > 0)
-    assert reached.sum() >= 4, x          # placement is not promised; eight of eight observed
+    assert reached.sum() >= 1, x          # placement is not promised (eight of eight observed)
     assert (x[1, :, 1][reached] > x[0, :, 1][reached]).all()   # the 100 MHz counter is one clock for the chip: ordered
-    # s_memtime is a counter per CU and the CUs' counters are not aligned: two samples on different CUs of an XCD differ by their
-    # offset as well (seen: a "negative" interval over a few milliseconds).  Only the single-workgroup form, which lands on the same CU
-    # of an idle chip, is held to an order here; bench.py uses the deltas over seconds and the driver's hwmon figure for short passes.
     assert (x[:, :, 0][:, reached] > 0).all()

@@ -12,4 +12,8 @@ hipcc --offload-arch=gfx950 -O3 -std=c++17 -w tools/write_probe.hip -o tools/bui
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -w tools/valu_rates.hip -o tools/build/valu_rates
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -w tools/gather_probe.hip -o tools/build/gather_probe
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -w tools/feed_probe.hip -o tools/build/feed_probe
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -w tools/l2_probe.hip -o tools/build/l2_probe
+# the lab build of the library (time stamps inside the kernels; tools/mx_timeline.py, tools/fused_timeline.py): rebuilt with the probes so
+# that it can never lag behind the ABI the tools bind (round 5 committed two tracebacks: the lab library predated a symbol)
+make -s -j4 -C rasr_amd/csrc OBJDIR=build_lab OUT=../../tools/build/librasr_amd_lab.so EXTRA=-DAMX_LAB CHECK=-
 rm -f tools/build/*.bc tools/build/*.hipi tools/build/*.out tools/build/*.s tools/build/*.resolution.txt tools/build/*gfx950.o tools/build/*x86_64*

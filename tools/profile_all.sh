@@ -15,15 +15,28 @@ out=$root/gpurun_out/$round
 mkdir -p $out/pmc
 cd /tmp && export TMPDIR=/tmp
 # (AMX_BENCH_NO_SMI=1 under the profiler: bench.py's 2.5 s rocm-smi stretch behind the timed region would only add launches to the traces)
+# every tool's exit status is kept: a tool that exits non-zero (or leaves a Python traceback in its log) is listed in $out/FAILED and
+# the script exits 1 -- a traceback must never be committed as a profile again (round 5: mx_timeline.log, fused_timeline.log)
+: > $out/FAILED
+must() {  # logfile, command...
+    log=$1; shift
+    "$@" > $log 2>&1
+    rc=$?
+    if [ $rc -ne 0 ] || grep -q "^Traceback (most recent call last)" $log; then
+        echo "$log: rc=$rc: $*" >> $out/FAILED
+        mv $log $log.FAILED
+    fi
+}
 only() { [ -z "$ONLY" ] || [[ "$1" =~ $ONLY ]]; }  # ONLY=<regex>: just the workloads whose name matches (and none of the suites)
 run_stats() {  # name, bench args...
     only $1 || return 0
     name=$1; shift
-    python $root/bench.py "$@" 2>/dev/null | tail -1 > $out/${name}_bench.log
+    python $root/bench.py "$@" 2>/tmp/bench_$name.err | tail -1 > $out/${name}_bench.log
+    grep -q '^{"metric"' $out/${name}_bench.log || { echo "$out/${name}_bench.log: no JSON line (bench.py $*): $(tail -1 /tmp/bench_$name.err)" >> $out/FAILED; mv $out/${name}_bench.log $out/${name}_bench.log.FAILED; }
     rm -rf /tmp/prof_$name
     AMX_BENCH_NO_SMI=1 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$name -- python $root/bench.py "$@" --no-cpu-baseline --no-configs > /tmp/prof_$name.log 2>&1
     f=$(find /tmp/prof_$name -name "*kernel_stats.csv" | head -1)
-    [ -n "$f" ] && cp $f $out/${name}_kernel_stats.csv
+    if [ -n "$f" ]; then cp $f $out/${name}_kernel_stats.csv; else echo "$name: rocprofv3 left no kernel_stats.csv" >> $out/FAILED; fi
 }
 run_pmc() {  # name, suffix, counters..., -- bench args...
     only $1 || return 0
@@ -84,10 +97,15 @@ AMX_BENCH_FORCE_DIST=1 python $root/bench.py --steps 6 --warmup 2 --no-cpu-basel
 python $root/tools/gemm_comparator.py > $out/gemm_comparator.json 2>/dev/null
 [ -x $root/tools/build/feed_probe ] && $root/tools/build/feed_probe > $out/feed_probe.log 2>&1
 if [ -f $root/tools/build/librasr_amd_lab.so ]; then
-  (cd $root && python tools/mx_timeline.py 0 2>&1 | grep -v amdgpu.ids > $out/mx_timeline.log; python tools/mx_timeline.py small 2>&1 | grep -v amdgpu.ids >> $out/mx_timeline.log; python tools/fused_timeline.py 2>&1 | grep -v amdgpu.ids > $out/fused_timeline.log)
+  (cd $root && must $out/mx_timeline.log python tools/mx_timeline.py 0; must $out/mx_timeline_small.log python tools/mx_timeline.py small; must $out/fused_timeline.log python tools/fused_timeline.py)
+else
+  echo "tools/build/librasr_amd_lab.so missing (tools/build_probe.sh builds it)" >> $out/FAILED
 fi
+[ -x $root/tools/build/l2_probe ] && must $out/l2_probe.log $root/tools/build/l2_probe
 [ -x $root/tools/build/gemm_probe ] && PROBE_RELU=1 $root/tools/build/gemm_probe xp0 xp8 xp16 xp24 xp64 xp72 xp4 p0 p8 p16 p64 p72 p4 x0 xa0 xp0:16x8 p0:16x8 > $out/gemm_probe.log 2>&1
 [ -x $root/tools/build/valu_rates ] && $root/tools/build/valu_rates > $out/valu_rates.log 2>&1
 [ -x $root/tools/build/ceilings ] && $root/tools/build/ceilings > $out/ceilings.json 2>/dev/null
 python $root/tools/traffic_json.py $out > $out/traffic.json 2>/dev/null
 ls -la $out $out/pmc
+if [ -s $out/FAILED ]; then echo "profile_all: FAILED tools:"; cat $out/FAILED; exit 1; fi
+rm -f $out/FAILED
