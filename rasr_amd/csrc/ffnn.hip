@@ -1446,7 +1446,11 @@ struct amx_ffnn {
     bool   is_mx() const { return precision == AMX_PREC_F16MX; }
     int    requested_precision = 0;   // amx_ffnn_model.precision; `precision` is what the handle computes in (mx_fallback)
     double mx_block_ratio      = 0.0; // AMX_PREC_F16MX requested: largest rms(block maxima) / rms(elements) over the layers
+#ifdef AMX_LAB  // an ablation variant computes on stale operands: its scores are never valid, the flag is not looked at
+    int    overflowed() const { return mx_dbg == 0 && h_overflow && *(volatile unsigned*)h_overflow; }
+#else
     int    overflowed() const { return h_overflow && *(volatile unsigned*)h_overflow; }
+#endif
 };
 
 namespace {
@@ -1626,6 +1630,8 @@ using MfgS = amx::mx::MxCfg<128, 64, 2, 2, 8, 0, 0, 2>;  // 147 KB: small batche
                                                          // 2048 x 2048 layer at batch 1024 is 64 K-tiles of 9 matrix instructions per wave: barrier and LDS round trip per K-tile were its time)
 using MfgS4 = amx::mx::MxCfg<128, 64, 2, 2, 4>;          //  74 KB, one K-tile per barrier, three in flight (tuning tile=6: A/B runs)
 using MfgSL = amx::mx::MxCfg<128, 64, 2, 2, 8, 0, 0, 2, 4>;  // hidden layers: MfgS + four loader waves (512 threads: a computing and a loading wave per SIMD)
+using MfgS8 = amx::mx::MxCfg<128, 64, 4, 2, 8, 0, 0, 2>;  // round 6 (tile=12): the one-tile-per-CU tile on EIGHT computing waves of 32 x 32 (two per SIMD: one wave's reads and conversions under the other's products), every wave issuing its share of the DMA
+using MfgSP = amx::mx::MxCfg<128, 64, 2, 2, 8, 0, 0, 2, 4, 3>;  // round 6, the default for hidden layers of small batches: MfgSL with the READ-AHEAD K loop (two register images, conversions issued first, a steady-state body without run-time wait selection); MfgSL stays as tile=11
 
 template<class C, int ACT, bool LAST>
 void launch_mx(amx_ffnn* h, int l, const void* x, int xkts, void* out, int ldo, int T, int Tpad, int n_valid) {
@@ -1709,6 +1715,22 @@ void launch_mx(amx_ffnn* h, int l, const void* x, int xkts, void* out, int ldo, 
             default: dbg = 0; break;
         }
     }
+    else if (C::BN == 128 && C::BT == 64 && C::PIPE == 3 && !LAST && ACT == AMX_ACT_RELU && (dbg == 4 || dbg == 8 || dbg == 16 || dbg == 20 || dbg == 24 || dbg == 28 || dbg == 128 || dbg == 156)) {
+        // round 6: the ablations of the one-tile-per-CU configuration with read-ahead (tools/hidden_layer_probe.py): 4 no fragment
+        // reads, 8 no matrix instructions, 16 no operand DMA behind the prologue, and their sums
+        if constexpr (C::BN == 128 && C::BT == 64 && C::PIPE == 3 && !LAST && ACT == AMX_ACT_RELU) {
+            switch (dbg) {
+                case 4: AMX_MX_LAUNCH(4); break;
+                case 8: AMX_MX_LAUNCH(8); break;
+                case 16: AMX_MX_LAUNCH(16); break;
+                case 20: AMX_MX_LAUNCH(20); break;
+                case 24: AMX_MX_LAUNCH(24); break;
+                case 128: AMX_MX_LAUNCH(128); break;
+                case 156: AMX_MX_LAUNCH(156); break;
+                default: AMX_MX_LAUNCH(28); break;
+            }
+        }
+    }
     else if (dbg == 2048 && ACT == AMX_ACT_RELU * (LAST ? 0 : 1)) {
         AMX_MX_LAUNCH(2048);  // time stamps of any tile configuration (tools/mx_timeline.py small)
     }
@@ -1756,9 +1778,16 @@ void launch_mx_cfg(amx_ffnn* h, int l, const void* x, int xkts, void* out, int l
             if constexpr (LAST)
                 launch_mx<MfgS, ACT, LAST>(h, l, x, xkts, out, ldo, T, Tpad, n_valid);
             else
-                launch_mx<MfgSL, ACT, LAST>(h, l, x, xkts, out, ldo, T, Tpad, n_valid);
+                launch_mx<MfgSP, ACT, LAST>(h, l, x, xkts, out, ldo, T, Tpad, n_valid);   // round 6: read-ahead K loop (bit-identical to MfgSL: tile=11)
             break;
         case 6: launch_mx<MfgS4, ACT, LAST>(h, l, x, xkts, out, ldo, T, Tpad, n_valid); break;
+        case 12: launch_mx<MfgS8, ACT, LAST>(h, l, x, xkts, out, ldo, T, Tpad, n_valid); break;
+        case 11:   // round 5's hidden-layer loop (no read-ahead): A/B runs
+            if constexpr (LAST)
+                launch_mx<MfgS, ACT, LAST>(h, l, x, xkts, out, ldo, T, Tpad, n_valid);
+            else
+                launch_mx<MfgSL, ACT, LAST>(h, l, x, xkts, out, ldo, T, Tpad, n_valid);
+            break;
         default: launch_mx<MfgA, ACT, LAST>(h, l, x, xkts, out, ldo, T, Tpad, n_valid); break;
     }
 }
@@ -1899,7 +1928,7 @@ int amx_ffnn_create(amx_ctx* ctx, const amx_ffnn_model* m, amx_ffnn** out) {
             return AMX_ERR_INVALID;
         AMX_REQUIRE(t_ksplit == 1 || t_ksplit == 4, AMX_ERR_INVALID, "amx_ffnn_create: tuning ksplit=%d: expected 1 | 4", t_ksplit);
         AMX_REQUIRE(t_ksplit == 1 || m->precision == AMX_PREC_F16MX, AMX_ERR_UNSUPPORTED, "amx_ffnn_create: tuning ksplit exists for AMX_PREC_F16MX only");
-        if (!tune.get_int("tile", -1, -1, 9, &t_tile, who) || !tune.get_int("graph", 1, 0, 1, &t_graph, who) ||
+        if (!tune.get_int("tile", -1, -1, 12, &t_tile, who) || !tune.get_int("graph", 1, 0, 1, &t_graph, who) ||
             !tune.get_int("persistent", 1, 0, 1, &t_persistent, who) || !tune.get_int("chunk", 32768, 256, 1 << 24, &t_chunk, who) ||
             !tune.get_int("mx_dbg", 0, 0, 1 << 16, &t_mx_dbg, who) || !tune.get_int("stagger", 0, 0, 100000, &t_stagger, who))
             return AMX_ERR_INVALID;

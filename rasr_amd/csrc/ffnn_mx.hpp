@@ -240,9 +240,19 @@ struct MxCfg {
     // file) that pipelines itself -- see the K loop.  Against the eight-wave tile: a third fewer fragment bytes out of LDS per K-tile
     // (4 x (128 + 128) rows instead of 8 x (64 + 128)), four conversions per SIMD and K-tile instead of six (a conversion takes the
     // matrix pipe), one barrier per K-tile among four waves instead of two among eight.
+    // PIPE = 3 (round 6): READ-AHEAD for the one-tile-per-CU configuration with loader waves (U K-tiles per barrier).  Round 6's ablations
+    // of a 2048 x 2048 layer at batch 1024 (profiles/r06/hidden_layer_probe.log): 33 us as is, 33 us with NO operand DMA behind the
+    // prologue, 30 us with no matrix instructions, 30 us with neither -- the period of an iteration is the computing wave's own chain
+    // barrier -> fragment reads -> LDS latency -> conversions -> products -> barrier, one wave per SIMD and nothing to overlap it with.
+    // Here a computing wave reads the fragments of K-tile k + 1 into a SECOND register image while it issues the products of K-tile k
+    // -- one or two LDS reads behind every matrix instruction (a burst of 18 reads holds an in-order wave as long as waiting for them
+    // did: measured, no gain).  The ring keeps its schedule with one more K-tile awaited per barrier (see the K loop).  Per accumulator
+    // the same matrix instructions in the same order: bit-identical scores.
     static_assert(PIPE_ == 0 || (PIPE_ == 1 && U_ == 1 && LW_ == 0 && PF_ == 0 && IW_ == 0 && STAGES_ == 3 && WN_ * WT_ == 8) ||
-                      (PIPE_ == 2 && U_ == 1 && LW_ == 0 && PF_ == 0 && IW_ == 0 && STAGES_ == 3 && WN_ * WT_ == 4 && BN_ / WN_ == 128 && BT_ / WT_ == 128),
-                  "ping-pong K loop: eight waves, every one of them issuing, plain three-stage ring; self-pipelined: four waves of 128 x 128");
+                      (PIPE_ == 2 && U_ == 1 && LW_ == 0 && PF_ == 0 && IW_ == 0 && STAGES_ == 3 && WN_ * WT_ == 4 && BN_ / WN_ == 128 && BT_ / WT_ == 128) ||
+                      (PIPE_ == 3 && U_ == 2 && LW_ > 0 && STAGES_ >= 2 * U_ + 1),
+                  "ping-pong K loop: eight waves, every one of them issuing, plain three-stage ring; self-pipelined: four waves of 128 x 128; "
+                  "read-ahead: loader waves, two K-tiles per barrier, a ring of at least three iterations");
     // PF > 0 (256 x 256 tiles only): waves 0-5 touch the 384 cache lines of the K-tile PF steps ahead of the one whose LDS-DMA they
     // have just issued (one dword per 128-byte line, 64 lines per wave-instruction) -- a software prefetch from the Infinity Cache /
     // HBM into L2.  The LDS ring holds two K-tiles in flight (~2 periods of 1.7 us); a K-tile whose lines miss L2 (23 % of the
@@ -363,11 +373,10 @@ __device__ __forceinline__ u32x6 q_fields_pair(f16x8 c0, f16x8 c1, f16x8 d0, f16
 template<bool FIRST>
 __device__ __forceinline__ u32x6 q_fields(f16x8 c0, f16x8 c1, unsigned scale_byte) {
     const f16x16 v = __builtin_shufflevector(c0, c1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
-    f16x32       w;
-    if (FIRST)
-        w = __builtin_shufflevector(v, v, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1);
-    else
-        w = __builtin_shufflevector(v, v, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+    // both halves hold the 16 values (round 6): an UNDEFINED half may be given any registers -- it got the destinations of fragment reads
+    // still in flight (the read-ahead loop), and the compiler's s_waitcnt lgkmcnt in front of the conversion waited for them.  The
+    // fields of the other half are not used either way.
+    const f16x32 w = __builtin_shufflevector(v, v, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
     u32x6       q;  // early-clobber result: see lane_pack
     const float scale = __uint_as_float(scale_byte << 23);
     asm("v_cvt_scalef32_pk32_fp6_f16 %0, %1, %2\n\ts_nop 2" : "=&v"(q) : "v"(w), "v"(scale));
@@ -553,7 +562,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const char* __restr
             s_bias[i] = bias[n0 + i];
 
 #pragma unroll
-        for (int s = 0; s < (C::PIPE > 0 ? C::STAGES : C::STAGES - C::U); ++s)
+        for (int s = 0; s < ((C::PIPE == 1 || C::PIPE == 2) ? C::STAGES : C::STAGES - C::U); ++s)
             if (s < KT)
                 stage(s, s);
         const int frow = lane & 31, fk = lane >> 5;
@@ -563,7 +572,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const char* __restr
             f16x8 a[2][C::MI], b[2][C::MJ];
             uint4 ra[C::MI], rb[C::MJ];
         };
-        Frag fr[C::U];
+        Frag fr[C::U];  // (read-ahead, PIPE 3: the two images swap roles every K-tile)
         auto reads = [&](int kt, Frag& F) {
             auto& a  = F.a;
             auto& b  = F.b;
@@ -592,13 +601,46 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const char* __restr
         // order).  Measured: no gain over the burst behind the barrier (MxCfg).
         constexpr int N_MFMA = 3 * C::MI * C::MJ, GAP = N_MFMA / C::PPW > 0 ? N_MFMA / C::PPW : 1;  // matrix instructions per piece
         int           dma_kt = -1;  // K-tile whose pieces the next products() issues (-1: none)
-        auto products = [&](Frag& F) {
+        // READ-AHEAD (PIPE 3): the fragment reads of K-tile side_kt go out BETWEEN the matrix instructions of the K-tile in front of
+        // them, into the other register image (side_F; nullptr: none).  A wave issues in order and the LDS takes its time over 18 wide
+        // reads (450 cycles for the four computing waves' 72 KB, tools/mx_timeline.py small): issued as one burst they held the
+        // matrix instructions back exactly as long as waiting for them had -- the read-ahead alone changed nothing
+        // (profiles/r06/hidden_layer_probe.log).  One or two reads behind each matrix instruction ride in its shadow.
+        // (the image is passed by reference, the switch as a flag: a captured pointer to it sent all four images to scratch)
+        constexpr int N_SIDE = 3 * (C::MI + C::MJ);  // reads of one K-tile: a[0][.] b[0][.] a[1][.] b[1][.] ra[.] rb[.]
+        auto side_read = [&](Frag& F, int side_kt, int p) {  // p: compile-time constant after unrolling
+            const char* ab = lds + (side_kt % C::STAGES) * C::STAGE_BYTES;
+            const char* bb = ab + C::A_BYTES;
+            if (p < C::MI)
+                F.a[0][p] = *(const f16x8*)(ab + h_off(a_row + 32 * p, fk));
+            else if (p < C::MI + C::MJ)
+                F.b[0][p - C::MI] = *(const f16x8*)(bb + h_off(b_row + 32 * (p - C::MI), fk));
+            else if (p < 2 * C::MI + C::MJ)
+                F.a[1][p - C::MI - C::MJ] = *(const f16x8*)(ab + h_off(a_row + 32 * (p - C::MI - C::MJ), 2 + fk));
+            else if (p < 2 * (C::MI + C::MJ))
+                F.b[1][p - 2 * C::MI - C::MJ] = *(const f16x8*)(bb + h_off(b_row + 32 * (p - 2 * C::MI - C::MJ), 2 + fk));
+            else if (p < 3 * C::MI + 2 * C::MJ)
+                F.ra[p - 2 * (C::MI + C::MJ)] = __builtin_bit_cast(uint4, *(const f16x8*)(ab + C::A_R + fk * (C::BN * 16) + (a_row + 32 * (p - 2 * (C::MI + C::MJ))) * 16));
+            else
+                F.rb[p - 3 * C::MI - 2 * C::MJ] = __builtin_bit_cast(uint4, *(const f16x8*)(bb + C::B_R + fk * (C::BT * 16) + (b_row + 32 * (p - 3 * C::MI - 2 * C::MJ)) * 16));
+        };
+        auto products_side = [&](Frag& F, Frag& SIDE, int side_kt, bool side_on) {
             auto& a  = F.a;
             auto& b  = F.b;
             auto& ra = F.ra;
             auto& rb = F.rb;
             int n_issued = 0;  // compile-time after unrolling
             auto after_mfma = [&]() {
+                if constexpr (C::PIPE == 3) {
+                    if (side_on && !(DBG & 4)) {   // (DBG 4, lab: no fragment reads behind the first K-tile's -- stale registers, timing only)
+                        const int lo = n_issued * N_SIDE / N_MFMA, hi = (n_issued + 1) * N_SIDE / N_MFMA;
+#pragma unroll
+                        for (int p = 0; p < N_SIDE; ++p)
+                            if (p >= lo && p < hi)
+                                side_read(SIDE, side_kt, p);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 if constexpr (C::SPREAD != ((DBG & 512) != 0)) {
                     if (n_issued % GAP == GAP / 2 && n_issued / GAP < C::PPW) {
                         if (dma_kt >= 0)
@@ -727,6 +769,66 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const char* __restr
             if (dma_kt >= 0)
                 prefetch(dma_kt + C::PF);  // SPREAD variant: the refill's prefetch follows its last piece, as in stage()
             dma_kt = -1;
+        };
+        auto products = [&](Frag& F) { products_side(F, F, 0, false); };
+        // PIPE 3, the order that lets ONE wave per SIMD overlap with itself (64 x 32 wave tile: two f16 products per k-slab, one pair
+        // conversion for the rows, one for the frames, two scaled products).  Round 6's ablations (profiles/r06/hidden_layer_probe.log):
+        // with neither fragment reads nor matrix instructions nor operand DMA the K loop still took 15 of its 26 us -- a conversion's
+        // RESULT was awaited right behind its issue (the v_mov that assemble the scaled operands), behind the f16 products.  Here the
+        // two conversions are ISSUED FIRST (their inputs -- every fragment and both scale bytes of the K-tile -- arrived under the
+        // previous K-tile's products), the four f16 products and the next K-tile's reads follow while they run, and the operands are
+        // assembled in front of the scaled products.  Per accumulator: f16 k-slab 0, f16 k-slab 1, scaled -- as everywhere.
+        auto products_ahead = [&](Frag& F, Frag& SIDE, int side_kt, bool side_on) {
+            static_assert(C::PIPE != 3 || (C::MI == 2 && C::MJ == 1), "read-ahead K loop: 64 x 32 wave tiles");
+            if constexpr (C::MI == 2 && C::MJ == 1) {
+                u32x6 qa, qb;
+                if constexpr ((DBG & 128) != 0) {
+                    qa = u32x6{F.ra[0].y, F.ra[0].z, F.ra[0].x, F.ra[1].y, F.ra[1].z, F.ra[1].x};
+                    qb = u32x6{0, 0, 0, F.rb[0].y, F.rb[0].z, F.rb[0].x};
+                }
+                else {
+                    qa = q_fields_pair(F.a[0][0], F.a[1][0], F.a[0][1], F.a[1][1], F.ra[0].w);
+                    qb = q_fields<false>(F.b[0][0], F.b[1][0], F.rb[0].w + 11u);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // (Assembling the operands of the scaled products BETWEEN the f16 products -- empty asm statements that make each
+                // tuple exist there -- was measured too: 27.4 -> 28.7 us per layer, slower.)  fp6 operands are six dwords: dwords 6 and 7
+                // of the builtin's eight are not read, so nothing is copied for them.
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    const int ks = n >> 1, i = n & 1;
+                    if constexpr ((DBG & 8) != 0) {
+                        keep_alive(F.a[ks][i]);
+                        keep_alive(F.b[ks][0]);
+                    }
+                    else
+                        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.a[ks][i], F.b[ks][0], acc[i][0], 0, 0, 0);
+                    if (side_on && !(DBG & 4)) {   // (DBG 4, lab: no fragment reads behind the first K-tile's -- stale registers, timing only)
+#pragma unroll
+                        for (int p = 0; p < N_SIDE; ++p)
+                            if (p >= n * N_SIDE / 4 && p < (n + 1) * N_SIDE / 4)
+                                side_read(SIDE, side_kt, p);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                const v8i av0 = v8i{(int)qa[0], (int)qa[1], (int)qa[2], (int)F.ra[0].x, (int)F.ra[0].y, (int)F.ra[0].z, (int)F.ra[0].w, (int)F.ra[0].w};
+                const v8i av1 = v8i{(int)qa[3], (int)qa[4], (int)qa[5], (int)F.ra[1].x, (int)F.ra[1].y, (int)F.ra[1].z, (int)F.ra[1].w, (int)F.ra[1].w};
+                const v8i bv0 = v8i{(int)F.rb[0].x, (int)F.rb[0].y, (int)F.rb[0].z, (int)qb[3], (int)qb[4], (int)qb[5], (int)qb[5], (int)qb[5]};
+                if constexpr ((DBG & 8) != 0) {
+                    keep_alive(av0);
+                    keep_alive(av1);
+                    keep_alive(bv0);
+                }
+                else {
+                    acc[0][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av0, bv0, acc[0][0], 2, 2, 0, (int)F.ra[0].w, 0, (int)F.rb[0].w);
+                    acc[1][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av1, bv0, acc[1][0], 2, 2, 0, (int)F.ra[1].w, 0, (int)F.rb[0].w);
+                }
+                // all six dwords of both conversions stay allocated until here: the unused half of the frames' conversion was handed
+                // out as a scratch register right behind its issue, and a vector instruction that WRITES a register of a conversion in
+                // flight waits for it (seen in the ISA: v_add_u32 v10 behind v_cvt ... v[10:15])
+                asm volatile("" ::"v"(qa), "v"(qb));
+                __builtin_amdgcn_sched_barrier(0);
+            }
         };
         // Skewed wave groups (8-wave tiles; waves w and w + 4 share a SIMD): between two barriers the EARLY wave of a SIMD reads
         // K-tile kt into registers and then issues its products, the LATE wave first issues the products of K-tile kt - 1 -- read in
@@ -946,7 +1048,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const char* __restr
             for (; kt < KT; ++kt)
                 iteration(kt, std::false_type{});
         }
-        else if constexpr (C::PIPE > 0) {
+        else if constexpr (C::PIPE == 1) {
             static_assert(DBG == 0 || DBG == 2048 || DBG == 128, "the ping-pong K loop: time stamps, and the no-conversion ablation (lab builds)");
             const bool second = wave >= C::NW / 2;  // the group that runs half a period behind (waves 4-7: the partners of waves 0-3)
             auto await_tile = [&](int ahead_tiles, int max_ahead) {  // own pieces of a K-tile have landed; `ahead_tiles` younger K-tiles may stay in flight
@@ -1001,6 +1103,91 @@ __global__ __launch_bounds__(C::THREADS) void gemm_mx_kernel(const char* __restr
             }
             if (!second)
                 __builtin_amdgcn_s_barrier();
+        }
+        else if constexpr (C::PIPE == 3) {
+            static_assert(DBG == 0 || DBG == 2048 || DBG == 4 || DBG == 8 || DBG == 16 || DBG == 24 || DBG == 28 || DBG == 20 || DBG == 128 || DBG == 156, "read-ahead K loop: time stamps and the ablations");
+            static_assert(C::U == 2, "two register images that swap roles every K-tile: an even number of K-tiles per barrier keeps the roles fixed");
+            // K-tiles up to `needed` have landed for this wave's own pieces; issued so far: up to `issued` (both clamped to the last K-tile)
+            auto await = [&](int needed, int issued) {
+                const int ahead = max(0, min(issued, KT - 1) - min(needed, KT - 1));
+                if (!issuer)
+                    mx_wait<0>();
+                else if (hi_wave)
+                    mx_wait_ahead<C::PPW, 0, C::STAGES - C::U>(ahead);
+                else
+                    mx_wait_ahead<C::PPW - 1, 0, C::STAGES - C::U>(ahead);
+            };
+            // TWO register images: while the products of K-tile k are issued from one, the reads of K-tile k + 1 fill the other, one or
+            // two reads behind every matrix instruction (products_side).  The ring keeps its schedule -- barrier i frees the slots of
+            // iteration i - 1 (K-tile 2 i - 2 was read under the products of 2 i - 3, K-tile 2 i - 1 under those of 2 i - 2; every
+            // wave awaits its reads in front of the barrier) and the loaders refill them -- with one more K-tile awaited: the second
+            // half of iteration i reads K-tile 2 i + 2, the first of iteration i + 1.
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            await(0, C::STAGES - C::U - 1);  // K-tile 0 has landed
+            __builtin_amdgcn_s_barrier();
+            if (!loader)
+                reads(0, fr[0]);
+            const int n_it = (KT + C::U - 1) / C::U;
+            // STEADY iterations (kt + STAGES - 1 < KT: both K-tiles of the refill exist, nothing is clamped) know every count at
+            // compile time: ONE s_waitcnt with a constant immediate and no guards.  The general form -- the nested selection of the
+            // immediate from a run-time `ahead`, the `< KT` guards of every read and piece -- compiled to ~60 scalar instructions and
+            // ~25 branches per iteration, and the EMPTY loop (no reads, no matrix instructions, no DMA, no conversions) took 0.36 us
+            // per iteration, half of the full loop's time (profiles/r06/hidden_layer_probe.log); it now runs for the tail only.
+            auto body = [&](int it, auto steady_tag) {
+                constexpr bool STEADY = decltype(steady_tag)::value;
+                const int kt = it * C::U;
+                // this wave's reads so far are complete.  The BUILTIN, not an asm statement: the compiler's wait-count pass must know
+                // that the image read under the previous products has arrived -- behind an asm wait it does not, and protects the
+                // first product with an s_waitcnt lgkmcnt of its own, which (LDS returns in order) waits for the reads just issued
+                // for the NEXT K-tile: the overlap this loop exists for was gone (seen in the ISA)
+                __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0), vmcnt / expcnt untouched
+                // K-tiles kt + 1 .. kt + U have landed (own pieces); K-tiles up to kt + STAGES - U - 1 are issued
+                if constexpr (STEADY) {
+                    constexpr int AHEAD = C::STAGES - 2 * C::U - 1;
+                    if (issuer) {   // (a computing wave has no vector-memory operation in flight inside the loop)
+                        if (hi_wave)
+                            mx_wait<AHEAD * C::PPW>();
+                        else
+                            mx_wait<AHEAD * (C::PPW - 1)>();
+                    }
+                }
+                else
+                    await(kt + C::U, kt + C::STAGES - C::U - 1);
+                __builtin_amdgcn_s_barrier();                   // ... for every wave; the slots of iteration it - 1 are free
+                stamp(it, 0);
+                if (issuer && !(DBG & 16)) {
+#pragma unroll
+                    for (int u = 0; u < C::U; ++u) {
+                        const int n = kt + u + C::STAGES - C::U;
+                        if (STEADY || n < KT)
+                            stage(n % C::STAGES, n);
+                    }
+                }
+                stamp(it, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (!loader) {
+#pragma unroll
+                    for (int u = 0; u < C::U; ++u)
+                        if (STEADY || kt + u < KT)
+                            products_ahead(fr[u & 1], fr[(u + 1) & 1], kt + u + 1, STEADY || kt + u + 1 < KT);
+                    // the products stay in front of the next iteration's waits: a matrix instruction touches no memory, so neither
+                    // the waits nor the barrier hold it -- left alone the compiler sank all of them behind the next top-of-loop
+                    // s_waitcnt lgkmcnt(0) (seen in the ISA)
+#pragma unroll
+                    for (int i = 0; i < C::MI; ++i)
+#pragma unroll
+                        for (int j = 0; j < C::MJ; ++j)
+                            asm volatile("" : "+v"(acc[i][j]));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                stamp(it, 3);
+            };
+            int it = 0;
+            for (; it * C::U + C::STAGES - 1 < KT; ++it)
+                body(it, std::true_type{});
+#pragma unroll 1
+            for (; it < n_it; ++it)
+                body(it, std::false_type{});
         }
         else if constexpr (C::U > 1 || C::LW > 0) {
             static_assert(!C::SKEW && !C::SPREAD && C::PF == 0 && (C::IW == C::NW || C::LW > 0), "plain burst refill only");

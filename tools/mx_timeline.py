@@ -56,9 +56,9 @@ tb = (C.c_ulonglong * 24)()
 L.amx_lab_mx_tile_stamps.restype = C.c_int
 if L.amx_lab_mx_tile_stamps(tb) == 0:
     ts = np.frombuffer(tb, dtype=np.uint64).reshape(4, 3, 2).astype(np.int64)
-    if ts[0, 0, 0] > 0:
-        dc, dr = ts[-1, 2, 0] - ts[0, 0, 0], ts[-1, 2, 1] - ts[0, 0, 1]
-        ghz = dc / (dr * 10.0) if dr > 0 else float("nan")
+    dc, dr = ts[-1, 2, 0] - ts[0, 0, 0], ts[-1, 2, 1] - ts[0, 0, 1]
+    if ts[0, 0, 0] > 0 and dc > 0 and dr > 0:   # the small-batch tile carries no tile stamps (one tile per workgroup): nothing to print
+        ghz = dc / (dr * 10.0)
         print("tiles of workgroup 0: %d s_memtime ticks in %d s_memrealtime ticks of 10 ns -> %.3f ticks per ns" % (dc, dr, ghz))
         print("tile   K-loop (prologue + %d K-tiles)   epilogue (+ the closing barrier)   gap to the next tile start      [us]" % (2048 // 32))
         for i in range(4):
