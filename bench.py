@@ -1641,12 +1641,10 @@ def decoder_facing(ctx, args, rank):
 
 
 def apply_contract(args):
-    """--contract -> the GMM scorers' tuning string (the quantised scorer is integer arithmetic: it takes no contract) and the oracle's mode"""
+    """--contract -> the context's arithmetic (amx_set_contract, main()), the GMM scorers' tuning string and the oracle's mode"""
     from_tuning = [i.split("=", 1)[1] for i in (args.gmm_tuning or "").split(",") if i.strip().startswith("contract=")]
     if from_tuning:
         args.contract = from_tuning[-1]
-    elif args.gmm_type == "SIMD-diagonal-maximum":
-        args.contract = "off"
     elif args.contract == "fma":
         args.gmm_tuning = ",".join(i for i in (args.gmm_tuning, "contract=fma") if i)
 
@@ -1694,6 +1692,7 @@ def main():
 
     import rasr_amd
     ctx = rasr_amd.Context(local)
+    ctx.set_contract(args.contract)   # every handle and every *_dev entry point of the run follows the build of the reference the line names
     stream = torch.cuda.Stream(device=local)
     with torch.cuda.stream(stream):
         ctx.use_torch_stream()

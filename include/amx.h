@@ -69,6 +69,33 @@ void amx_destroy(amx_ctx* ctx);
  * ((hipStream_t)1): the handle 0 that frameworks report for it would read as NULL here. */
 int amx_set_stream(amx_ctx* ctx, void* hip_stream);
 int amx_synchronize(amx_ctx* ctx);
+
+/* WHICH BUILD OF THE REFERENCE this context's f32 arithmetic follows (round 6; cmake_resources/CompileOptions.cmake:21-48).  RASR has
+ * two arithmetics, decided by how it was compiled:
+ *   AMX_CONTRACT_OFF  -DMARCH=x86-64 (or a host / compiler without fused multiply-adds): every product and every sum rounds once;
+ *   AMX_CONTRACT_FMA  its DEFAULT configuration, -march=native on an FMA host with GCC (-ffp-contract=fast; clang's default `on` fuses
+ *                     within a statement: treat clang builds as FMA too): `sum += a * b` is ONE fused multiply-add at the sites
+ *                     oracle/orc.h marks ORC_FMAF / ORC_FMA -- the GMM distance (Mm/GaussDiagonalMaximumFeatureScorer.cc:144-218,
+ *                     Mm/BatchFeatureScorer.cc:164-650), Signal::Regression (Signal/Regression.cc:24-65), Math::Vector's dot product
+ *                     (Math/Vector.hh:94-101: signal-matrix-multiplication-f32, the cosine transform), Filter::apply
+ *                     (Signal/Filterbank.cc:27-50), preemphasis with alpha != 1, the filter bank's geometry, the AR-to-cepstrum
+ *                     recursion, the gammatone design / cascade / integrations, the amplitude-spectrum-energy normalisation.
+ * The setting is read (a) by every *_dev entry point that takes the context directly (amx_regression_dev, amx_matrix_multiply_dev,
+ * amx_vector_normalize_dev, ...) at call time, (b) by amx_mfcc_create / amx_gammatone_create / amx_gmm_create at creation (a handle
+ * keeps the arithmetic it was created with; amx_gmm_model.tuning "contract=off|fma" overrides it per model).  Default: OFF.
+ * An adapter compiled INSIDE RASR's build knows the answer at compile time: pass AMX_CONTRACT_OF_THIS_BUILD right after amx_init --
+ * the macro is evaluated in the translation unit that includes this header, i.e. with RASR's own flags.
+ * Bit-exact against oracle/liboracle.so (OFF) / oracle/liboracle_fma.so (FMA) wherever the OFF arithmetic is (tests/test_contract_gpu.py). */
+enum { AMX_CONTRACT_OFF = 0, AMX_CONTRACT_FMA = 1 };
+#if defined(__FMA__) && (defined(__GNUC__) || defined(__clang__)) && !defined(AMX_ADAPTER_NO_FP_CONTRACT)
+#define AMX_CONTRACT_OF_THIS_BUILD AMX_CONTRACT_FMA /* -mfma / -march=native on an FMA host, GCC or clang defaults (define AMX_ADAPTER_NO_FP_CONTRACT when RASR is built with -ffp-contract=off) */
+#else
+#define AMX_CONTRACT_OF_THIS_BUILD AMX_CONTRACT_OFF
+#endif
+int amx_set_contract(amx_ctx* ctx, int contract);
+int amx_get_contract(const amx_ctx* ctx); /* AMX_CONTRACT_OFF | AMX_CONTRACT_FMA; < 0: ctx is NULL */
+/* "contract=off: RASR built with -DMARCH=x86-64 ..." -- one line an adapter logs next to the reference's own "Scaling factor" lines */
+const char* amx_contract_description(int contract);
 /* Per-kernel timing with HIP events on the context's stream (used by bench.py for the roofline
  * line).  enable=1 makes every launch of the named hot kernels record start/stop events. */
 int amx_profile_enable(amx_ctx* ctx, int enable);
@@ -211,6 +238,10 @@ typedef struct {
     double power;            /* generic-vector-f32-power value (e.g. 0.1 for the 10th root); 0 = node absent */
     int    n_ceps;           /* signal-cosine-transform nr-outputs; 0 = node absent                          */
     int    dct_normalize;    /* normalize                                                                    */
+    /* "contract=off|fma" (NULL: the context's arithmetic, amx_set_contract; OFF for a host-only handle): which build of the reference
+     * the design (centre frequencies, warping), the filter cascade, both integrations and the cosine transform follow -- bit for bit
+     * in either mode (oracle/orc_gammatone.c marks the contracted sites).  Unknown keys / values fail amx_gammatone_create. */
+    const char* tuning;
 } amx_gammatone_cfg;
 enum { AMX_GAMMATONE_HUMAN = 0, AMX_GAMMATONE_ERB = 1 };
 enum { AMX_WINDOW_HANNING = 0, AMX_WINDOW_RECTANGULAR = 1 };

@@ -334,9 +334,9 @@ def oracle_normalize_ex(x, type, level=0, length=0, right=0, contract=None):
     return out
 
 
-def oracle_vector_normalize(x, kind):
+def oracle_vector_normalize(x, kind, contract=None):
     """signal-vector-f32-<kind>-normalization of every row of x"""
-    L = Oracle()
+    L = Oracle(contract)
     x = np.ascontiguousarray(x, np.float32)
     out = np.empty_like(x)
     types = {"amplitude-spectrum-energy": 0, "energy": 1, "maximum": 2, "mean-energy": 3, "mean": 4, "variance": 5}

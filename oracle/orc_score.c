@@ -294,7 +294,8 @@ static float orc_seq_distance(const float* a, const float* b, int dim) { /* unro
     float score = 0;
     for (int i = 0; i < dim; ++i) {
         float df = a[i] - b[i];
-        score += df * df;
+        score    = ORC_FMAF(df, df, score); /* score += df * df: one vfmadd231ss per term in the default build (read off the disassembly of
+                                             * Mm::unrolledVectorDistance<float, float> in oracle/_ref/libref_native.so; round 6) */
     }
     return score;
 }
@@ -552,7 +553,7 @@ static int orc_gmm_score_quantized(const orc_gmm* h, int variant, const double* 
             isr[(size_t)c * dim + i] = (float)1 / (float)sqrt((double)v);
             ln += log((double)fabsf(v));
         }
-        lognorm[c] = (float)((double)dim * log((double)2 * M_PI) + ln);
+        lognorm[c] = (float)ORC_FMA((double)dim, log((double)2 * M_PI), ln); /* gaussLogNormFactor, as above (one vfmadd in the native build) */
     }
     float minMean = FLT_MAX, maxMean = -FLT_MAX;
     for (int d = 0; d < h->n_dens; ++d) {

@@ -129,6 +129,17 @@ class Context:
         except Exception:
             pass
 
+    CONTRACTS = {"off": 0, "fma": 1}
+
+    def set_contract(self, contract):
+        """which build of the reference the context's f32 arithmetic follows: "off" (-DMARCH=x86-64) | "fma" (RASR's default build);
+        amx_set_contract.  Read by the *_dev entry points at call time and by the front-end / GMM handles at creation."""
+        _lib.check(self.L.amx_set_contract(self.h, self.CONTRACTS[contract] if isinstance(contract, str) else int(contract)))
+        return self
+
+    def contract(self):
+        return {0: "off", 1: "fma"}[int(self.L.amx_get_contract(self.h))]
+
     def use_torch_stream(self):
         """Launch on torch's current HIP stream (so torch events / allocator ordering apply)."""
         import torch
@@ -244,7 +255,7 @@ class GammatoneExtractor:
         for k, v in kw.items():
             if not hasattr(cfg, k):
                 raise TypeError("unknown gammatone parameter %r" % k)
-            setattr(cfg, k, v)
+            setattr(cfg, k, _tuning(v) if k == "tuning" else v)
         self.cfg = cfg
         h = C.c_void_p()
         _lib.check(self.L.amx_gammatone_create(ctx.h if ctx is not None else None, C.byref(cfg), C.byref(h)))

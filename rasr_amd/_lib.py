@@ -38,7 +38,8 @@ class GammatoneCfg(C.Structure):
     _fields_ = [("sample_rate", C.c_double), ("cascade", C.c_int), ("min_freq", C.c_double), ("max_freq", C.c_double), ("q", C.c_double),
                 ("channels", C.c_int), ("cf_mode", C.c_int), ("warp_freq_break", C.c_double), ("warping_factor", C.c_double),
                 ("ti_window", C.c_int), ("ti_length_s", C.c_double), ("ti_shift_s", C.c_double), ("si_window", C.c_int),
-                ("si_length", C.c_int), ("si_shift", C.c_int), ("power", C.c_double), ("n_ceps", C.c_int), ("dct_normalize", C.c_int)]
+                ("si_length", C.c_int), ("si_shift", C.c_int), ("power", C.c_double), ("n_ceps", C.c_int), ("dct_normalize", C.c_int),
+                ("tuning", C.c_char_p)]
 
 
 class GammatoneInfo(C.Structure):
@@ -81,6 +82,9 @@ SIGNATURES = {
     "amx_init": (C.c_int, [C.c_int, C.POINTER(_P)]),
     "amx_destroy": (None, [_P]),
     "amx_set_stream": (C.c_int, [_P, _P]),
+    "amx_set_contract": (C.c_int, [_P, C.c_int]),
+    "amx_get_contract": (C.c_int, [_P]),
+    "amx_contract_description": (C.c_char_p, [C.c_int]),
     "amx_synchronize": (C.c_int, [_P]),
     "amx_profile_enable": (C.c_int, [_P, C.c_int]),
     "amx_profile_reset": (C.c_int, [_P]),

@@ -166,6 +166,7 @@ __device__ __forceinline__ int segment_of(const long long* __restrict__ frame_of
 }
 
 // one workgroup per frame, lanes over the coefficients
+template<bool FMA>   // FMA: the reference's default build (Signal/Regression.cc:24-65 compiled -march=native; INTEGRATION.md lists the contracted sites)
 __global__ __launch_bounds__(64) void regression_kernel(const float* __restrict__ in, int in_ld, const long long* __restrict__ frame_off,
                                                        int n_seg, int dim, int order, int right, float* __restrict__ out, int out_ld) {
     const long long t   = blockIdx.x;
@@ -180,8 +181,8 @@ __global__ __launch_bounds__(64) void regression_kernel(const float* __restrict_
                 long long tt = t - right + i;
                 tt           = tt < s0 ? s0 : (tt >= s1 ? s1 - 1 : tt);
                 const float dt = (float)((double)(float)i - (double)(float)(len - 1) / 2.0);
-                o              = o + dt * in[tt * in_ld + c];
-                tm             = tm + dt * dt;
+                o              = mad<FMA>(dt, in[tt * in_ld + c], o);   // vfmadd213ss
+                tm             = mad<FMA>(dt, dt, tm);                  // vfmadd231ss
             }
             o = o / tm;
         }
@@ -189,17 +190,17 @@ __global__ __launch_bounds__(64) void regression_kernel(const float* __restrict_
             float tm = 0.f, ns = 0.f;
             for (int i = 0; i < len; ++i) {
                 const float dt = (float)((double)(float)i - (double)(float)(len - 1) / 2.0);
-                tm             = tm + dt * dt;
-                ns             = ns + dt * dt * dt * dt;
+                tm             = tm + dt * dt;                     // dt * dt feeds both sums: stays a product (vmulss, vaddss)
+                ns             = mad<FMA>(dt * dt * dt, dt, ns);   // the last product of the fourth power is fused
             }
-            ns = tm * tm - (float)len * ns;
+            ns = mad<FMA>(tm, tm, -((float)len * ns));             // vmulss, vfmsub231ss
             for (int i = 0; i < len; ++i) {
                 long long tt = t - right + i;
                 tt           = tt < s0 ? s0 : (tt >= s1 ? s1 - 1 : tt);
                 const float f  = in[tt * in_ld + c];
                 const float dt = (float)((double)(float)i - (double)(float)(len - 1) / 2.0);
-                o              = o + f * tm;
-                o              = o - f * dt * dt * (float)len;
+                o              = mad<FMA>(f, tm, o);                          // vfmadd213ss
+                o              = mad<FMA>(-(f * dt * dt), (float)len, o);     // vmulss, vmulss, vfnmadd213ss
             }
             o = (float)((double)o * (2.0 / (double)ns));
         }
@@ -209,6 +210,7 @@ __global__ __launch_bounds__(64) void regression_kernel(const float* __restrict_
 
 // y[t][r] = sum_k M[r][k] x[t][k], f32, k ascending.  lane = frame (its row streams through L1), matrix rows are
 // wave-uniform -> scalar loads.  A 45 x 440 LDA over 64 k frames is 2.5 GFLOP: not worth an MFMA path that would change the sums.
+template<bool FMA>   // FMA: Math::Vector::operator* of the default build (result += a[i] * b[i] is one vfmadd231ss)
 __global__ __launch_bounds__(256) void matrix_multiply_kernel(const float* __restrict__ M, int rows, int cols, const float* __restrict__ in,
                                                              int in_ld, int T, float* __restrict__ out, int out_ld) {
     const int t  = blockIdx.x * 256 + threadIdx.x;
@@ -218,7 +220,7 @@ __global__ __launch_bounds__(256) void matrix_multiply_kernel(const float* __res
         const float* m   = M + (size_t)r * cols;
         float        acc = 0.f;
         for (int k = 0; k < cols; ++k)
-            acc = acc + m[k] * x[k];
+            acc = mad<FMA>(m[k], x[k], acc);
         if (t < T)
             out[(size_t)t * out_ld + r] = acc;
     }
@@ -268,7 +270,7 @@ namespace {
 // index order --, narrowed to f32; the elements are scaled with f32 operations.  A thread reads its whole row before it writes
 // the first element, so the identical view may be normalised in place.
 __global__ __launch_bounds__(256) void vector_normalize_kernel(const float* __restrict__ in, int in_ld, long long n, int dim, int type,
-                                                              float* __restrict__ out, int out_ld) {
+                                                              float* __restrict__ out, int out_ld, int fma) {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     if (t >= n)
         return;
@@ -287,7 +289,8 @@ __global__ __launch_bounds__(256) void vector_normalize_kernel(const float* __re
     float sub = 0.f, r = 1.f;
     if (type == AMX_VNORM_AMPLITUDE_SPECTRUM_ENERGY) {
         const float ff = v[0] * v[0], bb = v[dim - 1] * v[dim - 1];
-        const float ends = ff + bb;
+        // v.front() * v.front() + v.back() * v.back(): the FIRST product is fused in the reference's default build
+        const float ends = fma ? __builtin_fmaf(v[0], v[0], bb) : ff + bb;
         r = (float)1 / (float)sqrt(((double)ends + 2 * mid) / (double)(float)((size_t)(dim - 1) * 2));
     }
     else if (type == AMX_VNORM_ENERGY)
@@ -408,7 +411,7 @@ int amx_vector_normalize_dev(amx_ctx* ctx, int type, const float* in_dev, int in
     AMX_HIP(hipSetDevice(ctx->device));
     amx::ScopedKernelTimer timer(ctx, "normalize");
     hipLaunchKernelGGL(vector_normalize_kernel, dim3((unsigned)((n_vectors + 255) / 256)), dim3(256), 0, ctx->stream, in_dev, in_ld,
-                       (long long)n_vectors, dim, type, out_dev, out_ld);
+                       (long long)n_vectors, dim, type, out_dev, out_ld, ctx->contract == AMX_CONTRACT_FMA ? 1 : 0);
     AMX_HIP(hipGetLastError());
     return AMX_OK;
 }
@@ -449,8 +452,8 @@ int amx_regression_dev(amx_ctx* ctx, const amx_mfcc_plan* plan, const float* in_
                 "amx_regression_dev: input and output views overlap");
     AMX_HIP(hipSetDevice(ctx->device));
     amx::ScopedKernelTimer timer(ctx, "regression");
-    hipLaunchKernelGGL(amx::regression_kernel, dim3((unsigned)total), dim3(64), 0, ctx->stream, in_dev, in_ld, d_off, n_seg, dim, order, right,
-                       out_dev, out_ld);
+    hipLaunchKernelGGL(ctx->contract == AMX_CONTRACT_FMA ? amx::regression_kernel<true> : amx::regression_kernel<false>, dim3((unsigned)total),
+                       dim3(64), 0, ctx->stream, in_dev, in_ld, d_off, n_seg, dim, order, right, out_dev, out_ld);
     AMX_HIP(hipGetLastError());
     return AMX_OK;
 }
@@ -467,8 +470,8 @@ int amx_matrix_multiply_dev(amx_ctx* ctx, const float* matrix_dev, int rows, int
                 "amx_matrix_multiply_dev: input and output views overlap");
     AMX_HIP(hipSetDevice(ctx->device));
     amx::ScopedKernelTimer timer(ctx, "matrix_multiply");
-    hipLaunchKernelGGL(amx::matrix_multiply_kernel, dim3((T + 255) / 256, std::min(rows, 64)), dim3(256), 0, ctx->stream, matrix_dev, rows, cols,
-                       in_dev, in_ld, T, out_dev, out_ld);
+    hipLaunchKernelGGL(ctx->contract == AMX_CONTRACT_FMA ? amx::matrix_multiply_kernel<true> : amx::matrix_multiply_kernel<false>,
+                       dim3((T + 255) / 256, std::min(rows, 64)), dim3(256), 0, ctx->stream, matrix_dev, rows, cols, in_dev, in_ld, T, out_dev, out_ld);
     AMX_HIP(hipGetLastError());
     return AMX_OK;
 }

@@ -48,6 +48,7 @@ struct amx_ctx {
     bool                                     profiling  = false;
     std::map<std::string, amx::ProfileSlot>  prof;
     int                                      n_cu = 0;
+    int                                      contract = AMX_CONTRACT_OFF;   // amx_set_contract: which build of the reference the f32 arithmetic follows
     // scratch for amx_stats_accumulate_dev
     void*  scratch       = nullptr;
     size_t scratch_bytes = 0;
@@ -96,6 +97,17 @@ struct Tuning {
 // keys of amx_gmm_model.tuning (gmm.hip and gmm_simd.hip parse the same string)
 static const char* const gmm_tuning_keys[] = {"screen", "fused", "screen_all", "screen_kernel", "graph", "tied_prune", "chunk", "fused_waves", "fr",
                                               "simd_mfma", "contract", nullptr};
+
+// the ONE source of a fused multiply-add outside the GMM scorers (gmm_device.hpp has sq_acc<FMA>): a * b + c as the reference's
+// default build computes it at a contracted site (FMA) or with two roundings (the library is compiled with -ffp-contract=off)
+template<bool FMA>
+__host__ __device__ __forceinline__ float mad(float a, float b, float c) {
+    return FMA ? __builtin_fmaf(a, b, c) : a * b + c;
+}
+template<bool FMA>
+__host__ __device__ __forceinline__ double mad(double a, double b, double c) {
+    return FMA ? __builtin_fma(a, b, c) : a * b + c;
+}
 
 inline int ceil_div(long a, long b) {
     return (int)((a + b - 1) / b);

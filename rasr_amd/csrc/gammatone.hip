@@ -27,6 +27,7 @@
 struct amx_gammatone {
     amx_ctx*           ctx = nullptr;
     amx_gammatone_cfg  cfg;
+    bool               fma = false;   // contract=fma (cfg.tuning, else the context's): the reference's default build
     int                channels = 0, cascade = 0, ti_len = 0, ti_shift = 0, si_channels = 0, n_out = 0;
     std::vector<float> cf, coef, ti_win, si_win, dct;
     float *            d_coef = nullptr, *d_ti_win = nullptr, *d_si_win = nullptr, *d_dct = nullptr;
@@ -78,7 +79,9 @@ struct GtParams {
 // The two halves of a chunk's work have nothing in common but the chunk itself, so they run as a producer / consumer pair of waves
 // (on different SIMDs of the CU): wave 0 filters chunk k into one of two LDS buffers while wave 1 integrates chunk k - 1 from the
 // other; one workgroup barrier per chunk.  The critical path per sample is the longer of the two instead of their sum.
-template<int CASCADE>
+// FMA: the reference's default build (the sites: the cascade's two vfnmadd132ss and one vfmadd132ss per
+// section, the temporal integration's f64 vfmadd132sd).
+template<int CASCADE, bool FMA>
 __global__ __launch_bounds__(128) void gammatone_filter_kernel(GtParams p) {
     extern __shared__ float s_mem[];
     float*                  s_win = s_mem;                                 // [ti_len]
@@ -126,14 +129,11 @@ __global__ __launch_bounds__(128) void gammatone_filter_kernel(GtParams p) {
 #pragma unroll
             for (int c = 0; c < NC; ++c)
                 if (CASCADE || c < p.cascade) {
-                    const float p1 = b1 * w1[c];
-                    o              = o - p1;
-                    const float p2 = b2 * w2[c];
-                    o              = o - p2;
+                    o              = amx::mad<FMA>(-b1, w1[c], o);   // out -= b1 * buffer0
+                    o              = amx::mad<FMA>(-b2, w2[c], o);   // out -= b2 * buffer1
                     const float wn = o;
                     o              = o * a0;
-                    const float p3 = a1 * w1[c];
-                    o              = o + p3;
+                    o              = amx::mad<FMA>(a1, w1[c], o);    // out * a0 + a1 * buffer0: the SECOND product is the fused one
                     w2[c]          = w1[c];
                     w1[c]          = wn;
                 }
@@ -171,14 +171,14 @@ __global__ __launch_bounds__(128) void gammatone_filter_kernel(GtParams p) {
                             }
 #pragma unroll
                             for (int u = 0; u < 8; ++u)
-                                a = (float)((double)a + fabs((double)ov[u]) * (double)wv[u]);
+                                a = (float)amx::mad<FMA>(fabs((double)ov[u]), (double)wv[u], (double)a);
                         }
                         for (; k < m; ++k)
-                            a = (float)((double)a + fabs((double)so[k * 64]) * (double)(hann ? w[k] : 1.f));
+                            a = (float)amx::mad<FMA>(fabs((double)so[k * 64]), (double)(hann ? w[k] : 1.f), (double)a);
                     }
                     else
                         for (int k = 0; k < m; ++k)  // a short frame at the end of the segment: its own window
-                            a = (float)((double)a + fabs((double)s_o[(j + k) * 64 + lane]) * (double)gt_window(p.ti_window, flen[r], pos[r] + k));
+                            a = (float)amx::mad<FMA>(fabs((double)s_o[(j + k) * 64 + lane]), (double)gt_window(p.ti_window, flen[r], pos[r] + k), (double)a);
                     acc[r] = a;
                     j += m;
                     pos[r] += m;
@@ -216,7 +216,7 @@ struct GtPostParams {
     const float* dct;     // [n_ceps][si_channels]
     float*       out;     // [frames][n_out]
     long long    frames;
-    int          channels, si_length, si_shift, si_channels, n_ceps, dct_normalize, n_out;
+    int          channels, si_length, si_shift, si_channels, n_ceps, dct_normalize, n_out, fma;
     float        power;
 };
 
@@ -230,8 +230,7 @@ __global__ __launch_bounds__(128) void gammatone_post_kernel(GtPostParams p) {
         if (p.si_length > 0) {
             float acc = 0.f;
             for (int w = 0; w < p.si_length; ++w) {
-                const float pr = p.si_win[w] * in[ch * p.si_shift + w];
-                acc            = acc + pr;
+                acc = p.fma ? __builtin_fmaf(p.si_win[w], in[ch * p.si_shift + w], acc) : acc + p.si_win[w] * in[ch * p.si_shift + w];   // out += w[k] * in[..]: vfmadd132ss in the default build
             }
             v = acc;
         }
@@ -250,8 +249,7 @@ __global__ __launch_bounds__(128) void gammatone_post_kernel(GtPostParams p) {
         const float* row = p.dct + (size_t)k * p.si_channels;
         float        acc = 0.f;
         for (int n = 0; n < p.si_channels; ++n) {
-            const float pr = row[n] * s_si[n];
-            acc            = acc + pr;
+            acc = p.fma ? __builtin_fmaf(row[n], s_si[n], acc) : acc + row[n] * s_si[n];   // Math::Vector's dot product
         }
         if (p.dct_normalize)
             acc = acc / (float)p.si_channels;
@@ -264,10 +262,10 @@ namespace {
 struct GtWarp {  // Signal::WarpingFunction, all f32
     float factor, brk, maxf, beta = 0, b = 0, wbrk = 0;
     bool  check() const { return !(brk - maxf == 0) && !(factor <= 0) && !(factor * brk >= maxf); }
-    void  init() {
-        beta = (factor * brk - maxf) / (brk - maxf);
+    void  init(bool fma) {
+        beta = (fma ? std::fma(factor, brk, -maxf) : factor * brk - maxf) / (brk - maxf);   // vfmsub132ss in the default build
         b    = maxf * (1 - beta);
-        wbrk = beta * brk + b;  // warping(freqBreak_)
+        wbrk = fma ? std::fma(beta, brk, b) : beta * brk + b;  // warping(freqBreak_): vfmadd
     }
     float inverse(float f) const { return f < wbrk ? f / factor : (f - b) / beta; }
 };
@@ -317,6 +315,7 @@ void amx_gammatone_default_cfg(amx_gammatone_cfg* c) {
     c->power           = 0;
     c->n_ceps          = 0;
     c->dct_normalize   = 0;
+    c->tuning          = nullptr;
 }
 
 int amx_gammatone_create(amx_ctx* ctx, const amx_gammatone_cfg* c, amx_gammatone** out) {
@@ -332,9 +331,21 @@ int amx_gammatone_create(amx_ctx* ctx, const amx_gammatone_cfg* c, amx_gammatone
                         (c->si_window == AMX_WINDOW_HANNING || c->si_window == AMX_WINDOW_RECTANGULAR),
                 AMX_ERR_UNSUPPORTED, "gammatone: window type must be hanning or rectangular");
     AMX_REQUIRE(c->ti_length_s > 0 && c->ti_shift_s > 0, AMX_ERR_INVALID, "gammatone: temporal integration length / shift must be positive");
+    amx::Tuning tune;
+    std::string t_contract;
+    {
+        static const char* const keys[] = {"contract", nullptr};
+        static const char* const cons[] = {"off", "fma", nullptr};
+        if (!tune.parse(c->tuning, keys, "amx_gammatone_create") ||
+            !tune.get_word("contract", ctx && ctx->contract == AMX_CONTRACT_FMA ? "fma" : "off", cons, &t_contract, "amx_gammatone_create"))
+            return AMX_ERR_INVALID;
+    }
     amx_gammatone* h = new amx_gammatone;
     h->ctx           = ctx;
     h->cfg           = *c;
+    h->cfg.tuning    = nullptr;   // the caller's string is not kept
+    h->fma           = t_contract == "fma";
+    const bool fma   = h->fma;
     h->channels      = c->channels;
     h->cascade       = c->cascade;
     // ---- GammaTone::init with the node's f32 members
@@ -345,7 +356,7 @@ int amx_gammatone_create(amx_ctx* ctx, const amx_gammatone_cfg* c, amx_gammatone
         amx::set_error("gammatone: Maybe there is a problem with the warping function.");
         return AMX_ERR_INVALID;
     }
-    warp.init();
+    warp.init(fma);
     float g[3];
     if (c->cf_mode == AMX_GAMMATONE_HUMAN) {
         g[0] = 165.4;
@@ -363,7 +374,7 @@ int amx_gammatone_create(amx_ctx* ctx, const amx_gammatone_cfg* c, amx_gammatone
     const float xMax  = std::log10((double)(maxFreq / g[0] + g[1])) / g[2];
     const float scale = (xMax - xMin) / float((unsigned)(h->channels - 1));
     for (unsigned i = 0; i < (unsigned)h->channels; i++) {
-        const float exponent = g[2] * (xMin + i * scale);
+        const float exponent = g[2] * (fma ? std::fma((float)i, scale, xMin) : xMin + i * scale);   // vfmadd132ss in the default build
         h->cf[i]             = warp.inverse((float)(g[0] * (std::pow(10.0, (double)exponent) - g[1])));
     }
     const float k1Erb = l, k2Erb = 1 / (l * q);
@@ -552,9 +563,9 @@ int amx_gammatone_run_batch_dev(amx_gammatone* h, int n_seg, const long* sample_
         const dim3   grid(n_seg, (h->channels + 63) / 64);
         const size_t lds = (size_t)(((h->ti_len + 63) & ~63) + 2 * kGtChunk * 64) * 4;
         if (p.cascade == 4)  // the node's default
-            hipLaunchKernelGGL((gammatone_filter_kernel<4>), grid, dim3(128), lds, h->ctx->stream, p);
+            hipLaunchKernelGGL((h->fma ? gammatone_filter_kernel<4, true> : gammatone_filter_kernel<4, false>), grid, dim3(128), lds, h->ctx->stream, p);
         else
-            hipLaunchKernelGGL((gammatone_filter_kernel<0>), grid, dim3(128), lds, h->ctx->stream, p);
+            hipLaunchKernelGGL((h->fma ? gammatone_filter_kernel<0, true> : gammatone_filter_kernel<0, false>), grid, dim3(128), lds, h->ctx->stream, p);
     }
     if (tail) {
         GtPostParams q;
@@ -571,6 +582,7 @@ int amx_gammatone_run_batch_dev(amx_gammatone* h, int n_seg, const long* sample_
         q.dct_normalize = h->cfg.dct_normalize;
         q.n_out         = h->n_out;
         q.power         = (float)h->cfg.power;
+        q.fma           = h->fma ? 1 : 0;
         hipLaunchKernelGGL(gammatone_post_kernel, dim3((unsigned)frames), dim3(128), (size_t)h->si_channels * 4, h->ctx->stream, q);
     }
     AMX_HIP(hipGetLastError());

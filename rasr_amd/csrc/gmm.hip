@@ -1650,13 +1650,13 @@ bool screen_dim_supported(int d) {
 
 extern "C" int   amx_internal_gmm_presel_create(amx_ctx* ctx, int dim, size_t nk, const uint32_t* k_mean_host, const float* smeans_host,
                                                 const float* d_smeans, const uint32_t* d_k_mean, int n_clusters, int n_select, int iterations,
-                                                float backoff, void** out);
+                                                float backoff, int contract_fma, void** out);
 extern "C" void  amx_internal_gmm_presel_destroy(void* p);
 extern "C" int   amx_internal_gmm_presel_info(const void* p, int* n_clusters, uint32_t* cluster_of, float* cluster_means);
 extern "C" int   amx_internal_gmm_presel_score(void* p, amx_ctx* ctx, const float* feats_dev, int T, float* scores_dev, const uint32_t* d_mix_off,
                                                const uint32_t* d_k_mean, const float* d_k_const, const float* d_smeans, const float* d_isr0,
                                                int n_mix);
-extern "C" int   amx_internal_gmm_simd_create(const amx_gmm_model* m, void** out, float* scaling_out);
+extern "C" int   amx_internal_gmm_simd_create(const amx_gmm_model* m, int contract_fma, void** out, float* scaling_out);
 extern "C" void  amx_internal_gmm_simd_destroy(void* p);
 extern "C" float amx_internal_gmm_simd_scaling(const void* p);
 extern "C" int   amx_internal_gmm_simd_score(void* p, amx_ctx* ctx, int variant, const float* feats_dev, int T, float* scores_dev, uint32_t* best_dev);
@@ -1972,7 +1972,7 @@ int amx_gmm_create(amx_ctx* ctx, const amx_gmm_model* m, amx_gmm** out) {
         !tune.get_int("chunk", 65536, 256, 1 << 24, &t_chunk, who) || !tune.get_int("fused_waves", 0, 0, 16, &t_fused_waves, who) ||
         !tune.get_int("fr", 8, 2, 16, &t_fr, who) || !tune.get_int("simd_mfma", 1, 0, 1, &t_simd_mfma, who) ||
         !tune.get_int("graph", 1, 0, 1, &t_graph, who) || !tune.get_word("screen_kernel", "rows", screen_kernels, &t_screen_kernel, who) ||
-        !tune.get_word("contract", "off", contracts, &t_contract, who))
+        !tune.get_word("contract", ctx && ctx->contract == AMX_CONTRACT_FMA ? "fma" : "off", contracts, &t_contract, who))   // no key: the context's arithmetic (amx_set_contract)
         return AMX_ERR_INVALID;
     AMX_REQUIRE(t_fused_waves == 0 || t_fused_waves == 8 || t_fused_waves == 12 || t_fused_waves == 13 || t_fused_waves == 16, AMX_ERR_INVALID,
                 "amx_gmm_create: tuning fused_waves=%d: expected 8 | 12 | 13 | 16", t_fused_waves);
@@ -2361,7 +2361,7 @@ static int ensure_simd(amx_gmm* h) {
     v.mixture_weight_scale = h->mws;
     v.gaussian_scale = h->gsc;
     v.tuning = h->tune_simd_mfma ? nullptr : "simd_mfma=0";
-    const int r = amx_internal_gmm_simd_create(&v, &h->simd, nullptr);
+    const int r = amx_internal_gmm_simd_create(&v, h->contract_fma ? 1 : 0, &h->simd, nullptr);
     h->simd_status = r == AMX_OK ? 1 : r;
     return r;
 }
@@ -2409,11 +2409,9 @@ int amx_gmm_score_dev(amx_gmm* h, int mode, const float* feats_dev, int T, float
     AMX_REQUIRE(feats_dev && scores_dev, AMX_ERR_INVALID, "amx_gmm_score_dev: NULL buffer");
     AMX_HIP(hipSetDevice(h->ctx->device));
     const int fblocks = amx::ceil_div(T, 256);
-    // contract=fma covers the scorers whose contraction sites were read off the reference built both ways (maximum, log-add,
-    // batch-float); the quantised and preselection scorers (clustering distances, quantiser, int conversions)
-    // have not been examined under the reference's default flags and refuse rather than claim a build they were not checked against
-    AMX_REQUIRE(!h->contract_fma || mode == AMX_GMM_MAX || mode == AMX_GMM_SUM || mode == AMX_GMM_BATCH_FLOAT, AMX_ERR_UNSUPPORTED,
-                "amx_gmm_score_dev: tuning contract=fma covers modes maximum / sum / batch-float only (mode %d)", mode);
+    // contract=fma covers every mode (round 6): the float scorers fuse the distance's accumulate, the preselection scorer also its
+    // clustering distances (Mm::unrolledVectorDistance: one vfmadd231ss per term in the default build); the quantised scorers' arithmetic
+    // is integer -- their one f64 site, gaussLogNormFactor's N * log(2 pi) + logNorm, follows the contract on the host (gmm_simd.hip)
     if (mode == AMX_GMM_SIMD || mode == AMX_GMM_BATCH_INT || mode == AMX_GMM_PRESELECTION_INT) {
         const int r = ensure_simd(h);
         if (r != AMX_OK)
@@ -2437,7 +2435,7 @@ int amx_gmm_score_dev(amx_gmm* h, int mode, const float* feats_dev, int T, float
         AMX_REQUIRE(best_dev == nullptr, AMX_ERR_UNSUPPORTED, "amx_gmm_score_dev: preselection-batch-float does not assign densities");
         if (!h->presel) {
             const int r = amx_internal_gmm_presel_create(h->ctx, h->dim, h->nk, h->h_k_mean.data(), h->h_smeans.data(), h->d_smeans, h->d_k_mean,
-                                                         h->presel_clusters, h->presel_select, h->presel_iterations, h->presel_backoff, &h->presel);
+                                                         h->presel_clusters, h->presel_select, h->presel_iterations, h->presel_backoff, h->contract_fma ? 1 : 0, &h->presel);
             if (r != AMX_OK)
                 return r;
         }
@@ -2860,7 +2858,7 @@ int amx_gmm_preselection_clustering(amx_gmm* h, int* n_clusters, uint32_t* clust
     if (!h->presel) {
         AMX_HIP(hipSetDevice(h->ctx->device));
         const int r = amx_internal_gmm_presel_create(h->ctx, h->dim, h->nk, h->h_k_mean.data(), h->h_smeans.data(), h->d_smeans, h->d_k_mean,
-                                                     h->presel_clusters, h->presel_select, h->presel_iterations, h->presel_backoff, &h->presel);
+                                                     h->presel_clusters, h->presel_select, h->presel_iterations, h->presel_backoff, h->contract_fma ? 1 : 0, &h->presel);
         if (r != AMX_OK)
             return r;
     }

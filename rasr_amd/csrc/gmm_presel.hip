@@ -30,7 +30,7 @@ namespace amx {
 constexpr int kPreselMaxClusters = 256;  // Mm/DensityClustering.cc:21-22: parameter range 1..256 (ClusterIndex = u8)
 
 // lane = density (mixture entry): first closest cluster
-template<int DIM>
+template<int DIM, bool FMA>   // FMA: Mm::unrolledVectorDistance<f32, f32> of the reference's default build -- score += df * df is one vfmadd231ss per term (read off libref_native.so)
 __global__ __launch_bounds__(256) void presel_assign_kernel(const float* __restrict__ g_smeans, const uint32_t* __restrict__ g_k_mean, int nk,
                                                            const float* __restrict__ g_cm, int n_clusters, uint32_t* __restrict__ g_cluster_of,
                                                            int dim_rt) {
@@ -52,13 +52,13 @@ __global__ __launch_bounds__(256) void presel_assign_kernel(const float* __restr
 #pragma unroll
             for (int i = 0; i < DIM; ++i) {  // unrolledVectorDistance(meanForCluster, meanForDensity): sequential, a = cluster mean
                 const float df = cm[i] - mu[i];
-                score          = score + df * df;
+                score          = mad<FMA>(df, df, score);
             }
         }
         else
             for (int i = 0; i < dim; ++i) {
                 const float df = cm[i] - row[i];
-                score          = score + df * df;
+                score          = mad<FMA>(df, df, score);
             }
         if (score < bd) {
             bd = score;
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void presel_assign_kernel(const float* __restr
 
 // lane = frame: distances of the scaled feature to every cluster mean -> scratch [n_clusters x Tpad] (coalesced along frames),
 // threshold pair by `n_select` selection rounds over that column, lane masks per (wave, cluster)
-template<int DIM>
+template<int DIM, bool FMA>
 __global__ __launch_bounds__(64) void cluster_select_kernel(const float* __restrict__ g_feats, const float* __restrict__ g_isr0, int T, int Tpad,
                                                            const float* __restrict__ g_cm, int n_clusters, int n_select,
                                                            float* __restrict__ g_dist, unsigned long long* __restrict__ g_masks, int dim_rt) {
@@ -88,13 +88,13 @@ __global__ __launch_bounds__(64) void cluster_select_kernel(const float* __restr
 #pragma unroll
             for (int i = 0; i < DIM; ++i) {  // unrolledVectorDistance(feature, meanForCluster)
                 const float df = x(i) - cm[i];
-                score          = score + df * df;
+                score          = mad<FMA>(df, df, score);
             }
         }
         else
             for (int i = 0; i < dim; ++i) {
                 const float df = x(i) - cm[i];
-                score          = score + df * df;
+                score          = mad<FMA>(df, df, score);
             }
         g_dist[(size_t)c * Tpad + t] = score;
     }
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(64) void cluster_select_kernel(const float* __restr
     }
 }
 
-template<int DIM>
+template<int DIM, bool FMA>
 __global__ __launch_bounds__(256) void presel_score_kernel(const float* __restrict__ g_feats, float* __restrict__ g_scores,
                                                           const uint32_t* __restrict__ g_mix_off, const uint32_t* __restrict__ g_k_mean,
                                                           const float* __restrict__ g_k_const, const float* __restrict__ g_smeans,
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void presel_score_kernel(const float* __restri
             if (am == 0ull)
                 continue;  // no frame of this wave selected the density's cluster
             const float* mu = g_smeans + (size_t)g_k_mean[k] * dim;
-            const float  r  = batch_float_distance<DIM, false>(mu, x, g_k_const[k], dim);
+            const float  r  = batch_float_distance<DIM, FMA>(mu, x, g_k_const[k], dim);
             const bool  act = (am >> lane) & 1ull;
             best            = act ? (best < r ? best : r) : best;  // _mm_min_ps(score, r), the reference's operand order: a NaN sum replaces the score
         }
@@ -202,6 +202,7 @@ struct GlibcRand {
 };
 
 struct GmmPresel {
+    bool      fma = false;   // contract=fma: clustering distances and the scorer's distance as the reference's default build fuses them
     int       dim = 0, n_clusters = 0, n_select = 0;
     size_t    nk = 0;
     float     backoff = 40000.f;
@@ -232,7 +233,7 @@ extern "C" void amx_internal_gmm_presel_destroy(void* p) {
 // smeans_host [n_mean x dim] pre-scaled means, k_mean_host [nk]; device copies of both are the scorer's own (d_smeans, d_k_mean)
 extern "C" int amx_internal_gmm_presel_create(amx_ctx* ctx, int dim, size_t nk, const uint32_t* k_mean_host, const float* smeans_host,
                                               const float* d_smeans, const uint32_t* d_k_mean, int n_clusters, int n_select, int iterations,
-                                              float backoff, void** out) {
+                                              float backoff, int contract_fma, void** out) {
     using namespace amx;
     *out = nullptr;
     // DensityClusteringBase::init: "reducing number of clusters ... because there are too few densities"
@@ -243,6 +244,7 @@ extern "C" int amx_internal_gmm_presel_create(amx_ctx* ctx, int dim, size_t nk, 
                 n_clusters);
     AMX_REQUIRE(iterations >= 0, AMX_ERR_INVALID, "preselection: negative iteration count");
     GmmPresel* s = new GmmPresel;
+    s->fma = contract_fma != 0;
     s->dim = dim;
     s->nk = nk;
     s->n_clusters = n_clusters;
@@ -279,13 +281,13 @@ extern "C" int amx_internal_gmm_presel_create(amx_ctx* ctx, int dim, size_t nk, 
         switch (dim) {
 #define X(D)                                                                                                                        \
     case D:                                                                                                                         \
-        hipLaunchKernelGGL(presel_assign_kernel<D>, grid, dim3(256), 0, ctx->stream, d_smeans, d_k_mean, (int)nk, s->d_cm, n_clusters, \
+        hipLaunchKernelGGL((s->fma ? presel_assign_kernel<D, true> : presel_assign_kernel<D, false>), grid, dim3(256), 0, ctx->stream, d_smeans, d_k_mean, (int)nk, s->d_cm, n_clusters, \
                            s->d_cluster_of, dim);                                                                                   \
         break;
             AMX_PRESEL_DIMS(X)
 #undef X
             default:  // any other dimension: rows re-read from memory, the same sums
-                hipLaunchKernelGGL(presel_assign_kernel<0>, grid, dim3(256), 0, ctx->stream, d_smeans, d_k_mean, (int)nk, s->d_cm, n_clusters,
+                hipLaunchKernelGGL((s->fma ? presel_assign_kernel<0, true> : presel_assign_kernel<0, false>), grid, dim3(256), 0, ctx->stream, d_smeans, d_k_mean, (int)nk, s->d_cm, n_clusters,
                                    s->d_cluster_of, dim);
                 break;
         }
@@ -365,13 +367,13 @@ static int presel_score_chunk(amx::GmmPresel* s, amx_ctx* ctx, const float* feat
         switch (s->dim) {
 #define X(D)                                                                                                                             \
     case D:                                                                                                                              \
-        hipLaunchKernelGGL(cluster_select_kernel<D>, dim3(n_groups), dim3(64), 0, ctx->stream, feats_dev, d_isr0, T, Tpad, s->d_cm,     \
+        hipLaunchKernelGGL((s->fma ? cluster_select_kernel<D, true> : cluster_select_kernel<D, false>), dim3(n_groups), dim3(64), 0, ctx->stream, feats_dev, d_isr0, T, Tpad, s->d_cm,     \
                            s->n_clusters, s->n_select, s->d_dist, s->d_masks, s->dim);                                                   \
         break;
             AMX_PRESEL_DIMS(X)
 #undef X
             default:
-                hipLaunchKernelGGL(cluster_select_kernel<0>, dim3(n_groups), dim3(64), 0, ctx->stream, feats_dev, d_isr0, T, Tpad, s->d_cm,
+                hipLaunchKernelGGL((s->fma ? cluster_select_kernel<0, true> : cluster_select_kernel<0, false>), dim3(n_groups), dim3(64), 0, ctx->stream, feats_dev, d_isr0, T, Tpad, s->d_cm,
                                    s->n_clusters, s->n_select, s->d_dist, s->d_masks, s->dim);
                 break;
         }
@@ -385,13 +387,13 @@ static int presel_score_chunk(amx::GmmPresel* s, amx_ctx* ctx, const float* feat
     switch (s->dim) {
 #define X(D)                                                                                                                             \
     case D:                                                                                                                              \
-        hipLaunchKernelGGL(presel_score_kernel<D>, grid, dim3(256), 0, ctx->stream, feats_dev, scores_dev, d_mix_off, d_k_mean, d_k_const, \
+        hipLaunchKernelGGL((s->fma ? presel_score_kernel<D, true> : presel_score_kernel<D, false>), grid, dim3(256), 0, ctx->stream, feats_dev, scores_dev, d_mix_off, d_k_mean, d_k_const, \
                            d_smeans, d_isr0, s->d_cluster_of, s->d_masks, s->n_clusters, s->backoff, T, n_mix, mt, s->dim);              \
         break;
         AMX_PRESEL_DIMS(X)
 #undef X
         default:
-            hipLaunchKernelGGL(presel_score_kernel<0>, grid, dim3(256), 0, ctx->stream, feats_dev, scores_dev, d_mix_off, d_k_mean, d_k_const,
+            hipLaunchKernelGGL((s->fma ? presel_score_kernel<0, true> : presel_score_kernel<0, false>), grid, dim3(256), 0, ctx->stream, feats_dev, scores_dev, d_mix_off, d_k_mean, d_k_const,
                                d_smeans, d_isr0, s->d_cluster_of, s->d_masks, s->n_clusters, s->backoff, T, n_mix, mt, s->dim);
             break;
     }

@@ -460,7 +460,7 @@ static inline int cvt_s32_x86(double v) {
 }
 
 // SimdGaussDiagonalMaximumFeatureScorer::init + buildMixtureTable (Mm/SimdFeatureScorer.cc:68-137)
-int amx_internal_gmm_simd_create(const amx_gmm_model* m, void** out, float* scaling_out) {
+int amx_internal_gmm_simd_create(const amx_gmm_model* m, int contract_fma, void** out, float* scaling_out) {
     using namespace amx;
     *out = nullptr;
     const int    dim = m->dim;
@@ -473,7 +473,10 @@ int amx_internal_gmm_simd_create(const amx_gmm_model* m, void** out, float* scal
             isr[(size_t)c * dim + i] = (float)1 / (float)std::sqrt((double)v);
             lsum += std::log((double)std::fabs(v));
         }
-        lognorm[c] = (float)((double)dim * std::log((double)2 * M_PI) + lsum);
+        // gaussLogNormFactor (Mm/Utilities.hh:70-75): N * log(2 pi) + logNorm is one vfmadd in the reference's default build.  The
+        // scorers' other arithmetic is integer; the batch-int constant (s32)(logNorm scale^2 - scale_ logWeight), an f64 expression of two
+        // products, was not examined under the default flags and is evaluated unfused in both modes (the class is parity unpinned).
+        lognorm[c] = (float)(contract_fma ? std::fma((double)dim, std::log((double)2 * M_PI), lsum) : (double)dim * std::log((double)2 * M_PI) + lsum);
     }
     float min_mean = FLT_MAX, max_mean = -FLT_MAX;  // getScaling (:112-130): over all densities, unscaled 1/sigma
     for (int d = 0; d < m->n_dens; ++d) {

@@ -1265,18 +1265,22 @@ int amx_mfcc_create(amx_ctx* ctx, const amx_mfcc_cfg* cfg, amx_mfcc** out) {
     *out        = nullptr;
     amx::Tuning tune;
     {
-        static const char* const keys[] = {"fft", "wgs", "lpc", "prefetch", nullptr};
+        static const char* const keys[] = {"fft", "wgs", "lpc", "prefetch", "contract", nullptr};
         if (!tune.parse(cfg->tuning, keys, "amx_mfcc_create"))
             return AMX_ERR_INVALID;
     }
-    std::string t_fft, t_lpc;
+    std::string t_fft, t_lpc, t_contract;
     int         t_wgs, t_prefetch;
     {
         static const char* const ffts[] = {"stockham", "mfma", "r16", nullptr};
         static const char* const lpcs[] = {"regs", "lds", nullptr};
+        static const char* const cons[] = {"off", "fma", nullptr};
         const char*              who    = "amx_mfcc_create";
+        // contract: which build of the reference the TABLES follow bit for bit (filter-bank geometry, f64: amx_set_contract); the
+        // kernel's f32 chain is compared at 1e-4 against either build (its log10 / hypot are the device's)
         if (!tune.get_word("fft", "stockham", ffts, &t_fft, who) || !tune.get_word("lpc", "regs", lpcs, &t_lpc, who) ||
-            !tune.get_int("wgs", 0, 0, 64, &t_wgs, who) || !tune.get_int("prefetch", 1, 0, 1, &t_prefetch, who))
+            !tune.get_int("wgs", 0, 0, 64, &t_wgs, who) || !tune.get_int("prefetch", 1, 0, 1, &t_prefetch, who) ||
+            !tune.get_word("contract", ctx && ctx->contract == AMX_CONTRACT_FMA ? "fma" : "off", cons, &t_contract, who))
             return AMX_ERR_INVALID;
     }
     amx_mfcc* h = new amx_mfcc;
@@ -1285,7 +1289,7 @@ int amx_mfcc_create(amx_ctx* ctx, const amx_mfcc_cfg* cfg, amx_mfcc** out) {
     h->tune_lpc_lds  = t_lpc == "lds";
     h->tune_wgs      = t_wgs;
     h->tune_prefetch = t_prefetch != 0;  // default since the end of round 4 (0.753 -> 0.73 ms on config 2)
-    int r       = h->tab.build(*cfg);
+    int r       = h->tab.build(*cfg, t_contract == "fma");
     if (r != AMX_OK) {
         delete h;
         return r;

@@ -39,11 +39,12 @@ struct MelWarp {  // nest(Scaling(2595), MelWarpingCore) in the continuous domai
 
 struct BarkWarp {  // nest(Scaling(6), nest(ArcSinh, Scaling(1/600))) in the continuous domain
     Scaling outer{6.0}, inner{1.0 / 600.0};
+    bool    fma = false;  // contract=fma: DerivedArcSinh::value's u * u + 1 is one vfmadd132sd in the reference's default build
     double  operator()(double f) const { return outer(std::asinh(inner(f))); }
     // derive(): (const(6) o g)(f) * g'(f) with g' = (DerivedArcSinh o inner)(f) * const(1/600)
     double derivative(double f) const {
         const double u = inner(f);
-        return outer.a * ((1.0 / std::sqrt(u * u + 1.0)) * inner.a);
+        return outer.a * ((1.0 / std::sqrt(fma ? std::fma(u, u, 1.0) : u * u + 1.0)) * inner.a);
     }
     // invert(): inner^-1 o sinh o outer^-1
     double inverse(double b) const { return inner.inverse()(std::sinh(outer.inverse()(b))); }
@@ -106,7 +107,7 @@ double through_attribute(double v) {
 
 }  // namespace
 
-int MfccTables::build(const amx_mfcc_cfg& c) {
+int MfccTables::build(const amx_mfcc_cfg& c, bool fma) {
     cfg = c;
     AMX_REQUIRE(c.sample_rate > 0, AMX_ERR_INVALID, "mfcc: sample rate (%f) is not positive", c.sample_rate);
     AMX_REQUIRE(c.win_len_s > 0 && c.win_shift_s > 0, AMX_ERR_INVALID, "mfcc: window length/shift must be positive");
@@ -151,6 +152,10 @@ int MfccTables::build(const amx_mfcc_cfg& c) {
         const Scaling cont2disc = disc2cont.inverse();
         Warp          warp;
         warp.kind           = c.warping;
+        warp.bark.fma       = fma;
+        // a * b + c at the sites the reference's default build contracts (f64: coverage, the
+        // include-boundary count, stretch-to-cover's centres, setStart / setEnd)
+        auto mad = [&](double a, double b, double c3) { return fma ? std::fma(a, b, c3) : a * b + c3; };
         const double f_min  = 0.0;
         const double f_max  = warp(disc2cont((double)(n_bins - 1)));
         mel_max             = f_max;
@@ -162,7 +167,7 @@ int MfccTables::build(const amx_mfcc_cfg& c) {
         if (c.boundary == AMX_BOUNDARY_STRETCH_TO_COVER) {
             // StretchToCover::getNumberOfFilters, then init: stretch width and spacing so the last filter ends on f_max
             nf                     = (size_t)std::floor(postprocess_filter_count((f_max - f_min - width) / spacing + 1));
-            const double coverage  = (spacing * (double)(nf - 1) + width) / (f_max - f_min);
+            const double coverage  = mad(spacing, (double)(nf - 1), width) / (f_max - f_min);   // vfmadd132sd
             const bool   single_covers = nf == 1 && coverage > 1 && !almost_equal(coverage, 1);
             if (!single_covers) {
                 AMX_REQUIRE(almost_equal(coverage, 1) || coverage < 1, AMX_ERR_INVALID, "mfcc: filter bank coverage %f > 1", coverage);
@@ -171,7 +176,7 @@ int MfccTables::build(const amx_mfcc_cfg& c) {
             }
         }
         else if (c.boundary == AMX_BOUNDARY_INCLUDE)  // first centre at `spacing`, last filter reaches beyond f_max
-            nf = (size_t)std::ceil(postprocess_filter_count((f_max - (1 - centre_pos) * width) / spacing));
+            nf = (size_t)std::ceil(postprocess_filter_count(mad(-(1 - centre_pos), width, f_max) / spacing));   // vfnmadd132sd
         else  // emphasize-boundary: first centre at 0
             nf = (size_t)std::floor(postprocess_filter_count(f_max / spacing + 1));
         n_filters = (int)nf;
@@ -180,15 +185,15 @@ int MfccTables::build(const amx_mfcc_cfg& c) {
         filter_offset.assign(nf + 1, 0);
         filter_weights.clear();
         for (size_t i = 0; i < nf; ++i) {
-            const double centre = c.boundary == AMX_BOUNDARY_STRETCH_TO_COVER ? f_min + spacing * (double)i + centre_pos * width
+            const double centre = c.boundary == AMX_BOUNDARY_STRETCH_TO_COVER ? mad(centre_pos, width, mad(spacing, (double)i, f_min))   // two vfmadd
                                   : c.boundary == AMX_BOUNDARY_INCLUDE        ? spacing * (double)(i + 1)
                                                                               : spacing * (double)i;
             // FilterBuilder::setStart / setEnd
-            double left  = std::max(centre - centre_pos * width, f_min);
+            double left  = std::max(mad(-centre_pos, width, centre), f_min);   // vfnmadd231sd
             double first = cont2disc(warp.inverse(left));
             first        = almost_integer(first) ? std::round(first) : std::ceil(first);
             AMX_REQUIRE(first >= 0, AMX_ERR_INVALID, "mfcc: Start point of the filter at center %f became negative (%d).", centre, (int)first);
-            double right = std::min(centre + (1.0 - centre_pos) * width, f_max);
+            double right = std::min(mad(1.0 - centre_pos, width, centre), f_max);   // vfmadd132sd
             double last  = cont2disc(warp.inverse(right));
             last         = almost_integer(last) ? std::round(last) + 1 : std::ceil(last);
             const size_t b0 = (size_t)first;

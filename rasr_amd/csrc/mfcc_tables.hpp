@@ -33,7 +33,8 @@ struct MfccTables {
     std::vector<float> split_twiddle;  // [fft_len/4][2] cos,sin of +pi*k/(fft_len/2)    (real split)
 
     // returns AMX_OK or an error status (message via set_error)
-    int build(const amx_mfcc_cfg& c);
+    // fma: the geometry (f64) as the reference's default build contracts it (amx_set_contract / tuning contract=fma)
+    int build(const amx_mfcc_cfg& c, bool fma = false);
 
     long   n_frames(long n_samples) const;
     double frame_start_time(long frame) const;

@@ -45,6 +45,27 @@ namespace AmxHost {
     } while (0)
 #endif
 
+/** amx_init + the arithmetic of THIS translation unit's build (round 6).  The adapter is compiled inside RASR's build, with RASR's
+ *  flags: AMX_CONTRACT_OF_THIS_BUILD (include/amx.h) is FMA exactly when the compiler that builds RASR's own scorers fuses their
+ *  multiply-adds (-march=native on an FMA host: cmake_resources/CompileOptions.cmake:21-48), so the scores, features and statistics the
+ *  library hands back are bit-identical to what the replaced RASR build itself would have computed -- nobody has to remember a tuning
+ *  string.  Every handle created on the context afterwards inherits it.  `description` (optional) receives the line to log next to the
+ *  reference's own initialisation messages.  Returns amx_status. */
+inline int initContext(int device, amx_ctx** ctx, const char** description = nullptr) {
+    int r = amx_init(device, ctx);
+    if (r != AMX_OK)
+        return r;
+    r = amx_set_contract(*ctx, AMX_CONTRACT_OF_THIS_BUILD);
+    if (r != AMX_OK) {
+        amx_destroy(*ctx);
+        *ctx = nullptr;
+        return r;
+    }
+    if (description)
+        *description = amx_contract_description(AMX_CONTRACT_OF_THIS_BUILD);
+    return AMX_OK;
+}
+
 typedef float              Score;          // Mm::Score
 typedef unsigned           EmissionIndex;  // Mm::EmissionIndex
 typedef std::vector<float> FeatureVector;  // Mm::FeatureVector

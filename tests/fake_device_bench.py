@@ -72,6 +72,10 @@ class FakeContext(Strict):
     def use_torch_stream(self):
         pass
 
+    def set_contract(self, contract):
+        assert contract in ("off", "fma")
+        return self
+
     def profile(self, on):
         pass
 

@@ -221,7 +221,7 @@ def test_tuning_strings_are_parsed_strictly_and_nothing_reads_kernel_switches_fr
         with pytest.raises(rasr_amd.AmxError, match="tuning"):
             rasr_amd.GmmFeatureScorer(None, model, tuning=bad)
     out = subprocess.run(["strings", _lib.LIB_PATH], capture_output=True, text=True).stdout.split()
-    env_names = sorted({w for w in out if w.startswith("AMX_") and w.isupper() and not w.startswith("AMX_PREC_")})   # enum names in error texts
+    env_names = sorted({w for w in out if w.startswith("AMX_") and w.isupper() and not w.startswith(("AMX_PREC_", "AMX_CONTRACT_"))})   # enum names in error texts
     assert env_names == ["AMX_RCCL_LIB"], env_names
     srcs = os.path.join(ROOT, "rasr_amd", "csrc")
     for f in os.listdir(srcs):
@@ -362,3 +362,23 @@ def test_vector_files_accept_the_attribute_forms_an_xml_parser_accepts(tmp_path)
     n, ptr = C.c_int(), C.c_void_p()
     assert L.amx_nn_vector_read_f32(p.encode(), C.byref(n), C.byref(ptr)) == _lib.AMX_ERR_INVALID
     assert b"Vector dimension mismatch: 4 given and 3 read" in L.amx_last_error()
+
+
+def test_contract_macro_follows_the_including_translation_units_flags(tmp_path):
+    """AMX_CONTRACT_OF_THIS_BUILD is decided where include/amx.h is INCLUDED (the adapter, built with RASR's flags): FMA with -mfma /
+    -march=haswell, OFF for plain x86-64 and when the adapter says its build does not contract; rasr_amd/host's initContext compiles"""
+    import subprocess
+    src = tmp_path / "m.cc"
+    src.write_text('#include "%s/rasr_amd/host/BatchFeatureScorer.hh"\n#include <cstdio>\nint main() { std::printf("%%d\\n", AMX_CONTRACT_OF_THIS_BUILD); '
+                   'return &AmxHost::initContext == nullptr; }\n' % ROOT)
+    def value(*flags):
+        exe = str(tmp_path / "m")
+        subprocess.check_call(["g++", "-std=c++17", "-O0", *flags, "-c", str(src), "-o", exe + ".o"])
+        out = subprocess.run(["g++", "-std=c++17", "-E", "-dM", *flags, "-include", os.path.join(ROOT, "include", "amx.h"), "-x", "c++", "/dev/null"],
+                             capture_output=True, text=True, check=True).stdout
+        line = [l for l in out.splitlines() if l.startswith("#define AMX_CONTRACT_OF_THIS_BUILD")][0]
+        return line.split()[2]
+    assert value("-march=x86-64") == "AMX_CONTRACT_OFF"
+    assert value("-march=x86-64", "-mfma") == "AMX_CONTRACT_FMA"
+    assert value("-march=haswell") == "AMX_CONTRACT_FMA"
+    assert value("-march=haswell", "-DAMX_ADAPTER_NO_FP_CONTRACT") == "AMX_CONTRACT_OFF"

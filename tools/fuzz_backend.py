@@ -1,5 +1,6 @@
 """tools/fuzz_backend.py [n_cases] [seed] -- random segmentations, dimensions, strides and window settings through the feature back-end
-kernels (normalisation, regression, matrix multiplication) against oracle/orc_backend.c, bit for bit."""
+kernels (normalisation, regression, matrix multiplication) against oracle/orc_backend.c, bit for bit.  Every case draws one of the
+reference's two arithmetics (amx_set_contract off | fma) and is held to the oracle library of that build."""
 import os
 import sys
 
@@ -23,6 +24,8 @@ for case in range(n_cases):
     off = np.concatenate([[0], np.cumsum(lens)])
     F = int(off[-1])
     assert plan.total_frames == F
+    contract = ("off", "fma")[int(rng.integers(0, 2))]
+    ctx.set_contract(contract)
     dim, pad = int(rng.integers(1, 70)), int(rng.integers(0, 5))
     ld = dim + pad
     x = (rng.standard_normal((F, ld)) * 3 + 1).astype(np.float32)
@@ -35,7 +38,7 @@ for case in range(n_cases):
             want = fn(s)
             if not np.array_equal(got[off[i]:off[i + 1]].view(np.uint32), want.view(np.uint32)):
                 bad += 1
-                print("MISMATCH", what, "case", case, "lens", lens, "dim", dim, "segment", i)
+                print("MISMATCH", what, "contract", contract, "case", case, "lens", lens, "dim", dim, "segment", i)
                 return
 
     kw = dict(variance=bool(rng.integers(0, 2)))
@@ -50,13 +53,13 @@ for case in range(n_cases):
     out = torch.zeros((F, dim), dtype=torch.float32, device="cuda")
     ctx.regression(plan, xd, ld, dim, out, dim, order=order, right=right)
     torch.cuda.synchronize()
-    check("regression %d/%d" % (order, right), out.cpu().numpy(), lambda s: oracle_regression(s, order, right))
+    check("regression %d/%d" % (order, right), out.cpu().numpy(), lambda s: oracle_regression(s, order, right, contract=contract))
     rows = int(rng.integers(1, 60))
     M = rng.standard_normal((rows, dim)).astype(np.float32)
     out = torch.zeros((F, rows), dtype=torch.float32, device="cuda")
     ctx.matrix_multiply(torch.from_numpy(M).cuda(), rows, dim, xd, ld, F, out, rows)
     torch.cuda.synchronize()
-    want = oracle_matrix_multiply(M, x[:, :dim])
+    want = oracle_matrix_multiply(M, x[:, :dim], contract=contract)
     if not np.array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32)):
         bad += 1
         print("MISMATCH matrix multiply case", case, rows, dim, F)

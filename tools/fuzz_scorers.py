@@ -40,7 +40,9 @@ for case in range(n_cases):
     x = (rng.standard_normal((T, dim)) * rng.choice([0.5, 1.0, 2.0])).astype(np.float32)
     if rng.integers(0, 3) == 0:
         x[int(rng.integers(0, T))] *= 40.0   # saturates the u8 quantiser
-    o = OracleGmm(model)
+    contract = ("off", "fma")[int(rng.integers(0, 2))]   # the reference's two arithmetics: the context's setting reaches every scorer type
+    ctx.set_contract(contract)
+    o = OracleGmm(model, contract=contract)
     clusters = int(rng.choice([1, 2, 8, 16, 64, 256]))
     select = int(rng.integers(1, clusters + 1))
     iters = int(rng.integers(1, 7))
