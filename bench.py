@@ -938,7 +938,8 @@ class NnOnly:
         dims = [440] + [2048] * 6 + [10000]
         Ws, bs, acts, logp = synth.ffnn(dims, seed=7)
         self.nn = rasr_amd.NnBatchFeatureScorer(ctx, Ws, bs, acts, log_prior=logp, priori_scale=1.0, precision=args.precision, tuning=args.nn_tuning)
-        self.nn_precision = args.precision
+        self.nn_precision = self.nn.effective_precision()[0]   # (f16mx on heavy-tailed weights computes in split bf16: amx_ffnn_precision)
+        self.requested_precision = args.precision
         self.T = 1024
         x = np.random.Generator(np.random.PCG64(6 + rank)).standard_normal((self.T, 440)).astype(np.float32)
         self.x = torch.from_numpy(x).cuda()
@@ -1254,7 +1255,10 @@ def make_job(ctx, args, rank, world=1):
         return NullJob(args, rank, world)
     if args.workload in ("pipeline", "nn-pipeline"):
         job = (Pipeline if args.workload == "pipeline" else NnPipeline)(ctx, args, rank)
-        job.nn_precision = args.precision
+        # what the handle COMPUTES in: f16mx requested on heavy-tailed weights runs split bf16 (amx_ffnn_precision; mx_fallback=auto) --
+        # the roofline's kernel name and executed units follow the effective precision, the line names both
+        job.nn_precision = job.nn.effective_precision()[0] if hasattr(job.nn, "effective_precision") else args.precision
+        job.requested_precision = args.precision
     elif args.workload == "mfcc":
         job = MfccOnly(ctx, args, rank)
     elif args.workload == "gmm-train":
@@ -1718,6 +1722,9 @@ def main():
                 "data": "synthetic", "config": {"workload": WORKLOAD_NAMES[args.workload](args), "frames_per_step_per_gpu": job.units,
                                                 "contract": CONTRACT_TEXT[args.contract]},
                 "rtf": round(dt / (units * 0.01), 8), "build": rasr_amd.version()}
+        if getattr(job, "requested_precision", None) and job.requested_precision != getattr(job, "nn_precision", job.requested_precision):
+            line["config"]["precision_fallback"] = ("requested %s, the handle computes in %s (amx_ffnn_precision: block-maximum statistic of the weights "
+                                                    "above 4.0, tuning mx_fallback=auto)" % (job.requested_precision, job.nn_precision))
         line["roofline"] = job.roofline()
         if line["roofline"] and line["roofline"].get("traffic") is not None:
             line["roofline"]["traffic_source"] = TRAFFIC_SOURCE + " (offline rocprofv3 --pmc passes on the profiling box, not this run)"

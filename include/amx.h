@@ -342,16 +342,21 @@ typedef struct {
      * a value the key does not take fail the creation (AMX_ERR_INVALID): a typo must not silently select another kernel or arithmetic.
      * Read by amx_gmm_create only (amx_pms_write, amx_gmm_estimate, amx_prior_from_mixture_set ignore it).
      *
-     * contract=off|fma -- WHICH BUILD OF THE REFERENCE the scores are bit-identical to (not a speed switch; default off):
+     * contract=off|fma -- WHICH BUILD OF THE REFERENCE the scorer follows (without the key: the context's, amx_set_contract -- OFF unless
+     *   the adapter said otherwise; see there for what the two builds are):
      *   off  RASR configured with -DMARCH=x86-64, or built on a host without FMA units: every f32 operation of the distance
      *        (Mm/GaussDiagonalMaximumFeatureScorer.cc:144-218) rounds once;
      *   fma  RASR's DEFAULT configuration (cmake_resources/CompileOptions.cmake:39-48: -march=native) built with GCC on an FMA host:
-     *        its default -ffp-contract=fast turns `sum += df * df` into one fused multiply-add (vfmadd231ps / vfmadd231ss); about a
-     *        fifth of the d = 40 distances differ in the last bit from the other build.
-     *   Covers the modes AMX_GMM_MAX, AMX_GMM_SUM, AMX_GMM_BATCH_FLOAT, amx_gmm_best_density_dev and the Baum-Welch statistics; the
-     *   quantised and preselection scorers were not examined under the reference's default flags and return AMX_ERR_UNSUPPORTED with
-     *   contract=fma, as does fused_waves=13.  Both arithmetics are pinned on the reference's own function text compiled both ways
-     *   (tests/test_contract.py) and bit-exact on every kernel path (tests/test_gmm_gpu.py, tests/test_gmm_contract_gpu.py).
+     *        `sum += df * df` is ONE fused multiply-add (vfmadd231ps / vfmadd231ss); about a fifth of the d = 40 distances differ in
+     *        the last bit from the other build.  One vector operation fewer per dimension in the exact stage: the fused GMM kernel
+     *        runs 4.60 -> 4.18 ms on BASELINE config 5's shard (profiles/r05/gmm_contract_ab.log) -- bench.py's default is fma because
+     *        it is the reference's default build, and the line names the mode.
+     *   Every mode takes both (round 6).  Bit-exact, in the named build: AMX_GMM_MAX scores and density indices, AMX_GMM_BATCH_FLOAT,
+     *   AMX_GMM_PRESELECTION_FLOAT (clustering included), amx_gmm_best_density_dev, the quantised scorers (integer arithmetic; their
+     *   host-side gaussLogNormFactor follows the contract).  AMX_GMM_SUM: the DISTANCES and the best density follow the contract bit
+     *   for bit; the log-add score itself is a streaming sum with the device's expf / logf -- within 1e-5 of the reference's two-pass
+     *   form in either mode, not bit-exact.  Baum-Welch statistics: 2e-5 (the same expf).  fused_waves=13 (a lab kernel) has no fma
+     *   form and fails the creation with AMX_ERR_UNSUPPORTED.  tests/test_gmm_contract_gpu.py, tests/test_contract_gpu.py.
      *
      * Kernel selection for A/B runs and tests -- every path gives the same scores and density indices bit for bit (within a contract):
      * screen=0 (no MFMA / f32 screen: every density evaluated), fused=0 (two-kernel screen path instead of gmm_fused_kernel),

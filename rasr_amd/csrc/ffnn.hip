@@ -1474,6 +1474,30 @@ int ensure_workspace(amx_ffnn* h, int Tpad) {
     h->cap_T                            = 0;
     const size_t planes = h->precision == AMX_PREC_BF16X3 ? 2 : 1;  // split bf16: rows are [hi plane | lo plane]
     if (h->is_mx()) {  // 25 KB blocks per (256 rows, 32 k)
+        // The split-K workspace (tuning ksplit) is sized HERE, with the other buffers and outside any stream capture -- launch_mx
+        // used to grow it lazily, which on a retry after a failed allocation happened inside hipStreamBeginCapture and wrote through an
+        // iterator of the graph map it had just cleared (advisor, round 5).  Upper bound over the layers that can run split at this
+        // batch size: tiles of 128 x 64, four computing waves of two 32 x 32 blocks, 16 x 64 floats each.  A failed allocation
+        // switches the split off for the life of the handle (the default order: bit-identical to a handle created without ksplit).
+        if (h->mx_ksplit > 1) {
+            size_t need = 0;
+            for (int l = 0; l < h->n_layers; ++l) {
+                const long tiles = (long)(h->Npad[l] / 128) * (Tpad / 64);
+                if (tiles * h->mx_ksplit <= (long)std::max(h->ctx->n_cu, 8) && h->Kpad[l] / 32 >= 8 * h->mx_ksplit)
+                    need = std::max(need, (size_t)tiles * h->mx_ksplit * 4 * 2 * 16 * 64);
+            }
+            if (need > h->ks_ws_cap) {
+                hipFree(h->d_ks_ws);
+                h->d_ks_ws   = nullptr;
+                h->ks_ws_cap = 0;
+                if (hipMalloc((void**)&h->d_ks_ws, need * 4) != hipSuccess) {
+                    (void)hipGetLastError();
+                    h->mx_ksplit = 1;
+                }
+                else
+                    h->ks_ws_cap = need;
+            }
+        }
         AMX_HIP(hipMalloc(&h->d_in, (size_t)(Tpad / 256) * (h->Kpad[0] / 32) * amx::mx::BLK));
         if (h->max_hidden_pad > 0) {
             AMX_HIP(hipMalloc(&h->d_act[0], (size_t)(Tpad / 256) * (h->max_hidden_pad / 32) * amx::mx::BLK));
@@ -1637,7 +1661,7 @@ template<class C, int ACT, bool LAST>
 void launch_mx(amx_ffnn* h, int l, const void* x, int xkts, void* out, int ldo, int T, int Tpad, int n_valid) {
     const int ntn = h->Npad[l] / C::BN, ntt = Tpad / C::BT;
     const int gt = h->group_t >= 0 ? h->group_t : (C::BN == 256 ? 16 : 8), gn = h->group_n >= 0 ? h->group_n : (C::BN == 256 ? 8 : 2);
-    constexpr int lds_bytes = amx::gemm_scratch_bytes<C, LAST>() + C::BN * 4 + 16;   // + the split-K arrival flag
+    constexpr int lds_bytes = amx::gemm_scratch_bytes<C, LAST>() + C::BN * 4;   // stages / epilogue scratch + the tile's bias
     static_assert(lds_bytes <= 160 * 1024, "LDS budget");
     const int per_cu = std::max(1, (160 * 1024) / lds_bytes);
     // split-K across workgroups (tuning ksplit=4): only where it multiplies the CUs that pull operands -- the one-tile-per-CU
@@ -1646,24 +1670,8 @@ void launch_mx(amx_ffnn* h, int l, const void* x, int xkts, void* out, int ldo, 
     if (h->mx_ksplit > 1 && C::BN == 128 && C::BT == 64 && C::U == 2 && (long)ntn * ntt * h->mx_ksplit <= (long)std::max(h->ctx->n_cu, 8) &&
         h->Kpad[l] / 32 >= 8 * h->mx_ksplit)
         ksplit = h->mx_ksplit;
-    if (ksplit > 1) {
-        const size_t need_ws = (size_t)ntn * ntt * ksplit * C::NW * C::MI * C::MJ * 16 * 64;
-        if (need_ws > h->ks_ws_cap) {
-            for (auto& kv : h->graphs)  // captured passes hold the old workspace address
-                if (kv.second)
-                    hipGraphExecDestroy(kv.second);
-            h->graphs.clear();
-            hipFree(h->d_ks_ws);
-            h->d_ks_ws   = nullptr;
-            h->ks_ws_cap = 0;
-            if (hipMalloc((void**)&h->d_ks_ws, need_ws * 4) != hipSuccess) {
-                (void)hipGetLastError();
-                ksplit = 1;  // no workspace: the default order
-            }
-            else
-                h->ks_ws_cap = need_ws;
-        }
-    }
+    if (ksplit > 1 && (size_t)ntn * ntt * ksplit * C::NW * C::MI * C::MJ * 16 * 64 > h->ks_ws_cap)
+        ksplit = 1;  // (ensure_workspace sizes the workspace for every layer that can run split; nothing is allocated here: this may be inside a stream capture)
     int       grid   = std::min(ntn * ntt * ksplit, per_cu * std::max(h->ctx->n_cu, 8));
     if (grid >= 8)
         grid &= ~7;  // keep blockIdx % 8 == tile index % 8 for every stride step
@@ -1970,8 +1978,18 @@ int amx_ffnn_create(amx_ctx* ctx, const amx_ffnn_model* m, amx_ffnn** out) {
             if (sum_w2 > 0.0)
                 mx_ratio = std::max(mx_ratio, std::sqrt((sum_max2 / (double)n_blocks) / (sum_w2 / ((double)N * (double)K))));
         }
-        if (t_mx_fallback == "auto" && mx_ratio > 4.0)
+        if (t_mx_fallback == "auto" && mx_ratio > 4.0) {
+            // the handle computes in split bf16: twice the matrix work, other rounding than the caller asked for -- said ONCE, on
+            // stderr (the adapter logs amx_ffnn_precision as well), and a split-K request -- an f16mx schedule -- is refused rather
+            // than accepted and ignored (advisor, round 5)
+            AMX_REQUIRE(t_ksplit <= 1, AMX_ERR_INVALID,
+                        "amx_ffnn_create: tuning ksplit=%d applies to AMX_PREC_F16MX, but this network's weights are heavy-tailed (block-maximum "
+                        "statistic %.2f > 4.0) and the handle would compute in AMX_PREC_BF16X3: drop ksplit, or keep f16mx with mx_fallback=off",
+                        t_ksplit, mx_ratio);
+            std::fprintf(stderr, "rasr_amd: amx_ffnn_create: AMX_PREC_F16MX requested, computing in AMX_PREC_BF16X3 (block-maximum statistic of the "
+                                 "weights %.2f > 4.0; tuning mx_fallback=off keeps f16mx)\n", mx_ratio);
             prec = AMX_PREC_BF16X3;
+        }
     }
     amx_ffnn* h  = new amx_ffnn;
     h->ctx       = ctx;

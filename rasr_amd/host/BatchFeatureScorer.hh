@@ -191,6 +191,9 @@ public:
     int fetchPairs(int n, const unsigned* rows, const unsigned* emissions, float* dst) {
         return amx_gather_scores(block_.ctx(), block_.scores(), rows_, (int)nEmissions(), n, rows, emissions, dst);
     }
+    /** the arithmetic the handle COMPUTES in (AMX_PREC_*): AMX_PREC_F16MX requested on heavy-tailed weights runs AMX_PREC_BF16X3
+     *  (amx_ffnn_precision; blockRatio: the statistic that decided).  The adapter logs it next to the network's own messages. */
+    int effectivePrecision(double* blockRatio = nullptr) const { return amx_ffnn_precision(h_, blockRatio); }
 };
 
 class BatchFeatureScorer;

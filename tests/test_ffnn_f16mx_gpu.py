@@ -330,6 +330,8 @@ def test_f16mx_operand_families_that_are_not_gaussian(ctx, family, capsys):
     assert (ratio > 4.0) == heavy, (family, ratio)
     if heavy:
         assert np.array_equal(dflt.score(x).view(np.uint32), sx3.view(np.uint32))
+        with pytest.raises(rasr_amd.AmxError, match="ksplit"):   # an f16mx schedule on a handle that would compute in split bf16: refused, not ignored
+            rasr_amd.NnBatchFeatureScorer(ctx, Ws, bs, acts, log_prior=logp, precision="f16mx", tuning="ksplit=4")
     r32 = nn_parity_report(f32, want, gap=1e-5)
     # Ill-conditioned families (outliers of 2^8 .. 2^12, log-normal rows, features of hundreds): a score is then a difference of terms
     # 10^3 .. 10^5 times larger than itself, and f32 ACCUMULATION -- the reference's own sgemm -- is off by 2-5 times the bar there
