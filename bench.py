@@ -1744,6 +1744,10 @@ def main():
             r["shader_clock_GHz"] = sclk
             if HWMON:
                 r["hwmon"] = HWMON
+                if HWMON.get("socket_power_W"):
+                    # the step priced in joules: socket power over seconds of the same steps x the timed step (profiles/r06/energy.json has
+                    # the variants -- XCD super-tile shapes, best-density formats, plain stores: none lowers the time at the 1400 W cap)
+                    r["joules_per_step"] = round(HWMON["socket_power_W"] * (1e3 * dt / args.steps) * 1e-3, 3)
             # per-XCD ratios outside 0.5-1.2 x the driver's figure (without one: outside 0.5-2.45 GHz, the part's range) are the
             # unaligned-counter artefact, not a clock: masked (None), and the median is taken over what is left
             lo_, hi_ = (0.5 * HWMON["sclk_GHz"], 1.2 * HWMON["sclk_GHz"]) if HWMON else (0.5, 2.45)

@@ -57,7 +57,7 @@ typedef struct amx_ffnn amx_ffnn;
 
 /* ------------------------------------------------------------------ context */
 
-/* "rasr_amd <version> (gfx950; <compiler>; <flags>; src=<12 hex digits>)": the source hash is the SHA-1 of rasr_amd/csrc/* and
+/* "rasr_amd <version> (gfx950; <compiler>; <flags>; src=<12 hex digits>)": the source hash is the SHA-1 of the files of rasr_amd/csrc/ and
  * include/amx.h the library was built from (rasr_amd/csrc/Makefile), so that a measurement can be tied to a build. */
 const char* amx_version(void);
 const char* amx_last_error(void);

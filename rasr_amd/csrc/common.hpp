@@ -109,6 +109,18 @@ __host__ __device__ __forceinline__ double mad(double a, double b, double c) {
     return FMA ? __builtin_fma(a, b, c) : a * b + c;
 }
 
+// streaming stores of the score / best-density matrices (written once, read by a later kernel or the host): non-temporal, so that
+// gigabytes of results do not push the operand panels out of L2.  -DAMX_PLAIN_STORES (tools/energy_table.sh: a measurement build)
+// turns them into plain stores for the energy / time comparison of profiles/r06/energy.json.
+template<class V>
+__device__ __forceinline__ void nt_store(V v, V* p) {
+#ifdef AMX_PLAIN_STORES
+    *p = v;
+#else
+    __builtin_nontemporal_store(v, p);
+#endif
+}
+
 inline int ceil_div(long a, long b) {
     return (int)((a + b - 1) / b);
 }

@@ -421,7 +421,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[C::MI][C::MJ], char*
                 if (t < t_valid && !(NOSTORE && v.x != 123.456f)) {
                     float* o = (float*)out + (size_t)t * ldo + n;
                     if (n + 3 < n_valid && ((ldo & 3) == 0))
-                        __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, (f32x4*)o);  // 1.3 GB of scores per pass must not push the operand panels out of L2
+                        amx::nt_store(f32x4{v.x, v.y, v.z, v.w}, (f32x4*)o);  // 1.3 GB of scores per pass must not push the operand panels out of L2
                     else {
                         if (n < n_valid) o[0] = v.x;
                         if (n + 1 < n_valid) o[1] = v.y;
@@ -1123,7 +1123,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm_bf16_pipe_kernel(const bf16_t
 #pragma unroll
                         for (int it = 0; it < 8; ++it) {  // written once, never re-read here: keep the operand panels in L2
                             char* ub = (char*)((float*)out + (size_t)(tbase + it * 4) * ldo + nbase + ih * 64);
-                            __builtin_nontemporal_store(f32x4{o[it].x, o[it].y, o[it].z, o[it].w}, (f32x4*)(ub + voff));
+                            amx::nt_store(f32x4{o[it].x, o[it].y, o[it].z, o[it].w}, (f32x4*)(ub + voff));
                         }
                     }
                     else {

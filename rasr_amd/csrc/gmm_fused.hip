@@ -368,16 +368,16 @@ __global__ __launch_bounds__(NW * 64) void gmm_fused_kernel(const float* __restr
             if (wide_ok && m0 + 16 <= n_mix) {
                 typedef float    nt_f4 __attribute__((ext_vector_type(4)));
                 typedef unsigned nt_u4 __attribute__((ext_vector_type(4)));
-                __builtin_nontemporal_store(nt_f4{so[0], so[1], so[2], so[3]}, (nt_f4*)gs);
-                __builtin_nontemporal_store(nt_f4{so[4], so[5], so[6], so[7]}, (nt_f4*)(gs + 4));
+                amx::nt_store(nt_f4{so[0], so[1], so[2], so[3]}, (nt_f4*)gs);
+                amx::nt_store(nt_f4{so[4], so[5], so[6], so[7]}, (nt_f4*)(gs + 4));
                 if (BEST == 1) {
-                    __builtin_nontemporal_store(nt_u4{bo[0], bo[1], bo[2], bo[3]}, (nt_u4*)gb);
-                    __builtin_nontemporal_store(nt_u4{bo[4], bo[5], bo[6], bo[7]}, (nt_u4*)(gb + 4));
+                    amx::nt_store(nt_u4{bo[0], bo[1], bo[2], bo[3]}, (nt_u4*)gb);
+                    amx::nt_store(nt_u4{bo[4], bo[5], bo[6], bo[7]}, (nt_u4*)(gb + 4));
                 }
                 if (BEST == 2) {
                     typedef unsigned nt_u2 __attribute__((ext_vector_type(2)));
                     // (plain stores, left to the L2 to merge into lines, measured the same: 4.59-4.63 against 4.58-4.62 ms)
-                    __builtin_nontemporal_store(nt_u2{b8[0], b8[1]}, (nt_u2*)gb8);
+                    amx::nt_store(nt_u2{b8[0], b8[1]}, (nt_u2*)gb8);
                 }
             }
             else {
@@ -692,11 +692,11 @@ __global__ __launch_bounds__((4 + NE) * 64) void gmm_fused_spec_kernel(const flo
             if (wide_ok && m0 + 16 <= n_mix) {
                 typedef float    nt_f4 __attribute__((ext_vector_type(4)));
                 typedef unsigned nt_u4 __attribute__((ext_vector_type(4)));
-                __builtin_nontemporal_store(nt_f4{so[0], so[1], so[2], so[3]}, (nt_f4*)gs);
-                __builtin_nontemporal_store(nt_f4{so[4], so[5], so[6], so[7]}, (nt_f4*)(gs + 4));
+                amx::nt_store(nt_f4{so[0], so[1], so[2], so[3]}, (nt_f4*)gs);
+                amx::nt_store(nt_f4{so[4], so[5], so[6], so[7]}, (nt_f4*)(gs + 4));
                 if (BEST) {
-                    __builtin_nontemporal_store(nt_u4{bo[0], bo[1], bo[2], bo[3]}, (nt_u4*)gb);
-                    __builtin_nontemporal_store(nt_u4{bo[4], bo[5], bo[6], bo[7]}, (nt_u4*)(gb + 4));
+                    amx::nt_store(nt_u4{bo[0], bo[1], bo[2], bo[3]}, (nt_u4*)gb);
+                    amx::nt_store(nt_u4{bo[4], bo[5], bo[6], bo[7]}, (nt_u4*)(gb + 4));
                 }
             }
             else {

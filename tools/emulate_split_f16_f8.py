@@ -132,7 +132,13 @@ def forward(Ws, bs, acts, logp, x, scheme):
             xh, xqh, xql = split(y, scheme.get("hi"), scheme.get("lo"), scheme.get("x_scaling", "block"), scheme.get("tie_lo", False), scheme.get("pair", False))
             z = xh @ wh.T
             if scheme["kind"] == "f16x":
-                z = z + (xqh @ wql.T + xql @ wqh.T)
+                cross = scheme.get("cross", "both")   # round 6: "w" = q(x) r(w) only (the weights' residual), "x" = r(x) q(w) only
+                if cross == "both":
+                    z = z + (xqh @ wql.T + xql @ wqh.T)
+                elif cross == "w":
+                    z = z + xqh @ wql.T
+                else:
+                    z = z + xql @ wqh.T
         z = z + bs[l][None, :]
         if l < n - 1:
             y = np.maximum(z, 0.0).astype(np.float32) if acts[l] == 1 else z
@@ -164,12 +170,75 @@ def report(name, got, want, fp32=None):
     return r
 
 
+ONE_SIDED = [   # (name, nominal matrix units per f32 product, scheme)
+    ("f16 alone", 1.0, dict(kind="f16")),
+    ("f16 + q(x) r(w): the WEIGHTS' residual only (one 64-deep fp6 product per 64 k)", 1.25,
+     dict(kind="f16x", hi="e2m3", lo="e2m3", w_scaling="block", tie_lo=True, tie_w=True, pair_w=True, cross="w")),
+    ("f16 + r(x) q(w): the ACTIVATIONS' residual only", 1.25,
+     dict(kind="f16x", hi="e2m3", lo="e2m3", w_scaling="block", tie_lo=True, tie_w=True, pair_w=True, cross="x")),
+    ("f16 + both cross terms (AMX_PREC_F16MX as built)", 1.5,
+     dict(kind="f16x", hi="e2m3", lo="e2m3", w_scaling="block", tie_lo=True, tie_w=True, pair_w=True)),
+    ("bf16x3", 3.0, dict(kind="bf16x3")),
+]
+
+
+def families(a):
+    """round-5 review, item 6: is there a scheme under 1.5 nominal units that meets 1e-4 PURE relative (over |ref| > 1e-2) and the
+    1e-4 |ref| + 1e-4 bar on every operand family?  One cross term instead of two halves the scaled products (a 32x32x64 fp6 product
+    then covers 64 k of ONE term): 1.25 units.  The gate is evaluated here, before any kernel."""
+    from oracle import oracle_ffnn_score
+    from tests.ffnn_families import FAMILIES, make
+    table = {}
+    cases = [(f, make(f, [440, 768, 768, 1500], 384, 300 + len(f))) for f in FAMILIES]
+    dims = [440] + [2048] * 6 + [10000]
+    Ws, bs, acts, logp = synth.ffnn(dims, seed=7)
+    x = np.random.Generator(np.random.PCG64(6)).standard_normal((256, 440)).astype(np.float32)
+    cases.append(("config 4 (440-6x2048-10000, 256 frames)", (Ws, bs, acts, logp, x)))
+    for fam, (Ws, bs, acts, logp, x) in cases:
+        want = oracle_ffnn_score(Ws, bs, acts, x, log_prior=logp, prior_scale=1.0, acc64=True).astype(np.float64)
+        f32 = oracle_ffnn_score(Ws, bs, acts, x, log_prior=logp, prior_scale=1.0, acc64=False)
+        e32 = np.abs(f32.astype(np.float64) - want)
+        big = np.abs(want) > 1e-2
+        row = {"f32 accumulation (the reference's own arithmetic)": dict(units=None, worst_over_bar=float((e32 / (1e-4 * np.abs(want) + 1e-4)).max()),
+                                                                         worst_pure_relative=float((e32[big] / np.abs(want[big])).max()) if big.any() else 0.0,
+                                                                         argmin_mismatches=int((f32.argmin(axis=1) != want.argmin(axis=1)).sum()))}
+        for name, units, sch in ONE_SIDED:
+            got = forward(Ws, bs, acts, logp, x, sch)
+            err = np.abs(got.astype(np.float64) - want)
+            big = np.abs(want) > 1e-2
+            row[name] = dict(units=units, worst_over_bar=float((err / (1e-4 * np.abs(want) + 1e-4)).max()),
+                             worst_pure_relative=float((err[big] / np.abs(want[big])).max()) if big.any() else 0.0,
+                             argmin_mismatches=int((got.argmin(axis=1) != want.argmin(axis=1)).sum()))
+        table[fam] = row
+        print(fam)
+        for k, v in row.items():
+            print("    %-86s units %-5s worst/bar %8.3g  pure rel %8.3g" % (k[:86], v["units"], v["worst_over_bar"], v.get("worst_pure_relative", float("nan"))))
+    # the gate is asked where it CAN be met: on the families whose scores f32 accumulation itself -- the reference's sgemm -- keeps inside
+    # both bars (the others are ill-conditioned: a score there is a difference of terms 10^3 .. 10^5 times its size)
+    F32 = "f32 accumulation (the reference's own arithmetic)"
+    fair = [f for f in table if table[f][F32]["worst_over_bar"] <= 1.0 and table[f][F32]["worst_pure_relative"] <= 1e-4]
+    gate = {"families_where_f32_accumulation_meets_both_bars": fair}
+    for name, units, _ in ONE_SIDED:
+        fams_ok = [f for f in fair if table[f][name]["worst_over_bar"] <= 1.0 and table[f][name]["worst_pure_relative"] <= 1e-4]
+        gate[name] = dict(units=units, fair_families_meeting_both_bars=len(fams_ok), of=len(fair), failing=[f for f in fair if f not in fams_ok],
+                          worst_over_bar_on_fair_families=max(table[f][name]["worst_over_bar"] for f in fair))
+    print(json.dumps(gate, indent=1))
+    if a.out:
+        os.makedirs(os.path.dirname(a.out), exist_ok=True)
+        json.dump(dict(question="a precision mode under 1.5 nominal matrix units per product that meets 1e-4 pure relative and the 1e-4 |ref| + 1e-4 bar on the ten "
+                                "operand families (round-5 review, next #6)", gate=gate, table=table), open(a.out, "w"), indent=1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=None)
     ap.add_argument("--frames", type=int, default=1024)
     ap.add_argument("--only", default=None, help="substring filter on the scheme names")
+    ap.add_argument("--families", action="store_true", help="round 6: the ONE-SIDED corrections (1.25 nominal units per product) against the built scheme "
+                                                            "on the ten operand families of tests/ffnn_families.py and on config 4")
     a = ap.parse_args()
+    if a.families:
+        return families(a)
     from oracle import oracle_ffnn_score
     dims = [440] + [2048] * 6 + [10000]
     Ws, bs, acts, logp = synth.ffnn(dims, seed=7)
