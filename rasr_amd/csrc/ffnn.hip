@@ -257,25 +257,30 @@ struct GemmLd {
 constexpr int BK      = 64;   // k per stage: one 128-byte LDS row per matrix row
 constexpr int PAD_NT  = 256;  // N and T are padded to this (largest tile edge)
 
-template<int BN_, int BT_, int WN_, int WT_, int STAGES_, int BK_ = 64, bool X3_ = false>
+template<int BN_, int BT_, int WN_, int WT_, int STAGES_, int BK_ = 64, bool X3_ = false, int LW_ = 0>
 struct GemmCfg {
     static constexpr int BN = BN_, BT = BT_, WN = WN_, WT = WT_, STAGES = STAGES_, BKC = BK_;
+    // LW > 0 (round 6, gemm_bf16_kernel, hidden layers of small batches): LW extra LOADER waves issue every LDS-DMA piece and nothing
+    // else; the NW computing waves never touch the address unit (six pieces of ~70 cycles per K-tile and wave stood in front of the
+    // products of a 128 x 64 tile, one wave per SIMD and nothing to overlap them with -- gemm_mx_kernel's MxCfg::LW)
+    static constexpr int LW = LW_;
     // X3: split-bf16 tiles.  Every operand tile is staged as TWO planes (hi = bf16(v), lo = bf16(v - hi)), the hi plane first,
     // and a k-slab issues the three products hi.hi, lo.hi, hi.lo from ONE set of fragment reads (4 planes per 3 products).
     static constexpr bool X3     = X3_;
     static constexpr int  PLANES = X3 ? 2 : 1;
-    static constexpr int NW = WN * WT, THREADS = NW * 64;
+    static constexpr int NW = WN * WT, THREADS = (NW + LW_) * 64;
+    static constexpr int IW = LW_ > 0 ? LW_ : NW;           // waves that issue the LDS-DMA
     static constexpr int ROW_BYTES = BKC * 2;               // one LDS row per matrix row: 128 B (BK 64) or 64 B (BK 32)
     static constexpr int ROWS_PER_LOAD = 1024 / ROW_BYTES;  // rows covered by one wave-wide 16-byte global_load_lds
     static constexpr int CHUNKS = ROW_BYTES / 16;
     static constexpr int A_PLANE = BN * ROW_BYTES, B_PLANE = BT * ROW_BYTES;
     static constexpr int A_BYTES = PLANES * A_PLANE, B_BYTES = PLANES * B_PLANE, STAGE_BYTES = A_BYTES + B_BYTES;
     static constexpr int LDS_BYTES = STAGES * STAGE_BYTES;
-    static constexpr int A_LOADS = A_BYTES / 1024 / NW, B_LOADS = B_BYTES / 1024 / NW, LOADS = A_LOADS + B_LOADS;
+    static constexpr int A_LOADS = A_BYTES / 1024 / IW, B_LOADS = B_BYTES / 1024 / IW, LOADS = A_LOADS + B_LOADS;
     static constexpr int MI = BN / WN / 32, MJ = BT / WT / 32;  // 32x32 tiles per wave
     static_assert(BKC == 64 || BKC == 32, "BK must be 32 or 64");
     static_assert(!X3 || BKC == 32, "split-bf16 tiles are 32 k wide (four planes per stage)");
-    static_assert(BN % (ROWS_PER_LOAD * NW) == 0 && BT % (ROWS_PER_LOAD * NW) == 0, "staging needs whole row groups per wave");
+    static_assert(BN % (ROWS_PER_LOAD * IW) == 0 && BT % (ROWS_PER_LOAD * IW) == 0, "staging needs whole row groups per wave");
     static_assert(BN % (WN * 32) == 0 && BT % (WT * 32) == 0, "wave tile must be a multiple of 32x32");
     // XOR swizzle of the 16-byte chunks of a row so that ds_read_b128 of a 32-row MFMA fragment is conflict free:
     // 128-byte rows: chunk ^ ((row>>1)&7); 64-byte rows: chunk ^ ((row>>2)&3)
@@ -545,32 +550,38 @@ __global__ __launch_bounds__(C::THREADS) void gemm_bf16_kernel(const bf16_t* __r
     // ---- staging: one global_load_lds moves 8 rows x 128 B per wave.  LDS linear position of this
     // lane's 16 B for instruction i: pos = (i*NW + wave)*1024 + lane*16 -> row = pos/128, physical
     // chunk = (pos%128)/16; it must hold logical chunk = phys ^ ((row>>1)&7) of that row.
+    constexpr bool HAS_LW = C::LW > 0;
+    const bool     loader = HAS_LW && wave >= C::NW;                 // issues the LDS-DMA, takes part in the barriers, computes nothing
+    const bool     issuer = !HAS_LW || loader;
+    const int      iwave  = HAS_LW ? (loader ? wave - C::NW : 0) : wave;  // index among the issuing waves
     const bf16_t* gW[C::A_LOADS];
     const bf16_t* gX[C::B_LOADS];
 #pragma unroll
     for (int i = 0; i < C::A_LOADS; ++i) {
-        const int pos = (i * C::NW + wave) * 1024 + lane * 16;
+        const int pos = (i * C::IW + iwave) * 1024 + lane * 16;
         const int plane = pos / C::A_PLANE, rpos = pos % C::A_PLANE;  // split bf16: hi plane, then lo plane
         const int row = rpos / C::ROW_BYTES, phys = (rpos % C::ROW_BYTES) >> 4;
         gW[i]         = W + (size_t)(n0 + row) * ld.ldw + plane * ld.wlo + (phys ^ C::xor_term(row)) * 8;
     }
 #pragma unroll
     for (int i = 0; i < C::B_LOADS; ++i) {
-        const int pos = (i * C::NW + wave) * 1024 + lane * 16;
+        const int pos = (i * C::IW + iwave) * 1024 + lane * 16;
         const int plane = pos / C::B_PLANE, rpos = pos % C::B_PLANE;
         const int row = rpos / C::ROW_BYTES, phys = (rpos % C::ROW_BYTES) >> 4;
         gX[i]         = X + (size_t)(t0 + row) * ldx + plane * ld.xlo + (phys ^ C::xor_term(row)) * 8;
     }
     auto stage = [&](int slot, int kt) {
+        if (!issuer)
+            return;
         char* base = lds + slot * C::STAGE_BYTES;
 #pragma unroll
         for (int i = 0; i < C::A_LOADS; ++i)
             __builtin_amdgcn_global_load_lds((const void*)(gW[i] + (size_t)kt * C::BKC),
-                                             (__attribute__((address_space(3))) void*)(base + (i * C::NW + wave) * 1024), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(base + (i * C::IW + iwave) * 1024), 16, 0, 0);
 #pragma unroll
         for (int i = 0; i < C::B_LOADS; ++i)
             __builtin_amdgcn_global_load_lds((const void*)(gX[i] + (size_t)kt * C::BKC),
-                                             (__attribute__((address_space(3))) void*)(base + C::A_BYTES + (i * C::NW + wave) * 1024), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(base + C::A_BYTES + (i * C::IW + iwave) * 1024), 16, 0, 0);
     };
 
     f32x16 acc[C::MI][C::MJ];
@@ -603,7 +614,9 @@ __global__ __launch_bounds__(C::THREADS) void gemm_bf16_kernel(const bf16_t* __r
         // tiles kt .. min(kt+STAGES-2, KT-1) are outstanding; keep all but tile kt in flight
         const int ahead = min(C::STAGES - 2, KT - 1 - kt);
         static_assert(C::STAGES <= 6 && 4 * C::LOADS < 64, "vmcnt immediate");
-        if (C::STAGES >= 6 && ahead == 4)
+        if (!issuer)
+            ;  // a computing wave beside loader waves has no vector-memory operation in flight inside the loop
+        else if (C::STAGES >= 6 && ahead == 4)
             wait_vmcnt<4 * C::LOADS>();
         else if (C::STAGES >= 5 && ahead == 3)
             wait_vmcnt<3 * C::LOADS>();
@@ -616,10 +629,46 @@ __global__ __launch_bounds__(C::THREADS) void gemm_bf16_kernel(const bf16_t* __r
         __builtin_amdgcn_s_barrier();
         const bool more  = kt + C::STAGES - 1 < KT;
         const int  nslot = (kt + C::STAGES - 1) % C::STAGES;
-        if (more && !((VAR & 16) && kt > 0))  // VAR & 16: ablation, no operand loads after the first K-tile
-            stage(nslot, kt + C::STAGES - 1);
         const char* wbase = lds + (kt % C::STAGES) * C::STAGE_BYTES;
         const char* xbase = wbase + C::A_BYTES;
+        // Small tiles (128 x 64, plain bf16; round 6): ALL fragment reads of the K-tile go out as one burst in front of the refill's
+        // LDS-DMA pieces and of the first product -- the loop below pays the LDS round trip once per 16-k slab (four times per
+        // K-tile) and the pieces' issue time (six per wave, ~70 cycles each) in front of the first read, one wave per SIMD and nothing
+        // to overlap either with (the lesson of gemm_mx_kernel's one-tile-per-CU loop).  Same products, same
+        // order per accumulator: bit-identical.
+        constexpr bool BURST = C::BN == 128 && C::BT == 64 && !C::X3 && (VAR & (8 | 64)) == 0;
+        if constexpr (BURST) {
+            constexpr int KS = C::BKC / 16;
+            if (loader) {   // (only configurations with loader waves take this path with them: static_assert below)
+                if (more && !((VAR & 16) && kt > 0))
+                    stage(nslot, kt + C::STAGES - 1);
+                continue;
+            }
+            bf16x8 a[KS][C::MI], b[KS][C::MJ];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+                for (int i = 0; i < C::MI; ++i)
+                    a[ks][i] = *(const bf16x8*)(wbase + C::swz(wn * (C::BN / C::WN) + i * 32 + frow, ks * 2 + fk));
+#pragma unroll
+                for (int j = 0; j < C::MJ; ++j)
+                    b[ks][j] = *(const bf16x8*)(xbase + C::swz(wt * (C::BT / C::WT) + j * 32 + frow, ks * 2 + fk));
+            }
+            if (more && !((VAR & 16) && kt > 0))
+                stage(nslot, kt + C::STAGES - 1);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int i = 0; i < C::MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < C::MJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][i], b[ks][j], acc[i][j], 0, 0, 0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            continue;
+        }
+        static_assert(!HAS_LW || BURST, "loader waves: the small plain-bf16 tile only");
+        if (more && !((VAR & 16) && kt > 0))  // VAR & 16: ablation, no operand loads after the first K-tile
+            stage(nslot, kt + C::STAGES - 1);
         if (VAR & 64) {
             // ablation: operand streaming only (no fragment reads, no MFMA)
         }
@@ -693,6 +742,10 @@ __global__ __launch_bounds__(C::THREADS) void gemm_bf16_kernel(const bf16_t* __r
     }
     else if (VAR & 256)
         gemm_epilogue<C, ACT, LAST, true>(acc, lds, s_bias, out, ldo, ld.olo, n_valid, t_valid, n0, t0, tile_n, wn, wt, lane, tid, part_min, part_idx, part_ld);
+    else if (HAS_LW && loader) {
+        static_assert(!(HAS_LW && LAST), "loader waves: hidden layers only (the score epilogue's second barrier and its arg-min exchange count NW waves)");
+        __syncthreads();  // the epilogue's first barrier: every wave is done with the last K-tile
+    }
     else
         gemm_epilogue<C, ACT, LAST>(acc, lds, s_bias, out, ldo, ld.olo, n_valid, t_valid, n0, t0, tile_n, wn, wt, lane, tid, part_min, part_idx, part_ld);
     __syncthreads();  // LDS (stages / arg-min scratch) is reused by the next tile
@@ -1519,6 +1572,7 @@ int ensure_workspace(amx_ffnn* h, int Tpad) {
 using CfgA = amx::GemmCfg<128, 128, 2, 2, 2>;  //  64 KB LDS, 2 workgroups per CU
 using CfgC = amx::GemmCfg<256, 256, 2, 4, 2>;  // 128 KB LDS, 8 waves, wave tile 128x64
 using CfgS = amx::GemmCfg<128, 64, 2, 2, 2>;   //  48 KB LDS, 3 workgroups per CU: small batches (fills the CUs)
+using CfgS3L = amx::GemmCfg<128, 64, 2, 2, 3, 64, false, 4>;  // round 6: CfgS3 + four loader waves (hidden layers; opt-in tile=11: no gain measured)
 using CfgS3 = amx::GemmCfg<128, 64, 2, 2, 3>;  //  72 KB LDS, two K-tiles in flight: layers with about one tile per CU (batch 1024 hidden layers: 19 -> 15.5 us)
 // measured and dropped: GemmCfg<256,256,2,4,4,32> (4 stages of BK=32, three K-tiles in flight): 800 TF
 // measured and dropped: 256x128x64 3-stage (753 TF), 256x256 with 64x128 wave tiles (973 TF) vs CfgC (1000 TF), CfgA (870 TF)
@@ -1637,6 +1691,13 @@ void launch_bf16_cfg(amx_ffnn* h, int l, const void* x, int ldx, void* out, int 
         case 4: launch_bf16<CfgC, ACT, LAST>(h, l, x, ldx, out, ldo, T, Tpad); break;  // previous large-batch kernel (A/B runs)
         case 3: launch_bf16<CfgS, ACT, LAST>(h, l, x, ldx, out, ldo, T, Tpad); break;
         case 6: launch_bf16<CfgS3, ACT, LAST>(h, l, x, ldx, out, ldo, T, Tpad); break;
+        case 11:   // round 6, A/B runs: CfgS3 with four loader waves for the hidden layers -- bit-identical, and measured NO gain (17.4 against
+                   // 17.0 us per 2048 x 2048 layer at batch 1024): the tile is bound by the LDS time of its fragment reads (48 KB per K-tile)
+            if constexpr (LAST)
+                launch_bf16<CfgS3, ACT, LAST>(h, l, x, ldx, out, ldo, T, Tpad);
+            else
+                launch_bf16<CfgS3L, ACT, LAST>(h, l, x, ldx, out, ldo, T, Tpad);
+            break;
         default: launch_bf16<CfgA, ACT, LAST>(h, l, x, ldx, out, ldo, T, Tpad); break;
     }
 }

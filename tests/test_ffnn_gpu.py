@@ -133,7 +133,7 @@ def test_tile_configurations_agree(ctx, monkeypatch, n_out):
     xd = torch.from_numpy(x).cuda()
     ctx.use_torch_stream()
     results = {}
-    for cfg in ("0", "3", "6", "4", "2"):
+    for cfg in ("0", "3", "6", "4", "2", "11"):   # 11: tile 6 with loader waves for the hidden layers (round 6, opt-in)
         nn = rasr_amd.NnBatchFeatureScorer(ctx, Ws, bs, acts, log_prior=logp, precision="bf16", tuning="tile=" + cfg)
         sc = torch.full((8200, n_out), float("nan"), dtype=torch.float32, device="cuda")
         best = torch.zeros(8200, dtype=torch.int32, device="cuda")
@@ -149,7 +149,7 @@ def test_tile_configurations_agree(ctx, monkeypatch, n_out):
     assert np.isfinite(ref[0]).all()
     assert np.array_equal(ref[1], ref[0].argmin(axis=1))
     assert np.array_equal(ref[2], 2 * np.bincount(ref[1], minlength=n_out))
-    for cfg in ("3", "6", "4", "2"):
+    for cfg in ("3", "6", "4", "2", "11"):
         got = results[cfg]
         assert np.array_equal(got[0].view(np.uint32), ref[0].view(np.uint32)), cfg
         assert np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2]), cfg
