@@ -47,6 +47,10 @@ for w in range(8):
     a = st[w, lo:hi]
     nxt = st[w, lo + 1:hi + 1, 0]
     per = np.diff(st[w, lo:hi + 1, 0]).mean()
+    if (a[:, 2] == 0).all():   # a loop without the "fragments in registers" stamp (the read-ahead loop: reads ride between the products)
+        print("%4d  %6.1f   %15.1f  %13s  %15.1f  %22.1f   %d   (refill -> products: reads and products interleaved)"
+              % (w, per, (a[:, 1] - a[:, 0]).mean(), "-", (a[:, 3] - a[:, 1]).mean(), (nxt - a[:, 3]).mean(), st[w, lo, 0] - t0))
+        continue
     print("%4d  %6.1f   %15.1f  %13.1f  %15.1f  %22.1f   %d" % (w, per, (a[:, 1] - a[:, 0]).mean(), (a[:, 2] - a[:, 1]).mean(),
                                                                (a[:, 3] - a[:, 2]).mean(), (nxt - a[:, 3]).mean(), st[w, lo, 0] - t0))
 
