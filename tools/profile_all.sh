@@ -61,11 +61,11 @@ run_stats nn-pipeline-fp32 --workload nn-pipeline --precision fp32 --steps 3 --w
 run_stats gmm-train --workload gmm-train --steps 5 --warmup 2 --no-cpu-baseline
 run_stats gmm-trained --workload gmm-trained --steps 5 --warmup 2 --no-cpu-baseline
 run_stats mfcc --workload mfcc --steps 20 --warmup 2 --no-cpu-baseline
-run_stats gmm --workload gmm --steps 50 --warmup 5 --no-cpu-baseline
-run_stats gmm-tied --workload gmm-tied --steps 20 --warmup 3
-run_stats nn --workload nn --steps 50 --warmup 5 --no-cpu-baseline
-run_stats nn-bf16x3 --workload nn --precision bf16x3 --steps 50 --warmup 5 --no-cpu-baseline
-run_stats nn-bf16 --workload nn --precision bf16 --steps 50 --warmup 5 --no-cpu-baseline
+run_stats gmm --workload gmm --steps 400 --warmup 200 --no-cpu-baseline
+run_stats gmm-tied --workload gmm-tied --steps 200 --warmup 100
+run_stats nn --workload nn --steps 400 --warmup 200 --no-cpu-baseline
+run_stats nn-bf16x3 --workload nn --precision bf16x3 --steps 400 --warmup 200 --no-cpu-baseline
+run_stats nn-bf16 --workload nn --precision bf16 --steps 400 --warmup 200 --no-cpu-baseline
 run_stats mfcc-plp --workload mfcc --front-end plp --steps 8 --warmup 2 --no-cpu-baseline
 run_stats mfcc-mfplp --workload mfcc --front-end mfplp --steps 8 --warmup 2 --no-cpu-baseline
 run_stats mfcc-gammatone --workload mfcc --front-end gammatone --steps 3 --warmup 1 --no-cpu-baseline
