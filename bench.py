@@ -874,13 +874,13 @@ class GmmOnly:
                 # rows per frame for the bounds (whole rows of the bf16 image) and one 256-byte row per surviving (density, frame, tile)
                 # triple, mostly L2 hits -- are reported next to it as l2_rows_GBps.
                 launches = triples / float(4096 * self.T * 157) if self.T else 1.0
-                rows = (self.T * 32.0 * 10048 * 2 + (surv / max(launches, 1.0)) * 256.0 + self.T * 10000 * 8.0 + self.T * 4096 * 12.0)
+                rows = (self.T * 64.0 * 10048 * 2 + (surv / max(launches, 1.0)) * 256.0 + self.T * 10000 * 8.0 + self.T * 4096 * 12.0)
                 by = self.nk * 4.0 + self.T * 10000 * 8.0 + self.T * 40 * 4.0
                 ms_d, n_d = self.ctx.profile_get("gmm_dist")     # the distance kernel the `kernel` string names belongs to the time
                 ms_combine, ms = ms, ms + (ms_d if n_d else 0.0)
                 gbs = by / (ms * 1e-3) / 1e9
                 return dict(bound="hbm", kernel="tied_pruned_kernel + tied_bound_kernel + gmm_dist_kernel (+ tied_mask / tied_transpose / tied_list / tied_near)",
-                            note="exact pruning: bounds from 32 near densities per frame, then the reference's f64 rule over the surviving "
+                            note="exact pruning: bounds from 64 near densities per frame, then the reference's f64 rule over the surviving "
                                  "(density, frame, 64-mixture tile) triples only; algorithmic bytes = weight table once per batch + results",
                             achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4), traffic=None,
                             avg_launch_ms=round(ms, 4), launches=n, bytes_per_launch=by,

@@ -8,7 +8,7 @@
 //
 //   a^[k][m]     = fl32(m2lw[k][m] + logNorm[k])             (model; the bound kernel reads a bf16 image rounded up, [K][mix_pad])
 //   amin[j][k]   = min over the mixtures of tile j of a^[k][m] (model, [n_tiles][Kpad]);  aminG[k] = min over all tiles
-//   U[t][m]      = min over 32 densities NEAR frame t (the closest density of each residue class k mod 32) of
+//   U[t][m]      = min over 64 densities NEAR frame t (the closest density of each residue class k mod 64; 32 until round 6) of
 //                  s^_k = fl32(a^[k][m] + dist[k][t])         -- an upper bound of min_k s^_k, because it is a minimum over a subset
 //
 // Candidates -- the densities that can influence (best, idx), i.e. those whose f64 sum rounds to the winning f32 value, see
@@ -53,7 +53,12 @@ namespace amx {
 __device__ unsigned long long g_tied_hist[64];  // [0..31] candidates per (lane, wave); [32..63] survivors / 8 per wave
 #endif
 
-constexpr int kTiedNear     = 32;   // near densities per frame = residue classes of the density index
+#ifndef AMX_TIED_NEAR
+#define AMX_TIED_NEAR 64  // round 6 (profiles/r06/tied_ab.log): 32 until then.  Tighter bounds U leave 1.33 % instead of 1.59 % of the (density, frame,
+                          // tile) triples to the pruned scorer -- 74 -> 48 us -- for twice the bound kernel's row reads (17 -> 31 us): 0.140 -> 0.127 ms
+                          // per 256 frames; 16: 0.240 ms; 128: see the log.  Measurement builds: -DAMX_TIED_NEAR=16 | 32 | 128
+#endif
+constexpr int kTiedNear     = AMX_TIED_NEAR;   // near densities per frame = residue classes of the density index
 constexpr int kTiedCounters = 256;  // survivor counters (summed by the host)
 
 // dist [n_dens][Tpad] (coalesced along frames) -> dt [T][Kpad] (coalesced along the density list); 64 x 64 tiles through LDS
@@ -80,6 +85,7 @@ __global__ __launch_bounds__(256) void tied_transpose_kernel(const float* __rest
 // The frame's closest density of every residue class k mod 32, for tied_bound_kernel (any subset gives a valid bound; this one needs
 // no selection).  One workgroup per frame; nd / nk [T][32].
 constexpr int kTiedNearThreads = 1024;
+static_assert(kTiedNearThreads % kTiedNear == 0 && kTiedNear >= 8 && kTiedNear <= 128, "a thread of tied_near_kernel stays inside one residue class");
 
 __global__ __launch_bounds__(kTiedNearThreads) void tied_near_kernel(const float* __restrict__ g_dt, int K, int Kpad, float* __restrict__ g_nd,
                                                                     uint32_t* __restrict__ g_nk) {
