@@ -1561,7 +1561,9 @@ struct amx_gmm {
     void*               d_tied_ws    = nullptr;
     size_t              tied_ws_cap  = 0;
     unsigned long long* d_tied_surv  = nullptr;  // [256] survivors (density, frame, tile) of the calls so far, spread over 256 counters; [256] = triples examined
-    unsigned long long* h_tied_surv  = nullptr;  // pinned host copy, refreshed asynchronously after every pruned call
+    unsigned long long* h_tied_surv  = nullptr;  // pinned host copy, refreshed asynchronously after every 8th pruned call (tied_publish)
+    unsigned            tied_copy_tick = 0;      // pruned calls since the handle was made
+    bool                tied_capturing = false;  // the pruned launches are being recorded: the copy stays outside the graph
     unsigned long long  tied_seen    = 0;        // survivors / examined triples in the host copy at the previous decision
     unsigned long long  tied_triples = 0;
     int                 tied_dense_calls = 0;    // > 0: stay on gmm_tied_tile_kernel for that many calls, then probe again
@@ -2370,6 +2372,15 @@ static int ensure_simd(amx_gmm* h) {
 // dense or pruned for this call of a shared-list tied model: amx_gmm_model.tuning tied_prune=0 forces the dense kernel, =1 the pruned path,
 // default adaptive -- the pruned kernel counts the (density, frame, tile) triples it had to evaluate, the host reads the count of
 // EARLIER calls from pinned memory (no synchronisation) and stays on the dense kernel for 64 calls while more than 10 % stood
+// The 2 KB copy costs 4 us of stream time, a thirtieth of a decoder-sized pruned pass, and the decision below looks at windows of
+// many calls: every 8th pruned call publishes the counters (issued after the graph replay, never recorded in it).
+static int tied_publish(amx_gmm* h) {
+    if ((++h->tied_copy_tick & 7u) != 0)
+        return AMX_OK;
+    AMX_HIP(hipMemcpyAsync(h->h_tied_surv, h->d_tied_surv, 257 * 8, hipMemcpyDeviceToHost, h->ctx->stream));
+    return AMX_OK;
+}
+
 static bool tied_decide_prune(amx_gmm* h) {
     const int forced = h->tune_tied_prune;
     if (forced >= 0)
@@ -2546,7 +2557,7 @@ int amx_gmm_score_dev(amx_gmm* h, int mode, const float* feats_dev, int T, float
     }
     // ---- tied: chunk frames so the distance scratch stays <= 256 MB
     const int chunk_max = (int)std::max<size_t>(256, std::min<size_t>(16384, ((size_t)64 << 20) / (size_t)h->n_dens / 256 * 256));
-    // The pruned path of a shared-list model is six launches and a 2 KB copy: at the decoder's batch sizes their gaps are a seventh
+    // The pruned path of a shared-list model is six launches (and, every 8th call, a 2 KB copy): at the decoder's batch sizes their gaps are a seventh
     // of the pass, so repeated passes on unchanged buffers are replayed as one HIP graph like the screened CART path above (the
     // dense / pruned decision stays outside: a graph is only recorded and replayed for the pruned path).
     if (h->uniform && mode == AMX_GMM_MAX && h->tied_forced < 0 && T <= chunk_max && T <= 4096 && h->tune_screen) {
@@ -2580,7 +2591,9 @@ int amx_gmm_score_dev(amx_gmm* h, int mode, const float* feats_dev, int T, float
                 h->use_graphs = 0;
                 return nested(1);
             }
-            const int      r  = nested(1);
+            h->tied_capturing = true;
+            const int r       = nested(1);
+            h->tied_capturing = false;
             const bool     ok = hipStreamEndCapture(h->ctx->stream, &gr) == hipSuccess && r == AMX_OK && gr != nullptr;
             hipGraphExec_t ex = nullptr;
             if (!ok || hipGraphInstantiate(&ex, gr, nullptr, nullptr, 0) != hipSuccess) {
@@ -2598,7 +2611,7 @@ int amx_gmm_score_dev(amx_gmm* h, int mode, const float* feats_dev, int T, float
             h->tied_rep_triples += (unsigned long long)h->K * (unsigned long long)T * (unsigned long long)(h->mix_pad / 64);
         }
         AMX_HIP(hipGraphLaunch(it->second, h->ctx->stream));
-        return AMX_OK;
+        return tied_publish(h);
     }
     for (int t0 = 0; t0 < T; t0 += chunk_max) {
         const int Tc   = std::min(chunk_max, T - t0);
@@ -2685,7 +2698,8 @@ int amx_gmm_score_dev(amx_gmm* h, int mode, const float* feats_dev, int T, float
                                                         h->d_tied_surv, dt != nullptr);
                     if (r != AMX_OK)
                         return r;
-                    AMX_HIP(hipMemcpyAsync(h->h_tied_surv, h->d_tied_surv, 257 * 8, hipMemcpyDeviceToHost, h->ctx->stream));
+                    if (!h->tied_capturing && (r = tied_publish(h)) != AMX_OK)
+                        return r;
                     h->tied_rep_triples += (unsigned long long)h->K * (unsigned long long)Tc * (unsigned long long)(h->mix_pad / 64);
                 }
                 else

@@ -126,9 +126,15 @@ __global__ __launch_bounds__(kTiedNearThreads) void tied_near_kernel(const float
 // costs the wave one load, two unpacks, two sums and two minima for 128 mixtures.  64 mixtures = one tile = 32 lanes.
 __global__ __launch_bounds__(256) void tied_bound_kernel(const unsigned short* __restrict__ g_aup, const float* __restrict__ g_amax,
                                                         const float* __restrict__ g_nd, const uint32_t* __restrict__ g_nk, int n_mix,
-                                                        int mix_pad, int n_tiles, float* __restrict__ g_thr, float* __restrict__ g_thr_m) {
-    const int t = blockIdx.y, lane = threadIdx.x & 63;
-    const int m = 2 * (blockIdx.x * 256 + threadIdx.x);  // mix_pad is a multiple of 64: m + 1 < mix_pad with m
+                                                        int mix_pad, int n_tiles, float* __restrict__ g_thr, float* __restrict__ g_thr_m,
+                                                        int seg_per_xcd) {
+    // Workgroup b runs on XCD b % 8, and each XCD has its own L2.  A near row is wanted by ~4 of a 256-frame batch's frames, so a 1 KB
+    // segment of the table (512 mixtures) always goes to the SAME XCD, whatever the frame: segment s on XCD s % 8 (round 6; the grid is
+    // 8 x segments-per-XCD x T, one-dimensional).  The table's 82 MB are then spread over the eight L2s instead of streamed through each.
+    const int lane = threadIdx.x & 63;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int t = idx / seg_per_xcd, seg = xcd + 8 * (idx - t * seg_per_xcd);
+    const int m = 2 * (seg * 256 + threadIdx.x);  // mix_pad is a multiple of 64: m + 1 < mix_pad with m
     if (m >= mix_pad)
         return;  // whole 32-lane halves leave together (a half = one tile)
     const float*    nd = g_nd + (size_t)t * kTiedNear;
@@ -696,8 +702,9 @@ extern "C" int amx_internal_gmm_tied_score(amx_ctx* ctx, const float* dist_dev, 
             hipLaunchKernelGGL(amx::tied_transpose_kernel, dim3(Kpad / 64, (Tc + 63) / 64), dim3(256), 0, ctx->stream, dist_dev + t0, k_dens_dev,
                                K, Kpad, Tc, Tpad - t0, Tpad, w.dt);
         hipLaunchKernelGGL(amx::tied_near_kernel, dim3(Tc), dim3(amx::kTiedNearThreads), 0, ctx->stream, w.dt, K, Kpad, w.nd, w.nk);
-        hipLaunchKernelGGL(amx::tied_bound_kernel, dim3((mix_pad / 2 + 255) / 256, Tc), dim3(256), 0, ctx->stream, aup, amax, w.nd, w.nk, n_mix,
-                           mix_pad, n_tiles, w.thr, w.thr_m);
+        const int bound_spx = ((mix_pad / 2 + 255) / 256 + 7) / 8;   // 1 KB segments of a table row per XCD
+        hipLaunchKernelGGL(amx::tied_bound_kernel, dim3(8 * bound_spx * Tc), dim3(256), 0, ctx->stream, aup, amax, w.nd, w.nk, n_mix, mix_pad,
+                           n_tiles, w.thr, w.thr_m, bound_spx);
         hipLaunchKernelGGL(amx::tied_list_kernel, dim3(Tc), dim3(64 * amx::kTiedListWaves), 0, ctx->stream, w.dt, amin + (size_t)n_tiles * Kpad, w.thr, ln32, K, Kpad,
                            n_tiles, w.lk, w.ld, w.ll, w.ln, survivors_dev ? survivors_dev + amx::kTiedCounters : nullptr,
                            (unsigned long long)K * (unsigned long long)Tc * (unsigned long long)n_tiles);

@@ -1013,9 +1013,14 @@ def test_tied_pruned_adversarial_and_statistics(ctx, monkeypatch):
     from oracle import OracleGmm
     x = feats(256, 16, 78)
     osc, ob = OracleGmm(model).score(x, mode=0)
-    for _ in range(6):                                         # the statistics of the first calls arrive, later calls go dense
-        a, b = sc.score(x)
+    sc.screen_counts(True)
+    for _ in range(24):                                        # the statistics of the first calls arrive (the counters are published
+        a, b = sc.score(x)                                     # every 8th pruned call), later calls go dense
         assert np.array_equal(a.view(np.uint32), osc.view(np.uint32)) and np.array_equal(b, ob)
+    surv, triples = sc.screen_counts(True)
+    per_call = 512 * 256 * (640 // 64)
+    assert 0 < triples <= 9 * per_call and triples % per_call == 0, triples / per_call   # pruned passes only until the first report
+    assert surv > 0.5 * triples
     # equal f64 sums: the first density wins where (float)s rounded down, the LAST where it rounded up ((double)best > s again)
     assert set(np.unique(ob)) <= {0, 511}
 
