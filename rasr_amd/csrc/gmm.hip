@@ -621,6 +621,37 @@ __global__ __launch_bounds__(256) void gmm_dist_kernel(const float* __restrict__
     }
 }
 
+// The pruned scorer of a shared-list model (gmm_tied.hip) only reads the frame-major image dt[t][list position], and a decoder-sized
+// batch is ONE frame block of gmm_dist_kernel: 1024 workgroups that each stage 40 KB of frames for four densities, 20 us for 3 us of
+// arithmetic.  Here the roles are swapped -- lane = list position, the model's means / inverse deviations come from tables transposed
+// at creation ([dim][Kpad], coalesced, 2 x DIM registers per lane for the wave's whole life), the frame is wave-uniform and arrives
+// through the scalar cache, and the row dt[t][k0 .. k0 + 63] leaves as one 256-byte store.  Same operation order per (density, frame)
+// as gmm_distance: bit-identical distances.  Nothing density-major is written (no other kernel of the pruned path reads it).
+template<int DIM, bool FMA>
+__global__ __launch_bounds__(256) void gmm_dist_list_kernel(const float* __restrict__ g_feats, const float* __restrict__ g_means_t,
+                                                           const float* __restrict__ g_isr_t, int K, int Kpad, int T, int frames,
+                                                           float* __restrict__ g_dt) {
+    const int k  = blockIdx.x * 256 + threadIdx.x;
+    const int kk = k < Kpad ? k : Kpad - 1;
+    float     mu[DIM], is[DIM];
+#pragma unroll
+    for (int i = 0; i < DIM; ++i) {
+        mu[i] = g_means_t[(size_t)i * Kpad + kk];
+        is[i] = g_isr_t[(size_t)i * Kpad + kk];
+    }
+    const int t0 = blockIdx.y * frames, t1 = min(t0 + frames, T);
+    for (int t = t0; t < t1; ++t) {
+        const float* __restrict__ xr = g_feats + (size_t)t * DIM;  // wave-uniform: scalar loads
+        float x[DIM];
+#pragma unroll
+        for (int i = 0; i < DIM; ++i)
+            x[i] = xr[i];
+        const float dist = gmm_distance<DIM, FMA>(x, mu, is);
+        if (k < K)
+            g_dt[(size_t)t * Kpad + k] = dist;
+    }
+}
+
 struct GmmCombineParams {
     const float* __restrict__ dist;        // [n_dens x Tpad]
     float* __restrict__ scores;            // [T x n_mix]
@@ -1543,6 +1574,7 @@ struct amx_gmm {
     std::vector<uint32_t> mix_off, h_k_dens, h_d_mean, h_d_cov;  // topology (accumulator files)
     // device
     uint32_t *d_mix_off = nullptr, *d_k_mean = nullptr, *d_k_cov = nullptr, *d_k_dens = nullptr;
+    float *   d_means_t = nullptr, *d_isr_t = nullptr;  // same models: means / inverse deviations in list order, [dim][Kpad] (gmm_dist_list_kernel)
     uint32_t* d_dens_pos = nullptr;  // shared-list models whose list names every density at most once: density -> list position (~0: not listed)
     uint32_t *d_d_mean = nullptr, *d_d_cov = nullptr;
     double*   d_k_c64 = nullptr;
@@ -1614,7 +1646,7 @@ struct amx_gmm {
     int                                use_graphs = 1;
     // amx_gmm_model.tuning (A/B runs, tests)
     int         tune_screen = 1, tune_fused = 1, tune_screen_all = 0, tune_tied_prune = -1, tune_chunk = 65536, tune_fused_waves = 0, tune_fr = 8,
-                tune_simd_mfma = 1;
+                tune_simd_mfma = 1, tune_dist_list = 1;
     std::string tune_screen_kernel = "rows";
     // amx_gmm_model.tuning contract=fma: the distance's `sum += df * df` as one fused multiply-add = the reference's default build
     // (-march=native on an FMA host); off (default) = the reference built with -DMARCH=x86-64.  Not a speed switch: it selects WHICH
@@ -1935,6 +1967,38 @@ int launch_dist(amx_gmm* h, const amx::GmmDistParams& p, dim3 grid, double* dist
     return AMX_OK;
 }
 
+// the pruned path's frame-major distances straight from the transposed model tables; AMX_ERR_STATE: no instance for this dimension
+int launch_dist_list(amx_gmm* h, const float* feats, int T, float* dt) {
+    const int Kpad = (h->K + 63) & ~63;
+    // frames per wave: the 2 x dim table registers are loaded once per wave, so as many frames as still leave every SIMD two waves
+    int frames = 16;
+    while (frames > 2 && (long)amx::ceil_div(Kpad, 256) * 4 * amx::ceil_div(T, frames) < 8L * std::max(h->ctx->n_cu, 1))
+        frames /= 2;
+    if (h->tune_dist_list > 1)
+        frames = h->tune_dist_list;
+    const dim3 grid(amx::ceil_div(Kpad, 256), amx::ceil_div(T, frames));
+    switch (h->dim) {
+#define AMX_GMM_CASE(D)                                                                                                                         \
+    case D:                                                                                                                                     \
+        hipLaunchKernelGGL((h->contract_fma ? amx::gmm_dist_list_kernel<D, true> : amx::gmm_dist_list_kernel<D, false>), grid, dim3(256), 0,    \
+                           h->ctx->stream, feats, h->d_means_t, h->d_isr_t, h->K, Kpad, T, frames, dt);                                         \
+        break;
+        AMX_GMM_CASE(16)
+        AMX_GMM_CASE(24)
+        AMX_GMM_CASE(32)
+        AMX_GMM_CASE(33)
+        AMX_GMM_CASE(39)
+        AMX_GMM_CASE(40)
+        AMX_GMM_CASE(45)
+        AMX_GMM_CASE(48)
+#undef AMX_GMM_CASE
+        default:
+            return AMX_ERR_STATE;
+    }
+    AMX_HIP(hipGetLastError());
+    return AMX_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1964,7 +2028,7 @@ int amx_gmm_create(amx_ctx* ctx, const amx_gmm_model* m, amx_gmm** out) {
     if (!tune.parse(m->tuning, amx::gmm_tuning_keys, "amx_gmm_create"))
         return AMX_ERR_INVALID;
     // values are checked like keys: a typo must not silently select the default kernel (or the other arithmetic)
-    int         t_screen, t_fused, t_screen_all, t_tied_prune, t_chunk, t_fused_waves, t_fr, t_simd_mfma, t_graph;
+    int         t_screen, t_fused, t_screen_all, t_tied_prune, t_chunk, t_fused_waves, t_fr, t_simd_mfma, t_graph, t_dist_list;
     std::string t_screen_kernel, t_contract;
     static const char* const screen_kernels[] = {"rows", "persist", "simple", nullptr};
     static const char* const contracts[]      = {"off", "fma", nullptr};
@@ -1973,7 +2037,7 @@ int amx_gmm_create(amx_ctx* ctx, const amx_gmm_model* m, amx_gmm** out) {
         !tune.get_int("screen_all", 0, 0, 1, &t_screen_all, who) || !tune.get_int("tied_prune", -1, -1, 1, &t_tied_prune, who) ||
         !tune.get_int("chunk", 65536, 256, 1 << 24, &t_chunk, who) || !tune.get_int("fused_waves", 0, 0, 16, &t_fused_waves, who) ||
         !tune.get_int("fr", 8, 2, 16, &t_fr, who) || !tune.get_int("simd_mfma", 1, 0, 1, &t_simd_mfma, who) ||
-        !tune.get_int("graph", 1, 0, 1, &t_graph, who) || !tune.get_word("screen_kernel", "rows", screen_kernels, &t_screen_kernel, who) ||
+        !tune.get_int("graph", 1, 0, 1, &t_graph, who) || !tune.get_int("dist_list", 1, 0, 64, &t_dist_list, who) || !tune.get_word("screen_kernel", "rows", screen_kernels, &t_screen_kernel, who) ||
         !tune.get_word("contract", ctx && ctx->contract == AMX_CONTRACT_FMA ? "fma" : "off", contracts, &t_contract, who))   // no key: the context's arithmetic (amx_set_contract)
         return AMX_ERR_INVALID;
     AMX_REQUIRE(t_fused_waves == 0 || t_fused_waves == 8 || t_fused_waves == 12 || t_fused_waves == 13 || t_fused_waves == 16, AMX_ERR_INVALID,
@@ -1991,6 +2055,7 @@ int amx_gmm_create(amx_ctx* ctx, const amx_gmm_model* m, amx_gmm** out) {
     h->tune_fused_waves   = t_fused_waves;
     h->tune_fr            = t_fr;
     h->tune_simd_mfma     = t_simd_mfma;
+    h->tune_dist_list     = t_dist_list;
     h->tune_screen_kernel = t_screen_kernel;
     h->use_graphs         = t_graph;
     h->contract_fma       = t_contract == "fma";
@@ -2114,6 +2179,19 @@ int amx_gmm_create(amx_ctx* ctx, const amx_gmm_model* m, amx_gmm** out) {
             if (once && (r = gupload(&h->d_dens_pos, pos.data(), pos.size())) != AMX_OK) {
                 amx_gmm_destroy(h);
                 return r;
+            }
+            if (once) {  // the list's means and inverse deviations, transposed: lane = list position reads them coalesced
+                const int          Kpad = (h->K + 63) & ~63, dim = m->dim;
+                std::vector<float> mt((size_t)dim * Kpad, 0.f), it((size_t)dim * Kpad, 0.f);
+                for (int k = 0; k < h->K; ++k)
+                    for (int i = 0; i < dim; ++i) {
+                        mt[(size_t)i * Kpad + k] = m->means[(size_t)k_mean[k] * dim + i];
+                        it[(size_t)i * Kpad + k] = h->isr[(size_t)k_cov[k] * dim + i];
+                    }
+                if ((r = gupload(&h->d_means_t, mt.data(), mt.size())) != AMX_OK || (r = gupload(&h->d_isr_t, it.data(), it.size())) != AMX_OK) {
+                    amx_gmm_destroy(h);
+                    return r;
+                }
             }
         }
         // screen tables (gmm_tied_tile_kernel): an f32 image of the per-entry constant and its largest magnitude per mixture
@@ -2278,6 +2356,8 @@ void amx_gmm_destroy(amx_gmm* h) {
     hipFree(h->d_k_cov);
     hipFree(h->d_k_dens);
     hipFree(h->d_dens_pos);
+    hipFree(h->d_means_t);
+    hipFree(h->d_isr_t);
     hipFree(h->d_d_mean);
     hipFree(h->d_d_cov);
     hipFree(h->d_k_c64);
@@ -2676,7 +2756,9 @@ int amx_gmm_score_dev(amx_gmm* h, int mode, const float* feats_dev, int T, float
         }
         {
             amx::ScopedKernelTimer timer(h->ctx, "gmm_dist");
-            int r = launch_dist(h, dp, dim3(amx::ceil_div(h->n_dens, dp.dens_tile), fb), need64 ? h->d_dist64 : nullptr, stage, dt,
+            int r = dt && !need64 && h->d_means_t && h->tune_dist_list ? launch_dist_list(h, feats_dev + (size_t)t0 * h->dim, Tc, dt) : AMX_ERR_STATE;
+            if (r == AMX_ERR_STATE)  // (a dimension without an instance, or not the pruned one-pass path)
+                r = launch_dist(h, dp, dim3(amx::ceil_div(h->n_dens, dp.dens_tile), fb), need64 ? h->d_dist64 : nullptr, stage, dt,
                                 (h->K + 63) & ~63);
             if (r != AMX_OK)
                 return r;
