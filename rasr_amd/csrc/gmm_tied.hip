@@ -172,6 +172,116 @@ __global__ __launch_bounds__(256) void tied_bound_kernel(const unsigned short* _
         g_thr[(size_t)t * n_tiles + tile] = thr;
 }
 
+// The same bounds with EIGHT mixtures per lane, for tables below 4 GB (round 6).  Measured on the kernel above: with every row an L2
+// hit it still takes 25.7 of its 28 us, with fewer instructions but fewer waves per SIMD it is slower -- it is bound by the 20 096 x 64
+// dword-per-lane loads, each a 256-byte wave request, which leave a CU at ~50 GB/s where 1 KB requests reach 128 GB/s
+// (profiles/r06/l2_probe.log).  Here a wave reads 1 KB of a row per instruction (one wave = one 1 KB segment of the table = eight
+// tiles, on XCD segment % 8 as above), a quarter of the load and scalar instructions per byte; rows arrive eight at a time into one of
+// two register buffers while the other is summed (two packed adds per dword pair, one three-way minimum per two rows and mixture).
+#ifndef AMX_TIED_BOUND_B
+#define AMX_TIED_BOUND_B 4
+#define AMX_TIED_BOUND_NBUF 4
+#endif
+typedef float tied_f2 __attribute__((ext_vector_type(2)));
+typedef uint32_t tied_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ tied_u4 tied_load_u4(const unsigned short* tab, uint32_t row_off, uint32_t lane_off) {
+    typedef const __attribute__((address_space(1))) char* gptr;
+    gptr row = (gptr)tab + row_off;
+    asm("" : "+s"(row));
+    asm("" : "+v"(lane_off));
+    return *(const __attribute__((address_space(1))) tied_u4*)(row + lane_off);
+}
+
+// Work to XCDs: a row has S = mix_pad / 512 (rounded up) segments.  The first 8 (S / 8) keep the fixed home XCD segment % 8 (each
+// XCD's L2 then holds ITS segments of the rows the batch's frames share).  The remaining R = S % 8 would leave 8 - R XCDs idle a
+// third of the time (config 3: S = 20, XCDs 0-3 three segments per frame, 4-7 two: measured as 21 us of ARITHMETIC alone, where a
+// balanced chip needs 17), so their R x T (segment, frame) units are dealt round the XCDs: unit q = t R + j on XCD q % 8.
+__global__ __launch_bounds__(64) void tied_bound8_kernel(const unsigned short* __restrict__ g_aup, const float* __restrict__ g_amax,
+                                                        const float* __restrict__ g_nd, const uint32_t* __restrict__ g_nk, int n_mix,
+                                                        int mix_pad, int n_tiles, float* __restrict__ g_thr, float* __restrict__ g_thr_m,
+                                                        int T, int fixed_per_xcd, int rest) {
+    constexpr int B = AMX_TIED_BOUND_B, NBUF = AMX_TIED_BOUND_NBUF;  // rows per buffer, buffers: (NBUF - 1) B rows of 1 KB in flight per wave
+    static_assert(kTiedNear % (NBUF * B) == 0 && B % 2 == 0, "whole rounds of buffers, row pairs");
+    const int lane = threadIdx.x;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    int       t, seg;
+    if (idx < fixed_per_xcd * T) {
+        t   = idx / fixed_per_xcd;
+        seg = xcd + 8 * (idx - t * fixed_per_xcd);
+    }
+    else {
+        const int q = xcd + 8 * (idx - fixed_per_xcd * T);
+        if (q >= rest * T)
+            return;
+        t   = q / rest;
+        seg = 8 * fixed_per_xcd + (q - t * rest);
+    }
+    const int m = 8 * (seg * 64 + lane);  // mix_pad is a multiple of 64: m + 7 < mix_pad with m
+    const bool      in = m < mix_pad;  // (the last segment's upper lanes: they read the row's first bytes and store nothing)
+    const float*    nd = g_nd + (size_t)t * kTiedNear;
+    const uint32_t* nk = g_nk + (size_t)t * kTiedNear;
+    const uint32_t  row_bytes = (uint32_t)mix_pad * 2u, lane_off = in ? (uint32_t)m * 2u : 0u;
+    tied_u4         buf[NBUF][B];
+    float           u[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        u[j] = FLT_MAX;
+    auto fetch = [&](tied_u4 (&bf)[B], const uint32_t* k) {
+#pragma unroll
+        for (int i = 0; i < B; ++i)
+            bf[i] = tied_load_u4(g_aup, k[i] * row_bytes, lane_off);
+    };
+    auto sum = [&](const tied_u4 (&bf)[B], const float* d) {
+#pragma unroll
+        for (int i = 0; i < B; i += 2) {
+            const float da = d[i], db = d[i + 1];
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const tied_f2 a = tied_f2{__uint_as_float(bf[i][w] << 16), __uint_as_float(bf[i][w] & 0xffff0000u)} + tied_f2{da, da};
+                const tied_f2 c = tied_f2{__uint_as_float(bf[i + 1][w] << 16), __uint_as_float(bf[i + 1][w] & 0xffff0000u)} + tied_f2{db, db};
+                u[2 * w]        = fminf(fminf(u[2 * w], a.x), c.x);
+                u[2 * w + 1]    = fminf(fminf(u[2 * w + 1], a.y), c.y);
+            }
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < NBUF - 1; ++j)
+        fetch(buf[j], nk + j * B);
+#pragma unroll 1
+    for (int r = 0; r < kTiedNear; r += NBUF * B) {  // (a rolled loop: unrolled, the scheduler lifts all 64 loads to the top -- 394 registers)
+#pragma unroll
+        for (int j = 0; j < NBUF; ++j) {
+            const int nxt = r + (j + NBUF - 1) * B;  // the batch NBUF - 1 ahead goes into the buffer summed last
+            if (nxt < kTiedNear)
+                fetch(buf[(j + NBUF - 1) % NBUF], nk + nxt);
+            sum(buf[j], nd + r + j * B);
+        }
+    }
+    if (!in)
+        return;  // whole groups of eight lanes (a tile) leave together
+    // tau' = 2^-21 (2 max|a^| + |U|)
+    float thr8[8], thr = -__builtin_inff();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        thr8[j] = -__builtin_inff();
+        if (m + j < n_mix) {
+            thr8[j] = u[j] + (4.76837158e-7f * (2.f * g_amax[m + j] + fabsf(u[j])) + 1e-30f);
+            if (!(thr8[j] == thr8[j]))
+                thr8[j] = __builtin_inff();
+        }
+        thr = fmaxf(thr, thr8[j]);
+    }
+    float* out = g_thr_m + (size_t)t * mix_pad + m;  // the mixtures' own thresholds: tied_pruned_kernel screens with them (-inf: padding)
+    *(float4*)out       = make_float4(thr8[0], thr8[1], thr8[2], thr8[3]);
+    *(float4*)(out + 4) = make_float4(thr8[4], thr8[5], thr8[6], thr8[7]);
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1)
+        thr = fmaxf(thr, __shfl_xor(thr, o));
+    const int tile = m >> 6;
+    if ((lane & 7) == 0 && tile < n_tiles)
+        g_thr[(size_t)t * n_tiles + tile] = thr;
+}
+
 // One workgroup of 16 waves per frame: ThrG = max over the tiles, then the densities with fl32(aminG[k] + dist) <= ThrG, ascending,
 // with their distances and log-normalisation terms.  Wave w tests densities [256 w, 256 w + 256) of every 4096 (one trip to memory:
 // the frame's whole list is a handful of trips deep, not K / 256), the waves' counts meet in LDS, and each wave appends behind the
@@ -703,8 +813,14 @@ extern "C" int amx_internal_gmm_tied_score(amx_ctx* ctx, const float* dist_dev, 
                                K, Kpad, Tc, Tpad - t0, Tpad, w.dt);
         hipLaunchKernelGGL(amx::tied_near_kernel, dim3(Tc), dim3(amx::kTiedNearThreads), 0, ctx->stream, w.dt, K, Kpad, w.nd, w.nk);
         const int bound_spx = ((mix_pad / 2 + 255) / 256 + 7) / 8;   // 1 KB segments of a table row per XCD
-        hipLaunchKernelGGL(amx::tied_bound_kernel, dim3(8 * bound_spx * Tc), dim3(256), 0, ctx->stream, aup, amax, w.nd, w.nk, n_mix, mix_pad,
-                           n_tiles, w.thr, w.thr_m, bound_spx);
+        if ((unsigned long long)K * (unsigned long long)mix_pad * 2ull < (1ull << 32)) {
+            const int segs = (mix_pad + 511) / 512, fixed = segs / 8, rest = segs % 8;
+            hipLaunchKernelGGL(amx::tied_bound8_kernel, dim3(8 * (fixed * Tc + (rest * Tc + 7) / 8)), dim3(64), 0, ctx->stream, aup, amax, w.nd,
+                               w.nk, n_mix, mix_pad, n_tiles, w.thr, w.thr_m, Tc, fixed, rest);
+        }
+        else
+            hipLaunchKernelGGL(amx::tied_bound_kernel, dim3(8 * bound_spx * Tc), dim3(256), 0, ctx->stream, aup, amax, w.nd, w.nk, n_mix, mix_pad,
+                               n_tiles, w.thr, w.thr_m, bound_spx);
         hipLaunchKernelGGL(amx::tied_list_kernel, dim3(Tc), dim3(64 * amx::kTiedListWaves), 0, ctx->stream, w.dt, amin + (size_t)n_tiles * Kpad, w.thr, ln32, K, Kpad,
                            n_tiles, w.lk, w.ld, w.ll, w.ln, survivors_dev ? survivors_dev + amx::kTiedCounters : nullptr,
                            (unsigned long long)K * (unsigned long long)Tc * (unsigned long long)n_tiles);

@@ -1083,6 +1083,27 @@ def test_tied_non_finite_frames_keep_the_initial_result(ctx, pooled):
     assert_exact(ctx, model, x)
 
 
+@pytest.mark.parametrize("dim,n_dens,T", [(40, 1000, 256), (39, 257, 70), (33, 300, 1), (16, 64, 513), (45, 130, 100), (48, 96, 65),
+                                          (50, 200, 40)])
+@pytest.mark.parametrize("contract", ["off", "fma"])
+def test_tied_list_order_distances(ctx, dim, n_dens, T, contract, monkeypatch):
+    """the pruned path's distance kernel (gmm_dist_list_kernel: lane = list position, tables transposed at creation) against the
+    reference arithmetic, in both contracts, for every frames-per-wave setting and against the density-major kernel it replaces
+    (dist_list=0); odd dimensions take the scalar tail, dim 50 has no instance and falls back; pooled and per-density covariances"""
+    import rasr_amd
+    from oracle import OracleGmm
+    for pooled in (True, False):
+        model = synth.gmm_tied(130, n_dens, dim, seed=940 + n_dens, pooled=pooled)
+        x = feats(T, dim, 941)
+        if T > 8:
+            x[3] *= 25.0
+        osc, ob = OracleGmm(model, contract=contract).score(x, mode=0)
+        for dl in ("dist_list=1", "dist_list=0", "dist_list=2", "dist_list=16", "dist_list=64"):
+            sc, best = rasr_amd.GmmFeatureScorer(ctx, model, tuning="tied_prune=1,contract=%s,%s" % (contract, dl)).score(x)
+            assert np.array_equal(sc.view(np.uint32), osc.view(np.uint32)), (dl, pooled, np.abs(sc - osc).max())
+            assert np.array_equal(best, ob), (dl, pooled)
+
+
 # ---- gmm_fused_kernel (gmm_fused.hip): screen + exact evaluation in one kernel, pooled covariance, dim <= 40
 
 def _screen_worst_case(dim, n_mix, seed):
