@@ -364,7 +364,8 @@ typedef struct {
      * kernel | pruned scorer, default -1 adaptive), chunk=N (frames per internal pass, >= 256), fused_waves=8|12|16|13 (13: the
      * wave-specialised kernel), fr=2|4|8|16 (frames per workgroup of the uniform tied kernel), simd_mfma=0 (SIMD / batch-int scorers
      * without the i8 matrix kernel), dist_list=0 (pruned tied scorer: distances from the density-major kernel instead of the
-     * list-order one; N >= 2: N frames per wave of the list-order kernel). */
+     * list-order one; N >= 2: N frames per wave of the list-order kernel), near_fused=0 (the frame's near densities from
+     * tied_near_kernel instead of the list-order kernel's atomic minima). */
     const char*     tuning;
 } amx_gmm_model;
 

@@ -627,10 +627,16 @@ __global__ __launch_bounds__(256) void gmm_dist_kernel(const float* __restrict__
 // at creation ([dim][Kpad], coalesced, 2 x DIM registers per lane for the wave's whole life), the frame is wave-uniform and arrives
 // through the scalar cache, and the row dt[t][k0 .. k0 + 63] leaves as one 256-byte store.  Same operation order per (density, frame)
 // as gmm_distance: bit-identical distances.  Nothing density-major is written (no other kernel of the pruned path reads it).
-template<int DIM, bool FMA>
+// NEAR: the kernel also keeps, per (frame, lane = list position mod 64), the smallest key (distance bits << 32) | position -- the
+// frame's closest density of every residue class, which the pruned scorer's bounds start from (tied_near_kernel, gmm_tied.hip, then
+// does not run: a launch and a pass over the image less).  The four waves' keys of a frame meet in LDS, one wave takes the minimum to
+// the frame's 64 keys with atomics; the keys are in their empty state (+inf, 0) when the kernel starts (tied_list_kernel puts them back).
+template<int DIM, bool FMA, bool NEAR>
 __global__ __launch_bounds__(256) void gmm_dist_list_kernel(const float* __restrict__ g_feats, const float* __restrict__ g_means_t,
                                                            const float* __restrict__ g_isr_t, int K, int Kpad, int T, int frames,
-                                                           float* __restrict__ g_dt) {
+                                                           float* __restrict__ g_dt, unsigned long long* __restrict__ g_near) {
+    constexpr unsigned long long kEmpty = 0x7f80000000000000ull;
+    __shared__ unsigned long long s_key[NEAR ? 2 * 256 : 1];
     const int k  = blockIdx.x * 256 + threadIdx.x;
     const int kk = k < Kpad ? k : Kpad - 1;
     float     mu[DIM], is[DIM];
@@ -649,6 +655,18 @@ __global__ __launch_bounds__(256) void gmm_dist_list_kernel(const float* __restr
         const float dist = gmm_distance<DIM, FMA>(x, mu, is);
         if (k < K)
             g_dt[(size_t)t * Kpad + k] = dist;
+        if (NEAR) {
+            const int par = (t - t0) & 1;  // two buffers: the wave that reduces frame t may still read while frame t + 1 is written
+            s_key[par * 256 + threadIdx.x] = k < K ? ((unsigned long long)__float_as_uint(dist) << 32) | (unsigned)k : kEmpty;
+            __syncthreads();
+            if ((int)(threadIdx.x >> 6) == ((t - t0) & 3)) {
+                const unsigned long long* p = s_key + par * 256 + (threadIdx.x & 63);
+                const unsigned long long  a = p[0] < p[64] ? p[0] : p[64], b = p[128] < p[192] ? p[128] : p[192];
+                const unsigned long long  m = a < b ? a : b;
+                if (m < kEmpty)
+                    __hip_atomic_fetch_min(g_near + (size_t)t * 64 + (threadIdx.x & 63), m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
     }
 }
 
@@ -1595,7 +1613,8 @@ struct amx_gmm {
     unsigned long long* d_tied_surv  = nullptr;  // [256] survivors (density, frame, tile) of the calls so far, spread over 256 counters; [256] = triples examined
     unsigned long long* h_tied_surv  = nullptr;  // pinned host copy, refreshed asynchronously after every 8th pruned call (tied_publish)
     unsigned            tied_copy_tick = 0;      // pruned calls since the handle was made
-    bool                tied_capturing = false;  // the pruned launches are being recorded: the copy stays outside the graph
+    bool                tied_capturing = false;
+    bool                tied_keys_clean = false;  // the workspace's near keys are in their empty state (gmm_dist_list_kernel's atomics start from it)  // the pruned launches are being recorded: the copy stays outside the graph
     unsigned long long  tied_seen    = 0;        // survivors / examined triples in the host copy at the previous decision
     unsigned long long  tied_triples = 0;
     int                 tied_dense_calls = 0;    // > 0: stay on gmm_tied_tile_kernel for that many calls, then probe again
@@ -1646,7 +1665,7 @@ struct amx_gmm {
     int                                use_graphs = 1;
     // amx_gmm_model.tuning (A/B runs, tests)
     int         tune_screen = 1, tune_fused = 1, tune_screen_all = 0, tune_tied_prune = -1, tune_chunk = 65536, tune_fused_waves = 0, tune_fr = 8,
-                tune_simd_mfma = 1, tune_dist_list = 1;
+                tune_simd_mfma = 1, tune_dist_list = 1, tune_near_fused = 1;
     std::string tune_screen_kernel = "rows";
     // amx_gmm_model.tuning contract=fma: the distance's `sum += df * df` as one fused multiply-add = the reference's default build
     // (-march=native on an FMA host); off (default) = the reference built with -DMARCH=x86-64.  Not a speed switch: it selects WHICH
@@ -1703,8 +1722,10 @@ extern "C" size_t amx_internal_gmm_tied_workspace(int K, int T, int mix_pad);
 extern "C" int    amx_internal_gmm_tied_score(amx_ctx* ctx, const float* dist_dev, const uint32_t* k_dens_dev, int K, int T, int Tpad, int n_mix,
                                               int mix_pad, const unsigned short* aup, const float* amax, const float* m2lw_t, const float* ahat_t,
                                               const double* ln64, const float* ln32, const float* amin, void* workspace, float* scores,
-                                              uint32_t* best, unsigned long long* survivors_dev, int dt_written);
+                                              uint32_t* best, unsigned long long* survivors_dev, int dt_written, int near_written);
 extern "C" float* amx_internal_gmm_tied_dt(void* workspace, int K, int T, int have_positions);
+extern "C" unsigned long long* amx_internal_gmm_tied_near(void* workspace);
+extern "C" int                 amx_internal_gmm_tied_near_init(amx_ctx* ctx, void* workspace);
 extern "C" int amx_internal_gmm_fused_supported(int dim, int pooled, int Kp);
 extern "C" int amx_internal_gmm_fused_create(int dim, int n_mix, int n_tiles, const void* A2_host, const uint32_t* mix_off, const uint32_t* k_mean,
                                              const double* c64, const float* means, const float* p1, const float* p2, void** rec_dev,
@@ -1968,7 +1989,7 @@ int launch_dist(amx_gmm* h, const amx::GmmDistParams& p, dim3 grid, double* dist
 }
 
 // the pruned path's frame-major distances straight from the transposed model tables; AMX_ERR_STATE: no instance for this dimension
-int launch_dist_list(amx_gmm* h, const float* feats, int T, float* dt) {
+int launch_dist_list(amx_gmm* h, const float* feats, int T, float* dt, unsigned long long* near) {
     const int Kpad = (h->K + 63) & ~63;
     // frames per wave: the 2 x dim table registers are loaded once per wave, so as many frames as still leave every SIMD two waves
     int frames = 16;
@@ -1980,8 +2001,12 @@ int launch_dist_list(amx_gmm* h, const float* feats, int T, float* dt) {
     switch (h->dim) {
 #define AMX_GMM_CASE(D)                                                                                                                         \
     case D:                                                                                                                                     \
-        hipLaunchKernelGGL((h->contract_fma ? amx::gmm_dist_list_kernel<D, true> : amx::gmm_dist_list_kernel<D, false>), grid, dim3(256), 0,    \
-                           h->ctx->stream, feats, h->d_means_t, h->d_isr_t, h->K, Kpad, T, frames, dt);                                         \
+        if (near)                                                                                                                               \
+            hipLaunchKernelGGL((h->contract_fma ? amx::gmm_dist_list_kernel<D, true, true> : amx::gmm_dist_list_kernel<D, false, true>), grid,  \
+                               dim3(256), 0, h->ctx->stream, feats, h->d_means_t, h->d_isr_t, h->K, Kpad, T, frames, dt, near);                 \
+        else                                                                                                                                    \
+            hipLaunchKernelGGL((h->contract_fma ? amx::gmm_dist_list_kernel<D, true, false> : amx::gmm_dist_list_kernel<D, false, false>), grid,\
+                               dim3(256), 0, h->ctx->stream, feats, h->d_means_t, h->d_isr_t, h->K, Kpad, T, frames, dt, near);                 \
         break;
         AMX_GMM_CASE(16)
         AMX_GMM_CASE(24)
@@ -2028,7 +2053,7 @@ int amx_gmm_create(amx_ctx* ctx, const amx_gmm_model* m, amx_gmm** out) {
     if (!tune.parse(m->tuning, amx::gmm_tuning_keys, "amx_gmm_create"))
         return AMX_ERR_INVALID;
     // values are checked like keys: a typo must not silently select the default kernel (or the other arithmetic)
-    int         t_screen, t_fused, t_screen_all, t_tied_prune, t_chunk, t_fused_waves, t_fr, t_simd_mfma, t_graph, t_dist_list;
+    int         t_screen, t_fused, t_screen_all, t_tied_prune, t_chunk, t_fused_waves, t_fr, t_simd_mfma, t_graph, t_dist_list, t_near_fused;
     std::string t_screen_kernel, t_contract;
     static const char* const screen_kernels[] = {"rows", "persist", "simple", nullptr};
     static const char* const contracts[]      = {"off", "fma", nullptr};
@@ -2037,7 +2062,8 @@ int amx_gmm_create(amx_ctx* ctx, const amx_gmm_model* m, amx_gmm** out) {
         !tune.get_int("screen_all", 0, 0, 1, &t_screen_all, who) || !tune.get_int("tied_prune", -1, -1, 1, &t_tied_prune, who) ||
         !tune.get_int("chunk", 65536, 256, 1 << 24, &t_chunk, who) || !tune.get_int("fused_waves", 0, 0, 16, &t_fused_waves, who) ||
         !tune.get_int("fr", 8, 2, 16, &t_fr, who) || !tune.get_int("simd_mfma", 1, 0, 1, &t_simd_mfma, who) ||
-        !tune.get_int("graph", 1, 0, 1, &t_graph, who) || !tune.get_int("dist_list", 1, 0, 64, &t_dist_list, who) || !tune.get_word("screen_kernel", "rows", screen_kernels, &t_screen_kernel, who) ||
+        !tune.get_int("graph", 1, 0, 1, &t_graph, who) || !tune.get_int("dist_list", 1, 0, 64, &t_dist_list, who) ||
+        !tune.get_int("near_fused", 1, 0, 1, &t_near_fused, who) || !tune.get_word("screen_kernel", "rows", screen_kernels, &t_screen_kernel, who) ||
         !tune.get_word("contract", ctx && ctx->contract == AMX_CONTRACT_FMA ? "fma" : "off", contracts, &t_contract, who))   // no key: the context's arithmetic (amx_set_contract)
         return AMX_ERR_INVALID;
     AMX_REQUIRE(t_fused_waves == 0 || t_fused_waves == 8 || t_fused_waves == 12 || t_fused_waves == 13 || t_fused_waves == 16, AMX_ERR_INVALID,
@@ -2056,6 +2082,7 @@ int amx_gmm_create(amx_ctx* ctx, const amx_gmm_model* m, amx_gmm** out) {
     h->tune_fr            = t_fr;
     h->tune_simd_mfma     = t_simd_mfma;
     h->tune_dist_list     = t_dist_list;
+    h->tune_near_fused    = t_near_fused;
     h->tune_screen_kernel = t_screen_kernel;
     h->use_graphs         = t_graph;
     h->contract_fma       = t_contract == "fma";
@@ -2738,7 +2765,8 @@ int amx_gmm_score_dev(amx_gmm* h, int mode, const float* feats_dev, int T, float
         // these features leave too much standing (tied_decide_prune); decided here because the distance kernel then also writes the
         // frame-major image that path works on
         const bool prune = use_uni && mode == AMX_GMM_MAX && screen && (h->tied_forced >= 0 ? h->tied_forced == 1 : tied_decide_prune(h));
-        float*     dt    = nullptr;
+        float*              dt   = nullptr;
+        unsigned long long* near = nullptr;
         if (prune) {
             const size_t need_ws = amx_internal_gmm_tied_workspace(h->K, Tc, h->mix_pad);
             if (need_ws > h->tied_ws_cap) {
@@ -2750,13 +2778,29 @@ int amx_gmm_score_dev(amx_gmm* h, int mode, const float* feats_dev, int T, float
                 h->d_tied_ws   = nullptr;
                 h->tied_ws_cap = 0;
                 AMX_HIP(hipMalloc(&h->d_tied_ws, need_ws));
-                h->tied_ws_cap = need_ws;
+                h->tied_ws_cap     = need_ws;
+                h->tied_keys_clean = false;
             }
             dt = amx_internal_gmm_tied_dt(h->d_tied_ws, h->K, Tc, h->d_dens_pos != nullptr);
         }
         {
             amx::ScopedKernelTimer timer(h->ctx, "gmm_dist");
-            int r = dt && !need64 && h->d_means_t && h->tune_dist_list ? launch_dist_list(h, feats_dev + (size_t)t0 * h->dim, Tc, dt) : AMX_ERR_STATE;
+            const bool list_order = dt && !need64 && h->d_means_t && h->tune_dist_list;
+            if (list_order && h->tune_near_fused && !(h->tied_capturing && !h->tied_keys_clean)) {
+                near = amx_internal_gmm_tied_near(h->d_tied_ws);
+                if (near && !h->tied_keys_clean) {  // a new workspace, or a call that did not get as far as putting the keys back
+                    int ri = amx_internal_gmm_tied_near_init(h->ctx, h->d_tied_ws);
+                    if (ri != AMX_OK)
+                        return ri;
+                }
+                h->tied_keys_clean = false;  // until amx_internal_gmm_tied_score has been enqueued behind this kernel
+            }
+            int r = list_order ? launch_dist_list(h, feats_dev + (size_t)t0 * h->dim, Tc, dt, near) : AMX_ERR_STATE;
+            if (r == AMX_ERR_STATE) {
+                if (near)
+                    h->tied_keys_clean = true;  // nothing touched them
+                near = nullptr;
+            }
             if (r == AMX_ERR_STATE)  // (a dimension without an instance, or not the pruned one-pass path)
                 r = launch_dist(h, dp, dim3(amx::ceil_div(h->n_dens, dp.dens_tile), fb), need64 ? h->d_dist64 : nullptr, stage, dt,
                                 (h->K + 63) & ~63);
@@ -2777,9 +2821,11 @@ int amx_gmm_score_dev(amx_gmm* h, int mode, const float* feats_dev, int T, float
                 if (prune) {
                     int r = amx_internal_gmm_tied_score(h->ctx, h->d_dist, h->d_k_dens, h->K, Tc, Tpad, h->n_mix, h->mix_pad, h->d_aup,
                                                         h->d_amax, h->d_m2lw_t, h->d_ahat_t, h->d_ln64, h->d_ln32, h->d_amin, h->d_tied_ws, sc, bd,
-                                                        h->d_tied_surv, dt != nullptr);
+                                                        h->d_tied_surv, dt != nullptr, near != nullptr);
                     if (r != AMX_OK)
                         return r;
+                    if (near)
+                        h->tied_keys_clean = true;  // tied_list_kernel puts them back
                     if (!h->tied_capturing && (r = tied_publish(h)) != AMX_OK)
                         return r;
                     h->tied_rep_triples += (unsigned long long)h->K * (unsigned long long)Tc * (unsigned long long)(h->mix_pad / 64);

@@ -87,8 +87,19 @@ __global__ __launch_bounds__(256) void tied_transpose_kernel(const float* __rest
 constexpr int kTiedNearThreads = 1024;
 static_assert(kTiedNearThreads % kTiedNear == 0 && kTiedNear >= 8 && kTiedNear <= 128, "a thread of tied_near_kernel stays inside one residue class");
 
-__global__ __launch_bounds__(kTiedNearThreads) void tied_near_kernel(const float* __restrict__ g_dt, int K, int Kpad, float* __restrict__ g_nd,
-                                                                    uint32_t* __restrict__ g_nk) {
+// A near density is ONE 64-bit key, (distance bits << 32) | list position: distances are >= +0, so the keys order like the distances
+// (NaN above +inf), a minimum over keys is the closest density, and gmm_dist_list_kernel (gmm.hip) can keep the minima with atomics
+// instead of this kernel.  kTiedNearInit = (+inf, row 0) is what an empty class holds (row 0 stands in, its sum is +inf).
+constexpr unsigned long long kTiedNearInit = 0x7f80000000000000ull;
+
+__global__ __launch_bounds__(256) void tied_near_init_kernel(unsigned long long* __restrict__ g_near, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n)
+        g_near[i] = kTiedNearInit;
+}
+
+__global__ __launch_bounds__(kTiedNearThreads) void tied_near_kernel(const float* __restrict__ g_dt, int K, int Kpad,
+                                                                    unsigned long long* __restrict__ g_near) {
     constexpr int       NT = kTiedNearThreads;
     __shared__ float    s_v[NT];
     __shared__ uint32_t s_i[NT];
@@ -112,8 +123,8 @@ __global__ __launch_bounds__(kTiedNearThreads) void tied_near_kernel(const float
                 bv = s_v[tid + kTiedNear * j];
                 bi = s_i[tid + kTiedNear * j];
             }
-        g_nd[(size_t)t * kTiedNear + tid] = bv;  // +inf: empty class, or no finite distance (NaN / inf frame); row 0 stands in, its sum is +inf
-        g_nk[(size_t)t * kTiedNear + tid] = bi;
+        // +inf: empty class, or no finite distance (NaN / inf frame); row 0 stands in, its sum is +inf
+        g_near[(size_t)t * kTiedNear + tid] = ((unsigned long long)__float_as_uint(bv) << 32) | bi;
     }
 }
 
@@ -125,7 +136,7 @@ __global__ __launch_bounds__(kTiedNearThreads) void tied_near_kernel(const float
 // A lane takes TWO mixtures (one dword = two bf16 per row): the near densities and their distances are wave-uniform scalars, so a row
 // costs the wave one load, two unpacks, two sums and two minima for 128 mixtures.  64 mixtures = one tile = 32 lanes.
 __global__ __launch_bounds__(256) void tied_bound_kernel(const unsigned short* __restrict__ g_aup, const float* __restrict__ g_amax,
-                                                        const float* __restrict__ g_nd, const uint32_t* __restrict__ g_nk, int n_mix,
+                                                        const uint2* __restrict__ g_near, int n_mix,
                                                         int mix_pad, int n_tiles, float* __restrict__ g_thr, float* __restrict__ g_thr_m,
                                                         int seg_per_xcd) {
     // Workgroup b runs on XCD b % 8, and each XCD has its own L2.  A near row is wanted by ~4 of a 256-frame batch's frames, so a 1 KB
@@ -137,16 +148,15 @@ __global__ __launch_bounds__(256) void tied_bound_kernel(const unsigned short* _
     const int m = 2 * (seg * 256 + threadIdx.x);  // mix_pad is a multiple of 64: m + 1 < mix_pad with m
     if (m >= mix_pad)
         return;  // whole 32-lane halves leave together (a half = one tile)
-    const float*    nd = g_nd + (size_t)t * kTiedNear;
-    const uint32_t* nk = g_nk + (size_t)t * kTiedNear;
+    const uint2*    nr = g_near + (size_t)t * kTiedNear;  // .x = list position, .y = distance bits (little-endian halves of the key)
     uint32_t        v[kTiedNear];
 #pragma unroll
     for (int i = 0; i < kTiedNear; ++i)  // all rows in flight before the first use
-        v[i] = *(const uint32_t*)(g_aup + (size_t)nk[i] * mix_pad + m);
+        v[i] = *(const uint32_t*)(g_aup + (size_t)nr[i].x * mix_pad + m);
     float u0 = FLT_MAX, u1 = FLT_MAX;
 #pragma unroll
     for (int i = 0; i < kTiedNear; ++i) {
-        const float d = nd[i];
+        const float d = __uint_as_float(nr[i].y);
         u0            = fminf(u0, __uint_as_float(v[i] << 16) + d);
         u1            = fminf(u1, __uint_as_float(v[i] & 0xffff0000u) + d);
     }
@@ -179,8 +189,8 @@ __global__ __launch_bounds__(256) void tied_bound_kernel(const unsigned short* _
 // tiles, on XCD segment % 8 as above), a quarter of the load and scalar instructions per byte; rows arrive eight at a time into one of
 // two register buffers while the other is summed (two packed adds per dword pair, one three-way minimum per two rows and mixture).
 #ifndef AMX_TIED_BOUND_B
-#define AMX_TIED_BOUND_B 4
-#define AMX_TIED_BOUND_NBUF 4
+#define AMX_TIED_BOUND_B 4     // measured 4 x 2: 21.5 us, 2 x 2: 21.9, 2 x 4: 22.4, 4 x 4: 23.5 (64 / 56 / 72 / 128 registers)
+#define AMX_TIED_BOUND_NBUF 2
 #endif
 typedef float tied_f2 __attribute__((ext_vector_type(2)));
 typedef uint32_t tied_u4 __attribute__((ext_vector_type(4)));
@@ -197,7 +207,7 @@ __device__ __forceinline__ tied_u4 tied_load_u4(const unsigned short* tab, uint3
 // third of the time (config 3: S = 20, XCDs 0-3 three segments per frame, 4-7 two: measured as 21 us of ARITHMETIC alone, where a
 // balanced chip needs 17), so their R x T (segment, frame) units are dealt round the XCDs: unit q = t R + j on XCD q % 8.
 __global__ __launch_bounds__(64) void tied_bound8_kernel(const unsigned short* __restrict__ g_aup, const float* __restrict__ g_amax,
-                                                        const float* __restrict__ g_nd, const uint32_t* __restrict__ g_nk, int n_mix,
+                                                        const uint2* __restrict__ g_near, int n_mix,
                                                         int mix_pad, int n_tiles, float* __restrict__ g_thr, float* __restrict__ g_thr_m,
                                                         int T, int fixed_per_xcd, int rest) {
     constexpr int B = AMX_TIED_BOUND_B, NBUF = AMX_TIED_BOUND_NBUF;  // rows per buffer, buffers: (NBUF - 1) B rows of 1 KB in flight per wave
@@ -218,23 +228,22 @@ __global__ __launch_bounds__(64) void tied_bound8_kernel(const unsigned short* _
     }
     const int m = 8 * (seg * 64 + lane);  // mix_pad is a multiple of 64: m + 7 < mix_pad with m
     const bool      in = m < mix_pad;  // (the last segment's upper lanes: they read the row's first bytes and store nothing)
-    const float*    nd = g_nd + (size_t)t * kTiedNear;
-    const uint32_t* nk = g_nk + (size_t)t * kTiedNear;
+    const uint2*    nr = g_near + (size_t)t * kTiedNear;  // .x = list position, .y = distance bits (little-endian halves of the key)
     const uint32_t  row_bytes = (uint32_t)mix_pad * 2u, lane_off = in ? (uint32_t)m * 2u : 0u;
     tied_u4         buf[NBUF][B];
     float           u[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j)
         u[j] = FLT_MAX;
-    auto fetch = [&](tied_u4 (&bf)[B], const uint32_t* k) {
+    auto fetch = [&](tied_u4 (&bf)[B], const uint2* k) {
 #pragma unroll
         for (int i = 0; i < B; ++i)
-            bf[i] = tied_load_u4(g_aup, k[i] * row_bytes, lane_off);
+            bf[i] = tied_load_u4(g_aup, k[i].x * row_bytes, lane_off);
     };
-    auto sum = [&](const tied_u4 (&bf)[B], const float* d) {
+    auto sum = [&](const tied_u4 (&bf)[B], const uint2* d) {
 #pragma unroll
         for (int i = 0; i < B; i += 2) {
-            const float da = d[i], db = d[i + 1];
+            const float da = __uint_as_float(d[i].y), db = __uint_as_float(d[i + 1].y);
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
                 const tied_f2 a = tied_f2{__uint_as_float(bf[i][w] << 16), __uint_as_float(bf[i][w] & 0xffff0000u)} + tied_f2{da, da};
@@ -246,15 +255,15 @@ __global__ __launch_bounds__(64) void tied_bound8_kernel(const unsigned short* _
     };
 #pragma unroll
     for (int j = 0; j < NBUF - 1; ++j)
-        fetch(buf[j], nk + j * B);
+        fetch(buf[j], nr + j * B);
 #pragma unroll 1
     for (int r = 0; r < kTiedNear; r += NBUF * B) {  // (a rolled loop: unrolled, the scheduler lifts all 64 loads to the top -- 394 registers)
 #pragma unroll
         for (int j = 0; j < NBUF; ++j) {
             const int nxt = r + (j + NBUF - 1) * B;  // the batch NBUF - 1 ahead goes into the buffer summed last
             if (nxt < kTiedNear)
-                fetch(buf[(j + NBUF - 1) % NBUF], nk + nxt);
-            sum(buf[j], nd + r + j * B);
+                fetch(buf[(j + NBUF - 1) % NBUF], nr + nxt);
+            sum(buf[j], nr + r + j * B);
         }
     }
     if (!in)
@@ -292,7 +301,8 @@ __global__ __launch_bounds__(64 * kTiedListWaves) void tied_list_kernel(const fl
                                                                        const float* __restrict__ g_thr, const float* __restrict__ g_ln32, int K,
                                                                        int Kpad, int n_tiles, uint32_t* __restrict__ g_lk,
                                                                        float* __restrict__ g_ld, float* __restrict__ g_ll, int* __restrict__ g_ln,
-                                                                       unsigned long long* __restrict__ g_examined, unsigned long long examined) {
+                                                                       unsigned long long* __restrict__ g_examined, unsigned long long examined,
+                                                                       unsigned long long* __restrict__ g_near) {
     constexpr int    NWV = kTiedListWaves;
     __shared__ float s_thr[NWV];
     __shared__ int   s_cnt[NWV];
@@ -301,6 +311,9 @@ __global__ __launch_bounds__(64 * kTiedListWaves) void tied_list_kernel(const fl
     // the submitted triples on the host instead made the ratio wrong whenever the host ran ahead of the device)
     if (g_examined && t == 0 && threadIdx.x == 0)
         atomicAdd(g_examined, examined);
+    // the bound kernel has read the frame's near keys: back to the empty state, for the atomic minima of the next call
+    if (threadIdx.x < kTiedNear)
+        g_near[(size_t)t * kTiedNear + threadIdx.x] = kTiedNearInit;
     float thr = -__builtin_inff();
     for (int j = threadIdx.x; j < n_tiles; j += 64 * NWV)
         thr = fmaxf(thr, g_thr[(size_t)t * n_tiles + j]);
@@ -748,8 +761,9 @@ extern "C" int amx_internal_gmm_tied_create(int K, int n_mix, int mix_pad, const
 namespace {
 constexpr int kTiedFrames = 4096;  // frames per pass of amx_internal_gmm_tied_score: bounds the workspace
 struct TiedWs {
-    float *             dt, *ld, *ll, *thr, *thr_m, *nd;
-    uint32_t *          lk, *nk;
+    float *             dt, *ld, *ll, *thr, *thr_m;
+    uint32_t*           lk;
+    unsigned long long* near;  // [kTiedFrames][kTiedNear] keys, FIRST and of fixed size: its place and its empty state survive calls of any shape
     int*                ln;
     unsigned long long* mask;
     size_t              bytes;
@@ -759,7 +773,9 @@ TiedWs tied_ws(void* base, int K, int T, int mix_pad) {
     auto         al = [](size_t b) { return (b + 255) & ~(size_t)255; };
     char*        p  = (char*)base;
     TiedWs       w;
-    T    = std::min(T, kTiedFrames);
+    T      = std::min(T, kTiedFrames);
+    w.near = (unsigned long long*)p;
+    p += al((size_t)kTiedFrames * amx::kTiedNear * 8);
     w.dt = (float*)p;
     p += al((size_t)T * Kpad * 4);
     w.lk = (uint32_t*)p;
@@ -774,10 +790,6 @@ TiedWs tied_ws(void* base, int K, int T, int mix_pad) {
     p += al((size_t)T * n_tiles * 4);
     w.thr_m = (float*)p;
     p += al((size_t)T * mix_pad * 4);
-    w.nd = (float*)p;
-    p += al((size_t)T * amx::kTiedNear * 4);
-    w.nk = (uint32_t*)p;
-    p += al((size_t)T * amx::kTiedNear * 4);
     w.mask = (unsigned long long*)p;
     p += al((size_t)T * (Kpad / 64) * tiles_pad * 8);
     w.bytes = (size_t)(p - (char*)base);
@@ -795,10 +807,22 @@ extern "C" float* amx_internal_gmm_tied_dt(void* workspace, int K, int T, int ha
     return have_positions && T <= kTiedFrames ? tied_ws(workspace, K, T, 64).dt : nullptr;
 }
 
+// the near keys of a workspace (gmm_dist_list_kernel keeps the minima itself when the build has 64 classes = its lanes), and their
+// empty state, to be set once per allocation and after a failed call
+extern "C" unsigned long long* amx_internal_gmm_tied_near(void* workspace) {
+    return amx::kTiedNear == 64 ? (unsigned long long*)workspace : nullptr;
+}
+extern "C" int amx_internal_gmm_tied_near_init(amx_ctx* ctx, void* workspace) {
+    const int n = kTiedFrames * amx::kTiedNear;
+    hipLaunchKernelGGL(amx::tied_near_init_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, (unsigned long long*)workspace, n);
+    AMX_HIP(hipGetLastError());
+    return AMX_OK;
+}
+
 extern "C" int amx_internal_gmm_tied_score(amx_ctx* ctx, const float* dist_dev, const uint32_t* k_dens_dev, int K, int T, int Tpad, int n_mix,
                                            int mix_pad, const unsigned short* aup, const float* amax, const float* m2lw_t, const float* ahat_t,
                                            const double* ln64, const float* ln32, const float* amin, void* workspace, float* scores,
-                                           uint32_t* best, unsigned long long* survivors_dev, int dt_written) {
+                                           uint32_t* best, unsigned long long* survivors_dev, int dt_written, int near_written) {
     if (T <= 0)
         return AMX_OK;
     const int    Kpad = (K + 63) & ~63, n_tiles = mix_pad / 64, tiles_pad = (n_tiles + 63) & ~63;
@@ -811,19 +835,20 @@ extern "C" int amx_internal_gmm_tied_score(amx_ctx* ctx, const float* dist_dev, 
         if (!dt_written)  // (gmm_dist_kernel wrote w.dt: amx_internal_gmm_tied_dt)
             hipLaunchKernelGGL(amx::tied_transpose_kernel, dim3(Kpad / 64, (Tc + 63) / 64), dim3(256), 0, ctx->stream, dist_dev + t0, k_dens_dev,
                                K, Kpad, Tc, Tpad - t0, Tpad, w.dt);
-        hipLaunchKernelGGL(amx::tied_near_kernel, dim3(Tc), dim3(amx::kTiedNearThreads), 0, ctx->stream, w.dt, K, Kpad, w.nd, w.nk);
+        if (!(dt_written && near_written))
+            hipLaunchKernelGGL(amx::tied_near_kernel, dim3(Tc), dim3(amx::kTiedNearThreads), 0, ctx->stream, w.dt, K, Kpad, w.near);
         const int bound_spx = ((mix_pad / 2 + 255) / 256 + 7) / 8;   // 1 KB segments of a table row per XCD
         if ((unsigned long long)K * (unsigned long long)mix_pad * 2ull < (1ull << 32)) {
             const int segs = (mix_pad + 511) / 512, fixed = segs / 8, rest = segs % 8;
-            hipLaunchKernelGGL(amx::tied_bound8_kernel, dim3(8 * (fixed * Tc + (rest * Tc + 7) / 8)), dim3(64), 0, ctx->stream, aup, amax, w.nd,
-                               w.nk, n_mix, mix_pad, n_tiles, w.thr, w.thr_m, Tc, fixed, rest);
+            hipLaunchKernelGGL(amx::tied_bound8_kernel, dim3(8 * (fixed * Tc + (rest * Tc + 7) / 8)), dim3(64), 0, ctx->stream, aup, amax,
+                               (const uint2*)w.near, n_mix, mix_pad, n_tiles, w.thr, w.thr_m, Tc, fixed, rest);
         }
         else
-            hipLaunchKernelGGL(amx::tied_bound_kernel, dim3(8 * bound_spx * Tc), dim3(256), 0, ctx->stream, aup, amax, w.nd, w.nk, n_mix, mix_pad,
+            hipLaunchKernelGGL(amx::tied_bound_kernel, dim3(8 * bound_spx * Tc), dim3(256), 0, ctx->stream, aup, amax, (const uint2*)w.near, n_mix, mix_pad,
                                n_tiles, w.thr, w.thr_m, bound_spx);
         hipLaunchKernelGGL(amx::tied_list_kernel, dim3(Tc), dim3(64 * amx::kTiedListWaves), 0, ctx->stream, w.dt, amin + (size_t)n_tiles * Kpad, w.thr, ln32, K, Kpad,
                            n_tiles, w.lk, w.ld, w.ll, w.ln, survivors_dev ? survivors_dev + amx::kTiedCounters : nullptr,
-                           (unsigned long long)K * (unsigned long long)Tc * (unsigned long long)n_tiles);
+                           (unsigned long long)K * (unsigned long long)Tc * (unsigned long long)n_tiles, w.near);
         hipLaunchKernelGGL(amx::tied_mask_kernel, dim3(tiles_pad / 64, Tc), dim3(64 * amx::kTiedMaskWaves), 0, ctx->stream, w.lk, w.ld, w.ln,
                            amin_t, w.thr, Kpad, n_tiles, tiles_pad, (unsigned short*)w.mask);
         hipLaunchKernelGGL(amx::tied_pruned_kernel, dim3(8 * Tc, (n_tiles + 7) / 8), dim3(64), 0, ctx->stream, w.mask, w.lk, w.ld, w.ll, w.ln,

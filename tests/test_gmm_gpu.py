@@ -1098,10 +1098,45 @@ def test_tied_list_order_distances(ctx, dim, n_dens, T, contract, monkeypatch):
         if T > 8:
             x[3] *= 25.0
         osc, ob = OracleGmm(model, contract=contract).score(x, mode=0)
-        for dl in ("dist_list=1", "dist_list=0", "dist_list=2", "dist_list=16", "dist_list=64"):
+        for dl in ("dist_list=1", "dist_list=0", "dist_list=2", "dist_list=16", "dist_list=64", "near_fused=0"):
             sc, best = rasr_amd.GmmFeatureScorer(ctx, model, tuning="tied_prune=1,contract=%s,%s" % (contract, dl)).score(x)
             assert np.array_equal(sc.view(np.uint32), osc.view(np.uint32)), (dl, pooled, np.abs(sc - osc).max())
             assert np.array_equal(best, ob), (dl, pooled)
+
+
+def test_tied_near_keys_survive_calls_of_any_shape(ctx):
+    """the list-order distance kernel keeps the frame's near densities as atomic minima over 64-bit keys that tied_list_kernel puts
+    back into their empty state: calls of different lengths on ONE scorer (more frames, fewer, more again; device buffers, so that
+    repeated calls are graph replays), NaN / inf frames in between, and a second scorer created and dropped in between -- every
+    result bit-exact; then the same sequence with the keys from tied_near_kernel (near_fused=0)"""
+    import torch
+
+    import rasr_amd
+    from oracle import OracleGmm
+    model = synth.gmm_tied(300, 700, 40, seed=955, pooled=True)
+    orc = OracleGmm(model)
+    ctx.use_torch_stream()
+    for tuning in ("tied_prune=1", "tied_prune=1,near_fused=0"):
+        sc = rasr_amd.GmmFeatureScorer(ctx, model, tuning=tuning)
+        for rep, T in enumerate((256, 31, 256, 256, 256, 1, 700, 256, 256)):
+            x = feats(T, 40, 956 + rep)
+            if rep == 4:
+                x[7, 3] = np.nan
+                x[9, 0] = np.inf
+            xd = torch.from_numpy(x).cuda()
+            scores = torch.empty((T, 300), dtype=torch.float32, device="cuda")
+            best = torch.empty((T, 300), dtype=torch.int32, device="cuda")
+            for _ in range(3):                              # plain, recorded, replayed
+                scores.fill_(-1.0)
+                sc.score_dev(xd, T, scores, best)
+            torch.cuda.synchronize()
+            osc, ob = orc.score(x, mode=0)
+            assert np.array_equal(scores.cpu().numpy().view(np.uint32), osc.view(np.uint32)), (tuning, rep, T)
+            assert np.array_equal(best.cpu().numpy().astype(np.uint32), ob), (tuning, rep, T)
+            if rep == 2:
+                other = rasr_amd.GmmFeatureScorer(ctx, synth.gmm_tied(64, 128, 40, seed=957, pooled=True), tuning="tied_prune=1")
+                other.score(feats(50, 40, 958))
+                del other
 
 
 # ---- gmm_fused_kernel (gmm_fused.hip): screen + exact evaluation in one kernel, pooled covariance, dim <= 40
