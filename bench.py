@@ -866,11 +866,11 @@ class GmmOnly:
             ops = 2.0 * self.nk * self.T
             surv, triples = self.sc.screen_counts(True)
             if triples:
-                # pruned path (gmm_tied.hip): the time goes into reading rows of the 164 MB weight table at random -- 32 near rows per
+                # pruned path (gmm_tied.hip): the time goes into reading rows of the 164 MB weight table at random -- 64 near rows per
                 # frame for the bounds (whole rows of its bf16 image: every mixture) and one 256-byte row per surviving (density, frame, tile) triple --
                 # plus the scores and density indices that leave.  `achieved` = those bytes / time of the four kernels.
                 # `frac` follows SURVEY 8(d): the weight table once per batch (sum K_m x 4 B = 164 MB) + scores and density indices out
-                # (8 B per frame and mixture) over the time of the scorer's kernels.  The rows the pruned kernel really touches -- 32 near
+                # (8 B per frame and mixture) over the time of the scorer's kernels.  The rows the pruned kernel really touches -- 64 near
                 # rows per frame for the bounds (whole rows of the bf16 image) and one 256-byte row per surviving (density, frame, tile)
                 # triple, mostly L2 hits -- are reported next to it as l2_rows_GBps.
                 launches = triples / float(4096 * self.T * 157) if self.T else 1.0
@@ -879,12 +879,12 @@ class GmmOnly:
                 ms_d, n_d = self.ctx.profile_get("gmm_dist")     # the distance kernel the `kernel` string names belongs to the time
                 ms_combine, ms = ms, ms + (ms_d if n_d else 0.0)
                 gbs = by / (ms * 1e-3) / 1e9
-                return dict(bound="hbm", kernel="tied_pruned_kernel + tied_bound_kernel + gmm_dist_kernel (+ tied_mask / tied_transpose / tied_list / tied_near)",
+                return dict(bound="hbm", kernel="tied_pruned_kernel + tied_bound8_kernel + gmm_dist_list_kernel (+ tied_mask / tied_list; tied_near / tied_transpose off the list-order path)",
                             note="exact pruning: bounds from 64 near densities per frame, then the reference's f64 rule over the surviving "
                                  "(density, frame, 64-mixture tile) triples only; algorithmic bytes = weight table once per batch + results",
                             achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4), traffic=None,
                             avg_launch_ms=round(ms, 4), launches=n, bytes_per_launch=by,
-                            time_is="gmm_dist (%.4f ms) + gmm_combine (%.4f ms: near / bound / list / mask / pruned kernels)" % (ms - ms_combine, ms_combine),
+                            time_is="gmm_dist (%.4f ms: distances and the near densities) + gmm_combine (%.4f ms: bound / list / mask / pruned kernels)" % (ms - ms_combine, ms_combine),
                             l2_rows_GBps=round(rows / (ms * 1e-3) / 1e9, 1),
                             surviving_fraction=round(surv / float(triples), 5),
                             dense_equivalent_tops=round(ops / (ms * 1e-3) / 1e12, 2),
