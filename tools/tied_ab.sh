@@ -2,7 +2,9 @@
 # tools/tied_ab.sh -- BASELINE config 3, tied instance (4096 shared densities x 10 000 states, batch 256): variants that change the COUNT of
 # survivors the pruned scorer walks, not its schedule (round-5 review, item 4).  Per variant: the tied tests against the oracle (bit-exact),
 # bench.py --workload gmm-tied in steady state, rocprofv3 kernel averages.  Libraries: tools/build/librasr_amd_near{16,32,128}.so =
-# -DAMX_TIED_NEAR=16 | 32 | 128 (near densities per frame behind the bounds U; default 64 since round 6).  Writes gpurun_out/r06/tied_ab.log.
+# -DAMX_TIED_NEAR=16 | 32 | 128 (near densities per frame behind the bounds U; default 64 since round 6), built before the gpurun call by
+#   for n in 16 32 128; do make -C rasr_amd/csrc OBJDIR=build_near$n OUT=../../tools/build/librasr_amd_near$n.so EXTRA=-DAMX_TIED_NEAR=$n; done
+# (git-ignored; builds without 64 classes take tied_near_kernel instead of the distance kernel's atomic minima).  Writes gpurun_out/r06/tied_ab.log.
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/r06/tied_ab.log
 mkdir -p $root/gpurun_out/r06
