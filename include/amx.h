@@ -365,7 +365,8 @@ typedef struct {
      * wave-specialised kernel), fr=2|4|8|16 (frames per workgroup of the uniform tied kernel), simd_mfma=0 (SIMD / batch-int scorers
      * without the i8 matrix kernel), dist_list=0 (pruned tied scorer: distances from the density-major kernel instead of the
      * list-order one; N >= 2: N frames per wave of the list-order kernel), near_fused=0 (the frame's near densities from
-     * tied_near_kernel instead of the list-order kernel's atomic minima). */
+     * tied_near_kernel instead of the list-order kernel's atomic minima), fused_pack=0 (gmm_fused_kernel reads operand rows packed by
+     * gmm_screen_pack_kernel instead of packing its own). */
     const char*     tuning;
 } amx_gmm_model;
 

@@ -96,7 +96,7 @@ struct Tuning {
 
 // keys of amx_gmm_model.tuning (gmm.hip and gmm_simd.hip parse the same string)
 static const char* const gmm_tuning_keys[] = {"screen", "fused", "screen_all", "screen_kernel", "graph", "tied_prune", "chunk", "fused_waves", "fr",
-                                              "simd_mfma", "contract", "dist_list", "near_fused", nullptr};
+                                              "simd_mfma", "contract", "dist_list", "near_fused", "fused_pack", nullptr};
 
 // the ONE source of a fused multiply-add outside the GMM scorers (gmm_device.hpp has sq_acc<FMA>): a * b + c as the reference's
 // default build computes it at a contracted site (FMA) or with two roundings (the library is compiled with -ffp-contract=off)

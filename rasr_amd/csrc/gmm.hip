@@ -1665,7 +1665,7 @@ struct amx_gmm {
     int                                use_graphs = 1;
     // amx_gmm_model.tuning (A/B runs, tests)
     int         tune_screen = 1, tune_fused = 1, tune_screen_all = 0, tune_tied_prune = -1, tune_chunk = 65536, tune_fused_waves = 0, tune_fr = 8,
-                tune_simd_mfma = 1, tune_dist_list = 1, tune_near_fused = 1;
+                tune_simd_mfma = 1, tune_dist_list = 1, tune_near_fused = 1, tune_fused_pack = 1;
     std::string tune_screen_kernel = "rows";
     // amx_gmm_model.tuning contract=fma: the distance's `sum += df * df` as one fused multiply-add = the reference's default build
     // (-march=native on an FMA host); off (default) = the reference built with -DMARCH=x86-64.  Not a speed switch: it selects WHICH
@@ -1734,7 +1734,7 @@ extern "C" int amx_internal_gmm_fused_split(int n_cu, int Tpad, int n_tiles, int
 extern "C" int amx_internal_gmm_fused_score(amx_ctx* ctx, int dim, const void* rec_dev, const float* isr_dev, const float* feats, const void* X,
                                             const float* nx, const float* q, int T, int Tpad, int n_mix, int n_tiles, int split, float* scores,
                                             uint32_t* best, float* pmin, unsigned* pidx, int part_ld, unsigned long long* survivors, int forced_waves,
-                                            int best_bytes, int contract_fma);
+                                            int best_bytes, int contract_fma, float na_all);
 extern "C" int amx_internal_gmm_fused_waves(int Tpad, int forced_waves);
 
 // maximum approximation through the MFMA screen (see gmm_screen_kernel); frames in chunks that bound the mask workspace
@@ -1773,7 +1773,9 @@ int score_screened(amx_gmm* h, const float* feats_dev, int T, float* scores_dev,
         const float*       x = feats_dev + (size_t)t0 * h->dim;
         amx::GmmScreenDims d{Tc, Tpad, h->dim, h->scr_Kp, h->scr_Mpad16, h->pooled ? 1 : 0, h->scr_rmax2,
                              std::sqrt((float)(h->pooled ? h->dim : 2 * h->dim)), h->scr_na_all};
-        {
+        // the fused kernel packs its own operand rows (fused_pack=1, default; the wave-specialised lab kernel reads packed rows)
+        const bool own_pack = fused && h->tune_fused_pack && h->tune_fused_waves != 13;
+        if (!own_pack) {
             amx::ScopedKernelTimer timer(h->ctx, "gmm_screen_pack");
             hipLaunchKernelGGL(amx::gmm_screen_pack_kernel, dim3(Tpad / 4), dim3(256), 0, st, x, h->d_isr, h->d_scr_X, h->d_scr_nx, h->d_scr_q, d);
         }
@@ -1799,11 +1801,11 @@ int score_screened(amx_gmm* h, const float* feats_dev, int T, float* scores_dev,
             }
             {
                 amx::ScopedKernelTimer timer(h->ctx, "gmm");
-                int r = amx_internal_gmm_fused_score(h->ctx, h->dim, h->d_fus_rec, h->d_isr, x, h->d_scr_X, h->d_scr_nx, h->d_scr_q, Tc, Tpad,
+                int r = amx_internal_gmm_fused_score(h->ctx, h->dim, h->d_fus_rec, h->d_isr, x, own_pack ? nullptr : h->d_scr_X, h->d_scr_nx, h->d_scr_q, Tc, Tpad,
                                                      h->n_mix, n_tiles, split, scores_dev + (size_t)t0 * h->n_mix,
                                                      best_dev ? (uint32_t*)((char*)best_dev + (size_t)t0 * h->n_mix * best_bytes) : nullptr, pmin,
                                                      pidx, Tpad, h->count_survivors ? h->d_fus_surv : nullptr, h->tune_fused_waves, best_bytes,
-                                                     h->contract_fma ? 1 : 0);
+                                                     h->contract_fma ? 1 : 0, h->scr_na_all);
                 if (r != AMX_OK)
                     return r;
                 if (h->count_survivors)
@@ -2053,7 +2055,7 @@ int amx_gmm_create(amx_ctx* ctx, const amx_gmm_model* m, amx_gmm** out) {
     if (!tune.parse(m->tuning, amx::gmm_tuning_keys, "amx_gmm_create"))
         return AMX_ERR_INVALID;
     // values are checked like keys: a typo must not silently select the default kernel (or the other arithmetic)
-    int         t_screen, t_fused, t_screen_all, t_tied_prune, t_chunk, t_fused_waves, t_fr, t_simd_mfma, t_graph, t_dist_list, t_near_fused;
+    int         t_screen, t_fused, t_screen_all, t_tied_prune, t_chunk, t_fused_waves, t_fr, t_simd_mfma, t_graph, t_dist_list, t_near_fused, t_fused_pack;
     std::string t_screen_kernel, t_contract;
     static const char* const screen_kernels[] = {"rows", "persist", "simple", nullptr};
     static const char* const contracts[]      = {"off", "fma", nullptr};
@@ -2063,7 +2065,7 @@ int amx_gmm_create(amx_ctx* ctx, const amx_gmm_model* m, amx_gmm** out) {
         !tune.get_int("chunk", 65536, 256, 1 << 24, &t_chunk, who) || !tune.get_int("fused_waves", 0, 0, 16, &t_fused_waves, who) ||
         !tune.get_int("fr", 8, 2, 16, &t_fr, who) || !tune.get_int("simd_mfma", 1, 0, 1, &t_simd_mfma, who) ||
         !tune.get_int("graph", 1, 0, 1, &t_graph, who) || !tune.get_int("dist_list", 1, 0, 64, &t_dist_list, who) ||
-        !tune.get_int("near_fused", 1, 0, 1, &t_near_fused, who) || !tune.get_word("screen_kernel", "rows", screen_kernels, &t_screen_kernel, who) ||
+        !tune.get_int("near_fused", 1, 0, 1, &t_near_fused, who) || !tune.get_int("fused_pack", 1, 0, 1, &t_fused_pack, who) || !tune.get_word("screen_kernel", "rows", screen_kernels, &t_screen_kernel, who) ||
         !tune.get_word("contract", ctx && ctx->contract == AMX_CONTRACT_FMA ? "fma" : "off", contracts, &t_contract, who))   // no key: the context's arithmetic (amx_set_contract)
         return AMX_ERR_INVALID;
     AMX_REQUIRE(t_fused_waves == 0 || t_fused_waves == 8 || t_fused_waves == 12 || t_fused_waves == 13 || t_fused_waves == 16, AMX_ERR_INVALID,
@@ -2083,6 +2085,7 @@ int amx_gmm_create(amx_ctx* ctx, const amx_gmm_model* m, amx_gmm** out) {
     h->tune_simd_mfma     = t_simd_mfma;
     h->tune_dist_list     = t_dist_list;
     h->tune_near_fused    = t_near_fused;
+    h->tune_fused_pack    = t_fused_pack;
     h->tune_screen_kernel = t_screen_kernel;
     h->use_graphs         = t_graph;
     h->contract_fma       = t_contract == "fma";

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(NW * 64) void gmm_fused_kernel(const float* __restr
                                                         float* __restrict__ g_scores, uint32_t* __restrict__ g_best, int T, int Tpad,
                                                         int n_mix, int n_tiles, int r_split, float* __restrict__ g_part_min,
                                                         unsigned* __restrict__ g_part_idx, int part_ld,
-                                                        unsigned long long* __restrict__ g_survivors) {
+                                                        unsigned long long* __restrict__ g_survivors, float na_all) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int LD = fused_ld(DIM), REC = fused_rec_bytes(DIM), NP = REC / 1024;
 #ifdef FUSED_ISSUE_ALL
@@ -152,10 +152,44 @@ __global__ __launch_bounds__(NW * 64) void gmm_fused_kernel(const float* __restr
     constexpr int KS = (DIM + 2 + 15) / 16;
     static_assert(KS >= 1 && KS <= 4, "screen operand rows hold 64 columns");
     fus_f16x8 bx[KS];
+    float     nx, q;
+    if (g_X) {
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-        bx[ks] = *(const fus_f16x8*)(g_X + (size_t)tx * 64 + (ks * 2 + fk) * 8);
-    const float nx = g_nx[tx], q = g_q[tx];
+        for (int ks = 0; ks < KS; ++ks)
+            bx[ks] = *(const fus_f16x8*)(g_X + (size_t)tx * 64 + (ks * 2 + fk) * 8);
+        nx = g_nx[tx];
+        q  = g_q[tx];
+    }
+    else {
+        // Round 6: the lane packs its frame's operand row itself (gmm_screen_pack_kernel's arithmetic on the row it already holds: a
+        // launch and ~5 us less in front of a decoder-sized batch).  v = x / sigma, the f16 image of v, columns DIM and DIM + 1 = 1
+        // against the constant's c_hi + c_lo, ||row|| and the residual norm behind the threshold's error bound; a frame behind the
+        // last one packs zeros.  The two norms are summed in index order here and by a butterfly there: both are sums of 40
+        // non-negative terms, a few ulp apart, under a threshold that is twice its bound.
+        float n2 = 0.f, qq = 0.f, r2 = 0.f;
+        bool  fits = true;
+        _Float16 hv[KS * 16];
+#pragma unroll
+        for (int i = 0; i < KS * 16; ++i) {
+            float v = 0.f;
+            if (i < DIM)
+                v = live ? x[i] * g_isr[i] : 0.f;
+            fits &= fabsf(v) <= 65504.f;  // false for NaN as well
+            const _Float16 h = (_Float16)v;
+            const float    r = (float)h;
+            n2 += r * r;
+            r2 += (v - r) * (v - r);
+            qq += v * v;
+            hv[i] = (i == DIM || i == DIM + 1) ? (_Float16)(live ? 1.f : 0.f) : h;
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                bx[ks][e] = fk ? hv[(ks * 2 + 1) * 8 + e] : hv[ks * 16 + e];
+        nx = fits ? sqrtf(n2) : __builtin_inff();
+        q  = 1.6e-5f * qq + na_all * (sqrtf(r2) * 1.00001f);
+    }
     const bool  all = !(nx < __builtin_inff());  // operand row did not fit f16: keep every slot
     // stores of 16 bytes need aligned rows; otherwise (and on the model's last, partial tile) scalar guarded stores
     const bool wide_ok = (n_mix & (BEST == 2 ? 7 : 3)) == 0 && ((uintptr_t)g_scores & 15) == 0 &&
@@ -849,7 +883,7 @@ extern "C" int amx_internal_gmm_fused_split(int n_cu, int Tpad, int n_tiles, int
 extern "C" int amx_internal_gmm_fused_score(amx_ctx* ctx, int dim, const void* rec_dev, const float* isr_dev, const float* feats,
                                             const void* X, const float* nx, const float* q, int T, int Tpad, int n_mix, int n_tiles,
                                             int split, float* scores, uint32_t* best, float* pmin, unsigned* pidx, int part_ld,
-                                            unsigned long long* survivors, int forced_waves, int best_bytes, int contract_fma) {
+                                            unsigned long long* survivors, int forced_waves, int best_bytes, int contract_fma, float na_all) {
     const int   nw = fused_waves(Tpad, forced_waves), fpw = fused_frames(Tpad, forced_waves), ntt = (Tpad + fpw - 1) / fpw;
     const int   lds = 2 * amx::fused_rec_bytes(dim);
     const char* rec = (const char*)rec_dev;
@@ -859,7 +893,7 @@ extern "C" int amx_internal_gmm_fused_score(amx_ctx* ctx, int dim, const void* r
         auto k = contract_fma ? amx::gmm_fused_kernel<D, B, W, true> : amx::gmm_fused_kernel<D, B, W, false>;                   \
         hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);                                   \
         hipLaunchKernelGGL(k, dim3(ntt * split), dim3(W * 64), lds, st, feats, (const _Float16*)X, nx, q, rec, isr_dev, scores,  \
-                           best, T, Tpad, n_mix, n_tiles, split, pmin, pidx, part_ld, survivors);                          \
+                           best, T, Tpad, n_mix, n_tiles, split, pmin, pidx, part_ld, survivors, na_all);                  \
     }
 #define AMX_FUSED_SPEC(D, B, E)                                                                                                 \
     {                                                                                                                           \
@@ -881,6 +915,10 @@ extern "C" int amx_internal_gmm_fused_score(amx_ctx* ctx, int dim, const void* r
         else if (nw == 12) AMX_FUSED_LAUNCH(D, 0, 12)                                                                           \
         else AMX_FUSED_LAUNCH(D, 0, 8)                                                                                          \
     } break;
+    if (nw == 13 && !X) {
+        amx::set_error("gmm fused scorer: the specialised-wave kernel (fused_waves=13) reads packed operand rows (fused_pack=0)");
+        return AMX_ERR_UNSUPPORTED;
+    }
     if (nw == 13 && contract_fma) {
         amx::set_error("gmm fused scorer: the specialised-wave kernel (fused_waves=13) exists for contract=off only");
         return AMX_ERR_UNSUPPORTED;

@@ -1218,6 +1218,33 @@ def test_fused_shapes_exact(ctx, n_mix, T):
 
 
 @pytest.mark.parametrize("dim", [16, 24, 32, 33, 39, 40])
+@pytest.mark.parametrize("contract", ["off", "fma"])
+def test_fused_kernel_packs_its_own_operand_rows(ctx, dim, contract):
+    """gmm_fused_kernel packs the frames' f16 operand rows itself (round 6; fused_pack=0: the rows gmm_screen_pack_kernel wrote): both
+    forms bit-exact against the oracle, with frames that do not fit f16 (every slot kept), NaN / inf frames, a frame count that leaves
+    lanes behind the last frame, and equal survivor statistics within a few borderline densities (the two forms sum the row norms in
+    a different order)"""
+    import rasr_amd
+    from oracle import OracleGmm
+    model = synth.gmm_cart(83, 1, 16, dim, seed=470 + dim, pooled=True)
+    x = feats(333, dim, 471)
+    x[5] *= np.float32(3e5)                     # v = x / sigma beyond 65504
+    x[6, 1] = np.nan
+    x[7, 0] = np.inf
+    x[8] = 0.0
+    osc, ob = OracleGmm(model, contract=contract).score(x, mode=0)
+    counts = []
+    for pack in ("1", "0"):
+        sc = rasr_amd.GmmFeatureScorer(ctx, model, tuning="contract=%s,fused_pack=%s" % (contract, pack))
+        sc.screen_counts(True)
+        got, best = sc.score(x)
+        assert np.array_equal(got.view(np.uint32), osc.view(np.uint32)), (pack, np.abs(got - osc).max())
+        assert np.array_equal(best, ob), pack
+        counts.append(sc.screen_counts(True))
+    assert counts[0][1] == counts[1][1] and abs(counts[0][0] - counts[1][0]) <= 8, counts
+
+
+@pytest.mark.parametrize("dim", [16, 24, 32, 33, 39, 40])
 def test_fused_adversarial_twins(ctx, dim):
     """twin densities / one-ulp weight neighbours: the further survivors of a mixture go through the divergent loop in slot order"""
     model = _cart_adversarial(410 + dim, 83, dim, True)
