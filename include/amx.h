@@ -571,7 +571,8 @@ typedef struct {
      * Kernel selection for A/B runs and tests -- every tile configuration of a precision gives bit-identical scores: tile=N (GEMM tile
      * configuration: 0 128x128, 2 256x256 with all waves in phase, 8 256x256 with the ping-pong K loop (f16mx; the default for large
      * batches since round 5), 9 256x256 with ONE self-pipelined wave per SIMD (f16mx; measured 6 % behind 8, opt-in), 3 128x64 one tile per
-     * CU, 6 128x64 two per CU, 4 / 5 / 7 K-loop variants of 2; default by layer shape),
+     * CU, 6 128x64 two per CU, 4 / 5 / 7 K-loop variants of 2, 11 / 12 K-loop variants of 3, 14 (f16mx) hidden layers on 64x64 tiles with four
+     * K-tiles per barrier -- the default for fills that leave half the CUs without a 128x64 tile; default by layer shape),
      * graph=0 (no HIP-graph replay of small batches), persistent=0, group=TxN (tiles per XCD-aware super-tile), chunk=N (frames per
      * internal pass, >= 256), stagger=N (f16mx output layer of a large batch: XCD x starts x * N * 10 ns late; default 0). */
     const char*         tuning;

@@ -1716,6 +1716,7 @@ using MfgS = amx::mx::MxCfg<128, 64, 2, 2, 8, 0, 0, 2>;  // 147 KB: small batche
 using MfgS4 = amx::mx::MxCfg<128, 64, 2, 2, 4>;          //  74 KB, one K-tile per barrier, three in flight (tuning tile=6: A/B runs)
 using MfgSL = amx::mx::MxCfg<128, 64, 2, 2, 8, 0, 0, 2, 4>;  // hidden layers: MfgS + four loader waves (512 threads: a computing and a loading wave per SIMD)
 using MfgS8 = amx::mx::MxCfg<128, 64, 4, 2, 8, 0, 0, 2>;  // round 6 (tile=12): the one-tile-per-CU tile on EIGHT computing waves of 32 x 32 (two per SIMD: one wave's reads and conversions under the other's products), every wave issuing its share of the DMA
+using Mfg64 = amx::mx::MxCfg<64, 64, 2, 2, 8, 0, 0, 4, 4>;    // round 6 (tile=14): 64 x 64 tiles with loader waves, FOUR K-tiles per barrier (96 KB ring): hidden layers of fills that leave half the CUs without a 128 x 64 tile
 using MfgSP = amx::mx::MxCfg<128, 64, 2, 2, 8, 0, 0, 2, 4, 3>;  // round 6, the default for hidden layers of small batches: MfgSL with the READ-AHEAD K loop (two register images, conversions issued first, a steady-state body without run-time wait selection); MfgSL stays as tile=11
 
 template<class C, int ACT, bool LAST>
@@ -1833,6 +1834,12 @@ void launch_mx_cfg(amx_ffnn* h, int l, const void* x, int xkts, void* out, int l
             // everything is resident at once -- output layer at 256 frames 87 -> 42 us (profiles/r05/fill_breakdown.log); the same
             // K order, the same matrix instructions: bit-identical
             cfg = 6;
+        else if (!LAST && 2 * t64 <= ncu && h->mx_ksplit <= 1)  // (ksplit is the 128 x 64 tile's: a handle that asked for it keeps that tile)
+            // at most half a tile of 128 x 64 per CU (a hidden layer of a 256- or 512-frame fill): 64 x 64 tiles, four K-tiles per
+            // barrier -- twice the workgroups, half the iterations; 29.5 -> 27.7 us per 2048 x 2048 layer (hidden_layer_probe; two / three K-tiles
+            // per barrier on the same tile: 29.3 / 28.3 us; 128 x 64 with four spills, 64 x 128 spills), the same
+            // K order and matrix instructions per accumulator: bit-identical
+            cfg = 14;
         else
             cfg = 3;
     }
@@ -1851,7 +1858,13 @@ void launch_mx_cfg(amx_ffnn* h, int l, const void* x, int xkts, void* out, int l
             break;
         case 6: launch_mx<MfgS4, ACT, LAST>(h, l, x, xkts, out, ldo, T, Tpad, n_valid); break;
         case 12: launch_mx<MfgS8, ACT, LAST>(h, l, x, xkts, out, ldo, T, Tpad, n_valid); break;
-        case 11:   // round 5's hidden-layer loop (no read-ahead): A/B runs
+        case 14:
+            if constexpr (LAST)
+                launch_mx<MfgS, ACT, LAST>(h, l, x, xkts, out, ldo, T, Tpad, n_valid);
+            else
+                launch_mx<Mfg64, ACT, LAST>(h, l, x, xkts, out, ldo, T, Tpad, n_valid);
+            break;
+case 11:   // round 5's hidden-layer loop (no read-ahead): A/B runs
             if constexpr (LAST)
                 launch_mx<MfgS, ACT, LAST>(h, l, x, xkts, out, ldo, T, Tpad, n_valid);
             else
@@ -1997,7 +2010,7 @@ int amx_ffnn_create(amx_ctx* ctx, const amx_ffnn_model* m, amx_ffnn** out) {
             return AMX_ERR_INVALID;
         AMX_REQUIRE(t_ksplit == 1 || t_ksplit == 4, AMX_ERR_INVALID, "amx_ffnn_create: tuning ksplit=%d: expected 1 | 4", t_ksplit);
         AMX_REQUIRE(t_ksplit == 1 || m->precision == AMX_PREC_F16MX, AMX_ERR_UNSUPPORTED, "amx_ffnn_create: tuning ksplit exists for AMX_PREC_F16MX only");
-        if (!tune.get_int("tile", -1, -1, 12, &t_tile, who) || !tune.get_int("graph", 1, 0, 1, &t_graph, who) ||
+        if (!tune.get_int("tile", -1, -1, 14, &t_tile, who) || !tune.get_int("graph", 1, 0, 1, &t_graph, who) ||
             !tune.get_int("persistent", 1, 0, 1, &t_persistent, who) || !tune.get_int("chunk", 32768, 256, 1 << 24, &t_chunk, who) ||
             !tune.get_int("mx_dbg", 0, 0, 1 << 16, &t_mx_dbg, who) || !tune.get_int("stagger", 0, 0, 100000, &t_stagger, who))
             return AMX_ERR_INVALID;

@@ -263,7 +263,7 @@ struct MxCfg {
     // K-tile's period on the barrier and the LDS round trip, not on arithmetic: with U = 2 a wave reads two K-tiles into two
     // register images behind ONE barrier and issues both sets of products (still in ascending K: bit-identical results).
     static constexpr int U = U_;
-    static_assert(U_ >= 1 && U_ <= 2 && STAGES_ >= 2 * U_, "ring: U K-tiles being read + at least U in flight");
+    static_assert(U_ >= 1 && U_ <= 4 && STAGES_ >= 2 * U_, "ring: U K-tiles being read + at least U in flight");
     static_assert(PF_ == 0 || (BN_ == 256 && BT_ == 256 && WN_ * WT_ == 8), "the prefetch walks whole 256-row blocks with six waves");
     // LW > 0 (hidden layers only): LW extra LOADER waves that issue every LDS-DMA piece and nothing else; the NW compute waves never
     // touch the address unit.  A piece holds its issuing wave ~85 cycles (tools/mx_timeline.py small: 850 of the 2450 cycles of a

@@ -161,7 +161,7 @@ def test_f16mx_tile_configurations_agree(ctx, monkeypatch, n_out):
     xd = torch.from_numpy(x).cuda()
     ctx.use_torch_stream()
     results = {}
-    for cfg in ("0", "3", "6", "2", "4", "5", "7", "8", "9", "11", "12"):   # 4 / 5 / 7 / 8 / 9: the 256 x 256 tile's K-loop variants (L2 prefetch, one issuing wave per SIMD, both, ping-pong halves, one self-pipelined wave per SIMD); 11: the one-tile-per-CU configuration without read-ahead (3 has it since round 6)
+    for cfg in ("0", "3", "6", "2", "4", "5", "7", "8", "9", "11", "12", "14"):   # 14: hidden layers on 64 x 64 tiles, four K-tiles per barrier (the default below half a tile of 128 x 64 per CU); 4 / 5 / 7 / 8 / 9: the 256 x 256 tile's K-loop variants (L2 prefetch, one issuing wave per SIMD, both, ping-pong halves, one self-pipelined wave per SIMD); 11: the one-tile-per-CU configuration without read-ahead (3 has it since round 6)
         nn = rasr_amd.NnBatchFeatureScorer(ctx, Ws, bs, acts, log_prior=logp, precision="f16mx", tuning="tile=" + cfg)
         sc = torch.full((8200, n_out), float("nan"), dtype=torch.float32, device="cuda")
         best = torch.zeros(8200, dtype=torch.int32, device="cuda")
@@ -177,7 +177,7 @@ def test_f16mx_tile_configurations_agree(ctx, monkeypatch, n_out):
     assert np.isfinite(ref[0]).all()
     assert np.array_equal(ref[1], ref[0].argmin(axis=1))
     assert np.array_equal(ref[2], 2 * np.bincount(ref[1], minlength=n_out))
-    for cfg in ("3", "6", "2", "4", "5", "7", "8", "9", "11", "12"):
+    for cfg in ("3", "6", "2", "4", "5", "7", "8", "9", "11", "12", "14"):
         got = results[cfg]
         assert np.array_equal(got[0].view(np.uint32), ref[0].view(np.uint32)), cfg
         assert np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2]), cfg
