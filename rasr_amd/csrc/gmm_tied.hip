@@ -6,7 +6,7 @@
 // densely: K x n_mix x T sums, twice.  But a density far from the frame cannot win in ANY mixture, and that can be proven
 // per (density, frame, 64-mixture tile) from small tables:
 //
-//   a^[k][m]     = fl32(m2lw[k][m] + logNorm[k])             (model; the bound kernel reads an f16 image rounded up, [K][mix_pad])
+//   a^[k][m]     = fl32(m2lw[k][m] + logNorm[k])             (model; the bound kernel reads a bf16 image rounded up, [K][mix_pad])
 //   amin[j][k]   = min over the mixtures of tile j of a^[k][m] (model, [n_tiles][Kpad]);  aminG[k] = min over all tiles
 //   U[t][m]      = min over 64 densities NEAR frame t (the closest density of each residue class k mod 64; 32 until round 6) of
 //                  s^_k = fl32(a^[k][m] + dist[k][t])         -- an upper bound of min_k s^_k, because it is a minimum over a subset
@@ -130,12 +130,11 @@ __global__ __launch_bounds__(kTiedNearThreads) void tied_near_kernel(const float
 
 // Thr[t][tile] and the mixtures' own thresholds: U = min over the frame's near densities of fl32(a^ + dist); the tile's threshold is
 // the maximum of U + tau' over its real mixtures.
-// The sums only have to bound the minimum from ABOVE, so the near rows are read from an f16 image of a^ that was rounded UP (a^_up >=
-// a^, hence fl32(a^_up + dist) >= fl32(a^ + dist); beyond 65504: +inf): half the bytes of the kernel's only real traffic, for a bound
-// that is at most 2^-10 |a^| looser (bf16 until late in round 6: 2^-7).
-// A lane takes TWO mixtures (one dword = two f16 per row): the near densities and their distances are wave-uniform scalars, so a row
-// costs the wave one load, two conversions, two sums and two minima for 128 mixtures.  64 mixtures = one tile = 32 lanes.
-typedef _Float16 tied_h2 __attribute__((ext_vector_type(2)));
+// The sums only have to bound the minimum from ABOVE, so the 32 table rows per frame are read from a bf16 image of a^ that was
+// rounded UP (a^_up >= a^, hence fl32(a^_up + dist) >= fl32(a^ + dist)): half the bytes of the kernel's only real traffic, for a
+// bound that is at most 2^-8 |a^| looser.
+// A lane takes TWO mixtures (one dword = two bf16 per row): the near densities and their distances are wave-uniform scalars, so a row
+// costs the wave one load, two unpacks, two sums and two minima for 128 mixtures.  64 mixtures = one tile = 32 lanes.
 __global__ __launch_bounds__(256) void tied_bound_kernel(const unsigned short* __restrict__ g_aup, const float* __restrict__ g_amax,
                                                         const uint2* __restrict__ g_near, int n_mix,
                                                         int mix_pad, int n_tiles, float* __restrict__ g_thr, float* __restrict__ g_thr_m,
@@ -158,9 +157,8 @@ __global__ __launch_bounds__(256) void tied_bound_kernel(const unsigned short* _
 #pragma unroll
     for (int i = 0; i < kTiedNear; ++i) {
         const float d = __uint_as_float(nr[i].y);
-        const tied_h2 a = __builtin_bit_cast(tied_h2, v[i]);  // exact in f32: no margin needed on this path
-        u0              = fminf(u0, (float)a.x + d);
-        u1              = fminf(u1, (float)a.y + d);
+        u0            = fminf(u0, __uint_as_float(v[i] << 16) + d);
+        u1            = fminf(u1, __uint_as_float(v[i] & 0xffff0000u) + d);
     }
     // tau' = 2^-21 (2 max|a^| + |U|)
     float thr0 = -__builtin_inff(), thr1 = -__builtin_inff();
@@ -189,7 +187,7 @@ __global__ __launch_bounds__(256) void tied_bound_kernel(const unsigned short* _
 // dword-per-lane loads, each a 256-byte wave request, which leave a CU at ~50 GB/s where 1 KB requests reach 128 GB/s
 // (profiles/r06/l2_probe.log).  Here a wave reads 1 KB of a row per instruction (one wave = one 1 KB segment of the table = eight
 // tiles, on XCD segment % 8 as above), a quarter of the load and scalar instructions per byte; rows arrive eight at a time into one of
-// two register buffers while the other is summed -- in packed f16 since late in round 6 (one sum and one minimum per dword).
+// two register buffers while the other is summed (two packed adds per dword pair, one three-way minimum per two rows and mixture).
 #ifndef AMX_TIED_BOUND_B
 #define AMX_TIED_BOUND_B 4     // measured 4 x 2: 21.5 us, 2 x 2: 21.9, 2 x 4: 22.4, 4 x 4: 23.5 (64 / 56 / 72 / 128 registers)
 #define AMX_TIED_BOUND_NBUF 2
@@ -233,27 +231,25 @@ __global__ __launch_bounds__(64) void tied_bound8_kernel(const unsigned short* _
     const uint2*    nr = g_near + (size_t)t * kTiedNear;  // .x = list position, .y = distance bits (little-endian halves of the key)
     const uint32_t  row_bytes = (uint32_t)mix_pad * 2u, lane_off = in ? (uint32_t)m * 2u : 0u;
     tied_u4         buf[NBUF][B];
-    tied_h2         uh[4];  // running minima of the lane's eight mixtures, in f16 (see sum)
+    float           u[8];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-        uh[j] = tied_h2{(_Float16)__builtin_inff(), (_Float16)__builtin_inff()};
+    for (int j = 0; j < 8; ++j)
+        u[j] = FLT_MAX;
     auto fetch = [&](tied_u4 (&bf)[B], const uint2* k) {
 #pragma unroll
         for (int i = 0; i < B; ++i)
             bf[i] = tied_load_u4(g_aup, k[i].x * row_bytes, lane_off);
     };
-    // The sums and minima run in PACKED f16 (one v_pk_add_f16 and one v_pk_min_f16 per dword: the table's halves need no unpacking):
-    // round-to-nearest sums of an exact a^_up and a distance rounded to f16 are no upper bounds by themselves -- the epilogue adds what
-    // the two roundings can have lost, 2^-10 (|U| + max|a^|) (derivation there).
     auto sum = [&](const tied_u4 (&bf)[B], const uint2* d) {
 #pragma unroll
-        for (int i = 0; i < B; ++i) {
-            const _Float16 dh = (_Float16)__uint_as_float(d[i].y);  // beyond 65504: +inf, the row then bounds nothing
-            const tied_h2  dd = tied_h2{dh, dh};
+        for (int i = 0; i < B; i += 2) {
+            const float da = __uint_as_float(d[i].y), db = __uint_as_float(d[i + 1].y);
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
-                const uint32_t word = bf[i][w];  // (a copy: __builtin_bit_cast of the vector-element expression itself read element 0 for every w)
-                uh[w]               = __builtin_elementwise_min(uh[w], __builtin_bit_cast(tied_h2, word) + dd);
+                const tied_f2 a = tied_f2{__uint_as_float(bf[i][w] << 16), __uint_as_float(bf[i][w] & 0xffff0000u)} + tied_f2{da, da};
+                const tied_f2 c = tied_f2{__uint_as_float(bf[i + 1][w] << 16), __uint_as_float(bf[i + 1][w] & 0xffff0000u)} + tied_f2{db, db};
+                u[2 * w]        = fminf(fminf(u[2 * w], a.x), c.x);
+                u[2 * w + 1]    = fminf(fminf(u[2 * w + 1], a.y), c.y);
             }
         }
     };
@@ -272,18 +268,13 @@ __global__ __launch_bounds__(64) void tied_bound8_kernel(const unsigned short* _
     }
     if (!in)
         return;  // whole groups of eight lanes (a tile) leave together
-    // U from its f16 image U^ = min_k fl16(a^_up + fl16(d_k)), k* its arg-min: the exact sum s* = a^_up + d_k* is at most U^ + ulp16(d) / 2
-    // + ulp16(U^) / 2 <= U^ + 2^-11 (|d| + |U^|) (+ 2^-24 below the normal range), and |d| <= |s*| + |a^_up| <= |U^| + max|a^| up to the
-    // same terms: min_k fl32(a^ + d_k) <= U^ + 2^-11 (2 |U^| + max|a^|) (1 + 2^-10).  Added: 2^-10 (|U^| + max|a^|) + 2^-20.
     // tau' = 2^-21 (2 max|a^| + |U|)
     float thr8[8], thr = -__builtin_inff();
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         thr8[j] = -__builtin_inff();
         if (m + j < n_mix) {
-            const float amax = g_amax[m + j], uf = (float)((j & 1) ? uh[j >> 1].y : uh[j >> 1].x);
-            const float uj   = uf + (9.765625e-4f * (fabsf(uf) + amax) + 9.5367431640625e-7f);
-            thr8[j]          = uj + (4.76837158e-7f * (2.f * amax + fabsf(uj)) + 1e-30f);
+            thr8[j] = u[j] + (4.76837158e-7f * (2.f * g_amax[m + j] + fabsf(u[j])) + 1e-30f);
             if (!(thr8[j] == thr8[j]))
                 thr8[j] = __builtin_inff();
         }
@@ -725,18 +716,14 @@ __global__ __launch_bounds__(64) void tied_pruned_kernel(const unsigned long lon
 
 // amin[tile][k] = min over the real mixtures of the tile of a^[k][m]; aminG[k] = min over the tiles.  Returns one device table
 // [(n_tiles + 1)][Kpad] (+inf padded), row n_tiles = aminG, followed by amin transposed, [Kpad][tiles_pad].
-// the smallest f16 that is >= the f32 value (NaN stays NaN, beyond 65504: +inf; +0 for the padding columns)
-static unsigned short tied_f16_up(float v) {
-    if (v != v)
-        return 0x7e00u;
-    const _Float16 h = (_Float16)v;  // round to nearest even
-    unsigned short b;
-    memcpy(&b, &h, 2);
-    if (!((float)h < v))
-        return b;
-    if ((b & 0x7fffu) == 0)  // +-0 below a positive value: the smallest subnormal
-        return 0x0001u;
-    return (b & 0x8000u) ? (unsigned short)(b - 1u) : (unsigned short)(b + 1u);  // negative: towards zero; positive: away (0x7bff -> +inf)
+// bf16 that is >= the f32 value (NaN / inf pass through; +0 for the padding columns)
+static unsigned short tied_bf16_up(float v) {
+    uint32_t u;
+    memcpy(&u, &v, 4);
+    if ((u & 0x7f800000u) == 0x7f800000u || (u & 0xffffu) == 0)
+        return (unsigned short)(u >> 16);
+    // positive: truncation rounds down -> next bf16 up; negative: truncation (towards zero) already rounds up
+    return (unsigned short)((u >> 16) + ((u >> 31) ? 0u : 1u));
 }
 
 extern "C" int amx_internal_gmm_tied_create(int K, int n_mix, int mix_pad, const float* ahat_t_host, float** d_amin, unsigned short** d_aup) {
@@ -744,7 +731,7 @@ extern "C" int amx_internal_gmm_tied_create(int K, int n_mix, int mix_pad, const
     {
         std::vector<unsigned short> up((size_t)K * mix_pad);
         for (size_t i = 0; i < up.size(); ++i)
-            up[i] = tied_f16_up(ahat_t_host[i]);
+            up[i] = tied_bf16_up(ahat_t_host[i]);
         *d_aup = nullptr;
         AMX_HIP(hipMalloc((void**)d_aup, up.size() * 2));
         AMX_HIP(hipMemcpy(*d_aup, up.data(), up.size() * 2, hipMemcpyHostToDevice));
