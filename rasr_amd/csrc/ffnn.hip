@@ -1826,6 +1826,10 @@ void launch_mx_cfg(amx_ffnn* h, int l, const void* x, int xkts, void* out, int l
         const long t64 = (long)(h->Npad[l] / 128) * (Tpad / 64);  // tiles of 128 x 64
         if (t256 >= 2L * ncu)
             cfg = 8;  // round 5: the 256 x 256 tile with the ping-pong K loop (tile=2: all eight waves in phase, round 4's default)
+        else if (LAST && t256 <= ncu && 5 * t256 >= 3 * ncu)
+            // an output layer whose 256 x 256 tiles fill 60-100 % of the CUs in ONE round (config 4 at its own batch: 40 x 4 = 160 tiles):
+            // 87.5 us against 95 for 632 tiles of 128 x 128 on 512 slots (a full round and a quarter-full one); bit-identical
+            cfg = 8;
         else if (t128 >= ncu)
             cfg = 0;
         else if (t64 > ncu && t64 <= 2 * ncu)
