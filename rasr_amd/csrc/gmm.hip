@@ -2600,7 +2600,11 @@ int amx_gmm_score_dev(amx_gmm* h, int mode, const float* feats_dev, int T, float
     if (!h->tied && h->screen && mode == AMX_GMM_MAX) {
         // three launches and their gaps are a fifth of a 256-frame pass: replay them as a graph (not while profiling: the
         // per-launch events are not part of the graph).  First call plain (sizes the workspaces), second call captures.
-        if (!(h->use_graphs && !h->ctx->profiling && T <= 4096))
+        // (a pass that IS one launch -- the fused kernel packing its own operand rows, one chunk -- is cheaper launched than replayed:
+        // 0.0316 against 0.0369 ms per 256 frames, round 6)
+        const bool one_launch = h->d_fus_rec && h->tune_fused && !h->tune_screen_all && h->tune_fused_pack && h->tune_fused_waves != 13 &&
+                                T <= h->tune_chunk;
+        if (!(h->use_graphs && !h->ctx->profiling && T <= 4096) || one_launch)
             return score_screened(h, feats_dev, T, scores_dev, best_dev, false, nullptr, nullptr, nullptr);
         const amx_gmm::GraphKey key{feats_dev, scores_dev, best_dev, h->ctx->stream, T};
         auto                    it = h->graphs.find(key);

@@ -875,16 +875,18 @@ def test_batch_int_scorer_exact(ctx, kind, monkeypatch):
         rasr_amd.GmmFeatureScorer(ctx, private, feature_scorer_type="batch-diagonal-maximum-int").score(feats(4, 16, 1), want_best=False)
 
 
-def test_small_batch_graph_replay_and_workspace_growth(ctx):
+@pytest.mark.parametrize("tuning", [None, "fused_pack=0", "fused=0"])
+def test_small_batch_graph_replay_and_workspace_growth(ctx, tuning):
     """passes of <= 4096 frames on unchanged device buffers are replayed as HIP graphs from the third call on: results stay
     bit-identical when the buffer CONTENTS change, and a larger pass in between (which moves the workspaces the captured
-    graphs point to) must not leave stale graphs behind"""
+    graphs point to) must not leave stale graphs behind.  (The default pass is ONE launch since round 6 and is not recorded at
+    all; fused_pack=0 -- pack kernel + fused kernel -- and fused=0 -- three kernels -- are.)"""
     import torch
 
     import rasr_amd
     from oracle import OracleGmm
     model = synth.gmm_cart(64, 1, 16, 40, seed=160, pooled=True)
-    sc, o = rasr_amd.GmmFeatureScorer(ctx, model), OracleGmm(model)
+    sc, o = rasr_amd.GmmFeatureScorer(ctx, model, tuning=tuning), OracleGmm(model)
     ctx.use_torch_stream()
     xd = torch.empty((256, 40), dtype=torch.float32, device="cuda")
     scores = torch.empty((256, 64), dtype=torch.float32, device="cuda")
@@ -1456,7 +1458,8 @@ def test_tied_statistics_stay_consistent_when_the_host_runs_ahead(ctx):
     assert np.array_equal(scores.cpu().numpy().view(np.uint32), osc.view(np.uint32)) and np.array_equal(best.cpu().numpy().astype(np.uint32), ob)
 
 
-def test_fused_survivor_statistics_under_graph_replay(ctx):
+@pytest.mark.parametrize("tuning", [None, "fused_pack=0"])
+def test_fused_survivor_statistics_under_graph_replay(ctx, tuning):
     """decoder-sized passes on unchanged buffers are replayed as a HIP graph from the third call on: the (frame, mixture) pairs the
     statistic is normalised by must count the replays too (regression: only the captured call was counted, 1.02 survivors per mixture
     were reported as 1.8), and switching the counter off and on drops the graphs recorded with the other setting"""
@@ -1464,7 +1467,7 @@ def test_fused_survivor_statistics_under_graph_replay(ctx):
 
     import rasr_amd
     model = synth.gmm_cart(300, 16, 16, 40, seed=71, pooled=True)
-    sc = rasr_amd.GmmFeatureScorer(ctx, model)
+    sc = rasr_amd.GmmFeatureScorer(ctx, model, tuning=tuning)   # (None: one launch per pass, not recorded; fused_pack=0: two launches, replayed)
     T, M = 256, 300
     x = torch.from_numpy(feats(T, 40, 72)).cuda()
     scores = torch.empty((T, M), dtype=torch.float32, device="cuda")
