@@ -85,7 +85,7 @@ def parse():
                          "multiply-adds); off = configured with -DMARCH=x86-64.  The oracle that checks the run and the CPU baseline are built "
                          "the same way")
     ap.add_argument("--gmm-tuning", default=None, help='amx_gmm_model.tuning of every GMM scorer the workload builds, e.g. "screen=0" (A/B runs)')
-    ap.add_argument("--nn-tuning", default=None, help='amx_ffnn_model.tuning, e.g. "tile=4" or "graph=0"')
+    ap.add_argument("--nn-tuning", default=None, help='amx_ffnn_model.tuning, e.g. "tile=4" or "graph=1"')
     ap.add_argument("--mfcc-tuning", default=None, help='amx_mfcc_cfg.tuning, e.g. "fft=mfma" or "wgs=3"')
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the secondary BASELINE configs of the default run")
@@ -1273,11 +1273,11 @@ def make_job(ctx, args, rank, world=1):
 
 
 def is_graph_mode(args):
-    # config 4 (batch 1024) and the config-3 CART scorer (batch 256) replay their pass as a HIP graph, which the per-launch events of the
-    # library's profiler would switch off: that workload is timed without them and its kernel timings come from a separate profiled pass
-    return (args.workload == "nn" and "graph=0" not in (args.nn_tuning or "")) or \
+    # tuning graph=1 (opt-in since round 6: plain launches measured 3-5 % faster in this loop): config 4 (batch 1024) and the config-3
+    # scorers (batch 256) replay their pass as a HIP graph, which the per-launch events of the library's profiler would switch off
+    return (args.workload == "nn" and "graph=1" in (args.nn_tuning or "")) or \
            (args.workload in ("gmm", "gmm-tied") and args.gmm_type == "diagonal-maximum" and args.gmm_frames <= 4096
-            and "graph=0" not in (args.gmm_tuning or ""))
+            and "graph=1" in (args.gmm_tuning or ""))
 
 
 def reset_survivor_counters(job):
@@ -1508,9 +1508,9 @@ def secondary_configs(ctx, args, rank):
                              kernel=r.get("kernel"), roofline_frac=r.get("frac"), roofline_bound=r.get("bound"),
                              workload=WORKLOAD_NAMES[a.workload](a))
             if a.workload == "nn":
-                # config 4: `roofline_frac` is the WHOLE network against the wall time of a pass (HIP-graph replay); the largest
+                # config 4: `roofline_frac` is the WHOLE network against the wall time of a pass; the largest
                 # layer's own figure stays next to it
-                wn = job.whole_network(1e3 * dt / a.steps, "wall time of one pass (HIP-graph replay)")
+                wn = job.whole_network(1e3 * dt / a.steps, "wall time of one pass")
                 out[name].update(roofline_frac=wn["frac"], output_layer_frac=r.get("frac"), whole_network=wn,
                                  kernel="all 7 GEMMs of the pass; largest: " + str(r.get("kernel")))
             if r.get("time_is"):

@@ -360,7 +360,8 @@ typedef struct {
      *
      * Kernel selection for A/B runs and tests -- every path gives the same scores and density indices bit for bit (within a contract):
      * screen=0 (no MFMA / f32 screen: every density evaluated), fused=0 (two-kernel screen path instead of gmm_fused_kernel),
-     * screen_kernel=rows|persist|simple, graph=0 (no HIP-graph replay of small batches), tied_prune=0|1 (tied models: dense tile
+     * screen_kernel=rows|persist|simple, graph=1 (HIP-graph replay of repeated small passes; off by default since round 6: plain launches
+     * measured 3-5 % faster back to back and equal with a synchronisation per pass, profiles/r06/graph_ab.log), tied_prune=0|1 (tied models: dense tile
      * kernel | pruned scorer, default -1 adaptive), chunk=N (frames per internal pass, >= 256), fused_waves=8|12|16|13 (13: the
      * wave-specialised kernel), fr=2|4|8|16 (frames per workgroup of the uniform tied kernel), simd_mfma=0 (SIMD / batch-int scorers
      * without the i8 matrix kernel), dist_list=0 (pruned tied scorer: distances from the density-major kernel instead of the
@@ -573,7 +574,7 @@ typedef struct {
      * batches since round 5), 9 256x256 with ONE self-pipelined wave per SIMD (f16mx; measured 6 % behind 8, opt-in), 3 128x64 one tile per
      * CU, 6 128x64 two per CU, 4 / 5 / 7 K-loop variants of 2, 11 / 12 K-loop variants of 3, 14 (f16mx) hidden layers on 64x64 tiles with four
      * K-tiles per barrier -- the default for fills that leave half the CUs without a 128x64 tile; default by layer shape),
-     * graph=0 (no HIP-graph replay of small batches), persistent=0, group=TxN (tiles per XCD-aware super-tile), chunk=N (frames per
+     * graph=1 (HIP-graph replay of repeated small passes; off by default since round 6, see amx_gmm_model.tuning), persistent=0, group=TxN (tiles per XCD-aware super-tile), chunk=N (frames per
      * internal pass, >= 256), stagger=N (f16mx output layer of a large batch: XCD x starts x * N * 10 ns late; default 0). */
     const char*         tuning;
 } amx_ffnn_model;

@@ -2014,7 +2014,7 @@ int amx_ffnn_create(amx_ctx* ctx, const amx_ffnn_model* m, amx_ffnn** out) {
             return AMX_ERR_INVALID;
         AMX_REQUIRE(t_ksplit == 1 || t_ksplit == 4, AMX_ERR_INVALID, "amx_ffnn_create: tuning ksplit=%d: expected 1 | 4", t_ksplit);
         AMX_REQUIRE(t_ksplit == 1 || m->precision == AMX_PREC_F16MX, AMX_ERR_UNSUPPORTED, "amx_ffnn_create: tuning ksplit exists for AMX_PREC_F16MX only");
-        if (!tune.get_int("tile", -1, -1, 14, &t_tile, who) || !tune.get_int("graph", 1, 0, 1, &t_graph, who) ||
+        if (!tune.get_int("tile", -1, -1, 14, &t_tile, who) || !tune.get_int("graph", 0, 0, 1, &t_graph, who) ||
             !tune.get_int("persistent", 1, 0, 1, &t_persistent, who) || !tune.get_int("chunk", 32768, 256, 1 << 24, &t_chunk, who) ||
             !tune.get_int("mx_dbg", 0, 0, 1 << 16, &t_mx_dbg, who) || !tune.get_int("stagger", 0, 0, 100000, &t_stagger, who))
             return AMX_ERR_INVALID;

@@ -2064,7 +2064,7 @@ int amx_gmm_create(amx_ctx* ctx, const amx_gmm_model* m, amx_gmm** out) {
         !tune.get_int("screen_all", 0, 0, 1, &t_screen_all, who) || !tune.get_int("tied_prune", -1, -1, 1, &t_tied_prune, who) ||
         !tune.get_int("chunk", 65536, 256, 1 << 24, &t_chunk, who) || !tune.get_int("fused_waves", 0, 0, 16, &t_fused_waves, who) ||
         !tune.get_int("fr", 8, 2, 16, &t_fr, who) || !tune.get_int("simd_mfma", 1, 0, 1, &t_simd_mfma, who) ||
-        !tune.get_int("graph", 1, 0, 1, &t_graph, who) || !tune.get_int("dist_list", 1, 0, 64, &t_dist_list, who) ||
+        !tune.get_int("graph", 0, 0, 1, &t_graph, who) || !tune.get_int("dist_list", 1, 0, 64, &t_dist_list, who) ||
         !tune.get_int("near_fused", 1, 0, 1, &t_near_fused, who) || !tune.get_int("fused_pack", 1, 0, 1, &t_fused_pack, who) || !tune.get_word("screen_kernel", "rows", screen_kernels, &t_screen_kernel, who) ||
         !tune.get_word("contract", ctx && ctx->contract == AMX_CONTRACT_FMA ? "fma" : "off", contracts, &t_contract, who))   // no key: the context's arithmetic (amx_set_contract)
         return AMX_ERR_INVALID;

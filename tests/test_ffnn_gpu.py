@@ -156,14 +156,16 @@ def test_tile_configurations_agree(ctx, monkeypatch, n_out):
         assert abs(got[3] - ref[3]) <= 1e-9 * abs(ref[3]), cfg
 
 
-def test_small_batch_graph_replay(ctx):
-    """batches of <= 4096 frames on unchanged device buffers are replayed as a HIP graph from the third call on: the results
-    must follow the CURRENT buffer contents, and the fused statistics must keep accumulating"""
+@pytest.mark.parametrize("graph", ["graph=1", None])
+def test_small_batch_graph_replay(ctx, graph):
+    """tuning graph=1: batches of <= 4096 frames on unchanged device buffers are replayed as a HIP graph from the third call on: the
+    results must follow the CURRENT buffer contents, and the fused statistics must keep accumulating (None: the default since round 6,
+    plain launches)"""
     import torch
 
     import rasr_amd
     Ws, bs, acts, logp = synth.ffnn([64, 256, 256, 1000], seed=31)
-    nn = rasr_amd.NnBatchFeatureScorer(ctx, Ws, bs, acts, log_prior=logp, precision="bf16")
+    nn = rasr_amd.NnBatchFeatureScorer(ctx, Ws, bs, acts, log_prior=logp, precision="bf16", tuning=graph)
     T = 300
     xd = torch.empty((T, 64), dtype=torch.float32, device="cuda")
     sc = torch.empty((T, 1000), dtype=torch.float32, device="cuda")

@@ -875,9 +875,9 @@ def test_batch_int_scorer_exact(ctx, kind, monkeypatch):
         rasr_amd.GmmFeatureScorer(ctx, private, feature_scorer_type="batch-diagonal-maximum-int").score(feats(4, 16, 1), want_best=False)
 
 
-@pytest.mark.parametrize("tuning", [None, "fused_pack=0", "fused=0"])
+@pytest.mark.parametrize("tuning", [None, "graph=1", "graph=1,fused_pack=0", "graph=1,fused=0"])
 def test_small_batch_graph_replay_and_workspace_growth(ctx, tuning):
-    """passes of <= 4096 frames on unchanged device buffers are replayed as HIP graphs from the third call on: results stay
+    """tuning graph=1: passes of <= 4096 frames on unchanged device buffers are replayed as HIP graphs from the third call on: results stay
     bit-identical when the buffer CONTENTS change, and a larger pass in between (which moves the workspaces the captured
     graphs point to) must not leave stale graphs behind.  (The default pass is ONE launch since round 6 and is not recorded at
     all; fused_pack=0 -- pack kernel + fused kernel -- and fused=0 -- three kernels -- are.)"""
@@ -1118,7 +1118,7 @@ def test_tied_near_keys_survive_calls_of_any_shape(ctx):
     model = synth.gmm_tied(300, 700, 40, seed=955, pooled=True)
     orc = OracleGmm(model)
     ctx.use_torch_stream()
-    for tuning in ("tied_prune=1", "tied_prune=1,near_fused=0"):
+    for tuning in ("tied_prune=1,graph=1", "tied_prune=1", "tied_prune=1,near_fused=0,graph=1"):
         sc = rasr_amd.GmmFeatureScorer(ctx, model, tuning=tuning)
         for rep, T in enumerate((256, 31, 256, 256, 256, 1, 700, 256, 256)):
             x = feats(T, 40, 956 + rep)
@@ -1431,7 +1431,8 @@ def test_preselection_batch_int_errors(ctx):
         sc.score(feats(3, 40, 1), want_best=False)
 
 
-def test_tied_statistics_stay_consistent_when_the_host_runs_ahead(ctx):
+@pytest.mark.parametrize("tuning", ["graph=1", None])
+def test_tied_statistics_stay_consistent_when_the_host_runs_ahead(ctx, tuning):
     """200 passes enqueued back to back without a synchronisation (graph replays from the third on): the survivor statistic the host reads
     asynchronously must not mistake the device's lag for a high surviving fraction -- every pass takes the pruned path (regression: the
     denominator used to be counted on the host at submission time, the numerator arrived late, and the ratio of a later window came out
@@ -1440,7 +1441,7 @@ def test_tied_statistics_stay_consistent_when_the_host_runs_ahead(ctx):
 
     import rasr_amd
     model = synth.gmm_tied(1000, 4096, 40, seed=88, pooled=True)      # prunable: ~2 % of the (density, frame, tile) triples survive
-    sc = rasr_amd.GmmFeatureScorer(ctx, model)
+    sc = rasr_amd.GmmFeatureScorer(ctx, model, tuning=tuning)       # graph=1: replays from the third pass on; None: plain launches
     T, M = 256, 1000
     x = torch.from_numpy(feats(T, 40, 89)).cuda()
     scores = torch.empty((T, M), dtype=torch.float32, device="cuda")
@@ -1458,7 +1459,7 @@ def test_tied_statistics_stay_consistent_when_the_host_runs_ahead(ctx):
     assert np.array_equal(scores.cpu().numpy().view(np.uint32), osc.view(np.uint32)) and np.array_equal(best.cpu().numpy().astype(np.uint32), ob)
 
 
-@pytest.mark.parametrize("tuning", [None, "fused_pack=0"])
+@pytest.mark.parametrize("tuning", [None, "graph=1", "graph=1,fused_pack=0"])
 def test_fused_survivor_statistics_under_graph_replay(ctx, tuning):
     """decoder-sized passes on unchanged buffers are replayed as a HIP graph from the third call on: the (frame, mixture) pairs the
     statistic is normalised by must count the replays too (regression: only the captured call was counted, 1.02 survivors per mixture
