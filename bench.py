@@ -483,7 +483,7 @@ class Pipeline(NnPipeline):
     """Per-GPU shard of BASELINE config 5: every frame is scored by BOTH acoustic models.
     audio -> MFCC-40 -+-> CART GMM 10 000 states x 16 densities (diagonal-maximum) -> best state / density -> Viterbi accumulators
                       +-> 11-frame context -> FFNN 440-6x2048-10000 (bf16 MFMA)   -> best state -> per-state counts
-    The two legs only share the MFCC output and run on two HIP streams (AMX_BENCH_ONE_STREAM=1: one after the other, 1 % slower)."""
+    The two legs only share the MFCC output (AMX_BENCH_TWO_STREAMS=1 runs them on two HIP streams: 1 % faster, per-kernel times no longer exclusive)."""
 
     GCHUNK = int(os.environ.get("AMX_BENCH_GCHUNK", "65536"))  # frames per GMM pass (>= a step: one pass; scores + best densities = 5.1 GB)
 
@@ -534,7 +534,10 @@ class Pipeline(NnPipeline):
     def step(self):
         torch = self.torch
         self.front_end()
-        if os.environ.get("AMX_BENCH_ONE_STREAM"):  # both legs saturate the GPU: overlapping them gains 1 % (12.56 -> 12.44 ms, two alternations)
+        # Both legs saturate the GPU.  On two streams the step gains 1 % (12.56 -> 12.44 ms, two alternations) -- and every per-launch time
+        # (HIP events here, rocprofv3's durations alike) then includes the other leg's kernels: the GEMM's roofline fraction read 0.213
+        # instead of 0.272 for the same work.  One stream, so that a kernel's time is its own.
+        if not os.environ.get("AMX_BENCH_TWO_STREAMS"):
             self.gmm_leg()
             self.nn_leg()
             return
