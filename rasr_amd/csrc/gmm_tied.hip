@@ -555,9 +555,17 @@ __global__ __launch_bounds__(64) void tied_pruned_kernel(const unsigned long lon
     // by ~3 of a 256-frame batch's frames, so all frames of one tile go to ONE XCD, back to back: the grid is (8 T, tiles / 8),
     // xcd = x % 8, frame = x / 8, tile = 8 y + xcd.  The tile's 1 MB slice of the table then comes from HBM once instead of once per
     // frame that wants it.
-    const int tile = blockIdx.y * 8 + (blockIdx.x & 7), t = blockIdx.x >> 3;
-    if (tile >= n_tiles)
-        return;
+    // The tiles left over after the whole rows of eight (config 3: 157 = 19 x 8 + 5) would keep 8 - R XCDs idle for the last row: their
+    // R x T (tile, frame) items are dealt round the XCDs instead, item q = t R + j on XCD q % 8 (as in tied_bound8_kernel).
+    int tile = blockIdx.y * 8 + (blockIdx.x & 7), t = blockIdx.x >> 3;
+    const int rest = n_tiles & 7;
+    if (rest != 0 && (int)blockIdx.y == (n_tiles >> 3)) {
+        const int q = (blockIdx.x & 7) + 8 * (blockIdx.x >> 3);
+        if (q >= rest * T)
+            return;
+        t    = q / rest;
+        tile = (n_tiles & ~7) + (q - t * rest);
+    }
     const int       m      = tile * 64 + lane;
     const float     thr_m  = g_thr_m[(size_t)t * mix_pad + m];
     const bool      narrow = (unsigned long long)Kpad * mix_pad * 4ull < (1ull << 32);  // table offsets fit 32 bits
