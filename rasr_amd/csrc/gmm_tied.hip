@@ -17,23 +17,26 @@
 // max(|U|, max|a^|) since dist >= 0).  With Thr[t][j] = max over the tile's mixtures of U + tau', and fl32 monotone,
 //   fl32(amin[j][k] + dist[k][t]) > Thr[t][j]   ==>   no mixture of tile j has density k as a candidate for frame t
 // and the same with aminG and ThrG[t] = max_j Thr[t][j] for the whole model.  The kernels:
-//   tied_transpose_kernel   dist[k][t] -> dt[t][k] (list order), so that a frame's distances are one contiguous row; only when the
-//                           shared list repeats a density or a call is cut into passes -- otherwise gmm_dist_kernel (gmm.hip)
-//                           writes dt itself
-//   tied_near_kernel        the frame's near densities
-//   tied_bound_kernel       U and the mixtures' thresholds U + tau', Thr[t][j]
+//   gmm_dist_list_kernel    (gmm.hip; lists that name every density at most once, one pass) the frame-major distances dt[t][k] in
+//                           list order AND the frame's near densities: per residue class k mod 64 the smallest 64-bit key (distance
+//                           bits, position), kept with atomic minima; tied_list_kernel puts the keys back into their empty state
+//   tied_transpose_kernel + tied_near_kernel   the same two results for every other case (a list that repeats a density, a call cut
+//                           into passes, a dimension without an instance, builds with another number of near densities), from
+//                           gmm_dist_kernel's density-major distances
+//   tied_bound8_kernel      U and the mixtures' thresholds U + tau', Thr[t][j]: eight mixtures per lane, the near rows of a bf16 image of
+//                           a^ rounded up in 1 KB requests, table segments with a home XCD (tied_bound_kernel: tables of 4 GB and more)
 //   tied_list_kernel        per frame: the densities that pass the model-wide test (4 % on the config-3 instance), ascending, with
 //                           their distances and log-normalisation terms
-//   tied_mask_kernel        per (frame, tile): which list entries pass the TILE's test (1.2 % of all densities), as bit masks
-//   tied_pruned_kernel      per (tile, frame): the survivors compacted into LDS, each lane's own f32 screen over them (1.3 of ~65
+//   tied_mask_kernel        per (frame, tile): which list entries pass the TILE's test (1.3 % of all densities), as bit masks
+//   tied_pruned_kernel      per (tile, frame): the survivors compacted into LDS, each lane's own f32 screen over them (1.15 of ~54
 //                           pass per mixture), and the reference's f64 rule over what is left, in ascending k.
 // Running the rule over a subsequence that contains every candidate, in the original order, is bit-identical.
 //
-// What bounds these kernels is not arithmetic and not bytes: the pruned kernel is a few hundred instructions per wave that each wait
-// on the one before (list -> row addresses -> rows -> candidates -> weights), so its time is (instructions a wave issues) x (waves
-// per SIMD) x 4 cycles at about one instruction per issue slot, and the small kernels are as long as their chain of memory round
-// trips.  Hence one trip per wave in the list / mask kernels, and the 6-instruction survivor test in tied_pruned_kernel
-// (profiles/r03/NOTES_tied.md has the measurements that led here).
+// What bounds these kernels (round 6's measurements, profiles/r06/tied_steps.log): the pruned kernel is 40 192 one-wave items of very
+// different length (16 .. 180 survivors) at eight waves per SIMD -- neither 12 % fewer vector instructions nor one round trip less per
+// wave nor persistent waves move its 48 us; the bound kernel is its 329 MB of row requests (22 us with every row an L2 hit); the small
+// kernels are as long as their chain of memory round trips, hence one trip per wave in the list / mask kernels.
+// (profiles/r03/NOTES_tied.md has the measurements that led to the 6-instruction survivor test.)
 //
 // A model / feature distribution without that structure (everything survives) would make this slower than the dense
 // kernel -- each table element is then used once instead of 16 times from registers.  The kernel counts the survivors; the host
