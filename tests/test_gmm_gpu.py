@@ -1106,6 +1106,17 @@ def test_tied_list_order_distances(ctx, dim, n_dens, T, contract, monkeypatch):
             assert np.array_equal(best, ob), (dl, pooled)
 
 
+@pytest.mark.parametrize("n_mix", [4096, 4100, 5000, 8500])
+def test_tied_bound_segments_over_the_xcds(ctx, n_mix):
+    """the bound kernel gives the whole rounds of eight 512-mixture table segments a fixed home XCD and deals the left-over (segment, frame)
+    units round the XCDs, the pruned kernel does the same with its tiles: mixture counts with 8 / 9 / 10 / 17 segments (0, 1, 2 and 1 left
+    over) and 64 / 65 / 79 / 133 tiles (0, 1, 7 and 5 left over), a frame count that is no multiple of anything"""
+    model = synth.gmm_tied(n_mix, 160, 24, seed=960 + n_mix, pooled=True)
+    x = feats(45, 24, 961)
+    x[11] *= 20.0
+    assert_exact(ctx, model, x, tuning="tied_prune=1")
+
+
 def test_tied_near_keys_survive_calls_of_any_shape(ctx):
     """the list-order distance kernel keeps the frame's near densities as atomic minima over 64-bit keys that tied_list_kernel puts
     back into their empty state: calls of different lengths on ONE scorer (more frames, fewer, more again; device buffers, so that
